@@ -1,0 +1,43 @@
+"""Seeded synthetic inputs for the parity tests and bench.py (there is no dataset in the container).
+
+Frame generator (config 2 of BASELINE.json): sum of 3 octaves of value noise (uniform[0,255] lattices at 8/32/128 px pitch,
+bilinear-upsampled, weights 0.5/0.3/0.2), 300 axis-aligned rectangles (side 8..120 px, uniform grey) painted on top, then
+i.i.d. N(0,3) pixel noise, clamped to u8. RNG: numpy PCG64 seeded with `seed`.
+"""
+import numpy as np
+
+
+def _value_noise(rng, rows, cols, pitch):
+    gr, gc = rows // pitch + 2, cols // pitch + 2
+    lat = rng.uniform(0.0, 255.0, size=(gr, gc)).astype(np.float32)
+    y = np.arange(rows, dtype=np.float32) / pitch
+    x = np.arange(cols, dtype=np.float32) / pitch
+    y0 = y.astype(np.int32)
+    x0 = x.astype(np.int32)
+    fy = (y - y0)[:, None]
+    fx = (x - x0)[None, :]
+    a = lat[y0][:, x0]
+    b = lat[y0][:, x0 + 1]
+    c = lat[y0 + 1][:, x0]
+    d = lat[y0 + 1][:, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def synth_frame(rows=1080, cols=1920, seed=0, n_rect=300, noise_sigma=3.0, shift=(0, 0), noise_seed=None):
+    """Returns a (rows, cols) uint8 frame. `shift`=(dx,dy) translates the underlying scene (frame k+1 = frame k shifted),
+    `noise_seed` draws fresh pixel noise on the same scene."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pad = 64
+    R, Cc = rows + 2 * pad, cols + 2 * pad
+    img = 0.5 * _value_noise(rng, R, Cc, 8) + 0.3 * _value_noise(rng, R, Cc, 32) + 0.2 * _value_noise(rng, R, Cc, 128)
+    for _ in range(n_rect):
+        w = int(rng.integers(8, 121))
+        h = int(rng.integers(8, 121))
+        x = int(rng.integers(0, Cc - w))
+        y = int(rng.integers(0, R - h))
+        img[y:y + h, x:x + w] = float(rng.uniform(0.0, 255.0))
+    dx, dy = shift
+    img = img[pad + dy:pad + dy + rows, pad + dx:pad + dx + cols]
+    nrng = np.random.Generator(np.random.PCG64(seed * 7919 + 17 if noise_seed is None else noise_seed))
+    img = img + nrng.normal(0.0, noise_sigma, size=img.shape).astype(np.float32)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)

@@ -1,0 +1,110 @@
+/*
+ * ovo_oracle.h -- CPU ORACLE for the OpenVSLAM per-frame hot path.  TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load this library, and
+ * only as the checker / reported CPU baseline.  Nothing under openvslam_amd/ links or calls it.
+ *
+ * PARITY UNPINNED.  /root/reference holds nothing but upstream's takedown notice
+ * (/root/reference/README.md:1-4): no source, no tests, no golden vectors, and none of the third-party
+ * code whose arithmetic the path uses (OpenCV resize/FAST/GaussianBlur/fastAtan2/cvRound, g2o) exists in
+ * the build container.  Every function below is therefore a FROM-SPEC scalar restatement that follows the
+ * algorithm description in SURVEY.md section 8(a) (rows A0-A9, M1-M8, D1, B1-B4) plus the published
+ * algorithm definitions (Rosten & Drummond FAST-9/16 as implemented by OpenCV fast.cpp/fast_score.cpp;
+ * Rublee et al. ORB; Mur-Artal et al. ORB-SLAM2 DistributeOctTree).  Each function cites the *expected*
+ * upstream path (no line numbers can exist).  Where upstream behaviour is implementation-defined
+ * (std::sort tie order on node pointers, OpenCV-version-dependent blur arithmetic) the rule chosen here is
+ * written next to the code and in ORACLE_SPEC.md.  All parity claims in this repo are
+ * "bit-exact vs. this oracle", never "vs. OpenVSLAM".
+ *
+ * Build: make -C oracle   (g++ -O2 -ffp-contract=off -fopenmp) -> oracle/liboracle.so
+ */
+#ifndef OVO_ORACLE_H
+#define OVO_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Layout-compatible with cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id): 28 bytes. */
+typedef struct ovo_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} ovo_keypoint;
+
+/* feature::orb_params (expected: src/openvslam/feature/orb_params.{h,cc}); defaults 2000/1.2/8/20/7. */
+typedef struct ovo_orb_params {
+    int32_t max_num_keypts;
+    float scale_factor;
+    int32_t num_levels;
+    int32_t ini_fast_thr;
+    int32_t min_fast_thr;
+} ovo_orb_params;
+
+#define OVO_MAX_LEVELS 16
+
+/* A0: tables. Arrays must hold num_levels entries (u_max: 16). */
+int ovo_orb_tables(const ovo_orb_params* p, float* scale_factors, float* inv_scale_factors,
+                   float* level_sigma_sq, float* inv_level_sigma_sq, int32_t* num_keypts_per_level,
+                   int32_t* u_max16);
+/* A1: level sizes from the ORIGINAL image size. */
+int ovo_pyramid_sizes(const ovo_orb_params* p, int rows, int cols, int32_t* level_rows, int32_t* level_cols);
+/* A1: cv::resize(..., INTER_LINEAR) for CV_8UC1, 11-bit fixed-point coefficients. */
+int ovo_resize_linear_u8(const uint8_t* src, int srows, int scols, size_t sstride, uint8_t* dst, int drows,
+                         int dcols, size_t dstride);
+/* A3: cv::FAST(img, kps, thr, nonmax=true, TYPE_9_16) on a (sub-)image. Returns count (<= cap written). */
+int ovo_fast9_16(const uint8_t* img, int rows, int cols, size_t stride, int threshold, int nonmax,
+                 int32_t* xs, int32_t* ys, int32_t* scores, int cap);
+/* A4: quad-tree distribution. Inputs are candidate coordinates RELATIVE to (min_x,min_y) and responses, in
+ * emission order. Writes the indices (into the candidate arrays) of the selected keypoints in node-list
+ * order. Returns count. */
+int ovo_distribute_via_tree(const float* xs, const float* ys, const float* responses, int n, int min_x,
+                            int max_x, int min_y, int max_y, int num_keypts, int32_t* out_idx, int cap);
+/* A5: ic_angle + cv::fastAtan2 (degrees). */
+float ovo_fast_atan2(float y, float x);
+float ovo_ic_angle(const uint8_t* img, size_t stride, int x, int y, const int32_t* u_max16);
+/* A6: 7x7 sigma=2 Gaussian, 8.8 fixed point, BORDER_REFLECT_101. */
+int ovo_gaussian_blur_7x7(const uint8_t* src, int rows, int cols, size_t sstride, uint8_t* dst, size_t dstride);
+/* A7: util::cos / util::sin polynomial and one steered-BRIEF descriptor (32 bytes). */
+float ovo_util_cos(float v);
+float ovo_util_sin(float v);
+int ovo_orb_descriptor(const uint8_t* blurred, size_t stride, int x, int y, float angle_deg, uint8_t* desc32);
+const int8_t* ovo_orb_pattern(void); /* 256*4 int8 */
+
+/* A9: whole extractor with observable intermediates. */
+typedef struct ovo_orb ovo_orb;
+ovo_orb* ovo_orb_create(const ovo_orb_params* p);
+void ovo_orb_destroy(ovo_orb* h);
+void ovo_orb_set_threads(ovo_orb* h, int n); /* OpenMP threads over levels (upstream USE_OPENMP shape) */
+/* mask: NULL or rows x cols u8 (0 = masked out). Returns 0, writes *n_out (<= cap). */
+int ovo_orb_extract(ovo_orb* h, const uint8_t* img, int rows, int cols, size_t stride, const uint8_t* mask,
+                    size_t mask_stride, ovo_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+/* observables of the last extract */
+int ovo_orb_level_size(const ovo_orb* h, int level, int* rows, int* cols);
+const uint8_t* ovo_orb_level_image(const ovo_orb* h, int level);   /* contiguous rows*cols */
+const uint8_t* ovo_orb_level_blurred(const ovo_orb* h, int level); /* contiguous rows*cols (empty level: NULL) */
+int ovo_orb_level_num_candidates(const ovo_orb* h, int level);
+/* candidates in emission order: level-image coordinates (x,y) and FAST score */
+int ovo_orb_level_candidates(const ovo_orb* h, int level, int32_t* xs, int32_t* ys, int32_t* scores, int cap);
+int ovo_orb_level_num_keypts(const ovo_orb* h, int level);
+
+/* ---- matchers (ovo_match.cc) ---- */
+#define OVO_HAMMING_DIST_THR_LOW 50
+#define OVO_HAMMING_DIST_THR_HIGH 100
+#define OVO_MAX_HAMMING_DIST 256
+/* M1: match::base::compute_descriptor_distance_32 (8 x u32 parallel bit count). */
+uint32_t ovo_descriptor_distance_32(const uint8_t* a, const uint8_t* b);
+/* M2: match::robust::brute_force_match(frame, keyframe, matches).
+ *   desc_frm: n_frm x 32 (frame = idx_1 side), desc_kf: n_kf x 32 (keyframe = idx_2 side),
+ *   kf_valid: NULL or n_kf bytes (landmark present and not will_be_erased).
+ *   Output pairs (idx_1, idx_2) in emission order. Returns number of matches. */
+int ovo_robust_brute_force_match(const uint8_t* desc_frm, int n_frm, const uint8_t* desc_kf, int n_kf,
+                                 const uint8_t* kf_valid, float lowe_ratio, int32_t* pairs, int cap);
+/* Unconstrained per-query best / second best (first-seen tie rule) over all valid targets. */
+int ovo_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* t_valid,
+                      int32_t* best_idx, uint16_t* best, uint16_t* second);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
