@@ -1,0 +1,150 @@
+/*
+ * ovslam_hip.h -- C ABI of libovslam_hip.so: the MI355X (gfx950) implementation of OpenVSLAM's per-frame hot path.
+ *
+ * This is the drop-in boundary.  Upstream has NO plugin / FFI interface for this path: the
+ * boundary is the public surface of concrete C++ classes.  Each entry point below names the upstream class method whose
+ * body it replaces ("replaces:"), by EXPECTED path inside an OpenVSLAM checkout -- line numbers cannot be given because
+ * /root/reference contains only upstream's takedown notice (/root/reference/README.md:1-4).  The C++ classes with the
+ * upstream signatures that call this ABI live in openvslam_amd/cpp/ (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain C types only; no cv::, Eigen:: or torch types; all functions return ovs_status (0 = OK, <0 = error);
+ *   - "host" entry points take caller-owned host pointers and do H2D / kernels / D2H on the handle's own stream;
+ *   - "_dev" entry points take DEVICE pointers (inputs already resident in HBM) plus a hipStream_t passed as void*
+ *     (NULL = the handle's stream) and never synchronise: the caller orders and syncs the stream;
+ *   - handles are independent (own stream, own buffers, no global mutable state), so two extractors may run
+ *     concurrently from two threads (upstream: stereo left/right std::threads); one handle = one caller at a time;
+ *   - there is NO CPU fallback inside this library: without a usable HIP device every call fails with
+ *     OVS_ERR_NO_DEVICE / OVS_ERR_HIP.
+ */
+#ifndef OVSLAM_HIP_H
+#define OVSLAM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t ovs_status;
+#define OVS_OK 0
+#define OVS_ERR_INVALID (-1)     /* bad argument */
+#define OVS_ERR_NO_DEVICE (-2)   /* no HIP device visible */
+#define OVS_ERR_HIP (-3)         /* a HIP runtime call failed; see ovs_last_error() */
+#define OVS_ERR_CAPACITY (-4)    /* image / batch / output larger than the handle or buffer was created for */
+#define OVS_ERR_ALIGN (-5)       /* device image base or row stride not 4-byte aligned */
+
+#define OVS_MAX_LEVELS 16
+
+/* Thread-local text of the last HIP error seen by the calling thread ("" if none). */
+const char* ovs_last_error(void);
+/* Number of visible HIP devices (0 if none / runtime unusable). */
+int32_t ovs_device_count(void);
+/* gfx arch name of device `dev` into buf (e.g. "gfx950"). */
+ovs_status ovs_device_arch(int32_t dev, char* buf, size_t buflen);
+
+/* Layout-compatible with cv::KeyPoint: pt.x, pt.y, size, angle, response, octave, class_id (28 bytes). */
+typedef struct ovs_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} ovs_keypoint;
+
+/* replaces: feature::orb_params (src/openvslam/feature/orb_params.h): same five fields, same defaults
+ * (2000, 1.2, 8, 20, 7). Feature.mask_rectangles is applied by the C++ class (it rasterises rect_mask_). */
+typedef struct ovs_orb_params {
+    int32_t max_num_keypts;
+    float scale_factor;
+    int32_t num_levels;
+    int32_t ini_fast_thr;
+    int32_t min_fast_thr;
+} ovs_orb_params;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * ORB extractor.  replaces: feature::orb_extractor (src/openvslam/feature/orb_extractor.{h,cc}):
+ *   ctor/initialize/calc_scale_factors -> ovs_orb_create (+ ovs_orb_tables)
+ *   extract(image, mask, keypts, descriptors) -> ovs_orb_extract (host) / ovs_orb_extract_batch_dev (device, batched)
+ *   public member image_pyramid_ -> ovs_orb_pyramid_level
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ovs_orb ovs_orb;
+
+/* Creates an extractor able to process up to max_batch frames of up to max_rows x max_cols per call on HIP device
+ * `device`. All device memory is allocated here; extract calls never allocate. */
+ovs_status ovs_orb_create(const ovs_orb_params* params, int32_t max_rows, int32_t max_cols, int32_t max_batch, int32_t device,
+                          ovs_orb** out);
+ovs_status ovs_orb_destroy(ovs_orb* h);
+
+/* replaces: orb_extractor::get_scale_factors / get_inv_scale_factors / get_level_sigma_sq / get_inv_level_sigma_sq and
+ * num_keypts_per_level_. Any output pointer may be NULL. Arrays hold num_levels entries. */
+ovs_status ovs_orb_tables(const ovs_orb* h, float* scale_factors, float* inv_scale_factors, float* level_sigma_sq,
+                          float* inv_level_sigma_sq, int32_t* num_keypts_per_level);
+
+/* Upper bound on the keypoints one frame can produce (sum over levels of N_level + 3): size outputs with this. */
+int32_t ovs_orb_max_keypoints(const ovs_orb* h);
+
+/* replaces: orb_extractor::extract(const cv::_InputArray& image, const cv::_InputArray& mask,
+ *                                  std::vector<cv::KeyPoint>& keypts, const cv::_OutputArray& descriptors).
+ * image: rows x cols CV_8UC1 with `stride` bytes per row. mask: NULL or rows x cols u8, 0 = masked out (upstream:
+ * in_mask or rect_mask_). kps / desc: caller-owned, capacity `cap` keypoints (desc = cap x 32 bytes, row i of desc
+ * belongs to kps[i]; byte j bit i = test 8j+i). *n_out = number written. Keypoints are ordered level-major, within a
+ * level in quad-tree node-list order. Empty image (rows or cols 0): OK with *n_out = 0 (upstream: early return). */
+ovs_status ovs_orb_extract(ovs_orb* h, const uint8_t* image, int32_t rows, int32_t cols, size_t stride, const uint8_t* mask,
+                           size_t mask_stride, ovs_keypoint* kps, uint8_t* desc, int32_t cap, int32_t* n_out);
+
+/* Device-resident batched form of the same computation: `batch` frames of rows x cols u8 already in HBM, frame b at
+ * d_images + b*frame_stride, row stride `stride` (both multiples of 4, base 4-byte aligned). d_masks: NULL or same layout.
+ * Outputs stay in HBM: d_kps[b*cap + i], d_desc[(b*cap + i)*32], d_counts[b] (counts are clamped to cap).
+ * Asynchronous on `stream`. */
+ovs_status ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_images, int32_t batch, int32_t rows, int32_t cols, size_t stride,
+                                     size_t frame_stride, const uint8_t* d_masks, ovs_keypoint* d_kps, uint8_t* d_desc,
+                                     int32_t* d_counts, int32_t cap, void* stream);
+
+/* replaces: the public member orb_extractor::image_pyramid_ (read by match::stereo). Copies level `level` of frame
+ * `frame` (0 for the host API) of the LAST extract into host_dst (rows*cols bytes, contiguous) and reports its size.
+ * host_dst may be NULL to query the size only. Synchronises the handle's stream. */
+ovs_status ovs_orb_pyramid_level(ovs_orb* h, int32_t frame, int32_t level, uint8_t* host_dst, int32_t* rows, int32_t* cols);
+
+/* Test / profiling observables of the LAST extract (synchronise the handle's stream):
+ * FAST candidates of (frame, level) after the per-cell two-threshold rule, as level-image x, y and FAST score, sorted by
+ * upstream's emission order (cell row, cell column, then row-major inside the cell). Returns the count in *n_out. */
+ovs_status ovs_orb_debug_candidates(ovs_orb* h, int32_t frame, int32_t level, int32_t* xs, int32_t* ys, int32_t* scores,
+                                    int32_t cap, int32_t* n_out);
+/* Keypoints per level of (frame) of the last extract. */
+ovs_status ovs_orb_debug_level_counts(ovs_orb* h, int32_t frame, int32_t* counts /* num_levels */);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * 256-bit Hamming matching.  replaces: match::base::compute_descriptor_distance_32 and match::robust::brute_force_match
+ * (src/openvslam/match/base.h, robust.{h,cc}).
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define OVS_HAMMING_DIST_THR_LOW 50
+#define OVS_HAMMING_DIST_THR_HIGH 100
+#define OVS_MAX_HAMMING_DIST 256
+
+typedef struct ovs_matcher ovs_matcher;
+/* A matcher context sized for `max_batch` problems of up to max_n1 frame descriptors x max_n2 keyframe descriptors. */
+ovs_status ovs_matcher_create(int32_t max_n1, int32_t max_n2, int32_t max_batch, int32_t device, ovs_matcher** out);
+ovs_status ovs_matcher_destroy(ovs_matcher* m);
+
+/* replaces: unsigned int robust::brute_force_match(data::frame& frm, data::keyframe* keyfrm,
+ *                                                  std::vector<std::pair<int,int>>& matches) const.
+ * desc_1: n1 x 32 frame descriptors (idx_1 side); desc_2: n2 x 32 keyframe descriptors (idx_2 side); valid_2: NULL or n2
+ * bytes, non-zero where the keyframe keypoint holds a landmark that !will_be_erased(). pairs: capacity cap pairs of
+ * (idx_1, idx_2) in upstream's emission order (ascending idx_2). *n_out = number of matches. */
+ovs_status ovs_robust_brute_force_match(ovs_matcher* m, const uint8_t* desc_1, int32_t n1, const uint8_t* desc_2, int32_t n2,
+                                        const uint8_t* valid_2, float lowe_ratio, int32_t* pairs, int32_t cap, int32_t* n_out);
+
+/* Device-resident batched form: problem p uses d_desc_1 + p*stride_1 (n1[p] rows) and d_desc_2 + p*stride_2 (n2[p] rows);
+ * d_n1 / d_n2 are device int32[batch] (so extractor counts can be consumed without a host round trip); d_valid_2: NULL or
+ * batch x stride_2/32 bytes. Outputs: d_pairs[(p*cap + i)*2 + {0,1}], d_counts[p]. Asynchronous on `stream`. */
+ovs_status ovs_robust_brute_force_match_batch_dev(ovs_matcher* m, const uint8_t* d_desc_1, size_t stride_1, const int32_t* d_n1,
+                                                  const uint8_t* d_desc_2, size_t stride_2, const int32_t* d_n2,
+                                                  const uint8_t* d_valid_2, int32_t batch, float lowe_ratio, int32_t* d_pairs,
+                                                  int32_t* d_counts, int32_t cap, void* stream);
+
+/* Unconstrained best / second-best Hamming distance per query over all valid targets (first-seen = lowest index wins
+ * ties), the primitive under bow_tree / area / projection style matchers when the candidate set is "all". Host pointers. */
+ovs_status ovs_hamming_best2(ovs_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, const uint8_t* t_valid,
+                             int32_t* best_idx, uint16_t* best, uint16_t* second);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,78 @@
+"""ctypes loader for libovslam_hip.so (the C ABI declared in include/ovslam_hip.h).
+
+There is deliberately NO fallback: if the library has not been built (python -c "import __graft_entry__ as g; g.build()"
+or make -C openvslam_amd/csrc) or no HIP device is usable, importing / calling raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libovslam_hip.so")
+
+OVS_OK = 0
+STATUS_NAMES = {0: "OVS_OK", -1: "OVS_ERR_INVALID", -2: "OVS_ERR_NO_DEVICE", -3: "OVS_ERR_HIP", -4: "OVS_ERR_CAPACITY",
+                -5: "OVS_ERR_ALIGN"}
+
+
+class OvsError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = _lib.ovs_last_error().decode() if _lib is not None else ""
+        super().__init__("%s failed: %s%s" % (where, STATUS_NAMES.get(status, status), (" (" + msg + ")") if msg else ""))
+
+
+class OrbParams(C.Structure):
+    """feature::orb_params (expected: src/openvslam/feature/orb_params.h)."""
+    _fields_ = [("max_num_keypts", C.c_int32), ("scale_factor", C.c_float), ("num_levels", C.c_int32),
+                ("ini_fast_thr", C.c_int32), ("min_fast_thr", C.c_int32)]
+
+
+_lib = None
+
+# every symbol include/ovslam_hip.h declares: name -> (restype, argtypes)
+_vp, _i32, _sz, _f = C.c_void_p, C.c_int32, C.c_size_t, C.c_float
+SYMBOLS = {
+    "ovs_last_error": (C.c_char_p, []),
+    "ovs_device_count": (_i32, []),
+    "ovs_device_arch": (_i32, [_i32, C.c_char_p, _sz]),
+    "ovs_orb_create": (_i32, [C.POINTER(OrbParams), _i32, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "ovs_orb_destroy": (_i32, [_vp]),
+    "ovs_orb_tables": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "ovs_orb_max_keypoints": (_i32, [_vp]),
+    "ovs_orb_extract": (_i32, [_vp, _vp, _i32, _i32, _sz, _vp, _sz, _vp, _vp, _i32, C.POINTER(_i32)]),
+    "ovs_orb_extract_batch_dev": (_i32, [_vp, _vp, _i32, _i32, _i32, _sz, _sz, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "ovs_orb_pyramid_level": (_i32, [_vp, _i32, _i32, _vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "ovs_orb_debug_candidates": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, C.POINTER(_i32)]),
+    "ovs_orb_debug_level_counts": (_i32, [_vp, _i32, _vp]),
+    "ovs_matcher_create": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "ovs_matcher_destroy": (_i32, [_vp]),
+    "ovs_robust_brute_force_match": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _f, _vp, _i32, C.POINTER(_i32)]),
+    "ovs_robust_brute_force_match_batch_dev": (_i32, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _i32, _f, _vp, _vp, _i32, _vp]),
+    "ovs_hamming_best2": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+                              "There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)   # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, where):
+    if status != OVS_OK:
+        raise OvsError(status, where)
+
+
+def require_device():
+    n = lib().ovs_device_count()
+    if n < 1:
+        raise OvsError(-2, "ovs_device_count")
+    return n

@@ -1,0 +1,445 @@
+// orb_api.hip -- host side of the ORB extractor behind the C ABI (include/ovslam_hip.h): orb_params tables (A0), level
+// geometry, cv::resize coefficient tables, buffer ownership, launch sequence. Replaces the body of
+// feature::orb_extractor (expected: src/openvslam/feature/orb_extractor.{h,cc}, orb_params.{h,cc}).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ovs_common.h"
+
+namespace ovs {
+
+static thread_local std::string g_last_error;
+void set_last_error(const char* what, hipError_t e) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+}
+
+static inline int cv_round_f(float v) { return (int)std::nearbyintf(v); }
+
+// cv::resize INTER_LINEAR tables for one axis (OpenCV resize.cpp: fx = (float)((dx+0.5)*scale - 0.5); sx = cvFloor(fx);
+// fx -= sx; clamp; ialpha = saturate_cast<short>(cbuf * INTER_RESIZE_COEF_SCALE)).
+static void build_taps(int ssize, int dsize, ResizeTap* out) {
+    const double scale = (double)ssize / dsize;
+    for (int d = 0; d < dsize; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= s;
+        if (s < 0) { f = 0; s = 0; }
+        if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        out[d].o0 = (uint16_t)s;
+        out[d].o1 = (uint16_t)std::min(s + 1, ssize - 1);
+        out[d].a0 = (int16_t)cv_round_f((1.f - f) * 2048.f);
+        out[d].a1 = (int16_t)cv_round_f(f * 2048.f);
+    }
+}
+
+}   // namespace ovs
+
+using namespace ovs;
+
+struct ovs_orb {
+    ovs_orb_params p;
+    int device = 0;
+    int max_rows = 0, max_cols = 0, max_batch = 0;
+    hipStream_t stream = nullptr;
+    // A0 tables
+    std::vector<float> sf, isf, ls, ils;
+    std::vector<int> npl;
+    // geometry of the current image size
+    int cur_rows = 0, cur_cols = 0;
+    FrameGeo geo;
+    std::vector<ResizeTap> taps;
+    // device memory
+    FrameGeo* d_geo = nullptr;
+    ResizeTap* d_taps = nullptr;
+    size_t taps_cap = 0;
+    DevBuffers d{};
+    size_t pyr_cap = 0, cand_cap = 0, node_cap = 0, kps_cap = 0;
+    // host-API staging
+    uint8_t* d_img = nullptr;
+    uint8_t* d_mask = nullptr;
+    size_t img_pitch = 0;
+    ovs_keypoint* d_out_kps = nullptr;
+    uint8_t* d_out_desc = nullptr;
+    int32_t* d_out_counts = nullptr;
+    int out_cap = 0;
+    // last extract (for pyramid / debug getters)
+    const uint8_t* last_img0 = nullptr;
+    size_t last_stride0 = 0, last_frame_stride0 = 0;
+    int last_batch = 0;
+};
+
+namespace {
+
+void calc_tables(ovs_orb* h) {
+    const ovs_orb_params& p = h->p;
+    const int L = p.num_levels;
+    h->sf.assign(L, 1.0f);
+    h->isf.assign(L, 1.0f);
+    h->ls.assign(L, 1.0f);
+    h->ils.assign(L, 1.0f);
+    for (int l = 1; l < L; ++l) h->sf[l] = p.scale_factor * h->sf[l - 1];   // cumulative float product
+    for (int l = 0; l < L; ++l) {
+        h->isf[l] = 1.0f / h->sf[l];
+        h->ls[l] = h->sf[l] * h->sf[l];
+        h->ils[l] = 1.0f / h->ls[l];
+    }
+    h->npl.assign(L, 0);
+    double desired = p.max_num_keypts * (1.0 - 1.0 / p.scale_factor) / (1.0 - std::pow(1.0 / p.scale_factor, (double)L));
+    int total = 0;
+    for (int l = 0; l < L - 1; ++l) {
+        h->npl[l] = (int)std::round(desired);
+        total += h->npl[l];
+        desired *= 1.0 / p.scale_factor;
+    }
+    h->npl[L - 1] = std::max(p.max_num_keypts - total, 0);
+}
+
+// Level sizes, cell grids, root grids, capacities and offsets for an image of rows x cols. Returns false if the geometry
+// cannot be processed (level too small for the packed formats, too many root patches).
+bool build_geometry(const ovs_orb* h, int rows, int cols, FrameGeo& geo, std::vector<ResizeTap>& taps, size_t& pyr_bytes,
+                    size_t& cand_entries, size_t& node_entries) {
+    const int L = h->p.num_levels;
+    std::memset(&geo, 0, sizeof(geo));
+    geo.num_levels = L;
+    geo.ini_thr = std::min(std::max(h->p.ini_fast_thr, 0), 255);
+    geo.min_thr = std::min(std::max(h->p.min_fast_thr, 0), 255);
+    taps.clear();
+    pyr_bytes = 0;
+    cand_entries = 0;
+    node_entries = 0;
+    int cell_base = 0, kp_base = 0;
+    int prev_rows = rows, prev_cols = cols;
+    if (rows > 8191 || cols > 8191) return false;
+    for (int l = 0; l < L; ++l) {
+        LevelGeo& g = geo.lv[l];
+        if (l == 0) {
+            g.rows = rows;
+            g.cols = cols;
+        } else {
+            const double scale = h->sf[l];   // compute_image_pyramid: size from the ORIGINAL image
+            g.cols = (int)std::round(cols * 1.0 / scale);
+            g.rows = (int)std::round(rows * 1.0 / scale);
+            if (g.rows < 1 || g.cols < 1) return false;
+            g.pitch = (g.cols + 255) & ~255;
+            g.plane_off = (int64_t)pyr_bytes;
+            pyr_bytes += (size_t)g.pitch * g.rows;
+            g.xtab_off = (int64_t)taps.size();
+            taps.resize(taps.size() + g.cols);
+            build_taps(prev_cols, g.cols, &taps[g.xtab_off]);
+            g.ytab_off = (int64_t)taps.size();
+            taps.resize(taps.size() + g.rows);
+            build_taps(prev_rows, g.rows, &taps[g.ytab_off]);
+        }
+        prev_rows = g.rows;
+        prev_cols = g.cols;
+        g.scale = h->sf[l];
+        g.kp_size = (float)(unsigned)(kFastPatchSize * h->sf[l]);
+        g.max_bx = g.cols - kOrbPatchRadius;
+        g.max_by = g.rows - kOrbPatchRadius;
+        const int W = g.max_bx - kOrbPatchRadius, H = g.max_by - kOrbPatchRadius;
+        // valid cells: 19 + 64*i < max_border - overlap
+        g.ncx = W > kCellOverlap ? (W - kCellOverlap + kCellSize - 1) / kCellSize : 0;
+        g.ncy = H > kCellOverlap ? (H - kCellOverlap + kCellSize - 1) / kCellSize : 0;
+        if (g.ncx == 0 || g.ncy == 0) g.ncx = g.ncy = 0;
+        g.cell_base = cell_base;
+        cell_base += g.ncx * g.ncy;
+        g.n_keypts = h->npl[l];
+        g.gx = g.gy = 1;
+        g.dx = g.dy = 1.0;
+        if (g.ncx) {
+            // initialize_nodes: a row (landscape) or column (portrait) of near-square root patches
+            const double ratio = (double)W / H;
+            if (ratio > 1) {
+                g.gx = (int)std::round(ratio);
+                g.gy = 1;
+                g.dx = (double)W / g.gx;
+                g.dy = H;
+            } else {
+                g.gx = 1;
+                g.gy = (int)std::round(1 / ratio);
+                g.dx = W;
+                g.dy = (double)H / g.gy;
+            }
+            if (g.gx * g.gy > 64) return false;
+        }
+        const int nc = std::max(g.n_keypts, g.gx * g.gy) + 16;
+        g.max_nodes = 4 * nc;
+        if (g.max_nodes > 65535) return false;
+        g.kp_cap = std::max(g.n_keypts + 3, 4 * g.gx * g.gy);
+        g.kp_base = kp_base;
+        kp_base += g.kp_cap;
+        g.cand_cap = g.ncx * g.ncy * 1024;   // NMS leaves at most one survivor per 2x2 block of a 64x64 cell
+        g.cand_off = (int64_t)cand_entries;
+        cand_entries += (size_t)g.cand_cap;
+        g.node_off = (int64_t)node_entries;
+        node_entries += (size_t)2 * g.max_nodes;
+    }
+    geo.total_cells = cell_base;
+    geo.total_kp_cap = kp_base;
+    return true;
+}
+
+ovs_status ensure_geometry(ovs_orb* h, int rows, int cols) {
+    if (rows == h->cur_rows && cols == h->cur_cols) return OVS_OK;
+    if (rows > h->max_rows || cols > h->max_cols) return OVS_ERR_CAPACITY;
+    size_t pyr_bytes, cand_entries, node_entries;
+    if (!build_geometry(h, rows, cols, h->geo, h->taps, pyr_bytes, cand_entries, node_entries)) return OVS_ERR_INVALID;
+    if (pyr_bytes > h->d.pyr_frame_bytes || cand_entries > h->d.cand_frame_entries || node_entries > h->d.node_frame_entries ||
+        h->taps.size() > h->taps_cap || (size_t)h->geo.total_kp_cap > h->kps_cap)
+        return OVS_ERR_CAPACITY;
+    // the buffers keep the strides they were allocated with (max geometry); only offsets inside a frame block change
+    OVS_HIP_TRY(hipStreamSynchronize(h->stream));
+    OVS_HIP_TRY(hipMemcpy(h->d_geo, &h->geo, sizeof(FrameGeo), hipMemcpyHostToDevice));
+    if (!h->taps.empty())
+        OVS_HIP_TRY(hipMemcpy(h->d_taps, h->taps.data(), h->taps.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+    h->cur_rows = rows;
+    h->cur_cols = cols;
+    return OVS_OK;
+}
+
+ovs_status run_extract(ovs_orb* h, const uint8_t* d_images, int batch, int rows, int cols, size_t stride, size_t frame_stride,
+                       const uint8_t* d_masks, ovs_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int cap, hipStream_t s) {
+    ovs_status st = ensure_geometry(h, rows, cols);
+    if (st != OVS_OK) return st;
+    const FrameGeo& geo = h->geo;
+    const int L = geo.num_levels;
+    OVS_HIP_TRY(hipMemsetAsync(h->d.cand_count, 0, sizeof(uint32_t) * (size_t)batch * L, s));
+    // A1: each level from the previous one
+    for (int l = 1; l < L; ++l) {
+        const LevelGeo& g = geo.lv[l];
+        const LevelGeo& gp = geo.lv[l - 1];
+        const uint8_t* src = (l == 1) ? d_images : h->d.pyr + gp.plane_off;
+        const size_t src_fs = (l == 1) ? frame_stride : h->d.pyr_frame_bytes;
+        const int src_pitch = (l == 1) ? (int)stride : gp.pitch;
+        OVS_HIP_TRY(launch_resize(src, src_fs, src_pitch, gp.rows, gp.cols, h->d.pyr + g.plane_off, h->d.pyr_frame_bytes, g.pitch,
+                                  g.rows, g.cols, h->d_taps + g.xtab_off, h->d_taps + g.ytab_off, batch, s));
+    }
+    OVS_HIP_TRY(launch_fast(geo, h->d, d_images, stride, frame_stride, d_masks, rows, batch, s));
+    OVS_HIP_TRY(launch_tree(geo, h->d, batch, s));
+    OVS_HIP_TRY(launch_describe(geo, h->d, d_images, stride, frame_stride, d_kps, d_desc, d_counts, cap, batch, s));
+    h->last_img0 = d_images;
+    h->last_stride0 = stride;
+    h->last_frame_stride0 = frame_stride;
+    h->last_batch = batch;
+    return OVS_OK;
+}
+
+}   // namespace
+
+extern "C" {
+
+const char* ovs_last_error(void) { return g_last_error.c_str(); }
+
+int32_t ovs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+ovs_status ovs_device_arch(int32_t dev, char* buf, size_t buflen) {
+    if (!buf || buflen == 0) return OVS_ERR_INVALID;
+    hipDeviceProp_t prop;
+    OVS_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    std::snprintf(buf, buflen, "%s", prop.gcnArchName);
+    return OVS_OK;
+}
+
+ovs_status ovs_orb_create(const ovs_orb_params* params, int32_t max_rows, int32_t max_cols, int32_t max_batch, int32_t device,
+                          ovs_orb** out) {
+    if (!params || !out || params->num_levels < 1 || params->num_levels > OVS_MAX_LEVELS || !(params->scale_factor > 1.0f) ||
+        params->max_num_keypts < 1 || max_rows < 1 || max_cols < 1 || max_batch < 1)
+        return OVS_ERR_INVALID;
+    *out = nullptr;
+    if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
+    ovs_orb* h = new (std::nothrow) ovs_orb();
+    if (!h) return OVS_ERR_INVALID;
+    h->p = *params;
+    h->device = device;
+    h->max_rows = max_rows;
+    h->max_cols = max_cols;
+    h->max_batch = max_batch;
+    calc_tables(h);
+    FrameGeo geo;
+    std::vector<ResizeTap> taps;
+    size_t pyr_bytes, cand_entries, node_entries;
+    if (!build_geometry(h, max_rows, max_cols, geo, taps, pyr_bytes, cand_entries, node_entries)) {
+        delete h;
+        return OVS_ERR_INVALID;
+    }
+#define CREATE_TRY(expr)                       \
+    do {                                       \
+        hipError_t _e = (expr);                \
+        if (_e != hipSuccess) {                \
+            ovs::set_last_error(#expr, _e);    \
+            ovs_orb_destroy(h);                \
+            return OVS_ERR_HIP;                \
+        }                                      \
+    } while (0)
+    CREATE_TRY(hipSetDevice(device));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const int L = params->num_levels;
+    const size_t B = (size_t)max_batch;
+    h->d.pyr_frame_bytes = (pyr_bytes + 255) & ~(size_t)255;
+    h->d.cand_frame_entries = cand_entries;
+    h->d.node_frame_entries = node_entries;
+    h->taps_cap = taps.size() + 64;
+    h->kps_cap = (size_t)geo.total_kp_cap;
+    CREATE_TRY(hipMalloc(&h->d_geo, sizeof(FrameGeo)));
+    CREATE_TRY(hipMalloc(&h->d_taps, h->taps_cap * sizeof(ResizeTap)));
+    CREATE_TRY(hipMalloc(&h->d.pyr, std::max<size_t>(h->d.pyr_frame_bytes * B, 256)));
+    CREATE_TRY(hipMalloc(&h->d.cand, std::max<size_t>(cand_entries * B * sizeof(uint64_t), 256)));
+    CREATE_TRY(hipMalloc(&h->d.cand_count, sizeof(uint32_t) * B * L));
+    CREATE_TRY(hipMalloc(&h->d.nodes, std::max<size_t>(node_entries * B * 16, 256)));
+    CREATE_TRY(hipMalloc(&h->d.lvl_kps, std::max<size_t>(h->kps_cap * B * sizeof(uint64_t), 256)));
+    CREATE_TRY(hipMalloc(&h->d.lvl_count, sizeof(uint32_t) * B * L));
+    CREATE_TRY(hipMemset(h->d.lvl_count, 0, sizeof(uint32_t) * B * L));
+    h->d.geo = h->d_geo;
+    h->d.taps = h->d_taps;
+    // host-API staging: one frame
+    h->img_pitch = ((size_t)max_cols + 255) & ~(size_t)255;
+    h->out_cap = geo.total_kp_cap;
+    CREATE_TRY(hipMalloc(&h->d_img, h->img_pitch * max_rows));
+    CREATE_TRY(hipMalloc(&h->d_mask, h->img_pitch * max_rows));
+    CREATE_TRY(hipMalloc(&h->d_out_kps, sizeof(ovs_keypoint) * h->out_cap));
+    CREATE_TRY(hipMalloc(&h->d_out_desc, (size_t)32 * h->out_cap));
+    CREATE_TRY(hipMalloc(&h->d_out_counts, sizeof(int32_t) * 4));
+#undef CREATE_TRY
+    *out = h;
+    return OVS_OK;
+}
+
+ovs_status ovs_orb_destroy(ovs_orb* h) {
+    if (!h) return OVS_OK;
+    if (h->stream) hipStreamSynchronize(h->stream);
+    hipFree(h->d_geo);
+    hipFree(h->d_taps);
+    hipFree(h->d.pyr);
+    hipFree(h->d.cand);
+    hipFree(h->d.cand_count);
+    hipFree(h->d.nodes);
+    hipFree(h->d.lvl_kps);
+    hipFree(h->d.lvl_count);
+    hipFree(h->d_img);
+    hipFree(h->d_mask);
+    hipFree(h->d_out_kps);
+    hipFree(h->d_out_desc);
+    hipFree(h->d_out_counts);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return OVS_OK;
+}
+
+ovs_status ovs_orb_tables(const ovs_orb* h, float* sf, float* isf, float* ls, float* ils, int32_t* npl) {
+    if (!h) return OVS_ERR_INVALID;
+    for (int l = 0; l < h->p.num_levels; ++l) {
+        if (sf) sf[l] = h->sf[l];
+        if (isf) isf[l] = h->isf[l];
+        if (ls) ls[l] = h->ls[l];
+        if (ils) ils[l] = h->ils[l];
+        if (npl) npl[l] = h->npl[l];
+    }
+    return OVS_OK;
+}
+
+int32_t ovs_orb_max_keypoints(const ovs_orb* h) { return h ? h->out_cap : 0; }
+
+ovs_status ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_images, int32_t batch, int32_t rows, int32_t cols, size_t stride,
+                                     size_t frame_stride, const uint8_t* d_masks, ovs_keypoint* d_kps, uint8_t* d_desc,
+                                     int32_t* d_counts, int32_t cap, void* stream) {
+    if (!h || !d_images || !d_kps || !d_desc || !d_counts || batch < 1 || rows < 1 || cols < 1 || cap < 1) return OVS_ERR_INVALID;
+    if (batch > h->max_batch) return OVS_ERR_CAPACITY;
+    if (((uintptr_t)d_images & 3) || (stride & 3) || (frame_stride & 3) || stride < (size_t)cols) return OVS_ERR_ALIGN;
+    if (d_masks && ((uintptr_t)d_masks & 3)) return OVS_ERR_ALIGN;
+    OVS_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    return run_extract(h, d_images, batch, rows, cols, stride, frame_stride, d_masks, d_kps, d_desc, d_counts, cap, s);
+}
+
+ovs_status ovs_orb_extract(ovs_orb* h, const uint8_t* image, int32_t rows, int32_t cols, size_t stride, const uint8_t* mask,
+                           size_t mask_stride, ovs_keypoint* kps, uint8_t* desc, int32_t cap, int32_t* n_out) {
+    if (!h || !n_out) return OVS_ERR_INVALID;
+    *n_out = 0;
+    if (!image || rows <= 0 || cols <= 0) return OVS_OK;   // upstream: empty image -> early return
+    if (rows > h->max_rows || cols > h->max_cols) return OVS_ERR_CAPACITY;
+    if (cap < 0 || (cap > 0 && (!kps || !desc))) return OVS_ERR_INVALID;
+    OVS_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    OVS_HIP_TRY(hipMemcpy2DAsync(h->d_img, h->img_pitch, image, stride, cols, rows, hipMemcpyHostToDevice, s));
+    if (mask) OVS_HIP_TRY(hipMemcpy2DAsync(h->d_mask, h->img_pitch, mask, mask_stride, cols, rows, hipMemcpyHostToDevice, s));
+    ovs_status st = run_extract(h, h->d_img, 1, rows, cols, h->img_pitch, h->img_pitch * (size_t)rows, mask ? h->d_mask : nullptr,
+                                h->d_out_kps, h->d_out_desc, h->d_out_counts, h->out_cap, s);
+    if (st != OVS_OK) return st;
+    int32_t n = 0;
+    OVS_HIP_TRY(hipMemcpyAsync(&n, h->d_out_counts, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
+    const int32_t m = std::min(n, cap);
+    if (m > 0) {
+        OVS_HIP_TRY(hipMemcpyAsync(kps, h->d_out_kps, sizeof(ovs_keypoint) * m, hipMemcpyDeviceToHost, s));
+        OVS_HIP_TRY(hipMemcpyAsync(desc, h->d_out_desc, (size_t)32 * m, hipMemcpyDeviceToHost, s));
+        OVS_HIP_TRY(hipStreamSynchronize(s));
+    }
+    *n_out = m;
+    return n > cap ? OVS_ERR_CAPACITY : OVS_OK;
+}
+
+ovs_status ovs_orb_pyramid_level(ovs_orb* h, int32_t frame, int32_t level, uint8_t* host_dst, int32_t* rows, int32_t* cols) {
+    if (!h || level < 0 || level >= h->p.num_levels || frame < 0 || frame >= h->last_batch || !h->last_img0) return OVS_ERR_INVALID;
+    const LevelGeo& g = h->geo.lv[level];
+    if (rows) *rows = g.rows;
+    if (cols) *cols = g.cols;
+    if (!host_dst) return OVS_OK;
+    OVS_HIP_TRY(hipSetDevice(h->device));
+    OVS_HIP_TRY(hipStreamSynchronize(h->stream));
+    OVS_HIP_TRY(hipDeviceSynchronize());
+    if (level == 0)
+        OVS_HIP_TRY(hipMemcpy2D(host_dst, g.cols, h->last_img0 + (size_t)frame * h->last_frame_stride0, h->last_stride0, g.cols, g.rows,
+                                hipMemcpyDeviceToHost));
+    else
+        OVS_HIP_TRY(hipMemcpy2D(host_dst, g.cols, h->d.pyr + (size_t)frame * h->d.pyr_frame_bytes + g.plane_off, g.pitch, g.cols, g.rows,
+                                hipMemcpyDeviceToHost));
+    return OVS_OK;
+}
+
+ovs_status ovs_orb_debug_candidates(ovs_orb* h, int32_t frame, int32_t level, int32_t* xs, int32_t* ys, int32_t* scores, int32_t cap,
+                                    int32_t* n_out) {
+    if (!h || !n_out || level < 0 || level >= h->p.num_levels || frame < 0 || frame >= h->last_batch) return OVS_ERR_INVALID;
+    OVS_HIP_TRY(hipSetDevice(h->device));
+    OVS_HIP_TRY(hipDeviceSynchronize());
+    const LevelGeo& g = h->geo.lv[level];
+    const int L = h->p.num_levels;
+    uint32_t n = 0;
+    OVS_HIP_TRY(hipMemcpy(&n, h->d.cand_count + (size_t)frame * L + level, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    n = std::min<uint32_t>(n, (uint32_t)g.cand_cap);
+    std::vector<uint64_t> c(n);
+    if (n)
+        OVS_HIP_TRY(hipMemcpy(c.data(), h->d.cand + (size_t)frame * h->d.cand_frame_entries + g.cand_off, n * sizeof(uint64_t),
+                              hipMemcpyDeviceToHost));
+    const uint32_t ncx = (uint32_t)g.ncx;
+    std::sort(c.begin(), c.end(), [ncx](uint64_t a, uint64_t b) {
+        return cand_order(cand_x(a), cand_y(a), ncx) < cand_order(cand_x(b), cand_y(b), ncx);
+    });
+    for (uint32_t i = 0; i < n && (int32_t)i < cap; ++i) {
+        if (xs) xs[i] = (int32_t)cand_x(c[i]);
+        if (ys) ys[i] = (int32_t)cand_y(c[i]);
+        if (scores) scores[i] = (int32_t)cand_score(c[i]);
+    }
+    *n_out = (int32_t)n;
+    return OVS_OK;
+}
+
+ovs_status ovs_orb_debug_level_counts(ovs_orb* h, int32_t frame, int32_t* counts) {
+    if (!h || !counts || frame < 0 || frame >= h->max_batch) return OVS_ERR_INVALID;
+    OVS_HIP_TRY(hipSetDevice(h->device));
+    OVS_HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint32_t> c(h->p.num_levels);
+    OVS_HIP_TRY(hipMemcpy(c.data(), h->d.lvl_count + (size_t)frame * h->p.num_levels, sizeof(uint32_t) * c.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < c.size(); ++i) counts[i] = (int32_t)c[i];
+    return OVS_OK;
+}
+
+}   // extern "C"

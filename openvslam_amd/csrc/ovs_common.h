@@ -1,0 +1,104 @@
+// ovs_common.h -- internal declarations shared by the HIP translation units of libovslam_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ovslam_hip.h"
+
+namespace ovs {
+
+constexpr int kOrbPatchRadius = 19;   // orb_extractor::orb_patch_radius_
+constexpr int kFastPatchSize = 31;    // fast_patch_size_
+constexpr int kCellSize = 64;         // compute_fast_keypoints cell_size
+constexpr int kCellOverlap = 6;       // compute_fast_keypoints overlap
+constexpr int kDetOrigin = kOrbPatchRadius + 3;   // first pixel FAST can test (cell's own 3-px dead frame)
+
+// One bilinear tap pair of cv::resize's 11-bit fixed-point tables (computed on the host, double/float as OpenCV does).
+struct ResizeTap {
+    uint16_t o0, o1;   // source indices (o1 = min(o0+1, size-1))
+    int16_t a0, a1;    // 11-bit coefficients
+};
+
+// Geometry of one pyramid level for the handle's current (rows, cols). Lives in device memory; kernels read it uniformly.
+struct LevelGeo {
+    int32_t rows, cols;
+    int32_t pitch;            // bytes per row of this level's plane (levels >= 1; level 0 uses the caller's stride)
+    int32_t ncx, ncy;         // valid FAST cells
+    int32_t cell_base;        // prefix sum of ncx*ncy over lower levels
+    int32_t max_bx, max_by;   // cols-19, rows-19
+    int32_t n_keypts;         // N_level (num_keypts_per_level_)
+    int32_t kp_cap;           // N_level + 3
+    int32_t kp_base;          // prefix sum of kp_cap over lower levels
+    int32_t cand_cap;         // capacity of this level's candidate list
+    int32_t gx, gy;           // root grid of the quad-tree
+    int32_t max_nodes;        // 4*N_level + 16
+    int32_t pad0;
+    int64_t plane_off;        // byte offset of the plane inside one frame's pyramid block (levels >= 1)
+    int64_t cand_off;         // entry offset of the candidate list inside one frame's candidate block
+    int64_t node_off;         // entry offset of the node scratch inside one frame's node block
+    int64_t xtab_off, ytab_off;   // ResizeTap offsets (level >= 1: taps from level-1 to level)
+    double dx, dy;            // root patch size
+    float scale;              // scale_factors_[level]
+    float kp_size;            // (float)(unsigned)(31*scale)
+};
+
+struct FrameGeo {
+    int32_t num_levels;
+    int32_t total_cells;
+    int32_t total_kp_cap;
+    int32_t ini_thr, min_thr;
+    int32_t pad;
+    LevelGeo lv[OVS_MAX_LEVELS];
+};
+
+// Candidate entry (u64): [score:8 | y:13 | x:13 | node:16], score = FAST response (S-1), x/y = level-image coordinates.
+__host__ __device__ inline uint64_t cand_pack(uint32_t x, uint32_t y, uint32_t score, uint32_t node) {
+    return ((uint64_t)score << 42) | ((uint64_t)y << 29) | ((uint64_t)x << 16) | (uint64_t)node;
+}
+__host__ __device__ inline uint32_t cand_x(uint64_t c) { return (uint32_t)(c >> 16) & 0x1FFFu; }
+__host__ __device__ inline uint32_t cand_y(uint64_t c) { return (uint32_t)(c >> 29) & 0x1FFFu; }
+__host__ __device__ inline uint32_t cand_score(uint64_t c) { return (uint32_t)(c >> 42) & 0xFFu; }
+__host__ __device__ inline uint32_t cand_node(uint64_t c) { return (uint32_t)c & 0xFFFFu; }
+// Upstream's emission order of a candidate: cell row, cell column, then row-major inside the cell.
+__host__ __device__ inline uint32_t cand_order(uint32_t x, uint32_t y, uint32_t ncx) {
+    const uint32_t dx = x - kDetOrigin, dy = y - kDetOrigin;
+    return (((dy >> 6) * ncx + (dx >> 6)) << 12) | ((dy & 63u) << 6) | (dx & 63u);
+}
+
+// Selected keypoint of a level before description (u64): [score:8 | y:13 | x:13].
+struct DevBuffers {
+    const FrameGeo* geo;          // device copy
+    const ResizeTap* taps;        // device
+    uint8_t* pyr;                 // max_batch * pyr_frame_bytes (levels >= 1)
+    size_t pyr_frame_bytes;
+    uint64_t* cand;               // max_batch * cand_frame_entries
+    size_t cand_frame_entries;
+    uint32_t* cand_count;         // max_batch * num_levels
+    uint32_t* nodes;              // max_batch * node_frame_entries * 4 u32 (two ping-pong lists inside)
+    size_t node_frame_entries;
+    uint64_t* lvl_kps;            // max_batch * total_kp_cap
+    uint32_t* lvl_count;          // max_batch * num_levels
+};
+
+// ---- kernel launchers (each defined next to its kernel) ----
+hipError_t launch_resize(const uint8_t* src, size_t src_frame_stride, int src_pitch, int srows, int scols, uint8_t* dst,
+                         size_t dst_frame_stride, int dst_pitch, int drows, int dcols, const ResizeTap* xt, const ResizeTap* yt,
+                         int batch, hipStream_t s);
+hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
+                       const uint8_t* mask, int mask_rows, int batch, hipStream_t s);
+hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hipStream_t s);
+hipError_t launch_describe(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
+                           ovs_keypoint* kps, uint8_t* desc, int32_t* counts, int cap, int batch, hipStream_t s);
+
+void set_last_error(const char* what, hipError_t e);
+
+}   // namespace ovs
+
+#define OVS_HIP_TRY(expr)                                  \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) {                            \
+            ovs::set_last_error(#expr, _e);                \
+            return OVS_ERR_HIP;                            \
+        }                                                  \
+    } while (0)

@@ -1,0 +1,152 @@
+"""Host-side mirror of feature::orb_extractor / feature::orb_params (expected: src/openvslam/feature/orb_extractor.h,
+orb_params.h) over the C ABI. Same names, same argument meaning, same defaults; the computation is the HIP library's."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])   # cv::KeyPoint layout, 28 bytes
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class orb_params:
+    """feature::orb_params: max_num_keypts=2000, scale_factor=1.2, num_levels=8, ini_fast_thr=20, min_fast_thr=7."""
+
+    def __init__(self, max_num_keypts=2000, scale_factor=1.2, num_levels=8, ini_fast_thr=20, min_fast_thr=7,
+                 mask_rects=()):
+        self.max_num_keypts = int(max_num_keypts)
+        self.scale_factor = float(scale_factor)
+        self.num_levels = int(num_levels)
+        self.ini_fast_thr = int(ini_fast_thr)
+        self.min_fast_thr = int(min_fast_thr)
+        self.mask_rects = [tuple(map(float, r)) for r in mask_rects]   # [x_min, x_max, y_min, y_max] ratios
+        for r in self.mask_rects:
+            if len(r) != 4 or r[0] >= r[1] or r[2] >= r[3]:
+                raise ValueError("mask rectangle must be [x_min, x_max, y_min, y_max] with min < max")
+
+    def _c(self):
+        return _lib.OrbParams(self.max_num_keypts, self.scale_factor, self.num_levels, self.ini_fast_thr, self.min_fast_thr)
+
+
+class orb_extractor:
+    """feature::orb_extractor. `extract(image, mask)` returns (keypts, descriptors) instead of filling out-arguments.
+
+    max_rows/max_cols/max_batch size the device buffers once (upstream allocates lazily per frame; HBM is plentiful)."""
+
+    def __init__(self, params=None, max_rows=1080, max_cols=1920, max_batch=1, device=0):
+        self.orb_params_ = params or orb_params()
+        self._L = _lib.lib()
+        _lib.require_device()
+        h = C.c_void_p()
+        cp = self.orb_params_._c()
+        _lib.check(self._L.ovs_orb_create(C.byref(cp), max_rows, max_cols, max_batch, device, C.byref(h)), "ovs_orb_create")
+        self._h = h
+        self.max_batch = max_batch
+        self.max_keypoints = self._L.ovs_orb_max_keypoints(self._h)
+        n = self.orb_params_.num_levels
+        self.scale_factors_ = np.zeros(n, np.float32)
+        self.inv_scale_factors_ = np.zeros(n, np.float32)
+        self.level_sigma_sq_ = np.zeros(n, np.float32)
+        self.inv_level_sigma_sq_ = np.zeros(n, np.float32)
+        self.num_keypts_per_level_ = np.zeros(n, np.int32)
+        _lib.check(self._L.ovs_orb_tables(self._h, _p(self.scale_factors_), _p(self.inv_scale_factors_), _p(self.level_sigma_sq_),
+                                          _p(self.inv_level_sigma_sq_), _p(self.num_keypts_per_level_)), "ovs_orb_tables")
+        self._rect_mask = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.ovs_orb_destroy(self._h)
+            self._h = None
+
+    # upstream getters
+    def get_max_num_keypoints(self):
+        return self.orb_params_.max_num_keypts
+
+    def get_scale_factor(self):
+        return self.orb_params_.scale_factor
+
+    def get_num_scale_levels(self):
+        return self.orb_params_.num_levels
+
+    def get_initial_fast_threshold(self):
+        return self.orb_params_.ini_fast_thr
+
+    def get_minimum_fast_threshold(self):
+        return self.orb_params_.min_fast_thr
+
+    def get_scale_factors(self):
+        return self.scale_factors_.copy()
+
+    def get_inv_scale_factors(self):
+        return self.inv_scale_factors_.copy()
+
+    def get_level_sigma_sq(self):
+        return self.level_sigma_sq_.copy()
+
+    def get_inv_level_sigma_sq(self):
+        return self.inv_level_sigma_sq_.copy()
+
+    def create_rectangle_mask(self, cols, rows):
+        """orb_extractor::create_rectangle_mask: 255 everywhere, 0 inside every mask rectangle (ratios of the image size)."""
+        if self._rect_mask is None or self._rect_mask.shape != (rows, cols):
+            m = np.full((rows, cols), 255, np.uint8)
+            for (x0, x1, y0, y1) in self.orb_params_.mask_rects:
+                m[int(rows * y0):int(rows * y1), int(cols * x0):int(cols * x1)] = 0
+            self._rect_mask = m
+        return self._rect_mask
+
+    def extract(self, image, mask=None):
+        image = np.ascontiguousarray(image)
+        if image.dtype != np.uint8 or image.ndim != 2:
+            raise TypeError("image must be CV_8UC1 (upstream asserts image.type() == CV_8UC1)")
+        if image.size == 0:
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        if mask is None and self.orb_params_.mask_rects:
+            mask = self.create_rectangle_mask(image.shape[1], image.shape[0])
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, np.uint8)
+            if mask.shape != image.shape:
+                raise ValueError("mask must have the image's size")
+        cap = self.max_keypoints
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int32(0)
+        _lib.check(self._L.ovs_orb_extract(self._h, _p(image), image.shape[0], image.shape[1], image.strides[0], _p(mask),
+                                           mask.strides[0] if mask is not None else 0, _p(kps), _p(desc), cap, C.byref(n)),
+                   "ovs_orb_extract")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch_dev(self, d_images, d_kps, d_desc, d_counts, stream=None, d_masks=None):
+        """Device-resident batched extract. d_images: torch uint8 CUDA tensor (B, rows, cols) contiguous (cols % 4 == 0);
+        outputs: d_kps (B, cap, 7) float32/int32 raw 28-byte records, d_desc (B, cap, 32) uint8, d_counts (B,) int32."""
+        B, rows, cols = d_images.shape
+        cap = d_desc.shape[1]
+        _lib.check(self._L.ovs_orb_extract_batch_dev(self._h, d_images.data_ptr(), B, rows, cols, d_images.stride(1),
+                                                     d_images.stride(0), d_masks.data_ptr() if d_masks is not None else None,
+                                                     d_kps.data_ptr(), d_desc.data_ptr(), d_counts.data_ptr(), cap,
+                                                     stream), "ovs_orb_extract_batch_dev")
+
+    # observable state upstream exposes as the public member image_pyramid_
+    def image_pyramid(self, level, frame=0):
+        r, c = C.c_int32(), C.c_int32()
+        _lib.check(self._L.ovs_orb_pyramid_level(self._h, frame, level, None, C.byref(r), C.byref(c)), "ovs_orb_pyramid_level")
+        out = np.zeros((r.value, c.value), np.uint8)
+        _lib.check(self._L.ovs_orb_pyramid_level(self._h, frame, level, _p(out), C.byref(r), C.byref(c)), "ovs_orb_pyramid_level")
+        return out
+
+    def debug_candidates(self, level, frame=0, cap=1 << 20):
+        xs, ys, sc = (np.zeros(cap, np.int32) for _ in range(3))
+        n = C.c_int32()
+        _lib.check(self._L.ovs_orb_debug_candidates(self._h, frame, level, _p(xs), _p(ys), _p(sc), cap, C.byref(n)),
+                   "ovs_orb_debug_candidates")
+        return xs[:n.value].copy(), ys[:n.value].copy(), sc[:n.value].copy()
+
+    def debug_level_counts(self, frame=0):
+        c = np.zeros(self.orb_params_.num_levels, np.int32)
+        _lib.check(self._L.ovs_orb_debug_level_counts(self._h, frame, _p(c)), "ovs_orb_debug_level_counts")
+        return c

@@ -1,0 +1,116 @@
+"""GPU parity: HIP robust::brute_force_match / best2 (through the C ABI) == CPU oracle, exactly (match pairs and order)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def match():
+    from openvslam_amd import match
+    return match
+
+
+def _descs(rng, n1, n2, n_true, max_flip=40):
+    """n2 keyframe descriptors; n_true of the n1 frame descriptors are bit-flipped copies (random pairs sit
+    at ~128+-8 and never pass THR_LOW, so matches must be constructed)."""
+    d2 = rng.integers(0, 256, size=(n2, 32), dtype=np.uint8)
+    d1 = rng.integers(0, 256, size=(n1, 32), dtype=np.uint8)
+    src = rng.permutation(n2)[:n_true]
+    dst = rng.permutation(n1)[:n_true]
+    for s, t in zip(src, dst):
+        bits = np.unpackbits(d2[s])
+        k = int(rng.integers(0, max_flip + 1))
+        flip = rng.permutation(256)[:k]
+        bits[flip] ^= 1
+        d1[t] = np.packbits(bits)
+    return d1, d2
+
+
+@pytest.mark.parametrize("n1,n2,n_true", [(2000, 2000, 1200), (2004, 1987, 1500), (1, 1, 1), (300, 5, 5), (5, 300, 5), (777, 1023, 0)])
+@pytest.mark.parametrize("ratio", [0.9, 0.6])
+def test_brute_force_match(match, oracle, n1, n2, n_true, ratio):
+    rng = np.random.default_rng(n1 * 31 + n2)
+    d1, d2 = _descs(rng, n1, n2, min(n_true, n1, n2))
+    valid = (rng.random(n2) < 0.9).astype(np.uint8)
+    m = match.robust(ratio, False, max_n1=2048, max_n2=2048)
+    for v in (None, valid):
+        want = oracle.robust_brute_force_match(d1, d2, v, ratio)
+        got = m.brute_force_match(d1, d2, v)
+        assert np.array_equal(got, want)
+    if n_true >= 1000:
+        assert len(want) > n_true // 3
+
+
+def test_claim_conflicts(match, oracle):
+    """Several keyframe descriptors compete for the same frame descriptor: exercises the already-matched rule."""
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, size=(40, 32), dtype=np.uint8)
+    d1 = np.repeat(base, 3, axis=0)     # 120 frame descriptors, triplets of near-duplicates
+    d2 = np.repeat(base, 5, axis=0)     # 200 keyframe descriptors, 5 claimants per triplet
+    for d in (d1, d2):
+        for i in range(len(d)):
+            bits = np.unpackbits(d[i])
+            bits[rng.permutation(256)[:int(rng.integers(0, 12))]] ^= 1
+            d[i] = np.packbits(bits)
+    for ratio in (0.6, 0.9, 1.0):
+        m = match.robust(ratio, False, max_n1=256, max_n2=256)
+        assert np.array_equal(m.brute_force_match(d1, d2), oracle.robust_brute_force_match(d1, d2, None, ratio))
+
+
+def test_overflowing_near_lists_fall_back_exactly(match, oracle):
+    """Many identical descriptors overflow the near lists -> literal serial replay path."""
+    d1 = np.zeros((100, 32), np.uint8)
+    d2 = np.zeros((60, 32), np.uint8)
+    d1[::7, 0] = 1
+    d2[::5, 3] = 0x80
+    for ratio in (0.6, 0.9):
+        m = match.robust(ratio, False, max_n1=128, max_n2=128)
+        assert np.array_equal(m.brute_force_match(d1, d2), oracle.robust_brute_force_match(d1, d2, None, ratio))
+    # ratio 1.01: duplicates are accepted one by one until the frame side runs out
+    m = match.robust(1.01, False, max_n1=128, max_n2=128)
+    got = m.brute_force_match(d1, d2)
+    want = oracle.robust_brute_force_match(d1, d2, None, 1.01)
+    assert np.array_equal(got, want) and len(want) > 10
+
+
+def test_best2_and_distance_identities(match, oracle):
+    rng = np.random.default_rng(9)
+    q, t = _descs(rng, 500, 700, 300)
+    ctx = match._matcher_ctx(max_n1=1024, max_n2=1024)
+    valid = (rng.random(700) < 0.8).astype(np.uint8)
+    for v in (None, valid):
+        gi, gb, gs = match.hamming_best2(ctx, q, t, v)
+        wi, wb, ws = oracle.hamming_best2(q, t, v)
+        assert np.array_equal(gi, wi) and np.array_equal(gb, wb) and np.array_equal(gs, ws)
+    # d(a,a)=0 and d(a,~a)=256 through the kernel
+    a = rng.integers(0, 256, size=(4, 32), dtype=np.uint8)
+    gi, gb, gs = match.hamming_best2(ctx, a, a)
+    assert np.array_equal(gb, np.zeros(4)) and np.array_equal(gi, np.arange(4))
+    gi, gb, gs = match.hamming_best2(ctx, a[:1], ~a[:1])
+    assert gb[0] == 256 and gi[0] == -1   # strict '<' against MAX_HAMMING_DIST: 256 never wins
+
+
+def test_batch_dev(match, oracle):
+    import torch
+    rng = np.random.default_rng(11)
+    B, cap = 4, 512
+    d1 = np.zeros((B, cap, 32), np.uint8)
+    d2 = np.zeros((B, cap, 32), np.uint8)
+    n1 = np.array([500, 512, 37, 400], np.int32)
+    n2 = np.array([480, 512, 300, 1], np.int32)
+    for b in range(B):
+        a, c = _descs(rng, n1[b], n2[b], min(n1[b], n2[b]) // 2)
+        d1[b, :n1[b]] = a
+        d2[b, :n2[b]] = c
+    m = match.robust(0.9, False, max_n1=cap, max_n2=cap, max_batch=B)
+    td1, td2 = torch.from_numpy(d1).cuda(), torch.from_numpy(d2).cuda()
+    tn1, tn2 = torch.from_numpy(n1).cuda(), torch.from_numpy(n2).cuda()
+    pairs = torch.zeros((B, cap, 2), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    m.brute_force_match_batch_dev(td1, tn1, td2, tn2, pairs, cnt, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for b in range(B):
+        want = oracle.robust_brute_force_match(d1[b, :n1[b]], d2[b, :n2[b]], None, 0.9)
+        got = pairs[b, :int(cnt[b])].cpu().numpy()
+        assert np.array_equal(got, want)

@@ -1,0 +1,131 @@
+"""GPU parity: HIP orb_extractor (through the C ABI) == CPU oracle, bit for bit, stage by stage and end to end.
+Oracle = from-spec restatement (PARITY UNPINNED vs upstream, see oracle/ovo_oracle.h)."""
+import numpy as np
+import pytest
+
+from openvslam_amd.synth import synth_frame
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(1080, 1920, 2000), (480, 752, 1000), (376, 1241, 2000)]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from openvslam_amd import feature
+    return feature
+
+
+def _pair(hip, oracle, rows, cols, nfeat, seed=0, **kw):
+    img = synth_frame(rows, cols, seed=seed, **kw)
+    gp = hip.orb_params(max_num_keypts=nfeat)
+    ex = hip.orb_extractor(gp, max_rows=rows, max_cols=cols)
+    ox = oracle.OrbExtractor(oracle.make_params(nfeat))
+    return img, ex, ox
+
+
+@pytest.mark.parametrize("rows,cols,nfeat", SIZES)
+def test_tables(hip, oracle, rows, cols, nfeat):
+    ex = hip.orb_extractor(hip.orb_params(max_num_keypts=nfeat), max_rows=rows, max_cols=cols)
+    t = oracle.orb_tables(oracle.make_params(nfeat))
+    assert np.array_equal(ex.get_scale_factors(), t["scale_factors"])
+    assert np.array_equal(ex.get_inv_scale_factors(), t["inv_scale_factors"])
+    assert np.array_equal(ex.get_level_sigma_sq(), t["level_sigma_sq"])
+    assert np.array_equal(ex.get_inv_level_sigma_sq(), t["inv_level_sigma_sq"])
+    assert np.array_equal(ex.num_keypts_per_level_, t["num_keypts_per_level"])
+
+
+@pytest.mark.parametrize("rows,cols,nfeat", SIZES)
+def test_pyramid_and_candidates(hip, oracle, rows, cols, nfeat):
+    img, ex, ox = _pair(hip, oracle, rows, cols, nfeat)
+    ex.extract(img)
+    ox.extract(img)
+    for l in range(8):
+        assert np.array_equal(ex.image_pyramid(l), ox.level_image(l)), "pyramid level %d" % l
+    for l in range(8):
+        gx, gy, gs = ex.debug_candidates(l)
+        wx, wy, ws = ox.level_candidates(l)
+        assert len(gx) == len(wx), "level %d candidate count %d vs %d" % (l, len(gx), len(wx))
+        assert np.array_equal(gx, wx) and np.array_equal(gy, wy) and np.array_equal(gs, ws), "level %d candidates" % l
+
+
+@pytest.mark.parametrize("rows,cols,nfeat", SIZES)
+@pytest.mark.parametrize("seed", [0, 1])
+def test_extract_bit_exact(hip, oracle, rows, cols, nfeat, seed):
+    img, ex, ox = _pair(hip, oracle, rows, cols, nfeat, seed=seed)
+    gk, gd = ex.extract(img)
+    wk, wd = ox.extract(img)
+    assert len(gk) == len(wk)
+    assert np.array_equal(ex.debug_level_counts(), [ox.level_num_keypts(l) for l in range(8)])
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(gk[f], wk[f]), f
+    # float tolerance stated: IC angle must be bit-identical (same op sequence, no FMA); tolerance 0
+    assert np.array_equal(gk["angle"].view(np.uint32), wk["angle"].view(np.uint32))
+    assert np.array_equal(gd, wd)
+
+
+def test_flat_and_tiny_images(hip, oracle):
+    # flat image: no corners at either threshold -> zero keypoints; tiny image: levels without any cell
+    for img in (np.full((480, 752), 77, np.uint8), synth_frame(120, 160, seed=3), synth_frame(64, 64, seed=4)):
+        ex = hip.orb_extractor(hip.orb_params(max_num_keypts=500), max_rows=img.shape[0], max_cols=img.shape[1])
+        ox = oracle.OrbExtractor(oracle.make_params(500))
+        gk, gd = ex.extract(img)
+        wk, wd = ox.extract(img)
+        assert len(gk) == len(wk)
+        assert np.array_equal(gk.view(np.uint8), wk.view(np.uint8)) and np.array_equal(gd, wd)
+    ex = hip.orb_extractor(hip.orb_params(), max_rows=64, max_cols=64)
+    k, d = ex.extract(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)
+
+
+def test_low_texture_uses_min_threshold(hip, oracle):
+    # weak texture: most cells have no FAST-20 corner and fall back to threshold 7
+    rng = np.random.default_rng(5)
+    img = np.clip(128 + rng.normal(0, 6, size=(480, 752)), 0, 255).astype(np.uint8)
+    ex = hip.orb_extractor(hip.orb_params(max_num_keypts=1000), max_rows=480, max_cols=752)
+    ox = oracle.OrbExtractor(oracle.make_params(1000))
+    gk, gd = ex.extract(img)
+    wk, wd = ox.extract(img)
+    assert len(wk) > 100
+    assert np.array_equal(gk.view(np.uint8), wk.view(np.uint8)) and np.array_equal(gd, wd)
+
+
+def test_mask(hip, oracle):
+    img = synth_frame(480, 752, seed=7)
+    mask = np.full(img.shape, 255, np.uint8)
+    mask[100:300, 200:500] = 0
+    mask[:, 700:] = 0
+    ex = hip.orb_extractor(hip.orb_params(max_num_keypts=1000), max_rows=480, max_cols=752)
+    ox = oracle.OrbExtractor(oracle.make_params(1000))
+    gk, gd = ex.extract(img, mask)
+    wk, wd = ox.extract(img, mask)
+    assert len(gk) == len(wk) and len(wk) > 100
+    assert np.array_equal(gk.view(np.uint8), wk.view(np.uint8)) and np.array_equal(gd, wd)
+    # rectangle masks from orb_params (Feature.mask_rectangles)
+    ex2 = hip.orb_extractor(hip.orb_params(max_num_keypts=1000, mask_rects=[(0.2, 0.5, 0.1, 0.6)]), max_rows=480, max_cols=752)
+    gk2, gd2 = ex2.extract(img)
+    wk2, wd2 = ox.extract(img, ex2.create_rectangle_mask(752, 480))
+    assert np.array_equal(gk2.view(np.uint8), wk2.view(np.uint8)) and np.array_equal(gd2, wd2)
+
+
+def test_batch_dev_matches_host_api(hip, oracle):
+    import torch
+    rows, cols, B = 480, 752, 3
+    imgs = np.stack([synth_frame(rows, cols, seed=10 + b) for b in range(B)])
+    ex = hip.orb_extractor(hip.orb_params(max_num_keypts=1000), max_rows=rows, max_cols=cols, max_batch=B)
+    cap = ex.max_keypoints
+    d_img = torch.from_numpy(imgs).cuda()
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    ex.extract_batch_dev(d_img, d_kps, d_desc, d_cnt, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    cnt = d_cnt.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+    desc = d_desc.cpu().numpy()
+    ox = oracle.OrbExtractor(oracle.make_params(1000))
+    for b in range(B):
+        wk, wd = ox.extract(imgs[b])
+        assert cnt[b] == len(wk)
+        assert np.array_equal(kps[b, :cnt[b]].reshape(-1), wk.view(np.uint8).reshape(-1))
+        assert np.array_equal(desc[b, :cnt[b]], wd)
