@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on config 2: 1920x1080 mono, 8 pyramid levels, 2000 ORB features, extract + all-pairs
+Hamming match (match::robust::brute_force_match, thr 50 / ratio 0.9), device-resident, on N MI355X of one node.
+
+A "step" = one pass of the hot path over one batch of synthetic input per GPU: ORB-extract B frames already resident in HBM,
+then match every frame against its predecessor (B problems of ~2000 x ~2000 descriptors), all on one stream.
+value = ORB keypoints+descriptors produced per second, whole job (all ranks), with matches/s and Hamming distances/s next to
+it. Frames shard across ranks with no data-path collective (replicas) => "scaling": "weak".
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+       N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ROWS, COLS, NFEAT, LEVELS = 1080, 1920, 2000, 8
+LOWE_RATIO = 0.9
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+
+def level_sizes(rows, cols, scale=1.2, levels=8):
+    sf = np.float32(1.0)
+    out = [(rows, cols)]
+    for _ in range(1, levels):
+        sf = np.float32(scale) * sf
+        out.append((int(np.floor(rows / float(sf) + 0.5)), int(np.floor(cols / float(sf) + 0.5))))
+    return out
+
+
+def algorithmic_bytes(rows, cols, n_kp_frame, n_cand_frame):
+    """ALGORITHMIC bytes per frame for each extract kernel (SURVEY.md 8(d) minimum-pass model, split per kernel)."""
+    lv = level_sizes(rows, cols)
+    px = [r * c for r, c in lv]
+    return {
+        "pyramid": sum(px[:-1]) + sum(px[1:]),          # each level read once as a source, levels 1..7 written once
+        "fast": sum(px),                                # every level read once for FAST/NMS (6 419 321 B at 1080p)
+        "tree": 8 * n_cand_frame + 8 * n_kp_frame,      # candidate list read once, selected keypoints written
+        "describe": n_kp_frame * (43 * 43 + 32 + 28),   # 43x43 patch per keypoint in, descriptor + cv::KeyPoint out
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from openvslam_amd import _lib, feature, match
+    from openvslam_amd.synth import synth_video
+
+    B = args.batch
+    L = _lib.lib()
+    # ---- synthetic input, resident in HBM before the timed region (each rank gets its own frames)
+    frames = synth_video(ROWS, COLS, B, seed=100 + rank)
+    d_frames = torch.from_numpy(frames).cuda()
+    ex = feature.orb_extractor(feature.orb_params(NFEAT, 1.2, LEVELS, 20, 7), max_rows=ROWS, max_cols=COLS, max_batch=B,
+                               device=local_rank)
+    cap = ex.max_keypoints
+    mt = match.robust(LOWE_RATIO, False, max_n1=cap, max_n2=cap, max_batch=B, device=local_rank)
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    d_pairs = torch.zeros((B, cap, 2), dtype=torch.int32, device="cuda")
+    d_mcnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    # frame b (keyframe side, idx_2) is matched against frame b-1 inside its 8-frame scene (frame side, idx_1)
+    prev = torch.tensor([(b - 1) if b % 8 else min(b + 7, B - 1) for b in range(B)], dtype=torch.long, device="cuda")
+    d_desc_prev = torch.zeros_like(d_desc)
+    d_cnt_prev = torch.zeros_like(d_cnt)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ex.extract_batch_dev(d_frames, d_kps, d_desc, d_cnt, stream=stream)
+        torch.index_select(d_desc, 0, prev, out=d_desc_prev)      # gather "previous frame" descriptor blocks (device, same stream)
+        torch.index_select(d_cnt, 0, prev, out=d_cnt_prev)
+        mt.brute_force_match_batch_dev(d_desc_prev, d_cnt_prev, d_desc, d_cnt, d_pairs, d_mcnt, stream=stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    _lib.check(L.ovs_orb_profile_enable(ex._h, 1), "profile_enable")
+    _lib.check(L.ovs_matcher_profile_enable(mt._h, 1), "profile_enable")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- per-stage HIP-event times over the timed region (recorded on the launch stream by the library)
+    st4 = (C.c_float * 4)()
+    st2 = (C.c_float * 2)()
+    nc = C.c_int32()
+    _lib.check(L.ovs_orb_profile_read(ex._h, st4, C.byref(nc)), "profile_read")
+    calls = max(nc.value, 1)
+    _lib.check(L.ovs_matcher_profile_read(mt._h, st2, C.byref(nc)), "profile_read")
+    stage_ms = {"pyramid": st4[0] / calls, "fast": st4[1] / calls, "tree": st4[2] / calls, "describe": st4[3] / calls,
+                "match_near": st2[0] / calls, "match_resolve": st2[1] / calls}
+
+    cnt = d_cnt.cpu().numpy().astype(np.int64)
+    mcnt = d_mcnt.cpu().numpy().astype(np.int64)
+    kp_step = int(cnt.sum())
+    matches_step = int(mcnt.sum())
+    pairs_step = int((cnt * cnt[prev.cpu().numpy()]).sum())
+    totals = torch.tensor([kp_step, matches_step, pairs_step], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+    kp_all, matches_all, pairs_all = (float(x) for x in totals.cpu().numpy())
+
+    if rank == 0:
+        n_cand = 0
+        for l in range(LEVELS):
+            n_cand += len(ex.debug_candidates(l, frame=0)[0])
+        ab = algorithmic_bytes(ROWS, COLS, kp_step / B, n_cand)
+        ab["match_near"] = (2 * (kp_step / B) * 32 + (kp_step / B) * 8)   # (Nq+Nt)*32 + Nq*8 per problem (144 000 B at 2000x2000)
+        ab["match_resolve"] = (kp_step / B) * (4 + 8)
+        dom = max(stage_ms, key=lambda k: stage_ms[k])
+        achieved = ab[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": {"pyramid": "k_resize_linear_u8 (x7)", "fast": "k_fast_cells", "tree": "k_tree",
+                                           "describe": "k_describe", "match_near": "k_hamming_near",
+                                           "match_resolve": "k_bf_resolve"}[dom],
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": traffic, "algorithmic_bytes_per_launch": int(ab[dom] * B), "launch_ms": round(stage_ms[dom], 5)}
+        # whole extract against the SURVEY 8(d) per-frame figure (19 377 963 B at 1080p/2000)
+        extract_ms = sum(stage_ms[k] for k in ("pyramid", "fast", "tree", "describe"))
+        lv = level_sizes(ROWS, COLS)
+        px = [r * c for r, c in lv]
+        frame_bytes = px[0] + sum(px[1:]) + 2 * sum(px) + (kp_step / B) * 60
+        extract_gbs = frame_bytes * B / (extract_ms * 1e-3) / 1e9
+
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(frames)
+
+        out = {
+            "metric": "ORB kpts+descriptors/sec and Hamming matches/sec @1920x1080, 8-level pyramid",
+            "value": round(kp_all * args.steps / elapsed, 1),
+            "unit": "keypoints+descriptors/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 1920x1080 mono, 8 pyramid levels (x1.2), 2000 ORB features, extract + "
+                                   "robust::brute_force_match (thr 50, ratio 0.9) against the previous frame",
+                       "frames_per_step_per_gpu": B, "sharding": "frames across ranks, no collective"},
+            "frames_per_sec": round(B * world * args.steps / elapsed, 2),
+            "matches_per_sec": round(matches_all * args.steps / elapsed, 1),
+            "hamming_distances_per_sec": round(pairs_all * args.steps / elapsed, 1),
+            "keypoints_per_frame": round(kp_step / B, 2),
+            "matches_per_frame": round(matches_step / B, 2),
+            "stage_ms_per_step": {k: round(v, 5) for k, v in stage_ms.items()},
+            "extract_algorithmic_GBps": round(extract_gbs, 2),
+            "extract_frac_of_hbm_peak": round(extract_gbs / HBM_PEAK_GBS, 5),
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "parity": "bit-exact vs in-repo CPU oracle (from-spec restatement; upstream source unavailable: parity unpinned)",
+        }
+        if cpu:
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / cpu["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(frames, budget_s=12.0):
+    """The CPU oracle ("port": from-spec restatement, there is no reference source to build) timed on this box's host cores on a
+    bounded sample of the same workload: extract + brute_force_match of consecutive frames of the bench's own video."""
+    from oracle import binding as ob
+    ob.build()
+    threads = min(8, os.cpu_count() or 1)   # upstream's optional OpenMP shape: parallel over the 8 pyramid levels
+    ox = ob.OrbExtractor(ob.make_params(NFEAT), threads=threads)
+    n_kp = 0
+    n_match = 0
+    n_frames = 0
+    prev_desc = None
+    t0 = time.perf_counter()
+    i = 0
+    while True:
+        k, d = ox.extract(frames[i % len(frames)])
+        if prev_desc is not None:
+            n_match += len(ob.robust_brute_force_match(prev_desc, d, None, LOWE_RATIO))
+        prev_desc = d
+        n_kp += len(k)
+        n_frames += 1
+        i += 1
+        if time.perf_counter() - t0 > budget_s and n_frames >= 8:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(n_kp / dt, 1), "unit": "keypoints+descriptors/s", "cores": threads, "kind": "port",
+            "sample": "%d frames 1920x1080 (extract, OpenMP over levels) + %d brute_force_match calls, %.1f s wall" % (n_frames, n_frames - 1, dt),
+            "frames_per_sec": round(n_frames / dt, 3), "matches_per_sec": round(n_match / dt, 1)}
+
+
+if __name__ == "__main__":
+    main()

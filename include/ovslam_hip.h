@@ -10,8 +10,9 @@
  * Conventions
  *   - plain C types only; no cv::, Eigen:: or torch types; all functions return ovs_status (0 = OK, <0 = error);
  *   - "host" entry points take caller-owned host pointers and do H2D / kernels / D2H on the handle's own stream;
- *   - "_dev" entry points take DEVICE pointers (inputs already resident in HBM) plus a hipStream_t passed as void*
- *     (NULL = the handle's stream) and never synchronise: the caller orders and syncs the stream;
+ *   - "_dev" entry points take DEVICE pointers (inputs already resident in HBM) plus a hipStream_t passed as void*, used
+ *     verbatim (NULL = HIP's default stream, which is also what torch's default stream handle is) and never synchronise:
+ *     the caller orders and syncs the stream;
  *   - handles are independent (own stream, own buffers, no global mutable state), so two extractors may run
  *     concurrently from two threads (upstream: stereo left/right std::threads); one handle = one caller at a time;
  *   - there is NO CPU fallback inside this library: without a usable HIP device every call fails with
@@ -110,6 +111,12 @@ ovs_status ovs_orb_debug_candidates(ovs_orb* h, int32_t frame, int32_t level, in
 /* Keypoints per level of (frame) of the last extract. */
 ovs_status ovs_orb_debug_level_counts(ovs_orb* h, int32_t frame, int32_t* counts /* num_levels */);
 
+/* Measurement hooks (bench.py): when enabled, every extract call records HIP events on the stream it launches on, at the
+ * stage boundaries pyramid | FAST | quad-tree | describe. ovs_orb_profile_read waits for the recorded events, writes the
+ * accumulated milliseconds per stage (4 floats) and the number of calls they cover, and resets the accumulators. */
+ovs_status ovs_orb_profile_enable(ovs_orb* h, int32_t enable);
+ovs_status ovs_orb_profile_read(ovs_orb* h, float* stage_ms /* 4 */, int32_t* ncalls);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * 256-bit Hamming matching.  replaces: match::base::compute_descriptor_distance_32 and match::robust::brute_force_match
  * (src/openvslam/match/base.h, robust.{h,cc}).
@@ -138,6 +145,10 @@ ovs_status ovs_robust_brute_force_match_batch_dev(ovs_matcher* m, const uint8_t*
                                                   const uint8_t* d_desc_2, size_t stride_2, const int32_t* d_n2,
                                                   const uint8_t* d_valid_2, int32_t batch, float lowe_ratio, int32_t* d_pairs,
                                                   int32_t* d_counts, int32_t cap, void* stream);
+
+/* Measurement hooks: stages = all-pairs near-list kernel | resolve kernel (2 floats). */
+ovs_status ovs_matcher_profile_enable(ovs_matcher* m, int32_t enable);
+ovs_status ovs_matcher_profile_read(ovs_matcher* m, float* stage_ms /* 2 */, int32_t* ncalls);
 
 /* Unconstrained best / second-best Hamming distance per query over all valid targets (first-seen = lowest index wins
  * ties), the primitive under bow_tree / area / projection style matchers when the candidate set is "all". Host pointers. */

@@ -43,6 +43,10 @@ SYMBOLS = {
     "ovs_orb_pyramid_level": (_i32, [_vp, _i32, _i32, _vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "ovs_orb_debug_candidates": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, C.POINTER(_i32)]),
     "ovs_orb_debug_level_counts": (_i32, [_vp, _i32, _vp]),
+    "ovs_orb_profile_enable": (_i32, [_vp, _i32]),
+    "ovs_orb_profile_read": (_i32, [_vp, _vp, C.POINTER(_i32)]),
+    "ovs_matcher_profile_enable": (_i32, [_vp, _i32]),
+    "ovs_matcher_profile_read": (_i32, [_vp, _vp, C.POINTER(_i32)]),
     "ovs_matcher_create": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(_vp)]),
     "ovs_matcher_destroy": (_i32, [_vp]),
     "ovs_robust_brute_force_match": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _f, _vp, _i32, C.POINTER(_i32)]),
@@ -57,6 +61,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
                               "There is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: torch bundles its own libamdhip64.so.7; importing it first makes the dynamic linker
+        # bind this library to the same runtime (same soname), so torch tensors / streams and our kernels share one context.
+        # (A C++ host without torch binds to /opt/rocm's runtime through the library's RUNPATH.)
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)   # AttributeError if the .so does not export a declared symbol

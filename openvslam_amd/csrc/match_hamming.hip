@@ -25,8 +25,9 @@
 
 namespace ovs {
 
-constexpr int kNearK = 8;             // near-list capacity per query
-constexpr int kResolveThreads = 1024;
+constexpr int kNearSplit = 4;         // waves per workgroup; each scans a quarter of the frame descriptors for the same 64 queries
+constexpr int kNearSeg = 64;          // near-list capacity per (query, wave); beyond it: cooperative full scan, still exact
+constexpr int kTopK = 8;              // sorted smallest keys kept per query for the resolver's fast path
 
 __device__ __forceinline__ uint32_t hamming256(const uint32_t (&a)[8], const uint32_t* __restrict__ b) {
     uint32_t d = 0;
@@ -35,34 +36,110 @@ __device__ __forceinline__ uint32_t hamming256(const uint32_t (&a)[8], const uin
     return d;
 }
 
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+
+// Four consecutive 32-byte descriptors through the scalar data cache under ONE wait (hipcc otherwise waits after each load).
+// The loads, their count and the wait are all inside the statement (guide 5.7); outputs are early-clobber SGPR tuples.
+__device__ __forceinline__ void sload_desc4(const uint32_t* __restrict__ p, u32x8& b0, u32x8& b1, u32x8& b2, u32x8& b3) {
+    asm volatile(
+        "s_load_dwordx8 %0, %4, 0x0\n\t"
+        "s_load_dwordx8 %1, %4, 0x20\n\t"
+        "s_load_dwordx8 %2, %4, 0x40\n\t"
+        "s_load_dwordx8 %3, %4, 0x60\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(b0), "=&s"(b1), "=&s"(b2), "=&s"(b3)
+        : "s"(p)
+        : "memory");
+}
+
+__device__ __forceinline__ uint32_t hamming256v(const uint32_t (&a)[8], const u32x8& b) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d = __builtin_popcount(a[i] ^ b[i]) + d;
+    return d;
+}
+
+// keep the kTopK smallest keys (ascending) -- key = d << 16 | idx_1, i.e. (distance, first-seen) order
+__device__ __forceinline__ void topk_insert(uint32_t e, uint32_t (&t)[kTopK]) {
+    if (e < t[kTopK - 1]) {
+        t[kTopK - 1] = e;
+#pragma unroll
+        for (int k = kTopK - 1; k > 0; --k) {
+            const uint32_t lo = min(t[k - 1], t[k]), hi = max(t[k - 1], t[k]);
+            t[k - 1] = lo;
+            t[k] = hi;
+        }
+    }
+}
+
 // ---- 1. all pairs, near lists -------------------------------------------------------------------------------------
+// Workgroup = 4 waves x the same 64 queries (idx_2); wave w scans the w-th quarter of the frame descriptors (idx_1), four
+// per trip so four s_load_dwordx8 are in flight together. Entries with d <= near_thr go to the wave's own segment of the
+// query's list (count in a register: no atomics, no waits in the loop) and into a sorted top-8 kept in registers; the four
+// partial top-8s are merged through LDS at the end.
 __global__ __launch_bounds__(256) void k_hamming_near(const uint8_t* __restrict__ desc_1, size_t stride_1,
                                                      const int32_t* __restrict__ n1_arr, const uint8_t* __restrict__ desc_2,
                                                      size_t stride_2, const int32_t* __restrict__ n2_arr,
                                                      const uint8_t* __restrict__ valid_2, int max_n2, uint32_t near_thr,
-                                                     uint32_t* __restrict__ near_cnt, uint32_t* __restrict__ near_list) {
+                                                     uint32_t* __restrict__ near_cnt, uint32_t* __restrict__ near_list,
+                                                     uint32_t* __restrict__ near_top) {
+    __shared__ uint32_t s_top[kNearSplit][kTopK][64];
     const int p = blockIdx.y;
     const int n1 = n1_arr[p], n2 = n2_arr[p];
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 >= n2) return;
+    if ((int)blockIdx.x * 64 >= n2) return;
+    // wave index made provably uniform so the descriptor addresses below stay scalar (s_load_dwordx8)
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = blockIdx.x * 64 + lane;
     const bool active = q < n2 && (!valid_2 || valid_2[(size_t)p * (stride_2 / 32) + q]);
     uint32_t a[8];
     {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(desc_2 + (size_t)p * stride_2 + (size_t)(active ? q : 0) * 32);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(desc_2 + (size_t)p * stride_2 + (size_t)(q < n2 ? q : 0) * 32);
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = src[i];
     }
+    const int chunk = (((n1 + kNearSplit - 1) / kNearSplit) + 3) & ~3;
+    const int jb = min(n1, wv * chunk), je = min(n1, jb + chunk);
     const uint32_t* __restrict__ t = reinterpret_cast<const uint32_t*>(desc_1 + (size_t)p * stride_1);
-    uint32_t* my_list = near_list + ((size_t)p * max_n2 + q) * kNearK;
+    uint32_t* my_seg = near_list + (((size_t)p * max_n2 + q) * kNearSplit + wv) * kNearSeg;
+    uint32_t top[kTopK];
+#pragma unroll
+    for (int k = 0; k < kTopK; ++k) top[k] = ~0u;
     uint32_t cnt = 0;
-    for (int j = 0; j < n1; ++j) {
-        const uint32_t d = hamming256(a, t + (size_t)j * 8);   // wave-uniform address: scalar loads
-        if (d <= near_thr && active) {
-            if (cnt < (uint32_t)kNearK) my_list[cnt] = (d << 16) | (uint32_t)j;
-            ++cnt;
+    auto hit = [&](uint32_t d, int j) {
+        const uint32_t e = (d << 16) | (uint32_t)j;
+        if (cnt < (uint32_t)kNearSeg) my_seg[cnt] = e;
+        ++cnt;
+        topk_insert(e, top);
+    };
+    int j = jb;
+    if (active) {
+        for (; j + 4 <= je; j += 4) {   // wave-uniform addresses: scalar loads, four descriptors in flight
+            u32x8 b0, b1, b2, b3;
+            sload_desc4(t + (size_t)j * 8, b0, b1, b2, b3);
+            const uint32_t d0 = hamming256v(a, b0), d1 = hamming256v(a, b1), d2 = hamming256v(a, b2), d3 = hamming256v(a, b3);
+            if (d0 <= near_thr) hit(d0, j);
+            if (d1 <= near_thr) hit(d1, j + 1);
+            if (d2 <= near_thr) hit(d2, j + 2);
+            if (d3 <= near_thr) hit(d3, j + 3);
+        }
+        for (; j < je; ++j) {
+            const uint32_t d = hamming256(a, t + (size_t)j * 8);
+            if (d <= near_thr) hit(d, j);
         }
     }
-    if (q < n2) near_cnt[(size_t)p * max_n2 + q] = active ? cnt : 0u;
+#pragma unroll
+    for (int k = 0; k < kTopK; ++k) s_top[wv][k][lane] = top[k];
+    if (q < n2) near_cnt[((size_t)p * max_n2 + q) * kNearSplit + wv] = cnt;
+    __syncthreads();
+    if (wv == 0 && q < n2) {
+#pragma unroll
+        for (int w = 1; w < kNearSplit; ++w)
+#pragma unroll
+            for (int k = 0; k < kTopK; ++k) topk_insert(s_top[w][k][lane], top);
+        uint4* dst = reinterpret_cast<uint4*>(near_top + ((size_t)p * max_n2 + q) * kTopK);
+        dst[0] = make_uint4(top[0], top[1], top[2], top[3]);
+        dst[1] = make_uint4(top[4], top[5], top[6], top[7]);
+    }
 }
 
 // ---- 2./3. resolve ------------------------------------------------------------------------------------------------
@@ -70,169 +147,199 @@ __device__ __forceinline__ bool ratio_rejects(float lowe_ratio, uint32_t second,
     return __fmul_rn(lowe_ratio, (float)second) < (float)best;
 }
 
-__global__ __launch_bounds__(kResolveThreads) void k_bf_resolve(const uint8_t* __restrict__ desc_1, size_t stride_1,
-                                                               const int32_t* __restrict__ n1_arr,
-                                                               const uint8_t* __restrict__ desc_2, size_t stride_2,
-                                                               const int32_t* __restrict__ n2_arr,
-                                                               const uint8_t* __restrict__ valid_2, int max_n1, int max_n2,
-                                                               float lowe_ratio, const uint32_t* __restrict__ near_cnt,
-                                                               const uint32_t* __restrict__ near_list, int32_t* __restrict__ pairs,
-                                                               int32_t* __restrict__ counts, int cap) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* touch = reinterpret_cast<uint32_t*>(smem);                  // [max_n1] lowest pending query touching idx_1
-    int32_t* match = reinterpret_cast<int32_t*>(touch + max_n1);           // [max_n2] idx_1 matched to idx_2, -1 none
-    uint8_t* claimed = reinterpret_cast<uint8_t*>(match + max_n2);         // [max_n1]
-    uint8_t* pending = claimed + ((max_n1 + 15) & ~15);                    // [max_n2]
-    __shared__ uint32_t s_flag[4];
-    __shared__ unsigned long long s_red[kResolveThreads / 64];
-    __shared__ uint32_t s_wave[kResolveThreads / 64];
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// One wave per problem replays upstream's idx_2 loop, 64 queries (one per lane) at a time:
+//   * every unresolved lane evaluates its query against the current `already_matched` set: first two unclaimed keys of its
+//     sorted top-8 (rarely: a rescan of its full near list) -> best, second, accept?, target;
+//   * accepting lanes stamp mark[target] = lane (LDS atomicMin, epoch-tagged so the table is never cleared);
+//   * a lane is AFFECTED if a LOWER lane of this round wants one of the two frame keypoints its decision rests on (anything
+//     before `best` is already claimed, anything after `second` cannot matter; a best > THR_LOW is a final reject);
+//   * all lanes below the first affected lane commit at once -- by induction their inputs were exact -- the rest go round again.
+// A chunk whose near list overflowed kNearSeg falls back to a literal one-query-at-a-time replay with cooperative scans.
+__global__ __launch_bounds__(64) void k_bf_resolve(const uint8_t* __restrict__ desc_1, size_t stride_1,
+                                                  const int32_t* __restrict__ n1_arr, const uint8_t* __restrict__ desc_2,
+                                                  size_t stride_2, const int32_t* __restrict__ n2_arr, int max_n1, int max_n2,
+                                                  float lowe_ratio, const uint32_t* __restrict__ near_cnt,
+                                                  const uint32_t* __restrict__ near_list, const uint32_t* __restrict__ near_top,
+                                                  int32_t* __restrict__ pairs, int32_t* __restrict__ counts, int cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // explicit LDS address space: a volatile GENERIC pointer would be lowered to flat, system-scope accesses
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
+    typedef __attribute__((address_space(3))) volatile uint8_t lds_u8;
+    lds_u32* mark = (lds_u32*)(smem);                                  // [max_n1]
+    lds_u8* claimed = (lds_u8*)(smem + (size_t)max_n1 * 4);            // [max_n1]
+    const int lane = threadIdx.x;
     const int p = blockIdx.x;
     const int n1 = n1_arr[p], n2 = n2_arr[p];
-    const uint32_t* cnts = near_cnt + (size_t)p * max_n2;
-    const uint32_t* lists = near_list + (size_t)p * max_n2 * kNearK;
-
-    if (tid == 0) s_flag[0] = 0;
-    for (int i = tid; i < n1; i += kResolveThreads) claimed[i] = 0;
-    __syncthreads();
-    uint32_t any_overflow = 0;
-    for (int q = tid; q < n2; q += kResolveThreads) {
-        const uint32_t c = cnts[q];
-        match[q] = -1;
-        pending[q] = c > 0;
-        any_overflow |= c > (uint32_t)kNearK;
-    }
-    if (any_overflow) atomicOr(&s_flag[0], 1u);
-    __syncthreads();
-
-    if (s_flag[0] == 0) {
-        // ---- parallel rounds (every round finalises at least the lowest pending query)
-        for (int round = 0; round <= n2; ++round) {
-            for (int i = tid; i < n1; i += kResolveThreads) touch[i] = 0xFFFFFFFFu;
-            if (tid == 0) s_flag[1] = 0;
-            __syncthreads();
-            for (int q = tid; q < n2; q += kResolveThreads) {
-                if (!pending[q]) continue;
-                const uint32_t c = cnts[q];
-                for (uint32_t k = 0; k < c; ++k) atomicMin(&touch[lists[(size_t)q * kNearK + k] & 0xFFFFu], (uint32_t)q);
-            }
-            __syncthreads();
-            uint32_t still = 0;
-            for (int q = tid; q < n2; q += kResolveThreads) {
-                if (!pending[q]) continue;
-                const uint32_t c = cnts[q];
-                bool first = true;
-                for (uint32_t k = 0; k < c; ++k) first &= touch[lists[(size_t)q * kNearK + k] & 0xFFFFu] == (uint32_t)q;
-                if (!first) { still = 1; continue; }
-                // every earlier query sharing a candidate is final: replay upstream's inner loop on the near list
-                uint32_t best = OVS_MAX_HAMMING_DIST, second = OVS_MAX_HAMMING_DIST, best_idx = 0xFFFFFFFFu;
-                for (uint32_t k = 0; k < c; ++k) {   // list is in ascending idx_1, as upstream scans
-                    const uint32_t e = lists[(size_t)q * kNearK + k];
-                    const uint32_t j = e & 0xFFFFu, d = e >> 16;
-                    if (claimed[j]) continue;
-                    if (d < best) { second = best; best = d; best_idx = j; }
-                    else if (d < second) second = d;
-                }
-                pending[q] = 0;
-                if (best_idx == 0xFFFFFFFFu || best > OVS_HAMMING_DIST_THR_LOW) continue;
-                if (ratio_rejects(lowe_ratio, second, best)) continue;
-                match[q] = (int32_t)best_idx;
-                claimed[best_idx] = 1;
-            }
-            if (still) atomicOr(&s_flag[1], 1u);
-            __syncthreads();
-            if (s_flag[1] == 0) break;
-            __syncthreads();
-        }
-    } else {
-        // ---- literal serial replay (overflowing near lists): every query scans all unclaimed frame descriptors
-        for (int q = 0; q < n2; ++q) {
-            if (valid_2 && !valid_2[(size_t)p * (stride_2 / 32) + q]) continue;   // uniform
-            uint32_t a[8];
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(desc_2 + (size_t)p * stride_2 + (size_t)q * 32);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a[i] = src[i];
-            // per-thread best/second over its strided subset, then a block reduction of the two smallest (d, idx) keys
-            unsigned long long k1 = ~0ull, k2 = ~0ull;   // key = d << 32 | idx; k1 <= k2
-            for (int j = tid; j < n1; j += kResolveThreads) {
-                if (claimed[j]) continue;
-                const uint32_t* b = reinterpret_cast<const uint32_t*>(desc_1 + (size_t)p * stride_1 + (size_t)j * 32);
-                uint32_t d = 0;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) d += __builtin_popcount(a[i] ^ b[i]);
-                const unsigned long long key = ((unsigned long long)d << 32) | (uint32_t)j;
-                if (key < k1) { k2 = k1; k1 = key; }
-                else if (key < k2) k2 = key;
-            }
-            // reduce smallest key
-            unsigned long long m1 = k1;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned long long o = __shfl_xor(m1, off);
-                m1 = o < m1 ? o : m1;
-            }
-            if (lane == 0) s_red[wv] = m1;
-            __syncthreads();
-            unsigned long long g1 = ~0ull;
-            for (int w = 0; w < kResolveThreads / 64; ++w) g1 = s_red[w] < g1 ? s_red[w] : g1;
-            __syncthreads();
-            // second smallest distance: smallest key different from g1
-            unsigned long long m2 = (k1 == g1) ? k2 : k1;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned long long o = __shfl_xor(m2, off);
-                m2 = o < m2 ? o : m2;
-            }
-            if (lane == 0) s_red[wv] = m2;
-            __syncthreads();
-            unsigned long long g2 = ~0ull;
-            for (int w = 0; w < kResolveThreads / 64; ++w) g2 = s_red[w] < g2 ? s_red[w] : g2;
-            __syncthreads();
-            if (tid == 0 && g1 != ~0ull) {
-                const uint32_t best = (uint32_t)(g1 >> 32), best_idx = (uint32_t)g1;
-                const uint32_t second = g2 == ~0ull ? (uint32_t)OVS_MAX_HAMMING_DIST : (uint32_t)(g2 >> 32);
-                // upstream initialises best = second = MAX_HAMMING_DIST and uses strict `<`: a distance of 256 never wins
-                if (best < OVS_MAX_HAMMING_DIST && best <= OVS_HAMMING_DIST_THR_LOW &&
-                    !ratio_rejects(lowe_ratio, second < OVS_MAX_HAMMING_DIST ? second : OVS_MAX_HAMMING_DIST, best)) {
-                    match[q] = (int32_t)best_idx;
-                    claimed[best_idx] = 1;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    __syncthreads();
-    // ---- emit pairs in ascending idx_2 (upstream's emplace_back order)
-    const int ipt = (n2 + kResolveThreads - 1) / kResolveThreads;
-    const int b = tid * ipt, e = min(n2, b + ipt);
-    uint32_t mine = 0;
-    for (int q = b; q < e; ++q) mine += match[q] >= 0;
-    uint32_t incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t2 = __shfl_up(incl, off);
-        if (lane >= off) incl += t2;
-    }
-    if (lane == 63) s_wave[wv] = incl;
-    __syncthreads();
-    uint32_t pre = 0, total = 0;
-    for (int w = 0; w < kResolveThreads / 64; ++w) {
-        if (w < wv) pre += s_wave[w];
-        total += s_wave[w];
-    }
-    uint32_t pos = pre + incl - mine;
+    const uint32_t* cnts = near_cnt + (size_t)p * max_n2 * kNearSplit;
+    const uint32_t* lists = near_list + (size_t)p * max_n2 * kNearSplit * kNearSeg;
+    const uint32_t* tops = near_top + (size_t)p * max_n2 * kTopK;
     int32_t* out = pairs + (size_t)p * cap * 2;
-    for (int q = b; q < e; ++q) {
-        if (match[q] >= 0) {
+    for (int i = lane; i < n1; i += 64) {
+        claimed[i] = 0;
+        mark[i] = ~0u;
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t n_out = 0;
+    uint32_t epoch = 0;
+
+    for (int q0 = 0; q0 < n2; q0 += 64) {
+        const int q = q0 + lane;
+        uint32_t c4x = 0, c4y = 0, c4z = 0, c4w = 0;   // per-wave segment counts (named: a runtime-indexed array would live in scratch)
+        uint32_t top[kTopK];
+#pragma unroll
+        for (int k = 0; k < kTopK; ++k) top[k] = ~0u;
+        if (q < n2) {
+            const uint4 cc = *reinterpret_cast<const uint4*>(cnts + (size_t)q * kNearSplit);
+            c4x = cc.x; c4y = cc.y; c4z = cc.z; c4w = cc.w;
+        }
+        const uint32_t c = c4x + c4y + c4z + c4w;
+        const bool over = c4x > (uint32_t)kNearSeg || c4y > (uint32_t)kNearSeg || c4z > (uint32_t)kNearSeg || c4w > (uint32_t)kNearSeg;
+        if (c) {
+            const uint4* src = reinterpret_cast<const uint4*>(tops + (size_t)q * kTopK);
+            const uint4 lo = src[0], hi = src[1];
+            top[0] = lo.x; top[1] = lo.y; top[2] = lo.z; top[3] = lo.w;
+            top[4] = hi.x; top[5] = hi.y; top[6] = hi.z; top[7] = hi.w;
+        }
+        int32_t my_match = -1;
+
+        // evaluation of this lane's query against the current claims (lists are complete: !over); by-value so nothing
+        // has its address taken (references into lambdas ended up in scratch)
+        auto evaluate = [=]() __attribute__((always_inline)) -> uint2 {
+            uint32_t best = ~0u, second = ~0u;
+#pragma unroll
+            for (int k = 0; k < kTopK; ++k) {
+                const uint32_t e = top[k];
+                if (e != ~0u && !claimed[e & 0xFFFFu]) {   // keys ascend: the first two unclaimed are best and second
+                    if (best == ~0u) best = e;
+                    else if (second == ~0u) second = e;
+                }
+            }
+            if (second == ~0u && c > (uint32_t)kTopK) {   // rare: the top-8 is used up, rescan the whole near list
+                best = second = ~0u;
+                const uint32_t* seg = lists + (size_t)q * kNearSplit * kNearSeg;
+                const uint32_t ends[4] = {c4x, c4y, c4z, c4w};
+#pragma unroll
+                for (int w = 0; w < kNearSplit; ++w) {
+                    const uint32_t nw = ends[w];
+                    for (uint32_t k = 0; k < nw; ++k) {
+                        const uint32_t e = seg[w * kNearSeg + k];
+                        const bool alive = !claimed[e & 0xFFFFu];
+                        const uint32_t nb = (alive && e < best) ? e : best;
+                        const uint32_t ns = (alive && e < best) ? best : ((alive && e < second) ? e : second);
+                        best = nb;
+                        second = ns;
+                    }
+                }
+            }
+            return make_uint2(best, second);
+        };
+        auto accepts = [&](uint32_t best, uint32_t second) __attribute__((always_inline)) -> bool {
+            if (best == ~0u) return false;
+            const uint32_t bd = best >> 16;
+            const uint32_t sd = second == ~0u ? (uint32_t)OVS_MAX_HAMMING_DIST : (second >> 16);
+            return bd <= (uint32_t)OVS_HAMMING_DIST_THR_LOW && !ratio_rejects(lowe_ratio, sd, bd);
+        };
+
+        if (__ballot(over) == 0ull) {
+            unsigned long long unresolved = __ballot(c > 0);
+            while (unresolved) {
+                const bool mine = (unresolved >> lane) & 1ull;
+                uint32_t best = ~0u, second = ~0u;
+                bool acc = false;
+                ++epoch;
+                const uint32_t tag = (0xFFFFFFu - epoch) << 8;   // newer rounds carry smaller tags: atomicMin overrides stale marks
+                if (mine) {
+                    const uint2 r = evaluate();
+                    best = r.x;
+                    second = r.y;
+                    acc = accepts(best, second);
+                    if (acc) __hip_atomic_fetch_min((__attribute__((address_space(3))) uint32_t*)&mark[best & 0xFFFFu], tag | (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                __builtin_amdgcn_wave_barrier();
+                bool affected = false;
+                if (mine && best != ~0u && (best >> 16) <= (uint32_t)OVS_HAMMING_DIST_THR_LOW) {
+                    const uint32_t m1 = mark[best & 0xFFFFu];
+                    affected = (m1 & ~0xFFu) == tag && (m1 & 0xFFu) < (uint32_t)lane;
+                    if (second != ~0u) {
+                        const uint32_t m2 = mark[second & 0xFFFFu];
+                        affected |= (m2 & ~0xFFu) == tag && (m2 & 0xFFu) < (uint32_t)lane;
+                    }
+                }
+                const unsigned long long aff = __ballot(affected) & unresolved;
+                const int f = aff ? (__ffsll((long long)aff) - 1) : 64;
+                if (mine && lane < f) {
+                    if (acc) {
+                        my_match = (int32_t)(best & 0xFFFFu);
+                        claimed[best & 0xFFFFu] = 1;
+                    }
+                }
+                unresolved = f >= 64 ? 0ull : (unresolved & ~((1ull << f) - 1ull));
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            // ---- pathological chunk: literal replay, one query at a time; overflowed queries scan every frame descriptor
+            unsigned long long todo = __ballot(c > 0);
+            while (todo) {
+                const int i = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                uint32_t best = ~0u, second = ~0u;
+                const bool over_i = __shfl((int)over, i) != 0;
+                if (!over_i) {
+                    if (lane == i) {
+                        const uint2 r = evaluate();
+                        best = r.x;
+                        second = r.y;
+                    }
+                } else {
+                    const int qi = q0 + i;
+                    uint32_t a[8];
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(desc_2 + (size_t)p * stride_2 + (size_t)qi * 32);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a[k] = src[k];
+                    uint32_t k1 = ~0u, k2 = ~0u;
+                    for (int j = lane; j < n1; j += 64) {
+                        if (claimed[j]) continue;
+                        const uint32_t* b = reinterpret_cast<const uint32_t*>(desc_1 + (size_t)p * stride_1 + (size_t)j * 32);
+                        uint32_t d = 0;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) d += __builtin_popcount(a[k] ^ b[k]);
+                        if (d >= (uint32_t)OVS_MAX_HAMMING_DIST) continue;   // strict '<' against MAX_HAMMING_DIST upstream
+                        const uint32_t e = (d << 16) | (uint32_t)j;
+                        if (e < k1) { k2 = k1; k1 = e; }
+                        else if (e < k2) k2 = e;
+                    }
+                    const uint32_t g1 = wave_min_u32(k1);
+                    const uint32_t g2 = wave_min_u32(k1 == g1 ? k2 : k1);
+                    if (lane == i) { best = g1; second = g2; }
+                }
+                if (lane == i && accepts(best, second)) {
+                    my_match = (int32_t)(best & 0xFFFFu);
+                    claimed[best & 0xFFFFu] = 1;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // ---- emit this chunk's pairs in ascending idx_2
+        const unsigned long long m = __ballot(my_match >= 0);
+        if (my_match >= 0) {
+            const uint32_t pos = n_out + __popcll(m & ((1ull << lane) - 1ull));
             if (pos < (uint32_t)cap) {
-                out[2 * pos] = match[q];
+                out[2 * pos] = my_match;
                 out[2 * pos + 1] = q;
             }
-            ++pos;
         }
+        n_out += __popcll(m);
     }
-    if (tid == 0) counts[p] = (int32_t)(total < (uint32_t)cap ? total : (uint32_t)cap);
+    if (lane == 0) counts[p] = (int32_t)(n_out < (uint32_t)cap ? n_out : (uint32_t)cap);
 }
 
 // ---- unconstrained best / second best ----------------------------------------------------------------------------------
@@ -271,6 +378,7 @@ struct ovs_matcher {
     hipStream_t stream = nullptr;
     uint32_t* d_near_cnt = nullptr;
     uint32_t* d_near_list = nullptr;
+    uint32_t* d_near_top = nullptr;
     // host-API staging (one problem)
     uint8_t* d_desc_1 = nullptr;
     uint8_t* d_desc_2 = nullptr;
@@ -282,6 +390,7 @@ struct ovs_matcher {
     uint16_t* d_best = nullptr;
     uint16_t* d_second = nullptr;
     size_t resolve_lds = 0;
+    StageProfiler<2> prof;
 };
 
 namespace {
@@ -294,20 +403,24 @@ uint32_t near_threshold(float lowe_ratio) {
         if (!(lhs < (float)OVS_HAMMING_DIST_THR_LOW)) { tau = s; break; }
     }
     uint32_t thr = std::max<uint32_t>(OVS_HAMMING_DIST_THR_LOW, tau - 1);
-    return std::min<uint32_t>(thr, OVS_MAX_HAMMING_DIST);
+    // a distance of 256 can never become best (strict '<' against the initial MAX_HAMMING_DIST) and as `second` equals "none"
+    return std::min<uint32_t>(thr, OVS_MAX_HAMMING_DIST - 1);
 }
 
 ovs_status run_bf(ovs_matcher* m, const uint8_t* d1, size_t stride_1, const int32_t* d_n1, const uint8_t* d2, size_t stride_2,
                   const int32_t* d_n2, const uint8_t* d_valid, int batch, float lowe_ratio, int32_t* d_pairs, int32_t* d_counts, int cap,
                   hipStream_t s) {
     const uint32_t thr = near_threshold(lowe_ratio);
-    dim3 grid((m->max_n2 + 255) / 256, batch);
+    dim3 grid((m->max_n2 + 63) / 64, batch);
+    OVS_HIP_TRY(m->prof.begin(s));
     hipLaunchKernelGGL(k_hamming_near, grid, dim3(256), 0, s, d1, stride_1, d_n1, d2, stride_2, d_n2, d_valid, m->max_n2, thr,
-                       m->d_near_cnt, m->d_near_list);
+                       m->d_near_cnt, m->d_near_list, m->d_near_top);
     OVS_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_bf_resolve, dim3(batch), dim3(kResolveThreads), m->resolve_lds, s, d1, stride_1, d_n1, d2, stride_2, d_n2,
-                       d_valid, m->max_n1, m->max_n2, lowe_ratio, m->d_near_cnt, m->d_near_list, d_pairs, d_counts, cap);
+    OVS_HIP_TRY(m->prof.mark(1, s));
+    hipLaunchKernelGGL(k_bf_resolve, dim3(batch), dim3(64), m->resolve_lds, s, d1, stride_1, d_n1, d2, stride_2, d_n2, m->max_n1,
+                       m->max_n2, lowe_ratio, m->d_near_cnt, m->d_near_list, m->d_near_top, d_pairs, d_counts, cap);
     OVS_HIP_TRY(hipGetLastError());
+    OVS_HIP_TRY(m->prof.mark(2, s));
     return OVS_OK;
 }
 
@@ -325,7 +438,7 @@ ovs_status ovs_matcher_create(int32_t max_n1, int32_t max_n2, int32_t max_batch,
     m->max_n1 = max_n1;
     m->max_n2 = max_n2;
     m->max_batch = max_batch;
-    m->resolve_lds = (size_t)max_n1 * 4 + (size_t)max_n2 * 4 + (((size_t)max_n1 + 15) & ~(size_t)15) + (((size_t)max_n2 + 15) & ~(size_t)15);
+    m->resolve_lds = (size_t)max_n1 * 4 + (((size_t)max_n1 + 15) & ~(size_t)15);
     if (m->resolve_lds > 150 * 1024) {
         delete m;
         return OVS_ERR_CAPACITY;
@@ -342,8 +455,9 @@ ovs_status ovs_matcher_create(int32_t max_n1, int32_t max_n2, int32_t max_batch,
     CREATE_TRY(hipSetDevice(device));
     CREATE_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     const size_t B = (size_t)max_batch;
-    CREATE_TRY(hipMalloc(&m->d_near_cnt, sizeof(uint32_t) * B * max_n2));
-    CREATE_TRY(hipMalloc(&m->d_near_list, sizeof(uint32_t) * B * max_n2 * kNearK));
+    CREATE_TRY(hipMalloc(&m->d_near_cnt, sizeof(uint32_t) * B * max_n2 * kNearSplit));
+    CREATE_TRY(hipMalloc(&m->d_near_list, sizeof(uint32_t) * B * max_n2 * kNearSplit * kNearSeg));
+    CREATE_TRY(hipMalloc(&m->d_near_top, sizeof(uint32_t) * B * max_n2 * kTopK));
     CREATE_TRY(hipMalloc(&m->d_desc_1, (size_t)max_n1 * 32));
     CREATE_TRY(hipMalloc(&m->d_desc_2, (size_t)max_n2 * 32));
     CREATE_TRY(hipMalloc(&m->d_valid, (size_t)std::max(max_n1, max_n2)));
@@ -366,6 +480,7 @@ ovs_status ovs_matcher_destroy(ovs_matcher* m) {
     if (m->stream) hipStreamSynchronize(m->stream);
     hipFree(m->d_near_cnt);
     hipFree(m->d_near_list);
+    hipFree(m->d_near_top);
     hipFree(m->d_desc_1);
     hipFree(m->d_desc_2);
     hipFree(m->d_valid);
@@ -375,8 +490,24 @@ ovs_status ovs_matcher_destroy(ovs_matcher* m) {
     hipFree(m->d_best_idx);
     hipFree(m->d_best);
     hipFree(m->d_second);
+    m->prof.destroy();
     if (m->stream) hipStreamDestroy(m->stream);
     delete m;
+    return OVS_OK;
+}
+
+ovs_status ovs_matcher_profile_enable(ovs_matcher* m, int32_t enable) {
+    if (!m) return OVS_ERR_INVALID;
+    OVS_HIP_TRY(hipSetDevice(m->device));
+    m->prof.enabled = enable != 0;
+    if (enable) OVS_HIP_TRY(m->prof.ensure());
+    return OVS_OK;
+}
+
+ovs_status ovs_matcher_profile_read(ovs_matcher* m, float* stage_ms, int32_t* ncalls) {
+    if (!m || !stage_ms || !ncalls) return OVS_ERR_INVALID;
+    OVS_HIP_TRY(hipSetDevice(m->device));
+    OVS_HIP_TRY(m->prof.read(stage_ms, ncalls));
     return OVS_OK;
 }
 
@@ -388,7 +519,7 @@ ovs_status ovs_robust_brute_force_match_batch_dev(ovs_matcher* m, const uint8_t*
     if (batch > m->max_batch || stride_1 > (size_t)m->max_n1 * 32 || stride_2 > (size_t)m->max_n2 * 32) return OVS_ERR_CAPACITY;
     if (((uintptr_t)d_desc_1 & 3) || ((uintptr_t)d_desc_2 & 3) || (stride_1 & 31) || (stride_2 & 31)) return OVS_ERR_ALIGN;
     OVS_HIP_TRY(hipSetDevice(m->device));
-    hipStream_t s = stream ? (hipStream_t)stream : m->stream;
+    hipStream_t s = (hipStream_t)stream;   // verbatim: NULL is HIP's default stream (torch's default stream handle is 0)
     return run_bf(m, d_desc_1, stride_1, d_n1, d_desc_2, stride_2, d_n2, d_valid_2, batch, lowe_ratio, d_pairs, d_counts, cap, s);
 }
 

@@ -71,6 +71,7 @@ struct ovs_orb {
     const uint8_t* last_img0 = nullptr;
     size_t last_stride0 = 0, last_frame_stride0 = 0;
     int last_batch = 0;
+    StageProfiler<4> prof;
 };
 
 namespace {
@@ -193,7 +194,7 @@ ovs_status ensure_geometry(ovs_orb* h, int rows, int cols) {
         h->taps.size() > h->taps_cap || (size_t)h->geo.total_kp_cap > h->kps_cap)
         return OVS_ERR_CAPACITY;
     // the buffers keep the strides they were allocated with (max geometry); only offsets inside a frame block change
-    OVS_HIP_TRY(hipStreamSynchronize(h->stream));
+    OVS_HIP_TRY(hipDeviceSynchronize());   // rare: kernels of an earlier geometry may still read d_geo / d_taps
     OVS_HIP_TRY(hipMemcpy(h->d_geo, &h->geo, sizeof(FrameGeo), hipMemcpyHostToDevice));
     if (!h->taps.empty())
         OVS_HIP_TRY(hipMemcpy(h->d_taps, h->taps.data(), h->taps.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
@@ -209,6 +210,7 @@ ovs_status run_extract(ovs_orb* h, const uint8_t* d_images, int batch, int rows,
     const FrameGeo& geo = h->geo;
     const int L = geo.num_levels;
     OVS_HIP_TRY(hipMemsetAsync(h->d.cand_count, 0, sizeof(uint32_t) * (size_t)batch * L, s));
+    OVS_HIP_TRY(h->prof.begin(s));
     // A1: each level from the previous one
     for (int l = 1; l < L; ++l) {
         const LevelGeo& g = geo.lv[l];
@@ -219,9 +221,13 @@ ovs_status run_extract(ovs_orb* h, const uint8_t* d_images, int batch, int rows,
         OVS_HIP_TRY(launch_resize(src, src_fs, src_pitch, gp.rows, gp.cols, h->d.pyr + g.plane_off, h->d.pyr_frame_bytes, g.pitch,
                                   g.rows, g.cols, h->d_taps + g.xtab_off, h->d_taps + g.ytab_off, batch, s));
     }
+    OVS_HIP_TRY(h->prof.mark(1, s));
     OVS_HIP_TRY(launch_fast(geo, h->d, d_images, stride, frame_stride, d_masks, rows, batch, s));
+    OVS_HIP_TRY(h->prof.mark(2, s));
     OVS_HIP_TRY(launch_tree(geo, h->d, batch, s));
+    OVS_HIP_TRY(h->prof.mark(3, s));
     OVS_HIP_TRY(launch_describe(geo, h->d, d_images, stride, frame_stride, d_kps, d_desc, d_counts, cap, batch, s));
+    OVS_HIP_TRY(h->prof.mark(4, s));
     h->last_img0 = d_images;
     h->last_stride0 = stride;
     h->last_frame_stride0 = frame_stride;
@@ -329,6 +335,7 @@ ovs_status ovs_orb_destroy(ovs_orb* h) {
     hipFree(h->d_out_kps);
     hipFree(h->d_out_desc);
     hipFree(h->d_out_counts);
+    h->prof.destroy();
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return OVS_OK;
@@ -348,6 +355,21 @@ ovs_status ovs_orb_tables(const ovs_orb* h, float* sf, float* isf, float* ls, fl
 
 int32_t ovs_orb_max_keypoints(const ovs_orb* h) { return h ? h->out_cap : 0; }
 
+ovs_status ovs_orb_profile_enable(ovs_orb* h, int32_t enable) {
+    if (!h) return OVS_ERR_INVALID;
+    OVS_HIP_TRY(hipSetDevice(h->device));
+    h->prof.enabled = enable != 0;
+    if (enable) OVS_HIP_TRY(h->prof.ensure());
+    return OVS_OK;
+}
+
+ovs_status ovs_orb_profile_read(ovs_orb* h, float* stage_ms, int32_t* ncalls) {
+    if (!h || !stage_ms || !ncalls) return OVS_ERR_INVALID;
+    OVS_HIP_TRY(hipSetDevice(h->device));
+    OVS_HIP_TRY(h->prof.read(stage_ms, ncalls));
+    return OVS_OK;
+}
+
 ovs_status ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_images, int32_t batch, int32_t rows, int32_t cols, size_t stride,
                                      size_t frame_stride, const uint8_t* d_masks, ovs_keypoint* d_kps, uint8_t* d_desc,
                                      int32_t* d_counts, int32_t cap, void* stream) {
@@ -356,7 +378,7 @@ ovs_status ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_images, int32_
     if (((uintptr_t)d_images & 3) || (stride & 3) || (frame_stride & 3) || stride < (size_t)cols) return OVS_ERR_ALIGN;
     if (d_masks && ((uintptr_t)d_masks & 3)) return OVS_ERR_ALIGN;
     OVS_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s = (hipStream_t)stream;   // verbatim: NULL is HIP's default stream (torch's default stream handle is 0)
     return run_extract(h, d_images, batch, rows, cols, stride, frame_stride, d_masks, d_kps, d_desc, d_counts, cap, s);
 }
 

@@ -92,6 +92,82 @@ hipError_t launch_describe(const FrameGeo& hgeo, const DevBuffers& d, const uint
 
 void set_last_error(const char* what, hipError_t e);
 
+// Stage timer for bench.py: HIP events recorded on the launch stream at stage boundaries; a small ring of call slots.
+template <int NSTAGE>
+struct StageProfiler {
+    static constexpr int kSlots = 64;
+    bool enabled = false;
+    hipEvent_t ev[kSlots][NSTAGE + 1] = {};
+    bool created = false;
+    int head = 0, pending = 0;      // slots [head-pending, head) hold un-read calls
+    double acc_ms[NSTAGE] = {};
+    int acc_calls = 0;
+    int cur = -1;
+
+    hipError_t ensure() {
+        if (created) return hipSuccess;
+        for (int i = 0; i < kSlots; ++i)
+            for (int j = 0; j <= NSTAGE; ++j) {
+                hipError_t e = hipEventCreate(&ev[i][j]);
+                if (e != hipSuccess) return e;
+            }
+        created = true;
+        return hipSuccess;
+    }
+    hipError_t drain_one() {
+        const int slot = ((head - pending) % kSlots + kSlots) % kSlots;
+        hipError_t e = hipEventSynchronize(ev[slot][NSTAGE]);
+        if (e != hipSuccess) return e;
+        for (int j = 0; j < NSTAGE; ++j) {
+            float ms = 0;
+            e = hipEventElapsedTime(&ms, ev[slot][j], ev[slot][j + 1]);
+            if (e != hipSuccess) return e;
+            acc_ms[j] += ms;
+        }
+        ++acc_calls;
+        --pending;
+        return hipSuccess;
+    }
+    // begin a call: returns the slot to record into (-1 when disabled)
+    hipError_t begin(hipStream_t s) {
+        cur = -1;
+        if (!enabled) return hipSuccess;
+        hipError_t e = ensure();
+        if (e != hipSuccess) return e;
+        if (pending == kSlots) {
+            e = drain_one();
+            if (e != hipSuccess) return e;
+        }
+        cur = head % kSlots;
+        head = (head + 1) % kSlots;
+        ++pending;
+        return hipEventRecord(ev[cur][0], s);
+    }
+    hipError_t mark(int stage_done, hipStream_t s) {   // stage_done in 1..NSTAGE
+        if (cur < 0) return hipSuccess;
+        return hipEventRecord(ev[cur][stage_done], s);
+    }
+    hipError_t read(float* ms, int32_t* ncalls) {
+        while (pending > 0) {
+            hipError_t e = drain_one();
+            if (e != hipSuccess) return e;
+        }
+        for (int j = 0; j < NSTAGE; ++j) {
+            ms[j] = (float)acc_ms[j];
+            acc_ms[j] = 0;
+        }
+        *ncalls = acc_calls;
+        acc_calls = 0;
+        return hipSuccess;
+    }
+    void destroy() {
+        if (!created) return;
+        for (int i = 0; i < kSlots; ++i)
+            for (int j = 0; j <= NSTAGE; ++j) (void)hipEventDestroy(ev[i][j]);
+        created = false;
+    }
+};
+
 }   // namespace ovs
 
 #define OVS_HIP_TRY(expr)                                  \

@@ -23,12 +23,13 @@ def _value_noise(rng, rows, cols, pitch):
     return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
 
 
-def synth_frame(rows=1080, cols=1920, seed=0, n_rect=300, noise_sigma=3.0, shift=(0, 0), noise_seed=None):
-    """Returns a (rows, cols) uint8 frame. `shift`=(dx,dy) translates the underlying scene (frame k+1 = frame k shifted),
-    `noise_seed` draws fresh pixel noise on the same scene."""
+PAD = 64   # scene margin: |shift| <= PAD
+
+
+def synth_scene(rows=1080, cols=1920, seed=0, n_rect=300):
+    """The noise-free float32 scene (rows+2*PAD, cols+2*PAD) frames are cropped from."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    pad = 64
-    R, Cc = rows + 2 * pad, cols + 2 * pad
+    R, Cc = rows + 2 * PAD, cols + 2 * PAD
     img = 0.5 * _value_noise(rng, R, Cc, 8) + 0.3 * _value_noise(rng, R, Cc, 32) + 0.2 * _value_noise(rng, R, Cc, 128)
     for _ in range(n_rect):
         w = int(rng.integers(8, 121))
@@ -36,8 +37,33 @@ def synth_frame(rows=1080, cols=1920, seed=0, n_rect=300, noise_sigma=3.0, shift
         x = int(rng.integers(0, Cc - w))
         y = int(rng.integers(0, R - h))
         img[y:y + h, x:x + w] = float(rng.uniform(0.0, 255.0))
+    return img
+
+
+def frame_from_scene(scene, rows, cols, shift=(0, 0), noise_seed=0, noise_sigma=3.0):
     dx, dy = shift
-    img = img[pad + dy:pad + dy + rows, pad + dx:pad + dx + cols]
-    nrng = np.random.Generator(np.random.PCG64(seed * 7919 + 17 if noise_seed is None else noise_seed))
+    assert abs(dx) <= PAD and abs(dy) <= PAD
+    img = scene[PAD + dy:PAD + dy + rows, PAD + dx:PAD + dx + cols]
+    nrng = np.random.Generator(np.random.PCG64(noise_seed))
     img = img + nrng.normal(0.0, noise_sigma, size=img.shape).astype(np.float32)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def synth_frame(rows=1080, cols=1920, seed=0, n_rect=300, noise_sigma=3.0, shift=(0, 0), noise_seed=None):
+    """Returns a (rows, cols) uint8 frame. `shift`=(dx,dy) translates the underlying scene (frame k+1 = frame k shifted),
+    `noise_seed` draws fresh pixel noise on the same scene."""
+    scene = synth_scene(rows, cols, seed, n_rect)
+    return frame_from_scene(scene, rows, cols, shift, seed * 7919 + 17 if noise_seed is None else noise_seed, noise_sigma)
+
+
+def synth_video(rows, cols, n_frames, seed=0, frames_per_scene=8, step=(3, 2)):
+    """n_frames frames; every `frames_per_scene` consecutive frames pan over one scene by `step` px per frame with fresh
+    pixel noise (BASELINE config 2: frame k+1 = frame k shifted by (3, 2) px + fresh noise)."""
+    out = np.empty((n_frames, rows, cols), np.uint8)
+    scene = None
+    for i in range(n_frames):
+        k = i % frames_per_scene
+        if k == 0:
+            scene = synth_scene(rows, cols, seed * 1000 + i // frames_per_scene)
+        out[i] = frame_from_scene(scene, rows, cols, (step[0] * k, step[1] * k), noise_seed=seed * 100003 + i)
+    return out
