@@ -144,6 +144,8 @@ def main():
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
     kp_all, matches_all, pairs_all = (float(x) for x in totals.cpu().numpy())
 
+    ba_res = bench_local_ba(world, rank, dist, torch)
+
     if rank == 0:
         n_cand = 0
         for l in range(LEVELS):
@@ -202,6 +204,7 @@ def main():
             "extract_frac_of_hbm_peak": round(extract_gbs / HBM_PEAK_GBS, 5),
             "roofline": roof,
             "cpu_baseline": cpu,
+            "local_ba": ba_res,
             "parity": "bit-exact vs in-repo CPU oracle (from-spec restatement; upstream source unavailable: parity unpinned)",
         }
         if cpu:
@@ -210,6 +213,43 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_local_ba(world, rank, dist, torch, iters=20):
+    """BASELINE configs[4]: local BA, 50 keyframes x 2000 observations, 20 000 landmarks, fp64: one linearisation = residuals +
+    Jacobians + Hpp/Hll/Hpl/bp/bl blocks. Edges are sharded by keyframe over the ranks; Hll|bl (1.92 MB) are all-reduced over
+    RCCL. Reported beside the headline metric (not part of `value`)."""
+    from openvslam_amd import ba
+    from openvslam_amd.synth import synth_local_ba
+    d = synth_local_ba(seed=0)
+    shard = ba.shard_edges_by_keyframe(d["edges"], len(d["poses"]), rank, world)
+    poses = torch.from_numpy(d["poses"]).cuda()
+    fixed = torch.from_numpy(d["pose_fixed"]).cuda()
+    pts = torch.from_numpy(d["points"]).cuda()
+    edges = torch.from_numpy(shard.view(np.uint8)).cuda()
+    lin = ba.local_ba_linearizer(d["cam"], d["huber_delta"])
+    for _ in range(3):
+        out = lin.linearize(poses, fixed, pts, edges)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = lin.linearize(poses, fixed, pts, edges)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    n_edges = len(d["edges"])
+    alg_bytes = n_edges * 32 + 50 * 56 + 20000 * 24 + n_edges * 144 + 20000 * 96 + 50 * 336   # SURVEY 8(d): ~20.0 MB / iteration
+    return {"workload": "BASELINE configs[4]: 50 keyframes x 2000 observations, 20000 landmarks, fp64, Huber sqrt(5.991)",
+            "ms_per_linearisation": round(dt / iters * 1e3, 4), "edges_per_sec": round(n_edges * iters / dt, 1),
+            "algorithmic_GBps": round(alg_bytes * iters / dt / 1e9, 2), "allreduce_bytes": 20000 * 12 * 8 if world > 1 else 0,
+            "chi2": float(out["chi2"][0].item()), "tolerance_vs_oracle": "Hpl bit-exact; sums 1e-12 rel (1 GPU), 1e-10 rel (multi-rank)"}
 
 
 def cpu_baseline(frames, budget_s=12.0):

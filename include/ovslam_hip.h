@@ -155,6 +155,36 @@ ovs_status ovs_matcher_profile_read(ovs_matcher* m, float* stage_ms /* 2 */, int
 ovs_status ovs_hamming_best2(ovs_matcher* m, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, const uint8_t* t_valid,
                              int32_t* best_idx, uint16_t* best, uint16_t* second);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Local bundle adjustment: residual + Jacobian + normal-equation blocks (one Levenberg-Marquardt linearisation).
+ * replaces: the computeError / linearizeOplus / constructQuadraticForm loop g2o runs inside
+ * optimize::local_bundle_adjuster::optimize (src/openvslam/optimize/local_bundle_adjuster.cc; edge math in
+ * src/openvslam/optimize/g2o/se3/perspective_reproj_edge.{h,cc}). The sparse Schur solve stays on the host.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ovs_ba_cam {
+    double fx, fy, cx, cy;   /* perspective, monocular observation (2 residuals) */
+} ovs_ba_cam;
+
+typedef struct ovs_ba_edge {   /* one observation: reproj_edge_wrapper */
+    int32_t pose_idx, point_idx;
+    double obs_x, obs_y;
+    double inv_sigma_sq;       /* information = inv_level_sigma_sq[octave] * I2 */
+} ovs_ba_edge;
+
+/* poses: n_pose x 7 = (tx,ty,tz,qx,qy,qz,qw), world->camera (g2o SE3Quat::toVector order); pose_fixed: NULL or n_pose bytes;
+ * points: n_pt x 3. huber_delta <= 0 disables the robust kernel (the second optimisation round).
+ * Outputs: Hpp n_pose x 36 (row-major 6x6, pose order omega then upsilon), bp n_pose x 6, Hll n_pt x 9, bl n_pt x 3,
+ * Hpl n_edge x 18 (row-major 6x3 = Jp^T W Jl, zero for fixed poses), chi2[2] = {sum e^T Omega e, sum rho(.)}; b = -J^T W e.
+ * For an edge SHARD (multi-GPU: edges partitioned by keyframe) the same call produces the shard's partial sums; only
+ * Hll|bl need an all-reduce across shards (see openvslam_amd/ba.py). */
+ovs_status ovs_ba_linearize(int32_t device, const double* poses, const uint8_t* pose_fixed, int32_t n_pose, const double* points,
+                            int32_t n_pt, const ovs_ba_edge* edges, int32_t n_edge, const ovs_ba_cam* cam, double huber_delta,
+                            double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* chi2);
+/* Device-pointer form (cam stays a host pointer: it is passed by value to the kernel). Zeroes the outputs, asynchronous. */
+ovs_status ovs_ba_linearize_dev(const double* d_poses, const uint8_t* d_pose_fixed, int32_t n_pose, const double* d_points,
+                                int32_t n_pt, const ovs_ba_edge* d_edges, int32_t n_edge, const ovs_ba_cam* cam, double huber_delta,
+                                double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,8 @@ SYMBOLS = {
     "ovs_matcher_destroy": (_i32, [_vp]),
     "ovs_robust_brute_force_match": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _f, _vp, _i32, C.POINTER(_i32)]),
     "ovs_robust_brute_force_match_batch_dev": (_i32, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _i32, _f, _vp, _vp, _i32, _vp]),
+    "ovs_ba_linearize": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ovs_ba_linearize_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_hamming_best2": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
 }
 

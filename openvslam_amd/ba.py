@@ -1,0 +1,185 @@
+"""Host side of the local-BA linearisation (config 5 of BASELINE.json): mirrors what g2o does between
+optimize::local_bundle_adjuster::optimize's graph construction and its linear solve (expected:
+src/openvslam/optimize/local_bundle_adjuster.cc), with the residual/Jacobian/block accumulation on the GPU.
+
+Multi-GPU shape: edges are partitioned BY KEYFRAME across ranks (one process per GPU). Hpp/bp are then
+complete on the owning rank (summed across ranks only to replicate them: 50 x 42 doubles), Hpl is per edge (stays local),
+and the landmark blocks Hll|bl -- landmarks are seen from several keyframes -- need ONE sum across ranks: a single
+all-reduce of a dense n_pt x 12 fp64 buffer (1.92 MB at 20 000 landmarks; RCCL over xGMI on GPUs, gloo in the CPU tests).
+The sparse Schur solve stays on the host (`schur_solve`)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+EDGE_DTYPE = np.dtype([("pose_idx", "<i4"), ("point_idx", "<i4"), ("obs_x", "<f8"), ("obs_y", "<f8"), ("inv_sigma_sq", "<f8")])
+assert EDGE_DTYPE.itemsize == 32
+
+
+class BaCam(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double)]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def linearize(poses, pose_fixed, points, edges, cam, huber_delta, device=0):
+    """Single-GPU, host buffers in / host buffers out (ovs_ba_linearize). cam = (fx, fy, cx, cy)."""
+    L = _lib.lib()
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    edges = np.ascontiguousarray(edges, EDGE_DTYPE)
+    fixed = None if pose_fixed is None else np.ascontiguousarray(pose_fixed, np.uint8)
+    n_pose, n_pt, n_edge = len(poses), len(points), len(edges)
+    out = dict(Hpp=np.zeros((n_pose, 6, 6)), bp=np.zeros((n_pose, 6)), Hll=np.zeros((n_pt, 3, 3)), bl=np.zeros((n_pt, 3)),
+               Hpl=np.zeros((max(n_edge, 1), 6, 3)), chi2=np.zeros(2))
+    c = BaCam(*cam)
+    _lib.check(L.ovs_ba_linearize(device, _p(poses), _p(fixed), n_pose, _p(points), n_pt, _p(edges), n_edge, C.byref(c), float(huber_delta),
+                                  _p(out["Hpp"]), _p(out["bp"]), _p(out["Hll"]), _p(out["bl"]), _p(out["Hpl"]), _p(out["chi2"])),
+               "ovs_ba_linearize")
+    out["Hpl"] = out["Hpl"][:n_edge]
+    return out
+
+
+def shard_edges_by_keyframe(edges, n_pose, rank, world):
+    """Edges of keyframes [rank*ceil(n_pose/world), ...): contiguous keyframe blocks, 2000 edges each in config 5."""
+    per = -(-n_pose // world)
+    sel = (edges["pose_idx"] // per) == rank
+    return np.ascontiguousarray(edges[sel])
+
+
+def hip_backend(poses_t, fixed_t, points_t, edges_t, cam, huber_delta):
+    """Local shard on the current CUDA device through ovs_ba_linearize_dev. Tensors are torch CUDA tensors; edges_t is a uint8
+    tensor viewing EDGE_DTYPE records. Returns (HppBp [n_pose,42], HllBl [12*n_pt] = Hll|bl, Hpl [n_edge,18], chi2 [2])."""
+    import torch
+    L = _lib.lib()
+    n_pose, n_pt, n_edge = poses_t.shape[0], points_t.shape[0], edges_t.numel() // 32
+    dev = poses_t.device
+    hppbp = torch.empty((n_pose * 42,), dtype=torch.float64, device=dev)
+    hllbl = torch.empty((n_pt * 12,), dtype=torch.float64, device=dev)
+    hpl = torch.empty((max(n_edge, 1), 18), dtype=torch.float64, device=dev)
+    chi2 = torch.empty((2,), dtype=torch.float64, device=dev)
+    c = BaCam(*cam)
+    base_pp, base_ll = hppbp.data_ptr(), hllbl.data_ptr()
+    _lib.check(L.ovs_ba_linearize_dev(poses_t.data_ptr(), fixed_t.data_ptr() if fixed_t is not None else None, n_pose, points_t.data_ptr(),
+                                      n_pt, edges_t.data_ptr() if n_edge else None, n_edge, C.byref(c), float(huber_delta),
+                                      base_pp, base_pp + 8 * 36 * n_pose, base_ll, base_ll + 8 * 9 * n_pt, hpl.data_ptr(), chi2.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream), "ovs_ba_linearize_dev")
+    return hppbp, hllbl, hpl[:n_edge], chi2
+
+
+class local_ba_linearizer:
+    """One Levenberg-Marquardt linearisation of the local map, sharded over the ranks of a torch.distributed group.
+
+    Every rank holds all poses and points (0.48 MB at config 5: broadcast/replicated by the caller) and ITS shard of the edges.
+    `backend` computes the shard's partial blocks; the default is the HIP kernel."""
+
+    def __init__(self, cam, huber_delta, group=None, backend=hip_backend):
+        self.cam = tuple(float(v) for v in cam)
+        self.huber_delta = float(huber_delta)
+        self.group = group
+        self.backend = backend
+
+    def linearize(self, poses_t, fixed_t, points_t, edges_t):
+        import torch.distributed as dist
+        hppbp, hllbl, hpl, chi2 = self.backend(poses_t, fixed_t, points_t, edges_t, self.cam, self.huber_delta)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            # THE exchange step of this path: landmark blocks are shared between keyframes on different ranks
+            dist.all_reduce(hllbl, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(hppbp, op=dist.ReduceOp.SUM, group=self.group)   # replicate the (rank-exclusive) pose blocks: 50 x 42 f64
+            dist.all_reduce(chi2, op=dist.ReduceOp.SUM, group=self.group)
+        n_pose, n_pt = poses_t.shape[0], points_t.shape[0]
+        return dict(Hpp=hppbp[:36 * n_pose].view(n_pose, 6, 6), bp=hppbp[36 * n_pose:].view(n_pose, 6), Hll=hllbl[:9 * n_pt].view(n_pt, 3, 3),
+                    bl=hllbl[9 * n_pt:].view(n_pt, 3), Hpl=hpl.view(-1, 6, 3), chi2=chi2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Host-side reduced-camera solve (what g2o's BlockSolver_6_3 + linear solver do; dense here: 50 keyframes -> 300 x 300)
+# ---------------------------------------------------------------------------------------------------------------------
+def schur_solve(Hpp, bp, Hll, bl, Hpl, edges, pose_fixed, lam=0.0):
+    """Solve [Hpp Hpl; Hpl^T Hll] [dp; dl] = [bp; bl] by eliminating the landmarks. Returns (dp [n_pose,6], dl [n_pt,3])."""
+    Hpp, bp, Hll, bl, Hpl = (np.asarray(a, np.float64) for a in (Hpp, bp, Hll, bl, Hpl))
+    n_pose, n_pt = len(Hpp), len(Hll)
+    free = np.nonzero(~np.asarray(pose_fixed, bool))[0] if pose_fixed is not None else np.arange(n_pose)
+    slot = -np.ones(n_pose, np.int64)
+    slot[free] = np.arange(len(free))
+    Hll_d = Hll + lam * np.eye(3)[None] * np.maximum(np.einsum("nii->n", Hll)[:, None, None] / 3, 1e-12) if lam else Hll
+    # a landmark seen from a single keyframe has a rank-2 block (depth unobservable): leave it untouched, as local BA does
+    # by only inserting landmarks with >= 2 observations
+    seen = np.bincount(edges["point_idx"], minlength=n_pt) >= 2
+    Hinv = np.zeros_like(Hll)
+    Hinv[seen] = np.linalg.inv(Hll_d[seen])
+    S = np.zeros((6 * len(free), 6 * len(free)))
+    g = np.zeros(6 * len(free))
+    for k in free:
+        s = slot[k]
+        S[6 * s:6 * s + 6, 6 * s:6 * s + 6] = Hpp[k] * (1 + lam) if lam else Hpp[k]
+        g[6 * s:6 * s + 6] = bp[k]
+    pi, li = edges["pose_idx"], edges["point_idx"]
+    keep = slot[pi] >= 0
+    pi, li, W = pi[keep], li[keep], Hpl[keep]
+    WH = np.einsum("eab,ebc->eac", W, Hinv[li])                 # W_kj Hll_j^-1   (6x3)
+    np.subtract.at(g.reshape(-1, 6), slot[pi], np.einsum("eab,eb->ea", WH, bl[li]))
+    order = np.argsort(li, kind="stable")
+    pi_s, li_s, W_s, WH_s = pi[order], li[order], W[order], WH[order]
+    starts = np.flatnonzero(np.r_[True, li_s[1:] != li_s[:-1], True])
+    for a, b in zip(starts[:-1], starts[1:]):                   # all keyframe pairs seeing landmark j
+        for i in range(a, b):
+            si = slot[pi_s[i]]
+            for j in range(a, b):
+                sj = slot[pi_s[j]]
+                S[6 * si:6 * si + 6, 6 * sj:6 * sj + 6] -= WH_s[i] @ W_s[j].T
+    dp_free = np.linalg.solve(S, g)
+    dp = np.zeros((n_pose, 6))
+    dp[free] = dp_free.reshape(-1, 6)
+    rhs = bl.copy()
+    np.subtract.at(rhs, li, np.einsum("eab,ea->eb", W, dp[pi]))
+    dl = np.einsum("nab,nb->na", Hinv, rhs)
+    return dp, dl
+
+
+def se3_oplus(poses, dp):
+    """g2o VertexSE3Expmap::oplusImpl: T <- exp(update) * T with update = (omega, upsilon)."""
+    out = np.array(poses, np.float64).reshape(-1, 7).copy()
+    for i, u in enumerate(np.asarray(dp, np.float64)):
+        om, up = u[:3], u[3:]
+        th = np.linalg.norm(om)
+        Om = np.array([[0, -om[2], om[1]], [om[2], 0, -om[0]], [-om[1], om[0], 0]])
+        if th < 1e-5:
+            R = np.eye(3) + Om + 0.5 * Om @ Om
+            V = R
+        else:
+            R = np.eye(3) + np.sin(th) / th * Om + (1 - np.cos(th)) / th ** 2 * (Om @ Om)
+            V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * Om + (th - np.sin(th)) / th ** 3 * (Om @ Om)
+        Rold = quat_to_rot(out[i, 3:7])
+        Rn = R @ Rold
+        tn = R @ out[i, :3] + V @ up
+        out[i, :3] = tn
+        out[i, 3:7] = rot_to_quat(Rn)
+    return out
+
+
+def quat_to_rot(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def rot_to_quat(R):
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = np.zeros(4)
+        q[i] = 0.25 * s
+        q[j] = (R[j, i] + R[i, j]) / s
+        q[k] = (R[k, i] + R[i, k]) / s
+        q[3] = (R[k, j] - R[j, k]) / s
+    return q / np.linalg.norm(q)

@@ -67,3 +67,56 @@ def synth_video(rows, cols, n_frames, seed=0, frames_per_scene=8, step=(3, 2)):
             scene = synth_scene(rows, cols, seed * 1000 + i // frames_per_scene)
         out[i] = frame_from_scene(scene, rows, cols, (step[0] * k, step[1] * k), noise_seed=seed * 100003 + i)
     return out
+
+
+def synth_local_ba(n_pose=50, n_pt=20000, obs_per_pose=2000, seed=0, pose_noise=0.0, point_noise=0.0, n_fixed=2):
+    """BASELINE config 5: n_pose keyframes on a 10 m circle looking inward, n_pt landmarks uniform in a 4 m
+    cube, each keyframe observes its obs_per_pose nearest landmarks; perspective fx=fy=700, cx=960, cy=540; observation =
+    exact projection + N(0,1) px; octave U{0..7} (information = 1/1.2^(2*octave)); the first n_fixed poses are fixed.
+    pose_noise / point_noise perturb the INITIAL estimate (for Gauss-Newton tests). Returns a dict of numpy arrays."""
+    from .ba import EDGE_DTYPE, rot_to_quat
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cam = (700.0, 700.0, 960.0, 540.0)
+    pts = rng.uniform(-2.0, 2.0, size=(n_pt, 3))
+    poses = np.zeros((n_pose, 7))
+    Rs, ts = [], []
+    for k in range(n_pose):
+        a = 2 * np.pi * k / n_pose
+        Cw = np.array([10 * np.cos(a), 0.0, 10 * np.sin(a)])
+        z = -Cw / np.linalg.norm(Cw)
+        up = np.array([0.0, -1.0, 0.0])
+        x = np.cross(up, z); x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R = np.stack([x, y, z])
+        t = -R @ Cw
+        Rs.append(R); ts.append(t)
+        poses[k, :3] = t
+        poses[k, 3:] = rot_to_quat(R)
+    edges = np.zeros(n_pose * obs_per_pose, EDGE_DTYPE)
+    sig = np.float32(1.0)
+    inv_sig = []
+    for _ in range(8):
+        inv_sig.append(1.0 / float(np.float32(sig * sig)))
+        sig = np.float32(1.2) * sig
+    inv_sig = np.array(inv_sig)
+    for k in range(n_pose):
+        pc = pts @ Rs[k].T + ts[k]
+        near = np.argsort(pc[:, 2], kind="stable")[:obs_per_pose]
+        near.sort()
+        u = cam[0] * pc[near, 0] / pc[near, 2] + cam[2] + rng.normal(0, 1, len(near))
+        v = cam[1] * pc[near, 1] / pc[near, 2] + cam[3] + rng.normal(0, 1, len(near))
+        e = edges[k * obs_per_pose:(k + 1) * obs_per_pose]
+        e["pose_idx"] = k
+        e["point_idx"] = near
+        e["obs_x"] = u
+        e["obs_y"] = v
+        e["inv_sigma_sq"] = inv_sig[rng.integers(0, 8, len(near))]
+    fixed = np.zeros(n_pose, np.uint8)
+    fixed[:n_fixed] = 1
+    poses0, pts0 = poses.copy(), pts.copy()
+    if pose_noise:
+        poses0[n_fixed:, :3] += rng.normal(0, pose_noise, size=(n_pose - n_fixed, 3))
+    if point_noise:
+        pts0 += rng.normal(0, point_noise, size=pts.shape)
+    return dict(cam=cam, poses=poses0, points=pts0, poses_true=poses, points_true=pts, edges=edges, pose_fixed=fixed,
+                huber_delta=float(np.sqrt(5.991)))

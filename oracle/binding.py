@@ -74,7 +74,8 @@ def lib():
     return L
 
 
-_OPTIONAL = {}
+_OPTIONAL = {"ovo_ba_linearize": ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int)}
 
 
 def _p(a):
@@ -231,3 +232,23 @@ def hamming_best2(q, t, t_valid=None):
     s = np.zeros(len(q), np.uint16)
     lib().ovo_hamming_best2(_p(q), len(q), _p(t), len(t), _p(t_valid), _p(bi), _p(b), _p(s))
     return bi, b, s
+
+
+BA_EDGE_DTYPE = np.dtype([("pose_idx", "<i4"), ("point_idx", "<i4"), ("obs_x", "<f8"), ("obs_y", "<f8"), ("inv_sigma_sq", "<f8")])
+
+
+def ba_linearize(poses, pose_fixed, points, edges, cam, huber_delta):
+    """Oracle restatement of B1-B3 (ovo_ba.cc). Returns dict(Hpp, bp, Hll, bl, Hpl, chi2)."""
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    fixed = None if pose_fixed is None else np.ascontiguousarray(pose_fixed, np.uint8)
+    n_pose, n_pt, n_edge = len(poses), len(points), len(edges)
+    out = dict(Hpp=np.zeros((n_pose, 6, 6)), bp=np.zeros((n_pose, 6)), Hll=np.zeros((n_pt, 3, 3)), bl=np.zeros((n_pt, 3)),
+               Hpl=np.zeros((max(n_edge, 1), 6, 3)), chi2=np.zeros(2))
+    c = np.array(cam, np.float64)
+    rc = lib().ovo_ba_linearize(_p(poses), _p(fixed), n_pose, _p(points), n_pt, _p(edges), n_edge, _p(c), float(huber_delta), _p(out["Hpp"]),
+                                _p(out["bp"]), _p(out["Hll"]), _p(out["bl"]), _p(out["Hpl"]), _p(out["chi2"]))
+    assert rc == 0, rc
+    out["Hpl"] = out["Hpl"][:n_edge]
+    return out

@@ -1,0 +1,108 @@
+// ovo_ba.cc -- CPU ORACLE (test infrastructure, see ovo_oracle.h): residual / Jacobian / normal-equation blocks of local BA.
+// PARITY UNPINNED (upstream and g2o absent). Restates SURVEY.md 8(a) rows B1-B3:
+//   B1 optimize::g2o::se3::mono_perspective_reproj_edge::computeError   (expected: src/openvslam/optimize/g2o/se3/perspective_reproj_edge.cc)
+//   B2 ...::linearizeOplus (identical to ORB-SLAM2 EdgeSE3ProjectXYZ: vertex 0 = landmark, vertex 1 = pose, pose order omega then upsilon)
+//   B3 g2o BaseBinaryEdge::constructQuadraticForm + RobustKernelHuber::robustify (rho'' term dropped) + BlockSolver::buildSystem
+// fp64 throughout, fixed evaluation order (edges in input order), no FMA contraction.
+#include <cmath>
+#include <cstring>
+
+#include "ovo_oracle.h"
+
+extern "C" {
+
+typedef struct ovo_ba_cam {
+    double fx, fy, cx, cy;
+} ovo_ba_cam;
+
+typedef struct ovo_ba_edge {
+    int32_t pose_idx, point_idx;
+    double obs_x, obs_y;
+    double inv_sigma_sq;   // information = inv_level_sigma_sq[octave] * I2
+} ovo_ba_edge;
+
+// poses: n_pose x 7 = (tx, ty, tz, qx, qy, qz, qw) (g2o SE3Quat::toVector order), world -> camera.
+// Outputs (all zero-initialised here): Hpp n_pose x 36 (row-major 6x6), bp n_pose x 6, Hll n_pt x 9, bl n_pt x 3,
+// Hpl n_edge x 18 (row-major 6x3 = Jp^T W Jl; zero for fixed poses), chi2[2] = {sum e^T Omega e, sum rho(e^T Omega e)}.
+int ovo_ba_linearize(const double* poses, const uint8_t* pose_fixed, int n_pose, const double* points, int n_pt,
+                     const ovo_ba_edge* edges, int n_edge, const ovo_ba_cam* cam, double huber_delta, double* Hpp, double* bp,
+                     double* Hll, double* bl, double* Hpl, double* chi2) {
+    std::memset(Hpp, 0, sizeof(double) * 36 * n_pose);
+    std::memset(bp, 0, sizeof(double) * 6 * n_pose);
+    std::memset(Hll, 0, sizeof(double) * 9 * n_pt);
+    std::memset(bl, 0, sizeof(double) * 3 * n_pt);
+    std::memset(Hpl, 0, sizeof(double) * 18 * n_edge);
+    chi2[0] = chi2[1] = 0.0;
+    const double dsqr = huber_delta * huber_delta;
+    for (int e = 0; e < n_edge; ++e) {
+        const ovo_ba_edge& ed = edges[e];
+        if (ed.pose_idx < 0 || ed.pose_idx >= n_pose || ed.point_idx < 0 || ed.point_idx >= n_pt) return -1;
+        const double* P = poses + 7 * ed.pose_idx;
+        const double* X = points + 3 * ed.point_idx;
+        // unit quaternion -> rotation matrix (Eigen's toRotationMatrix form)
+        const double qx = P[3], qy = P[4], qz = P[5], qw = P[6];
+        const double tx2 = 2 * qx, ty2 = 2 * qy, tz2 = 2 * qz;
+        const double twx = tx2 * qw, twy = ty2 * qw, twz = tz2 * qw;
+        const double txx = tx2 * qx, txy = ty2 * qx, txz = tz2 * qx;
+        const double tyy = ty2 * qy, tyz = tz2 * qy, tzz = tz2 * qz;
+        const double R[3][3] = {{1 - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1 - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1 - (txx + tyy)}};
+        const double x = R[0][0] * X[0] + R[0][1] * X[1] + R[0][2] * X[2] + P[0];
+        const double y = R[1][0] * X[0] + R[1][1] * X[1] + R[1][2] * X[2] + P[1];
+        const double z = R[2][0] * X[0] + R[2][1] * X[1] + R[2][2] * X[2] + P[2];
+        const double invz = 1.0 / z, invz2 = invz * invz;
+        // B1: e = z_obs - pi(RX + t)
+        const double e0 = ed.obs_x - (cam->fx * x * invz + cam->cx);
+        const double e1 = ed.obs_y - (cam->fy * y * invz + cam->cy);
+        const double w = ed.inv_sigma_sq;
+        const double c2 = w * (e0 * e0 + e1 * e1);
+        // B3: Huber weights (g2o RobustKernelHuber::robustify; huber_delta <= 0 means "no robust kernel")
+        double rho0 = c2, rho1 = 1.0;
+        if (huber_delta > 0 && c2 > dsqr) {
+            const double sq = std::sqrt(c2);
+            rho0 = 2 * sq * huber_delta - dsqr;
+            rho1 = huber_delta / sq;
+        }
+        chi2[0] += c2;
+        chi2[1] += rho0;
+        // B2: Jacobians. Jl = -1/z * [fx 0 -fx x/z; 0 fy -fy y/z] * R   (2x3);  Jp (2x6), g2o SE3 order (omega, upsilon)
+        double Jl[2][3], Jp[2][6];
+        for (int c = 0; c < 3; ++c) {
+            Jl[0][c] = -invz * (cam->fx * R[0][c] - cam->fx * x * invz * R[2][c]);
+            Jl[1][c] = -invz * (cam->fy * R[1][c] - cam->fy * y * invz * R[2][c]);
+        }
+        Jp[0][0] = x * y * invz2 * cam->fx;
+        Jp[0][1] = -(1 + x * x * invz2) * cam->fx;
+        Jp[0][2] = y * invz * cam->fx;
+        Jp[0][3] = -invz * cam->fx;
+        Jp[0][4] = 0;
+        Jp[0][5] = x * invz2 * cam->fx;
+        Jp[1][0] = (1 + y * y * invz2) * cam->fy;
+        Jp[1][1] = -x * y * invz2 * cam->fy;
+        Jp[1][2] = -x * invz * cam->fy;
+        Jp[1][3] = 0;
+        Jp[1][4] = -invz * cam->fy;
+        Jp[1][5] = y * invz2 * cam->fy;
+        // weighted information W = rho1 * w * I2; omega_r = -rho1 * w * e
+        const double W = rho1 * w;
+        const double r0 = -W * e0, r1 = -W * e1;
+        double* hl = Hll + 9 * ed.point_idx;
+        double* gl = bl + 3 * ed.point_idx;
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) hl[3 * a + b] += W * (Jl[0][a] * Jl[0][b] + Jl[1][a] * Jl[1][b]);
+            gl[a] += Jl[0][a] * r0 + Jl[1][a] * r1;
+        }
+        if (!(pose_fixed && pose_fixed[ed.pose_idx])) {
+            double* hp = Hpp + 36 * ed.pose_idx;
+            double* gp = bp + 6 * ed.pose_idx;
+            double* hpl = Hpl + 18 * (size_t)e;
+            for (int a = 0; a < 6; ++a) {
+                for (int b = 0; b < 6; ++b) hp[6 * a + b] += W * (Jp[0][a] * Jp[0][b] + Jp[1][a] * Jp[1][b]);
+                gp[a] += Jp[0][a] * r0 + Jp[1][a] * r1;
+                for (int b = 0; b < 3; ++b) hpl[3 * a + b] = W * (Jp[0][a] * Jl[0][b] + Jp[1][a] * Jl[1][b]);
+            }
+        }
+    }
+    return 0;
+}
+
+}   // extern "C"
