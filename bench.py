@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ba", action="store_true", help="skip the local-BA side section (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -144,7 +145,7 @@ def main():
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
     kp_all, matches_all, pairs_all = (float(x) for x in totals.cpu().numpy())
 
-    ba_res = bench_local_ba(world, rank, dist, torch)
+    ba_res = None if args.no_ba else bench_local_ba(world, rank, dist, torch)
 
     if rank == 0:
         n_cand = 0

@@ -2,14 +2,16 @@
 // compute_orb_descriptor and correct_keypoint_scale (expected: src/openvslam/feature/orb_extractor.cc,
 // util/trigonometric.h; OpenCV fastAtan2, GaussianBlur, cvRound).
 //
-// One 256-thread workgroup per selected keypoint. Everything a keypoint needs lies in the 43x43 patch around it
-// (rBRIEF reaches +-18 px after rotation, the blur adds 3), so the patch is staged in LDS once and
-//   * the intensity-centroid moments are exact integer sums over the radius-15 disc (wave + LDS reduction),
+// One WAVE (a 64-thread workgroup) per selected keypoint -- no workgroup barriers, 30 keypoints in flight per CU.
+// Everything a keypoint needs lies in the 43x43 patch around it (rBRIEF reaches +-18 px after rotation, the blur adds 3):
+//   * the patch is staged in LDS as 43 aligned 64-byte row segments (three 16-byte loads per lane),
+//   * the intensity-centroid moments are exact integer sums over the radius-15 disc (two lanes per disc row + wave reduce),
 //   * the angle is cv::fastAtan2's float polynomial evaluated with explicit non-fused IEEE ops (__fmul_rn/__fadd_rn/
-//     __fdiv_rn) in the oracle's order, so the float result is bit-identical to the CPU,
-//   * the blur is evaluated ONLY where it is sampled: row pass 8.8 fixed point over 43x37 into LDS, column pass at the 512
-//     sample points (instead of blurring 6.4 MP per frame, upstream's cv::GaussianBlur of every level),
-//   * thread t evaluates test t; a wave's ballot is 8 descriptor bytes (bit i of byte j = test 8j+i).
+//     __fdiv_rn) in the oracle's order, so the float result is bit-identical to the CPU; every lane evaluates it (uniform),
+//   * the blur is evaluated ONLY where it is sampled: row pass in 8.8 fixed point over 43x37 (four outputs per lane-step from
+//     word reads, v_alignbyte_b32 + v_dot4_u32_u8), column pass at the 512 sample points (instead of blurring 6.4 MP per
+//     frame, upstream's cv::GaussianBlur of every level),
+//   * lane l evaluates tests l, l+64, l+128, l+192; each ballot is 8 descriptor bytes (bit i of byte j = test 8j+i).
 // Keypoints are written level-major at their final position: frame offset = sum of lower levels' counts.
 #include "ovs_common.h"
 
@@ -19,12 +21,16 @@ __constant__ int8_t c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
 __constant__ int32_t c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-__constant__ int32_t c_gauss7[7] = {18, 49, 33, 56, 33, 49, 18};
+__constant__ int32_t c_gauss7[7] = {18, 34, 48, 56, 48, 34, 18};   // oracle/ORACLE_SPEC.md rule 10
+constexpr uint32_t kG0123 = 18u | (34u << 8) | (48u << 16) | (56u << 24);
+constexpr uint32_t kG456 = 48u | (34u << 8) | (18u << 16);
 
 constexpr int kPatch = 43;       // 2*(18+3)+1
 constexpr int kPatchR = 21;
 constexpr int kBlurW = 37;       // 2*18+1
 constexpr int kBlurR = 18;
+constexpr int kPatchPitch = 64;   // bytes: one aligned 64-byte window of each image row
+constexpr int kHbPitch = 40;      // u16 per row of the row-blurred patch (37 used)
 
 // cv::fastAtan2 (scalar form), degrees in [0, 360). Every operation individually rounded (no FMA contraction).
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
@@ -67,17 +73,15 @@ __device__ __forceinline__ float util_cos(float v) {
 }
 __device__ __forceinline__ float util_sin(float v) { return util_cos(__fsub_rn(1.57079632679489661923f, v)); }
 
-__global__ __launch_bounds__(256) void k_describe(const FrameGeo* __restrict__ geo, const uint8_t* __restrict__ img0, size_t stride0,
-                                                 size_t frame_stride0, const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
-                                                 const uint64_t* __restrict__ lvl_kps, const uint32_t* __restrict__ lvl_count,
-                                                 ovs_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                 int32_t* __restrict__ counts, int cap) {
-    __shared__ uint8_t patch[kPatch][kPatch + 1];
-    __shared__ uint16_t hblur[kPatch][kBlurW + 1];
-    __shared__ int red[2][4];
-    __shared__ float s_trig[3];
+__global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ geo, const uint8_t* __restrict__ img0, size_t stride0,
+                                                size_t frame_stride0, const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
+                                                const uint64_t* __restrict__ lvl_kps, const uint32_t* __restrict__ lvl_count,
+                                                ovs_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                int32_t* __restrict__ counts, int cap) {
+    __shared__ __attribute__((aligned(16))) uint8_t patch[kPatch * kPatchPitch];
+    __shared__ __attribute__((aligned(16))) uint16_t hblur[kPatch * kHbPitch];
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lane = threadIdx.x;
     const int frame = blockIdx.y;
     const int L = geo->num_levels;
     int level = 0;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void k_describe(const FrameGeo* __restrict__ g
     const LevelGeo& g = geo->lv[level];
     const int slot = blockIdx.x - g.kp_base;
     const uint32_t* cnt = lvl_count + frame * L;
-    if (blockIdx.x == 0 && tid == 0) {
+    if (blockIdx.x == 0 && lane == 0) {
         int total = 0;
         for (int l = 0; l < L; ++l) total += cnt[l];
         counts[frame] = total < cap ? total : cap;
@@ -107,72 +111,110 @@ __global__ __launch_bounds__(256) void k_describe(const FrameGeo* __restrict__ g
         img = pyr + (size_t)frame * pyr_frame_bytes + g.plane_off;
         pitch = g.pitch;
     }
-    // ---- stage the 43x43 patch (keypoints are >= 22 px from every border, so it is always inside the level)
-    for (int i = tid; i < kPatch * kPatch; i += 256) {
-        const int r = i / kPatch, c = i - r * kPatch;
-        patch[r][c] = img[(size_t)(y - kPatchR + r) * pitch + (x - kPatchR + c)];
-    }
-    __syncthreads();
-    // ---- ic_angle: m10 = sum u*I, m01 = sum v*I over the disc |u| <= u_max[|v|], |v| <= 15 (exact integers)
-    int m10 = 0, m01 = 0;
-    for (int i = tid; i < 31 * 31; i += 256) {
-        const int v = i / 31 - 15, u = i - (v + 15) * 31 - 15;
-        const int av = v < 0 ? -v : v;
-        if ((u < 0 ? -u : u) <= c_umax[av]) {
-            const int val = patch[kPatchR + v][kPatchR + u];
-            m10 += u * val;
-            m01 += v * val;
+    // ---- stage the 43x43 patch as 43 aligned 64-byte row segments. Keypoints are >= 22 px from every border, so the patch
+    // is inside the level; a segment may run up to 20 bytes past the row's last pixel (into the pitch padding or the next
+    // row of the same frame -- rows y-21 .. y+21 never include the frame's last row), never outside the allocation.
+    const int xs = x - kPatchR;
+    const int xa = xs & ~15;
+    const int off = __builtin_amdgcn_readfirstlane(xs - xa);   // patch column c lives at segment byte off + c; wave-uniform
+    const uint8_t* seg0 = img + (size_t)(y - kPatchR) * pitch + xa;
+    if (((pitch & 15) == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i = lane + 64 * j;
+            if (i < kPatch * 4) {
+                const int r = i >> 2, q = i & 3;
+                *reinterpret_cast<uint4*>(patch + r * kPatchPitch + 16 * q) = *reinterpret_cast<const uint4*>(seg0 + (size_t)r * pitch + 16 * q);
+            }
+        }
+    } else {   // 4-byte aligned base / stride (the ABI's minimum)
+        for (int i = lane; i < kPatch * 16; i += 64) {
+            const int r = i >> 4, q = i & 15;
+            *reinterpret_cast<uint32_t*>(patch + r * kPatchPitch + 4 * q) = *reinterpret_cast<const uint32_t*>(seg0 + (size_t)r * pitch + 4 * q);
         }
     }
+    __syncthreads();   // single-wave workgroup: orders the LDS writes above against the reads below, no s_barrier cost
+
+    // ---- ic_angle: m10 = sum u*I, m01 = sum v*I over the disc |u| <= u_max[|v|], |v| <= 15 (exact integers).
+    // Lane 2k / 2k+1 sums the negative / non-negative u of disc row v = k - 15.
+    int m10 = 0, m01 = 0;
+    if (lane < 62) {
+        const int v = (lane >> 1) - 15, h = lane & 1;
+        const int um = c_umax[v < 0 ? -v : v];
+        const uint8_t* row = patch + (kPatchR + v) * kPatchPitch + off + kPatchR;
+        int sum = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        m10 += __shfl_xor(m10, off);
-        m01 += __shfl_xor(m01, off);
+        for (int j = 0; j < 16; ++j) {
+            const int u = h ? j : -(j + 1);
+            if ((h ? j : j + 1) <= um) {
+                const int val = row[u];
+                m10 += u * val;
+                sum += val;
+            }
+        }
+        m01 = v * sum;
     }
-    if (lane == 0) {
-        red[0][wv] = m10;
-        red[1][wv] = m01;
-    }
-    // ---- blur row pass (8.8 fixed point): hblur[r][c] = sum_k g[k] * patch[r][c + k], c <-> dx = c - 18
-    for (int i = tid; i < kPatch * kBlurW; i += 256) {
-        const int r = i / kBlurW, c = i - r * kBlurW;
-        uint32_t acc = 0;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) acc += (uint32_t)c_gauss7[k] * patch[r][c + k];
-        hblur[r][c] = (uint16_t)acc;
+    for (int o = 32; o > 0; o >>= 1) {
+        m10 += __shfl_xor(m10, o);
+        m01 += __shfl_xor(m01, o);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    const float rad = __fmul_rn(angle, 0.017453292519943295f);
+    const float cos_a = util_cos(rad), sin_a = util_sin(rad);
+
+    // ---- blur row pass (8.8 fixed point): hblur[r][c] = sum_k g[k] * patch[r][c + k], c <-> dx = c - 18.
+    // One lane-step = outputs c = 4q .. 4q+3 of row r from 4 aligned words (columns 37..39 are computed and never read).
+    const int sh = off & 3;
+    uint32_t* hb32 = reinterpret_cast<uint32_t*>(hblur);
+    for (int i = lane; i < kPatch * 10; i += 64) {
+        const int r = i / 10, q = i - r * 10;
+        const uint32_t* pw = reinterpret_cast<const uint32_t*>(patch + r * kPatchPitch + ((off + 4 * q) & ~3));
+        const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3];
+        const uint32_t n0 = __builtin_amdgcn_alignbyte(w1, w0, sh), n1 = __builtin_amdgcn_alignbyte(w2, w1, sh),
+                       n2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t a = j ? __builtin_amdgcn_alignbyte(n1, n0, j) : n0;
+            const uint32_t b = j ? __builtin_amdgcn_alignbyte(n2, n1, j) : n1;
+            o[j] = __builtin_amdgcn_udot4(a, kG0123, __builtin_amdgcn_udot4(b, kG456, 0u, false), false);   // <= 255*256
+        }
+        hb32[r * (kHbPitch / 2) + 2 * q] = o[0] | (o[1] << 16);
+        hb32[r * (kHbPitch / 2) + 2 * q + 1] = o[2] | (o[3] << 16);
     }
     __syncthreads();
-    if (tid == 0) {
-        const int M10 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        const int M01 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        const float angle = fast_atan2_deg((float)M01, (float)M10);
-        const float rad = __fmul_rn(angle, 0.017453292519943295f);
-        s_trig[0] = angle;
-        s_trig[1] = util_cos(rad);
-        s_trig[2] = util_sin(rad);
-    }
-    __syncthreads();
-    const float cos_a = s_trig[1], sin_a = s_trig[2];
-    // ---- steered BRIEF: test `tid`
+
+    // ---- steered BRIEF: column pass of the blur at the sampled points only; lane evaluates tests lane + 64*t
     auto blurred_at = [&](int px, int py) -> int {
         const float fx = (float)px, fy = (float)py;
         const int dy = __float2int_rn(__fadd_rn(__fmul_rn(fx, sin_a), __fmul_rn(fy, cos_a)));
         const int dx = __float2int_rn(__fsub_rn(__fmul_rn(fx, cos_a), __fmul_rn(fy, sin_a)));
+        const uint16_t* hp = hblur + (dy + kBlurR) * kHbPitch + dx + kBlurR;
         uint32_t acc = 0;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) acc += (uint32_t)c_gauss7[k] * hblur[dy + kBlurR + k][dx + kBlurR];
+        for (int k = 0; k < 7; ++k) acc += (uint32_t)c_gauss7[k] * hp[k * kHbPitch];
         return (int)((acc + 32768u) >> 16);
     };
-    const int8_t* p = c_pattern + tid * 4;
-    const int t0 = blurred_at(p[0], p[1]), t1 = blurred_at(p[2], p[3]);
-    const unsigned long long bits = __ballot(t0 < t1);
-    if (lane == 0) *reinterpret_cast<unsigned long long*>(desc + ((size_t)frame * cap + out_idx) * 32 + wv * 8) = bits;
-    if (tid == 0) {
+    unsigned long long bits[4];
+    const uint32_t* pat = reinterpret_cast<const uint32_t*>(c_pattern);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t pp = pat[lane + 64 * t];
+        const int t0 = blurred_at((int8_t)(pp & 0xFF), (int8_t)((pp >> 8) & 0xFF));
+        const int t1 = blurred_at((int8_t)((pp >> 16) & 0xFF), (int8_t)(pp >> 24));
+        bits[t] = __ballot(t0 < t1);
+    }
+    if (lane < 4) {
+        const unsigned long long b = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+        reinterpret_cast<unsigned long long*>(desc + ((size_t)frame * cap + out_idx) * 32)[lane] = b;
+    }
+    if (lane == 0) {
         ovs_keypoint k;
         k.x = __fmul_rn((float)x, g.scale);   // correct_keypoint_scale
         k.y = __fmul_rn((float)y, g.scale);
         k.size = g.kp_size;
-        k.angle = s_trig[0];
+        k.angle = angle;
         k.response = (float)cand_score(kp);
         k.octave = level;
         k.class_id = -1;
@@ -183,7 +225,7 @@ __global__ __launch_bounds__(256) void k_describe(const FrameGeo* __restrict__ g
 hipError_t launch_describe(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
                            ovs_keypoint* kps, uint8_t* desc, int32_t* counts, int cap, int batch, hipStream_t s) {
     dim3 grid(hgeo.total_kp_cap, batch);
-    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, s, d.geo, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.lvl_kps,
+    hipLaunchKernelGGL(k_describe, grid, dim3(64), 0, s, d.geo, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.lvl_kps,
                        d.lvl_count, kps, desc, counts, cap);
     return hipGetLastError();
 }

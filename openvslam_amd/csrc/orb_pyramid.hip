@@ -3,51 +3,107 @@
 // Integer-only on the device: the float/double part of OpenCV (source coordinate, coefficient rounding) is evaluated
 // once per geometry on the host into ResizeTap tables (orb_api.hip: build_taps) so no device float can change a pixel.
 //
-// HBM-bound streaming kernel: a thread produces 4 horizontally adjacent output pixels and stores one aligned u32;
-// a 64x4 block therefore writes four 256-byte row segments. The two source rows are re-read by ~1.7 output rows
-// (scale 1.2), which the per-CU L1 / XCD L2 absorb; algorithmic traffic per level = src plane + dst plane.
+// HBM-bound streaming kernel. A 256-thread workgroup produces a 128 x 16 output tile: the source rectangle its taps
+// touch (<= 160 x 22 bytes at scale 1.2) is staged in LDS with coalesced, aligned u32 loads -- v1 gathered 16 single bytes
+// per thread straight from global memory and was bound by the texture-addresser rate, not by bandwidth -- then every
+// thread gathers its 4 bytes per pixel from LDS, runs the two fixed-point passes and stores 4 pixels as one aligned u32
+// (two such groups per thread). Algorithmic traffic per level = source plane + destination plane, each touched once
+// (tile halos overlap by one row/column and hit L2).
 #include "ovs_common.h"
 
 namespace ovs {
 
+constexpr int kTileW = 128, kTileH = 16;
+constexpr int kSrcWords = 44;    // 176-byte LDS pitch: source span of 128 output px is <= 128*src/dst + 2 <= 160 at scale >= 1.0x..1.25
+constexpr int kSrcRows = 24;
+
 __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restrict__ src, size_t src_frame_stride, int src_pitch,
-                                                         uint8_t* __restrict__ dst, size_t dst_frame_stride, int dst_pitch,
-                                                         int drows, int dcols, const ResizeTap* __restrict__ xt,
+                                                         int srows, int scols, uint8_t* __restrict__ dst, size_t dst_frame_stride,
+                                                         int dst_pitch, int drows, int dcols, const ResizeTap* __restrict__ xt,
                                                          const ResizeTap* __restrict__ yt) {
-    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (y >= drows || x4 >= dcols) return;
+    __shared__ uint32_t tile[kSrcRows][kSrcWords];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+    const int x1 = min(x0 + kTileW, dcols) - 1, y1 = min(y0 + kTileH, drows) - 1;   // last output pixel of the tile
     const uint8_t* s = src + (size_t)blockIdx.z * src_frame_stride;
     uint8_t* d = dst + (size_t)blockIdx.z * dst_frame_stride;
-    const ResizeTap ty = yt[y];
-    const uint8_t* S0 = s + (size_t)ty.o0 * src_pitch;
-    const uint8_t* S1 = s + (size_t)ty.o1 * src_pitch;
-    const int b0 = ty.a0, b1 = ty.a1;
-    uint32_t out = 0;
+    // source rectangle touched by the tile's taps (tables are monotone)
+    const int sx_lo = xt[x0].o0 & ~3, sx_hi = xt[x1].o1;
+    const int sy_lo = yt[y0].o0, sy_hi = yt[y1].o1;
+    const int nwords = (sx_hi - sx_lo) / 4 + 1, nrows = sy_hi - sy_lo + 1;
+    if (nwords <= kSrcWords && nrows <= kSrcRows) {
+        for (int i = tid; i < nrows * nwords; i += 256) {
+            const int r = i / nwords, w = i - r * nwords;
+            const int gx = sx_lo + 4 * w;
+            uint32_t v = 0;
+            if (gx + 4 <= src_pitch) v = *reinterpret_cast<const uint32_t*>(s + (size_t)(sy_lo + r) * src_pitch + gx);
+            else {   // last partial word of an unpadded row (level 0 with stride == cols): byte-wise, never past the row
+                for (int b = 0; b < 4 && gx + b < src_pitch; ++b) v |= (uint32_t)s[(size_t)(sy_lo + r) * src_pitch + gx + b] << (8 * b);
+            }
+            tile[r][w] = v;
+        }
+        __syncthreads();
+        const uint8_t* tb = reinterpret_cast<const uint8_t*>(&tile[0][0]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int x = x4 + i;
-        if (x < dcols) {
-            const ResizeTap tx = xt[x];
-            const int r0 = S0[tx.o0] * tx.a0 + S0[tx.o1] * tx.a1;
-            const int r1 = S1[tx.o0] * tx.a0 + S1[tx.o1] * tx.a1;
-            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            v = v < 0 ? 0 : (v > 255 ? 255 : v);
-            out |= (uint32_t)v << (8 * i);
+        for (int g = 0; g < 2; ++g) {
+            const int idx = tid + g * 256;              // 512 groups of 4 pixels: 32 groups per row, 16 rows
+            const int y = y0 + (idx >> 5), x4 = x0 + (idx & 31) * 4;
+            if (y >= drows || x4 >= dcols) continue;
+            const ResizeTap ty = yt[y];
+            const uint8_t* S0 = tb + (ty.o0 - sy_lo) * (kSrcWords * 4) - sx_lo;
+            const uint8_t* S1 = tb + (ty.o1 - sy_lo) * (kSrcWords * 4) - sx_lo;
+            const int b0 = ty.a0, b1 = ty.a1;
+            uint32_t out = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int x = x4 + i;
+                if (x < dcols) {
+                    const ResizeTap tx = xt[x];
+                    const int r0 = S0[tx.o0] * tx.a0 + S0[tx.o1] * tx.a1;
+                    const int r1 = S1[tx.o0] * tx.a0 + S1[tx.o1] * tx.a1;
+                    int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                    out |= (uint32_t)v << (8 * i);
+                }
+            }
+            *reinterpret_cast<uint32_t*>(d + (size_t)y * dst_pitch + x4) = out;
+        }
+    } else {
+        // generic fallback (scale factors far from 1.2 whose source rectangle does not fit the LDS tile): gather from global
+#pragma unroll 1
+        for (int g = 0; g < 2; ++g) {
+            const int idx = tid + g * 256;
+            const int y = y0 + (idx >> 5), x4 = x0 + (idx & 31) * 4;
+            if (y >= drows || x4 >= dcols) continue;
+            const ResizeTap ty = yt[y];
+            const uint8_t* S0 = s + (size_t)ty.o0 * src_pitch;
+            const uint8_t* S1 = s + (size_t)ty.o1 * src_pitch;
+            const int b0 = ty.a0, b1 = ty.a1;
+            uint32_t out = 0;
+            for (int i = 0; i < 4; ++i) {
+                const int x = x4 + i;
+                if (x < dcols) {
+                    const ResizeTap tx = xt[x];
+                    const int r0 = S0[tx.o0] * tx.a0 + S0[tx.o1] * tx.a1;
+                    const int r1 = S1[tx.o0] * tx.a0 + S1[tx.o1] * tx.a1;
+                    int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                    out |= (uint32_t)v << (8 * i);
+                }
+            }
+            *reinterpret_cast<uint32_t*>(d + (size_t)y * dst_pitch + x4) = out;
         }
     }
-    *reinterpret_cast<uint32_t*>(d + (size_t)y * dst_pitch + x4) = out;
+    (void)srows;
+    (void)scols;
 }
 
 hipError_t launch_resize(const uint8_t* src, size_t src_frame_stride, int src_pitch, int srows, int scols, uint8_t* dst,
                          size_t dst_frame_stride, int dst_pitch, int drows, int dcols, const ResizeTap* xt, const ResizeTap* yt,
                          int batch, hipStream_t s) {
-    (void)srows;
-    (void)scols;
-    dim3 block(64, 4);
-    dim3 grid((dcols + 255) / 256, (drows + 3) / 4, batch);
-    hipLaunchKernelGGL(k_resize_linear_u8, grid, block, 0, s, src, src_frame_stride, src_pitch, dst, dst_frame_stride, dst_pitch,
-                       drows, dcols, xt, yt);
+    dim3 grid((dcols + kTileW - 1) / kTileW, (drows + kTileH - 1) / kTileH, batch);
+    hipLaunchKernelGGL(k_resize_linear_u8, grid, dim3(256), 0, s, src, src_frame_stride, src_pitch, srows, scols, dst, dst_frame_stride,
+                       dst_pitch, drows, dcols, xt, yt);
     return hipGetLastError();
 }
 

@@ -448,10 +448,13 @@ float ic_angle(const uint8_t* img, size_t stride, int x, int y, const int* u_max
 // ------------------------------------------------------------------------------------------------------------
 // A6  cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) for CV_8U: OpenCV >= 3.4.1 fixed-point path
 //     (ufixedpoint16 8.8 taps that sum to 256; row pass u8*tap -> 8.8, column pass 8.8*tap -> 16.16,
-//     round-half-up to u8). Taps: error-diffused rounding of exp(-x^2/8)/sum * 256 with the centre tap taking
-//     the remainder. OpenCV-version dependent upstream: this definition is the oracle's.
+//     round-half-up to u8). Taps: OpenCV's getGaussianKernelFixedPoint_ED rule -- from the outside in,
+//     v_i = cvRound(256*g_i + err), err carried to the next tap, mirrored, the centre tap takes 256 - 2*sum:
+//     256*g = 17.96, 33.55, 48.82, 55.32 -> 18 (err -.04), 34 (err -.49), 48, centre 56
+//     (tests/test_oracle_kat.py::test_blur_taps_and_rounding re-derives them). OpenCV-version dependent upstream
+//     (3.4.1..3.4.6 round every tap independently): this definition is the oracle's.
 // ------------------------------------------------------------------------------------------------------------
-const int kGauss7[7] = {18, 49, 33, 56, 33, 49, 18};
+const int kGauss7[7] = {18, 34, 48, 56, 48, 34, 18};
 inline int reflect101(int i, int n) {
     if (n == 1) return 0;
     while (i < 0 || i >= n) {

@@ -155,7 +155,17 @@ def test_blur_taps_and_rounding(oracle):
     img = np.zeros((15, 15), np.uint8)
     img[7, 7] = 255
     out = oracle.gaussian_blur(img).astype(int)
-    taps = [18, 49, 33, 56, 33, 49, 18]
+    # OpenCV's error-diffusion rule (getGaussianKernelFixedPoint_ED), re-derived here from the Gaussian itself
+    g = np.exp(-np.arange(-3, 4) ** 2 / (2 * 2.0 ** 2))
+    g /= g.sum()
+    half, err = [], 0.0
+    for i in range(3):
+        adj = g[i] * 256 + err
+        v = int(np.rint(adj))
+        err = adj - v
+        half.append(v)
+    taps = half + [256 - 2 * sum(half)] + half[::-1]
+    assert taps == [18, 34, 48, 56, 48, 34, 18]
     want = np.array([[(255 * taps[i] * taps[j] + 32768) >> 16 for j in range(7)] for i in range(7)])
     assert np.array_equal(out[4:11, 4:11], want)
     # BORDER_REFLECT_101: column -1 mirrors column 1

@@ -1,0 +1,201 @@
+// valu_rate.hip -- issue-rate micro-benchmark for the integer VALU instructions the ORB / Hamming kernels are built from.
+// Prints wave-instructions per cycle per SIMD assuming the clock reported by the device (and the raw Ginstr/s).
+// Build: hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
+
+constexpr int kIters = 2048;
+
+#define BODY8(INS)                                                                     \
+    asm volatile(INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7)               \
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) \
+                 : "v"(b), "v"(c));
+
+#define KERNEL(NAME, INS)                                                              \
+    __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed) {        \
+        uint32_t a[8];                                                                 \
+        for (int i = 0; i < 8; ++i) a[i] = seed * (threadIdx.x + 1) + i;               \
+        uint32_t b = seed ^ 0x00330044u, c = seed + 0x00110022u;                       \
+        for (int it = 0; it < kIters; ++it) { BODY8(INS) BODY8(INS) }                  \
+        uint32_t r = 0;                                                                \
+        for (int i = 0; i < 8; ++i) r ^= a[i];                                         \
+        if (r == 0x12345678u) out[threadIdx.x] = r;                                    \
+    }
+
+#define I_PK_MAX_I16(n) "v_pk_max_i16 %" #n ", %" #n ", %8\n"
+#define I_PK_MIN_U16(n) "v_pk_min_u16 %" #n ", %" #n ", %8\n"
+#define I_PK_MAX_F16(n) "v_pk_max_f16 %" #n ", %" #n ", %8\n"
+#define I_PK_MAX3_F16(n) "v_pk_maximum3_f16 %" #n ", %" #n ", %8, %9\n"
+#define I_PK_ADD_U16(n) "v_pk_add_u16 %" #n ", %" #n ", %8\n"
+#define I_PERM(n) "v_perm_b32 %" #n ", %" #n ", %8, %9\n"
+#define I_MAX_I32(n) "v_max_i32 %" #n ", %" #n ", %8\n"
+#define I_MAX3_I32(n) "v_max3_i32 %" #n ", %" #n ", %8, %9\n"
+#define I_MAX_I16(n) "v_max_i16 %" #n ", %" #n ", %8\n"
+#define I_MAX3_I16(n) "v_max3_i16 %" #n ", %" #n ", %8, %9\n"
+#define I_XOR(n) "v_xor_b32 %" #n ", %" #n ", %8\n"
+#define I_BCNT(n) "v_bcnt_u32_b32 %" #n ", %8, %" #n "\n"
+#define I_ADD_U32(n) "v_add_u32 %" #n ", %" #n ", %8\n"
+#define I_ADD3_U32(n) "v_add3_u32 %" #n ", %" #n ", %8, %9\n"
+#define I_FMA_F32(n) "v_fma_f32 %" #n ", %" #n ", %8, %9\n"
+#define I_PK_FMA_F32(n) "v_fma_f32 %" #n ", %" #n ", %8, %9\n"
+#define I_AND_OR(n) "v_and_or_b32 %" #n ", %" #n ", %8, %9\n"
+#define I_SAD_U8(n) "v_sad_u8 %" #n ", %" #n ", %8, %9\n"
+#define I_MAD_U32_U24(n) "v_mad_u32_u24 %" #n ", %" #n ", %8, %9\n"
+#define I_LSHL_OR(n) "v_lshl_or_b32 %" #n ", %" #n ", 3, %9\n"
+#define I_MOV(n) "v_mov_b32 %" #n ", %8\n"
+#define I_MAX_U16_SDWA(n) "v_max_u16_sdwa %" #n ", %" #n ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2\n"
+
+// rotating sources: every instruction reads three (two) DIFFERENT accumulator registers, as real code does
+#define BODY8R3(OP)                                                                    \
+    asm volatile(OP " %0, %1, %2, %5\n" OP " %1, %2, %3, %6\n" OP " %2, %3, %4, %7\n" OP " %3, %4, %5, %0\n"      \
+                 OP " %4, %5, %6, %1\n" OP " %5, %6, %7, %2\n" OP " %6, %7, %0, %3\n" OP " %7, %0, %1, %4\n"      \
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+#define BODY8R2(OP)                                                                    \
+    asm volatile(OP " %0, %1, %2\n" OP " %1, %2, %3\n" OP " %2, %3, %4\n" OP " %3, %4, %5\n"      \
+                 OP " %4, %5, %6\n" OP " %5, %6, %7\n" OP " %6, %7, %0\n" OP " %7, %0, %1\n"      \
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+#define KERNELR(NAME, BODY, OP)                                                        \
+    __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed) {        \
+        uint32_t a[8];                                                                 \
+        for (int i = 0; i < 8; ++i) a[i] = (seed * (threadIdx.x + 1) + i) & 0x00ff00ffu; \
+        for (int it = 0; it < kIters; ++it) { BODY(OP) BODY(OP) }                      \
+        uint32_t r = 0;                                                                \
+        for (int i = 0; i < 8; ++i) r ^= a[i];                                         \
+        if (r == 0x12345678u) out[threadIdx.x] = r;                                    \
+    }
+KERNELR(r_pk_max3_f16, BODY8R3, "v_pk_maximum3_f16")
+KERNELR(r_pk_max_f16, BODY8R2, "v_pk_max_f16")
+KERNELR(r_pk_max_i16, BODY8R2, "v_pk_max_i16")
+KERNELR(r_perm, BODY8R3, "v_perm_b32")
+KERNELR(r_max3_i32, BODY8R3, "v_max3_i32")
+KERNELR(r_xor, BODY8R2, "v_xor_b32")
+KERNELR(r_add_u32, BODY8R2, "v_add_u32")
+KERNELR(r_max_i16, BODY8R2, "v_max_i16")
+KERNELR(r_min_u16, BODY8R2, "v_min_u16")
+KERNELR(r_and_or, BODY8R3, "v_and_or_b32")
+KERNELR(r_fma_f32, BODY8R3, "v_fma_f32")
+
+KERNEL(k_pk_max_i16, I_PK_MAX_I16)
+KERNEL(k_pk_min_u16, I_PK_MIN_U16)
+KERNEL(k_pk_max_f16, I_PK_MAX_F16)
+KERNEL(k_pk_max3_f16, I_PK_MAX3_F16)
+KERNEL(k_pk_add_u16, I_PK_ADD_U16)
+KERNEL(k_perm, I_PERM)
+KERNEL(k_max_i32, I_MAX_I32)
+KERNEL(k_max3_i32, I_MAX3_I32)
+KERNEL(k_max_i16, I_MAX_I16)
+KERNEL(k_max3_i16, I_MAX3_I16)
+KERNEL(k_xor, I_XOR)
+KERNEL(k_bcnt, I_BCNT)
+KERNEL(k_add_u32, I_ADD_U32)
+KERNEL(k_add3_u32, I_ADD3_U32)
+KERNEL(k_fma_f32, I_FMA_F32)
+KERNEL(k_and_or, I_AND_OR)
+KERNEL(k_sad_u8, I_SAD_U8)
+KERNEL(k_mad_u32_u24, I_MAD_U32_U24)
+KERNEL(k_lshl_or, I_LSHL_OR)
+KERNEL(k_mov, I_MOV)
+KERNEL(k_max_u16_sdwa, I_MAX_U16_SDWA)
+
+// Do the packed f16 min/max instructions order u16 bit patterns 0..255 (f16 denormals) like integers, and return them unflushed?
+__global__ void k_f16_denorm_check(uint32_t* bad) {
+    const uint32_t a = threadIdx.x, b = blockIdx.x;   // 256 x 256
+    uint32_t n = 0;
+    for (uint32_t c = 0; c < 256; c += 5) {
+        const uint32_t pa = a | (b << 16), pb = b | (c << 16), pc = c | (a << 16);
+        uint32_t mx3, mn3, mx2, mn2;
+        asm volatile("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(mx3) : "v"(pa), "v"(pb), "v"(pc));
+        asm volatile("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(mn3) : "v"(pa), "v"(pb), "v"(pc));
+        asm volatile("v_pk_max_f16 %0, %1, %2" : "=v"(mx2) : "v"(pa), "v"(pb));
+        asm volatile("v_pk_min_f16 %0, %1, %2" : "=v"(mn2) : "v"(pa), "v"(pb));
+        auto mx = [](uint32_t x, uint32_t y) { return x > y ? x : y; };
+        auto mn = [](uint32_t x, uint32_t y) { return x < y ? x : y; };
+        const uint32_t e_mx3 = mx(mx(a, b), c) | (mx(mx(b, c), a) << 16), e_mn3 = mn(mn(a, b), c) | (mn(mn(b, c), a) << 16);
+        const uint32_t e_mx2 = mx(a, b) | (mx(b, c) << 16), e_mn2 = mn(a, b) | (mn(b, c) << 16);
+        n += (mx3 != e_mx3) + (mn3 != e_mn3);
+        n += ((mx2 != e_mx2) + (mn2 != e_mn2)) << 16;
+    }
+    if (n) atomicAdd(bad, n);
+}
+
+template <typename K>
+int run(const char* name, K kern, uint32_t* d_out, int cus, double clock_ghz) {
+    const int wg_per_cu = 8;   // 8 x 4 waves = 32 waves / CU = 8 waves / SIMD
+    dim3 grid(cus * wg_per_cu), block(256);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, grid, block, 0, 0, d_out, 12345u);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0, 0));
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, block, 0, 0, d_out, 12345u + i);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double waves = (double)cus * wg_per_cu * 4;
+    const double instr = waves * kIters * 16.0 * reps;
+    const double per_s = instr / (ms * 1e-3);
+    const double per_simd_cycle = per_s / (cus * 4.0) / (clock_ghz * 1e9);
+    printf("%-18s %8.3f ms  %8.2f Gwave-instr/s  %.3f wave-instr/cycle/SIMD (@%.2f GHz) => %.2f cycles/instr\n", name, ms / reps, per_s / 1e9,
+           per_simd_cycle, clock_ghz, 1.0 / per_simd_cycle);
+    return 0;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const double ghz = prop.clockRate / 1e6;
+    printf("device %s, %d CUs, clockRate %.3f GHz\n", prop.gcnArchName, cus, ghz);
+    uint32_t* d_out;
+    CHECK(hipMalloc(&d_out, 4096));
+    {
+        uint32_t* d_bad;
+        CHECK(hipMalloc(&d_bad, 4));
+        CHECK(hipMemset(d_bad, 0, 4));
+        hipLaunchKernelGGL(k_f16_denorm_check, dim3(256), dim3(256), 0, 0, d_bad);
+        uint32_t bad = 0;
+        CHECK(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
+        printf("f16 min/max on u8-in-u16 bit patterns: 3-input mismatches %u, 2-input mismatches %u (0 = usable as integer min/max)\n",
+               bad & 0xFFFFu, bad >> 16);
+    }
+#define RUN(k) if (run(#k, k, d_out, cus, ghz)) return 1;
+    RUN(k_fma_f32)
+    RUN(k_mov)
+    RUN(k_add_u32)
+    RUN(k_add3_u32)
+    RUN(k_xor)
+    RUN(k_bcnt)
+    RUN(k_and_or)
+    RUN(k_lshl_or)
+    RUN(k_perm)
+    RUN(k_max_i32)
+    RUN(k_max3_i32)
+    RUN(k_max_i16)
+    RUN(k_max3_i16)
+    RUN(k_max_u16_sdwa)
+    RUN(k_pk_max_i16)
+    RUN(k_pk_min_u16)
+    RUN(k_pk_add_u16)
+    RUN(k_pk_max_f16)
+    RUN(k_pk_max3_f16)
+    RUN(k_sad_u8)
+    RUN(r_pk_max3_f16)
+    RUN(r_pk_max_f16)
+    RUN(r_pk_max_i16)
+    RUN(r_perm)
+    RUN(r_max3_i32)
+    RUN(r_and_or)
+    RUN(r_xor)
+    RUN(r_add_u32)
+    RUN(r_max_i16)
+    RUN(r_min_u16)
+    RUN(r_fma_f32)
+    RUN(k_mad_u32_u24)
+    return 0;
+}
