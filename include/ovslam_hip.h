@@ -156,6 +156,84 @@ ovs_status ovs_hamming_best2(ovs_matcher* m, const uint8_t* q, int32_t nq, const
                              int32_t* best_idx, uint16_t* best, uint16_t* second);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Grid candidate generator and the windowed matchers built on it.
+ * replaces: data::assign_keypoints_to_grid / get_keypoints_in_cell (src/openvslam/data/common.{h,cc}),
+ *           match::projection::match_frame_and_landmarks (src/openvslam/match/projection.{h,cc}),
+ *           match::area::match_in_consistent_area (src/openvslam/match/area.{h,cc}),
+ *           match::bow_tree::match_frame_and_keyframe (src/openvslam/match/bow_tree.{h,cc}),
+ *           match::angle_checker (src/openvslam/match/angle_checker.h).
+ * Keypoints cross the boundary as ovs_keypoint arrays (= std::vector<cv::KeyPoint>::data(), e.g. frm.undist_keypts_).
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* camera::base::img_bounds_ and num_grid_cols_ / num_grid_rows_ (64 x 48 upstream). */
+typedef struct ovs_grid_params {
+    float min_x, min_y, max_x, max_y;
+    int32_t cols, rows;
+} ovs_grid_params;
+
+typedef struct ovs_wmatcher ovs_wmatcher;
+/* A context for problems of up to max_targets grid-side keypoints, max_queries queries and max_entries candidate pairs
+ * (a call that would produce more returns OVS_ERR_CAPACITY; nothing is truncated silently). */
+ovs_status ovs_wmatcher_create(int32_t max_targets, int32_t max_queries, int32_t max_entries, int32_t device, ovs_wmatcher** out);
+ovs_status ovs_wmatcher_destroy(ovs_wmatcher* w);
+
+/* replaces: data::assign_keypoints_to_grid(camera, undist_keypts, keypt_indices_in_cells).
+ * CSR result: cell id = cx*rows + cy (upstream keypt_indices_in_cells[cx][cy]), cell_start[cols*rows + 1], items = keypoint
+ * indices, ascending inside a cell (upstream's push_back order). items may be NULL. */
+ovs_status ovs_assign_keypoints_to_grid(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_keypoint* kps, int32_t n,
+                                        int32_t* cell_start, int32_t* items, int32_t* n_items);
+/* Device form: builds the context's grid from keypoints resident in HBM (used by the matchers below). */
+ovs_status ovs_grid_assign_dev(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_keypoint* d_kps, int32_t n, void* stream);
+
+/* replaces: unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::vector<data::landmark*>&
+ *                                                              local_landmarks, const float margin) const.
+ * Frame side: kps = frm.undist_keypts_, desc = frm.descriptors_ (n x 32), stereo_x_right = frm.stereo_x_right_ or NULL,
+ * occupied[i] != 0 iff frm.landmarks_[i] && frm.landmarks_[i]->has_observation() (NULL = none).
+ * Landmark side (flattened by the shim, in the order of local_landmarks): lm_xy = reproj_in_tracking_, lm_x_right =
+ * x_right_in_tracking_ (required iff stereo_x_right), lm_level = scale_level_in_tracking_, lm_desc = get_descriptor(),
+ * lm_valid[l] != 0 iff is_observable_in_tracking_ && !will_be_erased() (NULL = all).
+ * scale_factors = frm.scale_factors_. Output: assigned[l] = index of the frame keypoint landmark l is written to
+ * (frm.landmarks_[assigned[l]] = local_landmarks[l]) or -1; *num_matches = the return value. */
+ovs_status ovs_projection_match_frame_and_landmarks(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_keypoint* kps,
+                                                    const uint8_t* desc, const float* stereo_x_right, const uint8_t* occupied, int32_t n,
+                                                    const float* lm_xy, const float* lm_x_right, const int32_t* lm_level,
+                                                    const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m,
+                                                    const float* scale_factors, int32_t num_levels, float margin, float lowe_ratio,
+                                                    int32_t* assigned, int32_t* num_matches);
+/* Device-pointer form (scale_factors stays a host pointer); asynchronous on `stream`. */
+ovs_status ovs_projection_match_frame_and_landmarks_dev(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_keypoint* d_kps,
+                                                        const uint8_t* d_desc, const float* d_stereo_x_right, const uint8_t* d_occupied,
+                                                        int32_t n, const float* d_lm_xy, const float* d_lm_x_right,
+                                                        const int32_t* d_lm_level, const uint8_t* d_lm_desc, const uint8_t* d_lm_valid,
+                                                        int32_t m, const float* scale_factors, int32_t num_levels, float margin,
+                                                        float lowe_ratio, int32_t* d_assigned, int32_t* d_num_matches, void* stream);
+
+/* replaces: unsigned int area::match_in_consistent_area(data::frame& frm_1, data::frame& frm_2,
+ *               std::vector<cv::Point2f>& prev_matched_pts, std::vector<int>& matched_indices_2_in_frm_1, int margin).
+ * kps_i / desc_i = frm_i.undist_keypts_ / descriptors_; gp = frm_2's camera grid. prev_matched_xy (n1 x 2) is updated in
+ * place for the final matches; matched_2_in_1[n1]; lowe_ratio / check_orientation = the matcher's ctor arguments. */
+ovs_status ovs_area_match_in_consistent_area(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_keypoint* kps_1, const uint8_t* desc_1,
+                                             int32_t n1, const ovs_keypoint* kps_2, const uint8_t* desc_2, int32_t n2,
+                                             float* prev_matched_xy, int32_t* matched_2_in_1, int32_t margin, float lowe_ratio,
+                                             int32_t check_orientation, int32_t* num_matches);
+ovs_status ovs_area_match_in_consistent_area_dev(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_keypoint* d_kps_1,
+                                                 const uint8_t* d_desc_1, int32_t n1, const ovs_keypoint* d_kps_2,
+                                                 const uint8_t* d_desc_2, int32_t n2, float* d_prev_matched_xy,
+                                                 int32_t* d_matched_2_in_1, int32_t margin, float lowe_ratio, int32_t check_orientation,
+                                                 int32_t* d_num_matches, void* stream);
+
+/* replaces: unsigned int bow_tree::match_frame_and_keyframe(data::keyframe* keyfrm, data::frame& frm,
+ *                                                           std::vector<data::landmark*>& matched_lms_in_frm) const.
+ * The two BoW feature vectors (std::map<node id, std::vector<unsigned>>) are flattened to CSR over ascending node ids.
+ * kf_valid[i] != 0 iff the keyframe keypoint holds a landmark that !will_be_erased() (NULL = all).
+ * matched_kf_in_frm[j] = keyframe keypoint index whose landmark frame keypoint j receives, or -1. */
+ovs_status ovs_bow_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_valid,
+                                            int32_t n_kf, const int32_t* kf_node_ids, const int32_t* kf_node_start,
+                                            const int32_t* kf_items, int32_t kf_nodes, const ovs_keypoint* frm_kps,
+                                            const uint8_t* frm_desc, int32_t n_frm, const int32_t* frm_node_ids,
+                                            const int32_t* frm_node_start, const int32_t* frm_items, int32_t frm_nodes, float lowe_ratio,
+                                            int32_t check_orientation, int32_t* matched_kf_in_frm, int32_t* num_matches);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Local bundle adjustment: residual + Jacobian + normal-equation blocks (one Levenberg-Marquardt linearisation).
  * replaces: the computeError / linearizeOplus / constructQuadraticForm loop g2o runs inside
  * optimize::local_bundle_adjuster::optimize (src/openvslam/optimize/local_bundle_adjuster.cc; edge math in

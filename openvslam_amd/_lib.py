@@ -54,7 +54,25 @@ SYMBOLS = {
     "ovs_ba_linearize": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_hamming_best2": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "ovs_wmatcher_create": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "ovs_wmatcher_destroy": (_i32, [_vp]),
+    "ovs_assign_keypoints_to_grid": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, C.POINTER(_i32)]),
+    "ovs_grid_assign_dev": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "ovs_projection_match_frame_and_landmarks": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _f, _f,
+                                                        _vp, C.POINTER(_i32)]),
+    "ovs_projection_match_frame_and_landmarks_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _f,
+                                                            _f, _vp, _vp, _vp]),
+    "ovs_area_match_in_consistent_area": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _f, _i32, C.POINTER(_i32)]),
+    "ovs_area_match_in_consistent_area_dev": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _f, _i32, _vp, _vp]),
+    "ovs_bow_match_frame_and_keyframe": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _f, _i32,
+                                                _vp, C.POINTER(_i32)]),
 }
+
+
+class GridParams(C.Structure):
+    """camera::base::img_bounds_ + num_grid_cols_/num_grid_rows_ (ovs_grid_params)."""
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float), ("cols", C.c_int32),
+                ("rows", C.c_int32)]
 
 
 def lib():

@@ -1,0 +1,919 @@
+// match_window.hip -- D1 + M3 + M5 + M7: the grid candidate generator and the windowed matchers built on it
+// (expected: src/openvslam/data/common.{h,cc}; src/openvslam/match/{projection,area,bow_tree}.{h,cc}, angle_checker.h).
+//
+// These are small, latency-bound problems (a 3840x1920 frame with 4000 keypoints and 10 000 landmarks is ~3 Hamming distances
+// per landmark); what the device buys is that extract -> grid -> match never leaves HBM. Three stages, all exact:
+//   1. k_grid_assign   assign_keypoints_to_grid as a CSR (cell id = cx*rows + cy, members ascending = upstream's push_back order):
+//                      one workgroup, LDS histogram + scan + fill + per-cell sort.
+//   2. k_window_*/k_bow_*  get_keypoints_in_cell + compute_descriptor_distance_32 for every query (one lane per query, count pass,
+//                      scan, fill pass): a CSR of keys  d << 20 | octave << 16 | target  in UPSTREAM'S ENUMERATION ORDER
+//                      (cells x-major, then y, then members), because strict `<` keeps the first minimum.
+//   3. k_list_resolve  upstream's loops are sequential -- a query sees the targets earlier queries claimed (M3, M7) or the
+//                      distance they were matched at (M5). One wave replays them 64 queries per round, exactly as
+//                      match_hamming.hip's resolver does: every pending lane evaluates against the current state, accepting
+//                      lanes stamp their target, the first lane whose best / second candidate a LOWER lane stamped cuts the
+//                      round, everything below it commits. State per target is ONE number, thr[t]: a candidate at distance d is
+//                      alive iff d < thr[t] (256 = free, 0 = claimed, M5: the distance it is currently matched at), and thr only
+//                      ever decreases, so a decision that rests on (best, second) can only be changed by a lower lane taking
+//                      one of those two -- the argument of match_hamming.hip carries over unchanged.
+//      The rotation-histogram check (match::angle_checker, 30 bins, keep the 3 fullest) runs in the same kernel.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ovs_common.h"
+
+namespace ovs {
+
+struct GridP {
+    float min_x, min_y;
+    float inv_w, inv_h;
+    int32_t cols, rows;
+};
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr int kMarkSize = 4096;   // hashed stamp table of the resolver (collisions only cost an extra round)
+
+__device__ __forceinline__ uint32_t hamming256_g(const uint32_t (&a)[8], const uint32_t* __restrict__ b) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d = __builtin_popcount(a[i] ^ b[i]) + d;
+    return d;
+}
+
+// ---- 1. D1 assign_keypoints_to_grid ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_grid_assign(const ovs_keypoint* __restrict__ kps, int n, GridP gp, int32_t* __restrict__ cell_of,
+                                                     int32_t* __restrict__ cell_start, int32_t* __restrict__ items) {
+    extern __shared__ int32_t s_grid[];
+    const int nc = gp.cols * gp.rows;
+    int32_t* cnt = s_grid;            // [nc] histogram, then fill cursor
+    int32_t* start = s_grid + nc;     // [nc + 1]
+    __shared__ int32_t s_part[1024];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < nc; c += 1024) cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        // get_cell_indices: cvRound((pt - min) * inv_cell)
+        const int cx = __float2int_rn(__fmul_rn(__fsub_rn(kps[i].x, gp.min_x), gp.inv_w));
+        const int cy = __float2int_rn(__fmul_rn(__fsub_rn(kps[i].y, gp.min_y), gp.inv_h));
+        int c = -1;
+        if (0 <= cx && cx < gp.cols && 0 <= cy && cy < gp.rows) {
+            c = cx * gp.rows + cy;
+            atomicAdd(&cnt[c], 1);
+        }
+        cell_of[i] = c;
+    }
+    __syncthreads();
+    // exclusive scan: thread t owns cells [t*per, t*per + per)
+    const int per = (nc + 1023) / 1024;
+    int local = 0;
+    for (int k = 0; k < per; ++k) {
+        const int c = tid * per + k;
+        if (c < nc) local += cnt[c];
+    }
+    s_part[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - local;
+    for (int k = 0; k < per; ++k) {
+        const int c = tid * per + k;
+        if (c < nc) {
+            start[c] = run;
+            run += cnt[c];
+        }
+    }
+    if (tid == 1023) start[nc] = s_part[1023];
+    __syncthreads();
+    for (int c = tid; c <= nc; c += 1024) {
+        cell_start[c] = start[c];
+        if (c < nc) cnt[c] = start[c];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int c = cell_of[i];
+        if (c >= 0) items[atomicAdd(&cnt[c], 1)] = i;
+    }
+    __syncthreads();   // also makes this workgroup's global writes visible to itself
+    // members in ascending keypoint index (upstream pushes them in keypoint order)
+    for (int c = tid; c < nc; c += 1024) {
+        const int b = start[c], e = start[c + 1];
+        for (int i = b + 1; i < e; ++i) {
+            const int v = items[i];
+            int j = i - 1;
+            while (j >= b && items[j] > v) {
+                items[j + 1] = items[j];
+                --j;
+            }
+            items[j + 1] = v;
+        }
+    }
+}
+
+// ---- 2. candidate lists ---------------------------------------------------------------------------------------------------
+enum { kModeProjection = 0, kModeArea = 1 };
+
+struct WinArgs {
+    // targets: the frame whose grid is searched
+    const ovs_keypoint* t_kps;
+    const uint8_t* t_desc;
+    const uint8_t* t_occupied;   // projection: keypoint already holds a landmark with observations (NULL = none)
+    const float* t_x_right;      // projection: frm.stereo_x_right_ (NULL = monocular)
+    const int32_t* cell_start;
+    const int32_t* items;
+    GridP gp;
+    // queries
+    int n_q;
+    const float* q_xy;           // projection: reproj_in_tracking_; area: prev_matched_pts
+    const float* q_x_right;      // projection: x_right_in_tracking_
+    const int32_t* q_level;      // projection: scale_level_in_tracking_
+    const uint8_t* q_valid;      // projection: is_observable_in_tracking_ && !will_be_erased()
+    const ovs_keypoint* q_kps;   // area: frame-1 undistorted keypoints
+    const uint8_t* q_desc;
+    float margin;
+    float sf[OVS_MAX_LEVELS];
+    int mode;
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_window_lists(WinArgs a, uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                                                     uint32_t* __restrict__ keys, uint32_t key_cap, uint32_t* __restrict__ overflow) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.n_q) return;
+    bool valid = !a.q_valid || a.q_valid[q];
+    float r;
+    int minl, maxl;
+    if (a.mode == kModeProjection) {
+        const int lvl = valid ? a.q_level[q] : 0;
+        r = __fmul_rn(a.margin, a.sf[lvl]);
+        minl = lvl - 1;
+        maxl = lvl;
+    } else {
+        const int lvl = a.q_kps[q].octave;
+        if (0 < lvl) valid = false;   // "only level-0 keypoints"
+        r = a.margin;
+        minl = maxl = lvl;
+    }
+    uint32_t n = 0;
+    uint32_t pos = FILL ? offsets[q] : 0u;
+    if (valid) {
+        const float ref_x = a.q_xy[2 * q], ref_y = a.q_xy[2 * q + 1];
+        uint32_t qd[8];
+        if (FILL) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(a.q_desc + (size_t)q * 32);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qd[i] = src[i];
+        }
+        const GridP& g = a.gp;
+        // get_keypoints_in_cell
+        const int min_cx = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(ref_x, g.min_x), r), g.inv_w)));
+        const int max_cx = min(g.cols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(ref_x, g.min_x), r), g.inv_w)));
+        const int min_cy = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(ref_y, g.min_y), r), g.inv_h)));
+        const int max_cy = min(g.rows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(ref_y, g.min_y), r), g.inv_h)));
+        if (min_cx < g.cols && max_cx >= 0 && min_cy < g.rows && max_cy >= 0) {
+            const bool check_level = (0 < minl) || (0 <= maxl);
+            for (int cx = min_cx; cx <= max_cx; ++cx) {
+                for (int cy = min_cy; cy <= max_cy; ++cy) {
+                    const int c = cx * g.rows + cy;
+                    const int e = a.cell_start[c + 1];
+                    for (int k = a.cell_start[c]; k < e; ++k) {
+                        const int idx = a.items[k];
+                        const ovs_keypoint kp = a.t_kps[idx];
+                        if (check_level && (kp.octave < minl || (0 <= maxl && maxl < kp.octave))) continue;
+                        if (!(fabsf(__fsub_rn(kp.x, ref_x)) < r && fabsf(__fsub_rn(kp.y, ref_y)) < r)) continue;
+                        if (a.mode == kModeProjection) {
+                            if (a.t_occupied && a.t_occupied[idx]) continue;
+                            if (a.t_x_right) {
+                                const float xr = a.t_x_right[idx];
+                                if (0 < xr && r < fabsf(__fsub_rn(a.q_x_right[q], xr))) continue;
+                            }
+                        }
+                        if (FILL) {
+                            const uint32_t d = hamming256_g(qd, reinterpret_cast<const uint32_t*>(a.t_desc + (size_t)idx * 32));
+                            if (pos < key_cap) keys[pos] = (d << 20) | ((uint32_t)(kp.octave & 15) << 16) | (uint32_t)idx;
+                            else *overflow = 1u;
+                            ++pos;
+                        }
+                        ++n;
+                    }
+                }
+            }
+        }
+    }
+    if (!FILL) counts[q] = n;
+}
+
+// bow_tree: queries = the keyframe's feature-vector entries in walk order; the list of a query is its node's frame bucket
+struct BowArgs {
+    const uint8_t* kf_desc;
+    const uint8_t* kf_valid;
+    const int32_t* kf_node_ids;
+    const int32_t* kf_node_start;
+    const int32_t* kf_items;
+    int kf_nodes, n_q;           // n_q = kf_node_start[kf_nodes]
+    const uint8_t* frm_desc;
+    const int32_t* frm_node_ids;
+    const int32_t* frm_node_start;
+    const int32_t* frm_items;
+    int frm_nodes;
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bow_lists(BowArgs a, uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                                                  uint32_t* __restrict__ keys, uint32_t key_cap, uint32_t* __restrict__ overflow) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.n_q) return;
+    const int kf_idx = a.kf_items[q];
+    uint32_t n = 0;
+    if (!a.kf_valid || a.kf_valid[kf_idx]) {
+        // node of this entry: last node whose start <= q
+        int lo = 0, hi = a.kf_nodes - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.kf_node_start[mid] <= q) lo = mid;
+            else hi = mid - 1;
+        }
+        const int node = a.kf_node_ids[lo];
+        int l2 = 0, h2 = a.frm_nodes;   // lower_bound
+        while (l2 < h2) {
+            const int mid = (l2 + h2) >> 1;
+            if (a.frm_node_ids[mid] < node) l2 = mid + 1;
+            else h2 = mid;
+        }
+        if (l2 < a.frm_nodes && a.frm_node_ids[l2] == node) {
+            const int b = a.frm_node_start[l2], e = a.frm_node_start[l2 + 1];
+            n = (uint32_t)(e - b);
+            if (FILL) {
+                uint32_t qd[8];
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(a.kf_desc + (size_t)kf_idx * 32);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qd[i] = src[i];
+                uint32_t pos = offsets[q];
+                for (int k = b; k < e; ++k) {
+                    const int idx = a.frm_items[k];
+                    const uint32_t d = hamming256_g(qd, reinterpret_cast<const uint32_t*>(a.frm_desc + (size_t)idx * 32));
+                    if (pos < key_cap) keys[pos] = (d << 20) | (uint32_t)idx;
+                    else *overflow = 1u;
+                    ++pos;
+                }
+            }
+        }
+    }
+    if (!FILL) counts[q] = n;
+}
+
+// exclusive scan of counts[n] into offsets[n + 1] (one workgroup; n <= 65535)
+__global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* __restrict__ counts, int n, uint32_t* __restrict__ offsets) {
+    __shared__ uint32_t s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    uint32_t local = 0;
+    for (int k = 0; k < per; ++k) {
+        const int i = tid * per + k;
+        if (i < n) local += counts[i];
+    }
+    s_part[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - local;
+    for (int k = 0; k < per; ++k) {
+        const int i = tid * per + k;
+        if (i < n) {
+            offsets[i] = run;
+            run += counts[i];
+        }
+    }
+    if (tid == 1023) offsets[n] = s_part[1023];
+}
+
+// ---- 3. sequential-claim resolver ---------------------------------------------------------------------------------------
+enum { kRuleProjection = 0, kRuleArea = 1, kRuleBow = 2 };
+
+struct ResolveArgs {
+    const uint32_t* offsets;   // n_q + 1
+    const uint32_t* keys;
+    int n_q, n_t;
+    float lowe_ratio;
+    int check_orientation;
+    const ovs_keypoint* q_kps;    // area: frame-1 keypoints (angle); bow: keyframe keypoints (angle), indexed through q_items
+    const int32_t* q_items;       // bow: query -> keyframe keypoint index (NULL: identity)
+    const ovs_keypoint* t_kps;    // area / bow: target keypoints (angle, pt)
+    float* prev_matched_xy;       // area: updated for the final matches
+    int32_t* assigned;            // projection / area: [n_q] target or -1; bow: [n_t] keyframe keypoint index or -1
+    int32_t* num_matches;
+};
+
+template <int RULE>
+__device__ __forceinline__ bool rule_accepts(uint32_t best, uint32_t second, float ratio) {
+    if (best == kNone) return false;
+    const uint32_t bd = best >> 20;
+    const uint32_t sd = second == kNone ? (uint32_t)OVS_MAX_HAMMING_DIST : (second >> 20);
+    if (RULE == kRuleProjection) {
+        if (bd > (uint32_t)OVS_HAMMING_DIST_THR_HIGH) return false;
+        const int bl = (int)((best >> 16) & 15u), sl = second == kNone ? -1 : (int)((second >> 16) & 15u);
+        return !(bl == sl && (float)bd > __fmul_rn(ratio, (float)sd));
+    }
+    if (bd > (uint32_t)OVS_HAMMING_DIST_THR_LOW) return false;
+    return !(__fmul_rn((float)sd, ratio) < (float)bd);   // area: second * ratio < best; bow: ratio * second < best (same product)
+}
+
+template <int RULE>
+__global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_res[];
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
+    typedef __attribute__((address_space(3))) volatile uint16_t lds_u16;
+    lds_u32* mark = (lds_u32*)s_res;                                        // [kMarkSize]
+    lds_u32* hist = mark + kMarkSize;                                       // [32]
+    lds_u16* thr = (lds_u16*)(hist + 32);                                   // [n_t]  alive(d, t) <=> d < thr[t]
+    lds_u16* owner = thr + ((a.n_t + 1) & ~1);                              // [n_t]  area: query currently matched to t
+    lds_u16* match = owner + ((a.n_t + 1) & ~1);                            // [n_q]  target of query (0xFFFF none)
+    lds_u16* accepted = match + ((a.n_q + 1) & ~1);                         // [n_q]  target at acceptance time (orientation entries)
+    const int lane = threadIdx.x;
+    const uint32_t max_d = RULE == kRuleProjection ? OVS_HAMMING_DIST_THR_HIGH : OVS_HAMMING_DIST_THR_LOW;
+    for (int i = lane; i < a.n_t; i += 64) {
+        thr[i] = (uint16_t)OVS_MAX_HAMMING_DIST;
+        owner[i] = 0xFFFFu;
+    }
+    for (int i = lane; i < a.n_q; i += 64) {
+        match[i] = 0xFFFFu;
+        accepted[i] = 0xFFFFu;
+    }
+    for (int i = lane; i < kMarkSize; i += 64) mark[i] = ~0u;
+    if (lane < 32) hist[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t epoch = 0;
+
+    for (int q0 = 0; q0 < a.n_q; q0 += 64) {
+        const int q = q0 + lane;
+        uint32_t lb = 0, le = 0;
+        if (q < a.n_q) {
+            lb = a.offsets[q];
+            le = a.offsets[q + 1];
+        }
+        unsigned long long unresolved = __ballot(le > lb);
+        while (unresolved) {
+            const bool mine = (unresolved >> lane) & 1ull;
+            uint32_t best = kNone, second = kNone;
+            bool acc = false;
+            ++epoch;
+            const uint32_t tag = (0xFFFFFFu - epoch) << 8;   // newer rounds carry smaller tags: atomicMin overrides stale stamps
+            if (mine) {
+                uint32_t bd = OVS_MAX_HAMMING_DIST, sd = OVS_MAX_HAMMING_DIST;
+                for (uint32_t k = lb; k < le; ++k) {
+                    const uint32_t e = a.keys[k];
+                    const uint32_t d = e >> 20;
+                    if (!(d < (uint32_t)thr[e & 0xFFFFu])) continue;   // claimed / matched at a distance <= ours
+                    if (d < bd) {
+                        second = best;
+                        sd = bd;
+                        best = e;
+                        bd = d;
+                    } else if (d < sd) {
+                        second = e;
+                        sd = d;
+                    }
+                }
+                acc = rule_accepts<RULE>(best, second, a.lowe_ratio);
+                if (acc)
+                    __hip_atomic_fetch_min((__attribute__((address_space(3))) uint32_t*)&mark[(best & 0xFFFFu) & (kMarkSize - 1)],
+                                           tag | (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __builtin_amdgcn_wave_barrier();
+            bool affected = false;
+            if (mine && best != kNone && (best >> 20) <= max_d) {   // a best beyond the threshold is a final reject (it can only grow)
+                const uint32_t m1 = mark[(best & 0xFFFFu) & (kMarkSize - 1)];
+                affected = (m1 & ~0xFFu) == tag && (m1 & 0xFFu) < (uint32_t)lane;
+                if (second != kNone) {
+                    const uint32_t m2 = mark[(second & 0xFFFFu) & (kMarkSize - 1)];
+                    affected |= (m2 & ~0xFFu) == tag && (m2 & 0xFFu) < (uint32_t)lane;
+                }
+            }
+            const unsigned long long aff = __ballot(affected) & unresolved;
+            const int f = aff ? (__ffsll((long long)aff) - 1) : 64;
+            if (mine && lane < f && acc) {
+                const uint32_t t = best & 0xFFFFu;
+                if (RULE == kRuleArea) {
+                    const uint32_t prev = owner[t];
+                    if (prev != 0xFFFFu) match[prev] = 0xFFFFu;   // the earlier owner loses the target
+                    owner[t] = (uint16_t)q;
+                    thr[t] = (uint16_t)(best >> 20);
+                } else {
+                    thr[t] = 0;
+                }
+                match[q] = (uint16_t)t;
+                accepted[q] = (uint16_t)t;
+            }
+            unresolved = f >= 64 ? 0ull : (unresolved & ~((1ull << f) - 1ull));
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // ---- match::angle_checker: bin = cvRound(delta / 30) over every ACCEPTED query (a later-stolen match keeps its entry)
+    if (RULE != kRuleProjection && a.check_orientation) {
+        for (int q = lane; q < a.n_q; q += 64) {
+            const uint32_t t = accepted[q];
+            if (t == 0xFFFFu) continue;
+            const int qi = a.q_items ? a.q_items[q] : q;
+            float delta = __fsub_rn(a.q_kps[qi].angle, a.t_kps[t].angle);
+            if (delta < 0.0f) delta = __fadd_rn(delta, 360.0f);
+            if (360.0f <= delta) delta = __fsub_rn(delta, 360.0f);
+            int bin = __float2int_rn(__fmul_rn(delta, 1.0f / 30));
+            if (bin == 30) bin = 0;
+            __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t*)&hist[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            accepted[q] = (uint16_t)(0x8000u | (uint32_t)bin);   // reuse the slot: bin of this entry
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the three fullest bins, equal sizes -> lower bin first (ORACLE_SPEC rule 17)
+        int keep0 = -1, keep1 = -1, keep2 = -1;
+        {
+            const uint32_t h = lane < 30 ? (uint32_t)hist[lane] : 0u;
+            uint32_t key = lane < 30 ? ((h << 8) | (uint32_t)(31 - lane)) : 0u;   // larger count first, then lower bin
+            for (int k = 0; k < 3; ++k) {
+                uint32_t m = key;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const uint32_t o = __shfl_xor(m, off);
+                    m = o > m ? o : m;
+                }
+                const int b = 31 - (int)(m & 0xFFu);
+                if (k == 0) keep0 = b;
+                else if (k == 1) keep1 = b;
+                else keep2 = b;
+                if (key == m) key = 0u;
+            }
+        }
+        for (int q = lane; q < a.n_q; q += 64) {
+            const uint32_t v = accepted[q];
+            if (!(v & 0x8000u) || v == 0xFFFFu) continue;
+            const int bin = (int)(v & 0xFFu);
+            if (bin != keep0 && bin != keep1 && bin != keep2) match[q] = 0xFFFFu;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- outputs
+    uint32_t total = 0;
+    if (RULE == kRuleBow) {
+        for (int t = lane; t < a.n_t; t += 64) a.assigned[t] = -1;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
+    for (int q0 = 0; q0 < a.n_q; q0 += 64) {
+        const int q = q0 + lane;
+        uint32_t t = 0xFFFFu;
+        if (q < a.n_q) t = match[q];
+        if (q < a.n_q) {
+            if (RULE == kRuleBow) {
+                if (t != 0xFFFFu) a.assigned[t] = a.q_items ? a.q_items[q] : q;
+            } else {
+                a.assigned[q] = t == 0xFFFFu ? -1 : (int32_t)t;
+                if (RULE == kRuleArea && t != 0xFFFFu) {
+                    a.prev_matched_xy[2 * q] = a.t_kps[t].x;
+                    a.prev_matched_xy[2 * q + 1] = a.t_kps[t].y;
+                }
+            }
+        }
+        total += (uint32_t)__popcll(__ballot(t != 0xFFFFu));
+    }
+    if (lane == 0) *a.num_matches = (int32_t)total;
+}
+
+}   // namespace ovs
+
+using namespace ovs;
+
+struct ovs_wmatcher {
+    int device = 0;
+    int max_t = 0, max_q = 0;
+    uint32_t max_entries = 0;
+    hipStream_t stream = nullptr;
+    // grid of the target frame
+    int32_t* d_cell_of = nullptr;
+    int32_t* d_cell_start = nullptr;
+    int32_t* d_items = nullptr;
+    int grid_cells_cap = 0;
+    GridP gp{};
+    int grid_n = -1;
+    // candidate lists
+    uint32_t* d_counts = nullptr;
+    uint32_t* d_offsets = nullptr;
+    uint32_t* d_keys = nullptr;
+    uint32_t* d_overflow = nullptr;
+    int32_t* d_assigned = nullptr;      // max(max_q, max_t)
+    int32_t* d_num = nullptr;
+    // host-API staging
+    ovs_keypoint* d_t_kps = nullptr;
+    uint8_t* d_t_desc = nullptr;
+    uint8_t* d_t_flag = nullptr;
+    float* d_t_f = nullptr;
+    ovs_keypoint* d_q_kps = nullptr;
+    uint8_t* d_q_desc = nullptr;
+    uint8_t* d_q_flag = nullptr;
+    float* d_q_xy = nullptr;
+    float* d_q_f = nullptr;
+    int32_t* d_q_i = nullptr;
+    int32_t* d_csr = nullptr;           // bow feature vectors: 2 x (ids | start | items)
+    size_t csr_cap = 0;
+};
+
+namespace {
+
+constexpr int kMaxGridCells = 16384;
+
+GridP make_gridp(const ovs_grid_params& p) {
+    GridP g;
+    g.min_x = p.min_x;
+    g.min_y = p.min_y;
+    g.inv_w = (float)((double)p.cols / (double)(p.max_x - p.min_x));   // camera::base: double division, float member
+    g.inv_h = (float)((double)p.rows / (double)(p.max_y - p.min_y));
+    g.cols = p.cols;
+    g.rows = p.rows;
+    return g;
+}
+
+size_t resolve_lds_bytes(int n_q, int n_t) {
+    return (size_t)kMarkSize * 4 + 32 * 4 + (size_t)2 * 2 * ((n_t + 1) & ~1) + (size_t)2 * 2 * ((n_q + 1) & ~1);
+}
+
+template <int RULE>
+ovs_status launch_resolve(const ResolveArgs& ra, hipStream_t s) {
+    const size_t lds = resolve_lds_bytes(ra.n_q, ra.n_t);
+    if (lds > 150 * 1024) return OVS_ERR_CAPACITY;
+    if (lds > 64 * 1024)
+        OVS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_list_resolve<RULE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+    hipLaunchKernelGGL(k_list_resolve<RULE>, dim3(1), dim3(64), lds, s, ra);
+    OVS_HIP_TRY(hipGetLastError());
+    return OVS_OK;
+}
+
+ovs_status grid_assign(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_keypoint* d_kps, int n, hipStream_t s) {
+    if (!gp || gp->cols < 1 || gp->rows < 1 || gp->cols * gp->rows > kMaxGridCells || !(gp->max_x > gp->min_x) || !(gp->max_y > gp->min_y))
+        return OVS_ERR_INVALID;
+    if (n > w->max_t) return OVS_ERR_CAPACITY;
+    w->gp = make_gridp(*gp);
+    w->grid_n = n;
+    const int nc = gp->cols * gp->rows;
+    const size_t lds = (size_t)(2 * nc + 1) * sizeof(int32_t);
+    if (lds > 64 * 1024)
+        OVS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_assign), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_grid_assign, dim3(1), dim3(1024), lds, s, d_kps, n, w->gp, w->d_cell_of, w->d_cell_start, w->d_items);
+    OVS_HIP_TRY(hipGetLastError());
+    return OVS_OK;
+}
+
+template <typename ARGS, typename KCOUNT, typename KFILL>
+ovs_status build_lists(ovs_wmatcher* w, const ARGS& args, int n_q, KCOUNT kcount, KFILL kfill, hipStream_t s) {
+    if (n_q > w->max_q) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(hipMemsetAsync(w->d_overflow, 0, sizeof(uint32_t), s));
+    const dim3 grid((n_q + 255) / 256);
+    hipLaunchKernelGGL(kcount, grid, dim3(256), 0, s, args, w->d_counts, (const uint32_t*)w->d_offsets, w->d_keys, w->max_entries, w->d_overflow);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, (const uint32_t*)w->d_counts, n_q, w->d_offsets);
+    hipLaunchKernelGGL(kfill, grid, dim3(256), 0, s, args, w->d_counts, (const uint32_t*)w->d_offsets, w->d_keys, w->max_entries, w->d_overflow);
+    OVS_HIP_TRY(hipGetLastError());
+    return OVS_OK;
+}
+
+}   // namespace
+
+extern "C" {
+
+ovs_status ovs_wmatcher_create(int32_t max_targets, int32_t max_queries, int32_t max_entries, int32_t device, ovs_wmatcher** out) {
+    if (!out || max_targets < 1 || max_queries < 1 || max_entries < 1 || max_targets > 65534 || max_queries > 65534) return OVS_ERR_INVALID;
+    *out = nullptr;
+    if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
+    if (resolve_lds_bytes(max_queries, max_targets) > 150 * 1024) return OVS_ERR_CAPACITY;
+    ovs_wmatcher* w = new (std::nothrow) ovs_wmatcher();
+    if (!w) return OVS_ERR_INVALID;
+    w->device = device;
+    w->max_t = max_targets;
+    w->max_q = max_queries;
+    w->max_entries = (uint32_t)max_entries;
+#define CREATE_TRY(expr)                       \
+    do {                                       \
+        hipError_t _e = (expr);                \
+        if (_e != hipSuccess) {                \
+            ovs::set_last_error(#expr, _e);    \
+            ovs_wmatcher_destroy(w);           \
+            return OVS_ERR_HIP;                \
+        }                                      \
+    } while (0)
+    CREATE_TRY(hipSetDevice(device));
+    CREATE_TRY(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
+    const size_t T = (size_t)max_targets, Q = (size_t)max_queries, M = std::max(T, Q);
+    CREATE_TRY(hipMalloc(&w->d_cell_of, sizeof(int32_t) * T));
+    CREATE_TRY(hipMalloc(&w->d_cell_start, sizeof(int32_t) * (kMaxGridCells + 1)));
+    CREATE_TRY(hipMalloc(&w->d_items, sizeof(int32_t) * T));
+    CREATE_TRY(hipMalloc(&w->d_counts, sizeof(uint32_t) * (Q + 1)));
+    CREATE_TRY(hipMalloc(&w->d_offsets, sizeof(uint32_t) * (Q + 1)));
+    CREATE_TRY(hipMalloc(&w->d_keys, sizeof(uint32_t) * (size_t)max_entries));
+    CREATE_TRY(hipMalloc(&w->d_overflow, sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&w->d_assigned, sizeof(int32_t) * M));
+    CREATE_TRY(hipMalloc(&w->d_num, sizeof(int32_t)));
+    CREATE_TRY(hipMalloc(&w->d_t_kps, sizeof(ovs_keypoint) * T));
+    CREATE_TRY(hipMalloc(&w->d_t_desc, 32 * T));
+    CREATE_TRY(hipMalloc(&w->d_t_flag, T));
+    CREATE_TRY(hipMalloc(&w->d_t_f, sizeof(float) * T));
+    CREATE_TRY(hipMalloc(&w->d_q_kps, sizeof(ovs_keypoint) * Q));
+    CREATE_TRY(hipMalloc(&w->d_q_desc, 32 * Q));
+    CREATE_TRY(hipMalloc(&w->d_q_flag, Q));
+    CREATE_TRY(hipMalloc(&w->d_q_xy, sizeof(float) * 2 * Q));
+    CREATE_TRY(hipMalloc(&w->d_q_f, sizeof(float) * Q));
+    CREATE_TRY(hipMalloc(&w->d_q_i, sizeof(int32_t) * Q));
+    w->csr_cap = 4 * (T + Q) + 16;
+    CREATE_TRY(hipMalloc(&w->d_csr, sizeof(int32_t) * w->csr_cap));
+#undef CREATE_TRY
+    *out = w;
+    return OVS_OK;
+}
+
+ovs_status ovs_wmatcher_destroy(ovs_wmatcher* w) {
+    if (!w) return OVS_OK;
+    if (w->stream) hipStreamSynchronize(w->stream);
+    void* ptrs[] = {w->d_cell_of, w->d_cell_start, w->d_items, w->d_counts, w->d_offsets, w->d_keys, w->d_overflow, w->d_assigned, w->d_num,
+                    w->d_t_kps,   w->d_t_desc,     w->d_t_flag, w->d_t_f,    w->d_q_kps,   w->d_q_desc, w->d_q_flag,  w->d_q_xy,    w->d_q_f,
+                    w->d_q_i,     w->d_csr};
+    for (void* p : ptrs) hipFree(p);
+    if (w->stream) hipStreamDestroy(w->stream);
+    delete w;
+    return OVS_OK;
+}
+
+ovs_status ovs_grid_assign_dev(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_keypoint* d_kps, int32_t n, void* stream) {
+    if (!w || !d_kps || n < 0) return OVS_ERR_INVALID;
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    return grid_assign(w, gp, d_kps, n, (hipStream_t)stream);
+}
+
+ovs_status ovs_assign_keypoints_to_grid(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_keypoint* kps, int32_t n,
+                                        int32_t* cell_start, int32_t* items, int32_t* n_items) {
+    if (!w || !gp || (n > 0 && !kps) || n < 0 || !cell_start || !n_items) return OVS_ERR_INVALID;
+    if (n > w->max_t) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = w->stream;
+    if (n) OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, kps, sizeof(ovs_keypoint) * n, hipMemcpyHostToDevice, s));
+    ovs_status st = grid_assign(w, gp, w->d_t_kps, n, s);
+    if (st != OVS_OK) return st;
+    const int nc = gp->cols * gp->rows;
+    OVS_HIP_TRY(hipMemcpyAsync(cell_start, w->d_cell_start, sizeof(int32_t) * (nc + 1), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
+    *n_items = cell_start[nc];
+    if (items && *n_items > 0) {
+        OVS_HIP_TRY(hipMemcpyAsync(items, w->d_items, sizeof(int32_t) * *n_items, hipMemcpyDeviceToHost, s));
+        OVS_HIP_TRY(hipStreamSynchronize(s));
+    }
+    return OVS_OK;
+}
+
+ovs_status ovs_projection_match_frame_and_landmarks_dev(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_keypoint* d_kps,
+                                                        const uint8_t* d_desc, const float* d_stereo_x_right, const uint8_t* d_occupied,
+                                                        int32_t n, const float* d_lm_xy, const float* d_lm_x_right,
+                                                        const int32_t* d_lm_level, const uint8_t* d_lm_desc, const uint8_t* d_lm_valid,
+                                                        int32_t m, const float* scale_factors, int32_t num_levels, float margin,
+                                                        float lowe_ratio, int32_t* d_assigned, int32_t* d_num_matches, void* stream) {
+    if (!w || !d_kps || !d_desc || n < 0 || m < 0 || !d_assigned || !d_num_matches || !scale_factors || num_levels < 1 ||
+        num_levels > OVS_MAX_LEVELS || (m > 0 && (!d_lm_xy || !d_lm_level || !d_lm_desc)) || (d_stereo_x_right && !d_lm_x_right))
+        return OVS_ERR_INVALID;
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (m == 0) {
+        OVS_HIP_TRY(hipMemsetAsync(d_num_matches, 0, sizeof(int32_t), s));
+        return OVS_OK;
+    }
+    ovs_status st = grid_assign(w, gp, d_kps, n, s);
+    if (st != OVS_OK) return st;
+    WinArgs a{};
+    a.t_kps = d_kps;
+    a.t_desc = d_desc;
+    a.t_occupied = d_occupied;
+    a.t_x_right = d_stereo_x_right;
+    a.cell_start = w->d_cell_start;
+    a.items = w->d_items;
+    a.gp = w->gp;
+    a.n_q = m;
+    a.q_xy = d_lm_xy;
+    a.q_x_right = d_lm_x_right;
+    a.q_level = d_lm_level;
+    a.q_valid = d_lm_valid;
+    a.q_desc = d_lm_desc;
+    a.margin = margin;
+    for (int l = 0; l < OVS_MAX_LEVELS; ++l) a.sf[l] = l < num_levels ? scale_factors[l] : 1.0f;
+    a.mode = kModeProjection;
+    st = build_lists(w, a, m, k_window_lists<false>, k_window_lists<true>, s);
+    if (st != OVS_OK) return st;
+    ResolveArgs ra{};
+    ra.offsets = w->d_offsets;
+    ra.keys = w->d_keys;
+    ra.n_q = m;
+    ra.n_t = n;
+    ra.lowe_ratio = lowe_ratio;
+    ra.assigned = d_assigned;
+    ra.num_matches = d_num_matches;
+    return launch_resolve<kRuleProjection>(ra, s);
+}
+
+ovs_status ovs_projection_match_frame_and_landmarks(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_keypoint* kps,
+                                                    const uint8_t* desc, const float* stereo_x_right, const uint8_t* occupied, int32_t n,
+                                                    const float* lm_xy, const float* lm_x_right, const int32_t* lm_level,
+                                                    const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m,
+                                                    const float* scale_factors, int32_t num_levels, float margin, float lowe_ratio,
+                                                    int32_t* assigned, int32_t* num_matches) {
+    if (!w || !num_matches || n < 0 || m < 0) return OVS_ERR_INVALID;
+    *num_matches = 0;
+    if (m == 0) return OVS_OK;
+    if (!assigned) return OVS_ERR_INVALID;
+    if (n == 0) {
+        for (int i = 0; i < m; ++i) assigned[i] = -1;
+        return OVS_OK;
+    }
+    if (!kps || !desc || !lm_xy || !lm_level || !lm_desc) return OVS_ERR_INVALID;
+    if (n > w->max_t || m > w->max_q) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = w->stream;
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, kps, sizeof(ovs_keypoint) * n, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, desc, (size_t)32 * n, hipMemcpyHostToDevice, s));
+    if (stereo_x_right) OVS_HIP_TRY(hipMemcpyAsync(w->d_t_f, stereo_x_right, sizeof(float) * n, hipMemcpyHostToDevice, s));
+    if (occupied) OVS_HIP_TRY(hipMemcpyAsync(w->d_t_flag, occupied, (size_t)n, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_xy, lm_xy, sizeof(float) * 2 * m, hipMemcpyHostToDevice, s));
+    if (lm_x_right) OVS_HIP_TRY(hipMemcpyAsync(w->d_q_f, lm_x_right, sizeof(float) * m, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_i, lm_level, sizeof(int32_t) * m, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, lm_desc, (size_t)32 * m, hipMemcpyHostToDevice, s));
+    if (lm_valid) OVS_HIP_TRY(hipMemcpyAsync(w->d_q_flag, lm_valid, (size_t)m, hipMemcpyHostToDevice, s));
+    ovs_status st = ovs_projection_match_frame_and_landmarks_dev(
+        w, gp, w->d_t_kps, w->d_t_desc, stereo_x_right ? w->d_t_f : nullptr, occupied ? w->d_t_flag : nullptr, n, w->d_q_xy,
+        lm_x_right ? w->d_q_f : nullptr, w->d_q_i, w->d_q_desc, lm_valid ? w->d_q_flag : nullptr, m, scale_factors, num_levels, margin,
+        lowe_ratio, w->d_assigned, w->d_num, s);
+    if (st != OVS_OK) return st;
+    uint32_t overflow = 0;
+    OVS_HIP_TRY(hipMemcpyAsync(assigned, w->d_assigned, sizeof(int32_t) * m, hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
+    return overflow ? OVS_ERR_CAPACITY : OVS_OK;
+}
+
+ovs_status ovs_area_match_in_consistent_area_dev(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_keypoint* d_kps_1,
+                                                 const uint8_t* d_desc_1, int32_t n1, const ovs_keypoint* d_kps_2,
+                                                 const uint8_t* d_desc_2, int32_t n2, float* d_prev_matched_xy,
+                                                 int32_t* d_matched_2_in_1, int32_t margin, float lowe_ratio, int32_t check_orientation,
+                                                 int32_t* d_num_matches, void* stream) {
+    if (!w || n1 < 0 || n2 < 0 || !d_num_matches || (n1 > 0 && (!d_kps_1 || !d_desc_1 || !d_prev_matched_xy || !d_matched_2_in_1)) ||
+        (n2 > 0 && (!d_kps_2 || !d_desc_2)))
+        return OVS_ERR_INVALID;
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (n1 == 0) {
+        OVS_HIP_TRY(hipMemsetAsync(d_num_matches, 0, sizeof(int32_t), s));
+        return OVS_OK;
+    }
+    ovs_status st = grid_assign(w, gp, d_kps_2, n2, s);
+    if (st != OVS_OK) return st;
+    WinArgs a{};
+    a.t_kps = d_kps_2;
+    a.t_desc = d_desc_2;
+    a.cell_start = w->d_cell_start;
+    a.items = w->d_items;
+    a.gp = w->gp;
+    a.n_q = n1;
+    a.q_xy = d_prev_matched_xy;
+    a.q_kps = d_kps_1;
+    a.q_desc = d_desc_1;
+    a.margin = (float)margin;
+    a.mode = kModeArea;
+    st = build_lists(w, a, n1, k_window_lists<false>, k_window_lists<true>, s);
+    if (st != OVS_OK) return st;
+    ResolveArgs ra{};
+    ra.offsets = w->d_offsets;
+    ra.keys = w->d_keys;
+    ra.n_q = n1;
+    ra.n_t = n2;
+    ra.lowe_ratio = lowe_ratio;
+    ra.check_orientation = check_orientation;
+    ra.q_kps = d_kps_1;
+    ra.t_kps = d_kps_2;
+    ra.prev_matched_xy = d_prev_matched_xy;
+    ra.assigned = d_matched_2_in_1;
+    ra.num_matches = d_num_matches;
+    return launch_resolve<kRuleArea>(ra, s);
+}
+
+ovs_status ovs_area_match_in_consistent_area(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_keypoint* kps_1, const uint8_t* desc_1,
+                                             int32_t n1, const ovs_keypoint* kps_2, const uint8_t* desc_2, int32_t n2,
+                                             float* prev_matched_xy, int32_t* matched_2_in_1, int32_t margin, float lowe_ratio,
+                                             int32_t check_orientation, int32_t* num_matches) {
+    if (!w || !num_matches || n1 < 0 || n2 < 0) return OVS_ERR_INVALID;
+    *num_matches = 0;
+    if (n1 == 0) return OVS_OK;
+    if (!kps_1 || !desc_1 || !prev_matched_xy || !matched_2_in_1) return OVS_ERR_INVALID;
+    if (n2 == 0) {
+        for (int i = 0; i < n1; ++i) matched_2_in_1[i] = -1;
+        return OVS_OK;
+    }
+    if (!kps_2 || !desc_2) return OVS_ERR_INVALID;
+    if (n2 > w->max_t || n1 > w->max_q) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = w->stream;
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_kps, kps_1, sizeof(ovs_keypoint) * n1, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, desc_1, (size_t)32 * n1, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_xy, prev_matched_xy, sizeof(float) * 2 * n1, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, kps_2, sizeof(ovs_keypoint) * n2, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, desc_2, (size_t)32 * n2, hipMemcpyHostToDevice, s));
+    ovs_status st = ovs_area_match_in_consistent_area_dev(w, gp, w->d_q_kps, w->d_q_desc, n1, w->d_t_kps, w->d_t_desc, n2, w->d_q_xy,
+                                                          w->d_assigned, margin, lowe_ratio, check_orientation, w->d_num, s);
+    if (st != OVS_OK) return st;
+    uint32_t overflow = 0;
+    OVS_HIP_TRY(hipMemcpyAsync(matched_2_in_1, w->d_assigned, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(prev_matched_xy, w->d_q_xy, sizeof(float) * 2 * n1, hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
+    return overflow ? OVS_ERR_CAPACITY : OVS_OK;
+}
+
+ovs_status ovs_bow_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_valid,
+                                            int32_t n_kf, const int32_t* kf_node_ids, const int32_t* kf_node_start,
+                                            const int32_t* kf_items, int32_t kf_nodes, const ovs_keypoint* frm_kps,
+                                            const uint8_t* frm_desc, int32_t n_frm, const int32_t* frm_node_ids,
+                                            const int32_t* frm_node_start, const int32_t* frm_items, int32_t frm_nodes, float lowe_ratio,
+                                            int32_t check_orientation, int32_t* matched_kf_in_frm, int32_t* num_matches) {
+    if (!w || !num_matches || n_kf < 0 || n_frm < 0 || kf_nodes < 0 || frm_nodes < 0) return OVS_ERR_INVALID;
+    *num_matches = 0;
+    if (n_frm == 0) return OVS_OK;
+    if (!matched_kf_in_frm) return OVS_ERR_INVALID;
+    for (int i = 0; i < n_frm; ++i) matched_kf_in_frm[i] = -1;
+    if (n_kf == 0 || kf_nodes == 0 || frm_nodes == 0) return OVS_OK;
+    if (!kf_kps || !kf_desc || !kf_node_ids || !kf_node_start || !kf_items || !frm_kps || !frm_desc || !frm_node_ids || !frm_node_start ||
+        !frm_items)
+        return OVS_ERR_INVALID;
+    const int nq = kf_node_start[kf_nodes], nfi = frm_node_start[frm_nodes];
+    if (nq == 0 || nfi == 0) return OVS_OK;
+    if (n_frm > w->max_t || n_kf > w->max_q || nq > w->max_q) return OVS_ERR_CAPACITY;
+    const size_t need = (size_t)2 * kf_nodes + 1 + nq + (size_t)2 * frm_nodes + 1 + nfi;
+    if (need > w->csr_cap) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = w->stream;
+    int32_t* p = w->d_csr;
+    int32_t* d_kf_ids = p;          p += kf_nodes;
+    int32_t* d_kf_start = p;        p += kf_nodes + 1;
+    int32_t* d_kf_items = p;        p += nq;
+    int32_t* d_f_ids = p;           p += frm_nodes;
+    int32_t* d_f_start = p;         p += frm_nodes + 1;
+    int32_t* d_f_items = p;
+    OVS_HIP_TRY(hipMemcpyAsync(d_kf_ids, kf_node_ids, sizeof(int32_t) * kf_nodes, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(d_kf_start, kf_node_start, sizeof(int32_t) * (kf_nodes + 1), hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(d_kf_items, kf_items, sizeof(int32_t) * nq, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(d_f_ids, frm_node_ids, sizeof(int32_t) * frm_nodes, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(d_f_start, frm_node_start, sizeof(int32_t) * (frm_nodes + 1), hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(d_f_items, frm_items, sizeof(int32_t) * nfi, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_kps, kf_kps, sizeof(ovs_keypoint) * n_kf, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, kf_desc, (size_t)32 * n_kf, hipMemcpyHostToDevice, s));
+    if (kf_valid) OVS_HIP_TRY(hipMemcpyAsync(w->d_q_flag, kf_valid, (size_t)n_kf, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, frm_kps, sizeof(ovs_keypoint) * n_frm, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, frm_desc, (size_t)32 * n_frm, hipMemcpyHostToDevice, s));
+    BowArgs a{};
+    a.kf_desc = w->d_q_desc;
+    a.kf_valid = kf_valid ? w->d_q_flag : nullptr;
+    a.kf_node_ids = d_kf_ids;
+    a.kf_node_start = d_kf_start;
+    a.kf_items = d_kf_items;
+    a.kf_nodes = kf_nodes;
+    a.n_q = nq;
+    a.frm_desc = w->d_t_desc;
+    a.frm_node_ids = d_f_ids;
+    a.frm_node_start = d_f_start;
+    a.frm_items = d_f_items;
+    a.frm_nodes = frm_nodes;
+    ovs_status st = build_lists(w, a, nq, k_bow_lists<false>, k_bow_lists<true>, s);
+    if (st != OVS_OK) return st;
+    ResolveArgs ra{};
+    ra.offsets = w->d_offsets;
+    ra.keys = w->d_keys;
+    ra.n_q = nq;
+    ra.n_t = n_frm;
+    ra.lowe_ratio = lowe_ratio;
+    ra.check_orientation = check_orientation;
+    ra.q_kps = w->d_q_kps;
+    ra.q_items = d_kf_items;
+    ra.t_kps = w->d_t_kps;
+    ra.assigned = w->d_assigned;
+    ra.num_matches = w->d_num;
+    st = launch_resolve<kRuleBow>(ra, s);
+    if (st != OVS_OK) return st;
+    uint32_t overflow = 0;
+    OVS_HIP_TRY(hipMemcpyAsync(matched_kf_in_frm, w->d_assigned, sizeof(int32_t) * n_frm, hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
+    return overflow ? OVS_ERR_CAPACITY : OVS_OK;
+}
+
+}   // extern "C"

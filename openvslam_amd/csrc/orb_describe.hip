@@ -27,7 +27,7 @@ constexpr uint32_t kG456 = 48u | (34u << 8) | (18u << 16);
 
 constexpr int kPatch = 43;       // 2*(18+3)+1
 constexpr int kPatchR = 21;
-constexpr int kBlurW = 37;       // 2*18+1
+constexpr int kBlurW = 37;       // 2*18+1 (columns of the row-blurred patch that are read)
 constexpr int kBlurR = 18;
 constexpr int kPatchPitch = 64;   // bytes: one aligned 64-byte window of each image row
 constexpr int kHbPitch = 40;      // u16 per row of the row-blurred patch (37 used)

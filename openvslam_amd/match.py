@@ -1,4 +1,5 @@
-"""Host-side mirror of match::base / match::robust (expected: src/openvslam/match/base.h, robust.{h,cc}) over the C ABI."""
+"""Host-side mirror of match::base / robust / projection / area / bow_tree (expected: src/openvslam/match/*.{h,cc}) and of
+data::assign_keypoints_to_grid (src/openvslam/data/common.{h,cc}) over the C ABI."""
 import ctypes as C
 
 import numpy as np
@@ -72,3 +73,130 @@ def hamming_best2(ctx, q, t, t_valid=None):
     s = np.zeros(len(q), np.uint16)
     _lib.check(ctx._L.ovs_hamming_best2(ctx._h, _p(q), len(q), _p(t), len(t), _p(t_valid), _p(bi), _p(b), _p(s)), "ovs_hamming_best2")
     return bi, b, s
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"),
+                     ("class_id", "<i4")])   # cv::KeyPoint / ovs_keypoint
+
+
+def grid_params(cols, rows, num_grid_cols=64, num_grid_rows=48, min_x=0.0, min_y=0.0):
+    """camera::base for an undistorted image: img_bounds_ = [0, cols] x [0, rows], 64 x 48 cells."""
+    return _lib.GridParams(min_x, min_y, float(cols), float(rows), num_grid_cols, num_grid_rows)
+
+
+def flatten_bow(feat_vec):
+    """std::map<node id, std::vector<unsigned>> (a dict here) -> CSR over ascending node ids."""
+    ids = np.array(sorted(feat_vec), np.int32)
+    start = np.zeros(len(ids) + 1, np.int32)
+    items = []
+    for k, i in enumerate(ids):
+        items.extend(feat_vec[int(i)])
+        start[k + 1] = len(items)
+    return ids, start, np.array(items, np.int32)
+
+
+class _window_ctx:
+    def __init__(self, max_targets=8192, max_queries=16384, max_entries=1 << 21, device=0):
+        self._L = _lib.lib()
+        _lib.require_device()
+        h = C.c_void_p()
+        _lib.check(self._L.ovs_wmatcher_create(max_targets, max_queries, max_entries, device, C.byref(h)), "ovs_wmatcher_create")
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.ovs_wmatcher_destroy(self._h)
+            self._h = None
+
+    def assign_keypoints_to_grid(self, gp, keypts):
+        """data::assign_keypoints_to_grid -> (cell_start[cols*rows+1], items); cell id = cx*rows + cy."""
+        k = np.ascontiguousarray(keypts, KP_DTYPE)
+        nc = gp.cols * gp.rows
+        start = np.zeros(nc + 1, np.int32)
+        items = np.zeros(max(len(k), 1), np.int32)
+        n = C.c_int32()
+        _lib.check(self._L.ovs_assign_keypoints_to_grid(self._h, C.byref(gp), _p(k), len(k), _p(start), _p(items), C.byref(n)),
+                   "ovs_assign_keypoints_to_grid")
+        return start, items[:n.value].copy()
+
+
+class projection(_window_ctx):
+    """match::projection(lowe_ratio, check_orientation)."""
+
+    def __init__(self, lowe_ratio=0.6, check_orientation=True, **kw):
+        super().__init__(**kw)
+        self.lowe_ratio_ = float(lowe_ratio)
+        self.check_orientation_ = bool(check_orientation)
+
+    def match_frame_and_landmarks(self, gp, frm_keypts, frm_desc, scale_factors, lm_reproj, lm_level, lm_desc, margin=5.0,
+                                  frm_stereo_x_right=None, frm_occupied=None, lm_x_right=None, lm_valid=None):
+        """projection::match_frame_and_landmarks(frm, local_landmarks, margin): returns (assigned, num_matches) where
+        assigned[l] is the frame keypoint that receives landmark l (frm.landmarks_[assigned[l]] = local_landmarks[l]) or -1."""
+        k = np.ascontiguousarray(frm_keypts, KP_DTYPE)
+        d = np.ascontiguousarray(frm_desc, np.uint8).reshape(-1, 32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        xy = np.ascontiguousarray(lm_reproj, np.float32).reshape(-1, 2)
+        lv = np.ascontiguousarray(lm_level, np.int32)
+        ld = np.ascontiguousarray(lm_desc, np.uint8).reshape(-1, 32)
+        xr = None if frm_stereo_x_right is None else np.ascontiguousarray(frm_stereo_x_right, np.float32)
+        occ = None if frm_occupied is None else np.ascontiguousarray(frm_occupied, np.uint8)
+        lxr = None if lm_x_right is None else np.ascontiguousarray(lm_x_right, np.float32)
+        val = None if lm_valid is None else np.ascontiguousarray(lm_valid, np.uint8)
+        assigned = np.full(max(len(xy), 1), -1, np.int32)
+        n = C.c_int32()
+        _lib.check(self._L.ovs_projection_match_frame_and_landmarks(
+            self._h, C.byref(gp), _p(k), _p(d), _p(xr), _p(occ), len(k), _p(xy), _p(lxr), _p(lv), _p(ld), _p(val), len(xy), _p(sf), len(sf),
+            float(margin), self.lowe_ratio_, _p(assigned), C.byref(n)), "ovs_projection_match_frame_and_landmarks")
+        return assigned[:len(xy)].copy(), n.value
+
+
+class area(_window_ctx):
+    """match::area(lowe_ratio, check_orientation)."""
+
+    def __init__(self, lowe_ratio=0.9, check_orientation=True, **kw):
+        super().__init__(**kw)
+        self.lowe_ratio_ = float(lowe_ratio)
+        self.check_orientation_ = bool(check_orientation)
+
+    def match_in_consistent_area(self, gp, keypts_1, desc_1, keypts_2, desc_2, prev_matched_pts, margin=10):
+        """area::match_in_consistent_area(frm_1, frm_2, prev_matched_pts, matched_indices_2_in_frm_1, margin):
+        returns (num_matches, matched_indices_2_in_frm_1); prev_matched_pts (n1, 2) float32 is updated in place."""
+        k1 = np.ascontiguousarray(keypts_1, KP_DTYPE)
+        k2 = np.ascontiguousarray(keypts_2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc_1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(desc_2, np.uint8).reshape(-1, 32)
+        if prev_matched_pts.dtype != np.float32 or not prev_matched_pts.flags.c_contiguous or prev_matched_pts.shape != (len(k1), 2):
+            raise ValueError("prev_matched_pts must be a C-contiguous (n1, 2) float32 array (it is updated in place)")
+        matched = np.full(max(len(k1), 1), -1, np.int32)
+        n = C.c_int32()
+        _lib.check(self._L.ovs_area_match_in_consistent_area(self._h, C.byref(gp), _p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2),
+                                                             _p(prev_matched_pts), _p(matched), int(margin), self.lowe_ratio_,
+                                                             int(self.check_orientation_), C.byref(n)), "ovs_area_match_in_consistent_area")
+        return n.value, matched[:len(k1)].copy()
+
+
+class bow_tree(_window_ctx):
+    """match::bow_tree(lowe_ratio, check_orientation)."""
+
+    def __init__(self, lowe_ratio=0.6, check_orientation=True, **kw):
+        super().__init__(**kw)
+        self.lowe_ratio_ = float(lowe_ratio)
+        self.check_orientation_ = bool(check_orientation)
+
+    def match_frame_and_keyframe(self, kf_keypts, kf_desc, kf_bow_feat_vec, frm_keypts, frm_desc, frm_bow_feat_vec, kf_has_landmark=None):
+        """bow_tree::match_frame_and_keyframe(keyfrm, frm, matched_lms_in_frm): returns (num_matches, matched_kf_in_frm) where
+        matched_kf_in_frm[j] is the keyframe keypoint whose landmark frame keypoint j receives, or -1."""
+        kk = np.ascontiguousarray(kf_keypts, KP_DTYPE)
+        fk = np.ascontiguousarray(frm_keypts, KP_DTYPE)
+        kd = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32)
+        fd = np.ascontiguousarray(frm_desc, np.uint8).reshape(-1, 32)
+        v = None if kf_has_landmark is None else np.ascontiguousarray(kf_has_landmark, np.uint8)
+        ki, ks, kit = flatten_bow(kf_bow_feat_vec)
+        fi, fs, fit = flatten_bow(frm_bow_feat_vec)
+        out = np.full(max(len(fk), 1), -1, np.int32)
+        n = C.c_int32()
+        _lib.check(self._L.ovs_bow_match_frame_and_keyframe(self._h, _p(kk), _p(kd), _p(v), len(kk), _p(ki), _p(ks), _p(kit), len(ki), _p(fk),
+                                                            _p(fd), len(fk), _p(fi), _p(fs), _p(fit), len(fi), self.lowe_ratio_,
+                                                            int(self.check_orientation_), _p(out), C.byref(n)),
+                   "ovs_bow_match_frame_and_keyframe")
+        return n.value, out[:len(fk)].copy()

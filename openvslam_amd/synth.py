@@ -120,3 +120,76 @@ def synth_local_ba(n_pose=50, n_pt=20000, obs_per_pose=2000, seed=0, pose_noise=
         pts0 += rng.normal(0, point_noise, size=pts.shape)
     return dict(cam=cam, poses=poses0, points=pts0, poses_true=poses, points_true=pts, edges=edges, pose_fixed=fixed,
                 huber_delta=float(np.sqrt(5.991)))
+
+
+def flip_bits(rng, desc, max_flip=40):
+    """A copy of a 32-byte descriptor with U{0..max_flip} random bit flips."""
+    bits = np.unpackbits(desc)
+    k = int(rng.integers(0, max_flip + 1))
+    bits[rng.permutation(256)[:k]] ^= 1
+    return np.packbits(bits)
+
+
+def synth_keypoints(n, rows, cols, seed=0, num_levels=8, scale=1.2):
+    """n cv::KeyPoint records + random descriptors as an extractor would emit them (level-major, level-0 coordinates), for
+    matcher tests that do not need images."""
+    from .match import KP_DTYPE
+    rng = np.random.Generator(np.random.PCG64(seed))
+    k = np.zeros(n, KP_DTYPE)
+    octs = np.sort(rng.integers(0, num_levels, n))
+    sf = np.float32(scale) ** octs.astype(np.float32)
+    k["octave"] = octs
+    k["x"] = (np.floor(rng.uniform(22, cols / sf - 22)) * sf).astype(np.float32)
+    k["y"] = (np.floor(rng.uniform(22, rows / sf - 22)) * sf).astype(np.float32)
+    k["size"] = 31 * sf
+    k["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    k["response"] = rng.integers(7, 120, n)
+    k["class_id"] = -1
+    d = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    return k, d
+
+
+def synth_landmarks(kps, desc, n_lm, rows, cols, seed=0, n_from_frame=None, jitter=2.0, with_stereo=False):
+    """BASELINE config 4's landmark set: n_from_frame landmarks are frame keypoints (wrapping around, so some
+    keypoints are wanted by several landmarks) with U{0..40} flipped descriptor bits, reprojected within `jitter` px of their
+    keypoint and predicted at the keypoint's level or one above; the rest are distractors: uniform-random descriptors,
+    reprojections uniform over the image, levels U{0..7}. Returns dict(xy, level, desc, valid[, x_right])."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = len(kps)
+    if n_from_frame is None:
+        n_from_frame = min(n_lm, n)
+    xy = np.zeros((n_lm, 2), np.float32)
+    level = np.zeros(n_lm, np.int32)
+    d = rng.integers(0, 256, size=(n_lm, 32), dtype=np.uint8)
+    src = np.full(n_lm, -1, np.int64)
+    order = rng.permutation(n_lm)
+    for j, l in enumerate(order[:n_from_frame]):
+        i = int(rng.integers(0, n)) if j >= n else j
+        src[l] = i
+        xy[l] = (kps["x"][i] + rng.normal(0, jitter), kps["y"][i] + rng.normal(0, jitter))
+        level[l] = min(7, int(kps["octave"][i]) + int(rng.integers(0, 2)))
+        d[l] = flip_bits(rng, desc[i])
+    for l in order[n_from_frame:]:
+        xy[l] = (rng.uniform(0, cols), rng.uniform(0, rows))
+        level[l] = int(rng.integers(0, 8))
+    out = dict(xy=xy, level=level, desc=d, valid=(rng.random(n_lm) < 0.95).astype(np.uint8), src=src)
+    if with_stereo:
+        out["x_right"] = (xy[:, 0] - rng.uniform(2, 60, n_lm)).astype(np.float32)
+    return out
+
+
+def synth_bow(desc, seed=0, n_nodes=200):
+    """A stand-in for DBoW2's feature vector (node id -> keypoint indices): keypoints are bucketed by a locality-sensitive
+    hash of their descriptor (majority bit of 8 fixed byte groups), so near-duplicate descriptors tend to share a node as
+    they do in a vocabulary tree. Only the bucket structure matters to the matcher."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    groups = rng.permutation(256)[:8 * 16].reshape(8, 16)
+    bits = np.unpackbits(np.ascontiguousarray(desc, np.uint8).reshape(-1, 32), axis=1)
+    code = np.zeros(len(bits), np.int64)
+    for b in range(8):
+        code |= (bits[:, groups[b]].sum(1) >= 8).astype(np.int64) << b
+    node = (code * 7919) % n_nodes
+    fv = {}
+    for i, nd in enumerate(node):
+        fv.setdefault(int(nd), []).append(i)
+    return fv

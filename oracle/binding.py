@@ -234,6 +234,103 @@ def hamming_best2(q, t, t_valid=None):
     return bi, b, s
 
 
+class GridParams(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float), ("cols", C.c_int32),
+                ("rows", C.c_int32)]
+
+
+def grid_params(cols, rows, num_grid_cols=64, num_grid_rows=48, min_x=0.0, min_y=0.0):
+    return GridParams(min_x, min_y, float(cols), float(rows), num_grid_cols, num_grid_rows)
+
+
+def _soa(kps):
+    k = np.ascontiguousarray(kps, KP_DTYPE)
+    return (np.ascontiguousarray(k["x"]), np.ascontiguousarray(k["y"]), np.ascontiguousarray(k["octave"]), np.ascontiguousarray(k["angle"]))
+
+
+def assign_keypoints_to_grid(gp, kps):
+    xs, ys, _, _ = _soa(kps)
+    start = np.zeros(gp.cols * gp.rows + 1, np.int32)
+    items = np.zeros(max(len(xs), 1), np.int32)
+    L = lib()
+    L.ovo_assign_keypoints_to_grid.restype = C.c_int
+    n = L.ovo_assign_keypoints_to_grid(C.byref(gp), _p(xs), _p(ys), len(xs), _p(start), _p(items))
+    return start, items[:n].copy()
+
+
+def get_keypoints_in_cell(gp, kps, ref_x, ref_y, margin, min_level=-1, max_level=-1):
+    xs, ys, oc, _ = _soa(kps)
+    out = np.zeros(max(len(xs), 1), np.int32)
+    n = lib().ovo_get_keypoints_in_cell(C.byref(gp), _p(xs), _p(ys), _p(oc), len(xs), C.c_float(ref_x), C.c_float(ref_y), C.c_float(margin),
+                                        int(min_level), int(max_level), _p(out), len(out))
+    return out[:n].copy()
+
+
+def angle_checker_invalid(delta_angles):
+    d = np.ascontiguousarray(delta_angles, np.float32)
+    inv = np.zeros(max(len(d), 1), np.uint8)
+    lib().ovo_angle_checker_invalid(_p(d), len(d), _p(inv))
+    return inv[:len(d)].astype(bool)
+
+
+def projection_match_frame_and_landmarks(gp, frm_kps, frm_desc, scale_factors, lm_reproj, lm_level, lm_desc, margin=5.0, lowe_ratio=0.6,
+                                         frm_stereo_x_right=None, frm_occupied=None, lm_x_right=None, lm_valid=None):
+    xs, ys, oc, _ = _soa(frm_kps)
+    d = np.ascontiguousarray(frm_desc, np.uint8).reshape(-1, 32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    xy = np.ascontiguousarray(lm_reproj, np.float32).reshape(-1, 2)
+    lx, ly = np.ascontiguousarray(xy[:, 0]), np.ascontiguousarray(xy[:, 1])
+    lv = np.ascontiguousarray(lm_level, np.int32)
+    ld = np.ascontiguousarray(lm_desc, np.uint8).reshape(-1, 32)
+    xr = None if frm_stereo_x_right is None else np.ascontiguousarray(frm_stereo_x_right, np.float32)
+    occ = np.zeros(len(xs), np.uint8) if frm_occupied is None else np.ascontiguousarray(frm_occupied, np.uint8)
+    lxr = None if lm_x_right is None else np.ascontiguousarray(lm_x_right, np.float32)
+    val = None if lm_valid is None else np.ascontiguousarray(lm_valid, np.uint8)
+    assigned = np.full(max(len(xy), 1), -1, np.int32)
+    n = lib().ovo_projection_match_frame_and_landmarks(C.byref(gp), _p(xs), _p(ys), _p(oc), _p(xr), _p(d), _p(occ), len(xs), _p(lx), _p(ly),
+                                                       _p(lxr), _p(lv), _p(ld), _p(val), len(xy), _p(sf), C.c_float(margin),
+                                                       C.c_float(lowe_ratio), _p(assigned))
+    return assigned[:len(xy)].copy(), n
+
+
+def area_match_in_consistent_area(gp, kps_1, desc_1, kps_2, desc_2, prev_matched_pts, margin=10, lowe_ratio=0.9, check_orientation=True):
+    _, _, oc1, an1 = _soa(kps_1)
+    xs2, ys2, oc2, an2 = _soa(kps_2)
+    d1 = np.ascontiguousarray(desc_1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(desc_2, np.uint8).reshape(-1, 32)
+    assert prev_matched_pts.dtype == np.float32 and prev_matched_pts.flags.c_contiguous
+    matched = np.full(max(len(oc1), 1), -1, np.int32)
+    n = lib().ovo_area_match_in_consistent_area(C.byref(gp), _p(oc1), _p(an1), _p(d1), len(oc1), _p(xs2), _p(ys2), _p(oc2), _p(an2), _p(d2),
+                                                len(xs2), _p(prev_matched_pts), _p(matched), int(margin), C.c_float(lowe_ratio),
+                                                int(check_orientation))
+    return n, matched[:len(oc1)].copy()
+
+
+def _flatten_bow(feat_vec):
+    ids = np.array(sorted(feat_vec), np.int32)
+    start = np.zeros(len(ids) + 1, np.int32)
+    items = []
+    for k, i in enumerate(ids):
+        items.extend(feat_vec[int(i)])
+        start[k + 1] = len(items)
+    return ids, start, np.array(items, np.int32)
+
+
+def bow_match_frame_and_keyframe(kf_kps, kf_desc, kf_feat_vec, frm_kps, frm_desc, frm_feat_vec, lowe_ratio=0.6, check_orientation=True,
+                                 kf_has_landmark=None):
+    _, _, _, ka = _soa(kf_kps)
+    _, _, _, fa = _soa(frm_kps)
+    kd = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32)
+    fd = np.ascontiguousarray(frm_desc, np.uint8).reshape(-1, 32)
+    v = None if kf_has_landmark is None else np.ascontiguousarray(kf_has_landmark, np.uint8)
+    ki, ks, kit = _flatten_bow(kf_feat_vec)
+    fi, fs, fit = _flatten_bow(frm_feat_vec)
+    out = np.full(max(len(fa), 1), -1, np.int32)
+    n = lib().ovo_bow_match_frame_and_keyframe(_p(kd), _p(ka), _p(v), len(ka), _p(ki), _p(ks), _p(kit), len(ki), _p(fd), _p(fa), len(fa),
+                                               _p(fi), _p(fs), _p(fit), len(fi), C.c_float(lowe_ratio), int(check_orientation), _p(out))
+    return n, out[:len(fa)].copy()
+
+
 BA_EDGE_DTYPE = np.dtype([("pose_idx", "<i4"), ("point_idx", "<i4"), ("obs_x", "<f8"), ("obs_y", "<f8"), ("inv_sigma_sq", "<f8")])
 
 

@@ -1,0 +1,444 @@
+// ovo_match2.cc -- CPU ORACLE (test infrastructure, see ovo_oracle.h): the windowed matchers and their candidate generator,
+// restated from spec. PARITY UNPINNED (upstream absent). Expected upstream paths:
+//   D1  src/openvslam/data/common.{h,cc}            assign_keypoints_to_grid, get_cell_indices, get_keypoints_in_cell
+//   --  src/openvslam/match/angle_checker.h         30-bin rotation histogram, keep the 3 fullest bins
+//   M3  src/openvslam/match/projection.{h,cc}       match_frame_and_landmarks
+//   M4  src/openvslam/match/projection.{h,cc}       match_current_and_last_frames (perspective camera)
+//   M5  src/openvslam/match/area.{h,cc}             match_in_consistent_area
+//   M6  src/openvslam/match/stereo.{h,cc}           compute (+ get_right_keypoint_indices_in_each_row,
+//                                                   find_closest_keypoints_in_stereo, compute_subpixel_disparity)
+//   M7  src/openvslam/match/bow_tree.{h,cc}         match_frame_and_keyframe
+// Object graphs (data::frame, data::landmark*, camera::base) are flattened into SoA arrays exactly as the C ABI of
+// include/ovslam_hip.h flattens them; every rule that had to be chosen is listed in ORACLE_SPEC.md (rules 16+).
+#include "ovo_oracle.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <utility>
+#include <vector>
+
+namespace {
+
+inline uint32_t distance_32(const uint8_t* a, const uint8_t* b) { return ovo_descriptor_distance_32(a, b); }
+
+inline int cv_round(float v) { return (int)std::nearbyintf(v); }   // cvRound: round-half-to-even (SSE cvtss2si)
+inline int cv_floor(float v) { return (int)std::floor(v); }
+inline int cv_ceil(float v) { return (int)std::ceil(v); }
+
+struct Grid {
+    ovo_grid_params p;
+    float inv_w, inv_h;
+    std::vector<int32_t> start, items;   // cell id = cx * rows + cy (upstream: keypt_indices_in_cells[cx][cy])
+};
+
+// camera::base: inv_cell_width_ = num_grid_cols_ / (img_bounds_.max_x_ - img_bounds_.min_x_) (double division, float member)
+inline void grid_scales(const ovo_grid_params& p, float& inv_w, float& inv_h) {
+    inv_w = (float)((double)p.cols / (double)(p.max_x - p.min_x));
+    inv_h = (float)((double)p.rows / (double)(p.max_y - p.min_y));
+}
+
+// D1 get_cell_indices: cvRound of the scaled coordinate; keypoints falling outside the grid are in no cell.
+inline bool cell_of(const Grid& g, float x, float y, int& cx, int& cy) {
+    cx = cv_round((x - g.p.min_x) * g.inv_w);
+    cy = cv_round((y - g.p.min_y) * g.inv_h);
+    return 0 <= cx && cx < g.p.cols && 0 <= cy && cy < g.p.rows;
+}
+
+// D1 assign_keypoints_to_grid: push_back in keypoint order => ascending indices inside a cell.
+void build_grid(Grid& g, const ovo_grid_params& p, const float* xs, const float* ys, int n) {
+    g.p = p;
+    grid_scales(p, g.inv_w, g.inv_h);
+    const int nc = p.cols * p.rows;
+    g.start.assign(nc + 1, 0);
+    std::vector<int32_t> cell(n, -1);
+    for (int i = 0; i < n; ++i) {
+        int cx, cy;
+        if (cell_of(g, xs[i], ys[i], cx, cy)) {
+            cell[i] = cx * p.rows + cy;
+            ++g.start[cell[i] + 1];
+        }
+    }
+    for (int c = 0; c < nc; ++c) g.start[c + 1] += g.start[c];
+    g.items.assign(g.start[nc], 0);
+    std::vector<int32_t> fill(g.start.begin(), g.start.end() - 1);
+    for (int i = 0; i < n; ++i)
+        if (cell[i] >= 0) g.items[fill[cell[i]]++] = i;
+}
+
+// D1 get_keypoints_in_cell: cells [floor((ref - min - margin) * inv), ceil((ref - min + margin) * inv)] clamped to the grid,
+// x-major then y, members in cell order, filtered by level range and |dx| < margin && |dy| < margin.
+template <typename F>
+void for_keypoints_in_cell(const Grid& g, const float* xs, const float* ys, const int32_t* octaves, float ref_x, float ref_y,
+                           float margin, int min_level, int max_level, F&& f) {
+    const int min_cx = std::max(0, cv_floor((ref_x - g.p.min_x - margin) * g.inv_w));
+    if (g.p.cols <= min_cx) return;
+    const int max_cx = std::min(g.p.cols - 1, cv_ceil((ref_x - g.p.min_x + margin) * g.inv_w));
+    if (max_cx < 0) return;
+    const int min_cy = std::max(0, cv_floor((ref_y - g.p.min_y - margin) * g.inv_h));
+    if (g.p.rows <= min_cy) return;
+    const int max_cy = std::min(g.p.rows - 1, cv_ceil((ref_y - g.p.min_y + margin) * g.inv_h));
+    if (max_cy < 0) return;
+    const bool check_level = (0 < min_level) || (0 <= max_level);
+    for (int cx = min_cx; cx <= max_cx; ++cx) {
+        for (int cy = min_cy; cy <= max_cy; ++cy) {
+            const int c = cx * g.p.rows + cy;
+            for (int k = g.start[c]; k < g.start[c + 1]; ++k) {
+                const int idx = g.items[k];
+                if (check_level) {
+                    if (octaves[idx] < min_level || (0 <= max_level && max_level < octaves[idx])) continue;
+                }
+                const float dist_x = xs[idx] - ref_x, dist_y = ys[idx] - ref_y;
+                if (std::fabs(dist_x) < margin && std::fabs(dist_y) < margin) f(idx);
+            }
+        }
+    }
+}
+
+// match::angle_checker<int>: histogram_length 30, inv_histogram_length = 1/30 (so bins are 30 degrees wide and only
+// bins 0..12 are ever hit -- upstream's inherited ORB-SLAM2 quirk), keep the num_bins_to_keep = 3 fullest bins.
+// Tie rule (upstream: std::sort on sizes, implementation-defined): equal sizes -> lower bin index first.
+struct AngleChecker {
+    static constexpr int kLen = 30, kKeep = 3;
+    std::vector<int> bins[kLen];
+    void append(float delta_angle, int match) {
+        if (delta_angle < 0.0f) delta_angle += 360.0f;
+        if (360.0f <= delta_angle) delta_angle -= 360.0f;
+        int bin = cv_round(delta_angle * (1.0f / kLen));
+        if (bin == kLen) bin = 0;
+        bins[bin].push_back(match);
+    }
+    std::vector<int> invalid() const {
+        int order[kLen];
+        std::iota(order, order + kLen, 0);
+        std::stable_sort(order, order + kLen, [&](int a, int b) { return bins[a].size() > bins[b].size(); });
+        std::vector<int> out;
+        for (int b = 0; b < kLen; ++b) {
+            bool keep = false;
+            for (int k = 0; k < kKeep; ++k) keep |= order[k] == b;
+            if (!keep) out.insert(out.end(), bins[b].begin(), bins[b].end());
+        }
+        return out;
+    }
+};
+
+}   // namespace
+
+extern "C" {
+
+int ovo_assign_keypoints_to_grid(const ovo_grid_params* p, const float* xs, const float* ys, int n, int32_t* cell_start,
+                                 int32_t* items) {
+    Grid g;
+    build_grid(g, *p, xs, ys, n);
+    std::memcpy(cell_start, g.start.data(), sizeof(int32_t) * g.start.size());
+    if (!g.items.empty()) std::memcpy(items, g.items.data(), sizeof(int32_t) * g.items.size());
+    return (int)g.items.size();
+}
+
+int ovo_get_keypoints_in_cell(const ovo_grid_params* p, const float* xs, const float* ys, const int32_t* octaves, int n, float ref_x,
+                              float ref_y, float margin, int min_level, int max_level, int32_t* out, int cap) {
+    Grid g;
+    build_grid(g, *p, xs, ys, n);
+    int m = 0;
+    for_keypoints_in_cell(g, xs, ys, octaves, ref_x, ref_y, margin, min_level, max_level, [&](int idx) {
+        if (m < cap) out[m] = idx;
+        ++m;
+    });
+    return m;
+}
+
+void ovo_angle_checker_invalid(const float* delta_angles, int n, uint8_t* invalid) {
+    AngleChecker ac;
+    for (int i = 0; i < n; ++i) ac.append(delta_angles[i], i);
+    std::memset(invalid, 0, (size_t)n);
+    for (int i : ac.invalid()) invalid[i] = 1;
+}
+
+// M3  projection::match_frame_and_landmarks(frm, local_landmarks, margin): landmarks in order; candidates from the grid at
+// the reprojection with radius margin * scale_factors[pred_level], levels [pred_level-1, pred_level]; keypoints that
+// already hold a landmark with observations are skipped (including those assigned earlier in this very loop); stereo
+// keypoints must agree on x_right; strict `<` best/second WITH their levels; accept iff best <= THR_HIGH and not
+// (best_level == second_level && best > lowe_ratio * second); then frm.landmarks_[best_idx] = lm.
+// assigned[l] = frame keypoint index given to landmark l, or -1. Returns num_matches.
+int ovo_projection_match_frame_and_landmarks(const ovo_grid_params* gp, const float* xs, const float* ys, const int32_t* octaves,
+                                             const float* stereo_x_right, const uint8_t* desc, const uint8_t* occupied, int n,
+                                             const float* lm_x, const float* lm_y, const float* lm_x_right, const int32_t* lm_level,
+                                             const uint8_t* lm_desc, const uint8_t* lm_valid, int m, const float* scale_factors,
+                                             float margin, float lowe_ratio, int32_t* assigned) {
+    Grid g;
+    build_grid(g, *gp, xs, ys, n);
+    std::vector<uint8_t> occ(occupied, occupied + n);
+    int num_matches = 0;
+    for (int l = 0; l < m; ++l) {
+        assigned[l] = -1;
+        if (lm_valid && !lm_valid[l]) continue;   // !is_observable_in_tracking_ || will_be_erased()
+        const int pred = lm_level[l];
+        const float r = margin * scale_factors[pred];
+        unsigned best = OVO_MAX_HAMMING_DIST, second = OVO_MAX_HAMMING_DIST;
+        int best_level = -1, second_level = -1, best_idx = -1;
+        for_keypoints_in_cell(g, xs, ys, octaves, lm_x[l], lm_y[l], r, pred - 1, pred, [&](int idx) {
+            if (occ[idx]) return;
+            if (stereo_x_right && 0 < stereo_x_right[idx]) {
+                const float reproj_error = std::fabs(lm_x_right[l] - stereo_x_right[idx]);
+                if (r < reproj_error) return;
+            }
+            const unsigned d = distance_32(lm_desc + (size_t)l * 32, desc + (size_t)idx * 32);
+            if (d < best) {
+                second = best;
+                best = d;
+                second_level = best_level;
+                best_level = octaves[idx];
+                best_idx = idx;
+            } else if (d < second) {
+                second_level = octaves[idx];
+                second = d;
+            }
+        });
+        if (best <= OVO_HAMMING_DIST_THR_HIGH) {
+            if (best_level == second_level && (float)best > lowe_ratio * (float)second) continue;
+            assigned[l] = best_idx;
+            occ[best_idx] = 1;
+            ++num_matches;
+        }
+    }
+    return num_matches;
+}
+
+// M5  area::match_in_consistent_area(frm_1, frm_2, prev_matched_pts, matched_indices_2_in_frm_1, margin): level-0 keypoints
+// of frame 1 only; candidates of frame 2 around the previous matched position, level [0, 0]; a candidate already matched
+// at a distance <= ours is skipped; accept iff best <= THR_LOW and !(second * ratio < best); an earlier owner of the
+// target is unmatched (stolen); optional orientation histogram; finally prev_matched_pts is updated for the matches.
+int ovo_area_match_in_consistent_area(const ovo_grid_params* gp, const int32_t* octaves_1, const float* angles_1,
+                                      const uint8_t* desc_1, int n1, const float* xs_2, const float* ys_2, const int32_t* octaves_2,
+                                      const float* angles_2, const uint8_t* desc_2, int n2, float* prev_matched_xy,
+                                      int32_t* matched_2_in_1, int margin, float lowe_ratio, int check_orientation) {
+    Grid g;
+    build_grid(g, *gp, xs_2, ys_2, n2);
+    int num_matches = 0;
+    AngleChecker ac;
+    for (int i = 0; i < n1; ++i) matched_2_in_1[i] = -1;
+    std::vector<unsigned> matched_dists_2((size_t)n2, OVO_MAX_HAMMING_DIST);
+    std::vector<int> matched_1_in_2((size_t)n2, -1);
+    for (int idx_1 = 0; idx_1 < n1; ++idx_1) {
+        const int level_1 = octaves_1[idx_1];
+        if (0 < level_1) continue;
+        unsigned best = OVO_MAX_HAMMING_DIST, second = OVO_MAX_HAMMING_DIST;
+        int best_idx_2 = -1;
+        for_keypoints_in_cell(g, xs_2, ys_2, octaves_2, prev_matched_xy[2 * idx_1], prev_matched_xy[2 * idx_1 + 1], (float)margin,
+                              level_1, level_1, [&](int idx_2) {
+                                  const unsigned d = distance_32(desc_1 + (size_t)idx_1 * 32, desc_2 + (size_t)idx_2 * 32);
+                                  if (matched_dists_2[idx_2] <= d) return;
+                                  if (d < best) {
+                                      second = best;
+                                      best = d;
+                                      best_idx_2 = idx_2;
+                                  } else if (d < second) {
+                                      second = d;
+                                  }
+                              });
+        if (OVO_HAMMING_DIST_THR_LOW < best) continue;
+        if ((float)second * lowe_ratio < (float)best) continue;
+        const int prev_idx_1 = matched_1_in_2[best_idx_2];
+        if (0 <= prev_idx_1) {
+            matched_2_in_1[prev_idx_1] = -1;
+            --num_matches;
+        }
+        matched_2_in_1[idx_1] = best_idx_2;
+        matched_1_in_2[best_idx_2] = idx_1;
+        matched_dists_2[best_idx_2] = best;
+        ++num_matches;
+        if (check_orientation) ac.append(angles_1[idx_1] - angles_2[best_idx_2], idx_1);
+    }
+    if (check_orientation) {
+        for (int invalid_idx_1 : ac.invalid()) {
+            if (0 <= matched_2_in_1[invalid_idx_1]) {
+                matched_2_in_1[invalid_idx_1] = -1;
+                --num_matches;
+            }
+        }
+    }
+    for (int idx_1 = 0; idx_1 < n1; ++idx_1) {
+        if (0 <= matched_2_in_1[idx_1]) {
+            prev_matched_xy[2 * idx_1] = xs_2[matched_2_in_1[idx_1]];
+            prev_matched_xy[2 * idx_1 + 1] = ys_2[matched_2_in_1[idx_1]];
+        }
+    }
+    return num_matches;
+}
+
+// M7  bow_tree::match_frame_and_keyframe(keyfrm, frm, matched_lms_in_frm): walk the two BoW feature vectors (node id ->
+// keypoint indices, ascending node ids); inside a common node every keyframe keypoint with a live landmark scans the
+// frame keypoints of that node that are still unmatched; accept iff best <= THR_LOW and !(ratio * second < best);
+// optional orientation histogram. matched_kf_in_frm[frame idx] = keyframe keypoint index (its landmark) or -1.
+int ovo_bow_match_frame_and_keyframe(const uint8_t* kf_desc, const float* kf_angles, const uint8_t* kf_valid, int n_kf,
+                                     const int32_t* kf_node_ids, const int32_t* kf_node_start, const int32_t* kf_items, int kf_nodes,
+                                     const uint8_t* frm_desc, const float* frm_angles, int n_frm, const int32_t* frm_node_ids,
+                                     const int32_t* frm_node_start, const int32_t* frm_items, int frm_nodes, float lowe_ratio,
+                                     int check_orientation, int32_t* matched_kf_in_frm) {
+    (void)n_kf;
+    int num_matches = 0;
+    AngleChecker ac;
+    for (int i = 0; i < n_frm; ++i) matched_kf_in_frm[i] = -1;
+    int a = 0, b = 0;
+    while (a < kf_nodes && b < frm_nodes) {
+        if (kf_node_ids[a] == frm_node_ids[b]) {
+            for (int ka = kf_node_start[a]; ka < kf_node_start[a + 1]; ++ka) {
+                const int kf_idx = kf_items[ka];
+                if (kf_valid && !kf_valid[kf_idx]) continue;
+                unsigned best = OVO_MAX_HAMMING_DIST, second = OVO_MAX_HAMMING_DIST;
+                int best_frm_idx = -1;
+                for (int kb = frm_node_start[b]; kb < frm_node_start[b + 1]; ++kb) {
+                    const int frm_idx = frm_items[kb];
+                    if (matched_kf_in_frm[frm_idx] >= 0) continue;
+                    const unsigned d = distance_32(kf_desc + (size_t)kf_idx * 32, frm_desc + (size_t)frm_idx * 32);
+                    if (d < best) {
+                        second = best;
+                        best = d;
+                        best_frm_idx = frm_idx;
+                    } else if (d < second) {
+                        second = d;
+                    }
+                }
+                if (OVO_HAMMING_DIST_THR_LOW < best) continue;
+                if (lowe_ratio * (float)second < (float)best) continue;
+                matched_kf_in_frm[best_frm_idx] = kf_idx;
+                if (check_orientation) ac.append(kf_angles[kf_idx] - frm_angles[best_frm_idx], best_frm_idx);
+                ++num_matches;
+            }
+            ++a;
+            ++b;
+        } else if (kf_node_ids[a] < frm_node_ids[b]) {
+            a = (int)(std::lower_bound(kf_node_ids + a, kf_node_ids + kf_nodes, frm_node_ids[b]) - kf_node_ids);
+        } else {
+            b = (int)(std::lower_bound(frm_node_ids + b, frm_node_ids + frm_nodes, kf_node_ids[a]) - frm_node_ids);
+        }
+    }
+    if (check_orientation) {
+        for (int invalid_idx : ac.invalid()) {
+            matched_kf_in_frm[invalid_idx] = -1;
+            --num_matches;
+        }
+    }
+    return num_matches;
+}
+
+// M6  stereo::compute(stereo_x_right, depths). Keypoints are cv::KeyPoint records (level-0 coordinates, octave); the two
+// pyramids are the extractors' image_pyramid_ (unblurred). Steps as upstream / ORB-SLAM2 ComputeStereoMatches:
+//   rows: right keypoint i is a candidate for every image row in [floor(y - 2 s_i), ceil(y + 2 s_i)], s_i = scale_factors[octave];
+//   per left keypoint: candidates of row (int)y_left with |octave difference| <= 1 and x_right in [x_left - max_disp, x_left],
+//     max_disp = focal_x_baseline / true_baseline; best Hamming with strict `<`, must be < (THR_HIGH + THR_LOW) / 2;
+//   sub-pixel: on the left keypoint's pyramid level, 11x11 windows (centre value subtracted from each window), L1 distance
+//     for the 11 shifts -5..+5 of the right window; reject a best shift at either end; parabola through the three distances
+//     around the minimum, |delta| <= 1; x_right = scale * (x_r_scaled + best_shift + delta); disparity in [0, max_disp),
+//     a non-positive disparity becomes 0.01; depth = focal_x_baseline / disparity;
+//   finally matches whose L1 distance is >= 2.1 x the median accepted distance (1.5 * 1.4) are dropped.
+int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr_right, const int32_t* level_rows,
+                       const int32_t* level_cols, const size_t* stride_left, const size_t* stride_right, int num_levels,
+                       const ovo_keypoint* kps_left, const uint8_t* desc_left, int n_left, const ovo_keypoint* kps_right,
+                       const uint8_t* desc_right, int n_right, const float* scale_factors, const float* inv_scale_factors,
+                       float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths) {
+    (void)num_levels;
+    const int rows0 = level_rows[0];
+    for (int i = 0; i < n_left; ++i) stereo_x_right[i] = depths[i] = -1.0f;
+    // get_right_keypoint_indices_in_each_row(margin = 2.0)
+    std::vector<std::vector<int>> in_row((size_t)rows0);
+    for (int i = 0; i < n_right; ++i) {
+        const float y = kps_right[i].y;
+        const float r = 2.0f * scale_factors[kps_right[i].octave];
+        const int max_r = cv_ceil(y + r), min_r = cv_floor(y - r);
+        for (int row = min_r; row <= max_r; ++row)
+            if (0 <= row && row < rows0) in_row[row].push_back(i);   // upstream relies on the 19-px extraction border instead of clamping
+    }
+    const float min_disp = 0.0f;
+    const float max_disp = focal_x_baseline / true_baseline;
+    const unsigned hamm_dist_thr = (OVO_HAMMING_DIST_THR_HIGH + OVO_HAMMING_DIST_THR_LOW) / 2;
+    std::vector<std::pair<int, int>> correlation_and_idx_left;
+    for (int il = 0; il < n_left; ++il) {
+        const ovo_keypoint& kl = kps_left[il];
+        const int level_l = kl.octave;
+        const float y_left = kl.y, x_left = kl.x;
+        const int row = (int)y_left;
+        if (row < 0 || row >= rows0) continue;
+        const std::vector<int>& cands = in_row[row];
+        if (cands.empty()) continue;
+        const float min_x_right = x_left - max_disp, max_x_right = x_left - min_disp;
+        if (max_x_right < 0) continue;
+        // find_closest_keypoints_in_stereo
+        unsigned best_dist = hamm_dist_thr;
+        int best_idx_right = 0;
+        for (int ir : cands) {
+            const ovo_keypoint& kr = kps_right[ir];
+            if (kr.octave < level_l - 1 || kr.octave > level_l + 1) continue;
+            if (kr.x < min_x_right || max_x_right < kr.x) continue;
+            const unsigned d = distance_32(desc_left + (size_t)il * 32, desc_right + (size_t)ir * 32);
+            if (d < best_dist) {
+                best_idx_right = ir;
+                best_dist = d;
+            }
+        }
+        if (hamm_dist_thr <= best_dist) continue;
+        // compute_subpixel_disparity
+        const ovo_keypoint& kr = kps_right[best_idx_right];
+        const float isf = inv_scale_factors[level_l];
+        const int sxl = cv_round(kl.x * isf), syl = cv_round(kl.y * isf), sxr = cv_round(kr.x * isf);
+        constexpr int w = 5, Lr = 5;
+        const int lc = level_cols[level_l], lr = level_rows[level_l];
+        const int ini_x = sxr - Lr - w, end_x = sxr + Lr + w + 1;
+        if (ini_x < 0 || lc <= end_x) continue;
+        if (syl - w < 0 || lr <= syl + w || sxl - w < 0 || lc <= sxl + w) continue;   // (cannot trigger for extractor output)
+        const uint8_t* IL = pyr_left[level_l];
+        const uint8_t* IR = pyr_right[level_l];
+        const size_t sl = stride_left[level_l], sr = stride_right[level_l];
+        const int cl = IL[(size_t)syl * sl + sxl];
+        int best_correlation = INT_MAX, best_offset = 0;
+        float correlations[2 * Lr + 1];
+        for (int offset = -Lr; offset <= Lr; ++offset) {
+            const int cr = IR[(size_t)syl * sr + sxr + offset];
+            int sad = 0;   // cv::norm(L1) of two float patches holding integers: exact
+            for (int dy = -w; dy <= w; ++dy)
+                for (int dx = -w; dx <= w; ++dx) {
+                    const int a = (int)IL[(size_t)(syl + dy) * sl + sxl + dx] - cl;
+                    const int b = (int)IR[(size_t)(syl + dy) * sr + sxr + offset + dx] - cr;
+                    sad += std::abs(a - b);
+                }
+            const float correlation = (float)sad;
+            if (correlation < (float)best_correlation) {
+                best_correlation = (int)correlation;
+                best_offset = offset;
+            }
+            correlations[Lr + offset] = correlation;
+        }
+        if (best_offset == -Lr || best_offset == Lr) continue;
+        const float c1 = correlations[Lr + best_offset - 1], c2 = correlations[Lr + best_offset], c3 = correlations[Lr + best_offset + 1];
+        const float delta = (c1 - c3) / (2.0f * (c1 + c3 - 2.0f * c2));
+        if (delta < -1.0f || 1.0f < delta) continue;   // the denominator is > 0: c1 > c2 (first strict minimum) and c3 >= c2
+        float best_x_right = scale_factors[level_l] * ((float)sxr + (float)best_offset + delta);
+        float disp = x_left - best_x_right;
+        if (disp < min_disp || max_disp <= disp) continue;
+        if (disp <= 0.0f) {
+            disp = 0.01f;
+            best_x_right = x_left - 0.01f;
+        }
+        depths[il] = focal_x_baseline / disp;
+        stereo_x_right[il] = best_x_right;
+        correlation_and_idx_left.emplace_back(best_correlation, il);
+    }
+    std::sort(correlation_and_idx_left.begin(), correlation_and_idx_left.end());
+    int n_ok = (int)correlation_and_idx_left.size();
+    if (!correlation_and_idx_left.empty()) {
+        const float median = (float)correlation_and_idx_left[correlation_and_idx_left.size() / 2].first;
+        const float thr = 2.1f * median;
+        for (int i = (int)correlation_and_idx_left.size() - 1; 0 <= i; --i) {
+            if ((float)correlation_and_idx_left[i].first < thr) break;
+            const int il = correlation_and_idx_left[i].second;
+            stereo_x_right[il] = -1.0f;
+            depths[il] = -1.0f;
+            --n_ok;
+        }
+    }
+    return n_ok;
+}
+
+}   // extern "C"

@@ -104,6 +104,44 @@ int ovo_robust_brute_force_match(const uint8_t* desc_frm, int n_frm, const uint8
 int ovo_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* t_valid,
                       int32_t* best_idx, uint16_t* best, uint16_t* second);
 
+/* ---- windowed matchers and their candidate generator (ovo_match2.cc) ---- */
+/* camera::base::img_bounds_ + num_grid_cols_/num_grid_rows_ (64 x 48 upstream). */
+typedef struct ovo_grid_params {
+    float min_x, min_y, max_x, max_y;
+    int32_t cols, rows;
+} ovo_grid_params;
+/* D1 assign_keypoints_to_grid as CSR: cell id = cx*rows + cy, cell_start[cols*rows+1], items = keypoint indices. Returns #items. */
+int ovo_assign_keypoints_to_grid(const ovo_grid_params* p, const float* xs, const float* ys, int n, int32_t* cell_start,
+                                 int32_t* items);
+/* D1 get_keypoints_in_cell, indices in upstream's order. Returns the count (<= cap written). */
+int ovo_get_keypoints_in_cell(const ovo_grid_params* p, const float* xs, const float* ys, const int32_t* octaves, int n, float ref_x,
+                              float ref_y, float margin, int min_level, int max_level, int32_t* out, int cap);
+/* match::angle_checker<int>: invalid[i] = 1 iff match i falls outside the 3 fullest of the 30 bins. */
+void ovo_angle_checker_invalid(const float* delta_angles, int n, uint8_t* invalid);
+/* M3 projection::match_frame_and_landmarks. assigned[l] = frame keypoint index or -1. Returns num_matches. */
+int ovo_projection_match_frame_and_landmarks(const ovo_grid_params* gp, const float* xs, const float* ys, const int32_t* octaves,
+                                             const float* stereo_x_right, const uint8_t* desc, const uint8_t* occupied, int n,
+                                             const float* lm_x, const float* lm_y, const float* lm_x_right, const int32_t* lm_level,
+                                             const uint8_t* lm_desc, const uint8_t* lm_valid, int m, const float* scale_factors,
+                                             float margin, float lowe_ratio, int32_t* assigned);
+/* M5 area::match_in_consistent_area. prev_matched_xy (n1 x 2) is updated in place; matched_2_in_1[n1]. Returns num_matches. */
+int ovo_area_match_in_consistent_area(const ovo_grid_params* gp, const int32_t* octaves_1, const float* angles_1,
+                                      const uint8_t* desc_1, int n1, const float* xs_2, const float* ys_2, const int32_t* octaves_2,
+                                      const float* angles_2, const uint8_t* desc_2, int n2, float* prev_matched_xy,
+                                      int32_t* matched_2_in_1, int margin, float lowe_ratio, int check_orientation);
+/* M7 bow_tree::match_frame_and_keyframe. Feature vectors as CSR over ascending node ids. matched_kf_in_frm[n_frm]. */
+int ovo_bow_match_frame_and_keyframe(const uint8_t* kf_desc, const float* kf_angles, const uint8_t* kf_valid, int n_kf,
+                                     const int32_t* kf_node_ids, const int32_t* kf_node_start, const int32_t* kf_items, int kf_nodes,
+                                     const uint8_t* frm_desc, const float* frm_angles, int n_frm, const int32_t* frm_node_ids,
+                                     const int32_t* frm_node_start, const int32_t* frm_items, int frm_nodes, float lowe_ratio,
+                                     int check_orientation, int32_t* matched_kf_in_frm);
+/* M6 stereo::compute. Pyramids = the two extractors' image_pyramid_ (unblurred). Returns the number of valid depths. */
+int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr_right, const int32_t* level_rows,
+                       const int32_t* level_cols, const size_t* stride_left, const size_t* stride_right, int num_levels,
+                       const ovo_keypoint* kps_left, const uint8_t* desc_left, int n_left, const ovo_keypoint* kps_right,
+                       const uint8_t* desc_right, int n_right, const float* scale_factors, const float* inv_scale_factors,
+                       float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths);
+
 #ifdef __cplusplus
 }
 #endif

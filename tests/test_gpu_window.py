@@ -1,0 +1,128 @@
+"""GPU parity: the grid candidate generator (D1) and the windowed matchers (M3 projection::match_frame_and_landmarks, M5
+area::match_in_consistent_area, M7 bow_tree::match_frame_and_keyframe, angle_checker) through the C ABI == CPU oracle, exactly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def match():
+    from openvslam_amd import match
+    return match
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from openvslam_amd import synth
+    return synth
+
+
+@pytest.mark.parametrize("n,rows,cols", [(4000, 1920, 3840), (1000, 480, 752), (1, 480, 752), (0, 480, 752), (2500, 376, 1241)])
+def test_assign_keypoints_to_grid(match, synth, oracle, n, rows, cols):
+    k, _ = synth.synth_keypoints(n, rows, cols, seed=n + 1)
+    if n > 10:   # keypoints outside the image bounds fall in no cell; some exactly on cell borders (cvRound ties)
+        k["x"][:5] = [-3.0, cols + 7.0, cols / 64 * 2.5, cols / 64 * 3.5, 0.0]
+        k["y"][:5] = [10.0, 10.0, rows / 48 * 0.5, rows / 48 * 1.5, rows + 1.0]
+    gp = match.grid_params(cols, rows)
+    w = match.projection(0.8, False, max_targets=4096, max_queries=16)
+    start, items = w.assign_keypoints_to_grid(gp, k)
+    want_start, want_items = oracle.assign_keypoints_to_grid(oracle.grid_params(cols, rows), k)
+    assert np.array_equal(start, want_start) and np.array_equal(items, want_items)
+
+
+@pytest.mark.parametrize("n,m,rows,cols,stereo", [(4000, 10000, 1920, 3840, False), (2000, 3000, 1080, 1920, True), (300, 50, 480, 752, False),
+                                                 (5, 2000, 480, 752, True)])
+@pytest.mark.parametrize("ratio", [0.8, 0.6])
+def test_projection_match_frame_and_landmarks(match, synth, oracle, n, m, rows, cols, stereo, ratio):
+    """BASELINE config 4 geometry (3840x1920 / 4000 keypoints / 10 000 landmarks, margin 5) and smaller / stereo cases."""
+    k, d = synth.synth_keypoints(n, rows, cols, seed=11 * n + m)
+    lm = synth.synth_landmarks(k, d, m, rows, cols, seed=m, n_from_frame=min(m, int(1.3 * n)), with_stereo=stereo)
+    rng = np.random.default_rng(m)
+    sf = np.cumprod(np.concatenate([[1.0], np.full(7, 1.2)]).astype(np.float32)).astype(np.float32)
+    occ = (rng.random(n) < 0.1).astype(np.uint8)
+    xr = None
+    if stereo:   # some keypoints carry a right-image x; landmarks derived from them mostly agree
+        xr = np.where(rng.random(n) < 0.7, k["x"] - rng.uniform(2, 60, n), -1.0).astype(np.float32)
+        from_frame = lm["src"] >= 0
+        agree = from_frame & (rng.random(m) < 0.8)
+        lm["x_right"][agree] = xr[lm["src"][agree]] + rng.normal(0, 1.5, int(agree.sum())).astype(np.float32)
+    gp, ogp = match.grid_params(cols, rows), oracle.grid_params(cols, rows)
+    w = match.projection(ratio, True, max_targets=4096, max_queries=10240)
+    for margin in (5.0, 15.0):
+        got, gn = w.match_frame_and_landmarks(gp, k, d, sf, lm["xy"], lm["level"], lm["desc"], margin, frm_stereo_x_right=xr,
+                                              frm_occupied=occ, lm_x_right=lm.get("x_right"), lm_valid=lm["valid"])
+        want, wn = oracle.projection_match_frame_and_landmarks(ogp, k, d, sf, lm["xy"], lm["level"], lm["desc"], margin, ratio,
+                                                               frm_stereo_x_right=xr, frm_occupied=occ, lm_x_right=lm.get("x_right"),
+                                                               lm_valid=lm["valid"])
+        assert gn == wn and np.array_equal(got, want)
+        if n >= 2000:
+            assert wn > n // 4   # the construction yields real matches and real collisions
+            assigned = want[want >= 0]
+            assert len(np.unique(assigned)) == len(assigned)
+
+
+def _two_frames(oracle, synth, rows=480, cols=752, nfeat=1000, shift=(5, 0)):
+    a = synth.synth_frame(rows, cols, seed=21)
+    b = synth.synth_frame(rows, cols, seed=21, shift=shift, noise_seed=77)
+    ox = oracle.OrbExtractor(oracle.make_params(nfeat))
+    ka, da = ox.extract(a)
+    kb, db = ox.extract(b)
+    return ka, da, kb, db
+
+
+@pytest.mark.parametrize("check_orientation", [True, False])
+@pytest.mark.parametrize("ratio,margin", [(0.9, 100), (0.7, 30), (1.0, 200)])
+def test_area_match_in_consistent_area(match, synth, oracle, check_orientation, ratio, margin):
+    """BASELINE config 1: 752x480, 1000 features, initialisation matcher with margin 100 between two frames 5 px apart."""
+    ka, da, kb, db = _two_frames(oracle, synth)
+    gp, ogp = match.grid_params(752, 480), oracle.grid_params(752, 480)
+    w = match.area(ratio, check_orientation, max_targets=2048, max_queries=2048)
+    prev_g = np.ascontiguousarray(np.stack([ka["x"], ka["y"]], 1), np.float32)
+    prev_o = prev_g.copy()
+    for it in range(2):   # second call starts from the updated prev_matched_pts, as module::initializer does
+        gn, got = w.match_in_consistent_area(gp, ka, da, kb, db, prev_g, margin)
+        wn, want = oracle.area_match_in_consistent_area(ogp, ka, da, kb, db, prev_o, margin, ratio, check_orientation)
+        assert gn == wn and np.array_equal(got, want) and np.array_equal(prev_g.view(np.uint32), prev_o.view(np.uint32))
+    assert wn > 50
+    assert (ka["octave"][want >= 0] == 0).all()
+
+
+def test_area_steals_and_orientation(match, synth, oracle):
+    """Many near-duplicate level-0 descriptors in a small area: later queries steal targets from earlier ones, and the
+    orientation histogram (entries of stolen matches stay in it) removes the off-mode matches."""
+    rng = np.random.default_rng(5)
+    n = 400
+    k1, _ = synth.synth_keypoints(n, 480, 752, seed=3)
+    k1["octave"] = 0
+    k1["x"] = rng.uniform(100, 300, n).astype(np.float32)
+    k1["y"] = rng.uniform(100, 300, n).astype(np.float32)
+    k2 = k1.copy()
+    k2["x"] += rng.normal(0, 3, n).astype(np.float32)
+    k2["angle"] = np.where(rng.random(n) < 0.7, k1["angle"] + rng.normal(0, 4, n), rng.uniform(0, 360, n)).astype(np.float32) % 360
+    base = rng.integers(0, 256, size=(40, 32), dtype=np.uint8)
+    d1 = np.stack([synth.flip_bits(rng, base[i % 40], 14) for i in range(n)])
+    d2 = np.stack([synth.flip_bits(rng, base[i % 40], 14) for i in range(n)])
+    gp, ogp = match.grid_params(752, 480), oracle.grid_params(752, 480)
+    for ratio in (0.9, 1.0):
+        for co in (True, False):
+            w = match.area(ratio, co, max_targets=512, max_queries=512)
+            pg = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], 1), np.float32)
+            po = pg.copy()
+            gn, got = w.match_in_consistent_area(gp, k1, d1, k2, d2, pg, 60)
+            wn, want = oracle.area_match_in_consistent_area(ogp, k1, d1, k2, d2, po, 60, ratio, co)
+            assert gn == wn and np.array_equal(got, want) and np.array_equal(pg, po)
+
+
+@pytest.mark.parametrize("check_orientation", [True, False])
+@pytest.mark.parametrize("ratio", [0.75, 0.6])
+def test_bow_match_frame_and_keyframe(match, synth, oracle, check_orientation, ratio):
+    ka, da, kb, db = _two_frames(oracle, synth, shift=(3, 2))
+    fa, fb = synth.synth_bow(da, seed=1, n_nodes=120), synth.synth_bow(db, seed=1, n_nodes=120)
+    fb.pop(sorted(fb)[3])   # node present on one side only: exercises the lower_bound skips
+    has_lm = (np.random.default_rng(2).random(len(ka)) < 0.85).astype(np.uint8)
+    w = match.bow_tree(ratio, check_orientation, max_targets=2048, max_queries=2048)
+    gn, got = w.match_frame_and_keyframe(ka, da, fa, kb, db, fb, has_lm)
+    wn, want = oracle.bow_match_frame_and_keyframe(ka, da, fa, kb, db, fb, ratio, check_orientation, has_lm)
+    assert gn == wn and np.array_equal(got, want)
+    assert wn > 30
