@@ -234,6 +234,30 @@ ovs_status ovs_bow_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_keypoint*
                                             int32_t check_orientation, int32_t* matched_kf_in_frm, int32_t* num_matches);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Stereo matcher.  replaces: match::stereo (src/openvslam/match/stereo.{h,cc}): the ctor's image pyramids are the two
+ * extractors' image_pyramid_ members, which here never leave HBM -- the context reads the pyramids of the LAST extract of the
+ * two ovs_orb handles (same device, same image size).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ovs_stereo ovs_stereo;
+ovs_status ovs_stereo_create(int32_t max_rows, int32_t max_keypoints, int32_t device, ovs_stereo** out);
+ovs_status ovs_stereo_destroy(ovs_stereo* s);
+/* replaces: void stereo::compute(std::vector<float>& stereo_x_right, std::vector<float>& depths) const.
+ * kps_* / desc_* = the keypoints and descriptors the two handles extracted (frame 0 of their last extract);
+ * focal_x_baseline / true_baseline = camera->focal_x_baseline_ / true_baseline_. stereo_x_right / depths: n_left floats, -1 where
+ * no match. *n_valid (may be NULL) = number of keypoints that received a depth. */
+ovs_status ovs_stereo_compute(ovs_stereo* s, const ovs_orb* left, const ovs_orb* right, const ovs_keypoint* kps_left,
+                              const uint8_t* desc_left, int32_t n_left, const ovs_keypoint* kps_right, const uint8_t* desc_right,
+                              int32_t n_right, float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths,
+                              int32_t* n_valid);
+/* Device-resident form: keypoints / descriptors are the extractors' device outputs (frame_left / frame_right of their last batched
+ * extract), d_n_left / d_n_right their device counts (NULL: use cap_left / cap_right as the counts). Asynchronous on `stream`. */
+ovs_status ovs_stereo_compute_dev(ovs_stereo* s, const ovs_orb* left, int32_t frame_left, const ovs_orb* right, int32_t frame_right,
+                                  const ovs_keypoint* d_kps_left, const uint8_t* d_desc_left, const int32_t* d_n_left, int32_t cap_left,
+                                  const ovs_keypoint* d_kps_right, const uint8_t* d_desc_right, const int32_t* d_n_right, int32_t cap_right,
+                                  float focal_x_baseline, float true_baseline, float* d_stereo_x_right, float* d_depths,
+                                  int32_t* d_n_valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Local bundle adjustment: residual + Jacobian + normal-equation blocks (one Levenberg-Marquardt linearisation).
  * replaces: the computeError / linearizeOplus / constructQuadraticForm loop g2o runs inside
  * optimize::local_bundle_adjuster::optimize (src/openvslam/optimize/local_bundle_adjuster.cc; edge math in

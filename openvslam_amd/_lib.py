@@ -66,6 +66,10 @@ SYMBOLS = {
     "ovs_area_match_in_consistent_area_dev": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _f, _i32, _vp, _vp]),
     "ovs_bow_match_frame_and_keyframe": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _f, _i32,
                                                 _vp, C.POINTER(_i32)]),
+    "ovs_stereo_create": (_i32, [_i32, _i32, _i32, C.POINTER(_vp)]),
+    "ovs_stereo_destroy": (_i32, [_vp]),
+    "ovs_stereo_compute": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _f, _f, _vp, _vp, C.POINTER(_i32)]),
+    "ovs_stereo_compute_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _f, _f, _vp, _vp, _vp, _vp]),
 }
 
 

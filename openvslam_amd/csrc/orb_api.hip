@@ -237,6 +237,30 @@ ovs_status run_extract(ovs_orb* h, const uint8_t* d_images, int batch, int rows,
 
 }   // namespace
 
+namespace ovs {
+bool orb_pyramid_view(const ovs_orb* h, int frame, PyrView* out) {
+    if (!h || !out || !h->last_img0 || frame < 0 || frame >= h->last_batch) return false;
+    const int L = h->geo.num_levels;
+    out->num_levels = L;
+    for (int l = 0; l < L; ++l) {
+        const LevelGeo& g = h->geo.lv[l];
+        if (l == 0) {
+            out->base[0] = h->last_img0 + (size_t)frame * h->last_frame_stride0;
+            out->pitch[0] = (int32_t)h->last_stride0;
+        } else {
+            out->base[l] = h->d.pyr + (size_t)frame * h->d.pyr_frame_bytes + g.plane_off;
+            out->pitch[l] = g.pitch;
+        }
+        out->rows[l] = g.rows;
+        out->cols[l] = g.cols;
+        out->scale[l] = h->sf[l];
+        out->inv_scale[l] = h->isf[l];
+    }
+    return true;
+}
+int orb_device(const ovs_orb* h) { return h ? h->device : -1; }
+}   // namespace ovs
+
 extern "C" {
 
 const char* ovs_last_error(void) { return g_last_error.c_str(); }

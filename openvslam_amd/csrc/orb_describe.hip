@@ -31,6 +31,7 @@ constexpr int kBlurW = 37;       // 2*18+1 (columns of the row-blurred patch tha
 constexpr int kBlurR = 18;
 constexpr int kPatchPitch = 64;   // bytes: one aligned 64-byte window of each image row
 constexpr int kHbPitch = 40;      // u16 per row of the row-blurred patch (37 used)
+static_assert(kBlurW <= kHbPitch && kBlurW + 6 == kPatch, "blur window geometry");
 
 // cv::fastAtan2 (scalar form), degrees in [0, 360). Every operation individually rounded (no FMA contraction).
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {

@@ -92,6 +92,18 @@ hipError_t launch_describe(const FrameGeo& hgeo, const DevBuffers& d, const uint
 
 void set_last_error(const char* what, hipError_t e);
 
+// Device view of one frame's image pyramid (feature::orb_extractor::image_pyramid_) of an extractor's LAST extract.
+struct PyrView {
+    const uint8_t* base[OVS_MAX_LEVELS];
+    int32_t pitch[OVS_MAX_LEVELS];
+    int32_t rows[OVS_MAX_LEVELS], cols[OVS_MAX_LEVELS];
+    float scale[OVS_MAX_LEVELS], inv_scale[OVS_MAX_LEVELS];
+    int32_t num_levels;
+};
+// false if the handle has not extracted yet or `frame` is outside its last batch
+bool orb_pyramid_view(const ovs_orb* h, int frame, PyrView* out);
+int orb_device(const ovs_orb* h);
+
 // Stage timer for bench.py: HIP events recorded on the launch stream at stage boundaries; a small ring of call slots.
 template <int NSTAGE>
 struct StageProfiler {

@@ -200,3 +200,40 @@ class bow_tree(_window_ctx):
                                                             int(self.check_orientation_), _p(out), C.byref(n)),
                    "ovs_bow_match_frame_and_keyframe")
         return n.value, out[:len(fk)].copy()
+
+
+class stereo:
+    """match::stereo(left_image_pyramid, right_image_pyramid, keypts_left, keypts_right, descs_left, descs_right, scale_factors,
+    inv_scale_factors, focal_x_baseline, true_baseline). The pyramids and scale tables are those of the two extractors' last extract
+    (they stay in HBM), so the ctor takes the extractors."""
+
+    def __init__(self, extractor_left, extractor_right, keypts_left, descs_left, keypts_right, descs_right, focal_x_baseline, true_baseline,
+                 max_rows=2048, max_keypoints=8192, device=0):
+        self._L = _lib.lib()
+        _lib.require_device()
+        h = C.c_void_p()
+        _lib.check(self._L.ovs_stereo_create(max_rows, max_keypoints, device, C.byref(h)), "ovs_stereo_create")
+        self._h = h
+        self._el, self._er = extractor_left, extractor_right
+        self._kl = np.ascontiguousarray(keypts_left, KP_DTYPE)
+        self._kr = np.ascontiguousarray(keypts_right, KP_DTYPE)
+        self._dl = np.ascontiguousarray(descs_left, np.uint8).reshape(-1, 32)
+        self._dr = np.ascontiguousarray(descs_right, np.uint8).reshape(-1, 32)
+        self.focal_x_baseline_, self.true_baseline_ = float(focal_x_baseline), float(true_baseline)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.ovs_stereo_destroy(self._h)
+            self._h = None
+
+    def compute(self):
+        """stereo::compute(stereo_x_right, depths): returns (stereo_x_right, depths), -1 where a keypoint has no stereo match."""
+        n = len(self._kl)
+        xr = np.full(max(n, 1), -1, np.float32)
+        dp = np.full(max(n, 1), -1, np.float32)
+        nv = C.c_int32()
+        _lib.check(self._L.ovs_stereo_compute(self._h, self._el._h, self._er._h, _p(self._kl), _p(self._dl), n, _p(self._kr), _p(self._dr),
+                                              len(self._kr), self.focal_x_baseline_, self.true_baseline_, _p(xr), _p(dp), C.byref(nv)),
+                   "ovs_stereo_compute")
+        self.num_valid_ = nv.value
+        return xr[:n].copy(), dp[:n].copy()

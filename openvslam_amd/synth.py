@@ -193,3 +193,23 @@ def synth_bow(desc, seed=0, n_nodes=200):
     for i, nd in enumerate(node):
         fv.setdefault(int(nd), []).append(i)
     return fv
+
+
+def synth_stereo_pair(rows=376, cols=1241, seed=0, d_min=4.0, d_max=60.0, noise_sigma=2.0):
+    """BASELINE config 3 input: a rectified pair. The right image sees, at column x, the scene point the left
+    image shows at x + d(y): the disparity varies smoothly with the row inside [d_min, d_max] px (fractional, so the sub-pixel
+    refinement has something to find); each image gets its own pixel noise. Returns (left, right, disparity_per_row)."""
+    pad = int(np.ceil(d_max)) + 4
+    scene = synth_scene(rows, cols + pad, seed)
+    rng = np.random.Generator(np.random.PCG64(seed * 7919 + 13))
+    y = np.arange(rows)
+    d = d_min + (d_max - d_min) * (0.5 + 0.5 * np.sin(2 * np.pi * 1.5 * y / rows))
+    x = np.arange(cols)[None, :] + d[:, None]
+    x0 = np.floor(x).astype(np.int64)
+    f = (x - x0).astype(np.float32)
+    rowsel = y[:, None]
+    right = scene[rowsel, x0] * (1 - f) + scene[rowsel, x0 + 1] * f
+    left = scene[:rows, :cols]
+    left = np.clip(np.rint(left + rng.normal(0, noise_sigma, left.shape)), 0, 255).astype(np.uint8)
+    right = np.clip(np.rint(right + rng.normal(0, noise_sigma, right.shape)), 0, 255).astype(np.uint8)
+    return left, right, d.astype(np.float32)

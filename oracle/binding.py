@@ -331,6 +331,32 @@ def bow_match_frame_and_keyframe(kf_kps, kf_desc, kf_feat_vec, frm_kps, frm_desc
     return n, out[:len(fa)].copy()
 
 
+def stereo_compute(ox_left, ox_right, kps_left, desc_left, kps_right, desc_right, focal_x_baseline, true_baseline):
+    """stereo::compute on the pyramids of two OrbExtractor instances (their last extract). Returns (stereo_x_right, depths, n_valid)."""
+    L = lib()
+    tabs = orb_tables(ox_left.params)
+    nl = ox_left.params.num_levels
+    imgs_l = [np.ascontiguousarray(ox_left.level_image(l)) for l in range(nl)]
+    imgs_r = [np.ascontiguousarray(ox_right.level_image(l)) for l in range(nl)]
+    pl = (C.c_void_p * nl)(*[a.ctypes.data for a in imgs_l])
+    pr = (C.c_void_p * nl)(*[a.ctypes.data for a in imgs_r])
+    rows = np.array([a.shape[0] for a in imgs_l], np.int32)
+    cols = np.array([a.shape[1] for a in imgs_l], np.int32)
+    sl = (C.c_size_t * nl)(*[a.shape[1] for a in imgs_l])
+    sr = (C.c_size_t * nl)(*[a.shape[1] for a in imgs_r])
+    kl = np.ascontiguousarray(kps_left, KP_DTYPE)
+    kr = np.ascontiguousarray(kps_right, KP_DTYPE)
+    dl = np.ascontiguousarray(desc_left, np.uint8).reshape(-1, 32)
+    dr = np.ascontiguousarray(desc_right, np.uint8).reshape(-1, 32)
+    sf = np.ascontiguousarray(tabs["scale_factors"], np.float32)
+    isf = np.ascontiguousarray(tabs["inv_scale_factors"], np.float32)
+    xr = np.full(max(len(kl), 1), -1, np.float32)
+    dp = np.full(max(len(kl), 1), -1, np.float32)
+    n = L.ovo_stereo_compute(pl, pr, _p(rows), _p(cols), sl, sr, nl, _p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), _p(sf), _p(isf),
+                             C.c_float(focal_x_baseline), C.c_float(true_baseline), _p(xr), _p(dp))
+    return xr[:len(kl)].copy(), dp[:len(kl)].copy(), n
+
+
 BA_EDGE_DTYPE = np.dtype([("pose_idx", "<i4"), ("point_idx", "<i4"), ("obs_x", "<f8"), ("obs_y", "<f8"), ("inv_sigma_sq", "<f8")])
 
 

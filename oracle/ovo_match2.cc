@@ -333,7 +333,8 @@ int ovo_bow_match_frame_and_keyframe(const uint8_t* kf_desc, const float* kf_ang
 //     for the 11 shifts -5..+5 of the right window; reject a best shift at either end; parabola through the three distances
 //     around the minimum, |delta| <= 1; x_right = scale * (x_r_scaled + best_shift + delta); disparity in [0, max_disp),
 //     a non-positive disparity becomes 0.01; depth = focal_x_baseline / disparity;
-//   finally matches whose L1 distance is >= 2.1 x the median accepted distance (1.5 * 1.4) are dropped.
+//   finally matches whose L1 distance exceeds 2 x the median accepted distance are dropped (ORACLE_SPEC rule 20: upstream's
+//   factor is recalled as 2.0 with a strict comparison; ORB-SLAM2 used 1.5 * 1.4 = 2.1).
 int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr_right, const int32_t* level_rows,
                        const int32_t* level_cols, const size_t* stride_left, const size_t* stride_right, int num_levels,
                        const ovo_keypoint* kps_left, const uint8_t* desc_left, int n_left, const ovo_keypoint* kps_right,
@@ -429,13 +430,13 @@ int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr
     int n_ok = (int)correlation_and_idx_left.size();
     if (!correlation_and_idx_left.empty()) {
         const float median = (float)correlation_and_idx_left[correlation_and_idx_left.size() / 2].first;
-        const float thr = 2.1f * median;
-        for (int i = (int)correlation_and_idx_left.size() - 1; 0 <= i; --i) {
-            if ((float)correlation_and_idx_left[i].first < thr) break;
-            const int il = correlation_and_idx_left[i].second;
-            stereo_x_right[il] = -1.0f;
-            depths[il] = -1.0f;
-            --n_ok;
+        const float thr = 2.0f * median;
+        for (const auto& ci : correlation_and_idx_left) {
+            if (thr < (float)ci.first) {
+                stereo_x_right[ci.second] = -1.0f;
+                depths[ci.second] = -1.0f;
+                --n_ok;
+            }
         }
     }
     return n_ok;
