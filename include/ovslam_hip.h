@@ -207,6 +207,31 @@ ovs_status ovs_projection_match_frame_and_landmarks_dev(ovs_wmatcher* w, const o
                                                         int32_t m, const float* scale_factors, int32_t num_levels, float margin,
                                                         float lowe_ratio, int32_t* d_assigned, int32_t* d_num_matches, void* stream);
 
+/* camera::base subset needed by the matchers that reproject inside the call. model: 0 = perspective, 1 = equirectangular
+ * (camera::model_type_t); setup: 0 = Monocular, 1 = Stereo, 2 = RGBD (camera::setup_type_t). */
+typedef struct ovs_camera {
+    int32_t model, setup;
+    double fx, fy, cx, cy;
+    double focal_x_baseline, true_baseline;
+    int32_t cols, rows;
+} ovs_camera;
+
+/* replaces: unsigned int projection::match_current_and_last_frames(data::frame& curr_frm, const data::frame& last_frm,
+ *                                                                  const float margin) const.
+ * pose_cw_* = frm.cam_pose_cw_ as 12 doubles (rotation row-major, then translation). curr_*: undist_keypts_, descriptors_,
+ * stereo_x_right_ (or NULL), occupied as in match_frame_and_landmarks. last_kps = last_frm.undist_keypts_; last_pos_w[i] =
+ * landmarks_[i]->get_pos_in_world(), last_lm_desc[i] = landmarks_[i]->get_descriptor(), last_valid[i] != 0 iff landmarks_[i] &&
+ * !outlier_flags_[i] (rows of invalid entries are ignored). assigned[i] = current keypoint that receives last_frm.landmarks_[i]
+ * (curr_frm.landmarks_[assigned[i]] = lm) or -1. camera::reproject_to_image runs on the device in double precision
+ * (perspective: exact parity with the CPU oracle; equirectangular: asin/atan2 are the device library's). */
+ovs_status ovs_projection_match_current_and_last_frames(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp,
+                                                        const ovs_keypoint* curr_kps, const uint8_t* curr_desc,
+                                                        const float* curr_stereo_x_right, const uint8_t* curr_occupied, int32_t n_curr,
+                                                        const double* pose_cw_curr, const ovs_keypoint* last_kps, const double* last_pos_w,
+                                                        const uint8_t* last_lm_desc, const uint8_t* last_valid, int32_t n_last,
+                                                        const double* pose_cw_last, const float* scale_factors, int32_t num_levels,
+                                                        float margin, int32_t check_orientation, int32_t* assigned, int32_t* num_matches);
+
 /* replaces: unsigned int area::match_in_consistent_area(data::frame& frm_1, data::frame& frm_2,
  *               std::vector<cv::Point2f>& prev_matched_pts, std::vector<int>& matched_indices_2_in_frm_1, int margin).
  * kps_i / desc_i = frm_i.undist_keypts_ / descriptors_; gp = frm_2's camera grid. prev_matched_xy (n1 x 2) is updated in

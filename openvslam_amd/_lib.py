@@ -66,11 +66,19 @@ SYMBOLS = {
     "ovs_area_match_in_consistent_area_dev": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _f, _i32, _vp, _vp]),
     "ovs_bow_match_frame_and_keyframe": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _f, _i32,
                                                 _vp, C.POINTER(_i32)]),
+    "ovs_projection_match_current_and_last_frames": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
+                                                            _i32, _f, _i32, _vp, C.POINTER(_i32)]),
     "ovs_stereo_create": (_i32, [_i32, _i32, _i32, C.POINTER(_vp)]),
     "ovs_stereo_destroy": (_i32, [_vp]),
     "ovs_stereo_compute": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _f, _f, _vp, _vp, C.POINTER(_i32)]),
     "ovs_stereo_compute_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _f, _f, _vp, _vp, _vp, _vp]),
 }
+
+
+class Camera(C.Structure):
+    """camera::base subset (ovs_camera). model: 0 perspective, 1 equirectangular; setup: 0 mono, 1 stereo, 2 RGBD."""
+    _fields_ = [("model", C.c_int32), ("setup", C.c_int32), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("focal_x_baseline", C.c_double), ("true_baseline", C.c_double), ("cols", C.c_int32), ("rows", C.c_int32)]
 
 
 class GridParams(C.Structure):

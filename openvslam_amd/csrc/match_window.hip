@@ -117,7 +117,7 @@ __global__ __launch_bounds__(1024) void k_grid_assign(const ovs_keypoint* __rest
 }
 
 // ---- 2. candidate lists ---------------------------------------------------------------------------------------------------
-enum { kModeProjection = 0, kModeArea = 1 };
+enum { kModeProjection = 0, kModeArea = 1, kModeGeneric = 2 };
 
 struct WinArgs {
     // targets: the frame whose grid is searched
@@ -135,6 +135,9 @@ struct WinArgs {
     const int32_t* q_level;      // projection: scale_level_in_tracking_
     const uint8_t* q_valid;      // projection: is_observable_in_tracking_ && !will_be_erased()
     const ovs_keypoint* q_kps;   // area: frame-1 undistorted keypoints
+    const float* q_radius;       // generic: search radius, level window (filled by k_reproject_queries)
+    const int32_t* q_minl;
+    const int32_t* q_maxl;
     const uint8_t* q_desc;
     float margin;
     float sf[OVS_MAX_LEVELS];
@@ -154,6 +157,10 @@ __global__ __launch_bounds__(256) void k_window_lists(WinArgs a, uint32_t* __res
         r = __fmul_rn(a.margin, a.sf[lvl]);
         minl = lvl - 1;
         maxl = lvl;
+    } else if (a.mode == kModeGeneric) {
+        r = a.q_radius[q];
+        minl = a.q_minl[q];
+        maxl = a.q_maxl[q];
     } else {
         const int lvl = a.q_kps[q].octave;
         if (0 < lvl) valid = false;   // "only level-0 keypoints"
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(256) void k_window_lists(WinArgs a, uint32_t* __res
                         const ovs_keypoint kp = a.t_kps[idx];
                         if (check_level && (kp.octave < minl || (0 <= maxl && maxl < kp.octave))) continue;
                         if (!(fabsf(__fsub_rn(kp.x, ref_x)) < r && fabsf(__fsub_rn(kp.y, ref_y)) < r)) continue;
-                        if (a.mode == kModeProjection) {
+                        if (a.mode != kModeArea) {
                             if (a.t_occupied && a.t_occupied[idx]) continue;
                             if (a.t_x_right) {
                                 const float xr = a.t_x_right[idx];
@@ -207,6 +214,63 @@ __global__ __launch_bounds__(256) void k_window_lists(WinArgs a, uint32_t* __res
         }
     }
     if (!FILL) counts[q] = n;
+}
+
+// camera::perspective / camera::equirectangular ::reproject_to_image in double precision, one rounding per operation (the library
+// is built with -ffp-contract=off), same operation order as the oracle.
+struct CamP {
+    int32_t model, setup;
+    double fx, fy, cx, cy, fxb;
+    int32_t cols, rows;
+    float min_x, min_y, max_x, max_y;
+    double P[12];   // rot_cw row-major, trans_cw
+};
+
+__device__ __forceinline__ bool reproject_to_image(const CamP& c, const double* __restrict__ X, double& u, double& v, float& x_right) {
+    const double pcx = (c.P[0] * X[0] + c.P[1] * X[1]) + c.P[2] * X[2] + c.P[9];
+    const double pcy = (c.P[3] * X[0] + c.P[4] * X[1]) + c.P[5] * X[2] + c.P[10];
+    const double pcz = (c.P[6] * X[0] + c.P[7] * X[1]) + c.P[8] * X[2] + c.P[11];
+    if (c.model == 0) {
+        if (pcz <= 0.0) return false;
+        const double z_inv = 1.0 / pcz;
+        u = c.fx * pcx * z_inv + c.cx;
+        v = c.fy * pcy * z_inv + c.cy;
+        x_right = (float)(u - c.fxb * z_inv);
+        if (u < c.min_x || u > c.max_x) return false;
+        if (v < c.min_y || v > c.max_y) return false;
+        return true;
+    }
+    const double norm = sqrt((pcx * pcx + pcy * pcy) + pcz * pcz);
+    const double bx = pcx / norm, by = pcy / norm, bz = pcz / norm;
+    const double latitude = -asin(by);
+    const double longitude = atan2(bx, bz);
+    u = c.cols * (0.5 + longitude / (2.0 * 3.14159265358979323846));
+    v = c.rows * (0.5 - latitude / 3.14159265358979323846);
+    x_right = -1.0f;
+    return true;
+}
+
+// match_current_and_last_frames: one lane per last-frame keypoint -> query (reprojection, radius, level window, validity)
+__global__ __launch_bounds__(256) void k_reproject_queries(CamP cam, const ovs_keypoint* __restrict__ last_kps,
+                                                          const double* __restrict__ pos_w, const uint8_t* __restrict__ last_valid, int n,
+                                                          float margin, const float* __restrict__ sf_dev, int num_levels, int forward,
+                                                          int backward, float* __restrict__ q_xy, float* __restrict__ q_x_right,
+                                                          float* __restrict__ q_radius, int32_t* __restrict__ q_minl,
+                                                          int32_t* __restrict__ q_maxl, uint8_t* __restrict__ q_valid) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    bool valid = !last_valid || last_valid[i];
+    double u = 0, v = 0;
+    float xr = -1.0f;
+    if (valid) valid = reproject_to_image(cam, pos_w + 3 * (size_t)i, u, v, xr);
+    const int lvl = last_kps[i].octave;
+    q_xy[2 * i] = (float)u;
+    q_xy[2 * i + 1] = (float)v;
+    q_x_right[i] = xr;
+    q_radius[i] = __fmul_rn(margin, sf_dev[lvl]);
+    q_minl[i] = forward ? lvl : (backward ? 0 : lvl - 1);
+    q_maxl[i] = forward ? num_levels - 1 : (backward ? lvl : lvl + 1);
+    q_valid[i] = valid ? 1 : 0;
 }
 
 // bow_tree: queries = the keyframe's feature-vector entries in walk order; the list of a query is its node's frame bucket
@@ -298,7 +362,7 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* __restrict
 }
 
 // ---- 3. sequential-claim resolver ---------------------------------------------------------------------------------------
-enum { kRuleProjection = 0, kRuleArea = 1, kRuleBow = 2 };
+enum { kRuleProjection = 0, kRuleArea = 1, kRuleBow = 2, kRuleBestOnly = 3 };
 
 struct ResolveArgs {
     const uint32_t* offsets;   // n_q + 1
@@ -319,6 +383,7 @@ __device__ __forceinline__ bool rule_accepts(uint32_t best, uint32_t second, flo
     if (best == kNone) return false;
     const uint32_t bd = best >> 20;
     const uint32_t sd = second == kNone ? (uint32_t)OVS_MAX_HAMMING_DIST : (second >> 20);
+    if (RULE == kRuleBestOnly) return bd <= (uint32_t)OVS_HAMMING_DIST_THR_HIGH;   // match_current_and_last_frames: no ratio test
     if (RULE == kRuleProjection) {
         if (bd > (uint32_t)OVS_HAMMING_DIST_THR_HIGH) return false;
         const int bl = (int)((best >> 16) & 15u), sl = second == kNone ? -1 : (int)((second >> 16) & 15u);
@@ -340,7 +405,7 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
     lds_u16* match = owner + ((a.n_t + 1) & ~1);                            // [n_q]  target of query (0xFFFF none)
     lds_u16* accepted = match + ((a.n_q + 1) & ~1);                         // [n_q]  target at acceptance time (orientation entries)
     const int lane = threadIdx.x;
-    const uint32_t max_d = RULE == kRuleProjection ? OVS_HAMMING_DIST_THR_HIGH : OVS_HAMMING_DIST_THR_LOW;
+    const uint32_t max_d = (RULE == kRuleProjection || RULE == kRuleBestOnly) ? OVS_HAMMING_DIST_THR_HIGH : OVS_HAMMING_DIST_THR_LOW;
     for (int i = lane; i < a.n_t; i += 64) {
         thr[i] = (uint16_t)OVS_MAX_HAMMING_DIST;
         owner[i] = 0xFFFFu;
@@ -521,6 +586,10 @@ struct ovs_wmatcher {
     float* d_q_xy = nullptr;
     float* d_q_f = nullptr;
     int32_t* d_q_i = nullptr;
+    float* d_q_r = nullptr;
+    int32_t* d_q_i2 = nullptr;
+    double* d_q_pos = nullptr;
+    float* d_sf = nullptr;
     int32_t* d_csr = nullptr;           // bow feature vectors: 2 x (ids | start | items)
     size_t csr_cap = 0;
 };
@@ -629,6 +698,10 @@ ovs_status ovs_wmatcher_create(int32_t max_targets, int32_t max_queries, int32_t
     CREATE_TRY(hipMalloc(&w->d_q_xy, sizeof(float) * 2 * Q));
     CREATE_TRY(hipMalloc(&w->d_q_f, sizeof(float) * Q));
     CREATE_TRY(hipMalloc(&w->d_q_i, sizeof(int32_t) * Q));
+    CREATE_TRY(hipMalloc(&w->d_q_r, sizeof(float) * Q));
+    CREATE_TRY(hipMalloc(&w->d_q_i2, sizeof(int32_t) * Q));
+    CREATE_TRY(hipMalloc(&w->d_q_pos, sizeof(double) * 3 * Q));
+    CREATE_TRY(hipMalloc(&w->d_sf, sizeof(float) * OVS_MAX_LEVELS));
     w->csr_cap = 4 * (T + Q) + 16;
     CREATE_TRY(hipMalloc(&w->d_csr, sizeof(int32_t) * w->csr_cap));
 #undef CREATE_TRY
@@ -641,7 +714,7 @@ ovs_status ovs_wmatcher_destroy(ovs_wmatcher* w) {
     if (w->stream) hipStreamSynchronize(w->stream);
     void* ptrs[] = {w->d_cell_of, w->d_cell_start, w->d_items, w->d_counts, w->d_offsets, w->d_keys, w->d_overflow, w->d_assigned, w->d_num,
                     w->d_t_kps,   w->d_t_desc,     w->d_t_flag, w->d_t_f,    w->d_q_kps,   w->d_q_desc, w->d_q_flag,  w->d_q_xy,    w->d_q_f,
-                    w->d_q_i,     w->d_csr};
+                    w->d_q_i,     w->d_csr,        w->d_q_r,    w->d_q_i2,   w->d_q_pos,   w->d_sf};
     for (void* p : ptrs) hipFree(p);
     if (w->stream) hipStreamDestroy(w->stream);
     delete w;
@@ -910,6 +983,111 @@ ovs_status ovs_bow_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_keypoint*
     if (st != OVS_OK) return st;
     uint32_t overflow = 0;
     OVS_HIP_TRY(hipMemcpyAsync(matched_kf_in_frm, w->d_assigned, sizeof(int32_t) * n_frm, hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
+    return overflow ? OVS_ERR_CAPACITY : OVS_OK;
+}
+
+ovs_status ovs_projection_match_current_and_last_frames(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp,
+                                                        const ovs_keypoint* curr_kps, const uint8_t* curr_desc,
+                                                        const float* curr_stereo_x_right, const uint8_t* curr_occupied, int32_t n_curr,
+                                                        const double* pose_cw_curr, const ovs_keypoint* last_kps, const double* last_pos_w,
+                                                        const uint8_t* last_lm_desc, const uint8_t* last_valid, int32_t n_last,
+                                                        const double* pose_cw_last, const float* scale_factors, int32_t num_levels,
+                                                        float margin, int32_t check_orientation, int32_t* assigned, int32_t* num_matches) {
+    if (!w || !cam || !gp || !num_matches || n_curr < 0 || n_last < 0 || !pose_cw_curr || !pose_cw_last || !scale_factors || num_levels < 1 ||
+        num_levels > OVS_MAX_LEVELS || (cam->model != 0 && cam->model != 1))
+        return OVS_ERR_INVALID;
+    *num_matches = 0;
+    if (n_last == 0) return OVS_OK;
+    if (!assigned) return OVS_ERR_INVALID;
+    for (int i = 0; i < n_last; ++i) assigned[i] = -1;
+    if (n_curr == 0) return OVS_OK;
+    if (!curr_kps || !curr_desc || !last_kps || !last_pos_w || !last_lm_desc) return OVS_ERR_INVALID;
+    if (n_curr > w->max_t || n_last > w->max_q) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = w->stream;
+    // motion direction (host, double): trans_wc = -rot_cw^T trans_cw; trans_lc = rot_lw trans_wc + trans_lw
+    const double* Rc = pose_cw_curr;
+    const double* tc = pose_cw_curr + 9;
+    const double twc[3] = {-((Rc[0] * tc[0] + Rc[3] * tc[1]) + Rc[6] * tc[2]), -((Rc[1] * tc[0] + Rc[4] * tc[1]) + Rc[7] * tc[2]),
+                           -((Rc[2] * tc[0] + Rc[5] * tc[1]) + Rc[8] * tc[2])};
+    const double* Rl = pose_cw_last;
+    const double tlc_z = ((Rl[6] * twc[0] + Rl[7] * twc[1]) + Rl[8] * twc[2]) + pose_cw_last[11];
+    const int forward = cam->setup == 0 ? 0 : (tlc_z > cam->true_baseline);
+    const int backward = cam->setup == 0 ? 0 : (-tlc_z > cam->true_baseline);
+    CamP cp{};
+    cp.model = cam->model;
+    cp.setup = cam->setup;
+    cp.fx = cam->fx;
+    cp.fy = cam->fy;
+    cp.cx = cam->cx;
+    cp.cy = cam->cy;
+    cp.fxb = cam->focal_x_baseline;
+    cp.cols = cam->cols;
+    cp.rows = cam->rows;
+    cp.min_x = gp->min_x;
+    cp.min_y = gp->min_y;
+    cp.max_x = gp->max_x;
+    cp.max_y = gp->max_y;
+    std::memcpy(cp.P, pose_cw_curr, sizeof(double) * 12);
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, curr_kps, sizeof(ovs_keypoint) * n_curr, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, curr_desc, (size_t)32 * n_curr, hipMemcpyHostToDevice, s));
+    if (curr_stereo_x_right) OVS_HIP_TRY(hipMemcpyAsync(w->d_t_f, curr_stereo_x_right, sizeof(float) * n_curr, hipMemcpyHostToDevice, s));
+    if (curr_occupied) OVS_HIP_TRY(hipMemcpyAsync(w->d_t_flag, curr_occupied, (size_t)n_curr, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_kps, last_kps, sizeof(ovs_keypoint) * n_last, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_pos, last_pos_w, sizeof(double) * 3 * n_last, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, last_lm_desc, (size_t)32 * n_last, hipMemcpyHostToDevice, s));
+    uint8_t* d_last_valid = nullptr;
+    if (last_valid) {   // staged behind the query flags (the kernel writes q_valid in place: same index, read-then-write by one lane)
+        OVS_HIP_TRY(hipMemcpyAsync(w->d_q_flag, last_valid, (size_t)n_last, hipMemcpyHostToDevice, s));
+        d_last_valid = w->d_q_flag;
+    }
+    float sf16[OVS_MAX_LEVELS];
+    for (int l = 0; l < OVS_MAX_LEVELS; ++l) sf16[l] = l < num_levels ? scale_factors[l] : 1.0f;
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_sf, sf16, sizeof(sf16), hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));   // sf16 is a stack array
+    ovs_status st = grid_assign(w, gp, w->d_t_kps, n_curr, s);
+    if (st != OVS_OK) return st;
+    hipLaunchKernelGGL(k_reproject_queries, dim3((n_last + 255) / 256), dim3(256), 0, s, cp, (const ovs_keypoint*)w->d_q_kps,
+                       (const double*)w->d_q_pos, (const uint8_t*)d_last_valid, n_last, margin, (const float*)w->d_sf, num_levels, forward,
+                       backward, w->d_q_xy, w->d_q_f, w->d_q_r, w->d_q_i, w->d_q_i2, w->d_q_flag);
+    OVS_HIP_TRY(hipGetLastError());
+    WinArgs a{};
+    a.t_kps = w->d_t_kps;
+    a.t_desc = w->d_t_desc;
+    a.t_occupied = curr_occupied ? w->d_t_flag : nullptr;
+    a.t_x_right = curr_stereo_x_right ? w->d_t_f : nullptr;
+    a.cell_start = w->d_cell_start;
+    a.items = w->d_items;
+    a.gp = w->gp;
+    a.n_q = n_last;
+    a.q_xy = w->d_q_xy;
+    a.q_x_right = w->d_q_f;
+    a.q_valid = w->d_q_flag;
+    a.q_radius = w->d_q_r;
+    a.q_minl = w->d_q_i;
+    a.q_maxl = w->d_q_i2;
+    a.q_desc = w->d_q_desc;
+    a.margin = margin;
+    a.mode = kModeGeneric;
+    st = build_lists(w, a, n_last, k_window_lists<false>, k_window_lists<true>, s);
+    if (st != OVS_OK) return st;
+    ResolveArgs ra{};
+    ra.offsets = w->d_offsets;
+    ra.keys = w->d_keys;
+    ra.n_q = n_last;
+    ra.n_t = n_curr;
+    ra.check_orientation = check_orientation;
+    ra.q_kps = w->d_q_kps;
+    ra.t_kps = w->d_t_kps;
+    ra.assigned = w->d_assigned;
+    ra.num_matches = w->d_num;
+    st = launch_resolve<kRuleBestOnly>(ra, s);
+    if (st != OVS_OK) return st;
+    uint32_t overflow = 0;
+    OVS_HIP_TRY(hipMemcpyAsync(assigned, w->d_assigned, sizeof(int32_t) * n_last, hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipStreamSynchronize(s));

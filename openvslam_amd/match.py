@@ -150,6 +150,36 @@ class projection(_window_ctx):
         return assigned[:len(xy)].copy(), n.value
 
 
+    def match_current_and_last_frames(self, cam, gp, curr_keypts, curr_desc, pose_cw_curr, last_keypts, last_pos_w, last_lm_desc,
+                                      pose_cw_last, scale_factors, margin, curr_stereo_x_right=None, curr_occupied=None, last_valid=None):
+        """projection::match_current_and_last_frames(curr_frm, last_frm, margin): returns (assigned, num_matches); assigned[i] is the
+        current keypoint that receives last_frm.landmarks_[i], or -1. Poses are 3x4 [R|t] world->camera."""
+        ck = np.ascontiguousarray(curr_keypts, KP_DTYPE)
+        cd = np.ascontiguousarray(curr_desc, np.uint8).reshape(-1, 32)
+        lk = np.ascontiguousarray(last_keypts, KP_DTYPE)
+        pw = np.ascontiguousarray(last_pos_w, np.float64).reshape(-1, 3)
+        ld = np.ascontiguousarray(last_lm_desc, np.uint8).reshape(-1, 32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        pc = _pose12(pose_cw_curr)
+        pl = _pose12(pose_cw_last)
+        xr = None if curr_stereo_x_right is None else np.ascontiguousarray(curr_stereo_x_right, np.float32)
+        occ = None if curr_occupied is None else np.ascontiguousarray(curr_occupied, np.uint8)
+        val = None if last_valid is None else np.ascontiguousarray(last_valid, np.uint8)
+        assigned = np.full(max(len(lk), 1), -1, np.int32)
+        n = C.c_int32()
+        _lib.check(self._L.ovs_projection_match_current_and_last_frames(
+            self._h, C.byref(cam), C.byref(gp), _p(ck), _p(cd), _p(xr), _p(occ), len(ck), _p(pc), _p(lk), _p(pw), _p(ld), _p(val), len(lk),
+            _p(pl), _p(sf), len(sf), float(margin), int(self.check_orientation_), _p(assigned), C.byref(n)),
+            "ovs_projection_match_current_and_last_frames")
+        return assigned[:len(lk)].copy(), n.value
+
+
+def _pose12(pose_cw):
+    """3x4 (or 4x4) [R|t] -> 12 doubles: rotation row-major, then translation."""
+    T = np.asarray(pose_cw, np.float64)
+    return np.ascontiguousarray(np.concatenate([T[:3, :3].reshape(-1), T[:3, 3]]))
+
+
 class area(_window_ctx):
     """match::area(lowe_ratio, check_orientation)."""
 

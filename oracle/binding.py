@@ -331,6 +331,45 @@ def bow_match_frame_and_keyframe(kf_kps, kf_desc, kf_feat_vec, frm_kps, frm_desc
     return n, out[:len(fa)].copy()
 
 
+class Camera(C.Structure):
+    _fields_ = [("model", C.c_int32), ("setup", C.c_int32), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("focal_x_baseline", C.c_double), ("true_baseline", C.c_double), ("cols", C.c_int32), ("rows", C.c_int32)]
+
+
+def _pose12(pose_cw):
+    T = np.asarray(pose_cw, np.float64)
+    return np.ascontiguousarray(np.concatenate([T[:3, :3].reshape(-1), T[:3, 3]]))
+
+
+def reproject_to_image(cam, gp, pose_cw, pos_w):
+    out = np.zeros(2)
+    xr = C.c_float()
+    p = _pose12(pose_cw)
+    x = np.ascontiguousarray(pos_w, np.float64)
+    ok = lib().ovo_reproject_to_image(C.byref(cam), C.byref(gp), _p(p), _p(x), _p(out), C.byref(xr))
+    return bool(ok), out, xr.value
+
+
+def projection_match_current_and_last_frames(cam, gp, curr_kps, curr_desc, pose_cw_curr, last_kps, last_pos_w, last_lm_desc, pose_cw_last,
+                                             scale_factors, margin, check_orientation=True, curr_stereo_x_right=None, curr_occupied=None,
+                                             last_valid=None):
+    xs, ys, oc, an = _soa(curr_kps)
+    _, _, loc, lan = _soa(last_kps)
+    cd = np.ascontiguousarray(curr_desc, np.uint8).reshape(-1, 32)
+    pw = np.ascontiguousarray(last_pos_w, np.float64).reshape(-1, 3)
+    ld = np.ascontiguousarray(last_lm_desc, np.uint8).reshape(-1, 32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    xr = None if curr_stereo_x_right is None else np.ascontiguousarray(curr_stereo_x_right, np.float32)
+    occ = None if curr_occupied is None else np.ascontiguousarray(curr_occupied, np.uint8)
+    val = None if last_valid is None else np.ascontiguousarray(last_valid, np.uint8)
+    pc, pl = _pose12(pose_cw_curr), _pose12(pose_cw_last)
+    assigned = np.full(max(len(loc), 1), -1, np.int32)
+    n = lib().ovo_projection_match_current_and_last_frames(C.byref(cam), C.byref(gp), _p(xs), _p(ys), _p(oc), _p(an), _p(xr), _p(cd), _p(occ),
+                                                           len(xs), _p(pc), _p(loc), _p(lan), _p(pw), _p(ld), _p(val), len(loc), _p(pl),
+                                                           _p(sf), len(sf), C.c_float(margin), int(check_orientation), _p(assigned))
+    return assigned[:len(loc)].copy(), n
+
+
 def stereo_compute(ox_left, ox_right, kps_left, desc_left, kps_right, desc_right, focal_x_baseline, true_baseline):
     """stereo::compute on the pyramids of two OrbExtractor instances (their last extract). Returns (stereo_x_right, depths, n_valid)."""
     L = lib()

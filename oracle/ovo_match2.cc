@@ -324,6 +324,114 @@ int ovo_bow_match_frame_and_keyframe(const uint8_t* kf_desc, const float* kf_ang
     return num_matches;
 }
 
+// camera::perspective / camera::equirectangular ::reproject_to_image (expected: src/openvslam/camera/{perspective,equirectangular}.cc).
+// Double precision, one rounding per operation (no FMA contraction: the library is built with -ffp-contract=off).
+static bool reproject_to_image(const ovo_camera& cam, const ovo_grid_params& b, const double* P, const double* X, double* reproj,
+                               float* x_right) {
+    const double pc[3] = {(P[0] * X[0] + P[1] * X[1]) + P[2] * X[2] + P[9], (P[3] * X[0] + P[4] * X[1]) + P[5] * X[2] + P[10],
+                          (P[6] * X[0] + P[7] * X[1]) + P[8] * X[2] + P[11]};
+    if (cam.model == 0) {
+        if (pc[2] <= 0.0) return false;
+        const double z_inv = 1.0 / pc[2];
+        reproj[0] = cam.fx * pc[0] * z_inv + cam.cx;
+        reproj[1] = cam.fy * pc[1] * z_inv + cam.cy;
+        *x_right = (float)(reproj[0] - cam.focal_x_baseline * z_inv);
+        if (reproj[0] < b.min_x || reproj[0] > b.max_x) return false;
+        if (reproj[1] < b.min_y || reproj[1] > b.max_y) return false;
+        return true;
+    }
+    const double norm = std::sqrt((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]);
+    const double bx = pc[0] / norm, by = pc[1] / norm, bz = pc[2] / norm;
+    const double latitude = -std::asin(by);
+    const double longitude = std::atan2(bx, bz);
+    reproj[0] = cam.cols * (0.5 + longitude / (2.0 * M_PI));
+    reproj[1] = cam.rows * (0.5 - latitude / M_PI);
+    *x_right = -1.0f;
+    return true;
+}
+
+int ovo_reproject_to_image(const ovo_camera* cam, const ovo_grid_params* bounds, const double* pose_cw, const double* pos_w,
+                           double* reproj_xy, float* x_right) {
+    return reproject_to_image(*cam, *bounds, pose_cw, pos_w, reproj_xy, x_right) ? 1 : 0;
+}
+
+// M4  projection::match_current_and_last_frames(curr_frm, last_frm, margin): every last-frame keypoint with a live, inlier landmark
+// is reprojected with the CURRENT pose; the level window follows the motion (non-monocular only: forward if the z-translation
+// current->last exceeds the baseline -> [level, top]; backward -> [0, level]; else [level-1, level+1]); keypoints of the current
+// frame that already hold an observed landmark are skipped (sequential claim); stereo keypoints must agree on x_right; best
+// Hamming only (no ratio test), accept iff best <= THR_HIGH; orientation histogram keyed by the current keypoint.
+int ovo_projection_match_current_and_last_frames(const ovo_camera* cam, const ovo_grid_params* gp, const float* xs, const float* ys,
+                                                 const int32_t* octaves, const float* angles, const float* stereo_x_right,
+                                                 const uint8_t* desc, const uint8_t* occupied, int n_curr, const double* pose_cw_curr,
+                                                 const int32_t* last_octaves, const float* last_angles, const double* last_pos_w,
+                                                 const uint8_t* last_lm_desc, const uint8_t* last_valid, int n_last,
+                                                 const double* pose_cw_last, const float* scale_factors, int num_scale_levels,
+                                                 float margin, int check_orientation, int32_t* assigned) {
+    Grid g;
+    build_grid(g, *gp, xs, ys, n_curr);
+    std::vector<uint8_t> occ((size_t)n_curr, 0);
+    if (occupied) occ.assign(occupied, occupied + n_curr);
+    int num_matches = 0;
+    AngleChecker ac;
+    const double* Rc = pose_cw_curr;
+    const double* tc = pose_cw_curr + 9;
+    // trans_wc = -rot_cw^T * trans_cw; trans_lc = rot_lw * trans_wc + trans_lw
+    const double twc[3] = {-((Rc[0] * tc[0] + Rc[3] * tc[1]) + Rc[6] * tc[2]), -((Rc[1] * tc[0] + Rc[4] * tc[1]) + Rc[7] * tc[2]),
+                           -((Rc[2] * tc[0] + Rc[5] * tc[1]) + Rc[8] * tc[2])};
+    const double* Rl = pose_cw_last;
+    const double tlc_z = ((Rl[6] * twc[0] + Rl[7] * twc[1]) + Rl[8] * twc[2]) + pose_cw_last[11];
+    const bool assume_forward = cam->setup == 0 ? false : tlc_z > cam->true_baseline;
+    const bool assume_backward = cam->setup == 0 ? false : -tlc_z > cam->true_baseline;
+    std::vector<int> target_of((size_t)n_curr, -1);   // current keypoint -> last index that owns it (for the histogram removal)
+    for (int il = 0; il < n_last; ++il) {
+        assigned[il] = -1;
+        if (last_valid && !last_valid[il]) continue;
+        double reproj[2];
+        float x_right;
+        if (!reproject_to_image(*cam, *gp, pose_cw_curr, last_pos_w + 3 * (size_t)il, reproj, &x_right)) continue;
+        const int lvl = last_octaves[il];
+        const float r = margin * scale_factors[lvl];
+        int minl, maxl;
+        if (assume_forward) {
+            minl = lvl;
+            maxl = num_scale_levels - 1;
+        } else if (assume_backward) {
+            minl = 0;
+            maxl = lvl;
+        } else {
+            minl = lvl - 1;
+            maxl = lvl + 1;
+        }
+        unsigned best = OVO_MAX_HAMMING_DIST;
+        int best_idx = -1;
+        for_keypoints_in_cell(g, xs, ys, octaves, (float)reproj[0], (float)reproj[1], r, minl, maxl, [&](int idx) {
+            if (occ[idx]) return;
+            if (stereo_x_right && stereo_x_right[idx] > 0) {
+                const float reproj_error = std::fabs(x_right - stereo_x_right[idx]);
+                if (r < reproj_error) return;
+            }
+            const unsigned d = distance_32(last_lm_desc + (size_t)il * 32, desc + (size_t)idx * 32);
+            if (d < best) {
+                best = d;
+                best_idx = idx;
+            }
+        });
+        if (OVO_HAMMING_DIST_THR_HIGH < best) continue;
+        assigned[il] = best_idx;
+        occ[best_idx] = 1;
+        target_of[best_idx] = il;
+        ++num_matches;
+        if (check_orientation) ac.append(last_angles[il] - angles[best_idx], best_idx);
+    }
+    if (check_orientation) {
+        for (int invalid_idx : ac.invalid()) {
+            assigned[target_of[invalid_idx]] = -1;
+            --num_matches;
+        }
+    }
+    return num_matches;
+}
+
 // M6  stereo::compute(stereo_x_right, depths). Keypoints are cv::KeyPoint records (level-0 coordinates, octave); the two
 // pyramids are the extractors' image_pyramid_ (unblurred). Steps as upstream / ORB-SLAM2 ComputeStereoMatches:
 //   rows: right keypoint i is a candidate for every image row in [floor(y - 2 s_i), ceil(y + 2 s_i)], s_i = scale_factors[octave];

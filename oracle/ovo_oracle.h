@@ -135,6 +135,27 @@ int ovo_bow_match_frame_and_keyframe(const uint8_t* kf_desc, const float* kf_ang
                                      const uint8_t* frm_desc, const float* frm_angles, int n_frm, const int32_t* frm_node_ids,
                                      const int32_t* frm_node_start, const int32_t* frm_items, int frm_nodes, float lowe_ratio,
                                      int check_orientation, int32_t* matched_kf_in_frm);
+/* camera::base subset used by the matchers that reproject inside the call (M4). model: 0 = perspective, 1 = equirectangular;
+ * setup: 0 = monocular, 1 = stereo, 2 = RGBD. */
+typedef struct ovo_camera {
+    int32_t model, setup;
+    double fx, fy, cx, cy;
+    double focal_x_baseline, true_baseline;
+    int32_t cols, rows;
+} ovo_camera;
+/* camera::{perspective,equirectangular}::reproject_to_image(rot_cw, trans_cw, pos_w, reproj, x_right). pose_cw = 12 doubles
+ * (rotation row-major, then translation). Returns 1 if in the image. */
+int ovo_reproject_to_image(const ovo_camera* cam, const ovo_grid_params* bounds, const double* pose_cw, const double* pos_w,
+                           double* reproj_xy, float* x_right);
+/* M4 projection::match_current_and_last_frames(curr_frm, last_frm, margin). last_valid[i] != 0 iff last_frm.landmarks_[i] &&
+ * !last_frm.outlier_flags_[i]. assigned[i] = current-frame keypoint that receives last_frm.landmarks_[i], or -1. */
+int ovo_projection_match_current_and_last_frames(const ovo_camera* cam, const ovo_grid_params* gp, const float* xs, const float* ys,
+                                                 const int32_t* octaves, const float* angles, const float* stereo_x_right,
+                                                 const uint8_t* desc, const uint8_t* occupied, int n_curr, const double* pose_cw_curr,
+                                                 const int32_t* last_octaves, const float* last_angles, const double* last_pos_w,
+                                                 const uint8_t* last_lm_desc, const uint8_t* last_valid, int n_last,
+                                                 const double* pose_cw_last, const float* scale_factors, int num_scale_levels,
+                                                 float margin, int check_orientation, int32_t* assigned);
 /* M6 stereo::compute. Pyramids = the two extractors' image_pyramid_ (unblurred). Returns the number of valid depths. */
 int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr_right, const int32_t* level_rows,
                        const int32_t* level_cols, const size_t* stride_left, const size_t* stride_right, int num_levels,

@@ -126,3 +126,71 @@ def test_bow_match_frame_and_keyframe(match, synth, oracle, check_orientation, r
     wn, want = oracle.bow_match_frame_and_keyframe(ka, da, fa, kb, db, fb, ratio, check_orientation, has_lm)
     assert gn == wn and np.array_equal(got, want)
     assert wn > 30
+
+
+def _rot(axis, deg):
+    a = np.radians(deg)
+    c, s = np.cos(a), np.sin(a)
+    x, y, z = axis
+    return np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s, x * z * (1 - c) + y * s],
+                     [y * x * (1 - c) + z * s, c + y * y * (1 - c), y * z * (1 - c) - x * s],
+                     [z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c)]])
+
+
+def _last_and_current(synth, model, rows, cols, n, seed, forward_z):
+    """A current frame of n keypoints and a last frame whose landmarks are the current keypoints back-projected at random depths
+    (so they reproject onto them up to noise), plus distractors; the last camera sits `forward_z` metres behind along z."""
+    rng = np.random.default_rng(seed)
+    ck, cd = synth.synth_keypoints(n, rows, cols, seed=seed)
+    R = _rot((0, 1, 0), 2.0) @ _rot((1, 0, 0), -1.0)
+    t = np.array([0.05, -0.02, 0.3])
+    Tc = np.concatenate([R, t[:, None]], 1)
+    Tl = np.concatenate([np.eye(3), np.array([[0.0], [0.0], [-forward_z]])], 1)   # pos_l = pos_w - (0,0,forward_z)... last camera pose
+    fx = fy = 0.6 * cols
+    cx, cy = cols / 2.0, rows / 2.0
+    depth = rng.uniform(2.0, 20.0, n)
+    u = ck["x"].astype(np.float64) + rng.normal(0, 1.5, n)
+    v = ck["y"].astype(np.float64) + rng.normal(0, 1.5, n)
+    if model == 0:
+        pc = np.stack([(u - cx) / fx * depth, (v - cy) / fy * depth, depth], 1)
+    else:
+        lon = (u / cols - 0.5) * 2 * np.pi
+        lat = -(v / rows - 0.5) * np.pi
+        pc = np.stack([np.cos(lat) * np.sin(lon), -np.sin(lat), np.cos(lat) * np.cos(lon)], 1) * depth[:, None]
+    pw = (pc - t) @ R          # R^T (pc - t)
+    m = int(1.2 * n)
+    src = np.concatenate([rng.permutation(n), rng.integers(0, n, m - n)])
+    lk = ck[src].copy()
+    lk["angle"] = (lk["angle"] + np.where(rng.random(m) < 0.8, rng.normal(0, 5, m), rng.uniform(0, 360, m))) % 360
+    lk["octave"] = np.clip(lk["octave"] + rng.integers(-1, 2, m), 0, 7)
+    lpw = pw[src] + rng.normal(0, 0.002, (m, 3))
+    ld = np.stack([synth.flip_bits(rng, cd[i], 60) for i in src])
+    far = rng.random(m) < 0.1   # some landmarks behind the camera / far outside the image
+    lpw[far] = rng.uniform(-30, 30, (int(far.sum()), 3))
+    valid = (rng.random(m) < 0.9).astype(np.uint8)
+    return ck, cd, Tc, lk, lpw, ld, Tl, valid, (fx, fy, cx, cy)
+
+
+@pytest.mark.parametrize("model,setup,forward_z", [(0, 0, 0.0), (0, 1, 2.0), (0, 1, -2.0), (0, 2, 0.0), (1, 0, 0.0)])
+@pytest.mark.parametrize("check_orientation", [True, False])
+def test_projection_match_current_and_last_frames(match, synth, oracle, model, setup, forward_z, check_orientation):
+    from openvslam_amd import _lib
+    rows, cols, n = (960, 1920, 3000) if model == 1 else (720, 1280, 2000)
+    ck, cd, Tc, lk, lpw, ld, Tl, valid, (fx, fy, cx, cy) = _last_and_current(synth, model, rows, cols, n, 5 + model + setup, forward_z)
+    cam = _lib.Camera(model, setup, fx, fy, cx, cy, 0.12 * fx, 0.12, cols, rows)
+    ocam = oracle.Camera(model, setup, fx, fy, cx, cy, 0.12 * fx, 0.12, cols, rows)
+    gp, ogp = match.grid_params(cols, rows), oracle.grid_params(cols, rows)
+    sf = np.cumprod(np.concatenate([[1.0], np.full(7, 1.2)]).astype(np.float32)).astype(np.float32)
+    rng = np.random.default_rng(1)
+    occ = (rng.random(n) < 0.05).astype(np.uint8)
+    xr = None
+    if setup:
+        xr = np.where(rng.random(n) < 0.6, ck["x"] - rng.uniform(1, 40, n), -1.0).astype(np.float32)
+    w = match.projection(0.9, check_orientation, max_targets=4096, max_queries=4096)
+    for margin in (7.0, 15.0):
+        got, gn = w.match_current_and_last_frames(cam, gp, ck, cd, Tc, lk, lpw, ld, Tl, sf, margin, curr_stereo_x_right=xr,
+                                                  curr_occupied=occ, last_valid=valid)
+        want, wn = oracle.projection_match_current_and_last_frames(ocam, ogp, ck, cd, Tc, lk, lpw, ld, Tl, sf, margin, check_orientation,
+                                                                   curr_stereo_x_right=xr, curr_occupied=occ, last_valid=valid)
+        assert gn == wn and np.array_equal(got, want)
+    assert wn > n // 10
