@@ -191,21 +191,30 @@ __global__ __launch_bounds__(64) void k_bf_resolve(const uint8_t* __restrict__ d
     uint32_t n_out = 0;
     uint32_t epoch = 0;
 
+    // next chunk's counts + top-8 are fetched while the current chunk is replayed (their latency was ~1/3 of a chunk's time)
+    uint4 n_cc = make_uint4(0u, 0u, 0u, 0u), n_lo = make_uint4(~0u, ~0u, ~0u, ~0u), n_hi = n_lo;
+    auto fetch = [&](int qq) {
+        n_cc = make_uint4(0u, 0u, 0u, 0u);
+        n_lo = n_hi = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (qq < n2) {
+            n_cc = *reinterpret_cast<const uint4*>(cnts + (size_t)qq * kNearSplit);
+            const uint4* src = reinterpret_cast<const uint4*>(tops + (size_t)qq * kTopK);
+            n_lo = src[0];
+            n_hi = src[1];
+        }
+    };
+    fetch(lane);
     for (int q0 = 0; q0 < n2; q0 += 64) {
         const int q = q0 + lane;
-        uint32_t c4x = 0, c4y = 0, c4z = 0, c4w = 0;   // per-wave segment counts (named: a runtime-indexed array would live in scratch)
+        const uint4 cc = n_cc, lo = n_lo, hi = n_hi;
+        fetch(q + 64);
+        const uint32_t c4x = cc.x, c4y = cc.y, c4z = cc.z, c4w = cc.w;   // per-wave segment counts (named: a runtime-indexed array would live in scratch)
+        const uint32_t c = c4x + c4y + c4z + c4w;
+        const bool over = c4x > (uint32_t)kNearSeg || c4y > (uint32_t)kNearSeg || c4z > (uint32_t)kNearSeg || c4w > (uint32_t)kNearSeg;
         uint32_t top[kTopK];
 #pragma unroll
         for (int k = 0; k < kTopK; ++k) top[k] = ~0u;
-        if (q < n2) {
-            const uint4 cc = *reinterpret_cast<const uint4*>(cnts + (size_t)q * kNearSplit);
-            c4x = cc.x; c4y = cc.y; c4z = cc.z; c4w = cc.w;
-        }
-        const uint32_t c = c4x + c4y + c4z + c4w;
-        const bool over = c4x > (uint32_t)kNearSeg || c4y > (uint32_t)kNearSeg || c4z > (uint32_t)kNearSeg || c4w > (uint32_t)kNearSeg;
         if (c) {
-            const uint4* src = reinterpret_cast<const uint4*>(tops + (size_t)q * kTopK);
-            const uint4 lo = src[0], hi = src[1];
             top[0] = lo.x; top[1] = lo.y; top[2] = lo.z; top[3] = lo.w;
             top[4] = hi.x; top[5] = hi.y; top[6] = hi.z; top[7] = hi.w;
         }

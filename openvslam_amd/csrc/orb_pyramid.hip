@@ -5,9 +5,10 @@
 //
 // HBM-bound streaming kernel. A 256-thread workgroup produces a 128 x 16 output tile: the source rectangle its taps
 // touch (<= 160 x 22 bytes at scale 1.2) is staged in LDS with coalesced, aligned u32 loads -- v1 gathered 16 single bytes
-// per thread straight from global memory and was bound by the texture-addresser rate, not by bandwidth -- then every
-// thread gathers its 4 bytes per pixel from LDS, runs the two fixed-point passes and stores 4 pixels as one aligned u32
-// (two such groups per thread). Algorithmic traffic per level = source plane + destination plane, each touched once
+// per thread straight from global memory and was bound by the texture-addresser rate, not by bandwidth -- then the two
+// fixed-point passes run separably through LDS (horizontal pass once per staged source row into 16-bit words, vertical pass
+// per output row) and every thread stores 4 pixels as one aligned u32 (two such groups per thread). v2 evaluated the horizontal
+// pass per output pixel (twice per source row on average) and was VALU-bound at ~38 instructions per pixel. Algorithmic traffic per level = source plane + destination plane, each touched once
 // (tile halos overlap by one row/column and hit L2).
 #include "ovs_common.h"
 
@@ -22,6 +23,7 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restr
                                                          int dst_pitch, int drows, int dcols, const ResizeTap* __restrict__ xt,
                                                          const ResizeTap* __restrict__ yt) {
     __shared__ uint32_t tile[kSrcRows][kSrcWords];
+    __shared__ __attribute__((aligned(8))) uint32_t hrow[kSrcRows][kTileW / 2];   // horizontal pass, two u16 per word
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
     const int x1 = min(x0 + kTileW, dcols) - 1, y1 = min(y0 + kTileH, drows) - 1;   // last output pixel of the tile
@@ -31,41 +33,65 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restr
     const int sx_lo = xt[x0].o0 & ~3, sx_hi = xt[x1].o1;
     const int sy_lo = yt[y0].o0, sy_hi = yt[y1].o1;
     const int nwords = (sx_hi - sx_lo) / 4 + 1, nrows = sy_hi - sy_lo + 1;
-    if (nwords <= kSrcWords && nrows <= kSrcRows) {
-        for (int i = tid; i < nrows * nwords; i += 256) {
-            const int r = i / nwords, w = i - r * nwords;
-            const int gx = sx_lo + 4 * w;
-            uint32_t v = 0;
-            if (gx + 4 <= src_pitch) v = *reinterpret_cast<const uint32_t*>(s + (size_t)(sy_lo + r) * src_pitch + gx);
-            else {   // last partial word of an unpadded row (level 0 with stride == cols): byte-wise, never past the row
-                for (int b = 0; b < 4 && gx + b < src_pitch; ++b) v |= (uint32_t)s[(size_t)(sy_lo + r) * src_pitch + gx + b] << (8 * b);
+    if (nwords <= kSrcWords && nrows <= kSrcRows && (nrows - 1) * kSrcWords + nwords <= 4 * 256) {   // 4 staging slots per thread
+        // taps of this thread's column pair and of its two output rows: issued before the staging loads so their latency overlaps
+        const int xp = tid & 63, q = tid >> 6;
+        const int xa = min(x0 + 2 * xp, dcols - 1), xb = min(x0 + 2 * xp + 1, dcols - 1);
+        const ResizeTap ta = xt[xa], tbp = xt[xb];
+        const ResizeTap ty0 = yt[min(y0 + (tid >> 5), drows - 1)], ty1 = yt[min(y0 + 8 + (tid >> 5), drows - 1)];
+        // stage the source rectangle: 4 independent aligned u32 loads per thread in flight (fixed 44-word pitch: no runtime division)
+        {
+            uint32_t v[4];
+            int slot[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = tid + 256 * k;
+                const int r = i / kSrcWords, w = i - r * kSrcWords;
+                slot[k] = (r < nrows && w < nwords) ? i : -1;
+                v[k] = 0;
+                if (slot[k] >= 0) {
+                    const int gx = sx_lo + 4 * w;
+                    const uint8_t* p = s + (size_t)(sy_lo + r) * src_pitch + gx;
+                    if (gx + 4 <= src_pitch) v[k] = *reinterpret_cast<const uint32_t*>(p);
+                    else   // last partial word of an unpadded row (level 0 with stride == cols): byte-wise, never past the row
+                        for (int b = 0; b < 4 && gx + b < src_pitch; ++b) v[k] |= (uint32_t)p[b] << (8 * b);
+                }
             }
-            tile[r][w] = v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (slot[k] >= 0) (&tile[0][0])[slot[k]] = v[k];
         }
         __syncthreads();
         const uint8_t* tb = reinterpret_cast<const uint8_t*>(&tile[0][0]);
+        // ---- horizontal pass: hrow[r][x] = (S[r][o0]*a0 + S[r][o1]*a1) >> 4 (<= 32640: exact in 16 bits) for every staged source
+        // row and tile column. The ~1.7 output rows that share a source row reuse it; a thread owns a column pair, so its two
+        // x-taps are loaded once.
+        {
+            const int a_o0 = ta.o0 - sx_lo, a_o1 = ta.o1 - sx_lo, b_o0 = tbp.o0 - sx_lo, b_o1 = tbp.o1 - sx_lo;
+            for (int r = q; r < nrows; r += 4) {
+                const uint8_t* S = tb + r * (kSrcWords * 4);
+                const uint32_t ha = (uint32_t)(S[a_o0] * ta.a0 + S[a_o1] * ta.a1) >> 4;
+                const uint32_t hb = (uint32_t)(S[b_o0] * tbp.a0 + S[b_o1] * tbp.a1) >> 4;
+                hrow[r][xp] = ha | (hb << 16);
+            }
+        }
+        __syncthreads();
+        // ---- vertical pass + store: 512 groups of 4 pixels (32 groups per row, 16 rows), one aligned u32 store each
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const int idx = tid + g * 256;              // 512 groups of 4 pixels: 32 groups per row, 16 rows
-            const int y = y0 + (idx >> 5), x4 = x0 + (idx & 31) * 4;
+            const int idx = tid + g * 256;
+            const int y = y0 + (idx >> 5), xg = (idx & 31) * 4, x4 = x0 + xg;
             if (y >= drows || x4 >= dcols) continue;
-            const ResizeTap ty = yt[y];
-            const uint8_t* S0 = tb + (ty.o0 - sy_lo) * (kSrcWords * 4) - sx_lo;
-            const uint8_t* S1 = tb + (ty.o1 - sy_lo) * (kSrcWords * 4) - sx_lo;
+            const ResizeTap ty = g ? ty1 : ty0;
+            const uint2 h0 = *reinterpret_cast<const uint2*>(&hrow[ty.o0 - sy_lo][xg >> 1]);
+            const uint2 h1 = *reinterpret_cast<const uint2*>(&hrow[ty.o1 - sy_lo][xg >> 1]);
             const int b0 = ty.a0, b1 = ty.a1;
-            uint32_t out = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int x = x4 + i;
-                if (x < dcols) {
-                    const ResizeTap tx = xt[x];
-                    const int r0 = S0[tx.o0] * tx.a0 + S0[tx.o1] * tx.a1;
-                    const int r1 = S1[tx.o0] * tx.a0 + S1[tx.o1] * tx.a1;
-                    int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-                    v = v < 0 ? 0 : (v > 255 ? 255 : v);
-                    out |= (uint32_t)v << (8 * i);
-                }
-            }
+            auto vpass = [&](uint32_t r0, uint32_t r1) -> uint32_t {
+                const int v = (((b0 * (int)r0) >> 16) + ((b1 * (int)r1) >> 16) + 2) >> 2;
+                return (uint32_t)(v > 255 ? 255 : v);
+            };
+            const uint32_t out = vpass(h0.x & 0xFFFFu, h1.x & 0xFFFFu) | (vpass(h0.x >> 16, h1.x >> 16) << 8) |
+                                 (vpass(h0.y & 0xFFFFu, h1.y & 0xFFFFu) << 16) | (vpass(h0.y >> 16, h1.y >> 16) << 24);
             *reinterpret_cast<uint32_t*>(d + (size_t)y * dst_pitch + x4) = out;
         }
     } else {
