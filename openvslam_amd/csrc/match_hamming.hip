@@ -164,6 +164,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 //     before `best` is already claimed, anything after `second` cannot matter; a best > THR_LOW is a final reject);
 //   * all lanes below the first affected lane commit at once -- by induction their inputs were exact -- the rest go round again.
 // A chunk whose near list overflowed kNearSeg falls back to a literal one-query-at-a-time replay with cooperative scans.
+template <bool STAGED>
 __global__ __launch_bounds__(64) void k_bf_resolve(const uint8_t* __restrict__ desc_1, size_t stride_1,
                                                   const int32_t* __restrict__ n1_arr, const uint8_t* __restrict__ desc_2,
                                                   size_t stride_2, const int32_t* __restrict__ n2_arr, int max_n1, int max_n2,
@@ -191,23 +192,56 @@ __global__ __launch_bounds__(64) void k_bf_resolve(const uint8_t* __restrict__ d
     uint32_t n_out = 0;
     uint32_t epoch = 0;
 
-    // next chunk's counts + top-8 are fetched while the current chunk is replayed (their latency was ~1/3 of a chunk's time)
-    uint4 n_cc = make_uint4(0u, 0u, 0u, 0u), n_lo = make_uint4(~0u, ~0u, ~0u, ~0u), n_hi = n_lo;
-    auto fetch = [&](int qq) {
-        n_cc = make_uint4(0u, 0u, 0u, 0u);
-        n_lo = n_hi = make_uint4(~0u, ~0u, ~0u, ~0u);
-        if (qq < n2) {
-            n_cc = *reinterpret_cast<const uint4*>(cnts + (size_t)qq * kNearSplit);
-            const uint4* src = reinterpret_cast<const uint4*>(tops + (size_t)qq * kTopK);
-            n_lo = src[0];
-            n_hi = src[1];
+    // STAGED: every query's segment counts and sorted top-8 are copied into LDS up front (16 independent 16-byte loads per lane in
+    // flight), so the replay loop below never waits on HBM: with one wave per problem nothing else hides that latency, and hipcc
+    // cannot keep a software prefetch in flight across the loop's back edge (it drains vmcnt to 0 at the first use).
+    lds_u32* s_tops = (lds_u32*)(smem + (((size_t)max_n1 * 5 + 15) & ~(size_t)15));   // [n2][8]
+    lds_u32* s_cnts = s_tops + (size_t)max_n2 * kTopK;                                // [n2] four saturated u8 counts
+    if (STAGED) {
+        for (int q = lane; q < n2; q += 256) {
+            uint4 cc[4], lo[4], hi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int qq = q + 64 * u;
+                if (qq < n2) {
+                    cc[u] = *reinterpret_cast<const uint4*>(cnts + (size_t)qq * kNearSplit);
+                    const uint4* src = reinterpret_cast<const uint4*>(tops + (size_t)qq * kTopK);
+                    lo[u] = src[0];
+                    hi[u] = src[1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int qq = q + 64 * u;
+                if (qq < n2) {
+                    s_cnts[qq] = min(cc[u].x, 255u) | (min(cc[u].y, 255u) << 8) | (min(cc[u].z, 255u) << 16) | (min(cc[u].w, 255u) << 24);
+                    lds_u32* d = s_tops + (size_t)qq * kTopK;
+                    d[0] = lo[u].x; d[1] = lo[u].y; d[2] = lo[u].z; d[3] = lo[u].w;
+                    d[4] = hi[u].x; d[5] = hi[u].y; d[6] = hi[u].z; d[7] = hi[u].w;
+                }
+            }
         }
-    };
-    fetch(lane);
+        __builtin_amdgcn_wave_barrier();
+    }
     for (int q0 = 0; q0 < n2; q0 += 64) {
         const int q = q0 + lane;
-        const uint4 cc = n_cc, lo = n_lo, hi = n_hi;
-        fetch(q + 64);
+        uint4 cc = make_uint4(0u, 0u, 0u, 0u), lo = make_uint4(~0u, ~0u, ~0u, ~0u), hi = lo;
+        if (q < n2) {
+            if (STAGED) {
+                const uint32_t pk = s_cnts[q];
+                cc = make_uint4(pk & 255u, (pk >> 8) & 255u, (pk >> 16) & 255u, pk >> 24);
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const __attribute__((address_space(3))) u32x4* src = (const __attribute__((address_space(3))) u32x4*)(s_tops + (size_t)q * kTopK);
+                const u32x4 l4 = src[0], h4 = src[1];
+                lo = make_uint4(l4.x, l4.y, l4.z, l4.w);
+                hi = make_uint4(h4.x, h4.y, h4.z, h4.w);
+            } else {
+                cc = *reinterpret_cast<const uint4*>(cnts + (size_t)q * kNearSplit);
+                const uint4* src = reinterpret_cast<const uint4*>(tops + (size_t)q * kTopK);
+                lo = src[0];
+                hi = src[1];
+            }
+        }
         const uint32_t c4x = cc.x, c4y = cc.y, c4z = cc.z, c4w = cc.w;   // per-wave segment counts (named: a runtime-indexed array would live in scratch)
         const uint32_t c = c4x + c4y + c4z + c4w;
         const bool over = c4x > (uint32_t)kNearSeg || c4y > (uint32_t)kNearSeg || c4z > (uint32_t)kNearSeg || c4w > (uint32_t)kNearSeg;
@@ -224,10 +258,17 @@ __global__ __launch_bounds__(64) void k_bf_resolve(const uint8_t* __restrict__ d
         // has its address taken (references into lambdas ended up in scratch)
         auto evaluate = [=]() __attribute__((always_inline)) -> uint2 {
             uint32_t best = ~0u, second = ~0u;
+            // the eight claim flags are fetched as one batch of independent LDS reads (through the volatile pointer every read
+            // was followed by its own wait: ~8 serialized LDS round trips per evaluation); the compiler barrier at the top of each
+            // round keeps them from being cached across rounds
+            const __attribute__((address_space(3))) uint8_t* cl = (const __attribute__((address_space(3))) uint8_t*)claimed;
+            uint32_t dead[kTopK];
+#pragma unroll
+            for (int k = 0; k < kTopK; ++k) dead[k] = top[k] != ~0u ? (uint32_t)cl[top[k] & 0xFFFFu] : 1u;
 #pragma unroll
             for (int k = 0; k < kTopK; ++k) {
                 const uint32_t e = top[k];
-                if (e != ~0u && !claimed[e & 0xFFFFu]) {   // keys ascend: the first two unclaimed are best and second
+                if (!dead[k]) {   // keys ascend: the first two unclaimed are best and second
                     if (best == ~0u) best = e;
                     else if (second == ~0u) second = e;
                 }
@@ -264,6 +305,7 @@ __global__ __launch_bounds__(64) void k_bf_resolve(const uint8_t* __restrict__ d
                 const bool mine = (unresolved >> lane) & 1ull;
                 uint32_t best = ~0u, second = ~0u;
                 bool acc = false;
+                asm volatile("" ::: "memory");   // claims committed in the previous round must be re-read
                 ++epoch;
                 const uint32_t tag = (0xFFFFFFu - epoch) << 8;   // newer rounds carry smaller tags: atomicMin overrides stale marks
                 if (mine) {
@@ -278,7 +320,9 @@ __global__ __launch_bounds__(64) void k_bf_resolve(const uint8_t* __restrict__ d
                 if (mine && best != ~0u && (best >> 16) <= (uint32_t)OVS_HAMMING_DIST_THR_LOW) {
                     const uint32_t m1 = mark[best & 0xFFFFu];
                     affected = (m1 & ~0xFFu) == tag && (m1 & 0xFFu) < (uint32_t)lane;
-                    if (second != ~0u) {
+                    // losing `second` to a lower lane can only RAISE it, which never turns an accept (ratio * second >= best) into a
+                    // reject and never changes its target: only a lane the ratio test currently rejects has to look again
+                    if (second != ~0u && !acc) {
                         const uint32_t m2 = mark[second & 0xFFFFu];
                         affected |= (m2 & ~0xFFu) == tag && (m2 & 0xFFu) < (uint32_t)lane;
                     }
@@ -398,7 +442,8 @@ struct ovs_matcher {
     int32_t* d_best_idx = nullptr;
     uint16_t* d_best = nullptr;
     uint16_t* d_second = nullptr;
-    size_t resolve_lds = 0;
+    size_t resolve_lds = 0;        // mark + claimed
+    size_t resolve_lds_staged = 0; // + per-query top-8 and counts (0 = does not fit: the resolver reads them from HBM)
     StageProfiler<2> prof;
 };
 
@@ -426,8 +471,12 @@ ovs_status run_bf(ovs_matcher* m, const uint8_t* d1, size_t stride_1, const int3
                        m->d_near_cnt, m->d_near_list, m->d_near_top);
     OVS_HIP_TRY(hipGetLastError());
     OVS_HIP_TRY(m->prof.mark(1, s));
-    hipLaunchKernelGGL(k_bf_resolve, dim3(batch), dim3(64), m->resolve_lds, s, d1, stride_1, d_n1, d2, stride_2, d_n2, m->max_n1,
-                       m->max_n2, lowe_ratio, m->d_near_cnt, m->d_near_list, m->d_near_top, d_pairs, d_counts, cap);
+    if (m->resolve_lds_staged)
+        hipLaunchKernelGGL(k_bf_resolve<true>, dim3(batch), dim3(64), m->resolve_lds_staged, s, d1, stride_1, d_n1, d2, stride_2, d_n2,
+                           m->max_n1, m->max_n2, lowe_ratio, m->d_near_cnt, m->d_near_list, m->d_near_top, d_pairs, d_counts, cap);
+    else
+        hipLaunchKernelGGL(k_bf_resolve<false>, dim3(batch), dim3(64), m->resolve_lds, s, d1, stride_1, d_n1, d2, stride_2, d_n2, m->max_n1,
+                           m->max_n2, lowe_ratio, m->d_near_cnt, m->d_near_list, m->d_near_top, d_pairs, d_counts, cap);
     OVS_HIP_TRY(hipGetLastError());
     OVS_HIP_TRY(m->prof.mark(2, s));
     return OVS_OK;
@@ -451,6 +500,10 @@ ovs_status ovs_matcher_create(int32_t max_n1, int32_t max_n2, int32_t max_batch,
     if (m->resolve_lds > 150 * 1024) {
         delete m;
         return OVS_ERR_CAPACITY;
+    }
+    {
+        const size_t staged = (((size_t)max_n1 * 5 + 15) & ~(size_t)15) + (size_t)max_n2 * (kTopK + 1) * 4;
+        m->resolve_lds_staged = staged <= 150 * 1024 ? staged : 0;
     }
 #define CREATE_TRY(expr)                       \
     do {                                       \
@@ -477,8 +530,11 @@ ovs_status ovs_matcher_create(int32_t max_n1, int32_t max_n2, int32_t max_batch,
     CREATE_TRY(hipMalloc(&m->d_best, sizeof(uint16_t) * max_n2));
     CREATE_TRY(hipMalloc(&m->d_second, sizeof(uint16_t) * max_n2));
     if (m->resolve_lds > 64 * 1024)
-        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf_resolve), hipFuncAttributeMaxDynamicSharedMemorySize,
+        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf_resolve<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)m->resolve_lds));
+    if (m->resolve_lds_staged > 64 * 1024)
+        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf_resolve<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)m->resolve_lds_staged));
 #undef CREATE_TRY
     *out = m;
     return OVS_OK;

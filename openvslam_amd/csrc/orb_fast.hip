@@ -290,19 +290,18 @@ __global__ __launch_bounds__(256) void k_fast_cells(const FrameGeo* __restrict__
     }
     const int thr = __syncthreads_or(above_ini) ? geo->ini_thr : geo->min_thr;
 
-    // ---- emit: FAST response = S - 1; optional per-keypoint mask test.
-    int sv[16];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        sv[2 * i] = sa[i].x;
-        sv[2 * i + 1] = sa[i].y;
-        sv[8 + 2 * i] = sb[i].x;
-        sv[8 + 2 * i + 1] = sb[i].y;
-    }
+    // ---- emit: FAST response = S - 1; optional per-keypoint mask test. emit bit p <-> pixel (row0 + (p >> 3), c0 + (p & 7)).
     uint32_t emit = 0;
+    {
+        const s16x2 thrv = {(short)thr, (short)thr};
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
-        if (sv[p] > thr) emit |= 1u << p;
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t ua = (as_u32(thrv - sa[i]) >> 15) & 0x00010001u;   // sign of (thr - s): s > thr
+            const uint32_t ub = (as_u32(thrv - sb[i]) >> 15) & 0x00010001u;
+            emit |= ((ua | (ua >> 15)) & 3u) << (2 * i);
+            emit |= ((ub | (ub >> 15)) & 3u) << (8 + 2 * i);
+        }
+    }
     if (fmask && emit) {
         uint32_t m = emit;
         while (m) {
@@ -332,13 +331,15 @@ __global__ __launch_bounds__(256) void k_fast_cells(const FrameGeo* __restrict__
     for (int w2 = 0; w2 < wv; ++w2) pos += wave_tot[w2];
     uint64_t* list = cand + (size_t)frame * cand_frame_entries + g.cand_off;
     const uint32_t cap = (uint32_t)g.cand_cap;
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        if (emit & (1u << p)) {
-            const uint32_t x = min_x + 3 + c0 + (p & 7), y = min_y + 3 + row0 + (p >> 3);
-            if (pos < cap) list[pos] = cand_pack(x, y, (uint32_t)(sv[p] - 1), 0);
-            ++pos;
-        }
+    // survivors are rare (<= 1 % of the pixels): walk the set bits; an NMS survivor's score is still in the score map
+    const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(&smap[0][0]);
+    while (emit) {
+        const int p = __ffs(emit) - 1;
+        emit &= emit - 1;
+        const int px = c0 + (p & 7), py = row0 + (p >> 3);
+        const uint32_t v = sbytes[(py + 1) * (kSmapWords * 4) + 4 + px];
+        if (pos < cap) list[pos] = cand_pack((uint32_t)(min_x + 3 + px), (uint32_t)(min_y + 3 + py), v - 1u, 0);
+        ++pos;
     }
 }
 

@@ -24,3 +24,27 @@ for k in sorted(acc, key=lambda k: -sum(acc[k].get("SQ_WAVE_CYCLES", [0]))):
         v = acc[k].get(c)
         if v:
             print("    %-26s n=%-4d mean=%.6g" % (c, len(v), sum(v) / len(v)))
+
+# ---- per-launch HBM-side traffic for bench.py's roofline.traffic (profiles/pmc_traffic.json when --json is given).
+# Units / corrections (MI355X_MICROARCH.md HBM section, re-calibrated on this box with tools/ubench/hbm_calib.hip -- see
+# profiles/r01_hbm_calib.txt): FETCH_SIZE and WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports exactly HALF the bytes of a coalesced
+# read stream (4-byte and 16-byte per lane alike), WRITE_SIZE is exact. Both count requests on the L2's fabric side, i.e. lines
+# re-fetched by another XCD's L2 and Infinity-Cache hits are included.
+if "--json" in sys.argv:
+    import json
+    stage_of = {"ovs::k_fast_cells": "fast", "ovs::k_resize_linear_u8": "pyramid", "ovs::k_tree": "tree", "ovs::k_describe": "describe",
+                "ovs::k_hamming_near": "match_near", "ovs::k_bf_resolve": "match_resolve"}
+    launches_per_call = {"pyramid": 7}
+    out = {}
+    for k, st in stage_of.items():
+        kk = [n for n in acc if n.startswith(k)]
+        if not kk:
+            continue
+        f = sum(sum(acc[n].get("FETCH_SIZE", [])) for n in kk)
+        w = sum(sum(acc[n].get("WRITE_SIZE", [])) for n in kk)
+        nf = sum(len(acc[n].get("FETCH_SIZE", [])) for n in kk) or 1
+        nw = sum(len(acc[n].get("WRITE_SIZE", [])) for n in kk) or 1
+        per_launch = (2.0 * f / nf + w / nw) * 1024.0
+        out[st] = int(per_launch * launches_per_call.get(st, 1))
+    json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
+    print("traffic bytes per stage call:", out)
