@@ -147,6 +147,7 @@ bool build_geometry(const ovs_orb* h, int rows, int cols, FrameGeo& geo, std::ve
         g.ncx = W > kCellOverlap ? (W - kCellOverlap + kCellSize - 1) / kCellSize : 0;
         g.ncy = H > kCellOverlap ? (H - kCellOverlap + kCellSize - 1) / kCellSize : 0;
         if (g.ncx == 0 || g.ncy == 0) g.ncx = g.ncy = 0;
+        g.inv_ncx = g.ncx ? 1.0f / (float)g.ncx : 0.0f;
         g.cell_base = cell_base;
         cell_base += g.ncx * g.ncy;
         g.n_keypts = h->npl[l];

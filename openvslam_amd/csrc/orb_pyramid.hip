@@ -21,14 +21,24 @@ constexpr int kSrcRows = 24;
 __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restrict__ src, size_t src_frame_stride, int src_pitch,
                                                          int srows, int scols, uint8_t* __restrict__ dst, size_t dst_frame_stride,
                                                          int dst_pitch, int drows, int dcols, const ResizeTap* __restrict__ xt,
-                                                         const ResizeTap* __restrict__ yt) {
+                                                         const ResizeTap* __restrict__ yt, int tiles_x, int tiles_y, int batch, float inv_tiles_x,
+                                                         float inv_tiles_frame) {
     __shared__ uint32_t tile[kSrcRows][kSrcWords];
     __shared__ __attribute__((aligned(8))) uint32_t hrow[kSrcRows][kTileW / 2];   // horizontal pass, two u16 per word
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+    // XCD-aware tile order (workgroup b runs on XCD b % 8): XCD k takes the k-th contiguous eighth of the (frame, tile row, tile
+    // column) sequence, so tiles that share halo source lines share an L2. 1-D grid padded to a multiple of 8.
+    const int per_xcd = gridDim.x >> 3;
+    const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (tile_id >= tiles_x * tiles_y * batch) return;
+    // exact for tile_id < 2^22: (n + 0.5) / d is at least 0.5 / d away from an integer, far more than the float error
+    const int frame = (int)(((float)tile_id + 0.5f) * inv_tiles_frame);
+    const int trem = tile_id - frame * (tiles_x * tiles_y);
+    const int tyi = (int)(((float)trem + 0.5f) * inv_tiles_x), txi = trem - tyi * tiles_x;
+    const int x0 = txi * kTileW, y0 = tyi * kTileH;
     const int x1 = min(x0 + kTileW, dcols) - 1, y1 = min(y0 + kTileH, drows) - 1;   // last output pixel of the tile
-    const uint8_t* s = src + (size_t)blockIdx.z * src_frame_stride;
-    uint8_t* d = dst + (size_t)blockIdx.z * dst_frame_stride;
+    const uint8_t* s = src + (size_t)frame * src_frame_stride;
+    uint8_t* d = dst + (size_t)frame * dst_frame_stride;
     // source rectangle touched by the tile's taps (tables are monotone)
     const int sx_lo = xt[x0].o0 & ~3, sx_hi = xt[x1].o1;
     const int sy_lo = yt[y0].o0, sy_hi = yt[y1].o1;
@@ -127,9 +137,10 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restr
 hipError_t launch_resize(const uint8_t* src, size_t src_frame_stride, int src_pitch, int srows, int scols, uint8_t* dst,
                          size_t dst_frame_stride, int dst_pitch, int drows, int dcols, const ResizeTap* xt, const ResizeTap* yt,
                          int batch, hipStream_t s) {
-    dim3 grid((dcols + kTileW - 1) / kTileW, (drows + kTileH - 1) / kTileH, batch);
+    const int tiles_x = (dcols + kTileW - 1) / kTileW, tiles_y = (drows + kTileH - 1) / kTileH;
+    dim3 grid(((tiles_x * tiles_y * batch + 7) / 8) * 8);
     hipLaunchKernelGGL(k_resize_linear_u8, grid, dim3(256), 0, s, src, src_frame_stride, src_pitch, srows, scols, dst, dst_frame_stride,
-                       dst_pitch, drows, dcols, xt, yt);
+                       dst_pitch, drows, dcols, xt, yt, tiles_x, tiles_y, batch, 1.0f / (float)tiles_x, 1.0f / (float)(tiles_x * tiles_y));
     return hipGetLastError();
 }
 

@@ -32,7 +32,7 @@ struct LevelGeo {
     int32_t cand_cap;         // capacity of this level's candidate list
     int32_t gx, gy;           // root grid of the quad-tree
     int32_t max_nodes;        // 4*N_level + 16
-    int32_t pad0;
+    float inv_ncx;            // 1 / ncx (exact cell -> (row, column) split without an integer division)
     int64_t plane_off;        // byte offset of the plane inside one frame's pyramid block (levels >= 1)
     int64_t cand_off;         // entry offset of the candidate list inside one frame's candidate block
     int64_t node_off;         // entry offset of the node scratch inside one frame's node block
