@@ -44,6 +44,9 @@ public:
     //! Image pyramid (public upstream: match::stereo reads it)
     std::vector<cv::Mat> image_pyramid_;
 
+    //! the device context (match::stereo reads this extractor's pyramid where it lies, in HBM)
+    const ovs_orb* handle() const { return h_; }
+
 private:
     void initialize();
     void release();

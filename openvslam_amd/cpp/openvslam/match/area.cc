@@ -1,0 +1,29 @@
+// match::area::match_in_consistent_area over the C ABI. Replaces that function's body in src/openvslam/match/area.cc.
+#include "area.h"
+
+#include "window_ctx.h"
+
+namespace openvslam {
+namespace match {
+
+unsigned int area::match_in_consistent_area(data::frame& frm_1, data::frame& frm_2, std::vector<cv::Point2f>& prev_matched_pts,
+                                            std::vector<int>& matched_indices_2_in_frm_1, int margin) {
+    const int n1 = (int)frm_1.undist_keypts_.size(), n2 = (int)frm_2.undist_keypts_.size();
+    matched_indices_2_in_frm_1 = std::vector<int>((size_t)n1, -1);
+    if (n1 == 0 || n2 == 0) return 0;
+    static_assert(sizeof(cv::Point2f) == 2 * sizeof(float), "cv::Point2f is two floats");
+    static_assert(sizeof(int) == sizeof(int32_t), "int is 32 bit");
+    const ovs_grid_params gp = detail::grid_of(frm_2.camera_);
+    int32_t num_matches = 0;
+    detail::check(ovs_area_match_in_consistent_area(detail::window_ctx().get(n2, n1), &gp,
+                                                    reinterpret_cast<const ovs_keypoint*>(frm_1.undist_keypts_.data()), frm_1.descriptors_.data,
+                                                    n1, reinterpret_cast<const ovs_keypoint*>(frm_2.undist_keypts_.data()),
+                                                    frm_2.descriptors_.data, n2, reinterpret_cast<float*>(prev_matched_pts.data()),
+                                                    matched_indices_2_in_frm_1.data(), margin, lowe_ratio_, check_orientation_ ? 1 : 0,
+                                                    &num_matches),
+                  "ovs_area_match_in_consistent_area");
+    return (unsigned int)num_matches;
+}
+
+}   // namespace match
+}   // namespace openvslam

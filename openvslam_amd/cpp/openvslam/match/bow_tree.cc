@@ -1,0 +1,47 @@
+// match::bow_tree::match_frame_and_keyframe over the C ABI. Replaces that function's body in src/openvslam/match/bow_tree.cc.
+#include "bow_tree.h"
+
+#include "window_ctx.h"
+
+namespace openvslam {
+namespace match {
+
+namespace {
+void flatten(const data::bow_feature_vector& fv, std::vector<int32_t>& ids, std::vector<int32_t>& start, std::vector<int32_t>& items) {
+    ids.clear();
+    items.clear();
+    start.assign(1, 0);
+    for (const auto& node : fv) {   // std::map iterates in ascending node id
+        ids.push_back((int32_t)node.first);
+        for (const auto idx : node.second) items.push_back((int32_t)idx);
+        start.push_back((int32_t)items.size());
+    }
+}
+}   // namespace
+
+unsigned int bow_tree::match_frame_and_keyframe(data::keyframe* keyfrm, data::frame& frm, std::vector<data::landmark*>& matched_lms_in_frm) const {
+    const int n_kf = (int)keyfrm->num_keypts_, n_frm = (int)frm.num_keypts_;
+    matched_lms_in_frm = std::vector<data::landmark*>((size_t)n_frm, nullptr);
+    if (n_kf == 0 || n_frm == 0) return 0;
+    const auto keyfrm_lms = keyfrm->get_landmarks();
+    std::vector<uint8_t> valid((size_t)n_kf);
+    for (int i = 0; i < n_kf; ++i) valid[i] = keyfrm_lms[i] && !keyfrm_lms[i]->will_be_erased();
+    std::vector<int32_t> kid, kst, kit, fid, fst, fit;
+    flatten(keyfrm->bow_feat_vec_, kid, kst, kit);
+    flatten(frm.bow_feat_vec_, fid, fst, fit);
+    std::vector<int32_t> matched((size_t)n_frm, -1);
+    int32_t num_matches = 0;
+    detail::check(ovs_bow_match_frame_and_keyframe(detail::window_ctx().get(n_frm, n_kf),
+                                                   reinterpret_cast<const ovs_keypoint*>(keyfrm->keypts_.data()), keyfrm->descriptors_.data,
+                                                   valid.data(), n_kf, kid.data(), kst.data(), kit.data(), (int)kid.size(),
+                                                   reinterpret_cast<const ovs_keypoint*>(frm.keypts_.data()), frm.descriptors_.data, n_frm,
+                                                   fid.data(), fst.data(), fit.data(), (int)fid.size(), lowe_ratio_, check_orientation_ ? 1 : 0,
+                                                   matched.data(), &num_matches),
+                  "ovs_bow_match_frame_and_keyframe");
+    for (int j = 0; j < n_frm; ++j)
+        if (matched[j] >= 0) matched_lms_in_frm[j] = keyfrm_lms[matched[j]];
+    return (unsigned int)num_matches;
+}
+
+}   // namespace match
+}   // namespace openvslam

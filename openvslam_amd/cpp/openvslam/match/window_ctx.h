@@ -1,0 +1,56 @@
+// Shared helpers of the windowed-matcher shims: the per-thread device context (upstream stack-constructs a matcher per call; the
+// device context is kept per thread so a call does not allocate) and camera::base -> ovs_grid_params.
+#pragma once
+#include <ovslam_hip.h>
+
+#include <stdexcept>
+#include <string>
+
+#include "../data/frame_stub.h"
+
+namespace openvslam {
+namespace match {
+namespace detail {
+
+struct window_holder {
+    ovs_wmatcher* w = nullptr;
+    int cap_t = 0, cap_q = 0;
+    ~window_holder() {
+        if (w) ovs_wmatcher_destroy(w);
+    }
+    ovs_wmatcher* get(int n_t, int n_q) {
+        if (w && n_t <= cap_t && n_q <= cap_q) return w;
+        if (w) ovs_wmatcher_destroy(w);
+        w = nullptr;
+        cap_t = n_t < 8192 ? 8192 : n_t;
+        cap_q = n_q < 16384 ? 16384 : n_q;
+        const int st = ovs_wmatcher_create(cap_t, cap_q, 1 << 22, 0, &w);
+        if (st != OVS_OK) throw std::runtime_error(std::string("ovs_wmatcher_create failed: ") + ovs_last_error());
+        return w;
+    }
+};
+inline window_holder& window_ctx() {
+    thread_local window_holder h;
+    return h;
+}
+
+inline ovs_grid_params grid_of(const camera::base* cam) {
+    ovs_grid_params gp;
+    gp.min_x = cam->img_bounds_.min_x_;
+    gp.min_y = cam->img_bounds_.min_y_;
+    gp.max_x = cam->img_bounds_.max_x_;
+    gp.max_y = cam->img_bounds_.max_y_;
+    gp.cols = (int32_t)cam->num_grid_cols_;
+    gp.rows = (int32_t)cam->num_grid_rows_;
+    return gp;
+}
+
+inline void check(int st, const char* what) {
+    if (st != OVS_OK) throw std::runtime_error(std::string(what) + " failed: " + ovs_last_error());
+}
+
+static_assert(sizeof(cv::KeyPoint) == sizeof(ovs_keypoint), "cv::KeyPoint crosses the ABI as ovs_keypoint");
+
+}   // namespace detail
+}   // namespace match
+}   // namespace openvslam

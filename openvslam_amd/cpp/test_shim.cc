@@ -7,7 +7,11 @@
 #include <vector>
 
 #include "openvslam/feature/orb_extractor.h"
+#include "openvslam/match/area.h"
+#include "openvslam/match/bow_tree.h"
+#include "openvslam/match/projection.h"
 #include "openvslam/match/robust.h"
+#include "openvslam/match/stereo.h"
 
 using namespace openvslam;
 
@@ -55,6 +59,68 @@ int main(int argc, char** argv) {
         const int32_t p[2] = {m.first, m.second};
         std::fwrite(p, sizeof(p), 1, f);
     }
+    // ---- windowed matchers, driven as module::initializer / tracking_module / frame's stereo ctor drive them
+    camera::base cam;
+    cam.cols_ = cols;
+    cam.rows_ = rows;
+    cam.img_bounds_.max_x_ = (float)cols;
+    cam.img_bounds_.max_y_ = (float)rows;
+    data::frame frm_b;
+    frm_b.keypts_ = keyfrm.keypts_;
+    frm_b.descriptors_ = keyfrm.descriptors_;
+    frm_b.num_keypts_ = keyfrm.num_keypts_;
+    frm.undist_keypts_ = frm.keypts_;
+    frm_b.undist_keypts_ = frm_b.keypts_;
+    frm.camera_ = frm_b.camera_ = &cam;
+    frm.scale_factors_ = frm_b.scale_factors_ = extractor.get_scale_factors();
+    // area: initial guess = own position, margin 100
+    std::vector<cv::Point2f> prev_matched_pts(frm.num_keypts_);
+    for (unsigned i = 0; i < frm.num_keypts_; ++i) prev_matched_pts[i] = frm.undist_keypts_[i].pt;
+    std::vector<int> matched_2_in_1;
+    const unsigned n_area = match::area(0.9f, true).match_in_consistent_area(frm, frm_b, prev_matched_pts, matched_2_in_1, 100);
+    // projection: frame a's keypoints become landmarks reprojected at their position shifted by the frame offset
+    std::vector<std::unique_ptr<data::landmark>> local_lms_own;
+    std::vector<data::landmark*> local_lms;
+    for (unsigned i = 0; i < frm.num_keypts_; ++i) {
+        local_lms_own.emplace_back(new data::landmark());
+        auto* lm = local_lms_own.back().get();
+        lm->descriptor_ = frm.descriptors_.row((int)i);
+        lm->reproj_in_tracking_(0) = frm.keypts_[i].pt.x - 4.0;
+        lm->reproj_in_tracking_(1) = frm.keypts_[i].pt.y - 3.0;
+        lm->is_observable_in_tracking_ = (i % 7 != 0);
+        lm->scale_level_in_tracking_ = frm.keypts_[i].octave;
+        local_lms.push_back(lm);
+    }
+    frm_b.landmarks_.assign(frm_b.num_keypts_, nullptr);
+    const unsigned n_proj = match::projection(0.8f, true).match_frame_and_landmarks(frm_b, local_lms, 5.0f);
+    std::vector<int32_t> proj_assigned(frm.num_keypts_, -1);
+    for (unsigned j = 0; j < frm_b.num_keypts_; ++j)
+        for (unsigned l = 0; frm_b.landmarks_[j] && l < local_lms.size(); ++l)
+            if (local_lms[l] == frm_b.landmarks_[j]) proj_assigned[l] = (int32_t)j;
+    // bow: node = low 7 bits of the first descriptor byte
+    for (unsigned i = 0; i < keyfrm.num_keypts_; ++i) keyfrm.bow_feat_vec_[keyfrm.descriptors_.ptr((int)i)[0] & 127u].push_back(i);
+    for (unsigned i = 0; i < frm.num_keypts_; ++i) frm.bow_feat_vec_[frm.descriptors_.ptr((int)i)[0] & 127u].push_back(i);
+    std::vector<data::landmark*> matched_lms_in_frm;
+    const unsigned n_bow = match::bow_tree(0.75f, true).match_frame_and_keyframe(&keyfrm, frm, matched_lms_in_frm);
+    std::vector<int32_t> bow_kf_in_frm(frm.num_keypts_, -1);
+    for (unsigned j = 0; j < frm.num_keypts_; ++j)
+        for (unsigned i = 0; matched_lms_in_frm[j] && i < keyfrm.num_keypts_; ++i)
+            if (keyfrm.landmarks_[i] == matched_lms_in_frm[j]) bow_kf_in_frm[j] = (int32_t)i;
+    // stereo: a second extractor holds frame a's pyramid, the first one frame b's
+    feature::orb_extractor extractor_a(feature::orb_params(nfeat, 1.2f, 8, 20, 7));
+    std::vector<cv::KeyPoint> kps_a2;
+    cv::Mat desc_a2;
+    extractor_a.extract(a, cv::Mat(), kps_a2, desc_a2);
+    std::vector<float> stereo_x_right, depths;
+    match::stereo(&extractor_a, &extractor, kps_a2, keyfrm.keypts_, desc_a2, keyfrm.descriptors_, 386.1448f, 0.5372f).compute(stereo_x_right, depths);
+    const int32_t hdr2[4] = {(int32_t)n_area, (int32_t)n_proj, (int32_t)n_bow, (int32_t)stereo_x_right.size()};
+    std::fwrite(hdr2, sizeof(hdr2), 1, f);
+    std::fwrite(matched_2_in_1.data(), sizeof(int), matched_2_in_1.size(), f);
+    std::fwrite(prev_matched_pts.data(), sizeof(cv::Point2f), prev_matched_pts.size(), f);
+    std::fwrite(proj_assigned.data(), sizeof(int32_t), proj_assigned.size(), f);
+    std::fwrite(bow_kf_in_frm.data(), sizeof(int32_t), bow_kf_in_frm.size(), f);
+    std::fwrite(stereo_x_right.data(), sizeof(float), stereo_x_right.size(), f);
+    std::fwrite(depths.data(), sizeof(float), depths.size(), f);
     std::fclose(f);
     std::printf("shim ok: %u + %u keypoints, %u matches, scale[7]=%f\n", frm.num_keypts_, keyfrm.num_keypts_, n, extractor.get_scale_factors().at(7));
     return 0;
