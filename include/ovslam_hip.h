@@ -232,6 +232,20 @@ ovs_status ovs_projection_match_current_and_last_frames(ovs_wmatcher* w, const o
                                                         const double* pose_cw_last, const float* scale_factors, int32_t num_levels,
                                                         float margin, int32_t check_orientation, int32_t* assigned, int32_t* num_matches);
 
+/* replaces: the candidate search of  template<typename T> unsigned int fuse::replace_duplication(data::keyframe* keyfrm,
+ *               const T& landmarks_to_check, const float margin)  (src/openvslam/match/fuse.{h,cc}); landmarks are independent there.
+ * kps / desc / stereo_x_right = keyfrm->undist_keypts_ / descriptors_ / stereo_x_right_ (NULL = monocular); pose_cw = keyfrm pose.
+ * Per landmark (in the order of landmarks_to_check): lm_pos_w = get_pos_in_world(), lm_dist_min_max = (get_min_valid_distance(),
+ * get_max_valid_distance()), lm_normal = get_obs_mean_normal(), lm_desc = get_descriptor(), lm_valid != 0 iff lm &&
+ * !will_be_erased() && !is_observed_in_keyframe(keyfrm). inv_level_sigma_sq / log_scale_factor = the keyframe's tables.
+ * best_idx[l] = keypoint the landmark fuses with or -1; the shim then performs upstream's replace / add_observation in order. */
+ovs_status ovs_fuse_replace_duplication(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps,
+                                        const uint8_t* desc, const float* stereo_x_right, int32_t n, const double* pose_cw,
+                                        const double* lm_pos_w, const float* lm_dist_min_max, const double* lm_normal,
+                                        const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m, const float* scale_factors,
+                                        const float* inv_level_sigma_sq, int32_t num_levels, float log_scale_factor, float margin,
+                                        int32_t* best_idx, int32_t* num_fused);
+
 /* replaces: unsigned int area::match_in_consistent_area(data::frame& frm_1, data::frame& frm_2,
  *               std::vector<cv::Point2f>& prev_matched_pts, std::vector<int>& matched_indices_2_in_frm_1, int margin).
  * kps_i / desc_i = frm_i.undist_keypts_ / descriptors_; gp = frm_2's camera grid. prev_matched_xy (n1 x 2) is updated in

@@ -273,6 +273,95 @@ __global__ __launch_bounds__(256) void k_reproject_queries(CamP cam, const ovs_k
     q_valid[i] = valid ? 1 : 0;
 }
 
+// fuse::replace_duplication, candidate search: landmarks are independent (the write-back that follows is host-side graph surgery)
+struct FuseArgs {
+    const ovs_keypoint* t_kps;
+    const uint8_t* t_desc;
+    const float* t_x_right;
+    const int32_t* cell_start;
+    const int32_t* items;
+    GridP gp;
+    CamP cam;
+    double cc[3];                 // camera centre
+    const double* lm_pos_w;
+    const float* lm_dist;         // (min, max) valid distance
+    const double* lm_normal;
+    const uint8_t* lm_desc;
+    const uint8_t* lm_valid;
+    int m, num_levels;
+    float log_scale_factor, margin;
+    float sf[OVS_MAX_LEVELS], ils[OVS_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void k_fuse_best(FuseArgs a, int32_t* __restrict__ best_out, int32_t* __restrict__ num_fused) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= a.m) return;
+    int32_t result = -1;
+    do {
+        if (a.lm_valid && !a.lm_valid[l]) break;
+        const double* X = a.lm_pos_w + 3 * (size_t)l;
+        double u, v;
+        float x_right;
+        if (!reproject_to_image(a.cam, X, u, v, x_right)) break;
+        const double dx = X[0] - a.cc[0], dy = X[1] - a.cc[1], dz = X[2] - a.cc[2];
+        const double dist = sqrt((dx * dx + dy * dy) + dz * dz);
+        const float dmin = a.lm_dist[2 * l], dmax = a.lm_dist[2 * l + 1];
+        if (dist < dmin || dmax < dist) break;
+        const double* nrm = a.lm_normal + 3 * (size_t)l;
+        if ((dx * nrm[0] + dy * nrm[1]) + dz * nrm[2] < 0.5 * dist) break;
+        const float ratio = __fdiv_rn(dmax, (float)dist);
+        int pred = (int)ceilf(__fdiv_rn(logf(ratio), a.log_scale_factor));
+        if (pred < 0) pred = 0;
+        else if (a.num_levels <= pred) pred = a.num_levels - 1;
+        const float r = __fmul_rn(a.margin, a.sf[pred]);
+        const float ref_x = (float)u, ref_y = (float)v;
+        const GridP& g = a.gp;
+        const int min_cx = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(ref_x, g.min_x), r), g.inv_w)));
+        const int max_cx = min(g.cols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(ref_x, g.min_x), r), g.inv_w)));
+        const int min_cy = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(ref_y, g.min_y), r), g.inv_h)));
+        const int max_cy = min(g.rows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(ref_y, g.min_y), r), g.inv_h)));
+        if (!(min_cx < g.cols && max_cx >= 0 && min_cy < g.rows && max_cy >= 0)) break;
+        uint32_t qd[8];
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.lm_desc + (size_t)l * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qd[i] = src[i];
+        uint32_t best = OVS_MAX_HAMMING_DIST;
+        int best_idx = -1;
+        for (int cx = min_cx; cx <= max_cx; ++cx) {
+            for (int cy = min_cy; cy <= max_cy; ++cy) {
+                const int c = cx * g.rows + cy;
+                const int e = a.cell_start[c + 1];
+                for (int k = a.cell_start[c]; k < e; ++k) {
+                    const int idx = a.items[k];
+                    const ovs_keypoint kp = a.t_kps[idx];
+                    if (!(fabsf(__fsub_rn(kp.x, ref_x)) < r && fabsf(__fsub_rn(kp.y, ref_y)) < r)) continue;
+                    const int level = kp.octave;
+                    if (level < pred - 1 || pred < level) continue;
+                    const double ex = u - (double)kp.x, ey = v - (double)kp.y;
+                    const float xr = a.t_x_right ? a.t_x_right[idx] : -1.0f;
+                    if (xr >= 0) {
+                        const double exr = (double)x_right - (double)xr;
+                        const double e2 = (ex * ex + ey * ey) + exr * exr;
+                        if ((double)7.81473f < e2 * (double)a.ils[level]) continue;
+                    } else {
+                        const double e2 = ex * ex + ey * ey;
+                        if ((double)5.99146f < e2 * (double)a.ils[level]) continue;
+                    }
+                    const uint32_t d = hamming256_g(qd, reinterpret_cast<const uint32_t*>(a.t_desc + (size_t)idx * 32));
+                    if (d < best) {
+                        best = d;
+                        best_idx = idx;
+                    }
+                }
+            }
+        }
+        if (best <= (uint32_t)OVS_HAMMING_DIST_THR_LOW) result = best_idx;
+    } while (false);
+    best_out[l] = result;
+    const unsigned long long any = __ballot(result >= 0);
+    if ((threadIdx.x & 63) == 0 && any) atomicAdd(num_fused, (int32_t)__popcll(any));
+}
+
 // bow_tree: queries = the keyframe's feature-vector entries in walk order; the list of a query is its node's frame bucket
 struct BowArgs {
     const uint8_t* kf_desc;
@@ -1092,6 +1181,85 @@ ovs_status ovs_projection_match_current_and_last_frames(ovs_wmatcher* w, const o
     OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipStreamSynchronize(s));
     return overflow ? OVS_ERR_CAPACITY : OVS_OK;
+}
+
+ovs_status ovs_fuse_replace_duplication(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps,
+                                        const uint8_t* desc, const float* stereo_x_right, int32_t n, const double* pose_cw,
+                                        const double* lm_pos_w, const float* lm_dist_min_max, const double* lm_normal,
+                                        const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m, const float* scale_factors,
+                                        const float* inv_level_sigma_sq, int32_t num_levels, float log_scale_factor, float margin,
+                                        int32_t* best_idx, int32_t* num_fused) {
+    if (!w || !cam || !gp || !num_fused || n < 0 || m < 0 || !pose_cw || !scale_factors || !inv_level_sigma_sq || num_levels < 1 ||
+        num_levels > OVS_MAX_LEVELS || (cam->model != 0 && cam->model != 1))
+        return OVS_ERR_INVALID;
+    *num_fused = 0;
+    if (m == 0) return OVS_OK;
+    if (!best_idx) return OVS_ERR_INVALID;
+    for (int i = 0; i < m; ++i) best_idx[i] = -1;
+    if (n == 0) return OVS_OK;
+    if (!kps || !desc || !lm_pos_w || !lm_dist_min_max || !lm_normal || !lm_desc) return OVS_ERR_INVALID;
+    if (n > w->max_t || m > w->max_q) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = w->stream;
+    FuseArgs a{};
+    a.cam.model = cam->model;
+    a.cam.setup = cam->setup;
+    a.cam.fx = cam->fx;
+    a.cam.fy = cam->fy;
+    a.cam.cx = cam->cx;
+    a.cam.cy = cam->cy;
+    a.cam.fxb = cam->focal_x_baseline;
+    a.cam.cols = cam->cols;
+    a.cam.rows = cam->rows;
+    a.cam.min_x = gp->min_x;
+    a.cam.min_y = gp->min_y;
+    a.cam.max_x = gp->max_x;
+    a.cam.max_y = gp->max_y;
+    std::memcpy(a.cam.P, pose_cw, sizeof(double) * 12);
+    const double* R = pose_cw;
+    const double* t = pose_cw + 9;
+    a.cc[0] = -((R[0] * t[0] + R[3] * t[1]) + R[6] * t[2]);
+    a.cc[1] = -((R[1] * t[0] + R[4] * t[1]) + R[7] * t[2]);
+    a.cc[2] = -((R[2] * t[0] + R[5] * t[1]) + R[8] * t[2]);
+    for (int l = 0; l < OVS_MAX_LEVELS; ++l) {
+        a.sf[l] = l < num_levels ? scale_factors[l] : 1.0f;
+        a.ils[l] = l < num_levels ? inv_level_sigma_sq[l] : 1.0f;
+    }
+    a.num_levels = num_levels;
+    a.log_scale_factor = log_scale_factor;
+    a.margin = margin;
+    a.m = m;
+    // staging: landmark positions ride in d_q_pos, normals behind the key buffer (3 doubles per landmark <= max_entries * 4 bytes?)
+    if ((size_t)m * 3 * sizeof(double) > (size_t)w->max_entries * sizeof(uint32_t)) return OVS_ERR_CAPACITY;
+    double* d_normal = reinterpret_cast<double*>(w->d_keys);
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, kps, sizeof(ovs_keypoint) * n, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, desc, (size_t)32 * n, hipMemcpyHostToDevice, s));
+    if (stereo_x_right) OVS_HIP_TRY(hipMemcpyAsync(w->d_t_f, stereo_x_right, sizeof(float) * n, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_pos, lm_pos_w, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(d_normal, lm_normal, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_xy, lm_dist_min_max, sizeof(float) * 2 * m, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, lm_desc, (size_t)32 * m, hipMemcpyHostToDevice, s));
+    if (lm_valid) OVS_HIP_TRY(hipMemcpyAsync(w->d_q_flag, lm_valid, (size_t)m, hipMemcpyHostToDevice, s));
+    ovs_status st = grid_assign(w, gp, w->d_t_kps, n, s);
+    if (st != OVS_OK) return st;
+    a.t_kps = w->d_t_kps;
+    a.t_desc = w->d_t_desc;
+    a.t_x_right = stereo_x_right ? w->d_t_f : nullptr;
+    a.cell_start = w->d_cell_start;
+    a.items = w->d_items;
+    a.gp = w->gp;
+    a.lm_pos_w = w->d_q_pos;
+    a.lm_dist = w->d_q_xy;
+    a.lm_normal = d_normal;
+    a.lm_desc = w->d_q_desc;
+    a.lm_valid = lm_valid ? w->d_q_flag : nullptr;
+    OVS_HIP_TRY(hipMemsetAsync(w->d_num, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_fuse_best, dim3((m + 255) / 256), dim3(256), 0, s, a, w->d_assigned, w->d_num);
+    OVS_HIP_TRY(hipGetLastError());
+    OVS_HIP_TRY(hipMemcpyAsync(best_idx, w->d_assigned, sizeof(int32_t) * m, hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(num_fused, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
+    return OVS_OK;
 }
 
 }   // extern "C"

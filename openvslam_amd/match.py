@@ -232,6 +232,35 @@ class bow_tree(_window_ctx):
         return n.value, out[:len(fk)].copy()
 
 
+class fuse(_window_ctx):
+    """match::fuse(lowe_ratio): the candidate search of replace_duplication (the landmark-graph surgery stays with the caller)."""
+
+    def __init__(self, lowe_ratio=0.6, **kw):
+        super().__init__(**kw)
+        self.lowe_ratio_ = float(lowe_ratio)
+
+    def replace_duplication(self, cam, gp, keyfrm_keypts, keyfrm_desc, pose_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc,
+                            scale_factors, inv_level_sigma_sq, log_scale_factor, margin=3.0, keyfrm_stereo_x_right=None, lm_valid=None):
+        """returns (best_idx, num_fused): best_idx[l] = keyframe keypoint landmark l fuses with, or -1."""
+        k = np.ascontiguousarray(keyfrm_keypts, KP_DTYPE)
+        d = np.ascontiguousarray(keyfrm_desc, np.uint8).reshape(-1, 32)
+        pw = np.ascontiguousarray(lm_pos_w, np.float64).reshape(-1, 3)
+        dm = np.ascontiguousarray(lm_dist_min_max, np.float32).reshape(-1, 2)
+        nr = np.ascontiguousarray(lm_normal, np.float64).reshape(-1, 3)
+        ld = np.ascontiguousarray(lm_desc, np.uint8).reshape(-1, 32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        ils = np.ascontiguousarray(inv_level_sigma_sq, np.float32)
+        xr = None if keyfrm_stereo_x_right is None else np.ascontiguousarray(keyfrm_stereo_x_right, np.float32)
+        val = None if lm_valid is None else np.ascontiguousarray(lm_valid, np.uint8)
+        best = np.full(max(len(pw), 1), -1, np.int32)
+        n = C.c_int32()
+        _lib.check(self._L.ovs_fuse_replace_duplication(self._h, C.byref(cam), C.byref(gp), _p(k), _p(d), _p(xr), len(k), _p(_pose12(pose_cw)),
+                                                        _p(pw), _p(dm), _p(nr), _p(ld), _p(val), len(pw), _p(sf), _p(ils), len(sf),
+                                                        float(log_scale_factor), float(margin), _p(best), C.byref(n)),
+                   "ovs_fuse_replace_duplication")
+        return best[:len(pw)].copy(), n.value
+
+
 class stereo:
     """match::stereo(left_image_pyramid, right_image_pyramid, keypts_left, keypts_right, descs_left, descs_right, scale_factors,
     inv_scale_factors, focal_x_baseline, true_baseline). The pyramids and scale tables are those of the two extractors' last extract

@@ -370,6 +370,25 @@ def projection_match_current_and_last_frames(cam, gp, curr_kps, curr_desc, pose_
     return assigned[:len(loc)].copy(), n
 
 
+def fuse_replace_duplication(cam, gp, kf_kps, kf_desc, pose_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc, scale_factors,
+                             inv_level_sigma_sq, log_scale_factor, margin=3.0, kf_stereo_x_right=None, lm_valid=None):
+    xs, ys, oc, _ = _soa(kf_kps)
+    d = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32)
+    pw = np.ascontiguousarray(lm_pos_w, np.float64).reshape(-1, 3)
+    dm = np.ascontiguousarray(lm_dist_min_max, np.float32).reshape(-1, 2)
+    nr = np.ascontiguousarray(lm_normal, np.float64).reshape(-1, 3)
+    ld = np.ascontiguousarray(lm_desc, np.uint8).reshape(-1, 32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    ils = np.ascontiguousarray(inv_level_sigma_sq, np.float32)
+    xr = None if kf_stereo_x_right is None else np.ascontiguousarray(kf_stereo_x_right, np.float32)
+    val = None if lm_valid is None else np.ascontiguousarray(lm_valid, np.uint8)
+    best = np.full(max(len(pw), 1), -1, np.int32)
+    n = lib().ovo_fuse_replace_duplication(C.byref(cam), C.byref(gp), _p(xs), _p(ys), _p(oc), _p(xr), _p(d), len(xs), _p(_pose12(pose_cw)),
+                                           _p(pw), _p(dm), _p(nr), _p(ld), _p(val), len(pw), _p(sf), _p(ils), len(sf),
+                                           C.c_float(log_scale_factor), C.c_float(margin), _p(best))
+    return best[:len(pw)].copy(), n
+
+
 def stereo_compute(ox_left, ox_right, kps_left, desc_left, kps_right, desc_right, focal_x_baseline, true_baseline):
     """stereo::compute on the pyramids of two OrbExtractor instances (their last extract). Returns (stereo_x_right, depths, n_valid)."""
     L = lib()

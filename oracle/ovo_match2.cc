@@ -432,6 +432,71 @@ int ovo_projection_match_current_and_last_frames(const ovo_camera* cam, const ov
     return num_matches;
 }
 
+// M8  fuse::replace_duplication(keyfrm, landmarks_to_check, margin), candidate search (expected: src/openvslam/match/fuse.{h,cc}):
+// per landmark, independently: reproject with the keyframe pose; distance inside [min_valid, max_valid]; viewing angle
+// cam_to_lm . mean_normal >= 0.5 |cam_to_lm|; predicted level = clamp(ceil(log(max_valid / dist) / log_scale_factor), 0, L-1)
+// (landmark::predict_scale_level, float); ALL grid candidates within margin * scale_factors[pred]; keypoint level in
+// [pred-1, pred]; chi-square gate on the reprojection error (5.99146 mono, 7.81473 with a stereo x_right) scaled by
+// inv_level_sigma_sq[level]; best Hamming (strict <), accept iff best <= THR_LOW.
+int ovo_fuse_replace_duplication(const ovo_camera* cam, const ovo_grid_params* gp, const float* xs, const float* ys,
+                                 const int32_t* octaves, const float* stereo_x_right, const uint8_t* desc, int n, const double* pose_cw,
+                                 const double* lm_pos_w, const float* lm_dist_min_max, const double* lm_normal, const uint8_t* lm_desc,
+                                 const uint8_t* lm_valid, int m, const float* scale_factors, const float* inv_level_sigma_sq,
+                                 int num_scale_levels, float log_scale_factor, float margin, int32_t* best_idx_out) {
+    Grid g;
+    build_grid(g, *gp, xs, ys, n);
+    const double* R = pose_cw;
+    const double* t = pose_cw + 9;
+    // cam_center = -R^T t
+    const double cc[3] = {-((R[0] * t[0] + R[3] * t[1]) + R[6] * t[2]), -((R[1] * t[0] + R[4] * t[1]) + R[7] * t[2]),
+                          -((R[2] * t[0] + R[5] * t[1]) + R[8] * t[2])};
+    int num_fused = 0;
+    for (int l = 0; l < m; ++l) {
+        best_idx_out[l] = -1;
+        if (lm_valid && !lm_valid[l]) continue;
+        const double* X = lm_pos_w + 3 * (size_t)l;
+        double reproj[2];
+        float x_right;
+        if (!reproject_to_image(*cam, *gp, pose_cw, X, reproj, &x_right)) continue;
+        const double v[3] = {X[0] - cc[0], X[1] - cc[1], X[2] - cc[2]};
+        const double dist = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+        const float dmin = lm_dist_min_max[2 * l], dmax = lm_dist_min_max[2 * l + 1];
+        if (dist < dmin || dmax < dist) continue;
+        const double* nrm = lm_normal + 3 * (size_t)l;
+        if ((v[0] * nrm[0] + v[1] * nrm[1]) + v[2] * nrm[2] < 0.5 * dist) continue;
+        // landmark::predict_scale_level(cam_to_lm_dist, keyfrm)
+        const float ratio = dmax / (float)dist;
+        int pred = (int)std::ceil(std::log(ratio) / log_scale_factor);
+        if (pred < 0) pred = 0;
+        else if (num_scale_levels <= pred) pred = num_scale_levels - 1;
+        const float r = margin * scale_factors[pred];
+        unsigned best = OVO_MAX_HAMMING_DIST;
+        int best_idx = -1;
+        for_keypoints_in_cell(g, xs, ys, octaves, (float)reproj[0], (float)reproj[1], r, -1, -1, [&](int idx) {
+            const int level = octaves[idx];
+            if (level < pred - 1 || pred < level) return;
+            const double ex = reproj[0] - xs[idx], ey = reproj[1] - ys[idx];
+            if (stereo_x_right && stereo_x_right[idx] >= 0) {
+                const double exr = (double)x_right - (double)stereo_x_right[idx];
+                const double e2 = (ex * ex + ey * ey) + exr * exr;
+                if (7.81473f < e2 * inv_level_sigma_sq[level]) return;
+            } else {
+                const double e2 = ex * ex + ey * ey;
+                if (5.99146f < e2 * inv_level_sigma_sq[level]) return;
+            }
+            const unsigned d = distance_32(lm_desc + (size_t)l * 32, desc + (size_t)idx * 32);
+            if (d < best) {
+                best = d;
+                best_idx = idx;
+            }
+        });
+        if (OVO_HAMMING_DIST_THR_LOW < best) continue;
+        best_idx_out[l] = best_idx;
+        ++num_fused;
+    }
+    return num_fused;
+}
+
 // M6  stereo::compute(stereo_x_right, depths). Keypoints are cv::KeyPoint records (level-0 coordinates, octave); the two
 // pyramids are the extractors' image_pyramid_ (unblurred). Steps as upstream / ORB-SLAM2 ComputeStereoMatches:
 //   rows: right keypoint i is a candidate for every image row in [floor(y - 2 s_i), ceil(y + 2 s_i)], s_i = scale_factors[octave];

@@ -156,6 +156,14 @@ int ovo_projection_match_current_and_last_frames(const ovo_camera* cam, const ov
                                                  const uint8_t* last_lm_desc, const uint8_t* last_valid, int n_last,
                                                  const double* pose_cw_last, const float* scale_factors, int num_scale_levels,
                                                  float margin, int check_orientation, int32_t* assigned);
+/* M8 fuse::replace_duplication(keyfrm, landmarks_to_check, margin) -- the candidate search (the landmark-graph surgery that follows
+ * stays on the host). lm_valid[l] != 0 iff lm && !will_be_erased() && !is_observed_in_keyframe(keyfrm). lm_dist = (min, max) valid
+ * distances; lm_normal = obs_mean_normal. best_idx[l] = keyframe keypoint the landmark fuses with, or -1. Returns num_fused. */
+int ovo_fuse_replace_duplication(const ovo_camera* cam, const ovo_grid_params* gp, const float* xs, const float* ys,
+                                 const int32_t* octaves, const float* stereo_x_right, const uint8_t* desc, int n, const double* pose_cw,
+                                 const double* lm_pos_w, const float* lm_dist_min_max, const double* lm_normal, const uint8_t* lm_desc,
+                                 const uint8_t* lm_valid, int m, const float* scale_factors, const float* inv_level_sigma_sq,
+                                 int num_scale_levels, float log_scale_factor, float margin, int32_t* best_idx);
 /* M6 stereo::compute. Pyramids = the two extractors' image_pyramid_ (unblurred). Returns the number of valid depths. */
 int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr_right, const int32_t* level_rows,
                        const int32_t* level_cols, const size_t* stride_left, const size_t* stride_right, int num_levels,

@@ -194,3 +194,41 @@ def test_projection_match_current_and_last_frames(match, synth, oracle, model, s
                                                                    curr_stereo_x_right=xr, curr_occupied=occ, last_valid=valid)
         assert gn == wn and np.array_equal(got, want)
     assert wn > n // 10
+
+
+@pytest.mark.parametrize("model,setup", [(0, 0), (0, 1), (1, 0)])
+def test_fuse_replace_duplication(match, synth, oracle, model, setup):
+    """fuse::replace_duplication's candidate search: landmarks back-projected from the keyframe's own keypoints (some with wrong
+    depth range / viewing direction / level) plus distractors."""
+    from openvslam_amd import _lib
+    rows, cols, n = (960, 1920, 3000) if model == 1 else (720, 1280, 2000)
+    ck, cd, Tc, lk, lpw, ld, _, valid, (fx, fy, cx, cy) = _last_and_current(synth, model, rows, cols, n, 40 + model + setup, 0.0)
+    m = len(lk)
+    rng = np.random.default_rng(7)
+    R, t = Tc[:, :3], Tc[:, 3]
+    cc = -R.T @ t
+    v = lpw - cc
+    dist = np.linalg.norm(v, axis=1)
+    sf = np.cumprod(np.concatenate([[1.0], np.full(7, 1.2)]).astype(np.float32)).astype(np.float32)
+    ils = (1.0 / (sf * sf)).astype(np.float32)
+    lvl = np.clip(lk["octave"] + rng.integers(0, 2, m), 0, 7)
+    dmax = (dist * sf[lvl] * rng.uniform(0.85, 1.0, m)).astype(np.float32)      # predict_scale_level inverts this
+    dmin = (dmax / sf[7] * rng.uniform(0.5, 1.3, m)).astype(np.float32)
+    dmm = np.ascontiguousarray(np.stack([dmin, dmax], 1))
+    nrm = v / dist[:, None]
+    flip = rng.random(m) < 0.15
+    nrm[flip] = rng.normal(0, 1, (int(flip.sum()), 3))
+    cam = _lib.Camera(model, setup, fx, fy, cx, cy, 0.12 * fx, 0.12, cols, rows)
+    ocam = oracle.Camera(model, setup, fx, fy, cx, cy, 0.12 * fx, 0.12, cols, rows)
+    gp, ogp = match.grid_params(cols, rows), oracle.grid_params(cols, rows)
+    xr = None
+    if setup:
+        xr = np.where(rng.random(n) < 0.6, ck["x"] - 0.12 * fx / rng.uniform(2, 20, n), -1.0).astype(np.float32)
+    w = match.fuse(0.6, max_targets=4096, max_queries=4096)
+    for margin in (3.0, 8.0):
+        got, gn = w.replace_duplication(cam, gp, ck, cd, Tc, lpw, dmm, nrm, ld, sf, ils, float(np.log(np.float32(1.2))), margin,
+                                        keyfrm_stereo_x_right=xr, lm_valid=valid)
+        want, wn = oracle.fuse_replace_duplication(ocam, ogp, ck, cd, Tc, lpw, dmm, nrm, ld, sf, ils, float(np.log(np.float32(1.2))), margin,
+                                                   kf_stereo_x_right=xr, lm_valid=valid)
+        assert gn == wn and np.array_equal(got, want)
+    assert wn > n // 20
