@@ -312,6 +312,12 @@ typedef struct ovs_ba_edge {   /* one observation: reproj_edge_wrapper */
     double inv_sigma_sq;       /* information = inv_level_sigma_sq[octave] * I2 */
 } ovs_ba_edge;
 
+typedef struct ovs_ba_edge_stereo {   /* one stereo observation: stereo_perspective_reproj_edge (3 residuals: u, v, u_right) */
+    int32_t pose_idx, point_idx;
+    double obs_x, obs_y, obs_x_right;
+    double inv_sigma_sq;              /* information = inv_level_sigma_sq[octave] * I3 */
+} ovs_ba_edge_stereo;
+
 /* poses: n_pose x 7 = (tx,ty,tz,qx,qy,qz,qw), world->camera (g2o SE3Quat::toVector order); pose_fixed: NULL or n_pose bytes;
  * points: n_pt x 3. huber_delta <= 0 disables the robust kernel (the second optimisation round).
  * Outputs: Hpp n_pose x 36 (row-major 6x6, pose order omega then upsilon), bp n_pose x 6, Hll n_pt x 9, bl n_pt x 3,
@@ -325,6 +331,19 @@ ovs_status ovs_ba_linearize(int32_t device, const double* poses, const uint8_t* 
 ovs_status ovs_ba_linearize_dev(const double* d_poses, const uint8_t* d_pose_fixed, int32_t n_pose, const double* d_points,
                                 int32_t n_pt, const ovs_ba_edge* d_edges, int32_t n_edge, const ovs_ba_cam* cam, double huber_delta,
                                 double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream);
+
+/* Stereo edges (replaces: optimize::g2o::se3::stereo_perspective_reproj_edge::computeError / linearizeOplus,
+ * src/openvslam/optimize/g2o/se3/perspective_reproj_edge.{h,cc}): e = (u, v, u_r) - pi(RX + t), u_r = u - focal_x_baseline / z;
+ * Huber delta sqrt(7.815) in local BA. Same outputs as ovs_ba_linearize (Hpl: n_edge x 18 for THESE edges). The device form can
+ * accumulate (accumulate != 0) into blocks a preceding mono call produced, which is how a stereo / RGBD local BA mixes both. */
+ovs_status ovs_ba_linearize_stereo(int32_t device, const double* poses, const uint8_t* pose_fixed, int32_t n_pose, const double* points,
+                                   int32_t n_pt, const ovs_ba_edge_stereo* edges, int32_t n_edge, const ovs_ba_cam* cam,
+                                   double focal_x_baseline, double huber_delta, double* Hpp, double* bp, double* Hll, double* bl,
+                                   double* Hpl, double* chi2);
+ovs_status ovs_ba_linearize_stereo_dev(const double* d_poses, const uint8_t* d_pose_fixed, int32_t n_pose, const double* d_points,
+                                       int32_t n_pt, const ovs_ba_edge_stereo* d_edges, int32_t n_edge, const ovs_ba_cam* cam,
+                                       double focal_x_baseline, double huber_delta, int32_t accumulate, double* d_Hpp, double* d_bp,
+                                       double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,29 @@ def linearize(poses, pose_fixed, points, edges, cam, huber_delta, device=0):
     return out
 
 
+EDGE_STEREO_DTYPE = np.dtype([("pose_idx", "<i4"), ("point_idx", "<i4"), ("obs_x", "<f8"), ("obs_y", "<f8"), ("obs_x_right", "<f8"),
+                              ("inv_sigma_sq", "<f8")])
+assert EDGE_STEREO_DTYPE.itemsize == 40
+
+
+def linearize_stereo(poses, pose_fixed, points, edges, cam, focal_x_baseline, huber_delta, device=0):
+    """Stereo reprojection edges (3 residuals), host buffers in / out (ovs_ba_linearize_stereo). cam = (fx, fy, cx, cy)."""
+    L = _lib.lib()
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    edges = np.ascontiguousarray(edges, EDGE_STEREO_DTYPE)
+    fixed = None if pose_fixed is None else np.ascontiguousarray(pose_fixed, np.uint8)
+    n_pose, n_pt, n_edge = len(poses), len(points), len(edges)
+    out = dict(Hpp=np.zeros((n_pose, 6, 6)), bp=np.zeros((n_pose, 6)), Hll=np.zeros((n_pt, 3, 3)), bl=np.zeros((n_pt, 3)),
+               Hpl=np.zeros((max(n_edge, 1), 6, 3)), chi2=np.zeros(2))
+    c = BaCam(*cam)
+    _lib.check(L.ovs_ba_linearize_stereo(device, _p(poses), _p(fixed), n_pose, _p(points), n_pt, _p(edges), n_edge, C.byref(c),
+                                         float(focal_x_baseline), float(huber_delta), _p(out["Hpp"]), _p(out["bp"]), _p(out["Hll"]),
+                                         _p(out["bl"]), _p(out["Hpl"]), _p(out["chi2"])), "ovs_ba_linearize_stereo")
+    out["Hpl"] = out["Hpl"][:n_edge]
+    return out
+
+
 def shard_edges_by_keyframe(edges, n_pose, rank, world):
     """Edges of keyframes [rank*ceil(n_pose/world), ...): contiguous keyframe blocks, 2000 edges each in config 5."""
     per = -(-n_pose // world)

@@ -24,19 +24,41 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
+// D = 2: mono_perspective_reproj_edge; D = 3: stereo_perspective_reproj_edge (third residual u_r = u - bf / z).
+template <int D>
+struct EdgeOf;
+template <>
+struct EdgeOf<2> {
+    typedef ovs_ba_edge type;
+};
+template <>
+struct EdgeOf<3> {
+    typedef ovs_ba_edge_stereo type;
+};
+
+template <int D>
+__device__ __forceinline__ double dotD(const double (&A)[D][6], int a, const double (&B)[D][6], int b) {
+    double s = A[0][a] * B[0][b];
+#pragma unroll
+    for (int k = 1; k < D; ++k) s = s + A[k][a] * B[k][b];
+    return s;
+}
+
+template <int D>
 __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__ poses, const uint8_t* __restrict__ pose_fixed,
                                                      int n_pose, const double* __restrict__ points, int n_pt,
-                                                     const ovs_ba_edge* __restrict__ edges, int n_edge, ovs_ba_cam cam,
-                                                     double huber_delta, double* __restrict__ Hpp, double* __restrict__ bp,
+                                                     const typename EdgeOf<D>::type* __restrict__ edges, int n_edge, ovs_ba_cam cam,
+                                                     double bf, double huber_delta, double* __restrict__ Hpp, double* __restrict__ bp,
                                                      double* __restrict__ Hll, double* __restrict__ bl, double* __restrict__ Hpl,
                                                      double* __restrict__ chi2) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     const bool valid = e < n_edge;
     int pose = -1, pt = 0;
-    double Jl[2][3] = {}, Jp[2][6] = {};
-    double W = 0, r0 = 0, r1 = 0, c2 = 0, rho0 = 0;
+    // Jacobians padded to 6 columns so the landmark (3) and pose (6) blocks share dotD
+    double Jl[D][6] = {}, Jp[D][6] = {};
+    double W = 0, r[D] = {}, c2 = 0, rho0 = 0;
     if (valid) {
-        const ovs_ba_edge ed = edges[e];
+        const typename EdgeOf<D>::type ed = edges[e];
         pose = ed.pose_idx;
         pt = ed.point_idx;
         const double* P = poses + 7 * (size_t)pose;
@@ -52,10 +74,17 @@ __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__
         const double y = R[1][0] * X0 + R[1][1] * X1 + R[1][2] * X2 + P[1];
         const double z = R[2][0] * X0 + R[2][1] * X1 + R[2][2] * X2 + P[2];
         const double invz = 1.0 / z, invz2 = invz * invz;
-        const double e0 = ed.obs_x - (cam.fx * x * invz + cam.cx);
-        const double e1 = ed.obs_y - (cam.fy * y * invz + cam.cy);
+        double er[D];
+        const double u = cam.fx * x * invz + cam.cx;
+        er[0] = ed.obs_x - u;
+        er[1] = ed.obs_y - (cam.fy * y * invz + cam.cy);
+        double ss = er[0] * er[0] + er[1] * er[1];
+        if constexpr (D == 3) {
+            er[2] = ed.obs_x_right - (u - bf * invz);
+            ss = ss + er[2] * er[2];
+        }
         const double w = ed.inv_sigma_sq;
-        c2 = w * (e0 * e0 + e1 * e1);
+        c2 = w * ss;
         rho0 = c2;
         double rho1 = 1.0;
         const double dsqr = huber_delta * huber_delta;
@@ -68,6 +97,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__
         for (int c = 0; c < 3; ++c) {
             Jl[0][c] = -invz * (cam.fx * R[0][c] - cam.fx * x * invz * R[2][c]);
             Jl[1][c] = -invz * (cam.fy * R[1][c] - cam.fy * y * invz * R[2][c]);
+            if constexpr (D == 3) Jl[2][c] = Jl[0][c] - bf * R[2][c] * invz2;
         }
         Jp[0][0] = x * y * invz2 * cam.fx;
         Jp[0][1] = -(1 + x * x * invz2) * cam.fx;
@@ -81,17 +111,28 @@ __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__
         Jp[1][3] = 0;
         Jp[1][4] = -invz * cam.fy;
         Jp[1][5] = y * invz2 * cam.fy;
+        if constexpr (D == 3) {
+            Jp[2][0] = Jp[0][0] - bf * y * invz2;
+            Jp[2][1] = Jp[0][1] + bf * x * invz2;
+            Jp[2][2] = Jp[0][2];
+            Jp[2][3] = Jp[0][3];
+            Jp[2][4] = 0;
+            Jp[2][5] = Jp[0][5] - bf * invz2;
+        }
         W = rho1 * w;
-        r0 = -W * e0;
-        r1 = -W * e1;
+#pragma unroll
+        for (int k = 0; k < D; ++k) r[k] = -W * er[k];
         // landmark block: scattered fp64 atomics
         double* hl = Hll + 9 * (size_t)pt;
         double* gl = bl + 3 * (size_t)pt;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
 #pragma unroll
-            for (int b = 0; b < 3; ++b) atomicAdd(&hl[3 * a + b], W * (Jl[0][a] * Jl[0][b] + Jl[1][a] * Jl[1][b]));
-            atomicAdd(&gl[a], Jl[0][a] * r0 + Jl[1][a] * r1);
+            for (int b = 0; b < 3; ++b) atomicAdd(&hl[3 * a + b], W * dotD<D>(Jl, a, Jl, b));
+            double g = Jl[0][a] * r[0];
+#pragma unroll
+            for (int k = 1; k < D; ++k) g = g + Jl[k][a] * r[k];
+            atomicAdd(&gl[a], g);
         }
     }
     const bool free_pose = valid && !(pose_fixed && pose_fixed[pose]);
@@ -100,7 +141,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) hpl[3 * a + b] = W * (Jp[0][a] * Jl[0][b] + Jp[1][a] * Jl[1][b]);
+            for (int b = 0; b < 3; ++b) hpl[3 * a + b] = W * dotD<D>(Jp, a, Jl, b);
     }
     // chi2: one atomic per wave
     {
@@ -110,6 +151,12 @@ __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__
             atomicAdd(&chi2[1], s1);
         }
     }
+    auto grad = [&](int a) {
+        double g = Jp[0][a] * r[0];
+#pragma unroll
+        for (int k = 1; k < D; ++k) g = g + Jp[k][a] * r[k];
+        return g;
+    };
     // pose block
     const int p0 = __builtin_amdgcn_readfirstlane(pose);
     const bool uniform = __all(!valid || pose == p0) && p0 >= 0;
@@ -123,13 +170,13 @@ __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__
             for (int a = 0; a < 6; ++a) {
 #pragma unroll
                 for (int b = a; b < 6; ++b) {
-                    const double s = wave_sum_f64(m * (W * (Jp[0][a] * Jp[0][b] + Jp[1][a] * Jp[1][b])));
+                    const double s = wave_sum_f64(m * (W * dotD<D>(Jp, a, Jp, b)));
                     if ((threadIdx.x & 63) == 0) {
                         atomicAdd(&hp[6 * a + b], s);
                         if (b != a) atomicAdd(&hp[6 * b + a], s);
                     }
                 }
-                const double g = wave_sum_f64(m * (Jp[0][a] * r0 + Jp[1][a] * r1));
+                const double g = wave_sum_f64(m * grad(a));
                 if ((threadIdx.x & 63) == 0) atomicAdd(&gp[a], g);
             }
         }
@@ -139,8 +186,8 @@ __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
 #pragma unroll
-            for (int b = 0; b < 6; ++b) atomicAdd(&hp[6 * a + b], W * (Jp[0][a] * Jp[0][b] + Jp[1][a] * Jp[1][b]));
-            atomicAdd(&gp[a], Jp[0][a] * r0 + Jp[1][a] * r1);
+            for (int b = 0; b < 6; ++b) atomicAdd(&hp[6 * a + b], W * dotD<D>(Jp, a, Jp, b));
+            atomicAdd(&gp[a], grad(a));
         }
     }
 }
@@ -165,10 +212,91 @@ ovs_status ovs_ba_linearize_dev(const double* d_poses, const uint8_t* d_pose_fix
     OVS_HIP_TRY(hipMemsetAsync(d_chi2, 0, sizeof(double) * 2, s));
     if (n_edge == 0) return OVS_OK;
     OVS_HIP_TRY(hipMemsetAsync(d_Hpl, 0, sizeof(double) * 18 * (size_t)n_edge, s));   // blocks of fixed poses stay zero
-    hipLaunchKernelGGL(k_ba_linearize, dim3((n_edge + 255) / 256), dim3(256), 0, s, d_poses, d_pose_fixed, n_pose, d_points, n_pt, d_edges,
-                       n_edge, *cam, huber_delta, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi2);
+    hipLaunchKernelGGL(k_ba_linearize<2>, dim3((n_edge + 255) / 256), dim3(256), 0, s, d_poses, d_pose_fixed, n_pose, d_points, n_pt, d_edges,
+                       n_edge, *cam, 0.0, huber_delta, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi2);
     OVS_HIP_TRY(hipGetLastError());
     return OVS_OK;
+}
+
+ovs_status ovs_ba_linearize_stereo_dev(const double* d_poses, const uint8_t* d_pose_fixed, int32_t n_pose, const double* d_points,
+                                       int32_t n_pt, const ovs_ba_edge_stereo* d_edges, int32_t n_edge, const ovs_ba_cam* cam,
+                                       double focal_x_baseline, double huber_delta, int32_t accumulate, double* d_Hpp, double* d_bp,
+                                       double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream) {
+    if (!d_poses || !d_points || !cam || !d_Hpp || !d_bp || !d_Hll || !d_bl || !d_Hpl || !d_chi2 || n_pose < 1 || n_pt < 1 || n_edge < 0 ||
+        (n_edge > 0 && !d_edges))
+        return OVS_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) {
+        OVS_HIP_TRY(hipMemsetAsync(d_Hpp, 0, sizeof(double) * 36 * (size_t)n_pose, s));
+        OVS_HIP_TRY(hipMemsetAsync(d_bp, 0, sizeof(double) * 6 * (size_t)n_pose, s));
+        OVS_HIP_TRY(hipMemsetAsync(d_Hll, 0, sizeof(double) * 9 * (size_t)n_pt, s));
+        OVS_HIP_TRY(hipMemsetAsync(d_bl, 0, sizeof(double) * 3 * (size_t)n_pt, s));
+        OVS_HIP_TRY(hipMemsetAsync(d_chi2, 0, sizeof(double) * 2, s));
+    }
+    if (n_edge == 0) return OVS_OK;
+    OVS_HIP_TRY(hipMemsetAsync(d_Hpl, 0, sizeof(double) * 18 * (size_t)n_edge, s));
+    hipLaunchKernelGGL(k_ba_linearize<3>, dim3((n_edge + 255) / 256), dim3(256), 0, s, d_poses, d_pose_fixed, n_pose, d_points, n_pt, d_edges,
+                       n_edge, *cam, focal_x_baseline, huber_delta, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi2);
+    OVS_HIP_TRY(hipGetLastError());
+    return OVS_OK;
+}
+
+ovs_status ovs_ba_linearize_stereo(int32_t device, const double* poses, const uint8_t* pose_fixed, int32_t n_pose, const double* points,
+                                   int32_t n_pt, const ovs_ba_edge_stereo* edges, int32_t n_edge, const ovs_ba_cam* cam,
+                                   double focal_x_baseline, double huber_delta, double* Hpp, double* bp, double* Hll, double* bl,
+                                   double* Hpl, double* chi2) {
+    if (!poses || !points || !cam || !Hpp || !bp || !Hll || !bl || !Hpl || !chi2 || n_pose < 1 || n_pt < 1 || n_edge < 0 || (n_edge > 0 && !edges))
+        return OVS_ERR_INVALID;
+    if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
+    OVS_HIP_TRY(hipSetDevice(device));
+    const size_t ne = (size_t)std::max(n_edge, 1);
+    const size_t n_out = (size_t)42 * n_pose + (size_t)12 * n_pt + 18 * ne + 2;
+    double *d_poses = nullptr, *d_points = nullptr, *d_out = nullptr;
+    ovs_ba_edge_stereo* d_edges = nullptr;
+    uint8_t* d_fixed = nullptr;
+    ovs_status st = OVS_ERR_HIP;
+    hipError_t er = hipSuccess;
+    do {
+#define BA_TRY(expr)                              \
+    if ((er = (expr)) != hipSuccess) {            \
+        ovs::set_last_error(#expr, er);           \
+        break;                                    \
+    }
+        BA_TRY(hipMalloc(&d_poses, sizeof(double) * 7 * n_pose));
+        BA_TRY(hipMalloc(&d_points, sizeof(double) * 3 * n_pt));
+        BA_TRY(hipMalloc(&d_edges, sizeof(ovs_ba_edge_stereo) * ne));
+        BA_TRY(hipMalloc(&d_fixed, (size_t)n_pose));
+        BA_TRY(hipMalloc(&d_out, sizeof(double) * n_out));
+        BA_TRY(hipMemcpy(d_poses, poses, sizeof(double) * 7 * n_pose, hipMemcpyHostToDevice));
+        BA_TRY(hipMemcpy(d_points, points, sizeof(double) * 3 * n_pt, hipMemcpyHostToDevice));
+        if (n_edge) BA_TRY(hipMemcpy(d_edges, edges, sizeof(ovs_ba_edge_stereo) * (size_t)n_edge, hipMemcpyHostToDevice));
+        if (pose_fixed) BA_TRY(hipMemcpy(d_fixed, pose_fixed, (size_t)n_pose, hipMemcpyHostToDevice));
+        double* dHpp = d_out;
+        double* dbp = dHpp + 36 * (size_t)n_pose;
+        double* dHll = dbp + 6 * (size_t)n_pose;
+        double* dbl = dHll + 9 * (size_t)n_pt;
+        double* dHpl = dbl + 3 * (size_t)n_pt;
+        double* dchi = dHpl + 18 * ne;
+        st = ovs_ba_linearize_stereo_dev(d_poses, pose_fixed ? d_fixed : nullptr, n_pose, d_points, n_pt, d_edges, n_edge, cam, focal_x_baseline,
+                                         huber_delta, 0, dHpp, dbp, dHll, dbl, dHpl, dchi, nullptr);
+        if (st != OVS_OK) break;
+        st = OVS_ERR_HIP;
+        BA_TRY(hipDeviceSynchronize());
+        BA_TRY(hipMemcpy(Hpp, dHpp, sizeof(double) * 36 * n_pose, hipMemcpyDeviceToHost));
+        BA_TRY(hipMemcpy(bp, dbp, sizeof(double) * 6 * n_pose, hipMemcpyDeviceToHost));
+        BA_TRY(hipMemcpy(Hll, dHll, sizeof(double) * 9 * n_pt, hipMemcpyDeviceToHost));
+        BA_TRY(hipMemcpy(bl, dbl, sizeof(double) * 3 * n_pt, hipMemcpyDeviceToHost));
+        if (n_edge) BA_TRY(hipMemcpy(Hpl, dHpl, sizeof(double) * 18 * (size_t)n_edge, hipMemcpyDeviceToHost));
+        BA_TRY(hipMemcpy(chi2, dchi, sizeof(double) * 2, hipMemcpyDeviceToHost));
+        st = OVS_OK;
+#undef BA_TRY
+    } while (0);
+    hipFree(d_poses);
+    hipFree(d_points);
+    hipFree(d_edges);
+    hipFree(d_fixed);
+    hipFree(d_out);
+    return st;
 }
 
 ovs_status ovs_ba_linearize(int32_t device, const double* poses, const uint8_t* pose_fixed, int32_t n_pose, const double* points,

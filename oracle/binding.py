@@ -433,3 +433,30 @@ def ba_linearize(poses, pose_fixed, points, edges, cam, huber_delta):
     assert rc == 0, rc
     out["Hpl"] = out["Hpl"][:n_edge]
     return out
+
+
+BA_EDGE_STEREO_DTYPE = np.dtype([("pose_idx", "<i4"), ("point_idx", "<i4"), ("obs_x", "<f8"), ("obs_y", "<f8"), ("obs_x_right", "<f8"),
+                                 ("inv_sigma_sq", "<f8")])
+
+
+def ba_linearize_stereo(poses, pose_fixed, points, edges, cam, focal_x_baseline, huber_delta, accumulate_into=None):
+    """Oracle restatement of the stereo reprojection edge (ovo_ba.cc). Returns dict(Hpp, bp, Hll, bl, Hpl, chi2)."""
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    edges = np.ascontiguousarray(edges, BA_EDGE_STEREO_DTYPE)
+    fixed = None if pose_fixed is None else np.ascontiguousarray(pose_fixed, np.uint8)
+    n_pose, n_pt, n_edge = len(poses), len(points), len(edges)
+    if accumulate_into is None:
+        out = dict(Hpp=np.zeros((n_pose, 6, 6)), bp=np.zeros((n_pose, 6)), Hll=np.zeros((n_pt, 3, 3)), bl=np.zeros((n_pt, 3)), chi2=np.zeros(2))
+    else:
+        out = {k: accumulate_into[k].copy() for k in ("Hpp", "bp", "Hll", "bl", "chi2")}
+    out["Hpl"] = np.zeros((max(n_edge, 1), 6, 3))
+    c = np.array(cam, np.float64)
+    L = lib()
+    L.ovo_ba_linearize_stereo.restype = C.c_int
+    rc = L.ovo_ba_linearize_stereo(_p(poses), _p(fixed), n_pose, _p(points), n_pt, _p(edges), n_edge, _p(c), C.c_double(focal_x_baseline),
+                                   C.c_double(huber_delta), int(accumulate_into is not None), _p(out["Hpp"]), _p(out["bp"]), _p(out["Hll"]),
+                                   _p(out["bl"]), _p(out["Hpl"]), _p(out["chi2"]))
+    assert rc == 0, rc
+    out["Hpl"] = out["Hpl"][:n_edge]
+    return out

@@ -105,4 +105,102 @@ int ovo_ba_linearize(const double* poses, const uint8_t* pose_fixed, int n_pose,
     return 0;
 }
 
+typedef struct ovo_ba_edge_stereo {
+    int32_t pose_idx, point_idx;
+    double obs_x, obs_y, obs_x_right;
+    double inv_sigma_sq;   // information = inv_level_sigma_sq[octave] * I3
+} ovo_ba_edge_stereo;
+
+// B1/B2 stereo variant: optimize::g2o::se3::stereo_perspective_reproj_edge (expected: src/openvslam/optimize/g2o/se3/
+// perspective_reproj_edge.cc; identical to ORB-SLAM2 EdgeStereoSE3ProjectXYZ): e = (u, v, u_r) - pi(RX + t) with
+// u_r = u - bf / z; row 2 of the Jacobians = row 0 corrected by the bf / z^2 terms. Same outputs / conventions as
+// ovo_ba_linearize; `accumulate` != 0 adds into the given blocks instead of zeroing them (mixed mono + stereo graphs).
+int ovo_ba_linearize_stereo(const double* poses, const uint8_t* pose_fixed, int n_pose, const double* points, int n_pt,
+                            const ovo_ba_edge_stereo* edges, int n_edge, const ovo_ba_cam* cam, double bf, double huber_delta,
+                            int accumulate, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* chi2) {
+    if (!accumulate) {
+        std::memset(Hpp, 0, sizeof(double) * 36 * n_pose);
+        std::memset(bp, 0, sizeof(double) * 6 * n_pose);
+        std::memset(Hll, 0, sizeof(double) * 9 * n_pt);
+        std::memset(bl, 0, sizeof(double) * 3 * n_pt);
+        chi2[0] = chi2[1] = 0.0;
+    }
+    std::memset(Hpl, 0, sizeof(double) * 18 * n_edge);
+    const double dsqr = huber_delta * huber_delta;
+    for (int e = 0; e < n_edge; ++e) {
+        const ovo_ba_edge_stereo& ed = edges[e];
+        if (ed.pose_idx < 0 || ed.pose_idx >= n_pose || ed.point_idx < 0 || ed.point_idx >= n_pt) return -1;
+        const double* P = poses + 7 * ed.pose_idx;
+        const double* X = points + 3 * ed.point_idx;
+        const double qx = P[3], qy = P[4], qz = P[5], qw = P[6];
+        const double tx2 = 2 * qx, ty2 = 2 * qy, tz2 = 2 * qz;
+        const double twx = tx2 * qw, twy = ty2 * qw, twz = tz2 * qw;
+        const double txx = tx2 * qx, txy = ty2 * qx, txz = tz2 * qx;
+        const double tyy = ty2 * qy, tyz = tz2 * qy, tzz = tz2 * qz;
+        const double R[3][3] = {{1 - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1 - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1 - (txx + tyy)}};
+        const double x = R[0][0] * X[0] + R[0][1] * X[1] + R[0][2] * X[2] + P[0];
+        const double y = R[1][0] * X[0] + R[1][1] * X[1] + R[1][2] * X[2] + P[1];
+        const double z = R[2][0] * X[0] + R[2][1] * X[1] + R[2][2] * X[2] + P[2];
+        const double invz = 1.0 / z, invz2 = invz * invz;
+        const double u = cam->fx * x * invz + cam->cx;
+        double er[3];
+        er[0] = ed.obs_x - u;
+        er[1] = ed.obs_y - (cam->fy * y * invz + cam->cy);
+        er[2] = ed.obs_x_right - (u - bf * invz);
+        const double w = ed.inv_sigma_sq;
+        const double c2 = w * ((er[0] * er[0] + er[1] * er[1]) + er[2] * er[2]);
+        double rho0 = c2, rho1 = 1.0;
+        if (huber_delta > 0 && c2 > dsqr) {
+            const double sq = std::sqrt(c2);
+            rho0 = 2 * sq * huber_delta - dsqr;
+            rho1 = huber_delta / sq;
+        }
+        chi2[0] += c2;
+        chi2[1] += rho0;
+        double Jl[3][3], Jp[3][6];
+        for (int c = 0; c < 3; ++c) {
+            Jl[0][c] = -invz * (cam->fx * R[0][c] - cam->fx * x * invz * R[2][c]);
+            Jl[1][c] = -invz * (cam->fy * R[1][c] - cam->fy * y * invz * R[2][c]);
+            Jl[2][c] = Jl[0][c] - bf * R[2][c] * invz2;
+        }
+        Jp[0][0] = x * y * invz2 * cam->fx;
+        Jp[0][1] = -(1 + x * x * invz2) * cam->fx;
+        Jp[0][2] = y * invz * cam->fx;
+        Jp[0][3] = -invz * cam->fx;
+        Jp[0][4] = 0;
+        Jp[0][5] = x * invz2 * cam->fx;
+        Jp[1][0] = (1 + y * y * invz2) * cam->fy;
+        Jp[1][1] = -x * y * invz2 * cam->fy;
+        Jp[1][2] = -x * invz * cam->fy;
+        Jp[1][3] = 0;
+        Jp[1][4] = -invz * cam->fy;
+        Jp[1][5] = y * invz2 * cam->fy;
+        Jp[2][0] = Jp[0][0] - bf * y * invz2;
+        Jp[2][1] = Jp[0][1] + bf * x * invz2;
+        Jp[2][2] = Jp[0][2];
+        Jp[2][3] = Jp[0][3];
+        Jp[2][4] = 0;
+        Jp[2][5] = Jp[0][5] - bf * invz2;
+        const double W = rho1 * w;
+        const double r[3] = {-W * er[0], -W * er[1], -W * er[2]};
+        double* hl = Hll + 9 * ed.point_idx;
+        double* gl = bl + 3 * ed.point_idx;
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) hl[3 * a + b] += W * ((Jl[0][a] * Jl[0][b] + Jl[1][a] * Jl[1][b]) + Jl[2][a] * Jl[2][b]);
+            gl[a] += (Jl[0][a] * r[0] + Jl[1][a] * r[1]) + Jl[2][a] * r[2];
+        }
+        if (!(pose_fixed && pose_fixed[ed.pose_idx])) {
+            double* hp = Hpp + 36 * ed.pose_idx;
+            double* gp = bp + 6 * ed.pose_idx;
+            double* hpl = Hpl + 18 * (size_t)e;
+            for (int a = 0; a < 6; ++a) {
+                for (int b = 0; b < 6; ++b) hp[6 * a + b] += W * ((Jp[0][a] * Jp[0][b] + Jp[1][a] * Jp[1][b]) + Jp[2][a] * Jp[2][b]);
+                gp[a] += (Jp[0][a] * r[0] + Jp[1][a] * r[1]) + Jp[2][a] * r[2];
+                for (int b = 0; b < 3; ++b) hpl[3 * a + b] = W * ((Jp[0][a] * Jl[0][b] + Jp[1][a] * Jl[1][b]) + Jp[2][a] * Jl[2][b]);
+            }
+        }
+    }
+    return 0;
+}
+
 }   // extern "C"

@@ -62,3 +62,52 @@ def test_shard_partition(oracle):
         for i in range(world):
             for j in range(i + 1, world):
                 assert not (owners[i] & owners[j])
+
+
+def test_stereo_edge_jacobians_by_finite_differences(oracle):
+    """The stereo edge's analytic Jacobians (oracle) against central differences of its residual: J_point directly, J_pose through
+    the left-multiplicative SE3 update exp([omega, upsilon]) * T that g2o applies (order omega then upsilon)."""
+    from openvslam_amd.ba import quat_to_rot, rot_to_quat
+    rng = np.random.default_rng(4)
+    cam, bf = (520.0, 510.0, 320.0, 240.0), 0.11 * 520.0
+    R = quat_to_rot(np.array([0.1, -0.2, 0.05, 0.97]) / np.linalg.norm([0.1, -0.2, 0.05, 0.97]))
+    t = np.array([0.2, -0.1, 0.3])
+    X = np.array([0.4, -0.3, 4.0])
+    obs = np.array([400.0, 260.0, 380.0])
+
+    def residual(Rm, tv, Xv):
+        p = Rm @ Xv + tv
+        u = cam[0] * p[0] / p[2] + cam[2]
+        return obs - np.array([u, cam[1] * p[1] / p[2] + cam[3], u - bf / p[2]])
+
+    pose = np.concatenate([t, rot_to_quat(R)])[None]
+    e = np.zeros(1, oracle.BA_EDGE_STEREO_DTYPE)
+    e["obs_x"], e["obs_y"], e["obs_x_right"], e["inv_sigma_sq"] = obs[0], obs[1], obs[2], 1.0
+    out = oracle.ba_linearize_stereo(pose, None, X[None], e, cam, bf, 0.0)
+    # with W = I: Hll = Jl^T Jl, bl = -Jl^T e, Hpp = Jp^T Jp, bp = -Jp^T e
+    h = 1e-6
+    Jl = np.stack([(residual(R, t, X + h * np.eye(3)[i]) - residual(R, t, X - h * np.eye(3)[i])) / (2 * h) for i in range(3)], 1)
+
+    def exp_se3(w, v):
+        th = np.linalg.norm(w)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        if th < 1e-12:
+            return np.eye(3) + K, v
+        Rm = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * K @ K
+        return Rm, V @ v
+
+    cols = []
+    for i in range(6):
+        d6 = np.zeros(6)
+        d6[i] = h
+        Rp, tp = exp_se3(d6[:3], d6[3:])
+        Rm, tm = exp_se3(-d6[:3], -d6[3:])
+        cols.append((residual(Rp @ R, Rp @ t + tp, X) - residual(Rm @ R, Rm @ t + tm, X)) / (2 * h))
+    Jp = np.stack(cols, 1)
+    r0 = residual(R, t, X)
+    assert np.allclose(out["Hll"][0], Jl.T @ Jl, rtol=1e-5, atol=1e-4)
+    assert np.allclose(out["bl"][0], -Jl.T @ r0, rtol=1e-5, atol=1e-4)
+    assert np.allclose(out["Hpp"][0], Jp.T @ Jp, rtol=1e-5, atol=1e-2)
+    assert np.allclose(out["bp"][0], -Jp.T @ r0, rtol=1e-5, atol=1e-2)
+    assert np.allclose(out["Hpl"][0], Jp.T @ Jl, rtol=1e-5, atol=1e-3)

@@ -48,3 +48,37 @@ def test_device_linearizer_single_rank(oracle):
     got = {k: v.cpu().numpy() for k, v in out.items()}
     want = oracle.ba_linearize(d["poses"], d["pose_fixed"], d["points"], d["edges"], d["cam"], d["huber_delta"])
     _check(got, want, 1e-12)
+
+
+def _stereo_edges(d, bf, frac=1.0, seed=0):
+    """Stereo observations for a synth_local_ba scene: u_r = u - bf / z + N(0, 1)."""
+    from openvslam_amd import ba
+    rng = np.random.default_rng(seed)
+    e = d["edges"]
+    keep = rng.random(len(e)) < frac
+    e = e[keep]
+    se = np.zeros(len(e), ba.EDGE_STEREO_DTYPE)
+    for k in ("pose_idx", "point_idx", "obs_x", "obs_y", "inv_sigma_sq"):
+        se[k] = e[k]
+    # depth of each point in its keyframe
+    from openvslam_amd.ba import quat_to_rot
+    z = np.empty(len(e))
+    for p in np.unique(e["pose_idx"]):
+        R = quat_to_rot(d["poses_true"][p, 3:])
+        sel = e["pose_idx"] == p
+        z[sel] = (d["points_true"][e["point_idx"][sel]] @ R.T + d["poses_true"][p, :3])[:, 2]
+    se["obs_x_right"] = e["obs_x"] - bf / z + rng.normal(0, 1, len(e))
+    return se, d["edges"][~keep]
+
+
+@pytest.mark.parametrize("huber", [True, False])
+def test_stereo_edges(oracle, huber):
+    from openvslam_amd import ba
+    d = synth_local_ba(n_pose=20, n_pt=5000, obs_per_pose=1500, seed=3, pose_noise=0.02, point_noise=0.02)
+    bf = 0.12 * d["cam"][0]
+    se, _ = _stereo_edges(d, bf)
+    delta = float(np.sqrt(7.815)) if huber else 0.0
+    got = ba.linearize_stereo(d["poses"], d["pose_fixed"], d["points"], se, d["cam"], bf, delta)
+    want = oracle.ba_linearize_stereo(d["poses"], d["pose_fixed"], d["points"], se, d["cam"], bf, delta)
+    _check(got, want, 1e-12)
+    assert len(se) == 30000 and want["chi2"][0] > 0
