@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true", help="skip the local-BA side section (profiling runs)")
+    ap.add_argument("--pipeline", type=int, default=1, help="sub-batches of the extract issued on overlapping internal streams (1 = off)")
     args = ap.parse_args()
 
     import torch
@@ -84,6 +85,8 @@ def main():
     d_frames = torch.from_numpy(frames).cuda()
     ex = feature.orb_extractor(feature.orb_params(NFEAT, 1.2, LEVELS, 20, 7), max_rows=ROWS, max_cols=COLS, max_batch=B,
                                device=local_rank)
+    if args.pipeline > 1:
+        ex.set_pipeline(args.pipeline)
     cap = ex.max_keypoints
     mt = match.robust(LOWE_RATIO, False, max_n1=cap, max_n2=cap, max_batch=B, device=local_rank)
     d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")

@@ -98,6 +98,12 @@ ovs_status ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_images, int32_
                                      size_t frame_stride, const uint8_t* d_masks, ovs_keypoint* d_kps, uint8_t* d_desc,
                                      int32_t* d_counts, int32_t cap, void* stream);
 
+/* Sub-batch pipelining of ovs_orb_extract_batch_dev (no upstream counterpart: upstream extracts one frame per call). With
+ * n_sub > 1 the batch is cut into n_sub contiguous sub-batches whose pyramid -> FAST -> quad-tree -> describe chains are issued on
+ * n_sub internal streams, forked from / joined to the caller's stream with events: the latency-bound stages of one sub-batch
+ * overlap the VALU-bound FAST pass of another. Results are identical (frames are independent). n_sub in [1, 4]; 1 = off. */
+ovs_status ovs_orb_set_pipeline(ovs_orb* h, int32_t n_sub);
+
 /* replaces: the public member orb_extractor::image_pyramid_ (read by match::stereo). Copies level `level` of frame
  * `frame` (0 for the host API) of the LAST extract into host_dst (rows*cols bytes, contiguous) and reports its size.
  * host_dst may be NULL to query the size only. Synchronises the handle's stream. */

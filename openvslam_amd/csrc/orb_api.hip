@@ -72,6 +72,12 @@ struct ovs_orb {
     size_t last_stride0 = 0, last_frame_stride0 = 0;
     int last_batch = 0;
     StageProfiler<4> prof;
+    // optional sub-batch pipelining of the device-batch path (ovs_orb_set_pipeline)
+    static constexpr int kMaxSub = 4;
+    int pipeline = 1;
+    hipStream_t sub_stream[kMaxSub] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxSub] = {};
+    StageProfiler<4> prof_sub[kMaxSub];
 };
 
 namespace {
@@ -204,31 +210,67 @@ ovs_status ensure_geometry(ovs_orb* h, int rows, int cols) {
     return OVS_OK;
 }
 
-ovs_status run_extract(ovs_orb* h, const uint8_t* d_images, int batch, int rows, int cols, size_t stride, size_t frame_stride,
-                       const uint8_t* d_masks, ovs_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int cap, hipStream_t s) {
-    ovs_status st = ensure_geometry(h, rows, cols);
-    if (st != OVS_OK) return st;
+// pyramid -> FAST -> quad-tree -> describe for frames [f0, f0 + nb) of the batch, on stream s
+ovs_status run_chain(ovs_orb* h, StageProfiler<4>& prof, const uint8_t* d_images, int f0, int nb, size_t stride, size_t frame_stride,
+                     const uint8_t* d_masks, ovs_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int cap, int rows, hipStream_t s) {
     const FrameGeo& geo = h->geo;
     const int L = geo.num_levels;
-    OVS_HIP_TRY(hipMemsetAsync(h->d.cand_count, 0, sizeof(uint32_t) * (size_t)batch * L, s));
-    OVS_HIP_TRY(h->prof.begin(s));
+    DevBuffers d = h->d;   // views of this sub-batch
+    d.pyr += (size_t)f0 * d.pyr_frame_bytes;
+    d.cand += (size_t)f0 * d.cand_frame_entries;
+    d.cand_count += (size_t)f0 * L;
+    d.nodes += (size_t)f0 * d.node_frame_entries * 4;
+    d.lvl_kps += (size_t)f0 * geo.total_kp_cap;
+    d.lvl_count += (size_t)f0 * L;
+    const uint8_t* img = d_images + (size_t)f0 * frame_stride;
+    const uint8_t* msk = d_masks ? d_masks + (size_t)f0 * frame_stride : nullptr;
+    OVS_HIP_TRY(prof.begin(s));
     // A1: each level from the previous one
     for (int l = 1; l < L; ++l) {
         const LevelGeo& g = geo.lv[l];
         const LevelGeo& gp = geo.lv[l - 1];
-        const uint8_t* src = (l == 1) ? d_images : h->d.pyr + gp.plane_off;
-        const size_t src_fs = (l == 1) ? frame_stride : h->d.pyr_frame_bytes;
+        const uint8_t* src = (l == 1) ? img : d.pyr + gp.plane_off;
+        const size_t src_fs = (l == 1) ? frame_stride : d.pyr_frame_bytes;
         const int src_pitch = (l == 1) ? (int)stride : gp.pitch;
-        OVS_HIP_TRY(launch_resize(src, src_fs, src_pitch, gp.rows, gp.cols, h->d.pyr + g.plane_off, h->d.pyr_frame_bytes, g.pitch,
-                                  g.rows, g.cols, h->d_taps + g.xtab_off, h->d_taps + g.ytab_off, batch, s));
+        OVS_HIP_TRY(launch_resize(src, src_fs, src_pitch, gp.rows, gp.cols, d.pyr + g.plane_off, d.pyr_frame_bytes, g.pitch, g.rows, g.cols,
+                                  h->d_taps + g.xtab_off, h->d_taps + g.ytab_off, nb, s));
     }
-    OVS_HIP_TRY(h->prof.mark(1, s));
-    OVS_HIP_TRY(launch_fast(geo, h->d, d_images, stride, frame_stride, d_masks, rows, batch, s));
-    OVS_HIP_TRY(h->prof.mark(2, s));
-    OVS_HIP_TRY(launch_tree(geo, h->d, batch, s));
-    OVS_HIP_TRY(h->prof.mark(3, s));
-    OVS_HIP_TRY(launch_describe(geo, h->d, d_images, stride, frame_stride, d_kps, d_desc, d_counts, cap, batch, s));
-    OVS_HIP_TRY(h->prof.mark(4, s));
+    OVS_HIP_TRY(prof.mark(1, s));
+    OVS_HIP_TRY(launch_fast(geo, d, img, stride, frame_stride, msk, rows, nb, s));
+    OVS_HIP_TRY(prof.mark(2, s));
+    OVS_HIP_TRY(launch_tree(geo, d, nb, s));
+    OVS_HIP_TRY(prof.mark(3, s));
+    OVS_HIP_TRY(launch_describe(geo, d, img, stride, frame_stride, d_kps + (size_t)f0 * cap, d_desc + (size_t)f0 * cap * 32, d_counts + f0, cap, nb, s));
+    OVS_HIP_TRY(prof.mark(4, s));
+    return OVS_OK;
+}
+
+ovs_status run_extract(ovs_orb* h, const uint8_t* d_images, int batch, int rows, int cols, size_t stride, size_t frame_stride,
+                       const uint8_t* d_masks, ovs_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int cap, hipStream_t s) {
+    ovs_status st = ensure_geometry(h, rows, cols);
+    if (st != OVS_OK) return st;
+    const int L = h->geo.num_levels;
+    OVS_HIP_TRY(hipMemsetAsync(h->d.cand_count, 0, sizeof(uint32_t) * (size_t)batch * L, s));
+    const int nsub = std::min(h->pipeline, batch);
+    if (nsub <= 1) {
+        st = run_chain(h, h->prof, d_images, 0, batch, stride, frame_stride, d_masks, d_kps, d_desc, d_counts, cap, rows, s);
+        if (st != OVS_OK) return st;
+    } else {
+        // fork: the sub-batches run their chains on the handle's own streams, so the latency-bound stages of one (pyramid, quad-tree,
+        // describe) overlap the VALU-bound FAST pass of another; join: the caller's stream waits for all of them
+        OVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
+        const int per = (batch + nsub - 1) / nsub;
+        for (int k = 0; k < nsub; ++k) {
+            const int f0 = k * per, nb = std::min(per, batch - f0);
+            if (nb <= 0) break;
+            OVS_HIP_TRY(hipStreamWaitEvent(h->sub_stream[k], h->ev_fork, 0));
+            h->prof_sub[k].enabled = h->prof.enabled;
+            st = run_chain(h, h->prof_sub[k], d_images, f0, nb, stride, frame_stride, d_masks, d_kps, d_desc, d_counts, cap, rows, h->sub_stream[k]);
+            if (st != OVS_OK) return st;
+            OVS_HIP_TRY(hipEventRecord(h->ev_join[k], h->sub_stream[k]));
+            OVS_HIP_TRY(hipStreamWaitEvent(s, h->ev_join[k], 0));
+        }
+    }
     h->last_img0 = d_images;
     h->last_stride0 = stride;
     h->last_frame_stride0 = frame_stride;
@@ -361,6 +403,15 @@ ovs_status ovs_orb_destroy(ovs_orb* h) {
     hipFree(h->d_out_desc);
     hipFree(h->d_out_counts);
     h->prof.destroy();
+    for (int k = 0; k < ovs_orb::kMaxSub; ++k) {
+        h->prof_sub[k].destroy();
+        if (h->sub_stream[k]) {
+            hipStreamSynchronize(h->sub_stream[k]);
+            hipStreamDestroy(h->sub_stream[k]);
+        }
+        if (h->ev_join[k]) hipEventDestroy(h->ev_join[k]);
+    }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return OVS_OK;
@@ -385,6 +436,10 @@ ovs_status ovs_orb_profile_enable(ovs_orb* h, int32_t enable) {
     OVS_HIP_TRY(hipSetDevice(h->device));
     h->prof.enabled = enable != 0;
     if (enable) OVS_HIP_TRY(h->prof.ensure());
+    for (int k = 0; k < h->pipeline && h->pipeline > 1; ++k) {
+        h->prof_sub[k].enabled = h->prof.enabled;
+        if (enable) OVS_HIP_TRY(h->prof_sub[k].ensure());
+    }
     return OVS_OK;
 }
 
@@ -392,6 +447,31 @@ ovs_status ovs_orb_profile_read(ovs_orb* h, float* stage_ms, int32_t* ncalls) {
     if (!h || !stage_ms || !ncalls) return OVS_ERR_INVALID;
     OVS_HIP_TRY(hipSetDevice(h->device));
     OVS_HIP_TRY(h->prof.read(stage_ms, ncalls));
+    // pipelined calls: every sub-batch recorded its own chain on its own stream; a stage's time is the sum of its launches' own
+    // durations (they overlap launches of other stages in wall time)
+    for (int k = 0; k < ovs_orb::kMaxSub; ++k) {
+        if (!h->prof_sub[k].created) continue;
+        float ms[4];
+        int32_t nc = 0;
+        OVS_HIP_TRY(h->prof_sub[k].read(ms, &nc));
+        for (int j = 0; j < 4; ++j) stage_ms[j] += ms[j];
+        if (k == 0) *ncalls += nc;
+    }
+    return OVS_OK;
+}
+
+ovs_status ovs_orb_set_pipeline(ovs_orb* h, int32_t n_sub) {
+    if (!h || n_sub < 1 || n_sub > ovs_orb::kMaxSub) return OVS_ERR_INVALID;
+    OVS_HIP_TRY(hipSetDevice(h->device));
+    if (n_sub > 1) {
+        if (!h->ev_fork) OVS_HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int k = 0; k < n_sub; ++k) {
+            if (!h->sub_stream[k]) OVS_HIP_TRY(hipStreamCreateWithFlags(&h->sub_stream[k], hipStreamNonBlocking));
+            if (!h->ev_join[k]) OVS_HIP_TRY(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
+            if (h->prof.enabled) OVS_HIP_TRY(h->prof_sub[k].ensure());
+        }
+    }
+    h->pipeline = n_sub;
     return OVS_OK;
 }
 

@@ -121,6 +121,10 @@ class orb_extractor:
                    "ovs_orb_extract")
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    def set_pipeline(self, n_sub):
+        """Issue the device-batch extract as n_sub overlapping sub-batches on internal streams (ovs_orb_set_pipeline)."""
+        _lib.check(self._L.ovs_orb_set_pipeline(self._h, int(n_sub)), "ovs_orb_set_pipeline")
+
     def extract_batch_dev(self, d_images, d_kps, d_desc, d_counts, stream=None, d_masks=None):
         """Device-resident batched extract. d_images: torch uint8 CUDA tensor (B, rows, cols) contiguous (cols % 4 == 0);
         outputs: d_kps (B, cap, 7) float32/int32 raw 28-byte records, d_desc (B, cap, 32) uint8, d_counts (B,) int32."""

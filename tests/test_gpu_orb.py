@@ -108,11 +108,14 @@ def test_mask(hip, oracle):
     assert np.array_equal(gk2.view(np.uint8), wk2.view(np.uint8)) and np.array_equal(gd2, wd2)
 
 
-def test_batch_dev_matches_host_api(hip, oracle):
+@pytest.mark.parametrize("pipeline", [1, 2, 3])
+def test_batch_dev_matches_host_api(hip, oracle, pipeline):
+    """Device-resident batch (optionally issued as overlapping sub-batches on internal streams) == oracle, frame by frame."""
     import torch
-    rows, cols, B = 480, 752, 3
+    rows, cols, B = 480, 752, 5
     imgs = np.stack([synth_frame(rows, cols, seed=10 + b) for b in range(B)])
     ex = hip.orb_extractor(hip.orb_params(max_num_keypts=1000), max_rows=rows, max_cols=cols, max_batch=B)
+    ex.set_pipeline(pipeline)
     cap = ex.max_keypoints
     d_img = torch.from_numpy(imgs).cuda()
     d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
