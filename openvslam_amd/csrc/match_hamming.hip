@@ -164,45 +164,56 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 //     before `best` is already claimed, anything after `second` cannot matter; a best > THR_LOW is a final reject);
 //   * all lanes below the first affected lane commit at once -- by induction their inputs were exact -- the rest go round again.
 // A chunk whose near list overflowed kNearSeg falls back to a literal one-query-at-a-time replay with cooperative scans.
-template <bool STAGED>
-__global__ __launch_bounds__(64) void k_bf_resolve(const uint8_t* __restrict__ desc_1, size_t stride_1,
-                                                  const int32_t* __restrict__ n1_arr, const uint8_t* __restrict__ desc_2,
-                                                  size_t stride_2, const int32_t* __restrict__ n2_arr, int max_n1, int max_n2,
-                                                  float lowe_ratio, const uint32_t* __restrict__ near_cnt,
-                                                  const uint32_t* __restrict__ near_list, const uint32_t* __restrict__ near_top,
-                                                  int32_t* __restrict__ pairs, int32_t* __restrict__ counts, int cap) {
+// NW = waves per problem (1 or 4): a round replays 64 * NW queries at once; with NW = 4 the four waves meet at workgroup barriers
+// (three per round) and the number of rounds per problem drops ~2.5x -- the kernel is pure dependent latency on otherwise idle CUs.
+template <bool STAGED, int NW>
+__global__ __launch_bounds__(64 * NW) void k_bf_resolve(const uint8_t* __restrict__ desc_1, size_t stride_1,
+                                                       const int32_t* __restrict__ n1_arr, const uint8_t* __restrict__ desc_2,
+                                                       size_t stride_2, const int32_t* __restrict__ n2_arr, int max_n1, int max_n2,
+                                                       float lowe_ratio, const uint32_t* __restrict__ near_cnt,
+                                                       const uint32_t* __restrict__ near_list, const uint32_t* __restrict__ near_top,
+                                                       int32_t* __restrict__ pairs, int32_t* __restrict__ counts, int cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // explicit LDS address space: a volatile GENERIC pointer would be lowered to flat, system-scope accesses
     typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
     typedef __attribute__((address_space(3))) volatile uint8_t lds_u8;
+    __shared__ uint32_t s_wave[NW];   // per-wave first affected thread / per-wave match count
+    constexpr int T = 64 * NW;
     lds_u32* mark = (lds_u32*)(smem);                                  // [max_n1]
     lds_u8* claimed = (lds_u8*)(smem + (size_t)max_n1 * 4);            // [max_n1]
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = blockIdx.x;
     const int n1 = n1_arr[p], n2 = n2_arr[p];
     const uint32_t* cnts = near_cnt + (size_t)p * max_n2 * kNearSplit;
     const uint32_t* lists = near_list + (size_t)p * max_n2 * kNearSplit * kNearSeg;
     const uint32_t* tops = near_top + (size_t)p * max_n2 * kTopK;
     int32_t* out = pairs + (size_t)p * cap * 2;
-    for (int i = lane; i < n1; i += 64) {
+    auto wg_barrier = [&]() __attribute__((always_inline)) {
+        if (NW == 1) __builtin_amdgcn_wave_barrier();
+        else __syncthreads();
+    };
+    auto wg_any = [&](bool v) __attribute__((always_inline)) -> bool {
+        if (NW == 1) return __ballot(v) != 0ull;
+        return __syncthreads_or(v ? 1 : 0) != 0;
+    };
+    for (int i = tid; i < n1; i += T) {
         claimed[i] = 0;
         mark[i] = ~0u;
     }
-    __builtin_amdgcn_wave_barrier();
     uint32_t n_out = 0;
     uint32_t epoch = 0;
 
-    // STAGED: every query's segment counts and sorted top-8 are copied into LDS up front (16 independent 16-byte loads per lane in
-    // flight), so the replay loop below never waits on HBM: with one wave per problem nothing else hides that latency, and hipcc
-    // cannot keep a software prefetch in flight across the loop's back edge (it drains vmcnt to 0 at the first use).
+    // STAGED: every query's segment counts and sorted top-8 are copied into LDS up front (independent 16-byte loads in flight), so
+    // the replay loop below never waits on HBM: nothing else hides that latency, and hipcc cannot keep a software prefetch in flight
+    // across the loop's back edge (it drains vmcnt to 0 at the first use).
     lds_u32* s_tops = (lds_u32*)(smem + (((size_t)max_n1 * 5 + 15) & ~(size_t)15));   // [n2][8]
     lds_u32* s_cnts = s_tops + (size_t)max_n2 * kTopK;                                // [n2] four saturated u8 counts
     if (STAGED) {
-        for (int q = lane; q < n2; q += 256) {
+        for (int q = tid; q < n2; q += 4 * T) {
             uint4 cc[4], lo[4], hi[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int qq = q + 64 * u;
+                const int qq = q + T * u;
                 if (qq < n2) {
                     cc[u] = *reinterpret_cast<const uint4*>(cnts + (size_t)qq * kNearSplit);
                     const uint4* src = reinterpret_cast<const uint4*>(tops + (size_t)qq * kTopK);
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(64) void k_bf_resolve(const uint8_t* __restrict__ d
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int qq = q + 64 * u;
+                const int qq = q + T * u;
                 if (qq < n2) {
                     s_cnts[qq] = min(cc[u].x, 255u) | (min(cc[u].y, 255u) << 8) | (min(cc[u].z, 255u) << 16) | (min(cc[u].w, 255u) << 24);
                     lds_u32* d = s_tops + (size_t)qq * kTopK;
@@ -221,10 +232,10 @@ __global__ __launch_bounds__(64) void k_bf_resolve(const uint8_t* __restrict__ d
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
     }
-    for (int q0 = 0; q0 < n2; q0 += 64) {
-        const int q = q0 + lane;
+    wg_barrier();
+    for (int q0 = 0; q0 < n2; q0 += T) {
+        const int q = q0 + tid;
         uint4 cc = make_uint4(0u, 0u, 0u, 0u), lo = make_uint4(~0u, ~0u, ~0u, ~0u), hi = lo;
         if (q < n2) {
             if (STAGED) {
@@ -253,10 +264,10 @@ __global__ __launch_bounds__(64) void k_bf_resolve(const uint8_t* __restrict__ d
             top[4] = hi.x; top[5] = hi.y; top[6] = hi.z; top[7] = hi.w;
         }
         int32_t my_match = -1;
+        bool more = c > (uint32_t)kTopK;   // the near list holds entries beyond the register top-8
 
-        // evaluation of this lane's query against the current claims (lists are complete: !over); by-value so nothing
-        // has its address taken (references into lambdas ended up in scratch)
-        auto evaluate = [=]() __attribute__((always_inline)) -> uint2 {
+        // evaluation of this lane's query against the current claims (lists are complete: !over)
+        auto evaluate = [&]() __attribute__((always_inline)) -> uint2 {
             uint32_t best = ~0u, second = ~0u;
             // the eight claim flags are fetched as one batch of independent LDS reads (through the volatile pointer every read
             // was followed by its own wait: ~8 serialized LDS round trips per evaluation); the compiler barrier at the top of each
@@ -273,22 +284,39 @@ __global__ __launch_bounds__(64) void k_bf_resolve(const uint8_t* __restrict__ d
                     else if (second == ~0u) second = e;
                 }
             }
-            if (second == ~0u && c > (uint32_t)kTopK) {   // rare: the top-8 is used up, rescan the whole near list
-                best = second = ~0u;
+            if (second == ~0u && more) {
+                // the top-8 has run dry but the near list is longer (dense clusters of near-duplicates): rescan the whole list, eight
+                // independent loads at a time (a one-entry-per-trip loop pays one HBM round trip per entry on an otherwise idle CU),
+                // and REFILL the register top-8 with the eight smallest keys that are still unclaimed, so the query does not rescan
+                // again until those are gone too.
+                uint32_t nt[kTopK];
+#pragma unroll
+                for (int k = 0; k < kTopK; ++k) nt[k] = ~0u;
                 const uint32_t* seg = lists + (size_t)q * kNearSplit * kNearSeg;
                 const uint32_t ends[4] = {c4x, c4y, c4z, c4w};
+                uint32_t alive_total = 0;
 #pragma unroll
                 for (int w = 0; w < kNearSplit; ++w) {
                     const uint32_t nw = ends[w];
-                    for (uint32_t k = 0; k < nw; ++k) {
-                        const uint32_t e = seg[w * kNearSeg + k];
-                        const bool alive = !claimed[e & 0xFFFFu];
-                        const uint32_t nb = (alive && e < best) ? e : best;
-                        const uint32_t ns = (alive && e < best) ? best : ((alive && e < second) ? e : second);
-                        best = nb;
-                        second = ns;
+                    for (uint32_t k0 = 0; k0 < nw; k0 += 8) {
+                        uint32_t e8[8], d8[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) e8[u] = k0 + u < nw ? seg[w * kNearSeg + k0 + u] : ~0u;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) d8[u] = e8[u] != ~0u ? (uint32_t)cl[e8[u] & 0xFFFFu] : 1u;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (!d8[u]) {
+                                ++alive_total;
+                                topk_insert(e8[u], nt);
+                            }
                     }
                 }
+#pragma unroll
+                for (int k = 0; k < kTopK; ++k) top[k] = nt[k];
+                more = alive_total > (uint32_t)kTopK;   // everything alive is now in registers unless there were more than eight
+                best = nt[0];
+                second = nt[1];
             }
             return make_uint2(best, second);
         };
@@ -299,10 +327,9 @@ __global__ __launch_bounds__(64) void k_bf_resolve(const uint8_t* __restrict__ d
             return bd <= (uint32_t)OVS_HAMMING_DIST_THR_LOW && !ratio_rejects(lowe_ratio, sd, bd);
         };
 
-        if (__ballot(over) == 0ull) {
-            unsigned long long unresolved = __ballot(c > 0);
-            while (unresolved) {
-                const bool mine = (unresolved >> lane) & 1ull;
+        if (!wg_any(over)) {
+            bool mine = c > 0;
+            while (wg_any(mine)) {   // (NW > 1: this barrier also publishes the previous round's commits)
                 uint32_t best = ~0u, second = ~0u;
                 bool acc = false;
                 asm volatile("" ::: "memory");   // claims committed in the previous round must be re-read
@@ -313,86 +340,110 @@ __global__ __launch_bounds__(64) void k_bf_resolve(const uint8_t* __restrict__ d
                     best = r.x;
                     second = r.y;
                     acc = accepts(best, second);
-                    if (acc) __hip_atomic_fetch_min((__attribute__((address_space(3))) uint32_t*)&mark[best & 0xFFFFu], tag | (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (acc) __hip_atomic_fetch_min((__attribute__((address_space(3))) uint32_t*)&mark[best & 0xFFFFu], tag | (uint32_t)tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                __builtin_amdgcn_wave_barrier();
+                wg_barrier();
                 bool affected = false;
                 if (mine && best != ~0u && (best >> 16) <= (uint32_t)OVS_HAMMING_DIST_THR_LOW) {
                     const uint32_t m1 = mark[best & 0xFFFFu];
-                    affected = (m1 & ~0xFFu) == tag && (m1 & 0xFFu) < (uint32_t)lane;
+                    affected = (m1 & ~0xFFu) == tag && (m1 & 0xFFu) < (uint32_t)tid;
                     // losing `second` to a lower lane can only RAISE it, which never turns an accept (ratio * second >= best) into a
                     // reject and never changes its target: only a lane the ratio test currently rejects has to look again
                     if (second != ~0u && !acc) {
                         const uint32_t m2 = mark[second & 0xFFFFu];
-                        affected |= (m2 & ~0xFFu) == tag && (m2 & 0xFFu) < (uint32_t)lane;
+                        affected |= (m2 & ~0xFFu) == tag && (m2 & 0xFFu) < (uint32_t)tid;
                     }
                 }
-                const unsigned long long aff = __ballot(affected) & unresolved;
-                const int f = aff ? (__ffsll((long long)aff) - 1) : 64;
-                if (mine && lane < f) {
+                const unsigned long long aff = __ballot(affected && mine);
+                int f = aff ? (wv * 64 + __ffsll((long long)aff) - 1) : T;   // first affected thread of this wave
+                if (NW > 1) {
+                    if (lane == 0) s_wave[wv] = (uint32_t)f;
+                    __syncthreads();
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) f = min(f, (int)s_wave[w]);
+                }
+                if (mine && tid < f) {
                     if (acc) {
                         my_match = (int32_t)(best & 0xFFFFu);
                         claimed[best & 0xFFFFu] = 1;
                     }
+                    mine = false;
                 }
-                unresolved = f >= 64 ? 0ull : (unresolved & ~((1ull << f) - 1ull));
-                __builtin_amdgcn_wave_barrier();
+                if (NW == 1) __builtin_amdgcn_wave_barrier();
             }
         } else {
-            // ---- pathological chunk: literal replay, one query at a time; overflowed queries scan every frame descriptor
-            unsigned long long todo = __ballot(c > 0);
-            while (todo) {
-                const int i = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                uint32_t best = ~0u, second = ~0u;
-                const bool over_i = __shfl((int)over, i) != 0;
-                if (!over_i) {
-                    if (lane == i) {
-                        const uint2 r = evaluate();
-                        best = r.x;
-                        second = r.y;
-                    }
-                } else {
-                    const int qi = q0 + i;
-                    uint32_t a[8];
-                    const uint32_t* src = reinterpret_cast<const uint32_t*>(desc_2 + (size_t)p * stride_2 + (size_t)qi * 32);
+            // ---- pathological chunk: literal replay, one query at a time, wave after wave; overflowed queries scan every frame descriptor
+            for (int w = 0; w < NW; ++w) {
+                if (wv == w) {
+                    const int qw0 = q0 + 64 * w;
+                    unsigned long long todo = __ballot(c > 0);
+                    while (todo) {
+                        const int i = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        uint32_t best = ~0u, second = ~0u;
+                        const bool over_i = __shfl((int)over, i) != 0;
+                        if (!over_i) {
+                            if (lane == i) {
+                                const uint2 r = evaluate();
+                                best = r.x;
+                                second = r.y;
+                            }
+                        } else {
+                            const int qi = qw0 + i;
+                            uint32_t a[8];
+                            const uint32_t* src = reinterpret_cast<const uint32_t*>(desc_2 + (size_t)p * stride_2 + (size_t)qi * 32);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) a[k] = src[k];
-                    uint32_t k1 = ~0u, k2 = ~0u;
-                    for (int j = lane; j < n1; j += 64) {
-                        if (claimed[j]) continue;
-                        const uint32_t* b = reinterpret_cast<const uint32_t*>(desc_1 + (size_t)p * stride_1 + (size_t)j * 32);
-                        uint32_t d = 0;
+                            for (int k = 0; k < 8; ++k) a[k] = src[k];
+                            uint32_t k1 = ~0u, k2 = ~0u;
+                            for (int j = lane; j < n1; j += 64) {
+                                if (claimed[j]) continue;
+                                const uint32_t* b = reinterpret_cast<const uint32_t*>(desc_1 + (size_t)p * stride_1 + (size_t)j * 32);
+                                uint32_t d = 0;
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) d += __builtin_popcount(a[k] ^ b[k]);
-                        if (d >= (uint32_t)OVS_MAX_HAMMING_DIST) continue;   // strict '<' against MAX_HAMMING_DIST upstream
-                        const uint32_t e = (d << 16) | (uint32_t)j;
-                        if (e < k1) { k2 = k1; k1 = e; }
-                        else if (e < k2) k2 = e;
+                                for (int k = 0; k < 8; ++k) d += __builtin_popcount(a[k] ^ b[k]);
+                                if (d >= (uint32_t)OVS_MAX_HAMMING_DIST) continue;   // strict '<' against MAX_HAMMING_DIST upstream
+                                const uint32_t e = (d << 16) | (uint32_t)j;
+                                if (e < k1) { k2 = k1; k1 = e; }
+                                else if (e < k2) k2 = e;
+                            }
+                            const uint32_t g1 = wave_min_u32(k1);
+                            const uint32_t g2 = wave_min_u32(k1 == g1 ? k2 : k1);
+                            if (lane == i) { best = g1; second = g2; }
+                        }
+                        if (lane == i && accepts(best, second)) {
+                            my_match = (int32_t)(best & 0xFFFFu);
+                            claimed[best & 0xFFFFu] = 1;
+                        }
+                        __builtin_amdgcn_wave_barrier();
                     }
-                    const uint32_t g1 = wave_min_u32(k1);
-                    const uint32_t g2 = wave_min_u32(k1 == g1 ? k2 : k1);
-                    if (lane == i) { best = g1; second = g2; }
                 }
-                if (lane == i && accepts(best, second)) {
-                    my_match = (int32_t)(best & 0xFFFFu);
-                    claimed[best & 0xFFFFu] = 1;
-                }
-                __builtin_amdgcn_wave_barrier();
+                wg_barrier();
             }
         }
         // ---- emit this chunk's pairs in ascending idx_2
         const unsigned long long m = __ballot(my_match >= 0);
+        uint32_t base = n_out, total = (uint32_t)__popcll(m);
+        if (NW > 1) {
+            if (lane == 0) s_wave[wv] = total;
+            __syncthreads();
+            total = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                if (w < wv) base += s_wave[w];
+                total += s_wave[w];
+            }
+            __syncthreads();   // s_wave is reused by the next chunk's rounds
+        }
         if (my_match >= 0) {
-            const uint32_t pos = n_out + __popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
             if (pos < (uint32_t)cap) {
                 out[2 * pos] = my_match;
                 out[2 * pos + 1] = q;
             }
         }
-        n_out += __popcll(m);
+        n_out += total;
     }
-    if (lane == 0) counts[p] = (int32_t)(n_out < (uint32_t)cap ? n_out : (uint32_t)cap);
+    if (tid == 0) counts[p] = (int32_t)(n_out < (uint32_t)cap ? n_out : (uint32_t)cap);
 }
 
 // ---- unconstrained best / second best ----------------------------------------------------------------------------------
@@ -472,10 +523,10 @@ ovs_status run_bf(ovs_matcher* m, const uint8_t* d1, size_t stride_1, const int3
     OVS_HIP_TRY(hipGetLastError());
     OVS_HIP_TRY(m->prof.mark(1, s));
     if (m->resolve_lds_staged)
-        hipLaunchKernelGGL(k_bf_resolve<true>, dim3(batch), dim3(64), m->resolve_lds_staged, s, d1, stride_1, d_n1, d2, stride_2, d_n2,
+        hipLaunchKernelGGL((k_bf_resolve<true, 4>), dim3(batch), dim3(256), m->resolve_lds_staged, s, d1, stride_1, d_n1, d2, stride_2, d_n2,
                            m->max_n1, m->max_n2, lowe_ratio, m->d_near_cnt, m->d_near_list, m->d_near_top, d_pairs, d_counts, cap);
     else
-        hipLaunchKernelGGL(k_bf_resolve<false>, dim3(batch), dim3(64), m->resolve_lds, s, d1, stride_1, d_n1, d2, stride_2, d_n2, m->max_n1,
+        hipLaunchKernelGGL((k_bf_resolve<false, 1>), dim3(batch), dim3(64), m->resolve_lds, s, d1, stride_1, d_n1, d2, stride_2, d_n2, m->max_n1,
                            m->max_n2, lowe_ratio, m->d_near_cnt, m->d_near_list, m->d_near_top, d_pairs, d_counts, cap);
     OVS_HIP_TRY(hipGetLastError());
     OVS_HIP_TRY(m->prof.mark(2, s));
@@ -530,10 +581,10 @@ ovs_status ovs_matcher_create(int32_t max_n1, int32_t max_n2, int32_t max_batch,
     CREATE_TRY(hipMalloc(&m->d_best, sizeof(uint16_t) * max_n2));
     CREATE_TRY(hipMalloc(&m->d_second, sizeof(uint16_t) * max_n2));
     if (m->resolve_lds > 64 * 1024)
-        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf_resolve<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf_resolve<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)m->resolve_lds));
     if (m->resolve_lds_staged > 64 * 1024)
-        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf_resolve<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf_resolve<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)m->resolve_lds_staged));
 #undef CREATE_TRY
     *out = m;
