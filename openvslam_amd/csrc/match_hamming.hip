@@ -293,11 +293,11 @@ __global__ __launch_bounds__(64 * NW) void k_bf_resolve(const uint8_t* __restric
 #pragma unroll
                 for (int k = 0; k < kTopK; ++k) nt[k] = ~0u;
                 const uint32_t* seg = lists + (size_t)q * kNearSplit * kNearSeg;
-                const uint32_t ends[4] = {c4x, c4y, c4z, c4w};
                 uint32_t alive_total = 0;
-#pragma unroll
+#pragma unroll 1   // compact code: this path runs on a lone wave and its footprint matters more than its trip count
                 for (int w = 0; w < kNearSplit; ++w) {
-                    const uint32_t nw = ends[w];
+                    const uint32_t nw = w == 0 ? c4x : w == 1 ? c4y : w == 2 ? c4z : c4w;
+#pragma unroll 1
                     for (uint32_t k0 = 0; k0 < nw; k0 += 8) {
                         uint32_t e8[8], d8[8];
 #pragma unroll
