@@ -17,7 +17,7 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), r
 names = sorted({c for k in acc for c in acc[k]})
 print("# mean per dispatch; source: rocprofv3 --pmc (separate passes), %s" % root)
 for k in sorted(acc, key=lambda k: -sum(acc[k].get("SQ_WAVE_CYCLES", [0]))):
-    if not (k.startswith("ovs::") or "ovs" in k):
+    if "ovs" not in k:
         continue
     print(k)
     for c in names:
@@ -37,7 +37,7 @@ if "--json" in sys.argv:
     launches_per_call = {"pyramid": 7}
     out = {}
     for k, st in stage_of.items():
-        kk = [n for n in acc if n.startswith(k)]
+        kk = [n for n in acc if k in n]
         if not kk:
             continue
         f = sum(sum(acc[n].get("FETCH_SIZE", [])) for n in kk)
