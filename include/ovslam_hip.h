@@ -278,6 +278,16 @@ ovs_status ovs_bow_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_keypoint*
                                             const int32_t* frm_node_start, const int32_t* frm_items, int32_t frm_nodes, float lowe_ratio,
                                             int32_t check_orientation, int32_t* matched_kf_in_frm, int32_t* num_matches);
 
+/* replaces: unsigned int bow_tree::match_keyframes(data::keyframe* keyfrm_1, data::keyframe* keyfrm_2,
+ *                                                  std::vector<data::landmark*>& matched_lms_in_keyfrm_1) const.
+ * valid_i[k] != 0 iff keyframe i's keypoint k holds a landmark that !will_be_erased(). matched_2_in_1[idx_1] = idx_2 (the shim
+ * writes keyfrm_2's landmark there) or -1. */
+ovs_status ovs_bow_match_keyframes(ovs_wmatcher* w, const ovs_keypoint* kps_1, const uint8_t* desc_1, const uint8_t* valid_1, int32_t n1,
+                                   const int32_t* node_ids_1, const int32_t* node_start_1, const int32_t* items_1, int32_t nodes_1,
+                                   const ovs_keypoint* kps_2, const uint8_t* desc_2, const uint8_t* valid_2, int32_t n2,
+                                   const int32_t* node_ids_2, const int32_t* node_start_2, const int32_t* items_2, int32_t nodes_2,
+                                   float lowe_ratio, int32_t check_orientation, int32_t* matched_2_in_1, int32_t* num_matches);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Stereo matcher.  replaces: match::stereo (src/openvslam/match/stereo.{h,cc}): the ctor's image pyramids are the two
  * extractors' image_pyramid_ members, which here never leave HBM -- the context reads the pyramids of the LAST extract of the

@@ -371,6 +371,7 @@ struct BowArgs {
     const int32_t* kf_items;
     int kf_nodes, n_q;           // n_q = kf_node_start[kf_nodes]
     const uint8_t* frm_desc;
+    const uint8_t* frm_valid;    // match_keyframes: the target keypoint must hold a live landmark too (NULL = all)
     const int32_t* frm_node_ids;
     const int32_t* frm_node_start;
     const int32_t* frm_items;
@@ -401,7 +402,9 @@ __global__ __launch_bounds__(256) void k_bow_lists(BowArgs a, uint32_t* __restri
         }
         if (l2 < a.frm_nodes && a.frm_node_ids[l2] == node) {
             const int b = a.frm_node_start[l2], e = a.frm_node_start[l2 + 1];
-            n = (uint32_t)(e - b);
+            if (!a.frm_valid) n = (uint32_t)(e - b);
+            else
+                for (int k = b; k < e; ++k) n += a.frm_valid[a.frm_items[k]] ? 1u : 0u;
             if (FILL) {
                 uint32_t qd[8];
                 const uint32_t* src = reinterpret_cast<const uint32_t*>(a.kf_desc + (size_t)kf_idx * 32);
@@ -410,6 +413,7 @@ __global__ __launch_bounds__(256) void k_bow_lists(BowArgs a, uint32_t* __restri
                 uint32_t pos = offsets[q];
                 for (int k = b; k < e; ++k) {
                     const int idx = a.frm_items[k];
+                    if (a.frm_valid && !a.frm_valid[idx]) continue;
                     const uint32_t d = hamming256_g(qd, reinterpret_cast<const uint32_t*>(a.frm_desc + (size_t)idx * 32));
                     if (pos < key_cap) keys[pos] = (d << 20) | (uint32_t)idx;
                     else *overflow = 1u;
@@ -464,6 +468,8 @@ struct ResolveArgs {
     const ovs_keypoint* t_kps;    // area / bow: target keypoints (angle, pt)
     float* prev_matched_xy;       // area: updated for the final matches
     int32_t* assigned;            // projection / area: [n_q] target or -1; bow: [n_t] keyframe keypoint index or -1
+    int bow_by_query;             // bow (match_keyframes): output [n_out_q] indexed by q_items[q] = target or -1
+    int n_out_q;
     int32_t* num_matches;
 };
 
@@ -617,7 +623,8 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
     // ---- outputs
     uint32_t total = 0;
     if (RULE == kRuleBow) {
-        for (int t = lane; t < a.n_t; t += 64) a.assigned[t] = -1;
+        const int n_clear = a.bow_by_query ? a.n_out_q : a.n_t;
+        for (int t = lane; t < n_clear; t += 64) a.assigned[t] = -1;
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
     }
@@ -627,7 +634,11 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
         if (q < a.n_q) t = match[q];
         if (q < a.n_q) {
             if (RULE == kRuleBow) {
-                if (t != 0xFFFFu) a.assigned[t] = a.q_items ? a.q_items[q] : q;
+                if (t != 0xFFFFu) {
+                    const int qi = a.q_items ? a.q_items[q] : q;
+                    if (a.bow_by_query) a.assigned[qi] = (int32_t)t;
+                    else a.assigned[t] = qi;
+                }
             } else {
                 a.assigned[q] = t == 0xFFFFu ? -1 : (int32_t)t;
                 if (RULE == kRuleArea && t != 0xFFFFu) {
@@ -1001,7 +1012,9 @@ ovs_status ovs_area_match_in_consistent_area(ovs_wmatcher* w, const ovs_grid_par
     return overflow ? OVS_ERR_CAPACITY : OVS_OK;
 }
 
-ovs_status ovs_bow_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_valid,
+} // extern "C" (helper below has internal linkage)
+
+static ovs_status bow_match_impl(ovs_wmatcher* w, int by_query, const uint8_t* frm_valid, const ovs_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_valid,
                                             int32_t n_kf, const int32_t* kf_node_ids, const int32_t* kf_node_start,
                                             const int32_t* kf_items, int32_t kf_nodes, const ovs_keypoint* frm_kps,
                                             const uint8_t* frm_desc, int32_t n_frm, const int32_t* frm_node_ids,
@@ -1009,16 +1022,18 @@ ovs_status ovs_bow_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_keypoint*
                                             int32_t check_orientation, int32_t* matched_kf_in_frm, int32_t* num_matches) {
     if (!w || !num_matches || n_kf < 0 || n_frm < 0 || kf_nodes < 0 || frm_nodes < 0) return OVS_ERR_INVALID;
     *num_matches = 0;
-    if (n_frm == 0) return OVS_OK;
+    const int n_out = by_query ? n_kf : n_frm;
+    if (n_out == 0) return OVS_OK;
     if (!matched_kf_in_frm) return OVS_ERR_INVALID;
-    for (int i = 0; i < n_frm; ++i) matched_kf_in_frm[i] = -1;
+    for (int i = 0; i < n_out; ++i) matched_kf_in_frm[i] = -1;
+    if (n_frm == 0) return OVS_OK;
     if (n_kf == 0 || kf_nodes == 0 || frm_nodes == 0) return OVS_OK;
     if (!kf_kps || !kf_desc || !kf_node_ids || !kf_node_start || !kf_items || !frm_kps || !frm_desc || !frm_node_ids || !frm_node_start ||
         !frm_items)
         return OVS_ERR_INVALID;
     const int nq = kf_node_start[kf_nodes], nfi = frm_node_start[frm_nodes];
     if (nq == 0 || nfi == 0) return OVS_OK;
-    if (n_frm > w->max_t || n_kf > w->max_q || nq > w->max_q) return OVS_ERR_CAPACITY;
+    if (n_frm > w->max_t || n_kf > w->max_q || nq > w->max_q || (by_query && n_kf > std::max(w->max_t, w->max_q))) return OVS_ERR_CAPACITY;
     const size_t need = (size_t)2 * kf_nodes + 1 + nq + (size_t)2 * frm_nodes + 1 + nfi;
     if (need > w->csr_cap) return OVS_ERR_CAPACITY;
     OVS_HIP_TRY(hipSetDevice(w->device));
@@ -1041,6 +1056,7 @@ ovs_status ovs_bow_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_keypoint*
     if (kf_valid) OVS_HIP_TRY(hipMemcpyAsync(w->d_q_flag, kf_valid, (size_t)n_kf, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, frm_kps, sizeof(ovs_keypoint) * n_frm, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, frm_desc, (size_t)32 * n_frm, hipMemcpyHostToDevice, s));
+    if (frm_valid) OVS_HIP_TRY(hipMemcpyAsync(w->d_t_flag, frm_valid, (size_t)n_frm, hipMemcpyHostToDevice, s));
     BowArgs a{};
     a.kf_desc = w->d_q_desc;
     a.kf_valid = kf_valid ? w->d_q_flag : nullptr;
@@ -1050,6 +1066,7 @@ ovs_status ovs_bow_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_keypoint*
     a.kf_nodes = kf_nodes;
     a.n_q = nq;
     a.frm_desc = w->d_t_desc;
+    a.frm_valid = frm_valid ? w->d_t_flag : nullptr;
     a.frm_node_ids = d_f_ids;
     a.frm_node_start = d_f_start;
     a.frm_items = d_f_items;
@@ -1068,14 +1085,38 @@ ovs_status ovs_bow_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_keypoint*
     ra.t_kps = w->d_t_kps;
     ra.assigned = w->d_assigned;
     ra.num_matches = w->d_num;
+    ra.bow_by_query = by_query;
+    ra.n_out_q = n_kf;
     st = launch_resolve<kRuleBow>(ra, s);
     if (st != OVS_OK) return st;
     uint32_t overflow = 0;
-    OVS_HIP_TRY(hipMemcpyAsync(matched_kf_in_frm, w->d_assigned, sizeof(int32_t) * n_frm, hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(matched_kf_in_frm, w->d_assigned, sizeof(int32_t) * n_out, hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipStreamSynchronize(s));
     return overflow ? OVS_ERR_CAPACITY : OVS_OK;
+}
+
+
+extern "C" {
+
+ovs_status ovs_bow_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_valid,
+                                            int32_t n_kf, const int32_t* kf_node_ids, const int32_t* kf_node_start,
+                                            const int32_t* kf_items, int32_t kf_nodes, const ovs_keypoint* frm_kps,
+                                            const uint8_t* frm_desc, int32_t n_frm, const int32_t* frm_node_ids,
+                                            const int32_t* frm_node_start, const int32_t* frm_items, int32_t frm_nodes, float lowe_ratio,
+                                            int32_t check_orientation, int32_t* matched_kf_in_frm, int32_t* num_matches) {
+    return bow_match_impl(w, 0, nullptr, kf_kps, kf_desc, kf_valid, n_kf, kf_node_ids, kf_node_start, kf_items, kf_nodes, frm_kps, frm_desc, n_frm,
+                          frm_node_ids, frm_node_start, frm_items, frm_nodes, lowe_ratio, check_orientation, matched_kf_in_frm, num_matches);
+}
+
+ovs_status ovs_bow_match_keyframes(ovs_wmatcher* w, const ovs_keypoint* kps_1, const uint8_t* desc_1, const uint8_t* valid_1, int32_t n1,
+                                   const int32_t* node_ids_1, const int32_t* node_start_1, const int32_t* items_1, int32_t nodes_1,
+                                   const ovs_keypoint* kps_2, const uint8_t* desc_2, const uint8_t* valid_2, int32_t n2,
+                                   const int32_t* node_ids_2, const int32_t* node_start_2, const int32_t* items_2, int32_t nodes_2,
+                                   float lowe_ratio, int32_t check_orientation, int32_t* matched_2_in_1, int32_t* num_matches) {
+    return bow_match_impl(w, 1, valid_2, kps_1, desc_1, valid_1, n1, node_ids_1, node_start_1, items_1, nodes_1, kps_2, desc_2, n2, node_ids_2,
+                          node_start_2, items_2, nodes_2, lowe_ratio, check_orientation, matched_2_in_1, num_matches);
 }
 
 ovs_status ovs_projection_match_current_and_last_frames(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp,

@@ -232,6 +232,25 @@ class bow_tree(_window_ctx):
         return n.value, out[:len(fk)].copy()
 
 
+    def match_keyframes(self, kps_1, desc_1, bow_feat_vec_1, kps_2, desc_2, bow_feat_vec_2, has_landmark_1=None, has_landmark_2=None):
+        """bow_tree::match_keyframes(keyfrm_1, keyfrm_2, matched_lms_in_keyfrm_1): returns (num_matches, matched_2_in_1) where
+        matched_2_in_1[idx_1] is the keyframe-2 keypoint whose landmark keyframe-1 keypoint idx_1 receives, or -1."""
+        k1 = np.ascontiguousarray(kps_1, KP_DTYPE)
+        k2 = np.ascontiguousarray(kps_2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc_1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(desc_2, np.uint8).reshape(-1, 32)
+        v1 = None if has_landmark_1 is None else np.ascontiguousarray(has_landmark_1, np.uint8)
+        v2 = None if has_landmark_2 is None else np.ascontiguousarray(has_landmark_2, np.uint8)
+        i1, s1, t1 = flatten_bow(bow_feat_vec_1)
+        i2, s2, t2 = flatten_bow(bow_feat_vec_2)
+        out = np.full(max(len(k1), 1), -1, np.int32)
+        n = C.c_int32()
+        _lib.check(self._L.ovs_bow_match_keyframes(self._h, _p(k1), _p(d1), _p(v1), len(k1), _p(i1), _p(s1), _p(t1), len(i1), _p(k2), _p(d2),
+                                                   _p(v2), len(k2), _p(i2), _p(s2), _p(t2), len(i2), self.lowe_ratio_,
+                                                   int(self.check_orientation_), _p(out), C.byref(n)), "ovs_bow_match_keyframes")
+        return n.value, out[:len(k1)].copy()
+
+
 class fuse(_window_ctx):
     """match::fuse(lowe_ratio): the candidate search of replace_duplication (the landmark-graph surgery stays with the caller)."""
 

@@ -370,6 +370,22 @@ def projection_match_current_and_last_frames(cam, gp, curr_kps, curr_desc, pose_
     return assigned[:len(loc)].copy(), n
 
 
+def bow_match_keyframes(kps_1, desc_1, feat_vec_1, kps_2, desc_2, feat_vec_2, lowe_ratio=0.6, check_orientation=True, has_lm_1=None,
+                        has_lm_2=None):
+    _, _, _, a1 = _soa(kps_1)
+    _, _, _, a2 = _soa(kps_2)
+    d1 = np.ascontiguousarray(desc_1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(desc_2, np.uint8).reshape(-1, 32)
+    v1 = None if has_lm_1 is None else np.ascontiguousarray(has_lm_1, np.uint8)
+    v2 = None if has_lm_2 is None else np.ascontiguousarray(has_lm_2, np.uint8)
+    i1, s1, t1 = _flatten_bow(feat_vec_1)
+    i2, s2, t2 = _flatten_bow(feat_vec_2)
+    out = np.full(max(len(a1), 1), -1, np.int32)
+    n = lib().ovo_bow_match_keyframes(_p(d1), _p(a1), _p(v1), len(a1), _p(i1), _p(s1), _p(t1), len(i1), _p(d2), _p(a2), _p(v2), len(a2), _p(i2),
+                                      _p(s2), _p(t2), len(i2), C.c_float(lowe_ratio), int(check_orientation), _p(out))
+    return n, out[:len(a1)].copy()
+
+
 def fuse_replace_duplication(cam, gp, kf_kps, kf_desc, pose_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc, scale_factors,
                              inv_level_sigma_sq, log_scale_factor, margin=3.0, kf_stereo_x_right=None, lm_valid=None):
     xs, ys, oc, _ = _soa(kf_kps)

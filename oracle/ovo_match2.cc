@@ -497,6 +497,61 @@ int ovo_fuse_replace_duplication(const ovo_camera* cam, const ovo_grid_params* g
     return num_fused;
 }
 
+// M7  bow_tree::match_keyframes(keyfrm_1, keyfrm_2, matched_lms_in_keyfrm_1): as match_frame_and_keyframe, but both sides must
+// hold a live landmark, and the result is indexed by keyframe-1 keypoints. matched_2_in_1[idx_1] = idx_2 or -1.
+int ovo_bow_match_keyframes(const uint8_t* desc_1, const float* angles_1, const uint8_t* valid_1, int n1, const int32_t* node_ids_1,
+                            const int32_t* node_start_1, const int32_t* items_1, int nodes_1, const uint8_t* desc_2, const float* angles_2,
+                            const uint8_t* valid_2, int n2, const int32_t* node_ids_2, const int32_t* node_start_2, const int32_t* items_2,
+                            int nodes_2, float lowe_ratio, int check_orientation, int32_t* matched_2_in_1) {
+    int num_matches = 0;
+    AngleChecker ac;
+    for (int i = 0; i < n1; ++i) matched_2_in_1[i] = -1;
+    std::vector<uint8_t> already_2((size_t)n2, 0);
+    int a = 0, b = 0;
+    while (a < nodes_1 && b < nodes_2) {
+        if (node_ids_1[a] == node_ids_2[b]) {
+            for (int ka = node_start_1[a]; ka < node_start_1[a + 1]; ++ka) {
+                const int idx_1 = items_1[ka];
+                if (valid_1 && !valid_1[idx_1]) continue;
+                unsigned best = OVO_MAX_HAMMING_DIST, second = OVO_MAX_HAMMING_DIST;
+                int best_idx_2 = -1;
+                for (int kb = node_start_2[b]; kb < node_start_2[b + 1]; ++kb) {
+                    const int idx_2 = items_2[kb];
+                    if (valid_2 && !valid_2[idx_2]) continue;
+                    if (already_2[idx_2]) continue;
+                    const unsigned d = distance_32(desc_1 + (size_t)idx_1 * 32, desc_2 + (size_t)idx_2 * 32);
+                    if (d < best) {
+                        second = best;
+                        best = d;
+                        best_idx_2 = idx_2;
+                    } else if (d < second) {
+                        second = d;
+                    }
+                }
+                if (OVO_HAMMING_DIST_THR_LOW < best) continue;
+                if (lowe_ratio * (float)second < (float)best) continue;
+                matched_2_in_1[idx_1] = best_idx_2;
+                already_2[best_idx_2] = 1;
+                ++num_matches;
+                if (check_orientation) ac.append(angles_1[idx_1] - angles_2[best_idx_2], idx_1);
+            }
+            ++a;
+            ++b;
+        } else if (node_ids_1[a] < node_ids_2[b]) {
+            a = (int)(std::lower_bound(node_ids_1 + a, node_ids_1 + nodes_1, node_ids_2[b]) - node_ids_1);
+        } else {
+            b = (int)(std::lower_bound(node_ids_2 + b, node_ids_2 + nodes_2, node_ids_1[a]) - node_ids_2);
+        }
+    }
+    if (check_orientation) {
+        for (int invalid_idx : ac.invalid()) {
+            matched_2_in_1[invalid_idx] = -1;
+            --num_matches;
+        }
+    }
+    return num_matches;
+}
+
 // M6  stereo::compute(stereo_x_right, depths). Keypoints are cv::KeyPoint records (level-0 coordinates, octave); the two
 // pyramids are the extractors' image_pyramid_ (unblurred). Steps as upstream / ORB-SLAM2 ComputeStereoMatches:
 //   rows: right keypoint i is a candidate for every image row in [floor(y - 2 s_i), ceil(y + 2 s_i)], s_i = scale_factors[octave];

@@ -164,6 +164,11 @@ int ovo_fuse_replace_duplication(const ovo_camera* cam, const ovo_grid_params* g
                                  const double* lm_pos_w, const float* lm_dist_min_max, const double* lm_normal, const uint8_t* lm_desc,
                                  const uint8_t* lm_valid, int m, const float* scale_factors, const float* inv_level_sigma_sq,
                                  int num_scale_levels, float log_scale_factor, float margin, int32_t* best_idx);
+/* M7 bow_tree::match_keyframes. matched_2_in_1[n1] = keyframe-2 keypoint matched to keyframe-1 keypoint, or -1. */
+int ovo_bow_match_keyframes(const uint8_t* desc_1, const float* angles_1, const uint8_t* valid_1, int n1, const int32_t* node_ids_1,
+                            const int32_t* node_start_1, const int32_t* items_1, int nodes_1, const uint8_t* desc_2, const float* angles_2,
+                            const uint8_t* valid_2, int n2, const int32_t* node_ids_2, const int32_t* node_start_2, const int32_t* items_2,
+                            int nodes_2, float lowe_ratio, int check_orientation, int32_t* matched_2_in_1);
 /* M6 stereo::compute. Pyramids = the two extractors' image_pyramid_ (unblurred). Returns the number of valid depths. */
 int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr_right, const int32_t* level_rows,
                        const int32_t* level_cols, const size_t* stride_left, const size_t* stride_right, int num_levels,

@@ -232,3 +232,18 @@ def test_fuse_replace_duplication(match, synth, oracle, model, setup):
                                                    kf_stereo_x_right=xr, lm_valid=valid)
         assert gn == wn and np.array_equal(got, want)
     assert wn > n // 20
+
+
+@pytest.mark.parametrize("check_orientation", [True, False])
+def test_bow_match_keyframes(match, synth, oracle, check_orientation):
+    ka, da, kb, db = _two_frames(oracle, synth, shift=(2, 3))
+    fa, fb = synth.synth_bow(da, seed=4, n_nodes=90), synth.synth_bow(db, seed=4, n_nodes=90)
+    fa.pop(sorted(fa)[5])
+    rng = np.random.default_rng(3)
+    v1 = (rng.random(len(ka)) < 0.8).astype(np.uint8)
+    v2 = (rng.random(len(kb)) < 0.8).astype(np.uint8)
+    w = match.bow_tree(0.75, check_orientation, max_targets=2048, max_queries=2048)
+    gn, got = w.match_keyframes(ka, da, fa, kb, db, fb, v1, v2)
+    wn, want = oracle.bow_match_keyframes(ka, da, fa, kb, db, fb, 0.75, check_orientation, v1, v2)
+    assert gn == wn and np.array_equal(got, want)
+    assert wn > 20 and (v1[want >= 0] == 1).all() and (v2[want[want >= 0]] == 1).all()
