@@ -238,6 +238,19 @@ ovs_status ovs_projection_match_current_and_last_frames(ovs_wmatcher* w, const o
                                                         const double* pose_cw_last, const float* scale_factors, int32_t num_levels,
                                                         float margin, int32_t check_orientation, int32_t* assigned, int32_t* num_matches);
 
+/* replaces: unsigned int projection::match_frame_and_keyframe(data::frame& curr_frm, data::keyframe* keyfrm,
+ *               const std::set<data::landmark*>& already_matched_lms, const float margin, const unsigned int hamm_dist_thr) const.
+ * curr_occupied[j] != 0 iff curr_frm.landmarks_[j]; kf_kps = keyfrm->undist_keypts_; per keyframe keypoint i: kf_pos_w, kf_dist_min_max
+ * (min / max valid distance), kf_lm_desc of landmarks[i]; kf_valid[i] != 0 iff landmarks[i] && !will_be_erased() &&
+ * !already_matched_lms.count(landmarks[i]). assigned[i] = current keypoint that receives landmarks[i], or -1. */
+ovs_status ovs_projection_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp,
+                                                   const ovs_keypoint* curr_kps, const uint8_t* curr_desc, const uint8_t* curr_occupied,
+                                                   int32_t n_curr, const double* pose_cw_curr, const ovs_keypoint* kf_kps,
+                                                   const double* kf_pos_w, const float* kf_dist_min_max, const uint8_t* kf_lm_desc,
+                                                   const uint8_t* kf_valid, int32_t n_kf, const float* scale_factors, int32_t num_levels,
+                                                   float log_scale_factor, float margin, uint32_t hamm_dist_thr, int32_t check_orientation,
+                                                   int32_t* assigned, int32_t* num_matches);
+
 /* replaces: the candidate search of  template<typename T> unsigned int fuse::replace_duplication(data::keyframe* keyfrm,
  *               const T& landmarks_to_check, const float margin)  (src/openvslam/match/fuse.{h,cc}); landmarks are independent there.
  * kps / desc / stereo_x_right = keyfrm->undist_keypts_ / descriptors_ / stereo_x_right_ (NULL = monocular); pose_cw = keyfrm pose.

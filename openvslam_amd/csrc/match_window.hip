@@ -254,22 +254,41 @@ __device__ __forceinline__ bool reproject_to_image(const CamP& c, const double* 
 __global__ __launch_bounds__(256) void k_reproject_queries(CamP cam, const ovs_keypoint* __restrict__ last_kps,
                                                           const double* __restrict__ pos_w, const uint8_t* __restrict__ last_valid, int n,
                                                           float margin, const float* __restrict__ sf_dev, int num_levels, int forward,
-                                                          int backward, float* __restrict__ q_xy, float* __restrict__ q_x_right,
-                                                          float* __restrict__ q_radius, int32_t* __restrict__ q_minl,
-                                                          int32_t* __restrict__ q_maxl, uint8_t* __restrict__ q_valid) {
+                                                          int backward, const float* __restrict__ dist_min_max, double ccx, double ccy,
+                                                          double ccz, float log_scale_factor, float* __restrict__ q_xy,
+                                                          float* __restrict__ q_x_right, float* __restrict__ q_radius,
+                                                          int32_t* __restrict__ q_minl, int32_t* __restrict__ q_maxl,
+                                                          uint8_t* __restrict__ q_valid) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     bool valid = !last_valid || last_valid[i];
     double u = 0, v = 0;
     float xr = -1.0f;
-    if (valid) valid = reproject_to_image(cam, pos_w + 3 * (size_t)i, u, v, xr);
-    const int lvl = last_kps[i].octave;
+    const double* X = pos_w + 3 * (size_t)i;
+    if (valid) valid = reproject_to_image(cam, X, u, v, xr);
+    int lvl, minl, maxl;
+    if (dist_min_max) {
+        // match_frame_and_keyframe: valid distance range, level from the distance (landmark::predict_scale_level), window [pred-1, pred+1]
+        const double dx = X[0] - ccx, dy = X[1] - ccy, dz = X[2] - ccz;
+        const double dist = sqrt((dx * dx + dy * dy) + dz * dz);
+        const float dmin = dist_min_max[2 * i], dmax = dist_min_max[2 * i + 1];
+        if (dist < dmin || dmax < dist) valid = false;
+        lvl = valid ? (int)ceilf(__fdiv_rn(logf(__fdiv_rn(dmax, (float)dist)), log_scale_factor)) : 0;
+        if (lvl < 0) lvl = 0;
+        else if (num_levels <= lvl) lvl = num_levels - 1;
+        minl = lvl - 1;
+        maxl = lvl + 1;
+    } else {
+        lvl = last_kps[i].octave;
+        minl = forward ? lvl : (backward ? 0 : lvl - 1);
+        maxl = forward ? num_levels - 1 : (backward ? lvl : lvl + 1);
+    }
     q_xy[2 * i] = (float)u;
     q_xy[2 * i + 1] = (float)v;
     q_x_right[i] = xr;
     q_radius[i] = __fmul_rn(margin, sf_dev[lvl]);
-    q_minl[i] = forward ? lvl : (backward ? 0 : lvl - 1);
-    q_maxl[i] = forward ? num_levels - 1 : (backward ? lvl : lvl + 1);
+    q_minl[i] = minl;
+    q_maxl[i] = maxl;
     q_valid[i] = valid ? 1 : 0;
 }
 
@@ -468,17 +487,18 @@ struct ResolveArgs {
     const ovs_keypoint* t_kps;    // area / bow: target keypoints (angle, pt)
     float* prev_matched_xy;       // area: updated for the final matches
     int32_t* assigned;            // projection / area: [n_q] target or -1; bow: [n_t] keyframe keypoint index or -1
+    uint32_t best_only_thr;       // BestOnly: accept iff best <= this (match_current_and_last_frames: THR_HIGH)
     int bow_by_query;             // bow (match_keyframes): output [n_out_q] indexed by q_items[q] = target or -1
     int n_out_q;
     int32_t* num_matches;
 };
 
 template <int RULE>
-__device__ __forceinline__ bool rule_accepts(uint32_t best, uint32_t second, float ratio) {
+__device__ __forceinline__ bool rule_accepts(uint32_t best, uint32_t second, float ratio, uint32_t best_only_thr) {
     if (best == kNone) return false;
     const uint32_t bd = best >> 20;
     const uint32_t sd = second == kNone ? (uint32_t)OVS_MAX_HAMMING_DIST : (second >> 20);
-    if (RULE == kRuleBestOnly) return bd <= (uint32_t)OVS_HAMMING_DIST_THR_HIGH;   // match_current_and_last_frames: no ratio test
+    if (RULE == kRuleBestOnly) return bd <= best_only_thr;   // match_current_and_last_frames / match_frame_and_keyframe: no ratio test
     if (RULE == kRuleProjection) {
         if (bd > (uint32_t)OVS_HAMMING_DIST_THR_HIGH) return false;
         const int bl = (int)((best >> 16) & 15u), sl = second == kNone ? -1 : (int)((second >> 16) & 15u);
@@ -500,7 +520,7 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
     lds_u16* match = owner + ((a.n_t + 1) & ~1);                            // [n_q]  target of query (0xFFFF none)
     lds_u16* accepted = match + ((a.n_q + 1) & ~1);                         // [n_q]  target at acceptance time (orientation entries)
     const int lane = threadIdx.x;
-    const uint32_t max_d = (RULE == kRuleProjection || RULE == kRuleBestOnly) ? OVS_HAMMING_DIST_THR_HIGH : OVS_HAMMING_DIST_THR_LOW;
+    const uint32_t max_d = RULE == kRuleBestOnly ? a.best_only_thr : (RULE == kRuleProjection ? OVS_HAMMING_DIST_THR_HIGH : OVS_HAMMING_DIST_THR_LOW);
     for (int i = lane; i < a.n_t; i += 64) {
         thr[i] = (uint16_t)OVS_MAX_HAMMING_DIST;
         owner[i] = 0xFFFFu;
@@ -544,7 +564,7 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
                         sd = d;
                     }
                 }
-                acc = rule_accepts<RULE>(best, second, a.lowe_ratio);
+                acc = rule_accepts<RULE>(best, second, a.lowe_ratio, a.best_only_thr);
                 if (acc)
                     __hip_atomic_fetch_min((__attribute__((address_space(3))) uint32_t*)&mark[(best & 0xFFFFu) & (kMarkSize - 1)],
                                            tag | (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1182,7 +1202,7 @@ ovs_status ovs_projection_match_current_and_last_frames(ovs_wmatcher* w, const o
     if (st != OVS_OK) return st;
     hipLaunchKernelGGL(k_reproject_queries, dim3((n_last + 255) / 256), dim3(256), 0, s, cp, (const ovs_keypoint*)w->d_q_kps,
                        (const double*)w->d_q_pos, (const uint8_t*)d_last_valid, n_last, margin, (const float*)w->d_sf, num_levels, forward,
-                       backward, w->d_q_xy, w->d_q_f, w->d_q_r, w->d_q_i, w->d_q_i2, w->d_q_flag);
+                       backward, (const float*)nullptr, 0.0, 0.0, 0.0, 0.0f, w->d_q_xy, w->d_q_f, w->d_q_r, w->d_q_i, w->d_q_i2, w->d_q_flag);
     OVS_HIP_TRY(hipGetLastError());
     WinArgs a{};
     a.t_kps = w->d_t_kps;
@@ -1214,6 +1234,7 @@ ovs_status ovs_projection_match_current_and_last_frames(ovs_wmatcher* w, const o
     ra.t_kps = w->d_t_kps;
     ra.assigned = w->d_assigned;
     ra.num_matches = w->d_num;
+    ra.best_only_thr = OVS_HAMMING_DIST_THR_HIGH;
     st = launch_resolve<kRuleBestOnly>(ra, s);
     if (st != OVS_OK) return st;
     uint32_t overflow = 0;
@@ -1301,6 +1322,108 @@ ovs_status ovs_fuse_replace_duplication(ovs_wmatcher* w, const ovs_camera* cam, 
     OVS_HIP_TRY(hipMemcpyAsync(num_fused, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipStreamSynchronize(s));
     return OVS_OK;
+}
+
+ovs_status ovs_projection_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp,
+                                                   const ovs_keypoint* curr_kps, const uint8_t* curr_desc, const uint8_t* curr_occupied,
+                                                   int32_t n_curr, const double* pose_cw_curr, const ovs_keypoint* kf_kps,
+                                                   const double* kf_pos_w, const float* kf_dist_min_max, const uint8_t* kf_lm_desc,
+                                                   const uint8_t* kf_valid, int32_t n_kf, const float* scale_factors, int32_t num_levels,
+                                                   float log_scale_factor, float margin, uint32_t hamm_dist_thr, int32_t check_orientation,
+                                                   int32_t* assigned, int32_t* num_matches) {
+    if (!w || !cam || !gp || !num_matches || n_curr < 0 || n_kf < 0 || !pose_cw_curr || !scale_factors || num_levels < 1 ||
+        num_levels > OVS_MAX_LEVELS || (cam->model != 0 && cam->model != 1))
+        return OVS_ERR_INVALID;
+    *num_matches = 0;
+    if (n_kf == 0) return OVS_OK;
+    if (!assigned) return OVS_ERR_INVALID;
+    for (int i = 0; i < n_kf; ++i) assigned[i] = -1;
+    if (n_curr == 0) return OVS_OK;
+    if (!curr_kps || !curr_desc || !kf_kps || !kf_pos_w || !kf_dist_min_max || !kf_lm_desc) return OVS_ERR_INVALID;
+    if (n_curr > w->max_t || n_kf > w->max_q) return OVS_ERR_CAPACITY;
+    if ((size_t)n_kf * 2 * sizeof(float) > (size_t)w->max_entries * sizeof(uint32_t)) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = w->stream;
+    CamP cp{};
+    cp.model = cam->model;
+    cp.setup = cam->setup;
+    cp.fx = cam->fx;
+    cp.fy = cam->fy;
+    cp.cx = cam->cx;
+    cp.cy = cam->cy;
+    cp.fxb = cam->focal_x_baseline;
+    cp.cols = cam->cols;
+    cp.rows = cam->rows;
+    cp.min_x = gp->min_x;
+    cp.min_y = gp->min_y;
+    cp.max_x = gp->max_x;
+    cp.max_y = gp->max_y;
+    std::memcpy(cp.P, pose_cw_curr, sizeof(double) * 12);
+    const double* R = pose_cw_curr;
+    const double* t = pose_cw_curr + 9;
+    const double ccx = -((R[0] * t[0] + R[3] * t[1]) + R[6] * t[2]), ccy = -((R[1] * t[0] + R[4] * t[1]) + R[7] * t[2]),
+                 ccz = -((R[2] * t[0] + R[5] * t[1]) + R[8] * t[2]);
+    float* d_dist = reinterpret_cast<float*>(w->d_keys);   // consumed by k_reproject_queries before the key buffer is written
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, curr_kps, sizeof(ovs_keypoint) * n_curr, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, curr_desc, (size_t)32 * n_curr, hipMemcpyHostToDevice, s));
+    if (curr_occupied) OVS_HIP_TRY(hipMemcpyAsync(w->d_t_flag, curr_occupied, (size_t)n_curr, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_kps, kf_kps, sizeof(ovs_keypoint) * n_kf, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_pos, kf_pos_w, sizeof(double) * 3 * n_kf, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(d_dist, kf_dist_min_max, sizeof(float) * 2 * n_kf, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, kf_lm_desc, (size_t)32 * n_kf, hipMemcpyHostToDevice, s));
+    uint8_t* d_valid = nullptr;
+    if (kf_valid) {
+        OVS_HIP_TRY(hipMemcpyAsync(w->d_q_flag, kf_valid, (size_t)n_kf, hipMemcpyHostToDevice, s));
+        d_valid = w->d_q_flag;
+    }
+    float sf16[OVS_MAX_LEVELS];
+    for (int l = 0; l < OVS_MAX_LEVELS; ++l) sf16[l] = l < num_levels ? scale_factors[l] : 1.0f;
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_sf, sf16, sizeof(sf16), hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));   // sf16 is a stack array
+    ovs_status st = grid_assign(w, gp, w->d_t_kps, n_curr, s);
+    if (st != OVS_OK) return st;
+    hipLaunchKernelGGL(k_reproject_queries, dim3((n_kf + 255) / 256), dim3(256), 0, s, cp, (const ovs_keypoint*)w->d_q_kps,
+                       (const double*)w->d_q_pos, (const uint8_t*)d_valid, n_kf, margin, (const float*)w->d_sf, num_levels, 0, 0,
+                       (const float*)d_dist, ccx, ccy, ccz, log_scale_factor, w->d_q_xy, w->d_q_f, w->d_q_r, w->d_q_i, w->d_q_i2, w->d_q_flag);
+    OVS_HIP_TRY(hipGetLastError());
+    WinArgs a{};
+    a.t_kps = w->d_t_kps;
+    a.t_desc = w->d_t_desc;
+    a.t_occupied = curr_occupied ? w->d_t_flag : nullptr;
+    a.cell_start = w->d_cell_start;
+    a.items = w->d_items;
+    a.gp = w->gp;
+    a.n_q = n_kf;
+    a.q_xy = w->d_q_xy;
+    a.q_x_right = w->d_q_f;
+    a.q_valid = w->d_q_flag;
+    a.q_radius = w->d_q_r;
+    a.q_minl = w->d_q_i;
+    a.q_maxl = w->d_q_i2;
+    a.q_desc = w->d_q_desc;
+    a.margin = margin;
+    a.mode = kModeGeneric;
+    st = build_lists(w, a, n_kf, k_window_lists<false>, k_window_lists<true>, s);
+    if (st != OVS_OK) return st;
+    ResolveArgs ra{};
+    ra.offsets = w->d_offsets;
+    ra.keys = w->d_keys;
+    ra.n_q = n_kf;
+    ra.n_t = n_curr;
+    ra.check_orientation = check_orientation;
+    ra.q_kps = w->d_q_kps;
+    ra.t_kps = w->d_t_kps;
+    ra.assigned = w->d_assigned;
+    ra.num_matches = w->d_num;
+    ra.best_only_thr = hamm_dist_thr;
+    st = launch_resolve<kRuleBestOnly>(ra, s);
+    if (st != OVS_OK) return st;
+    uint32_t overflow = 0;
+    OVS_HIP_TRY(hipMemcpyAsync(assigned, w->d_assigned, sizeof(int32_t) * n_kf, hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
+    return overflow ? OVS_ERR_CAPACITY : OVS_OK;
 }
 
 }   // extern "C"

@@ -174,6 +174,28 @@ class projection(_window_ctx):
         return assigned[:len(lk)].copy(), n.value
 
 
+    def match_frame_and_keyframe(self, cam, gp, curr_keypts, curr_desc, pose_cw_curr, kf_keypts, kf_pos_w, kf_dist_min_max, kf_lm_desc,
+                                 scale_factors, log_scale_factor, margin, hamm_dist_thr, curr_occupied=None, kf_valid=None):
+        """projection::match_frame_and_keyframe(curr_frm, keyfrm, already_matched_lms, margin, hamm_dist_thr): returns
+        (assigned, num_matches); assigned[i] is the current keypoint that receives the keyframe's landmark i, or -1."""
+        ck = np.ascontiguousarray(curr_keypts, KP_DTYPE)
+        cd = np.ascontiguousarray(curr_desc, np.uint8).reshape(-1, 32)
+        kk = np.ascontiguousarray(kf_keypts, KP_DTYPE)
+        pw = np.ascontiguousarray(kf_pos_w, np.float64).reshape(-1, 3)
+        dm = np.ascontiguousarray(kf_dist_min_max, np.float32).reshape(-1, 2)
+        ld = np.ascontiguousarray(kf_lm_desc, np.uint8).reshape(-1, 32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        occ = None if curr_occupied is None else np.ascontiguousarray(curr_occupied, np.uint8)
+        val = None if kf_valid is None else np.ascontiguousarray(kf_valid, np.uint8)
+        assigned = np.full(max(len(kk), 1), -1, np.int32)
+        n = C.c_int32()
+        _lib.check(self._L.ovs_projection_match_frame_and_keyframe(
+            self._h, C.byref(cam), C.byref(gp), _p(ck), _p(cd), _p(occ), len(ck), _p(_pose12(pose_cw_curr)), _p(kk), _p(pw), _p(dm), _p(ld),
+            _p(val), len(kk), _p(sf), len(sf), float(log_scale_factor), float(margin), int(hamm_dist_thr), int(self.check_orientation_),
+            _p(assigned), C.byref(n)), "ovs_projection_match_frame_and_keyframe")
+        return assigned[:len(kk)].copy(), n.value
+
+
 def _pose12(pose_cw):
     """3x4 (or 4x4) [R|t] -> 12 doubles: rotation row-major, then translation."""
     T = np.asarray(pose_cw, np.float64)

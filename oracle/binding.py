@@ -386,6 +386,26 @@ def bow_match_keyframes(kps_1, desc_1, feat_vec_1, kps_2, desc_2, feat_vec_2, lo
     return n, out[:len(a1)].copy()
 
 
+def projection_match_frame_and_keyframe(cam, gp, curr_kps, curr_desc, pose_cw_curr, kf_kps, kf_pos_w, kf_dist_min_max, kf_lm_desc,
+                                        scale_factors, log_scale_factor, margin, hamm_dist_thr, check_orientation=True, curr_occupied=None,
+                                        kf_valid=None):
+    xs, ys, oc, an = _soa(curr_kps)
+    _, _, _, kan = _soa(kf_kps)
+    cd = np.ascontiguousarray(curr_desc, np.uint8).reshape(-1, 32)
+    pw = np.ascontiguousarray(kf_pos_w, np.float64).reshape(-1, 3)
+    dm = np.ascontiguousarray(kf_dist_min_max, np.float32).reshape(-1, 2)
+    ld = np.ascontiguousarray(kf_lm_desc, np.uint8).reshape(-1, 32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    occ = None if curr_occupied is None else np.ascontiguousarray(curr_occupied, np.uint8)
+    val = None if kf_valid is None else np.ascontiguousarray(kf_valid, np.uint8)
+    assigned = np.full(max(len(kan), 1), -1, np.int32)
+    n = lib().ovo_projection_match_frame_and_keyframe(C.byref(cam), C.byref(gp), _p(xs), _p(ys), _p(oc), _p(an), _p(cd), _p(occ), len(xs),
+                                                      _p(_pose12(pose_cw_curr)), _p(kan), _p(pw), _p(dm), _p(ld), _p(val), len(kan), _p(sf),
+                                                      len(sf), C.c_float(log_scale_factor), C.c_float(margin), C.c_uint(hamm_dist_thr),
+                                                      int(check_orientation), _p(assigned))
+    return assigned[:len(kan)].copy(), n
+
+
 def fuse_replace_duplication(cam, gp, kf_kps, kf_desc, pose_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc, scale_factors,
                              inv_level_sigma_sq, log_scale_factor, margin=3.0, kf_stereo_x_right=None, lm_valid=None):
     xs, ys, oc, _ = _soa(kf_kps)

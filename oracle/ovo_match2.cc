@@ -552,6 +552,70 @@ int ovo_bow_match_keyframes(const uint8_t* desc_1, const float* angles_1, const 
     return num_matches;
 }
 
+// M4  projection::match_frame_and_keyframe(curr_frm, keyfrm, already_matched_lms, margin, hamm_dist_thr): every live keyframe
+// landmark that is not already matched is reprojected with the CURRENT frame's pose; it must lie inside its valid distance range;
+// predicted level from the distance (landmark::predict_scale_level); window margin * scale_factors[pred], levels [pred-1, pred+1];
+// current keypoints that already hold ANY landmark are skipped (sequential claim); best Hamming only, accept iff best <=
+// hamm_dist_thr; orientation histogram keyed by the current keypoint. assigned[i] = current keypoint or -1.
+int ovo_projection_match_frame_and_keyframe(const ovo_camera* cam, const ovo_grid_params* gp, const float* xs, const float* ys,
+                                            const int32_t* octaves, const float* angles, const uint8_t* desc, const uint8_t* occupied,
+                                            int n_curr, const double* pose_cw_curr, const float* kf_angles, const double* kf_pos_w,
+                                            const float* kf_dist_min_max, const uint8_t* kf_lm_desc, const uint8_t* kf_valid, int n_kf,
+                                            const float* scale_factors, int num_scale_levels, float log_scale_factor, float margin,
+                                            unsigned hamm_dist_thr, int check_orientation, int32_t* assigned) {
+    Grid g;
+    build_grid(g, *gp, xs, ys, n_curr);
+    std::vector<uint8_t> occ((size_t)n_curr, 0);
+    if (occupied) occ.assign(occupied, occupied + n_curr);
+    const double* R = pose_cw_curr;
+    const double* t = pose_cw_curr + 9;
+    const double cc[3] = {-((R[0] * t[0] + R[3] * t[1]) + R[6] * t[2]), -((R[1] * t[0] + R[4] * t[1]) + R[7] * t[2]),
+                          -((R[2] * t[0] + R[5] * t[1]) + R[8] * t[2])};
+    int num_matches = 0;
+    AngleChecker ac;
+    std::vector<int> owner((size_t)n_curr, -1);
+    for (int i = 0; i < n_kf; ++i) {
+        assigned[i] = -1;
+        if (kf_valid && !kf_valid[i]) continue;
+        const double* X = kf_pos_w + 3 * (size_t)i;
+        double reproj[2];
+        float x_right;
+        if (!reproject_to_image(*cam, *gp, pose_cw_curr, X, reproj, &x_right)) continue;
+        const double v[3] = {X[0] - cc[0], X[1] - cc[1], X[2] - cc[2]};
+        const double dist = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+        const float dmin = kf_dist_min_max[2 * i], dmax = kf_dist_min_max[2 * i + 1];
+        if (dist < dmin || dmax < dist) continue;
+        const float ratio = dmax / (float)dist;
+        int pred = (int)std::ceil(std::log(ratio) / log_scale_factor);
+        if (pred < 0) pred = 0;
+        else if (num_scale_levels <= pred) pred = num_scale_levels - 1;
+        const float r = margin * scale_factors[pred];
+        unsigned best = OVO_MAX_HAMMING_DIST;
+        int best_idx = -1;
+        for_keypoints_in_cell(g, xs, ys, octaves, (float)reproj[0], (float)reproj[1], r, pred - 1, pred + 1, [&](int idx) {
+            if (occ[idx]) return;
+            const unsigned d = distance_32(kf_lm_desc + (size_t)i * 32, desc + (size_t)idx * 32);
+            if (d < best) {
+                best = d;
+                best_idx = idx;
+            }
+        });
+        if (hamm_dist_thr < best) continue;
+        assigned[i] = best_idx;
+        occ[best_idx] = 1;
+        owner[best_idx] = i;
+        ++num_matches;
+        if (check_orientation) ac.append(kf_angles[i] - angles[best_idx], best_idx);
+    }
+    if (check_orientation) {
+        for (int invalid_idx : ac.invalid()) {
+            assigned[owner[invalid_idx]] = -1;
+            --num_matches;
+        }
+    }
+    return num_matches;
+}
+
 // M6  stereo::compute(stereo_x_right, depths). Keypoints are cv::KeyPoint records (level-0 coordinates, octave); the two
 // pyramids are the extractors' image_pyramid_ (unblurred). Steps as upstream / ORB-SLAM2 ComputeStereoMatches:
 //   rows: right keypoint i is a candidate for every image row in [floor(y - 2 s_i), ceil(y + 2 s_i)], s_i = scale_factors[octave];

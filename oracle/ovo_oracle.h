@@ -169,6 +169,14 @@ int ovo_bow_match_keyframes(const uint8_t* desc_1, const float* angles_1, const 
                             const int32_t* node_start_1, const int32_t* items_1, int nodes_1, const uint8_t* desc_2, const float* angles_2,
                             const uint8_t* valid_2, int n2, const int32_t* node_ids_2, const int32_t* node_start_2, const int32_t* items_2,
                             int nodes_2, float lowe_ratio, int check_orientation, int32_t* matched_2_in_1);
+/* M4 projection::match_frame_and_keyframe(curr_frm, keyfrm, already_matched_lms, margin, hamm_dist_thr). kf_valid[i] != 0 iff
+ * landmarks[i] && !will_be_erased() && !already_matched_lms.count(landmarks[i]); occupied[j] != 0 iff curr_frm.landmarks_[j]. */
+int ovo_projection_match_frame_and_keyframe(const ovo_camera* cam, const ovo_grid_params* gp, const float* xs, const float* ys,
+                                            const int32_t* octaves, const float* angles, const uint8_t* desc, const uint8_t* occupied,
+                                            int n_curr, const double* pose_cw_curr, const float* kf_angles, const double* kf_pos_w,
+                                            const float* kf_dist_min_max, const uint8_t* kf_lm_desc, const uint8_t* kf_valid, int n_kf,
+                                            const float* scale_factors, int num_scale_levels, float log_scale_factor, float margin,
+                                            unsigned hamm_dist_thr, int check_orientation, int32_t* assigned);
 /* M6 stereo::compute. Pyramids = the two extractors' image_pyramid_ (unblurred). Returns the number of valid depths. */
 int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr_right, const int32_t* level_rows,
                        const int32_t* level_cols, const size_t* stride_left, const size_t* stride_right, int num_levels,

@@ -247,3 +247,32 @@ def test_bow_match_keyframes(match, synth, oracle, check_orientation):
     wn, want = oracle.bow_match_keyframes(ka, da, fa, kb, db, fb, 0.75, check_orientation, v1, v2)
     assert gn == wn and np.array_equal(got, want)
     assert wn > 20 and (v1[want >= 0] == 1).all() and (v2[want[want >= 0]] == 1).all()
+
+
+@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("check_orientation,thr", [(True, 100), (False, 50)])
+def test_projection_match_frame_and_keyframe(match, synth, oracle, model, check_orientation, thr):
+    from openvslam_amd import _lib
+    rows, cols, n = (960, 1920, 3000) if model == 1 else (720, 1280, 2000)
+    ck, cd, Tc, lk, lpw, ld, _, valid, (fx, fy, cx, cy) = _last_and_current(synth, model, rows, cols, n, 60 + model, 0.0)
+    m = len(lk)
+    rng = np.random.default_rng(17)
+    R, t = Tc[:, :3], Tc[:, 3]
+    dist = np.linalg.norm(lpw - (-R.T @ t), axis=1)
+    sf = np.cumprod(np.concatenate([[1.0], np.full(7, 1.2)]).astype(np.float32)).astype(np.float32)
+    lvl = np.clip(lk["octave"] + rng.integers(-1, 2, m), 0, 7)
+    dmax = (dist * sf[lvl] * rng.uniform(0.85, 1.0, m)).astype(np.float32)
+    dmin = (dmax / sf[7] * rng.uniform(0.5, 1.3, m)).astype(np.float32)
+    dmm = np.ascontiguousarray(np.stack([dmin, dmax], 1))
+    occ = (rng.random(n) < 0.1).astype(np.uint8)
+    cam = _lib.Camera(model, 0, fx, fy, cx, cy, 0.0, 0.0, cols, rows)
+    ocam = oracle.Camera(model, 0, fx, fy, cx, cy, 0.0, 0.0, cols, rows)
+    gp, ogp = match.grid_params(cols, rows), oracle.grid_params(cols, rows)
+    lsf = float(np.log(np.float32(1.2)))
+    w = match.projection(0.9, check_orientation, max_targets=4096, max_queries=4096)
+    for margin in (10.0, 20.0):
+        got, gn = w.match_frame_and_keyframe(cam, gp, ck, cd, Tc, lk, lpw, dmm, ld, sf, lsf, margin, thr, curr_occupied=occ, kf_valid=valid)
+        want, wn = oracle.projection_match_frame_and_keyframe(ocam, ogp, ck, cd, Tc, lk, lpw, dmm, ld, sf, lsf, margin, thr, check_orientation,
+                                                              curr_occupied=occ, kf_valid=valid)
+        assert gn == wn and np.array_equal(got, want)
+    assert wn > n // 20
