@@ -301,6 +301,21 @@ ovs_status ovs_bow_match_keyframes(ovs_wmatcher* w, const ovs_keypoint* kps_1, c
                                    const int32_t* node_ids_2, const int32_t* node_start_2, const int32_t* items_2, int32_t nodes_2,
                                    float lowe_ratio, int32_t check_orientation, int32_t* matched_2_in_1, int32_t* num_matches);
 
+/* replaces: unsigned int robust::match_for_triangulation(data::keyframe* keyfrm_1, data::keyframe* keyfrm_2, const Mat33_t& E_12,
+ *               std::vector<std::pair<unsigned int, unsigned int>>& matched_idx_pairs)  and  robust::check_epipolar_constraint
+ * (src/openvslam/match/robust.{h,cc}). kps_i = undist_keypts_, has_lm_i[k] != 0 iff the keypoint already holds a landmark,
+ * x_right_i = stereo_x_right_ (NULL = monocular), bearings_i = bearings_ (n x 3 doubles), E_12 row-major, epipole_in_2 = keyfrm_1's
+ * camera centre as a bearing in keyfrm_2 (camera->reproject_to_bearing). matched_2_in_1[idx_1] = idx_2 or -1: the shim emits the
+ * pairs (idx_1, matched_2_in_1[idx_1]) in ascending idx_1 as upstream does. */
+ovs_status ovs_robust_match_for_triangulation(ovs_wmatcher* w, const ovs_keypoint* kps_1, const uint8_t* desc_1, const uint8_t* has_lm_1,
+                                              const float* x_right_1, const double* bearings_1, int32_t n1, const int32_t* node_ids_1,
+                                              const int32_t* node_start_1, const int32_t* items_1, int32_t nodes_1,
+                                              const ovs_keypoint* kps_2, const uint8_t* desc_2, const uint8_t* has_lm_2,
+                                              const float* x_right_2, const double* bearings_2, int32_t n2, const int32_t* node_ids_2,
+                                              const int32_t* node_start_2, const int32_t* items_2, int32_t nodes_2, const double* E_12,
+                                              const double* epipole_in_2, const float* scale_factors, int32_t num_levels,
+                                              int32_t check_orientation, int32_t* matched_2_in_1, int32_t* num_matches);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Stereo matcher.  replaces: match::stereo (src/openvslam/match/stereo.{h,cc}): the ctor's image pyramids are the two
  * extractors' image_pyramid_ members, which here never leave HBM -- the context reads the pyramids of the LAST extract of the

@@ -74,6 +74,8 @@ SYMBOLS = {
                                                             _i32, _f, _i32, _vp, C.POINTER(_i32)]),
     "ovs_projection_match_frame_and_keyframe": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _f, _f,
                                                        C.c_uint32, _i32, _vp, C.POINTER(_i32)]),
+    "ovs_robust_match_for_triangulation": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
+                                                  _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, C.POINTER(_i32)]),
     "ovs_bow_match_keyframes": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _f, _i32, _vp,
                                        C.POINTER(_i32)]),
     "ovs_fuse_replace_duplication": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _f, _f, _vp,

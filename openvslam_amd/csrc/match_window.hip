@@ -391,6 +391,16 @@ struct BowArgs {
     int kf_nodes, n_q;           // n_q = kf_node_start[kf_nodes]
     const uint8_t* frm_desc;
     const uint8_t* frm_valid;    // match_keyframes: the target keypoint must hold a live landmark too (NULL = all)
+    // robust::match_for_triangulation (tri != 0): pair filters d <= THR_LOW, epipole proximity, epipolar constraint; candidates are
+    // listed in REVERSE bucket order because upstream lets a later equal distance replace an earlier one
+    int tri;
+    const ovs_keypoint* kf_kps;  // octave of keypoint 1 (threshold scale)
+    const float* kf_x_right;
+    const float* frm_x_right;
+    const double* kf_bearings;
+    const double* frm_bearings;
+    double E[9], epipole[3];
+    float sf[OVS_MAX_LEVELS];
     const int32_t* frm_node_ids;
     const int32_t* frm_node_start;
     const int32_t* frm_items;
@@ -421,6 +431,39 @@ __global__ __launch_bounds__(256) void k_bow_lists(BowArgs a, uint32_t* __restri
         }
         if (l2 < a.frm_nodes && a.frm_node_ids[l2] == node) {
             const int b = a.frm_node_start[l2], e = a.frm_node_start[l2 + 1];
+            if (a.tri) {
+                uint32_t qd[8];
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(a.kf_desc + (size_t)kf_idx * 32);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qd[i] = src[i];
+                const bool stereo_1 = a.kf_x_right && 0 <= a.kf_x_right[kf_idx];
+                const double* b1 = a.kf_bearings + 3 * (size_t)kf_idx;
+                const double thr = (0.2 * 3.14159265358979323846 / 180.0) * (double)a.sf[a.kf_kps[kf_idx].octave];
+                uint32_t pos = FILL ? offsets[q] : 0u;
+                for (int k = e - 1; k >= b; --k) {
+                    const int idx = a.frm_items[k];
+                    if (a.frm_valid && !a.frm_valid[idx]) continue;
+                    const uint32_t d = hamming256_g(qd, reinterpret_cast<const uint32_t*>(a.frm_desc + (size_t)idx * 32));
+                    if ((uint32_t)OVS_HAMMING_DIST_THR_LOW < d) continue;
+                    const double* b2 = a.frm_bearings + 3 * (size_t)idx;
+                    if (!stereo_1 && !(a.frm_x_right && 0 <= a.frm_x_right[idx])) {
+                        const double cos_dist = (a.epipole[0] * b2[0] + a.epipole[1] * b2[1]) + a.epipole[2] * b2[2];
+                        if (0.99862953475 < cos_dist) continue;
+                    }
+                    const double ex = (a.E[0] * b2[0] + a.E[1] * b2[1]) + a.E[2] * b2[2], ey = (a.E[3] * b2[0] + a.E[4] * b2[1]) + a.E[5] * b2[2],
+                                 ez = (a.E[6] * b2[0] + a.E[7] * b2[1]) + a.E[8] * b2[2];
+                    const double nrm = sqrt((ex * ex + ey * ey) + ez * ez);
+                    const double cos_residual = ((ex * b1[0] + ey * b1[1]) + ez * b1[2]) / nrm;
+                    const double residual_rad = 3.14159265358979323846 / 2.0 - fabs(acos(cos_residual));
+                    if (!(residual_rad < thr)) continue;
+                    if (FILL) {
+                        if (pos < key_cap) keys[pos] = (d << 20) | (uint32_t)idx;
+                        else *overflow = 1u;
+                        ++pos;
+                    }
+                    ++n;
+                }
+            } else {
             if (!a.frm_valid) n = (uint32_t)(e - b);
             else
                 for (int k = b; k < e; ++k) n += a.frm_valid[a.frm_items[k]] ? 1u : 0u;
@@ -438,6 +481,7 @@ __global__ __launch_bounds__(256) void k_bow_lists(BowArgs a, uint32_t* __restri
                     else *overflow = 1u;
                     ++pos;
                 }
+            }
             }
         }
     }
@@ -474,7 +518,7 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* __restrict
 }
 
 // ---- 3. sequential-claim resolver ---------------------------------------------------------------------------------------
-enum { kRuleProjection = 0, kRuleArea = 1, kRuleBow = 2, kRuleBestOnly = 3 };
+enum { kRuleProjection = 0, kRuleArea = 1, kRuleBow = 2, kRuleBestOnly = 3, kRuleTriang = 4 };   // Triang = BestOnly accept, Bow output
 
 struct ResolveArgs {
     const uint32_t* offsets;   // n_q + 1
@@ -498,7 +542,7 @@ __device__ __forceinline__ bool rule_accepts(uint32_t best, uint32_t second, flo
     if (best == kNone) return false;
     const uint32_t bd = best >> 20;
     const uint32_t sd = second == kNone ? (uint32_t)OVS_MAX_HAMMING_DIST : (second >> 20);
-    if (RULE == kRuleBestOnly) return bd <= best_only_thr;   // match_current_and_last_frames / match_frame_and_keyframe: no ratio test
+    if (RULE == kRuleBestOnly || RULE == kRuleTriang) return bd <= best_only_thr;   // match_current_and_last_frames / match_frame_and_keyframe: no ratio test
     if (RULE == kRuleProjection) {
         if (bd > (uint32_t)OVS_HAMMING_DIST_THR_HIGH) return false;
         const int bl = (int)((best >> 16) & 15u), sl = second == kNone ? -1 : (int)((second >> 16) & 15u);
@@ -520,7 +564,7 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
     lds_u16* match = owner + ((a.n_t + 1) & ~1);                            // [n_q]  target of query (0xFFFF none)
     lds_u16* accepted = match + ((a.n_q + 1) & ~1);                         // [n_q]  target at acceptance time (orientation entries)
     const int lane = threadIdx.x;
-    const uint32_t max_d = RULE == kRuleBestOnly ? a.best_only_thr : (RULE == kRuleProjection ? OVS_HAMMING_DIST_THR_HIGH : OVS_HAMMING_DIST_THR_LOW);
+    const uint32_t max_d = (RULE == kRuleBestOnly || RULE == kRuleTriang) ? a.best_only_thr : (RULE == kRuleProjection ? OVS_HAMMING_DIST_THR_HIGH : OVS_HAMMING_DIST_THR_LOW);
     for (int i = lane; i < a.n_t; i += 64) {
         thr[i] = (uint16_t)OVS_MAX_HAMMING_DIST;
         owner[i] = 0xFFFFu;
@@ -642,7 +686,8 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
     }
     // ---- outputs
     uint32_t total = 0;
-    if (RULE == kRuleBow) {
+    constexpr bool kBowOut = RULE == kRuleBow || RULE == kRuleTriang;
+    if (kBowOut) {
         const int n_clear = a.bow_by_query ? a.n_out_q : a.n_t;
         for (int t = lane; t < n_clear; t += 64) a.assigned[t] = -1;
         __builtin_amdgcn_wave_barrier();
@@ -653,7 +698,7 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
         uint32_t t = 0xFFFFu;
         if (q < a.n_q) t = match[q];
         if (q < a.n_q) {
-            if (RULE == kRuleBow) {
+            if (kBowOut) {
                 if (t != 0xFFFFu) {
                     const int qi = a.q_items ? a.q_items[q] : q;
                     if (a.bow_by_query) a.assigned[qi] = (int32_t)t;
@@ -710,6 +755,8 @@ struct ovs_wmatcher {
     int32_t* d_q_i2 = nullptr;
     double* d_q_pos = nullptr;
     float* d_sf = nullptr;
+    double* d_tri_b1 = nullptr;
+    double* d_tri_b2 = nullptr;
     int32_t* d_csr = nullptr;           // bow feature vectors: 2 x (ids | start | items)
     size_t csr_cap = 0;
 };
@@ -822,6 +869,8 @@ ovs_status ovs_wmatcher_create(int32_t max_targets, int32_t max_queries, int32_t
     CREATE_TRY(hipMalloc(&w->d_q_i2, sizeof(int32_t) * Q));
     CREATE_TRY(hipMalloc(&w->d_q_pos, sizeof(double) * 3 * Q));
     CREATE_TRY(hipMalloc(&w->d_sf, sizeof(float) * OVS_MAX_LEVELS));
+    CREATE_TRY(hipMalloc(&w->d_tri_b1, sizeof(double) * 3 * Q));
+    CREATE_TRY(hipMalloc(&w->d_tri_b2, sizeof(double) * 3 * T));
     w->csr_cap = 4 * (T + Q) + 16;
     CREATE_TRY(hipMalloc(&w->d_csr, sizeof(int32_t) * w->csr_cap));
 #undef CREATE_TRY
@@ -834,7 +883,8 @@ ovs_status ovs_wmatcher_destroy(ovs_wmatcher* w) {
     if (w->stream) hipStreamSynchronize(w->stream);
     void* ptrs[] = {w->d_cell_of, w->d_cell_start, w->d_items, w->d_counts, w->d_offsets, w->d_keys, w->d_overflow, w->d_assigned, w->d_num,
                     w->d_t_kps,   w->d_t_desc,     w->d_t_flag, w->d_t_f,    w->d_q_kps,   w->d_q_desc, w->d_q_flag,  w->d_q_xy,    w->d_q_f,
-                    w->d_q_i,     w->d_csr,        w->d_q_r,    w->d_q_i2,   w->d_q_pos,   w->d_sf};
+                    w->d_q_i,     w->d_csr,        w->d_q_r,    w->d_q_i2,   w->d_q_pos,   w->d_sf,
+                    w->d_tri_b1,  w->d_tri_b2};
     for (void* p : ptrs) hipFree(p);
     if (w->stream) hipStreamDestroy(w->stream);
     delete w;
@@ -1034,7 +1084,18 @@ ovs_status ovs_area_match_in_consistent_area(ovs_wmatcher* w, const ovs_grid_par
 
 } // extern "C" (helper below has internal linkage)
 
-static ovs_status bow_match_impl(ovs_wmatcher* w, int by_query, const uint8_t* frm_valid, const ovs_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_valid,
+struct TriParams {   // robust::match_for_triangulation extras (host pointers)
+    const float* x_right_1;
+    const float* x_right_2;
+    const double* bearings_1;
+    const double* bearings_2;
+    const double* E_12;
+    const double* epipole_in_2;
+    const float* scale_factors;
+    int num_levels;
+};
+
+static ovs_status bow_match_impl(ovs_wmatcher* w, int by_query, const uint8_t* frm_valid, const TriParams* tri, const ovs_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_valid,
                                             int32_t n_kf, const int32_t* kf_node_ids, const int32_t* kf_node_start,
                                             const int32_t* kf_items, int32_t kf_nodes, const ovs_keypoint* frm_kps,
                                             const uint8_t* frm_desc, int32_t n_frm, const int32_t* frm_node_ids,
@@ -1087,6 +1148,25 @@ static ovs_status bow_match_impl(ovs_wmatcher* w, int by_query, const uint8_t* f
     a.n_q = nq;
     a.frm_desc = w->d_t_desc;
     a.frm_valid = frm_valid ? w->d_t_flag : nullptr;
+    if (tri) {
+        a.tri = 1;
+        a.kf_kps = w->d_q_kps;
+        OVS_HIP_TRY(hipMemcpyAsync(w->d_tri_b1, tri->bearings_1, sizeof(double) * 3 * n_kf, hipMemcpyHostToDevice, s));
+        OVS_HIP_TRY(hipMemcpyAsync(w->d_tri_b2, tri->bearings_2, sizeof(double) * 3 * n_frm, hipMemcpyHostToDevice, s));
+        a.kf_bearings = w->d_tri_b1;
+        a.frm_bearings = w->d_tri_b2;
+        if (tri->x_right_1) {
+            OVS_HIP_TRY(hipMemcpyAsync(w->d_q_f, tri->x_right_1, sizeof(float) * n_kf, hipMemcpyHostToDevice, s));
+            a.kf_x_right = w->d_q_f;
+        }
+        if (tri->x_right_2) {
+            OVS_HIP_TRY(hipMemcpyAsync(w->d_t_f, tri->x_right_2, sizeof(float) * n_frm, hipMemcpyHostToDevice, s));
+            a.frm_x_right = w->d_t_f;
+        }
+        std::memcpy(a.E, tri->E_12, sizeof(double) * 9);
+        std::memcpy(a.epipole, tri->epipole_in_2, sizeof(double) * 3);
+        for (int l = 0; l < OVS_MAX_LEVELS; ++l) a.sf[l] = l < tri->num_levels ? tri->scale_factors[l] : 1.0f;
+    }
     a.frm_node_ids = d_f_ids;
     a.frm_node_start = d_f_start;
     a.frm_items = d_f_items;
@@ -1107,7 +1187,8 @@ static ovs_status bow_match_impl(ovs_wmatcher* w, int by_query, const uint8_t* f
     ra.num_matches = w->d_num;
     ra.bow_by_query = by_query;
     ra.n_out_q = n_kf;
-    st = launch_resolve<kRuleBow>(ra, s);
+    ra.best_only_thr = OVS_HAMMING_DIST_THR_LOW;
+    st = tri ? launch_resolve<kRuleTriang>(ra, s) : launch_resolve<kRuleBow>(ra, s);
     if (st != OVS_OK) return st;
     uint32_t overflow = 0;
     OVS_HIP_TRY(hipMemcpyAsync(matched_kf_in_frm, w->d_assigned, sizeof(int32_t) * n_out, hipMemcpyDeviceToHost, s));
@@ -1126,7 +1207,7 @@ ovs_status ovs_bow_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_keypoint*
                                             const uint8_t* frm_desc, int32_t n_frm, const int32_t* frm_node_ids,
                                             const int32_t* frm_node_start, const int32_t* frm_items, int32_t frm_nodes, float lowe_ratio,
                                             int32_t check_orientation, int32_t* matched_kf_in_frm, int32_t* num_matches) {
-    return bow_match_impl(w, 0, nullptr, kf_kps, kf_desc, kf_valid, n_kf, kf_node_ids, kf_node_start, kf_items, kf_nodes, frm_kps, frm_desc, n_frm,
+    return bow_match_impl(w, 0, nullptr, nullptr, kf_kps, kf_desc, kf_valid, n_kf, kf_node_ids, kf_node_start, kf_items, kf_nodes, frm_kps, frm_desc, n_frm,
                           frm_node_ids, frm_node_start, frm_items, frm_nodes, lowe_ratio, check_orientation, matched_kf_in_frm, num_matches);
 }
 
@@ -1135,8 +1216,29 @@ ovs_status ovs_bow_match_keyframes(ovs_wmatcher* w, const ovs_keypoint* kps_1, c
                                    const ovs_keypoint* kps_2, const uint8_t* desc_2, const uint8_t* valid_2, int32_t n2,
                                    const int32_t* node_ids_2, const int32_t* node_start_2, const int32_t* items_2, int32_t nodes_2,
                                    float lowe_ratio, int32_t check_orientation, int32_t* matched_2_in_1, int32_t* num_matches) {
-    return bow_match_impl(w, 1, valid_2, kps_1, desc_1, valid_1, n1, node_ids_1, node_start_1, items_1, nodes_1, kps_2, desc_2, n2, node_ids_2,
+    return bow_match_impl(w, 1, valid_2, nullptr, kps_1, desc_1, valid_1, n1, node_ids_1, node_start_1, items_1, nodes_1, kps_2, desc_2, n2, node_ids_2,
                           node_start_2, items_2, nodes_2, lowe_ratio, check_orientation, matched_2_in_1, num_matches);
+}
+
+ovs_status ovs_robust_match_for_triangulation(ovs_wmatcher* w, const ovs_keypoint* kps_1, const uint8_t* desc_1, const uint8_t* has_lm_1,
+                                              const float* x_right_1, const double* bearings_1, int32_t n1, const int32_t* node_ids_1,
+                                              const int32_t* node_start_1, const int32_t* items_1, int32_t nodes_1,
+                                              const ovs_keypoint* kps_2, const uint8_t* desc_2, const uint8_t* has_lm_2,
+                                              const float* x_right_2, const double* bearings_2, int32_t n2, const int32_t* node_ids_2,
+                                              const int32_t* node_start_2, const int32_t* items_2, int32_t nodes_2, const double* E_12,
+                                              const double* epipole_in_2, const float* scale_factors, int32_t num_levels,
+                                              int32_t check_orientation, int32_t* matched_2_in_1, int32_t* num_matches) {
+    if (!bearings_1 || !bearings_2 || !E_12 || !epipole_in_2 || !scale_factors || num_levels < 1 || num_levels > OVS_MAX_LEVELS || n1 < 0 || n2 < 0)
+        return OVS_ERR_INVALID;
+    // "valid" for the bow kernels = the keypoint has NO landmark yet
+    std::vector<uint8_t> v1((size_t)std::max(n1, 1), 1), v2((size_t)std::max(n2, 1), 1);
+    if (has_lm_1)
+        for (int i = 0; i < n1; ++i) v1[i] = has_lm_1[i] ? 0 : 1;
+    if (has_lm_2)
+        for (int i = 0; i < n2; ++i) v2[i] = has_lm_2[i] ? 0 : 1;
+    TriParams tp{x_right_1, x_right_2, bearings_1, bearings_2, E_12, epipole_in_2, scale_factors, num_levels};
+    return bow_match_impl(w, 1, v2.data(), &tp, kps_1, desc_1, v1.data(), n1, node_ids_1, node_start_1, items_1, nodes_1, kps_2, desc_2, n2,
+                          node_ids_2, node_start_2, items_2, nodes_2, 0.0f, check_orientation, matched_2_in_1, num_matches);
 }
 
 ovs_status ovs_projection_match_current_and_last_frames(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp,

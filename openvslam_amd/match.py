@@ -337,3 +337,41 @@ class stereo:
                    "ovs_stereo_compute")
         self.num_valid_ = nv.value
         return xr[:n].copy(), dp[:n].copy()
+
+
+class robust_triangulation(_window_ctx):
+    """match::robust(lowe_ratio, check_orientation)::match_for_triangulation (the BoW + epipolar-constraint matcher of
+    mapping_module::create_new_landmarks). Separate context class: it runs on the windowed-matcher kernels."""
+
+    def __init__(self, lowe_ratio=0.6, check_orientation=True, **kw):
+        super().__init__(**kw)
+        self.lowe_ratio_ = float(lowe_ratio)
+        self.check_orientation_ = bool(check_orientation)
+
+    def match_for_triangulation(self, kps_1, desc_1, bow_feat_vec_1, bearings_1, kps_2, desc_2, bow_feat_vec_2, bearings_2, E_12, epipole_in_2,
+                                scale_factors, has_lm_1=None, has_lm_2=None, x_right_1=None, x_right_2=None):
+        """returns (num_matches, matched_idx_pairs) with matched_idx_pairs an (n, 2) array of (idx_1, idx_2), ascending idx_1."""
+        k1 = np.ascontiguousarray(kps_1, KP_DTYPE)
+        k2 = np.ascontiguousarray(kps_2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc_1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(desc_2, np.uint8).reshape(-1, 32)
+        b1 = np.ascontiguousarray(bearings_1, np.float64).reshape(-1, 3)
+        b2 = np.ascontiguousarray(bearings_2, np.float64).reshape(-1, 3)
+        h1 = None if has_lm_1 is None else np.ascontiguousarray(has_lm_1, np.uint8)
+        h2 = None if has_lm_2 is None else np.ascontiguousarray(has_lm_2, np.uint8)
+        x1 = None if x_right_1 is None else np.ascontiguousarray(x_right_1, np.float32)
+        x2 = None if x_right_2 is None else np.ascontiguousarray(x_right_2, np.float32)
+        E = np.ascontiguousarray(E_12, np.float64).reshape(9)
+        ep = np.ascontiguousarray(epipole_in_2, np.float64).reshape(3)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        i1, s1, t1 = flatten_bow(bow_feat_vec_1)
+        i2, s2, t2 = flatten_bow(bow_feat_vec_2)
+        out = np.full(max(len(k1), 1), -1, np.int32)
+        n = C.c_int32()
+        _lib.check(self._L.ovs_robust_match_for_triangulation(self._h, _p(k1), _p(d1), _p(h1), _p(x1), _p(b1), len(k1), _p(i1), _p(s1), _p(t1),
+                                                              len(i1), _p(k2), _p(d2), _p(h2), _p(x2), _p(b2), len(k2), _p(i2), _p(s2), _p(t2),
+                                                              len(i2), _p(E), _p(ep), _p(sf), len(sf), int(self.check_orientation_), _p(out),
+                                                              C.byref(n)), "ovs_robust_match_for_triangulation")
+        m = out[:len(k1)]
+        idx = np.nonzero(m >= 0)[0]
+        return n.value, np.stack([idx, m[idx]], 1).astype(np.int32)

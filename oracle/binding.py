@@ -406,6 +406,30 @@ def projection_match_frame_and_keyframe(cam, gp, curr_kps, curr_desc, pose_cw_cu
     return assigned[:len(kan)].copy(), n
 
 
+def robust_match_for_triangulation(kps_1, desc_1, feat_vec_1, bearings_1, kps_2, desc_2, feat_vec_2, bearings_2, E_12, epipole_in_2,
+                                   scale_factors, check_orientation=True, has_lm_1=None, has_lm_2=None, x_right_1=None, x_right_2=None):
+    _, _, o1, a1 = _soa(kps_1)
+    _, _, _, a2 = _soa(kps_2)
+    d1 = np.ascontiguousarray(desc_1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(desc_2, np.uint8).reshape(-1, 32)
+    b1 = np.ascontiguousarray(bearings_1, np.float64).reshape(-1, 3)
+    b2 = np.ascontiguousarray(bearings_2, np.float64).reshape(-1, 3)
+    h1 = None if has_lm_1 is None else np.ascontiguousarray(has_lm_1, np.uint8)
+    h2 = None if has_lm_2 is None else np.ascontiguousarray(has_lm_2, np.uint8)
+    x1 = None if x_right_1 is None else np.ascontiguousarray(x_right_1, np.float32)
+    x2 = None if x_right_2 is None else np.ascontiguousarray(x_right_2, np.float32)
+    E = np.ascontiguousarray(E_12, np.float64).reshape(9)
+    ep = np.ascontiguousarray(epipole_in_2, np.float64).reshape(3)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    i1, s1, t1 = _flatten_bow(feat_vec_1)
+    i2, s2, t2 = _flatten_bow(feat_vec_2)
+    out = np.full(max(len(a1), 1), -1, np.int32)
+    n = lib().ovo_robust_match_for_triangulation(_p(d1), _p(a1), _p(o1), _p(h1), _p(x1), _p(b1), len(a1), _p(i1), _p(s1), _p(t1), len(i1),
+                                                 _p(d2), _p(a2), _p(h2), _p(x2), _p(b2), len(a2), _p(i2), _p(s2), _p(t2), len(i2), _p(E), _p(ep),
+                                                 _p(sf), int(check_orientation), _p(out))
+    return n, out[:len(a1)].copy()
+
+
 def fuse_replace_duplication(cam, gp, kf_kps, kf_desc, pose_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc, scale_factors,
                              inv_level_sigma_sq, log_scale_factor, margin=3.0, kf_stereo_x_right=None, lm_valid=None):
     xs, ys, oc, _ = _soa(kf_kps)

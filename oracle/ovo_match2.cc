@@ -616,6 +616,80 @@ int ovo_projection_match_frame_and_keyframe(const ovo_camera* cam, const ovo_gri
     return num_matches;
 }
 
+// M2  robust::match_for_triangulation(keyfrm_1, keyfrm_2, E_12, matched_idx_pairs) + robust::check_epipolar_constraint
+// (expected: src/openvslam/match/robust.cc): common BoW nodes; keyframe-1 keypoints WITHOUT a landmark against keyframe-2
+// keypoints without a landmark that no earlier keypoint took; a candidate needs d <= THR_LOW and d <= the best so far (a later
+// equal distance replaces an earlier one), must not sit within 3 degrees of the epipole when neither side is a stereo keypoint,
+// and must satisfy the epipolar constraint: angle between bearing_1 and the epipolar plane E_12 * bearing_2 below
+// 0.2 deg * scale_factors[octave_1]. Orientation histogram keyed by idx_1. matched_2_in_1[idx_1] = idx_2 or -1.
+int ovo_robust_match_for_triangulation(const uint8_t* desc_1, const float* angles_1, const int32_t* octaves_1, const uint8_t* has_lm_1,
+                                       const float* x_right_1, const double* bearings_1, int n1, const int32_t* node_ids_1,
+                                       const int32_t* node_start_1, const int32_t* items_1, int nodes_1, const uint8_t* desc_2,
+                                       const float* angles_2, const uint8_t* has_lm_2, const float* x_right_2, const double* bearings_2,
+                                       int n2, const int32_t* node_ids_2, const int32_t* node_start_2, const int32_t* items_2, int nodes_2,
+                                       const double* E_12, const double* epipole_in_2, const float* scale_factors, int check_orientation,
+                                       int32_t* matched_2_in_1) {
+    int num_matches = 0;
+    AngleChecker ac;
+    for (int i = 0; i < n1; ++i) matched_2_in_1[i] = -1;
+    std::vector<uint8_t> already_2((size_t)n2, 0);
+    const double kPi = 3.14159265358979323846;
+    int a = 0, b = 0;
+    while (a < nodes_1 && b < nodes_2) {
+        if (node_ids_1[a] == node_ids_2[b]) {
+            for (int ka = node_start_1[a]; ka < node_start_1[a + 1]; ++ka) {
+                const int idx_1 = items_1[ka];
+                if (has_lm_1 && has_lm_1[idx_1]) continue;   // only keypoints without a 3D point are triangulated
+                const bool is_stereo_1 = x_right_1 && 0 <= x_right_1[idx_1];
+                const double* b1 = bearings_1 + 3 * (size_t)idx_1;
+                unsigned best = OVO_HAMMING_DIST_THR_LOW;
+                int best_idx_2 = -1;
+                for (int kb = node_start_2[b]; kb < node_start_2[b + 1]; ++kb) {
+                    const int idx_2 = items_2[kb];
+                    if (has_lm_2 && has_lm_2[idx_2]) continue;
+                    if (already_2[idx_2]) continue;
+                    const bool is_stereo_2 = x_right_2 && 0 <= x_right_2[idx_2];
+                    const double* b2 = bearings_2 + 3 * (size_t)idx_2;
+                    const unsigned d = distance_32(desc_1 + (size_t)idx_1 * 32, desc_2 + (size_t)idx_2 * 32);
+                    if (OVO_HAMMING_DIST_THR_LOW < d || best < d) continue;
+                    if (!is_stereo_1 && !is_stereo_2) {
+                        const double cos_dist = (epipole_in_2[0] * b2[0] + epipole_in_2[1] * b2[1]) + epipole_in_2[2] * b2[2];
+                        if (0.99862953475 < cos_dist) continue;
+                    }
+                    // check_epipolar_constraint
+                    const double ep[3] = {(E_12[0] * b2[0] + E_12[1] * b2[1]) + E_12[2] * b2[2], (E_12[3] * b2[0] + E_12[4] * b2[1]) + E_12[5] * b2[2],
+                                          (E_12[6] * b2[0] + E_12[7] * b2[1]) + E_12[8] * b2[2]};
+                    const double nrm = std::sqrt((ep[0] * ep[0] + ep[1] * ep[1]) + ep[2] * ep[2]);
+                    const double cos_residual = ((ep[0] * b1[0] + ep[1] * b1[1]) + ep[2] * b1[2]) / nrm;
+                    const double residual_rad = kPi / 2.0 - std::fabs(std::acos(cos_residual));
+                    const double residual_rad_thr = 0.2 * kPi / 180.0;
+                    if (!(residual_rad < residual_rad_thr * scale_factors[octaves_1[idx_1]])) continue;
+                    best_idx_2 = idx_2;
+                    best = d;
+                }
+                if (best_idx_2 < 0) continue;
+                already_2[best_idx_2] = 1;
+                matched_2_in_1[idx_1] = best_idx_2;
+                ++num_matches;
+                if (check_orientation) ac.append(angles_1[idx_1] - angles_2[best_idx_2], idx_1);
+            }
+            ++a;
+            ++b;
+        } else if (node_ids_1[a] < node_ids_2[b]) {
+            a = (int)(std::lower_bound(node_ids_1 + a, node_ids_1 + nodes_1, node_ids_2[b]) - node_ids_1);
+        } else {
+            b = (int)(std::lower_bound(node_ids_2 + b, node_ids_2 + nodes_2, node_ids_1[a]) - node_ids_2);
+        }
+    }
+    if (check_orientation) {
+        for (int invalid_idx : ac.invalid()) {
+            matched_2_in_1[invalid_idx] = -1;
+            --num_matches;
+        }
+    }
+    return num_matches;
+}
+
 // M6  stereo::compute(stereo_x_right, depths). Keypoints are cv::KeyPoint records (level-0 coordinates, octave); the two
 // pyramids are the extractors' image_pyramid_ (unblurred). Steps as upstream / ORB-SLAM2 ComputeStereoMatches:
 //   rows: right keypoint i is a candidate for every image row in [floor(y - 2 s_i), ceil(y + 2 s_i)], s_i = scale_factors[octave];

@@ -177,6 +177,15 @@ int ovo_projection_match_frame_and_keyframe(const ovo_camera* cam, const ovo_gri
                                             const float* kf_dist_min_max, const uint8_t* kf_lm_desc, const uint8_t* kf_valid, int n_kf,
                                             const float* scale_factors, int num_scale_levels, float log_scale_factor, float margin,
                                             unsigned hamm_dist_thr, int check_orientation, int32_t* assigned);
+/* M2 robust::match_for_triangulation. has_lm_i[k] != 0 iff keyframe i's keypoint k already holds a landmark; x_right_i = stereo_x_right_
+ * (NULL = monocular); bearings_i = n x 3 doubles; epipole_in_2 = keyfrm_1's centre as a bearing in keyfrm_2. matched_2_in_1[n1]. */
+int ovo_robust_match_for_triangulation(const uint8_t* desc_1, const float* angles_1, const int32_t* octaves_1, const uint8_t* has_lm_1,
+                                       const float* x_right_1, const double* bearings_1, int n1, const int32_t* node_ids_1,
+                                       const int32_t* node_start_1, const int32_t* items_1, int nodes_1, const uint8_t* desc_2,
+                                       const float* angles_2, const uint8_t* has_lm_2, const float* x_right_2, const double* bearings_2,
+                                       int n2, const int32_t* node_ids_2, const int32_t* node_start_2, const int32_t* items_2, int nodes_2,
+                                       const double* E_12, const double* epipole_in_2, const float* scale_factors, int check_orientation,
+                                       int32_t* matched_2_in_1);
 /* M6 stereo::compute. Pyramids = the two extractors' image_pyramid_ (unblurred). Returns the number of valid depths. */
 int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr_right, const int32_t* level_rows,
                        const int32_t* level_cols, const size_t* stride_left, const size_t* stride_right, int num_levels,

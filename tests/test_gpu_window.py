@@ -276,3 +276,68 @@ def test_projection_match_frame_and_keyframe(match, synth, oracle, model, check_
                                                               curr_occupied=occ, kf_valid=valid)
         assert gn == wn and np.array_equal(got, want)
     assert wn > n // 20
+
+
+def _two_view_geometry(rows, cols, n, seed):
+    """Two keyframes observing the same random 3D points (plus unrelated keypoints): keypoints, descriptors, unit bearings, the
+    essential matrix E_12 (x1^T E_12 x2 = 0 for bearings) and keyframe 1's centre as a bearing in keyframe 2."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 0.7 * cols
+    cx, cy = cols / 2.0, rows / 2.0
+    R1, t1 = np.eye(3), np.zeros(3)
+    R2 = _rot((0, 1, 0), 4.0) @ _rot((1, 0, 0), 1.5)
+    t2 = np.array([-0.6, 0.05, 0.1])
+    X = np.stack([rng.uniform(-4, 4, n), rng.uniform(-2.5, 2.5, n), rng.uniform(4, 15, n)], 1)
+
+    def project(R, t):
+        pc = X @ R.T + t
+        return np.stack([fx * pc[:, 0] / pc[:, 2] + cx, fy * pc[:, 1] / pc[:, 2] + cy], 1), pc
+
+    return fx, fy, cx, cy, R1, t1, R2, t2, X, project
+
+
+@pytest.mark.parametrize("check_orientation", [True, False])
+@pytest.mark.parametrize("stereo", [False, True])
+def test_robust_match_for_triangulation(match, synth, oracle, check_orientation, stereo):
+    rows, cols, n = 720, 1280, 1500
+    fx, fy, cx, cy, R1, t1, R2, t2, X, project = _two_view_geometry(rows, cols, n, 9)
+    rng = np.random.default_rng(10)
+    u1, _ = project(R1, t1)
+    u2, _ = project(R2, t2)
+    k1, d1 = synth.synth_keypoints(n, rows, cols, seed=31)
+    k2 = k1.copy()
+    k1["x"], k1["y"] = u1[:, 0], u1[:, 1]
+    k2["x"], k2["y"] = u2[:, 0] + rng.normal(0, 0.4, n), u2[:, 1] + rng.normal(0, 0.4, n)
+    off = rng.random(n) < 0.15                      # violate the epipolar constraint
+    k2["y"][off] += rng.uniform(8, 40, int(off.sum()))
+    k2["angle"] = (k1["angle"] + np.where(rng.random(n) < 0.8, rng.normal(0, 4, n), rng.uniform(0, 360, n))) % 360
+    d2 = np.stack([synth.flip_bits(rng, d1[i], 45) for i in range(n)])
+    dup = rng.integers(0, n, n // 5)                # near-duplicate descriptors: competing candidates
+    d2[dup] = np.stack([synth.flip_bits(rng, d1[(i + 1) % n], 20) for i in dup])
+    perm = rng.permutation(n)
+    k2, d2 = k2[perm], d2[perm]
+
+    def bearings(k):
+        b = np.stack([(k["x"].astype(np.float64) - cx) / fx, (k["y"].astype(np.float64) - cy) / fy, np.ones(len(k))], 1)
+        return b / np.linalg.norm(b, axis=1)[:, None]
+
+    b1, b2 = bearings(k1), bearings(k2)
+    R12, t12 = R1 @ R2.T, t1 - R1 @ R2.T @ t2       # x1 = R12 x2 + t12
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    E12 = tx @ R12
+    c1_in_2 = R2 @ (-R1.T @ t1) + t2
+    epipole = c1_in_2 / np.linalg.norm(c1_in_2)
+    fv1, fv2 = synth.synth_bow(d1, seed=2, n_nodes=60), synth.synth_bow(d2, seed=2, n_nodes=60)
+    h1 = (rng.random(n) < 0.3).astype(np.uint8)
+    h2 = (rng.random(n) < 0.3).astype(np.uint8)
+    x1 = x2 = None
+    if stereo:
+        x1 = np.where(rng.random(n) < 0.4, k1["x"] - 10, -1.0).astype(np.float32)
+        x2 = np.where(rng.random(n) < 0.4, k2["x"] - 10, -1.0).astype(np.float32)
+    sf = np.cumprod(np.concatenate([[1.0], np.full(7, 1.2)]).astype(np.float32)).astype(np.float32)
+    w = match.robust_triangulation(0.6, check_orientation, max_targets=2048, max_queries=2048)
+    gn, pairs = w.match_for_triangulation(k1, d1, fv1, b1, k2, d2, fv2, b2, E12, epipole, sf, h1, h2, x1, x2)
+    wn, want = oracle.robust_match_for_triangulation(k1, d1, fv1, b1, k2, d2, fv2, b2, E12, epipole, sf, check_orientation, h1, h2, x1, x2)
+    idx = np.nonzero(want >= 0)[0]
+    assert gn == wn and np.array_equal(pairs, np.stack([idx, want[idx]], 1))
+    assert wn > 50 and (h1[idx] == 0).all() and (h2[want[idx]] == 0).all()
