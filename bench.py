@@ -149,6 +149,9 @@ def main():
     kp_all, matches_all, pairs_all = (float(x) for x in totals.cpu().numpy())
 
     ba_res = None if args.no_ba else bench_local_ba(world, rank, dist, torch)
+    side = None
+    if rank == 0 and not args.no_ba and not args.no_cpu_baseline:
+        side = bench_other_configs()
 
     if rank == 0:
         n_cand = 0
@@ -209,6 +212,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "local_ba": ba_res,
+            "other_configs": side,
             "parity": "bit-exact vs in-repo CPU oracle (from-spec restatement; upstream source unavailable: parity unpinned)",
         }
         if cpu:
@@ -254,6 +258,64 @@ def bench_local_ba(world, rank, dist, torch, iters=20):
             "ms_per_linearisation": round(dt / iters * 1e3, 4), "edges_per_sec": round(n_edges * iters / dt, 1),
             "algorithmic_GBps": round(alg_bytes * iters / dt / 1e9, 2), "allreduce_bytes": 20000 * 12 * 8 if world > 1 else 0,
             "chi2": float(out["chi2"][0].item()), "tolerance_vs_oracle": "Hpl bit-exact; sums 1e-12 rel (1 GPU), 1e-10 rel (multi-rank)"}
+
+
+def bench_other_configs(iters=10):
+    """BASELINE configs[0], [2], [3] (parity-test cases) timed once each through the HOST entry points (H2D + kernels +
+    D2H per call: these matchers are latency-bound, tiny problems) next to the CPU oracle on the same inputs. Not part of `value`."""
+    import numpy as np
+    from oracle import binding as ob
+    from openvslam_amd import feature, match, synth
+    out = {}
+
+    def timeit(fn, n):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        return (time.perf_counter() - t0) / n * 1e3, r
+
+    sf = np.cumprod(np.concatenate([[1.0], np.full(7, 1.2)]).astype(np.float32)).astype(np.float32)
+    # configs[0]: 752x480, 1000 features, area::match_in_consistent_area (margin 100) between two frames 5 px apart
+    a = synth.synth_frame(480, 752, seed=0)
+    b = synth.synth_frame(480, 752, seed=0, shift=(5, 0), noise_seed=4242)
+    ex = feature.orb_extractor(feature.orb_params(1000), max_rows=480, max_cols=752)
+    ka, da = ex.extract(a)
+    kb, db = ex.extract(b)
+    gp, ogp = match.grid_params(752, 480), ob.grid_params(752, 480)
+    am = match.area(0.9, True, max_targets=2048, max_queries=2048)
+    prev0 = np.ascontiguousarray(np.stack([ka["x"], ka["y"]], 1), np.float32)
+    g_ms, (gn, _) = timeit(lambda: am.match_in_consistent_area(gp, ka, da, kb, db, prev0.copy(), 100), iters)
+    c_ms, (cn, _) = timeit(lambda: ob.area_match_in_consistent_area(ogp, ka, da, kb, db, prev0.copy(), 100, 0.9, True), 3)
+    e_ms, _ = timeit(lambda: ex.extract(a), iters)
+    out["config0_euroc_mono_init"] = {"extract_ms_per_frame_host_api": round(e_ms, 3), "area_match_ms": round(g_ms, 3),
+                                      "area_match_cpu_oracle_ms": round(c_ms, 3), "matches": int(gn), "parity": bool(gn == cn)}
+    # configs[2]: KITTI geometry 1241x376 x2, 2000 features each, stereo::compute
+    left, right, _ = synth.synth_stereo_pair(376, 1241, seed=1)
+    el = feature.orb_extractor(feature.orb_params(2000), max_rows=376, max_cols=1241)
+    er = feature.orb_extractor(feature.orb_params(2000), max_rows=376, max_cols=1241)
+    kl, dl = el.extract(left)
+    kr, dr = er.extract(right)
+    st = match.stereo(el, er, kl, dl, kr, dr, 386.1448, 0.5372)
+    g_ms, (xr, _) = timeit(st.compute, iters)
+    oxl, oxr = ob.OrbExtractor(ob.make_params(2000)), ob.OrbExtractor(ob.make_params(2000))
+    oxl.extract(left)
+    oxr.extract(right)
+    c_ms, (wxr, _, _) = timeit(lambda: ob.stereo_compute(oxl, oxr, kl, dl, kr, dr, 386.1448, 0.5372), 3)
+    out["config2_kitti_stereo"] = {"stereo_compute_ms": round(g_ms, 3), "stereo_compute_cpu_oracle_ms": round(c_ms, 3),
+                                   "valid_depths": int((xr >= 0).sum()), "parity": bool(np.array_equal(xr.view(np.uint32), wxr.view(np.uint32)))}
+    # configs[3]: 3840x1920, 4000 frame keypoints, 10 000 landmarks, projection::match_frame_and_landmarks, margin 5
+    k, d = synth.synth_keypoints(4000, 1920, 3840, seed=1)
+    lm = synth.synth_landmarks(k, d, 10000, 1920, 3840, seed=2, n_from_frame=5200)
+    gp, ogp = match.grid_params(3840, 1920), ob.grid_params(3840, 1920)
+    pm = match.projection(0.8, True, max_targets=4096, max_queries=10240)
+    g_ms, (ga, gn) = timeit(lambda: pm.match_frame_and_landmarks(gp, k, d, sf, lm["xy"], lm["level"], lm["desc"], 5.0, lm_valid=lm["valid"]), iters)
+    c_ms, (ca, cn) = timeit(lambda: ob.projection_match_frame_and_landmarks(ogp, k, d, sf, lm["xy"], lm["level"], lm["desc"], 5.0, 0.8,
+                                                                           lm_valid=lm["valid"]), 3)
+    out["config3_equirect_projection"] = {"match_frame_and_landmarks_ms": round(g_ms, 3), "cpu_oracle_ms": round(c_ms, 3), "matches": int(gn),
+                                          "parity": bool(np.array_equal(ga, ca))}
+    out["note"] = "host entry points (H2D + kernels + D2H per call); CPU oracle single-threaded on the same inputs"
+    return out
 
 
 def cpu_baseline(frames, budget_s=12.0):

@@ -144,11 +144,15 @@ struct WinArgs {
     int mode;
 };
 
+// One WAVE per query: the lanes take the cells of the query's window (a 100-px margin covers ~340 of the 64 x 48 cells -- a single
+// lane walking them was ~0.7 ms of dependent loads per pass), count their members that pass the filters, and an exclusive scan over
+// the lanes places every cell's members at their position in UPSTREAM'S ORDER (cells x-major, then y, then members).
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_window_lists(WinArgs a, uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
                                                      uint32_t* __restrict__ keys, uint32_t key_cap, uint32_t* __restrict__ overflow) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= a.n_q) return;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= a.n_q) return;   // wave-uniform
     bool valid = !a.q_valid || a.q_valid[q];
     float r;
     int minl, maxl;
@@ -167,10 +171,11 @@ __global__ __launch_bounds__(256) void k_window_lists(WinArgs a, uint32_t* __res
         r = a.margin;
         minl = maxl = lvl;
     }
-    uint32_t n = 0;
-    uint32_t pos = FILL ? offsets[q] : 0u;
+    uint32_t total = 0;
     if (valid) {
+        const uint32_t base = FILL ? offsets[q] : 0u;
         const float ref_x = a.q_xy[2 * q], ref_y = a.q_xy[2 * q + 1];
+        const float q_xr = (a.mode != kModeArea && a.t_x_right) ? a.q_x_right[q] : 0.0f;
         uint32_t qd[8];
         if (FILL) {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(a.q_desc + (size_t)q * 32);
@@ -185,35 +190,56 @@ __global__ __launch_bounds__(256) void k_window_lists(WinArgs a, uint32_t* __res
         const int max_cy = min(g.rows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(ref_y, g.min_y), r), g.inv_h)));
         if (min_cx < g.cols && max_cx >= 0 && min_cy < g.rows && max_cy >= 0) {
             const bool check_level = (0 < minl) || (0 <= maxl);
-            for (int cx = min_cx; cx <= max_cx; ++cx) {
-                for (int cy = min_cy; cy <= max_cy; ++cy) {
-                    const int c = cx * g.rows + cy;
-                    const int e = a.cell_start[c + 1];
-                    for (int k = a.cell_start[c]; k < e; ++k) {
-                        const int idx = a.items[k];
-                        const ovs_keypoint kp = a.t_kps[idx];
-                        if (check_level && (kp.octave < minl || (0 <= maxl && maxl < kp.octave))) continue;
-                        if (!(fabsf(__fsub_rn(kp.x, ref_x)) < r && fabsf(__fsub_rn(kp.y, ref_y)) < r)) continue;
-                        if (a.mode != kModeArea) {
-                            if (a.t_occupied && a.t_occupied[idx]) continue;
-                            if (a.t_x_right) {
-                                const float xr = a.t_x_right[idx];
-                                if (0 < xr && r < fabsf(__fsub_rn(a.q_x_right[q], xr))) continue;
-                            }
-                        }
-                        if (FILL) {
-                            const uint32_t d = hamming256_g(qd, reinterpret_cast<const uint32_t*>(a.t_desc + (size_t)idx * 32));
-                            if (pos < key_cap) keys[pos] = (d << 20) | ((uint32_t)(kp.octave & 15) << 16) | (uint32_t)idx;
-                            else *overflow = 1u;
-                            ++pos;
-                        }
-                        ++n;
+            const int ncy = max_cy - min_cy + 1, ncell = (max_cx - min_cx + 1) * ncy;
+            auto passes = [&](int idx, const ovs_keypoint& kp) -> bool {
+                if (check_level && (kp.octave < minl || (0 <= maxl && maxl < kp.octave))) return false;
+                if (!(fabsf(__fsub_rn(kp.x, ref_x)) < r && fabsf(__fsub_rn(kp.y, ref_y)) < r)) return false;
+                if (a.mode != kModeArea) {
+                    if (a.t_occupied && a.t_occupied[idx]) return false;
+                    if (a.t_x_right) {
+                        const float xr = a.t_x_right[idx];
+                        if (0 < xr && r < fabsf(__fsub_rn(q_xr, xr))) return false;
                     }
                 }
+                return true;
+            };
+            for (int c0 = 0; c0 < ncell; c0 += 64) {
+                const int ci = c0 + lane;
+                int b = 0, e = 0;
+                if (ci < ncell) {
+                    const int cxo = ci / ncy;
+                    const int c = (min_cx + cxo) * g.rows + min_cy + (ci - cxo * ncy);
+                    b = a.cell_start[c];
+                    e = a.cell_start[c + 1];
+                }
+                uint32_t n_pass = 0;
+                for (int k = b; k < e; ++k) {
+                    const int idx = a.items[k];
+                    n_pass += passes(idx, a.t_kps[idx]) ? 1u : 0u;
+                }
+                uint32_t incl = n_pass;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t t = __shfl_up(incl, off);
+                    if (lane >= off) incl += t;
+                }
+                if (FILL && n_pass) {
+                    uint32_t pos = base + total + (incl - n_pass);
+                    for (int k = b; k < e; ++k) {
+                        const int idx = a.items[k];
+                        const ovs_keypoint kp = a.t_kps[idx];
+                        if (!passes(idx, kp)) continue;
+                        const uint32_t d = hamming256_g(qd, reinterpret_cast<const uint32_t*>(a.t_desc + (size_t)idx * 32));
+                        if (pos < key_cap) keys[pos] = (d << 20) | ((uint32_t)(kp.octave & 15) << 16) | (uint32_t)idx;
+                        else *overflow = 1u;
+                        ++pos;
+                    }
+                }
+                total += __shfl(incl, 63);
             }
         }
     }
-    if (!FILL) counts[q] = n;
+    if (!FILL && lane == 0) counts[q] = total;
 }
 
 // camera::perspective / camera::equirectangular ::reproject_to_image in double precision, one rounding per operation (the library
@@ -531,6 +557,7 @@ struct ResolveArgs {
     const ovs_keypoint* t_kps;    // area / bow: target keypoints (angle, pt)
     float* prev_matched_xy;       // area: updated for the final matches
     int32_t* assigned;            // projection / area: [n_q] target or -1; bow: [n_t] keyframe keypoint index or -1
+    uint32_t key_pool;            // LDS words available for a copy of the key CSR
     uint32_t best_only_thr;       // BestOnly: accept iff best <= this (match_current_and_last_frames: THR_HIGH)
     int bow_by_query;             // bow (match_keyframes): output [n_out_q] indexed by q_items[q] = target or -1
     int n_out_q;
@@ -575,6 +602,23 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
     }
     for (int i = lane; i < kMarkSize; i += 64) mark[i] = ~0u;
     if (lane < 32) hist[lane] = 0;
+    // the candidate CSR is one contiguous array: when it fits the rest of the LDS allocation it is copied there once (coalesced
+    // 16-byte loads), and the rounds below never touch HBM
+    lds_u32* s_keys = (lds_u32*)(accepted + ((a.n_q + 1) & ~1));
+    const uint32_t n_keys = a.offsets[a.n_q];
+    const bool keys_in_lds = n_keys <= a.key_pool;
+    if (keys_in_lds) {
+        const uint32_t n4 = n_keys >> 2;
+        const uint4* src4 = reinterpret_cast<const uint4*>(a.keys);
+        for (uint32_t i = lane; i < n4; i += 64) {
+            const uint4 v = src4[i];
+            s_keys[4 * i] = v.x;
+            s_keys[4 * i + 1] = v.y;
+            s_keys[4 * i + 2] = v.z;
+            s_keys[4 * i + 3] = v.w;
+        }
+        for (uint32_t i = 4 * n4 + lane; i < n_keys; i += 64) s_keys[i] = a.keys[i];
+    }
     __builtin_amdgcn_wave_barrier();
     uint32_t epoch = 0;
 
@@ -592,20 +636,32 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
             bool acc = false;
             ++epoch;
             const uint32_t tag = (0xFFFFFFu - epoch) << 8;   // newer rounds carry smaller tags: atomicMin overrides stale stamps
+            asm volatile("" ::: "memory");   // thr[] committed in the previous round must be re-read
             if (mine) {
                 uint32_t bd = OVS_MAX_HAMMING_DIST, sd = OVS_MAX_HAMMING_DIST;
-                for (uint32_t k = lb; k < le; ++k) {
-                    const uint32_t e = a.keys[k];
-                    const uint32_t d = e >> 20;
-                    if (!(d < (uint32_t)thr[e & 0xFFFFu])) continue;   // claimed / matched at a distance <= ours
-                    if (d < bd) {
-                        second = best;
-                        sd = bd;
-                        best = e;
-                        bd = d;
-                    } else if (d < sd) {
-                        second = e;
-                        sd = d;
+                // eight keys and their eight thr[] values are fetched as independent batches (one load round trip per batch instead of
+                // one per entry: on a lone wave that latency is the whole cost); keys come from LDS when the CSR was staged
+                const __attribute__((address_space(3))) uint16_t* thr_nv = (const __attribute__((address_space(3))) uint16_t*)thr;
+                for (uint32_t k0 = lb; k0 < le; k0 += 8) {
+                    uint32_t e8[8], t8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        e8[u] = k0 + u < le ? (keys_in_lds ? (uint32_t)s_keys[k0 + u] : a.keys[k0 + u]) : kNone;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t8[u] = e8[u] != kNone ? (uint32_t)thr_nv[e8[u] & 0xFFFFu] : 0u;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const uint32_t e = e8[u], d = e >> 20;
+                        if (e == kNone || !(d < t8[u])) continue;   // claimed / matched at a distance <= ours
+                        if (d < bd) {
+                            second = best;
+                            sd = bd;
+                            best = e;
+                            bd = d;
+                        } else if (d < sd) {
+                            second = e;
+                            sd = d;
+                        }
                     }
                 }
                 acc = rule_accepts<RULE>(best, second, a.lowe_ratio, a.best_only_thr);
@@ -781,12 +837,19 @@ size_t resolve_lds_bytes(int n_q, int n_t) {
 }
 
 template <int RULE>
-ovs_status launch_resolve(const ResolveArgs& ra, hipStream_t s) {
-    const size_t lds = resolve_lds_bytes(ra.n_q, ra.n_t);
-    if (lds > 150 * 1024) return OVS_ERR_CAPACITY;
-    if (lds > 64 * 1024)
+ovs_status launch_resolve(const ResolveArgs& ra_in, hipStream_t s) {
+    ResolveArgs ra = ra_in;
+    const size_t fixed = resolve_lds_bytes(ra.n_q, ra.n_t);
+    if (fixed > 150 * 1024) return OVS_ERR_CAPACITY;
+    // the rest of a 96 KiB allocation holds a copy of the key CSR when it fits (checked on the device: the size is only known there)
+    const size_t lds = std::max(fixed, (size_t)96 * 1024);
+    ra.key_pool = (uint32_t)((lds - fixed) / 4);
+    static thread_local size_t configured[8] = {};
+    if (lds > configured[RULE]) {
         OVS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_list_resolve<RULE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
+        configured[RULE] = lds;
+    }
     hipLaunchKernelGGL(k_list_resolve<RULE>, dim3(1), dim3(64), lds, s, ra);
     OVS_HIP_TRY(hipGetLastError());
     return OVS_OK;
@@ -808,10 +871,10 @@ ovs_status grid_assign(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_key
 }
 
 template <typename ARGS, typename KCOUNT, typename KFILL>
-ovs_status build_lists(ovs_wmatcher* w, const ARGS& args, int n_q, KCOUNT kcount, KFILL kfill, hipStream_t s) {
+ovs_status build_lists(ovs_wmatcher* w, const ARGS& args, int n_q, KCOUNT kcount, KFILL kfill, hipStream_t s, int q_per_block = 4) {
     if (n_q > w->max_q) return OVS_ERR_CAPACITY;
     OVS_HIP_TRY(hipMemsetAsync(w->d_overflow, 0, sizeof(uint32_t), s));
-    const dim3 grid((n_q + 255) / 256);
+    const dim3 grid((n_q + q_per_block - 1) / q_per_block);
     hipLaunchKernelGGL(kcount, grid, dim3(256), 0, s, args, w->d_counts, (const uint32_t*)w->d_offsets, w->d_keys, w->max_entries, w->d_overflow);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, (const uint32_t*)w->d_counts, n_q, w->d_offsets);
     hipLaunchKernelGGL(kfill, grid, dim3(256), 0, s, args, w->d_counts, (const uint32_t*)w->d_offsets, w->d_keys, w->max_entries, w->d_overflow);
@@ -1171,7 +1234,7 @@ static ovs_status bow_match_impl(ovs_wmatcher* w, int by_query, const uint8_t* f
     a.frm_node_start = d_f_start;
     a.frm_items = d_f_items;
     a.frm_nodes = frm_nodes;
-    ovs_status st = build_lists(w, a, nq, k_bow_lists<false>, k_bow_lists<true>, s);
+    ovs_status st = build_lists(w, a, nq, k_bow_lists<false>, k_bow_lists<true>, s, 256);
     if (st != OVS_OK) return st;
     ResolveArgs ra{};
     ra.offsets = w->d_offsets;
