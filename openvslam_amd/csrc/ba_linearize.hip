@@ -44,6 +44,8 @@ __device__ __forceinline__ double dotD(const double (&A)[D][6], int a, const dou
     return s;
 }
 
+constexpr int kEdgesPerThread = 2;   // 1, 2, 4 measured within 2 % of each other at 100 k edges: fabric-side fp64 atomics bound the kernel
+
 template <int D>
 __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__ poses, const uint8_t* __restrict__ pose_fixed,
                                                      int n_pose, const double* __restrict__ points, int n_pt,
@@ -51,7 +53,38 @@ __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__
                                                      double bf, double huber_delta, double* __restrict__ Hpp, double* __restrict__ bp,
                                                      double* __restrict__ Hll, double* __restrict__ bl, double* __restrict__ Hpl,
                                                      double* __restrict__ chi2) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    // A workgroup takes kEdgesPerThread * 256 consecutive edges; lane l of wave w handles edges base + 64 (4 k + w) + l. Edges arrive
+    // grouped by keyframe, so a wave usually sees ONE pose for all its iterations: its 21 + 6 pose-block terms are accumulated per lane
+    // across the iterations and reduced across the wave once (the 27 fp64 wave reductions per 64 edges were a quarter of the kernel).
+    double acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+    int acc_pose = -1;
+    auto flush = [&]() {
+        if (acc_pose < 0) return;
+        double* hp = Hpp + 36 * (size_t)acc_pose;
+        double* gp = bp + 6 * (size_t)acc_pose;
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int b = a; b < 6; ++b) {
+                const double sv = wave_sum_f64(acc[t]);
+                acc[t++] = 0.0;
+                if ((threadIdx.x & 63) == 0) {
+                    atomicAdd(&hp[6 * a + b], sv);
+                    if (b != a) atomicAdd(&hp[6 * b + a], sv);
+                }
+            }
+            const double g = wave_sum_f64(acc[t]);
+            acc[t++] = 0.0;
+            if ((threadIdx.x & 63) == 0) atomicAdd(&gp[a], g);
+        }
+        acc_pose = -1;
+    };
+#pragma unroll 1
+    for (int it = 0; it < kEdgesPerThread; ++it) {
+    const int e = (blockIdx.x * kEdgesPerThread + it) * 256 + threadIdx.x;
     const bool valid = e < n_edge;
     int pose = -1, pt = 0;
     // Jacobians padded to 6 columns so the landmark (3) and pose (6) blocks share dotD
@@ -136,12 +169,12 @@ __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__
         }
     }
     const bool free_pose = valid && !(pose_fixed && pose_fixed[pose]);
-    if (free_pose) {
+    if (valid) {   // blocks of fixed poses are zero (written here: no 14 MB memset in front of the kernel)
         double* hpl = Hpl + 18 * (size_t)e;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) hpl[3 * a + b] = W * dotD<D>(Jp, a, Jl, b);
+            for (int b = 0; b < 3; ++b) hpl[3 * a + b] = free_pose ? W * dotD<D>(Jp, a, Jl, b) : 0.0;
     }
     // chi2: one atomic per wave
     {
@@ -161,35 +194,45 @@ __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__
     const int p0 = __builtin_amdgcn_readfirstlane(pose);
     const bool uniform = __all(!valid || pose == p0) && p0 >= 0;
     if (uniform) {
-        const bool any_free = __any(free_pose);
-        if (any_free) {   // wave-uniform: all valid lanes share pose p0, hence the same fixed flag
-            double* hp = Hpp + 36 * (size_t)p0;
-            double* gp = bp + 6 * (size_t)p0;
-            const double m = free_pose ? 1.0 : 0.0;
+        if (__any(free_pose)) {   // wave-uniform: all valid lanes share pose p0, hence the same fixed flag
+            if (acc_pose != p0) flush();
+            acc_pose = p0;
+            if (free_pose) {
+                int t = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                    for (int b = a; b < 6; ++b) acc[t++] += W * dotD<D>(Jp, a, Jp, b);
+                    acc[t++] += grad(a);
+                }
+            }
+        }
+    } else {
+        flush();
+        if (free_pose) {
+            double* hp = Hpp + 36 * (size_t)pose;
+            double* gp = bp + 6 * (size_t)pose;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
 #pragma unroll
-                for (int b = a; b < 6; ++b) {
-                    const double s = wave_sum_f64(m * (W * dotD<D>(Jp, a, Jp, b)));
-                    if ((threadIdx.x & 63) == 0) {
-                        atomicAdd(&hp[6 * a + b], s);
-                        if (b != a) atomicAdd(&hp[6 * b + a], s);
-                    }
-                }
-                const double g = wave_sum_f64(m * grad(a));
-                if ((threadIdx.x & 63) == 0) atomicAdd(&gp[a], g);
+                for (int b = 0; b < 6; ++b) atomicAdd(&hp[6 * a + b], W * dotD<D>(Jp, a, Jp, b));
+                atomicAdd(&gp[a], grad(a));
             }
         }
-    } else if (free_pose) {
-        double* hp = Hpp + 36 * (size_t)pose;
-        double* gp = bp + 6 * (size_t)pose;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-#pragma unroll
-            for (int b = 0; b < 6; ++b) atomicAdd(&hp[6 * a + b], W * dotD<D>(Jp, a, Jp, b));
-            atomicAdd(&gp[a], grad(a));
-        }
     }
+    }   // edges of this thread
+    flush();
+}
+
+// one launch instead of five hipMemsetAsync calls (each costs a launch: they were ~25 us of a 128 us linearisation call)
+__global__ __launch_bounds__(256) void k_ba_zero(double* __restrict__ a, size_t na, double* __restrict__ b, size_t nb, double* __restrict__ c,
+                                                size_t nc, double* __restrict__ d, size_t nd, double* __restrict__ e, size_t ne) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    for (size_t k = i; k < na; k += stride) a[k] = 0.0;
+    for (size_t k = i; k < nb; k += stride) b[k] = 0.0;
+    for (size_t k = i; k < nc; k += stride) c[k] = 0.0;
+    for (size_t k = i; k < nd; k += stride) d[k] = 0.0;
+    for (size_t k = i; k < ne; k += stride) e[k] = 0.0;
 }
 
 }   // namespace ovs
@@ -205,14 +248,11 @@ ovs_status ovs_ba_linearize_dev(const double* d_poses, const uint8_t* d_pose_fix
         (n_edge > 0 && !d_edges))
         return OVS_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    OVS_HIP_TRY(hipMemsetAsync(d_Hpp, 0, sizeof(double) * 36 * (size_t)n_pose, s));
-    OVS_HIP_TRY(hipMemsetAsync(d_bp, 0, sizeof(double) * 6 * (size_t)n_pose, s));
-    OVS_HIP_TRY(hipMemsetAsync(d_Hll, 0, sizeof(double) * 9 * (size_t)n_pt, s));
-    OVS_HIP_TRY(hipMemsetAsync(d_bl, 0, sizeof(double) * 3 * (size_t)n_pt, s));
-    OVS_HIP_TRY(hipMemsetAsync(d_chi2, 0, sizeof(double) * 2, s));
+    hipLaunchKernelGGL(k_ba_zero, dim3(128), dim3(256), 0, s, d_Hpp, (size_t)36 * n_pose, d_bp, (size_t)6 * n_pose, d_Hll, (size_t)9 * n_pt, d_bl,
+                       (size_t)3 * n_pt, d_chi2, (size_t)2);
+    OVS_HIP_TRY(hipGetLastError());
     if (n_edge == 0) return OVS_OK;
-    OVS_HIP_TRY(hipMemsetAsync(d_Hpl, 0, sizeof(double) * 18 * (size_t)n_edge, s));   // blocks of fixed poses stay zero
-    hipLaunchKernelGGL(k_ba_linearize<2>, dim3((n_edge + 255) / 256), dim3(256), 0, s, d_poses, d_pose_fixed, n_pose, d_points, n_pt, d_edges,
+    hipLaunchKernelGGL(k_ba_linearize<2>, dim3((n_edge + 256 * kEdgesPerThread - 1) / (256 * kEdgesPerThread)), dim3(256), 0, s, d_poses, d_pose_fixed, n_pose, d_points, n_pt, d_edges,
                        n_edge, *cam, 0.0, huber_delta, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi2);
     OVS_HIP_TRY(hipGetLastError());
     return OVS_OK;
@@ -227,15 +267,12 @@ ovs_status ovs_ba_linearize_stereo_dev(const double* d_poses, const uint8_t* d_p
         return OVS_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate) {
-        OVS_HIP_TRY(hipMemsetAsync(d_Hpp, 0, sizeof(double) * 36 * (size_t)n_pose, s));
-        OVS_HIP_TRY(hipMemsetAsync(d_bp, 0, sizeof(double) * 6 * (size_t)n_pose, s));
-        OVS_HIP_TRY(hipMemsetAsync(d_Hll, 0, sizeof(double) * 9 * (size_t)n_pt, s));
-        OVS_HIP_TRY(hipMemsetAsync(d_bl, 0, sizeof(double) * 3 * (size_t)n_pt, s));
-        OVS_HIP_TRY(hipMemsetAsync(d_chi2, 0, sizeof(double) * 2, s));
+        hipLaunchKernelGGL(k_ba_zero, dim3(128), dim3(256), 0, s, d_Hpp, (size_t)36 * n_pose, d_bp, (size_t)6 * n_pose, d_Hll, (size_t)9 * n_pt,
+                           d_bl, (size_t)3 * n_pt, d_chi2, (size_t)2);
+        OVS_HIP_TRY(hipGetLastError());
     }
     if (n_edge == 0) return OVS_OK;
-    OVS_HIP_TRY(hipMemsetAsync(d_Hpl, 0, sizeof(double) * 18 * (size_t)n_edge, s));
-    hipLaunchKernelGGL(k_ba_linearize<3>, dim3((n_edge + 255) / 256), dim3(256), 0, s, d_poses, d_pose_fixed, n_pose, d_points, n_pt, d_edges,
+    hipLaunchKernelGGL(k_ba_linearize<3>, dim3((n_edge + 256 * kEdgesPerThread - 1) / (256 * kEdgesPerThread)), dim3(256), 0, s, d_poses, d_pose_fixed, n_pose, d_points, n_pt, d_edges,
                        n_edge, *cam, focal_x_baseline, huber_delta, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi2);
     OVS_HIP_TRY(hipGetLastError());
     return OVS_OK;
