@@ -3,8 +3,8 @@
 // Integer-only on the device: the float/double part of OpenCV (source coordinate, coefficient rounding) is evaluated
 // once per geometry on the host into ResizeTap tables (orb_api.hip: build_taps) so no device float can change a pixel.
 //
-// HBM-bound streaming kernel. A 256-thread workgroup produces a 128 x 16 output tile: the source rectangle its taps
-// touch (<= 160 x 22 bytes at scale 1.2) is staged in LDS with coalesced, aligned u32 loads -- v1 gathered 16 single bytes
+// HBM-bound streaming kernel. A 256-thread workgroup produces a 128 x 32 output tile: the source rectangle its taps
+// touch (<= 160 x 41 bytes at scale 1.2) is staged in LDS with coalesced, aligned u32 loads -- v1 gathered 16 single bytes
 // per thread straight from global memory and was bound by the texture-addresser rate, not by bandwidth -- then the two
 // fixed-point passes run separably through LDS (horizontal pass once per staged source row into 16-bit words, vertical pass
 // per output row) and every thread stores 4 pixels as one aligned u32 (two such groups per thread). v2 evaluated the horizontal
@@ -14,9 +14,11 @@
 
 namespace ovs {
 
-constexpr int kTileW = 128, kTileH = 16;
+constexpr int kTileW = 128, kTileH = 32;
+constexpr int kGroups = kTileW * kTileH / 4 / 256;   // 4-pixel groups per thread
+constexpr int kSlots = 8;                            // staging loads per thread in flight
 constexpr int kSrcWords = 44;    // 176-byte LDS pitch: source span of 128 output px is <= 128*src/dst + 2 <= 160 at scale >= 1.0x..1.25
-constexpr int kSrcRows = 24;
+constexpr int kSrcRows = 44;    // 32 output rows span <= 32 * 1.25 + 2 source rows (16-row tiles: 0.167 ms, 32: 0.142, 64: 0.165)
 
 __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restrict__ src, size_t src_frame_stride, int src_pitch,
                                                          int srows, int scols, uint8_t* __restrict__ dst, size_t dst_frame_stride,
@@ -43,18 +45,20 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restr
     const int sx_lo = xt[x0].o0 & ~3, sx_hi = xt[x1].o1;
     const int sy_lo = yt[y0].o0, sy_hi = yt[y1].o1;
     const int nwords = (sx_hi - sx_lo) / 4 + 1, nrows = sy_hi - sy_lo + 1;
-    if (nwords <= kSrcWords && nrows <= kSrcRows && (nrows - 1) * kSrcWords + nwords <= 4 * 256) {   // 4 staging slots per thread
+    if (nwords <= kSrcWords && nrows <= kSrcRows && (nrows - 1) * kSrcWords + nwords <= kSlots * 256) {   // kSlots staging slots per thread
         // taps of this thread's column pair and of its two output rows: issued before the staging loads so their latency overlaps
         const int xp = tid & 63, q = tid >> 6;
         const int xa = min(x0 + 2 * xp, dcols - 1), xb = min(x0 + 2 * xp + 1, dcols - 1);
         const ResizeTap ta = xt[xa], tbp = xt[xb];
-        const ResizeTap ty0 = yt[min(y0 + (tid >> 5), drows - 1)], ty1 = yt[min(y0 + 8 + (tid >> 5), drows - 1)];
+        ResizeTap tys[kGroups];
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) tys[g] = yt[min(y0 + 8 * g + (tid >> 5), drows - 1)];
         // stage the source rectangle: 4 independent aligned u32 loads per thread in flight (fixed 44-word pitch: no runtime division)
         {
-            uint32_t v[4];
-            int slot[4];
+            uint32_t v[kSlots];
+            int slot[kSlots];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < kSlots; ++k) {
                 const int i = tid + 256 * k;
                 const int r = i / kSrcWords, w = i - r * kSrcWords;
                 slot[k] = (r < nrows && w < nwords) ? i : -1;
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restr
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < kSlots; ++k)
                 if (slot[k] >= 0) (&tile[0][0])[slot[k]] = v[k];
         }
         __syncthreads();
@@ -86,13 +90,13 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restr
             }
         }
         __syncthreads();
-        // ---- vertical pass + store: 512 groups of 4 pixels (32 groups per row, 16 rows), one aligned u32 store each
+        // ---- vertical pass + store: 4-pixel groups (32 per row), one aligned u32 store each
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < kGroups; ++g) {
             const int idx = tid + g * 256;
             const int y = y0 + (idx >> 5), xg = (idx & 31) * 4, x4 = x0 + xg;
             if (y >= drows || x4 >= dcols) continue;
-            const ResizeTap ty = g ? ty1 : ty0;
+            const ResizeTap ty = tys[g];
             const uint2 h0 = *reinterpret_cast<const uint2*>(&hrow[ty.o0 - sy_lo][xg >> 1]);
             const uint2 h1 = *reinterpret_cast<const uint2*>(&hrow[ty.o1 - sy_lo][xg >> 1]);
             const int b0 = ty.a0, b1 = ty.a1;
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restr
     } else {
         // generic fallback (scale factors far from 1.2 whose source rectangle does not fit the LDS tile): gather from global
 #pragma unroll 1
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < kGroups; ++g) {
             const int idx = tid + g * 256;
             const int y = y0 + (idx >> 5), x4 = x0 + (idx & 31) * 4;
             if (y >= drows || x4 >= dcols) continue;
