@@ -151,7 +151,10 @@ def main():
     ba_res = None if args.no_ba else bench_local_ba(world, rank, dist, torch)
     side = None
     if rank == 0 and not args.no_ba and not args.no_cpu_baseline:
-        side = bench_other_configs()
+        try:
+            side = bench_other_configs()
+        except Exception as ex:   # a side section must never cost the headline line
+            side = {"error": repr(ex)}
 
     if rank == 0:
         n_cand = 0
