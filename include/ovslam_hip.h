@@ -389,6 +389,27 @@ ovs_status ovs_ba_linearize_stereo_dev(const double* d_poses, const uint8_t* d_p
                                        double focal_x_baseline, double huber_delta, int32_t accumulate, double* d_Hpp, double* d_bp,
                                        double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Pose-only optimisation of one frame.  replaces: unsigned int optimize::pose_optimizer::optimize(data::frame& frm) const
+ * (src/openvslam/optimize/pose_optimizer.{h,cc}; perspective mono / stereo pose_opt edges): 4 rounds x 10 Levenberg-Marquardt
+ * iterations with Huber kernels in the first two rounds and chi2 outlier re-classification (5.991 / 7.815) after every round, in ONE
+ * kernel launch. The shim flattens the frame's landmarks into ovs_pose_obs records, writes pose_cw_out back with
+ * frm.set_cam_pose(...), outlier_flags into frm.outlier_flags_ and returns *num_valid.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ovs_pose_obs {   /* one observed landmark: pose_opt_edge_wrapper */
+    double pos_w[3];
+    double obs_x, obs_y, obs_x_right;   /* undistorted keypoint; obs_x_right is read only when is_stereo != 0 */
+    double inv_sigma_sq;                /* frm.inv_level_sigma_sq_[octave] */
+    int32_t is_stereo, pad;
+} ovs_pose_obs;
+/* pose_cw_*: 12 doubles (rotation row-major, translation), world -> camera. n_obs <= 8192. */
+ovs_status ovs_pose_optimize(int32_t device, const double* pose_cw_in, const ovs_pose_obs* obs, int32_t n_obs, const ovs_ba_cam* cam,
+                             double focal_x_baseline, double* pose_cw_out, uint8_t* outlier_flags, int32_t* num_valid);
+/* Device-resident batch: frame p owns observations [d_obs_offsets[p], d_obs_offsets[p + 1]); one workgroup per frame. */
+ovs_status ovs_pose_optimize_batch_dev(const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
+                                       const ovs_ba_cam* cam, double focal_x_baseline, double* d_poses_out, uint8_t* d_outlier,
+                                       int32_t* d_num_valid, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,27 @@ def linearize_stereo(poses, pose_fixed, points, edges, cam, focal_x_baseline, hu
     return out
 
 
+POSE_OBS_DTYPE = np.dtype([("pos_w", "<f8", (3,)), ("obs_x", "<f8"), ("obs_y", "<f8"), ("obs_x_right", "<f8"), ("inv_sigma_sq", "<f8"),
+                           ("is_stereo", "<i4"), ("pad", "<i4")])
+assert POSE_OBS_DTYPE.itemsize == 64
+
+
+def pose_optimize(pose_cw, obs, cam, focal_x_baseline=0.0, device=0):
+    """optimize::pose_optimizer::optimize(frm) on the device (ovs_pose_optimize). pose_cw: 3x4 [R|t]; obs: POSE_OBS_DTYPE records.
+    Returns (pose_cw 3x4, outlier_flags bool[n], num_valid)."""
+    L = _lib.lib()
+    o = np.ascontiguousarray(obs, POSE_OBS_DTYPE)
+    T = np.asarray(pose_cw, np.float64)
+    pin = np.ascontiguousarray(np.concatenate([T[:3, :3].reshape(-1), T[:3, 3]]))
+    pout = np.zeros(12)
+    out = np.zeros(max(len(o), 1), np.uint8)
+    nv = C.c_int32()
+    c = BaCam(*cam)
+    _lib.check(L.ovs_pose_optimize(device, _p(pin), _p(o), len(o), C.byref(c), float(focal_x_baseline), _p(pout), _p(out), C.byref(nv)),
+               "ovs_pose_optimize")
+    return np.concatenate([pout[:9].reshape(3, 3), pout[9:, None]], 1), out[:len(o)].astype(bool), nv.value
+
+
 def shard_edges_by_keyframe(edges, n_pose, rank, world):
     """Edges of keyframes [rank*ceil(n_pose/world), ...): contiguous keyframe blocks, 2000 edges each in config 5."""
     per = -(-n_pose // world)

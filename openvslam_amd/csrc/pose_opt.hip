@@ -1,0 +1,373 @@
+// pose_opt.hip -- optimize::pose_optimizer::optimize (expected: src/openvslam/optimize/pose_optimizer.{h,cc},
+// optimize/g2o/se3/{perspective_pose_opt_edge.*, shot_vertex.*}; g2o OptimizationAlgorithmLevenberg + RobustKernelHuber): the
+// per-frame, pose-only bundle adjustment of the tracking thread. It runs right after the matchers on every
+// frame, so it belongs on the device with them: ONE launch does all 4 rounds x 10 Levenberg-Marquardt iterations.
+//
+// One 256-thread workgroup per frame. The <= 8192 observations stay in HBM/L2 (64 B each) and are re-read every pass; a thread owns
+// observations tid, tid + 256, ... and keeps their inlier flags in a 32-bit register mask. Per LM iteration: every thread
+// accumulates the 21 + 6 normal-equation terms and the robustified chi2 of its observations, a fixed-order block reduction
+// (wave shuffles, then waves 0..3) produces H, b, chi; thread 0 solves the 6x6 system by Cholesky, applies exp(dx) * T and the
+// workgroup evaluates the trial pose's chi2 -- g2o's accept / reject / lambda schedule as restated in oracle/ovo_pose.cc.
+// fp64 throughout; per-observation quantities follow the oracle's operation order, the SUMS are associated differently (tree vs
+// sequential), so parity with the oracle is to a stated tolerance (tests: pose 1e-9, identical inlier flags away from the chi2 gates).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "ovs_common.h"
+
+namespace ovs {
+
+struct PoseD {
+    double R[9], t[3];
+};
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ void se3_exp_d(const double* u, PoseD& out) {
+    const double wx = u[0], wy = u[1], wz = u[2];
+    const double theta = sqrt((wx * wx + wy * wy) + wz * wz);
+    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double O2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) O2[3 * i + j] = (O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j]) + O[3 * i + 2] * O[6 + j];
+    double V[9];
+    for (int i = 0; i < 9; ++i) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        if (theta < 0.00001) {
+            out.R[i] = (I + O[i]) + O2[i];
+            V[i] = out.R[i];
+        } else {
+            const double s = sin(theta), c = cos(theta);
+            out.R[i] = (I + s / theta * O[i]) + (1 - c) / (theta * theta) * O2[i];
+            V[i] = (I + (1 - c) / (theta * theta) * O[i]) + (theta - s) / (theta * theta * theta) * O2[i];
+        }
+    }
+    for (int i = 0; i < 3; ++i) out.t[i] = (V[3 * i] * u[3] + V[3 * i + 1] * u[4]) + V[3 * i + 2] * u[5];
+}
+
+__device__ void compose_d(const PoseD& a, const PoseD& b, PoseD& out) {
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) out.R[3 * i + j] = (a.R[3 * i] * b.R[j] + a.R[3 * i + 1] * b.R[3 + j]) + a.R[3 * i + 2] * b.R[6 + j];
+        out.t[i] = ((a.R[3 * i] * b.t[0] + a.R[3 * i + 1] * b.t[1]) + a.R[3 * i + 2] * b.t[2]) + a.t[i];
+    }
+}
+
+__device__ bool solve6_d(const double* H, double lambda, const double* b, double* x) {
+    double L[36];
+    for (int i = 0; i < 36; ++i) L[i] = 0;
+    for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j <= i; ++j) {
+            double s = H[6 * i + j] + (i == j ? lambda : 0.0);
+            for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
+            if (i == j) {
+                if (!(s > 0)) return false;
+                L[6 * i + i] = sqrt(s);
+            } else {
+                L[6 * i + j] = s / L[6 * j + j];
+            }
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
+        y[i] = s / L[6 * i + i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+        for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
+        x[i] = s / L[6 * i + i];
+    }
+    return true;
+}
+
+// chi2 of one observation; with acc != nullptr also its 21 (upper triangle, row-major) + 6 + 1 contributions: H, b, robust chi2
+__device__ __forceinline__ double pose_edge(const double* R, const double* t, const ovs_pose_obs& o, const ovs_ba_cam& cam, double bf,
+                                            double delta, double* acc) {
+    const double x = ((R[0] * o.pos_w[0] + R[1] * o.pos_w[1]) + R[2] * o.pos_w[2]) + t[0];
+    const double y = ((R[3] * o.pos_w[0] + R[4] * o.pos_w[1]) + R[5] * o.pos_w[2]) + t[1];
+    const double z = ((R[6] * o.pos_w[0] + R[7] * o.pos_w[1]) + R[8] * o.pos_w[2]) + t[2];
+    const double invz = 1.0 / z, invz2 = invz * invz;
+    const bool st = o.is_stereo != 0;
+    const double u = cam.fx * x * invz + cam.cx;
+    const double e0 = o.obs_x - u;
+    const double e1 = o.obs_y - (cam.fy * y * invz + cam.cy);
+    const double e2 = st ? o.obs_x_right - (u - bf * invz) : 0.0;
+    double ss = e0 * e0 + e1 * e1;
+    if (st) ss = ss + e2 * e2;
+    const double c2 = o.inv_sigma_sq * ss;
+    if (!acc) return c2;
+    double rho0 = c2, rho1 = 1.0;
+    const double dsqr = delta * delta;
+    if (delta > 0 && c2 > dsqr) {
+        const double sq = sqrt(c2);
+        rho0 = 2 * sq * delta - dsqr;
+        rho1 = delta / sq;
+    }
+    double J[3][6];
+    J[0][0] = x * y * invz2 * cam.fx;
+    J[0][1] = -(1 + x * x * invz2) * cam.fx;
+    J[0][2] = y * invz * cam.fx;
+    J[0][3] = -invz * cam.fx;
+    J[0][4] = 0;
+    J[0][5] = x * invz2 * cam.fx;
+    J[1][0] = (1 + y * y * invz2) * cam.fy;
+    J[1][1] = -x * y * invz2 * cam.fy;
+    J[1][2] = -x * invz * cam.fy;
+    J[1][3] = 0;
+    J[1][4] = -invz * cam.fy;
+    J[1][5] = y * invz2 * cam.fy;
+    J[2][0] = J[0][0] - bf * y * invz2;
+    J[2][1] = J[0][1] + bf * x * invz2;
+    J[2][2] = J[0][2];
+    J[2][3] = J[0][3];
+    J[2][4] = 0;
+    J[2][5] = J[0][5] - bf * invz2;
+    const double W = rho1 * o.inv_sigma_sq;
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int b = a; b < 6; ++b) {
+            double s = J[0][a] * J[0][b] + J[1][a] * J[1][b];
+            if (st) s = s + J[2][a] * J[2][b];
+            acc[k++] += W * s;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        double g = J[0][a] * e0 + J[1][a] * e1;
+        if (st) g = g + J[2][a] * e2;
+        acc[21 + a] += -(W * g);
+    }
+    acc[27] += rho0;
+    return c2;
+}
+
+constexpr int kPoseMaxObs = 8192;   // 32 observations per thread: the inlier flags of a thread fit one register
+
+__global__ __launch_bounds__(256) void k_pose_optimize(const double* __restrict__ poses_in, const ovs_pose_obs* __restrict__ obs_all,
+                                                      const int32_t* __restrict__ obs_offsets, ovs_ba_cam cam, double bf,
+                                                      double* __restrict__ poses_out, uint8_t* __restrict__ outlier_all,
+                                                      int32_t* __restrict__ num_valid) {
+    __shared__ double s_part[4][28];
+    __shared__ double s_sum[28];
+    __shared__ PoseD s_T, s_Tn;
+    __shared__ double s_ctl[4];   // [0] = continue trials of this iteration, [1] = continue iterations of this round
+    __shared__ int s_cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int p = blockIdx.x;
+    const int o0 = obs_offsets[p], n = obs_offsets[p + 1] - o0;
+    const ovs_pose_obs* obs = obs_all + o0;
+    uint8_t* outlier = outlier_all + o0;
+    const double d_mono = sqrt(5.991), d_stereo = sqrt(7.815);
+
+    // fixed-order block reduction of NV per-thread values into s_sum
+    auto reduce = [&](const double* v, int nv) {
+        for (int i = 0; i < nv; ++i) {
+            const double s = wave_sum_d(v[i]);
+            if (lane == 0) s_part[wv][i] = s;
+        }
+        __syncthreads();
+        if (tid < nv) s_sum[tid] = ((s_part[0][tid] + s_part[1][tid]) + s_part[2][tid]) + s_part[3][tid];
+        __syncthreads();
+    };
+
+    PoseD T0;
+    for (int i = 0; i < 9; ++i) T0.R[i] = poses_in[12 * (size_t)p + i];
+    for (int i = 0; i < 3; ++i) T0.t[i] = poses_in[12 * (size_t)p + 9 + i];
+    uint32_t active = 0xFFFFFFFFu;   // bit k <-> observation tid + 256 k
+    for (int i = tid; i < n; i += 256) outlier[i] = 0;
+    if (tid == 0) s_T = T0;
+    __syncthreads();
+    int num_bad = 0;
+    if (n >= 5) {
+        for (int trial = 0; trial < 4; ++trial) {
+            const bool robust = trial < 2;
+            if (tid == 0) s_T = T0;
+            __syncthreads();
+            double lambda = 0, ni = 2;   // held identically by every thread (all control flow below is workgroup-uniform)
+            for (int it = 0; it < 10; ++it) {
+                // ---- linearise at s_T
+                double acc[28];
+#pragma unroll
+                for (int i = 0; i < 28; ++i) acc[i] = 0;
+                {
+                    double R[9], t[3];
+                    for (int i = 0; i < 9; ++i) R[i] = s_T.R[i];
+                    for (int i = 0; i < 3; ++i) t[i] = s_T.t[i];
+                    for (int k = 0, i = tid; i < n; i += 256, ++k)
+                        if ((active >> k) & 1u) {
+                            const ovs_pose_obs o = obs[i];
+                            pose_edge(R, t, o, cam, bf, robust ? (o.is_stereo ? d_stereo : d_mono) : 0.0, acc);
+                        }
+                }
+                reduce(acc, 28);
+                double H[36], b[6];
+                {
+                    int k = 0;
+                    for (int a = 0; a < 6; ++a)
+                        for (int c = a; c < 6; ++c) {
+                            H[6 * a + c] = s_sum[k];
+                            H[6 * c + a] = s_sum[k];
+                            ++k;
+                        }
+                    for (int a = 0; a < 6; ++a) b[a] = s_sum[21 + a];
+                }
+                double current_chi = s_sum[27];
+                __syncthreads();   // s_sum is rewritten by the trial reductions below
+                if (it == 0) {
+                    double max_diag = 0;
+                    for (int j = 0; j < 6; ++j) max_diag = fmax(fabs(H[7 * j]), max_diag);
+                    lambda = 1e-5 * max_diag;
+                    ni = 2;
+                }
+                double rho = 0;
+                int qmax = 0;
+                do {
+                    // thread 0: solve, trial pose
+                    double dx[6] = {0, 0, 0, 0, 0, 0};
+                    if (tid == 0) {
+                        const bool ok = solve6_d(H, lambda, b, dx);
+                        if (ok) {
+                            PoseD E;
+                            se3_exp_d(dx, E);
+                            compose_d(E, s_T, s_Tn);
+                        }
+                        s_ctl[0] = ok ? 1.0 : 0.0;
+                        double scale = 0;
+                        if (ok)
+                            for (int j = 0; j < 6; ++j) scale += dx[j] * (lambda * dx[j] + b[j]);
+                        s_ctl[1] = scale + 1e-3;
+                    }
+                    __syncthreads();
+                    const bool ok = s_ctl[0] != 0.0;
+                    const double scale = s_ctl[1];
+                    double temp_chi = 1.7976931348623157e308;
+                    if (ok) {
+                        double R[9], t[3];
+                        for (int i = 0; i < 9; ++i) R[i] = s_Tn.R[i];
+                        for (int i = 0; i < 3; ++i) t[i] = s_Tn.t[i];
+                        double part = 0;
+                        for (int k = 0, i = tid; i < n; i += 256, ++k)
+                            if ((active >> k) & 1u) {
+                                const ovs_pose_obs o = obs[i];
+                                const double c2 = pose_edge(R, t, o, cam, bf, 0.0, nullptr);
+                                const double delta = robust ? (o.is_stereo ? d_stereo : d_mono) : 0.0;
+                                double r = c2;
+                                if (delta > 0 && c2 > delta * delta) r = 2 * sqrt(c2) * delta - delta * delta;
+                                part += r;
+                            }
+                        reduce(&part, 1);
+                        temp_chi = s_sum[0];
+                    }
+                    __syncthreads();
+                    rho = (current_chi - temp_chi) / scale;
+                    if (rho > 0 && isfinite(temp_chi)) {
+                        double alpha = 1. - pow(2 * rho - 1, 3.0);
+                        alpha = fmin(alpha, 2.0 / 3.0);
+                        lambda *= fmax(1.0 / 3.0, alpha);
+                        ni = 2;
+                        current_chi = temp_chi;
+                        if (tid == 0) s_T = s_Tn;
+                    } else {
+                        lambda *= ni;
+                        ni *= 2;
+                    }
+                    ++qmax;
+                    __syncthreads();
+                } while (rho < 0 && qmax < 10);
+                if (qmax == 10 || rho == 0) break;
+            }
+            // ---- re-classify every observation with the optimised pose
+            {
+                double R[9], t[3];
+                for (int i = 0; i < 9; ++i) R[i] = s_T.R[i];
+                for (int i = 0; i < 3; ++i) t[i] = s_T.t[i];
+                int bad = 0;
+                active = 0;
+                for (int k = 0, i = tid; i < n; i += 256, ++k) {
+                    const ovs_pose_obs o = obs[i];
+                    const double c2 = pose_edge(R, t, o, cam, bf, 0.0, nullptr);
+                    const bool out = (o.is_stereo ? 7.815 : 5.991) < c2;
+                    outlier[i] = out ? 1 : 0;
+                    if (out) ++bad;
+                    else active |= 1u << k;
+                }
+                // block sum of bad (integers: exact)
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
+                if (lane == 0) s_cnt[wv] = bad;
+                __syncthreads();
+                num_bad = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+                __syncthreads();
+            }
+            if (n < 10) break;
+        }
+    }
+    if (tid < 9) poses_out[12 * (size_t)p + tid] = s_T.R[tid];
+    if (tid < 3) poses_out[12 * (size_t)p + 9 + tid] = s_T.t[tid];
+    if (tid == 0) num_valid[p] = n >= 5 ? n - num_bad : 0;
+}
+
+}   // namespace ovs
+
+using namespace ovs;
+
+extern "C" {
+
+ovs_status ovs_pose_optimize_batch_dev(const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
+                                       const ovs_ba_cam* cam, double focal_x_baseline, double* d_poses_out, uint8_t* d_outlier,
+                                       int32_t* d_num_valid, void* stream) {
+    if (!d_poses_in || !d_obs || !d_obs_offsets || !cam || !d_poses_out || !d_outlier || !d_num_valid || batch < 1) return OVS_ERR_INVALID;
+    hipLaunchKernelGGL(k_pose_optimize, dim3(batch), dim3(256), 0, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, *cam,
+                       focal_x_baseline, d_poses_out, d_outlier, d_num_valid);
+    OVS_HIP_TRY(hipGetLastError());
+    return OVS_OK;
+}
+
+ovs_status ovs_pose_optimize(int32_t device, const double* pose_cw_in, const ovs_pose_obs* obs, int32_t n_obs, const ovs_ba_cam* cam,
+                             double focal_x_baseline, double* pose_cw_out, uint8_t* outlier_flags, int32_t* num_valid) {
+    if (!pose_cw_in || !cam || !pose_cw_out || !num_valid || n_obs < 0 || (n_obs > 0 && (!obs || !outlier_flags))) return OVS_ERR_INVALID;
+    if (n_obs > kPoseMaxObs) return OVS_ERR_CAPACITY;
+    if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
+    OVS_HIP_TRY(hipSetDevice(device));
+    const size_t no = (size_t)std::max(n_obs, 1);
+    unsigned char* d = nullptr;
+    const size_t off_obs = 256, off_off = off_obs + sizeof(ovs_pose_obs) * no, off_out = (off_off + 8 + 255) & ~(size_t)255, off_fl = off_out + 128,
+                 off_nv = (off_fl + no + 7) & ~(size_t)7;
+    OVS_HIP_TRY(hipMalloc(&d, off_nv + 16));
+    ovs_status st = OVS_ERR_HIP;
+    hipError_t er = hipSuccess;
+    do {
+#define P_TRY(expr)                               \
+    if ((er = (expr)) != hipSuccess) {            \
+        ovs::set_last_error(#expr, er);           \
+        break;                                    \
+    }
+        const int32_t offs[2] = {0, n_obs};
+        P_TRY(hipMemcpy(d, pose_cw_in, sizeof(double) * 12, hipMemcpyHostToDevice));
+        if (n_obs) P_TRY(hipMemcpy(d + off_obs, obs, sizeof(ovs_pose_obs) * (size_t)n_obs, hipMemcpyHostToDevice));
+        P_TRY(hipMemcpy(d + off_off, offs, sizeof(offs), hipMemcpyHostToDevice));
+        st = ovs_pose_optimize_batch_dev(reinterpret_cast<double*>(d), reinterpret_cast<ovs_pose_obs*>(d + off_obs),
+                                         reinterpret_cast<int32_t*>(d + off_off), 1, cam, focal_x_baseline,
+                                         reinterpret_cast<double*>(d + off_out), d + off_fl, reinterpret_cast<int32_t*>(d + off_nv), nullptr);
+        if (st != OVS_OK) break;
+        st = OVS_ERR_HIP;
+        P_TRY(hipDeviceSynchronize());
+        P_TRY(hipMemcpy(pose_cw_out, d + off_out, sizeof(double) * 12, hipMemcpyDeviceToHost));
+        if (n_obs) P_TRY(hipMemcpy(outlier_flags, d + off_fl, (size_t)n_obs, hipMemcpyDeviceToHost));
+        P_TRY(hipMemcpy(num_valid, d + off_nv, sizeof(int32_t), hipMemcpyDeviceToHost));
+        st = OVS_OK;
+#undef P_TRY
+    } while (0);
+    hipFree(d);
+    return st;
+}
+
+}   // extern "C"

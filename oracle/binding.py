@@ -520,3 +520,21 @@ def ba_linearize_stereo(poses, pose_fixed, points, edges, cam, focal_x_baseline,
     assert rc == 0, rc
     out["Hpl"] = out["Hpl"][:n_edge]
     return out
+
+
+POSE_OBS_DTYPE = np.dtype([("pos_w", "<f8", (3,)), ("obs_x", "<f8"), ("obs_y", "<f8"), ("obs_x_right", "<f8"), ("inv_sigma_sq", "<f8"),
+                           ("is_stereo", "<i4"), ("pad", "<i4")])
+assert POSE_OBS_DTYPE.itemsize == 64
+
+
+def pose_optimize(pose_cw, obs, cam, focal_x_baseline=0.0):
+    """optimize::pose_optimizer::optimize (ovo_pose.cc). Returns (pose_cw 3x4, outlier flags, num_valid)."""
+    o = np.ascontiguousarray(obs, POSE_OBS_DTYPE)
+    pin = _pose12(pose_cw)
+    pout = np.zeros(12)
+    out = np.zeros(max(len(o), 1), np.uint8)
+    nv = C.c_int()
+    c = np.array(cam, np.float64)
+    rc = lib().ovo_pose_optimize(_p(pin), _p(o), len(o), _p(c), C.c_double(focal_x_baseline), _p(pout), _p(out), C.byref(nv))
+    assert rc == 0
+    return np.concatenate([pout[:9].reshape(3, 3), pout[9:, None]], 1), out[:len(o)].astype(bool), nv.value

@@ -193,6 +193,17 @@ int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr
                        const uint8_t* desc_right, int n_right, const float* scale_factors, const float* inv_scale_factors,
                        float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths);
 
+/* ---- optimize::pose_optimizer (ovo_pose.cc) ---- */
+typedef struct ovo_pose_obs {   /* one observed landmark of the frame: pose_opt_edge_wrapper */
+    double pos_w[3];
+    double obs_x, obs_y, obs_x_right;   /* undistorted keypoint; obs_x_right only for stereo keypoints */
+    double inv_sigma_sq;                /* inv_level_sigma_sq[octave] */
+    int32_t is_stereo, pad;
+} ovo_pose_obs;
+/* pose_cw: 12 doubles (rotation row-major, translation). cam4 = fx, fy, cx, cy. outlier[n] = frm.outlier_flags_. */
+int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* obs, int n, const double* cam4, double focal_x_baseline,
+                      double* pose_cw_out, uint8_t* outlier, int* num_valid);
+
 #ifdef __cplusplus
 }
 #endif
