@@ -7,7 +7,7 @@
 // observations tid, tid + 256, ... and keeps their inlier flags in a 32-bit register mask. Per LM iteration: every thread
 // accumulates the 21 + 6 normal-equation terms and the robustified chi2 of its observations, a fixed-order block reduction
 // (wave shuffles, then waves 0..3) produces H, b, chi; thread 0 solves the 6x6 system by Cholesky, applies exp(dx) * T and the
-// workgroup evaluates the trial pose's chi2 -- g2o's accept / reject / lambda schedule as restated in oracle/ovo_pose.cc.
+// workgroup evaluates the trial pose's chi2 -- g2o's accept / reject / lambda schedule as restated by the CPU checker under oracle/.
 // fp64 throughout; per-observation quantities follow the oracle's operation order, the SUMS are associated differently (tree vs
 // sequential), so parity with the oracle is to a stated tolerance (tests: pose 1e-9, identical inlier flags away from the chi2 gates).
 #include <algorithm>
