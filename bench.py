@@ -319,9 +319,7 @@ def bench_other_configs(iters=10):
                                           "parity": bool(np.array_equal(ga, ca))}
     # per-frame pose-only optimisation (tracking thread): 2000 observations, 40 % stereo, 10 % outliers
     from openvslam_amd import ba
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from test_gpu_pose import make_frame
-    T0, pobs, pcam, pbf, _ = make_frame(ob.POSE_OBS_DTYPE, 2000, 7)
+    T0, pobs, pcam, pbf, _ = synth.synth_pose_frame(ob.POSE_OBS_DTYPE, 2000, 7)
     g_ms, (gT, gout, gnv) = timeit(lambda: ba.pose_optimize(T0, pobs, pcam, pbf), iters)
     c_ms, (cT, cout, cnv) = timeit(lambda: ob.pose_optimize(T0, pobs, pcam, pbf), 3)
     out["pose_optimizer_2000_obs"] = {"pose_optimize_ms": round(g_ms, 3), "cpu_oracle_ms": round(c_ms, 3), "num_valid": int(gnv),

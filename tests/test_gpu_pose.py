@@ -7,38 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _rot(axis, deg):
-    a = np.radians(deg)
-    c, s = np.cos(a), np.sin(a)
-    x, y, z = axis
-    return np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s, x * z * (1 - c) + y * s],
-                     [y * x * (1 - c) + z * s, c + y * y * (1 - c), y * z * (1 - c) - x * s],
-                     [z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c)]])
-
-
-def make_frame(dtype, n, seed, stereo_frac=0.4, outlier_frac=0.1, pose_err=1.0):
-    rng = np.random.default_rng(seed)
-    Rt = _rot((0, 1, 0), 5) @ _rot((1, 0, 0), -3)
-    tt = np.array([0.3, -0.1, 0.2])
-    X = np.stack([rng.uniform(-5, 5, n), rng.uniform(-3, 3, n), rng.uniform(4, 20, n)], 1)
-    cam, bf = (700.0, 700.0, 960.0, 540.0), 70.0
-    pc = X @ Rt.T + tt
-    u = cam[0] * pc[:, 0] / pc[:, 2] + cam[2]
-    v = cam[1] * pc[:, 1] / pc[:, 2] + cam[3]
-    obs = np.zeros(n, dtype)
-    obs["pos_w"] = X
-    sig = 1.2 ** rng.integers(0, 8, n)
-    obs["obs_x"] = u + rng.normal(0, 1, n) * sig
-    obs["obs_y"] = v + rng.normal(0, 1, n) * sig
-    obs["inv_sigma_sq"] = 1 / sig ** 2
-    st = rng.random(n) < stereo_frac
-    obs["is_stereo"] = st
-    obs["obs_x_right"] = np.where(st, u - bf / pc[:, 2] + rng.normal(0, 1, n) * sig, 0)
-    bad = rng.random(n) < outlier_frac
-    obs["obs_x"][bad] += rng.uniform(20, 100, int(bad.sum()))
-    T0 = np.concatenate([_rot((0, 1, 0), 5 + 0.8 * pose_err) @ _rot((1, 0, 0), -3 + 0.4 * pose_err),
-                         (tt + pose_err * np.array([0.05, 0.03, -0.04]))[:, None]], 1)
-    return T0, obs, cam, bf, (Rt, tt, bad)
+from openvslam_amd.synth import synth_pose_frame as make_frame
 
 
 @pytest.mark.parametrize("n,stereo_frac,outlier_frac,pose_err", [(1500, 0.4, 0.1, 1.0), (2000, 0.0, 0.2, 2.0), (300, 1.0, 0.05, 0.5), (7, 0.5, 0.0, 1.0),
