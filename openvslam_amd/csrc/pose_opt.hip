@@ -338,10 +338,29 @@ ovs_status ovs_pose_optimize(int32_t device, const double* pose_cw_in, const ovs
     if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
     OVS_HIP_TRY(hipSetDevice(device));
     const size_t no = (size_t)std::max(n_obs, 1);
-    unsigned char* d = nullptr;
     const size_t off_obs = 256, off_off = off_obs + sizeof(ovs_pose_obs) * no, off_out = (off_off + 8 + 255) & ~(size_t)255, off_fl = off_out + 128,
                  off_nv = (off_fl + no + 7) & ~(size_t)7;
-    OVS_HIP_TRY(hipMalloc(&d, off_nv + 16));
+    // per-thread, per-device staging buffer that only grows: this runs once per tracked frame, a hipMalloc / hipFree pair per call
+    // would cost more than the optimisation itself
+    struct Scratch {
+        unsigned char* p = nullptr;
+        size_t cap = 0;
+        int device = -1;
+        ~Scratch() {
+            if (p) (void)hipFree(p);
+        }
+    };
+    static thread_local Scratch scratch;
+    if (scratch.device != device || scratch.cap < off_nv + 16) {
+        if (scratch.p) (void)hipFree(scratch.p);
+        scratch.p = nullptr;
+        scratch.cap = 0;
+        const size_t want = std::max<size_t>(off_nv + 16, (size_t)1 << 20);
+        OVS_HIP_TRY(hipMalloc(&scratch.p, want));
+        scratch.cap = want;
+        scratch.device = device;
+    }
+    unsigned char* d = scratch.p;
     ovs_status st = OVS_ERR_HIP;
     hipError_t er = hipSuccess;
     do {
@@ -359,14 +378,13 @@ ovs_status ovs_pose_optimize(int32_t device, const double* pose_cw_in, const ovs
                                          reinterpret_cast<double*>(d + off_out), d + off_fl, reinterpret_cast<int32_t*>(d + off_nv), nullptr);
         if (st != OVS_OK) break;
         st = OVS_ERR_HIP;
-        P_TRY(hipDeviceSynchronize());
+        P_TRY(hipStreamSynchronize(nullptr));
         P_TRY(hipMemcpy(pose_cw_out, d + off_out, sizeof(double) * 12, hipMemcpyDeviceToHost));
         if (n_obs) P_TRY(hipMemcpy(outlier_flags, d + off_fl, (size_t)n_obs, hipMemcpyDeviceToHost));
         P_TRY(hipMemcpy(num_valid, d + off_nv, sizeof(int32_t), hipMemcpyDeviceToHost));
         st = OVS_OK;
 #undef P_TRY
     } while (0);
-    hipFree(d);
     return st;
 }
 
