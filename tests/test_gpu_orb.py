@@ -132,3 +132,56 @@ def test_batch_dev_matches_host_api(hip, oracle, pipeline):
         assert cnt[b] == len(wk)
         assert np.array_equal(kps[b, :cnt[b]].reshape(-1), wk.view(np.uint8).reshape(-1))
         assert np.array_equal(desc[b, :cnt[b]], wd)
+
+
+def test_two_extractors_run_concurrently_from_two_threads(hip, oracle):
+    """Upstream extracts the left and right image of a stereo frame on two std::threads with two extractor instances: handles are
+    independent (own stream, own buffers), so two host threads may call extract() on two handles at the same time."""
+    import threading
+    rows, cols = 376, 1241
+    imgs = [synth_frame(rows, cols, seed=40 + i) for i in range(2)]
+    exs = [hip.orb_extractor(hip.orb_params(max_num_keypts=2000), max_rows=rows, max_cols=cols) for _ in range(2)]
+    results = [[None] * 6, [None] * 6]
+
+    def work(k):
+        for rep in range(6):
+            results[k][rep] = exs[k].extract(imgs[k])
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    ox = oracle.OrbExtractor(oracle.make_params(2000))
+    for k in range(2):
+        wk, wd = ox.extract(imgs[k])
+        for rep in range(6):
+            gk, gd = results[k][rep]
+            assert np.array_equal(gk.view(np.uint8), wk.view(np.uint8)) and np.array_equal(gd, wd)
+
+
+def test_error_statuses(hip):
+    """The ABI never throws and never falls back: bad arguments and exceeded capacities come back as status codes."""
+    import ctypes as C
+    from openvslam_amd import _lib
+    L = _lib.lib()
+    h = C.c_void_p()
+    p = _lib.OrbParams(2000, 1.2, 8, 20, 7)
+    assert L.ovs_orb_create(C.byref(p), 0, 640, 1, 0, C.byref(h)) == -1                      # OVS_ERR_INVALID
+    assert L.ovs_orb_create(C.byref(p), 480, 640, 1, 99, C.byref(h)) == -2                   # OVS_ERR_NO_DEVICE
+    bad = _lib.OrbParams(2000, 1.0, 8, 20, 7)
+    assert L.ovs_orb_create(C.byref(bad), 480, 640, 1, 0, C.byref(h)) == -1                  # scale factor must exceed 1
+    assert L.ovs_orb_create(C.byref(p), 480, 640, 1, 0, C.byref(h)) == 0
+    img = np.zeros((600, 640), np.uint8)
+    kps = np.zeros(4096 * 7, np.float32)
+    desc = np.zeros((4096, 32), np.uint8)
+    n = C.c_int32(-5)
+    st = L.ovs_orb_extract(h, img.ctypes.data_as(C.c_void_p), 600, 640, 640, None, 0, kps.ctypes.data_as(C.c_void_p),
+                           desc.ctypes.data_as(C.c_void_p), 4096, C.byref(n))
+    assert st == -4 and n.value == 0                                                         # OVS_ERR_CAPACITY: taller than max_rows
+    st = L.ovs_orb_extract(h, None, 0, 0, 0, None, 0, None, None, 0, C.byref(n))
+    assert st == 0 and n.value == 0                                                          # empty image: upstream's early return
+    assert L.ovs_orb_destroy(h) == 0
+    m = C.c_void_p()
+    assert L.ovs_matcher_create(70000, 100, 1, 0, C.byref(m)) == -1                          # indices are 16 bit
+    assert L.ovs_wmatcher_create(60000, 60000, 1 << 20, 0, C.byref(m)) == -4                 # resolver state would not fit LDS
