@@ -376,6 +376,16 @@ ovs_status ovs_ba_linearize_dev(const double* d_poses, const uint8_t* d_pose_fix
                                 int32_t n_pt, const ovs_ba_edge* d_edges, int32_t n_edge, const ovs_ba_cam* cam, double huber_delta,
                                 double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream);
 
+/* Equirectangular edges (replaces: optimize::g2o::se3::equirectangular_reproj_edge::computeError / linearizeOplus,
+ * src/openvslam/optimize/g2o/se3/equirectangular_reproj_edge.{h,cc}): e = z - (cols (1/2 + atan2(x, z) / 2 pi), rows (1/2 + asin(y / |p|) / pi)),
+ * no wrap-around correction at the +-180 degree seam (oracle/ORACLE_SPEC.md rule 26). Same edge records and outputs as ovs_ba_linearize. */
+ovs_status ovs_ba_linearize_equirect(int32_t device, const double* poses, const uint8_t* pose_fixed, int32_t n_pose, const double* points,
+                                     int32_t n_pt, const ovs_ba_edge* edges, int32_t n_edge, int32_t cols, int32_t rows, double huber_delta,
+                                     double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* chi2);
+ovs_status ovs_ba_linearize_equirect_dev(const double* d_poses, const uint8_t* d_pose_fixed, int32_t n_pose, const double* d_points,
+                                         int32_t n_pt, const ovs_ba_edge* d_edges, int32_t n_edge, int32_t cols, int32_t rows,
+                                         double huber_delta, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl,
+                                         double* d_chi2, void* stream);
 /* Stereo edges (replaces: optimize::g2o::se3::stereo_perspective_reproj_edge::computeError / linearizeOplus,
  * src/openvslam/optimize/g2o/se3/perspective_reproj_edge.{h,cc}): e = (u, v, u_r) - pi(RX + t), u_r = u - focal_x_baseline / z;
  * Huber delta sqrt(7.815) in local BA. Same outputs as ovs_ba_linearize (Hpl: n_edge x 18 for THESE edges). The device form can

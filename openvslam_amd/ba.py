@@ -43,6 +43,23 @@ def linearize(poses, pose_fixed, points, edges, cam, huber_delta, device=0):
     return out
 
 
+def linearize_equirect(poses, pose_fixed, points, edges, cols, rows, huber_delta, device=0):
+    """Equirectangular reprojection edges, host buffers in / out (ovs_ba_linearize_equirect)."""
+    L = _lib.lib()
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    edges = np.ascontiguousarray(edges, EDGE_DTYPE)
+    fixed = None if pose_fixed is None else np.ascontiguousarray(pose_fixed, np.uint8)
+    n_pose, n_pt, n_edge = len(poses), len(points), len(edges)
+    out = dict(Hpp=np.zeros((n_pose, 6, 6)), bp=np.zeros((n_pose, 6)), Hll=np.zeros((n_pt, 3, 3)), bl=np.zeros((n_pt, 3)),
+               Hpl=np.zeros((max(n_edge, 1), 6, 3)), chi2=np.zeros(2))
+    _lib.check(L.ovs_ba_linearize_equirect(device, _p(poses), _p(fixed), n_pose, _p(points), n_pt, _p(edges), n_edge, int(cols), int(rows),
+                                           float(huber_delta), _p(out["Hpp"]), _p(out["bp"]), _p(out["Hll"]), _p(out["bl"]), _p(out["Hpl"]),
+                                           _p(out["chi2"])), "ovs_ba_linearize_equirect")
+    out["Hpl"] = out["Hpl"][:n_edge]
+    return out
+
+
 EDGE_STEREO_DTYPE = np.dtype([("pose_idx", "<i4"), ("point_idx", "<i4"), ("obs_x", "<f8"), ("obs_y", "<f8"), ("obs_x_right", "<f8"),
                               ("inv_sigma_sq", "<f8")])
 assert EDGE_STEREO_DTYPE.itemsize == 40

@@ -50,7 +50,7 @@ template <int D>
 __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__ poses, const uint8_t* __restrict__ pose_fixed,
                                                      int n_pose, const double* __restrict__ points, int n_pt,
                                                      const typename EdgeOf<D>::type* __restrict__ edges, int n_edge, ovs_ba_cam cam,
-                                                     double bf, double huber_delta, double* __restrict__ Hpp, double* __restrict__ bp,
+                                                     int model, double bf, double huber_delta, double* __restrict__ Hpp, double* __restrict__ bp,
                                                      double* __restrict__ Hll, double* __restrict__ bl, double* __restrict__ Hpl,
                                                      double* __restrict__ chi2) {
     // A workgroup takes kEdgesPerThread * 256 consecutive edges; lane l of wave w handles edges base + 64 (4 k + w) + l. Edges arrive
@@ -106,15 +106,28 @@ __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__
         const double x = R[0][0] * X0 + R[0][1] * X1 + R[0][2] * X2 + P[0];
         const double y = R[1][0] * X0 + R[1][1] * X1 + R[1][2] * X2 + P[1];
         const double z = R[2][0] * X0 + R[2][1] * X1 + R[2][2] * X2 + P[2];
-        const double invz = 1.0 / z, invz2 = invz * invz;
         double er[D];
+        double ss;
+        // equirectangular (model 1, mono only; cam.fx / cam.fy carry cols / rows): quantities shared by the residual and the Jacobians
+        double eq_L = 0, eq_rxz = 0;
+        const double invz = 1.0 / z, invz2 = invz * invz;
+        if (D == 2 && model == 1) {
+            eq_L = sqrt((x * x + y * y) + z * z);
+            eq_rxz = x * x + z * z;
+            const double theta = atan2(x, z);
+            const double phi = -asin(y / eq_L);
+            er[0] = ed.obs_x - cam.fx * (0.5 + theta / (2.0 * 3.14159265358979323846));
+            er[1] = ed.obs_y - cam.fy * (0.5 - phi / 3.14159265358979323846);
+            ss = er[0] * er[0] + er[1] * er[1];
+        } else {
         const double u = cam.fx * x * invz + cam.cx;
         er[0] = ed.obs_x - u;
         er[1] = ed.obs_y - (cam.fy * y * invz + cam.cy);
-        double ss = er[0] * er[0] + er[1] * er[1];
+        ss = er[0] * er[0] + er[1] * er[1];
         if constexpr (D == 3) {
             er[2] = ed.obs_x_right - (u - bf * invz);
             ss = ss + er[2] * er[2];
+        }
         }
         const double w = ed.inv_sigma_sq;
         c2 = w * ss;
@@ -126,6 +139,26 @@ __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__
             rho0 = 2 * sq * huber_delta - dsqr;
             rho1 = huber_delta / sq;
         }
+        if (D == 2 && model == 1) {
+            // equirectangular_reproj_edge::linearizeOplus: with dp the derivative of pos_c w.r.t. one state component,
+            //   d u = (cols / 2 pi) (z dp_x - x dp_z) / (x^2 + z^2),  d v = (rows / pi) (L dp_y - y dL) / (L sqrt(x^2 + z^2)),  dL = pos_c . dp / L,
+            // and J = -d(u, v). Columns: rotation (e_k x pos_c), translation (e_k), landmark (R's columns).
+            const double a0 = -(cam.fx / (2.0 * 3.14159265358979323846)) * (1.0 / eq_rxz);
+            const double a1 = -(cam.fy / 3.14159265358979323846) * (1.0 / (eq_L * sqrt(eq_rxz)));
+            auto col = [&](double dx, double dy, double dz, double& j0, double& j1) {
+                const double dL = (1.0 / eq_L) * ((x * dx + y * dy) + z * dz);
+                j0 = a0 * (z * dx - x * dz);
+                j1 = a1 * (eq_L * dy - y * dL);
+            };
+            col(0.0, -z, y, Jp[0][0], Jp[1][0]);
+            col(z, 0.0, -x, Jp[0][1], Jp[1][1]);
+            col(-y, x, 0.0, Jp[0][2], Jp[1][2]);
+            col(1.0, 0.0, 0.0, Jp[0][3], Jp[1][3]);
+            col(0.0, 1.0, 0.0, Jp[0][4], Jp[1][4]);
+            col(0.0, 0.0, 1.0, Jp[0][5], Jp[1][5]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) col(R[0][c], R[1][c], R[2][c], Jl[0][c], Jl[1][c]);
+        } else {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             Jl[0][c] = -invz * (cam.fx * R[0][c] - cam.fx * x * invz * R[2][c]);
@@ -151,6 +184,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__
             Jp[2][3] = Jp[0][3];
             Jp[2][4] = 0;
             Jp[2][5] = Jp[0][5] - bf * invz2;
+        }
         }
         W = rho1 * w;
 #pragma unroll
@@ -241,9 +275,9 @@ using namespace ovs;
 
 extern "C" {
 
-ovs_status ovs_ba_linearize_dev(const double* d_poses, const uint8_t* d_pose_fixed, int32_t n_pose, const double* d_points,
-                                int32_t n_pt, const ovs_ba_edge* d_edges, int32_t n_edge, const ovs_ba_cam* cam, double huber_delta,
-                                double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream) {
+static ovs_status ba_linearize_dev_impl(int model, const double* d_poses, const uint8_t* d_pose_fixed, int32_t n_pose, const double* d_points,
+                                        int32_t n_pt, const ovs_ba_edge* d_edges, int32_t n_edge, const ovs_ba_cam* cam, double huber_delta,
+                                        double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream) {
     if (!d_poses || !d_points || !cam || !d_Hpp || !d_bp || !d_Hll || !d_bl || !d_Hpl || !d_chi2 || n_pose < 1 || n_pt < 1 || n_edge < 0 ||
         (n_edge > 0 && !d_edges))
         return OVS_ERR_INVALID;
@@ -253,9 +287,26 @@ ovs_status ovs_ba_linearize_dev(const double* d_poses, const uint8_t* d_pose_fix
     OVS_HIP_TRY(hipGetLastError());
     if (n_edge == 0) return OVS_OK;
     hipLaunchKernelGGL(k_ba_linearize<2>, dim3((n_edge + 256 * kEdgesPerThread - 1) / (256 * kEdgesPerThread)), dim3(256), 0, s, d_poses, d_pose_fixed, n_pose, d_points, n_pt, d_edges,
-                       n_edge, *cam, 0.0, huber_delta, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi2);
+                       n_edge, *cam, model, 0.0, huber_delta, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi2);
     OVS_HIP_TRY(hipGetLastError());
     return OVS_OK;
+}
+
+ovs_status ovs_ba_linearize_dev(const double* d_poses, const uint8_t* d_pose_fixed, int32_t n_pose, const double* d_points,
+                                int32_t n_pt, const ovs_ba_edge* d_edges, int32_t n_edge, const ovs_ba_cam* cam, double huber_delta,
+                                double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream) {
+    return ba_linearize_dev_impl(0, d_poses, d_pose_fixed, n_pose, d_points, n_pt, d_edges, n_edge, cam, huber_delta, d_Hpp, d_bp, d_Hll, d_bl,
+                                 d_Hpl, d_chi2, stream);
+}
+
+ovs_status ovs_ba_linearize_equirect_dev(const double* d_poses, const uint8_t* d_pose_fixed, int32_t n_pose, const double* d_points,
+                                         int32_t n_pt, const ovs_ba_edge* d_edges, int32_t n_edge, int32_t cols, int32_t rows,
+                                         double huber_delta, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl,
+                                         double* d_chi2, void* stream) {
+    if (cols < 1 || rows < 1) return OVS_ERR_INVALID;
+    const ovs_ba_cam c = {(double)cols, (double)rows, 0.0, 0.0};   // the kernel reads cols / rows from fx / fy for model 1
+    return ba_linearize_dev_impl(1, d_poses, d_pose_fixed, n_pose, d_points, n_pt, d_edges, n_edge, &c, huber_delta, d_Hpp, d_bp, d_Hll, d_bl,
+                                 d_Hpl, d_chi2, stream);
 }
 
 ovs_status ovs_ba_linearize_stereo_dev(const double* d_poses, const uint8_t* d_pose_fixed, int32_t n_pose, const double* d_points,
@@ -273,9 +324,27 @@ ovs_status ovs_ba_linearize_stereo_dev(const double* d_poses, const uint8_t* d_p
     }
     if (n_edge == 0) return OVS_OK;
     hipLaunchKernelGGL(k_ba_linearize<3>, dim3((n_edge + 256 * kEdgesPerThread - 1) / (256 * kEdgesPerThread)), dim3(256), 0, s, d_poses, d_pose_fixed, n_pose, d_points, n_pt, d_edges,
-                       n_edge, *cam, focal_x_baseline, huber_delta, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi2);
+                       n_edge, *cam, 0, focal_x_baseline, huber_delta, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi2);
     OVS_HIP_TRY(hipGetLastError());
     return OVS_OK;
+}
+
+static ovs_status ba_linearize_host_impl(int model, int32_t device, const double* poses, const uint8_t* pose_fixed, int32_t n_pose,
+                                         const double* points, int32_t n_pt, const ovs_ba_edge* edges, int32_t n_edge, const ovs_ba_cam* cam,
+                                         double huber_delta, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* chi2);
+
+ovs_status ovs_ba_linearize(int32_t device, const double* poses, const uint8_t* pose_fixed, int32_t n_pose, const double* points,
+                            int32_t n_pt, const ovs_ba_edge* edges, int32_t n_edge, const ovs_ba_cam* cam, double huber_delta,
+                            double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* chi2) {
+    return ba_linearize_host_impl(0, device, poses, pose_fixed, n_pose, points, n_pt, edges, n_edge, cam, huber_delta, Hpp, bp, Hll, bl, Hpl, chi2);
+}
+
+ovs_status ovs_ba_linearize_equirect(int32_t device, const double* poses, const uint8_t* pose_fixed, int32_t n_pose, const double* points,
+                                     int32_t n_pt, const ovs_ba_edge* edges, int32_t n_edge, int32_t cols, int32_t rows, double huber_delta,
+                                     double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* chi2) {
+    if (cols < 1 || rows < 1) return OVS_ERR_INVALID;
+    const ovs_ba_cam c = {(double)cols, (double)rows, 0.0, 0.0};
+    return ba_linearize_host_impl(1, device, poses, pose_fixed, n_pose, points, n_pt, edges, n_edge, &c, huber_delta, Hpp, bp, Hll, bl, Hpl, chi2);
 }
 
 ovs_status ovs_ba_linearize_stereo(int32_t device, const double* poses, const uint8_t* pose_fixed, int32_t n_pose, const double* points,
@@ -336,9 +405,9 @@ ovs_status ovs_ba_linearize_stereo(int32_t device, const double* poses, const ui
     return st;
 }
 
-ovs_status ovs_ba_linearize(int32_t device, const double* poses, const uint8_t* pose_fixed, int32_t n_pose, const double* points,
-                            int32_t n_pt, const ovs_ba_edge* edges, int32_t n_edge, const ovs_ba_cam* cam, double huber_delta,
-                            double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* chi2) {
+static ovs_status ba_linearize_host_impl(int model, int32_t device, const double* poses, const uint8_t* pose_fixed, int32_t n_pose,
+                                         const double* points, int32_t n_pt, const ovs_ba_edge* edges, int32_t n_edge, const ovs_ba_cam* cam,
+                                         double huber_delta, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* chi2) {
     if (!poses || !points || !cam || !Hpp || !bp || !Hll || !bl || !Hpl || !chi2 || n_pose < 1 || n_pt < 1 || n_edge < 0 || (n_edge > 0 && !edges))
         return OVS_ERR_INVALID;
     if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
@@ -373,7 +442,7 @@ ovs_status ovs_ba_linearize(int32_t device, const double* poses, const uint8_t* 
         double* dbl = dHll + 9 * (size_t)n_pt;
         double* dHpl = dbl + 3 * (size_t)n_pt;
         double* dchi = dHpl + 18 * (size_t)std::max(n_edge, 1);
-        st = ovs_ba_linearize_dev(reinterpret_cast<double*>(d_in), pose_fixed ? d_in + off_f : nullptr, n_pose,
+        st = ba_linearize_dev_impl(model, reinterpret_cast<double*>(d_in), pose_fixed ? d_in + off_f : nullptr, n_pose,
                                   reinterpret_cast<double*>(d_in + off_pt), n_pt, reinterpret_cast<ovs_ba_edge*>(d_in + off_e), n_edge, cam,
                                   huber_delta, dHpp, dbp, dHll, dbl, dHpl, dchi, nullptr);
         if (st != OVS_OK) break;

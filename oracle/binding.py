@@ -538,3 +538,22 @@ def pose_optimize(pose_cw, obs, cam, focal_x_baseline=0.0):
     rc = lib().ovo_pose_optimize(_p(pin), _p(o), len(o), _p(c), C.c_double(focal_x_baseline), _p(pout), _p(out), C.byref(nv))
     assert rc == 0
     return np.concatenate([pout[:9].reshape(3, 3), pout[9:, None]], 1), out[:len(o)].astype(bool), nv.value
+
+
+def ba_linearize_equirect(poses, pose_fixed, points, edges, cols, rows, huber_delta):
+    """Oracle restatement of the equirectangular reprojection edge (ovo_ba.cc). Returns dict(Hpp, bp, Hll, bl, Hpl, chi2)."""
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    fixed = None if pose_fixed is None else np.ascontiguousarray(pose_fixed, np.uint8)
+    n_pose, n_pt, n_edge = len(poses), len(points), len(edges)
+    out = dict(Hpp=np.zeros((n_pose, 6, 6)), bp=np.zeros((n_pose, 6)), Hll=np.zeros((n_pt, 3, 3)), bl=np.zeros((n_pt, 3)),
+               Hpl=np.zeros((max(n_edge, 1), 6, 3)), chi2=np.zeros(2))
+    L = lib()
+    L.ovo_ba_linearize_equirect.restype = C.c_int
+    rc = L.ovo_ba_linearize_equirect(_p(poses), _p(fixed), n_pose, _p(points), n_pt, _p(edges), n_edge, int(cols), int(rows),
+                                     C.c_double(huber_delta), _p(out["Hpp"]), _p(out["bp"]), _p(out["Hll"]), _p(out["bl"]), _p(out["Hpl"]),
+                                     _p(out["chi2"]))
+    assert rc == 0, rc
+    out["Hpl"] = out["Hpl"][:n_edge]
+    return out

@@ -105,6 +105,89 @@ int ovo_ba_linearize(const double* poses, const uint8_t* pose_fixed, int n_pose,
     return 0;
 }
 
+// B1/B2 equirectangular variant: optimize::g2o::se3::equirectangular_reproj_edge (expected: src/openvslam/optimize/g2o/se3/
+// equirectangular_reproj_edge.cc). pi(p) = (cols (1/2 + atan2(x, z) / 2 pi), rows (1/2 + asin(y / |p|) / pi)); e = obs - pi(RX + t), NO
+// wrap-around correction at the seam (ORACLE_SPEC rule 26). With dp the derivative of pos_c w.r.t. one state component:
+//   d u = (cols / 2 pi) (z dp_x - x dp_z) / (x^2 + z^2),  d v = (rows / pi) (L dp_y - y dL) / (L sqrt(x^2 + z^2)),  dL = pos_c . dp / L, J = -d(u, v);
+// columns: rotation e_k x pos_c, translation e_k, landmark R's columns. Same blocks / conventions as ovo_ba_linearize.
+int ovo_ba_linearize_equirect(const double* poses, const uint8_t* pose_fixed, int n_pose, const double* points, int n_pt,
+                              const ovo_ba_edge* edges, int n_edge, int cols, int rows, double huber_delta, double* Hpp, double* bp,
+                              double* Hll, double* bl, double* Hpl, double* chi2) {
+    std::memset(Hpp, 0, sizeof(double) * 36 * n_pose);
+    std::memset(bp, 0, sizeof(double) * 6 * n_pose);
+    std::memset(Hll, 0, sizeof(double) * 9 * n_pt);
+    std::memset(bl, 0, sizeof(double) * 3 * n_pt);
+    std::memset(Hpl, 0, sizeof(double) * 18 * n_edge);
+    chi2[0] = chi2[1] = 0.0;
+    const double kPi = 3.14159265358979323846;
+    const double dsqr = huber_delta * huber_delta;
+    for (int e = 0; e < n_edge; ++e) {
+        const ovo_ba_edge& ed = edges[e];
+        if (ed.pose_idx < 0 || ed.pose_idx >= n_pose || ed.point_idx < 0 || ed.point_idx >= n_pt) return -1;
+        const double* P = poses + 7 * ed.pose_idx;
+        const double* X = points + 3 * ed.point_idx;
+        const double qx = P[3], qy = P[4], qz = P[5], qw = P[6];
+        const double tx2 = 2 * qx, ty2 = 2 * qy, tz2 = 2 * qz;
+        const double twx = tx2 * qw, twy = ty2 * qw, twz = tz2 * qw;
+        const double txx = tx2 * qx, txy = ty2 * qx, txz = tz2 * qx;
+        const double tyy = ty2 * qy, tyz = tz2 * qy, tzz = tz2 * qz;
+        const double R[3][3] = {{1 - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1 - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1 - (txx + tyy)}};
+        const double x = R[0][0] * X[0] + R[0][1] * X[1] + R[0][2] * X[2] + P[0];
+        const double y = R[1][0] * X[0] + R[1][1] * X[1] + R[1][2] * X[2] + P[1];
+        const double z = R[2][0] * X[0] + R[2][1] * X[1] + R[2][2] * X[2] + P[2];
+        const double L = std::sqrt((x * x + y * y) + z * z);
+        const double rxz = x * x + z * z;
+        const double theta = std::atan2(x, z);
+        const double phi = -std::asin(y / L);
+        const double e0 = ed.obs_x - cols * (0.5 + theta / (2.0 * kPi));
+        const double e1 = ed.obs_y - rows * (0.5 - phi / kPi);
+        const double w = ed.inv_sigma_sq;
+        const double c2 = w * (e0 * e0 + e1 * e1);
+        double rho0 = c2, rho1 = 1.0;
+        if (huber_delta > 0 && c2 > dsqr) {
+            const double sq = std::sqrt(c2);
+            rho0 = 2 * sq * huber_delta - dsqr;
+            rho1 = huber_delta / sq;
+        }
+        chi2[0] += c2;
+        chi2[1] += rho0;
+        const double a0 = -((double)cols / (2.0 * kPi)) * (1.0 / rxz);
+        const double a1 = -((double)rows / kPi) * (1.0 / (L * std::sqrt(rxz)));
+        double Jl[2][3], Jp[2][6];
+        auto col = [&](double dx, double dy, double dz, double& j0, double& j1) {
+            const double dL = (1.0 / L) * ((x * dx + y * dy) + z * dz);
+            j0 = a0 * (z * dx - x * dz);
+            j1 = a1 * (L * dy - y * dL);
+        };
+        col(0.0, -z, y, Jp[0][0], Jp[1][0]);
+        col(z, 0.0, -x, Jp[0][1], Jp[1][1]);
+        col(-y, x, 0.0, Jp[0][2], Jp[1][2]);
+        col(1.0, 0.0, 0.0, Jp[0][3], Jp[1][3]);
+        col(0.0, 1.0, 0.0, Jp[0][4], Jp[1][4]);
+        col(0.0, 0.0, 1.0, Jp[0][5], Jp[1][5]);
+        for (int c = 0; c < 3; ++c) col(R[0][c], R[1][c], R[2][c], Jl[0][c], Jl[1][c]);
+        const double W = rho1 * w;
+        const double r0 = -W * e0, r1 = -W * e1;
+        double* hl = Hll + 9 * ed.point_idx;
+        double* gl = bl + 3 * ed.point_idx;
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) hl[3 * a + b] += W * (Jl[0][a] * Jl[0][b] + Jl[1][a] * Jl[1][b]);
+            gl[a] += Jl[0][a] * r0 + Jl[1][a] * r1;
+        }
+        if (!(pose_fixed && pose_fixed[ed.pose_idx])) {
+            double* hp = Hpp + 36 * ed.pose_idx;
+            double* gp = bp + 6 * ed.pose_idx;
+            double* hpl = Hpl + 18 * (size_t)e;
+            for (int a = 0; a < 6; ++a) {
+                for (int b = 0; b < 6; ++b) hp[6 * a + b] += W * (Jp[0][a] * Jp[0][b] + Jp[1][a] * Jp[1][b]);
+                gp[a] += Jp[0][a] * r0 + Jp[1][a] * r1;
+                for (int b = 0; b < 3; ++b) hpl[3 * a + b] = W * (Jp[0][a] * Jl[0][b] + Jp[1][a] * Jl[1][b]);
+            }
+        }
+    }
+    return 0;
+}
+
 typedef struct ovo_ba_edge_stereo {
     int32_t pose_idx, point_idx;
     double obs_x, obs_y, obs_x_right;

@@ -111,3 +111,56 @@ def test_stereo_edge_jacobians_by_finite_differences(oracle):
     assert np.allclose(out["Hpp"][0], Jp.T @ Jp, rtol=1e-5, atol=1e-2)
     assert np.allclose(out["bp"][0], -Jp.T @ r0, rtol=1e-5, atol=1e-2)
     assert np.allclose(out["Hpl"][0], Jp.T @ Jl, rtol=1e-5, atol=1e-3)
+
+
+def test_equirectangular_edge_jacobians_by_finite_differences(oracle):
+    """Equirectangular edge: analytic Jacobians (oracle) against central differences of the residual, for points in all four
+    longitude quadrants (but away from the +-180 degree seam, where the residual is discontinuous by construction: rule 26)."""
+    from openvslam_amd.ba import quat_to_rot, rot_to_quat
+    cols, rows = 1920, 960
+    q = np.array([0.15, 0.1, -0.2, 0.95])
+    R = quat_to_rot(q / np.linalg.norm(q))
+    t = np.array([0.1, -0.2, 0.05])
+
+    def project(p):
+        L = np.linalg.norm(p)
+        return np.array([cols * (0.5 + np.arctan2(p[0], p[2]) / (2 * np.pi)), rows * (0.5 + np.arcsin(p[1] / L) / np.pi)])
+
+    def exp_se3(w, v):
+        th = np.linalg.norm(w)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        if th < 1e-12:
+            return np.eye(3) + K, v
+        Rm = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * K @ K
+        return Rm, V @ v
+
+    h = 1e-6
+    for X in ([0.5, -0.3, 4.0], [3.0, 1.0, -0.5], [-2.0, 0.4, 1.0], [-1.5, -2.0, -1.0]):
+        X = np.array(X)
+        obs = project(R @ X + t) + np.array([1.5, -0.7])
+
+        def residual(Rm, tv, Xv):
+            return obs - project(Rm @ Xv + tv)
+
+        pose = np.concatenate([t, rot_to_quat(R)])[None]
+        e = np.zeros(1, oracle.BA_EDGE_DTYPE)
+        e["obs_x"], e["obs_y"], e["inv_sigma_sq"] = obs[0], obs[1], 1.0
+        out = oracle.ba_linearize_equirect(pose, None, X[None], e, cols, rows, 0.0)
+        Jl = np.stack([(residual(R, t, X + h * np.eye(3)[i]) - residual(R, t, X - h * np.eye(3)[i])) / (2 * h) for i in range(3)], 1)
+        cl = []
+        for i in range(6):
+            d6 = np.zeros(6)
+            d6[i] = h
+            Rp, tp = exp_se3(d6[:3], d6[3:])
+            Rm, tm = exp_se3(-d6[:3], -d6[3:])
+            cl.append((residual(Rp @ R, Rp @ t + tp, X) - residual(Rm @ R, Rm @ t + tm, X)) / (2 * h))
+        Jp = np.stack(cl, 1)
+        r0 = residual(R, t, X)
+        assert np.allclose(r0, [1.5, -0.7], atol=1e-9)
+        assert np.isclose(out["chi2"][0], r0 @ r0, rtol=1e-9)
+        assert np.allclose(out["Hll"][0], Jl.T @ Jl, rtol=1e-5, atol=1e-2)
+        assert np.allclose(out["bl"][0], -Jl.T @ r0, rtol=1e-5, atol=1e-3)
+        assert np.allclose(out["Hpp"][0], Jp.T @ Jp, rtol=1e-5, atol=1e-1)
+        assert np.allclose(out["bp"][0], -Jp.T @ r0, rtol=1e-5, atol=1e-2)
+        assert np.allclose(out["Hpl"][0], Jp.T @ Jl, rtol=1e-5, atol=1e-1)

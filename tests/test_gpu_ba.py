@@ -82,3 +82,57 @@ def test_stereo_edges(oracle, huber):
     want = oracle.ba_linearize_stereo(d["poses"], d["pose_fixed"], d["points"], se, d["cam"], bf, delta)
     _check(got, want, 1e-12)
     assert len(se) == 30000 and want["chi2"][0] > 0
+
+
+def _equirect_scene(seed, n_pose=20, n_pt=5000, obs_per_pose=1500, cols=1920, rows=960):
+    """Landmarks on a shell around the rig, equirectangular observations with 1 px noise, perturbed initial state."""
+    from openvslam_amd import ba
+    rng = np.random.default_rng(seed)
+    pts = rng.normal(size=(n_pt, 3))
+    pts *= (rng.uniform(3.0, 9.0, n_pt) / np.linalg.norm(pts, axis=1))[:, None]
+    poses = np.zeros((n_pose, 7))
+    for i in range(n_pose):
+        q = np.concatenate([rng.normal(0, 0.1, 3), [1.0]])
+        poses[i, 3:] = q / np.linalg.norm(q)
+        poses[i, :3] = rng.normal(0, 0.4, 3)
+    edges = np.zeros(n_pose * obs_per_pose, ba.EDGE_DTYPE)
+    for i in range(n_pose):
+        sel = rng.choice(n_pt, obs_per_pose, replace=False)
+        p = pts[sel] @ ba.quat_to_rot(poses[i, 3:]).T + poses[i, :3]
+        u = cols * (0.5 + np.arctan2(p[:, 0], p[:, 2]) / (2 * np.pi))
+        v = rows * (0.5 + np.arcsin(p[:, 1] / np.linalg.norm(p, axis=1)) / np.pi)
+        e = edges[i * obs_per_pose:(i + 1) * obs_per_pose]
+        e["pose_idx"], e["point_idx"] = i, sel
+        e["obs_x"], e["obs_y"] = u + rng.normal(0, 1, obs_per_pose), v + rng.normal(0, 1, obs_per_pose)
+        e["inv_sigma_sq"] = 1.0 / 1.2 ** (2 * rng.integers(0, 8, obs_per_pose))
+    noisy_pts = pts + rng.normal(0, 0.02, pts.shape)
+    noisy = poses.copy()
+    noisy[:, :3] += rng.normal(0, 0.02, (n_pose, 3))
+    fixed = np.zeros(n_pose, np.uint8)
+    fixed[:3] = 1
+    return noisy, fixed, noisy_pts, edges
+
+
+@pytest.mark.parametrize("huber", [True, False])
+def test_equirectangular_edges(oracle, huber):
+    """atan2 / asin come from two maths libraries (ocml on the GPU, glibc in the oracle), so the residuals and with Huber the
+    weights can differ in the last place: every block within 1e-11 relative; without Huber the Jacobian-only Hpl blocks are exact."""
+    from openvslam_amd import ba
+    poses, fixed, pts, edges = _equirect_scene(5)
+    delta = float(np.sqrt(5.991)) if huber else 0.0
+    got = ba.linearize_equirect(poses, fixed, pts, edges, 1920, 960, delta)
+    want = oracle.ba_linearize_equirect(poses, fixed, pts, edges, 1920, 960, delta)
+    if not huber:
+        assert np.array_equal(got["Hpl"], want["Hpl"])
+    for k in ("Hpl", "Hpp", "bp", "Hll", "bl", "chi2"):
+        scale = np.abs(want[k]).max()
+        assert np.allclose(got[k], want[k], rtol=1e-11, atol=1e-11 * scale), k
+    assert want["chi2"][0] > 0 and np.abs(want["Hpl"]).max() > 0
+    assert ba.linearize_equirect is not None
+
+
+def test_equirectangular_rejects_bad_image_size():
+    from openvslam_amd import ba
+    poses, fixed, pts, edges = _equirect_scene(6, n_pose=2, n_pt=50, obs_per_pose=20)
+    with pytest.raises(RuntimeError):
+        ba.linearize_equirect(poses, fixed, pts, edges, 0, 960, 0.0)
