@@ -265,6 +265,46 @@ ovs_status ovs_fuse_replace_duplication(ovs_wmatcher* w, const ovs_camera* cam, 
                                         const float* inv_level_sigma_sq, int32_t num_levels, float log_scale_factor, float margin,
                                         int32_t* best_idx, int32_t* num_fused);
 
+/* replaces: the candidate search of  template<typename T> unsigned int fuse::detect_duplication(data::keyframe* keyfrm,
+ *               const Mat44_t& Sim3_cw, const T& landmarks_to_check, const float margin, std::vector<data::landmark*>&
+ *               duplicated_lms_in_keyfrm)  (src/openvslam/match/fuse.{h,cc}; loop closing). sim3_cw = the top 3 rows of Sim3_cw as 12 doubles
+ * (sR row-major, then the translation column); it is decomposed here as upstream does (scale from the first row). No chi-square gate.
+ * lm_valid != 0 iff lm && !will_be_erased() && lm is not already a landmark of keyfrm. best_idx as for ovs_fuse_replace_duplication. */
+ovs_status ovs_fuse_detect_duplication(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps,
+                                       const uint8_t* desc, int32_t n, const double* sim3_cw, const double* lm_pos_w,
+                                       const float* lm_dist_min_max, const double* lm_normal, const uint8_t* lm_desc, const uint8_t* lm_valid,
+                                       int32_t m, const float* scale_factors, int32_t num_levels, float log_scale_factor, float margin,
+                                       int32_t* best_idx, int32_t* num_found);
+
+/* replaces: unsigned int projection::match_by_Sim3_transform(data::keyframe* keyfrm, const Mat44_t& Sim3_cw,
+ *               const std::vector<data::landmark*>& landmarks, std::vector<data::landmark*>& matched_lms_in_keyfrm, float margin)
+ * (src/openvslam/match/projection.{h,cc}; loop closing). occupied[k] != 0 iff matched_lms_in_keyfrm[k] != nullptr on entry; lm_valid != 0
+ * iff the landmark is live and not already in matched_lms_in_keyfrm. Landmarks claim keypoints in order (sequential claim, replayed
+ * exactly). assigned[l] = keypoint that receives landmark l, or -1. */
+ovs_status ovs_projection_match_by_sim3_transform(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps,
+                                                  const uint8_t* desc, const uint8_t* occupied, int32_t n, const double* sim3_cw,
+                                                  const double* lm_pos_w, const float* lm_dist_min_max, const double* lm_normal,
+                                                  const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m, const float* scale_factors,
+                                                  int32_t num_levels, float log_scale_factor, float margin, int32_t* assigned,
+                                                  int32_t* num_matches);
+
+/* replaces: unsigned int projection::match_keyframes_mutually(data::keyframe* keyfrm_1, data::keyframe* keyfrm_2,
+ *               std::vector<data::landmark*>& matched_lms_in_keyfrm_1, float s_12, const Mat33_t& rot_12, const Vec3_t& trans_12,
+ *               float margin)  (src/openvslam/match/projection.{h,cc}; Sim3 refinement in loop detection). Per keyframe k: keypoints,
+ * descriptors, pose_cw (12 doubles) and, indexed by keypoint, the landmark's world position / (min, max) valid distance / descriptor;
+ * lm_valid_k[i] != 0 iff keypoint i has a live landmark that takes part (side 1: not already in matched_lms_in_keyfrm_1; side 2: its
+ * keypoint is not the partner of an already matched landmark). Both keyframes share the ORB scale tables.
+ * matched_2_in_1[idx_1] = idx_2 for the pairs both directions agree on, else -1. */
+ovs_status ovs_projection_match_keyframes_mutually(ovs_wmatcher* w, const ovs_camera* cam_1, const ovs_grid_params* gp_1,
+                                                   const ovs_keypoint* kps_1, const uint8_t* desc_1, int32_t n1, const double* pose_cw_1,
+                                                   const double* lm_pos_w_1, const float* lm_dist_1, const uint8_t* lm_desc_1,
+                                                   const uint8_t* lm_valid_1, const ovs_camera* cam_2, const ovs_grid_params* gp_2,
+                                                   const ovs_keypoint* kps_2, const uint8_t* desc_2, int32_t n2, const double* pose_cw_2,
+                                                   const double* lm_pos_w_2, const float* lm_dist_2, const uint8_t* lm_desc_2,
+                                                   const uint8_t* lm_valid_2, double s_12, const double* rot_12, const double* trans_12,
+                                                   const float* scale_factors, int32_t num_levels, float log_scale_factor, float margin,
+                                                   int32_t* matched_2_in_1, int32_t* num_matches);
+
 /* replaces: unsigned int area::match_in_consistent_area(data::frame& frm_1, data::frame& frm_2,
  *               std::vector<cv::Point2f>& prev_matched_pts, std::vector<int>& matched_indices_2_in_frm_1, int margin).
  * kps_i / desc_i = frm_i.undist_keypts_ / descriptors_; gp = frm_2's camera grid. prev_matched_xy (n1 x 2) is updated in

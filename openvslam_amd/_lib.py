@@ -84,6 +84,12 @@ SYMBOLS = {
                                        C.POINTER(_i32)]),
     "ovs_fuse_replace_duplication": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _f, _f, _vp,
                                             C.POINTER(_i32)]),
+    "ovs_fuse_detect_duplication": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _f, _f, _vp,
+                                           C.POINTER(_i32)]),
+    "ovs_projection_match_by_sim3_transform": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _f, _f,
+                                                      _vp, C.POINTER(_i32)]),
+    "ovs_projection_match_keyframes_mutually": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
+                                                       _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _i32, _f, _f, _vp, C.POINTER(_i32)]),
     "ovs_stereo_create": (_i32, [_i32, _i32, _i32, C.POINTER(_vp)]),
     "ovs_stereo_destroy": (_i32, [_vp]),
     "ovs_stereo_compute": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _f, _f, _vp, _vp, C.POINTER(_i32)]),

@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256) void k_reproject_queries(CamP cam, const ovs_k
                                                           double ccz, float log_scale_factor, float* __restrict__ q_xy,
                                                           float* __restrict__ q_x_right, float* __restrict__ q_radius,
                                                           int32_t* __restrict__ q_minl, int32_t* __restrict__ q_maxl,
-                                                          uint8_t* __restrict__ q_valid) {
+                                                          uint8_t* __restrict__ q_valid, const double* __restrict__ normals = nullptr,
+                                                          int level_up = 1) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     bool valid = !last_valid || last_valid[i];
@@ -299,11 +300,15 @@ __global__ __launch_bounds__(256) void k_reproject_queries(CamP cam, const ovs_k
         const double dist = sqrt((dx * dx + dy * dy) + dz * dz);
         const float dmin = dist_min_max[2 * i], dmax = dist_min_max[2 * i + 1];
         if (dist < dmin || dmax < dist) valid = false;
+        if (normals) {   // match_by_Sim3_transform: viewing-angle gate against the landmark's mean normal
+            const double* nrm = normals + 3 * (size_t)i;
+            if ((dx * nrm[0] + dy * nrm[1]) + dz * nrm[2] < 0.5 * dist) valid = false;
+        }
         lvl = valid ? (int)ceilf(__fdiv_rn(logf(__fdiv_rn(dmax, (float)dist)), log_scale_factor)) : 0;
         if (lvl < 0) lvl = 0;
         else if (num_levels <= lvl) lvl = num_levels - 1;
         minl = lvl - 1;
-        maxl = lvl + 1;
+        maxl = lvl + level_up;
     } else {
         lvl = last_kps[i].octave;
         minl = forward ? lvl : (backward ? 0 : lvl - 1);
@@ -336,7 +341,14 @@ struct FuseArgs {
     int m, num_levels;
     float log_scale_factor, margin;
     float sf[OVS_MAX_LEVELS], ils[OVS_MAX_LEVELS];
+    int variant;                  // kFuseReplace / kFuseDetect / kFuseMutual
+    uint32_t max_dist;            // acceptance threshold on the best Hamming distance
+    double P1[12];                // kFuseMutual: pose of the landmark's own keyframe (pos_1 = R_1w X + t_1w, then cam.P = [s R_21 | t_21])
 };
+
+// kFuseReplace: fuse::replace_duplication (chi-square gate); kFuseDetect: fuse::detect_duplication (no chi-square gate);
+// kFuseMutual: one direction of projection::match_keyframes_mutually (no viewing-angle gate, distance = |pos in the other keyframe|)
+enum { kFuseReplace = 0, kFuseDetect = 1, kFuseMutual = 2 };
 
 __global__ __launch_bounds__(256) void k_fuse_best(FuseArgs a, int32_t* __restrict__ best_out, int32_t* __restrict__ num_fused) {
     const int l = blockIdx.x * 256 + threadIdx.x;
@@ -344,16 +356,35 @@ __global__ __launch_bounds__(256) void k_fuse_best(FuseArgs a, int32_t* __restri
     int32_t result = -1;
     do {
         if (a.lm_valid && !a.lm_valid[l]) break;
-        const double* X = a.lm_pos_w + 3 * (size_t)l;
+        const double* Xw = a.lm_pos_w + 3 * (size_t)l;
+        double X1[3];
+        const double* X = Xw;
+        if (a.variant == kFuseMutual) {
+            X1[0] = (a.P1[0] * Xw[0] + a.P1[1] * Xw[1]) + a.P1[2] * Xw[2] + a.P1[9];
+            X1[1] = (a.P1[3] * Xw[0] + a.P1[4] * Xw[1]) + a.P1[5] * Xw[2] + a.P1[10];
+            X1[2] = (a.P1[6] * Xw[0] + a.P1[7] * Xw[1]) + a.P1[8] * Xw[2] + a.P1[11];
+            X = X1;
+        }
         double u, v;
         float x_right;
         if (!reproject_to_image(a.cam, X, u, v, x_right)) break;
-        const double dx = X[0] - a.cc[0], dy = X[1] - a.cc[1], dz = X[2] - a.cc[2];
+        double dx, dy, dz;
+        if (a.variant == kFuseMutual) {   // pos_2 = s R_21 pos_1 + t_21 (the same expression reproject_to_image evaluates)
+            dx = (a.cam.P[0] * X[0] + a.cam.P[1] * X[1]) + a.cam.P[2] * X[2] + a.cam.P[9];
+            dy = (a.cam.P[3] * X[0] + a.cam.P[4] * X[1]) + a.cam.P[5] * X[2] + a.cam.P[10];
+            dz = (a.cam.P[6] * X[0] + a.cam.P[7] * X[1]) + a.cam.P[8] * X[2] + a.cam.P[11];
+        } else {
+            dx = X[0] - a.cc[0];
+            dy = X[1] - a.cc[1];
+            dz = X[2] - a.cc[2];
+        }
         const double dist = sqrt((dx * dx + dy * dy) + dz * dz);
         const float dmin = a.lm_dist[2 * l], dmax = a.lm_dist[2 * l + 1];
         if (dist < dmin || dmax < dist) break;
-        const double* nrm = a.lm_normal + 3 * (size_t)l;
-        if ((dx * nrm[0] + dy * nrm[1]) + dz * nrm[2] < 0.5 * dist) break;
+        if (a.variant != kFuseMutual) {
+            const double* nrm = a.lm_normal + 3 * (size_t)l;
+            if ((dx * nrm[0] + dy * nrm[1]) + dz * nrm[2] < 0.5 * dist) break;
+        }
         const float ratio = __fdiv_rn(dmax, (float)dist);
         int pred = (int)ceilf(__fdiv_rn(logf(ratio), a.log_scale_factor));
         if (pred < 0) pred = 0;
@@ -382,15 +413,17 @@ __global__ __launch_bounds__(256) void k_fuse_best(FuseArgs a, int32_t* __restri
                     if (!(fabsf(__fsub_rn(kp.x, ref_x)) < r && fabsf(__fsub_rn(kp.y, ref_y)) < r)) continue;
                     const int level = kp.octave;
                     if (level < pred - 1 || pred < level) continue;
-                    const double ex = u - (double)kp.x, ey = v - (double)kp.y;
-                    const float xr = a.t_x_right ? a.t_x_right[idx] : -1.0f;
-                    if (xr >= 0) {
-                        const double exr = (double)x_right - (double)xr;
-                        const double e2 = (ex * ex + ey * ey) + exr * exr;
-                        if ((double)7.81473f < e2 * (double)a.ils[level]) continue;
-                    } else {
-                        const double e2 = ex * ex + ey * ey;
-                        if ((double)5.99146f < e2 * (double)a.ils[level]) continue;
+                    if (a.variant == kFuseReplace) {
+                        const double ex = u - (double)kp.x, ey = v - (double)kp.y;
+                        const float xr = a.t_x_right ? a.t_x_right[idx] : -1.0f;
+                        if (xr >= 0) {
+                            const double exr = (double)x_right - (double)xr;
+                            const double e2 = (ex * ex + ey * ey) + exr * exr;
+                            if ((double)7.81473f < e2 * (double)a.ils[level]) continue;
+                        } else {
+                            const double e2 = ex * ex + ey * ey;
+                            if ((double)5.99146f < e2 * (double)a.ils[level]) continue;
+                        }
                     }
                     const uint32_t d = hamming256_g(qd, reinterpret_cast<const uint32_t*>(a.t_desc + (size_t)idx * 32));
                     if (d < best) {
@@ -400,11 +433,25 @@ __global__ __launch_bounds__(256) void k_fuse_best(FuseArgs a, int32_t* __restri
                 }
             }
         }
-        if (best <= (uint32_t)OVS_HAMMING_DIST_THR_LOW) result = best_idx;
+        if (best <= a.max_dist) result = best_idx;
     } while (false);
     best_out[l] = result;
     const unsigned long long any = __ballot(result >= 0);
     if ((threadIdx.x & 63) == 0 && any) atomicAdd(num_fused, (int32_t)__popcll(any));
+}
+
+// projection::match_keyframes_mutually, last step: keep idx_1 -> idx_2 only if idx_2 -> idx_1 came back
+__global__ __launch_bounds__(256) void k_cross_check(const int32_t* __restrict__ m_2_in_1, const int32_t* __restrict__ m_1_in_2, int n1, int n2,
+                                                     int32_t* __restrict__ out, int32_t* __restrict__ num) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int32_t r = -1;
+    if (i < n1) {
+        const int32_t j = m_2_in_1[i];
+        if (j >= 0 && j < n2 && m_1_in_2[j] == i) r = j;
+        out[i] = r;
+    }
+    const unsigned long long any = __ballot(r >= 0);
+    if ((threadIdx.x & 63) == 0 && any) atomicAdd(num, (int32_t)__popcll(any));
 }
 
 // bow_tree: queries = the keyframe's feature-vector entries in walk order; the list of a query is its node's frame bucket
@@ -917,7 +964,7 @@ ovs_status ovs_wmatcher_create(int32_t max_targets, int32_t max_queries, int32_t
     CREATE_TRY(hipMalloc(&w->d_keys, sizeof(uint32_t) * (size_t)max_entries));
     CREATE_TRY(hipMalloc(&w->d_overflow, sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&w->d_assigned, sizeof(int32_t) * M));
-    CREATE_TRY(hipMalloc(&w->d_num, sizeof(int32_t)));
+    CREATE_TRY(hipMalloc(&w->d_num, sizeof(int32_t) * 4));   // [0] result count, [1] per-direction scratch count
     CREATE_TRY(hipMalloc(&w->d_t_kps, sizeof(ovs_keypoint) * T));
     CREATE_TRY(hipMalloc(&w->d_t_desc, 32 * T));
     CREATE_TRY(hipMalloc(&w->d_t_flag, T));
@@ -1480,6 +1527,8 @@ ovs_status ovs_fuse_replace_duplication(ovs_wmatcher* w, const ovs_camera* cam, 
     a.lm_normal = d_normal;
     a.lm_desc = w->d_q_desc;
     a.lm_valid = lm_valid ? w->d_q_flag : nullptr;
+    a.variant = kFuseReplace;
+    a.max_dist = OVS_HAMMING_DIST_THR_LOW;
     OVS_HIP_TRY(hipMemsetAsync(w->d_num, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k_fuse_best, dim3((m + 255) / 256), dim3(256), 0, s, a, w->d_assigned, w->d_num);
     OVS_HIP_TRY(hipGetLastError());
@@ -1589,6 +1638,275 @@ ovs_status ovs_projection_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_ca
     OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipStreamSynchronize(s));
     return overflow ? OVS_ERR_CAPACITY : OVS_OK;
+}
+
+namespace {
+void fill_cam(CamP& cp, const ovs_camera* cam, const ovs_grid_params* gp, const double* P) {
+    cp.model = cam->model;
+    cp.setup = cam->setup;
+    cp.fx = cam->fx;
+    cp.fy = cam->fy;
+    cp.cx = cam->cx;
+    cp.cy = cam->cy;
+    cp.fxb = cam->focal_x_baseline;
+    cp.cols = cam->cols;
+    cp.rows = cam->rows;
+    cp.min_x = gp->min_x;
+    cp.min_y = gp->min_y;
+    cp.max_x = gp->max_x;
+    cp.max_y = gp->max_y;
+    std::memcpy(cp.P, P, sizeof(double) * 12);
+}
+// Sim3_cw = [s R | t'] -> scale s = |first row of sR|, rot_cw = sR / s, trans_cw = t' / s, camera centre -R^T t (upstream decomposes the
+// 4x4 the same way in fuse::detect_duplication / projection::match_by_Sim3_transform)
+void decompose_sim3(const double* S, double* P, double* cc) {
+    const double sc = std::sqrt((S[0] * S[0] + S[1] * S[1]) + S[2] * S[2]);
+    for (int i = 0; i < 9; ++i) P[i] = S[i] / sc;
+    for (int i = 0; i < 3; ++i) P[9 + i] = S[9 + i] / sc;
+    cc[0] = -((P[0] * P[9] + P[3] * P[10]) + P[6] * P[11]);
+    cc[1] = -((P[1] * P[9] + P[4] * P[10]) + P[7] * P[11]);
+    cc[2] = -((P[2] * P[9] + P[5] * P[10]) + P[8] * P[11]);
+}
+}   // namespace
+
+ovs_status ovs_fuse_detect_duplication(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps,
+                                       const uint8_t* desc, int32_t n, const double* sim3_cw, const double* lm_pos_w,
+                                       const float* lm_dist_min_max, const double* lm_normal, const uint8_t* lm_desc, const uint8_t* lm_valid,
+                                       int32_t m, const float* scale_factors, int32_t num_levels, float log_scale_factor, float margin,
+                                       int32_t* best_idx, int32_t* num_found) {
+    if (!w || !cam || !gp || !num_found || n < 0 || m < 0 || !sim3_cw || !scale_factors || num_levels < 1 || num_levels > OVS_MAX_LEVELS ||
+        (cam->model != 0 && cam->model != 1))
+        return OVS_ERR_INVALID;
+    *num_found = 0;
+    if (m == 0) return OVS_OK;
+    if (!best_idx) return OVS_ERR_INVALID;
+    for (int i = 0; i < m; ++i) best_idx[i] = -1;
+    if (n == 0) return OVS_OK;
+    if (!kps || !desc || !lm_pos_w || !lm_dist_min_max || !lm_normal || !lm_desc) return OVS_ERR_INVALID;
+    if (n > w->max_t || m > w->max_q) return OVS_ERR_CAPACITY;
+    if ((size_t)m * 3 * sizeof(double) > (size_t)w->max_entries * sizeof(uint32_t)) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = w->stream;
+    FuseArgs a{};
+    double P[12];
+    decompose_sim3(sim3_cw, P, a.cc);
+    fill_cam(a.cam, cam, gp, P);
+    for (int l = 0; l < OVS_MAX_LEVELS; ++l) {
+        a.sf[l] = l < num_levels ? scale_factors[l] : 1.0f;
+        a.ils[l] = 1.0f;
+    }
+    a.num_levels = num_levels;
+    a.log_scale_factor = log_scale_factor;
+    a.margin = margin;
+    a.m = m;
+    a.variant = kFuseDetect;
+    a.max_dist = OVS_HAMMING_DIST_THR_LOW;
+    double* d_normal = reinterpret_cast<double*>(w->d_keys);
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, kps, sizeof(ovs_keypoint) * n, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, desc, (size_t)32 * n, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_pos, lm_pos_w, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(d_normal, lm_normal, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_xy, lm_dist_min_max, sizeof(float) * 2 * m, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, lm_desc, (size_t)32 * m, hipMemcpyHostToDevice, s));
+    if (lm_valid) OVS_HIP_TRY(hipMemcpyAsync(w->d_q_flag, lm_valid, (size_t)m, hipMemcpyHostToDevice, s));
+    ovs_status st = grid_assign(w, gp, w->d_t_kps, n, s);
+    if (st != OVS_OK) return st;
+    a.t_kps = w->d_t_kps;
+    a.t_desc = w->d_t_desc;
+    a.cell_start = w->d_cell_start;
+    a.items = w->d_items;
+    a.gp = w->gp;
+    a.lm_pos_w = w->d_q_pos;
+    a.lm_dist = w->d_q_xy;
+    a.lm_normal = d_normal;
+    a.lm_desc = w->d_q_desc;
+    a.lm_valid = lm_valid ? w->d_q_flag : nullptr;
+    OVS_HIP_TRY(hipMemsetAsync(w->d_num, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_fuse_best, dim3((m + 255) / 256), dim3(256), 0, s, a, w->d_assigned, w->d_num);
+    OVS_HIP_TRY(hipGetLastError());
+    OVS_HIP_TRY(hipMemcpyAsync(best_idx, w->d_assigned, sizeof(int32_t) * m, hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(num_found, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
+    return OVS_OK;
+}
+
+ovs_status ovs_projection_match_by_sim3_transform(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps,
+                                                  const uint8_t* desc, const uint8_t* occupied, int32_t n, const double* sim3_cw,
+                                                  const double* lm_pos_w, const float* lm_dist_min_max, const double* lm_normal,
+                                                  const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m, const float* scale_factors,
+                                                  int32_t num_levels, float log_scale_factor, float margin, int32_t* assigned,
+                                                  int32_t* num_matches) {
+    if (!w || !cam || !gp || !num_matches || n < 0 || m < 0 || !sim3_cw || !scale_factors || num_levels < 1 || num_levels > OVS_MAX_LEVELS ||
+        (cam->model != 0 && cam->model != 1))
+        return OVS_ERR_INVALID;
+    *num_matches = 0;
+    if (m == 0) return OVS_OK;
+    if (!assigned) return OVS_ERR_INVALID;
+    for (int i = 0; i < m; ++i) assigned[i] = -1;
+    if (n == 0) return OVS_OK;
+    if (!kps || !desc || !lm_pos_w || !lm_dist_min_max || !lm_normal || !lm_desc) return OVS_ERR_INVALID;
+    if (n > w->max_t || m > w->max_q) return OVS_ERR_CAPACITY;
+    // (min, max) distances then the normals ride in the key buffer; both are consumed before the lists are written
+    if ((size_t)m * (2 * sizeof(float) + 3 * sizeof(double)) > (size_t)w->max_entries * sizeof(uint32_t)) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = w->stream;
+    CamP cp{};
+    double P[12], cc[3];
+    decompose_sim3(sim3_cw, P, cc);
+    fill_cam(cp, cam, gp, P);
+    float* d_dist = reinterpret_cast<float*>(w->d_keys);
+    double* d_normal = reinterpret_cast<double*>(d_dist + 2 * (size_t)m);
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, kps, sizeof(ovs_keypoint) * n, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, desc, (size_t)32 * n, hipMemcpyHostToDevice, s));
+    if (occupied) OVS_HIP_TRY(hipMemcpyAsync(w->d_t_flag, occupied, (size_t)n, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_pos, lm_pos_w, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(d_dist, lm_dist_min_max, sizeof(float) * 2 * m, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(d_normal, lm_normal, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, lm_desc, (size_t)32 * m, hipMemcpyHostToDevice, s));
+    uint8_t* d_valid = nullptr;
+    if (lm_valid) {
+        OVS_HIP_TRY(hipMemcpyAsync(w->d_q_flag, lm_valid, (size_t)m, hipMemcpyHostToDevice, s));
+        d_valid = w->d_q_flag;
+    }
+    float sf16[OVS_MAX_LEVELS];
+    for (int l = 0; l < OVS_MAX_LEVELS; ++l) sf16[l] = l < num_levels ? scale_factors[l] : 1.0f;
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_sf, sf16, sizeof(sf16), hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));   // sf16 is a stack array
+    ovs_status st = grid_assign(w, gp, w->d_t_kps, n, s);
+    if (st != OVS_OK) return st;
+    hipLaunchKernelGGL(k_reproject_queries, dim3((m + 255) / 256), dim3(256), 0, s, cp, (const ovs_keypoint*)nullptr, (const double*)w->d_q_pos,
+                       (const uint8_t*)d_valid, m, margin, (const float*)w->d_sf, num_levels, 0, 0, (const float*)d_dist, cc[0], cc[1], cc[2],
+                       log_scale_factor, w->d_q_xy, w->d_q_f, w->d_q_r, w->d_q_i, w->d_q_i2, w->d_q_flag, (const double*)d_normal, 0);
+    OVS_HIP_TRY(hipGetLastError());
+    WinArgs a{};
+    a.t_kps = w->d_t_kps;
+    a.t_desc = w->d_t_desc;
+    a.t_occupied = occupied ? w->d_t_flag : nullptr;
+    a.cell_start = w->d_cell_start;
+    a.items = w->d_items;
+    a.gp = w->gp;
+    a.n_q = m;
+    a.q_xy = w->d_q_xy;
+    a.q_x_right = w->d_q_f;
+    a.q_valid = w->d_q_flag;
+    a.q_radius = w->d_q_r;
+    a.q_minl = w->d_q_i;
+    a.q_maxl = w->d_q_i2;
+    a.q_desc = w->d_q_desc;
+    a.margin = margin;
+    a.mode = kModeGeneric;
+    st = build_lists(w, a, m, k_window_lists<false>, k_window_lists<true>, s);
+    if (st != OVS_OK) return st;
+    ResolveArgs ra{};
+    ra.offsets = w->d_offsets;
+    ra.keys = w->d_keys;
+    ra.n_q = m;
+    ra.n_t = n;
+    ra.check_orientation = 0;
+    ra.q_kps = nullptr;
+    ra.t_kps = w->d_t_kps;
+    ra.assigned = w->d_assigned;
+    ra.num_matches = w->d_num;
+    ra.best_only_thr = OVS_HAMMING_DIST_THR_LOW;
+    st = launch_resolve<kRuleBestOnly>(ra, s);
+    if (st != OVS_OK) return st;
+    uint32_t overflow = 0;
+    OVS_HIP_TRY(hipMemcpyAsync(assigned, w->d_assigned, sizeof(int32_t) * m, hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
+    return overflow ? OVS_ERR_CAPACITY : OVS_OK;
+}
+
+// one direction of match_keyframes_mutually: the landmarks of keyframe A (pose P_a, world positions) against the keypoints of keyframe B
+static ovs_status mutual_pass(ovs_wmatcher* w, const ovs_camera* cam_b, const ovs_grid_params* gp_b, const ovs_keypoint* kps_b,
+                              const uint8_t* desc_b, int n_b, const double* pose_cw_a, const double* sim_ba, const double* lm_pos_w_a,
+                              const float* lm_dist_a, const uint8_t* lm_desc_a, const uint8_t* lm_valid_a, int n_a, const float* scale_factors,
+                              int num_levels, float log_scale_factor, float margin, int32_t* d_out, hipStream_t s) {
+    FuseArgs a{};
+    fill_cam(a.cam, cam_b, gp_b, sim_ba);
+    std::memcpy(a.P1, pose_cw_a, sizeof(double) * 12);
+    for (int l = 0; l < OVS_MAX_LEVELS; ++l) {
+        a.sf[l] = l < num_levels ? scale_factors[l] : 1.0f;
+        a.ils[l] = 1.0f;
+    }
+    a.num_levels = num_levels;
+    a.log_scale_factor = log_scale_factor;
+    a.margin = margin;
+    a.m = n_a;
+    a.variant = kFuseMutual;
+    a.max_dist = OVS_HAMMING_DIST_THR_HIGH;
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, kps_b, sizeof(ovs_keypoint) * n_b, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, desc_b, (size_t)32 * n_b, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_pos, lm_pos_w_a, sizeof(double) * 3 * n_a, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_xy, lm_dist_a, sizeof(float) * 2 * n_a, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, lm_desc_a, (size_t)32 * n_a, hipMemcpyHostToDevice, s));
+    if (lm_valid_a) OVS_HIP_TRY(hipMemcpyAsync(w->d_q_flag, lm_valid_a, (size_t)n_a, hipMemcpyHostToDevice, s));
+    ovs_status st = grid_assign(w, gp_b, w->d_t_kps, n_b, s);
+    if (st != OVS_OK) return st;
+    a.t_kps = w->d_t_kps;
+    a.t_desc = w->d_t_desc;
+    a.cell_start = w->d_cell_start;
+    a.items = w->d_items;
+    a.gp = w->gp;
+    a.lm_pos_w = w->d_q_pos;
+    a.lm_dist = w->d_q_xy;
+    a.lm_desc = w->d_q_desc;
+    a.lm_valid = lm_valid_a ? w->d_q_flag : nullptr;
+    hipLaunchKernelGGL(k_fuse_best, dim3((n_a + 255) / 256), dim3(256), 0, s, a, d_out, w->d_num + 1);   // per-direction count: scratch
+    OVS_HIP_TRY(hipGetLastError());
+    return OVS_OK;
+}
+
+ovs_status ovs_projection_match_keyframes_mutually(ovs_wmatcher* w, const ovs_camera* cam_1, const ovs_grid_params* gp_1,
+                                                   const ovs_keypoint* kps_1, const uint8_t* desc_1, int32_t n1, const double* pose_cw_1,
+                                                   const double* lm_pos_w_1, const float* lm_dist_1, const uint8_t* lm_desc_1,
+                                                   const uint8_t* lm_valid_1, const ovs_camera* cam_2, const ovs_grid_params* gp_2,
+                                                   const ovs_keypoint* kps_2, const uint8_t* desc_2, int32_t n2, const double* pose_cw_2,
+                                                   const double* lm_pos_w_2, const float* lm_dist_2, const uint8_t* lm_desc_2,
+                                                   const uint8_t* lm_valid_2, double s_12, const double* rot_12, const double* trans_12,
+                                                   const float* scale_factors, int32_t num_levels, float log_scale_factor, float margin,
+                                                   int32_t* matched_2_in_1, int32_t* num_matches) {
+    if (!w || !cam_1 || !cam_2 || !gp_1 || !gp_2 || !num_matches || n1 < 0 || n2 < 0 || !pose_cw_1 || !pose_cw_2 || !rot_12 || !trans_12 ||
+        !scale_factors || num_levels < 1 || num_levels > OVS_MAX_LEVELS || (cam_1->model != 0 && cam_1->model != 1) ||
+        (cam_2->model != 0 && cam_2->model != 1) || !(s_12 > 0.0))
+        return OVS_ERR_INVALID;
+    *num_matches = 0;
+    if (n1 == 0) return OVS_OK;
+    if (!matched_2_in_1) return OVS_ERR_INVALID;
+    for (int i = 0; i < n1; ++i) matched_2_in_1[i] = -1;
+    if (n2 == 0) return OVS_OK;
+    if (!kps_1 || !desc_1 || !lm_pos_w_1 || !lm_dist_1 || !lm_desc_1 || !kps_2 || !desc_2 || !lm_pos_w_2 || !lm_dist_2 || !lm_desc_2)
+        return OVS_ERR_INVALID;
+    const int nmax = std::max(n1, n2);
+    if (nmax > w->max_t || nmax > w->max_q) return OVS_ERR_CAPACITY;
+    if ((size_t)(n1 + n2) > (size_t)w->max_entries) return OVS_ERR_CAPACITY;   // the two one-way results ride in the key buffer
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = w->stream;
+    // Sim3 in both directions: [s_12 R_12 | t_12] takes keyframe-2 coordinates to keyframe 1; [R_12^T / s_12 | -(R_12^T / s_12) t_12] back
+    double S12[12], S21[12];
+    for (int i = 0; i < 9; ++i) S12[i] = s_12 * rot_12[i];
+    for (int i = 0; i < 3; ++i) S12[9 + i] = trans_12[i];
+    const double inv_s = 1.0 / s_12;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) S21[3 * r + c] = inv_s * rot_12[3 * c + r];
+    for (int r = 0; r < 3; ++r) S21[9 + r] = -((S21[3 * r] * trans_12[0] + S21[3 * r + 1] * trans_12[1]) + S21[3 * r + 2] * trans_12[2]);
+    int32_t* d_2_in_1 = reinterpret_cast<int32_t*>(w->d_keys);
+    int32_t* d_1_in_2 = d_2_in_1 + n1;
+    ovs_status st = mutual_pass(w, cam_2, gp_2, kps_2, desc_2, n2, pose_cw_1, S21, lm_pos_w_1, lm_dist_1, lm_desc_1, lm_valid_1, n1, scale_factors,
+                                num_levels, log_scale_factor, margin, d_2_in_1, s);
+    if (st != OVS_OK) return st;
+    st = mutual_pass(w, cam_1, gp_1, kps_1, desc_1, n1, pose_cw_2, S12, lm_pos_w_2, lm_dist_2, lm_desc_2, lm_valid_2, n2, scale_factors, num_levels,
+                     log_scale_factor, margin, d_1_in_2, s);
+    if (st != OVS_OK) return st;
+    OVS_HIP_TRY(hipMemsetAsync(w->d_num, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_cross_check, dim3((n1 + 255) / 256), dim3(256), 0, s, (const int32_t*)d_2_in_1, (const int32_t*)d_1_in_2, n1, n2,
+                       w->d_assigned, w->d_num);
+    OVS_HIP_TRY(hipGetLastError());
+    OVS_HIP_TRY(hipMemcpyAsync(matched_2_in_1, w->d_assigned, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
+    return OVS_OK;
 }
 
 }   // extern "C"

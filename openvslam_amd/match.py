@@ -196,6 +196,58 @@ class projection(_window_ctx):
         return assigned[:len(kk)].copy(), n.value
 
 
+    def match_by_Sim3_transform(self, cam, gp, keyfrm_keypts, keyfrm_desc, Sim3_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc,
+                                scale_factors, log_scale_factor, margin, keyfrm_occupied=None, lm_valid=None):
+        """projection::match_by_Sim3_transform(keyfrm, Sim3_cw, landmarks, matched_lms_in_keyfrm, margin): returns (assigned,
+        num_matches); assigned[l] is the keyframe keypoint that receives landmark l, or -1."""
+        k = np.ascontiguousarray(keyfrm_keypts, KP_DTYPE)
+        d = np.ascontiguousarray(keyfrm_desc, np.uint8).reshape(-1, 32)
+        pw = np.ascontiguousarray(lm_pos_w, np.float64).reshape(-1, 3)
+        dm = np.ascontiguousarray(lm_dist_min_max, np.float32).reshape(-1, 2)
+        nr = np.ascontiguousarray(lm_normal, np.float64).reshape(-1, 3)
+        ld = np.ascontiguousarray(lm_desc, np.uint8).reshape(-1, 32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        occ = None if keyfrm_occupied is None else np.ascontiguousarray(keyfrm_occupied, np.uint8)
+        val = None if lm_valid is None else np.ascontiguousarray(lm_valid, np.uint8)
+        assigned = np.full(max(len(pw), 1), -1, np.int32)
+        n = C.c_int32()
+        _lib.check(self._L.ovs_projection_match_by_sim3_transform(
+            self._h, C.byref(cam), C.byref(gp), _p(k), _p(d), _p(occ), len(k), _p(_pose12(Sim3_cw)), _p(pw), _p(dm), _p(nr), _p(ld), _p(val),
+            len(pw), _p(sf), len(sf), float(log_scale_factor), float(margin), _p(assigned), C.byref(n)),
+            "ovs_projection_match_by_sim3_transform")
+        return assigned[:len(pw)].copy(), n.value
+
+    def match_keyframes_mutually(self, cam, gp, keypts_1, desc_1, pose_cw_1, lm_pos_w_1, lm_dist_1, lm_desc_1, lm_valid_1, keypts_2, desc_2,
+                                 pose_cw_2, lm_pos_w_2, lm_dist_2, lm_desc_2, lm_valid_2, s_12, rot_12, trans_12, scale_factors,
+                                 log_scale_factor, margin, cam_2=None, gp_2=None):
+        """projection::match_keyframes_mutually(keyfrm_1, keyfrm_2, matched_lms_in_keyfrm_1, s_12, rot_12, trans_12, margin): returns
+        (num_matches, matched_2_in_1); per-keypoint landmark arrays, lm_valid_k marks the keypoints whose landmark takes part."""
+        k1 = np.ascontiguousarray(keypts_1, KP_DTYPE)
+        k2 = np.ascontiguousarray(keypts_2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc_1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(desc_2, np.uint8).reshape(-1, 32)
+        p1 = np.ascontiguousarray(lm_pos_w_1, np.float64).reshape(-1, 3)
+        p2 = np.ascontiguousarray(lm_pos_w_2, np.float64).reshape(-1, 3)
+        m1 = np.ascontiguousarray(lm_dist_1, np.float32).reshape(-1, 2)
+        m2 = np.ascontiguousarray(lm_dist_2, np.float32).reshape(-1, 2)
+        l1 = np.ascontiguousarray(lm_desc_1, np.uint8).reshape(-1, 32)
+        l2 = np.ascontiguousarray(lm_desc_2, np.uint8).reshape(-1, 32)
+        v1 = None if lm_valid_1 is None else np.ascontiguousarray(lm_valid_1, np.uint8)
+        v2 = None if lm_valid_2 is None else np.ascontiguousarray(lm_valid_2, np.uint8)
+        R = np.ascontiguousarray(rot_12, np.float64).reshape(9)
+        t = np.ascontiguousarray(trans_12, np.float64).reshape(3)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        cam_2 = cam if cam_2 is None else cam_2
+        gp_2 = gp if gp_2 is None else gp_2
+        out = np.full(max(len(k1), 1), -1, np.int32)
+        n = C.c_int32()
+        _lib.check(self._L.ovs_projection_match_keyframes_mutually(
+            self._h, C.byref(cam), C.byref(gp), _p(k1), _p(d1), len(k1), _p(_pose12(pose_cw_1)), _p(p1), _p(m1), _p(l1), _p(v1), C.byref(cam_2),
+            C.byref(gp_2), _p(k2), _p(d2), len(k2), _p(_pose12(pose_cw_2)), _p(p2), _p(m2), _p(l2), _p(v2), float(s_12), _p(R), _p(t), _p(sf),
+            len(sf), float(log_scale_factor), float(margin), _p(out), C.byref(n)), "ovs_projection_match_keyframes_mutually")
+        return n.value, out[:len(k1)].copy()
+
+
 def _pose12(pose_cw):
     """3x4 (or 4x4) [R|t] -> 12 doubles: rotation row-major, then translation."""
     T = np.asarray(pose_cw, np.float64)
@@ -299,6 +351,26 @@ class fuse(_window_ctx):
                                                         _p(pw), _p(dm), _p(nr), _p(ld), _p(val), len(pw), _p(sf), _p(ils), len(sf),
                                                         float(log_scale_factor), float(margin), _p(best), C.byref(n)),
                    "ovs_fuse_replace_duplication")
+        return best[:len(pw)].copy(), n.value
+
+
+    def detect_duplication(self, cam, gp, keyfrm_keypts, keyfrm_desc, Sim3_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc, scale_factors,
+                           log_scale_factor, margin, lm_valid=None):
+        """fuse::detect_duplication(keyfrm, Sim3_cw, landmarks_to_check, margin, duplicated_lms_in_keyfrm), candidate search: returns
+        (best_idx, num_found)."""
+        k = np.ascontiguousarray(keyfrm_keypts, KP_DTYPE)
+        d = np.ascontiguousarray(keyfrm_desc, np.uint8).reshape(-1, 32)
+        pw = np.ascontiguousarray(lm_pos_w, np.float64).reshape(-1, 3)
+        dm = np.ascontiguousarray(lm_dist_min_max, np.float32).reshape(-1, 2)
+        nr = np.ascontiguousarray(lm_normal, np.float64).reshape(-1, 3)
+        ld = np.ascontiguousarray(lm_desc, np.uint8).reshape(-1, 32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        val = None if lm_valid is None else np.ascontiguousarray(lm_valid, np.uint8)
+        best = np.full(max(len(pw), 1), -1, np.int32)
+        n = C.c_int32()
+        _lib.check(self._L.ovs_fuse_detect_duplication(self._h, C.byref(cam), C.byref(gp), _p(k), _p(d), len(k), _p(_pose12(Sim3_cw)), _p(pw),
+                                                       _p(dm), _p(nr), _p(ld), _p(val), len(pw), _p(sf), len(sf), float(log_scale_factor),
+                                                       float(margin), _p(best), C.byref(n)), "ovs_fuse_detect_duplication")
         return best[:len(pw)].copy(), n.value
 
 

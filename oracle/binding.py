@@ -557,3 +557,64 @@ def ba_linearize_equirect(poses, pose_fixed, points, edges, cols, rows, huber_de
     assert rc == 0, rc
     out["Hpl"] = out["Hpl"][:n_edge]
     return out
+
+
+def fuse_detect_duplication(cam, gp, kf_kps, kf_desc, sim3_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc, scale_factors,
+                            log_scale_factor, margin, lm_valid=None):
+    xs, ys, oc, _ = _soa(kf_kps)
+    d = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32)
+    pw = np.ascontiguousarray(lm_pos_w, np.float64).reshape(-1, 3)
+    dm = np.ascontiguousarray(lm_dist_min_max, np.float32).reshape(-1, 2)
+    nr = np.ascontiguousarray(lm_normal, np.float64).reshape(-1, 3)
+    ld = np.ascontiguousarray(lm_desc, np.uint8).reshape(-1, 32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    val = None if lm_valid is None else np.ascontiguousarray(lm_valid, np.uint8)
+    best = np.full(max(len(pw), 1), -1, np.int32)
+    n = lib().ovo_fuse_detect_duplication(C.byref(cam), C.byref(gp), _p(xs), _p(ys), _p(oc), _p(d), len(xs), _p(_pose12(sim3_cw)), _p(pw),
+                                          _p(dm), _p(nr), _p(ld), _p(val), len(pw), _p(sf), len(sf), C.c_float(log_scale_factor),
+                                          C.c_float(margin), _p(best))
+    return best[:len(pw)].copy(), n
+
+
+def projection_match_by_sim3_transform(cam, gp, kf_kps, kf_desc, sim3_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc, scale_factors,
+                                       log_scale_factor, margin, kf_occupied=None, lm_valid=None):
+    xs, ys, oc, _ = _soa(kf_kps)
+    d = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32)
+    pw = np.ascontiguousarray(lm_pos_w, np.float64).reshape(-1, 3)
+    dm = np.ascontiguousarray(lm_dist_min_max, np.float32).reshape(-1, 2)
+    nr = np.ascontiguousarray(lm_normal, np.float64).reshape(-1, 3)
+    ld = np.ascontiguousarray(lm_desc, np.uint8).reshape(-1, 32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    occ = None if kf_occupied is None else np.ascontiguousarray(kf_occupied, np.uint8)
+    val = None if lm_valid is None else np.ascontiguousarray(lm_valid, np.uint8)
+    assigned = np.full(max(len(pw), 1), -1, np.int32)
+    n = lib().ovo_projection_match_by_sim3_transform(C.byref(cam), C.byref(gp), _p(xs), _p(ys), _p(oc), _p(d), _p(occ), len(xs),
+                                                     _p(_pose12(sim3_cw)), _p(pw), _p(dm), _p(nr), _p(ld), _p(val), len(pw), _p(sf), len(sf),
+                                                     C.c_float(log_scale_factor), C.c_float(margin), _p(assigned))
+    return assigned[:len(pw)].copy(), n
+
+
+def projection_match_keyframes_mutually(cam, gp, kps_1, desc_1, pose_cw_1, lm_pos_w_1, lm_dist_1, lm_desc_1, lm_valid_1, kps_2, desc_2,
+                                        pose_cw_2, lm_pos_w_2, lm_dist_2, lm_desc_2, lm_valid_2, s_12, rot_12, trans_12, scale_factors,
+                                        log_scale_factor, margin):
+    x1, y1, o1, _ = _soa(kps_1)
+    x2, y2, o2, _ = _soa(kps_2)
+    d1 = np.ascontiguousarray(desc_1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(desc_2, np.uint8).reshape(-1, 32)
+    p1 = np.ascontiguousarray(lm_pos_w_1, np.float64).reshape(-1, 3)
+    p2 = np.ascontiguousarray(lm_pos_w_2, np.float64).reshape(-1, 3)
+    m1 = np.ascontiguousarray(lm_dist_1, np.float32).reshape(-1, 2)
+    m2 = np.ascontiguousarray(lm_dist_2, np.float32).reshape(-1, 2)
+    l1 = np.ascontiguousarray(lm_desc_1, np.uint8).reshape(-1, 32)
+    l2 = np.ascontiguousarray(lm_desc_2, np.uint8).reshape(-1, 32)
+    v1 = None if lm_valid_1 is None else np.ascontiguousarray(lm_valid_1, np.uint8)
+    v2 = None if lm_valid_2 is None else np.ascontiguousarray(lm_valid_2, np.uint8)
+    R = np.ascontiguousarray(rot_12, np.float64).reshape(9)
+    t = np.ascontiguousarray(trans_12, np.float64).reshape(3)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    out = np.full(max(len(x1), 1), -1, np.int32)
+    n = lib().ovo_projection_match_keyframes_mutually(
+        C.byref(cam), C.byref(gp), _p(x1), _p(y1), _p(o1), _p(d1), len(x1), _p(_pose12(pose_cw_1)), _p(p1), _p(m1), _p(l1), _p(v1),
+        C.byref(cam), C.byref(gp), _p(x2), _p(y2), _p(o2), _p(d2), len(x2), _p(_pose12(pose_cw_2)), _p(p2), _p(m2), _p(l2), _p(v2),
+        C.c_double(s_12), _p(R), _p(t), _p(sf), len(sf), C.c_float(log_scale_factor), C.c_float(margin), _p(out))
+    return n, out[:len(x1)].copy()

@@ -616,6 +616,202 @@ int ovo_projection_match_frame_and_keyframe(const ovo_camera* cam, const ovo_gri
     return num_matches;
 }
 
+// Sim3_cw = [sR | t'] (12 doubles, rows of sR then t') -> rot_cw = sR / s, trans_cw = t' / s with s = |first row of sR|; camera centre
+// -rot_cw^T trans_cw (as fuse::detect_duplication / projection::match_by_Sim3_transform decompose the 4x4 Sim3).
+static void decompose_sim3(const double* S, double* P, double* cc) {
+    const double sc = std::sqrt((S[0] * S[0] + S[1] * S[1]) + S[2] * S[2]);
+    for (int i = 0; i < 9; ++i) P[i] = S[i] / sc;
+    for (int i = 0; i < 3; ++i) P[9 + i] = S[9 + i] / sc;
+    cc[0] = -((P[0] * P[9] + P[3] * P[10]) + P[6] * P[11]);
+    cc[1] = -((P[1] * P[9] + P[4] * P[10]) + P[7] * P[11]);
+    cc[2] = -((P[2] * P[9] + P[5] * P[10]) + P[8] * P[11]);
+}
+
+// M8  fuse::detect_duplication(keyfrm, Sim3_cw, landmarks_to_check, margin, duplicated_lms_in_keyfrm), candidate search (expected:
+// src/openvslam/match/fuse.cc): as replace_duplication's search but with the Sim3-corrected pose and WITHOUT the chi-square gate: reproject,
+// distance range, viewing angle, predicted level, all grid candidates within margin * scale_factors[pred] at levels [pred-1, pred], best
+// Hamming (strict <), accept iff best <= THR_LOW. lm_valid carries "!will_be_erased && not already a landmark of this keyframe". The
+// bookkeeping that follows (duplicated_lms_in_keyfrm / add_observation) is host-side graph surgery on best_idx and outside the ABI.
+int ovo_fuse_detect_duplication(const ovo_camera* cam, const ovo_grid_params* gp, const float* xs, const float* ys, const int32_t* octaves,
+                                const uint8_t* desc, int n, const double* sim3_cw, const double* lm_pos_w, const float* lm_dist_min_max,
+                                const double* lm_normal, const uint8_t* lm_desc, const uint8_t* lm_valid, int m, const float* scale_factors,
+                                int num_scale_levels, float log_scale_factor, float margin, int32_t* best_idx_out) {
+    Grid g;
+    build_grid(g, *gp, xs, ys, n);
+    double P[12], cc[3];
+    decompose_sim3(sim3_cw, P, cc);
+    int num = 0;
+    for (int l = 0; l < m; ++l) {
+        best_idx_out[l] = -1;
+        if (lm_valid && !lm_valid[l]) continue;
+        const double* X = lm_pos_w + 3 * (size_t)l;
+        double reproj[2];
+        float x_right;
+        if (!reproject_to_image(*cam, *gp, P, X, reproj, &x_right)) continue;
+        const double v[3] = {X[0] - cc[0], X[1] - cc[1], X[2] - cc[2]};
+        const double dist = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+        const float dmin = lm_dist_min_max[2 * l], dmax = lm_dist_min_max[2 * l + 1];
+        if (dist < dmin || dmax < dist) continue;
+        const double* nrm = lm_normal + 3 * (size_t)l;
+        if ((v[0] * nrm[0] + v[1] * nrm[1]) + v[2] * nrm[2] < 0.5 * dist) continue;
+        const float ratio = dmax / (float)dist;
+        int pred = (int)std::ceil(std::log(ratio) / log_scale_factor);
+        if (pred < 0) pred = 0;
+        else if (num_scale_levels <= pred) pred = num_scale_levels - 1;
+        const float r = margin * scale_factors[pred];
+        unsigned best = OVO_MAX_HAMMING_DIST;
+        int best_idx = -1;
+        for_keypoints_in_cell(g, xs, ys, octaves, (float)reproj[0], (float)reproj[1], r, -1, -1, [&](int idx) {
+            const int level = octaves[idx];
+            if (level < pred - 1 || pred < level) return;
+            const unsigned d = distance_32(lm_desc + (size_t)l * 32, desc + (size_t)idx * 32);
+            if (d < best) {
+                best = d;
+                best_idx = idx;
+            }
+        });
+        if (OVO_HAMMING_DIST_THR_LOW < best) continue;
+        best_idx_out[l] = best_idx;
+        ++num;
+    }
+    return num;
+}
+
+// M4  projection::match_by_Sim3_transform(keyfrm, Sim3_cw, landmarks, matched_lms_in_keyfrm, margin) (expected: src/openvslam/match/
+// projection.cc; ORB-SLAM2 SearchByProjection(pKF, Scw, vpPoints, vpMatched, th)): landmarks in order; skipped when erased or already in
+// matched_lms_in_keyfrm (lm_valid); Sim3-corrected pose; distance range; viewing angle; predicted level; window margin * sf[pred], levels
+// [pred-1, pred]; keypoints that already hold a match are skipped (sequential claim); best Hamming, accept iff best <= THR_LOW; no
+// orientation check. assigned[l] = keypoint index or -1.
+int ovo_projection_match_by_sim3_transform(const ovo_camera* cam, const ovo_grid_params* gp, const float* xs, const float* ys,
+                                           const int32_t* octaves, const uint8_t* desc, const uint8_t* occupied, int n, const double* sim3_cw,
+                                           const double* lm_pos_w, const float* lm_dist_min_max, const double* lm_normal, const uint8_t* lm_desc,
+                                           const uint8_t* lm_valid, int m, const float* scale_factors, int num_scale_levels,
+                                           float log_scale_factor, float margin, int32_t* assigned) {
+    Grid g;
+    build_grid(g, *gp, xs, ys, n);
+    std::vector<uint8_t> occ((size_t)n, 0);
+    if (occupied) occ.assign(occupied, occupied + n);
+    double P[12], cc[3];
+    decompose_sim3(sim3_cw, P, cc);
+    int num_matches = 0;
+    for (int l = 0; l < m; ++l) {
+        assigned[l] = -1;
+        if (lm_valid && !lm_valid[l]) continue;
+        const double* X = lm_pos_w + 3 * (size_t)l;
+        double reproj[2];
+        float x_right;
+        if (!reproject_to_image(*cam, *gp, P, X, reproj, &x_right)) continue;
+        const double v[3] = {X[0] - cc[0], X[1] - cc[1], X[2] - cc[2]};
+        const double dist = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+        const float dmin = lm_dist_min_max[2 * l], dmax = lm_dist_min_max[2 * l + 1];
+        if (dist < dmin || dmax < dist) continue;
+        const double* nrm = lm_normal + 3 * (size_t)l;
+        if ((v[0] * nrm[0] + v[1] * nrm[1]) + v[2] * nrm[2] < 0.5 * dist) continue;
+        const float ratio = dmax / (float)dist;
+        int pred = (int)std::ceil(std::log(ratio) / log_scale_factor);
+        if (pred < 0) pred = 0;
+        else if (num_scale_levels <= pred) pred = num_scale_levels - 1;
+        const float r = margin * scale_factors[pred];
+        unsigned best = OVO_MAX_HAMMING_DIST;
+        int best_idx = -1;
+        for_keypoints_in_cell(g, xs, ys, octaves, (float)reproj[0], (float)reproj[1], r, pred - 1, pred, [&](int idx) {
+            if (occ[idx]) return;
+            const unsigned d = distance_32(lm_desc + (size_t)l * 32, desc + (size_t)idx * 32);
+            if (d < best) {
+                best = d;
+                best_idx = idx;
+            }
+        });
+        if (OVO_HAMMING_DIST_THR_LOW < best) continue;
+        assigned[l] = best_idx;
+        occ[best_idx] = 1;
+        ++num_matches;
+    }
+    return num_matches;
+}
+
+// one direction of match_keyframes_mutually: landmarks of keyframe A into keyframe B through pos_a = R_aw X + t_aw, pos_b = S_ba pos_a
+static void mutual_pass(const ovo_camera& cam_b, const ovo_grid_params& gp_b, const float* xs, const float* ys, const int32_t* octaves,
+                        const uint8_t* desc, int n_b, const double* pose_cw_a, const double* S_ba, const double* lm_pos_w,
+                        const float* lm_dist_min_max, const uint8_t* lm_desc, const uint8_t* lm_valid, int n_a, const float* scale_factors,
+                        int num_scale_levels, float log_scale_factor, float margin, std::vector<int>& out) {
+    Grid g;
+    build_grid(g, gp_b, xs, ys, n_b);
+    out.assign((size_t)n_a, -1);
+    const double* Pa = pose_cw_a;
+    for (int i = 0; i < n_a; ++i) {
+        if (lm_valid && !lm_valid[i]) continue;
+        const double* X = lm_pos_w + 3 * (size_t)i;
+        const double pa[3] = {(Pa[0] * X[0] + Pa[1] * X[1]) + Pa[2] * X[2] + Pa[9], (Pa[3] * X[0] + Pa[4] * X[1]) + Pa[5] * X[2] + Pa[10],
+                              (Pa[6] * X[0] + Pa[7] * X[1]) + Pa[8] * X[2] + Pa[11]};
+        double reproj[2];
+        float x_right;
+        if (!reproject_to_image(cam_b, gp_b, S_ba, pa, reproj, &x_right)) continue;
+        const double pb[3] = {(S_ba[0] * pa[0] + S_ba[1] * pa[1]) + S_ba[2] * pa[2] + S_ba[9],
+                              (S_ba[3] * pa[0] + S_ba[4] * pa[1]) + S_ba[5] * pa[2] + S_ba[10],
+                              (S_ba[6] * pa[0] + S_ba[7] * pa[1]) + S_ba[8] * pa[2] + S_ba[11]};
+        const double dist = std::sqrt((pb[0] * pb[0] + pb[1] * pb[1]) + pb[2] * pb[2]);
+        const float dmin = lm_dist_min_max[2 * i], dmax = lm_dist_min_max[2 * i + 1];
+        if (dist < dmin || dmax < dist) continue;
+        const float ratio = dmax / (float)dist;
+        int pred = (int)std::ceil(std::log(ratio) / log_scale_factor);
+        if (pred < 0) pred = 0;
+        else if (num_scale_levels <= pred) pred = num_scale_levels - 1;
+        const float r = margin * scale_factors[pred];
+        unsigned best = OVO_MAX_HAMMING_DIST;
+        int best_idx = -1;
+        for_keypoints_in_cell(g, xs, ys, octaves, (float)reproj[0], (float)reproj[1], r, -1, -1, [&](int idx) {
+            const int level = octaves[idx];
+            if (level < pred - 1 || pred < level) return;
+            const unsigned d = distance_32(lm_desc + (size_t)i * 32, desc + (size_t)idx * 32);
+            if (d < best) {
+                best = d;
+                best_idx = idx;
+            }
+        });
+        if (best <= OVO_HAMMING_DIST_THR_HIGH) out[(size_t)i] = best_idx;
+    }
+}
+
+// M4  projection::match_keyframes_mutually(keyfrm_1, keyfrm_2, matched_lms_in_keyfrm_1, s_12, rot_12, trans_12, margin) (expected:
+// src/openvslam/match/projection.cc; ORB-SLAM2 SearchBySim3): every unmatched live landmark of keyframe 1 is carried into keyframe 2
+// with Sim3_21 = [R_12^T / s_12 | -(R_12^T / s_12) t_12] and vice versa with Sim3_12 = [s_12 R_12 | t_12]; each side independently takes the
+// best Hamming candidate (no claim) in the window margin * sf[pred], levels [pred-1, pred], accept iff best <= THR_HIGH; a pair survives
+// only if both directions agree. lm_valid_k: keypoint k has a live landmark that is not already matched (for side 2: whose keypoint is not
+// the partner of an already matched landmark). matched_2_in_1[idx_1] = idx_2 or -1.
+int ovo_projection_match_keyframes_mutually(const ovo_camera* cam_1, const ovo_grid_params* gp_1, const float* xs_1, const float* ys_1,
+                                            const int32_t* octaves_1, const uint8_t* desc_1, int n1, const double* pose_cw_1,
+                                            const double* lm_pos_w_1, const float* lm_dist_1, const uint8_t* lm_desc_1, const uint8_t* lm_valid_1,
+                                            const ovo_camera* cam_2, const ovo_grid_params* gp_2, const float* xs_2, const float* ys_2,
+                                            const int32_t* octaves_2, const uint8_t* desc_2, int n2, const double* pose_cw_2,
+                                            const double* lm_pos_w_2, const float* lm_dist_2, const uint8_t* lm_desc_2, const uint8_t* lm_valid_2,
+                                            double s_12, const double* rot_12, const double* trans_12, const float* scale_factors,
+                                            int num_scale_levels, float log_scale_factor, float margin, int32_t* matched_2_in_1) {
+    double S12[12], S21[12];
+    for (int i = 0; i < 9; ++i) S12[i] = s_12 * rot_12[i];
+    for (int i = 0; i < 3; ++i) S12[9 + i] = trans_12[i];
+    const double inv_s = 1.0 / s_12;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) S21[3 * r + c] = inv_s * rot_12[3 * c + r];
+    for (int r = 0; r < 3; ++r) S21[9 + r] = -((S21[3 * r] * trans_12[0] + S21[3 * r + 1] * trans_12[1]) + S21[3 * r + 2] * trans_12[2]);
+    std::vector<int> m21, m12;
+    mutual_pass(*cam_2, *gp_2, xs_2, ys_2, octaves_2, desc_2, n2, pose_cw_1, S21, lm_pos_w_1, lm_dist_1, lm_desc_1, lm_valid_1, n1, scale_factors,
+                num_scale_levels, log_scale_factor, margin, m21);
+    mutual_pass(*cam_1, *gp_1, xs_1, ys_1, octaves_1, desc_1, n1, pose_cw_2, S12, lm_pos_w_2, lm_dist_2, lm_desc_2, lm_valid_2, n2, scale_factors,
+                num_scale_levels, log_scale_factor, margin, m12);
+    int num = 0;
+    for (int i = 0; i < n1; ++i) {
+        matched_2_in_1[i] = -1;
+        const int j = m21[(size_t)i];
+        if (j < 0) continue;
+        if (m12[(size_t)j] == i) {
+            matched_2_in_1[i] = j;
+            ++num;
+        }
+    }
+    return num;
+}
+
 // M2  robust::match_for_triangulation(keyfrm_1, keyfrm_2, E_12, matched_idx_pairs) + robust::check_epipolar_constraint
 // (expected: src/openvslam/match/robust.cc): common BoW nodes; keyframe-1 keypoints WITHOUT a landmark against keyframe-2
 // keypoints without a landmark that no earlier keypoint took; a candidate needs d <= THR_LOW and d <= the best so far (a later

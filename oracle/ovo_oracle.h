@@ -179,6 +179,23 @@ int ovo_projection_match_frame_and_keyframe(const ovo_camera* cam, const ovo_gri
                                             unsigned hamm_dist_thr, int check_orientation, int32_t* assigned);
 /* M2 robust::match_for_triangulation. has_lm_i[k] != 0 iff keyframe i's keypoint k already holds a landmark; x_right_i = stereo_x_right_
  * (NULL = monocular); bearings_i = n x 3 doubles; epipole_in_2 = keyfrm_1's centre as a bearing in keyfrm_2. matched_2_in_1[n1]. */
+int ovo_fuse_detect_duplication(const ovo_camera* cam, const ovo_grid_params* gp, const float* xs, const float* ys, const int32_t* octaves,
+                                const uint8_t* desc, int n, const double* sim3_cw, const double* lm_pos_w, const float* lm_dist_min_max,
+                                const double* lm_normal, const uint8_t* lm_desc, const uint8_t* lm_valid, int m, const float* scale_factors,
+                                int num_scale_levels, float log_scale_factor, float margin, int32_t* best_idx_out);
+int ovo_projection_match_by_sim3_transform(const ovo_camera* cam, const ovo_grid_params* gp, const float* xs, const float* ys,
+                                           const int32_t* octaves, const uint8_t* desc, const uint8_t* occupied, int n, const double* sim3_cw,
+                                           const double* lm_pos_w, const float* lm_dist_min_max, const double* lm_normal, const uint8_t* lm_desc,
+                                           const uint8_t* lm_valid, int m, const float* scale_factors, int num_scale_levels,
+                                           float log_scale_factor, float margin, int32_t* assigned);
+int ovo_projection_match_keyframes_mutually(const ovo_camera* cam_1, const ovo_grid_params* gp_1, const float* xs_1, const float* ys_1,
+                                            const int32_t* octaves_1, const uint8_t* desc_1, int n1, const double* pose_cw_1,
+                                            const double* lm_pos_w_1, const float* lm_dist_1, const uint8_t* lm_desc_1, const uint8_t* lm_valid_1,
+                                            const ovo_camera* cam_2, const ovo_grid_params* gp_2, const float* xs_2, const float* ys_2,
+                                            const int32_t* octaves_2, const uint8_t* desc_2, int n2, const double* pose_cw_2,
+                                            const double* lm_pos_w_2, const float* lm_dist_2, const uint8_t* lm_desc_2, const uint8_t* lm_valid_2,
+                                            double s_12, const double* rot_12, const double* trans_12, const float* scale_factors,
+                                            int num_scale_levels, float log_scale_factor, float margin, int32_t* matched_2_in_1);
 int ovo_robust_match_for_triangulation(const uint8_t* desc_1, const float* angles_1, const int32_t* octaves_1, const uint8_t* has_lm_1,
                                        const float* x_right_1, const double* bearings_1, int n1, const int32_t* node_ids_1,
                                        const int32_t* node_start_1, const int32_t* items_1, int nodes_1, const uint8_t* desc_2,

@@ -341,3 +341,120 @@ def test_robust_match_for_triangulation(match, synth, oracle, check_orientation,
     idx = np.nonzero(want >= 0)[0]
     assert gn == wn and np.array_equal(pairs, np.stack([idx, want[idx]], 1))
     assert wn > 50 and (h1[idx] == 0).all() and (h2[want[idx]] == 0).all()
+
+
+def _sim3_scene(synth, model, seed, scale=1.7):
+    """The fuse scene (landmarks back-projected from the keyframe's keypoints, some with a wrong range / normal / level) seen through
+    a Sim3 pose [sR | st]: the decomposition has to recover (R, t)."""
+    rows, cols, n = (960, 1920, 3000) if model == 1 else (720, 1280, 2000)
+    ck, cd, Tc, lk, lpw, ld, _, valid, intr = _last_and_current(synth, model, rows, cols, n, seed, 0.0)
+    m = len(lk)
+    rng = np.random.default_rng(seed + 1)
+    R, t = Tc[:, :3], Tc[:, 3]
+    v = lpw - (-R.T @ t)
+    dist = np.linalg.norm(v, axis=1)
+    sf = np.cumprod(np.concatenate([[1.0], np.full(7, 1.2)]).astype(np.float32)).astype(np.float32)
+    lvl = np.clip(lk["octave"] + rng.integers(0, 2, m), 0, 7)
+    dmax = (dist * sf[lvl] * rng.uniform(0.85, 1.0, m)).astype(np.float32)
+    dmin = (dmax / sf[7] * rng.uniform(0.5, 1.3, m)).astype(np.float32)
+    dmm = np.ascontiguousarray(np.stack([dmin, dmax], 1))
+    nrm = v / dist[:, None]
+    flip = rng.random(m) < 0.15
+    nrm[flip] = rng.normal(0, 1, (int(flip.sum()), 3))
+    S = np.concatenate([scale * R, (scale * t)[:, None]], 1)
+    return rows, cols, n, ck, cd, S, lpw, dmm, nrm, ld, valid, sf, intr
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_fuse_detect_duplication(match, synth, oracle, model):
+    from openvslam_amd import _lib
+    rows, cols, n, ck, cd, S, lpw, dmm, nrm, ld, valid, sf, (fx, fy, cx, cy) = _sim3_scene(synth, model, 80 + model)
+    cam = _lib.Camera(model, 0, fx, fy, cx, cy, 0.0, 0.0, cols, rows)
+    ocam = oracle.Camera(model, 0, fx, fy, cx, cy, 0.0, 0.0, cols, rows)
+    gp, ogp = match.grid_params(cols, rows), oracle.grid_params(cols, rows)
+    lsf = float(np.log(np.float32(1.2)))
+    w = match.fuse(0.6, max_targets=4096, max_queries=4096)
+    for margin in (4.0, 10.0):
+        got, gn = w.detect_duplication(cam, gp, ck, cd, S, lpw, dmm, nrm, ld, sf, lsf, margin, lm_valid=valid)
+        want, wn = oracle.fuse_detect_duplication(ocam, ogp, ck, cd, S, lpw, dmm, nrm, ld, sf, lsf, margin, lm_valid=valid)
+        assert gn == wn and np.array_equal(got, want)
+    assert wn > n // 20
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_projection_match_by_sim3_transform(match, synth, oracle, model):
+    from openvslam_amd import _lib
+    rows, cols, n, ck, cd, S, lpw, dmm, nrm, ld, valid, sf, (fx, fy, cx, cy) = _sim3_scene(synth, model, 90 + model, scale=0.6)
+    rng = np.random.default_rng(5)
+    # several landmarks per keypoint (duplicates later in the list) so that the sequential claim decides
+    extra = rng.integers(0, len(lpw), len(lpw) // 3)
+    lpw2 = np.concatenate([lpw, lpw[extra] + rng.normal(0, 0.002, (len(extra), 3))])
+    dmm2, nrm2, valid2 = np.concatenate([dmm, dmm[extra]]), np.concatenate([nrm, nrm[extra]]), np.concatenate([valid, valid[extra]])
+    ld2 = np.concatenate([ld, np.stack([synth.flip_bits(rng, ld[i], 6) for i in extra])])
+    occ = (rng.random(n) < 0.1).astype(np.uint8)
+    cam = _lib.Camera(model, 0, fx, fy, cx, cy, 0.0, 0.0, cols, rows)
+    ocam = oracle.Camera(model, 0, fx, fy, cx, cy, 0.0, 0.0, cols, rows)
+    gp, ogp = match.grid_params(cols, rows), oracle.grid_params(cols, rows)
+    lsf = float(np.log(np.float32(1.2)))
+    w = match.projection(0.9, False, max_targets=4096, max_queries=8192, max_entries=1 << 20)
+    for margin in (5.0, 10.0):
+        got, gn = w.match_by_Sim3_transform(cam, gp, ck, cd, S, lpw2, dmm2, nrm2, ld2, sf, lsf, margin, keyfrm_occupied=occ, lm_valid=valid2)
+        want, wn = oracle.projection_match_by_sim3_transform(ocam, ogp, ck, cd, S, lpw2, dmm2, nrm2, ld2, sf, lsf, margin, kf_occupied=occ,
+                                                             lm_valid=valid2)
+        assert gn == wn and np.array_equal(got, want)
+    assert wn > n // 20
+    hit = want[want >= 0]
+    assert len(np.unique(hit)) == len(hit) and not occ[hit].any()
+
+
+@pytest.mark.parametrize("s_12", [1.0, 1.35])
+def test_projection_match_keyframes_mutually(match, synth, oracle, s_12):
+    """Two keyframes of the same points; keyframe 2's map is s_12 times smaller (scale drift), Sim3_12 = (s_12, R_12, t_12) undoes it."""
+    from openvslam_amd import _lib
+    rows, cols, n = 720, 1280, 1800
+    fx, fy, cx, cy, R1, t1, R2, t2, X, project = _two_view_geometry(rows, cols, n, 21)
+    rng = np.random.default_rng(22)
+    u1, p1 = project(R1, t1)
+    u2, p2 = project(R2, t2)
+    k1, d1 = synth.synth_keypoints(n, rows, cols, seed=33)
+    k2 = k1.copy()
+    k1["x"], k1["y"] = u1[:, 0] + rng.normal(0, 0.5, n), u1[:, 1] + rng.normal(0, 0.5, n)
+    k2["x"], k2["y"] = u2[:, 0] + rng.normal(0, 0.5, n), u2[:, 1] + rng.normal(0, 0.5, n)
+    k2["octave"] = np.clip(k1["octave"] + rng.integers(-1, 2, n), 0, 7)
+    d2 = np.stack([synth.flip_bits(rng, d1[i], 40) for i in range(n)])
+    dup = rng.integers(0, n, n // 6)                 # confusable descriptors: the two directions disagree for some
+    d2[dup] = np.stack([synth.flip_bits(rng, d1[(i + 7) % n], 25) for i in dup])
+    perm = rng.permutation(n)
+    k2, d2, X2, p2 = k2[perm], d2[perm], X[perm] / s_12, p2[perm]
+    T1 = np.concatenate([R1, t1[:, None]], 1)
+    T2 = np.concatenate([R2, (t2 / s_12)[:, None]], 1)
+    R12, t12 = R1 @ R2.T, t1 - R1 @ R2.T @ t2
+    sf = np.cumprod(np.concatenate([[1.0], np.full(7, 1.2)]).astype(np.float32)).astype(np.float32)
+    inv = np.argsort(perm)
+    # landmark of keypoint i in keyframe 1 lands on keypoint inv[i] of keyframe 2 at distance |p2| / s_12; and the other way round |p1|
+    dist_1_in_2 = np.linalg.norm(p2[inv], axis=1) / s_12
+    dist_2_in_1 = np.linalg.norm(p1[perm], axis=1)
+
+    def ranges(dist, octave):
+        lvl = np.clip(octave + rng.integers(0, 2, n), 0, 7)
+        dmax = (dist * sf[lvl] * rng.uniform(0.85, 1.0, n)).astype(np.float32)
+        dmin = (dmax / sf[7] * rng.uniform(0.5, 1.3, n)).astype(np.float32)
+        return np.ascontiguousarray(np.stack([dmin, dmax], 1))
+
+    dm1, dm2 = ranges(dist_1_in_2, k2["octave"][inv]), ranges(dist_2_in_1, k1["octave"][perm])
+    l1 = np.stack([synth.flip_bits(rng, d1[i], 10) for i in range(n)])
+    l2 = np.stack([synth.flip_bits(rng, d2[i], 10) for i in range(n)])
+    v1, v2 = (rng.random(n) < 0.85).astype(np.uint8), (rng.random(n) < 0.85).astype(np.uint8)
+    cam = _lib.Camera(0, 0, fx, fy, cx, cy, 0.0, 0.0, cols, rows)
+    ocam = oracle.Camera(0, 0, fx, fy, cx, cy, 0.0, 0.0, cols, rows)
+    gp, ogp = match.grid_params(cols, rows), oracle.grid_params(cols, rows)
+    lsf = float(np.log(np.float32(1.2)))
+    w = match.projection(0.9, False, max_targets=4096, max_queries=4096)
+    for margin in (7.5, 15.0):
+        gn, got = w.match_keyframes_mutually(cam, gp, k1, d1, T1, X, dm1, l1, v1, k2, d2, T2, X2, dm2, l2, v2, s_12, R12, t12, sf, lsf, margin)
+        wn, want = oracle.projection_match_keyframes_mutually(ocam, ogp, k1, d1, T1, X, dm1, l1, v1, k2, d2, T2, X2, dm2, l2, v2, s_12, R12, t12,
+                                                              sf, lsf, margin)
+        assert gn == wn and np.array_equal(got, want)
+    assert wn > n // 5
+    ok = want >= 0
+    assert (want[ok] == inv[ok]).mean() > 0.9 and v1[ok].all() and v2[want[ok]].all()
