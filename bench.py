@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true", help="skip the local-BA side section (profiling runs)")
     ap.add_argument("--pipeline", type=int, default=1, help="sub-batches of the extract issued on overlapping internal streams (1 = off)")
+    ap.add_argument("--overlap", type=int, default=1, help="1: matching of step k runs on a second stream under the extraction of step "
+                                                            "k+1 (double-buffered outputs); 0: one stream, strictly serial")
     args = ap.parse_args()
 
     import torch
@@ -89,22 +91,43 @@ def main():
         ex.set_pipeline(args.pipeline)
     cap = ex.max_keypoints
     mt = match.robust(LOWE_RATIO, False, max_n1=cap, max_n2=cap, max_batch=B, device=local_rank)
-    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
-    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
-    d_cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
-    d_pairs = torch.zeros((B, cap, 2), dtype=torch.int32, device="cuda")
-    d_mcnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    # outputs are double-buffered so that step k's matching (stream B) can run under step k+1's extraction (stream A)
+    n_buf = 2 if args.overlap else 1
+    bufs = []
+    for _ in range(n_buf):
+        bufs.append(dict(kps=torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"),
+                         desc=torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
+                         cnt=torch.zeros((B,), dtype=torch.int32, device="cuda"),
+                         pairs=torch.zeros((B, cap, 2), dtype=torch.int32, device="cuda"),
+                         mcnt=torch.zeros((B,), dtype=torch.int32, device="cuda"),
+                         desc_prev=torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
+                         cnt_prev=torch.zeros((B,), dtype=torch.int32, device="cuda")))
+    d_cnt, d_mcnt = bufs[0]["cnt"], bufs[0]["mcnt"]
     # frame b (keyframe side, idx_2) is matched against frame b-1 inside its 8-frame scene (frame side, idx_1)
     prev = torch.tensor([(b - 1) if b % 8 else min(b + 7, B - 1) for b in range(B)], dtype=torch.long, device="cuda")
-    d_desc_prev = torch.zeros_like(d_desc)
-    d_cnt_prev = torch.zeros_like(d_cnt)
-    stream = torch.cuda.current_stream().cuda_stream
+    s_ext = torch.cuda.current_stream()
+    s_match = torch.cuda.Stream() if args.overlap else s_ext
+    ev_ext = [torch.cuda.Event() for _ in range(n_buf)]
+    ev_match = [torch.cuda.Event() for _ in range(n_buf)]
+    step_no = [0]
 
     def step():
-        ex.extract_batch_dev(d_frames, d_kps, d_desc, d_cnt, stream=stream)
-        torch.index_select(d_desc, 0, prev, out=d_desc_prev)      # gather "previous frame" descriptor blocks (device, same stream)
-        torch.index_select(d_cnt, 0, prev, out=d_cnt_prev)
-        mt.brute_force_match_batch_dev(d_desc_prev, d_cnt_prev, d_desc, d_cnt, d_pairs, d_mcnt, stream=stream)
+        k = step_no[0] % n_buf
+        step_no[0] += 1
+        b = bufs[k]
+        if args.overlap:
+            s_ext.wait_event(ev_match[k])      # the matcher of two steps ago has released this buffer set
+        ex.extract_batch_dev(d_frames, b["kps"], b["desc"], b["cnt"], stream=s_ext.cuda_stream)
+        if args.overlap:
+            ev_ext[k].record(s_ext)
+            s_match.wait_event(ev_ext[k])
+        with torch.cuda.stream(s_match):
+            torch.index_select(b["desc"], 0, prev, out=b["desc_prev"])   # gather "previous frame" descriptor blocks (device)
+            torch.index_select(b["cnt"], 0, prev, out=b["cnt_prev"])
+            mt.brute_force_match_batch_dev(b["desc_prev"], b["cnt_prev"], b["desc"], b["cnt"], b["pairs"], b["mcnt"],
+                                           stream=s_match.cuda_stream)
+            if args.overlap:
+                ev_match[k].record(s_match)
 
     def barrier():
         if world > 1:
@@ -203,7 +226,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 1920x1080 mono, 8 pyramid levels (x1.2), 2000 ORB features, extract + "
                                    "robust::brute_force_match (thr 50, ratio 0.9) against the previous frame",
-                       "frames_per_step_per_gpu": B, "sharding": "frames across ranks, no collective"},
+                       "frames_per_step_per_gpu": B, "sharding": "frames across ranks, no collective",
+                       "schedule": ("matching of step k on a second stream under the extraction of step k+1 (double-buffered)"
+                                    if args.overlap else "one stream, serial")},
             "frames_per_sec": round(B * world * args.steps / elapsed, 2),
             "matches_per_sec": round(matches_all * args.steps / elapsed, 1),
             "hamming_distances_per_sec": round(pairs_all * args.steps / elapsed, 1),

@@ -189,6 +189,7 @@ bool build_geometry(const ovs_orb* h, int rows, int cols, FrameGeo& geo, std::ve
     }
     geo.total_cells = cell_base;
     geo.total_kp_cap = kp_base;
+    for (int l = 0; l < OVS_MAX_LEVELS; ++l) geo.cell_base_tab[l] = l < L ? geo.lv[l].cell_base : INT32_MAX;
     return true;
 }
 

@@ -6,8 +6,7 @@
 //   corner(t) <=> S(p) > t,  cornerScore = S(p) - 1 (independent of t for detected corners),
 //   NMS keeps p <=> S(p) > t and S(p) > S(q) for the 8 neighbours q inside the SAME cell's testable area
 //   (neighbours with S(q) <= t score 0 upstream, but then S(q) <= t < S(p) anyway).
-// So one threshold-free score plane per cell serves both thresholds: the cell uses ini_fast_thr if any NMS survivor
-// exceeds it, else min_fast_thr ("if keypts_in_cell.empty() retry") -- no second pass over the pixels.
+// So the cell uses ini_fast_thr if any NMS survivor exceeds it, else min_fast_thr ("if keypts_in_cell.empty() retry").
 // The 64x64 testable areas of neighbouring cells tile the level exactly (cell stride 64, overlap 6 = two 3-px dead
 // frames), so every pixel is scored once.
 //
@@ -22,11 +21,13 @@
 // 16-bit integer ops issue at one wave-instruction per 4 cycles), so instructions per pixel are the only currency.
 //
 // Mapping: one 256-thread workgroup per cell; the <=70x70 u8 tile is staged in LDS with aligned 16-byte loads (cell
-// origin x = 19+64j => tile origin 16+64j). Thread (run, rp) scores pixels [8*run, 8*run+8) of rows 2*rp and 2*rp+1
-// from one 8x5-word register window (the two rows share 6 of their 7 window rows). Scores go to an LDS score map; NMS is
-// evaluated on packed pairs as well (3x3 max via shared horizontal maxima); survivors are appended to the (frame, level)
-// candidate list with ONE global atomic per workgroup. List order is irrelevant downstream (the quad-tree kernel uses
-// counts and an explicit emission-order key).
+// origin x = 19+64j => tile origin 16+64j). Two-stage evaluation (v3; v2 scored every pixel with the 75-op network above, which
+// is still the definition of S): thread (run, rp) runs the 10-op cardinal test on pixels [8*run, 8*run+8) of rows 2*rp and
+// 2*rp+1 as packed pairs; the ~5 % that pass are compacted into an LDS list and scored exactly, one pixel per lane, with the
+// same network in 32-bit ops; NMS reads the sparse score map (unscored pixels hold 0, and indeed have S <= t). The cell is
+// processed with ini_fast_thr and, only if no NMS survivor came out, again with min_fast_thr. Survivors are appended to the
+// (frame, level) candidate list with ONE global atomic per workgroup. List order is irrelevant downstream (the quad-tree
+// kernel uses counts and an explicit emission-order key).
 #include "ovs_common.h"
 
 namespace ovs {
@@ -116,56 +117,109 @@ __device__ __forceinline__ s16x2 fast_strength_pair(const uint32_t (&w)[8][5]) {
     return vmax(vmax(c - min_a, max_b - c), zero);
 }
 
-// bytes (B, B+1) of the 16-byte row {w0..w3} as a packed pair
-template <int B>
-__device__ __forceinline__ s16x2 row_pair(const uint32_t (&w)[4]) {
-    return as_s16x2(pick2<(B & 3)>(w[(B >> 2) + ((B & 3) == 3 ? 1 : 0)], w[B >> 2]));
+// ---- sparse evaluation -------------------------------------------------------------------------------------------------------
+// S(p) > t needs 9 contiguous ring pixels all brighter than c + t (or all darker than c - t); any 9-arc of the 16-ring contains two
+// ADJACENT cardinal points (ring positions 0, 4, 8, 12), so with up / dn / lf / rt the four cardinals
+//   max over adjacent cardinal pairs of min(a, b) = min(max(up, dn), max(lf, rt)) =: bc   must exceed c + t, or
+//   min over adjacent cardinal pairs of max(a, b) = max(min(up, dn), min(lf, rt)) =: dc   must lie below c - t.
+// 6 packed min/max + 4 more ops per pixel pair instead of 75, and on BASELINE-like frames it rejects ~95 % of the pixels at
+// ini_fast_thr = 20 (61 % at min_fast_thr = 7). Only the survivors get the exact S (one pixel per lane, 32-bit ops).
+template <int P, int R0>
+__device__ __forceinline__ uint32_t cardinal_test_pair(const uint32_t (&w)[8][5], s16x2 thrv) {
+    const s16x2 c = window_pair<6 + P, R0 + 3>(w);
+    const s16x2 up = window_pair<6 + P, R0 + 0>(w), dn = window_pair<6 + P, R0 + 6>(w);
+    const s16x2 lf = window_pair<3 + P, R0 + 3>(w), rt = window_pair<9 + P, R0 + 3>(w);
+    const s16x2 bc = umin2(umax2(up, dn), umax2(lf, rt));
+    const s16x2 dc = umax2(umin2(up, dn), umin2(lf, rt));
+    const s16x2 m = vmax(bc - c, c - dc);
+    return as_u32((thrv - m) >> 15);   // each half all-ones iff m > thr
 }
 
-// Horizontal neighbourhood maxima of one score-map row around the run's 8 pixels (row bytes: pixel p at byte 4+p).
-// h2[i] = max(s[x-1], s[x+1]), h3[i] = max(h2, s[x]) for the pixel pair x = 2i, 2i+1.
-__device__ __forceinline__ void row_hmax(const uint32_t (&w)[4], s16x2 (&h2)[4], s16x2 (&h3)[4]) {
-    const s16x2 l0 = row_pair<3>(w), l1 = row_pair<5>(w), l2 = row_pair<7>(w), l3 = row_pair<9>(w), l4 = row_pair<11>(w);
-    h2[0] = umax2(l0, l1);
-    h2[1] = umax2(l1, l2);
-    h2[2] = umax2(l2, l3);
-    h2[3] = umax2(l3, l4);
-    h3[0] = umax3(l0, l1, row_pair<4>(w));
-    h3[1] = umax3(l1, l2, row_pair<6>(w));
-    h3[2] = umax3(l2, l3, row_pair<8>(w));
-    h3[3] = umax3(l3, l4, row_pair<10>(w));
+// exact S of one pixel; p = LDS address of the top-left byte of its 7x7 neighbourhood in the staged tile (pitch kTileWords * 4)
+__device__ __forceinline__ uint32_t fast_strength_one(const uint8_t* p) {
+    constexpr int kP = kTileWords * 4;
+    const uint32_t c = p[3 * kP + 3];
+    uint32_t r[16];
+    r[0] = p[6 * kP + 3];
+    r[1] = p[6 * kP + 4];
+    r[2] = p[5 * kP + 5];
+    r[3] = p[4 * kP + 6];
+    r[4] = p[3 * kP + 6];
+    r[5] = p[2 * kP + 6];
+    r[6] = p[1 * kP + 5];
+    r[7] = p[0 * kP + 4];
+    r[8] = p[0 * kP + 3];
+    r[9] = p[0 * kP + 2];
+    r[10] = p[1 * kP + 1];
+    r[11] = p[2 * kP + 0];
+    r[12] = p[3 * kP + 0];
+    r[13] = p[4 * kP + 0];
+    r[14] = p[5 * kP + 1];
+    r[15] = p[6 * kP + 2];
+    uint32_t pmx[8], pmn[8], qmx[8], qmn[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        pmx[i] = max(r[2 * i], r[2 * i + 1]);
+        pmn[i] = min(r[2 * i], r[2 * i + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        qmx[i] = max(pmx[i], pmx[(i + 1) & 7]);
+        qmn[i] = min(pmn[i], pmn[(i + 1) & 7]);
+    }
+    uint32_t min_a = 255u, max_b = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t ea = r[(2 * i + 15) & 15], eb = r[(2 * i + 8) & 15];
+        min_a = min(min_a, max(max(qmx[i], qmx[(i + 2) & 7]), min(ea, eb)));
+        max_b = max(max_b, min(min(qmn[i], qmn[(i + 2) & 7]), max(ea, eb)));
+    }
+    const int s = max((int)c - (int)min_a, (int)max_b - (int)c);
+    return (uint32_t)max(s, 0);
 }
+
+constexpr int kMaxSurvivors = 1024;   // NMS survivors are pairwise non-adjacent: at most 32 x 32 per 64 x 64 cell
 
 __global__ __launch_bounds__(256) void k_fast_cells(const FrameGeo* __restrict__ geo, const uint8_t* __restrict__ img0, size_t stride0,
                                                    size_t frame_stride0, const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                                    uint64_t* __restrict__ cand, size_t cand_frame_entries,
                                                    uint32_t* __restrict__ cand_count, const uint8_t* __restrict__ mask,
-                                                   int mask_rows) {
+                                                   int batch) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[kTileRowsMax][kTileWords];
-    __shared__ uint32_t smap[kSmapRows][kSmapWords];
-    __shared__ uint32_t wave_tot[4];
-    __shared__ uint32_t list_base;
+    __shared__ __attribute__((aligned(16))) uint32_t smap[kSmapRows][kSmapWords];
+    __shared__ uint16_t clist[4][kCellSize * kCellSize / 4];   // per wave: its pixels that passed the cardinal test, (y << 8) | x
+    __shared__ uint32_t olist[kMaxSurvivors];                  // NMS survivors: (S << 16) | (y << 8) | x
+    __shared__ uint32_t wave_cnt[4];
+    __shared__ uint32_t n_out, list_base;
 
     const int tid = threadIdx.x;
-    const int frame = blockIdx.y;
     const int L = geo->num_levels;
-    // XCD-aware cell order: workgroup b runs on XCD b % 8 (each XCD has its own L2), so XCD k takes the k-th CONTIGUOUS eighth of the
+    // XCD-aware work order. Workgroup b runs on XCD b % 8 (each XCD has its own L2), so XCD k takes the k-th CONTIGUOUS eighth of every
     // frame's cells: neighbouring cells, which share tile halo lines, then hit the same L2 instead of fetching the line once per XCD
-    // (fabric traffic 3.0x -> see profiles/). The grid is padded to a multiple of 8; surplus workgroups exit.
-    const int per_xcd = gridDim.x >> 3;
-    const int cell_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    // (fabric traffic 3.0x -> see profiles/). Inside an XCD's share the FRAME index runs fastest: the workgroups in flight at any moment
+    // then reserve list space on `batch` times as many (frame, level) counters -- with frame-major order all of them hammered the 8
+    // counters of one frame, and same-address atomics at the fabric side cost ~0.05 ms per launch. The grid is 8 * per_xcd * batch.
+    const int per_xcd = (geo->total_cells + 7) >> 3;
+    const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+    const int slot = idx / batch, frame = idx - slot * batch;
+    const int cell_id = xcd * per_xcd + slot;
     if (cell_id >= geo->total_cells) return;
+    // The prologue is a chain of dependent scalar loads in front of the tile fetch, and nothing else can run in this workgroup until the
+    // tile is in LDS: keep the chain at three round trips (kernel arguments -> header + level table -> the level's geometry).
     int level = 0;
-    for (int l = 1; l < L; ++l)
-        if (cell_id >= geo->lv[l].cell_base) level = l;
+#pragma unroll
+    for (int l = 1; l < OVS_MAX_LEVELS; ++l) level += (cell_id >= geo->cell_base_tab[l]) ? 1 : 0;
     const LevelGeo& g = geo->lv[level];
-    const int cell = cell_id - g.cell_base;
-    const int ci = (int)(((float)cell + 0.5f) * g.inv_ncx), cj = cell - ci * g.ncx;   // exact: cell < 2^22 (see orb_pyramid.hip)
+    const int g_ncx = g.ncx, g_cell_base = g.cell_base, g_max_bx = g.max_bx, g_max_by = g.max_by, g_pitch = g.pitch;
+    const float g_inv_ncx = g.inv_ncx, scale = g.scale;
+    const int64_t g_plane_off = g.plane_off;
+    const int cell = cell_id - g_cell_base;
+    const int ci = (int)(((float)cell + 0.5f) * g_inv_ncx), cj = cell - ci * g_ncx;   // exact: cell < 2^22 (see orb_pyramid.hip)
 
     const int min_x = kOrbPatchRadius + cj * kCellSize, min_y = kOrbPatchRadius + ci * kCellSize;
     int max_x = min_x + kCellSize + kCellOverlap, max_y = min_y + kCellSize + kCellOverlap;
-    if (g.max_bx < max_x) max_x = g.max_bx;
-    if (g.max_by < max_y) max_y = g.max_by;
+    if (g_max_bx < max_x) max_x = g_max_bx;
+    if (g_max_by < max_y) max_y = g_max_by;
     const int cw = max_x - min_x, ch = max_y - min_y;
     const int iw = cw - 6, ih = ch - 6;   // testable area of this cell (> 0 for every valid cell)
 
@@ -175,24 +229,15 @@ __global__ __launch_bounds__(256) void k_fast_cells(const FrameGeo* __restrict__
         img = img0 + (size_t)frame * frame_stride0;
         pitch = (int)stride0;
     } else {
-        img = pyr + (size_t)frame * pyr_frame_bytes + g.plane_off;
-        pitch = g.pitch;
-    }
-    const float scale = g.scale;
-    const uint8_t* fmask = mask ? mask + (size_t)frame * frame_stride0 : nullptr;   // same layout as the level-0 frames
-    (void)mask_rows;
-    // upstream: skip the cell if one of its corners is masked (mask is indexed in level-0 coordinates, float scale, trunc)
-    if (fmask) {
-        auto in_mask = [&](unsigned y, unsigned x) {
-            return fmask[(size_t)(unsigned)(y * scale) * stride0 + (unsigned)(x * scale)] == 0;
-        };
-        if (in_mask(min_y, min_x) || in_mask(max_y, min_x) || in_mask(min_y, max_x) || in_mask(max_y, max_x)) return;
+        img = pyr + (size_t)frame * pyr_frame_bytes + g_plane_off;
+        pitch = g_pitch;
     }
 
-    // ---- stage the tile: tile byte u of row r <-> image (min_x - 3 + u, min_y + r); min_x - 3 = 16 + 64*cj
+    // ---- fetch the tile: tile byte u of row r <-> image (min_x - 3 + u, min_y + r); min_x - 3 = 16 + 64*cj is 16-byte aligned. The 70 x 5
+    //      16-byte chunks go two per thread (the second for tid < 94), BOTH requested before either is waited for.
     const int ax0 = min_x - 3;
     const bool vec16 = ((pitch & 15) == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0);
-    for (int idx = tid; idx < kTileRowsMax * 5; idx += 256) {
+    auto fetch_chunk = [&](int idx) -> uint4 {
         const int r = idx / 5, q = idx - r * 5;
         uint4 v = {0u, 0u, 0u, 0u};
         const int gx = ax0 + 16 * q;
@@ -208,153 +253,159 @@ __global__ __launch_bounds__(256) void k_fast_cells(const FrameGeo* __restrict__
                 if (gx + 16 <= pitch) v.w = p4[3];
             }
         }
-        *reinterpret_cast<uint4*>(&tile[r][4 * q]) = v;
+        return v;
+    };
+    constexpr int kChunks = kTileRowsMax * 5;
+    const uint4 va = fetch_chunk(tid);
+    uint4 vb = {0u, 0u, 0u, 0u};
+    if (tid + 256 < kChunks) vb = fetch_chunk(tid + 256);
+
+    const uint8_t* fmask = mask ? mask + (size_t)frame * frame_stride0 : nullptr;   // same layout as the level-0 frames
+    // upstream: skip the cell if one of its corners is masked (mask is indexed in level-0 coordinates, float scale, trunc)
+    if (fmask) {
+        auto in_mask = [&](unsigned y, unsigned x) {
+            return fmask[(size_t)(unsigned)(y * scale) * stride0 + (unsigned)(x * scale)] == 0;
+        };
+        if (in_mask(min_y, min_x) || in_mask(max_y, min_x) || in_mask(min_y, max_x) || in_mask(max_y, max_x)) return;
     }
-    // zero frame of the score map (interior is fully written below)
-    if (tid < kSmapWords) {
-        smap[0][tid] = 0;
-        smap[kSmapRows - 1][tid] = 0;
-    } else if (tid >= 64 && tid < 128) {
-        smap[tid - 63][0] = 0;
-        smap[tid - 63][kSmapWords - 1] = 0;
+
+    // the score map holds S for the pixels that were evaluated and 0 elsewhere (pixel (x, y) at byte 4 + x of row y + 1)
+    uint32_t* const smap_flat = &smap[0][0];
+    static_assert((kSmapRows * kSmapWords) % 4 == 0, "score map is cleared with 16-byte stores");
+    for (int i = tid; i < kSmapRows * kSmapWords / 4; i += 256) reinterpret_cast<uint4*>(smap_flat)[i] = uint4{0u, 0u, 0u, 0u};
+    if (tid == 0) n_out = 0;
+    if (tid < 4) wave_cnt[tid] = 0;
+    {
+        const int r = tid / 5, q = tid - r * 5;
+        *reinterpret_cast<uint4*>(&tile[r][4 * q]) = va;
+        if (tid + 256 < kChunks) {
+            const int r2 = (tid + 256) / 5, q2 = (tid + 256) - r2 * 5;
+            *reinterpret_cast<uint4*>(&tile[r2][4 * q2]) = vb;
+        }
     }
-    __syncthreads();
 
     const int run = tid & 7, rp = tid >> 3;
     const int c0 = run * 8, row0 = 2 * rp;
-    // ---- scores of 2 rows x 8 pixels, packed pairs: sa[i] = row0 pixels (2i, 2i+1), sb[i] = row0+1
-    s16x2 sa[4], sb[4];
-    {
-        uint32_t w[8][5];
+    const int lane = tid & 63, wv = tid >> 6;
+    // candidate-mask layout: pair j (pixels c0 + 2j, c0 + 2j + 1) of row row0 -> bits j and 16 + j; of row row0 + 1 -> bits 4 + j and 20 + j
+    uint32_t valid = 0x00FF00FFu;
+    if (iw < kCellSize || ih < kCellSize) {   // testable area clipped by the level border (workgroup-uniform)
+        valid = 0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const uint2 a = *reinterpret_cast<const uint2*>(&tile[row0 + r][2 * run]);
-            const uint2 b = *reinterpret_cast<const uint2*>(&tile[row0 + r][2 * run + 2]);
-            w[r][0] = a.x;
-            w[r][1] = a.y;
-            w[r][2] = b.x;
-            w[r][3] = b.y;
+        for (int j = 0; j < 4; ++j) {
+            const int x = c0 + 2 * j;
+            const uint32_t colm = (x < iw ? 1u : 0u) | (x + 1 < iw ? 0x10000u : 0u);
+            valid |= (row0 < ih ? colm : 0u) << j;
+            valid |= (row0 + 1 < ih ? colm : 0u) << (4 + j);
+        }
+    }
+    const uint8_t* const tbytes = reinterpret_cast<const uint8_t*>(&tile[0][0]);
+    uint8_t* const sbytes = reinterpret_cast<uint8_t*>(smap_flat);
+    uint64_t* const list = cand + (size_t)frame * cand_frame_entries + g.cand_off;
+    const uint32_t cap = (uint32_t)g.cand_cap;
+    __syncthreads();
+
+    // the part of the 8x5-word window the cardinal test reads: rows 0, 1, 6, 7 words 1..3 and rows 3, 4 words 0..4
+    uint32_t w[8][5];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r == 2 || r == 5) continue;
+        const uint2 b = *reinterpret_cast<const uint2*>(&tile[row0 + r][2 * run + 2]);
+        w[r][1] = tile[row0 + r][2 * run + 1];
+        w[r][2] = b.x;
+        w[r][3] = b.y;
+        if (r == 3 || r == 4) {
+            w[r][0] = tile[row0 + r][2 * run];
             w[r][4] = tile[row0 + r][2 * run + 4];
         }
-        sa[0] = fast_strength_pair<0, 0>(w);
-        sa[1] = fast_strength_pair<2, 0>(w);
-        sa[2] = fast_strength_pair<4, 0>(w);
-        sa[3] = fast_strength_pair<6, 0>(w);
-        sb[0] = fast_strength_pair<0, 1>(w);
-        sb[1] = fast_strength_pair<2, 1>(w);
-        sb[2] = fast_strength_pair<4, 1>(w);
-        sb[3] = fast_strength_pair<6, 1>(w);
     }
-    // outside the testable area -> 0 (tile bytes there are padding or belong to the next cell)
-    {
-        const uint32_t ra = (row0 < ih) ? 0xFFFFFFFFu : 0u, rb = (row0 + 1 < ih) ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int x = c0 + 2 * i;
-            const uint32_t m = (x + 1 < iw) ? 0xFFFFFFFFu : ((x < iw) ? 0x0000FFFFu : 0u);
-            sa[i] = as_s16x2(as_u32(sa[i]) & m & ra);
-            sb[i] = as_s16x2(as_u32(sb[i]) & m & rb);
-        }
-    }
-    // score map rows (pixel row + 1), pixel p of the run at byte 4 + c0 + p
-    {
-        constexpr uint32_t pack = 0x06040200u;   // bytes 0,2 of src1 then bytes 0,2 of src0
-        smap[row0 + 1][1 + 2 * run] = __builtin_amdgcn_perm(as_u32(sa[1]), as_u32(sa[0]), pack);
-        smap[row0 + 1][2 + 2 * run] = __builtin_amdgcn_perm(as_u32(sa[3]), as_u32(sa[2]), pack);
-        smap[row0 + 2][1 + 2 * run] = __builtin_amdgcn_perm(as_u32(sb[1]), as_u32(sb[0]), pack);
-        smap[row0 + 2][2 + 2 * run] = __builtin_amdgcn_perm(as_u32(sb[3]), as_u32(sb[2]), pack);
-    }
-    __syncthreads();
 
-    // ---- NMS (strict, 8 neighbours inside the cell): rows U = row0-1, A = row0, B = row0+1, D = row0+2
-    int above_ini = 0;
-    {
-        uint32_t wu[4], wa[4], wb[4], wd[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            wu[i] = smap[row0 + 0][2 * run + i];
-            wa[i] = smap[row0 + 1][2 * run + i];
-            wb[i] = smap[row0 + 2][2 * run + i];
-            wd[i] = smap[row0 + 3][2 * run + i];
+    int thr = geo->ini_thr;
+    for (;;) {
+        // ---- 1. cardinal test on packed pairs -> candidate mask
+        uint32_t cmask = 0;
+        {
+            const s16x2 thrv = {(short)thr, (short)thr};
+            cmask |= cardinal_test_pair<0, 0>(w, thrv) & 0x00010001u;
+            cmask |= cardinal_test_pair<2, 0>(w, thrv) & 0x00020002u;
+            cmask |= cardinal_test_pair<4, 0>(w, thrv) & 0x00040004u;
+            cmask |= cardinal_test_pair<6, 0>(w, thrv) & 0x00080008u;
+            cmask |= cardinal_test_pair<0, 1>(w, thrv) & 0x00100010u;
+            cmask |= cardinal_test_pair<2, 1>(w, thrv) & 0x00200020u;
+            cmask |= cardinal_test_pair<4, 1>(w, thrv) & 0x00400040u;
+            cmask |= cardinal_test_pair<6, 1>(w, thrv) & 0x00800080u;
+            cmask &= valid;
         }
-        s16x2 h2u[4], h3u[4], h2a[4], h3a[4], h2b[4], h3b[4], h2d[4], h3d[4];
-        row_hmax(wu, h2u, h3u);
-        row_hmax(wa, h2a, h3a);
-        row_hmax(wb, h2b, h3b);
-        row_hmax(wd, h2d, h3d);
-        s16x2 top = {0, 0};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const s16x2 na = umax3(h3u[i], h2a[i], h3b[i]);
-            const s16x2 nb = umax3(h3a[i], h2b[i], h3d[i]);
-            // keep s where s > neighbours: (n - s) < 0  -> arithmetic shift gives an all-ones half
-            sa[i] = sa[i] & ((na - sa[i]) >> 15);
-            sb[i] = sb[i] & ((nb - sb[i]) >> 15);
-            top = umax3(top, sa[i], sb[i]);
+        // ---- 2. compact the wave's candidates into its own list segment (order is irrelevant; no workgroup barrier needed: a wave's LDS
+        //         operations complete in order, and the wave is the only reader of its segment)
+        const int n_mine = __popc(cmask);
+        uint32_t pos = n_mine ? atomicAdd(&wave_cnt[wv], (uint32_t)n_mine) : 0u;
+        uint16_t* const my_list = clist[wv];
+        while (cmask) {
+            const int b = __ffs(cmask) - 1;
+            cmask &= cmask - 1;
+            const int j = b & 3, rowsel = (b >> 2) & 1, hi = b >> 4;
+            my_list[pos++] = (uint16_t)(((row0 + rowsel) << 8) | (c0 + 2 * j + hi));
         }
-        above_ini = (top.x > geo->ini_thr) | (top.y > geo->ini_thr);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int n_cand = (int)*reinterpret_cast<volatile uint32_t*>(&wave_cnt[wv]);
+        // ---- 3. exact S for the wave's candidates, one per lane, into the shared score map
+        for (int i = lane; i < n_cand; i += 64) {
+            const uint32_t e = my_list[i];
+            const int x = e & 255, y = e >> 8;
+            const uint32_t sc = fast_strength_one(tbytes + y * (kTileWords * 4) + x + 3);
+            sbytes[(y + 1) * (kSmapWords * 4) + 4 + x] = (uint8_t)sc;
+        }
+        __syncthreads();
+        // ---- 4. strict NMS over the 8 neighbours (unevaluated neighbours have S <= thr < S(p): 0 in the map), survivors -> olist
+        int any = 0;
+        for (int i = lane; i < n_cand; i += 64) {
+            const uint32_t e = my_list[i];
+            const int x = e & 255, y = e >> 8;
+            const uint8_t* q = sbytes + (y + 1) * (kSmapWords * 4) + 4 + x;
+            const uint32_t sc = q[0];
+            if ((int)sc <= thr) continue;
+            constexpr int kS = kSmapWords * 4;
+            const uint32_t nb = max(max(max((uint32_t)q[-kS - 1], (uint32_t)q[-kS]), max((uint32_t)q[-kS + 1], (uint32_t)q[-1])),
+                                    max(max((uint32_t)q[1], (uint32_t)q[kS - 1]), max((uint32_t)q[kS], (uint32_t)q[kS + 1])));
+            if (sc <= nb) continue;
+            any = 1;
+            if (fmask) {   // upstream drops masked keypoints after the empty-cell decision
+                const uint32_t gx = min_x + 3 + x, gy = min_y + 3 + y;
+                if (fmask[(size_t)(unsigned)(gy * scale) * stride0 + (unsigned)(gx * scale)] == 0) continue;
+            }
+            const uint32_t o = atomicAdd(&n_out, 1u);
+            olist[o] = (sc << 16) | e;
+        }
+        if (__syncthreads_or(any) || thr <= geo->min_thr) break;
+        // "if keypts_in_cell.empty()": again with min_fast_thr (rare: flat cells)
+        thr = geo->min_thr;
+        for (int i = tid; i < kSmapRows * kSmapWords / 4; i += 256) reinterpret_cast<uint4*>(smap_flat)[i] = uint4{0u, 0u, 0u, 0u};
+        if (tid < 4) wave_cnt[tid] = 0;
+        __syncthreads();
     }
-    const int thr = __syncthreads_or(above_ini) ? geo->ini_thr : geo->min_thr;
 
-    // ---- emit: FAST response = S - 1; optional per-keypoint mask test. emit bit p <-> pixel (row0 + (p >> 3), c0 + (p & 7)).
-    uint32_t emit = 0;
-    {
-        const s16x2 thrv = {(short)thr, (short)thr};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t ua = (as_u32(thrv - sa[i]) >> 15) & 0x00010001u;   // sign of (thr - s): s > thr
-            const uint32_t ub = (as_u32(thrv - sb[i]) >> 15) & 0x00010001u;
-            emit |= ((ua | (ua >> 15)) & 3u) << (2 * i);
-            emit |= ((ub | (ub >> 15)) & 3u) << (8 + 2 * i);
-        }
-    }
-    if (fmask && emit) {
-        uint32_t m = emit;
-        while (m) {
-            const int p = __ffs(m) - 1;
-            m &= m - 1;
-            const uint32_t x = min_x + 3 + c0 + (p & 7), y = min_y + 3 + row0 + (p >> 3);
-            if (fmask[(size_t)(unsigned)(y * scale) * stride0 + (unsigned)(x * scale)] == 0) emit &= ~(1u << p);
-        }
-    }
-    const int n_out = __popc(emit);
-    // block-level exclusive scan of n_out
-    const int lane = tid & 63, wv = tid >> 6;
-    int incl = n_out;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) wave_tot[wv] = incl;
+    // ---- 5. append to the (frame, level) candidate list: one global atomic per workgroup; FAST response = S - 1
+    const uint32_t total = n_out;
+    if (total == 0) return;
+    if (tid == 0) list_base = atomicAdd(&cand_count[frame * L + level], total);
     __syncthreads();
-    if (tid == 0) {
-        const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-        list_base = total ? atomicAdd(&cand_count[frame * L + level], total) : 0u;
-    }
-    __syncthreads();
-    uint32_t pos = list_base + (incl - n_out);
-    for (int w2 = 0; w2 < wv; ++w2) pos += wave_tot[w2];
-    uint64_t* list = cand + (size_t)frame * cand_frame_entries + g.cand_off;
-    const uint32_t cap = (uint32_t)g.cand_cap;
-    // survivors are rare (<= 1 % of the pixels): walk the set bits; an NMS survivor's score is still in the score map
-    const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(&smap[0][0]);
-    while (emit) {
-        const int p = __ffs(emit) - 1;
-        emit &= emit - 1;
-        const int px = c0 + (p & 7), py = row0 + (p >> 3);
-        const uint32_t v = sbytes[(py + 1) * (kSmapWords * 4) + 4 + px];
-        if (pos < cap) list[pos] = cand_pack((uint32_t)(min_x + 3 + px), (uint32_t)(min_y + 3 + py), v - 1u, 0);
-        ++pos;
+    const uint32_t base = list_base;
+    for (uint32_t i = tid; i < total; i += 256) {
+        const uint32_t o = olist[i];
+        const uint32_t x = o & 255u, y = (o >> 8) & 255u, sc = o >> 16;
+        if (base + i < cap) list[base + i] = cand_pack((uint32_t)(min_x + 3) + x, (uint32_t)(min_y + 3) + y, sc - 1u, 0);
     }
 }
 
 hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
                        const uint8_t* mask, int mask_rows, int batch, hipStream_t s) {
-    if (hgeo.total_cells == 0) return hipSuccess;
-    dim3 grid(((hgeo.total_cells + 7) / 8) * 8, batch);
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, s, d.geo, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
-                       d.cand_frame_entries, d.cand_count, mask, mask_rows);
+    (void)mask_rows;
+    if (hgeo.total_cells == 0 || batch <= 0) return hipSuccess;
+    const unsigned per_xcd = (unsigned)(hgeo.total_cells + 7) / 8u;
+    hipLaunchKernelGGL(k_fast_cells, dim3(8u * per_xcd * (unsigned)batch), dim3(256), 0, s, d.geo, img0, stride0, frame_stride0, d.pyr,
+                       d.pyr_frame_bytes, d.cand, d.cand_frame_entries, d.cand_count, mask, batch);
     return hipGetLastError();
 }
 

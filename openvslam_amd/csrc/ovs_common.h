@@ -48,6 +48,7 @@ struct FrameGeo {
     int32_t total_kp_cap;
     int32_t ini_thr, min_thr;
     int32_t pad;
+    int32_t cell_base_tab[OVS_MAX_LEVELS];   // lv[l].cell_base for l < num_levels, INT32_MAX above: one scalar load finds a cell's level
     LevelGeo lv[OVS_MAX_LEVELS];
 };
 
