@@ -105,8 +105,10 @@ def main():
     d_cnt, d_mcnt = bufs[0]["cnt"], bufs[0]["mcnt"]
     # frame b (keyframe side, idx_2) is matched against frame b-1 inside its 8-frame scene (frame side, idx_1)
     prev = torch.tensor([(b - 1) if b % 8 else min(b + 7, B - 1) for b in range(B)], dtype=torch.long, device="cuda")
-    s_ext = torch.cuda.current_stream()
-    s_match = torch.cuda.Stream() if args.overlap else s_ext
+    # the extraction chain is the critical path: it gets the high-priority queue, matching fills the slots it leaves free
+    s_ext = torch.cuda.Stream(priority=-1) if args.overlap else torch.cuda.current_stream()
+    s_match = torch.cuda.Stream(priority=0) if args.overlap else s_ext
+    torch.cuda.synchronize()   # inputs and buffers were created on the default stream
     ev_ext = [torch.cuda.Event() for _ in range(n_buf)]
     ev_match = [torch.cuda.Event() for _ in range(n_buf)]
     step_no = [0]

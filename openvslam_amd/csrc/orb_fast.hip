@@ -10,20 +10,18 @@
 // The 64x64 testable areas of neighbouring cells tile the level exactly (cell stride 64, overlap 6 = two 3-px dead
 // frames), so every pixel is scored once.
 //
-// S in 75 packed ops per PAIR of pixels (v1 used 176). With r[0..15] the raw ring values and j even:
+// S network (v2 ran it on every pixel as 75 packed ops per PAIR of pixels; v3 runs it in 32-bit ops on the pre-test survivors only).
+// With r[0..15] the raw ring values and j even:
 //   the two 9-arcs {j-1..j+7} and {j..j+8} share the 8-window W_j = {j..j+7}, so
 //   min_arcs max_9 r = min_j max( max W_j, min(r[j-1], r[j+8]) ),   max_arcs min_9 r = max_j min( min W_j, max(r[j-1], r[j+8]) )
 //   S = max( c - min_arcs max_9 r,  max_arcs min_9 r - c ).
-//   The eight even windows come from 8 pair + 8 quad min/max, the oct step folds into the arc step as a three-input
-//   min/max (two pixels per register; 3-input packed min/max exists only in the f16 pipe -- see umin3/umax3 below).
+//   The eight even windows come from 8 pair + 8 quad min/max, the oct step folds into the arc step.
 //   Checked against the 16-arc definition on random rings (tests/test_oracle_kat.py).
-// The kernel is VALU-issue bound (rocprofv3 PMC, profiles/r01_pmc_*.txt: SQ_ACTIVE_INST_VALU ~ 90 % of SIMD time, packed
-// 16-bit integer ops issue at one wave-instruction per 4 cycles), so instructions per pixel are the only currency.
 //
 // Mapping: one 256-thread workgroup per cell; the <=70x70 u8 tile is staged in LDS with aligned 16-byte loads (cell
 // origin x = 19+64j => tile origin 16+64j). Two-stage evaluation (v3; v2 scored every pixel with the 75-op network above, which
 // is still the definition of S): thread (run, rp) runs the 10-op cardinal test on pixels [8*run, 8*run+8) of rows 2*rp and
-// 2*rp+1 as packed pairs; the ~5 % that pass are compacted into an LDS list and scored exactly, one pixel per lane, with the
+// 2*rp+1 as packed pairs; the 5 % (level 0) to 38 % (level 7) that pass are compacted into an LDS list and scored exactly, one pixel per lane, with the
 // same network in 32-bit ops; NMS reads the sparse score map (unscored pixels hold 0, and indeed have S <= t). The cell is
 // processed with ini_fast_thr and, only if no NMS survivor came out, again with min_fast_thr. Survivors are appended to the
 // (frame, level) candidate list with ONE global atomic per workgroup. List order is irrelevant downstream (the quad-tree
@@ -58,64 +56,13 @@ __device__ __forceinline__ s16x2 window_pair(const uint32_t (&w)[8][5]) {
 }
 
 // Packed 2 x u16 min / max of values 0..255 through the f16 pipe: such bit patterns are positive f16 denormals, ordered like
-// the integers and returned unflushed (checked exhaustively on gfx950 by tools/ubench/valu_rate.hip), and gfx950 has
-// THREE-input packed f16 minimum / maximum (v_pk_minimum3_f16 / v_pk_maximum3_f16) at the issue rate of v_pk_max_i16,
-// which the integer pipe lacks.
+// the integers and returned unflushed (checked exhaustively on gfx950 by tools/ubench/valu_rate.hip). (v2 needed this pipe for
+// its three-input packed min / max, v_pk_minimum3_f16 / v_pk_maximum3_f16, which the integer pipe lacks.)
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ h16x2 as_h(s16x2 v) { return __builtin_bit_cast(h16x2, v); }
 __device__ __forceinline__ s16x2 as_s(h16x2 v) { return __builtin_bit_cast(s16x2, v); }
 __device__ __forceinline__ s16x2 umin2(s16x2 a, s16x2 b) { return as_s(__builtin_elementwise_minimum(as_h(a), as_h(b))); }
 __device__ __forceinline__ s16x2 umax2(s16x2 a, s16x2 b) { return as_s(__builtin_elementwise_maximum(as_h(a), as_h(b))); }
-__device__ __forceinline__ s16x2 umin3(s16x2 a, s16x2 b, s16x2 c) {
-    return as_s(__builtin_elementwise_minimum(__builtin_elementwise_minimum(as_h(a), as_h(b)), as_h(c)));
-}
-__device__ __forceinline__ s16x2 umax3(s16x2 a, s16x2 b, s16x2 c) {
-    return as_s(__builtin_elementwise_maximum(__builtin_elementwise_maximum(as_h(a), as_h(b)), as_h(c)));
-}
-
-// Threshold-free FAST-9/16 strength S (clamped at 0) for pixels P and P+1 (P even) of the run, window rows R0..R0+6.
-template <int P, int R0>
-__device__ __forceinline__ s16x2 fast_strength_pair(const uint32_t (&w)[8][5]) {
-    const s16x2 c = window_pair<6 + P, R0 + 3>(w);
-    s16x2 r[16];
-    r[0] = window_pair<6 + P + 0, R0 + 6>(w);
-    r[1] = window_pair<6 + P + 1, R0 + 6>(w);
-    r[2] = window_pair<6 + P + 2, R0 + 5>(w);
-    r[3] = window_pair<6 + P + 3, R0 + 4>(w);
-    r[4] = window_pair<6 + P + 3, R0 + 3>(w);
-    r[5] = window_pair<6 + P + 3, R0 + 2>(w);
-    r[6] = window_pair<6 + P + 2, R0 + 1>(w);
-    r[7] = window_pair<6 + P + 1, R0 + 0>(w);
-    r[8] = window_pair<6 + P + 0, R0 + 0>(w);
-    r[9] = window_pair<6 + P - 1, R0 + 0>(w);
-    r[10] = window_pair<6 + P - 2, R0 + 1>(w);
-    r[11] = window_pair<6 + P - 3, R0 + 2>(w);
-    r[12] = window_pair<6 + P - 3, R0 + 3>(w);
-    r[13] = window_pair<6 + P - 3, R0 + 4>(w);
-    r[14] = window_pair<6 + P - 2, R0 + 5>(w);
-    r[15] = window_pair<6 + P - 1, R0 + 6>(w);
-    s16x2 pmx[8], pmn[8], qmx[8], qmn[8], ta[8], tb[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        pmx[i] = umax2(r[2 * i], r[2 * i + 1]);
-        pmn[i] = umin2(r[2 * i], r[2 * i + 1]);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        qmx[i] = umax2(pmx[i], pmx[(i + 1) & 7]);   // max r[2i .. 2i+3]
-        qmn[i] = umin2(pmn[i], pmn[(i + 1) & 7]);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const s16x2 ea = r[(2 * i + 15) & 15], eb = r[(2 * i + 8) & 15];
-        ta[i] = umax3(qmx[i], qmx[(i + 2) & 7], umin2(ea, eb));   // the cheaper-to-beat of the two 9-arcs around window 2i..2i+7
-        tb[i] = umin3(qmn[i], qmn[(i + 2) & 7], umax2(ea, eb));
-    }
-    const s16x2 min_a = umin2(umin3(ta[0], ta[1], ta[2]), umin3(umin3(ta[3], ta[4], ta[5]), ta[6], ta[7]));   // min over arcs of max(ring)
-    const s16x2 max_b = umax2(umax3(tb[0], tb[1], tb[2]), umax3(umax3(tb[3], tb[4], tb[5]), tb[6], tb[7]));   // max over arcs of min(ring)
-    const s16x2 zero = {0, 0};
-    return vmax(vmax(c - min_a, max_b - c), zero);
-}
 
 // ---- sparse evaluation -------------------------------------------------------------------------------------------------------
 // S(p) > t needs 9 contiguous ring pixels all brighter than c + t (or all darker than c - t); any 9-arc of the 16-ring contains two
@@ -180,7 +127,7 @@ __device__ __forceinline__ uint32_t fast_strength_one(const uint8_t* p) {
 
 constexpr int kMaxSurvivors = 1024;   // NMS survivors are pairwise non-adjacent: at most 32 x 32 per 64 x 64 cell
 
-__global__ __launch_bounds__(256) void k_fast_cells(const FrameGeo* __restrict__ geo, const uint8_t* __restrict__ img0, size_t stride0,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fast_cells(const FrameGeo* __restrict__ geo, const uint8_t* __restrict__ img0, size_t stride0,
                                                    size_t frame_stride0, const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                                    uint64_t* __restrict__ cand, size_t cand_frame_entries,
                                                    uint32_t* __restrict__ cand_count, const uint8_t* __restrict__ mask,
@@ -188,10 +135,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(const FrameGeo* __restrict__
     __shared__ __attribute__((aligned(16))) uint32_t tile[kTileRowsMax][kTileWords];
     __shared__ __attribute__((aligned(16))) uint32_t smap[kSmapRows][kSmapWords];
     __shared__ uint16_t clist[4][kCellSize * kCellSize / 4];   // per wave: its pixels that passed the cardinal test, (y << 8) | x
-    __shared__ uint32_t olist[kMaxSurvivors];                  // NMS survivors: (S << 16) | (y << 8) | x
     __shared__ uint32_t wave_cnt[4];
     __shared__ uint32_t n_out, list_base;
 
+    // NMS survivors, (S << 16) | (y << 8) | x, are collected over the tile: its last reader (the exact scoring) is a barrier behind by
+    // then, and the pass that re-reads the tile (min_fast_thr) only runs when no survivor was written. 18.9 KB of LDS -> 8 workgroups/CU.
+    static_assert(sizeof(tile) >= kMaxSurvivors * sizeof(uint32_t), "survivor list aliases the tile");
+    uint32_t* const olist = &tile[0][0];
     const int tid = threadIdx.x;
     const int L = geo->num_levels;
     // XCD-aware work order. Workgroup b runs on XCD b % 8 (each XCD has its own L2), so XCD k takes the k-th CONTIGUOUS eighth of every
