@@ -351,6 +351,18 @@ def bench_other_configs(iters=10):
     c_ms, (cT, cout, cnv) = timeit(lambda: ob.pose_optimize(T0, pobs, pcam, pbf), 3)
     out["pose_optimizer_2000_obs"] = {"pose_optimize_ms": round(g_ms, 3), "cpu_oracle_ms": round(c_ms, 3), "num_valid": int(gnv),
                                       "parity": bool(np.allclose(gT, cT, rtol=0, atol=1e-9) and gnv == cnv)}
+    # BASELINE configs[4] end to end: both optimisation rounds of local_bundle_adjuster::optimize (5 + 10 LM iterations, outlier gate)
+    from oracle import lba
+    d = synth.synth_local_ba(seed=0, pose_noise=0.03, point_noise=0.03)
+    g_ms, gr = timeit(lambda: ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], d["edges"], d["cam"]), 2)
+    c_ms, cr = timeit(lambda: lba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], d["edges"], d["cam"]), 1)
+    out["config4_local_ba_optimize"] = {"local_ba_optimize_ms": round(g_ms, 1), "cpu_oracle_ms": round(c_ms, 1),
+                                        "lm_iterations": [int(gr["info"][4]), int(gr["info"][5])],
+                                        "chi2_before_after": [float(gr["info"][0]), float(gr["info"][3])],
+                                        "outliers": int(gr["mono_outlier"].sum()),
+                                        "parity": bool(np.allclose(gr["poses"], cr["poses"], rtol=1e-7, atol=1e-8)
+                                                       and np.allclose(gr["points"], cr["points"], rtol=1e-7, atol=1e-8)),
+                                        "note": "linearisations on the GPU, reduced camera system (<= 300 x 300) on one host core"}
     out["note"] = "host entry points (H2D + kernels + D2H per call); CPU oracle single-threaded on the same inputs"
     return out
 

@@ -439,6 +439,20 @@ ovs_status ovs_ba_linearize_stereo_dev(const double* d_poses, const uint8_t* d_p
                                        double focal_x_baseline, double huber_delta, int32_t accumulate, double* d_Hpp, double* d_bp,
                                        double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream);
 
+/* replaces: the optimisation inside  void optimize::local_bundle_adjuster::optimize(data::keyframe* curr_keyfrm, bool* const
+ *               force_stop_flag) const  (src/openvslam/optimize/local_bundle_adjuster.{h,cc}): everything between the graph build and the
+ * write-back, i.e. optimizer.optimize(num_first_iter) with Huber kernels (sqrt(5.991) mono, sqrt(7.815) stereo), the chi-square /
+ * depth-positive outlier test that moves edges to level 1 and drops the kernels, optimizer.optimize(num_second_iter), and the final
+ * outlier test. g2o's Levenberg-Marquardt schedule and BlockSolver_6_3's landmark elimination are restated (oracle/ORACLE_SPEC.md
+ * rules 25, 28); linearisations run on the device (ba_linearize kernels), the reduced camera system is solved on the host.
+ * poses (n_pose x 7, in/out; fixed ones untouched), points (n_pt x 3, in/out), mono / stereo edges as for ovs_ba_linearize(_stereo).
+ * force_stop_flag: NULL or the caller's flag, polled between iterations. mono_outlier / stereo_outlier: 1 for the observations the
+ * caller must erase. info: NULL or 6 doubles {robust chi2 before / after round 1, chi2 before / after round 2, iterations 1, 2}. */
+ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* pose_fixed, int32_t n_pose, double* points, int32_t n_pt,
+                                 const ovs_ba_edge* mono, int32_t n_mono, const ovs_ba_edge_stereo* stereo, int32_t n_stereo,
+                                 const ovs_ba_cam* cam, double focal_x_baseline, int32_t num_first_iter, int32_t num_second_iter,
+                                 const volatile uint8_t* force_stop_flag, uint8_t* mono_outlier, uint8_t* stereo_outlier, double* info);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Pose-only optimisation of one frame.  replaces: unsigned int optimize::pose_optimizer::optimize(data::frame& frm) const
  * (src/openvslam/optimize/pose_optimizer.{h,cc}; perspective mono / stereo pose_opt edges): 4 rounds x 10 Levenberg-Marquardt

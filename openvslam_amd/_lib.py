@@ -56,6 +56,7 @@ SYMBOLS = {
     "ovs_ba_linearize_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_equirect": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_equirect_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ovs_local_ba_optimize": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_stereo": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_stereo_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp,
                                            _vp, _vp]),

@@ -104,6 +104,25 @@ def pose_optimize(pose_cw, obs, cam, focal_x_baseline=0.0, device=0):
     return np.concatenate([pout[:9].reshape(3, 3), pout[9:, None]], 1), out[:len(o)].astype(bool), nv.value
 
 
+def local_ba_optimize(poses, pose_fixed, points, edges, cam, stereo_edges=None, focal_x_baseline=0.0, num_first_iter=5, num_second_iter=10,
+                      force_stop_flag=None, device=0):
+    """optimize::local_bundle_adjuster::optimize behind the graph build (ovs_local_ba_optimize): returns dict(poses, points,
+    mono_outlier, stereo_outlier, info). force_stop_flag: a 1-element uint8 array another thread may set."""
+    L = _lib.lib()
+    P = np.array(poses, np.float64).reshape(-1, 7).copy()
+    X = np.array(points, np.float64).reshape(-1, 3).copy()
+    em = np.ascontiguousarray(edges if edges is not None else np.zeros(0, EDGE_DTYPE), EDGE_DTYPE)
+    es = np.ascontiguousarray(stereo_edges if stereo_edges is not None else np.zeros(0, EDGE_STEREO_DTYPE), EDGE_STEREO_DTYPE)
+    fixed = None if pose_fixed is None else np.ascontiguousarray(pose_fixed, np.uint8)
+    om, os_ = np.zeros(max(len(em), 1), np.uint8), np.zeros(max(len(es), 1), np.uint8)
+    info = np.zeros(6)
+    c = BaCam(*cam)
+    _lib.check(L.ovs_local_ba_optimize(device, _p(P), _p(fixed), len(P), _p(X), len(X), _p(em) if len(em) else None, len(em),
+                                       _p(es) if len(es) else None, len(es), C.byref(c), float(focal_x_baseline), int(num_first_iter),
+                                       int(num_second_iter), _p(force_stop_flag), _p(om), _p(os_), _p(info)), "ovs_local_ba_optimize")
+    return dict(poses=P, points=X, mono_outlier=om[:len(em)].astype(bool), stereo_outlier=os_[:len(es)].astype(bool), info=info)
+
+
 def shard_edges_by_keyframe(edges, n_pose, rank, world):
     """Edges of keyframes [rank*ceil(n_pose/world), ...): contiguous keyframe blocks, 2000 edges each in config 5."""
     per = -(-n_pose // world)

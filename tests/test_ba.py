@@ -164,3 +164,48 @@ def test_equirectangular_edge_jacobians_by_finite_differences(oracle):
         assert np.allclose(out["Hpp"][0], Jp.T @ Jp, rtol=1e-5, atol=1e-1)
         assert np.allclose(out["bp"][0], -Jp.T @ r0, rtol=1e-5, atol=1e-2)
         assert np.allclose(out["Hpl"][0], Jp.T @ Jl, rtol=1e-5, atol=1e-1)
+
+
+def _lba_scene(seed, n_pose=10, n_pt=1500, obs_per_pose=500, outlier_frac=0.04, stereo_frac=0.0):
+    """A perturbed local map with gross outliers: returns (scene dict, mono edges, stereo edges, bf, injected-outlier masks)."""
+    from openvslam_amd.ba import EDGE_STEREO_DTYPE, quat_to_rot
+    d = synth_local_ba(n_pose=n_pose, n_pt=n_pt, obs_per_pose=obs_per_pose, seed=seed, pose_noise=0.03, point_noise=0.03, n_fixed=2)
+    rng = np.random.default_rng(seed + 100)
+    e = d["edges"].copy()
+    bad = rng.random(len(e)) < outlier_frac
+    e["obs_x"][bad] += rng.choice([-1, 1], int(bad.sum())) * rng.uniform(15, 60, int(bad.sum()))
+    bf = 0.12 * d["cam"][0]
+    is_st = rng.random(len(e)) < stereo_frac
+    mono = np.ascontiguousarray(e[~is_st])
+    st = np.zeros(int(is_st.sum()), EDGE_STEREO_DTYPE)
+    if len(st):
+        es = e[is_st]
+        for k in ("pose_idx", "point_idx", "obs_x", "obs_y", "inv_sigma_sq"):
+            st[k] = es[k]
+        z = np.empty(len(es))
+        for p in np.unique(es["pose_idx"]):
+            sel = es["pose_idx"] == p
+            z[sel] = (d["points_true"][es["point_idx"][sel]] @ quat_to_rot(d["poses_true"][p, 3:]).T + d["poses_true"][p, :3])[:, 2]
+        st["obs_x_right"] = es["obs_x"] - bf / z + rng.normal(0, 1, len(es))
+    return d, mono, st, bf, bad[~is_st], bad[is_st]
+
+
+def test_local_ba_oracle_converges_and_flags_outliers(oracle):
+    """B4 oracle on a perturbed local map (mono + stereo edges, 4 % gross outliers): the robust chi2 drops (its floor is the outliers' linear Huber cost),
+    the injected outliers are flagged, poses and points move towards the truth, fixed poses stay put."""
+    from oracle import lba
+    d, mono, st, bf, bad_m, bad_s = _lba_scene(1, stereo_frac=0.3)
+    r = lba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], mono, d["cam"], st, bf)
+    info = r["info"]
+    assert info[1] < 0.5 * info[0] and info[3] <= info[2] and info[4] >= 3 and info[5] >= 3
+    assert (r["mono_outlier"][bad_m]).mean() > 0.8 and (r["stereo_outlier"][bad_s]).mean() > 0.8   # the rest sit on coarse octaves
+    assert r["mono_outlier"][~bad_m].mean() < 0.05 and r["stereo_outlier"][~bad_s].mean() < 0.05
+    fixed = d["pose_fixed"].astype(bool)
+    assert np.array_equal(r["poses"][fixed], d["poses"][fixed])
+    err0 = np.abs(d["poses"][~fixed, :3] - d["poses_true"][~fixed, :3]).mean()
+    err1 = np.abs(r["poses"][~fixed, :3] - d["poses_true"][~fixed, :3]).mean()
+    assert err1 < 0.3 * err0
+    seen = np.bincount(np.r_[mono["point_idx"], st["point_idx"]], minlength=len(d["points"])) >= 3
+    p0 = np.abs(d["points"][seen] - d["points_true"][seen]).mean()
+    p1 = np.abs(r["points"][seen] - d["points_true"][seen]).mean()
+    assert p1 < 0.8 * p0

@@ -136,3 +136,39 @@ def test_equirectangular_rejects_bad_image_size():
     poses, fixed, pts, edges = _equirect_scene(6, n_pose=2, n_pt=50, obs_per_pose=20)
     with pytest.raises(RuntimeError):
         ba.linearize_equirect(poses, fixed, pts, edges, 0, 960, 0.0)
+
+
+@pytest.mark.parametrize("stereo_frac,n_pose,n_pt,obs", [(0.0, 10, 1500, 500), (0.3, 10, 1500, 500), (1.0, 6, 800, 300), (0.0, 50, 20000, 2000)])
+def test_local_ba_optimize(oracle, stereo_frac, n_pose, n_pt, obs):
+    """B4: both rounds of local_bundle_adjuster::optimize against the numpy / C oracle. The two sides sum the blocks in different
+    orders (atomics vs sequential) and the host solves differ in operation order, so states agree to 1e-7 relative after 15
+    Levenberg-Marquardt iterations; iteration counts and the outlier flags must be identical apart from observations whose chi2 sits
+    within 1e-6 of the gate."""
+    from oracle import lba
+    from openvslam_amd import ba
+    from test_ba import _lba_scene
+    d, mono, st, bf, _, _ = _lba_scene(3, n_pose=n_pose, n_pt=n_pt, obs_per_pose=obs, stereo_frac=stereo_frac)
+    got = ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], mono, d["cam"], st, bf)
+    want = lba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], mono, d["cam"], st, bf)
+    assert np.array_equal(got["info"][4:], want["info"][4:]) and want["info"][4] >= 3
+    assert np.allclose(got["info"][:4], want["info"][:4], rtol=1e-7)
+    assert np.allclose(got["poses"], want["poses"], rtol=1e-7, atol=1e-8)
+    assert np.allclose(got["points"], want["points"], rtol=1e-7, atol=1e-8)
+    for k in ("mono_outlier", "stereo_outlier"):
+        assert (got[k] != want[k]).sum() <= max(1, len(want[k]) // 5000), k
+    fixed = d["pose_fixed"].astype(bool)
+    assert np.array_equal(got["poses"][fixed], d["poses"][fixed])
+
+
+def test_local_ba_force_stop_and_bad_args():
+    from openvslam_amd import ba
+    from test_ba import _lba_scene
+    d, mono, st, bf, _, _ = _lba_scene(5, n_pose=6, n_pt=600, obs_per_pose=250)
+    stop = np.ones(1, np.uint8)     # raised before the call: no iteration runs, the state comes back unchanged
+    r = ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], mono, d["cam"], force_stop_flag=stop)
+    assert r["info"][4] == 0 and r["info"][5] == 0
+    assert np.allclose(r["poses"], d["poses"], rtol=0, atol=1e-12) and np.array_equal(r["points"], d["points"])
+    bad = mono.copy()
+    bad["point_idx"][0] = 10 ** 6
+    with pytest.raises(RuntimeError):
+        ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], bad, d["cam"])
