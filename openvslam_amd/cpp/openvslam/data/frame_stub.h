@@ -14,13 +14,33 @@ struct Vec2_t {   // Eigen::Vector2d stand-in
     double operator()(int i) const { return v[i]; }
     double& operator()(int i) { return v[i]; }
 };
+struct Vec3_t {   // Eigen::Vector3d stand-in
+    double v[3] = {0, 0, 0};
+    double operator()(int i) const { return v[i]; }
+    double& operator()(int i) { return v[i]; }
+};
+struct Mat33_t {   // Eigen::Matrix3d stand-in; (r, c) access as Eigen
+    double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double operator()(int r, int c) const { return m[3 * r + c]; }
+    double& operator()(int r, int c) { return m[3 * r + c]; }
+};
+struct Mat44_t {   // Eigen::Matrix4d stand-in
+    double m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double operator()(int r, int c) const { return m[4 * r + c]; }
+    double& operator()(int r, int c) { return m[4 * r + c]; }
+};
 
 namespace camera {
 struct image_bounds {
     float min_x_ = 0, max_x_ = 0, min_y_ = 0, max_y_ = 0;
 };
+enum class setup_type_t { Monocular = 0, Stereo = 1, RGBD = 2 };
+enum class model_type_t { Perspective = 0, Fisheye = 1, Equirectangular = 2 };
 class base {
 public:
+    setup_type_t setup_type_ = setup_type_t::Monocular;
+    model_type_t model_type_ = model_type_t::Perspective;
+    double fx_ = 0, fy_ = 0, cx_ = 0, cy_ = 0;   // camera::perspective's members (the shims read them through a static_cast there)
     unsigned int cols_ = 0, rows_ = 0;
     image_bounds img_bounds_;
     unsigned int num_grid_cols_ = 64, num_grid_rows_ = 48;
@@ -37,6 +57,8 @@ public:
     bool will_be_erased() const { return will_be_erased_; }
     bool has_observation() const { return num_observations_ > 0; }
     cv::Mat get_descriptor() const { return descriptor_; }
+    Vec3_t get_pos_in_world() const { return pos_w_; }
+    Vec3_t pos_w_;
     bool will_be_erased_ = false;
     unsigned int num_observations_ = 1;
     cv::Mat descriptor_;
@@ -55,9 +77,11 @@ public:
     std::vector<float> stereo_x_right_;
     cv::Mat descriptors_;
     std::vector<landmark*> landmarks_;
+    std::vector<bool> outlier_flags_;
     std::vector<float> scale_factors_;
     camera::base* camera_ = nullptr;
     bow_feature_vector bow_feat_vec_;
+    Mat44_t cam_pose_cw_;
 };
 
 class keyframe {
@@ -65,10 +89,33 @@ public:
     unsigned int num_keypts_ = 0;
     std::vector<cv::KeyPoint> keypts_;
     std::vector<cv::KeyPoint> undist_keypts_;
+    std::vector<float> stereo_x_right_;
+    std::vector<Vec3_t> bearings_;
     cv::Mat descriptors_;
     std::vector<landmark*> landmarks_;
+    std::vector<float> scale_factors_;
+    camera::base* camera_ = nullptr;
     bow_feature_vector bow_feat_vec_;
+    Mat44_t cam_pose_cw_;
     std::vector<landmark*> get_landmarks() const { return landmarks_; }
+    landmark* get_landmark(unsigned int idx) const { return landmarks_.at(idx); }
+    Mat33_t get_rotation() const {
+        Mat33_t r;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) r(i, j) = cam_pose_cw_(i, j);
+        return r;
+    }
+    Vec3_t get_translation() const {
+        Vec3_t t;
+        for (int i = 0; i < 3; ++i) t(i) = cam_pose_cw_(i, 3);
+        return t;
+    }
+    Vec3_t get_cam_center() const {   // -R^T t
+        Vec3_t c;
+        for (int i = 0; i < 3; ++i)
+            c(i) = -((cam_pose_cw_(0, i) * cam_pose_cw_(0, 3) + cam_pose_cw_(1, i) * cam_pose_cw_(1, 3)) + cam_pose_cw_(2, i) * cam_pose_cw_(2, 3));
+        return c;
+    }
 };
 
 }   // namespace data

@@ -6,18 +6,7 @@
 namespace openvslam {
 namespace match {
 
-namespace {
-void flatten(const data::bow_feature_vector& fv, std::vector<int32_t>& ids, std::vector<int32_t>& start, std::vector<int32_t>& items) {
-    ids.clear();
-    items.clear();
-    start.assign(1, 0);
-    for (const auto& node : fv) {   // std::map iterates in ascending node id
-        ids.push_back((int32_t)node.first);
-        for (const auto idx : node.second) items.push_back((int32_t)idx);
-        start.push_back((int32_t)items.size());
-    }
-}
-}   // namespace
+using detail::flatten_bow;
 
 unsigned int bow_tree::match_frame_and_keyframe(data::keyframe* keyfrm, data::frame& frm, std::vector<data::landmark*>& matched_lms_in_frm) const {
     const int n_kf = (int)keyfrm->num_keypts_, n_frm = (int)frm.num_keypts_;
@@ -27,8 +16,8 @@ unsigned int bow_tree::match_frame_and_keyframe(data::keyframe* keyfrm, data::fr
     std::vector<uint8_t> valid((size_t)n_kf);
     for (int i = 0; i < n_kf; ++i) valid[i] = keyfrm_lms[i] && !keyfrm_lms[i]->will_be_erased();
     std::vector<int32_t> kid, kst, kit, fid, fst, fit;
-    flatten(keyfrm->bow_feat_vec_, kid, kst, kit);
-    flatten(frm.bow_feat_vec_, fid, fst, fit);
+    flatten_bow(keyfrm->bow_feat_vec_, kid, kst, kit);
+    flatten_bow(frm.bow_feat_vec_, fid, fst, fit);
     std::vector<int32_t> matched((size_t)n_frm, -1);
     int32_t num_matches = 0;
     detail::check(ovs_bow_match_frame_and_keyframe(detail::window_ctx().get(n_frm, n_kf),

@@ -42,5 +42,40 @@ unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::
     return (unsigned int)num_matches;
 }
 
+unsigned int projection::match_current_and_last_frames(data::frame& curr_frm, const data::frame& last_frm, const float margin) const {
+    const int n_curr = (int)curr_frm.num_keypts_, n_last = (int)last_frm.num_keypts_;
+    if (n_curr == 0 || n_last == 0) return 0;
+    std::vector<double> last_pos((size_t)3 * n_last);
+    std::vector<uint8_t> last_valid((size_t)n_last), last_desc((size_t)32 * n_last), occupied((size_t)n_curr);
+    for (int i = 0; i < n_last; ++i) {
+        const auto* lm = last_frm.landmarks_[i];
+        last_valid[i] = lm && !(i < (int)last_frm.outlier_flags_.size() && last_frm.outlier_flags_[i]);
+        if (!last_valid[i]) continue;
+        const Vec3_t pos_w = lm->get_pos_in_world();
+        for (int a = 0; a < 3; ++a) last_pos[(size_t)3 * i + a] = pos_w(a);
+        const cv::Mat d = lm->get_descriptor();
+        std::memcpy(&last_desc[(size_t)32 * i], d.data, 32);
+    }
+    for (int i = 0; i < n_curr; ++i) occupied[i] = curr_frm.landmarks_[i] && curr_frm.landmarks_[i]->has_observation();
+    const bool stereo = !curr_frm.stereo_x_right_.empty();
+    const ovs_grid_params gp = detail::grid_of(curr_frm.camera_);
+    const ovs_camera cam = detail::camera_of(curr_frm.camera_);
+    double pose_curr[12], pose_last[12];
+    detail::pose12(curr_frm.cam_pose_cw_, pose_curr);
+    detail::pose12(last_frm.cam_pose_cw_, pose_last);
+    std::vector<int32_t> assigned((size_t)n_last, -1);
+    int32_t num_matches = 0;
+    detail::check(ovs_projection_match_current_and_last_frames(
+                      detail::window_ctx().get(n_curr, n_last), &cam, &gp, reinterpret_cast<const ovs_keypoint*>(curr_frm.undist_keypts_.data()),
+                      curr_frm.descriptors_.data, stereo ? curr_frm.stereo_x_right_.data() : nullptr, occupied.data(), n_curr, pose_curr,
+                      reinterpret_cast<const ovs_keypoint*>(last_frm.undist_keypts_.data()), last_pos.data(), last_desc.data(), last_valid.data(),
+                      n_last, pose_last, curr_frm.scale_factors_.data(), (int)curr_frm.scale_factors_.size(), margin, check_orientation_ ? 1 : 0,
+                      assigned.data(), &num_matches),
+                  "ovs_projection_match_current_and_last_frames");
+    for (int i = 0; i < n_last; ++i)
+        if (assigned[i] >= 0) curr_frm.landmarks_[assigned[i]] = last_frm.landmarks_[i];
+    return (unsigned int)num_matches;
+}
+
 }   // namespace match
 }   // namespace openvslam

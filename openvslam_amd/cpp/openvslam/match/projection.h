@@ -1,4 +1,5 @@
-// match::projection (expected: src/openvslam/match/projection.h). match_frame_and_landmarks runs on the MI355X.
+// match::projection (expected: src/openvslam/match/projection.h). match_frame_and_landmarks and
+// match_current_and_last_frames run on the MI355X (the other overloads: python mirrors in openvslam_amd/match.py, same flattening).
 #pragma once
 #include <vector>
 
@@ -15,6 +16,9 @@ public:
 
     //! 3D points already projected by tracking_module::search_local_landmarks -> frame keypoints (frm.landmarks_ is updated)
     unsigned int match_frame_and_landmarks(data::frame& frm, const std::vector<data::landmark*>& local_landmarks, const float margin = 5.0) const;
+
+    //! last frame's 3D points reprojected with the current pose (motion model) -> current keypoints (curr_frm.landmarks_ is updated)
+    unsigned int match_current_and_last_frames(data::frame& curr_frm, const data::frame& last_frm, const float margin) const;
 };
 
 }   // namespace match

@@ -1,6 +1,10 @@
 // match::robust::brute_force_match over the C ABI. Replaces that function's body in src/openvslam/match/robust.cc.
 #include "robust.h"
 
+#include <cmath>
+
+#include "window_ctx.h"
+
 #include <ovslam_hip.h>
 
 #include <stdexcept>
@@ -50,6 +54,54 @@ unsigned int robust::brute_force_match(data::frame& frm, data::keyframe* keyfrm,
     if (st != OVS_OK) throw std::runtime_error(std::string("ovs_robust_brute_force_match failed: ") + ovs_last_error());
     for (int i = 0; i < n; ++i) matches.emplace_back(std::make_pair(pairs[2 * i], pairs[2 * i + 1]));
     return (unsigned int)n;
+}
+
+unsigned int robust::match_for_triangulation(data::keyframe* keyfrm_1, data::keyframe* keyfrm_2, const Mat33_t& E_12,
+                                             std::vector<std::pair<unsigned int, unsigned int>>& matched_idx_pairs) const {
+    matched_idx_pairs.clear();
+    const int n1 = (int)keyfrm_1->num_keypts_, n2 = (int)keyfrm_2->num_keypts_;
+    if (n1 == 0 || n2 == 0) return 0;
+    // keyfrm_1's camera centre seen from keyfrm_2, as a bearing (upstream: camera->reproject_to_bearing of rot_2w * center_1 + trans_2w)
+    const Vec3_t c1 = keyfrm_1->get_cam_center();
+    const Mat33_t rot_2w = keyfrm_2->get_rotation();
+    const Vec3_t trans_2w = keyfrm_2->get_translation();
+    double epipole[3];
+    for (int i = 0; i < 3; ++i) epipole[i] = ((rot_2w(i, 0) * c1(0) + rot_2w(i, 1) * c1(1)) + rot_2w(i, 2) * c1(2)) + trans_2w(i);
+    const double norm = std::sqrt((epipole[0] * epipole[0] + epipole[1] * epipole[1]) + epipole[2] * epipole[2]);
+    for (int i = 0; i < 3; ++i) epipole[i] /= norm;
+    auto flatten_kf = [](const data::keyframe* kf, int n, std::vector<uint8_t>& has_lm, std::vector<double>& bearings) {
+        has_lm.resize((size_t)n);
+        bearings.resize((size_t)3 * n);
+        for (int i = 0; i < n; ++i) {
+            has_lm[i] = kf->get_landmark((unsigned)i) != nullptr;
+            for (int a = 0; a < 3; ++a) bearings[(size_t)3 * i + a] = kf->bearings_[i](a);
+        }
+    };
+    std::vector<uint8_t> has_1, has_2;
+    std::vector<double> b1, b2;
+    flatten_kf(keyfrm_1, n1, has_1, b1);
+    flatten_kf(keyfrm_2, n2, has_2, b2);
+    std::vector<int32_t> id1, st1, it1, id2, st2, it2;
+    detail::flatten_bow(keyfrm_1->bow_feat_vec_, id1, st1, it1);
+    detail::flatten_bow(keyfrm_2->bow_feat_vec_, id2, st2, it2);
+    double E[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) E[3 * i + j] = E_12(i, j);
+    std::vector<int32_t> matched((size_t)n1, -1);
+    int32_t num_matches = 0;
+    detail::check(ovs_robust_match_for_triangulation(
+                      detail::window_ctx().get(n2, n1), reinterpret_cast<const ovs_keypoint*>(keyfrm_1->undist_keypts_.data()),
+                      keyfrm_1->descriptors_.data, has_1.data(), keyfrm_1->stereo_x_right_.empty() ? nullptr : keyfrm_1->stereo_x_right_.data(),
+                      b1.data(), n1, id1.data(), st1.data(), it1.data(), (int)id1.size(),
+                      reinterpret_cast<const ovs_keypoint*>(keyfrm_2->undist_keypts_.data()), keyfrm_2->descriptors_.data, has_2.data(),
+                      keyfrm_2->stereo_x_right_.empty() ? nullptr : keyfrm_2->stereo_x_right_.data(), b2.data(), n2, id2.data(), st2.data(),
+                      it2.data(), (int)id2.size(), E, epipole, keyfrm_1->scale_factors_.data(), (int)keyfrm_1->scale_factors_.size(),
+                      check_orientation_ ? 1 : 0, matched.data(), &num_matches),
+                  "ovs_robust_match_for_triangulation");
+    matched_idx_pairs.reserve((size_t)num_matches);
+    for (int i = 0; i < n1; ++i)
+        if (matched[i] >= 0) matched_idx_pairs.emplace_back((unsigned)i, (unsigned)matched[i]);
+    return (unsigned int)matched_idx_pairs.size();
 }
 
 }   // namespace match

@@ -1,5 +1,5 @@
-// match::robust (expected: src/openvslam/match/robust.h). brute_force_match runs on the MI355X; the RANSAC / triangulation
-// wrappers around it (match_frame_and_keyframe, match_for_triangulation) are callers and stay upstream's.
+// match::robust (expected: src/openvslam/match/robust.h). brute_force_match and match_for_triangulation (incl.
+// check_epipolar_constraint) run on the MI355X; match_frame_and_keyframe = brute_force_match + upstream's host-side essential-matrix RANSAC.
 #pragma once
 #include <utility>
 #include <vector>
@@ -16,6 +16,10 @@ public:
     ~robust() final = default;
 
     unsigned int brute_force_match(data::frame& frm, data::keyframe* keyfrm, std::vector<std::pair<int, int>>& matches) const;
+
+    //! keypoints of two keyframes without landmarks, through the common BoW nodes, gated by the epipolar constraint of E_12
+    unsigned int match_for_triangulation(data::keyframe* keyfrm_1, data::keyframe* keyfrm_2, const Mat33_t& E_12,
+                                         std::vector<std::pair<unsigned int, unsigned int>>& matched_idx_pairs) const;
 };
 
 }   // namespace match

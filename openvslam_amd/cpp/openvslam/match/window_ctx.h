@@ -5,6 +5,7 @@
 
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "../data/frame_stub.h"
 
@@ -43,6 +44,40 @@ inline ovs_grid_params grid_of(const camera::base* cam) {
     gp.cols = (int32_t)cam->num_grid_cols_;
     gp.rows = (int32_t)cam->num_grid_rows_;
     return gp;
+}
+
+inline ovs_camera camera_of(const camera::base* cam) {
+    ovs_camera c;
+    c.model = cam->model_type_ == camera::model_type_t::Equirectangular ? 1 : 0;
+    c.setup = (int32_t)cam->setup_type_;
+    c.fx = cam->fx_;
+    c.fy = cam->fy_;
+    c.cx = cam->cx_;
+    c.cy = cam->cy_;
+    c.focal_x_baseline = cam->focal_x_baseline_;
+    c.true_baseline = cam->true_baseline_;
+    c.cols = (int32_t)cam->cols_;
+    c.rows = (int32_t)cam->rows_;
+    return c;
+}
+
+// rows 0..2 of a 4x4 [R|t] -> 12 doubles: rotation row-major, then translation
+inline void pose12(const Mat44_t& T, double* out) {
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) out[3 * i + j] = T(i, j);
+        out[9 + i] = T(i, 3);
+    }
+}
+
+inline void flatten_bow(const data::bow_feature_vector& fv, std::vector<int32_t>& ids, std::vector<int32_t>& start, std::vector<int32_t>& items) {
+    ids.clear();
+    items.clear();
+    start.assign(1, 0);
+    for (const auto& node : fv) {   // std::map iterates in ascending node id
+        ids.push_back((int32_t)node.first);
+        for (const auto idx : node.second) items.push_back((int32_t)idx);
+        start.push_back((int32_t)items.size());
+    }
 }
 
 inline void check(int st, const char* what) {

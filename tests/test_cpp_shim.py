@@ -35,13 +35,15 @@ def test_shim_matches_oracle(oracle, tmp_path):
     kb = np.frombuffer(raw[off:off + 28 * nb], np.uint8); off += 28 * nb
     db = np.frombuffer(raw[off:off + 32 * nb], np.uint8).reshape(nb, 32); off += 32 * nb
     pairs = np.frombuffer(raw[off:off + 8 * nm], np.int32).reshape(nm, 2); off += 8 * nm
-    n_area, n_proj, n_bow, n_st = (int(v) for v in np.frombuffer(raw[off:off + 16], np.int32)); off += 16
+    n_area, n_proj, n_bow, n_st, n_cl, n_tri = (int(v) for v in np.frombuffer(raw[off:off + 24], np.int32)); off += 24
     area_m = np.frombuffer(raw[off:off + 4 * na], np.int32); off += 4 * na
     area_prev = np.frombuffer(raw[off:off + 8 * na], np.float32).reshape(na, 2); off += 8 * na
     proj_assigned = np.frombuffer(raw[off:off + 4 * na], np.int32); off += 4 * na
     bow_m = np.frombuffer(raw[off:off + 4 * na], np.int32); off += 4 * na
     st_x = np.frombuffer(raw[off:off + 4 * n_st], np.uint32); off += 4 * n_st
     st_d = np.frombuffer(raw[off:off + 4 * n_st], np.uint32); off += 4 * n_st
+    cl_assigned = np.frombuffer(raw[off:off + 4 * na], np.int32); off += 4 * na
+    tri_m = np.frombuffer(raw[off:off + 4 * na], np.int32); off += 4 * na
     assert off == len(raw)
     ox = oracle.OrbExtractor(oracle.make_params(nfeat))
     wa, wda = ox.extract(a)
@@ -75,3 +77,31 @@ def test_shim_matches_oracle(oracle, tmp_path):
     oxb.extract(b)
     wx, wd, _ = oracle.stereo_compute(oxa, oxb, wa, wda, wb, wdb, 386.1448, 0.5372)
     assert n_st == na and np.array_equal(st_x, wx.view(np.uint32)) and np.array_equal(st_d, wd.view(np.uint32))
+
+    # ---- projection::match_current_and_last_frames (identity poses, landmarks back-projected from the shifted keypoints)
+    fx = fy = 500.0
+    cx, cy = cols / 2.0, rows / 2.0
+    ocam = oracle.Camera(0, 0, fx, fy, cx, cy, 0.0, 0.0, cols, rows)
+    idx = np.arange(na)
+    z = 2.0 + (idx % 7).astype(np.float64)
+    pos = np.stack([((wa["x"].astype(np.float64) - 4.0) - cx) / fx * z, ((wa["y"].astype(np.float64) - 3.0) - cy) / fy * z, z], 1)
+    last_valid = ((idx % 13 != 5) & (idx % 11 != 0)).astype(np.uint8)
+    T = np.eye(4)[:3]
+    want, wn = oracle.projection_match_current_and_last_frames(ocam, gp, wb, wdb, T, wa, pos, wda, T, sf, 15.0, True, last_valid=last_valid)
+    assert n_cl == wn and np.array_equal(cl_assigned, want) and wn > 100
+
+    # ---- robust::match_for_triangulation
+    def bearings(k):
+        vx, vy = (k["x"].astype(np.float64) - cx) / fx, (k["y"].astype(np.float64) - cy) / fy
+        nrm = np.sqrt((vx * vx + vy * vy) + 1.0)
+        return np.stack([vx / nrm, vy / nrm, 1.0 / nrm], 1)
+
+    t12 = np.array([0.2, 0.15, 0.0])
+    E12 = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    ep = np.array([-0.2, -0.15, 0.0])
+    ep = ep / np.sqrt((ep[0] * ep[0] + ep[1] * ep[1]) + ep[2] * ep[2])
+    h1 = (np.arange(na) % 3 == 0).astype(np.uint8)
+    h2 = (np.arange(nb) % 4 == 0).astype(np.uint8)
+    wn, want = oracle.robust_match_for_triangulation(wa, wda, fv_a, bearings(wa), wb, wdb, fv_b, bearings(wb), E12, ep, sf, True, has_lm_1=h1,
+                                                     has_lm_2=h2)
+    assert n_tri == wn and np.array_equal(tri_m, want) and wn > 20
