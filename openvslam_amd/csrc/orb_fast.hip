@@ -237,44 +237,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int run = tid & 7, rp = tid >> 3;
     const int c0 = run * 8, row0 = 2 * rp;
     const int lane = tid & 63, wv = tid >> 6;
-    // candidate-mask layout: pair j (pixels c0 + 2j, c0 + 2j + 1) of row row0 -> bits j and 16 + j; of row row0 + 1 -> bits 4 + j and 20 + j
-    uint32_t valid = 0x00FF00FFu;
-    if (iw < kCellSize || ih < kCellSize) {   // testable area clipped by the level border (workgroup-uniform)
-        valid = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int x = c0 + 2 * j;
-            const uint32_t colm = (x < iw ? 1u : 0u) | (x + 1 < iw ? 0x10000u : 0u);
-            valid |= (row0 < ih ? colm : 0u) << j;
-            valid |= (row0 + 1 < ih ? colm : 0u) << (4 + j);
-        }
-    }
     const uint8_t* const tbytes = reinterpret_cast<const uint8_t*>(&tile[0][0]);
     uint8_t* const sbytes = reinterpret_cast<uint8_t*>(smap_flat);
-    uint64_t* const list = cand + (size_t)frame * cand_frame_entries + g.cand_off;
-    const uint32_t cap = (uint32_t)g.cand_cap;
     __syncthreads();
-
-    // the part of the 8x5-word window the cardinal test reads: rows 0, 1, 6, 7 words 1..3 and rows 3, 4 words 0..4
-    uint32_t w[8][5];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (r == 2 || r == 5) continue;
-        const uint2 b = *reinterpret_cast<const uint2*>(&tile[row0 + r][2 * run + 2]);
-        w[r][1] = tile[row0 + r][2 * run + 1];
-        w[r][2] = b.x;
-        w[r][3] = b.y;
-        if (r == 3 || r == 4) {
-            w[r][0] = tile[row0 + r][2 * run];
-            w[r][4] = tile[row0 + r][2 * run + 4];
-        }
-    }
 
     int thr = geo->ini_thr;
     for (;;) {
-        // ---- 1. cardinal test on packed pairs -> candidate mask
+        // ---- 1. cardinal test on packed pairs -> candidate mask. It reads this part of the thread's 8x5-word window (re-read in the rare
+        //         second pass rather than kept in 22 registers across the scoring): rows 0, 1, 6, 7 words 1..3 and rows 3, 4 words 0..4
         uint32_t cmask = 0;
         {
+            uint32_t w[8][5];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (r == 2 || r == 5) continue;
+                const uint2 b = *reinterpret_cast<const uint2*>(&tile[row0 + r][2 * run + 2]);
+                w[r][1] = tile[row0 + r][2 * run + 1];
+                w[r][2] = b.x;
+                w[r][3] = b.y;
+                if (r == 3 || r == 4) {
+                    w[r][0] = tile[row0 + r][2 * run];
+                    w[r][4] = tile[row0 + r][2 * run + 4];
+                }
+            }
             const s16x2 thrv = {(short)thr, (short)thr};
             cmask |= cardinal_test_pair<0, 0>(w, thrv) & 0x00010001u;
             cmask |= cardinal_test_pair<2, 0>(w, thrv) & 0x00020002u;
@@ -284,7 +269,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             cmask |= cardinal_test_pair<2, 1>(w, thrv) & 0x00200020u;
             cmask |= cardinal_test_pair<4, 1>(w, thrv) & 0x00400040u;
             cmask |= cardinal_test_pair<6, 1>(w, thrv) & 0x00800080u;
-            cmask &= valid;
+            // candidate-mask layout: pair j (pixels c0 + 2j, c0 + 2j + 1) of row row0 -> bits j and 16 + j; of row row0 + 1 -> bits 4 + j
+            // and 20 + j. Testable area clipped by the level border (workgroup-uniform, rare): mask the pixels outside.
+            if (iw < kCellSize || ih < kCellSize) {
+                uint32_t valid = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int x = c0 + 2 * j;
+                    const uint32_t colm = (x < iw ? 1u : 0u) | (x + 1 < iw ? 0x10000u : 0u);
+                    valid |= (row0 < ih ? colm : 0u) << j;
+                    valid |= (row0 + 1 < ih ? colm : 0u) << (4 + j);
+                }
+                cmask &= valid;
+            }
         }
         // ---- 2. compact the wave's candidates into its own list segment (order is irrelevant; no workgroup barrier needed: a wave's LDS
         //         operations complete in order, and the wave is the only reader of its segment)
@@ -342,6 +339,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (tid == 0) list_base = atomicAdd(&cand_count[frame * L + level], total);
     __syncthreads();
     const uint32_t base = list_base;
+    uint64_t* const list = cand + (size_t)frame * cand_frame_entries + g.cand_off;
+    const uint32_t cap = (uint32_t)g.cand_cap;
     for (uint32_t i = tid; i < total; i += 256) {
         const uint32_t o = olist[i];
         const uint32_t x = o & 255u, y = (o >> 8) & 255u, sc = o >> 16;
