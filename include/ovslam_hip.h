@@ -439,6 +439,24 @@ ovs_status ovs_ba_linearize_stereo_dev(const double* d_poses, const uint8_t* d_p
                                        double focal_x_baseline, double huber_delta, int32_t accumulate, double* d_Hpp, double* d_bp,
                                        double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Bag-of-words transform.  replaces: the per-descriptor tree descent of DBoW2::TemplatedVocabulary::transform(
+ *   const std::vector<TDescriptor>& features, BowVector& v, FeatureVector& fv, int levelsup) as called by data::frame::compute_bow /
+ *   data::keyframe::compute_bow (src/openvslam/data/frame.cc, keyframe.cc; levelsup = 4). DBoW2 is a third-party dependency.
+ * The vocabulary is handed over as a tree: node 0 = root, child_start[n_nodes + 1] / children = CSR of child node ids (DBoW2 order),
+ * node_desc n_nodes x 32 bytes, node_weight (word weights; inner nodes ignored), node_word_id (-1 for inner nodes), depth = L.
+ * Per feature: word_id, weight (the leaf's) and node_id (the ancestor at level L - levelsup, 0 if levelsup >= L). The BowVector
+ * (v[word] += weight in feature order, then L1-normalised) and the FeatureVector (fv[node].push_back(i)) are std::maps the shim fills
+ * from these arrays exactly as DBoW2 does. The _dev form takes the extractor's device outputs (descriptors B x cap x 32, counts B). */
+typedef struct ovs_vocab ovs_vocab;
+ovs_status ovs_vocab_create(int32_t device, int32_t n_nodes, const int32_t* child_start, const int32_t* children, const uint8_t* node_desc,
+                            const double* node_weight, const int32_t* node_word_id, int32_t depth, int32_t max_features, ovs_vocab** out);
+ovs_status ovs_vocab_destroy(ovs_vocab* v);
+ovs_status ovs_bow_transform(ovs_vocab* v, const uint8_t* desc, int32_t n, int32_t levelsup, int32_t* word_id, double* weight,
+                             int32_t* node_id);
+ovs_status ovs_bow_transform_dev(ovs_vocab* v, const uint8_t* d_desc, const int32_t* d_counts, int32_t batch, int32_t cap, int32_t levelsup,
+                                 int32_t* d_word_id, double* d_weight, int32_t* d_node_id, void* stream);
+
 /* replaces: the optimisation inside  void optimize::local_bundle_adjuster::optimize(data::keyframe* curr_keyfrm, bool* const
  *               force_stop_flag) const  (src/openvslam/optimize/local_bundle_adjuster.{h,cc}): everything between the graph build and the
  * write-back, i.e. optimizer.optimize(num_first_iter) with Huber kernels (sqrt(5.991) mono, sqrt(7.815) stereo), the chi-square /

@@ -56,6 +56,10 @@ SYMBOLS = {
     "ovs_ba_linearize_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_equirect": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_equirect_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ovs_vocab_create": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
+    "ovs_vocab_destroy": (_i32, [_vp]),
+    "ovs_bow_transform": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "ovs_bow_transform_dev": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ovs_local_ba_optimize": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_stereo": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_stereo_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp,

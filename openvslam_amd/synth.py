@@ -250,3 +250,42 @@ def synth_pose_frame(dtype, n, seed, stereo_frac=0.4, outlier_frac=0.1, pose_err
     T0 = np.concatenate([_rot_axis((0, 1, 0), 5 + 0.8 * pose_err) @ _rot_axis((1, 0, 0), -3 + 0.4 * pose_err),
                          (tt + pose_err * np.array([0.05, 0.03, -0.04]))[:, None]], 1)
     return T0, obs, cam, bf, (Rt, tt, bad)
+
+
+def synth_vocabulary(k=10, depth=4, seed=0, flip=28):
+    """A stand-in ORB vocabulary tree (the real orb_vocab file is not in the container): node 0 is the root, every inner node has k
+    children (the last inner level keeps between k/2 and k so ragged nodes are exercised), a child's descriptor is its parent's with
+    `flip` random bits flipped (k-majority clusters look like that), leaves are the words with TF-IDF-like weights; some leaves carry
+    weight 0 (DBoW2 drops those features). Node ids are in creation order, children of a node are consecutive, as DBoW2 creates them.
+    Returns dict(child_start, children, desc, weight, word_id, depth)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    desc = [rng.integers(0, 256, 32, dtype=np.uint8)]
+    kids = [[]]
+    level_nodes = [0]
+    for lvl in range(depth):
+        nxt = []
+        for n in level_nodes:
+            nk = k if lvl < depth - 1 else int(rng.integers(max(2, k // 2), k + 1))
+            for _ in range(nk):
+                d = desc[n].copy()
+                pos = rng.choice(256, size=flip, replace=False)
+                bits = np.unpackbits(d)
+                bits[pos] ^= 1
+                desc.append(np.packbits(bits))
+                kids.append([])
+                kids[n].append(len(desc) - 1)
+                nxt.append(len(desc) - 1)
+        level_nodes = nxt
+    n_nodes = len(desc)
+    child_start = np.zeros(n_nodes + 1, np.int32)
+    children = []
+    for n in range(n_nodes):
+        children.extend(kids[n])
+        child_start[n + 1] = len(children)
+    word_id = -np.ones(n_nodes, np.int32)
+    leaves = [n for n in range(n_nodes) if not kids[n]]
+    word_id[leaves] = np.arange(len(leaves), dtype=np.int32)
+    weight = np.zeros(n_nodes)
+    weight[leaves] = np.where(rng.random(len(leaves)) < 0.03, 0.0, rng.uniform(0.5, 9.0, len(leaves)))
+    return dict(child_start=child_start, children=np.asarray(children, np.int32), desc=np.stack(desc), weight=weight, word_id=word_id,
+                depth=depth)

@@ -618,3 +618,18 @@ def projection_match_keyframes_mutually(cam, gp, kps_1, desc_1, pose_cw_1, lm_po
         C.byref(cam), C.byref(gp), _p(x2), _p(y2), _p(o2), _p(d2), len(x2), _p(_pose12(pose_cw_2)), _p(p2), _p(m2), _p(l2), _p(v2),
         C.c_double(s_12), _p(R), _p(t), _p(sf), len(sf), C.c_float(log_scale_factor), C.c_float(margin), _p(out))
     return n, out[:len(x1)].copy()
+
+
+def bow_transform(vocab, desc, levelsup=4):
+    """DBoW2 transform, per feature: (word_id, weight, node_id). vocab = dict(child_start, children, desc, weight, word_id, depth)."""
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    cs = np.ascontiguousarray(vocab["child_start"], np.int32)
+    ch = np.ascontiguousarray(vocab["children"], np.int32)
+    nd = np.ascontiguousarray(vocab["desc"], np.uint8)
+    nw = np.ascontiguousarray(vocab["weight"], np.float64)
+    wi = np.ascontiguousarray(vocab["word_id"], np.int32)
+    n = len(d)
+    word, weight, node = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1)), np.zeros(max(n, 1), np.int32)
+    lib().ovo_bow_transform(len(wi), _p(cs), _p(ch), _p(nd), _p(nw), _p(wi), int(vocab["depth"]), _p(d), n, int(levelsup), _p(word), _p(weight),
+                            _p(node))
+    return word[:n].copy(), weight[:n].copy(), node[:n].copy()

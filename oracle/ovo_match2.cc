@@ -1004,4 +1004,38 @@ int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr
     return n_ok;
 }
 
+// SURVEY 8(f) #4  DBoW2 TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (third-party, absent: restated from the
+// published DBoW2 algorithm, ORACLE_SPEC rule 29): from the root, at each level the child with the smallest Hamming distance, first
+// minimum in child order (strict `<`); nid = the node reached at level L - levelsup (the root if that is <= 0); stop at a leaf.
+int ovo_bow_transform(int n_nodes, const int32_t* child_start, const int32_t* children, const uint8_t* node_desc, const double* node_weight,
+                      const int32_t* node_word_id, int depth, const uint8_t* desc, int n, int levelsup, int32_t* word_id, double* weight,
+                      int32_t* node_id) {
+    (void)n_nodes;
+    const int nid_level = depth - levelsup;
+    for (int f = 0; f < n; ++f) {
+        const uint8_t* q = desc + (size_t)32 * f;
+        int final_id = 0, current_level = 0, nid = 0;
+        while (child_start[final_id] != child_start[final_id + 1]) {
+            ++current_level;
+            const int c0 = child_start[final_id], c1 = child_start[final_id + 1];
+            int best_id = children[c0];
+            unsigned best_d = distance_32(q, node_desc + (size_t)32 * best_id);
+            for (int i = c0 + 1; i < c1; ++i) {
+                const int id = children[i];
+                const unsigned d = distance_32(q, node_desc + (size_t)32 * id);
+                if (d < best_d) {
+                    best_d = d;
+                    best_id = id;
+                }
+            }
+            final_id = best_id;
+            if (current_level == nid_level) nid = final_id;
+        }
+        word_id[f] = node_word_id[final_id];
+        weight[f] = node_weight[final_id];
+        node_id[f] = nid_level <= 0 ? 0 : nid;
+    }
+    return 0;
+}
+
 }   // extern "C"

@@ -196,6 +196,9 @@ int ovo_projection_match_keyframes_mutually(const ovo_camera* cam_1, const ovo_g
                                             const double* lm_pos_w_2, const float* lm_dist_2, const uint8_t* lm_desc_2, const uint8_t* lm_valid_2,
                                             double s_12, const double* rot_12, const double* trans_12, const float* scale_factors,
                                             int num_scale_levels, float log_scale_factor, float margin, int32_t* matched_2_in_1);
+int ovo_bow_transform(int n_nodes, const int32_t* child_start, const int32_t* children, const uint8_t* node_desc, const double* node_weight,
+                      const int32_t* node_word_id, int depth, const uint8_t* desc, int n, int levelsup, int32_t* word_id, double* weight,
+                      int32_t* node_id);
 int ovo_robust_match_for_triangulation(const uint8_t* desc_1, const float* angles_1, const int32_t* octaves_1, const uint8_t* has_lm_1,
                                        const float* x_right_1, const double* bearings_1, int n1, const int32_t* node_ids_1,
                                        const int32_t* node_start_1, const int32_t* items_1, int nodes_1, const uint8_t* desc_2,
