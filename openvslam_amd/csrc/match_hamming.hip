@@ -52,6 +52,24 @@ __device__ __forceinline__ void sload_desc4(const uint32_t* __restrict__ p, u32x
         : "memory");
 }
 
+// eight descriptors under one wait: half as many stalls per pair as sload_desc4 (64 SGPRs of payload)
+__device__ __forceinline__ void sload_desc8(const uint32_t* __restrict__ p, u32x8& b0, u32x8& b1, u32x8& b2, u32x8& b3, u32x8& b4, u32x8& b5,
+                                            u32x8& b6, u32x8& b7) {
+    asm volatile(
+        "s_load_dwordx8 %0, %8, 0x0\n\t"
+        "s_load_dwordx8 %1, %8, 0x20\n\t"
+        "s_load_dwordx8 %2, %8, 0x40\n\t"
+        "s_load_dwordx8 %3, %8, 0x60\n\t"
+        "s_load_dwordx8 %4, %8, 0x80\n\t"
+        "s_load_dwordx8 %5, %8, 0xa0\n\t"
+        "s_load_dwordx8 %6, %8, 0xc0\n\t"
+        "s_load_dwordx8 %7, %8, 0xe0\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(b0), "=&s"(b1), "=&s"(b2), "=&s"(b3), "=&s"(b4), "=&s"(b5), "=&s"(b6), "=&s"(b7)
+        : "s"(p)
+        : "memory");
+}
+
 __device__ __forceinline__ uint32_t hamming256v(const uint32_t (&a)[8], const u32x8& b) {
     uint32_t d = 0;
 #pragma unroll
@@ -113,7 +131,24 @@ __global__ __launch_bounds__(256) void k_hamming_near(const uint8_t* __restrict_
     };
     int j = jb;
     if (active) {
-        for (; j + 4 <= je; j += 4) {   // wave-uniform addresses: scalar loads, four descriptors in flight
+        for (; j + 8 <= je; j += 8) {   // wave-uniform addresses: scalar loads, eight descriptors in flight
+            u32x8 b0, b1, b2, b3, b4, b5, b6, b7;
+            sload_desc8(t + (size_t)j * 8, b0, b1, b2, b3, b4, b5, b6, b7);
+            const uint32_t d0 = hamming256v(a, b0), d1 = hamming256v(a, b1), d2 = hamming256v(a, b2), d3 = hamming256v(a, b3);
+            const uint32_t d4 = hamming256v(a, b4), d5 = hamming256v(a, b5), d6 = hamming256v(a, b6), d7 = hamming256v(a, b7);
+            // near distances are rare (the true match and near-duplicates): one test per eight pairs on the common path
+            if (min(min(min(d0, d1), min(d2, d3)), min(min(d4, d5), min(d6, d7))) <= near_thr) {
+                if (d0 <= near_thr) hit(d0, j);
+                if (d1 <= near_thr) hit(d1, j + 1);
+                if (d2 <= near_thr) hit(d2, j + 2);
+                if (d3 <= near_thr) hit(d3, j + 3);
+                if (d4 <= near_thr) hit(d4, j + 4);
+                if (d5 <= near_thr) hit(d5, j + 5);
+                if (d6 <= near_thr) hit(d6, j + 6);
+                if (d7 <= near_thr) hit(d7, j + 7);
+            }
+        }
+        for (; j + 4 <= je; j += 4) {   // remainder: four at a time
             u32x8 b0, b1, b2, b3;
             sload_desc4(t + (size_t)j * 8, b0, b1, b2, b3);
             const uint32_t d0 = hamming256v(a, b0), d1 = hamming256v(a, b1), d2 = hamming256v(a, b2), d3 = hamming256v(a, b3);
