@@ -1,0 +1,128 @@
+"""Empty / degenerate / over-capacity inputs through the C ABI of the matcher, BA and BoW entry points: the ABI never throws, never
+falls back and leaves well-defined outputs (upstream's functions return a count and cannot fail)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from openvslam_amd import _lib, match, synth
+    return _lib, match, synth
+
+
+def _cam(_lib, cols=752, rows=480, model=0):
+    return _lib.Camera(model, 0, 500.0, 500.0, cols / 2.0, rows / 2.0, 0.0, 0.0, cols, rows)
+
+
+def test_empty_sides_of_windowed_matchers(ctx, oracle):
+    _lib, match, synth = ctx
+    rows, cols = 480, 752
+    k, d = synth.synth_keypoints(400, rows, cols, seed=1)
+    k0, d0 = k[:0], d[:0]
+    gp = match.grid_params(cols, rows)
+    cam = _cam(_lib, cols, rows)
+    sf = np.cumprod(np.concatenate([[1.0], np.full(7, 1.2)]).astype(np.float32)).astype(np.float32)
+    lsf = float(np.log(np.float32(1.2)))
+    T = np.eye(4)[:3]
+    pos = np.zeros((400, 3))
+    pos[:, 2] = 5.0
+    dm = np.tile(np.array([[0.1, 100.0]], np.float32), (400, 1))
+    nrm = np.tile(np.array([[0.0, 0.0, 1.0]]), (400, 1))
+    p = match.projection(0.9, True, max_targets=1024, max_queries=1024)
+    f = match.fuse(0.6, max_targets=1024, max_queries=1024)
+    a = match.area(0.9, True, max_targets=1024, max_queries=1024)
+    # no keypoints in the frame: nothing can match, every output is -1
+    got, n = p.match_frame_and_keyframe(cam, gp, k0, d0, T, k, pos, dm, d, sf, lsf, 10.0, 100)
+    assert n == 0 and (got == -1).all() and len(got) == 400
+    got, n = p.match_by_Sim3_transform(cam, gp, k0, d0, T, pos, dm, nrm, d, sf, lsf, 10.0)
+    assert n == 0 and (got == -1).all()
+    got, n = f.detect_duplication(cam, gp, k0, d0, T, pos, dm, nrm, d, sf, lsf, 4.0)
+    assert n == 0 and (got == -1).all()
+    got, n = p.match_current_and_last_frames(cam, gp, k0, d0, T, k, pos, d, T, sf, 15.0)
+    assert n == 0 and (got == -1).all()
+    # no landmarks / no last-frame keypoints: zero-length outputs
+    got, n = p.match_frame_and_keyframe(cam, gp, k, d, T, k0, pos[:0], dm[:0], d0, sf, lsf, 10.0, 100)
+    assert n == 0 and len(got) == 0
+    got, n = f.detect_duplication(cam, gp, k, d, T, pos[:0], dm[:0], nrm[:0], d0, sf, lsf, 4.0)
+    assert n == 0 and len(got) == 0
+    n, got = p.match_keyframes_mutually(cam, gp, k0, d0, T, pos[:0], dm[:0], d0, None, k, d, T, pos, dm, d, None, 1.0, np.eye(3), np.zeros(3), sf, lsf,
+                                        7.5)
+    assert n == 0 and len(got) == 0
+    n, got = p.match_keyframes_mutually(cam, gp, k, d, T, pos, dm, d, None, k0, d0, T, pos[:0], dm[:0], d0, None, 1.0, np.eye(3), np.zeros(3), sf, lsf,
+                                        7.5)
+    assert n == 0 and (got == -1).all() and len(got) == 400
+    prev = np.zeros((0, 2), np.float32)
+    n, got = a.match_in_consistent_area(gp, k0, d0, k, d, prev, 100)
+    assert n == 0 and len(got) == 0
+    # every landmark invalid / behind the camera
+    got, n = f.detect_duplication(cam, gp, k, d, T, pos, dm, nrm, d, sf, lsf, 4.0, lm_valid=np.zeros(400, np.uint8))
+    assert n == 0 and (got == -1).all()
+    got, n = p.match_by_Sim3_transform(cam, gp, k, d, T, -pos, dm, nrm, d, sf, lsf, 10.0)
+    assert n == 0 and (got == -1).all()
+
+
+def test_capacity_and_argument_errors(ctx):
+    _lib, match, synth = ctx
+    rows, cols = 480, 752
+    k, d = synth.synth_keypoints(600, rows, cols, seed=2)
+    gp = match.grid_params(cols, rows)
+    cam = _cam(_lib, cols, rows)
+    sf = np.cumprod(np.concatenate([[1.0], np.full(7, 1.2)]).astype(np.float32)).astype(np.float32)
+    lsf = float(np.log(np.float32(1.2)))
+    T = np.eye(4)[:3]
+    pos = np.zeros((600, 3))
+    pos[:, 2] = 5.0
+    dm = np.tile(np.array([[0.1, 100.0]], np.float32), (600, 1))
+    nrm = np.tile(np.array([[0.0, 0.0, 1.0]]), (600, 1))
+    small = match.fuse(0.6, max_targets=256, max_queries=256)
+    with pytest.raises(_lib.OvsError) as e:
+        small.detect_duplication(cam, gp, k, d, T, pos, dm, nrm, d, sf, lsf, 4.0)
+    assert e.value.status == -4                                   # OVS_ERR_CAPACITY, nothing written
+    bad_cam = _cam(_lib, cols, rows, model=7)
+    p = match.projection(0.9, True, max_targets=1024, max_queries=1024)
+    with pytest.raises(_lib.OvsError) as e:
+        p.match_by_Sim3_transform(bad_cam, gp, k, d, T, pos, dm, nrm, d, sf, lsf, 10.0)
+    assert e.value.status == -1                                   # OVS_ERR_INVALID: unknown camera model
+    with pytest.raises(_lib.OvsError):
+        p.match_keyframes_mutually(cam, gp, k, d, T, pos, dm, d, None, k, d, T, pos, dm, d, None, 0.0, np.eye(3), np.zeros(3), sf, lsf, 7.5)   # s_12 <= 0
+
+
+def test_ba_degenerate_graphs(oracle):
+    from openvslam_amd import ba
+    from openvslam_amd.synth import synth_local_ba
+    d = synth_local_ba(n_pose=4, n_pt=60, obs_per_pose=30, seed=9, pose_noise=0.02, point_noise=0.02)
+    # no edges at all: the state comes back unchanged, no iteration runs
+    r = ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], d["edges"][:0], d["cam"])
+    assert r["info"][4] == 0 and np.allclose(r["poses"], d["poses"], atol=1e-12) and np.array_equal(r["points"], d["points"])
+    # all poses fixed: only the landmarks move (structure-only BA), parity with the oracle
+    from oracle import lba
+    fixed = np.ones(4, np.uint8)
+    got = ba.local_ba_optimize(d["poses"], fixed, d["points"], d["edges"], d["cam"])
+    want = lba.local_ba_optimize(d["poses"], fixed, d["points"], d["edges"], d["cam"])
+    assert np.array_equal(got["poses"], d["poses"]) and np.allclose(got["points"], want["points"], rtol=1e-7, atol=1e-8)
+    assert np.array_equal(got["info"][4:], want["info"][4:])
+    # linearisation of an empty edge set: all blocks zero
+    out = ba.linearize(d["poses"], d["pose_fixed"], d["points"], d["edges"][:0], d["cam"], 2.4)
+    assert not out["Hpp"].any() and not out["Hll"].any() and out["chi2"][0] == 0 and out["Hpl"].shape[0] == 0
+
+
+def test_vocab_argument_errors():
+    from openvslam_amd import _lib, bow, synth
+    v = synth.synth_vocabulary(k=4, depth=2, seed=1)
+    bad = dict(v)
+    bad["children"] = v["children"].copy()
+    bad["children"][0] = 0                                          # the root cannot be a child
+    with pytest.raises(_lib.OvsError):
+        bow.vocabulary(bad)
+    ok = bow.vocabulary(v, max_features=16)
+    with pytest.raises(_lib.OvsError) as e:
+        ok.transform_features(np.zeros((17, 32), np.uint8))
+    assert e.value.status == -4
+    single = dict(child_start=np.array([0, 0], np.int32), children=np.zeros(0, np.int32), desc=np.zeros((1, 32), np.uint8),
+                  weight=np.array([2.0]), word_id=np.array([0], np.int32), depth=0)
+    w, wt, nd = bow.vocabulary(single).transform_features(np.ones((3, 32), np.uint8))     # a vocabulary that is one leaf
+    assert (w == 0).all() and (wt == 2.0).all() and (nd == 0).all()
