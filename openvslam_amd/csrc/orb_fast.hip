@@ -20,8 +20,8 @@
 //
 // Mapping: one 256-thread workgroup per cell; the <=70x70 u8 tile is staged in LDS with aligned 16-byte loads (cell
 // origin x = 19+64j => tile origin 16+64j). Two-stage evaluation (v3; v2 scored every pixel with the 75-op network above, which
-// is still the definition of S): thread (run, rp) runs the 10-op cardinal test on pixels [8*run, 8*run+8) of rows 2*rp and
-// 2*rp+1 as packed pairs; the 5 % (level 0) to 38 % (level 7) that pass are compacted into an LDS list and scored exactly, one pixel per lane, with the
+// is still the definition of S): thread (run, rp) runs the 16-op diameter test on pixels [8*run, 8*run+8) of rows 2*rp and
+// 2*rp+1 as packed pairs; the 2.4 % (level 0) to 26 % (level 7) that pass are compacted into an LDS list and scored exactly, one pixel per lane, with the
 // same network in 32-bit ops; NMS reads the sparse score map (unscored pixels hold 0, and indeed have S <= t). The cell is
 // processed with ini_fast_thr and, only if no NMS survivor came out, again with min_fast_thr. Survivors are appended to the
 // (frame, level) candidate list with ONE global atomic per workgroup. List order is irrelevant downstream (the quad-tree
@@ -65,19 +65,22 @@ __device__ __forceinline__ s16x2 umin2(s16x2 a, s16x2 b) { return as_s(__builtin
 __device__ __forceinline__ s16x2 umax2(s16x2 a, s16x2 b) { return as_s(__builtin_elementwise_maximum(as_h(a), as_h(b))); }
 
 // ---- sparse evaluation -------------------------------------------------------------------------------------------------------
-// S(p) > t needs 9 contiguous ring pixels all brighter than c + t (or all darker than c - t); any 9-arc of the 16-ring contains two
-// ADJACENT cardinal points (ring positions 0, 4, 8, 12), so with up / dn / lf / rt the four cardinals
-//   max over adjacent cardinal pairs of min(a, b) = min(max(up, dn), max(lf, rt)) =: bc   must exceed c + t, or
-//   min over adjacent cardinal pairs of max(a, b) = max(min(up, dn), min(lf, rt)) =: dc   must lie below c - t.
-// 6 packed min/max + 4 more ops per pixel pair instead of 75, and on BASELINE-like frames it rejects ~95 % of the pixels at
-// ini_fast_thr = 20 (61 % at min_fast_thr = 7). Only the survivors get the exact S (one pixel per lane, 32-bit ops).
+// S(p) > t needs 9 contiguous ring pixels all brighter than c + t (or all darker than c - t). A 9-arc of the 16-ring contains at least
+// one end of EVERY diameter (i, i + 8), so for the four even diameters (cardinals and diagonals; OpenCV's own pre-test walks all eight)
+//   bright: min_i max(r[i], r[i+8]) > c + t      dark: max_i min(r[i], r[i+8]) < c - t      for i in {0, 2, 4, 6}
+// is necessary. 12 packed min/max + 4 more ops and 9 byte extractions per pixel pair instead of 75 + 17, and on BASELINE-like frames it
+// rejects 97.6 % of the pixels at level 0 and 74 % at level 7 for ini_fast_thr = 20 (92 % overall; true corners: 4.4 %). The two
+// cardinal diameters alone (v3.0) let 13 % through: the extra 10 ops here save 42 % of the exact evaluations. Only the survivors get
+// the exact S (one pixel per lane, 32-bit ops).
 template <int P, int R0>
-__device__ __forceinline__ uint32_t cardinal_test_pair(const uint32_t (&w)[8][5], s16x2 thrv) {
+__device__ __forceinline__ uint32_t diameter_test_pair(const uint32_t (&w)[8][5], s16x2 thrv) {
     const s16x2 c = window_pair<6 + P, R0 + 3>(w);
-    const s16x2 up = window_pair<6 + P, R0 + 0>(w), dn = window_pair<6 + P, R0 + 6>(w);
-    const s16x2 lf = window_pair<3 + P, R0 + 3>(w), rt = window_pair<9 + P, R0 + 3>(w);
-    const s16x2 bc = umin2(umax2(up, dn), umax2(lf, rt));
-    const s16x2 dc = umax2(umin2(up, dn), umin2(lf, rt));
+    const s16x2 a0 = window_pair<6 + P, R0 + 6>(w), b0 = window_pair<6 + P, R0 + 0>(w);           // ring 0 / 8:  (0, +3) / (0, -3)
+    const s16x2 a2 = window_pair<6 + P + 2, R0 + 5>(w), b2 = window_pair<6 + P - 2, R0 + 1>(w);   // ring 2 / 10: (+2, +2) / (-2, -2)
+    const s16x2 a4 = window_pair<6 + P + 3, R0 + 3>(w), b4 = window_pair<6 + P - 3, R0 + 3>(w);   // ring 4 / 12: (+3, 0) / (-3, 0)
+    const s16x2 a6 = window_pair<6 + P + 2, R0 + 1>(w), b6 = window_pair<6 + P - 2, R0 + 5>(w);   // ring 6 / 14: (+2, -2) / (-2, +2)
+    const s16x2 bc = umin2(umin2(umax2(a0, b0), umax2(a2, b2)), umin2(umax2(a4, b4), umax2(a6, b6)));
+    const s16x2 dc = umax2(umax2(umin2(a0, b0), umin2(a2, b2)), umax2(umin2(a4, b4), umin2(a6, b6)));
     const s16x2 m = vmax(bc - c, c - dc);
     return as_u32((thrv - m) >> 15);   // each half all-ones iff m > thr
 }
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                    int batch) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[kTileRowsMax][kTileWords];
     __shared__ __attribute__((aligned(16))) uint32_t smap[kSmapRows][kSmapWords];
-    __shared__ uint16_t clist[4][kCellSize * kCellSize / 4];   // per wave: its pixels that passed the cardinal test, (y << 8) | x
+    __shared__ uint16_t clist[4][kCellSize * kCellSize / 4];   // per wave: its pixels that passed the diameter test, (y << 8) | x
     __shared__ uint32_t wave_cnt[4];
     __shared__ uint32_t n_out, list_base;
 
@@ -243,14 +246,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
     int thr = geo->ini_thr;
     for (;;) {
-        // ---- 1. cardinal test on packed pairs -> candidate mask. It reads this part of the thread's 8x5-word window (re-read in the rare
-        //         second pass rather than kept in 22 registers across the scoring): rows 0, 1, 6, 7 words 1..3 and rows 3, 4 words 0..4
+        // ---- 1. diameter test on packed pairs -> candidate mask. It reads this part of the thread's 8x5-word window (re-read in the rare
+        //         second pass rather than kept in 28 registers across the scoring): words 1..3 of every row, words 0 and 4 of rows 3, 4
         uint32_t cmask = 0;
         {
             uint32_t w[8][5];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                if (r == 2 || r == 5) continue;
                 const uint2 b = *reinterpret_cast<const uint2*>(&tile[row0 + r][2 * run + 2]);
                 w[r][1] = tile[row0 + r][2 * run + 1];
                 w[r][2] = b.x;
@@ -261,14 +263,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 }
             }
             const s16x2 thrv = {(short)thr, (short)thr};
-            cmask |= cardinal_test_pair<0, 0>(w, thrv) & 0x00010001u;
-            cmask |= cardinal_test_pair<2, 0>(w, thrv) & 0x00020002u;
-            cmask |= cardinal_test_pair<4, 0>(w, thrv) & 0x00040004u;
-            cmask |= cardinal_test_pair<6, 0>(w, thrv) & 0x00080008u;
-            cmask |= cardinal_test_pair<0, 1>(w, thrv) & 0x00100010u;
-            cmask |= cardinal_test_pair<2, 1>(w, thrv) & 0x00200020u;
-            cmask |= cardinal_test_pair<4, 1>(w, thrv) & 0x00400040u;
-            cmask |= cardinal_test_pair<6, 1>(w, thrv) & 0x00800080u;
+            cmask |= diameter_test_pair<0, 0>(w, thrv) & 0x00010001u;
+            cmask |= diameter_test_pair<2, 0>(w, thrv) & 0x00020002u;
+            cmask |= diameter_test_pair<4, 0>(w, thrv) & 0x00040004u;
+            cmask |= diameter_test_pair<6, 0>(w, thrv) & 0x00080008u;
+            cmask |= diameter_test_pair<0, 1>(w, thrv) & 0x00100010u;
+            cmask |= diameter_test_pair<2, 1>(w, thrv) & 0x00200020u;
+            cmask |= diameter_test_pair<4, 1>(w, thrv) & 0x00400040u;
+            cmask |= diameter_test_pair<6, 1>(w, thrv) & 0x00800080u;
             // candidate-mask layout: pair j (pixels c0 + 2j, c0 + 2j + 1) of row row0 -> bits j and 16 + j; of row row0 + 1 -> bits 4 + j
             // and 20 + j. Testable area clipped by the level border (workgroup-uniform, rare): mask the pixels outside.
             if (iw < kCellSize || ih < kCellSize) {
