@@ -16,16 +16,26 @@ namespace ovs {
 
 constexpr int kTileW = 128, kTileH = 32;
 constexpr int kGroups = kTileW * kTileH / 4 / 256;   // 4-pixel groups per thread
-constexpr int kSlots = 8;                            // staging loads per thread in flight
-constexpr int kSrcWords = 44;    // 176-byte LDS pitch: source span of 128 output px is <= 128*src/dst + 2 <= 160 at scale >= 1.0x..1.25
+constexpr int kSlots = 8;                            // u32 staging loads per thread in flight (generic-alignment path)
+constexpr int kSrcWords = 48;    // 192-byte LDS pitch: source span of 128 output px is <= 128*src/dst + 2 <= 160 at scale <= 1.25, + 15
+                                 // bytes so that the staged rectangle starts on a 16-byte boundary (16-byte staging loads)
+constexpr int kRowChunks = kSrcWords / 4;   // 16-byte chunks per staged row
+constexpr int kChunkSlots = 3;              // 44 rows x 12 chunks <= 3 * 256
 constexpr int kSrcRows = 44;    // 32 output rows span <= 32 * 1.25 + 2 source rows (16-row tiles: 0.167 ms, 32: 0.142, 64: 0.165)
+
+// high 32 bits of the 48-bit product of two 24-bit operands (full-rate VOP3; hipcc has no builtin for it)
+__device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 
 __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restrict__ src, size_t src_frame_stride, int src_pitch,
                                                          int srows, int scols, uint8_t* __restrict__ dst, size_t dst_frame_stride,
                                                          int dst_pitch, int drows, int dcols, const ResizeTap* __restrict__ xt,
                                                          const ResizeTap* __restrict__ yt, int tiles_x, int tiles_y, int batch, float inv_tiles_x,
                                                          float inv_tiles_frame) {
-    __shared__ uint32_t tile[kSrcRows][kSrcWords];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[kSrcRows][kSrcWords];
     __shared__ __attribute__((aligned(8))) uint32_t hrow[kSrcRows][kTileW / 2];   // horizontal pass, two u16 per word
     const int tid = threadIdx.x;
     // XCD-aware tile order (workgroup b runs on XCD b % 8): XCD k takes the k-th contiguous eighth of the (frame, tile row, tile
@@ -42,10 +52,10 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restr
     const uint8_t* s = src + (size_t)frame * src_frame_stride;
     uint8_t* d = dst + (size_t)frame * dst_frame_stride;
     // source rectangle touched by the tile's taps (tables are monotone)
-    const int sx_lo = xt[x0].o0 & ~3, sx_hi = xt[x1].o1;
+    const int sx_lo = xt[x0].o0 & ~15, sx_hi = xt[x1].o1;
     const int sy_lo = yt[y0].o0, sy_hi = yt[y1].o1;
     const int nwords = (sx_hi - sx_lo) / 4 + 1, nrows = sy_hi - sy_lo + 1;
-    if (nwords <= kSrcWords && nrows <= kSrcRows && (nrows - 1) * kSrcWords + nwords <= kSlots * 256) {   // kSlots staging slots per thread
+    if (nwords <= kSrcWords && nrows <= kSrcRows && (nrows - 1) * kSrcWords + nwords <= kSlots * 256 && nrows * kRowChunks <= kChunkSlots * 256) {   // kSlots staging slots per thread
         // taps of this thread's column pair and of its two output rows: issued before the staging loads so their latency overlaps
         const int xp = tid & 63, q = tid >> 6;
         const int xa = min(x0 + 2 * xp, dcols - 1), xb = min(x0 + 2 * xp + 1, dcols - 1);
@@ -53,8 +63,34 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restr
         ResizeTap tys[kGroups];
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) tys[g] = yt[min(y0 + 8 * g + (tid >> 5), drows - 1)];
-        // stage the source rectangle: 4 independent aligned u32 loads per thread in flight (fixed 44-word pitch: no runtime division)
-        {
+        // stage the source rectangle. Planes whose rows are 16-byte aligned (every pyramid level; level 0 when the caller's stride and
+        // base allow): three 16-byte loads per thread in flight, one ds_write_b128 each. Otherwise aligned u32 loads, eight in flight.
+        if (((src_pitch & 15) == 0) && ((reinterpret_cast<uintptr_t>(s) & 15) == 0)) {
+            uint4 v[kChunkSlots];
+            int slot[kChunkSlots];
+#pragma unroll
+            for (int k = 0; k < kChunkSlots; ++k) {
+                const int i = tid + 256 * k;
+                const int r = i / kRowChunks, c = i - r * kRowChunks;
+                slot[k] = (r < nrows && 4 * c < nwords) ? i : -1;
+                v[k] = uint4{0u, 0u, 0u, 0u};
+                if (slot[k] >= 0) {
+                    const int gx = sx_lo + 16 * c;
+                    const uint8_t* p = s + (size_t)(sy_lo + r) * src_pitch + gx;
+                    if (gx + 16 <= src_pitch) {
+                        v[k] = *reinterpret_cast<const uint4*>(p);
+                    } else {   // row tail
+                        const uint32_t* p4 = reinterpret_cast<const uint32_t*>(p);
+                        if (gx + 4 <= src_pitch) v[k].x = p4[0];
+                        if (gx + 8 <= src_pitch) v[k].y = p4[1];
+                        if (gx + 12 <= src_pitch) v[k].z = p4[2];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kChunkSlots; ++k)
+                if (slot[k] >= 0) reinterpret_cast<uint4*>(&tile[0][0])[slot[k]] = v[k];
+        } else {
             uint32_t v[kSlots];
             int slot[kSlots];
 #pragma unroll
@@ -99,13 +135,17 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restr
             const ResizeTap ty = tys[g];
             const uint2 h0 = *reinterpret_cast<const uint2*>(&hrow[ty.o0 - sy_lo][xg >> 1]);
             const uint2 h1 = *reinterpret_cast<const uint2*>(&hrow[ty.o1 - sy_lo][xg >> 1]);
-            const int b0 = ty.a0, b1 = ty.a1;
-            auto vpass = [&](uint32_t r0, uint32_t r1) -> uint32_t {
-                const int v = (((b0 * (int)r0) >> 16) + ((b1 * (int)r1) >> 16) + 2) >> 2;
-                return (uint32_t)(v > 255 ? 255 : v);
+            // ((b0 * r0) >> 16) + ((b1 * r1) >> 16): both factors shifted left by 8 make it the HIGH half of a 24 x 24-bit product
+            // (v_mul_hi_u32_u24, full rate); v_perm_b32 extracts a 16-bit half and shifts it in one go. b0 + b1 = 2048 and r <= 32640, so the sum
+            // is <= 1020 and (sum + 2) >> 2 <= 255: OpenCV's saturate_cast never clamps here.
+            const uint32_t b0 = (uint32_t)ty.a0 << 8, b1 = (uint32_t)ty.a1 << 8;
+            constexpr uint32_t kLo = 0x0c01000cu, kHi = 0x0c03020cu;   // (half << 8) as a 32-bit value
+            auto vpass = [&](uint32_t w0, uint32_t w1, uint32_t sel) -> uint32_t {
+                const uint32_t r0 = __builtin_amdgcn_perm(w0, w0, sel), r1 = __builtin_amdgcn_perm(w1, w1, sel);
+                return (mulhi_u24(b0, r0) + mulhi_u24(b1, r1) + 2u) >> 2;
             };
-            const uint32_t out = vpass(h0.x & 0xFFFFu, h1.x & 0xFFFFu) | (vpass(h0.x >> 16, h1.x >> 16) << 8) |
-                                 (vpass(h0.y & 0xFFFFu, h1.y & 0xFFFFu) << 16) | (vpass(h0.y >> 16, h1.y >> 16) << 24);
+            const uint32_t out = vpass(h0.x, h1.x, kLo) | (vpass(h0.x, h1.x, kHi) << 8) | (vpass(h0.y, h1.y, kLo) << 16) |
+                                 (vpass(h0.y, h1.y, kHi) << 24);
             *reinterpret_cast<uint32_t*>(d + (size_t)y * dst_pitch + x4) = out;
         }
     } else {
