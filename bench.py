@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true", help="skip the local-BA side section (profiling runs)")
     ap.add_argument("--pipeline", type=int, default=1, help="sub-batches of the extract issued on overlapping internal streams (1 = off)")
+    ap.add_argument("--chains", type=int, default=1, help="independent extract->match pipelines the batch is split over (own handles and "
+                                                          "streams, no cross-chain synchronisation)")
     ap.add_argument("--overlap", type=int, default=1, help="1: matching of step k runs on a second stream under the extraction of step "
                                                             "k+1 (double-buffered outputs); 0: one stream, strictly serial")
     args = ap.parse_args()
@@ -85,51 +87,70 @@ def main():
     # ---- synthetic input, resident in HBM before the timed region (each rank gets its own frames)
     frames = synth_video(ROWS, COLS, B, seed=100 + rank)
     d_frames = torch.from_numpy(frames).cuda()
-    ex = feature.orb_extractor(feature.orb_params(NFEAT, 1.2, LEVELS, 20, 7), max_rows=ROWS, max_cols=COLS, max_batch=B,
-                               device=local_rank)
-    if args.pipeline > 1:
-        ex.set_pipeline(args.pipeline)
-    cap = ex.max_keypoints
-    mt = match.robust(LOWE_RATIO, False, max_n1=cap, max_n2=cap, max_batch=B, device=local_rank)
-    # outputs are double-buffered so that step k's matching (stream B) can run under step k+1's extraction (stream A)
-    n_buf = 2 if args.overlap else 1
-    bufs = []
-    for _ in range(n_buf):
-        bufs.append(dict(kps=torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"),
-                         desc=torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
-                         cnt=torch.zeros((B,), dtype=torch.int32, device="cuda"),
-                         pairs=torch.zeros((B, cap, 2), dtype=torch.int32, device="cuda"),
-                         mcnt=torch.zeros((B,), dtype=torch.int32, device="cuda"),
-                         desc_prev=torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
-                         cnt_prev=torch.zeros((B,), dtype=torch.int32, device="cuda")))
-    d_cnt, d_mcnt = bufs[0]["cnt"], bufs[0]["mcnt"]
-    # frame b (keyframe side, idx_2) is matched against frame b-1 inside its 8-frame scene (frame side, idx_1)
-    prev = torch.tensor([(b - 1) if b % 8 else min(b + 7, B - 1) for b in range(B)], dtype=torch.long, device="cuda")
-    # the extraction chain is the critical path: it gets the high-priority queue, matching fills the slots it leaves free
-    s_ext = torch.cuda.Stream(priority=-1) if args.overlap else torch.cuda.current_stream()
-    s_match = torch.cuda.Stream(priority=0) if args.overlap else s_ext
+    n_chain = max(1, args.chains)
+    if B % (8 * n_chain):
+        raise SystemExit("--batch must be a multiple of 8 * --chains")
+    Bc = B // n_chain
+
+    class Chain:
+        """One extract -> match pipeline over Bc frames: its own extractor / matcher handles, output buffers and streams. Chains share
+        nothing, so the GPU always has kernels of several chains to pick from and the latency-bound ones (quad-tree, resolver) run under
+        another chain's FAST or pyramid; inside a chain the matching of step k runs under the extraction of step k+1."""
+
+        def __init__(self, lo):
+            self.frames = d_frames[lo:lo + Bc]
+            self.ex = feature.orb_extractor(feature.orb_params(NFEAT, 1.2, LEVELS, 20, 7), max_rows=ROWS, max_cols=COLS, max_batch=Bc,
+                                            device=local_rank)
+            if args.pipeline > 1:
+                self.ex.set_pipeline(args.pipeline)
+            cap = self.ex.max_keypoints
+            self.mt = match.robust(LOWE_RATIO, False, max_n1=cap, max_n2=cap, max_batch=Bc, device=local_rank)
+            # outputs are double-buffered so that step k's matching can run under step k+1's extraction
+            self.n_buf = 2 if args.overlap else 1
+            self.bufs = []
+            for _ in range(self.n_buf):
+                self.bufs.append(dict(kps=torch.zeros((Bc, cap, 7), dtype=torch.float32, device="cuda"),
+                                      desc=torch.zeros((Bc, cap, 32), dtype=torch.uint8, device="cuda"),
+                                      cnt=torch.zeros((Bc,), dtype=torch.int32, device="cuda"),
+                                      pairs=torch.zeros((Bc, cap, 2), dtype=torch.int32, device="cuda"),
+                                      mcnt=torch.zeros((Bc,), dtype=torch.int32, device="cuda"),
+                                      desc_prev=torch.zeros((Bc, cap, 32), dtype=torch.uint8, device="cuda"),
+                                      cnt_prev=torch.zeros((Bc,), dtype=torch.int32, device="cuda")))
+            # frame b (keyframe side, idx_2) is matched against frame b-1 inside its 8-frame scene (frame side, idx_1)
+            self.prev = torch.tensor([(b - 1) if b % 8 else min(b + 7, Bc - 1) for b in range(Bc)], dtype=torch.long, device="cuda")
+            # the extraction is the critical path: it gets the high-priority queue, matching fills the slots it leaves free
+            multi = args.overlap or n_chain > 1
+            self.s_ext = torch.cuda.Stream(priority=-1) if multi else torch.cuda.current_stream()
+            self.s_match = torch.cuda.Stream(priority=0) if args.overlap else self.s_ext
+            self.ev_ext = [torch.cuda.Event() for _ in range(self.n_buf)]
+            self.ev_match = [torch.cuda.Event() for _ in range(self.n_buf)]
+            self.k = 0
+
+        def step(self):
+            k = self.k % self.n_buf
+            self.k += 1
+            b = self.bufs[k]
+            if args.overlap:
+                self.s_ext.wait_event(self.ev_match[k])      # the matcher of two steps ago has released this buffer set
+            self.ex.extract_batch_dev(self.frames, b["kps"], b["desc"], b["cnt"], stream=self.s_ext.cuda_stream)
+            if args.overlap:
+                self.ev_ext[k].record(self.s_ext)
+                self.s_match.wait_event(self.ev_ext[k])
+            with torch.cuda.stream(self.s_match):
+                torch.index_select(b["desc"], 0, self.prev, out=b["desc_prev"])   # gather "previous frame" descriptor blocks (device)
+                torch.index_select(b["cnt"], 0, self.prev, out=b["cnt_prev"])
+                self.mt.brute_force_match_batch_dev(b["desc_prev"], b["cnt_prev"], b["desc"], b["cnt"], b["pairs"], b["mcnt"],
+                                                    stream=self.s_match.cuda_stream)
+                if args.overlap:
+                    self.ev_match[k].record(self.s_match)
+
+    chains = [Chain(c * Bc) for c in range(n_chain)]
+    ex = chains[0].ex
     torch.cuda.synchronize()   # inputs and buffers were created on the default stream
-    ev_ext = [torch.cuda.Event() for _ in range(n_buf)]
-    ev_match = [torch.cuda.Event() for _ in range(n_buf)]
-    step_no = [0]
 
     def step():
-        k = step_no[0] % n_buf
-        step_no[0] += 1
-        b = bufs[k]
-        if args.overlap:
-            s_ext.wait_event(ev_match[k])      # the matcher of two steps ago has released this buffer set
-        ex.extract_batch_dev(d_frames, b["kps"], b["desc"], b["cnt"], stream=s_ext.cuda_stream)
-        if args.overlap:
-            ev_ext[k].record(s_ext)
-            s_match.wait_event(ev_ext[k])
-        with torch.cuda.stream(s_match):
-            torch.index_select(b["desc"], 0, prev, out=b["desc_prev"])   # gather "previous frame" descriptor blocks (device)
-            torch.index_select(b["cnt"], 0, prev, out=b["cnt_prev"])
-            mt.brute_force_match_batch_dev(b["desc_prev"], b["cnt_prev"], b["desc"], b["cnt"], b["pairs"], b["mcnt"],
-                                           stream=s_match.cuda_stream)
-            if args.overlap:
-                ev_match[k].record(s_match)
+        for ch in chains:
+            ch.step()
 
     def barrier():
         if world > 1:
@@ -139,8 +160,9 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    _lib.check(L.ovs_orb_profile_enable(ex._h, 1), "profile_enable")
-    _lib.check(L.ovs_matcher_profile_enable(mt._h, 1), "profile_enable")
+    for ch in chains:
+        _lib.check(L.ovs_orb_profile_enable(ch.ex._h, 1), "profile_enable")
+        _lib.check(L.ovs_matcher_profile_enable(ch.mt._h, 1), "profile_enable")
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -154,20 +176,26 @@ def main():
         elapsed = float(tt.item())
 
     # ---- per-stage HIP-event times over the timed region (recorded on the launch stream by the library)
-    st4 = (C.c_float * 4)()
-    st2 = (C.c_float * 2)()
-    nc = C.c_int32()
-    _lib.check(L.ovs_orb_profile_read(ex._h, st4, C.byref(nc)), "profile_read")
-    calls = max(nc.value, 1)
-    _lib.check(L.ovs_matcher_profile_read(mt._h, st2, C.byref(nc)), "profile_read")
-    stage_ms = {"pyramid": st4[0] / calls, "fast": st4[1] / calls, "tree": st4[2] / calls, "describe": st4[3] / calls,
-                "match_near": st2[0] / calls, "match_resolve": st2[1] / calls}
+    # (summed over the chains: with several chains in flight the figures are per-chain launch durations under sharing)
+    stage_ms = {"pyramid": 0.0, "fast": 0.0, "tree": 0.0, "describe": 0.0, "match_near": 0.0, "match_resolve": 0.0}
+    for ch in chains:
+        st4 = (C.c_float * 4)()
+        st2 = (C.c_float * 2)()
+        nc = C.c_int32()
+        _lib.check(L.ovs_orb_profile_read(ch.ex._h, st4, C.byref(nc)), "profile_read")
+        calls = max(nc.value, 1)
+        _lib.check(L.ovs_matcher_profile_read(ch.mt._h, st2, C.byref(nc)), "profile_read")
+        for key, v in zip(("pyramid", "fast", "tree", "describe"), st4):
+            stage_ms[key] += v / calls
+        stage_ms["match_near"] += st2[0] / calls
+        stage_ms["match_resolve"] += st2[1] / calls
 
-    cnt = d_cnt.cpu().numpy().astype(np.int64)
-    mcnt = d_mcnt.cpu().numpy().astype(np.int64)
-    kp_step = int(cnt.sum())
-    matches_step = int(mcnt.sum())
-    pairs_step = int((cnt * cnt[prev.cpu().numpy()]).sum())
+    kp_step = matches_step = pairs_step = 0
+    for ch in chains:
+        cnt = ch.bufs[0]["cnt"].cpu().numpy().astype(np.int64)
+        kp_step += int(cnt.sum())
+        matches_step += int(ch.bufs[0]["mcnt"].cpu().numpy().astype(np.int64).sum())
+        pairs_step += int((cnt * cnt[ch.prev.cpu().numpy()]).sum())
     totals = torch.tensor([kp_step, matches_step, pairs_step], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
@@ -201,7 +229,8 @@ def main():
                                            "describe": "k_describe", "match_near": "k_hamming_near",
                                            "match_resolve": "k_bf_resolve"}[dom],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "algorithmic_bytes_per_launch": int(ab[dom] * B), "launch_ms": round(stage_ms[dom], 5)}
+                "traffic": traffic, "algorithmic_bytes_per_launch": int(ab[dom] * Bc), "launch_ms": round(stage_ms[dom] / n_chain, 5),
+                "launches_per_step": n_chain}
         # whole extract against the SURVEY 8(d) per-frame figure (19 377 963 B at 1080p/2000)
         extract_ms = sum(stage_ms[k] for k in ("pyramid", "fast", "tree", "describe"))
         lv = level_sizes(ROWS, COLS)
@@ -229,8 +258,9 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 1920x1080 mono, 8 pyramid levels (x1.2), 2000 ORB features, extract + "
                                    "robust::brute_force_match (thr 50, ratio 0.9) against the previous frame",
                        "frames_per_step_per_gpu": B, "sharding": "frames across ranks, no collective",
-                       "schedule": ("matching of step k on a second stream under the extraction of step k+1 (double-buffered)"
-                                    if args.overlap else "one stream, serial")},
+                       "schedule": ("%d independent chain(s) of %d frames; " % (n_chain, Bc))
+                                   + ("matching of step k on a second stream under the extraction of step k+1 (double-buffered)"
+                                      if args.overlap else "extraction and matching serial on one stream")},
             "frames_per_sec": round(B * world * args.steps / elapsed, 2),
             "matches_per_sec": round(matches_all * args.steps / elapsed, 1),
             "hamming_distances_per_sec": round(pairs_all * args.steps / elapsed, 1),
