@@ -241,7 +241,7 @@ ovs_status ovs_projection_match_current_and_last_frames(ovs_wmatcher* w, const o
 /* replaces: unsigned int projection::match_frame_and_keyframe(data::frame& curr_frm, data::keyframe* keyfrm,
  *               const std::set<data::landmark*>& already_matched_lms, const float margin, const unsigned int hamm_dist_thr) const.
  * curr_occupied[j] != 0 iff curr_frm.landmarks_[j]; kf_kps = keyfrm->undist_keypts_; per keyframe keypoint i: kf_pos_w, kf_dist_min_max
- * (min / max valid distance), kf_lm_desc of landmarks[i]; kf_valid[i] != 0 iff landmarks[i] && !will_be_erased() &&
+ * (the RAW min_valid_dist_ / max_valid_dist_ members, see ovs_fuse_replace_duplication), kf_lm_desc of landmarks[i]; kf_valid[i] != 0 iff landmarks[i] && !will_be_erased() &&
  * !already_matched_lms.count(landmarks[i]). assigned[i] = current keypoint that receives landmarks[i], or -1. */
 ovs_status ovs_projection_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp,
                                                    const ovs_keypoint* curr_kps, const uint8_t* curr_desc, const uint8_t* curr_occupied,
@@ -254,8 +254,9 @@ ovs_status ovs_projection_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_ca
 /* replaces: the candidate search of  template<typename T> unsigned int fuse::replace_duplication(data::keyframe* keyfrm,
  *               const T& landmarks_to_check, const float margin)  (src/openvslam/match/fuse.{h,cc}); landmarks are independent there.
  * kps / desc / stereo_x_right = keyfrm->undist_keypts_ / descriptors_ / stereo_x_right_ (NULL = monocular); pose_cw = keyfrm pose.
- * Per landmark (in the order of landmarks_to_check): lm_pos_w = get_pos_in_world(), lm_dist_min_max = (get_min_valid_distance(),
- * get_max_valid_distance()), lm_normal = get_obs_mean_normal(), lm_desc = get_descriptor(), lm_valid != 0 iff lm &&
+ * Per landmark (in the order of landmarks_to_check): lm_pos_w = get_pos_in_world(), lm_dist_min_max = the RAW (min_valid_dist_,
+ * max_valid_dist_) members (the kernel applies the getters' 0.7 / 1.3 widening to the range gate and, like landmark::predict_scale_level,
+ * the raw maximum to the level prediction), lm_normal = get_obs_mean_normal(), lm_desc = get_descriptor(), lm_valid != 0 iff lm &&
  * !will_be_erased() && !is_observed_in_keyframe(keyfrm). inv_level_sigma_sq / log_scale_factor = the keyframe's tables.
  * best_idx[l] = keypoint the landmark fuses with or -1; the shim then performs upstream's replace / add_observation in order. */
 ovs_status ovs_fuse_replace_duplication(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps,

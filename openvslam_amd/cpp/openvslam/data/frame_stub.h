@@ -50,6 +50,8 @@ public:
 
 namespace data {
 
+class keyframe;
+
 using bow_feature_vector = std::map<unsigned int, std::vector<unsigned int>>;   // DBoW2::FeatureVector
 
 class landmark {
@@ -58,7 +60,24 @@ public:
     bool has_observation() const { return num_observations_ > 0; }
     cv::Mat get_descriptor() const { return descriptor_; }
     Vec3_t get_pos_in_world() const { return pos_w_; }
-    Vec3_t pos_w_;
+    Vec3_t get_obs_mean_normal() const { return mean_normal_; }
+    float get_min_valid_distance() const { return 0.7 * min_valid_dist_; }   // upstream widens the stored range by 30 %
+    float get_max_valid_distance() const { return 1.3 * max_valid_dist_; }
+    unsigned int num_observations() const { return num_observations_; }
+    bool is_observed_in_keyframe(keyframe* keyfrm) const { return observations_.count(keyfrm) != 0; }
+    int get_index_in_keyframe(keyframe* keyfrm) const {
+        const auto it = observations_.find(keyfrm);
+        return it == observations_.end() ? -1 : (int)it->second;
+    }
+    void add_observation(keyframe* keyfrm, unsigned int idx) {
+        if (observations_.count(keyfrm)) return;
+        observations_[keyfrm] = idx;
+        ++num_observations_;
+    }
+    inline void replace(landmark* lm);   // defined after keyframe
+    Vec3_t pos_w_, mean_normal_;
+    float min_valid_dist_ = 0, max_valid_dist_ = 0;
+    std::map<keyframe*, unsigned int> observations_;
     bool will_be_erased_ = false;
     unsigned int num_observations_ = 1;
     cv::Mat descriptor_;
@@ -79,9 +98,12 @@ public:
     std::vector<landmark*> landmarks_;
     std::vector<bool> outlier_flags_;
     std::vector<float> scale_factors_;
+    std::vector<float> inv_level_sigma_sq_;
+    float log_scale_factor_ = 0;
     camera::base* camera_ = nullptr;
     bow_feature_vector bow_feat_vec_;
     Mat44_t cam_pose_cw_;
+    void set_cam_pose(const Mat44_t& cam_pose_cw) { cam_pose_cw_ = cam_pose_cw; }
 };
 
 class keyframe {
@@ -94,11 +116,15 @@ public:
     cv::Mat descriptors_;
     std::vector<landmark*> landmarks_;
     std::vector<float> scale_factors_;
+    std::vector<float> inv_level_sigma_sq_;
+    float log_scale_factor_ = 0;
     camera::base* camera_ = nullptr;
     bow_feature_vector bow_feat_vec_;
     Mat44_t cam_pose_cw_;
+    Mat44_t get_cam_pose() const { return cam_pose_cw_; }
     std::vector<landmark*> get_landmarks() const { return landmarks_; }
     landmark* get_landmark(unsigned int idx) const { return landmarks_.at(idx); }
+    void add_landmark(landmark* lm, unsigned int idx) { landmarks_.at(idx) = lm; }
     Mat33_t get_rotation() const {
         Mat33_t r;
         for (int i = 0; i < 3; ++i)
@@ -117,6 +143,23 @@ public:
         return c;
     }
 };
+
+// landmark::replace(lm): this landmark's observations move to lm (keyframes that already see lm just drop this one), then it is erased
+inline void landmark::replace(landmark* lm) {
+    if (lm == this) return;
+    for (const auto& obs : observations_) {
+        keyframe* kf = obs.first;
+        if (!lm->is_observed_in_keyframe(kf)) {
+            kf->add_landmark(lm, obs.second);
+            lm->add_observation(kf, obs.second);
+        } else {
+            kf->add_landmark(nullptr, obs.second);
+        }
+    }
+    observations_.clear();
+    num_observations_ = 0;
+    will_be_erased_ = true;
+}
 
 }   // namespace data
 }   // namespace openvslam

@@ -32,5 +32,29 @@ unsigned int bow_tree::match_frame_and_keyframe(data::keyframe* keyfrm, data::fr
     return (unsigned int)num_matches;
 }
 
+unsigned int bow_tree::match_keyframes(data::keyframe* keyfrm_1, data::keyframe* keyfrm_2, std::vector<data::landmark*>& matched_lms_in_keyfrm_1) const {
+    const int n1 = (int)keyfrm_1->num_keypts_, n2 = (int)keyfrm_2->num_keypts_;
+    matched_lms_in_keyfrm_1 = std::vector<data::landmark*>((size_t)n1, nullptr);
+    if (n1 == 0 || n2 == 0) return 0;
+    const auto lms_1 = keyfrm_1->get_landmarks(), lms_2 = keyfrm_2->get_landmarks();
+    std::vector<uint8_t> v1((size_t)n1), v2((size_t)n2);
+    for (int i = 0; i < n1; ++i) v1[i] = lms_1[i] && !lms_1[i]->will_be_erased();
+    for (int i = 0; i < n2; ++i) v2[i] = lms_2[i] && !lms_2[i]->will_be_erased();
+    std::vector<int32_t> id1, st1, it1, id2, st2, it2;
+    flatten_bow(keyfrm_1->bow_feat_vec_, id1, st1, it1);
+    flatten_bow(keyfrm_2->bow_feat_vec_, id2, st2, it2);
+    std::vector<int32_t> matched((size_t)n1, -1);
+    int32_t num_matches = 0;
+    detail::check(ovs_bow_match_keyframes(detail::window_ctx().get(n2, n1), reinterpret_cast<const ovs_keypoint*>(keyfrm_1->keypts_.data()),
+                                          keyfrm_1->descriptors_.data, v1.data(), n1, id1.data(), st1.data(), it1.data(), (int)id1.size(),
+                                          reinterpret_cast<const ovs_keypoint*>(keyfrm_2->keypts_.data()), keyfrm_2->descriptors_.data, v2.data(), n2,
+                                          id2.data(), st2.data(), it2.data(), (int)id2.size(), lowe_ratio_, check_orientation_ ? 1 : 0,
+                                          matched.data(), &num_matches),
+                  "ovs_bow_match_keyframes");
+    for (int i = 0; i < n1; ++i)
+        if (matched[i] >= 0) matched_lms_in_keyfrm_1[(size_t)i] = lms_2[(size_t)matched[i]];
+    return (unsigned int)num_matches;
+}
+
 }   // namespace match
 }   // namespace openvslam

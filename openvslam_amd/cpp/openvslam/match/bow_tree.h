@@ -14,6 +14,9 @@ public:
     ~bow_tree() final = default;
 
     unsigned int match_frame_and_keyframe(data::keyframe* keyfrm, data::frame& frm, std::vector<data::landmark*>& matched_lms_in_frm) const;
+
+    //! loop detection: landmarks of two keyframes through their common vocabulary nodes
+    unsigned int match_keyframes(data::keyframe* keyfrm_1, data::keyframe* keyfrm_2, std::vector<data::landmark*>& matched_lms_in_keyfrm_1) const;
 };
 
 }   // namespace match

@@ -1,0 +1,122 @@
+// match::fuse over the C ABI. Replaces the bodies of fuse::replace_duplication / detect_duplication in src/openvslam/match/fuse.cc.
+#include "fuse.h"
+
+#include <cstring>
+#include <set>
+#include <unordered_set>
+
+#include "window_ctx.h"
+
+namespace openvslam {
+namespace match {
+
+namespace {
+struct flat_landmarks {
+    std::vector<double> pos, normal;
+    std::vector<float> dist;
+    std::vector<uint8_t> desc, valid;
+    template <typename IT, typename PRED>
+    flat_landmarks(IT begin, IT end, size_t m, PRED is_valid) : pos(3 * m), normal(3 * m), dist(2 * m), desc(32 * m), valid(m) {
+        size_t l = 0;
+        for (IT it = begin; it != end; ++it, ++l) {
+            data::landmark* lm = *it;
+            valid[l] = is_valid(lm) ? 1 : 0;
+            if (!valid[l]) continue;
+            const Vec3_t p = lm->get_pos_in_world(), n = lm->get_obs_mean_normal();
+            for (int a = 0; a < 3; ++a) {
+                pos[3 * l + a] = p(a);
+                normal[3 * l + a] = n(a);
+            }
+            dist[2 * l] = lm->min_valid_dist_;   // raw members: the kernel widens the gate as the getters do and predicts the level from the raw maximum
+            dist[2 * l + 1] = lm->max_valid_dist_;
+            const cv::Mat d = lm->get_descriptor();
+            std::memcpy(&desc[32 * l], d.data, 32);
+        }
+    }
+};
+}   // namespace
+
+template <typename T>
+unsigned int fuse::replace_duplication(data::keyframe* keyfrm, const T& landmarks_to_check, const float margin) const {
+    const int n = (int)keyfrm->num_keypts_, m = (int)landmarks_to_check.size();
+    if (n == 0 || m == 0) return 0;
+    auto usable = [&](data::landmark* lm) { return lm && !lm->will_be_erased() && !lm->is_observed_in_keyframe(keyfrm); };
+    const flat_landmarks f(landmarks_to_check.begin(), landmarks_to_check.end(), (size_t)m, usable);
+    const ovs_grid_params gp = detail::grid_of(keyfrm->camera_);
+    const ovs_camera cam = detail::camera_of(keyfrm->camera_);
+    double pose[12];
+    detail::pose12(keyfrm->get_cam_pose(), pose);
+    std::vector<int32_t> best((size_t)m, -1);
+    int32_t num = 0;
+    detail::check(ovs_fuse_replace_duplication(
+                      detail::window_ctx().get(n, m), &cam, &gp, reinterpret_cast<const ovs_keypoint*>(keyfrm->undist_keypts_.data()),
+                      keyfrm->descriptors_.data, keyfrm->stereo_x_right_.empty() ? nullptr : keyfrm->stereo_x_right_.data(), n, pose, f.pos.data(),
+                      f.dist.data(), f.normal.data(), f.desc.data(), f.valid.data(), m, keyfrm->scale_factors_.data(),
+                      keyfrm->inv_level_sigma_sq_.data(), (int)keyfrm->scale_factors_.size(), keyfrm->log_scale_factor_, margin, best.data(), &num),
+                  "ovs_fuse_replace_duplication");
+    // upstream's write-back, in the order of landmarks_to_check; an earlier replacement can erase or attach a later landmark
+    unsigned int num_fused = 0;
+    int l = 0;
+    for (auto it = landmarks_to_check.begin(); it != landmarks_to_check.end(); ++it, ++l) {
+        data::landmark* lm = *it;
+        if (best[l] < 0 || !usable(lm)) continue;
+        auto* lm_in_keyfrm = keyfrm->get_landmark((unsigned)best[l]);
+        if (lm_in_keyfrm) {
+            if (!lm_in_keyfrm->will_be_erased()) {
+                if (lm->num_observations() < lm_in_keyfrm->num_observations())   // keep the more reliable one
+                    lm->replace(lm_in_keyfrm);
+                else
+                    lm_in_keyfrm->replace(lm);
+            }
+        } else {
+            lm->add_observation(keyfrm, (unsigned)best[l]);
+            keyfrm->add_landmark(lm, (unsigned)best[l]);
+        }
+        ++num_fused;
+    }
+    return num_fused;
+}
+
+// the two instantiations upstream uses (mapping_module::fuse_landmark_duplication)
+template unsigned int fuse::replace_duplication(data::keyframe*, const std::vector<data::landmark*>&, const float) const;
+template unsigned int fuse::replace_duplication(data::keyframe*, const std::unordered_set<data::landmark*>&, const float) const;
+
+unsigned int fuse::detect_duplication(data::keyframe* keyfrm, const Mat44_t& Sim3_cw, const std::vector<data::landmark*>& landmarks_to_check,
+                                      const float margin, std::vector<data::landmark*>& duplicated_lms_in_keyfrm) const {
+    const int n = (int)keyfrm->num_keypts_, m = (int)landmarks_to_check.size();
+    duplicated_lms_in_keyfrm = std::vector<data::landmark*>((size_t)m, nullptr);
+    if (n == 0 || m == 0) return 0;
+    const auto valid_lms = keyfrm->get_landmarks();
+    const std::set<data::landmark*> already_matched(valid_lms.begin(), valid_lms.end());
+    auto usable = [&](data::landmark* lm) { return lm && !lm->will_be_erased() && !already_matched.count(lm); };
+    const flat_landmarks f(landmarks_to_check.begin(), landmarks_to_check.end(), (size_t)m, usable);
+    const ovs_grid_params gp = detail::grid_of(keyfrm->camera_);
+    const ovs_camera cam = detail::camera_of(keyfrm->camera_);
+    double sim3[12];
+    detail::pose12(Sim3_cw, sim3);
+    std::vector<int32_t> best((size_t)m, -1);
+    int32_t num = 0;
+    detail::check(ovs_fuse_detect_duplication(detail::window_ctx().get(n, m), &cam, &gp,
+                                              reinterpret_cast<const ovs_keypoint*>(keyfrm->undist_keypts_.data()), keyfrm->descriptors_.data, n,
+                                              sim3, f.pos.data(), f.dist.data(), f.normal.data(), f.desc.data(), f.valid.data(), m,
+                                              keyfrm->scale_factors_.data(), (int)keyfrm->scale_factors_.size(), keyfrm->log_scale_factor_,
+                                              margin, best.data(), &num),
+                  "ovs_fuse_detect_duplication");
+    unsigned int num_fused = 0;
+    for (int l = 0; l < m; ++l) {
+        if (best[l] < 0) continue;
+        data::landmark* lm = landmarks_to_check[l];
+        auto* lm_in_keyfrm = keyfrm->get_landmark((unsigned)best[l]);
+        if (lm_in_keyfrm) {
+            if (!lm_in_keyfrm->will_be_erased()) duplicated_lms_in_keyfrm[l] = lm_in_keyfrm;   // replaced by the caller under the map mutex
+        } else {
+            lm->add_observation(keyfrm, (unsigned)best[l]);
+            keyfrm->add_landmark(lm, (unsigned)best[l]);
+        }
+        ++num_fused;
+    }
+    return num_fused;
+}
+
+}   // namespace match
+}   // namespace openvslam

@@ -77,5 +77,125 @@ unsigned int projection::match_current_and_last_frames(data::frame& curr_frm, co
     return (unsigned int)num_matches;
 }
 
+namespace {
+// per keypoint of a keyframe: its landmark's position / valid distance range / mean normal / descriptor (rows of keypoints without a
+// usable landmark stay zero and are masked by `valid`)
+struct kf_landmarks {
+    std::vector<double> pos, normal;
+    std::vector<float> dist;
+    std::vector<uint8_t> desc, valid;
+    template <typename PRED>
+    kf_landmarks(const std::vector<data::landmark*>& lms, PRED usable) : pos(3 * lms.size()), normal(3 * lms.size()), dist(2 * lms.size()),
+                                                                          desc(32 * lms.size()), valid(lms.size()) {
+        for (size_t i = 0; i < lms.size(); ++i) {
+            data::landmark* lm = lms[i];
+            valid[i] = usable(lm, i) ? 1 : 0;
+            if (!valid[i]) continue;
+            const Vec3_t p = lm->get_pos_in_world(), n = lm->get_obs_mean_normal();
+            for (int a = 0; a < 3; ++a) {
+                pos[3 * i + a] = p(a);
+                normal[3 * i + a] = n(a);
+            }
+            dist[2 * i] = lm->min_valid_dist_;   // raw members: the kernel widens the gate as the getters do and predicts the level from the raw maximum
+            dist[2 * i + 1] = lm->max_valid_dist_;
+            const cv::Mat d = lm->get_descriptor();
+            std::memcpy(&desc[32 * i], d.data, 32);
+        }
+    }
+};
+}   // namespace
+
+unsigned int projection::match_frame_and_keyframe(data::frame& curr_frm, data::keyframe* keyfrm, const std::set<data::landmark*>& already_matched_lms,
+                                                  const float margin, const unsigned int hamm_dist_thr) const {
+    const int n_curr = (int)curr_frm.num_keypts_, n_kf = (int)keyfrm->num_keypts_;
+    if (n_curr == 0 || n_kf == 0) return 0;
+    const auto lms = keyfrm->get_landmarks();
+    const kf_landmarks f(lms, [&](data::landmark* lm, size_t) { return lm && !lm->will_be_erased() && !already_matched_lms.count(lm); });
+    std::vector<uint8_t> occupied((size_t)n_curr);
+    for (int i = 0; i < n_curr; ++i) occupied[i] = curr_frm.landmarks_[i] != nullptr;
+    const ovs_grid_params gp = detail::grid_of(curr_frm.camera_);
+    const ovs_camera cam = detail::camera_of(curr_frm.camera_);
+    double pose[12];
+    detail::pose12(curr_frm.cam_pose_cw_, pose);
+    std::vector<int32_t> assigned((size_t)n_kf, -1);
+    int32_t num_matches = 0;
+    detail::check(ovs_projection_match_frame_and_keyframe(
+                      detail::window_ctx().get(n_curr, n_kf), &cam, &gp, reinterpret_cast<const ovs_keypoint*>(curr_frm.undist_keypts_.data()),
+                      curr_frm.descriptors_.data, occupied.data(), n_curr, pose, reinterpret_cast<const ovs_keypoint*>(keyfrm->undist_keypts_.data()),
+                      f.pos.data(), f.dist.data(), f.desc.data(), f.valid.data(), n_kf, curr_frm.scale_factors_.data(),
+                      (int)curr_frm.scale_factors_.size(), curr_frm.log_scale_factor_, margin, hamm_dist_thr, check_orientation_ ? 1 : 0,
+                      assigned.data(), &num_matches),
+                  "ovs_projection_match_frame_and_keyframe");
+    for (int i = 0; i < n_kf; ++i)
+        if (assigned[i] >= 0) curr_frm.landmarks_[assigned[i]] = lms[i];
+    return (unsigned int)num_matches;
+}
+
+unsigned int projection::match_by_Sim3_transform(data::keyframe* keyfrm, const Mat44_t& Sim3_cw, const std::vector<data::landmark*>& landmarks,
+                                                 std::vector<data::landmark*>& matched_lms_in_keyfrm, const float margin) const {
+    const int n = (int)keyfrm->num_keypts_, m = (int)landmarks.size();
+    if (n == 0 || m == 0) return 0;
+    std::set<data::landmark*> already_matched(matched_lms_in_keyfrm.begin(), matched_lms_in_keyfrm.end());
+    already_matched.erase(static_cast<data::landmark*>(nullptr));
+    const kf_landmarks f(landmarks, [&](data::landmark* lm, size_t) { return lm && !lm->will_be_erased() && !already_matched.count(lm); });
+    std::vector<uint8_t> occupied((size_t)n);
+    for (int k = 0; k < n; ++k) occupied[k] = matched_lms_in_keyfrm.at((size_t)k) != nullptr;
+    const ovs_grid_params gp = detail::grid_of(keyfrm->camera_);
+    const ovs_camera cam = detail::camera_of(keyfrm->camera_);
+    double sim3[12];
+    detail::pose12(Sim3_cw, sim3);
+    std::vector<int32_t> assigned((size_t)m, -1);
+    int32_t num_matches = 0;
+    detail::check(ovs_projection_match_by_sim3_transform(
+                      detail::window_ctx().get(n, m), &cam, &gp, reinterpret_cast<const ovs_keypoint*>(keyfrm->undist_keypts_.data()),
+                      keyfrm->descriptors_.data, occupied.data(), n, sim3, f.pos.data(), f.dist.data(), f.normal.data(), f.desc.data(), f.valid.data(),
+                      m, keyfrm->scale_factors_.data(), (int)keyfrm->scale_factors_.size(), keyfrm->log_scale_factor_, margin, assigned.data(),
+                      &num_matches),
+                  "ovs_projection_match_by_sim3_transform");
+    for (int l = 0; l < m; ++l)
+        if (assigned[l] >= 0) matched_lms_in_keyfrm[(size_t)assigned[l]] = landmarks[l];
+    return (unsigned int)num_matches;
+}
+
+unsigned int projection::match_keyframes_mutually(data::keyframe* keyfrm_1, data::keyframe* keyfrm_2, std::vector<data::landmark*>& matched_lms_in_keyfrm_1,
+                                                  const float& s_12, const Mat33_t& rot_12, const Vec3_t& trans_12, const float margin) const {
+    const int n1 = (int)keyfrm_1->num_keypts_, n2 = (int)keyfrm_2->num_keypts_;
+    if (n1 == 0 || n2 == 0) return 0;
+    const auto lms_1 = keyfrm_1->get_landmarks(), lms_2 = keyfrm_2->get_landmarks();
+    // upstream's two is_already_matched vectors
+    std::vector<bool> matched_1((size_t)n1, false), matched_2((size_t)n2, false);
+    for (int i = 0; i < n1; ++i) {
+        auto* lm = matched_lms_in_keyfrm_1.at((size_t)i);
+        if (!lm) continue;
+        matched_1[i] = true;
+        const int idx_2 = lm->get_index_in_keyframe(keyfrm_2);
+        if (0 <= idx_2 && idx_2 < n2) matched_2[idx_2] = true;
+    }
+    const kf_landmarks f1(lms_1, [&](data::landmark* lm, size_t i) { return lm && !matched_1[i] && !lm->will_be_erased(); });
+    const kf_landmarks f2(lms_2, [&](data::landmark* lm, size_t i) { return lm && !matched_2[i] && !lm->will_be_erased(); });
+    const ovs_grid_params gp_1 = detail::grid_of(keyfrm_1->camera_), gp_2 = detail::grid_of(keyfrm_2->camera_);
+    const ovs_camera cam_1 = detail::camera_of(keyfrm_1->camera_), cam_2 = detail::camera_of(keyfrm_2->camera_);
+    double pose_1[12], pose_2[12], R[9], t[3];
+    detail::pose12(keyfrm_1->get_cam_pose(), pose_1);
+    detail::pose12(keyfrm_2->get_cam_pose(), pose_2);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = rot_12(i, j);
+        t[i] = trans_12(i);
+    }
+    std::vector<int32_t> m21((size_t)n1, -1);
+    int32_t num_matches = 0;
+    const int nmax = n1 > n2 ? n1 : n2;
+    detail::check(ovs_projection_match_keyframes_mutually(
+                      detail::window_ctx().get(nmax, nmax), &cam_1, &gp_1, reinterpret_cast<const ovs_keypoint*>(keyfrm_1->undist_keypts_.data()),
+                      keyfrm_1->descriptors_.data, n1, pose_1, f1.pos.data(), f1.dist.data(), f1.desc.data(), f1.valid.data(), &cam_2, &gp_2,
+                      reinterpret_cast<const ovs_keypoint*>(keyfrm_2->undist_keypts_.data()), keyfrm_2->descriptors_.data, n2, pose_2, f2.pos.data(),
+                      f2.dist.data(), f2.desc.data(), f2.valid.data(), (double)s_12, R, t, keyfrm_1->scale_factors_.data(),
+                      (int)keyfrm_1->scale_factors_.size(), keyfrm_1->log_scale_factor_, margin, m21.data(), &num_matches),
+                  "ovs_projection_match_keyframes_mutually");
+    for (int i = 0; i < n1; ++i)
+        if (m21[i] >= 0) matched_lms_in_keyfrm_1[(size_t)i] = lms_2[(size_t)m21[i]];
+    return (unsigned int)num_matches;
+}
+
 }   // namespace match
 }   // namespace openvslam

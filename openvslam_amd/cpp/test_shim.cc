@@ -5,11 +5,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <set>
 #include <vector>
 
 #include "openvslam/feature/orb_extractor.h"
 #include "openvslam/match/area.h"
 #include "openvslam/match/bow_tree.h"
+#include "openvslam/match/fuse.h"
+#include "openvslam/optimize/pose_optimizer.h"
 #include "openvslam/match/projection.h"
 #include "openvslam/match/robust.h"
 #include "openvslam/match/stereo.h"
@@ -181,6 +184,142 @@ int main(int argc, char** argv) {
     const unsigned n_tri = match::robust(0.6f, true).match_for_triangulation(&kf1, &kf2, E_12, tri_pairs);
     std::vector<int32_t> tri_2_in_1(kf1.num_keypts_, -1);
     for (const auto& pr : tri_pairs) tri_2_in_1[pr.first] = (int32_t)pr.second;
+    // pose_optimizer: the current frame with the landmarks match_current_and_last_frames gave it, from a perturbed pose
+    data::frame pfrm = curr;
+    pfrm.inv_level_sigma_sq_.resize(pfrm.scale_factors_.size());
+    for (size_t l = 0; l < pfrm.scale_factors_.size(); ++l) pfrm.inv_level_sigma_sq_[l] = 1.0f / (pfrm.scale_factors_[l] * pfrm.scale_factors_[l]);
+    pfrm.cam_pose_cw_(0, 3) = 0.02;
+    pfrm.cam_pose_cw_(1, 3) = -0.015;
+    pfrm.cam_pose_cw_(2, 3) = 0.01;
+    const unsigned n_pose_valid = optimize::pose_optimizer().optimize(pfrm);
+    // fuse::replace_duplication: keyframe = frame b (identity pose); landmarks_to_check = frame a's landmarks (positions as above); every
+    // fifth keypoint of the keyframe already owns a landmark with three observations
+    data::keyframe fkf;
+    fkf.keypts_ = fkf.undist_keypts_ = keyfrm.keypts_;
+    fkf.descriptors_ = keyfrm.descriptors_;
+    fkf.num_keypts_ = keyfrm.num_keypts_;
+    fkf.scale_factors_ = extractor.get_scale_factors();
+    fkf.inv_level_sigma_sq_ = pfrm.inv_level_sigma_sq_;
+    fkf.log_scale_factor_ = std::log(1.2f);
+    fkf.camera_ = &pcam;
+    fkf.landmarks_.assign(fkf.num_keypts_, nullptr);
+    std::vector<std::unique_ptr<data::landmark>> fuse_own;
+    for (unsigned j = 0; j < fkf.num_keypts_; j += 5) {
+        fuse_own.emplace_back(new data::landmark());
+        auto* lm = fuse_own.back().get();
+        lm->num_observations_ = 2;          // + the observation added below = 3
+        lm->add_observation(&fkf, j);
+        fkf.landmarks_[j] = lm;
+    }
+    const size_t n_kf_lms = fuse_own.size();
+    std::vector<data::landmark*> to_check;
+    const std::vector<float> sfs = extractor.get_scale_factors();
+    for (unsigned i = 0; i < last.num_keypts_; ++i) {
+        fuse_own.emplace_back(new data::landmark());
+        auto* lm = fuse_own.back().get();
+        if (last.landmarks_[i]) lm->pos_w_ = last.landmarks_[i]->pos_w_;
+        else lm->pos_w_(2) = -1.0;          // behind the camera
+        const double dist = std::sqrt((lm->pos_w_(0) * lm->pos_w_(0) + lm->pos_w_(1) * lm->pos_w_(1)) + lm->pos_w_(2) * lm->pos_w_(2));
+        for (int a = 0; a < 3; ++a) lm->mean_normal_(a) = lm->pos_w_(a) / dist;
+        lm->max_valid_dist_ = (float)(dist * sfs[(size_t)last.undist_keypts_[i].octave] * 0.93);   // 0.93: keeps ceil(log ratio) off the knife edge
+        lm->min_valid_dist_ = lm->max_valid_dist_ / sfs.back() * 0.8f;
+        lm->descriptor_ = last.descriptors_.row((int)i);
+        lm->num_observations_ = 1 + i % 4;
+        lm->will_be_erased_ = (i % 17 == 3);
+        to_check.push_back(lm);
+    }
+    const unsigned n_fused = match::fuse(0.6f).replace_duplication(&fkf, to_check, 3.0f);
+    std::vector<int32_t> fuse_slots(fkf.num_keypts_, -1);   // who sits on keypoint j afterwards: index in to_check, or 100000 + original owner
+    for (unsigned j = 0; j < fkf.num_keypts_; ++j) {
+        if (!fkf.landmarks_[j]) continue;
+        for (size_t q = 0; q < fuse_own.size(); ++q)
+            if (fuse_own[q].get() == fkf.landmarks_[j]) fuse_slots[j] = q < n_kf_lms ? (int32_t)(100000 + q) : (int32_t)(q - n_kf_lms);
+    }
+    std::vector<uint8_t> fuse_erased(fuse_own.size());
+    for (size_t q = 0; q < fuse_own.size(); ++q) fuse_erased[q] = fuse_own[q]->will_be_erased();
+    // ---- the remaining projection overloads and bow_tree::match_keyframes on one scene: keyframes A (frame a) and B (frame b), identity
+    //      poses, every keypoint owns a landmark at depth 5 back-projected from its own position
+    auto make_kf = [&](data::keyframe& kf, const std::vector<cv::KeyPoint>& kps, const cv::Mat& desc, std::vector<std::unique_ptr<data::landmark>>& own) {
+        kf.keypts_ = kf.undist_keypts_ = kps;
+        kf.descriptors_ = desc;
+        kf.num_keypts_ = kps.size();
+        kf.scale_factors_ = sfs;
+        kf.inv_level_sigma_sq_ = pfrm.inv_level_sigma_sq_;
+        kf.log_scale_factor_ = std::log(1.2f);
+        kf.camera_ = &pcam;
+        kf.landmarks_.assign(kf.num_keypts_, nullptr);
+        for (unsigned i = 0; i < kf.num_keypts_; ++i) {
+            kf.bow_feat_vec_[desc.ptr((int)i)[0] & 127u].push_back(i);
+            if (i % 9 == 4) continue;
+            own.emplace_back(new data::landmark());
+            auto* lm = own.back().get();
+            lm->pos_w_(0) = ((double)kps[i].pt.x - pcam.cx_) / pcam.fx_ * 5.0;
+            lm->pos_w_(1) = ((double)kps[i].pt.y - pcam.cy_) / pcam.fy_ * 5.0;
+            lm->pos_w_(2) = 5.0;
+            const double dist = std::sqrt((lm->pos_w_(0) * lm->pos_w_(0) + lm->pos_w_(1) * lm->pos_w_(1)) + 25.0);
+            for (int a = 0; a < 3; ++a) lm->mean_normal_(a) = lm->pos_w_(a) / dist;
+            lm->max_valid_dist_ = (float)(dist * sfs[(size_t)kps[i].octave] * 0.93);
+            lm->min_valid_dist_ = lm->max_valid_dist_ / sfs.back() * 0.8f;
+            lm->descriptor_ = desc.row((int)i);
+            lm->will_be_erased_ = (i % 19 == 6);
+            lm->add_observation(&kf, i);
+            kf.landmarks_[i] = lm;
+        }
+    };
+    std::vector<std::unique_ptr<data::landmark>> own_a, own_b;
+    data::keyframe kfa, kfb;
+    make_kf(kfa, frm.keypts_, frm.descriptors_, own_a);
+    make_kf(kfb, keyfrm.keypts_, keyfrm.descriptors_, own_b);
+    auto index_in = [](const data::keyframe& kf, const data::landmark* lm) -> int32_t {
+        if (!lm) return -1;
+        for (unsigned i = 0; i < kf.num_keypts_; ++i)
+            if (kf.landmarks_[i] == lm) return (int32_t)i;
+        return -2;
+    };
+    // match_frame_and_keyframe: frame b looks at keyframe A's landmarks from a camera displaced by the image shift at depth 5
+    data::frame fb2 = frm_b;
+    fb2.camera_ = &pcam;
+    fb2.log_scale_factor_ = std::log(1.2f);
+    fb2.landmarks_.assign(fb2.num_keypts_, nullptr);
+    fb2.cam_pose_cw_(0, 3) = -4.0 / pcam.fx_ * 5.0;
+    fb2.cam_pose_cw_(1, 3) = -3.0 / pcam.fy_ * 5.0;
+    std::set<data::landmark*> already;
+    for (unsigned i = 0; i < kfa.num_keypts_; i += 23)
+        if (kfa.landmarks_[i]) already.insert(kfa.landmarks_[i]);
+    const unsigned n_fk = match::projection(0.9f, true).match_frame_and_keyframe(fb2, &kfa, already, 10.0f, 100);
+    std::vector<int32_t> fk_owner(fb2.num_keypts_);
+    for (unsigned j = 0; j < fb2.num_keypts_; ++j) fk_owner[j] = index_in(kfa, fb2.landmarks_[j]);
+    // match_by_Sim3_transform: keyframe B under the Sim3 [1.5 R | 1.5 t] of that same displaced pose, keyframe A's landmarks
+    Mat44_t S_cw = fb2.cam_pose_cw_;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) S_cw(i, j) *= 1.5;
+    std::vector<data::landmark*> lms_a = kfa.get_landmarks();
+    std::vector<data::landmark*> matched_in_b(kfb.num_keypts_, nullptr);
+    for (unsigned j = 0; j < kfb.num_keypts_; j += 29) matched_in_b[j] = lms_a[(j * 7) % kfa.num_keypts_];   // may be null
+    const std::vector<data::landmark*> matched_in_b_before = matched_in_b;
+    const unsigned n_s3 = match::projection(0.9f, false).match_by_Sim3_transform(&kfb, S_cw, lms_a, matched_in_b, 8.0f);
+    std::vector<int32_t> s3_owner(kfb.num_keypts_);
+    for (unsigned j = 0; j < kfb.num_keypts_; ++j) s3_owner[j] = index_in(kfa, matched_in_b[j]);
+    // match_keyframes_mutually: Sim3_12 = (1, I, t_12) with t_12 the displacement that takes B's camera coordinates to A's
+    std::vector<data::landmark*> matched_1(kfa.num_keypts_, nullptr);
+    for (unsigned i = 0; i < kfa.num_keypts_; i += 31) matched_1[i] = kfb.landmarks_[(i * 3) % kfb.num_keypts_];   // may be null
+    Mat33_t R_12;
+    Vec3_t t_12;
+    t_12(0) = 4.0 / pcam.fx_ * 5.0;
+    t_12(1) = 3.0 / pcam.fy_ * 5.0;
+    t_12(2) = 0.0;
+    const std::vector<data::landmark*> matched_1_before = matched_1;
+    const unsigned n_mut = match::projection(0.9f, false).match_keyframes_mutually(&kfa, &kfb, matched_1, 1.0f, R_12, t_12, 7.5f);
+    std::vector<int32_t> mut_2_in_1(kfa.num_keypts_);
+    for (unsigned i = 0; i < kfa.num_keypts_; ++i) mut_2_in_1[i] = matched_1[i] == matched_1_before[i] && matched_1[i] ? -3 : index_in(kfb, matched_1[i]);
+    // bow_tree::match_keyframes
+    std::vector<data::landmark*> bow_lms_1;
+    const unsigned n_bk = match::bow_tree(0.75f, true).match_keyframes(&kfa, &kfb, bow_lms_1);
+    std::vector<int32_t> bk_2_in_1(kfa.num_keypts_);
+    for (unsigned i = 0; i < kfa.num_keypts_; ++i) bk_2_in_1[i] = index_in(kfb, bow_lms_1[i]);
+    const int32_t hdr4[4] = {(int32_t)n_fk, (int32_t)n_s3, (int32_t)n_mut, (int32_t)n_bk};
+    (void)matched_in_b_before;
+    const int32_t hdr3[4] = {(int32_t)n_pose_valid, (int32_t)n_fused, (int32_t)n_kf_lms, (int32_t)to_check.size()};
     const int32_t hdr2[6] = {(int32_t)n_area, (int32_t)n_proj, (int32_t)n_bow, (int32_t)stereo_x_right.size(), (int32_t)n_cl, (int32_t)n_tri};
     std::fwrite(hdr2, sizeof(hdr2), 1, f);
     std::fwrite(matched_2_in_1.data(), sizeof(int), matched_2_in_1.size(), f);
@@ -191,6 +330,18 @@ int main(int argc, char** argv) {
     std::fwrite(depths.data(), sizeof(float), depths.size(), f);
     std::fwrite(cl_assigned.data(), sizeof(int32_t), cl_assigned.size(), f);
     std::fwrite(tri_2_in_1.data(), sizeof(int32_t), tri_2_in_1.size(), f);
+    std::fwrite(hdr3, sizeof(hdr3), 1, f);
+    std::fwrite(pfrm.cam_pose_cw_.m, sizeof(double), 12, f);
+    std::vector<uint8_t> pose_outliers(pfrm.num_keypts_);
+    for (unsigned j = 0; j < pfrm.num_keypts_; ++j) pose_outliers[j] = pfrm.outlier_flags_[j];
+    std::fwrite(pose_outliers.data(), 1, pose_outliers.size(), f);
+    std::fwrite(fuse_slots.data(), sizeof(int32_t), fuse_slots.size(), f);
+    std::fwrite(fuse_erased.data(), 1, fuse_erased.size(), f);
+    std::fwrite(hdr4, sizeof(hdr4), 1, f);
+    std::fwrite(fk_owner.data(), sizeof(int32_t), fk_owner.size(), f);
+    std::fwrite(s3_owner.data(), sizeof(int32_t), s3_owner.size(), f);
+    std::fwrite(mut_2_in_1.data(), sizeof(int32_t), mut_2_in_1.size(), f);
+    std::fwrite(bk_2_in_1.data(), sizeof(int32_t), bk_2_in_1.size(), f);
     std::fclose(f);
     std::printf("shim ok: %u + %u keypoints, %u matches, scale[7]=%f\n", frm.num_keypts_, keyfrm.num_keypts_, n, extractor.get_scale_factors().at(7));
     return 0;

@@ -298,8 +298,10 @@ __global__ __launch_bounds__(256) void k_reproject_queries(CamP cam, const ovs_k
         // match_frame_and_keyframe: valid distance range, level from the distance (landmark::predict_scale_level), window [pred-1, pred+1]
         const double dx = X[0] - ccx, dy = X[1] - ccy, dz = X[2] - ccz;
         const double dist = sqrt((dx * dx + dy * dy) + dz * dz);
+        // landmark::get_min_valid_distance() = 0.7 * min_valid_dist_, get_max_valid_distance() = 1.3 * max_valid_dist_ (double product
+        // returned as float) gate the range; predict_scale_level uses the RAW max_valid_dist_
         const float dmin = dist_min_max[2 * i], dmax = dist_min_max[2 * i + 1];
-        if (dist < dmin || dmax < dist) valid = false;
+        if (dist < (double)(float)(0.7 * (double)dmin) || (double)(float)(1.3 * (double)dmax) < dist) valid = false;
         if (normals) {   // match_by_Sim3_transform: viewing-angle gate against the landmark's mean normal
             const double* nrm = normals + 3 * (size_t)i;
             if ((dx * nrm[0] + dy * nrm[1]) + dz * nrm[2] < 0.5 * dist) valid = false;
@@ -379,8 +381,8 @@ __global__ __launch_bounds__(256) void k_fuse_best(FuseArgs a, int32_t* __restri
             dz = X[2] - a.cc[2];
         }
         const double dist = sqrt((dx * dx + dy * dy) + dz * dz);
-        const float dmin = a.lm_dist[2 * l], dmax = a.lm_dist[2 * l + 1];
-        if (dist < dmin || dmax < dist) break;
+        const float dmin = a.lm_dist[2 * l], dmax = a.lm_dist[2 * l + 1];   // raw min_valid_dist_ / max_valid_dist_
+        if (dist < (double)(float)(0.7 * (double)dmin) || (double)(float)(1.3 * (double)dmax) < dist) break;
         if (a.variant != kFuseMutual) {
             const double* nrm = a.lm_normal + 3 * (size_t)l;
             if ((dx * nrm[0] + dy * nrm[1]) + dz * nrm[2] < 0.5 * dist) break;

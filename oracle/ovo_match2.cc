@@ -324,6 +324,12 @@ int ovo_bow_match_frame_and_keyframe(const uint8_t* kf_desc, const float* kf_ang
     return num_matches;
 }
 
+// landmark::get_min_valid_distance() / get_max_valid_distance() (expected: src/openvslam/data/landmark.cc): the stored range widened by
+// 30 %, `return 0.7 * min_valid_dist_;` / `return 1.3 * max_valid_dist_;` -- a double product returned as float. The range gate uses
+// these; landmark::predict_scale_level uses the RAW max_valid_dist_. The *_dist_min_max arrays below carry the raw members.
+static inline double valid_min(float raw) { return (double)(float)(0.7 * (double)raw); }
+static inline double valid_max(float raw) { return (double)(float)(1.3 * (double)raw); }
+
 // camera::perspective / camera::equirectangular ::reproject_to_image (expected: src/openvslam/camera/{perspective,equirectangular}.cc).
 // Double precision, one rounding per operation (no FMA contraction: the library is built with -ffp-contract=off).
 static bool reproject_to_image(const ovo_camera& cam, const ovo_grid_params& b, const double* P, const double* X, double* reproj,
@@ -461,7 +467,7 @@ int ovo_fuse_replace_duplication(const ovo_camera* cam, const ovo_grid_params* g
         const double v[3] = {X[0] - cc[0], X[1] - cc[1], X[2] - cc[2]};
         const double dist = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
         const float dmin = lm_dist_min_max[2 * l], dmax = lm_dist_min_max[2 * l + 1];
-        if (dist < dmin || dmax < dist) continue;
+        if (dist < valid_min(dmin) || valid_max(dmax) < dist) continue;
         const double* nrm = lm_normal + 3 * (size_t)l;
         if ((v[0] * nrm[0] + v[1] * nrm[1]) + v[2] * nrm[2] < 0.5 * dist) continue;
         // landmark::predict_scale_level(cam_to_lm_dist, keyfrm)
@@ -584,7 +590,7 @@ int ovo_projection_match_frame_and_keyframe(const ovo_camera* cam, const ovo_gri
         const double v[3] = {X[0] - cc[0], X[1] - cc[1], X[2] - cc[2]};
         const double dist = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
         const float dmin = kf_dist_min_max[2 * i], dmax = kf_dist_min_max[2 * i + 1];
-        if (dist < dmin || dmax < dist) continue;
+        if (dist < valid_min(dmin) || valid_max(dmax) < dist) continue;
         const float ratio = dmax / (float)dist;
         int pred = (int)std::ceil(std::log(ratio) / log_scale_factor);
         if (pred < 0) pred = 0;
@@ -651,7 +657,7 @@ int ovo_fuse_detect_duplication(const ovo_camera* cam, const ovo_grid_params* gp
         const double v[3] = {X[0] - cc[0], X[1] - cc[1], X[2] - cc[2]};
         const double dist = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
         const float dmin = lm_dist_min_max[2 * l], dmax = lm_dist_min_max[2 * l + 1];
-        if (dist < dmin || dmax < dist) continue;
+        if (dist < valid_min(dmin) || valid_max(dmax) < dist) continue;
         const double* nrm = lm_normal + 3 * (size_t)l;
         if ((v[0] * nrm[0] + v[1] * nrm[1]) + v[2] * nrm[2] < 0.5 * dist) continue;
         const float ratio = dmax / (float)dist;
@@ -704,7 +710,7 @@ int ovo_projection_match_by_sim3_transform(const ovo_camera* cam, const ovo_grid
         const double v[3] = {X[0] - cc[0], X[1] - cc[1], X[2] - cc[2]};
         const double dist = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
         const float dmin = lm_dist_min_max[2 * l], dmax = lm_dist_min_max[2 * l + 1];
-        if (dist < dmin || dmax < dist) continue;
+        if (dist < valid_min(dmin) || valid_max(dmax) < dist) continue;
         const double* nrm = lm_normal + 3 * (size_t)l;
         if ((v[0] * nrm[0] + v[1] * nrm[1]) + v[2] * nrm[2] < 0.5 * dist) continue;
         const float ratio = dmax / (float)dist;
@@ -752,7 +758,7 @@ static void mutual_pass(const ovo_camera& cam_b, const ovo_grid_params& gp_b, co
                               (S_ba[6] * pa[0] + S_ba[7] * pa[1]) + S_ba[8] * pa[2] + S_ba[11]};
         const double dist = std::sqrt((pb[0] * pb[0] + pb[1] * pb[1]) + pb[2] * pb[2]);
         const float dmin = lm_dist_min_max[2 * i], dmax = lm_dist_min_max[2 * i + 1];
-        if (dist < dmin || dmax < dist) continue;
+        if (dist < valid_min(dmin) || valid_max(dmax) < dist) continue;
         const float ratio = dmax / (float)dist;
         int pred = (int)std::ceil(std::log(ratio) / log_scale_factor);
         if (pred < 0) pred = 0;

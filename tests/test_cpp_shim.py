@@ -1,4 +1,4 @@
-"""The C++ class shims (openvslam_amd/cpp: feature::orb_extractor and match::{robust, area, projection, bow_tree, stereo} with
+"""The C++ class shims (openvslam_amd/cpp: feature::orb_extractor and match::{robust, area, projection, bow_tree, stereo, fuse} and optimize::pose_optimizer with
 upstream's signatures) produce the oracle's results when driven the way tracking / initialisation code drives them."""
 import os
 import subprocess
@@ -44,6 +44,16 @@ def test_shim_matches_oracle(oracle, tmp_path):
     st_d = np.frombuffer(raw[off:off + 4 * n_st], np.uint32); off += 4 * n_st
     cl_assigned = np.frombuffer(raw[off:off + 4 * na], np.int32); off += 4 * na
     tri_m = np.frombuffer(raw[off:off + 4 * na], np.int32); off += 4 * na
+    n_pose_valid, n_fused, n_kf_lms, n_check = (int(v) for v in np.frombuffer(raw[off:off + 16], np.int32)); off += 16
+    pose_out = np.frombuffer(raw[off:off + 96], np.float64).reshape(3, 4); off += 96
+    pose_outliers = np.frombuffer(raw[off:off + nb], np.uint8); off += nb
+    fuse_slots = np.frombuffer(raw[off:off + 4 * nb], np.int32); off += 4 * nb
+    fuse_erased = np.frombuffer(raw[off:off + n_kf_lms + n_check], np.uint8); off += n_kf_lms + n_check
+    n_fk, n_s3, n_mut, n_bk = (int(v) for v in np.frombuffer(raw[off:off + 16], np.int32)); off += 16
+    fk_owner = np.frombuffer(raw[off:off + 4 * nb], np.int32); off += 4 * nb
+    s3_owner = np.frombuffer(raw[off:off + 4 * nb], np.int32); off += 4 * nb
+    mut_m = np.frombuffer(raw[off:off + 4 * na], np.int32); off += 4 * na
+    bk_m = np.frombuffer(raw[off:off + 4 * na], np.int32); off += 4 * na
     assert off == len(raw)
     ox = oracle.OrbExtractor(oracle.make_params(nfeat))
     wa, wda = ox.extract(a)
@@ -105,3 +115,123 @@ def test_shim_matches_oracle(oracle, tmp_path):
     wn, want = oracle.robust_match_for_triangulation(wa, wda, fv_a, bearings(wa), wb, wdb, fv_b, bearings(wb), E12, ep, sf, True, has_lm_1=h1,
                                                      has_lm_2=h2)
     assert n_tri == wn and np.array_equal(tri_m, want) and wn > 20
+
+    # ---- optimize::pose_optimizer (the frame as match_current_and_last_frames left it, perturbed pose)
+    inv_sig = (np.float32(1.0) / (sf * sf)).astype(np.float32)
+    held = np.flatnonzero(want_cl_holder := np.isin(np.arange(nb), cl_assigned[cl_assigned >= 0]))
+    owner = {int(j): int(i) for i, j in enumerate(cl_assigned) if j >= 0}
+    obs = np.zeros(len(held), oracle.POSE_OBS_DTYPE)
+    for k, j in enumerate(held):
+        obs[k]["pos_w"] = pos[owner[int(j)]]
+        obs[k]["obs_x"], obs[k]["obs_y"] = wb["x"][j], wb["y"][j]
+        obs[k]["inv_sigma_sq"] = inv_sig[wb["octave"][j]]
+    T0 = np.eye(4)[:3].copy()
+    T0[:, 3] = [0.02, -0.015, 0.01]
+    wT, wout, wnv = oracle.pose_optimize(T0, obs, (fx, fy, cx, cy), 0.0)
+    assert n_pose_valid == wnv and np.allclose(pose_out, wT, rtol=0, atol=1e-9) and wnv > 100
+    exp_flags = np.zeros(nb, np.uint8)
+    exp_flags[held] = wout
+    assert np.array_equal(pose_outliers, exp_flags)
+
+    # ---- match::fuse::replace_duplication: the oracle's candidate search + upstream's write-back rules replayed here
+    assert n_check == na and n_kf_lms == (nb + 4) // 5
+    has_lm = (idx % 13 != 5)
+    fpos = np.where(has_lm[:, None], pos, np.array([[0.0, 0.0, -1.0]]))
+    dist = np.sqrt((fpos[:, 0] * fpos[:, 0] + fpos[:, 1] * fpos[:, 1]) + fpos[:, 2] * fpos[:, 2])
+    nrm = fpos / dist[:, None]
+    stored_max = (dist * sf[wa["octave"]].astype(np.float64) * 0.93).astype(np.float32)
+    stored_min = (stored_max / sf[-1] * np.float32(0.8)).astype(np.float32)
+    dmm = np.stack([stored_min, stored_max], 1).astype(np.float32)     # the ABI takes the raw members
+    erased = (idx % 17 == 3)
+    best, _ = oracle.fuse_replace_duplication(ocam, gp, wb, wdb, T, fpos, dmm, nrm, wda, sf, inv_sig, float(np.log(np.float32(1.2))), 3.0,
+                                              lm_valid=(~erased).astype(np.uint8))
+    slots = {j: ("kf", j // 5) for j in range(0, nb, 5)}           # keypoint -> landmark
+    n_obs = {("kf", q): 3 for q in range(n_kf_lms)}
+    n_obs.update({("c", i): 1 + i % 4 for i in range(na)})
+    dead = {("c", i) for i in range(na) if erased[i]}
+    seen_in_kf = set(slots.values())
+    exp_fused = 0
+    for i in range(na):
+        lm = ("c", i)
+        if best[i] < 0 or lm in dead or lm in seen_in_kf:
+            continue
+        j = int(best[i])
+        cur = slots.get(j)
+        if cur is not None:
+            if cur not in dead:
+                if n_obs[lm] < n_obs[cur]:                          # lm->replace(cur): lm's observations (none in this keyframe) move, lm dies
+                    dead.add(lm)
+                else:                                               # cur->replace(lm): lm takes cur's keypoint
+                    dead.add(cur)
+                    seen_in_kf.discard(cur)
+                    slots[j] = lm
+                    seen_in_kf.add(lm)
+                    n_obs[lm] += 1
+        else:
+            slots[j] = lm
+            seen_in_kf.add(lm)
+            n_obs[lm] += 1
+        exp_fused += 1
+    exp_slots = np.full(nb, -1, np.int32)
+    for j, lm in slots.items():
+        exp_slots[j] = 100000 + lm[1] if lm[0] == "kf" else lm[1]
+    exp_erased = np.array([("kf", q) in dead for q in range(n_kf_lms)] + [("c", i) in dead for i in range(na)], np.uint8)
+    assert n_fused == exp_fused and exp_fused > 100
+    assert np.array_equal(fuse_slots, exp_slots) and np.array_equal(fuse_erased, exp_erased)
+
+    # ---- the remaining projection overloads and bow_tree::match_keyframes: keyframes A / B, a landmark at depth 5 on every keypoint
+    def kf_scene(k):
+        n = len(k)
+        ii = np.arange(n)
+        p = np.stack([(k["x"].astype(np.float64) - cx) / fx * 5.0, (k["y"].astype(np.float64) - cy) / fy * 5.0, np.full(n, 5.0)], 1)
+        d = np.sqrt((p[:, 0] * p[:, 0] + p[:, 1] * p[:, 1]) + 25.0)
+        smax = (d * sf[k["octave"]].astype(np.float64) * 0.93).astype(np.float32)
+        smin = (smax / sf[-1] * np.float32(0.8)).astype(np.float32)
+        rng_ = np.stack([smin, smax], 1).astype(np.float32)
+        exists = ii % 9 != 4
+        live = exists & (ii % 19 != 6)
+        return p, p / d[:, None], rng_, exists, live
+
+    pa, na_n, dma, ex_a, live_a = kf_scene(wa)
+    pb, _, dmb, ex_b, live_b = kf_scene(wb)
+    lsf = float(np.log(np.float32(1.2)))
+    Tc = np.eye(4)[:3].copy()
+    Tc[0, 3], Tc[1, 3] = -4.0 / fx * 5.0, -3.0 / fy * 5.0
+    ia = np.arange(na)
+    already = ex_a & (ia % 23 == 0)
+    want, wn = oracle.projection_match_frame_and_keyframe(ocam, gp, wb, wdb, Tc, wa, pa, dma, wda, sf, lsf, 10.0, 100, True,
+                                                          kf_valid=(live_a & ~already).astype(np.uint8))
+    exp = np.full(nb, -1, np.int32)
+    exp[want[want >= 0]] = np.flatnonzero(want >= 0)
+    assert n_fk == wn and np.array_equal(fk_owner, exp) and wn > 100
+
+    pre_b = {j: (j * 7) % na for j in range(0, nb, 29)}
+    occ = np.zeros(nb, np.uint8)
+    in_already = np.zeros(na, bool)
+    exp = np.full(nb, -1, np.int32)
+    for j, l in pre_b.items():
+        if ex_a[l]:
+            occ[j] = 1
+            in_already[l] = True
+            exp[j] = l
+    want, wn = oracle.projection_match_by_sim3_transform(ocam, gp, wb, wdb, 1.5 * Tc, pa, dma, na_n, wda, sf, lsf, 8.0, kf_occupied=occ,
+                                                         lm_valid=(live_a & ~in_already).astype(np.uint8))
+    exp[want[want >= 0]] = np.flatnonzero(want >= 0)
+    assert n_s3 == wn and np.array_equal(s3_owner, exp) and wn > 100
+
+    m1 = np.zeros(na, bool)
+    m2 = np.zeros(nb, bool)
+    for i in range(0, na, 31):
+        j = (i * 3) % nb
+        if ex_b[j]:
+            m1[i] = True
+            m2[j] = True
+    t12 = np.array([4.0 / fx * 5.0, 3.0 / fy * 5.0, 0.0])
+    wn, want = oracle.projection_match_keyframes_mutually(ocam, gp, wa, wda, T, pa, dma, wda, (live_a & ~m1).astype(np.uint8), wb, wdb, T, pb, dmb,
+                                                          wdb, (live_b & ~m2).astype(np.uint8), 1.0, np.eye(3), t12, sf, lsf, 7.5)
+    exp = np.where(m1, -3, want).astype(np.int32)
+    assert n_mut == wn and np.array_equal(mut_m, exp) and wn > 50
+
+    wn, want = oracle.bow_match_keyframes(wa, wda, fv_a, wb, wdb, fv_b, 0.75, True, has_lm_1=live_a.astype(np.uint8),
+                                          has_lm_2=live_b.astype(np.uint8))
+    assert n_bk == wn and np.array_equal(bk_m, want) and wn > 20
