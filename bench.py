@@ -52,8 +52,8 @@ def algorithmic_bytes(rows, cols, n_kp_frame, n_cand_frame):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU (a multiple of 8: frames come in 8-frame scenes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true", help="skip the local-BA side section (profiling runs)")
