@@ -322,7 +322,8 @@ def bench_local_ba(world, rank, dist, torch, iters=20):
 
 def bench_other_configs(iters=10):
     """BASELINE configs[0], [2], [3] (parity-test cases) timed once each through the HOST entry points (H2D + kernels +
-    D2H per call: these matchers are latency-bound, tiny problems) next to the CPU oracle on the same inputs. Not part of `value`."""
+    D2H per call: these matchers are latency-bound, tiny problems) next to the CPU oracle on the same inputs. Not part of `value`.
+    Part of the cpu_baseline leg: the oracle is only timed and compared here, it never feeds the product path."""
     import numpy as np
     from oracle import binding as ob
     from openvslam_amd import feature, match, synth

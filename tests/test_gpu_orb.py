@@ -7,7 +7,7 @@ from openvslam_amd.synth import synth_frame
 
 pytestmark = pytest.mark.gpu
 
-SIZES = [(1080, 1920, 2000), (480, 752, 1000), (376, 1241, 2000)]
+SIZES = [(1080, 1920, 2000), (480, 752, 1000), (376, 1241, 2000), (1920, 3840, 4000), (500, 644, 700)]   # BASELINE configs 2, 1, 3, 4 + an odd size
 
 
 @pytest.fixture(scope="module")
