@@ -6,13 +6,14 @@
 //   * every linearisation (residuals, Jacobians, J^T W J / J^T W e blocks, chi2) is one or two launches of the kernels in
 //     ba_linearize.hip over buffers that stay in HBM; poses and points (0.48 MB at config 5) are re-uploaded per Levenberg-Marquardt
 //     trial, the blocks come back once per trial;
-//   * the reduced camera system (landmarks eliminated: S = Hpp - sum_j W_j Hll_j^-1 W_j^T) is formed and Cholesky-factored on the
-//     HOST, as BASELINE's north star asks -- it is at most 6 * n_pose square;
+//   * the reduced camera system (landmarks eliminated: S = Hpp - sum_j W_j Hll_j^-1 W_j^T) is formed (<= 8 host threads) and
+//     Cholesky-factored on the HOST, as BASELINE's north star asks -- it is at most 6 * n_pose square;
 //   * g2o's damping schedule (ORACLE_SPEC rule 25), the chi-square outlier gates between the two rounds and the final outlier flags.
 // A trial's linearisation is kept as the next iteration's system when the step is accepted, so an iteration costs one launch pair.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "ovs_common.h"
@@ -138,19 +139,23 @@ bool inv3_sym(const double* H, double lambda, double* out) {   // (H + lambda I)
     return true;
 }
 
-bool cholesky_solve(std::vector<double>& A, int n, std::vector<double>& b) {   // in place: A -> L, b -> x
-    for (int i = 0; i < n; ++i) {
-        for (int j = 0; j <= i; ++j) {
-            double s = A[(size_t)i * n + j];
-            const double* li = &A[(size_t)i * n];
-            const double* lj = &A[(size_t)j * n];
-            for (int k = 0; k < j; ++k) s -= li[k] * lj[k];
-            if (i == j) {
-                if (!(s > 0.0)) return false;
-                A[(size_t)i * n + i] = std::sqrt(s);
-            } else {
-                A[(size_t)i * n + j] = s / A[(size_t)j * n + j];
-            }
+// In place: A (lower triangle read, row-major) -> L, b -> x. Right-looking form: the inner loop is an axpy over a contiguous row
+// segment against a contiguous copy of the pivot column, which the host compiler vectorises without re-associating any sum.
+bool cholesky_solve(std::vector<double>& A, int n, std::vector<double>& b) {
+    std::vector<double> col((size_t)n);
+    for (int j = 0; j < n; ++j) {
+        const double piv = A[(size_t)j * n + j];
+        if (!(piv > 0.0)) return false;
+        const double ljj = std::sqrt(piv);
+        A[(size_t)j * n + j] = ljj;
+        for (int i = j + 1; i < n; ++i) {
+            A[(size_t)i * n + j] /= ljj;
+            col[i] = A[(size_t)i * n + j];
+        }
+        for (int i = j + 1; i < n; ++i) {
+            const double lij = col[i];
+            double* row = &A[(size_t)i * n];
+            for (int k = j + 1; k <= i; ++k) row[k] -= lij * col[k];
         }
     }
     for (int i = 0; i < n; ++i) {
@@ -166,17 +171,40 @@ bool cholesky_solve(std::vector<double>& A, int n, std::vector<double>& b) {   /
     return true;
 }
 
-struct Blocks {   // one linearisation, host copy: Hpp | bp | Hll | bl | Hpl (mono edges, then stereo edges) | chi2[2]
-    std::vector<double> buf;
-    double *Hpp, *bp, *Hll, *bl, *Hpl, *chi2;
+struct Blocks {   // one linearisation, host copy in PINNED memory (16 MB per trial at config 5: pageable copies cost more than the kernels):
+                  // Hpp | bp | Hll | bl | Hpl (mono edges, then stereo edges) | chi2[2]
+    double* buf = nullptr;
+    size_t cap = 0, used = 0;
+    double *Hpp = nullptr, *bp = nullptr, *Hll = nullptr, *bl = nullptr, *Hpl = nullptr, *chi2 = nullptr;
+    Blocks() = default;
+    Blocks(const Blocks&) = delete;
+    Blocks& operator=(const Blocks&) = delete;
+    ~Blocks() {
+        if (buf) hipHostFree(buf);
+    }
+    hipError_t reserve(int n_pose, int n_pt, size_t n_edge_max) {
+        cap = (size_t)42 * n_pose + (size_t)12 * n_pt + 18 * std::max<size_t>(n_edge_max, 1) + 2;
+        return hipHostMalloc(reinterpret_cast<void**>(&buf), sizeof(double) * cap, hipHostMallocDefault);
+    }
     void layout(int n_pose, int n_pt, size_t n_edge) {
-        buf.assign((size_t)42 * n_pose + (size_t)12 * n_pt + 18 * std::max<size_t>(n_edge, 1) + 2, 0.0);
-        Hpp = buf.data();
+        Hpp = buf;
         bp = Hpp + (size_t)36 * n_pose;
         Hll = bp + (size_t)6 * n_pose;
         bl = Hll + (size_t)9 * n_pt;
         Hpl = bl + (size_t)3 * n_pt;
         chi2 = Hpl + 18 * std::max<size_t>(n_edge, 1);
+        used = (size_t)(chi2 - buf) + 2;
+    }
+    void swap(Blocks& o) {
+        std::swap(buf, o.buf);
+        std::swap(cap, o.cap);
+        std::swap(used, o.used);
+        std::swap(Hpp, o.Hpp);
+        std::swap(bp, o.bp);
+        std::swap(Hll, o.Hll);
+        std::swap(bl, o.bl);
+        std::swap(Hpl, o.Hpl);
+        std::swap(chi2, o.chi2);
     }
 };
 
@@ -296,7 +324,7 @@ struct Lba {
             if (st != OVS_OK) return st;
         }
         out.layout(n_pose, n_pt, n_edge());
-        OVS_HIP_TRY(hipMemcpyAsync(out.buf.data(), d_out, sizeof(double) * out.buf.size(), hipMemcpyDeviceToHost, stream));
+        OVS_HIP_TRY(hipMemcpyAsync(out.buf, d_out, sizeof(double) * out.used, hipMemcpyDeviceToHost, stream));
         OVS_HIP_TRY(hipStreamSynchronize(stream));
         return OVS_OK;
     }
@@ -334,37 +362,66 @@ struct Lba {
             }
         }
         std::vector<double> Hinv((size_t)9 * n_pt);
-        std::vector<double> Y;   // W_e Hll^-1 of the landmark's edges
-        for (int j = 0; j < n_pt; ++j) {
-            if (!inv3_sym(B.Hll + (size_t)9 * j, lambda, &Hinv[(size_t)9 * j])) return false;
-            const double* Hi = &Hinv[(size_t)9 * j];
-            const int e0 = lm_start[j], e1 = lm_start[(size_t)j + 1];
-            Y.resize((size_t)18 * (e1 - e0));
-            for (int i = e0; i < e1; ++i) {
-                const int e = lm_edges[i];
-                if (slot[edge_pose[e]] < 0) continue;
-                const double* W = B.Hpl + (size_t)18 * e;
-                double* y = &Y[(size_t)18 * (i - e0)];
-                for (int a = 0; a < 6; ++a)
-                    for (int c = 0; c < 3; ++c) y[3 * a + c] = (W[3 * a] * Hi[c] + W[3 * a + 1] * Hi[3 + c]) + W[3 * a + 2] * Hi[6 + c];
-                const int s = slot[edge_pose[e]];
-                const double* blj = B.bl + (size_t)3 * j;
-                for (int a = 0; a < 6; ++a) g[(size_t)6 * s + a] -= (y[3 * a] * blj[0] + y[3 * a + 1] * blj[1]) + y[3 * a + 2] * blj[2];
-            }
-            for (int i = e0; i < e1; ++i) {
-                const int si = slot[edge_pose[lm_edges[i]]];
-                if (si < 0) continue;
-                const double* y = &Y[(size_t)18 * (i - e0)];
-                for (int i2 = e0; i2 < e1; ++i2) {
-                    const int e2 = lm_edges[i2];
-                    const int s2 = slot[edge_pose[e2]];
-                    if (s2 < 0 || s2 < si) continue;   // upper block triangle only; mirrored below
-                    const double* W2 = B.Hpl + (size_t)18 * e2;
-                    double* dst = &S[(size_t)(6 * si) * n + 6 * s2];
+        // landmark elimination: S -= W_j (Hll_j + lambda I)^-1 W_j^T, g -= W_j (..)^-1 bl_j. Landmarks are split over host threads, each
+        // with its own accumulator (0.7 MB at 49 free poses), summed in thread order afterwards (deterministic for a given thread count).
+        const int n_thr = (int)std::max(1u, std::min(8u, std::min(std::thread::hardware_concurrency(), (unsigned)(n_pt / 512 + 1))));
+        std::vector<std::vector<double>> Sacc((size_t)n_thr), gacc((size_t)n_thr);
+        std::vector<int> ok((size_t)n_thr, 1);
+        auto work = [&](int t) {
+            std::vector<double>& St = Sacc[(size_t)t];
+            std::vector<double>& gt = gacc[(size_t)t];
+            St.assign((size_t)n * n, 0.0);
+            gt.assign((size_t)n, 0.0);
+            std::vector<double> Y;   // W_e Hll^-1 of the landmark's edges
+            const int j0 = (int)((long long)n_pt * t / n_thr), j1 = (int)((long long)n_pt * (t + 1) / n_thr);
+            for (int j = j0; j < j1; ++j) {
+                if (!inv3_sym(B.Hll + (size_t)9 * j, lambda, &Hinv[(size_t)9 * j])) {
+                    ok[(size_t)t] = 0;
+                    return;
+                }
+                const double* Hi = &Hinv[(size_t)9 * j];
+                const int e0 = lm_start[j], e1 = lm_start[(size_t)j + 1];
+                Y.resize((size_t)18 * (e1 - e0));
+                for (int i = e0; i < e1; ++i) {
+                    const int e = lm_edges[i];
+                    if (slot[edge_pose[e]] < 0) continue;
+                    const double* W = B.Hpl + (size_t)18 * e;
+                    double* y = &Y[(size_t)18 * (i - e0)];
                     for (int a = 0; a < 6; ++a)
-                        for (int b = 0; b < 6; ++b) dst[(size_t)a * n + b] -= (y[3 * a] * W2[3 * b] + y[3 * a + 1] * W2[3 * b + 1]) + y[3 * a + 2] * W2[3 * b + 2];
+                        for (int c = 0; c < 3; ++c) y[3 * a + c] = (W[3 * a] * Hi[c] + W[3 * a + 1] * Hi[3 + c]) + W[3 * a + 2] * Hi[6 + c];
+                    const int sl = slot[edge_pose[e]];
+                    const double* blj = B.bl + (size_t)3 * j;
+                    for (int a = 0; a < 6; ++a) gt[(size_t)6 * sl + a] -= (y[3 * a] * blj[0] + y[3 * a + 1] * blj[1]) + y[3 * a + 2] * blj[2];
+                }
+                for (int i = e0; i < e1; ++i) {
+                    const int si = slot[edge_pose[lm_edges[i]]];
+                    if (si < 0) continue;
+                    const double* y = &Y[(size_t)18 * (i - e0)];
+                    for (int i2 = e0; i2 < e1; ++i2) {
+                        const int e2 = lm_edges[i2];
+                        const int s2 = slot[edge_pose[e2]];
+                        if (s2 < 0 || s2 < si) continue;   // upper block triangle only; mirrored below
+                        const double* W2 = B.Hpl + (size_t)18 * e2;
+                        double* dst = &St[(size_t)(6 * si) * n + 6 * s2];
+                        for (int a = 0; a < 6; ++a)
+                            for (int b = 0; b < 6; ++b)
+                                dst[(size_t)a * n + b] -= (y[3 * a] * W2[3 * b] + y[3 * a + 1] * W2[3 * b + 1]) + y[3 * a + 2] * W2[3 * b + 2];
+                    }
                 }
             }
+        };
+        {
+            std::vector<std::thread> pool;
+            for (int t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
+            work(0);
+            for (auto& th : pool) th.join();
+        }
+        for (int t = 0; t < n_thr; ++t) {
+            if (!ok[(size_t)t]) return false;
+            const std::vector<double>& St = Sacc[(size_t)t];
+            const std::vector<double>& gt = gacc[(size_t)t];
+            for (size_t i = 0; i < S.size(); ++i) S[i] += St[i];
+            for (size_t i = 0; i < g.size(); ++i) g[i] += gt[i];
         }
         // diagonal blocks received each (i, i2) and (i2, i) pair of the same pose twice only when two edges share pose and landmark,
         // which a valid graph does not contain; off-diagonal blocks: mirror the upper triangle
@@ -398,6 +455,8 @@ struct Lba {
     ovs_status run_round(std::vector<Pose>& T, std::vector<double>& X, int iters, bool robust, const volatile uint8_t* stop, double* chi_start,
                          double* chi_end, int* n_iter) {
         Blocks cur, trial;
+        OVS_HIP_TRY(cur.reserve(n_pose, n_pt, cap_mono + cap_stereo));
+        OVS_HIP_TRY(trial.reserve(n_pose, n_pt, cap_mono + cap_stereo));
         ovs_status st = linearize(T, X, robust, cur);
         if (st != OVS_OK) return st;
         double current_chi = cur.chi2[1];
@@ -450,7 +509,7 @@ struct Lba {
                     current_chi = temp_chi;
                     T.swap(Tn);
                     X.swap(Xn);
-                    std::swap(cur, trial);   // the accepted trial's blocks are the next iteration's system
+                    cur.swap(trial);   // the accepted trial's blocks are the next iteration's system
                 } else {
                     lambda *= ni;
                     ni *= 2;

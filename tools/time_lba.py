@@ -1,0 +1,12 @@
+"""Time ovs_local_ba_optimize on BASELINE config 5 (perturbed start). Usage (GPU box): python tools/time_lba.py"""
+import sys
+import time
+
+sys.path.insert(0, ".")
+from openvslam_amd import ba, synth
+
+d = synth.synth_local_ba(seed=0, pose_noise=0.03, point_noise=0.03)
+for rep in range(3):
+    t = time.perf_counter()
+    r = ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], d["edges"], d["cam"])
+    print("local_ba_optimize %.1f ms, iterations %s, chi2 %.1f -> %.1f" % ((time.perf_counter() - t) * 1e3, r["info"][4:], r["info"][0], r["info"][3]))
