@@ -14,14 +14,15 @@
 // Tie rule for equal counts (implementation-defined upstream: pointer order): later-created node first = list position
 // ascending, exactly as the oracle defines it.
 //
-// One 1024-thread workgroup per (level, frame) problem; node lists (< 4N+64 records) ping-pong in an L2-resident global
+// One 512-thread workgroup per (level, frame) problem (1024 threads finish one problem sooner, 0.076 vs 0.087 ms per 32 frames, but only two
+// such workgroups fit a CU; at 128 frames per launch 512 threads win, 0.247 vs 0.278 ms); node lists (< 4N+64 records) ping-pong in an L2-resident global
 // scratch, everything else lives in LDS. The kernel is latency-bound by design (a handful of passes over ~10^4
 // candidates); throughput comes from running levels x frames problems concurrently.
 #include "ovs_common.h"
 
 namespace ovs {
 
-constexpr int kTreeThreads = 1024;
+constexpr int kTreeThreads = 512;
 constexpr uint32_t kNotInS = 0xFFFFFFFFu;
 
 struct NodeRec {
