@@ -149,17 +149,19 @@ __device__ __forceinline__ double pose_edge(const double* R, const double* t, co
     return c2;
 }
 
-constexpr int kPoseMaxObs = 8192;   // 32 observations per thread: the inlier flags of a thread fit one register
+constexpr int kPoseMaxObs = 8192;   // <= 32 observations per thread: the inlier flags of a thread fit one register
+constexpr int kPoseThreads = 256;   // one workgroup per frame: 0.75 ms per 2000-observation frame; 1024 threads: 1.5 ms (16-wave barriers and reductions dominate)
+constexpr int kPoseWaves = kPoseThreads / 64;
 
-__global__ __launch_bounds__(256) void k_pose_optimize(const double* __restrict__ poses_in, const ovs_pose_obs* __restrict__ obs_all,
+__global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __restrict__ poses_in, const ovs_pose_obs* __restrict__ obs_all,
                                                       const int32_t* __restrict__ obs_offsets, ovs_ba_cam cam, double bf,
                                                       double* __restrict__ poses_out, uint8_t* __restrict__ outlier_all,
                                                       int32_t* __restrict__ num_valid) {
-    __shared__ double s_part[4][28];
+    __shared__ double s_part[kPoseWaves][28];
     __shared__ double s_sum[28];
     __shared__ PoseD s_T, s_Tn;
     __shared__ double s_ctl[4];   // [0] = continue trials of this iteration, [1] = continue iterations of this round
-    __shared__ int s_cnt[4];
+    __shared__ int s_cnt[kPoseWaves];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = blockIdx.x;
     const int o0 = obs_offsets[p], n = obs_offsets[p + 1] - o0;
@@ -174,15 +176,19 @@ __global__ __launch_bounds__(256) void k_pose_optimize(const double* __restrict_
             if (lane == 0) s_part[wv][i] = s;
         }
         __syncthreads();
-        if (tid < nv) s_sum[tid] = ((s_part[0][tid] + s_part[1][tid]) + s_part[2][tid]) + s_part[3][tid];
+        if (tid < nv) {   // fixed order: wave 0, 1, 2, ...
+            double s = s_part[0][tid];
+            for (int w = 1; w < kPoseWaves; ++w) s += s_part[w][tid];
+            s_sum[tid] = s;
+        }
         __syncthreads();
     };
 
     PoseD T0;
     for (int i = 0; i < 9; ++i) T0.R[i] = poses_in[12 * (size_t)p + i];
     for (int i = 0; i < 3; ++i) T0.t[i] = poses_in[12 * (size_t)p + 9 + i];
-    uint32_t active = 0xFFFFFFFFu;   // bit k <-> observation tid + 256 k
-    for (int i = tid; i < n; i += 256) outlier[i] = 0;
+    uint32_t active = 0xFFFFFFFFu;   // bit k <-> observation tid + kPoseThreads * k
+    for (int i = tid; i < n; i += kPoseThreads) outlier[i] = 0;
     if (tid == 0) s_T = T0;
     __syncthreads();
     int num_bad = 0;
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(256) void k_pose_optimize(const double* __restrict_
                     double R[9], t[3];
                     for (int i = 0; i < 9; ++i) R[i] = s_T.R[i];
                     for (int i = 0; i < 3; ++i) t[i] = s_T.t[i];
-                    for (int k = 0, i = tid; i < n; i += 256, ++k)
+                    for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k)
                         if ((active >> k) & 1u) {
                             const ovs_pose_obs o = obs[i];
                             pose_edge(R, t, o, cam, bf, robust ? (o.is_stereo ? d_stereo : d_mono) : 0.0, acc);
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256) void k_pose_optimize(const double* __restrict_
                         for (int i = 0; i < 9; ++i) R[i] = s_Tn.R[i];
                         for (int i = 0; i < 3; ++i) t[i] = s_Tn.t[i];
                         double part = 0;
-                        for (int k = 0, i = tid; i < n; i += 256, ++k)
+                        for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k)
                             if ((active >> k) & 1u) {
                                 const ovs_pose_obs o = obs[i];
                                 const double c2 = pose_edge(R, t, o, cam, bf, 0.0, nullptr);
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(256) void k_pose_optimize(const double* __restrict_
                 for (int i = 0; i < 3; ++i) t[i] = s_T.t[i];
                 int bad = 0;
                 active = 0;
-                for (int k = 0, i = tid; i < n; i += 256, ++k) {
+                for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k) {
                     const ovs_pose_obs o = obs[i];
                     const double c2 = pose_edge(R, t, o, cam, bf, 0.0, nullptr);
                     const bool out = (o.is_stereo ? 7.815 : 5.991) < c2;
@@ -304,7 +310,8 @@ __global__ __launch_bounds__(256) void k_pose_optimize(const double* __restrict_
                 for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
                 if (lane == 0) s_cnt[wv] = bad;
                 __syncthreads();
-                num_bad = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+                num_bad = 0;
+                for (int w = 0; w < kPoseWaves; ++w) num_bad += s_cnt[w];
                 __syncthreads();
             }
             if (n < 10) break;
@@ -325,7 +332,7 @@ ovs_status ovs_pose_optimize_batch_dev(const double* d_poses_in, const ovs_pose_
                                        const ovs_ba_cam* cam, double focal_x_baseline, double* d_poses_out, uint8_t* d_outlier,
                                        int32_t* d_num_valid, void* stream) {
     if (!d_poses_in || !d_obs || !d_obs_offsets || !cam || !d_poses_out || !d_outlier || !d_num_valid || batch < 1) return OVS_ERR_INVALID;
-    hipLaunchKernelGGL(k_pose_optimize, dim3(batch), dim3(256), 0, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, *cam,
+    hipLaunchKernelGGL(k_pose_optimize, dim3(batch), dim3(kPoseThreads), 0, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, *cam,
                        focal_x_baseline, d_poses_out, d_outlier, d_num_valid);
     OVS_HIP_TRY(hipGetLastError());
     return OVS_OK;
