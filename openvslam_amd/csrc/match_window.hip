@@ -628,29 +628,44 @@ __device__ __forceinline__ bool rule_accepts(uint32_t best, uint32_t second, flo
     return !(__fmul_rn((float)sd, ratio) < (float)bd);   // area: second * ratio < best; bow: ratio * second < best (same product)
 }
 
-template <int RULE>
-__global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
+// NW waves replay 64 * NW queries per round. The decision rule is the single-wave one with "lane" read as "thread": a thread is
+// affected if a LOWER thread of the round stamps one of the two targets its decision rests on, every thread below the first affected one
+// commits. With NW > 1 the waves meet at three LDS-only workgroup barriers per round; the rounds are dependent LDS latency either way, so
+// a round of 256 queries costs little more than a round of 64 and a 10 000-landmark problem needs a quarter of the rounds.
+template <int RULE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_res[];
     typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
     typedef __attribute__((address_space(3))) volatile uint16_t lds_u16;
+    constexpr int T = 64 * NW;
+    __shared__ uint32_t s_first[NW], s_any[NW], s_keep[4];
     lds_u32* mark = (lds_u32*)s_res;                                        // [kMarkSize]
     lds_u32* hist = mark + kMarkSize;                                       // [32]
     lds_u16* thr = (lds_u16*)(hist + 32);                                   // [n_t]  alive(d, t) <=> d < thr[t]
     lds_u16* owner = thr + ((a.n_t + 1) & ~1);                              // [n_t]  area: query currently matched to t
     lds_u16* match = owner + ((a.n_t + 1) & ~1);                            // [n_q]  target of query (0xFFFF none)
     lds_u16* accepted = match + ((a.n_q + 1) & ~1);                         // [n_q]  target at acceptance time (orientation entries)
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto wg_barrier = [&]() {
+        if (NW == 1) {
+            __builtin_amdgcn_wave_barrier();
+        } else {   // orders LDS traffic only: the key loads of the global path need not drain
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
+    };
     const uint32_t max_d = (RULE == kRuleBestOnly || RULE == kRuleTriang) ? a.best_only_thr : (RULE == kRuleProjection ? OVS_HAMMING_DIST_THR_HIGH : OVS_HAMMING_DIST_THR_LOW);
-    for (int i = lane; i < a.n_t; i += 64) {
+    for (int i = tid; i < a.n_t; i += T) {
         thr[i] = (uint16_t)OVS_MAX_HAMMING_DIST;
         owner[i] = 0xFFFFu;
     }
-    for (int i = lane; i < a.n_q; i += 64) {
+    for (int i = tid; i < a.n_q; i += T) {
         match[i] = 0xFFFFu;
         accepted[i] = 0xFFFFu;
     }
-    for (int i = lane; i < kMarkSize; i += 64) mark[i] = ~0u;
-    if (lane < 32) hist[lane] = 0;
+    for (int i = tid; i < kMarkSize; i += T) mark[i] = ~0u;
+    if (tid < 32) hist[tid] = 0;
     // the candidate CSR is one contiguous array: when it fits the rest of the LDS allocation it is copied there once (coalesced
     // 16-byte loads), and the rounds below never touch HBM
     lds_u32* s_keys = (lds_u32*)(accepted + ((a.n_q + 1) & ~1));
@@ -659,37 +674,50 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
     if (keys_in_lds) {
         const uint32_t n4 = n_keys >> 2;
         const uint4* src4 = reinterpret_cast<const uint4*>(a.keys);
-        for (uint32_t i = lane; i < n4; i += 64) {
+        for (uint32_t i = tid; i < n4; i += T) {
             const uint4 v = src4[i];
             s_keys[4 * i] = v.x;
             s_keys[4 * i + 1] = v.y;
             s_keys[4 * i + 2] = v.z;
             s_keys[4 * i + 3] = v.w;
         }
-        for (uint32_t i = 4 * n4 + lane; i < n_keys; i += 64) s_keys[i] = a.keys[i];
+        for (uint32_t i = 4 * n4 + tid; i < n_keys; i += T) s_keys[i] = a.keys[i];
     }
-    __builtin_amdgcn_wave_barrier();
+    wg_barrier();
     uint32_t epoch = 0;
 
-    for (int q0 = 0; q0 < a.n_q; q0 += 64) {
-        const int q = q0 + lane;
+    for (int q0 = 0; q0 < a.n_q; q0 += T) {
+        const int q = q0 + tid;
         uint32_t lb = 0, le = 0;
         if (q < a.n_q) {
             lb = a.offsets[q];
             le = a.offsets[q + 1];
         }
-        unsigned long long unresolved = __ballot(le > lb);
-        while (unresolved) {
-            const bool mine = (unresolved >> lane) & 1ull;
+        bool pending = le > lb;
+        for (;;) {
+            // ---- any query of the batch still undecided? (the barrier also publishes the previous round's commits)
+            {
+                const unsigned long long pb = __ballot(pending);
+                if (NW == 1) {
+                    if (!pb) break;
+                } else {
+                    if (lane == 0) s_any[wv] = pb != 0ull;
+                    wg_barrier();
+                    uint32_t any = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) any |= s_any[w];
+                    if (!any) break;
+                }
+            }
             uint32_t best = kNone, second = kNone;
             bool acc = false;
             ++epoch;
             const uint32_t tag = (0xFFFFFFu - epoch) << 8;   // newer rounds carry smaller tags: atomicMin overrides stale stamps
             asm volatile("" ::: "memory");   // thr[] committed in the previous round must be re-read
-            if (mine) {
+            if (pending) {
                 uint32_t bd = OVS_MAX_HAMMING_DIST, sd = OVS_MAX_HAMMING_DIST;
                 // eight keys and their eight thr[] values are fetched as independent batches (one load round trip per batch instead of
-                // one per entry: on a lone wave that latency is the whole cost); keys come from LDS when the CSR was staged
+                // one per entry: that latency is the whole cost); keys come from LDS when the CSR was staged
                 const __attribute__((address_space(3))) uint16_t* thr_nv = (const __attribute__((address_space(3))) uint16_t*)thr;
                 for (uint32_t k0 = lb; k0 < le; k0 += 8) {
                     uint32_t e8[8], t8[8];
@@ -716,21 +744,34 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
                 acc = rule_accepts<RULE>(best, second, a.lowe_ratio, a.best_only_thr);
                 if (acc)
                     __hip_atomic_fetch_min((__attribute__((address_space(3))) uint32_t*)&mark[(best & 0xFFFFu) & (kMarkSize - 1)],
-                                           tag | (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                           tag | (uint32_t)tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            __builtin_amdgcn_wave_barrier();
+            wg_barrier();
             bool affected = false;
-            if (mine && best != kNone && (best >> 20) <= max_d) {   // a best beyond the threshold is a final reject (it can only grow)
+            if (pending && best != kNone && (best >> 20) <= max_d) {   // a best beyond the threshold is a final reject (it can only grow)
                 const uint32_t m1 = mark[(best & 0xFFFFu) & (kMarkSize - 1)];
-                affected = (m1 & ~0xFFu) == tag && (m1 & 0xFFu) < (uint32_t)lane;
+                affected = (m1 & ~0xFFu) == tag && (m1 & 0xFFu) < (uint32_t)tid;
                 if (second != kNone) {
                     const uint32_t m2 = mark[(second & 0xFFFFu) & (kMarkSize - 1)];
-                    affected |= (m2 & ~0xFFu) == tag && (m2 & 0xFFu) < (uint32_t)lane;
+                    affected |= (m2 & ~0xFFu) == tag && (m2 & 0xFFu) < (uint32_t)tid;
                 }
             }
-            const unsigned long long aff = __ballot(affected) & unresolved;
-            const int f = aff ? (__ffsll((long long)aff) - 1) : 64;
-            if (mine && lane < f && acc) {
+            // ---- first affected thread of the workgroup
+            int f;
+            {
+                const unsigned long long aff = __ballot(affected && pending);
+                const int fw = aff ? (wv * 64 + __ffsll((long long)aff) - 1) : T;
+                if (NW == 1) {
+                    f = fw;
+                } else {
+                    if (lane == 0) s_first[wv] = (uint32_t)fw;
+                    wg_barrier();
+                    f = T;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) f = min(f, (int)s_first[w]);
+                }
+            }
+            if (pending && tid < f && acc) {
                 const uint32_t t = best & 0xFFFFu;
                 if (RULE == kRuleArea) {
                     const uint32_t prev = owner[t];
@@ -743,13 +784,14 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
                 match[q] = (uint16_t)t;
                 accepted[q] = (uint16_t)t;
             }
-            unresolved = f >= 64 ? 0ull : (unresolved & ~((1ull << f) - 1ull));
-            __builtin_amdgcn_wave_barrier();
+            if (tid < f) pending = false;
+            if (NW == 1) __builtin_amdgcn_wave_barrier();   // NW > 1: the barrier at the top of the loop publishes the commits
         }
     }
+    wg_barrier();
     // ---- match::angle_checker: bin = cvRound(delta / 30) over every ACCEPTED query (a later-stolen match keeps its entry)
     if (RULE != kRuleProjection && a.check_orientation) {
-        for (int q = lane; q < a.n_q; q += 64) {
+        for (int q = tid; q < a.n_q; q += T) {
             const uint32_t t = accepted[q];
             if (t == 0xFFFFu) continue;
             const int qi = a.q_items ? a.q_items[q] : q;
@@ -761,10 +803,9 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
             __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t*)&hist[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             accepted[q] = (uint16_t)(0x8000u | (uint32_t)bin);   // reuse the slot: bin of this entry
         }
-        __builtin_amdgcn_wave_barrier();
-        // the three fullest bins, equal sizes -> lower bin first (ORACLE_SPEC rule 17)
-        int keep0 = -1, keep1 = -1, keep2 = -1;
-        {
+        wg_barrier();
+        // the three fullest bins, equal sizes -> lower bin first (ORACLE_SPEC rule 17); wave 0 picks them
+        if (wv == 0) {
             const uint32_t h = lane < 30 ? (uint32_t)hist[lane] : 0u;
             uint32_t key = lane < 30 ? ((h << 8) | (uint32_t)(31 - lane)) : 0u;   // larger count first, then lower bin
             for (int k = 0; k < 3; ++k) {
@@ -774,32 +815,31 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
                     const uint32_t o = __shfl_xor(m, off);
                     m = o > m ? o : m;
                 }
-                const int b = 31 - (int)(m & 0xFFu);
-                if (k == 0) keep0 = b;
-                else if (k == 1) keep1 = b;
-                else keep2 = b;
+                if (lane == 0) s_keep[k] = (uint32_t)(31 - (int)(m & 0xFFu));
                 if (key == m) key = 0u;
             }
         }
-        for (int q = lane; q < a.n_q; q += 64) {
+        wg_barrier();
+        const int keep0 = (int)s_keep[0], keep1 = (int)s_keep[1], keep2 = (int)s_keep[2];
+        for (int q = tid; q < a.n_q; q += T) {
             const uint32_t v = accepted[q];
             if (!(v & 0x8000u) || v == 0xFFFFu) continue;
             const int bin = (int)(v & 0xFFu);
             if (bin != keep0 && bin != keep1 && bin != keep2) match[q] = 0xFFFFu;
         }
-        __builtin_amdgcn_wave_barrier();
+        wg_barrier();
     }
     // ---- outputs
     uint32_t total = 0;
     constexpr bool kBowOut = RULE == kRuleBow || RULE == kRuleTriang;
     if (kBowOut) {
         const int n_clear = a.bow_by_query ? a.n_out_q : a.n_t;
-        for (int t = lane; t < n_clear; t += 64) a.assigned[t] = -1;
-        __builtin_amdgcn_wave_barrier();
+        for (int t = tid; t < n_clear; t += T) a.assigned[t] = -1;
         __threadfence_block();
+        __syncthreads();   // global writes above must land before the scattered ones below
     }
-    for (int q0 = 0; q0 < a.n_q; q0 += 64) {
-        const int q = q0 + lane;
+    for (int q0 = 0; q0 < a.n_q; q0 += T) {
+        const int q = q0 + tid;
         uint32_t t = 0xFFFFu;
         if (q < a.n_q) t = match[q];
         if (q < a.n_q) {
@@ -819,7 +859,17 @@ __global__ __launch_bounds__(64) void k_list_resolve(ResolveArgs a) {
         }
         total += (uint32_t)__popcll(__ballot(t != 0xFFFFu));
     }
-    if (lane == 0) *a.num_matches = (int32_t)total;
+    if (NW == 1) {
+        if (lane == 0) *a.num_matches = (int32_t)total;
+    } else {
+        if (lane == 0) s_first[wv] = total;
+        wg_barrier();
+        if (tid == 0) {
+            uint32_t sum = 0;
+            for (int w = 0; w < NW; ++w) sum += s_first[w];
+            *a.num_matches = (int32_t)sum;
+        }
+    }
 }
 
 }   // namespace ovs
@@ -893,13 +943,18 @@ ovs_status launch_resolve(const ResolveArgs& ra_in, hipStream_t s) {
     // the rest of a 96 KiB allocation holds a copy of the key CSR when it fits (checked on the device: the size is only known there)
     const size_t lds = std::max(fixed, (size_t)96 * 1024);
     ra.key_pool = (uint32_t)((lds - fixed) / 4);
-    static thread_local size_t configured[8] = {};
-    if (lds > configured[RULE]) {
-        OVS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_list_resolve<RULE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds));
-        configured[RULE] = lds;
+    // four waves (256 queries per round) once a problem has more than a couple of rounds' worth of queries
+    const bool wide = ra.n_q > 256;
+    static thread_local size_t configured[2][8] = {};
+    if (lds > configured[wide][RULE]) {
+        const void* fn = wide ? reinterpret_cast<const void*>(k_list_resolve<RULE, 4>) : reinterpret_cast<const void*>(k_list_resolve<RULE, 1>);
+        OVS_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured[wide][RULE] = lds;
     }
-    hipLaunchKernelGGL(k_list_resolve<RULE>, dim3(1), dim3(64), lds, s, ra);
+    if (wide)
+        hipLaunchKernelGGL((k_list_resolve<RULE, 4>), dim3(1), dim3(256), lds, s, ra);
+    else
+        hipLaunchKernelGGL((k_list_resolve<RULE, 1>), dim3(1), dim3(64), lds, s, ra);
     OVS_HIP_TRY(hipGetLastError());
     return OVS_OK;
 }

@@ -2,7 +2,8 @@
 import sys
 import time
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openvslam_amd import ba, synth
 
 d = synth.synth_local_ba(seed=0, pose_noise=0.03, point_noise=0.03)
