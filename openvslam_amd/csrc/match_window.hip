@@ -712,7 +712,7 @@ __global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
             uint32_t best = kNone, second = kNone;
             bool acc = false;
             ++epoch;
-            const uint32_t tag = (0xFFFFFFu - epoch) << 8;   // newer rounds carry smaller tags: atomicMin overrides stale stamps
+            const uint32_t tag = (0x3FFFFFu - epoch) << 10;   // newer rounds carry smaller tags: atomicMin overrides stale stamps; low 10 bits: thread
             asm volatile("" ::: "memory");   // thr[] committed in the previous round must be re-read
             if (pending) {
                 uint32_t bd = OVS_MAX_HAMMING_DIST, sd = OVS_MAX_HAMMING_DIST;
@@ -750,10 +750,10 @@ __global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
             bool affected = false;
             if (pending && best != kNone && (best >> 20) <= max_d) {   // a best beyond the threshold is a final reject (it can only grow)
                 const uint32_t m1 = mark[(best & 0xFFFFu) & (kMarkSize - 1)];
-                affected = (m1 & ~0xFFu) == tag && (m1 & 0xFFu) < (uint32_t)tid;
+                affected = (m1 & ~0x3FFu) == tag && (m1 & 0x3FFu) < (uint32_t)tid;
                 if (second != kNone) {
                     const uint32_t m2 = mark[(second & 0xFFFFu) & (kMarkSize - 1)];
-                    affected |= (m2 & ~0xFFu) == tag && (m2 & 0xFFu) < (uint32_t)tid;
+                    affected |= (m2 & ~0x3FFu) == tag && (m2 & 0x3FFu) < (uint32_t)tid;
                 }
             }
             // ---- first affected thread of the workgroup
@@ -943,15 +943,18 @@ ovs_status launch_resolve(const ResolveArgs& ra_in, hipStream_t s) {
     // the rest of a 96 KiB allocation holds a copy of the key CSR when it fits (checked on the device: the size is only known there)
     const size_t lds = std::max(fixed, (size_t)96 * 1024);
     ra.key_pool = (uint32_t)((lds - fixed) / 4);
-    // four waves (256 queries per round) once a problem has more than a couple of rounds' worth of queries
-    const bool wide = ra.n_q > 256;
-    static thread_local size_t configured[2][8] = {};
-    if (lds > configured[wide][RULE]) {
-        const void* fn = wide ? reinterpret_cast<const void*>(k_list_resolve<RULE, 4>) : reinterpret_cast<const void*>(k_list_resolve<RULE, 1>);
+    // 1 / 4 / 8 waves (64 / 256 / 512 queries per round) by problem size
+    const int width = ra.n_q > 2048 ? 2 : (ra.n_q > 256 ? 1 : 0);
+    static thread_local size_t configured[3][8] = {};
+    if (lds > configured[width][RULE]) {
+        const void* fn = width == 2 ? reinterpret_cast<const void*>(k_list_resolve<RULE, 8>)
+                                    : (width == 1 ? reinterpret_cast<const void*>(k_list_resolve<RULE, 4>) : reinterpret_cast<const void*>(k_list_resolve<RULE, 1>));
         OVS_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured[wide][RULE] = lds;
+        configured[width][RULE] = lds;
     }
-    if (wide)
+    if (width == 2)
+        hipLaunchKernelGGL((k_list_resolve<RULE, 8>), dim3(1), dim3(512), lds, s, ra);
+    else if (width == 1)
         hipLaunchKernelGGL((k_list_resolve<RULE, 4>), dim3(1), dim3(256), lds, s, ra);
     else
         hipLaunchKernelGGL((k_list_resolve<RULE, 1>), dim3(1), dim3(64), lds, s, ra);
