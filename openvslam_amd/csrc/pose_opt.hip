@@ -150,7 +150,7 @@ __device__ __forceinline__ double pose_edge(const double* R, const double* t, co
 }
 
 constexpr int kPoseMaxObs = 8192;   // <= 32 observations per thread: the inlier flags of a thread fit one register
-constexpr int kPoseThreads = 256;   // one workgroup per frame: 0.75 ms per 2000-observation frame; 128 threads: 1.1 ms, 1024 threads: 1.5 ms (16-wave barriers and reductions)
+constexpr int kPoseThreads = 256;   // one workgroup per frame: 0.75 ms per 2000-observation frame; 128 threads: 1.1 ms, 512: 0.94 ms, 1024: 1.5 ms (cross-wave barriers and reductions)
 constexpr int kPoseWaves = kPoseThreads / 64;
 
 __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __restrict__ poses_in, const ovs_pose_obs* __restrict__ obs_all,
