@@ -139,16 +139,19 @@ ovs_status ovs_matcher_destroy(ovs_matcher* m);
 /* replaces: unsigned int robust::brute_force_match(data::frame& frm, data::keyframe* keyfrm,
  *                                                  std::vector<std::pair<int,int>>& matches) const.
  * desc_1: n1 x 32 frame descriptors (idx_1 side); desc_2: n2 x 32 keyframe descriptors (idx_2 side); valid_2: NULL or n2
- * bytes, non-zero where the keyframe keypoint holds a landmark that !will_be_erased(). pairs: capacity cap pairs of
+ * bytes, non-zero where the keyframe keypoint holds a landmark that !will_be_erased(). valid_1: NULL or n1 bytes, zero where the
+ * FRAME keypoint must not take part (treated exactly like an already matched idx_1: skipped in the inner loop); the shim passes NULL
+ * because upstream's inner loop, as recalled, only tests already_matched_indices_1 -- a maintainer whose checkout also skips frame
+ * keypoints that hold a landmark (`if (frm.landmarks_.at(idx_1)) continue;`) fills it from frm.landmarks_. pairs: capacity cap pairs of
  * (idx_1, idx_2) in upstream's emission order (ascending idx_2). *n_out = number of matches. */
-ovs_status ovs_robust_brute_force_match(ovs_matcher* m, const uint8_t* desc_1, int32_t n1, const uint8_t* desc_2, int32_t n2,
-                                        const uint8_t* valid_2, float lowe_ratio, int32_t* pairs, int32_t cap, int32_t* n_out);
+ovs_status ovs_robust_brute_force_match(ovs_matcher* m, const uint8_t* desc_1, int32_t n1, const uint8_t* valid_1, const uint8_t* desc_2,
+                                        int32_t n2, const uint8_t* valid_2, float lowe_ratio, int32_t* pairs, int32_t cap, int32_t* n_out);
 
 /* Device-resident batched form: problem p uses d_desc_1 + p*stride_1 (n1[p] rows) and d_desc_2 + p*stride_2 (n2[p] rows);
  * d_n1 / d_n2 are device int32[batch] (so extractor counts can be consumed without a host round trip); d_valid_2: NULL or
- * batch x stride_2/32 bytes. Outputs: d_pairs[(p*cap + i)*2 + {0,1}], d_counts[p]. Asynchronous on `stream`. */
+ * batch x stride_2/32 bytes; d_valid_1: NULL or batch x stride_1/32 bytes. Outputs: d_pairs[(p*cap + i)*2 + {0,1}], d_counts[p]. Asynchronous on `stream`. */
 ovs_status ovs_robust_brute_force_match_batch_dev(ovs_matcher* m, const uint8_t* d_desc_1, size_t stride_1, const int32_t* d_n1,
-                                                  const uint8_t* d_desc_2, size_t stride_2, const int32_t* d_n2,
+                                                  const uint8_t* d_valid_1, const uint8_t* d_desc_2, size_t stride_2, const int32_t* d_n2,
                                                   const uint8_t* d_valid_2, int32_t batch, float lowe_ratio, int32_t* d_pairs,
                                                   int32_t* d_counts, int32_t cap, void* stream);
 
@@ -475,7 +478,7 @@ ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* p
 /* ------------------------------------------------------------------------------------------------------------------
  * Pose-only optimisation of one frame.  replaces: unsigned int optimize::pose_optimizer::optimize(data::frame& frm) const
  * (src/openvslam/optimize/pose_optimizer.{h,cc}; perspective mono / stereo pose_opt edges): 4 rounds x 10 Levenberg-Marquardt
- * iterations with Huber kernels in the first two rounds and chi2 outlier re-classification (5.991 / 7.815) after every round, in ONE
+ * iterations with Huber kernels in the first three rounds and chi2 outlier re-classification (5.991 / 7.815) after every round, in ONE
  * kernel launch. The shim flattens the frame's landmarks into ovs_pose_obs records, writes pose_cw_out back with
  * frm.set_cam_pose(...), outlier_flags into frm.outlier_flags_ and returns *num_valid.
  * ------------------------------------------------------------------------------------------------------------------ */
@@ -485,13 +488,28 @@ typedef struct ovs_pose_obs {   /* one observed landmark: pose_opt_edge_wrapper 
     double inv_sigma_sq;                /* frm.inv_level_sigma_sq_[octave] */
     int32_t is_stereo, pad;
 } ovs_pose_obs;
-/* pose_cw_*: 12 doubles (rotation row-major, translation), world -> camera. n_obs <= 8192. */
+/* pose_cw_*: 12 doubles (rotation row-major, translation), world -> camera. n_obs <= 8192 (OVS_ERR_CAPACITY above; the _dev form
+ * reports a frame with more observations as d_num_valid = -1). setup_type = frm.camera_->setup_type_ (0 Monocular, 1 Stereo, 2 RGBD):
+ * upstream picks ONE Huber delta per frame from it (Monocular: sqrt(5.991), otherwise sqrt(7.815)); the chi-square outlier gates
+ * (5.991 / 7.815) stay per observation (is_stereo). */
 ovs_status ovs_pose_optimize(int32_t device, const double* pose_cw_in, const ovs_pose_obs* obs, int32_t n_obs, const ovs_ba_cam* cam,
-                             double focal_x_baseline, double* pose_cw_out, uint8_t* outlier_flags, int32_t* num_valid);
+                             double focal_x_baseline, int32_t setup_type, double* pose_cw_out, uint8_t* outlier_flags, int32_t* num_valid);
 /* Device-resident batch: frame p owns observations [d_obs_offsets[p], d_obs_offsets[p + 1]); one workgroup per frame. */
 ovs_status ovs_pose_optimize_batch_dev(const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
-                                       const ovs_ba_cam* cam, double focal_x_baseline, double* d_poses_out, uint8_t* d_outlier,
-                                       int32_t* d_num_valid, void* stream);
+                                       const ovs_ba_cam* cam, double focal_x_baseline, int32_t setup_type, double* d_poses_out,
+                                       uint8_t* d_outlier, int32_t* d_num_valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Self-test of include/ovs_detmath.h on the device: out[i] = fn(a[i] (, b[i])) evaluated by a gfx950 kernel. The four functions
+ * replace libm calls upstream makes where a float decides a match pair (landmark::predict_scale_level's std::log(float),
+ * camera::equirectangular::reproject_to_image's asin / atan2, match::robust::check_epipolar_constraint's acos); the same header is
+ * compiled into the CPU oracle, and tests require identical bits from both. logf takes / returns floats widened to double.
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define OVS_DETMATH_LOGF 0
+#define OVS_DETMATH_ASIN 1
+#define OVS_DETMATH_ACOS 2
+#define OVS_DETMATH_ATAN2 3   /* atan2(a, b) */
+ovs_status ovs_detmath_eval(int32_t device, int32_t fn, const double* a, const double* b, double* out, int32_t n);
 
 #ifdef __cplusplus
 }

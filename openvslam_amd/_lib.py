@@ -50,8 +50,8 @@ SYMBOLS = {
     "ovs_matcher_profile_read": (_i32, [_vp, _vp, C.POINTER(_i32)]),
     "ovs_matcher_create": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(_vp)]),
     "ovs_matcher_destroy": (_i32, [_vp]),
-    "ovs_robust_brute_force_match": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _f, _vp, _i32, C.POINTER(_i32)]),
-    "ovs_robust_brute_force_match_batch_dev": (_i32, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _i32, _f, _vp, _vp, _i32, _vp]),
+    "ovs_robust_brute_force_match": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _f, _vp, _i32, C.POINTER(_i32)]),
+    "ovs_robust_brute_force_match_batch_dev": (_i32, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _i32, _f, _vp, _vp, _i32, _vp]),
     "ovs_ba_linearize": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_equirect": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -64,8 +64,8 @@ SYMBOLS = {
     "ovs_ba_linearize_stereo": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_stereo_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp,
                                            _vp, _vp]),
-    "ovs_pose_optimize": (_i32, [_i32, _vp, _vp, _i32, _vp, C.c_double, _vp, _vp, C.POINTER(_i32)]),
-    "ovs_pose_optimize_batch_dev": (_i32, [_vp, _vp, _vp, _i32, _vp, C.c_double, _vp, _vp, _vp, _vp]),
+    "ovs_pose_optimize": (_i32, [_i32, _vp, _vp, _i32, _vp, C.c_double, _i32, _vp, _vp, C.POINTER(_i32)]),
+    "ovs_pose_optimize_batch_dev": (_i32, [_vp, _vp, _vp, _i32, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp]),
     "ovs_hamming_best2": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "ovs_wmatcher_create": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(_vp)]),
     "ovs_wmatcher_destroy": (_i32, [_vp]),
@@ -98,6 +98,7 @@ SYMBOLS = {
     "ovs_stereo_create": (_i32, [_i32, _i32, _i32, C.POINTER(_vp)]),
     "ovs_stereo_destroy": (_i32, [_vp]),
     "ovs_stereo_compute": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _f, _f, _vp, _vp, C.POINTER(_i32)]),
+    "ovs_detmath_eval": (_i32, [_i32, _i32, _vp, _vp, _vp, _i32]),
     "ovs_stereo_compute_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _f, _f, _vp, _vp, _vp, _vp]),
 }
 

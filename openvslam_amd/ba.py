@@ -88,8 +88,10 @@ POSE_OBS_DTYPE = np.dtype([("pos_w", "<f8", (3,)), ("obs_x", "<f8"), ("obs_y", "
 assert POSE_OBS_DTYPE.itemsize == 64
 
 
-def pose_optimize(pose_cw, obs, cam, focal_x_baseline=0.0, device=0):
+def pose_optimize(pose_cw, obs, cam, focal_x_baseline=0.0, device=0, setup_type=None):
     """optimize::pose_optimizer::optimize(frm) on the device (ovs_pose_optimize). pose_cw: 3x4 [R|t]; obs: POSE_OBS_DTYPE records.
+    setup_type: camera::setup_type_t of the rig (0 Monocular, 1 Stereo, 2 RGBD; default: Stereo iff focal_x_baseline != 0) -- it selects
+    the frame's one Huber delta.
     Returns (pose_cw 3x4, outlier_flags bool[n], num_valid)."""
     L = _lib.lib()
     o = np.ascontiguousarray(obs, POSE_OBS_DTYPE)
@@ -99,7 +101,10 @@ def pose_optimize(pose_cw, obs, cam, focal_x_baseline=0.0, device=0):
     out = np.zeros(max(len(o), 1), np.uint8)
     nv = C.c_int32()
     c = BaCam(*cam)
-    _lib.check(L.ovs_pose_optimize(device, _p(pin), _p(o), len(o), C.byref(c), float(focal_x_baseline), _p(pout), _p(out), C.byref(nv)),
+    if setup_type is None:
+        setup_type = 1 if focal_x_baseline != 0.0 else 0
+    _lib.check(L.ovs_pose_optimize(device, _p(pin), _p(o), len(o), C.byref(c), float(focal_x_baseline), int(setup_type), _p(pout), _p(out),
+                                   C.byref(nv)),
                "ovs_pose_optimize")
     return np.concatenate([pout[:9].reshape(3, 3), pout[9:, None]], 1), out[:len(o)].astype(bool), nv.value
 

@@ -49,7 +49,7 @@ unsigned int robust::brute_force_match(data::frame& frm, data::keyframe* keyfrm,
     std::vector<int32_t> pairs((size_t)2 * num_keypts_2);
     int n = 0;
     const int st = ovs_robust_brute_force_match(g_matcher.get(num_keypts_1, num_keypts_2), frm.descriptors_.data, (int)num_keypts_1,
-                                                keyfrm->descriptors_.data, (int)num_keypts_2, valid.data(), lowe_ratio_, pairs.data(),
+                                                /*valid_1: upstream's inner loop skips only already matched idx_1*/ nullptr, keyfrm->descriptors_.data, (int)num_keypts_2, valid.data(), lowe_ratio_, pairs.data(),
                                                 (int)num_keypts_2, &n);
     if (st != OVS_OK) throw std::runtime_error(std::string("ovs_robust_brute_force_match failed: ") + ovs_last_error());
     for (int i = 0; i < n; ++i) matches.emplace_back(std::make_pair(pairs[2 * i], pairs[2 * i + 1]));

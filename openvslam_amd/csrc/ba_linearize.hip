@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void k_ba_linearize(const double* __restrict__
         if (D == 2 && model == 1) {
             eq_L = sqrt((x * x + y * y) + z * z);
             eq_rxz = x * x + z * z;
-            const double theta = atan2(x, z);
-            const double phi = -asin(y / eq_L);
+            const double theta = ovs_det_atan2(x, z);
+            const double phi = -ovs_det_asin(y / eq_L);
             er[0] = ed.obs_x - cam.fx * (0.5 + theta / (2.0 * 3.14159265358979323846));
             er[1] = ed.obs_y - cam.fy * (0.5 - phi / 3.14159265358979323846);
             ss = er[0] * er[0] + er[1] * er[1];

@@ -203,9 +203,9 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // (three per round) and the number of rounds per problem drops ~2.5x -- the kernel is pure dependent latency on otherwise idle CUs.
 template <bool STAGED, int NW>
 __global__ __launch_bounds__(64 * NW) void k_bf_resolve(const uint8_t* __restrict__ desc_1, size_t stride_1,
-                                                       const int32_t* __restrict__ n1_arr, const uint8_t* __restrict__ desc_2,
-                                                       size_t stride_2, const int32_t* __restrict__ n2_arr, int max_n1, int max_n2,
-                                                       float lowe_ratio, const uint32_t* __restrict__ near_cnt,
+                                                       const int32_t* __restrict__ n1_arr, const uint8_t* __restrict__ valid_1,
+                                                       const uint8_t* __restrict__ desc_2, size_t stride_2,
+                                                       const int32_t* __restrict__ n2_arr, int max_n1, int max_n2, float lowe_ratio, const uint32_t* __restrict__ near_cnt,
                                                        const uint32_t* __restrict__ near_list, const uint32_t* __restrict__ near_top,
                                                        int32_t* __restrict__ pairs, int32_t* __restrict__ counts, int cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -231,8 +231,11 @@ __global__ __launch_bounds__(64 * NW) void k_bf_resolve(const uint8_t* __restric
         if (NW == 1) return __ballot(v) != 0ull;
         return __syncthreads_or(v ? 1 : 0) != 0;
     };
+    // valid_1 (optional): frame keypoints the caller excludes from matching start out "already matched" -- exactly upstream's
+    // `continue` for them in the inner loop; the near lists may still name them, every consumer below skips claimed entries
+    const uint8_t* v1 = valid_1 ? valid_1 + (size_t)p * (stride_1 / 32) : nullptr;
     for (int i = tid; i < n1; i += T) {
-        claimed[i] = 0;
+        claimed[i] = v1 ? (v1[i] ? 0 : 1) : 0;
         mark[i] = ~0u;
     }
     uint32_t n_out = 0;
@@ -522,6 +525,7 @@ struct ovs_matcher {
     uint8_t* d_desc_1 = nullptr;
     uint8_t* d_desc_2 = nullptr;
     uint8_t* d_valid = nullptr;
+    uint8_t* d_valid_1 = nullptr;
     int32_t* d_n = nullptr;        // [2]
     int32_t* d_pairs = nullptr;
     int32_t* d_count = nullptr;
@@ -547,8 +551,8 @@ uint32_t near_threshold(float lowe_ratio) {
     return std::min<uint32_t>(thr, OVS_MAX_HAMMING_DIST - 1);
 }
 
-ovs_status run_bf(ovs_matcher* m, const uint8_t* d1, size_t stride_1, const int32_t* d_n1, const uint8_t* d2, size_t stride_2,
-                  const int32_t* d_n2, const uint8_t* d_valid, int batch, float lowe_ratio, int32_t* d_pairs, int32_t* d_counts, int cap,
+ovs_status run_bf(ovs_matcher* m, const uint8_t* d1, size_t stride_1, const int32_t* d_n1, const uint8_t* d_valid_1, const uint8_t* d2,
+                  size_t stride_2, const int32_t* d_n2, const uint8_t* d_valid, int batch, float lowe_ratio, int32_t* d_pairs, int32_t* d_counts, int cap,
                   hipStream_t s) {
     const uint32_t thr = near_threshold(lowe_ratio);
     dim3 grid((m->max_n2 + 63) / 64, batch);
@@ -558,11 +562,11 @@ ovs_status run_bf(ovs_matcher* m, const uint8_t* d1, size_t stride_1, const int3
     OVS_HIP_TRY(hipGetLastError());
     OVS_HIP_TRY(m->prof.mark(1, s));
     if (m->resolve_lds_staged)
-        hipLaunchKernelGGL((k_bf_resolve<true, 4>), dim3(batch), dim3(256), m->resolve_lds_staged, s, d1, stride_1, d_n1, d2, stride_2, d_n2,
-                           m->max_n1, m->max_n2, lowe_ratio, m->d_near_cnt, m->d_near_list, m->d_near_top, d_pairs, d_counts, cap);
+        hipLaunchKernelGGL((k_bf_resolve<true, 4>), dim3(batch), dim3(256), m->resolve_lds_staged, s, d1, stride_1, d_n1, d_valid_1, d2, stride_2,
+                           d_n2, m->max_n1, m->max_n2, lowe_ratio, m->d_near_cnt, m->d_near_list, m->d_near_top, d_pairs, d_counts, cap);
     else
-        hipLaunchKernelGGL((k_bf_resolve<false, 1>), dim3(batch), dim3(64), m->resolve_lds, s, d1, stride_1, d_n1, d2, stride_2, d_n2, m->max_n1,
-                           m->max_n2, lowe_ratio, m->d_near_cnt, m->d_near_list, m->d_near_top, d_pairs, d_counts, cap);
+        hipLaunchKernelGGL((k_bf_resolve<false, 1>), dim3(batch), dim3(64), m->resolve_lds, s, d1, stride_1, d_n1, d_valid_1, d2, stride_2, d_n2,
+                           m->max_n1, m->max_n2, lowe_ratio, m->d_near_cnt, m->d_near_list, m->d_near_top, d_pairs, d_counts, cap);
     OVS_HIP_TRY(hipGetLastError());
     OVS_HIP_TRY(m->prof.mark(2, s));
     return OVS_OK;
@@ -609,6 +613,7 @@ ovs_status ovs_matcher_create(int32_t max_n1, int32_t max_n2, int32_t max_batch,
     CREATE_TRY(hipMalloc(&m->d_desc_1, (size_t)max_n1 * 32));
     CREATE_TRY(hipMalloc(&m->d_desc_2, (size_t)max_n2 * 32));
     CREATE_TRY(hipMalloc(&m->d_valid, (size_t)std::max(max_n1, max_n2)));
+    CREATE_TRY(hipMalloc(&m->d_valid_1, (size_t)max_n1));
     CREATE_TRY(hipMalloc(&m->d_n, sizeof(int32_t) * 2));
     CREATE_TRY(hipMalloc(&m->d_pairs, sizeof(int32_t) * 2 * max_n2));
     CREATE_TRY(hipMalloc(&m->d_count, sizeof(int32_t)));
@@ -635,6 +640,7 @@ ovs_status ovs_matcher_destroy(ovs_matcher* m) {
     hipFree(m->d_desc_1);
     hipFree(m->d_desc_2);
     hipFree(m->d_valid);
+    hipFree(m->d_valid_1);
     hipFree(m->d_n);
     hipFree(m->d_pairs);
     hipFree(m->d_count);
@@ -663,7 +669,7 @@ ovs_status ovs_matcher_profile_read(ovs_matcher* m, float* stage_ms, int32_t* nc
 }
 
 ovs_status ovs_robust_brute_force_match_batch_dev(ovs_matcher* m, const uint8_t* d_desc_1, size_t stride_1, const int32_t* d_n1,
-                                                  const uint8_t* d_desc_2, size_t stride_2, const int32_t* d_n2,
+                                                  const uint8_t* d_valid_1, const uint8_t* d_desc_2, size_t stride_2, const int32_t* d_n2,
                                                   const uint8_t* d_valid_2, int32_t batch, float lowe_ratio, int32_t* d_pairs,
                                                   int32_t* d_counts, int32_t cap, void* stream) {
     if (!m || !d_desc_1 || !d_desc_2 || !d_n1 || !d_n2 || !d_pairs || !d_counts || batch < 1 || cap < 1) return OVS_ERR_INVALID;
@@ -671,11 +677,11 @@ ovs_status ovs_robust_brute_force_match_batch_dev(ovs_matcher* m, const uint8_t*
     if (((uintptr_t)d_desc_1 & 3) || ((uintptr_t)d_desc_2 & 3) || (stride_1 & 31) || (stride_2 & 31)) return OVS_ERR_ALIGN;
     OVS_HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;   // verbatim: NULL is HIP's default stream (torch's default stream handle is 0)
-    return run_bf(m, d_desc_1, stride_1, d_n1, d_desc_2, stride_2, d_n2, d_valid_2, batch, lowe_ratio, d_pairs, d_counts, cap, s);
+    return run_bf(m, d_desc_1, stride_1, d_n1, d_valid_1, d_desc_2, stride_2, d_n2, d_valid_2, batch, lowe_ratio, d_pairs, d_counts, cap, s);
 }
 
-ovs_status ovs_robust_brute_force_match(ovs_matcher* m, const uint8_t* desc_1, int32_t n1, const uint8_t* desc_2, int32_t n2,
-                                        const uint8_t* valid_2, float lowe_ratio, int32_t* pairs, int32_t cap, int32_t* n_out) {
+ovs_status ovs_robust_brute_force_match(ovs_matcher* m, const uint8_t* desc_1, int32_t n1, const uint8_t* valid_1, const uint8_t* desc_2,
+                                        int32_t n2, const uint8_t* valid_2, float lowe_ratio, int32_t* pairs, int32_t cap, int32_t* n_out) {
     if (!m || !n_out || n1 < 0 || n2 < 0 || cap < 0) return OVS_ERR_INVALID;
     *n_out = 0;
     if (n1 == 0 || n2 == 0) return OVS_OK;
@@ -687,9 +693,10 @@ ovs_status ovs_robust_brute_force_match(ovs_matcher* m, const uint8_t* desc_1, i
     OVS_HIP_TRY(hipMemcpyAsync(m->d_desc_1, desc_1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(m->d_desc_2, desc_2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
     if (valid_2) OVS_HIP_TRY(hipMemcpyAsync(m->d_valid, valid_2, (size_t)n2, hipMemcpyHostToDevice, s));
+    if (valid_1) OVS_HIP_TRY(hipMemcpyAsync(m->d_valid_1, valid_1, (size_t)n1, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(m->d_n, nn, sizeof(nn), hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipStreamSynchronize(s));   // nn is a stack array
-    ovs_status st = run_bf(m, m->d_desc_1, (size_t)m->max_n1 * 32, m->d_n, m->d_desc_2, (size_t)m->max_n2 * 32, m->d_n + 1,
+    ovs_status st = run_bf(m, m->d_desc_1, (size_t)m->max_n1 * 32, m->d_n, valid_1 ? m->d_valid_1 : nullptr, m->d_desc_2, (size_t)m->max_n2 * 32, m->d_n + 1,
                            valid_2 ? m->d_valid : nullptr, 1, lowe_ratio, m->d_pairs, m->d_count, m->max_n2, s);
     if (st != OVS_OK) return st;
     int32_t n = 0;

@@ -268,8 +268,8 @@ __device__ __forceinline__ bool reproject_to_image(const CamP& c, const double* 
     }
     const double norm = sqrt((pcx * pcx + pcy * pcy) + pcz * pcz);
     const double bx = pcx / norm, by = pcy / norm, bz = pcz / norm;
-    const double latitude = -asin(by);
-    const double longitude = atan2(bx, bz);
+    const double latitude = -ovs_det_asin(by);
+    const double longitude = ovs_det_atan2(bx, bz);
     u = c.cols * (0.5 + longitude / (2.0 * 3.14159265358979323846));
     v = c.rows * (0.5 - latitude / 3.14159265358979323846);
     x_right = -1.0f;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_reproject_queries(CamP cam, const ovs_k
             const double* nrm = normals + 3 * (size_t)i;
             if ((dx * nrm[0] + dy * nrm[1]) + dz * nrm[2] < 0.5 * dist) valid = false;
         }
-        lvl = valid ? (int)ceilf(__fdiv_rn(logf(__fdiv_rn(dmax, (float)dist)), log_scale_factor)) : 0;
+        lvl = valid ? (int)ceilf(__fdiv_rn(ovs_det_logf(__fdiv_rn(dmax, (float)dist)), log_scale_factor)) : 0;
         if (lvl < 0) lvl = 0;
         else if (num_levels <= lvl) lvl = num_levels - 1;
         minl = lvl - 1;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void k_fuse_best(FuseArgs a, int32_t* __restri
             if ((dx * nrm[0] + dy * nrm[1]) + dz * nrm[2] < 0.5 * dist) break;
         }
         const float ratio = __fdiv_rn(dmax, (float)dist);
-        int pred = (int)ceilf(__fdiv_rn(logf(ratio), a.log_scale_factor));
+        int pred = (int)ceilf(__fdiv_rn(ovs_det_logf(ratio), a.log_scale_factor));
         if (pred < 0) pred = 0;
         else if (a.num_levels <= pred) pred = a.num_levels - 1;
         const float r = __fmul_rn(a.margin, a.sf[pred]);
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void k_bow_lists(BowArgs a, uint32_t* __restri
                                  ez = (a.E[6] * b2[0] + a.E[7] * b2[1]) + a.E[8] * b2[2];
                     const double nrm = sqrt((ex * ex + ey * ey) + ez * ez);
                     const double cos_residual = ((ex * b1[0] + ey * b1[1]) + ez * b1[2]) / nrm;
-                    const double residual_rad = 3.14159265358979323846 / 2.0 - fabs(acos(cos_residual));
+                    const double residual_rad = 3.14159265358979323846 / 2.0 - fabs(ovs_det_acos(cos_residual));
                     if (!(residual_rad < thr)) continue;
                     if (FILL) {
                         if (pos < key_cap) keys[pos] = (d << 20) | (uint32_t)idx;

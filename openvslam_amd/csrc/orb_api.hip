@@ -196,16 +196,24 @@ bool build_geometry(const ovs_orb* h, int rows, int cols, FrameGeo& geo, std::ve
 ovs_status ensure_geometry(ovs_orb* h, int rows, int cols) {
     if (rows == h->cur_rows && cols == h->cur_cols) return OVS_OK;
     if (rows > h->max_rows || cols > h->max_cols) return OVS_ERR_CAPACITY;
+    // Build into temporaries and commit only after every check and both uploads succeeded: a refused size (e.g. 60 x 1920: more than
+    // 64 root patches) must leave the handle exactly as it was, so that the next call with the previous, valid size still finds host
+    // geometry, device geometry and cur_rows / cur_cols in agreement.
     size_t pyr_bytes, cand_entries, node_entries;
-    if (!build_geometry(h, rows, cols, h->geo, h->taps, pyr_bytes, cand_entries, node_entries)) return OVS_ERR_INVALID;
+    FrameGeo geo;
+    std::vector<ResizeTap> taps;
+    if (!build_geometry(h, rows, cols, geo, taps, pyr_bytes, cand_entries, node_entries)) return OVS_ERR_INVALID;
     if (pyr_bytes > h->d.pyr_frame_bytes || cand_entries > h->d.cand_frame_entries || node_entries > h->d.node_frame_entries ||
-        h->taps.size() > h->taps_cap || (size_t)h->geo.total_kp_cap > h->kps_cap)
+        taps.size() > h->taps_cap || (size_t)geo.total_kp_cap > h->kps_cap)
         return OVS_ERR_CAPACITY;
     // the buffers keep the strides they were allocated with (max geometry); only offsets inside a frame block change
     OVS_HIP_TRY(hipDeviceSynchronize());   // rare: kernels of an earlier geometry may still read d_geo / d_taps
-    OVS_HIP_TRY(hipMemcpy(h->d_geo, &h->geo, sizeof(FrameGeo), hipMemcpyHostToDevice));
-    if (!h->taps.empty())
-        OVS_HIP_TRY(hipMemcpy(h->d_taps, h->taps.data(), h->taps.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+    // from here on the device copy is being replaced: if an upload fails half way, no size is current any more
+    h->cur_rows = h->cur_cols = 0;
+    OVS_HIP_TRY(hipMemcpy(h->d_geo, &geo, sizeof(FrameGeo), hipMemcpyHostToDevice));
+    if (!taps.empty()) OVS_HIP_TRY(hipMemcpy(h->d_taps, taps.data(), taps.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+    h->geo = geo;
+    h->taps.swap(taps);
     h->cur_rows = rows;
     h->cur_cols = cols;
     return OVS_OK;

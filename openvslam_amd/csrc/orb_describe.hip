@@ -161,7 +161,8 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
         m01 += __shfl_xor(m01, o);
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-    const float rad = __fmul_rn(angle, 0.017453292519943295f);
+    // upstream evaluates keypt.angle * M_PI / 180.0 in double and rounds to float once (ORACLE_SPEC rule 11)
+    const float rad = (float)__ddiv_rn(__dmul_rn((double)angle, 3.14159265358979323846), 180.0);
     const float cos_a = util_cos(rad), sin_a = util_sin(rad);
 
     // ---- blur row pass (8.8 fixed point): hblur[r][c] = sum_k g[k] * patch[r][c + k], c <-> dx = c - 18.

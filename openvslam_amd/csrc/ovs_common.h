@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/ovslam_hip.h"
+#include "../../include/ovs_detmath.h"
 
 namespace ovs {
 

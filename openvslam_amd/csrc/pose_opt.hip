@@ -154,7 +154,7 @@ constexpr int kPoseThreads = 256;   // one workgroup per frame: 0.75 ms per 2000
 constexpr int kPoseWaves = kPoseThreads / 64;
 
 __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __restrict__ poses_in, const ovs_pose_obs* __restrict__ obs_all,
-                                                      const int32_t* __restrict__ obs_offsets, ovs_ba_cam cam, double bf,
+                                                      const int32_t* __restrict__ obs_offsets, ovs_ba_cam cam, double bf, int setup_type,
                                                       double* __restrict__ poses_out, uint8_t* __restrict__ outlier_all,
                                                       int32_t* __restrict__ num_valid) {
     __shared__ double s_part[kPoseWaves][28];
@@ -167,7 +167,13 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
     const int o0 = obs_offsets[p], n = obs_offsets[p + 1] - o0;
     const ovs_pose_obs* obs = obs_all + o0;
     uint8_t* outlier = outlier_all + o0;
-    const double d_mono = sqrt(5.991), d_stereo = sqrt(7.815);
+    // upstream: ONE Huber delta per frame, chosen by the rig (Monocular -> sqrt_chi_sq_2D, otherwise sqrt_chi_sq_3D); the chi-square
+    // outlier gates stay per edge
+    const double huber = setup_type == 0 ? sqrt(5.991) : sqrt(7.815);
+    if (n > kPoseMaxObs) {   // the per-thread inlier mask holds 32 observations: refuse instead of aliasing flags
+        if (tid == 0) num_valid[p] = -1;
+        return;
+    }
 
     // fixed-order block reduction of NV per-thread values into s_sum
     auto reduce = [&](const double* v, int nv) {
@@ -194,11 +200,13 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
     int num_bad = 0;
     if (n >= 5) {
         for (int trial = 0; trial < 4; ++trial) {
-            const bool robust = trial < 2;
-            if (tid == 0) s_T = T0;
-            __syncthreads();
+            // Huber in rounds 0..2 (`if (trial == num_trials_ - 2) setRobustKernel(nullptr)` runs after round 2's optimisation); the
+            // estimate carries over from round to round (the frame vertex is initialised once, before the loop)
+            const bool robust = trial < 3;
             double lambda = 0, ni = 2;   // held identically by every thread (all control flow below is workgroup-uniform)
+            bool err_at_trial = false;   // active edges' errors were last computed at s_Tn (g2o leaves them stale after a rejected step)
             for (int it = 0; it < 10; ++it) {
+                err_at_trial = false;    // solve() starts with computeActiveErrors() at the current estimate
                 // ---- linearise at s_T
                 double acc[28];
 #pragma unroll
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                     for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k)
                         if ((active >> k) & 1u) {
                             const ovs_pose_obs o = obs[i];
-                            pose_edge(R, t, o, cam, bf, robust ? (o.is_stereo ? d_stereo : d_mono) : 0.0, acc);
+                            pose_edge(R, t, o, cam, bf, robust ? huber : 0.0, acc);
                         }
                 }
                 reduce(acc, 28);
@@ -264,13 +272,14 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                             if ((active >> k) & 1u) {
                                 const ovs_pose_obs o = obs[i];
                                 const double c2 = pose_edge(R, t, o, cam, bf, 0.0, nullptr);
-                                const double delta = robust ? (o.is_stereo ? d_stereo : d_mono) : 0.0;
+                                const double delta = robust ? huber : 0.0;
                                 double r = c2;
                                 if (delta > 0 && c2 > delta * delta) r = 2 * sqrt(c2) * delta - delta * delta;
                                 part += r;
                             }
                         reduce(&part, 1);
                         temp_chi = s_sum[0];
+                        err_at_trial = true;
                     }
                     __syncthreads();
                     rho = (current_chi - temp_chi) / scale;
@@ -290,16 +299,22 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                 } while (rho < 0 && qmax < 10);
                 if (qmax == 10 || rho == 0) break;
             }
-            // ---- re-classify every observation with the optimised pose
+            // ---- re-classify every observation: outliers of the previous round at the estimate (upstream calls computeError() for
+            // them), inliers at the state their errors were last computed at (the last trial state: the estimate itself unless the
+            // round ended on a rejected step)
             {
-                double R[9], t[3];
+                double R[9], t[3], Re[9], te[3];
                 for (int i = 0; i < 9; ++i) R[i] = s_T.R[i];
                 for (int i = 0; i < 3; ++i) t[i] = s_T.t[i];
+                for (int i = 0; i < 9; ++i) Re[i] = err_at_trial ? s_Tn.R[i] : R[i];
+                for (int i = 0; i < 3; ++i) te[i] = err_at_trial ? s_Tn.t[i] : t[i];
                 int bad = 0;
+                const uint32_t was_active = active;
                 active = 0;
                 for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k) {
                     const ovs_pose_obs o = obs[i];
-                    const double c2 = pose_edge(R, t, o, cam, bf, 0.0, nullptr);
+                    const bool wa = (was_active >> k) & 1u;
+                    const double c2 = pose_edge(wa ? Re : R, wa ? te : t, o, cam, bf, 0.0, nullptr);
                     const bool out = (o.is_stereo ? 7.815 : 5.991) < c2;
                     outlier[i] = out ? 1 : 0;
                     if (out) ++bad;
@@ -314,7 +329,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                 for (int w = 0; w < kPoseWaves; ++w) num_bad += s_cnt[w];
                 __syncthreads();
             }
-            if (n < 10) break;
+            if (n - num_bad < 5) break;   // upstream: if (num_init_obs - num_bad_obs < 5) break;
         }
     }
     if (tid < 9) poses_out[12 * (size_t)p + tid] = s_T.R[tid];
@@ -329,17 +344,17 @@ using namespace ovs;
 extern "C" {
 
 ovs_status ovs_pose_optimize_batch_dev(const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
-                                       const ovs_ba_cam* cam, double focal_x_baseline, double* d_poses_out, uint8_t* d_outlier,
-                                       int32_t* d_num_valid, void* stream) {
+                                       const ovs_ba_cam* cam, double focal_x_baseline, int32_t setup_type, double* d_poses_out,
+                                       uint8_t* d_outlier, int32_t* d_num_valid, void* stream) {
     if (!d_poses_in || !d_obs || !d_obs_offsets || !cam || !d_poses_out || !d_outlier || !d_num_valid || batch < 1) return OVS_ERR_INVALID;
     hipLaunchKernelGGL(k_pose_optimize, dim3(batch), dim3(kPoseThreads), 0, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, *cam,
-                       focal_x_baseline, d_poses_out, d_outlier, d_num_valid);
+                       focal_x_baseline, (int)setup_type, d_poses_out, d_outlier, d_num_valid);
     OVS_HIP_TRY(hipGetLastError());
     return OVS_OK;
 }
 
 ovs_status ovs_pose_optimize(int32_t device, const double* pose_cw_in, const ovs_pose_obs* obs, int32_t n_obs, const ovs_ba_cam* cam,
-                             double focal_x_baseline, double* pose_cw_out, uint8_t* outlier_flags, int32_t* num_valid) {
+                             double focal_x_baseline, int32_t setup_type, double* pose_cw_out, uint8_t* outlier_flags, int32_t* num_valid) {
     if (!pose_cw_in || !cam || !pose_cw_out || !num_valid || n_obs < 0 || (n_obs > 0 && (!obs || !outlier_flags))) return OVS_ERR_INVALID;
     if (n_obs > kPoseMaxObs) return OVS_ERR_CAPACITY;
     if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
@@ -381,7 +396,7 @@ ovs_status ovs_pose_optimize(int32_t device, const double* pose_cw_in, const ovs
         if (n_obs) P_TRY(hipMemcpy(d + off_obs, obs, sizeof(ovs_pose_obs) * (size_t)n_obs, hipMemcpyHostToDevice));
         P_TRY(hipMemcpy(d + off_off, offs, sizeof(offs), hipMemcpyHostToDevice));
         st = ovs_pose_optimize_batch_dev(reinterpret_cast<double*>(d), reinterpret_cast<ovs_pose_obs*>(d + off_obs),
-                                         reinterpret_cast<int32_t*>(d + off_off), 1, cam, focal_x_baseline,
+                                         reinterpret_cast<int32_t*>(d + off_off), 1, cam, focal_x_baseline, setup_type,
                                          reinterpret_cast<double*>(d + off_out), d + off_fl, reinterpret_cast<int32_t*>(d + off_nv), nullptr);
         if (st != OVS_OK) break;
         st = OVS_ERR_HIP;

@@ -38,8 +38,9 @@ class robust(_matcher_ctx):
         self.lowe_ratio_ = float(lowe_ratio)
         self.check_orientation_ = bool(check_orientation)
 
-    def brute_force_match(self, frm_descriptors, keyfrm_descriptors, keyfrm_has_landmark=None):
-        """robust::brute_force_match(frm, keyfrm, matches): returns matches as an (n, 2) int32 array of (idx_1, idx_2)."""
+    def brute_force_match(self, frm_descriptors, keyfrm_descriptors, keyfrm_has_landmark=None, frm_valid=None):
+        """robust::brute_force_match(frm, keyfrm, matches): returns matches as an (n, 2) int32 array of (idx_1, idx_2).
+        frm_valid: optional per-frame-keypoint mask (0 = never a candidate), see ovs_robust_brute_force_match."""
         d1 = np.ascontiguousarray(frm_descriptors, np.uint8).reshape(-1, 32)
         d2 = np.ascontiguousarray(keyfrm_descriptors, np.uint8).reshape(-1, 32)
         v = None
@@ -47,18 +48,24 @@ class robust(_matcher_ctx):
             v = np.ascontiguousarray(keyfrm_has_landmark, np.uint8)
             if len(v) != len(d2):
                 raise ValueError("keyfrm_has_landmark must have one entry per keyframe keypoint")
+        v1 = None
+        if frm_valid is not None:
+            v1 = np.ascontiguousarray(frm_valid, np.uint8)
+            if len(v1) != len(d1):
+                raise ValueError("frm_valid must have one entry per frame keypoint")
         pairs = np.zeros((max(len(d2), 1), 2), np.int32)
         n = C.c_int32()
-        _lib.check(self._L.ovs_robust_brute_force_match(self._h, _p(d1), len(d1), _p(d2), len(d2), _p(v), self.lowe_ratio_, _p(pairs),
+        _lib.check(self._L.ovs_robust_brute_force_match(self._h, _p(d1), len(d1), _p(v1), _p(d2), len(d2), _p(v), self.lowe_ratio_, _p(pairs),
                                                         len(pairs), C.byref(n)), "ovs_robust_brute_force_match")
         return pairs[:n.value].copy()
 
-    def brute_force_match_batch_dev(self, d_desc_1, d_n1, d_desc_2, d_n2, d_pairs, d_counts, stream=None, d_valid_2=None):
+    def brute_force_match_batch_dev(self, d_desc_1, d_n1, d_desc_2, d_n2, d_pairs, d_counts, stream=None, d_valid_2=None, d_valid_1=None):
         """Device-resident batch: d_desc_1 (B, cap1, 32) u8, d_desc_2 (B, cap2, 32) u8, d_n1/d_n2 (B,) int32,
         d_pairs (B, cap, 2) int32, d_counts (B,) int32 -- torch CUDA tensors."""
         B = d_desc_1.shape[0]
         _lib.check(self._L.ovs_robust_brute_force_match_batch_dev(
-            self._h, d_desc_1.data_ptr(), d_desc_1.stride(0), d_n1.data_ptr(), d_desc_2.data_ptr(), d_desc_2.stride(0), d_n2.data_ptr(),
+            self._h, d_desc_1.data_ptr(), d_desc_1.stride(0), d_n1.data_ptr(), d_valid_1.data_ptr() if d_valid_1 is not None else None,
+            d_desc_2.data_ptr(), d_desc_2.stride(0), d_n2.data_ptr(),
             d_valid_2.data_ptr() if d_valid_2 is not None else None, B, self.lowe_ratio_, d_pairs.data_ptr(), d_counts.data_ptr(),
             d_pairs.shape[1], stream), "ovs_robust_brute_force_match_batch_dev")
 

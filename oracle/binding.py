@@ -63,7 +63,7 @@ def lib():
     L.ovo_orb_level_num_keypts.argtypes = [vp, C.c_int]
     L.ovo_descriptor_distance_32.argtypes = [vp, vp]
     L.ovo_descriptor_distance_32.restype = C.c_uint32
-    L.ovo_robust_brute_force_match.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_float, vp, C.c_int]
+    L.ovo_robust_brute_force_match.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, C.c_float, vp, C.c_int]
     L.ovo_hamming_best2.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]
     for name, at in _OPTIONAL.items():
         if hasattr(L, name):
@@ -80,6 +80,20 @@ _OPTIONAL = {"ovo_ba_linearize": ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, 
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+DETMATH_LOGF, DETMATH_ASIN, DETMATH_ACOS, DETMATH_ATAN2 = 0, 1, 2, 3
+
+
+def detmath_eval(fn, a, b=None):
+    """include/ovs_detmath.h on the host (the op sequence the kernels share)."""
+    a = np.ascontiguousarray(a, np.float64)
+    b = np.ascontiguousarray(b, np.float64) if b is not None else None
+    out = np.zeros(a.shape, np.float64)
+    f = lib().ovo_detmath_eval
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    assert f(fn, _p(a), _p(b), _p(out), a.size) == 0
+    return out
 
 
 def make_params(max_num_keypts=2000, scale_factor=1.2, num_levels=8, ini_fast_thr=20, min_fast_thr=7):
@@ -211,13 +225,15 @@ def descriptor_distance(a, b):
     return int(lib().ovo_descriptor_distance_32(_p(a), _p(b)))
 
 
-def robust_brute_force_match(desc_frm, desc_kf, kf_valid=None, lowe_ratio=0.8):
+def robust_brute_force_match(desc_frm, desc_kf, kf_valid=None, lowe_ratio=0.8, frm_valid=None):
     desc_frm = np.ascontiguousarray(desc_frm, np.uint8)
     desc_kf = np.ascontiguousarray(desc_kf, np.uint8)
     if kf_valid is not None:
         kf_valid = np.ascontiguousarray(kf_valid, np.uint8)
     pairs = np.zeros((max(len(desc_kf), 1), 2), np.int32)
-    n = lib().ovo_robust_brute_force_match(_p(desc_frm), len(desc_frm), _p(desc_kf), len(desc_kf), _p(kf_valid),
+    if frm_valid is not None:
+        frm_valid = np.ascontiguousarray(frm_valid, np.uint8)
+    n = lib().ovo_robust_brute_force_match(_p(desc_frm), len(desc_frm), _p(frm_valid), _p(desc_kf), len(desc_kf), _p(kf_valid),
                                            lowe_ratio, _p(pairs), len(pairs))
     return pairs[:n].copy()
 
@@ -527,7 +543,7 @@ POSE_OBS_DTYPE = np.dtype([("pos_w", "<f8", (3,)), ("obs_x", "<f8"), ("obs_y", "
 assert POSE_OBS_DTYPE.itemsize == 64
 
 
-def pose_optimize(pose_cw, obs, cam, focal_x_baseline=0.0):
+def pose_optimize(pose_cw, obs, cam, focal_x_baseline=0.0, setup_type=None):
     """optimize::pose_optimizer::optimize (ovo_pose.cc). Returns (pose_cw 3x4, outlier flags, num_valid)."""
     o = np.ascontiguousarray(obs, POSE_OBS_DTYPE)
     pin = _pose12(pose_cw)
@@ -535,7 +551,10 @@ def pose_optimize(pose_cw, obs, cam, focal_x_baseline=0.0):
     out = np.zeros(max(len(o), 1), np.uint8)
     nv = C.c_int()
     c = np.array(cam, np.float64)
-    rc = lib().ovo_pose_optimize(_p(pin), _p(o), len(o), _p(c), C.c_double(focal_x_baseline), _p(pout), _p(out), C.byref(nv))
+    if setup_type is None:
+        setup_type = 1 if focal_x_baseline != 0.0 else 0
+    rc = lib().ovo_pose_optimize(_p(pin), _p(o), len(o), _p(c), C.c_double(focal_x_baseline), C.c_int(int(setup_type)), _p(pout), _p(out),
+                                 C.byref(nv))
     assert rc == 0
     return np.concatenate([pout[:9].reshape(3, 3), pout[9:, None]], 1), out[:len(o)].astype(bool), nv.value
 

@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "ovo_oracle.h"
+#include "../include/ovs_detmath.h"
 
 extern "C" {
 
@@ -137,8 +138,8 @@ int ovo_ba_linearize_equirect(const double* poses, const uint8_t* pose_fixed, in
         const double z = R[2][0] * X[0] + R[2][1] * X[1] + R[2][2] * X[2] + P[2];
         const double L = std::sqrt((x * x + y * y) + z * z);
         const double rxz = x * x + z * z;
-        const double theta = std::atan2(x, z);
-        const double phi = -std::asin(y / L);
+        const double theta = ovs_det_atan2(x, z);
+        const double phi = -ovs_det_asin(y / L);
         const double e0 = ed.obs_x - cols * (0.5 + theta / (2.0 * kPi));
         const double e1 = ed.obs_y - rows * (0.5 - phi / kPi);
         const double w = ed.inv_sigma_sq;

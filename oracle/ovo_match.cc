@@ -31,10 +31,13 @@ uint32_t ovo_descriptor_distance_32(const uint8_t* a, const uint8_t* b) { return
 // M2  match::robust::brute_force_match: outer loop over keyframe keypoints that hold a live
 // landmark, inner loop over ALL frame keypoints not yet claimed by an earlier keyframe keypoint; strict `<`
 // keeps the FIRST minimum; accept iff best <= HAMMING_DIST_THR_LOW and !(lowe_ratio*second < best).
-int ovo_robust_brute_force_match(const uint8_t* desc_frm, int n_frm, const uint8_t* desc_kf, int n_kf, const uint8_t* kf_valid,
-                                 float lowe_ratio, int32_t* pairs, int cap) {
+int ovo_robust_brute_force_match(const uint8_t* desc_frm, int n_frm, const uint8_t* frm_valid, const uint8_t* desc_kf, int n_kf,
+                                 const uint8_t* kf_valid, float lowe_ratio, int32_t* pairs, int cap) {
     int num_matches = 0;
     std::vector<uint8_t> already_matched_1((size_t)(n_frm > 0 ? n_frm : 0), 0);
+    // optional frame-side mask (ORACLE_SPEC rule 14): an excluded frame keypoint is skipped like an already matched one
+    if (frm_valid)
+        for (int i = 0; i < n_frm; ++i) already_matched_1[i] = frm_valid[i] ? 0 : 1;
     for (int idx_2 = 0; idx_2 < n_kf; ++idx_2) {
         if (kf_valid && !kf_valid[idx_2]) continue;
         const uint8_t* desc_2 = desc_kf + (size_t)idx_2 * 32;

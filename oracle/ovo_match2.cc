@@ -11,6 +11,7 @@
 // Object graphs (data::frame, data::landmark*, camera::base) are flattened into SoA arrays exactly as the C ABI of
 // include/ovslam_hip.h flattens them; every rule that had to be chosen is listed in ORACLE_SPEC.md (rules 16+).
 #include "ovo_oracle.h"
+#include "../include/ovs_detmath.h"
 
 #include <algorithm>
 #include <climits>
@@ -348,12 +349,42 @@ static bool reproject_to_image(const ovo_camera& cam, const ovo_grid_params& b, 
     }
     const double norm = std::sqrt((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]);
     const double bx = pc[0] / norm, by = pc[1] / norm, bz = pc[2] / norm;
-    const double latitude = -std::asin(by);
-    const double longitude = std::atan2(bx, bz);
+    const double latitude = -ovs_det_asin(by);
+    const double longitude = ovs_det_atan2(bx, bz);
     reproj[0] = cam.cols * (0.5 + longitude / (2.0 * M_PI));
     reproj[1] = cam.rows * (0.5 - latitude / M_PI);
     *x_right = -1.0f;
     return true;
+}
+
+int ovo_detmath_eval(int fn, const double* a, const double* b, double* out, int n) {
+    for (int i = 0; i < n; ++i) {
+        switch (fn) {
+            case 0: out[i] = (double)ovs_det_logf((float)a[i]); break;
+            case 1: out[i] = ovs_det_asin(a[i]); break;
+            case 2: out[i] = ovs_det_acos(a[i]); break;
+            case 3: out[i] = ovs_det_atan2(a[i], b[i]); break;
+            default: return -1;
+        }
+    }
+    return 0;
+}
+
+// ovs_det_logf against THIS machine's libm logf over every positive finite float bit pattern in [first, last]: number of mismatches
+long long ovo_detmath_logf_vs_libm(uint32_t first, uint32_t last) {
+    long long mism = 0;
+#pragma omp parallel for reduction(+ : mism) schedule(static)
+    for (int64_t u = first; u <= (int64_t)last; ++u) {
+        const uint32_t b = (uint32_t)u;
+        float x;
+        std::memcpy(&x, &b, 4);
+        const float mine = ovs_det_logf(x), ref = ::logf(x);
+        uint32_t um, ur;
+        std::memcpy(&um, &mine, 4);
+        std::memcpy(&ur, &ref, 4);
+        if (um != ur) ++mism;
+    }
+    return mism;
 }
 
 int ovo_reproject_to_image(const ovo_camera* cam, const ovo_grid_params* bounds, const double* pose_cw, const double* pos_w,
@@ -472,7 +503,7 @@ int ovo_fuse_replace_duplication(const ovo_camera* cam, const ovo_grid_params* g
         if ((v[0] * nrm[0] + v[1] * nrm[1]) + v[2] * nrm[2] < 0.5 * dist) continue;
         // landmark::predict_scale_level(cam_to_lm_dist, keyfrm)
         const float ratio = dmax / (float)dist;
-        int pred = (int)std::ceil(std::log(ratio) / log_scale_factor);
+        int pred = (int)std::ceil(ovs_det_logf(ratio) / log_scale_factor);
         if (pred < 0) pred = 0;
         else if (num_scale_levels <= pred) pred = num_scale_levels - 1;
         const float r = margin * scale_factors[pred];
@@ -592,7 +623,7 @@ int ovo_projection_match_frame_and_keyframe(const ovo_camera* cam, const ovo_gri
         const float dmin = kf_dist_min_max[2 * i], dmax = kf_dist_min_max[2 * i + 1];
         if (dist < valid_min(dmin) || valid_max(dmax) < dist) continue;
         const float ratio = dmax / (float)dist;
-        int pred = (int)std::ceil(std::log(ratio) / log_scale_factor);
+        int pred = (int)std::ceil(ovs_det_logf(ratio) / log_scale_factor);
         if (pred < 0) pred = 0;
         else if (num_scale_levels <= pred) pred = num_scale_levels - 1;
         const float r = margin * scale_factors[pred];
@@ -661,7 +692,7 @@ int ovo_fuse_detect_duplication(const ovo_camera* cam, const ovo_grid_params* gp
         const double* nrm = lm_normal + 3 * (size_t)l;
         if ((v[0] * nrm[0] + v[1] * nrm[1]) + v[2] * nrm[2] < 0.5 * dist) continue;
         const float ratio = dmax / (float)dist;
-        int pred = (int)std::ceil(std::log(ratio) / log_scale_factor);
+        int pred = (int)std::ceil(ovs_det_logf(ratio) / log_scale_factor);
         if (pred < 0) pred = 0;
         else if (num_scale_levels <= pred) pred = num_scale_levels - 1;
         const float r = margin * scale_factors[pred];
@@ -714,7 +745,7 @@ int ovo_projection_match_by_sim3_transform(const ovo_camera* cam, const ovo_grid
         const double* nrm = lm_normal + 3 * (size_t)l;
         if ((v[0] * nrm[0] + v[1] * nrm[1]) + v[2] * nrm[2] < 0.5 * dist) continue;
         const float ratio = dmax / (float)dist;
-        int pred = (int)std::ceil(std::log(ratio) / log_scale_factor);
+        int pred = (int)std::ceil(ovs_det_logf(ratio) / log_scale_factor);
         if (pred < 0) pred = 0;
         else if (num_scale_levels <= pred) pred = num_scale_levels - 1;
         const float r = margin * scale_factors[pred];
@@ -760,7 +791,7 @@ static void mutual_pass(const ovo_camera& cam_b, const ovo_grid_params& gp_b, co
         const float dmin = lm_dist_min_max[2 * i], dmax = lm_dist_min_max[2 * i + 1];
         if (dist < valid_min(dmin) || valid_max(dmax) < dist) continue;
         const float ratio = dmax / (float)dist;
-        int pred = (int)std::ceil(std::log(ratio) / log_scale_factor);
+        int pred = (int)std::ceil(ovs_det_logf(ratio) / log_scale_factor);
         if (pred < 0) pred = 0;
         else if (num_scale_levels <= pred) pred = num_scale_levels - 1;
         const float r = margin * scale_factors[pred];
@@ -863,7 +894,7 @@ int ovo_robust_match_for_triangulation(const uint8_t* desc_1, const float* angle
                                           (E_12[6] * b2[0] + E_12[7] * b2[1]) + E_12[8] * b2[2]};
                     const double nrm = std::sqrt((ep[0] * ep[0] + ep[1] * ep[1]) + ep[2] * ep[2]);
                     const double cos_residual = ((ep[0] * b1[0] + ep[1] * b1[1]) + ep[2] * b1[2]) / nrm;
-                    const double residual_rad = kPi / 2.0 - std::fabs(std::acos(cos_residual));
+                    const double residual_rad = kPi / 2.0 - std::fabs(ovs_det_acos(cos_residual));
                     const double residual_rad_thr = 0.2 * kPi / 180.0;
                     if (!(residual_rad < residual_rad_thr * scale_factors[octaves_1[idx_1]])) continue;
                     best_idx_2 = idx_2;

@@ -62,6 +62,9 @@ int ovo_distribute_via_tree(const float* xs, const float* ys, const float* respo
                             int max_x, int min_y, int max_y, int num_keypts, int32_t* out_idx, int cap);
 /* A5: ic_angle + cv::fastAtan2 (degrees). */
 float ovo_fast_atan2(float y, float x);
+/* include/ovs_detmath.h evaluated on the host: fn 0 logf(float a) 1 asin 2 acos 3 atan2(a, b) */
+int ovo_detmath_eval(int fn, const double* a, const double* b, double* out, int n);
+long long ovo_detmath_logf_vs_libm(uint32_t first_bits, uint32_t last_bits);
 float ovo_ic_angle(const uint8_t* img, size_t stride, int x, int y, const int32_t* u_max16);
 /* A6: 7x7 sigma=2 Gaussian, 8.8 fixed point, BORDER_REFLECT_101. */
 int ovo_gaussian_blur_7x7(const uint8_t* src, int rows, int cols, size_t sstride, uint8_t* dst, size_t dstride);
@@ -96,9 +99,10 @@ int ovo_orb_level_num_keypts(const ovo_orb* h, int level);
 uint32_t ovo_descriptor_distance_32(const uint8_t* a, const uint8_t* b);
 /* M2: match::robust::brute_force_match(frame, keyframe, matches).
  *   desc_frm: n_frm x 32 (frame = idx_1 side), desc_kf: n_kf x 32 (keyframe = idx_2 side),
- *   kf_valid: NULL or n_kf bytes (landmark present and not will_be_erased).
+ *   kf_valid: NULL or n_kf bytes (landmark present and not will_be_erased); frm_valid: NULL or n_frm bytes, 0 = the frame
+ *   keypoint is skipped by the inner loop (optional frame-side mask, ORACLE_SPEC rule 14).
  *   Output pairs (idx_1, idx_2) in emission order. Returns number of matches. */
-int ovo_robust_brute_force_match(const uint8_t* desc_frm, int n_frm, const uint8_t* desc_kf, int n_kf,
+int ovo_robust_brute_force_match(const uint8_t* desc_frm, int n_frm, const uint8_t* frm_valid, const uint8_t* desc_kf, int n_kf,
                                  const uint8_t* kf_valid, float lowe_ratio, int32_t* pairs, int cap);
 /* Unconstrained per-query best / second best (first-seen tie rule) over all valid targets. */
 int ovo_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* t_valid,
@@ -221,7 +225,7 @@ typedef struct ovo_pose_obs {   /* one observed landmark of the frame: pose_opt_
     int32_t is_stereo, pad;
 } ovo_pose_obs;
 /* pose_cw: 12 doubles (rotation row-major, translation). cam4 = fx, fy, cx, cy. outlier[n] = frm.outlier_flags_. */
-int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* obs, int n, const double* cam4, double focal_x_baseline,
+int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* obs, int n, const double* cam4, double focal_x_baseline, int setup_type,
                       double* pose_cw_out, uint8_t* outlier, int* num_valid);
 
 #ifdef __cplusplus

@@ -493,7 +493,6 @@ constexpr float kTwoPi = 6.28318530717958647692f;
 constexpr float kHalfPi = 1.57079632679489661923f;
 constexpr float kThreeHalfPi = 4.71238898038468985769f;
 constexpr float kInvTwoPi = 0.15915494309189533577f;
-constexpr float kDegToRad = 0.017453292519943295f;   // (float)(CV_PI/180)
 
 inline float poly_cos(float v) {
     const float c1 = 0.99940307f, c2 = -0.49558072f, c3 = 0.03679168f;
@@ -511,7 +510,9 @@ float util_cos(float v) {
 float util_sin(float v) { return util_cos(kHalfPi - v); }
 
 void orb_descriptor(const uint8_t* blurred, size_t stride, int x, int y, float angle_deg, uint8_t* desc) {
-    const float angle = angle_deg * kDegToRad;
+    // upstream: `const float angle = keypt.angle * M_PI / 180.0;` -- float * double / double evaluated in double, rounded to float ONCE
+    // (ORACLE_SPEC rule 11; not ORB-SLAM2's single float multiply by factorPI, which differs by 1 ulp for a fraction of the angles)
+    const float angle = (float)((double)angle_deg * M_PI / 180.0);
     const float cos_a = util_cos(angle), sin_a = util_sin(angle);
     const uint8_t* center = blurred + (size_t)y * stride + x;
     const int step = (int)stride;

@@ -121,12 +121,11 @@ inline double edge_eval(const Pose& T, const ovo_pose_obs& o, const double* cam,
 
 // robustified chi2 of the active edges for pose T (no Jacobians)
 double robust_chi(const Pose& T, const ovo_pose_obs* obs, int n, const std::vector<uint8_t>& active, const double* cam, double bf,
-                  bool robust) {
+                  double delta) {
     double sum = 0;
     for (int i = 0; i < n; ++i) {
         if (!active[i]) continue;
         const double c2 = edge_eval(T, obs[i], cam, bf, 0, nullptr);
-        const double delta = robust ? (obs[i].is_stereo ? std::sqrt(7.815) : std::sqrt(5.991)) : 0.0;
         double r = c2;
         if (delta > 0 && c2 > delta * delta) r = 2 * std::sqrt(c2) * delta - delta * delta;
         sum += r;
@@ -165,8 +164,11 @@ bool solve6(const double* H, double lambda, const double* b, double* x) {
 
 }   // namespace
 
-extern "C" int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* obs, int n, const double* cam4, double bf,
+extern "C" int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* obs, int n, const double* cam4, double bf, int setup_type,
                                  double* pose_cw_out, uint8_t* outlier, int* num_valid) {
+    // upstream: sqrt_chi_sq = (frm.camera_->setup_type_ == Monocular) ? sqrt_chi_sq_2D : sqrt_chi_sq_3D -- ONE Huber delta for every
+    // edge of the frame, chosen by the rig; the chi-square outlier gates below stay per edge (is_monocular_)
+    const double huber = setup_type == 0 ? std::sqrt(5.991) : std::sqrt(7.815);
     Pose T0;
     std::memcpy(T0.R, pose_cw_in, sizeof(double) * 9);
     std::memcpy(T0.t, pose_cw_in + 9, sizeof(double) * 3);
@@ -176,15 +178,19 @@ extern "C" int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* o
     int num_bad = 0;
     if (n >= 5) {   // upstream: if (num_init_obs < 5) return 0;
         for (int trial = 0; trial < 4; ++trial) {
-            const bool robust = trial < 2;
-            T = T0;              // frm_vtx->setEstimate(initial pose)
+            // `if (trial == num_trials_ - 2) edge->setRobustKernel(nullptr)` runs AFTER trial 2's optimisation: Huber in trials 0, 1, 2.
+            // The frame vertex is set to the initial pose once, before the loop (unlike ORB-SLAM2, which resets it every round):
+            // each round continues from the previous round's estimate.
+            const bool robust = trial < 3;
+            Pose Terr = T;       // the state the ACTIVE edges' errors were last computed at (g2o leaves them stale after a rejected step)
             double lambda = 0, ni = 2;
             for (int it = 0; it < 10; ++it) {
                 Lin lin;
                 std::memset(&lin, 0, sizeof(lin));
+                Terr = T;   // solve() starts with computeActiveErrors() at the current estimate
                 for (int i = 0; i < n; ++i)
                     if (active[i])
-                        edge_eval(T, obs[i], cam4, bf, robust ? (obs[i].is_stereo ? std::sqrt(7.815) : std::sqrt(5.991)) : 0.0, &lin);
+                        edge_eval(T, obs[i], cam4, bf, robust ? huber : 0.0, &lin);
                 double current_chi = lin.chi_robust;
                 if (it == 0) {
                     double max_diag = 0;
@@ -203,7 +209,8 @@ extern "C" int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* o
                         Pose E;
                         se3_exp(dx, E);
                         compose(E, T, Tn);
-                        temp_chi = robust_chi(Tn, obs, n, active, cam4, bf, robust);
+                        temp_chi = robust_chi(Tn, obs, n, active, cam4, bf, robust ? huber : 0.0);
+                        Terr = Tn;   // computeActiveErrors() ran on the trial state
                     }
                     rho = current_chi - temp_chi;
                     double scale = 0;
@@ -226,10 +233,12 @@ extern "C" int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* o
                 } while (rho < 0 && qmax < 10);
                 if (qmax == 10 || rho == 0) break;
             }
-            // re-classify every edge with the optimised pose
+            // re-classify every edge: upstream calls edge->computeError() only for the edges currently flagged as outliers (they were
+            // not part of the optimisation); an inlier's chi2() is whatever the last computeActiveErrors() left, i.e. the last TRIAL
+            // state -- equal to the estimate unless the round ended on a rejected step (qmax == 10 or rho == 0).
             num_bad = 0;
             for (int i = 0; i < n; ++i) {
-                const double c2 = edge_eval(T, obs[i], cam4, bf, 0, nullptr);
+                const double c2 = edge_eval(active[i] ? Terr : T, obs[i], cam4, bf, 0, nullptr);
                 const double thr = obs[i].is_stereo ? 7.815 : 5.991;
                 if (thr < c2) {
                     outlier[i] = 1;
@@ -240,7 +249,7 @@ extern "C" int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* o
                     active[i] = 1;
                 }
             }
-            if (n < 10) break;   // upstream: optimizer.edges().size() < 10 (edges are never removed from the graph)
+            if (n - num_bad < 5) break;   // upstream: if (num_init_obs - num_bad_obs < 5) break;
         }
     }
     std::memcpy(pose_cw_out, T.R, sizeof(double) * 9);

@@ -1,0 +1,96 @@
+"""include/ovs_detmath.h: the deterministic log / asin / acos / atan2 that replace libm wherever a float decides a match pair
+(VERDICT round 1, weak #2). CPU part: pinned against glibc through numpy (an independent implementation), so a transcription error
+in a coefficient shows up here and not as a silently shared bug. GPU part: gfx950 and the host produce identical bits."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+
+
+def _ulp_diff(a, b):
+    ia = a.view(np.int64).copy()
+    ib = b.view(np.int64).copy()
+    ia[ia < 0] = np.int64(-2**63) - ia[ia < 0]   # monotone map of the sign-magnitude encoding
+    ib[ib < 0] = np.int64(-2**63) - ib[ib < 0]
+    return np.abs(ia - ib)
+
+
+def _samples(rng):
+    x = np.concatenate([rng.uniform(-1, 1, 400000), np.linspace(-1, 1, 20001), np.array([0.5, -0.5, 0.975, -0.975, 1.0, -1.0, 0.0, -0.0]),
+                        np.nextafter(np.array([0.5, -0.5, 0.975, 1.0, -1.0]), 0.0), rng.uniform(-1e-6, 1e-6, 1000),
+                        1.0 - np.geomspace(1e-16, 1e-2, 2000), -1.0 + np.geomspace(1e-16, 1e-2, 2000)])
+    return x
+
+
+def test_asin_acos_within_one_ulp_of_glibc():
+    x = _samples(np.random.default_rng(1))
+    got = ob.detmath_eval(ob.DETMATH_ASIN, x)
+    assert _ulp_diff(got, np.arcsin(x)).max() <= 1
+    got = ob.detmath_eval(ob.DETMATH_ACOS, x)
+    assert _ulp_diff(got, np.arccos(x)).max() <= 1
+    assert np.isnan(ob.detmath_eval(ob.DETMATH_ASIN, np.array([1.0000001, -2.0, np.nan]))).all()
+
+
+def test_atan2_within_two_ulp_of_glibc():
+    rng = np.random.default_rng(2)
+    y = np.concatenate([rng.normal(size=400000), rng.normal(size=20000) * 1e-9, np.zeros(8), rng.normal(size=20000)])
+    x = np.concatenate([rng.normal(size=400000), rng.normal(size=20000), np.array([1, -1, 0, -0.0, 2, -2, 1e300, -1e300]),
+                        rng.normal(size=20000) * 1e-9])
+    got = ob.detmath_eval(ob.DETMATH_ATAN2, y, x)
+    want = np.arctan2(y, x)
+    d = _ulp_diff(got, want)
+    # y / x is rounded before the arctangent: worst case ~1.5 ulp from the true value, i.e. up to 2 ulp from glibc's result
+    assert d.max() <= 2 and (d > 1).mean() < 1e-4 and (d == 0).mean() > 0.8
+    # the +-180 degree seam of the equirectangular projection: x < 0, y = +-tiny / +-0
+    ys = np.array([0.0, -0.0, 1e-300, -1e-300, 1e-17, -1e-17])
+    xs = -np.ones(6)
+    got = ob.detmath_eval(ob.DETMATH_ATAN2, ys, xs)
+    assert np.array_equal(got, np.arctan2(ys, xs)) and got[0] == np.pi and got[1] == -np.pi
+    # special values
+    inf = np.inf
+    ys = np.array([inf, -inf, inf, -inf, 1.0, -1.0, 1.0, inf, 0.0, 3.0])
+    xs = np.array([inf, inf, -inf, -inf, inf, inf, -inf, 1.0, 5.0, 0.0])
+    assert np.array_equal(ob.detmath_eval(ob.DETMATH_ATAN2, ys, xs), np.arctan2(ys, xs))
+
+
+def test_logf_equals_glibc_exhaustively():
+    """landmark::predict_scale_level calls std::log(float) = glibc logf; ovs_det_logf restates glibc's algorithm (table + cubic in double).
+    Every positive finite float (2^31 - 2^23 - 1 bit patterns) against this machine's libm: zero mismatches => the rule is pinned."""
+    import ctypes as C
+    f = ob.lib().ovo_detmath_logf_vs_libm
+    f.restype = C.c_longlong
+    f.argtypes = [C.c_uint32, C.c_uint32]
+    assert f(1, 0x7F7FFFFF) == 0
+    sp = ob.detmath_eval(ob.DETMATH_LOGF, np.array([0.0, -1.0, np.inf, np.nan, 1.0]))
+    assert sp[0] == -np.inf and np.isnan(sp[1]) and sp[2] == np.inf and np.isnan(sp[3]) and sp[4] == 0.0
+
+
+@pytest.mark.gpu
+def test_device_and_host_agree_bit_for_bit():
+    import ctypes as C
+    from openvslam_amd import _lib
+    L = _lib.lib()
+    _lib.require_device()
+    rng = np.random.default_rng(4)
+
+    def dev(fn, a, b=None):
+        a = np.ascontiguousarray(a, np.float64)
+        out = np.zeros_like(a)
+        pb = np.ascontiguousarray(b, np.float64) if b is not None else None
+        _lib.check(L.ovs_detmath_eval(0, fn, a.ctypes.data, pb.ctypes.data if pb is not None else None, out.ctypes.data, a.size),
+                   "ovs_detmath_eval")
+        return out
+
+    x = _samples(rng)
+    for fn in (ob.DETMATH_ASIN, ob.DETMATH_ACOS):
+        assert np.array_equal(dev(fn, x).view(np.uint64), ob.detmath_eval(fn, x).view(np.uint64))
+    y = np.concatenate([rng.normal(size=500000), np.array([0.0, -0.0, 1e-300, -1e-300, 1e-17, -1e-17])])
+    xx = np.concatenate([rng.normal(size=500000), -np.ones(6)])
+    assert np.array_equal(dev(ob.DETMATH_ATAN2, y, xx).view(np.uint64), ob.detmath_eval(ob.DETMATH_ATAN2, y, xx).view(np.uint64))
+    # logf: every float in three binades around 1 (2^23 mantissas x 3 exponents would be 25M; take every 7th) + wide range + 1.2^k +- 2 ulp
+    m = (np.arange(0, 3 << 23, 7, dtype=np.uint32) + np.uint32(0x3F000000)).view(np.float32)
+    k = (np.float64(1.2) ** np.arange(-40, 41)).astype(np.float32)
+    k = np.concatenate([k, np.nextafter(k, np.float32(0)), np.nextafter(k, np.float32(1e30)),
+                        np.nextafter(np.nextafter(k, np.float32(0)), np.float32(0)), np.nextafter(np.nextafter(k, np.float32(1e30)), np.float32(1e30))])
+    xs = np.concatenate([m, np.exp(rng.uniform(-80, 80, 500000)).astype(np.float32), k]).astype(np.float64)
+    assert np.array_equal(dev(ob.DETMATH_LOGF, xs).view(np.uint64), ob.detmath_eval(ob.DETMATH_LOGF, xs).view(np.uint64))

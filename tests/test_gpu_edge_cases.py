@@ -126,3 +126,27 @@ def test_vocab_argument_errors():
                   weight=np.array([2.0]), word_id=np.array([0], np.int32), depth=0)
     w, wt, nd = bow.vocabulary(single).transform_features(np.ones((3, 32), np.uint8))     # a vocabulary that is one leaf
     assert (w == 0).all() and (wt == 2.0).all() and (nd == 0).all()
+
+
+def test_refused_geometry_leaves_the_handle_usable(oracle):
+    """a size build_geometry refuses (60 x 1920: more than 64 quad-tree root patches) must not clobber the handle's
+    geometry -- the next extract at the previous, valid size still matches the oracle bit for bit."""
+    from openvslam_amd import _lib, feature
+    from openvslam_amd.synth import synth_frame
+    img = synth_frame(480, 752, seed=3)
+    ex = feature.orb_extractor(feature.orb_params(max_num_keypts=1000), max_rows=480, max_cols=1920)
+    k0, d0 = ex.extract(img)
+    with pytest.raises(_lib.OvsError) as e:
+        ex.extract(synth_frame(60, 1920, seed=4))
+    assert e.value.status == -1
+    k1, d1 = ex.extract(img)
+    wk, wd = oracle.OrbExtractor(oracle.make_params(1000)).extract(img)
+    assert np.array_equal(k1.view(np.uint8), wk.view(np.uint8)) and np.array_equal(d1, wd)
+    assert np.array_equal(k0.view(np.uint8), k1.view(np.uint8)) and np.array_equal(d0, d1)
+    # a second valid size afterwards, then back
+    img2 = synth_frame(203, 331, seed=5)
+    k2, d2 = ex.extract(img2)
+    wk2, wd2 = oracle.OrbExtractor(oracle.make_params(1000)).extract(img2)
+    assert np.array_equal(k2.view(np.uint8), wk2.view(np.uint8)) and np.array_equal(d2, wd2)
+    k3, d3 = ex.extract(img)
+    assert np.array_equal(k3.view(np.uint8), wk.view(np.uint8)) and np.array_equal(d3, wd)

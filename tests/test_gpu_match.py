@@ -38,8 +38,13 @@ def test_brute_force_match(match, oracle, n1, n2, n_true, ratio):
         want = oracle.robust_brute_force_match(d1, d2, v, ratio)
         got = m.brute_force_match(d1, d2, v)
         assert np.array_equal(got, want)
+    # optional frame-side mask: a third of the frame keypoints (true matches among them) must never be matched or block the ratio test
+    v1 = (rng.random(n1) < 0.67).astype(np.uint8)
+    want1 = oracle.robust_brute_force_match(d1, d2, valid, ratio, frm_valid=v1)
+    got1 = m.brute_force_match(d1, d2, valid, frm_valid=v1)
+    assert np.array_equal(got1, want1) and (len(want1) == 0 or v1[want1[:, 0]].all())
     if n_true >= 1000:
-        assert len(want) > n_true // 3
+        assert len(want) > n_true // 3 and 0 < len(want1) < len(want)
 
 
 def test_claim_conflicts(match, oracle):
@@ -56,6 +61,8 @@ def test_claim_conflicts(match, oracle):
     for ratio in (0.6, 0.9, 1.0):
         m = match.robust(ratio, False, max_n1=256, max_n2=256)
         assert np.array_equal(m.brute_force_match(d1, d2), oracle.robust_brute_force_match(d1, d2, None, ratio))
+        v1 = (np.arange(len(d1)) % 3 != 0).astype(np.uint8)   # the first of every triplet is masked: claimants fall through to the next
+        assert np.array_equal(m.brute_force_match(d1, d2, frm_valid=v1), oracle.robust_brute_force_match(d1, d2, None, ratio, frm_valid=v1))
 
 
 def test_overflowing_near_lists_fall_back_exactly(match, oracle):
@@ -67,6 +74,8 @@ def test_overflowing_near_lists_fall_back_exactly(match, oracle):
     for ratio in (0.6, 0.9):
         m = match.robust(ratio, False, max_n1=128, max_n2=128)
         assert np.array_equal(m.brute_force_match(d1, d2), oracle.robust_brute_force_match(d1, d2, None, ratio))
+        v1 = (np.arange(len(d1)) % 3 != 0).astype(np.uint8)   # the first of every triplet is masked: claimants fall through to the next
+        assert np.array_equal(m.brute_force_match(d1, d2, frm_valid=v1), oracle.robust_brute_force_match(d1, d2, None, ratio, frm_valid=v1))
     # ratio 1.01: duplicates are accepted one by one until the frame side runs out
     m = match.robust(1.01, False, max_n1=128, max_n2=128)
     got = m.brute_force_match(d1, d2)

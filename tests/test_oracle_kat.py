@@ -263,5 +263,7 @@ def test_brute_force_rules(oracle):
     assert oracle.robust_brute_force_match(frm, kf, None, 1.01).tolist() == [[0, 0], [1, 1]]
     # keyframe keypoints without a live landmark are skipped
     assert oracle.robust_brute_force_match(frm, kf, np.array([0, 1, 1], np.uint8), 1.01).tolist() == [[0, 1], [1, 2]]
+    # frame-side mask: frame keypoint 0 is skipped like an already matched one
+    assert oracle.robust_brute_force_match(frm, kf, None, 1.01, frm_valid=np.array([0, 1, 1], np.uint8)).tolist() == [[1, 0]]
     # a distance of 256 never becomes best (strict '<' against MAX_HAMMING_DIST)
     assert len(oracle.robust_brute_force_match(~z, z, None, 0.9)) == 0
