@@ -90,6 +90,28 @@ int32_t ovs_orb_max_keypoints(const ovs_orb* h);
 ovs_status ovs_orb_extract(ovs_orb* h, const uint8_t* image, int32_t rows, int32_t cols, size_t stride, const uint8_t* mask,
                            size_t mask_stride, ovs_keypoint* kps, uint8_t* desc, int32_t cap, int32_t* n_out);
 
+/* Asynchronous pair behind ovs_orb_extract (which is submit + collect): the handle owns TWO slots of pinned staging memory, uploads on
+ * its own copy stream and runs kernels + the single result D2H on its compute stream, so the upload of frame k+1 overlaps the kernels
+ * of frame k ("copies overlapped on a second stream, double-buffered pinned host memory"). At most two frames may be in
+ * flight; collect returns them in submission order and is the only point that waits (one event per frame). The image / mask buffers may
+ * be reused as soon as submit returns. */
+ovs_status ovs_orb_extract_submit(ovs_orb* h, const uint8_t* image, int32_t rows, int32_t cols, size_t stride, const uint8_t* mask,
+                                  size_t mask_stride);
+ovs_status ovs_orb_extract_collect(ovs_orb* h, ovs_keypoint* kps, uint8_t* desc, int32_t cap, int32_t* n_out);
+/* Upload strategy of the host path: 1 (default) = row bands copied through the slot's pinned buffer, each band's DMA overlapping the
+ * CPU copy of the next; 0 = hipMemcpy2DAsync straight from the caller's pageable rows. Same results; measured in bench.py. */
+ovs_status ovs_orb_set_host_mode(ovs_orb* h, int32_t mode);
+/* h2d | kernels | d2h milliseconds of the last collected frame (HIP events; valid after ovs_orb_profile_enable(h, 1)). */
+ovs_status ovs_orb_host_profile_read(const ovs_orb* h, float* h2d_kernels_d2h_ms);
+
+/* replaces: the public member orb_extractor::image_pyramid_ on the host path WITHOUT a copy per level: with enable != 0 every submitted
+ * frame also brings its pyramid block (levels 1 .. L-1, one D2H) into pinned memory owned by the handle; ovs_orb_host_pyramid_level
+ * returns a pointer into that block for the last COLLECTED frame (valid until the slot is reused two submits later), with its pitch.
+ * Level 0 reports base = NULL: it is the caller's own image (upstream aliases it as well). Default: disabled -- a monocular tracker
+ * never reads image_pyramid_, and match::stereo reads the device copy (ovs_stereo_compute). */
+ovs_status ovs_orb_set_host_pyramid(ovs_orb* h, int32_t enable);
+ovs_status ovs_orb_host_pyramid_level(const ovs_orb* h, int32_t level, const uint8_t** base, int32_t* rows, int32_t* cols, int32_t* pitch);
+
 /* Device-resident batched form of the same computation: `batch` frames of rows x cols u8 already in HBM, frame b at
  * d_images + b*frame_stride, row stride `stride` (both multiples of 4, base 4-byte aligned). d_masks: NULL or same layout.
  * Outputs stay in HBM: d_kps[b*cap + i], d_desc[(b*cap + i)*32], d_counts[b] (counts are clamped to cap).
@@ -106,7 +128,7 @@ ovs_status ovs_orb_set_pipeline(ovs_orb* h, int32_t n_sub);
 
 /* replaces: the public member orb_extractor::image_pyramid_ (read by match::stereo). Copies level `level` of frame
  * `frame` (0 for the host API) of the LAST extract into host_dst (rows*cols bytes, contiguous) and reports its size.
- * host_dst may be NULL to query the size only. Synchronises the handle's stream. */
+ * host_dst may be NULL to query the size only. Waits for the stream the last extract ran on (not for the device). */
 ovs_status ovs_orb_pyramid_level(ovs_orb* h, int32_t frame, int32_t level, uint8_t* host_dst, int32_t* rows, int32_t* cols);
 
 /* Test / profiling observables of the LAST extract (synchronise the handle's stream):
@@ -463,7 +485,8 @@ ovs_status ovs_bow_transform_dev(ovs_vocab* v, const uint8_t* d_desc, const int3
 
 /* replaces: the optimisation inside  void optimize::local_bundle_adjuster::optimize(data::keyframe* curr_keyfrm, bool* const
  *               force_stop_flag) const  (src/openvslam/optimize/local_bundle_adjuster.{h,cc}): everything between the graph build and the
- * write-back, i.e. optimizer.optimize(num_first_iter) with Huber kernels (sqrt(5.991) mono, sqrt(7.815) stereo), the chi-square /
+ * write-back, i.e. optimizer.optimize(num_first_iter) with Huber kernels (ONE delta per rig: setup_type 0 = Monocular -> sqrtf(5.99146f),
+ * otherwise sqrtf(7.81473f), as upstream picks it from keyfrm->camera_->setup_type_), the chi-square (5.99146f mono / 7.81473f stereo edge) /
  * depth-positive outlier test that moves edges to level 1 and drops the kernels, optimizer.optimize(num_second_iter), and the final
  * outlier test. g2o's Levenberg-Marquardt schedule and BlockSolver_6_3's landmark elimination are restated (oracle/ORACLE_SPEC.md
  * rules 25, 28); linearisations run on the device (ba_linearize kernels), the reduced camera system is solved on the host.
@@ -472,13 +495,13 @@ ovs_status ovs_bow_transform_dev(ovs_vocab* v, const uint8_t* d_desc, const int3
  * caller must erase. info: NULL or 6 doubles {robust chi2 before / after round 1, chi2 before / after round 2, iterations 1, 2}. */
 ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* pose_fixed, int32_t n_pose, double* points, int32_t n_pt,
                                  const ovs_ba_edge* mono, int32_t n_mono, const ovs_ba_edge_stereo* stereo, int32_t n_stereo,
-                                 const ovs_ba_cam* cam, double focal_x_baseline, int32_t num_first_iter, int32_t num_second_iter,
+                                 const ovs_ba_cam* cam, double focal_x_baseline, int32_t setup_type, int32_t num_first_iter, int32_t num_second_iter,
                                  const volatile uint8_t* force_stop_flag, uint8_t* mono_outlier, uint8_t* stereo_outlier, double* info);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Pose-only optimisation of one frame.  replaces: unsigned int optimize::pose_optimizer::optimize(data::frame& frm) const
  * (src/openvslam/optimize/pose_optimizer.{h,cc}; perspective mono / stereo pose_opt edges): 4 rounds x 10 Levenberg-Marquardt
- * iterations with Huber kernels in the first three rounds and chi2 outlier re-classification (5.991 / 7.815) after every round, in ONE
+ * iterations with Huber kernels in the first three rounds and chi2 outlier re-classification (5.99146f / 7.81473f) after every round, in ONE
  * kernel launch. The shim flattens the frame's landmarks into ovs_pose_obs records, writes pose_cw_out back with
  * frm.set_cam_pose(...), outlier_flags into frm.outlier_flags_ and returns *num_valid.
  * ------------------------------------------------------------------------------------------------------------------ */
@@ -490,8 +513,8 @@ typedef struct ovs_pose_obs {   /* one observed landmark: pose_opt_edge_wrapper 
 } ovs_pose_obs;
 /* pose_cw_*: 12 doubles (rotation row-major, translation), world -> camera. n_obs <= 8192 (OVS_ERR_CAPACITY above; the _dev form
  * reports a frame with more observations as d_num_valid = -1). setup_type = frm.camera_->setup_type_ (0 Monocular, 1 Stereo, 2 RGBD):
- * upstream picks ONE Huber delta per frame from it (Monocular: sqrt(5.991), otherwise sqrt(7.815)); the chi-square outlier gates
- * (5.991 / 7.815) stay per observation (is_stereo). */
+ * upstream picks ONE Huber delta per frame from it (Monocular: sqrtf(5.99146f), otherwise sqrtf(7.81473f)); the chi-square outlier
+ * gates (5.99146f / 7.81473f) stay per observation (is_stereo). */
 ovs_status ovs_pose_optimize(int32_t device, const double* pose_cw_in, const ovs_pose_obs* obs, int32_t n_obs, const ovs_ba_cam* cam,
                              double focal_x_baseline, int32_t setup_type, double* pose_cw_out, uint8_t* outlier_flags, int32_t* num_valid);
 /* Device-resident batch: frame p owns observations [d_obs_offsets[p], d_obs_offsets[p + 1]); one workgroup per frame. */

@@ -39,6 +39,12 @@ SYMBOLS = {
     "ovs_orb_tables": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_orb_max_keypoints": (_i32, [_vp]),
     "ovs_orb_extract": (_i32, [_vp, _vp, _i32, _i32, _sz, _vp, _sz, _vp, _vp, _i32, C.POINTER(_i32)]),
+    "ovs_orb_extract_submit": (_i32, [_vp, _vp, _i32, _i32, _sz, _vp, _sz]),
+    "ovs_orb_extract_collect": (_i32, [_vp, _vp, _vp, _i32, C.POINTER(_i32)]),
+    "ovs_orb_set_host_mode": (_i32, [_vp, _i32]),
+    "ovs_orb_host_profile_read": (_i32, [_vp, _vp]),
+    "ovs_orb_set_host_pyramid": (_i32, [_vp, _i32]),
+    "ovs_orb_host_pyramid_level": (_i32, [_vp, _i32, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "ovs_orb_extract_batch_dev": (_i32, [_vp, _vp, _i32, _i32, _i32, _sz, _sz, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ovs_orb_set_pipeline": (_i32, [_vp, _i32]),
     "ovs_orb_pyramid_level": (_i32, [_vp, _i32, _i32, _vp, C.POINTER(_i32), C.POINTER(_i32)]),
@@ -60,7 +66,7 @@ SYMBOLS = {
     "ovs_vocab_destroy": (_i32, [_vp]),
     "ovs_bow_transform": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "ovs_bow_transform_dev": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
-    "ovs_local_ba_optimize": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ovs_local_ba_optimize": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_stereo": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_stereo_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp,
                                            _vp, _vp]),

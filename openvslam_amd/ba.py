@@ -110,7 +110,7 @@ def pose_optimize(pose_cw, obs, cam, focal_x_baseline=0.0, device=0, setup_type=
 
 
 def local_ba_optimize(poses, pose_fixed, points, edges, cam, stereo_edges=None, focal_x_baseline=0.0, num_first_iter=5, num_second_iter=10,
-                      force_stop_flag=None, device=0):
+                      force_stop_flag=None, device=0, setup_type=None):
     """optimize::local_bundle_adjuster::optimize behind the graph build (ovs_local_ba_optimize): returns dict(poses, points,
     mono_outlier, stereo_outlier, info). force_stop_flag: a 1-element uint8 array another thread may set."""
     L = _lib.lib()
@@ -122,8 +122,10 @@ def local_ba_optimize(poses, pose_fixed, points, edges, cam, stereo_edges=None, 
     om, os_ = np.zeros(max(len(em), 1), np.uint8), np.zeros(max(len(es), 1), np.uint8)
     info = np.zeros(6)
     c = BaCam(*cam)
+    if setup_type is None:   # camera::setup_type_t of the rig (selects the Huber delta): Stereo iff there is a baseline
+        setup_type = 1 if focal_x_baseline != 0.0 else 0
     _lib.check(L.ovs_local_ba_optimize(device, _p(P), _p(fixed), len(P), _p(X), len(X), _p(em) if len(em) else None, len(em),
-                                       _p(es) if len(es) else None, len(es), C.byref(c), float(focal_x_baseline), int(num_first_iter),
+                                       _p(es) if len(es) else None, len(es), C.byref(c), float(focal_x_baseline), int(setup_type), int(num_first_iter),
                                        int(num_second_iter), _p(force_stop_flag), _p(om), _p(os_), _p(info)), "ovs_local_ba_optimize")
     return dict(poses=P, points=X, mono_outlier=om[:len(em)].astype(bool), stereo_outlier=os_[:len(es)].astype(bool), info=info)
 

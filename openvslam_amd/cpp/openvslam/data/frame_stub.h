@@ -3,6 +3,8 @@
 // headers are used instead and the shim bodies compile unchanged.
 #pragma once
 #include <map>
+#include <mutex>
+#include <set>
 #include <vector>
 
 #include "../../cv_stub.h"
@@ -52,11 +54,25 @@ namespace data {
 
 class keyframe;
 
+// data::map_database: only the lock local_bundle_adjuster takes around its write-back
+class map_database {
+public:
+    static inline std::mutex mtx_database_;
+};
+
 using bow_feature_vector = std::map<unsigned int, std::vector<unsigned int>>;   // DBoW2::FeatureVector
 
 class landmark {
 public:
+    unsigned int id_ = 0;
     bool will_be_erased() const { return will_be_erased_; }
+    std::map<keyframe*, unsigned int> get_observations() const { return observations_; }
+    void set_pos_in_world(const Vec3_t& pos_w) { pos_w_ = pos_w; }
+    void update_normal_and_depth() { ++num_normal_updates_; }   // upstream recomputes mean_normal_ / valid distances from the observations
+    void erase_observation(keyframe* keyfrm) {
+        if (observations_.erase(keyfrm)) --num_observations_;
+    }
+    unsigned int num_normal_updates_ = 0;
     bool has_observation() const { return num_observations_ > 0; }
     cv::Mat get_descriptor() const { return descriptor_; }
     Vec3_t get_pos_in_world() const { return pos_w_; }
@@ -94,6 +110,7 @@ public:
     std::vector<cv::KeyPoint> keypts_;
     std::vector<cv::KeyPoint> undist_keypts_;
     std::vector<float> stereo_x_right_;
+    std::vector<Vec3_t> bearings_;
     cv::Mat descriptors_;
     std::vector<landmark*> landmarks_;
     std::vector<bool> outlier_flags_;
@@ -106,8 +123,26 @@ public:
     void set_cam_pose(const Mat44_t& cam_pose_cw) { cam_pose_cw_ = cam_pose_cw; }
 };
 
+class keyframe;
+// data::graph_node: only the covisibility list local_bundle_adjuster walks
+class graph_node {
+public:
+    std::vector<keyframe*> get_covisibilities() const { return covisibilities_; }
+    std::vector<keyframe*> covisibilities_;
+};
+
 class keyframe {
 public:
+    unsigned int id_ = 0;
+    bool will_be_erased() const { return will_be_erased_; }
+    bool will_be_erased_ = false;
+    graph_node graph_node_storage_;
+    graph_node* graph_node_ = &graph_node_storage_;
+    void set_cam_pose(const Mat44_t& cam_pose_cw) { cam_pose_cw_ = cam_pose_cw; }
+    void erase_landmark(landmark* lm) {
+        const int idx = lm->get_index_in_keyframe(this);
+        if (0 <= idx) landmarks_.at((size_t)idx) = nullptr;
+    }
     unsigned int num_keypts_ = 0;
     std::vector<cv::KeyPoint> keypts_;
     std::vector<cv::KeyPoint> undist_keypts_;

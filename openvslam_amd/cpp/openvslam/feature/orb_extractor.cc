@@ -3,9 +3,12 @@
 
 #include <ovslam_hip.h>
 
+#include <algorithm>
 #include <cassert>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 
 namespace openvslam {
 namespace feature {
@@ -16,13 +19,19 @@ namespace {
 }
 }   // namespace
 
-orb_extractor::orb_extractor(const orb_params& orb_params) : orb_params_(orb_params) { initialize(); }
+orb_extractor::orb_extractor(const orb_params& orb_params) : orb_params_(orb_params) {
+    initialize();
+    register_self();
+}
 
 orb_extractor::orb_extractor(const unsigned int max_num_keypts, const float scale_factor, const unsigned int num_levels,
                              const unsigned int ini_fast_thr, const unsigned int min_fast_thr, const std::vector<std::vector<float>>& mask_rects)
     : orb_extractor(orb_params(max_num_keypts, scale_factor, num_levels, ini_fast_thr, min_fast_thr, mask_rects)) {}
 
-orb_extractor::~orb_extractor() { release(); }
+orb_extractor::~orb_extractor() {
+    unregister_self();
+    release();
+}
 
 void orb_extractor::release() {
     if (h_) ovs_orb_destroy(h_);
@@ -62,8 +71,9 @@ void orb_extractor::ensure_handle(int rows, int cols) {
     p.num_levels = (int32_t)orb_params_.num_levels_;
     p.ini_fast_thr = (int32_t)orb_params_.ini_fast_thr_;
     p.min_fast_thr = (int32_t)orb_params_.min_fast_thr;
-    const int st = ovs_orb_create(&p, rows, cols, 1, 0, &h_);
+    const int st = ovs_orb_create(&p, rows, cols, 1, device_, &h_);
     if (st != OVS_OK) fail("ovs_orb_create", st);
+    ovs_orb_set_host_pyramid(h_, download_pyramid_ ? 1 : 0);
     h_rows_ = rows;
     h_cols_ = cols;
 }
@@ -72,7 +82,7 @@ void orb_extractor::create_rectangle_mask(const unsigned int cols, const unsigne
     if (!rect_mask_.empty() && rect_mask_.rows == (int)rows && rect_mask_.cols == (int)cols) return;
     rect_mask_ = cv::Mat();
     rect_mask_.create(rows, cols, cv::CV_8UC1);
-    std::fill(rect_mask_.storage.begin(), rect_mask_.storage.end(), (uint8_t)255);
+    for (unsigned y = 0; y < rows; ++y) std::fill(rect_mask_.ptr(y), rect_mask_.ptr(y) + cols, (uint8_t)255);
     for (const auto& r : orb_params_.mask_rects_) {
         // upstream: rect_mask_.rowRange(rows*y_min, rows*y_max).colRange(cols*x_min, cols*x_max) = 0
         const unsigned x0 = cols * r.at(0), x1 = cols * r.at(1), y0 = rows * r.at(2), y1 = rows * r.at(3);
@@ -82,38 +92,73 @@ void orb_extractor::create_rectangle_mask(const unsigned int cols, const unsigne
 }
 
 void orb_extractor::extract(const cv::_InputArray& in_image, const cv::_InputArray& in_image_mask, std::vector<cv::KeyPoint>& keypts,
-                            cv::_OutputArray& out_descriptors) {
+                            const cv::_OutputArray& out_descriptors) {
     if (in_image.empty()) return;   // upstream: early return
-    const cv::Mat& image = in_image;
+    const cv::Mat image = in_image.getMat();
     assert(image.type() == cv::CV_8UC1);
-    const cv::Mat* mask = nullptr;
+    cv::Mat mask;
     if (!in_image_mask.empty()) {
-        mask = &in_image_mask;
+        mask = in_image_mask.getMat();
     } else if (!orb_params_.mask_rects_.empty()) {
         create_rectangle_mask(image.cols, image.rows);
-        mask = &rect_mask_;
+        mask = rect_mask_;
     }
     ensure_handle(image.rows, image.cols);
     const int cap = ovs_orb_max_keypoints(h_);
     keypts.resize(cap);
-    std::vector<uint8_t> desc((size_t)cap * 32);
+    desc_buf_.resize((size_t)cap * 32);
     int n = 0;
-    const int st = ovs_orb_extract(h_, image.data, image.rows, image.cols, image.step, mask ? mask->data : nullptr, mask ? mask->step : 0,
-                                   reinterpret_cast<ovs_keypoint*>(keypts.data()), desc.data(), cap, &n);
+    // ONE call, ONE wait: upload (banded through pinned memory), pyramid -> FAST -> quad-tree -> describe, one D2H of the results and
+    // -- when image_pyramid_ is wanted on the host -- one D2H of the whole pyramid block into pinned memory the Mats below alias
+    const int st = ovs_orb_extract(h_, image.data, image.rows, image.cols, image.step, mask.empty() ? nullptr : mask.data,
+                                   mask.empty() ? 0 : mask.step, reinterpret_cast<ovs_keypoint*>(keypts.data()), desc_buf_.data(), cap, &n);
     if (st != OVS_OK) fail("ovs_orb_extract", st);   // no silent CPU fallback
     keypts.resize(n);
-    out_descriptors = cv::Mat();
     out_descriptors.create(n, 32, cv::CV_8U);
-    if (n) std::copy(desc.begin(), desc.begin() + (size_t)n * 32, out_descriptors.data);
-    for (unsigned int l = 0; l < orb_params_.num_levels_; ++l) {
-        int r = 0, c = 0;
-        int s2 = ovs_orb_pyramid_level(h_, 0, l, nullptr, &r, &c);
-        if (s2 != OVS_OK) fail("ovs_orb_pyramid_level", s2);
-        image_pyramid_[l] = cv::Mat();
-        image_pyramid_[l].create(r, c, cv::CV_8U);
-        s2 = ovs_orb_pyramid_level(h_, 0, l, image_pyramid_[l].data, &r, &c);
-        if (s2 != OVS_OK) fail("ovs_orb_pyramid_level", s2);
+    if (n) {
+        cv::Mat descriptors = out_descriptors.getMat();
+        for (int i = 0; i < n; ++i) std::copy(desc_buf_.begin() + (size_t)i * 32, desc_buf_.begin() + (size_t)(i + 1) * 32, descriptors.ptr(i));
     }
+    // image_pyramid_: level 0 aliases the caller's image (as upstream: `image_pyramid_.at(0) = image`), levels >= 1 alias the handle's
+    // pinned copy of the device pyramid (no per-level copies); with the download disabled the vector holds empty Mats above level 0
+    image_pyramid_[0] = image;
+    for (unsigned int l = 1; l < orb_params_.num_levels_; ++l) {
+        if (!download_pyramid_) {
+            image_pyramid_[l] = cv::Mat();
+            continue;
+        }
+        const uint8_t* base = nullptr;
+        int r = 0, c = 0, pitch = 0;
+        const int s2 = ovs_orb_host_pyramid_level(h_, (int)l, &base, &r, &c, &pitch);
+        if (s2 != OVS_OK) fail("ovs_orb_host_pyramid_level", s2);
+        image_pyramid_[l] = cv::Mat(r, c, cv::CV_8U, const_cast<uint8_t*>(base), (size_t)pitch);
+    }
+}
+
+void orb_extractor::set_image_pyramid_download(const bool enable) {
+    download_pyramid_ = enable;
+    if (h_) ovs_orb_set_host_pyramid(h_, enable ? 1 : 0);
+}
+
+// ---- registry: &extractor->image_pyramid_ -> device context. match::stereo keeps upstream's ctor (it receives the two extractors'
+// image_pyramid_ members by reference) and finds the pyramids where they lie, in HBM, through this table.
+namespace {
+std::mutex g_registry_mtx;
+std::unordered_map<const std::vector<cv::Mat>*, const orb_extractor*> g_registry;
+}   // namespace
+
+void orb_extractor::register_self() {
+    std::lock_guard<std::mutex> lock(g_registry_mtx);
+    g_registry[&image_pyramid_] = this;
+}
+void orb_extractor::unregister_self() {
+    std::lock_guard<std::mutex> lock(g_registry_mtx);
+    g_registry.erase(&image_pyramid_);
+}
+const ovs_orb* orb_extractor::device_context_of(const std::vector<cv::Mat>& image_pyramid) {
+    std::lock_guard<std::mutex> lock(g_registry_mtx);
+    const auto it = g_registry.find(&image_pyramid);
+    return it == g_registry.end() ? nullptr : it->second->h_;
 }
 
 }   // namespace feature

@@ -23,7 +23,7 @@ public:
 
     //! Extract keypoints and each descriptor of them
     void extract(const cv::_InputArray& in_image, const cv::_InputArray& in_image_mask, std::vector<cv::KeyPoint>& keypts,
-                 cv::_OutputArray& out_descriptors);
+                 const cv::_OutputArray& out_descriptors);
 
     unsigned int get_max_num_keypoints() const { return orb_params_.max_num_keypts_; }
     void set_max_num_keypoints(const unsigned int max_num_keypts);
@@ -44,20 +44,36 @@ public:
     //! Image pyramid (public upstream: match::stereo reads it)
     std::vector<cv::Mat> image_pyramid_;
 
+    // ---- additions of the MI355X backend (no upstream counterpart; defaults keep upstream's behaviour) ----
     //! the device context (match::stereo reads this extractor's pyramid where it lies, in HBM)
     const ovs_orb* handle() const { return h_; }
+    //! the device context behind an image_pyramid_ member (nullptr if `image_pyramid` is not one): lets match::stereo keep
+    //! upstream's constructor, which receives the two extractors' image_pyramid_ by reference
+    static const ovs_orb* device_context_of(const std::vector<cv::Mat>& image_pyramid);
+    //! false: image_pyramid_ levels >= 1 stay on the device (monocular tracking never reads them; saves a 4.3 MB D2H per 1080p frame)
+    void set_image_pyramid_download(const bool enable);
+    //! HIP device this extractor runs on (before the first extract). Stereo rigs may put left / right on two GPUs.
+    void set_device(const int device) {
+        if (device != device_) release();
+        device_ = device;
+    }
 
 private:
     void initialize();
     void release();
     void ensure_handle(int rows, int cols);
     void create_rectangle_mask(const unsigned int cols, const unsigned int rows);
+    void register_self();
+    void unregister_self();
 
     orb_params orb_params_;
     std::vector<float> scale_factors_, inv_scale_factors_, level_sigma_sq_, inv_level_sigma_sq_;
     cv::Mat rect_mask_;
     ovs_orb* h_ = nullptr;
     int h_rows_ = 0, h_cols_ = 0;
+    int device_ = 0;
+    bool download_pyramid_ = true;
+    std::vector<uint8_t> desc_buf_;
 };
 
 }   // namespace feature

@@ -1,0 +1,55 @@
+// match::angle_checker<T> (expected: src/openvslam/match/angle_checker.h), host side: the 30-bin rotation histogram that keeps the
+// three fullest bins. The windowed matchers evaluate it inside their device resolver; robust::brute_force_match applies it on the
+// host AFTER the device match, which is exact because upstream, too, only removes matches at the very end.
+// Rule (oracle/ORACLE_SPEC.md 17): delta wrapped into [0, 360), bin = cvRound(delta * (1 / 30)) (bins are 30 degrees wide: upstream's
+// inherited quirk), bin 30 -> 0; the three fullest bins stay, ties resolved towards the lower bin index.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <vector>
+
+namespace openvslam {
+namespace match {
+
+template <typename T>
+class angle_checker {
+public:
+    explicit angle_checker(const unsigned int histogram_length = 30, const unsigned int num_bins_thr = 3)
+        : histogram_length_(histogram_length), inv_histogram_length_(1.0f / histogram_length), num_bins_thr_(num_bins_thr),
+          angle_histogram_(histogram_length) {}
+
+    void append_delta_angle(float delta_angle, const T& match) {
+        if (delta_angle < 0.0f) delta_angle += 360.0f;
+        if (360.0f <= delta_angle) delta_angle -= 360.0f;
+        unsigned int bin = (unsigned int)std::nearbyintf(delta_angle * inv_histogram_length_);   // cvRound: half to even
+        if (bin == histogram_length_) bin = 0;
+        angle_histogram_.at(bin).push_back(match);
+    }
+
+    std::vector<T> get_valid_matches() const { return collect(true); }
+    std::vector<T> get_invalid_matches() const { return collect(false); }
+
+private:
+    std::vector<T> collect(const bool kept) const {
+        std::vector<unsigned int> order(histogram_length_);
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(),
+                         [&](unsigned int a, unsigned int b) { return angle_histogram_[a].size() > angle_histogram_[b].size(); });
+        std::vector<T> out;
+        for (unsigned int bin = 0; bin < histogram_length_; ++bin) {
+            bool is_kept = false;
+            for (unsigned int k = 0; k < num_bins_thr_ && k < histogram_length_; ++k) is_kept |= order[k] == bin;
+            if (is_kept == kept) out.insert(out.end(), angle_histogram_[bin].begin(), angle_histogram_[bin].end());
+        }
+        return out;
+    }
+
+    const unsigned int histogram_length_;
+    const float inv_histogram_length_;
+    const unsigned int num_bins_thr_;
+    std::vector<std::vector<T>> angle_histogram_;
+};
+
+}   // namespace match
+}   // namespace openvslam

@@ -3,6 +3,8 @@
 
 #include <cmath>
 
+#include "../solve/essential_solver.h"
+#include "angle_checker.h"
 #include "window_ctx.h"
 
 #include <ovslam_hip.h>
@@ -52,8 +54,53 @@ unsigned int robust::brute_force_match(data::frame& frm, data::keyframe* keyfrm,
                                                 /*valid_1: upstream's inner loop skips only already matched idx_1*/ nullptr, keyfrm->descriptors_.data, (int)num_keypts_2, valid.data(), lowe_ratio_, pairs.data(),
                                                 (int)num_keypts_2, &n);
     if (st != OVS_OK) throw std::runtime_error(std::string("ovs_robust_brute_force_match failed: ") + ovs_last_error());
+    matches.clear();
+    matches.reserve((size_t)n);
     for (int i = 0; i < n; ++i) matches.emplace_back(std::make_pair(pairs[2 * i], pairs[2 * i + 1]));
-    return (unsigned int)n;
+    unsigned int num_matches = (unsigned int)n;
+    if (check_orientation_) {
+        // upstream fills the histogram while matching and erases the invalid entries at the end: a pure post-filter
+        angle_checker<int> angle_checker;
+        for (const auto& m : matches)
+            angle_checker.append_delta_angle(frm.keypts_.at((size_t)m.first).angle - keyfrm->keypts_.at((size_t)m.second).angle, m.first);
+        for (const auto invalid_idx_1 : angle_checker.get_invalid_matches()) {
+            for (auto itr = matches.begin(); itr != matches.end(); ++itr) {
+                if (itr->first == invalid_idx_1) {
+                    matches.erase(itr);
+                    --num_matches;
+                    break;
+                }
+            }
+        }
+    }
+    return num_matches;
+}
+
+unsigned int robust::match_frame_and_keyframe(data::frame& frm, data::keyframe* keyfrm, std::vector<data::landmark*>& matched_lms_in_frm) {
+    // initialisation
+    const auto num_frm_keypts = frm.num_keypts_;
+    const auto keyfrm_lms = keyfrm->get_landmarks();
+    unsigned int num_inlier_matches = 0;
+    matched_lms_in_frm = std::vector<data::landmark*>(num_frm_keypts, nullptr);
+
+    // brute-force match on the device
+    std::vector<std::pair<int, int>> matches;
+    brute_force_match(frm, keyfrm, matches);
+
+    // eight-point RANSAC on the bearings keeps only the inliers (upstream: solve::essential_solver, 50 iterations, no recompute)
+    solve::essential_solver solver(frm.bearings_, keyfrm->bearings_, matches);
+    solver.find_via_ransac(50, false);
+    if (!solver.solution_is_valid()) return 0;
+    const auto is_inlier_matches = solver.get_inlier_matches();
+
+    for (unsigned int i = 0; i < matches.size(); ++i) {
+        if (!is_inlier_matches.at(i)) continue;
+        const auto frm_idx = matches.at(i).first;
+        const auto keyfrm_idx = matches.at(i).second;
+        matched_lms_in_frm.at((size_t)frm_idx) = keyfrm_lms.at((size_t)keyfrm_idx);
+        ++num_inlier_matches;
+    }
+    return num_inlier_matches;
 }
 
 unsigned int robust::match_for_triangulation(data::keyframe* keyfrm_1, data::keyframe* keyfrm_2, const Mat33_t& E_12,

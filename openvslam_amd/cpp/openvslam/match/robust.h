@@ -15,6 +15,10 @@ public:
     explicit robust(const float lowe_ratio, const bool check_orientation) : base(lowe_ratio, check_orientation) {}
     ~robust() final = default;
 
+    //! brute-force match + upstream's host-side essential-matrix RANSAC (solve::essential_solver); only the inliers are written to
+    //! matched_lms_in_frm (indexed by frame keypoint)
+    unsigned int match_frame_and_keyframe(data::frame& frm, data::keyframe* keyfrm, std::vector<data::landmark*>& matched_lms_in_frm);
+
     unsigned int brute_force_match(data::frame& frm, data::keyframe* keyfrm, std::vector<std::pair<int, int>>& matches) const;
 
     //! keypoints of two keyframes without landmarks, through the common BoW nodes, gated by the epipolar constraint of E_12

@@ -31,8 +31,13 @@ void stereo::compute(std::vector<float>& stereo_x_right, std::vector<float>& dep
     stereo_x_right.assign((size_t)n_left, -1.0f);
     depths.assign((size_t)n_left, -1.0f);
     if (n_left == 0 || n_right == 0) return;
-    const int rows0 = extractor_left_->image_pyramid_.at(0).rows;
-    detail::check(ovs_stereo_compute(g_stereo.get(rows0, n_left > n_right ? n_left : n_right), extractor_left_->handle(), extractor_right_->handle(),
+    const ovs_orb* left = feature::orb_extractor::device_context_of(left_image_pyramid_);
+    const ovs_orb* right = feature::orb_extractor::device_context_of(right_image_pyramid_);
+    if (!left || !right)
+        throw std::runtime_error("match::stereo: the image pyramids must be the image_pyramid_ members of two feature::orb_extractor objects "
+                                 "that have extracted (their pixels are read on the device)");
+    const int rows0 = left_image_pyramid_.at(0).rows;
+    detail::check(ovs_stereo_compute(g_stereo.get(rows0, n_left > n_right ? n_left : n_right), left, right,
                                      reinterpret_cast<const ovs_keypoint*>(keypts_left_.data()), descs_left_.data, n_left,
                                      reinterpret_cast<const ovs_keypoint*>(keypts_right_.data()), descs_right_.data, n_right, focal_x_baseline_,
                                      true_baseline_, stereo_x_right.data(), depths.data(), nullptr),

@@ -116,7 +116,10 @@ int main(int argc, char** argv) {
     cv::Mat desc_a2;
     extractor_a.extract(a, cv::Mat(), kps_a2, desc_a2);
     std::vector<float> stereo_x_right, depths;
-    match::stereo(&extractor_a, &extractor, kps_a2, keyfrm.keypts_, desc_a2, keyfrm.descriptors_, 386.1448f, 0.5372f).compute(stereo_x_right, depths);
+    const std::vector<float> st_sfs = extractor.get_scale_factors(), st_isfs = extractor.get_inv_scale_factors();
+    match::stereo(extractor_a.image_pyramid_, extractor.image_pyramid_, kps_a2, keyfrm.keypts_, desc_a2, keyfrm.descriptors_, st_sfs, st_isfs, 386.1448f,
+                  0.5372f)
+        .compute(stereo_x_right, depths);
     // match_current_and_last_frames: frame a is the last frame, its landmarks sit where frame b (the current frame, identity pose) sees
     // them: the keypoint shifted by the frame offset, back-projected at a depth that varies with the index
     camera::base pcam = cam;

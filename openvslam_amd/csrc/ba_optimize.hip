@@ -208,8 +208,12 @@ struct Blocks {   // one linearisation, host copy in PINNED memory (16 MB per tr
     }
 };
 
+// upstream: constexpr float chi_sq_2D = 5.99146, chi_sq_3D = 7.81473 and their float square roots, widened to double where g2o consumes them
+constexpr double kChi2D = 0x1.7f7414p+2, kChi3D = 0x1.f4248ap+2, kSqrtChi2D = 0x1.394fbcp+1, kSqrtChi3D = 0x1.65d26ap+1;
+
 struct Lba {
     int n_pose = 0, n_pt = 0;
+    int setup_type = 0;   // camera::setup_type_t of the rig: selects the Huber delta of the mono edges
     const uint8_t* fixed = nullptr;
     ovs_ba_cam cam{};
     double bf = 0;
@@ -314,7 +318,9 @@ struct Lba {
         double* dbl = dHll + (size_t)9 * n_pt;
         double* dHpl = dbl + (size_t)3 * n_pt;
         double* dchi = dHpl + 18 * ne;
-        const double d_mono_h = robust ? std::sqrt(5.991) : 0.0, d_stereo_h = robust ? std::sqrt(7.815) : 0.0;
+        // upstream: sqrt_chi_sq = (keyfrm->camera_->setup_type_ == Monocular) ? sqrt_chi_sq_2D : sqrt_chi_sq_3D -- the Huber delta follows the
+        // RIG, not the edge (a mono observation in a stereo rig gets the 3D delta); float constants (ORACLE_SPEC rule 28)
+        const double d_mono_h = robust ? (setup_type == 0 ? kSqrtChi2D : kSqrtChi3D) : 0.0, d_stereo_h = robust ? kSqrtChi3D : 0.0;
         st = ovs_ba_linearize_dev(d_poses, d_fixed, n_pose, d_points, n_pt, d_mono, (int32_t)mono.size(), &cam, d_mono_h, dHpp, dbp, dHll, dbl, dHpl,
                                   dchi, stream);
         if (st != OVS_OK) return st;
@@ -530,7 +536,7 @@ extern "C" {
 
 ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* pose_fixed, int32_t n_pose, double* points, int32_t n_pt,
                                  const ovs_ba_edge* mono, int32_t n_mono, const ovs_ba_edge_stereo* stereo, int32_t n_stereo,
-                                 const ovs_ba_cam* cam, double focal_x_baseline, int32_t num_first_iter, int32_t num_second_iter,
+                                 const ovs_ba_cam* cam, double focal_x_baseline, int32_t setup_type, int32_t num_first_iter, int32_t num_second_iter,
                                  const volatile uint8_t* force_stop_flag, uint8_t* mono_outlier, uint8_t* stereo_outlier, double* info) {
     if (!poses || !points || !cam || n_pose < 1 || n_pt < 1 || n_mono < 0 || n_stereo < 0 || (n_mono > 0 && (!mono || !mono_outlier)) ||
         (n_stereo > 0 && (!stereo || !stereo_outlier)) || num_first_iter < 0 || num_second_iter < 0)
@@ -547,6 +553,7 @@ ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* p
     L.fixed = pose_fixed;
     L.cam = *cam;
     L.bf = focal_x_baseline;
+    L.setup_type = setup_type;
     L.cap_mono = (size_t)n_mono;
     L.cap_stereo = (size_t)n_stereo;
     L.slot.assign((size_t)n_pose, -1);
@@ -576,8 +583,8 @@ ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* p
     if (st != OVS_OK) return st;
     std::vector<double> chi_r1 = chi;
     std::vector<uint8_t> out_r1((size_t)n_mono + n_stereo);
-    for (int i = 0; i < n_mono; ++i) out_r1[i] = (5.991 < chi[i]) || !depth[i];
-    for (int i = 0; i < n_stereo; ++i) out_r1[(size_t)n_mono + i] = (7.815 < chi[(size_t)n_mono + i]) || !depth[(size_t)n_mono + i];
+    for (int i = 0; i < n_mono; ++i) out_r1[i] = (kChi2D < chi[i]) || !depth[i];
+    for (int i = 0; i < n_stereo; ++i) out_r1[(size_t)n_mono + i] = (kChi3D < chi[(size_t)n_mono + i]) || !depth[(size_t)n_mono + i];
     const bool stopped = force_stop_flag && *force_stop_flag;
     std::vector<int> map_m, map_s;   // active edge of round 2 -> original index
     if (!stopped) {
@@ -609,12 +616,12 @@ ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* p
     if (st != OVS_OK) return st;
     for (int i = 0; i < n_mono; ++i) {
         const double c = (!stopped && !out_r1[i]) ? chi[i] : chi_r1[i];
-        mono_outlier[i] = (5.991 < c) || !depth[i];
+        mono_outlier[i] = (kChi2D < c) || !depth[i];
     }
     for (int i = 0; i < n_stereo; ++i) {
         const size_t e = (size_t)n_mono + i;
         const double c = (!stopped && !out_r1[e]) ? chi[e] : chi_r1[e];
-        stereo_outlier[i] = (7.815 < c) || !depth[e];
+        stereo_outlier[i] = (kChi3D < c) || !depth[e];
     }
     std::vector<double> p7;
     L.pack_poses(T, p7);

@@ -395,7 +395,10 @@ ovs_status ovs_stereo_compute(ovs_stereo* s, const ovs_orb* left, const ovs_orb*
     if (n_left > s->max_kps || n_right > s->max_kps) return OVS_ERR_CAPACITY;
     OVS_HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = s->stream;
-    OVS_HIP_TRY(hipDeviceSynchronize());   // the extractors ran on their own streams
+    // the extractors ran on their own streams: wait for exactly those two (never the whole device -- tracking and mapping threads
+    // share it)
+    OVS_HIP_TRY(hipStreamSynchronize(ovs::orb_last_stream(left)));
+    OVS_HIP_TRY(hipStreamSynchronize(ovs::orb_last_stream(right)));
     OVS_HIP_TRY(hipMemcpyAsync(s->d_kps_l, kps_left, sizeof(ovs_keypoint) * n_left, hipMemcpyHostToDevice, st));
     OVS_HIP_TRY(hipMemcpyAsync(s->d_desc_l, desc_left, (size_t)32 * n_left, hipMemcpyHostToDevice, st));
     OVS_HIP_TRY(hipMemcpyAsync(s->d_kps_r, kps_right, sizeof(ovs_keypoint) * n_right, hipMemcpyHostToDevice, st));

@@ -59,14 +59,35 @@ struct ovs_orb {
     size_t taps_cap = 0;
     DevBuffers d{};
     size_t pyr_cap = 0, cand_cap = 0, node_cap = 0, kps_cap = 0;
-    // host-API staging
-    uint8_t* d_img = nullptr;
-    uint8_t* d_mask = nullptr;
+    // host-API staging: two slots (double buffering). A slot owns a device image (+ mask), a pinned input staging buffer, a pinned
+    // output block [counts 16 B | keypoints | descriptors] and, on demand, a pinned copy of the pyramid block. H2D copies run on
+    // copy_stream, kernels and the D2H of the results on `stream`: the upload of frame k+1 overlaps the kernels of frame k.
+    struct HostSlot {
+        uint8_t* d_img = nullptr;
+        uint8_t* d_mask = nullptr;
+        uint8_t* h_in = nullptr;     // pinned, img_pitch x max_rows
+        uint8_t* h_mask = nullptr;   // pinned, lazily
+        uint8_t* h_out = nullptr;    // pinned
+        uint8_t* h_pyr = nullptr;    // pinned, lazily (ovs_orb_set_host_pyramid)
+        hipEvent_t ev_h2d = nullptr, ev_done = nullptr;
+        hipEvent_t t[4] = {};        // profiling: h2d begin / h2d end / kernels end / d2h end
+        bool pending = false, has_pyr = false, timed = false;
+        int rows = 0, cols = 0;
+    };
+    HostSlot slot[2];
+    hipStream_t copy_stream = nullptr;
+    unsigned n_submitted = 0, n_collected = 0;
+    int last_slot = -1;              // slot of the last COLLECTED frame (host pyramid getter)
+    bool host_pyr = false;
+    int host_mode = 1;               // 0: hipMemcpy2DAsync straight from the caller's (pageable) rows; 1: banded copy through pinned staging
+    float host_ms[3] = {0, 0, 0};    // h2d | kernels | d2h of the last collected frame (profiling enabled)
     size_t img_pitch = 0;
     ovs_keypoint* d_out_kps = nullptr;
     uint8_t* d_out_desc = nullptr;
     int32_t* d_out_counts = nullptr;
     int out_cap = 0;
+    size_t out_block_bytes = 0, out_off_desc = 0;
+    hipStream_t last_stream = nullptr;   // stream of the last extract (device-batch form: the caller's)
     // last extract (for pyramid / debug getters)
     const uint8_t* last_img0 = nullptr;
     size_t last_stride0 = 0, last_frame_stride0 = 0;
@@ -284,6 +305,7 @@ ovs_status run_extract(ovs_orb* h, const uint8_t* d_images, int batch, int rows,
     h->last_stride0 = stride;
     h->last_frame_stride0 = frame_stride;
     h->last_batch = batch;
+    h->last_stream = s;
     return OVS_OK;
 }
 
@@ -311,6 +333,7 @@ bool orb_pyramid_view(const ovs_orb* h, int frame, PyrView* out) {
     return true;
 }
 int orb_device(const ovs_orb* h) { return h ? h->device : -1; }
+hipStream_t orb_last_stream(const ovs_orb* h) { return h ? h->last_stream : nullptr; }
 }   // namespace ovs
 
 extern "C" {
@@ -385,11 +408,24 @@ ovs_status ovs_orb_create(const ovs_orb_params* params, int32_t max_rows, int32_
     // host-API staging: one frame
     h->img_pitch = ((size_t)max_cols + 255) & ~(size_t)255;
     h->out_cap = geo.total_kp_cap;
-    CREATE_TRY(hipMalloc(&h->d_img, h->img_pitch * max_rows));
-    CREATE_TRY(hipMalloc(&h->d_mask, h->img_pitch * max_rows));
-    CREATE_TRY(hipMalloc(&h->d_out_kps, sizeof(ovs_keypoint) * h->out_cap));
-    CREATE_TRY(hipMalloc(&h->d_out_desc, (size_t)32 * h->out_cap));
-    CREATE_TRY(hipMalloc(&h->d_out_counts, sizeof(int32_t) * 4));
+    // one contiguous device output block [counts | keypoints | descriptors] so that ONE D2H brings a frame's results back
+    h->out_off_desc = (16 + sizeof(ovs_keypoint) * (size_t)h->out_cap + 31) & ~(size_t)31;
+    h->out_block_bytes = h->out_off_desc + (size_t)32 * h->out_cap;
+    {
+        uint8_t* blk = nullptr;
+        CREATE_TRY(hipMalloc(&blk, h->out_block_bytes));
+        h->d_out_counts = reinterpret_cast<int32_t*>(blk);
+        h->d_out_kps = reinterpret_cast<ovs_keypoint*>(blk + 16);
+        h->d_out_desc = blk + h->out_off_desc;
+    }
+    CREATE_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (auto& sl : h->slot) {
+        CREATE_TRY(hipMalloc(&sl.d_img, h->img_pitch * max_rows));
+        CREATE_TRY(hipHostMalloc(&sl.h_in, h->img_pitch * max_rows, hipHostMallocDefault));
+        CREATE_TRY(hipHostMalloc(&sl.h_out, h->out_block_bytes, hipHostMallocDefault));
+        CREATE_TRY(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+    }
 #undef CREATE_TRY
     *out = h;
     return OVS_OK;
@@ -406,11 +442,21 @@ ovs_status ovs_orb_destroy(ovs_orb* h) {
     hipFree(h->d.nodes);
     hipFree(h->d.lvl_kps);
     hipFree(h->d.lvl_count);
-    hipFree(h->d_img);
-    hipFree(h->d_mask);
-    hipFree(h->d_out_kps);
-    hipFree(h->d_out_desc);
-    hipFree(h->d_out_counts);
+    if (h->copy_stream) hipStreamSynchronize(h->copy_stream);
+    for (auto& sl : h->slot) {
+        hipFree(sl.d_img);
+        hipFree(sl.d_mask);
+        if (sl.h_in) hipHostFree(sl.h_in);
+        if (sl.h_mask) hipHostFree(sl.h_mask);
+        if (sl.h_out) hipHostFree(sl.h_out);
+        if (sl.h_pyr) hipHostFree(sl.h_pyr);
+        if (sl.ev_h2d) hipEventDestroy(sl.ev_h2d);
+        if (sl.ev_done) hipEventDestroy(sl.ev_done);
+        for (auto& e : sl.t)
+            if (e) hipEventDestroy(e);
+    }
+    hipFree(h->d_out_counts);   // base of the [counts | keypoints | descriptors] block
+    if (h->copy_stream) hipStreamDestroy(h->copy_stream);
     h->prof.destroy();
     for (int k = 0; k < ovs_orb::kMaxSub; ++k) {
         h->prof_sub[k].destroy();
@@ -496,31 +542,157 @@ ovs_status ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_images, int32_
     return run_extract(h, d_images, batch, rows, cols, stride, frame_stride, d_masks, d_kps, d_desc, d_counts, cap, s);
 }
 
+// ---- host-pointer path: submit / collect over two slots; ovs_orb_extract = submit + collect ----------------------------------------
+namespace {
+
+// rows of `cols` bytes from the caller's (pageable) buffer to the device image of a slot, on copy_stream
+ovs_status upload_plane(ovs_orb* h, const uint8_t* src, size_t stride, int rows, int cols, uint8_t* staging, uint8_t* d_dst) {
+    hipStream_t cs = h->copy_stream;
+    const size_t pitch = h->img_pitch;
+    if (h->host_mode == 0 || !staging) {
+        OVS_HIP_TRY(hipMemcpy2DAsync(d_dst, pitch, src, stride, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, cs));
+        return OVS_OK;
+    }
+    // banded: the CPU copies band k+1 into pinned memory while the DMA engine moves band k (a pageable hipMemcpy does the same inside
+    // the runtime, but through its own small staging chunks and with a blocking wait at the end)
+    const int band = std::max(32, (rows + 7) / 8);
+    for (int r0 = 0; r0 < rows; r0 += band) {
+        const int nr = std::min(band, rows - r0);
+        uint8_t* st = staging + (size_t)r0 * pitch;
+        if (stride == (size_t)cols && pitch == (size_t)cols) {
+            std::memcpy(st, src + (size_t)r0 * stride, (size_t)nr * cols);
+        } else {
+            for (int r = 0; r < nr; ++r) std::memcpy(st + (size_t)r * pitch, src + (size_t)(r0 + r) * stride, (size_t)cols);
+        }
+        OVS_HIP_TRY(hipMemcpyAsync(d_dst + (size_t)r0 * pitch, st, (size_t)nr * pitch, hipMemcpyHostToDevice, cs));
+    }
+    return OVS_OK;
+}
+
+}   // namespace
+
+ovs_status ovs_orb_extract_submit(ovs_orb* h, const uint8_t* image, int32_t rows, int32_t cols, size_t stride, const uint8_t* mask,
+                                  size_t mask_stride) {
+    if (!h || !image || rows <= 0 || cols <= 0 || stride < (size_t)cols || (mask && mask_stride < (size_t)cols)) return OVS_ERR_INVALID;
+    if (rows > h->max_rows || cols > h->max_cols) return OVS_ERR_CAPACITY;
+    if (h->n_submitted - h->n_collected >= 2) return OVS_ERR_CAPACITY;   // both slots in flight: collect first
+    OVS_HIP_TRY(hipSetDevice(h->device));
+    ovs_orb::HostSlot& sl = h->slot[h->n_submitted & 1];
+    hipStream_t s = h->stream, cs = h->copy_stream;
+    // a geometry change synchronises the device (ensure_geometry): do it before anything of this frame is enqueued
+    ovs_status st = ensure_geometry(h, rows, cols);
+    if (st != OVS_OK) return st;
+    const bool timed = h->prof.enabled;
+    if (timed)
+        for (auto& e : sl.t)
+            if (!e) OVS_HIP_TRY(hipEventCreate(&e));
+    if (timed) OVS_HIP_TRY(hipEventRecord(sl.t[0], cs));
+    st = upload_plane(h, image, stride, rows, cols, sl.h_in, sl.d_img);
+    if (st != OVS_OK) return st;
+    if (mask) {
+        if (!sl.d_mask) OVS_HIP_TRY(hipMalloc(&sl.d_mask, h->img_pitch * h->max_rows));
+        if (!sl.h_mask) OVS_HIP_TRY(hipHostMalloc(&sl.h_mask, h->img_pitch * h->max_rows, hipHostMallocDefault));
+        st = upload_plane(h, mask, mask_stride, rows, cols, sl.h_mask, sl.d_mask);
+        if (st != OVS_OK) return st;
+    }
+    if (timed) OVS_HIP_TRY(hipEventRecord(sl.t[1], cs));
+    OVS_HIP_TRY(hipEventRecord(sl.ev_h2d, cs));
+    OVS_HIP_TRY(hipStreamWaitEvent(s, sl.ev_h2d, 0));
+    st = run_extract(h, sl.d_img, 1, rows, cols, h->img_pitch, h->img_pitch * (size_t)rows, mask ? sl.d_mask : nullptr, h->d_out_kps,
+                     h->d_out_desc, h->d_out_counts, h->out_cap, s);
+    if (st != OVS_OK) return st;
+    if (timed) OVS_HIP_TRY(hipEventRecord(sl.t[2], s));
+    // ONE D2H for counts + keypoints + descriptors (120 KB at 2000 features: cheaper than a count round trip followed by two copies)
+    OVS_HIP_TRY(hipMemcpyAsync(sl.h_out, h->d_out_counts, h->out_block_bytes, hipMemcpyDeviceToHost, s));
+    sl.has_pyr = false;
+    if (h->host_pyr && h->p.num_levels > 1) {
+        if (!sl.h_pyr) OVS_HIP_TRY(hipHostMalloc(&sl.h_pyr, h->d.pyr_frame_bytes, hipHostMallocDefault));
+        const LevelGeo& gl = h->geo.lv[h->p.num_levels - 1];
+        const size_t used = (size_t)gl.plane_off + (size_t)gl.pitch * gl.rows;   // levels 1 .. L-1 are contiguous in the frame block
+        OVS_HIP_TRY(hipMemcpyAsync(sl.h_pyr, h->d.pyr, used, hipMemcpyDeviceToHost, s));
+        sl.has_pyr = true;
+    }
+    if (timed) OVS_HIP_TRY(hipEventRecord(sl.t[3], s));
+    OVS_HIP_TRY(hipEventRecord(sl.ev_done, s));
+    sl.pending = true;
+    sl.timed = timed;
+    sl.rows = rows;
+    sl.cols = cols;
+    ++h->n_submitted;
+    return OVS_OK;
+}
+
+ovs_status ovs_orb_extract_collect(ovs_orb* h, ovs_keypoint* kps, uint8_t* desc, int32_t cap, int32_t* n_out) {
+    if (!h || !n_out || cap < 0 || (cap > 0 && (!kps || !desc))) return OVS_ERR_INVALID;
+    *n_out = 0;
+    if (h->n_collected == h->n_submitted) return OVS_ERR_INVALID;   // nothing in flight
+    OVS_HIP_TRY(hipSetDevice(h->device));
+    const int si = (int)(h->n_collected & 1);
+    ovs_orb::HostSlot& sl = h->slot[si];
+    OVS_HIP_TRY(hipEventSynchronize(sl.ev_done));   // the only wait of a frame
+    sl.pending = false;
+    ++h->n_collected;
+    h->last_slot = si;
+    if (sl.timed) {
+        OVS_HIP_TRY(hipEventElapsedTime(&h->host_ms[0], sl.t[0], sl.t[1]));
+        OVS_HIP_TRY(hipEventElapsedTime(&h->host_ms[1], sl.t[1], sl.t[2]));
+        OVS_HIP_TRY(hipEventElapsedTime(&h->host_ms[2], sl.t[2], sl.t[3]));
+    }
+    const int32_t n = *reinterpret_cast<const int32_t*>(sl.h_out);
+    const int32_t m = std::min(n, cap);
+    if (m > 0) {
+        std::memcpy(kps, sl.h_out + 16, sizeof(ovs_keypoint) * (size_t)m);
+        std::memcpy(desc, sl.h_out + h->out_off_desc, (size_t)32 * m);
+    }
+    *n_out = m;
+    return n > cap ? OVS_ERR_CAPACITY : OVS_OK;
+}
+
 ovs_status ovs_orb_extract(ovs_orb* h, const uint8_t* image, int32_t rows, int32_t cols, size_t stride, const uint8_t* mask,
                            size_t mask_stride, ovs_keypoint* kps, uint8_t* desc, int32_t cap, int32_t* n_out) {
     if (!h || !n_out) return OVS_ERR_INVALID;
     *n_out = 0;
     if (!image || rows <= 0 || cols <= 0) return OVS_OK;   // upstream: empty image -> early return
-    if (rows > h->max_rows || cols > h->max_cols) return OVS_ERR_CAPACITY;
     if (cap < 0 || (cap > 0 && (!kps || !desc))) return OVS_ERR_INVALID;
-    OVS_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
-    OVS_HIP_TRY(hipMemcpy2DAsync(h->d_img, h->img_pitch, image, stride, cols, rows, hipMemcpyHostToDevice, s));
-    if (mask) OVS_HIP_TRY(hipMemcpy2DAsync(h->d_mask, h->img_pitch, mask, mask_stride, cols, rows, hipMemcpyHostToDevice, s));
-    ovs_status st = run_extract(h, h->d_img, 1, rows, cols, h->img_pitch, h->img_pitch * (size_t)rows, mask ? h->d_mask : nullptr,
-                                h->d_out_kps, h->d_out_desc, h->d_out_counts, h->out_cap, s);
+    if (h->n_submitted != h->n_collected) return OVS_ERR_INVALID;   // frames submitted asynchronously must be collected first
+    const ovs_status st = ovs_orb_extract_submit(h, image, rows, cols, stride, mask, mask_stride);
     if (st != OVS_OK) return st;
-    int32_t n = 0;
-    OVS_HIP_TRY(hipMemcpyAsync(&n, h->d_out_counts, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    OVS_HIP_TRY(hipStreamSynchronize(s));
-    const int32_t m = std::min(n, cap);
-    if (m > 0) {
-        OVS_HIP_TRY(hipMemcpyAsync(kps, h->d_out_kps, sizeof(ovs_keypoint) * m, hipMemcpyDeviceToHost, s));
-        OVS_HIP_TRY(hipMemcpyAsync(desc, h->d_out_desc, (size_t)32 * m, hipMemcpyDeviceToHost, s));
-        OVS_HIP_TRY(hipStreamSynchronize(s));
+    return ovs_orb_extract_collect(h, kps, desc, cap, n_out);
+}
+
+ovs_status ovs_orb_set_host_pyramid(ovs_orb* h, int32_t enable) {
+    if (!h) return OVS_ERR_INVALID;
+    h->host_pyr = enable != 0;
+    return OVS_OK;
+}
+
+ovs_status ovs_orb_set_host_mode(ovs_orb* h, int32_t mode) {
+    if (!h || mode < 0 || mode > 1) return OVS_ERR_INVALID;
+    h->host_mode = mode;
+    return OVS_OK;
+}
+
+ovs_status ovs_orb_host_pyramid_level(const ovs_orb* h, int32_t level, const uint8_t** base, int32_t* rows, int32_t* cols, int32_t* pitch) {
+    if (!h || level < 0 || level >= h->p.num_levels || h->last_slot < 0) return OVS_ERR_INVALID;
+    const ovs_orb::HostSlot& sl = h->slot[h->last_slot];
+    const LevelGeo& g = h->geo.lv[level];
+    if (rows) *rows = g.rows;
+    if (cols) *cols = g.cols;
+    if (level == 0) {   // level 0 is the caller's own image (upstream aliases it too)
+        if (base) *base = nullptr;
+        if (pitch) *pitch = 0;
+        return OVS_OK;
     }
-    *n_out = m;
-    return n > cap ? OVS_ERR_CAPACITY : OVS_OK;
+    if (!sl.has_pyr || sl.rows != h->cur_rows || sl.cols != h->cur_cols) return OVS_ERR_INVALID;   // enable ovs_orb_set_host_pyramid first
+    if (base) *base = sl.h_pyr + g.plane_off;
+    if (pitch) *pitch = g.pitch;
+    return OVS_OK;
+}
+
+ovs_status ovs_orb_host_profile_read(const ovs_orb* h, float* h2d_kernels_d2h_ms) {
+    if (!h || !h2d_kernels_d2h_ms) return OVS_ERR_INVALID;
+    for (int i = 0; i < 3; ++i) h2d_kernels_d2h_ms[i] = h->host_ms[i];
+    return OVS_OK;
 }
 
 ovs_status ovs_orb_pyramid_level(ovs_orb* h, int32_t frame, int32_t level, uint8_t* host_dst, int32_t* rows, int32_t* cols) {
@@ -530,14 +702,17 @@ ovs_status ovs_orb_pyramid_level(ovs_orb* h, int32_t frame, int32_t level, uint8
     if (cols) *cols = g.cols;
     if (!host_dst) return OVS_OK;
     OVS_HIP_TRY(hipSetDevice(h->device));
-    OVS_HIP_TRY(hipStreamSynchronize(h->stream));
-    OVS_HIP_TRY(hipDeviceSynchronize());
+    // only the stream the last extract ran on is waited for -- never the whole device: a second extractor on another thread (stereo
+    // left / right) must not be stalled by this getter
+    OVS_HIP_TRY(hipStreamSynchronize(h->last_stream));
+    hipStream_t s = h->stream;
     if (level == 0)
-        OVS_HIP_TRY(hipMemcpy2D(host_dst, g.cols, h->last_img0 + (size_t)frame * h->last_frame_stride0, h->last_stride0, g.cols, g.rows,
-                                hipMemcpyDeviceToHost));
+        OVS_HIP_TRY(hipMemcpy2DAsync(host_dst, g.cols, h->last_img0 + (size_t)frame * h->last_frame_stride0, h->last_stride0, g.cols, g.rows,
+                                     hipMemcpyDeviceToHost, s));
     else
-        OVS_HIP_TRY(hipMemcpy2D(host_dst, g.cols, h->d.pyr + (size_t)frame * h->d.pyr_frame_bytes + g.plane_off, g.pitch, g.cols, g.rows,
-                                hipMemcpyDeviceToHost));
+        OVS_HIP_TRY(hipMemcpy2DAsync(host_dst, g.cols, h->d.pyr + (size_t)frame * h->d.pyr_frame_bytes + g.plane_off, g.pitch, g.cols, g.rows,
+                                     hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
     return OVS_OK;
 }
 

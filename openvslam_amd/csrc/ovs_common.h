@@ -105,6 +105,7 @@ struct PyrView {
 // false if the handle has not extracted yet or `frame` is outside its last batch
 bool orb_pyramid_view(const ovs_orb* h, int frame, PyrView* out);
 int orb_device(const ovs_orb* h);
+hipStream_t orb_last_stream(const ovs_orb* h);   // the stream the handle's last extract was enqueued on
 
 // Stage timer for bench.py: HIP events recorded on the launch stream at stage boundaries; a small ring of call slots.
 template <int NSTAGE>

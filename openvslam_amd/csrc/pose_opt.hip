@@ -169,7 +169,10 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
     uint8_t* outlier = outlier_all + o0;
     // upstream: ONE Huber delta per frame, chosen by the rig (Monocular -> sqrt_chi_sq_2D, otherwise sqrt_chi_sq_3D); the chi-square
     // outlier gates stay per edge
-    const double huber = setup_type == 0 ? sqrt(5.991) : sqrt(7.815);
+    // upstream: constexpr float chi_sq_2D = 5.99146; const float sqrt_chi_sq_2D = std::sqrt(chi_sq_2D); (3D: 7.81473) -- FLOAT constants widened
+    // to double where g2o consumes them (ORACLE_SPEC rule 25); hex literals so no library sqrt is involved
+    const double kChi2D = 0x1.7f7414p+2, kChi3D = 0x1.f4248ap+2, kSqrtChi2D = 0x1.394fbcp+1, kSqrtChi3D = 0x1.65d26ap+1;
+    const double huber = setup_type == 0 ? kSqrtChi2D : kSqrtChi3D;
     if (n > kPoseMaxObs) {   // the per-thread inlier mask holds 32 observations: refuse instead of aliasing flags
         if (tid == 0) num_valid[p] = -1;
         return;
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                     const ovs_pose_obs o = obs[i];
                     const bool wa = (was_active >> k) & 1u;
                     const double c2 = pose_edge(wa ? Re : R, wa ? te : t, o, cam, bf, 0.0, nullptr);
-                    const bool out = (o.is_stereo ? 7.815 : 5.991) < c2;
+                    const bool out = (o.is_stereo ? kChi3D : kChi2D) < c2;
                     outlier[i] = out ? 1 : 0;
                     if (out) ++bad;
                     else active |= 1u << k;

@@ -2,8 +2,8 @@
 (expected: src/openvslam/optimize/local_bundle_adjuster.cc; g2o OptimizationAlgorithmLevenberg, BlockSolver_6_3, RobustKernelHuber).
 
 Restated from the published g2o algorithm (upstream and g2o sources are absent: parity unpinned), ORACLE_SPEC rules 25 and 28:
-  round 1: all edges, Huber(sqrt 5.991 mono / sqrt 7.815 stereo), num_first_iter Levenberg-Marquardt iterations;
-  outliers (chi2 > 5.991 / 7.815 or depth <= 0) go to level 1, kernels are dropped;
+  round 1: all edges, Huber (one delta per rig: Monocular sqrtf(5.99146f), otherwise sqrtf(7.81473f)), num_first_iter LM iterations;
+  outliers (chi2 > 5.99146f mono edge / 7.81473f stereo edge, or depth <= 0) go to level 1, kernels are dropped;
   round 2: num_second_iter iterations on the inliers; final outlier test (level-1 edges keep their round-1 chi2, depth is re-tested).
 LM: lambda0 = 1e-5 max|diag H| over the active vertices; trial (H + lambda I) dx = b by landmark elimination + dense Cholesky;
 rho = (chi - chi_new) / (dx.(lambda dx + b) + 1e-3); accept (rho > 0): lambda *= clamp(1 - (2 rho - 1)^3, 1/3, 2/3), ni = 2; reject:
@@ -15,7 +15,9 @@ import numpy as np
 
 from . import binding as ob
 
-CHI2_MONO, CHI2_STEREO = 5.991, 7.815
+# upstream: constexpr float chi_sq_2D = 5.99146, chi_sq_3D = 7.81473 and their FLOAT square roots (ORACLE_SPEC rules 25 / 28)
+CHI2_MONO, CHI2_STEREO = float(np.float32(5.99146)), float(np.float32(7.81473))
+SQRT_CHI2_MONO, SQRT_CHI2_STEREO = float(np.sqrt(np.float32(5.99146))), float(np.sqrt(np.float32(7.81473)))
 
 
 def _quat_to_rot(q):
@@ -67,8 +69,9 @@ def _oplus(R, t, u):
 
 
 class _Graph:
-    def __init__(self, n_pose, n_pt, fixed, mono, stereo, cam, bf):
+    def __init__(self, n_pose, n_pt, fixed, mono, stereo, cam, bf, setup_type=0):
         self.n_pose, self.n_pt, self.cam, self.bf = n_pose, n_pt, cam, bf
+        self.setup_type = setup_type
         self.fixed = np.zeros(n_pose, np.uint8) if fixed is None else np.ascontiguousarray(fixed, np.uint8)
         self.free = np.flatnonzero(self.fixed == 0)
         self.slot = -np.ones(n_pose, np.int64)
@@ -101,9 +104,10 @@ class _Graph:
         for k, (R, t) in enumerate(T):
             poses[k, :3] = t
             poses[k, 3:] = _rot_to_quat(R)
-        out = ob.ba_linearize(poses, self.fixed, X, self.mono, self.cam, np.sqrt(CHI2_MONO) if robust else 0.0)
+        out = ob.ba_linearize(poses, self.fixed, X, self.mono, self.cam,
+                              (SQRT_CHI2_MONO if self.setup_type == 0 else SQRT_CHI2_STEREO) if robust else 0.0)
         if len(self.stereo):
-            s = ob.ba_linearize_stereo(poses, self.fixed, X, self.stereo, self.cam, self.bf, np.sqrt(CHI2_STEREO) if robust else 0.0)
+            s = ob.ba_linearize_stereo(poses, self.fixed, X, self.stereo, self.cam, self.bf, SQRT_CHI2_STEREO if robust else 0.0)
             for k in ("Hpp", "bp", "Hll", "bl", "chi2"):
                 out[k] = out[k] + s[k]
             out["Hpl"] = np.concatenate([out["Hpl"], s["Hpl"]])
@@ -216,14 +220,17 @@ class _Graph:
         return T, X, chi_start, chi, n_iter
 
 
-def local_ba_optimize(poses, pose_fixed, points, mono, cam, stereo=None, focal_x_baseline=0.0, num_first_iter=5, num_second_iter=10):
+def local_ba_optimize(poses, pose_fixed, points, mono, cam, stereo=None, focal_x_baseline=0.0, num_first_iter=5, num_second_iter=10,
+                      setup_type=None):
+    if setup_type is None:
+        setup_type = 1 if focal_x_baseline != 0.0 else 0
     poses = np.array(poses, np.float64).reshape(-1, 7)
     X = np.array(points, np.float64).reshape(-1, 3).copy()
     mono = np.ascontiguousarray(mono if mono is not None else np.zeros(0, ob.BA_EDGE_DTYPE), ob.BA_EDGE_DTYPE)
     stereo = np.ascontiguousarray(stereo if stereo is not None else np.zeros(0, ob.BA_EDGE_STEREO_DTYPE), ob.BA_EDGE_STEREO_DTYPE)
     n_pose, n_pt, nm = len(poses), len(X), len(mono)
     T = [(_quat_to_rot(p[3:]), p[:3].copy()) for p in poses]
-    G = _Graph(n_pose, n_pt, pose_fixed, mono, stereo, tuple(cam), focal_x_baseline)
+    G = _Graph(n_pose, n_pt, pose_fixed, mono, stereo, tuple(cam), focal_x_baseline, setup_type)
     info = np.zeros(6)
     T, X, info[0], info[1], info[4] = G.run_round(T, X, num_first_iter, True)
     chi_r1, depth = G.edge_chi2(T, X)

@@ -5,7 +5,7 @@
 // One free vertex (the frame's pose, world -> camera), one unary edge per observed landmark (2 residuals, or 3 for a stereo
 // keypoint), landmark positions fixed. Upstream's schedule: 4 rounds; every round re-initialises the pose vertex with the frame's
 // INITIAL pose, runs 10 Levenberg-Marquardt iterations over the current inlier edges, then re-classifies EVERY edge with the new
-// pose (chi2 > 5.991 mono / 7.815 stereo -> outlier, excluded from the next round); from round 2 on the Huber kernel is removed; the
+// pose (chi2 > 5.99146f mono / 7.81473f stereo -> outlier, excluded from the next round); from round 2 on the Huber kernel is removed; the
 // loop stops early when fewer than 10 edges are left in the graph (all edges stay in the graph upstream, so this only triggers for
 // n < 10). Result: final pose, outlier flags, number of inliers.
 //
@@ -168,7 +168,11 @@ extern "C" int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* o
                                  double* pose_cw_out, uint8_t* outlier, int* num_valid) {
     // upstream: sqrt_chi_sq = (frm.camera_->setup_type_ == Monocular) ? sqrt_chi_sq_2D : sqrt_chi_sq_3D -- ONE Huber delta for every
     // edge of the frame, chosen by the rig; the chi-square outlier gates below stay per edge (is_monocular_)
-    const double huber = setup_type == 0 ? std::sqrt(5.991) : std::sqrt(7.815);
+    // upstream: constexpr float chi_sq_2D = 5.99146; const float sqrt_chi_sq_2D = std::sqrt(chi_sq_2D); (3D: 7.81473) -- FLOAT constants widened
+    // to double where g2o consumes them (ORACLE_SPEC rule 25); hex literals so no library sqrt is involved
+    const float chi_sq_2D = 5.99146f, chi_sq_3D = 7.81473f;
+    const float sqrt_chi_sq_2D = std::sqrt(chi_sq_2D), sqrt_chi_sq_3D = std::sqrt(chi_sq_3D);
+    const double huber = setup_type == 0 ? (double)sqrt_chi_sq_2D : (double)sqrt_chi_sq_3D;
     Pose T0;
     std::memcpy(T0.R, pose_cw_in, sizeof(double) * 9);
     std::memcpy(T0.t, pose_cw_in + 9, sizeof(double) * 3);
@@ -239,7 +243,7 @@ extern "C" int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* o
             num_bad = 0;
             for (int i = 0; i < n; ++i) {
                 const double c2 = edge_eval(active[i] ? Terr : T, obs[i], cam4, bf, 0, nullptr);
-                const double thr = obs[i].is_stereo ? 7.815 : 5.991;
+                const double thr = obs[i].is_stereo ? (double)chi_sq_3D : (double)chi_sq_2D;
                 if (thr < c2) {
                     outlier[i] = 1;
                     active[i] = 0;

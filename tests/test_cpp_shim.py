@@ -235,3 +235,165 @@ def test_shim_matches_oracle(oracle, tmp_path):
     wn, want = oracle.bow_match_keyframes(wa, wda, fv_a, wb, wdb, fv_b, 0.75, True, has_lm_1=live_a.astype(np.uint8),
                                           has_lm_2=live_b.astype(np.uint8))
     assert n_bk == wn and np.array_equal(bk_m, want) and wn > 20
+
+
+LBA_SHIM = os.path.join(ROOT, "openvslam_amd", "cpp", "test_lba_shim")
+
+
+def _pose7_to_44(p):
+    from openvslam_amd.ba import quat_to_rot
+    T = np.eye(4)
+    T[:3, :3] = quat_to_rot(p[3:])
+    T[:3, 3] = p[:3]
+    return T
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stereo_frac,setup", [(0.0, 0), (0.4, 1)])
+def test_local_bundle_adjuster_class_matches_oracle(oracle, tmp_path, stereo_frac, setup):
+    """optimize::local_bundle_adjuster::optimize(curr_keyfrm, force_stop_flag) through the CLASS: the shim collects local / fixed
+    keyframes and local landmarks from covisibility + observations as upstream does, flattens them, calls ovs_local_ba_optimize, erases
+    outlier observations and writes poses / positions back. Compared with the oracle run on the same flattened problem (1e-7: the two
+    sides sum in different orders, and the class walks unordered_maps)."""
+    import struct
+    from oracle import lba
+    from test_ba import _lba_scene
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "openvslam_amd", "cpp")])
+    d, mono, st, bf, _, _ = _lba_scene(11, n_pose=9, n_pt=1200, obs_per_pose=400, stereo_frac=stereo_frac)
+    n_kf = len(d["poses"])
+    # keyframe 0 has id 0 and is covisible (local but constant, as upstream's `id_ == 0` rule); keyframe 1 is NOT covisible -> a fixed
+    # keyframe; the rest are local, the last one is the current keyframe
+    ids = np.arange(n_kf) * 3
+    covisible = np.ones(n_kf, np.int32)
+    covisible[1] = 0
+    fixed = np.zeros(n_kf, np.uint8)
+    fixed[:2] = 1
+    # the class only sees landmarks that some LOCAL keyframe observes: restrict the flat problem to them
+    local_obs = np.r_[mono["point_idx"][mono["pose_idx"] != 1], st["point_idx"][st["pose_idx"] != 1]]
+    keep = np.zeros(len(d["points"]), bool)
+    keep[local_obs] = True
+    remap = -np.ones(len(keep), np.int64)
+    remap[keep] = np.arange(int(keep.sum()))
+    mono = mono[keep[mono["point_idx"]]].copy()
+    st = st[keep[st["point_idx"]]].copy()
+    mono["point_idx"] = remap[mono["point_idx"]]
+    st["point_idx"] = remap[st["point_idx"]]
+    pts = d["points"][keep]
+    if setup == 0:
+        bf = 0.0
+    sig = np.float32(1.0)
+    ils = []
+    for _ in range(8):
+        ils.append(np.float32(1.0) / np.float32(sig * sig))
+        sig = np.float32(1.2) * sig
+    ils = np.array(ils, np.float32)
+
+    def octave_of(inv):   # the scene stores 1 / sigma^2 as double(float): recover the octave the keypoint carries
+        return np.argmin(np.abs(ils.astype(np.float64)[None, :] - inv[:, None]), 1).astype(np.int32)
+
+    blob = struct.pack("<6i5d", n_kf, len(pts), len(mono) + len(st), n_kf - 1, setup, 0, *d["cam"], bf) + ils.tobytes()
+    for k in range(n_kf):
+        blob += struct.pack("<2i", int(ids[k]), int(covisible[k])) + _pose7_to_44(d["poses"][k]).astype("<f8").tobytes()
+    for j in range(len(pts)):
+        blob += struct.pack("<i3d", 7 * j + 1, *pts[j])
+    # observations: float keypoints (the class reads cv::KeyPoint floats), so the oracle gets the same float-rounded observations
+    mono["obs_x"] = mono["obs_x"].astype(np.float32)
+    mono["obs_y"] = mono["obs_y"].astype(np.float32)
+    for k in ("obs_x", "obs_y", "obs_x_right"):
+        st[k] = st[k].astype(np.float32)
+    mono["inv_sigma_sq"] = ils[octave_of(mono["inv_sigma_sq"])]
+    st["inv_sigma_sq"] = ils[octave_of(st["inv_sigma_sq"])]
+    for e in mono:
+        blob += struct.pack("<2i3fi", int(e["pose_idx"]), int(e["point_idx"]), e["obs_x"], e["obs_y"], -1.0,
+                            int(octave_of(np.array([e["inv_sigma_sq"]]))[0]))
+    for e in st:
+        blob += struct.pack("<2i3fi", int(e["pose_idx"]), int(e["point_idx"]), e["obs_x"], e["obs_y"], e["obs_x_right"],
+                            int(octave_of(np.array([e["inv_sigma_sq"]]))[0]))
+    (tmp_path / "scene.bin").write_bytes(blob)
+    subprocess.check_call([LBA_SHIM, "lba", str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")])
+    raw = (tmp_path / "out.bin").read_bytes()
+    poses_out = np.frombuffer(raw[:128 * n_kf], np.float64).reshape(n_kf, 4, 4)
+    off = 128 * n_kf
+    rec = np.frombuffer(raw[off:off + 28 * len(pts)], np.dtype([("p", "<f8", (3,)), ("upd", "<i4")]))
+    off += 28 * len(pts)
+    erased = np.frombuffer(raw[off:], np.uint8)
+    assert len(erased) == len(mono) + len(st) and not (erased == 2).any()   # keyframe slot and landmark observation always agree
+    want = lba.local_ba_optimize(d["poses"], fixed, pts, mono, d["cam"], st, bf, setup_type=setup)
+    assert want["info"][4] >= 3 and want["info"][5] >= 1
+    for k in range(n_kf):
+        if k == 1:
+            assert np.array_equal(poses_out[k], _pose7_to_44(d["poses"][k]))    # a fixed (non-local) keyframe is never written back
+        elif k == 0:   # local but constant (id 0): written back as vertex->estimate(), i.e. through a quaternion round trip
+            assert np.allclose(poses_out[k], _pose7_to_44(d["poses"][k]), rtol=0, atol=1e-13)
+        else:
+            assert np.allclose(poses_out[k], _pose7_to_44(want["poses"][k]), rtol=1e-7, atol=1e-8)
+    assert np.allclose(rec["p"], want["points"], rtol=1e-7, atol=1e-8)
+    assert (rec["upd"] == 1).all()                                            # update_normal_and_depth() once per local landmark
+    want_out = np.r_[want["mono_outlier"], want["stereo_outlier"]]
+    assert (erased.astype(bool) != want_out).sum() <= 1 and want_out.sum() > 20
+
+    # force_stop_flag already raised: upstream returns before optimising -- nothing moves, nothing is erased
+    blob2 = bytearray(blob)
+    blob2[20:24] = struct.pack("<i", 1)
+    (tmp_path / "scene2.bin").write_bytes(bytes(blob2))
+    subprocess.check_call([LBA_SHIM, "lba", str(tmp_path / "scene2.bin"), str(tmp_path / "out2.bin")])
+    raw2 = (tmp_path / "out2.bin").read_bytes()
+    p2 = np.frombuffer(raw2[:128 * n_kf], np.float64).reshape(n_kf, 4, 4)
+    assert all(np.array_equal(p2[k], _pose7_to_44(d["poses"][k])) for k in range(n_kf))
+    assert not np.frombuffer(raw2[128 * n_kf + 28 * len(pts):], np.uint8).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("check_orientation", [False, True])
+def test_robust_match_frame_and_keyframe_class(oracle, tmp_path, check_orientation):
+    """robust::match_frame_and_keyframe through the class: the device brute-force match (== oracle, incl. the host-side orientation
+    histogram when check_orientation), then the essential-matrix RANSAC keeps the geometrically consistent pairs -- the true
+    correspondences of a two-view scene survive, matches planted between unrelated points do not."""
+    import struct
+    from test_gpu_window import _rot
+    from openvslam_amd import synth
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "openvslam_amd", "cpp")])
+    rng = np.random.default_rng(8)
+    n_true, n_wrong, n_extra = 500, 60, 300
+    n = n_true + n_wrong
+    X = np.stack([rng.uniform(-4, 4, n), rng.uniform(-2.5, 2.5, n), rng.uniform(4, 15, n)], 1)
+    R2 = _rot((0, 1, 0), 5.0) @ _rot((1, 0, 0), -2.0)
+    t2 = np.array([-0.7, 0.1, 0.15])
+    b1 = X / np.linalg.norm(X, axis=1, keepdims=True)
+    X2 = X @ R2.T + t2
+    X2[n_true:] = np.stack([rng.uniform(-4, 4, n_wrong), rng.uniform(-2.5, 2.5, n_wrong), rng.uniform(4, 15, n_wrong)], 1)   # unrelated
+    b2 = X2 / np.linalg.norm(X2, axis=1, keepdims=True)
+    d1 = rng.integers(0, 256, (n + n_extra, 32), dtype=np.uint8)
+    d2 = np.stack([synth.flip_bits(rng, d1[i], 20) for i in range(n)] + [rng.integers(0, 256, 32, dtype=np.uint8) for _ in range(n_extra)])
+    bb1 = np.concatenate([b1, rng.normal(size=(n_extra, 3))])
+    bb2 = np.concatenate([b2, rng.normal(size=(n_extra, 3))])
+    bb1 /= np.linalg.norm(bb1, axis=1, keepdims=True)
+    bb2 /= np.linalg.norm(bb2, axis=1, keepdims=True)
+    perm = rng.permutation(len(d2))           # keyframe keypoints in another order
+    d2, bb2 = d2[perm], bb2[perm]
+    src_of_kf = perm                          # keyframe keypoint j was made from frame keypoint perm[j] (if < n)
+    ang1 = rng.uniform(0, 360, len(d1)).astype(np.float32)
+    ang2 = ((ang1[perm] if True else 0) + rng.normal(0, 4, len(d2))).astype(np.float32) % np.float32(360)
+    ang2[rng.random(len(d2)) < 0.1] = rng.uniform(0, 360)     # some wildly rotated: the histogram removes them
+    has_lm = (rng.random(len(d2)) < 0.9).astype(np.uint8)
+    blob = struct.pack("<3if", len(d1), len(d2), int(check_orientation), 0.8)
+    blob += ang1.tobytes() + d1.tobytes() + bb1.astype("<f8").tobytes() + ang2.tobytes() + d2.tobytes() + bb2.astype("<f8").tobytes() + has_lm.tobytes()
+    (tmp_path / "mfk.bin").write_bytes(blob)
+    subprocess.check_call([LBA_SHIM, "mfk", str(tmp_path / "mfk.bin"), str(tmp_path / "mfk_out.bin")])
+    raw = (tmp_path / "mfk_out.bin").read_bytes()
+    n_bf, n_inl = (int(v) for v in np.frombuffer(raw[:8], np.int32))
+    bf = np.frombuffer(raw[8:8 + 8 * n_bf], np.int32).reshape(n_bf, 2)
+    owner = np.frombuffer(raw[8 + 8 * n_bf:], np.int32)
+    want = oracle.robust_brute_force_match(d1, d2, has_lm, 0.8)
+    if check_orientation:
+        delta = ang1[want[:, 0]] - ang2[want[:, 1]]
+        bad = oracle.angle_checker_invalid(delta)
+        want = want[~bad.astype(bool)]
+    assert np.array_equal(bf, want) and n_bf > 400
+    got_pairs = {(int(i), int(j)) for i, j in enumerate(owner) if j >= 0}
+    assert len(got_pairs) == n_inl and got_pairs <= {(int(a), int(b)) for a, b in bf}
+    true_pairs = {(i, j) for i, j in got_pairs if src_of_kf[j] == i and i < n_true}
+    wrong_pairs = {(i, j) for i, j in got_pairs if src_of_kf[j] == i and n_true <= i < n}
+    n_true_bf = sum(1 for a, b in bf if src_of_kf[b] == a and a < n_true)
+    n_wrong_bf = sum(1 for a, b in bf if src_of_kf[b] == a and n_true <= a < n)
+    assert len(true_pairs) > 0.9 * n_true_bf and n_wrong_bf > 20 and len(wrong_pairs) < 0.3 * n_wrong_bf
