@@ -98,8 +98,9 @@ ovs_status ovs_orb_extract(ovs_orb* h, const uint8_t* image, int32_t rows, int32
 ovs_status ovs_orb_extract_submit(ovs_orb* h, const uint8_t* image, int32_t rows, int32_t cols, size_t stride, const uint8_t* mask,
                                   size_t mask_stride);
 ovs_status ovs_orb_extract_collect(ovs_orb* h, ovs_keypoint* kps, uint8_t* desc, int32_t cap, int32_t* n_out);
-/* Upload strategy of the host path: 1 (default) = row bands copied through the slot's pinned buffer, each band's DMA overlapping the
- * CPU copy of the next; 0 = hipMemcpy2DAsync straight from the caller's pageable rows. Same results; measured in bench.py. */
+/* Upload strategy of the host path: 0 (default) = hipMemcpy2DAsync straight from the caller's pageable rows (0.054 ms per 1080p frame on
+ * the MI355X box); 1 = row bands copied through the slot's pinned buffer, each band's DMA overlapping the CPU copy of the next (0.12 ms:
+ * kept for hosts whose runtime stages pageable copies badly). Same results; both are measured by openvslam_amd/cpp/bench_shim. */
 ovs_status ovs_orb_set_host_mode(ovs_orb* h, int32_t mode);
 /* h2d | kernels | d2h milliseconds of the last collected frame (HIP events; valid after ovs_orb_profile_enable(h, 1)). */
 ovs_status ovs_orb_host_profile_read(const ovs_orb* h, float* h2d_kernels_d2h_ms);
