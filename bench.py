@@ -85,8 +85,11 @@ def main():
     B = args.batch
     L = _lib.lib()
     # ---- synthetic input, resident in HBM before the timed region (each rank gets its own frames)
+    # TWO distinct batches, alternated step by step: 2 x 265 MB of input cannot sit in the 256 MiB Infinity Cache, so level-0 reads
+    # of the timed region come from HBM (bench hygiene)
     frames = synth_video(ROWS, COLS, B, seed=100 + rank)
     d_frames = torch.from_numpy(frames).cuda()
+    d_frames_alt = torch.from_numpy(synth_video(ROWS, COLS, B, seed=900 + rank)).cuda()
     n_chain = max(1, args.chains)
     if B % (8 * n_chain):
         raise SystemExit("--batch must be a multiple of 8 * --chains")
@@ -98,7 +101,7 @@ def main():
         another chain's FAST or pyramid; inside a chain the matching of step k runs under the extraction of step k+1."""
 
         def __init__(self, lo):
-            self.frames = d_frames[lo:lo + Bc]
+            self.frames = [d_frames[lo:lo + Bc], d_frames_alt[lo:lo + Bc]]
             self.ex = feature.orb_extractor(feature.orb_params(NFEAT, 1.2, LEVELS, 20, 7), max_rows=ROWS, max_cols=COLS, max_batch=Bc,
                                             device=local_rank)
             if args.pipeline > 1:
@@ -132,7 +135,7 @@ def main():
             b = self.bufs[k]
             if args.overlap:
                 self.s_ext.wait_event(self.ev_match[k])      # the matcher of two steps ago has released this buffer set
-            self.ex.extract_batch_dev(self.frames, b["kps"], b["desc"], b["cnt"], stream=self.s_ext.cuda_stream)
+            self.ex.extract_batch_dev(self.frames[self.k & 1], b["kps"], b["desc"], b["cnt"], stream=self.s_ext.cuda_stream)
             if args.overlap:
                 self.ev_ext[k].record(self.s_ext)
                 self.s_match.wait_event(self.ev_ext[k])
@@ -190,6 +193,32 @@ def main():
         stage_ms["match_near"] += st2[0] / calls
         stage_ms["match_resolve"] += st2[1] / calls
 
+    # ---- the same stages with each kernel ALONE on the GPU (extract, sync, match, sync): what the per-kernel rooflines below are quoted
+    # on, because under the two-stream schedule the matcher and the pyramid stretch each other
+    iso_ms = {k: 0.0 for k in stage_ms}
+    n_iso = 4
+    for ch in chains:
+        for _ in range(n_iso):
+            b = ch.bufs[0]
+            ch.ex.extract_batch_dev(ch.frames[0], b["kps"], b["desc"], b["cnt"], stream=ch.s_ext.cuda_stream)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(ch.s_match):
+                torch.index_select(b["desc"], 0, ch.prev, out=b["desc_prev"])
+                torch.index_select(b["cnt"], 0, ch.prev, out=b["cnt_prev"])
+                ch.mt.brute_force_match_batch_dev(b["desc_prev"], b["cnt_prev"], b["desc"], b["cnt"], b["pairs"], b["mcnt"],
+                                                    stream=ch.s_match.cuda_stream)
+            torch.cuda.synchronize()
+        st4 = (C.c_float * 4)()
+        st2 = (C.c_float * 2)()
+        nc = C.c_int32()
+        _lib.check(L.ovs_orb_profile_read(ch.ex._h, st4, C.byref(nc)), "profile_read")
+        calls = max(nc.value, 1)
+        _lib.check(L.ovs_matcher_profile_read(ch.mt._h, st2, C.byref(nc)), "profile_read")
+        for key, v in zip(("pyramid", "fast", "tree", "describe"), st4):
+            iso_ms[key] += v / calls
+        iso_ms["match_near"] += st2[0] / calls
+        iso_ms["match_resolve"] += st2[1] / calls
+
     kp_step = matches_step = pairs_step = 0
     for ch in chains:
         cnt = ch.bufs[0]["cnt"].cpu().numpy().astype(np.int64)
@@ -218,18 +247,24 @@ def main():
         ab["match_resolve"] = (kp_step / B) * (4 + 8)
         dom = max(stage_ms, key=lambda k: stage_ms[k])
         achieved = ab[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
+        # roofline.traffic: HBM-side bytes per launch from rocprofv3 PMC passes. Counters cannot be collected from inside this process, so
+        # the value is READ from the committed summary of the same command (tools/gpu_pmc.sh -> profiles/pmc_traffic.json) and labelled.
         traffic = None
+        pmc = {}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                pmc = json.load(open(tpath))
+                traffic = pmc.get(dom)
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "kernel": {"pyramid": "k_resize_linear_u8 (x7)", "fast": "k_fast_cells", "tree": "k_tree",
                                            "describe": "k_describe", "match_near": "k_hamming_near",
                                            "match_resolve": "k_bf_resolve"}[dom],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "algorithmic_bytes_per_launch": int(ab[dom] * Bc), "launch_ms": round(stage_ms[dom] / n_chain, 5),
+                "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --overlap 0`, "
+                                                      "(2*FETCH + WRITE) KiB; not measured in this run)" if traffic else None,
+                "algorithmic_bytes_per_launch": int(ab[dom] * Bc), "launch_ms": round(stage_ms[dom] / n_chain, 5),
                 "launches_per_step": n_chain}
         # whole extract against the SURVEY 8(d) per-frame figure (19 377 963 B at 1080p/2000)
         extract_ms = sum(stage_ms[k] for k in ("pyramid", "fast", "tree", "describe"))
@@ -237,6 +272,40 @@ def main():
         px = [r * c for r, c in lv]
         frame_bytes = px[0] + sum(px[1:]) + 2 * sum(px) + (kp_step / B) * 60
         extract_gbs = frame_bytes * B / (extract_ms * 1e-3) / 1e9
+
+        # ---- integer-VALU rooflines ("pair-distances/s vs the integer-ALU peak"): FAST and the matcher are issue-bound,
+        # not HBM-bound, so their honest ceiling is the VALU issue rate measured on this chip (profiles/r01_valu_issue_rate.txt:
+        # 2-operand 32-bit ops 2.4 cycles per wave-instruction, v_bcnt / packed / 3-operand ops 4.2), 1024 SIMDs x 2.4 GHz.
+        simd_hz = 1024 * 2.4e9
+        pairs_launch = pairs_step / n_chain
+        near_s = iso_ms["match_near"] / n_chain * 1e-3
+        near_peak = simd_hz * 64.0 / (8 * 2.4 + 8 * 4.2)          # 8 v_xor_b32 + 8 v_bcnt_u32_b32 per 64 pairs
+        valu_counts = pmc.get("insts_valu", {}) if isinstance(pmc.get("insts_valu"), dict) else {}
+        roofline_valu = {
+            "k_hamming_near": {"unit": "pair-distances/s", "achieved": round(pairs_launch / near_s, 1), "peak": round(near_peak, 1),
+                               "frac": round(pairs_launch / near_s / near_peak, 4), "launch_ms_alone": round(near_s * 1e3, 5),
+                               "floor_model": "8 v_xor_b32 (2.4 cyc) + 8 v_bcnt_u32_b32 (4.2 cyc) per 64 pairs per SIMD",
+                               "min_wave_insts_per_launch": int(pairs_launch / 64 * 16),
+                               "insts_valu_per_launch": valu_counts.get("match_near"),
+                               "achieved_GBps_algorithmic": round(ab["match_near"] * Bc / near_s / 1e9, 2)},
+        }
+        if valu_counts.get("fast"):
+            fast_s = iso_ms["fast"] / n_chain * 1e-3
+            roofline_valu["k_fast_cells"] = {"unit": "VALU wave-instructions/s", "achieved": round(valu_counts["fast"] / fast_s, 1),
+                                             "peak": round(simd_hz / 4.2, 1), "frac": round(valu_counts["fast"] / fast_s / (simd_hz / 4.2), 4),
+                                             "launch_ms_alone": round(fast_s * 1e3, 5), "insts_valu_per_launch": valu_counts["fast"],
+                                             "insts_source": "profiles/pmc_traffic.json (SQ_INSTS_VALU pass)",
+                                             "floor_model": "packed 16-bit / 3-operand ops issue one wave-instruction per 4.2 cycles"}
+        # ---- per-call latency of orb_extractor::extract through the C++ class boundary at THIS config's size, H2D / D2H
+        # included (openvslam_amd/cpp/bench_shim; one call = one upload, one kernel chain, one D2H, one wait)
+        class_lat = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import class_latency
+                class_lat = class_latency.measure(ROWS, COLS, NFEAT, 100)
+            except Exception as ex_:   # a side section must never cost the headline line
+                class_lat = {"error": repr(ex_)}
 
         cpu = None
         if not args.no_cpu_baseline:
@@ -257,7 +326,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 1920x1080 mono, 8 pyramid levels (x1.2), 2000 ORB features, extract + "
                                    "robust::brute_force_match (thr 50, ratio 0.9) against the previous frame",
-                       "frames_per_step_per_gpu": B, "sharding": "frames across ranks, no collective",
+                       "frames_per_step_per_gpu": B, "distinct_input_batches": 2, "sharding": "frames across ranks, no collective",
                        "schedule": ("%d independent chain(s) of %d frames; " % (n_chain, Bc))
                                    + ("matching of step k on a second stream under the extraction of step k+1 (double-buffered)"
                                       if args.overlap else "extraction and matching serial on one stream")},
@@ -267,9 +336,12 @@ def main():
             "keypoints_per_frame": round(kp_step / B, 2),
             "matches_per_frame": round(matches_step / B, 2),
             "stage_ms_per_step": {k: round(v, 5) for k, v in stage_ms.items()},
+            "stage_ms_per_step_each_kernel_alone": {k: round(v, 5) for k, v in iso_ms.items()},
             "extract_algorithmic_GBps": round(extract_gbs, 2),
             "extract_frac_of_hbm_peak": round(extract_gbs / HBM_PEAK_GBS, 5),
             "roofline": roof,
+            "roofline_valu": roofline_valu,
+            "class_boundary_latency": class_lat,
             "cpu_baseline": cpu,
             "local_ba": ba_res,
             "other_configs": side,

@@ -91,23 +91,81 @@ __device__ __forceinline__ void topk_insert(uint32_t e, uint32_t (&t)[kTopK]) {
 }
 
 // ---- 1. all pairs, near lists -------------------------------------------------------------------------------------
-// Workgroup = 4 waves x the same 64 queries (idx_2); wave w scans the w-th quarter of the frame descriptors (idx_1), four
-// per trip so four s_load_dwordx8 are in flight together. Entries with d <= near_thr go to the wave's own segment of the
-// query's list (count in a register: no atomics, no waits in the loop) and into a sorted top-8 kept in registers; the four
-// partial top-8s are merged through LDS at the end.
+// Workgroup = 4 waves x the same 64 queries (idx_2); wave w scans the w-th quarter of the frame descriptors (idx_1). The descriptors
+// of the quarter stream through the scalar cache in groups of FOUR into two SGPR sets that are double-buffered: the loads of the next
+// group are in flight while the current one is XORed / popcounted (SMEM returns out of order, so only lgkmcnt(0) is a usable wait --
+// the overlap has to come from issuing early, not from partial waits). Entries with d <= near_thr go to the wave's own segment of the
+// query's list (count in a register: no atomics, no waits in the loop) and into a sorted top-8 kept in registers; the four partial
+// top-8s are merged through LDS at the end.
+//
+// v2 (round 2): (i) the popcount accumulate is pinned to the 8 x (v_xor, v_bcnt acc) chain -- hipcc split it into 6 independent
+// v_bcnt + 3 v_add3_u32 per descriptor (19 instead of 16 VALU per pair); (ii) 1-D grid in XCD-major order, so all chunks of a problem
+// run on ONE XCD and its 64 KB of frame descriptors are fetched into one L2 instead of eight (fabric traffic was 9.7x algorithmic);
+// (iii) the double-buffered scalar loads above.
+
+// d += popcount(a ^ b): one v_xor_b32 (SGPR operand) + one v_bcnt_u32_b32 with accumulate, kept as a chain
+// (asm volatile: volatile statements keep their program order, so the machine scheduler cannot sink the NEXT group's scalar loads
+// below this group's arithmetic -- which it does when the v_bcnt are ordinary instructions)
+__device__ __forceinline__ void xor_bcnt_acc(uint32_t& d, uint32_t a, uint32_t b_sgpr) {
+    const uint32_t x = a ^ b_sgpr;
+    asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x));
+}
+__device__ __forceinline__ void xor_bcnt_first(uint32_t& d, uint32_t a, uint32_t b_sgpr) {
+    const uint32_t x = a ^ b_sgpr;
+    asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(d) : "v"(x));
+}
+
+// SGPR sets pinned to fixed registers: the load statement and the wait statement must name the SAME physical registers (the loads land
+// asynchronously; a compiler-inserted copy between the two statements would copy stale values)
+#define OVS_SET_A0 "s[36:43]"
+#define OVS_SET_A1 "s[44:51]"
+#define OVS_SET_A2 "s[52:59]"
+#define OVS_SET_A3 "s[60:67]"
+#define OVS_SET_B0 "s[68:75]"
+#define OVS_SET_B1 "s[76:83]"
+#define OVS_SET_B2 "s[84:91]"
+#define OVS_SET_B3 "s[92:99]"
+
+#define OVS_ISSUE4(p, r0, r1, r2, r3, R0, R1, R2, R3)                                                                       \
+    asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_load_dwordx8 %3, %4, 0x60" \
+                 : "={" R0 "}"(r0), "={" R1 "}"(r1), "={" R2 "}"(r2), "={" R3 "}"(r3)                                        \
+                 : "s"(p)                                                                                                    \
+                 : "memory")
+#define OVS_WAIT4(r0, r1, r2, r3, R0, R1, R2, R3) \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+{" R0 "}"(r0), "+{" R1 "}"(r1), "+{" R2 "}"(r2), "+{" R3 "}"(r3)::"memory")
+
+__device__ __forceinline__ void dist4(const uint32_t (&a)[8], const u32x8& b0, const u32x8& b1, const u32x8& b2, const u32x8& b3, uint32_t& d0,
+                                      uint32_t& d1, uint32_t& d2, uint32_t& d3) {
+    xor_bcnt_first(d0, a[0], b0[0]);
+    xor_bcnt_first(d1, a[0], b1[0]);
+    xor_bcnt_first(d2, a[0], b2[0]);
+    xor_bcnt_first(d3, a[0], b3[0]);
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {   // four independent chains interleaved: no back-to-back dependent v_bcnt
+        xor_bcnt_acc(d0, a[i], b0[i]);
+        xor_bcnt_acc(d1, a[i], b1[i]);
+        xor_bcnt_acc(d2, a[i], b2[i]);
+        xor_bcnt_acc(d3, a[i], b3[i]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_hamming_near(const uint8_t* __restrict__ desc_1, size_t stride_1,
                                                      const int32_t* __restrict__ n1_arr, const uint8_t* __restrict__ desc_2,
                                                      size_t stride_2, const int32_t* __restrict__ n2_arr,
                                                      const uint8_t* __restrict__ valid_2, int max_n2, uint32_t near_thr,
                                                      uint32_t* __restrict__ near_cnt, uint32_t* __restrict__ near_list,
-                                                     uint32_t* __restrict__ near_top) {
+                                                     uint32_t* __restrict__ near_top, int chunks, int total_wg) {
     __shared__ uint32_t s_top[kNearSplit][kTopK][64];
-    const int p = blockIdx.y;
+    // XCD-major work order (workgroup b runs on XCD b % 8): XCD k takes the k-th contiguous eighth of the (problem, chunk) sequence
+    const int per_xcd = gridDim.x >> 3;
+    const int wg = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (wg >= total_wg) return;
+    const int p = wg / chunks, chunk_id = wg - p * chunks;
     const int n1 = n1_arr[p], n2 = n2_arr[p];
-    if ((int)blockIdx.x * 64 >= n2) return;
+    if (chunk_id * 64 >= n2) return;
     // wave index made provably uniform so the descriptor addresses below stay scalar (s_load_dwordx8)
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q = blockIdx.x * 64 + lane;
+    const int q = chunk_id * 64 + lane;
     const bool active = q < n2 && (!valid_2 || valid_2[(size_t)p * (stride_2 / 32) + q]);
     uint32_t a[8];
     {
@@ -115,7 +173,7 @@ __global__ __launch_bounds__(256) void k_hamming_near(const uint8_t* __restrict_
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = src[i];
     }
-    const int chunk = (((n1 + kNearSplit - 1) / kNearSplit) + 3) & ~3;
+    const int chunk = (((n1 + kNearSplit - 1) / kNearSplit) + 7) & ~7;
     const int jb = min(n1, wv * chunk), je = min(n1, jb + chunk);
     const uint32_t* __restrict__ t = reinterpret_cast<const uint32_t*>(desc_1 + (size_t)p * stride_1);
     uint32_t* my_seg = near_list + (((size_t)p * max_n2 + q) * kNearSplit + wv) * kNearSeg;
@@ -129,33 +187,44 @@ __global__ __launch_bounds__(256) void k_hamming_near(const uint8_t* __restrict_
         ++cnt;
         topk_insert(e, top);
     };
+    auto group = [&](uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, int j) {
+        // near distances are rare (the true match and near-duplicates): one test per four pairs on the common path
+        if (min(min(d0, d1), min(d2, d3)) <= near_thr) {
+            if (d0 <= near_thr) hit(d0, j);
+            if (d1 <= near_thr) hit(d1, j + 1);
+            if (d2 <= near_thr) hit(d2, j + 2);
+            if (d3 <= near_thr) hit(d3, j + 3);
+        }
+    };
     int j = jb;
     if (active) {
-        for (; j + 8 <= je; j += 8) {   // wave-uniform addresses: scalar loads, eight descriptors in flight
-            u32x8 b0, b1, b2, b3, b4, b5, b6, b7;
-            sload_desc8(t + (size_t)j * 8, b0, b1, b2, b3, b4, b5, b6, b7);
-            const uint32_t d0 = hamming256v(a, b0), d1 = hamming256v(a, b1), d2 = hamming256v(a, b2), d3 = hamming256v(a, b3);
-            const uint32_t d4 = hamming256v(a, b4), d5 = hamming256v(a, b5), d6 = hamming256v(a, b6), d7 = hamming256v(a, b7);
-            // near distances are rare (the true match and near-duplicates): one test per eight pairs on the common path
-            if (min(min(min(d0, d1), min(d2, d3)), min(min(d4, d5), min(d6, d7))) <= near_thr) {
-                if (d0 <= near_thr) hit(d0, j);
-                if (d1 <= near_thr) hit(d1, j + 1);
-                if (d2 <= near_thr) hit(d2, j + 2);
-                if (d3 <= near_thr) hit(d3, j + 3);
-                if (d4 <= near_thr) hit(d4, j + 4);
-                if (d5 <= near_thr) hit(d5, j + 5);
-                if (d6 <= near_thr) hit(d6, j + 6);
-                if (d7 <= near_thr) hit(d7, j + 7);
+        const int n8 = (je - jb) >> 3;   // iterations of 8 descriptors = one A group + one B group
+        if (n8 > 0) {
+            u32x8 a0, a1, a2, a3, b0, b1, b2, b3;
+            const uint32_t* pa = t + (size_t)j * 8;
+            OVS_ISSUE4(pa, a0, a1, a2, a3, OVS_SET_A0, OVS_SET_A1, OVS_SET_A2, OVS_SET_A3);
+            for (int it = 0; it < n8; ++it, j += 8) {
+                const uint32_t* pb = t + (size_t)(j + 4) * 8;
+                OVS_WAIT4(a0, a1, a2, a3, OVS_SET_A0, OVS_SET_A1, OVS_SET_A2, OVS_SET_A3);
+                OVS_ISSUE4(pb, b0, b1, b2, b3, OVS_SET_B0, OVS_SET_B1, OVS_SET_B2, OVS_SET_B3);
+                uint32_t d0, d1, d2, d3;
+                dist4(a, a0, a1, a2, a3, d0, d1, d2, d3);
+                group(d0, d1, d2, d3, j);
+                OVS_WAIT4(b0, b1, b2, b3, OVS_SET_B0, OVS_SET_B1, OVS_SET_B2, OVS_SET_B3);
+                if (it + 1 < n8) {   // wave-uniform: the next A group (the last iteration has none to fetch)
+                    const uint32_t* pn = t + (size_t)(j + 8) * 8;
+                    OVS_ISSUE4(pn, a0, a1, a2, a3, OVS_SET_A0, OVS_SET_A1, OVS_SET_A2, OVS_SET_A3);
+                }
+                dist4(a, b0, b1, b2, b3, d0, d1, d2, d3);
+                group(d0, d1, d2, d3, j + 4);
             }
         }
         for (; j + 4 <= je; j += 4) {   // remainder: four at a time
             u32x8 b0, b1, b2, b3;
             sload_desc4(t + (size_t)j * 8, b0, b1, b2, b3);
-            const uint32_t d0 = hamming256v(a, b0), d1 = hamming256v(a, b1), d2 = hamming256v(a, b2), d3 = hamming256v(a, b3);
-            if (d0 <= near_thr) hit(d0, j);
-            if (d1 <= near_thr) hit(d1, j + 1);
-            if (d2 <= near_thr) hit(d2, j + 2);
-            if (d3 <= near_thr) hit(d3, j + 3);
+            uint32_t d0, d1, d2, d3;
+            dist4(a, b0, b1, b2, b3, d0, d1, d2, d3);
+            group(d0, d1, d2, d3, j);
         }
         for (; j < je; ++j) {
             const uint32_t d = hamming256(a, t + (size_t)j * 8);
@@ -555,10 +624,11 @@ ovs_status run_bf(ovs_matcher* m, const uint8_t* d1, size_t stride_1, const int3
                   size_t stride_2, const int32_t* d_n2, const uint8_t* d_valid, int batch, float lowe_ratio, int32_t* d_pairs, int32_t* d_counts, int cap,
                   hipStream_t s) {
     const uint32_t thr = near_threshold(lowe_ratio);
-    dim3 grid((m->max_n2 + 63) / 64, batch);
+    const int chunks = (m->max_n2 + 63) / 64, total_wg = chunks * batch;
+    dim3 grid(((total_wg + 7) / 8) * 8);
     OVS_HIP_TRY(m->prof.begin(s));
     hipLaunchKernelGGL(k_hamming_near, grid, dim3(256), 0, s, d1, stride_1, d_n1, d2, stride_2, d_n2, d_valid, m->max_n2, thr,
-                       m->d_near_cnt, m->d_near_list, m->d_near_top);
+                       m->d_near_cnt, m->d_near_list, m->d_near_top, chunks, total_wg);
     OVS_HIP_TRY(hipGetLastError());
     OVS_HIP_TRY(m->prof.mark(1, s));
     if (m->resolve_lds_staged)

@@ -12,12 +12,12 @@ acc = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> [values pe
 for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            k = row.get("Kernel_Name", "?").split("(")[0]
+            k = row.get("Kernel_Name", "?").replace("(anonymous namespace)::", "").split("(")[0]
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 names = sorted({c for k in acc for c in acc[k]})
 print("# mean per dispatch; source: rocprofv3 --pmc (separate passes), %s" % root)
 for k in sorted(acc, key=lambda k: -sum(acc[k].get("SQ_WAVE_CYCLES", [0]))):
-    if "ovs" not in k:
+    if "ovs" not in k and not k.startswith("k_") and "void k_" not in k:
         continue
     print(k)
     for c in names:
@@ -46,5 +46,15 @@ if "--json" in sys.argv:
         nw = sum(len(acc[n].get("WRITE_SIZE", [])) for n in kk) or 1
         per_launch = (2.0 * f / nf + w / nw) * 1024.0
         out[st] = int(per_launch * launches_per_call.get(st, 1))
+    # VALU / SALU wave-instructions per stage call (SQ pass) for bench.py's roofline_valu
+    for cname, key in (("SQ_INSTS_VALU", "insts_valu"), ("SQ_INSTS_SALU", "insts_salu")):
+        d = {}
+        for k, st in stage_of.items():
+            kk = [n for n in acc if k in n]
+            vals = [v for n in kk for v in acc[n].get(cname, [])]
+            if vals:
+                d[st] = int(sum(vals) / len(vals) * launches_per_call.get(st, 1))
+        if d:
+            out[key] = d
     json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
     print("traffic bytes per stage call:", out)

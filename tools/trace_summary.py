@@ -9,7 +9,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 acc = defaultdict(list)
 per_grid = defaultdict(list)
 for r in rows:
-    name = r["Kernel_Name"].split("(")[0]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     acc[name].append(dur)
     per_grid[(name, r.get("Grid_Size_X", "?"), r.get("Grid_Size_Y", "?"), r.get("Grid_Size_Z", "?"))].append(dur)
