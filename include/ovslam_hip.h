@@ -466,6 +466,22 @@ ovs_status ovs_ba_linearize_stereo_dev(const double* d_poses, const uint8_t* d_p
                                        double focal_x_baseline, double huber_delta, int32_t accumulate, double* d_Hpp, double* d_bp,
                                        double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream);
 
+/* Atomics-free form of the same linearisation (round 2): the edge set is indexed ONCE (by landmark and by keyframe) into a graph handle
+ * resident in HBM; every call then evaluates Hll | bl by one lane per landmark over its edges in ascending index (exactly the order a
+ * sequential loop adds them: bit-identical to the CPU oracle), Hpl per edge, Hpp | bp by one workgroup per keyframe with a fixed-shape
+ * tree, chi2 by a fixed tree -- identical bits from run to run, no fp64 atomics. mono / stereo edges as for ovs_ba_linearize(_stereo);
+ * Hpl rows: the mono edges in input order, then the stereo edges. d_chi2 receives THREE doubles: chi2, robustified chi2, and
+ * max |diagonal| over the free pose blocks and the landmarks that have edges (g2o's computeLambdaInit input). huber_mono / huber_stereo:
+ * the Huber deltas of the two edge kinds (0 = no kernel). For an edge shard (multi-GPU: edges partitioned by keyframe) build the graph
+ * from the shard; Hll | bl | chi2 are then partial sums to be all-reduced, Hpp | bp are complete on the shard that owns the keyframe. */
+typedef struct ovs_ba_graph ovs_ba_graph;
+ovs_status ovs_ba_graph_create(int32_t device, int32_t n_pose, const uint8_t* pose_fixed, int32_t n_pt, const ovs_ba_edge* mono, int32_t n_mono,
+                               const ovs_ba_edge_stereo* stereo, int32_t n_stereo, const ovs_ba_cam* cam, double focal_x_baseline,
+                               ovs_ba_graph** out);
+ovs_status ovs_ba_graph_destroy(ovs_ba_graph* g);
+ovs_status ovs_ba_graph_linearize_dev(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo,
+                                      double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Bag-of-words transform.  replaces: the per-descriptor tree descent of DBoW2::TemplatedVocabulary::transform(
  *   const std::vector<TDescriptor>& features, BowVector& v, FeatureVector& fv, int levelsup) as called by data::frame::compute_bow /

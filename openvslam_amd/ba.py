@@ -137,49 +137,123 @@ def shard_edges_by_keyframe(edges, n_pose, rank, world):
     return np.ascontiguousarray(edges[sel])
 
 
+class graph:
+    """ovs_ba_graph: a local-BA edge set indexed once (by landmark and by keyframe) and kept in HBM; linearize() is atomics-free and
+    bit-reproducible. edges / stereo_edges: EDGE_DTYPE / EDGE_STEREO_DTYPE records (host). For a multi-rank shard pass the shard's edges."""
+
+    def __init__(self, n_pose, pose_fixed, n_pt, edges, cam, stereo_edges=None, focal_x_baseline=0.0, device=0):
+        self._L = _lib.lib()
+        _lib.require_device()
+        em = np.ascontiguousarray(edges if edges is not None else np.zeros(0, EDGE_DTYPE), EDGE_DTYPE)
+        es = np.ascontiguousarray(stereo_edges if stereo_edges is not None else np.zeros(0, EDGE_STEREO_DTYPE), EDGE_STEREO_DTYPE)
+        fixed = None if pose_fixed is None else np.ascontiguousarray(pose_fixed, np.uint8)
+        self.n_pose, self.n_pt, self.n_edge = int(n_pose), int(n_pt), len(em) + len(es)
+        h = C.c_void_p()
+        c = BaCam(*cam)
+        _lib.check(self._L.ovs_ba_graph_create(device, self.n_pose, _p(fixed), self.n_pt, _p(em) if len(em) else None, len(em),
+                                               _p(es) if len(es) else None, len(es), C.byref(c), float(focal_x_baseline), C.byref(h)),
+                   "ovs_ba_graph_create")
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.ovs_ba_graph_destroy(h)
+
+    def linearize_dev(self, poses_t, points_t, huber_mono, huber_stereo=0.0, out=None, stream=None):
+        """torch CUDA tensors in; returns dict of views into TWO device buffers: `pose` = Hpp | bp (complete on the shard that owns the
+        keyframe) and `packed` = Hll | bl | chi2[3] (what a multi-rank run all-reduces, in ONE collective), plus Hpl."""
+        import torch
+        dev = poses_t.device
+        n_pose, n_pt, n_edge = self.n_pose, self.n_pt, self.n_edge
+        if out is None:
+            out = dict(pose=torch.empty((42 * n_pose,), dtype=torch.float64, device=dev),
+                       packed=torch.empty((12 * n_pt + 4,), dtype=torch.float64, device=dev),
+                       hpl=torch.empty((max(n_edge, 1), 18), dtype=torch.float64, device=dev))
+        bp_, bl_ = out["pose"].data_ptr(), out["packed"].data_ptr()
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(self._L.ovs_ba_graph_linearize_dev(self._h, poses_t.data_ptr(), points_t.data_ptr(), float(huber_mono), float(huber_stereo),
+                                                      bp_, bp_ + 8 * 36 * n_pose, bl_, bl_ + 8 * 9 * n_pt, out["hpl"].data_ptr(),
+                                                      bl_ + 8 * 12 * n_pt, stream), "ovs_ba_graph_linearize_dev")
+        return out
+
+    @staticmethod
+    def views(out, n_pose, n_pt, n_edge):
+        return dict(Hpp=out["pose"][:36 * n_pose].view(n_pose, 6, 6), bp=out["pose"][36 * n_pose:].view(n_pose, 6),
+                    Hll=out["packed"][:9 * n_pt].view(n_pt, 3, 3), bl=out["packed"][9 * n_pt:12 * n_pt].view(n_pt, 3),
+                    chi2=out["packed"][12 * n_pt:12 * n_pt + 2], max_diag=out["packed"][12 * n_pt + 2:12 * n_pt + 3],
+                    Hpl=out["hpl"][:n_edge].view(-1, 6, 3))
+
+
 def hip_backend(poses_t, fixed_t, points_t, edges_t, cam, huber_delta):
-    """Local shard on the current CUDA device through ovs_ba_linearize_dev. Tensors are torch CUDA tensors; edges_t is a uint8
-    tensor viewing EDGE_DTYPE records. Returns (HppBp [n_pose,42], HllBl [12*n_pt] = Hll|bl, Hpl [n_edge,18], chi2 [2])."""
+    """Local shard on the current CUDA device through ovs_ba_linearize_dev (the round-1 atomics kernel; kept for comparison). Tensors are
+    torch CUDA tensors; edges_t is a uint8 tensor viewing EDGE_DTYPE records. Returns (HppBp [n_pose*42], packed [12*n_pt + 4] =
+    Hll | bl | chi2, Hpl [n_edge,18])."""
     import torch
     L = _lib.lib()
     n_pose, n_pt, n_edge = poses_t.shape[0], points_t.shape[0], edges_t.numel() // 32
     dev = poses_t.device
     hppbp = torch.empty((n_pose * 42,), dtype=torch.float64, device=dev)
-    hllbl = torch.empty((n_pt * 12,), dtype=torch.float64, device=dev)
+    packed = torch.zeros((n_pt * 12 + 4,), dtype=torch.float64, device=dev)
     hpl = torch.empty((max(n_edge, 1), 18), dtype=torch.float64, device=dev)
-    chi2 = torch.empty((2,), dtype=torch.float64, device=dev)
     c = BaCam(*cam)
-    base_pp, base_ll = hppbp.data_ptr(), hllbl.data_ptr()
+    base_pp, base_ll = hppbp.data_ptr(), packed.data_ptr()
     _lib.check(L.ovs_ba_linearize_dev(poses_t.data_ptr(), fixed_t.data_ptr() if fixed_t is not None else None, n_pose, points_t.data_ptr(),
                                       n_pt, edges_t.data_ptr() if n_edge else None, n_edge, C.byref(c), float(huber_delta),
-                                      base_pp, base_pp + 8 * 36 * n_pose, base_ll, base_ll + 8 * 9 * n_pt, hpl.data_ptr(), chi2.data_ptr(),
-                                      torch.cuda.current_stream().cuda_stream), "ovs_ba_linearize_dev")
-    return hppbp, hllbl, hpl[:n_edge], chi2
+                                      base_pp, base_pp + 8 * 36 * n_pose, base_ll, base_ll + 8 * 9 * n_pt, hpl.data_ptr(),
+                                      base_ll + 8 * 12 * n_pt, torch.cuda.current_stream().cuda_stream), "ovs_ba_linearize_dev")
+    return hppbp, packed, hpl[:n_edge]
+
+
+class graph_backend:
+    """Default shard backend of local_ba_linearizer: the atomics-free graph (built once per edge set, cached by the edge tensor)."""
+
+    def __init__(self):
+        self._key, self._g, self._out = None, None, None
+
+    def __call__(self, poses_t, fixed_t, points_t, edges_t, cam, huber_delta):
+        key = (edges_t.data_ptr(), edges_t.numel(), poses_t.shape[0], points_t.shape[0])
+        if key != self._key:
+            edges = np.ascontiguousarray(edges_t.cpu().numpy()).view(EDGE_DTYPE)
+            fixed = fixed_t.cpu().numpy() if fixed_t is not None else None
+            self._g = graph(poses_t.shape[0], fixed, points_t.shape[0], edges, cam, device=poses_t.device.index or 0)
+            self._key, self._out = key, None
+        self._out = self._g.linearize_dev(poses_t, points_t, huber_delta, 0.0, out=self._out)
+        return self._out["pose"], self._out["packed"], self._out["hpl"][:self._g.n_edge]
 
 
 class local_ba_linearizer:
     """One Levenberg-Marquardt linearisation of the local map, sharded over the ranks of a torch.distributed group.
 
-    Every rank holds all poses and points (0.48 MB at config 5: broadcast/replicated by the caller) and ITS shard of the edges.
-    `backend` computes the shard's partial blocks; the default is the HIP kernel."""
+    Every rank holds all poses and points (0.48 MB at config 5: replicated by the caller) and ITS shard of the edges (whole keyframes).
+    `backend(poses, fixed, points, edges, cam, huber)` computes the shard's blocks and returns (HppBp, packed = Hll | bl | chi2, Hpl).
+    THE exchange step of this path is ONE all-reduce of `packed` (landmarks are shared between keyframes on different ranks; 1.92 MB at
+    20 k landmarks -- latency-dominated, so never three collectives where one does). Hpp | bp need no collective: a keyframe's block is
+    complete on the rank that owns its edges and zero elsewhere; `gather_pose_blocks=True` sums them onto every rank (only the rank that
+    solves the reduced camera system needs them -- pass dst to reduce instead of all-reduce)."""
 
-    def __init__(self, cam, huber_delta, group=None, backend=hip_backend):
+    def __init__(self, cam, huber_delta, group=None, backend=None, gather_pose_blocks=True, dst=None):
         self.cam = tuple(float(v) for v in cam)
         self.huber_delta = float(huber_delta)
         self.group = group
-        self.backend = backend
+        self.backend = backend if backend is not None else graph_backend()
+        self.gather_pose_blocks = gather_pose_blocks
+        self.dst = dst
 
     def linearize(self, poses_t, fixed_t, points_t, edges_t):
         import torch.distributed as dist
-        hppbp, hllbl, hpl, chi2 = self.backend(poses_t, fixed_t, points_t, edges_t, self.cam, self.huber_delta)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            # THE exchange step of this path: landmark blocks are shared between keyframes on different ranks
-            dist.all_reduce(hllbl, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(hppbp, op=dist.ReduceOp.SUM, group=self.group)   # replicate the (rank-exclusive) pose blocks: 50 x 42 f64
-            dist.all_reduce(chi2, op=dist.ReduceOp.SUM, group=self.group)
+        hppbp, packed, hpl = self.backend(poses_t, fixed_t, points_t, edges_t, self.cam, self.huber_delta)
         n_pose, n_pt = poses_t.shape[0], points_t.shape[0]
-        return dict(Hpp=hppbp[:36 * n_pose].view(n_pose, 6, 6), bp=hppbp[36 * n_pose:].view(n_pose, 6), Hll=hllbl[:9 * n_pt].view(n_pt, 3, 3),
-                    bl=hllbl[9 * n_pt:].view(n_pt, 3), Hpl=hpl.view(-1, 6, 3), chi2=chi2)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(packed[:12 * n_pt + 2], op=dist.ReduceOp.SUM, group=self.group)
+            if self.gather_pose_blocks:
+                if self.dst is None:
+                    dist.all_reduce(hppbp, op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    dist.reduce(hppbp, self.dst, op=dist.ReduceOp.SUM, group=self.group)
+        return dict(Hpp=hppbp[:36 * n_pose].view(n_pose, 6, 6), bp=hppbp[36 * n_pose:].view(n_pose, 6), Hll=packed[:9 * n_pt].view(n_pt, 3, 3),
+                    bl=packed[9 * n_pt:12 * n_pt].view(n_pt, 3), Hpl=hpl.view(-1, 6, 3), chi2=packed[12 * n_pt:12 * n_pt + 2])
 
 
 # ---------------------------------------------------------------------------------------------------------------------

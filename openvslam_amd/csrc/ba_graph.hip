@@ -1,0 +1,729 @@
+// ba_graph.hip -- B1-B4 without atomics: a local-BA graph resident in HBM (edges indexed by landmark and by keyframe once per edge set),
+// deterministic linearisation, landmark elimination (Schur complement) and back-substitution on the device
+// (expected: src/openvslam/optimize/local_bundle_adjuster.cc; g2o BlockSolver_6_3::buildSystem / ::solve, OptimizationAlgorithmLevenberg).
+//
+// Why: k_ba_linearize issued 1.2 M scattered fp64 atomics per linearisation (0.022 of HBM, sums that change from
+// run to run), and ovs_local_ba_optimize downloaded 16 MB of blocks per Levenberg-Marquardt trial to eliminate the landmarks on the host.
+// Here every sum has a fixed order:
+//   k_lin_landmark   one lane per landmark walks ITS edges in ascending index (mono first, then stereo -- the oracle's association):
+//                    Hll | bl exactly as a sequential loop would add them, Hpl per edge, per-landmark chi2 partials;
+//   k_lin_pose       one workgroup per keyframe over ITS edges: 21 + 6 pose-block terms per lane, fixed-shape tree reduction;
+//   k_reduce_scalars chi2 (and the Levenberg-Marquardt start damping: max |H_jj|) by one workgroup, fixed tree;
+//   k_lm_prepare     (Hll + lambda I)^-1 per landmark and Y_e = W_e Hll^-1 per edge;
+//   k_schur_pairs    one workgroup per pair of free keyframes (a, b >= a): S_ab = [a == b](Hpp_a + lambda I) - sum over the landmarks both
+//                    observe of Y_ea W_eb^T, the pair's entry list built once per edge set on the host;
+//   k_schur_rhs      g_a = bp_a - sum over a's edges of Y_e bl_j;
+//   (host)           Cholesky of the reduced camera system, at most 6 n_pose square -- BASELINE's north star keeps this solve on the host;
+//   k_backsub        dxl_j = Hll^-1 (bl_j - sum W_e^T dxp), the trial points X + dxl and the landmark part of g2o's gain-ratio scale.
+// Per trial 0.7 MB (S, g, bp) come down and 5 KB (poses, dxp) go up, instead of 16 MB down.
+// Per-edge arithmetic is the expression sequence of k_ba_linearize / the oracle (every product individually rounded), so Hpl, Hll and bl
+// are bit-identical to the CPU oracle; Hpp, bp and chi2 are tree sums (1e-15 relative), identical from run to run.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ovs_common.h"
+
+namespace ovs {
+
+struct GEdge {   // mono and stereo observations in one record; stereo iff index >= n_mono
+    int32_t pose, pt;
+    double ox, oy, oxr, w;
+};
+
+// Jacobians are carried as [3][6] arrays; the third row is zero for a mono edge (never read: dot3 stops at two rows)
+__device__ __forceinline__ double dot3(const double (&A)[3][6], int a, const double (&B)[3][6], int b, bool stereo) {
+    double s = A[0][a] * B[0][b];
+    s = s + A[1][a] * B[1][b];
+    if (stereo) s = s + A[2][a] * B[2][b];
+    return s;
+}
+
+// residual, Jacobians, Huber weight of one perspective edge -- the operation order of k_ba_linearize<2|3> (model 0) and of the CPU oracle
+__device__ __forceinline__ void edge_lin(const double* __restrict__ P, const double* __restrict__ X, const GEdge& ed, bool stereo,
+                                         const ovs_ba_cam& cam, double bf, double huber, double (&Jl)[3][6], double (&Jp)[3][6], double (&r)[3],
+                                         double& W, double& c2, double& rho0) {
+    const double qx = P[3], qy = P[4], qz = P[5], qw = P[6];
+    const double tx2 = 2 * qx, ty2 = 2 * qy, tz2 = 2 * qz;
+    const double twx = tx2 * qw, twy = ty2 * qw, twz = tz2 * qw;
+    const double txx = tx2 * qx, txy = ty2 * qx, txz = tz2 * qx;
+    const double tyy = ty2 * qy, tyz = tz2 * qy, tzz = tz2 * qz;
+    const double R[3][3] = {{1 - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1 - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1 - (txx + tyy)}};
+    const double X0 = X[0], X1 = X[1], X2 = X[2];
+    const double x = R[0][0] * X0 + R[0][1] * X1 + R[0][2] * X2 + P[0];
+    const double y = R[1][0] * X0 + R[1][1] * X1 + R[1][2] * X2 + P[1];
+    const double z = R[2][0] * X0 + R[2][1] * X1 + R[2][2] * X2 + P[2];
+    const double invz = 1.0 / z, invz2 = invz * invz;
+    double er[3] = {0.0, 0.0, 0.0};
+    const double u = cam.fx * x * invz + cam.cx;
+    er[0] = ed.ox - u;
+    er[1] = ed.oy - (cam.fy * y * invz + cam.cy);
+    double ss = er[0] * er[0] + er[1] * er[1];
+    if (stereo) {
+        er[2] = ed.oxr - (u - bf * invz);
+        ss = ss + er[2] * er[2];
+    }
+    const double w = ed.w;
+    c2 = w * ss;
+    rho0 = c2;
+    double rho1 = 1.0;
+    const double dsqr = huber * huber;
+    if (huber > 0 && c2 > dsqr) {
+        const double sq = sqrt(c2);
+        rho0 = 2 * sq * huber - dsqr;
+        rho1 = huber / sq;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Jl[0][c] = Jl[1][c] = Jl[2][c] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Jl[0][c] = -invz * (cam.fx * R[0][c] - cam.fx * x * invz * R[2][c]);
+        Jl[1][c] = -invz * (cam.fy * R[1][c] - cam.fy * y * invz * R[2][c]);
+        Jl[2][c] = stereo ? Jl[0][c] - bf * R[2][c] * invz2 : 0.0;
+    }
+    Jp[0][0] = x * y * invz2 * cam.fx;
+    Jp[0][1] = -(1 + x * x * invz2) * cam.fx;
+    Jp[0][2] = y * invz * cam.fx;
+    Jp[0][3] = -invz * cam.fx;
+    Jp[0][4] = 0;
+    Jp[0][5] = x * invz2 * cam.fx;
+    Jp[1][0] = (1 + y * y * invz2) * cam.fy;
+    Jp[1][1] = -x * y * invz2 * cam.fy;
+    Jp[1][2] = -x * invz * cam.fy;
+    Jp[1][3] = 0;
+    Jp[1][4] = -invz * cam.fy;
+    Jp[1][5] = y * invz2 * cam.fy;
+    if (stereo) {
+        Jp[2][0] = Jp[0][0] - bf * y * invz2;
+        Jp[2][1] = Jp[0][1] + bf * x * invz2;
+        Jp[2][2] = Jp[0][2];
+        Jp[2][3] = Jp[0][3];
+        Jp[2][4] = 0;
+        Jp[2][5] = Jp[0][5] - bf * invz2;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Jp[2][c] = 0.0;
+    }
+    W = rho1 * w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r[k] = -W * er[k];
+}
+
+struct GraphDev {   // device views shared by the kernels
+    const GEdge* edges;
+    int n_mono, n_edge, n_pose, n_pt;
+    const int32_t* lm_start;     // [n_pt + 1] into lm_edges; per landmark: mono edges ascending, then stereo edges ascending
+    const int32_t* lm_edges;
+    const int32_t* lm_nmono;     // [n_pt] how many of the landmark's edges are mono
+    const int32_t* pose_start;   // [n_pose + 1] into pose_edges
+    const int32_t* pose_edges;
+    const uint8_t* fixed;        // [n_pose]
+    ovs_ba_cam cam;
+    double bf;
+};
+
+// ---- linearisation ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_lin_landmark(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points,
+                                                     double huber_mono, double huber_stereo, double* __restrict__ Hll, double* __restrict__ bl,
+                                                     double* __restrict__ Hpl, double* __restrict__ lm_chi) {
+    const int j = blockIdx.x * 128 + threadIdx.x;
+    if (j >= g.n_pt) return;
+    const double* X = points + 3 * (size_t)j;
+    double hm[9], gm[3], hs[9], gs[3];   // mono and stereo partial sums kept apart: the oracle adds (mono total) + (stereo total)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) hm[i] = hs[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gm[i] = gs[i] = 0.0;
+    double c2m = 0, r0m = 0, c2s = 0, r0s = 0;
+    const int e0 = g.lm_start[j], e1 = g.lm_start[j + 1], nm = g.lm_nmono[j];
+    auto body = [&](const bool stereo, double (&h)[9], double (&gg)[3], double& c2a, double& r0a, int i) __attribute__((always_inline)) {
+        const int e = g.lm_edges[i];
+        const GEdge ed = g.edges[e];
+        double Jl[3][6], Jp[3][6], r[3], W, c2, rho0;
+        edge_lin(poses + 7 * (size_t)ed.pose, X, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) h[3 * a + b] += W * dot3(Jl, a, Jl, b, stereo);
+            double t = Jl[0][a] * r[0];
+            t = t + Jl[1][a] * r[1];
+            if (stereo) t = t + Jl[2][a] * r[2];
+            gg[a] += t;
+        }
+        const bool free_pose = !g.fixed[ed.pose];
+        double* hpl = Hpl + 18 * (size_t)e;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) hpl[3 * a + b] = free_pose ? W * dot3(Jp, a, Jl, b, stereo) : 0.0;
+        c2a += c2;
+        r0a += rho0;
+    };
+    for (int i = e0; i < e0 + nm; ++i) body(false, hm, gm, c2m, r0m, i);
+    for (int i = e0 + nm; i < e1; ++i) body(true, hs, gs, c2s, r0s, i);
+    double* H = Hll + 9 * (size_t)j;
+    double* B = bl + 3 * (size_t)j;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) H[i] = hm[i] + hs[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) B[i] = gm[i] + gs[i];
+    lm_chi[2 * (size_t)j] = c2m + c2s;
+    lm_chi[2 * (size_t)j + 1] = r0m + r0s;
+}
+
+// fixed-shape reduction of NV per-thread values over a 256-thread workgroup: lanes by xor-shuffle, then the four waves in order
+template <int NV>
+__device__ __forceinline__ void block_sum_256(double (&v)[NV], double (*s_part)[NV]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double x = v[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        if (lane == 0) s_part[wv][i] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = ((s_part[0][i] + s_part[1][i]) + s_part[2][i]) + s_part[3][i];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_lin_pose(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points,
+                                                 double huber_mono, double huber_stereo, double* __restrict__ Hpp, double* __restrict__ bp) {
+    __shared__ double s_part[4][27];
+    const int k = blockIdx.x;
+    double acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+    const bool free_pose = !g.fixed[k];
+    if (free_pose) {
+        const double* P = poses + 7 * (size_t)k;
+        const int e0 = g.pose_start[k], e1 = g.pose_start[k + 1];
+        for (int i = e0 + (int)threadIdx.x; i < e1; i += 256) {
+            const int e = g.pose_edges[i];
+            const bool stereo = e >= g.n_mono;
+            const GEdge ed = g.edges[e];
+            double Jl[3][6], Jp[3][6], r[3], W, c2, rho0;
+            edge_lin(P, points + 3 * (size_t)ed.pt, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
+            int t = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                for (int b = a; b < 6; ++b) acc[t++] += W * dot3(Jp, a, Jp, b, stereo);
+                double gq = Jp[0][a] * r[0];
+                gq = gq + Jp[1][a] * r[1];
+                if (stereo) gq = gq + Jp[2][a] * r[2];
+                acc[t++] += gq;
+            }
+        }
+    }
+    block_sum_256<27>(acc, s_part);
+    if (threadIdx.x == 0) {
+        double* hp = Hpp + 36 * (size_t)k;
+        double* gp = bp + 6 * (size_t)k;
+        int t = 0;
+        for (int a = 0; a < 6; ++a) {
+            for (int b = a; b < 6; ++b) {
+                hp[6 * a + b] = acc[t];
+                hp[6 * b + a] = acc[t];
+                ++t;
+            }
+            gp[a] = acc[t++];
+        }
+    }
+}
+
+// chi2[0..1] = sum of the per-landmark partials; chi2[2] = max |diagonal| over free pose blocks and landmarks with edges (g2o's
+// computeLambdaInit); one workgroup, fixed order
+__global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const double* __restrict__ lm_chi, const double* __restrict__ Hpp,
+                                                        const double* __restrict__ Hll, double* __restrict__ chi2) {
+    __shared__ double s0[1024], s1[1024], s2[1024];
+    double a = 0, b = 0, m = 0;
+    for (int j = threadIdx.x; j < g.n_pt; j += 1024) {
+        a += lm_chi[2 * (size_t)j];
+        b += lm_chi[2 * (size_t)j + 1];
+        if (g.lm_start[j + 1] > g.lm_start[j])
+            for (int d = 0; d < 3; ++d) m = fmax(m, fabs(Hll[9 * (size_t)j + 4 * d]));
+    }
+    for (int k = threadIdx.x; k < g.n_pose; k += 1024)
+        if (!g.fixed[k])
+            for (int d = 0; d < 6; ++d) m = fmax(m, fabs(Hpp[36 * (size_t)k + 7 * d]));
+    s0[threadIdx.x] = a;
+    s1[threadIdx.x] = b;
+    s2[threadIdx.x] = m;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s0[threadIdx.x] += s0[threadIdx.x + w];
+            s1[threadIdx.x] += s1[threadIdx.x + w];
+            s2[threadIdx.x] = fmax(s2[threadIdx.x], s2[threadIdx.x + w]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        chi2[0] = s0[0];
+        chi2[1] = s1[0];
+        chi2[2] = s2[0];
+    }
+}
+
+// ---- landmark elimination ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool inv3_sym_d(const double* H, double lambda, double* out) {   // (H + lambda I)^-1 by cofactors
+    const double a = H[0] + lambda, b = H[1], c = H[2], d = H[4] + lambda, e = H[5], f = H[8] + lambda;
+    const double A = d * f - e * e, B = c * e - b * f, Cc = b * e - c * d;
+    const double det = (a * A + b * B) + c * Cc;
+    if (!(fabs(det) > 0.0) || !isfinite(det)) return false;
+    const double id = 1.0 / det;
+    out[0] = A * id;
+    out[1] = out[3] = B * id;
+    out[2] = out[6] = Cc * id;
+    out[4] = (a * f - c * c) * id;
+    out[5] = out[7] = (b * c - a * e) * id;
+    out[8] = (a * d - b * b) * id;
+    return true;
+}
+
+__global__ __launch_bounds__(128) void k_lm_prepare(GraphDev g, const double* __restrict__ Hll, const double* __restrict__ Hpl, double lambda,
+                                                   double* __restrict__ Hinv, double* __restrict__ Y, int32_t* __restrict__ fail) {
+    const int j = blockIdx.x * 128 + threadIdx.x;
+    if (j >= g.n_pt) return;
+    double Hi[9];
+    if (!inv3_sym_d(Hll + 9 * (size_t)j, lambda, Hi)) {
+        *fail = 1;   // benign race: every writer stores 1
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Hinv[9 * (size_t)j + i] = Hi[i];
+    for (int i = g.lm_start[j]; i < g.lm_start[j + 1]; ++i) {
+        const int e = g.lm_edges[i];
+        const double* W = Hpl + 18 * (size_t)e;
+        double* y = Y + 18 * (size_t)e;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) y[3 * a + c] = (W[3 * a] * Hi[c] + W[3 * a + 1] * Hi[3 + c]) + W[3 * a + 2] * Hi[6 + c];
+    }
+}
+
+// S block (a, b), a <= b in slot order: entries = (edge of a, edge of b) pairs that share a landmark
+__global__ __launch_bounds__(256) void k_schur_pairs(const int32_t* __restrict__ pair_start, const int2* __restrict__ pair_ent,
+                                                    const int32_t* __restrict__ pair_ab, const int32_t* __restrict__ slot_pose,
+                                                    const double* __restrict__ Hpp, const double* __restrict__ Hpl, const double* __restrict__ Y,
+                                                    double lambda, int n, double* __restrict__ S) {
+    __shared__ double s_part[4][36];
+    const int pr = blockIdx.x;
+    const int sa = pair_ab[2 * pr], sb = pair_ab[2 * pr + 1];
+    double acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+    for (int i = pair_start[pr] + (int)threadIdx.x; i < pair_start[pr + 1]; i += 256) {
+        const int2 en = pair_ent[i];
+        const double* y = Y + 18 * (size_t)en.x;
+        const double* W2 = Hpl + 18 * (size_t)en.y;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) acc[6 * a + b] += (y[3 * a] * W2[3 * b] + y[3 * a + 1] * W2[3 * b + 1]) + y[3 * a + 2] * W2[3 * b + 2];
+    }
+    block_sum_256<36>(acc, s_part);
+    if (threadIdx.x == 0) {   // (a register array must not be indexed by threadIdx: that would put it in scratch)
+#pragma unroll
+        for (int i = 0; i < 36; ++i) s_part[0][i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        const int a = threadIdx.x / 6, b = threadIdx.x - 6 * a;
+        double v = -s_part[0][threadIdx.x];
+        if (sa == sb) v = (Hpp[36 * (size_t)slot_pose[sa] + 6 * a + b] + (a == b ? lambda : 0.0)) + v;
+        S[(size_t)(6 * sa + a) * n + 6 * sb + b] = v;
+        if (sa != sb) S[(size_t)(6 * sb + b) * n + 6 * sa + a] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_schur_rhs(GraphDev g, const int32_t* __restrict__ slot_pose, const double* __restrict__ bp,
+                                                  const double* __restrict__ bl, const double* __restrict__ Y, double* __restrict__ rhs) {
+    __shared__ double s_part[4][6];
+    const int s = blockIdx.x, k = slot_pose[s];
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = g.pose_start[k] + (int)threadIdx.x; i < g.pose_start[k + 1]; i += 256) {
+        const int e = g.pose_edges[i];
+        const double* y = Y + 18 * (size_t)e;
+        const double* b = bl + 3 * (size_t)g.edges[e].pt;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[a] += (y[3 * a] * b[0] + y[3 * a + 1] * b[1]) + y[3 * a + 2] * b[2];
+    }
+    block_sum_256<6>(acc, s_part);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) rhs[6 * s + a] = bp[6 * (size_t)k + a] - acc[a];
+    }
+}
+
+// dxl_j = Hll^-1 (bl_j - sum_e W_e^T dxp[pose(e)]); X_trial = X + dxl; lm_scale[j] = dxl . (lambda dxl + bl_j)
+__global__ __launch_bounds__(128) void k_backsub(GraphDev g, const double* __restrict__ Hinv, const double* __restrict__ Hpl,
+                                                const double* __restrict__ bl, const double* __restrict__ dxp, double lambda,
+                                                const double* __restrict__ X, double* __restrict__ Xn, double* __restrict__ lm_scale) {
+    const int j = blockIdx.x * 128 + threadIdx.x;
+    if (j >= g.n_pt) return;
+    double r[3] = {bl[3 * (size_t)j], bl[3 * (size_t)j + 1], bl[3 * (size_t)j + 2]};
+    for (int i = g.lm_start[j]; i < g.lm_start[j + 1]; ++i) {
+        const int e = g.lm_edges[i];
+        const int k = g.edges[e].pose;
+        if (g.fixed[k]) continue;
+        const double* W = Hpl + 18 * (size_t)e;
+        const double* d = dxp + 6 * (size_t)k;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            r[c] -= ((W[c] * d[0] + W[3 + c] * d[1]) + (W[6 + c] * d[2] + W[9 + c] * d[3])) + (W[12 + c] * d[4] + W[15 + c] * d[5]);
+    }
+    const double* Hi = Hinv + 9 * (size_t)j;
+    double sc = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double dl = (Hi[3 * c] * r[0] + Hi[3 * c + 1] * r[1]) + Hi[3 * c + 2] * r[2];
+        Xn[3 * (size_t)j + c] = X[3 * (size_t)j + c] + dl;
+        sc += dl * (lambda * dl + bl[3 * (size_t)j + c]);
+    }
+    lm_scale[j] = sc;
+}
+
+__global__ __launch_bounds__(1024) void k_sum_1024(const double* __restrict__ v, int n, double* __restrict__ out) {
+    __shared__ double s0[1024];
+    double a = 0;
+    for (int j = threadIdx.x; j < n; j += 1024) a += v[j];
+    s0[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s0[threadIdx.x] += s0[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s0[0];
+}
+
+// per-edge chi2 = e^T Omega e (no kernel) and the sign of the depth (reproj_edge_wrapper::depth_is_positive)
+__global__ __launch_bounds__(256) void k_edge_chi2(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points,
+                                                  double* __restrict__ chi2, uint8_t* __restrict__ depth_pos) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= g.n_edge) return;
+    const GEdge ed = g.edges[e];
+    const bool stereo = e >= g.n_mono;
+    const double* P = poses + 7 * (size_t)ed.pose;
+    const double* X = points + 3 * (size_t)ed.pt;
+    const double qx = P[3], qy = P[4], qz = P[5], qw = P[6];
+    const double tx2 = 2 * qx, ty2 = 2 * qy, tz2 = 2 * qz;
+    const double twx = tx2 * qw, twy = ty2 * qw, twz = tz2 * qw;
+    const double txx = tx2 * qx, txy = ty2 * qx, txz = tz2 * qx;
+    const double tyy = ty2 * qy, tyz = tz2 * qy, tzz = tz2 * qz;
+    const double x = (1 - (tyy + tzz)) * X[0] + (txy - twz) * X[1] + (txz + twy) * X[2] + P[0];
+    const double y = (txy + twz) * X[0] + (1 - (txx + tzz)) * X[1] + (tyz - twx) * X[2] + P[1];
+    const double z = (txz - twy) * X[0] + (tyz + twx) * X[1] + (1 - (txx + tyy)) * X[2] + P[2];
+    const double invz = 1.0 / z;
+    const double u = g.cam.fx * x * invz + g.cam.cx;
+    const double e0 = ed.ox - u, e1 = ed.oy - (g.cam.fy * y * invz + g.cam.cy);
+    double ss = e0 * e0 + e1 * e1;
+    if (stereo) {
+        const double e2 = ed.oxr - (u - g.bf * invz);
+        ss = ss + e2 * e2;
+    }
+    chi2[e] = ed.w * ss;
+    depth_pos[e] = z > 0.0 ? 1 : 0;
+}
+
+}   // namespace ovs
+
+using namespace ovs;
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The graph handle: device copies of the edge set and its indices; no per-call allocation on the linearisation path.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct ovs_ba_graph {
+    int device = 0;
+    int n_pose = 0, n_pt = 0, n_mono = 0, n_stereo = 0, n_free = 0;
+    ovs_ba_cam cam{};
+    double bf = 0;
+    std::vector<uint8_t> fixed;
+    std::vector<int32_t> slot, slot_pose;   // pose -> reduced-system block (-1 fixed); block -> pose
+    std::vector<int32_t> edge_pose, edge_pt;
+    // device
+    GEdge* d_edges = nullptr;
+    int32_t *d_lm_start = nullptr, *d_lm_edges = nullptr, *d_lm_nmono = nullptr, *d_pose_start = nullptr, *d_pose_edges = nullptr;
+    uint8_t* d_fixed = nullptr;
+    int32_t *d_pair_start = nullptr, *d_pair_ab = nullptr, *d_slot_pose = nullptr, *d_fail = nullptr;
+    int2* d_pair_ent = nullptr;
+    int n_pairs = 0;
+    double* d_lm_tmp = nullptr;   // [2 n_pt] per-landmark partials (chi2 / scale)
+    // solver work space (allocated on first use: ovs_ba_graph_linearize_dev alone does not need it)
+    double *d_Hinv = nullptr, *d_Y = nullptr, *d_S = nullptr, *d_rhs = nullptr, *d_dxp = nullptr, *d_scal = nullptr;
+    bool pairs_built = false;
+
+    GraphDev view() const {
+        GraphDev g;
+        g.edges = d_edges;
+        g.n_mono = n_mono;
+        g.n_edge = n_mono + n_stereo;
+        g.n_pose = n_pose;
+        g.n_pt = n_pt;
+        g.lm_start = d_lm_start;
+        g.lm_edges = d_lm_edges;
+        g.lm_nmono = d_lm_nmono;
+        g.pose_start = d_pose_start;
+        g.pose_edges = d_pose_edges;
+        g.fixed = d_fixed;
+        g.cam = cam;
+        g.bf = bf;
+        return g;
+    }
+    int n_edge() const { return n_mono + n_stereo; }
+};
+
+namespace {
+
+template <typename T>
+hipError_t upload(T** dst, const std::vector<T>& v) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), sizeof(T) * std::max<size_t>(v.size(), 1));
+    if (e != hipSuccess) return e;
+    if (!v.empty()) e = hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);
+    return e;
+}
+
+ovs_status graph_linearize(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo, double* d_Hpp,
+                           double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s) {
+    const GraphDev v = g->view();
+    hipLaunchKernelGGL(k_lin_landmark, dim3((g->n_pt + 127) / 128), dim3(128), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hll, d_bl,
+                       d_Hpl, g->d_lm_tmp);
+    OVS_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_lin_pose, dim3(g->n_pose), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp);
+    OVS_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(1024), 0, s, v, g->d_lm_tmp, d_Hpp, d_Hll, d_chi3);
+    OVS_HIP_TRY(hipGetLastError());
+    return OVS_OK;
+}
+
+}   // namespace
+
+extern "C" {
+
+ovs_status ovs_ba_graph_destroy(ovs_ba_graph* g) {
+    if (!g) return OVS_OK;
+    (void)hipSetDevice(g->device);
+    hipFree(g->d_edges);
+    hipFree(g->d_lm_start);
+    hipFree(g->d_lm_edges);
+    hipFree(g->d_lm_nmono);
+    hipFree(g->d_pose_start);
+    hipFree(g->d_pose_edges);
+    hipFree(g->d_fixed);
+    hipFree(g->d_pair_start);
+    hipFree(g->d_pair_ab);
+    hipFree(g->d_pair_ent);
+    hipFree(g->d_slot_pose);
+    hipFree(g->d_fail);
+    hipFree(g->d_lm_tmp);
+    hipFree(g->d_Hinv);
+    hipFree(g->d_Y);
+    hipFree(g->d_S);
+    hipFree(g->d_rhs);
+    hipFree(g->d_dxp);
+    hipFree(g->d_scal);
+    delete g;
+    return OVS_OK;
+}
+
+ovs_status ovs_ba_graph_create(int32_t device, int32_t n_pose, const uint8_t* pose_fixed, int32_t n_pt, const ovs_ba_edge* mono, int32_t n_mono,
+                               const ovs_ba_edge_stereo* stereo, int32_t n_stereo, const ovs_ba_cam* cam, double focal_x_baseline,
+                               ovs_ba_graph** out) {
+    if (!out || !cam || n_pose < 1 || n_pt < 1 || n_mono < 0 || n_stereo < 0 || (n_mono > 0 && !mono) || (n_stereo > 0 && !stereo))
+        return OVS_ERR_INVALID;
+    *out = nullptr;
+    for (int i = 0; i < n_mono; ++i)
+        if (mono[i].pose_idx < 0 || mono[i].pose_idx >= n_pose || mono[i].point_idx < 0 || mono[i].point_idx >= n_pt) return OVS_ERR_INVALID;
+    for (int i = 0; i < n_stereo; ++i)
+        if (stereo[i].pose_idx < 0 || stereo[i].pose_idx >= n_pose || stereo[i].point_idx < 0 || stereo[i].point_idx >= n_pt) return OVS_ERR_INVALID;
+    if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
+    OVS_HIP_TRY(hipSetDevice(device));
+    ovs_ba_graph* g = new (std::nothrow) ovs_ba_graph();
+    if (!g) return OVS_ERR_INVALID;
+    g->device = device;
+    g->n_pose = n_pose;
+    g->n_pt = n_pt;
+    g->n_mono = n_mono;
+    g->n_stereo = n_stereo;
+    g->cam = *cam;
+    g->bf = focal_x_baseline;
+    g->fixed.assign((size_t)n_pose, 0);
+    if (pose_fixed) g->fixed.assign(pose_fixed, pose_fixed + n_pose);
+    g->slot.assign((size_t)n_pose, -1);
+    for (int k = 0; k < n_pose; ++k)
+        if (!g->fixed[k]) {
+            g->slot[k] = g->n_free++;
+            g->slot_pose.push_back(k);
+        }
+    const int ne = n_mono + n_stereo;
+    std::vector<GEdge> edges((size_t)ne);
+    g->edge_pose.resize((size_t)ne);
+    g->edge_pt.resize((size_t)ne);
+    for (int i = 0; i < n_mono; ++i) {
+        edges[i] = GEdge{mono[i].pose_idx, mono[i].point_idx, mono[i].obs_x, mono[i].obs_y, 0.0, mono[i].inv_sigma_sq};
+        g->edge_pose[i] = mono[i].pose_idx;
+        g->edge_pt[i] = mono[i].point_idx;
+    }
+    for (int i = 0; i < n_stereo; ++i) {
+        edges[(size_t)n_mono + i] = GEdge{stereo[i].pose_idx, stereo[i].point_idx, stereo[i].obs_x, stereo[i].obs_y, stereo[i].obs_x_right,
+                                          stereo[i].inv_sigma_sq};
+        g->edge_pose[(size_t)n_mono + i] = stereo[i].pose_idx;
+        g->edge_pt[(size_t)n_mono + i] = stereo[i].point_idx;
+    }
+    // counting sorts: ascending edge index inside every landmark / keyframe (mono edges have the lower indices, so "mono first" is free)
+    std::vector<int32_t> lm_start((size_t)n_pt + 1, 0), lm_edges((size_t)ne), lm_nmono((size_t)n_pt, 0), pose_start((size_t)n_pose + 1, 0),
+        pose_edges((size_t)ne);
+    for (int e = 0; e < ne; ++e) {
+        ++lm_start[(size_t)g->edge_pt[e] + 1];
+        ++pose_start[(size_t)g->edge_pose[e] + 1];
+        if (e < n_mono) ++lm_nmono[g->edge_pt[e]];
+    }
+    for (int j = 0; j < n_pt; ++j) lm_start[(size_t)j + 1] += lm_start[j];
+    for (int k = 0; k < n_pose; ++k) pose_start[(size_t)k + 1] += pose_start[k];
+    {
+        std::vector<int32_t> fl(lm_start.begin(), lm_start.end() - 1), fp(pose_start.begin(), pose_start.end() - 1);
+        for (int e = 0; e < ne; ++e) {
+            lm_edges[(size_t)fl[g->edge_pt[e]]++] = e;
+            pose_edges[(size_t)fp[g->edge_pose[e]]++] = e;
+        }
+    }
+#define G_TRY(expr)                            \
+    do {                                       \
+        hipError_t _e = (expr);                \
+        if (_e != hipSuccess) {                \
+            ovs::set_last_error(#expr, _e);    \
+            ovs_ba_graph_destroy(g);           \
+            return OVS_ERR_HIP;                \
+        }                                      \
+    } while (0)
+    G_TRY(upload(&g->d_edges, edges));
+    G_TRY(upload(&g->d_lm_start, lm_start));
+    G_TRY(upload(&g->d_lm_edges, lm_edges));
+    G_TRY(upload(&g->d_lm_nmono, lm_nmono));
+    G_TRY(upload(&g->d_pose_start, pose_start));
+    G_TRY(upload(&g->d_pose_edges, pose_edges));
+    G_TRY(upload(&g->d_fixed, g->fixed));
+    G_TRY(hipMalloc(&g->d_lm_tmp, sizeof(double) * 2 * (size_t)n_pt));
+    // reduced-system pair lists: for every landmark all (edge a, edge b) with free poses and slot(a) <= slot(b)
+    if (g->n_free > 0) {
+        const int nf = g->n_free;
+        const int n_pairs = nf * (nf + 1) / 2;
+        auto pair_id = [nf](int a, int b) { return a * nf - a * (a - 1) / 2 + (b - a); };
+        std::vector<int32_t> pstart((size_t)n_pairs + 1, 0), pab((size_t)2 * n_pairs);
+        for (int a = 0; a < nf; ++a)
+            for (int b = a; b < nf; ++b) {
+                pab[(size_t)2 * pair_id(a, b)] = a;
+                pab[(size_t)2 * pair_id(a, b) + 1] = b;
+            }
+        auto for_pairs = [&](auto&& fn) {
+            for (int j = 0; j < n_pt; ++j)
+                for (int i = lm_start[j]; i < lm_start[(size_t)j + 1]; ++i) {
+                    const int ea = lm_edges[i], sa = g->slot[g->edge_pose[ea]];
+                    if (sa < 0) continue;
+                    for (int i2 = lm_start[j]; i2 < lm_start[(size_t)j + 1]; ++i2) {
+                        const int eb = lm_edges[i2], sb = g->slot[g->edge_pose[eb]];
+                        if (sb < 0 || sb < sa) continue;
+                        // two edges of one keyframe to one landmark do not occur in a valid graph; (ea, ea) is the diagonal term
+                        if (sb == sa && eb != ea) continue;
+                        fn(pair_id(sa, sb), ea, eb);
+                    }
+                }
+        };
+        for_pairs([&](int p, int, int) { ++pstart[(size_t)p + 1]; });
+        for (int p = 0; p < n_pairs; ++p) pstart[(size_t)p + 1] += pstart[p];
+        std::vector<int2> ent((size_t)pstart[n_pairs]);
+        std::vector<int32_t> fill(pstart.begin(), pstart.end() - 1);
+        for_pairs([&](int p, int ea, int eb) { ent[(size_t)fill[p]++] = int2{ea, eb}; });
+        g->n_pairs = n_pairs;
+        G_TRY(upload(&g->d_pair_start, pstart));
+        G_TRY(upload(&g->d_pair_ab, pab));
+        G_TRY(upload(&g->d_pair_ent, ent));
+        G_TRY(upload(&g->d_slot_pose, g->slot_pose));
+    }
+#undef G_TRY
+    *out = g;
+    return OVS_OK;
+}
+
+ovs_status ovs_ba_graph_linearize_dev(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo,
+                                      double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream) {
+    if (!g || !d_poses || !d_points || !d_Hpp || !d_bp || !d_Hll || !d_bl || !d_Hpl || !d_chi2) return OVS_ERR_INVALID;
+    OVS_HIP_TRY(hipSetDevice(g->device));
+    return graph_linearize(g, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi2, (hipStream_t)stream);
+}
+
+}   // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Levenberg-Marquardt on top of the graph (used by ovs_local_ba_optimize in ba_optimize.hip)
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace ovs {
+
+ovs_status ba_graph_ensure_solver(ovs_ba_graph* g) {
+    if (g->d_Hinv) return OVS_OK;
+    const size_t ne = std::max<size_t>((size_t)g->n_edge(), 1), n = (size_t)6 * std::max(g->n_free, 1);
+    OVS_HIP_TRY(hipMalloc(&g->d_Hinv, sizeof(double) * 9 * (size_t)g->n_pt));
+    OVS_HIP_TRY(hipMalloc(&g->d_Y, sizeof(double) * 18 * ne));
+    OVS_HIP_TRY(hipMalloc(&g->d_S, sizeof(double) * (n * n + n + 6 * (size_t)g->n_pose)));   // S | rhs | bp copy: one D2H
+    OVS_HIP_TRY(hipMalloc(&g->d_dxp, sizeof(double) * 6 * (size_t)g->n_pose));
+    OVS_HIP_TRY(hipMalloc(&g->d_scal, sizeof(double) * 8));
+    OVS_HIP_TRY(hipMalloc(&g->d_fail, sizeof(int32_t)));
+    g->d_rhs = g->d_S + n * n;
+    return OVS_OK;
+}
+
+// (H + lambda I) dx = b, landmarks eliminated on the device. Leaves S | rhs | bp contiguous at g->d_S for one download.
+ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_bp, const double* d_Hll, const double* d_bl, const double* d_Hpl,
+                          double lambda, hipStream_t s) {
+    const GraphDev v = g->view();
+    const int n = 6 * g->n_free;
+    OVS_HIP_TRY(hipMemsetAsync(g->d_fail, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_lm_prepare, dim3((g->n_pt + 127) / 128), dim3(128), 0, s, v, d_Hll, d_Hpl, lambda, g->d_Hinv, g->d_Y, g->d_fail);
+    OVS_HIP_TRY(hipGetLastError());
+    if (g->n_free > 0) {
+        hipLaunchKernelGGL(k_schur_pairs, dim3(g->n_pairs), dim3(256), 0, s, g->d_pair_start, g->d_pair_ent, g->d_pair_ab, g->d_slot_pose, d_Hpp,
+                           d_Hpl, g->d_Y, lambda, n, g->d_S);
+        OVS_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_schur_rhs, dim3(g->n_free), dim3(256), 0, s, v, g->d_slot_pose, d_bp, d_bl, g->d_Y, g->d_rhs);
+        OVS_HIP_TRY(hipGetLastError());
+        OVS_HIP_TRY(hipMemcpyAsync(g->d_rhs + n, d_bp, sizeof(double) * 6 * (size_t)g->n_pose, hipMemcpyDeviceToDevice, s));
+    }
+    return OVS_OK;
+}
+
+ovs_status ba_graph_backsub(ovs_ba_graph* g, const double* d_Hpl, const double* d_bl, double lambda, const double* d_X, double* d_Xn, hipStream_t s) {
+    const GraphDev v = g->view();
+    hipLaunchKernelGGL(k_backsub, dim3((g->n_pt + 127) / 128), dim3(128), 0, s, v, g->d_Hinv, d_Hpl, d_bl, g->d_dxp, lambda, d_X, d_Xn, g->d_lm_tmp);
+    OVS_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_sum_1024, dim3(1), dim3(1024), 0, s, g->d_lm_tmp, g->n_pt, g->d_scal);
+    OVS_HIP_TRY(hipGetLastError());
+    return OVS_OK;
+}
+
+ovs_status ba_graph_edge_chi2(ovs_ba_graph* g, const double* d_poses, const double* d_points, double* d_chi, uint8_t* d_depth, hipStream_t s) {
+    if (g->n_edge() == 0) return OVS_OK;
+    hipLaunchKernelGGL(k_edge_chi2, dim3((g->n_edge() + 255) / 256), dim3(256), 0, s, g->view(), d_poses, d_points, d_chi, d_depth);
+    OVS_HIP_TRY(hipGetLastError());
+    return OVS_OK;
+}
+
+ovs_status ba_graph_linearize(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo, double* d_Hpp,
+                              double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s) {
+    return graph_linearize(g, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi3, s);
+}
+
+}   // namespace ovs
+
+namespace ovs {
+struct BaGraphInfo {
+    int n_free;
+    const int32_t* slot;
+    double *d_S, *d_dxp, *d_scal;
+    int32_t* d_fail;
+};
+BaGraphInfo ba_graph_info(ovs_ba_graph* g) { return BaGraphInfo{g->n_free, g->slot.data(), g->d_S, g->d_dxp, g->d_scal, g->d_fail}; }
+}   // namespace ovs

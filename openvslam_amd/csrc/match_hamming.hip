@@ -103,16 +103,28 @@ __device__ __forceinline__ void topk_insert(uint32_t e, uint32_t (&t)[kTopK]) {
 // run on ONE XCD and its 64 KB of frame descriptors are fetched into one L2 instead of eight (fabric traffic was 9.7x algorithmic);
 // (iii) the double-buffered scalar loads above.
 
-// d += popcount(a ^ b): one v_xor_b32 (SGPR operand) + one v_bcnt_u32_b32 with accumulate, kept as a chain
-// (asm volatile: volatile statements keep their program order, so the machine scheduler cannot sink the NEXT group's scalar loads
-// below this group's arithmetic -- which it does when the v_bcnt are ordinary instructions)
-__device__ __forceinline__ void xor_bcnt_acc(uint32_t& d, uint32_t a, uint32_t b_sgpr) {
-    const uint32_t x = a ^ b_sgpr;
-    asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x));
+// One word of four descriptors in ONE asm volatile statement: four v_xor_b32 (SGPR operand) followed by the four v_bcnt_u32_b32 that
+// accumulate them, so no v_bcnt issues directly behind the v_xor it depends on (hipcc pairs them back to back), the popcount stays an
+// 8-deep accumulate chain per descriptor (hipcc splits it into 6 independent v_bcnt + 3 v_add3_u32: 19 instead of 16 VALU per pair),
+// and -- volatile statements keep their program order -- the machine scheduler cannot sink the NEXT group's scalar loads below this
+// group's arithmetic.
+__device__ __forceinline__ void xor_bcnt4_first(uint32_t a, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t& d0, uint32_t& d1,
+                                                uint32_t& d2, uint32_t& d3) {
+    uint32_t t0, t1, t2, t3;
+    asm volatile(
+        "v_xor_b32 %4, %9, %8\n\tv_xor_b32 %5, %10, %8\n\tv_xor_b32 %6, %11, %8\n\tv_xor_b32 %7, %12, %8\n\t"
+        "v_bcnt_u32_b32 %0, %4, 0\n\tv_bcnt_u32_b32 %1, %5, 0\n\tv_bcnt_u32_b32 %2, %6, 0\n\tv_bcnt_u32_b32 %3, %7, 0"
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(a), "s"(s0), "s"(s1), "s"(s2), "s"(s3));
 }
-__device__ __forceinline__ void xor_bcnt_first(uint32_t& d, uint32_t a, uint32_t b_sgpr) {
-    const uint32_t x = a ^ b_sgpr;
-    asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(d) : "v"(x));
+__device__ __forceinline__ void xor_bcnt4_acc(uint32_t a, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t& d0, uint32_t& d1,
+                                              uint32_t& d2, uint32_t& d3) {
+    uint32_t t0, t1, t2, t3;
+    asm volatile(
+        "v_xor_b32 %4, %9, %8\n\tv_xor_b32 %5, %10, %8\n\tv_xor_b32 %6, %11, %8\n\tv_xor_b32 %7, %12, %8\n\t"
+        "v_bcnt_u32_b32 %0, %4, %0\n\tv_bcnt_u32_b32 %1, %5, %1\n\tv_bcnt_u32_b32 %2, %6, %2\n\tv_bcnt_u32_b32 %3, %7, %3"
+        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(a), "s"(s0), "s"(s1), "s"(s2), "s"(s3));
 }
 
 // SGPR sets pinned to fixed registers: the load statement and the wait statement must name the SAME physical registers (the loads land
@@ -136,17 +148,9 @@ __device__ __forceinline__ void xor_bcnt_first(uint32_t& d, uint32_t a, uint32_t
 
 __device__ __forceinline__ void dist4(const uint32_t (&a)[8], const u32x8& b0, const u32x8& b1, const u32x8& b2, const u32x8& b3, uint32_t& d0,
                                       uint32_t& d1, uint32_t& d2, uint32_t& d3) {
-    xor_bcnt_first(d0, a[0], b0[0]);
-    xor_bcnt_first(d1, a[0], b1[0]);
-    xor_bcnt_first(d2, a[0], b2[0]);
-    xor_bcnt_first(d3, a[0], b3[0]);
+    xor_bcnt4_first(a[0], b0[0], b1[0], b2[0], b3[0], d0, d1, d2, d3);
 #pragma unroll
-    for (int i = 1; i < 8; ++i) {   // four independent chains interleaved: no back-to-back dependent v_bcnt
-        xor_bcnt_acc(d0, a[i], b0[i]);
-        xor_bcnt_acc(d1, a[i], b1[i]);
-        xor_bcnt_acc(d2, a[i], b2[i]);
-        xor_bcnt_acc(d3, a[i], b3[i]);
-    }
+    for (int i = 1; i < 8; ++i) xor_bcnt4_acc(a[i], b0[i], b1[i], b2[i], b3[i], d0, d1, d2, d3);
 }
 
 __global__ __launch_bounds__(256) void k_hamming_near(const uint8_t* __restrict__ desc_1, size_t stride_1,

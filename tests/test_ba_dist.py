@@ -1,6 +1,6 @@
-"""The N>1 path of the local-BA linearisation on CPU: world_size 2, gloo. Edges are sharded by keyframe, every rank computes
+"""The N>1 path of the local-BA linearisation on CPU: world_size 2 and 4, gloo. Edges are sharded by keyframe, every rank computes
 its shard's partial blocks (here with the ORACLE as the shard backend -- this test is about the sharding and the exchange
-step, the HIP backend is covered by tests/test_gpu_ba.py), then Hll|bl are all-reduced. Result must equal the one-process
+step, the HIP backend runs under a 1-rank nccl group in tests/test_gpu_ba.py::test_graph_backend_under_nccl_group), then Hll|bl|chi2 are all-reduced in ONE packed collective. Result must equal the one-process
 linearisation within the stated multi-rank tolerance 1e-10 (rel.; summation order differs)."""
 import os
 import socket
@@ -20,8 +20,8 @@ def _oracle_backend(poses_t, fixed_t, points_t, edges_t, cam, huber_delta):
     edges = edges_t.numpy().view(ob.BA_EDGE_DTYPE)
     o = ob.ba_linearize(poses_t.numpy(), fixed_t.numpy() if fixed_t is not None else None, points_t.numpy(), edges, cam, huber_delta)
     hppbp = torch.from_numpy(np.concatenate([o["Hpp"].ravel(), o["bp"].ravel()]))
-    hllbl = torch.from_numpy(np.concatenate([o["Hll"].ravel(), o["bl"].ravel()]))
-    return hppbp, hllbl, torch.from_numpy(o["Hpl"].reshape(-1, 18).copy()), torch.from_numpy(o["chi2"].copy())
+    packed = torch.from_numpy(np.concatenate([o["Hll"].ravel(), o["bl"].ravel(), o["chi2"].ravel(), np.zeros(2)]))   # ONE buffer, ONE collective
+    return hppbp, packed, torch.from_numpy(o["Hpl"].reshape(-1, 18).copy())
 
 
 def _worker(rank, world, port, q):
@@ -39,17 +39,18 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_world_size_2_gloo(oracle):
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 4])
+def test_world_size_n_gloo(oracle, world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=100) for _ in range(2)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
@@ -60,7 +61,7 @@ def test_world_size_2_gloo(oracle):
             scale = np.abs(want[k]).max()
             assert np.allclose(out[k], want[k], rtol=1e-10, atol=1e-10 * scale), (rank, k)
         # Hpl stays local: this rank's edges only, bit-identical to the one-process value
-        sel = (d["edges"]["pose_idx"] // 4) == rank
+        sel = (d["edges"]["pose_idx"] // (8 // world)) == rank
         assert np.array_equal(hpl, want["Hpl"][sel])
     # the two ranks hold the SAME reduced landmark blocks
     assert np.array_equal(res[0][1]["Hll"], res[1][1]["Hll"]) and np.array_equal(res[0][1]["bl"], res[1][1]["bl"])

@@ -172,3 +172,74 @@ def test_local_ba_force_stop_and_bad_args():
     bad["point_idx"][0] = 10 ** 6
     with pytest.raises(RuntimeError):
         ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], bad, d["cam"])
+
+
+@pytest.mark.parametrize("stereo_frac", [0.0, 0.35])
+def test_graph_linearize_is_deterministic_and_matches_oracle(oracle, stereo_frac):
+    """The atomics-free graph path (round 2): Hll | bl | Hpl BIT-identical to the oracle (one lane per landmark adds its edges in the
+    oracle's order), Hpp | bp | chi2 within 1e-13 (fixed-shape tree vs sequential sum), and two runs give identical bits."""
+    import torch
+    from oracle import lba
+    from openvslam_amd import ba
+    from test_ba import _lba_scene
+    d, mono, st, bf, _, _ = _lba_scene(21, n_pose=12, n_pt=3000, obs_per_pose=700, stereo_frac=stereo_frac)
+    hm, hs = lba.SQRT_CHI2_MONO, lba.SQRT_CHI2_STEREO
+    g = ba.graph(len(d["poses"]), d["pose_fixed"], len(d["points"]), mono, d["cam"], st, bf)
+    P, X = torch.from_numpy(d["poses"]).cuda(), torch.from_numpy(d["points"]).cuda()
+    runs = []
+    for _ in range(2):
+        out = g.linearize_dev(P, X, hm, hs)
+        torch.cuda.synchronize()
+        v = ba.graph.views(out, g.n_pose, g.n_pt, g.n_edge)
+        runs.append({k: t.cpu().numpy().copy() for k, t in v.items()})
+    for k in runs[0]:
+        assert np.array_equal(runs[0][k], runs[1][k]), k            # bit-reproducible
+    want = oracle.ba_linearize(d["poses"], d["pose_fixed"], d["points"], mono, d["cam"], hm)
+    if len(st):
+        s = oracle.ba_linearize_stereo(d["poses"], d["pose_fixed"], d["points"], st, d["cam"], bf, hs)
+        for k in ("Hpp", "bp", "Hll", "bl", "chi2"):
+            want[k] = want[k] + s[k]
+        want["Hpl"] = np.concatenate([want["Hpl"], s["Hpl"]])
+    got = runs[0]
+    for k in ("Hpl", "Hll", "bl"):
+        assert np.array_equal(got[k], want[k]), k
+    for k in ("Hpp", "bp", "chi2"):
+        scale = np.abs(want[k]).max()
+        assert np.allclose(got[k], want[k], rtol=1e-13, atol=1e-13 * scale), k
+    free = d["pose_fixed"] == 0
+    md = max(np.abs(np.einsum("kii->ki", want["Hpp"][free])).max(), np.abs(np.einsum("kii->ki", want["Hll"])).max())
+    assert np.isclose(got["max_diag"][0], md, rtol=1e-13)
+
+
+def test_graph_backend_under_nccl_group(oracle):
+    """The HIP backend and a collective in ONE process group: a 1-rank nccl (RCCL) group drives local_ba_linearizer with the graph backend,
+    i.e. the code path of `bench.py --gpus N` (the packed Hll | bl | chi2 all-reduce is issued when world_size > 1; with one rank the call
+    sequence up to the collective is what runs here, and an explicit all_reduce of the packed buffer checks RCCL accepts it)."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from openvslam_amd import ba
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        d = synth_local_ba(n_pose=10, n_pt=1500, obs_per_pose=400, seed=13)
+        lin = ba.local_ba_linearizer(d["cam"], d["huber_delta"])
+        P, F, X = torch.from_numpy(d["poses"]).cuda(), torch.from_numpy(d["pose_fixed"]).cuda(), torch.from_numpy(d["points"]).cuda()
+        E = torch.from_numpy(d["edges"].view(np.uint8)).cuda()
+        out = lin.linearize(P, F, X, E)
+        packed = lin.backend._out["packed"]
+        before = packed.clone()
+        dist.all_reduce(packed[:12 * 1500 + 2], op=dist.ReduceOp.SUM)     # sum over one rank: unchanged
+        torch.cuda.synchronize()
+        assert torch.equal(before, packed)
+        got = {k: v.cpu().numpy() for k, v in out.items()}
+        want = oracle.ba_linearize(d["poses"], d["pose_fixed"], d["points"], d["edges"], d["cam"], d["huber_delta"])
+        assert np.array_equal(got["Hpl"], want["Hpl"]) and np.array_equal(got["Hll"], want["Hll"]) and np.array_equal(got["bl"], want["bl"])
+        for k in ("Hpp", "bp", "chi2"):
+            assert np.allclose(got[k], want[k], rtol=1e-13, atol=1e-13 * np.abs(want[k]).max()), k
+    finally:
+        dist.destroy_process_group()
