@@ -482,6 +482,21 @@ ovs_status ovs_ba_graph_destroy(ovs_ba_graph* g);
 ovs_status ovs_ba_graph_linearize_dev(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo,
                                       double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream);
 
+/* Natively sharded linearisation (BASELINE config 5): ONE process drives devices 0 .. n_gpus-1 -- the shape in which
+ * mapping_module would use it. Edges are partitioned by keyframe into n_gpus contiguous keyframe blocks (one ovs_ba_graph per device); a
+ * call uploads the state to every device, linearises the shards concurrently and sums the landmark blocks with ONE packed RCCL all-reduce
+ * of Hll | bl | chi2 over xGMI; Hpp | bp and Hpl are complete on the shard that owns the keyframe and are only collected. Host pointers
+ * in / out, same layouts as ovs_ba_linearize (Hpl: mono edges in input order, then stereo; chi2: 2 doubles). RCCL is loaded lazily
+ * (dlopen) and only for n_gpus > 1; n_gpus = 1 runs the same code without a communicator. Results equal the single-device graph path
+ * within 1e-10 relative (the all-reduce changes the association of the landmark sums); Hpl is bit-identical. */
+typedef struct ovs_ba_multi ovs_ba_multi;
+ovs_status ovs_ba_multi_create(int32_t n_gpus, int32_t n_pose, const uint8_t* pose_fixed, int32_t n_pt, const ovs_ba_edge* mono, int32_t n_mono,
+                               const ovs_ba_edge_stereo* stereo, int32_t n_stereo, const ovs_ba_cam* cam, double focal_x_baseline,
+                               ovs_ba_multi** out);
+ovs_status ovs_ba_multi_destroy(ovs_ba_multi* m);
+ovs_status ovs_ba_multi_linearize(ovs_ba_multi* m, const double* poses, const double* points, double huber_mono, double huber_stereo, double* Hpp,
+                                  double* bp, double* Hll, double* bl, double* Hpl, double* chi2);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Bag-of-words transform.  replaces: the per-descriptor tree descent of DBoW2::TemplatedVocabulary::transform(
  *   const std::vector<TDescriptor>& features, BowVector& v, FeatureVector& fv, int levelsup) as called by data::frame::compute_bow /

@@ -134,10 +134,10 @@ struct Lm {
     // one optimizer.optimize(iters) call on graph g. Returns the number of iterations entered.
     ovs_status run_round(ovs_ba_graph* g, std::vector<Pose>& T, int iters, bool robust, const volatile uint8_t* stop, double* chi_start,
                          double* chi_end, int* n_iter) {
+        ovs_status st = ovs::ba_graph_ensure_solver(g);   // (before ba_graph_info: the work space is allocated on first use)
+        if (st != OVS_OK) return st;
         const ovs::BaGraphInfo gi = ovs::ba_graph_info(g);
         const int nf = gi.n_free, n = 6 * nf;
-        ovs_status st = ovs::ba_graph_ensure_solver(g);
-        if (st != OVS_OK) return st;
         st = upload_poses(T, d_poses);
         if (st != OVS_OK) return st;
         st = ovs::ba_graph_linearize(g, d_poses, d_X, huber_mono(robust), huber_stereo(robust), cur.Hpp, cur.bp, cur.Hll, cur.bl, cur.Hpl, cur.chi,

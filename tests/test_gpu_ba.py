@@ -243,3 +243,42 @@ def test_graph_backend_under_nccl_group(oracle):
             assert np.allclose(got[k], want[k], rtol=1e-13, atol=1e-13 * np.abs(want[k]).max()), k
     finally:
         dist.destroy_process_group()
+
+
+def test_native_multi_device_entry_one_gpu(oracle):
+    """ovs_ba_multi_* (the native sharded entry) with n_gpus = 1: same partition / collect code as N devices, no communicator.
+    More devices than the box has must fail loudly."""
+    import ctypes as C
+    from openvslam_amd import _lib, ba
+    from oracle import lba
+    from test_ba import _lba_scene
+    L = _lib.lib()
+    d, mono, st, bf, _, _ = _lba_scene(31, n_pose=9, n_pt=1200, obs_per_pose=400, stereo_frac=0.3)
+    n_pose, n_pt = len(d["poses"]), len(d["points"])
+    cam = ba.BaCam(*d["cam"])
+    h = C.c_void_p()
+    fixed = np.ascontiguousarray(d["pose_fixed"], np.uint8)
+    _lib.check(L.ovs_ba_multi_create(1, n_pose, fixed.ctypes.data, n_pt, mono.ctypes.data, len(mono), st.ctypes.data, len(st), C.byref(cam), bf,
+                                     C.byref(h)), "ovs_ba_multi_create")
+    try:
+        out = dict(Hpp=np.zeros((n_pose, 6, 6)), bp=np.zeros((n_pose, 6)), Hll=np.zeros((n_pt, 3, 3)), bl=np.zeros((n_pt, 3)),
+                   Hpl=np.zeros((len(mono) + len(st), 6, 3)), chi2=np.zeros(2))
+        P, X = np.ascontiguousarray(d["poses"]), np.ascontiguousarray(d["points"])
+        _lib.check(L.ovs_ba_multi_linearize(h, P.ctypes.data, X.ctypes.data, lba.SQRT_CHI2_MONO, lba.SQRT_CHI2_STEREO, out["Hpp"].ctypes.data,
+                                            out["bp"].ctypes.data, out["Hll"].ctypes.data, out["bl"].ctypes.data, out["Hpl"].ctypes.data,
+                                            out["chi2"].ctypes.data), "ovs_ba_multi_linearize")
+    finally:
+        L.ovs_ba_multi_destroy(h)
+    want = oracle.ba_linearize(d["poses"], d["pose_fixed"], d["points"], mono, d["cam"], lba.SQRT_CHI2_MONO)
+    s = oracle.ba_linearize_stereo(d["poses"], d["pose_fixed"], d["points"], st, d["cam"], bf, lba.SQRT_CHI2_STEREO)
+    for k in ("Hpp", "bp", "Hll", "bl", "chi2"):
+        want[k] = want[k] + s[k]
+    want["Hpl"] = np.concatenate([want["Hpl"], s["Hpl"]])
+    assert np.array_equal(out["Hpl"], want["Hpl"]) and np.array_equal(out["Hll"], want["Hll"]) and np.array_equal(out["bl"], want["bl"])
+    for k in ("Hpp", "bp", "chi2"):
+        assert np.allclose(out[k], want[k], rtol=1e-13, atol=1e-13 * np.abs(want[k]).max()), k
+    h2 = C.c_void_p()
+    n_dev = L.ovs_device_count()
+    if n_dev < 8:
+        assert L.ovs_ba_multi_create(n_dev + 1, n_pose, fixed.ctypes.data, n_pt, mono.ctypes.data, len(mono), st.ctypes.data, len(st), C.byref(cam),
+                                     bf, C.byref(h2)) == -2
