@@ -510,6 +510,20 @@ typedef struct ovs_vocab ovs_vocab;
 ovs_status ovs_vocab_create(int32_t device, int32_t n_nodes, const int32_t* child_start, const int32_t* children, const uint8_t* node_desc,
                             const double* node_weight, const int32_t* node_word_id, int32_t depth, int32_t max_features, ovs_vocab** out);
 ovs_status ovs_vocab_destroy(ovs_vocab* v);
+/* On-disk vocabularies (replaces: DBoW2::TemplatedVocabulary::loadFromBinaryFile / loadFromTextFile and fbow::Vocabulary::readFromFile as
+ * called by system.cc for data::bow_vocabulary). The format is detected from the content: FBoW (.fbow), the DBoW2 fork's binary (.dbow2)
+ * or DBoW2 / ORB-SLAM2 text. ovs_vocab_tree_* parse on the host only (no device needed) into the arrays ovs_vocab_create takes;
+ * ovs_vocab_load_file = parse + create. Layouts: csrc/bow_vocab_io.hip; FBoW inner nodes get ids in block order (ORACLE_SPEC rule 30). */
+#define OVS_VOCAB_DBOW2_TEXT 1
+#define OVS_VOCAB_DBOW2_BINARY 2
+#define OVS_VOCAB_FBOW 3
+typedef struct ovs_vocab_tree ovs_vocab_tree;
+ovs_status ovs_vocab_tree_load(const char* path, ovs_vocab_tree** out, int32_t* format, int32_t* n_nodes, int32_t* depth);
+/* any pointer may be NULL; sizes: child_start n_nodes + 1, children n_nodes - 1, node_desc n_nodes x 32, node_weight / node_word_id n_nodes */
+ovs_status ovs_vocab_tree_arrays(const ovs_vocab_tree* t, int32_t* child_start, int32_t* children, uint8_t* node_desc, double* node_weight,
+                                 int32_t* node_word_id);
+ovs_status ovs_vocab_tree_free(ovs_vocab_tree* t);
+ovs_status ovs_vocab_load_file(int32_t device, const char* path, int32_t max_features, ovs_vocab** out, int32_t* format);
 ovs_status ovs_bow_transform(ovs_vocab* v, const uint8_t* desc, int32_t n, int32_t levelsup, int32_t* word_id, double* weight,
                              int32_t* node_id);
 ovs_status ovs_bow_transform_dev(ovs_vocab* v, const uint8_t* d_desc, const int32_t* d_counts, int32_t batch, int32_t cap, int32_t levelsup,

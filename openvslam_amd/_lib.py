@@ -70,6 +70,10 @@ SYMBOLS = {
     "ovs_ba_multi_linearize": (_i32, [_vp, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_vocab_create": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
     "ovs_vocab_destroy": (_i32, [_vp]),
+    "ovs_vocab_tree_load": (_i32, [C.c_char_p, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "ovs_vocab_tree_arrays": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "ovs_vocab_tree_free": (_i32, [_vp]),
+    "ovs_vocab_load_file": (_i32, [_i32, C.c_char_p, _i32, C.POINTER(_vp), C.POINTER(_i32)]),
     "ovs_bow_transform": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "ovs_bow_transform_dev": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ovs_local_ba_optimize": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

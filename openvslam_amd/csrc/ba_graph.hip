@@ -25,6 +25,15 @@
 
 #include "ovs_common.h"
 
+#define OVS_LAUNCH_TRY(name)                                  \
+    do {                                                      \
+        hipError_t _e = hipGetLastError();                    \
+        if (_e != hipSuccess) {                               \
+            ovs::set_last_error("launch of " name, _e);       \
+            return OVS_ERR_HIP;                               \
+        }                                                     \
+    } while (0)
+
 namespace ovs {
 
 struct GEdge {   // mono and stereo observations in one record; stereo iff index >= n_mono
@@ -492,11 +501,11 @@ ovs_status graph_linearize(ovs_ba_graph* g, const double* d_poses, const double*
     const GraphDev v = g->view();
     hipLaunchKernelGGL(k_lin_landmark, dim3((g->n_pt + 127) / 128), dim3(128), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hll, d_bl,
                        d_Hpl, g->d_lm_tmp);
-    OVS_HIP_TRY(hipGetLastError());
+    OVS_LAUNCH_TRY("k_lin_landmark");
     hipLaunchKernelGGL(k_lin_pose, dim3(g->n_pose), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp);
-    OVS_HIP_TRY(hipGetLastError());
+    OVS_LAUNCH_TRY("k_lin_pose");
     hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(1024), 0, s, v, g->d_lm_tmp, d_Hpp, d_Hll, d_chi3);
-    OVS_HIP_TRY(hipGetLastError());
+    OVS_LAUNCH_TRY("k_reduce_scalars");
     return OVS_OK;
 }
 
@@ -523,7 +532,6 @@ ovs_status ovs_ba_graph_destroy(ovs_ba_graph* g) {
     hipFree(g->d_Hinv);
     hipFree(g->d_Y);
     hipFree(g->d_S);
-    hipFree(g->d_rhs);
     hipFree(g->d_dxp);
     hipFree(g->d_scal);
     delete g;
@@ -683,13 +691,13 @@ ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_
     const int n = 6 * g->n_free;
     OVS_HIP_TRY(hipMemsetAsync(g->d_fail, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k_lm_prepare, dim3((g->n_pt + 127) / 128), dim3(128), 0, s, v, d_Hll, d_Hpl, lambda, g->d_Hinv, g->d_Y, g->d_fail);
-    OVS_HIP_TRY(hipGetLastError());
+    OVS_LAUNCH_TRY("k_lm_prepare");
     if (g->n_free > 0) {
         hipLaunchKernelGGL(k_schur_pairs, dim3(g->n_pairs), dim3(256), 0, s, g->d_pair_start, g->d_pair_ent, g->d_pair_ab, g->d_slot_pose, d_Hpp,
                            d_Hpl, g->d_Y, lambda, n, g->d_S);
-        OVS_HIP_TRY(hipGetLastError());
+        OVS_LAUNCH_TRY("k_schur_pairs");
         hipLaunchKernelGGL(k_schur_rhs, dim3(g->n_free), dim3(256), 0, s, v, g->d_slot_pose, d_bp, d_bl, g->d_Y, g->d_rhs);
-        OVS_HIP_TRY(hipGetLastError());
+        OVS_LAUNCH_TRY("k_schur_rhs");
         OVS_HIP_TRY(hipMemcpyAsync(g->d_rhs + n, d_bp, sizeof(double) * 6 * (size_t)g->n_pose, hipMemcpyDeviceToDevice, s));
     }
     return OVS_OK;
@@ -698,16 +706,16 @@ ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_
 ovs_status ba_graph_backsub(ovs_ba_graph* g, const double* d_Hpl, const double* d_bl, double lambda, const double* d_X, double* d_Xn, hipStream_t s) {
     const GraphDev v = g->view();
     hipLaunchKernelGGL(k_backsub, dim3((g->n_pt + 127) / 128), dim3(128), 0, s, v, g->d_Hinv, d_Hpl, d_bl, g->d_dxp, lambda, d_X, d_Xn, g->d_lm_tmp);
-    OVS_HIP_TRY(hipGetLastError());
+    OVS_LAUNCH_TRY("k_backsub");
     hipLaunchKernelGGL(k_sum_1024, dim3(1), dim3(1024), 0, s, g->d_lm_tmp, g->n_pt, g->d_scal);
-    OVS_HIP_TRY(hipGetLastError());
+    OVS_LAUNCH_TRY("k_sum_1024");
     return OVS_OK;
 }
 
 ovs_status ba_graph_edge_chi2(ovs_ba_graph* g, const double* d_poses, const double* d_points, double* d_chi, uint8_t* d_depth, hipStream_t s) {
     if (g->n_edge() == 0) return OVS_OK;
     hipLaunchKernelGGL(k_edge_chi2, dim3((g->n_edge() + 255) / 256), dim3(256), 0, s, g->view(), d_poses, d_points, d_chi, d_depth);
-    OVS_HIP_TRY(hipGetLastError());
+    OVS_LAUNCH_TRY("k_edge_chi2");
     return OVS_OK;
 }
 

@@ -10,7 +10,10 @@
 //   * g2o's damping schedule (ORACLE_SPEC rule 25), the chi-square outlier gates between the two rounds and the final outlier flags.
 // Round 1: 16 MB per trial crossed PCIe and the landmark elimination ran on 8 host threads (117 ms at config 5).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -68,6 +71,10 @@ struct DevBlocks {   // one linearisation in HBM: Hpp | bp | Hll | bl | Hpl | ch
 
 struct Lm {
     int n_pose = 0, n_pt = 0, setup_type = 0;
+    // OVS_BA_TRACE=1: wall-clock breakdown on stderr (where a call's milliseconds go; tools/time_lba.py)
+    double t_schur = 0, t_chol = 0, t_trial = 0;
+    int n_trials = 0;
+    static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     hipStream_t stream = nullptr;
     DevBlocks cur, trial;
     double *d_poses = nullptr, *d_poses_n = nullptr, *d_X = nullptr, *d_Xn = nullptr, *d_echi = nullptr;
@@ -161,6 +168,8 @@ struct Lm {
             double rho = 0;
             int qmax = 0;
             do {
+                const double t0 = now();
+                ++n_trials;
                 st = ovs::ba_graph_schur(g, cur.Hpp, cur.bp, cur.Hll, cur.bl, cur.Hpl, lambda, stream);
                 if (st != OVS_OK) return st;
                 int32_t* h_fail = reinterpret_cast<int32_t*>(h_chi + 8);
@@ -168,12 +177,16 @@ struct Lm {
                 OVS_HIP_TRY(hipMemcpyAsync(h_fail, gi.d_fail, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
                 OVS_HIP_TRY(hipStreamSynchronize(stream));
                 bool ok = *h_fail == 0;
+                const double t1 = now();
+                t_schur += t1 - t0;
                 const double* h_bp = h_pin + (size_t)n * n + n;
                 if (ok && n > 0) {
                     S.assign(h_pin, h_pin + (size_t)n * n);
                     rhs.assign(h_pin + (size_t)n * n, h_pin + (size_t)n * n + n);
                     ok = cholesky_solve(S, n, rhs);
                 }
+                const double t2 = now();
+                t_chol += t2 - t1;
                 double temp_chi = 1.7976931348623157e308;
                 double scale = 1e-3;
                 if (ok) {
@@ -203,6 +216,7 @@ struct Lm {
                             for (int a = 0; a < 6; ++a) sc += dxp[(size_t)6 * k + a] * (lambda * dxp[(size_t)6 * k + a] + h_bp[(size_t)6 * k + a]);
                     scale = (sc + h_chi[4]) + 1e-3;
                 }
+                t_trial += now() - t2;
                 rho = (current_chi - temp_chi) / scale;
                 if (ok && rho > 0 && std::isfinite(temp_chi)) {
                     double alpha = 1.0 - std::pow(2 * rho - 1, 3.0);
@@ -266,8 +280,11 @@ ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* p
     OVS_HIP_TRY(hipSetDevice(device));
     // ---- round 1 graph: all edges (validates the indices)
     GraphGuard g1, g2;
+    const bool trace = std::getenv("OVS_BA_TRACE") != nullptr;
+    const double t_begin = Lm::now();
     ovs_status st = ovs_ba_graph_create(device, n_pose, pose_fixed, n_pt, mono, n_mono, stereo, n_stereo, cam, focal_x_baseline, &g1.g);
     if (st != OVS_OK) return st;
+    const double t_g1 = Lm::now();
     const size_t ne = (size_t)n_mono + n_stereo;
     Lm L;
     L.setup_type = setup_type;
@@ -324,6 +341,10 @@ ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* p
     for (int k = 0; k < n_pose; ++k)
         if (!(pose_fixed && pose_fixed[k])) std::memcpy(poses + 7 * (size_t)k, &p7[(size_t)7 * k], sizeof(double) * 7);
     OVS_HIP_TRY(hipMemcpy(points, L.d_X, sizeof(double) * 3 * (size_t)n_pt, hipMemcpyDeviceToHost));
+    if (trace)
+        std::fprintf(stderr, "[ovs_local_ba_optimize] total %.2f ms: graph build (round 1) %.2f, %d trials: schur+download %.2f, host cholesky %.2f, "
+                             "update+linearise %.2f ms\n",
+                     Lm::now() - t_begin, t_g1 - t_begin, L.n_trials, L.t_schur, L.t_chol, L.t_trial);
     if (info) {
         info_l[4] = it1;
         info_l[5] = it2;

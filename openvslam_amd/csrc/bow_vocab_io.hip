@@ -1,0 +1,260 @@
+// bow_vocab_io.hip -- SURVEY 8(f) #4, the on-disk vocabulary formats of data::bow_vocabulary (expected call sites:
+// src/openvslam/system.cc `bow_vocab_->loadFromBinaryFile(vocab_file_path)` with DBoW2, `bow_vocab_->readFromFile(...)` with FBoW).
+// Host code only: a file is parsed into the tree arrays ovs_vocab_create takes (node 0 = root, CSR of children in creation order,
+// 32-byte node descriptors, node weights, word ids). The third-party readers are absent from the container (un-vendored DBoW2 / FBoW
+// forks); their published layouts are restated:
+//   * DBoW2 text   (TemplatedVocabulary::loadFromTextFile, the ORB-SLAM2 ORBvoc.txt format): header "k L scoring weighting", then one line
+//                  per node in creation order: "parent_id is_leaf b0 ... b31 weight"; node ids are 1, 2, ... in file order, word ids
+//                  0, 1, ... in order of the leaves.
+//   * DBoW2 binary (the fork's loadFromBinaryFile / saveToBinaryFile, orb_vocab.dbow2): u32 nb_nodes, u32 size_node (= 41 for ORB),
+//                  i32 k, i32 L, i32 scoring, i32 weighting, then nb_nodes records {i32 parent, u8[32] descriptor, f32 weight, u8 is_leaf}.
+//   * FBoW         (fbow::Vocabulary::toStream / fromStream, orb_vocab.fbow): u64 signature 55824124, the `params` struct (descriptor name
+//                  char[50], u32 alignment, u32 nblocks, u64 desc_size_bytes_wp, u64 block_size_bytes_wp, u64 feature_off_start,
+//                  u64 child_off_start, u64 total_size, i32 desc_type, i32 desc_size, u32 m_k; natural alignment, 120 bytes), then
+//                  total_size bytes of blocks. Block b at b * block_size_bytes_wp: u16 N (nodes in the block), u16 is_leaf, the N features at
+//                  feature_off_start (desc_size_bytes_wp apart), and at child_off_start N records {u32 id_or_childblock, f32 weight}: bit 31
+//                  set = leaf, the low 31 bits are then the word id; otherwise they are the block holding the node's children. Block 0 holds
+//                  the root's children. Inner FBoW nodes carry no id of their own: node ids are assigned here as 1 + (block * k + slot),
+//                  i.e. in block order (oracle/ORACLE_SPEC.md rule 30).
+// Tests write synthetic vocabularies in all three formats (tools/vocab_io.py, the committed generator) and require the loaded tree and
+// its transform to equal the source tree's.
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "ovs_common.h"
+
+namespace {
+
+struct Tree {
+    int depth = 0;
+    std::vector<int32_t> parent;   // per node (root: -1)
+    std::vector<uint8_t> desc;     // 32 per node
+    std::vector<double> weight;
+    std::vector<int32_t> word;     // -1 for inner nodes
+};
+
+bool read_all(const char* path, std::vector<unsigned char>& buf) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    f.seekg(0, std::ios::end);
+    const std::streamoff n = f.tellg();
+    if (n < 0) return false;
+    f.seekg(0, std::ios::beg);
+    buf.resize((size_t)n);
+    if (n > 0) f.read(reinterpret_cast<char*>(buf.data()), n);
+    return (bool)f || f.eof();
+}
+
+template <typename T>
+bool get(const std::vector<unsigned char>& b, size_t off, T* v) {
+    if (off + sizeof(T) > b.size()) return false;
+    std::memcpy(v, b.data() + off, sizeof(T));
+    return true;
+}
+
+bool parse_fbow(const std::vector<unsigned char>& b, Tree& t) {
+    uint64_t sig = 0;
+    if (!get(b, 0, &sig) || sig != 55824124ull) return false;
+    struct Params {
+        char desc_name[50];
+        uint32_t alignment, nblocks;
+        uint64_t desc_size_bytes_wp, block_size_bytes_wp, feature_off_start, child_off_start, total_size;
+        int32_t desc_type, desc_size;
+        uint32_t m_k;
+    } p;
+    static_assert(sizeof(Params) == 120, "fbow::Vocabulary::params layout");
+    if (!get(b, 8, &p)) return false;
+    const size_t base = 8 + sizeof(Params);
+    if (p.desc_size != 32 || p.m_k == 0 || p.m_k > 65535 || p.nblocks == 0 || p.block_size_bytes_wp == 0 ||
+        base + p.total_size > b.size() || (uint64_t)p.nblocks * p.block_size_bytes_wp > p.total_size)
+        return false;
+    // node ids: 0 = root, 1 + block * k + slot for the node in `slot` of `block`
+    const size_t n_nodes = 1 + (size_t)p.nblocks * p.m_k;
+    t.parent.assign(n_nodes, -2);   // -2: slot not used
+    t.desc.assign(n_nodes * 32, 0);
+    t.weight.assign(n_nodes, 0.0);
+    t.word.assign(n_nodes, -1);
+    t.parent[0] = -1;
+    std::vector<int32_t> block_parent(p.nblocks, -2), block_depth(p.nblocks, 0);
+    block_parent[0] = 0;
+    block_depth[0] = 1;
+    int depth = 0;
+    for (uint32_t blk = 0; blk < p.nblocks; ++blk) {
+        if (block_parent[blk] == -2) continue;   // unreachable block (blocks are written parents first)
+        const size_t bo = base + (size_t)blk * p.block_size_bytes_wp;
+        uint16_t n = 0, leaf = 0;
+        if (!get(b, bo, &n) || !get(b, bo + 2, &leaf) || n > p.m_k) return false;
+        depth = std::max(depth, (int)block_depth[blk]);
+        for (uint16_t s = 0; s < n; ++s) {
+            const size_t id = 1 + (size_t)blk * p.m_k + s;
+            const size_t fo = bo + p.feature_off_start + (size_t)s * p.desc_size_bytes_wp;
+            const size_t co = bo + p.child_off_start + (size_t)s * 8;
+            uint32_t idc = 0;
+            float w = 0;
+            if (fo + 32 > b.size() || !get(b, co, &idc) || !get(b, co + 4, &w)) return false;
+            std::memcpy(&t.desc[id * 32], b.data() + fo, 32);
+            t.parent[id] = block_parent[blk];
+            t.weight[id] = (double)w;
+            if (idc & 0x80000000u) {
+                t.word[id] = (int32_t)(idc & 0x7FFFFFFFu);
+            } else {
+                const uint32_t cb = idc & 0x7FFFFFFFu;
+                if (cb >= p.nblocks || cb <= blk) return false;
+                block_parent[cb] = (int32_t)id;
+                block_depth[cb] = block_depth[blk] + 1;
+            }
+        }
+    }
+    t.depth = depth;
+    return true;
+}
+
+bool parse_dbow2_binary(const std::vector<unsigned char>& b, Tree& t) {
+    uint32_t nb_nodes = 0, size_node = 0;
+    int32_t k = 0, L = 0, scoring = 0, weighting = 0;
+    if (!get(b, 0, &nb_nodes) || !get(b, 4, &size_node) || !get(b, 8, &k) || !get(b, 12, &L) || !get(b, 16, &scoring) || !get(b, 20, &weighting))
+        return false;
+    if (size_node != 41 || k < 1 || k > 65535 || L < 0 || L > 16 || (size_t)24 + (size_t)nb_nodes * size_node > b.size()) return false;
+    const size_t n_nodes = (size_t)nb_nodes + 1;
+    t.depth = L;
+    t.parent.assign(n_nodes, -1);
+    t.desc.assign(n_nodes * 32, 0);
+    t.weight.assign(n_nodes, 0.0);
+    t.word.assign(n_nodes, -1);
+    int32_t n_words = 0;
+    for (size_t nid = 1; nid < n_nodes; ++nid) {
+        const unsigned char* r = b.data() + 24 + (nid - 1) * size_node;
+        int32_t parent;
+        float w;
+        std::memcpy(&parent, r, 4);
+        std::memcpy(&w, r + 36, 4);
+        if (parent < 0 || (size_t)parent >= nid) return false;   // parents are written before their children
+        t.parent[nid] = parent;
+        std::memcpy(&t.desc[nid * 32], r + 4, 32);
+        t.weight[nid] = (double)w;
+        if (r[40]) t.word[nid] = n_words++;
+    }
+    return true;
+}
+
+bool parse_dbow2_text(const std::vector<unsigned char>& b, Tree& t) {
+    std::istringstream f(std::string(reinterpret_cast<const char*>(b.data()), b.size()));
+    int k, L, scoring, weighting;
+    if (!(f >> k >> L >> scoring >> weighting) || k < 1 || k > 65535 || L < 0 || L > 16) return false;
+    t.depth = L;
+    t.parent.assign(1, -1);
+    t.desc.assign(32, 0);
+    t.weight.assign(1, 0.0);
+    t.word.assign(1, -1);
+    int32_t n_words = 0;
+    int parent, is_leaf;
+    while (f >> parent >> is_leaf) {
+        const size_t nid = t.parent.size();
+        if (parent < 0 || (size_t)parent >= nid) return false;
+        t.parent.push_back(parent);
+        for (int i = 0; i < 32; ++i) {
+            int v;
+            if (!(f >> v) || v < 0 || v > 255) return false;
+            t.desc.push_back((uint8_t)v);
+        }
+        double w;
+        if (!(f >> w)) return false;
+        t.weight.push_back(w);
+        t.word.push_back(is_leaf > 0 ? n_words++ : -1);
+    }
+    return t.parent.size() > 1;
+}
+
+}   // namespace
+
+struct ovs_vocab_tree {
+    int format = 0, depth = 0;
+    std::vector<int32_t> child_start, children, word;
+    std::vector<uint8_t> desc;
+    std::vector<double> weight;
+};
+
+extern "C" {
+
+ovs_status ovs_vocab_tree_load(const char* path, ovs_vocab_tree** out, int32_t* format_out, int32_t* n_nodes_out, int32_t* depth_out) {
+    if (!path || !out) return OVS_ERR_INVALID;
+    *out = nullptr;
+    std::vector<unsigned char> buf;
+    if (!read_all(path, buf) || buf.size() < 8) return OVS_ERR_INVALID;
+    Tree t;
+    int format = 0;
+    if (parse_fbow(buf, t)) format = OVS_VOCAB_FBOW;
+    else if ((t = Tree(), parse_dbow2_binary(buf, t))) format = OVS_VOCAB_DBOW2_BINARY;
+    else if ((t = Tree(), parse_dbow2_text(buf, t))) format = OVS_VOCAB_DBOW2_TEXT;
+    else return OVS_ERR_INVALID;
+    // compact away unused FBoW slots, keep the relative order of the node ids; build the CSR (children in id order = creation order)
+    const size_t n_all = t.parent.size();
+    std::vector<int32_t> new_id(n_all, -1);
+    int32_t n_nodes = 0;
+    for (size_t i = 0; i < n_all; ++i)
+        if (t.parent[i] != -2) new_id[i] = n_nodes++;
+    ovs_vocab_tree* v = new (std::nothrow) ovs_vocab_tree();
+    if (!v) return OVS_ERR_INVALID;
+    v->format = format;
+    v->depth = t.depth;
+    v->child_start.assign((size_t)n_nodes + 1, 0);
+    v->children.assign((size_t)std::max(n_nodes - 1, 1), 0);
+    v->word.resize((size_t)n_nodes);
+    v->desc.resize((size_t)n_nodes * 32);
+    v->weight.resize((size_t)n_nodes);
+    for (size_t i = 0; i < n_all; ++i) {
+        if (new_id[i] < 0) continue;
+        const int32_t id = new_id[i];
+        std::memcpy(&v->desc[(size_t)id * 32], &t.desc[i * 32], 32);
+        v->weight[(size_t)id] = t.weight[i];
+        v->word[(size_t)id] = t.word[i];
+        if (t.parent[i] >= 0) ++v->child_start[(size_t)new_id[(size_t)t.parent[i]] + 1];
+    }
+    for (int32_t i = 0; i < n_nodes; ++i) v->child_start[(size_t)i + 1] += v->child_start[i];
+    {
+        std::vector<int32_t> fill(v->child_start.begin(), v->child_start.end() - 1);
+        for (size_t i = 0; i < n_all; ++i)
+            if (new_id[i] >= 0 && t.parent[i] >= 0) v->children[(size_t)fill[(size_t)new_id[(size_t)t.parent[i]]]++] = new_id[i];
+    }
+    if (format_out) *format_out = format;
+    if (n_nodes_out) *n_nodes_out = n_nodes;
+    if (depth_out) *depth_out = t.depth;
+    *out = v;
+    return OVS_OK;
+}
+
+ovs_status ovs_vocab_tree_arrays(const ovs_vocab_tree* v, int32_t* child_start, int32_t* children, uint8_t* node_desc, double* node_weight,
+                                 int32_t* node_word_id) {
+    if (!v) return OVS_ERR_INVALID;
+    const size_t n = v->word.size();
+    if (child_start) std::memcpy(child_start, v->child_start.data(), sizeof(int32_t) * (n + 1));
+    if (children && n > 1) std::memcpy(children, v->children.data(), sizeof(int32_t) * (n - 1));
+    if (node_desc) std::memcpy(node_desc, v->desc.data(), n * 32);
+    if (node_weight) std::memcpy(node_weight, v->weight.data(), sizeof(double) * n);
+    if (node_word_id) std::memcpy(node_word_id, v->word.data(), sizeof(int32_t) * n);
+    return OVS_OK;
+}
+
+ovs_status ovs_vocab_tree_free(ovs_vocab_tree* v) {
+    delete v;
+    return OVS_OK;
+}
+
+ovs_status ovs_vocab_load_file(int32_t device, const char* path, int32_t max_features, ovs_vocab** out, int32_t* format_out) {
+    if (!path || !out || max_features < 1) return OVS_ERR_INVALID;
+    *out = nullptr;
+    ovs_vocab_tree* t = nullptr;
+    int32_t n_nodes = 0, depth = 0;
+    ovs_status st = ovs_vocab_tree_load(path, &t, format_out, &n_nodes, &depth);
+    if (st != OVS_OK) return st;
+    st = ovs_vocab_create(device, n_nodes, t->child_start.data(), t->children.data(), t->desc.data(), t->weight.data(), t->word.data(), depth,
+                          max_features, out);
+    ovs_vocab_tree_free(t);
+    return st;
+}
+
+}   // extern "C"
