@@ -72,3 +72,27 @@ def assemble(word, weight, node):
         for w in bow_vec:
             bow_vec[w] /= norm
     return dict(sorted(bow_vec.items())), dict(sorted(feat_vec.items()))
+
+
+def load_vocabulary_tree(path):
+    """Parse an on-disk ORB vocabulary (DBoW2 text, the DBoW2 fork's binary .dbow2, FBoW .fbow; detected from the content) on the host:
+    returns (vocab dict for `vocabulary`, format code 1 / 2 / 3). No device needed (ovs_vocab_tree_load)."""
+    L = _lib.lib()
+    h, fmt, n, depth = C.c_void_p(), C.c_int32(), C.c_int32(), C.c_int32()
+    _lib.check(L.ovs_vocab_tree_load(str(path).encode(), C.byref(h), C.byref(fmt), C.byref(n), C.byref(depth)), "ovs_vocab_tree_load")
+    try:
+        n = n.value
+        out = dict(child_start=np.zeros(n + 1, np.int32), children=np.zeros(max(n - 1, 1), np.int32), desc=np.zeros((n, 32), np.uint8),
+                   weight=np.zeros(n), word_id=np.zeros(n, np.int32), depth=depth.value)
+        _lib.check(L.ovs_vocab_tree_arrays(h, _p(out["child_start"]), _p(out["children"]), _p(out["desc"]), _p(out["weight"]), _p(out["word_id"])),
+                   "ovs_vocab_tree_arrays")
+        out["children"] = out["children"][:n - 1]
+    finally:
+        L.ovs_vocab_tree_free(h)
+    return out, fmt.value
+
+
+def load_vocabulary(path, max_features=8192, device=0):
+    """data::bow_vocabulary from a file: parse + upload (the C ABI does both in ovs_vocab_load_file; this mirror keeps the host arrays)."""
+    tree, _ = load_vocabulary_tree(path)
+    return vocabulary(tree, max_features=max_features, device=device)

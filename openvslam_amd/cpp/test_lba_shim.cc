@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "openvslam/data/bow_vocabulary.h"
 #include "openvslam/match/robust.h"
 #include "openvslam/optimize/local_bundle_adjuster.h"
 
@@ -166,9 +167,45 @@ int run_mfk(const char* in, const char* out) {
     std::printf("mfk shim ok: %u brute-force matches, %u inliers\n", n_bf, n_inl);
     return 0;
 }
+// data::bow_vocabulary: load a vocabulary file, transform N x 32 descriptors, dump the BowVector and the FeatureVector
+int run_bow(const char* vocab_path, const char* desc_path, const char* out) {
+    data::bow_vocabulary voc;
+    voc.loadFromBinaryFile(vocab_path);
+    const auto buf = read_all(desc_path);
+    const int n = (int)(buf.size() / 32);
+    cv::Mat desc(n, 32, cv::CV_8U);
+    for (int i = 0; i < n; ++i) std::memcpy(desc.ptr(i), buf.data() + (size_t)i * 32, 32);
+    std::vector<cv::Mat> feats;
+    for (int i = 0; i < n; ++i) feats.push_back(desc.row(i));
+    data::bow_vector v1, v2;
+    data::bow_feature_vector_t f1, f2;
+    voc.transform(feats, v1, f1, 4);     // DBoW2 signature
+    voc.transform(desc, 4, v2, f2);      // FBoW signature
+    if (v1 != v2 || f1 != f2) return 3;
+    FILE* f = std::fopen(out, "wb");
+    const int32_t hdr[2] = {(int32_t)v1.size(), (int32_t)f1.size()};
+    std::fwrite(hdr, sizeof(hdr), 1, f);
+    for (const auto& e : v1) {
+        const int32_t w = (int32_t)e.first;
+        std::fwrite(&w, 4, 1, f);
+        std::fwrite(&e.second, 8, 1, f);
+    }
+    for (const auto& e : f1) {
+        const int32_t h2[2] = {(int32_t)e.first, (int32_t)e.second.size()};
+        std::fwrite(h2, sizeof(h2), 1, f);
+        for (const auto i : e.second) {
+            const int32_t ii = (int32_t)i;
+            std::fwrite(&ii, 4, 1, f);
+        }
+    }
+    std::fclose(f);
+    std::printf("bow shim ok: %d features, %zu words, %zu nodes\n", n, v1.size(), f1.size());
+    return 0;
+}
 }   // namespace
 
 int main(int argc, char** argv) {
+    if (argc == 5 && std::string(argv[1]) == "bow") return run_bow(argv[2], argv[3], argv[4]);
     if (argc != 4) return 2;
     if (std::string(argv[1]) == "lba") return run_lba(argv[2], argv[3]);
     if (std::string(argv[1]) == "mfk") return run_mfk(argv[2], argv[3]);
