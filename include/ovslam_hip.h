@@ -127,6 +127,14 @@ ovs_status ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_images, int32_
  * overlap the VALU-bound FAST pass of another. Results are identical (frames are independent). n_sub in [1, 4]; 1 = off. */
 ovs_status ovs_orb_set_pipeline(ovs_orb* h, int32_t n_sub);
 
+/* Level-0 FAST beside the pyramid (no upstream counterpart; default ON): FAST on level 0 reads the caller's image and does not depend on
+ * the seven resize launches, so it is issued on an internal stream next to them (integer-VALU-bound beside latency / bandwidth-bound) and the
+ * remaining levels follow the pyramid. Identical results (cells are independent). With it ON the four stage times of ovs_orb_profile_read are
+ * {pyramid window (level-0 FAST running beside it), FAST levels >= 1, quad-tree, describe}; ovs_orb_profile_read_aux returns the level-0 FAST
+ * launch's own duration. OFF = one FAST launch over all levels after the pyramid (what per-kernel rooflines are quoted on). */
+ovs_status ovs_orb_set_fast_split(ovs_orb* h, int32_t enable);
+ovs_status ovs_orb_profile_read_aux(ovs_orb* h, float* fast_level0_ms, int32_t* ncalls);
+
 /* replaces: the public member orb_extractor::image_pyramid_ (read by match::stereo). Copies level `level` of frame
  * `frame` (0 for the host API) of the LAST extract into host_dst (rows*cols bytes, contiguous) and reports its size.
  * host_dst may be NULL to query the size only. Waits for the stream the last extract ran on (not for the device). */

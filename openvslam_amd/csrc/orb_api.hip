@@ -100,6 +100,12 @@ struct ovs_orb {
     hipStream_t sub_stream[kMaxSub] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSub] = {};
     StageProfiler<4> prof_sub[kMaxSub];
+    // FAST on level 0 needs no pyramid: it runs on aux_stream BESIDE the seven resize launches (VALU-bound next to latency / bandwidth-bound),
+    // the remaining levels follow the pyramid on the main stream (ovs_orb_set_fast_split; default on)
+    bool fast_split = true;
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_aux_fork = nullptr, ev_aux_join = nullptr;
+    StageProfiler<1> prof_aux;
 };
 
 namespace {
@@ -256,6 +262,16 @@ ovs_status run_chain(ovs_orb* h, StageProfiler<4>& prof, const uint8_t* d_images
     const uint8_t* img = d_images + (size_t)f0 * frame_stride;
     const uint8_t* msk = d_masks ? d_masks + (size_t)f0 * frame_stride : nullptr;
     OVS_HIP_TRY(prof.begin(s));
+    const bool split = h->fast_split && L > 1 && &prof == &h->prof && geo.lv[1].cell_base > 0;
+    if (split) {
+        OVS_HIP_TRY(hipEventRecord(h->ev_aux_fork, s));
+        OVS_HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_aux_fork, 0));
+        h->prof_aux.enabled = prof.enabled;
+        OVS_HIP_TRY(h->prof_aux.begin(h->aux_stream));
+        OVS_HIP_TRY(launch_fast(geo, d, img, stride, frame_stride, msk, rows, nb, h->aux_stream, 0, geo.lv[1].cell_base));
+        OVS_HIP_TRY(h->prof_aux.mark(1, h->aux_stream));
+        OVS_HIP_TRY(hipEventRecord(h->ev_aux_join, h->aux_stream));
+    }
     // A1: each level from the previous one
     for (int l = 1; l < L; ++l) {
         const LevelGeo& g = geo.lv[l];
@@ -267,7 +283,12 @@ ovs_status run_chain(ovs_orb* h, StageProfiler<4>& prof, const uint8_t* d_images
                                   h->d_taps + g.xtab_off, h->d_taps + g.ytab_off, nb, s));
     }
     OVS_HIP_TRY(prof.mark(1, s));
-    OVS_HIP_TRY(launch_fast(geo, d, img, stride, frame_stride, msk, rows, nb, s));
+    if (split) {
+        OVS_HIP_TRY(launch_fast(geo, d, img, stride, frame_stride, msk, rows, nb, s, geo.lv[1].cell_base, -1));
+        OVS_HIP_TRY(hipStreamWaitEvent(s, h->ev_aux_join, 0));
+    } else {
+        OVS_HIP_TRY(launch_fast(geo, d, img, stride, frame_stride, msk, rows, nb, s));
+    }
     OVS_HIP_TRY(prof.mark(2, s));
     OVS_HIP_TRY(launch_tree(geo, d, nb, s));
     OVS_HIP_TRY(prof.mark(3, s));
@@ -420,6 +441,9 @@ ovs_status ovs_orb_create(const ovs_orb_params* params, int32_t max_rows, int32_
         h->d_out_desc = blk + h->out_off_desc;
     }
     CREATE_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_aux_fork, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_aux_join, hipEventDisableTiming));
     for (auto& sl : h->slot) {
         CREATE_TRY(hipMalloc(&sl.d_img, h->img_pitch * max_rows));
         CREATE_TRY(hipHostMalloc(&sl.h_in, h->img_pitch * max_rows, hipHostMallocDefault));
@@ -457,6 +481,13 @@ ovs_status ovs_orb_destroy(ovs_orb* h) {
             if (e) hipEventDestroy(e);
     }
     hipFree(h->d_out_counts);   // base of the [counts | keypoints | descriptors] block
+    if (h->aux_stream) {
+        hipStreamSynchronize(h->aux_stream);
+        hipStreamDestroy(h->aux_stream);
+    }
+    if (h->ev_aux_fork) hipEventDestroy(h->ev_aux_fork);
+    if (h->ev_aux_join) hipEventDestroy(h->ev_aux_join);
+    h->prof_aux.destroy();
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
     h->prof.destroy();
     for (int k = 0; k < ovs_orb::kMaxSub; ++k) {
@@ -513,6 +544,22 @@ ovs_status ovs_orb_profile_read(ovs_orb* h, float* stage_ms, int32_t* ncalls) {
         for (int j = 0; j < 4; ++j) stage_ms[j] += ms[j];
         if (k == 0) *ncalls += nc;
     }
+    return OVS_OK;
+}
+
+ovs_status ovs_orb_set_fast_split(ovs_orb* h, int32_t enable) {
+    if (!h) return OVS_ERR_INVALID;
+    h->fast_split = enable != 0;
+    return OVS_OK;
+}
+
+ovs_status ovs_orb_profile_read_aux(ovs_orb* h, float* fast_level0_ms, int32_t* ncalls) {
+    if (!h || !fast_level0_ms || !ncalls) return OVS_ERR_INVALID;
+    OVS_HIP_TRY(hipSetDevice(h->device));
+    *fast_level0_ms = 0;
+    *ncalls = 0;
+    if (!h->prof_aux.created) return OVS_OK;
+    OVS_HIP_TRY(h->prof_aux.read(fast_level0_ms, ncalls));
     return OVS_OK;
 }
 

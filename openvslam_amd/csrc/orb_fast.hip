@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                    size_t frame_stride0, const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                                    uint64_t* __restrict__ cand, size_t cand_frame_entries,
                                                    uint32_t* __restrict__ cand_count, const uint8_t* __restrict__ mask,
-                                                   int batch) {
+                                                   int batch, int cell_lo, int n_cells) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[kTileRowsMax][kTileWords];
     __shared__ __attribute__((aligned(16))) uint32_t smap[kSmapRows][kSmapWords];
     __shared__ uint16_t clist[4][kCellSize * kCellSize / 4];   // per wave: its pixels that passed the diameter test, (y << 8) | x
@@ -152,11 +152,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // (fabric traffic 3.0x -> see profiles/). Inside an XCD's share the FRAME index runs fastest: the workgroups in flight at any moment
     // then reserve list space on `batch` times as many (frame, level) counters -- with frame-major order all of them hammered the 8
     // counters of one frame, and same-address atomics at the fabric side cost ~0.05 ms per launch. The grid is 8 * per_xcd * batch.
-    const int per_xcd = (geo->total_cells + 7) >> 3;
+    // The launch covers cells [cell_lo, cell_lo + n_cells): all of them, or one level range (level 0 runs beside the pyramid, see orb_api.hip).
+    const int per_xcd = (n_cells + 7) >> 3;
     const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
     const int slot = idx / batch, frame = idx - slot * batch;
-    const int cell_id = xcd * per_xcd + slot;
-    if (cell_id >= geo->total_cells) return;
+    if (xcd * per_xcd + slot >= n_cells) return;
+    const int cell_id = cell_lo + xcd * per_xcd + slot;
     // The prologue is a chain of dependent scalar loads in front of the tile fetch, and nothing else can run in this workgroup until the
     // tile is in LDS: keep the chain at three round trips (kernel arguments -> header + level table -> the level's geometry).
     int level = 0;
@@ -351,12 +352,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 }
 
 hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
-                       const uint8_t* mask, int mask_rows, int batch, hipStream_t s) {
+                       const uint8_t* mask, int mask_rows, int batch, hipStream_t s, int cell_lo, int n_cells) {
     (void)mask_rows;
-    if (hgeo.total_cells == 0 || batch <= 0) return hipSuccess;
-    const unsigned per_xcd = (unsigned)(hgeo.total_cells + 7) / 8u;
+    if (n_cells < 0) n_cells = hgeo.total_cells - cell_lo;
+    if (n_cells <= 0 || batch <= 0) return hipSuccess;
+    const unsigned per_xcd = (unsigned)(n_cells + 7) / 8u;
     hipLaunchKernelGGL(k_fast_cells, dim3(8u * per_xcd * (unsigned)batch), dim3(256), 0, s, d.geo, img0, stride0, frame_stride0, d.pyr,
-                       d.pyr_frame_bytes, d.cand, d.cand_frame_entries, d.cand_count, mask, batch);
+                       d.pyr_frame_bytes, d.cand, d.cand_frame_entries, d.cand_count, mask, batch, cell_lo, n_cells);
     return hipGetLastError();
 }
 

@@ -121,6 +121,10 @@ class orb_extractor:
                    "ovs_orb_extract")
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    def set_fast_split(self, enable):
+        """Level-0 FAST beside the pyramid on an internal stream (default on); off = one FAST launch after the pyramid."""
+        _lib.check(self._L.ovs_orb_set_fast_split(self._h, 1 if enable else 0), "ovs_orb_set_fast_split")
+
     def set_pipeline(self, n_sub):
         """Issue the device-batch extract as n_sub overlapping sub-batches on internal streams (ovs_orb_set_pipeline)."""
         _lib.check(self._L.ovs_orb_set_pipeline(self._h, int(n_sub)), "ovs_orb_set_pipeline")
