@@ -128,6 +128,7 @@ struct GraphDev {   // device views shared by the kernels
     const int32_t* pose_start;   // [n_pose + 1] into pose_edges
     const int32_t* pose_edges;
     const uint8_t* fixed;        // [n_pose]
+    const uint8_t* active;       // [n_edge] 0 = the edge is at g2o level 1 (an outlier of round 1): it contributes nothing
     ovs_ba_cam cam;
     double bf;
 };
@@ -148,6 +149,12 @@ __global__ __launch_bounds__(128) void k_lin_landmark(GraphDev g, const double* 
     const int e0 = g.lm_start[j], e1 = g.lm_start[j + 1], nm = g.lm_nmono[j];
     auto body = [&](const bool stereo, double (&h)[9], double (&gg)[3], double& c2a, double& r0a, int i) __attribute__((always_inline)) {
         const int e = g.lm_edges[i];
+        if (!g.active[e]) {   // exact zeros: the sums of the remaining edges keep their order and value
+            double* hz = Hpl + 18 * (size_t)e;
+#pragma unroll
+            for (int a = 0; a < 18; ++a) hz[a] = 0.0;
+            return;
+        }
         const GEdge ed = g.edges[e];
         double Jl[3][6], Jp[3][6], r[3], W, c2, rho0;
         edge_lin(poses + 7 * (size_t)ed.pose, X, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
@@ -211,6 +218,7 @@ __global__ __launch_bounds__(256) void k_lin_pose(GraphDev g, const double* __re
         const int e0 = g.pose_start[k], e1 = g.pose_start[k + 1];
         for (int i = e0 + (int)threadIdx.x; i < e1; i += 256) {
             const int e = g.pose_edges[i];
+            if (!g.active[e]) continue;
             const bool stereo = e >= g.n_mono;
             const GEdge ed = g.edges[e];
             double Jl[3][6], Jp[3][6], r[3], W, c2, rho0;
@@ -454,7 +462,10 @@ struct ovs_ba_graph {
     std::vector<uint8_t> fixed;
     std::vector<int32_t> slot, slot_pose;   // pose -> reduced-system block (-1 fixed); block -> pose
     std::vector<int32_t> edge_pose, edge_pt;
-    // device
+    // device: ONE allocation + ONE upload per graph (a dozen hipMalloc / hipMemcpy pairs cost more than the kernels of a whole LM trial)
+    unsigned char* d_arena = nullptr;
+    unsigned char* d_solver_arena = nullptr;
+    uint8_t* d_active = nullptr;
     GEdge* d_edges = nullptr;
     int32_t *d_lm_start = nullptr, *d_lm_edges = nullptr, *d_lm_nmono = nullptr, *d_pose_start = nullptr, *d_pose_edges = nullptr;
     uint8_t* d_fixed = nullptr;
@@ -479,6 +490,7 @@ struct ovs_ba_graph {
         g.pose_start = d_pose_start;
         g.pose_edges = d_pose_edges;
         g.fixed = d_fixed;
+        g.active = d_active;
         g.cam = cam;
         g.bf = bf;
         return g;
@@ -488,13 +500,21 @@ struct ovs_ba_graph {
 
 namespace {
 
-template <typename T>
-hipError_t upload(T** dst, const std::vector<T>& v) {
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), sizeof(T) * std::max<size_t>(v.size(), 1));
-    if (e != hipSuccess) return e;
-    if (!v.empty()) e = hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);
-    return e;
-}
+// host image of the device arena: arrays appended at 256-byte aligned offsets, uploaded with one hipMemcpy
+struct Blob {
+    std::vector<unsigned char> bytes;
+    size_t reserve_bytes(size_t n) {
+        const size_t off = (bytes.size() + 255) & ~(size_t)255;
+        bytes.resize(off + n, 0);
+        return off;
+    }
+    template <typename T>
+    size_t add(const std::vector<T>& v) {
+        const size_t off = reserve_bytes(sizeof(T) * std::max<size_t>(v.size(), 1));
+        if (!v.empty()) std::memcpy(&bytes[off], v.data(), sizeof(T) * v.size());
+        return off;
+    }
+};
 
 ovs_status graph_linearize(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo, double* d_Hpp,
                            double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s) {
@@ -516,24 +536,8 @@ extern "C" {
 ovs_status ovs_ba_graph_destroy(ovs_ba_graph* g) {
     if (!g) return OVS_OK;
     (void)hipSetDevice(g->device);
-    hipFree(g->d_edges);
-    hipFree(g->d_lm_start);
-    hipFree(g->d_lm_edges);
-    hipFree(g->d_lm_nmono);
-    hipFree(g->d_pose_start);
-    hipFree(g->d_pose_edges);
-    hipFree(g->d_fixed);
-    hipFree(g->d_pair_start);
-    hipFree(g->d_pair_ab);
-    hipFree(g->d_pair_ent);
-    hipFree(g->d_slot_pose);
-    hipFree(g->d_fail);
-    hipFree(g->d_lm_tmp);
-    hipFree(g->d_Hinv);
-    hipFree(g->d_Y);
-    hipFree(g->d_S);
-    hipFree(g->d_dxp);
-    hipFree(g->d_scal);
+    hipFree(g->d_arena);          // every array of the graph lives in one of the two arenas
+    hipFree(g->d_solver_arena);
     delete g;
     return OVS_OK;
 }
@@ -608,14 +612,12 @@ ovs_status ovs_ba_graph_create(int32_t device, int32_t n_pose, const uint8_t* po
             return OVS_ERR_HIP;                \
         }                                      \
     } while (0)
-    G_TRY(upload(&g->d_edges, edges));
-    G_TRY(upload(&g->d_lm_start, lm_start));
-    G_TRY(upload(&g->d_lm_edges, lm_edges));
-    G_TRY(upload(&g->d_lm_nmono, lm_nmono));
-    G_TRY(upload(&g->d_pose_start, pose_start));
-    G_TRY(upload(&g->d_pose_edges, pose_edges));
-    G_TRY(upload(&g->d_fixed, g->fixed));
-    G_TRY(hipMalloc(&g->d_lm_tmp, sizeof(double) * 2 * (size_t)n_pt));
+    Blob blob;
+    const size_t o_edges = blob.add(edges), o_lm_start = blob.add(lm_start), o_lm_edges = blob.add(lm_edges), o_lm_nmono = blob.add(lm_nmono),
+                 o_pose_start = blob.add(pose_start), o_pose_edges = blob.add(pose_edges), o_fixed = blob.add(g->fixed);
+    const size_t o_active = blob.add(std::vector<uint8_t>((size_t)std::max(ne, 1), (uint8_t)1));
+    const size_t o_lm_tmp = blob.reserve_bytes(sizeof(double) * 2 * (size_t)n_pt);
+    size_t o_pair_start = 0, o_pair_ab = 0, o_pair_ent = 0, o_slot_pose = 0;
     // reduced-system pair lists: for every landmark all (edge a, edge b) with free poses and slot(a) <= slot(b)
     if (g->n_free > 0) {
         const int nf = g->n_free;
@@ -647,10 +649,28 @@ ovs_status ovs_ba_graph_create(int32_t device, int32_t n_pose, const uint8_t* po
         std::vector<int32_t> fill(pstart.begin(), pstart.end() - 1);
         for_pairs([&](int p, int ea, int eb) { ent[(size_t)fill[p]++] = int2{ea, eb}; });
         g->n_pairs = n_pairs;
-        G_TRY(upload(&g->d_pair_start, pstart));
-        G_TRY(upload(&g->d_pair_ab, pab));
-        G_TRY(upload(&g->d_pair_ent, ent));
-        G_TRY(upload(&g->d_slot_pose, g->slot_pose));
+        o_pair_start = blob.add(pstart);
+        o_pair_ab = blob.add(pab);
+        o_pair_ent = blob.add(ent);
+        o_slot_pose = blob.add(g->slot_pose);
+    }
+    G_TRY(hipMalloc(&g->d_arena, blob.bytes.size()));
+    G_TRY(hipMemcpy(g->d_arena, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
+    unsigned char* A = g->d_arena;
+    g->d_edges = reinterpret_cast<GEdge*>(A + o_edges);
+    g->d_lm_start = reinterpret_cast<int32_t*>(A + o_lm_start);
+    g->d_lm_edges = reinterpret_cast<int32_t*>(A + o_lm_edges);
+    g->d_lm_nmono = reinterpret_cast<int32_t*>(A + o_lm_nmono);
+    g->d_pose_start = reinterpret_cast<int32_t*>(A + o_pose_start);
+    g->d_pose_edges = reinterpret_cast<int32_t*>(A + o_pose_edges);
+    g->d_fixed = A + o_fixed;
+    g->d_active = A + o_active;
+    g->d_lm_tmp = reinterpret_cast<double*>(A + o_lm_tmp);
+    if (g->n_free > 0) {
+        g->d_pair_start = reinterpret_cast<int32_t*>(A + o_pair_start);
+        g->d_pair_ab = reinterpret_cast<int32_t*>(A + o_pair_ab);
+        g->d_pair_ent = reinterpret_cast<int2*>(A + o_pair_ent);
+        g->d_slot_pose = reinterpret_cast<int32_t*>(A + o_slot_pose);
     }
 #undef G_TRY
     *out = g;
@@ -674,12 +694,17 @@ namespace ovs {
 ovs_status ba_graph_ensure_solver(ovs_ba_graph* g) {
     if (g->d_Hinv) return OVS_OK;
     const size_t ne = std::max<size_t>((size_t)g->n_edge(), 1), n = (size_t)6 * std::max(g->n_free, 1);
-    OVS_HIP_TRY(hipMalloc(&g->d_Hinv, sizeof(double) * 9 * (size_t)g->n_pt));
-    OVS_HIP_TRY(hipMalloc(&g->d_Y, sizeof(double) * 18 * ne));
-    OVS_HIP_TRY(hipMalloc(&g->d_S, sizeof(double) * (n * n + n + 6 * (size_t)g->n_pose)));   // S | rhs | bp copy: one D2H
-    OVS_HIP_TRY(hipMalloc(&g->d_dxp, sizeof(double) * 6 * (size_t)g->n_pose));
-    OVS_HIP_TRY(hipMalloc(&g->d_scal, sizeof(double) * 8));
-    OVS_HIP_TRY(hipMalloc(&g->d_fail, sizeof(int32_t)));
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t b_hinv = al(sizeof(double) * 9 * (size_t)g->n_pt), b_y = al(sizeof(double) * 18 * ne),
+                 b_s = al(sizeof(double) * (n * n + n + 6 * (size_t)g->n_pose)), b_dxp = al(sizeof(double) * 6 * (size_t)g->n_pose);
+    OVS_HIP_TRY(hipMalloc(&g->d_solver_arena, b_hinv + b_y + b_s + b_dxp + 512));
+    unsigned char* A = g->d_solver_arena;
+    g->d_Hinv = reinterpret_cast<double*>(A);
+    g->d_Y = reinterpret_cast<double*>(A + b_hinv);
+    g->d_S = reinterpret_cast<double*>(A + b_hinv + b_y);   // S | rhs | bp copy: one D2H
+    g->d_dxp = reinterpret_cast<double*>(A + b_hinv + b_y + b_s);
+    g->d_scal = reinterpret_cast<double*>(A + b_hinv + b_y + b_s + b_dxp);
+    g->d_fail = reinterpret_cast<int32_t*>(A + b_hinv + b_y + b_s + b_dxp + 256);
     g->d_rhs = g->d_S + n * n;
     return OVS_OK;
 }
@@ -709,6 +734,14 @@ ovs_status ba_graph_backsub(ovs_ba_graph* g, const double* d_Hpl, const double* 
     OVS_LAUNCH_TRY("k_backsub");
     hipLaunchKernelGGL(k_sum_1024, dim3(1), dim3(1024), 0, s, g->d_lm_tmp, g->n_pt, g->d_scal);
     OVS_LAUNCH_TRY("k_sum_1024");
+    return OVS_OK;
+}
+
+// level-1 edges (round-1 outliers) are masked instead of rebuilding the graph: an inactive edge contributes exact zeros
+ovs_status ba_graph_set_active(ovs_ba_graph* g, const uint8_t* host_mask, hipStream_t s) {
+    if (g->n_edge() == 0) return OVS_OK;
+    OVS_HIP_TRY(hipMemcpyAsync(g->d_active, host_mask, (size_t)g->n_edge(), hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
     return OVS_OK;
 }
 

@@ -28,6 +28,7 @@ ovs_status ba_graph_ensure_solver(ovs_ba_graph* g);
 ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_bp, const double* d_Hll, const double* d_bl, const double* d_Hpl,
                           double lambda, hipStream_t s);
 ovs_status ba_graph_backsub(ovs_ba_graph* g, const double* d_Hpl, const double* d_bl, double lambda, const double* d_X, double* d_Xn, hipStream_t s);
+ovs_status ba_graph_set_active(ovs_ba_graph* g, const uint8_t* host_mask, hipStream_t s);
 ovs_status ba_graph_edge_chi2(ovs_ba_graph* g, const double* d_poses, const double* d_points, double* d_chi, uint8_t* d_depth, hipStream_t s);
 ovs_status ba_graph_linearize(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo, double* d_Hpp,
                               double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s);
@@ -49,23 +50,36 @@ using ovs::set_last_error;
 constexpr double kChi2D = 0x1.7f7414p+2, kChi3D = 0x1.f4248ap+2, kSqrtChi2D = 0x1.394fbcp+1, kSqrtChi3D = 0x1.65d26ap+1;
 
 struct DevBlocks {   // one linearisation in HBM: Hpp | bp | Hll | bl | Hpl | chi2[2], max|diag|
-    double* base = nullptr;
     double *Hpp = nullptr, *bp = nullptr, *Hll = nullptr, *bl = nullptr, *Hpl = nullptr, *chi = nullptr;
-    hipError_t alloc(int n_pose, int n_pt, size_t n_edge) {
-        const size_t n = (size_t)42 * n_pose + (size_t)12 * n_pt + 18 * std::max<size_t>(n_edge, 1) + 4;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), sizeof(double) * n);
-        if (e != hipSuccess) return e;
+    static size_t doubles(int n_pose, int n_pt, size_t n_edge) { return (size_t)42 * n_pose + (size_t)12 * n_pt + 18 * std::max<size_t>(n_edge, 1) + 4; }
+    void carve(double* base, int n_pose, int n_pt, size_t n_edge) {
         Hpp = base;
         bp = Hpp + (size_t)36 * n_pose;
         Hll = bp + (size_t)6 * n_pose;
         bl = Hll + (size_t)9 * n_pt;
         Hpl = bl + (size_t)3 * n_pt;
         chi = Hpl + 18 * std::max<size_t>(n_edge, 1);
-        return hipSuccess;
     }
+};
+
+// Per-thread work space that only grows: local BA runs once per keyframe on the mapping thread, and a dozen hipMalloc / hipHostMalloc /
+// stream-create calls per call (3-5 ms) would cost as much as the optimisation itself.
+struct LmScratch {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    unsigned char* d = nullptr;
+    size_t d_cap = 0;
+    double* h_pin = nullptr;
+    size_t pin_cap = 0;
+    ~LmScratch() { release(); }
     void release() {
-        if (base) (void)hipFree(base);
-        base = nullptr;
+        if (d) (void)hipFree(d);
+        if (h_pin) (void)hipHostFree(h_pin);
+        if (stream) (void)hipStreamDestroy(stream);
+        d = nullptr;
+        h_pin = nullptr;
+        stream = nullptr;
+        d_cap = pin_cap = 0;
     }
 };
 
@@ -82,34 +96,46 @@ struct Lm {
     double* h_pin = nullptr;   // pinned: S | rhs | bp | chi3 | scal | fail
     size_t pin_doubles = 0;
 
-    ~Lm() {
-        cur.release();
-        trial.release();
-        hipFree(d_poses);
-        hipFree(d_poses_n);
-        hipFree(d_X);
-        hipFree(d_Xn);
-        hipFree(d_echi);
-        hipFree(d_edepth);
-        if (h_pin) hipHostFree(h_pin);
-        if (stream) hipStreamDestroy(stream);
-    }
-
-    ovs_status init(int np, int npt, size_t ne_max, const double* points) {
+    ovs_status init(int device, int np, int npt, size_t ne_max, const double* points) {
+        static thread_local LmScratch sc;
         n_pose = np;
         n_pt = npt;
-        OVS_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        OVS_HIP_TRY(cur.alloc(np, npt, ne_max));
-        OVS_HIP_TRY(trial.alloc(np, npt, ne_max));
-        OVS_HIP_TRY(hipMalloc(&d_poses, sizeof(double) * 7 * np));
-        OVS_HIP_TRY(hipMalloc(&d_poses_n, sizeof(double) * 7 * np));
-        OVS_HIP_TRY(hipMalloc(&d_X, sizeof(double) * 3 * npt));
-        OVS_HIP_TRY(hipMalloc(&d_Xn, sizeof(double) * 3 * npt));
-        OVS_HIP_TRY(hipMalloc(&d_echi, sizeof(double) * std::max<size_t>(ne_max, 1)));
-        OVS_HIP_TRY(hipMalloc(&d_edepth, std::max<size_t>(ne_max, 1)));
+        if (sc.device != device) {
+            sc.release();
+            sc.device = device;
+        }
+        if (!sc.stream) OVS_HIP_TRY(hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking));
+        stream = sc.stream;
+        auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t nb = al(sizeof(double) * DevBlocks::doubles(np, npt, ne_max)), b_p = al(sizeof(double) * 7 * np), b_x = al(sizeof(double) * 3 * npt),
+                     b_e = al(sizeof(double) * std::max<size_t>(ne_max, 1)), b_d = al(std::max<size_t>(ne_max, 1));
+        const size_t need = 2 * nb + 2 * b_p + 2 * b_x + b_e + b_d;
+        if (sc.d_cap < need) {
+            if (sc.d) (void)hipFree(sc.d);
+            sc.d = nullptr;
+            sc.d_cap = 0;
+            OVS_HIP_TRY(hipMalloc(&sc.d, need));
+            sc.d_cap = need;
+        }
+        unsigned char* A = sc.d;
+        cur.carve(reinterpret_cast<double*>(A), np, npt, ne_max);
+        trial.carve(reinterpret_cast<double*>(A + nb), np, npt, ne_max);
+        d_poses = reinterpret_cast<double*>(A + 2 * nb);
+        d_poses_n = reinterpret_cast<double*>(A + 2 * nb + b_p);
+        d_X = reinterpret_cast<double*>(A + 2 * nb + 2 * b_p);
+        d_Xn = reinterpret_cast<double*>(A + 2 * nb + 2 * b_p + b_x);
+        d_echi = reinterpret_cast<double*>(A + 2 * nb + 2 * b_p + 2 * b_x);
+        d_edepth = A + 2 * nb + 2 * b_p + 2 * b_x + b_e;
         const size_t n = (size_t)6 * np;
         pin_doubles = n * n + n + 6 * (size_t)np + 16;
-        OVS_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_pin), sizeof(double) * pin_doubles, hipHostMallocDefault));
+        if (sc.pin_cap < pin_doubles) {
+            if (sc.h_pin) (void)hipHostFree(sc.h_pin);
+            sc.h_pin = nullptr;
+            sc.pin_cap = 0;
+            OVS_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sc.h_pin), sizeof(double) * pin_doubles, hipHostMallocDefault));
+            sc.pin_cap = pin_doubles;
+        }
+        h_pin = sc.h_pin;
         OVS_HIP_TRY(hipMemcpyAsync(d_X, points, sizeof(double) * 3 * npt, hipMemcpyHostToDevice, stream));
         OVS_HIP_TRY(hipStreamSynchronize(stream));
         return OVS_OK;
@@ -279,7 +305,7 @@ ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* p
     if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
     OVS_HIP_TRY(hipSetDevice(device));
     // ---- round 1 graph: all edges (validates the indices)
-    GraphGuard g1, g2;
+    GraphGuard g1;
     const bool trace = std::getenv("OVS_BA_TRACE") != nullptr;
     const double t_begin = Lm::now();
     ovs_status st = ovs_ba_graph_create(device, n_pose, pose_fixed, n_pt, mono, n_mono, stereo, n_stereo, cam, focal_x_baseline, &g1.g);
@@ -288,7 +314,7 @@ ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* p
     const size_t ne = (size_t)n_mono + n_stereo;
     Lm L;
     L.setup_type = setup_type;
-    st = L.init(n_pose, n_pt, ne, points);
+    st = L.init(device, n_pose, n_pt, ne, points);
     if (st != OVS_OK) return st;
     std::vector<Pose> T((size_t)n_pose);
     for (int k = 0; k < n_pose; ++k) {
@@ -310,17 +336,15 @@ ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* p
     for (int i = 0; i < n_stereo; ++i) out_r1[(size_t)n_mono + i] = (kChi3D < chi[(size_t)n_mono + i]) || !depth[(size_t)n_mono + i];
     const bool stopped = force_stop_flag && *force_stop_flag;
     if (!stopped) {
-        // ---- round 2: inliers only (outliers go to level 1), no robust kernel
-        std::vector<ovs_ba_edge> m2;
-        std::vector<ovs_ba_edge_stereo> s2;
-        for (int i = 0; i < n_mono; ++i)
-            if (!out_r1[i]) m2.push_back(mono[i]);
-        for (int i = 0; i < n_stereo; ++i)
-            if (!out_r1[(size_t)n_mono + i]) s2.push_back(stereo[i]);
-        st = ovs_ba_graph_create(device, n_pose, pose_fixed, n_pt, m2.data(), (int32_t)m2.size(), s2.data(), (int32_t)s2.size(), cam, focal_x_baseline,
-                                 &g2.g);
+        // ---- round 2: inliers only (outliers go to level 1), no robust kernel. The graph is kept: level-1 edges are masked, they then
+        // contribute exact zeros and the sums over the remaining edges keep their order -- the result a rebuilt graph would give, without
+        // indexing 100 k edges a second time
+        std::vector<uint8_t> act(ne);
+        size_t n_act = 0;
+        for (size_t e = 0; e < ne; ++e) n_act += (act[e] = out_r1[e] ? 0 : 1);
+        st = ovs::ba_graph_set_active(g1.g, act.data(), L.stream);
         if (st != OVS_OK) return st;
-        st = L.run_round(g2.g, T, (m2.size() + s2.size()) ? num_second_iter : 0, false, force_stop_flag, &info_l[2], &info_l[3], &it2);
+        st = L.run_round(g1.g, T, n_act ? num_second_iter : 0, false, force_stop_flag, &info_l[2], &info_l[3], &it2);
         if (st != OVS_OK) return st;
     }
     // ---- final outlier flags: an edge optimised in round 2 is judged at the final state; a level-1 edge keeps its round-1 chi2
