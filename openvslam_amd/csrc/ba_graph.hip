@@ -19,7 +19,10 @@
 // Per-edge arithmetic is the expression sequence of k_ba_linearize / the oracle (every product individually rounded), so Hpl, Hll and bl
 // are bit-identical to the CPU oracle; Hpp, bp and chi2 are tree sums (1e-15 relative), identical from run to run.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -554,6 +557,9 @@ ovs_status ovs_ba_graph_create(int32_t device, int32_t n_pose, const uint8_t* po
         if (stereo[i].pose_idx < 0 || stereo[i].pose_idx >= n_pose || stereo[i].point_idx < 0 || stereo[i].point_idx >= n_pt) return OVS_ERR_INVALID;
     if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
     OVS_HIP_TRY(hipSetDevice(device));
+    const bool trace = std::getenv("OVS_BA_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     ovs_ba_graph* g = new (std::nothrow) ovs_ba_graph();
     if (!g) return OVS_ERR_INVALID;
     g->device = device;
@@ -612,7 +618,9 @@ ovs_status ovs_ba_graph_create(int32_t device, int32_t n_pose, const uint8_t* po
             return OVS_ERR_HIP;                \
         }                                      \
     } while (0)
+    const double t1 = now();
     Blob blob;
+    blob.bytes.reserve((size_t)ne * 96 + (size_t)n_pt * 32 + ((size_t)1 << 16));
     const size_t o_edges = blob.add(edges), o_lm_start = blob.add(lm_start), o_lm_edges = blob.add(lm_edges), o_lm_nmono = blob.add(lm_nmono),
                  o_pose_start = blob.add(pose_start), o_pose_edges = blob.add(pose_edges), o_fixed = blob.add(g->fixed);
     const size_t o_active = blob.add(std::vector<uint8_t>((size_t)std::max(ne, 1), (uint8_t)1));
@@ -654,6 +662,7 @@ ovs_status ovs_ba_graph_create(int32_t device, int32_t n_pose, const uint8_t* po
         o_pair_ent = blob.add(ent);
         o_slot_pose = blob.add(g->slot_pose);
     }
+    const double t2 = now();
     G_TRY(hipMalloc(&g->d_arena, blob.bytes.size()));
     G_TRY(hipMemcpy(g->d_arena, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
     unsigned char* A = g->d_arena;
@@ -673,6 +682,9 @@ ovs_status ovs_ba_graph_create(int32_t device, int32_t n_pose, const uint8_t* po
         g->d_slot_pose = reinterpret_cast<int32_t*>(A + o_slot_pose);
     }
 #undef G_TRY
+    if (trace)
+        std::fprintf(stderr, "[ovs_ba_graph_create] %.2f ms: edge records + counting sorts %.2f, blob + pair lists %.2f, malloc + upload of %.1f MB %.2f\n",
+                     now() - t0, t1 - t0, t2 - t1, blob.bytes.size() / 1e6, now() - t2);
     *out = g;
     return OVS_OK;
 }

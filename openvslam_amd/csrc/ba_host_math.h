@@ -127,7 +127,8 @@ static inline __attribute__((always_inline)) bool cholesky_solve_body(std::vecto
 }
 
 // The same loop nest compiled twice: for the x86-64 baseline (SSE2) and for AVX2 (4 doubles per operation; products and differences stay
-// individually rounded: no FMA, -ffp-contract=off); chosen once at run time. 288 x 288 at config 5: 0.66 ms -> see DESIGN.md.
+// individually rounded: no FMA, -ffp-contract=off); chosen once at run time. 288 x 288 at config 5: 0.66 -> 0.47 ms per solve. (A panel-blocked version on a 4-thread pool was
+// measured too: bit-identical, but no faster on hosts whose cores are shared, so the solve stays single-threaded.)
 __attribute__((target("avx2"))) inline bool cholesky_solve_avx2(std::vector<double>& A, int n, std::vector<double>& b) {
     return cholesky_solve_body(A, n, b);
 }

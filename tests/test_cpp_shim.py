@@ -411,5 +411,6 @@ def test_class_boundary_latency_and_two_threads():
     best = min(r["pageable_no_pyramid"]["median_ms"], r["staged_no_pyramid"]["median_ms"])
     assert best < 0.8, r                      # measured 0.27 ms; generous bound against noisy neighbours
     tt = r["two_threads"]
-    assert max(tt["left_ms"], tt["right_ms"]) < 1.6 * tt["solo_ms"], tt   # measured 1.07x: running in parallel, not back to back
+    # measured 1.1-1.6x (two frames share one GPU's CUs): running in parallel, not back to back (serialised = 2x or more)
+    assert max(tt["left_ms"], tt["right_ms"]) < 1.9 * tt["solo_ms"], tt
     assert r["pageable_no_pyramid"]["keypoints"] > 1900
