@@ -270,6 +270,9 @@ ovs_status run_chain(ovs_orb* h, StageProfiler<4>& prof, const uint8_t* d_images
         OVS_HIP_TRY(h->prof_aux.begin(h->aux_stream));
         OVS_HIP_TRY(launch_fast(geo, d, img, stride, frame_stride, msk, rows, nb, h->aux_stream, 0, geo.lv[1].cell_base));
         OVS_HIP_TRY(h->prof_aux.mark(1, h->aux_stream));
+        // level 0's quad-tree (the longest pole: ~20 k candidates per frame, latency-bound) follows on the same stream, under the FAST of
+        // the other levels
+        OVS_HIP_TRY(launch_tree(geo, d, nb, h->aux_stream, 0, 1));
         OVS_HIP_TRY(hipEventRecord(h->ev_aux_join, h->aux_stream));
     }
     // A1: each level from the previous one
@@ -285,12 +288,16 @@ ovs_status run_chain(ovs_orb* h, StageProfiler<4>& prof, const uint8_t* d_images
     OVS_HIP_TRY(prof.mark(1, s));
     if (split) {
         OVS_HIP_TRY(launch_fast(geo, d, img, stride, frame_stride, msk, rows, nb, s, geo.lv[1].cell_base, -1));
-        OVS_HIP_TRY(hipStreamWaitEvent(s, h->ev_aux_join, 0));
     } else {
         OVS_HIP_TRY(launch_fast(geo, d, img, stride, frame_stride, msk, rows, nb, s));
     }
     OVS_HIP_TRY(prof.mark(2, s));
-    OVS_HIP_TRY(launch_tree(geo, d, nb, s));
+    if (split) {
+        OVS_HIP_TRY(launch_tree(geo, d, nb, s, 1, -1));
+        OVS_HIP_TRY(hipStreamWaitEvent(s, h->ev_aux_join, 0));   // describe needs every level's keypoints
+    } else {
+        OVS_HIP_TRY(launch_tree(geo, d, nb, s));
+    }
     OVS_HIP_TRY(prof.mark(3, s));
     OVS_HIP_TRY(launch_describe(geo, d, img, stride, frame_stride, d_kps + (size_t)f0 * cap, d_desc + (size_t)f0 * cap * 32, d_counts + f0, cap, nb, s));
     OVS_HIP_TRY(prof.mark(4, s));

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
                                                       size_t cand_frame_entries, const uint32_t* __restrict__ cand_count,
                                                       NodeRec* __restrict__ nodes, size_t node_frame_entries,
                                                       uint64_t* __restrict__ lvl_kps, uint32_t* __restrict__ lvl_count, int NCmax,
-                                                      int P2max) {
+                                                      int P2max, int level_lo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // ---- LDS carve (all offsets multiples of 16)
     const int NN = 4 * NCmax;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
     uint32_t* s_misc = s_wave + 16;                                       // [80]: [0..63] root counts / root pos, [64..] scalars
 
     const int tid = threadIdx.x;
-    const int level = blockIdx.x, frame = blockIdx.y;
+    const int level = level_lo + (int)blockIdx.x, frame = blockIdx.y;   // the launch covers levels [level_lo, level_lo + gridDim.x)
     const int L = geo->num_levels;
     const LevelGeo& g = geo->lv[level];
     const uint32_t N = (uint32_t)g.n_keypts;
@@ -343,7 +343,9 @@ static size_t tree_lds_bytes(int NCmax, int P2max) {
     return (size_t)(8 * NCmax) * 4 + (size_t)NCmax * 5 * 4 + (size_t)P2max * 4 + (size_t)P2max * 8 + (size_t)NCmax * 4 + 16 * 4 + 80 * 4;
 }
 
-hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hipStream_t s) {
+hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hipStream_t s, int level_lo, int n_levels) {
+    if (n_levels < 0) n_levels = hgeo.num_levels - level_lo;
+    if (n_levels <= 0 || batch <= 0) return hipSuccess;
     int NCmax = 0;
     for (int l = 0; l < hgeo.num_levels; ++l) NCmax = std::max(NCmax, hgeo.lv[l].max_nodes / 4);
     NCmax = (NCmax + 3) & ~3;
@@ -356,9 +358,9 @@ hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hip
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    dim3 grid(hgeo.num_levels, batch);
+    dim3 grid(n_levels, batch);
     hipLaunchKernelGGL(k_tree, grid, dim3(kTreeThreads), lds, s, d.geo, d.cand, d.cand_frame_entries, d.cand_count,
-                       reinterpret_cast<NodeRec*>(d.nodes), d.node_frame_entries, d.lvl_kps, d.lvl_count, NCmax, P2max);
+                       reinterpret_cast<NodeRec*>(d.nodes), d.node_frame_entries, d.lvl_kps, d.lvl_count, NCmax, P2max, level_lo);
     return hipGetLastError();
 }
 
