@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU (a multiple of 8: frames come in 8-frame scenes)")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU (a multiple of 8: frames come in 8-frame scenes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true", help="skip the local-BA side section (profiling runs)")
     ap.add_argument("--pipeline", type=int, default=1, help="sub-batches of the extract issued on overlapping internal streams (1 = off)")
