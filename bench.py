@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1, help="sub-batches of the extract issued on overlapping internal streams (1 = off)")
     ap.add_argument("--chains", type=int, default=1, help="independent extract->match pipelines the batch is split over (own handles and "
                                                           "streams, no cross-chain synchronisation)")
+    ap.add_argument("--fast-split", type=int, default=1, help="1: FAST on level 0 (+ its quad-tree) runs on an internal stream beside the pyramid; "
+                                                                "0: one FAST launch over all levels after the pyramid (profiling runs)")
     ap.add_argument("--overlap", type=int, default=1, help="1: matching of step k runs on a second stream under the extraction of step "
                                                             "k+1 (double-buffered outputs); 0: one stream, strictly serial")
     args = ap.parse_args()
@@ -106,6 +108,7 @@ def main():
                                             device=local_rank)
             if args.pipeline > 1:
                 self.ex.set_pipeline(args.pipeline)
+            self.ex.set_fast_split(bool(args.fast_split))
             cap = self.ex.max_keypoints
             self.mt = match.robust(LOWE_RATIO, False, max_n1=cap, max_n2=cap, max_batch=Bc, device=local_rank)
             # outputs are double-buffered so that step k's matching can run under step k+1's extraction

@@ -91,23 +91,20 @@ __device__ __forceinline__ void topk_insert(uint32_t e, uint32_t (&t)[kTopK]) {
 }
 
 // ---- 1. all pairs, near lists -------------------------------------------------------------------------------------
-// Workgroup = 4 waves x the same 64 queries (idx_2); wave w scans the w-th quarter of the frame descriptors (idx_1). The descriptors
-// of the quarter stream through the scalar cache in groups of FOUR into two SGPR sets that are double-buffered: the loads of the next
-// group are in flight while the current one is XORed / popcounted (SMEM returns out of order, so only lgkmcnt(0) is a usable wait --
-// the overlap has to come from issuing early, not from partial waits). Entries with d <= near_thr go to the wave's own segment of the
-// query's list (count in a register: no atomics, no waits in the loop) and into a sorted top-8 kept in registers; the four partial
-// top-8s are merged through LDS at the end.
-//
-// v2 (round 2): (i) the popcount accumulate is pinned to the 8 x (v_xor, v_bcnt acc) chain -- hipcc split it into 6 independent
-// v_bcnt + 3 v_add3_u32 per descriptor (19 instead of 16 VALU per pair); (ii) 1-D grid in XCD-major order, so all chunks of a problem
-// run on ONE XCD and its 64 KB of frame descriptors are fetched into one L2 instead of eight (fabric traffic was 9.7x algorithmic);
-// (iii) the double-buffered scalar loads above.
+// v3 (round 2). One lane per query (idx_2), 256 queries per workgroup; ALL four waves scan the same frame descriptors (idx_1), which are
+// staged through LDS in double-buffered chunks of kTgtChunk descriptors and read back with BROADCAST ds_read_b128 (every lane the same
+// address: conflict-free, one 32-byte descriptor = two LDS instructions per wave). LDS returns in order, so the next group of four
+// descriptors is in flight while the current one is XORed / popcounted, without the "wait for everything" that scalar loads force
+// (v2 streamed the descriptors through SGPRs: SMEM returns out of order, only lgkmcnt(0) is usable, and the 64 SGPRs of payload capped
+// residency at 6 workgroups per CU: 0.57 of the integer-VALU floor). The popcount is pinned to the 8 x (v_xor, v_bcnt accumulate) chain per
+// pair -- hipcc splits it into 6 independent v_bcnt + 3 v_add3_u32 (19 instead of 16 VALU).
+// Entries with d <= near_thr go to one of the query's four list segments (by quarter of the idx_1 range, the resolver's format) and
+// into a sorted top-8 kept in registers. 1-D grid in XCD-major order: all chunks of a problem run on ONE XCD, so its descriptors are
+// fetched into one L2 instead of eight (fabric traffic was 9.7x algorithmic in round 1).
+constexpr int kTgtChunk = 128;   // descriptors per LDS stage: 4 KB, one 16-byte global load per thread
 
-// One word of four descriptors in ONE asm volatile statement: four v_xor_b32 (SGPR operand) followed by the four v_bcnt_u32_b32 that
-// accumulate them, so no v_bcnt issues directly behind the v_xor it depends on (hipcc pairs them back to back), the popcount stays an
-// 8-deep accumulate chain per descriptor (hipcc splits it into 6 independent v_bcnt + 3 v_add3_u32: 19 instead of 16 VALU per pair),
-// and -- volatile statements keep their program order -- the machine scheduler cannot sink the NEXT group's scalar loads below this
-// group's arithmetic.
+// One word of four descriptors in ONE asm volatile statement: four v_xor_b32 followed by the four v_bcnt_u32_b32 that accumulate them,
+// so no v_bcnt issues directly behind the v_xor it depends on and the popcount stays an accumulate chain.
 __device__ __forceinline__ void xor_bcnt4_first(uint32_t a, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t& d0, uint32_t& d1,
                                                 uint32_t& d2, uint32_t& d3) {
     uint32_t t0, t1, t2, t3;
@@ -115,7 +112,7 @@ __device__ __forceinline__ void xor_bcnt4_first(uint32_t a, uint32_t s0, uint32_
         "v_xor_b32 %4, %9, %8\n\tv_xor_b32 %5, %10, %8\n\tv_xor_b32 %6, %11, %8\n\tv_xor_b32 %7, %12, %8\n\t"
         "v_bcnt_u32_b32 %0, %4, 0\n\tv_bcnt_u32_b32 %1, %5, 0\n\tv_bcnt_u32_b32 %2, %6, 0\n\tv_bcnt_u32_b32 %3, %7, 0"
         : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-        : "v"(a), "s"(s0), "s"(s1), "s"(s2), "s"(s3));
+        : "v"(a), "v"(s0), "v"(s1), "v"(s2), "v"(s3));
 }
 __device__ __forceinline__ void xor_bcnt4_acc(uint32_t a, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t& d0, uint32_t& d1,
                                               uint32_t& d2, uint32_t& d3) {
@@ -124,33 +121,21 @@ __device__ __forceinline__ void xor_bcnt4_acc(uint32_t a, uint32_t s0, uint32_t 
         "v_xor_b32 %4, %9, %8\n\tv_xor_b32 %5, %10, %8\n\tv_xor_b32 %6, %11, %8\n\tv_xor_b32 %7, %12, %8\n\t"
         "v_bcnt_u32_b32 %0, %4, %0\n\tv_bcnt_u32_b32 %1, %5, %1\n\tv_bcnt_u32_b32 %2, %6, %2\n\tv_bcnt_u32_b32 %3, %7, %3"
         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-        : "v"(a), "s"(s0), "s"(s1), "s"(s2), "s"(s3));
+        : "v"(a), "v"(s0), "v"(s1), "v"(s2), "v"(s3));
 }
 
-// SGPR sets pinned to fixed registers: the load statement and the wait statement must name the SAME physical registers (the loads land
-// asynchronously; a compiler-inserted copy between the two statements would copy stale values)
-#define OVS_SET_A0 "s[36:43]"
-#define OVS_SET_A1 "s[44:51]"
-#define OVS_SET_A2 "s[52:59]"
-#define OVS_SET_A3 "s[60:67]"
-#define OVS_SET_B0 "s[68:75]"
-#define OVS_SET_B1 "s[76:83]"
-#define OVS_SET_B2 "s[84:91]"
-#define OVS_SET_B3 "s[92:99]"
-
-#define OVS_ISSUE4(p, r0, r1, r2, r3, R0, R1, R2, R3)                                                                       \
-    asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_load_dwordx8 %3, %4, 0x60" \
-                 : "={" R0 "}"(r0), "={" R1 "}"(r1), "={" R2 "}"(r2), "={" R3 "}"(r3)                                        \
-                 : "s"(p)                                                                                                    \
-                 : "memory")
-#define OVS_WAIT4(r0, r1, r2, r3, R0, R1, R2, R3) \
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+{" R0 "}"(r0), "+{" R1 "}"(r1), "+{" R2 "}"(r2), "+{" R3 "}"(r3)::"memory")
-
-__device__ __forceinline__ void dist4(const uint32_t (&a)[8], const u32x8& b0, const u32x8& b1, const u32x8& b2, const u32x8& b3, uint32_t& d0,
-                                      uint32_t& d1, uint32_t& d2, uint32_t& d3) {
-    xor_bcnt4_first(a[0], b0[0], b1[0], b2[0], b3[0], d0, d1, d2, d3);
-#pragma unroll
-    for (int i = 1; i < 8; ++i) xor_bcnt4_acc(a[i], b0[i], b1[i], b2[i], b3[i], d0, d1, d2, d3);
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native vector: inline-asm register operand (HIP's uint4 is a struct)
+// four descriptors as they come out of LDS: (lo, hi) halves each
+__device__ __forceinline__ void dist4(const uint32_t (&a)[8], const u32x4& l0, const u32x4& h0, const u32x4& l1, const u32x4& h1, const u32x4& l2,
+                                      const u32x4& h2, const u32x4& l3, const u32x4& h3, uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3) {
+    xor_bcnt4_first(a[0], l0.x, l1.x, l2.x, l3.x, d0, d1, d2, d3);
+    xor_bcnt4_acc(a[1], l0.y, l1.y, l2.y, l3.y, d0, d1, d2, d3);
+    xor_bcnt4_acc(a[2], l0.z, l1.z, l2.z, l3.z, d0, d1, d2, d3);
+    xor_bcnt4_acc(a[3], l0.w, l1.w, l2.w, l3.w, d0, d1, d2, d3);
+    xor_bcnt4_acc(a[4], h0.x, h1.x, h2.x, h3.x, d0, d1, d2, d3);
+    xor_bcnt4_acc(a[5], h0.y, h1.y, h2.y, h3.y, d0, d1, d2, d3);
+    xor_bcnt4_acc(a[6], h0.z, h1.z, h2.z, h3.z, d0, d1, d2, d3);
+    xor_bcnt4_acc(a[7], h0.w, h1.w, h2.w, h3.w, d0, d1, d2, d3);
 }
 
 __global__ __launch_bounds__(256) void k_hamming_near(const uint8_t* __restrict__ desc_1, size_t stride_1,
@@ -159,91 +144,114 @@ __global__ __launch_bounds__(256) void k_hamming_near(const uint8_t* __restrict_
                                                      const uint8_t* __restrict__ valid_2, int max_n2, uint32_t near_thr,
                                                      uint32_t* __restrict__ near_cnt, uint32_t* __restrict__ near_list,
                                                      uint32_t* __restrict__ near_top, int chunks, int total_wg) {
-    __shared__ uint32_t s_top[kNearSplit][kTopK][64];
+    __shared__ __attribute__((aligned(16))) uint4 tgt[2][kTgtChunk * 2];   // [buffer][descriptor * 2 + half]
     // XCD-major work order (workgroup b runs on XCD b % 8): XCD k takes the k-th contiguous eighth of the (problem, chunk) sequence
     const int per_xcd = gridDim.x >> 3;
     const int wg = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (wg >= total_wg) return;
     const int p = wg / chunks, chunk_id = wg - p * chunks;
     const int n1 = n1_arr[p], n2 = n2_arr[p];
-    if (chunk_id * 64 >= n2) return;
-    // wave index made provably uniform so the descriptor addresses below stay scalar (s_load_dwordx8)
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q = chunk_id * 64 + lane;
+    if (chunk_id * 256 >= n2) return;
+    const int tid = threadIdx.x;
+    const int q = chunk_id * 256 + tid;
     const bool active = q < n2 && (!valid_2 || valid_2[(size_t)p * (stride_2 / 32) + q]);
     uint32_t a[8];
     {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(desc_2 + (size_t)p * stride_2 + (size_t)(q < n2 ? q : 0) * 32);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = src[i];
+        const uint4* src = reinterpret_cast<const uint4*>(desc_2 + (size_t)p * stride_2 + (size_t)(q < n2 ? q : 0) * 32);
+        const uint4 lo = src[0], hi = src[1];
+        a[0] = lo.x, a[1] = lo.y, a[2] = lo.z, a[3] = lo.w, a[4] = hi.x, a[5] = hi.y, a[6] = hi.z, a[7] = hi.w;
     }
-    const int chunk = (((n1 + kNearSplit - 1) / kNearSplit) + 7) & ~7;
-    const int jb = min(n1, wv * chunk), je = min(n1, jb + chunk);
-    const uint32_t* __restrict__ t = reinterpret_cast<const uint32_t*>(desc_1 + (size_t)p * stride_1);
-    uint32_t* my_seg = near_list + (((size_t)p * max_n2 + q) * kNearSplit + wv) * kNearSeg;
+    // list segments by quarter of the idx_1 range (the format k_bf_resolve reads)
+    const int quarter = (((n1 + kNearSplit - 1) / kNearSplit) + 7) & ~7;
+    uint32_t* const my_list = near_list + ((size_t)p * max_n2 + (q < n2 ? q : 0)) * kNearSplit * kNearSeg;
     uint32_t top[kTopK];
 #pragma unroll
     for (int k = 0; k < kTopK; ++k) top[k] = ~0u;
-    uint32_t cnt = 0;
+    uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
     auto hit = [&](uint32_t d, int j) {
         const uint32_t e = (d << 16) | (uint32_t)j;
-        if (cnt < (uint32_t)kNearSeg) my_seg[cnt] = e;
-        ++cnt;
+        const int seg = (j >= quarter ? 1 : 0) + (j >= 2 * quarter ? 1 : 0) + (j >= 3 * quarter ? 1 : 0);
+        const uint32_t c = seg == 0 ? cnt0 : seg == 1 ? cnt1 : seg == 2 ? cnt2 : cnt3;
+        if (c < (uint32_t)kNearSeg) my_list[seg * kNearSeg + c] = e;
+        cnt0 += seg == 0;
+        cnt1 += seg == 1;
+        cnt2 += seg == 2;
+        cnt3 += seg == 3;
         topk_insert(e, top);
     };
-    auto group = [&](uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, int j) {
-        // near distances are rare (the true match and near-duplicates): one test per four pairs on the common path
-        if (min(min(d0, d1), min(d2, d3)) <= near_thr) {
-            if (d0 <= near_thr) hit(d0, j);
-            if (d1 <= near_thr) hit(d1, j + 1);
-            if (d2 <= near_thr) hit(d2, j + 2);
-            if (d3 <= near_thr) hit(d3, j + 3);
-        }
-    };
-    int j = jb;
-    if (active) {
-        const int n8 = (je - jb) >> 3;   // iterations of 8 descriptors = one A group + one B group
-        if (n8 > 0) {
-            u32x8 a0, a1, a2, a3, b0, b1, b2, b3;
-            const uint32_t* pa = t + (size_t)j * 8;
-            OVS_ISSUE4(pa, a0, a1, a2, a3, OVS_SET_A0, OVS_SET_A1, OVS_SET_A2, OVS_SET_A3);
-            for (int it = 0; it < n8; ++it, j += 8) {
-                const uint32_t* pb = t + (size_t)(j + 4) * 8;
-                OVS_WAIT4(a0, a1, a2, a3, OVS_SET_A0, OVS_SET_A1, OVS_SET_A2, OVS_SET_A3);
-                OVS_ISSUE4(pb, b0, b1, b2, b3, OVS_SET_B0, OVS_SET_B1, OVS_SET_B2, OVS_SET_B3);
-                uint32_t d0, d1, d2, d3;
-                dist4(a, a0, a1, a2, a3, d0, d1, d2, d3);
-                group(d0, d1, d2, d3, j);
-                OVS_WAIT4(b0, b1, b2, b3, OVS_SET_B0, OVS_SET_B1, OVS_SET_B2, OVS_SET_B3);
-                if (it + 1 < n8) {   // wave-uniform: the next A group (the last iteration has none to fetch)
-                    const uint32_t* pn = t + (size_t)(j + 8) * 8;
-                    OVS_ISSUE4(pn, a0, a1, a2, a3, OVS_SET_A0, OVS_SET_A1, OVS_SET_A2, OVS_SET_A3);
-                }
-                dist4(a, b0, b1, b2, b3, d0, d1, d2, d3);
-                group(d0, d1, d2, d3, j + 4);
-            }
-        }
-        for (; j + 4 <= je; j += 4) {   // remainder: four at a time
-            u32x8 b0, b1, b2, b3;
-            sload_desc4(t + (size_t)j * 8, b0, b1, b2, b3);
-            uint32_t d0, d1, d2, d3;
-            dist4(a, b0, b1, b2, b3, d0, d1, d2, d3);
-            group(d0, d1, d2, d3, j);
-        }
-        for (; j < je; ++j) {
-            const uint32_t d = hamming256(a, t + (size_t)j * 8);
-            if (d <= near_thr) hit(d, j);
-        }
+    const uint4* __restrict__ gsrc = reinterpret_cast<const uint4*>(desc_1 + (size_t)p * stride_1);
+    const int n_chunks = (n1 + kTgtChunk - 1) / kTgtChunk;
+    // stage chunk 0
+    {
+        uint4 v = {0u, 0u, 0u, 0u};
+        if ((tid >> 1) < n1) v = gsrc[tid];
+        tgt[0][tid] = v;
     }
-#pragma unroll
-    for (int k = 0; k < kTopK; ++k) s_top[wv][k][lane] = top[k];
-    if (q < n2) near_cnt[((size_t)p * max_n2 + q) * kNearSplit + wv] = cnt;
     __syncthreads();
-    if (wv == 0 && q < n2) {
-#pragma unroll
-        for (int w = 1; w < kNearSplit; ++w)
-#pragma unroll
-            for (int k = 0; k < kTopK; ++k) topk_insert(s_top[w][k][lane], top);
+    for (int c = 0; c < n_chunks; ++c) {
+        const int buf = c & 1, j0 = c * kTgtChunk;
+        // request the next chunk now; it is written to the other buffer after this chunk's arithmetic
+        uint4 nxt = {0u, 0u, 0u, 0u};
+        const bool has_next = c + 1 < n_chunks;
+        if (has_next && j0 + kTgtChunk + (tid >> 1) < n1) nxt = gsrc[(size_t)(j0 + kTgtChunk) * 2 + tid];
+        const int jn = min(kTgtChunk, n1 - j0);   // descriptors of this chunk (the staged tail beyond n1 is zero and masked below)
+        // LDS reads and their waits are issued by hand: hipcc's wait insertion turns the loop-carried "A was requested an iteration ago"
+        // into s_waitcnt lgkmcnt(0) right behind the requests for B, which serialises request and use. LDS returns in order, so
+        // lgkmcnt(8) = "everything but the eight newest requests has arrived". The two register sets are pinned (v[40:71], v[72:103]) so
+        // that the request and the wait statement name the same physical registers.
+        const uint32_t lds_base = (uint32_t)(uintptr_t)(&tgt[buf][0]);   // LDS byte address (low 32 bits of the flat address)
+        auto group = [&](const u32x4& l0, const u32x4& h0, const u32x4& l1, const u32x4& h1, const u32x4& l2, const u32x4& h2, const u32x4& l3,
+                         const u32x4& h3, int j) __attribute__((always_inline)) {
+            uint32_t d0, d1, d2, d3;
+            dist4(a, l0, h0, l1, h1, l2, h2, l3, h3, d0, d1, d2, d3);
+            // near distances are rare (the true match and near-duplicates): one test per four pairs on the common path
+            if (active && min(min(d0, d1), min(d2, d3)) <= near_thr) {
+                if (d0 <= near_thr && j < jn) hit(d0, j0 + j);
+                if (d1 <= near_thr && j + 1 < jn) hit(d1, j0 + j + 1);
+                if (d2 <= near_thr && j + 2 < jn) hit(d2, j0 + j + 2);
+                if (d3 <= near_thr && j + 3 < jn) hit(d3, j0 + j + 3);
+            }
+        };
+#define OVS_LDS_REQ4(addr, P, V0, V1, V2, V3, V4, V5, V6, V7)                                                                              \
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t" \
+                 "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112" \
+                 : "={" V0 "}"(P##0l), "={" V1 "}"(P##0h), "={" V2 "}"(P##1l), "={" V3 "}"(P##1h), "={" V4 "}"(P##2l), "={" V5 "}"(P##2h),  \
+                   "={" V6 "}"(P##3l), "={" V7 "}"(P##3h)                                                                                   \
+                 : "v"(addr)                                                                                                               \
+                 : "memory")
+#define OVS_LDS_WAIT4(N, P, V0, V1, V2, V3, V4, V5, V6, V7)                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                                          \
+                 : "+{" V0 "}"(P##0l), "+{" V1 "}"(P##0h), "+{" V2 "}"(P##1l), "+{" V3 "}"(P##1h), "+{" V4 "}"(P##2l), "+{" V5 "}"(P##2h), \
+                   "+{" V6 "}"(P##3l), "+{" V7 "}"(P##3h)::"memory")
+#define OVS_VA "v[40:43]", "v[44:47]", "v[48:51]", "v[52:55]", "v[56:59]", "v[60:63]", "v[64:67]", "v[68:71]"
+#define OVS_VB "v[72:75]", "v[76:79]", "v[80:83]", "v[84:87]", "v[88:91]", "v[92:95]", "v[96:99]", "v[100:103]"
+#define OVS_X(M, ...) M(__VA_ARGS__)
+        const int jend = (jn + 7) & ~7;   // groups of 8 = two register sets; <= kTgtChunk
+        u32x4 A0l, A0h, A1l, A1h, A2l, A2h, A3l, A3h, B0l, B0h, B1l, B1h, B2l, B2h, B3l, B3h;
+        uint32_t addr = lds_base;
+        OVS_X(OVS_LDS_REQ4, addr, A, OVS_VA);
+        for (int j = 0; j < jend; j += 8) {
+            const uint32_t addr_b = addr + 128u;
+            OVS_X(OVS_LDS_REQ4, addr_b, B, OVS_VB);
+            OVS_X(OVS_LDS_WAIT4, 8, A, OVS_VA);
+            group(A0l, A0h, A1l, A1h, A2l, A2h, A3l, A3h, j);
+            addr += 256u;
+            if (j + 8 < jend) {   // wave-uniform
+                OVS_X(OVS_LDS_REQ4, addr, A, OVS_VA);
+                OVS_X(OVS_LDS_WAIT4, 8, B, OVS_VB);
+            } else {
+                OVS_X(OVS_LDS_WAIT4, 0, B, OVS_VB);
+            }
+            group(B0l, B0h, B1l, B1h, B2l, B2h, B3l, B3h, j + 4);
+        }
+        if (has_next) tgt[buf ^ 1][tid] = nxt;
+        __syncthreads();
+    }
+    if (q < n2) {
+        near_cnt[((size_t)p * max_n2 + q) * kNearSplit + 0] = cnt0;
+        near_cnt[((size_t)p * max_n2 + q) * kNearSplit + 1] = cnt1;
+        near_cnt[((size_t)p * max_n2 + q) * kNearSplit + 2] = cnt2;
+        near_cnt[((size_t)p * max_n2 + q) * kNearSplit + 3] = cnt3;
         uint4* dst = reinterpret_cast<uint4*>(near_top + ((size_t)p * max_n2 + q) * kTopK);
         dst[0] = make_uint4(top[0], top[1], top[2], top[3]);
         dst[1] = make_uint4(top[4], top[5], top[6], top[7]);
@@ -628,7 +636,7 @@ ovs_status run_bf(ovs_matcher* m, const uint8_t* d1, size_t stride_1, const int3
                   size_t stride_2, const int32_t* d_n2, const uint8_t* d_valid, int batch, float lowe_ratio, int32_t* d_pairs, int32_t* d_counts, int cap,
                   hipStream_t s) {
     const uint32_t thr = near_threshold(lowe_ratio);
-    const int chunks = (m->max_n2 + 63) / 64, total_wg = chunks * batch;
+    const int chunks = (m->max_n2 + 255) / 256, total_wg = chunks * batch;
     dim3 grid(((total_wg + 7) / 8) * 8);
     OVS_HIP_TRY(m->prof.begin(s));
     hipLaunchKernelGGL(k_hamming_near, grid, dim3(256), 0, s, d1, stride_1, d_n1, d2, stride_2, d_n2, d_valid, m->max_n2, thr,

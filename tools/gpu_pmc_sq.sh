@@ -4,7 +4,7 @@ tag=${1:-pmcsq}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/$tag
 mkdir -p $out
-cmd="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ba --overlap 0 --batch 128"
+cmd="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ba --overlap 0 --batch 128 --fast-split 0"
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $out/p1 -o p1 -- $cmd > $out/p1.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --output-format csv -d $out/p2 -o p2 -- $cmd > $out/p2.log 2>&1
