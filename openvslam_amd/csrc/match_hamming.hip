@@ -36,47 +36,6 @@ __device__ __forceinline__ uint32_t hamming256(const uint32_t (&a)[8], const uin
     return d;
 }
 
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-
-// Four consecutive 32-byte descriptors through the scalar data cache under ONE wait (hipcc otherwise waits after each load).
-// The loads, their count and the wait are all inside the statement (guide 5.7); outputs are early-clobber SGPR tuples.
-__device__ __forceinline__ void sload_desc4(const uint32_t* __restrict__ p, u32x8& b0, u32x8& b1, u32x8& b2, u32x8& b3) {
-    asm volatile(
-        "s_load_dwordx8 %0, %4, 0x0\n\t"
-        "s_load_dwordx8 %1, %4, 0x20\n\t"
-        "s_load_dwordx8 %2, %4, 0x40\n\t"
-        "s_load_dwordx8 %3, %4, 0x60\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&s"(b0), "=&s"(b1), "=&s"(b2), "=&s"(b3)
-        : "s"(p)
-        : "memory");
-}
-
-// eight descriptors under one wait: half as many stalls per pair as sload_desc4 (64 SGPRs of payload)
-__device__ __forceinline__ void sload_desc8(const uint32_t* __restrict__ p, u32x8& b0, u32x8& b1, u32x8& b2, u32x8& b3, u32x8& b4, u32x8& b5,
-                                            u32x8& b6, u32x8& b7) {
-    asm volatile(
-        "s_load_dwordx8 %0, %8, 0x0\n\t"
-        "s_load_dwordx8 %1, %8, 0x20\n\t"
-        "s_load_dwordx8 %2, %8, 0x40\n\t"
-        "s_load_dwordx8 %3, %8, 0x60\n\t"
-        "s_load_dwordx8 %4, %8, 0x80\n\t"
-        "s_load_dwordx8 %5, %8, 0xa0\n\t"
-        "s_load_dwordx8 %6, %8, 0xc0\n\t"
-        "s_load_dwordx8 %7, %8, 0xe0\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&s"(b0), "=&s"(b1), "=&s"(b2), "=&s"(b3), "=&s"(b4), "=&s"(b5), "=&s"(b6), "=&s"(b7)
-        : "s"(p)
-        : "memory");
-}
-
-__device__ __forceinline__ uint32_t hamming256v(const uint32_t (&a)[8], const u32x8& b) {
-    uint32_t d = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) d = __builtin_popcount(a[i] ^ b[i]) + d;
-    return d;
-}
-
 // keep the kTopK smallest keys (ascending) -- key = d << 16 | idx_1, i.e. (distance, first-seen) order
 __device__ __forceinline__ void topk_insert(uint32_t e, uint32_t (&t)[kTopK]) {
     if (e < t[kTopK - 1]) {
@@ -91,51 +50,50 @@ __device__ __forceinline__ void topk_insert(uint32_t e, uint32_t (&t)[kTopK]) {
 }
 
 // ---- 1. all pairs, near lists -------------------------------------------------------------------------------------
-// v3 (round 2). One lane per query (idx_2), 256 queries per workgroup; ALL four waves scan the same frame descriptors (idx_1), which are
-// staged through LDS in double-buffered chunks of kTgtChunk descriptors and read back with BROADCAST ds_read_b128 (every lane the same
-// address: conflict-free, one 32-byte descriptor = two LDS instructions per wave). LDS returns in order, so the next group of four
-// descriptors is in flight while the current one is XORed / popcounted, without the "wait for everything" that scalar loads force
-// (v2 streamed the descriptors through SGPRs: SMEM returns out of order, only lgkmcnt(0) is usable, and the 64 SGPRs of payload capped
-// residency at 6 workgroups per CU: 0.57 of the integer-VALU floor). The popcount is pinned to the 8 x (v_xor, v_bcnt accumulate) chain per
-// pair -- hipcc splits it into 6 independent v_bcnt + 3 v_add3_u32 (19 instead of 16 VALU).
-// Entries with d <= near_thr go to one of the query's four list segments (by quarter of the idx_1 range, the resolver's format) and
-// into a sorted top-8 kept in registers. 1-D grid in XCD-major order: all chunks of a problem run on ONE XCD, so its descriptors are
-// fetched into one L2 instead of eight (fabric traffic was 9.7x algorithmic in round 1).
-constexpr int kTgtChunk = 128;   // descriptors per LDS stage: 4 KB, one 16-byte global load per thread
+// The O(n1 * n2) part runs on the matrix cores. A 256-bit Hamming distance is an exact integer dot product: with the frame
+// descriptor a expanded to {0, 1} bytes and the keyframe descriptor b to {+1, -1} bytes (bit set -> +1),
+//     sum_k a_k * b_k = |a & b| - |a & ~b| = 2 |a & b| - |a|,   d(a, b) = |a| + |b| - 2 |a & b| = |b| - sum_k a_k * b_k,
+// so one v_mfma_i32_32x32x32_i8 chain of 8 steps (K = 256) yields the 32 x 32 distances of a tile, bit-exact in int32. The kernel
+// is compute-bound (n1 pairs per 32 bytes of keyframe descriptor), which is what the matrix core is for; nothing is approximated.
+//   * Workgroup = 4 waves x 64 queries (idx_2) each = 256 queries; every wave scans ALL frame descriptors (idx_1) in tiles of 32.
+//   * The wave's 64 queries live in registers as two B operands (2 x 8 steps x 4 VGPRs of +-1 bytes), expanded once.
+//   * Per 32-descriptor tile a lane loads 16 raw bytes (row = lane & 31, half = lane >> 5), expands them step by step into the
+//     A operand (4 VGPRs of 0/1 bytes: shift + and per VGPR -- the order of the 256 bit positions along K is free as long as A
+//     and B use the same one, so byte v of a VGPR takes bit (base + v) of each of the word's four bytes) and feeds TWO MFMAs
+//     (one per query tile). 64 + ~20 VALU and 16 MFMA per 2048 pairs, against 16 VALU per PAIR on the vector path.
+//   * C layout (guide 3, fragment layout): lane holds column (query) lane & 31, rows (frame keypoints) (r & 3) + 8 (r >> 2) +
+//     4 (lane >> 5). A pair is near iff acc >= |b| - near_thr: one v_max3 per two pairs and one branch per tile on the common path.
+//   * Near pairs (rare) go to the query's list; the list keeps its four segments so the resolver's layout is unchanged (now:
+//     C-tile half x first / second half of the tiles -- one writer lane per segment, so the fill counts are registers). At the end
+//     each thread builds one query's sorted top-8 from the entries its own wave wrote.
+// History (round 2, config 2, 128 problems of 2000 x 2000): scalar-cache + v_bcnt vector path 0.303 ms (0.57 of its VALU issue
+// floor); LDS-broadcast vector path 0.394 ms; see DESIGN.md for this kernel's numbers.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 
-// One word of four descriptors in ONE asm volatile statement: four v_xor_b32 followed by the four v_bcnt_u32_b32 that accumulate them,
-// so no v_bcnt issues directly behind the v_xor it depends on and the popcount stays an accumulate chain.
-__device__ __forceinline__ void xor_bcnt4_first(uint32_t a, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t& d0, uint32_t& d1,
-                                                uint32_t& d2, uint32_t& d3) {
-    uint32_t t0, t1, t2, t3;
-    asm volatile(
-        "v_xor_b32 %4, %9, %8\n\tv_xor_b32 %5, %10, %8\n\tv_xor_b32 %6, %11, %8\n\tv_xor_b32 %7, %12, %8\n\t"
-        "v_bcnt_u32_b32 %0, %4, 0\n\tv_bcnt_u32_b32 %1, %5, 0\n\tv_bcnt_u32_b32 %2, %6, 0\n\tv_bcnt_u32_b32 %3, %7, 0"
-        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-        : "v"(a), "v"(s0), "v"(s1), "v"(s2), "v"(s3));
-}
-__device__ __forceinline__ void xor_bcnt4_acc(uint32_t a, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t& d0, uint32_t& d1,
-                                              uint32_t& d2, uint32_t& d3) {
-    uint32_t t0, t1, t2, t3;
-    asm volatile(
-        "v_xor_b32 %4, %9, %8\n\tv_xor_b32 %5, %10, %8\n\tv_xor_b32 %6, %11, %8\n\tv_xor_b32 %7, %12, %8\n\t"
-        "v_bcnt_u32_b32 %0, %4, %0\n\tv_bcnt_u32_b32 %1, %5, %1\n\tv_bcnt_u32_b32 %2, %6, %2\n\tv_bcnt_u32_b32 %3, %7, %3"
-        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-        : "v"(a), "v"(s0), "v"(s1), "v"(s2), "v"(s3));
-}
+constexpr int kNearQueries = 256;   // queries per workgroup (4 waves x 2 tiles of 32)
+constexpr int kQueueSlots = 128;    // per-wave ring of queued C-tile columns (drained 64 at a time)
+static_assert(kNearSplit == 4, "segment counts are stored as one uint4 per query");
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native vector: inline-asm register operand (HIP's uint4 is a struct)
-// four descriptors as they come out of LDS: (lo, hi) halves each
-__device__ __forceinline__ void dist4(const uint32_t (&a)[8], const u32x4& l0, const u32x4& h0, const u32x4& l1, const u32x4& h1, const u32x4& l2,
-                                      const u32x4& h2, const u32x4& l3, const u32x4& h3, uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3) {
-    xor_bcnt4_first(a[0], l0.x, l1.x, l2.x, l3.x, d0, d1, d2, d3);
-    xor_bcnt4_acc(a[1], l0.y, l1.y, l2.y, l3.y, d0, d1, d2, d3);
-    xor_bcnt4_acc(a[2], l0.z, l1.z, l2.z, l3.z, d0, d1, d2, d3);
-    xor_bcnt4_acc(a[3], l0.w, l1.w, l2.w, l3.w, d0, d1, d2, d3);
-    xor_bcnt4_acc(a[4], h0.x, h1.x, h2.x, h3.x, d0, d1, d2, d3);
-    xor_bcnt4_acc(a[5], h0.y, h1.y, h2.y, h3.y, d0, d1, d2, d3);
-    xor_bcnt4_acc(a[6], h0.z, h1.z, h2.z, h3.z, d0, d1, d2, d3);
-    xor_bcnt4_acc(a[7], h0.w, h1.w, h2.w, h3.w, d0, d1, d2, d3);
+// step s of the K loop covers bits (s & 1) * 4 + v (v = 0..3: the VGPR) of every byte of word s >> 1 of the lane's 16-byte half
+__device__ __forceinline__ v4i expand01(uint32_t w, int base) {
+    v4i r;
+    r[0] = (int)((w >> base) & 0x01010101u);
+    r[1] = (int)((w >> (base + 1)) & 0x01010101u);
+    r[2] = (int)((w >> (base + 2)) & 0x01010101u);
+    r[3] = (int)((w >> (base + 3)) & 0x01010101u);
+    return r;
+}
+// 0/1 bytes -> +1 / -1 bytes: 0xFF - 0xFE * z per byte (no carries: every byte product is <= 0xFE)
+__device__ __forceinline__ v4i to_pm1(v4i z) {
+    v4i r;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) r[v] = (int)~((uint32_t)z[v] * 0xFEu);
+    return r;
+}
+__device__ __forceinline__ int max16(const v16i& c) {
+    return max(max(max(max(c[0], c[1]), max(c[2], c[3])), max(max(c[4], c[5]), max(c[6], c[7]))),
+               max(max(max(c[8], c[9]), max(c[10], c[11])), max(max(c[12], c[13]), max(c[14], c[15]))));
 }
 
 __global__ __launch_bounds__(256) void k_hamming_near(const uint8_t* __restrict__ desc_1, size_t stride_1,
@@ -144,114 +102,165 @@ __global__ __launch_bounds__(256) void k_hamming_near(const uint8_t* __restrict_
                                                      const uint8_t* __restrict__ valid_2, int max_n2, uint32_t near_thr,
                                                      uint32_t* __restrict__ near_cnt, uint32_t* __restrict__ near_list,
                                                      uint32_t* __restrict__ near_top, int chunks, int total_wg) {
-    __shared__ __attribute__((aligned(16))) uint4 tgt[2][kTgtChunk * 2];   // [buffer][descriptor * 2 + half]
-    // XCD-major work order (workgroup b runs on XCD b % 8): XCD k takes the k-th contiguous eighth of the (problem, chunk) sequence
+    __shared__ uint32_t s_segcnt[kNearSplit][kNearQueries];
+    __shared__ int4 s_queue[4][4][kQueueSlots];    // per wave: queued C-tile columns, [quarter of the 16 accumulators][slot]
+    __shared__ uint32_t s_qmeta[4][kQueueSlots];   // tile << 8 | half << 6 | query of the wave
+    __shared__ int2 s_ctx[4][64];                  // per query of the wave: acceptance bound, |b|
+    // XCD-major work order (workgroup b runs on XCD b % 8): XCD k takes the k-th contiguous eighth of the (problem, chunk) sequence,
+    // so the chunks of one problem share one L2
     const int per_xcd = gridDim.x >> 3;
     const int wg = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (wg >= total_wg) return;
     const int p = wg / chunks, chunk_id = wg - p * chunks;
     const int n1 = n1_arr[p], n2 = n2_arr[p];
-    if (chunk_id * 256 >= n2) return;
-    const int tid = threadIdx.x;
-    const int q = chunk_id * 256 + tid;
-    const bool active = q < n2 && (!valid_2 || valid_2[(size_t)p * (stride_2 / 32) + q]);
-    uint32_t a[8];
-    {
+    if (chunk_id * kNearQueries >= n2) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int w = 0; w < kNearSplit; ++w) s_segcnt[w][tid] = 0;
+    __syncthreads();
+
+    // ---- this wave's 64 queries -> two B operands (+-1 bytes), |b| and the per-lane acceptance bound
+    const int q_wave = chunk_id * kNearQueries + wv * 64;
+    v4i qb[2][8];
+    int need[2], pcq[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = q_wave + u * 32 + col;
+        const bool act = q < n2 && (!valid_2 || valid_2[(size_t)p * (stride_2 / 32) + q]);
         const uint4* src = reinterpret_cast<const uint4*>(desc_2 + (size_t)p * stride_2 + (size_t)(q < n2 ? q : 0) * 32);
         const uint4 lo = src[0], hi = src[1];
-        a[0] = lo.x, a[1] = lo.y, a[2] = lo.z, a[3] = lo.w, a[4] = hi.x, a[5] = hi.y, a[6] = hi.z, a[7] = hi.w;
-    }
-    // list segments by quarter of the idx_1 range (the format k_bf_resolve reads)
-    const int quarter = (((n1 + kNearSplit - 1) / kNearSplit) + 7) & ~7;
-    uint32_t* const my_list = near_list + ((size_t)p * max_n2 + (q < n2 ? q : 0)) * kNearSplit * kNearSeg;
-    uint32_t top[kTopK];
+        pcq[u] = __builtin_popcount(lo.x) + __builtin_popcount(lo.y) + __builtin_popcount(lo.z) + __builtin_popcount(lo.w) +
+                 __builtin_popcount(hi.x) + __builtin_popcount(hi.y) + __builtin_popcount(hi.z) + __builtin_popcount(hi.w);
+        const uint4 mine = half ? hi : lo;
+        const uint32_t w4[4] = {mine.x, mine.y, mine.z, mine.w};
 #pragma unroll
-    for (int k = 0; k < kTopK; ++k) top[k] = ~0u;
-    uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
-    auto hit = [&](uint32_t d, int j) {
-        const uint32_t e = (d << 16) | (uint32_t)j;
-        const int seg = (j >= quarter ? 1 : 0) + (j >= 2 * quarter ? 1 : 0) + (j >= 3 * quarter ? 1 : 0);
-        const uint32_t c = seg == 0 ? cnt0 : seg == 1 ? cnt1 : seg == 2 ? cnt2 : cnt3;
-        if (c < (uint32_t)kNearSeg) my_list[seg * kNearSeg + c] = e;
-        cnt0 += seg == 0;
-        cnt1 += seg == 1;
-        cnt2 += seg == 2;
-        cnt3 += seg == 3;
-        topk_insert(e, top);
-    };
-    const uint4* __restrict__ gsrc = reinterpret_cast<const uint4*>(desc_1 + (size_t)p * stride_1);
-    const int n_chunks = (n1 + kTgtChunk - 1) / kTgtChunk;
-    // stage chunk 0
-    {
-        uint4 v = {0u, 0u, 0u, 0u};
-        if ((tid >> 1) < n1) v = gsrc[tid];
-        tgt[0][tid] = v;
+        for (int s = 0; s < 8; ++s) qb[u][s] = to_pm1(expand01(w4[s >> 1], (s & 1) * 4));
+        need[u] = act ? pcq[u] - (int)near_thr : 0x7FFFFFFF;   // inactive query: no accumulator value reaches the bound
     }
-    __syncthreads();
-    for (int c = 0; c < n_chunks; ++c) {
-        const int buf = c & 1, j0 = c * kTgtChunk;
-        // request the next chunk now; it is written to the other buffer after this chunk's arithmetic
-        uint4 nxt = {0u, 0u, 0u, 0u};
-        const bool has_next = c + 1 < n_chunks;
-        if (has_next && j0 + kTgtChunk + (tid >> 1) < n1) nxt = gsrc[(size_t)(j0 + kTgtChunk) * 2 + tid];
-        const int jn = min(kTgtChunk, n1 - j0);   // descriptors of this chunk (the staged tail beyond n1 is zero and masked below)
-        // LDS reads and their waits are issued by hand: hipcc's wait insertion turns the loop-carried "A was requested an iteration ago"
-        // into s_waitcnt lgkmcnt(0) right behind the requests for B, which serialises request and use. LDS returns in order, so
-        // lgkmcnt(8) = "everything but the eight newest requests has arrived". The two register sets are pinned (v[40:71], v[72:103]) so
-        // that the request and the wait statement name the same physical registers.
-        const uint32_t lds_base = (uint32_t)(uintptr_t)(&tgt[buf][0]);   // LDS byte address (low 32 bits of the flat address)
-        auto group = [&](const u32x4& l0, const u32x4& h0, const u32x4& l1, const u32x4& h1, const u32x4& l2, const u32x4& h2, const u32x4& l3,
-                         const u32x4& h3, int j) __attribute__((always_inline)) {
-            uint32_t d0, d1, d2, d3;
-            dist4(a, l0, h0, l1, h1, l2, h2, l3, h3, d0, d1, d2, d3);
-            // near distances are rare (the true match and near-duplicates): one test per four pairs on the common path
-            if (active && min(min(d0, d1), min(d2, d3)) <= near_thr) {
-                if (d0 <= near_thr && j < jn) hit(d0, j0 + j);
-                if (d1 <= near_thr && j + 1 < jn) hit(d1, j0 + j + 1);
-                if (d2 <= near_thr && j + 2 < jn) hit(d2, j0 + j + 2);
-                if (d3 <= near_thr && j + 3 < jn) hit(d3, j0 + j + 3);
+    if (half == 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) s_ctx[wv][u * 32 + col] = make_int2(need[u], pcq[u]);
+    }
+    // Near pairs are rare per PAIR (about 3 per 1000 on consecutive video frames) but nearly every 32 x 32 tile holds one, so a
+    // per-tile "any lane has one" branch into row-by-row tests would run on every tile with one or two useful lanes. Instead a lane
+    // whose tile column holds a near pair appends its 16 accumulators to a wave-level queue in LDS (slots compacted with the ballot,
+    // no row tests on this path), and when 64 columns are queued the wave drains them with every lane busy: lane k takes entry k,
+    // counts its near rows, reserves that many slots of the query's list segment with ONE LDS atomic and stores the entries.
+    // The list of a query keeps four segments (the resolver's layout): segment = 2 * (C-tile half the column came from) + (0 / 1 for
+    // the first / second half of the tiles).
+    const int n_tiles = (n1 + 31) >> 5, phase_tiles = (n_tiles + 1) >> 1;
+    int q_head = 0, q_tail = 0;   // wave-uniform ring indices (entries q_head .. q_tail - 1, slots taken mod kQueueSlots)
+    auto drain = [&](int n_take) __attribute__((always_inline)) {
+        if (lane < n_take) {
+            const int e = (q_head + lane) & (kQueueSlots - 1);
+            const uint32_t meta = s_qmeta[wv][e];
+            const int tile_e = (int)(meta >> 8), half_e = (int)(meta >> 6) & 1, qi = (int)(meta & 63u);
+            const int2 ctx = s_ctx[wv][qi];
+            int v[16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int4 x = s_queue[wv][k][e];
+                v[4 * k] = x.x; v[4 * k + 1] = x.y; v[4 * k + 2] = x.z; v[4 * k + 3] = x.w;
             }
-        };
-#define OVS_LDS_REQ4(addr, P, V0, V1, V2, V3, V4, V5, V6, V7)                                                                              \
-    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t" \
-                 "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112" \
-                 : "={" V0 "}"(P##0l), "={" V1 "}"(P##0h), "={" V2 "}"(P##1l), "={" V3 "}"(P##1h), "={" V4 "}"(P##2l), "={" V5 "}"(P##2h),  \
-                   "={" V6 "}"(P##3l), "={" V7 "}"(P##3h)                                                                                   \
-                 : "v"(addr)                                                                                                               \
-                 : "memory")
-#define OVS_LDS_WAIT4(N, P, V0, V1, V2, V3, V4, V5, V6, V7)                                                                            \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                                          \
-                 : "+{" V0 "}"(P##0l), "+{" V1 "}"(P##0h), "+{" V2 "}"(P##1l), "+{" V3 "}"(P##1h), "+{" V4 "}"(P##2l), "+{" V5 "}"(P##2h), \
-                   "+{" V6 "}"(P##3l), "+{" V7 "}"(P##3h)::"memory")
-#define OVS_VA "v[40:43]", "v[44:47]", "v[48:51]", "v[52:55]", "v[56:59]", "v[60:63]", "v[64:67]", "v[68:71]"
-#define OVS_VB "v[72:75]", "v[76:79]", "v[80:83]", "v[84:87]", "v[88:91]", "v[92:95]", "v[96:99]", "v[100:103]"
-#define OVS_X(M, ...) M(__VA_ARGS__)
-        const int jend = (jn + 7) & ~7;   // groups of 8 = two register sets; <= kTgtChunk
-        u32x4 A0l, A0h, A1l, A1h, A2l, A2h, A3l, A3h, B0l, B0h, B1l, B1h, B2l, B2h, B3l, B3h;
-        uint32_t addr = lds_base;
-        OVS_X(OVS_LDS_REQ4, addr, A, OVS_VA);
-        for (int j = 0; j < jend; j += 8) {
-            const uint32_t addr_b = addr + 128u;
-            OVS_X(OVS_LDS_REQ4, addr_b, B, OVS_VB);
-            OVS_X(OVS_LDS_WAIT4, 8, A, OVS_VA);
-            group(A0l, A0h, A1l, A1h, A2l, A2h, A3l, A3h, j);
-            addr += 256u;
-            if (j + 8 < jend) {   // wave-uniform
-                OVS_X(OVS_LDS_REQ4, addr, A, OVS_VA);
-                OVS_X(OVS_LDS_WAIT4, 8, B, OVS_VB);
-            } else {
-                OVS_X(OVS_LDS_WAIT4, 0, B, OVS_VB);
+            uint32_t nh = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nh += v[r] >= ctx.x ? 1u : 0u;
+            const int seg = 2 * half_e + (tile_e >= phase_tiles ? 1 : 0);
+            uint32_t slot = atomicAdd(&s_segcnt[seg][wv * 64 + qi], nh);
+            uint32_t* dst = near_list + (((size_t)p * max_n2 + (q_wave + qi)) * kNearSplit + seg) * kNearSeg;
+            const int j_base = tile_e * 32 + 4 * half_e;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (v[r] >= ctx.x) {
+                    // past kNearSeg the segment counts as overflowed (the resolver then rescans that query): the clamp only keeps the store in bounds
+                    dst[min(slot, (uint32_t)kNearSeg - 1u)] = ((uint32_t)(ctx.y - v[r]) << 16) | (uint32_t)(j_base + (r & 3) + 8 * (r >> 2));
+                    ++slot;
+                }
             }
-            group(B0l, B0h, B1l, B1h, B2l, B2h, B3l, B3h, j + 4);
         }
-        if (has_next) tgt[buf ^ 1][tid] = nxt;
-        __syncthreads();
+        q_head += n_take;
+    };
+
+    const uint8_t* __restrict__ t = desc_1 + (size_t)p * stride_1;
+    auto load_rows = [&](int j0) __attribute__((always_inline)) -> uint4 {
+        const int row = min(j0 + col, n1 - 1);   // rows past n1 re-read the last descriptor; their accumulators are voided below
+        return *reinterpret_cast<const uint4*>(t + (size_t)row * 32 + half * 16);
+    };
+    if (n1 > 0) {
+        uint4 raw = load_rows(0);
+        for (int tile = 0; tile < n_tiles; ++tile) {
+            const int j0 = tile << 5;
+            const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
+            if (tile + 1 < n_tiles) raw = load_rows(j0 + 32);   // next tile's bytes are in flight under this tile's MFMAs
+            v16i acc[2];
+            acc[0] = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            acc[1] = acc[0];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const v4i a = expand01(w4[s >> 1], (s & 1) * 4);
+                acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qb[0][s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qb[1][s], acc[1], 0, 0, 0);
+            }
+            if (j0 + 32 > n1) {   // last, partial tile (wave-uniform): rows past n1 can never be near
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool in = j0 + (r & 3) + 8 * (r >> 2) + 4 * half < n1;
+                    acc[0][r] = in ? acc[0][r] : (int)0x80000000;
+                    acc[1][r] = in ? acc[1][r] : (int)0x80000000;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool has = max16(acc[u]) >= need[u];
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+                if (m) {
+                    if (has) {
+                        const int e = (q_tail + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) &
+                                      (kQueueSlots - 1);
+                        s_qmeta[wv][e] = ((uint32_t)tile << 8) | (uint32_t)(half << 6) | (uint32_t)(u * 32 + col);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            s_queue[wv][k][e] = make_int4(acc[u][4 * k], acc[u][4 * k + 1], acc[u][4 * k + 2], acc[u][4 * k + 3]);
+                    }
+                    q_tail += __builtin_popcountll(m);
+                    if (q_tail - q_head >= 64) drain(64);   // at most 63 were queued before this column set: never more than 127 entries
+                }
+            }
+        }
+        if (q_tail > q_head) drain(q_tail - q_head);
     }
+    // Workgroup scope is enough (and an agent-scope fence would cost an L2 write-back + invalidate per workgroup: buffer_wbl2 sc1 /
+    // buffer_inv sc1, which also evicts the descriptors every other workgroup of the XCD is streaming): the entries read back below
+    // were written by lanes of the reader's OWN wave, through the CU's write-through L1.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    // ---- per query: segment counts and the sorted top-8 of its list. Thread tid <-> query tid of the workgroup; eight entries per
+    // segment in flight at a time.
+    const int q = chunk_id * kNearQueries + tid;
     if (q < n2) {
-        near_cnt[((size_t)p * max_n2 + q) * kNearSplit + 0] = cnt0;
-        near_cnt[((size_t)p * max_n2 + q) * kNearSplit + 1] = cnt1;
-        near_cnt[((size_t)p * max_n2 + q) * kNearSplit + 2] = cnt2;
-        near_cnt[((size_t)p * max_n2 + q) * kNearSplit + 3] = cnt3;
+        uint32_t top[kTopK];
+#pragma unroll
+        for (int k = 0; k < kTopK; ++k) top[k] = ~0u;
+        uint32_t c[kNearSplit];
+#pragma unroll
+        for (int w = 0; w < kNearSplit; ++w) c[w] = s_segcnt[w][tid];
+        const uint32_t* lst = near_list + ((size_t)p * max_n2 + q) * kNearSplit * kNearSeg;
+        const uint32_t longest = min((uint32_t)kNearSeg, max(max(c[0], c[1]), max(c[2], c[3])));
+        for (uint32_t k0 = 0; k0 < longest; k0 += 8) {
+            uint32_t e[kNearSplit][8];
+#pragma unroll
+            for (int w = 0; w < kNearSplit; ++w)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    e[w][i] = k0 + i < min(c[w], (uint32_t)kNearSeg)
+                                  ? __hip_atomic_load(lst + w * kNearSeg + k0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                  : ~0u;
+#pragma unroll
+            for (int w = 0; w < kNearSplit; ++w)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) topk_insert(e[w][i], top);
+        }
+        *reinterpret_cast<uint4*>(near_cnt + ((size_t)p * max_n2 + q) * kNearSplit) = make_uint4(c[0], c[1], c[2], c[3]);
         uint4* dst = reinterpret_cast<uint4*>(near_top + ((size_t)p * max_n2 + q) * kTopK);
         dst[0] = make_uint4(top[0], top[1], top[2], top[3]);
         dst[1] = make_uint4(top[4], top[5], top[6], top[7]);
@@ -636,7 +645,7 @@ ovs_status run_bf(ovs_matcher* m, const uint8_t* d1, size_t stride_1, const int3
                   size_t stride_2, const int32_t* d_n2, const uint8_t* d_valid, int batch, float lowe_ratio, int32_t* d_pairs, int32_t* d_counts, int cap,
                   hipStream_t s) {
     const uint32_t thr = near_threshold(lowe_ratio);
-    const int chunks = (m->max_n2 + 255) / 256, total_wg = chunks * batch;
+    const int chunks = (m->max_n2 + kNearQueries - 1) / kNearQueries, total_wg = chunks * batch;
     dim3 grid(((total_wg + 7) / 8) * 8);
     OVS_HIP_TRY(m->prof.begin(s));
     hipLaunchKernelGGL(k_hamming_near, grid, dim3(256), 0, s, d1, stride_1, d_n1, d2, stride_2, d_n2, d_valid, m->max_n2, thr,
