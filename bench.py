@@ -294,16 +294,21 @@ def main():
         simd_hz = 1024 * 2.4e9
         pairs_launch = pairs_step / n_chain
         near_s = iso_ms["match_near"] / n_chain * 1e-3
-        near_peak = simd_hz * 64.0 / (8 * 2.4 + 8 * 4.2)          # 8 v_xor_b32 + 8 v_bcnt_u32_b32 per 64 pairs
+        # k_hamming_near runs on the matrix cores since round 2: a 256-bit Hamming distance is an exact i8 dot product of 256 terms
+        # (2 * 256 integer ops per pair, v_mfma_i32_32x32x32_i8). Peak: 2x the dense bf16 rate of MI355X_MICROARCH.md (2.5 PF) = 5.0e15;
+        # the issue-rate ceiling measured on this chip with tools/ubench/mfma_i8_ubench is 4.6e15 (34.8 cycles per MFMA per SIMD).
+        near_ops = pairs_launch * 512.0
         valu_counts = pmc.get("insts_valu", {}) if isinstance(pmc.get("insts_valu"), dict) else {}
-        roofline_valu = {
-            "k_hamming_near": {"unit": "pair-distances/s", "achieved": round(pairs_launch / near_s, 1), "peak": round(near_peak, 1),
-                               "frac": round(pairs_launch / near_s / near_peak, 4), "launch_ms_alone": round(near_s * 1e3, 5),
-                               "floor_model": "8 v_xor_b32 (2.4 cyc) + 8 v_bcnt_u32_b32 (4.2 cyc) per 64 pairs per SIMD",
-                               "min_wave_insts_per_launch": int(pairs_launch / 64 * 16),
-                               "insts_valu_per_launch": valu_counts.get("match_near"),
+        roofline_mfma = {
+            "k_hamming_near": {"bound": "mfma", "unit": "TOP/s (i8)", "achieved": round(near_ops / near_s / 1e12, 1), "peak": 5000.0,
+                               "frac": round(near_ops / near_s / 5.0e15, 4), "ubench_ceiling": 4600.0,
+                               "frac_of_ubench_ceiling": round(near_ops / near_s / 4.6e15, 4),
+                               "launch_ms_alone": round(near_s * 1e3, 5), "pair_distances_per_s": round(pairs_launch / near_s, 1),
+                               "ops_model": "512 integer ops per pair (256 multiply-adds), 8 x v_mfma_i32_32x32x32_i8 per 32 x 32 pairs",
+                               "vector_path_floor_pairs_per_s": round(simd_hz * 64.0 / (8 * 2.4 + 8 * 4.2), 1),
                                "achieved_GBps_algorithmic": round(ab["match_near"] * Bc / near_s / 1e9, 2)},
         }
+        roofline_valu = {}
         if valu_counts.get("fast"):
             fast_s = iso_ms["fast"] / n_chain * 1e-3
             roofline_valu["k_fast_cells"] = {"unit": "VALU wave-instructions/s", "achieved": round(valu_counts["fast"] / fast_s, 1),
@@ -357,6 +362,7 @@ def main():
             "extract_frac_of_hbm_peak": round(extract_gbs / HBM_PEAK_GBS, 5),
             "roofline": roof,
             "roofline_valu": roofline_valu,
+            "roofline_mfma": roofline_mfma,
             "class_boundary_latency": class_lat,
             "cpu_baseline": cpu,
             "local_ba": ba_res,

@@ -96,7 +96,7 @@ __device__ __forceinline__ int max16(const v16i& c) {
                max(max(max(c[8], c[9]), max(c[10], c[11])), max(max(c[12], c[13]), max(c[14], c[15]))));
 }
 
-__global__ __launch_bounds__(256) void k_hamming_near(const uint8_t* __restrict__ desc_1, size_t stride_1,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_hamming_near(const uint8_t* __restrict__ desc_1, size_t stride_1,
                                                      const int32_t* __restrict__ n1_arr, const uint8_t* __restrict__ desc_2,
                                                      size_t stride_2, const int32_t* __restrict__ n2_arr,
                                                      const uint8_t* __restrict__ valid_2, int max_n2, uint32_t near_thr,

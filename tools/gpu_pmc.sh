@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over a short bench run (separate passes: SQ issue mix, SQ stalls, TCC read bytes, TCC write bytes).
+# PMC passes over a short bench run (separate passes: SQ issue mix, SQ stalls, TCC read bytes, TCC write bytes, MFMA).
 # Usage (on the GPU box, from the repo root): tools/gpu_pmc.sh <tag>
 tag=${1:-pmc}
 export TMPDIR=/tmp
@@ -11,8 +11,9 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU 
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --output-format csv -d $out/p2 -o p2 -- $cmd > $out/p2.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/p3 -o p3 -- $cmd > $out/p3.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/p4 -o p4 -- $cmd > $out/p4.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_MFMA --output-format csv -d $out/p5 -o p5 -- $cmd > $out/p5.log 2>&1
 cd - > /dev/null
-python tools/pmc_summary.py $out > $out/summary.txt 2>&1
+python tools/pmc_summary.py $out --json $out/pmc_traffic.json > $out/summary.txt 2>&1
 # keep only the small artefacts
 find $out -name '*.csv' -size +8M -delete
 ls -la $out $out/p1 2>/dev/null | head -40
