@@ -230,6 +230,30 @@ def main():
         iso_ms["match_near"] += st2[0] / calls
         iso_ms["match_resolve"] += st2[1] / calls
 
+    # ---- the popcount (vector-ALU) form of the all-pairs stage, alone, on the same inputs: bit-identical output (checked), its time
+    # is what roofline_valu is quoted on; the timed region above runs the default (matrix-core) form
+    popc_ms = 0.0
+    popc_same = True
+    for ch in chains:
+        b = ch.bufs[0]
+        ref_cnt = b["mcnt"].clone()
+        ref_pairs = b["pairs"].clone()
+        ch.mt.set_near_path("popcount")
+        for _ in range(n_iso):
+            with torch.cuda.stream(ch.s_match):
+                ch.mt.brute_force_match_batch_dev(b["desc_prev"], b["cnt_prev"], b["desc"], b["cnt"], b["pairs"], b["mcnt"],
+                                                    stream=ch.s_match.cuda_stream)
+            torch.cuda.synchronize()
+        st2 = (C.c_float * 2)()
+        nc = C.c_int32()
+        _lib.check(L.ovs_matcher_profile_read(ch.mt._h, st2, C.byref(nc)), "profile_read")
+        popc_ms += st2[0] / max(nc.value, 1)
+        popc_same = popc_same and bool(torch.equal(ref_cnt, b["mcnt"]))
+        for i in range(min(4, Bc)):
+            k = int(ref_cnt[i])
+            popc_same = popc_same and bool(torch.equal(ref_pairs[i, :k], b["pairs"][i, :k]))
+        ch.mt.set_near_path("matrix")
+
     kp_step = matches_step = pairs_step = 0
     for ch in chains:
         cnt = ch.bufs[0]["cnt"].cpu().numpy().astype(np.int64)
@@ -269,7 +293,9 @@ def main():
         if os.path.exists(tpath):
             try:
                 pmc = json.load(open(tpath))
-                traffic = pmc.get(dom)
+                # the PMC passes may have run at another frames-per-launch: every per-launch count here is linear in it
+                pmc_scale = Bc / float(pmc.get("batch", Bc))
+                traffic = int(pmc[dom] * pmc_scale) if dom in pmc else None
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "kernel": {"pyramid": "k_resize_linear_u8 (x7)", "fast": "k_fast_cells", "tree": "k_tree",
@@ -277,7 +303,8 @@ def main():
                                            "match_resolve": "k_bf_resolve"}[dom],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --overlap 0`, "
-                                                      "(2*FETCH + WRITE) KiB; not measured in this run)" if traffic else None,
+                                                      "(2*FETCH + WRITE) KiB, collected at %s frames per launch and scaled to %d; not measured in this run)"
+                                                      % (pmc.get("batch", "the same"), Bc) if traffic else None,
                 "algorithmic_bytes_per_launch": int(ab[dom] * Bc), "launch_ms": round(iso_ms[dom] / n_chain, 5),
                 "launch_ms_source": "HIP events on the launch stream, kernel alone on the GPU (4 launches after the timed region, same inputs)",
                 "launches_per_step": n_chain}
@@ -298,7 +325,7 @@ def main():
         # (2 * 256 integer ops per pair, v_mfma_i32_32x32x32_i8). Peak: 2x the dense bf16 rate of MI355X_MICROARCH.md (2.5 PF) = 5.0e15;
         # the issue-rate ceiling measured on this chip with tools/ubench/mfma_i8_ubench is 4.6e15 (34.8 cycles per MFMA per SIMD).
         near_ops = pairs_launch * 512.0
-        valu_counts = pmc.get("insts_valu", {}) if isinstance(pmc.get("insts_valu"), dict) else {}
+        valu_counts = {k: int(v * Bc / float(pmc.get("batch", Bc))) for k, v in pmc["insts_valu"].items()} if isinstance(pmc.get("insts_valu"), dict) else {}
         roofline_mfma = {
             "k_hamming_near": {"bound": "mfma", "unit": "TOP/s (i8)", "achieved": round(near_ops / near_s / 1e12, 1), "peak": 5000.0,
                                "frac": round(near_ops / near_s / 5.0e15, 4), "ubench_ceiling": 4600.0,
@@ -308,7 +335,15 @@ def main():
                                "vector_path_floor_pairs_per_s": round(simd_hz * 64.0 / (8 * 2.4 + 8 * 4.2), 1),
                                "achieved_GBps_algorithmic": round(ab["match_near"] * Bc / near_s / 1e9, 2)},
         }
-        roofline_valu = {}
+        popc_s = popc_ms / n_chain * 1e-3
+        popc_peak = simd_hz * 64.0 / (8 * 2.4 + 8 * 4.2)          # 8 v_xor_b32 + 8 v_bcnt_u32_b32 per 64 pairs per SIMD
+        roofline_valu = {
+            "k_hamming_near_popc": {"unit": "pair-distances/s", "achieved": round(pairs_launch / popc_s, 1), "peak": round(popc_peak, 1),
+                                    "frac": round(pairs_launch / popc_s / popc_peak, 4), "launch_ms_alone": round(popc_s * 1e3, 5),
+                                    "floor_model": "8 v_xor_b32 (2.4 cyc) + 8 v_bcnt_u32_b32 (4.2 cyc) per 64 pairs per SIMD",
+                                    "note": "the selectable popcount form of the all-pairs stage (ovs_matcher_set_near_path); not the form the "
+                                            "timed region runs", "same_pairs_as_matrix_path": popc_same},
+        }
         if valu_counts.get("fast"):
             fast_s = iso_ms["fast"] / n_chain * 1e-3
             roofline_valu["k_fast_cells"] = {"unit": "VALU wave-instructions/s", "achieved": round(valu_counts["fast"] / fast_s, 1),

@@ -186,6 +186,13 @@ ovs_status ovs_robust_brute_force_match_batch_dev(ovs_matcher* m, const uint8_t*
                                                   const uint8_t* d_valid_2, int32_t batch, float lowe_ratio, int32_t* d_pairs,
                                                   int32_t* d_counts, int32_t cap, void* stream);
 
+/* The all-pairs stage of brute_force_match has two bit-identical implementations: OVS_NEAR_PATH_MATRIX (default) evaluates the
+ * 256-bit Hamming distances as exact i8 dot products on the matrix cores, OVS_NEAR_PATH_POPCOUNT is the vector-ALU xor / popcount
+ * form (BASELINE north star). Same near lists, same pairs; the switch exists for measurement and for parity tests of both. */
+#define OVS_NEAR_PATH_MATRIX 0
+#define OVS_NEAR_PATH_POPCOUNT 1
+ovs_status ovs_matcher_set_near_path(ovs_matcher* m, int32_t path);
+
 /* Measurement hooks: stages = all-pairs near-list kernel | resolve kernel (2 floats). */
 ovs_status ovs_matcher_profile_enable(ovs_matcher* m, int32_t enable);
 ovs_status ovs_matcher_profile_read(ovs_matcher* m, float* stage_ms /* 2 */, int32_t* ncalls);

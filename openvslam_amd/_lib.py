@@ -54,6 +54,7 @@ SYMBOLS = {
     "ovs_orb_debug_level_counts": (_i32, [_vp, _i32, _vp]),
     "ovs_orb_profile_enable": (_i32, [_vp, _i32]),
     "ovs_orb_profile_read": (_i32, [_vp, _vp, C.POINTER(_i32)]),
+    "ovs_matcher_set_near_path": (_i32, [_vp, _i32]),
     "ovs_matcher_profile_enable": (_i32, [_vp, _i32]),
     "ovs_matcher_profile_read": (_i32, [_vp, _vp, C.POINTER(_i32)]),
     "ovs_matcher_create": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(_vp)]),

@@ -267,6 +267,216 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+
+// Four consecutive 32-byte descriptors through the scalar data cache under ONE wait (hipcc otherwise waits after each load).
+// The loads, their count and the wait are all inside the statement (guide 5.7); outputs are early-clobber SGPR tuples.
+__device__ __forceinline__ void sload_desc4(const uint32_t* __restrict__ p, u32x8& b0, u32x8& b1, u32x8& b2, u32x8& b3) {
+    asm volatile(
+        "s_load_dwordx8 %0, %4, 0x0\n\t"
+        "s_load_dwordx8 %1, %4, 0x20\n\t"
+        "s_load_dwordx8 %2, %4, 0x40\n\t"
+        "s_load_dwordx8 %3, %4, 0x60\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(b0), "=&s"(b1), "=&s"(b2), "=&s"(b3)
+        : "s"(p)
+        : "memory");
+}
+
+// eight descriptors under one wait: half as many stalls per pair as sload_desc4 (64 SGPRs of payload)
+__device__ __forceinline__ void sload_desc8(const uint32_t* __restrict__ p, u32x8& b0, u32x8& b1, u32x8& b2, u32x8& b3, u32x8& b4, u32x8& b5,
+                                            u32x8& b6, u32x8& b7) {
+    asm volatile(
+        "s_load_dwordx8 %0, %8, 0x0\n\t"
+        "s_load_dwordx8 %1, %8, 0x20\n\t"
+        "s_load_dwordx8 %2, %8, 0x40\n\t"
+        "s_load_dwordx8 %3, %8, 0x60\n\t"
+        "s_load_dwordx8 %4, %8, 0x80\n\t"
+        "s_load_dwordx8 %5, %8, 0xa0\n\t"
+        "s_load_dwordx8 %6, %8, 0xc0\n\t"
+        "s_load_dwordx8 %7, %8, 0xe0\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(b0), "=&s"(b1), "=&s"(b2), "=&s"(b3), "=&s"(b4), "=&s"(b5), "=&s"(b6), "=&s"(b7)
+        : "s"(p)
+        : "memory");
+}
+
+__device__ __forceinline__ uint32_t hamming256v(const uint32_t (&a)[8], const u32x8& b) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d = __builtin_popcount(a[i] ^ b[i]) + d;
+    return d;
+}
+
+// ---- 1b. all pairs, near lists: the popcount path (OVS_NEAR_PATH_POPCOUNT) ---------------------------------------------
+// The vector-ALU form of the same stage (BASELINE north star: "Hamming distance uses popcount"), kept selectable and under the same
+// parity tests; it is the kernel `roofline_valu` is quoted on. Same outputs as k_hamming_near (a query's four list segments are the
+// four waves' quarters of idx_1 here), 2.3x slower on config 2.
+// Workgroup = 4 waves x the same 64 queries (idx_2); wave w scans the w-th quarter of the frame descriptors (idx_1). The descriptors
+// of the quarter stream through the scalar cache in groups of FOUR into two SGPR sets that are double-buffered: the loads of the next
+// group are in flight while the current one is XORed / popcounted (SMEM returns out of order, so only lgkmcnt(0) is a usable wait --
+// the overlap has to come from issuing early, not from partial waits). Entries with d <= near_thr go to the wave's own segment of the
+// query's list (count in a register: no atomics, no waits in the loop) and into a sorted top-8 kept in registers; the four partial
+// top-8s are merged through LDS at the end.
+//
+// v2 (round 2): (i) the popcount accumulate is pinned to the 8 x (v_xor, v_bcnt acc) chain -- hipcc split it into 6 independent
+// v_bcnt + 3 v_add3_u32 per descriptor (19 instead of 16 VALU per pair); (ii) 1-D grid in XCD-major order, so all chunks of a problem
+// run on ONE XCD and its 64 KB of frame descriptors are fetched into one L2 instead of eight (fabric traffic was 9.7x algorithmic);
+// (iii) the double-buffered scalar loads above. 0.303 ms per 128 problems of 2000 x 2000 = 0.57 of the VALU issue floor.
+//
+// v3 (round 2, measured and NOT kept): frame descriptors staged in LDS and read back with broadcast ds_read_b128 (256 queries per
+// workgroup, one self-contained asm block per descriptor: two LDS reads of the next descriptor, 8 x (v_xor, v_bcnt), lgkmcnt(0)).
+// Bit-identical results, but 0.394 ms (0.44 of the floor): the LDS return has to be waited for inside every 16-instruction block
+// (a wait placed in the NEXT statement lets hipcc copy VGPRs whose data has not landed), and a 16-VALU block is shorter than the
+// ds_read_b128 round trip. The scalar-cache form stays.
+
+// One word of four descriptors in ONE asm volatile statement: four v_xor_b32 (SGPR operand) followed by the four v_bcnt_u32_b32 that
+// accumulate them, so no v_bcnt issues directly behind the v_xor it depends on (hipcc pairs them back to back), the popcount stays an
+// 8-deep accumulate chain per descriptor (hipcc splits it into 6 independent v_bcnt + 3 v_add3_u32: 19 instead of 16 VALU per pair),
+// and -- volatile statements keep their program order -- the machine scheduler cannot sink the NEXT group's scalar loads below this
+// group's arithmetic.
+__device__ __forceinline__ void xor_bcnt4_first(uint32_t a, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t& d0, uint32_t& d1,
+                                                uint32_t& d2, uint32_t& d3) {
+    uint32_t t0, t1, t2, t3;
+    asm volatile(
+        "v_xor_b32 %4, %9, %8\n\tv_xor_b32 %5, %10, %8\n\tv_xor_b32 %6, %11, %8\n\tv_xor_b32 %7, %12, %8\n\t"
+        "v_bcnt_u32_b32 %0, %4, 0\n\tv_bcnt_u32_b32 %1, %5, 0\n\tv_bcnt_u32_b32 %2, %6, 0\n\tv_bcnt_u32_b32 %3, %7, 0"
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(a), "s"(s0), "s"(s1), "s"(s2), "s"(s3));
+}
+__device__ __forceinline__ void xor_bcnt4_acc(uint32_t a, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t& d0, uint32_t& d1,
+                                              uint32_t& d2, uint32_t& d3) {
+    uint32_t t0, t1, t2, t3;
+    asm volatile(
+        "v_xor_b32 %4, %9, %8\n\tv_xor_b32 %5, %10, %8\n\tv_xor_b32 %6, %11, %8\n\tv_xor_b32 %7, %12, %8\n\t"
+        "v_bcnt_u32_b32 %0, %4, %0\n\tv_bcnt_u32_b32 %1, %5, %1\n\tv_bcnt_u32_b32 %2, %6, %2\n\tv_bcnt_u32_b32 %3, %7, %3"
+        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(a), "s"(s0), "s"(s1), "s"(s2), "s"(s3));
+}
+
+// SGPR sets pinned to fixed registers: the load statement and the wait statement must name the SAME physical registers (the loads land
+// asynchronously; a compiler-inserted copy between the two statements would copy stale values)
+#define OVS_SET_A0 "s[36:43]"
+#define OVS_SET_A1 "s[44:51]"
+#define OVS_SET_A2 "s[52:59]"
+#define OVS_SET_A3 "s[60:67]"
+#define OVS_SET_B0 "s[68:75]"
+#define OVS_SET_B1 "s[76:83]"
+#define OVS_SET_B2 "s[84:91]"
+#define OVS_SET_B3 "s[92:99]"
+
+#define OVS_ISSUE4(p, r0, r1, r2, r3, R0, R1, R2, R3)                                                                       \
+    asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_load_dwordx8 %3, %4, 0x60" \
+                 : "={" R0 "}"(r0), "={" R1 "}"(r1), "={" R2 "}"(r2), "={" R3 "}"(r3)                                        \
+                 : "s"(p)                                                                                                    \
+                 : "memory")
+#define OVS_WAIT4(r0, r1, r2, r3, R0, R1, R2, R3) \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+{" R0 "}"(r0), "+{" R1 "}"(r1), "+{" R2 "}"(r2), "+{" R3 "}"(r3)::"memory")
+
+__device__ __forceinline__ void dist4(const uint32_t (&a)[8], const u32x8& b0, const u32x8& b1, const u32x8& b2, const u32x8& b3, uint32_t& d0,
+                                      uint32_t& d1, uint32_t& d2, uint32_t& d3) {
+    xor_bcnt4_first(a[0], b0[0], b1[0], b2[0], b3[0], d0, d1, d2, d3);
+#pragma unroll
+    for (int i = 1; i < 8; ++i) xor_bcnt4_acc(a[i], b0[i], b1[i], b2[i], b3[i], d0, d1, d2, d3);
+}
+
+__global__ __launch_bounds__(256) void k_hamming_near_popc(const uint8_t* __restrict__ desc_1, size_t stride_1,
+                                                     const int32_t* __restrict__ n1_arr, const uint8_t* __restrict__ desc_2,
+                                                     size_t stride_2, const int32_t* __restrict__ n2_arr,
+                                                     const uint8_t* __restrict__ valid_2, int max_n2, uint32_t near_thr,
+                                                     uint32_t* __restrict__ near_cnt, uint32_t* __restrict__ near_list,
+                                                     uint32_t* __restrict__ near_top, int chunks, int total_wg) {
+    __shared__ uint32_t s_top[kNearSplit][kTopK][64];
+    // XCD-major work order (workgroup b runs on XCD b % 8): XCD k takes the k-th contiguous eighth of the (problem, chunk) sequence
+    const int per_xcd = gridDim.x >> 3;
+    const int wg = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (wg >= total_wg) return;
+    const int p = wg / chunks, chunk_id = wg - p * chunks;
+    const int n1 = n1_arr[p], n2 = n2_arr[p];
+    if (chunk_id * 64 >= n2) return;
+    // wave index made provably uniform so the descriptor addresses below stay scalar (s_load_dwordx8)
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = chunk_id * 64 + lane;
+    const bool active = q < n2 && (!valid_2 || valid_2[(size_t)p * (stride_2 / 32) + q]);
+    uint32_t a[8];
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(desc_2 + (size_t)p * stride_2 + (size_t)(q < n2 ? q : 0) * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = src[i];
+    }
+    const int chunk = (((n1 + kNearSplit - 1) / kNearSplit) + 7) & ~7;
+    const int jb = min(n1, wv * chunk), je = min(n1, jb + chunk);
+    const uint32_t* __restrict__ t = reinterpret_cast<const uint32_t*>(desc_1 + (size_t)p * stride_1);
+    uint32_t* my_seg = near_list + (((size_t)p * max_n2 + q) * kNearSplit + wv) * kNearSeg;
+    uint32_t top[kTopK];
+#pragma unroll
+    for (int k = 0; k < kTopK; ++k) top[k] = ~0u;
+    uint32_t cnt = 0;
+    auto hit = [&](uint32_t d, int j) {
+        const uint32_t e = (d << 16) | (uint32_t)j;
+        if (cnt < (uint32_t)kNearSeg) my_seg[cnt] = e;
+        ++cnt;
+        topk_insert(e, top);
+    };
+    auto group = [&](uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, int j) {
+        // near distances are rare (the true match and near-duplicates): one test per four pairs on the common path
+        if (min(min(d0, d1), min(d2, d3)) <= near_thr) {
+            if (d0 <= near_thr) hit(d0, j);
+            if (d1 <= near_thr) hit(d1, j + 1);
+            if (d2 <= near_thr) hit(d2, j + 2);
+            if (d3 <= near_thr) hit(d3, j + 3);
+        }
+    };
+    int j = jb;
+    if (active) {
+        const int n8 = (je - jb) >> 3;   // iterations of 8 descriptors = one A group + one B group
+        if (n8 > 0) {
+            u32x8 a0, a1, a2, a3, b0, b1, b2, b3;
+            const uint32_t* pa = t + (size_t)j * 8;
+            OVS_ISSUE4(pa, a0, a1, a2, a3, OVS_SET_A0, OVS_SET_A1, OVS_SET_A2, OVS_SET_A3);
+            for (int it = 0; it < n8; ++it, j += 8) {
+                const uint32_t* pb = t + (size_t)(j + 4) * 8;
+                OVS_WAIT4(a0, a1, a2, a3, OVS_SET_A0, OVS_SET_A1, OVS_SET_A2, OVS_SET_A3);
+                OVS_ISSUE4(pb, b0, b1, b2, b3, OVS_SET_B0, OVS_SET_B1, OVS_SET_B2, OVS_SET_B3);
+                uint32_t d0, d1, d2, d3;
+                dist4(a, a0, a1, a2, a3, d0, d1, d2, d3);
+                group(d0, d1, d2, d3, j);
+                OVS_WAIT4(b0, b1, b2, b3, OVS_SET_B0, OVS_SET_B1, OVS_SET_B2, OVS_SET_B3);
+                if (it + 1 < n8) {   // wave-uniform: the next A group (the last iteration has none to fetch)
+                    const uint32_t* pn = t + (size_t)(j + 8) * 8;
+                    OVS_ISSUE4(pn, a0, a1, a2, a3, OVS_SET_A0, OVS_SET_A1, OVS_SET_A2, OVS_SET_A3);
+                }
+                dist4(a, b0, b1, b2, b3, d0, d1, d2, d3);
+                group(d0, d1, d2, d3, j + 4);
+            }
+        }
+        for (; j + 4 <= je; j += 4) {   // remainder: four at a time
+            u32x8 b0, b1, b2, b3;
+            sload_desc4(t + (size_t)j * 8, b0, b1, b2, b3);
+            uint32_t d0, d1, d2, d3;
+            dist4(a, b0, b1, b2, b3, d0, d1, d2, d3);
+            group(d0, d1, d2, d3, j);
+        }
+        for (; j < je; ++j) {
+            const uint32_t d = hamming256(a, t + (size_t)j * 8);
+            if (d <= near_thr) hit(d, j);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kTopK; ++k) s_top[wv][k][lane] = top[k];
+    if (q < n2) near_cnt[((size_t)p * max_n2 + q) * kNearSplit + wv] = cnt;
+    __syncthreads();
+    if (wv == 0 && q < n2) {
+#pragma unroll
+        for (int w = 1; w < kNearSplit; ++w)
+#pragma unroll
+            for (int k = 0; k < kTopK; ++k) topk_insert(s_top[w][k][lane], top);
+        uint4* dst = reinterpret_cast<uint4*>(near_top + ((size_t)p * max_n2 + q) * kTopK);
+        dst[0] = make_uint4(top[0], top[1], top[2], top[3]);
+        dst[1] = make_uint4(top[4], top[5], top[6], top[7]);
+    }
+}
+
 // ---- 2./3. resolve ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool ratio_rejects(float lowe_ratio, uint32_t second, uint32_t best) {
     return __fmul_rn(lowe_ratio, (float)second) < (float)best;
@@ -607,6 +817,7 @@ using namespace ovs;
 struct ovs_matcher {
     int device = 0;
     int max_n1 = 0, max_n2 = 0, max_batch = 0;
+    int near_path = OVS_NEAR_PATH_MATRIX;
     hipStream_t stream = nullptr;
     uint32_t* d_near_cnt = nullptr;
     uint32_t* d_near_list = nullptr;
@@ -645,11 +856,16 @@ ovs_status run_bf(ovs_matcher* m, const uint8_t* d1, size_t stride_1, const int3
                   size_t stride_2, const int32_t* d_n2, const uint8_t* d_valid, int batch, float lowe_ratio, int32_t* d_pairs, int32_t* d_counts, int cap,
                   hipStream_t s) {
     const uint32_t thr = near_threshold(lowe_ratio);
-    const int chunks = (m->max_n2 + kNearQueries - 1) / kNearQueries, total_wg = chunks * batch;
-    dim3 grid(((total_wg + 7) / 8) * 8);
     OVS_HIP_TRY(m->prof.begin(s));
-    hipLaunchKernelGGL(k_hamming_near, grid, dim3(256), 0, s, d1, stride_1, d_n1, d2, stride_2, d_n2, d_valid, m->max_n2, thr,
-                       m->d_near_cnt, m->d_near_list, m->d_near_top, chunks, total_wg);
+    if (m->near_path == OVS_NEAR_PATH_POPCOUNT) {
+        const int chunks = (m->max_n2 + 63) / 64, total_wg = chunks * batch;
+        hipLaunchKernelGGL(k_hamming_near_popc, dim3(((total_wg + 7) / 8) * 8), dim3(256), 0, s, d1, stride_1, d_n1, d2, stride_2, d_n2, d_valid,
+                           m->max_n2, thr, m->d_near_cnt, m->d_near_list, m->d_near_top, chunks, total_wg);
+    } else {
+        const int chunks = (m->max_n2 + kNearQueries - 1) / kNearQueries, total_wg = chunks * batch;
+        hipLaunchKernelGGL(k_hamming_near, dim3(((total_wg + 7) / 8) * 8), dim3(256), 0, s, d1, stride_1, d_n1, d2, stride_2, d_n2, d_valid,
+                           m->max_n2, thr, m->d_near_cnt, m->d_near_list, m->d_near_top, chunks, total_wg);
+    }
     OVS_HIP_TRY(hipGetLastError());
     OVS_HIP_TRY(m->prof.mark(1, s));
     if (m->resolve_lds_staged)
@@ -741,6 +957,12 @@ ovs_status ovs_matcher_destroy(ovs_matcher* m) {
     m->prof.destroy();
     if (m->stream) hipStreamDestroy(m->stream);
     delete m;
+    return OVS_OK;
+}
+
+ovs_status ovs_matcher_set_near_path(ovs_matcher* m, int32_t path) {
+    if (!m || (path != OVS_NEAR_PATH_MATRIX && path != OVS_NEAR_PATH_POPCOUNT)) return OVS_ERR_INVALID;
+    m->near_path = path;
     return OVS_OK;
 }
 

@@ -27,13 +27,19 @@ def _descs(rng, n1, n2, n_true, max_flip=40):
     return d1, d2
 
 
+@pytest.fixture(params=["matrix", "popcount"])
+def near_path(request):
+    """Both implementations of the all-pairs stage (ovs_matcher_set_near_path) run every brute_force_match test."""
+    return request.param
+
+
 @pytest.mark.parametrize("n1,n2,n_true", [(2000, 2000, 1200), (2004, 1987, 1500), (1, 1, 1), (300, 5, 5), (5, 300, 5), (777, 1023, 0)])
 @pytest.mark.parametrize("ratio", [0.9, 0.6])
-def test_brute_force_match(match, oracle, n1, n2, n_true, ratio):
+def test_brute_force_match(match, oracle, n1, n2, n_true, ratio, near_path):
     rng = np.random.default_rng(n1 * 31 + n2)
     d1, d2 = _descs(rng, n1, n2, min(n_true, n1, n2))
     valid = (rng.random(n2) < 0.9).astype(np.uint8)
-    m = match.robust(ratio, False, max_n1=2048, max_n2=2048)
+    m = match.robust(ratio, False, max_n1=2048, max_n2=2048, near_path=near_path)
     for v in (None, valid):
         want = oracle.robust_brute_force_match(d1, d2, v, ratio)
         got = m.brute_force_match(d1, d2, v)
@@ -47,7 +53,7 @@ def test_brute_force_match(match, oracle, n1, n2, n_true, ratio):
         assert len(want) > n_true // 3 and 0 < len(want1) < len(want)
 
 
-def test_claim_conflicts(match, oracle):
+def test_claim_conflicts(match, oracle, near_path):
     """Several keyframe descriptors compete for the same frame descriptor: exercises the already-matched rule."""
     rng = np.random.default_rng(3)
     base = rng.integers(0, 256, size=(40, 32), dtype=np.uint8)
@@ -59,25 +65,25 @@ def test_claim_conflicts(match, oracle):
             bits[rng.permutation(256)[:int(rng.integers(0, 12))]] ^= 1
             d[i] = np.packbits(bits)
     for ratio in (0.6, 0.9, 1.0):
-        m = match.robust(ratio, False, max_n1=256, max_n2=256)
+        m = match.robust(ratio, False, max_n1=256, max_n2=256, near_path=near_path)
         assert np.array_equal(m.brute_force_match(d1, d2), oracle.robust_brute_force_match(d1, d2, None, ratio))
         v1 = (np.arange(len(d1)) % 3 != 0).astype(np.uint8)   # the first of every triplet is masked: claimants fall through to the next
         assert np.array_equal(m.brute_force_match(d1, d2, frm_valid=v1), oracle.robust_brute_force_match(d1, d2, None, ratio, frm_valid=v1))
 
 
-def test_overflowing_near_lists_fall_back_exactly(match, oracle):
+def test_overflowing_near_lists_fall_back_exactly(match, oracle, near_path):
     """Many identical descriptors overflow the near lists -> literal serial replay path."""
     d1 = np.zeros((100, 32), np.uint8)
     d2 = np.zeros((60, 32), np.uint8)
     d1[::7, 0] = 1
     d2[::5, 3] = 0x80
     for ratio in (0.6, 0.9):
-        m = match.robust(ratio, False, max_n1=128, max_n2=128)
+        m = match.robust(ratio, False, max_n1=128, max_n2=128, near_path=near_path)
         assert np.array_equal(m.brute_force_match(d1, d2), oracle.robust_brute_force_match(d1, d2, None, ratio))
         v1 = (np.arange(len(d1)) % 3 != 0).astype(np.uint8)   # the first of every triplet is masked: claimants fall through to the next
         assert np.array_equal(m.brute_force_match(d1, d2, frm_valid=v1), oracle.robust_brute_force_match(d1, d2, None, ratio, frm_valid=v1))
     # ratio 1.01: duplicates are accepted one by one until the frame side runs out
-    m = match.robust(1.01, False, max_n1=128, max_n2=128)
+    m = match.robust(1.01, False, max_n1=128, max_n2=128, near_path=near_path)
     got = m.brute_force_match(d1, d2)
     want = oracle.robust_brute_force_match(d1, d2, None, 1.01)
     assert np.array_equal(got, want) and len(want) > 10
@@ -100,7 +106,7 @@ def test_best2_and_distance_identities(match, oracle):
     assert gb[0] == 256 and gi[0] == -1   # strict '<' against MAX_HAMMING_DIST: 256 never wins
 
 
-def test_batch_dev(match, oracle):
+def test_batch_dev(match, oracle, near_path):
     import torch
     rng = np.random.default_rng(11)
     B, cap = 4, 512
@@ -112,7 +118,7 @@ def test_batch_dev(match, oracle):
         a, c = _descs(rng, n1[b], n2[b], min(n1[b], n2[b]) // 2)
         d1[b, :n1[b]] = a
         d2[b, :n2[b]] = c
-    m = match.robust(0.9, False, max_n1=cap, max_n2=cap, max_batch=B)
+    m = match.robust(0.9, False, max_n1=cap, max_n2=cap, max_batch=B, near_path=near_path)
     td1, td2 = torch.from_numpy(d1).cuda(), torch.from_numpy(d2).cuda()
     tn1, tn2 = torch.from_numpy(n1).cuda(), torch.from_numpy(n2).cuda()
     pairs = torch.zeros((B, cap, 2), dtype=torch.int32, device="cuda")
@@ -123,3 +129,57 @@ def test_batch_dev(match, oracle):
         want = oracle.robust_brute_force_match(d1[b, :n1[b]], d2[b, :n2[b]], None, 0.9)
         got = pairs[b, :int(cnt[b])].cpu().numpy()
         assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n1", [1, 31, 32, 33, 65, 255, 257])
+def test_near_stage_edge_patterns(match, oracle, near_path, n1):
+    """Descriptors the all-pairs stage could get wrong: all-zero / all-one descriptors on either side (the matrix path's acceptance
+    bound |b| - near_thr goes negative, a padded tile row would then look near), exact duplicates of the LAST frame descriptor (the one
+    the matrix path re-reads for rows past n1), a keyframe-side count that leaves partial 32-query tiles and partial workgroups."""
+    rng = np.random.default_rng(100 + n1)
+    for n2 in (1, 33, 300):
+        d1 = rng.integers(0, 256, size=(n1, 32), dtype=np.uint8)
+        d2 = rng.integers(0, 256, size=(n2, 32), dtype=np.uint8)
+        d1[0] = 0
+        d1[-1] = rng.integers(0, 2, size=32, dtype=np.uint8)        # very few bits set
+        d2[0] = 0
+        d2[n2 // 2] = 255
+        d2[-1] = d1[-1]                                             # exact copy of the last frame descriptor
+        if n2 > 4:
+            d2[3] = d1[-1] ^ np.eye(32, dtype=np.uint8)[5]          # one bit away from it
+            d2[4] = np.eye(32, dtype=np.uint8)[7] * 3               # two bits set: near the all-zero frame descriptor
+        if n1 > 2:
+            d1[1] = 255
+        for ratio in (0.9, 0.6, 1.01):
+            m = match.robust(ratio, False, max_n1=512, max_n2=512, near_path=near_path)
+            want = oracle.robust_brute_force_match(d1, d2, None, ratio)
+            got = m.brute_force_match(d1, d2, None)
+            assert np.array_equal(got, want), (n1, n2, ratio)
+
+
+def test_near_paths_agree_on_large_batch(match):
+    """Full-size property (no oracle: 64 problems of ~2000 x 2000): the matrix path and the popcount path return the same pairs."""
+    import torch
+    rng = np.random.default_rng(9)
+    B, cap = 64, 2048
+    n1 = rng.integers(1900, 2049, B).astype(np.int32)
+    n2 = rng.integers(1900, 2049, B).astype(np.int32)
+    d2 = rng.integers(0, 256, size=(B, cap, 32), dtype=np.uint8)
+    d1 = d2[:, ::-1].copy()
+    noise = (rng.random((B, cap, 32)) < 0.02).astype(np.uint8) * rng.integers(1, 256, size=(B, cap, 32), dtype=np.uint8)
+    d1 ^= noise                                                     # ~5 flipped bits per descriptor: most pairs are true matches
+    d1[:, 100:140] = d1[:, 100:101]                                 # a cluster of duplicates: claim conflicts and long near lists
+    td1, td2 = torch.from_numpy(d1).cuda(), torch.from_numpy(d2).cuda()
+    tn1, tn2 = torch.from_numpy(n1).cuda(), torch.from_numpy(n2).cuda()
+    out = {}
+    for path in ("matrix", "popcount"):
+        m = match.robust(0.9, False, max_n1=cap, max_n2=cap, max_batch=B, near_path=path)
+        pairs = torch.zeros((B, cap, 2), dtype=torch.int32, device="cuda")
+        cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        m.brute_force_match_batch_dev(td1, tn1, td2, tn2, pairs, cnt, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out[path] = (pairs.cpu().numpy(), cnt.cpu().numpy())
+    assert np.array_equal(out["matrix"][1], out["popcount"][1]) and out["matrix"][1].min() > 1000
+    for b in range(B):
+        k = out["matrix"][1][b]
+        assert np.array_equal(out["matrix"][0][b, :k], out["popcount"][0][b, :k])

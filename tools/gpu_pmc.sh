@@ -13,7 +13,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ou
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/p4 -o p4 -- $cmd > $out/p4.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_MFMA --output-format csv -d $out/p5 -o p5 -- $cmd > $out/p5.log 2>&1
 cd - > /dev/null
-python tools/pmc_summary.py $out --json $out/pmc_traffic.json > $out/summary.txt 2>&1
+python tools/pmc_summary.py $out --json $out/pmc_traffic.json --batch 128 > $out/summary.txt 2>&1
 # keep only the small artefacts
 find $out -name '*.csv' -size +8M -delete
 ls -la $out $out/p1 2>/dev/null | head -40

@@ -56,5 +56,7 @@ if "--json" in sys.argv:
                 d[st] = int(sum(vals) / len(vals) * launches_per_call.get(st, 1))
         if d:
             out[key] = d
+    if "--batch" in sys.argv:
+        out["batch"] = int(sys.argv[sys.argv.index("--batch") + 1])   # frames per launch the passes ran at (bench.py scales by it)
     json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
     print("traffic bytes per stage call:", out)
