@@ -139,19 +139,10 @@ class _window_ctx:
 class projection(_window_ctx):
     """match::projection(lowe_ratio, check_orientation)."""
 
-    NEAR_PATHS = {"matrix": 0, "popcount": 1}   # OVS_NEAR_PATH_MATRIX / OVS_NEAR_PATH_POPCOUNT
-
-    def __init__(self, lowe_ratio=0.6, check_orientation=True, near_path="matrix", **kw):
+    def __init__(self, lowe_ratio=0.6, check_orientation=True, **kw):
         super().__init__(**kw)
         self.lowe_ratio_ = float(lowe_ratio)
         self.check_orientation_ = bool(check_orientation)
-        self.set_near_path(near_path)
-
-    def set_near_path(self, near_path):
-        """Implementation of the all-pairs stage: "matrix" (i8 dot products on the matrix cores, default) or "popcount" (xor / popcount on
-        the vector ALU). Bit-identical results."""
-        _lib.check(self._L.ovs_matcher_set_near_path(self._h, self.NEAR_PATHS[near_path]), "ovs_matcher_set_near_path")
-        self.near_path_ = near_path
 
     def match_frame_and_landmarks(self, gp, frm_keypts, frm_desc, scale_factors, lm_reproj, lm_level, lm_desc, margin=5.0,
                                   frm_stereo_x_right=None, frm_occupied=None, lm_x_right=None, lm_valid=None):
@@ -307,19 +298,10 @@ class area(_window_ctx):
 class bow_tree(_window_ctx):
     """match::bow_tree(lowe_ratio, check_orientation)."""
 
-    NEAR_PATHS = {"matrix": 0, "popcount": 1}   # OVS_NEAR_PATH_MATRIX / OVS_NEAR_PATH_POPCOUNT
-
-    def __init__(self, lowe_ratio=0.6, check_orientation=True, near_path="matrix", **kw):
+    def __init__(self, lowe_ratio=0.6, check_orientation=True, **kw):
         super().__init__(**kw)
         self.lowe_ratio_ = float(lowe_ratio)
         self.check_orientation_ = bool(check_orientation)
-        self.set_near_path(near_path)
-
-    def set_near_path(self, near_path):
-        """Implementation of the all-pairs stage: "matrix" (i8 dot products on the matrix cores, default) or "popcount" (xor / popcount on
-        the vector ALU). Bit-identical results."""
-        _lib.check(self._L.ovs_matcher_set_near_path(self._h, self.NEAR_PATHS[near_path]), "ovs_matcher_set_near_path")
-        self.near_path_ = near_path
 
     def match_frame_and_keyframe(self, kf_keypts, kf_desc, kf_bow_feat_vec, frm_keypts, frm_desc, frm_bow_feat_vec, kf_has_landmark=None):
         """bow_tree::match_frame_and_keyframe(keyfrm, frm, matched_lms_in_frm): returns (num_matches, matched_kf_in_frm) where
@@ -449,19 +431,10 @@ class robust_triangulation(_window_ctx):
     """match::robust(lowe_ratio, check_orientation)::match_for_triangulation (the BoW + epipolar-constraint matcher of
     mapping_module::create_new_landmarks). Separate context class: it runs on the windowed-matcher kernels."""
 
-    NEAR_PATHS = {"matrix": 0, "popcount": 1}   # OVS_NEAR_PATH_MATRIX / OVS_NEAR_PATH_POPCOUNT
-
-    def __init__(self, lowe_ratio=0.6, check_orientation=True, near_path="matrix", **kw):
+    def __init__(self, lowe_ratio=0.6, check_orientation=True, **kw):
         super().__init__(**kw)
         self.lowe_ratio_ = float(lowe_ratio)
         self.check_orientation_ = bool(check_orientation)
-        self.set_near_path(near_path)
-
-    def set_near_path(self, near_path):
-        """Implementation of the all-pairs stage: "matrix" (i8 dot products on the matrix cores, default) or "popcount" (xor / popcount on
-        the vector ALU). Bit-identical results."""
-        _lib.check(self._L.ovs_matcher_set_near_path(self._h, self.NEAR_PATHS[near_path]), "ovs_matcher_set_near_path")
-        self.near_path_ = near_path
 
     def match_for_triangulation(self, kps_1, desc_1, bow_feat_vec_1, bearings_1, kps_2, desc_2, bow_feat_vec_2, bearings_2, E_12, epipole_in_2,
                                 scale_factors, has_lm_1=None, has_lm_2=None, x_right_1=None, x_right_2=None):
