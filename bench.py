@@ -524,7 +524,7 @@ def bench_other_configs(iters=10):
                                         "outliers": int(gr["mono_outlier"].sum()),
                                         "parity": bool(np.allclose(gr["poses"], cr["poses"], rtol=1e-7, atol=1e-8)
                                                        and np.allclose(gr["points"], cr["points"], rtol=1e-7, atol=1e-8)),
-                                        "note": "linearisations on the GPU, landmark elimination + Cholesky of the reduced camera system (<= 300 x 300) on <= 8 host threads"}
+                                        "note": "linearisation, landmark elimination (Schur complement) and back-substitution on the GPU (ovs_ba_graph); only the reduced camera system (<= 300 x 300) crosses PCIe and is Cholesky-solved on the host, once per LM trial"}
     out["note"] = "host entry points (H2D + kernels + D2H per call); CPU oracle single-threaded on the same inputs"
     return out
 
