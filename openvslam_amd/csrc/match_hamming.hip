@@ -187,11 +187,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         return *reinterpret_cast<const uint4*>(t + (size_t)row * 32 + half * 16);
     };
     if (n1 > 0) {
-        uint4 raw = load_rows(0);
-        for (int tile = 0; tile < n_tiles; ++tile) {
+        // The workgroups of a problem run side by side on one XCD and would all ask L2 for the same descriptor lines at the same moment
+        // (each such miss goes out to the fabric: 5x the algorithmic reads were measured): every chunk starts its sweep at a different
+        // tile, so a line is first touched by one workgroup and found in L2 by the others.
+        const int tile_first = (chunk_id * n_tiles) / chunks;
+        uint4 raw = load_rows(tile_first << 5);
+        for (int it = 0; it < n_tiles; ++it) {
+            const int tile = it + tile_first - (it + tile_first >= n_tiles ? n_tiles : 0);
+            const int tile_next = tile + 1 == n_tiles ? 0 : tile + 1;
             const int j0 = tile << 5;
             const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
-            if (tile + 1 < n_tiles) raw = load_rows(j0 + 32);   // next tile's bytes are in flight under this tile's MFMAs
+            if (it + 1 < n_tiles) raw = load_rows(tile_next << 5);   // next tile's bytes are in flight under this tile's MFMAs
             v16i acc[2];
             acc[0] = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             acc[1] = acc[0];
