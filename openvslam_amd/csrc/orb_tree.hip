@@ -14,6 +14,11 @@
 // Tie rule for equal counts (implementation-defined upstream: pointer order): later-created node first = list position
 // ascending, exactly as the oracle defines it.
 //
+// Candidate sweeps (round 2): a node's split point is a function of its bounds alone, so the sweep that MOVES a candidate into a new
+// child can already COUNT it into that child's own children (the next pass's child counts), and the sweep of the last pass can feed
+// "max response per node" directly. One sweep over the candidates per pass plus one at the start (root and root-child counts), instead
+// of two per pass plus four: 1 + P against 2 P + 4 for P passes (P ~ 6-8).
+//
 // One 512-thread workgroup per (level, frame) problem (1024 threads finish one problem sooner, 0.076 vs 0.087 ms per 32 frames, but only two
 // such workgroups fit a CU; at 128 frames per launch 512 threads win, 0.247 vs 0.278 ms); node lists (< 4N+64 records) ping-pong in an L2-resident global
 // scratch, everything else lives in LDS. The kernel is latency-bound by design (a handful of passes over ~10^4
@@ -22,8 +27,22 @@
 
 namespace ovs {
 
-constexpr int kTreeThreads = 512;
+constexpr int kTreeThreadsBatch = 512, kTreeThreadsFew = 1024;   // threads per (level, frame) problem: launches of many / of few problems
+
+// -DOVS_TREE_TIMING: thread 0 of the (level 0, frame 0) workgroup records wall_clock64() (10 ns ticks) at the step boundaries of every
+// pass and prints the intervals at the end (one printf: the intervals themselves stay clean). Measurement aid, off in the product build.
+#ifdef OVS_TREE_TIMING
+#define OVS_TT_DECL long long tt_[64]; int ntt_ = 0;
+#define OVS_TT_MARK() do { if (ntt_ < 62) tt_[ntt_++] = wall_clock64(); } while (0)
+#define OVS_TT_PRINT(n_) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && level_lo == 0) { printf("k_tree n=%u:", (unsigned)(n_)); for (int i_ = 1; i_ < ntt_; ++i_) printf(" %lld", tt_[i_] - tt_[i_ - 1]); printf("\n"); } } while (0)
+#else
+#define OVS_TT_DECL
+#define OVS_TT_MARK() do {} while (0)
+#define OVS_TT_PRINT(n_) do {} while (0)
+#endif
 constexpr uint32_t kNotInS = 0xFFFFFFFFu;
+constexpr int kSweepLoads = 4;      // candidate loads in flight per thread in a sweep
+constexpr int kRankDirect = 1024;   // pool ordering: direct rank counting up to this many nodes, bitonic sort beyond
 
 struct NodeRec {
     uint32_t xb;      // bx | ex << 16
@@ -42,6 +61,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 }
 
 // Exclusive scan of one value per thread over the whole block (two barriers). s_wave: 16 words of LDS.
+template <int kTreeThreads>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave, uint32_t& total) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t incl = wave_incl_scan(v, lane);
@@ -60,13 +80,14 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave
 }
 
 // out[i] = sum_{j<i} in[j] for i < n (in/out in LDS, may alias); returns the total. Contains barriers.
+template <int kTreeThreads>
 __device__ __forceinline__ uint32_t array_excl_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* s_wave) {
     const int ipt = (n + kTreeThreads - 1) / kTreeThreads;
     const int b = threadIdx.x * ipt, e = min(n, b + ipt);
     uint32_t sum = 0;
     for (int i = b; i < e; ++i) sum += in[i];
     uint32_t total;
-    uint32_t run = block_excl_scan(sum, s_wave, total);
+    uint32_t run = block_excl_scan<kTreeThreads>(sum, s_wave, total);
     for (int i = b; i < e; ++i) {
         const uint32_t v = in[i];
         out[i] = run;
@@ -76,6 +97,7 @@ __device__ __forceinline__ uint32_t array_excl_scan(const uint32_t* in, uint32_t
     return total;
 }
 
+template <int kTreeThreads>
 __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restrict__ geo, uint64_t* __restrict__ cand,
                                                       size_t cand_frame_entries, const uint32_t* __restrict__ cand_count,
                                                       NodeRec* __restrict__ nodes, size_t node_frame_entries,
@@ -85,19 +107,22 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
     // ---- LDS carve (all offsets multiples of 16)
     const int NN = 4 * NCmax;
     uint32_t* child_cnt = reinterpret_cast<uint32_t*>(smem);             // [NN] count of child k of current node j at 4j+k
-    uint32_t* cmap = child_cnt + NN;                                      // [NN] new list position of that child
-    unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);   // [NN] aliases child_cnt+cmap (final step)
+    uint32_t* child_nxt = child_cnt + NN;                                 // [NN] the same for the list being built (ping-pong)
+    uint32_t* cmap = child_nxt + NN;                                      // [NN] new list position of that child
     uint32_t* nch = cmap + NN;                                            // [NCmax] non-empty children (0 for leaves)
     uint32_t* keep_pos = nch + NCmax;                                     // [NCmax] new position if the node survives
     uint32_t* base = keep_pos + NCmax;                                    // [NCmax] creation index of the node's first child
     uint32_t* rank = base + NCmax;                                        // [NCmax] processing rank, kNotInS if not split
     uint32_t* tmp = rank + NCmax;                                         // [NCmax] scan scratch
     uint32_t* sidx = tmp + NCmax;                                         // [P2max] node at processing rank r
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(sidx + P2max);   // [P2max]
-    uint32_t* splitxy = reinterpret_cast<uint32_t*>(keys + P2max);        // [NCmax] cx | cy << 16 (valid where nch/rank say)
-    uint32_t* s_wave = splitxy + NCmax;                                   // [16]
-    uint32_t* s_misc = s_wave + 16;                                       // [80]: [0..63] root counts / root pos, [64..] scalars
+    // the sort keys of the sorted phase live in child_nxt: 8 * P2max < 16 * NCmax bytes, and child_nxt is cleared only after step 3
+    uint32_t* nxb = sidx + P2max;                                         // [NCmax] bx | ex << 16 of the current nodes
+    uint32_t* nyb = nxb + NCmax;                                          // [NCmax] by | ey << 16
+    uint32_t* s_wave = nyb + NCmax;                                       // [16]
+    uint32_t* s_misc = s_wave + 16;                                       // [80 + 256]: [0..63] root counts / root pos, [64..] scalars, [80..] root-child counts
 
+    OVS_TT_DECL
+    OVS_TT_MARK();
     const int tid = threadIdx.x;
     const int level = level_lo + (int)blockIdx.x, frame = blockIdx.y;   // the launch covers levels [level_lo, level_lo + gridDim.x)
     const int L = geo->num_levels;
@@ -114,26 +139,48 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
         return;
     }
 
-    // ---- initialize_nodes: root patches, candidates to roots (double division, as upstream's keypt.pt.x / delta_x)
+    // ---- initialize_nodes: root patches, candidates to roots (double division, as upstream's keypt.pt.x / delta_x). The same sweep
+    //      counts every candidate into its root AND into the root's child it falls in (the first pass's child counts).
     const int gx = g.gx, gy = g.gy, nroot = gx * gy;
     const double dx = g.dx, dy = g.dy;
     if (tid < 64) s_misc[tid] = 0;
+    for (int i = tid; i < 256; i += kTreeThreads) s_misc[80 + i] = 0;
+    for (int i = tid; i < NN; i += kTreeThreads) child_cnt[i] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += kTreeThreads) {
-        const uint64_t c = list[i];
-        const float fx = (float)((int)cand_x(c) - kOrbPatchRadius), fy = (float)((int)cand_y(c) - kOrbPatchRadius);
-        uint32_t ix = (uint32_t)((double)fx / dx), iy = (uint32_t)((double)fy / dy);
-        ix = min(ix, (uint32_t)gx - 1u);
-        iy = min(iy, (uint32_t)gy - 1u);
-        const uint32_t r = ix + iy * gx;
-        atomicAdd(&s_misc[r], 1u);
-        list[i] = (c & ~0xFFFFull) | r;
+    // Every candidate sweep works on kSweepLoads candidates per thread at a time, in three separate steps -- all loads, then all LDS
+    // look-ups, then all counter updates and stores -- so that the look-ups of different candidates overlap: written as one loop
+    // they form a chain of dependent LDS round trips per candidate, because no LDS read may move across an LDS atomic.
+    for (uint32_t i0 = tid; i0 < n; i0 += kTreeThreads * kSweepLoads) {
+        uint64_t cc[kSweepLoads];
+        uint32_t key[kSweepLoads];
+#pragma unroll
+        for (int u = 0; u < kSweepLoads; ++u) cc[u] = i0 + u * kTreeThreads < n ? list[i0 + u * kTreeThreads] : 0ull;
+#pragma unroll
+        for (int u = 0; u < kSweepLoads; ++u) {
+            const uint64_t c = cc[u];
+            const uint32_t x = cand_x(c) - kOrbPatchRadius, y = cand_y(c) - kOrbPatchRadius;
+            const float fx = (float)(int)x, fy = (float)(int)y;
+            uint32_t ix = (uint32_t)((double)fx / dx), iy = (uint32_t)((double)fy / dy);
+            ix = min(ix, (uint32_t)gx - 1u);
+            iy = min(iy, (uint32_t)gy - 1u);
+            const uint32_t bx = (uint32_t)(int)(dx * ix), ex = (uint32_t)(int)(dx * (ix + 1)), by = (uint32_t)(int)(dy * iy), ey = (uint32_t)(int)(dy * (iy + 1));
+            const uint32_t cx = bx + ((ex - bx + 1u) >> 1), cy = by + ((ey - by + 1u) >> 1);
+            key[u] = 4 * (ix + iy * gx) + (x >= cx ? 1u : 0u) + (y >= cy ? 2u : 0u);   // root * 4 + child of the root
+        }
+#pragma unroll
+        for (int u = 0; u < kSweepLoads; ++u) {
+            const uint32_t i = i0 + u * kTreeThreads;
+            if (i < n) {
+                atomicAdd(&s_misc[80 + key[u]], 1u);   // the root's own count is the sum of its four child counts
+                list[i] = (cc[u] & ~0xFFFFull) | (key[u] >> 2);   // the root's raw index; the first pass maps it to the list position through s_misc
+            }
+        }
     }
     __syncthreads();
     if (tid == 0) {
         uint32_t pos = 0;
         for (int r = 0; r < nroot; ++r) {
-            const uint32_t cnt = s_misc[r];
+            const uint32_t cnt = s_misc[80 + 4 * r] + s_misc[80 + 4 * r + 1] + s_misc[80 + 4 * r + 2] + s_misc[80 + 4 * r + 3];
             if (cnt) {
                 const int ix = r % gx, iy = r / gx;
                 NodeRec rec;
@@ -142,6 +189,8 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
                 rec.count = cnt;
                 rec.pad = 0;
                 cur[pos] = rec;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) child_cnt[4 * pos + k] = cnt > 1 ? s_misc[80 + 4 * r + k] : 0u;   // leaves carry no child counts
                 s_misc[r] = pos++;
             } else
                 s_misc[r] = 0xFFFFu;
@@ -149,92 +198,111 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
         s_misc[64] = pos;   // list size
     }
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += kTreeThreads) {
-        const uint64_t c = list[i];
-        list[i] = (c & ~0xFFFFull) | s_misc[(uint32_t)c & 0xFFFFu];
-    }
     uint32_t size = s_misc[64];
-    __syncthreads();
+    bool first_pass = true, done_final = false;
+    unsigned long long* best = nullptr;
 
     int phase = 1;
+    OVS_TT_MARK();   // kernel entry -> roots built
     for (int guard = 0; guard < 64; ++guard) {   // upstream's while(true); depth is bounded by log2(image size) << 64
-        const uint32_t prev = size;
-        // ---- 1. split coordinates of every current node; clear child counters
+        // ---- 1. split coordinates and bounds of every current node (its child counts were produced by the previous sweep)
         for (uint32_t j = tid; j < size; j += kTreeThreads) {
             const NodeRec r = cur[j];
-            const uint32_t bx = r.xb & 0xFFFFu, ex = r.xb >> 16, by = r.yb & 0xFFFFu, ey = r.yb >> 16;
-            // divide_node: half = ceil((end - begin) / 2.0)
-            const uint32_t cx = bx + ((ex - bx + 1u) >> 1), cy = by + ((ey - by + 1u) >> 1);
-            splitxy[j] = cx | (cy << 16);
+            nxb[j] = r.xb;
+            nyb[j] = r.yb;
             tmp[j] = r.count > 1 ? 1u : 0u;   // non-leaf flag
-            child_cnt[4 * j + 0] = 0;
-            child_cnt[4 * j + 1] = 0;
-            child_cnt[4 * j + 2] = 0;
-            child_cnt[4 * j + 3] = 0;
-        }
-        __syncthreads();
-        // ---- 2. count candidates per child of every non-leaf node
-        for (uint32_t i = tid; i < n; i += kTreeThreads) {
-            const uint64_t c = list[i];
-            const uint32_t nd = (uint32_t)c & 0xFFFFu;
-            if (tmp[nd]) {
-                const uint32_t s = splitxy[nd];
-                const uint32_t x = cand_x(c) - kOrbPatchRadius, y = cand_y(c) - kOrbPatchRadius;
-                const uint32_t k = (x >= (s & 0xFFFFu) ? 1u : 0u) + (y >= (s >> 16) ? 2u : 0u);
-                atomicAdd(&child_cnt[4 * nd + k], 1u);
-            }
-        }
-        __syncthreads();
-        for (uint32_t j = tid; j < size; j += kTreeThreads)
             nch[j] = (child_cnt[4 * j] != 0) + (child_cnt[4 * j + 1] != 0) + (child_cnt[4 * j + 2] != 0) + (child_cnt[4 * j + 3] != 0);
+        }
         __syncthreads();
+        unsigned long long* const keys = reinterpret_cast<unsigned long long*>(child_nxt);
 
+        OVS_TT_MARK();   // step 1
         // ---- 3. processing order: sidx[r] = node processed r-th, M nodes are split
         uint32_t M;
         if (phase == 1) {
             // all non-leaf nodes in list order
-            M = array_excl_scan(tmp, rank, (int)size, s_wave);   // rank[j] = #non-leaf before j
+            M = array_excl_scan<kTreeThreads>(tmp, rank, (int)size, s_wave);   // rank[j] = #non-leaf before j
             for (uint32_t j = tid; j < size; j += kTreeThreads) {
                 if (tmp[j]) sidx[rank[j]] = j;
                 else rank[j] = kNotInS;
             }
             __syncthreads();
         } else {
-            // sort the pool by (count desc, list position asc); leaves sort to the end
-            uint32_t P2 = 1;
-            while (P2 < size) P2 <<= 1;
-            for (uint32_t j = tid; j < P2; j += kTreeThreads) {
-                unsigned long long key = ~0ull;
-                if (j < size && tmp[j]) key = ((unsigned long long)(0xFFFFFFu - cur[j].count) << 16) | j;
-                keys[j] = key;
-            }
-            __syncthreads();
-            for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1) {
-                for (uint32_t jj = k2 >> 1; jj > 0; jj >>= 1) {
-                    for (uint32_t i = tid; i < P2; i += kTreeThreads) {
-                        const uint32_t ixj = i ^ jj;
-                        if (ixj > i) {
-                            const unsigned long long a = keys[i], b = keys[ixj];
-                            const bool up = (i & k2) == 0;
-                            if (up ? (a > b) : (a < b)) {
-                                keys[i] = b;
-                                keys[ixj] = a;
+            // order the pool by (count desc, list position asc); leaves sort to the end. Keys are unique, so a node's place is the number
+            // of smaller keys. Up to kRankDirect nodes that number is counted directly (every thread streams the key array from LDS,
+            // all lanes reading the same address: two barriers), beyond it a bitonic sort runs (log^2 stages, one barrier each:
+            // 55 barriers at 1024 keys, which was a third of a single frame's quad-tree time).
+            uint32_t npool_cur;
+            if (size <= (uint32_t)kRankDirect) {
+                for (uint32_t j = tid; j < size; j += kTreeThreads)
+                    keys[j] = tmp[j] ? (((unsigned long long)(0xFFFFFFu - cur[j].count) << 16) | j) : ~0ull;
+                npool_cur = array_excl_scan<kTreeThreads>(tmp, rank, (int)size, s_wave);   // rank[] is scratch here; barriers inside publish keys[]
+                for (uint32_t j = tid; j < size; j += kTreeThreads) rank[j] = 0;
+                __syncthreads();
+                // the key array is cut into `parts` slices so that all threads count (size is usually well below the thread count)
+                uint32_t S2 = 1, lg = 0;
+                while (S2 < size) { S2 <<= 1; ++lg; }
+                const uint32_t parts = max(1u, (uint32_t)kTreeThreads >> lg);
+                for (uint32_t w = tid; w < S2 * parts; w += kTreeThreads) {
+                    const uint32_t j = w & (S2 - 1u), part = w >> lg;
+                    if (j >= size || !tmp[j]) continue;
+                    const unsigned long long kj = keys[j];
+                    const uint32_t lo = part * size / parts, hi = (part + 1u) * size / parts;
+                    uint32_t r = 0, i = lo;
+                    for (; i + 8 <= hi; i += 8) {
+                        unsigned long long kk[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) kk[u] = keys[i + u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) r += kk[u] < kj ? 1u : 0u;
+                    }
+                    for (; i < hi; ++i) r += keys[i] < kj ? 1u : 0u;
+                    if (r) atomicAdd(&rank[j], r);
+                }
+                __syncthreads();
+                for (uint32_t j = tid; j < size; j += kTreeThreads) {
+                    if (!tmp[j]) continue;
+                    const uint32_t r = rank[j];
+                    sidx[r] = j;
+                    base[r] = nch[j] - 1u;   // gain of splitting the r-th pool node (nch >= 1 for a non-leaf)
+                }
+            } else {
+                uint32_t P2 = 1;
+                while (P2 < size) P2 <<= 1;
+                for (uint32_t j = tid; j < P2; j += kTreeThreads) {
+                    unsigned long long key = ~0ull;
+                    if (j < size && tmp[j]) key = ((unsigned long long)(0xFFFFFFu - cur[j].count) << 16) | j;
+                    keys[j] = key;
+                }
+                __syncthreads();
+                for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1) {
+                    for (uint32_t jj = k2 >> 1; jj > 0; jj >>= 1) {
+                        for (uint32_t i = tid; i < P2; i += kTreeThreads) {
+                            const uint32_t ixj = i ^ jj;
+                            if (ixj > i) {
+                                const unsigned long long a = keys[i], b = keys[ixj];
+                                const bool up = (i & k2) == 0;
+                                if (up ? (a > b) : (a < b)) {
+                                    keys[i] = b;
+                                    keys[ixj] = a;
+                                }
                             }
                         }
+                        __syncthreads();
                     }
-                    __syncthreads();
+                }
+                // pool size, gains in processing order
+                npool_cur = array_excl_scan<kTreeThreads>(tmp, rank, (int)size, s_wave);   // rank[] reused below
+                for (uint32_t r = tid; r < npool_cur; r += kTreeThreads) {
+                    const uint32_t j = (uint32_t)keys[r] & 0xFFFFu;
+                    sidx[r] = j;
+                    base[r] = nch[j] - 1u;   // gain of splitting the r-th pool node (nch >= 1 for a non-leaf)
                 }
             }
-            // pool size, gains in processing order, first rank at which #nodes reaches N
-            uint32_t npool_cur = array_excl_scan(tmp, rank, (int)size, s_wave);   // rank[] reused below
-            for (uint32_t r = tid; r < npool_cur; r += kTreeThreads) {
-                const uint32_t j = (uint32_t)keys[r] & 0xFFFFu;
-                sidx[r] = j;
-                base[r] = nch[j] - 1u;   // gain of splitting the r-th pool node (nch >= 1 for a non-leaf)
-            }
+            // first rank at which #nodes reaches N
             if (tid == 0) s_misc[65] = npool_cur;   // M candidate (atomicMin below)
             __syncthreads();
-            array_excl_scan(base, base, (int)npool_cur, s_wave);   // base[r] = gain of ranks < r
+            array_excl_scan<kTreeThreads>(base, base, (int)npool_cur, s_wave);   // base[r] = gain of ranks < r
             for (uint32_t r = tid; r < npool_cur; r += kTreeThreads) {
                 const uint32_t after = size + base[r] + (nch[sidx[r]] - 1u);
                 if (after >= N) atomicMin(&s_misc[65], r + 1u);
@@ -247,18 +315,23 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
             __syncthreads();
         }
 
+        OVS_TT_MARK();   // step 3
         // ---- 4. creation index of each split node's first child (processing order), positions of survivors (list order)
         for (uint32_t r = tid; r < M; r += kTreeThreads) tmp[r] = nch[sidx[r]];
+        for (int i = tid; i < NN; i += kTreeThreads) child_nxt[i] = 0;   // the sort keys are dead: next pass's child counts / `best`
         __syncthreads();
-        const uint32_t total_new = array_excl_scan(tmp, tmp, (int)M, s_wave);
+        const uint32_t total_new = array_excl_scan<kTreeThreads>(tmp, tmp, (int)M, s_wave);
         for (uint32_t r = tid; r < M; r += kTreeThreads) base[sidx[r]] = tmp[r];
         __syncthreads();
         for (uint32_t j = tid; j < size; j += kTreeThreads) tmp[j] = (rank[j] == kNotInS) ? 1u : 0u;
         __syncthreads();
-        array_excl_scan(tmp, keep_pos, (int)size, s_wave);
+        array_excl_scan<kTreeThreads>(tmp, keep_pos, (int)size, s_wave);
         const uint32_t new_size = total_new + (size - M);
+        // upstream's stop rules, known before the candidates move: the last pass's sweep feeds find_keypoints_with_max_response directly
+        const bool final_pass = N <= new_size || new_size == size;
 
-        // ---- 5. write the new list; count splittable children (the next pool)
+        OVS_TT_MARK();   // step 4
+        // ---- 5. write the new list; count splittable children (the next pool); a surviving node keeps its child counts
         uint32_t my_pool = 0;
         for (uint32_t j = tid; j < size; j += kTreeThreads) {
             const NodeRec r = cur[j];
@@ -266,10 +339,14 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
                 const uint32_t p = total_new + keep_pos[j];
                 keep_pos[j] = p;
                 nxt[p] = r;
+                if (!final_pass) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) child_nxt[4 * p + k] = child_cnt[4 * j + k];
+                }
             } else {
                 const uint32_t bx = r.xb & 0xFFFFu, ex = r.xb >> 16, by = r.yb & 0xFFFFu, ey = r.yb >> 16;
-                const uint32_t s = splitxy[j];
-                const uint32_t cx = s & 0xFFFFu, cy = s >> 16;
+                // divide_node: half = ceil((end - begin) / 2.0)
+                const uint32_t cx = bx + ((ex - bx + 1u) >> 1), cy = by + ((ey - by + 1u) >> 1);
                 uint32_t c = base[j];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -290,43 +367,109 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
             }
         }
         uint32_t npool_new;
-        block_excl_scan(my_pool, s_wave, npool_new);   // barriers inside: nxt / cmap / keep_pos now visible
+        block_excl_scan<kTreeThreads>(my_pool, s_wave, npool_new);   // barriers inside: nxt / cmap / keep_pos / copied child counts now visible
 
-        // ---- 6. move every candidate to its new node
-        for (uint32_t i = tid; i < n; i += kTreeThreads) {
-            const uint64_t c = list[i];
-            const uint32_t nd = (uint32_t)c & 0xFFFFu;
-            uint32_t p;
-            if (rank[nd] == kNotInS) p = keep_pos[nd];
-            else {
-                const uint32_t s = splitxy[nd];
-                const uint32_t x = cand_x(c) - kOrbPatchRadius, y = cand_y(c) - kOrbPatchRadius;
-                const uint32_t k = (x >= (s & 0xFFFFu) ? 1u : 0u) + (y >= (s >> 16) ? 2u : 0u);
-                p = cmap[4 * nd + k];
+        OVS_TT_MARK();   // step 5
+        // ---- 6. one sweep over the candidates: move each to its new node and count it into that node's own children (the next pass's
+        //         child counts); in the last pass: per-node max (score, first in emission order) instead
+        if (final_pass) best = reinterpret_cast<unsigned long long*>(child_nxt);   // zeroed above, 8 * new_size <= 16 * NCmax bytes
+        const uint32_t ncx_cells = (uint32_t)g.ncx;
+        for (uint32_t i0 = tid; i0 < n; i0 += kTreeThreads * kSweepLoads) {
+            uint64_t cc[kSweepLoads];
+            uint32_t pp[kSweepLoads], gc[kSweepLoads];   // new node; counter of the new node's child the candidate falls in (or ~0)
+#pragma unroll
+            for (int u = 0; u < kSweepLoads; ++u) cc[u] = i0 + u * kTreeThreads < n ? list[i0 + u * kTreeThreads] : 0ull;
+            // look-ups in three rounds of independent LDS reads (node -> rank / survivor position / bounds -> child position / child
+            // count); everything is read unconditionally (in bounds for any node) and selected afterwards
+            uint32_t nd[kSweepLoads], rk[kSweepLoads], kp[kSweepLoads], xb[kSweepLoads], yb[kSweepLoads], ck[kSweepLoads];
+#pragma unroll
+            for (int u = 0; u < kSweepLoads; ++u) {
+                const uint32_t raw = (uint32_t)cc[u] & 0xFFFFu;
+                nd[u] = first_pass ? s_misc[raw & 63u] : raw;
+                if (!(i0 + u * kTreeThreads < n)) nd[u] = 0;
             }
-            list[i] = (c & ~0xFFFFull) | p;
+#pragma unroll
+            for (int u = 0; u < kSweepLoads; ++u) {
+                rk[u] = rank[nd[u]];
+                kp[u] = keep_pos[nd[u]];
+                xb[u] = nxb[nd[u]];
+                yb[u] = nyb[nd[u]];
+            }
+            uint32_t xx[kSweepLoads], yy[kSweepLoads], ccx[kSweepLoads], ccy[kSweepLoads];
+#pragma unroll
+            for (int u = 0; u < kSweepLoads; ++u) {
+                const uint32_t cx = (xb[u] & 0xFFFFu) + (((xb[u] >> 16) - (xb[u] & 0xFFFFu) + 1u) >> 1);
+                const uint32_t cy = (yb[u] & 0xFFFFu) + (((yb[u] >> 16) - (yb[u] & 0xFFFFu) + 1u) >> 1);
+                xx[u] = cand_x(cc[u]) - kOrbPatchRadius;
+                yy[u] = cand_y(cc[u]) - kOrbPatchRadius;
+                const uint32_t k = (xx[u] >= cx ? 1u : 0u) + (yy[u] >= cy ? 2u : 0u);
+                ck[u] = 4 * nd[u] + k;
+                // the chosen child's own split point
+                const uint32_t cbx = (k & 1u) ? cx : (xb[u] & 0xFFFFu), cex = (k & 1u) ? (xb[u] >> 16) : cx;
+                const uint32_t cby = (k & 2u) ? cy : (yb[u] & 0xFFFFu), cey = (k & 2u) ? (yb[u] >> 16) : cy;
+                ccx[u] = cbx + ((cex - cbx + 1u) >> 1);
+                ccy[u] = cby + ((cey - cby + 1u) >> 1);
+            }
+            uint32_t cm[kSweepLoads], cn[kSweepLoads];
+#pragma unroll
+            for (int u = 0; u < kSweepLoads; ++u) {
+                cm[u] = cmap[ck[u]];
+                cn[u] = child_cnt[ck[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < kSweepLoads; ++u) {
+                const bool split = rk[u] != kNotInS && i0 + u * kTreeThreads < n;
+                pp[u] = split ? cm[u] : kp[u];
+                gc[u] = (split && !final_pass && cn[u] > 1u) ? 4 * pp[u] + (xx[u] >= ccx[u] ? 1u : 0u) + (yy[u] >= ccy[u] ? 2u : 0u) : ~0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kSweepLoads; ++u) {
+                const uint32_t i = i0 + u * kTreeThreads;
+                if (i < n) {
+                    const uint64_t c = cc[u];
+                    if (final_pass) {
+                        const unsigned long long key = ((unsigned long long)(cand_score(c) + 1u) << 32) | (0xFFFFFFFFu - cand_order(cand_x(c), cand_y(c), ncx_cells));
+                        __hip_atomic_fetch_max(&best[pp[u]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        if (gc[u] != ~0u) atomicAdd(&child_nxt[gc[u]], 1u);
+                        list[i] = (c & ~0xFFFFull) | pp[u];
+                    }
+                }
+            }
         }
         __syncthreads();
-        NodeRec* t = cur;
-        cur = nxt;
-        nxt = t;
+        {
+            NodeRec* t = cur;
+            cur = nxt;
+            nxt = t;
+            uint32_t* tc = child_cnt;
+            child_cnt = child_nxt;
+            child_nxt = tc;
+        }
+        OVS_TT_MARK();   // step 6 (the sweep)
         size = new_size;
-        // ---- 7. upstream's stop rules
-        if (N <= size || size == prev) break;
+        first_pass = false;
+        if (final_pass) {
+            done_final = true;
+            break;
+        }
         if (phase == 1 && N < size + 3u * npool_new) phase = 2;
     }
 
-    // ---- find_keypoints_with_max_response: per node max (score, first in emission order); output in list order
-    for (uint32_t j = tid; j < size; j += kTreeThreads) best[j] = 0ull;
-    __syncthreads();
+    // ---- find_keypoints_with_max_response; output in list order
     const uint32_t ncx = (uint32_t)g.ncx;
-    for (uint32_t i = tid; i < n; i += kTreeThreads) {
-        const uint64_t c = list[i];
-        const uint32_t x = cand_x(c), y = cand_y(c);
-        const unsigned long long key = ((unsigned long long)(cand_score(c) + 1u) << 32) | (0xFFFFFFFFu - cand_order(x, y, ncx));
-        __hip_atomic_fetch_max(&best[(uint32_t)c & 0xFFFFu], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (!done_final) {   // not reachable (the loop ends through its last pass); kept so that an exhausted guard still yields keypoints
+        best = reinterpret_cast<unsigned long long*>(child_nxt);
+        for (uint32_t j = tid; j < size; j += kTreeThreads) best[j] = 0ull;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += kTreeThreads) {
+            const uint64_t c = list[i];
+            const uint32_t x = cand_x(c), y = cand_y(c);
+            const unsigned long long key = ((unsigned long long)(cand_score(c) + 1u) << 32) | (0xFFFFFFFFu - cand_order(x, y, ncx));
+            __hip_atomic_fetch_max(&best[(uint32_t)c & 0xFFFFu], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const uint32_t kp_cap = (uint32_t)g.kp_cap;
     for (uint32_t j = tid; j < size && j < kp_cap; j += kTreeThreads) {
         const unsigned long long key = best[j];
@@ -336,11 +479,13 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
         const uint32_t x = kDetOrigin + 64u * cj + (ord & 63u), y = kDetOrigin + 64u * ci + ((ord >> 6) & 63u);
         out[j] = cand_pack(x, y, score, 0);
     }
+    OVS_TT_MARK();
+    OVS_TT_PRINT(n);
     if (tid == 0) lvl_count[frame * L + level] = size < kp_cap ? size : kp_cap;
 }
 
 static size_t tree_lds_bytes(int NCmax, int P2max) {
-    return (size_t)(8 * NCmax) * 4 + (size_t)NCmax * 5 * 4 + (size_t)P2max * 4 + (size_t)P2max * 8 + (size_t)NCmax * 4 + 16 * 4 + 80 * 4;
+    return (size_t)(12 * NCmax) * 4 + (size_t)NCmax * 5 * 4 + (size_t)P2max * 4 + (size_t)NCmax * 2 * 4 + 16 * 4 + (80 + 256) * 4;
 }
 
 hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hipStream_t s, int level_lo, int n_levels) {
@@ -352,15 +497,24 @@ hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hip
     int P2max = 1;
     while (P2max < NCmax) P2max <<= 1;
     const size_t lds = tree_lds_bytes(NCmax, P2max);
-    static thread_local size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // A sweep over a level's candidates is bound by one workgroup's instruction latency (two waves per SIMD at 512 threads), not by
+    // memory: with few problems in the launch (a tracker's single frame) 1024 threads halve it; with many, 512 threads let more
+    // problems share a CU and win (0.247 vs 0.278 ms per 128 frames).
+    const bool few = (long long)n_levels * batch <= 64;
+    static thread_local size_t configured[2] = {0, 0};
+    const void* fn = few ? reinterpret_cast<const void*>(k_tree<kTreeThreadsFew>) : reinterpret_cast<const void*>(k_tree<kTreeThreadsBatch>);
+    if (lds > configured[few ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        configured = lds;
+        configured[few ? 1 : 0] = lds;
     }
     dim3 grid(n_levels, batch);
-    hipLaunchKernelGGL(k_tree, grid, dim3(kTreeThreads), lds, s, d.geo, d.cand, d.cand_frame_entries, d.cand_count,
-                       reinterpret_cast<NodeRec*>(d.nodes), d.node_frame_entries, d.lvl_kps, d.lvl_count, NCmax, P2max, level_lo);
+    if (few)
+        hipLaunchKernelGGL(k_tree<kTreeThreadsFew>, grid, dim3(kTreeThreadsFew), lds, s, d.geo, d.cand, d.cand_frame_entries, d.cand_count,
+                           reinterpret_cast<NodeRec*>(d.nodes), d.node_frame_entries, d.lvl_kps, d.lvl_count, NCmax, P2max, level_lo);
+    else
+        hipLaunchKernelGGL(k_tree<kTreeThreadsBatch>, grid, dim3(kTreeThreadsBatch), lds, s, d.geo, d.cand, d.cand_frame_entries, d.cand_count,
+                           reinterpret_cast<NodeRec*>(d.nodes), d.node_frame_entries, d.lvl_kps, d.lvl_count, NCmax, P2max, level_lo);
     return hipGetLastError();
 }
 

@@ -134,6 +134,33 @@ def test_batch_dev_matches_host_api(hip, oracle, pipeline):
         assert np.array_equal(desc[b, :cnt[b]], wd)
 
 
+def test_large_batch_takes_the_many_problem_tree_kernel(hip, oracle):
+    """launch_tree runs 1024-thread workgroups when a launch holds <= 64 (level, frame) problems and 512-thread ones above: 70 small
+    frames put both the level-0 launch and the level-1..7 launch on the 512-thread kernel (every other test here stays below 64)."""
+    import torch
+    rows, cols, B = 240, 320, 70
+    imgs = np.stack([synth_frame(rows, cols, seed=200 + b) for b in range(B)])
+    ex = hip.orb_extractor(hip.orb_params(max_num_keypts=400), max_rows=rows, max_cols=cols, max_batch=B)
+    cap = ex.max_keypoints
+    d_img = torch.from_numpy(imgs).cuda()
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    for split in (True, False):
+        ex.set_fast_split(split)
+        ex.extract_batch_dev(d_img, d_kps, d_desc, d_cnt, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        cnt = d_cnt.cpu().numpy()
+        kps = d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+        desc = d_desc.cpu().numpy()
+        ox = oracle.OrbExtractor(oracle.make_params(400))
+        for b in range(0, B, 3):
+            wk, wd = ox.extract(imgs[b])
+            assert cnt[b] == len(wk)
+            assert np.array_equal(kps[b, :cnt[b]].reshape(-1), wk.view(np.uint8).reshape(-1))
+            assert np.array_equal(desc[b, :cnt[b]], wd)
+
+
 def test_two_extractors_run_concurrently_from_two_threads(hip, oracle):
     """Upstream extracts the left and right image of a stereo frame on two std::threads with two extractor instances: handles are
     independent (own stream, own buffers), so two host threads may call extract() on two handles at the same time."""
@@ -185,3 +212,15 @@ def test_error_statuses(hip):
     m = C.c_void_p()
     assert L.ovs_matcher_create(70000, 100, 1, 0, C.byref(m)) == -1                          # indices are 16 bit
     assert L.ovs_wmatcher_create(60000, 60000, 1 << 20, 0, C.byref(m)) == -4                 # resolver state would not fit LDS
+
+
+def test_more_than_1024_nodes_per_level(hip, oracle):
+    """8000 features at 3840x1920: level 0 asks for ~1740 nodes, above the quad-tree's direct-ranking limit (kRankDirect = 1024 in
+    csrc/orb_tree.hip), so the sorted phase takes its bitonic-sort path; order-exact against the oracle like every other size."""
+    img, ex, ox = _pair(hip, oracle, 1920, 3840, 8000, seed=2)
+    gk, gd = ex.extract(img)
+    wk, wd = ox.extract(img)
+    assert len(gk) == len(wk) and ox.level_num_keypts(0) > 1024
+    for f in ("x", "y", "response", "octave"):
+        assert np.array_equal(gk[f], wk[f]), f
+    assert np.array_equal(gd, wd)
