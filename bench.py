@@ -267,7 +267,7 @@ def main():
 
     ba_res = None if args.no_ba else bench_local_ba(world, rank, dist, torch)
     side = None
-    if rank == 0 and not args.no_ba and not args.no_cpu_baseline:
+    if world == 1 and not args.no_ba and not args.no_cpu_baseline:
         try:
             side = bench_other_configs()
         except Exception as ex:   # a side section must never cost the headline line
@@ -363,7 +363,7 @@ def main():
                 class_lat = {"error": repr(ex_)}
 
         cpu = None
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:   # the CPU baseline is a rank-0, N = 1 section (the scaling runs skip it)
             cpu = cpu_baseline(frames)
 
         out = {
