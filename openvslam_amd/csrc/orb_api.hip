@@ -218,6 +218,7 @@ bool build_geometry(const ovs_orb* h, int rows, int cols, FrameGeo& geo, std::ve
     geo.total_cells = cell_base;
     geo.total_kp_cap = kp_base;
     for (int l = 0; l < OVS_MAX_LEVELS; ++l) geo.cell_base_tab[l] = l < L ? geo.lv[l].cell_base : INT32_MAX;
+    if (tree_lds_bytes_for(geo) > kMaxLdsPerWorkgroup) return false;   // too many keypoints on one level for the quad-tree's LDS arrays
     return true;
 }
 
@@ -420,6 +421,18 @@ ovs_status ovs_orb_create(const ovs_orb_params* params, int32_t max_rows, int32_
     const size_t B = (size_t)max_batch;
     h->d.pyr_frame_bytes = (pyr_bytes + 255) & ~(size_t)255;
     h->d.cand_frame_entries = cand_entries;
+    // The per-level node and keypoint capacities depend on the root grid (round(W / H) x 1 patches, at most 64), i.e. on the ASPECT
+    // RATIO of the image, not on its size: a small elongated image can need more of both than the largest image the handle was created
+    // for (found by tools/fuzz_parity.py: 1664 x 257 on a 2000 x 1300 handle). Size them for the worst grid.
+    {
+        size_t node_worst = 0, kp_worst = 0;
+        for (int l = 0; l < L; ++l) {
+            node_worst += (size_t)2 * 4 * (std::max(geo.lv[l].n_keypts, 64) + 16);
+            kp_worst += (size_t)std::max(geo.lv[l].n_keypts + 3, 4 * 64);
+        }
+        node_entries = std::max(node_entries, node_worst);
+        geo.total_kp_cap = (int)std::max<size_t>((size_t)geo.total_kp_cap, kp_worst);
+    }
     h->d.node_frame_entries = node_entries;
     h->taps_cap = taps.size() + 64;
     h->kps_cap = (size_t)geo.total_kp_cap;

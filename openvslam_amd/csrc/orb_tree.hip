@@ -372,7 +372,14 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
         OVS_TT_MARK();   // step 5
         // ---- 6. one sweep over the candidates: move each to its new node and count it into that node's own children (the next pass's
         //         child counts); in the last pass: per-node max (score, first in emission order) instead
-        if (final_pass) best = reinterpret_cast<unsigned long long*>(child_nxt);   // zeroed above, 8 * new_size <= 16 * NCmax bytes
+        if (final_pass) {
+            // The last pass may end with up to max_nodes = 4 * NCmax nodes (e.g. 36 root patches all split when the level wants 7
+            // keypoints): `best` takes BOTH child-count arrays (2 * NN words = max_nodes 64-bit entries); the current counts were last
+            // read in step 5, behind the barriers of the scan above. (Found by tools/fuzz_parity.py on a 1860 x 136 image.)
+            best = reinterpret_cast<unsigned long long*>(smem);
+            for (uint32_t j = tid; j < new_size; j += kTreeThreads) best[j] = 0ull;
+            __syncthreads();
+        }
         const uint32_t ncx_cells = (uint32_t)g.ncx;
         for (uint32_t i0 = tid; i0 < n; i0 += kTreeThreads * kSweepLoads) {
             uint64_t cc[kSweepLoads];
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
     // ---- find_keypoints_with_max_response; output in list order
     const uint32_t ncx = (uint32_t)g.ncx;
     if (!done_final) {   // not reachable (the loop ends through its last pass); kept so that an exhausted guard still yields keypoints
-        best = reinterpret_cast<unsigned long long*>(child_nxt);
+        best = reinterpret_cast<unsigned long long*>(smem);   // both child-count arrays: max_nodes entries
         for (uint32_t j = tid; j < size; j += kTreeThreads) best[j] = 0ull;
         __syncthreads();
         for (uint32_t i = tid; i < n; i += kTreeThreads) {
@@ -486,6 +493,17 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
 
 static size_t tree_lds_bytes(int NCmax, int P2max) {
     return (size_t)(12 * NCmax) * 4 + (size_t)NCmax * 5 * 4 + (size_t)P2max * 4 + (size_t)NCmax * 2 * 4 + 16 * 4 + (80 + 256) * 4;
+}
+
+// LDS the quad-tree kernel needs for this geometry (its per-node arrays are sized by the largest level); build_geometry refuses
+// parameter sets that exceed the 160 KB a workgroup can have (about 2100 keypoints on ONE level, e.g. 9 600 features over 8 levels)
+size_t tree_lds_bytes_for(const FrameGeo& hgeo) {
+    int NCmax = 0;
+    for (int l = 0; l < hgeo.num_levels; ++l) NCmax = std::max(NCmax, hgeo.lv[l].max_nodes / 4);
+    NCmax = (NCmax + 3) & ~3;
+    int P2max = 1;
+    while (P2max < NCmax) P2max <<= 1;
+    return tree_lds_bytes(NCmax, P2max);
 }
 
 hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hipStream_t s, int level_lo, int n_levels) {

@@ -89,6 +89,8 @@ hipError_t launch_resize(const uint8_t* src, size_t src_frame_stride, int src_pi
 hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
                        const uint8_t* mask, int mask_rows, int batch, hipStream_t s, int cell_lo = 0, int n_cells = -1);
 hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hipStream_t s, int level_lo = 0, int n_levels = -1);
+size_t tree_lds_bytes_for(const FrameGeo& hgeo);
+constexpr size_t kMaxLdsPerWorkgroup = 160 * 1024;
 hipError_t launch_describe(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
                            ovs_keypoint* kps, uint8_t* desc, int32_t* counts, int cap, int batch, hipStream_t s);
 

@@ -184,7 +184,7 @@ class OrbExtractor:
 
     def extract(self, img, mask=None):
         img = np.ascontiguousarray(img, np.uint8)
-        cap = self.params.max_num_keypts + 4 * self.params.num_levels + 64
+        cap = self.params.max_num_keypts + 260 * self.params.num_levels + 64   # a level may return 4 nodes per root patch (<= 64 patches)
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int(0)

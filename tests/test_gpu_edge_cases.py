@@ -152,3 +152,22 @@ def test_refused_geometry_leaves_the_handle_usable(oracle):
     assert np.array_equal(k2.view(np.uint8), wk2.view(np.uint8)) and np.array_equal(d2, wd2)
     k3, d3 = ex.extract(img)
     assert np.array_equal(k3.view(np.uint8), wk.view(np.uint8)) and np.array_equal(d3, wd)
+
+
+def test_elongated_images_more_root_patches_than_keypoints(oracle):
+    """Found by tools/fuzz_parity.py. (i) A small elongated image needs MORE quad-tree node / keypoint capacity than the largest image the
+    handle was created for (capacities depend on the root grid = aspect ratio): 1664 x 257 on a 2000 x 1300 handle used to fail with
+    OVS_ERR_CAPACITY. (ii) With more root patches than requested keypoints a level ends its only pass with 4 nodes per patch (1860 x 136,
+    30 features over 3 levels: 76 / 92 / 144 keypoints), more than the per-node LDS arrays' nominal size: the max-response table must
+    hold max_nodes entries."""
+    from openvslam_amd import feature
+    rng = np.random.default_rng(17)
+    ex = feature.orb_extractor(feature.orb_params(30, 1.5, 3, 29, 15), max_rows=1300, max_cols=2000)
+    ox = oracle.OrbExtractor(oracle.make_params(30, 1.5, 3, 29, 15))
+    for rows, cols in ((136, 1860), (1088, 1860), (257, 1664), (1300, 140), (136, 1860)):
+        img = rng.integers(0, 256, (rows, (cols + 3) & ~3), dtype=np.uint8)[:, :cols]
+        gk, gd = ex.extract(img)
+        wk, wd = ox.extract(np.ascontiguousarray(img))
+        assert len(gk) == len(wk), (rows, cols, len(gk), len(wk))
+        assert (rows, cols) != (136, 1860) or len(wk) > 200   # 4 keypoints per root patch on every level
+        assert np.array_equal(gk.view(np.uint8), wk.view(np.uint8)) and np.array_equal(gd, wd), (rows, cols)

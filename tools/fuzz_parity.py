@@ -1,0 +1,198 @@
+"""Randomised parity campaign (GPU box): HIP path vs the CPU oracle on image sizes, parameters and image statistics the fixed tests do
+not enumerate. Every case is bit-exact or the run fails with the seed that reproduces it.
+
+  python tools/fuzz_parity.py [--cases 120] [--seed 1] [--out gpurun_out/fuzz.txt]
+
+Families: (A) orb_extractor::extract -- rows x cols from 64 to ~1300 x 2000 (odd sizes included, stride = cols rounded to 4), 1..8
+levels, scale factor 1.1..1.5, 30..3000 features, thresholds, image kinds (value noise + rectangles, white noise, low-contrast, flat with a
+few blobs, checkerboard, gradients), rectangle masks; one handle reused over several sizes (geometry rebuild path). (B) brute_force_match --
+random problem sizes, duplicate clusters, ratios, masks on both sides, both implementations of the all-pairs stage. (C) stereo::compute on
+random disparity fields. The oracle is test infrastructure (oracle/): this tool is a test driver, not product code."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from openvslam_amd import feature, match, synth   # noqa: E402
+from oracle import binding as ob                   # noqa: E402
+
+
+def make_image(rng, rows, cols):
+    kind = int(rng.integers(0, 7))
+    if kind == 0:
+        img = synth.synth_frame(rows, cols, seed=int(rng.integers(0, 1 << 30)), n_rect=int(rng.integers(5, 300)))
+    elif kind == 1:
+        img = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+    elif kind == 2:   # low contrast: only the min_fast_thr fallback finds anything
+        img = (118 + rng.integers(0, 14, (rows, cols))).astype(np.uint8)
+    elif kind == 3:   # flat with a few bright / dark blobs: most cells empty
+        img = np.full((rows, cols), int(rng.integers(20, 235)), np.uint8)
+        for _ in range(int(rng.integers(1, 40))):
+            y, x = int(rng.integers(0, rows - 4)), int(rng.integers(0, cols - 4))
+            h, w = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+            img[y:y + h, x:x + w] = int(rng.integers(0, 256))
+    elif kind == 4:   # checkerboard: every block corner is a corner, many equal scores (tie rules)
+        p = int(rng.integers(3, 17))
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        img = (((yy // p + xx // p) & 1) * int(rng.integers(60, 255))).astype(np.uint8)
+    elif kind == 5:   # smooth gradients + sparse noise
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        img = ((xx * 255 // max(cols - 1, 1) + yy * 255 // max(rows - 1, 1)) // 2).astype(np.uint8)
+        m = rng.random((rows, cols)) < 0.01
+        img[m] = rng.integers(0, 256, int(m.sum()), dtype=np.uint8)
+    else:             # saturated regions
+        img = np.clip(rng.normal(128, 90, (rows, cols)), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(img), kind
+
+
+def fuzz_extract(rng, n_cases, log):
+    done = 0
+    while done < n_cases:
+        L = int(rng.integers(1, 9))
+        sf = float(rng.choice([1.1, 1.2, 1.2, 1.2, 1.25, 1.3, 1.5]))
+        nfeat = int(rng.choice([30, 100, 500, 1000, 2000, 3000]))
+        ini = int(rng.integers(8, 41))
+        mn = int(rng.integers(2, ini + 1))
+        max_rows, max_cols = 1300, 2000
+        # the coarsest level must keep a FAST-testable area: min side / sf^(L-1) > 2 * 19 + 7
+        shrink = sf ** (L - 1)
+        lo = int(np.ceil(46 * shrink)) + 2
+        if lo >= 600:
+            continue
+        try:
+            ex = feature.orb_extractor(feature.orb_params(nfeat, sf, L, ini, mn), max_rows=max_rows, max_cols=max_cols)
+        except Exception as e:   # parameter sets the ABI rejects must be rejected by the oracle too
+            log("extract: create rejected (%s) for nfeat=%d sf=%.2f L=%d" % (e, nfeat, sf, L))
+            continue
+        ox = ob.OrbExtractor(ob.make_params(nfeat, sf, L, ini, mn), threads=8)
+        for _ in range(3):   # the same handle across sizes: geometry rebuild
+            rows = int(rng.integers(lo, min(max_rows, 1300) + 1))
+            cols = int(rng.integers(lo, min(max_cols, 2000) + 1))
+            if rng.random() < 0.5:
+                cols = (cols + 3) & ~3
+            buf = np.zeros((rows, (cols + 3) & ~3), np.uint8)
+            img, kind = make_image(rng, rows, cols)
+            buf[:, :cols] = img
+            view = buf[:, :cols]                       # stride = cols rounded up to 4 (the ABI's alignment rule)
+            mask = None
+            if rng.random() < 0.25:
+                mask = np.ones((rows, cols), np.uint8)
+                for _ in range(int(rng.integers(1, 4))):
+                    y0, x0 = int(rng.integers(0, rows)), int(rng.integers(0, cols))
+                    mask[y0:y0 + int(rng.integers(1, rows)), x0:x0 + int(rng.integers(1, cols))] = 0
+            t = time.time()
+            try:
+                gk, gd = ex.extract(view, mask)
+            except Exception as e:
+                # the one documented refusal: more than 64 root patches on some level (border-reduced aspect ratio above 64:1)
+                worst = 0.0
+                for l in range(L):
+                    w_, h_ = round(cols / sf ** l) - 38, round(rows / sf ** l) - 38
+                    if w_ > 6 and h_ > 6:
+                        worst = max(worst, w_ / h_, h_ / w_)
+                log("extract %4dx%-4d L=%d sf=%.2f N=%-4d -> refused (%s), worst root-grid ratio %.1f" % (cols, rows, L, sf, nfeat, e, worst))
+                if worst < 64.4:
+                    return False
+                continue
+            wk, wd = ox.extract(np.ascontiguousarray(img), mask)
+            ok = len(gk) == len(wk) and np.array_equal(gd, wd) and all(
+                np.array_equal(gk[f].view(np.uint32) if gk[f].dtype == np.float32 else gk[f],
+                               wk[f].view(np.uint32) if wk[f].dtype == np.float32 else wk[f])
+                for f in ("x", "y", "size", "angle", "response", "octave", "class_id"))
+            log("extract %4dx%-4d L=%d sf=%.2f N=%-4d thr=%d/%d kind=%d mask=%d -> %4d kp %s (%.1fs)" % (
+                cols, rows, L, sf, nfeat, ini, mn, kind, mask is not None, len(wk), "ok" if ok else "MISMATCH", time.time() - t))
+            if not ok:
+                log("  counts hip %d oracle %d; per level hip %s oracle %s" % (len(gk), len(wk), list(ex.debug_level_counts()),
+                                                                               [ox.level_num_keypts(l) for l in range(L)]))
+                m = min(len(gk), len(wk))
+                for f in ("octave", "x", "y", "response", "angle", "size"):
+                    d = np.nonzero(gk[f][:m] != wk[f][:m])[0]
+                    if len(d):
+                        log("  first %s difference at %d: hip %s oracle %s (octave %d); %d differ" % (f, d[0], gk[f][d[0]], wk[f][d[0]], wk["octave"][d[0]], len(d)))
+                dd = np.nonzero((gd[:m] != wd[:m]).any(1))[0]
+                log("  descriptors differ at %d rows, first %s" % (len(dd), dd[:5]))
+                np.save(os.path.join(ROOT, "gpurun_out", "fuzz_fail_img.npy"), img)
+                return False
+            done += 1
+    return True
+
+
+def fuzz_match(rng, n_cases, log):
+    for case in range(n_cases):
+        n1 = int(rng.choice([1, 7, 31, 33, 64, 255, 500, 1000, 2000, 2047]))
+        n2 = int(rng.choice([1, 5, 32, 65, 256, 257, 700, 1500, 2048]))
+        ratio = float(rng.choice([0.6, 0.75, 0.9, 1.0, 1.01]))
+        d2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+        d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+        n_true = int(rng.integers(0, min(n1, n2) + 1))
+        src, dst = rng.permutation(n2)[:n_true], rng.permutation(n1)[:n_true]
+        for s_, t_ in zip(src, dst):
+            d1[t_] = synth.flip_bits(rng, d2[s_], max_flip=int(rng.integers(0, 70)))
+        if rng.random() < 0.5 and n1 > 8:   # clusters of near-duplicates: claim conflicts, long near lists, overflow fallback
+            k = int(rng.integers(2, min(n1, 200)))
+            for i in range(1, k):
+                d1[i] = synth.flip_bits(rng, d1[0], max_flip=int(rng.integers(0, 6)))
+        v2 = (rng.random(n2) < 0.85).astype(np.uint8) if rng.random() < 0.5 else None
+        v1 = (rng.random(n1) < 0.8).astype(np.uint8) if rng.random() < 0.3 else None
+        want = ob.robust_brute_force_match(d1, d2, v2, ratio, frm_valid=v1)
+        for path in ("matrix", "popcount"):
+            m = match.robust(ratio, False, max_n1=2048, max_n2=2048, near_path=path)
+            got = m.brute_force_match(d1, d2, v2, frm_valid=v1)
+            ok = np.array_equal(got, want)
+            log("match %4d x %-4d ratio %.2f true %4d %-8s -> %4d pairs %s" % (n1, n2, ratio, n_true, path, len(want), "ok" if ok else "MISMATCH"))
+            if not ok:
+                return False
+    return True
+
+
+def fuzz_stereo(rng, n_cases, log):
+    for case in range(n_cases):
+        rows, cols = int(rng.integers(200, 500)), int(rng.integers(400, 1300)) & ~3
+        left, right, _ = synth.synth_stereo_pair(rows, cols, seed=int(rng.integers(0, 1 << 30)), d_min=float(rng.uniform(1, 8)),
+                                                 d_max=float(rng.uniform(20, 90)))
+        nfeat = int(rng.choice([500, 1000, 2000]))
+        fxb = float(rng.uniform(100, 600))
+        el = feature.orb_extractor(feature.orb_params(nfeat), max_rows=rows, max_cols=cols)
+        er = feature.orb_extractor(feature.orb_params(nfeat), max_rows=rows, max_cols=cols)
+        kl, dl = el.extract(left)
+        kr, dr = er.extract(right)
+        xr, dep = match.stereo(el, er, kl, dl, kr, dr, fxb, 0.5372).compute()
+        oxl, oxr = ob.OrbExtractor(ob.make_params(nfeat)), ob.OrbExtractor(ob.make_params(nfeat))
+        wkl, wdl = oxl.extract(left)
+        wkr, wdr = oxr.extract(right)
+        wxr, wdep, _ = ob.stereo_compute(oxl, oxr, wkl, wdl, wkr, wdr, fxb, 0.5372)
+        ok = np.array_equal(xr.view(np.uint32), wxr.view(np.uint32)) and np.array_equal(dep.view(np.uint32), wdep.view(np.uint32))
+        log("stereo %4dx%-4d N=%d -> %4d depths %s" % (cols, rows, nfeat, int((wxr >= 0).sum()), "ok" if ok else "MISMATCH"))
+        if not ok:
+            return False
+    return True
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    lines = []
+
+    def log(s):
+        lines.append(s)
+        print(s, flush=True)
+
+    rng = np.random.default_rng(a.seed)
+    t0 = time.time()
+    ok = fuzz_extract(rng, a.cases, log) and fuzz_match(rng, max(a.cases // 2, 1), log) and fuzz_stereo(rng, max(a.cases // 12, 1), log)
+    log("# seed %d: %s, %d lines, %.0f s" % (a.seed, "ALL BIT-EXACT" if ok else "FAILED", len(lines), time.time() - t0))
+    if a.out:
+        open(a.out, "w").write("\n".join(lines) + "\n")
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
