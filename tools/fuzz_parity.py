@@ -173,6 +173,101 @@ def fuzz_stereo(rng, n_cases, log):
     return True
 
 
+def fuzz_window(rng, n_cases, log):
+    """projection::match_frame_and_landmarks, area::match_in_consistent_area, bow_tree::match_frame_and_keyframe on random geometry."""
+    for case in range(n_cases):
+        rows, cols = int(rng.integers(200, 1400)), int(rng.integers(240, 2600))
+        n, m = int(rng.choice([0, 1, 50, 700, 2000, 4000])), int(rng.choice([0, 1, 30, 500, 3000, 9000]))
+        ratio, margin = float(rng.choice([0.6, 0.8, 0.9, 1.0])), float(rng.choice([3.0, 5.0, 15.0, 40.0]))
+        stereo = bool(rng.random() < 0.4)
+        seed = int(rng.integers(0, 1 << 30))
+        k, d = synth.synth_keypoints(n, rows, cols, seed=seed)
+        lm = synth.synth_landmarks(k, d, m, rows, cols, seed=seed + 1, n_from_frame=min(m, int(1.3 * n)), with_stereo=stereo)
+        sf = np.cumprod(np.concatenate([[1.0], np.full(7, 1.2)]).astype(np.float32)).astype(np.float32)
+        occ = (rng.random(n) < 0.1).astype(np.uint8)
+        xr = None
+        if stereo and n:
+            xr = np.where(rng.random(n) < 0.7, k["x"] - rng.uniform(2, 60, n), -1.0).astype(np.float32)
+        gp, ogp = match.grid_params(cols, rows), ob.grid_params(cols, rows)
+        w = match.projection(ratio, True, max_targets=4096, max_queries=10240)
+        got, gn = w.match_frame_and_landmarks(gp, k, d, sf, lm["xy"], lm["level"], lm["desc"], margin, frm_stereo_x_right=xr, frm_occupied=occ,
+                                              lm_x_right=lm.get("x_right"), lm_valid=lm["valid"])
+        want, wn = ob.projection_match_frame_and_landmarks(ogp, k, d, sf, lm["xy"], lm["level"], lm["desc"], margin, ratio, frm_stereo_x_right=xr,
+                                                           frm_occupied=occ, lm_x_right=lm.get("x_right"), lm_valid=lm["valid"])
+        ok = gn == wn and np.array_equal(got, want)
+        log("projection %4dx%-4d n=%-4d m=%-4d ratio %.1f margin %4.1f stereo %d -> %4d %s" % (cols, rows, n, m, ratio, margin, stereo, wn, "ok" if ok else "MISMATCH"))
+        if not ok:
+            return False
+        # area + bow on two extracted frames of a random size
+        rows2, cols2 = int(rng.integers(200, 700)), int(rng.integers(300, 1000)) & ~3
+        nfeat = int(rng.choice([300, 1000, 2000]))
+        sh = (int(rng.integers(0, 12)), int(rng.integers(0, 8)))
+        a = synth.synth_frame(rows2, cols2, seed=seed & 0xFFFF)
+        b = synth.synth_frame(rows2, cols2, seed=seed & 0xFFFF, shift=sh, noise_seed=7 + (seed & 0xFF))
+        ox = ob.OrbExtractor(ob.make_params(nfeat))
+        ka, da = ox.extract(a)
+        kb, db = ox.extract(b)
+        co = bool(rng.random() < 0.5)
+        mg = float(rng.choice([10, 30, 100, 200]))
+        gp2, ogp2 = match.grid_params(cols2, rows2), ob.grid_params(cols2, rows2)
+        wa = match.area(ratio, co, max_targets=4096, max_queries=4096)
+        pg = np.ascontiguousarray(np.stack([ka["x"], ka["y"]], 1), np.float32)
+        po = pg.copy()
+        gn, got = wa.match_in_consistent_area(gp2, ka, da, kb, db, pg, mg)
+        wn, want = ob.area_match_in_consistent_area(ogp2, ka, da, kb, db, po, mg, ratio, co)
+        ok = gn == wn and np.array_equal(got, want) and np.array_equal(pg.view(np.uint32), po.view(np.uint32))
+        log("area       %4dx%-4d N=%-4d shift %s ratio %.1f margin %3.0f orient %d -> %4d %s" % (cols2, rows2, nfeat, sh, ratio, mg, co, wn, "ok" if ok else "MISMATCH"))
+        if not ok:
+            return False
+        nn = int(rng.choice([20, 120, 600]))
+        fa, fb = synth.synth_bow(da, seed=1, n_nodes=nn), synth.synth_bow(db, seed=1, n_nodes=nn)
+        has_lm = (rng.random(len(ka)) < 0.85).astype(np.uint8)
+        wb = match.bow_tree(ratio, co, max_targets=4096, max_queries=4096)
+        gn, got = wb.match_frame_and_keyframe(ka, da, fa, kb, db, fb, has_lm)
+        wn, want = ob.bow_match_frame_and_keyframe(ka, da, fa, kb, db, fb, ratio, co, has_lm)
+        ok = gn == wn and np.array_equal(got, want)
+        log("bow        %4dx%-4d N=%-4d nodes %3d ratio %.1f orient %d -> %4d %s" % (cols2, rows2, nfeat, nn, ratio, co, wn, "ok" if ok else "MISMATCH"))
+        if not ok:
+            return False
+    return True
+
+
+def fuzz_batch(rng, n_cases, log):
+    """ovs_orb_extract_batch_dev: random batch sizes (both quad-tree kernels), level-0 split on / off, sub-batch pipelines."""
+    import torch
+    for case in range(n_cases):
+        rows, cols = int(rng.integers(100, 500)), int(rng.integers(120, 700)) & ~3
+        B = int(rng.choice([1, 2, 7, 9, 16, 70]))
+        nfeat = int(rng.choice([100, 500, 1500]))
+        L = int(rng.integers(2, 9))
+        if min(rows, cols) / 1.2 ** (L - 1) < 50:
+            continue
+        imgs = np.stack([make_image(rng, rows, cols)[0] for _ in range(B)])
+        ex = feature.orb_extractor(feature.orb_params(nfeat, 1.2, L), max_rows=rows, max_cols=cols, max_batch=B)
+        split, pipe = bool(rng.random() < 0.5), int(rng.integers(1, 4))
+        ex.set_fast_split(split)
+        ex.set_pipeline(pipe)
+        cap = ex.max_keypoints
+        d_img = torch.from_numpy(imgs).cuda()
+        d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+        d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        d_cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        ex.extract_batch_dev(d_img, d_kps, d_desc, d_cnt, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        cnt = d_cnt.cpu().numpy()
+        kps = d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+        desc = d_desc.cpu().numpy()
+        ox = ob.OrbExtractor(ob.make_params(nfeat, 1.2, L), threads=8)
+        ok = True
+        for b in range(0, B, max(1, B // 8)):
+            wk, wd = ox.extract(imgs[b])
+            ok = ok and cnt[b] == len(wk) and np.array_equal(kps[b, :cnt[b]].reshape(-1), wk.view(np.uint8).reshape(-1)) and np.array_equal(desc[b, :cnt[b]], wd)
+        log("batch %4dx%-4d B=%-2d L=%d N=%-4d split %d pipeline %d -> %s" % (cols, rows, B, L, nfeat, split, pipe, "ok" if ok else "MISMATCH"))
+        if not ok:
+            return False
+    return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=120)
@@ -187,7 +282,8 @@ def main():
 
     rng = np.random.default_rng(a.seed)
     t0 = time.time()
-    ok = fuzz_extract(rng, a.cases, log) and fuzz_match(rng, max(a.cases // 2, 1), log) and fuzz_stereo(rng, max(a.cases // 12, 1), log)
+    ok = (fuzz_extract(rng, a.cases, log) and fuzz_match(rng, max(a.cases // 2, 1), log) and fuzz_stereo(rng, max(a.cases // 12, 1), log)
+          and fuzz_window(rng, max(a.cases // 6, 1), log) and fuzz_batch(rng, max(a.cases // 6, 1), log))
     log("# seed %d: %s, %d lines, %.0f s" % (a.seed, "ALL BIT-EXACT" if ok else "FAILED", len(lines), time.time() - t0))
     if a.out:
         open(a.out, "w").write("\n".join(lines) + "\n")
