@@ -301,8 +301,8 @@ def fuzz_optimize(rng, n_cases, log):
             got = ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], mono, d["cam"], st, bf2)
             want = lba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], mono, d["cam"], st, bf2)
             # iteration counts: equal, except that a round which has converged to machine precision may stop an iteration earlier or later
-            # on one side (g2o's stop test compares chi2 changes of ~1e-12 relative) -- then the states must agree to 1e-9
-            close = float(np.abs(got["poses"] - want["poses"]).max()) < 1e-9 and float(np.abs(got["points"] - want["points"]).max()) < 1e-9
+            # on one side (g2o's stop test compares chi2 changes of ~1e-12 relative) -- then the states must still agree to 1e-7
+            close = float(np.abs(got["poses"] - want["poses"]).max()) < 1e-7 and float(np.abs(got["points"] - want["points"]).max()) < 1e-7
             ok = ((np.array_equal(got["info"][4:], want["info"][4:]) or close) and np.allclose(got["info"][:4], want["info"][:4], rtol=1e-6, atol=1e-6)
                   and np.allclose(got["poses"], want["poses"], rtol=1e-6, atol=1e-7) and np.allclose(got["points"], want["points"], rtol=1e-6, atol=1e-7)
                   and all((got[k] != want[k]).sum() <= 1 for k in ("mono_outlier", "stereo_outlier")))
@@ -315,6 +315,63 @@ def fuzz_optimize(rng, n_cases, log):
                                                                                 [int((got[k] != want[k]).sum()) for k in ("mono_outlier", "stereo_outlier")]))
             if not ok:
                 return False
+    return True
+
+
+def fuzz_reprojection(rng, n_cases, log):
+    """projection::match_current_and_last_frames and fuse::replace_duplication: reprojection through both camera models, scale-level
+    prediction (logf), viewing-angle and depth-range gates -- the float decisions of the windowed matchers, on random scenes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_window import _last_and_current
+    from openvslam_amd import _lib
+    for case in range(n_cases):
+        model = int(rng.integers(0, 2))
+        setup = 0 if model == 1 else int(rng.integers(0, 3))
+        rows = int(rng.integers(300, 1100))
+        cols = 2 * rows if model == 1 else int(rng.integers(400, 2000))
+        n = int(rng.choice([50, 600, 2000, 3500]))
+        fz = float(rng.choice([0.0, 0.0, 2.0, -2.0, 0.7]))
+        co = bool(rng.random() < 0.5)
+        seed = int(rng.integers(0, 1 << 30))
+        ck, cd, Tc, lk, lpw, ld, Tl, valid, (fx, fy, cx, cy) = _last_and_current(synth, model, rows, cols, n, seed, fz)
+        cam = _lib.Camera(model, setup, fx, fy, cx, cy, 0.12 * fx, 0.12, cols, rows)
+        ocam = ob.Camera(model, setup, fx, fy, cx, cy, 0.12 * fx, 0.12, cols, rows)
+        gp, ogp = match.grid_params(cols, rows), ob.grid_params(cols, rows)
+        sf = np.cumprod(np.concatenate([[1.0], np.full(7, 1.2)]).astype(np.float32)).astype(np.float32)
+        occ = (rng.random(n) < 0.05).astype(np.uint8)
+        xr = np.where(rng.random(n) < 0.6, ck["x"] - rng.uniform(1, 40, n), -1.0).astype(np.float32) if setup else None
+        margin = float(rng.choice([3.0, 7.0, 15.0, 30.0]))
+        w = match.projection(0.9, co, max_targets=4096, max_queries=8192)
+        got, gn = w.match_current_and_last_frames(cam, gp, ck, cd, Tc, lk, lpw, ld, Tl, sf, margin, curr_stereo_x_right=xr, curr_occupied=occ, last_valid=valid)
+        want, wn = ob.projection_match_current_and_last_frames(ocam, ogp, ck, cd, Tc, lk, lpw, ld, Tl, sf, margin, co, curr_stereo_x_right=xr,
+                                                               curr_occupied=occ, last_valid=valid)
+        ok = gn == wn and np.array_equal(got, want)
+        log("last/current model %d setup %d %4dx%-4d n=%-4d fz %+.1f margin %4.1f orient %d -> %4d %s" % (model, setup, cols, rows, n, fz, margin, co, wn, "ok" if ok else "MISMATCH"))
+        if not ok:
+            return False
+        # fuse::replace_duplication on the same scene
+        m = len(lk)
+        R, t = Tc[:, :3], Tc[:, 3]
+        cc = -R.T @ t
+        v = lpw - cc
+        dist = np.linalg.norm(v, axis=1)
+        ils = (1.0 / (sf * sf)).astype(np.float32)
+        lvl = np.clip(lk["octave"] + rng.integers(0, 2, m), 0, 7)
+        dmax = (dist * sf[lvl] * rng.uniform(0.85, 1.0, m)).astype(np.float32)
+        dmin = (dmax / sf[7] * rng.uniform(0.5, 1.3, m)).astype(np.float32)
+        dmm = np.ascontiguousarray(np.stack([dmin, dmax], 1))
+        nrm = v / dist[:, None]
+        flip = rng.random(m) < 0.15
+        nrm[flip] = rng.normal(0, 1, (int(flip.sum()), 3))
+        xr2 = np.where(rng.random(n) < 0.6, ck["x"] - 0.12 * fx / rng.uniform(2, 20, n), -1.0).astype(np.float32) if setup else None
+        wf = match.fuse(0.6, max_targets=4096, max_queries=8192)
+        lsf = float(np.log(np.float32(1.2)))
+        got, gn = wf.replace_duplication(cam, gp, ck, cd, Tc, lpw, dmm, nrm, ld, sf, ils, lsf, margin, keyfrm_stereo_x_right=xr2, lm_valid=valid)
+        want, wn = ob.fuse_replace_duplication(ocam, ogp, ck, cd, Tc, lpw, dmm, nrm, ld, sf, ils, lsf, margin, kf_stereo_x_right=xr2, lm_valid=valid)
+        ok = gn == wn and np.array_equal(got, want)
+        log("fuse       model %d setup %d %4dx%-4d n=%-4d margin %4.1f -> %4d %s" % (model, setup, cols, rows, n, margin, wn, "ok" if ok else "MISMATCH"))
+        if not ok:
+            return False
     return True
 
 
@@ -334,7 +391,7 @@ def main():
     t0 = time.time()
     ok = (fuzz_extract(rng, a.cases, log) and fuzz_match(rng, max(a.cases // 2, 1), log) and fuzz_stereo(rng, max(a.cases // 12, 1), log)
           and fuzz_window(rng, max(a.cases // 6, 1), log) and fuzz_batch(rng, max(a.cases // 6, 1), log)
-          and fuzz_optimize(rng, max(a.cases // 6, 1), log))
+          and fuzz_optimize(rng, max(a.cases // 6, 1), log) and fuzz_reprojection(rng, max(a.cases // 6, 1), log))
     log("# seed %d: %s, %d lines, %.0f s" % (a.seed, "ALL PASSED (keypoints, descriptors, match pairs, stereo floats bit-exact; optimisers within the stated tolerances)" if ok else "FAILED", len(lines), time.time() - t0))
     if a.out:
         open(a.out, "w").write("\n".join(lines) + "\n")
