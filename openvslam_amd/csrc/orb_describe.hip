@@ -21,6 +21,42 @@ __constant__ int8_t c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
 __constant__ int32_t c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+// ic_angle: per disc row |v| and half (u < 0 / u >= 0), four words of 0/1 mask bytes and four of (u + 16) * mask weight bytes for the
+// sixteen pixels u = -16 .. -1 / 0 .. 15 (from u_max above)
+__constant__ uint32_t c_ic_tab[16 * 2 * 8] = {
+    0x01010100u, 0x01010101u, 0x01010101u, 0x01010101u, 0x03020100u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu,   // |v| = 0, left half
+    0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u, 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x1f1e1d1cu,   // |v| = 0, right half
+    0x01010100u, 0x01010101u, 0x01010101u, 0x01010101u, 0x03020100u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu,   // |v| = 1, left half
+    0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u, 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x1f1e1d1cu,   // |v| = 1, right half
+    0x01010100u, 0x01010101u, 0x01010101u, 0x01010101u, 0x03020100u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu,   // |v| = 2, left half
+    0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u, 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x1f1e1d1cu,   // |v| = 2, right half
+    0x01010100u, 0x01010101u, 0x01010101u, 0x01010101u, 0x03020100u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu,   // |v| = 3, left half
+    0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u, 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x1f1e1d1cu,   // |v| = 3, right half
+    0x01010000u, 0x01010101u, 0x01010101u, 0x01010101u, 0x03020000u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu,   // |v| = 4, left half
+    0x01010101u, 0x01010101u, 0x01010101u, 0x00010101u, 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x001e1d1cu,   // |v| = 4, right half
+    0x01010000u, 0x01010101u, 0x01010101u, 0x01010101u, 0x03020000u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu,   // |v| = 5, left half
+    0x01010101u, 0x01010101u, 0x01010101u, 0x00010101u, 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x001e1d1cu,   // |v| = 5, right half
+    0x01010000u, 0x01010101u, 0x01010101u, 0x01010101u, 0x03020000u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu,   // |v| = 6, left half
+    0x01010101u, 0x01010101u, 0x01010101u, 0x00010101u, 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x001e1d1cu,   // |v| = 6, right half
+    0x01000000u, 0x01010101u, 0x01010101u, 0x01010101u, 0x03000000u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu,   // |v| = 7, left half
+    0x01010101u, 0x01010101u, 0x01010101u, 0x00000101u, 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x00001d1cu,   // |v| = 7, right half
+    0x01000000u, 0x01010101u, 0x01010101u, 0x01010101u, 0x03000000u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu,   // |v| = 8, left half
+    0x01010101u, 0x01010101u, 0x01010101u, 0x00000101u, 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x00001d1cu,   // |v| = 8, right half
+    0x00000000u, 0x01010101u, 0x01010101u, 0x01010101u, 0x00000000u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu,   // |v| = 9, left half
+    0x01010101u, 0x01010101u, 0x01010101u, 0x00000001u, 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x0000001cu,   // |v| = 9, right half
+    0x00000000u, 0x01010100u, 0x01010101u, 0x01010101u, 0x00000000u, 0x07060500u, 0x0b0a0908u, 0x0f0e0d0cu,   // |v| = 10, left half
+    0x01010101u, 0x01010101u, 0x01010101u, 0x00000000u, 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x00000000u,   // |v| = 10, right half
+    0x00000000u, 0x01010000u, 0x01010101u, 0x01010101u, 0x00000000u, 0x07060000u, 0x0b0a0908u, 0x0f0e0d0cu,   // |v| = 11, left half
+    0x01010101u, 0x01010101u, 0x00010101u, 0x00000000u, 0x13121110u, 0x17161514u, 0x001a1918u, 0x00000000u,   // |v| = 11, right half
+    0x00000000u, 0x01000000u, 0x01010101u, 0x01010101u, 0x00000000u, 0x07000000u, 0x0b0a0908u, 0x0f0e0d0cu,   // |v| = 12, left half
+    0x01010101u, 0x01010101u, 0x00000101u, 0x00000000u, 0x13121110u, 0x17161514u, 0x00001918u, 0x00000000u,   // |v| = 12, right half
+    0x00000000u, 0x00000000u, 0x01010101u, 0x01010101u, 0x00000000u, 0x00000000u, 0x0b0a0908u, 0x0f0e0d0cu,   // |v| = 13, left half
+    0x01010101u, 0x01010101u, 0x00000001u, 0x00000000u, 0x13121110u, 0x17161514u, 0x00000018u, 0x00000000u,   // |v| = 13, right half
+    0x00000000u, 0x00000000u, 0x01010000u, 0x01010101u, 0x00000000u, 0x00000000u, 0x0b0a0000u, 0x0f0e0d0cu,   // |v| = 14, left half
+    0x01010101u, 0x00010101u, 0x00000000u, 0x00000000u, 0x13121110u, 0x00161514u, 0x00000000u, 0x00000000u,   // |v| = 14, right half
+    0x00000000u, 0x00000000u, 0x00000000u, 0x01010100u, 0x00000000u, 0x00000000u, 0x00000000u, 0x0f0e0d00u,   // |v| = 15, left half
+    0x01010101u, 0x00000000u, 0x00000000u, 0x00000000u, 0x13121110u, 0x00000000u, 0x00000000u, 0x00000000u,   // |v| = 15, right half
+};
 __constant__ int32_t c_gauss7[7] = {18, 34, 48, 56, 48, 34, 18};   // oracle/ORACLE_SPEC.md rule 10
 constexpr uint32_t kG0123 = 18u | (34u << 8) | (48u << 16) | (56u << 24);
 constexpr uint32_t kG456 = 48u | (34u << 8) | (18u << 16);
@@ -138,22 +174,27 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
 
     // ---- ic_angle: m10 = sum u*I, m01 = sum v*I over the disc |u| <= u_max[|v|], |v| <= 15 (exact integers).
     // Lane 2k / 2k+1 sums the negative / non-negative u of disc row v = k - 15.
+    // Sixteen pixels per lane as four words (v_alignbyte_b32 for the sub-word offset), sums as v_dot4_u32_u8 against 0/1 mask bytes and
+    // (u + 16) * mask weight bytes built from u_max: 4 LDS word reads + 8 dot products instead of 16 byte reads with a compare each.
     int m10 = 0, m01 = 0;
     if (lane < 62) {
         const int v = (lane >> 1) - 15, h = lane & 1;
-        const int um = c_umax[v < 0 ? -v : v];
-        const uint8_t* row = patch + (kPatchR + v) * kPatchPitch + off + kPatchR;
-        int sum = 0;
+        // lane h = 0: u = -16 .. -1 (pixel j <-> u = j - 16, inside the disc iff j >= 16 - u_max); h = 1: u = 0 .. 15 (inside iff j <= u_max)
+        const int first = off + kPatchR + (h ? 0 : -16);                     // byte offset of pixel j = 0 in the row segment (>= 5)
+        const uint32_t* pw = reinterpret_cast<const uint32_t*>(patch + (kPatchR + v) * kPatchPitch + (first & ~3));
+        const int shb = first & 3;
+        const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3], w4 = pw[4];
+        const uint32_t px[4] = {__builtin_amdgcn_alignbyte(w1, w0, shb), __builtin_amdgcn_alignbyte(w2, w1, shb),
+                                __builtin_amdgcn_alignbyte(w3, w2, shb), __builtin_amdgcn_alignbyte(w4, w3, shb)};
+        const uint32_t* tab = c_ic_tab + (((v < 0 ? -v : v) * 2 + h) << 3);
+        uint32_t sum = 0, wsum = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int u = h ? j : -(j + 1);
-            if ((h ? j : j + 1) <= um) {
-                const int val = row[u];
-                m10 += u * val;
-                sum += val;
-            }
+        for (int q = 0; q < 4; ++q) {
+            sum = __builtin_amdgcn_udot4(px[q], tab[q], sum, false);
+            wsum = __builtin_amdgcn_udot4(px[q], tab[4 + q], wsum, false);
         }
-        m01 = v * sum;
+        m10 = (int)wsum - 16 * (int)sum;
+        m01 = v * (int)sum;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

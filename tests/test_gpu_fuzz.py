@@ -1,0 +1,26 @@
+"""A short slice of the randomised parity campaign (tools/fuzz_parity.py) inside the GPU suite: every family once, fixed seeds. The full
+campaign (~20 seeds x 240-360 cases, profiles/r02_fuzz_parity.txt) is run with the tool itself."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.mark.parametrize("seed", [101, 102])
+def test_fuzz_slice(oracle, seed):
+    import fuzz_parity as fz
+    rng = np.random.default_rng(seed)
+    lines = []
+    assert fz.fuzz_extract(rng, 24, lines.append), lines[-8:]
+    assert fz.fuzz_match(rng, 10, lines.append), lines[-4:]
+    assert fz.fuzz_stereo(rng, 2, lines.append), lines[-2:]
+    assert fz.fuzz_window(rng, 3, lines.append), lines[-4:]
+    assert fz.fuzz_batch(rng, 4, lines.append), lines[-2:]
+    assert fz.fuzz_optimize(rng, 4, lines.append), lines[-4:]
+    assert fz.fuzz_reprojection(rng, 3, lines.append), lines[-4:]
+    assert len(lines) > 50
