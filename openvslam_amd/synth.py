@@ -289,3 +289,48 @@ def synth_vocabulary(k=10, depth=4, seed=0, flip=28):
     weight[leaves] = np.where(rng.random(len(leaves)) < 0.03, 0.0, rng.uniform(0.5, 9.0, len(leaves)))
     return dict(child_start=child_start, children=np.asarray(children, np.int32), desc=np.stack(desc), weight=weight, word_id=word_id,
                 depth=depth)
+
+
+def synth_map(n_pose=8, n_pt=600, obs_per_pose=250, seed=0, stereo_frac=0.0, pose_noise=0.02, point_noise=0.02):
+    """A map database (openvslam_amd.io.map_database) holding the synth_local_ba scene: one keyframe per pose whose keypoints are its
+    observations (undistorted = observed position, octave from the information, random descriptors), one landmark per observed point.
+    Returns (db, scene) where scene is the synth_local_ba dict the map was built from."""
+    from . import io
+    from .match import KP_DTYPE
+    d = synth_local_ba(n_pose=n_pose, n_pt=n_pt, obs_per_pose=obs_per_pose, seed=seed, pose_noise=pose_noise, point_noise=point_noise, n_fixed=1)
+    rng = np.random.default_rng(seed + 7)
+    inv = io.inv_level_sigma_sq(1.2, 8)
+    db = io.map_database()
+    db.cameras = {"cam": {"model_type": "Perspective", "setup_type": "Stereo" if stereo_frac > 0 else "Monocular", "color_order": "Gray",
+                          "cols": 1920, "rows": 1080, "fps": 30.0, "fx": d["cam"][0], "fy": d["cam"][1], "cx": d["cam"][2], "cy": d["cam"][3],
+                          "k1": 0.0, "k2": 0.0, "p1": 0.0, "p2": 0.0, "k3": 0.0, "focal_x_baseline": 0.12 * d["cam"][0]}}
+    e = d["edges"]
+    bf = 0.12 * d["cam"][0]
+    from .ba import quat_to_rot
+    for k in range(n_pose):
+        ek = e[e["pose_idx"] == k]
+        n = len(ek)
+        kp = np.zeros(n, KP_DTYPE)
+        kp["x"], kp["y"] = ek["obs_x"], ek["obs_y"]
+        kp["octave"] = [int(np.argmin(np.abs(inv - w))) for w in ek["inv_sigma_sq"]]
+        kp["angle"] = rng.uniform(0, 360, n)
+        kp["class_id"] = -1
+        xr = np.full(n, -1.0, np.float32)
+        dep = np.full(n, -1.0, np.float32)
+        if stereo_frac > 0:
+            z = (d["points_true"][ek["point_idx"]] @ quat_to_rot(d["poses_true"][k, 3:]).T + d["poses_true"][k, :3])[:, 2]
+            st = rng.random(n) < stereo_frac
+            xr[st] = (ek["obs_x"][st] - bf / z[st] + rng.normal(0, 1, int(st.sum()))).astype(np.float32)
+            dep[st] = z[st]
+        db.keyframes[k] = io.keyframe(id=k, src_frm_id=10 * k, ts=0.1 * k, cam="cam", depth_thr=40.0, rot_cw=d["poses"][k, 3:].copy(),
+                                      trans_cw=d["poses"][k, :3].copy(), keypts=kp,
+                                      undists=np.stack([ek["obs_x"], ek["obs_y"]], 1).astype(np.float32), x_rights=xr, depths=dep,
+                                      descs=rng.integers(0, 256, (n, 32), dtype=np.uint8), lm_ids=ek["point_idx"].astype(np.int64),
+                                      span_parent=k - 1, span_children=[k + 1] if k + 1 < n_pose else [], loop_edges=[])
+    seen = np.unique(e["point_idx"])
+    for j in seen:
+        first = int(e["pose_idx"][e["point_idx"] == j].min())
+        db.landmarks[int(j)] = io.landmark(id=int(j), first_keyfrm=first, pos_w=d["points"][j].copy(), ref_keyfrm=first,
+                                           n_vis=int((e["point_idx"] == j).sum()), n_fnd=int((e["point_idx"] == j).sum()))
+    db.frame_next_id, db.keyframe_next_id, db.landmark_next_id = 10 * n_pose, n_pose, int(seen.max()) + 1
+    return db, d

@@ -1,0 +1,87 @@
+"""Map database MessagePack files (openvslam_amd/io.py; SURVEY 8(f) #4 "wire / on-disk formats"). CPU part: the file layout, a write /
+read round trip, the graph local_bundle_adjuster::optimize builds from a loaded map. GPU part: optimising a loaded map through the
+device path equals the oracle on the same arrays."""
+import numpy as np
+import pytest
+
+
+def _db(tmp_path, **kw):
+    from openvslam_amd import io, synth
+    db, d = synth.synth_map(**kw)
+    path = str(tmp_path / "map.msg")
+    io.save_map_database(path, db)
+    return io, db, d, path
+
+
+def test_file_layout(tmp_path):
+    import msgpack
+    io, db, d, path = _db(tmp_path, n_pose=4, n_pt=200, obs_per_pose=60)
+    obj = msgpack.unpackb(open(path, "rb").read(), raw=False, strict_map_key=False)
+    assert set(obj) == {"cameras", "frame_next_id", "keyframe_next_id", "landmark_next_id", "keyframes", "landmarks"}
+    kf = obj["keyframes"]["2"]   # ids are string keys, as nlohmann::json object keys are
+    assert set(kf) == {"src_frm_id", "ts", "cam", "depth_thr", "rot_cw", "trans_cw", "n_keypts", "keypts", "undists", "x_rights", "depths",
+                       "descs", "lm_ids", "n_scale_levels", "scale_factor", "span_parent", "span_children", "loop_edges"}
+    assert kf["n_keypts"] == 60 == len(kf["keypts"]) == len(kf["descs"]) and len(kf["descs"][0]) == 8 and len(kf["rot_cw"]) == 4
+    # a descriptor row is its 32 bytes read as 8 little-endian uint32
+    want = np.frombuffer(db.keyframes[2].descs[5].tobytes(), "<u4")
+    assert kf["descs"][5] == [int(v) for v in want]
+    assert set(obj["landmarks"][str(db.keyframes[2].lm_ids[0])]) == {"1st_keyfrm", "pos_w", "ref_keyfrm", "n_vis", "n_fnd"}
+
+
+@pytest.mark.parametrize("stereo_frac", [0.0, 0.4])
+def test_round_trip_and_local_ba_graph(tmp_path, stereo_frac):
+    io, db, d, path = _db(tmp_path, n_pose=6, n_pt=500, obs_per_pose=200, seed=3, stereo_frac=stereo_frac)
+    back = io.load_map_database(path)
+    assert sorted(back.keyframes) == sorted(db.keyframes) and sorted(back.landmarks) == sorted(db.landmarks)
+    for k in db.keyframes:
+        a, b = db.keyframes[k], back.keyframes[k]
+        assert np.array_equal(a.descs, b.descs) and np.array_equal(a.lm_ids, b.lm_ids) and np.array_equal(a.rot_cw, b.rot_cw)
+        assert np.array_equal(a.keypts["x"], b.keypts["x"]) and np.array_equal(a.keypts["octave"], b.keypts["octave"])
+        assert np.array_equal(a.x_rights, b.x_rights) and np.array_equal(a.undists, b.undists) and a.span_children == b.span_children
+    for l in db.landmarks:
+        assert np.array_equal(db.landmarks[l].pos_w, back.landmarks[l].pos_w) and db.landmarks[l].first_keyfrm == back.landmarks[l].first_keyfrm
+    # the graph of the last keyframe: every keyframe is local or fixed, every observation of a local landmark is one edge
+    cur = max(back.keyframes)
+    prob = io.local_ba_problem(back, cur)
+    assert prob["keyfrm_ids"][0] == cur and len(set(prob["keyfrm_ids"])) == len(prob["keyfrm_ids"])
+    assert prob["pose_fixed"][prob["n_local"]:].all() and prob["pose_fixed"][prob["keyfrm_ids"].index(0)] == 1
+    e = d["edges"]
+    local_lms = set(prob["lm_ids"])
+    n_edges = sum(1 for j in e["point_idx"] if int(j) in local_lms)
+    assert len(prob["mono"]) + len(prob["stereo"]) == n_edges
+    assert (len(prob["stereo"]) > 0) == (stereo_frac > 0)
+    # an edge carries the keypoint's undistorted position and its level's information
+    m = prob["mono"][0]
+    kid, lid = prob["keyfrm_ids"][m["pose_idx"]], prob["lm_ids"][m["point_idx"]]
+    kf = back.keyframes[kid]
+    idx = int(np.nonzero(kf.lm_ids == lid)[0][0])
+    assert m["obs_x"] == float(kf.undists[idx, 0]) and m["inv_sigma_sq"] == io.inv_level_sigma_sq(1.2, 8)[kf.keypts["octave"][idx]]
+
+
+def test_rejects_other_files(tmp_path):
+    import msgpack
+    from openvslam_amd import io
+    p = str(tmp_path / "x.msg")
+    open(p, "wb").write(msgpack.packb({"hello": 1}))
+    with pytest.raises(ValueError):
+        io.load_map_database(p)
+    io2, db, d, path = _db(tmp_path, n_pose=3, n_pt=100, obs_per_pose=30)
+    obj = msgpack.unpackb(open(path, "rb").read(), raw=False, strict_map_key=False)
+    obj["keyframes"]["1"]["descs"].pop()
+    open(p, "wb").write(msgpack.packb(obj))
+    with pytest.raises(ValueError):
+        io.load_map_database(p)
+
+
+@pytest.mark.gpu
+def test_optimize_a_loaded_map(tmp_path, oracle):
+    from oracle import lba
+    from openvslam_amd import ba
+    io, db, d, path = _db(tmp_path, n_pose=8, n_pt=900, obs_per_pose=300, seed=5, stereo_frac=0.3, pose_noise=0.03, point_noise=0.03)
+    prob = io.local_ba_problem(io.load_map_database(path), 7)
+    args = (prob["poses"], prob["pose_fixed"], prob["points"], prob["mono"], prob["cam"], prob["stereo"], prob["focal_x_baseline"])
+    got = ba.local_ba_optimize(*args, setup_type=prob["setup_type"])
+    want = lba.local_ba_optimize(*args, setup_type=prob["setup_type"])
+    assert np.array_equal(got["info"][4:], want["info"][4:])
+    assert np.allclose(got["poses"], want["poses"], rtol=1e-7, atol=1e-8) and np.allclose(got["points"], want["points"], rtol=1e-7, atol=1e-8)
+    assert got["info"][1] < 0.2 * got["info"][0]   # the perturbed map was actually optimised
