@@ -23,4 +23,5 @@ def test_fuzz_slice(oracle, seed):
     assert fz.fuzz_batch(rng, 4, lines.append), lines[-2:]
     assert fz.fuzz_optimize(rng, 4, lines.append), lines[-4:]
     assert fz.fuzz_reprojection(rng, 3, lines.append), lines[-4:]
+    assert fz.fuzz_sim3(rng, 2, lines.append), lines[-4:]
     assert len(lines) > 50

@@ -375,6 +375,39 @@ def fuzz_reprojection(rng, n_cases, log):
     return True
 
 
+def fuzz_sim3(rng, n_cases, log):
+    """fuse::detect_duplication and projection::match_by_Sim3_transform: Sim3 pose decomposition, viewing-angle / range gates."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_window import _sim3_scene
+    from openvslam_amd import _lib
+    for case in range(n_cases):
+        model = int(rng.integers(0, 2))
+        seed = int(rng.integers(0, 1 << 30))
+        scale = float(rng.choice([0.4, 0.6, 1.0, 1.7, 3.0]))
+        margin = float(rng.choice([3.0, 5.0, 10.0, 20.0]))
+        rows, cols, n, ck, cd, S, lpw, dmm, nrm, ld, valid, sf, (fx, fy, cx, cy) = _sim3_scene(synth, model, seed, scale=scale)
+        cam = _lib.Camera(model, 0, fx, fy, cx, cy, 0.0, 0.0, cols, rows)
+        ocam = ob.Camera(model, 0, fx, fy, cx, cy, 0.0, 0.0, cols, rows)
+        gp, ogp = match.grid_params(cols, rows), ob.grid_params(cols, rows)
+        lsf = float(np.log(np.float32(1.2)))
+        wf = match.fuse(0.6, max_targets=4096, max_queries=8192)
+        got, gn = wf.detect_duplication(cam, gp, ck, cd, S, lpw, dmm, nrm, ld, sf, lsf, margin, lm_valid=valid)
+        want, wn = ob.fuse_detect_duplication(ocam, ogp, ck, cd, S, lpw, dmm, nrm, ld, sf, lsf, margin, lm_valid=valid)
+        ok = gn == wn and np.array_equal(got, want)
+        log("detect_duplication model %d scale %.1f margin %4.1f -> %4d %s" % (model, scale, margin, wn, "ok" if ok else "MISMATCH"))
+        if not ok:
+            return False
+        occ = (rng.random(n) < 0.1).astype(np.uint8)
+        wp = match.projection(0.9, False, max_targets=4096, max_queries=8192, max_entries=1 << 20)
+        got, gn = wp.match_by_Sim3_transform(cam, gp, ck, cd, S, lpw, dmm, nrm, ld, sf, lsf, margin, keyfrm_occupied=occ, lm_valid=valid)
+        want, wn = ob.projection_match_by_sim3_transform(ocam, ogp, ck, cd, S, lpw, dmm, nrm, ld, sf, lsf, margin, kf_occupied=occ, lm_valid=valid)
+        ok = gn == wn and np.array_equal(got, want)
+        log("match_by_Sim3      model %d scale %.1f margin %4.1f -> %4d %s" % (model, scale, margin, wn, "ok" if ok else "MISMATCH"))
+        if not ok:
+            return False
+    return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=120)
@@ -391,7 +424,8 @@ def main():
     t0 = time.time()
     ok = (fuzz_extract(rng, a.cases, log) and fuzz_match(rng, max(a.cases // 2, 1), log) and fuzz_stereo(rng, max(a.cases // 12, 1), log)
           and fuzz_window(rng, max(a.cases // 6, 1), log) and fuzz_batch(rng, max(a.cases // 6, 1), log)
-          and fuzz_optimize(rng, max(a.cases // 6, 1), log) and fuzz_reprojection(rng, max(a.cases // 6, 1), log))
+          and fuzz_optimize(rng, max(a.cases // 6, 1), log) and fuzz_reprojection(rng, max(a.cases // 6, 1), log)
+          and fuzz_sim3(rng, max(a.cases // 12, 1), log))
     log("# seed %d: %s, %d lines, %.0f s" % (a.seed, "ALL PASSED (keypoints, descriptors, match pairs, stereo floats bit-exact; optimisers within the stated tolerances)" if ok else "FAILED", len(lines), time.time() - t0))
     if a.out:
         open(a.out, "w").write("\n".join(lines) + "\n")
