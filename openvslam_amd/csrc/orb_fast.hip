@@ -245,6 +245,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint8_t* const sbytes = reinterpret_cast<uint8_t*>(smap_flat);
     __syncthreads();
 
+    // candidate-mask layout: pair j (pixels c0 + 2j, c0 + 2j + 1) of row row0 -> bits j and 16 + j; of row row0 + 1 -> bits 4 + j and
+    // 20 + j. Where the level border clips the testable area (workgroup-uniform, ~9 % of the cells) the pixels outside are masked. The
+    // empty asm keeps this a real branch: hipcc otherwise hoists the block out of the loop below AND evaluates it speculatively for
+    // every cell (~60 VALU per thread, a tenth of the kernel's instructions -- found in the ISA, round 2).
+    uint32_t valid = ~0u;
+    if (iw < kCellSize || ih < kCellSize) {
+        asm volatile("" ::: "memory");
+        valid = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = c0 + 2 * j;
+            const uint32_t colm = (x < iw ? 1u : 0u) | (x + 1 < iw ? 0x10000u : 0u);
+            valid |= (row0 < ih ? colm : 0u) << j;
+            valid |= (row0 + 1 < ih ? colm : 0u) << (4 + j);
+        }
+    }
+
     int thr = geo->ini_thr;
     for (;;) {
         // ---- 1. diameter test on packed pairs -> candidate mask. It reads this part of the thread's 8x5-word window (re-read in the rare
@@ -272,19 +289,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             cmask |= diameter_test_pair<2, 1>(w, thrv) & 0x00200020u;
             cmask |= diameter_test_pair<4, 1>(w, thrv) & 0x00400040u;
             cmask |= diameter_test_pair<6, 1>(w, thrv) & 0x00800080u;
-            // candidate-mask layout: pair j (pixels c0 + 2j, c0 + 2j + 1) of row row0 -> bits j and 16 + j; of row row0 + 1 -> bits 4 + j
-            // and 20 + j. Testable area clipped by the level border (workgroup-uniform, rare): mask the pixels outside.
-            if (iw < kCellSize || ih < kCellSize) {
-                uint32_t valid = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int x = c0 + 2 * j;
-                    const uint32_t colm = (x < iw ? 1u : 0u) | (x + 1 < iw ? 0x10000u : 0u);
-                    valid |= (row0 < ih ? colm : 0u) << j;
-                    valid |= (row0 + 1 < ih ? colm : 0u) << (4 + j);
-                }
-                cmask &= valid;
-            }
+            cmask &= valid;
         }
         // ---- 2. compact the wave's candidates into its own list segment (order is irrelevant; no workgroup barrier needed: a wave's LDS
         //         operations complete in order, and the wave is the only reader of its segment)
