@@ -37,7 +37,7 @@ if "--json" in sys.argv:
     launches_per_call = {"pyramid": 7}
     out = {}
     for k, st in stage_of.items():
-        kk = [n for n in acc if k in n]
+        kk = [n for n in acc if n.replace("void ", "").split("<")[0].strip() == k]   # exact kernel (k_hamming_near, not k_hamming_near_popc)
         if not kk:
             continue
         f = sum(sum(acc[n].get("FETCH_SIZE", [])) for n in kk)
@@ -50,7 +50,7 @@ if "--json" in sys.argv:
     for cname, key in (("SQ_INSTS_VALU", "insts_valu"), ("SQ_INSTS_SALU", "insts_salu")):
         d = {}
         for k, st in stage_of.items():
-            kk = [n for n in acc if k in n]
+            kk = [n for n in acc if n.replace("void ", "").split("<")[0].strip() == k]
             vals = [v for n in kk for v in acc[n].get(cname, [])]
             if vals:
                 d[st] = int(sum(vals) / len(vals) * launches_per_call.get(st, 1))
