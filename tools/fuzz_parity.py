@@ -50,7 +50,7 @@ def make_image(rng, rows, cols):
     return np.ascontiguousarray(img), kind
 
 
-def fuzz_extract(rng, n_cases, log):
+def fuzz_extract(rng, n_cases, log, max_rows=1300, max_cols=2000):
     done = 0
     while done < n_cases:
         L = int(rng.integers(1, 9))
@@ -58,7 +58,6 @@ def fuzz_extract(rng, n_cases, log):
         nfeat = int(rng.choice([30, 100, 500, 1000, 2000, 3000]))
         ini = int(rng.integers(8, 41))
         mn = int(rng.integers(2, ini + 1))
-        max_rows, max_cols = 1300, 2000
         # the coarsest level must keep a FAST-testable area: min side / sf^(L-1) > 2 * 19 + 7
         shrink = sf ** (L - 1)
         lo = int(np.ceil(46 * shrink)) + 2
@@ -71,8 +70,8 @@ def fuzz_extract(rng, n_cases, log):
             continue
         ox = ob.OrbExtractor(ob.make_params(nfeat, sf, L, ini, mn), threads=8)
         for _ in range(3):   # the same handle across sizes: geometry rebuild
-            rows = int(rng.integers(lo, min(max_rows, 1300) + 1))
-            cols = int(rng.integers(lo, min(max_cols, 2000) + 1))
+            rows = int(rng.integers(lo, max_rows + 1))
+            cols = int(rng.integers(lo, max_cols + 1))
             if rng.random() < 0.5:
                 cols = (cols + 3) & ~3
             buf = np.zeros((rows, (cols + 3) & ~3), np.uint8)
@@ -413,6 +412,7 @@ def main():
     ap.add_argument("--cases", type=int, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--big", type=int, default=0, help="only family A, this many cases, image sizes up to 2200 x 3900")
     a = ap.parse_args()
     lines = []
 
@@ -422,6 +422,12 @@ def main():
 
     rng = np.random.default_rng(a.seed)
     t0 = time.time()
+    if a.big:
+        ok = fuzz_extract(rng, a.big, log, max_rows=2200, max_cols=3900)
+        log("# seed %d (big images): %s, %d lines, %.0f s" % (a.seed, "ALL BIT-EXACT" if ok else "FAILED", len(lines), time.time() - t0))
+        if a.out:
+            open(a.out, "w").write("\n".join(lines) + "\n")
+        sys.exit(0 if ok else 1)
     ok = (fuzz_extract(rng, a.cases, log) and fuzz_match(rng, max(a.cases // 2, 1), log) and fuzz_stereo(rng, max(a.cases // 12, 1), log)
           and fuzz_window(rng, max(a.cases // 6, 1), log) and fuzz_batch(rng, max(a.cases // 6, 1), log)
           and fuzz_optimize(rng, max(a.cases // 6, 1), log) and fuzz_reprojection(rng, max(a.cases // 6, 1), log)
