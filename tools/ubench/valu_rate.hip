@@ -77,6 +77,37 @@ KERNELR(r_max_i16, BODY8R2, "v_max_i16")
 KERNELR(r_min_u16, BODY8R2, "v_min_u16")
 KERNELR(r_and_or, BODY8R3, "v_and_or_b32")
 KERNELR(r_fma_f32, BODY8R3, "v_fma_f32")
+// round 2: the rest of the VOP2 / VOP3 integer vocabulary of the kernels (which forms issue at the fast rate?)
+KERNELR(r_and, BODY8R2, "v_and_b32")
+KERNELR(r_or, BODY8R2, "v_or_b32")
+KERNELR(r_sub_u32, BODY8R2, "v_sub_u32")
+KERNELR(r_lshlrev, BODY8R2, "v_lshlrev_b32")
+KERNELR(r_lshrrev, BODY8R2, "v_lshrrev_b32")
+KERNELR(r_max_u32, BODY8R2, "v_max_u32")
+KERNELR(r_min_i32, BODY8R2, "v_min_i32")
+KERNELR(r_mul_u32_u24, BODY8R2, "v_mul_u32_u24")
+KERNELR(r_mul_hi_u32_u24, BODY8R2, "v_mul_hi_u32_u24")
+KERNELR(r_mul_lo_u16, BODY8R2, "v_mul_lo_u16")
+KERNELR(r_add_u16, BODY8R2, "v_add_u16")
+KERNELR(r_sub_u16, BODY8R2, "v_sub_u16")
+KERNELR(r_lshlrev_b16, BODY8R2, "v_lshlrev_b16")
+KERNELR(r_ashrrev_i16, BODY8R2, "v_ashrrev_i16")
+KERNELR(r_max_u16, BODY8R2, "v_max_u16")
+KERNELR(r_bfe_u32, BODY8R3, "v_bfe_u32")
+KERNELR(r_alignbit, BODY8R3, "v_alignbit_b32")
+KERNELR(r_alignbyte, BODY8R3, "v_alignbyte_b32")
+KERNELR(r_mad_u16, BODY8R3, "v_mad_u16")
+KERNELR(r_mad_i32_i24, BODY8R3, "v_mad_i32_i24")
+KERNELR(r_lshl_add, BODY8R3, "v_lshl_add_u32")
+KERNELR(r_or3, BODY8R3, "v_or3_b32")
+KERNELR(r_dot4_u32_u8, BODY8R3, "v_dot4_u32_u8")
+KERNELR(r_dot2_u32_u16, BODY8R3, "v_dot2_u32_u16")
+KERNELR(r_bfi, BODY8R3, "v_bfi_b32")
+KERNELR(r_min3_u16, BODY8R3, "v_min3_u16")
+KERNELR(r_med3_i32, BODY8R3, "v_med3_i32")
+KERNELR(r_cndmask, BODY8R2, "v_cndmask_b32")
+KERNELR(r_pk_sub_i16, BODY8R2, "v_pk_sub_i16")
+KERNELR(r_pk_lshrrev_b16, BODY8R2, "v_pk_lshrrev_b16")
 
 KERNEL(k_pk_max_i16, I_PK_MAX_I16)
 KERNEL(k_pk_min_u16, I_PK_MIN_U16)
@@ -197,5 +228,9 @@ int main() {
     RUN(r_min_u16)
     RUN(r_fma_f32)
     RUN(k_mad_u32_u24)
+    RUN(r_and) RUN(r_or) RUN(r_sub_u32) RUN(r_lshlrev) RUN(r_lshrrev) RUN(r_max_u32) RUN(r_min_i32) RUN(r_mul_u32_u24) RUN(r_mul_hi_u32_u24)
+    RUN(r_mul_lo_u16) RUN(r_add_u16) RUN(r_sub_u16) RUN(r_lshlrev_b16) RUN(r_ashrrev_i16) RUN(r_max_u16) RUN(r_bfe_u32) RUN(r_alignbit)
+    RUN(r_alignbyte) RUN(r_mad_u16) RUN(r_mad_i32_i24) RUN(r_lshl_add) RUN(r_or3) RUN(r_dot4_u32_u8) RUN(r_dot2_u32_u16) RUN(r_bfi)
+    RUN(r_min3_u16) RUN(r_med3_i32) RUN(r_cndmask) RUN(r_pk_sub_i16) RUN(r_pk_lshrrev_b16)
     return 0;
 }
