@@ -350,7 +350,7 @@ def main():
                                              "peak": round(simd_hz / 4.2, 1), "frac": round(valu_counts["fast"] / fast_s / (simd_hz / 4.2), 4),
                                              "launch_ms_alone": round(fast_s * 1e3, 5), "insts_valu_per_launch": valu_counts["fast"],
                                              "insts_source": "profiles/pmc_traffic.json (SQ_INSTS_VALU pass)",
-                                             "floor_model": "packed 16-bit / 3-operand ops issue one wave-instruction per 4.2 cycles"}
+                                             "floor_model": "packed 16-bit / 3-operand ops issue one wave-instruction per 4.2 cycles; an upper bound on the issue-slot use since round 2: about a sixth of the instructions are 16-bit VOP2 min / max that issue in 2.3 cycles"}
         # ---- per-call latency of orb_extractor::extract through the C++ class boundary at THIS config's size, H2D / D2H
         # included (openvslam_amd/cpp/bench_shim; one call = one upload, one kernel chain, one D2H, one wait)
         class_lat = None
