@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "openvslam/data/bow_vocabulary.h"
+#include "openvslam/io/map_database_io.h"
 #include "openvslam/match/robust.h"
 #include "openvslam/optimize/local_bundle_adjuster.h"
 
@@ -202,9 +203,43 @@ int run_bow(const char* vocab_path, const char* desc_path, const char* out) {
     std::printf("bow shim ok: %d features, %zu words, %zu nodes\n", n, v1.size(), f1.size());
     return 0;
 }
+
+// io::map_database_io::load_message_pack: `mapinfo` prints what was read (no device needed); `map` runs local_bundle_adjuster::optimize on
+// keyframe `curr` of the loaded map and dumps every keyframe pose (16 doubles, ascending id) and landmark position (ascending id)
+int run_mapinfo(const char* in) {
+    const io::loaded_map m = io::map_database_io::load_message_pack(in);
+    size_t n_obs = 0, n_kp = 0, n_cov = 0;
+    unsigned long long desc_sum = 0;
+    for (const auto& kf : m.keyframes) {
+        n_kp += kf.second->num_keypts_;
+        n_cov += kf.second->graph_node_->covisibilities_.size();
+        for (int r = 0; r < kf.second->descriptors_.rows; ++r)
+            for (int c = 0; c < 32; ++c) desc_sum += (unsigned long long)kf.second->descriptors_.ptr(r)[c] * (unsigned)(c + 1);
+    }
+    for (const auto& lm : m.landmarks) n_obs += lm.second->num_observations();
+    std::printf("map: %zu cameras, %zu keyframes, %zu landmarks, %zu keypoints, %zu observations, %zu covisibility links, descriptor checksum %llu\n",
+                m.cameras.size(), m.keyframes.size(), m.landmarks.size(), n_kp, n_obs, n_cov, desc_sum);
+    return 0;
+}
+
+int run_map(const char* in, const char* curr_id, const char* out) {
+    io::loaded_map m = io::map_database_io::load_message_pack(in);
+    data::keyframe* curr = m.keyframes.at((unsigned int)std::atoi(curr_id)).get();
+    bool stop = false;
+    optimize::local_bundle_adjuster(5, 10).optimize(curr, &stop);
+    FILE* f = std::fopen(out, "wb");
+    for (const auto& kf : m.keyframes) std::fwrite(kf.second->cam_pose_cw_.m, sizeof(double), 16, f);
+    for (const auto& lm : m.landmarks) std::fwrite(lm.second->pos_w_.v, sizeof(double), 3, f);
+    std::fclose(f);
+    std::printf("map lba ok: %zu keyframes, %zu landmarks, current keyframe %u with %zu covisibilities\n", m.keyframes.size(), m.landmarks.size(),
+                curr->id_, curr->graph_node_->covisibilities_.size());
+    return 0;
+}
 }   // namespace
 
 int main(int argc, char** argv) {
+    if (argc == 3 && std::string(argv[1]) == "mapinfo") return run_mapinfo(argv[2]);
+    if (argc == 5 && std::string(argv[1]) == "map") return run_map(argv[2], argv[3], argv[4]);
     if (argc == 5 && std::string(argv[1]) == "bow") return run_bow(argv[2], argv[3], argv[4]);
     if (argc != 4) return 2;
     if (std::string(argv[1]) == "lba") return run_lba(argv[2], argv[3]);

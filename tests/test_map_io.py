@@ -85,3 +85,62 @@ def test_optimize_a_loaded_map(tmp_path, oracle):
     assert np.array_equal(got["info"][4:], want["info"][4:])
     assert np.allclose(got["poses"], want["poses"], rtol=1e-7, atol=1e-8) and np.allclose(got["points"], want["points"], rtol=1e-7, atol=1e-8)
     assert got["info"][1] < 0.2 * got["info"][0]   # the perturbed map was actually optimised
+
+
+def _lba_shim():
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "openvslam_amd", "cpp"), "test_lba_shim"])
+    return os.path.join(root, "openvslam_amd", "cpp", "test_lba_shim")
+
+
+def test_cpp_loader_reads_the_same_map(tmp_path):
+    """io::map_database_io::load_message_pack (openvslam_amd/cpp/openvslam/io/) against the Python reader: counts, descriptor bytes,
+    observations re-registered from lm_ids, covisibility lists (no device needed: `mapinfo` only parses)."""
+    import re
+    import subprocess
+    io, db, d, path = _db(tmp_path, n_pose=6, n_pt=500, obs_per_pose=200, seed=3, stereo_frac=0.3)
+    out = subprocess.run([_lba_shim(), "mapinfo", path], capture_output=True, text=True, check=True).stdout
+    got = [int(v) for v in re.findall(r"\d+", out)]
+    desc_sum = sum(int((kf.descs.astype(np.uint64) * np.arange(1, 33, dtype=np.uint64)).sum()) for kf in db.keyframes.values())
+    want = [len(db.cameras), len(db.keyframes), len(db.landmarks), sum(len(k.keypts) for k in db.keyframes.values()),
+            sum(len(v) for v in db.observations().values()), sum(len(db.covisibilities(k)) for k in db.keyframes), desc_sum]
+    assert got == want, (out, want)
+    bad = str(tmp_path / "bad.msg")
+    open(bad, "wb").write(b"\x81\xa5hello\x01")
+    assert subprocess.run([_lba_shim(), "mapinfo", bad], capture_output=True).returncode != 0
+
+
+@pytest.mark.gpu
+def test_cpp_class_optimizes_a_loaded_map(tmp_path):
+    """map.msg -> io::map_database_io -> optimize::local_bundle_adjuster::optimize through the C++ classes == the Python path
+    (io.local_ba_problem -> ovs_local_ba_optimize) on the same file. The two build their graphs in different orders (unordered_map
+    iteration vs id order), so the sums are associated differently: states agree to 1e-6."""
+    import subprocess
+    from openvslam_amd import ba
+    io, db, d, path = _db(tmp_path, n_pose=8, n_pt=900, obs_per_pose=300, seed=5, stereo_frac=0.3, pose_noise=0.03, point_noise=0.03)
+    curr = 7
+    out = str(tmp_path / "out.bin")
+    subprocess.check_call([_lba_shim(), "map", path, str(curr), out])
+    raw = np.fromfile(out, np.float64)
+    nk, nl = len(db.keyframes), len(db.landmarks)
+    T = raw[:16 * nk].reshape(nk, 4, 4)
+    P = raw[16 * nk:].reshape(nl, 3)
+    prob = io.local_ba_problem(io.load_map_database(path), curr)
+    res = ba.local_ba_optimize(prob["poses"], prob["pose_fixed"], prob["points"], prob["mono"], prob["cam"], prob["stereo"], prob["focal_x_baseline"],
+                               setup_type=prob["setup_type"])
+    kf_ids, lm_ids = sorted(db.keyframes), sorted(db.landmarks)
+    moved = 0
+    for row, kid in enumerate(prob["keyfrm_ids"]):
+        want = np.eye(4)
+        want[:3, :3] = ba.quat_to_rot(res["poses"][row, 3:])
+        want[:3, 3] = res["poses"][row, :3]
+        assert np.allclose(T[kf_ids.index(kid)], want, atol=1e-6), kid
+        moved += int(not np.allclose(res["poses"][row], prob["poses"][row], atol=1e-9))
+    assert moved >= 3   # the local keyframes were actually optimised
+    for row, lid in enumerate(prob["lm_ids"]):
+        assert np.allclose(P[lm_ids.index(lid)], res["points"][row], atol=1e-6), lid
+    untouched = [l for l in lm_ids if l not in set(prob["lm_ids"])]
+    for lid in untouched[:50]:
+        assert np.array_equal(P[lm_ids.index(lid)], db.landmarks[lid].pos_w)
