@@ -1,4 +1,4 @@
-"""The N>1 path of the local-BA linearisation on CPU: world_size 2 and 4, gloo. Edges are sharded by keyframe, every rank computes
+"""The N>1 path of the local-BA linearisation on CPU: world_size 2, 4 and 8 (the driver's scaling run), gloo. Edges are sharded by keyframe, every rank computes
 its shard's partial blocks (here with the ORACLE as the shard backend -- this test is about the sharding and the exchange
 step, the HIP backend runs under a 1-rank nccl group in tests/test_gpu_ba.py::test_graph_backend_under_nccl_group), then Hll|bl|chi2 are all-reduced in ONE packed collective. Result must equal the one-process
 linearisation within the stated multi-rank tolerance 1e-10 (rel.; summation order differs)."""
@@ -40,7 +40,7 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_world_size_n_gloo(oracle, world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
