@@ -267,3 +267,31 @@ def test_brute_force_rules(oracle):
     assert oracle.robust_brute_force_match(frm, kf, None, 1.01, frm_valid=np.array([0, 1, 1], np.uint8)).tolist() == [[1, 0]]
     # a distance of 256 never becomes best (strict '<' against MAX_HAMMING_DIST)
     assert len(oracle.robust_brute_force_match(~z, z, None, 0.9)) == 0
+
+
+def test_hamming_distance_as_integer_dot_product():
+    """The identity the matrix-core form of the all-pairs stage rests on (csrc/match_hamming.hip k_hamming_near): with the frame descriptor a
+    expanded to {0, 1} bytes and the keyframe descriptor b to {+1, -1} bytes, d(a, b) = |b| - sum_k a_k b_k, for ANY common order of the
+    256 bit positions along K; and d <= thr  <=>  sum >= |b| - thr (the per-query bound the kernel compares its accumulators with),
+    including all-zero / all-one descriptors where that bound is negative / large."""
+    rng = np.random.default_rng(0)
+    d = rng.integers(0, 256, (64, 32), dtype=np.uint8)
+    d[0], d[1] = 0, 255
+    bits = np.unpackbits(d, axis=1, bitorder="little").astype(np.int32)          # (64, 256), bit i of byte j at 8 j + i
+    perm = rng.permutation(256)                                                  # any K order, as long as both sides use it
+    a01 = bits[:, perm]
+    bpm = (2 * bits - 1)[:, perm]
+    dot = a01 @ bpm.T                                                            # [frame a, keyframe b]
+    pc = bits.sum(1)
+    ham = (bits[:, None, :] != bits[None, :, :]).sum(-1)
+    assert np.array_equal(pc[None, :] - dot, ham)
+    for thr in (0, 50, 55, 255):
+        assert np.array_equal(dot >= (pc[None, :] - thr), ham <= thr)
+    # the kernel's operand expansion: byte v of VGPR (word w, bit base + v) -- a fixed bijection of the 128 bits of a lane's half
+    seen = set()
+    for word in range(4):
+        for step in range(2):
+            for v in range(4):
+                for byte in range(4):
+                    seen.add(32 * word + 8 * byte + 4 * step + v)
+    assert seen == set(range(128))
