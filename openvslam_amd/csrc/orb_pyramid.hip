@@ -118,11 +118,13 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restr
         // x-taps are loaded once.
         {
             const int a_o0 = ta.o0 - sx_lo, a_o1 = ta.o1 - sx_lo, b_o0 = tbp.o0 - sx_lo, b_o1 = tbp.o1 - sx_lo;
-            for (int r = q; r < nrows; r += 4) {
-                const uint8_t* S = tb + r * (kSrcWords * 4);
+            // pointers stepped by four rows: indexed by r, hipcc multiplied with v_mul_lo_u32 (quarter rate) twice per unrolled iteration
+            const uint8_t* S = tb + q * (kSrcWords * 4);
+            uint32_t* H = &hrow[q][xp];
+            for (int r = q; r < nrows; r += 4, S += 4 * (kSrcWords * 4), H += 4 * (kTileW / 2)) {
                 const uint32_t ha = (uint32_t)(S[a_o0] * ta.a0 + S[a_o1] * ta.a1) >> 4;
                 const uint32_t hb = (uint32_t)(S[b_o0] * tbp.a0 + S[b_o1] * tbp.a1) >> 4;
-                hrow[r][xp] = ha | (hb << 16);
+                *H = ha | (hb << 16);
             }
         }
         __syncthreads();
