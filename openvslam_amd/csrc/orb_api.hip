@@ -37,6 +37,34 @@ static void build_taps(int ssize, int dsize, ResizeTap* out) {
     }
 }
 
+// Conditions under which k_resize_linear_u8 (v4, orb_pyramid.hip) may run a level: every 128 x 32 output tile's source rectangle fits the
+// kernel's LDS tile (48 words x 44 rows, the rectangle starting on a 16-byte boundary), and the four source bytes of every column pair
+// (x even, min(x + 1, dcols - 1)) lie inside the two aligned words that start at o0(x) & ~3.
+static bool resize_windows_ok(const ResizeTap* xt, int dcols, const ResizeTap* yt, int drows) {
+    constexpr int kTw = 128, kTh = 32, kWords = 48, kRows = 44;
+    for (int x0 = 0; x0 < dcols; x0 += kTw) {
+        const int x1 = std::min(x0 + kTw, dcols) - 1;
+        const int lo = xt[x0].o0 & ~15, hi = xt[x1].o1;
+        if (hi < lo || (hi - lo) / 4 + 1 > kWords) return false;
+    }
+    for (int y0 = 0; y0 < drows; y0 += kTh) {
+        const int y1 = std::min(y0 + kTh, drows) - 1;
+        if (yt[y1].o1 < yt[y0].o0 || yt[y1].o1 - yt[y0].o0 + 1 > kRows) return false;
+    }
+    for (int x = 0; x < dcols; x += 2) {
+        const int xb = std::min(x + 1, dcols - 1);
+        const int base = xt[x].o0 & ~3;
+        const int o[4] = {xt[x].o0, xt[x].o1, xt[xb].o0, xt[xb].o1};
+        for (int k = 0; k < 4; ++k)
+            if (o[k] < base || o[k] > base + 7) return false;
+        if (xt[x].a0 < 0 || xt[x].a1 < 0 || xt[xb].a0 < 0 || xt[xb].a1 < 0 || xt[x].a0 > 2048 || xt[x].a1 > 2048 || xt[xb].a0 > 2048 || xt[xb].a1 > 2048)
+            return false;
+    }
+    for (int y = 0; y < drows; ++y)
+        if (yt[y].a0 < 0 || yt[y].a1 < 0 || yt[y].a0 > 2048 || yt[y].a1 > 2048) return false;
+    return true;
+}
+
 }   // namespace ovs
 
 using namespace ovs;
@@ -169,6 +197,7 @@ bool build_geometry(const ovs_orb* h, int rows, int cols, FrameGeo& geo, std::ve
             g.ytab_off = (int64_t)taps.size();
             taps.resize(taps.size() + g.rows);
             build_taps(prev_rows, g.rows, &taps[g.ytab_off]);
+            g.resize_hwin_ok = resize_windows_ok(&taps[g.xtab_off], g.cols, &taps[g.ytab_off], g.rows) ? 1 : 0;
         }
         prev_rows = g.rows;
         prev_cols = g.cols;
@@ -182,6 +211,7 @@ bool build_geometry(const ovs_orb* h, int rows, int cols, FrameGeo& geo, std::ve
         g.ncy = H > kCellOverlap ? (H - kCellOverlap + kCellSize - 1) / kCellSize : 0;
         if (g.ncx == 0 || g.ncy == 0) g.ncx = g.ncy = 0;
         g.inv_ncx = g.ncx ? 1.0f / (float)g.ncx : 0.0f;
+        g.ncx_magic = g.ncx > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)g.ncx - 1) / (uint64_t)g.ncx) : 0u;   // ncx == 1: see k_fast_cells
         g.cell_base = cell_base;
         cell_base += g.ncx * g.ncy;
         g.n_keypts = h->npl[l];
@@ -284,7 +314,7 @@ ovs_status run_chain(ovs_orb* h, StageProfiler<4>& prof, const uint8_t* d_images
         const size_t src_fs = (l == 1) ? frame_stride : d.pyr_frame_bytes;
         const int src_pitch = (l == 1) ? (int)stride : gp.pitch;
         OVS_HIP_TRY(launch_resize(src, src_fs, src_pitch, gp.rows, gp.cols, d.pyr + g.plane_off, d.pyr_frame_bytes, g.pitch, g.rows, g.cols,
-                                  h->d_taps + g.xtab_off, h->d_taps + g.ytab_off, nb, s));
+                                  h->d_taps + g.xtab_off, h->d_taps + g.ytab_off, nb, s, g.resize_hwin_ok));
     }
     OVS_HIP_TRY(prof.mark(1, s));
     if (split) {

@@ -28,6 +28,9 @@
 // kernel uses counts and an explicit emission-order key).
 #include "ovs_common.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace ovs {
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -143,7 +146,7 @@ __device__ __forceinline__ uint32_t fast_strength_one(const uint8_t* p) {
 
 constexpr int kMaxSurvivors = 1024;   // NMS survivors are pairwise non-adjacent: at most 32 x 32 per 64 x 64 cell
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fast_cells(const FrameGeo* __restrict__ geo, const uint8_t* __restrict__ img0, size_t stride0,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fast_cells_v3(const FrameGeo* __restrict__ geo, const uint8_t* __restrict__ img0, size_t stride0,
                                                    size_t frame_stride0, const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                                    uint64_t* __restrict__ cand, size_t cand_frame_entries,
                                                    uint32_t* __restrict__ cand_count, const uint8_t* __restrict__ mask,
@@ -369,14 +372,420 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
 }
 
+// ================================================================================================================================
+// v4 (round 3): the same algorithm with the instruction diet VERDICT round 2 asked for.
+//   * pre-test on FOUR pixels per register in the fast-class 32-bit ops (v_sub / v_and / v_or, 2.3-2.5 cycles per wave-instruction)
+//     instead of two per register in packed 16-bit ops (4.2): the tile is staged a second time as R = (p >> 2) | 0x80 per byte, and with
+//     th6 = (t + 1) >> 2 the byte-wise differences
+//         X_i = R_i - (C - K),  Y_i = (C + K) - R_i      (K = 0x80808080 - th6 * 0x01010101, C = centre bytes, R_i = ring bytes)
+//     never borrow across bytes (every byte stays in [1, 191]) and carry in bit 7 "r6 >= c6 + th6" resp. "r6 <= c6 - th6". Since
+//     r - c > t implies (r >> 2) - (c >> 2) >= (t + 1) >> 2, the four-even-diameter condition on these bits is still NECESSARY for
+//     S > t; it lets ~1.3x as many pixels through as the exact 8-bit form (tools/fast_pretest_model.py), all of which get the exact S.
+//     Ring positions 2 / 6 / 10 / 14 are word-aligned for a 4-pixel group, so a group costs 5 v_alignbyte + 34 fast ops (v3: 104 slow ops);
+//   * survivors of the four waves are pooled in ONE list (wave prefix sum by DPP, one LDS atomic per wave): the exact scoring and the NMS
+//     run ceil(n / 256) rounds for the workgroup instead of ceil(n_w / 64) per wave (79 survivors per wave on average: 2 rounds at 62 %
+//     lane use before);
+//   * the prologue's cell arithmetic stays on the scalar unit (integer reciprocals from the host instead of float conversions).
+// LDS: raw tile 5.6 KB + R tile 5.6 KB + score map 4.75 KB + pooled list 8 KB = 24.2 KB -> 6 workgroups per CU.
+__device__ __forceinline__ uint32_t wave_prefix_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+    return v;
+}
+
+__device__ __forceinline__ uint32_t to_r6(uint32_t w) { return __builtin_amdgcn_bitop3_b32(w >> 2, 0x3f3f3f3fu, 0x80808080u, 0xea); }   // (a & b) | c
+
+// bit 7 of byte b <-> pixel 4g + b of the group passes the four-diameter test. w = the thread's 8 x 5-word window of the R tile,
+// G = group (0 / 1) inside the thread's 8-pixel run, R0 = row (0 / 1) of its row pair; kk = K above.
+// v_bitop3_b32: a & (b | c)
+__device__ __forceinline__ uint32_t and_or3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xe0); }
+
+template <int G, int R0>
+__device__ __forceinline__ void swar_diameter_test(const uint32_t (&w)[8][5], uint32_t kk, uint32_t& bright, uint32_t& dark) {
+    const uint32_t c = __builtin_amdgcn_alignbyte(w[R0 + 3][G + 2], w[R0 + 3][G + 1], 2);
+    const uint32_t p0 = __builtin_amdgcn_alignbyte(w[R0 + 6][G + 2], w[R0 + 6][G + 1], 2);    // (0, +3)
+    const uint32_t p8 = __builtin_amdgcn_alignbyte(w[R0 + 0][G + 2], w[R0 + 0][G + 1], 2);    // (0, -3)
+    const uint32_t p4 = __builtin_amdgcn_alignbyte(w[R0 + 3][G + 3], w[R0 + 3][G + 2], 1);    // (+3, 0)
+    const uint32_t p12 = __builtin_amdgcn_alignbyte(w[R0 + 3][G + 1], w[R0 + 3][G + 0], 3);   // (-3, 0)
+    const uint32_t p2 = w[R0 + 5][G + 2], p14 = w[R0 + 5][G + 1];                             // (+2, +2), (-2, +2)
+    const uint32_t p6 = w[R0 + 1][G + 2], p10 = w[R0 + 1][G + 1];                             // (+2, -2), (-2, -2)
+    const uint32_t cb = c - kk, cd = c + kk;
+    // bit 7 of every byte: all four diameters have a bright (dark) end
+    bright = and_or3(and_or3(and_or3((p0 - cb) | (p8 - cb), p2 - cb, p10 - cb), p4 - cb, p12 - cb), p6 - cb, p14 - cb);
+    dark = and_or3(and_or3(and_or3((cd - p0) | (cd - p8), cd - p2, cd - p10), cd - p4, cd - p12), cd - p6, cd - p14);
+}
+
+// S of one polarity: max over the sixteen 9-arcs of the arc's minimum ring value, minus the centre (clamped at 0). For the dark polarity
+// the caller passes the complemented bytes (255 - v): max_arcs min_9 (c - r) = max_arcs min_9 ((255 - r) - (255 - c)).
+__device__ __forceinline__ uint32_t fast_strength_bright(const uint32_t (&r)[16], uint32_t c) {
+    uint32_t pmn[8], qmn[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pmn[i] = mn16(r[2 * i], r[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qmn[i] = mn16(pmn[i], pmn[(i + 1) & 7]);
+    uint32_t best = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {   // the two 9-arcs {2i - 1 .. 2i + 7} and {2i .. 2i + 8} share the window {2i .. 2i + 7}
+        const uint32_t ea = r[(2 * i + 15) & 15], eb = r[(2 * i + 8) & 15];
+        best = mx16(best, mn16(mn16(qmn[i], qmn[(i + 2) & 7]), mx16(ea, eb)));
+    }
+    return best > c ? best - c : 0u;
+}
+
+// exact S of one candidate whose necessary test passed for ONE polarity (flip = 0: bright, 0xff: dark): the other polarity's arc value is
+// <= thr, so max(bright, dark) = this polarity's value whenever it matters (S > thr), and the pixel is no corner otherwise.
+// p = LDS address of the top-left byte of its 7x7 neighbourhood in the staged tile (pitch kTileWords * 4)
+__device__ __forceinline__ void load_ring(const uint8_t* p, uint32_t (&r)[16], uint32_t& c) {
+    constexpr int kP = kTileWords * 4;
+    c = p[3 * kP + 3];
+    r[0] = p[6 * kP + 3];
+    r[1] = p[6 * kP + 4];
+    r[2] = p[5 * kP + 5];
+    r[3] = p[4 * kP + 6];
+    r[4] = p[3 * kP + 6];
+    r[5] = p[2 * kP + 6];
+    r[6] = p[1 * kP + 5];
+    r[7] = p[0 * kP + 4];
+    r[8] = p[0 * kP + 3];
+    r[9] = p[0 * kP + 2];
+    r[10] = p[1 * kP + 1];
+    r[11] = p[2 * kP + 0];
+    r[12] = p[3 * kP + 0];
+    r[13] = p[4 * kP + 0];
+    r[14] = p[5 * kP + 1];
+    r[15] = p[6 * kP + 2];
+}
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() carries a workgroup-scope fence over ALL address spaces, i.e. an
+// s_waitcnt vmcnt(0) that would drain the next cell's tile loads (in flight across the whole body of the loop below) at every barrier
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// geometry of one cell (all wave-uniform)
+struct CellGeo {
+    const uint8_t* tile_org;   // image address of tile byte 0 of row 0
+    int pitch, level, min_x, min_y, max_x, max_y, cw, ch;
+    int64_t cand_off;
+    int cand_cap;
+    float scale;
+    bool vec16;
+};
+
+// 24.2 KB of LDS admit six workgroups per CU: cap the registers at the 80 that six waves per SIMD leave (hipcc took 95 unasked)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_fast_cells(const FrameGeo* __restrict__ geo, const uint8_t* __restrict__ img0, size_t stride0,
+                                                   size_t frame_stride0, const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
+                                                   uint64_t* __restrict__ cand, size_t cand_frame_entries,
+                                                   uint32_t* __restrict__ cand_count, const uint8_t* __restrict__ mask,
+                                                   int batch, uint32_t batch_magic, int cell_lo, int n_cells, int cells_per_wg) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[kTileRowsMax][kTileWords];
+    __shared__ __attribute__((aligned(16))) uint32_t rtile[kTileRowsMax][kTileWords];
+    __shared__ __attribute__((aligned(16))) uint32_t smap[kSmapRows][kSmapWords];
+    __shared__ uint16_t clist[kCellSize * kCellSize];   // pixels that passed the diameter test, (y << 8) | x, all four waves
+    __shared__ uint32_t n_cand_wg, n_out, list_base;
+
+    static_assert(sizeof(tile) >= kMaxSurvivors * sizeof(uint32_t), "survivor list aliases the tile");
+    uint32_t* const olist = &tile[0][0];
+    const int tid = threadIdx.x;
+    const int L = geo->num_levels;
+    // Work order: a workgroup takes `cells_per_wg` CONSECUTIVE cells of one frame (they share tile halo columns, and the workgroup lives long
+    // enough that its launch and the first tile's load latency are paid once per group, not once per cell: round 3 measured 4.4 of 6 possible
+    // waves per SIMD resident with one cell per workgroup). XCD-aware as before: XCD k takes the k-th contiguous eighth of the groups, the
+    // frame index runs fastest inside an XCD's share.
+    const int n_groups = (n_cells + cells_per_wg - 1) / cells_per_wg;
+    const int per_xcd = (n_groups + 7) >> 3;
+    const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+    const int slot = batch == 1 ? idx : (int)__umulhi((uint32_t)idx, batch_magic), frame = idx - slot * batch;
+    const int group = xcd * per_xcd + slot;
+    if (slot >= per_xcd || group >= n_groups) return;
+    const int cell_first = cell_lo + group * cells_per_wg;
+    const int cell_end = min(cell_first + cells_per_wg, cell_lo + n_cells);
+
+    auto cell_geo = [&](int cell_id) -> CellGeo {
+        // level of the cell: sign bits of (base[l] - 1 - cell_id), pure scalar arithmetic (a compare-and-add form came out of hipcc as
+        // v_cndmask + v_readfirstlane pairs)
+        uint32_t level_u = 0;
+#pragma unroll
+        for (int l = 1; l < OVS_MAX_LEVELS; ++l) level_u += (uint32_t)(geo->cell_base_tab[l] - 1 - cell_id) >> 31;
+        const int level = (int)level_u;
+        const LevelGeo& g = geo->lv[level];
+        const int g_ncx = g.ncx;
+        const int cell = cell_id - g.cell_base;
+        // exact: cell * ncx < 2^32 (levels are <= 8191 px wide: ncx <= 128, cell < 2^14); a one-column grid has no 32-bit reciprocal
+        const int ci = g_ncx == 1 ? cell : (int)__umulhi((uint32_t)cell, g.ncx_magic), cj = cell - ci * g_ncx;
+        CellGeo c;
+        c.level = level;
+        c.min_x = kOrbPatchRadius + cj * kCellSize;
+        c.min_y = kOrbPatchRadius + ci * kCellSize;
+        c.max_x = min(c.min_x + kCellSize + kCellOverlap, g.max_bx);
+        c.max_y = min(c.min_y + kCellSize + kCellOverlap, g.max_by);
+        c.cw = c.max_x - c.min_x;
+        c.ch = c.max_y - c.min_y;
+        const uint8_t* img;
+        if (level == 0) {
+            img = img0 + (size_t)frame * frame_stride0;
+            c.pitch = (int)stride0;
+        } else {
+            img = pyr + (size_t)frame * pyr_frame_bytes + g.plane_off;
+            c.pitch = g.pitch;
+        }
+        c.vec16 = ((c.pitch & 15) == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0);
+        // tile byte u of row r <-> image (min_x - 3 + u, min_y + r); min_x - 3 = 16 + 64 * cj is 16-byte aligned
+        c.tile_org = img + (size_t)c.min_y * c.pitch + (c.min_x - 3);
+        c.cand_off = g.cand_off;
+        c.cand_cap = g.cand_cap;
+        c.scale = g.scale;
+        return c;
+    };
+    auto fetch_chunk = [&](const CellGeo& c, int r, int q) -> uint4 {
+        uint4 v = {0u, 0u, 0u, 0u};
+        const int gx = c.min_x - 3 + 16 * q;
+        if (r < c.ch) {
+            const uint8_t* p = c.tile_org + (size_t)r * c.pitch + 16 * q;
+            if (c.vec16) {
+                if (gx < c.pitch) v = *reinterpret_cast<const uint4*>(p);
+            } else {   // 4-byte aligned base/stride (enforced by the ABI), row tail
+                const uint32_t* p4 = reinterpret_cast<const uint32_t*>(p);
+                if (gx + 4 <= c.pitch) v.x = p4[0];
+                if (gx + 8 <= c.pitch) v.y = p4[1];
+                if (gx + 12 <= c.pitch) v.z = p4[2];
+                if (gx + 16 <= c.pitch) v.w = p4[3];
+            }
+        }
+        return v;
+    };
+    constexpr int kChunks = kTileRowsMax * 5;
+    const int ra = (tid * 0x3334) >> 16, qa = tid - 5 * ra;                       // tid / 5, tid % 5
+    const int rb = ((tid + 256) * 0x3334) >> 16, qb = (tid + 256) - 5 * rb;
+    const bool has_b = tid + 256 < kChunks;
+    const int run = tid & 7, rp = tid >> 3;
+    const int c0 = run * 8, row0 = 2 * rp;
+    const uint8_t* const tbytes = reinterpret_cast<const uint8_t*>(&tile[0][0]);
+    uint32_t* const smap_flat = &smap[0][0];
+    uint8_t* const sbytes = reinterpret_cast<uint8_t*>(smap_flat);
+    static_assert((kSmapRows * kSmapWords) % 4 == 0, "score map is cleared with 16-byte stores");
+    const uint8_t* const fmask = mask ? mask + (size_t)frame * frame_stride0 : nullptr;   // same layout as the level-0 frames
+    const int ini_thr = geo->ini_thr, min_thr = geo->min_thr;
+
+    CellGeo cg = cell_geo(cell_first);
+    uint4 va = fetch_chunk(cg, ra, qa), vb = {0u, 0u, 0u, 0u};
+    if (has_b) vb = fetch_chunk(cg, rb, qb);
+
+    for (int cell_id = cell_first; cell_id < cell_end; ++cell_id) {
+        // ---- stage the tile this thread's two chunks belong to (requested one cell ago): raw bytes for the exact scoring, and
+        //      R = (p >> 2) | 0x80 per byte for the diameter test
+        for (int i = tid; i < kSmapRows * kSmapWords / 4; i += 256) reinterpret_cast<uint4*>(smap_flat)[i] = uint4{0u, 0u, 0u, 0u};
+        if (tid == 0) {
+            n_out = 0;
+            n_cand_wg = 0;
+        }
+        *reinterpret_cast<uint4*>(&tile[ra][4 * qa]) = va;
+        *reinterpret_cast<uint4*>(&rtile[ra][4 * qa]) = uint4{to_r6(va.x), to_r6(va.y), to_r6(va.z), to_r6(va.w)};
+        if (has_b) {
+            *reinterpret_cast<uint4*>(&tile[rb][4 * qb]) = vb;
+            *reinterpret_cast<uint4*>(&rtile[rb][4 * qb]) = uint4{to_r6(vb.x), to_r6(vb.y), to_r6(vb.z), to_r6(vb.w)};
+        }
+        const CellGeo c = cg;
+        // ---- request the next cell's tile: the loads are in flight under everything below (the barriers are LDS-only)
+        if (cell_id + 1 < cell_end) {
+            cg = cell_geo(cell_id + 1);
+            va = fetch_chunk(cg, ra, qa);
+            if (has_b) vb = fetch_chunk(cg, rb, qb);
+        }
+        lds_barrier();
+
+        const int min_x = c.min_x, min_y = c.min_y;
+        const int iw = c.cw - 6, ih = c.ch - 6;   // testable area of this cell (> 0 for every valid cell)
+        const float scale = c.scale;
+        bool skip = false;
+        if (fmask) {   // upstream: skip the cell if one of its corners is masked (level-0 coordinates, float scale, trunc)
+            auto in_mask = [&](unsigned y, unsigned x) {
+                return fmask[(size_t)(unsigned)(y * scale) * stride0 + (unsigned)(x * scale)] == 0;
+            };
+            skip = in_mask(min_y, min_x) || in_mask(c.max_y, min_x) || in_mask(min_y, c.max_x) || in_mask(c.max_y, c.max_x);
+        }
+        if (!skip) {
+            // candidate-mask layout: bit 8 * b + 2 * R0 + G <-> pixel c0 + 4 * G + b of row row0 + R0. Where the level border clips the testable
+            // area (workgroup-uniform, ~9 % of the cells) the pixels outside are masked; the empty asm keeps this a real branch (see v3).
+            uint32_t valid = 0x0f0f0f0fu;
+            if (iw < kCellSize || ih < kCellSize) {
+                asm volatile("" ::: "memory");
+                valid = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int G = 0; G < 2; ++G) {
+                        const uint32_t colok = (c0 + 4 * G + b < iw) ? 1u : 0u;
+                        valid |= ((row0 < ih ? colok : 0u) << (8 * b + G)) | ((row0 + 1 < ih ? colok : 0u) << (8 * b + 2 + G));
+                    }
+            }
+
+            int thr = ini_thr;
+            for (;;) {
+                // ---- 1. four-diameter test, four pixels per register, on the R tile: candidate mask + "dark end" mask
+                uint32_t cmask, dmask;
+                {
+                    uint32_t w[8][5];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const uint2 b = *reinterpret_cast<const uint2*>(&rtile[row0 + r][2 * run + 2]);
+                        w[r][1] = rtile[row0 + r][2 * run + 1];
+                        w[r][2] = b.x;
+                        w[r][3] = b.y;
+                        if (r == 3 || r == 4) {
+                            w[r][0] = rtile[row0 + r][2 * run];
+                            w[r][4] = rtile[row0 + r][2 * run + 4];
+                        }
+                    }
+                    const uint32_t kk = 0x80808080u - (uint32_t)((thr + 1) >> 2) * 0x01010101u;
+                    uint32_t b00, d00, b10, d10, b01, d01, b11, d11;
+                    swar_diameter_test<0, 0>(w, kk, b00, d00);
+                    swar_diameter_test<1, 0>(w, kk, b10, d10);
+                    swar_diameter_test<0, 1>(w, kk, b01, d01);
+                    swar_diameter_test<1, 1>(w, kk, b11, d11);
+                    constexpr uint32_t kM = 0x80808080u;
+                    const uint32_t bm = ((b00 & kM) >> 7) | ((b10 & kM) >> 6) | ((b01 & kM) >> 5) | ((b11 & kM) >> 4);
+                    dmask = (((d00 & kM) >> 7) | ((d10 & kM) >> 6) | ((d01 & kM) >> 5) | ((d11 & kM) >> 4)) & valid;
+                    cmask = (bm & valid) | dmask;
+                    // entry flags: 0x40 = evaluate the dark polarity (the bright test failed), 0x80 = both tests passed (evaluate both)
+                    dmask = (dmask & ~bm) | ((dmask & bm) << 4);   // bits 4..7 of every byte are free in the mask layout
+                }
+                // ---- 2. pool the candidates of the four waves: exclusive prefix inside the wave, one LDS atomic per wave for its base
+                {
+                    const uint32_t n_mine = (uint32_t)__popc(cmask);
+                    const uint32_t incl = wave_prefix_incl(n_mine);
+                    const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    uint32_t base = 0;
+                    if ((tid & 63) == 0 && wave_total) base = atomicAdd(&n_cand_wg, wave_total);
+                    uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + incl - n_mine;
+                    while (cmask) {
+                        const int b = __ffs(cmask) - 1;
+                        cmask &= cmask - 1;
+                        const uint32_t fl = (((dmask >> b) & 1u) << 6) | (((dmask >> (b + 4)) & 1u) << 7);
+                        clist[pos++] = (uint16_t)(((row0 + ((b >> 1) & 1)) << 8) | (c0 + 4 * (b & 1) + (b >> 3)) | fl);
+                    }
+                }
+                lds_barrier();
+                const int n_cand = (int)n_cand_wg;
+                // ---- 3. exact S for the candidates, one per lane, into the score map: one polarity per candidate (both where both tests passed)
+                for (int i = tid; i < n_cand; i += 256) {
+                    const uint32_t e = clist[i];
+                    const int x = e & 63, y = e >> 8;
+                    uint32_t r[16], c;
+                    load_ring(tbytes + y * (kTileWords * 4) + x + 3, r, c);
+                    const uint32_t flip = (e & 0x40u) ? 0xffu : 0u;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) r[k] ^= flip;
+                    c ^= flip;
+                    uint32_t sc = fast_strength_bright(r, c);
+                    if (__builtin_amdgcn_ballot_w64((e & 0x80u) != 0) != 0) {   // rare: some lane's pixel passed both tests
+                        if (e & 0x80u) {
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) r[k] ^= 0xffu;
+                            sc = mx16(sc, fast_strength_bright(r, c ^ 0xffu));
+                        }
+                    }
+                    sbytes[(y + 1) * (kSmapWords * 4) + 4 + x] = (uint8_t)sc;
+                }
+                lds_barrier();
+                // ---- 4. strict NMS over the 8 neighbours (unevaluated neighbours have S <= thr < S(p): 0 in the map), survivors -> olist
+                //      (olist aliases the tile: every wave is past its last tile read, the scoring, by the barrier above)
+                for (int i = tid; i < n_cand; i += 256) {
+                    const uint32_t e = clist[i] & 0x3f3fu;
+                    const int x = e & 255, y = e >> 8;
+                    const uint8_t* q = sbytes + (y + 1) * (kSmapWords * 4) + 4 + x;
+                    const uint32_t sc = q[0];
+                    if ((int)sc <= thr) continue;
+                    constexpr int kS = kSmapWords * 4;
+                    const uint32_t nb = mx16(mx16(mx16((uint32_t)q[-kS - 1], (uint32_t)q[-kS]), mx16((uint32_t)q[-kS + 1], (uint32_t)q[-1])),
+                                             mx16(mx16((uint32_t)q[1], (uint32_t)q[kS - 1]), mx16((uint32_t)q[kS], (uint32_t)q[kS + 1])));
+                    if (sc <= nb) continue;
+                    // n_out counts the NMS survivors ("keypts_in_cell" before upstream's mask filter); masked ones are dropped at the append
+                    const uint32_t o = atomicAdd(&n_out, 1u);
+                    olist[o] = (sc << 16) | e;
+                }
+                lds_barrier();
+                if (n_out != 0 || thr <= min_thr) break;
+                // "if keypts_in_cell.empty()": again with min_fast_thr (rare: flat cells). No survivor was written, so the tile is intact.
+                thr = min_thr;
+                for (int i = tid; i < kSmapRows * kSmapWords / 4; i += 256) reinterpret_cast<uint4*>(smap_flat)[i] = uint4{0u, 0u, 0u, 0u};
+                if (tid == 0) n_cand_wg = 0;
+                lds_barrier();
+            }
+
+            // ---- 5. append to the (frame, level) candidate list: one global atomic per workgroup; FAST response = S - 1
+            uint32_t total = n_out;
+            if (total != 0) {
+                if (fmask) {
+                    // upstream drops masked keypoints after the empty-cell decision: compact olist in place (rare path, one wave)
+                    lds_barrier();
+                    if (tid < 64) {
+                        uint32_t kept = 0;
+                        for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+                            const uint32_t i = i0 + tid;
+                            uint32_t o = 0;
+                            bool keep = false;
+                            if (i < total) {
+                                o = olist[i];
+                                const uint32_t gx = min_x + 3 + (o & 255u), gy = min_y + 3 + ((o >> 8) & 255u);
+                                keep = fmask[(size_t)(unsigned)(gy * scale) * stride0 + (unsigned)(gx * scale)] != 0;
+                            }
+                            const unsigned long long bal = __ballot(keep);
+                            const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                            if (keep) olist[kept + off] = o;   // kept + off <= i: in-place compaction never overtakes its own reads
+                            kept += (uint32_t)__popcll(bal);
+                        }
+                        if (tid == 0) n_out = kept;
+                    }
+                    lds_barrier();
+                    total = n_out;
+                }
+                if (total != 0) {
+                    if (tid == 0) list_base = atomicAdd(&cand_count[frame * L + c.level], total);
+                    lds_barrier();   // the atomic's return is waited for by thread 0 before its LDS store; the barrier publishes it
+                    const uint32_t base = list_base;
+                    uint64_t* const list = cand + (size_t)frame * cand_frame_entries + c.cand_off;
+                    const uint32_t cap = (uint32_t)c.cand_cap;
+                    for (uint32_t i = tid; i < total; i += 256) {
+                        const uint32_t o = olist[i];
+                        const uint32_t x = o & 255u, y = (o >> 8) & 255u, sc = o >> 16;
+                        if (base + i < cap) list[base + i] = cand_pack((uint32_t)(min_x + 3) + x, (uint32_t)(min_y + 3) + y, sc - 1u, 0);
+                    }
+                }
+            }
+        }
+        lds_barrier();   // the next cell's staging overwrites tile / olist, smap and the counters
+    }
+}
+
 hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
                        const uint8_t* mask, int mask_rows, int batch, hipStream_t s, int cell_lo, int n_cells) {
     (void)mask_rows;
     if (n_cells < 0) n_cells = hgeo.total_cells - cell_lo;
     if (n_cells <= 0 || batch <= 0) return hipSuccess;
     const unsigned per_xcd = (unsigned)(n_cells + 7) / 8u;
-    hipLaunchKernelGGL(k_fast_cells, dim3(8u * per_xcd * (unsigned)batch), dim3(256), 0, s, d.geo, img0, stride0, frame_stride0, d.pyr,
-                       d.pyr_frame_bytes, d.cand, d.cand_frame_entries, d.cand_count, mask, batch, cell_lo, n_cells);
+    const char* const env_v3 = getenv("OVS_FAST_V3");   // A/B aid (round 3), read per launch so that one process can time both
+    const bool use_v3 = env_v3 && env_v3[0] == '1';
+    // slot = idx / batch as a multiply-high: exact while idx * batch < 2^32 (idx < per_xcd * batch)
+    if ((uint64_t)per_xcd * (uint64_t)batch * (uint64_t)batch >= (1ull << 32)) return hipErrorInvalidValue;
+    const uint32_t batch_magic = batch > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)batch - 1) / (uint64_t)batch) : 0u;
+    const char* const env_k = getenv("OVS_FAST_CELLS");   // tuning aid: consecutive cells per workgroup
+    const int cells_per_wg = env_k ? std::min(std::max(atoi(env_k), 1), 64) : 6;
+    if (use_v3)
+        hipLaunchKernelGGL(k_fast_cells_v3, dim3(8u * per_xcd * (unsigned)batch), dim3(256), 0, s, d.geo, img0, stride0, frame_stride0, d.pyr,
+                           d.pyr_frame_bytes, d.cand, d.cand_frame_entries, d.cand_count, mask, batch, cell_lo, n_cells);
+    else
+    {
+        const unsigned n_groups = ((unsigned)n_cells + (unsigned)cells_per_wg - 1) / (unsigned)cells_per_wg, gper = (n_groups + 7) / 8u;
+        hipLaunchKernelGGL(k_fast_cells, dim3(8u * gper * (unsigned)batch), dim3(256), 0, s, d.geo, img0, stride0, frame_stride0, d.pyr,
+                           d.pyr_frame_bytes, d.cand, d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg);
+    }
     return hipGetLastError();
 }
 

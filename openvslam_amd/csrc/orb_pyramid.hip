@@ -12,6 +12,8 @@
 // (tile halos overlap by one row/column and hit L2).
 #include "ovs_common.h"
 
+#include <cstdlib>
+
 namespace ovs {
 
 constexpr int kTileW = 128, kTileH = 32;
@@ -30,7 +32,7 @@ __device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b) {
     return d;
 }
 
-__global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restrict__ src, size_t src_frame_stride, int src_pitch,
+__global__ __launch_bounds__(256) void k_resize_linear_u8_v3(const uint8_t* __restrict__ src, size_t src_frame_stride, int src_pitch,
                                                          int srows, int scols, uint8_t* __restrict__ dst, size_t dst_frame_stride,
                                                          int dst_pitch, int drows, int dcols, const ResizeTap* __restrict__ xt,
                                                          const ResizeTap* __restrict__ yt, int tiles_x, int tiles_y, int batch, float inv_tiles_x,
@@ -180,13 +182,181 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restr
     (void)scols;
 }
 
+// ================================================================================================================================
+// v4 (round 3): the same two fixed-point passes with about half the vector instructions (~33 lane-ops per output pixel
+// for ~12 of arithmetic).
+//   * horizontal pass: the four source bytes of a thread's column pair lie inside two aligned words (checked per level on the host,
+//     LevelGeo::resize_hwin_ok; the v3 kernel stays as the path for geometries where they do not): ONE ds_read2_b32 instead of four
+//     ds_read_u8, one v_perm_b32 per column to pair (S[o0], S[o1]) as 2 x u16, one v_dot2_u32_u16 against (16 a0, 16 a1) -- the
+//     factor 16 makes h >> 4 the byte-aligned middle of the result, so a third v_perm_b32 packs both columns' 16-bit values;
+//   * vertical pass: v_mul_u32_u24 / v_add_u32 / v_lshrrev_b32 in their SDWA forms read the 16-bit halves and write the result byte
+//     in place: 5 instructions per pixel (v3: 2 v_perm + 2 v_mul_hi + 3 + 1.75 to pack), same integers:
+//         out = (((b0 * r0) >> 16) + ((b1 * r1) >> 16) + 2) >> 2,   r = h >> 4,   h = S[o0] * a0 + S[o1] * a1;
+//   * frame / tile indices from integer reciprocals on the scalar unit.
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_dot2_u32_u16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// b * (low / high 16 bits of w), b < 2^24
+__device__ __forceinline__ uint32_t mul_lo16(uint32_t b, uint32_t w) {
+    uint32_t d;
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(d) : "v"(b), "v"(w));
+    return d;
+}
+__device__ __forceinline__ uint32_t mul_hi16(uint32_t b, uint32_t w) {
+    uint32_t d;
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(d) : "v"(b), "v"(w));
+    return d;
+}
+// (p >> 16) + (q >> 16)
+__device__ __forceinline__ uint32_t add_hi16(uint32_t p, uint32_t q) {
+    uint32_t d;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(d) : "v"(p), "v"(q));
+    return d;
+}
+// bytes (t0 >> 2, t1 >> 2, t2 >> 2, t3 >> 2), every t < 1024. The byte writes preserve the rest of the destination, i.e. read it: one
+// wait state between them (partial-dword write followed by a read of the same register).
+__device__ __forceinline__ uint32_t pack_shr2(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t two) {
+    uint32_t d;
+    asm volatile(
+        "v_lshrrev_b32_sdwa %0, %5, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n"
+        "s_nop 0\n"
+        "v_lshrrev_b32_sdwa %0, %5, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n"
+        "s_nop 0\n"
+        "v_lshrrev_b32_sdwa %0, %5, %3 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n"
+        "s_nop 0\n"
+        "v_lshrrev_b32_sdwa %0, %5, %4 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n"
+        "s_nop 0\n"
+        : "=&v"(d)
+        : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(two));
+    return d;
+}
+__device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t d, uint32_t magic) { return d == 1 ? n : __umulhi(n, magic); }
+
+__global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restrict__ src, size_t src_frame_stride, int src_pitch,
+                                                         uint8_t* __restrict__ dst, size_t dst_frame_stride, int dst_pitch, int drows,
+                                                         int dcols, const ResizeTap* __restrict__ xt, const ResizeTap* __restrict__ yt,
+                                                         int tiles_x, int tiles_frame, int batch, uint32_t tiles_x_magic,
+                                                         uint32_t tiles_frame_magic) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[kSrcRows * kSrcWords + 4];   // + 4: the pair read of a row's last word
+    __shared__ __attribute__((aligned(8))) uint32_t hrow[kSrcRows][kTileW / 2];        // horizontal pass, two u16 per word
+    const int tid = threadIdx.x;
+    const int per_xcd = gridDim.x >> 3;
+    const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);   // XCD-aware order, see v3
+    if (tile_id >= tiles_frame * batch) return;
+    const int frame = (int)udiv_magic((uint32_t)tile_id, (uint32_t)tiles_frame, tiles_frame_magic);
+    const int trem = tile_id - frame * tiles_frame;
+    const int tyi = (int)udiv_magic((uint32_t)trem, (uint32_t)tiles_x, tiles_x_magic), txi = trem - tyi * tiles_x;
+    const int x0 = txi * kTileW, y0 = tyi * kTileH;
+    const int x1 = min(x0 + kTileW, dcols) - 1, y1 = min(y0 + kTileH, drows) - 1;   // last output pixel of the tile
+    const uint8_t* s = src + (size_t)frame * src_frame_stride;
+    uint8_t* d = dst + (size_t)frame * dst_frame_stride;
+    const int sx_lo = xt[x0].o0 & ~15, sx_hi = xt[x1].o1;
+    const int sy_lo = yt[y0].o0, sy_hi = yt[y1].o1;
+    const int nwords = (sx_hi - sx_lo) / 4 + 1, nrows = sy_hi - sy_lo + 1;
+    // the launcher chose this kernel only for levels whose source rectangles fit (scale <= 1.25, 16-byte aligned rows)
+    const int xp = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xa = min(x0 + 2 * xp, dcols - 1), xb = min(x0 + 2 * xp + 1, dcols - 1);
+    const ResizeTap ta = xt[xa], tbp = xt[xb];
+    ResizeTap tys[kGroups];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) tys[g] = yt[min(y0 + 8 * g + (tid >> 5), drows - 1)];
+    {
+        uint4 v[kChunkSlots];
+        int slot[kChunkSlots];
+        const uint8_t* const org = s + (size_t)sy_lo * src_pitch + sx_lo;
+#pragma unroll
+        for (int k = 0; k < kChunkSlots; ++k) {
+            const int i = tid + 256 * k;
+            const int r = (i * 0x1556) >> 16, c = i - r * kRowChunks;   // i / 12 for i < 768
+            static_assert(kRowChunks == 12 && kChunkSlots * 256 <= 768, "chunk index split");
+            slot[k] = (r < nrows && 4 * c < nwords) ? i : -1;
+            v[k] = uint4{0u, 0u, 0u, 0u};
+            if (slot[k] >= 0) {
+                const int gx = sx_lo + 16 * c;
+                const uint8_t* p = org + (size_t)r * src_pitch + 16 * c;
+                if (gx + 16 <= src_pitch) {
+                    v[k] = *reinterpret_cast<const uint4*>(p);
+                } else {   // row tail
+                    const uint32_t* p4 = reinterpret_cast<const uint32_t*>(p);
+                    if (gx + 4 <= src_pitch) v[k].x = p4[0];
+                    if (gx + 8 <= src_pitch) v[k].y = p4[1];
+                    if (gx + 12 <= src_pitch) v[k].z = p4[2];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kChunkSlots; ++k)
+            if (slot[k] >= 0) reinterpret_cast<uint4*>(&tile[0])[slot[k]] = v[k];
+    }
+    __syncthreads();
+    // ---- horizontal pass
+    {
+        const int a_o0 = ta.o0 - sx_lo, wa = a_o0 >> 2, base = 4 * wa;
+        const uint32_t sa0 = (uint32_t)(a_o0 - base) & 7u, sa1 = (uint32_t)(ta.o1 - sx_lo - base) & 7u;
+        const uint32_t sb0 = (uint32_t)(tbp.o0 - sx_lo - base) & 7u, sb1 = (uint32_t)(tbp.o1 - sx_lo - base) & 7u;
+        const uint32_t sel_a = sa0 | 0x0c00u | (sa1 << 16) | 0x0c000000u, sel_b = sb0 | 0x0c00u | (sb1 << 16) | 0x0c000000u;
+        const uint32_t ca = ((uint32_t)(uint16_t)ta.a0 << 4) | ((uint32_t)(uint16_t)ta.a1 << 20);
+        const uint32_t cb = ((uint32_t)(uint16_t)tbp.a0 << 4) | ((uint32_t)(uint16_t)tbp.a1 << 20);
+        // wave q owns source rows q, q + 4, ...: eleven fixed steps cover all 44 tile rows (rows >= nrows hold stale bytes and produce
+        // values nobody reads), so the loop is straight-line code with immediate LDS offsets and every read in flight before the first use
+        const uint32_t* T = &tile[q * kSrcWords + wa];
+        uint32_t* H = &hrow[q][xp];
+        static_assert(kSrcRows == 44, "eleven steps of four rows");
+        uint32_t lo[11], hi[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            lo[k] = T[4 * k * kSrcWords];
+            hi[k] = T[4 * k * kSrcWords + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const uint32_t ha = dot2_u16(__builtin_amdgcn_perm(hi[k], lo[k], sel_a), ca);   // 16 * (S[o0] * a0 + S[o1] * a1) < 2^23
+            const uint32_t hb = dot2_u16(__builtin_amdgcn_perm(hi[k], lo[k], sel_b), cb);
+            H[4 * k * (kTileW / 2)] = __builtin_amdgcn_perm(hb, ha, 0x06050201u);            // (ha >> 8) | ((hb >> 8) << 16)
+        }
+    }
+    __syncthreads();
+    // ---- vertical pass + store: 4-pixel groups (32 per row), one aligned u32 store each
+    const uint32_t two = 2u;
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+        const int idx = tid + g * 256;
+        const int y = y0 + (idx >> 5), xg = (idx & 31) * 4, x4 = x0 + xg;
+        if (y >= drows || x4 >= dcols) continue;
+        const ResizeTap ty = tys[g];
+        const uint2 h0 = *reinterpret_cast<const uint2*>(&hrow[ty.o0 - sy_lo][xg >> 1]);
+        const uint2 h1 = *reinterpret_cast<const uint2*>(&hrow[ty.o1 - sy_lo][xg >> 1]);
+        const uint32_t b0 = (uint32_t)(uint16_t)ty.a0, b1 = (uint32_t)(uint16_t)ty.a1;
+        const uint32_t t0 = add_hi16(mul_lo16(b0, h0.x), mul_lo16(b1, h1.x)) + 2u;
+        const uint32_t t1 = add_hi16(mul_hi16(b0, h0.x), mul_hi16(b1, h1.x)) + 2u;
+        const uint32_t t2 = add_hi16(mul_lo16(b0, h0.y), mul_lo16(b1, h1.y)) + 2u;
+        const uint32_t t3 = add_hi16(mul_hi16(b0, h0.y), mul_hi16(b1, h1.y)) + 2u;
+        *reinterpret_cast<uint32_t*>(d + (size_t)y * dst_pitch + x4) = pack_shr2(t0, t1, t2, t3, two);
+    }
+}
+
 hipError_t launch_resize(const uint8_t* src, size_t src_frame_stride, int src_pitch, int srows, int scols, uint8_t* dst,
                          size_t dst_frame_stride, int dst_pitch, int drows, int dcols, const ResizeTap* xt, const ResizeTap* yt,
-                         int batch, hipStream_t s) {
+                         int batch, hipStream_t s, int hwin_ok) {
     const int tiles_x = (dcols + kTileW - 1) / kTileW, tiles_y = (drows + kTileH - 1) / kTileH;
-    dim3 grid(((tiles_x * tiles_y * batch + 7) / 8) * 8);
-    hipLaunchKernelGGL(k_resize_linear_u8, grid, dim3(256), 0, s, src, src_frame_stride, src_pitch, srows, scols, dst, dst_frame_stride,
-                       dst_pitch, drows, dcols, xt, yt, tiles_x, tiles_y, batch, 1.0f / (float)tiles_x, 1.0f / (float)(tiles_x * tiles_y));
+    const int tiles_frame = tiles_x * tiles_y;
+    dim3 grid(((tiles_frame * batch + 7) / 8) * 8);
+    const char* const env_v3 = getenv("OVS_RESIZE_V3");   // A/B aid (round 3), read per launch so that one process can time both
+    const bool force_v3 = env_v3 && env_v3[0] == '1';
+    // v4 needs: the host-checked tap windows (hwin_ok also says every tile's source rectangle fits the LDS tile), 16-byte aligned source
+    // rows, and tile_id * tiles_frame < 2^32 for the multiply-high divisions
+    const bool v4 = !force_v3 && hwin_ok && ((src_pitch & 15) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
+                    ((src_frame_stride & 15) == 0) && (uint64_t)tiles_frame * (uint64_t)tiles_frame * (uint64_t)batch < (1ull << 32);
+    auto magic = [](int d) { return d > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d) : 0u; };
+    if (v4)
+        hipLaunchKernelGGL(k_resize_linear_u8, grid, dim3(256), 0, s, src, src_frame_stride, src_pitch, dst, dst_frame_stride, dst_pitch,
+                           drows, dcols, xt, yt, tiles_x, tiles_frame, batch, magic(tiles_x), magic(tiles_frame));
+    else
+        hipLaunchKernelGGL(k_resize_linear_u8_v3, grid, dim3(256), 0, s, src, src_frame_stride, src_pitch, srows, scols, dst,
+                           dst_frame_stride, dst_pitch, drows, dcols, xt, yt, tiles_x, tiles_y, batch, 1.0f / (float)tiles_x,
+                           1.0f / (float)tiles_frame);
     return hipGetLastError();
 }
 

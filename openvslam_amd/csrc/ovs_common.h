@@ -33,7 +33,10 @@ struct LevelGeo {
     int32_t cand_cap;         // capacity of this level's candidate list
     int32_t gx, gy;           // root grid of the quad-tree
     int32_t max_nodes;        // 4*N_level + 16
-    float inv_ncx;            // 1 / ncx (exact cell -> (row, column) split without an integer division)
+    float inv_ncx;            // 1 / ncx (k_fast_cells_v3: cell -> (row, column) through a float product)
+    int32_t resize_hwin_ok;   // level >= 1: every tile of k_resize_linear_u8 (v4) finds its source rectangle inside the LDS tile and every
+                              // column pair's four source bytes inside two aligned words (checked on the host against the tap tables)
+    uint32_t ncx_magic;       // ceil(2^32 / ncx): cell / ncx == umulhi(cell, ncx_magic) for cell * ncx < 2^32 (scalar unit, no conversions)
     int64_t plane_off;        // byte offset of the plane inside one frame's pyramid block (levels >= 1)
     int64_t cand_off;         // entry offset of the candidate list inside one frame's candidate block
     int64_t node_off;         // entry offset of the node scratch inside one frame's node block
@@ -85,7 +88,7 @@ struct DevBuffers {
 // ---- kernel launchers (each defined next to its kernel) ----
 hipError_t launch_resize(const uint8_t* src, size_t src_frame_stride, int src_pitch, int srows, int scols, uint8_t* dst,
                          size_t dst_frame_stride, int dst_pitch, int drows, int dcols, const ResizeTap* xt, const ResizeTap* yt,
-                         int batch, hipStream_t s);
+                         int batch, hipStream_t s, int hwin_ok);
 hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
                        const uint8_t* mask, int mask_rows, int batch, hipStream_t s, int cell_lo = 0, int n_cells = -1);
 hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hipStream_t s, int level_lo = 0, int n_levels = -1);
