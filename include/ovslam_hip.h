@@ -493,6 +493,11 @@ typedef struct ovs_ba_graph ovs_ba_graph;
 ovs_status ovs_ba_graph_create(int32_t device, int32_t n_pose, const uint8_t* pose_fixed, int32_t n_pt, const ovs_ba_edge* mono, int32_t n_mono,
                                const ovs_ba_edge_stereo* stereo, int32_t n_stereo, const ovs_ba_cam* cam, double focal_x_baseline,
                                ovs_ba_graph** out);
+/* Equirectangular graph (replaces: the equirectangular_reproj_edge branch of local_bundle_adjuster::optimize's graph build): every edge is a
+ * monocular equirectangular edge as in ovs_ba_linearize_equirect (cols / rows = camera->cols_ / rows_). Same handle, same linearize call
+ * (huber_stereo is unused). */
+ovs_status ovs_ba_graph_create_equirect(int32_t device, int32_t n_pose, const uint8_t* pose_fixed, int32_t n_pt, const ovs_ba_edge* mono,
+                                        int32_t n_mono, int32_t cols, int32_t rows, ovs_ba_graph** out);
 ovs_status ovs_ba_graph_destroy(ovs_ba_graph* g);
 ovs_status ovs_ba_graph_linearize_dev(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo,
                                       double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream);
@@ -559,6 +564,13 @@ ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* p
                                  const ovs_ba_cam* cam, double focal_x_baseline, int32_t setup_type, int32_t num_first_iter, int32_t num_second_iter,
                                  const volatile uint8_t* force_stop_flag, uint8_t* mono_outlier, uint8_t* stereo_outlier, double* info);
 
+/* Equirectangular local map (camera::model_type_t::Equirectangular keyframes: optimize::g2o::se3::equirectangular_reproj_edge, every edge
+ * monocular, Monocular rig -> Huber sqrtf(5.99146f), gate 5.99146f; depth_is_positive() is always true for this model). Same schedule,
+ * outputs and info as ovs_local_ba_optimize. */
+ovs_status ovs_local_ba_optimize_equirect(int32_t device, double* poses, const uint8_t* pose_fixed, int32_t n_pose, double* points, int32_t n_pt,
+                                          const ovs_ba_edge* mono, int32_t n_mono, int32_t cols, int32_t rows, int32_t num_first_iter,
+                                          int32_t num_second_iter, const volatile uint8_t* force_stop_flag, uint8_t* mono_outlier, double* info);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Pose-only optimisation of one frame.  replaces: unsigned int optimize::pose_optimizer::optimize(data::frame& frm) const
  * (src/openvslam/optimize/pose_optimizer.{h,cc}; perspective mono / stereo pose_opt edges): 4 rounds x 10 Levenberg-Marquardt
@@ -582,6 +594,16 @@ ovs_status ovs_pose_optimize(int32_t device, const double* pose_cw_in, const ovs
 ovs_status ovs_pose_optimize_batch_dev(const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
                                        const ovs_ba_cam* cam, double focal_x_baseline, int32_t setup_type, double* d_poses_out,
                                        uint8_t* d_outlier, int32_t* d_num_valid, void* stream);
+/* Equirectangular frames.  replaces: the `camera::model_type_t::Equirectangular` branch of pose_optimizer::optimize, i.e.
+ * optimize::g2o::se3::equirectangular_pose_opt_edge::computeError / linearizeOplus (src/openvslam/optimize/g2o/se3/
+ * equirectangular_pose_opt_edge.{h,cc}): e = z - (cols (1/2 + atan2(x, z) / 2 pi), rows (1/2 + asin(y / |p|) / pi)), no wrap-around at the
+ * +-180 degree seam (oracle/ORACLE_SPEC.md rule 26). Every edge is monocular and the rig is Monocular (Huber sqrtf(5.99146f), gate
+ * 5.99146f); obs[i].is_stereo / obs_x_right are ignored. cols / rows = camera->cols_ / rows_. Same schedule, outputs and limits. */
+ovs_status ovs_pose_optimize_equirect(int32_t device, const double* pose_cw_in, const ovs_pose_obs* obs, int32_t n_obs, int32_t cols, int32_t rows,
+                                      double* pose_cw_out, uint8_t* outlier_flags, int32_t* num_valid);
+ovs_status ovs_pose_optimize_equirect_batch_dev(const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
+                                                int32_t cols, int32_t rows, double* d_poses_out, uint8_t* d_outlier, int32_t* d_num_valid,
+                                                void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Self-test of include/ovs_detmath.h on the device: out[i] = fn(a[i] (, b[i])) evaluated by a gfx950 kernel. The four functions

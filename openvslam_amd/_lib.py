@@ -66,6 +66,7 @@ SYMBOLS = {
     "ovs_ba_linearize_equirect": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_equirect_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_graph_create": (_i32, [_i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.POINTER(_vp)]),
+    "ovs_ba_graph_create_equirect": (_i32, [_i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, C.POINTER(_vp)]),
     "ovs_ba_graph_destroy": (_i32, [_vp]),
     "ovs_ba_graph_linearize_dev": (_i32, [_vp, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_multi_create": (_i32, [_i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.POINTER(_vp)]),
@@ -80,11 +81,14 @@ SYMBOLS = {
     "ovs_bow_transform": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "ovs_bow_transform_dev": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ovs_local_ba_optimize": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ovs_local_ba_optimize_equirect": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ovs_ba_linearize_stereo": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_stereo_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp,
                                            _vp, _vp]),
     "ovs_pose_optimize": (_i32, [_i32, _vp, _vp, _i32, _vp, C.c_double, _i32, _vp, _vp, C.POINTER(_i32)]),
     "ovs_pose_optimize_batch_dev": (_i32, [_vp, _vp, _vp, _i32, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp]),
+    "ovs_pose_optimize_equirect": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, C.POINTER(_i32)]),
+    "ovs_pose_optimize_equirect_batch_dev": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ovs_hamming_best2": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "ovs_wmatcher_create": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(_vp)]),
     "ovs_wmatcher_destroy": (_i32, [_vp]),

@@ -109,6 +109,22 @@ def pose_optimize(pose_cw, obs, cam, focal_x_baseline=0.0, device=0, setup_type=
     return np.concatenate([pout[:9].reshape(3, 3), pout[9:, None]], 1), out[:len(o)].astype(bool), nv.value
 
 
+def pose_optimize_equirect(pose_cw, obs, cols, rows, device=0):
+    """optimize::pose_optimizer::optimize(frm) for an equirectangular frame (ovs_pose_optimize_equirect: equirectangular_pose_opt_edge, every
+    edge monocular, Monocular rig). obs: POSE_OBS_DTYPE records (is_stereo / obs_x_right ignored); cols / rows = camera->cols_ / rows_.
+    Returns (pose_cw 3x4, outlier_flags bool[n], num_valid)."""
+    L = _lib.lib()
+    o = np.ascontiguousarray(obs, POSE_OBS_DTYPE)
+    T = np.asarray(pose_cw, np.float64)
+    pin = np.ascontiguousarray(np.concatenate([T[:3, :3].reshape(-1), T[:3, 3]]))
+    pout = np.zeros(12)
+    out = np.zeros(max(len(o), 1), np.uint8)
+    nv = C.c_int32()
+    _lib.check(L.ovs_pose_optimize_equirect(device, _p(pin), _p(o), len(o), int(cols), int(rows), _p(pout), _p(out), C.byref(nv)),
+               "ovs_pose_optimize_equirect")
+    return np.concatenate([pout[:9].reshape(3, 3), pout[9:, None]], 1), out[:len(o)].astype(bool), nv.value
+
+
 def local_ba_optimize(poses, pose_fixed, points, edges, cam, stereo_edges=None, focal_x_baseline=0.0, num_first_iter=5, num_second_iter=10,
                       force_stop_flag=None, device=0, setup_type=None):
     """optimize::local_bundle_adjuster::optimize behind the graph build (ovs_local_ba_optimize): returns dict(poses, points,
@@ -128,6 +144,22 @@ def local_ba_optimize(poses, pose_fixed, points, edges, cam, stereo_edges=None, 
                                        _p(es) if len(es) else None, len(es), C.byref(c), float(focal_x_baseline), int(setup_type), int(num_first_iter),
                                        int(num_second_iter), _p(force_stop_flag), _p(om), _p(os_), _p(info)), "ovs_local_ba_optimize")
     return dict(poses=P, points=X, mono_outlier=om[:len(em)].astype(bool), stereo_outlier=os_[:len(es)].astype(bool), info=info)
+
+
+def local_ba_optimize_equirect(poses, pose_fixed, points, edges, cols, rows, num_first_iter=5, num_second_iter=10, force_stop_flag=None, device=0):
+    """local_bundle_adjuster::optimize for an equirectangular local map (ovs_local_ba_optimize_equirect: equirectangular_reproj_edge, every
+    edge monocular). Returns dict(poses, points, mono_outlier, info)."""
+    L = _lib.lib()
+    P = np.array(poses, np.float64).reshape(-1, 7).copy()
+    X = np.array(points, np.float64).reshape(-1, 3).copy()
+    em = np.ascontiguousarray(edges if edges is not None else np.zeros(0, EDGE_DTYPE), EDGE_DTYPE)
+    fixed = None if pose_fixed is None else np.ascontiguousarray(pose_fixed, np.uint8)
+    om = np.zeros(max(len(em), 1), np.uint8)
+    info = np.zeros(6)
+    _lib.check(L.ovs_local_ba_optimize_equirect(device, _p(P), _p(fixed), len(P), _p(X), len(X), _p(em) if len(em) else None, len(em), int(cols),
+                                                int(rows), int(num_first_iter), int(num_second_iter), _p(force_stop_flag), _p(om), _p(info)),
+               "ovs_local_ba_optimize_equirect")
+    return dict(poses=P, points=X, mono_outlier=om[:len(em)].astype(bool), info=info)
 
 
 def shard_edges_by_keyframe(edges, n_pose, rank, world):

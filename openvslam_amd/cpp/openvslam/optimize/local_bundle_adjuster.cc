@@ -114,10 +114,13 @@ void local_bundle_adjuster::optimize(data::keyframe* curr_keyfrm, bool* const fo
     std::vector<uint8_t> pose_fixed;
     const camera::base* camera = curr_keyfrm->camera_;
     auto add_keyfrm = [&](data::keyframe* keyfrm, const bool is_constant) {
-        if (keyfrm->camera_->model_type_ != camera::model_type_t::Perspective)
-            throw std::runtime_error("local_bundle_adjuster: only camera::model_type_t::Perspective edges are implemented (INTEGRATION.md)");
-        if (keyfrm->camera_ != camera && (keyfrm->camera_->fx_ != camera->fx_ || keyfrm->camera_->fy_ != camera->fy_ ||
-                                          keyfrm->camera_->cx_ != camera->cx_ || keyfrm->camera_->cy_ != camera->cy_))
+        // upstream's reproj_edge_wrapper switches on keyfrm->camera_->model_type_: perspective and equirectangular edges exist on the device
+        if (keyfrm->camera_->model_type_ != camera::model_type_t::Perspective && keyfrm->camera_->model_type_ != camera::model_type_t::Equirectangular)
+            throw std::runtime_error("local_bundle_adjuster: camera::model_type_t::Fisheye edges are not implemented (INTEGRATION.md)");
+        if (keyfrm->camera_ != camera &&
+            (keyfrm->camera_->model_type_ != camera->model_type_ || keyfrm->camera_->fx_ != camera->fx_ || keyfrm->camera_->fy_ != camera->fy_ ||
+             keyfrm->camera_->cx_ != camera->cx_ || keyfrm->camera_->cy_ != camera->cy_ || keyfrm->camera_->cols_ != camera->cols_ ||
+             keyfrm->camera_->rows_ != camera->rows_))
             throw std::runtime_error("local_bundle_adjuster: all keyframes of the local map must share one camera");
         pose_index[keyfrm] = (int32_t)keyfrms.size();
         keyfrms.push_back(keyfrm);
@@ -157,7 +160,7 @@ void local_bundle_adjuster::optimize(data::keyframe* curr_keyfrm, bool* const fo
             const auto& undist_keypt = keyfrm->undist_keypts_.at(idx);
             const float x_right = keyfrm->stereo_x_right_.empty() ? -1.0f : keyfrm->stereo_x_right_.at(idx);
             const float inv_sigma_sq = keyfrm->inv_level_sigma_sq_.at((size_t)undist_keypt.octave);
-            const bool is_monocular = x_right < 0;
+            const bool is_monocular = x_right < 0 || camera->model_type_ == camera::model_type_t::Equirectangular;
             if (is_monocular) {
                 ovs_ba_edge e;
                 e.pose_idx = pit->second;
@@ -187,12 +190,17 @@ void local_bundle_adjuster::optimize(data::keyframe* curr_keyfrm, bool* const fo
     const ovs_ba_cam cam = {camera->fx_, camera->fy_, camera->cx_, camera->cy_};
     std::vector<uint8_t> mono_outlier(mono.size() + 1), stereo_outlier(stereo.size() + 1);
     static_assert(sizeof(bool) == 1, "force_stop_flag is polled as a byte");
-    const int st = ovs_local_ba_optimize(0, poses.data(), pose_fixed.data(), (int32_t)keyfrms.size(), points.data(), (int32_t)lms.size(),
-                                         mono.empty() ? nullptr : mono.data(), (int32_t)mono.size(), stereo.empty() ? nullptr : stereo.data(),
-                                         (int32_t)stereo.size(), &cam, camera->focal_x_baseline_, (int32_t)camera->setup_type_,
-                                         (int32_t)num_first_iter_, (int32_t)num_second_iter_,
-                                         reinterpret_cast<const volatile uint8_t*>(force_stop_flag), mono_outlier.data(), stereo_outlier.data(),
-                                         nullptr);
+    const int st =
+        camera->model_type_ == camera::model_type_t::Equirectangular
+            ? ovs_local_ba_optimize_equirect(0, poses.data(), pose_fixed.data(), (int32_t)keyfrms.size(), points.data(), (int32_t)lms.size(),
+                                             mono.empty() ? nullptr : mono.data(), (int32_t)mono.size(), (int32_t)camera->cols_, (int32_t)camera->rows_,
+                                             (int32_t)num_first_iter_, (int32_t)num_second_iter_,
+                                             reinterpret_cast<const volatile uint8_t*>(force_stop_flag), mono_outlier.data(), nullptr)
+            : ovs_local_ba_optimize(0, poses.data(), pose_fixed.data(), (int32_t)keyfrms.size(), points.data(), (int32_t)lms.size(),
+                                    mono.empty() ? nullptr : mono.data(), (int32_t)mono.size(), stereo.empty() ? nullptr : stereo.data(),
+                                    (int32_t)stereo.size(), &cam, camera->focal_x_baseline_, (int32_t)camera->setup_type_, (int32_t)num_first_iter_,
+                                    (int32_t)num_second_iter_, reinterpret_cast<const volatile uint8_t*>(force_stop_flag), mono_outlier.data(),
+                                    stereo_outlier.data(), nullptr);
     if (st != OVS_OK) throw std::runtime_error(std::string("ovs_local_ba_optimize failed: ") + ovs_last_error());
 
     // 7. count the outlier observations

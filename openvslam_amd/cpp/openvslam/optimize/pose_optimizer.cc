@@ -12,9 +12,11 @@ namespace optimize {
 
 unsigned int pose_optimizer::optimize(data::frame& frm) const {
     if (num_trials_ != 4 || num_each_iter_ != 10) throw std::runtime_error("pose_optimizer: only upstream's 4 x 10 schedule is implemented");
-    // only the perspective pose_opt edges exist on the device; fisheye / equirectangular frames must not be optimised with them
-    if (frm.camera_->model_type_ != camera::model_type_t::Perspective)
-        throw std::runtime_error("pose_optimizer: only camera::model_type_t::Perspective is implemented (see INTEGRATION.md)");
+    // upstream's `switch (frm.camera_->model_type_)`: perspective and equirectangular pose_opt edges exist on the device; fisheye frames
+    // (perspective edges on undistorted keypoints upstream) are out of scope
+    const bool equirect = frm.camera_->model_type_ == camera::model_type_t::Equirectangular;
+    if (!equirect && frm.camera_->model_type_ != camera::model_type_t::Perspective)
+        throw std::runtime_error("pose_optimizer: camera::model_type_t::Fisheye is not implemented (see INTEGRATION.md)");
     const unsigned int n = frm.num_keypts_;
     std::vector<ovs_pose_obs> obs;
     std::vector<unsigned int> idx_of;
@@ -34,7 +36,7 @@ unsigned int pose_optimizer::optimize(data::frame& frm) const {
         o.pos_w[2] = p(2);
         o.obs_x = kp.pt.x;
         o.obs_y = kp.pt.y;
-        o.is_stereo = has_stereo && frm.stereo_x_right_[idx] >= 0;
+        o.is_stereo = !equirect && has_stereo && frm.stereo_x_right_[idx] >= 0;
         o.obs_x_right = o.is_stereo ? frm.stereo_x_right_[idx] : 0.0;
         o.inv_sigma_sq = frm.inv_level_sigma_sq_.at((size_t)kp.octave);
         obs.push_back(o);
@@ -49,8 +51,10 @@ unsigned int pose_optimizer::optimize(data::frame& frm) const {
     const ovs_ba_cam cam = {frm.camera_->fx_, frm.camera_->fy_, frm.camera_->cx_, frm.camera_->cy_};
     std::vector<uint8_t> outlier(obs.size());
     int32_t num_valid = 0;
-    const int st = ovs_pose_optimize(0, pose_in, obs.data(), (int32_t)obs.size(), &cam, frm.camera_->focal_x_baseline_,
-                                     (int32_t)frm.camera_->setup_type_, pose_out, outlier.data(), &num_valid);
+    const int st = equirect ? ovs_pose_optimize_equirect(0, pose_in, obs.data(), (int32_t)obs.size(), (int32_t)frm.camera_->cols_,
+                                                         (int32_t)frm.camera_->rows_, pose_out, outlier.data(), &num_valid)
+                            : ovs_pose_optimize(0, pose_in, obs.data(), (int32_t)obs.size(), &cam, frm.camera_->focal_x_baseline_,
+                                                (int32_t)frm.camera_->setup_type_, pose_out, outlier.data(), &num_valid);
     if (st != OVS_OK) throw std::runtime_error(std::string("ovs_pose_optimize failed: ") + ovs_last_error());
     for (size_t k = 0; k < obs.size(); ++k) frm.outlier_flags_[idx_of[k]] = outlier[k] != 0;
     Mat44_t T;

@@ -122,6 +122,62 @@ __device__ __forceinline__ void edge_lin(const double* __restrict__ P, const dou
     for (int k = 0; k < 3; ++k) r[k] = -W * er[k];
 }
 
+// the equirectangular edge (model 1; expected: src/openvslam/optimize/g2o/se3/equirectangular_reproj_edge.{h,cc}): the operation order of
+// k_ba_linearize's equirectangular model and of the CPU checker; cam = {cols, rows, -, -}; mono edges only (rows 2 stay zero)
+__device__ __forceinline__ void edge_lin_equirect(const double* __restrict__ P, const double* __restrict__ X, const GEdge& ed, const ovs_ba_cam& cam,
+                                                  double huber, double (&Jl)[3][6], double (&Jp)[3][6], double (&r)[3], double& W, double& c2,
+                                                  double& rho0) {
+    const double qx = P[3], qy = P[4], qz = P[5], qw = P[6];
+    const double tx2 = 2 * qx, ty2 = 2 * qy, tz2 = 2 * qz;
+    const double twx = tx2 * qw, twy = ty2 * qw, twz = tz2 * qw;
+    const double txx = tx2 * qx, txy = ty2 * qx, txz = tz2 * qx;
+    const double tyy = ty2 * qy, tyz = tz2 * qy, tzz = tz2 * qz;
+    const double R[3][3] = {{1 - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1 - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1 - (txx + tyy)}};
+    const double X0 = X[0], X1 = X[1], X2 = X[2];
+    const double x = R[0][0] * X0 + R[0][1] * X1 + R[0][2] * X2 + P[0];
+    const double y = R[1][0] * X0 + R[1][1] * X1 + R[1][2] * X2 + P[1];
+    const double z = R[2][0] * X0 + R[2][1] * X1 + R[2][2] * X2 + P[2];
+    const double kPi = 3.14159265358979323846;
+    const double cols = cam.fx, rows = cam.fy;
+    const double L = sqrt((x * x + y * y) + z * z);
+    const double rxz = x * x + z * z;
+    const double theta = ovs_det_atan2(x, z);
+    const double phi = -ovs_det_asin(y / L);
+    const double e0 = ed.ox - cols * (0.5 + theta / (2.0 * kPi));
+    const double e1 = ed.oy - rows * (0.5 - phi / kPi);
+    const double w = ed.w;
+    c2 = w * (e0 * e0 + e1 * e1);
+    rho0 = c2;
+    double rho1 = 1.0;
+    const double dsqr = huber * huber;
+    if (huber > 0 && c2 > dsqr) {
+        const double sq = sqrt(c2);
+        rho0 = 2 * sq * huber - dsqr;
+        rho1 = huber / sq;
+    }
+    const double a0 = -(cols / (2.0 * kPi)) * (1.0 / rxz);
+    const double a1 = -(rows / kPi) * (1.0 / (L * sqrt(rxz)));
+    auto col = [&](double dx, double dy, double dz, double& j0, double& j1) {
+        const double dL = (1.0 / L) * ((x * dx + y * dy) + z * dz);
+        j0 = a0 * (z * dx - x * dz);
+        j1 = a1 * (L * dy - y * dL);
+    };
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Jl[0][c] = Jl[1][c] = Jl[2][c] = Jp[2][c] = 0.0;
+    col(0.0, -z, y, Jp[0][0], Jp[1][0]);
+    col(z, 0.0, -x, Jp[0][1], Jp[1][1]);
+    col(-y, x, 0.0, Jp[0][2], Jp[1][2]);
+    col(1.0, 0.0, 0.0, Jp[0][3], Jp[1][3]);
+    col(0.0, 1.0, 0.0, Jp[0][4], Jp[1][4]);
+    col(0.0, 0.0, 1.0, Jp[0][5], Jp[1][5]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) col(R[0][c], R[1][c], R[2][c], Jl[0][c], Jl[1][c]);
+    W = rho1 * w;
+    r[0] = -W * e0;
+    r[1] = -W * e1;
+    r[2] = 0.0;
+}
+
 struct GraphDev {   // device views shared by the kernels
     const GEdge* edges;
     int n_mono, n_edge, n_pose, n_pt;
@@ -132,8 +188,9 @@ struct GraphDev {   // device views shared by the kernels
     const int32_t* pose_edges;
     const uint8_t* fixed;        // [n_pose]
     const uint8_t* active;       // [n_edge] 0 = the edge is at g2o level 1 (an outlier of round 1): it contributes nothing
-    ovs_ba_cam cam;
+    ovs_ba_cam cam;        // model 1: {cols, rows, -, -}
     double bf;
+    int model;             // 0 perspective (mono / stereo edges), 1 equirectangular (mono edges)
 };
 
 // ---- linearisation ----------------------------------------------------------------------------------------------------------
@@ -160,7 +217,8 @@ __global__ __launch_bounds__(128) void k_lin_landmark(GraphDev g, const double* 
         }
         const GEdge ed = g.edges[e];
         double Jl[3][6], Jp[3][6], r[3], W, c2, rho0;
-        edge_lin(poses + 7 * (size_t)ed.pose, X, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
+        if (g.model == 1) edge_lin_equirect(poses + 7 * (size_t)ed.pose, X, ed, g.cam, huber_mono, Jl, Jp, r, W, c2, rho0);
+        else edge_lin(poses + 7 * (size_t)ed.pose, X, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
 #pragma unroll
@@ -225,7 +283,8 @@ __global__ __launch_bounds__(256) void k_lin_pose(GraphDev g, const double* __re
             const bool stereo = e >= g.n_mono;
             const GEdge ed = g.edges[e];
             double Jl[3][6], Jp[3][6], r[3], W, c2, rho0;
-            edge_lin(P, points + 3 * (size_t)ed.pt, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
+            if (g.model == 1) edge_lin_equirect(P, points + 3 * (size_t)ed.pt, ed, g.cam, huber_mono, Jl, Jp, r, W, c2, rho0);
+            else edge_lin(P, points + 3 * (size_t)ed.pt, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
             int t = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
@@ -438,6 +497,17 @@ __global__ __launch_bounds__(256) void k_edge_chi2(GraphDev g, const double* __r
     const double x = (1 - (tyy + tzz)) * X[0] + (txy - twz) * X[1] + (txz + twy) * X[2] + P[0];
     const double y = (txy + twz) * X[0] + (1 - (txx + tzz)) * X[1] + (tyz - twx) * X[2] + P[1];
     const double z = (txz - twy) * X[0] + (tyz + twx) * X[1] + (1 - (txx + tyy)) * X[2] + P[2];
+    if (g.model == 1) {   // equirectangular: reproj_edge_wrapper::depth_is_positive() is true for this camera model
+        const double kPi = 3.14159265358979323846;
+        const double L = sqrt((x * x + y * y) + z * z);
+        const double theta = ovs_det_atan2(x, z);
+        const double phi = -ovs_det_asin(y / L);
+        const double q0 = ed.ox - g.cam.fx * (0.5 + theta / (2.0 * kPi));
+        const double q1 = ed.oy - g.cam.fy * (0.5 - phi / kPi);
+        chi2[e] = ed.w * (q0 * q0 + q1 * q1);
+        depth_pos[e] = 1;
+        return;
+    }
     const double invz = 1.0 / z;
     const double u = g.cam.fx * x * invz + g.cam.cx;
     const double e0 = ed.ox - u, e1 = ed.oy - (g.cam.fy * y * invz + g.cam.cy);
@@ -462,6 +532,7 @@ struct ovs_ba_graph {
     int n_pose = 0, n_pt = 0, n_mono = 0, n_stereo = 0, n_free = 0;
     ovs_ba_cam cam{};
     double bf = 0;
+    int model = 0;
     std::vector<uint8_t> fixed;
     std::vector<int32_t> slot, slot_pose;   // pose -> reduced-system block (-1 fixed); block -> pose
     std::vector<int32_t> edge_pose, edge_pt;
@@ -496,6 +567,7 @@ struct ovs_ba_graph {
         g.active = d_active;
         g.cam = cam;
         g.bf = bf;
+        g.model = model;
         return g;
     }
     int n_edge() const { return n_mono + n_stereo; }
@@ -545,8 +617,8 @@ ovs_status ovs_ba_graph_destroy(ovs_ba_graph* g) {
     return OVS_OK;
 }
 
-ovs_status ovs_ba_graph_create(int32_t device, int32_t n_pose, const uint8_t* pose_fixed, int32_t n_pt, const ovs_ba_edge* mono, int32_t n_mono,
-                               const ovs_ba_edge_stereo* stereo, int32_t n_stereo, const ovs_ba_cam* cam, double focal_x_baseline,
+static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const uint8_t* pose_fixed, int32_t n_pt, const ovs_ba_edge* mono,
+                               int32_t n_mono, const ovs_ba_edge_stereo* stereo, int32_t n_stereo, const ovs_ba_cam* cam, double focal_x_baseline,
                                ovs_ba_graph** out) {
     if (!out || !cam || n_pose < 1 || n_pt < 1 || n_mono < 0 || n_stereo < 0 || (n_mono > 0 && !mono) || (n_stereo > 0 && !stereo))
         return OVS_ERR_INVALID;
@@ -569,6 +641,7 @@ ovs_status ovs_ba_graph_create(int32_t device, int32_t n_pose, const uint8_t* po
     g->n_stereo = n_stereo;
     g->cam = *cam;
     g->bf = focal_x_baseline;
+    g->model = model;
     g->fixed.assign((size_t)n_pose, 0);
     if (pose_fixed) g->fixed.assign(pose_fixed, pose_fixed + n_pose);
     g->slot.assign((size_t)n_pose, -1);
@@ -687,6 +760,19 @@ ovs_status ovs_ba_graph_create(int32_t device, int32_t n_pose, const uint8_t* po
                      now() - t0, t1 - t0, t2 - t1, blob.bytes.size() / 1e6, now() - t2);
     *out = g;
     return OVS_OK;
+}
+
+ovs_status ovs_ba_graph_create(int32_t device, int32_t n_pose, const uint8_t* pose_fixed, int32_t n_pt, const ovs_ba_edge* mono, int32_t n_mono,
+                               const ovs_ba_edge_stereo* stereo, int32_t n_stereo, const ovs_ba_cam* cam, double focal_x_baseline,
+                               ovs_ba_graph** out) {
+    return graph_create(0, device, n_pose, pose_fixed, n_pt, mono, n_mono, stereo, n_stereo, cam, focal_x_baseline, out);
+}
+
+ovs_status ovs_ba_graph_create_equirect(int32_t device, int32_t n_pose, const uint8_t* pose_fixed, int32_t n_pt, const ovs_ba_edge* mono,
+                                        int32_t n_mono, int32_t cols, int32_t rows, ovs_ba_graph** out) {
+    if (cols < 1 || rows < 1) return OVS_ERR_INVALID;
+    const ovs_ba_cam cam = {(double)cols, (double)rows, 0.0, 0.0};
+    return graph_create(1, device, n_pose, pose_fixed, n_pt, mono, n_mono, nullptr, 0, &cam, 0.0, out);
 }
 
 ovs_status ovs_ba_graph_linearize_dev(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo,

@@ -293,12 +293,12 @@ struct GraphGuard {
 
 }   // namespace
 
-extern "C" {
-
-ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* pose_fixed, int32_t n_pose, double* points, int32_t n_pt,
-                                 const ovs_ba_edge* mono, int32_t n_mono, const ovs_ba_edge_stereo* stereo, int32_t n_stereo,
-                                 const ovs_ba_cam* cam, double focal_x_baseline, int32_t setup_type, int32_t num_first_iter, int32_t num_second_iter,
-                                 const volatile uint8_t* force_stop_flag, uint8_t* mono_outlier, uint8_t* stereo_outlier, double* info) {
+// model 0: perspective (ovs_ba_graph_create), model 1: equirectangular (cam = {cols, rows, -, -}, mono edges only)
+static ovs_status local_ba_optimize_impl(int model, int32_t device, double* poses, const uint8_t* pose_fixed, int32_t n_pose, double* points,
+                                         int32_t n_pt, const ovs_ba_edge* mono, int32_t n_mono, const ovs_ba_edge_stereo* stereo, int32_t n_stereo,
+                                         const ovs_ba_cam* cam, double focal_x_baseline, int32_t setup_type, int32_t num_first_iter,
+                                         int32_t num_second_iter, const volatile uint8_t* force_stop_flag, uint8_t* mono_outlier,
+                                         uint8_t* stereo_outlier, double* info) {
     if (!poses || !points || !cam || n_pose < 1 || n_pt < 1 || n_mono < 0 || n_stereo < 0 || (n_mono > 0 && (!mono || !mono_outlier)) ||
         (n_stereo > 0 && (!stereo || !stereo_outlier)) || num_first_iter < 0 || num_second_iter < 0)
         return OVS_ERR_INVALID;
@@ -308,7 +308,8 @@ ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* p
     GraphGuard g1;
     const bool trace = std::getenv("OVS_BA_TRACE") != nullptr;
     const double t_begin = Lm::now();
-    ovs_status st = ovs_ba_graph_create(device, n_pose, pose_fixed, n_pt, mono, n_mono, stereo, n_stereo, cam, focal_x_baseline, &g1.g);
+    ovs_status st = model == 1 ? ovs_ba_graph_create_equirect(device, n_pose, pose_fixed, n_pt, mono, n_mono, (int32_t)cam->fx, (int32_t)cam->fy, &g1.g)
+                               : ovs_ba_graph_create(device, n_pose, pose_fixed, n_pt, mono, n_mono, stereo, n_stereo, cam, focal_x_baseline, &g1.g);
     if (st != OVS_OK) return st;
     const double t_g1 = Lm::now();
     const size_t ne = (size_t)n_mono + n_stereo;
@@ -375,6 +376,25 @@ ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* p
         std::memcpy(info, info_l, sizeof(info_l));
     }
     return OVS_OK;
+}
+
+extern "C" {
+
+ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* pose_fixed, int32_t n_pose, double* points, int32_t n_pt,
+                                 const ovs_ba_edge* mono, int32_t n_mono, const ovs_ba_edge_stereo* stereo, int32_t n_stereo,
+                                 const ovs_ba_cam* cam, double focal_x_baseline, int32_t setup_type, int32_t num_first_iter, int32_t num_second_iter,
+                                 const volatile uint8_t* force_stop_flag, uint8_t* mono_outlier, uint8_t* stereo_outlier, double* info) {
+    return local_ba_optimize_impl(0, device, poses, pose_fixed, n_pose, points, n_pt, mono, n_mono, stereo, n_stereo, cam, focal_x_baseline, setup_type,
+                                  num_first_iter, num_second_iter, force_stop_flag, mono_outlier, stereo_outlier, info);
+}
+
+ovs_status ovs_local_ba_optimize_equirect(int32_t device, double* poses, const uint8_t* pose_fixed, int32_t n_pose, double* points, int32_t n_pt,
+                                          const ovs_ba_edge* mono, int32_t n_mono, int32_t cols, int32_t rows, int32_t num_first_iter,
+                                          int32_t num_second_iter, const volatile uint8_t* force_stop_flag, uint8_t* mono_outlier, double* info) {
+    if (cols < 1 || rows < 1) return OVS_ERR_INVALID;
+    const ovs_ba_cam cam = {(double)cols, (double)rows, 0.0, 0.0};
+    return local_ba_optimize_impl(1, device, poses, pose_fixed, n_pose, points, n_pt, mono, n_mono, nullptr, 0, &cam, 0.0, 0, num_first_iter,
+                                  num_second_iter, force_stop_flag, mono_outlier, nullptr, info);
 }
 
 }   // extern "C"

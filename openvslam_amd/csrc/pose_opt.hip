@@ -87,8 +87,61 @@ __device__ bool solve6_d(const double* H, double lambda, const double* b, double
 }
 
 // chi2 of one observation; with acc != nullptr also its 21 (upper triangle, row-major) + 6 + 1 contributions: H, b, robust chi2
+// equirectangular_pose_opt_edge (expected: src/openvslam/optimize/g2o/se3/equirectangular_pose_opt_edge.{h,cc}): cam = {cols, rows, -, -};
+// the operation order of the CPU checker (and of the pose part of k_ba_linearize's equirectangular model); asin / atan2 from ovs_detmath.h
+__device__ __forceinline__ double pose_edge_equirect(const double* R, const double* t, const ovs_pose_obs& o, const ovs_ba_cam& cam, double delta,
+                                                     double* acc) {
+    const double x = ((R[0] * o.pos_w[0] + R[1] * o.pos_w[1]) + R[2] * o.pos_w[2]) + t[0];
+    const double y = ((R[3] * o.pos_w[0] + R[4] * o.pos_w[1]) + R[5] * o.pos_w[2]) + t[1];
+    const double z = ((R[6] * o.pos_w[0] + R[7] * o.pos_w[1]) + R[8] * o.pos_w[2]) + t[2];
+    const double kPi = 3.14159265358979323846;
+    const double cols = cam.fx, rows = cam.fy;
+    const double L = sqrt((x * x + y * y) + z * z);
+    const double rxz = x * x + z * z;
+    const double theta = ovs_det_atan2(x, z);
+    const double phi = -ovs_det_asin(y / L);
+    const double e0 = o.obs_x - cols * (0.5 + theta / (2.0 * kPi));
+    const double e1 = o.obs_y - rows * (0.5 - phi / kPi);
+    const double c2 = o.inv_sigma_sq * (e0 * e0 + e1 * e1);
+    if (!acc) return c2;
+    double rho0 = c2, rho1 = 1.0;
+    const double dsqr = delta * delta;
+    if (delta > 0 && c2 > dsqr) {
+        const double sq = sqrt(c2);
+        rho0 = 2 * sq * delta - dsqr;
+        rho1 = delta / sq;
+    }
+    const double a0 = -(cols / (2.0 * kPi)) * (1.0 / rxz);
+    const double a1 = -(rows / kPi) * (1.0 / (L * sqrt(rxz)));
+    double J[2][6];
+    auto col = [&](double dx, double dy, double dz, double& j0, double& j1) {
+        const double dL = (1.0 / L) * ((x * dx + y * dy) + z * dz);
+        j0 = a0 * (z * dx - x * dz);
+        j1 = a1 * (L * dy - y * dL);
+    };
+    col(0.0, -z, y, J[0][0], J[1][0]);
+    col(z, 0.0, -x, J[0][1], J[1][1]);
+    col(-y, x, 0.0, J[0][2], J[1][2]);
+    col(1.0, 0.0, 0.0, J[0][3], J[1][3]);
+    col(0.0, 1.0, 0.0, J[0][4], J[1][4]);
+    col(0.0, 0.0, 1.0, J[0][5], J[1][5]);
+    const double W = rho1 * o.inv_sigma_sq;
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int b = a; b < 6; ++b) acc[k++] += W * (J[0][a] * J[0][b] + J[1][a] * J[1][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] += -(W * (J[0][a] * e0 + J[1][a] * e1));
+    acc[27] += rho0;
+    return c2;
+}
+
+template <int MODEL>
 __device__ __forceinline__ double pose_edge(const double* R, const double* t, const ovs_pose_obs& o, const ovs_ba_cam& cam, double bf,
                                             double delta, double* acc) {
+    if (MODEL == 1) return pose_edge_equirect(R, t, o, cam, delta, acc);
     const double x = ((R[0] * o.pos_w[0] + R[1] * o.pos_w[1]) + R[2] * o.pos_w[2]) + t[0];
     const double y = ((R[3] * o.pos_w[0] + R[4] * o.pos_w[1]) + R[5] * o.pos_w[2]) + t[1];
     const double z = ((R[6] * o.pos_w[0] + R[7] * o.pos_w[1]) + R[8] * o.pos_w[2]) + t[2];
@@ -153,6 +206,7 @@ constexpr int kPoseMaxObs = 8192;   // <= 32 observations per thread: the inlier
 constexpr int kPoseThreads = 256;   // one workgroup per frame: 0.75 ms per 2000-observation frame; 128 threads: 1.1 ms, 512: 0.94 ms, 1024: 1.5 ms (cross-wave barriers and reductions)
 constexpr int kPoseWaves = kPoseThreads / 64;
 
+template <int MODEL>   // 0 perspective (mono / stereo edges), 1 equirectangular (mono edges)
 __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __restrict__ poses_in, const ovs_pose_obs* __restrict__ obs_all,
                                                       const int32_t* __restrict__ obs_offsets, ovs_ba_cam cam, double bf, int setup_type,
                                                       double* __restrict__ poses_out, uint8_t* __restrict__ outlier_all,
@@ -221,7 +275,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                     for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k)
                         if ((active >> k) & 1u) {
                             const ovs_pose_obs o = obs[i];
-                            pose_edge(R, t, o, cam, bf, robust ? huber : 0.0, acc);
+                            pose_edge<MODEL>(R, t, o, cam, bf, robust ? huber : 0.0, acc);
                         }
                 }
                 reduce(acc, 28);
@@ -274,7 +328,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                         for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k)
                             if ((active >> k) & 1u) {
                                 const ovs_pose_obs o = obs[i];
-                                const double c2 = pose_edge(R, t, o, cam, bf, 0.0, nullptr);
+                                const double c2 = pose_edge<MODEL>(R, t, o, cam, bf, 0.0, nullptr);
                                 const double delta = robust ? huber : 0.0;
                                 double r = c2;
                                 if (delta > 0 && c2 > delta * delta) r = 2 * sqrt(c2) * delta - delta * delta;
@@ -317,8 +371,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                 for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k) {
                     const ovs_pose_obs o = obs[i];
                     const bool wa = (was_active >> k) & 1u;
-                    const double c2 = pose_edge(wa ? Re : R, wa ? te : t, o, cam, bf, 0.0, nullptr);
-                    const bool out = (o.is_stereo ? kChi3D : kChi2D) < c2;
+                    const double c2 = pose_edge<MODEL>(wa ? Re : R, wa ? te : t, o, cam, bf, 0.0, nullptr);
+                    const bool out = ((MODEL == 0 && o.is_stereo) ? kChi3D : kChi2D) < c2;
                     outlier[i] = out ? 1 : 0;
                     if (out) ++bad;
                     else active |= 1u << k;
@@ -346,18 +400,39 @@ using namespace ovs;
 
 extern "C" {
 
-ovs_status ovs_pose_optimize_batch_dev(const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
-                                       const ovs_ba_cam* cam, double focal_x_baseline, int32_t setup_type, double* d_poses_out,
-                                       uint8_t* d_outlier, int32_t* d_num_valid, void* stream) {
-    if (!d_poses_in || !d_obs || !d_obs_offsets || !cam || !d_poses_out || !d_outlier || !d_num_valid || batch < 1) return OVS_ERR_INVALID;
-    hipLaunchKernelGGL(k_pose_optimize, dim3(batch), dim3(kPoseThreads), 0, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, *cam,
-                       focal_x_baseline, (int)setup_type, d_poses_out, d_outlier, d_num_valid);
+static ovs_status pose_optimize_batch_dev(int model, const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
+                                          const ovs_ba_cam& cam, double focal_x_baseline, int32_t setup_type, double* d_poses_out,
+                                          uint8_t* d_outlier, int32_t* d_num_valid, void* stream) {
+    if (!d_poses_in || !d_obs || !d_obs_offsets || !d_poses_out || !d_outlier || !d_num_valid || batch < 1) return OVS_ERR_INVALID;
+    if (model == 1)
+        hipLaunchKernelGGL(k_pose_optimize<1>, dim3(batch), dim3(kPoseThreads), 0, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, cam,
+                           0.0, 0, d_poses_out, d_outlier, d_num_valid);
+    else
+        hipLaunchKernelGGL(k_pose_optimize<0>, dim3(batch), dim3(kPoseThreads), 0, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, cam,
+                           focal_x_baseline, (int)setup_type, d_poses_out, d_outlier, d_num_valid);
     OVS_HIP_TRY(hipGetLastError());
     return OVS_OK;
 }
 
-ovs_status ovs_pose_optimize(int32_t device, const double* pose_cw_in, const ovs_pose_obs* obs, int32_t n_obs, const ovs_ba_cam* cam,
-                             double focal_x_baseline, int32_t setup_type, double* pose_cw_out, uint8_t* outlier_flags, int32_t* num_valid) {
+ovs_status ovs_pose_optimize_batch_dev(const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
+                                       const ovs_ba_cam* cam, double focal_x_baseline, int32_t setup_type, double* d_poses_out,
+                                       uint8_t* d_outlier, int32_t* d_num_valid, void* stream) {
+    if (!cam) return OVS_ERR_INVALID;
+    return pose_optimize_batch_dev(0, d_poses_in, d_obs, d_obs_offsets, batch, *cam, focal_x_baseline, setup_type, d_poses_out, d_outlier, d_num_valid,
+                                   stream);
+}
+
+ovs_status ovs_pose_optimize_equirect_batch_dev(const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
+                                                int32_t cols, int32_t rows, double* d_poses_out, uint8_t* d_outlier, int32_t* d_num_valid,
+                                                void* stream) {
+    if (cols < 1 || rows < 1) return OVS_ERR_INVALID;
+    const ovs_ba_cam cam = {(double)cols, (double)rows, 0.0, 0.0};
+    return pose_optimize_batch_dev(1, d_poses_in, d_obs, d_obs_offsets, batch, cam, 0.0, 0, d_poses_out, d_outlier, d_num_valid, stream);
+}
+
+static ovs_status pose_optimize_host(int model, int32_t device, const double* pose_cw_in, const ovs_pose_obs* obs, int32_t n_obs,
+                                     const ovs_ba_cam* cam, double focal_x_baseline, int32_t setup_type, double* pose_cw_out,
+                                     uint8_t* outlier_flags, int32_t* num_valid) {
     if (!pose_cw_in || !cam || !pose_cw_out || !num_valid || n_obs < 0 || (n_obs > 0 && (!obs || !outlier_flags))) return OVS_ERR_INVALID;
     if (n_obs > kPoseMaxObs) return OVS_ERR_CAPACITY;
     if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
@@ -398,9 +473,9 @@ ovs_status ovs_pose_optimize(int32_t device, const double* pose_cw_in, const ovs
         P_TRY(hipMemcpy(d, pose_cw_in, sizeof(double) * 12, hipMemcpyHostToDevice));
         if (n_obs) P_TRY(hipMemcpy(d + off_obs, obs, sizeof(ovs_pose_obs) * (size_t)n_obs, hipMemcpyHostToDevice));
         P_TRY(hipMemcpy(d + off_off, offs, sizeof(offs), hipMemcpyHostToDevice));
-        st = ovs_pose_optimize_batch_dev(reinterpret_cast<double*>(d), reinterpret_cast<ovs_pose_obs*>(d + off_obs),
-                                         reinterpret_cast<int32_t*>(d + off_off), 1, cam, focal_x_baseline, setup_type,
-                                         reinterpret_cast<double*>(d + off_out), d + off_fl, reinterpret_cast<int32_t*>(d + off_nv), nullptr);
+        st = pose_optimize_batch_dev(model, reinterpret_cast<double*>(d), reinterpret_cast<ovs_pose_obs*>(d + off_obs),
+                                     reinterpret_cast<int32_t*>(d + off_off), 1, *cam, focal_x_baseline, setup_type,
+                                     reinterpret_cast<double*>(d + off_out), d + off_fl, reinterpret_cast<int32_t*>(d + off_nv), nullptr);
         if (st != OVS_OK) break;
         st = OVS_ERR_HIP;
         P_TRY(hipStreamSynchronize(nullptr));
@@ -411,6 +486,18 @@ ovs_status ovs_pose_optimize(int32_t device, const double* pose_cw_in, const ovs
 #undef P_TRY
     } while (0);
     return st;
+}
+
+ovs_status ovs_pose_optimize(int32_t device, const double* pose_cw_in, const ovs_pose_obs* obs, int32_t n_obs, const ovs_ba_cam* cam,
+                             double focal_x_baseline, int32_t setup_type, double* pose_cw_out, uint8_t* outlier_flags, int32_t* num_valid) {
+    return pose_optimize_host(0, device, pose_cw_in, obs, n_obs, cam, focal_x_baseline, setup_type, pose_cw_out, outlier_flags, num_valid);
+}
+
+ovs_status ovs_pose_optimize_equirect(int32_t device, const double* pose_cw_in, const ovs_pose_obs* obs, int32_t n_obs, int32_t cols, int32_t rows,
+                                      double* pose_cw_out, uint8_t* outlier_flags, int32_t* num_valid) {
+    if (cols < 1 || rows < 1) return OVS_ERR_INVALID;
+    const ovs_ba_cam cam = {(double)cols, (double)rows, 0.0, 0.0};
+    return pose_optimize_host(1, device, pose_cw_in, obs, n_obs, &cam, 0.0, 0, pose_cw_out, outlier_flags, num_valid);
 }
 
 }   // extern "C"

@@ -252,6 +252,48 @@ def synth_pose_frame(dtype, n, seed, stereo_frac=0.4, outlier_frac=0.1, pose_err
     return T0, obs, cam, bf, (Rt, tt, bad)
 
 
+def equirect_project(pc, cols, rows):
+    """camera::equirectangular::reproject_to_image on camera-frame points (numpy; for generating test inputs)."""
+    theta = np.arctan2(pc[:, 0], pc[:, 2])
+    phi = -np.arcsin(pc[:, 1] / np.linalg.norm(pc, axis=1))
+    return cols * (0.5 + theta / (2 * np.pi)), rows * (0.5 - phi / np.pi)
+
+
+def synth_pose_frame_equirect(dtype, n, seed, cols=3840, rows=1920, outlier_frac=0.1, pose_err=1.0, seam_frac=0.0, pole_frac=0.0):
+    """An equirectangular frame for optimize::pose_optimizer (BASELINE configs[3] geometry): n landmarks ALL AROUND the camera (bearings over
+    the whole sphere), observations with level-dependent pixel noise, gross outliers, a perturbed initial pose. seam_frac / pole_frac of the
+    landmarks are placed within a few pixels of the +-180 degree seam (behind the camera) / of the poles, where the projection is most
+    sensitive. Returns (T0 3x4, obs, cols, rows, (R_true, t_true, outlier_mask))."""
+    rng = np.random.default_rng(seed)
+    Rt = _rot_axis((0, 1, 0), 25) @ _rot_axis((1, 0, 0), -7)
+    tt = np.array([0.3, -0.1, 0.2])
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    n_seam, n_pole = int(n * seam_frac), int(n * pole_frac)
+    if n_seam:   # camera-frame bearings just either side of theta = +-pi
+        th = np.pi - rng.uniform(0.0005, 0.01, n_seam) * rng.choice([-1, 1], n_seam)
+        ph = rng.uniform(-1.0, 1.0, n_seam)
+        d[:n_seam] = np.stack([np.sin(th) * np.cos(ph), -np.sin(ph), np.cos(th) * np.cos(ph)], 1)
+    if n_pole:
+        ph = (np.pi / 2 - rng.uniform(0.002, 0.03, n_pole)) * rng.choice([-1, 1], n_pole)
+        th = rng.uniform(-np.pi, np.pi, n_pole)
+        d[n_seam:n_seam + n_pole] = np.stack([np.sin(th) * np.cos(ph), -np.sin(ph), np.cos(th) * np.cos(ph)], 1)
+    pc = d * rng.uniform(3, 25, n)[:, None]
+    X = (pc - tt) @ Rt                     # world points whose camera-frame positions are pc
+    u, v = equirect_project(pc, cols, rows)
+    obs = np.zeros(n, dtype)
+    obs["pos_w"] = X
+    sig = 1.2 ** rng.integers(0, 8, n)
+    obs["obs_x"] = u + rng.normal(0, 1, n) * sig
+    obs["obs_y"] = v + rng.normal(0, 1, n) * sig
+    obs["inv_sigma_sq"] = 1 / sig ** 2
+    bad = rng.random(n) < outlier_frac
+    obs["obs_x"][bad] += rng.uniform(20, 100, int(bad.sum()))
+    T0 = np.concatenate([_rot_axis((0, 1, 0), 25 + 0.8 * pose_err) @ _rot_axis((1, 0, 0), -7 + 0.4 * pose_err),
+                         (tt + pose_err * np.array([0.05, 0.03, -0.04]))[:, None]], 1)
+    return T0, obs, cols, rows, (Rt, tt, bad)
+
+
 def synth_vocabulary(k=10, depth=4, seed=0, flip=28):
     """A stand-in ORB vocabulary tree (the real orb_vocab file is not in the container): node 0 is the root, every inner node has k
     children (the last inner level keeps between k/2 and k so ragged nodes are exercised), a child's descriptor is its parent's with

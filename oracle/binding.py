@@ -559,6 +559,31 @@ def pose_optimize(pose_cw, obs, cam, focal_x_baseline=0.0, setup_type=None):
     return np.concatenate([pout[:9].reshape(3, 3), pout[9:, None]], 1), out[:len(o)].astype(bool), nv.value
 
 
+def ba_edge_chi2_equirect(poses, points, edges, cols, rows):
+    """chi2 of every equirectangular edge at (poses n x 7, points) -- ovo_ba_edge_chi2_equirect."""
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    out = np.zeros(max(len(edges), 1))
+    L = lib()
+    L.ovo_ba_edge_chi2_equirect.restype = C.c_int
+    rc = L.ovo_ba_edge_chi2_equirect(_p(poses), len(poses), _p(points), len(points), _p(edges), len(edges), int(cols), int(rows), _p(out))
+    assert rc == 0, rc
+    return out[:len(edges)]
+
+
+def pose_optimize_equirect(pose_cw, obs, cols, rows):
+    """pose_optimizer::optimize for an equirectangular frame (ovo_pose.cc: equirectangular_pose_opt_edge). Returns (pose 3x4, flags, num_valid)."""
+    o = np.ascontiguousarray(obs, POSE_OBS_DTYPE)
+    pin = _pose12(pose_cw)
+    pout = np.zeros(12)
+    out = np.zeros(max(len(o), 1), np.uint8)
+    nv = C.c_int()
+    rc = lib().ovo_pose_optimize_equirect(_p(pin), _p(o), len(o), C.c_int(int(cols)), C.c_int(int(rows)), _p(pout), _p(out), C.byref(nv))
+    assert rc == 0
+    return np.concatenate([pout[:9].reshape(3, 3), pout[9:, None]], 1), out[:len(o)].astype(bool), nv.value
+
+
 def ba_linearize_equirect(poses, pose_fixed, points, edges, cols, rows, huber_delta):
     """Oracle restatement of the equirectangular reprojection edge (ovo_ba.cc). Returns dict(Hpp, bp, Hll, bl, Hpl, chi2)."""
     poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)

@@ -69,8 +69,9 @@ def _oplus(R, t, u):
 
 
 class _Graph:
-    def __init__(self, n_pose, n_pt, fixed, mono, stereo, cam, bf, setup_type=0):
+    def __init__(self, n_pose, n_pt, fixed, mono, stereo, cam, bf, setup_type=0, equirect=None):
         self.n_pose, self.n_pt, self.cam, self.bf = n_pose, n_pt, cam, bf
+        self.equirect = equirect   # None: perspective edges; (cols, rows): equirectangular_reproj_edge (mono edges only)
         self.setup_type = setup_type
         self.fixed = np.zeros(n_pose, np.uint8) if fixed is None else np.ascontiguousarray(fixed, np.uint8)
         self.free = np.flatnonzero(self.fixed == 0)
@@ -104,6 +105,8 @@ class _Graph:
         for k, (R, t) in enumerate(T):
             poses[k, :3] = t
             poses[k, 3:] = _rot_to_quat(R)
+        if self.equirect is not None:
+            return ob.ba_linearize_equirect(poses, self.fixed, X, self.mono, self.equirect[0], self.equirect[1], SQRT_CHI2_MONO if robust else 0.0)
         out = ob.ba_linearize(poses, self.fixed, X, self.mono, self.cam,
                               (SQRT_CHI2_MONO if self.setup_type == 0 else SQRT_CHI2_STEREO) if robust else 0.0)
         if len(self.stereo):
@@ -114,6 +117,13 @@ class _Graph:
         return out
 
     def edge_chi2(self, T, X):
+        if self.equirect is not None:   # depth_is_positive() is always true for the equirectangular model
+            poses = np.zeros((self.n_pose, 7))
+            for k, (R, t) in enumerate(T):
+                poses[k, :3] = t
+                poses[k, 3:] = _rot_to_quat(R)
+            chi = ob.ba_edge_chi2_equirect(poses, X, self.mono, self.equirect[0], self.equirect[1])
+            return chi, np.ones(len(chi), bool)
         R = np.stack([r for r, _ in T])
         t = np.stack([tt for _, tt in T])
         fx, fy, cx, cy = self.cam
@@ -220,8 +230,14 @@ class _Graph:
         return T, X, chi_start, chi, n_iter
 
 
+def local_ba_optimize_equirect(poses, pose_fixed, points, mono, cols, rows, num_first_iter=5, num_second_iter=10):
+    """The same two rounds over equirectangular_reproj_edge (every edge monocular, Monocular rig)."""
+    return local_ba_optimize(poses, pose_fixed, points, mono, (float(cols), float(rows), 0.0, 0.0), None, 0.0, num_first_iter, num_second_iter,
+                             setup_type=0, equirect=(int(cols), int(rows)))
+
+
 def local_ba_optimize(poses, pose_fixed, points, mono, cam, stereo=None, focal_x_baseline=0.0, num_first_iter=5, num_second_iter=10,
-                      setup_type=None):
+                      setup_type=None, equirect=None):
     if setup_type is None:
         setup_type = 1 if focal_x_baseline != 0.0 else 0
     poses = np.array(poses, np.float64).reshape(-1, 7)
@@ -230,7 +246,7 @@ def local_ba_optimize(poses, pose_fixed, points, mono, cam, stereo=None, focal_x
     stereo = np.ascontiguousarray(stereo if stereo is not None else np.zeros(0, ob.BA_EDGE_STEREO_DTYPE), ob.BA_EDGE_STEREO_DTYPE)
     n_pose, n_pt, nm = len(poses), len(X), len(mono)
     T = [(_quat_to_rot(p[3:]), p[:3].copy()) for p in poses]
-    G = _Graph(n_pose, n_pt, pose_fixed, mono, stereo, tuple(cam), focal_x_baseline, setup_type)
+    G = _Graph(n_pose, n_pt, pose_fixed, mono, stereo, tuple(cam), focal_x_baseline, setup_type, equirect)
     info = np.zeros(6)
     T, X, info[0], info[1], info[4] = G.run_round(T, X, num_first_iter, True)
     chi_r1, depth = G.edge_chi2(T, X)

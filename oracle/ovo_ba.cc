@@ -189,6 +189,34 @@ int ovo_ba_linearize_equirect(const double* poses, const uint8_t* pose_fixed, in
     return 0;
 }
 
+// per-edge chi2 = e^T Omega e of the equirectangular edge at (poses, points) -- what g2o's edge->chi2() returns after computeError(); used by
+// the local-BA restatement (lba.py) for the outlier gates, with the SAME asin / atan2 as the linearisation above
+int ovo_ba_edge_chi2_equirect(const double* poses, int n_pose, const double* points, int n_pt, const ovo_ba_edge* edges, int n_edge, int cols,
+                              int rows, double* chi2) {
+    const double kPi = 3.14159265358979323846;
+    for (int e = 0; e < n_edge; ++e) {
+        const ovo_ba_edge& ed = edges[e];
+        if (ed.pose_idx < 0 || ed.pose_idx >= n_pose || ed.point_idx < 0 || ed.point_idx >= n_pt) return -1;
+        const double* P = poses + 7 * ed.pose_idx;
+        const double* X = points + 3 * ed.point_idx;
+        const double qx = P[3], qy = P[4], qz = P[5], qw = P[6];
+        const double tx2 = 2 * qx, ty2 = 2 * qy, tz2 = 2 * qz;
+        const double twx = tx2 * qw, twy = ty2 * qw, twz = tz2 * qw;
+        const double txx = tx2 * qx, txy = ty2 * qx, txz = tz2 * qx;
+        const double tyy = ty2 * qy, tyz = tz2 * qy, tzz = tz2 * qz;
+        const double x = (1 - (tyy + tzz)) * X[0] + (txy - twz) * X[1] + (txz + twy) * X[2] + P[0];
+        const double y = (txy + twz) * X[0] + (1 - (txx + tzz)) * X[1] + (tyz - twx) * X[2] + P[1];
+        const double z = (txz - twy) * X[0] + (tyz + twx) * X[1] + (1 - (txx + tyy)) * X[2] + P[2];
+        const double L = std::sqrt((x * x + y * y) + z * z);
+        const double theta = ovs_det_atan2(x, z);
+        const double phi = -ovs_det_asin(y / L);
+        const double e0 = ed.obs_x - cols * (0.5 + theta / (2.0 * kPi));
+        const double e1 = ed.obs_y - rows * (0.5 - phi / kPi);
+        chi2[e] = ed.inv_sigma_sq * (e0 * e0 + e1 * e1);
+    }
+    return 0;
+}
+
 typedef struct ovo_ba_edge_stereo {
     int32_t pose_idx, point_idx;
     double obs_x, obs_y, obs_x_right;

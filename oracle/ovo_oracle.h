@@ -227,6 +227,9 @@ typedef struct ovo_pose_obs {   /* one observed landmark of the frame: pose_opt_
 /* pose_cw: 12 doubles (rotation row-major, translation). cam4 = fx, fy, cx, cy. outlier[n] = frm.outlier_flags_. */
 int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* obs, int n, const double* cam4, double focal_x_baseline, int setup_type,
                       double* pose_cw_out, uint8_t* outlier, int* num_valid);
+/* equirectangular frames (equirectangular_pose_opt_edge): monocular edges only, Monocular rig; see ovo_pose.cc */
+int ovo_pose_optimize_equirect(const double* pose_cw_in, const ovo_pose_obs* obs, int n, int cols, int rows, double* pose_cw_out,
+                               uint8_t* outlier, int* num_valid);
 
 #ifdef __cplusplus
 }

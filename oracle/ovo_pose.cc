@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "ovo_oracle.h"
+#include "../include/ovs_detmath.h"
 
 namespace {
 
@@ -62,7 +63,55 @@ struct Lin {
 };
 
 // residual, chi2 and (optionally) the edge's contribution to H, b for one observation
-inline double edge_eval(const Pose& T, const ovo_pose_obs& o, const double* cam, double bf, double delta, Lin* lin) {
+// equirectangular variant (expected: src/openvslam/optimize/g2o/se3/equirectangular_pose_opt_edge.{h,cc}): cam = {cols, rows, -, -},
+// e = obs - (cols (1/2 + atan2(x, z) / 2 pi), rows (1/2 + asin(y / |p|) / pi)), no seam wrap-around (ORACLE_SPEC rule 26); the 2 x 6
+// Jacobian is the pose part of ovo_ba_linearize_equirect, same operation order. asin / atan2: include/ovs_detmath.h (shared, rule 24).
+inline double edge_eval_equirect(const Pose& T, const ovo_pose_obs& o, const double* cam, double delta, Lin* lin) {
+    const double x = ((T.R[0] * o.pos_w[0] + T.R[1] * o.pos_w[1]) + T.R[2] * o.pos_w[2]) + T.t[0];
+    const double y = ((T.R[3] * o.pos_w[0] + T.R[4] * o.pos_w[1]) + T.R[5] * o.pos_w[2]) + T.t[1];
+    const double z = ((T.R[6] * o.pos_w[0] + T.R[7] * o.pos_w[1]) + T.R[8] * o.pos_w[2]) + T.t[2];
+    const double kPi = 3.14159265358979323846;
+    const double cols = cam[0], rows = cam[1];
+    const double L = std::sqrt((x * x + y * y) + z * z);
+    const double rxz = x * x + z * z;
+    const double theta = ovs_det_atan2(x, z);
+    const double phi = -ovs_det_asin(y / L);
+    const double e0 = o.obs_x - cols * (0.5 + theta / (2.0 * kPi));
+    const double e1 = o.obs_y - rows * (0.5 - phi / kPi);
+    const double c2 = o.inv_sigma_sq * (e0 * e0 + e1 * e1);
+    if (!lin) return c2;
+    double rho0 = c2, rho1 = 1.0;
+    const double dsqr = delta * delta;
+    if (delta > 0 && c2 > dsqr) {
+        const double sq = std::sqrt(c2);
+        rho0 = 2 * sq * delta - dsqr;
+        rho1 = delta / sq;
+    }
+    lin->chi_robust += rho0;
+    const double a0 = -(cols / (2.0 * kPi)) * (1.0 / rxz);
+    const double a1 = -(rows / kPi) * (1.0 / (L * std::sqrt(rxz)));
+    double J[2][6];
+    auto col = [&](double dx, double dy, double dz, double& j0, double& j1) {
+        const double dL = (1.0 / L) * ((x * dx + y * dy) + z * dz);
+        j0 = a0 * (z * dx - x * dz);
+        j1 = a1 * (L * dy - y * dL);
+    };
+    col(0.0, -z, y, J[0][0], J[1][0]);
+    col(z, 0.0, -x, J[0][1], J[1][1]);
+    col(-y, x, 0.0, J[0][2], J[1][2]);
+    col(1.0, 0.0, 0.0, J[0][3], J[1][3]);
+    col(0.0, 1.0, 0.0, J[0][4], J[1][4]);
+    col(0.0, 0.0, 1.0, J[0][5], J[1][5]);
+    const double W = rho1 * o.inv_sigma_sq;
+    for (int a = 0; a < 6; ++a) {
+        for (int b = 0; b < 6; ++b) lin->H[6 * a + b] += W * (J[0][a] * J[0][b] + J[1][a] * J[1][b]);
+        lin->b[a] += -(W * (J[0][a] * e0 + J[1][a] * e1));
+    }
+    return c2;
+}
+
+inline double edge_eval(const Pose& T, const ovo_pose_obs& o, const double* cam, double bf, double delta, Lin* lin, int model = 0) {
+    if (model == 1) return edge_eval_equirect(T, o, cam, delta, lin);
     const double x = ((T.R[0] * o.pos_w[0] + T.R[1] * o.pos_w[1]) + T.R[2] * o.pos_w[2]) + T.t[0];
     const double y = ((T.R[3] * o.pos_w[0] + T.R[4] * o.pos_w[1]) + T.R[5] * o.pos_w[2]) + T.t[1];
     const double z = ((T.R[6] * o.pos_w[0] + T.R[7] * o.pos_w[1]) + T.R[8] * o.pos_w[2]) + T.t[2];
@@ -121,11 +170,11 @@ inline double edge_eval(const Pose& T, const ovo_pose_obs& o, const double* cam,
 
 // robustified chi2 of the active edges for pose T (no Jacobians)
 double robust_chi(const Pose& T, const ovo_pose_obs* obs, int n, const std::vector<uint8_t>& active, const double* cam, double bf,
-                  double delta) {
+                  double delta, int model) {
     double sum = 0;
     for (int i = 0; i < n; ++i) {
         if (!active[i]) continue;
-        const double c2 = edge_eval(T, obs[i], cam, bf, 0, nullptr);
+        const double c2 = edge_eval(T, obs[i], cam, bf, 0, nullptr, model);
         double r = c2;
         if (delta > 0 && c2 > delta * delta) r = 2 * std::sqrt(c2) * delta - delta * delta;
         sum += r;
@@ -164,8 +213,9 @@ bool solve6(const double* H, double lambda, const double* b, double* x) {
 
 }   // namespace
 
-extern "C" int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* obs, int n, const double* cam4, double bf, int setup_type,
-                                 double* pose_cw_out, uint8_t* outlier, int* num_valid) {
+namespace {
+int pose_optimize_impl(const double* pose_cw_in, const ovo_pose_obs* obs, int n, const double* cam4, double bf, int setup_type, int model,
+                       double* pose_cw_out, uint8_t* outlier, int* num_valid) {
     // upstream: sqrt_chi_sq = (frm.camera_->setup_type_ == Monocular) ? sqrt_chi_sq_2D : sqrt_chi_sq_3D -- ONE Huber delta for every
     // edge of the frame, chosen by the rig; the chi-square outlier gates below stay per edge (is_monocular_)
     // upstream: constexpr float chi_sq_2D = 5.99146; const float sqrt_chi_sq_2D = std::sqrt(chi_sq_2D); (3D: 7.81473) -- FLOAT constants widened
@@ -194,7 +244,7 @@ extern "C" int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* o
                 Terr = T;   // solve() starts with computeActiveErrors() at the current estimate
                 for (int i = 0; i < n; ++i)
                     if (active[i])
-                        edge_eval(T, obs[i], cam4, bf, robust ? huber : 0.0, &lin);
+                        edge_eval(T, obs[i], cam4, bf, robust ? huber : 0.0, &lin, model);
                 double current_chi = lin.chi_robust;
                 if (it == 0) {
                     double max_diag = 0;
@@ -213,7 +263,7 @@ extern "C" int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* o
                         Pose E;
                         se3_exp(dx, E);
                         compose(E, T, Tn);
-                        temp_chi = robust_chi(Tn, obs, n, active, cam4, bf, robust ? huber : 0.0);
+                        temp_chi = robust_chi(Tn, obs, n, active, cam4, bf, robust ? huber : 0.0, model);
                         Terr = Tn;   // computeActiveErrors() ran on the trial state
                     }
                     rho = current_chi - temp_chi;
@@ -242,8 +292,8 @@ extern "C" int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* o
             // state -- equal to the estimate unless the round ended on a rejected step (qmax == 10 or rho == 0).
             num_bad = 0;
             for (int i = 0; i < n; ++i) {
-                const double c2 = edge_eval(active[i] ? Terr : T, obs[i], cam4, bf, 0, nullptr);
-                const double thr = obs[i].is_stereo ? (double)chi_sq_3D : (double)chi_sq_2D;
+                const double c2 = edge_eval(active[i] ? Terr : T, obs[i], cam4, bf, 0, nullptr, model);
+                const double thr = (model == 0 && obs[i].is_stereo) ? (double)chi_sq_3D : (double)chi_sq_2D;
                 if (thr < c2) {
                     outlier[i] = 1;
                     active[i] = 0;
@@ -260,4 +310,18 @@ extern "C" int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* o
     std::memcpy(pose_cw_out + 9, T.t, sizeof(double) * 3);
     *num_valid = n >= 5 ? n - num_bad : 0;
     return 0;
+}
+}   // namespace
+
+extern "C" int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* obs, int n, const double* cam4, double bf, int setup_type,
+                                 double* pose_cw_out, uint8_t* outlier, int* num_valid) {
+    return pose_optimize_impl(pose_cw_in, obs, n, cam4, bf, setup_type, 0, pose_cw_out, outlier, num_valid);
+}
+
+// equirectangular frames (upstream: `case camera::model_type_t::Equirectangular` of pose_optimizer::optimize -> equirectangular_pose_opt_edge):
+// every edge is monocular, the rig is Monocular (one Huber delta sqrtf(5.99146f), gate 5.99146f); obs[i].is_stereo / obs_x_right are ignored
+extern "C" int ovo_pose_optimize_equirect(const double* pose_cw_in, const ovo_pose_obs* obs, int n, int cols, int rows, double* pose_cw_out,
+                                          uint8_t* outlier, int* num_valid) {
+    const double cam[4] = {(double)cols, (double)rows, 0.0, 0.0};
+    return pose_optimize_impl(pose_cw_in, obs, n, cam, 0.0, 0, 1, pose_cw_out, outlier, num_valid);
 }
