@@ -12,6 +12,7 @@
 #include "openvslam/io/map_database_io.h"
 #include "openvslam/match/robust.h"
 #include "openvslam/optimize/local_bundle_adjuster.h"
+#include "openvslam/optimize/pose_optimizer.h"
 
 using namespace openvslam;
 
@@ -44,8 +45,9 @@ struct Reader {
 int run_lba(const char* in, const char* out) {
     const auto buf = read_all(in);
     Reader r{buf.data()};
-    const int n_kf = r.get<int32_t>(), n_lm = r.get<int32_t>(), n_obs = r.get<int32_t>(), curr = r.get<int32_t>(), setup = r.get<int32_t>();
+    const int n_kf = r.get<int32_t>(), n_lm = r.get<int32_t>(), n_obs = r.get<int32_t>(), curr = r.get<int32_t>(), setup_model = r.get<int32_t>();
     const int stop_before = r.get<int32_t>();
+    const int setup = setup_model & 0xff, model = setup_model >> 8;   // model: camera::model_type_t (0 perspective, 2 equirectangular)
     camera::base cam;
     cam.fx_ = r.get<double>();
     cam.fy_ = r.get<double>();
@@ -53,6 +55,11 @@ int run_lba(const char* in, const char* out) {
     cam.cy_ = r.get<double>();
     cam.focal_x_baseline_ = (float)r.get<double>();
     cam.setup_type_ = (camera::setup_type_t)setup;
+    cam.model_type_ = (camera::model_type_t)model;
+    if (cam.model_type_ == camera::model_type_t::Equirectangular) {   // the scene file carries (cols, rows) in the fx / fy slots
+        cam.cols_ = (unsigned)cam.fx_;
+        cam.rows_ = (unsigned)cam.fy_;
+    }
     std::vector<float> ils(8);
     for (auto& v : ils) v = r.get<float>();
     std::vector<std::unique_ptr<data::keyframe>> kfs;
@@ -235,9 +242,58 @@ int run_map(const char* in, const char* curr_id, const char* out) {
                 curr->id_, curr->graph_node_->covisibilities_.size());
     return 0;
 }
+// optimize::pose_optimizer::optimize(frm) through the class. File: int32 model (camera::model_type_t), int32 n, double[4] (fx fy cx cy, or
+// cols rows - - for an equirectangular camera), float[8] inv_level_sigma_sq, double[16] cam_pose_cw, then per keypoint: double[3] landmark
+// position, float x, float y, int32 octave. Dumps the pose, the return value and outlier_flags_.
+int run_pose(const char* in, const char* out) {
+    const auto buf = read_all(in);
+    Reader r{buf.data()};
+    const int model = r.get<int32_t>(), n = r.get<int32_t>();
+    camera::base cam;
+    cam.fx_ = r.get<double>();
+    cam.fy_ = r.get<double>();
+    cam.cx_ = r.get<double>();
+    cam.cy_ = r.get<double>();
+    cam.model_type_ = (camera::model_type_t)model;
+    if (cam.model_type_ == camera::model_type_t::Equirectangular) {
+        cam.cols_ = (unsigned)cam.fx_;
+        cam.rows_ = (unsigned)cam.fy_;
+    }
+    data::frame frm;
+    frm.camera_ = &cam;
+    frm.inv_level_sigma_sq_.resize(8);
+    for (auto& v : frm.inv_level_sigma_sq_) v = r.get<float>();
+    for (int i = 0; i < 16; ++i) frm.cam_pose_cw_.m[i] = r.get<double>();
+    std::vector<std::unique_ptr<data::landmark>> lms;
+    for (int i = 0; i < n; ++i) {
+        lms.emplace_back(new data::landmark());
+        for (int a = 0; a < 3; ++a) lms.back()->pos_w_(a) = r.get<double>();
+        cv::KeyPoint kp;
+        kp.pt.x = r.get<float>();
+        kp.pt.y = r.get<float>();
+        kp.octave = r.get<int32_t>();
+        frm.undist_keypts_.push_back(kp);
+        frm.keypts_.push_back(kp);
+        frm.landmarks_.push_back(lms.back().get());
+    }
+    frm.num_keypts_ = (unsigned)n;
+    const unsigned int nv = optimize::pose_optimizer(4, 10).optimize(frm);
+    FILE* f = std::fopen(out, "wb");
+    std::fwrite(frm.cam_pose_cw_.m, sizeof(double), 16, f);
+    const int32_t nvi = (int32_t)nv;
+    std::fwrite(&nvi, 4, 1, f);
+    for (int i = 0; i < n; ++i) {
+        const uint8_t o = frm.outlier_flags_[(size_t)i] ? 1 : 0;
+        std::fwrite(&o, 1, 1, f);
+    }
+    std::fclose(f);
+    std::printf("pose shim ok: %d keypoints, %u valid\n", n, nv);
+    return 0;
+}
 }   // namespace
 
 int main(int argc, char** argv) {
+    if (argc == 4 && std::string(argv[1]) == "pose") return run_pose(argv[2], argv[3]);
     if (argc == 3 && std::string(argv[1]) == "mapinfo") return run_mapinfo(argv[2]);
     if (argc == 5 && std::string(argv[1]) == "map") return run_map(argv[2], argv[3], argv[4]);
     if (argc == 5 && std::string(argv[1]) == "bow") return run_bow(argv[2], argv[3], argv[4]);

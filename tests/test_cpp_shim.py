@@ -414,3 +414,107 @@ def test_class_boundary_latency_and_two_threads():
     # measured 1.1-1.6x (two frames share one GPU's CUs): running in parallel, not back to back (serialised = 2x or more)
     assert max(tt["left_ms"], tt["right_ms"]) < 1.9 * tt["solo_ms"], tt
     assert r["pageable_no_pyramid"]["keypoints"] > 1900
+
+
+@pytest.mark.gpu
+def test_local_bundle_adjuster_class_equirectangular(oracle, tmp_path):
+    """The same class on an equirectangular local map (camera::model_type_t::Equirectangular, BASELINE configs[3]): the shim builds monocular
+    edges only and calls ovs_local_ba_optimize_equirect; compared with the oracle's equirectangular_reproj_edge rounds."""
+    import struct
+    from oracle import lba
+    from test_gpu_ba import _equirect_scene
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "openvslam_amd", "cpp")])
+    cols, rows = 3840, 1920
+    poses, _, pts_all, mono = _equirect_scene(21, n_pose=8, n_pt=1000, obs_per_pose=350, cols=cols, rows=rows)
+    lat_ok = np.abs(pts_all[:, 1]) / np.linalg.norm(pts_all, axis=1) < 0.95
+    mono = mono[lat_ok[mono["point_idx"]]]
+    n_kf = len(poses)
+    ids = np.arange(n_kf) * 3
+    covisible = np.ones(n_kf, np.int32)
+    covisible[1] = 0
+    fixed = np.zeros(n_kf, np.uint8)
+    fixed[:2] = 1
+    keep = np.zeros(len(pts_all), bool)
+    keep[mono["point_idx"][mono["pose_idx"] != 1]] = True
+    remap = -np.ones(len(keep), np.int64)
+    remap[keep] = np.arange(int(keep.sum()))
+    mono = mono[keep[mono["point_idx"]]].copy()
+    mono["point_idx"] = remap[mono["point_idx"]]
+    pts = pts_all[keep]
+    sig = np.float32(1.0)
+    ils = []
+    for _ in range(8):
+        ils.append(np.float32(1.0) / np.float32(sig * sig))
+        sig = np.float32(1.2) * sig
+    ils = np.array(ils, np.float32)
+    octave = np.argmin(np.abs(ils.astype(np.float64)[None, :] - mono["inv_sigma_sq"][:, None]), 1).astype(np.int32)
+    mono["inv_sigma_sq"] = ils[octave]
+    mono["obs_x"] = mono["obs_x"].astype(np.float32)
+    mono["obs_y"] = mono["obs_y"].astype(np.float32)
+    blob = struct.pack("<6i5d", n_kf, len(pts), len(mono), n_kf - 1, 0 | (2 << 8), 0, float(cols), float(rows), 0.0, 0.0, 0.0) + ils.tobytes()
+    for k in range(n_kf):
+        blob += struct.pack("<2i", int(ids[k]), int(covisible[k])) + _pose7_to_44(poses[k]).astype("<f8").tobytes()
+    for j in range(len(pts)):
+        blob += struct.pack("<i3d", 7 * j + 1, *pts[j])
+    for e, o in zip(mono, octave):
+        blob += struct.pack("<2i3fi", int(e["pose_idx"]), int(e["point_idx"]), e["obs_x"], e["obs_y"], -1.0, int(o))
+    (tmp_path / "scene.bin").write_bytes(blob)
+    subprocess.check_call([LBA_SHIM, "lba", str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")])
+    raw = (tmp_path / "out.bin").read_bytes()
+    poses_out = np.frombuffer(raw[:128 * n_kf], np.float64).reshape(n_kf, 4, 4)
+    off = 128 * n_kf
+    rec = np.frombuffer(raw[off:off + 28 * len(pts)], np.dtype([("p", "<f8", (3,)), ("upd", "<i4")]))
+    erased = np.frombuffer(raw[off + 28 * len(pts):], np.uint8)
+    want = lba.local_ba_optimize_equirect(poses, fixed, pts, mono, cols, rows)
+    assert want["info"][4] >= 2 and len(erased) == len(mono) and not (erased == 2).any()
+    for k in range(2, n_kf):
+        assert np.allclose(poses_out[k], _pose7_to_44(want["poses"][k]), rtol=1e-7, atol=1e-8)
+    assert np.array_equal(poses_out[1], _pose7_to_44(poses[1]))
+    assert np.allclose(rec["p"], want["points"], rtol=1e-7, atol=1e-8)
+    assert (erased.astype(bool) != want["mono_outlier"]).sum() <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", [0, 2])
+def test_pose_optimizer_class_per_camera_model(oracle, tmp_path, model):
+    """optimize::pose_optimizer::optimize(frm) through the CLASS for a perspective (0) and an equirectangular (2) camera: the shim's
+    `switch (camera->model_type_)` picks ovs_pose_optimize / ovs_pose_optimize_equirect. Keypoints are floats in the class, so the oracle
+    gets the same float-rounded observations."""
+    import struct
+    from openvslam_amd.synth import synth_pose_frame, synth_pose_frame_equirect
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "openvslam_amd", "cpp")])
+    n = 900
+    if model == 2:
+        T0, obs, cols, rows, _ = synth_pose_frame_equirect(oracle.POSE_OBS_DTYPE, n, 31, outlier_frac=0.1, seam_frac=0.05, pole_frac=0.05)
+        camv = (float(cols), float(rows), 0.0, 0.0)
+    else:
+        T0, obs, cam, _, _ = synth_pose_frame(oracle.POSE_OBS_DTYPE, n, 32, stereo_frac=0.0, outlier_frac=0.1)
+        camv = tuple(cam)
+    sig = np.float32(1.0)
+    ils = []
+    for _ in range(8):
+        ils.append(np.float32(1.0) / np.float32(sig * sig))
+        sig = np.float32(1.2) * sig
+    ils = np.array(ils, np.float32)
+    octave = np.argmin(np.abs(ils.astype(np.float64)[None, :] - obs["inv_sigma_sq"][:, None]), 1).astype(np.int32)
+    obs["inv_sigma_sq"] = ils[octave]
+    obs["obs_x"] = obs["obs_x"].astype(np.float32)
+    obs["obs_y"] = obs["obs_y"].astype(np.float32)
+    obs["is_stereo"] = 0
+    T44 = np.eye(4)
+    T44[:3] = T0
+    blob = struct.pack("<2i4d", model, n, *camv) + ils.tobytes() + T44.astype("<f8").tobytes()
+    for o, oc in zip(obs, octave):
+        blob += struct.pack("<3d2fi", *o["pos_w"], o["obs_x"], o["obs_y"], int(oc))
+    (tmp_path / "frame.bin").write_bytes(blob)
+    subprocess.check_call([LBA_SHIM, "pose", str(tmp_path / "frame.bin"), str(tmp_path / "pose.bin")])
+    raw = (tmp_path / "pose.bin").read_bytes()
+    T = np.frombuffer(raw[:128], np.float64).reshape(4, 4)
+    nv = int(np.frombuffer(raw[128:132], np.int32)[0])
+    flags = np.frombuffer(raw[132:], np.uint8).astype(bool)
+    if model == 2:
+        wT, wout, wnv = oracle.pose_optimize_equirect(T0, obs, int(camv[0]), int(camv[1]))
+    else:
+        wT, wout, wnv = oracle.pose_optimize(T0, obs, camv, 0.0)
+    assert np.allclose(T[:3], wT, rtol=0, atol=1e-9) and np.array_equal(T[3], [0, 0, 0, 1])
+    assert nv == wnv and np.array_equal(flags, wout) and wnv > 600
