@@ -72,10 +72,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched as plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run, rendezvous on
+        # 127.0.0.1 (the container hostname may not resolve); rank 0's JSON line passes through on stdout, the exit code is the job's
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d needs %d HIP devices on this node, found %d" % (args.gpus, args.gpus, have))
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE=%d (torch.distributed.run --nproc-per-node must equal --gpus)" % (args.gpus, world))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d HIP devices on this node" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -266,6 +284,9 @@ def main():
     kp_all, matches_all, pairs_all = (float(x) for x in totals.cpu().numpy())
 
     ba_res = None if args.no_ba else bench_local_ba(world, rank, dist, torch)
+    # a local map eight times larger (a loop-closure sized window): the size at which sharding the linearisation over GPUs can pay, see
+    # DESIGN.md section 5 for the expected curve. Multi-rank runs only (a 1-GPU run keeps the default bench short).
+    ba_large = None if (args.no_ba or world == 1) else bench_local_ba(world, rank, dist, torch, iters=10, n_pose=200, n_pt=100000, obs_per_pose=5000)
     side = None
     if world == 1 and not args.no_ba and not args.no_cpu_baseline:
         try:
@@ -273,6 +294,7 @@ def main():
         except Exception as ex:   # a side section must never cost the headline line
             side = {"error": repr(ex)}
 
+    out = None
     if rank == 0:
         n_cand = 0
         for l in range(LEVELS):
@@ -401,24 +423,39 @@ def main():
             "class_boundary_latency": class_lat,
             "cpu_baseline": cpu,
             "local_ba": ba_res,
+            "local_ba_large": ba_large,
             "other_configs": side,
             "parity": "bit-exact vs in-repo CPU oracle (from-spec restatement; upstream source unavailable: parity unpinned)",
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(out["value"] / cpu["value"], 1)
-        print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    native_multi = None
+    if rank == 0 and world > 1 and not args.no_ba:
+        # SURVEY 8(e) "measure both": the native one-process entry (ovs_ba_multi_*) over all of this node's devices with the packed RCCL
+        # all-reduce and with the direct xGMI peer exchange, in a SUBPROCESS with a time limit (a side measurement must never cost the
+        # headline line; the process group is gone: the other ranks are exiting and their devices are idle)
+        import subprocess
+        try:
+            pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ba_multi_bench.py"), str(world)], capture_output=True, text=True, timeout=180)
+            native_multi = json.loads(pr.stdout.strip().splitlines()[-1]) if pr.stdout.strip() else {"error": "no output", "stderr": pr.stderr[-300:]}
+        except Exception as ex:
+            native_multi = {"error": repr(ex)}
+    if rank == 0:
+        if native_multi is not None:
+            out["local_ba_native_multi"] = native_multi
+        print(json.dumps(out))
 
 
-def bench_local_ba(world, rank, dist, torch, iters=20):
+def bench_local_ba(world, rank, dist, torch, iters=20, n_pose=50, n_pt=20000, obs_per_pose=2000):
     """BASELINE configs[4]: local BA, 50 keyframes x 2000 observations, 20 000 landmarks, fp64: one linearisation = residuals +
     Jacobians + Hpp/Hll/Hpl/bp/bl blocks. Edges are sharded by keyframe over the ranks; Hll|bl (1.92 MB) are all-reduced over
     RCCL. Reported beside the headline metric (not part of `value`)."""
     from openvslam_amd import ba
     from openvslam_amd.synth import synth_local_ba
-    d = synth_local_ba(seed=0)
+    d = synth_local_ba(n_pose=n_pose, n_pt=n_pt, obs_per_pose=obs_per_pose, seed=0)
     shard = ba.shard_edges_by_keyframe(d["edges"], len(d["poses"]), rank, world)
     poses = torch.from_numpy(d["poses"]).cuda()
     fixed = torch.from_numpy(d["pose_fixed"]).cuda()
@@ -442,10 +479,11 @@ def bench_local_ba(world, rank, dist, torch, iters=20):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     n_edges = len(d["edges"])
-    alg_bytes = n_edges * 32 + 50 * 56 + 20000 * 24 + n_edges * 144 + 20000 * 96 + 50 * 336   # ~20.0 MB / iteration
-    return {"workload": "BASELINE configs[4]: 50 keyframes x 2000 observations, 20000 landmarks, fp64, Huber sqrt(5.991)",
+    alg_bytes = n_edges * 32 + n_pose * 56 + n_pt * 24 + n_edges * 144 + n_pt * 96 + n_pose * 336   # ~20.0 MB / iteration at config 5
+    return {"workload": "%s%d keyframes x %d observations, %d landmarks, fp64, Huber sqrt(5.991)"
+                        % ("BASELINE configs[4]: " if (n_pose, n_pt, obs_per_pose) == (50, 20000, 2000) else "", n_pose, obs_per_pose, n_pt),
             "ms_per_linearisation": round(dt / iters * 1e3, 4), "edges_per_sec": round(n_edges * iters / dt, 1),
-            "algorithmic_GBps": round(alg_bytes * iters / dt / 1e9, 2), "allreduce_bytes": 20000 * 12 * 8 if world > 1 else 0,
+            "algorithmic_GBps": round(alg_bytes * iters / dt / 1e9, 2), "allreduce_bytes": (n_pt * 12 + 2) * 8 if world > 1 else 0,
             "chi2": float(out["chi2"][0].item()), "kernels": "ovs_ba_graph: k_lin_landmark + k_lin_pose + k_reduce_scalars (no atomics, bit-reproducible)",
             "exchange": "ONE packed all-reduce of Hll|bl|chi2 per linearisation" if world > 1 else "none (1 rank)",
             "tolerance_vs_oracle": "Hpl, Hll, bl bit-exact; Hpp, bp, chi2 1e-13 rel (1 GPU); landmark sums 1e-10 rel (multi-rank)"}

@@ -514,6 +514,12 @@ ovs_status ovs_ba_multi_create(int32_t n_gpus, int32_t n_pose, const uint8_t* po
                                const ovs_ba_edge_stereo* stereo, int32_t n_stereo, const ovs_ba_cam* cam, double focal_x_baseline,
                                ovs_ba_multi** out);
 ovs_status ovs_ba_multi_destroy(ovs_ba_multi* m);
+/* How the landmark blocks are summed across the devices (SURVEY 8(e) asks for both to be measured): one packed ncclAllReduce (default), or
+ * a direct exchange -- every device reads the peers' packed blocks over xGMI through peer-mapped pointers and sums them itself in a fixed
+ * device order (bit-identical on every device and from run to run). OVS_ERR_NO_DEVICE if some pair of devices has no peer access. */
+#define OVS_BA_EXCHANGE_RCCL 0
+#define OVS_BA_EXCHANGE_PEER 1
+ovs_status ovs_ba_multi_set_exchange(ovs_ba_multi* m, int32_t exchange);
 ovs_status ovs_ba_multi_linearize(ovs_ba_multi* m, const double* poses, const double* points, double huber_mono, double huber_stereo, double* Hpp,
                                   double* bp, double* Hll, double* bl, double* Hpl, double* chi2);
 

@@ -71,6 +71,7 @@ SYMBOLS = {
     "ovs_ba_graph_linearize_dev": (_i32, [_vp, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_multi_create": (_i32, [_i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.POINTER(_vp)]),
     "ovs_ba_multi_destroy": (_i32, [_vp]),
+    "ovs_ba_multi_set_exchange": (_i32, [_vp, _i32]),
     "ovs_ba_multi_linearize": (_i32, [_vp, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_vocab_create": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
     "ovs_vocab_destroy": (_i32, [_vp]),

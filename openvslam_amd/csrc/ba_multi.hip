@@ -45,6 +45,31 @@ struct Rccl {
 };
 Rccl g_rccl;
 
+// Direct exchange over xGMI ("measure both"): every device sums the packed buffers of ALL devices itself, reading the peers'
+// copies through peer-mapped pointers -- one hop, no ring, and a FIXED summation order (device 0, 1, ...), so every device holds bit-identical
+// sums that do not change from run to run. 16-byte loads; the buffers are 1.92 MB at config 5, i.e. the exchange is latency-bound and a
+// one-hop all-read moves (N - 1) x 1.92 MB into each device over N - 1 different links at once.
+struct PeerPtrs {
+    const double* in[8];
+};
+__global__ __launch_bounds__(256) void k_peer_sum(PeerPtrs p, int n_dev, size_t n, double* __restrict__ out) {
+    const size_t n2 = n >> 1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+        double2 a = reinterpret_cast<const double2*>(p.in[0])[i];
+        for (int d = 1; d < n_dev; ++d) {
+            const double2 b = reinterpret_cast<const double2*>(p.in[d])[i];
+            a.x += b.x;
+            a.y += b.y;
+        }
+        reinterpret_cast<double2*>(out)[i] = a;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double a = p.in[0][n - 1];
+        for (int d = 1; d < n_dev; ++d) a += p.in[d][n - 1];
+        out[n - 1] = a;
+    }
+}
+
 struct Shard {
     int device = 0;
     int pose_lo = 0, pose_hi = 0;               // keyframes [pose_lo, pose_hi) belong to this shard
@@ -54,6 +79,11 @@ struct Shard {
     double *d_poses = nullptr, *d_points = nullptr, *d_pose_blocks = nullptr, *d_packed = nullptr, *d_hpl = nullptr;
     double* h_hpl = nullptr;                     // pinned
     void* comm = nullptr;
+    // direct exchange: the summed blocks (the peers keep reading d_packed while this device writes its sum), and the two events that order
+    // the devices against each other: "my shard's blocks are complete" / "I have finished reading everybody's blocks"
+    double* d_sum = nullptr;
+    hipEvent_t ev_lin = nullptr, ev_sum = nullptr;
+    bool sum_pending = false;
 };
 
 }   // namespace
@@ -63,6 +93,8 @@ struct ovs_ba_multi {
     std::vector<Shard> shards;
     double* h_packed = nullptr;   // pinned: Hll | bl | chi2 from device 0
     double* h_pose = nullptr;     // pinned: per-shard Hpp | bp blocks
+    int exchange = OVS_BA_EXCHANGE_RCCL;
+    bool peer_ok = false;         // every pair of devices has peer access enabled
 };
 
 extern "C" {
@@ -79,6 +111,9 @@ ovs_status ovs_ba_multi_destroy(ovs_ba_multi* m) {
         hipFree(s.d_pose_blocks);
         hipFree(s.d_packed);
         hipFree(s.d_hpl);
+        hipFree(s.d_sum);
+        if (s.ev_lin) hipEventDestroy(s.ev_lin);
+        if (s.ev_sum) hipEventDestroy(s.ev_sum);
         if (s.h_hpl) hipHostFree(s.h_hpl);
         if (s.stream) hipStreamDestroy(s.stream);
     }
@@ -150,6 +185,29 @@ ovs_status ovs_ba_multi_create(int32_t n_gpus, int32_t n_pose, const uint8_t* po
         M_TRY(hipMalloc(&s.d_packed, sizeof(double) * (12 * (size_t)n_pt + 4)));
         M_TRY(hipMalloc(&s.d_hpl, sizeof(double) * 18 * ne));
         M_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.h_hpl), sizeof(double) * 18 * ne, hipHostMallocDefault));
+        if (n_gpus > 1) {
+            M_TRY(hipMalloc(&s.d_sum, sizeof(double) * (12 * (size_t)n_pt + 4)));
+            M_TRY(hipEventCreateWithFlags(&s.ev_lin, hipEventDisableTiming));
+            M_TRY(hipEventCreateWithFlags(&s.ev_sum, hipEventDisableTiming));
+        }
+    }
+    if (n_gpus > 1) {   // peer access for the direct exchange; failing to get it only disables that variant
+        bool ok = true;
+        for (int a = 0; a < n_gpus && ok; ++a) {
+            M_TRY(hipSetDevice(a));
+            for (int b = 0; b < n_gpus && ok; ++b) {
+                if (a == b) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) {
+                    ok = false;
+                    break;
+                }
+                const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+                (void)hipGetLastError();
+            }
+        }
+        m->peer_ok = ok;
     }
     M_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_packed), sizeof(double) * (12 * (size_t)n_pt + 4), hipHostMallocDefault));
     M_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_pose), sizeof(double) * 42 * (size_t)n_pose * (size_t)n_gpus, hipHostMallocDefault));
@@ -176,9 +234,14 @@ ovs_status ovs_ba_multi_linearize(ovs_ba_multi* m, const double* poses, const do
                                   double* bp, double* Hll, double* bl, double* Hpl, double* chi2) {
     if (!m || !poses || !points || !Hpp || !bp || !Hll || !bl || !Hpl || !chi2) return OVS_ERR_INVALID;
     const size_t np = (size_t)m->n_pose, npt = (size_t)m->n_pt;
+    const bool peer = m->n_gpus > 1 && m->exchange == OVS_BA_EXCHANGE_PEER;
+    if (peer && !m->peer_ok) return OVS_ERR_NO_DEVICE;
     // 1. state to every device, shard linearisations (asynchronous, one stream per device)
     for (Shard& s : m->shards) {
         OVS_HIP_TRY(hipSetDevice(s.device));
+        // a peer may still be reading this device's blocks for the previous call's sum
+        for (Shard& o : m->shards)
+            if (o.sum_pending && &o != &s) OVS_HIP_TRY(hipStreamWaitEvent(s.stream, o.ev_sum, 0));
         OVS_HIP_TRY(hipMemcpyAsync(s.d_poses, poses, sizeof(double) * 7 * np, hipMemcpyHostToDevice, s.stream));
         OVS_HIP_TRY(hipMemcpyAsync(s.d_points, points, sizeof(double) * 3 * npt, hipMemcpyHostToDevice, s.stream));
         const ovs_status st = ovs_ba_graph_linearize_dev(s.graph, s.d_poses, s.d_points, huber_mono, huber_stereo, s.d_pose_blocks,
@@ -186,8 +249,29 @@ ovs_status ovs_ba_multi_linearize(ovs_ba_multi* m, const double* poses, const do
                                                          s.d_packed + 12 * npt, s.stream);
         if (st != OVS_OK) return st;
     }
-    // 2. THE exchange step: one packed all-reduce of Hll | bl | chi2[2] (max |diag| is not a sum: excluded) across the devices
-    if (m->n_gpus > 1) {
+    for (Shard& s : m->shards) s.sum_pending = false;
+    // 2. THE exchange step: Hll | bl | chi2[2] summed across the devices (max |diag| is not a sum: excluded)
+    const double* packed_of_dev0 = m->shards[0].d_packed;
+    if (peer) {
+        const size_t n = 12 * npt + 2;
+        PeerPtrs pp{};
+        for (size_t d = 0; d < m->shards.size(); ++d) pp.in[d] = m->shards[d].d_packed;
+        for (Shard& s : m->shards) {
+            OVS_HIP_TRY(hipSetDevice(s.device));
+            OVS_HIP_TRY(hipEventRecord(s.ev_lin, s.stream));
+        }
+        for (Shard& s : m->shards) {
+            OVS_HIP_TRY(hipSetDevice(s.device));
+            for (Shard& o : m->shards)
+                if (&o != &s) OVS_HIP_TRY(hipStreamWaitEvent(s.stream, o.ev_lin, 0));
+            const unsigned blocks = (unsigned)std::min<size_t>((n / 2 + 255) / 256, 1024);
+            hipLaunchKernelGGL(k_peer_sum, dim3(std::max(blocks, 1u)), dim3(256), 0, s.stream, pp, m->n_gpus, n, s.d_sum);
+            OVS_HIP_TRY(hipGetLastError());
+            OVS_HIP_TRY(hipEventRecord(s.ev_sum, s.stream));
+            s.sum_pending = true;
+        }
+        packed_of_dev0 = m->shards[0].d_sum;
+    } else if (m->n_gpus > 1) {
         if (g_rccl.GroupStart() != 0) return OVS_ERR_HIP;
         for (Shard& s : m->shards) {
             OVS_HIP_TRY(hipSetDevice(s.device));
@@ -199,7 +283,7 @@ ovs_status ovs_ba_multi_linearize(ovs_ba_multi* m, const double* poses, const do
     for (size_t d = 0; d < m->shards.size(); ++d) {
         Shard& s = m->shards[d];
         OVS_HIP_TRY(hipSetDevice(s.device));
-        if (d == 0) OVS_HIP_TRY(hipMemcpyAsync(m->h_packed, s.d_packed, sizeof(double) * (12 * npt + 4), hipMemcpyDeviceToHost, s.stream));
+        if (d == 0) OVS_HIP_TRY(hipMemcpyAsync(m->h_packed, packed_of_dev0, sizeof(double) * (12 * npt + 2), hipMemcpyDeviceToHost, s.stream));
         OVS_HIP_TRY(hipMemcpyAsync(m->h_pose + 42 * np * d, s.d_pose_blocks, sizeof(double) * 42 * np, hipMemcpyDeviceToHost, s.stream));
         const size_t ne = s.mono_src.size() + s.stereo_src.size();
         if (ne) OVS_HIP_TRY(hipMemcpyAsync(s.h_hpl, s.d_hpl, sizeof(double) * 18 * ne, hipMemcpyDeviceToHost, s.stream));
@@ -223,6 +307,13 @@ ovs_status ovs_ba_multi_linearize(ovs_ba_multi* m, const double* poses, const do
         for (size_t i = 0; i < s.stereo_src.size(); ++i)
             std::memcpy(Hpl + 18 * ((size_t)m->n_mono + (size_t)s.stereo_src[i]), s.h_hpl + 18 * (s.mono_src.size() + i), sizeof(double) * 18);
     }
+    return OVS_OK;
+}
+
+ovs_status ovs_ba_multi_set_exchange(ovs_ba_multi* m, int32_t exchange) {
+    if (!m || (exchange != OVS_BA_EXCHANGE_RCCL && exchange != OVS_BA_EXCHANGE_PEER)) return OVS_ERR_INVALID;
+    if (exchange == OVS_BA_EXCHANGE_PEER && m->n_gpus > 1 && !m->peer_ok) return OVS_ERR_NO_DEVICE;   // no peer access between some pair
+    m->exchange = exchange;
     return OVS_OK;
 }
 

@@ -24,6 +24,97 @@ def _oracle_backend(poses_t, fixed_t, points_t, edges_t, cam, huber_delta):
     return hppbp, packed, torch.from_numpy(o["Hpl"].reshape(-1, 18).copy())
 
 
+def _numpy_backend(poses_t, fixed_t, points_t, edges_t, cam, huber_delta):
+    """The shard's blocks restated in vectorised numpy, independent of the C oracle (the multi-rank test must not prove the
+    oracle against itself): residual, Huber weight, the 2 x 3 / 2 x 6 Jacobians of the perspective edge, block sums by np.add.at, and the
+    SAME packing local_ba_linearizer expects -- (Hpp | bp), (Hll | bl | chi2[2] | pad[2]), Hpl."""
+    from oracle import binding as ob   # (the record dtype only)
+    P, X = poses_t.numpy(), points_t.numpy()
+    e = edges_t.numpy().view(ob.BA_EDGE_DTYPE)
+    fixed = fixed_t.numpy().astype(bool) if fixed_t is not None else np.zeros(len(P), bool)
+    fx, fy, cx, cy = cam
+    q = P[:, 3:]
+    x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], 1),
+                  np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], 1),
+                  np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)], 1)      # (n_pose, 3, 3)
+    pi, li = e["pose_idx"], e["point_idx"]
+    Re = R[pi]
+    pc = np.einsum("eab,eb->ea", Re, X[li]) + P[pi, :3]
+    px, py, iz = pc[:, 0], pc[:, 1], 1.0 / pc[:, 2]
+    r = np.stack([e["obs_x"] - (fx * px * iz + cx), e["obs_y"] - (fy * py * iz + cy)], 1)
+    c2 = e["inv_sigma_sq"] * (r * r).sum(1)
+    rho0, rho1 = c2.copy(), np.ones_like(c2)
+    if huber_delta > 0:
+        big = c2 > huber_delta * huber_delta
+        sq = np.sqrt(c2[big])
+        rho0[big] = 2 * sq * huber_delta - huber_delta * huber_delta
+        rho1[big] = huber_delta / sq
+    W = rho1 * e["inv_sigma_sq"]
+    Jl = np.stack([-iz[:, None] * (fx * Re[:, 0] - (fx * px * iz)[:, None] * Re[:, 2]),
+                   -iz[:, None] * (fy * Re[:, 1] - (fy * py * iz)[:, None] * Re[:, 2])], 1)                    # (E, 2, 3)
+    iz2, zero = iz * iz, np.zeros_like(iz)
+    Jp = np.stack([np.stack([px * py * iz2 * fx, -(1 + px * px * iz2) * fx, py * iz * fx, -iz * fx, zero, px * iz2 * fx], 1),
+                   np.stack([(1 + py * py * iz2) * fy, -px * py * iz2 * fy, -px * iz * fy, zero, -iz * fy, py * iz2 * fy], 1)], 1)   # (E, 2, 6)
+    wr = -(W[:, None] * r)
+    n_pose, n_pt = len(P), len(X)
+    Hll, bl = np.zeros((n_pt, 3, 3)), np.zeros((n_pt, 3))
+    np.add.at(Hll, li, W[:, None, None] * np.einsum("eka,ekb->eab", Jl, Jl))
+    np.add.at(bl, li, np.einsum("eka,ek->ea", Jl, wr))
+    free = ~fixed[pi]
+    Hpp, bp = np.zeros((n_pose, 6, 6)), np.zeros((n_pose, 6))
+    np.add.at(Hpp, pi[free], (W[:, None, None] * np.einsum("eka,ekb->eab", Jp, Jp))[free])
+    np.add.at(bp, pi[free], np.einsum("eka,ek->ea", Jp, wr)[free])
+    Hpl = W[:, None, None] * np.einsum("eka,ekb->eab", Jp, Jl)
+    Hpl[~free] = 0.0
+    hppbp = torch.from_numpy(np.concatenate([Hpp.ravel(), bp.ravel()]))
+    packed = torch.from_numpy(np.concatenate([Hll.ravel(), bl.ravel(), [c2.sum(), rho0.sum()], np.zeros(2)]))
+    return hppbp, packed, torch.from_numpy(Hpl.reshape(-1, 18).copy())
+
+
+def _worker_numpy(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = synth_local_ba(n_pose=8, n_pt=500, obs_per_pose=200, seed=6, pose_noise=0.02, point_noise=0.02)
+        shard = ba.shard_edges_by_keyframe(d["edges"], 8, rank, world)
+        lin = ba.local_ba_linearizer(d["cam"], d["huber_delta"], backend=_numpy_backend)
+        out = lin.linearize(torch.from_numpy(d["poses"]), torch.from_numpy(d["pose_fixed"]), torch.from_numpy(d["points"]),
+                            torch.from_numpy(shard.view(np.uint8)))
+        q.put((rank, {k: v.numpy().copy() for k, v in out.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_world_size_2_with_a_backend_that_is_not_the_oracle(oracle):
+    """Partition by keyframe + ONE packed all-reduce with an independent numpy shard backend; the reduced blocks are then compared with the
+    C oracle's one-process linearisation -- two implementations, two process counts."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_numpy, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    d = synth_local_ba(n_pose=8, n_pt=500, obs_per_pose=200, seed=6, pose_noise=0.02, point_noise=0.02)
+    want = oracle.ba_linearize(d["poses"], d["pose_fixed"], d["points"], d["edges"], d["cam"], d["huber_delta"])
+    for rank, out in res:
+        for k in ("Hpp", "bp", "Hll", "bl", "chi2"):
+            scale = np.abs(want[k]).max()
+            assert np.allclose(out[k], want[k], rtol=1e-10, atol=1e-10 * scale), (rank, k)
+        sel = (d["edges"]["pose_idx"] // 4) == rank
+        assert np.allclose(out["Hpl"], want["Hpl"][sel], rtol=1e-12, atol=1e-12 * np.abs(want["Hpl"]).max())
+    assert np.array_equal(res[0][1]["Hll"], res[1][1]["Hll"]) and want["chi2"][1] < want["chi2"][0]
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -344,3 +344,24 @@ def test_native_multi_device_entry_one_gpu(oracle):
     if n_dev < 8:
         assert L.ovs_ba_multi_create(n_dev + 1, n_pose, fixed.ctypes.data, n_pt, mono.ctypes.data, len(mono), st.ctypes.data, len(st), C.byref(cam),
                                      bf, C.byref(h2)) == -2
+
+
+def test_native_multi_device_entry_two_gpus(oracle):
+    """ovs_ba_multi_* with n_gpus = 2 (needs two devices on the node: skipped on the 1-GPU test box, run by the driver's multi-GPU tier):
+    both exchange variants -- packed RCCL all-reduce and direct xGMI peer sums -- against the one-device result."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from openvslam_amd import _lib
+    if _lib.lib().ovs_device_count() < 2:
+        pytest.skip("needs >= 2 HIP devices")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "ba_multi_bench.py"), "2", "12", "3000", "600", "3"], capture_output=True, text=True,
+                         timeout=300)
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert "error" not in res, res
+    for name in ("rccl", "peer"):
+        assert name + "_error" not in res, res
+        assert res[name + "_pose_blocks_and_Hpl_bit_equal_to_one_device"] and res[name + "_landmark_sums_max_rel_diff"] < 1e-10, res
+    assert res["peer_reproducible"]
