@@ -254,6 +254,30 @@ ovs_status ovs_projection_match_frame_and_landmarks_dev(ovs_wmatcher* w, const o
                                                         int32_t m, const float* scale_factors, int32_t num_levels, float margin,
                                                         float lowe_ratio, int32_t* d_assigned, int32_t* d_num_matches, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Frame residency.  A frame's matcher-side data resident in HBM: what data::frame's constructor produces once per
+ * frame -- undist_keypts_, descriptors_, stereo_x_right_ (NULL = monocular) and the keypoint grid of data::assign_keypoints_to_grid
+ * (keypt_indices_in_cells_) -- uploaded with one copy and indexed once. tracking_module calls two to four matchers on the same frame;
+ * the *_f entry points below take the handle instead of re-uploading and re-indexing the frame in every call, stage their per-call host
+ * arrays through one pinned buffer (one copy up) and fetch the result block with one copy down. Device arenas of destroyed handles are
+ * pooled: creating one handle per tracked frame costs no hipMalloc in steady state. The handle is read-only after creation and may be
+ * shared by matcher contexts / threads on the same device.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ovs_frame_dev ovs_frame_dev;
+ovs_status ovs_frame_dev_create(int32_t device, const ovs_grid_params* gp, const ovs_keypoint* undist_kps, const uint8_t* desc,
+                                const float* stereo_x_right, int32_t n, ovs_frame_dev** out);
+ovs_status ovs_frame_dev_destroy(ovs_frame_dev* f);
+int32_t ovs_frame_dev_num_keypoints(const ovs_frame_dev* f);
+/* projection::match_frame_and_landmarks with the frame side resident (arguments as ovs_projection_match_frame_and_landmarks). */
+ovs_status ovs_projection_match_frame_and_landmarks_f(ovs_wmatcher* w, const ovs_frame_dev* frm, const uint8_t* occupied, const float* lm_xy,
+                                                      const float* lm_x_right, const int32_t* lm_level, const uint8_t* lm_desc,
+                                                      const uint8_t* lm_valid, int32_t m, const float* scale_factors, int32_t num_levels,
+                                                      float margin, float lowe_ratio, int32_t* assigned, int32_t* num_matches);
+/* area::match_in_consistent_area with both frames resident (initializer: frm_1 is matched against every new frame until it succeeds). */
+ovs_status ovs_area_match_in_consistent_area_f(ovs_wmatcher* w, const ovs_frame_dev* frm_1, const ovs_frame_dev* frm_2, float* prev_matched_xy,
+                                               int32_t* matched_2_in_1, int32_t margin, float lowe_ratio, int32_t check_orientation,
+                                               int32_t* num_matches);
+
 /* camera::base subset needed by the matchers that reproject inside the call. model: 0 = perspective, 1 = equirectangular
  * (camera::model_type_t); setup: 0 = Monocular, 1 = Stereo, 2 = RGBD (camera::setup_type_t). */
 typedef struct ovs_camera {
@@ -278,6 +302,13 @@ ovs_status ovs_projection_match_current_and_last_frames(ovs_wmatcher* w, const o
                                                         const uint8_t* last_lm_desc, const uint8_t* last_valid, int32_t n_last,
                                                         const double* pose_cw_last, const float* scale_factors, int32_t num_levels,
                                                         float margin, int32_t check_orientation, int32_t* assigned, int32_t* num_matches);
+/* The same with the current frame resident (ovs_frame_dev; its grid parameters are the handle's). */
+ovs_status ovs_projection_match_current_and_last_frames_f(ovs_wmatcher* w, const ovs_camera* cam, const ovs_frame_dev* curr,
+                                                          const uint8_t* curr_occupied, const double* pose_cw_curr, const ovs_keypoint* last_kps,
+                                                          const double* last_pos_w, const uint8_t* last_lm_desc, const uint8_t* last_valid,
+                                                          int32_t n_last, const double* pose_cw_last, const float* scale_factors,
+                                                          int32_t num_levels, float margin, int32_t check_orientation, int32_t* assigned,
+                                                          int32_t* num_matches);
 
 /* replaces: unsigned int projection::match_frame_and_keyframe(data::frame& curr_frm, data::keyframe* keyfrm,
  *               const std::set<data::landmark*>& already_matched_lms, const float margin, const unsigned int hamm_dist_thr) const.

@@ -69,6 +69,13 @@ SYMBOLS = {
     "ovs_ba_graph_create_equirect": (_i32, [_i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, C.POINTER(_vp)]),
     "ovs_ba_graph_destroy": (_i32, [_vp]),
     "ovs_ba_graph_linearize_dev": (_i32, [_vp, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ovs_frame_dev_create": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, C.POINTER(_vp)]),
+    "ovs_frame_dev_destroy": (_i32, [_vp]),
+    "ovs_frame_dev_num_keypoints": (_i32, [_vp]),
+    "ovs_projection_match_frame_and_landmarks_f": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _f, _f, _vp, C.POINTER(_i32)]),
+    "ovs_area_match_in_consistent_area_f": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _f, _i32, C.POINTER(_i32)]),
+    "ovs_projection_match_current_and_last_frames_f": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _f, _i32, _vp,
+                                                               C.POINTER(_i32)]),
     "ovs_ba_multi_create": (_i32, [_i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.POINTER(_vp)]),
     "ovs_ba_multi_destroy": (_i32, [_vp]),
     "ovs_ba_multi_set_exchange": (_i32, [_vp, _i32]),

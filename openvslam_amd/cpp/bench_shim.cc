@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -13,6 +14,9 @@
 #include <ovslam_hip.h>
 
 #include "openvslam/feature/orb_extractor.h"
+#include "openvslam/match/area.h"
+#include "openvslam/match/projection.h"
+#include "openvslam/optimize/pose_optimizer.h"
 
 using namespace openvslam;
 using clk = std::chrono::steady_clock;
@@ -107,6 +111,101 @@ int main(int argc, char** argv) {
         tl.join();
         tr.join();
         std::printf(", \"two_threads\": {\"solo_ms\": %.4f, \"left_ms\": %.4f, \"right_ms\": %.4f}", solo, l, r);
+    }
+    // ---- one tracked frame through the classes, as tracking_module::track() strings them together (what matters is that the
+    // frame's keypoints / descriptors / grid go up once and every matcher after the first finds them in HBM):
+    //   orb_extractor::extract -> projection::match_current_and_last_frames (first matcher on the frame: creates the device cache)
+    //   -> pose_optimizer::optimize -> projection::match_frame_and_landmarks against the local map (frame already resident)
+    {
+        feature::orb_extractor ex(feature::orb_params(nfeat, 1.2f, 8, 20, 7));
+        ex.set_image_pyramid_download(false);
+        camera::base pcam;
+        pcam.cols_ = cols;
+        pcam.rows_ = rows;
+        pcam.img_bounds_.max_x_ = (float)cols;
+        pcam.img_bounds_.max_y_ = (float)rows;
+        pcam.fx_ = pcam.fy_ = 500.0;
+        pcam.cx_ = cols / 2.0;
+        pcam.cy_ = rows / 2.0;
+        data::frame last;
+        ex.extract(a, cv::Mat(), last.keypts_, last.descriptors_);
+        last.num_keypts_ = last.keypts_.size();
+        last.undist_keypts_ = last.keypts_;
+        last.camera_ = &pcam;
+        last.scale_factors_ = ex.get_scale_factors();
+        std::vector<std::unique_ptr<data::landmark>> own;
+        last.landmarks_.assign(last.num_keypts_, nullptr);
+        last.outlier_flags_.assign(last.num_keypts_, false);
+        std::vector<data::landmark*> local_lms;
+        for (unsigned i = 0; i < last.num_keypts_; ++i) {   // landmarks where the next frame (image b = a shifted by (5, 0)) sees them
+            own.emplace_back(new data::landmark());
+            auto* lm = own.back().get();
+            const double z = 2.0 + (double)(i % 7);
+            lm->pos_w_(0) = (((double)last.undist_keypts_[i].pt.x - 5.0) - pcam.cx_) / pcam.fx_ * z;
+            lm->pos_w_(1) = ((double)last.undist_keypts_[i].pt.y - pcam.cy_) / pcam.fy_ * z;
+            lm->pos_w_(2) = z;
+            lm->descriptor_ = last.descriptors_.row((int)i);
+            lm->reproj_in_tracking_(0) = last.undist_keypts_[i].pt.x - 5.0;
+            lm->reproj_in_tracking_(1) = last.undist_keypts_[i].pt.y;
+            lm->is_observable_in_tracking_ = true;
+            lm->scale_level_in_tracking_ = last.undist_keypts_[i].octave;
+            last.landmarks_[i] = lm;
+            local_lms.push_back(lm);
+        }
+        std::vector<double> t_ext, t_cl, t_pose, t_lm, t_all;
+        unsigned n_cl = 0, n_pose = 0, n_lm = 0;
+        for (int i = 0; i < iters + 5; ++i) {
+            const auto t0 = clk::now();
+            data::frame curr;
+            ex.extract(b, cv::Mat(), curr.keypts_, curr.descriptors_);
+            curr.num_keypts_ = curr.keypts_.size();
+            curr.undist_keypts_ = curr.keypts_;
+            curr.camera_ = &pcam;
+            curr.scale_factors_ = last.scale_factors_;
+            curr.inv_level_sigma_sq_.resize(curr.scale_factors_.size());
+            for (size_t l = 0; l < curr.scale_factors_.size(); ++l) curr.inv_level_sigma_sq_[l] = 1.0f / (curr.scale_factors_[l] * curr.scale_factors_[l]);
+            curr.landmarks_.assign(curr.num_keypts_, nullptr);
+            curr.cam_pose_cw_(0, 3) = 0.01;   // motion-model guess, slightly off
+            const auto t1 = clk::now();
+            n_cl = match::projection(0.9f, true).match_current_and_last_frames(curr, last, 15.0f);
+            const auto t2 = clk::now();
+            n_pose = optimize::pose_optimizer().optimize(curr);
+            const auto t3 = clk::now();
+            for (auto& l : curr.landmarks_) l = nullptr;   // (search_local_landmarks looks for the landmarks not yet tracked)
+            n_lm = match::projection(0.8f, true).match_frame_and_landmarks(curr, local_lms, 5.0f);
+            const auto t4 = clk::now();
+            if (i < 5) continue;
+            auto ms = [](clk::time_point x, clk::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+            t_ext.push_back(ms(t0, t1));
+            t_cl.push_back(ms(t1, t2));
+            t_pose.push_back(ms(t2, t3));
+            t_lm.push_back(ms(t3, t4));
+            t_all.push_back(ms(t0, t4));
+        }
+        // the initializer's matcher on two resident frames
+        data::frame f1 = last, f2;
+        ex.extract(b, cv::Mat(), f2.keypts_, f2.descriptors_);
+        f2.num_keypts_ = f2.keypts_.size();
+        f2.undist_keypts_ = f2.keypts_;
+        f2.camera_ = &pcam;
+        std::vector<double> t_area;
+        unsigned n_area = 0;
+        for (int i = 0; i < iters + 5; ++i) {
+            std::vector<cv::Point2f> prev(f1.num_keypts_);
+            for (unsigned k = 0; k < f1.num_keypts_; ++k) prev[k] = f1.undist_keypts_[k].pt;
+            std::vector<int> m21;
+            const auto t0 = clk::now();
+            n_area = match::area(0.9f, true).match_in_consistent_area(f1, f2, prev, m21, 100);
+            if (i >= 5) t_area.push_back(std::chrono::duration<double, std::milli>(clk::now() - t0).count());
+        }
+        std::printf(", \"tracking_per_frame\": {\"extract_median_ms\": %.4f, \"match_current_and_last_frames_median_ms\": %.4f, "
+                    "\"pose_optimize_median_ms\": %.4f, \"match_frame_and_landmarks_median_ms\": %.4f, \"frame_total_median_ms\": %.4f, "
+                    "\"frame_total_p95_ms\": %.4f, \"area_match_in_consistent_area_median_ms\": %.4f, \"keypoints\": %u, \"matches_cl\": %u, "
+                    "\"pose_inliers\": %u, \"matches_local_map\": %u, \"matches_area\": %u, "
+                    "\"note\": \"classes with upstream signatures; match_current_and_last_frames includes the once-per-frame upload of the frame "
+                    "(ovs_frame_dev), match_frame_and_landmarks finds it resident\"}",
+                    stats(t_ext).median, stats(t_cl).median, stats(t_pose).median, stats(t_lm).median, stats(t_all).median, stats(t_all).p95,
+                    stats(t_area).median, last.num_keypts_, n_cl, n_pose, n_lm, n_area);
     }
     std::printf("}\n");
     return 0;

@@ -2,6 +2,7 @@
 // (expected: src/openvslam/data/{frame,keyframe,landmark}.h, src/openvslam/camera/base.h). In an OpenVSLAM checkout the real
 // headers are used instead and the shim bodies compile unchanged.
 #pragma once
+#include <memory>
 #include <map>
 #include <mutex>
 #include <set>
@@ -104,8 +105,20 @@ public:
     int scale_level_in_tracking_ = 0;
 };
 
+// The frame's matcher-side data resident in HBM (ovs_frame_dev, include/ovslam_hip.h): created by the first matcher that needs it and
+// shared by copies of the frame (upstream copies frames: last_frm = curr_frm). The ONE member an integration adds to data::frame:
+// keypoints and descriptors never change after the constructor, so the cache needs no invalidation.
+struct frame_device_cache {
+    void* handle = nullptr;                 // ovs_frame_dev*
+    void (*destroy)(void*) = nullptr;
+    ~frame_device_cache() {
+        if (handle && destroy) destroy(handle);
+    }
+};
+
 class frame {
 public:
+    mutable std::shared_ptr<frame_device_cache> device_cache_;
     unsigned int num_keypts_ = 0;
     std::vector<cv::KeyPoint> keypts_;
     std::vector<cv::KeyPoint> undist_keypts_;

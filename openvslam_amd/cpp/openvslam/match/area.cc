@@ -13,15 +13,12 @@ unsigned int area::match_in_consistent_area(data::frame& frm_1, data::frame& frm
     if (n1 == 0 || n2 == 0) return 0;
     static_assert(sizeof(cv::Point2f) == 2 * sizeof(float), "cv::Point2f is two floats");
     static_assert(sizeof(int) == sizeof(int32_t), "int is 32 bit");
-    const ovs_grid_params gp = detail::grid_of(frm_2.camera_);
     int32_t num_matches = 0;
-    detail::check(ovs_area_match_in_consistent_area(detail::window_ctx().get(n2, n1), &gp,
-                                                    reinterpret_cast<const ovs_keypoint*>(frm_1.undist_keypts_.data()), frm_1.descriptors_.data,
-                                                    n1, reinterpret_cast<const ovs_keypoint*>(frm_2.undist_keypts_.data()),
-                                                    frm_2.descriptors_.data, n2, reinterpret_cast<float*>(prev_matched_pts.data()),
-                                                    matched_indices_2_in_frm_1.data(), margin, lowe_ratio_, check_orientation_ ? 1 : 0,
-                                                    &num_matches),
-                  "ovs_area_match_in_consistent_area");
+    // both frames resident: module::initializer matches its init frame against every incoming frame until the map is created
+    detail::check(ovs_area_match_in_consistent_area_f(detail::window_ctx().get(n2, n1), detail::device_frame_of(frm_1), detail::device_frame_of(frm_2),
+                                                      reinterpret_cast<float*>(prev_matched_pts.data()), matched_indices_2_in_frm_1.data(), margin,
+                                                      lowe_ratio_, check_orientation_ ? 1 : 0, &num_matches),
+                  "ovs_area_match_in_consistent_area_f");
     return (unsigned int)num_matches;
 }
 

@@ -28,15 +28,14 @@ unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::
     }
     for (int i = 0; i < n; ++i) occupied[i] = frm.landmarks_[i] && frm.landmarks_[i]->has_observation();
     const bool stereo = !frm.stereo_x_right_.empty();
-    const ovs_grid_params gp = detail::grid_of(frm.camera_);
     std::vector<int32_t> assigned((size_t)m, -1);
     int32_t num_matches = 0;
-    detail::check(ovs_projection_match_frame_and_landmarks(
-                      detail::window_ctx().get(n, m), &gp, reinterpret_cast<const ovs_keypoint*>(frm.undist_keypts_.data()), frm.descriptors_.data,
-                      stereo ? frm.stereo_x_right_.data() : nullptr, occupied.data(), n, lm_xy.data(), stereo ? lm_x_right.data() : nullptr,
-                      lm_level.data(), lm_desc.data(), lm_valid.data(), m, frm.scale_factors_.data(), (int)frm.scale_factors_.size(), margin,
-                      lowe_ratio_, assigned.data(), &num_matches),
-                  "ovs_projection_match_frame_and_landmarks");
+    // the frame's keypoints, descriptors and grid are resident (uploaded by the first matcher call on this frame)
+    detail::check(ovs_projection_match_frame_and_landmarks_f(detail::window_ctx().get(n, m), detail::device_frame_of(frm), occupied.data(), lm_xy.data(),
+                                                             stereo ? lm_x_right.data() : nullptr, lm_level.data(), lm_desc.data(), lm_valid.data(), m,
+                                                             frm.scale_factors_.data(), (int)frm.scale_factors_.size(), margin, lowe_ratio_,
+                                                             assigned.data(), &num_matches),
+                  "ovs_projection_match_frame_and_landmarks_f");
     for (int l = 0; l < m; ++l)
         if (assigned[l] >= 0) frm.landmarks_[assigned[l]] = local_landmarks[l];
     return (unsigned int)num_matches;
@@ -57,21 +56,18 @@ unsigned int projection::match_current_and_last_frames(data::frame& curr_frm, co
         std::memcpy(&last_desc[(size_t)32 * i], d.data, 32);
     }
     for (int i = 0; i < n_curr; ++i) occupied[i] = curr_frm.landmarks_[i] && curr_frm.landmarks_[i]->has_observation();
-    const bool stereo = !curr_frm.stereo_x_right_.empty();
-    const ovs_grid_params gp = detail::grid_of(curr_frm.camera_);
     const ovs_camera cam = detail::camera_of(curr_frm.camera_);
     double pose_curr[12], pose_last[12];
     detail::pose12(curr_frm.cam_pose_cw_, pose_curr);
     detail::pose12(last_frm.cam_pose_cw_, pose_last);
     std::vector<int32_t> assigned((size_t)n_last, -1);
     int32_t num_matches = 0;
-    detail::check(ovs_projection_match_current_and_last_frames(
-                      detail::window_ctx().get(n_curr, n_last), &cam, &gp, reinterpret_cast<const ovs_keypoint*>(curr_frm.undist_keypts_.data()),
-                      curr_frm.descriptors_.data, stereo ? curr_frm.stereo_x_right_.data() : nullptr, occupied.data(), n_curr, pose_curr,
+    detail::check(ovs_projection_match_current_and_last_frames_f(
+                      detail::window_ctx().get(n_curr, n_last), &cam, detail::device_frame_of(curr_frm), occupied.data(), pose_curr,
                       reinterpret_cast<const ovs_keypoint*>(last_frm.undist_keypts_.data()), last_pos.data(), last_desc.data(), last_valid.data(),
                       n_last, pose_last, curr_frm.scale_factors_.data(), (int)curr_frm.scale_factors_.size(), margin, check_orientation_ ? 1 : 0,
                       assigned.data(), &num_matches),
-                  "ovs_projection_match_current_and_last_frames");
+                  "ovs_projection_match_current_and_last_frames_f");
     for (int i = 0; i < n_last; ++i)
         if (assigned[i] >= 0) curr_frm.landmarks_[assigned[i]] = last_frm.landmarks_[i];
     return (unsigned int)num_matches;

@@ -3,6 +3,7 @@
 #pragma once
 #include <ovslam_hip.h>
 
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -63,6 +64,22 @@ inline ovs_camera camera_of(const camera::base* cam) {
     c.cols = (int32_t)cam->cols_;
     c.rows = (int32_t)cam->rows_;
     return c;
+}
+
+// the frame's device-side cache: uploaded + indexed on first use, reused by every later matcher call on the same frame (or a copy of it)
+inline const ovs_frame_dev* device_frame_of(const data::frame& frm) {
+    if (frm.device_cache_ && frm.device_cache_->handle) return static_cast<const ovs_frame_dev*>(frm.device_cache_->handle);
+    const ovs_grid_params gp = grid_of(frm.camera_);
+    ovs_frame_dev* f = nullptr;
+    const bool stereo = !frm.stereo_x_right_.empty();
+    const int st = ovs_frame_dev_create(0, &gp, reinterpret_cast<const ovs_keypoint*>(frm.undist_keypts_.data()), frm.descriptors_.data,
+                                        stereo ? frm.stereo_x_right_.data() : nullptr, (int32_t)frm.undist_keypts_.size(), &f);
+    if (st != OVS_OK) throw std::runtime_error(std::string("ovs_frame_dev_create failed: ") + ovs_last_error());
+    auto c = std::make_shared<data::frame_device_cache>();
+    c->handle = f;
+    c->destroy = [](void* h) { ovs_frame_dev_destroy(static_cast<ovs_frame_dev*>(h)); };
+    frm.device_cache_ = c;
+    return f;
 }
 
 // rows 0..2 of a 4x4 [R|t] -> 12 doubles: rotation row-major, then translation

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -914,6 +915,13 @@ struct ovs_wmatcher {
     double* d_tri_b2 = nullptr;
     int32_t* d_csr = nullptr;           // bow feature vectors: 2 x (ids | start | items)
     size_t csr_cap = 0;
+    // round 3: d_overflow | d_num[4] | pad | d_assigned are ONE block (a call's results come down with one copy), and the frame-handle
+    // entry points stage their per-call host arrays through one pinned buffer into one device arena (one copy up)
+    uint32_t* d_res_block = nullptr;
+    int32_t* h_res = nullptr;           // pinned mirror of the result block
+    unsigned char* h_stage = nullptr;   // pinned
+    unsigned char* d_stage = nullptr;
+    size_t stage_cap = 0;
 };
 
 namespace {
@@ -1022,9 +1030,17 @@ ovs_status ovs_wmatcher_create(int32_t max_targets, int32_t max_queries, int32_t
     CREATE_TRY(hipMalloc(&w->d_counts, sizeof(uint32_t) * (Q + 1)));
     CREATE_TRY(hipMalloc(&w->d_offsets, sizeof(uint32_t) * (Q + 1)));
     CREATE_TRY(hipMalloc(&w->d_keys, sizeof(uint32_t) * (size_t)max_entries));
-    CREATE_TRY(hipMalloc(&w->d_overflow, sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc(&w->d_assigned, sizeof(int32_t) * M));
-    CREATE_TRY(hipMalloc(&w->d_num, sizeof(int32_t) * 4));   // [0] result count, [1] per-direction scratch count
+    // result block: [0] overflow flag, [1..4] counts ([1] result count, [2] per-direction scratch count), [8..] assigned
+    CREATE_TRY(hipMalloc(&w->d_res_block, sizeof(int32_t) * (8 + M)));
+    w->d_overflow = w->d_res_block;
+    w->d_num = reinterpret_cast<int32_t*>(w->d_res_block) + 1;
+    w->d_assigned = reinterpret_cast<int32_t*>(w->d_res_block) + 8;
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&w->h_res), sizeof(int32_t) * (8 + M), hipHostMallocDefault));
+    // per-call query-side staging: keypoints 28 + descriptors 32 + positions 24 + xy 8 + four 4-byte arrays + flags, per query, and the
+    // target-side flags; 256-byte alignment slack per array
+    w->stage_cap = Q * (28 + 32 + 24 + 8 + 16 + 1) + T * 2 + 16 * 256 + 4096;
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&w->h_stage), w->stage_cap, hipHostMallocDefault));
+    CREATE_TRY(hipMalloc(&w->d_stage, w->stage_cap));
     CREATE_TRY(hipMalloc(&w->d_t_kps, sizeof(ovs_keypoint) * T));
     CREATE_TRY(hipMalloc(&w->d_t_desc, 32 * T));
     CREATE_TRY(hipMalloc(&w->d_t_flag, T));
@@ -1051,7 +1067,9 @@ ovs_status ovs_wmatcher_create(int32_t max_targets, int32_t max_queries, int32_t
 ovs_status ovs_wmatcher_destroy(ovs_wmatcher* w) {
     if (!w) return OVS_OK;
     if (w->stream) hipStreamSynchronize(w->stream);
-    void* ptrs[] = {w->d_cell_of, w->d_cell_start, w->d_items, w->d_counts, w->d_offsets, w->d_keys, w->d_overflow, w->d_assigned, w->d_num,
+    if (w->h_res) hipHostFree(w->h_res);
+    if (w->h_stage) hipHostFree(w->h_stage);
+    void* ptrs[] = {w->d_cell_of, w->d_cell_start, w->d_items, w->d_counts, w->d_offsets, w->d_keys, w->d_res_block, w->d_stage,
                     w->d_t_kps,   w->d_t_desc,     w->d_t_flag, w->d_t_f,    w->d_q_kps,   w->d_q_desc, w->d_q_flag,  w->d_q_xy,    w->d_q_f,
                     w->d_q_i,     w->d_csr,        w->d_q_r,    w->d_q_i2,   w->d_q_pos,   w->d_sf,
                     w->d_tri_b1,  w->d_tri_b2};
@@ -1967,6 +1985,426 @@ ovs_status ovs_projection_match_keyframes_mutually(ovs_wmatcher* w, const ovs_ca
     OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipStreamSynchronize(s));
     return OVS_OK;
+}
+
+}   // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Frame residency behind the class boundary (round 3): a frame's matcher-side data -- undistorted keypoints,
+// descriptors, stereo_x_right and the keypoint grid data::assign_keypoints_to_grid builds in the frame's constructor -- is uploaded and
+// indexed ONCE per frame (ovs_frame_dev), and the matchers that tracking_module calls two to four times on the same frame take the handle.
+// What remains per call is what really changes per call: the landmark side, staged through ONE pinned buffer into ONE device arena (one
+// copy up), and the result block (one copy down).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct ovs_frame_dev {
+    int device = 0;
+    int n = 0, cap = 0, n_cells = 0;
+    bool has_stereo = false;
+    GridP gp{};
+    ovs_grid_params gpp{};
+    unsigned char* arena = nullptr;
+    size_t arena_bytes = 0;
+    ovs_keypoint* d_kps = nullptr;
+    uint8_t* d_desc = nullptr;
+    float* d_x_right = nullptr;
+    int32_t *d_cell_of = nullptr, *d_cell_start = nullptr, *d_items = nullptr;
+};
+
+namespace {
+
+size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// device arenas of destroyed frame handles, kept for the next frame (a tracker creates one handle per frame: a hipMalloc / hipFree pair
+// per frame would cost more than the upload). Bounded; keyed by device and size.
+struct FrameArenaPool {
+    struct Item {
+        int device;
+        size_t bytes;
+        unsigned char* p;
+    };
+    std::mutex mu;
+    std::vector<Item> free_list;
+    unsigned char* take(int device, size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < free_list.size(); ++i)
+            if (free_list[i].device == device && free_list[i].bytes == bytes) {
+                unsigned char* p = free_list[i].p;
+                free_list.erase(free_list.begin() + (long)i);
+                return p;
+            }
+        return nullptr;
+    }
+    void give(int device, size_t bytes, unsigned char* p) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (free_list.size() < 8) {
+                free_list.push_back(Item{device, bytes, p});
+                return;
+            }
+        }
+        (void)hipSetDevice(device);
+        (void)hipFree(p);
+    }
+};
+FrameArenaPool g_frame_pool;
+
+// pinned staging for the once-per-frame upload, per thread (frames are created by the tracking thread; stereo rigs by two)
+struct FrameStage {
+    unsigned char* h = nullptr;
+    size_t cap = 0;
+    hipStream_t stream = nullptr;
+    int device = -1;
+    ~FrameStage() {
+        if (h) (void)hipHostFree(h);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+// per-call staging of host arrays: memcpy into the context's pinned buffer, ONE hipMemcpyAsync for all of them
+struct Stager {
+    ovs_wmatcher* w;
+    size_t used = 0;
+    bool overflow = false;
+    explicit Stager(ovs_wmatcher* w_) : w(w_) {}
+    template <typename T>
+    const T* put(const T* src, size_t count) {   // nullptr in -> nullptr out
+        if (!src) return nullptr;
+        const size_t bytes = sizeof(T) * count, off = al256(used);
+        if (off + bytes > w->stage_cap) {
+            overflow = true;
+            return nullptr;
+        }
+        std::memcpy(w->h_stage + off, src, bytes);
+        used = off + bytes;
+        return reinterpret_cast<const T*>(w->d_stage + off);
+    }
+    template <typename T>
+    T* reserve(size_t count) {   // device-only scratch in the same arena (filled by a kernel)
+        const size_t bytes = sizeof(T) * count, off = al256(used);
+        if (off + bytes > w->stage_cap) {
+            overflow = true;
+            return nullptr;
+        }
+        used = off + bytes;
+        return reinterpret_cast<T*>(w->d_stage + off);
+    }
+    hipError_t flush(hipStream_t s) { return used ? hipMemcpyAsync(w->d_stage, w->h_stage, used, hipMemcpyHostToDevice, s) : hipSuccess; }
+};
+
+// results: overflow flag, counts and `n_out` assignments in one copy
+ovs_status fetch_results(ovs_wmatcher* w, int n_out, int32_t* assigned, int32_t* num_matches, hipStream_t s) {
+    OVS_HIP_TRY(hipMemcpyAsync(w->h_res, w->d_res_block, sizeof(int32_t) * (8 + (size_t)n_out), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(assigned, w->h_res + 8, sizeof(int32_t) * (size_t)n_out);
+    *num_matches = w->h_res[1];
+    return w->h_res[0] ? OVS_ERR_CAPACITY : OVS_OK;
+}
+
+}   // namespace
+
+extern "C" {
+
+ovs_status ovs_frame_dev_destroy(ovs_frame_dev* f) {
+    if (!f) return OVS_OK;
+    if (f->arena) g_frame_pool.give(f->device, f->arena_bytes, f->arena);
+    delete f;
+    return OVS_OK;
+}
+
+ovs_status ovs_frame_dev_create(int32_t device, const ovs_grid_params* gp, const ovs_keypoint* undist_kps, const uint8_t* desc,
+                                const float* stereo_x_right, int32_t n, ovs_frame_dev** out) {
+    if (!out || !gp || n < 0 || n > 65534 || (n > 0 && (!undist_kps || !desc))) return OVS_ERR_INVALID;
+    *out = nullptr;
+    if (gp->cols < 1 || gp->rows < 1 || gp->cols * gp->rows > kMaxGridCells || !(gp->max_x > gp->min_x) || !(gp->max_y > gp->min_y)) return OVS_ERR_INVALID;
+    if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
+    OVS_HIP_TRY(hipSetDevice(device));
+    ovs_frame_dev* f = new (std::nothrow) ovs_frame_dev();
+    if (!f) return OVS_ERR_INVALID;
+    f->device = device;
+    f->n = n;
+    f->cap = std::max((n + 4095) & ~4095, 4096);   // capacity classes of 4096 keypoints: pooled arenas fit the next frame
+    f->n_cells = gp->cols * gp->rows;
+    f->has_stereo = stereo_x_right != nullptr;
+    f->gpp = *gp;
+    f->gp = make_gridp(*gp);
+    const size_t C = (size_t)f->cap;
+    const size_t o_kps = 0, o_desc = al256(o_kps + sizeof(ovs_keypoint) * C), o_xr = al256(o_desc + 32 * C), o_cellof = al256(o_xr + 4 * C),
+                 o_items = al256(o_cellof + 4 * C), o_start = al256(o_items + 4 * C);
+    f->arena_bytes = al256(o_start + sizeof(int32_t) * (kMaxGridCells + 1));
+    f->arena = g_frame_pool.take(device, f->arena_bytes);
+    if (!f->arena) {
+        const hipError_t e = hipMalloc(&f->arena, f->arena_bytes);
+        if (e != hipSuccess) {
+            ovs::set_last_error("hipMalloc(frame arena)", e);
+            delete f;
+            return OVS_ERR_HIP;
+        }
+    }
+    f->d_kps = reinterpret_cast<ovs_keypoint*>(f->arena + o_kps);
+    f->d_desc = f->arena + o_desc;
+    f->d_x_right = reinterpret_cast<float*>(f->arena + o_xr);
+    f->d_cell_of = reinterpret_cast<int32_t*>(f->arena + o_cellof);
+    f->d_items = reinterpret_cast<int32_t*>(f->arena + o_items);
+    f->d_cell_start = reinterpret_cast<int32_t*>(f->arena + o_start);
+    static thread_local FrameStage st;
+    ovs_status rc = OVS_ERR_HIP;
+    hipError_t er = hipSuccess;
+    do {
+#define F_TRY(expr)                           \
+    if ((er = (expr)) != hipSuccess) {        \
+        ovs::set_last_error(#expr, er);       \
+        break;                                \
+    }
+        if (st.device != device) {
+            if (st.stream) (void)hipStreamDestroy(st.stream);
+            st.stream = nullptr;
+            st.device = device;
+        }
+        if (!st.stream) F_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+        // the three arrays keep their arena offsets in the staging buffer, so ONE copy of [0, end of the last array) uploads them
+        const size_t up_bytes = n ? (stereo_x_right ? o_xr + 4 * (size_t)n : o_desc + 32 * (size_t)n) : 0;
+        if (st.cap < up_bytes) {
+            if (st.h) (void)hipHostFree(st.h);
+            st.h = nullptr;
+            st.cap = 0;
+            const size_t want = std::max(up_bytes, al256(o_xr + 4 * (size_t)4096 * 4));
+            F_TRY(hipHostMalloc(reinterpret_cast<void**>(&st.h), want, hipHostMallocDefault));
+            st.cap = want;
+        }
+        if (n) {
+            std::memcpy(st.h + o_kps, undist_kps, sizeof(ovs_keypoint) * (size_t)n);
+            std::memcpy(st.h + o_desc, desc, 32 * (size_t)n);
+            if (stereo_x_right) std::memcpy(st.h + o_xr, stereo_x_right, 4 * (size_t)n);
+            F_TRY(hipMemcpyAsync(f->arena, st.h, up_bytes, hipMemcpyHostToDevice, st.stream));
+        }
+        const size_t lds = (size_t)(2 * f->n_cells + 1) * sizeof(int32_t);
+        if (lds > 64 * 1024)
+            F_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_assign), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_grid_assign, dim3(1), dim3(1024), lds, st.stream, (const ovs_keypoint*)f->d_kps, n, f->gp, f->d_cell_of, f->d_cell_start,
+                           f->d_items);
+        F_TRY(hipGetLastError());
+        F_TRY(hipStreamSynchronize(st.stream));   // the handle is used from other streams afterwards
+        rc = OVS_OK;
+#undef F_TRY
+    } while (0);
+    if (rc != OVS_OK) {
+        ovs_frame_dev_destroy(f);
+        return rc;
+    }
+    *out = f;
+    return OVS_OK;
+}
+
+int32_t ovs_frame_dev_num_keypoints(const ovs_frame_dev* f) { return f ? f->n : -1; }
+
+ovs_status ovs_projection_match_frame_and_landmarks_f(ovs_wmatcher* w, const ovs_frame_dev* frm, const uint8_t* occupied, const float* lm_xy,
+                                                      const float* lm_x_right, const int32_t* lm_level, const uint8_t* lm_desc,
+                                                      const uint8_t* lm_valid, int32_t m, const float* scale_factors, int32_t num_levels,
+                                                      float margin, float lowe_ratio, int32_t* assigned, int32_t* num_matches) {
+    if (!w || !frm || !num_matches || m < 0 || !scale_factors || num_levels < 1 || num_levels > OVS_MAX_LEVELS) return OVS_ERR_INVALID;
+    *num_matches = 0;
+    if (m == 0) return OVS_OK;
+    if (!assigned) return OVS_ERR_INVALID;
+    const int n = frm->n;
+    if (n == 0) {
+        for (int i = 0; i < m; ++i) assigned[i] = -1;
+        return OVS_OK;
+    }
+    if (!lm_xy || !lm_level || !lm_desc || (frm->has_stereo && !lm_x_right)) return OVS_ERR_INVALID;
+    if (frm->device != w->device) return OVS_ERR_INVALID;
+    if (n > w->max_t || m > w->max_q) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = w->stream;
+    Stager stg(w);
+    WinArgs a{};
+    a.t_kps = frm->d_kps;
+    a.t_desc = frm->d_desc;
+    a.t_occupied = stg.put(occupied, (size_t)n);
+    a.t_x_right = frm->has_stereo ? frm->d_x_right : nullptr;
+    a.cell_start = frm->d_cell_start;
+    a.items = frm->d_items;
+    a.gp = frm->gp;
+    a.n_q = m;
+    a.q_xy = stg.put(lm_xy, (size_t)2 * m);
+    a.q_x_right = frm->has_stereo ? stg.put(lm_x_right, (size_t)m) : nullptr;
+    a.q_level = stg.put(lm_level, (size_t)m);
+    a.q_valid = stg.put(lm_valid, (size_t)m);
+    a.q_desc = stg.put(lm_desc, (size_t)32 * m);
+    a.margin = margin;
+    for (int l = 0; l < OVS_MAX_LEVELS; ++l) a.sf[l] = l < num_levels ? scale_factors[l] : 1.0f;
+    a.mode = kModeProjection;
+    if (stg.overflow) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(stg.flush(s));
+    ovs_status st = build_lists(w, a, m, k_window_lists<false>, k_window_lists<true>, s);
+    if (st != OVS_OK) return st;
+    ResolveArgs ra{};
+    ra.offsets = w->d_offsets;
+    ra.keys = w->d_keys;
+    ra.n_q = m;
+    ra.n_t = n;
+    ra.lowe_ratio = lowe_ratio;
+    ra.assigned = w->d_assigned;
+    ra.num_matches = w->d_num;
+    st = launch_resolve<kRuleProjection>(ra, s);
+    if (st != OVS_OK) return st;
+    return fetch_results(w, m, assigned, num_matches, s);
+}
+
+ovs_status ovs_area_match_in_consistent_area_f(ovs_wmatcher* w, const ovs_frame_dev* frm_1, const ovs_frame_dev* frm_2, float* prev_matched_xy,
+                                               int32_t* matched_2_in_1, int32_t margin, float lowe_ratio, int32_t check_orientation,
+                                               int32_t* num_matches) {
+    if (!w || !frm_1 || !frm_2 || !num_matches) return OVS_ERR_INVALID;
+    *num_matches = 0;
+    const int n1 = frm_1->n, n2 = frm_2->n;
+    if (n1 == 0) return OVS_OK;
+    if (!prev_matched_xy || !matched_2_in_1) return OVS_ERR_INVALID;
+    if (n2 == 0) {
+        for (int i = 0; i < n1; ++i) matched_2_in_1[i] = -1;
+        return OVS_OK;
+    }
+    if (frm_1->device != w->device || frm_2->device != w->device) return OVS_ERR_INVALID;
+    if (n2 > w->max_t || n1 > w->max_q) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = w->stream;
+    Stager stg(w);
+    // prev_matched_pts are read AND updated by the resolver: they live in the staging arena and come back with their own copy
+    const float* d_prev_c = stg.put(prev_matched_xy, (size_t)2 * n1);
+    if (stg.overflow) return OVS_ERR_CAPACITY;
+    float* d_prev = const_cast<float*>(d_prev_c);
+    OVS_HIP_TRY(stg.flush(s));
+    WinArgs a{};
+    a.t_kps = frm_2->d_kps;
+    a.t_desc = frm_2->d_desc;
+    a.cell_start = frm_2->d_cell_start;
+    a.items = frm_2->d_items;
+    a.gp = frm_2->gp;
+    a.n_q = n1;
+    a.q_xy = d_prev;
+    a.q_kps = frm_1->d_kps;
+    a.q_desc = frm_1->d_desc;
+    a.margin = (float)margin;
+    a.mode = kModeArea;
+    ovs_status st = build_lists(w, a, n1, k_window_lists<false>, k_window_lists<true>, s);
+    if (st != OVS_OK) return st;
+    ResolveArgs ra{};
+    ra.offsets = w->d_offsets;
+    ra.keys = w->d_keys;
+    ra.n_q = n1;
+    ra.n_t = n2;
+    ra.lowe_ratio = lowe_ratio;
+    ra.check_orientation = check_orientation;
+    ra.q_kps = frm_1->d_kps;
+    ra.t_kps = frm_2->d_kps;
+    ra.prev_matched_xy = d_prev;
+    ra.assigned = w->d_assigned;
+    ra.num_matches = w->d_num;
+    st = launch_resolve<kRuleArea>(ra, s);
+    if (st != OVS_OK) return st;
+    OVS_HIP_TRY(hipMemcpyAsync(w->h_stage, d_prev, sizeof(float) * 2 * (size_t)n1, hipMemcpyDeviceToHost, s));
+    st = fetch_results(w, n1, matched_2_in_1, num_matches, s);
+    std::memcpy(prev_matched_xy, w->h_stage, sizeof(float) * 2 * (size_t)n1);
+    return st;
+}
+
+ovs_status ovs_projection_match_current_and_last_frames_f(ovs_wmatcher* w, const ovs_camera* cam, const ovs_frame_dev* curr,
+                                                          const uint8_t* curr_occupied, const double* pose_cw_curr, const ovs_keypoint* last_kps,
+                                                          const double* last_pos_w, const uint8_t* last_lm_desc, const uint8_t* last_valid,
+                                                          int32_t n_last, const double* pose_cw_last, const float* scale_factors,
+                                                          int32_t num_levels, float margin, int32_t check_orientation, int32_t* assigned,
+                                                          int32_t* num_matches) {
+    if (!w || !cam || !curr || !num_matches || n_last < 0 || !pose_cw_curr || !pose_cw_last || !scale_factors || num_levels < 1 ||
+        num_levels > OVS_MAX_LEVELS || (cam->model != 0 && cam->model != 1))
+        return OVS_ERR_INVALID;
+    *num_matches = 0;
+    if (n_last == 0) return OVS_OK;
+    if (!assigned) return OVS_ERR_INVALID;
+    for (int i = 0; i < n_last; ++i) assigned[i] = -1;
+    const int n_curr = curr->n;
+    if (n_curr == 0) return OVS_OK;
+    if (!last_kps || !last_pos_w || !last_lm_desc) return OVS_ERR_INVALID;
+    if (curr->device != w->device) return OVS_ERR_INVALID;
+    if (n_curr > w->max_t || n_last > w->max_q) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = w->stream;
+    // motion direction (host, double): trans_wc = -rot_cw^T trans_cw; trans_lc = rot_lw trans_wc + trans_lw
+    const double* Rc = pose_cw_curr;
+    const double* tc = pose_cw_curr + 9;
+    const double twc[3] = {-((Rc[0] * tc[0] + Rc[3] * tc[1]) + Rc[6] * tc[2]), -((Rc[1] * tc[0] + Rc[4] * tc[1]) + Rc[7] * tc[2]),
+                           -((Rc[2] * tc[0] + Rc[5] * tc[1]) + Rc[8] * tc[2])};
+    const double* Rl = pose_cw_last;
+    const double tlc_z = ((Rl[6] * twc[0] + Rl[7] * twc[1]) + Rl[8] * twc[2]) + pose_cw_last[11];
+    const int forward = cam->setup == 0 ? 0 : (tlc_z > cam->true_baseline);
+    const int backward = cam->setup == 0 ? 0 : (-tlc_z > cam->true_baseline);
+    CamP cp{};
+    cp.model = cam->model;
+    cp.setup = cam->setup;
+    cp.fx = cam->fx;
+    cp.fy = cam->fy;
+    cp.cx = cam->cx;
+    cp.cy = cam->cy;
+    cp.fxb = cam->focal_x_baseline;
+    cp.cols = cam->cols;
+    cp.rows = cam->rows;
+    cp.min_x = curr->gpp.min_x;
+    cp.min_y = curr->gpp.min_y;
+    cp.max_x = curr->gpp.max_x;
+    cp.max_y = curr->gpp.max_y;
+    std::memcpy(cp.P, pose_cw_curr, sizeof(double) * 12);
+    float sf16[OVS_MAX_LEVELS];
+    for (int l = 0; l < OVS_MAX_LEVELS; ++l) sf16[l] = l < num_levels ? scale_factors[l] : 1.0f;
+    Stager stg(w);
+    const uint8_t* d_occ = stg.put(curr_occupied, (size_t)n_curr);
+    const ovs_keypoint* d_q_kps = stg.put(last_kps, (size_t)n_last);
+    const double* d_q_pos = stg.put(last_pos_w, (size_t)3 * n_last);
+    const uint8_t* d_q_desc = stg.put(last_lm_desc, (size_t)32 * n_last);
+    const float* d_sf = stg.put(sf16, (size_t)OVS_MAX_LEVELS);
+    // the query flags are written by k_reproject_queries (in place over last_valid when given: same index, read-then-write by one lane)
+    uint8_t* d_q_flag = last_valid ? const_cast<uint8_t*>(stg.put(last_valid, (size_t)n_last)) : stg.reserve<uint8_t>((size_t)n_last);
+    float* d_q_xy = stg.reserve<float>((size_t)2 * n_last);
+    float* d_q_f = stg.reserve<float>((size_t)n_last);
+    float* d_q_r = stg.reserve<float>((size_t)n_last);
+    int32_t* d_q_i = stg.reserve<int32_t>((size_t)n_last);
+    int32_t* d_q_i2 = stg.reserve<int32_t>((size_t)n_last);
+    if (stg.overflow) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(stg.flush(s));
+    hipLaunchKernelGGL(k_reproject_queries, dim3((n_last + 255) / 256), dim3(256), 0, s, cp, d_q_kps, d_q_pos, (const uint8_t*)(last_valid ? d_q_flag : nullptr),
+                       n_last, margin, d_sf, num_levels, forward, backward, (const float*)nullptr, 0.0, 0.0, 0.0, 0.0f, d_q_xy, d_q_f, d_q_r, d_q_i, d_q_i2,
+                       d_q_flag);
+    OVS_HIP_TRY(hipGetLastError());
+    WinArgs a{};
+    a.t_kps = curr->d_kps;
+    a.t_desc = curr->d_desc;
+    a.t_occupied = d_occ;
+    a.t_x_right = curr->has_stereo ? curr->d_x_right : nullptr;
+    a.cell_start = curr->d_cell_start;
+    a.items = curr->d_items;
+    a.gp = curr->gp;
+    a.n_q = n_last;
+    a.q_xy = d_q_xy;
+    a.q_x_right = d_q_f;
+    a.q_valid = d_q_flag;
+    a.q_radius = d_q_r;
+    a.q_minl = d_q_i;
+    a.q_maxl = d_q_i2;
+    a.q_desc = d_q_desc;
+    a.margin = margin;
+    a.mode = kModeGeneric;
+    ovs_status st = build_lists(w, a, n_last, k_window_lists<false>, k_window_lists<true>, s);
+    if (st != OVS_OK) return st;
+    ResolveArgs ra{};
+    ra.offsets = w->d_offsets;
+    ra.keys = w->d_keys;
+    ra.n_q = n_last;
+    ra.n_t = n_curr;
+    ra.check_orientation = check_orientation;
+    ra.q_kps = d_q_kps;
+    ra.t_kps = curr->d_kps;
+    ra.assigned = w->d_assigned;
+    ra.num_matches = w->d_num;
+    ra.best_only_thr = OVS_HAMMING_DIST_THR_HIGH;
+    st = launch_resolve<kRuleBestOnly>(ra, s);
+    if (st != OVS_OK) return st;
+    return fetch_results(w, n_last, assigned, num_matches, s);
 }
 
 }   // extern "C"

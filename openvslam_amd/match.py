@@ -136,6 +136,28 @@ class _window_ctx:
         return start, items[:n.value].copy()
 
 
+class frame_dev:
+    """A frame's matcher-side data resident in HBM (ovs_frame_dev): undistorted keypoints, descriptors, stereo_x_right and the keypoint grid,
+    uploaded and indexed once; pass it as `frm_keypts` / `curr_keypts` / `keypts_1` / `keypts_2` to the matchers below instead of host arrays."""
+
+    def __init__(self, gp, keypts, desc, stereo_x_right=None, device=0):
+        self._L = _lib.lib()
+        _lib.require_device()
+        k = np.ascontiguousarray(keypts, KP_DTYPE)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        xr = None if stereo_x_right is None else np.ascontiguousarray(stereo_x_right, np.float32)
+        h = C.c_void_p()
+        _lib.check(self._L.ovs_frame_dev_create(device, C.byref(gp), _p(k), _p(d), _p(xr), len(k), C.byref(h)), "ovs_frame_dev_create")
+        self._h = h
+        self.num_keypts = len(k)
+        self.has_stereo = xr is not None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.ovs_frame_dev_destroy(h)
+
+
 class projection(_window_ctx):
     """match::projection(lowe_ratio, check_orientation)."""
 
@@ -148,10 +170,22 @@ class projection(_window_ctx):
                                   frm_stereo_x_right=None, frm_occupied=None, lm_x_right=None, lm_valid=None):
         """projection::match_frame_and_landmarks(frm, local_landmarks, margin): returns (assigned, num_matches) where
         assigned[l] is the frame keypoint that receives landmark l (frm.landmarks_[assigned[l]] = local_landmarks[l]) or -1."""
-        k = np.ascontiguousarray(frm_keypts, KP_DTYPE)
-        d = np.ascontiguousarray(frm_desc, np.uint8).reshape(-1, 32)
         sf = np.ascontiguousarray(scale_factors, np.float32)
         xy = np.ascontiguousarray(lm_reproj, np.float32).reshape(-1, 2)
+        if isinstance(frm_keypts, frame_dev):   # the frame side is resident: gp / frm_desc / frm_stereo_x_right are the handle's
+            lv = np.ascontiguousarray(lm_level, np.int32)
+            ld = np.ascontiguousarray(lm_desc, np.uint8).reshape(-1, 32)
+            occ = None if frm_occupied is None else np.ascontiguousarray(frm_occupied, np.uint8)
+            lxr = None if lm_x_right is None else np.ascontiguousarray(lm_x_right, np.float32)
+            val = None if lm_valid is None else np.ascontiguousarray(lm_valid, np.uint8)
+            assigned = np.full(max(len(xy), 1), -1, np.int32)
+            n = C.c_int32()
+            _lib.check(self._L.ovs_projection_match_frame_and_landmarks_f(
+                self._h, frm_keypts._h, _p(occ), _p(xy), _p(lxr), _p(lv), _p(ld), _p(val), len(xy), _p(sf), len(sf), float(margin), self.lowe_ratio_,
+                _p(assigned), C.byref(n)), "ovs_projection_match_frame_and_landmarks_f")
+            return assigned[:len(xy)].copy(), n.value
+        k = np.ascontiguousarray(frm_keypts, KP_DTYPE)
+        d = np.ascontiguousarray(frm_desc, np.uint8).reshape(-1, 32)
         lv = np.ascontiguousarray(lm_level, np.int32)
         ld = np.ascontiguousarray(lm_desc, np.uint8).reshape(-1, 32)
         xr = None if frm_stereo_x_right is None else np.ascontiguousarray(frm_stereo_x_right, np.float32)
@@ -170,14 +204,23 @@ class projection(_window_ctx):
                                       pose_cw_last, scale_factors, margin, curr_stereo_x_right=None, curr_occupied=None, last_valid=None):
         """projection::match_current_and_last_frames(curr_frm, last_frm, margin): returns (assigned, num_matches); assigned[i] is the
         current keypoint that receives last_frm.landmarks_[i], or -1. Poses are 3x4 [R|t] world->camera."""
-        ck = np.ascontiguousarray(curr_keypts, KP_DTYPE)
-        cd = np.ascontiguousarray(curr_desc, np.uint8).reshape(-1, 32)
         lk = np.ascontiguousarray(last_keypts, KP_DTYPE)
         pw = np.ascontiguousarray(last_pos_w, np.float64).reshape(-1, 3)
         ld = np.ascontiguousarray(last_lm_desc, np.uint8).reshape(-1, 32)
         sf = np.ascontiguousarray(scale_factors, np.float32)
         pc = _pose12(pose_cw_curr)
         pl = _pose12(pose_cw_last)
+        if isinstance(curr_keypts, frame_dev):   # the current frame is resident
+            occ = None if curr_occupied is None else np.ascontiguousarray(curr_occupied, np.uint8)
+            val = None if last_valid is None else np.ascontiguousarray(last_valid, np.uint8)
+            assigned = np.full(max(len(lk), 1), -1, np.int32)
+            n = C.c_int32()
+            _lib.check(self._L.ovs_projection_match_current_and_last_frames_f(
+                self._h, C.byref(cam), curr_keypts._h, _p(occ), _p(pc), _p(lk), _p(pw), _p(ld), _p(val), len(lk), _p(pl), _p(sf), len(sf), float(margin),
+                1 if self.check_orientation_ else 0, _p(assigned), C.byref(n)), "ovs_projection_match_current_and_last_frames_f")
+            return assigned[:len(lk)].copy(), n.value
+        ck = np.ascontiguousarray(curr_keypts, KP_DTYPE)
+        cd = np.ascontiguousarray(curr_desc, np.uint8).reshape(-1, 32)
         xr = None if curr_stereo_x_right is None else np.ascontiguousarray(curr_stereo_x_right, np.float32)
         occ = None if curr_occupied is None else np.ascontiguousarray(curr_occupied, np.uint8)
         val = None if last_valid is None else np.ascontiguousarray(last_valid, np.uint8)
@@ -281,6 +324,16 @@ class area(_window_ctx):
     def match_in_consistent_area(self, gp, keypts_1, desc_1, keypts_2, desc_2, prev_matched_pts, margin=10):
         """area::match_in_consistent_area(frm_1, frm_2, prev_matched_pts, matched_indices_2_in_frm_1, margin):
         returns (num_matches, matched_indices_2_in_frm_1); prev_matched_pts (n1, 2) float32 is updated in place."""
+        if isinstance(keypts_1, frame_dev) and isinstance(keypts_2, frame_dev):   # both frames resident (gp / desc_* are the handles')
+            n1 = keypts_1.num_keypts
+            if prev_matched_pts.dtype != np.float32 or not prev_matched_pts.flags.c_contiguous or prev_matched_pts.shape != (n1, 2):
+                raise ValueError("prev_matched_pts must be a C-contiguous (n1, 2) float32 array (it is updated in place)")
+            matched = np.full(max(n1, 1), -1, np.int32)
+            n = C.c_int32()
+            _lib.check(self._L.ovs_area_match_in_consistent_area_f(self._h, keypts_1._h, keypts_2._h, _p(prev_matched_pts), _p(matched), int(margin),
+                                                                   self.lowe_ratio_, int(self.check_orientation_), C.byref(n)),
+                       "ovs_area_match_in_consistent_area_f")
+            return n.value, matched[:n1].copy()
         k1 = np.ascontiguousarray(keypts_1, KP_DTYPE)
         k2 = np.ascontiguousarray(keypts_2, KP_DTYPE)
         d1 = np.ascontiguousarray(desc_1, np.uint8).reshape(-1, 32)

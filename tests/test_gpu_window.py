@@ -56,6 +56,12 @@ def test_projection_match_frame_and_landmarks(match, synth, oracle, n, m, rows, 
                                                                frm_stereo_x_right=xr, frm_occupied=occ, lm_x_right=lm.get("x_right"),
                                                                lm_valid=lm["valid"])
         assert gn == wn and np.array_equal(got, want)
+        # the frame side resident in HBM (ovs_frame_dev: uploaded and indexed once, then handed to the matcher): identical pairs
+        fd = match.frame_dev(gp, k, d, xr)
+        for _ in range(2):
+            got_f, gn_f = w.match_frame_and_landmarks(gp, fd, None, sf, lm["xy"], lm["level"], lm["desc"], margin, frm_occupied=occ,
+                                                      lm_x_right=lm.get("x_right"), lm_valid=lm["valid"])
+            assert gn_f == wn and np.array_equal(got_f, want)
         if n >= 2000:
             assert wn > n // 4   # the construction yields real matches and real collisions
             assigned = want[want >= 0]
@@ -84,6 +90,14 @@ def test_area_match_in_consistent_area(match, synth, oracle, check_orientation, 
         gn, got = w.match_in_consistent_area(gp, ka, da, kb, db, prev_g, margin)
         wn, want = oracle.area_match_in_consistent_area(ogp, ka, da, kb, db, prev_o, margin, ratio, check_orientation)
         assert gn == wn and np.array_equal(got, want) and np.array_equal(prev_g.view(np.uint32), prev_o.view(np.uint32))
+    # both frames resident (the initializer matches its init frame against every incoming frame)
+    f1, f2 = match.frame_dev(gp, ka, da), match.frame_dev(gp, kb, db)
+    prev_f = np.ascontiguousarray(np.stack([ka["x"], ka["y"]], 1), np.float32)
+    prev_o = prev_f.copy()
+    for it in range(2):
+        gn, got = w.match_in_consistent_area(gp, f1, None, f2, None, prev_f, margin)
+        wn, want = oracle.area_match_in_consistent_area(ogp, ka, da, kb, db, prev_o, margin, ratio, check_orientation)
+        assert gn == wn and np.array_equal(got, want) and np.array_equal(prev_f.view(np.uint32), prev_o.view(np.uint32))
     assert wn > 50
     assert (ka["octave"][want >= 0] == 0).all()
 
@@ -193,6 +207,9 @@ def test_projection_match_current_and_last_frames(match, synth, oracle, model, s
         want, wn = oracle.projection_match_current_and_last_frames(ocam, ogp, ck, cd, Tc, lk, lpw, ld, Tl, sf, margin, check_orientation,
                                                                    curr_stereo_x_right=xr, curr_occupied=occ, last_valid=valid)
         assert gn == wn and np.array_equal(got, want)
+        fd = match.frame_dev(gp, ck, cd, xr)   # the current frame resident
+        got_f, gn_f = w.match_current_and_last_frames(cam, gp, fd, None, Tc, lk, lpw, ld, Tl, sf, margin, curr_occupied=occ, last_valid=valid)
+        assert gn_f == wn and np.array_equal(got_f, want)
     assert wn > n // 10
 
 
