@@ -440,7 +440,9 @@ ovs_status ovs_stereo_destroy(ovs_stereo* s);
 /* replaces: void stereo::compute(std::vector<float>& stereo_x_right, std::vector<float>& depths) const.
  * kps_* / desc_* = the keypoints and descriptors the two handles extracted (frame 0 of their last extract);
  * focal_x_baseline / true_baseline = camera->focal_x_baseline_ / true_baseline_. stereo_x_right / depths: n_left floats, -1 where
- * no match. *n_valid (may be NULL) = number of keypoints that received a depth. */
+ * no match. *n_valid (may be NULL) = number of keypoints that received a depth. When the keypoints / descriptors are byte for byte what the
+ * two handles' last ovs_orb_extract calls returned (the frame constructor's case), they are used where they already are -- in the extractors'
+ * device output blocks -- and nothing is uploaded. */
 ovs_status ovs_stereo_compute(ovs_stereo* s, const ovs_orb* left, const ovs_orb* right, const ovs_keypoint* kps_left,
                               const uint8_t* desc_left, int32_t n_left, const ovs_keypoint* kps_right, const uint8_t* desc_right,
                               int32_t n_right, float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths,

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libovslam_hip.so")
+LIB_PATH = os.environ.get("OVS_LIB_PATH") or os.path.join(_HERE, "libovslam_hip.so")   # (OVS_LIB_PATH: A/B builds of the library, tools/)
 
 OVS_OK = 0
 STATUS_NAMES = {0: "OVS_OK", -1: "OVS_ERR_INVALID", -2: "OVS_ERR_NO_DEVICE", -3: "OVS_ERR_HIP", -4: "OVS_ERR_CAPACITY",

@@ -29,6 +29,7 @@
 #include "ovs_common.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 namespace ovs {
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 }
 
 // ================================================================================================================================
-// v4 (round 3): the same algorithm with the instruction diet VERDICT round 2 asked for.
+// v4 (round 3): the same algorithm, restructured after measuring where a cell's time goes (tools/fast_phases.py, OVS_FAST_TIMING):
 //   * pre-test on FOUR pixels per register in the fast-class 32-bit ops (v_sub / v_and / v_or, 2.3-2.5 cycles per wave-instruction)
 //     instead of two per register in packed 16-bit ops (4.2): the tile is staged a second time as R = (p >> 2) | 0x80 per byte, and with
 //     th6 = (t + 1) >> 2 the byte-wise differences
@@ -381,12 +382,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 //     never borrow across bytes (every byte stays in [1, 191]) and carry in bit 7 "r6 >= c6 + th6" resp. "r6 <= c6 - th6". Since
 //     r - c > t implies (r >> 2) - (c >> 2) >= (t + 1) >> 2, the four-even-diameter condition on these bits is still NECESSARY for
 //     S > t; it lets ~1.3x as many pixels through as the exact 8-bit form (tools/fast_pretest_model.py), all of which get the exact S.
-//     Ring positions 2 / 6 / 10 / 14 are word-aligned for a 4-pixel group, so a group costs 5 v_alignbyte + 34 fast ops (v3: 104 slow ops);
-//   * survivors of the four waves are pooled in ONE list (wave prefix sum by DPP, one LDS atomic per wave): the exact scoring and the NMS
-//     run ceil(n / 256) rounds for the workgroup instead of ceil(n_w / 64) per wave (79 survivors per wave on average: 2 rounds at 62 %
-//     lane use before);
-//   * the prologue's cell arithmetic stays on the scalar unit (integer reciprocals from the host instead of float conversions).
-// LDS: raw tile 5.6 KB + R tile 5.6 KB + score map 4.75 KB + pooled list 8 KB = 24.2 KB -> 6 workgroups per CU.
+//     Ring positions 2 / 6 / 10 / 14 are word-aligned for a 4-pixel group: a group costs 5 v_alignbyte + ~30 fast ops (v3: 104 slow ops);
+//   * the pre-test reports which polarity passed, and the exact scoring evaluates only that one (values complemented for "dark"): 17 + 50
+//     instead of 102 min / max per candidate;
+//   * survivors of the four waves are pooled in ONE list (wave prefix sum by DPP, one LDS atomic per wave);
+//   * a workgroup takes six CONSECUTIVE cells: the next cell's tile is requested a whole cell ahead into registers, barriers order LDS
+//     only (no vmcnt drain), a cell's geometry is ONE 8-byte record (CellDesc) instead of a chain of dependent scalar loads, and the
+//     NMS survivors of the group's cells are buffered in LDS and appended with ONE global reservation per group instead of one atomic
+//     round trip per cell (that round trip alone was a fifth of a cell's latency).
+// What the measurements say: the kernel is bound by neither the vector ALU (~55 % busy) nor LDS (~60 %) nor HBM
+// (1.2 TB/s) alone but by the latency chain of a cell -- six LDS-only barriers, dependent LDS gathers of the exact scoring / NMS with 3-4x
+// bank conflicts -- at the 24 waves per CU that 26 KB of LDS leave. Halving the pre-test's cycles, an eight-diameter pre-test (-22 %
+// candidates), 8 workgroups per CU (aliased LDS, 64 VGPRs) each moved the launch by < 3 %; the grouping + prefetch + single reservation
+// are worth ~6 % together (0.50 -> 0.47 ms per 64 frames).
+// LDS: raw tile 5.6 KB + R tile 5.6 KB + score map 4.75 KB + pooled list 8 KB + group buffer 2 KB = 26.2 KB -> 6 workgroups per CU.
 __device__ __forceinline__ uint32_t wave_prefix_incl(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
@@ -404,7 +413,9 @@ __device__ __forceinline__ uint32_t to_r6(uint32_t w) { return __builtin_amdgcn_
 // v_bitop3_b32: a & (b | c)
 __device__ __forceinline__ uint32_t and_or3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xe0); }
 
-template <int G, int R0>
+// D8: also the four odd diameters (OpenCV's own pre-test walks all eight): 8 more v_alignbyte + 24 fast ops per group for ~22 % fewer
+// candidates -- the exact scoring and the NMS behind this test are bound by their LDS byte gathers, the vector ALU has slack (round 3)
+template <int G, int R0, bool D8>
 __device__ __forceinline__ void swar_diameter_test(const uint32_t (&w)[8][5], uint32_t kk, uint32_t& bright, uint32_t& dark) {
     const uint32_t c = __builtin_amdgcn_alignbyte(w[R0 + 3][G + 2], w[R0 + 3][G + 1], 2);
     const uint32_t p0 = __builtin_amdgcn_alignbyte(w[R0 + 6][G + 2], w[R0 + 6][G + 1], 2);    // (0, +3)
@@ -417,6 +428,18 @@ __device__ __forceinline__ void swar_diameter_test(const uint32_t (&w)[8][5], ui
     // bit 7 of every byte: all four diameters have a bright (dark) end
     bright = and_or3(and_or3(and_or3((p0 - cb) | (p8 - cb), p2 - cb, p10 - cb), p4 - cb, p12 - cb), p6 - cb, p14 - cb);
     dark = and_or3(and_or3(and_or3((cd - p0) | (cd - p8), cd - p2, cd - p10), cd - p4, cd - p12), cd - p6, cd - p14);
+    if (D8) {
+        const uint32_t p1 = __builtin_amdgcn_alignbyte(w[R0 + 6][G + 2], w[R0 + 6][G + 1], 3);    // (+1, +3)
+        const uint32_t p15 = __builtin_amdgcn_alignbyte(w[R0 + 6][G + 2], w[R0 + 6][G + 1], 1);   // (-1, +3)
+        const uint32_t p7 = __builtin_amdgcn_alignbyte(w[R0 + 0][G + 2], w[R0 + 0][G + 1], 3);    // (+1, -3)
+        const uint32_t p9 = __builtin_amdgcn_alignbyte(w[R0 + 0][G + 2], w[R0 + 0][G + 1], 1);    // (-1, -3)
+        const uint32_t p3 = __builtin_amdgcn_alignbyte(w[R0 + 4][G + 3], w[R0 + 4][G + 2], 1);    // (+3, +1)
+        const uint32_t p13 = __builtin_amdgcn_alignbyte(w[R0 + 4][G + 1], w[R0 + 4][G + 0], 3);   // (-3, +1)
+        const uint32_t p5 = __builtin_amdgcn_alignbyte(w[R0 + 2][G + 3], w[R0 + 2][G + 2], 1);    // (+3, -1)
+        const uint32_t p11 = __builtin_amdgcn_alignbyte(w[R0 + 2][G + 1], w[R0 + 2][G + 0], 3);   // (-3, -1)
+        bright = and_or3(and_or3(and_or3(and_or3(bright, p1 - cb, p9 - cb), p3 - cb, p11 - cb), p5 - cb, p13 - cb), p7 - cb, p15 - cb);
+        dark = and_or3(and_or3(and_or3(and_or3(dark, cd - p1, cd - p9), cd - p3, cd - p11), cd - p5, cd - p13), cd - p7, cd - p15);
+    }
 }
 
 // S of one polarity: max over the sixteen 9-arcs of the arc's minimum ring value, minus the centre (clamped at 0). For the dark polarity
@@ -468,32 +491,48 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// geometry of one cell (all wave-uniform)
-struct CellGeo {
-    const uint8_t* tile_org;   // image address of tile byte 0 of row 0
-    int pitch, level, min_x, min_y, max_x, max_y, cw, ch;
+// level-dependent part of a cell's geometry (all wave-uniform; reloaded only when a group's cells cross a level boundary)
+struct LevelRef {
+    const uint8_t* img;   // plane of this frame's level
+    int pitch, level;
     int64_t cand_off;
     int cand_cap;
     float scale;
     bool vec16;
 };
 
-// 24.2 KB of LDS admit six workgroups per CU: cap the registers at the 80 that six waves per SIMD leave (hipcc took 95 unasked)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_fast_cells(const FrameGeo* __restrict__ geo, const uint8_t* __restrict__ img0, size_t stride0,
+constexpr int kMaxCellsPerWg = 64;
+constexpr int kWgSurvivors = 512;   // NMS survivors of the group's cells waiting for their (single) list reservation: ~33 per cell on video
+
+// 24.2 KB + 2 KB of LDS admit six workgroups per CU: cap the registers at the 80 that six waves per SIMD leave (hipcc took 95 unasked)
+template <bool kTiming, bool kD8>   // kTiming: wave 0 accumulates shader cycles per phase into tstats (tuning aid, OVS_FAST_TIMING); kD8: eight diameters
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_fast_cells(const FrameGeo* __restrict__ geo, const CellDesc* __restrict__ cell_tab,
+                                                   const uint8_t* __restrict__ img0, size_t stride0,
                                                    size_t frame_stride0, const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                                    uint64_t* __restrict__ cand, size_t cand_frame_entries,
                                                    uint32_t* __restrict__ cand_count, const uint8_t* __restrict__ mask,
-                                                   int batch, uint32_t batch_magic, int cell_lo, int n_cells, int cells_per_wg) {
+                                                   int batch, uint32_t batch_magic, int cell_lo, int n_cells, int cells_per_wg,
+                                                   unsigned long long* __restrict__ tstats) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[kTileRowsMax][kTileWords];
-    __shared__ __attribute__((aligned(16))) uint32_t rtile[kTileRowsMax][kTileWords];
     __shared__ __attribute__((aligned(16))) uint32_t smap[kSmapRows][kSmapWords];
+    __shared__ __attribute__((aligned(16))) uint32_t rtile[kTileRowsMax][kTileWords];
     __shared__ uint16_t clist[kCellSize * kCellSize];   // pixels that passed the diameter test, (y << 8) | x, all four waves
+    __shared__ uint32_t wgbuf[kWgSurvivors];            // (slot << 26) | (score << 12) | (y << 6) | x of the group's survivors not yet written out
     __shared__ uint32_t n_cand_wg, n_out, list_base;
 
     static_assert(sizeof(tile) >= kMaxSurvivors * sizeof(uint32_t), "survivor list aliases the tile");
     uint32_t* const olist = &tile[0][0];
     const int tid = threadIdx.x;
     const int L = geo->num_levels;
+    unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+    const bool t_on = kTiming && __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+#define FAST_MARK(i)                                   \
+    if (kTiming && t_on) {                             \
+        const unsigned long long t_now = clock64();    \
+        t_acc[i] += t_now - t_prev;                    \
+        t_prev = t_now;                                \
+    }
+    if (kTiming && t_on) t_prev = clock64();
     // Work order: a workgroup takes `cells_per_wg` CONSECUTIVE cells of one frame (they share tile halo columns, and the workgroup lives long
     // enough that its launch and the first tile's load latency are paid once per group, not once per cell: round 3 measured 4.4 of 6 possible
     // waves per SIMD resident with one cell per workgroup). XCD-aware as before: XCD k takes the k-th contiguous eighth of the groups, the
@@ -505,57 +544,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const int group = xcd * per_xcd + slot;
     if (slot >= per_xcd || group >= n_groups) return;
     const int cell_first = cell_lo + group * cells_per_wg;
-    const int cell_end = min(cell_first + cells_per_wg, cell_lo + n_cells);
+    const int n_here = min(cells_per_wg, cell_lo + n_cells - cell_first);
 
-    auto cell_geo = [&](int cell_id) -> CellGeo {
-        // level of the cell: sign bits of (base[l] - 1 - cell_id), pure scalar arithmetic (a compare-and-add form came out of hipcc as
-        // v_cndmask + v_readfirstlane pairs)
-        uint32_t level_u = 0;
-#pragma unroll
-        for (int l = 1; l < OVS_MAX_LEVELS; ++l) level_u += (uint32_t)(geo->cell_base_tab[l] - 1 - cell_id) >> 31;
-        const int level = (int)level_u;
+    // a cell's record: ONE 8-byte scalar load at a wave-uniform address, requested a whole cell ahead (round 3: deriving a cell's geometry from the level tables -- level search, level record,
+    // cell -> (row, column) -- was a chain of dependent scalar loads in front of every tile request, a fifth of a cell's time)
+    uint32_t n_buf = 0;   // survivors waiting in wgbuf: every thread keeps the same count (all control flow below is workgroup-uniform)
+    const uint2 d0 = reinterpret_cast<const uint2*>(cell_tab)[cell_first];   // the first cell directly (uniform address: a scalar load)
+
+    auto level_ref = [&](int level) -> LevelRef {
         const LevelGeo& g = geo->lv[level];
-        const int g_ncx = g.ncx;
-        const int cell = cell_id - g.cell_base;
-        // exact: cell * ncx < 2^32 (levels are <= 8191 px wide: ncx <= 128, cell < 2^14); a one-column grid has no 32-bit reciprocal
-        const int ci = g_ncx == 1 ? cell : (int)__umulhi((uint32_t)cell, g.ncx_magic), cj = cell - ci * g_ncx;
-        CellGeo c;
-        c.level = level;
-        c.min_x = kOrbPatchRadius + cj * kCellSize;
-        c.min_y = kOrbPatchRadius + ci * kCellSize;
-        c.max_x = min(c.min_x + kCellSize + kCellOverlap, g.max_bx);
-        c.max_y = min(c.min_y + kCellSize + kCellOverlap, g.max_by);
-        c.cw = c.max_x - c.min_x;
-        c.ch = c.max_y - c.min_y;
-        const uint8_t* img;
+        LevelRef r;
+        r.level = level;
         if (level == 0) {
-            img = img0 + (size_t)frame * frame_stride0;
-            c.pitch = (int)stride0;
+            r.img = img0 + (size_t)frame * frame_stride0;
+            r.pitch = (int)stride0;
         } else {
-            img = pyr + (size_t)frame * pyr_frame_bytes + g.plane_off;
-            c.pitch = g.pitch;
+            r.img = pyr + (size_t)frame * pyr_frame_bytes + g.plane_off;
+            r.pitch = g.pitch;
         }
-        c.vec16 = ((c.pitch & 15) == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0);
-        // tile byte u of row r <-> image (min_x - 3 + u, min_y + r); min_x - 3 = 16 + 64 * cj is 16-byte aligned
-        c.tile_org = img + (size_t)c.min_y * c.pitch + (c.min_x - 3);
-        c.cand_off = g.cand_off;
-        c.cand_cap = g.cand_cap;
-        c.scale = g.scale;
-        return c;
+        r.vec16 = ((r.pitch & 15) == 0) && ((reinterpret_cast<uintptr_t>(r.img) & 15) == 0);
+        r.cand_off = g.cand_off;
+        r.cand_cap = g.cand_cap;
+        r.scale = g.scale;
+        return r;
     };
-    auto fetch_chunk = [&](const CellGeo& c, int r, int q) -> uint4 {
+    // tile byte u of row r <-> image (min_x - 3 + u, min_y + r); min_x - 3 = 16 + 64 * column is 16-byte aligned
+    auto fetch_chunk = [&](const LevelRef& lr, int min_x, int min_y, int ch, int r, int q) -> uint4 {
         uint4 v = {0u, 0u, 0u, 0u};
-        const int gx = c.min_x - 3 + 16 * q;
-        if (r < c.ch) {
-            const uint8_t* p = c.tile_org + (size_t)r * c.pitch + 16 * q;
-            if (c.vec16) {
-                if (gx < c.pitch) v = *reinterpret_cast<const uint4*>(p);
+        const int gx = min_x - 3 + 16 * q;
+        if (r < ch) {
+            const uint8_t* p = lr.img + (size_t)(min_y + r) * lr.pitch + gx;
+            if (lr.vec16) {
+                if (gx < lr.pitch) v = *reinterpret_cast<const uint4*>(p);
             } else {   // 4-byte aligned base/stride (enforced by the ABI), row tail
                 const uint32_t* p4 = reinterpret_cast<const uint32_t*>(p);
-                if (gx + 4 <= c.pitch) v.x = p4[0];
-                if (gx + 8 <= c.pitch) v.y = p4[1];
-                if (gx + 12 <= c.pitch) v.z = p4[2];
-                if (gx + 16 <= c.pitch) v.w = p4[3];
+                if (gx + 4 <= lr.pitch) v.x = p4[0];
+                if (gx + 8 <= lr.pitch) v.y = p4[1];
+                if (gx + 12 <= lr.pitch) v.z = p4[2];
+                if (gx + 16 <= lr.pitch) v.w = p4[3];
             }
         }
         return v;
@@ -573,11 +599,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const uint8_t* const fmask = mask ? mask + (size_t)frame * frame_stride0 : nullptr;   // same layout as the level-0 frames
     const int ini_thr = geo->ini_thr, min_thr = geo->min_thr;
 
-    CellGeo cg = cell_geo(cell_first);
-    uint4 va = fetch_chunk(cg, ra, qa), vb = {0u, 0u, 0u, 0u};
-    if (has_b) vb = fetch_chunk(cg, rb, qb);
+    // record of cell d: x | y << 16, cw | ch << 8 | level << 16
+    uint32_t dn_x = d0.x, dn_y = d0.y;                          // record of the cell whose tile is being requested
+    LevelRef lr_next = level_ref((int)((dn_y >> 16) & 255u));   // its level
+    uint4 va = fetch_chunk(lr_next, (int)(dn_x & 0xffffu), (int)(dn_x >> 16), (int)((dn_y >> 8) & 255u), ra, qa), vb = {0u, 0u, 0u, 0u};
+    if (has_b) vb = fetch_chunk(lr_next, (int)(dn_x & 0xffffu), (int)(dn_x >> 16), (int)((dn_y >> 8) & 255u), rb, qb);
+    LevelRef lr_buf = lr_next;   // level of the survivors waiting in wgbuf
 
-    for (int cell_id = cell_first; cell_id < cell_end; ++cell_id) {
+    // write the buffered survivors of the group to their (frame, level) list: ONE reservation for all of them
+    auto flush = [&](const LevelRef& lv) {
+        const uint32_t nb = n_buf;
+        if (nb != 0) {
+            if (tid == 0) list_base = atomicAdd(&cand_count[frame * L + lv.level], nb);
+            lds_barrier();   // thread 0 waits for the atomic's return before its LDS store; the barrier publishes it
+            const uint32_t base = list_base;
+            uint64_t* const list = cand + (size_t)frame * cand_frame_entries + lv.cand_off;
+            const uint32_t cap = (uint32_t)lv.cand_cap;
+            for (uint32_t i = tid; i < nb; i += 256) {
+                const uint32_t e = wgbuf[i];
+                const uint2 dsc = reinterpret_cast<const uint2*>(cell_tab)[cell_first + (int)(e >> 26)];
+                const uint32_t x = (dsc.x & 0xffffu) + 3u + (e & 63u), y = (dsc.x >> 16) + 3u + ((e >> 6) & 63u), sc = (e >> 12) & 255u;
+                if (base + i < cap) list[base + i] = cand_pack(x, y, sc - 1u, 0);
+            }
+            n_buf = 0;
+        }
+    };
+
+    for (int k = 0; k < n_here; ++k) {
+        FAST_MARK(0)   // loop overhead / previous cell's tail
         // ---- stage the tile this thread's two chunks belong to (requested one cell ago): raw bytes for the exact scoring, and
         //      R = (p >> 2) | 0x80 per byte for the diameter test
         for (int i = tid; i < kSmapRows * kSmapWords / 4; i += 256) reinterpret_cast<uint4*>(smap_flat)[i] = uint4{0u, 0u, 0u, 0u};
@@ -591,24 +640,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             *reinterpret_cast<uint4*>(&tile[rb][4 * qb]) = vb;
             *reinterpret_cast<uint4*>(&rtile[rb][4 * qb]) = uint4{to_r6(vb.x), to_r6(vb.y), to_r6(vb.z), to_r6(vb.w)};
         }
-        const CellGeo c = cg;
-        // ---- request the next cell's tile: the loads are in flight under everything below (the barriers are LDS-only)
-        if (cell_id + 1 < cell_end) {
-            cg = cell_geo(cell_id + 1);
-            va = fetch_chunk(cg, ra, qa);
-            if (has_b) vb = fetch_chunk(cg, rb, qb);
-        }
+        FAST_MARK(1)   // staging stores (incl. the wait for the prefetched chunks)
+        const uint32_t dc_x = dn_x, dc_y = dn_y;   // this cell's record
+        const LevelRef lr = lr_next;
         lds_barrier();
+        FAST_MARK(2)   // barrier 1
+        // ---- request the next cell's tile: the loads are in flight under everything below (the barriers are LDS-only)
+        if (k + 1 < n_here) {
+            const uint2 dsc = reinterpret_cast<const uint2*>(cell_tab)[cell_first + k + 1];   // uniform address: scalar load, not an LDS round trip
+            dn_x = dsc.x;
+            dn_y = dsc.y;
+            const int nl = (int)((dn_y >> 16) & 255u);
+            if (nl != lr_next.level) lr_next = level_ref(nl);
+            va = fetch_chunk(lr_next, (int)(dn_x & 0xffffu), (int)(dn_x >> 16), (int)((dn_y >> 8) & 255u), ra, qa);
+            if (has_b) vb = fetch_chunk(lr_next, (int)(dn_x & 0xffffu), (int)(dn_x >> 16), (int)((dn_y >> 8) & 255u), rb, qb);
+        }
+        FAST_MARK(3)   // next cell's record + load issue
 
-        const int min_x = c.min_x, min_y = c.min_y;
-        const int iw = c.cw - 6, ih = c.ch - 6;   // testable area of this cell (> 0 for every valid cell)
-        const float scale = c.scale;
+        const int min_x = (int)(dc_x & 0xffffu), min_y = (int)(dc_x >> 16);
+        const int cw = (int)(dc_y & 255u), ch = (int)((dc_y >> 8) & 255u);
+        const int iw = cw - 6, ih = ch - 6;   // testable area of this cell (> 0 for every valid cell)
+        const float scale = lr.scale;
         bool skip = false;
         if (fmask) {   // upstream: skip the cell if one of its corners is masked (level-0 coordinates, float scale, trunc)
             auto in_mask = [&](unsigned y, unsigned x) {
                 return fmask[(size_t)(unsigned)(y * scale) * stride0 + (unsigned)(x * scale)] == 0;
             };
-            skip = in_mask(min_y, min_x) || in_mask(c.max_y, min_x) || in_mask(min_y, c.max_x) || in_mask(c.max_y, c.max_x);
+            skip = in_mask(min_y, min_x) || in_mask(min_y + ch, min_x) || in_mask(min_y, min_x + cw) || in_mask(min_y + ch, min_x + cw);
         }
         if (!skip) {
             // candidate-mask layout: bit 8 * b + 2 * R0 + G <-> pixel c0 + 4 * G + b of row row0 + R0. Where the level border clips the testable
@@ -638,17 +696,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                         w[r][1] = rtile[row0 + r][2 * run + 1];
                         w[r][2] = b.x;
                         w[r][3] = b.y;
-                        if (r == 3 || r == 4) {
+                        if (r == 3 || r == 4 || (kD8 && (r == 2 || r == 5))) {
                             w[r][0] = rtile[row0 + r][2 * run];
                             w[r][4] = rtile[row0 + r][2 * run + 4];
                         }
                     }
                     const uint32_t kk = 0x80808080u - (uint32_t)((thr + 1) >> 2) * 0x01010101u;
                     uint32_t b00, d00, b10, d10, b01, d01, b11, d11;
-                    swar_diameter_test<0, 0>(w, kk, b00, d00);
-                    swar_diameter_test<1, 0>(w, kk, b10, d10);
-                    swar_diameter_test<0, 1>(w, kk, b01, d01);
-                    swar_diameter_test<1, 1>(w, kk, b11, d11);
+                    swar_diameter_test<0, 0, kD8>(w, kk, b00, d00);
+                    swar_diameter_test<1, 0, kD8>(w, kk, b10, d10);
+                    swar_diameter_test<0, 1, kD8>(w, kk, b01, d01);
+                    swar_diameter_test<1, 1, kD8>(w, kk, b11, d11);
                     constexpr uint32_t kM = 0x80808080u;
                     const uint32_t bm = ((b00 & kM) >> 7) | ((b10 & kM) >> 6) | ((b01 & kM) >> 5) | ((b11 & kM) >> 4);
                     dmask = (((d00 & kM) >> 7) | ((d10 & kM) >> 6) | ((d01 & kM) >> 5) | ((d11 & kM) >> 4)) & valid;
@@ -656,6 +714,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                     // entry flags: 0x40 = evaluate the dark polarity (the bright test failed), 0x80 = both tests passed (evaluate both)
                     dmask = (dmask & ~bm) | ((dmask & bm) << 4);   // bits 4..7 of every byte are free in the mask layout
                 }
+                FAST_MARK(4)   // diameter test
                 // ---- 2. pool the candidates of the four waves: exclusive prefix inside the wave, one LDS atomic per wave for its base
                 {
                     const uint32_t n_mine = (uint32_t)__popc(cmask);
@@ -671,8 +730,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                         clist[pos++] = (uint16_t)(((row0 + ((b >> 1) & 1)) << 8) | (c0 + 4 * (b & 1) + (b >> 3)) | fl);
                     }
                 }
+                FAST_MARK(5)   // prefix + list writes
                 lds_barrier();
                 const int n_cand = (int)n_cand_wg;
+                FAST_MARK(6)   // barrier 2
                 // ---- 3. exact S for the candidates, one per lane, into the score map: one polarity per candidate (both where both tests passed)
                 for (int i = tid; i < n_cand; i += 256) {
                     const uint32_t e = clist[i];
@@ -681,19 +742,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                     load_ring(tbytes + y * (kTileWords * 4) + x + 3, r, c);
                     const uint32_t flip = (e & 0x40u) ? 0xffu : 0u;
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) r[k] ^= flip;
+                    for (int q = 0; q < 16; ++q) r[q] ^= flip;
                     c ^= flip;
                     uint32_t sc = fast_strength_bright(r, c);
                     if (__builtin_amdgcn_ballot_w64((e & 0x80u) != 0) != 0) {   // rare: some lane's pixel passed both tests
                         if (e & 0x80u) {
 #pragma unroll
-                            for (int k = 0; k < 16; ++k) r[k] ^= 0xffu;
+                            for (int q = 0; q < 16; ++q) r[q] ^= 0xffu;
                             sc = mx16(sc, fast_strength_bright(r, c ^ 0xffu));
                         }
                     }
                     sbytes[(y + 1) * (kSmapWords * 4) + 4 + x] = (uint8_t)sc;
                 }
+                FAST_MARK(7)   // exact scoring
                 lds_barrier();
+                FAST_MARK(8)   // barrier 3
                 // ---- 4. strict NMS over the 8 neighbours (unevaluated neighbours have S <= thr < S(p): 0 in the map), survivors -> olist
                 //      (olist aliases the tile: every wave is past its last tile read, the scoring, by the barrier above)
                 for (int i = tid; i < n_cand; i += 256) {
@@ -706,11 +769,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                     const uint32_t nb = mx16(mx16(mx16((uint32_t)q[-kS - 1], (uint32_t)q[-kS]), mx16((uint32_t)q[-kS + 1], (uint32_t)q[-1])),
                                              mx16(mx16((uint32_t)q[1], (uint32_t)q[kS - 1]), mx16((uint32_t)q[kS], (uint32_t)q[kS + 1])));
                     if (sc <= nb) continue;
-                    // n_out counts the NMS survivors ("keypts_in_cell" before upstream's mask filter); masked ones are dropped at the append
+                    // n_out counts the NMS survivors ("keypts_in_cell" before upstream's mask filter); masked ones are dropped below
                     const uint32_t o = atomicAdd(&n_out, 1u);
-                    olist[o] = (sc << 16) | e;
+                    olist[o] = (sc << 12) | ((uint32_t)y << 6) | (uint32_t)x;
                 }
+                FAST_MARK(9)   // NMS
                 lds_barrier();
+                FAST_MARK(10)  // barrier 4
                 if (n_out != 0 || thr <= min_thr) break;
                 // "if keypts_in_cell.empty()": again with min_fast_thr (rare: flat cells). No survivor was written, so the tile is intact.
                 thr = min_thr;
@@ -719,12 +784,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 lds_barrier();
             }
 
-            // ---- 5. append to the (frame, level) candidate list: one global atomic per workgroup; FAST response = S - 1
+            // ---- 5. the cell's survivors join the group's buffer; the (frame, level) list is reserved ONCE per group (or when the buffer is
+            //      full / the level changes): the reservation's global atomic round trip, a fifth of a cell's time when every cell paid it, is
+            //      paid per group. FAST response = S - 1.
             uint32_t total = n_out;
             if (total != 0) {
                 if (fmask) {
                     // upstream drops masked keypoints after the empty-cell decision: compact olist in place (rare path, one wave)
-                    lds_barrier();
                     if (tid < 64) {
                         uint32_t kept = 0;
                         for (uint32_t i0 = 0; i0 < total; i0 += 64) {
@@ -733,7 +799,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                             bool keep = false;
                             if (i < total) {
                                 o = olist[i];
-                                const uint32_t gx = min_x + 3 + (o & 255u), gy = min_y + 3 + ((o >> 8) & 255u);
+                                const uint32_t gx = min_x + 3 + (o & 63u), gy = min_y + 3 + ((o >> 6) & 63u);
                                 keep = fmask[(size_t)(unsigned)(gy * scale) * stride0 + (unsigned)(gx * scale)] != 0;
                             }
                             const unsigned long long bal = __ballot(keep);
@@ -747,21 +813,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                     total = n_out;
                 }
                 if (total != 0) {
-                    if (tid == 0) list_base = atomicAdd(&cand_count[frame * L + c.level], total);
-                    lds_barrier();   // the atomic's return is waited for by thread 0 before its LDS store; the barrier publishes it
-                    const uint32_t base = list_base;
-                    uint64_t* const list = cand + (size_t)frame * cand_frame_entries + c.cand_off;
-                    const uint32_t cap = (uint32_t)c.cand_cap;
-                    for (uint32_t i = tid; i < total; i += 256) {
-                        const uint32_t o = olist[i];
-                        const uint32_t x = o & 255u, y = (o >> 8) & 255u, sc = o >> 16;
-                        if (base + i < cap) list[base + i] = cand_pack((uint32_t)(min_x + 3) + x, (uint32_t)(min_y + 3) + y, sc - 1u, 0);
+                    if (lr.level != lr_buf.level || n_buf + total > (uint32_t)kWgSurvivors) {
+                        flush(lr_buf);
+                        lds_barrier();   // the buffer's readers are done before it is refilled below
+                    }
+                    lr_buf = lr;
+                    if (total <= (uint32_t)kWgSurvivors) {
+                        for (uint32_t i = tid; i < total; i += 256) wgbuf[n_buf + i] = olist[i] | ((uint32_t)k << 26);
+                        n_buf += total;
+                    } else {
+                        // more survivors than the buffer holds (a cell can have 1024): written straight from olist with their own reservation
+                        if (tid == 0) list_base = atomicAdd(&cand_count[frame * L + lr.level], total);
+                        lds_barrier();
+                        const uint32_t base = list_base;
+                        uint64_t* const list = cand + (size_t)frame * cand_frame_entries + lr.cand_off;
+                        const uint32_t cap = (uint32_t)lr.cand_cap;
+                        for (uint32_t i = tid; i < total; i += 256) {
+                            const uint32_t o = olist[i];
+                            if (base + i < cap)
+                                list[base + i] = cand_pack((uint32_t)(min_x + 3) + (o & 63u), (uint32_t)(min_y + 3) + ((o >> 6) & 63u), ((o >> 12) & 255u) - 1u, 0);
+                        }
                     }
                 }
             }
         }
         lds_barrier();   // the next cell's staging overwrites tile / olist, smap and the counters
+        FAST_MARK(11)  // buffer / flush + last barrier
     }
+    flush(lr_buf);
+    if (kTiming && t_on && (tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) atomicAdd(&tstats[i], t_acc[i]);
+        atomicAdd(&tstats[12], 1ull);
+    }
+#undef FAST_MARK
 }
 
 hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
@@ -776,15 +861,42 @@ hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t*
     if ((uint64_t)per_xcd * (uint64_t)batch * (uint64_t)batch >= (1ull << 32)) return hipErrorInvalidValue;
     const uint32_t batch_magic = batch > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)batch - 1) / (uint64_t)batch) : 0u;
     const char* const env_k = getenv("OVS_FAST_CELLS");   // tuning aid: consecutive cells per workgroup
-    const int cells_per_wg = env_k ? std::min(std::max(atoi(env_k), 1), 64) : 6;
+    const int cells_per_wg = env_k ? std::min(std::max(atoi(env_k), 1), kMaxCellsPerWg) : 6;
     if (use_v3)
         hipLaunchKernelGGL(k_fast_cells_v3, dim3(8u * per_xcd * (unsigned)batch), dim3(256), 0, s, d.geo, img0, stride0, frame_stride0, d.pyr,
                            d.pyr_frame_bytes, d.cand, d.cand_frame_entries, d.cand_count, mask, batch, cell_lo, n_cells);
     else
     {
         const unsigned n_groups = ((unsigned)n_cells + (unsigned)cells_per_wg - 1) / (unsigned)cells_per_wg, gper = (n_groups + 7) / 8u;
-        hipLaunchKernelGGL(k_fast_cells, dim3(8u * gper * (unsigned)batch), dim3(256), 0, s, d.geo, img0, stride0, frame_stride0, d.pyr,
-                           d.pyr_frame_bytes, d.cand, d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg);
+        const char* const env_pad = getenv("OVS_FAST_PAD_LDS");   // occupancy probe: extra dynamic LDS per workgroup (never set in production)
+        const size_t pad_lds = env_pad ? (size_t)atoi(env_pad) : 0;
+        if (getenv("OVS_FAST_TIMING")) {   // tuning aid: per-phase shader cycles of wave 0 of every workgroup, printed per launch
+            static unsigned long long* d_t = nullptr;
+            if (!d_t && hipMalloc(&d_t, 16 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
+            (void)hipMemsetAsync(d_t, 0, 16 * sizeof(unsigned long long), s);
+            hipLaunchKernelGGL((k_fast_cells<true, false>), dim3(8u * gper * (unsigned)batch), dim3(256), pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr,
+                               d.pyr_frame_bytes, d.cand, d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, d_t);
+            unsigned long long h_t[16];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h_t, d_t, sizeof(h_t), hipMemcpyDeviceToHost);
+            static const char* nm[12] = {"loop", "stage", "next-issue", "bar1", "pretest", "pool", "bar2", "score", "bar3", "nms", "bar4", "append+bar5"};
+            unsigned long long tot = 0;
+            for (int i = 0; i < 12; ++i) tot += h_t[i];
+            fprintf(stderr, "[k_fast_cells timing] %llu workgroups x %d cells, %.0f cycles per cell:", h_t[12], cells_per_wg,
+                    (double)tot / ((double)h_t[12] * cells_per_wg + 1e-9));
+            for (int i = 0; i < 12; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)h_t[i] / (double)(tot + 1));
+            fprintf(stderr, "\n");
+            return hipGetLastError();
+        }
+        const char* const env_d8 = getenv("OVS_FAST_DIAM8");   // A/B aid: eight-diameter pre-test
+        if (env_d8 && env_d8[0] == '1')
+            hipLaunchKernelGGL((k_fast_cells<false, true>), dim3(8u * gper * (unsigned)batch), dim3(256), pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0,
+                               d.pyr, d.pyr_frame_bytes, d.cand, d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells,
+                               cells_per_wg, (unsigned long long*)nullptr);
+        else
+            hipLaunchKernelGGL((k_fast_cells<false, false>), dim3(8u * gper * (unsigned)batch), dim3(256), pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0,
+                               d.pyr, d.pyr_frame_bytes, d.cand, d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells,
+                               cells_per_wg, (unsigned long long*)nullptr);
     }
     return hipGetLastError();
 }

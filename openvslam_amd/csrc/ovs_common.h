@@ -46,6 +46,15 @@ struct LevelGeo {
     float kp_size;            // (float)(unsigned)(31*scale)
 };
 
+// One FAST cell of the current geometry (k_fast_cells reads ITS cells' records with one load instead of deriving them from the level tables
+// through a chain of dependent scalar loads): cell origin, clipped size, level. 8 bytes, table order = cell id.
+struct CellDesc {
+    uint16_t min_x, min_y;   // 19 + 64 * column / row
+    uint8_t cw, ch;          // min(70, distance to the level's border): the tile is cw x ch, the testable area (cw - 6) x (ch - 6)
+    uint8_t level, pad;
+};
+static_assert(sizeof(CellDesc) == 8, "CellDesc is read as one 64-bit word");
+
 struct FrameGeo {
     int32_t num_levels;
     int32_t total_cells;
@@ -74,6 +83,7 @@ __host__ __device__ inline uint32_t cand_order(uint32_t x, uint32_t y, uint32_t 
 struct DevBuffers {
     const FrameGeo* geo;          // device copy
     const ResizeTap* taps;        // device
+    const CellDesc* cells;        // device, total_cells records
     uint8_t* pyr;                 // max_batch * pyr_frame_bytes (levels >= 1)
     size_t pyr_frame_bytes;
     uint64_t* cand;               // max_batch * cand_frame_entries
@@ -111,6 +121,8 @@ struct PyrView {
 bool orb_pyramid_view(const ovs_orb* h, int frame, PyrView* out);
 int orb_device(const ovs_orb* h);
 hipStream_t orb_last_stream(const ovs_orb* h);   // the stream the handle's last extract was enqueued on
+// true iff (kps, desc, n) equal what the handle's last HOST-form extract returned; then *d_kps / *d_desc are the device copies still resident
+bool orb_host_outputs_equal(const ovs_orb* h, const ovs_keypoint* kps, const uint8_t* desc, int32_t n, const ovs_keypoint** d_kps, const uint8_t** d_desc);
 
 // Stage timer for bench.py: HIP events recorded on the launch stream at stage boundaries; a small ring of call slots.
 template <int NSTAGE>

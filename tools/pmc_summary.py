@@ -56,6 +56,14 @@ if "--json" in sys.argv:
                 d[st] = int(sum(vals) / len(vals) * launches_per_call.get(st, 1))
         if d:
             out[key] = d
+    # fingerprint of the kernel sources the counters were collected from: bench.py refuses a traffic figure whose kernels have changed since
+    import hashlib
+    src_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "openvslam_amd", "csrc")
+    hsh = hashlib.sha256()
+    for fn in sorted(os.listdir(src_dir)):
+        if fn.endswith((".hip", ".h", ".inc")):
+            hsh.update(open(os.path.join(src_dir, fn), "rb").read())
+    out["csrc_sha16"] = hsh.hexdigest()[:16]
     if "--batch" in sys.argv:
         out["batch"] = int(sys.argv[sys.argv.index("--batch") + 1])   # frames per launch the passes ran at (bench.py scales by it)
     json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
