@@ -78,7 +78,8 @@ ovs_status ovs_orb_destroy(ovs_orb* h);
 ovs_status ovs_orb_tables(const ovs_orb* h, float* scale_factors, float* inv_scale_factors, float* level_sigma_sq,
                           float* inv_level_sigma_sq, int32_t* num_keypts_per_level);
 
-/* Upper bound on the keypoints one frame can produce (sum over levels of N_level + 3): size outputs with this. */
+/* Upper bound on the keypoints one frame can produce (sum over levels of N_level + 3; 2 N_level + 3 after
+ * ovs_orb_set_variant(OVS_VARIANT_TREE_SWITCH_FACTOR, 1) -- ask again after changing that variant): size outputs with this. */
 int32_t ovs_orb_max_keypoints(const ovs_orb* h);
 
 /* replaces: orb_extractor::extract(const cv::_InputArray& image, const cv::_InputArray& mask,
@@ -133,6 +134,18 @@ ovs_status ovs_orb_set_pipeline(ovs_orb* h, int32_t n_sub);
  * {pyramid window (level-0 FAST running beside it), FAST levels >= 1, quad-tree, describe}; ovs_orb_profile_read_aux returns the level-0 FAST
  * launch's own duration. OFF = one FAST launch over all levels after the pyramid (what per-kernel rooflines are quoted on). */
 ovs_status ovs_orb_set_fast_split(ovs_orb* h, int32_t enable);
+/* Variants of the three rules of the extraction that upstream's (absent) sources and OpenCV version decide and that cannot be pinned in this
+ * repository (oracle/ORACLE_SPEC.md rules 6, 7, 10): if a checkout or an OpenCV build shows the other choice, matching it
+ * is this call, not a kernel rewrite. Defaults unchanged; the CPU checker has the same switches and every setting is parity-tested.
+ *   OVS_VARIANT_TREE_SWITCH_FACTOR  3 (default: ORB-SLAM2's `N < nodes + 3 * splittable`) | 1
+ *   OVS_VARIANT_TREE_TIE_ORDER      0 (default: equal counts -> later-created node first) | 1 (earlier-created first)
+ *   OVS_VARIANT_BLUR_TAPS           0 (default: 18 34 48 56 48 34 18, OpenCV >= 3.4.7 error-diffused fixed point) | 1 (18 34 49 55 49 34 18,
+ *                                   every tap rounded on its own: older OpenCV; sum 257, result saturates)
+ * Takes effect from the next extract. OVS_ERR_INVALID for an unknown (which, value). */
+#define OVS_VARIANT_TREE_SWITCH_FACTOR 0
+#define OVS_VARIANT_TREE_TIE_ORDER 1
+#define OVS_VARIANT_BLUR_TAPS 2
+ovs_status ovs_orb_set_variant(ovs_orb* h, int32_t which, int32_t value);
 ovs_status ovs_orb_profile_read_aux(ovs_orb* h, float* fast_level0_ms, int32_t* ncalls);
 
 /* replaces: the public member orb_extractor::image_pyramid_ (read by match::stereo). Copies level `level` of frame

@@ -87,6 +87,7 @@ struct ovs_orb {
     size_t taps_cap = 0;
     CellDesc* d_cells = nullptr;
     size_t cells_cap = 0;
+    int32_t variant = 0;   // FrameGeo::variant
     DevBuffers d{};
     size_t pyr_cap = 0, cand_cap = 0, node_cap = 0, kps_cap = 0;
     // host-API staging: two slots (double buffering). A slot owns a device image (+ mask), a pinned input staging buffer, a pinned
@@ -117,7 +118,14 @@ struct ovs_orb {
     uint8_t* d_out_desc = nullptr;
     int32_t* d_out_counts = nullptr;
     int out_cap = 0;
+    int out_cap_variant[2] = {0, 0};   // by FrameGeo::variant bit 0; buffers are allocated for [1], the layout follows the current variant
     size_t out_block_bytes = 0, out_off_desc = 0;
+    void set_out_layout() {
+        out_cap = out_cap_variant[variant & 1];
+        out_off_desc = (16 + sizeof(ovs_keypoint) * (size_t)out_cap + 31) & ~(size_t)31;
+        out_block_bytes = out_off_desc + (size_t)32 * out_cap;
+        d_out_desc = reinterpret_cast<uint8_t*>(d_out_counts) + out_off_desc;
+    }
     hipStream_t last_stream = nullptr;   // stream of the last extract (device-batch form: the caller's)
     int32_t last_host_count = -1;        // keypoints the last HOST-form extract returned (they are still in d_out_kps / d_out_desc)
     // last extract (for pyramid / debug getters)
@@ -172,6 +180,7 @@ bool build_geometry(const ovs_orb* h, int rows, int cols, FrameGeo& geo, std::ve
     const int L = h->p.num_levels;
     std::memset(&geo, 0, sizeof(geo));
     geo.num_levels = L;
+    geo.variant = h->variant;
     geo.ini_thr = std::min(std::max(h->p.ini_fast_thr, 0), 255);
     geo.min_thr = std::min(std::max(h->p.min_fast_thr, 0), 255);
     taps.clear();
@@ -239,7 +248,9 @@ bool build_geometry(const ovs_orb* h, int rows, int cols, FrameGeo& geo, std::ve
         const int nc = std::max(g.n_keypts, g.gx * g.gy) + 16;
         g.max_nodes = 4 * nc;
         if (g.max_nodes > 65535) return false;
-        g.kp_cap = std::max(g.n_keypts + 3, 4 * g.gx * g.gy);
+        // the tree ends with fewer than N + 3 nodes when the pool is split one at a time from N < size + 3 * pool on (rule 6 as fixed);
+        // with the factor-1 variant the last all-at-once pass starts from size + pool <= N and may end with up to size + 3 * pool <= 2 N
+        g.kp_cap = std::max(((geo.variant & 1) ? 2 * g.n_keypts : g.n_keypts) + 3, 4 * g.gx * g.gy);
         g.kp_base = kp_base;
         kp_base += g.kp_cap;
         g.cand_cap = g.ncx * g.ncy * 1024;   // NMS leaves at most one survivor per 2x2 block of a 64x64 cell
@@ -493,17 +504,19 @@ ovs_status ovs_orb_create(const ovs_orb_params* params, int32_t max_rows, int32_
     // RATIO of the image, not on its size: a small elongated image can need more of both than the largest image the handle was created
     // for (found by tools/fuzz_parity.py: 1664 x 257 on a 2000 x 1300 handle). Size them for the worst grid.
     {
-        size_t node_worst = 0, kp_worst = 0;
+        size_t node_worst = 0, kp_worst[2] = {0, 0};
         for (int l = 0; l < L; ++l) {
             node_worst += (size_t)2 * 4 * (std::max(geo.lv[l].n_keypts, 64) + 16);
-            kp_worst += (size_t)std::max(geo.lv[l].n_keypts + 3, 4 * 64);
+            kp_worst[0] += (size_t)std::max(geo.lv[l].n_keypts + 3, 4 * 64);
+            kp_worst[1] += (size_t)std::max(2 * geo.lv[l].n_keypts + 3, 4 * 64);   // ovs_orb_set_variant(TREE_SWITCH_FACTOR, 1)
         }
         node_entries = std::max(node_entries, node_worst);
-        geo.total_kp_cap = (int)std::max<size_t>((size_t)geo.total_kp_cap, kp_worst);
+        h->out_cap_variant[0] = (int)kp_worst[0];
+        h->out_cap_variant[1] = (int)kp_worst[1];
     }
     h->d.node_frame_entries = node_entries;
     h->taps_cap = taps.size() + 64;
-    h->kps_cap = (size_t)geo.total_kp_cap;
+    h->kps_cap = (size_t)h->out_cap_variant[1];
     CREATE_TRY(hipMalloc(&h->d_geo, sizeof(FrameGeo)));
     CREATE_TRY(hipMalloc(&h->d_taps, h->taps_cap * sizeof(ResizeTap)));
     h->cells_cap = cells_max.size() + 64;   // (the cell count is monotone in rows and cols: the largest image has the most cells)
@@ -520,17 +533,16 @@ ovs_status ovs_orb_create(const ovs_orb_params* params, int32_t max_rows, int32_
     h->d.cells = h->d_cells;
     // host-API staging: one frame
     h->img_pitch = ((size_t)max_cols + 255) & ~(size_t)255;
-    h->out_cap = geo.total_kp_cap;
-    // one contiguous device output block [counts | keypoints | descriptors] so that ONE D2H brings a frame's results back
-    h->out_off_desc = (16 + sizeof(ovs_keypoint) * (size_t)h->out_cap + 31) & ~(size_t)31;
-    h->out_block_bytes = h->out_off_desc + (size_t)32 * h->out_cap;
+    // one contiguous device output block [counts | keypoints | descriptors] so that ONE D2H brings a frame's results back; allocated
+    // for the larger of the two capacities, laid out (and copied) for the current one
+    const size_t out_block_alloc = ((16 + sizeof(ovs_keypoint) * (size_t)h->out_cap_variant[1] + 31) & ~(size_t)31) + (size_t)32 * h->out_cap_variant[1];
     {
         uint8_t* blk = nullptr;
-        CREATE_TRY(hipMalloc(&blk, h->out_block_bytes));
+        CREATE_TRY(hipMalloc(&blk, out_block_alloc));
         h->d_out_counts = reinterpret_cast<int32_t*>(blk);
         h->d_out_kps = reinterpret_cast<ovs_keypoint*>(blk + 16);
-        h->d_out_desc = blk + h->out_off_desc;
     }
+    h->set_out_layout();
     CREATE_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_aux_fork, hipEventDisableTiming));
@@ -538,7 +550,7 @@ ovs_status ovs_orb_create(const ovs_orb_params* params, int32_t max_rows, int32_
     for (auto& sl : h->slot) {
         CREATE_TRY(hipMalloc(&sl.d_img, h->img_pitch * max_rows));
         CREATE_TRY(hipHostMalloc(&sl.h_in, h->img_pitch * max_rows, hipHostMallocDefault));
-        CREATE_TRY(hipHostMalloc(&sl.h_out, h->out_block_bytes, hipHostMallocDefault));
+        CREATE_TRY(hipHostMalloc(&sl.h_out, out_block_alloc, hipHostMallocDefault));
         CREATE_TRY(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
     }
@@ -635,6 +647,24 @@ ovs_status ovs_orb_profile_read(ovs_orb* h, float* stage_ms, int32_t* ncalls) {
         OVS_HIP_TRY(h->prof_sub[k].read(ms, &nc));
         for (int j = 0; j < 4; ++j) stage_ms[j] += ms[j];
         if (k == 0) *ncalls += nc;
+    }
+    return OVS_OK;
+}
+
+ovs_status ovs_orb_set_variant(ovs_orb* h, int32_t which, int32_t value) {
+    if (!h) return OVS_ERR_INVALID;
+    int32_t v = h->variant;
+    if (which == OVS_VARIANT_TREE_SWITCH_FACTOR && (value == 3 || value == 1)) v = (v & ~1) | (value == 1 ? 1 : 0);
+    else if (which == OVS_VARIANT_TREE_TIE_ORDER && (value == 0 || value == 1)) v = (v & ~2) | (value ? 2 : 0);
+    else if (which == OVS_VARIANT_BLUR_TAPS && (value == 0 || value == 1)) v = (v & ~4) | (value ? 4 : 0);
+    else return OVS_ERR_INVALID;
+    if (v != h->variant) {
+        OVS_HIP_TRY(hipSetDevice(h->device));
+        OVS_HIP_TRY(hipDeviceSynchronize());   // the output block's layout follows the variant's capacity: nothing may be in flight
+        h->variant = v;
+        h->cur_rows = h->cur_cols = 0;   // the device copy of the geometry carries the flags: rebuilt by the next extract
+        h->last_host_count = -1;
+        h->set_out_layout();             // ovs_orb_max_keypoints changes with TREE_SWITCH_FACTOR
     }
     return OVS_OK;
 }

@@ -57,9 +57,11 @@ __constant__ uint32_t c_ic_tab[16 * 2 * 8] = {
     0x00000000u, 0x00000000u, 0x00000000u, 0x01010100u, 0x00000000u, 0x00000000u, 0x00000000u, 0x0f0e0d00u,   // |v| = 15, left half
     0x01010101u, 0x00000000u, 0x00000000u, 0x00000000u, 0x13121110u, 0x00000000u, 0x00000000u, 0x00000000u,   // |v| = 15, right half
 };
-__constant__ int32_t c_gauss7[7] = {18, 34, 48, 56, 48, 34, 18};   // oracle/ORACLE_SPEC.md rule 10
 constexpr uint32_t kG0123 = 18u | (34u << 8) | (48u << 16) | (56u << 24);
 constexpr uint32_t kG456 = 48u | (34u << 8) | (18u << 16);
+// variant (geo->variant bit 2, ORACLE_SPEC rule 10): independently rounded taps 18, 34, 49, 55 (sum 257, result saturates at 255)
+constexpr uint32_t kG0123Indep = 18u | (34u << 8) | (49u << 16) | (55u << 24);
+constexpr uint32_t kG456Indep = 49u | (34u << 8) | (18u << 16);
 
 constexpr int kPatch = 43;       // 2*(18+3)+1
 constexpr int kPatchR = 21;
@@ -209,6 +211,8 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
     // ---- blur row pass (8.8 fixed point): hblur[r][c] = sum_k g[k] * patch[r][c + k], c <-> dx = c - 18.
     // One lane-step = outputs c = 4q .. 4q+3 of row r from 4 aligned words (columns 37..39 are computed and never read).
     const int sh = off & 3;
+    const bool taps_indep = (geo->variant & 4) != 0;
+    const uint32_t g0123 = taps_indep ? kG0123Indep : kG0123, g456 = taps_indep ? kG456Indep : kG456;
     uint32_t* hb32 = reinterpret_cast<uint32_t*>(hblur);
     for (int i = lane; i < kPatch * 10; i += 64) {
         const int r = i / 10, q = i - r * 10;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
         for (int j = 0; j < 4; ++j) {
             const uint32_t a = j ? __builtin_amdgcn_alignbyte(n1, n0, j) : n0;
             const uint32_t b = j ? __builtin_amdgcn_alignbyte(n2, n1, j) : n1;
-            o[j] = __builtin_amdgcn_udot4(a, kG0123, __builtin_amdgcn_udot4(b, kG456, 0u, false), false);   // <= 255*256
+            o[j] = __builtin_amdgcn_udot4(a, g0123, __builtin_amdgcn_udot4(b, g456, 0u, false), false);   // <= 255 * 257 = 65535
         }
         hb32[r * (kHbPitch / 2) + 2 * q] = o[0] | (o[1] << 16);
         hb32[r * (kHbPitch / 2) + 2 * q + 1] = o[2] | (o[3] << 16);
@@ -236,8 +240,8 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
         const uint16_t* hp = hblur + (dy + kBlurR) * kHbPitch + dx + kBlurR;
         uint32_t acc = 0;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) acc += (uint32_t)c_gauss7[k] * hp[k * kHbPitch];
-        return (int)((acc + 32768u) >> 16);
+        for (int k = 0; k < 7; ++k) acc += ((g0123 >> (8 * (k < 4 ? k : 6 - k))) & 255u) * hp[k * kHbPitch];   // symmetric taps: g[k] = g[6 - k]
+        return (int)min((acc + 32768u) >> 16, 255u);   // (only the 257-sum variant can exceed 255)
     };
     unsigned long long bits[4];
     const uint32_t* pat = reinterpret_cast<const uint32_t*>(c_pattern);

@@ -127,6 +127,8 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
     const int level = level_lo + (int)blockIdx.x, frame = blockIdx.y;   // the launch covers levels [level_lo, level_lo + gridDim.x)
     const int L = geo->num_levels;
     const LevelGeo& g = geo->lv[level];
+    const uint32_t switch_factor = (geo->variant & 1) ? 1u : 3u;   // ORACLE_SPEC rule 6
+    const bool tie_earlier = (geo->variant & 2) != 0;                // rule 7: equal counts -> earlier-created node (higher list position) first
     const uint32_t N = (uint32_t)g.n_keypts;
     uint32_t n = cand_count[frame * L + level];
     if (n > (uint32_t)g.cand_cap) n = g.cand_cap;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
             uint32_t npool_cur;
             if (size <= (uint32_t)kRankDirect) {
                 for (uint32_t j = tid; j < size; j += kTreeThreads)
-                    keys[j] = tmp[j] ? (((unsigned long long)(0xFFFFFFu - cur[j].count) << 16) | j) : ~0ull;
+                    keys[j] = tmp[j] ? (((unsigned long long)(0xFFFFFFu - cur[j].count) << 16) | (tie_earlier ? 0xFFFFu - j : j)) : ~0ull;
                 npool_cur = array_excl_scan<kTreeThreads>(tmp, rank, (int)size, s_wave);   // rank[] is scratch here; barriers inside publish keys[]
                 for (uint32_t j = tid; j < size; j += kTreeThreads) rank[j] = 0;
                 __syncthreads();
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
                 while (P2 < size) P2 <<= 1;
                 for (uint32_t j = tid; j < P2; j += kTreeThreads) {
                     unsigned long long key = ~0ull;
-                    if (j < size && tmp[j]) key = ((unsigned long long)(0xFFFFFFu - cur[j].count) << 16) | j;
+                    if (j < size && tmp[j]) key = ((unsigned long long)(0xFFFFFFu - cur[j].count) << 16) | (tie_earlier ? 0xFFFFu - j : j);
                     keys[j] = key;
                 }
                 __syncthreads();
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
                 // pool size, gains in processing order
                 npool_cur = array_excl_scan<kTreeThreads>(tmp, rank, (int)size, s_wave);   // rank[] reused below
                 for (uint32_t r = tid; r < npool_cur; r += kTreeThreads) {
-                    const uint32_t j = (uint32_t)keys[r] & 0xFFFFu;
+                    const uint32_t jl = (uint32_t)keys[r] & 0xFFFFu, j = tie_earlier ? 0xFFFFu - jl : jl;
                     sidx[r] = j;
                     base[r] = nch[j] - 1u;   // gain of splitting the r-th pool node (nch >= 1 for a non-leaf)
                 }
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
             done_final = true;
             break;
         }
-        if (phase == 1 && N < size + 3u * npool_new) phase = 2;
+        if (phase == 1 && N < size + switch_factor * npool_new) phase = 2;
     }
 
     // ---- find_keypoints_with_max_response; output in list order

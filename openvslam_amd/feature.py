@@ -125,6 +125,13 @@ class orb_extractor:
         """Level-0 FAST beside the pyramid on an internal stream (default on); off = one FAST launch after the pyramid."""
         _lib.check(self._L.ovs_orb_set_fast_split(self._h, 1 if enable else 0), "ovs_orb_set_fast_split")
 
+    def set_variant(self, which, value):
+        """ovs_orb_set_variant: "tree_switch_factor" (3 | 1), "tree_tie_order" (0 later-created first | 1 earlier first), "blur_taps" (0 | 1) --
+        the rules of oracle/ORACLE_SPEC.md (6, 7, 10) that cannot be pinned without upstream's sources, as run-time choices."""
+        idx = {"tree_switch_factor": 0, "tree_tie_order": 1, "blur_taps": 2}[which]
+        _lib.check(self._L.ovs_orb_set_variant(self._h, idx, int(value)), "ovs_orb_set_variant")
+        self.max_keypoints = self._L.ovs_orb_max_keypoints(self._h)   # tree_switch_factor = 1 can return up to 2 N per level
+
     def set_pipeline(self, n_sub):
         """Issue the device-batch extract as n_sub overlapping sub-batches on internal streams (ovs_orb_set_pipeline)."""
         _lib.check(self._L.ovs_orb_set_pipeline(self._h, int(n_sub)), "ovs_orb_set_pipeline")

@@ -52,6 +52,9 @@ def lib():
     L.ovo_orb_create.restype = vp
     L.ovo_orb_destroy.argtypes = [vp]
     L.ovo_orb_set_threads.argtypes = [vp, C.c_int]
+    L.ovo_orb_set_variant.argtypes = [vp, C.c_int, C.c_int]
+    L.ovo_distribute_via_tree_v.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.ovo_gaussian_blur_7x7_v.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t, C.c_int]
     L.ovo_orb_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t, vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.ovo_orb_level_size.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.ovo_orb_level_image.argtypes = [vp, C.c_int]
@@ -132,19 +135,22 @@ def fast9_16(img, threshold, nonmax=True):
     return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
 
 
-def distribute_via_tree(xs, ys, responses, min_x, max_x, min_y, max_y, num_keypts):
+def distribute_via_tree(xs, ys, responses, min_x, max_x, min_y, max_y, num_keypts, switch_factor=3, tie_earlier_first=False):
+    """switch_factor / tie_earlier_first: ORACLE_SPEC rules 6 / 7 as run-time variants (defaults = the rules as fixed)."""
     xs = np.ascontiguousarray(xs, np.float32)
     ys = np.ascontiguousarray(ys, np.float32)
     rs = np.ascontiguousarray(responses, np.float32)
     out = np.zeros(max(len(xs), 1), np.int32)
-    n = lib().ovo_distribute_via_tree(_p(xs), _p(ys), _p(rs), len(xs), min_x, max_x, min_y, max_y, num_keypts, _p(out), len(out))
+    n = lib().ovo_distribute_via_tree_v(_p(xs), _p(ys), _p(rs), len(xs), min_x, max_x, min_y, max_y, num_keypts, int(switch_factor),
+                                        int(bool(tie_earlier_first)), _p(out), len(out))
     return out[:n].copy()
 
 
-def gaussian_blur(img):
+def gaussian_blur(img, taps_variant=0):
+    """taps_variant: ORACLE_SPEC rule 10 as a run-time variant (0 = 18 34 48 56 ..., 1 = 18 34 49 55 ... saturating)."""
     img = np.ascontiguousarray(img, np.uint8)
     dst = np.zeros_like(img)
-    assert lib().ovo_gaussian_blur_7x7(_p(img), img.shape[0], img.shape[1], img.strides[0], _p(dst), dst.strides[0]) == 0
+    assert lib().ovo_gaussian_blur_7x7_v(_p(img), img.shape[0], img.shape[1], img.strides[0], _p(dst), dst.strides[0], int(taps_variant)) == 0
     return dst
 
 
@@ -182,9 +188,14 @@ class OrbExtractor:
             lib().ovo_orb_destroy(self._h)
             self._h = None
 
+    def set_variant(self, which, value):
+        """ORACLE_SPEC rules 6 / 7 / 10 as run-time variants (ovo_orb_set_variant): same names and values as feature.orb_extractor.set_variant."""
+        idx = {"tree_switch_factor": 0, "tree_tie_order": 1, "blur_taps": 2}[which]
+        assert lib().ovo_orb_set_variant(self._h, idx, int(value)) == 0, (which, value)
+
     def extract(self, img, mask=None):
         img = np.ascontiguousarray(img, np.uint8)
-        cap = self.params.max_num_keypts + 260 * self.params.num_levels + 64   # a level may return 4 nodes per root patch (<= 64 patches)
+        cap = 2 * self.params.max_num_keypts + 260 * self.params.num_levels + 64   # a level may return 4 nodes per root patch (<= 64 patches); 2 N under tree_switch_factor = 1
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int(0)

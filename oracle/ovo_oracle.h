@@ -68,6 +68,9 @@ long long ovo_detmath_logf_vs_libm(uint32_t first_bits, uint32_t last_bits);
 float ovo_ic_angle(const uint8_t* img, size_t stride, int x, int y, const int32_t* u_max16);
 /* A6: 7x7 sigma=2 Gaussian, 8.8 fixed point, BORDER_REFLECT_101. */
 int ovo_gaussian_blur_7x7(const uint8_t* src, int rows, int cols, size_t sstride, uint8_t* dst, size_t dstride);
+int ovo_gaussian_blur_7x7_v(const uint8_t* src, int rows, int cols, size_t sstride, uint8_t* dst, size_t dstride, int taps_variant);
+int ovo_distribute_via_tree_v(const float* xs, const float* ys, const float* responses, int n, int min_x, int max_x, int min_y, int max_y,
+                              int num_keypts, int switch_factor, int tie_earlier_first, int32_t* out_idx, int cap);
 /* A7: util::cos / util::sin polynomial and one steered-BRIEF descriptor (32 bytes). */
 float ovo_util_cos(float v);
 float ovo_util_sin(float v);
@@ -79,6 +82,10 @@ typedef struct ovo_orb ovo_orb;
 ovo_orb* ovo_orb_create(const ovo_orb_params* p);
 void ovo_orb_destroy(ovo_orb* h);
 void ovo_orb_set_threads(ovo_orb* h, int n); /* OpenMP threads over levels (upstream USE_OPENMP shape) */
+/* ORACLE_SPEC rules 6, 7, 10 as run-time variants: which 0 = quad-tree switch factor (3 default | 1), 1 = equal-count tie order of the sorted
+ * phase (0 later-created node first, default | 1 earlier-created first), 2 = blur taps (0 = 18,34,48,56 error-diffused, default | 1 = 18,34,49,55
+ * independently rounded, saturating). Returns -1 for an unknown pair. */
+int ovo_orb_set_variant(ovo_orb* h, int which, int value);
 /* mask: NULL or rows x cols u8 (0 = masked out). Returns 0, writes *n_out (<= cap). */
 int ovo_orb_extract(ovo_orb* h, const uint8_t* img, int rows, int cols, size_t stride, const uint8_t* mask,
                     size_t mask_stride, ovo_keypoint* kps, uint8_t* desc, int cap, int* n_out);

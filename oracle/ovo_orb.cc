@@ -308,8 +308,10 @@ void assign_child_nodes(const std::array<Node, 4>& children, std::list<Node>& no
     }
 }
 
+// switch_factor / tie_earlier_first: the two implementation-dependent choices of this stage as run-time variants (ORACLE_SPEC rules 6, 7):
+// ORB-SLAM2's `N < nodes + 3 * splittable` vs a factor of 1, and the order of equal-count nodes in the sorted phase
 std::vector<int> distribute_via_tree(const std::vector<Cand>& cands, int min_x, int max_x, int min_y, int max_y,
-                                     unsigned num_keypts) {
+                                     unsigned num_keypts, unsigned switch_factor = 3, bool tie_earlier_first = false) {
     std::vector<int> result;
     if (cands.empty()) return result;
     // ---- initialize_nodes: a row (landscape) or column (portrait) of near-square root patches
@@ -372,16 +374,16 @@ std::vector<int> distribute_via_tree(const std::vector<Cand>& cands, int min_x, 
             it = nodes.erase(it);
         }
         if (num_keypts <= nodes.size() || nodes.size() == prev_size) { is_filled = true; break; }
-        if (num_keypts < nodes.size() + 3 * pool.size()) { is_filled = false; break; }
+        if (num_keypts < nodes.size() + switch_factor * pool.size()) { is_filled = false; break; }
     }
     while (!is_filled) {
         const size_t prev_size = nodes.size();
         auto prev_pool = pool;
         pool.clear();
         // descending by keypoint count; ties: later-created node first (see TIE RULE above)
-        std::sort(prev_pool.begin(), prev_pool.end(), [](const std::pair<int, Node*>& a, const std::pair<int, Node*>& b) {
+        std::sort(prev_pool.begin(), prev_pool.end(), [tie_earlier_first](const std::pair<int, Node*>& a, const std::pair<int, Node*>& b) {
             if (a.first != b.first) return a.first > b.first;
-            return a.second->seq > b.second->seq;
+            return tie_earlier_first ? a.second->seq < b.second->seq : a.second->seq > b.second->seq;
         });
         for (const auto& pn : prev_pool) {
             const auto children = divide_node(*pn.second);
@@ -455,6 +457,10 @@ float ic_angle(const uint8_t* img, size_t stride, int x, int y, const int* u_max
 //     (3.4.1..3.4.6 round every tap independently): this definition is the oracle's.
 // ------------------------------------------------------------------------------------------------------------
 const int kGauss7[7] = {18, 34, 48, 56, 48, 34, 18};
+inline const int* ovo_kGauss7Default() { return kGauss7; }
+// variant 1 (ORACLE_SPEC rule 10): every tap rounded on its own, cvRound(256 g_i) -- OpenCV's 8-bit fixed-point separable filter before
+// 3.4.1's getGaussianKernelFixedPoint_ED (and 3.4.1 .. 3.4.6 as recalled). The taps sum to 257, so the result can reach 257: saturate_cast.
+const int kGauss7Indep[7] = {18, 34, 49, 55, 49, 34, 18};
 inline int reflect101(int i, int n) {
     if (n == 1) return 0;
     while (i < 0 || i >= n) {
@@ -463,14 +469,15 @@ inline int reflect101(int i, int n) {
     }
     return i;
 }
-void gaussian_blur_7x7(const uint8_t* src, int rows, int cols, size_t sstride, uint8_t* dst, size_t dstride) {
+void gaussian_blur_7x7(const uint8_t* src, int rows, int cols, size_t sstride, uint8_t* dst, size_t dstride, int taps_variant = 0) {
+    const int* const kGauss7 = taps_variant == 1 ? kGauss7Indep : ovo_kGauss7Default();
     std::vector<uint16_t> h((size_t)rows * cols);
     for (int y = 0; y < rows; ++y) {
         const uint8_t* S = src + (size_t)y * sstride;
         for (int x = 0; x < cols; ++x) {
             unsigned acc = 0;
             for (int k = -3; k <= 3; ++k) acc += (unsigned)kGauss7[k + 3] * S[reflect101(x + k, cols)];
-            h[(size_t)y * cols + x] = (uint16_t)acc;   // <= 255*256
+            h[(size_t)y * cols + x] = (uint16_t)acc;   // <= 255 * 257 = 65535
         }
     }
     for (int y = 0; y < rows; ++y) {
@@ -478,7 +485,8 @@ void gaussian_blur_7x7(const uint8_t* src, int rows, int cols, size_t sstride, u
         for (int x = 0; x < cols; ++x) {
             uint32_t acc = 0;
             for (int k = -3; k <= 3; ++k) acc += (uint32_t)kGauss7[k + 3] * h[(size_t)reflect101(y + k, rows) * cols + x];
-            D[x] = (uint8_t)((acc + 32768u) >> 16);
+            const uint32_t v = (acc + 32768u) >> 16;
+            D[x] = (uint8_t)(v > 255u ? 255u : v);   // (only the 257-sum variant can exceed 255)
         }
     }
 }
@@ -544,6 +552,7 @@ struct ovo_orb {
     std::vector<int> npl;
     int u_max[16];
     int threads = 1;
+    int tree_switch_factor = 3, tree_tie_earlier_first = 0, blur_taps = 0;   // ORACLE_SPEC rules 6, 7, 10 as run-time variants
     // observables of the last extract
     std::vector<int> lrows, lcols;
     std::vector<std::vector<uint8_t>> pyr, blurred;
@@ -600,7 +609,8 @@ void compute_level(ovo_orb* h, int level, const uint8_t* mask, size_t mask_strid
     }
     // ---- distribute, then translate / octave / size
     const std::vector<int> sel =
-        distribute_via_tree(to_distribute, min_border_x, max_border_x, min_border_y, max_border_y, (unsigned)h->npl[level]);
+        distribute_via_tree(to_distribute, min_border_x, max_border_x, min_border_y, max_border_y, (unsigned)h->npl[level],
+                            (unsigned)h->tree_switch_factor, h->tree_tie_earlier_first != 0);
     const unsigned scaled_patch_size = (unsigned)(kFastPatchSize * scale_factor);
     kps.reserve(sel.size());
     for (int idx : sel) {
@@ -674,11 +684,25 @@ int ovo_distribute_via_tree(const float* xs, const float* ys, const float* respo
     return (int)sel.size();
 }
 
+int ovo_distribute_via_tree_v(const float* xs, const float* ys, const float* responses, int n, int min_x, int max_x, int min_y, int max_y,
+                              int num_keypts, int switch_factor, int tie_earlier_first, int32_t* out_idx, int cap) {
+    std::vector<Cand> c(n);
+    for (int i = 0; i < n; ++i) c[i] = {xs[i], ys[i], responses[i], i};
+    const auto sel = distribute_via_tree(c, min_x, max_x, min_y, max_y, (unsigned)num_keypts, (unsigned)switch_factor, tie_earlier_first != 0);
+    for (size_t i = 0; i < sel.size() && (int)i < cap; ++i) out_idx[i] = sel[i];
+    return (int)sel.size();
+}
+
 float ovo_fast_atan2(float y, float x) { return fast_atan2(y, x); }
 float ovo_ic_angle(const uint8_t* img, size_t stride, int x, int y, const int32_t* u_max16) { return ic_angle(img, stride, x, y, u_max16); }
 int ovo_gaussian_blur_7x7(const uint8_t* src, int rows, int cols, size_t sstride, uint8_t* dst, size_t dstride) {
     if (!src || !dst || rows < 1 || cols < 1) return -1;
     gaussian_blur_7x7(src, rows, cols, sstride, dst, dstride);
+    return 0;
+}
+int ovo_gaussian_blur_7x7_v(const uint8_t* src, int rows, int cols, size_t sstride, uint8_t* dst, size_t dstride, int taps_variant) {
+    if (!src || !dst || rows < 1 || cols < 1 || taps_variant < 0 || taps_variant > 1) return -1;
+    gaussian_blur_7x7(src, rows, cols, sstride, dst, dstride, taps_variant);
     return 0;
 }
 float ovo_util_cos(float v) { return util_cos(v); }
@@ -698,6 +722,15 @@ ovo_orb* ovo_orb_create(const ovo_orb_params* p) {
 }
 void ovo_orb_destroy(ovo_orb* h) { delete h; }
 void ovo_orb_set_threads(ovo_orb* h, int n) { h->threads = std::max(1, n); }
+// which: 0 quad-tree switch factor (3 | 1), 1 equal-count tie order (0 later-created first | 1 earlier-created first), 2 blur taps (0 | 1)
+int ovo_orb_set_variant(ovo_orb* h, int which, int value) {
+    if (!h) return -1;
+    if (which == 0 && (value == 3 || value == 1)) h->tree_switch_factor = value;
+    else if (which == 1 && (value == 0 || value == 1)) h->tree_tie_earlier_first = value;
+    else if (which == 2 && (value == 0 || value == 1)) h->blur_taps = value;
+    else return -1;
+    return 0;
+}
 
 int ovo_orb_extract(ovo_orb* h, const uint8_t* img, int rows, int cols, size_t stride, const uint8_t* mask, size_t mask_stride,
                     ovo_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
@@ -729,7 +762,7 @@ int ovo_orb_extract(ovo_orb* h, const uint8_t* img, int rows, int cols, size_t s
         if (k.empty()) continue;
         // ---- blur a copy of the level, describe, then correct_keypoint_scale
         h->blurred[l].resize(h->pyr[l].size());
-        gaussian_blur_7x7(h->pyr[l].data(), h->lrows[l], h->lcols[l], h->lcols[l], h->blurred[l].data(), h->lcols[l]);
+        gaussian_blur_7x7(h->pyr[l].data(), h->lrows[l], h->lcols[l], h->lcols[l], h->blurred[l].data(), h->lcols[l], h->blur_taps);
         all_desc[l].resize(k.size() * 32);
         for (size_t i = 0; i < k.size(); ++i) {
             orb_descriptor(h->blurred[l].data(), h->lcols[l], cv_round(k[i].x), cv_round(k[i].y), k[i].angle, &all_desc[l][i * 32]);

@@ -64,6 +64,57 @@ def test_extract_bit_exact(hip, oracle, rows, cols, nfeat, seed):
     assert np.array_equal(gd, wd)
 
 
+@pytest.mark.parametrize("factor,tie,taps", [(1, 0, 0), (3, 1, 0), (3, 0, 1), (1, 1, 1)])
+@pytest.mark.parametrize("rows,cols,nfeat", [(1080, 1920, 2000), (480, 752, 1000), (500, 644, 700)])
+def test_extract_bit_exact_under_every_variant(hip, oracle, rows, cols, nfeat, factor, tie, taps):
+    """ORACLE_SPEC rules 6 (quad-tree switch factor), 7 (equal-count tie order) and 10 (blur taps) as run-time variants of BOTH sides
+    (ovs_orb_set_variant / ovo_orb_set_variant): byte-equal keypoints and descriptors in every setting, and back to the defaults."""
+    img, ex, ox = _pair(hip, oracle, rows, cols, nfeat, seed=2)
+    gk0, gd0 = ex.extract(img)
+    for e in (ex, ox):
+        e.set_variant("tree_switch_factor", factor)
+        e.set_variant("tree_tie_order", tie)
+        e.set_variant("blur_taps", taps)
+    gk, gd = ex.extract(img)
+    wk, wd = ox.extract(img)
+    assert len(gk) == len(wk) and np.array_equal(gk.view(np.uint8), wk.view(np.uint8)) and np.array_equal(gd, wd)
+    assert not (np.array_equal(gd, gd0) and len(gk) == len(gk0))   # the variants are not no-ops on this frame
+    for e in (ex, ox):
+        e.set_variant("tree_switch_factor", 3)
+        e.set_variant("tree_tie_order", 0)
+        e.set_variant("blur_taps", 0)
+    gk1, gd1 = ex.extract(img)
+    assert np.array_equal(gk1.view(np.uint8), gk0.view(np.uint8)) and np.array_equal(gd1, gd0)
+    with pytest.raises(RuntimeError):
+        ex.set_variant("tree_switch_factor", 2)
+
+
+def test_switch_factor_one_overshoot(hip, oracle):
+    """tree_switch_factor = 1 lets the last all-at-once pass end far beyond N (dense corners: 64 -> 256 nodes when a level wants ~130): the
+    outputs are sized 2 N + 3 per level in that variant (ovs_orb_max_keypoints changes) and stay byte-equal with the oracle."""
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    overshoot = 0
+    for nfeat in (300, 420, 600, 900):
+        ex = hip.orb_extractor(hip.orb_params(max_num_keypts=nfeat), max_rows=480, max_cols=640)
+        ox = oracle.OrbExtractor(oracle.make_params(nfeat))
+        cap3 = ex.max_keypoints
+        for e in (ex, ox):
+            e.set_variant("tree_switch_factor", 1)
+        assert ex.max_keypoints >= cap3 and (nfeat < 900 or ex.max_keypoints > cap3)
+        gk, gd = ex.extract(img)
+        wk, wd = ox.extract(img)
+        assert len(gk) == len(wk) and np.array_equal(gk.view(np.uint8), wk.view(np.uint8)) and np.array_equal(gd, wd)
+        overshoot += len(gk) > nfeat + 3 * 8   # more than sum over levels of N + 3: some level's list passed its factor-3 capacity
+        ex.set_variant("tree_switch_factor", 3)
+        ox.set_variant("tree_switch_factor", 3)
+        assert ex.max_keypoints == cap3
+        gk, gd = ex.extract(img)
+        wk, wd = ox.extract(img)
+        assert len(gk) <= nfeat + 3 * 8 and np.array_equal(gk.view(np.uint8), wk.view(np.uint8)) and np.array_equal(gd, wd)
+    assert overshoot >= 1   # at least one size really needed the larger capacity
+
+
 def test_flat_and_tiny_images(hip, oracle):
     # flat image: no corners at either threshold -> zero keypoints; tiny image: levels without any cell
     for img in (np.full((480, 752), 77, np.uint8), synth_frame(120, 160, seed=3), synth_frame(64, 64, seed=4)):

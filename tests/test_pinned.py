@@ -61,7 +61,17 @@ def test_oracle_resize_and_blur_equal_opencv(oracle, pins, gen, name):
         if l > 0:
             prev = oracle.resize_linear(prev, *sizes[l])
         _check_plane(pins, "pyr_%s_%d" % (name, l), prev, name)
-        _check_plane(pins, "blur_%s_%d" % (name, l), oracle.gaussian_blur(prev), name)   # rule 10 is OpenCV-version dependent
+        # rule 10 is OpenCV-version dependent: ONE of the tap variants must reproduce the build the fixture came from (and then
+        # ovs_orb_set_variant(OVS_VARIANT_BLUR_TAPS, that one) / ovo_orb_set_variant is the setting that matches it)
+        errs = []
+        for variant in (0, 1):
+            try:
+                _check_plane(pins, "blur_%s_%d" % (name, l), oracle.gaussian_blur(prev, variant), name)
+                break
+            except AssertionError as e:
+                errs.append(e)
+        else:
+            raise AssertionError("no blur-tap variant matches OpenCV %s at level %d: %s" % (pins["opencv_version"], l, errs[0]))
 
 
 def test_oracle_fast_equals_opencv(oracle, pins, gen):
