@@ -74,6 +74,9 @@ private:
     value arr(size_t n, int depth) {
         value v;
         v.kind = value::array;
+        // n comes straight from the file (up to 2^32 - 1): every element takes at least one byte, so a count beyond the bytes left is a
+        // truncated or corrupt file -- say so before reserving for it
+        if (n > (size_t)(end_ - p_)) throw std::runtime_error("msgpack: truncated");
         v.a.reserve(n);
         for (size_t k = 0; k < n; ++k) v.a.push_back(next(depth + 1));
         return v;
@@ -81,6 +84,7 @@ private:
     value obj(size_t n, int depth) {
         value v;
         v.kind = value::object;
+        if (n > (size_t)(end_ - p_) / 2) throw std::runtime_error("msgpack: truncated");   // a key and a value per entry
         v.o.reserve(n);
         for (size_t k = 0; k < n; ++k) {
             value key = next(depth + 1);

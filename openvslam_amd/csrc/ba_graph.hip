@@ -682,6 +682,22 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
             pose_edges[(size_t)fp[g->edge_pose[e]]++] = e;
         }
     }
+    // A keyframe observes a landmark at most once (upstream: landmark::add_observation ignores a second observation by the same keyframe).
+    // The reduced system's pair lists below rely on that -- two edges of one free keyframe to one landmark would need cross terms that
+    // the lists do not carry, while Hpp / Hll / rhs would still count both edges --, so a caller-built edge list that breaks it is refused.
+    {
+        std::vector<int32_t> seen((size_t)n_pose, -1);
+        for (int j = 0; j < n_pt; ++j)
+            for (int i = lm_start[j]; i < lm_start[(size_t)j + 1]; ++i) {
+                const int32_t k = g->edge_pose[lm_edges[i]];
+                if (seen[k] == j) {
+                    ovs::set_last_error_text("ovs_ba_graph_create: keyframe " + std::to_string(k) + " has two edges to landmark " + std::to_string(j));
+                    ovs_ba_graph_destroy(g);
+                    return OVS_ERR_INVALID;
+                }
+                seen[k] = j;
+            }
+    }
 #define G_TRY(expr)                            \
     do {                                       \
         hipError_t _e = (expr);                \
@@ -718,7 +734,7 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
                     for (int i2 = lm_start[j]; i2 < lm_start[(size_t)j + 1]; ++i2) {
                         const int eb = lm_edges[i2], sb = g->slot[g->edge_pose[eb]];
                         if (sb < 0 || sb < sa) continue;
-                        // two edges of one keyframe to one landmark do not occur in a valid graph; (ea, ea) is the diagonal term
+                        // (ea, ea) is the diagonal term; two different edges of one keyframe to one landmark were refused above
                         if (sb == sa && eb != ea) continue;
                         fn(pair_id(sa, sb), ea, eb);
                     }

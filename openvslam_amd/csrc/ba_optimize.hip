@@ -88,6 +88,7 @@ struct Lm {
     // OVS_BA_TRACE=1: wall-clock breakdown on stderr (where a call's milliseconds go; tools/time_lba.py)
     double t_schur = 0, t_chol = 0, t_trial = 0;
     int n_trials = 0;
+    bool err_at_trial = false;   // the active edges' errors were last computed at the trial state (d_poses_n, d_Xn), which was then rejected
     static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     hipStream_t stream = nullptr;
     DevBlocks cur, trial;
@@ -183,6 +184,7 @@ struct Lm {
         *chi_start = current_chi;
         *chi_end = current_chi;
         *n_iter = 0;
+        err_at_trial = false;
         if (iters <= 0) return OVS_OK;
         // computeLambdaInit: tau * the largest diagonal entry of the active vertices' Hessian blocks
         double lambda = 1e-5 * h_chi[2], ni = 2;
@@ -193,6 +195,7 @@ struct Lm {
             ++*n_iter;
             double rho = 0;
             int qmax = 0;
+            err_at_trial = false;   // solve() starts with computeActiveErrors() at the current estimate
             do {
                 const double t0 = now();
                 ++n_trials;
@@ -236,6 +239,7 @@ struct Lm {
                     OVS_HIP_TRY(hipMemcpyAsync(h_chi + 4, gi.d_scal, sizeof(double), hipMemcpyDeviceToHost, stream));
                     OVS_HIP_TRY(hipStreamSynchronize(stream));   // also covers dxp / p7 (locals)
                     temp_chi = h_chi[1];
+                    err_at_trial = true;   // computeActiveErrors() ran on the trial state (d_poses_n, d_Xn); cleared below if it is accepted
                     double sc = 0;
                     for (int k = 0; k < n_pose; ++k)
                         if (gi.slot[k] >= 0)
@@ -254,6 +258,7 @@ struct Lm {
                     std::swap(d_X, d_Xn);
                     std::swap(d_poses, d_poses_n);
                     std::swap(cur, trial);   // the accepted trial's blocks are the next iteration's system
+                    err_at_trial = false;    // the trial state is the estimate now
                 } else {
                     lambda *= ni;
                     ni *= 2;
@@ -267,16 +272,23 @@ struct Lm {
         return OVS_OK;
     }
 
-    // chi2 and depth sign of every edge of graph g at the state (T, d_X)
+    // What upstream reads after optimizer.optimize(): edge->chi2() -- the error STORED by the last computeActiveErrors(), i.e. at the last
+    // LM trial state when the round ended on a rejected step (g2o pops the estimate back but leaves the errors) -- and
+    // edge->depth_is_positive(), which is evaluated from the vertices' current, accepted estimates (T, d_X).
     ovs_status edge_chi2(ovs_ba_graph* g, const std::vector<Pose>& T, size_t ne, std::vector<double>& chi, std::vector<uint8_t>& depth) {
         ovs_status st = upload_poses(T, d_poses);
         if (st != OVS_OK) return st;
-        st = ovs::ba_graph_edge_chi2(g, d_poses, d_X, d_echi, d_edepth, stream);
-        if (st != OVS_OK) return st;
         chi.resize(ne);
         depth.resize(ne);
+        if (err_at_trial) {
+            st = ovs::ba_graph_edge_chi2(g, d_poses_n, d_Xn, d_echi, d_edepth, stream);
+            if (st != OVS_OK) return st;
+            if (ne) OVS_HIP_TRY(hipMemcpyAsync(chi.data(), d_echi, sizeof(double) * ne, hipMemcpyDeviceToHost, stream));
+        }
+        st = ovs::ba_graph_edge_chi2(g, d_poses, d_X, d_echi, d_edepth, stream);
+        if (st != OVS_OK) return st;
         if (ne) {
-            OVS_HIP_TRY(hipMemcpyAsync(chi.data(), d_echi, sizeof(double) * ne, hipMemcpyDeviceToHost, stream));
+            if (!err_at_trial) OVS_HIP_TRY(hipMemcpyAsync(chi.data(), d_echi, sizeof(double) * ne, hipMemcpyDeviceToHost, stream));
             OVS_HIP_TRY(hipMemcpyAsync(depth.data(), d_edepth, ne, hipMemcpyDeviceToHost, stream));
         }
         OVS_HIP_TRY(hipStreamSynchronize(stream));

@@ -20,7 +20,9 @@
 // its transform to equal the source tree's.
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <fstream>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -69,9 +71,15 @@ bool parse_fbow(const std::vector<unsigned char>& b, Tree& t) {
     static_assert(sizeof(Params) == 120, "fbow::Vocabulary::params layout");
     if (!get(b, 8, &p)) return false;
     const size_t base = 8 + sizeof(Params);
-    if (p.desc_size != 32 || p.m_k == 0 || p.m_k > 65535 || p.nblocks == 0 || p.block_size_bytes_wp == 0 ||
-        base + p.total_size > b.size() || (uint64_t)p.nblocks * p.block_size_bytes_wp > p.total_size)
+    // every header field comes from the file: compare by division / against the bytes that are really there, never through a sum or a
+    // product of two of them (u64 wrap-around), and bound the node count by the file size before anything is allocated from it
+    if (p.desc_size != 32 || p.m_k == 0 || p.m_k > 65535 || p.nblocks == 0 || p.block_size_bytes_wp == 0 || p.total_size > b.size() - base ||
+        p.block_size_bytes_wp > p.total_size / p.nblocks)
         return false;
+    if (p.desc_size_bytes_wp < 32 || p.desc_size_bytes_wp > p.block_size_bytes_wp || p.feature_off_start > p.block_size_bytes_wp ||
+        p.child_off_start > p.block_size_bytes_wp || (p.block_size_bytes_wp - p.feature_off_start) / p.desc_size_bytes_wp < p.m_k ||
+        (p.block_size_bytes_wp - p.child_off_start) / 8 < p.m_k)
+        return false;   // a block holds m_k features and m_k child records: nblocks * m_k * 40 <= total_size <= file size
     // node ids: 0 = root, 1 + block * k + slot for the node in `slot` of `block`
     const size_t n_nodes = 1 + (size_t)p.nblocks * p.m_k;
     t.parent.assign(n_nodes, -2);   // -2: slot not used
@@ -118,8 +126,14 @@ bool parse_dbow2_binary(const std::vector<unsigned char>& b, Tree& t) {
     int32_t k = 0, L = 0, scoring = 0, weighting = 0;
     if (!get(b, 0, &nb_nodes) || !get(b, 4, &size_node) || !get(b, 8, &k) || !get(b, 12, &L) || !get(b, 16, &scoring) || !get(b, 20, &weighting))
         return false;
-    if (size_node != 41 || k < 1 || k > 65535 || L < 0 || L > 16 || (size_t)24 + (size_t)nb_nodes * size_node > b.size()) return false;
-    const size_t n_nodes = (size_t)nb_nodes + 1;
+    if (size_node != 41 || k < 1 || k > 65535 || L < 0 || L > 16 || b.size() < 24 || (b.size() - 24) % size_node != 0) return false;
+    // The fork's saveToBinaryFile writes nb_nodes = m_nodes.size(), which COUNTS THE ROOT, followed by one record per non-root node
+    // (nb_nodes - 1 records; its loader's resize(nb_nodes + 1) only absorbs the extra !eof() read). The record count is therefore taken
+    // from the file size, and a header that counts the records themselves (what this repository's generator wrote until round 3) is
+    // accepted as well; anything else is a truncated or foreign file.
+    const size_t records = (b.size() - 24) / size_node;
+    if (records == 0 || ((size_t)nb_nodes != records + 1 && (size_t)nb_nodes != records)) return false;
+    const size_t n_nodes = records + 1;
     t.depth = L;
     t.parent.assign(n_nodes, -1);
     t.desc.assign(n_nodes * 32, 0);
@@ -180,9 +194,25 @@ struct ovs_vocab_tree {
 
 extern "C" {
 
+static ovs_status vocab_tree_load_impl(const char* path, ovs_vocab_tree** out, int32_t* format_out, int32_t* n_nodes_out, int32_t* depth_out);
+
+// no C++ exception may cross the C ABI: a file whose header asks for more memory than there is (std::bad_alloc from a vector sized
+// by it) or any other parsing failure is reported as OVS_ERR_INVALID
 ovs_status ovs_vocab_tree_load(const char* path, ovs_vocab_tree** out, int32_t* format_out, int32_t* n_nodes_out, int32_t* depth_out) {
     if (!path || !out) return OVS_ERR_INVALID;
     *out = nullptr;
+    try {
+        return vocab_tree_load_impl(path, out, format_out, n_nodes_out, depth_out);
+    } catch (const std::exception& e) {
+        ovs::set_last_error_text(std::string("ovs_vocab_tree_load(") + path + "): " + e.what());
+    } catch (...) {
+        ovs::set_last_error_text(std::string("ovs_vocab_tree_load(") + path + "): unknown exception");
+    }
+    *out = nullptr;
+    return OVS_ERR_INVALID;
+}
+
+static ovs_status vocab_tree_load_impl(const char* path, ovs_vocab_tree** out, int32_t* format_out, int32_t* n_nodes_out, int32_t* depth_out) {
     std::vector<unsigned char> buf;
     if (!read_all(path, buf) || buf.size() < 8) return OVS_ERR_INVALID;
     Tree t;
@@ -197,8 +227,7 @@ ovs_status ovs_vocab_tree_load(const char* path, ovs_vocab_tree** out, int32_t* 
     int32_t n_nodes = 0;
     for (size_t i = 0; i < n_all; ++i)
         if (t.parent[i] != -2) new_id[i] = n_nodes++;
-    ovs_vocab_tree* v = new (std::nothrow) ovs_vocab_tree();
-    if (!v) return OVS_ERR_INVALID;
+    std::unique_ptr<ovs_vocab_tree> v(new ovs_vocab_tree());
     v->format = format;
     v->depth = t.depth;
     v->child_start.assign((size_t)n_nodes + 1, 0);
@@ -223,7 +252,7 @@ ovs_status ovs_vocab_tree_load(const char* path, ovs_vocab_tree** out, int32_t* 
     if (format_out) *format_out = format;
     if (n_nodes_out) *n_nodes_out = n_nodes;
     if (depth_out) *depth_out = t.depth;
-    *out = v;
+    *out = v.release();
     return OVS_OK;
 }
 

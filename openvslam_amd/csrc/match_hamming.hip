@@ -141,6 +141,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int u = 0; u < 2; ++u) s_ctx[wv][u * 32 + col] = make_int2(need[u], pcq[u]);
     }
+    // s_ctx / s_queue / s_qmeta are written by some lanes of a wave and read by OTHER lanes of the same wave: a wavefront-scope release /
+    // acquire pair plus a wave barrier states that hand-over to the compiler (no instruction is emitted: a wave's DS operations execute
+    // in order), instead of leaving it to the fact that it cannot prove the dynamic indices distinct.
+    auto wave_handover = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    wave_handover();
     // Near pairs are rare per PAIR (about 3 per 1000 on consecutive video frames) but nearly every 32 x 32 tile holds one, so a
     // per-tile "any lane has one" branch into row-by-row tests would run on every tile with one or two useful lanes. Instead a lane
     // whose tile column holds a near pair appends its 16 accumulators to a wave-level queue in LDS (slots compacted with the ballot,
@@ -151,6 +160,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int n_tiles = (n1 + 31) >> 5, phase_tiles = (n_tiles + 1) >> 1;
     int q_head = 0, q_tail = 0;   // wave-uniform ring indices (entries q_head .. q_tail - 1, slots taken mod kQueueSlots)
     auto drain = [&](int n_take) __attribute__((always_inline)) {
+        wave_handover();   // the queue entries stored by the producing lanes -> the draining lanes
         if (lane < n_take) {
             const int e = (q_head + lane) & (kQueueSlots - 1);
             const uint32_t meta = s_qmeta[wv][e];
@@ -178,6 +188,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
             }
         }
+        wave_handover();   // the drained slots are free for the next column sets only after every lane has read its entry
         q_head += n_take;
     };
 

@@ -17,6 +17,7 @@ static thread_local std::string g_last_error;
 void set_last_error(const char* what, hipError_t e) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
 }
+void set_last_error_text(const std::string& what) { g_last_error = what; }
 
 static inline int cv_round_f(float v) { return (int)std::nearbyintf(v); }
 

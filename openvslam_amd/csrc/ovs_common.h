@@ -1,6 +1,8 @@
 // ovs_common.h -- internal declarations shared by the HIP translation units of libovslam_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <string>
 #include <stdint.h>
 
 #include "../../include/ovslam_hip.h"
@@ -109,6 +111,7 @@ hipError_t launch_describe(const FrameGeo& hgeo, const DevBuffers& d, const uint
                            ovs_keypoint* kps, uint8_t* desc, int32_t* counts, int cap, int batch, hipStream_t s);
 
 void set_last_error(const char* what, hipError_t e);
+void set_last_error_text(const std::string& what);   // failures that are not HIP errors (a refused file, an exception stopped at the ABI)
 
 // Device view of one frame's image pyramid (feature::orb_extractor::image_pyramid_) of an extractor's LAST extract.
 struct PyrView {

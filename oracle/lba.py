@@ -186,8 +186,11 @@ class _Graph:
         chi = cur["chi2"][1]
         chi_start = chi
         n_iter = 0
+        # (Terr, Xerr): the state the ACTIVE edges' errors were last computed at. g2o's edge->chi2() reads the stored error: after a rejected
+        # trial the estimate is popped back but the errors stay those of the trial state until the next computeActiveErrors()
+        Terr, Xerr = T, X
         if iters <= 0 or len(self.pi) == 0:
-            return T, X, chi_start, chi, 0
+            return T, X, chi_start, chi, 0, Terr, Xerr
         has_edge = np.bincount(self.li, minlength=self.n_pt) > 0
         md = 0.0
         if len(self.free):
@@ -200,6 +203,7 @@ class _Graph:
                 break
             n_iter += 1
             rho, qmax = 0.0, 0
+            Terr, Xerr = T, X   # solve() starts with computeActiveErrors() at the current estimate
             while True:
                 sol = self.solve(cur, lam)
                 temp, scale = np.finfo(np.float64).max, 1e-3
@@ -208,6 +212,7 @@ class _Graph:
                     Tn = [(_oplus(R, t, dxp[k]) if self.slot[k] >= 0 else (R, t)) for k, (R, t) in enumerate(T)]
                     Xn = X + dxl
                     trial = self.linearize(Tn, Xn, robust)
+                    Terr, Xerr = Tn, Xn   # computeActiveErrors() ran on the trial state, accepted or not
                     temp = trial["chi2"][1]
                     scale = (dxp[self.free] * (lam * dxp[self.free] + cur["bp"][self.free])).sum() + (dxl * (lam * dxl + cur["bl"])).sum() + 1e-3
                 rho = (chi - temp) / scale
@@ -227,7 +232,7 @@ class _Graph:
                     break
             if qmax == 10 or rho == 0 or not np.isfinite(lam):
                 break
-        return T, X, chi_start, chi, n_iter
+        return T, X, chi_start, chi, n_iter, Terr, Xerr
 
 
 def local_ba_optimize_equirect(poses, pose_fixed, points, mono, cols, rows, num_first_iter=5, num_second_iter=10):
@@ -248,14 +253,18 @@ def local_ba_optimize(poses, pose_fixed, points, mono, cam, stereo=None, focal_x
     T = [(_quat_to_rot(p[3:]), p[:3].copy()) for p in poses]
     G = _Graph(n_pose, n_pt, pose_fixed, mono, stereo, tuple(cam), focal_x_baseline, setup_type, equirect)
     info = np.zeros(6)
-    T, X, info[0], info[1], info[4] = G.run_round(T, X, num_first_iter, True)
-    chi_r1, depth = G.edge_chi2(T, X)
+    T, X, info[0], info[1], info[4], Terr, Xerr = G.run_round(T, X, num_first_iter, True)
+    # edge->chi2() is the error stored by the last computeActiveErrors() (the last TRIAL state when the round ended on a rejected step);
+    # edge->depth_is_positive() is evaluated from the vertices' current (accepted) estimates
+    chi_r1 = G.edge_chi2(Terr, Xerr)[0]
+    depth = G.edge_chi2(T, X)[1]
     gate = np.concatenate([np.full(nm, CHI2_MONO), np.full(len(stereo), CHI2_STEREO)])
     out_r1 = (gate < chi_r1) | ~depth
     G.set_edges(mono[~out_r1[:nm]], stereo[~out_r1[nm:]])
-    T, X, info[2], info[3], info[5] = G.run_round(T, X, num_second_iter, False)
+    T, X, info[2], info[3], info[5], Terr, Xerr = G.run_round(T, X, num_second_iter, False)
     G.set_edges(mono, stereo)
-    chi, depth = G.edge_chi2(T, X)
+    chi = G.edge_chi2(Terr, Xerr)[0]
+    depth = G.edge_chi2(T, X)[1]
     c = np.where(out_r1, chi_r1, chi)
     outlier = (gate < c) | ~depth
     P = poses.copy()

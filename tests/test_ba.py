@@ -209,3 +209,50 @@ def test_local_ba_oracle_converges_and_flags_outliers(oracle):
     p0 = np.abs(d["points"][seen] - d["points_true"][seen]).mean()
     p1 = np.abs(r["points"][seen] - d["points_true"][seen]).mean()
     assert p1 < 0.8 * p0
+
+
+def test_local_ba_oracle_judges_edges_at_the_last_trial_state(oracle, monkeypatch):
+    """edge->chi2() reads the error stored by the last computeActiveErrors(): when a round ends on a REJECTED Levenberg-Marquardt trial, that
+    is the trial state, not the accepted estimate g2o pops back to -- while depth_is_positive() sees the accepted estimate. Recorded here
+    through the states local_ba_optimize hands to edge_chi2: chi2 from the state of the round's LAST linearisation (accepted or not), depth
+    from the accepted state. (On a converged problem the rejected trials have lambda so large that the two agree to ~1e-18; the rule matters
+    when a round is cut short -- force stop, ten rejections at a moderate lambda.)"""
+    from oracle import lba
+    chi_states, lin_states = [], []
+    real_chi, real_lin = lba._Graph.edge_chi2, lba._Graph.linearize
+
+    def spy_chi(self, T, X):
+        chi_states.append((np.array(X), len(lin_states)))
+        return real_chi(self, T, X)
+
+    def spy_lin(self, T, X, robust):
+        lin_states.append(np.array(X))
+        return real_lin(self, T, X, robust)
+
+    monkeypatch.setattr(lba._Graph, "edge_chi2", spy_chi)
+    monkeypatch.setattr(lba._Graph, "linearize", spy_lin)
+    d, mono, st, bf, _, _ = _lba_scene(4, n_pose=6, n_pt=400, obs_per_pose=200)
+    # 30 second-round iterations: the round does not run out of iterations, it ends when the trials stop being accepted (converged)
+    r = lba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], mono, d["cam"], None, 0.0, num_first_iter=2, num_second_iter=30)
+    assert len(chi_states) == 4 and r["info"][4] == 2 and r["info"][5] < 30
+    (x_err1, n1), (x_acc1, _), (x_err2, n2), (x_acc2, _) = chi_states
+    assert np.array_equal(x_err1, lin_states[n1 - 1]) and np.array_equal(x_err2, lin_states[n2 - 1])   # the last linearised state of each round
+    assert np.array_equal(x_acc2, r["points"]) and np.abs(x_err2 - x_acc2).max() < 1e-6
+    # a round whose last trial is rejected at a moderate lambda: one iteration from a far-off start with a huge first step is not available
+    # through the public arguments, so the rule is exercised directly on run_round with a stop flag raised by the first rejected trial
+    G = lba._Graph(len(d["poses"]), len(d["points"]), d["pose_fixed"], mono, np.zeros(0, oracle.BA_EDGE_STEREO_DTYPE), tuple(d["cam"]), 0.0, 0)
+    T0 = [(lba._quat_to_rot(p[3:]), p[:3].copy()) for p in d["poses"]]
+    stop = [0]
+    orig_solve = G.solve
+
+    def bad_solve(B, lam):            # a step 50x too long: the trial is rejected, and the flag ends the round right there
+        sol = orig_solve(B, lam)
+        stop[0] = 1
+        return None if sol is None else (50.0 * sol[0], 50.0 * sol[1])
+
+    G.solve = bad_solve
+    T1, X1, c0, c1, n_it, Terr, Xerr = G.run_round(T0, d["points"].copy(), 5, True, stop)
+    assert n_it == 1 and c1 == c0 and np.array_equal(X1, d["points"])          # nothing accepted
+    assert np.abs(Xerr - X1).max() > 1e-3                                       # but the errors were last computed 50 steps away
+    chi_stale, chi_acc = real_chi(G, Terr, Xerr)[0], real_chi(G, T1, X1)[0]
+    assert chi_stale.sum() > chi_acc.sum()

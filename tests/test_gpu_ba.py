@@ -234,6 +234,11 @@ def test_local_ba_force_stop_and_bad_args():
     bad["point_idx"][0] = 10 ** 6
     with pytest.raises(RuntimeError):
         ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], bad, d["cam"])
+    # one keyframe with two edges to one landmark (upstream's landmark::add_observation never produces it; the reduced system's pair
+    # lists would miss the cross terms): refused at graph creation, with the pair named in ovs_last_error
+    dup = np.concatenate([mono, mono[3:4]])
+    with pytest.raises(RuntimeError, match="two edges to landmark"):
+        ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], dup, d["cam"])
 
 
 @pytest.mark.parametrize("stereo_frac", [0.0, 0.35])

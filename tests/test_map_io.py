@@ -110,6 +110,12 @@ def test_cpp_loader_reads_the_same_map(tmp_path):
     bad = str(tmp_path / "bad.msg")
     open(bad, "wb").write(b"\x81\xa5hello\x01")
     assert subprocess.run([_lba_shim(), "mapinfo", bad], capture_output=True).returncode != 0
+    # element counts larger than the bytes that follow (array32 / map32 with 2^32 - 1 entries): refused as truncated, not answered with a
+    # multi-GB reserve
+    for blob in (b"\xdd\xff\xff\xff\xff\x01\x02", b"\xdf\xff\xff\xff\xff\xa1a\x01", b"\x81\xa1k\xdd\x7f\xff\xff\xff"):
+        open(bad, "wb").write(blob)
+        r = subprocess.run([_lba_shim(), "mapinfo", bad], capture_output=True, text=True)
+        assert r.returncode != 0 and "truncated" in r.stderr and "bad_alloc" not in r.stderr, r.stderr
 
 
 @pytest.mark.gpu

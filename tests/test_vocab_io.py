@@ -47,6 +47,34 @@ def test_formats_round_trip_on_the_host(tmp_path, fmt, code):
     assert (got["weight"][got["word_id"] < 0] >= 0).all()
 
 
+def test_dbow2_binary_header_conventions(tmp_path):
+    """The fork's saveToBinaryFile writes nb_nodes INCLUDING the root and nb_nodes - 1 records (what a real orb_vocab.dbow2 carries, as
+    recalled; the generator's default); a header that counts the records is read the same way; any other count, or a file whose size is
+    not 24 + 41 * records, is refused."""
+    import struct
+    import vocab_io
+    from openvslam_amd import _lib, bow
+    v = _vocab(k=5, depth=3)
+    n = len(v["word_id"])
+    a, b = tmp_path / "root_counted.dbow2", tmp_path / "records_counted.dbow2"
+    vocab_io.write_dbow2_binary(str(a), v)
+    vocab_io.write_dbow2_binary(str(b), v, header_counts_root=False)
+    ra, rb = a.read_bytes(), b.read_bytes()
+    assert struct.unpack_from("<I", ra)[0] == n and struct.unpack_from("<I", rb)[0] == n - 1 and len(ra) == len(rb) == 24 + 41 * (n - 1)
+    ga, gb = bow.load_vocabulary_tree(a)[0], bow.load_vocabulary_tree(b)[0]
+    for key in ("child_start", "children", "word_id", "weight"):
+        assert np.array_equal(ga[key], gb[key]) and (key == "weight" or np.array_equal(ga[key], v[key]))
+    assert np.array_equal(ga["desc"], gb["desc"])
+    for bad in (n + 1, n - 2, 0):
+        c = tmp_path / "bad.dbow2"
+        c.write_bytes(struct.pack("<I", bad) + ra[4:])
+        with pytest.raises(_lib.OvsError):
+            bow.load_vocabulary_tree(c)
+    c.write_bytes(ra[:-7])   # a partial last record
+    with pytest.raises(_lib.OvsError):
+        bow.load_vocabulary_tree(c)
+
+
 def test_garbage_and_truncated_files_are_refused(tmp_path):
     import vocab_io
     from openvslam_amd import _lib, bow
@@ -64,6 +92,21 @@ def test_garbage_and_truncated_files_are_refused(tmp_path):
             bow.load_vocabulary_tree(q)
     with pytest.raises(_lib.OvsError):
         bow.load_vocabulary_tree(tmp_path / "does_not_exist.dbow2")
+    # FBoW header fields that would wrap a u64 sum / product or ask for far more nodes than the file can hold: refused, no exception
+    # crosses the ABI (file offsets: nblocks 64, desc_size_bytes_wp 72, block_size_bytes_wp 80, feature_off_start 88, child_off_start 96,
+    # total_size 104, m_k 120)
+    import struct
+    q = tmp_path / "v.fbow"
+    vocab_io.WRITERS["fbow"](str(q), v)
+    raw = bytearray(q.read_bytes())
+    bow.load_vocabulary_tree(q)
+    for off, fmt, val in ((104, "<Q", 2**64 - 64), (88, "<Q", 2**64 - 16), (96, "<Q", 2**64 - 8), (72, "<Q", 2**63), (80, "<Q", 4),
+                          (64, "<I", 2**32 - 1), (120, "<I", 65535)):
+        bad = bytearray(raw)
+        struct.pack_into(fmt, bad, off, val)
+        q.write_bytes(bytes(bad))
+        with pytest.raises(_lib.OvsError):
+            bow.load_vocabulary_tree(q)
 
 
 @pytest.mark.gpu

@@ -40,11 +40,13 @@ def write_dbow2_text(path, vocab):
             f.write("%d %d %s %s\n" % (parent[i], 1 if leaf else 0, " ".join(str(int(b)) for b in vocab["desc"][i]), repr(float(vocab["weight"][i]))))
 
 
-def write_dbow2_binary(path, vocab):
+def write_dbow2_binary(path, vocab, header_counts_root=True):
+    """header_counts_root: the fork's saveToBinaryFile writes nb_nodes = m_nodes.size() INCLUDING the root and then nb_nodes - 1 records
+    (recalled; the default). False writes the record count itself (this generator's convention before round 3; the loader takes both)."""
     parent, k = _check_dbow2_order(vocab)
     n = len(parent)
     with open(path, "wb") as f:
-        f.write(struct.pack("<IIiiii", n - 1, 41, k, vocab["depth"], 0, 0))
+        f.write(struct.pack("<IIiiii", n if header_counts_root else n - 1, 41, k, vocab["depth"], 0, 0))
         for i in range(1, n):
             f.write(struct.pack("<i", int(parent[i])) + bytes(vocab["desc"][i]) + struct.pack("<f", float(vocab["weight"][i]))
                     + (b"\x01" if vocab["word_id"][i] >= 0 else b"\x00"))
