@@ -78,6 +78,11 @@ ovs_status ovs_orb_destroy(ovs_orb* h);
 ovs_status ovs_orb_tables(const ovs_orb* h, float* scale_factors, float* inv_scale_factors, float* level_sigma_sq,
                           float* inv_level_sigma_sq, int32_t* num_keypts_per_level);
 
+/* Test hook for failure handling above the ABI (openvslam_amd/cpp/openvslam/util/device_policy.h, tests/test_cpp_shim.py): after
+ * `skip_calls` further HIP runtime calls that the library checks on a run-time path, the next `n_calls` of them still execute but are
+ * REPORTED as failed (hipErrorLaunchFailure -> OVS_ERR_HIP), any thread. (0, 0) disarms. Nothing else in the library reads it. */
+ovs_status ovs_debug_inject_hip_failures(int32_t skip_calls, int32_t n_calls);
+
 /* Upper bound on the keypoints one frame can produce (sum over levels of N_level + 3; 2 N_level + 3 after
  * ovs_orb_set_variant(OVS_VARIANT_TREE_SWITCH_FACTOR, 1) -- ask again after changing that variant): size outputs with this. */
 int32_t ovs_orb_max_keypoints(const ovs_orb* h);

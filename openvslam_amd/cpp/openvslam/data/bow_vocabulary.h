@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../cv_stub.h"
+#include "../util/device_policy.h"
 
 namespace openvslam {
 namespace data {
@@ -62,8 +63,9 @@ private:
         if (n == 0) return;
         std::vector<int32_t> word((size_t)n), node((size_t)n);
         std::vector<double> weight((size_t)n);
-        const int st = ovs_bow_transform(v_, desc, n, levelsup, word.data(), weight.data(), node.data());
-        if (st != OVS_OK) throw std::runtime_error(std::string("ovs_bow_transform failed: ") + ovs_last_error());
+        // failure policy (util/device_policy.h): one retry, then empty vectors (a frame without words matches no keyframe by BoW)
+        if (!util::run_guarded("ovs_bow_transform", [&] { return ovs_bow_transform(v_, desc, n, levelsup, word.data(), weight.data(), node.data()); }, [] {}))
+            return;
         for (int i = 0; i < n; ++i) {
             if (!(weight[(size_t)i] > 0)) continue;   // DBoW2: `if (w > 0)` -- stopped words carry weight 0
             v[(unsigned int)word[(size_t)i]] += weight[(size_t)i];

@@ -3,21 +3,19 @@
 
 #include <ovslam_hip.h>
 
+#include "../util/device_policy.h"
+
 #include <algorithm>
 #include <cassert>
 #include <mutex>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <utility>
+#include <vector>
 
 namespace openvslam {
 namespace feature {
-
-namespace {
-[[noreturn]] void fail(const char* where, int st) {
-    throw std::runtime_error(std::string(where) + " failed (" + std::to_string(st) + "): " + ovs_last_error());
-}
-}   // namespace
 
 orb_extractor::orb_extractor(const orb_params& orb_params) : orb_params_(orb_params) {
     initialize();
@@ -72,7 +70,10 @@ void orb_extractor::ensure_handle(int rows, int cols) {
     p.ini_fast_thr = (int32_t)orb_params_.ini_fast_thr_;
     p.min_fast_thr = (int32_t)orb_params_.min_fast_thr;
     const int st = ovs_orb_create(&p, rows, cols, 1, device_, &h_);
-    if (st != OVS_OK) fail("ovs_orb_create", st);
+    if (st != OVS_OK) {
+        h_ = nullptr;
+        throw util::device_error(st, std::string("ovs_orb_create: ") + ovs_last_error());   // caught by run_guarded in extract()
+    }
     ovs_orb_set_host_pyramid(h_, download_pyramid_ ? 1 : 0);
     h_rows_ = rows;
     h_cols_ = cols;
@@ -103,16 +104,38 @@ void orb_extractor::extract(const cv::_InputArray& in_image, const cv::_InputArr
         create_rectangle_mask(image.cols, image.rows);
         mask = rect_mask_;
     }
-    ensure_handle(image.rows, image.cols);
-    const int cap = ovs_orb_max_keypoints(h_);
-    keypts.resize(cap);
-    desc_buf_.resize((size_t)cap * 32);
     int n = 0;
     // ONE call, ONE wait: upload (banded through pinned memory), pyramid -> FAST -> quad-tree -> describe, one D2H of the results and
-    // -- when image_pyramid_ is wanted on the host -- one D2H of the whole pyramid block into pinned memory the Mats below alias
-    const int st = ovs_orb_extract(h_, image.data, image.rows, image.cols, image.step, mask.empty() ? nullptr : mask.data,
-                                   mask.empty() ? 0 : mask.step, reinterpret_cast<ovs_keypoint*>(keypts.data()), desc_buf_.data(), cap, &n);
-    if (st != OVS_OK) fail("ovs_orb_extract", st);   // no silent CPU fallback
+    // -- when image_pyramid_ is wanted on the host -- one D2H of the whole pyramid block into pinned memory the Mats below alias.
+    // No silent CPU fallback; the failure policy of util/device_policy.h instead: one retry on a rebuilt handle, then
+    // a frame without keypoints (tracking then fails for this frame and relocalises, as it does for any featureless frame).
+    std::vector<std::pair<const uint8_t*, int>> pyr_base(orb_params_.num_levels_);
+    std::vector<int> pyr_rows(orb_params_.num_levels_), pyr_cols(orb_params_.num_levels_);
+    const bool ok = util::run_guarded(
+        "orb_extractor::extract",
+        [&] {
+            ensure_handle(image.rows, image.cols);
+            const int cap = ovs_orb_max_keypoints(h_);
+            keypts.resize(cap);
+            desc_buf_.resize((size_t)cap * 32);
+            int st = ovs_orb_extract(h_, image.data, image.rows, image.cols, image.step, mask.empty() ? nullptr : mask.data,
+                                     mask.empty() ? 0 : mask.step, reinterpret_cast<ovs_keypoint*>(keypts.data()), desc_buf_.data(), cap, &n);
+            for (unsigned int l = 1; st == OVS_OK && download_pyramid_ && l < orb_params_.num_levels_; ++l) {
+                int pitch = 0;
+                st = ovs_orb_host_pyramid_level(h_, (int)l, &pyr_base[l].first, &pyr_rows[l], &pyr_cols[l], &pitch);
+                pyr_base[l].second = pitch;
+            }
+            return st;
+        },
+        [&] { release(); });
+    if (!ok) {
+        release();
+        keypts.clear();
+        out_descriptors.create(0, 32, cv::CV_8U);
+        image_pyramid_[0] = image;
+        for (unsigned int l = 1; l < orb_params_.num_levels_; ++l) image_pyramid_[l] = cv::Mat();
+        return;
+    }
     keypts.resize(n);
     out_descriptors.create(n, 32, cv::CV_8U);
     if (n) {
@@ -127,11 +150,7 @@ void orb_extractor::extract(const cv::_InputArray& in_image, const cv::_InputArr
             image_pyramid_[l] = cv::Mat();
             continue;
         }
-        const uint8_t* base = nullptr;
-        int r = 0, c = 0, pitch = 0;
-        const int s2 = ovs_orb_host_pyramid_level(h_, (int)l, &base, &r, &c, &pitch);
-        if (s2 != OVS_OK) fail("ovs_orb_host_pyramid_level", s2);
-        image_pyramid_[l] = cv::Mat(r, c, cv::CV_8U, const_cast<uint8_t*>(base), (size_t)pitch);
+        image_pyramid_[l] = cv::Mat(pyr_rows[l], pyr_cols[l], cv::CV_8U, const_cast<uint8_t*>(pyr_base[l].first), (size_t)pyr_base[l].second);
     }
 }
 

@@ -20,13 +20,16 @@ unsigned int bow_tree::match_frame_and_keyframe(data::keyframe* keyfrm, data::fr
     flatten_bow(frm.bow_feat_vec_, fid, fst, fit);
     std::vector<int32_t> matched((size_t)n_frm, -1);
     int32_t num_matches = 0;
-    detail::check(ovs_bow_match_frame_and_keyframe(detail::window_ctx().get(n_frm, n_kf),
+    if (!detail::guarded("ovs_bow_match_frame_and_keyframe", [&] {
+            return ovs_bow_match_frame_and_keyframe(detail::window_ctx().get(n_frm, n_kf),
                                                    reinterpret_cast<const ovs_keypoint*>(keyfrm->keypts_.data()), keyfrm->descriptors_.data,
                                                    valid.data(), n_kf, kid.data(), kst.data(), kit.data(), (int)kid.size(),
                                                    reinterpret_cast<const ovs_keypoint*>(frm.keypts_.data()), frm.descriptors_.data, n_frm,
                                                    fid.data(), fst.data(), fit.data(), (int)fid.size(), lowe_ratio_, check_orientation_ ? 1 : 0,
-                                                   matched.data(), &num_matches),
-                  "ovs_bow_match_frame_and_keyframe");
+                                                   matched.data(), &num_matches);
+        }, {})) {
+        return 0;
+    }
     for (int j = 0; j < n_frm; ++j)
         if (matched[j] >= 0) matched_lms_in_frm[j] = keyfrm_lms[matched[j]];
     return (unsigned int)num_matches;
@@ -45,12 +48,15 @@ unsigned int bow_tree::match_keyframes(data::keyframe* keyfrm_1, data::keyframe*
     flatten_bow(keyfrm_2->bow_feat_vec_, id2, st2, it2);
     std::vector<int32_t> matched((size_t)n1, -1);
     int32_t num_matches = 0;
-    detail::check(ovs_bow_match_keyframes(detail::window_ctx().get(n2, n1), reinterpret_cast<const ovs_keypoint*>(keyfrm_1->keypts_.data()),
+    if (!detail::guarded("ovs_bow_match_keyframes", [&] {
+            return ovs_bow_match_keyframes(detail::window_ctx().get(n2, n1), reinterpret_cast<const ovs_keypoint*>(keyfrm_1->keypts_.data()),
                                           keyfrm_1->descriptors_.data, v1.data(), n1, id1.data(), st1.data(), it1.data(), (int)id1.size(),
                                           reinterpret_cast<const ovs_keypoint*>(keyfrm_2->keypts_.data()), keyfrm_2->descriptors_.data, v2.data(), n2,
                                           id2.data(), st2.data(), it2.data(), (int)id2.size(), lowe_ratio_, check_orientation_ ? 1 : 0,
-                                          matched.data(), &num_matches),
-                  "ovs_bow_match_keyframes");
+                                          matched.data(), &num_matches);
+        }, {})) {
+        return 0;
+    }
     for (int i = 0; i < n1; ++i)
         if (matched[i] >= 0) matched_lms_in_keyfrm_1[(size_t)i] = lms_2[(size_t)matched[i]];
     return (unsigned int)num_matches;

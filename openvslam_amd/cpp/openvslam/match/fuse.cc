@@ -48,12 +48,15 @@ unsigned int fuse::replace_duplication(data::keyframe* keyfrm, const T& landmark
     detail::pose12(keyfrm->get_cam_pose(), pose);
     std::vector<int32_t> best((size_t)m, -1);
     int32_t num = 0;
-    detail::check(ovs_fuse_replace_duplication(
+    if (!detail::guarded("ovs_fuse_replace_duplication", [&] {
+            return ovs_fuse_replace_duplication(
                       detail::window_ctx().get(n, m), &cam, &gp, reinterpret_cast<const ovs_keypoint*>(keyfrm->undist_keypts_.data()),
                       keyfrm->descriptors_.data, keyfrm->stereo_x_right_.empty() ? nullptr : keyfrm->stereo_x_right_.data(), n, pose, f.pos.data(),
                       f.dist.data(), f.normal.data(), f.desc.data(), f.valid.data(), m, keyfrm->scale_factors_.data(),
-                      keyfrm->inv_level_sigma_sq_.data(), (int)keyfrm->scale_factors_.size(), keyfrm->log_scale_factor_, margin, best.data(), &num),
-                  "ovs_fuse_replace_duplication");
+                      keyfrm->inv_level_sigma_sq_.data(), (int)keyfrm->scale_factors_.size(), keyfrm->log_scale_factor_, margin, best.data(), &num);
+        }, {})) {
+        return 0;
+    }
     // upstream's write-back, in the order of landmarks_to_check; an earlier replacement can erase or attach a later landmark
     unsigned int num_fused = 0;
     int l = 0;
@@ -96,12 +99,15 @@ unsigned int fuse::detect_duplication(data::keyframe* keyfrm, const Mat44_t& Sim
     detail::pose12(Sim3_cw, sim3);
     std::vector<int32_t> best((size_t)m, -1);
     int32_t num = 0;
-    detail::check(ovs_fuse_detect_duplication(detail::window_ctx().get(n, m), &cam, &gp,
+    if (!detail::guarded("ovs_fuse_detect_duplication", [&] {
+            return ovs_fuse_detect_duplication(detail::window_ctx().get(n, m), &cam, &gp,
                                               reinterpret_cast<const ovs_keypoint*>(keyfrm->undist_keypts_.data()), keyfrm->descriptors_.data, n,
                                               sim3, f.pos.data(), f.dist.data(), f.normal.data(), f.desc.data(), f.valid.data(), m,
                                               keyfrm->scale_factors_.data(), (int)keyfrm->scale_factors_.size(), keyfrm->log_scale_factor_,
-                                              margin, best.data(), &num),
-                  "ovs_fuse_detect_duplication");
+                                              margin, best.data(), &num);
+        }, {})) {
+        return 0;
+    }
     unsigned int num_fused = 0;
     for (int l = 0; l < m; ++l) {
         if (best[l] < 0) continue;

@@ -31,11 +31,14 @@ unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::
     std::vector<int32_t> assigned((size_t)m, -1);
     int32_t num_matches = 0;
     // the frame's keypoints, descriptors and grid are resident (uploaded by the first matcher call on this frame)
-    detail::check(ovs_projection_match_frame_and_landmarks_f(detail::window_ctx().get(n, m), detail::device_frame_of(frm), occupied.data(), lm_xy.data(),
+    if (!detail::guarded("ovs_projection_match_frame_and_landmarks_f", [&] {
+            return ovs_projection_match_frame_and_landmarks_f(detail::window_ctx().get(n, m), detail::device_frame_of(frm), occupied.data(), lm_xy.data(),
                                                              stereo ? lm_x_right.data() : nullptr, lm_level.data(), lm_desc.data(), lm_valid.data(), m,
                                                              frm.scale_factors_.data(), (int)frm.scale_factors_.size(), margin, lowe_ratio_,
-                                                             assigned.data(), &num_matches),
-                  "ovs_projection_match_frame_and_landmarks_f");
+                                                             assigned.data(), &num_matches);
+        }, {&frm})) {
+        return 0;
+    }
     for (int l = 0; l < m; ++l)
         if (assigned[l] >= 0) frm.landmarks_[assigned[l]] = local_landmarks[l];
     return (unsigned int)num_matches;
@@ -62,12 +65,15 @@ unsigned int projection::match_current_and_last_frames(data::frame& curr_frm, co
     detail::pose12(last_frm.cam_pose_cw_, pose_last);
     std::vector<int32_t> assigned((size_t)n_last, -1);
     int32_t num_matches = 0;
-    detail::check(ovs_projection_match_current_and_last_frames_f(
+    if (!detail::guarded("ovs_projection_match_current_and_last_frames_f", [&] {
+            return ovs_projection_match_current_and_last_frames_f(
                       detail::window_ctx().get(n_curr, n_last), &cam, detail::device_frame_of(curr_frm), occupied.data(), pose_curr,
                       reinterpret_cast<const ovs_keypoint*>(last_frm.undist_keypts_.data()), last_pos.data(), last_desc.data(), last_valid.data(),
                       n_last, pose_last, curr_frm.scale_factors_.data(), (int)curr_frm.scale_factors_.size(), margin, check_orientation_ ? 1 : 0,
-                      assigned.data(), &num_matches),
-                  "ovs_projection_match_current_and_last_frames_f");
+                      assigned.data(), &num_matches);
+        }, {&curr_frm})) {
+        return 0;
+    }
     for (int i = 0; i < n_last; ++i)
         if (assigned[i] >= 0) curr_frm.landmarks_[assigned[i]] = last_frm.landmarks_[i];
     return (unsigned int)num_matches;
@@ -115,13 +121,16 @@ unsigned int projection::match_frame_and_keyframe(data::frame& curr_frm, data::k
     detail::pose12(curr_frm.cam_pose_cw_, pose);
     std::vector<int32_t> assigned((size_t)n_kf, -1);
     int32_t num_matches = 0;
-    detail::check(ovs_projection_match_frame_and_keyframe(
+    if (!detail::guarded("ovs_projection_match_frame_and_keyframe", [&] {
+            return ovs_projection_match_frame_and_keyframe(
                       detail::window_ctx().get(n_curr, n_kf), &cam, &gp, reinterpret_cast<const ovs_keypoint*>(curr_frm.undist_keypts_.data()),
                       curr_frm.descriptors_.data, occupied.data(), n_curr, pose, reinterpret_cast<const ovs_keypoint*>(keyfrm->undist_keypts_.data()),
                       f.pos.data(), f.dist.data(), f.desc.data(), f.valid.data(), n_kf, curr_frm.scale_factors_.data(),
                       (int)curr_frm.scale_factors_.size(), curr_frm.log_scale_factor_, margin, hamm_dist_thr, check_orientation_ ? 1 : 0,
-                      assigned.data(), &num_matches),
-                  "ovs_projection_match_frame_and_keyframe");
+                      assigned.data(), &num_matches);
+        }, {})) {
+        return 0;
+    }
     for (int i = 0; i < n_kf; ++i)
         if (assigned[i] >= 0) curr_frm.landmarks_[assigned[i]] = lms[i];
     return (unsigned int)num_matches;
@@ -142,12 +151,15 @@ unsigned int projection::match_by_Sim3_transform(data::keyframe* keyfrm, const M
     detail::pose12(Sim3_cw, sim3);
     std::vector<int32_t> assigned((size_t)m, -1);
     int32_t num_matches = 0;
-    detail::check(ovs_projection_match_by_sim3_transform(
+    if (!detail::guarded("ovs_projection_match_by_sim3_transform", [&] {
+            return ovs_projection_match_by_sim3_transform(
                       detail::window_ctx().get(n, m), &cam, &gp, reinterpret_cast<const ovs_keypoint*>(keyfrm->undist_keypts_.data()),
                       keyfrm->descriptors_.data, occupied.data(), n, sim3, f.pos.data(), f.dist.data(), f.normal.data(), f.desc.data(), f.valid.data(),
                       m, keyfrm->scale_factors_.data(), (int)keyfrm->scale_factors_.size(), keyfrm->log_scale_factor_, margin, assigned.data(),
-                      &num_matches),
-                  "ovs_projection_match_by_sim3_transform");
+                      &num_matches);
+        }, {})) {
+        return 0;
+    }
     for (int l = 0; l < m; ++l)
         if (assigned[l] >= 0) matched_lms_in_keyfrm[(size_t)assigned[l]] = landmarks[l];
     return (unsigned int)num_matches;
@@ -181,13 +193,16 @@ unsigned int projection::match_keyframes_mutually(data::keyframe* keyfrm_1, data
     std::vector<int32_t> m21((size_t)n1, -1);
     int32_t num_matches = 0;
     const int nmax = n1 > n2 ? n1 : n2;
-    detail::check(ovs_projection_match_keyframes_mutually(
+    if (!detail::guarded("ovs_projection_match_keyframes_mutually", [&] {
+            return ovs_projection_match_keyframes_mutually(
                       detail::window_ctx().get(nmax, nmax), &cam_1, &gp_1, reinterpret_cast<const ovs_keypoint*>(keyfrm_1->undist_keypts_.data()),
                       keyfrm_1->descriptors_.data, n1, pose_1, f1.pos.data(), f1.dist.data(), f1.desc.data(), f1.valid.data(), &cam_2, &gp_2,
                       reinterpret_cast<const ovs_keypoint*>(keyfrm_2->undist_keypts_.data()), keyfrm_2->descriptors_.data, n2, pose_2, f2.pos.data(),
                       f2.dist.data(), f2.desc.data(), f2.valid.data(), (double)s_12, R, t, keyfrm_1->scale_factors_.data(),
-                      (int)keyfrm_1->scale_factors_.size(), keyfrm_1->log_scale_factor_, margin, m21.data(), &num_matches),
-                  "ovs_projection_match_keyframes_mutually");
+                      (int)keyfrm_1->scale_factors_.size(), keyfrm_1->log_scale_factor_, margin, m21.data(), &num_matches);
+        }, {})) {
+        return 0;
+    }
     for (int i = 0; i < n1; ++i)
         if (m21[i] >= 0) matched_lms_in_keyfrm_1[(size_t)i] = lms_2[(size_t)m21[i]];
     return (unsigned int)num_matches;

@@ -30,8 +30,17 @@ struct matcher_holder {
         cap1 = n1 < 4096 ? 4096 : n1;
         cap2 = n2 < 4096 ? 4096 : n2;
         const int st = ovs_matcher_create(cap1, cap2, 1, 0, &m);
-        if (st != OVS_OK) throw std::runtime_error(std::string("ovs_matcher_create failed: ") + ovs_last_error());
+        if (st != OVS_OK) {
+            m = nullptr;
+            cap1 = cap2 = 0;
+            throw util::device_error(st, std::string("ovs_matcher_create: ") + ovs_last_error());   // caught by run_guarded
+        }
         return m;
+    }
+    void reset() {
+        if (m) ovs_matcher_destroy(m);
+        m = nullptr;
+        cap1 = cap2 = 0;
     }
 };
 thread_local matcher_holder g_matcher;
@@ -50,11 +59,18 @@ unsigned int robust::brute_force_match(data::frame& frm, data::keyframe* keyfrm,
     }
     std::vector<int32_t> pairs((size_t)2 * num_keypts_2);
     int n = 0;
-    const int st = ovs_robust_brute_force_match(g_matcher.get(num_keypts_1, num_keypts_2), frm.descriptors_.data, (int)num_keypts_1,
-                                                /*valid_1: upstream's inner loop skips only already matched idx_1*/ nullptr, keyfrm->descriptors_.data, (int)num_keypts_2, valid.data(), lowe_ratio_, pairs.data(),
-                                                (int)num_keypts_2, &n);
-    if (st != OVS_OK) throw std::runtime_error(std::string("ovs_robust_brute_force_match failed: ") + ovs_last_error());
     matches.clear();
+    // failure policy (util/device_policy.h): one retry on a fresh matcher context, then zero matches
+    if (!util::run_guarded(
+            "ovs_robust_brute_force_match",
+            [&] {
+                return ovs_robust_brute_force_match(g_matcher.get(num_keypts_1, num_keypts_2), frm.descriptors_.data, (int)num_keypts_1,
+                                                    /*valid_1: upstream's inner loop skips only already matched idx_1*/ nullptr,
+                                                    keyfrm->descriptors_.data, (int)num_keypts_2, valid.data(), lowe_ratio_, pairs.data(),
+                                                    (int)num_keypts_2, &n);
+            },
+            [] { g_matcher.reset(); }))
+        return 0;
     matches.reserve((size_t)n);
     for (int i = 0; i < n; ++i) matches.emplace_back(std::make_pair(pairs[2 * i], pairs[2 * i + 1]));
     unsigned int num_matches = (unsigned int)n;
@@ -136,15 +152,18 @@ unsigned int robust::match_for_triangulation(data::keyframe* keyfrm_1, data::key
         for (int j = 0; j < 3; ++j) E[3 * i + j] = E_12(i, j);
     std::vector<int32_t> matched((size_t)n1, -1);
     int32_t num_matches = 0;
-    detail::check(ovs_robust_match_for_triangulation(
+    if (!detail::guarded("ovs_robust_match_for_triangulation", [&] {
+            return ovs_robust_match_for_triangulation(
                       detail::window_ctx().get(n2, n1), reinterpret_cast<const ovs_keypoint*>(keyfrm_1->undist_keypts_.data()),
                       keyfrm_1->descriptors_.data, has_1.data(), keyfrm_1->stereo_x_right_.empty() ? nullptr : keyfrm_1->stereo_x_right_.data(),
                       b1.data(), n1, id1.data(), st1.data(), it1.data(), (int)id1.size(),
                       reinterpret_cast<const ovs_keypoint*>(keyfrm_2->undist_keypts_.data()), keyfrm_2->descriptors_.data, has_2.data(),
                       keyfrm_2->stereo_x_right_.empty() ? nullptr : keyfrm_2->stereo_x_right_.data(), b2.data(), n2, id2.data(), st2.data(),
                       it2.data(), (int)id2.size(), E, epipole, keyfrm_1->scale_factors_.data(), (int)keyfrm_1->scale_factors_.size(),
-                      check_orientation_ ? 1 : 0, matched.data(), &num_matches),
-                  "ovs_robust_match_for_triangulation");
+                      check_orientation_ ? 1 : 0, matched.data(), &num_matches);
+        }, {})) {
+        return 0;
+    }
     matched_idx_pairs.reserve((size_t)num_matches);
     for (int i = 0; i < n1; ++i)
         if (matched[i] >= 0) matched_idx_pairs.emplace_back((unsigned)i, (unsigned)matched[i]);

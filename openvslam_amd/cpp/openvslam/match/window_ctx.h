@@ -3,12 +3,14 @@
 #pragma once
 #include <ovslam_hip.h>
 
+#include <initializer_list>
 #include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../data/frame_stub.h"
+#include "../util/device_policy.h"
 
 namespace openvslam {
 namespace match {
@@ -27,8 +29,17 @@ struct window_holder {
         cap_t = n_t < 8192 ? 8192 : n_t;
         cap_q = n_q < 16384 ? 16384 : n_q;
         const int st = ovs_wmatcher_create(cap_t, cap_q, 1 << 22, 0, &w);
-        if (st != OVS_OK) throw std::runtime_error(std::string("ovs_wmatcher_create failed: ") + ovs_last_error());
+        if (st != OVS_OK) {
+            w = nullptr;
+            cap_t = cap_q = 0;
+            throw util::device_error(st, std::string("ovs_wmatcher_create: ") + ovs_last_error());   // caught by guarded()
+        }
         return w;
+    }
+    void reset() {
+        if (w) ovs_wmatcher_destroy(w);
+        w = nullptr;
+        cap_t = cap_q = 0;
     }
 };
 inline window_holder& window_ctx() {
@@ -74,7 +85,7 @@ inline const ovs_frame_dev* device_frame_of(const data::frame& frm) {
     const bool stereo = !frm.stereo_x_right_.empty();
     const int st = ovs_frame_dev_create(0, &gp, reinterpret_cast<const ovs_keypoint*>(frm.undist_keypts_.data()), frm.descriptors_.data,
                                         stereo ? frm.stereo_x_right_.data() : nullptr, (int32_t)frm.undist_keypts_.size(), &f);
-    if (st != OVS_OK) throw std::runtime_error(std::string("ovs_frame_dev_create failed: ") + ovs_last_error());
+    if (st != OVS_OK) throw util::device_error(st, std::string("ovs_frame_dev_create: ") + ovs_last_error());   // caught by guarded()
     auto c = std::make_shared<data::frame_device_cache>();
     c->handle = f;
     c->destroy = [](void* h) { ovs_frame_dev_destroy(static_cast<ovs_frame_dev*>(h)); };
@@ -101,8 +112,16 @@ inline void flatten_bow(const data::bow_feature_vector& fv, std::vector<int32_t>
     }
 }
 
-inline void check(int st, const char* what) {
-    if (st != OVS_OK) throw std::runtime_error(std::string(what) + " failed: " + ovs_last_error());
+// One ABI call of a windowed matcher under the failure policy of util/device_policy.h: `call` re-evaluates window_ctx().get(...) and
+// device_frame_of(...) each time it runs; before the retry the thread's matcher context and the device caches of the frames the call
+// uses are dropped. false -> the caller returns zero matches (its outputs may be partly written: it must not read them).
+template <class Call>
+inline bool guarded(const char* what, Call&& call, std::initializer_list<const data::frame*> frames = {}) {
+    return util::run_guarded(what, call, [&] {
+        window_ctx().reset();
+        for (const data::frame* f : frames)
+            if (f) f->device_cache_.reset();
+    });
 }
 
 static_assert(sizeof(cv::KeyPoint) == sizeof(ovs_keypoint), "cv::KeyPoint crosses the ABI as ovs_keypoint");

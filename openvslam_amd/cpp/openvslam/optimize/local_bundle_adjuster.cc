@@ -5,6 +5,8 @@
 
 #include <ovslam_hip.h>
 
+#include "../util/device_policy.h"
+
 #include <cmath>
 #include <stdexcept>
 #include <string>
@@ -190,18 +192,29 @@ void local_bundle_adjuster::optimize(data::keyframe* curr_keyfrm, bool* const fo
     const ovs_ba_cam cam = {camera->fx_, camera->fy_, camera->cx_, camera->cy_};
     std::vector<uint8_t> mono_outlier(mono.size() + 1), stereo_outlier(stereo.size() + 1);
     static_assert(sizeof(bool) == 1, "force_stop_flag is polled as a byte");
-    const int st =
-        camera->model_type_ == camera::model_type_t::Equirectangular
-            ? ovs_local_ba_optimize_equirect(0, poses.data(), pose_fixed.data(), (int32_t)keyfrms.size(), points.data(), (int32_t)lms.size(),
-                                             mono.empty() ? nullptr : mono.data(), (int32_t)mono.size(), (int32_t)camera->cols_, (int32_t)camera->rows_,
-                                             (int32_t)num_first_iter_, (int32_t)num_second_iter_,
-                                             reinterpret_cast<const volatile uint8_t*>(force_stop_flag), mono_outlier.data(), nullptr)
-            : ovs_local_ba_optimize(0, poses.data(), pose_fixed.data(), (int32_t)keyfrms.size(), points.data(), (int32_t)lms.size(),
-                                    mono.empty() ? nullptr : mono.data(), (int32_t)mono.size(), stereo.empty() ? nullptr : stereo.data(),
-                                    (int32_t)stereo.size(), &cam, camera->focal_x_baseline_, (int32_t)camera->setup_type_, (int32_t)num_first_iter_,
-                                    (int32_t)num_second_iter_, reinterpret_cast<const volatile uint8_t*>(force_stop_flag), mono_outlier.data(),
-                                    stereo_outlier.data(), nullptr);
-    if (st != OVS_OK) throw std::runtime_error(std::string("ovs_local_ba_optimize failed: ") + ovs_last_error());
+    // failure policy (util/device_policy.h): one retry from the same start state, then the local map is left exactly as it was -- for the
+    // mapping module that is a local BA that was aborted before its first iteration
+    const std::vector<double> poses_in = poses, points_in = points;
+    if (!util::run_guarded(
+            "ovs_local_ba_optimize",
+            [&] {
+                poses = poses_in;     // in / out arguments
+                points = points_in;
+                return camera->model_type_ == camera::model_type_t::Equirectangular
+                           ? ovs_local_ba_optimize_equirect(0, poses.data(), pose_fixed.data(), (int32_t)keyfrms.size(), points.data(),
+                                                            (int32_t)lms.size(), mono.empty() ? nullptr : mono.data(), (int32_t)mono.size(),
+                                                            (int32_t)camera->cols_, (int32_t)camera->rows_, (int32_t)num_first_iter_,
+                                                            (int32_t)num_second_iter_, reinterpret_cast<const volatile uint8_t*>(force_stop_flag),
+                                                            mono_outlier.data(), nullptr)
+                           : ovs_local_ba_optimize(0, poses.data(), pose_fixed.data(), (int32_t)keyfrms.size(), points.data(), (int32_t)lms.size(),
+                                                   mono.empty() ? nullptr : mono.data(), (int32_t)mono.size(),
+                                                   stereo.empty() ? nullptr : stereo.data(), (int32_t)stereo.size(), &cam,
+                                                   camera->focal_x_baseline_, (int32_t)camera->setup_type_, (int32_t)num_first_iter_,
+                                                   (int32_t)num_second_iter_, reinterpret_cast<const volatile uint8_t*>(force_stop_flag),
+                                                   mono_outlier.data(), stereo_outlier.data(), nullptr);
+            },
+            [] {}))
+        return;
 
     // 7. count the outlier observations
     std::vector<std::pair<data::keyframe*, data::landmark*>> outlier_observations;

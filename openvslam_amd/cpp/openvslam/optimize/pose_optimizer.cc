@@ -3,6 +3,8 @@
 
 #include <ovslam_hip.h>
 
+#include "../util/device_policy.h"
+
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -51,11 +53,18 @@ unsigned int pose_optimizer::optimize(data::frame& frm) const {
     const ovs_ba_cam cam = {frm.camera_->fx_, frm.camera_->fy_, frm.camera_->cx_, frm.camera_->cy_};
     std::vector<uint8_t> outlier(obs.size());
     int32_t num_valid = 0;
-    const int st = equirect ? ovs_pose_optimize_equirect(0, pose_in, obs.data(), (int32_t)obs.size(), (int32_t)frm.camera_->cols_,
-                                                         (int32_t)frm.camera_->rows_, pose_out, outlier.data(), &num_valid)
-                            : ovs_pose_optimize(0, pose_in, obs.data(), (int32_t)obs.size(), &cam, frm.camera_->focal_x_baseline_,
-                                                (int32_t)frm.camera_->setup_type_, pose_out, outlier.data(), &num_valid);
-    if (st != OVS_OK) throw std::runtime_error(std::string("ovs_pose_optimize failed: ") + ovs_last_error());
+    // failure policy (util/device_policy.h): one retry, then "no inliers" with the pose and the outlier flags left as they were -- tracking
+    // treats that as a failed track of this frame
+    if (!util::run_guarded(
+            "ovs_pose_optimize",
+            [&] {
+                return equirect ? ovs_pose_optimize_equirect(0, pose_in, obs.data(), (int32_t)obs.size(), (int32_t)frm.camera_->cols_,
+                                                             (int32_t)frm.camera_->rows_, pose_out, outlier.data(), &num_valid)
+                                : ovs_pose_optimize(0, pose_in, obs.data(), (int32_t)obs.size(), &cam, frm.camera_->focal_x_baseline_,
+                                                    (int32_t)frm.camera_->setup_type_, pose_out, outlier.data(), &num_valid);
+            },
+            [] {}))
+        return 0;
     for (size_t k = 0; k < obs.size(); ++k) frm.outlier_flags_[idx_of[k]] = outlier[k] != 0;
     Mat44_t T;
     for (int i = 0; i < 3; ++i) {

@@ -18,6 +18,7 @@ void set_last_error(const char* what, hipError_t e) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
 }
 void set_last_error_text(const std::string& what) { g_last_error = what; }
+std::atomic<int32_t> g_injected_hip_failures{0}, g_injected_hip_skip{0};
 
 static inline int cv_round_f(float v) { return (int)std::nearbyintf(v); }
 
@@ -667,6 +668,13 @@ ovs_status ovs_orb_set_variant(ovs_orb* h, int32_t which, int32_t value) {
         h->last_host_count = -1;
         h->set_out_layout();             // ovs_orb_max_keypoints changes with TREE_SWITCH_FACTOR
     }
+    return OVS_OK;
+}
+
+ovs_status ovs_debug_inject_hip_failures(int32_t skip_calls, int32_t n_calls) {
+    ovs::g_injected_hip_failures.store(0, std::memory_order_relaxed);
+    ovs::g_injected_hip_skip.store(skip_calls > 0 ? skip_calls : 0, std::memory_order_relaxed);
+    ovs::g_injected_hip_failures.store(n_calls > 0 ? n_calls : 0, std::memory_order_relaxed);
     return OVS_OK;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <string>
 #include <stdint.h>
 
@@ -111,6 +112,16 @@ hipError_t launch_describe(const FrameGeo& hgeo, const DevBuffers& d, const uint
                            ovs_keypoint* kps, uint8_t* desc, int32_t* counts, int cap, int batch, hipStream_t s);
 
 void set_last_error(const char* what, hipError_t e);
+// ovs_debug_inject_hip_failures(skip, n): after `skip` further OVS_HIP_TRY-checked calls, the next n of them (the calls themselves
+// still run) report hipErrorLaunchFailure. One relaxed atomic load per checked HIP call when nothing is armed.
+extern std::atomic<int32_t> g_injected_hip_failures, g_injected_hip_skip;
+inline hipError_t fault_filter(hipError_t e) {
+    if (g_injected_hip_failures.load(std::memory_order_relaxed) > 0) {
+        if (g_injected_hip_skip.load(std::memory_order_relaxed) > 0 && g_injected_hip_skip.fetch_sub(1, std::memory_order_relaxed) > 0) return e;
+        if (g_injected_hip_failures.fetch_sub(1, std::memory_order_relaxed) > 0) return hipErrorLaunchFailure;
+    }
+    return e;
+}
 void set_last_error_text(const std::string& what);   // failures that are not HIP errors (a refused file, an exception stopped at the ABI)
 
 // Device view of one frame's image pyramid (feature::orb_extractor::image_pyramid_) of an extractor's LAST extract.
@@ -208,7 +219,7 @@ struct StageProfiler {
 
 #define OVS_HIP_TRY(expr)                                  \
     do {                                                   \
-        hipError_t _e = (expr);                            \
+        hipError_t _e = ovs::fault_filter(expr);           \
         if (_e != hipSuccess) {                            \
             ovs::set_last_error(#expr, _e);                \
             return OVS_ERR_HIP;                            \
