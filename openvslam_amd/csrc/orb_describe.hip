@@ -13,6 +13,8 @@
 //     frame, upstream's cv::GaussianBlur of every level),
 //   * lane l evaluates tests l, l+64, l+128, l+192; each ballot is 8 descriptor bytes (bit i of byte j = test 8j+i).
 // Keypoints are written level-major at their final position: frame offset = sum of lower levels' counts.
+#include <cstdlib>
+
 #include "ovs_common.h"
 
 namespace ovs {
@@ -116,20 +118,38 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
                                                 size_t frame_stride0, const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                                 const uint64_t* __restrict__ lvl_kps, const uint32_t* __restrict__ lvl_count,
                                                 ovs_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                int32_t* __restrict__ counts, int cap) {
+                                                int32_t* __restrict__ counts, int cap, int batch, int xcd_map) {
     __shared__ __attribute__((aligned(16))) uint8_t patch[kPatch * kPatchPitch];
     __shared__ __attribute__((aligned(16))) uint16_t hblur[kPatch * kHbPitch];
 
     const int lane = threadIdx.x;
-    const int frame = blockIdx.y;
+    // Workgroup -> (frame, keypoint slot). Workgroups are handed to the eight XCDs round-robin in launch order, and each XCD has its own
+    // 4 MB L2: with the plain (slot, frame) order the patches of one frame -- which overlap heavily: 2000 x 43 rows x one or two 128-byte
+    // lines = 14 MB of line fetches over a 6.8 MB pyramid -- are spread over all eight L2s and every line comes in from the fabric again
+    // (13.8 MB per 1080p frame measured). Mapped so that XCD x walks the slots of frame 8 g + x in order, a level's plane (<= 2 MB)
+    // stays in that XCD's L2 while its keypoints are described: 5.7 MB per frame, 2.4x less (profiles/r03_describe_pmc.txt).
+    // The kernel's TIME does not move with it: it is bound by the vector ALU (637 VALU instructions per keypoint-wave x 4 cycles x 253
+    // waves per SIMD = the 0.33 ms per 128 frames), see DESIGN.md section 3.4 for what was tried against that.
+    int frame, kslot;
+    const int total_cap = geo->total_kp_cap;
+    if (xcd_map) {
+        const uint32_t w = blockIdx.x, x = w & 7u, j = w >> 3;
+        const uint32_t grp = j / (uint32_t)total_cap;
+        kslot = (int)(j - grp * (uint32_t)total_cap);
+        frame = (int)(grp * 8u + x);
+        if (frame >= batch) return;
+    } else {
+        frame = blockIdx.x / (uint32_t)total_cap;
+        kslot = blockIdx.x - frame * total_cap;
+    }
     const int L = geo->num_levels;
     int level = 0;
     for (int l = 1; l < L; ++l)
-        if ((int)blockIdx.x >= geo->lv[l].kp_base) level = l;
+        if (kslot >= geo->lv[l].kp_base) level = l;
     const LevelGeo& g = geo->lv[level];
-    const int slot = blockIdx.x - g.kp_base;
+    const int slot = kslot - g.kp_base;
     const uint32_t* cnt = lvl_count + frame * L;
-    if (blockIdx.x == 0 && lane == 0) {
+    if (kslot == 0 && lane == 0) {
         int total = 0;
         for (int l = 0; l < L; ++l) total += cnt[l];
         counts[frame] = total < cap ? total : cap;
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
     for (int l = 0; l < level; ++l) out_idx += cnt[l];
     if (out_idx >= cap) return;
 
-    const uint64_t kp = lvl_kps[(size_t)frame * geo->total_kp_cap + g.kp_base + slot];
+    const uint64_t kp = lvl_kps[(size_t)frame * total_cap + kslot];
     const int x = (int)cand_x(kp), y = (int)cand_y(kp);
     const uint8_t* img;
     int pitch;
@@ -214,21 +234,25 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
     const bool taps_indep = (geo->variant & 4) != 0;
     const uint32_t g0123 = taps_indep ? kG0123Indep : kG0123, g456 = taps_indep ? kG456Indep : kG456;
     uint32_t* hb32 = reinterpret_cast<uint32_t*>(hblur);
+    // output j of a lane-step is the tap string slid j bytes along the twelve pixels n0 n1 n2: sliding the TAPS (wave-uniform words, built
+    // once) instead of the pixels needs 2 + 2 + 3 + 3 dot products and no per-output byte alignment (was 8 dot products + 6 alignments)
+    const unsigned long long taps = (unsigned long long)g0123 | ((unsigned long long)g456 << 32);   // g0 .. g6 in bytes 0 .. 6
+    const uint32_t t1a = (uint32_t)(taps << 8), t1b = (uint32_t)(taps >> 24);
+    const uint32_t t2a = (uint32_t)(taps << 16), t2b = (uint32_t)(taps >> 16), t2c = (uint32_t)(taps >> 48);
+    const uint32_t t3a = (uint32_t)(taps << 24), t3b = (uint32_t)(taps >> 8), t3c = (uint32_t)(taps >> 40);
     for (int i = lane; i < kPatch * 10; i += 64) {
         const int r = i / 10, q = i - r * 10;
         const uint32_t* pw = reinterpret_cast<const uint32_t*>(patch + r * kPatchPitch + ((off + 4 * q) & ~3));
         const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3];
         const uint32_t n0 = __builtin_amdgcn_alignbyte(w1, w0, sh), n1 = __builtin_amdgcn_alignbyte(w2, w1, sh),
                        n2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
-        uint32_t o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t a = j ? __builtin_amdgcn_alignbyte(n1, n0, j) : n0;
-            const uint32_t b = j ? __builtin_amdgcn_alignbyte(n2, n1, j) : n1;
-            o[j] = __builtin_amdgcn_udot4(a, g0123, __builtin_amdgcn_udot4(b, g456, 0u, false), false);   // <= 255 * 257 = 65535
-        }
-        hb32[r * (kHbPitch / 2) + 2 * q] = o[0] | (o[1] << 16);
-        hb32[r * (kHbPitch / 2) + 2 * q + 1] = o[2] | (o[3] << 16);
+        // every sum <= 255 * 257 = 65535
+        const uint32_t o0 = __builtin_amdgcn_udot4(n0, g0123, __builtin_amdgcn_udot4(n1, g456, 0u, false), false);
+        const uint32_t o1 = __builtin_amdgcn_udot4(n0, t1a, __builtin_amdgcn_udot4(n1, t1b, 0u, false), false);
+        const uint32_t o2 = __builtin_amdgcn_udot4(n0, t2a, __builtin_amdgcn_udot4(n1, t2b, __builtin_amdgcn_udot4(n2, t2c, 0u, false), false), false);
+        const uint32_t o3 = __builtin_amdgcn_udot4(n0, t3a, __builtin_amdgcn_udot4(n1, t3b, __builtin_amdgcn_udot4(n2, t3c, 0u, false), false), false);
+        hb32[r * (kHbPitch / 2) + 2 * q] = o0 | (o1 << 16);
+        hb32[r * (kHbPitch / 2) + 2 * q + 1] = o2 | (o3 << 16);
     }
     __syncthreads();
 
@@ -238,10 +262,10 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
         const int dy = __float2int_rn(__fadd_rn(__fmul_rn(fx, sin_a), __fmul_rn(fy, cos_a)));
         const int dx = __float2int_rn(__fsub_rn(__fmul_rn(fx, cos_a), __fmul_rn(fy, sin_a)));
         const uint16_t* hp = hblur + (dy + kBlurR) * kHbPitch + dx + kBlurR;
-        uint32_t acc = 0;
+        uint32_t acc = 32768u;   // round half up
 #pragma unroll
         for (int k = 0; k < 7; ++k) acc += ((g0123 >> (8 * (k < 4 ? k : 6 - k))) & 255u) * hp[k * kHbPitch];   // symmetric taps: g[k] = g[6 - k]
-        return (int)min((acc + 32768u) >> 16, 255u);   // (only the 257-sum variant can exceed 255)
+        return (int)min(acc >> 16, 255u);   // (only the 257-sum variant can exceed 255)
     };
     unsigned long long bits[4];
     const uint32_t* pat = reinterpret_cast<const uint32_t*>(c_pattern);
@@ -271,9 +295,12 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
 
 hipError_t launch_describe(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
                            ovs_keypoint* kps, uint8_t* desc, int32_t* counts, int cap, int batch, hipStream_t s) {
-    dim3 grid(hgeo.total_kp_cap, batch);
+    const char* e = std::getenv("OVS_DESCRIBE_XCD");   // 0: plain frame-major order (A/B of the XCD mapping; read per launch)
+    const int xcd_map = e ? std::atoi(e) : 1;
+    const int frames = xcd_map ? ((batch + 7) & ~7) : batch;   // frame 8 g + x on XCD x: pad the last group
+    dim3 grid((unsigned)hgeo.total_kp_cap * (unsigned)frames);
     hipLaunchKernelGGL(k_describe, grid, dim3(64), 0, s, d.geo, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.lvl_kps,
-                       d.lvl_count, kps, desc, counts, cap);
+                       d.lvl_count, kps, desc, counts, cap, batch, xcd_map);
     return hipGetLastError();
 }
 
