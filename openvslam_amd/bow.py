@@ -1,7 +1,9 @@
 """data::bow_vocabulary (DBoW2 ORB vocabulary) on the MI355X: the per-descriptor tree descent of `transform`.
 
-The vocabulary is a plain tree description (see `synth.synth_vocabulary` for the layout); loading upstream's `orb_vocab.dbow2` /
-`.fbow` binary files is not implemented -- their formats are not recalled with confidence and no file is in the container."""
+The vocabulary is a plain tree description (see `synth.synth_vocabulary` for the layout) or one of upstream's vocabulary files: DBoW2 text,
+the DBoW2 fork's binary `orb_vocab.dbow2` and FBoW `orb_vocab.fbow` are parsed by `load_vocabulary_tree` / `load_vocabulary`
+(`csrc/bow_vocab_io.hip`; layouts restated from the formats' published descriptions, oracle/ORACLE_SPEC.md rule 30 -- no real vocabulary file is
+in the container, tests write synthetic ones with `tools/vocab_io.py`)."""
 import ctypes as C
 
 import numpy as np

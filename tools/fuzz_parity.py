@@ -69,6 +69,14 @@ def fuzz_extract(rng, n_cases, log, max_rows=1300, max_cols=2000):
             log("extract: create rejected (%s) for nfeat=%d sf=%.2f L=%d" % (e, nfeat, sf, L))
             continue
         ox = ob.OrbExtractor(ob.make_params(nfeat, sf, L, ini, mn), threads=8)
+        # ORACLE_SPEC rules 6 / 7 / 10 as run-time variants: a third of the handles run a random non-default combination on BOTH sides
+        variant = (3, 0, 0)
+        if rng.random() < 0.35:
+            variant = (int(rng.choice([3, 1])), int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+            for e in (ex, ox):
+                e.set_variant("tree_switch_factor", variant[0])
+                e.set_variant("tree_tie_order", variant[1])
+                e.set_variant("blur_taps", variant[2])
         for _ in range(3):   # the same handle across sizes: geometry rebuild
             rows = int(rng.integers(lo, max_rows + 1))
             cols = int(rng.integers(lo, max_cols + 1))
@@ -103,8 +111,9 @@ def fuzz_extract(rng, n_cases, log, max_rows=1300, max_cols=2000):
                 np.array_equal(gk[f].view(np.uint32) if gk[f].dtype == np.float32 else gk[f],
                                wk[f].view(np.uint32) if wk[f].dtype == np.float32 else wk[f])
                 for f in ("x", "y", "size", "angle", "response", "octave", "class_id"))
-            log("extract %4dx%-4d L=%d sf=%.2f N=%-4d thr=%d/%d kind=%d mask=%d -> %4d kp %s (%.1fs)" % (
-                cols, rows, L, sf, nfeat, ini, mn, kind, mask is not None, len(wk), "ok" if ok else "MISMATCH", time.time() - t))
+            log("extract %4dx%-4d L=%d sf=%.2f N=%-4d thr=%d/%d kind=%d mask=%d variant=%d%d%d -> %4d kp %s (%.1fs)" % (
+                cols, rows, L, sf, nfeat, ini, mn, kind, mask is not None, variant[0], variant[1], variant[2], len(wk),
+                "ok" if ok else "MISMATCH", time.time() - t))
             if not ok:
                 log("  counts hip %d oracle %d; per level hip %s oracle %s" % (len(gk), len(wk), list(ex.debug_level_counts()),
                                                                                [ox.level_num_keypts(l) for l in range(L)]))
@@ -293,6 +302,18 @@ def fuzz_optimize(rng, n_cases, log):
         log("pose_optimize n=%-4d -> %4d inliers, max |dT| %.1e, %d flag flips %s" % (n, wnv, float(np.abs(T - wT).max()), len(diff), "ok" if ok else "MISMATCH"))
         if not ok:
             return False
+        if case % 2 == 0:   # equirectangular_pose_opt_edge: bearings all around, some on the seam / near the poles
+            ne = int(rng.choice([8, 80, 600, 3000]))
+            T0e, obse, cols, rows, _ = synth.synth_pose_frame_equirect(ob.POSE_OBS_DTYPE, ne, int(rng.integers(0, 1 << 30)), outlier_frac=float(rng.uniform(0, 0.25)),
+                                                                       pose_err=float(rng.uniform(0.2, 2.0)), seam_frac=float(rng.choice([0.0, 0.1])),
+                                                                       pole_frac=float(rng.choice([0.0, 0.05])))
+            Te, oute, nve = ba.pose_optimize_equirect(T0e, obse, cols, rows)
+            wTe, woute, wnve = ob.pose_optimize_equirect(T0e, obse, cols, rows)
+            flips = int((oute != woute).sum())
+            ok = np.allclose(Te, wTe, rtol=0, atol=1e-7) and flips <= max(1, ne // 500) and abs(nve - wnve) <= flips
+            log("pose_optimize_equirect n=%-4d -> %4d inliers, max |dT| %.1e, %d flag flips %s" % (ne, wnve, float(np.abs(Te - wTe).max()), flips, "ok" if ok else "MISMATCH"))
+            if not ok:
+                return False
         if case % 3 == 0:
             n_pose, n_pt = int(rng.integers(3, 14)), int(rng.integers(200, 2500))
             d, mono, st, bf2, _, _ = _lba_scene(int(rng.integers(0, 1000)), n_pose=n_pose, n_pt=n_pt, obs_per_pose=int(rng.integers(80, min(n_pt, 700))),
