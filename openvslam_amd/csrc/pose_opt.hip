@@ -14,6 +14,8 @@
 #include <cmath>
 #include <cstring>
 
+#include <cstdlib>
+
 #include "ovs_common.h"
 
 namespace ovs {
@@ -36,15 +38,19 @@ __device__ void se3_exp_d(const double* u, PoseD& out) {
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) O2[3 * i + j] = (O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j]) + O[3 * i + 2] * O[6 + j];
     double V[9];
+    const bool small = theta < 0.00001;
+    // the three coefficients once (the expressions of upstream's Sophus-style exp, evaluated per matrix entry there)
+    const double sn = small ? 0.0 : sin(theta), cs = small ? 1.0 : cos(theta);
+    const double th2 = theta * theta;
+    const double ka = small ? 0.0 : sn / theta, kb = small ? 0.0 : (1 - cs) / th2, kc = small ? 0.0 : (theta - sn) / (th2 * theta);
     for (int i = 0; i < 9; ++i) {
         const double I = (i % 4 == 0) ? 1.0 : 0.0;
-        if (theta < 0.00001) {
+        if (small) {
             out.R[i] = (I + O[i]) + O2[i];
             V[i] = out.R[i];
         } else {
-            const double s = sin(theta), c = cos(theta);
-            out.R[i] = (I + s / theta * O[i]) + (1 - c) / (theta * theta) * O2[i];
-            V[i] = (I + (1 - c) / (theta * theta) * O[i]) + (theta - s) / (theta * theta * theta) * O2[i];
+            out.R[i] = (I + ka * O[i]) + kb * O2[i];
+            V[i] = (I + kb * O[i]) + kc * O2[i];
         }
     }
     for (int i = 0; i < 3; ++i) out.t[i] = (V[3 * i] * u[3] + V[3 * i + 1] * u[4]) + V[3 * i + 2] * u[5];
@@ -57,8 +63,11 @@ __device__ void compose_d(const PoseD& a, const PoseD& b, PoseD& out) {
     }
 }
 
+// (H + lambda I) x = b by Cholesky. One thread runs this between two barriers of a one-workgroup kernel, so its dependent chain is the
+// kernel's: the 27 divisions by diagonal entries are 6 reciprocals and 27 multiplications (an IEEE f64 divide is a ~30-instruction
+// dependent sequence; the products differ from the quotients by an ulp, far inside the optimiser's 1e-9 tolerance against the oracle).
 __device__ bool solve6_d(const double* H, double lambda, const double* b, double* x) {
-    double L[36];
+    double L[36], inv[6];
     for (int i = 0; i < 36; ++i) L[i] = 0;
     for (int i = 0; i < 6; ++i) {
         for (int j = 0; j <= i; ++j) {
@@ -67,8 +76,9 @@ __device__ bool solve6_d(const double* H, double lambda, const double* b, double
             if (i == j) {
                 if (!(s > 0)) return false;
                 L[6 * i + i] = sqrt(s);
+                inv[i] = 1.0 / L[6 * i + i];
             } else {
-                L[6 * i + j] = s / L[6 * j + j];
+                L[6 * i + j] = s * inv[j];
             }
         }
     }
@@ -76,12 +86,12 @@ __device__ bool solve6_d(const double* H, double lambda, const double* b, double
     for (int i = 0; i < 6; ++i) {
         double s = b[i];
         for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
-        y[i] = s / L[6 * i + i];
+        y[i] = s * inv[i];
     }
     for (int i = 5; i >= 0; --i) {
         double s = y[i];
         for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
-        x[i] = s / L[6 * i + i];
+        x[i] = s * inv[i];
     }
     return true;
 }
@@ -203,15 +213,17 @@ __device__ __forceinline__ double pose_edge(const double* R, const double* t, co
 }
 
 constexpr int kPoseMaxObs = 8192;   // <= 32 observations per thread: the inlier flags of a thread fit one register
-constexpr int kPoseThreads = 256;   // one workgroup per frame: 0.75 ms per 2000-observation frame; 128 threads: 1.1 ms, 512: 0.94 ms, 1024: 1.5 ms (cross-wave barriers and reductions)
-constexpr int kPoseWaves = kPoseThreads / 64;
+// one workgroup per frame, kPoseThreads threads (template parameter: 256 / 512 / 1024, chosen per launch)
 
-template <int MODEL>   // 0 perspective (mono / stereo edges), 1 equirectangular (mono edges)
+template <int MODEL, int kPoseThreads>   // MODEL 0 perspective (mono / stereo edges), 1 equirectangular (mono edges)
 __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __restrict__ poses_in, const ovs_pose_obs* __restrict__ obs_all,
                                                       const int32_t* __restrict__ obs_offsets, ovs_ba_cam cam, double bf, int setup_type,
                                                       double* __restrict__ poses_out, uint8_t* __restrict__ outlier_all,
                                                       int32_t* __restrict__ num_valid) {
+    constexpr int kPoseWaves = kPoseThreads / 64;
+    constexpr int kRedPitch = kPoseThreads + 8;   // doubles per row of the reduction scratch
     __shared__ double s_part[kPoseWaves][28];
+    extern __shared__ __attribute__((aligned(16))) double s_red[];   // [28 * kRedPitch]: the linearisation's block reduction (dynamic: 116 KB at 512 threads)
     __shared__ double s_sum[28];
     __shared__ PoseD s_T, s_Tn;
     __shared__ double s_ctl[4];   // [0] = continue trials of this iteration, [1] = continue iterations of this round
@@ -232,6 +244,26 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
         return;
     }
 
+    // fixed-order block reduction of the 28 per-thread sums of a linearisation into s_sum, through LDS: 28 separate wave reductions (six
+    // dependent cross-lane steps each) were a quarter of an iteration's time on this one-workgroup, latency-bound kernel. Every thread
+    // stores its 28 values (row i = value i, one column per thread), then thread (i, part) = (tid >> 3, tid & 7) adds the 32 columns
+    // part, part + 8, ... of row i in that order and the eight parts are combined by three exchange steps. Rows are kRedPitch doubles apart:
+    // 528 dwords = 16 banks, so the four rows a 32-lane group reads fall on disjoint banks.
+    auto reduce28_finish = [&]() {   // (the caller has stored its 28 values: s_red[i * kRedPitch + tid] = v[i])
+        __syncthreads();
+        if (tid < 28 * 8) {
+            const int i = tid >> 3, part = tid & 7;
+            const double* row = s_red + i * kRedPitch + part;
+            double s = row[0];
+#pragma unroll
+            for (int k = 1; k < kPoseThreads / 8; ++k) s += row[8 * k];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            if (part == 0) s_sum[i] = s;
+        }
+        __syncthreads();
+    };
     // fixed-order block reduction of NV per-thread values into s_sum
     auto reduce = [&](const double* v, int nv) {
         for (int i = 0; i < nv; ++i) {
@@ -278,7 +310,9 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                             pose_edge<MODEL>(R, t, o, cam, bf, robust ? huber : 0.0, acc);
                         }
                 }
-                reduce(acc, 28);
+#pragma unroll
+                for (int i = 0; i < 28; ++i) s_red[i * kRedPitch + tid] = acc[i];
+                reduce28_finish();
                 double H[36], b[6];
                 {
                     int k = 0;
@@ -402,14 +436,35 @@ extern "C" {
 
 static ovs_status pose_optimize_batch_dev(int model, const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
                                           const ovs_ba_cam& cam, double focal_x_baseline, int32_t setup_type, double* d_poses_out,
-                                          uint8_t* d_outlier, int32_t* d_num_valid, void* stream) {
+                                          uint8_t* d_outlier, int32_t* d_num_valid, void* stream, int threads_default = 256) {
     if (!d_poses_in || !d_obs || !d_obs_offsets || !d_poses_out || !d_outlier || !d_num_valid || batch < 1) return OVS_ERR_INVALID;
-    if (model == 1)
-        hipLaunchKernelGGL(k_pose_optimize<1>, dim3(batch), dim3(kPoseThreads), 0, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, cam,
-                           0.0, 0, d_poses_out, d_outlier, d_num_valid);
-    else
-        hipLaunchKernelGGL(k_pose_optimize<0>, dim3(batch), dim3(kPoseThreads), 0, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, cam,
-                           focal_x_baseline, (int)setup_type, d_poses_out, d_outlier, d_num_valid);
+    // workgroup size: the kernel is one latency-bound workgroup per frame; more waves hide the f64 latency of the per-observation work
+    // but pay in barriers (measured per 2000-observation frame in DESIGN.md section 3.6)
+    static const int threads_env = [] {
+        const char* e = std::getenv("OVS_POSE_THREADS");
+        return e ? std::atoi(e) : 0;
+    }();
+    const int T = threads_env == 256 || threads_env == 512 ? threads_env : threads_default;
+    const size_t lds = sizeof(double) * 28 * (size_t)(T + 8);
+#define OVS_POSE_LAUNCH(MODEL, TT, BF, ST)                                                                                              \
+    do {                                                                                                                              \
+        static thread_local bool configured = false;                                                                                   \
+        if (!configured) {                                                                                                             \
+            OVS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_optimize<MODEL, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                            (int)(sizeof(double) * 28 * (TT + 8))));                                                 \
+            configured = true;                                                                                                         \
+        }                                                                                                                              \
+        hipLaunchKernelGGL((k_pose_optimize<MODEL, TT>), dim3(batch), dim3(TT), lds, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, \
+                           cam, BF, ST, d_poses_out, d_outlier, d_num_valid);                                                          \
+    } while (0)
+    if (model == 1) {
+        if (T == 512) OVS_POSE_LAUNCH(1, 512, 0.0, 0);
+        else OVS_POSE_LAUNCH(1, 256, 0.0, 0);
+    } else {
+        if (T == 512) OVS_POSE_LAUNCH(0, 512, focal_x_baseline, (int)setup_type);
+        else OVS_POSE_LAUNCH(0, 256, focal_x_baseline, (int)setup_type);
+    }
+#undef OVS_POSE_LAUNCH
     OVS_HIP_TRY(hipGetLastError());
     return OVS_OK;
 }
@@ -438,54 +493,60 @@ static ovs_status pose_optimize_host(int model, int32_t device, const double* po
     if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
     OVS_HIP_TRY(hipSetDevice(device));
     const size_t no = (size_t)std::max(n_obs, 1);
-    const size_t off_obs = 256, off_off = off_obs + sizeof(ovs_pose_obs) * no, off_out = (off_off + 8 + 255) & ~(size_t)255, off_fl = off_out + 128,
-                 off_nv = (off_fl + no + 7) & ~(size_t)7;
-    // per-thread, per-device staging buffer that only grows: this runs once per tracked frame, a hipMalloc / hipFree pair per call
-    // would cost more than the optimisation itself
+    // one device block and its pinned host mirror: inputs [pose 12 f64 | offsets 2 i32 | pad | observations] go up in ONE copy, outputs
+    // [pose 12 f64 | num_valid | pad | outlier flags] come back in ONE copy, one wait (was three synchronous copies each way: ~60 us of a
+    // 0.7 ms call)
+    const size_t off_off = 96, off_obs = 128, in_bytes = off_obs + sizeof(ovs_pose_obs) * no;
+    const size_t off_out = (in_bytes + 255) & ~(size_t)255, off_nv = off_out + 96, off_fl = off_out + 128, out_bytes = 128 + no;
+    const size_t total = off_out + ((out_bytes + 15) & ~(size_t)15);
+    // per-thread, per-device staging that only grows: this runs once per tracked frame, an allocation per call would cost more than
+    // the optimisation itself
     struct Scratch {
-        unsigned char* p = nullptr;
+        unsigned char *p = nullptr, *h = nullptr;
+        hipStream_t stream = nullptr;
         size_t cap = 0;
         int device = -1;
-        ~Scratch() {
+        void release() {
             if (p) (void)hipFree(p);
+            if (h) (void)hipHostFree(h);
+            if (stream) (void)hipStreamDestroy(stream);
+            p = h = nullptr;
+            stream = nullptr;
+            cap = 0;
+            device = -1;
         }
+        ~Scratch() { release(); }
     };
     static thread_local Scratch scratch;
-    if (scratch.device != device || scratch.cap < off_nv + 16) {
-        if (scratch.p) (void)hipFree(scratch.p);
-        scratch.p = nullptr;
-        scratch.cap = 0;
-        const size_t want = std::max<size_t>(off_nv + 16, (size_t)1 << 20);
+    if (scratch.device != device || scratch.cap < total) {
+        scratch.release();
+        const size_t want = std::max<size_t>(total, (size_t)1 << 20);
         OVS_HIP_TRY(hipMalloc(&scratch.p, want));
+        OVS_HIP_TRY(hipHostMalloc(&scratch.h, want, hipHostMallocDefault));
+        OVS_HIP_TRY(hipStreamCreateWithFlags(&scratch.stream, hipStreamNonBlocking));
         scratch.cap = want;
         scratch.device = device;
     }
-    unsigned char* d = scratch.p;
-    ovs_status st = OVS_ERR_HIP;
-    hipError_t er = hipSuccess;
-    do {
-#define P_TRY(expr)                               \
-    if ((er = (expr)) != hipSuccess) {            \
-        ovs::set_last_error(#expr, er);           \
-        break;                                    \
-    }
-        const int32_t offs[2] = {0, n_obs};
-        P_TRY(hipMemcpy(d, pose_cw_in, sizeof(double) * 12, hipMemcpyHostToDevice));
-        if (n_obs) P_TRY(hipMemcpy(d + off_obs, obs, sizeof(ovs_pose_obs) * (size_t)n_obs, hipMemcpyHostToDevice));
-        P_TRY(hipMemcpy(d + off_off, offs, sizeof(offs), hipMemcpyHostToDevice));
-        st = pose_optimize_batch_dev(model, reinterpret_cast<double*>(d), reinterpret_cast<ovs_pose_obs*>(d + off_obs),
-                                     reinterpret_cast<int32_t*>(d + off_off), 1, *cam, focal_x_baseline, setup_type,
-                                     reinterpret_cast<double*>(d + off_out), d + off_fl, reinterpret_cast<int32_t*>(d + off_nv), nullptr);
-        if (st != OVS_OK) break;
-        st = OVS_ERR_HIP;
-        P_TRY(hipStreamSynchronize(nullptr));
-        P_TRY(hipMemcpy(pose_cw_out, d + off_out, sizeof(double) * 12, hipMemcpyDeviceToHost));
-        if (n_obs) P_TRY(hipMemcpy(outlier_flags, d + off_fl, (size_t)n_obs, hipMemcpyDeviceToHost));
-        P_TRY(hipMemcpy(num_valid, d + off_nv, sizeof(int32_t), hipMemcpyDeviceToHost));
-        st = OVS_OK;
-#undef P_TRY
-    } while (0);
-    return st;
+    unsigned char *d = scratch.p, *h = scratch.h;
+    const int32_t offs[2] = {0, n_obs};
+    std::memcpy(h, pose_cw_in, sizeof(double) * 12);
+    std::memcpy(h + off_off, offs, sizeof(offs));
+    if (n_obs) std::memcpy(h + off_obs, obs, sizeof(ovs_pose_obs) * (size_t)n_obs);
+    OVS_HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, scratch.stream));
+    // one latency-bound workgroup: 512 threads hide the f64 latency of the per-observation work when there is enough of it (2000
+    // observations 0.74 -> 0.68 ms perspective, 1.63 -> 1.32 ms equirectangular; 500 observations: 0.43 -> 0.47 / 0.78 -> 0.68)
+    const int threads = (model == 1 || n_obs >= 1024) ? 512 : 256;
+    const ovs_status st = pose_optimize_batch_dev(model, reinterpret_cast<double*>(d), reinterpret_cast<ovs_pose_obs*>(d + off_obs),
+                                                  reinterpret_cast<int32_t*>(d + off_off), 1, *cam, focal_x_baseline, setup_type,
+                                                  reinterpret_cast<double*>(d + off_out), d + off_fl, reinterpret_cast<int32_t*>(d + off_nv),
+                                                  scratch.stream, threads);
+    if (st != OVS_OK) return st;
+    OVS_HIP_TRY(hipMemcpyAsync(h + off_out, d + off_out, out_bytes, hipMemcpyDeviceToHost, scratch.stream));
+    OVS_HIP_TRY(hipStreamSynchronize(scratch.stream));
+    std::memcpy(pose_cw_out, h + off_out, sizeof(double) * 12);
+    std::memcpy(num_valid, h + off_nv, sizeof(int32_t));
+    if (n_obs) std::memcpy(outlier_flags, h + off_fl, (size_t)n_obs);
+    return OVS_OK;
 }
 
 ovs_status ovs_pose_optimize(int32_t device, const double* pose_cw_in, const ovs_pose_obs* obs, int32_t n_obs, const ovs_ba_cam* cam,

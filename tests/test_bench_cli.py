@@ -1,0 +1,52 @@
+"""bench.py's launch contract: the driver runs plain `python bench.py --gpus N`; the script starts its own ranks under torch.distributed.run
+when WORLD_SIZE is unset, and stops with a clear message -- before allocating anything -- when the node has fewer devices than asked for."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    return subprocess.run([sys.executable, BENCH, *args], capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_refuses_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this is the GPU-less tier's test")
+    for n in ("1", "2"):
+        r = _run("--gpus", n, "--steps", "1", "--warmup", "0")
+        assert r.returncode != 0 and "needs a HIP device" in r.stderr and r.stdout.strip() == ""   # no JSON line, no CPU fallback
+
+
+@pytest.mark.gpu
+def test_asking_for_more_devices_than_the_node_has_stops_early():
+    import torch
+    have = torch.cuda.device_count()
+    r = _run("--gpus", str(have + 1), "--steps", "1", "--warmup", "0", timeout=300)
+    assert r.returncode != 0 and ("needs %d HIP devices on this node, found %d" % (have + 1, have)) in r.stderr and r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_has_the_contract_fields():
+    """One short run (2 steps, small side sections off): ONE JSON line on stdout with the fields the driver and the judge read."""
+    r = _run("--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-ba", "--batch", "32", timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "u8" and d["vs_baseline"] is None and d["value"] > 0
+    roof = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in roof, k
+    assert roof["bound"] == "hbm" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
+    assert "workload" in d["config"] and "model" not in d["config"]
