@@ -322,7 +322,7 @@ def main():
                 hsh = hashlib.sha256()
                 src_dir = os.path.join(ROOT, "openvslam_amd", "csrc")
                 for fn in sorted(os.listdir(src_dir)):
-                    if fn.endswith((".hip", ".h", ".inc")):
+                    if fn.endswith((".h", ".inc")) or fn.startswith(("orb_", "match_hamming")):   # the kernels the traffic file covers (extraction, brute-force matcher) and the shared headers
                         hsh.update(open(os.path.join(src_dir, fn), "rb").read())
                 if pmc.get("csrc_sha16") != hsh.hexdigest()[:16]:
                     pmc_stale = "profiles/pmc_traffic.json was collected from other kernel sources (csrc fingerprint %s, now %s): re-run tools/gpu_pmc.sh" % (

@@ -61,7 +61,7 @@ if "--json" in sys.argv:
     src_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "openvslam_amd", "csrc")
     hsh = hashlib.sha256()
     for fn in sorted(os.listdir(src_dir)):
-        if fn.endswith((".hip", ".h", ".inc")):
+        if fn.endswith((".h", ".inc")) or fn.startswith(("orb_", "match_hamming")):   # the kernels the traffic file covers (extraction, brute-force matcher) and the shared headers
             hsh.update(open(os.path.join(src_dir, fn), "rb").read())
     out["csrc_sha16"] = hsh.hexdigest()[:16]
     if "--batch" in sys.argv:
