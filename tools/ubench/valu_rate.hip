@@ -57,6 +57,14 @@ constexpr int kIters = 2048;
     asm volatile(OP " %0, %1, %2\n" OP " %1, %2, %3\n" OP " %2, %3, %4\n" OP " %3, %4, %5\n"      \
                  OP " %4, %5, %6\n" OP " %5, %6, %7\n" OP " %6, %7, %0\n" OP " %7, %0, %1\n"      \
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+#define BODY8R1(OP)                                                                    \
+    asm volatile(OP " %0, %1\n" OP " %1, %2\n" OP " %2, %3\n" OP " %3, %4\n" OP " %4, %5\n" OP " %5, %6\n" OP " %6, %7\n" OP " %7, %0\n" \
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+#define BODY8R3D(OP)                                                                   \
+    asm volatile(OP " %0, %1, %2, %3\n" OP " %1, %2, %3, %0\n" OP " %2, %3, %0, %1\n" OP " %3, %0, %1, %2\n"      \
+                 OP " %0, %1, %2, %3\n" OP " %1, %2, %3, %0\n" OP " %2, %3, %0, %1\n" OP " %3, %0, %1, %2\n"      \
+                 : "+v"(*reinterpret_cast<double*>(&a[0])), "+v"(*reinterpret_cast<double*>(&a[2])), "+v"(*reinterpret_cast<double*>(&a[4])), \
+                   "+v"(*reinterpret_cast<double*>(&a[6])));
 #define KERNELR(NAME, BODY, OP)                                                        \
     __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed) {        \
         uint32_t a[8];                                                                 \
@@ -108,6 +116,15 @@ KERNELR(r_med3_i32, BODY8R3, "v_med3_i32")
 KERNELR(r_cndmask, BODY8R2, "v_cndmask_b32")
 KERNELR(r_pk_sub_i16, BODY8R2, "v_pk_sub_i16")
 KERNELR(r_pk_lshrrev_b16, BODY8R2, "v_pk_lshrrev_b16")
+// round 3: candidates for the pyramid's vertical pass and the describe kernel
+KERNELR(r_mad_u32_u16, BODY8R3, "v_mad_u32_u16")
+KERNELR(r_mad_u32_u24, BODY8R3, "v_mad_u32_u24")
+KERNELR(r_add3_u32, BODY8R3, "v_add3_u32")
+KERNELR(r_lshl_or, BODY8R3, "v_lshl_or_b32")
+KERNELR(r_cvt_f32_i32, BODY8R1, "v_cvt_f32_i32")
+KERNELR(r_mul_f32, BODY8R2, "v_mul_f32")
+KERNELR(r_add_f32, BODY8R2, "v_add_f32")
+KERNELR(r_fma_f64, BODY8R3D, "v_fma_f64")
 
 KERNEL(k_pk_max_i16, I_PK_MAX_I16)
 KERNEL(k_pk_min_u16, I_PK_MIN_U16)
@@ -232,5 +249,6 @@ int main() {
     RUN(r_mul_lo_u16) RUN(r_add_u16) RUN(r_sub_u16) RUN(r_lshlrev_b16) RUN(r_ashrrev_i16) RUN(r_max_u16) RUN(r_bfe_u32) RUN(r_alignbit)
     RUN(r_alignbyte) RUN(r_mad_u16) RUN(r_mad_i32_i24) RUN(r_lshl_add) RUN(r_or3) RUN(r_dot4_u32_u8) RUN(r_dot2_u32_u16) RUN(r_bfi)
     RUN(r_min3_u16) RUN(r_med3_i32) RUN(r_cndmask) RUN(r_pk_sub_i16) RUN(r_pk_lshrrev_b16)
+    RUN(r_mad_u32_u16) RUN(r_mad_u32_u24) RUN(r_add3_u32) RUN(r_lshl_or) RUN(r_cvt_f32_i32) RUN(r_mul_f32) RUN(r_add_f32) RUN(r_fma_f64)
     return 0;
 }
