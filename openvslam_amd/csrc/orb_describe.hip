@@ -114,6 +114,26 @@ __device__ __forceinline__ float util_cos(float v) {
 }
 __device__ __forceinline__ float util_sin(float v) { return util_cos(__fsub_rn(1.57079632679489661923f, v)); }
 
+template <int BYTE>
+__device__ __forceinline__ float cvt_s8(uint32_t w) {   // (float)(int8_t)(w >> 8 * BYTE)
+    float f;
+    if (BYTE == 0) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(f) : "v"(w));
+    if (BYTE == 1) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(f) : "v"(w));
+    if (BYTE == 2) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(f) : "v"(w));
+    if (BYTE == 3) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(f) : "v"(w));
+    return f;
+}
+
+__device__ __forceinline__ int wave_total_in_lane63(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+    return v;
+}
+
 __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ geo, const uint8_t* __restrict__ img0, size_t stride0,
                                                 size_t frame_stride0, const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                                 const uint64_t* __restrict__ lvl_kps, const uint32_t* __restrict__ lvl_count,
@@ -218,11 +238,10 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
         m10 = (int)wsum - 16 * (int)sum;
         m01 = v * (int)sum;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
-    }
+    // wave totals by the DPP prefix pattern (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31: lane 63 ends with the sum of all lanes) and one
+    // v_readlane each: 12 cross-lane adds instead of 12 ds_bpermute round trips + 12 adds (integer sums: any order gives the same bits)
+    m10 = __builtin_amdgcn_readlane(wave_total_in_lane63(m10), 63);
+    m01 = __builtin_amdgcn_readlane(wave_total_in_lane63(m01), 63);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // upstream evaluates keypt.angle * M_PI / 180.0 in double and rounds to float once (ORACLE_SPEC rule 11)
     const float rad = (float)__ddiv_rn(__dmul_rn((double)angle, 3.14159265358979323846), 180.0);
@@ -240,31 +259,45 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
     const uint32_t t1a = (uint32_t)(taps << 8), t1b = (uint32_t)(taps >> 24);
     const uint32_t t2a = (uint32_t)(taps << 16), t2b = (uint32_t)(taps >> 16), t2c = (uint32_t)(taps >> 48);
     const uint32_t t3a = (uint32_t)(taps << 24), t3b = (uint32_t)(taps >> 8), t3c = (uint32_t)(taps >> 40);
-    for (int i = lane; i < kPatch * 10; i += 64) {
-        const int r = i / 10, q = i - r * 10;
-        const uint32_t* pw = reinterpret_cast<const uint32_t*>(patch + r * kPatchPitch + ((off + 4 * q) & ~3));
-        const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3];
-        const uint32_t n0 = __builtin_amdgcn_alignbyte(w1, w0, sh), n1 = __builtin_amdgcn_alignbyte(w2, w1, sh),
-                       n2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
-        // every sum <= 255 * 257 = 65535
-        const uint32_t o0 = __builtin_amdgcn_udot4(n0, g0123, __builtin_amdgcn_udot4(n1, g456, 0u, false), false);
-        const uint32_t o1 = __builtin_amdgcn_udot4(n0, t1a, __builtin_amdgcn_udot4(n1, t1b, 0u, false), false);
-        const uint32_t o2 = __builtin_amdgcn_udot4(n0, t2a, __builtin_amdgcn_udot4(n1, t2b, __builtin_amdgcn_udot4(n2, t2c, 0u, false), false), false);
-        const uint32_t o3 = __builtin_amdgcn_udot4(n0, t3a, __builtin_amdgcn_udot4(n1, t3b, __builtin_amdgcn_udot4(n2, t3c, 0u, false), false), false);
-        hb32[r * (kHbPitch / 2) + 2 * q] = o0 | (o1 << 16);
-        hb32[r * (kHbPitch / 2) + 2 * q + 1] = o2 | (o3 << 16);
+    // lane -> (row r0 = lane / 10 of a six-row band, column group q = lane % 10), lanes 60 .. 63 idle; band it covers rows 6 it + r0. Every
+    // address is the lane's base plus a compile-time constant (no per-step index arithmetic: the 64-lane stride over the 430 steps cost
+    // twelve instructions per step for the division by ten)
+    if (lane < 60) {
+        const int r0 = (lane * 0x199a) >> 16, q = lane - 10 * r0;   // lane / 10 for lane < 64
+        const uint32_t* const pw0 = reinterpret_cast<const uint32_t*>(patch + r0 * kPatchPitch + ((off + 4 * q) & ~3));
+        uint32_t* const hb0 = hb32 + r0 * (kHbPitch / 2) + 2 * q;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            if (it == 7 && r0 != 0) break;   // rows 42 .. 47: only row 42 exists
+            const uint32_t* pw = pw0 + it * 6 * (kPatchPitch / 4);
+            const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3];
+            const uint32_t n0 = __builtin_amdgcn_alignbyte(w1, w0, sh), n1 = __builtin_amdgcn_alignbyte(w2, w1, sh),
+                           n2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
+            // every sum <= 255 * 257 = 65535
+            const uint32_t o0 = __builtin_amdgcn_udot4(n0, g0123, __builtin_amdgcn_udot4(n1, g456, 0u, false), false);
+            const uint32_t o1 = __builtin_amdgcn_udot4(n0, t1a, __builtin_amdgcn_udot4(n1, t1b, 0u, false), false);
+            const uint32_t o2 = __builtin_amdgcn_udot4(n0, t2a, __builtin_amdgcn_udot4(n1, t2b, __builtin_amdgcn_udot4(n2, t2c, 0u, false), false), false);
+            const uint32_t o3 = __builtin_amdgcn_udot4(n0, t3a, __builtin_amdgcn_udot4(n1, t3b, __builtin_amdgcn_udot4(n2, t3c, 0u, false), false), false);
+            uint32_t* hb = hb0 + it * 6 * (kHbPitch / 2);
+            hb[0] = o0 | (o1 << 16);
+            hb[1] = o2 | (o3 << 16);
+        }
     }
     __syncthreads();
 
     // ---- steered BRIEF: column pass of the blur at the sampled points only; lane evaluates tests lane + 64*t
-    auto blurred_at = [&](int px, int py) -> int {
-        const float fx = (float)px, fy = (float)py;
+    auto blurred_at = [&](float fx, float fy) -> int {
         const int dy = __float2int_rn(__fadd_rn(__fmul_rn(fx, sin_a), __fmul_rn(fy, cos_a)));
         const int dx = __float2int_rn(__fsub_rn(__fmul_rn(fx, cos_a), __fmul_rn(fy, sin_a)));
         const uint16_t* hp = hblur + (dy + kBlurR) * kHbPitch + dx + kBlurR;
+        // symmetric taps g[k] = g[6 - k]: three 2.3-cycle adds + four multiply-adds instead of seven multiply-adds (sums <= 2 * 65535: exact)
+        const uint32_t a0 = (uint32_t)hp[0] + hp[6 * kHbPitch], a1 = (uint32_t)hp[kHbPitch] + hp[5 * kHbPitch],
+                       a2 = (uint32_t)hp[2 * kHbPitch] + hp[4 * kHbPitch], a3 = hp[3 * kHbPitch];
         uint32_t acc = 32768u;   // round half up
-#pragma unroll
-        for (int k = 0; k < 7; ++k) acc += ((g0123 >> (8 * (k < 4 ? k : 6 - k))) & 255u) * hp[k * kHbPitch];   // symmetric taps: g[k] = g[6 - k]
+        acc += (g0123 & 255u) * a0;
+        acc += ((g0123 >> 8) & 255u) * a1;
+        acc += ((g0123 >> 16) & 255u) * a2;
+        acc += (g0123 >> 24) * a3;
         return (int)min(acc >> 16, 255u);   // (only the 257-sum variant can exceed 255)
     };
     unsigned long long bits[4];
@@ -272,8 +305,9 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const uint32_t pp = pat[lane + 64 * t];
-        const int t0 = blurred_at((int8_t)(pp & 0xFF), (int8_t)((pp >> 8) & 0xFF));
-        const int t1 = blurred_at((int8_t)((pp >> 16) & 0xFF), (int8_t)(pp >> 24));
+        // the four signed pattern bytes straight to float (SDWA byte select with sign extension: one instruction each, not extract + convert)
+        const int t0 = blurred_at(cvt_s8<0>(pp), cvt_s8<1>(pp));
+        const int t1 = blurred_at(cvt_s8<2>(pp), cvt_s8<3>(pp));
         bits[t] = __ballot(t0 < t1);
     }
     if (lane < 4) {
