@@ -3,7 +3,7 @@
 cd /root/repo
 export TMPDIR=/tmp
 for v in 1 0; do
-  out=$PWD/gpurun_out/r3l_x$v
+  out=$PWD/gpurun_out/describe_pmc_x$v
   mkdir -p $out
   cmd="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ba --overlap 0 --batch 128 --fast-split 0"
   ( cd /tmp
