@@ -62,6 +62,7 @@ def main():
                                                           "streams, no cross-chain synchronisation)")
     ap.add_argument("--fast-split", type=int, default=1, help="1: FAST on level 0 (+ its quad-tree) runs on an internal stream beside the pyramid; "
                                                                 "0: one FAST launch over all levels after the pyramid (profiling runs)")
+    ap.add_argument("--match-first", type=int, default=0, help="1: the matcher's stream gets the high-priority queue instead of the extraction's (A/B)")
     ap.add_argument("--overlap", type=int, default=1, help="1: matching of step k runs on a second stream under the extraction of step "
                                                             "k+1 (double-buffered outputs); 0: one stream, strictly serial")
     args = ap.parse_args()
@@ -144,8 +145,8 @@ def main():
             self.prev = torch.tensor([(b - 1) if b % 8 else min(b + 7, Bc - 1) for b in range(Bc)], dtype=torch.long, device="cuda")
             # the extraction is the critical path: it gets the high-priority queue, matching fills the slots it leaves free
             multi = args.overlap or n_chain > 1
-            self.s_ext = torch.cuda.Stream(priority=-1) if multi else torch.cuda.current_stream()
-            self.s_match = torch.cuda.Stream(priority=0) if args.overlap else self.s_ext
+            self.s_ext = torch.cuda.Stream(priority=0 if args.match_first else -1) if multi else torch.cuda.current_stream()
+            self.s_match = torch.cuda.Stream(priority=-1 if args.match_first else 0) if args.overlap else self.s_ext
             self.ev_ext = [torch.cuda.Event() for _ in range(self.n_buf)]
             self.ev_match = [torch.cuda.Event() for _ in range(self.n_buf)]
             self.k = 0
