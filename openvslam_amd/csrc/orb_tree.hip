@@ -41,7 +41,10 @@ constexpr int kTreeThreadsBatch = 512, kTreeThreadsFew = 1024;   // threads per 
 #define OVS_TT_PRINT(n_) do {} while (0)
 #endif
 constexpr uint32_t kNotInS = 0xFFFFFFFFu;
-constexpr int kSweepLoads = 4;      // candidate loads in flight per thread in a sweep
+// candidate loads in flight per thread in a sweep. Each one holds ~15 registers across the three look-up rounds: with four the 512-thread
+// kernel needs 109 VGPRs (two workgroups per CU), with two 75 (three per CU) -- for this latency-bound kernel the third workgroup is worth
+// more than the deeper software pipeline: 0.346 -> 0.311 ms per 256 frames, 63 -> 60.7 us for a single frame (one: 0.327 ms)
+constexpr int kSweepLoads = 2;
 constexpr int kRankDirect = 1024;   // pool ordering: direct rank counting up to this many nodes, bitonic sort beyond
 
 struct NodeRec {
