@@ -115,6 +115,28 @@ def test_switch_factor_one_overshoot(hip, oracle):
     assert overshoot >= 1   # at least one size really needed the larger capacity
 
 
+@pytest.mark.parametrize("ini,mn", [(7, 5), (12, 3), (20, 7)])
+def test_dense_cells(hip, oracle, ini, mn):
+    """White noise at a low threshold: more than half of a cell's 4096 pixels pass the diameter pre-test (the pooled candidate list of a cell
+    is at its fullest, the exact scoring runs many rounds per cell) next to a low-contrast patch whose cells fall back to min_fast_thr.
+    Candidates, keypoints and descriptors stay byte-equal with the oracle."""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (300, 420), dtype=np.uint8)
+    img[100:200, 150:300] = (120 + rng.integers(0, 24, (100, 150))).astype(np.uint8)   # a low-contrast patch: cells of mixed density
+    ex = hip.orb_extractor(hip.orb_params(max_num_keypts=1500, num_levels=4, ini_fast_thr=ini, min_fast_thr=mn), max_rows=300, max_cols=420)
+    ox = oracle.OrbExtractor(oracle.make_params(1500, 1.2, 4, ini, mn))
+    gk, gd = ex.extract(img)
+    wk, wd = ox.extract(img)
+    assert len(gk) == len(wk) and np.array_equal(gk.view(np.uint8), wk.view(np.uint8)) and np.array_equal(gd, wd)
+    dense = 0
+    for level in range(4):
+        gx, gy, gs = ex.debug_candidates(level)   # (sorted by the debug entry point as the oracle emits them)
+        wx, wy, ws = ox.level_candidates(level)
+        assert len(gx) == len(wx) and np.array_equal(gx, wx) and np.array_equal(gy, wy) and np.array_equal(gs, ws), "level %d candidates" % level
+        dense += len(wx)
+    assert dense > 3000   # (NMS survivors; the lists in front of them were several times longer)
+
+
 def test_flat_and_tiny_images(hip, oracle):
     # flat image: no corners at either threshold -> zero keypoints; tiny image: levels without any cell
     for img in (np.full((480, 752), 77, np.uint8), synth_frame(120, 160, seed=3), synth_frame(64, 64, seed=4)):
