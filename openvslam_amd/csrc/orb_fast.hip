@@ -502,11 +502,13 @@ struct LevelRef {
 };
 
 constexpr int kMaxCellsPerWg = 64;
-constexpr int kWgSurvivors = 512;   // NMS survivors of the group's cells waiting for their (single) list reservation: ~33 per cell on video
+constexpr int kWgSurvivors = 256;   // NMS survivors of the group's cells waiting for their (single) list reservation: ~33 per cell on video
+constexpr int kListCap = 2048;      // pooled candidate list of a cell; a denser cell (noise at a low threshold) is scored exhaustively instead
 
-// 24.2 KB + 2 KB of LDS admit six workgroups per CU: cap the registers at the 80 that six waves per SIMD leave (hipcc took 95 unasked)
+// 21.1 KB of LDS admit SEVEN workgroups per CU (round 3: the pooled list holds 2048 entries instead of a cell's 4096 pixels, the group buffer 256
+// survivors instead of 512; six workgroups: 1.96 ms per 256 frames, seven: 1.91): cap the registers at the 72 that seven waves per SIMD leave
 template <bool kTiming, bool kD8>   // kTiming: wave 0 accumulates shader cycles per phase into tstats (tuning aid, OVS_FAST_TIMING); kD8: eight diameters
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_fast_cells(const FrameGeo* __restrict__ geo, const CellDesc* __restrict__ cell_tab,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_fast_cells(const FrameGeo* __restrict__ geo, const CellDesc* __restrict__ cell_tab,
                                                    const uint8_t* __restrict__ img0, size_t stride0,
                                                    size_t frame_stride0, const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                                    uint64_t* __restrict__ cand, size_t cand_frame_entries,
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     __shared__ __attribute__((aligned(16))) uint32_t tile[kTileRowsMax][kTileWords];
     __shared__ __attribute__((aligned(16))) uint32_t smap[kSmapRows][kSmapWords];
     __shared__ __attribute__((aligned(16))) uint32_t rtile[kTileRowsMax][kTileWords];
-    __shared__ uint16_t clist[kCellSize * kCellSize];   // pixels that passed the diameter test, (y << 8) | x, all four waves
+    __shared__ uint16_t clist[kListCap];                // pixels that passed the diameter test, (y << 8) | x, all four waves
     __shared__ uint32_t wgbuf[kWgSurvivors];            // (slot << 26) | (score << 12) | (y << 6) | x of the group's survivors not yet written out
     __shared__ uint32_t n_cand_wg, n_out, list_base;
 
@@ -727,13 +729,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                         const int b = __ffs(cmask) - 1;
                         cmask &= cmask - 1;
                         const uint32_t fl = (((dmask >> b) & 1u) << 6) | (((dmask >> (b + 4)) & 1u) << 7);
-                        clist[pos++] = (uint16_t)(((row0 + ((b >> 1) & 1)) << 8) | (c0 + 4 * (b & 1) + (b >> 3)) | fl);
+                        if (pos < (uint32_t)kListCap) clist[pos] = (uint16_t)(((row0 + ((b >> 1) & 1)) << 8) | (c0 + 4 * (b & 1) + (b >> 3)) | fl);
+                        ++pos;
                     }
                 }
                 FAST_MARK(5)   // prefix + list writes
                 lds_barrier();
-                const int n_cand = (int)n_cand_wg;
+                int n_cand = (int)n_cand_wg;
                 FAST_MARK(6)   // barrier 2
+                if (n_cand > kListCap) {
+                    // Dense cell (workgroup-uniform; white noise at a low threshold): more candidates than the list holds. No list then: every
+                    // thread scores ITS sixteen pixels exhaustively, both polarities, and suppresses them itself. A pixel the pre-test rejected
+                    // has S <= thr, so the complete score map gives the same survivors as the sparse one (whose unscored pixels read 0).
+                    for (uint32_t m = valid; m;) {
+                        const int b = __ffs(m) - 1;
+                        m &= m - 1;
+                        const int x = c0 + 4 * (b & 1) + (b >> 3), y = row0 + ((b >> 1) & 1);
+                        uint32_t r[16], c;
+                        load_ring(tbytes + y * (kTileWords * 4) + x + 3, r, c);
+                        uint32_t sc = fast_strength_bright(r, c);
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) r[q] ^= 0xffu;
+                        sc = mx16(sc, fast_strength_bright(r, c ^ 0xffu));
+                        sbytes[(y + 1) * (kSmapWords * 4) + 4 + x] = (uint8_t)sc;
+                    }
+                    lds_barrier();
+                    for (uint32_t m = valid; m;) {
+                        const int b = __ffs(m) - 1;
+                        m &= m - 1;
+                        const int x = c0 + 4 * (b & 1) + (b >> 3), y = row0 + ((b >> 1) & 1);
+                        const uint8_t* q = sbytes + (y + 1) * (kSmapWords * 4) + 4 + x;
+                        const uint32_t sc = q[0];
+                        if ((int)sc <= thr) continue;
+                        constexpr int kS = kSmapWords * 4;
+                        const uint32_t nb = mx16(mx16(mx16((uint32_t)q[-kS - 1], (uint32_t)q[-kS]), mx16((uint32_t)q[-kS + 1], (uint32_t)q[-1])),
+                                                 mx16(mx16((uint32_t)q[1], (uint32_t)q[kS - 1]), mx16((uint32_t)q[kS], (uint32_t)q[kS + 1])));
+                        if (sc <= nb) continue;
+                        const uint32_t o = atomicAdd(&n_out, 1u);
+                        olist[o] = (sc << 12) | ((uint32_t)y << 6) | (uint32_t)x;
+                    }
+                    n_cand = 0;   // the sparse passes below have nothing left to do
+                }
                 // ---- 3. exact S for the candidates, one per lane, into the score map: one polarity per candidate (both where both tests passed)
                 for (int i = tid; i < n_cand; i += 256) {
                     const uint32_t e = clist[i];
