@@ -395,7 +395,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // bank conflicts -- at the 24 waves per CU that 26 KB of LDS leave. Halving the pre-test's cycles, an eight-diameter pre-test (-22 %
 // candidates), 8 workgroups per CU (aliased LDS, 64 VGPRs) each moved the launch by < 3 %; the grouping + prefetch + single reservation
 // are worth ~6 % together (0.50 -> 0.47 ms per 64 frames).
-// LDS: raw tile 5.6 KB + R tile 5.6 KB + score map 4.75 KB + pooled list 8 KB + group buffer 2 KB = 26.2 KB -> 6 workgroups per CU.
+// LDS: raw tile 5.6 KB + R tile 5.6 KB + score map 4.75 KB + pooled list 4 KB + group buffer 1 KB = 21.1 KB -> 7 workgroups per CU (until late in
+// round 3: an 8 KB list for all 4096 pixels of a cell and a 2 KB buffer, 26.2 KB, six workgroups; see kListCap).
 __device__ __forceinline__ uint32_t wave_prefix_incl(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
