@@ -79,7 +79,7 @@ def main():
         # launched as plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run, rendezvous on
         # 127.0.0.1 (the container hostname may not resolve); rank 0's JSON line passes through on stdout, the exit code is the job's
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and os.environ.get("OVS_BENCH_ONE_DEVICE") != "1":
             raise SystemExit("bench.py --gpus %d needs %d HIP devices on this node, found %d" % (args.gpus, args.gpus, have))
         import socket
         import subprocess
@@ -93,12 +93,21 @@ def main():
         raise SystemExit(subprocess.call(cmd, env=env))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE=%d (torch.distributed.run --nproc-per-node must equal --gpus)" % (args.gpus, world))
+    # Test hook (tests/test_bench_cli.py): OVS_BENCH_ONE_DEVICE=1 puts every rank on device 0 and uses gloo for the process group (RCCL refuses
+    # two ranks on one device), so that the multi-rank code path -- sharding, barriers, max-over-ranks clock, the sums over ranks, the
+    # sharded local-BA exchange, rank 0's single JSON line -- runs on a one-GPU box. Its numbers mean nothing; the line says so.
+    one_device = os.environ.get("OVS_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("rank %d: LOCAL_RANK %d but only %d HIP devices on this node" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from openvslam_amd import _lib, feature, match
     from openvslam_amd.synth import synth_video
@@ -440,6 +449,7 @@ def main():
             "local_ba_large": ba_large,
             "other_configs": side,
             "parity": "bit-exact vs in-repo CPU oracle (from-spec restatement; upstream source unavailable: parity unpinned)",
+            **({"test_hook": "OVS_BENCH_ONE_DEVICE=1: all ranks on ONE device over gloo -- a code-path test, not a measurement"} if one_device else {}),
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(out["value"] / cpu["value"], 1)

@@ -50,3 +50,23 @@ def test_single_gpu_line_has_the_contract_fields():
         assert k in roof, k
     assert roof["bound"] == "hbm" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
     assert "workload" in d["config"] and "model" not in d["config"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_code_path_on_one_device():
+    """`bench.py --gpus 2` end to end on a one-GPU box: the script starts its two ranks itself (torch.distributed.run on 127.0.0.1); the
+    OVS_BENCH_ONE_DEVICE test hook puts both on device 0 over gloo. Checks what the driver's scaling run relies on: ONE JSON line, from rank 0,
+    n_gpus = 2, weak scaling (twice the frames of a rank), the sharded local-BA sections present with a non-zero exchange size."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["OVS_BENCH_ONE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32", "--no-cpu-baseline"], capture_output=True,
+                       text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_step_per_gpu"] == 32 and "test_hook" in d
+    assert abs(d["frames_per_sec"] * d["ms_per_step"] / 1e3 - 64) < 0.5   # both ranks' frames in the whole-job rate
+    assert d["keypoints_per_frame"] > 1500 and d["value"] > 0
+    for sec in ("local_ba", "local_ba_large"):
+        assert d[sec]["allreduce_bytes"] > 0 and d[sec]["ms_per_linearisation"] > 0 and "all-reduce" in d[sec]["exchange"]
