@@ -725,13 +725,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                     const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     uint32_t base = 0;
                     if ((tid & 63) == 0 && wave_total) base = atomicAdd(&n_cand_wg, wave_total);
-                    uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + incl - n_mine;
-                    while (cmask) {
-                        const int b = __ffs(cmask) - 1;
-                        cmask &= cmask - 1;
-                        const uint32_t fl = (((dmask >> b) & 1u) << 6) | (((dmask >> (b + 4)) & 1u) << 7);
-                        if (pos < (uint32_t)kListCap) clist[pos] = (uint16_t)(((row0 + ((b >> 1) & 1)) << 8) | (c0 + 4 * (b & 1) + (b >> 3)) | fl);
-                        ++pos;
+                    const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    uint32_t pos = wave_base + incl - n_mine;
+                    // a wave whose range does not fit the list writes nothing: the cell then holds more than kListCap candidates in total and
+                    // takes the exhaustive path below, which does not read the list (no per-entry bound check in the common case)
+                    if (wave_base + wave_total <= (uint32_t)kListCap) {
+                        while (cmask) {
+                            const int b = __ffs(cmask) - 1;
+                            cmask &= cmask - 1;
+                            const uint32_t fl = (((dmask >> b) & 1u) << 6) | (((dmask >> (b + 4)) & 1u) << 7);
+                            clist[pos++] = (uint16_t)(((row0 + ((b >> 1) & 1)) << 8) | (c0 + 4 * (b & 1) + (b >> 3)) | fl);
+                        }
                     }
                 }
                 FAST_MARK(5)   // prefix + list writes
