@@ -94,3 +94,42 @@ def test_device_and_host_agree_bit_for_bit():
                         np.nextafter(np.nextafter(k, np.float32(0)), np.float32(0)), np.nextafter(np.nextafter(k, np.float32(1e30)), np.float32(1e30))])
     xs = np.concatenate([m, np.exp(rng.uniform(-80, 80, 500000)).astype(np.float32), k]).astype(np.float64)
     assert np.array_equal(dev(ob.DETMATH_LOGF, xs).view(np.uint64), ob.detmath_eval(ob.DETMATH_LOGF, xs).view(np.uint64))
+
+
+def test_equirectangular_decisions_do_not_depend_on_the_shared_asin_atan2():
+    """The kernels and the oracle share ovs_det_asin / ovs_det_atan2 (<= 1 / <= 2 ulp from glibc): parity between them on the equirectangular
+    reprojection holds by construction, so it cannot show whether an upstream build (libm) would decide differently. This test can: the
+    DECISIONS that hang on those values -- the pixel a bearing reprojects to, the grid cell of assign_keypoints_to_grid it falls in, the
+    window test |u - u_kp| <= margin -- are evaluated through the shared functions and through numpy (glibc) for two million bearings, incl. the
+    +-180 degree seam and the poles. They differ only where the libm value itself sits within a few ulp of the decision threshold."""
+    rng = np.random.default_rng(5)
+    n = 2_000_000
+    p = rng.normal(size=(n, 3))
+    p[:50000, 0] = rng.normal(size=50000) * 1e-6      # the seam (x ~ 0 behind the camera) and the forward direction
+    p[:50000, 2] = -np.abs(p[:50000, 2])
+    p[50000:100000, [0, 2]] *= 1e-5                   # the poles
+    cols, rows = 3840.0, 1920.0
+    norm = np.sqrt((p[:, 0] * p[:, 0] + p[:, 1] * p[:, 1]) + p[:, 2] * p[:, 2])
+    s = p[:, 1] / norm
+    s = np.clip(s, -1.0, 1.0)
+
+    def project(atan2, asin):
+        u = cols * (0.5 + atan2(p[:, 0], p[:, 2]) / (2 * np.pi))
+        v = rows * (0.5 + asin(s) / np.pi)
+        return u, v
+
+    u_d, v_d = project(lambda y, x: ob.detmath_eval(ob.DETMATH_ATAN2, y, x), lambda a: ob.detmath_eval(ob.DETMATH_ASIN, a))
+    u_l, v_l = project(np.arctan2, np.arcsin)
+    assert np.abs(u_d - u_l).max() < 4e-12 * cols and np.abs(v_d - v_l).max() < 4e-12 * rows        # a few ulp of a pixel coordinate
+    # grid cell of data::assign_keypoints_to_grid (64 x 48 cells over the image) and a +-15 px window around a keypoint at the image centre
+    cw, ch = cols / 64, rows / 48
+    cell_d = np.floor(u_d / cw) + 64 * np.floor(v_d / ch)
+    cell_l = np.floor(u_l / cw) + 64 * np.floor(v_l / ch)
+    flips = cell_d != cell_l
+    win_d = (np.abs(u_d - cols / 2) <= 15.0) & (np.abs(v_d - rows / 2) <= 15.0)
+    win_l = (np.abs(u_l - cols / 2) <= 15.0) & (np.abs(v_l - rows / 2) <= 15.0)
+    flips |= win_d != win_l
+    assert flips.sum() <= 2            # (measure-zero boundaries; a flip needs a pixel coordinate within ~1e-12 of a cell edge)
+    if flips.any():                    # and where one happens, libm's own value is on the edge to within rounding
+        edge = np.minimum(np.abs(u_l[flips] / cw - np.rint(u_l[flips] / cw)), np.abs(v_l[flips] / ch - np.rint(v_l[flips] / ch)))
+        assert (edge < 1e-9).all() or (np.abs(np.abs(u_l[flips] - cols / 2) - 15.0) < 1e-9).all()
