@@ -1,7 +1,8 @@
 // match_stereo.hip -- M6: match::stereo::compute (expected: src/openvslam/match/stereo.{h,cc}; ORB-SLAM2 ComputeStereoMatches).
 //
 // Every left keypoint is independent upstream too (its loop is an OpenMP parallel-for), so this is a plain data-parallel path:
-//   k_stereo_rows<COUNT|FILL>  get_right_keypoint_indices_in_each_row as a CSR over image rows (count, scan, fill). Bucket order is
+//   k_stereo_index             get_right_keypoint_indices_in_each_row as a CSR over image rows: count, scan and fill by ONE workgroup with the
+//                              row counters in LDS (round 3: was two memsets + three launches, a quarter of a call's latency). Bucket order is
 //                              irrelevant: strict `<` over ascending indices = minimum of (distance, index).
 //   k_stereo_match             one lane per left keypoint: candidates of row (int)y, |octave difference| <= 1, disparity window,
 //                              Hamming distance, best < (THR_HIGH + THR_LOW) / 2.
@@ -11,6 +12,7 @@
 //   k_stereo_outliers          one workgroup: median of the accepted L1 distances by two-pass radix select (they are < 2^16),
 //                              matches above 2 x median are dropped.
 #include <algorithm>
+#include <cstring>
 #include <new>
 
 #include "ovs_common.h"
@@ -19,38 +21,38 @@ namespace ovs {
 
 constexpr int kStereoWin = 5, kStereoSlide = 5;
 
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_stereo_rows(const ovs_keypoint* __restrict__ kps_right, const int32_t* __restrict__ n_ptr, int n_fixed,
-                                                    PyrView pv, uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ cursor,
-                                                    uint32_t* __restrict__ row_items, uint32_t item_cap, uint32_t* __restrict__ overflow) {
-    const int n = n_ptr ? *n_ptr : n_fixed;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const ovs_keypoint k = kps_right[i];
-    const float r = __fmul_rn(2.0f, pv.scale[k.octave]);
-    const int max_r = (int)ceilf(__fadd_rn(k.y, r)), min_r = (int)floorf(__fsub_rn(k.y, r));
+// count -> scan -> fill in one workgroup: s_row[r] first counts the right keypoints whose vertical band covers image row r, then holds the
+// fill cursor of that row. Dynamic LDS: (rows0 + 1) + 1024 words.
+__global__ __launch_bounds__(1024) void k_stereo_index(const ovs_keypoint* __restrict__ kps_right, const int32_t* __restrict__ n_ptr, int n_fixed,
+                                                      PyrView pv, uint32_t* __restrict__ row_off, uint32_t* __restrict__ row_items, uint32_t item_cap,
+                                                      uint32_t* __restrict__ overflow) {
+    extern __shared__ uint32_t s_dyn[];
     const int rows0 = pv.rows[0];
-    for (int row = max(min_r, 0); row <= min(max_r, rows0 - 1); ++row) {
-        if (FILL) {
-            const uint32_t pos = atomicAdd(&cursor[row], 1u);
-            if (pos < item_cap) row_items[pos] = (uint32_t)i;
-            else *overflow = 1u;
-        } else {
-            atomicAdd(&row_cnt[row], 1u);
-        }
-    }
-}
-
-// exclusive scan of counts[n] into offsets[n + 1], and a copy of the offsets as fill cursors (one workgroup)
-__global__ __launch_bounds__(1024) void k_stereo_scan(const uint32_t* __restrict__ counts, int n, uint32_t* __restrict__ offsets,
-                                                     uint32_t* __restrict__ cursor) {
-    __shared__ uint32_t s_part[1024];
+    uint32_t* const s_row = s_dyn;               // [rows0 + 1]
+    uint32_t* const s_part = s_dyn + rows0 + 1;   // [1024]
     const int tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
+    const int n = n_ptr ? *n_ptr : n_fixed;
+    for (int r = tid; r <= rows0; r += 1024) s_row[r] = 0;
+    if (tid == 0) *overflow = 0u;
+    __syncthreads();
+    auto band = [&](int i, int& lo, int& hi) {
+        const ovs_keypoint k = kps_right[i];
+        const float r = __fmul_rn(2.0f, pv.scale[k.octave]);
+        hi = min((int)ceilf(__fadd_rn(k.y, r)), rows0 - 1);
+        lo = max((int)floorf(__fsub_rn(k.y, r)), 0);
+    };
+    for (int i = tid; i < n; i += 1024) {
+        int lo, hi;
+        band(i, lo, hi);
+        for (int row = lo; row <= hi; ++row) atomicAdd(&s_row[row], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of s_row[0 .. rows0) into row_off[0 .. rows0] (and in place: the fill cursors)
+    const int per = (rows0 + 1023) / 1024;
     uint32_t local = 0;
     for (int k = 0; k < per; ++k) {
-        const int i = tid * per + k;
-        if (i < n) local += counts[i];
+        const int r = tid * per + k;
+        if (r < rows0) local += s_row[r];
     }
     s_part[tid] = local;
     __syncthreads();
@@ -62,14 +64,25 @@ __global__ __launch_bounds__(1024) void k_stereo_scan(const uint32_t* __restrict
     }
     uint32_t run = s_part[tid] - local;
     for (int k = 0; k < per; ++k) {
-        const int i = tid * per + k;
-        if (i < n) {
-            offsets[i] = run;
-            cursor[i] = run;
-            run += counts[i];
+        const int r = tid * per + k;
+        if (r < rows0) {
+            const uint32_t c = s_row[r];
+            row_off[r] = run;
+            s_row[r] = run;
+            run += c;
         }
     }
-    if (tid == 1023) offsets[n] = s_part[1023];
+    if (tid == 1023) row_off[rows0] = s_part[1023];
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        int lo, hi;
+        band(i, lo, hi);
+        for (int row = lo; row <= hi; ++row) {
+            const uint32_t pos = atomicAdd(&s_row[row], 1u);
+            if (pos < item_cap) row_items[pos] = (uint32_t)i;
+            else *overflow = 1u;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_stereo_match(const ovs_keypoint* __restrict__ kps_left, const uint8_t* __restrict__ desc_left,
@@ -270,9 +283,7 @@ struct ovs_stereo {
     int max_rows = 0, max_kps = 0;
     uint32_t item_cap = 0;
     hipStream_t stream = nullptr;
-    uint32_t* d_row_cnt = nullptr;
     uint32_t* d_row_off = nullptr;
-    uint32_t* d_cursor = nullptr;
     uint32_t* d_row_items = nullptr;
     uint32_t* d_overflow = nullptr;
     int32_t* d_best_right = nullptr;
@@ -285,6 +296,10 @@ struct ovs_stereo {
     uint8_t* d_desc_r = nullptr;
     float* d_x_right = nullptr;
     float* d_depths = nullptr;
+    // n_valid | overflow | pad | x_right[max_kps] | depths[max_kps] in ONE device block with a pinned mirror: one copy brings a call's
+    // results back (d_n_valid, d_overflow, d_x_right, d_depths point into it)
+    uint8_t* d_res = nullptr;
+    uint8_t* h_res = nullptr;
 };
 
 extern "C" {
@@ -313,20 +328,20 @@ ovs_status ovs_stereo_create(int32_t max_rows, int32_t max_keypoints, int32_t de
     CREATE_TRY(hipSetDevice(device));
     CREATE_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     const size_t R = (size_t)max_rows + 1, K = (size_t)max_keypoints;
-    CREATE_TRY(hipMalloc(&s->d_row_cnt, sizeof(uint32_t) * R));
     CREATE_TRY(hipMalloc(&s->d_row_off, sizeof(uint32_t) * R));
-    CREATE_TRY(hipMalloc(&s->d_cursor, sizeof(uint32_t) * R));
     CREATE_TRY(hipMalloc(&s->d_row_items, sizeof(uint32_t) * s->item_cap));
-    CREATE_TRY(hipMalloc(&s->d_overflow, sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&s->d_best_right, sizeof(int32_t) * K));
     CREATE_TRY(hipMalloc(&s->d_sad, sizeof(int32_t) * K));
-    CREATE_TRY(hipMalloc(&s->d_n_valid, sizeof(int32_t)));
     CREATE_TRY(hipMalloc(&s->d_kps_l, sizeof(ovs_keypoint) * K));
     CREATE_TRY(hipMalloc(&s->d_kps_r, sizeof(ovs_keypoint) * K));
     CREATE_TRY(hipMalloc(&s->d_desc_l, 32 * K));
     CREATE_TRY(hipMalloc(&s->d_desc_r, 32 * K));
-    CREATE_TRY(hipMalloc(&s->d_x_right, sizeof(float) * K));
-    CREATE_TRY(hipMalloc(&s->d_depths, sizeof(float) * K));
+    CREATE_TRY(hipMalloc(&s->d_res, 16 + 2 * sizeof(float) * K));
+    CREATE_TRY(hipHostMalloc(&s->h_res, 16 + 2 * sizeof(float) * K, hipHostMallocDefault));
+    s->d_n_valid = reinterpret_cast<int32_t*>(s->d_res);
+    s->d_overflow = reinterpret_cast<uint32_t*>(s->d_res + 4);
+    s->d_x_right = reinterpret_cast<float*>(s->d_res + 16);
+    s->d_depths = s->d_x_right + K;
 #undef CREATE_TRY
     *out = s;
     return OVS_OK;
@@ -335,9 +350,9 @@ ovs_status ovs_stereo_create(int32_t max_rows, int32_t max_keypoints, int32_t de
 ovs_status ovs_stereo_destroy(ovs_stereo* s) {
     if (!s) return OVS_OK;
     if (s->stream) hipStreamSynchronize(s->stream);
-    void* ptrs[] = {s->d_row_cnt, s->d_row_off, s->d_cursor, s->d_row_items, s->d_overflow, s->d_best_right, s->d_sad,
-                    s->d_n_valid, s->d_kps_l,   s->d_kps_r,  s->d_desc_l,    s->d_desc_r,   s->d_x_right,    s->d_depths};
+    void* ptrs[] = {s->d_row_off, s->d_row_items, s->d_best_right, s->d_sad, s->d_kps_l, s->d_kps_r, s->d_desc_l, s->d_desc_r, s->d_res};
     for (void* p : ptrs) hipFree(p);
+    if (s->h_res) hipHostFree(s->h_res);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
     return OVS_OK;
@@ -361,14 +376,9 @@ ovs_status ovs_stereo_compute_dev(ovs_stereo* s, const ovs_orb* left, int32_t fr
     hipStream_t st = (hipStream_t)stream;
     const int rows0 = pl.rows[0];
     const float max_disp = focal_x_baseline / true_baseline;
-    OVS_HIP_TRY(hipMemsetAsync(s->d_row_cnt, 0, sizeof(uint32_t) * (rows0 + 1), st));
-    OVS_HIP_TRY(hipMemsetAsync(s->d_overflow, 0, sizeof(uint32_t), st));
-    const dim3 gr((cap_right + 255) / 256), gl((cap_left + 255) / 256);
-    hipLaunchKernelGGL(k_stereo_rows<false>, gr, dim3(256), 0, st, d_kps_right, d_n_right, cap_right, pr, s->d_row_cnt, s->d_cursor,
-                       s->d_row_items, s->item_cap, s->d_overflow);
-    hipLaunchKernelGGL(k_stereo_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)s->d_row_cnt, rows0, s->d_row_off, s->d_cursor);
-    hipLaunchKernelGGL(k_stereo_rows<true>, gr, dim3(256), 0, st, d_kps_right, d_n_right, cap_right, pr, s->d_row_cnt, s->d_cursor,
-                       s->d_row_items, s->item_cap, s->d_overflow);
+    const dim3 gl((cap_left + 255) / 256);
+    hipLaunchKernelGGL(k_stereo_index, dim3(1), dim3(1024), sizeof(uint32_t) * (size_t)(rows0 + 1 + 1024), st, d_kps_right, d_n_right, cap_right, pr,
+                       s->d_row_off, s->d_row_items, s->item_cap, s->d_overflow);
     hipLaunchKernelGGL(k_stereo_match, gl, dim3(256), 0, st, d_kps_left, d_desc_left, d_n_left, cap_left, d_kps_right, d_desc_right, pr,
                        (const uint32_t*)s->d_row_off, (const uint32_t*)s->d_row_items, s->item_cap, max_disp, s->d_best_right);
     hipLaunchKernelGGL(k_stereo_subpixel, dim3((cap_left + 15) / 16), dim3(256), 0, st, d_kps_left, d_n_left, cap_left, d_kps_right,
@@ -415,13 +425,16 @@ ovs_status ovs_stereo_compute(ovs_stereo* s, const ovs_orb* left, const ovs_orb*
     ovs_status rc = ovs_stereo_compute_dev(s, left, 0, right, 0, dkl, ddl, nullptr, n_left, dkr, ddr, nullptr, n_right, focal_x_baseline,
                                            true_baseline, s->d_x_right, s->d_depths, s->d_n_valid, st);
     if (rc != OVS_OK) return rc;
-    uint32_t overflow = 0;
-    int32_t nv = 0;
-    OVS_HIP_TRY(hipMemcpyAsync(stereo_x_right, s->d_x_right, sizeof(float) * n_left, hipMemcpyDeviceToHost, st));
-    OVS_HIP_TRY(hipMemcpyAsync(depths, s->d_depths, sizeof(float) * n_left, hipMemcpyDeviceToHost, st));
-    OVS_HIP_TRY(hipMemcpyAsync(&nv, s->d_n_valid, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    OVS_HIP_TRY(hipMemcpyAsync(&overflow, s->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    // one copy for [n_valid | overflow | x_right (whole region) | depths of the first n_left] into the pinned mirror, one wait
+    const size_t off_depths = 16 + sizeof(float) * (size_t)s->max_kps, bytes = off_depths + sizeof(float) * (size_t)n_left;
+    OVS_HIP_TRY(hipMemcpyAsync(s->h_res, s->d_res, bytes, hipMemcpyDeviceToHost, st));
     OVS_HIP_TRY(hipStreamSynchronize(st));
+    std::memcpy(stereo_x_right, s->h_res + 16, sizeof(float) * (size_t)n_left);
+    std::memcpy(depths, s->h_res + off_depths, sizeof(float) * (size_t)n_left);
+    int32_t nv;
+    uint32_t overflow;
+    std::memcpy(&nv, s->h_res, sizeof(nv));
+    std::memcpy(&overflow, s->h_res + 4, sizeof(overflow));
     if (n_valid) *n_valid = nv;
     return overflow ? OVS_ERR_CAPACITY : OVS_OK;
 }
