@@ -225,6 +225,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
     __shared__ double s_part[kPoseWaves][28];
     extern __shared__ __attribute__((aligned(16))) double s_red[];   // [28 * kRedPitch]: the linearisation's block reduction (dynamic: 116 KB at 512 threads)
     __shared__ double s_sum[28];
+    __shared__ double s_sys[28];   // the current iteration's system (copied from s_sum, which the trial reductions overwrite)
     __shared__ PoseD s_T, s_Tn;
     __shared__ double s_ctl[4];   // [0] = continue trials of this iteration, [1] = continue iterations of this round
     __shared__ int s_cnt[kPoseWaves];
@@ -294,50 +295,59 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
             const bool robust = trial < 3;
             double lambda = 0, ni = 2;   // held identically by every thread (all control flow below is workgroup-uniform)
             bool err_at_trial = false;   // active edges' errors were last computed at s_Tn (g2o leaves them stale after a rejected step)
-            for (int it = 0; it < 10; ++it) {
-                err_at_trial = false;    // solve() starts with computeActiveErrors() at the current estimate
-                // ---- linearise at s_T
+            // An iteration's FIRST trial evaluates the whole system at the trial state, not just its chi2: when the step is accepted -- the
+            // common case -- that IS the next iteration's linearisation (same state, same operations, same bits), which then starts without a
+            // pass over the observations and without its reduction. Retries after a rejection evaluate chi2 only.
+            bool have_lin = false;       // s_sum holds the system at s_T
+            auto linearise_at = [&](bool at_trial) __attribute__((always_inline)) {   // state s_Tn / s_T -> s_sum[0 .. 27] (H upper triangle, b, robust chi2)
                 double acc[28];
 #pragma unroll
                 for (int i = 0; i < 28; ++i) acc[i] = 0;
-                {
-                    double R[9], t[3];
-                    for (int i = 0; i < 9; ++i) R[i] = s_T.R[i];
-                    for (int i = 0; i < 3; ++i) t[i] = s_T.t[i];
-                    for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k)
-                        if ((active >> k) & 1u) {
-                            const ovs_pose_obs o = obs[i];
-                            pose_edge<MODEL>(R, t, o, cam, bf, robust ? huber : 0.0, acc);
-                        }
-                }
+                double R[9], t[3];
+                for (int i = 0; i < 9; ++i) R[i] = at_trial ? s_Tn.R[i] : s_T.R[i];
+                for (int i = 0; i < 3; ++i) t[i] = at_trial ? s_Tn.t[i] : s_T.t[i];
+                for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k)
+                    if ((active >> k) & 1u) {
+                        const ovs_pose_obs o = obs[i];
+                        pose_edge<MODEL>(R, t, o, cam, bf, robust ? huber : 0.0, acc);
+                    }
 #pragma unroll
                 for (int i = 0; i < 28; ++i) s_red[i * kRedPitch + tid] = acc[i];
                 reduce28_finish();
-                double H[36], b[6];
-                {
-                    int k = 0;
-                    for (int a = 0; a < 6; ++a)
-                        for (int c = a; c < 6; ++c) {
-                            H[6 * a + c] = s_sum[k];
-                            H[6 * c + a] = s_sum[k];
-                            ++k;
-                        }
-                    for (int a = 0; a < 6; ++a) b[a] = s_sum[21 + a];
-                }
+            };
+            for (int it = 0; it < 10; ++it) {
+                err_at_trial = false;    // solve() starts with computeActiveErrors() at the current estimate
+                if (!have_lin) linearise_at(false);
+                have_lin = false;
+                // the system stays in LDS (s_sys: H upper triangle row-major, b, chi2): only thread 0 needs it, for the solve, and 42 doubles
+                // held by every thread across the trial's linearisation would not fit the register file of a 512-thread workgroup
                 double current_chi = s_sum[27];
-                __syncthreads();   // s_sum is rewritten by the trial reductions below
+                if (tid < 28) s_sys[tid] = s_sum[tid];
                 if (it == 0) {
                     double max_diag = 0;
-                    for (int j = 0; j < 6; ++j) max_diag = fmax(fabs(H[7 * j]), max_diag);
+                    const int dg[6] = {0, 6, 11, 15, 18, 20};   // (a, a) in the packed upper triangle
+                    for (int j = 0; j < 6; ++j) max_diag = fmax(fabs(s_sum[dg[j]]), max_diag);
                     lambda = 1e-5 * max_diag;
                     ni = 2;
                 }
+                __syncthreads();   // s_sum is rewritten by the trial reductions below
                 double rho = 0;
                 int qmax = 0;
                 do {
                     // thread 0: solve, trial pose
                     double dx[6] = {0, 0, 0, 0, 0, 0};
                     if (tid == 0) {
+                        double H[36], b[6];
+                        {
+                            int k = 0;
+                            for (int a = 0; a < 6; ++a)
+                                for (int c = a; c < 6; ++c) {
+                                    H[6 * a + c] = s_sys[k];
+                                    H[6 * c + a] = s_sys[k];
+                                    ++k;
+                                }
+                            for (int a = 0; a < 6; ++a) b[a] = s_sys[21 + a];
+                        }
                         const bool ok = solve6_d(H, lambda, b, dx);
                         if (ok) {
                             PoseD E;
@@ -354,7 +364,12 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                     const bool ok = s_ctl[0] != 0.0;
                     const double scale = s_ctl[1];
                     double temp_chi = 1.7976931348623157e308;
-                    if (ok) {
+                    const bool full = ok && qmax == 0;   // (workgroup-uniform)
+                    if (full) {
+                        linearise_at(true);
+                        temp_chi = s_sum[27];
+                        err_at_trial = true;
+                    } else if (ok) {
                         double R[9], t[3];
                         for (int i = 0; i < 9; ++i) R[i] = s_Tn.R[i];
                         for (int i = 0; i < 3; ++i) t[i] = s_Tn.t[i];
@@ -381,6 +396,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                         ni = 2;
                         current_chi = temp_chi;
                         if (tid == 0) s_T = s_Tn;
+                        have_lin = full;   // the system just evaluated at s_Tn is the one the next iteration needs
                     } else {
                         lambda *= ni;
                         ni *= 2;
@@ -533,9 +549,10 @@ static ovs_status pose_optimize_host(int model, int32_t device, const double* po
     std::memcpy(h + off_off, offs, sizeof(offs));
     if (n_obs) std::memcpy(h + off_obs, obs, sizeof(ovs_pose_obs) * (size_t)n_obs);
     OVS_HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, scratch.stream));
-    // one latency-bound workgroup: 512 threads hide the f64 latency of the per-observation work when there is enough of it (2000
-    // observations 0.74 -> 0.68 ms perspective, 1.63 -> 1.32 ms equirectangular; 500 observations: 0.43 -> 0.47 / 0.78 -> 0.68)
-    const int threads = (model == 1 || n_obs >= 1024) ? 512 : 256;
+    // one latency-bound workgroup: 512 threads hide the f64 latency of the per-observation work when there is enough of it; measured,
+    // 256 / 512 threads: perspective 2000 observations 0.509 / 0.512 ms, 1000: 0.438 / 0.422, 500: 0.286 / 0.293; equirectangular
+    // 2000: 1.39 / 1.15, 1000: 0.759 / 0.786, 500: 0.427 / 0.588
+    const int threads = (model == 1 ? n_obs >= 1500 : n_obs >= 768) ? 512 : 256;
     const ovs_status st = pose_optimize_batch_dev(model, reinterpret_cast<double*>(d), reinterpret_cast<ovs_pose_obs*>(d + off_obs),
                                                   reinterpret_cast<int32_t*>(d + off_off), 1, *cam, focal_x_baseline, setup_type,
                                                   reinterpret_cast<double*>(d + off_out), d + off_fl, reinterpret_cast<int32_t*>(d + off_nv),

@@ -516,7 +516,8 @@ def test_pose_optimizer_class_per_camera_model(oracle, tmp_path, model):
         wT, wout, wnv = oracle.pose_optimize_equirect(T0, obs, int(camv[0]), int(camv[1]))
     else:
         wT, wout, wnv = oracle.pose_optimize(T0, obs, camv, 0.0)
-    assert np.allclose(T[:3], wT, rtol=0, atol=1e-9) and np.array_equal(T[3], [0, 0, 0, 1])
+    # 2e-8 on the equirectangular model: the oracle's own sensitivity to summation order (tests/test_ba.py::test_pose_oracle_order_sensitivity)
+    assert np.allclose(T[:3], wT, rtol=0, atol=2e-8 if model == 2 else 1e-9) and np.array_equal(T[3], [0, 0, 0, 1])
     assert nv == wnv and np.array_equal(flags, wout) and wnv > 600
 
 
