@@ -16,6 +16,8 @@
 
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "ovs_common.h"
 
 namespace ovs {
@@ -148,15 +150,17 @@ __device__ __forceinline__ double pose_edge_equirect(const double* R, const doub
     return c2;
 }
 
-template <int MODEL>
-__device__ __forceinline__ double pose_edge(const double* R, const double* t, const ovs_pose_obs& o, const ovs_ba_cam& cam, double bf,
-                                            double delta, double* acc) {
+// STEREO = false: the frame holds no stereo observation (every monocular frame), so the third residual row is not even evaluated under a
+// false predicate -- hipcc if-converts `if (st)` into ~100 unconditional instructions plus 28 selects per observation, a third of the edge
+template <int MODEL, bool STEREO>
+__device__ __forceinline__ double pose_edge_impl(const double* R, const double* t, const ovs_pose_obs& o, const ovs_ba_cam& cam, double bf,
+                                                 double delta, double* acc) {
     if (MODEL == 1) return pose_edge_equirect(R, t, o, cam, delta, acc);
     const double x = ((R[0] * o.pos_w[0] + R[1] * o.pos_w[1]) + R[2] * o.pos_w[2]) + t[0];
     const double y = ((R[3] * o.pos_w[0] + R[4] * o.pos_w[1]) + R[5] * o.pos_w[2]) + t[1];
     const double z = ((R[6] * o.pos_w[0] + R[7] * o.pos_w[1]) + R[8] * o.pos_w[2]) + t[2];
     const double invz = 1.0 / z, invz2 = invz * invz;
-    const bool st = o.is_stereo != 0;
+    const bool st = STEREO && o.is_stereo != 0;
     const double u = cam.fx * x * invz + cam.cx;
     const double e0 = o.obs_x - u;
     const double e1 = o.obs_y - (cam.fy * y * invz + cam.cy);
@@ -255,9 +259,19 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
         if (tid < 28 * 8) {
             const int i = tid >> 3, part = tid & 7;
             const double* row = s_red + i * kRedPitch + part;
-            double s = row[0];
+            // sixteen LDS reads in flight per batch: left to itself hipcc (at the 256-register ceiling of the 512-thread build) reused one
+            // register pair for every read, i.e. 32 dependent LDS round trips -- 8 960 cycles per reduction, a quarter of the kernel
+            double s = 0;
 #pragma unroll
-            for (int k = 1; k < kPoseThreads / 8; ++k) s += row[8 * k];
+            for (int k0 = 0; k0 < kPoseThreads / 8; k0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = row[8 * (k0 + u)];
+                asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                             "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s = (k0 + u == 0) ? v[u] : s + v[u];   // (the same order as ever: columns part, part + 8, ...)
+            }
             s += __shfl_xor(s, 1);
             s += __shfl_xor(s, 2);
             s += __shfl_xor(s, 4);
@@ -284,7 +298,12 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
     for (int i = 0; i < 9; ++i) T0.R[i] = poses_in[12 * (size_t)p + i];
     for (int i = 0; i < 3; ++i) T0.t[i] = poses_in[12 * (size_t)p + 9 + i];
     uint32_t active = 0xFFFFFFFFu;   // bit k <-> observation tid + kPoseThreads * k
-    for (int i = tid; i < n; i += kPoseThreads) outlier[i] = 0;
+    int st_any = 0;
+    for (int i = tid; i < n; i += kPoseThreads) {
+        outlier[i] = 0;
+        if (MODEL == 0) st_any |= obs[i].is_stereo;
+    }
+    const bool has_stereo = MODEL == 0 && __builtin_amdgcn_readfirstlane(__syncthreads_or(st_any)) != 0;
     if (tid == 0) s_T = T0;
     __syncthreads();
     int num_bad = 0;
@@ -306,11 +325,15 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                 double R[9], t[3];
                 for (int i = 0; i < 9; ++i) R[i] = at_trial ? s_Tn.R[i] : s_T.R[i];
                 for (int i = 0; i < 3; ++i) t[i] = at_trial ? s_Tn.t[i] : s_T.t[i];
-                for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k)
-                    if ((active >> k) & 1u) {
-                        const ovs_pose_obs o = obs[i];
-                        pose_edge<MODEL>(R, t, o, cam, bf, robust ? huber : 0.0, acc);
-                    }
+                auto sweep = [&](auto stereo_tag) __attribute__((always_inline)) {
+                    for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k)
+                        if ((active >> k) & 1u) {
+                            const ovs_pose_obs o = obs[i];
+                            pose_edge_impl<MODEL, decltype(stereo_tag)::value>(R, t, o, cam, bf, robust ? huber : 0.0, acc);
+                        }
+                };
+                if (has_stereo) sweep(std::true_type{});   // (workgroup-uniform)
+                else sweep(std::false_type{});
 #pragma unroll
                 for (int i = 0; i < 28; ++i) s_red[i * kRedPitch + tid] = acc[i];
                 reduce28_finish();
@@ -374,15 +397,19 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                         for (int i = 0; i < 9; ++i) R[i] = s_Tn.R[i];
                         for (int i = 0; i < 3; ++i) t[i] = s_Tn.t[i];
                         double part = 0;
-                        for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k)
-                            if ((active >> k) & 1u) {
-                                const ovs_pose_obs o = obs[i];
-                                const double c2 = pose_edge<MODEL>(R, t, o, cam, bf, 0.0, nullptr);
-                                const double delta = robust ? huber : 0.0;
-                                double r = c2;
-                                if (delta > 0 && c2 > delta * delta) r = 2 * sqrt(c2) * delta - delta * delta;
-                                part += r;
-                            }
+                        auto sweep = [&](auto stereo_tag) __attribute__((always_inline)) {
+                            for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k)
+                                if ((active >> k) & 1u) {
+                                    const ovs_pose_obs o = obs[i];
+                                    const double c2 = pose_edge_impl<MODEL, decltype(stereo_tag)::value>(R, t, o, cam, bf, 0.0, nullptr);
+                                    const double delta = robust ? huber : 0.0;
+                                    double r = c2;
+                                    if (delta > 0 && c2 > delta * delta) r = 2 * sqrt(c2) * delta - delta * delta;
+                                    part += r;
+                                }
+                        };
+                        if (has_stereo) sweep(std::true_type{});
+                        else sweep(std::false_type{});
                         reduce(&part, 1);
                         temp_chi = s_sum[0];
                         err_at_trial = true;
@@ -421,7 +448,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                 for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k) {
                     const ovs_pose_obs o = obs[i];
                     const bool wa = (was_active >> k) & 1u;
-                    const double c2 = pose_edge<MODEL>(wa ? Re : R, wa ? te : t, o, cam, bf, 0.0, nullptr);
+                    const double c2 = pose_edge_impl<MODEL, true>(wa ? Re : R, wa ? te : t, o, cam, bf, 0.0, nullptr);
                     const bool out = ((MODEL == 0 && o.is_stereo) ? kChi3D : kChi2D) < c2;
                     outlier[i] = out ? 1 : 0;
                     if (out) ++bad;
