@@ -629,10 +629,16 @@ __device__ __forceinline__ bool rule_accepts(uint32_t best, uint32_t second, flo
     return !(__fmul_rn((float)sd, ratio) < (float)bd);   // area: second * ratio < best; bow: ratio * second < best (same product)
 }
 
-// NW waves replay 64 * NW queries per round. The decision rule is the single-wave one with "lane" read as "thread": a thread is
-// affected if a LOWER thread of the round stamps one of the two targets its decision rests on, every thread below the first affected one
-// commits. With NW > 1 the waves meet at three LDS-only workgroup barriers per round; the rounds are dependent LDS latency either way, so
-// a round of 256 queries costs little more than a round of 64 and a 10 000-landmark problem needs a quarter of the rounds.
+// NW waves replay 64 * NW queries per round. A pending query evaluates (best, second) against the current claims and stamps EVERY live
+// candidate of its list with its thread index (LDS atomicMin, epoch-tagged). It is AFFECTED if a lower thread of the round stamped its best
+// (or, where the rule has a ratio test, its second): some earlier, still undecided query has that target in its list, so it could still
+// claim it -- or could still come to look at it, which is why the stamps cover all live candidates and not just the claimable ones: an
+// early commit must not change what an earlier query sees when it evaluates again. An unaffected query is final whatever the others do
+// (candidate sets only shrink), so EVERY unaffected query of the round commits -- round 2 committed only the ones below the first affected
+// thread, and one cluster of neighbours sharing a target held the whole batch back (~6 rounds per 256 tracked-frame queries). The lowest
+// pending query is never affected, so each round makes progress; the number of rounds is the longest chain of queries sharing candidates.
+// tests/test_resolver_rule.py is the executable statement of this rule against the sequential loops (and of why the stamps must cover
+// every live candidate). With NW > 1 the waves meet at two LDS-only workgroup barriers per round.
 template <int RULE, int NW>
 __global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_res[];
@@ -731,6 +737,10 @@ __global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
                     for (int u = 0; u < 8; ++u) {
                         const uint32_t e = e8[u], d = e >> 20;
                         if (e == kNone || !(d < t8[u])) continue;   // claimed / matched at a distance <= ours
+                        // every live candidate, whatever its distance: a later query must neither rest on a target this one may still
+                        // claim nor claim a target this one may still come to look at
+                        __hip_atomic_fetch_min((__attribute__((address_space(3))) uint32_t*)&mark[(e & 0xFFFFu) & (kMarkSize - 1)],
+                                               tag | (uint32_t)tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (d < bd) {
                             second = best;
                             sd = bd;
@@ -743,36 +753,18 @@ __global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
                     }
                 }
                 acc = rule_accepts<RULE>(best, second, a.lowe_ratio, a.best_only_thr);
-                if (acc)
-                    __hip_atomic_fetch_min((__attribute__((address_space(3))) uint32_t*)&mark[(best & 0xFFFFu) & (kMarkSize - 1)],
-                                           tag | (uint32_t)tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             wg_barrier();
             bool affected = false;
             if (pending && best != kNone && (best >> 20) <= max_d) {   // a best beyond the threshold is a final reject (it can only grow)
                 const uint32_t m1 = mark[(best & 0xFFFFu) & (kMarkSize - 1)];
                 affected = (m1 & ~0x3FFu) == tag && (m1 & 0x3FFu) < (uint32_t)tid;
-                if (second != kNone) {
+                if (RULE != kRuleBestOnly && RULE != kRuleTriang && second != kNone) {   // (no ratio test: the decision rests on `best` alone)
                     const uint32_t m2 = mark[(second & 0xFFFFu) & (kMarkSize - 1)];
                     affected |= (m2 & ~0x3FFu) == tag && (m2 & 0x3FFu) < (uint32_t)tid;
                 }
             }
-            // ---- first affected thread of the workgroup
-            int f;
-            {
-                const unsigned long long aff = __ballot(affected && pending);
-                const int fw = aff ? (wv * 64 + __ffsll((long long)aff) - 1) : T;
-                if (NW == 1) {
-                    f = fw;
-                } else {
-                    if (lane == 0) s_first[wv] = (uint32_t)fw;
-                    wg_barrier();
-                    f = T;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) f = min(f, (int)s_first[w]);
-                }
-            }
-            if (pending && tid < f && acc) {
+            if (pending && !affected && acc) {
                 const uint32_t t = best & 0xFFFFu;
                 if (RULE == kRuleArea) {
                     const uint32_t prev = owner[t];
@@ -785,7 +777,7 @@ __global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
                 match[q] = (uint16_t)t;
                 accepted[q] = (uint16_t)t;
             }
-            if (tid < f) pending = false;
+            if (!affected) pending = false;
             if (NW == 1) __builtin_amdgcn_wave_barrier();   // NW > 1: the barrier at the top of the loop publishes the commits
         }
     }

@@ -1,0 +1,114 @@
+"""The parallel commit rule of k_list_resolve (openvslam_amd/csrc/match_window.hip) as an executable model, checked against the
+sequential loops it replaces (match::projection / area / bow_tree: a query sees the targets earlier queries claimed).
+
+Rule: in a round every pending query evaluates (best, second) against the current claims and stamps every LIVE candidate of its list with
+its own index (minimum wins); a query is affected if a lower pending query stamped its best (or its second, where the rule has a ratio
+test); every unaffected query commits. The second model below stamps only the candidates a query could still CLAIM (distance within the
+rule's threshold) -- tempting, and wrong: a later query then commits a target that an earlier, still pending query has yet to look at
+again (as its second-best), so the test also pins that this variant does differ from the sequential result."""
+import numpy as np
+
+MAXD = 256
+
+
+def _accepts(rule, bd, sd, ratio):
+    if rule == "best_only":               # match_current_and_last_frames: no ratio test
+        return bd <= 100
+    if bd > 50:
+        return False
+    return not (np.float32(ratio) * np.float32(sd) < np.float32(bd))
+
+
+def _evaluate(cands, thr):
+    best = second = None
+    bd = sd = MAXD
+    for d, t in cands:
+        if not d < thr[t]:                # claimed (thr 0) or, area, matched at a distance <= ours
+            continue
+        if d < bd:
+            second, sd, best, bd = best, bd, (d, t), d
+        elif d < sd:
+            second, sd = (d, t), d
+    return best, second, bd, sd
+
+
+def _commit(rule, q, best, thr, owner, match):
+    t = best[1]
+    if rule == "area":                    # a closer later query steals the target; the earlier owner loses it
+        if owner[t] is not None:
+            match.pop(owner[t], None)
+        owner[t] = q
+        thr[t] = best[0]
+    else:
+        thr[t] = 0
+    match[q] = t
+
+
+def sequential(rule, lists, n_t, ratio):
+    thr, owner, match = [MAXD] * n_t, [None] * n_t, {}
+    for q, cands in enumerate(lists):
+        best, second, bd, sd = _evaluate(cands, thr)
+        if best is not None and _accepts(rule, bd, sd, ratio):
+            _commit(rule, q, best, thr, owner, match)
+    return match
+
+
+def parallel(rule, lists, n_t, ratio, batch, max_d, stamp_claimable_only=False):
+    thr, owner, match, rounds = [MAXD] * n_t, [None] * n_t, {}, 0
+    for q0 in range(0, len(lists), batch):
+        pending = {q for q in range(q0, min(q0 + batch, len(lists))) if lists[q]}
+        while pending:
+            rounds += 1
+            mark, ev = {}, {}
+            for q in sorted(pending):
+                for d, t in lists[q]:
+                    if d < thr[t] and (d <= max_d or not stamp_claimable_only):
+                        mark[t] = min(mark.get(t, 1 << 30), q)
+                ev[q] = _evaluate(lists[q], thr)
+            still, commits = set(), []
+            for q in sorted(pending):
+                best, second, bd, sd = ev[q]
+                affected = False
+                if best is not None and bd <= max_d:      # a best beyond the threshold is a final reject: it can only grow
+                    affected = mark.get(best[1], 1 << 30) < q
+                    if rule != "best_only" and second is not None:
+                        affected = affected or mark.get(second[1], 1 << 30) < q
+                if affected:
+                    still.add(q)
+                elif best is not None and _accepts(rule, bd, sd, ratio):
+                    commits.append((q, best))
+            assert len(still) < len(pending)              # the lowest pending query is never affected
+            for q, best in commits:
+                _commit(rule, q, best, thr, owner, match)
+            pending = still
+    return match, rounds
+
+
+def _random_problem(rng):
+    n_t, n_q = int(rng.integers(5, 80)), int(rng.integers(5, 120))
+    lists = []
+    for _ in range(n_q):
+        k = int(rng.integers(0, 8))
+        ts = rng.choice(n_t, size=min(k, n_t), replace=False)
+        lists.append([(int(rng.integers(0, 130)), int(t)) for t in ts])
+    return lists, n_t, float(rng.choice([0.6, 0.8, 0.9, 1.0])), int(rng.choice([16, 64]))
+
+
+def test_parallel_rule_equals_the_sequential_loops():
+    rng = np.random.default_rng(1)
+    for rule, max_d in (("bow", 50), ("area", 50), ("best_only", 100)):
+        for _ in range(700):
+            lists, n_t, ratio, batch = _random_problem(rng)
+            got, rounds = parallel(rule, lists, n_t, ratio, batch, max_d)
+            assert got == sequential(rule, lists, n_t, ratio)
+            assert rounds <= len(lists) + len(lists) // batch + 1
+
+
+def test_stamping_only_claimable_candidates_is_not_exact():
+    rng = np.random.default_rng(0)
+    differs = 0
+    for _ in range(300):
+        lists, n_t, ratio, batch = _random_problem(rng)
+        got, _ = parallel("bow", lists, n_t, ratio, batch, 50, stamp_claimable_only=True)
+        differs += got != sequential("bow", lists, n_t, ratio)
+    assert differs > 0
