@@ -28,6 +28,21 @@ LOWE_RATIO = 0.9
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 
 
+
+PMC_STAGE_SOURCES = {"fast": ("orb_fast.hip",), "pyramid": ("orb_pyramid.hip",), "tree": ("orb_tree.hip",),
+                     "describe": ("orb_describe.hip", "orb_pattern.inc"), "match_near": ("match_hamming.hip",),
+                     "match_resolve": ("match_hamming.hip",)}
+
+
+def pmc_stage_fingerprint(src_dir, stage, read=None):
+    """sha256[:16] of the sources a stage's kernels are compiled from: its .hip file(s) and the shared headers of csrc/."""
+    import hashlib
+    read = read or (lambda fn: open(os.path.join(src_dir, fn), "rb").read())
+    hsh = hashlib.sha256()
+    for fn in sorted(set(PMC_STAGE_SOURCES[stage]) | {f for f in os.listdir(src_dir) if f.endswith(".h")}):
+        hsh.update(fn.encode() + b"\0" + read(fn))
+    return hsh.hexdigest()[:16]
+
 def level_sizes(rows, cols, scale=1.2, levels=8):
     sf = np.float32(1.0)
     out = [(rows, cols)]
@@ -327,16 +342,14 @@ def main():
         if os.path.exists(tpath):
             try:
                 pmc = json.load(open(tpath))
-                # the counters describe the kernels they were collected from: a summary older than the current kernel sources is refused
-                import hashlib
-                hsh = hashlib.sha256()
+                # the counters describe the kernels they were collected from: a stage's figure is refused when the sources of that stage's
+                # kernels (its .hip file + the shared headers) have changed since (per stage: a matcher edit does not age the FAST counters)
                 src_dir = os.path.join(ROOT, "openvslam_amd", "csrc")
-                for fn in sorted(os.listdir(src_dir)):
-                    if fn.endswith((".h", ".inc")) or fn.startswith(("orb_", "match_hamming")):   # the kernels the traffic file covers (extraction, brute-force matcher) and the shared headers
-                        hsh.update(open(os.path.join(src_dir, fn), "rb").read())
-                if pmc.get("csrc_sha16") != hsh.hexdigest()[:16]:
-                    pmc_stale = "profiles/pmc_traffic.json was collected from other kernel sources (csrc fingerprint %s, now %s): re-run tools/gpu_pmc.sh" % (
-                        pmc.get("csrc_sha16"), hsh.hexdigest()[:16])
+                by_stage = pmc.get("csrc_sha16_by_stage", {})
+                now = pmc_stage_fingerprint(src_dir, dom)
+                if by_stage.get(dom) != now:
+                    pmc_stale = "profiles/pmc_traffic.json: the %s counters were collected from other kernel sources (fingerprint %s, now %s): re-run tools/gpu_pmc.sh" % (
+                        dom, by_stage.get(dom), now)
                     pmc = {}
                 # the PMC passes may have run at another frames-per-launch: every per-launch count here is linear in it
                 pmc_scale = Bc / float(pmc.get("batch", Bc))

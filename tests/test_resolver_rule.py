@@ -112,3 +112,4 @@ def test_stamping_only_claimable_candidates_is_not_exact():
         got, _ = parallel("bow", lists, n_t, ratio, batch, 50, stamp_claimable_only=True)
         differs += got != sequential("bow", lists, n_t, ratio)
     assert differs > 0
+

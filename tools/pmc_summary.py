@@ -7,6 +7,22 @@ import os
 import sys
 from collections import defaultdict
 
+PMC_STAGE_SOURCES = {"fast": ("orb_fast.hip",), "pyramid": ("orb_pyramid.hip",), "tree": ("orb_tree.hip",),
+                     "describe": ("orb_describe.hip", "orb_pattern.inc"), "match_near": ("match_hamming.hip",),
+                     "match_resolve": ("match_hamming.hip",)}
+
+
+def pmc_stage_fingerprint(src_dir, stage, read=None):
+    """sha256[:16] of the sources a stage's kernels are compiled from: its .hip file(s) and the shared headers of csrc/."""
+    import hashlib
+    read = read or (lambda fn: open(os.path.join(src_dir, fn), "rb").read())
+    hsh = hashlib.sha256()
+    for fn in sorted(set(PMC_STAGE_SOURCES[stage]) | {f for f in os.listdir(src_dir) if f.endswith(".h")}):
+        hsh.update(fn.encode() + b"\0" + read(fn))
+    return hsh.hexdigest()[:16]
+
+
+
 root = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> [values per dispatch]
 for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
@@ -56,14 +72,10 @@ if "--json" in sys.argv:
                 d[st] = int(sum(vals) / len(vals) * launches_per_call.get(st, 1))
         if d:
             out[key] = d
-    # fingerprint of the kernel sources the counters were collected from: bench.py refuses a traffic figure whose kernels have changed since
-    import hashlib
+    # fingerprints of the kernel sources the counters were collected from, per stage: bench.py refuses a stage's figure when that stage's
+    # sources have changed since
     src_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "openvslam_amd", "csrc")
-    hsh = hashlib.sha256()
-    for fn in sorted(os.listdir(src_dir)):
-        if fn.endswith((".h", ".inc")) or fn.startswith(("orb_", "match_hamming")):   # the kernels the traffic file covers (extraction, brute-force matcher) and the shared headers
-            hsh.update(open(os.path.join(src_dir, fn), "rb").read())
-    out["csrc_sha16"] = hsh.hexdigest()[:16]
+    out["csrc_sha16_by_stage"] = {st: pmc_stage_fingerprint(src_dir, st) for st in PMC_STAGE_SOURCES}
     if "--batch" in sys.argv:
         out["batch"] = int(sys.argv[sys.argv.index("--batch") + 1])   # frames per launch the passes ran at (bench.py scales by it)
     json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
