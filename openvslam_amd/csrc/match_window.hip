@@ -9,13 +9,13 @@
 //                      scan, fill pass): a CSR of keys  d << 20 | octave << 16 | target  in UPSTREAM'S ENUMERATION ORDER
 //                      (cells x-major, then y, then members), because strict `<` keeps the first minimum.
 //   3. k_list_resolve  upstream's loops are sequential -- a query sees the targets earlier queries claimed (M3, M7) or the
-//                      distance they were matched at (M5). One wave replays them 64 queries per round, exactly as
-//                      match_hamming.hip's resolver does: every pending lane evaluates against the current state, accepting
-//                      lanes stamp their target, the first lane whose best / second candidate a LOWER lane stamped cuts the
-//                      round, everything below it commits. State per target is ONE number, thr[t]: a candidate at distance d is
+//                      distance they were matched at (M5). A workgroup replays them 64 * NW queries per round: every pending thread
+//                      evaluates against the current state and stamps every live candidate of its list; a thread is affected if a
+//                      LOWER thread stamped the best / second candidate its decision rests on; every unaffected thread commits (the
+//                      rule is spelled out at the kernel). State per target is ONE number, thr[t]: a candidate at distance d is
 //                      alive iff d < thr[t] (256 = free, 0 = claimed, M5: the distance it is currently matched at), and thr only
-//                      ever decreases, so a decision that rests on (best, second) can only be changed by a lower lane taking
-//                      one of those two -- the argument of match_hamming.hip carries over unchanged.
+//                      ever decreases, so a decision that rests on (best, second) can only be changed by a lower thread taking
+//                      one of those two.
 //      The rotation-histogram check (match::angle_checker, 30 bins, keep the 3 fullest) runs in the same kernel.
 #include <algorithm>
 #include <cmath>

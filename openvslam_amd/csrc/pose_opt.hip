@@ -42,7 +42,8 @@ __device__ void se3_exp_d(const double* u, PoseD& out) {
     double V[9];
     const bool small = theta < 0.00001;
     // the three coefficients once (the expressions of upstream's Sophus-style exp, evaluated per matrix entry there)
-    const double sn = small ? 0.0 : sin(theta), cs = small ? 1.0 : cos(theta);
+    double sn = 0.0, cs = 1.0;
+    if (!small) sincos(theta, &sn, &cs);   // one argument reduction, one pass over the two polynomials (sin() and cos() each evaluate both)
     const double th2 = theta * theta;
     const double ka = small ? 0.0 : sn / theta, kb = small ? 0.0 : (1 - cs) / th2, kc = small ? 0.0 : (theta - sn) / (th2 * theta);
     for (int i = 0; i < 9; ++i) {
