@@ -19,6 +19,7 @@
 //      The rotation-histogram check (match::angle_checker, 30 bins, keep the 3 fullest) runs in the same kernel.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -608,6 +609,7 @@ struct ResolveArgs {
     float* prev_matched_xy;       // area: updated for the final matches
     int32_t* assigned;            // projection / area: [n_q] target or -1; bow: [n_t] keyframe keypoint index or -1
     uint32_t key_pool;            // LDS words available for a copy of the key CSR
+    int offsets_in_lds;           // the list bounds are staged in LDS (room for n_q + 1 words before the key pool)
     uint32_t best_only_thr;       // BestOnly: accept iff best <= this (match_current_and_last_frames: THR_HIGH)
     int bow_by_query;             // bow (match_keyframes): output [n_out_q] indexed by q_items[q] = target or -1
     int n_out_q;
@@ -675,7 +677,11 @@ __global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
     if (tid < 32) hist[tid] = 0;
     // the candidate CSR is one contiguous array: when it fits the rest of the LDS allocation it is copied there once (coalesced
     // 16-byte loads), and the rounds below never touch HBM
-    lds_u32* s_keys = (lds_u32*)(accepted + ((a.n_q + 1) & ~1));
+    // the queries' list bounds, staged once (coalesced): every batch of the loop below used to start with two dependent global loads
+    lds_u32* s_off = (lds_u32*)(accepted + ((a.n_q + 1) & ~1));             // [n_q + 1] (if offsets_in_lds)
+    lds_u32* s_keys = s_off + (a.offsets_in_lds ? ((a.n_q + 4) & ~3) : 0);
+    if (a.offsets_in_lds)
+        for (int i = tid; i <= a.n_q; i += T) s_off[i] = a.offsets[i];
     const uint32_t n_keys = a.offsets[a.n_q];
     const bool keys_in_lds = n_keys <= a.key_pool;
     if (keys_in_lds) {
@@ -697,8 +703,8 @@ __global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
         const int q = q0 + tid;
         uint32_t lb = 0, le = 0;
         if (q < a.n_q) {
-            lb = a.offsets[q];
-            le = a.offsets[q + 1];
+            lb = a.offsets_in_lds ? (uint32_t)s_off[q] : a.offsets[q];
+            le = a.offsets_in_lds ? (uint32_t)s_off[q + 1] : a.offsets[q + 1];
         }
         bool pending = le > lb;
         for (;;) {
@@ -726,11 +732,13 @@ __global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
                 // eight keys and their eight thr[] values are fetched as independent batches (one load round trip per batch instead of
                 // one per entry: that latency is the whole cost); keys come from LDS when the CSR was staged
                 const __attribute__((address_space(3))) uint16_t* thr_nv = (const __attribute__((address_space(3))) uint16_t*)thr;
+                // (the staged keys never change: read them through a plain pointer too, or each of the eight reads waits for the one before)
+                const __attribute__((address_space(3))) uint32_t* keys_nv = (const __attribute__((address_space(3))) uint32_t*)s_keys;
                 for (uint32_t k0 = lb; k0 < le; k0 += 8) {
                     uint32_t e8[8], t8[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
-                        e8[u] = k0 + u < le ? (keys_in_lds ? (uint32_t)s_keys[k0 + u] : a.keys[k0 + u]) : kNone;
+                        e8[u] = k0 + u < le ? (keys_in_lds ? keys_nv[k0 + u] : a.keys[k0 + u]) : kNone;
 #pragma unroll
                     for (int u = 0; u < 8; ++u) t8[u] = e8[u] != kNone ? (uint32_t)thr_nv[e8[u] & 0xFFFFu] : 0u;
 #pragma unroll
@@ -938,13 +946,22 @@ size_t resolve_lds_bytes(int n_q, int n_t) {
 template <int RULE>
 ovs_status launch_resolve(const ResolveArgs& ra_in, hipStream_t s) {
     ResolveArgs ra = ra_in;
-    const size_t fixed = resolve_lds_bytes(ra.n_q, ra.n_t);
+    size_t fixed = resolve_lds_bytes(ra.n_q, ra.n_t);
     if (fixed > 150 * 1024) return OVS_ERR_CAPACITY;
-    // the rest of a 96 KiB allocation holds a copy of the key CSR when it fits (checked on the device: the size is only known there)
-    const size_t lds = std::max(fixed, (size_t)96 * 1024);
+    // the queries' list bounds are staged in LDS too unless the problem is so large that they would take the room of everything else
+    const size_t off_bytes = (size_t)4 * ((ra.n_q + 4) & ~3);
+    ra.offsets_in_lds = fixed + off_bytes <= (size_t)120 * 1024 ? 1 : 0;
+    if (ra.offsets_in_lds) fixed += off_bytes;
+    // the rest of the allocation (96 KiB, or 24 KiB beyond the fixed part for the largest problems) holds a copy of the key CSR when it
+    // fits (checked on the device: the size is only known there)
+    const size_t lds = std::min((size_t)150 * 1024, std::max((size_t)96 * 1024, fixed + (size_t)24 * 1024));
     ra.key_pool = (uint32_t)((lds - fixed) / 4);
-    // 1 / 4 / 8 waves (64 / 256 / 512 queries per round) by problem size
-    const int width = ra.n_q > 2048 ? 2 : (ra.n_q > 256 ? 1 : 0);
+    // 1 / 4 / 8 waves (64 / 256 / 512 queries per round) by problem size: up to 256, up to 1024, beyond
+    static const int wide_from = [] {
+        const char* e = std::getenv("OVS_RESOLVE_WIDE_FROM");   // tuning aid: queries from which a round takes 512 instead of 256 of them
+        return e ? std::atoi(e) : 1024;   // (2048 until the commit rule changed: tracked frame, 2008 queries: 0.158 -> 0.147 ms, area 0.123 -> 0.094)
+    }();
+    const int width = ra.n_q > wide_from ? 2 : (ra.n_q > 256 ? 1 : 0);
     static thread_local size_t configured[3][8] = {};
     if (lds > configured[width][RULE]) {
         const void* fn = width == 2 ? reinterpret_cast<const void*>(k_list_resolve<RULE, 8>)
