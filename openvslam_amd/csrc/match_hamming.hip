@@ -515,6 +515,9 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 //   * a lane is AFFECTED if a LOWER lane of this round wants one of the two frame keypoints its decision rests on (anything
 //     before `best` is already claimed, anything after `second` cannot matter; a best > THR_LOW is a final reject);
 //   * all lanes below the first affected lane commit at once -- by induction their inputs were exact -- the rest go round again.
+// (Round 3 gave the windowed matchers' resolver, match_window.hip k_list_resolve, a wider commit rule -- every thread no lower thread
+// can interfere with commits, not just the prefix. Here it was measured and reverted: it needs every unclaimed register candidate stamped,
+// and these near lists overlap so much that more queries end up waiting: 0.129 -> 0.213 ms per 256 problems.)
 // A chunk whose near list overflowed kNearSeg falls back to a literal one-query-at-a-time replay with cooperative scans.
 // NW = waves per problem (1 or 4): a round replays 64 * NW queries at once; with NW = 4 the four waves meet at workgroup barriers
 // (three per round) and the number of rounds per problem drops ~2.5x -- the kernel is pure dependent latency on otherwise idle CUs.
