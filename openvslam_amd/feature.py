@@ -42,11 +42,30 @@ class orb_extractor:
         self.orb_params_ = params or orb_params()
         self._L = _lib.lib()
         _lib.require_device()
+        self._h = None
+        self._shape = (max_rows, max_cols, max_batch, device)
+        self.max_batch = max_batch
+        self._variants = {}
+        self._fast_split = None
+        self._pipeline = None
+        self._initialize()
+
+    def _initialize(self):
+        """orb_extractor::initialize(): (re)build the tables and the device state from orb_params_ (upstream's setters call it too)."""
+        if self._h:
+            self._L.ovs_orb_destroy(self._h)
+            self._h = None
+        max_rows, max_cols, max_batch, device = self._shape
         h = C.c_void_p()
         cp = self.orb_params_._c()
         _lib.check(self._L.ovs_orb_create(C.byref(cp), max_rows, max_cols, max_batch, device, C.byref(h)), "ovs_orb_create")
         self._h = h
-        self.max_batch = max_batch
+        for idx, value in self._variants.items():   # the rule switches and the schedule choices survive a re-initialisation
+            _lib.check(self._L.ovs_orb_set_variant(self._h, idx, value), "ovs_orb_set_variant")
+        if self._fast_split is not None:
+            _lib.check(self._L.ovs_orb_set_fast_split(self._h, self._fast_split), "ovs_orb_set_fast_split")
+        if self._pipeline is not None:
+            _lib.check(self._L.ovs_orb_set_pipeline(self._h, self._pipeline), "ovs_orb_set_pipeline")
         self.max_keypoints = self._L.ovs_orb_max_keypoints(self._h)
         n = self.orb_params_.num_levels
         self.scale_factors_ = np.zeros(n, np.float32)
@@ -63,9 +82,29 @@ class orb_extractor:
             self._L.ovs_orb_destroy(self._h)
             self._h = None
 
-    # upstream getters
+    # upstream getters / setters (every setter re-initialises, as upstream's do)
     def get_max_num_keypoints(self):
         return self.orb_params_.max_num_keypts
+
+    def set_max_num_keypoints(self, max_num_keypts):
+        self.orb_params_.max_num_keypts = int(max_num_keypts)
+        self._initialize()
+
+    def set_scale_factor(self, scale_factor):
+        self.orb_params_.scale_factor = float(scale_factor)
+        self._initialize()
+
+    def set_num_scale_levels(self, num_levels):
+        self.orb_params_.num_levels = int(num_levels)
+        self._initialize()
+
+    def set_initial_fast_threshold(self, initial_fast_threshold):
+        self.orb_params_.ini_fast_thr = int(initial_fast_threshold)
+        self._initialize()
+
+    def set_minimum_fast_threshold(self, minimum_fast_threshold):
+        self.orb_params_.min_fast_thr = int(minimum_fast_threshold)
+        self._initialize()
 
     def get_scale_factor(self):
         return self.orb_params_.scale_factor
@@ -124,17 +163,20 @@ class orb_extractor:
     def set_fast_split(self, enable):
         """Level-0 FAST beside the pyramid on an internal stream (default on); off = one FAST launch after the pyramid."""
         _lib.check(self._L.ovs_orb_set_fast_split(self._h, 1 if enable else 0), "ovs_orb_set_fast_split")
+        self._fast_split = 1 if enable else 0
 
     def set_variant(self, which, value):
         """ovs_orb_set_variant: "tree_switch_factor" (3 | 1), "tree_tie_order" (0 later-created first | 1 earlier first), "blur_taps" (0 | 1) --
         the rules of oracle/ORACLE_SPEC.md (6, 7, 10) that cannot be pinned without upstream's sources, as run-time choices."""
         idx = {"tree_switch_factor": 0, "tree_tie_order": 1, "blur_taps": 2}[which]
         _lib.check(self._L.ovs_orb_set_variant(self._h, idx, int(value)), "ovs_orb_set_variant")
+        self._variants[idx] = int(value)
         self.max_keypoints = self._L.ovs_orb_max_keypoints(self._h)   # tree_switch_factor = 1 can return up to 2 N per level
 
     def set_pipeline(self, n_sub):
         """Issue the device-batch extract as n_sub overlapping sub-batches on internal streams (ovs_orb_set_pipeline)."""
         _lib.check(self._L.ovs_orb_set_pipeline(self._h, int(n_sub)), "ovs_orb_set_pipeline")
+        self._pipeline = int(n_sub)
 
     def extract_batch_dev(self, d_images, d_kps, d_desc, d_counts, stream=None, d_masks=None):
         """Device-resident batched extract. d_images: torch uint8 CUDA tensor (B, rows, cols) contiguous (cols % 4 == 0);
