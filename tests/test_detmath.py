@@ -133,3 +133,22 @@ def test_equirectangular_decisions_do_not_depend_on_the_shared_asin_atan2():
     if flips.any():                    # and where one happens, libm's own value is on the edge to within rounding
         edge = np.minimum(np.abs(u_l[flips] / cw - np.rint(u_l[flips] / cw)), np.abs(v_l[flips] / ch - np.rint(v_l[flips] / ch)))
         assert (edge < 1e-9).all() or (np.abs(np.abs(u_l[flips] - cols / 2) - 15.0) < 1e-9).all()
+
+
+def test_asin_atan2_against_the_correctly_rounded_value():
+    """The same functions against mpmath (50 digits, rounded to nearest double): an implementation-independent statement of their error --
+    asin / acos within 1 ulp, atan2 within 2 ulp of the correctly rounded result -- so the glibc comparisons above are not the only pin."""
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 50
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-1, 1, 6000), 1.0 - np.geomspace(1e-16, 1e-2, 500), -1.0 + np.geomspace(1e-16, 1e-2, 500),
+                        rng.uniform(-1e-5, 1e-5, 500), np.array([0.5, -0.5, 0.975, 1.0, -1.0, 0.0])])
+    want = np.array([float(mp.asin(mp.mpf(float(v)))) for v in x])
+    assert _ulp_diff(ob.detmath_eval(ob.DETMATH_ASIN, x), want).max() <= 1
+    want = np.array([float(mp.acos(mp.mpf(float(v)))) for v in x])
+    assert _ulp_diff(ob.detmath_eval(ob.DETMATH_ACOS, x), want).max() <= 1
+    y = np.concatenate([rng.normal(size=6000), rng.normal(size=1000) * 1e-9, rng.normal(size=1000)])
+    xx = np.concatenate([rng.normal(size=6000), rng.normal(size=1000), rng.normal(size=1000) * 1e-9])
+    want = np.array([float(mp.atan2(mp.mpf(float(a)), mp.mpf(float(b)))) for a, b in zip(y, xx)])
+    d = _ulp_diff(ob.detmath_eval(ob.DETMATH_ATAN2, y, xx), want)
+    assert d.max() <= 2 and (d == 0).mean() > 0.8
