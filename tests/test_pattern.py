@@ -19,6 +19,9 @@ def test_pattern_copies():
     assert a == b and len(a) == 1024
     assert hashlib.sha256(bytes(v + 128 for v in a)).hexdigest() == SHA
     assert min(a) == -13 and max(a) == 12
+    # the rows every reprint of OpenCV's bit_pattern_31_ (orb.cpp; ORB-SLAM2's ORBextractor.cc) opens and closes with
+    assert a[:20] == [8, -3, 9, 5, 4, 2, 7, -12, -11, 9, -8, 2, 7, -12, 12, -13, 2, -13, 2, 12]
+    assert a[-8:] == [7, 0, 12, -2, -1, -6, 0, -11]
     # every sample stays inside the radius the extractor reserves (orb_patch_radius_ = 19 after rotation + rounding)
     import math
     assert max(math.hypot(a[i], a[i + 1]) for i in range(0, 1024, 2)) < 18.5
