@@ -183,3 +183,67 @@ def test_prefix_rule_is_exact_too_and_which_rule_needs_fewer_rounds():
                 acc["all"] += ra
     assert sparse["all"] < sparse["prefix"]
     assert dense["all"] > dense["prefix"]
+
+
+def parallel_union(rule, lists, n_t, ratio, batch, max_d):
+    """A candidate for the next version of both resolvers (not in the kernels yet): commit the UNION of the two safe sets -- every query
+    below the first one affected in the prefix rule's sense (a lower accepting query stamped its best / second), and every query no lower
+    pending query can interfere with (best not in any lower pending query's live list, second not among their claimable candidates).
+    Final rejects do not stamp. Never more rounds than either rule alone."""
+    thr, owner, match, rounds = [MAXD] * n_t, [None] * n_t, {}, 0
+    for q0 in range(0, len(lists), batch):
+        pending = {q for q in range(q0, min(q0 + batch, len(lists))) if lists[q]}
+        while pending:
+            rounds += 1
+            live, claimable, accepted, ev = {}, {}, {}, {}
+            for q in sorted(pending):
+                ev[q] = _evaluate(lists[q], thr)
+                best, second, bd, sd = ev[q]
+                if best is None or bd > max_d:
+                    continue
+                if _accepts(rule, bd, sd, ratio):
+                    accepted[best[1]] = min(accepted.get(best[1], 1 << 30), q)
+                for d, t in lists[q]:
+                    if d < thr[t]:
+                        live[t] = min(live.get(t, 1 << 30), q)
+                        if d <= max_d:
+                            claimable[t] = min(claimable.get(t, 1 << 30), q)
+            first = 1 << 30
+            for q in sorted(pending):
+                best, second, bd, sd = ev[q]
+                if best is not None and bd <= max_d and (accepted.get(best[1], 1 << 30) < q or
+                                                         (second is not None and accepted.get(second[1], 1 << 30) < q)):
+                    first = q
+                    break
+            still, commits = set(), []
+            for q in sorted(pending):
+                best, second, bd, sd = ev[q]
+                blocked = False
+                if best is not None and bd <= max_d:
+                    blocked = live.get(best[1], 1 << 30) < q
+                    if rule != "best_only" and second is not None:
+                        blocked = blocked or claimable.get(second[1], 1 << 30) < q
+                if blocked and q >= first:
+                    still.add(q)
+                elif best is not None and _accepts(rule, bd, sd, ratio):
+                    commits.append((q, best))
+            assert len(still) < len(pending)
+            for q, best in commits:
+                _commit(rule, q, best, thr, owner, match)
+            pending = still
+    return match, rounds
+
+
+def test_union_of_both_rules_is_exact_and_needs_the_fewest_rounds():
+    rng = np.random.default_rng(12)
+    for gen, n in ((_tracked_frame_like_problem, 40), (_random_problem, 200)):
+        for rule, max_d in (("bow", 50), ("area", 50), ("best_only", 100)):
+            r_union = r_prefix = r_all = 0
+            for _ in range(n):
+                lists, n_t, ratio, batch = gen(rng)
+                got, r = parallel_union(rule, lists, n_t, ratio, batch, max_d)
+                assert got == sequential(rule, lists, n_t, ratio)
+                r_union += r
+                r_prefix += parallel_prefix(rule, lists, n_t, ratio, batch, max_d)[1]
+                r_all += parallel(rule, lists, n_t, ratio, batch, max_d)[1]
+            assert r_union <= min(r_prefix, r_all)
