@@ -52,3 +52,21 @@ def test_model_equals_oracle(oracle, kind, shape):
             want = oracle.distribute_via_tree(xs, ys, sc, 19, 19 + W, 19, 19 + H, N)
             got = tree_model(xs, ys, sc, 19, 19 + W, 19, 19 + H, N)
             assert list(want) == list(got), (kind, shape, n, N)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "cluster", "mixed"])
+@pytest.mark.parametrize("shape", [(1882, 1042), (498, 263), (300, 700), (64, 64)])
+def test_sorted_path_code_formulation_equals_oracle(oracle, kind, shape):
+    """The candidate formulation for the next kernel version (tools/tree_model.py tree_model_sorted): candidates sorted once by
+    (root, path code), every node a range of the sorted array, no per-pass candidate sweeps -- same keypoints in the same order."""
+    from tree_model import tree_model_sorted
+    W, H = shape
+    rng = np.random.default_rng(zlib.crc32(repr(("sorted", kind, shape)).encode()))
+    for n in (1, 2, 17, 200, 1500):
+        if n > (W - 6) * (H - 6) // 2:
+            continue
+        xs, ys, sc = _cands(rng, n, W, H, kind)
+        for N in (1, 5, 122, 434, 3000):
+            want = oracle.distribute_via_tree(xs, ys, sc, 19, 19 + W, 19, 19 + H, N)
+            got = tree_model_sorted(xs, ys, sc, 19, 19 + W, 19, 19 + H, N)
+            assert list(want) == list(got), (kind, shape, n, N)
