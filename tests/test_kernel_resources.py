@@ -1,0 +1,29 @@
+"""The occupancy figures DESIGN.md argues with, read from the gfx950 code objects hipcc emits here (no device): the hot kernels stay free of
+scratch and inside the register / LDS budgets their workgroups-per-CU depend on. A compiler or source change that pushes one of them over
+its tier shows up here and not as an unexplained slowdown on the device."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    import kernel_resources as kr
+    rows = kr.collect(files={"orb_fast.hip", "orb_describe.hip", "orb_tree.hip", "orb_pyramid.hip"})
+    return {name: dict(vgpr=v, agpr=a, sgpr=s, scratch=p, lds=g, max_wg=w) for (_, name, v, a, s, p, g, w) in rows}
+
+
+def test_hot_kernels_have_no_scratch_and_keep_their_occupancy_tier(kernels):
+    fast = kernels["ovs::k_fast_cells<false, false>"]
+    # seven 256-thread workgroups per CU: <= 72 registers (512 / 7 waves per SIMD) and <= 160 KiB / 7 of LDS
+    assert fast["scratch"] == 0 and fast["vgpr"] + fast["agpr"] <= 72 and fast["lds"] <= 160 * 1024 // 7
+    desc = kernels["ovs::k_describe"]
+    assert desc["scratch"] == 0 and desc["vgpr"] <= 32 and desc["lds"] <= 6400          # 25 one-wave workgroups per CU by LDS
+    tree = kernels["ovs::k_tree<512>"]
+    assert tree["scratch"] == 0 and tree["vgpr"] <= 80 and tree["lds"] == 0             # three 512-thread workgroups per CU (dynamic LDS aside)
+    assert kernels["ovs::k_tree<1024>"]["scratch"] == 0 and kernels["ovs::k_tree<1024>"]["vgpr"] <= 128
+    pyr = kernels["ovs::k_resize_linear_u8"]
+    assert pyr["scratch"] == 0 and pyr["vgpr"] <= 64 and pyr["lds"] <= 20 * 1024        # eight workgroups per CU

@@ -18,10 +18,13 @@ def demangle(names):
     return [o or n for o, n in zip(out, names)]   # (extern "C" kernels have nothing to demangle)
 
 
-def main():
+def collect(files=None):
+    """[(file, kernel, vgpr, agpr, sgpr, scratch bytes, static LDS bytes, max workgroup size)] for csrc/*.hip (or the named files)."""
     rows = []
     with tempfile.TemporaryDirectory() as td:
         for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
+            if files is not None and os.path.basename(src) not in files:
+                continue
             base = os.path.splitext(os.path.basename(src))[0]
             subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-c", src, "-o", os.path.join(td, base + ".o"), "-save-temps=obj"], cwd=CSRC, check=True,
                            stderr=subprocess.DEVNULL)
@@ -35,9 +38,14 @@ def main():
                              int(f.get("private_segment_fixed_size", 0)), int(f.get("group_segment_fixed_size", 0)),
                              int(f.get("max_flat_workgroup_size", 0))))
     names = demangle([r[1] for r in rows])
+    return [(r[0], n) + r[2:] for r, n in zip(rows, names)]
+
+
+def main():
+    rows = collect()
     print("# hipcc %s; vgpr = unified VGPR + AGPR count; waves/SIMD = floor(512 / vgpr) capped at 8 (LDS may bind lower)" % " ".join(FLAGS))
     print("%-18s %-58s %5s %5s %5s %8s %9s %7s %10s" % ("file", "kernel", "vgpr", "agpr", "sgpr", "scratch", "lds_stat", "max_wg", "waves/SIMD"))
-    for (base, _, v, a, s, p, g, w), n in zip(rows, names):
+    for (base, n, v, a, s, p, g, w) in rows:
         tot = max(v, 1)
         print("%-18s %-58s %5d %5d %5d %8d %9d %7d %10d" % (base, n[:58], v, a, s, p, g, w, min(8, 512 // tot)))
 
