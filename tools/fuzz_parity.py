@@ -431,12 +431,53 @@ def fuzz_sim3(rng, n_cases, log):
     return True
 
 
+def fuzz_contention(rng, n_cases, log):
+    """The sequential-claim resolvers under heavy contention: bow_tree::match_frame_and_keyframe over a vocabulary of a few nodes (lists of
+    hundreds of shared candidates per query) and area::match_in_consistent_area with a window that covers most of the image. This is the
+    shape on which an interim commit rule of round 3 failed (seed 901 of the standard campaign, by luck); run with --contention N."""
+    for case in range(n_cases):
+        rows2, cols2 = int(rng.integers(200, 500)), int(rng.integers(300, 700)) & ~3
+        nfeat = int(rng.choice([300, 600, 1000]))
+        seed = int(rng.integers(0, 1 << 30))
+        sh = (int(rng.integers(0, 12)), int(rng.integers(0, 8)))
+        a = synth.synth_frame(rows2, cols2, seed=seed & 0xFFFF)
+        b = synth.synth_frame(rows2, cols2, seed=seed & 0xFFFF, shift=sh, noise_seed=7 + (seed & 0xFF))
+        ox = ob.OrbExtractor(ob.make_params(nfeat))
+        ka, da = ox.extract(a)
+        kb, db = ox.extract(b)
+        ratio = float(rng.choice([0.6, 0.75, 0.9, 1.0]))
+        co = bool(rng.random() < 0.5)
+        gp2, ogp2 = match.grid_params(cols2, rows2), ob.grid_params(cols2, rows2)
+        wa = match.area(ratio, co, max_targets=4096, max_queries=4096)
+        pg = np.ascontiguousarray(np.stack([ka["x"], ka["y"]], 1), np.float32)
+        po = pg.copy()
+        mg = float(rng.choice([200, 400]))
+        gn, got = wa.match_in_consistent_area(gp2, ka, da, kb, db, pg, mg)
+        wn, want = ob.area_match_in_consistent_area(ogp2, ka, da, kb, db, po, mg, ratio, co)
+        ok = gn == wn and np.array_equal(got, want) and np.array_equal(pg.view(np.uint32), po.view(np.uint32))
+        log("contention area %4dx%-4d N=%-4d ratio %.2f margin %3.0f orient %d -> %4d %s" % (cols2, rows2, nfeat, ratio, mg, co, wn, "ok" if ok else "MISMATCH"))
+        if not ok:
+            return False
+        nn = int(rng.choice([3, 6, 12]))
+        fa, fb = synth.synth_bow(da, seed=1, n_nodes=nn), synth.synth_bow(db, seed=1, n_nodes=nn)
+        has_lm = (rng.random(len(ka)) < 0.9).astype(np.uint8)
+        wb = match.bow_tree(ratio, co, max_targets=4096, max_queries=4096)
+        gn, got = wb.match_frame_and_keyframe(ka, da, fa, kb, db, fb, has_lm)
+        wn, want = ob.bow_match_frame_and_keyframe(ka, da, fa, kb, db, fb, ratio, co, has_lm)
+        ok = gn == wn and np.array_equal(got, want)
+        log("contention bow  %4dx%-4d N=%-4d nodes %3d ratio %.2f orient %d -> %4d %s" % (cols2, rows2, nfeat, nn, ratio, co, wn, "ok" if ok else "MISMATCH"))
+        if not ok:
+            return False
+    return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default=None)
     ap.add_argument("--big", type=int, default=0, help="only family A, this many cases, image sizes up to 2200 x 3900")
+    ap.add_argument("--contention", type=int, default=0, help="only the resolver-contention family, this many cases")
     a = ap.parse_args()
     lines = []
 
@@ -449,6 +490,12 @@ def main():
     if a.big:
         ok = fuzz_extract(rng, a.big, log, max_rows=2200, max_cols=3900)
         log("# seed %d (big images): %s, %d lines, %.0f s" % (a.seed, "ALL BIT-EXACT" if ok else "FAILED", len(lines), time.time() - t0))
+        if a.out:
+            open(a.out, "w").write("\n".join(lines) + "\n")
+        sys.exit(0 if ok else 1)
+    if a.contention:
+        ok = fuzz_contention(rng, a.contention, log)
+        log("# seed %d (resolver contention): %s, %d lines, %.0f s" % (a.seed, "ALL BIT-EXACT" if ok else "FAILED", len(lines), time.time() - t0))
         if a.out:
             open(a.out, "w").write("\n".join(lines) + "\n")
         sys.exit(0 if ok else 1)
