@@ -247,3 +247,27 @@ def test_union_of_both_rules_is_exact_and_needs_the_fewest_rounds():
                 r_prefix += parallel_prefix(rule, lists, n_t, ratio, batch, max_d)[1]
                 r_all += parallel(rule, lists, n_t, ratio, batch, max_d)[1]
             assert r_union <= min(r_prefix, r_all)
+
+
+def _bow_like_problem(rng):
+    """bow_tree's lists: the queries of a vocabulary node all hold the SAME candidate set (the node's frame keypoints), at different distances,
+    and true matches are close -- the extreme of contention (tools/fuzz_parity.py --contention on the device)."""
+    lists, n_t = [], 0
+    for _ in range(int(rng.integers(2, 6))):
+        members = list(range(n_t, n_t + int(rng.integers(3, 40))))
+        n_t = members[-1] + 1
+        for _ in range(int(rng.integers(3, 40))):
+            true = int(rng.choice(members))
+            lists.append([(int(rng.integers(5, 45)) if t == true else int(rng.integers(30, 140)), t) for t in members])
+    return lists, n_t, float(rng.choice([0.6, 0.75, 0.9, 1.0])), int(rng.choice([16, 64]))
+
+
+def test_rules_on_lists_shared_by_a_whole_node():
+    rng = np.random.default_rng(21)
+    for _ in range(150):
+        lists, n_t, ratio, batch = _bow_like_problem(rng)
+        want = sequential("bow", lists, n_t, ratio)
+        for rule_fn in (parallel, parallel_prefix, parallel_union):
+            got, rounds = rule_fn("bow", lists, n_t, ratio, batch, 50)
+            assert got == want
+        assert len(want) > 0
