@@ -734,13 +734,24 @@ __global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
                 const __attribute__((address_space(3))) uint16_t* thr_nv = (const __attribute__((address_space(3))) uint16_t*)thr;
                 // (the staged keys never change: read them through a plain pointer too, or each of the eight reads waits for the one before)
                 const __attribute__((address_space(3))) uint32_t* keys_nv = (const __attribute__((address_space(3))) uint32_t*)s_keys;
+                // UNCONDITIONAL loads (indices clamped into the list, results masked afterwards): a load under a per-lane condition gets its own
+                // branch and its own wait, i.e. eight serialised round trips for the keys and eight for thr[] (seen in the ISA)
+                const uint32_t last = le - 1u;   // (pending => le > lb)
                 for (uint32_t k0 = lb; k0 < le; k0 += 8) {
                     uint32_t e8[8], t8[8];
+                    if (keys_in_lds) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        e8[u] = k0 + u < le ? (keys_in_lds ? keys_nv[k0 + u] : a.keys[k0 + u]) : kNone;
+                        for (int u = 0; u < 8; ++u) e8[u] = keys_nv[min(k0 + u, last)];
+                    } else {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t8[u] = e8[u] != kNone ? (uint32_t)thr_nv[e8[u] & 0xFFFFu] : 0u;
+                        for (int u = 0; u < 8; ++u) e8[u] = a.keys[min(k0 + u, last)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) e8[u] = k0 + u < le ? e8[u] : kNone;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t8[u] = (uint32_t)thr_nv[e8[u] != kNone ? (e8[u] & 0xFFFFu) : 0u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t8[u] = e8[u] != kNone ? t8[u] : 0u;
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const uint32_t e = e8[u], d = e >> 20;
