@@ -629,7 +629,7 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
         if (stereo[i].pose_idx < 0 || stereo[i].pose_idx >= n_pose || stereo[i].point_idx < 0 || stereo[i].point_idx >= n_pt) return OVS_ERR_INVALID;
     if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
     OVS_HIP_TRY(hipSetDevice(device));
-    const bool trace = std::getenv("OVS_BA_TRACE") != nullptr;
+    const bool trace = ovs::tuning().ba_trace;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     ovs_ba_graph* g = new (std::nothrow) ovs_ba_graph();

@@ -318,7 +318,7 @@ static ovs_status local_ba_optimize_impl(int model, int32_t device, double* pose
     OVS_HIP_TRY(hipSetDevice(device));
     // ---- round 1 graph: all edges (validates the indices)
     GraphGuard g1;
-    const bool trace = std::getenv("OVS_BA_TRACE") != nullptr;
+    const bool trace = ovs::tuning().ba_trace;
     const double t_begin = Lm::now();
     ovs_status st = model == 1 ? ovs_ba_graph_create_equirect(device, n_pose, pose_fixed, n_pt, mono, n_mono, (int32_t)cam->fx, (int32_t)cam->fy, &g1.g)
                                : ovs_ba_graph_create(device, n_pose, pose_fixed, n_pt, mono, n_mono, stereo, n_stereo, cam, focal_x_baseline, &g1.g);

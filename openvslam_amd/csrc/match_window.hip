@@ -968,17 +968,13 @@ ovs_status launch_resolve(const ResolveArgs& ra_in, hipStream_t s) {
     const size_t lds = std::min((size_t)150 * 1024, std::max((size_t)96 * 1024, fixed + (size_t)24 * 1024));
     ra.key_pool = (uint32_t)((lds - fixed) / 4);
     // 1 / 4 / 8 waves (64 / 256 / 512 queries per round) by problem size: up to 256, up to 1024, beyond
-    static const int wide_from = [] {
-        const char* e = std::getenv("OVS_RESOLVE_WIDE_FROM");   // tuning aid: queries from which a round takes 512 instead of 256 of them
-        return e ? std::atoi(e) : 1024;   // (2048 until the commit rule changed: tracked frame, 2008 queries: 0.158 -> 0.147 ms, area 0.123 -> 0.094)
-    }();
+    const int wide_from = tuning().resolve_wide_from;   // 1024 (2048 until the commit rule changed: tracked frame, 2008 queries: 0.158 -> 0.147 ms, area 0.123 -> 0.094)
     const int width = ra.n_q > wide_from ? 2 : (ra.n_q > 256 ? 1 : 0);
-    static thread_local size_t configured[3][8] = {};
-    if (lds > configured[width][RULE]) {
+    {
+        static LdsAttrCache configured[3];   // per (RULE: this instantiation, width), per device
         const void* fn = width == 2 ? reinterpret_cast<const void*>(k_list_resolve<RULE, 8>)
                                     : (width == 1 ? reinterpret_cast<const void*>(k_list_resolve<RULE, 4>) : reinterpret_cast<const void*>(k_list_resolve<RULE, 1>));
-        OVS_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured[width][RULE] = lds;
+        OVS_HIP_TRY(ensure_dynamic_lds(fn, lds, configured[width]));
     }
     if (width == 2)
         hipLaunchKernelGGL((k_list_resolve<RULE, 8>), dim3(1), dim3(512), lds, s, ra);

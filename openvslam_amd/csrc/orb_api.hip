@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -19,6 +20,26 @@ void set_last_error(const char* what, hipError_t e) {
 }
 void set_last_error_text(const std::string& what) { g_last_error = what; }
 std::atomic<int32_t> g_injected_hip_failures{0}, g_injected_hip_skip{0};
+
+const Tuning& tuning() {
+    static const Tuning t = [] {
+        auto num = [](const char* name, int dflt) {
+            const char* e = std::getenv(name);
+            return e && e[0] ? std::atoi(e) : dflt;
+        };
+        Tuning v;
+        v.fast_cells = std::max(0, num("OVS_FAST_CELLS", 0));
+        v.fast_pad_lds = std::max(0, num("OVS_FAST_PAD_LDS", 0));
+        v.fast_bufs = num("OVS_FAST_BUFS", 1) == 2 ? 2 : 1;
+        v.fast_timing = std::getenv("OVS_FAST_TIMING") != nullptr;
+        v.describe_xcd = num("OVS_DESCRIBE_XCD", 1) != 0;
+        v.resolve_wide_from = num("OVS_RESOLVE_WIDE_FROM", 1024);
+        v.pose_threads = num("OVS_POSE_THREADS", 0);
+        v.ba_trace = std::getenv("OVS_BA_TRACE") != nullptr;
+        return v;
+    }();
+    return t;
+}
 
 static inline int cv_round_f(float v) { return (int)std::nearbyintf(v); }
 

@@ -329,8 +329,7 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
 
 hipError_t launch_describe(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
                            ovs_keypoint* kps, uint8_t* desc, int32_t* counts, int cap, int batch, hipStream_t s) {
-    const char* e = std::getenv("OVS_DESCRIBE_XCD");   // 0: plain frame-major order (A/B of the XCD mapping; read per launch)
-    const int xcd_map = e ? std::atoi(e) : 1;
+    const int xcd_map = tuning().describe_xcd ? 1 : 0;   // 0: plain frame-major order (A/B of the XCD mapping)
     const int frames = xcd_map ? ((batch + 7) & ~7) : batch;   // frame 8 g + x on XCD x: pad the last group
     dim3 grid((unsigned)hgeo.total_kp_cap * (unsigned)frames);
     hipLaunchKernelGGL(k_describe, grid, dim3(64), 0, s, d.geo, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.lvl_kps,

@@ -31,63 +31,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 namespace ovs {
-
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-
-constexpr int kTileRowsMax = kCellSize + kCellOverlap;   // 70
-constexpr int kTileWords = 20;                           // 80-byte LDS pitch
-constexpr int kSmapWords = 18;                           // 72-byte pitch: 4 + 64 + 4
-constexpr int kSmapRows = 66;                            // 1 + 64 + 1
-
-__device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
-__device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ s16x2 vmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ s16x2 vmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
-
-// bytes M and M+1 (M in 0..6) of the 8-byte window {hi,lo} zero-extended into the two 16-bit halves
-template <int M>
-__device__ __forceinline__ uint32_t pick2(uint32_t hi, uint32_t lo) {
-    constexpr uint32_t sel = (uint32_t)M | (0x0cu << 8) | ((uint32_t)(M + 1) << 16) | (0x0cu << 24);
-    return __builtin_amdgcn_perm(hi, lo, sel);
-}
-
-// pixels at byte offsets Q, Q+1 of window row R
-template <int Q, int R>
-__device__ __forceinline__ s16x2 window_pair(const uint32_t (&w)[8][5]) {
-    return as_s16x2(pick2<(Q & 3)>(w[R][(Q >> 2) + ((Q & 3) == 3 ? 1 : 0)], w[R][Q >> 2]));
-}
-
-// Packed 2 x u16 min / max of values 0..255 through the f16 pipe: such bit patterns are positive f16 denormals, ordered like
-// the integers and returned unflushed (checked exhaustively on gfx950 by tools/ubench/valu_rate.hip). (v2 needed this pipe for
-// its three-input packed min / max, v_pk_minimum3_f16 / v_pk_maximum3_f16, which the integer pipe lacks.)
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ h16x2 as_h(s16x2 v) { return __builtin_bit_cast(h16x2, v); }
-__device__ __forceinline__ s16x2 as_s(h16x2 v) { return __builtin_bit_cast(s16x2, v); }
-__device__ __forceinline__ s16x2 umin2(s16x2 a, s16x2 b) { return as_s(__builtin_elementwise_minimum(as_h(a), as_h(b))); }
-__device__ __forceinline__ s16x2 umax2(s16x2 a, s16x2 b) { return as_s(__builtin_elementwise_maximum(as_h(a), as_h(b))); }
-
-// ---- sparse evaluation -------------------------------------------------------------------------------------------------------
-// S(p) > t needs 9 contiguous ring pixels all brighter than c + t (or all darker than c - t). A 9-arc of the 16-ring contains at least
-// one end of EVERY diameter (i, i + 8), so for the four even diameters (cardinals and diagonals; OpenCV's own pre-test walks all eight)
-//   bright: min_i max(r[i], r[i+8]) > c + t      dark: max_i min(r[i], r[i+8]) < c - t      for i in {0, 2, 4, 6}
-// is necessary. 12 packed min/max + 4 more ops and 9 byte extractions per pixel pair instead of 75 + 17, and on BASELINE-like frames it
-// rejects 97.6 % of the pixels at level 0 and 74 % at level 7 for ini_fast_thr = 20 (92 % overall; true corners: 4.4 %). The two
-// cardinal diameters alone (v3.0) let 13 % through: the extra 10 ops here save 42 % of the exact evaluations. Only the survivors get
-// the exact S (one pixel per lane, 32-bit ops).
-template <int P, int R0>
-__device__ __forceinline__ uint32_t diameter_test_pair(const uint32_t (&w)[8][5], s16x2 thrv) {
-    const s16x2 c = window_pair<6 + P, R0 + 3>(w);
-    const s16x2 a0 = window_pair<6 + P, R0 + 6>(w), b0 = window_pair<6 + P, R0 + 0>(w);           // ring 0 / 8:  (0, +3) / (0, -3)
-    const s16x2 a2 = window_pair<6 + P + 2, R0 + 5>(w), b2 = window_pair<6 + P - 2, R0 + 1>(w);   // ring 2 / 10: (+2, +2) / (-2, -2)
-    const s16x2 a4 = window_pair<6 + P + 3, R0 + 3>(w), b4 = window_pair<6 + P - 3, R0 + 3>(w);   // ring 4 / 12: (+3, 0) / (-3, 0)
-    const s16x2 a6 = window_pair<6 + P + 2, R0 + 1>(w), b6 = window_pair<6 + P - 2, R0 + 5>(w);   // ring 6 / 14: (+2, -2) / (-2, +2)
-    const s16x2 bc = umin2(umin2(umax2(a0, b0), umax2(a2, b2)), umin2(umax2(a4, b4), umax2(a6, b6)));
-    const s16x2 dc = umax2(umax2(umin2(a0, b0), umin2(a2, b2)), umax2(umin2(a4, b4), umin2(a6, b6)));
-    const s16x2 m = vmax(bc - c, c - dc);
-    return as_u32((thrv - m) >> 15);   // each half all-ones iff m > thr
-}
 
 // 16-bit VOP2 min / max: one wave-instruction per ~2.3 cycles on gfx950 against ~4.1 for v_min_u32 / v_max_u32 (tools/ubench/valu_rate.hip);
 // operands here are u8 values, and gfx9 16-bit ops zero the destination's upper half, so results mix freely with 32-bit arithmetic
@@ -102,276 +48,13 @@ __device__ __forceinline__ uint32_t mx16(uint32_t a, uint32_t b) {
     return d;
 }
 
-// exact S of one pixel; p = LDS address of the top-left byte of its 7x7 neighbourhood in the staged tile (pitch kTileWords * 4)
-__device__ __forceinline__ uint32_t fast_strength_one(const uint8_t* p) {
-    constexpr int kP = kTileWords * 4;
-    const uint32_t c = p[3 * kP + 3];
-    uint32_t r[16];
-    r[0] = p[6 * kP + 3];
-    r[1] = p[6 * kP + 4];
-    r[2] = p[5 * kP + 5];
-    r[3] = p[4 * kP + 6];
-    r[4] = p[3 * kP + 6];
-    r[5] = p[2 * kP + 6];
-    r[6] = p[1 * kP + 5];
-    r[7] = p[0 * kP + 4];
-    r[8] = p[0 * kP + 3];
-    r[9] = p[0 * kP + 2];
-    r[10] = p[1 * kP + 1];
-    r[11] = p[2 * kP + 0];
-    r[12] = p[3 * kP + 0];
-    r[13] = p[4 * kP + 0];
-    r[14] = p[5 * kP + 1];
-    r[15] = p[6 * kP + 2];
-    uint32_t pmx[8], pmn[8], qmx[8], qmn[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        pmx[i] = mx16(r[2 * i], r[2 * i + 1]);
-        pmn[i] = mn16(r[2 * i], r[2 * i + 1]);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        qmx[i] = mx16(pmx[i], pmx[(i + 1) & 7]);
-        qmn[i] = mn16(pmn[i], pmn[(i + 1) & 7]);
-    }
-    uint32_t min_a = 255u, max_b = 0u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t ea = r[(2 * i + 15) & 15], eb = r[(2 * i + 8) & 15];
-        min_a = mn16(min_a, mx16(mx16(qmx[i], qmx[(i + 2) & 7]), mn16(ea, eb)));
-        max_b = mx16(max_b, mn16(mn16(qmn[i], qmn[(i + 2) & 7]), mx16(ea, eb)));
-    }
-    const int s = max((int)c - (int)min_a, (int)max_b - (int)c);
-    return (uint32_t)max(s, 0);
-}
-
+constexpr int kTileRowsMax = kCellSize + kCellOverlap;   // 70
+constexpr int kTileWords = 20;                           // 80-byte LDS pitch: five 16-byte chunks per row, chunk i of the tile at byte 16 * i
+constexpr int kTileBytes = kTileRowsMax * kTileWords * 4;
+constexpr int kChunks = kTileRowsMax * 5;                // 350: one per thread + a second one for threads 0..93
+constexpr int kSmapWords = 18;                           // 72-byte pitch: 4 + 64 + 4
+constexpr int kSmapRows = 66;                            // 1 + 64 + 1
 constexpr int kMaxSurvivors = 1024;   // NMS survivors are pairwise non-adjacent: at most 32 x 32 per 64 x 64 cell
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fast_cells_v3(const FrameGeo* __restrict__ geo, const uint8_t* __restrict__ img0, size_t stride0,
-                                                   size_t frame_stride0, const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
-                                                   uint64_t* __restrict__ cand, size_t cand_frame_entries,
-                                                   uint32_t* __restrict__ cand_count, const uint8_t* __restrict__ mask,
-                                                   int batch, int cell_lo, int n_cells) {
-    __shared__ __attribute__((aligned(16))) uint32_t tile[kTileRowsMax][kTileWords];
-    __shared__ __attribute__((aligned(16))) uint32_t smap[kSmapRows][kSmapWords];
-    __shared__ uint16_t clist[4][kCellSize * kCellSize / 4];   // per wave: its pixels that passed the diameter test, (y << 8) | x
-    __shared__ uint32_t wave_cnt[4];
-    __shared__ uint32_t n_out, list_base;
-
-    // NMS survivors, (S << 16) | (y << 8) | x, are collected over the tile: its last reader (the exact scoring) is a barrier behind by
-    // then, and the pass that re-reads the tile (min_fast_thr) only runs when no survivor was written. 18.9 KB of LDS -> 8 workgroups/CU.
-    static_assert(sizeof(tile) >= kMaxSurvivors * sizeof(uint32_t), "survivor list aliases the tile");
-    uint32_t* const olist = &tile[0][0];
-    const int tid = threadIdx.x;
-    const int L = geo->num_levels;
-    // XCD-aware work order. Workgroup b runs on XCD b % 8 (each XCD has its own L2), so XCD k takes the k-th CONTIGUOUS eighth of every
-    // frame's cells: neighbouring cells, which share tile halo lines, then hit the same L2 instead of fetching the line once per XCD
-    // (fabric traffic 3.0x -> see profiles/). Inside an XCD's share the FRAME index runs fastest: the workgroups in flight at any moment
-    // then reserve list space on `batch` times as many (frame, level) counters -- with frame-major order all of them hammered the 8
-    // counters of one frame, and same-address atomics at the fabric side cost ~0.05 ms per launch. The grid is 8 * per_xcd * batch.
-    // The launch covers cells [cell_lo, cell_lo + n_cells): all of them, or one level range (level 0 runs beside the pyramid, see orb_api.hip).
-    const int per_xcd = (n_cells + 7) >> 3;
-    const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-    const int slot = idx / batch, frame = idx - slot * batch;
-    if (xcd * per_xcd + slot >= n_cells) return;
-    const int cell_id = cell_lo + xcd * per_xcd + slot;
-    // The prologue is a chain of dependent scalar loads in front of the tile fetch, and nothing else can run in this workgroup until the
-    // tile is in LDS: keep the chain at three round trips (kernel arguments -> header + level table -> the level's geometry).
-    int level = 0;
-#pragma unroll
-    for (int l = 1; l < OVS_MAX_LEVELS; ++l) level += (cell_id >= geo->cell_base_tab[l]) ? 1 : 0;
-    const LevelGeo& g = geo->lv[level];
-    const int g_ncx = g.ncx, g_cell_base = g.cell_base, g_max_bx = g.max_bx, g_max_by = g.max_by, g_pitch = g.pitch;
-    const float g_inv_ncx = g.inv_ncx, scale = g.scale;
-    const int64_t g_plane_off = g.plane_off;
-    const int cell = cell_id - g_cell_base;
-    const int ci = (int)(((float)cell + 0.5f) * g_inv_ncx), cj = cell - ci * g_ncx;   // exact: cell < 2^22 (see orb_pyramid.hip)
-
-    const int min_x = kOrbPatchRadius + cj * kCellSize, min_y = kOrbPatchRadius + ci * kCellSize;
-    int max_x = min_x + kCellSize + kCellOverlap, max_y = min_y + kCellSize + kCellOverlap;
-    if (g_max_bx < max_x) max_x = g_max_bx;
-    if (g_max_by < max_y) max_y = g_max_by;
-    const int cw = max_x - min_x, ch = max_y - min_y;
-    const int iw = cw - 6, ih = ch - 6;   // testable area of this cell (> 0 for every valid cell)
-
-    const uint8_t* img;
-    int pitch;
-    if (level == 0) {
-        img = img0 + (size_t)frame * frame_stride0;
-        pitch = (int)stride0;
-    } else {
-        img = pyr + (size_t)frame * pyr_frame_bytes + g_plane_off;
-        pitch = g_pitch;
-    }
-
-    // ---- fetch the tile: tile byte u of row r <-> image (min_x - 3 + u, min_y + r); min_x - 3 = 16 + 64*cj is 16-byte aligned. The 70 x 5
-    //      16-byte chunks go two per thread (the second for tid < 94), BOTH requested before either is waited for.
-    const int ax0 = min_x - 3;
-    const bool vec16 = ((pitch & 15) == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0);
-    auto fetch_chunk = [&](int idx) -> uint4 {
-        const int r = idx / 5, q = idx - r * 5;
-        uint4 v = {0u, 0u, 0u, 0u};
-        const int gx = ax0 + 16 * q;
-        if (r < ch) {
-            const uint8_t* p = img + (size_t)(min_y + r) * pitch + gx;
-            if (vec16 && gx + 16 <= pitch) {
-                v = *reinterpret_cast<const uint4*>(p);
-            } else {   // 4-byte aligned base/stride (enforced by the ABI), row tail
-                const uint32_t* p4 = reinterpret_cast<const uint32_t*>(p);
-                if (gx + 4 <= pitch) v.x = p4[0];
-                if (gx + 8 <= pitch) v.y = p4[1];
-                if (gx + 12 <= pitch) v.z = p4[2];
-                if (gx + 16 <= pitch) v.w = p4[3];
-            }
-        }
-        return v;
-    };
-    constexpr int kChunks = kTileRowsMax * 5;
-    const uint4 va = fetch_chunk(tid);
-    uint4 vb = {0u, 0u, 0u, 0u};
-    if (tid + 256 < kChunks) vb = fetch_chunk(tid + 256);
-
-    const uint8_t* fmask = mask ? mask + (size_t)frame * frame_stride0 : nullptr;   // same layout as the level-0 frames
-    // upstream: skip the cell if one of its corners is masked (mask is indexed in level-0 coordinates, float scale, trunc)
-    if (fmask) {
-        auto in_mask = [&](unsigned y, unsigned x) {
-            return fmask[(size_t)(unsigned)(y * scale) * stride0 + (unsigned)(x * scale)] == 0;
-        };
-        if (in_mask(min_y, min_x) || in_mask(max_y, min_x) || in_mask(min_y, max_x) || in_mask(max_y, max_x)) return;
-    }
-
-    // the score map holds S for the pixels that were evaluated and 0 elsewhere (pixel (x, y) at byte 4 + x of row y + 1)
-    uint32_t* const smap_flat = &smap[0][0];
-    static_assert((kSmapRows * kSmapWords) % 4 == 0, "score map is cleared with 16-byte stores");
-    for (int i = tid; i < kSmapRows * kSmapWords / 4; i += 256) reinterpret_cast<uint4*>(smap_flat)[i] = uint4{0u, 0u, 0u, 0u};
-    if (tid == 0) n_out = 0;
-    if (tid < 4) wave_cnt[tid] = 0;
-    {
-        const int r = tid / 5, q = tid - r * 5;
-        *reinterpret_cast<uint4*>(&tile[r][4 * q]) = va;
-        if (tid + 256 < kChunks) {
-            const int r2 = (tid + 256) / 5, q2 = (tid + 256) - r2 * 5;
-            *reinterpret_cast<uint4*>(&tile[r2][4 * q2]) = vb;
-        }
-    }
-
-    const int run = tid & 7, rp = tid >> 3;
-    const int c0 = run * 8, row0 = 2 * rp;
-    const int lane = tid & 63, wv = tid >> 6;
-    const uint8_t* const tbytes = reinterpret_cast<const uint8_t*>(&tile[0][0]);
-    uint8_t* const sbytes = reinterpret_cast<uint8_t*>(smap_flat);
-    __syncthreads();
-
-    // candidate-mask layout: pair j (pixels c0 + 2j, c0 + 2j + 1) of row row0 -> bits j and 16 + j; of row row0 + 1 -> bits 4 + j and
-    // 20 + j. Where the level border clips the testable area (workgroup-uniform, ~9 % of the cells) the pixels outside are masked. The
-    // empty asm keeps this a real branch: hipcc otherwise hoists the block out of the loop below AND evaluates it speculatively for
-    // every cell (~60 VALU per thread, a tenth of the kernel's instructions -- found in the ISA, round 2).
-    uint32_t valid = ~0u;
-    if (iw < kCellSize || ih < kCellSize) {
-        asm volatile("" ::: "memory");
-        valid = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int x = c0 + 2 * j;
-            const uint32_t colm = (x < iw ? 1u : 0u) | (x + 1 < iw ? 0x10000u : 0u);
-            valid |= (row0 < ih ? colm : 0u) << j;
-            valid |= (row0 + 1 < ih ? colm : 0u) << (4 + j);
-        }
-    }
-
-    int thr = geo->ini_thr;
-    for (;;) {
-        // ---- 1. diameter test on packed pairs -> candidate mask. It reads this part of the thread's 8x5-word window (re-read in the rare
-        //         second pass rather than kept in 28 registers across the scoring): words 1..3 of every row, words 0 and 4 of rows 3, 4
-        uint32_t cmask = 0;
-        {
-            uint32_t w[8][5];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const uint2 b = *reinterpret_cast<const uint2*>(&tile[row0 + r][2 * run + 2]);
-                w[r][1] = tile[row0 + r][2 * run + 1];
-                w[r][2] = b.x;
-                w[r][3] = b.y;
-                if (r == 3 || r == 4) {
-                    w[r][0] = tile[row0 + r][2 * run];
-                    w[r][4] = tile[row0 + r][2 * run + 4];
-                }
-            }
-            const s16x2 thrv = {(short)thr, (short)thr};
-            cmask |= diameter_test_pair<0, 0>(w, thrv) & 0x00010001u;
-            cmask |= diameter_test_pair<2, 0>(w, thrv) & 0x00020002u;
-            cmask |= diameter_test_pair<4, 0>(w, thrv) & 0x00040004u;
-            cmask |= diameter_test_pair<6, 0>(w, thrv) & 0x00080008u;
-            cmask |= diameter_test_pair<0, 1>(w, thrv) & 0x00100010u;
-            cmask |= diameter_test_pair<2, 1>(w, thrv) & 0x00200020u;
-            cmask |= diameter_test_pair<4, 1>(w, thrv) & 0x00400040u;
-            cmask |= diameter_test_pair<6, 1>(w, thrv) & 0x00800080u;
-            cmask &= valid;
-        }
-        // ---- 2. compact the wave's candidates into its own list segment (order is irrelevant; no workgroup barrier needed: a wave's LDS
-        //         operations complete in order, and the wave is the only reader of its segment)
-        const int n_mine = __popc(cmask);
-        uint32_t pos = n_mine ? atomicAdd(&wave_cnt[wv], (uint32_t)n_mine) : 0u;
-        uint16_t* const my_list = clist[wv];
-        while (cmask) {
-            const int b = __ffs(cmask) - 1;
-            cmask &= cmask - 1;
-            const int j = b & 3, rowsel = (b >> 2) & 1, hi = b >> 4;
-            my_list[pos++] = (uint16_t)(((row0 + rowsel) << 8) | (c0 + 2 * j + hi));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int n_cand = (int)*reinterpret_cast<volatile uint32_t*>(&wave_cnt[wv]);
-        // ---- 3. exact S for the wave's candidates, one per lane, into the shared score map
-        for (int i = lane; i < n_cand; i += 64) {
-            const uint32_t e = my_list[i];
-            const int x = e & 255, y = e >> 8;
-            const uint32_t sc = fast_strength_one(tbytes + y * (kTileWords * 4) + x + 3);
-            sbytes[(y + 1) * (kSmapWords * 4) + 4 + x] = (uint8_t)sc;
-        }
-        __syncthreads();
-        // ---- 4. strict NMS over the 8 neighbours (unevaluated neighbours have S <= thr < S(p): 0 in the map), survivors -> olist
-        int any = 0;
-        for (int i = lane; i < n_cand; i += 64) {
-            const uint32_t e = my_list[i];
-            const int x = e & 255, y = e >> 8;
-            const uint8_t* q = sbytes + (y + 1) * (kSmapWords * 4) + 4 + x;
-            const uint32_t sc = q[0];
-            if ((int)sc <= thr) continue;
-            constexpr int kS = kSmapWords * 4;
-            const uint32_t nb = mx16(mx16(mx16((uint32_t)q[-kS - 1], (uint32_t)q[-kS]), mx16((uint32_t)q[-kS + 1], (uint32_t)q[-1])),
-                                     mx16(mx16((uint32_t)q[1], (uint32_t)q[kS - 1]), mx16((uint32_t)q[kS], (uint32_t)q[kS + 1])));
-            if (sc <= nb) continue;
-            any = 1;
-            if (fmask) {   // upstream drops masked keypoints after the empty-cell decision
-                const uint32_t gx = min_x + 3 + x, gy = min_y + 3 + y;
-                if (fmask[(size_t)(unsigned)(gy * scale) * stride0 + (unsigned)(gx * scale)] == 0) continue;
-            }
-            const uint32_t o = atomicAdd(&n_out, 1u);
-            olist[o] = (sc << 16) | e;
-        }
-        if (__syncthreads_or(any) || thr <= geo->min_thr) break;
-        // "if keypts_in_cell.empty()": again with min_fast_thr (rare: flat cells)
-        thr = geo->min_thr;
-        for (int i = tid; i < kSmapRows * kSmapWords / 4; i += 256) reinterpret_cast<uint4*>(smap_flat)[i] = uint4{0u, 0u, 0u, 0u};
-        if (tid < 4) wave_cnt[tid] = 0;
-        __syncthreads();
-    }
-
-    // ---- 5. append to the (frame, level) candidate list: one global atomic per workgroup; FAST response = S - 1
-    const uint32_t total = n_out;
-    if (total == 0) return;
-    if (tid == 0) list_base = atomicAdd(&cand_count[frame * L + level], total);
-    __syncthreads();
-    const uint32_t base = list_base;
-    uint64_t* const list = cand + (size_t)frame * cand_frame_entries + g.cand_off;
-    const uint32_t cap = (uint32_t)g.cand_cap;
-    for (uint32_t i = tid; i < total; i += 256) {
-        const uint32_t o = olist[i];
-        const uint32_t x = o & 255u, y = (o >> 8) & 255u, sc = o >> 16;
-        if (base + i < cap) list[base + i] = cand_pack((uint32_t)(min_x + 3) + x, (uint32_t)(min_y + 3) + y, sc - 1u, 0);
-    }
-}
 
 // ================================================================================================================================
 // v4 (round 3): the same algorithm, restructured after measuring where a cell's time goes (tools/fast_phases.py, OVS_FAST_TIMING):
@@ -414,9 +97,7 @@ __device__ __forceinline__ uint32_t to_r6(uint32_t w) { return __builtin_amdgcn_
 // v_bitop3_b32: a & (b | c)
 __device__ __forceinline__ uint32_t and_or3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xe0); }
 
-// D8: also the four odd diameters (OpenCV's own pre-test walks all eight): 8 more v_alignbyte + 24 fast ops per group for ~22 % fewer
-// candidates -- the exact scoring and the NMS behind this test are bound by their LDS byte gathers, the vector ALU has slack (round 3)
-template <int G, int R0, bool D8>
+template <int G, int R0>
 __device__ __forceinline__ void swar_diameter_test(const uint32_t (&w)[8][5], uint32_t kk, uint32_t& bright, uint32_t& dark) {
     const uint32_t c = __builtin_amdgcn_alignbyte(w[R0 + 3][G + 2], w[R0 + 3][G + 1], 2);
     const uint32_t p0 = __builtin_amdgcn_alignbyte(w[R0 + 6][G + 2], w[R0 + 6][G + 1], 2);    // (0, +3)
@@ -429,18 +110,6 @@ __device__ __forceinline__ void swar_diameter_test(const uint32_t (&w)[8][5], ui
     // bit 7 of every byte: all four diameters have a bright (dark) end
     bright = and_or3(and_or3(and_or3((p0 - cb) | (p8 - cb), p2 - cb, p10 - cb), p4 - cb, p12 - cb), p6 - cb, p14 - cb);
     dark = and_or3(and_or3(and_or3((cd - p0) | (cd - p8), cd - p2, cd - p10), cd - p4, cd - p12), cd - p6, cd - p14);
-    if (D8) {
-        const uint32_t p1 = __builtin_amdgcn_alignbyte(w[R0 + 6][G + 2], w[R0 + 6][G + 1], 3);    // (+1, +3)
-        const uint32_t p15 = __builtin_amdgcn_alignbyte(w[R0 + 6][G + 2], w[R0 + 6][G + 1], 1);   // (-1, +3)
-        const uint32_t p7 = __builtin_amdgcn_alignbyte(w[R0 + 0][G + 2], w[R0 + 0][G + 1], 3);    // (+1, -3)
-        const uint32_t p9 = __builtin_amdgcn_alignbyte(w[R0 + 0][G + 2], w[R0 + 0][G + 1], 1);    // (-1, -3)
-        const uint32_t p3 = __builtin_amdgcn_alignbyte(w[R0 + 4][G + 3], w[R0 + 4][G + 2], 1);    // (+3, +1)
-        const uint32_t p13 = __builtin_amdgcn_alignbyte(w[R0 + 4][G + 1], w[R0 + 4][G + 0], 3);   // (-3, +1)
-        const uint32_t p5 = __builtin_amdgcn_alignbyte(w[R0 + 2][G + 3], w[R0 + 2][G + 2], 1);    // (+3, -1)
-        const uint32_t p11 = __builtin_amdgcn_alignbyte(w[R0 + 2][G + 1], w[R0 + 2][G + 0], 3);   // (-3, -1)
-        bright = and_or3(and_or3(and_or3(and_or3(bright, p1 - cb, p9 - cb), p3 - cb, p11 - cb), p5 - cb, p13 - cb), p7 - cb, p15 - cb);
-        dark = and_or3(and_or3(and_or3(and_or3(dark, cd - p1, cd - p9), cd - p3, cd - p11), cd - p5, cd - p13), cd - p7, cd - p15);
-    }
 }
 
 // S of one polarity: max over the sixteen 9-arcs of the arc's minimum ring value, minus the centre (clamped at 0). For the dark polarity
@@ -506,29 +175,56 @@ constexpr int kMaxCellsPerWg = 64;
 constexpr int kWgSurvivors = 256;   // NMS survivors of the group's cells waiting for their (single) list reservation: ~33 per cell on video
 constexpr int kListCap = 2048;      // pooled candidate list of a cell; a denser cell (noise at a low threshold) is scored exhaustively instead
 
-// 21.1 KB of LDS admit SEVEN workgroups per CU (round 3: the pooled list holds 2048 entries instead of a cell's 4096 pixels, the group buffer 256
-// survivors instead of 512; six workgroups: 1.96 ms per 256 frames, seven: 1.91): cap the registers at the 72 that seven waves per SIMD leave
-template <bool kTiming, bool kD8>   // kTiming: wave 0 accumulates shader cycles per phase into tstats (tuning aid, OVS_FAST_TIMING); kD8: eight diameters
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_fast_cells(const FrameGeo* __restrict__ geo, const CellDesc* __restrict__ cell_tab,
-                                                   const uint8_t* __restrict__ img0, size_t stride0,
-                                                   size_t frame_stride0, const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
-                                                   uint64_t* __restrict__ cand, size_t cand_frame_entries,
-                                                   uint32_t* __restrict__ cand_count, const uint8_t* __restrict__ mask,
-                                                   int batch, uint32_t batch_magic, int cell_lo, int n_cells, int cells_per_wg,
-                                                   unsigned long long* __restrict__ tstats) {
-    __shared__ __attribute__((aligned(16))) uint32_t tile[kTileRowsMax][kTileWords];
+// ---- LDS-DMA (round 4) -------------------------------------------------------------------------------------------------------------
+// global_load_lds_dwordx4: lane l of the wave copies 16 bytes from (uniform base + its 32-bit offset) to LDS byte address M0 + 16 * l, with
+// no vector register in between; masked-off lanes copy nothing. The tile's layout (chunk i at byte 16 * i) is exactly that image, so a
+// wave stages 1 KiB of the tile with ONE instruction whose per-lane operand (row * pitch + 16 * column chunk) changes only at a level
+// boundary. hipcc neither knows M0 is live across the statement nor counts the copy: M0 is saved / restored inside the statement, and
+// the copy is retired by the explicit s_waitcnt vmcnt(0) of wait_tile() (the issuing wave's own counter: a wave reads ITS chunks back
+// right after that wait; other waves' chunks only behind the following barrier). Over-waiting is the only interaction with the waits
+// hipcc emits for its own loads (vmcnt counts retire in issue order), never under-waiting.
+__device__ __forceinline__ void glds16(const uint8_t* base, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(lds_dst)
+                 : "memory");
+}
+// 4-byte form (lane l -> M0 + 4 * l): planes whose base or pitch is only 4-byte aligned (a caller's level-0 image)
+__device__ __forceinline__ void glds4(const uint8_t* base, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ void wait_tile() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
+
+// LDS per workgroup: raw tile(s) 5.6 KB each + R tile 5.6 KB + score map 4.75 KB + pooled list 4 KB + group buffer 1 KB.
+//   kBufs = 1 (21.1 KB, seven workgroups per CU, 72 VGPRs): the next cell's tile is requested when the current cell's last tile read (the exact
+//              scoring; the NMS survivor list aliases the R tile) is behind every wave, and lands under the cell's tail and the other six workgroups;
+//   kBufs = 2 (26.7 KB, six workgroups per CU, 84 VGPRs): requested a whole cell ahead into the other buffer.
+// kTiming: wave 0 accumulates shader cycles per phase into tstats (tuning aid, OVS_FAST_TIMING).
+template <int kBufs, bool kTiming>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kBufs == 1 ? 7 : 6, kBufs == 1 ? 7 : 6))) void k_fast_cells(
+    const FrameGeo* __restrict__ geo, const CellDesc* __restrict__ cell_tab, const uint8_t* __restrict__ img0, size_t stride0, size_t frame_stride0,
+    const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes, uint64_t* __restrict__ cand, size_t cand_frame_entries, uint32_t* __restrict__ cand_count,
+    const uint8_t* __restrict__ mask, int batch, uint32_t batch_magic, int cell_lo, int n_cells, int cells_per_wg, unsigned long long* __restrict__ tstats) {
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[kBufs][kTileRowsMax][kTileWords];
     __shared__ __attribute__((aligned(16))) uint32_t smap[kSmapRows][kSmapWords];
     __shared__ __attribute__((aligned(16))) uint32_t rtile[kTileRowsMax][kTileWords];
     __shared__ uint16_t clist[kListCap];                // pixels that passed the diameter test, (y << 8) | x, all four waves
     __shared__ uint32_t wgbuf[kWgSurvivors];            // (slot << 26) | (score << 12) | (y << 6) | x of the group's survivors not yet written out
     __shared__ uint32_t n_cand_wg, n_out, list_base;
 
-    static_assert(sizeof(tile) >= kMaxSurvivors * sizeof(uint32_t), "survivor list aliases the tile");
-    uint32_t* const olist = &tile[0][0];
+    static_assert(sizeof(rtile) >= kMaxSurvivors * sizeof(uint32_t), "survivor list aliases the R tile");
+    uint32_t* const olist = &rtile[0][0];   // written by the NMS, when every wave is past its last R-tile read (the pre-test)
     const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = geo->num_levels;
     unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
-    const bool t_on = kTiming && __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+    const bool t_on = kTiming && wave == 0;
 #define FAST_MARK(i)                                   \
     if (kTiming && t_on) {                             \
         const unsigned long long t_now = clock64();    \
@@ -536,10 +232,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
         t_prev = t_now;                                \
     }
     if (kTiming && t_on) t_prev = clock64();
-    // Work order: a workgroup takes `cells_per_wg` CONSECUTIVE cells of one frame (they share tile halo columns, and the workgroup lives long
-    // enough that its launch and the first tile's load latency are paid once per group, not once per cell: round 3 measured 4.4 of 6 possible
-    // waves per SIMD resident with one cell per workgroup). XCD-aware as before: XCD k takes the k-th contiguous eighth of the groups, the
-    // frame index runs fastest inside an XCD's share.
+    // Work order: a workgroup takes `cells_per_wg` CONSECUTIVE cells of one frame (the workgroup lives long enough that its launch and the
+    // first tile's load latency are paid once per group, not once per cell). XCD-aware: XCD k takes the k-th contiguous eighth of the
+    // groups, the frame index runs fastest inside an XCD's share.
     const int n_groups = (n_cells + cells_per_wg - 1) / cells_per_wg;
     const int per_xcd = (n_groups + 7) >> 3;
     const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
@@ -549,10 +244,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     const int cell_first = cell_lo + group * cells_per_wg;
     const int n_here = min(cells_per_wg, cell_lo + n_cells - cell_first);
 
-    // a cell's record: ONE 8-byte scalar load at a wave-uniform address, requested a whole cell ahead (round 3: deriving a cell's geometry from the level tables -- level search, level record,
-    // cell -> (row, column) -- was a chain of dependent scalar loads in front of every tile request, a fifth of a cell's time)
+    // a cell's record: ONE 8-byte scalar load at a wave-uniform address (x | y << 16, cw | ch << 8 | level << 16)
     uint32_t n_buf = 0;   // survivors waiting in wgbuf: every thread keeps the same count (all control flow below is workgroup-uniform)
-    const uint2 d0 = reinterpret_cast<const uint2*>(cell_tab)[cell_first];   // the first cell directly (uniform address: a scalar load)
+    const uint2 d0 = reinterpret_cast<const uint2*>(cell_tab)[cell_first];
 
     auto level_ref = [&](int level) -> LevelRef {
         const LevelGeo& g = geo->lv[level];
@@ -571,42 +265,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
         r.scale = g.scale;
         return r;
     };
-    // tile byte u of row r <-> image (min_x - 3 + u, min_y + r); min_x - 3 = 16 + 64 * column is 16-byte aligned
-    auto fetch_chunk = [&](const LevelRef& lr, int min_x, int min_y, int ch, int r, int q) -> uint4 {
-        uint4 v = {0u, 0u, 0u, 0u};
-        const int gx = min_x - 3 + 16 * q;
-        if (r < ch) {
-            const uint8_t* p = lr.img + (size_t)(min_y + r) * lr.pitch + gx;
-            if (lr.vec16) {
-                if (gx < lr.pitch) v = *reinterpret_cast<const uint4*>(p);
-            } else {   // 4-byte aligned base/stride (enforced by the ABI), row tail
-                const uint32_t* p4 = reinterpret_cast<const uint32_t*>(p);
-                if (gx + 4 <= lr.pitch) v.x = p4[0];
-                if (gx + 8 <= lr.pitch) v.y = p4[1];
-                if (gx + 12 <= lr.pitch) v.z = p4[2];
-                if (gx + 16 <= lr.pitch) v.w = p4[3];
-            }
-        }
-        return v;
-    };
-    constexpr int kChunks = kTileRowsMax * 5;
+    // this thread's chunks of a tile: chunk tid = (row ra, column chunk qa), chunk tid + 256 = (rb, qb) for the first 94 threads
     const int ra = (tid * 0x3334) >> 16, qa = tid - 5 * ra;                       // tid / 5, tid % 5
     const int rb = ((tid + 256) * 0x3334) >> 16, qb = (tid + 256) - 5 * rb;
     const bool has_b = tid + 256 < kChunks;
+    uint32_t off_a = 0, off_b = 0;   // byte offsets of the two chunks from a tile's origin in the current level's plane
+    auto chunk_offsets = [&](const LevelRef& lv) {
+        off_a = (uint32_t)(ra * lv.pitch + 16 * qa);
+        off_b = (uint32_t)(rb * lv.pitch + 16 * qb);
+    };
+    // tile byte u of row r <-> image (min_x - 3 + u, min_y + r); min_x - 3 = 16 + 64 * column is 16-byte aligned. Rows >= ch and chunks at or
+    // beyond the plane's pitch are NOT copied: those tile bytes keep whatever an earlier cell left there, and only feed pixels outside the cell's
+    // testable area, whose pre-test bits the `valid` mask removes (the exact scorer and the NMS only ever see valid pixels).
+    auto issue_tile = [&](const LevelRef& lv, uint32_t rec_x, uint32_t rec_y, uint32_t lds_tile) {
+        const int min_x = (int)(rec_x & 0xffffu), min_y = (int)(rec_x >> 16), ch = (int)((rec_y >> 8) & 255u);
+        const int gx = min_x - 3;
+        const uint8_t* const base = lv.img + (size_t)min_y * (size_t)lv.pitch + (size_t)gx;
+        if (lv.vec16) {
+            if (ra < ch && gx + 16 * qa < lv.pitch) glds16(base, off_a, lds_tile + 1024u * (uint32_t)wave);
+            if (has_b && rb < ch && gx + 16 * qb < lv.pitch) glds16(base, off_b, lds_tile + 4096u + 1024u * (uint32_t)wave);
+        } else {   // 4-byte aligned base / pitch (enforced by the ABI): 1400 words, 64 per wave-instruction
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                int lane = tid & 63;
+                asm volatile("" : "+v"(lane));   // keeps the per-lane (row, word) of this rare path out of registers that live across the cell loop
+                const int i = 64 * (wave + 4 * j) + lane;
+                const int r = (i * 0x0ccd) >> 16, c4 = i - 20 * r;   // i / 20 for i < 1536
+                if (i < kTileRowsMax * kTileWords && r < ch && gx + 4 * c4 + 4 <= lv.pitch)
+                    glds4(base, (uint32_t)(r * lv.pitch + 4 * c4), lds_tile + 256u * (uint32_t)(wave + 4 * j));
+            }
+        }
+    };
     const int run = tid & 7, rp = tid >> 3;
     const int c0 = run * 8, row0 = 2 * rp;
-    const uint8_t* const tbytes = reinterpret_cast<const uint8_t*>(&tile[0][0]);
     uint32_t* const smap_flat = &smap[0][0];
     uint8_t* const sbytes = reinterpret_cast<uint8_t*>(smap_flat);
     static_assert((kSmapRows * kSmapWords) % 4 == 0, "score map is cleared with 16-byte stores");
     const uint8_t* const fmask = mask ? mask + (size_t)frame * frame_stride0 : nullptr;   // same layout as the level-0 frames
     const int ini_thr = geo->ini_thr, min_thr = geo->min_thr;
+    const uint32_t lds_tile0 = lds_addr(&tiles[0][0][0]);
 
-    // record of cell d: x | y << 16, cw | ch << 8 | level << 16
-    uint32_t dn_x = d0.x, dn_y = d0.y;                          // record of the cell whose tile is being requested
+    uint32_t dn_x = d0.x, dn_y = d0.y;                          // record of the cell whose tile is in flight
     LevelRef lr_next = level_ref((int)((dn_y >> 16) & 255u));   // its level
-    uint4 va = fetch_chunk(lr_next, (int)(dn_x & 0xffffu), (int)(dn_x >> 16), (int)((dn_y >> 8) & 255u), ra, qa), vb = {0u, 0u, 0u, 0u};
-    if (has_b) vb = fetch_chunk(lr_next, (int)(dn_x & 0xffffu), (int)(dn_x >> 16), (int)((dn_y >> 8) & 255u), rb, qb);
+    chunk_offsets(lr_next);
+    issue_tile(lr_next, dn_x, dn_y, lds_tile0);
     LevelRef lr_buf = lr_next;   // level of the survivors waiting in wgbuf
 
     // write the buffered survivors of the group to their (frame, level) list: ONE reservation for all of them
@@ -627,38 +329,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
             n_buf = 0;
         }
     };
-
-    for (int k = 0; k < n_here; ++k) {
-        FAST_MARK(0)   // loop overhead / previous cell's tail
-        // ---- stage the tile this thread's two chunks belong to (requested one cell ago): raw bytes for the exact scoring, and
-        //      R = (p >> 2) | 0x80 per byte for the diameter test
-        for (int i = tid; i < kSmapRows * kSmapWords / 4; i += 256) reinterpret_cast<uint4*>(smap_flat)[i] = uint4{0u, 0u, 0u, 0u};
-        if (tid == 0) {
-            n_out = 0;
-            n_cand_wg = 0;
-        }
-        *reinterpret_cast<uint4*>(&tile[ra][4 * qa]) = va;
-        *reinterpret_cast<uint4*>(&rtile[ra][4 * qa]) = uint4{to_r6(va.x), to_r6(va.y), to_r6(va.z), to_r6(va.w)};
-        if (has_b) {
-            *reinterpret_cast<uint4*>(&tile[rb][4 * qb]) = vb;
-            *reinterpret_cast<uint4*>(&rtile[rb][4 * qb]) = uint4{to_r6(vb.x), to_r6(vb.y), to_r6(vb.z), to_r6(vb.w)};
-        }
-        FAST_MARK(1)   // staging stores (incl. the wait for the prefetched chunks)
-        const uint32_t dc_x = dn_x, dc_y = dn_y;   // this cell's record
-        const LevelRef lr = lr_next;
-        lds_barrier();
-        FAST_MARK(2)   // barrier 1
-        // ---- request the next cell's tile: the loads are in flight under everything below (the barriers are LDS-only)
+    // request the tile of cell k + 1 (workgroup-uniform)
+    auto request_next = [&](int k) {
         if (k + 1 < n_here) {
             const uint2 dsc = reinterpret_cast<const uint2*>(cell_tab)[cell_first + k + 1];   // uniform address: scalar load, not an LDS round trip
             dn_x = dsc.x;
             dn_y = dsc.y;
             const int nl = (int)((dn_y >> 16) & 255u);
-            if (nl != lr_next.level) lr_next = level_ref(nl);
-            va = fetch_chunk(lr_next, (int)(dn_x & 0xffffu), (int)(dn_x >> 16), (int)((dn_y >> 8) & 255u), ra, qa);
-            if (has_b) vb = fetch_chunk(lr_next, (int)(dn_x & 0xffffu), (int)(dn_x >> 16), (int)((dn_y >> 8) & 255u), rb, qb);
+            if (nl != lr_next.level) {
+                lr_next = level_ref(nl);
+                chunk_offsets(lr_next);
+            }
+            issue_tile(lr_next, dn_x, dn_y, lds_tile0 + (kBufs == 2 ? (uint32_t)((k + 1) & 1) * (uint32_t)kTileBytes : 0u));
         }
-        FAST_MARK(3)   // next cell's record + load issue
+    };
+
+    for (int k = 0; k < n_here; ++k) {
+        FAST_MARK(0)   // loop overhead / previous cell's tail
+        uint32_t(*const tile)[kTileWords] = tiles[kBufs == 2 ? (k & 1) : 0];
+        const uint8_t* const tbytes = reinterpret_cast<const uint8_t*>(&tile[0][0]);
+        const uint32_t dc_x = dn_x, dc_y = dn_y;   // this cell's record
+        const LevelRef lr = lr_next;
+        // ---- the tile has landed (this wave's chunks; with the 4-byte form a chunk is other waves' words: barrier first)
+        wait_tile();
+        if (!lr.vec16) lds_barrier();
+        FAST_MARK(1)   // wait for the tile
+        // R = (p >> 2) | 0x80 per byte for the diameter test: every thread converts the chunks its own lanes copied
+        {
+            const uint4 va = *reinterpret_cast<const uint4*>(&tile[ra][4 * qa]);
+            *reinterpret_cast<uint4*>(&rtile[ra][4 * qa]) = uint4{to_r6(va.x), to_r6(va.y), to_r6(va.z), to_r6(va.w)};
+            if (has_b) {
+                const uint4 vb = *reinterpret_cast<const uint4*>(&tile[rb][4 * qb]);
+                *reinterpret_cast<uint4*>(&rtile[rb][4 * qb]) = uint4{to_r6(vb.x), to_r6(vb.y), to_r6(vb.z), to_r6(vb.w)};
+            }
+        }
+        for (int i = tid; i < kSmapRows * kSmapWords / 4; i += 256) reinterpret_cast<uint4*>(smap_flat)[i] = uint4{0u, 0u, 0u, 0u};
+        if (tid == 0) {
+            n_out = 0;
+            n_cand_wg = 0;
+        }
+        lds_barrier();
+        FAST_MARK(2)   // R pass + clears + barrier 1
+        if (kBufs == 2) request_next(k);   // into the other buffer: its last readers (cell k - 1's scoring) are behind the barrier above
+        FAST_MARK(3)   // next cell's record + copy issue
 
         const int min_x = (int)(dc_x & 0xffffu), min_y = (int)(dc_x >> 16);
         const int cw = (int)(dc_y & 255u), ch = (int)((dc_y >> 8) & 255u);
@@ -673,7 +386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
         }
         if (!skip) {
             // candidate-mask layout: bit 8 * b + 2 * R0 + G <-> pixel c0 + 4 * G + b of row row0 + R0. Where the level border clips the testable
-            // area (workgroup-uniform, ~9 % of the cells) the pixels outside are masked; the empty asm keeps this a real branch (see v3).
+            // area (workgroup-uniform, ~9 % of the cells) the pixels outside are masked; the empty asm keeps this a real branch.
             uint32_t valid = 0x0f0f0f0fu;
             if (iw < kCellSize || ih < kCellSize) {
                 asm volatile("" ::: "memory");
@@ -699,17 +412,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                         w[r][1] = rtile[row0 + r][2 * run + 1];
                         w[r][2] = b.x;
                         w[r][3] = b.y;
-                        if (r == 3 || r == 4 || (kD8 && (r == 2 || r == 5))) {
+                        if (r == 3 || r == 4) {
                             w[r][0] = rtile[row0 + r][2 * run];
                             w[r][4] = rtile[row0 + r][2 * run + 4];
                         }
                     }
                     const uint32_t kk = 0x80808080u - (uint32_t)((thr + 1) >> 2) * 0x01010101u;
                     uint32_t b00, d00, b10, d10, b01, d01, b11, d11;
-                    swar_diameter_test<0, 0, kD8>(w, kk, b00, d00);
-                    swar_diameter_test<1, 0, kD8>(w, kk, b10, d10);
-                    swar_diameter_test<0, 1, kD8>(w, kk, b01, d01);
-                    swar_diameter_test<1, 1, kD8>(w, kk, b11, d11);
+                    swar_diameter_test<0, 0>(w, kk, b00, d00);
+                    swar_diameter_test<1, 0>(w, kk, b10, d10);
+                    swar_diameter_test<0, 1>(w, kk, b01, d01);
+                    swar_diameter_test<1, 1>(w, kk, b11, d11);
                     constexpr uint32_t kM = 0x80808080u;
                     const uint32_t bm = ((b00 & kM) >> 7) | ((b10 & kM) >> 6) | ((b01 & kM) >> 5) | ((b11 & kM) >> 4);
                     dmask = (((d00 & kM) >> 7) | ((d10 & kM) >> 6) | ((d01 & kM) >> 5) | ((d11 & kM) >> 4)) & valid;
@@ -799,7 +512,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                 lds_barrier();
                 FAST_MARK(8)   // barrier 3
                 // ---- 4. strict NMS over the 8 neighbours (unevaluated neighbours have S <= thr < S(p): 0 in the map), survivors -> olist
-                //      (olist aliases the tile: every wave is past its last tile read, the scoring, by the barrier above)
+                //      (olist aliases the R tile: every wave is past its last R-tile read, the pre-test, by the barriers above; a retry with
+                //      min_fast_thr only happens when NO survivor was written, i.e. with the R tile intact)
                 for (int i = tid; i < n_cand; i += 256) {
                     const uint32_t e = clist[i] & 0x3f3fu;
                     const int x = e & 255, y = e >> 8;
@@ -818,13 +532,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                 lds_barrier();
                 FAST_MARK(10)  // barrier 4
                 if (n_out != 0 || thr <= min_thr) break;
-                // "if keypts_in_cell.empty()": again with min_fast_thr (rare: flat cells). No survivor was written, so the tile is intact.
+                // "if keypts_in_cell.empty()": again with min_fast_thr (rare: flat cells). No survivor was written, so the R tile is intact.
                 thr = min_thr;
                 for (int i = tid; i < kSmapRows * kSmapWords / 4; i += 256) reinterpret_cast<uint4*>(smap_flat)[i] = uint4{0u, 0u, 0u, 0u};
                 if (tid == 0) n_cand_wg = 0;
                 lds_barrier();
             }
-
+        }
+        // one buffer: the raw tile's last readers (the exact scoring of the last pass) are behind barrier 4 -- request the next cell's tile now;
+        // it lands under the tail below and under the other workgroups of the CU
+        if (kBufs == 1) request_next(k);
+        if (!skip) {
             // ---- 5. the cell's survivors join the group's buffer; the (frame, level) list is reserved ONCE per group (or when the buffer is
             //      full / the level changes): the reservation's global atomic round trip, a fifth of a cell's time when every cell paid it, is
             //      paid per group. FAST response = S - 1.
@@ -878,7 +596,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                 }
             }
         }
-        lds_barrier();   // the next cell's staging overwrites tile / olist, smap and the counters
+        lds_barrier();   // the next cell's staging overwrites the R tile / olist, smap and the counters
         FAST_MARK(11)  // buffer / flush + last barrier
     }
     flush(lr_buf);
@@ -895,55 +613,52 @@ hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t*
     (void)mask_rows;
     if (n_cells < 0) n_cells = hgeo.total_cells - cell_lo;
     if (n_cells <= 0 || batch <= 0) return hipSuccess;
+    const Tuning& tn = tuning();   // environment switches, read ONCE per process
     const unsigned per_xcd = (unsigned)(n_cells + 7) / 8u;
-    const char* const env_v3 = getenv("OVS_FAST_V3");   // A/B aid (round 3), read per launch so that one process can time both
-    const bool use_v3 = env_v3 && env_v3[0] == '1';
     // slot = idx / batch as a multiply-high: exact while idx * batch < 2^32 (idx < per_xcd * batch)
     if ((uint64_t)per_xcd * (uint64_t)batch * (uint64_t)batch >= (1ull << 32)) return hipErrorInvalidValue;
     const uint32_t batch_magic = batch > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)batch - 1) / (uint64_t)batch) : 0u;
-    const char* const env_k = getenv("OVS_FAST_CELLS");   // tuning aid: consecutive cells per workgroup
     // Six cells per workgroup amortise a group's set-up when the launch holds many times more cells than the chip has workgroup slots
     // (256 CUs x 7); a tracker's single frame (~1000 cells in this launch) would leave most CUs with one workgroup walking six cells in
     // turn -- there two per workgroup are best (measured: 1 frame 41.6 -> 22.0 us, 4 frames 59 -> 45 us, 16 frames 144 -> 132 us with three)
     const long long launch_cells = (long long)n_cells * batch;
     const int cells_auto = (int)std::min<long long>(6, std::max<long long>(2, (launch_cells + 2800) / 5600));
-    const int cells_per_wg = env_k ? std::min(std::max(atoi(env_k), 1), kMaxCellsPerWg) : cells_auto;
-    if (use_v3)
-        hipLaunchKernelGGL(k_fast_cells_v3, dim3(8u * per_xcd * (unsigned)batch), dim3(256), 0, s, d.geo, img0, stride0, frame_stride0, d.pyr,
-                           d.pyr_frame_bytes, d.cand, d.cand_frame_entries, d.cand_count, mask, batch, cell_lo, n_cells);
-    else
-    {
-        const unsigned n_groups = ((unsigned)n_cells + (unsigned)cells_per_wg - 1) / (unsigned)cells_per_wg, gper = (n_groups + 7) / 8u;
-        const char* const env_pad = getenv("OVS_FAST_PAD_LDS");   // occupancy probe: extra dynamic LDS per workgroup (never set in production)
-        const size_t pad_lds = env_pad ? (size_t)atoi(env_pad) : 0;
-        if (getenv("OVS_FAST_TIMING")) {   // tuning aid: per-phase shader cycles of wave 0 of every workgroup, printed per launch
-            static unsigned long long* d_t = nullptr;
-            if (!d_t && hipMalloc(&d_t, 16 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
-            (void)hipMemsetAsync(d_t, 0, 16 * sizeof(unsigned long long), s);
-            hipLaunchKernelGGL((k_fast_cells<true, false>), dim3(8u * gper * (unsigned)batch), dim3(256), pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr,
-                               d.pyr_frame_bytes, d.cand, d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, d_t);
-            unsigned long long h_t[16];
-            (void)hipStreamSynchronize(s);
-            (void)hipMemcpy(h_t, d_t, sizeof(h_t), hipMemcpyDeviceToHost);
-            static const char* nm[12] = {"loop", "stage", "next-issue", "bar1", "pretest", "pool", "bar2", "score", "bar3", "nms", "bar4", "append+bar5"};
-            unsigned long long tot = 0;
-            for (int i = 0; i < 12; ++i) tot += h_t[i];
-            fprintf(stderr, "[k_fast_cells timing] %llu workgroups x %d cells, %.0f cycles per cell:", h_t[12], cells_per_wg,
-                    (double)tot / ((double)h_t[12] * cells_per_wg + 1e-9));
-            for (int i = 0; i < 12; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)h_t[i] / (double)(tot + 1));
-            fprintf(stderr, "\n");
-            return hipGetLastError();
-        }
-        const char* const env_d8 = getenv("OVS_FAST_DIAM8");   // A/B aid: eight-diameter pre-test
-        if (env_d8 && env_d8[0] == '1')
-            hipLaunchKernelGGL((k_fast_cells<false, true>), dim3(8u * gper * (unsigned)batch), dim3(256), pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0,
-                               d.pyr, d.pyr_frame_bytes, d.cand, d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells,
-                               cells_per_wg, (unsigned long long*)nullptr);
+    const int cells_per_wg = tn.fast_cells > 0 ? std::min(tn.fast_cells, kMaxCellsPerWg) : cells_auto;
+    const unsigned n_groups = ((unsigned)n_cells + (unsigned)cells_per_wg - 1) / (unsigned)cells_per_wg, gper = (n_groups + 7) / 8u;
+    const dim3 grid(8u * gper * (unsigned)batch), block(256);
+    const size_t pad_lds = (size_t)tn.fast_pad_lds;   // occupancy probe: extra dynamic LDS per workgroup (0 in production)
+    if (tn.fast_timing) {   // tuning aid: per-phase shader cycles of wave 0 of every workgroup, printed per launch
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxTuningDevices) return hipErrorInvalidDevice;
+        static unsigned long long* d_t[kMaxTuningDevices] = {};
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!d_t[dev] && hipMalloc(&d_t[dev], 16 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(d_t[dev], 0, 16 * sizeof(unsigned long long), s);
+        if (tn.fast_bufs == 2)
+            hipLaunchKernelGGL((k_fast_cells<2, true>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
+                               d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, d_t[dev]);
         else
-            hipLaunchKernelGGL((k_fast_cells<false, false>), dim3(8u * gper * (unsigned)batch), dim3(256), pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0,
-                               d.pyr, d.pyr_frame_bytes, d.cand, d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells,
-                               cells_per_wg, (unsigned long long*)nullptr);
+            hipLaunchKernelGGL((k_fast_cells<1, true>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
+                               d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, d_t[dev]);
+        unsigned long long h_t[16];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h_t, d_t[dev], sizeof(h_t), hipMemcpyDeviceToHost);
+        static const char* nm[12] = {"loop", "tile-wait", "rpass+bar1", "next-issue", "pretest", "pool", "bar2", "score", "bar3", "nms", "bar4", "append+bar5"};
+        unsigned long long tot = 0;
+        for (int i = 0; i < 12; ++i) tot += h_t[i];
+        fprintf(stderr, "[k_fast_cells<%d> timing] %llu workgroups x %d cells, %.0f cycles per cell:", tn.fast_bufs, h_t[12], cells_per_wg,
+                (double)tot / ((double)h_t[12] * cells_per_wg + 1e-9));
+        for (int i = 0; i < 12; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)h_t[i] / (double)(tot + 1));
+        fprintf(stderr, "\n");
+        return hipGetLastError();
     }
+    if (tn.fast_bufs == 2)
+        hipLaunchKernelGGL((k_fast_cells<2, false>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
+                           d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, (unsigned long long*)nullptr);
+    else
+        hipLaunchKernelGGL((k_fast_cells<1, false>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
+                           d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, (unsigned long long*)nullptr);
     return hipGetLastError();
 }
 

@@ -32,7 +32,7 @@ __device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b) {
     return d;
 }
 
-__global__ __launch_bounds__(256) void k_resize_linear_u8_v3(const uint8_t* __restrict__ src, size_t src_frame_stride, int src_pitch,
+__global__ __launch_bounds__(256) void k_resize_linear_u8_generic(const uint8_t* __restrict__ src, size_t src_frame_stride, int src_pitch,
                                                          int srows, int scols, uint8_t* __restrict__ dst, size_t dst_frame_stride,
                                                          int dst_pitch, int drows, int dcols, const ResizeTap* __restrict__ xt,
                                                          const ResizeTap* __restrict__ yt, int tiles_x, int tiles_y, int batch, float inv_tiles_x,
@@ -343,18 +343,16 @@ hipError_t launch_resize(const uint8_t* src, size_t src_frame_stride, int src_pi
     const int tiles_x = (dcols + kTileW - 1) / kTileW, tiles_y = (drows + kTileH - 1) / kTileH;
     const int tiles_frame = tiles_x * tiles_y;
     dim3 grid(((tiles_frame * batch + 7) / 8) * 8);
-    const char* const env_v3 = getenv("OVS_RESIZE_V3");   // A/B aid (round 3), read per launch so that one process can time both
-    const bool force_v3 = env_v3 && env_v3[0] == '1';
     // v4 needs: the host-checked tap windows (hwin_ok also says every tile's source rectangle fits the LDS tile), 16-byte aligned source
     // rows, and tile_id * tiles_frame < 2^32 for the multiply-high divisions
-    const bool v4 = !force_v3 && hwin_ok && ((src_pitch & 15) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
+    const bool v4 = hwin_ok && ((src_pitch & 15) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
                     ((src_frame_stride & 15) == 0) && (uint64_t)tiles_frame * (uint64_t)tiles_frame * (uint64_t)batch < (1ull << 32);
     auto magic = [](int d) { return d > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d) : 0u; };
     if (v4)
         hipLaunchKernelGGL(k_resize_linear_u8, grid, dim3(256), 0, s, src, src_frame_stride, src_pitch, dst, dst_frame_stride, dst_pitch,
                            drows, dcols, xt, yt, tiles_x, tiles_frame, batch, magic(tiles_x), magic(tiles_frame));
     else
-        hipLaunchKernelGGL(k_resize_linear_u8_v3, grid, dim3(256), 0, s, src, src_frame_stride, src_pitch, srows, scols, dst,
+        hipLaunchKernelGGL(k_resize_linear_u8_generic, grid, dim3(256), 0, s, src, src_frame_stride, src_pitch, srows, scols, dst,
                            dst_frame_stride, dst_pitch, drows, dcols, xt, yt, tiles_x, tiles_y, batch, 1.0f / (float)tiles_x,
                            1.0f / (float)tiles_frame);
     return hipGetLastError();

@@ -524,12 +524,11 @@ hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hip
     // memory: with few problems in the launch (a tracker's single frame) 1024 threads halve it; with many, 512 threads let more
     // problems share a CU and win (0.247 vs 0.278 ms per 128 frames).
     const bool few = (long long)n_levels * batch <= 64;
-    static thread_local size_t configured[2] = {0, 0};
+    static LdsAttrCache configured[2];   // per device
     const void* fn = few ? reinterpret_cast<const void*>(k_tree<kTreeThreadsFew>) : reinterpret_cast<const void*>(k_tree<kTreeThreadsBatch>);
-    if (lds > configured[few ? 1 : 0]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dynamic_lds(fn, lds, configured[few ? 1 : 0]);
         if (e != hipSuccess) return e;
-        configured[few ? 1 : 0] = lds;
     }
     dim3 grid(n_levels, batch);
     if (few)

@@ -111,6 +111,39 @@ constexpr size_t kMaxLdsPerWorkgroup = 160 * 1024;
 hipError_t launch_describe(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
                            ovs_keypoint* kps, uint8_t* desc, int32_t* counts, int cap, int batch, hipStream_t s);
 
+// Tuning / A-B switches of the launchers. Read from the environment ONCE per process (first use; thread-safe static initialisation) -- the
+// launch paths never call getenv, which is not safe against a host application's concurrent setenv. All default to the production setting.
+constexpr int kMaxTuningDevices = 16;
+struct Tuning {
+    int fast_cells;        // OVS_FAST_CELLS: consecutive cells per k_fast_cells workgroup (0 = by launch size)
+    int fast_pad_lds;      // OVS_FAST_PAD_LDS: extra dynamic LDS per k_fast_cells workgroup (occupancy probe)
+    int fast_bufs;         // OVS_FAST_BUFS: 1 (default) or 2 raw-tile buffers in k_fast_cells
+    bool fast_timing;      // OVS_FAST_TIMING: per-phase cycle counts of k_fast_cells, printed per launch
+    bool describe_xcd;     // OVS_DESCRIBE_XCD=0: plain frame-major order in k_describe
+    int resolve_wide_from; // OVS_RESOLVE_WIDE_FROM: queries from which a resolver round takes 512 of them
+    int pose_threads;      // OVS_POSE_THREADS: 256 / 512 (0 = by problem size)
+    bool ba_trace;         // OVS_BA_TRACE: per-iteration trace of the LM loops on stderr
+};
+const Tuning& tuning();
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: remember the largest size set for one kernel on every device
+struct LdsAttrCache {
+    std::atomic<size_t> set[kMaxTuningDevices] = {};
+};
+inline hipError_t ensure_dynamic_lds(const void* fn, size_t bytes, LdsAttrCache& c) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool cached = dev >= 0 && dev < kMaxTuningDevices;
+    if (cached && bytes <= c.set[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && cached) {
+        size_t cur = c.set[dev].load(std::memory_order_relaxed);
+        while (cur < bytes && !c.set[dev].compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+    }
+    return e;
+}
+
 void set_last_error(const char* what, hipError_t e);
 // ovs_debug_inject_hip_failures(skip, n): after `skip` further OVS_HIP_TRY-checked calls, the next n of them (the calls themselves
 // still run) report hipErrorLaunchFailure. One relaxed atomic load per checked HIP call when nothing is armed.

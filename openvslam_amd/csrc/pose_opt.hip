@@ -484,20 +484,13 @@ static ovs_status pose_optimize_batch_dev(int model, const double* d_poses_in, c
     if (!d_poses_in || !d_obs || !d_obs_offsets || !d_poses_out || !d_outlier || !d_num_valid || batch < 1) return OVS_ERR_INVALID;
     // workgroup size: the kernel is one latency-bound workgroup per frame; more waves hide the f64 latency of the per-observation work
     // but pay in barriers (measured per 2000-observation frame in DESIGN.md section 3.6)
-    static const int threads_env = [] {
-        const char* e = std::getenv("OVS_POSE_THREADS");
-        return e ? std::atoi(e) : 0;
-    }();
+    const int threads_env = tuning().pose_threads;
     const int T = threads_env == 256 || threads_env == 512 ? threads_env : threads_default;
     const size_t lds = sizeof(double) * 28 * (size_t)(T + 8);
 #define OVS_POSE_LAUNCH(MODEL, TT, BF, ST)                                                                                              \
     do {                                                                                                                              \
-        static thread_local bool configured = false;                                                                                   \
-        if (!configured) {                                                                                                             \
-            OVS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_optimize<MODEL, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                            (int)(sizeof(double) * 28 * (TT + 8))));                                                 \
-            configured = true;                                                                                                         \
-        }                                                                                                                              \
+        static LdsAttrCache configured; /* per device: a second device needs the attribute too (116 KB of dynamic LDS at 512 threads) */  \
+        OVS_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(k_pose_optimize<MODEL, TT>), sizeof(double) * 28 * (TT + 8), configured)); \
         hipLaunchKernelGGL((k_pose_optimize<MODEL, TT>), dim3(batch), dim3(TT), lds, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, \
                            cam, BF, ST, d_poses_out, d_outlier, d_num_valid);                                                          \
     } while (0)
