@@ -19,6 +19,7 @@ namespace detail {
 struct window_holder {
     ovs_wmatcher* w = nullptr;
     int cap_t = 0, cap_q = 0;
+    int entries = 1 << 22;   // candidate-list budget; doubled by grow() after OVS_ERR_CAPACITY, up to 2^26 (256 MB of keys)
     ~window_holder() {
         if (w) ovs_wmatcher_destroy(w);
     }
@@ -28,7 +29,7 @@ struct window_holder {
         w = nullptr;
         cap_t = n_t < 8192 ? 8192 : n_t;
         cap_q = n_q < 16384 ? 16384 : n_q;
-        const int st = ovs_wmatcher_create(cap_t, cap_q, 1 << 22, 0, &w);
+        const int st = ovs_wmatcher_create(cap_t, cap_q, entries, 0, &w);
         if (st != OVS_OK) {
             w = nullptr;
             cap_t = cap_q = 0;
@@ -40,6 +41,12 @@ struct window_holder {
         if (w) ovs_wmatcher_destroy(w);
         w = nullptr;
         cap_t = cap_q = 0;
+    }
+    bool grow() {
+        if (entries >= (1 << 26)) return false;
+        entries <<= 1;
+        reset();   // rebuilt with the larger budget by the next get()
+        return true;
     }
 };
 inline window_holder& window_ctx() {
@@ -117,11 +124,14 @@ inline void flatten_bow(const data::bow_feature_vector& fv, std::vector<int32_t>
 // uses are dropped. false -> the caller returns zero matches (its outputs may be partly written: it must not read them).
 template <class Call>
 inline bool guarded(const char* what, Call&& call, std::initializer_list<const data::frame*> frames = {}) {
-    return util::run_guarded(what, call, [&] {
-        window_ctx().reset();
-        for (const data::frame* f : frames)
-            if (f) f->device_cache_.reset();
-    });
+    return util::run_guarded(
+        what, call,
+        [&] {
+            window_ctx().reset();
+            for (const data::frame* f : frames)
+                if (f) f->device_cache_.reset();
+        },
+        [] { return window_ctx().grow(); });
 }
 
 static_assert(sizeof(cv::KeyPoint) == sizeof(ovs_keypoint), "cv::KeyPoint crosses the ABI as ovs_keypoint");

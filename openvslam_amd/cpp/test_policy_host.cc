@@ -53,8 +53,32 @@ static void check_run_guarded() {
     s0 = Snapshot::take();
     expect(!scripted({OVS_ERR_NO_DEVICE, OVS_OK}) && calls == 1 && resets == 0 && Snapshot::take().moved_by(s0, 1, 0, 0, 1),
            "OVS_ERR_NO_DEVICE: no retry, the empty result");
+    // deterministic caller-side statuses surface as exceptions instead of a tracker that silently never matches
     s0 = Snapshot::take();
-    expect(!scripted({OVS_ERR_CAPACITY}) && calls == 1 && resets == 0 && Snapshot::take().moved_by(s0, 1, 0, 0, 1), "OVS_ERR_CAPACITY: no retry, the empty result");
+    bool threw = false;
+    try {
+        scripted({OVS_ERR_CAPACITY});
+    } catch (const std::length_error&) {
+        threw = true;
+    }
+    expect(threw && calls == 1 && resets == 0 && Snapshot::take().moved_by(s0, 1, 0, 0, 0), "OVS_ERR_CAPACITY, nothing to grow: std::length_error");
+    {
+        int n = 0, grown = 0;
+        s0 = Snapshot::take();
+        const bool okg = util::run_guarded(
+            "grow", [&] { return n++ == 0 ? OVS_ERR_CAPACITY : OVS_OK; }, [&] {}, [&] { ++grown; return true; });
+        expect(okg && n == 2 && grown == 1 && Snapshot::take().moved_by(s0, 1, 1, 1, 0), "OVS_ERR_CAPACITY with a context that can grow: enlarged once, retried, ok");
+    }
+    threw = false;
+    s0 = Snapshot::take();
+    try {
+        scripted({OVS_ERR_INVALID});
+    } catch (const std::invalid_argument&) {
+        threw = true;
+    }
+    expect(threw && calls == 1 && Snapshot::take().moved_by(s0, 1, 0, 0, 0) && util::device_failures().surfaced.load() >= 2 &&
+               util::device_failures().by_status[1].load() >= 1,
+           "OVS_ERR_INVALID: std::invalid_argument, counted per status");
     // a context holder that cannot build its handle throws device_error inside the guarded call: same policy, by its status
     int thrown = 0;
     s0 = Snapshot::take();

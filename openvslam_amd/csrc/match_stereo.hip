@@ -306,6 +306,8 @@ extern "C" {
 
 ovs_status ovs_stereo_create(int32_t max_rows, int32_t max_keypoints, int32_t device, ovs_stereo** out) {
     if (!out || max_rows < 1 || max_keypoints < 1 || max_keypoints > 65535) return OVS_ERR_INVALID;
+    // k_stereo_index keeps the row CSR of the right image in LDS: (rows + 1 + 1024) words of the CU's 160 KiB
+    if (sizeof(uint32_t) * ((size_t)max_rows + 1 + 1024) > kMaxLdsPerWorkgroup) return OVS_ERR_CAPACITY;
     *out = nullptr;
     if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
     ovs_stereo* s = new (std::nothrow) ovs_stereo();
@@ -377,8 +379,14 @@ ovs_status ovs_stereo_compute_dev(ovs_stereo* s, const ovs_orb* left, int32_t fr
     const int rows0 = pl.rows[0];
     const float max_disp = focal_x_baseline / true_baseline;
     const dim3 gl((cap_left + 255) / 256);
-    hipLaunchKernelGGL(k_stereo_index, dim3(1), dim3(1024), sizeof(uint32_t) * (size_t)(rows0 + 1 + 1024), st, d_kps_right, d_n_right, cap_right, pr,
+    const size_t index_lds = sizeof(uint32_t) * (size_t)(rows0 + 1 + 1024);
+    if (index_lds > 64 * 1024) {   // above the default limit of dynamic LDS (images taller than ~15 000 rows): raise it, per device
+        static LdsAttrCache configured;
+        OVS_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(k_stereo_index), index_lds, configured));
+    }
+    hipLaunchKernelGGL(k_stereo_index, dim3(1), dim3(1024), index_lds, st, d_kps_right, d_n_right, cap_right, pr,
                        s->d_row_off, s->d_row_items, s->item_cap, s->d_overflow);
+    OVS_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_stereo_match, gl, dim3(256), 0, st, d_kps_left, d_desc_left, d_n_left, cap_left, d_kps_right, d_desc_right, pr,
                        (const uint32_t*)s->d_row_off, (const uint32_t*)s->d_row_items, s->item_cap, max_disp, s->d_best_right);
     hipLaunchKernelGGL(k_stereo_subpixel, dim3((cap_left + 15) / 16), dim3(256), 0, st, d_kps_left, d_n_left, cap_left, d_kps_right,

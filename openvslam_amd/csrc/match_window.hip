@@ -2104,7 +2104,19 @@ struct Stager {
         used = off + bytes;
         return reinterpret_cast<T*>(w->d_stage + off);
     }
-    hipError_t flush(hipStream_t s) { return used ? hipMemcpyAsync(w->d_stage, w->h_stage, used, hipMemcpyHostToDevice, s) : hipSuccess; }
+    hipError_t flush(hipStream_t s) {
+        flushed_on = s;
+        flushed = true;
+        return used ? hipMemcpyAsync(w->d_stage, w->h_stage, used, hipMemcpyHostToDevice, s) : hipSuccess;
+    }
+    // A call returns with its stream idle, on EVERY path: the next call (or the shim's immediate retry) memcpy's into the same pinned buffer, and
+    // a frame arena may go back to the pool -- neither may happen while a copy or a kernel of a failed call is still in flight. After a
+    // successful call the stream is already idle (fetch_results synchronised it) and this costs a microsecond.
+    hipStream_t flushed_on = nullptr;
+    bool flushed = false;
+    ~Stager() {
+        if (flushed) (void)hipStreamSynchronize(flushed_on);
+    }
 };
 
 // results: overflow flag, counts and `n_out` assignments in one copy
@@ -2318,7 +2330,7 @@ ovs_status ovs_area_match_in_consistent_area_f(ovs_wmatcher* w, const ovs_frame_
     if (st != OVS_OK) return st;
     OVS_HIP_TRY(hipMemcpyAsync(w->h_stage, d_prev, sizeof(float) * 2 * (size_t)n1, hipMemcpyDeviceToHost, s));
     st = fetch_results(w, n1, matched_2_in_1, num_matches, s);
-    std::memcpy(prev_matched_xy, w->h_stage, sizeof(float) * 2 * (size_t)n1);
+    if (st != OVS_ERR_HIP) std::memcpy(prev_matched_xy, w->h_stage, sizeof(float) * 2 * (size_t)n1);   // only behind fetch_results' synchronisation
     return st;
 }
 
