@@ -72,6 +72,8 @@ typedef struct ovs_orb ovs_orb;
 ovs_status ovs_orb_create(const ovs_orb_params* params, int32_t max_rows, int32_t max_cols, int32_t max_batch, int32_t device,
                           ovs_orb** out);
 ovs_status ovs_orb_destroy(ovs_orb* h);
+/* the HIP device the handle was created on (-1 for NULL): matcher / stereo contexts of the class shims are created on the same one */
+int32_t ovs_orb_device(const ovs_orb* h);
 
 /* replaces: orb_extractor::get_scale_factors / get_inv_scale_factors / get_level_sigma_sq / get_inv_level_sigma_sq and
  * num_keypts_per_level_. Any output pointer may be NULL. Arrays hold num_levels entries. */
@@ -661,6 +663,66 @@ ovs_status ovs_pose_optimize_equirect(int32_t device, const double* pose_cw_in, 
 ovs_status ovs_pose_optimize_equirect_batch_dev(const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
                                                 int32_t cols, int32_t rows, double* d_poses_out, uint8_t* d_outlier, int32_t* d_num_valid,
                                                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Keyframe residency (round 4).  data::keyframe copies undist_keypts_, descriptors_, stereo_x_right_, bearings_ and the keypoint grid from
+ * the frame it is made of and never changes them (expected: src/openvslam/data/keyframe.{h,cc}), while mapping_module and the loop closer
+ * hand the same keyframe to a matcher again and again: fuse::replace_duplication over ~20 covisible keyframes per new keyframe
+ * (expected: src/openvslam/mapping_module.cc::fuse_landmark_duplication), bow_tree / robust::match_for_triangulation per neighbour
+ * (create_new_landmarks), match_keyframes_mutually and match_by_Sim3_transform per loop candidate. The *_f twins below take an
+ * ovs_frame_dev for every (grid parameters, keypoints, descriptors, stereo_x_right, n) group of their host-array forms -- the handle
+ * is created once per keyframe (same constructor as for a frame) and shared by every thread on that device; nothing else about the
+ * calls changes, results are bit-identical to the host-array forms. replaces: the same upstream functions as the forms they twin.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* 3 doubles per keypoint (data::keyframe::bearings_) for ovs_robust_match_for_triangulation_f: uploaded once. Call it before the handle is
+ * shared between threads (the class shims do it inside the keyframe cache's creation lock). */
+ovs_status ovs_frame_dev_attach_bearings(ovs_frame_dev* f, const double* bearings);
+int32_t ovs_frame_dev_device(const ovs_frame_dev* f);   /* the device the handle lives on (-1 for NULL) */
+/* bow_tree::match_frame_and_keyframe (src/openvslam/match/bow_tree.cc): keyframe and frame resident; BoW feature vectors as in the host form */
+ovs_status ovs_bow_match_frame_and_keyframe_f(ovs_wmatcher* w, const ovs_frame_dev* keyfrm, const uint8_t* kf_valid, const int32_t* kf_node_ids,
+                                              const int32_t* kf_node_start, const int32_t* kf_items, int32_t kf_nodes, const ovs_frame_dev* frm,
+                                              const int32_t* frm_node_ids, const int32_t* frm_node_start, const int32_t* frm_items, int32_t frm_nodes,
+                                              float lowe_ratio, int32_t check_orientation, int32_t* matched_kf_in_frm, int32_t* num_matches);
+/* bow_tree::match_keyframes */
+ovs_status ovs_bow_match_keyframes_f(ovs_wmatcher* w, const ovs_frame_dev* keyfrm_1, const uint8_t* valid_1, const int32_t* node_ids_1,
+                                     const int32_t* node_start_1, const int32_t* items_1, int32_t nodes_1, const ovs_frame_dev* keyfrm_2,
+                                     const uint8_t* valid_2, const int32_t* node_ids_2, const int32_t* node_start_2, const int32_t* items_2, int32_t nodes_2,
+                                     float lowe_ratio, int32_t check_orientation, int32_t* matched_2_in_1, int32_t* num_matches);
+/* robust::match_for_triangulation (src/openvslam/match/robust.cc): both handles must carry bearings (ovs_frame_dev_attach_bearings) */
+ovs_status ovs_robust_match_for_triangulation_f(ovs_wmatcher* w, const ovs_frame_dev* keyfrm_1, const uint8_t* has_lm_1, const int32_t* node_ids_1,
+                                                const int32_t* node_start_1, const int32_t* items_1, int32_t nodes_1, const ovs_frame_dev* keyfrm_2,
+                                                const uint8_t* has_lm_2, const int32_t* node_ids_2, const int32_t* node_start_2, const int32_t* items_2,
+                                                int32_t nodes_2, const double* E_12, const double* epipole_in_2, const float* scale_factors,
+                                                int32_t num_levels, int32_t check_orientation, int32_t* matched_2_in_1, int32_t* num_matches);
+/* fuse::replace_duplication (src/openvslam/match/fuse.cc) */
+ovs_status ovs_fuse_replace_duplication_f(ovs_wmatcher* w, const ovs_camera* cam, const ovs_frame_dev* keyfrm, const double* pose_cw, const double* lm_pos_w,
+                                          const float* lm_dist_min_max, const double* lm_normal, const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m,
+                                          const float* scale_factors, const float* inv_level_sigma_sq, int32_t num_levels, float log_scale_factor,
+                                          float margin, int32_t* best_idx, int32_t* num_fused);
+/* fuse::detect_duplication */
+ovs_status ovs_fuse_detect_duplication_f(ovs_wmatcher* w, const ovs_camera* cam, const ovs_frame_dev* keyfrm, const double* sim3_cw, const double* lm_pos_w,
+                                         const float* lm_dist_min_max, const double* lm_normal, const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m,
+                                         const float* scale_factors, int32_t num_levels, float log_scale_factor, float margin, int32_t* best_idx,
+                                         int32_t* num_found);
+/* projection::match_frame_and_keyframe (src/openvslam/match/projection.cc): the CURRENT FRAME resident (the keyframe side is its landmarks) */
+ovs_status ovs_projection_match_frame_and_keyframe_f(ovs_wmatcher* w, const ovs_camera* cam, const ovs_frame_dev* curr, const uint8_t* curr_occupied,
+                                                     const double* pose_cw_curr, const ovs_keypoint* kf_kps, const double* kf_pos_w,
+                                                     const float* kf_dist_min_max, const uint8_t* kf_lm_desc, const uint8_t* kf_valid, int32_t n_kf,
+                                                     const float* scale_factors, int32_t num_levels, float log_scale_factor, float margin,
+                                                     uint32_t hamm_dist_thr, int32_t check_orientation, int32_t* assigned, int32_t* num_matches);
+/* projection::match_by_Sim3_transform */
+ovs_status ovs_projection_match_by_sim3_transform_f(ovs_wmatcher* w, const ovs_camera* cam, const ovs_frame_dev* keyfrm, const uint8_t* occupied,
+                                                    const double* sim3_cw, const double* lm_pos_w, const float* lm_dist_min_max, const double* lm_normal,
+                                                    const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m, const float* scale_factors,
+                                                    int32_t num_levels, float log_scale_factor, float margin, int32_t* assigned, int32_t* num_matches);
+/* projection::match_keyframes_mutually */
+ovs_status ovs_projection_match_keyframes_mutually_f(ovs_wmatcher* w, const ovs_camera* cam_1, const ovs_frame_dev* keyfrm_1, const double* pose_cw_1,
+                                                     const double* lm_pos_w_1, const float* lm_dist_1, const uint8_t* lm_desc_1, const uint8_t* lm_valid_1,
+                                                     const ovs_camera* cam_2, const ovs_frame_dev* keyfrm_2, const double* pose_cw_2,
+                                                     const double* lm_pos_w_2, const float* lm_dist_2, const uint8_t* lm_desc_2, const uint8_t* lm_valid_2,
+                                                     double s_12, const double* rot_12, const double* trans_12, const float* scale_factors,
+                                                     int32_t num_levels, float log_scale_factor, float margin, int32_t* matched_2_in_1,
+                                                     int32_t* num_matches);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Self-test of include/ovs_detmath.h on the device: out[i] = fn(a[i] (, b[i])) evaluated by a gfx950 kernel. The four functions

@@ -36,6 +36,7 @@ SYMBOLS = {
     "ovs_device_arch": (_i32, [_i32, C.c_char_p, _sz]),
     "ovs_orb_create": (_i32, [C.POINTER(OrbParams), _i32, _i32, _i32, _i32, C.POINTER(_vp)]),
     "ovs_orb_destroy": (_i32, [_vp]),
+    "ovs_orb_device": (_i32, [_vp]),
     "ovs_orb_tables": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_orb_max_keypoints": (_i32, [_vp]),
     "ovs_debug_inject_hip_failures": (_i32, [_i32, _i32]),
@@ -78,6 +79,21 @@ SYMBOLS = {
     "ovs_area_match_in_consistent_area_f": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _f, _i32, C.POINTER(_i32)]),
     "ovs_projection_match_current_and_last_frames_f": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _f, _i32, _vp,
                                                                C.POINTER(_i32)]),
+    "ovs_frame_dev_attach_bearings": (_i32, [_vp, _vp]),
+    "ovs_frame_dev_device": (_i32, [_vp]),
+    # keyframe-side twins (round 4): an ovs_frame_dev where the host form takes (gp, kps, desc, [x_right], n)
+    "ovs_bow_match_frame_and_keyframe_f": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _f, _i32, _vp, C.POINTER(_i32)]),
+    "ovs_bow_match_keyframes_f": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _f, _i32, _vp, C.POINTER(_i32)]),
+    "ovs_robust_match_for_triangulation_f": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp,
+                                                    C.POINTER(_i32)]),
+    "ovs_fuse_replace_duplication_f": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _f, _f, _vp, C.POINTER(_i32)]),
+    "ovs_fuse_detect_duplication_f": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _f, _f, _vp, C.POINTER(_i32)]),
+    "ovs_projection_match_frame_and_keyframe_f": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _f, _f, C.c_uint32, _i32,
+                                                         _vp, C.POINTER(_i32)]),
+    "ovs_projection_match_by_sim3_transform_f": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _f, _f, _vp,
+                                                        C.POINTER(_i32)]),
+    "ovs_projection_match_keyframes_mutually_f": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp,
+                                                         _vp, _i32, _f, _f, _vp, C.POINTER(_i32)]),
     "ovs_ba_multi_create": (_i32, [_i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.POINTER(_vp)]),
     "ovs_ba_multi_destroy": (_i32, [_vp]),
     "ovs_ba_multi_set_exchange": (_i32, [_vp, _i32]),

@@ -3,6 +3,7 @@
 // usage: bench_shim rows cols nfeat frame_a.raw frame_b.raw iters
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +16,7 @@
 
 #include "openvslam/feature/orb_extractor.h"
 #include "openvslam/match/area.h"
+#include "openvslam/match/fuse.h"
 #include "openvslam/match/projection.h"
 #include "openvslam/optimize/pose_optimizer.h"
 
@@ -206,6 +208,77 @@ int main(int argc, char** argv) {
                     "(ovs_frame_dev), match_frame_and_landmarks finds it resident\"}",
                     stats(t_ext).median, stats(t_cl).median, stats(t_pose).median, stats(t_lm).median, stats(t_all).median, stats(t_all).p95,
                     stats(t_area).median, last.num_keypts_, n_cl, n_pose, n_lm, n_area);
+    }
+    // ---- mapping side (round 4): fuse::replace_duplication of one new keyframe's landmarks into 20 covisible keyframes, as
+    // mapping_module::fuse_landmark_duplication does per new keyframe. The keyframes are long-lived: their handles are resident after the
+    // first call, so a call moves the landmarks to check up and the best indices down, nothing else.
+    {
+        feature::orb_extractor ex(feature::orb_params(nfeat, 1.2f, 8, 20, 7));
+        ex.set_image_pyramid_download(false);
+        camera::base pcam;
+        pcam.cols_ = cols;
+        pcam.rows_ = rows;
+        pcam.img_bounds_.max_x_ = (float)cols;
+        pcam.img_bounds_.max_y_ = (float)rows;
+        pcam.fx_ = pcam.fy_ = 500.0;
+        pcam.cx_ = cols / 2.0;
+        pcam.cy_ = rows / 2.0;
+        data::frame src;
+        ex.extract(b, cv::Mat(), src.keypts_, src.descriptors_);
+        src.num_keypts_ = src.keypts_.size();
+        src.undist_keypts_ = src.keypts_;
+        src.camera_ = &pcam;
+        src.scale_factors_ = ex.get_scale_factors();
+        src.inv_level_sigma_sq_.resize(src.scale_factors_.size());
+        for (size_t l = 0; l < src.scale_factors_.size(); ++l) src.inv_level_sigma_sq_[l] = 1.0f / (src.scale_factors_[l] * src.scale_factors_[l]);
+        src.log_scale_factor_ = std::log(1.2f);
+        src.landmarks_.assign(src.num_keypts_, nullptr);
+        const int n_kf = 20;
+        std::vector<std::unique_ptr<data::keyframe>> kfs;
+        for (int k = 0; k < n_kf; ++k) {
+            data::frame f = src;
+            f.device_cache_ = std::make_shared<data::frame_device_cache>();   // every keyframe its own data (here: equal content)
+            kfs.emplace_back(new data::keyframe(f));
+            kfs.back()->cam_pose_cw_(0, 3) = 0.002 * k;
+        }
+        std::vector<std::unique_ptr<data::landmark>> own;
+        std::vector<data::landmark*> to_check;
+        for (unsigned i = 0; i < src.num_keypts_; ++i) {
+            own.emplace_back(new data::landmark());
+            auto* lm = own.back().get();
+            const double z = 3.0 + (double)(i % 5);
+            lm->pos_w_(0) = ((double)src.undist_keypts_[i].pt.x - pcam.cx_) / pcam.fx_ * z;
+            lm->pos_w_(1) = ((double)src.undist_keypts_[i].pt.y - pcam.cy_) / pcam.fy_ * z;
+            lm->pos_w_(2) = z;
+            const double nrm = std::sqrt((lm->pos_w_(0) * lm->pos_w_(0) + lm->pos_w_(1) * lm->pos_w_(1)) + z * z);
+            for (int c = 0; c < 3; ++c) lm->mean_normal_(c) = lm->pos_w_(c) / nrm;
+            lm->max_valid_dist_ = (float)(nrm * src.scale_factors_[(size_t)src.undist_keypts_[i].octave] * 0.93);
+            lm->min_valid_dist_ = lm->max_valid_dist_ / src.scale_factors_.back();
+            lm->descriptor_ = src.descriptors_.row((int)i);
+            to_check.push_back(lm);
+        }
+        std::vector<double> t_first, t_res;
+        unsigned n_fused = 0;
+        for (int i = 0; i < iters / 4 + 3; ++i) {
+            for (int k = 0; k < n_kf; ++k) {
+                data::keyframe& kf = *kfs[(size_t)k];
+                kf.landmarks_.assign(kf.num_keypts_, nullptr);   // undo the previous round's fusions: the same work every time
+                for (auto* lm : to_check) {
+                    lm->observations_.clear();
+                    lm->num_observations_ = 1;
+                }
+                const auto t0 = clk::now();
+                n_fused = match::fuse(0.6f).replace_duplication(&kf, to_check, 3.0f);
+                const double ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+                (i == 0 ? t_first : t_res).push_back(ms);
+            }
+        }
+        std::printf(", \"mapping_fuse\": {\"keyframes\": %d, \"keypoints\": %u, \"landmarks_to_check\": %zu, \"fused_per_call\": %u, "
+                    "\"first_call_median_ms\": %.4f, \"resident_call_median_ms\": %.4f, \"resident_call_p95_ms\": %.4f, \"resident_20_keyframes_ms\": %.4f, "
+                    "\"note\": \"fuse::replace_duplication through the class, host-side landmark flattening and write-back included; first call = "
+                    "upload + grid of the keyframe (ovs_frame_dev), later calls find it resident\"}",
+                    n_kf, src.num_keypts_, to_check.size(), n_fused, stats(t_first).median, stats(t_res).median, stats(t_res).p95,
+                    stats(t_res).median * n_kf);
     }
     std::printf("}\n");
     return 0;

@@ -105,20 +105,47 @@ public:
     int scale_level_in_tracking_ = 0;
 };
 
-// The frame's matcher-side data resident in HBM (ovs_frame_dev, include/ovslam_hip.h): created by the first matcher that needs it and
-// shared by copies of the frame (upstream copies frames: last_frm = curr_frm). The ONE member an integration adds to data::frame:
-// keypoints and descriptors never change after the constructor, so the cache needs no invalidation.
+// The matcher-side data of a frame -- and of the keyframe made from it -- resident in HBM (ovs_frame_dev, include/ovslam_hip.h): created by
+// the first matcher that needs it, on the device the frame's extractor ran on, and shared by copies of the frame (upstream copies frames:
+// last_frm = curr_frm) AND by the keyframe constructed from it (keyframe::keyframe(const frame&) copies the member: a keyframe's keypoints,
+// descriptors, stereo_x_right_ and grid ARE its frame's, so creating a keyframe uploads nothing). The ONE member an integration adds to
+// data::frame and data::keyframe. Keypoints and descriptors never change after the frame's constructor, so there is no invalidation;
+// tracking and mapping threads may ask for the handle at the same time, so creation happens under the holder's lock, and a user keeps
+// its own reference for the duration of a call (a drop() after a device failure never frees a handle another thread is using).
 struct frame_device_cache {
-    void* handle = nullptr;                 // ovs_frame_dev*
-    void (*destroy)(void*) = nullptr;
-    ~frame_device_cache() {
-        if (handle && destroy) destroy(handle);
+    int device = 0;                    // HIP device of the extractor that produced the keypoints (set before the first matcher call)
+    std::mutex mu;
+    std::shared_ptr<void> handle;      // ovs_frame_dev with its deleter
+    bool has_bearings = false;         // bearings_ attached (robust::match_for_triangulation needs them; tracking never does)
+    // create: () -> std::shared_ptr<void> (throws on failure); extend: (void*) -> void, run once under the lock when `want_bearings`
+    template <class Create, class Extend>
+    std::shared_ptr<void> get(Create&& create, bool want_bearings, Extend&& extend) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!handle) {
+            handle = create();
+            has_bearings = false;
+        }
+        if (want_bearings && !has_bearings) {
+            extend(handle.get());
+            has_bearings = true;
+        }
+        return handle;
+    }
+    void drop() {
+        std::lock_guard<std::mutex> lock(mu);
+        handle.reset();
+        has_bearings = false;
+    }
+    bool resident() {
+        std::lock_guard<std::mutex> lock(mu);
+        return handle != nullptr;
     }
 };
 
 class frame {
 public:
-    mutable std::shared_ptr<frame_device_cache> device_cache_;
+    // never null, never reassigned except by whole-frame assignment (which shares the other frame's cache)
+    std::shared_ptr<frame_device_cache> device_cache_ = std::make_shared<frame_device_cache>();
     unsigned int num_keypts_ = 0;
     std::vector<cv::KeyPoint> keypts_;
     std::vector<cv::KeyPoint> undist_keypts_;
@@ -146,6 +173,14 @@ public:
 
 class keyframe {
 public:
+    keyframe() = default;
+    //! upstream: keyframe::keyframe(const frame& frm, map_database*, bow_database*) copies the frame's members -- the device cache with them
+    explicit keyframe(const frame& frm)
+        : device_cache_(frm.device_cache_), num_keypts_(frm.num_keypts_), keypts_(frm.keypts_), undist_keypts_(frm.undist_keypts_),
+          stereo_x_right_(frm.stereo_x_right_), bearings_(frm.bearings_), descriptors_(frm.descriptors_), landmarks_(frm.landmarks_),
+          scale_factors_(frm.scale_factors_), inv_level_sigma_sq_(frm.inv_level_sigma_sq_), log_scale_factor_(frm.log_scale_factor_),
+          camera_(frm.camera_), bow_feat_vec_(frm.bow_feat_vec_), cam_pose_cw_(frm.cam_pose_cw_) {}
+    std::shared_ptr<frame_device_cache> device_cache_ = std::make_shared<frame_device_cache>();
     unsigned int id_ = 0;
     bool will_be_erased() const { return will_be_erased_; }
     bool will_be_erased_ = false;

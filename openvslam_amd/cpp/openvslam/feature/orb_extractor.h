@@ -53,6 +53,8 @@ public:
     //! false: image_pyramid_ levels >= 1 stay on the device (monocular tracking never reads them; saves a 4.3 MB D2H per 1080p frame)
     void set_image_pyramid_download(const bool enable);
     //! HIP device this extractor runs on (before the first extract). Stereo rigs may put left / right on two GPUs.
+    //! the device the frame's matcher-side cache belongs on: data::frame's constructor sets device_cache_->device = extractor_->get_device()
+    int get_device() const { return device_; }
     void set_device(const int device) {
         if (device != device_) release();
         device_ = device;

@@ -16,11 +16,13 @@ unsigned int area::match_in_consistent_area(data::frame& frm_1, data::frame& frm
     int32_t num_matches = 0;
     const std::vector<cv::Point2f> prev_in = prev_matched_pts;   // in / out: restored if the device call fails half way
     // both frames resident: module::initializer matches its init frame against every incoming frame until the map is created
+    const int device = detail::device_of(frm_2);
     if (!detail::guarded("ovs_area_match_in_consistent_area_f", [&] {
-            return ovs_area_match_in_consistent_area_f(detail::window_ctx().get(n2, n1), detail::device_frame_of(frm_1), detail::device_frame_of(frm_2),
+            const auto h1 = detail::device_handle_of(frm_1), h2 = detail::device_handle_of(frm_2);
+            return ovs_area_match_in_consistent_area_f(detail::window_ctx(device).get(n2, n1), detail::dev(h1), detail::dev(h2),
                                                       reinterpret_cast<float*>(prev_matched_pts.data()), matched_indices_2_in_frm_1.data(), margin,
                                                       lowe_ratio_, check_orientation_ ? 1 : 0, &num_matches);
-        }, {&frm_1, &frm_2})) {
+        }, {frm_1.device_cache_.get(), frm_2.device_cache_.get()}, device)) {
         matched_indices_2_in_frm_1.assign((size_t)n1, -1);
         prev_matched_pts = prev_in;
         return 0;

@@ -20,14 +20,15 @@ unsigned int bow_tree::match_frame_and_keyframe(data::keyframe* keyfrm, data::fr
     flatten_bow(frm.bow_feat_vec_, fid, fst, fit);
     std::vector<int32_t> matched((size_t)n_frm, -1);
     int32_t num_matches = 0;
-    if (!detail::guarded("ovs_bow_match_frame_and_keyframe", [&] {
-            return ovs_bow_match_frame_and_keyframe(detail::window_ctx().get(n_frm, n_kf),
-                                                   reinterpret_cast<const ovs_keypoint*>(keyfrm->keypts_.data()), keyfrm->descriptors_.data,
-                                                   valid.data(), n_kf, kid.data(), kst.data(), kit.data(), (int)kid.size(),
-                                                   reinterpret_cast<const ovs_keypoint*>(frm.keypts_.data()), frm.descriptors_.data, n_frm,
-                                                   fid.data(), fst.data(), fit.data(), (int)fid.size(), lowe_ratio_, check_orientation_ ? 1 : 0,
-                                                   matched.data(), &num_matches);
-        }, {})) {
+    // both sides resident (the handles hold undist_keypts_: the matcher reads angles only, which undistortion does not change); only the
+    // keyframe's landmark flags and the two BoW feature vectors travel
+    const int device = detail::device_of(frm);
+    if (!detail::guarded("ovs_bow_match_frame_and_keyframe_f", [&] {
+            const auto hk = detail::device_handle_of(*keyfrm), hf = detail::device_handle_of(frm);
+            return ovs_bow_match_frame_and_keyframe_f(detail::window_ctx(device).get(n_frm, n_kf), detail::dev(hk), valid.data(), kid.data(), kst.data(),
+                                                     kit.data(), (int)kid.size(), detail::dev(hf), fid.data(), fst.data(), fit.data(), (int)fid.size(),
+                                                     lowe_ratio_, check_orientation_ ? 1 : 0, matched.data(), &num_matches);
+        }, {keyfrm->device_cache_.get(), frm.device_cache_.get()}, device)) {
         return 0;
     }
     for (int j = 0; j < n_frm; ++j)
@@ -48,13 +49,13 @@ unsigned int bow_tree::match_keyframes(data::keyframe* keyfrm_1, data::keyframe*
     flatten_bow(keyfrm_2->bow_feat_vec_, id2, st2, it2);
     std::vector<int32_t> matched((size_t)n1, -1);
     int32_t num_matches = 0;
-    if (!detail::guarded("ovs_bow_match_keyframes", [&] {
-            return ovs_bow_match_keyframes(detail::window_ctx().get(n2, n1), reinterpret_cast<const ovs_keypoint*>(keyfrm_1->keypts_.data()),
-                                          keyfrm_1->descriptors_.data, v1.data(), n1, id1.data(), st1.data(), it1.data(), (int)id1.size(),
-                                          reinterpret_cast<const ovs_keypoint*>(keyfrm_2->keypts_.data()), keyfrm_2->descriptors_.data, v2.data(), n2,
-                                          id2.data(), st2.data(), it2.data(), (int)id2.size(), lowe_ratio_, check_orientation_ ? 1 : 0,
-                                          matched.data(), &num_matches);
-        }, {})) {
+    const int device = detail::device_of(*keyfrm_1);
+    if (!detail::guarded("ovs_bow_match_keyframes_f", [&] {
+            const auto h1 = detail::device_handle_of(*keyfrm_1), h2 = detail::device_handle_of(*keyfrm_2);
+            return ovs_bow_match_keyframes_f(detail::window_ctx(device).get(n2, n1), detail::dev(h1), v1.data(), id1.data(), st1.data(), it1.data(),
+                                            (int)id1.size(), detail::dev(h2), v2.data(), id2.data(), st2.data(), it2.data(), (int)id2.size(), lowe_ratio_,
+                                            check_orientation_ ? 1 : 0, matched.data(), &num_matches);
+        }, {keyfrm_1->device_cache_.get(), keyfrm_2->device_cache_.get()}, device)) {
         return 0;
     }
     for (int i = 0; i < n1; ++i)

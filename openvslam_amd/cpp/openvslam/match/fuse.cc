@@ -42,19 +42,20 @@ unsigned int fuse::replace_duplication(data::keyframe* keyfrm, const T& landmark
     if (n == 0 || m == 0) return 0;
     auto usable = [&](data::landmark* lm) { return lm && !lm->will_be_erased() && !lm->is_observed_in_keyframe(keyfrm); };
     const flat_landmarks f(landmarks_to_check.begin(), landmarks_to_check.end(), (size_t)m, usable);
-    const ovs_grid_params gp = detail::grid_of(keyfrm->camera_);
     const ovs_camera cam = detail::camera_of(keyfrm->camera_);
     double pose[12];
     detail::pose12(keyfrm->get_cam_pose(), pose);
     std::vector<int32_t> best((size_t)m, -1);
     int32_t num = 0;
-    if (!detail::guarded("ovs_fuse_replace_duplication", [&] {
-            return ovs_fuse_replace_duplication(
-                      detail::window_ctx().get(n, m), &cam, &gp, reinterpret_cast<const ovs_keypoint*>(keyfrm->undist_keypts_.data()),
-                      keyfrm->descriptors_.data, keyfrm->stereo_x_right_.empty() ? nullptr : keyfrm->stereo_x_right_.data(), n, pose, f.pos.data(),
-                      f.dist.data(), f.normal.data(), f.desc.data(), f.valid.data(), m, keyfrm->scale_factors_.data(),
-                      keyfrm->inv_level_sigma_sq_.data(), (int)keyfrm->scale_factors_.size(), keyfrm->log_scale_factor_, margin, best.data(), &num);
-        }, {})) {
+    const int device = detail::device_of(*keyfrm);
+    // the keyframe is resident: mapping_module::fuse_landmark_duplication calls this on ~20 covisible keyframes per new keyframe, and again with
+    // the roles swapped -- only the landmarks to check travel
+    if (!detail::guarded("ovs_fuse_replace_duplication_f", [&] {
+            const auto h = detail::device_handle_of(*keyfrm);
+            return ovs_fuse_replace_duplication_f(detail::window_ctx(device).get(n, m), &cam, detail::dev(h), pose, f.pos.data(), f.dist.data(), f.normal.data(),
+                                                  f.desc.data(), f.valid.data(), m, keyfrm->scale_factors_.data(), keyfrm->inv_level_sigma_sq_.data(),
+                                                  (int)keyfrm->scale_factors_.size(), keyfrm->log_scale_factor_, margin, best.data(), &num);
+        }, {keyfrm->device_cache_.get()}, device)) {
         return 0;
     }
     // upstream's write-back, in the order of landmarks_to_check; an earlier replacement can erase or attach a later landmark
@@ -93,19 +94,18 @@ unsigned int fuse::detect_duplication(data::keyframe* keyfrm, const Mat44_t& Sim
     const std::set<data::landmark*> already_matched(valid_lms.begin(), valid_lms.end());
     auto usable = [&](data::landmark* lm) { return lm && !lm->will_be_erased() && !already_matched.count(lm); };
     const flat_landmarks f(landmarks_to_check.begin(), landmarks_to_check.end(), (size_t)m, usable);
-    const ovs_grid_params gp = detail::grid_of(keyfrm->camera_);
     const ovs_camera cam = detail::camera_of(keyfrm->camera_);
     double sim3[12];
     detail::pose12(Sim3_cw, sim3);
     std::vector<int32_t> best((size_t)m, -1);
     int32_t num = 0;
-    if (!detail::guarded("ovs_fuse_detect_duplication", [&] {
-            return ovs_fuse_detect_duplication(detail::window_ctx().get(n, m), &cam, &gp,
-                                              reinterpret_cast<const ovs_keypoint*>(keyfrm->undist_keypts_.data()), keyfrm->descriptors_.data, n,
-                                              sim3, f.pos.data(), f.dist.data(), f.normal.data(), f.desc.data(), f.valid.data(), m,
-                                              keyfrm->scale_factors_.data(), (int)keyfrm->scale_factors_.size(), keyfrm->log_scale_factor_,
-                                              margin, best.data(), &num);
-        }, {})) {
+    const int device = detail::device_of(*keyfrm);
+    if (!detail::guarded("ovs_fuse_detect_duplication_f", [&] {
+            const auto h = detail::device_handle_of(*keyfrm);
+            return ovs_fuse_detect_duplication_f(detail::window_ctx(device).get(n, m), &cam, detail::dev(h), sim3, f.pos.data(), f.dist.data(), f.normal.data(),
+                                                 f.desc.data(), f.valid.data(), m, keyfrm->scale_factors_.data(), (int)keyfrm->scale_factors_.size(),
+                                                 keyfrm->log_scale_factor_, margin, best.data(), &num);
+        }, {keyfrm->device_cache_.get()}, device)) {
         return 0;
     }
     unsigned int num_fused = 0;

@@ -31,12 +31,14 @@ unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::
     std::vector<int32_t> assigned((size_t)m, -1);
     int32_t num_matches = 0;
     // the frame's keypoints, descriptors and grid are resident (uploaded by the first matcher call on this frame)
+    const int device = detail::device_of(frm);
     if (!detail::guarded("ovs_projection_match_frame_and_landmarks_f", [&] {
-            return ovs_projection_match_frame_and_landmarks_f(detail::window_ctx().get(n, m), detail::device_frame_of(frm), occupied.data(), lm_xy.data(),
+            const auto h = detail::device_handle_of(frm);
+            return ovs_projection_match_frame_and_landmarks_f(detail::window_ctx(device).get(n, m), detail::dev(h), occupied.data(), lm_xy.data(),
                                                              stereo ? lm_x_right.data() : nullptr, lm_level.data(), lm_desc.data(), lm_valid.data(), m,
                                                              frm.scale_factors_.data(), (int)frm.scale_factors_.size(), margin, lowe_ratio_,
                                                              assigned.data(), &num_matches);
-        }, {&frm})) {
+        }, {frm.device_cache_.get()}, device)) {
         return 0;
     }
     for (int l = 0; l < m; ++l)
@@ -65,13 +67,15 @@ unsigned int projection::match_current_and_last_frames(data::frame& curr_frm, co
     detail::pose12(last_frm.cam_pose_cw_, pose_last);
     std::vector<int32_t> assigned((size_t)n_last, -1);
     int32_t num_matches = 0;
+    const int device = detail::device_of(curr_frm);
     if (!detail::guarded("ovs_projection_match_current_and_last_frames_f", [&] {
+            const auto h = detail::device_handle_of(curr_frm);
             return ovs_projection_match_current_and_last_frames_f(
-                      detail::window_ctx().get(n_curr, n_last), &cam, detail::device_frame_of(curr_frm), occupied.data(), pose_curr,
+                      detail::window_ctx(device).get(n_curr, n_last), &cam, detail::dev(h), occupied.data(), pose_curr,
                       reinterpret_cast<const ovs_keypoint*>(last_frm.undist_keypts_.data()), last_pos.data(), last_desc.data(), last_valid.data(),
                       n_last, pose_last, curr_frm.scale_factors_.data(), (int)curr_frm.scale_factors_.size(), margin, check_orientation_ ? 1 : 0,
                       assigned.data(), &num_matches);
-        }, {&curr_frm})) {
+        }, {curr_frm.device_cache_.get()}, device)) {
         return 0;
     }
     for (int i = 0; i < n_last; ++i)
@@ -115,20 +119,21 @@ unsigned int projection::match_frame_and_keyframe(data::frame& curr_frm, data::k
     const kf_landmarks f(lms, [&](data::landmark* lm, size_t) { return lm && !lm->will_be_erased() && !already_matched_lms.count(lm); });
     std::vector<uint8_t> occupied((size_t)n_curr);
     for (int i = 0; i < n_curr; ++i) occupied[i] = curr_frm.landmarks_[i] != nullptr;
-    const ovs_grid_params gp = detail::grid_of(curr_frm.camera_);
     const ovs_camera cam = detail::camera_of(curr_frm.camera_);
     double pose[12];
     detail::pose12(curr_frm.cam_pose_cw_, pose);
     std::vector<int32_t> assigned((size_t)n_kf, -1);
     int32_t num_matches = 0;
-    if (!detail::guarded("ovs_projection_match_frame_and_keyframe", [&] {
-            return ovs_projection_match_frame_and_keyframe(
-                      detail::window_ctx().get(n_curr, n_kf), &cam, &gp, reinterpret_cast<const ovs_keypoint*>(curr_frm.undist_keypts_.data()),
-                      curr_frm.descriptors_.data, occupied.data(), n_curr, pose, reinterpret_cast<const ovs_keypoint*>(keyfrm->undist_keypts_.data()),
-                      f.pos.data(), f.dist.data(), f.desc.data(), f.valid.data(), n_kf, curr_frm.scale_factors_.data(),
-                      (int)curr_frm.scale_factors_.size(), curr_frm.log_scale_factor_, margin, hamm_dist_thr, check_orientation_ ? 1 : 0,
-                      assigned.data(), &num_matches);
-        }, {})) {
+    const int device = detail::device_of(curr_frm);
+    // the current frame is resident (relocalisation calls this for every candidate keyframe on the same frame)
+    if (!detail::guarded("ovs_projection_match_frame_and_keyframe_f", [&] {
+            const auto h = detail::device_handle_of(curr_frm);
+            return ovs_projection_match_frame_and_keyframe_f(
+                      detail::window_ctx(device).get(n_curr, n_kf), &cam, detail::dev(h), occupied.data(), pose,
+                      reinterpret_cast<const ovs_keypoint*>(keyfrm->undist_keypts_.data()), f.pos.data(), f.dist.data(), f.desc.data(), f.valid.data(), n_kf,
+                      curr_frm.scale_factors_.data(), (int)curr_frm.scale_factors_.size(), curr_frm.log_scale_factor_, margin, hamm_dist_thr,
+                      check_orientation_ ? 1 : 0, assigned.data(), &num_matches);
+        }, {curr_frm.device_cache_.get()}, device)) {
         return 0;
     }
     for (int i = 0; i < n_kf; ++i)
@@ -145,19 +150,19 @@ unsigned int projection::match_by_Sim3_transform(data::keyframe* keyfrm, const M
     const kf_landmarks f(landmarks, [&](data::landmark* lm, size_t) { return lm && !lm->will_be_erased() && !already_matched.count(lm); });
     std::vector<uint8_t> occupied((size_t)n);
     for (int k = 0; k < n; ++k) occupied[k] = matched_lms_in_keyfrm.at((size_t)k) != nullptr;
-    const ovs_grid_params gp = detail::grid_of(keyfrm->camera_);
     const ovs_camera cam = detail::camera_of(keyfrm->camera_);
     double sim3[12];
     detail::pose12(Sim3_cw, sim3);
     std::vector<int32_t> assigned((size_t)m, -1);
     int32_t num_matches = 0;
-    if (!detail::guarded("ovs_projection_match_by_sim3_transform", [&] {
-            return ovs_projection_match_by_sim3_transform(
-                      detail::window_ctx().get(n, m), &cam, &gp, reinterpret_cast<const ovs_keypoint*>(keyfrm->undist_keypts_.data()),
-                      keyfrm->descriptors_.data, occupied.data(), n, sim3, f.pos.data(), f.dist.data(), f.normal.data(), f.desc.data(), f.valid.data(),
-                      m, keyfrm->scale_factors_.data(), (int)keyfrm->scale_factors_.size(), keyfrm->log_scale_factor_, margin, assigned.data(),
-                      &num_matches);
-        }, {})) {
+    const int device = detail::device_of(*keyfrm);
+    if (!detail::guarded("ovs_projection_match_by_sim3_transform_f", [&] {
+            const auto h = detail::device_handle_of(*keyfrm);
+            return ovs_projection_match_by_sim3_transform_f(
+                      detail::window_ctx(device).get(n, m), &cam, detail::dev(h), occupied.data(), sim3, f.pos.data(), f.dist.data(), f.normal.data(),
+                      f.desc.data(), f.valid.data(), m, keyfrm->scale_factors_.data(), (int)keyfrm->scale_factors_.size(), keyfrm->log_scale_factor_,
+                      margin, assigned.data(), &num_matches);
+        }, {keyfrm->device_cache_.get()}, device)) {
         return 0;
     }
     for (int l = 0; l < m; ++l)
@@ -181,7 +186,6 @@ unsigned int projection::match_keyframes_mutually(data::keyframe* keyfrm_1, data
     }
     const kf_landmarks f1(lms_1, [&](data::landmark* lm, size_t i) { return lm && !matched_1[i] && !lm->will_be_erased(); });
     const kf_landmarks f2(lms_2, [&](data::landmark* lm, size_t i) { return lm && !matched_2[i] && !lm->will_be_erased(); });
-    const ovs_grid_params gp_1 = detail::grid_of(keyfrm_1->camera_), gp_2 = detail::grid_of(keyfrm_2->camera_);
     const ovs_camera cam_1 = detail::camera_of(keyfrm_1->camera_), cam_2 = detail::camera_of(keyfrm_2->camera_);
     double pose_1[12], pose_2[12], R[9], t[3];
     detail::pose12(keyfrm_1->get_cam_pose(), pose_1);
@@ -193,14 +197,15 @@ unsigned int projection::match_keyframes_mutually(data::keyframe* keyfrm_1, data
     std::vector<int32_t> m21((size_t)n1, -1);
     int32_t num_matches = 0;
     const int nmax = n1 > n2 ? n1 : n2;
-    if (!detail::guarded("ovs_projection_match_keyframes_mutually", [&] {
-            return ovs_projection_match_keyframes_mutually(
-                      detail::window_ctx().get(nmax, nmax), &cam_1, &gp_1, reinterpret_cast<const ovs_keypoint*>(keyfrm_1->undist_keypts_.data()),
-                      keyfrm_1->descriptors_.data, n1, pose_1, f1.pos.data(), f1.dist.data(), f1.desc.data(), f1.valid.data(), &cam_2, &gp_2,
-                      reinterpret_cast<const ovs_keypoint*>(keyfrm_2->undist_keypts_.data()), keyfrm_2->descriptors_.data, n2, pose_2, f2.pos.data(),
-                      f2.dist.data(), f2.desc.data(), f2.valid.data(), (double)s_12, R, t, keyfrm_1->scale_factors_.data(),
-                      (int)keyfrm_1->scale_factors_.size(), keyfrm_1->log_scale_factor_, margin, m21.data(), &num_matches);
-        }, {})) {
+    const int device = detail::device_of(*keyfrm_1);
+    if (!detail::guarded("ovs_projection_match_keyframes_mutually_f", [&] {
+            const auto h1 = detail::device_handle_of(*keyfrm_1), h2 = detail::device_handle_of(*keyfrm_2);
+            return ovs_projection_match_keyframes_mutually_f(
+                      detail::window_ctx(device).get(nmax, nmax), &cam_1, detail::dev(h1), pose_1, f1.pos.data(), f1.dist.data(), f1.desc.data(),
+                      f1.valid.data(), &cam_2, detail::dev(h2), pose_2, f2.pos.data(), f2.dist.data(), f2.desc.data(), f2.valid.data(), (double)s_12, R, t,
+                      keyfrm_1->scale_factors_.data(), (int)keyfrm_1->scale_factors_.size(), keyfrm_1->log_scale_factor_, margin, m21.data(),
+                      &num_matches);
+        }, {keyfrm_1->device_cache_.get(), keyfrm_2->device_cache_.get()}, device)) {
         return 0;
     }
     for (int i = 0; i < n1; ++i)

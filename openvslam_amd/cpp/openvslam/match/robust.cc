@@ -19,6 +19,7 @@ namespace {
 // upstream stack-constructs a matcher per call; the device context is kept per thread so a call does not allocate
 struct matcher_holder {
     ovs_matcher* m = nullptr;
+    int device = 0;
     int cap1 = 0, cap2 = 0;
     ~matcher_holder() {
         if (m) ovs_matcher_destroy(m);
@@ -29,7 +30,7 @@ struct matcher_holder {
         m = nullptr;
         cap1 = n1 < 4096 ? 4096 : n1;
         cap2 = n2 < 4096 ? 4096 : n2;
-        const int st = ovs_matcher_create(cap1, cap2, 1, 0, &m);
+        const int st = ovs_matcher_create(cap1, cap2, 1, device, &m);
         if (st != OVS_OK) {
             m = nullptr;
             cap1 = cap2 = 0;
@@ -43,7 +44,17 @@ struct matcher_holder {
         cap1 = cap2 = 0;
     }
 };
-thread_local matcher_holder g_matcher;
+// one context per (thread, device): the frame's device decides
+matcher_holder& matcher_ctx(int device) {
+    thread_local std::vector<std::unique_ptr<matcher_holder>> per_device;
+    if (device < 0) device = 0;
+    if ((size_t)device >= per_device.size()) per_device.resize((size_t)device + 1);
+    if (!per_device[(size_t)device]) {
+        per_device[(size_t)device] = std::make_unique<matcher_holder>();
+        per_device[(size_t)device]->device = device;
+    }
+    return *per_device[(size_t)device];
+}
 }   // namespace
 
 unsigned int robust::brute_force_match(data::frame& frm, data::keyframe* keyfrm, std::vector<std::pair<int, int>>& matches) const {
@@ -61,15 +72,16 @@ unsigned int robust::brute_force_match(data::frame& frm, data::keyframe* keyfrm,
     int n = 0;
     matches.clear();
     // failure policy (util/device_policy.h): one retry on a fresh matcher context, then zero matches
+    const int device = detail::device_of(frm);
     if (!util::run_guarded(
             "ovs_robust_brute_force_match",
             [&] {
-                return ovs_robust_brute_force_match(g_matcher.get(num_keypts_1, num_keypts_2), frm.descriptors_.data, (int)num_keypts_1,
+                return ovs_robust_brute_force_match(matcher_ctx(device).get(num_keypts_1, num_keypts_2), frm.descriptors_.data, (int)num_keypts_1,
                                                     /*valid_1: upstream's inner loop skips only already matched idx_1*/ nullptr,
                                                     keyfrm->descriptors_.data, (int)num_keypts_2, valid.data(), lowe_ratio_, pairs.data(),
                                                     (int)num_keypts_2, &n);
             },
-            [] { g_matcher.reset(); }))
+            [device] { matcher_ctx(device).reset(); }))
         return 0;
     matches.reserve((size_t)n);
     for (int i = 0; i < n; ++i) matches.emplace_back(std::make_pair(pairs[2 * i], pairs[2 * i + 1]));
@@ -132,18 +144,13 @@ unsigned int robust::match_for_triangulation(data::keyframe* keyfrm_1, data::key
     for (int i = 0; i < 3; ++i) epipole[i] = ((rot_2w(i, 0) * c1(0) + rot_2w(i, 1) * c1(1)) + rot_2w(i, 2) * c1(2)) + trans_2w(i);
     const double norm = std::sqrt((epipole[0] * epipole[0] + epipole[1] * epipole[1]) + epipole[2] * epipole[2]);
     for (int i = 0; i < 3; ++i) epipole[i] /= norm;
-    auto flatten_kf = [](const data::keyframe* kf, int n, std::vector<uint8_t>& has_lm, std::vector<double>& bearings) {
+    auto flatten_kf = [](const data::keyframe* kf, int n, std::vector<uint8_t>& has_lm) {
         has_lm.resize((size_t)n);
-        bearings.resize((size_t)3 * n);
-        for (int i = 0; i < n; ++i) {
-            has_lm[i] = kf->get_landmark((unsigned)i) != nullptr;
-            for (int a = 0; a < 3; ++a) bearings[(size_t)3 * i + a] = kf->bearings_[i](a);
-        }
+        for (int i = 0; i < n; ++i) has_lm[i] = kf->get_landmark((unsigned)i) != nullptr;
     };
     std::vector<uint8_t> has_1, has_2;
-    std::vector<double> b1, b2;
-    flatten_kf(keyfrm_1, n1, has_1, b1);
-    flatten_kf(keyfrm_2, n2, has_2, b2);
+    flatten_kf(keyfrm_1, n1, has_1);
+    flatten_kf(keyfrm_2, n2, has_2);
     std::vector<int32_t> id1, st1, it1, id2, st2, it2;
     detail::flatten_bow(keyfrm_1->bow_feat_vec_, id1, st1, it1);
     detail::flatten_bow(keyfrm_2->bow_feat_vec_, id2, st2, it2);
@@ -152,16 +159,16 @@ unsigned int robust::match_for_triangulation(data::keyframe* keyfrm_1, data::key
         for (int j = 0; j < 3; ++j) E[3 * i + j] = E_12(i, j);
     std::vector<int32_t> matched((size_t)n1, -1);
     int32_t num_matches = 0;
-    if (!detail::guarded("ovs_robust_match_for_triangulation", [&] {
-            return ovs_robust_match_for_triangulation(
-                      detail::window_ctx().get(n2, n1), reinterpret_cast<const ovs_keypoint*>(keyfrm_1->undist_keypts_.data()),
-                      keyfrm_1->descriptors_.data, has_1.data(), keyfrm_1->stereo_x_right_.empty() ? nullptr : keyfrm_1->stereo_x_right_.data(),
-                      b1.data(), n1, id1.data(), st1.data(), it1.data(), (int)id1.size(),
-                      reinterpret_cast<const ovs_keypoint*>(keyfrm_2->undist_keypts_.data()), keyfrm_2->descriptors_.data, has_2.data(),
-                      keyfrm_2->stereo_x_right_.empty() ? nullptr : keyfrm_2->stereo_x_right_.data(), b2.data(), n2, id2.data(), st2.data(),
-                      it2.data(), (int)id2.size(), E, epipole, keyfrm_1->scale_factors_.data(), (int)keyfrm_1->scale_factors_.size(),
-                      check_orientation_ ? 1 : 0, matched.data(), &num_matches);
-        }, {})) {
+    // both keyframes resident, bearings included (attached to a handle the first time a triangulation asks for them): mapping_module::
+    // create_new_landmarks calls this for ~10-20 covisible keyframes per new keyframe
+    const int device = detail::device_of(*keyfrm_1);
+    if (!detail::guarded("ovs_robust_match_for_triangulation_f", [&] {
+            const auto h1 = detail::device_handle_of(*keyfrm_1, true), h2 = detail::device_handle_of(*keyfrm_2, true);
+            return ovs_robust_match_for_triangulation_f(detail::window_ctx(device).get(n2, n1), detail::dev(h1), has_1.data(), id1.data(), st1.data(),
+                                                       it1.data(), (int)id1.size(), detail::dev(h2), has_2.data(), id2.data(), st2.data(), it2.data(),
+                                                       (int)id2.size(), E, epipole, keyfrm_1->scale_factors_.data(),
+                                                       (int)keyfrm_1->scale_factors_.size(), check_orientation_ ? 1 : 0, matched.data(), &num_matches);
+        }, {keyfrm_1->device_cache_.get(), keyfrm_2->device_cache_.get()}, device)) {
         return 0;
     }
     matched_idx_pairs.reserve((size_t)num_matches);

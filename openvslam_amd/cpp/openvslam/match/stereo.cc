@@ -9,17 +9,19 @@ namespace match {
 namespace {
 struct stereo_holder {
     ovs_stereo* s = nullptr;
+    int device = 0;   // the device of the extractors whose pyramids are read (match::stereo runs where they live)
     int cap_rows = 0, cap_kps = 0;
     ~stereo_holder() {
         if (s) ovs_stereo_destroy(s);
     }
-    ovs_stereo* get(int rows, int kps) {
-        if (s && rows <= cap_rows && kps <= cap_kps) return s;
+    ovs_stereo* get(int rows, int kps, int dev) {
+        if (s && rows <= cap_rows && kps <= cap_kps && dev == device) return s;
+        device = dev;
         if (s) ovs_stereo_destroy(s);
         s = nullptr;
         cap_rows = rows < 2160 ? 2160 : rows;
         cap_kps = kps < 8192 ? 8192 : kps;
-        const int st = ovs_stereo_create(cap_rows, cap_kps, 0, &s);
+        const int st = ovs_stereo_create(cap_rows, cap_kps, device, &s);
         if (st != OVS_OK) {
             s = nullptr;
             cap_rows = cap_kps = 0;
@@ -57,7 +59,7 @@ void stereo::compute(std::vector<float>& stereo_x_right, std::vector<float>& dep
     if (!util::run_guarded(
             "ovs_stereo_compute",
             [&] {
-                return ovs_stereo_compute(g_stereo.get(rows0, n_left > n_right ? n_left : n_right), left, right,
+                return ovs_stereo_compute(g_stereo.get(rows0, n_left > n_right ? n_left : n_right, ovs_orb_device(left)), left, right,
                                           reinterpret_cast<const ovs_keypoint*>(keypts_left_.data()), descs_left_.data, n_left,
                                           reinterpret_cast<const ovs_keypoint*>(keypts_right_.data()), descs_right_.data, n_right, focal_x_baseline_,
                                           true_baseline_, stereo_x_right.data(), depths.data(), nullptr);

@@ -5,6 +5,7 @@
 
 #include <initializer_list>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -18,6 +19,7 @@ namespace detail {
 
 struct window_holder {
     ovs_wmatcher* w = nullptr;
+    int device = 0;
     int cap_t = 0, cap_q = 0;
     int entries = 1 << 22;   // candidate-list budget; doubled by grow() after OVS_ERR_CAPACITY, up to 2^26 (256 MB of keys)
     ~window_holder() {
@@ -29,7 +31,7 @@ struct window_holder {
         w = nullptr;
         cap_t = n_t < 8192 ? 8192 : n_t;
         cap_q = n_q < 16384 ? 16384 : n_q;
-        const int st = ovs_wmatcher_create(cap_t, cap_q, entries, 0, &w);
+        const int st = ovs_wmatcher_create(cap_t, cap_q, entries, device, &w);
         if (st != OVS_OK) {
             w = nullptr;
             cap_t = cap_q = 0;
@@ -49,9 +51,16 @@ struct window_holder {
         return true;
     }
 };
-inline window_holder& window_ctx() {
-    thread_local window_holder h;
-    return h;
+// one matcher context per (thread, device): a frame is matched on the device its extractor ran on (frame i -> GPU i mod G)
+inline window_holder& window_ctx(int device = 0) {
+    thread_local std::vector<std::unique_ptr<window_holder>> per_device;
+    if (device < 0) device = 0;
+    if ((size_t)device >= per_device.size()) per_device.resize((size_t)device + 1);
+    if (!per_device[(size_t)device]) {
+        per_device[(size_t)device] = std::make_unique<window_holder>();
+        per_device[(size_t)device]->device = device;
+    }
+    return *per_device[(size_t)device];
 }
 
 inline ovs_grid_params grid_of(const camera::base* cam) {
@@ -84,21 +93,33 @@ inline ovs_camera camera_of(const camera::base* cam) {
     return c;
 }
 
-// the frame's device-side cache: uploaded + indexed on first use, reused by every later matcher call on the same frame (or a copy of it)
-inline const ovs_frame_dev* device_frame_of(const data::frame& frm) {
-    if (frm.device_cache_ && frm.device_cache_->handle) return static_cast<const ovs_frame_dev*>(frm.device_cache_->handle);
-    const ovs_grid_params gp = grid_of(frm.camera_);
-    ovs_frame_dev* f = nullptr;
-    const bool stereo = !frm.stereo_x_right_.empty();
-    const int st = ovs_frame_dev_create(0, &gp, reinterpret_cast<const ovs_keypoint*>(frm.undist_keypts_.data()), frm.descriptors_.data,
-                                        stereo ? frm.stereo_x_right_.data() : nullptr, (int32_t)frm.undist_keypts_.size(), &f);
-    if (st != OVS_OK) throw util::device_error(st, std::string("ovs_frame_dev_create: ") + ovs_last_error());   // caught by guarded()
-    auto c = std::make_shared<data::frame_device_cache>();
-    c->handle = f;
-    c->destroy = [](void* h) { ovs_frame_dev_destroy(static_cast<ovs_frame_dev*>(h)); };
-    frm.device_cache_ = c;
-    return f;
+// the device-side cache of a frame or keyframe: uploaded + indexed on first use (on the cache's device), then shared by every later matcher
+// call on the object, its copies and the keyframe made from it. The caller keeps the returned reference for the duration of its ABI call.
+template <class F>   // data::frame or data::keyframe: the same members
+inline std::shared_ptr<void> device_handle_of(const F& frm, bool want_bearings = false) {
+    data::frame_device_cache& cache = *frm.device_cache_;
+    return cache.get(
+        [&]() -> std::shared_ptr<void> {
+            const ovs_grid_params gp = grid_of(frm.camera_);
+            ovs_frame_dev* f = nullptr;
+            const bool stereo = !frm.stereo_x_right_.empty();
+            const int st = ovs_frame_dev_create(cache.device, &gp, reinterpret_cast<const ovs_keypoint*>(frm.undist_keypts_.data()), frm.descriptors_.data,
+                                                stereo ? frm.stereo_x_right_.data() : nullptr, (int32_t)frm.undist_keypts_.size(), &f);
+            if (st != OVS_OK) throw util::device_error(st, std::string("ovs_frame_dev_create: ") + ovs_last_error());   // caught by guarded()
+            return std::shared_ptr<void>(f, [](void* h) { ovs_frame_dev_destroy(static_cast<ovs_frame_dev*>(h)); });
+        },
+        want_bearings,
+        [&](void* h) {
+            std::vector<double> b(3 * frm.bearings_.size());
+            for (size_t i = 0; i < frm.bearings_.size(); ++i)
+                for (int a = 0; a < 3; ++a) b[3 * i + (size_t)a] = frm.bearings_[i](a);
+            const int st = ovs_frame_dev_attach_bearings(static_cast<ovs_frame_dev*>(h), b.data());
+            if (st != OVS_OK) throw util::device_error(st, std::string("ovs_frame_dev_attach_bearings: ") + ovs_last_error());
+        });
 }
+inline const ovs_frame_dev* dev(const std::shared_ptr<void>& h) { return static_cast<const ovs_frame_dev*>(h.get()); }
+template <class F>
+inline int device_of(const F& frm) { return frm.device_cache_->device; }
 
 // rows 0..2 of a 4x4 [R|t] -> 12 doubles: rotation row-major, then translation
 inline void pose12(const Mat44_t& T, double* out) {
@@ -123,15 +144,15 @@ inline void flatten_bow(const data::bow_feature_vector& fv, std::vector<int32_t>
 // device_frame_of(...) each time it runs; before the retry the thread's matcher context and the device caches of the frames the call
 // uses are dropped. false -> the caller returns zero matches (its outputs may be partly written: it must not read them).
 template <class Call>
-inline bool guarded(const char* what, Call&& call, std::initializer_list<const data::frame*> frames = {}) {
+inline bool guarded(const char* what, Call&& call, std::initializer_list<data::frame_device_cache*> caches = {}, int device = 0) {
     return util::run_guarded(
         what, call,
         [&] {
-            window_ctx().reset();
-            for (const data::frame* f : frames)
-                if (f) f->device_cache_.reset();
+            window_ctx(device).reset();
+            for (data::frame_device_cache* c : caches)
+                if (c) c->drop();
         },
-        [] { return window_ctx().grow(); });
+        [device] { return window_ctx(device).grow(); });
 }
 
 static_assert(sizeof(cv::KeyPoint) == sizeof(ovs_keypoint), "cv::KeyPoint crosses the ABI as ovs_keypoint");

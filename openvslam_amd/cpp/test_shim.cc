@@ -76,6 +76,8 @@ int main(int argc, char** argv) {
     frm.undist_keypts_ = frm.keypts_;
     frm_b.undist_keypts_ = frm_b.keypts_;
     frm.camera_ = frm_b.camera_ = &cam;
+    keyfrm.undist_keypts_ = keyfrm.keypts_;   // (a real keyframe always carries both; the resident handle holds the undistorted ones)
+    keyfrm.camera_ = &cam;
     frm.scale_factors_ = frm_b.scale_factors_ = extractor.get_scale_factors();
     // area: initial guess = own position, margin 100
     std::vector<cv::Point2f> prev_matched_pts(frm.num_keypts_);

@@ -935,6 +935,22 @@ struct ovs_wmatcher {
     size_t stage_cap = 0;
 };
 
+// a frame / keyframe resident in HBM (created by ovs_frame_dev_create below)
+struct ovs_frame_dev {
+    int device = 0;
+    int n = 0, cap = 0, n_cells = 0;
+    bool has_stereo = false;
+    GridP gp{};
+    ovs_grid_params gpp{};
+    unsigned char* arena = nullptr;
+    size_t arena_bytes = 0;
+    ovs_keypoint* d_kps = nullptr;
+    uint8_t* d_desc = nullptr;
+    float* d_x_right = nullptr;
+    int32_t *d_cell_of = nullptr, *d_cell_start = nullptr, *d_items = nullptr;
+    double* d_bearings = nullptr;   // optional (ovs_frame_dev_attach_bearings): 3 doubles per keypoint, for match_for_triangulation
+};
+
 namespace {
 
 constexpr int kMaxGridCells = 16384;
@@ -998,6 +1014,34 @@ ovs_status grid_assign(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_key
         OVS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_assign), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_grid_assign, dim3(1), dim3(1024), lds, s, d_kps, n, w->gp, w->d_cell_of, w->d_cell_start, w->d_items);
     OVS_HIP_TRY(hipGetLastError());
+    return OVS_OK;
+}
+
+// The TARGET side of a windowed call (the keypoints that are searched through the grid): either host arrays -- uploaded into the context's
+// buffers and indexed by k_grid_assign, per call -- or a frame / keyframe RESIDENT in HBM (ovs_frame_dev: uploaded and indexed once, when the
+// handle was created). Keyframes are the long-lived, immutable objects of the map: mapping_module matches every new keyframe against ~20
+// covisible ones (fuse::replace_duplication), loop closing against more; with the handle none of those calls moves keypoints or descriptors.
+struct TargetRef {
+    const ovs_keypoint* kps;
+    const uint8_t* desc;
+    const float* x_right;
+    const int32_t* cell_start;
+    const int32_t* items;
+    GridP gp;
+};
+ovs_status stage_target(ovs_wmatcher* w, const ovs_frame_dev* res, const ovs_grid_params* gp, const ovs_keypoint* kps, const uint8_t* desc,
+                        const float* x_right, int n, hipStream_t s, TargetRef* t) {
+    if (res) {
+        if (res->device != w->device || res->n != n) return OVS_ERR_INVALID;
+        *t = TargetRef{res->d_kps, res->d_desc, res->has_stereo ? res->d_x_right : nullptr, res->d_cell_start, res->d_items, res->gp};
+        return OVS_OK;
+    }
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, kps, sizeof(ovs_keypoint) * (size_t)n, hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, desc, (size_t)32 * n, hipMemcpyHostToDevice, s));
+    if (x_right) OVS_HIP_TRY(hipMemcpyAsync(w->d_t_f, x_right, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, s));
+    const ovs_status st = grid_assign(w, gp, w->d_t_kps, n, s);
+    if (st != OVS_OK) return st;
+    *t = TargetRef{w->d_t_kps, w->d_t_desc, x_right ? w->d_t_f : nullptr, w->d_cell_start, w->d_items, w->gp};
     return OVS_OK;
 }
 
@@ -1299,7 +1343,7 @@ struct TriParams {   // robust::match_for_triangulation extras (host pointers)
     int num_levels;
 };
 
-static ovs_status bow_match_impl(ovs_wmatcher* w, int by_query, const uint8_t* frm_valid, const TriParams* tri, const ovs_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_valid,
+static ovs_status bow_match_impl(ovs_wmatcher* w, const ovs_frame_dev* res_kf, const ovs_frame_dev* res_frm, int by_query, const uint8_t* frm_valid, const TriParams* tri, const ovs_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_valid,
                                             int32_t n_kf, const int32_t* kf_node_ids, const int32_t* kf_node_start,
                                             const int32_t* kf_items, int32_t kf_nodes, const ovs_keypoint* frm_kps,
                                             const uint8_t* frm_desc, int32_t n_frm, const int32_t* frm_node_ids,
@@ -1313,9 +1357,10 @@ static ovs_status bow_match_impl(ovs_wmatcher* w, int by_query, const uint8_t* f
     for (int i = 0; i < n_out; ++i) matched_kf_in_frm[i] = -1;
     if (n_frm == 0) return OVS_OK;
     if (n_kf == 0 || kf_nodes == 0 || frm_nodes == 0) return OVS_OK;
-    if (!kf_kps || !kf_desc || !kf_node_ids || !kf_node_start || !kf_items || !frm_kps || !frm_desc || !frm_node_ids || !frm_node_start ||
-        !frm_items)
+    if ((!res_kf && (!kf_kps || !kf_desc)) || !kf_node_ids || !kf_node_start || !kf_items || (!res_frm && (!frm_kps || !frm_desc)) || !frm_node_ids ||
+        !frm_node_start || !frm_items)
         return OVS_ERR_INVALID;
+    if ((res_kf && (res_kf->device != w->device || res_kf->n != n_kf)) || (res_frm && (res_frm->device != w->device || res_frm->n != n_frm))) return OVS_ERR_INVALID;
     const int nq = kf_node_start[kf_nodes], nfi = frm_node_start[frm_nodes];
     if (nq == 0 || nfi == 0) return OVS_OK;
     if (n_frm > w->max_t || n_kf > w->max_q || nq > w->max_q || (by_query && n_kf > std::max(w->max_t, w->max_q))) return OVS_ERR_CAPACITY;
@@ -1336,34 +1381,64 @@ static ovs_status bow_match_impl(ovs_wmatcher* w, int by_query, const uint8_t* f
     OVS_HIP_TRY(hipMemcpyAsync(d_f_ids, frm_node_ids, sizeof(int32_t) * frm_nodes, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(d_f_start, frm_node_start, sizeof(int32_t) * (frm_nodes + 1), hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(d_f_items, frm_items, sizeof(int32_t) * nfi, hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_kps, kf_kps, sizeof(ovs_keypoint) * n_kf, hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, kf_desc, (size_t)32 * n_kf, hipMemcpyHostToDevice, s));
+    // keypoints (angle, octave) and descriptors of either side: resident (a frame / keyframe handle) or uploaded per call
+    const ovs_keypoint* d_kf_kps = w->d_q_kps;
+    const uint8_t* d_kf_desc = w->d_q_desc;
+    const ovs_keypoint* d_frm_kps = w->d_t_kps;
+    const uint8_t* d_frm_desc = w->d_t_desc;
+    if (res_kf) {
+        d_kf_kps = res_kf->d_kps;
+        d_kf_desc = res_kf->d_desc;
+    } else {
+        OVS_HIP_TRY(hipMemcpyAsync(w->d_q_kps, kf_kps, sizeof(ovs_keypoint) * n_kf, hipMemcpyHostToDevice, s));
+        OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, kf_desc, (size_t)32 * n_kf, hipMemcpyHostToDevice, s));
+    }
     if (kf_valid) OVS_HIP_TRY(hipMemcpyAsync(w->d_q_flag, kf_valid, (size_t)n_kf, hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, frm_kps, sizeof(ovs_keypoint) * n_frm, hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, frm_desc, (size_t)32 * n_frm, hipMemcpyHostToDevice, s));
+    if (res_frm) {
+        d_frm_kps = res_frm->d_kps;
+        d_frm_desc = res_frm->d_desc;
+    } else {
+        OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, frm_kps, sizeof(ovs_keypoint) * n_frm, hipMemcpyHostToDevice, s));
+        OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, frm_desc, (size_t)32 * n_frm, hipMemcpyHostToDevice, s));
+    }
     if (frm_valid) OVS_HIP_TRY(hipMemcpyAsync(w->d_t_flag, frm_valid, (size_t)n_frm, hipMemcpyHostToDevice, s));
     BowArgs a{};
-    a.kf_desc = w->d_q_desc;
+    a.kf_desc = d_kf_desc;
     a.kf_valid = kf_valid ? w->d_q_flag : nullptr;
     a.kf_node_ids = d_kf_ids;
     a.kf_node_start = d_kf_start;
     a.kf_items = d_kf_items;
     a.kf_nodes = kf_nodes;
     a.n_q = nq;
-    a.frm_desc = w->d_t_desc;
+    a.frm_desc = d_frm_desc;
     a.frm_valid = frm_valid ? w->d_t_flag : nullptr;
     if (tri) {
         a.tri = 1;
-        a.kf_kps = w->d_q_kps;
-        OVS_HIP_TRY(hipMemcpyAsync(w->d_tri_b1, tri->bearings_1, sizeof(double) * 3 * n_kf, hipMemcpyHostToDevice, s));
-        OVS_HIP_TRY(hipMemcpyAsync(w->d_tri_b2, tri->bearings_2, sizeof(double) * 3 * n_frm, hipMemcpyHostToDevice, s));
-        a.kf_bearings = w->d_tri_b1;
-        a.frm_bearings = w->d_tri_b2;
-        if (tri->x_right_1) {
+        a.kf_kps = d_kf_kps;
+        // bearings and stereo_x_right: from the handle when it carries them (ovs_frame_dev_attach_bearings), else uploaded
+        if (res_kf && res_kf->d_bearings) {
+            a.kf_bearings = res_kf->d_bearings;
+        } else {
+            if (!tri->bearings_1) return OVS_ERR_INVALID;
+            OVS_HIP_TRY(hipMemcpyAsync(w->d_tri_b1, tri->bearings_1, sizeof(double) * 3 * n_kf, hipMemcpyHostToDevice, s));
+            a.kf_bearings = w->d_tri_b1;
+        }
+        if (res_frm && res_frm->d_bearings) {
+            a.frm_bearings = res_frm->d_bearings;
+        } else {
+            if (!tri->bearings_2) return OVS_ERR_INVALID;
+            OVS_HIP_TRY(hipMemcpyAsync(w->d_tri_b2, tri->bearings_2, sizeof(double) * 3 * n_frm, hipMemcpyHostToDevice, s));
+            a.frm_bearings = w->d_tri_b2;
+        }
+        if (res_kf) {
+            a.kf_x_right = res_kf->has_stereo ? res_kf->d_x_right : nullptr;
+        } else if (tri->x_right_1) {
             OVS_HIP_TRY(hipMemcpyAsync(w->d_q_f, tri->x_right_1, sizeof(float) * n_kf, hipMemcpyHostToDevice, s));
             a.kf_x_right = w->d_q_f;
         }
-        if (tri->x_right_2) {
+        if (res_frm) {
+            a.frm_x_right = res_frm->has_stereo ? res_frm->d_x_right : nullptr;
+        } else if (tri->x_right_2) {
             OVS_HIP_TRY(hipMemcpyAsync(w->d_t_f, tri->x_right_2, sizeof(float) * n_frm, hipMemcpyHostToDevice, s));
             a.frm_x_right = w->d_t_f;
         }
@@ -1384,9 +1459,9 @@ static ovs_status bow_match_impl(ovs_wmatcher* w, int by_query, const uint8_t* f
     ra.n_t = n_frm;
     ra.lowe_ratio = lowe_ratio;
     ra.check_orientation = check_orientation;
-    ra.q_kps = w->d_q_kps;
+    ra.q_kps = d_kf_kps;
     ra.q_items = d_kf_items;
-    ra.t_kps = w->d_t_kps;
+    ra.t_kps = d_frm_kps;
     ra.assigned = w->d_assigned;
     ra.num_matches = w->d_num;
     ra.bow_by_query = by_query;
@@ -1411,7 +1486,7 @@ ovs_status ovs_bow_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_keypoint*
                                             const uint8_t* frm_desc, int32_t n_frm, const int32_t* frm_node_ids,
                                             const int32_t* frm_node_start, const int32_t* frm_items, int32_t frm_nodes, float lowe_ratio,
                                             int32_t check_orientation, int32_t* matched_kf_in_frm, int32_t* num_matches) {
-    return bow_match_impl(w, 0, nullptr, nullptr, kf_kps, kf_desc, kf_valid, n_kf, kf_node_ids, kf_node_start, kf_items, kf_nodes, frm_kps, frm_desc, n_frm,
+    return bow_match_impl(w, nullptr, nullptr, 0, nullptr, nullptr, kf_kps, kf_desc, kf_valid, n_kf, kf_node_ids, kf_node_start, kf_items, kf_nodes, frm_kps, frm_desc, n_frm,
                           frm_node_ids, frm_node_start, frm_items, frm_nodes, lowe_ratio, check_orientation, matched_kf_in_frm, num_matches);
 }
 
@@ -1420,7 +1495,7 @@ ovs_status ovs_bow_match_keyframes(ovs_wmatcher* w, const ovs_keypoint* kps_1, c
                                    const ovs_keypoint* kps_2, const uint8_t* desc_2, const uint8_t* valid_2, int32_t n2,
                                    const int32_t* node_ids_2, const int32_t* node_start_2, const int32_t* items_2, int32_t nodes_2,
                                    float lowe_ratio, int32_t check_orientation, int32_t* matched_2_in_1, int32_t* num_matches) {
-    return bow_match_impl(w, 1, valid_2, nullptr, kps_1, desc_1, valid_1, n1, node_ids_1, node_start_1, items_1, nodes_1, kps_2, desc_2, n2, node_ids_2,
+    return bow_match_impl(w, nullptr, nullptr, 1, valid_2, nullptr, kps_1, desc_1, valid_1, n1, node_ids_1, node_start_1, items_1, nodes_1, kps_2, desc_2, n2, node_ids_2,
                           node_start_2, items_2, nodes_2, lowe_ratio, check_orientation, matched_2_in_1, num_matches);
 }
 
@@ -1441,7 +1516,7 @@ ovs_status ovs_robust_match_for_triangulation(ovs_wmatcher* w, const ovs_keypoin
     if (has_lm_2)
         for (int i = 0; i < n2; ++i) v2[i] = has_lm_2[i] ? 0 : 1;
     TriParams tp{x_right_1, x_right_2, bearings_1, bearings_2, E_12, epipole_in_2, scale_factors, num_levels};
-    return bow_match_impl(w, 1, v2.data(), &tp, kps_1, desc_1, v1.data(), n1, node_ids_1, node_start_1, items_1, nodes_1, kps_2, desc_2, n2,
+    return bow_match_impl(w, nullptr, nullptr, 1, v2.data(), &tp, kps_1, desc_1, v1.data(), n1, node_ids_1, node_start_1, items_1, nodes_1, kps_2, desc_2, n2,
                           node_ids_2, node_start_2, items_2, nodes_2, 0.0f, check_orientation, matched_2_in_1, num_matches);
 }
 
@@ -1551,7 +1626,7 @@ ovs_status ovs_projection_match_current_and_last_frames(ovs_wmatcher* w, const o
     return overflow ? OVS_ERR_CAPACITY : OVS_OK;
 }
 
-ovs_status ovs_fuse_replace_duplication(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps,
+static ovs_status fuse_replace_duplication_impl(ovs_wmatcher* w, const ovs_frame_dev* res, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps,
                                         const uint8_t* desc, const float* stereo_x_right, int32_t n, const double* pose_cw,
                                         const double* lm_pos_w, const float* lm_dist_min_max, const double* lm_normal,
                                         const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m, const float* scale_factors,
@@ -1565,7 +1640,7 @@ ovs_status ovs_fuse_replace_duplication(ovs_wmatcher* w, const ovs_camera* cam, 
     if (!best_idx) return OVS_ERR_INVALID;
     for (int i = 0; i < m; ++i) best_idx[i] = -1;
     if (n == 0) return OVS_OK;
-    if (!kps || !desc || !lm_pos_w || !lm_dist_min_max || !lm_normal || !lm_desc) return OVS_ERR_INVALID;
+    if ((!res && (!kps || !desc)) || !lm_pos_w || !lm_dist_min_max || !lm_normal || !lm_desc) return OVS_ERR_INVALID;
     if (n > w->max_t || m > w->max_q) return OVS_ERR_CAPACITY;
     OVS_HIP_TRY(hipSetDevice(w->device));
     hipStream_t s = w->stream;
@@ -1600,22 +1675,20 @@ ovs_status ovs_fuse_replace_duplication(ovs_wmatcher* w, const ovs_camera* cam, 
     // staging: landmark positions ride in d_q_pos, normals behind the key buffer (3 doubles per landmark <= max_entries * 4 bytes?)
     if ((size_t)m * 3 * sizeof(double) > (size_t)w->max_entries * sizeof(uint32_t)) return OVS_ERR_CAPACITY;
     double* d_normal = reinterpret_cast<double*>(w->d_keys);
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, kps, sizeof(ovs_keypoint) * n, hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, desc, (size_t)32 * n, hipMemcpyHostToDevice, s));
-    if (stereo_x_right) OVS_HIP_TRY(hipMemcpyAsync(w->d_t_f, stereo_x_right, sizeof(float) * n, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(w->d_q_pos, lm_pos_w, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(d_normal, lm_normal, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(w->d_q_xy, lm_dist_min_max, sizeof(float) * 2 * m, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, lm_desc, (size_t)32 * m, hipMemcpyHostToDevice, s));
     if (lm_valid) OVS_HIP_TRY(hipMemcpyAsync(w->d_q_flag, lm_valid, (size_t)m, hipMemcpyHostToDevice, s));
-    ovs_status st = grid_assign(w, gp, w->d_t_kps, n, s);
+    TargetRef tg;
+    ovs_status st = stage_target(w, res, gp, kps, desc, stereo_x_right, n, s, &tg);
     if (st != OVS_OK) return st;
-    a.t_kps = w->d_t_kps;
-    a.t_desc = w->d_t_desc;
-    a.t_x_right = stereo_x_right ? w->d_t_f : nullptr;
-    a.cell_start = w->d_cell_start;
-    a.items = w->d_items;
-    a.gp = w->gp;
+    a.t_kps = tg.kps;
+    a.t_desc = tg.desc;
+    a.t_x_right = tg.x_right;
+    a.cell_start = tg.cell_start;
+    a.items = tg.items;
+    a.gp = tg.gp;
     a.lm_pos_w = w->d_q_pos;
     a.lm_dist = w->d_q_xy;
     a.lm_normal = d_normal;
@@ -1632,7 +1705,7 @@ ovs_status ovs_fuse_replace_duplication(ovs_wmatcher* w, const ovs_camera* cam, 
     return OVS_OK;
 }
 
-ovs_status ovs_projection_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp,
+static ovs_status projection_match_frame_and_keyframe_impl(ovs_wmatcher* w, const ovs_frame_dev* res, const ovs_camera* cam, const ovs_grid_params* gp,
                                                    const ovs_keypoint* curr_kps, const uint8_t* curr_desc, const uint8_t* curr_occupied,
                                                    int32_t n_curr, const double* pose_cw_curr, const ovs_keypoint* kf_kps,
                                                    const double* kf_pos_w, const float* kf_dist_min_max, const uint8_t* kf_lm_desc,
@@ -1647,7 +1720,7 @@ ovs_status ovs_projection_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_ca
     if (!assigned) return OVS_ERR_INVALID;
     for (int i = 0; i < n_kf; ++i) assigned[i] = -1;
     if (n_curr == 0) return OVS_OK;
-    if (!curr_kps || !curr_desc || !kf_kps || !kf_pos_w || !kf_dist_min_max || !kf_lm_desc) return OVS_ERR_INVALID;
+    if ((!res && (!curr_kps || !curr_desc)) || !kf_kps || !kf_pos_w || !kf_dist_min_max || !kf_lm_desc) return OVS_ERR_INVALID;
     if (n_curr > w->max_t || n_kf > w->max_q) return OVS_ERR_CAPACITY;
     if ((size_t)n_kf * 2 * sizeof(float) > (size_t)w->max_entries * sizeof(uint32_t)) return OVS_ERR_CAPACITY;
     OVS_HIP_TRY(hipSetDevice(w->device));
@@ -1672,8 +1745,6 @@ ovs_status ovs_projection_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_ca
     const double ccx = -((R[0] * t[0] + R[3] * t[1]) + R[6] * t[2]), ccy = -((R[1] * t[0] + R[4] * t[1]) + R[7] * t[2]),
                  ccz = -((R[2] * t[0] + R[5] * t[1]) + R[8] * t[2]);
     float* d_dist = reinterpret_cast<float*>(w->d_keys);   // consumed by k_reproject_queries before the key buffer is written
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, curr_kps, sizeof(ovs_keypoint) * n_curr, hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, curr_desc, (size_t)32 * n_curr, hipMemcpyHostToDevice, s));
     if (curr_occupied) OVS_HIP_TRY(hipMemcpyAsync(w->d_t_flag, curr_occupied, (size_t)n_curr, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(w->d_q_kps, kf_kps, sizeof(ovs_keypoint) * n_kf, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(w->d_q_pos, kf_pos_w, sizeof(double) * 3 * n_kf, hipMemcpyHostToDevice, s));
@@ -1688,19 +1759,20 @@ ovs_status ovs_projection_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_ca
     for (int l = 0; l < OVS_MAX_LEVELS; ++l) sf16[l] = l < num_levels ? scale_factors[l] : 1.0f;
     OVS_HIP_TRY(hipMemcpyAsync(w->d_sf, sf16, sizeof(sf16), hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipStreamSynchronize(s));   // sf16 is a stack array
-    ovs_status st = grid_assign(w, gp, w->d_t_kps, n_curr, s);
+    TargetRef tg;
+    ovs_status st = stage_target(w, res, gp, curr_kps, curr_desc, nullptr, n_curr, s, &tg);
     if (st != OVS_OK) return st;
     hipLaunchKernelGGL(k_reproject_queries, dim3((n_kf + 255) / 256), dim3(256), 0, s, cp, (const ovs_keypoint*)w->d_q_kps,
                        (const double*)w->d_q_pos, (const uint8_t*)d_valid, n_kf, margin, (const float*)w->d_sf, num_levels, 0, 0,
                        (const float*)d_dist, ccx, ccy, ccz, log_scale_factor, w->d_q_xy, w->d_q_f, w->d_q_r, w->d_q_i, w->d_q_i2, w->d_q_flag);
     OVS_HIP_TRY(hipGetLastError());
     WinArgs a{};
-    a.t_kps = w->d_t_kps;
-    a.t_desc = w->d_t_desc;
+    a.t_kps = tg.kps;
+    a.t_desc = tg.desc;
     a.t_occupied = curr_occupied ? w->d_t_flag : nullptr;
-    a.cell_start = w->d_cell_start;
-    a.items = w->d_items;
-    a.gp = w->gp;
+    a.cell_start = tg.cell_start;
+    a.items = tg.items;
+    a.gp = tg.gp;
     a.n_q = n_kf;
     a.q_xy = w->d_q_xy;
     a.q_x_right = w->d_q_f;
@@ -1720,7 +1792,7 @@ ovs_status ovs_projection_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_ca
     ra.n_t = n_curr;
     ra.check_orientation = check_orientation;
     ra.q_kps = w->d_q_kps;
-    ra.t_kps = w->d_t_kps;
+    ra.t_kps = tg.kps;
     ra.assigned = w->d_assigned;
     ra.num_matches = w->d_num;
     ra.best_only_thr = hamm_dist_thr;
@@ -1763,7 +1835,7 @@ void decompose_sim3(const double* S, double* P, double* cc) {
 }
 }   // namespace
 
-ovs_status ovs_fuse_detect_duplication(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps,
+static ovs_status fuse_detect_duplication_impl(ovs_wmatcher* w, const ovs_frame_dev* res, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps,
                                        const uint8_t* desc, int32_t n, const double* sim3_cw, const double* lm_pos_w,
                                        const float* lm_dist_min_max, const double* lm_normal, const uint8_t* lm_desc, const uint8_t* lm_valid,
                                        int32_t m, const float* scale_factors, int32_t num_levels, float log_scale_factor, float margin,
@@ -1776,7 +1848,7 @@ ovs_status ovs_fuse_detect_duplication(ovs_wmatcher* w, const ovs_camera* cam, c
     if (!best_idx) return OVS_ERR_INVALID;
     for (int i = 0; i < m; ++i) best_idx[i] = -1;
     if (n == 0) return OVS_OK;
-    if (!kps || !desc || !lm_pos_w || !lm_dist_min_max || !lm_normal || !lm_desc) return OVS_ERR_INVALID;
+    if ((!res && (!kps || !desc)) || !lm_pos_w || !lm_dist_min_max || !lm_normal || !lm_desc) return OVS_ERR_INVALID;
     if (n > w->max_t || m > w->max_q) return OVS_ERR_CAPACITY;
     if ((size_t)m * 3 * sizeof(double) > (size_t)w->max_entries * sizeof(uint32_t)) return OVS_ERR_CAPACITY;
     OVS_HIP_TRY(hipSetDevice(w->device));
@@ -1796,20 +1868,19 @@ ovs_status ovs_fuse_detect_duplication(ovs_wmatcher* w, const ovs_camera* cam, c
     a.variant = kFuseDetect;
     a.max_dist = OVS_HAMMING_DIST_THR_LOW;
     double* d_normal = reinterpret_cast<double*>(w->d_keys);
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, kps, sizeof(ovs_keypoint) * n, hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, desc, (size_t)32 * n, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(w->d_q_pos, lm_pos_w, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(d_normal, lm_normal, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(w->d_q_xy, lm_dist_min_max, sizeof(float) * 2 * m, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, lm_desc, (size_t)32 * m, hipMemcpyHostToDevice, s));
     if (lm_valid) OVS_HIP_TRY(hipMemcpyAsync(w->d_q_flag, lm_valid, (size_t)m, hipMemcpyHostToDevice, s));
-    ovs_status st = grid_assign(w, gp, w->d_t_kps, n, s);
+    TargetRef tg;
+    ovs_status st = stage_target(w, res, gp, kps, desc, nullptr, n, s, &tg);
     if (st != OVS_OK) return st;
-    a.t_kps = w->d_t_kps;
-    a.t_desc = w->d_t_desc;
-    a.cell_start = w->d_cell_start;
-    a.items = w->d_items;
-    a.gp = w->gp;
+    a.t_kps = tg.kps;
+    a.t_desc = tg.desc;
+    a.cell_start = tg.cell_start;
+    a.items = tg.items;
+    a.gp = tg.gp;
     a.lm_pos_w = w->d_q_pos;
     a.lm_dist = w->d_q_xy;
     a.lm_normal = d_normal;
@@ -1824,7 +1895,7 @@ ovs_status ovs_fuse_detect_duplication(ovs_wmatcher* w, const ovs_camera* cam, c
     return OVS_OK;
 }
 
-ovs_status ovs_projection_match_by_sim3_transform(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps,
+static ovs_status projection_match_by_sim3_transform_impl(ovs_wmatcher* w, const ovs_frame_dev* res, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps,
                                                   const uint8_t* desc, const uint8_t* occupied, int32_t n, const double* sim3_cw,
                                                   const double* lm_pos_w, const float* lm_dist_min_max, const double* lm_normal,
                                                   const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m, const float* scale_factors,
@@ -1838,7 +1909,7 @@ ovs_status ovs_projection_match_by_sim3_transform(ovs_wmatcher* w, const ovs_cam
     if (!assigned) return OVS_ERR_INVALID;
     for (int i = 0; i < m; ++i) assigned[i] = -1;
     if (n == 0) return OVS_OK;
-    if (!kps || !desc || !lm_pos_w || !lm_dist_min_max || !lm_normal || !lm_desc) return OVS_ERR_INVALID;
+    if ((!res && (!kps || !desc)) || !lm_pos_w || !lm_dist_min_max || !lm_normal || !lm_desc) return OVS_ERR_INVALID;
     if (n > w->max_t || m > w->max_q) return OVS_ERR_CAPACITY;
     // (min, max) distances then the normals ride in the key buffer; both are consumed before the lists are written
     if ((size_t)m * (2 * sizeof(float) + 3 * sizeof(double)) > (size_t)w->max_entries * sizeof(uint32_t)) return OVS_ERR_CAPACITY;
@@ -1850,8 +1921,6 @@ ovs_status ovs_projection_match_by_sim3_transform(ovs_wmatcher* w, const ovs_cam
     fill_cam(cp, cam, gp, P);
     float* d_dist = reinterpret_cast<float*>(w->d_keys);
     double* d_normal = reinterpret_cast<double*>(d_dist + 2 * (size_t)m);
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, kps, sizeof(ovs_keypoint) * n, hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, desc, (size_t)32 * n, hipMemcpyHostToDevice, s));
     if (occupied) OVS_HIP_TRY(hipMemcpyAsync(w->d_t_flag, occupied, (size_t)n, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(w->d_q_pos, lm_pos_w, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(d_dist, lm_dist_min_max, sizeof(float) * 2 * m, hipMemcpyHostToDevice, s));
@@ -1866,19 +1935,20 @@ ovs_status ovs_projection_match_by_sim3_transform(ovs_wmatcher* w, const ovs_cam
     for (int l = 0; l < OVS_MAX_LEVELS; ++l) sf16[l] = l < num_levels ? scale_factors[l] : 1.0f;
     OVS_HIP_TRY(hipMemcpyAsync(w->d_sf, sf16, sizeof(sf16), hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipStreamSynchronize(s));   // sf16 is a stack array
-    ovs_status st = grid_assign(w, gp, w->d_t_kps, n, s);
+    TargetRef tg;
+    ovs_status st = stage_target(w, res, gp, kps, desc, nullptr, n, s, &tg);
     if (st != OVS_OK) return st;
     hipLaunchKernelGGL(k_reproject_queries, dim3((m + 255) / 256), dim3(256), 0, s, cp, (const ovs_keypoint*)nullptr, (const double*)w->d_q_pos,
                        (const uint8_t*)d_valid, m, margin, (const float*)w->d_sf, num_levels, 0, 0, (const float*)d_dist, cc[0], cc[1], cc[2],
                        log_scale_factor, w->d_q_xy, w->d_q_f, w->d_q_r, w->d_q_i, w->d_q_i2, w->d_q_flag, (const double*)d_normal, 0);
     OVS_HIP_TRY(hipGetLastError());
     WinArgs a{};
-    a.t_kps = w->d_t_kps;
-    a.t_desc = w->d_t_desc;
+    a.t_kps = tg.kps;
+    a.t_desc = tg.desc;
     a.t_occupied = occupied ? w->d_t_flag : nullptr;
-    a.cell_start = w->d_cell_start;
-    a.items = w->d_items;
-    a.gp = w->gp;
+    a.cell_start = tg.cell_start;
+    a.items = tg.items;
+    a.gp = tg.gp;
     a.n_q = m;
     a.q_xy = w->d_q_xy;
     a.q_x_right = w->d_q_f;
@@ -1898,7 +1968,7 @@ ovs_status ovs_projection_match_by_sim3_transform(ovs_wmatcher* w, const ovs_cam
     ra.n_t = n;
     ra.check_orientation = 0;
     ra.q_kps = nullptr;
-    ra.t_kps = w->d_t_kps;
+    ra.t_kps = tg.kps;
     ra.assigned = w->d_assigned;
     ra.num_matches = w->d_num;
     ra.best_only_thr = OVS_HAMMING_DIST_THR_LOW;
@@ -1913,7 +1983,7 @@ ovs_status ovs_projection_match_by_sim3_transform(ovs_wmatcher* w, const ovs_cam
 }
 
 // one direction of match_keyframes_mutually: the landmarks of keyframe A (pose P_a, world positions) against the keypoints of keyframe B
-static ovs_status mutual_pass(ovs_wmatcher* w, const ovs_camera* cam_b, const ovs_grid_params* gp_b, const ovs_keypoint* kps_b,
+static ovs_status mutual_pass(ovs_wmatcher* w, const ovs_frame_dev* res_b, const ovs_camera* cam_b, const ovs_grid_params* gp_b, const ovs_keypoint* kps_b,
                               const uint8_t* desc_b, int n_b, const double* pose_cw_a, const double* sim_ba, const double* lm_pos_w_a,
                               const float* lm_dist_a, const uint8_t* lm_desc_a, const uint8_t* lm_valid_a, int n_a, const float* scale_factors,
                               int num_levels, float log_scale_factor, float margin, int32_t* d_out, hipStream_t s) {
@@ -1930,19 +2000,18 @@ static ovs_status mutual_pass(ovs_wmatcher* w, const ovs_camera* cam_b, const ov
     a.m = n_a;
     a.variant = kFuseMutual;
     a.max_dist = OVS_HAMMING_DIST_THR_HIGH;
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_kps, kps_b, sizeof(ovs_keypoint) * n_b, hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_t_desc, desc_b, (size_t)32 * n_b, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(w->d_q_pos, lm_pos_w_a, sizeof(double) * 3 * n_a, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(w->d_q_xy, lm_dist_a, sizeof(float) * 2 * n_a, hipMemcpyHostToDevice, s));
     OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, lm_desc_a, (size_t)32 * n_a, hipMemcpyHostToDevice, s));
     if (lm_valid_a) OVS_HIP_TRY(hipMemcpyAsync(w->d_q_flag, lm_valid_a, (size_t)n_a, hipMemcpyHostToDevice, s));
-    ovs_status st = grid_assign(w, gp_b, w->d_t_kps, n_b, s);
+    TargetRef tg;
+    ovs_status st = stage_target(w, res_b, gp_b, kps_b, desc_b, nullptr, n_b, s, &tg);
     if (st != OVS_OK) return st;
-    a.t_kps = w->d_t_kps;
-    a.t_desc = w->d_t_desc;
-    a.cell_start = w->d_cell_start;
-    a.items = w->d_items;
-    a.gp = w->gp;
+    a.t_kps = tg.kps;
+    a.t_desc = tg.desc;
+    a.cell_start = tg.cell_start;
+    a.items = tg.items;
+    a.gp = tg.gp;
     a.lm_pos_w = w->d_q_pos;
     a.lm_dist = w->d_q_xy;
     a.lm_desc = w->d_q_desc;
@@ -1952,7 +2021,7 @@ static ovs_status mutual_pass(ovs_wmatcher* w, const ovs_camera* cam_b, const ov
     return OVS_OK;
 }
 
-ovs_status ovs_projection_match_keyframes_mutually(ovs_wmatcher* w, const ovs_camera* cam_1, const ovs_grid_params* gp_1,
+static ovs_status projection_match_keyframes_mutually_impl(ovs_wmatcher* w, const ovs_frame_dev* res_1, const ovs_frame_dev* res_2, const ovs_camera* cam_1, const ovs_grid_params* gp_1,
                                                    const ovs_keypoint* kps_1, const uint8_t* desc_1, int32_t n1, const double* pose_cw_1,
                                                    const double* lm_pos_w_1, const float* lm_dist_1, const uint8_t* lm_desc_1,
                                                    const uint8_t* lm_valid_1, const ovs_camera* cam_2, const ovs_grid_params* gp_2,
@@ -1970,7 +2039,7 @@ ovs_status ovs_projection_match_keyframes_mutually(ovs_wmatcher* w, const ovs_ca
     if (!matched_2_in_1) return OVS_ERR_INVALID;
     for (int i = 0; i < n1; ++i) matched_2_in_1[i] = -1;
     if (n2 == 0) return OVS_OK;
-    if (!kps_1 || !desc_1 || !lm_pos_w_1 || !lm_dist_1 || !lm_desc_1 || !kps_2 || !desc_2 || !lm_pos_w_2 || !lm_dist_2 || !lm_desc_2)
+    if ((!res_1 && (!kps_1 || !desc_1)) || !lm_pos_w_1 || !lm_dist_1 || !lm_desc_1 || (!res_2 && (!kps_2 || !desc_2)) || !lm_pos_w_2 || !lm_dist_2 || !lm_desc_2)
         return OVS_ERR_INVALID;
     const int nmax = std::max(n1, n2);
     if (nmax > w->max_t || nmax > w->max_q) return OVS_ERR_CAPACITY;
@@ -1987,10 +2056,10 @@ ovs_status ovs_projection_match_keyframes_mutually(ovs_wmatcher* w, const ovs_ca
     for (int r = 0; r < 3; ++r) S21[9 + r] = -((S21[3 * r] * trans_12[0] + S21[3 * r + 1] * trans_12[1]) + S21[3 * r + 2] * trans_12[2]);
     int32_t* d_2_in_1 = reinterpret_cast<int32_t*>(w->d_keys);
     int32_t* d_1_in_2 = d_2_in_1 + n1;
-    ovs_status st = mutual_pass(w, cam_2, gp_2, kps_2, desc_2, n2, pose_cw_1, S21, lm_pos_w_1, lm_dist_1, lm_desc_1, lm_valid_1, n1, scale_factors,
+    ovs_status st = mutual_pass(w, res_2, cam_2, gp_2, kps_2, desc_2, n2, pose_cw_1, S21, lm_pos_w_1, lm_dist_1, lm_desc_1, lm_valid_1, n1, scale_factors,
                                 num_levels, log_scale_factor, margin, d_2_in_1, s);
     if (st != OVS_OK) return st;
-    st = mutual_pass(w, cam_1, gp_1, kps_1, desc_1, n1, pose_cw_2, S12, lm_pos_w_2, lm_dist_2, lm_desc_2, lm_valid_2, n2, scale_factors, num_levels,
+    st = mutual_pass(w, res_1, cam_1, gp_1, kps_1, desc_1, n1, pose_cw_2, S12, lm_pos_w_2, lm_dist_2, lm_desc_2, lm_valid_2, n2, scale_factors, num_levels,
                      log_scale_factor, margin, d_1_in_2, s);
     if (st != OVS_OK) return st;
     OVS_HIP_TRY(hipMemsetAsync(w->d_num, 0, sizeof(int32_t), s));
@@ -2012,19 +2081,6 @@ ovs_status ovs_projection_match_keyframes_mutually(ovs_wmatcher* w, const ovs_ca
 // What remains per call is what really changes per call: the landmark side, staged through ONE pinned buffer into ONE device arena (one
 // copy up), and the result block (one copy down).
 // ---------------------------------------------------------------------------------------------------------------------------
-struct ovs_frame_dev {
-    int device = 0;
-    int n = 0, cap = 0, n_cells = 0;
-    bool has_stereo = false;
-    GridP gp{};
-    ovs_grid_params gpp{};
-    unsigned char* arena = nullptr;
-    size_t arena_bytes = 0;
-    ovs_keypoint* d_kps = nullptr;
-    uint8_t* d_desc = nullptr;
-    float* d_x_right = nullptr;
-    int32_t *d_cell_of = nullptr, *d_cell_start = nullptr, *d_items = nullptr;
-};
 
 namespace {
 
@@ -2135,6 +2191,7 @@ extern "C" {
 ovs_status ovs_frame_dev_destroy(ovs_frame_dev* f) {
     if (!f) return OVS_OK;
     if (f->arena) g_frame_pool.give(f->device, f->arena_bytes, f->arena);
+    if (f->d_bearings) (void)hipFree(f->d_bearings);
     delete f;
     return OVS_OK;
 }
@@ -2434,5 +2491,158 @@ ovs_status ovs_projection_match_current_and_last_frames_f(ovs_wmatcher* w, const
     if (st != OVS_OK) return st;
     return fetch_results(w, n_last, assigned, num_matches, s);
 }
+
+}   // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Keyframe-side matchers: the host-array forms and their resident twins (_f, round 4). A twin takes an ovs_frame_dev handle wherever the
+// host form takes (grid parameters, keypoints, descriptors, stereo_x_right, n) of the TARGET frame / keyframe; everything else -- the
+// landmark side, poses, thresholds, outputs -- is unchanged, and so are the results (tests/test_gpu_resident.py: bit-equal to the host forms).
+// ---------------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+ovs_status ovs_fuse_replace_duplication(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps, const uint8_t* desc,
+                                        const float* stereo_x_right, int32_t n, const double* pose_cw, const double* lm_pos_w, const float* lm_dist_min_max,
+                                        const double* lm_normal, const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m, const float* scale_factors,
+                                        const float* inv_level_sigma_sq, int32_t num_levels, float log_scale_factor, float margin, int32_t* best_idx,
+                                        int32_t* num_fused) {
+    return fuse_replace_duplication_impl(w, nullptr, cam, gp, kps, desc, stereo_x_right, n, pose_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc, lm_valid, m,
+                                         scale_factors, inv_level_sigma_sq, num_levels, log_scale_factor, margin, best_idx, num_fused);
+}
+ovs_status ovs_fuse_replace_duplication_f(ovs_wmatcher* w, const ovs_camera* cam, const ovs_frame_dev* keyfrm, const double* pose_cw, const double* lm_pos_w,
+                                          const float* lm_dist_min_max, const double* lm_normal, const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m,
+                                          const float* scale_factors, const float* inv_level_sigma_sq, int32_t num_levels, float log_scale_factor,
+                                          float margin, int32_t* best_idx, int32_t* num_fused) {
+    if (!keyfrm) return OVS_ERR_INVALID;
+    return fuse_replace_duplication_impl(w, keyfrm, cam, &keyfrm->gpp, nullptr, nullptr, nullptr, keyfrm->n, pose_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc,
+                                         lm_valid, m, scale_factors, inv_level_sigma_sq, num_levels, log_scale_factor, margin, best_idx, num_fused);
+}
+
+ovs_status ovs_projection_match_frame_and_keyframe(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* curr_kps,
+                                                   const uint8_t* curr_desc, const uint8_t* curr_occupied, int32_t n_curr, const double* pose_cw_curr,
+                                                   const ovs_keypoint* kf_kps, const double* kf_pos_w, const float* kf_dist_min_max, const uint8_t* kf_lm_desc,
+                                                   const uint8_t* kf_valid, int32_t n_kf, const float* scale_factors, int32_t num_levels,
+                                                   float log_scale_factor, float margin, uint32_t hamm_dist_thr, int32_t check_orientation, int32_t* assigned,
+                                                   int32_t* num_matches) {
+    return projection_match_frame_and_keyframe_impl(w, nullptr, cam, gp, curr_kps, curr_desc, curr_occupied, n_curr, pose_cw_curr, kf_kps, kf_pos_w, kf_dist_min_max,
+                                                    kf_lm_desc, kf_valid, n_kf, scale_factors, num_levels, log_scale_factor, margin, hamm_dist_thr,
+                                                    check_orientation, assigned, num_matches);
+}
+ovs_status ovs_projection_match_frame_and_keyframe_f(ovs_wmatcher* w, const ovs_camera* cam, const ovs_frame_dev* curr, const uint8_t* curr_occupied,
+                                                     const double* pose_cw_curr, const ovs_keypoint* kf_kps, const double* kf_pos_w,
+                                                     const float* kf_dist_min_max, const uint8_t* kf_lm_desc, const uint8_t* kf_valid, int32_t n_kf,
+                                                     const float* scale_factors, int32_t num_levels, float log_scale_factor, float margin,
+                                                     uint32_t hamm_dist_thr, int32_t check_orientation, int32_t* assigned, int32_t* num_matches) {
+    if (!curr) return OVS_ERR_INVALID;
+    return projection_match_frame_and_keyframe_impl(w, curr, cam, &curr->gpp, nullptr, nullptr, curr_occupied, curr->n, pose_cw_curr, kf_kps, kf_pos_w, kf_dist_min_max,
+                                                    kf_lm_desc, kf_valid, n_kf, scale_factors, num_levels, log_scale_factor, margin, hamm_dist_thr,
+                                                    check_orientation, assigned, num_matches);
+}
+
+ovs_status ovs_fuse_detect_duplication(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps, const uint8_t* desc, int32_t n,
+                                       const double* sim3_cw, const double* lm_pos_w, const float* lm_dist_min_max, const double* lm_normal,
+                                       const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m, const float* scale_factors, int32_t num_levels,
+                                       float log_scale_factor, float margin, int32_t* best_idx, int32_t* num_found) {
+    return fuse_detect_duplication_impl(w, nullptr, cam, gp, kps, desc, n, sim3_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc, lm_valid, m, scale_factors, num_levels,
+                                        log_scale_factor, margin, best_idx, num_found);
+}
+ovs_status ovs_fuse_detect_duplication_f(ovs_wmatcher* w, const ovs_camera* cam, const ovs_frame_dev* keyfrm, const double* sim3_cw, const double* lm_pos_w,
+                                         const float* lm_dist_min_max, const double* lm_normal, const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m,
+                                         const float* scale_factors, int32_t num_levels, float log_scale_factor, float margin, int32_t* best_idx,
+                                         int32_t* num_found) {
+    if (!keyfrm) return OVS_ERR_INVALID;
+    return fuse_detect_duplication_impl(w, keyfrm, cam, &keyfrm->gpp, nullptr, nullptr, keyfrm->n, sim3_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc, lm_valid, m,
+                                        scale_factors, num_levels, log_scale_factor, margin, best_idx, num_found);
+}
+
+ovs_status ovs_projection_match_by_sim3_transform(ovs_wmatcher* w, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps, const uint8_t* desc,
+                                                  const uint8_t* occupied, int32_t n, const double* sim3_cw, const double* lm_pos_w,
+                                                  const float* lm_dist_min_max, const double* lm_normal, const uint8_t* lm_desc, const uint8_t* lm_valid,
+                                                  int32_t m, const float* scale_factors, int32_t num_levels, float log_scale_factor, float margin,
+                                                  int32_t* assigned, int32_t* num_matches) {
+    return projection_match_by_sim3_transform_impl(w, nullptr, cam, gp, kps, desc, occupied, n, sim3_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc, lm_valid, m,
+                                                   scale_factors, num_levels, log_scale_factor, margin, assigned, num_matches);
+}
+ovs_status ovs_projection_match_by_sim3_transform_f(ovs_wmatcher* w, const ovs_camera* cam, const ovs_frame_dev* keyfrm, const uint8_t* occupied,
+                                                    const double* sim3_cw, const double* lm_pos_w, const float* lm_dist_min_max, const double* lm_normal,
+                                                    const uint8_t* lm_desc, const uint8_t* lm_valid, int32_t m, const float* scale_factors,
+                                                    int32_t num_levels, float log_scale_factor, float margin, int32_t* assigned, int32_t* num_matches) {
+    if (!keyfrm) return OVS_ERR_INVALID;
+    return projection_match_by_sim3_transform_impl(w, keyfrm, cam, &keyfrm->gpp, nullptr, nullptr, occupied, keyfrm->n, sim3_cw, lm_pos_w, lm_dist_min_max, lm_normal,
+                                                   lm_desc, lm_valid, m, scale_factors, num_levels, log_scale_factor, margin, assigned, num_matches);
+}
+
+ovs_status ovs_projection_match_keyframes_mutually(ovs_wmatcher* w, const ovs_camera* cam_1, const ovs_grid_params* gp_1, const ovs_keypoint* kps_1,
+                                                   const uint8_t* desc_1, int32_t n1, const double* pose_cw_1, const double* lm_pos_w_1,
+                                                   const float* lm_dist_1, const uint8_t* lm_desc_1, const uint8_t* lm_valid_1, const ovs_camera* cam_2,
+                                                   const ovs_grid_params* gp_2, const ovs_keypoint* kps_2, const uint8_t* desc_2, int32_t n2,
+                                                   const double* pose_cw_2, const double* lm_pos_w_2, const float* lm_dist_2, const uint8_t* lm_desc_2,
+                                                   const uint8_t* lm_valid_2, double s_12, const double* rot_12, const double* trans_12,
+                                                   const float* scale_factors, int32_t num_levels, float log_scale_factor, float margin,
+                                                   int32_t* matched_2_in_1, int32_t* num_matches) {
+    return projection_match_keyframes_mutually_impl(w, nullptr, nullptr, cam_1, gp_1, kps_1, desc_1, n1, pose_cw_1, lm_pos_w_1, lm_dist_1, lm_desc_1, lm_valid_1, cam_2,
+                                                    gp_2, kps_2, desc_2, n2, pose_cw_2, lm_pos_w_2, lm_dist_2, lm_desc_2, lm_valid_2, s_12, rot_12, trans_12,
+                                                    scale_factors, num_levels, log_scale_factor, margin, matched_2_in_1, num_matches);
+}
+ovs_status ovs_projection_match_keyframes_mutually_f(ovs_wmatcher* w, const ovs_camera* cam_1, const ovs_frame_dev* keyfrm_1, const double* pose_cw_1,
+                                                     const double* lm_pos_w_1, const float* lm_dist_1, const uint8_t* lm_desc_1, const uint8_t* lm_valid_1,
+                                                     const ovs_camera* cam_2, const ovs_frame_dev* keyfrm_2, const double* pose_cw_2,
+                                                     const double* lm_pos_w_2, const float* lm_dist_2, const uint8_t* lm_desc_2, const uint8_t* lm_valid_2,
+                                                     double s_12, const double* rot_12, const double* trans_12, const float* scale_factors,
+                                                     int32_t num_levels, float log_scale_factor, float margin, int32_t* matched_2_in_1,
+                                                     int32_t* num_matches) {
+    if (!keyfrm_1 || !keyfrm_2) return OVS_ERR_INVALID;
+    return projection_match_keyframes_mutually_impl(w, keyfrm_1, keyfrm_2, cam_1, &keyfrm_1->gpp, nullptr, nullptr, keyfrm_1->n, pose_cw_1, lm_pos_w_1, lm_dist_1,
+                                                    lm_desc_1, lm_valid_1, cam_2, &keyfrm_2->gpp, nullptr, nullptr, keyfrm_2->n, pose_cw_2, lm_pos_w_2, lm_dist_2,
+                                                    lm_desc_2, lm_valid_2, s_12, rot_12, trans_12, scale_factors, num_levels, log_scale_factor, margin,
+                                                    matched_2_in_1, num_matches);
+}
+
+// bow_tree / robust::match_for_triangulation with both sides resident: only the per-call flags and the BoW feature vectors (node CSRs) travel
+ovs_status ovs_bow_match_frame_and_keyframe_f(ovs_wmatcher* w, const ovs_frame_dev* keyfrm, const uint8_t* kf_valid, const int32_t* kf_node_ids,
+                                              const int32_t* kf_node_start, const int32_t* kf_items, int32_t kf_nodes, const ovs_frame_dev* frm,
+                                              const int32_t* frm_node_ids, const int32_t* frm_node_start, const int32_t* frm_items, int32_t frm_nodes,
+                                              float lowe_ratio, int32_t check_orientation, int32_t* matched_kf_in_frm, int32_t* num_matches) {
+    if (!keyfrm || !frm) return OVS_ERR_INVALID;
+    return bow_match_impl(w, keyfrm, frm, 0, nullptr, nullptr, nullptr, nullptr, kf_valid, keyfrm->n, kf_node_ids, kf_node_start, kf_items, kf_nodes, nullptr, nullptr,
+                          frm->n, frm_node_ids, frm_node_start, frm_items, frm_nodes, lowe_ratio, check_orientation, matched_kf_in_frm, num_matches);
+}
+ovs_status ovs_bow_match_keyframes_f(ovs_wmatcher* w, const ovs_frame_dev* keyfrm_1, const uint8_t* valid_1, const int32_t* node_ids_1,
+                                     const int32_t* node_start_1, const int32_t* items_1, int32_t nodes_1, const ovs_frame_dev* keyfrm_2,
+                                     const uint8_t* valid_2, const int32_t* node_ids_2, const int32_t* node_start_2, const int32_t* items_2, int32_t nodes_2,
+                                     float lowe_ratio, int32_t check_orientation, int32_t* matched_2_in_1, int32_t* num_matches) {
+    if (!keyfrm_1 || !keyfrm_2) return OVS_ERR_INVALID;
+    return bow_match_impl(w, keyfrm_1, keyfrm_2, 1, valid_2, nullptr, nullptr, nullptr, valid_1, keyfrm_1->n, node_ids_1, node_start_1, items_1, nodes_1, nullptr, nullptr,
+                          keyfrm_2->n, node_ids_2, node_start_2, items_2, nodes_2, lowe_ratio, check_orientation, matched_2_in_1, num_matches);
+}
+ovs_status ovs_robust_match_for_triangulation_f(ovs_wmatcher* w, const ovs_frame_dev* keyfrm_1, const uint8_t* has_lm_1, const int32_t* node_ids_1,
+                                                const int32_t* node_start_1, const int32_t* items_1, int32_t nodes_1, const ovs_frame_dev* keyfrm_2,
+                                                const uint8_t* has_lm_2, const int32_t* node_ids_2, const int32_t* node_start_2, const int32_t* items_2,
+                                                int32_t nodes_2, const double* E_12, const double* epipole_in_2, const float* scale_factors,
+                                                int32_t num_levels, int32_t check_orientation, int32_t* matched_2_in_1, int32_t* num_matches) {
+    if (!keyfrm_1 || !keyfrm_2 || !keyfrm_1->d_bearings || !keyfrm_2->d_bearings || !E_12 || !epipole_in_2 || !scale_factors || num_levels < 1 ||
+        num_levels > OVS_MAX_LEVELS)
+        return OVS_ERR_INVALID;
+    const int n1 = keyfrm_1->n, n2 = keyfrm_2->n;
+    std::vector<uint8_t> v1((size_t)std::max(n1, 1), 1), v2((size_t)std::max(n2, 1), 1);   // "valid" for the bow kernels = NO landmark yet
+    if (has_lm_1)
+        for (int i = 0; i < n1; ++i) v1[i] = has_lm_1[i] ? 0 : 1;
+    if (has_lm_2)
+        for (int i = 0; i < n2; ++i) v2[i] = has_lm_2[i] ? 0 : 1;
+    TriParams tp{nullptr, nullptr, nullptr, nullptr, E_12, epipole_in_2, scale_factors, num_levels};
+    return bow_match_impl(w, keyfrm_1, keyfrm_2, 1, v2.data(), &tp, nullptr, nullptr, v1.data(), n1, node_ids_1, node_start_1, items_1, nodes_1, nullptr, nullptr, n2,
+                          node_ids_2, node_start_2, items_2, nodes_2, 0.0f, check_orientation, matched_2_in_1, num_matches);
+}
+
+// 3 doubles per keypoint (data::keyframe::bearings_), uploaded once. Call it before the handle is shared between threads.
+ovs_status ovs_frame_dev_attach_bearings(ovs_frame_dev* f, const double* bearings) {
+    if (!f || (f->n > 0 && !bearings)) return OVS_ERR_INVALID;
+    if (f->n == 0) return OVS_OK;
+    OVS_HIP_TRY(hipSetDevice(f->device));
+    if (!f->d_bearings) OVS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f->d_bearings), sizeof(double) * 3 * (size_t)f->cap));
+    OVS_HIP_TRY(hipMemcpy(f->d_bearings, bearings, sizeof(double) * 3 * (size_t)f->n, hipMemcpyHostToDevice));
+    return OVS_OK;
+}
+int32_t ovs_frame_dev_device(const ovs_frame_dev* f) { return f ? f->device : -1; }
 
 }   // extern "C"

@@ -582,6 +582,8 @@ ovs_status ovs_orb_create(const ovs_orb_params* params, int32_t max_rows, int32_
     return OVS_OK;
 }
 
+int32_t ovs_orb_device(const ovs_orb* h) { return ovs::orb_device(h); }
+
 ovs_status ovs_orb_destroy(ovs_orb* h) {
     if (!h) return OVS_OK;
     if (h->stream) hipStreamSynchronize(h->stream);

@@ -152,6 +152,17 @@ class frame_dev:
         self.num_keypts = len(k)
         self.has_stereo = xr is not None
 
+    def attach_bearings(self, bearings):
+        """3 doubles per keypoint (keyframe::bearings_), uploaded once: robust_triangulation.match_for_triangulation needs them."""
+        b = np.ascontiguousarray(bearings, np.float64).reshape(-1, 3)
+        assert len(b) == self.num_keypts
+        _lib.check(self._L.ovs_frame_dev_attach_bearings(self._h, _p(b)), "ovs_frame_dev_attach_bearings")
+        return self
+
+    @property
+    def device(self):
+        return self._L.ovs_frame_dev_device(self._h)
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
@@ -236,9 +247,12 @@ class projection(_window_ctx):
     def match_frame_and_keyframe(self, cam, gp, curr_keypts, curr_desc, pose_cw_curr, kf_keypts, kf_pos_w, kf_dist_min_max, kf_lm_desc,
                                  scale_factors, log_scale_factor, margin, hamm_dist_thr, curr_occupied=None, kf_valid=None):
         """projection::match_frame_and_keyframe(curr_frm, keyfrm, already_matched_lms, margin, hamm_dist_thr): returns
-        (assigned, num_matches); assigned[i] is the current keypoint that receives the keyframe's landmark i, or -1."""
-        ck = np.ascontiguousarray(curr_keypts, KP_DTYPE)
-        cd = np.ascontiguousarray(curr_desc, np.uint8).reshape(-1, 32)
+        (assigned, num_matches); assigned[i] is the current keypoint that receives the keyframe's landmark i, or -1.
+        curr_keypts may be a frame_dev (the current frame resident; curr_desc and gp are then ignored)."""
+        resident = isinstance(curr_keypts, frame_dev)
+        if not resident:
+            ck = np.ascontiguousarray(curr_keypts, KP_DTYPE)
+            cd = np.ascontiguousarray(curr_desc, np.uint8).reshape(-1, 32)
         kk = np.ascontiguousarray(kf_keypts, KP_DTYPE)
         pw = np.ascontiguousarray(kf_pos_w, np.float64).reshape(-1, 3)
         dm = np.ascontiguousarray(kf_dist_min_max, np.float32).reshape(-1, 2)
@@ -248,6 +262,12 @@ class projection(_window_ctx):
         val = None if kf_valid is None else np.ascontiguousarray(kf_valid, np.uint8)
         assigned = np.full(max(len(kk), 1), -1, np.int32)
         n = C.c_int32()
+        if resident:
+            _lib.check(self._L.ovs_projection_match_frame_and_keyframe_f(
+                self._h, C.byref(cam), curr_keypts._h, _p(occ), _p(_pose12(pose_cw_curr)), _p(kk), _p(pw), _p(dm), _p(ld), _p(val), len(kk), _p(sf),
+                len(sf), float(log_scale_factor), float(margin), int(hamm_dist_thr), int(self.check_orientation_), _p(assigned), C.byref(n)),
+                "ovs_projection_match_frame_and_keyframe_f")
+            return assigned[:len(kk)].copy(), n.value
         _lib.check(self._L.ovs_projection_match_frame_and_keyframe(
             self._h, C.byref(cam), C.byref(gp), _p(ck), _p(cd), _p(occ), len(ck), _p(_pose12(pose_cw_curr)), _p(kk), _p(pw), _p(dm), _p(ld),
             _p(val), len(kk), _p(sf), len(sf), float(log_scale_factor), float(margin), int(hamm_dist_thr), int(self.check_orientation_),
@@ -258,9 +278,11 @@ class projection(_window_ctx):
     def match_by_Sim3_transform(self, cam, gp, keyfrm_keypts, keyfrm_desc, Sim3_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc,
                                 scale_factors, log_scale_factor, margin, keyfrm_occupied=None, lm_valid=None):
         """projection::match_by_Sim3_transform(keyfrm, Sim3_cw, landmarks, matched_lms_in_keyfrm, margin): returns (assigned,
-        num_matches); assigned[l] is the keyframe keypoint that receives landmark l, or -1."""
-        k = np.ascontiguousarray(keyfrm_keypts, KP_DTYPE)
-        d = np.ascontiguousarray(keyfrm_desc, np.uint8).reshape(-1, 32)
+        num_matches); assigned[l] is the keyframe keypoint that receives landmark l, or -1. keyfrm_keypts may be a frame_dev."""
+        resident = isinstance(keyfrm_keypts, frame_dev)
+        if not resident:
+            k = np.ascontiguousarray(keyfrm_keypts, KP_DTYPE)
+            d = np.ascontiguousarray(keyfrm_desc, np.uint8).reshape(-1, 32)
         pw = np.ascontiguousarray(lm_pos_w, np.float64).reshape(-1, 3)
         dm = np.ascontiguousarray(lm_dist_min_max, np.float32).reshape(-1, 2)
         nr = np.ascontiguousarray(lm_normal, np.float64).reshape(-1, 3)
@@ -270,6 +292,11 @@ class projection(_window_ctx):
         val = None if lm_valid is None else np.ascontiguousarray(lm_valid, np.uint8)
         assigned = np.full(max(len(pw), 1), -1, np.int32)
         n = C.c_int32()
+        if resident:
+            _lib.check(self._L.ovs_projection_match_by_sim3_transform_f(
+                self._h, C.byref(cam), keyfrm_keypts._h, _p(occ), _p(_pose12(Sim3_cw)), _p(pw), _p(dm), _p(nr), _p(ld), _p(val), len(pw), _p(sf),
+                len(sf), float(log_scale_factor), float(margin), _p(assigned), C.byref(n)), "ovs_projection_match_by_sim3_transform_f")
+            return assigned[:len(pw)].copy(), n.value
         _lib.check(self._L.ovs_projection_match_by_sim3_transform(
             self._h, C.byref(cam), C.byref(gp), _p(k), _p(d), _p(occ), len(k), _p(_pose12(Sim3_cw)), _p(pw), _p(dm), _p(nr), _p(ld), _p(val),
             len(pw), _p(sf), len(sf), float(log_scale_factor), float(margin), _p(assigned), C.byref(n)),
@@ -280,11 +307,15 @@ class projection(_window_ctx):
                                  pose_cw_2, lm_pos_w_2, lm_dist_2, lm_desc_2, lm_valid_2, s_12, rot_12, trans_12, scale_factors,
                                  log_scale_factor, margin, cam_2=None, gp_2=None):
         """projection::match_keyframes_mutually(keyfrm_1, keyfrm_2, matched_lms_in_keyfrm_1, s_12, rot_12, trans_12, margin): returns
-        (num_matches, matched_2_in_1); per-keypoint landmark arrays, lm_valid_k marks the keypoints whose landmark takes part."""
-        k1 = np.ascontiguousarray(keypts_1, KP_DTYPE)
-        k2 = np.ascontiguousarray(keypts_2, KP_DTYPE)
-        d1 = np.ascontiguousarray(desc_1, np.uint8).reshape(-1, 32)
-        d2 = np.ascontiguousarray(desc_2, np.uint8).reshape(-1, 32)
+        (num_matches, matched_2_in_1); per-keypoint landmark arrays, lm_valid_k marks the keypoints whose landmark takes part.
+        keypts_1 and keypts_2 may both be frame_dev handles (both keyframes resident)."""
+        resident = isinstance(keypts_1, frame_dev) and isinstance(keypts_2, frame_dev)
+        if not resident:
+            k1 = np.ascontiguousarray(keypts_1, KP_DTYPE)
+            k2 = np.ascontiguousarray(keypts_2, KP_DTYPE)
+            d1 = np.ascontiguousarray(desc_1, np.uint8).reshape(-1, 32)
+            d2 = np.ascontiguousarray(desc_2, np.uint8).reshape(-1, 32)
+        n1 = keypts_1.num_keypts if resident else len(k1)
         p1 = np.ascontiguousarray(lm_pos_w_1, np.float64).reshape(-1, 3)
         p2 = np.ascontiguousarray(lm_pos_w_2, np.float64).reshape(-1, 3)
         m1 = np.ascontiguousarray(lm_dist_1, np.float32).reshape(-1, 2)
@@ -298,8 +329,14 @@ class projection(_window_ctx):
         sf = np.ascontiguousarray(scale_factors, np.float32)
         cam_2 = cam if cam_2 is None else cam_2
         gp_2 = gp if gp_2 is None else gp_2
-        out = np.full(max(len(k1), 1), -1, np.int32)
+        out = np.full(max(n1, 1), -1, np.int32)
         n = C.c_int32()
+        if resident:
+            _lib.check(self._L.ovs_projection_match_keyframes_mutually_f(
+                self._h, C.byref(cam), keypts_1._h, _p(_pose12(pose_cw_1)), _p(p1), _p(m1), _p(l1), _p(v1), C.byref(cam_2), keypts_2._h,
+                _p(_pose12(pose_cw_2)), _p(p2), _p(m2), _p(l2), _p(v2), float(s_12), _p(R), _p(t), _p(sf), len(sf), float(log_scale_factor),
+                float(margin), _p(out), C.byref(n)), "ovs_projection_match_keyframes_mutually_f")
+            return n.value, out[:n1].copy()
         _lib.check(self._L.ovs_projection_match_keyframes_mutually(
             self._h, C.byref(cam), C.byref(gp), _p(k1), _p(d1), len(k1), _p(_pose12(pose_cw_1)), _p(p1), _p(m1), _p(l1), _p(v1), C.byref(cam_2),
             C.byref(gp_2), _p(k2), _p(d2), len(k2), _p(_pose12(pose_cw_2)), _p(p2), _p(m2), _p(l2), _p(v2), float(s_12), _p(R), _p(t), _p(sf),
@@ -358,16 +395,23 @@ class bow_tree(_window_ctx):
 
     def match_frame_and_keyframe(self, kf_keypts, kf_desc, kf_bow_feat_vec, frm_keypts, frm_desc, frm_bow_feat_vec, kf_has_landmark=None):
         """bow_tree::match_frame_and_keyframe(keyfrm, frm, matched_lms_in_frm): returns (num_matches, matched_kf_in_frm) where
-        matched_kf_in_frm[j] is the keyframe keypoint whose landmark frame keypoint j receives, or -1."""
+        matched_kf_in_frm[j] is the keyframe keypoint whose landmark frame keypoint j receives, or -1. kf_keypts and frm_keypts may
+        both be frame_dev handles (keyframe and frame resident)."""
+        v = None if kf_has_landmark is None else np.ascontiguousarray(kf_has_landmark, np.uint8)
+        ki, ks, kit = flatten_bow(kf_bow_feat_vec)
+        fi, fs, fit = flatten_bow(frm_bow_feat_vec)
+        n = C.c_int32()
+        if isinstance(kf_keypts, frame_dev) and isinstance(frm_keypts, frame_dev):
+            out = np.full(max(frm_keypts.num_keypts, 1), -1, np.int32)
+            _lib.check(self._L.ovs_bow_match_frame_and_keyframe_f(self._h, kf_keypts._h, _p(v), _p(ki), _p(ks), _p(kit), len(ki), frm_keypts._h, _p(fi),
+                                                                  _p(fs), _p(fit), len(fi), self.lowe_ratio_, int(self.check_orientation_), _p(out),
+                                                                  C.byref(n)), "ovs_bow_match_frame_and_keyframe_f")
+            return n.value, out[:frm_keypts.num_keypts].copy()
         kk = np.ascontiguousarray(kf_keypts, KP_DTYPE)
         fk = np.ascontiguousarray(frm_keypts, KP_DTYPE)
         kd = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32)
         fd = np.ascontiguousarray(frm_desc, np.uint8).reshape(-1, 32)
-        v = None if kf_has_landmark is None else np.ascontiguousarray(kf_has_landmark, np.uint8)
-        ki, ks, kit = flatten_bow(kf_bow_feat_vec)
-        fi, fs, fit = flatten_bow(frm_bow_feat_vec)
         out = np.full(max(len(fk), 1), -1, np.int32)
-        n = C.c_int32()
         _lib.check(self._L.ovs_bow_match_frame_and_keyframe(self._h, _p(kk), _p(kd), _p(v), len(kk), _p(ki), _p(ks), _p(kit), len(ki), _p(fk),
                                                             _p(fd), len(fk), _p(fi), _p(fs), _p(fit), len(fi), self.lowe_ratio_,
                                                             int(self.check_orientation_), _p(out), C.byref(n)),
@@ -377,17 +421,24 @@ class bow_tree(_window_ctx):
 
     def match_keyframes(self, kps_1, desc_1, bow_feat_vec_1, kps_2, desc_2, bow_feat_vec_2, has_landmark_1=None, has_landmark_2=None):
         """bow_tree::match_keyframes(keyfrm_1, keyfrm_2, matched_lms_in_keyfrm_1): returns (num_matches, matched_2_in_1) where
-        matched_2_in_1[idx_1] is the keyframe-2 keypoint whose landmark keyframe-1 keypoint idx_1 receives, or -1."""
-        k1 = np.ascontiguousarray(kps_1, KP_DTYPE)
-        k2 = np.ascontiguousarray(kps_2, KP_DTYPE)
-        d1 = np.ascontiguousarray(desc_1, np.uint8).reshape(-1, 32)
-        d2 = np.ascontiguousarray(desc_2, np.uint8).reshape(-1, 32)
+        matched_2_in_1[idx_1] is the keyframe-2 keypoint whose landmark keyframe-1 keypoint idx_1 receives, or -1. kps_1 and kps_2 may
+        both be frame_dev handles."""
         v1 = None if has_landmark_1 is None else np.ascontiguousarray(has_landmark_1, np.uint8)
         v2 = None if has_landmark_2 is None else np.ascontiguousarray(has_landmark_2, np.uint8)
         i1, s1, t1 = flatten_bow(bow_feat_vec_1)
         i2, s2, t2 = flatten_bow(bow_feat_vec_2)
-        out = np.full(max(len(k1), 1), -1, np.int32)
         n = C.c_int32()
+        if isinstance(kps_1, frame_dev) and isinstance(kps_2, frame_dev):
+            out = np.full(max(kps_1.num_keypts, 1), -1, np.int32)
+            _lib.check(self._L.ovs_bow_match_keyframes_f(self._h, kps_1._h, _p(v1), _p(i1), _p(s1), _p(t1), len(i1), kps_2._h, _p(v2), _p(i2), _p(s2),
+                                                         _p(t2), len(i2), self.lowe_ratio_, int(self.check_orientation_), _p(out), C.byref(n)),
+                       "ovs_bow_match_keyframes_f")
+            return n.value, out[:kps_1.num_keypts].copy()
+        k1 = np.ascontiguousarray(kps_1, KP_DTYPE)
+        k2 = np.ascontiguousarray(kps_2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc_1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(desc_2, np.uint8).reshape(-1, 32)
+        out = np.full(max(len(k1), 1), -1, np.int32)
         _lib.check(self._L.ovs_bow_match_keyframes(self._h, _p(k1), _p(d1), _p(v1), len(k1), _p(i1), _p(s1), _p(t1), len(i1), _p(k2), _p(d2),
                                                    _p(v2), len(k2), _p(i2), _p(s2), _p(t2), len(i2), self.lowe_ratio_,
                                                    int(self.check_orientation_), _p(out), C.byref(n)), "ovs_bow_match_keyframes")
@@ -403,9 +454,12 @@ class fuse(_window_ctx):
 
     def replace_duplication(self, cam, gp, keyfrm_keypts, keyfrm_desc, pose_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc,
                             scale_factors, inv_level_sigma_sq, log_scale_factor, margin=3.0, keyfrm_stereo_x_right=None, lm_valid=None):
-        """returns (best_idx, num_fused): best_idx[l] = keyframe keypoint landmark l fuses with, or -1."""
-        k = np.ascontiguousarray(keyfrm_keypts, KP_DTYPE)
-        d = np.ascontiguousarray(keyfrm_desc, np.uint8).reshape(-1, 32)
+        """returns (best_idx, num_fused): best_idx[l] = keyframe keypoint landmark l fuses with, or -1. keyfrm_keypts may be a frame_dev
+        (the keyframe resident, stereo_x_right included; keyfrm_desc, gp and keyfrm_stereo_x_right are then ignored)."""
+        resident = isinstance(keyfrm_keypts, frame_dev)
+        if not resident:
+            k = np.ascontiguousarray(keyfrm_keypts, KP_DTYPE)
+            d = np.ascontiguousarray(keyfrm_desc, np.uint8).reshape(-1, 32)
         pw = np.ascontiguousarray(lm_pos_w, np.float64).reshape(-1, 3)
         dm = np.ascontiguousarray(lm_dist_min_max, np.float32).reshape(-1, 2)
         nr = np.ascontiguousarray(lm_normal, np.float64).reshape(-1, 3)
@@ -416,6 +470,11 @@ class fuse(_window_ctx):
         val = None if lm_valid is None else np.ascontiguousarray(lm_valid, np.uint8)
         best = np.full(max(len(pw), 1), -1, np.int32)
         n = C.c_int32()
+        if resident:
+            _lib.check(self._L.ovs_fuse_replace_duplication_f(self._h, C.byref(cam), keyfrm_keypts._h, _p(_pose12(pose_cw)), _p(pw), _p(dm), _p(nr), _p(ld),
+                                                              _p(val), len(pw), _p(sf), _p(ils), len(sf), float(log_scale_factor), float(margin),
+                                                              _p(best), C.byref(n)), "ovs_fuse_replace_duplication_f")
+            return best[:len(pw)].copy(), n.value
         _lib.check(self._L.ovs_fuse_replace_duplication(self._h, C.byref(cam), C.byref(gp), _p(k), _p(d), _p(xr), len(k), _p(_pose12(pose_cw)),
                                                         _p(pw), _p(dm), _p(nr), _p(ld), _p(val), len(pw), _p(sf), _p(ils), len(sf),
                                                         float(log_scale_factor), float(margin), _p(best), C.byref(n)),
@@ -426,9 +485,11 @@ class fuse(_window_ctx):
     def detect_duplication(self, cam, gp, keyfrm_keypts, keyfrm_desc, Sim3_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc, scale_factors,
                            log_scale_factor, margin, lm_valid=None):
         """fuse::detect_duplication(keyfrm, Sim3_cw, landmarks_to_check, margin, duplicated_lms_in_keyfrm), candidate search: returns
-        (best_idx, num_found)."""
-        k = np.ascontiguousarray(keyfrm_keypts, KP_DTYPE)
-        d = np.ascontiguousarray(keyfrm_desc, np.uint8).reshape(-1, 32)
+        (best_idx, num_found). keyfrm_keypts may be a frame_dev."""
+        resident = isinstance(keyfrm_keypts, frame_dev)
+        if not resident:
+            k = np.ascontiguousarray(keyfrm_keypts, KP_DTYPE)
+            d = np.ascontiguousarray(keyfrm_desc, np.uint8).reshape(-1, 32)
         pw = np.ascontiguousarray(lm_pos_w, np.float64).reshape(-1, 3)
         dm = np.ascontiguousarray(lm_dist_min_max, np.float32).reshape(-1, 2)
         nr = np.ascontiguousarray(lm_normal, np.float64).reshape(-1, 3)
@@ -437,6 +498,11 @@ class fuse(_window_ctx):
         val = None if lm_valid is None else np.ascontiguousarray(lm_valid, np.uint8)
         best = np.full(max(len(pw), 1), -1, np.int32)
         n = C.c_int32()
+        if resident:
+            _lib.check(self._L.ovs_fuse_detect_duplication_f(self._h, C.byref(cam), keyfrm_keypts._h, _p(_pose12(Sim3_cw)), _p(pw), _p(dm), _p(nr), _p(ld),
+                                                             _p(val), len(pw), _p(sf), len(sf), float(log_scale_factor), float(margin), _p(best),
+                                                             C.byref(n)), "ovs_fuse_detect_duplication_f")
+            return best[:len(pw)].copy(), n.value
         _lib.check(self._L.ovs_fuse_detect_duplication(self._h, C.byref(cam), C.byref(gp), _p(k), _p(d), len(k), _p(_pose12(Sim3_cw)), _p(pw),
                                                        _p(dm), _p(nr), _p(ld), _p(val), len(pw), _p(sf), len(sf), float(log_scale_factor),
                                                        float(margin), _p(best), C.byref(n)), "ovs_fuse_detect_duplication")
@@ -491,7 +557,25 @@ class robust_triangulation(_window_ctx):
 
     def match_for_triangulation(self, kps_1, desc_1, bow_feat_vec_1, bearings_1, kps_2, desc_2, bow_feat_vec_2, bearings_2, E_12, epipole_in_2,
                                 scale_factors, has_lm_1=None, has_lm_2=None, x_right_1=None, x_right_2=None):
-        """returns (num_matches, matched_idx_pairs) with matched_idx_pairs an (n, 2) array of (idx_1, idx_2), ascending idx_1."""
+        """returns (num_matches, matched_idx_pairs) with matched_idx_pairs an (n, 2) array of (idx_1, idx_2), ascending idx_1.
+        kps_1 and kps_2 may both be frame_dev handles with bearings attached (descriptors, stereo_x_right and bearings then come from them)."""
+        if isinstance(kps_1, frame_dev) and isinstance(kps_2, frame_dev):
+            h1 = None if has_lm_1 is None else np.ascontiguousarray(has_lm_1, np.uint8)
+            h2 = None if has_lm_2 is None else np.ascontiguousarray(has_lm_2, np.uint8)
+            E = np.ascontiguousarray(E_12, np.float64).reshape(9)
+            ep = np.ascontiguousarray(epipole_in_2, np.float64).reshape(3)
+            sf = np.ascontiguousarray(scale_factors, np.float32)
+            i1, s1, t1 = flatten_bow(bow_feat_vec_1)
+            i2, s2, t2 = flatten_bow(bow_feat_vec_2)
+            out = np.full(max(kps_1.num_keypts, 1), -1, np.int32)
+            n = C.c_int32()
+            _lib.check(self._L.ovs_robust_match_for_triangulation_f(self._h, kps_1._h, _p(h1), _p(i1), _p(s1), _p(t1), len(i1), kps_2._h, _p(h2), _p(i2),
+                                                                    _p(s2), _p(t2), len(i2), _p(E), _p(ep), _p(sf), len(sf),
+                                                                    int(self.check_orientation_), _p(out), C.byref(n)),
+                       "ovs_robust_match_for_triangulation_f")
+            m = out[:kps_1.num_keypts]
+            idx = np.nonzero(m >= 0)[0]
+            return n.value, np.stack([idx, m[idx]], 1).astype(np.int32)
         k1 = np.ascontiguousarray(kps_1, KP_DTYPE)
         k2 = np.ascontiguousarray(kps_2, KP_DTYPE)
         d1 = np.ascontiguousarray(desc_1, np.uint8).reshape(-1, 32)

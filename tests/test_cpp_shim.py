@@ -538,3 +538,29 @@ def test_shims_never_throw_on_device_failures(tmp_path):
     last = r.stdout.strip().splitlines()[-1].split()
     failed, retried, recovered, degraded = (int(last[i]) for i in (1, 3, 5, 7))
     assert recovered >= 6 and degraded >= 5 and failed == recovered + degraded and retried == failed
+
+
+@pytest.mark.gpu
+def test_keyframe_residency_shared_cache_and_two_threads(tmp_path):
+    """Round 4: a keyframe shares its frame's device cache; tracking-style and mapping-style calls racing on the first use of the same
+    (empty) caches give the single-threaded results every iteration; device 1 when there is one. The program prints one line per check
+    (openvslam_amd/cpp/test_threads_shim.cc). The ThreadSanitizer build of the same program (host side instrumented) runs too: a data
+    race reported in the shim layer fails the test; if the sanitizer cannot run beside the HIP runtime on this box the fact is reported,
+    not hidden."""
+    cpp = os.path.join(ROOT, "openvslam_amd", "cpp")
+    subprocess.check_call(["make", "-s", "-C", cpp])
+    rows, cols, nfeat = 480, 752, 1000
+    synth_frame(rows, cols, seed=21).tofile(tmp_path / "a.raw")
+    synth_frame(rows, cols, seed=21, shift=(4, 3), noise_seed=5).tofile(tmp_path / "b.raw")
+    args = [str(rows), str(cols), str(nfeat), str(tmp_path / "a.raw"), str(tmp_path / "b.raw")]
+    r = subprocess.run([os.path.join(cpp, "test_threads_shim")] + args + ["40"], capture_output=True, text=True)
+    print(r.stdout)
+    assert r.returncode == 0 and "ALL OK" in r.stdout and "FAIL" not in r.stdout, r.stdout + r.stderr
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=0")
+    t = subprocess.run([os.path.join(cpp, "test_threads_shim_tsan")] + args + ["6"], capture_output=True, text=True, env=env)
+    races = [ln for ln in t.stderr.splitlines() if "WARNING: ThreadSanitizer: data race" in ln]
+    in_shim = "openvslam/" in t.stderr and races   # a report whose stack passes through the shim sources
+    if "ALL OK" in t.stdout:
+        assert not in_shim, t.stderr[-4000:]
+    else:
+        print("ThreadSanitizer build did not complete beside the HIP runtime here (rc %d): %s" % (t.returncode, (t.stderr or t.stdout)[-600:]))

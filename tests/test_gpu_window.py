@@ -140,6 +140,12 @@ def test_bow_match_frame_and_keyframe(match, synth, oracle, check_orientation, r
     wn, want = oracle.bow_match_frame_and_keyframe(ka, da, fa, kb, db, fb, ratio, check_orientation, has_lm)
     assert gn == wn and np.array_equal(got, want)
     assert wn > 30
+    # keyframe and frame resident (round 4): same result, nothing but the landmark flags and the BoW vectors travels
+    gp = match.grid_params(752, 480)
+    fka, fkb = match.frame_dev(gp, ka, da), match.frame_dev(gp, kb, db)
+    for _ in range(2):   # the handles are reusable
+        gn_f, got_f = w.match_frame_and_keyframe(fka, None, fa, fkb, None, fb, has_lm)
+        assert gn_f == wn and np.array_equal(got_f, want)
 
 
 def _rot(axis, deg):
@@ -248,6 +254,9 @@ def test_fuse_replace_duplication(match, synth, oracle, model, setup):
         want, wn = oracle.fuse_replace_duplication(ocam, ogp, ck, cd, Tc, lpw, dmm, nrm, ld, sf, ils, float(np.log(np.float32(1.2))), margin,
                                                    kf_stereo_x_right=xr, lm_valid=valid)
         assert gn == wn and np.array_equal(got, want)
+        kf = match.frame_dev(gp, ck, cd, xr)   # the keyframe resident
+        got_f, gn_f = w.replace_duplication(cam, None, kf, None, Tc, lpw, dmm, nrm, ld, sf, ils, float(np.log(np.float32(1.2))), margin, lm_valid=valid)
+        assert gn_f == wn and np.array_equal(got_f, want)
     assert wn > n // 20
 
 
@@ -263,6 +272,9 @@ def test_bow_match_keyframes(match, synth, oracle, check_orientation):
     gn, got = w.match_keyframes(ka, da, fa, kb, db, fb, v1, v2)
     wn, want = oracle.bow_match_keyframes(ka, da, fa, kb, db, fb, 0.75, check_orientation, v1, v2)
     assert gn == wn and np.array_equal(got, want)
+    gp = match.grid_params(752, 480)
+    gn_f, got_f = w.match_keyframes(match.frame_dev(gp, ka, da), None, fa, match.frame_dev(gp, kb, db), None, fb, v1, v2)   # both keyframes resident
+    assert gn_f == wn and np.array_equal(got_f, want)
     assert wn > 20 and (v1[want >= 0] == 1).all() and (v2[want[want >= 0]] == 1).all()
 
 
@@ -292,6 +304,9 @@ def test_projection_match_frame_and_keyframe(match, synth, oracle, model, check_
         want, wn = oracle.projection_match_frame_and_keyframe(ocam, ogp, ck, cd, Tc, lk, lpw, dmm, ld, sf, lsf, margin, thr, check_orientation,
                                                               curr_occupied=occ, kf_valid=valid)
         assert gn == wn and np.array_equal(got, want)
+        got_f, gn_f = w.match_frame_and_keyframe(cam, None, match.frame_dev(gp, ck, cd), None, Tc, lk, lpw, dmm, ld, sf, lsf, margin, thr,
+                                                 curr_occupied=occ, kf_valid=valid)   # the current frame resident
+        assert gn_f == wn and np.array_equal(got_f, want)
     assert wn > n // 20
 
 
@@ -357,6 +372,12 @@ def test_robust_match_for_triangulation(match, synth, oracle, check_orientation,
     wn, want = oracle.robust_match_for_triangulation(k1, d1, fv1, b1, k2, d2, fv2, b2, E12, epipole, sf, check_orientation, h1, h2, x1, x2)
     idx = np.nonzero(want >= 0)[0]
     assert gn == wn and np.array_equal(pairs, np.stack([idx, want[idx]], 1))
+    # both keyframes resident, stereo_x_right and bearings included
+    gp = match.grid_params(cols, rows, min_x=-200.0, min_y=-200.0)
+    f1 = match.frame_dev(gp, k1, d1, x1).attach_bearings(b1)
+    f2 = match.frame_dev(gp, k2, d2, x2).attach_bearings(b2)
+    gn_f, pairs_f = w.match_for_triangulation(f1, None, fv1, None, f2, None, fv2, None, E12, epipole, sf, h1, h2)
+    assert gn_f == wn and np.array_equal(pairs_f, pairs)
     assert wn > 50 and (h1[idx] == 0).all() and (h2[want[idx]] == 0).all()
 
 
@@ -395,6 +416,8 @@ def test_fuse_detect_duplication(match, synth, oracle, model):
         got, gn = w.detect_duplication(cam, gp, ck, cd, S, lpw, dmm, nrm, ld, sf, lsf, margin, lm_valid=valid)
         want, wn = oracle.fuse_detect_duplication(ocam, ogp, ck, cd, S, lpw, dmm, nrm, ld, sf, lsf, margin, lm_valid=valid)
         assert gn == wn and np.array_equal(got, want)
+        got_f, gn_f = w.detect_duplication(cam, None, match.frame_dev(gp, ck, cd), None, S, lpw, dmm, nrm, ld, sf, lsf, margin, lm_valid=valid)
+        assert gn_f == wn and np.array_equal(got_f, want)
     assert wn > n // 20
 
 
@@ -419,6 +442,9 @@ def test_projection_match_by_sim3_transform(match, synth, oracle, model):
         want, wn = oracle.projection_match_by_sim3_transform(ocam, ogp, ck, cd, S, lpw2, dmm2, nrm2, ld2, sf, lsf, margin, kf_occupied=occ,
                                                              lm_valid=valid2)
         assert gn == wn and np.array_equal(got, want)
+        got_f, gn_f = w.match_by_Sim3_transform(cam, None, match.frame_dev(gp, ck, cd), None, S, lpw2, dmm2, nrm2, ld2, sf, lsf, margin,
+                                                keyfrm_occupied=occ, lm_valid=valid2)
+        assert gn_f == wn and np.array_equal(got_f, want)
     assert wn > n // 20
     hit = want[want >= 0]
     assert len(np.unique(hit)) == len(hit) and not occ[hit].any()
@@ -472,6 +498,9 @@ def test_projection_match_keyframes_mutually(match, synth, oracle, s_12):
         wn, want = oracle.projection_match_keyframes_mutually(ocam, ogp, k1, d1, T1, X, dm1, l1, v1, k2, d2, T2, X2, dm2, l2, v2, s_12, R12, t12,
                                                               sf, lsf, margin)
         assert gn == wn and np.array_equal(got, want)
+        gn_f, got_f = w.match_keyframes_mutually(cam, None, match.frame_dev(gp, k1, d1), None, T1, X, dm1, l1, v1, match.frame_dev(gp, k2, d2), None, T2,
+                                                 X2, dm2, l2, v2, s_12, R12, t12, sf, lsf, margin)
+        assert gn_f == wn and np.array_equal(got_f, want)
     assert wn > n // 5
     ok = want >= 0
     assert (want[ok] == inv[ok]).mean() > 0.9 and v1[ok].all() and v2[want[ok]].all()
