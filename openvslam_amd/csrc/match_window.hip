@@ -1057,6 +1057,62 @@ ovs_status build_lists(ovs_wmatcher* w, const ARGS& args, int n_q, KCOUNT kcount
     return OVS_OK;
 }
 
+
+size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// per-call staging of host arrays: memcpy into the context's pinned buffer, ONE hipMemcpyAsync for all of them
+struct Stager {
+    ovs_wmatcher* w;
+    size_t used = 0;
+    bool overflow = false;
+    explicit Stager(ovs_wmatcher* w_) : w(w_) {}
+    template <typename T>
+    const T* put(const T* src, size_t count) {   // nullptr in -> nullptr out
+        if (!src) return nullptr;
+        const size_t bytes = sizeof(T) * count, off = al256(used);
+        if (off + bytes > w->stage_cap) {
+            overflow = true;
+            return nullptr;
+        }
+        std::memcpy(w->h_stage + off, src, bytes);
+        used = off + bytes;
+        return reinterpret_cast<const T*>(w->d_stage + off);
+    }
+    template <typename T>
+    T* reserve(size_t count) {   // device-only scratch in the same arena (filled by a kernel)
+        const size_t bytes = sizeof(T) * count, off = al256(used);
+        if (off + bytes > w->stage_cap) {
+            overflow = true;
+            return nullptr;
+        }
+        used = off + bytes;
+        return reinterpret_cast<T*>(w->d_stage + off);
+    }
+    hipError_t flush(hipStream_t s) {
+        flushed_on = s;
+        flushed = true;
+        return used ? hipMemcpyAsync(w->d_stage, w->h_stage, used, hipMemcpyHostToDevice, s) : hipSuccess;
+    }
+    // A call returns with its stream idle, on EVERY path: the next call (or the shim's immediate retry) memcpy's into the same pinned buffer, and
+    // a frame arena may go back to the pool -- neither may happen while a copy or a kernel of a failed call is still in flight. After a
+    // successful call the stream is already idle (fetch_results synchronised it) and this costs a microsecond.
+    hipStream_t flushed_on = nullptr;
+    bool flushed = false;
+    ~Stager() {
+        if (flushed) (void)hipStreamSynchronize(flushed_on);
+    }
+};
+
+// results: overflow flag, counts and `n_out` assignments in one copy
+ovs_status fetch_results(ovs_wmatcher* w, int n_out, int32_t* assigned, int32_t* num_matches, hipStream_t s, bool check_overflow = true) {
+    OVS_HIP_TRY(hipMemcpyAsync(w->h_res, w->d_res_block, sizeof(int32_t) * (8 + (size_t)n_out), hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(assigned, w->h_res + 8, sizeof(int32_t) * (size_t)n_out);
+    *num_matches = w->h_res[1];
+    return (check_overflow && w->h_res[0]) ? OVS_ERR_CAPACITY : OVS_OK;   // (k_fuse_best writes no overflow flag: the word may be stale)
+}
+
+
 }   // namespace
 
 extern "C" {
@@ -1672,14 +1728,15 @@ static ovs_status fuse_replace_duplication_impl(ovs_wmatcher* w, const ovs_frame
     a.log_scale_factor = log_scale_factor;
     a.margin = margin;
     a.m = m;
-    // staging: landmark positions ride in d_q_pos, normals behind the key buffer (3 doubles per landmark <= max_entries * 4 bytes?)
-    if ((size_t)m * 3 * sizeof(double) > (size_t)w->max_entries * sizeof(uint32_t)) return OVS_ERR_CAPACITY;
-    double* d_normal = reinterpret_cast<double*>(w->d_keys);
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_pos, lm_pos_w, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipMemcpyAsync(d_normal, lm_normal, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_xy, lm_dist_min_max, sizeof(float) * 2 * m, hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, lm_desc, (size_t)32 * m, hipMemcpyHostToDevice, s));
-    if (lm_valid) OVS_HIP_TRY(hipMemcpyAsync(w->d_q_flag, lm_valid, (size_t)m, hipMemcpyHostToDevice, s));
+    // the landmark side: five host arrays through the context's pinned buffer, ONE copy up (five pageable hipMemcpyAsync cost more than the kernel)
+    Stager stg(w);
+    a.lm_pos_w = stg.put(lm_pos_w, (size_t)3 * m);
+    a.lm_normal = stg.put(lm_normal, (size_t)3 * m);
+    a.lm_dist = stg.put(lm_dist_min_max, (size_t)2 * m);
+    a.lm_desc = stg.put(lm_desc, (size_t)32 * m);
+    a.lm_valid = stg.put(lm_valid, (size_t)m);
+    if (stg.overflow) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(stg.flush(s));
     TargetRef tg;
     ovs_status st = stage_target(w, res, gp, kps, desc, stereo_x_right, n, s, &tg);
     if (st != OVS_OK) return st;
@@ -1689,20 +1746,12 @@ static ovs_status fuse_replace_duplication_impl(ovs_wmatcher* w, const ovs_frame
     a.cell_start = tg.cell_start;
     a.items = tg.items;
     a.gp = tg.gp;
-    a.lm_pos_w = w->d_q_pos;
-    a.lm_dist = w->d_q_xy;
-    a.lm_normal = d_normal;
-    a.lm_desc = w->d_q_desc;
-    a.lm_valid = lm_valid ? w->d_q_flag : nullptr;
     a.variant = kFuseReplace;
     a.max_dist = OVS_HAMMING_DIST_THR_LOW;
     OVS_HIP_TRY(hipMemsetAsync(w->d_num, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k_fuse_best, dim3((m + 255) / 256), dim3(256), 0, s, a, w->d_assigned, w->d_num);
     OVS_HIP_TRY(hipGetLastError());
-    OVS_HIP_TRY(hipMemcpyAsync(best_idx, w->d_assigned, sizeof(int32_t) * m, hipMemcpyDeviceToHost, s));
-    OVS_HIP_TRY(hipMemcpyAsync(num_fused, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    OVS_HIP_TRY(hipStreamSynchronize(s));
-    return OVS_OK;
+    return fetch_results(w, m, best_idx, num_fused, s, false);   // one copy down through the pinned mirror
 }
 
 static ovs_status projection_match_frame_and_keyframe_impl(ovs_wmatcher* w, const ovs_frame_dev* res, const ovs_camera* cam, const ovs_grid_params* gp,
@@ -1850,7 +1899,6 @@ static ovs_status fuse_detect_duplication_impl(ovs_wmatcher* w, const ovs_frame_
     if (n == 0) return OVS_OK;
     if ((!res && (!kps || !desc)) || !lm_pos_w || !lm_dist_min_max || !lm_normal || !lm_desc) return OVS_ERR_INVALID;
     if (n > w->max_t || m > w->max_q) return OVS_ERR_CAPACITY;
-    if ((size_t)m * 3 * sizeof(double) > (size_t)w->max_entries * sizeof(uint32_t)) return OVS_ERR_CAPACITY;
     OVS_HIP_TRY(hipSetDevice(w->device));
     hipStream_t s = w->stream;
     FuseArgs a{};
@@ -1867,12 +1915,14 @@ static ovs_status fuse_detect_duplication_impl(ovs_wmatcher* w, const ovs_frame_
     a.m = m;
     a.variant = kFuseDetect;
     a.max_dist = OVS_HAMMING_DIST_THR_LOW;
-    double* d_normal = reinterpret_cast<double*>(w->d_keys);
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_pos, lm_pos_w, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipMemcpyAsync(d_normal, lm_normal, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_xy, lm_dist_min_max, sizeof(float) * 2 * m, hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipMemcpyAsync(w->d_q_desc, lm_desc, (size_t)32 * m, hipMemcpyHostToDevice, s));
-    if (lm_valid) OVS_HIP_TRY(hipMemcpyAsync(w->d_q_flag, lm_valid, (size_t)m, hipMemcpyHostToDevice, s));
+    Stager stg(w);   // the landmark side through the pinned buffer: one copy up
+    a.lm_pos_w = stg.put(lm_pos_w, (size_t)3 * m);
+    a.lm_normal = stg.put(lm_normal, (size_t)3 * m);
+    a.lm_dist = stg.put(lm_dist_min_max, (size_t)2 * m);
+    a.lm_desc = stg.put(lm_desc, (size_t)32 * m);
+    a.lm_valid = stg.put(lm_valid, (size_t)m);
+    if (stg.overflow) return OVS_ERR_CAPACITY;
+    OVS_HIP_TRY(stg.flush(s));
     TargetRef tg;
     ovs_status st = stage_target(w, res, gp, kps, desc, nullptr, n, s, &tg);
     if (st != OVS_OK) return st;
@@ -1881,18 +1931,10 @@ static ovs_status fuse_detect_duplication_impl(ovs_wmatcher* w, const ovs_frame_
     a.cell_start = tg.cell_start;
     a.items = tg.items;
     a.gp = tg.gp;
-    a.lm_pos_w = w->d_q_pos;
-    a.lm_dist = w->d_q_xy;
-    a.lm_normal = d_normal;
-    a.lm_desc = w->d_q_desc;
-    a.lm_valid = lm_valid ? w->d_q_flag : nullptr;
     OVS_HIP_TRY(hipMemsetAsync(w->d_num, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k_fuse_best, dim3((m + 255) / 256), dim3(256), 0, s, a, w->d_assigned, w->d_num);
     OVS_HIP_TRY(hipGetLastError());
-    OVS_HIP_TRY(hipMemcpyAsync(best_idx, w->d_assigned, sizeof(int32_t) * m, hipMemcpyDeviceToHost, s));
-    OVS_HIP_TRY(hipMemcpyAsync(num_found, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    OVS_HIP_TRY(hipStreamSynchronize(s));
-    return OVS_OK;
+    return fetch_results(w, m, best_idx, num_found, s, false);
 }
 
 static ovs_status projection_match_by_sim3_transform_impl(ovs_wmatcher* w, const ovs_frame_dev* res, const ovs_camera* cam, const ovs_grid_params* gp, const ovs_keypoint* kps,
@@ -2084,7 +2126,6 @@ static ovs_status projection_match_keyframes_mutually_impl(ovs_wmatcher* w, cons
 
 namespace {
 
-size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // device arenas of destroyed frame handles, kept for the next frame (a tracker creates one handle per frame: a hipMalloc / hipFree pair
 // per frame would cost more than the upload). Bounded; keyed by device and size.
@@ -2131,58 +2172,6 @@ struct FrameStage {
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
-
-// per-call staging of host arrays: memcpy into the context's pinned buffer, ONE hipMemcpyAsync for all of them
-struct Stager {
-    ovs_wmatcher* w;
-    size_t used = 0;
-    bool overflow = false;
-    explicit Stager(ovs_wmatcher* w_) : w(w_) {}
-    template <typename T>
-    const T* put(const T* src, size_t count) {   // nullptr in -> nullptr out
-        if (!src) return nullptr;
-        const size_t bytes = sizeof(T) * count, off = al256(used);
-        if (off + bytes > w->stage_cap) {
-            overflow = true;
-            return nullptr;
-        }
-        std::memcpy(w->h_stage + off, src, bytes);
-        used = off + bytes;
-        return reinterpret_cast<const T*>(w->d_stage + off);
-    }
-    template <typename T>
-    T* reserve(size_t count) {   // device-only scratch in the same arena (filled by a kernel)
-        const size_t bytes = sizeof(T) * count, off = al256(used);
-        if (off + bytes > w->stage_cap) {
-            overflow = true;
-            return nullptr;
-        }
-        used = off + bytes;
-        return reinterpret_cast<T*>(w->d_stage + off);
-    }
-    hipError_t flush(hipStream_t s) {
-        flushed_on = s;
-        flushed = true;
-        return used ? hipMemcpyAsync(w->d_stage, w->h_stage, used, hipMemcpyHostToDevice, s) : hipSuccess;
-    }
-    // A call returns with its stream idle, on EVERY path: the next call (or the shim's immediate retry) memcpy's into the same pinned buffer, and
-    // a frame arena may go back to the pool -- neither may happen while a copy or a kernel of a failed call is still in flight. After a
-    // successful call the stream is already idle (fetch_results synchronised it) and this costs a microsecond.
-    hipStream_t flushed_on = nullptr;
-    bool flushed = false;
-    ~Stager() {
-        if (flushed) (void)hipStreamSynchronize(flushed_on);
-    }
-};
-
-// results: overflow flag, counts and `n_out` assignments in one copy
-ovs_status fetch_results(ovs_wmatcher* w, int n_out, int32_t* assigned, int32_t* num_matches, hipStream_t s) {
-    OVS_HIP_TRY(hipMemcpyAsync(w->h_res, w->d_res_block, sizeof(int32_t) * (8 + (size_t)n_out), hipMemcpyDeviceToHost, s));
-    OVS_HIP_TRY(hipStreamSynchronize(s));
-    std::memcpy(assigned, w->h_res + 8, sizeof(int32_t) * (size_t)n_out);
-    *num_matches = w->h_res[1];
-    return w->h_res[0] ? OVS_ERR_CAPACITY : OVS_OK;
-}
 
 }   // namespace
 

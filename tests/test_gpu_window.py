@@ -504,3 +504,31 @@ def test_projection_match_keyframes_mutually(match, synth, oracle, s_12):
     assert wn > n // 5
     ok = want >= 0
     assert (want[ok] == inv[ok]).mean() > 0.9 and v1[ok].all() and v2[want[ok]].all()
+
+
+@pytest.mark.parametrize("n_nodes,ratio,check_orientation", [(3, 0.9, False), (6, 0.75, True), (12, 0.6, True), (3, 1.0, False)])
+def test_resolver_under_heavy_contention(match, synth, oracle, n_nodes, ratio, check_orientation):
+    """The sequential-claim resolvers where almost every query competes for the same targets: bow_tree::match_frame_and_keyframe over a
+    vocabulary of 3-12 nodes (lists of hundreds of shared candidates per query -- the shape on which an interim commit rule of round 3
+    failed, fuzz seed 901) and area::match_in_consistent_area with a window covering the image. Fixed form of
+    `tools/fuzz_parity.py --contention` (40 random cases of it: profiles/r04a_fuzz.txt)."""
+    rows, cols = 336, 292
+    a = synth.synth_frame(rows, cols, seed=4003)
+    b = synth.synth_frame(rows, cols, seed=4003, shift=(7, 3), noise_seed=11)
+    ox = oracle.OrbExtractor(oracle.make_params(1000))
+    ka, da = ox.extract(a)
+    kb, db = ox.extract(b)
+    fa, fb = synth.synth_bow(da, seed=1, n_nodes=n_nodes), synth.synth_bow(db, seed=1, n_nodes=n_nodes)
+    has_lm = (np.random.default_rng(5).random(len(ka)) < 0.9).astype(np.uint8)
+    w = match.bow_tree(ratio, check_orientation, max_targets=4096, max_queries=4096)
+    gn, got = w.match_frame_and_keyframe(ka, da, fa, kb, db, fb, has_lm)
+    wn, want = oracle.bow_match_frame_and_keyframe(ka, da, fa, kb, db, fb, ratio, check_orientation, has_lm)
+    assert gn == wn and np.array_equal(got, want)
+    assert wn > 50 and max(len(v) for v in fa.values()) > len(ka) // (2 * n_nodes)
+    gp, ogp = match.grid_params(cols, rows), oracle.grid_params(cols, rows)
+    wa = match.area(ratio, check_orientation, max_targets=4096, max_queries=4096)
+    pg = np.ascontiguousarray(np.stack([ka["x"], ka["y"]], 1), np.float32)
+    po = pg.copy()
+    gn, got = wa.match_in_consistent_area(gp, ka, da, kb, db, pg, 400)
+    wn, want = oracle.area_match_in_consistent_area(ogp, ka, da, kb, db, po, 400, ratio, check_orientation)
+    assert gn == wn and np.array_equal(got, want) and np.array_equal(pg.view(np.uint32), po.view(np.uint32))

