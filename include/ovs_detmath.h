@@ -148,6 +148,60 @@ OVS_DM_FN double asin_pq(double t) {
 // std::log(float) as glibc computes it (see logf_glibc above)
 OVS_DM_FN float ovs_det_logf(float x) { return ovs_dm::logf_glibc(x); }
 
+// sinf / cosf as glibc >= 2.28 computes them (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h + sincosf_data.c: the ARM
+// optimized-routines algorithm): |x| < pi/4 -> the polynomial directly; otherwise n = round(x * 2/pi) through a 2^24-scaled multiply,
+// r = x - n * (pi/2) in double, a degree-7 sine or degree-8 cosine polynomial of r by quadrant, everything in double, ONE rounding to float.
+// EXHAUSTIVELY equal to this container's glibc 2.35 sinf and cosf on every float in [0, 6.3] (1 086 953 883 values, the range the
+// descriptor's angles live in; tests/test_detmath.py::test_sinf_cosf_equal_glibc_exhaustively runs the check in C through the oracle
+// library). Used by the `trig` variant of the rBRIEF steering (oracle/ORACLE_SPEC.md rule 11): what upstream computes IF it calls
+// std::cos / std::sin on the float angle instead of util::cos / util::sin. Valid for |x| < 120 (the callers pass [0, 2 pi]).
+namespace ovs_dm {
+struct sincosf_tab {
+    double sign[4];
+    double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3;
+};
+OVS_DM_FN float sincosf_poly(double x, double x2, const sincosf_tab& p, int n) {
+    if ((n & 1) == 0) {
+        const double x3 = x * x2;
+        const double s1 = p.s2 + x2 * p.s3;
+        const double x7 = x3 * x2;
+        const double s = x + x3 * p.s1;
+        return (float)(s + x7 * s1);
+    }
+    const double x4 = x2 * x2;
+    const double c2 = p.c3 + x2 * p.c4;
+    const double c1 = p.c0 + x2 * p.c1;
+    const double x6 = x4 * x2;
+    const double c = c1 + x4 * p.c2;
+    return (float)(c + x6 * c2);
+}
+OVS_DM_FN uint32_t abstop12(float x) {
+    uint32_t u;
+    __builtin_memcpy(&u, &x, 4);
+    return (u >> 20) & 0x7ffu;
+}
+// want_cos = 0: sinf(y), 1: cosf(y)
+OVS_DM_FN float sincosf_glibc(float y, int want_cos) {
+    const sincosf_tab T0 = {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5,
+                            -0x1.6c087e89a359dp-10, 0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13};
+    const sincosf_tab T1 = {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5,
+                            0x1.6c087e89a359dp-10, -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13};
+    double x = (double)y;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {   // |y| < pi/4
+        if (abstop12(y) < abstop12(0x1p-12f)) return want_cos ? 1.0f : y;
+        return sincosf_poly(x, x * x, T0, want_cos);
+    }
+    const double r = x * T0.hpi_inv;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - (double)n * T0.hpi;
+    const double s = T0.sign[n & 3];
+    return sincosf_poly(x * s, x * x, (n & 2) ? T1 : T0, n ^ want_cos);
+}
+}   // namespace ovs_dm
+OVS_DM_FN float ovs_det_sinf(float x) { return ovs_dm::sincosf_glibc(x, 0); }
+OVS_DM_FN float ovs_det_cosf(float x) { return ovs_dm::sincosf_glibc(x, 1); }
+
+
 OVS_DM_FN double ovs_det_atan(double x) { return ovs_dm::atan_d(x); }
 
 OVS_DM_FN double ovs_det_atan2(double y, double x) {

@@ -148,10 +148,13 @@ ovs_status ovs_orb_set_fast_split(ovs_orb* h, int32_t enable);
  *   OVS_VARIANT_TREE_TIE_ORDER      0 (default: equal counts -> later-created node first) | 1 (earlier-created first)
  *   OVS_VARIANT_BLUR_TAPS           0 (default: 18 34 48 56 48 34 18, OpenCV >= 3.4.7 error-diffused fixed point) | 1 (18 34 49 55 49 34 18,
  *                                   every tap rounded on its own: older OpenCV; sum 257, result saturates)
+ *   OVS_VARIANT_TRIG                0 (default: util::cos / util::sin, the polynomial of src/openvslam/util/trigonometric.h) | 1 (std::cos /
+ *                                   std::sin on the float angle as glibc >= 2.28 computes them: ORB-SLAM2's form; rule 11, round 4)
  * Takes effect from the next extract. OVS_ERR_INVALID for an unknown (which, value). */
 #define OVS_VARIANT_TREE_SWITCH_FACTOR 0
 #define OVS_VARIANT_TREE_TIE_ORDER 1
 #define OVS_VARIANT_BLUR_TAPS 2
+#define OVS_VARIANT_TRIG 3
 ovs_status ovs_orb_set_variant(ovs_orb* h, int32_t which, int32_t value);
 ovs_status ovs_orb_profile_read_aux(ovs_orb* h, float* fast_level0_ms, int32_t* ncalls);
 
@@ -242,6 +245,14 @@ typedef struct ovs_wmatcher ovs_wmatcher;
  * (a call that would produce more returns OVS_ERR_CAPACITY; nothing is truncated silently). */
 ovs_status ovs_wmatcher_create(int32_t max_targets, int32_t max_queries, int32_t max_entries, int32_t device, ovs_wmatcher** out);
 ovs_status ovs_wmatcher_destroy(ovs_wmatcher* w);
+/* oracle/ORACLE_SPEC.md rule 17 (match::angle_checker), tagged M / L for the keep rule, as a run-time variant (process-wide; oracle:
+ * ovo_match_set_variant): ANGLE_KEEP_RULE 0 (default: the three fullest of the 30 bins are kept whatever they hold) | 1 (ORB-SLAM2's
+ * ComputeThreeMaxima: a second bin with fewer than 0.1 x the fullest bin's entries is dropped together with the third, a third bin below that
+ * alone). Applies to every matcher with check_orientation (the device resolvers and, through ovs_match_get_variant, the host-side
+ * match::angle_checker of the class shims). */
+#define OVS_MATCH_VARIANT_ANGLE_KEEP_RULE 0
+ovs_status ovs_match_set_variant(int32_t which, int32_t value);
+int32_t ovs_match_get_variant(int32_t which);   /* -1 for an unknown variant */
 
 /* replaces: data::assign_keypoints_to_grid(camera, undist_keypts, keypt_indices_in_cells).
  * CSR result: cell id = cx*rows + cy (upstream keypt_indices_in_cells[cx][cy]), cell_start[cols*rows + 1], items = keypoint
@@ -457,6 +468,12 @@ ovs_status ovs_robust_match_for_triangulation(ovs_wmatcher* w, const ovs_keypoin
 typedef struct ovs_stereo ovs_stereo;
 ovs_status ovs_stereo_create(int32_t max_rows, int32_t max_keypoints, int32_t device, ovs_stereo** out);
 ovs_status ovs_stereo_destroy(ovs_stereo* s);
+/* The two choices of stereo::compute that upstream's (absent) source decides (oracle/ORACLE_SPEC.md rule 20, tagged L), as run-time variants on
+ * both sides (oracle: ovo_stereo_compute_v): OUTLIER_FACTOR 0 (default: matches with L1 distance > 2.0 x median dropped) | 1 (2.1 = ORB-SLAM2's
+ * 1.5f * 1.4f); PARABOLA 0 (default: the sub-pixel parabola in float arithmetic) | 1 (in double, rounded to float once). */
+#define OVS_STEREO_VARIANT_OUTLIER_FACTOR 0
+#define OVS_STEREO_VARIANT_PARABOLA 1
+ovs_status ovs_stereo_set_variant(ovs_stereo* s, int32_t which, int32_t value);
 /* replaces: void stereo::compute(std::vector<float>& stereo_x_right, std::vector<float>& depths) const.
  * kps_* / desc_* = the keypoints and descriptors the two handles extracted (frame 0 of their last extract);
  * focal_x_baseline / true_baseline = camera->focal_x_baseline_ / true_baseline_. stereo_x_right / depths: n_left floats, -1 where
@@ -650,6 +667,11 @@ typedef struct ovs_pose_obs {   /* one observed landmark: pose_opt_edge_wrapper 
 ovs_status ovs_pose_optimize(int32_t device, const double* pose_cw_in, const ovs_pose_obs* obs, int32_t n_obs, const ovs_ba_cam* cam,
                              double focal_x_baseline, int32_t setup_type, double* pose_cw_out, uint8_t* outlier_flags, int32_t* num_valid);
 /* Device-resident batch: frame p owns observations [d_obs_offsets[p], d_obs_offsets[p + 1]); one workgroup per frame. */
+/* oracle/ORACLE_SPEC.md rule 25 (iv), tagged L, as a run-time variant (process-wide; the oracle has ovo_pose_set_variant): RESET_EACH_ROUND
+ * 0 (default: the frame vertex is initialised once, every round continues from the previous round's estimate -- OpenVSLAM as recalled) | 1 (the
+ * estimate is re-set to pose_cw_in at the start of each of the four rounds -- ORB-SLAM2's Optimizer::PoseOptimization). */
+#define OVS_POSE_VARIANT_RESET_EACH_ROUND 0
+ovs_status ovs_pose_set_variant(int32_t which, int32_t value);
 ovs_status ovs_pose_optimize_batch_dev(const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
                                        const ovs_ba_cam* cam, double focal_x_baseline, int32_t setup_type, double* d_poses_out,
                                        uint8_t* d_outlier, int32_t* d_num_valid, void* stream);
@@ -734,6 +756,8 @@ ovs_status ovs_projection_match_keyframes_mutually_f(ovs_wmatcher* w, const ovs_
 #define OVS_DETMATH_ASIN 1
 #define OVS_DETMATH_ACOS 2
 #define OVS_DETMATH_ATAN2 3   /* atan2(a, b) */
+#define OVS_DETMATH_SINF 4    /* float in, float out (widened): the OVS_VARIANT_TRIG = 1 steering */
+#define OVS_DETMATH_COSF 5
 ovs_status ovs_detmath_eval(int32_t device, int32_t fn, const double* a, const double* b, double* out, int32_t n);
 
 #ifdef __cplusplus

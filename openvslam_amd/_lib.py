@@ -111,6 +111,7 @@ SYMBOLS = {
     "ovs_ba_linearize_stereo": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_ba_linearize_stereo_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp,
                                            _vp, _vp]),
+    "ovs_pose_set_variant": (_i32, [_i32, _i32]),
     "ovs_pose_optimize": (_i32, [_i32, _vp, _vp, _i32, _vp, C.c_double, _i32, _vp, _vp, C.POINTER(_i32)]),
     "ovs_pose_optimize_batch_dev": (_i32, [_vp, _vp, _vp, _i32, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp]),
     "ovs_pose_optimize_equirect": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, C.POINTER(_i32)]),
@@ -118,6 +119,8 @@ SYMBOLS = {
     "ovs_hamming_best2": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "ovs_wmatcher_create": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(_vp)]),
     "ovs_wmatcher_destroy": (_i32, [_vp]),
+    "ovs_match_set_variant": (_i32, [_i32, _i32]),
+    "ovs_match_get_variant": (_i32, [_i32]),
     "ovs_assign_keypoints_to_grid": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, C.POINTER(_i32)]),
     "ovs_grid_assign_dev": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "ovs_projection_match_frame_and_landmarks": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _f, _f,
@@ -146,6 +149,7 @@ SYMBOLS = {
                                                        _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _i32, _f, _f, _vp, C.POINTER(_i32)]),
     "ovs_stereo_create": (_i32, [_i32, _i32, _i32, C.POINTER(_vp)]),
     "ovs_stereo_destroy": (_i32, [_vp]),
+    "ovs_stereo_set_variant": (_i32, [_vp, _i32, _i32]),
     "ovs_stereo_compute": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _f, _f, _vp, _vp, C.POINTER(_i32)]),
     "ovs_detmath_eval": (_i32, [_i32, _i32, _vp, _vp, _vp, _i32]),
     "ovs_stereo_compute_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _f, _f, _vp, _vp, _vp, _vp]),

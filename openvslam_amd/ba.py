@@ -88,6 +88,11 @@ POSE_OBS_DTYPE = np.dtype([("pos_w", "<f8", (3,)), ("obs_x", "<f8"), ("obs_y", "
 assert POSE_OBS_DTYPE.itemsize == 64
 
 
+def pose_set_variant(which, value):
+    """ovs_pose_set_variant: "reset_each_round" (0 | 1), process-wide (oracle/ORACLE_SPEC.md rule 25 (iv))."""
+    _lib.check(_lib.lib().ovs_pose_set_variant({"reset_each_round": 0}[which], int(value)), "ovs_pose_set_variant")
+
+
 def pose_optimize(pose_cw, obs, cam, focal_x_baseline=0.0, device=0, setup_type=None):
     """optimize::pose_optimizer::optimize(frm) on the device (ovs_pose_optimize). pose_cw: 3x4 [R|t]; obs: POSE_OBS_DTYPE records.
     setup_type: camera::setup_type_t of the rig (0 Monocular, 1 Stereo, 2 RGBD; default: Stereo iff focal_x_baseline != 0) -- it selects

@@ -4,6 +4,8 @@
 // Rule (oracle/ORACLE_SPEC.md 17): delta wrapped into [0, 360), bin = cvRound(delta * (1 / 30)) (bins are 30 degrees wide: upstream's
 // inherited quirk), bin 30 -> 0; the three fullest bins stay, ties resolved towards the lower bin index.
 #pragma once
+#include <ovslam_hip.h>
+
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -36,10 +38,17 @@ private:
         std::iota(order.begin(), order.end(), 0u);
         std::stable_sort(order.begin(), order.end(),
                          [&](unsigned int a, unsigned int b) { return angle_histogram_[a].size() > angle_histogram_[b].size(); });
+        // rule 17's alternative, the same process-wide switch the device resolvers read (ovs_match_set_variant): ORB-SLAM2's 0.1 x max rule
+        unsigned int n_keep = num_bins_thr_ < histogram_length_ ? num_bins_thr_ : histogram_length_;
+        if (ovs_match_get_variant(OVS_MATCH_VARIANT_ANGLE_KEEP_RULE) == 1 && n_keep == 3) {
+            const float max1 = (float)angle_histogram_[order[0]].size();
+            if ((float)angle_histogram_[order[1]].size() < 0.1f * max1) n_keep = 1;
+            else if ((float)angle_histogram_[order[2]].size() < 0.1f * max1) n_keep = 2;
+        }
         std::vector<T> out;
         for (unsigned int bin = 0; bin < histogram_length_; ++bin) {
             bool is_kept = false;
-            for (unsigned int k = 0; k < num_bins_thr_ && k < histogram_length_; ++k) is_kept |= order[k] == bin;
+            for (unsigned int k = 0; k < n_keep; ++k) is_kept |= order[k] == bin;
             if (is_kept == kept) out.insert(out.end(), angle_histogram_[bin].begin(), angle_histogram_[bin].end());
         }
         return out;

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_stereo_subpixel(const ovs_keypoint* __r
                                                         const ovs_keypoint* __restrict__ kps_right, const int32_t* __restrict__ best_right,
                                                         PyrView pl, PyrView pr, float focal_x_baseline, float max_disp,
                                                         float* __restrict__ stereo_x_right, float* __restrict__ depths,
-                                                        int32_t* __restrict__ sad_out) {
+                                                        int32_t* __restrict__ sad_out, int variant) {
     const int n = n_ptr ? *n_ptr : n_fixed;
     const int il = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int j = threadIdx.x & 15;                // shift index: offset = j - 5 for j < 11
@@ -185,7 +185,10 @@ __global__ __launch_bounds__(256) void k_stereo_subpixel(const ovs_keypoint* __r
     float out_x = -1.0f, out_d = -1.0f;
     int32_t out_sad = -1;
     if (ok && bj != 0 && bj != 2 * kStereoSlide) {
-        const float delta = __fdiv_rn(__fsub_rn(c1, c3), __fmul_rn(2.0f, __fsub_rn(__fadd_rn(c1, c3), __fmul_rn(2.0f, c2))));
+        // rule 20: float arithmetic (default) | double, rounded to float once (variant bit 1)
+        const float delta = (variant & 2) ? (float)__ddiv_rn(__dsub_rn((double)c1, (double)c3),
+                                                             __dmul_rn(2.0, __dsub_rn(__dadd_rn((double)c1, (double)c3), __dmul_rn(2.0, (double)c2))))
+                                          : __fdiv_rn(__fsub_rn(c1, c3), __fmul_rn(2.0f, __fsub_rn(__fadd_rn(c1, c3), __fmul_rn(2.0f, c2))));
         if (!(delta < -1.0f || 1.0f < delta)) {
             float best_x_right = __fmul_rn(pl.scale[level], __fadd_rn(__fadd_rn((float)sxr, (float)(bj - kStereoSlide)), delta));
             float disp = __fsub_rn(kl.x, best_x_right);
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void k_stereo_subpixel(const ovs_keypoint* __r
 // median of the accepted L1 distances (element size/2 of the ascending order), then drop everything above 2 x median
 __global__ __launch_bounds__(1024) void k_stereo_outliers(const int32_t* __restrict__ n_ptr, int n_fixed, const int32_t* __restrict__ sad,
                                                          float* __restrict__ stereo_x_right, float* __restrict__ depths,
-                                                         int32_t* __restrict__ n_valid) {
+                                                         int32_t* __restrict__ n_valid, int variant) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_sel[3];   // chosen high byte, rank inside it, total
     __shared__ uint32_t s_cnt;
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(1024) void k_stereo_outliers(const int32_t* __restr
         s_sel[1] = (hi << 8) | b;   // the median
     }
     __syncthreads();
-    const float thr = __fmul_rn(2.0f, (float)s_sel[1]);
+    const float thr = __fmul_rn((variant & 1) ? 2.1f : 2.0f, (float)s_sel[1]);   // rule 20: 2.0 (default) | ORB-SLAM2's 1.5f * 1.4f
     uint32_t kept = 0;
     for (int i = tid; i < n; i += 1024) {
         const int v = sad[i];
@@ -281,6 +284,7 @@ using namespace ovs;
 struct ovs_stereo {
     int device = 0;
     int max_rows = 0, max_kps = 0;
+    int variant = 0;   // ovs_stereo_set_variant: bit 0 outlier factor 2.1, bit 1 parabola in double
     uint32_t item_cap = 0;
     hipStream_t stream = nullptr;
     uint32_t* d_row_off = nullptr;
@@ -360,6 +364,14 @@ ovs_status ovs_stereo_destroy(ovs_stereo* s) {
     return OVS_OK;
 }
 
+ovs_status ovs_stereo_set_variant(ovs_stereo* s, int32_t which, int32_t value) {
+    if (!s || (value != 0 && value != 1)) return OVS_ERR_INVALID;
+    if (which == OVS_STEREO_VARIANT_OUTLIER_FACTOR) s->variant = (s->variant & ~1) | value;
+    else if (which == OVS_STEREO_VARIANT_PARABOLA) s->variant = (s->variant & ~2) | (value << 1);
+    else return OVS_ERR_INVALID;
+    return OVS_OK;
+}
+
 ovs_status ovs_stereo_compute_dev(ovs_stereo* s, const ovs_orb* left, int32_t frame_left, const ovs_orb* right, int32_t frame_right,
                                   const ovs_keypoint* d_kps_left, const uint8_t* d_desc_left, const int32_t* d_n_left, int32_t cap_left,
                                   const ovs_keypoint* d_kps_right, const uint8_t* d_desc_right, const int32_t* d_n_right, int32_t cap_right,
@@ -390,9 +402,9 @@ ovs_status ovs_stereo_compute_dev(ovs_stereo* s, const ovs_orb* left, int32_t fr
     hipLaunchKernelGGL(k_stereo_match, gl, dim3(256), 0, st, d_kps_left, d_desc_left, d_n_left, cap_left, d_kps_right, d_desc_right, pr,
                        (const uint32_t*)s->d_row_off, (const uint32_t*)s->d_row_items, s->item_cap, max_disp, s->d_best_right);
     hipLaunchKernelGGL(k_stereo_subpixel, dim3((cap_left + 15) / 16), dim3(256), 0, st, d_kps_left, d_n_left, cap_left, d_kps_right,
-                       (const int32_t*)s->d_best_right, pl, pr, focal_x_baseline, max_disp, d_stereo_x_right, d_depths, s->d_sad);
+                       (const int32_t*)s->d_best_right, pl, pr, focal_x_baseline, max_disp, d_stereo_x_right, d_depths, s->d_sad, s->variant);
     hipLaunchKernelGGL(k_stereo_outliers, dim3(1), dim3(1024), 0, st, d_n_left, cap_left, (const int32_t*)s->d_sad, d_stereo_x_right,
-                       d_depths, d_n_valid ? d_n_valid : s->d_n_valid);
+                       d_depths, d_n_valid ? d_n_valid : s->d_n_valid, s->variant);
     OVS_HIP_TRY(hipGetLastError());
     return OVS_OK;
 }

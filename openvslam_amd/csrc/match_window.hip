@@ -603,6 +603,7 @@ struct ResolveArgs {
     int n_q, n_t;
     float lowe_ratio;
     int check_orientation;
+    int angle_keep_rule;   // ovs_match_set_variant(OVS_MATCH_VARIANT_ANGLE_KEEP_RULE): filled in by launch_resolve
     const ovs_keypoint* q_kps;    // area: frame-1 keypoints (angle); bow: keyframe keypoints (angle), indexed through q_items
     const int32_t* q_items;       // bow: query -> keyframe keypoint index (NULL: identity)
     const ovs_keypoint* t_kps;    // area / bow: target keypoints (angle, pt)
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
     typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
     typedef __attribute__((address_space(3))) volatile uint16_t lds_u16;
     constexpr int T = 64 * NW;
-    __shared__ uint32_t s_first[NW], s_any[NW], s_keep[4];
+    __shared__ uint32_t s_first[NW], s_any[NW], s_keep[4], s_keep_cnt[4];
     lds_u32* mark = (lds_u32*)s_res;                                        // [kMarkSize]
     lds_u32* hist = mark + kMarkSize;                                       // [32]
     lds_u16* thr = (lds_u16*)(hist + 32);                                   // [n_t]  alive(d, t) <=> d < thr[t]
@@ -827,8 +828,18 @@ __global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
                     const uint32_t o = __shfl_xor(m, off);
                     m = o > m ? o : m;
                 }
-                if (lane == 0) s_keep[k] = (uint32_t)(31 - (int)(m & 0xFFu));
+                if (lane == 0) {
+                    s_keep[k] = (uint32_t)(31 - (int)(m & 0xFFu));
+                    s_keep_cnt[k] = m >> 8;
+                }
                 if (key == m) key = 0u;
+            }
+            // rule 17's alternative (ORB-SLAM2's ComputeThreeMaxima): a second bin below 0.1 x the fullest drops out and takes the third with it,
+            // a third bin below that alone (bin 99 matches nothing)
+            if (a.angle_keep_rule && lane == 0) {
+                const float max1 = (float)s_keep_cnt[0];
+                if ((float)s_keep_cnt[1] < __fmul_rn(0.1f, max1)) s_keep[1] = s_keep[2] = 99u;
+                else if ((float)s_keep_cnt[2] < __fmul_rn(0.1f, max1)) s_keep[2] = 99u;
             }
         }
         wg_barrier();
@@ -887,6 +898,9 @@ __global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
 }   // namespace ovs
 
 using namespace ovs;
+
+// ovs_match_set_variant(OVS_MATCH_VARIANT_ANGLE_KEEP_RULE, 0 | 1): process-wide, read at every resolver launch
+static std::atomic<int> g_angle_keep_rule{0};
 
 struct ovs_wmatcher {
     int device = 0;
@@ -973,6 +987,7 @@ size_t resolve_lds_bytes(int n_q, int n_t) {
 template <int RULE>
 ovs_status launch_resolve(const ResolveArgs& ra_in, hipStream_t s) {
     ResolveArgs ra = ra_in;
+    ra.angle_keep_rule = g_angle_keep_rule.load(std::memory_order_relaxed);
     size_t fixed = resolve_lds_bytes(ra.n_q, ra.n_t);
     if (fixed > 150 * 1024) return OVS_ERR_CAPACITY;
     // the queries' list bounds are staged in LDS too unless the problem is so large that they would take the room of everything else
@@ -2633,5 +2648,12 @@ ovs_status ovs_frame_dev_attach_bearings(ovs_frame_dev* f, const double* bearing
     return OVS_OK;
 }
 int32_t ovs_frame_dev_device(const ovs_frame_dev* f) { return f ? f->device : -1; }
+
+ovs_status ovs_match_set_variant(int32_t which, int32_t value) {
+    if (which != OVS_MATCH_VARIANT_ANGLE_KEEP_RULE || (value != 0 && value != 1)) return OVS_ERR_INVALID;
+    g_angle_keep_rule.store(value, std::memory_order_relaxed);
+    return OVS_OK;
+}
+int32_t ovs_match_get_variant(int32_t which) { return which == OVS_MATCH_VARIANT_ANGLE_KEEP_RULE ? g_angle_keep_rule.load(std::memory_order_relaxed) : -1; }
 
 }   // extern "C"

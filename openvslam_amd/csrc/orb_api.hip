@@ -682,6 +682,7 @@ ovs_status ovs_orb_set_variant(ovs_orb* h, int32_t which, int32_t value) {
     if (which == OVS_VARIANT_TREE_SWITCH_FACTOR && (value == 3 || value == 1)) v = (v & ~1) | (value == 1 ? 1 : 0);
     else if (which == OVS_VARIANT_TREE_TIE_ORDER && (value == 0 || value == 1)) v = (v & ~2) | (value ? 2 : 0);
     else if (which == OVS_VARIANT_BLUR_TAPS && (value == 0 || value == 1)) v = (v & ~4) | (value ? 4 : 0);
+    else if (which == OVS_VARIANT_TRIG && (value == 0 || value == 1)) v = (v & ~8) | (value ? 8 : 0);
     else return OVS_ERR_INVALID;
     if (v != h->variant) {
         OVS_HIP_TRY(hipSetDevice(h->device));

@@ -245,7 +245,10 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // upstream evaluates keypt.angle * M_PI / 180.0 in double and rounds to float once (ORACLE_SPEC rule 11)
     const float rad = (float)__ddiv_rn(__dmul_rn((double)angle, 3.14159265358979323846), 180.0);
-    const float cos_a = util_cos(rad), sin_a = util_sin(rad);
+    // rule 11 as a run-time variant (geo->variant bit 3, wave-uniform): libm's cosf / sinf (ovs_detmath.h: glibc's algorithm, bit for bit)
+    // instead of OpenVSLAM's util::cos / util::sin polynomial
+    const bool trig_libm = (geo->variant & 8) != 0;
+    const float cos_a = trig_libm ? ovs_det_cosf(rad) : util_cos(rad), sin_a = trig_libm ? ovs_det_sinf(rad) : util_sin(rad);
 
     // ---- blur row pass (8.8 fixed point): hblur[r][c] = sum_k g[k] * patch[r][c + k], c <-> dx = c - 18.
     // One lane-step = outputs c = 4q .. 4q+3 of row r from 4 aligned words (columns 37..39 are computed and never read).

@@ -64,7 +64,7 @@ struct FrameGeo {
     int32_t total_kp_cap;
     int32_t ini_thr, min_thr;
     int32_t variant;   // ORACLE_SPEC rules 6, 7, 10 as run-time variants: bit 0 quad-tree switch factor 1 (default 3), bit 1 equal-count tie order
-                       // earlier-created first (default later first), bit 2 blur taps 18,34,49,55 saturating (default 18,34,48,56)
+                       // earlier-created first (default later first), bit 2 blur taps 18,34,49,55 saturating (default 18,34,48,56), bit 3 steering by libm's cosf / sinf (default util::cos / util::sin)
     int32_t cell_base_tab[OVS_MAX_LEVELS];   // lv[l].cell_base for l < num_levels, INT32_MAX above: one scalar load finds a cell's level
     LevelGeo lv[OVS_MAX_LEVELS];
 };

@@ -224,7 +224,7 @@ template <int MODEL, int kPoseThreads>   // MODEL 0 perspective (mono / stereo e
 __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __restrict__ poses_in, const ovs_pose_obs* __restrict__ obs_all,
                                                       const int32_t* __restrict__ obs_offsets, ovs_ba_cam cam, double bf, int setup_type,
                                                       double* __restrict__ poses_out, uint8_t* __restrict__ outlier_all,
-                                                      int32_t* __restrict__ num_valid) {
+                                                      int32_t* __restrict__ num_valid, int reset_each_round) {
     constexpr int kPoseWaves = kPoseThreads / 64;
     constexpr int kRedPitch = kPoseThreads + 8;   // doubles per row of the reduction scratch
     __shared__ double s_part[kPoseWaves][28];
@@ -313,6 +313,10 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
             // Huber in rounds 0..2 (`if (trial == num_trials_ - 2) setRobustKernel(nullptr)` runs after round 2's optimisation); the
             // estimate carries over from round to round (the frame vertex is initialised once, before the loop)
             const bool robust = trial < 3;
+            if (reset_each_round) {   // rule 25 (iv)'s alternative (ORB-SLAM2): every round starts from the input pose again (kernel argument: uniform)
+                if (tid == 0) s_T = T0;
+                __syncthreads();
+            }
             double lambda = 0, ni = 2;   // held identically by every thread (all control flow below is workgroup-uniform)
             bool err_at_trial = false;   // active edges' errors were last computed at s_Tn (g2o leaves them stale after a rejected step)
             // An iteration's FIRST trial evaluates the whole system at the trial state, not just its chi2: when the step is accepted -- the
@@ -476,6 +480,9 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
 
 using namespace ovs;
 
+// ovs_pose_set_variant(OVS_POSE_VARIANT_RESET_EACH_ROUND, 0 | 1): process-wide, read at every launch
+static std::atomic<int> g_pose_reset_each_round{0};
+
 extern "C" {
 
 static ovs_status pose_optimize_batch_dev(int model, const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
@@ -492,7 +499,7 @@ static ovs_status pose_optimize_batch_dev(int model, const double* d_poses_in, c
         static LdsAttrCache configured; /* per device: a second device needs the attribute too (116 KB of dynamic LDS at 512 threads) */  \
         OVS_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(k_pose_optimize<MODEL, TT>), sizeof(double) * 28 * (TT + 8), configured)); \
         hipLaunchKernelGGL((k_pose_optimize<MODEL, TT>), dim3(batch), dim3(TT), lds, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, \
-                           cam, BF, ST, d_poses_out, d_outlier, d_num_valid);                                                          \
+                           cam, BF, ST, d_poses_out, d_outlier, d_num_valid, g_pose_reset_each_round.load(std::memory_order_relaxed));     \
     } while (0)
     if (model == 1) {
         if (T == 512) OVS_POSE_LAUNCH(1, 512, 0.0, 0);
@@ -503,6 +510,12 @@ static ovs_status pose_optimize_batch_dev(int model, const double* d_poses_in, c
     }
 #undef OVS_POSE_LAUNCH
     OVS_HIP_TRY(hipGetLastError());
+    return OVS_OK;
+}
+
+ovs_status ovs_pose_set_variant(int32_t which, int32_t value) {
+    if (which != OVS_POSE_VARIANT_RESET_EACH_ROUND || (value != 0 && value != 1)) return OVS_ERR_INVALID;
+    g_pose_reset_each_round.store(value, std::memory_order_relaxed);
     return OVS_OK;
 }
 

@@ -17,6 +17,8 @@ __global__ __launch_bounds__(256) void k_detmath_eval(int fn, const double* __re
         case OVS_DETMATH_ASIN: r = ovs_det_asin(a[i]); break;
         case OVS_DETMATH_ACOS: r = ovs_det_acos(a[i]); break;
         case OVS_DETMATH_ATAN2: r = ovs_det_atan2(a[i], b[i]); break;
+        case OVS_DETMATH_SINF: r = (double)ovs_det_sinf((float)a[i]); break;
+        case OVS_DETMATH_COSF: r = (double)ovs_det_cosf((float)a[i]); break;
         default: r = 0.0; break;
     }
     out[i] = r;
@@ -25,7 +27,7 @@ __global__ __launch_bounds__(256) void k_detmath_eval(int fn, const double* __re
 }   // namespace ovs
 
 extern "C" ovs_status ovs_detmath_eval(int32_t device, int32_t fn, const double* a, const double* b, double* out, int32_t n) {
-    if (n < 0 || !a || !out || fn < OVS_DETMATH_LOGF || fn > OVS_DETMATH_ATAN2 || (fn == OVS_DETMATH_ATAN2 && !b)) return OVS_ERR_INVALID;
+    if (n < 0 || !a || !out || fn < OVS_DETMATH_LOGF || fn > OVS_DETMATH_COSF || (fn == OVS_DETMATH_ATAN2 && !b)) return OVS_ERR_INVALID;
     if (ovs_device_count() < 1) return OVS_ERR_NO_DEVICE;
     if (n == 0) return OVS_OK;
     if (hipSetDevice(device) != hipSuccess) return OVS_ERR_HIP;

@@ -168,7 +168,7 @@ class orb_extractor:
     def set_variant(self, which, value):
         """ovs_orb_set_variant: "tree_switch_factor" (3 | 1), "tree_tie_order" (0 later-created first | 1 earlier first), "blur_taps" (0 | 1) --
         the rules of oracle/ORACLE_SPEC.md (6, 7, 10) that cannot be pinned without upstream's sources, as run-time choices."""
-        idx = {"tree_switch_factor": 0, "tree_tie_order": 1, "blur_taps": 2}[which]
+        idx = {"tree_switch_factor": 0, "tree_tie_order": 1, "blur_taps": 2, "trig": 3}[which]
         _lib.check(self._L.ovs_orb_set_variant(self._h, idx, int(value)), "ovs_orb_set_variant")
         self._variants[idx] = int(value)
         self.max_keypoints = self._L.ovs_orb_max_keypoints(self._h)   # tree_switch_factor = 1 can return up to 2 N per level

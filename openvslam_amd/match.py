@@ -95,6 +95,11 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
                      ("class_id", "<i4")])   # cv::KeyPoint / ovs_keypoint
 
 
+def set_variant(which, value):
+    """ovs_match_set_variant: "angle_keep_rule" (0 top-3 | 1 top-3 with the 0.1 x max rule), process-wide (oracle/ORACLE_SPEC.md rule 17)."""
+    _lib.check(_lib.lib().ovs_match_set_variant({"angle_keep_rule": 0}[which], int(value)), "ovs_match_set_variant")
+
+
 def grid_params(cols, rows, num_grid_cols=64, num_grid_rows=48, min_x=0.0, min_y=0.0):
     """camera::base for an undistorted image: img_bounds_ = [0, cols] x [0, rows], 64 x 48 cells."""
     return _lib.GridParams(min_x, min_y, float(cols), float(rows), num_grid_cols, num_grid_rows)
@@ -532,6 +537,11 @@ class stereo:
         if getattr(self, "_h", None):
             self._L.ovs_stereo_destroy(self._h)
             self._h = None
+
+    def set_variant(self, which, value):
+        """ovs_stereo_set_variant: "outlier_factor" (0: 2.0 | 1: 2.1), "parabola" (0: float | 1: double) -- ORACLE_SPEC rule 20's L-tagged choices."""
+        idx = {"outlier_factor": 0, "parabola": 1}[which]
+        _lib.check(self._L.ovs_stereo_set_variant(self._h, idx, int(value)), "ovs_stereo_set_variant")
 
     def compute(self):
         """stereo::compute(stereo_x_right, depths): returns (stereo_x_right, depths), -1 where a keypoint has no stereo match."""

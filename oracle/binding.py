@@ -47,6 +47,12 @@ def lib():
     L.ovo_util_sin.argtypes = [C.c_float]
     L.ovo_util_sin.restype = C.c_float
     L.ovo_orb_descriptor.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_float, vp]
+    L.ovo_orb_descriptor_v.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_float, vp, C.c_int]
+    L.ovo_trig_mismatches_vs_libm.argtypes = [C.c_uint32, C.c_uint32]
+    L.ovo_trig_mismatches_vs_libm.restype = C.c_long
+    for fn in (L.ovo_det_sinf, L.ovo_det_cosf, L.ovo_util_cos, L.ovo_util_sin):
+        fn.argtypes = [C.c_float]
+        fn.restype = C.c_float
     L.ovo_orb_pattern.restype = C.POINTER(C.c_int8)
     L.ovo_orb_create.argtypes = [C.POINTER(OrbParams)]
     L.ovo_orb_create.restype = vp
@@ -85,7 +91,7 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-DETMATH_LOGF, DETMATH_ASIN, DETMATH_ACOS, DETMATH_ATAN2 = 0, 1, 2, 3
+DETMATH_LOGF, DETMATH_ASIN, DETMATH_ACOS, DETMATH_ATAN2, DETMATH_SINF, DETMATH_COSF = 0, 1, 2, 3, 4, 5
 
 
 def detmath_eval(fn, a, b=None):
@@ -160,11 +166,17 @@ def ic_angle(img, x, y, u_max):
     return float(lib().ovo_ic_angle(_p(img), img.strides[0], x, y, _p(um)))
 
 
-def orb_descriptor(blurred, x, y, angle_deg):
+def orb_descriptor(blurred, x, y, angle_deg, trig_variant=0):
     blurred = np.ascontiguousarray(blurred, np.uint8)
     d = np.zeros(32, np.uint8)
-    lib().ovo_orb_descriptor(_p(blurred), blurred.strides[0], x, y, angle_deg, _p(d))
+    assert lib().ovo_orb_descriptor_v(_p(blurred), blurred.strides[0], x, y, angle_deg, _p(d), int(trig_variant)) == 0
     return d
+
+
+def trig_mismatches_vs_libm(lo, hi):
+    """ovs_det_sinf / ovs_det_cosf against this machine's libm on every float in [lo, hi] (C loop): number of differing values."""
+    lo_b, hi_b = (int(np.float32(v).view(np.uint32)) for v in (lo, hi))
+    return int(lib().ovo_trig_mismatches_vs_libm(lo_b, hi_b))
 
 
 def orb_pattern():
@@ -190,7 +202,7 @@ class OrbExtractor:
 
     def set_variant(self, which, value):
         """ORACLE_SPEC rules 6 / 7 / 10 as run-time variants (ovo_orb_set_variant): same names and values as feature.orb_extractor.set_variant."""
-        idx = {"tree_switch_factor": 0, "tree_tie_order": 1, "blur_taps": 2}[which]
+        idx = {"tree_switch_factor": 0, "tree_tie_order": 1, "blur_taps": 2, "trig": 3}[which]
         assert lib().ovo_orb_set_variant(self._h, idx, int(value)) == 0, (which, value)
 
     def extract(self, img, mask=None):
@@ -291,6 +303,11 @@ def get_keypoints_in_cell(gp, kps, ref_x, ref_y, margin, min_level=-1, max_level
     n = lib().ovo_get_keypoints_in_cell(C.byref(gp), _p(xs), _p(ys), _p(oc), len(xs), C.c_float(ref_x), C.c_float(ref_y), C.c_float(margin),
                                         int(min_level), int(max_level), _p(out), len(out))
     return out[:n].copy()
+
+
+def match_set_variant(which, value):
+    """ovo_match_set_variant: "angle_keep_rule" (0 top-3 | 1 top-3 with ORB-SLAM2's 0.1 x max rule), process-wide (ORACLE_SPEC rule 17)."""
+    assert lib().ovo_match_set_variant({"angle_keep_rule": 0}[which], int(value)) == 0
 
 
 def angle_checker_invalid(delta_angles):
@@ -476,8 +493,10 @@ def fuse_replace_duplication(cam, gp, kf_kps, kf_desc, pose_cw, lm_pos_w, lm_dis
     return best[:len(pw)].copy(), n
 
 
-def stereo_compute(ox_left, ox_right, kps_left, desc_left, kps_right, desc_right, focal_x_baseline, true_baseline):
-    """stereo::compute on the pyramids of two OrbExtractor instances (their last extract). Returns (stereo_x_right, depths, n_valid)."""
+def stereo_compute(ox_left, ox_right, kps_left, desc_left, kps_right, desc_right, focal_x_baseline, true_baseline, outlier_factor_21=False,
+                   parabola_double=False):
+    """stereo::compute on the pyramids of two OrbExtractor instances (their last extract). Returns (stereo_x_right, depths, n_valid).
+    outlier_factor_21 / parabola_double: ORACLE_SPEC rule 20's alternatives (ovs_stereo_set_variant on the HIP side)."""
     L = lib()
     tabs = orb_tables(ox_left.params)
     nl = ox_left.params.num_levels
@@ -497,8 +516,9 @@ def stereo_compute(ox_left, ox_right, kps_left, desc_left, kps_right, desc_right
     isf = np.ascontiguousarray(tabs["inv_scale_factors"], np.float32)
     xr = np.full(max(len(kl), 1), -1, np.float32)
     dp = np.full(max(len(kl), 1), -1, np.float32)
-    n = L.ovo_stereo_compute(pl, pr, _p(rows), _p(cols), sl, sr, nl, _p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), _p(sf), _p(isf),
-                             C.c_float(focal_x_baseline), C.c_float(true_baseline), _p(xr), _p(dp))
+    n = L.ovo_stereo_compute_v(pl, pr, _p(rows), _p(cols), sl, sr, nl, _p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), _p(sf), _p(isf),
+                               C.c_float(focal_x_baseline), C.c_float(true_baseline), _p(xr), _p(dp),
+                               C.c_int((1 if outlier_factor_21 else 0) | (2 if parabola_double else 0)))
     return xr[:len(kl)].copy(), dp[:len(kl)].copy(), n
 
 
@@ -552,6 +572,11 @@ def ba_linearize_stereo(poses, pose_fixed, points, edges, cam, focal_x_baseline,
 POSE_OBS_DTYPE = np.dtype([("pos_w", "<f8", (3,)), ("obs_x", "<f8"), ("obs_y", "<f8"), ("obs_x_right", "<f8"), ("inv_sigma_sq", "<f8"),
                            ("is_stereo", "<i4"), ("pad", "<i4")])
 assert POSE_OBS_DTYPE.itemsize == 64
+
+
+def pose_set_variant(which, value):
+    """ovo_pose_set_variant: "reset_each_round" (0 | 1), process-wide (ORACLE_SPEC rule 25 (iv))."""
+    assert lib().ovo_pose_set_variant({"reset_each_round": 0}[which], int(value)) == 0
 
 
 def pose_optimize(pose_cw, obs, cam, focal_x_baseline=0.0, setup_type=None):

@@ -101,6 +101,10 @@ void for_keypoints_in_cell(const Grid& g, const float* xs, const float* ys, cons
 // match::angle_checker<int>: histogram_length 30, inv_histogram_length = 1/30 (so bins are 30 degrees wide and only
 // bins 0..12 are ever hit -- upstream's inherited ORB-SLAM2 quirk), keep the num_bins_to_keep = 3 fullest bins.
 // Tie rule (upstream: std::sort on sizes, implementation-defined): equal sizes -> lower bin index first.
+// ORACLE_SPEC rule 17 as a run-time variant (process-wide, ovo_match_set_variant): 0 (default) the three fullest bins are kept whatever their
+// sizes; 1 ORB-SLAM2's ComputeThreeMaxima: the second (and with it the third) is dropped when it holds fewer than 0.1 x the fullest bin's
+// entries, the third alone when only it does
+int g_angle_keep_rule = 0;
 struct AngleChecker {
     static constexpr int kLen = 30, kKeep = 3;
     std::vector<int> bins[kLen];
@@ -115,10 +119,16 @@ struct AngleChecker {
         int order[kLen];
         std::iota(order, order + kLen, 0);
         std::stable_sort(order, order + kLen, [&](int a, int b) { return bins[a].size() > bins[b].size(); });
+        int n_keep = kKeep;
+        if (g_angle_keep_rule) {
+            const float max1 = (float)bins[order[0]].size();
+            if ((float)bins[order[1]].size() < 0.1f * max1) n_keep = 1;
+            else if ((float)bins[order[2]].size() < 0.1f * max1) n_keep = 2;
+        }
         std::vector<int> out;
         for (int b = 0; b < kLen; ++b) {
             bool keep = false;
-            for (int k = 0; k < kKeep; ++k) keep |= order[k] == b;
+            for (int k = 0; k < n_keep; ++k) keep |= order[k] == b;
             if (!keep) out.insert(out.end(), bins[b].begin(), bins[b].end());
         }
         return out;
@@ -148,6 +158,12 @@ int ovo_get_keypoints_in_cell(const ovo_grid_params* p, const float* xs, const f
         ++m;
     });
     return m;
+}
+
+int ovo_match_set_variant(int which, int value) {
+    if (which != 0 || (value != 0 && value != 1)) return -1;
+    g_angle_keep_rule = value;
+    return 0;
 }
 
 void ovo_angle_checker_invalid(const float* delta_angles, int n, uint8_t* invalid) {
@@ -364,6 +380,8 @@ int ovo_detmath_eval(int fn, const double* a, const double* b, double* out, int 
             case 1: out[i] = ovs_det_asin(a[i]); break;
             case 2: out[i] = ovs_det_acos(a[i]); break;
             case 3: out[i] = ovs_det_atan2(a[i], b[i]); break;
+            case 4: out[i] = (double)ovs_det_sinf((float)a[i]); break;
+            case 5: out[i] = (double)ovs_det_cosf((float)a[i]); break;
             default: return -1;
         }
     }
@@ -934,11 +952,13 @@ int ovo_robust_match_for_triangulation(const uint8_t* desc_1, const float* angle
 //     a non-positive disparity becomes 0.01; depth = focal_x_baseline / disparity;
 //   finally matches whose L1 distance exceeds 2 x the median accepted distance are dropped (ORACLE_SPEC rule 20: upstream's
 //   factor is recalled as 2.0 with a strict comparison; ORB-SLAM2 used 1.5 * 1.4 = 2.1).
-int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr_right, const int32_t* level_rows,
-                       const int32_t* level_cols, const size_t* stride_left, const size_t* stride_right, int num_levels,
-                       const ovo_keypoint* kps_left, const uint8_t* desc_left, int n_left, const ovo_keypoint* kps_right,
-                       const uint8_t* desc_right, int n_right, const float* scale_factors, const float* inv_scale_factors,
-                       float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths) {
+// variant (ORACLE_SPEC rule 20's two L-tagged choices as run-time switches): bit 0 = outlier factor 2.1 (ORB-SLAM2's 1.5f * 1.4f) instead of 2.0,
+// bit 1 = the sub-pixel parabola evaluated in double and rounded to float once instead of float arithmetic
+int ovo_stereo_compute_v(const uint8_t* const* pyr_left, const uint8_t* const* pyr_right, const int32_t* level_rows,
+                         const int32_t* level_cols, const size_t* stride_left, const size_t* stride_right, int num_levels,
+                         const ovo_keypoint* kps_left, const uint8_t* desc_left, int n_left, const ovo_keypoint* kps_right,
+                         const uint8_t* desc_right, int n_right, const float* scale_factors, const float* inv_scale_factors,
+                         float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths, int variant) {
     (void)num_levels;
     const int rows0 = level_rows[0];
     for (int i = 0; i < n_left; ++i) stereo_x_right[i] = depths[i] = -1.0f;
@@ -1012,7 +1032,8 @@ int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr
         }
         if (best_offset == -Lr || best_offset == Lr) continue;
         const float c1 = correlations[Lr + best_offset - 1], c2 = correlations[Lr + best_offset], c3 = correlations[Lr + best_offset + 1];
-        const float delta = (c1 - c3) / (2.0f * (c1 + c3 - 2.0f * c2));
+        const float delta = (variant & 2) ? (float)(((double)c1 - (double)c3) / (2.0 * (((double)c1 + (double)c3) - 2.0 * (double)c2)))
+                                          : (c1 - c3) / (2.0f * (c1 + c3 - 2.0f * c2));
         if (delta < -1.0f || 1.0f < delta) continue;   // the denominator is > 0: c1 > c2 (first strict minimum) and c3 >= c2
         float best_x_right = scale_factors[level_l] * ((float)sxr + (float)best_offset + delta);
         float disp = x_left - best_x_right;
@@ -1029,7 +1050,7 @@ int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr
     int n_ok = (int)correlation_and_idx_left.size();
     if (!correlation_and_idx_left.empty()) {
         const float median = (float)correlation_and_idx_left[correlation_and_idx_left.size() / 2].first;
-        const float thr = 2.0f * median;
+        const float thr = ((variant & 1) ? 2.1f : 2.0f) * median;
         for (const auto& ci : correlation_and_idx_left) {
             if (thr < (float)ci.first) {
                 stereo_x_right[ci.second] = -1.0f;
@@ -1039,6 +1060,15 @@ int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr
         }
     }
     return n_ok;
+}
+
+int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr_right, const int32_t* level_rows,
+                       const int32_t* level_cols, const size_t* stride_left, const size_t* stride_right, int num_levels,
+                       const ovo_keypoint* kps_left, const uint8_t* desc_left, int n_left, const ovo_keypoint* kps_right,
+                       const uint8_t* desc_right, int n_right, const float* scale_factors, const float* inv_scale_factors,
+                       float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths) {
+    return ovo_stereo_compute_v(pyr_left, pyr_right, level_rows, level_cols, stride_left, stride_right, num_levels, kps_left, desc_left, n_left, kps_right,
+                                desc_right, n_right, scale_factors, inv_scale_factors, focal_x_baseline, true_baseline, stereo_x_right, depths, 0);
 }
 
 // SURVEY 8(f) #4  DBoW2 TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (third-party, absent: restated from the

@@ -75,6 +75,10 @@ int ovo_distribute_via_tree_v(const float* xs, const float* ys, const float* res
 float ovo_util_cos(float v);
 float ovo_util_sin(float v);
 int ovo_orb_descriptor(const uint8_t* blurred, size_t stride, int x, int y, float angle_deg, uint8_t* desc32);
+int ovo_orb_descriptor_v(const uint8_t* blurred, size_t stride, int x, int y, float angle_deg, uint8_t* desc32, int trig_variant);
+long ovo_trig_mismatches_vs_libm(uint32_t lo_bits, uint32_t hi_bits);
+float ovo_det_sinf(float v);
+float ovo_det_cosf(float v);
 const int8_t* ovo_orb_pattern(void); /* 256*4 int8 */
 
 /* A9: whole extractor with observable intermediates. */
@@ -128,6 +132,7 @@ int ovo_assign_keypoints_to_grid(const ovo_grid_params* p, const float* xs, cons
 int ovo_get_keypoints_in_cell(const ovo_grid_params* p, const float* xs, const float* ys, const int32_t* octaves, int n, float ref_x,
                               float ref_y, float margin, int min_level, int max_level, int32_t* out, int cap);
 /* match::angle_checker<int>: invalid[i] = 1 iff match i falls outside the 3 fullest of the 30 bins. */
+int ovo_match_set_variant(int which, int value);   /* which 0: angle_checker drops bins below 0.1 x the fullest (0 | 1), process-wide */
 void ovo_angle_checker_invalid(const float* delta_angles, int n, uint8_t* invalid);
 /* M3 projection::match_frame_and_landmarks. assigned[l] = frame keypoint index or -1. Returns num_matches. */
 int ovo_projection_match_frame_and_landmarks(const ovo_grid_params* gp, const float* xs, const float* ys, const int32_t* octaves,
@@ -223,6 +228,11 @@ int ovo_stereo_compute(const uint8_t* const* pyr_left, const uint8_t* const* pyr
                        const ovo_keypoint* kps_left, const uint8_t* desc_left, int n_left, const ovo_keypoint* kps_right,
                        const uint8_t* desc_right, int n_right, const float* scale_factors, const float* inv_scale_factors,
                        float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths);
+int ovo_stereo_compute_v(const uint8_t* const* pyr_left, const uint8_t* const* pyr_right, const int32_t* level_rows,
+                       const int32_t* level_cols, const size_t* stride_left, const size_t* stride_right, int num_levels,
+                       const ovo_keypoint* kps_left, const uint8_t* desc_left, int n_left, const ovo_keypoint* kps_right,
+                       const uint8_t* desc_right, int n_right, const float* scale_factors, const float* inv_scale_factors,
+                       float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths, int variant);
 
 /* ---- optimize::pose_optimizer (ovo_pose.cc) ---- */
 typedef struct ovo_pose_obs {   /* one observed landmark of the frame: pose_opt_edge_wrapper */
@@ -232,6 +242,7 @@ typedef struct ovo_pose_obs {   /* one observed landmark of the frame: pose_opt_
     int32_t is_stereo, pad;
 } ovo_pose_obs;
 /* pose_cw: 12 doubles (rotation row-major, translation). cam4 = fx, fy, cx, cy. outlier[n] = frm.outlier_flags_. */
+int ovo_pose_set_variant(int which, int value);   /* which 0: reset the frame vertex every round (0 | 1), process-wide */
 int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* obs, int n, const double* cam4, double focal_x_baseline, int setup_type,
                       double* pose_cw_out, uint8_t* outlier, int* num_valid);
 /* equirectangular frames (equirectangular_pose_opt_edge): monocular edges only, Monocular rig; see ovo_pose.cc */

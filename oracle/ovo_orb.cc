@@ -2,6 +2,7 @@
 // PARITY UNPINNED: upstream sources are absent (/root/reference/README.md:1-4); citations name the EXPECTED
 // upstream path and the SURVEY.md section 8(a) row that describes the behaviour being restated.
 #include "ovo_oracle.h"
+#include "../include/ovs_detmath.h"
 
 #include <algorithm>
 #include <array>
@@ -517,11 +518,13 @@ float util_cos(float v) {
 }
 float util_sin(float v) { return util_cos(kHalfPi - v); }
 
-void orb_descriptor(const uint8_t* blurred, size_t stride, int x, int y, float angle_deg, uint8_t* desc) {
+// trig_variant (ORACLE_SPEC rule 11): 0 util::cos / util::sin (OpenVSLAM's util/trigonometric.h polynomial), 1 std::cos / std::sin on the float
+// angle as glibc computes them (ovs_det_cosf / ovs_det_sinf of include/ovs_detmath.h, exhaustively equal to glibc's on [0, 6.3])
+void orb_descriptor(const uint8_t* blurred, size_t stride, int x, int y, float angle_deg, uint8_t* desc, int trig_variant = 0) {
     // upstream: `const float angle = keypt.angle * M_PI / 180.0;` -- float * double / double evaluated in double, rounded to float ONCE
     // (ORACLE_SPEC rule 11; not ORB-SLAM2's single float multiply by factorPI, which differs by 1 ulp for a fraction of the angles)
     const float angle = (float)((double)angle_deg * M_PI / 180.0);
-    const float cos_a = util_cos(angle), sin_a = util_sin(angle);
+    const float cos_a = trig_variant ? ovs_det_cosf(angle) : util_cos(angle), sin_a = trig_variant ? ovs_det_sinf(angle) : util_sin(angle);
     const uint8_t* center = blurred + (size_t)y * stride + x;
     const int step = (int)stride;
     auto value = [&](int px, int py) -> int {
@@ -552,7 +555,7 @@ struct ovo_orb {
     std::vector<int> npl;
     int u_max[16];
     int threads = 1;
-    int tree_switch_factor = 3, tree_tie_earlier_first = 0, blur_taps = 0;   // ORACLE_SPEC rules 6, 7, 10 as run-time variants
+    int tree_switch_factor = 3, tree_tie_earlier_first = 0, blur_taps = 0, trig = 0;   // ORACLE_SPEC rules 6, 7, 10, 11 as run-time variants
     // observables of the last extract
     std::vector<int> lrows, lcols;
     std::vector<std::vector<uint8_t>> pyr, blurred;
@@ -711,6 +714,25 @@ int ovo_orb_descriptor(const uint8_t* blurred, size_t stride, int x, int y, floa
     orb_descriptor(blurred, stride, x, y, angle_deg, desc32);
     return 0;
 }
+int ovo_orb_descriptor_v(const uint8_t* blurred, size_t stride, int x, int y, float angle_deg, uint8_t* desc32, int trig_variant) {
+    if (trig_variant < 0 || trig_variant > 1) return -1;
+    orb_descriptor(blurred, stride, x, y, angle_deg, desc32, trig_variant);
+    return 0;
+}
+// the shared sinf / cosf restatement against THIS machine's libm over the float bit patterns [lo_bits, hi_bits]: number of values where either differs
+long ovo_trig_mismatches_vs_libm(uint32_t lo_bits, uint32_t hi_bits) {
+    long bad = 0;
+    for (uint64_t u = lo_bits; u <= hi_bits; ++u) {
+        const uint32_t v = (uint32_t)u;
+        float x;
+        std::memcpy(&x, &v, 4);
+        const float a = ovs_det_sinf(x), b = sinf(x), c = ovs_det_cosf(x), d = cosf(x);
+        bad += std::memcmp(&a, &b, 4) != 0 || std::memcmp(&c, &d, 4) != 0;
+    }
+    return bad;
+}
+float ovo_det_sinf(float v) { return ovs_det_sinf(v); }
+float ovo_det_cosf(float v) { return ovs_det_cosf(v); }
 const int8_t* ovo_orb_pattern(void) { return kPattern; }
 
 ovo_orb* ovo_orb_create(const ovo_orb_params* p) {
@@ -722,12 +744,14 @@ ovo_orb* ovo_orb_create(const ovo_orb_params* p) {
 }
 void ovo_orb_destroy(ovo_orb* h) { delete h; }
 void ovo_orb_set_threads(ovo_orb* h, int n) { h->threads = std::max(1, n); }
-// which: 0 quad-tree switch factor (3 | 1), 1 equal-count tie order (0 later-created first | 1 earlier-created first), 2 blur taps (0 | 1)
+// which: 0 quad-tree switch factor (3 | 1), 1 equal-count tie order (0 later-created first | 1 earlier-created first), 2 blur taps (0 | 1),
+// 3 steering trigonometry (0 util::cos / util::sin | 1 libm's cosf / sinf)
 int ovo_orb_set_variant(ovo_orb* h, int which, int value) {
     if (!h) return -1;
     if (which == 0 && (value == 3 || value == 1)) h->tree_switch_factor = value;
     else if (which == 1 && (value == 0 || value == 1)) h->tree_tie_earlier_first = value;
     else if (which == 2 && (value == 0 || value == 1)) h->blur_taps = value;
+    else if (which == 3 && (value == 0 || value == 1)) h->trig = value;
     else return -1;
     return 0;
 }
@@ -765,7 +789,7 @@ int ovo_orb_extract(ovo_orb* h, const uint8_t* img, int rows, int cols, size_t s
         gaussian_blur_7x7(h->pyr[l].data(), h->lrows[l], h->lcols[l], h->lcols[l], h->blurred[l].data(), h->lcols[l], h->blur_taps);
         all_desc[l].resize(k.size() * 32);
         for (size_t i = 0; i < k.size(); ++i) {
-            orb_descriptor(h->blurred[l].data(), h->lcols[l], cv_round(k[i].x), cv_round(k[i].y), k[i].angle, &all_desc[l][i * 32]);
+            orb_descriptor(h->blurred[l].data(), h->lcols[l], cv_round(k[i].x), cv_round(k[i].y), k[i].angle, &all_desc[l][i * 32], h->trig);
             k[i].x *= h->sf[l];
             k[i].y *= h->sf[l];
         }

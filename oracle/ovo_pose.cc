@@ -214,6 +214,9 @@ bool solve6(const double* H, double lambda, const double* b, double* x) {
 }   // namespace
 
 namespace {
+// ORACLE_SPEC rule 25 (iv) as a run-time variant: 0 (default) the frame vertex is initialised ONCE, rounds continue from the previous estimate
+// (OpenVSLAM as recalled); 1 it is re-set to the input pose at the start of every round (ORB-SLAM2's Optimizer::PoseOptimization)
+int g_pose_reset_each_round = 0;
 int pose_optimize_impl(const double* pose_cw_in, const ovo_pose_obs* obs, int n, const double* cam4, double bf, int setup_type, int model,
                        double* pose_cw_out, uint8_t* outlier, int* num_valid) {
     // upstream: sqrt_chi_sq = (frm.camera_->setup_type_ == Monocular) ? sqrt_chi_sq_2D : sqrt_chi_sq_3D -- ONE Huber delta for every
@@ -236,6 +239,7 @@ int pose_optimize_impl(const double* pose_cw_in, const ovo_pose_obs* obs, int n,
             // The frame vertex is set to the initial pose once, before the loop (unlike ORB-SLAM2, which resets it every round):
             // each round continues from the previous round's estimate.
             const bool robust = trial < 3;
+            if (g_pose_reset_each_round) T = T0;
             Pose Terr = T;       // the state the ACTIVE edges' errors were last computed at (g2o leaves them stale after a rejected step)
             double lambda = 0, ni = 2;
             for (int it = 0; it < 10; ++it) {
@@ -312,6 +316,12 @@ int pose_optimize_impl(const double* pose_cw_in, const ovo_pose_obs* obs, int n,
     return 0;
 }
 }   // namespace
+
+extern "C" int ovo_pose_set_variant(int which, int value) {
+    if (which != 0 || (value != 0 && value != 1)) return -1;
+    g_pose_reset_each_round = value;
+    return 0;
+}
 
 extern "C" int ovo_pose_optimize(const double* pose_cw_in, const ovo_pose_obs* obs, int n, const double* cam4, double bf, int setup_type,
                                  double* pose_cw_out, uint8_t* outlier, int* num_valid) {

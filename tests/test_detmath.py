@@ -65,6 +65,18 @@ def test_logf_equals_glibc_exhaustively():
     assert sp[0] == -np.inf and np.isnan(sp[1]) and sp[2] == np.inf and np.isnan(sp[3]) and sp[4] == 0.0
 
 
+def test_sinf_cosf_equal_glibc_exhaustively():
+    """ovs_det_sinf / ovs_det_cosf (glibc >= 2.28's sinf / cosf restated: the OVS_VARIANT_TRIG = 1 steering) against this machine's libm on
+    EVERY float of [0, 6.3] -- all angles a keypoint can have, 1.09e9 values, ~12 s of C -- and hand-checked special values."""
+    assert ob.trig_mismatches_vs_libm(0.0, 6.3) == 0
+    f = ob.lib()
+    assert f.ovo_det_cosf(0.0) == 1.0 and f.ovo_det_sinf(0.0) == 0.0
+    assert f.ovo_det_sinf(np.float32(np.pi / 2)) == 1.0 and abs(f.ovo_det_cosf(np.float32(np.pi))) == 1.0
+    # and they differ from util::cos / util::sin (the default steering) by the polynomial's ~1e-3, not by rounding
+    a = np.float32(0.7)
+    assert 1e-5 < abs(f.ovo_det_cosf(a) - f.ovo_util_cos(a)) < 2e-3
+
+
 @pytest.mark.gpu
 def test_device_and_host_agree_bit_for_bit():
     import ctypes as C
@@ -94,6 +106,15 @@ def test_device_and_host_agree_bit_for_bit():
                         np.nextafter(np.nextafter(k, np.float32(0)), np.float32(0)), np.nextafter(np.nextafter(k, np.float32(1e30)), np.float32(1e30))])
     xs = np.concatenate([m, np.exp(rng.uniform(-80, 80, 500000)).astype(np.float32), k]).astype(np.float64)
     assert np.array_equal(dev(ob.DETMATH_LOGF, xs).view(np.uint64), ob.detmath_eval(ob.DETMATH_LOGF, xs).view(np.uint64))
+    # sinf / cosf (the `trig` variant's steering): every 5th float of [0, 2 pi] + the quadrant boundaries +- 3 ulp
+    u = np.arange(0, int(np.float32(6.2832).view(np.uint32)), 5, dtype=np.uint32).view(np.float32)
+    q = np.float32([np.pi / 4, np.pi / 2, 3 * np.pi / 4, np.pi, 5 * np.pi / 4, 3 * np.pi / 2, 7 * np.pi / 4, 2 * np.pi])
+    nb = [q]
+    for _ in range(3):
+        nb += [np.nextafter(nb[-1], np.float32(0)), np.nextafter(nb[-1 if len(nb) == 1 else -2], np.float32(10))]
+    ang = np.concatenate([u] + nb).astype(np.float64)
+    for fn in (ob.DETMATH_SINF, ob.DETMATH_COSF):
+        assert np.array_equal(dev(fn, ang).view(np.uint64), ob.detmath_eval(fn, ang).view(np.uint64))
 
 
 def test_equirectangular_decisions_do_not_depend_on_the_shared_asin_atan2():

@@ -64,10 +64,10 @@ def test_extract_bit_exact(hip, oracle, rows, cols, nfeat, seed):
     assert np.array_equal(gd, wd)
 
 
-@pytest.mark.parametrize("factor,tie,taps", [(1, 0, 0), (3, 1, 0), (3, 0, 1), (1, 1, 1)])
+@pytest.mark.parametrize("factor,tie,taps,trig", [(1, 0, 0, 0), (3, 1, 0, 0), (3, 0, 1, 0), (1, 1, 1, 0), (3, 0, 0, 1), (1, 1, 1, 1)])
 @pytest.mark.parametrize("rows,cols,nfeat", [(1080, 1920, 2000), (480, 752, 1000), (500, 644, 700)])
-def test_extract_bit_exact_under_every_variant(hip, oracle, rows, cols, nfeat, factor, tie, taps):
-    """ORACLE_SPEC rules 6 (quad-tree switch factor), 7 (equal-count tie order) and 10 (blur taps) as run-time variants of BOTH sides
+def test_extract_bit_exact_under_every_variant(hip, oracle, rows, cols, nfeat, factor, tie, taps, trig):
+    """ORACLE_SPEC rules 6 (quad-tree switch factor), 7 (equal-count tie order), 10 (blur taps) and 11 (steering trigonometry) as run-time variants of BOTH sides
     (ovs_orb_set_variant / ovo_orb_set_variant): byte-equal keypoints and descriptors in every setting, and back to the defaults."""
     img, ex, ox = _pair(hip, oracle, rows, cols, nfeat, seed=2)
     gk0, gd0 = ex.extract(img)
@@ -75,6 +75,7 @@ def test_extract_bit_exact_under_every_variant(hip, oracle, rows, cols, nfeat, f
         e.set_variant("tree_switch_factor", factor)
         e.set_variant("tree_tie_order", tie)
         e.set_variant("blur_taps", taps)
+        e.set_variant("trig", trig)
     gk, gd = ex.extract(img)
     wk, wd = ox.extract(img)
     assert len(gk) == len(wk) and np.array_equal(gk.view(np.uint8), wk.view(np.uint8)) and np.array_equal(gd, wd)
@@ -83,6 +84,7 @@ def test_extract_bit_exact_under_every_variant(hip, oracle, rows, cols, nfeat, f
         e.set_variant("tree_switch_factor", 3)
         e.set_variant("tree_tie_order", 0)
         e.set_variant("blur_taps", 0)
+        e.set_variant("trig", 0)
     gk1, gd1 = ex.extract(img)
     assert np.array_equal(gk1.view(np.uint8), gk0.view(np.uint8)) and np.array_equal(gd1, gd0)
     with pytest.raises(RuntimeError):

@@ -38,6 +38,28 @@ def test_pose_optimize(oracle, n, stereo_frac, outlier_frac, pose_err):
         assert nv == 0 and np.array_equal(T, T0)
 
 
+@pytest.mark.parametrize("n,stereo_frac,outlier_frac,pose_err", [(1500, 0.4, 0.1, 1.0), (2000, 0.0, 0.25, 3.0)])
+def test_pose_optimize_reset_each_round_variant(oracle, n, stereo_frac, outlier_frac, pose_err):
+    """ORACLE_SPEC rule 25 (iv) as a run-time variant of BOTH sides (ovs_pose_set_variant / ovo_pose_set_variant): ORB-SLAM2's re-set of the
+    frame vertex at the start of every round. Same tolerance as the default schedule; and the variant is not a no-op."""
+    from openvslam_amd import ba
+    T0, obs, cam, bf, _ = make_frame(oracle.POSE_OBS_DTYPE, n, n, stereo_frac, outlier_frac, pose_err)
+    T_def, out_def, _ = ba.pose_optimize(T0, obs, cam, bf)
+    try:
+        ba.pose_set_variant("reset_each_round", 1)
+        oracle.pose_set_variant("reset_each_round", 1)
+        T, out, nv = ba.pose_optimize(T0, obs, cam, bf)
+        wT, wout, wnv = oracle.pose_optimize(T0, obs, cam, bf)
+    finally:
+        ba.pose_set_variant("reset_each_round", 0)
+        oracle.pose_set_variant("reset_each_round", 0)
+    assert np.allclose(T, wT, rtol=0, atol=1e-9) and (out != wout).sum() <= 2 and abs(nv - wnv) <= 2
+    assert not np.array_equal(T, T_def)   # another schedule: the last bits of the pose differ
+    assert np.allclose(T, T_def, rtol=0, atol=1e-4)   # ... and only those: both converge to the same optimum
+    T2, _, _ = ba.pose_optimize(T0, obs, cam, bf)
+    assert np.array_equal(T2, T_def)      # the default is back
+
+
 # ---- equirectangular frames (BASELINE configs[3]: 3840 x 1920): equirectangular_pose_opt_edge
 @pytest.mark.parametrize("n,outlier_frac,pose_err,seam,pole", [(1500, 0.1, 1.0, 0.0, 0.0), (2000, 0.2, 2.0, 0.1, 0.05), (300, 0.05, 0.5, 0.3, 0.3),
                                                                (7, 0.0, 1.0, 0.0, 0.0), (3, 0.0, 1.0, 0.0, 0.0), (8192, 0.15, 1.0, 0.05, 0.05)])

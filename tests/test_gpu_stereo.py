@@ -31,6 +31,20 @@ def test_stereo_compute_kitti_geometry(mods, oracle, rows, cols, nfeat, seed):
         wxr, wdp, wn = oracle.stereo_compute(oxl, oxr, wkl, wdl, wkr, wdr, fxb, b)
         assert st.num_valid_ == wn
         assert np.array_equal(xr.view(np.uint32), wxr.view(np.uint32)) and np.array_equal(dp.view(np.uint32), wdp.view(np.uint32))
+        # ORACLE_SPEC rule 20's two L-tagged choices as run-time variants of BOTH sides: bit-equal in every setting, and not no-ops
+        changed = 0
+        for f21, pdbl in ((True, False), (False, True), (True, True)):
+            st.set_variant("outlier_factor", int(f21))
+            st.set_variant("parabola", int(pdbl))
+            vxr, vdp = st.compute()
+            oxr_, odp_, on = oracle.stereo_compute(oxl, oxr, wkl, wdl, wkr, wdr, fxb, b, outlier_factor_21=f21, parabola_double=pdbl)
+            assert st.num_valid_ == on and np.array_equal(vxr.view(np.uint32), oxr_.view(np.uint32)) and np.array_equal(vdp.view(np.uint32), odp_.view(np.uint32))
+            changed += not np.array_equal(vxr.view(np.uint32), xr.view(np.uint32))
+            if f21 and not pdbl:
+                assert on >= wn   # a larger factor keeps at least as many matches
+        st.set_variant("outlier_factor", 0)
+        st.set_variant("parabola", 0)
+        assert changed >= 1
     assert wn > len(kl) // 10
 
 

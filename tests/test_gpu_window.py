@@ -532,3 +532,33 @@ def test_resolver_under_heavy_contention(match, synth, oracle, n_nodes, ratio, c
     gn, got = wa.match_in_consistent_area(gp, ka, da, kb, db, pg, 400)
     wn, want = oracle.area_match_in_consistent_area(ogp, ka, da, kb, db, po, 400, ratio, check_orientation)
     assert gn == wn and np.array_equal(got, want) and np.array_equal(pg.view(np.uint32), po.view(np.uint32))
+
+
+def test_angle_keep_rule_variant_on_both_sides(match, synth, oracle):
+    """ORACLE_SPEC rule 17's alternative (ORB-SLAM2's 0.1 x max rule in angle_checker) as a process-wide run-time variant of BOTH sides
+    (ovs_match_set_variant / ovo_match_set_variant): the device resolver and the oracle agree in either setting, and on a frame pair with one
+    dominant rotation bin the rule removes matches the default keeps."""
+    ka, da, kb, db = _two_frames(oracle, synth, shift=(3, 2))
+    gp, ogp = match.grid_params(752, 480), oracle.grid_params(752, 480)
+    fa, fb = synth.synth_bow(da, seed=1, n_nodes=120), synth.synth_bow(db, seed=1, n_nodes=120)
+    has_lm = np.ones(len(ka), np.uint8)
+    res = {}
+    try:
+        for rule in (0, 1):
+            match.set_variant("angle_keep_rule", rule)
+            oracle.match_set_variant("angle_keep_rule", rule)
+            w = match.area(0.9, True, max_targets=2048, max_queries=2048)
+            pg = np.ascontiguousarray(np.stack([ka["x"], ka["y"]], 1), np.float32)
+            po = pg.copy()
+            gn, got = w.match_in_consistent_area(gp, ka, da, kb, db, pg, 100)
+            wn, want = oracle.area_match_in_consistent_area(ogp, ka, da, kb, db, po, 100, 0.9, True)
+            assert gn == wn and np.array_equal(got, want)
+            wb = match.bow_tree(0.75, True, max_targets=2048, max_queries=2048)
+            bn, bgot = wb.match_frame_and_keyframe(ka, da, fa, kb, db, fb, has_lm)
+            own, owant = oracle.bow_match_frame_and_keyframe(ka, da, fa, kb, db, fb, 0.75, True, has_lm)
+            assert bn == own and np.array_equal(bgot, owant)
+            res[rule] = (wn, own)
+    finally:
+        match.set_variant("angle_keep_rule", 0)
+        oracle.match_set_variant("angle_keep_rule", 0)
+    assert res[1][0] <= res[0][0] and res[1][1] <= res[0][1] and res[1] != res[0]
