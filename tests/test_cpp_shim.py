@@ -563,9 +563,20 @@ def test_keyframe_residency_shared_cache_and_two_threads(tmp_path):
         import shutil
         if shutil.which("setarch"):
             t = subprocess.run(["setarch", os.uname().machine, "-R"] + tsan, capture_output=True, text=True, env=env)
-    races = [ln for ln in t.stderr.splitlines() if "WARNING: ThreadSanitizer: data race" in ln]
-    in_shim = "openvslam/" in t.stderr and races   # a report whose stack passes through the shim sources
+    log = os.environ.get("OVS_TSAN_LOG")
+    if log:
+        open(log, "w").write(t.stdout + "\n==== stderr ====\n" + t.stderr)
+    # A report counts when one of its two access stacks has its innermost frame in the shim layer or the test itself (the HIP runtime and the
+    # library are not instrumented: the sanitizer cannot see the happens-before their internal synchronisation provides, and reports frees
+    # of buffers they handed between their own threads -- those have runtime / allocator frames innermost)
+    reports = t.stderr.split("WARNING: ThreadSanitizer: data race")[1:]
+    ours = []
+    for rep in reports:
+        tops = [ln for ln in rep.splitlines() if ln.lstrip().startswith("#0 ")][:2]
+        if any(("openvslam/" in ln or "test_threads_shim.cc" in ln) for ln in tops):
+            ours.append(rep[:1500])
     if "ALL OK" in t.stdout:
-        assert not in_shim, t.stderr[-4000:]
+        print("ThreadSanitizer build ran: %d reports, %d with an innermost frame in the shim layer" % (len(reports), len(ours)))
+        assert not ours, ours[0]
     else:
         print("ThreadSanitizer build did not complete beside the HIP runtime here (rc %d): %s" % (t.returncode, (t.stderr or t.stdout)[-600:]))
