@@ -198,6 +198,10 @@ OVS_DM_FN float sincosf_glibc(float y, int want_cos) {
     return sincosf_poly(x * s, x * x, (n & 2) ? T1 : T0, n ^ want_cos);
 }
 }   // namespace ovs_dm
+// keypt.angle * M_PI / 180.0 evaluated in double and rounded to float once (ORACLE_SPEC rule 11), as ONE double multiplication by RN(pi / 180):
+// bit-identical to the two-operation form for EVERY float angle in [0, 360] (all 1 135 869 953 of them: tests/test_detmath.py::
+// test_deg2rad_single_multiply_is_exact runs the comparison in C), and a thirtieth of the instructions of an IEEE f64 division on the device
+OVS_DM_FN float ovs_det_deg2rad(float angle_deg) { return (float)((double)angle_deg * 0x1.1df46a2529d39p-6); }
 OVS_DM_FN float ovs_det_sinf(float x) { return ovs_dm::sincosf_glibc(x, 0); }
 OVS_DM_FN float ovs_det_cosf(float x) { return ovs_dm::sincosf_glibc(x, 1); }
 

@@ -244,7 +244,8 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
     m01 = __builtin_amdgcn_readlane(wave_total_in_lane63(m01), 63);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // upstream evaluates keypt.angle * M_PI / 180.0 in double and rounds to float once (ORACLE_SPEC rule 11)
-    const float rad = (float)__ddiv_rn(__dmul_rn((double)angle, 3.14159265358979323846), 180.0);
+    // (one f64 multiply by RN(pi / 180): exhaustively equal to the product-then-quotient form on [0, 360], include/ovs_detmath.h)
+    const float rad = ovs_det_deg2rad(angle);
     // rule 11 as a run-time variant (geo->variant bit 3, wave-uniform): libm's cosf / sinf (ovs_detmath.h: glibc's algorithm, bit for bit)
     // instead of OpenVSLAM's util::cos / util::sin polynomial
     const bool trig_libm = (geo->variant & 8) != 0;

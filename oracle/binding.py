@@ -50,6 +50,8 @@ def lib():
     L.ovo_orb_descriptor_v.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_float, vp, C.c_int]
     L.ovo_trig_mismatches_vs_libm.argtypes = [C.c_uint32, C.c_uint32]
     L.ovo_trig_mismatches_vs_libm.restype = C.c_long
+    L.ovo_deg2rad_mismatches.argtypes = [C.c_uint32, C.c_uint32]
+    L.ovo_deg2rad_mismatches.restype = C.c_long
     for fn in (L.ovo_det_sinf, L.ovo_det_cosf, L.ovo_util_cos, L.ovo_util_sin):
         fn.argtypes = [C.c_float]
         fn.restype = C.c_float
@@ -171,6 +173,12 @@ def orb_descriptor(blurred, x, y, angle_deg, trig_variant=0):
     d = np.zeros(32, np.uint8)
     assert lib().ovo_orb_descriptor_v(_p(blurred), blurred.strides[0], x, y, angle_deg, _p(d), int(trig_variant)) == 0
     return d
+
+
+def deg2rad_mismatches(lo, hi):
+    """ovs_det_deg2rad (one f64 multiply, what k_describe evaluates) against `(float)((double)a * M_PI / 180.0)` on every float of [lo, hi]."""
+    lo_b, hi_b = (int(np.float32(v).view(np.uint32)) for v in (lo, hi))
+    return int(lib().ovo_deg2rad_mismatches(lo_b, hi_b))
 
 
 def trig_mismatches_vs_libm(lo, hi):

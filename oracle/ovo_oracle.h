@@ -77,6 +77,7 @@ float ovo_util_sin(float v);
 int ovo_orb_descriptor(const uint8_t* blurred, size_t stride, int x, int y, float angle_deg, uint8_t* desc32);
 int ovo_orb_descriptor_v(const uint8_t* blurred, size_t stride, int x, int y, float angle_deg, uint8_t* desc32, int trig_variant);
 long ovo_trig_mismatches_vs_libm(uint32_t lo_bits, uint32_t hi_bits);
+long ovo_deg2rad_mismatches(uint32_t lo_bits, uint32_t hi_bits);
 float ovo_det_sinf(float v);
 float ovo_det_cosf(float v);
 const int8_t* ovo_orb_pattern(void); /* 256*4 int8 */

@@ -731,6 +731,18 @@ long ovo_trig_mismatches_vs_libm(uint32_t lo_bits, uint32_t hi_bits) {
     }
     return bad;
 }
+// the kernels' one-multiply deg -> rad against upstream's literal expression over the float bit patterns [lo_bits, hi_bits]: number of differing values
+long ovo_deg2rad_mismatches(uint32_t lo_bits, uint32_t hi_bits) {
+    long bad = 0;
+    for (uint64_t u = lo_bits; u <= hi_bits; ++u) {
+        const uint32_t v = (uint32_t)u;
+        float a;
+        std::memcpy(&a, &v, 4);
+        const float lit = (float)((double)a * M_PI / 180.0), one = ovs_det_deg2rad(a);
+        bad += std::memcmp(&lit, &one, 4) != 0;
+    }
+    return bad;
+}
 float ovo_det_sinf(float v) { return ovs_det_sinf(v); }
 float ovo_det_cosf(float v) { return ovs_det_cosf(v); }
 const int8_t* ovo_orb_pattern(void) { return kPattern; }

@@ -65,6 +65,12 @@ def test_logf_equals_glibc_exhaustively():
     assert sp[0] == -np.inf and np.isnan(sp[1]) and sp[2] == np.inf and np.isnan(sp[3]) and sp[4] == 0.0
 
 
+def test_deg2rad_single_multiply_is_exact():
+    """k_describe converts the keypoint angle with ONE double multiplication by RN(pi / 180); upstream's expression (rule 11) is a double
+    product and a double quotient. Equal after the rounding to float for EVERY float in [0, 360] -- fastAtan2's whole range."""
+    assert ob.deg2rad_mismatches(0.0, 360.0) == 0
+
+
 def test_sinf_cosf_equal_glibc_exhaustively():
     """ovs_det_sinf / ovs_det_cosf (glibc >= 2.28's sinf / cosf restated: the OVS_VARIANT_TRIG = 1 steering) against this machine's libm on
     EVERY float of [0, 6.3] -- all angles a keypoint can have, 1.09e9 values, ~12 s of C -- and hand-checked special values."""
