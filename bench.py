@@ -404,11 +404,16 @@ def main():
         }
         if valu_counts.get("fast"):
             fast_s = iso_ms["fast"] / n_chain * 1e-3
+            # one VALU wave-instruction occupies a SIMD's issue slot for 4 cycles: on this kernel SQ_ACTIVE_INST_VALU (busy quad-cycles) equals
+            # SQ_INSTS_VALU to four digits (profiles/r04b_pmc_sq_summary.txt), i.e. the 2.3-cycle back-to-back rate tools/ubench/valu_rate.hip measures
+            # for 16-bit VOP2 ops is not what a mixed instruction stream gets. (Rounds 2-3 priced every instruction at 4.2 cycles: overstated.)
             roofline_valu["k_fast_cells"] = {"unit": "VALU wave-instructions/s", "achieved": round(valu_counts["fast"] / fast_s, 1),
-                                             "peak": round(simd_hz / 4.2, 1), "frac": round(valu_counts["fast"] / fast_s / (simd_hz / 4.2), 4),
+                                             "peak": round(simd_hz / 4.0, 1), "frac": round(valu_counts["fast"] / fast_s / (simd_hz / 4.0), 4),
                                              "launch_ms_alone": round(fast_s * 1e3, 5), "insts_valu_per_launch": valu_counts["fast"],
                                              "insts_source": "profiles/pmc_traffic.json (SQ_INSTS_VALU pass)",
-                                             "floor_model": "packed 16-bit / 3-operand ops issue one wave-instruction per 4.2 cycles; an upper bound on the issue-slot use since round 2: about a sixth of the instructions are 16-bit VOP2 min / max that issue in 2.3 cycles"}
+                                             "floor_model": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per VALU wave-instruction (the counter's own "
+                                                            "busy measure: SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU on this kernel); LDS pipe busy 47 % "
+                                                            "beside it (SQ_LDS_IDX_ACTIVE, a third of it bank conflicts)"}
         # ---- per-call latency of orb_extractor::extract through the C++ class boundary at THIS config's size, H2D / D2H
         # included (openvslam_amd/cpp/bench_shim; one call = one upload, one kernel chain, one D2H, one wait)
         class_lat = None

@@ -1,10 +1,13 @@
-"""A SECOND, independent restatement of three OpenCV stages of the extraction -- cv::resize(INTER_LINEAR, 8UC1), cv::FAST(TYPE_9_16) with
-its corner score and non-maximum suppression, and the 7x7 sigma-2 fixed-point GaussianBlur -- written in vectorised numpy from the
-algorithm text of oracle/ORACLE_SPEC.md (rules 3, 5, 10) and the public description of those OpenCV functions, NOT from oracle/ovo_orb.cc
-(whole-array formulation, no per-pixel loops, different decomposition). tests/test_nversion.py compares it with the C oracle bit for bit.
+"""A SECOND, independent restatement of the arithmetic stages of the extraction -- cv::resize(INTER_LINEAR, 8UC1), cv::FAST(TYPE_9_16) with its
+corner score and non-maximum suppression, the 7x7 sigma-2 fixed-point GaussianBlur, ic_angle + cv::fastAtan2, and the steered rBRIEF-256 --
+written in vectorised numpy from the algorithm text of oracle/ORACLE_SPEC.md (rules 3, 5, 9, 10, 11) and the public description of those
+OpenCV / OpenVSLAM functions, NOT from oracle/ovo_orb.cc (whole-array formulation, no per-pixel loops, different decomposition).
+tests/test_nversion.py compares it with the C oracle bit for bit, and reproduces the committed golden angles and descriptors of all 1008
+keypoints with the oracle's C code out of the loop (only the keypoint positions -- cell loop + quad-tree, which have their own executable
+model in tools/tree_model.py -- are taken as given).
 
 Why: the reference tree is absent, so the oracle cannot be pinned to it ("What's missing" #1). Two implementations
-written separately from the same specification that agree on every pixel of the golden inputs is the strongest evidence available here
+written separately from the same specification that agree on every pixel / bit of the golden inputs is the strongest evidence available here
 that the oracle implements its specification -- it says nothing about whether the SPECIFICATION is upstream's (that is what the run-time
 variants of ORACLE_SPEC.md hedge). Test infrastructure only: nothing under openvslam_amd/ imports this."""
 import numpy as np
@@ -104,3 +107,75 @@ def gaussian_blur_7x7(img, taps_variant=0):
     col = sum(k[i] * row[i:i + H, :] for i in range(7))                            # 16.16
     col = np.minimum(col, 0xFFFFFFFF)
     return np.minimum((col + 32768) >> 16, 255).astype(np.uint8)
+
+
+# ---- rule 9: intensity-centroid orientation, cv::fastAtan2 (scalar form), every operation rounded to float32 ----------------------------
+_UMAX = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+_F = np.float32
+
+
+def fast_atan2_deg(y, x):
+    """cv::fastAtan2(y, x) for float32 arrays, degrees in [0, 360]."""
+    y, x = np.asarray(y, _F), np.asarray(x, _F)
+    s = _F(180.0 / np.pi)
+    p1, p3, p5, p7 = _F(0.9997878412794807) * s, _F(-0.3258083974640975) * s, _F(0.1555786518463281) * s, _F(-0.04432655554792128) * s
+    eps = _F(2.2204460492503131e-16)
+    ax, ay = np.abs(x), np.abs(y)
+    swap = ax < ay
+    num, den = np.where(swap, ax, ay), np.where(swap, ay, ax) + eps
+    with np.errstate(invalid="ignore", divide="ignore"):
+        c = (num / den).astype(_F)
+    c2 = c * c
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+    a = np.where(swap, _F(90.0) - a, a).astype(_F)
+    a = np.where(x < 0, _F(180.0) - a, a).astype(_F)
+    a = np.where(y < 0, _F(360.0) - a, a).astype(_F)
+    return a
+
+
+def ic_angle(img, xs, ys):
+    """orb_extractor::ic_angle at integer keypoint positions of one (unblurred) level: integer moments over the radius-15 disc."""
+    I = np.asarray(img, np.uint8).astype(np.int64)
+    xs, ys = np.asarray(xs, np.int64), np.asarray(ys, np.int64)
+    m10 = np.zeros(len(xs), np.int64)
+    m01 = np.zeros(len(xs), np.int64)
+    for v in range(-15, 16):
+        um = _UMAX[abs(v)]
+        u = np.arange(-um, um + 1)
+        row = I[(ys + v)[:, None], xs[:, None] + u[None, :]]
+        m10 += (row * u[None, :]).sum(1)
+        m01 += v * row.sum(1)
+    return fast_atan2_deg(m01.astype(_F), m10.astype(_F))
+
+
+# ---- rule 11: steered rBRIEF-256 on the blurred level ---------------------------------------------------------------------------------------
+def _util_cos(v):
+    """openvslam::util::cos: reduction by floor(v / 2 pi), even polynomial on [0, pi / 2], float32 throughout."""
+    v = np.asarray(v, _F)
+    two_pi, half_pi, pi, three_half_pi = _F(6.28318530717958647692), _F(1.57079632679489661923), _F(3.14159265358979323846), _F(4.71238898038468985769)
+    v = v - np.floor(v * _F(0.15915494309189533577)).astype(_F) * two_pi
+    v = np.abs(v).astype(_F)
+
+    def poly(t):
+        t2 = t * t
+        return _F(0.99940307) + t2 * (_F(-0.49558072) + _F(0.03679168) * t2)
+
+    return np.where(v < half_pi, poly(v), np.where(v < pi, -poly(pi - v), np.where(v < three_half_pi, -poly(v - pi), poly(two_pi - v)))).astype(_F)
+
+
+def orb_descriptors(blurred, xs, ys, angles_deg, pattern):
+    """compute_orb_descriptor for keypoints (xs, ys) of one blurred level; pattern = the 256 x 4 int8 rBRIEF table."""
+    B = np.asarray(blurred, np.uint8)
+    xs, ys = np.asarray(xs, np.int64), np.asarray(ys, np.int64)
+    rad = (np.asarray(angles_deg, _F).astype(np.float64) * np.pi / 180.0).astype(_F)   # double product and quotient, ONE rounding to float
+    c, s = _util_cos(rad), _util_cos(_F(1.57079632679489661923) - rad)
+    pat = np.asarray(pattern, np.int64).reshape(256, 4).astype(_F)
+
+    def sample(px, py):   # (256,) pattern coordinates against (n,) keypoints -> (n, 256) intensities
+        fx, fy = px[None, :], py[None, :]
+        dy = np.rint(fx * s[:, None] + fy * c[:, None]).astype(np.int64)
+        dx = np.rint(fx * c[:, None] - fy * s[:, None]).astype(np.int64)
+        return B[ys[:, None] + dy, xs[:, None] + dx]
+
+    bits = sample(pat[:, 0], pat[:, 1]) < sample(pat[:, 2], pat[:, 3])
+    return np.packbits(bits, axis=1, bitorder="little")

@@ -108,3 +108,61 @@ def test_golden_keypoints_follow_from_the_second_restatement(oracle):
         n_checked += len(kl)
         assert len(surv) > 0 and len(x20) <= len(x7)
     assert n_checked == len(kps)
+
+
+def test_orientation_and_descriptor_second_restatement(oracle):
+    """ic_angle + cv::fastAtan2 (rule 9) and the steered rBRIEF (rule 11) in float32 numpy against the oracle's single-keypoint functions,
+    on random positions of a noisy image and a synthetic frame: angles by bit pattern, descriptors by byte."""
+    rng = np.random.default_rng(21)
+    pat = oracle.orb_pattern()
+    for img in (IMAGES["white_noise"], IMAGES["synth_752x480"]):
+        H, W = img.shape
+        xs = rng.integers(22, W - 22, 300)
+        ys = rng.integers(22, H - 22, 300)
+        tab = oracle.orb_tables(oracle.make_params(1000))
+        got = nv.ic_angle(img, xs, ys)
+        want = np.array([oracle.ic_angle(img, int(x), int(y), tab["u_max"]) for x, y in zip(xs, ys)], np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        blurred = oracle.gaussian_blur(img)
+        gd = nv.orb_descriptors(blurred, xs, ys, want, pat)
+        wd = np.stack([oracle.orb_descriptor(blurred, int(x), int(y), float(a)) for x, y, a in zip(xs, ys, want)])
+        assert np.array_equal(gd, wd)
+    # fastAtan2 on axes, diagonals, zero and tiny arguments
+    yy = np.array([0, 0, 1, -1, 1, -1, 1e-30, 5, -3, 0, 7], np.float32)
+    xx = np.array([0, 1, 0, 0, 1, -1, -1e-30, 5, 3, -2, -7], np.float32)
+    import ctypes as C
+    f = oracle.lib().ovo_fast_atan2
+    f.restype = C.c_float
+    f.argtypes = [C.c_float, C.c_float]
+    want = np.array([f(float(a), float(b)) for a, b in zip(yy, xx)], np.float32)
+    assert np.array_equal(nv.fast_atan2_deg(yy, xx).view(np.uint32), want.view(np.uint32))
+
+
+def test_golden_angles_and_descriptors_follow_from_the_numpy_chain(oracle):
+    """End to end with the oracle's C code out of the loop (only its keypoint POSITIONS, i.e. the cell loop and the quad-tree, are taken from
+    the golden file): numpy pyramid -> numpy ic_angle / fastAtan2 -> numpy blur -> numpy rBRIEF == the committed golden angles and descriptors of
+    all 1008 keypoints of tests/golden/orb_752x480_seed0.npz."""
+    from openvslam_amd.feature import KP_DTYPE
+    g = np.load(os.path.join(GOLDEN, "orb_752x480_seed0.npz"))
+    kps = g["kps_a"].view(KP_DTYPE).reshape(-1) if g["kps_a"].dtype != KP_DTYPE else g["kps_a"]
+    desc = g["desc_a"]
+    img = synth.synth_frame(480, 752, seed=0)
+    lr, lc = oracle.pyramid_sizes(oracle.make_params(1000), 480, 752)
+    sf = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2))]).astype(np.float32)).astype(np.float32)
+    pat = oracle.orb_pattern()
+    cur = img
+    n = 0
+    for level in range(8):
+        if level:
+            cur = nv.resize_linear_u8(cur, int(lr[level]), int(lc[level]))
+        sel = np.nonzero(kps["octave"] == level)[0]
+        if not len(sel):
+            continue
+        xs = np.rint(kps["x"][sel] / sf[level]).astype(int)
+        ys = np.rint(kps["y"][sel] / sf[level]).astype(int)
+        ang = nv.ic_angle(cur, xs, ys)
+        assert np.array_equal(ang.view(np.uint32), kps["angle"][sel].view(np.uint32)), level
+        d = nv.orb_descriptors(nv.gaussian_blur_7x7(cur), xs, ys, ang, pat)
+        assert np.array_equal(d, desc[sel]), level
+        n += len(sel)
+    assert n == len(kps) == 1008
