@@ -38,7 +38,7 @@ struct image_bounds {
     float min_x_ = 0, max_x_ = 0, min_y_ = 0, max_y_ = 0;
 };
 enum class setup_type_t { Monocular = 0, Stereo = 1, RGBD = 2 };
-enum class model_type_t { Perspective = 0, Fisheye = 1, Equirectangular = 2 };
+enum class model_type_t { Perspective = 0, Fisheye = 1, Equirectangular = 2, RadialDivision = 3 };
 class base {
 public:
     setup_type_t setup_type_ = setup_type_t::Monocular;

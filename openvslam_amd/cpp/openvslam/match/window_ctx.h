@@ -75,10 +75,10 @@ inline ovs_grid_params grid_of(const camera::base* cam) {
 }
 
 inline ovs_camera camera_of(const camera::base* cam) {
-    // the device reprojects with camera::perspective or camera::equirectangular only; a fisheye frame must not silently be treated
-    // as a pinhole (INTEGRATION.md lists the unsupported models)
-    if (cam->model_type_ == camera::model_type_t::Fisheye)
-        throw std::runtime_error("camera::model_type_t::Fisheye: reproject_to_image is not implemented on the device");
+    // camera::fisheye and camera::radial_division: upstream undistorts a frame's keypoints in its constructor and both models'
+    // reproject_to_image are the pinhole projection with the model's fx, fy, cx, cy on those undistorted coordinates (the distortion lives in
+    // undistort_keypoints / convert_keypoints_to_bearings only, outside this path) -- oracle/ORACLE_SPEC.md rule 31. So on the device they ARE
+    // the perspective model; only camera::equirectangular projects differently.
     ovs_camera c;
     c.model = cam->model_type_ == camera::model_type_t::Equirectangular ? 1 : 0;
     c.setup = (int32_t)cam->setup_type_;

@@ -116,9 +116,8 @@ void local_bundle_adjuster::optimize(data::keyframe* curr_keyfrm, bool* const fo
     std::vector<uint8_t> pose_fixed;
     const camera::base* camera = curr_keyfrm->camera_;
     auto add_keyfrm = [&](data::keyframe* keyfrm, const bool is_constant) {
-        // upstream's reproj_edge_wrapper switches on keyfrm->camera_->model_type_: perspective and equirectangular edges exist on the device
-        if (keyfrm->camera_->model_type_ != camera::model_type_t::Perspective && keyfrm->camera_->model_type_ != camera::model_type_t::Equirectangular)
-            throw std::runtime_error("local_bundle_adjuster: camera::model_type_t::Fisheye edges are not implemented (INTEGRATION.md)");
+        // upstream's reproj_edge_wrapper switches on keyfrm->camera_->model_type_: Perspective, Fisheye and RadialDivision use the perspective
+        // reprojection edges (undistorted keypoints, the model's fx, fy, cx, cy), Equirectangular its own (ORACLE_SPEC rule 31)
         if (keyfrm->camera_ != camera &&
             (keyfrm->camera_->model_type_ != camera->model_type_ || keyfrm->camera_->fx_ != camera->fx_ || keyfrm->camera_->fy_ != camera->fy_ ||
              keyfrm->camera_->cx_ != camera->cx_ || keyfrm->camera_->cy_ != camera->cy_ || keyfrm->camera_->cols_ != camera->cols_ ||

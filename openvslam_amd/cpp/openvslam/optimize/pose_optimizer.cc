@@ -14,11 +14,9 @@ namespace optimize {
 
 unsigned int pose_optimizer::optimize(data::frame& frm) const {
     if (num_trials_ != 4 || num_each_iter_ != 10) throw std::runtime_error("pose_optimizer: only upstream's 4 x 10 schedule is implemented");
-    // upstream's `switch (frm.camera_->model_type_)`: perspective and equirectangular pose_opt edges exist on the device; fisheye frames
-    // (perspective edges on undistorted keypoints upstream) are out of scope
+    // upstream's `switch (frm.camera_->model_type_)`: Perspective, Fisheye and RadialDivision all create perspective_pose_opt_edge (mono / stereo)
+    // with the model's fx, fy, cx, cy -- the keypoints are undistorted --, Equirectangular its own edge (ORACLE_SPEC rule 31)
     const bool equirect = frm.camera_->model_type_ == camera::model_type_t::Equirectangular;
-    if (!equirect && frm.camera_->model_type_ != camera::model_type_t::Perspective)
-        throw std::runtime_error("pose_optimizer: camera::model_type_t::Fisheye is not implemented (see INTEGRATION.md)");
     const unsigned int n = frm.num_keypts_;
     std::vector<ovs_pose_obs> obs;
     std::vector<unsigned int> idx_of;

@@ -203,6 +203,16 @@ int main(int argc, char** argv) {
     char line[160];
     std::snprintf(line, sizeof(line), "%d iterations of (tracking thread || mapping thread) on shared caches: every result equals the single-threaded one", iters);
     expect(mismatches.load() == 0, line);
+    // ---- camera::fisheye / radial_division: pinhole reprojection on undistorted keypoints, i.e. the perspective results (ORACLE_SPEC rule 31)
+    for (const auto model : {camera::model_type_t::Fisheye, camera::model_type_t::RadialDivision}) {
+        s.cam.model_type_ = model;
+        Objects o(s, 0);
+        Counts c;
+        tracking_calls(s, o.fa, *o.kf, c);
+        mapping_calls(s, *o.kf, *o.kt1, *o.kt2, c);
+        expect(c == ref, model == camera::model_type_t::Fisheye ? "a fisheye camera gives the perspective results (no refusal)" : "a radial-division camera gives the perspective results");
+    }
+    s.cam.model_type_ = camera::model_type_t::Perspective;
     // ---- device 1
     if (ovs_device_count() >= 2) {
         Objects o(s, 1);
