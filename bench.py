@@ -64,6 +64,45 @@ def algorithmic_bytes(rows, cols, n_kp_frame, n_cand_frame):
     }
 
 
+def live_pmc_traffic(stage_kernel_prefix, batch=128, timeout_s=150):
+    """HBM-side bytes and VALU wave-instructions per launch of the kernels whose name starts with `stage_kernel_prefix`, measured NOW: three
+    rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU; each counter in its own run, with --kernel-trace only) over a short child run of this script (2 steps + 1 warm-up, `batch` frames per
+    launch, one stream, one FAST launch per step). Units and the gfx950 correction as tools/pmc_summary.py: both counters in KiB, FETCH_SIZE reports half
+    the bytes of a coalesced read stream (profiles/r01_hbm_calib.txt). Returns ({"bytes", "insts_valu", "batch"} per launch at `batch` frames, note) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-ba", "--overlap", "0",
+             "--batch", str(batch), "--fast-split", "0", "--live-pmc", "0"]
+    means = {}
+    with tempfile.TemporaryDirectory(prefix="ovs_pmc_", dir="/tmp") as td:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+            out = os.path.join(td, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--"] + child
+            try:
+                pr = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            except Exception as ex:   # timeout, OSError
+                return None, "rocprofv3 --pmc %s: %r" % (counter, ex)
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        name = row.get("Kernel_Name", "").replace("void ", "")
+                        if name.startswith(stage_kernel_prefix) and row.get("Counter_Name") == counter:
+                            vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "rocprofv3 --pmc %s: no %s dispatches in the output (rc %d)" % (counter, stage_kernel_prefix, pr.returncode)
+            means[counter] = sum(vals) / len(vals)
+    return {"bytes": int((2.0 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024.0), "insts_valu": int(means["SQ_INSTS_VALU"]), "batch": batch}, \
+        "%d frames per launch" % batch
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +119,9 @@ def main():
     ap.add_argument("--match-first", type=int, default=0, help="1: the matcher's stream gets the high-priority queue instead of the extraction's (A/B)")
     ap.add_argument("--overlap", type=int, default=1, help="1: matching of step k runs on a second stream under the extraction of step "
                                                             "k+1 (double-buffered outputs); 0: one stream, strictly serial")
+    ap.add_argument("--live-pmc", type=int, default=1, help="1: roofline.traffic from rocprofv3 --pmc passes THIS run spawns (two short child runs of this "
+                                                             "script under the profiler, FETCH_SIZE and WRITE_SIZE separately); falls back to the committed "
+                                                             "profiles/pmc_traffic.json when rocprofv3 is missing, fails or times out; 0: the committed file only")
     args = ap.parse_args()
 
     import torch
@@ -333,8 +375,9 @@ def main():
         # both sets of HIP-event times are printed
         dom = max(iso_ms, key=lambda k: iso_ms[k])
         achieved = ab[dom] * B / (iso_ms[dom] * 1e-3) / 1e9
-        # roofline.traffic: HBM-side bytes per launch from rocprofv3 PMC passes. Counters cannot be collected from inside this process, so
-        # the value is READ from the committed summary of the same command (tools/gpu_pmc.sh -> profiles/pmc_traffic.json) and labelled.
+        # roofline.traffic: HBM-side bytes per launch from rocprofv3 PMC passes. Counters cannot be collected from inside this process: at
+        # N = 1 the run spawns short child runs of itself under rocprofv3 (live_pmc_traffic, --live-pmc 1) after the timed region; the committed
+        # summary of the same command (tools/gpu_pmc.sh -> profiles/pmc_traffic.json) is the labelled fallback, and the source of the other stages.
         traffic = None
         pmc = {}
         pmc_stale = None
@@ -356,13 +399,30 @@ def main():
                 traffic = int(pmc[dom] * pmc_scale) if dom in pmc else None
             except Exception:
                 traffic = None
+        traffic_live_note = None
+        live_valu = None
+        if args.live_pmc and world == 1 and not one_device and dom == "fast":
+            try:
+                live, note = live_pmc_traffic("ovs::k_fast_cells")
+            except Exception as ex_:   # a side measurement must never cost the headline line
+                live, note = None, repr(ex_)
+            if live is not None:
+                traffic = int(live["bytes"] * (Bc / float(live["batch"])))
+                traffic_live_note = ("measured in THIS run: rocprofv3 --pmc child passes of `bench.py --steps 2 --overlap 0 --fast-split 0` (FETCH_SIZE, "
+                                     "WRITE_SIZE, SQ_INSTS_VALU each in its own pass, --kernel-trace only), (2*FETCH + WRITE) KiB per k_fast_cells launch "
+                                     "at %s, scaled to %d" % (note, Bc))
+                live_valu = int(live["insts_valu"] * (Bc / float(live["batch"])))
+            else:
+                traffic_live_note = "live PMC passes unavailable (%s)" % note
         roof = {"bound": "hbm", "kernel": {"pyramid": "k_resize_linear_u8 (x7)", "fast": "k_fast_cells", "tree": "k_tree",
                                            "describe": "k_describe", "match_near": "k_hamming_near",
                                            "match_resolve": "k_bf_resolve"}[dom],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --overlap 0`, "
-                                                      "(2*FETCH + WRITE) KiB, collected at %s frames per launch and scaled to %d; not measured in this run)"
-                                                      % (pmc.get("batch", "the same"), Bc) if traffic else pmc_stale,
+                "traffic": traffic,
+                "traffic_source": traffic_live_note if live_valu is not None else
+                ((traffic_live_note + "; " if traffic_live_note else "") +
+                 ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --overlap 0`, (2*FETCH + WRITE) KiB, collected at "
+                  "%s frames per launch and scaled to %d; not measured in this run)" % (pmc.get("batch", "the same"), Bc) if traffic else str(pmc_stale))),
                 "algorithmic_bytes_per_launch": int(ab[dom] * Bc), "launch_ms": round(iso_ms[dom] / n_chain, 5),
                 "launch_ms_source": "HIP events on the launch stream, kernel alone on the GPU (4 launches after the timed region, same inputs)",
                 "launches_per_step": n_chain}
@@ -402,6 +462,8 @@ def main():
                                     "note": "the selectable popcount form of the all-pairs stage (ovs_matcher_set_near_path); not the form the "
                                             "timed region runs", "same_pairs_as_matrix_path": popc_same},
         }
+        if live_valu is not None:
+            valu_counts["fast"] = live_valu
         if valu_counts.get("fast"):
             fast_s = iso_ms["fast"] / n_chain * 1e-3
             # one VALU wave-instruction occupies a SIMD's issue slot for 4 cycles: on this kernel SQ_ACTIVE_INST_VALU (busy quad-cycles) equals
@@ -410,7 +472,8 @@ def main():
             roofline_valu["k_fast_cells"] = {"unit": "VALU wave-instructions/s", "achieved": round(valu_counts["fast"] / fast_s, 1),
                                              "peak": round(simd_hz / 4.0, 1), "frac": round(valu_counts["fast"] / fast_s / (simd_hz / 4.0), 4),
                                              "launch_ms_alone": round(fast_s * 1e3, 5), "insts_valu_per_launch": valu_counts["fast"],
-                                             "insts_source": "profiles/pmc_traffic.json (SQ_INSTS_VALU pass)",
+                                             "insts_source": "rocprofv3 --pmc SQ_INSTS_VALU child pass of this run" if live_valu is not None
+                                             else "profiles/pmc_traffic.json (SQ_INSTS_VALU pass)",
                                              "floor_model": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per VALU wave-instruction (the counter's own "
                                                             "busy measure: SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU on this kernel); LDS pipe busy 47 % "
                                                             "beside it (SQ_LDS_IDX_ACTIVE, a third of it bank conflicts)"}

@@ -30,7 +30,6 @@ const Tuning& tuning() {
         Tuning v;
         v.fast_cells = std::max(0, num("OVS_FAST_CELLS", 0));
         v.fast_pad_lds = std::max(0, num("OVS_FAST_PAD_LDS", 0));
-        v.fast_bufs = num("OVS_FAST_BUFS", 1) == 2 ? 2 : 1;
         v.fast_timing = std::getenv("OVS_FAST_TIMING") != nullptr;
         v.describe_xcd = num("OVS_DESCRIBE_XCD", 1) != 0;
         v.resolve_wide_from = num("OVS_RESOLVE_WIDE_FROM", 1024);

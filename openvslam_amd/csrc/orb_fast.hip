@@ -201,17 +201,17 @@ __device__ __forceinline__ void glds4(const uint8_t* base, uint32_t voff, uint32
 __device__ __forceinline__ void wait_tile() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
 
-// LDS per workgroup: raw tile(s) 5.6 KB each + R tile 5.6 KB + score map 4.75 KB + pooled list 4 KB + group buffer 1 KB.
-//   kBufs = 1 (21.1 KB, seven workgroups per CU, 72 VGPRs): the next cell's tile is requested when the current cell's last tile read (the exact
-//              scoring; the NMS survivor list aliases the R tile) is behind every wave, and lands under the cell's tail and the other six workgroups;
-//   kBufs = 2 (26.7 KB, six workgroups per CU, 84 VGPRs): requested a whole cell ahead into the other buffer.
+// LDS per workgroup: raw tile 5.6 KB + R tile 5.6 KB + score map 4.75 KB + pooled list 4 KB + group buffer 1 KB = 21.1 KB, seven workgroups
+// per CU, 72 VGPRs. The next cell's tile is requested when the current cell's last tile read (the exact scoring; the NMS survivor list aliases
+// the R tile) is behind every wave, and lands under the cell's tail and the other six workgroups. (A second raw-tile buffer, requested a whole
+// cell ahead -- 26.7 KB, six workgroups per CU -- measured 5-10 % slower in round 4 and is gone.)
 // kTiming: wave 0 accumulates shader cycles per phase into tstats (tuning aid, OVS_FAST_TIMING).
-template <int kBufs, bool kTiming>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kBufs == 1 ? 7 : 6, kBufs == 1 ? 7 : 6))) void k_fast_cells(
+template <bool kTiming>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_fast_cells(
     const FrameGeo* __restrict__ geo, const CellDesc* __restrict__ cell_tab, const uint8_t* __restrict__ img0, size_t stride0, size_t frame_stride0,
     const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes, uint64_t* __restrict__ cand, size_t cand_frame_entries, uint32_t* __restrict__ cand_count,
     const uint8_t* __restrict__ mask, int batch, uint32_t batch_magic, int cell_lo, int n_cells, int cells_per_wg, unsigned long long* __restrict__ tstats) {
-    __shared__ __attribute__((aligned(16))) uint32_t tiles[kBufs][kTileRowsMax][kTileWords];
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[1][kTileRowsMax][kTileWords];
     __shared__ __attribute__((aligned(16))) uint32_t smap[kSmapRows][kSmapWords];
     __shared__ __attribute__((aligned(16))) uint32_t rtile[kTileRowsMax][kTileWords];
     __shared__ uint16_t clist[kListCap];                // pixels that passed the diameter test, (y << 8) | x, all four waves
@@ -340,13 +340,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kBufs == 1 
                 lr_next = level_ref(nl);
                 chunk_offsets(lr_next);
             }
-            issue_tile(lr_next, dn_x, dn_y, lds_tile0 + (kBufs == 2 ? (uint32_t)((k + 1) & 1) * (uint32_t)kTileBytes : 0u));
+            issue_tile(lr_next, dn_x, dn_y, lds_tile0);
         }
     };
 
     for (int k = 0; k < n_here; ++k) {
         FAST_MARK(0)   // loop overhead / previous cell's tail
-        uint32_t(*const tile)[kTileWords] = tiles[kBufs == 2 ? (k & 1) : 0];
+        uint32_t(*const tile)[kTileWords] = tiles[0];
         const uint8_t* const tbytes = reinterpret_cast<const uint8_t*>(&tile[0][0]);
         const uint32_t dc_x = dn_x, dc_y = dn_y;   // this cell's record
         const LevelRef lr = lr_next;
@@ -370,7 +370,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kBufs == 1 
         }
         lds_barrier();
         FAST_MARK(2)   // R pass + clears + barrier 1
-        if (kBufs == 2) request_next(k);   // into the other buffer: its last readers (cell k - 1's scoring) are behind the barrier above
         FAST_MARK(3)   // next cell's record + copy issue
 
         const int min_x = (int)(dc_x & 0xffffu), min_y = (int)(dc_x >> 16);
@@ -541,7 +540,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kBufs == 1 
         }
         // one buffer: the raw tile's last readers (the exact scoring of the last pass) are behind barrier 4 -- request the next cell's tile now;
         // it lands under the tail below and under the other workgroups of the CU
-        if (kBufs == 1) request_next(k);
+        request_next(k);
         if (!skip) {
             // ---- 5. the cell's survivors join the group's buffer; the (frame, level) list is reserved ONCE per group (or when the buffer is
             //      full / the level changes): the reservation's global atomic round trip, a fifth of a cell's time when every cell paid it, is
@@ -635,29 +634,21 @@ hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t*
         std::lock_guard<std::mutex> lock(mu);
         if (!d_t[dev] && hipMalloc(&d_t[dev], 16 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_t[dev], 0, 16 * sizeof(unsigned long long), s);
-        if (tn.fast_bufs == 2)
-            hipLaunchKernelGGL((k_fast_cells<2, true>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
-                               d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, d_t[dev]);
-        else
-            hipLaunchKernelGGL((k_fast_cells<1, true>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
-                               d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, d_t[dev]);
+        hipLaunchKernelGGL((k_fast_cells<true>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
+                           d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, d_t[dev]);
         unsigned long long h_t[16];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h_t, d_t[dev], sizeof(h_t), hipMemcpyDeviceToHost);
         static const char* nm[12] = {"loop", "tile-wait", "rpass+bar1", "next-issue", "pretest", "pool", "bar2", "score", "bar3", "nms", "bar4", "append+bar5"};
         unsigned long long tot = 0;
         for (int i = 0; i < 12; ++i) tot += h_t[i];
-        fprintf(stderr, "[k_fast_cells<%d> timing] %llu workgroups x %d cells, %.0f cycles per cell:", tn.fast_bufs, h_t[12], cells_per_wg,
+        fprintf(stderr, "[k_fast_cells timing] %llu workgroups x %d cells, %.0f cycles per cell:", h_t[12], cells_per_wg,
                 (double)tot / ((double)h_t[12] * cells_per_wg + 1e-9));
         for (int i = 0; i < 12; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)h_t[i] / (double)(tot + 1));
         fprintf(stderr, "\n");
         return hipGetLastError();
     }
-    if (tn.fast_bufs == 2)
-        hipLaunchKernelGGL((k_fast_cells<2, false>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
-                           d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, (unsigned long long*)nullptr);
-    else
-        hipLaunchKernelGGL((k_fast_cells<1, false>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
+    hipLaunchKernelGGL((k_fast_cells<false>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
                            d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, (unsigned long long*)nullptr);
     return hipGetLastError();
 }

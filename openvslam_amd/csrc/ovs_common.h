@@ -117,7 +117,6 @@ constexpr int kMaxTuningDevices = 16;
 struct Tuning {
     int fast_cells;        // OVS_FAST_CELLS: consecutive cells per k_fast_cells workgroup (0 = by launch size)
     int fast_pad_lds;      // OVS_FAST_PAD_LDS: extra dynamic LDS per k_fast_cells workgroup (occupancy probe)
-    int fast_bufs;         // OVS_FAST_BUFS: 1 (default) or 2 raw-tile buffers in k_fast_cells
     bool fast_timing;      // OVS_FAST_TIMING: per-phase cycle counts of k_fast_cells, printed per launch
     bool describe_xcd;     // OVS_DESCRIBE_XCD=0: plain frame-major order in k_describe
     int resolve_wide_from; // OVS_RESOLVE_WIDE_FROM: queries from which a resolver round takes 512 of them

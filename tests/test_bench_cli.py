@@ -70,3 +70,35 @@ def test_two_ranks_code_path_on_one_device():
     assert d["keypoints_per_frame"] > 1500 and d["value"] > 0
     for sec in ("local_ba", "local_ba_large"):
         assert d[sec]["allreduce_bytes"] > 0 and d[sec]["ms_per_linearisation"] > 0 and "all-reduce" in d[sec]["exchange"]
+
+
+def test_live_pmc_parses_the_profilers_counter_csv(tmp_path, monkeypatch):
+    """bench.py's own PMC passes (roofline.traffic measured in the run): the parser against a stand-in `rocprofv3` that writes the csv layout of
+    rocprofv3 --pmc (one row per dispatch and counter); (2 * FETCH_SIZE + WRITE_SIZE) KiB per k_fast_cells launch, other kernels ignored; a
+    profiler that fails or produces nothing gives (None, reason), never an exception."""
+    import stat
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("""#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+out, counter = a[a.index("-d") + 1], a[a.index("--pmc") + 1]
+if os.environ.get("FAKE_ROCPROF_FAIL"):
+    sys.exit(1)
+os.makedirs(os.path.join(out, "host", "1234"), exist_ok=True)
+val = {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 48.0, "SQ_INSTS_VALU": 7.0e6}[counter]
+with open(os.path.join(out, "host", "1234", "p_counter_collection.csv"), "w") as f:
+    f.write('"Correlation_Id","Dispatch_Id","Agent_Id","Kernel_Name","Counter_Name","Counter_Value"\\n')
+    for i in range(3):
+        f.write('%d,%d,"Agent 4","void ovs::k_fast_cells<false>(ovs::FrameGeo const*, int)","%s",%f\\n' % (i, i, counter, val + i - 1))
+        f.write('%d,%d,"Agent 4","ovs::k_describe(ovs::FrameGeo const*)","%s",%f\\n' % (i, i, counter, 5.0e9))
+""")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    got, note = bench.live_pmc_traffic("ovs::k_fast_cells", batch=64, timeout_s=30)
+    assert got == {"bytes": int((2 * 1000.0 + 48.0) * 1024), "insts_valu": 7000000, "batch": 64} and "64 frames" in note
+    monkeypatch.setenv("FAKE_ROCPROF_FAIL", "1")
+    got, note = bench.live_pmc_traffic("ovs::k_fast_cells", batch=64, timeout_s=30)
+    assert got is None and "FETCH_SIZE" in note

@@ -17,11 +17,9 @@ def kernels():
 
 
 def test_hot_kernels_have_no_scratch_and_keep_their_occupancy_tier(kernels):
-    fast = kernels["ovs::k_fast_cells<1, false>"]
+    fast = kernels["ovs::k_fast_cells<false>"]
     # seven 256-thread workgroups per CU: <= 72 registers (512 / 7 waves per SIMD) and <= 160 KiB / 7 of LDS
     assert fast["scratch"] == 0 and fast["vgpr"] + fast["agpr"] <= 72 and fast["lds"] <= 160 * 1024 // 7
-    fast2 = kernels["ovs::k_fast_cells<2, false>"]   # two raw-tile buffers: six workgroups per CU
-    assert fast2["scratch"] == 0 and fast2["vgpr"] + fast2["agpr"] <= 84 and fast2["lds"] <= 160 * 1024 // 6
     desc = kernels["ovs::k_describe"]
     assert desc["scratch"] == 0 and desc["vgpr"] <= 32 and desc["lds"] <= 6400          # 25 one-wave workgroups per CU by LDS
     tree = kernels["ovs::k_tree<512>"]

@@ -1,5 +1,5 @@
 """A/B of kernel variants: the same device-resident batch through ovs_orb_extract_batch_dev under different tuning switches
-(OVS_FAST_BUFS, OVS_FAST_CELLS, ... -- the library reads them ONCE per process, so every variant runs in its own child process),
+(OVS_FAST_CELLS, OVS_FAST_TIMING, ... -- the library reads them ONCE per process, so every variant runs in its own child process),
 per-stage HIP-event times with every kernel alone on the GPU, and a hash comparison of all outputs between the variants.
 Usage (GPU box): python tools/ab_extract.py [batch] [reps] [VAR=VAL,VAR=VAL ...]   (each further argument is one variant's environment)"""
 import ctypes as C
@@ -59,7 +59,7 @@ if __name__ == "__main__":
         sys.exit(0)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-    variants = sys.argv[3:] or ["", "OVS_FAST_BUFS=2"]
+    variants = sys.argv[3:] or ["", "OVS_FAST_CELLS=4"]
     ref = None
     for v in variants:
         env = dict(os.environ, OVS_AB_CHILD="1")
