@@ -69,14 +69,15 @@ def fuzz_extract(rng, n_cases, log, max_rows=1300, max_cols=2000):
             log("extract: create rejected (%s) for nfeat=%d sf=%.2f L=%d" % (e, nfeat, sf, L))
             continue
         ox = ob.OrbExtractor(ob.make_params(nfeat, sf, L, ini, mn), threads=8)
-        # ORACLE_SPEC rules 6 / 7 / 10 as run-time variants: a third of the handles run a random non-default combination on BOTH sides
-        variant = (3, 0, 0)
+        # ORACLE_SPEC rules 6 / 7 / 10 / 11 (trig) as run-time variants: a third of the handles run a random non-default combination on BOTH sides
+        variant = (3, 0, 0, 0)
         if rng.random() < 0.35:
-            variant = (int(rng.choice([3, 1])), int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+            variant = (int(rng.choice([3, 1])), int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2)))
             for e in (ex, ox):
                 e.set_variant("tree_switch_factor", variant[0])
                 e.set_variant("tree_tie_order", variant[1])
                 e.set_variant("blur_taps", variant[2])
+                e.set_variant("trig", variant[3])
         for _ in range(3):   # the same handle across sizes: geometry rebuild
             rows = int(rng.integers(lo, max_rows + 1))
             cols = int(rng.integers(lo, max_cols + 1))
@@ -111,8 +112,8 @@ def fuzz_extract(rng, n_cases, log, max_rows=1300, max_cols=2000):
                 np.array_equal(gk[f].view(np.uint32) if gk[f].dtype == np.float32 else gk[f],
                                wk[f].view(np.uint32) if wk[f].dtype == np.float32 else wk[f])
                 for f in ("x", "y", "size", "angle", "response", "octave", "class_id"))
-            log("extract %4dx%-4d L=%d sf=%.2f N=%-4d thr=%d/%d kind=%d mask=%d variant=%d%d%d -> %4d kp %s (%.1fs)" % (
-                cols, rows, L, sf, nfeat, ini, mn, kind, mask is not None, variant[0], variant[1], variant[2], len(wk),
+            log("extract %4dx%-4d L=%d sf=%.2f N=%-4d thr=%d/%d kind=%d mask=%d variant=%d%d%d%d -> %4d kp %s (%.1fs)" % (
+                cols, rows, L, sf, nfeat, ini, mn, kind, mask is not None, variant[0], variant[1], variant[2], variant[3], len(wk),
                 "ok" if ok else "MISMATCH", time.time() - t))
             if not ok:
                 log("  counts hip %d oracle %d; per level hip %s oracle %s" % (len(gk), len(wk), list(ex.debug_level_counts()),
