@@ -631,7 +631,10 @@ ovs_status ovs_bow_transform_dev(ovs_vocab* v, const uint8_t* d_desc, const int3
  * otherwise sqrtf(7.81473f), as upstream picks it from keyfrm->camera_->setup_type_), the chi-square (5.99146f mono / 7.81473f stereo edge) /
  * depth-positive outlier test that moves edges to level 1 and drops the kernels, optimizer.optimize(num_second_iter), and the final
  * outlier test. g2o's Levenberg-Marquardt schedule and BlockSolver_6_3's landmark elimination are restated (oracle/ORACLE_SPEC.md
- * rules 25, 28); linearisations run on the device (ba_linearize kernels), the reduced camera system is solved on the host.
+ * rules 25, 28); linearisations run on the device (ba_linearize kernels), and since round 4 so does the solve of the reduced camera
+ * system (csrc/ba_solve.hip: one-workgroup blocked Cholesky on the f64 matrix cores; an LM trial reads back three scalars and a flag).
+ * ovs_local_ba_set_solver(1) selects the host Cholesky of rounds 1-3 instead (what BASELINE's north star describes; also the path of
+ * systems beyond 1024 unknowns): same schedule, results equal to ~1e-10 relative (tests/test_gpu_ba.py).
  * poses (n_pose x 7, in/out; fixed ones untouched), points (n_pt x 3, in/out), mono / stereo edges as for ovs_ba_linearize(_stereo).
  * force_stop_flag: NULL or the caller's flag, polled between iterations. mono_outlier / stereo_outlier: 1 for the observations the
  * caller must erase. info: NULL or 6 doubles {robust chi2 before / after round 1, chi2 before / after round 2, iterations 1, 2}. */
@@ -646,6 +649,12 @@ ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* p
 ovs_status ovs_local_ba_optimize_equirect(int32_t device, double* poses, const uint8_t* pose_fixed, int32_t n_pose, double* points, int32_t n_pt,
                                           const ovs_ba_edge* mono, int32_t n_mono, int32_t cols, int32_t rows, int32_t num_first_iter,
                                           int32_t num_second_iter, const volatile uint8_t* force_stop_flag, uint8_t* mono_outlier, double* info);
+/* where ovs_local_ba_optimize(_equirect) solves the reduced camera system: 0 = device (default), 1 = host. Process-wide. */
+ovs_status ovs_local_ba_set_solver(int32_t where);
+int32_t ovs_local_ba_get_solver(void);
+/* The device solver alone on host arrays (test entry): S (n x n, row-major, symmetric positive definite; the lower triangle is read),
+ * rhs (n) -> x (n); n <= 1024. OVS_ERR_INVALID when a pivot is not positive. */
+ovs_status ovs_ba_dense_solve(int32_t device, const double* S, const double* rhs, int32_t n, double* x);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Pose-only optimisation of one frame.  replaces: unsigned int optimize::pose_optimizer::optimize(data::frame& frm) const

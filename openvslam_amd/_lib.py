@@ -112,6 +112,9 @@ SYMBOLS = {
     "ovs_ba_linearize_stereo_dev": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp,
                                            _vp, _vp]),
     "ovs_pose_set_variant": (_i32, [_i32, _i32]),
+    "ovs_local_ba_set_solver": (_i32, [_i32]),
+    "ovs_local_ba_get_solver": (_i32, []),
+    "ovs_ba_dense_solve": (_i32, [_i32, _vp, _vp, _i32, _vp]),
     "ovs_pose_optimize": (_i32, [_i32, _vp, _vp, _i32, _vp, C.c_double, _i32, _vp, _vp, C.POINTER(_i32)]),
     "ovs_pose_optimize_batch_dev": (_i32, [_vp, _vp, _vp, _i32, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp]),
     "ovs_pose_optimize_equirect": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, C.POINTER(_i32)]),

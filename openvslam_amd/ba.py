@@ -88,6 +88,26 @@ POSE_OBS_DTYPE = np.dtype([("pos_w", "<f8", (3,)), ("obs_x", "<f8"), ("obs_y", "
 assert POSE_OBS_DTYPE.itemsize == 64
 
 
+def local_ba_set_solver(where):
+    """ovs_local_ba_set_solver: "device" (default: csrc/ba_solve.hip) | "host" (the Cholesky of rounds 1-3), process-wide."""
+    _lib.check(_lib.lib().ovs_local_ba_set_solver({"device": 0, "host": 1}[where]), "ovs_local_ba_set_solver")
+
+
+def local_ba_get_solver():
+    return ("device", "host")[_lib.lib().ovs_local_ba_get_solver()]
+
+
+def dense_solve(S, rhs, device=0):
+    """ovs_ba_dense_solve: the reduced camera system's device solver alone (S symmetric positive definite, n <= 1024)."""
+    S = np.ascontiguousarray(S, np.float64)
+    rhs = np.ascontiguousarray(rhs, np.float64)
+    n = S.shape[0]
+    assert S.shape == (n, n) and rhs.shape == (n,)
+    x = np.empty(n, np.float64)
+    _lib.check(_lib.lib().ovs_ba_dense_solve(device, S.ctypes.data, rhs.ctypes.data, n, x.ctypes.data), "ovs_ba_dense_solve")
+    return x
+
+
 def pose_set_variant(which, value):
     """ovs_pose_set_variant: "reset_each_round" (0 | 1), process-wide (oracle/ORACLE_SPEC.md rule 25 (iv))."""
     _lib.check(_lib.lib().ovs_pose_set_variant({"reset_each_round": 0}[which], int(value)), "ovs_pose_set_variant")

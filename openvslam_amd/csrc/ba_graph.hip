@@ -39,6 +39,10 @@
 
 namespace ovs {
 
+// ba_solve.hip: the padded layout of the reduced camera system
+int dense_solve_pad(int n);
+size_t dense_solve_doubles(int n);
+
 struct GEdge {   // mono and stereo observations in one record; stereo iff index >= n_mono
     int32_t pose, pt;
     double ox, oy, oxr, w;
@@ -543,12 +547,13 @@ struct ovs_ba_graph {
     GEdge* d_edges = nullptr;
     int32_t *d_lm_start = nullptr, *d_lm_edges = nullptr, *d_lm_nmono = nullptr, *d_pose_start = nullptr, *d_pose_edges = nullptr;
     uint8_t* d_fixed = nullptr;
-    int32_t *d_pair_start = nullptr, *d_pair_ab = nullptr, *d_slot_pose = nullptr, *d_fail = nullptr;
+    int32_t *d_pair_start = nullptr, *d_pair_ab = nullptr, *d_slot_pose = nullptr, *d_slot_of_pose = nullptr, *d_fail = nullptr;
     int2* d_pair_ent = nullptr;
     int n_pairs = 0;
     double* d_lm_tmp = nullptr;   // [2 n_pt] per-landmark partials (chi2 / scale)
     // solver work space (allocated on first use: ovs_ba_graph_linearize_dev alone does not need it)
-    double *d_Hinv = nullptr, *d_Y = nullptr, *d_S = nullptr, *d_rhs = nullptr, *d_dxp = nullptr, *d_scal = nullptr;
+    double *d_Hinv = nullptr, *d_Y = nullptr, *d_S = nullptr, *d_rhs = nullptr, *d_bp_copy = nullptr, *d_dxp = nullptr, *d_scal = nullptr;
+    int s_pitch = 0;   // doubles per row of d_S
     bool pairs_built = false;
 
     GraphDev view() const {
@@ -715,6 +720,7 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     const size_t o_active = blob.add(std::vector<uint8_t>((size_t)std::max(ne, 1), (uint8_t)1));
     const size_t o_lm_tmp = blob.reserve_bytes(sizeof(double) * 2 * (size_t)n_pt);
     size_t o_pair_start = 0, o_pair_ab = 0, o_pair_ent = 0, o_slot_pose = 0;
+    const size_t o_slot_of_pose = blob.add(g->slot);   // keyframe -> block of the reduced system or -1 (k_pose_update)
     // reduced-system pair lists: for every landmark all (edge a, edge b) with free poses and slot(a) <= slot(b)
     if (g->n_free > 0) {
         const int nf = g->n_free;
@@ -764,6 +770,7 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     g->d_fixed = A + o_fixed;
     g->d_active = A + o_active;
     g->d_lm_tmp = reinterpret_cast<double*>(A + o_lm_tmp);
+    g->d_slot_of_pose = reinterpret_cast<int32_t*>(A + o_slot_of_pose);
     if (g->n_free > 0) {
         g->d_pair_start = reinterpret_cast<int32_t*>(A + o_pair_start);
         g->d_pair_ab = reinterpret_cast<int32_t*>(A + o_pair_ab);
@@ -805,39 +812,50 @@ ovs_status ovs_ba_graph_linearize_dev(ovs_ba_graph* g, const double* d_poses, co
 // ---------------------------------------------------------------------------------------------------------------------------
 namespace ovs {
 
-ovs_status ba_graph_ensure_solver(ovs_ba_graph* g) {
+// The reduced camera system is stored the way the device solver wants it (ba_solve.hip): pitch n_pad = 6 n_free rounded up to 16, an identity
+// block on the padding, the right-hand side as row n_pad, zero rows behind it. The padding survives a solve, so it is written once here.
+ovs_status ba_graph_ensure_solver(ovs_ba_graph* g, hipStream_t s) {
     if (g->d_Hinv) return OVS_OK;
-    const size_t ne = std::max<size_t>((size_t)g->n_edge(), 1), n = (size_t)6 * std::max(g->n_free, 1);
+    const size_t ne = std::max<size_t>((size_t)g->n_edge(), 1);
+    const int n = 6 * std::max(g->n_free, 1), n_pad = dense_solve_pad(n);
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t sys = dense_solve_doubles(n);
     const size_t b_hinv = al(sizeof(double) * 9 * (size_t)g->n_pt), b_y = al(sizeof(double) * 18 * ne),
-                 b_s = al(sizeof(double) * (n * n + n + 6 * (size_t)g->n_pose)), b_dxp = al(sizeof(double) * 6 * (size_t)g->n_pose);
+                 b_s = al(sizeof(double) * (sys + 6 * (size_t)g->n_pose)), b_dxp = al(sizeof(double) * 6 * (size_t)g->n_pose);
     OVS_HIP_TRY(hipMalloc(&g->d_solver_arena, b_hinv + b_y + b_s + b_dxp + 512));
     unsigned char* A = g->d_solver_arena;
     g->d_Hinv = reinterpret_cast<double*>(A);
     g->d_Y = reinterpret_cast<double*>(A + b_hinv);
-    g->d_S = reinterpret_cast<double*>(A + b_hinv + b_y);   // S | rhs | bp copy: one D2H
+    g->d_S = reinterpret_cast<double*>(A + b_hinv + b_y);   // padded system | bp copy
     g->d_dxp = reinterpret_cast<double*>(A + b_hinv + b_y + b_s);
     g->d_scal = reinterpret_cast<double*>(A + b_hinv + b_y + b_s + b_dxp);
     g->d_fail = reinterpret_cast<int32_t*>(A + b_hinv + b_y + b_s + b_dxp + 256);
-    g->d_rhs = g->d_S + n * n;
+    g->s_pitch = n_pad;
+    g->d_rhs = g->d_S + (size_t)n_pad * n_pad;
+    g->d_bp_copy = g->d_S + sys;
+    OVS_HIP_TRY(hipMemsetAsync(g->d_S, 0, sizeof(double) * sys, s));
+    const std::vector<double> ones((size_t)std::max(n_pad - n, 1), 1.0);
+    if (n_pad > n)
+        OVS_HIP_TRY(hipMemcpy2DAsync(g->d_S + (size_t)n * n_pad + n, sizeof(double) * ((size_t)n_pad + 1), ones.data(), sizeof(double), sizeof(double),
+                                     (size_t)(n_pad - n), hipMemcpyHostToDevice, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));   // `ones` is a local
     return OVS_OK;
 }
 
-// (H + lambda I) dx = b, landmarks eliminated on the device. Leaves S | rhs | bp contiguous at g->d_S for one download.
+// (H + lambda I) dx = b, landmarks eliminated on the device: S (pitch g->s_pitch) and rhs at g->d_S, a copy of bp behind the system.
 ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_bp, const double* d_Hll, const double* d_bl, const double* d_Hpl,
                           double lambda, hipStream_t s) {
     const GraphDev v = g->view();
-    const int n = 6 * g->n_free;
     OVS_HIP_TRY(hipMemsetAsync(g->d_fail, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k_lm_prepare, dim3((g->n_pt + 127) / 128), dim3(128), 0, s, v, d_Hll, d_Hpl, lambda, g->d_Hinv, g->d_Y, g->d_fail);
     OVS_LAUNCH_TRY("k_lm_prepare");
     if (g->n_free > 0) {
         hipLaunchKernelGGL(k_schur_pairs, dim3(g->n_pairs), dim3(256), 0, s, g->d_pair_start, g->d_pair_ent, g->d_pair_ab, g->d_slot_pose, d_Hpp,
-                           d_Hpl, g->d_Y, lambda, n, g->d_S);
+                           d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S);
         OVS_LAUNCH_TRY("k_schur_pairs");
         hipLaunchKernelGGL(k_schur_rhs, dim3(g->n_free), dim3(256), 0, s, v, g->d_slot_pose, d_bp, d_bl, g->d_Y, g->d_rhs);
         OVS_LAUNCH_TRY("k_schur_rhs");
-        OVS_HIP_TRY(hipMemcpyAsync(g->d_rhs + n, d_bp, sizeof(double) * 6 * (size_t)g->n_pose, hipMemcpyDeviceToDevice, s));
+        OVS_HIP_TRY(hipMemcpyAsync(g->d_bp_copy, d_bp, sizeof(double) * 6 * (size_t)g->n_pose, hipMemcpyDeviceToDevice, s));
     }
     return OVS_OK;
 }
@@ -879,6 +897,11 @@ struct BaGraphInfo {
     const int32_t* slot;
     double *d_S, *d_dxp, *d_scal;
     int32_t* d_fail;
+    const int32_t* d_slot_of_pose;
+    int s_pitch;
+    double *d_rhs, *d_bp_copy;
 };
-BaGraphInfo ba_graph_info(ovs_ba_graph* g) { return BaGraphInfo{g->n_free, g->slot.data(), g->d_S, g->d_dxp, g->d_scal, g->d_fail}; }
+BaGraphInfo ba_graph_info(ovs_ba_graph* g) {
+    return BaGraphInfo{g->n_free, g->slot.data(), g->d_S, g->d_dxp, g->d_scal, g->d_fail, g->d_slot_of_pose, g->s_pitch, g->d_rhs, g->d_bp_copy};
+}
 }   // namespace ovs

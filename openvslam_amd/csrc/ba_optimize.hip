@@ -24,7 +24,7 @@ struct ovs_ba_graph;
 
 namespace ovs {
 // ba_graph.hip
-ovs_status ba_graph_ensure_solver(ovs_ba_graph* g);
+ovs_status ba_graph_ensure_solver(ovs_ba_graph* g, hipStream_t s);
 ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_bp, const double* d_Hll, const double* d_bl, const double* d_Hpl,
                           double lambda, hipStream_t s);
 ovs_status ba_graph_backsub(ovs_ba_graph* g, const double* d_Hpl, const double* d_bl, double lambda, const double* d_X, double* d_Xn, hipStream_t s);
@@ -35,10 +35,22 @@ ovs_status ba_graph_linearize(ovs_ba_graph* g, const double* d_poses, const doub
 struct BaGraphInfo {
     int n_free;
     const int32_t* slot;        // pose -> reduced block or -1
-    double *d_S, *d_dxp, *d_scal;
+    double *d_S, *d_dxp, *d_scal;   // S | rhs | bp copy;  6 per keyframe;  [0] landmarks' / [1] keyframes' part of the gain ratio's denominator
     int32_t* d_fail;
+    const int32_t* d_slot_of_pose;
+    int s_pitch;                 // doubles per row of d_S (6 n_free rounded up to 16; ba_solve.hip's padded layout)
+    double *d_rhs, *d_bp_copy;   // row s_pitch of the system; bp behind the system
 };
 BaGraphInfo ba_graph_info(ovs_ba_graph* g);
+// ba_solve.hip
+int dense_solve_max_n();
+int dense_solve_pad(int n);
+size_t dense_solve_doubles(int n);
+ovs_status launch_dense_solve(double* d_S, int n, int32_t* d_fail, hipStream_t s, unsigned long long* d_tstats = nullptr);
+ovs_status launch_pose_update(const double* d_T, const int32_t* d_slot_of_pose, int n_pose, const double* d_x, const double* d_bp, double lambda,
+                              double* d_Tn, double* d_p7n, double* d_dxp, double* d_scal_pose, hipStream_t s);
+// where the reduced camera system is solved: 0 = on the device (k_chol_solve), 1 = on the host (ba_host_math.h cholesky_solve)
+std::atomic<int> g_lba_solver{0};
 }   // namespace ovs
 
 namespace {
@@ -91,8 +103,9 @@ struct Lm {
     bool err_at_trial = false;   // the active edges' errors were last computed at the trial state (d_poses_n, d_Xn), which was then rejected
     static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     hipStream_t stream = nullptr;
-    DevBlocks cur, trial;
-    double *d_poses = nullptr, *d_poses_n = nullptr, *d_X = nullptr, *d_Xn = nullptr, *d_echi = nullptr;
+    DevBlocks cur, trial, work;   // accepted state | last evaluated trial | where the next trial is evaluated (device solver only)
+    double *d_poses = nullptr, *d_poses_n = nullptr, *d_poses_w = nullptr, *d_X = nullptr, *d_Xn = nullptr, *d_Xw = nullptr, *d_echi = nullptr;
+    double *d_T = nullptr, *d_Tn = nullptr, *d_Tw = nullptr;   // R | t per keyframe (12 doubles), the state k_pose_update advances
     uint8_t* d_edepth = nullptr;
     double* h_pin = nullptr;   // pinned: S | rhs | bp | chi3 | scal | fail
     size_t pin_doubles = 0;
@@ -110,7 +123,8 @@ struct Lm {
         auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t nb = al(sizeof(double) * DevBlocks::doubles(np, npt, ne_max)), b_p = al(sizeof(double) * 7 * np), b_x = al(sizeof(double) * 3 * npt),
                      b_e = al(sizeof(double) * std::max<size_t>(ne_max, 1)), b_d = al(std::max<size_t>(ne_max, 1));
-        const size_t need = 2 * nb + 2 * b_p + 2 * b_x + b_e + b_d;
+        const size_t b_t = al(sizeof(double) * 12 * np);
+        const size_t need = 3 * nb + 3 * b_p + 3 * b_x + 3 * b_t + b_e + b_d;
         if (sc.d_cap < need) {
             if (sc.d) (void)hipFree(sc.d);
             sc.d = nullptr;
@@ -121,14 +135,23 @@ struct Lm {
         unsigned char* A = sc.d;
         cur.carve(reinterpret_cast<double*>(A), np, npt, ne_max);
         trial.carve(reinterpret_cast<double*>(A + nb), np, npt, ne_max);
-        d_poses = reinterpret_cast<double*>(A + 2 * nb);
-        d_poses_n = reinterpret_cast<double*>(A + 2 * nb + b_p);
-        d_X = reinterpret_cast<double*>(A + 2 * nb + 2 * b_p);
-        d_Xn = reinterpret_cast<double*>(A + 2 * nb + 2 * b_p + b_x);
-        d_echi = reinterpret_cast<double*>(A + 2 * nb + 2 * b_p + 2 * b_x);
-        d_edepth = A + 2 * nb + 2 * b_p + 2 * b_x + b_e;
-        const size_t n = (size_t)6 * np;
-        pin_doubles = n * n + n + 6 * (size_t)np + 16;
+        work.carve(reinterpret_cast<double*>(A + 2 * nb), np, npt, ne_max);
+        A += 3 * nb;
+        d_poses = reinterpret_cast<double*>(A);
+        d_poses_n = reinterpret_cast<double*>(A + b_p);
+        d_poses_w = reinterpret_cast<double*>(A + 2 * b_p);
+        A += 3 * b_p;
+        d_X = reinterpret_cast<double*>(A);
+        d_Xn = reinterpret_cast<double*>(A + b_x);
+        d_Xw = reinterpret_cast<double*>(A + 2 * b_x);
+        A += 3 * b_x;
+        d_T = reinterpret_cast<double*>(A);
+        d_Tn = reinterpret_cast<double*>(A + b_t);
+        d_Tw = reinterpret_cast<double*>(A + 2 * b_t);
+        A += 3 * b_t;
+        d_echi = reinterpret_cast<double*>(A);
+        d_edepth = A + b_e;
+        pin_doubles = ovs::dense_solve_doubles(6 * np) + 6 * (size_t)np + 16;   // padded system | bp | chi3, scal, fail
         if (sc.pin_cap < pin_doubles) {
             if (sc.h_pin) (void)hipHostFree(sc.h_pin);
             sc.h_pin = nullptr;
@@ -168,16 +191,27 @@ struct Lm {
     // one optimizer.optimize(iters) call on graph g. Returns the number of iterations entered.
     ovs_status run_round(ovs_ba_graph* g, std::vector<Pose>& T, int iters, bool robust, const volatile uint8_t* stop, double* chi_start,
                          double* chi_end, int* n_iter) {
-        ovs_status st = ovs::ba_graph_ensure_solver(g);   // (before ba_graph_info: the work space is allocated on first use)
+        ovs_status st = ovs::ba_graph_ensure_solver(g, stream);   // (before ba_graph_info: the work space is allocated on first use)
         if (st != OVS_OK) return st;
         const ovs::BaGraphInfo gi = ovs::ba_graph_info(g);
         const int nf = gi.n_free, n = 6 * nf;
         st = upload_poses(T, d_poses);
         if (st != OVS_OK) return st;
+        // the reduced camera system is solved where ovs_local_ba_set_solver says; systems beyond the one-workgroup solver's LDS go to the host
+        const bool dev_solve = ovs::g_lba_solver.load(std::memory_order_relaxed) == 0 && n <= ovs::dense_solve_max_n();
+        if (dev_solve) {
+            std::vector<double> rt((size_t)12 * n_pose);
+            for (int k = 0; k < n_pose; ++k) {
+                std::memcpy(&rt[(size_t)12 * k], T[k].R, sizeof(double) * 9);
+                std::memcpy(&rt[(size_t)12 * k + 9], T[k].t, sizeof(double) * 3);
+            }
+            OVS_HIP_TRY(hipMemcpyAsync(d_T, rt.data(), sizeof(double) * rt.size(), hipMemcpyHostToDevice, stream));
+            OVS_HIP_TRY(hipStreamSynchronize(stream));   // rt is a local
+        }
         st = ovs::ba_graph_linearize(g, d_poses, d_X, huber_mono(robust), huber_stereo(robust), cur.Hpp, cur.bp, cur.Hll, cur.bl, cur.Hpl, cur.chi,
                                      stream);
         if (st != OVS_OK) return st;
-        double* h_chi = h_pin + ((size_t)n * n + n + 6 * (size_t)n_pose);
+        double* h_chi = h_pin + pin_doubles - 16;
         OVS_HIP_TRY(hipMemcpyAsync(h_chi, cur.chi, sizeof(double) * 3, hipMemcpyDeviceToHost, stream));
         OVS_HIP_TRY(hipStreamSynchronize(stream));
         double current_chi = h_chi[1];
@@ -202,16 +236,73 @@ struct Lm {
                 st = ovs::ba_graph_schur(g, cur.Hpp, cur.bp, cur.Hll, cur.bl, cur.Hpl, lambda, stream);
                 if (st != OVS_OK) return st;
                 int32_t* h_fail = reinterpret_cast<int32_t*>(h_chi + 8);
-                if (n > 0) OVS_HIP_TRY(hipMemcpyAsync(h_pin, gi.d_S, sizeof(double) * ((size_t)n * n + n + 6 * (size_t)n_pose), hipMemcpyDeviceToHost, stream));
+                if (dev_solve) {
+                    // ---- the whole trial on the device: solve, keyframe / landmark updates, linearisation at the trial state (into the
+                    //      `work` set: a failed solve must leave the last evaluated trial state, which edge_chi2 may still need, untouched)
+                    if (n > 0) {
+                        st = ovs::launch_dense_solve(gi.d_S, n, gi.d_fail, stream);
+                        if (st != OVS_OK) return st;
+                    }
+                    st = ovs::launch_pose_update(d_T, gi.d_slot_of_pose, n_pose, gi.d_rhs, cur.bp, lambda, d_Tw, d_poses_w, gi.d_dxp,
+                                                 gi.d_scal + 1, stream);
+                    if (st != OVS_OK) return st;
+                    st = ovs::ba_graph_backsub(g, cur.Hpl, cur.bl, lambda, d_X, d_Xw, stream);
+                    if (st != OVS_OK) return st;
+                    st = ovs::ba_graph_linearize(g, d_poses_w, d_Xw, huber_mono(robust), huber_stereo(robust), work.Hpp, work.bp, work.Hll, work.bl,
+                                                 work.Hpl, work.chi, stream);
+                    if (st != OVS_OK) return st;
+                    OVS_HIP_TRY(hipMemcpyAsync(h_chi, work.chi, sizeof(double) * 3, hipMemcpyDeviceToHost, stream));
+                    OVS_HIP_TRY(hipMemcpyAsync(h_chi + 4, gi.d_scal, sizeof(double) * 2, hipMemcpyDeviceToHost, stream));
+                    OVS_HIP_TRY(hipMemcpyAsync(h_fail, gi.d_fail, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                    OVS_HIP_TRY(hipStreamSynchronize(stream));
+                    const bool ok = *h_fail == 0;
+                    double temp_chi = 1.7976931348623157e308, scale = 1e-3;
+                    if (ok) {
+                        temp_chi = h_chi[1];
+                        scale = (h_chi[5] + h_chi[4]) + 1e-3;   // keyframes' part, then the landmarks' (g2o's computeScale order)
+                        std::swap(trial, work);
+                        std::swap(d_poses_n, d_poses_w);
+                        std::swap(d_Xn, d_Xw);
+                        std::swap(d_Tn, d_Tw);
+                        err_at_trial = true;
+                    }
+                    t_trial += now() - t0;
+                    rho = (current_chi - temp_chi) / scale;
+                    if (ok && rho > 0 && std::isfinite(temp_chi)) {
+                        double alpha = 1.0 - std::pow(2 * rho - 1, 3.0);
+                        alpha = std::min(alpha, 2.0 / 3.0);
+                        lambda *= std::max(1.0 / 3.0, alpha);
+                        ni = 2;
+                        current_chi = temp_chi;
+                        std::swap(d_X, d_Xn);
+                        std::swap(d_poses, d_poses_n);
+                        std::swap(d_T, d_Tn);
+                        std::swap(cur, trial);
+                        err_at_trial = false;
+                    } else {
+                        lambda *= ni;
+                        ni *= 2;
+                        if (!std::isfinite(lambda)) break;
+                    }
+                    ++qmax;
+                    continue;
+                }
+                const size_t np_ = (size_t)gi.s_pitch, sys_rows = np_ + 1;   // S rows and the rhs row
+                double* const h_bp_w = h_pin + sys_rows * np_;
+                if (n > 0) {
+                    OVS_HIP_TRY(hipMemcpyAsync(h_pin, gi.d_S, sizeof(double) * sys_rows * np_, hipMemcpyDeviceToHost, stream));
+                    OVS_HIP_TRY(hipMemcpyAsync(h_bp_w, gi.d_bp_copy, sizeof(double) * 6 * (size_t)n_pose, hipMemcpyDeviceToHost, stream));
+                }
                 OVS_HIP_TRY(hipMemcpyAsync(h_fail, gi.d_fail, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
                 OVS_HIP_TRY(hipStreamSynchronize(stream));
                 bool ok = *h_fail == 0;
                 const double t1 = now();
                 t_schur += t1 - t0;
-                const double* h_bp = h_pin + (size_t)n * n + n;
+                const double* h_bp = h_bp_w;
                 if (ok && n > 0) {
-                    S.assign(h_pin, h_pin + (size_t)n * n);
-                    rhs.assign(h_pin + (size_t)n * n, h_pin + (size_t)n * n + n);
+                    S.resize((size_t)n * n);
+                    for (int i = 0; i < n; ++i) std::memcpy(&S[(size_t)i * n], h_pin + (size_t)i * np_, sizeof(double) * n);   // drop the padding
+                    rhs.assign(h_pin + np_ * np_, h_pin + np_ * np_ + n);
                     ok = cholesky_solve(S, n, rhs);
                 }
                 const double t2 = now();
@@ -269,6 +360,15 @@ struct Lm {
             if (qmax == 10 || rho == 0 || !std::isfinite(lambda)) break;
         }
         *chi_end = current_chi;
+        if (dev_solve) {   // the accepted keyframe state comes back once per round
+            std::vector<double> rt((size_t)12 * n_pose);
+            OVS_HIP_TRY(hipMemcpyAsync(rt.data(), d_T, sizeof(double) * rt.size(), hipMemcpyDeviceToHost, stream));
+            OVS_HIP_TRY(hipStreamSynchronize(stream));
+            for (int k = 0; k < n_pose; ++k) {
+                std::memcpy(T[k].R, &rt[(size_t)12 * k], sizeof(double) * 9);
+                std::memcpy(T[k].t, &rt[(size_t)12 * k + 9], sizeof(double) * 3);
+            }
+        }
         return OVS_OK;
     }
 
@@ -380,7 +480,7 @@ static ovs_status local_ba_optimize_impl(int model, int32_t device, double* pose
     OVS_HIP_TRY(hipMemcpy(points, L.d_X, sizeof(double) * 3 * (size_t)n_pt, hipMemcpyDeviceToHost));
     if (trace)
         std::fprintf(stderr, "[ovs_local_ba_optimize] total %.2f ms: graph build (round 1) %.2f, %d trials: schur+download %.2f, host cholesky %.2f, "
-                             "update+linearise %.2f ms\n",
+                             "update+linearise (device solver: the whole trial) %.2f ms\n",
                      Lm::now() - t_begin, t_g1 - t_begin, L.n_trials, L.t_schur, L.t_chol, L.t_trial);
     if (info) {
         info_l[4] = it1;
@@ -399,6 +499,13 @@ ovs_status ovs_local_ba_optimize(int32_t device, double* poses, const uint8_t* p
     return local_ba_optimize_impl(0, device, poses, pose_fixed, n_pose, points, n_pt, mono, n_mono, stereo, n_stereo, cam, focal_x_baseline, setup_type,
                                   num_first_iter, num_second_iter, force_stop_flag, mono_outlier, stereo_outlier, info);
 }
+
+ovs_status ovs_local_ba_set_solver(int32_t where) {
+    if (where != 0 && where != 1) return OVS_ERR_INVALID;
+    ovs::g_lba_solver.store(where, std::memory_order_relaxed);
+    return OVS_OK;
+}
+int32_t ovs_local_ba_get_solver(void) { return ovs::g_lba_solver.load(std::memory_order_relaxed); }
 
 ovs_status ovs_local_ba_optimize_equirect(int32_t device, double* poses, const uint8_t* pose_fixed, int32_t n_pose, double* points, int32_t n_pt,
                                           const ovs_ba_edge* mono, int32_t n_mono, int32_t cols, int32_t rows, int32_t num_first_iter,

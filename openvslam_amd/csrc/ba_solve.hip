@@ -1,0 +1,515 @@
+// ba_solve.hip -- the reduced camera system of local BA on the device (round 4):
+//   k_chol_solve    dense Cholesky + both substitutions of  S x = rhs  (S = 6 n_free square, symmetric positive definite after the
+//                   landmarks were eliminated: ba_graph.hip k_schur_pairs / k_schur_rhs) in ONE workgroup, the trailing updates on the
+//                   f64 matrix cores;
+//   k_pose_update   the Levenberg-Marquardt trial state of the keyframes: T <- exp(dx) T per free keyframe (g2o SE3Quat::exp as in
+//                   ba_host_math.h se3_oplus), the 7-double record the linearisation kernels read, and the keyframes' part of the gain
+//                   ratio's denominator.
+// Upstream solves this system on the host (g2o BlockSolver + a dense / CSparse Cholesky inside optimizer.optimize(), expected
+// src/openvslam/optimize/local_bundle_adjuster.cc); until round 4 so did this library (ba_host_math.h cholesky_solve, still selectable:
+// ovs_local_ba_set_solver(1)). One LM trial then cost a 0.66 MB download, 0.47 ms of host arithmetic and two uploads, 15 times per call
+// at BASELINE config 5 (288 x 288) -- more than the linearisations. Here a trial never leaves the device: the host reads back three
+// scalars and a flag.
+//
+// Algorithm (right-looking, blocked by 16 columns, lower triangle, in place in HBM / L2; the matrix is 0.66 MB at config 5):
+//   for every panel j0:  stage rows j0.. of columns [j0, j0 + 16) in LDS; wave 0 factors the 16 x 16 diagonal block in registers (one row
+//   per lane, broadcasts by v_readlane); one thread per remaining row solves its 16 entries against the block; the trailing matrix gets
+//   C -= P_i P_c^T per 16 x 16 tile with four v_mfma_f64_16x16x4_f64 (A = -P_i from LDS, B = P_c from LDS, C from / to memory).
+//   The right-hand side rides along as one more ROW of the matrix (it is stored right behind S): its "row solve" is the forward
+//   substitution, so only the backward substitution is left, done block-wise from L^T, which the row solves store into the (otherwise
+//   unused) upper triangle so that its rows are contiguous too.
+//   n is padded to a multiple of 16 with an identity block (loads substitute it, stores skip it).
+// Numerics: fused multiply-adds and the matrix cores' internal order instead of the host's mul / sub pairs in column order -- results
+// agree with the host solve to ~1e-13 relative on these systems (tests/test_gpu_ba.py::test_dense_solve_*), far inside the 1e-7 the
+// optimiser's result is stated to (ORACLE_SPEC rule 25); identical bits from run to run (no atomics, fixed tile order).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "ovs_common.h"
+
+#define OVS_LAUNCH_TRY(name)                                  \
+    do {                                                      \
+        hipError_t _e = hipGetLastError();                    \
+        if (_e != hipSuccess) {                               \
+            ovs::set_last_error("launch of " name, _e);       \
+            return OVS_ERR_HIP;                               \
+        }                                                     \
+    } while (0)
+
+namespace ovs {
+
+namespace {
+
+constexpr int kNb = 16;       // panel width = tile edge
+constexpr int kPitch = 17;    // doubles per staged panel row (odd: rows of a tile fall into different banks)
+constexpr int kSolveThreads = 512;   // 8 waves, 256 registers each: two batches of kBatch C tiles (4 doubles each) stay in flight per wave
+constexpr int kBatch = 6;
+constexpr int kMaxN = 1024;          // unknowns; the backward substitution gives a thread kMaxN / kSolveThreads columns
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {   // src_lane is wave-uniform
+    union {
+        double d;
+        int i[2];
+    } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], src_lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane);
+    return u.d;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Storage of the system (ba_graph.hip lays the reduced camera system out like this): (n_pad + 16) rows of n_pad doubles, n_pad = n rounded up
+// to the panel width. Rows / columns n .. n_pad - 1 carry an identity block, row n_pad is the right-hand side, the rows behind it are zero
+// (they only complete the last 16-row tile). Every access below is then plain row * n_pad + column; the padding reproduces itself (the
+// Cholesky factor of an identity block is the identity, products with zero rows vanish), so it is written once per graph.
+}   // namespace
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains every outstanding global load (s_waitcnt vmcnt(0)), i.e. the
+// C tiles / L rows requested ahead of their use below. Memory written by this kernel and read back from HBM / L2 by OTHER waves (the
+// trailing tiles) is ordered by the one full barrier at the end of a panel.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// column-major walk over the tiles (ti, tc) behind a panel: tc = 0 .. mt - 2 (tile columns), ti = tc .. mt - 1 (the last tile row carries the
+// rhs). The first tiles are those of the NEXT panel's columns.
+__device__ __forceinline__ void tile_advance(int& ti, int& tc, int mt, int steps) {
+    for (int s = 0; s < steps; ++s)
+        if (++ti >= mt) {
+            ++tc;
+            ti = tc;
+        }
+}
+
+// 1 / sqrt(p) by v_rsq_f64 + three Newton steps (enough from an 11-bit seed); sqrt(p) = p * that. A pivot step then costs ~15 dependent
+// operations instead of the ~45 of an IEEE sqrt followed by an IEEE division -- the 6 n_free pivot steps are the one chain of the
+// factorisation nothing can overlap.
+__device__ __forceinline__ double rsqrt_newton(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    const double h = 0.5 * p;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) y = y * __builtin_fma(-h * y, y, 1.5);
+    return y;
+}
+
+// S: the padded system above (lower triangle read). On return the rhs row holds x, S is overwritten (L on and below the diagonal, the
+// diagonal blocks' L^T above it). *fail |= 2 when a pivot is not positive (the system is not positive definite; x is then
+// unspecified). dbuf: the LDS holds two panels -- the trailing update then writes the next panel's columns straight into the other one.
+// tstats: NULL, or 8 counters thread 0 adds its phase times to (wall_clock64 ticks of 10 ns; OVS_BA_TRACE with ovs_ba_dense_solve)
+__global__ __launch_bounds__(kSolveThreads) void k_chol_solve(double* __restrict__ S, int n_pad, int dbuf, int32_t* __restrict__ fail,
+                                                             unsigned long long* __restrict__ tstats) {
+    extern __shared__ double lds[];
+    const int panel_doubles = (n_pad + kNb) * kPitch;
+    double* P = lds;                                                  // the panel: row r <-> logical row j0 + r
+    double* Pn = lds + (dbuf ? panel_doubles : 0);                    // next panel (dbuf) or the same storage
+    double* const vec = lds + (dbuf ? 2 : 1) * (size_t)panel_doubles; // n_pad: y, then x
+    double* const invd = vec + n_pad;                                 // n_pad: 1 / L[c][c]
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int kWaves = kSolveThreads / 64;
+    const int n_rows = n_pad + kNb;
+    const int rl = lane & 15, kq = lane >> 4;
+    if (tid == 0) s_bad = 0;
+    for (int i = tid; i < n_pad; i += kSolveThreads) vec[i] = 0.0;
+    unsigned long long t_prev = tstats ? wall_clock64() : 0;
+#define SOLVE_MARK(i)                                        \
+    if (tstats && tid == 0) {                                \
+        const unsigned long long t_now = wall_clock64();     \
+        atomicAdd(&tstats[i], t_now - t_prev);               \
+        t_prev = t_now;                                      \
+    }
+
+    for (int j0 = 0; j0 < n_pad; j0 += kNb) {
+        const int m = n_rows - j0;        // staged rows
+        const int mt = (m - kNb) / kNb;   // tile rows behind the panel; tile columns: mt - 1
+        // ---- this wave's first kBatch tiles: their C values are requested now and arrive under the panel's factorisation
+        int ti = 0, tc = 0;
+        tile_advance(ti, tc, mt, wave);
+        // a batch = kBatch tile descriptors (ti | tc << 16, -1 = none; wave-uniform) and their C values (4 doubles per lane and tile).
+        // Addresses are 32-bit byte offsets from S, rebuilt where they are used: kept as 64-bit pointers from the loads to the stores they
+        // would cost as many registers as the values.
+        int da[kBatch], db[kBatch];
+        v4d accA[kBatch], accB[kBatch];
+        const uint32_t row_step = 4u * (uint32_t)n_pad * 8u;   // bytes between the 4 rows of a lane's C values
+        const char* const Sb = reinterpret_cast<const char*>(S);
+        char* const Sw = reinterpret_cast<char*>(S);
+        auto tile_off = [&](int d) -> uint32_t {   // byte offset of this lane's first C value of tile d
+            const int i = d & 0xffff, c = d >> 16;
+            return ((uint32_t)(j0 + kNb + kNb * i + kq) * (uint32_t)n_pad + (uint32_t)(j0 + kNb + kNb * c + rl)) * 8u;
+        };
+        auto gather = [&](int (&gd)[kBatch], v4d (&acc)[kBatch]) {
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q) {
+                gd[q] = tc < mt - 1 ? (ti | (tc << 16)) : -1;
+                if (gd[q] >= 0) {
+                    const uint32_t o = tile_off(gd[q]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[q][e] = *reinterpret_cast<const double*>(Sb + (o + (uint32_t)e * row_step));
+                    tile_advance(ti, tc, mt, kWaves);
+                }
+            }
+        };
+        gather(da, accA);
+        if (j0 == 0 || !dbuf)
+            for (int idx = tid; idx < m * kNb; idx += kSolveThreads) {
+                const int r = idx >> 4, c = idx & 15;
+                P[r * kPitch + c] = S[(size_t)(j0 + r) * n_pad + j0 + c];
+            }
+        lds_barrier();
+        SOLVE_MARK(0)   // tile requests + panel load + barrier
+        // ---- diagonal block: lane r holds row r (entries c <= r are the lower triangle)
+        if (wave == 0) {
+            const int r = lane & 15;
+            double a[kNb];
+#pragma unroll
+            for (int c = 0; c < kNb; ++c) a[c] = P[r * kPitch + c];
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < kNb; ++k) {
+                const double piv = lane_bcast(a[k], k);
+                bad |= !(piv > 0.0);
+                const double y = rsqrt_newton(piv);
+                a[k] = (r == k) ? piv * y : a[k] * y;
+                if (lane == k) invd[j0 + k] = y;
+#pragma unroll
+                for (int c = k + 1; c < kNb; ++c) a[c] = __builtin_fma(-a[k], lane_bcast(a[k], c), a[c]);   // L[c][k] sits in lane c
+                __builtin_amdgcn_sched_barrier(0);   // keeps the 120 broadcasts of the unrolled nest from being hoisted (scalar register spills)
+            }
+            if (lane < kNb) {
+#pragma unroll
+                for (int c = 0; c < kNb; ++c)
+                    if (c <= r) P[r * kPitch + c] = a[c];
+                if (bad && lane == 0) s_bad = 1;
+            }
+        }
+        lds_barrier();
+        SOLVE_MARK(1)   // diagonal block + barrier
+        if (s_bad) {
+            if (tid == 0) atomicOr(fail, 2);
+            return;
+        }
+        // ---- the rows below: x L_dd^T = p, one thread per row; the rhs row's solution is this block of y
+        for (int r = kNb + tid; r < m; r += kSolveThreads) {
+            const int R = j0 + r;
+            double x[kNb];
+#pragma unroll
+            for (int c = 0; c < kNb; ++c) x[c] = P[r * kPitch + c];
+            const double* Ld = P;
+            asm volatile("" : "+v"(Ld));   // opaque per row: the 136 entries of L_dd are not hoisted out of the row loop into registers
+#pragma unroll
+            for (int c = 0; c < kNb; ++c) {
+                double v = x[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) v = __builtin_fma(-x[k], Ld[c * kPitch + k], v);
+                x[c] = v * invd[j0 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < kNb; ++c) P[r * kPitch + c] = x[c];
+            if (R == n_pad) {
+#pragma unroll
+                for (int c = 0; c < kNb; ++c) vec[j0 + c] = x[c];   // y
+            }
+        }
+        lds_barrier();
+        SOLVE_MARK(2)   // row solves + barrier
+        // ---- the finished panel goes back to memory (the backward substitution reads L row-wise, and the diagonal blocks' L^T)
+        for (int idx = tid; idx < m * kNb; idx += kSolveThreads) {
+            const int r = idx >> 4, c = idx & 15;
+            S[(size_t)(j0 + r) * n_pad + j0 + c] = (r < kNb && c > r) ? P[c * kPitch + r] : P[r * kPitch + c];   // (L_dd^T above the diagonal)
+        }
+        SOLVE_MARK(3)   // write-back (thread 0's share)
+        // ---- trailing update C -= P_i P_c^T: kBatch tiles of a wave are computed while its next kBatch are on their way
+        auto compute = [&](const int (&gd)[kBatch], v4d (&acc)[kBatch]) {
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q)
+                if (gd[q] >= 0) {
+                    const double* pa = P + (kNb + kNb * (gd[q] & 0xffff) + rl) * kPitch + kq;
+                    const double* pb = P + (kNb + kNb * (gd[q] >> 16) + rl) * kPitch + kq;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * s4], pb[4 * s4], acc[q], 0, 0, 0);
+                }
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q)
+                if (gd[q] >= 0) {
+                    const uint32_t o = tile_off(gd[q]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) *reinterpret_cast<double*>(Sw + (o + (uint32_t)e * row_step)) = acc[q][e];
+                    if (dbuf && (gd[q] >> 16) == 0) {   // the next panel's columns
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Pn[(kNb * (gd[q] & 0xffff) + kq + 4 * e) * kPitch + rl] = acc[q][e];
+                    }
+                }
+        };
+        for (;;) {
+            const bool more_b = tc < mt - 1;
+            if (more_b) gather(db, accB);
+            compute(da, accA);
+            if (!more_b) break;
+            const bool more_a = tc < mt - 1;
+            if (more_a) gather(da, accA);
+            compute(db, accB);
+            if (!more_a) break;
+        }
+        SOLVE_MARK(4)   // trailing update, wave 0's tiles
+        __syncthreads();
+        SOLVE_MARK(5)   // ... waiting for the other waves
+        if (dbuf) {
+            double* const t = P;
+            P = Pn;
+            Pn = t;
+        }
+    }
+    // ---- backward substitution L^T x = y, right-looking, from the last block: wave 0 solves the 16 x 16 block (lane c holds row c of
+    //      L_dd^T), then thread c' < jb takes the block's 16 columns out of y[c']. The block's data for the NEXT step is requested before
+    //      this step's arithmetic, so no step waits for memory.
+    constexpr int kCols = kMaxN / kSolveThreads;   // columns c' = tid + u * kSolveThreads of a thread
+    double lr[kCols][kNb], lr_next[kCols][kNb], tt[kNb];
+    auto request_rows = [&](int jb, double (&L16)[kCols][kNb]) {
+#pragma unroll
+        for (int u = 0; u < kCols; ++u)
+#pragma unroll
+            for (int k = 0; k < kNb; ++k) L16[u][k] = tid + u * kSolveThreads < jb ? S[(size_t)(jb + k) * n_pad + tid + u * kSolveThreads] : 0.0;
+    };
+    auto request_block = [&](int jb) {   // wave 0: row rl of the diagonal block's L^T
+        const int C = jb + rl;
+#pragma unroll
+        for (int k = 0; k < kNb; ++k) tt[k] = k > rl ? S[(size_t)C * n_pad + jb + k] : 0.0;
+    };
+    request_rows(n_pad - kNb, lr_next);
+    if (wave == 0) request_block(n_pad - kNb);
+    for (int jb = n_pad - kNb; jb >= 0; jb -= kNb) {
+#pragma unroll
+        for (int u = 0; u < kCols; ++u)
+#pragma unroll
+            for (int k = 0; k < kNb; ++k) lr[u][k] = lr_next[u][k];
+        if (jb >= kNb) request_rows(jb - kNb, lr_next);
+        if (wave == 0) {
+            double r = vec[jb + rl];
+            const double iv = invd[jb + rl];
+#pragma unroll
+            for (int k = kNb - 1; k >= 0; --k) {
+                const double xk = lane_bcast(r * iv, k);   // lane k holds its finished residual
+                if (rl == k) r = xk;
+                else if (rl < k) r = __builtin_fma(-tt[k], xk, r);
+            }
+            if (lane < kNb) vec[jb + rl] = r;
+            if (jb >= kNb) request_block(jb - kNb);   // in flight under the barrier and the column update
+        }
+        lds_barrier();
+#pragma unroll
+        for (int u = 0; u < kCols; ++u)
+            if (tid + u * kSolveThreads < jb) {
+                double v = vec[tid + u * kSolveThreads];
+#pragma unroll
+                for (int k = 0; k < kNb; ++k) v = __builtin_fma(-lr[u][k], vec[jb + k], v);
+                vec[tid + u * kSolveThreads] = v;
+            }
+        lds_barrier();
+    }
+    for (int i = tid; i < n_pad; i += kSolveThreads) S[(size_t)n_pad * n_pad + i] = vec[i];
+    SOLVE_MARK(6)   // backward substitution
+#undef SOLVE_MARK
+}
+static_assert(kMaxN % kSolveThreads == 0, "columns per thread in the backward substitution");
+
+// ---- LM trial state of the keyframes ------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ void dev_rot_to_quat(const double* R, double* q) {   // ba_host_math.h rot_to_quat
+    const double tr = R[0] + R[4] + R[8];
+    if (tr > 0) {
+        double s = sqrt(tr + 1.0);
+        q[3] = 0.5 * s;
+        s = 0.5 / s;
+        q[0] = (R[7] - R[5]) * s;
+        q[1] = (R[2] - R[6]) * s;
+        q[2] = (R[3] - R[1]) * s;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double s = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+        double qq[4];
+        qq[i] = 0.5 * s;
+        s = 0.5 / s;
+        qq[3] = (R[3 * k + j] - R[3 * j + k]) * s;
+        qq[j] = (R[3 * j + i] + R[3 * i + j]) * s;
+        qq[k] = (R[3 * k + i] + R[3 * i + k]) * s;
+        for (int a = 0; a < 4; ++a) q[a] = qq[a];
+    }
+    if (q[3] < 0)
+        for (int a = 0; a < 4; ++a) q[a] = -q[a];
+    const double nn = sqrt((q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]));
+    for (int a = 0; a < 4; ++a) q[a] /= nn;
+}
+
+__device__ void dev_se3_oplus(const double* TR, const double* Tt, const double* u, double* nR, double* nt) {   // ba_host_math.h se3_oplus
+    const double wx = u[0], wy = u[1], wz = u[2];
+    const double theta = sqrt((wx * wx + wy * wy) + wz * wz);
+    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double O2[9], E[9], V[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) O2[3 * i + j] = (O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j]) + O[3 * i + 2] * O[6 + j];
+    const bool small = theta < 0.00001;
+    const double s = small ? 0.0 : sin(theta), c = small ? 1.0 : cos(theta);
+    for (int i = 0; i < 9; ++i) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        if (small) {
+            E[i] = (I + O[i]) + O2[i];
+            V[i] = E[i];
+        } else {
+            E[i] = (I + s / theta * O[i]) + (1 - c) / (theta * theta) * O2[i];
+            V[i] = (I + (1 - c) / (theta * theta) * O[i]) + (theta - s) / (theta * theta * theta) * O2[i];
+        }
+    }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) nR[3 * i + j] = (E[3 * i] * TR[j] + E[3 * i + 1] * TR[3 + j]) + E[3 * i + 2] * TR[6 + j];
+        const double te = (V[3 * i] * u[3] + V[3 * i + 1] * u[4]) + V[3 * i + 2] * u[5];
+        nt[i] = ((E[3 * i] * Tt[0] + E[3 * i + 1] * Tt[1]) + E[3 * i + 2] * Tt[2]) + te;
+    }
+}
+
+}   // namespace
+
+// T (12 doubles per keyframe: R row-major | t) -> Tn, the 7-double records p7n (t | quaternion x y z w), dxp (6 per keyframe, zeros for
+// fixed ones) and scal_pose = sum over free keyframes, in keyframe order, of dx . (lambda dx + bp)  (the keyframes' part of g2o's
+// computeScale; the landmarks' part comes from k_backsub)
+__global__ __launch_bounds__(256) void k_pose_update(const double* __restrict__ T, const int32_t* __restrict__ slot_of_pose, int n_pose,
+                                                    const double* __restrict__ x, const double* __restrict__ bp, double lambda,
+                                                    double* __restrict__ Tn, double* __restrict__ p7n, double* __restrict__ dxp,
+                                                    double* __restrict__ scal_pose) {
+    __shared__ double s_term[256][7];   // a keyframe's six products (and whether it is free): thread 0 adds them in keyframe order
+    double sc = 0;
+    for (int base = 0; base < n_pose; base += 256) {
+        const int k = base + (int)threadIdx.x;
+        if (k < n_pose) {
+            const int sl = slot_of_pose[k];
+            double u[6] = {0, 0, 0, 0, 0, 0};
+            double nR[9], nt[3];
+            if (sl >= 0) {
+                for (int a = 0; a < 6; ++a) u[a] = x[6 * (size_t)sl + a];
+                dev_se3_oplus(T + 12 * (size_t)k, T + 12 * (size_t)k + 9, u, nR, nt);
+            } else {
+                for (int a = 0; a < 9; ++a) nR[a] = T[12 * (size_t)k + a];
+                for (int a = 0; a < 3; ++a) nt[a] = T[12 * (size_t)k + 9 + a];
+            }
+            for (int a = 0; a < 9; ++a) Tn[12 * (size_t)k + a] = nR[a];
+            for (int a = 0; a < 3; ++a) {
+                Tn[12 * (size_t)k + 9 + a] = nt[a];
+                p7n[7 * (size_t)k + a] = nt[a];
+            }
+            dev_rot_to_quat(nR, p7n + 7 * (size_t)k + 3);
+            for (int a = 0; a < 6; ++a) {
+                dxp[6 * (size_t)k + a] = u[a];
+                s_term[threadIdx.x][a] = u[a] * (lambda * u[a] + bp[6 * (size_t)k + a]);
+            }
+            s_term[threadIdx.x][6] = sl >= 0 ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int cnt = min(256, n_pose - base);
+            for (int i = 0; i < cnt; ++i)
+                if (s_term[i][6] != 0.0)
+                    for (int a = 0; a < 6; ++a) sc += s_term[i][a];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *scal_pose = sc;
+}
+
+// largest system the one-workgroup solver stages: (n_pad + 16) x 17 + 2 n_pad doubles of LDS (and one thread per unknown)
+int dense_solve_max_n() { return kMaxN; }
+
+int dense_solve_pad(int n) { return (n + kNb - 1) / kNb * kNb; }
+size_t dense_solve_doubles(int n) { return (size_t)(dense_solve_pad(n) + kNb) * dense_solve_pad(n); }   // the padded system's storage
+
+// d_S: the padded system of n unknowns (see above); the solution replaces the right-hand side at d_S + n_pad * n_pad
+ovs_status launch_dense_solve(double* d_S, int n, int32_t* d_fail, hipStream_t s, unsigned long long* d_tstats) {
+    if (n < 1 || n > dense_solve_max_n()) return OVS_ERR_INVALID;
+    const int n_pad = dense_solve_pad(n);
+    const size_t panel = sizeof(double) * (size_t)(n_pad + kNb) * kPitch, rest = sizeof(double) * 2 * (size_t)n_pad;
+    const int dbuf = 2 * panel + rest <= (size_t)150 * 1024 ? 1 : 0;   // two panels in LDS up to 528 unknowns
+    const size_t lds = (dbuf ? 2 : 1) * panel + rest;
+    static LdsAttrCache cache;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_chol_solve), lds, cache);
+    if (e != hipSuccess) {
+        set_last_error("hipFuncSetAttribute(k_chol_solve)", e);
+        return OVS_ERR_HIP;
+    }
+    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(kSolveThreads), lds, s, d_S, n_pad, dbuf, d_fail, d_tstats);
+    OVS_LAUNCH_TRY("k_chol_solve");
+    return OVS_OK;
+}
+
+ovs_status launch_pose_update(const double* d_T, const int32_t* d_slot_of_pose, int n_pose, const double* d_x, const double* d_bp, double lambda,
+                              double* d_Tn, double* d_p7n, double* d_dxp, double* d_scal_pose, hipStream_t s) {
+    hipLaunchKernelGGL(k_pose_update, dim3(1), dim3(256), 0, s, d_T, d_slot_of_pose, n_pose, d_x, d_bp, lambda, d_Tn, d_p7n, d_dxp, d_scal_pose);
+    OVS_LAUNCH_TRY("k_pose_update");
+    return OVS_OK;
+}
+
+}   // namespace ovs
+
+extern "C" {
+
+// the solver alone, on host arrays (a test / debugging entry: tests/test_gpu_ba.py compares it with numpy's solve)
+ovs_status ovs_ba_dense_solve(int32_t device, const double* S, const double* rhs, int32_t n, double* x) {
+    if (!S || !rhs || !x || n < 1 || n > ovs::dense_solve_max_n()) return OVS_ERR_INVALID;
+    if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
+    OVS_HIP_TRY(hipSetDevice(device));
+    const int n_pad = ovs::dense_solve_pad(n);
+    std::vector<double> h(ovs::dense_solve_doubles(n), 0.0);
+    for (int i = 0; i < n; ++i) std::memcpy(&h[(size_t)i * n_pad], S + (size_t)i * n, sizeof(double) * n);
+    for (int i = n; i < n_pad; ++i) h[(size_t)i * n_pad + i] = 1.0;
+    std::memcpy(&h[(size_t)n_pad * n_pad], rhs, sizeof(double) * n);
+    double* d = nullptr;
+    const size_t bytes = sizeof(double) * h.size();
+    OVS_HIP_TRY(hipMalloc(&d, bytes + 256));
+    int32_t* d_fail = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(d) + bytes);
+    unsigned long long* d_t = ovs::tuning().ba_trace ? reinterpret_cast<unsigned long long*>(d_fail + 2) : nullptr;   // 8 counters behind the flag
+    ovs_status st = OVS_OK;
+    int32_t h_fail = 0;
+    hipError_t e = hipMemcpy(d, h.data(), bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_fail, 0, 128);
+    if (e == hipSuccess) {
+        st = ovs::launch_dense_solve(d, n, d_fail, nullptr, d_t);
+        if (st == OVS_OK) e = hipDeviceSynchronize();
+    }
+    if (d_t && e == hipSuccess && st == OVS_OK) {
+        unsigned long long h_t[8] = {};
+        (void)hipMemcpy(h_t, d_t, sizeof(h_t), hipMemcpyDeviceToHost);
+        static const char* nm[7] = {"requests+panel load", "diagonal block", "row solves", "write-back", "trailing (wave 0)", "trailing (others)", "backward"};
+        std::fprintf(stderr, "[k_chol_solve n=%d]", n);
+        for (int i = 0; i < 7; ++i) std::fprintf(stderr, " %s %.1f us,", nm[i], h_t[i] * 0.01);
+        std::fprintf(stderr, "\n");
+    }
+    if (e == hipSuccess && st == OVS_OK) e = hipMemcpy(x, d + (size_t)n_pad * n_pad, sizeof(double) * n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && st == OVS_OK) e = hipMemcpy(&h_fail, d_fail, sizeof(int32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        ovs::set_last_error("ovs_ba_dense_solve", e);
+        return OVS_ERR_HIP;
+    }
+    if (st != OVS_OK) return st;
+    if (h_fail) {
+        ovs::set_last_error_text("ovs_ba_dense_solve: the matrix is not positive definite");
+        return OVS_ERR_INVALID;
+    }
+    return OVS_OK;
+}
+
+}   // extern "C"

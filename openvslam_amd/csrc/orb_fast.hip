@@ -50,7 +50,6 @@ __device__ __forceinline__ uint32_t mx16(uint32_t a, uint32_t b) {
 
 constexpr int kTileRowsMax = kCellSize + kCellOverlap;   // 70
 constexpr int kTileWords = 20;                           // 80-byte LDS pitch: five 16-byte chunks per row, chunk i of the tile at byte 16 * i
-constexpr int kTileBytes = kTileRowsMax * kTileWords * 4;
 constexpr int kChunks = kTileRowsMax * 5;                // 350: one per thread + a second one for threads 0..93
 constexpr int kSmapWords = 18;                           // 72-byte pitch: 4 + 64 + 4
 constexpr int kSmapRows = 66;                            // 1 + 64 + 1
