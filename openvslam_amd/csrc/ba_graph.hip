@@ -10,12 +10,12 @@
 //   k_lin_pose       one workgroup per keyframe over ITS edges: 21 + 6 pose-block terms per lane, fixed-shape tree reduction;
 //   k_reduce_scalars chi2 (and the Levenberg-Marquardt start damping: max |H_jj|) by one workgroup, fixed tree;
 //   k_lm_prepare     (Hll + lambda I)^-1 per landmark and Y_e = W_e Hll^-1 per edge;
-//   k_schur_pairs    one workgroup per pair of free keyframes (a, b >= a): S_ab = [a == b](Hpp_a + lambda I) - sum over the landmarks both
-//                    observe of Y_ea W_eb^T, the pair's entry list built once per edge set on the host;
+//   k_schur_pairs    one wave per pair of free keyframes (a, b >= a): S_ab = [a == b](Hpp_a + lambda I) - sum over the landmarks both
+//                    observe of Y_ea W_eb^T; the common landmarks are found on the device (k_edge_table: keyframe x landmark -> edge);
 //   k_schur_rhs      g_a = bp_a - sum over a's edges of Y_e bl_j;
-//   (host)           Cholesky of the reduced camera system, at most 6 n_pose square -- BASELINE's north star keeps this solve on the host;
+//   ba_solve.hip     Cholesky of the reduced camera system and the keyframes' trial state (round 4; ovs_local_ba_set_solver(1): on the
+//                    host as in rounds 1-3 and in BASELINE's north star -- then 0.7 MB come down and 5 KB go up per trial);
 //   k_backsub        dxl_j = Hll^-1 (bl_j - sum W_e^T dxp), the trial points X + dxl and the landmark part of g2o's gain-ratio scale.
-// Per trial 0.7 MB (S, g, bp) come down and 5 KB (poses, dxp) go up, instead of 16 MB down.
 // Per-edge arithmetic is the expression sequence of k_ba_linearize / the oracle (every product individually rounded), so Hpl, Hll and bl
 // are bit-identical to the CPU oracle; Hpp, bp and chi2 are tree sums (1e-15 relative), identical from run to run.
 #include <algorithm>
@@ -389,38 +389,91 @@ __global__ __launch_bounds__(128) void k_lm_prepare(GraphDev g, const double* __
     }
 }
 
-// S block (a, b), a <= b in slot order: entries = (edge of a, edge of b) pairs that share a landmark
-__global__ __launch_bounds__(256) void k_schur_pairs(const int32_t* __restrict__ pair_start, const int2* __restrict__ pair_ent,
-                                                    const int32_t* __restrict__ pair_ab, const int32_t* __restrict__ slot_pose,
+// edge_of[s * n_pt + j] = the edge of free keyframe s (slot order) to landmark j, or -1: what k_schur_pairs intersects two keyframes'
+// observations with (a keyframe observes a landmark at most once: checked at graph creation)
+__global__ __launch_bounds__(256) void k_edge_table(const GEdge* __restrict__ edges, int n_edge, const int32_t* __restrict__ slot_of_pose, int n_pt,
+                                                   int32_t* __restrict__ edge_of) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_edge) return;
+    const int s = slot_of_pose[edges[e].pose];
+    if (s >= 0) edge_of[(size_t)s * n_pt + edges[e].pt] = e;
+}
+
+// S block (a, b), a <= b in slot order: S_ab = [a == b](Hpp_a + lambda I) - sum over the landmarks both keyframes observe of Y_ea W_eb^T.
+// One WAVE per pair (round 4; until then a workgroup per pair fed from host-built pair lists, 3 ms of every graph build and 2.4 MB of its
+// upload at config 5): the wave walks keyframe a's observations 64 at a time, looks each landmark up in keyframe b's row of edge_of, and
+// queues the common ones in LDS in list order; whenever 64 are queued every lane takes one (108 multiply-adds on two 18-double records),
+// so the arithmetic runs with all lanes busy whatever the overlap of the two keyframes. Lane l accumulates queue entries l, l + 64, ...;
+// the 64 partial blocks are folded by a fixed xor tree: the same bits from run to run.
+__global__ __launch_bounds__(256) void k_schur_pairs(const int32_t* __restrict__ pose_start, const int32_t* __restrict__ pose_edges,
+                                                    const int32_t* __restrict__ pose_pt, const int32_t* __restrict__ pair_ab, int n_pairs,
+                                                    const int32_t* __restrict__ slot_pose, const int32_t* __restrict__ edge_of, int n_pt,
                                                     const double* __restrict__ Hpp, const double* __restrict__ Hpl, const double* __restrict__ Y,
-                                                    double lambda, int n, double* __restrict__ S) {
-    __shared__ double s_part[4][36];
-    const int pr = blockIdx.x;
+                                                    double lambda, int pitch, double* __restrict__ S) {
+    __shared__ int2 s_queue[4][128];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int pr = blockIdx.x * 4 + wave;
+    if (pr >= n_pairs) return;   // (no workgroup barrier below: the four waves are independent)
     const int sa = pair_ab[2 * pr], sb = pair_ab[2 * pr + 1];
+    const int ka = slot_pose[sa];
+    const int32_t* const tb = edge_of + (size_t)sb * n_pt;
+    int2* const q = s_queue[wave];
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-    for (int i = pair_start[pr] + (int)threadIdx.x; i < pair_start[pr + 1]; i += 256) {
-        const int2 en = pair_ent[i];
-        const double* y = Y + 18 * (size_t)en.x;
-        const double* W2 = Hpl + 18 * (size_t)en.y;
+    auto take = [&](int cnt) {   // lanes < cnt: one queued (edge of a, edge of b) each
+        if (lane < cnt) {
+            const int2 en = q[lane];
+            const double* y = Y + 18 * (size_t)en.x;
+            const double* W2 = Hpl + 18 * (size_t)en.y;
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+            for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int b = 0; b < 6; ++b) acc[6 * a + b] += (y[3 * a] * W2[3 * b] + y[3 * a + 1] * W2[3 * b + 1]) + y[3 * a + 2] * W2[3 * b + 2];
+                for (int b = 0; b < 6; ++b) acc[6 * a + b] += (y[3 * a] * W2[3 * b] + y[3 * a + 1] * W2[3 * b + 1]) + y[3 * a + 2] * W2[3 * b + 2];
+        }
+    };
+    int qn = 0;
+    const int i1 = pose_start[ka + 1];
+    for (int base = pose_start[ka]; base < i1; base += 64) {
+        const int i = base + lane;
+        int ea = 0, eb = -1;
+        if (i < i1) {
+            ea = pose_edges[i];
+            eb = tb[pose_pt[i]];
+        }
+        const unsigned long long bal = __ballot(eb >= 0);
+        if (eb >= 0) q[qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = int2{ea, eb};
+        qn += __popcll(bal);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (qn >= 64) {
+            take(64);
+            const int2 rest = q[64 + lane];   // (lanes >= qn - 64 read stale entries that nobody uses)
+            __builtin_amdgcn_wave_barrier();
+            q[lane] = rest;
+            qn -= 64;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    block_sum_256<36>(acc, s_part);
-    if (threadIdx.x == 0) {   // (a register array must not be indexed by threadIdx: that would put it in scratch)
+    take(qn);
 #pragma unroll
-        for (int i = 0; i < 36; ++i) s_part[0][i] = acc[i];
+    for (int i = 0; i < 36; ++i) {
+        double x = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        acc[i] = x;
     }
-    __syncthreads();
-    if (threadIdx.x < 36) {
-        const int a = threadIdx.x / 6, b = threadIdx.x - 6 * a;
-        double v = -s_part[0][threadIdx.x];
-        if (sa == sb) v = (Hpp[36 * (size_t)slot_pose[sa] + 6 * a + b] + (a == b ? lambda : 0.0)) + v;
-        S[(size_t)(6 * sa + a) * n + 6 * sb + b] = v;
-        if (sa != sb) S[(size_t)(6 * sb + b) * n + 6 * sa + a] = v;
+    // every lane holds the 36 sums: lane t < 36 writes entry t (a register array must not be indexed by the lane: selected by compares)
+    double mine = 0.0;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) mine = lane == i ? acc[i] : mine;
+    if (lane < 36) {
+        const int a = lane / 6, b = lane - 6 * a;
+        double v = -mine;
+        if (sa == sb) v = (Hpp[36 * (size_t)ka + 6 * a + b] + (a == b ? lambda : 0.0)) + v;
+        S[(size_t)(6 * sa + a) * pitch + 6 * sb + b] = v;
+        if (sa != sb) S[(size_t)(6 * sb + b) * pitch + 6 * sa + a] = v;
     }
 }
 
@@ -547,14 +600,13 @@ struct ovs_ba_graph {
     GEdge* d_edges = nullptr;
     int32_t *d_lm_start = nullptr, *d_lm_edges = nullptr, *d_lm_nmono = nullptr, *d_pose_start = nullptr, *d_pose_edges = nullptr;
     uint8_t* d_fixed = nullptr;
-    int32_t *d_pair_start = nullptr, *d_pair_ab = nullptr, *d_slot_pose = nullptr, *d_slot_of_pose = nullptr, *d_fail = nullptr;
-    int2* d_pair_ent = nullptr;
+    int32_t *d_pose_pt = nullptr, *d_pair_ab = nullptr, *d_slot_pose = nullptr, *d_slot_of_pose = nullptr, *d_fail = nullptr;
+    int32_t* d_edge_of = nullptr;   // [n_free x n_pt], solver arena
     int n_pairs = 0;
     double* d_lm_tmp = nullptr;   // [2 n_pt] per-landmark partials (chi2 / scale)
     // solver work space (allocated on first use: ovs_ba_graph_linearize_dev alone does not need it)
     double *d_Hinv = nullptr, *d_Y = nullptr, *d_S = nullptr, *d_rhs = nullptr, *d_bp_copy = nullptr, *d_dxp = nullptr, *d_scal = nullptr;
     int s_pitch = 0;   // doubles per row of d_S
-    bool pairs_built = false;
 
     GraphDev view() const {
         GraphDev g;
@@ -688,8 +740,8 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
         }
     }
     // A keyframe observes a landmark at most once (upstream: landmark::add_observation ignores a second observation by the same keyframe).
-    // The reduced system's pair lists below rely on that -- two edges of one free keyframe to one landmark would need cross terms that
-    // the lists do not carry, while Hpp / Hll / rhs would still count both edges --, so a caller-built edge list that breaks it is refused.
+    // The reduced system relies on that -- k_edge_table keeps ONE edge per (keyframe, landmark), and two edges of one free keyframe to one
+    // landmark would need cross terms, while Hpp / Hll / rhs would still count both edges --, so a caller-built edge list that breaks it is refused.
     {
         std::vector<int32_t> seen((size_t)n_pose, -1);
         for (int j = 0; j < n_pt; ++j)
@@ -719,42 +771,26 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
                  o_pose_start = blob.add(pose_start), o_pose_edges = blob.add(pose_edges), o_fixed = blob.add(g->fixed);
     const size_t o_active = blob.add(std::vector<uint8_t>((size_t)std::max(ne, 1), (uint8_t)1));
     const size_t o_lm_tmp = blob.reserve_bytes(sizeof(double) * 2 * (size_t)n_pt);
-    size_t o_pair_start = 0, o_pair_ab = 0, o_pair_ent = 0, o_slot_pose = 0;
-    const size_t o_slot_of_pose = blob.add(g->slot);   // keyframe -> block of the reduced system or -1 (k_pose_update)
-    // reduced-system pair lists: for every landmark all (edge a, edge b) with free poses and slot(a) <= slot(b)
+    size_t o_pair_ab = 0, o_slot_pose = 0;
+    const size_t o_slot_of_pose = blob.add(g->slot);   // keyframe -> block of the reduced system or -1 (k_pose_update, k_edge_table)
+    // the landmark of every entry of pose_edges: k_schur_pairs walks a keyframe's observations without touching the 48-byte edge records
+    std::vector<int32_t> pose_pt((size_t)ne);
+    for (int i = 0; i < ne; ++i) pose_pt[i] = g->edge_pt[pose_edges[i]];
+    const size_t o_pose_pt = blob.add(pose_pt);
+    // reduced system: the blocks (a, b), a <= b in slot order, one wave each (which landmarks two keyframes share is found on the device)
     if (g->n_free > 0) {
         const int nf = g->n_free;
         const int n_pairs = nf * (nf + 1) / 2;
-        auto pair_id = [nf](int a, int b) { return a * nf - a * (a - 1) / 2 + (b - a); };
-        std::vector<int32_t> pstart((size_t)n_pairs + 1, 0), pab((size_t)2 * n_pairs);
+        std::vector<int32_t> pab((size_t)2 * n_pairs);
+        int p = 0;
         for (int a = 0; a < nf; ++a)
             for (int b = a; b < nf; ++b) {
-                pab[(size_t)2 * pair_id(a, b)] = a;
-                pab[(size_t)2 * pair_id(a, b) + 1] = b;
+                pab[(size_t)2 * p] = a;
+                pab[(size_t)2 * p + 1] = b;
+                ++p;
             }
-        auto for_pairs = [&](auto&& fn) {
-            for (int j = 0; j < n_pt; ++j)
-                for (int i = lm_start[j]; i < lm_start[(size_t)j + 1]; ++i) {
-                    const int ea = lm_edges[i], sa = g->slot[g->edge_pose[ea]];
-                    if (sa < 0) continue;
-                    for (int i2 = lm_start[j]; i2 < lm_start[(size_t)j + 1]; ++i2) {
-                        const int eb = lm_edges[i2], sb = g->slot[g->edge_pose[eb]];
-                        if (sb < 0 || sb < sa) continue;
-                        // (ea, ea) is the diagonal term; two different edges of one keyframe to one landmark were refused above
-                        if (sb == sa && eb != ea) continue;
-                        fn(pair_id(sa, sb), ea, eb);
-                    }
-                }
-        };
-        for_pairs([&](int p, int, int) { ++pstart[(size_t)p + 1]; });
-        for (int p = 0; p < n_pairs; ++p) pstart[(size_t)p + 1] += pstart[p];
-        std::vector<int2> ent((size_t)pstart[n_pairs]);
-        std::vector<int32_t> fill(pstart.begin(), pstart.end() - 1);
-        for_pairs([&](int p, int ea, int eb) { ent[(size_t)fill[p]++] = int2{ea, eb}; });
         g->n_pairs = n_pairs;
-        o_pair_start = blob.add(pstart);
         o_pair_ab = blob.add(pab);
-        o_pair_ent = blob.add(ent);
         o_slot_pose = blob.add(g->slot_pose);
     }
     const double t2 = now();
@@ -771,15 +807,14 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     g->d_active = A + o_active;
     g->d_lm_tmp = reinterpret_cast<double*>(A + o_lm_tmp);
     g->d_slot_of_pose = reinterpret_cast<int32_t*>(A + o_slot_of_pose);
+    g->d_pose_pt = reinterpret_cast<int32_t*>(A + o_pose_pt);
     if (g->n_free > 0) {
-        g->d_pair_start = reinterpret_cast<int32_t*>(A + o_pair_start);
         g->d_pair_ab = reinterpret_cast<int32_t*>(A + o_pair_ab);
-        g->d_pair_ent = reinterpret_cast<int2*>(A + o_pair_ent);
         g->d_slot_pose = reinterpret_cast<int32_t*>(A + o_slot_pose);
     }
 #undef G_TRY
     if (trace)
-        std::fprintf(stderr, "[ovs_ba_graph_create] %.2f ms: edge records + counting sorts %.2f, blob + pair lists %.2f, malloc + upload of %.1f MB %.2f\n",
+        std::fprintf(stderr, "[ovs_ba_graph_create] %.2f ms: edge records + counting sorts %.2f, blob %.2f, malloc + upload of %.1f MB %.2f\n",
                      now() - t0, t1 - t0, t2 - t1, blob.bytes.size() / 1e6, now() - t2);
     *out = g;
     return OVS_OK;
@@ -821,8 +856,9 @@ ovs_status ba_graph_ensure_solver(ovs_ba_graph* g, hipStream_t s) {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t sys = dense_solve_doubles(n);
     const size_t b_hinv = al(sizeof(double) * 9 * (size_t)g->n_pt), b_y = al(sizeof(double) * 18 * ne),
-                 b_s = al(sizeof(double) * (sys + 6 * (size_t)g->n_pose)), b_dxp = al(sizeof(double) * 6 * (size_t)g->n_pose);
-    OVS_HIP_TRY(hipMalloc(&g->d_solver_arena, b_hinv + b_y + b_s + b_dxp + 512));
+                 b_s = al(sizeof(double) * (sys + 6 * (size_t)g->n_pose)), b_dxp = al(sizeof(double) * 6 * (size_t)g->n_pose),
+                 b_tab = al(sizeof(int32_t) * (size_t)std::max(g->n_free, 1) * (size_t)g->n_pt);
+    OVS_HIP_TRY(hipMalloc(&g->d_solver_arena, b_hinv + b_y + b_s + b_dxp + 512 + b_tab));
     unsigned char* A = g->d_solver_arena;
     g->d_Hinv = reinterpret_cast<double*>(A);
     g->d_Y = reinterpret_cast<double*>(A + b_hinv);
@@ -830,6 +866,12 @@ ovs_status ba_graph_ensure_solver(ovs_ba_graph* g, hipStream_t s) {
     g->d_dxp = reinterpret_cast<double*>(A + b_hinv + b_y + b_s);
     g->d_scal = reinterpret_cast<double*>(A + b_hinv + b_y + b_s + b_dxp);
     g->d_fail = reinterpret_cast<int32_t*>(A + b_hinv + b_y + b_s + b_dxp + 256);
+    g->d_edge_of = reinterpret_cast<int32_t*>(A + b_hinv + b_y + b_s + b_dxp + 512);
+    OVS_HIP_TRY(hipMemsetAsync(g->d_edge_of, 0xff, b_tab, s));   // -1
+    if (g->n_edge() > 0 && g->n_free > 0) {
+        hipLaunchKernelGGL(k_edge_table, dim3((g->n_edge() + 255) / 256), dim3(256), 0, s, g->d_edges, g->n_edge(), g->d_slot_of_pose, g->n_pt, g->d_edge_of);
+        OVS_LAUNCH_TRY("k_edge_table");
+    }
     g->s_pitch = n_pad;
     g->d_rhs = g->d_S + (size_t)n_pad * n_pad;
     g->d_bp_copy = g->d_S + sys;
@@ -850,8 +892,8 @@ ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_
     hipLaunchKernelGGL(k_lm_prepare, dim3((g->n_pt + 127) / 128), dim3(128), 0, s, v, d_Hll, d_Hpl, lambda, g->d_Hinv, g->d_Y, g->d_fail);
     OVS_LAUNCH_TRY("k_lm_prepare");
     if (g->n_free > 0) {
-        hipLaunchKernelGGL(k_schur_pairs, dim3(g->n_pairs), dim3(256), 0, s, g->d_pair_start, g->d_pair_ent, g->d_pair_ab, g->d_slot_pose, d_Hpp,
-                           d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S);
+        hipLaunchKernelGGL(k_schur_pairs, dim3((g->n_pairs + 3) / 4), dim3(256), 0, s, g->d_pose_start, g->d_pose_edges, g->d_pose_pt, g->d_pair_ab,
+                           g->n_pairs, g->d_slot_pose, g->d_edge_of, g->n_pt, d_Hpp, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S);
         OVS_LAUNCH_TRY("k_schur_pairs");
         hipLaunchKernelGGL(k_schur_rhs, dim3(g->n_free), dim3(256), 0, s, v, g->d_slot_pose, d_bp, d_bl, g->d_Y, g->d_rhs);
         OVS_LAUNCH_TRY("k_schur_rhs");
