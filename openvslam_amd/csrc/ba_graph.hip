@@ -10,7 +10,7 @@
 //   k_lin_pose       one workgroup per keyframe over ITS edges: 21 + 6 pose-block terms per lane, fixed-shape tree reduction;
 //   k_reduce_scalars chi2 (and the Levenberg-Marquardt start damping: max |H_jj|) by one workgroup, fixed tree;
 //   k_lm_prepare     (Hll + lambda I)^-1 per landmark and Y_e = W_e Hll^-1 per edge;
-//   k_schur_pairs    one wave per pair of free keyframes (a, b >= a): S_ab = [a == b](Hpp_a + lambda I) - sum over the landmarks both
+//   k_schur_pairs    one workgroup per pair of free keyframes (a, b >= a): S_ab = [a == b](Hpp_a + lambda I) - sum over the landmarks both
 //                    observe of Y_ea W_eb^T; the common landmarks are found on the device (k_edge_table: keyframe x landmark -> edge);
 //   k_schur_rhs      g_a = bp_a - sum over a's edges of Y_e bl_j;
 //   ba_solve.hip     Cholesky of the reduced camera system and the keyframes' trial state (round 4; ovs_local_ba_set_solver(1): on the
@@ -323,11 +323,28 @@ __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const doubl
                                                         const double* __restrict__ Hll, double* __restrict__ chi2) {
     __shared__ double s0[1024], s1[1024], s2[1024];
     double a = 0, b = 0, m = 0;
-    for (int j = threadIdx.x; j < g.n_pt; j += 1024) {
-        a += lm_chi[2 * (size_t)j];
-        b += lm_chi[2 * (size_t)j + 1];
-        if (g.lm_start[j + 1] > g.lm_start[j])
-            for (int d = 0; d < 3; ++d) m = fmax(m, fabs(Hll[9 * (size_t)j + 4 * d]));
+    // four landmarks of a thread in flight (all loads first, then the additions in the order of the plain loop: the same bits)
+    for (int j0 = threadIdx.x; j0 < g.n_pt; j0 += 4 * 1024) {
+        double ca[4], cb[4], dm[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 1024 * u;
+            const bool in = j < g.n_pt;
+            const size_t jj = in ? (size_t)j : 0;
+            const double2 c = reinterpret_cast<const double2*>(lm_chi)[jj];
+            const bool has = in && g.lm_start[jj + 1] > g.lm_start[jj];
+            const double d0 = Hll[9 * jj], d1 = Hll[9 * jj + 4], d2 = Hll[9 * jj + 8];
+            ca[u] = in ? c.x : 0.0;
+            cb[u] = in ? c.y : 0.0;
+            dm[u] = has ? fmax(fmax(fabs(d0), fabs(d1)), fabs(d2)) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + 1024 * u < g.n_pt) {
+                a += ca[u];
+                b += cb[u];
+                m = fmax(m, dm[u]);
+            }
     }
     for (int k = threadIdx.x; k < g.n_pose; k += 1024)
         if (!g.fixed[k])
@@ -400,20 +417,21 @@ __global__ __launch_bounds__(256) void k_edge_table(const GEdge* __restrict__ ed
 }
 
 // S block (a, b), a <= b in slot order: S_ab = [a == b](Hpp_a + lambda I) - sum over the landmarks both keyframes observe of Y_ea W_eb^T.
-// One WAVE per pair (round 4; until then a workgroup per pair fed from host-built pair lists, 3 ms of every graph build and 2.4 MB of its
-// upload at config 5): the wave walks keyframe a's observations 64 at a time, looks each landmark up in keyframe b's row of edge_of, and
-// queues the common ones in LDS in list order; whenever 64 are queued every lane takes one (108 multiply-adds on two 18-double records),
-// so the arithmetic runs with all lanes busy whatever the overlap of the two keyframes. Lane l accumulates queue entries l, l + 64, ...;
-// the 64 partial blocks are folded by a fixed xor tree: the same bits from run to run.
+// One workgroup per pair, no host-built pair lists (round 4; until then they cost 3 ms of every graph build and 2.4 MB of its upload at
+// config 5): each of the four waves walks a contiguous quarter of keyframe a's observations 64 at a time, looks each landmark up in
+// keyframe b's row of edge_of, and queues the common ones in LDS in list order; whenever 64 are queued every lane takes one (108
+// multiply-adds on two 18-double records), so the arithmetic runs with all lanes busy whatever the overlap of the two keyframes. Lane l
+// accumulates queue entries l, l + 64, ...; the 64 partial blocks of a wave are folded by a fixed xor tree, the four waves' blocks in wave
+// order: the same bits from run to run. (One wave per pair walked the whole list in 32 dependent steps: 107 us per launch at config 5.)
 __global__ __launch_bounds__(256) void k_schur_pairs(const int32_t* __restrict__ pose_start, const int32_t* __restrict__ pose_edges,
-                                                    const int32_t* __restrict__ pose_pt, const int32_t* __restrict__ pair_ab, int n_pairs,
+                                                    const int32_t* __restrict__ pose_pt, const int32_t* __restrict__ pair_ab,
                                                     const int32_t* __restrict__ slot_pose, const int32_t* __restrict__ edge_of, int n_pt,
                                                     const double* __restrict__ Hpp, const double* __restrict__ Hpl, const double* __restrict__ Y,
                                                     double lambda, int pitch, double* __restrict__ S) {
     __shared__ int2 s_queue[4][128];
+    __shared__ double s_part[4][36];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int pr = blockIdx.x * 4 + wave;
-    if (pr >= n_pairs) return;   // (no workgroup barrier below: the four waves are independent)
+    const int pr = blockIdx.x;
     const int sa = pair_ab[2 * pr], sb = pair_ab[2 * pr + 1];
     const int ka = slot_pose[sa];
     const int32_t* const tb = edge_of + (size_t)sb * n_pt;
@@ -433,8 +451,10 @@ __global__ __launch_bounds__(256) void k_schur_pairs(const int32_t* __restrict__
         }
     };
     int qn = 0;
-    const int i1 = pose_start[ka + 1];
-    for (int base = pose_start[ka]; base < i1; base += 64) {
+    const int i_lo = pose_start[ka], i_hi = pose_start[ka + 1];
+    const int quarter = ((i_hi - i_lo + 255) >> 8) << 6;   // a multiple of 64
+    const int i0 = i_lo + wave * quarter, i1 = min(i0 + quarter, i_hi);
+    for (int base = i0; base < i1; base += 64) {
         const int i = base + lane;
         int ea = 0, eb = -1;
         if (i < i1) {
@@ -462,15 +482,12 @@ __global__ __launch_bounds__(256) void k_schur_pairs(const int32_t* __restrict__
         double x = acc[i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-        acc[i] = x;
+        if (lane == 0) s_part[wave][i] = x;
     }
-    // every lane holds the 36 sums: lane t < 36 writes entry t (a register array must not be indexed by the lane: selected by compares)
-    double mine = 0.0;
-#pragma unroll
-    for (int i = 0; i < 36; ++i) mine = lane == i ? acc[i] : mine;
-    if (lane < 36) {
-        const int a = lane / 6, b = lane - 6 * a;
-        double v = -mine;
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        const int t = threadIdx.x, a = t / 6, b = t - 6 * a;
+        double v = -(((s_part[0][t] + s_part[1][t]) + s_part[2][t]) + s_part[3][t]);
         if (sa == sb) v = (Hpp[36 * (size_t)ka + 6 * a + b] + (a == b ? lambda : 0.0)) + v;
         S[(size_t)(6 * sa + a) * pitch + 6 * sb + b] = v;
         if (sa != sb) S[(size_t)(6 * sb + b) * pitch + 6 * sa + a] = v;
@@ -527,7 +544,14 @@ __global__ __launch_bounds__(128) void k_backsub(GraphDev g, const double* __res
 __global__ __launch_bounds__(1024) void k_sum_1024(const double* __restrict__ v, int n, double* __restrict__ out) {
     __shared__ double s0[1024];
     double a = 0;
-    for (int j = threadIdx.x; j < n; j += 1024) a += v[j];
+    for (int j0 = threadIdx.x; j0 < n; j0 += 4 * 1024) {   // four loads in flight, added in the plain loop's order
+        double c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = j0 + 1024 * u < n ? v[j0 + 1024 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + 1024 * u < n) a += c[u];
+    }
     s0[threadIdx.x] = a;
     __syncthreads();
     for (int w = 512; w > 0; w >>= 1) {
@@ -892,8 +916,8 @@ ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_
     hipLaunchKernelGGL(k_lm_prepare, dim3((g->n_pt + 127) / 128), dim3(128), 0, s, v, d_Hll, d_Hpl, lambda, g->d_Hinv, g->d_Y, g->d_fail);
     OVS_LAUNCH_TRY("k_lm_prepare");
     if (g->n_free > 0) {
-        hipLaunchKernelGGL(k_schur_pairs, dim3((g->n_pairs + 3) / 4), dim3(256), 0, s, g->d_pose_start, g->d_pose_edges, g->d_pose_pt, g->d_pair_ab,
-                           g->n_pairs, g->d_slot_pose, g->d_edge_of, g->n_pt, d_Hpp, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S);
+        hipLaunchKernelGGL(k_schur_pairs, dim3(g->n_pairs), dim3(256), 0, s, g->d_pose_start, g->d_pose_edges, g->d_pose_pt, g->d_pair_ab,
+                           g->d_slot_pose, g->d_edge_of, g->n_pt, d_Hpp, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S);
         OVS_LAUNCH_TRY("k_schur_pairs");
         hipLaunchKernelGGL(k_schur_rhs, dim3(g->n_free), dim3(256), 0, s, v, g->d_slot_pose, d_bp, d_bl, g->d_Y, g->d_rhs);
         OVS_LAUNCH_TRY("k_schur_rhs");

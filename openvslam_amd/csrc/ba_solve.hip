@@ -85,12 +85,15 @@ __device__ __forceinline__ void lds_barrier() {
 
 // column-major walk over the tiles (ti, tc) behind a panel: tc = 0 .. mt - 2 (tile columns), ti = tc .. mt - 1 (the last tile row carries the
 // rhs). The first tiles are those of the NEXT panel's columns.
-__device__ __forceinline__ void tile_advance(int& ti, int& tc, int mt, int steps) {
-    for (int s = 0; s < steps; ++s)
-        if (++ti >= mt) {
-            ++tc;
-            ti = tc;
-        }
+// the t-th tile of that walk: column tc holds mt - tc tiles, so tc = the largest integer with tc mt - tc (tc - 1) / 2 <= t
+__device__ __forceinline__ void tile_seek(int& ti, int& tc, int mt, int t) {
+    const float b = 2.0f * (float)mt + 1.0f;
+    int c = (int)((b - __builtin_sqrtf(fmaxf(b * b - 8.0f * (float)t, 0.0f))) * 0.5f);
+    c = min(max(c, 0), mt);
+    while (c > 0 && c * mt - c * (c - 1) / 2 > t) --c;
+    while ((c + 1) * mt - (c + 1) * c / 2 <= t) ++c;
+    tc = __builtin_amdgcn_readfirstlane(c);
+    ti = __builtin_amdgcn_readfirstlane(c + (t - (c * mt - c * (c - 1) / 2)));
 }
 
 // 1 / sqrt(p) by v_rsq_f64 + three Newton steps (enough from an 11-bit seed); sqrt(p) = p * that. A pivot step then costs ~15 dependent
@@ -136,8 +139,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_solve(double* __restrict
         const int m = n_rows - j0;        // staged rows
         const int mt = (m - kNb) / kNb;   // tile rows behind the panel; tile columns: mt - 1
         // ---- this wave's first kBatch tiles: their C values are requested now and arrive under the panel's factorisation
-        int ti = 0, tc = 0;
-        tile_advance(ti, tc, mt, wave);
+        const int n_tiles = (mt - 1) * (mt + 2) / 2;
+        int tlin = wave;   // this wave's tiles: tlin, tlin + kWaves, ...
         // a batch = kBatch tile descriptors (ti | tc << 16, -1 = none; wave-uniform) and their C values (4 doubles per lane and tile).
         // Addresses are 32-bit byte offsets from S, rebuilt where they are used: kept as 64-bit pointers from the loads to the stores they
         // would cost as many registers as the values.
@@ -153,12 +156,15 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_solve(double* __restrict
         auto gather = [&](int (&gd)[kBatch], v4d (&acc)[kBatch]) {
 #pragma unroll
             for (int q = 0; q < kBatch; ++q) {
-                gd[q] = tc < mt - 1 ? (ti | (tc << 16)) : -1;
-                if (gd[q] >= 0) {
+                gd[q] = -1;
+                if (tlin < n_tiles) {
+                    int ti, tc;
+                    tile_seek(ti, tc, mt, tlin);
+                    gd[q] = ti | (tc << 16);
                     const uint32_t o = tile_off(gd[q]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[q][e] = *reinterpret_cast<const double*>(Sb + (o + (uint32_t)e * row_step));
-                    tile_advance(ti, tc, mt, kWaves);
+                    tlin += kWaves;
                 }
             }
         };
@@ -201,26 +207,42 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_solve(double* __restrict
             if (tid == 0) atomicOr(fail, 2);
             return;
         }
-        // ---- the rows below: x L_dd^T = p, one thread per row; the rhs row's solution is this block of y
-        for (int r = kNb + tid; r < m; r += kSolveThreads) {
-            const int R = j0 + r;
-            double x[kNb];
+        // ---- the rows below: x L_dd^T = p, one thread per row; the rhs row's solution is this block of y. A wave keeps the block's 136
+        //      entries in three registers spread over its lanes (entry t = c (c + 1) / 2 + k in lane t % 64) and broadcasts them with
+        //      v_readlane: read from LDS by every lane, the 136 uniform loads per row made this phase LDS-bound.
+        {
+            double lreg[3];
 #pragma unroll
-            for (int c = 0; c < kNb; ++c) x[c] = P[r * kPitch + c];
-            const double* Ld = P;
-            asm volatile("" : "+v"(Ld));   // opaque per row: the 136 entries of L_dd are not hoisted out of the row loop into registers
-#pragma unroll
-            for (int c = 0; c < kNb; ++c) {
-                double v = x[c];
-#pragma unroll
-                for (int k = 0; k < c; ++k) v = __builtin_fma(-x[k], Ld[c * kPitch + k], v);
-                x[c] = v * invd[j0 + c];
+            for (int u = 0; u < 3; ++u) {
+                const int t = lane + 64 * u;   // -> (c, k), k <= c: c = the largest integer with c (c + 1) / 2 <= t
+                int c = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                c += ((c + 1) * (c + 2) / 2 <= t) ? 1 : 0;
+                c -= (c * (c + 1) / 2 > t) ? 1 : 0;
+                const int k = t - c * (c + 1) / 2;
+                lreg[u] = t < kNb * (kNb + 1) / 2 ? P[c * kPitch + k] : 0.0;
             }
+            double ivreg = invd[j0 + (lane & 15)];
+            for (int r = kNb + tid; r < m; r += kSolveThreads) {   // (v_readlane reads its lane whatever the execution mask)
+                asm volatile("" : "+v"(lreg[0]), "+v"(lreg[1]), "+v"(lreg[2]), "+v"(ivreg));   // broadcasts stay inside the row loop (scalar registers)
+                double x[kNb];
 #pragma unroll
-            for (int c = 0; c < kNb; ++c) P[r * kPitch + c] = x[c];
-            if (R == n_pad) {
+                for (int c = 0; c < kNb; ++c) x[c] = P[r * kPitch + c];
 #pragma unroll
-                for (int c = 0; c < kNb; ++c) vec[j0 + c] = x[c];   // y
+                for (int c = 0; c < kNb; ++c) {
+                    double v = x[c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) {
+                        const int t = c * (c + 1) / 2 + k;
+                        v = __builtin_fma(-x[k], lane_bcast(lreg[t >> 6], t & 63), v);
+                    }
+                    x[c] = v * lane_bcast(ivreg, c);
+                }
+#pragma unroll
+                for (int c = 0; c < kNb; ++c) P[r * kPitch + c] = x[c];
+                if (j0 + r == n_pad) {
+#pragma unroll
+                    for (int c = 0; c < kNb; ++c) vec[j0 + c] = x[c];   // y
+                }
             }
         }
         lds_barrier();
@@ -254,11 +276,11 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_solve(double* __restrict
                 }
         };
         for (;;) {
-            const bool more_b = tc < mt - 1;
+            const bool more_b = tlin < n_tiles;
             if (more_b) gather(db, accB);
             compute(da, accA);
             if (!more_b) break;
-            const bool more_a = tc < mt - 1;
+            const bool more_a = tlin < n_tiles;
             if (more_a) gather(da, accA);
             compute(db, accB);
             if (!more_a) break;
