@@ -251,6 +251,8 @@ __global__ __launch_bounds__(128) void k_lin_landmark(GraphDev g, const double* 
     for (int i = 0; i < 3; ++i) B[i] = gm[i] + gs[i];
     lm_chi[2 * (size_t)j] = c2m + c2s;
     lm_chi[2 * (size_t)j + 1] = r0m + r0s;
+    // largest |diagonal entry| of this landmark's block (0 without edges): what k_reduce_scalars needs of Hll, 8 bytes instead of a 72-byte row
+    lm_chi[2 * (size_t)g.n_pt + j] = e1 > e0 ? fmax(fmax(fabs(hm[0] + hs[0]), fabs(hm[4] + hs[4])), fabs(hm[8] + hs[8])) : 0.0;
 }
 
 // fixed-shape reduction of NV per-thread values over a 256-thread workgroup: lanes by xor-shuffle, then the four waves in order
@@ -332,11 +334,10 @@ __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const doubl
             const bool in = j < g.n_pt;
             const size_t jj = in ? (size_t)j : 0;
             const double2 c = reinterpret_cast<const double2*>(lm_chi)[jj];
-            const bool has = in && g.lm_start[jj + 1] > g.lm_start[jj];
-            const double d0 = Hll[9 * jj], d1 = Hll[9 * jj + 4], d2 = Hll[9 * jj + 8];
+            const double d = lm_chi[2 * (size_t)g.n_pt + jj];   // written by k_lin_landmark
             ca[u] = in ? c.x : 0.0;
             cb[u] = in ? c.y : 0.0;
-            dm[u] = has ? fmax(fmax(fabs(d0), fabs(d1)), fabs(d2)) : 0.0;
+            dm[u] = in ? d : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -627,7 +628,7 @@ struct ovs_ba_graph {
     int32_t *d_pose_pt = nullptr, *d_pair_ab = nullptr, *d_slot_pose = nullptr, *d_slot_of_pose = nullptr, *d_fail = nullptr;
     int32_t* d_edge_of = nullptr;   // [n_free x n_pt], solver arena
     int n_pairs = 0;
-    double* d_lm_tmp = nullptr;   // [2 n_pt] per-landmark partials (chi2 / scale)
+    double* d_lm_tmp = nullptr;   // [3 n_pt] per-landmark partials (chi2 pair, max |diagonal|; or the gain ratio's scale terms)
     // solver work space (allocated on first use: ovs_ba_graph_linearize_dev alone does not need it)
     double *d_Hinv = nullptr, *d_Y = nullptr, *d_S = nullptr, *d_rhs = nullptr, *d_bp_copy = nullptr, *d_dxp = nullptr, *d_scal = nullptr;
     int s_pitch = 0;   // doubles per row of d_S
@@ -794,7 +795,7 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     const size_t o_edges = blob.add(edges), o_lm_start = blob.add(lm_start), o_lm_edges = blob.add(lm_edges), o_lm_nmono = blob.add(lm_nmono),
                  o_pose_start = blob.add(pose_start), o_pose_edges = blob.add(pose_edges), o_fixed = blob.add(g->fixed);
     const size_t o_active = blob.add(std::vector<uint8_t>((size_t)std::max(ne, 1), (uint8_t)1));
-    const size_t o_lm_tmp = blob.reserve_bytes(sizeof(double) * 2 * (size_t)n_pt);
+    const size_t o_lm_tmp = blob.reserve_bytes(sizeof(double) * 3 * (size_t)n_pt);
     size_t o_pair_ab = 0, o_slot_pose = 0;
     const size_t o_slot_of_pose = blob.add(g->slot);   // keyframe -> block of the reduced system or -1 (k_pose_update, k_edge_table)
     // the landmark of every entry of pose_edges: k_schur_pairs walks a keyframe's observations without touching the 48-byte edge records

@@ -11,17 +11,26 @@
 // at BASELINE config 5 (288 x 288) -- more than the linearisations. Here a trial never leaves the device: the host reads back three
 // scalars and a flag.
 //
-// Algorithm (right-looking, blocked by 16 columns, lower triangle, in place in HBM / L2; the matrix is 0.66 MB at config 5):
-//   for every panel j0:  stage rows j0.. of columns [j0, j0 + 16) in LDS; wave 0 factors the 16 x 16 diagonal block in registers (one row
-//   per lane, broadcasts by v_readlane); one thread per remaining row solves its 16 entries against the block; the trailing matrix gets
-//   C -= P_i P_c^T per 16 x 16 tile with four v_mfma_f64_16x16x4_f64 (A = -P_i from LDS, B = P_c from LDS, C from / to memory).
-//   The right-hand side rides along as one more ROW of the matrix (it is stored right behind S): its "row solve" is the forward
-//   substitution, so only the backward substitution is left, done block-wise from L^T, which the row solves store into the (otherwise
-//   unused) upper triangle so that its rows are contiguous too.
-//   n is padded to a multiple of 16 with an identity block (loads substitute it, stores skip it).
+// Algorithm (right-looking, blocked by 16 columns, lower triangle, in place in HBM / L2; the matrix is 0.66 MB at config 5), 8 waves:
+//   for every panel j0:  the panel (rows j0.. of columns [j0, j0 + 16)) sits in LDS; wave 0 factors the 16 x 16 diagonal block in registers
+//   (one row per lane, broadcasts by v_readlane, reciprocal square roots by v_rsq_f64 + Newton); one thread per remaining row solves its 16
+//   entries against the block (the block's entries broadcast from registers too); the trailing matrix gets C -= P_i P_c^T per 16 x 16 tile
+//   with four v_mfma_f64_16x16x4_f64 (A = -P_i, B = P_c from LDS, C from / to memory) -- a wave's first tiles are requested BEFORE the panel is
+//   factored, later batches one batch ahead, and barriers inside a panel order LDS only, so the requests stay in flight; the tiles of the
+//   next panel's columns are written straight into a second LDS panel (systems up to 528 unknowns).
+//   The right-hand side rides along as one more ROW of the matrix: its "row solve" is the forward substitution. The backward substitution
+//   L^T x = y runs block-wise from the last block, right-looking: wave 0 solves a 16 x 16 block (from the block's L^T, which the panel
+//   write-back leaves above the diagonal), then every thread takes the block's columns out of its own unknown, with the rows of L it needs
+//   for the NEXT block already requested.
+//   The system is stored padded to a multiple of 16 with an identity block (layout below).
+// Where the time goes at 288 unknowns (OVS_BA_TRACE=1 with ovs_ba_dense_solve; ~240 us per solve): the trailing tiles travel through one
+// compute unit's 64 bytes per clock (8 MB read + written: ~125 us with the requests), the 288 pivot steps of the diagonal blocks are one
+// dependent chain (~50 us), row solves ~25 us, backward substitution ~35 us. Tried and dropped in round 4: the whole triangle resident in
+// registers as matrix-core accumulators (189 tiles = 378 KB of the 512 KB register file: needs one wave per SIMD with 512 registers, and the
+// compiler spills the other phases' arrays).
 // Numerics: fused multiply-adds and the matrix cores' internal order instead of the host's mul / sub pairs in column order -- results
-// agree with the host solve to ~1e-13 relative on these systems (tests/test_gpu_ba.py::test_dense_solve_*), far inside the 1e-7 the
-// optimiser's result is stated to (ORACLE_SPEC rule 25); identical bits from run to run (no atomics, fixed tile order).
+// agree with LAPACK's to ~cond x 1e-16 relative (tests/test_gpu_ba.py::test_dense_solve_matches_numpy), far inside the 1e-7 the optimiser's
+// result is stated to (ORACLE_SPEC rule 28); identical bits from run to run (no atomics, fixed tile order).
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -107,6 +116,135 @@ __device__ __forceinline__ double rsqrt_newton(double p) {
     return y;
 }
 
+// ---- the phases of one panel, shared by the two kernels below ------------------------------------------------------------------------
+// diagonal block: wave 0, lane r holds row r (entries c <= r are the lower triangle); leaves L_dd in P rows 0..15 and 1 / L[c][c] in invd
+__device__ __forceinline__ void factor_diagonal_block(double* __restrict__ P, double* __restrict__ invd, int j0, int lane, int* s_bad) {
+    const int r = lane & 15;
+    double a[kNb];
+#pragma unroll
+    for (int c = 0; c < kNb; ++c) a[c] = P[r * kPitch + c];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < kNb; ++k) {
+        const double piv = lane_bcast(a[k], k);
+        bad |= !(piv > 0.0);
+        const double y = rsqrt_newton(piv);
+        a[k] = (r == k) ? piv * y : a[k] * y;
+        if (lane == k) invd[j0 + k] = y;
+#pragma unroll
+        for (int c = k + 1; c < kNb; ++c) a[c] = __builtin_fma(-a[k], lane_bcast(a[k], c), a[c]);   // L[c][k] sits in lane c
+        __builtin_amdgcn_sched_barrier(0);   // keeps the 120 broadcasts of the unrolled nest from being hoisted (scalar register spills)
+    }
+    if (lane < kNb) {
+#pragma unroll
+        for (int c = 0; c < kNb; ++c)
+            if (c <= r) P[r * kPitch + c] = a[c];
+        if (bad && lane == 0) *s_bad = 1;
+    }
+}
+
+// the rows below the block: x L_dd^T = p, one thread per row; the rhs row's solution is this block of y. A wave keeps the block's 136
+// entries in three registers spread over its lanes (entry t = c (c + 1) / 2 + k in lane t % 64) and broadcasts them with v_readlane: read
+// from LDS by every lane, the 136 uniform loads per row made this phase LDS-bound.
+__device__ __forceinline__ void solve_rows(double* __restrict__ P, const double* __restrict__ invd, double* __restrict__ vec, int j0, int m,
+                                           int n_pad, int tid, int lane) {
+    double lreg[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int t = lane + 64 * u;   // -> (c, k), k <= c: c = the largest integer with c (c + 1) / 2 <= t
+        int c = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        c += ((c + 1) * (c + 2) / 2 <= t) ? 1 : 0;
+        c -= (c * (c + 1) / 2 > t) ? 1 : 0;
+        const int k = t - c * (c + 1) / 2;
+        lreg[u] = t < kNb * (kNb + 1) / 2 ? P[c * kPitch + k] : 0.0;
+    }
+    double ivreg = invd[j0 + (lane & 15)];
+    for (int r = kNb + tid; r < m; r += kSolveThreads) {   // (v_readlane reads its lane whatever the execution mask)
+        asm volatile("" : "+v"(lreg[0]), "+v"(lreg[1]), "+v"(lreg[2]), "+v"(ivreg));   // broadcasts stay inside the row loop (scalar registers)
+        double x[kNb];
+#pragma unroll
+        for (int c = 0; c < kNb; ++c) x[c] = P[r * kPitch + c];
+#pragma unroll
+        for (int c = 0; c < kNb; ++c) {
+            double v = x[c];
+#pragma unroll
+            for (int k = 0; k < c; ++k) {
+                const int t = c * (c + 1) / 2 + k;
+                v = __builtin_fma(-x[k], lane_bcast(lreg[t >> 6], t & 63), v);
+            }
+            x[c] = v * lane_bcast(ivreg, c);
+        }
+#pragma unroll
+        for (int c = 0; c < kNb; ++c) P[r * kPitch + c] = x[c];
+        if (j0 + r == n_pad) {
+#pragma unroll
+            for (int c = 0; c < kNb; ++c) vec[j0 + c] = x[c];   // y
+        }
+    }
+}
+
+// the finished panel goes back to memory (the backward substitution reads L row-wise, and the diagonal blocks' L^T)
+__device__ __forceinline__ void write_back_panel(double* __restrict__ S, const double* __restrict__ P, int j0, int m, int n_pad, int tid) {
+    for (int idx = tid; idx < m * kNb; idx += kSolveThreads) {
+        const int r = idx >> 4, c = idx & 15;
+        S[(size_t)(j0 + r) * n_pad + j0 + c] = (r < kNb && c > r) ? P[c * kPitch + r] : P[r * kPitch + c];   // (L_dd^T above the diagonal)
+    }
+}
+
+// backward substitution L^T x = y, right-looking, from the last block: wave 0 solves the 16 x 16 block (lane c holds row c of L_dd^T), then
+// thread c' < jb takes the block's 16 columns out of y[c']. The block's data for the NEXT step is requested before this step's arithmetic, so
+// no step waits for memory. Ends with x in the rhs row.
+__device__ __forceinline__ void backward_substitution(double* __restrict__ S, double* __restrict__ vec, const double* __restrict__ invd,
+                                                      int n_pad, int tid, int lane, int wave) {
+    const int rl = lane & 15;
+    constexpr int kCols = kMaxN / kSolveThreads;   // columns c' = tid + u * kSolveThreads of a thread
+    double lr[kCols][kNb], lr_next[kCols][kNb], tt[kNb];
+    auto request_rows = [&](int jb, double (&L16)[kCols][kNb]) {
+#pragma unroll
+        for (int u = 0; u < kCols; ++u)
+#pragma unroll
+            for (int k = 0; k < kNb; ++k) L16[u][k] = tid + u * kSolveThreads < jb ? S[(size_t)(jb + k) * n_pad + tid + u * kSolveThreads] : 0.0;
+    };
+    auto request_block = [&](int jb) {   // wave 0: row rl of the diagonal block's L^T
+        const int C = jb + rl;
+#pragma unroll
+        for (int k = 0; k < kNb; ++k) tt[k] = k > rl ? S[(size_t)C * n_pad + jb + k] : 0.0;
+    };
+    request_rows(n_pad - kNb, lr_next);
+    if (wave == 0) request_block(n_pad - kNb);
+    for (int jb = n_pad - kNb; jb >= 0; jb -= kNb) {
+#pragma unroll
+        for (int u = 0; u < kCols; ++u)
+#pragma unroll
+            for (int k = 0; k < kNb; ++k) lr[u][k] = lr_next[u][k];
+        if (jb >= kNb) request_rows(jb - kNb, lr_next);
+        if (wave == 0) {
+            double r = vec[jb + rl];
+            const double iv = invd[jb + rl];
+#pragma unroll
+            for (int k = kNb - 1; k >= 0; --k) {
+                const double xk = lane_bcast(r * iv, k);   // lane k holds its finished residual
+                if (rl == k) r = xk;
+                else if (rl < k) r = __builtin_fma(-tt[k], xk, r);
+            }
+            if (lane < kNb) vec[jb + rl] = r;
+            if (jb >= kNb) request_block(jb - kNb);   // in flight under the barrier and the column update
+        }
+        lds_barrier();
+#pragma unroll
+        for (int u = 0; u < kCols; ++u)
+            if (tid + u * kSolveThreads < jb) {
+                double v = vec[tid + u * kSolveThreads];
+#pragma unroll
+                for (int k = 0; k < kNb; ++k) v = __builtin_fma(-lr[u][k], vec[jb + k], v);
+                vec[tid + u * kSolveThreads] = v;
+            }
+        lds_barrier();
+    }
+    for (int i = tid; i < n_pad; i += kSolveThreads) S[(size_t)n_pad * n_pad + i] = vec[i];
+}
+
+
 // S: the padded system above (lower triangle read). On return the rhs row holds x, S is overwritten (L on and below the diagonal, the
 // diagonal blocks' L^T above it). *fail |= 2 when a pivot is not positive (the system is not positive definite; x is then
 // unspecified). dbuf: the LDS holds two panels -- the trailing update then writes the next panel's columns straight into the other one.
@@ -176,82 +314,17 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_solve(double* __restrict
             }
         lds_barrier();
         SOLVE_MARK(0)   // tile requests + panel load + barrier
-        // ---- diagonal block: lane r holds row r (entries c <= r are the lower triangle)
-        if (wave == 0) {
-            const int r = lane & 15;
-            double a[kNb];
-#pragma unroll
-            for (int c = 0; c < kNb; ++c) a[c] = P[r * kPitch + c];
-            bool bad = false;
-#pragma unroll
-            for (int k = 0; k < kNb; ++k) {
-                const double piv = lane_bcast(a[k], k);
-                bad |= !(piv > 0.0);
-                const double y = rsqrt_newton(piv);
-                a[k] = (r == k) ? piv * y : a[k] * y;
-                if (lane == k) invd[j0 + k] = y;
-#pragma unroll
-                for (int c = k + 1; c < kNb; ++c) a[c] = __builtin_fma(-a[k], lane_bcast(a[k], c), a[c]);   // L[c][k] sits in lane c
-                __builtin_amdgcn_sched_barrier(0);   // keeps the 120 broadcasts of the unrolled nest from being hoisted (scalar register spills)
-            }
-            if (lane < kNb) {
-#pragma unroll
-                for (int c = 0; c < kNb; ++c)
-                    if (c <= r) P[r * kPitch + c] = a[c];
-                if (bad && lane == 0) s_bad = 1;
-            }
-        }
+        if (wave == 0) factor_diagonal_block(P, invd, j0, lane, &s_bad);
         lds_barrier();
         SOLVE_MARK(1)   // diagonal block + barrier
         if (s_bad) {
             if (tid == 0) atomicOr(fail, 2);
             return;
         }
-        // ---- the rows below: x L_dd^T = p, one thread per row; the rhs row's solution is this block of y. A wave keeps the block's 136
-        //      entries in three registers spread over its lanes (entry t = c (c + 1) / 2 + k in lane t % 64) and broadcasts them with
-        //      v_readlane: read from LDS by every lane, the 136 uniform loads per row made this phase LDS-bound.
-        {
-            double lreg[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int t = lane + 64 * u;   // -> (c, k), k <= c: c = the largest integer with c (c + 1) / 2 <= t
-                int c = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-                c += ((c + 1) * (c + 2) / 2 <= t) ? 1 : 0;
-                c -= (c * (c + 1) / 2 > t) ? 1 : 0;
-                const int k = t - c * (c + 1) / 2;
-                lreg[u] = t < kNb * (kNb + 1) / 2 ? P[c * kPitch + k] : 0.0;
-            }
-            double ivreg = invd[j0 + (lane & 15)];
-            for (int r = kNb + tid; r < m; r += kSolveThreads) {   // (v_readlane reads its lane whatever the execution mask)
-                asm volatile("" : "+v"(lreg[0]), "+v"(lreg[1]), "+v"(lreg[2]), "+v"(ivreg));   // broadcasts stay inside the row loop (scalar registers)
-                double x[kNb];
-#pragma unroll
-                for (int c = 0; c < kNb; ++c) x[c] = P[r * kPitch + c];
-#pragma unroll
-                for (int c = 0; c < kNb; ++c) {
-                    double v = x[c];
-#pragma unroll
-                    for (int k = 0; k < c; ++k) {
-                        const int t = c * (c + 1) / 2 + k;
-                        v = __builtin_fma(-x[k], lane_bcast(lreg[t >> 6], t & 63), v);
-                    }
-                    x[c] = v * lane_bcast(ivreg, c);
-                }
-#pragma unroll
-                for (int c = 0; c < kNb; ++c) P[r * kPitch + c] = x[c];
-                if (j0 + r == n_pad) {
-#pragma unroll
-                    for (int c = 0; c < kNb; ++c) vec[j0 + c] = x[c];   // y
-                }
-            }
-        }
+        solve_rows(P, invd, vec, j0, m, n_pad, tid, lane);
         lds_barrier();
         SOLVE_MARK(2)   // row solves + barrier
-        // ---- the finished panel goes back to memory (the backward substitution reads L row-wise, and the diagonal blocks' L^T)
-        for (int idx = tid; idx < m * kNb; idx += kSolveThreads) {
-            const int r = idx >> 4, c = idx & 15;
-            S[(size_t)(j0 + r) * n_pad + j0 + c] = (r < kNb && c > r) ? P[c * kPitch + r] : P[r * kPitch + c];   // (L_dd^T above the diagonal)
-        }
+        write_back_panel(S, P, j0, m, n_pad, tid);
         SOLVE_MARK(3)   // write-back (thread 0's share)
         // ---- trailing update C -= P_i P_c^T: kBatch tiles of a wave are computed while its next kBatch are on their way
         auto compute = [&](const int (&gd)[kBatch], v4d (&acc)[kBatch]) {
@@ -294,54 +367,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_solve(double* __restrict
             Pn = t;
         }
     }
-    // ---- backward substitution L^T x = y, right-looking, from the last block: wave 0 solves the 16 x 16 block (lane c holds row c of
-    //      L_dd^T), then thread c' < jb takes the block's 16 columns out of y[c']. The block's data for the NEXT step is requested before
-    //      this step's arithmetic, so no step waits for memory.
-    constexpr int kCols = kMaxN / kSolveThreads;   // columns c' = tid + u * kSolveThreads of a thread
-    double lr[kCols][kNb], lr_next[kCols][kNb], tt[kNb];
-    auto request_rows = [&](int jb, double (&L16)[kCols][kNb]) {
-#pragma unroll
-        for (int u = 0; u < kCols; ++u)
-#pragma unroll
-            for (int k = 0; k < kNb; ++k) L16[u][k] = tid + u * kSolveThreads < jb ? S[(size_t)(jb + k) * n_pad + tid + u * kSolveThreads] : 0.0;
-    };
-    auto request_block = [&](int jb) {   // wave 0: row rl of the diagonal block's L^T
-        const int C = jb + rl;
-#pragma unroll
-        for (int k = 0; k < kNb; ++k) tt[k] = k > rl ? S[(size_t)C * n_pad + jb + k] : 0.0;
-    };
-    request_rows(n_pad - kNb, lr_next);
-    if (wave == 0) request_block(n_pad - kNb);
-    for (int jb = n_pad - kNb; jb >= 0; jb -= kNb) {
-#pragma unroll
-        for (int u = 0; u < kCols; ++u)
-#pragma unroll
-            for (int k = 0; k < kNb; ++k) lr[u][k] = lr_next[u][k];
-        if (jb >= kNb) request_rows(jb - kNb, lr_next);
-        if (wave == 0) {
-            double r = vec[jb + rl];
-            const double iv = invd[jb + rl];
-#pragma unroll
-            for (int k = kNb - 1; k >= 0; --k) {
-                const double xk = lane_bcast(r * iv, k);   // lane k holds its finished residual
-                if (rl == k) r = xk;
-                else if (rl < k) r = __builtin_fma(-tt[k], xk, r);
-            }
-            if (lane < kNb) vec[jb + rl] = r;
-            if (jb >= kNb) request_block(jb - kNb);   // in flight under the barrier and the column update
-        }
-        lds_barrier();
-#pragma unroll
-        for (int u = 0; u < kCols; ++u)
-            if (tid + u * kSolveThreads < jb) {
-                double v = vec[tid + u * kSolveThreads];
-#pragma unroll
-                for (int k = 0; k < kNb; ++k) v = __builtin_fma(-lr[u][k], vec[jb + k], v);
-                vec[tid + u * kSolveThreads] = v;
-            }
-        lds_barrier();
-    }
-    for (int i = tid; i < n_pad; i += kSolveThreads) S[(size_t)n_pad * n_pad + i] = vec[i];
+    backward_substitution(S, vec, invd, n_pad, tid, lane, wave);
     SOLVE_MARK(6)   // backward substitution
 #undef SOLVE_MARK
 }
