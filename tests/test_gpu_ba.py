@@ -446,3 +446,39 @@ def test_local_ba_device_and_host_solver_agree(stereo_frac, n_pose, n_pt, obs):
         assert np.array_equal(dev[k], host[k]), k
     again = ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], mono, d["cam"], st, bf)
     assert np.array_equal(again["poses"], dev["poses"]) and np.array_equal(again["points"], dev["points"])   # no atomics anywhere
+
+
+@pytest.mark.gpu
+def test_local_ba_with_every_keyframe_fixed_and_with_one_free(oracle):
+    """The reduced camera system's edge sizes: no free keyframe (only landmarks move: no system to solve) and a single free keyframe (6
+    unknowns inside one padded 16 x 16 block), both against the oracle."""
+    from oracle import lba
+    from openvslam_amd import ba
+    from test_ba import _lba_scene
+    d, mono, st, bf, _, _ = _lba_scene(5, n_pose=6, n_pt=600, obs_per_pose=300, stereo_frac=0.2)
+    for n_free in (0, 1):
+        fixed = np.ones(len(d["poses"]), np.uint8)
+        fixed[len(fixed) - n_free:] = 0
+        got = ba.local_ba_optimize(d["poses"], fixed, d["points"], mono, d["cam"], st, bf)
+        want = lba.local_ba_optimize(d["poses"], fixed, d["points"], mono, d["cam"], st, bf)
+        assert np.array_equal(got["info"][4:], want["info"][4:])
+        assert np.allclose(got["info"][:4], want["info"][:4], rtol=1e-7)
+        assert np.allclose(got["points"], want["points"], rtol=1e-7, atol=1e-8)
+        assert np.allclose(got["poses"], want["poses"], rtol=1e-7, atol=1e-8)
+        assert np.array_equal(got["poses"][fixed.astype(bool)], d["poses"][fixed.astype(bool)])
+
+
+@pytest.mark.gpu
+def test_local_ba_beyond_the_device_solvers_size_takes_the_host_solve():
+    """More than 1024 unknowns (172 free keyframes): ovs_local_ba_optimize solves the reduced camera system on the host as in rounds 1-3; the
+    result must not depend on the solver setting then, and the optimisation must still converge."""
+    from openvslam_amd import ba
+    d = synth_local_ba(n_pose=174, n_pt=6000, obs_per_pose=400, seed=3, pose_noise=0.02, point_noise=0.02, n_fixed=2)
+    a = ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], d["edges"], d["cam"])
+    try:
+        ba.local_ba_set_solver("host")
+        b = ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], d["edges"], d["cam"])
+    finally:
+        ba.local_ba_set_solver("device")
+    assert np.array_equal(a["poses"], b["poses"]) and np.array_equal(a["points"], b["points"])
+    assert a["info"][3] < 0.1 * a["info"][0] and a["info"][4] >= 3
