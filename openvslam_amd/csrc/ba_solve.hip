@@ -105,17 +105,6 @@ __device__ __forceinline__ void tile_seek(int& ti, int& tc, int mt, int t) {
     ti = __builtin_amdgcn_readfirstlane(c + (t - (c * mt - c * (c - 1) / 2)));
 }
 
-// 1 / sqrt(p) by v_rsq_f64 + three Newton steps (enough from an 11-bit seed); sqrt(p) = p * that. A pivot step then costs ~15 dependent
-// operations instead of the ~45 of an IEEE sqrt followed by an IEEE division -- the 6 n_free pivot steps are the one chain of the
-// factorisation nothing can overlap.
-__device__ __forceinline__ double rsqrt_newton(double p) {
-    double y = __builtin_amdgcn_rsq(p);
-    const double h = 0.5 * p;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) y = y * __builtin_fma(-h * y, y, 1.5);
-    return y;
-}
-
 // ---- the phases of one panel, shared by the two kernels below ------------------------------------------------------------------------
 // diagonal block: wave 0, lane r holds row r (entries c <= r are the lower triangle); leaves L_dd in P rows 0..15 and 1 / L[c][c] in invd
 __device__ __forceinline__ void factor_diagonal_block(double* __restrict__ P, double* __restrict__ invd, int j0, int lane, int* s_bad) {

@@ -34,6 +34,7 @@ const Tuning& tuning() {
         v.describe_xcd = num("OVS_DESCRIBE_XCD", 1) != 0;
         v.resolve_wide_from = num("OVS_RESOLVE_WIDE_FROM", 1024);
         v.pose_threads = num("OVS_POSE_THREADS", 0);
+        v.pose_groups = std::max(0, num("OVS_POSE_GROUPS", 0));
         v.ba_trace = std::getenv("OVS_BA_TRACE") != nullptr;
         return v;
     }();

@@ -121,6 +121,7 @@ struct Tuning {
     bool describe_xcd;     // OVS_DESCRIBE_XCD=0: plain frame-major order in k_describe
     int resolve_wide_from; // OVS_RESOLVE_WIDE_FROM: queries from which a resolver round takes 512 of them
     int pose_threads;      // OVS_POSE_THREADS: 256 / 512 (0 = by problem size)
+    int pose_groups;       // OVS_POSE_GROUPS: workgroups a single frame's pose optimisation is spread over (0 = by observation count, 1 = one)
     bool ba_trace;         // OVS_BA_TRACE: per-iteration trace of the LM loops on stderr
 };
 const Tuning& tuning();
@@ -246,6 +247,19 @@ struct StageProfiler {
         created = false;
     }
 };
+
+// 1 / sqrt(p) by v_rsq_f64 + three Newton steps (enough from an 11-bit seed); sqrt(p) = p * that. A Cholesky pivot then costs ~15 dependent
+// operations instead of the ~45 of an IEEE sqrt followed by an IEEE division (results differ from those by an ulp or two): the pivots are
+// the one chain of a factorisation nothing can overlap (ba_solve.hip: 6 n_free of them; pose_opt.hip: 6 per LM trial on one lane).
+#ifdef __HIPCC__
+__device__ __forceinline__ double rsqrt_newton(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    const double h = 0.5 * p;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) y = y * __builtin_fma(-h * y, y, 1.5);
+    return y;
+}
+#endif
 
 }   // namespace ovs
 

@@ -44,8 +44,10 @@ __device__ void se3_exp_d(const double* u, PoseD& out) {
     // the three coefficients once (the expressions of upstream's Sophus-style exp, evaluated per matrix entry there)
     double sn = 0.0, cs = 1.0;
     if (!small) sincos(theta, &sn, &cs);   // one argument reduction, one pass over the two polynomials (sin() and cos() each evaluate both)
-    const double th2 = theta * theta;
-    const double ka = small ? 0.0 : sn / theta, kb = small ? 0.0 : (1 - cs) / th2, kc = small ? 0.0 : (theta - sn) / (th2 * theta);
+    // one division for the three coefficients sin / theta, (1 - cos) / theta^2, (theta - sin) / theta^3 (round 4: three IEEE divides were ~90
+    // dependent instructions of the one lane every trial waits for; the products differ from the quotients by an ulp)
+    const double it = small ? 0.0 : 1.0 / theta, it2 = it * it;
+    const double ka = sn * it, kb = (1 - cs) * it2, kc = (theta - sn) * (it2 * it);
     for (int i = 0; i < 9; ++i) {
         const double I = (i % 4 == 0) ? 1.0 : 0.0;
         if (small) {
@@ -67,8 +69,9 @@ __device__ void compose_d(const PoseD& a, const PoseD& b, PoseD& out) {
 }
 
 // (H + lambda I) x = b by Cholesky. One thread runs this between two barriers of a one-workgroup kernel, so its dependent chain is the
-// kernel's: the 27 divisions by diagonal entries are 6 reciprocals and 27 multiplications (an IEEE f64 divide is a ~30-instruction
-// dependent sequence; the products differ from the quotients by an ulp, far inside the optimiser's 1e-9 tolerance against the oracle).
+// kernel's: the 27 divisions by diagonal entries are 6 reciprocal square roots (v_rsq_f64 + Newton, round 4: ~15 dependent operations
+// instead of an IEEE sqrt and an IEEE divide of ~55) and 27 multiplications; the products differ from the quotients by an ulp or two, far
+// inside the optimiser's 1e-9 tolerance against the oracle.
 __device__ bool solve6_d(const double* H, double lambda, const double* b, double* x) {
     double L[36], inv[6];
     for (int i = 0; i < 36; ++i) L[i] = 0;
@@ -78,8 +81,7 @@ __device__ bool solve6_d(const double* H, double lambda, const double* b, double
             for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
             if (i == j) {
                 if (!(s > 0)) return false;
-                L[6 * i + i] = sqrt(s);
-                inv[i] = 1.0 / L[6 * i + i];
+                inv[i] = rsqrt_newton(s);   // (L[i][i] itself is never read: every use below is a multiplication by its reciprocal)
             } else {
                 L[6 * i + j] = s * inv[j];
             }
@@ -224,7 +226,12 @@ template <int MODEL, int kPoseThreads>   // MODEL 0 perspective (mono / stereo e
 __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __restrict__ poses_in, const ovs_pose_obs* __restrict__ obs_all,
                                                       const int32_t* __restrict__ obs_offsets, ovs_ba_cam cam, double bf, int setup_type,
                                                       double* __restrict__ poses_out, uint8_t* __restrict__ outlier_all,
-                                                      int32_t* __restrict__ num_valid, int reset_each_round) {
+                                                      int32_t* __restrict__ num_valid, int reset_each_round, int G, double* __restrict__ gpart,
+                                                      unsigned int* __restrict__ gsync) {
+    // G > 1 (round 4, single-frame latency path): the frame's observations are spread over G workgroups (blockIdx.y). Every sum over the
+    // observations is then a sum of G workgroup partials exchanged through memory behind a grid-wide barrier; each workgroup adds them in
+    // the same order, solves the same 6 x 6 system and takes the same branches, so there is no second barrier and no broadcast.
+    // gpart: [frame][2][G][28] doubles (two epochs), gsync: [frame][2] = arrival counter, abort flag.
     constexpr int kPoseWaves = kPoseThreads / 64;
     constexpr int kRedPitch = kPoseThreads + 8;   // doubles per row of the reduction scratch
     __shared__ double s_part[kPoseWaves][28];
@@ -235,7 +242,57 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
     __shared__ double s_ctl[4];   // [0] = continue trials of this iteration, [1] = continue iterations of this round
     __shared__ int s_cnt[kPoseWaves];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int p = blockIdx.x;
+    // G > 1 is launched for ONE frame with 8 G workgroups of which every eighth works: consecutive workgroups are dealt round-robin to the
+    // eight XCDs, so the G workers share one XCD's L2 and the barrier's atomics and the partials never cross the fabric
+    if (G > 1 && (blockIdx.y & 7u) != 0u) return;
+    const int p = blockIdx.x, grp = G > 1 ? (int)(blockIdx.y >> 3) : 0;
+    const int gtid = grp * kPoseThreads + tid, gstride = G * kPoseThreads;   // this thread's observations: gtid, gtid + gstride, ...
+    double* const my_part = gpart ? gpart + (size_t)p * 2 * G * 28 : nullptr;
+    unsigned int* const my_sync = gsync ? gsync + 2 * (size_t)p : nullptr;
+    unsigned int epoch = 0;   // grid barriers passed (workgroup-uniform, the same in every workgroup of the frame)
+    __shared__ int s_abort;
+    if (tid == 0) s_abort = 0;
+    // exchange nv <= 28 workgroup sums (in s_sum) between the frame's workgroups: afterwards s_sum holds the sums over all of them, added in
+    // workgroup order. Returns false when the barrier was abandoned (a workgroup of the frame never arrived within 50 ms: the launch is
+    // reported as failed and the caller falls back to one workgroup per frame).
+    auto exchange = [&](int nv) -> bool {
+        if (G == 1) return true;
+        ++epoch;
+        double* const mine = my_part + ((size_t)(epoch & 1u) * G + grp) * 28;
+        if (tid < nv) __hip_atomic_store(&mine[tid], s_sum[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(&my_sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int target = epoch * (unsigned int)G;
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(&my_sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (__hip_atomic_load(&my_sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > 5000000ull) {
+                    __hip_atomic_store(&my_sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_abort = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        if (s_abort) return false;
+        // one load per thread, all of them in flight together (G dependent loads per thread cost G round trips to L2), then the sums in
+        // workgroup order from LDS (s_red is free here: the linearisation's reduction is over)
+        if (tid < 28 * G) s_red[tid] = __hip_atomic_load(&my_part[(size_t)(epoch & 1u) * G * 28 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (tid < nv) {
+            double v = s_red[tid];
+            for (int g = 1; g < G; ++g) v += s_red[g * 28 + tid];
+            s_sum[tid] = v;
+        }
+        __syncthreads();
+        return true;
+    };
+#define POSE_EXCHANGE(nv)                                        \
+    if (!exchange(nv)) {                                         \
+        if (tid == 0 && grp == 0) num_valid[p] = -2;             \
+        return;                                                  \
+    }
     const int o0 = obs_offsets[p], n = obs_offsets[p + 1] - o0;
     const ovs_pose_obs* obs = obs_all + o0;
     uint8_t* outlier = outlier_all + o0;
@@ -298,12 +355,11 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
     PoseD T0;
     for (int i = 0; i < 9; ++i) T0.R[i] = poses_in[12 * (size_t)p + i];
     for (int i = 0; i < 3; ++i) T0.t[i] = poses_in[12 * (size_t)p + 9 + i];
-    uint32_t active = 0xFFFFFFFFu;   // bit k <-> observation tid + kPoseThreads * k
+    uint32_t active = 0xFFFFFFFFu;   // bit k <-> observation gtid + gstride * k
     int st_any = 0;
-    for (int i = tid; i < n; i += kPoseThreads) {
-        outlier[i] = 0;
-        if (MODEL == 0) st_any |= obs[i].is_stereo;
-    }
+    for (int i = gtid; i < n; i += gstride) outlier[i] = 0;
+    if (MODEL == 0)
+        for (int i = tid; i < n; i += kPoseThreads) st_any |= obs[i].is_stereo;   // (every workgroup scans the whole frame: the flag must be the same in all)
     const bool has_stereo = MODEL == 0 && __builtin_amdgcn_readfirstlane(__syncthreads_or(st_any)) != 0;
     if (tid == 0) s_T = T0;
     __syncthreads();
@@ -323,7 +379,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
             // common case -- that IS the next iteration's linearisation (same state, same operations, same bits), which then starts without a
             // pass over the observations and without its reduction. Retries after a rejection evaluate chi2 only.
             bool have_lin = false;       // s_sum holds the system at s_T
-            auto linearise_at = [&](bool at_trial) __attribute__((always_inline)) {   // state s_Tn / s_T -> s_sum[0 .. 27] (H upper triangle, b, robust chi2)
+            auto linearise_at = [&](bool at_trial) __attribute__((always_inline)) -> bool {   // state s_Tn / s_T -> s_sum[0 .. 27] (H upper triangle, b, robust chi2)
                 double acc[28];
 #pragma unroll
                 for (int i = 0; i < 28; ++i) acc[i] = 0;
@@ -331,7 +387,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                 for (int i = 0; i < 9; ++i) R[i] = at_trial ? s_Tn.R[i] : s_T.R[i];
                 for (int i = 0; i < 3; ++i) t[i] = at_trial ? s_Tn.t[i] : s_T.t[i];
                 auto sweep = [&](auto stereo_tag) __attribute__((always_inline)) {
-                    for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k)
+                    for (int k = 0, i = gtid; i < n; i += gstride, ++k)
                         if ((active >> k) & 1u) {
                             const ovs_pose_obs o = obs[i];
                             pose_edge_impl<MODEL, decltype(stereo_tag)::value>(R, t, o, cam, bf, robust ? huber : 0.0, acc);
@@ -342,10 +398,14 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
 #pragma unroll
                 for (int i = 0; i < 28; ++i) s_red[i * kRedPitch + tid] = acc[i];
                 reduce28_finish();
+                return exchange(28);
             };
             for (int it = 0; it < 10; ++it) {
                 err_at_trial = false;    // solve() starts with computeActiveErrors() at the current estimate
-                if (!have_lin) linearise_at(false);
+                if (!have_lin && !linearise_at(false)) {
+                    if (tid == 0 && grp == 0) num_valid[p] = -2;
+                    return;
+                }
                 have_lin = false;
                 // the system stays in LDS (s_sys: H upper triangle row-major, b, chi2): only thread 0 needs it, for the solve, and 42 doubles
                 // held by every thread across the trial's linearisation would not fit the register file of a 512-thread workgroup
@@ -394,7 +454,10 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                     double temp_chi = 1.7976931348623157e308;
                     const bool full = ok && qmax == 0;   // (workgroup-uniform)
                     if (full) {
-                        linearise_at(true);
+                        if (!linearise_at(true)) {
+                            if (tid == 0 && grp == 0) num_valid[p] = -2;
+                            return;
+                        }
                         temp_chi = s_sum[27];
                         err_at_trial = true;
                     } else if (ok) {
@@ -403,7 +466,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                         for (int i = 0; i < 3; ++i) t[i] = s_Tn.t[i];
                         double part = 0;
                         auto sweep = [&](auto stereo_tag) __attribute__((always_inline)) {
-                            for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k)
+                            for (int k = 0, i = gtid; i < n; i += gstride, ++k)
                                 if ((active >> k) & 1u) {
                                     const ovs_pose_obs o = obs[i];
                                     const double c2 = pose_edge_impl<MODEL, decltype(stereo_tag)::value>(R, t, o, cam, bf, 0.0, nullptr);
@@ -416,6 +479,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                         if (has_stereo) sweep(std::true_type{});
                         else sweep(std::false_type{});
                         reduce(&part, 1);
+                        POSE_EXCHANGE(1)
                         temp_chi = s_sum[0];
                         err_at_trial = true;
                     }
@@ -450,7 +514,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                 int bad = 0;
                 const uint32_t was_active = active;
                 active = 0;
-                for (int k = 0, i = tid; i < n; i += kPoseThreads, ++k) {
+                for (int k = 0, i = gtid; i < n; i += gstride, ++k) {
                     const ovs_pose_obs o = obs[i];
                     const bool wa = (was_active >> k) & 1u;
                     const double c2 = pose_edge_impl<MODEL, true>(wa ? Re : R, wa ? te : t, o, cam, bf, 0.0, nullptr);
@@ -467,13 +531,23 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                 num_bad = 0;
                 for (int w = 0; w < kPoseWaves; ++w) num_bad += s_cnt[w];
                 __syncthreads();
+                if (G > 1) {   // (counts below 2^53 are exact as doubles)
+                    if (tid == 0) s_sum[0] = (double)num_bad;
+                    __syncthreads();
+                    POSE_EXCHANGE(1)
+                    num_bad = (int)s_sum[0];
+                    __syncthreads();
+                }
             }
             if (n - num_bad < 5) break;   // upstream: if (num_init_obs - num_bad_obs < 5) break;
         }
     }
-    if (tid < 9) poses_out[12 * (size_t)p + tid] = s_T.R[tid];
-    if (tid < 3) poses_out[12 * (size_t)p + 9 + tid] = s_T.t[tid];
-    if (tid == 0) num_valid[p] = n >= 5 ? n - num_bad : 0;
+    if (grp == 0) {
+        if (tid < 9) poses_out[12 * (size_t)p + tid] = s_T.R[tid];
+        if (tid < 3) poses_out[12 * (size_t)p + 9 + tid] = s_T.t[tid];
+        if (tid == 0) num_valid[p] = n >= 5 ? n - num_bad : 0;
+    }
+#undef POSE_EXCHANGE
 }
 
 }   // namespace ovs
@@ -487,7 +561,8 @@ extern "C" {
 
 static ovs_status pose_optimize_batch_dev(int model, const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
                                           const ovs_ba_cam& cam, double focal_x_baseline, int32_t setup_type, double* d_poses_out,
-                                          uint8_t* d_outlier, int32_t* d_num_valid, void* stream, int threads_default = 256) {
+                                          uint8_t* d_outlier, int32_t* d_num_valid, void* stream, int threads_default = 256, int groups = 1,
+                                          double* d_gpart = nullptr, unsigned int* d_gsync = nullptr) {
     if (!d_poses_in || !d_obs || !d_obs_offsets || !d_poses_out || !d_outlier || !d_num_valid || batch < 1) return OVS_ERR_INVALID;
     // workgroup size: the kernel is one latency-bound workgroup per frame; more waves hide the f64 latency of the per-observation work
     // but pay in barriers (measured per 2000-observation frame in DESIGN.md section 3.6)
@@ -498,8 +573,9 @@ static ovs_status pose_optimize_batch_dev(int model, const double* d_poses_in, c
     do {                                                                                                                              \
         static LdsAttrCache configured; /* per device: a second device needs the attribute too (116 KB of dynamic LDS at 512 threads) */  \
         OVS_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(k_pose_optimize<MODEL, TT>), sizeof(double) * 28 * (TT + 8), configured)); \
-        hipLaunchKernelGGL((k_pose_optimize<MODEL, TT>), dim3(batch), dim3(TT), lds, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, \
-                           cam, BF, ST, d_poses_out, d_outlier, d_num_valid, g_pose_reset_each_round.load(std::memory_order_relaxed));     \
+        hipLaunchKernelGGL((k_pose_optimize<MODEL, TT>), dim3(batch, groups > 1 ? 8 * groups : 1), dim3(TT), lds, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, \
+                           cam, BF, ST, d_poses_out, d_outlier, d_num_valid, g_pose_reset_each_round.load(std::memory_order_relaxed), groups, d_gpart, \
+                           d_gsync);                                                                                                  \
     } while (0)
     if (model == 1) {
         if (T == 512) OVS_POSE_LAUNCH(1, 512, 0.0, 0);
@@ -546,9 +622,10 @@ static ovs_status pose_optimize_host(int model, int32_t device, const double* po
     // one device block and its pinned host mirror: inputs [pose 12 f64 | offsets 2 i32 | pad | observations] go up in ONE copy, outputs
     // [pose 12 f64 | num_valid | pad | outlier flags] come back in ONE copy, one wait (was three synchronous copies each way: ~60 us of a
     // 0.7 ms call)
-    const size_t off_off = 96, off_obs = 128, in_bytes = off_obs + sizeof(ovs_pose_obs) * no;
+    const size_t off_off = 96, off_sync = 112, off_obs = 128, in_bytes = off_obs + sizeof(ovs_pose_obs) * no;
     const size_t off_out = (in_bytes + 255) & ~(size_t)255, off_nv = off_out + 96, off_fl = off_out + 128, out_bytes = 128 + no;
-    const size_t total = off_out + ((out_bytes + 15) & ~(size_t)15);
+    constexpr int kMaxGroups = 8;
+    const size_t off_part = (off_out + out_bytes + 255) & ~(size_t)255, total = off_part + sizeof(double) * 2 * kMaxGroups * 28;
     // per-thread, per-device staging that only grows: this runs once per tracked frame, an allocation per call would cost more than
     // the optimisation itself
     struct Scratch {
@@ -581,19 +658,37 @@ static ovs_status pose_optimize_host(int model, int32_t device, const double* po
     const int32_t offs[2] = {0, n_obs};
     std::memcpy(h, pose_cw_in, sizeof(double) * 12);
     std::memcpy(h + off_off, offs, sizeof(offs));
+    std::memset(h + off_sync, 0, 16);   // the grid barrier's arrival counter and abort flag
     if (n_obs) std::memcpy(h + off_obs, obs, sizeof(ovs_pose_obs) * (size_t)n_obs);
     OVS_HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, scratch.stream));
     // one latency-bound workgroup: 512 threads hide the f64 latency of the per-observation work when there is enough of it; measured,
     // 256 / 512 threads: perspective 2000 observations 0.509 / 0.512 ms, 1000: 0.438 / 0.422, 500: 0.286 / 0.293; equirectangular
     // 2000: 1.39 / 1.15, 1000: 0.759 / 0.786, 500: 0.427 / 0.588
-    const int threads = (model == 1 ? n_obs >= 1500 : n_obs >= 768) ? 512 : 256;
-    const ovs_status st = pose_optimize_batch_dev(model, reinterpret_cast<double*>(d), reinterpret_cast<ovs_pose_obs*>(d + off_obs),
-                                                  reinterpret_cast<int32_t*>(d + off_off), 1, *cam, focal_x_baseline, setup_type,
-                                                  reinterpret_cast<double*>(d + off_out), d + off_fl, reinterpret_cast<int32_t*>(d + off_nv),
-                                                  scratch.stream, threads);
-    if (st != OVS_OK) return st;
-    OVS_HIP_TRY(hipMemcpyAsync(h + off_out, d + off_out, out_bytes, hipMemcpyDeviceToHost, scratch.stream));
-    OVS_HIP_TRY(hipStreamSynchronize(scratch.stream));
+    // Round 4: a frame with 1500 or more observations is spread over four workgroups of 256 threads on one XCD: the per-iteration pass over
+    // the observations shrinks to a quarter, at the price of one grid-wide barrier per pass (~1.5 us: arrival counter + partial sums through
+    // that XCD's L2). Means over 8 synthetic frames, 1 / 4 workgroups (profiles/r04w_pose_groups.txt; r04u_pose_groups.txt has 2 and 8
+    // too): 300 observations 0.253 / 0.345 ms, 700: 0.280 / 0.327, 1000: 0.392 / 0.397, 1300: 0.408 / 0.367, 2000: 0.452 / 0.381,
+    // 4000: 0.614 / 0.378. A frame's time also depends on how many rejected trials its converged rounds end on (+-20 % between frames of
+    // one size), hence means, and hence a threshold above the crossover. OVS_POSE_GROUPS=g forces g; the one-workgroup form is also the
+    // fallback if a barrier is ever abandoned (num_valid == -2).
+    const int groups_env = tuning().pose_groups;
+    int groups = groups_env > 0 ? std::min(groups_env, kMaxGroups) : (n_obs >= 1500 ? 4 : 1);
+    for (;;) {
+        const int threads = groups > 1 ? 256 : ((model == 1 ? n_obs >= 1500 : n_obs >= 768) ? 512 : 256);
+        const ovs_status st = pose_optimize_batch_dev(model, reinterpret_cast<double*>(d), reinterpret_cast<ovs_pose_obs*>(d + off_obs),
+                                                      reinterpret_cast<int32_t*>(d + off_off), 1, *cam, focal_x_baseline, setup_type,
+                                                      reinterpret_cast<double*>(d + off_out), d + off_fl, reinterpret_cast<int32_t*>(d + off_nv),
+                                                      scratch.stream, threads, groups, reinterpret_cast<double*>(d + off_part),
+                                                      reinterpret_cast<unsigned int*>(d + off_sync));
+        if (st != OVS_OK) return st;
+        OVS_HIP_TRY(hipMemcpyAsync(h + off_out, d + off_out, out_bytes, hipMemcpyDeviceToHost, scratch.stream));
+        OVS_HIP_TRY(hipStreamSynchronize(scratch.stream));
+        int32_t nv = 0;
+        std::memcpy(&nv, h + off_nv, sizeof(nv));
+        if (nv != -2 || groups == 1) break;
+        groups = 1;   // a workgroup of the frame was not scheduled within 50 ms: run the frame in one workgroup
+        OVS_HIP_TRY(hipMemcpyAsync(d, h, off_obs, hipMemcpyHostToDevice, scratch.stream));   // (re-arms the barrier words)
+    }
     std::memcpy(pose_cw_out, h + off_out, sizeof(double) * 12);
     std::memcpy(num_valid, h + off_nv, sizeof(int32_t));
     if (n_obs) std::memcpy(outlier_flags, h + off_fl, (size_t)n_obs);

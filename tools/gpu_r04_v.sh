@@ -1,0 +1,9 @@
+#!/bin/bash
+cd /root/repo
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_pose.py tests/test_cpp_shim.py -q -m gpu 2>&1 | grep -E "passed|failed|^E  " | head
+timeout 400 python tools/class_latency.py 1080 1920 2000 200 > gpurun_out/r04v_class_latency.json 2> gpurun_out/r04v_class_latency.err
+python -c "
+import json
+d=json.load(open('gpurun_out/r04v_class_latency.json'))
+print(json.dumps(d.get('tracking_per_frame'))[:520])"
