@@ -664,15 +664,15 @@ static ovs_status pose_optimize_host(int model, int32_t device, const double* po
     // one latency-bound workgroup: 512 threads hide the f64 latency of the per-observation work when there is enough of it; measured,
     // 256 / 512 threads: perspective 2000 observations 0.509 / 0.512 ms, 1000: 0.438 / 0.422, 500: 0.286 / 0.293; equirectangular
     // 2000: 1.39 / 1.15, 1000: 0.759 / 0.786, 500: 0.427 / 0.588
-    // Round 4: a frame with 1500 or more observations is spread over four workgroups of 256 threads on one XCD: the per-iteration pass over
+    // Round 4: a frame with 1200 or more observations is spread over four workgroups of 256 threads on one XCD: the per-iteration pass over
     // the observations shrinks to a quarter, at the price of one grid-wide barrier per pass (~1.5 us: arrival counter + partial sums through
     // that XCD's L2). Means over 8 synthetic frames, 1 / 4 workgroups (profiles/r04w_pose_groups.txt; r04u_pose_groups.txt has 2 and 8
     // too): 300 observations 0.253 / 0.345 ms, 700: 0.280 / 0.327, 1000: 0.392 / 0.397, 1300: 0.408 / 0.367, 2000: 0.452 / 0.381,
     // 4000: 0.614 / 0.378. A frame's time also depends on how many rejected trials its converged rounds end on (+-20 % between frames of
-    // one size), hence means, and hence a threshold above the crossover. OVS_POSE_GROUPS=g forces g; the one-workgroup form is also the
+    // one size), hence means, and hence a threshold a little above the crossover (tracked 1080p frames carry ~1300 matches: mean of four frame pairs 0.400 -> 0.376 ms). OVS_POSE_GROUPS=g forces g; the one-workgroup form is also the
     // fallback if a barrier is ever abandoned (num_valid == -2).
     const int groups_env = tuning().pose_groups;
-    int groups = groups_env > 0 ? std::min(groups_env, kMaxGroups) : (n_obs >= 1500 ? 4 : 1);
+    int groups = groups_env > 0 ? std::min(groups_env, kMaxGroups) : (n_obs >= 1200 ? 4 : 1);
     for (;;) {
         const int threads = groups > 1 ? 256 : ((model == 1 ? n_obs >= 1500 : n_obs >= 768) ? 512 : 256);
         const ovs_status st = pose_optimize_batch_dev(model, reinterpret_cast<double*>(d), reinterpret_cast<ovs_pose_obs*>(d + off_obs),

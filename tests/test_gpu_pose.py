@@ -84,7 +84,7 @@ def test_pose_optimize_equirect(oracle, n, outlier_frac, pose_err, seam, pole):
 
 
 def test_single_frame_groups_agree_with_the_batch_form():
-    """Round 4: ovs_pose_optimize spreads one frame with >= 1500 observations over four workgroups (grid barrier per pass, partial sums added
+    """Round 4: ovs_pose_optimize spreads one frame with >= 1200 observations over four workgroups (grid barrier per pass, partial sums added
     in workgroup order); ovs_pose_optimize_batch_dev runs one workgroup per frame. Same schedule, sums associated differently: poses to 2e-8
     (ORACLE_SPEC rule 25: which trial a converged round ends on is rounding noise; 2.1e-9 seen), the same inlier flags (no observation of
     these frames sits on a chi2 gate), and each form gives the same bits twice."""
