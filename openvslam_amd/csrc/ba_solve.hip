@@ -25,9 +25,14 @@
 //   The system is stored padded to a multiple of 16 with an identity block (layout below).
 // Where the time goes at 288 unknowns (OVS_BA_TRACE=1 with ovs_ba_dense_solve; ~240 us per solve): the trailing tiles travel through one
 // compute unit's 64 bytes per clock (8 MB read + written: ~125 us with the requests), the 288 pivot steps of the diagonal blocks are one
-// dependent chain (~50 us), row solves ~25 us, backward substitution ~35 us. Tried and dropped in round 4: the whole triangle resident in
+// dependent chain (~50 us), row solves ~25 us, backward substitution ~35 us. Tried and dropped in round 4: (i) the whole triangle resident in
 // registers as matrix-core accumulators (189 tiles = 378 KB of the 512 KB register file: needs one wave per SIMD with 512 registers, and the
-// compiler spills the other phases' arrays).
+// compiler spills the other phases' arrays); (ii) the last tile columns resident in LDS (27 tiles, 40 % of the tile updates): no change --
+// the batches wait on s_waitcnt vmcnt(0), i.e. also on the requests just issued for the next batch, because loads under a branch cannot be
+// counted; (iii) therefore unconditional, software-pipelined requests 12 tiles deep (the compiler then emits vmcnt(44..47)): 48 loads per
+// lane in flight from 8 waves saturate the compute unit's miss queue instead, requests 39 -> 65 us, no net gain. One compute unit moves
+// ~30-50 GB/s of 128-byte tile rows; spreading the tiles over more compute units costs a panel broadcast and two grid barriers per panel,
+// about what it saves at this size.
 // Numerics: fused multiply-adds and the matrix cores' internal order instead of the host's mul / sub pairs in column order -- results
 // agree with LAPACK's to ~cond x 1e-16 relative (tests/test_gpu_ba.py::test_dense_solve_matches_numpy), far inside the 1e-7 the optimiser's
 // result is stated to (ORACLE_SPEC rule 28); identical bits from run to run (no atomics, fixed tile order).
