@@ -27,3 +27,22 @@ def test_hot_kernels_have_no_scratch_and_keep_their_occupancy_tier(kernels):
     assert kernels["ovs::k_tree<1024>"]["scratch"] == 0 and kernels["ovs::k_tree<1024>"]["vgpr"] <= 128
     pyr = kernels["ovs::k_resize_linear_u8"]
     assert pyr["scratch"] == 0 and pyr["vgpr"] <= 64 and pyr["lds"] <= 20 * 1024        # eight workgroups per CU
+
+
+@pytest.fixture(scope="module")
+def ba_kernels():
+    import kernel_resources as kr
+    rows = kr.collect(files={"ba_solve.hip", "ba_graph.hip", "pose_opt.hip"})
+    return {name: dict(vgpr=v, agpr=a, sgpr=s, scratch=p, lds=g, max_wg=w) for (_, name, v, a, s, p, g, w) in rows}
+
+
+def test_optimiser_kernels_keep_their_register_budgets(ba_kernels):
+    """Round 4's kernels of the optimisers: the one-workgroup Cholesky holds its in-flight trailing tiles in registers (512 threads: two waves
+    per SIMD, 256 registers each) and must not spill; the pair kernel of the reduced camera system keeps three waves per SIMD; the
+    256-thread pose optimiser (the form a frame spread over several workgroups uses) stays free of scratch."""
+    solve = [v for k, v in ba_kernels.items() if k.startswith("ovs::k_chol_solve")]
+    assert len(solve) == 1 and solve[0]["scratch"] == 0 and solve[0]["vgpr"] + solve[0]["agpr"] <= 256
+    pairs = [v for k, v in ba_kernels.items() if k.startswith("ovs::k_schur_pairs")]
+    assert len(pairs) == 1 and pairs[0]["scratch"] == 0 and pairs[0]["vgpr"] + pairs[0]["agpr"] <= 168     # 512 / 3 waves per SIMD
+    pose = {k: v for k, v in ba_kernels.items() if k.startswith("ovs::k_pose_optimize<")}
+    assert pose["ovs::k_pose_optimize<0, 256>"]["scratch"] == 0 and pose["ovs::k_pose_optimize<1, 256>"]["scratch"] == 0
