@@ -98,6 +98,15 @@ int32_t ovs_orb_max_keypoints(const ovs_orb* h);
 ovs_status ovs_orb_extract(ovs_orb* h, const uint8_t* image, int32_t rows, int32_t cols, size_t stride, const uint8_t* mask,
                            size_t mask_stride, ovs_keypoint* kps, uint8_t* desc, int32_t cap, int32_t* n_out);
 
+/* Stereo rig in ONE call: upstream's frame constructor runs  extractor_left_->extract(...)  and  extractor_right_->extract(...)  on two
+ * std::threads (src/openvslam/data/frame.cc, stereo constructor); two extractors on two threads cost 0.36 ms each here against 0.23 ms
+ * alone (the ~25 runtime calls of a frame queue on the runtime's locks), while a batch of two costs no more launches than one frame.
+ * Results are bit-identical to two ovs_orb_extract calls. The handle must have been created with max_batch >= 2 (OVS_ERR_CAPACITY
+ * otherwise); masks: both or neither; cap applies to each side. */
+ovs_status ovs_orb_extract_pair(ovs_orb* h, const uint8_t* left, const uint8_t* right, int32_t rows, int32_t cols, size_t stride,
+                                const uint8_t* mask_left, const uint8_t* mask_right, size_t mask_stride, ovs_keypoint* kps_left,
+                                uint8_t* desc_left, int32_t* n_left, ovs_keypoint* kps_right, uint8_t* desc_right, int32_t* n_right, int32_t cap);
+
 /* Asynchronous pair behind ovs_orb_extract (which is submit + collect): the handle owns TWO slots of pinned staging memory, uploads on
  * its own copy stream and runs kernels + the single result D2H on its compute stream, so the upload of frame k+1 overlaps the kernels
  * of frame k ("copies overlapped on a second stream, double-buffered pinned host memory"). At most two frames may be in

@@ -41,6 +41,7 @@ SYMBOLS = {
     "ovs_orb_max_keypoints": (_i32, [_vp]),
     "ovs_debug_inject_hip_failures": (_i32, [_i32, _i32]),
     "ovs_orb_extract": (_i32, [_vp, _vp, _i32, _i32, _sz, _vp, _sz, _vp, _vp, _i32, C.POINTER(_i32)]),
+    "ovs_orb_extract_pair": (_i32, [_vp, _vp, _vp, _i32, _i32, _sz, _vp, _vp, _sz, _vp, _vp, C.POINTER(_i32), _vp, _vp, C.POINTER(_i32), _i32]),
     "ovs_orb_extract_submit": (_i32, [_vp, _vp, _i32, _i32, _sz, _vp, _sz]),
     "ovs_orb_extract_collect": (_i32, [_vp, _vp, _vp, _i32, C.POINTER(_i32)]),
     "ovs_orb_set_host_mode": (_i32, [_vp, _i32]),

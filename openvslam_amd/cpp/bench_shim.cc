@@ -71,6 +71,10 @@ static Stats run(feature::orb_extractor& ex, const cv::Mat& a, const cv::Mat& b,
     return stats(ms);
 }
 
+// page-locked host memory straight from the HIP runtime (this program is plain g++: no HIP headers)
+extern "C" int hipHostMalloc(void** ptr, size_t size, unsigned int flags);
+extern "C" int hipHostFree(void* ptr);
+
 int main(int argc, char** argv) {
     if (argc != 7) return 2;
     const int rows = std::atoi(argv[1]), cols = std::atoi(argv[2]), nfeat = std::atoi(argv[3]), iters = std::atoi(argv[6]);
@@ -112,7 +116,27 @@ int main(int argc, char** argv) {
         std::thread tr([&] { loop(ex_r, b, k2, d2, &r); });
         tl.join();
         tr.join();
-        std::printf(", \"two_threads\": {\"solo_ms\": %.4f, \"left_ms\": %.4f, \"right_ms\": %.4f}", solo, l, r);
+        std::printf(", \"two_threads\": {\"solo_ms\": %.4f, \"left_ms\": %.4f, \"right_ms\": %.4f", solo, l, r);
+        // the same with both images in page-locked memory (hipHostMalloc; a capture buffer registered once with hipHostRegister behaves the
+        // same): a copy from pageable memory pins its pages per call, and two threads doing that in one process queue on the process's
+        // memory-map lock -- most of what the right / left extractors lose to each other above
+        void *pa = nullptr, *pb = nullptr;
+        const size_t bytes = (size_t)rows * cols;
+        if (hipHostMalloc(&pa, bytes, 0) == 0 && hipHostMalloc(&pb, bytes, 0) == 0) {
+            std::memcpy(pa, a.data, bytes);
+            std::memcpy(pb, b.data, bytes);
+            const cv::Mat ap(rows, cols, cv::CV_8U, pa, (size_t)cols), bp(rows, cols, cv::CV_8U, pb, (size_t)cols);
+            double solo_p = 0, lp = 0, rp = 0;
+            loop(ex_l, ap, k1, d1, &solo_p);
+            std::thread t1([&] { loop(ex_l, ap, k1, d1, &lp); });
+            std::thread t2([&] { loop(ex_r, bp, k2, d2, &rp); });
+            t1.join();
+            t2.join();
+            std::printf(", \"pinned_input\": {\"solo_ms\": %.4f, \"left_ms\": %.4f, \"right_ms\": %.4f}", solo_p, lp, rp);
+        }
+        if (pa) hipHostFree(pa);
+        if (pb) hipHostFree(pb);
+        std::printf("}");
     }
     // ---- one tracked frame through the classes, as tracking_module::track() strings them together (what matters is that the
     // frame's keypoints / descriptors / grid go up once and every matcher after the first finds them in HBM):

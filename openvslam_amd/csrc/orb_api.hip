@@ -129,6 +129,14 @@ struct ovs_orb {
         int rows = 0, cols = 0;
     };
     HostSlot slot[2];
+    // ovs_orb_extract_pair (stereo left / right in one call): two device images (+ masks), one output block for both frames, allocated on
+    // first use
+    struct PairBuf {
+        uint8_t *d_img = nullptr, *d_mask = nullptr, *d_out = nullptr, *h_out = nullptr;
+        size_t frame_bytes = 0, off_kps = 0, off_desc = 0, out_bytes = 0;
+        int cap = 0;
+        hipEvent_t ev_h2d = nullptr;
+    } pair;
     hipStream_t copy_stream = nullptr;
     unsigned n_submitted = 0, n_collected = 0;
     int last_slot = -1;              // slot of the last COLLECTED frame (host pyramid getter)
@@ -597,6 +605,11 @@ ovs_status ovs_orb_destroy(ovs_orb* h) {
     hipFree(h->d.lvl_kps);
     hipFree(h->d.lvl_count);
     if (h->copy_stream) hipStreamSynchronize(h->copy_stream);
+    hipFree(h->pair.d_img);
+    hipFree(h->pair.d_mask);
+    hipFree(h->pair.d_out);
+    if (h->pair.h_out) hipHostFree(h->pair.h_out);
+    if (h->pair.ev_h2d) hipEventDestroy(h->pair.ev_h2d);
     for (auto& sl : h->slot) {
         hipFree(sl.d_img);
         hipFree(sl.d_mask);
@@ -862,6 +875,73 @@ ovs_status ovs_orb_extract(ovs_orb* h, const uint8_t* image, int32_t rows, int32
     const ovs_status st = ovs_orb_extract_submit(h, image, rows, cols, stride, mask, mask_stride);
     if (st != OVS_OK) return st;
     return ovs_orb_extract_collect(h, kps, desc, cap, n_out);
+}
+
+ovs_status ovs_orb_extract_pair(ovs_orb* h, const uint8_t* left, const uint8_t* right, int32_t rows, int32_t cols, size_t stride,
+                                const uint8_t* mask_left, const uint8_t* mask_right, size_t mask_stride, ovs_keypoint* kps_left,
+                                uint8_t* desc_left, int32_t* n_left, ovs_keypoint* kps_right, uint8_t* desc_right, int32_t* n_right, int32_t cap) {
+    if (!h || !n_left || !n_right) return OVS_ERR_INVALID;
+    *n_left = *n_right = 0;
+    if (!left || !right || rows <= 0 || cols <= 0) return OVS_OK;   // upstream: empty image -> early return
+    if (cap < 0 || (cap > 0 && (!kps_left || !desc_left || !kps_right || !desc_right)) || stride < (size_t)cols) return OVS_ERR_INVALID;
+    if ((mask_left == nullptr) != (mask_right == nullptr) || (mask_left && mask_stride < (size_t)cols)) return OVS_ERR_INVALID;
+    if (h->max_batch < 2 || rows > h->max_rows || cols > h->max_cols) return OVS_ERR_CAPACITY;
+    if (h->n_submitted != h->n_collected) return OVS_ERR_INVALID;   // frames submitted asynchronously must be collected first
+    OVS_HIP_TRY(hipSetDevice(h->device));
+    ovs_status st = ensure_geometry(h, rows, cols);
+    if (st != OVS_OK) return st;
+    ovs_orb::PairBuf& pb = h->pair;
+    if (!pb.d_img) {
+        pb.frame_bytes = h->img_pitch * (size_t)h->max_rows;
+        OVS_HIP_TRY(hipMalloc(&pb.d_img, 2 * pb.frame_bytes));
+        OVS_HIP_TRY(hipEventCreateWithFlags(&pb.ev_h2d, hipEventDisableTiming));
+    }
+    if (pb.cap < h->out_cap_variant[1]) {   // [counts | keypoints of both frames | descriptors of both frames], for the larger capacity
+        if (pb.d_out) (void)hipFree(pb.d_out);
+        if (pb.h_out) (void)hipHostFree(pb.h_out);
+        pb.d_out = pb.h_out = nullptr;
+        pb.cap = h->out_cap_variant[1];
+        const size_t bytes = 32 + ((2 * sizeof(ovs_keypoint) * (size_t)pb.cap + 31) & ~(size_t)31) + (size_t)64 * pb.cap;
+        OVS_HIP_TRY(hipMalloc(&pb.d_out, bytes));
+        OVS_HIP_TRY(hipHostMalloc(&pb.h_out, bytes, hipHostMallocDefault));
+    }
+    const int fcap = h->out_cap;   // per frame, current variant
+    pb.off_kps = 32;
+    pb.off_desc = 32 + ((2 * sizeof(ovs_keypoint) * (size_t)fcap + 31) & ~(size_t)31);
+    pb.out_bytes = pb.off_desc + (size_t)64 * fcap;
+    hipStream_t s = h->stream, cs = h->copy_stream;
+    st = upload_plane(h, left, stride, rows, cols, nullptr, pb.d_img);
+    if (st == OVS_OK) st = upload_plane(h, right, stride, rows, cols, nullptr, pb.d_img + pb.frame_bytes);
+    if (st != OVS_OK) return st;
+    if (mask_left) {
+        if (!pb.d_mask) OVS_HIP_TRY(hipMalloc(&pb.d_mask, 2 * pb.frame_bytes));
+        st = upload_plane(h, mask_left, mask_stride, rows, cols, nullptr, pb.d_mask);
+        if (st == OVS_OK) st = upload_plane(h, mask_right, mask_stride, rows, cols, nullptr, pb.d_mask + pb.frame_bytes);
+        if (st != OVS_OK) return st;
+    }
+    OVS_HIP_TRY(hipEventRecord(pb.ev_h2d, cs));
+    OVS_HIP_TRY(hipStreamWaitEvent(s, pb.ev_h2d, 0));
+    st = run_extract(h, pb.d_img, 2, rows, cols, h->img_pitch, pb.frame_bytes, mask_left ? pb.d_mask : nullptr,
+                     reinterpret_cast<ovs_keypoint*>(pb.d_out + pb.off_kps), pb.d_out + pb.off_desc, reinterpret_cast<int32_t*>(pb.d_out), fcap, s);
+    if (st != OVS_OK) return st;
+    OVS_HIP_TRY(hipMemcpyAsync(pb.h_out, pb.d_out, pb.out_bytes, hipMemcpyDeviceToHost, s));
+    OVS_HIP_TRY(hipStreamSynchronize(s));
+    const int32_t* cnt = reinterpret_cast<const int32_t*>(pb.h_out);
+    ovs_keypoint* const kout[2] = {kps_left, kps_right};
+    uint8_t* const dout[2] = {desc_left, desc_right};
+    int32_t* const nout[2] = {n_left, n_right};
+    bool over = false;
+    for (int f = 0; f < 2; ++f) {
+        const int32_t m = std::min(cnt[f], cap);
+        if (m > 0) {
+            std::memcpy(kout[f], pb.h_out + pb.off_kps + sizeof(ovs_keypoint) * (size_t)fcap * f, sizeof(ovs_keypoint) * (size_t)m);
+            std::memcpy(dout[f], pb.h_out + pb.off_desc + (size_t)32 * fcap * f, (size_t)32 * m);
+        }
+        *nout[f] = m;
+        over |= cnt[f] > cap;
+    }
+    h->last_host_count = *n_left;
+    return over ? OVS_ERR_CAPACITY : OVS_OK;
 }
 
 ovs_status ovs_orb_set_host_pyramid(ovs_orb* h, int32_t enable) {

@@ -160,6 +160,26 @@ class orb_extractor:
                    "ovs_orb_extract")
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    def extract_pair(self, left, right, mask_left=None, mask_right=None):
+        """A stereo rig's left and right image in one call (ovs_orb_extract_pair; the extractor needs max_batch >= 2): the results of two
+        extract() calls, bit for bit, at the launch count of one. Returns ((kps, desc) left, (kps, desc) right)."""
+        left, right = np.ascontiguousarray(left), np.ascontiguousarray(right)
+        if left.dtype != np.uint8 or left.ndim != 2 or right.dtype != np.uint8 or right.shape != left.shape:
+            raise TypeError("both images must be CV_8UC1 of one size")
+        if (mask_left is None) != (mask_right is None):
+            raise ValueError("masks: both or neither")
+        if mask_left is not None:
+            mask_left, mask_right = np.ascontiguousarray(mask_left, np.uint8), np.ascontiguousarray(mask_right, np.uint8)
+            if mask_left.shape != left.shape or mask_right.shape != left.shape:
+                raise ValueError("masks must have the images' size")
+        cap = self.max_keypoints
+        out = [(np.zeros(cap, KP_DTYPE), np.zeros((cap, 32), np.uint8), C.c_int32(0)) for _ in range(2)]
+        _lib.check(self._L.ovs_orb_extract_pair(self._h, _p(left), _p(right), left.shape[0], left.shape[1], left.strides[0], _p(mask_left),
+                                                _p(mask_right), mask_left.strides[0] if mask_left is not None else 0, _p(out[0][0]),
+                                                _p(out[0][1]), C.byref(out[0][2]), _p(out[1][0]), _p(out[1][1]), C.byref(out[1][2]), cap),
+                   "ovs_orb_extract_pair")
+        return tuple((k[:n.value].copy(), d[:n.value].copy()) for k, d, n in out)
+
     def set_fast_split(self, enable):
         """Level-0 FAST beside the pyramid on an internal stream (default on); off = one FAST launch after the pyramid."""
         _lib.check(self._L.ovs_orb_set_fast_split(self._h, 1 if enable else 0), "ovs_orb_set_fast_split")

@@ -299,3 +299,30 @@ def test_more_than_1024_nodes_per_level(hip, oracle):
     for f in ("x", "y", "response", "octave"):
         assert np.array_equal(gk[f], wk[f]), f
     assert np.array_equal(gd, wd)
+
+
+@pytest.mark.gpu
+def test_extract_pair_equals_two_extracts():
+    """ovs_orb_extract_pair (a stereo rig's two images as one batch of two): bit-identical to two ovs_orb_extract calls, with and without
+    masks, on a size that is not a multiple of the tile sizes; refused with OVS_ERR_CAPACITY on a handle created for one frame and with
+    OVS_ERR_INVALID for one mask out of two."""
+    from openvslam_amd import feature
+    from openvslam_amd.synth import synth_frame
+    rows, cols = 486, 754
+    a = synth_frame(rows, cols, seed=11)
+    b = synth_frame(rows, cols, seed=11, shift=(7, 0), noise_seed=2)
+    one = feature.orb_extractor(feature.orb_params(1000), max_rows=rows, max_cols=cols)
+    two = feature.orb_extractor(feature.orb_params(1000), max_rows=rows, max_cols=cols, max_batch=2)
+    m = np.ones((rows, cols), np.uint8)
+    m[100:220, 300:500] = 0
+    for masks in (None, (m, m)):
+        want = [one.extract(img, None if masks is None else m) for img in (a, b)]
+        got = two.extract_pair(a, b, *(masks or ()))
+        for (wk, wd), (gk, gd) in zip(want, got):
+            assert len(wk) > 300 and np.array_equal(wk, gk) and np.array_equal(wd, gd)
+    again = two.extract_pair(a, b)
+    assert np.array_equal(again[0][0], two.extract(a)[0])   # the pair path and the single-frame path share the handle
+    with pytest.raises(RuntimeError):
+        one.extract_pair(a, b)
+    with pytest.raises(ValueError):
+        two.extract_pair(a, b, m, None)
