@@ -385,26 +385,36 @@ __device__ __forceinline__ bool inv3_sym_d(const double* H, double lambda, doubl
     return true;
 }
 
-__global__ __launch_bounds__(128) void k_lm_prepare(GraphDev g, const double* __restrict__ Hll, const double* __restrict__ Hpl, double lambda,
+// One thread per EDGE (round 4; a thread per landmark walking its ~5 edges left the launch at 157 workgroups and 33 us): every edge inverts its
+// landmark's damped block itself (30 flops on 72 bytes that sit in L2) and the landmark's first edge stores it; threads t < n_pt also cover the
+// landmarks without edges, whose inverse k_backsub still reads. The same expressions as before: identical bits.
+__global__ __launch_bounds__(256) void k_lm_prepare(GraphDev g, const double* __restrict__ Hll, const double* __restrict__ Hpl, double lambda,
                                                    double* __restrict__ Hinv, double* __restrict__ Y, int32_t* __restrict__ fail) {
-    const int j = blockIdx.x * 128 + threadIdx.x;
-    if (j >= g.n_pt) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < g.n_pt && g.lm_start[t + 1] == g.lm_start[t]) {
+        double Hi[9];
+        if (!inv3_sym_d(Hll + 9 * (size_t)t, lambda, Hi)) *fail = 1;   // benign race: every writer stores 1
+        else
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Hinv[9 * (size_t)t + i] = Hi[i];
+    }
+    if (t >= g.n_edge) return;
+    const int e = t, j = g.edges[e].pt;
     double Hi[9];
     if (!inv3_sym_d(Hll + 9 * (size_t)j, lambda, Hi)) {
-        *fail = 1;   // benign race: every writer stores 1
+        *fail = 1;
         return;
     }
+    if (g.lm_edges[g.lm_start[j]] == e) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) Hinv[9 * (size_t)j + i] = Hi[i];
-    for (int i = g.lm_start[j]; i < g.lm_start[j + 1]; ++i) {
-        const int e = g.lm_edges[i];
-        const double* W = Hpl + 18 * (size_t)e;
-        double* y = Y + 18 * (size_t)e;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) y[3 * a + c] = (W[3 * a] * Hi[c] + W[3 * a + 1] * Hi[3 + c]) + W[3 * a + 2] * Hi[6 + c];
+        for (int i = 0; i < 9; ++i) Hinv[9 * (size_t)j + i] = Hi[i];
     }
+    const double* W = Hpl + 18 * (size_t)e;
+    double* y = Y + 18 * (size_t)e;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) y[3 * a + c] = (W[3 * a] * Hi[c] + W[3 * a + 1] * Hi[3 + c]) + W[3 * a + 2] * Hi[6 + c];
 }
 
 // edge_of[s * n_pt + j] = the edge of free keyframe s (slot order) to landmark j, or -1: what k_schur_pairs intersects two keyframes'
@@ -914,7 +924,8 @@ ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_
                           double lambda, hipStream_t s) {
     const GraphDev v = g->view();
     OVS_HIP_TRY(hipMemsetAsync(g->d_fail, 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_lm_prepare, dim3((g->n_pt + 127) / 128), dim3(128), 0, s, v, d_Hll, d_Hpl, lambda, g->d_Hinv, g->d_Y, g->d_fail);
+    hipLaunchKernelGGL(k_lm_prepare, dim3((std::max(g->n_pt, g->n_edge()) + 255) / 256), dim3(256), 0, s, v, d_Hll, d_Hpl, lambda, g->d_Hinv, g->d_Y,
+                       g->d_fail);
     OVS_LAUNCH_TRY("k_lm_prepare");
     if (g->n_free > 0) {
         hipLaunchKernelGGL(k_schur_pairs, dim3(g->n_pairs), dim3(256), 0, s, g->d_pose_start, g->d_pose_edges, g->d_pose_pt, g->d_pair_ab,
