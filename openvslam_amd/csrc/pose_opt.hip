@@ -199,20 +199,25 @@ __device__ __forceinline__ double pose_edge_impl(const double* R, const double* 
     J[2][4] = 0;
     J[2][5] = J[0][5] - bf * invz2;
     const double W = rho1 * o.inv_sigma_sq;
+    // J[0][4], J[1][3] and J[2][4] are exact zeros: their products are +-0 and adding them changes no bit of a sum (x + (+-0) = x; a sum that
+    // is itself a zero then enters acc += W * s, where its sign is lost as well), so those multiply-adds are simply not issued -- 14 of the 54
+    // products of a monocular observation. The compiler may not do this itself (0 * x is not 0 for x = inf / NaN, which the edges never hold).
     int k = 0;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
 #pragma unroll
-        for (int b = a; b < 6; ++b) {
-            double s = J[0][a] * J[0][b] + J[1][a] * J[1][b];
-            if (st) s = s + J[2][a] * J[2][b];
-            acc[k++] += W * s;
+        for (int b = a; b < 6; ++b, ++k) {
+            const bool z0 = a == 4 || b == 4, z1 = a == 3 || b == 3;   // row 0 (and row 2 like it) / row 1 contribute nothing
+            if (z0 && z1) continue;                                     // (3, 4): every product is a zero, the sum stays +0
+            double s = z0 ? J[1][a] * J[1][b] : (z1 ? J[0][a] * J[0][b] : J[0][a] * J[0][b] + J[1][a] * J[1][b]);
+            if (st && !z0) s = s + J[2][a] * J[2][b];
+            acc[k] += W * s;
         }
     }
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-        double g = J[0][a] * e0 + J[1][a] * e1;
-        if (st) g = g + J[2][a] * e2;
+        double g = a == 4 ? J[1][a] * e1 : (a == 3 ? J[0][a] * e0 : J[0][a] * e0 + J[1][a] * e1);
+        if (st && a != 4) g = g + J[2][a] * e2;
         acc[21 + a] += -(W * g);
     }
     acc[27] += rho0;
