@@ -102,3 +102,17 @@ with open(os.path.join(out, "host", "1234", "p_counter_collection.csv"), "w") as
     monkeypatch.setenv("FAKE_ROCPROF_FAIL", "1")
     got, note = bench.live_pmc_traffic("ovs::k_fast_cells", batch=64, timeout_s=30)
     assert got is None and "FETCH_SIZE" in note
+
+
+def test_committed_pmc_summary_was_collected_from_these_kernel_sources():
+    """profiles/pmc_traffic.json is bench.py's fall-back for roofline.traffic and the source of the other stages' counters: its per-stage
+    fingerprints (a stage's .hip file + the shared headers of csrc/) must be those of the tree, i.e. the PMC passes were re-run
+    (tools/gpu_pmc.sh) after the last change to a kernel's sources."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    src = os.path.join(ROOT, "openvslam_amd", "csrc")
+    pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for stage, fp in pm["csrc_sha16_by_stage"].items():
+        assert fp == bench.pmc_stage_fingerprint(src, stage), "stale counters for stage %s: re-run tools/gpu_pmc.sh" % stage
