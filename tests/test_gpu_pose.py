@@ -119,3 +119,41 @@ def test_single_frame_groups_agree_with_the_batch_form():
         got = np.concatenate([T1[:, :3].ravel(), T1[:, 3]])
         assert np.allclose(got, out[k], rtol=0, atol=2e-8), np.abs(got - out[k]).max()
         assert nv1 == nv[k] and np.array_equal(flags1.astype(np.uint8), fl[offs[k]:offs[k + 1]])
+
+
+def test_grouped_pose_optimiser_beside_a_saturated_device():
+    """The four workgroups of a frame meet at a grid-wide barrier, so they must all become resident while other streams fill the device: 150
+    pose optimisations of a 2000-observation frame (four workgroups) beside a thread that keeps 64-frame batch extractions in flight give
+    the bits of an undisturbed call every time, and finish (the barrier has a 50 ms bail-out to the one-workgroup form)."""
+    import threading
+    import torch
+    from openvslam_amd import ba, feature
+    from openvslam_amd.synth import synth_video
+    from oracle import binding as ob
+    T0, obs, cam, bf, _ = make_frame(ob.POSE_OBS_DTYPE, 2000, 21)
+    ref = ba.pose_optimize(T0, obs, cam, bf)
+    rows, cols, B = 480, 752, 64
+    ex = feature.orb_extractor(feature.orb_params(1000), max_rows=rows, max_cols=cols, max_batch=B)
+    d_img = torch.from_numpy(synth_video(rows, cols, B, seed=5)).cuda()
+    cap = ex.max_keypoints
+    d_kps = torch.empty((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.empty(B, dtype=torch.int32, device="cuda")
+    stop = threading.Event()
+    busy_stream = torch.cuda.Stream()
+
+    def load():
+        while not stop.is_set():
+            for _ in range(4):
+                ex.extract_batch_dev(d_img, d_kps, d_desc, d_cnt, stream=busy_stream.cuda_stream)
+            busy_stream.synchronize()
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        for _ in range(150):
+            T, out, nv = ba.pose_optimize(T0, obs, cam, bf)
+            assert nv == ref[2] and np.array_equal(T, ref[0]) and np.array_equal(out, ref[1])
+    finally:
+        stop.set()
+        th.join()
