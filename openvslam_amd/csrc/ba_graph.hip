@@ -640,7 +640,7 @@ struct ovs_ba_graph {
     int n_pairs = 0;
     double* d_lm_tmp = nullptr;   // [3 n_pt] per-landmark partials (chi2 pair, max |diagonal|; or the gain ratio's scale terms)
     // solver work space (allocated on first use: ovs_ba_graph_linearize_dev alone does not need it)
-    double *d_Hinv = nullptr, *d_Y = nullptr, *d_S = nullptr, *d_rhs = nullptr, *d_bp_copy = nullptr, *d_dxp = nullptr, *d_scal = nullptr;
+    double *d_Hinv = nullptr, *d_Y = nullptr, *d_S = nullptr, *d_rhs = nullptr, *d_dxp = nullptr, *d_scal = nullptr;
     int s_pitch = 0;   // doubles per row of d_S
 
     GraphDev view() const {
@@ -897,7 +897,7 @@ ovs_status ba_graph_ensure_solver(ovs_ba_graph* g, hipStream_t s) {
     unsigned char* A = g->d_solver_arena;
     g->d_Hinv = reinterpret_cast<double*>(A);
     g->d_Y = reinterpret_cast<double*>(A + b_hinv);
-    g->d_S = reinterpret_cast<double*>(A + b_hinv + b_y);   // padded system | bp copy
+    g->d_S = reinterpret_cast<double*>(A + b_hinv + b_y);   // padded system
     g->d_dxp = reinterpret_cast<double*>(A + b_hinv + b_y + b_s);
     g->d_scal = reinterpret_cast<double*>(A + b_hinv + b_y + b_s + b_dxp);
     g->d_fail = reinterpret_cast<int32_t*>(A + b_hinv + b_y + b_s + b_dxp + 256);
@@ -909,7 +909,6 @@ ovs_status ba_graph_ensure_solver(ovs_ba_graph* g, hipStream_t s) {
     }
     g->s_pitch = n_pad;
     g->d_rhs = g->d_S + (size_t)n_pad * n_pad;
-    g->d_bp_copy = g->d_S + sys;
     OVS_HIP_TRY(hipMemsetAsync(g->d_S, 0, sizeof(double) * sys, s));
     const std::vector<double> ones((size_t)std::max(n_pad - n, 1), 1.0);
     if (n_pad > n)
@@ -919,7 +918,7 @@ ovs_status ba_graph_ensure_solver(ovs_ba_graph* g, hipStream_t s) {
     return OVS_OK;
 }
 
-// (H + lambda I) dx = b, landmarks eliminated on the device: S (pitch g->s_pitch) and rhs at g->d_S, a copy of bp behind the system.
+// (H + lambda I) dx = b, landmarks eliminated on the device: S (pitch g->s_pitch) and rhs at g->d_S.
 ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_bp, const double* d_Hll, const double* d_bl, const double* d_Hpl,
                           double lambda, hipStream_t s) {
     const GraphDev v = g->view();
@@ -933,7 +932,6 @@ ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_
         OVS_LAUNCH_TRY("k_schur_pairs");
         hipLaunchKernelGGL(k_schur_rhs, dim3(g->n_free), dim3(256), 0, s, v, g->d_slot_pose, d_bp, d_bl, g->d_Y, g->d_rhs);
         OVS_LAUNCH_TRY("k_schur_rhs");
-        OVS_HIP_TRY(hipMemcpyAsync(g->d_bp_copy, d_bp, sizeof(double) * 6 * (size_t)g->n_pose, hipMemcpyDeviceToDevice, s));
     }
     return OVS_OK;
 }
@@ -977,9 +975,9 @@ struct BaGraphInfo {
     int32_t* d_fail;
     const int32_t* d_slot_of_pose;
     int s_pitch;
-    double *d_rhs, *d_bp_copy;
+    double* d_rhs;
 };
 BaGraphInfo ba_graph_info(ovs_ba_graph* g) {
-    return BaGraphInfo{g->n_free, g->slot.data(), g->d_S, g->d_dxp, g->d_scal, g->d_fail, g->d_slot_of_pose, g->s_pitch, g->d_rhs, g->d_bp_copy};
+    return BaGraphInfo{g->n_free, g->slot.data(), g->d_S, g->d_dxp, g->d_scal, g->d_fail, g->d_slot_of_pose, g->s_pitch, g->d_rhs};
 }
 }   // namespace ovs
