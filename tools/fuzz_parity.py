@@ -283,6 +283,8 @@ def fuzz_optimize(rng, n_cases, log):
     from test_ba import _lba_scene
     from openvslam_amd import ba
     from oracle import lba
+    if os.environ.get("OVS_FUZZ_LBA_SOLVER"):   # "host": the reduced camera system on the host (to tell a solver effect from the scene's conditioning)
+        ba.local_ba_set_solver(os.environ["OVS_FUZZ_LBA_SOLVER"])
     for case in range(n_cases):
         n = int(rng.choice([3, 8, 60, 500, 2000, 6000]))
         T0, obs, cam, bf, _ = synth.synth_pose_frame(ob.POSE_OBS_DTYPE, n, int(rng.integers(0, 1 << 30)), float(rng.uniform(0, 1)),
@@ -326,13 +328,18 @@ def fuzz_optimize(rng, n_cases, log):
             # (seed 321: one side ran a tenth iteration in a converged round and a landmark seen by two keyframes moved 1.4e-7 in it)
             same_iters = np.array_equal(got["info"][4:], want["info"][4:])
             close = float(np.abs(got["poses"] - want["poses"]).max()) < 1e-7 and float(np.abs(got["points"] - want["points"]).max()) < 1e-6
-            pt_atol = 1e-7 if same_iters else 1e-6
+            # landmarks observed by a single keyframe have no depth constraint but the damping: their position follows the solve's last
+            # digits (seed 4601, 891 landmarks over 444 observations: 8.7e-8 with the host solve, 1.7e-7 with the device solve, pose
+            # 2.8e-8 either way). Upstream's local map holds no such landmarks (they are culled); the tight bound is for scenes without them.
+            n_obs = np.bincount(np.r_[mono["point_idx"], st["point_idx"]], minlength=len(d["points"]))
+            lonely = bool(((n_obs > 0) & (n_obs < 2)).any())
+            pt_atol = 1e-7 if (same_iters and not lonely) else 1e-6
             ok = ((same_iters or close) and np.allclose(got["info"][:4], want["info"][:4], rtol=1e-6, atol=1e-6)
                   and np.allclose(got["poses"], want["poses"], rtol=1e-6, atol=1e-7) and np.allclose(got["points"], want["points"], rtol=1e-6, atol=pt_atol)
                   and all((got[k] != want[k]).sum() <= 1 for k in ("mono_outlier", "stereo_outlier")))
-            log("local_ba %2d keyframes %4d landmarks %5d + %5d edges -> iterations %s, max |d pose| %.1e |d point| %.1e %s" % (
-                n_pose, n_pt, len(mono), len(st), want["info"][4:6], float(np.abs(got["poses"] - want["poses"]).max()),
-                float(np.abs(got["points"] - want["points"]).max()), "ok" if ok else "MISMATCH"))
+            log("local_ba %2d keyframes %4d landmarks %5d + %5d edges%s -> iterations %s, max |d pose| %.1e |d point| %.1e %s" % (
+                n_pose, n_pt, len(mono), len(st), " (single-view landmarks)" if lonely else "", want["info"][4:6],
+                float(np.abs(got["poses"] - want["poses"]).max()), float(np.abs(got["points"] - want["points"]).max()), "ok" if ok else "MISMATCH"))
             if not ok:
                 log("  info hip %s oracle %s" % (got["info"], want["info"]))
                 log("  max |d pose| %.2e, max |d point| %.2e, outlier flips %s" % (float(np.abs(got["poses"] - want["poses"]).max()), float(np.abs(got["points"] - want["points"]).max()),
