@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                                                       const int32_t* __restrict__ obs_offsets, ovs_ba_cam cam, double bf, int setup_type,
                                                       double* __restrict__ poses_out, uint8_t* __restrict__ outlier_all,
                                                       int32_t* __restrict__ num_valid, int reset_each_round, int G, double* __restrict__ gpart,
-                                                      unsigned int* __restrict__ gsync) {
+                                                      unsigned int* __restrict__ gsync, int batch_retries) {
     // G > 1 (round 4, single-frame latency path): the frame's observations are spread over G workgroups (blockIdx.y). Every sum over the
     // observations is then a sum of G workgroup partials exchanged through memory behind a grid-wide barrier; each workgroup adds them in
     // the same order, solves the same 6 x 6 system and takes the same branches, so there is no second barrier and no broadcast.
@@ -244,6 +244,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
     __shared__ double s_sum[28];
     __shared__ double s_sys[28];   // the current iteration's system (copied from s_sum, which the trial reductions overwrite)
     __shared__ PoseD s_T, s_Tn;
+    __shared__ PoseD s_Tq[9];              // trial poses of an iteration's retries 1 .. 9 (evaluated together, see below)
+    __shared__ double s_okq[9], s_scq[9];  // ... whether the solve succeeded, and the gain ratio's denominator
     __shared__ double s_ctl[4];   // [0] = continue trials of this iteration, [1] = continue iterations of this round
     __shared__ int s_cnt[kPoseWaves];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -427,6 +429,107 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                 double rho = 0;
                 int qmax = 0;
                 do {
+                    if (qmax == 1 && batch_retries) {
+                        // ---- The first trial was rejected. g2o would now retry up to nine times with lambda * nu, nu doubling -- a sequence
+                        // that does not depend on the outcomes, and (in a converged round, where the gain ratio is rounding noise) usually runs
+                        // to the end: nine times [one lane's solve, a pass over the observations, a reduction, four barriers]. Round 4: the nine
+                        // solves run on nine lanes at once, ONE pass evaluates the nine trial poses, one reduction returns the nine chi2, and
+                        // every thread then replays g2o's accept / reject decisions over them in order. Per trial the arithmetic is the
+                        // sequential form's, so are the results, bit for bit (OVS_POSE_BATCH_RETRIES=0 keeps the sequential form; tests compare).
+                        if (tid < 9) {
+                            double lam = lambda, nn = ni;
+                            for (int j = 0; j < tid; ++j) {
+                                lam *= nn;
+                                nn *= 2;
+                            }
+                            double H[36], b[6], dxq[6] = {0, 0, 0, 0, 0, 0};
+                            {
+                                int k = 0;
+                                for (int a = 0; a < 6; ++a)
+                                    for (int c = a; c < 6; ++c) {
+                                        H[6 * a + c] = s_sys[k];
+                                        H[6 * c + a] = s_sys[k];
+                                        ++k;
+                                    }
+                                for (int a = 0; a < 6; ++a) b[a] = s_sys[21 + a];
+                            }
+                            const bool okq = solve6_d(H, lam, b, dxq);
+                            if (okq) {
+                                PoseD E;
+                                se3_exp_d(dxq, E);
+                                compose_d(E, s_T, s_Tq[tid]);
+                            }
+                            s_okq[tid] = okq ? 1.0 : 0.0;
+                            double scale = 0;
+                            if (okq)
+                                for (int j = 0; j < 6; ++j) scale += dxq[j] * (lam * dxq[j] + b[j]);
+                            s_scq[tid] = scale + 1e-3;
+                        }
+                        __syncthreads();
+                        double part[9];
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) part[q] = 0;
+#pragma unroll 1
+                        for (int q = 0; q < 9; ++q) {
+                            if (s_okq[q] == 0.0) continue;   // (workgroup-uniform)
+                            double R[9], t[3];
+                            for (int i = 0; i < 9; ++i) R[i] = s_Tq[q].R[i];
+                            for (int i = 0; i < 3; ++i) t[i] = s_Tq[q].t[i];
+                            double pq = 0;
+                            auto sweep = [&](auto stereo_tag) __attribute__((always_inline)) {
+                                for (int k = 0, i = gtid; i < n; i += gstride, ++k)
+                                    if ((active >> k) & 1u) {
+                                        const ovs_pose_obs o = obs[i];
+                                        const double c2 = pose_edge_impl<MODEL, decltype(stereo_tag)::value>(R, t, o, cam, bf, 0.0, nullptr);
+                                        const double delta = robust ? huber : 0.0;
+                                        double r = c2;
+                                        if (delta > 0 && c2 > delta * delta) r = 2 * sqrt(c2) * delta - delta * delta;
+                                        pq += r;
+                                    }
+                            };
+                            if (has_stereo) sweep(std::true_type{});
+                            else sweep(std::false_type{});
+#pragma unroll
+                            for (int u = 0; u < 9; ++u) part[u] = u == q ? pq : part[u];   // (no dynamic index into the register array)
+                        }
+                        reduce(part, 9);
+                        POSE_EXCHANGE(9)
+                        double lam = lambda, nn = ni;
+                        int last_ok = -1;
+                        bool accepted = false;
+                        for (int q = 0; q < 9; ++q) {
+                            const bool okq = s_okq[q] != 0.0;
+                            const double temp_chi = okq ? s_sum[q] : 1.7976931348623157e308;
+                            if (okq) last_ok = q;
+                            rho = (current_chi - temp_chi) / s_scq[q];
+                            ++qmax;
+                            if (rho > 0 && isfinite(temp_chi)) {
+                                double alpha = 1. - pow(2 * rho - 1, 3.0);
+                                alpha = fmin(alpha, 2.0 / 3.0);
+                                lambda = lam * fmax(1.0 / 3.0, alpha);
+                                ni = 2;
+                                current_chi = temp_chi;
+                                accepted = true;
+                                break;
+                            }
+                            lam *= nn;
+                            nn *= 2;
+                            lambda = lam;
+                            ni = nn;
+                            if (!(rho < 0)) break;   // rho == 0 (or NaN): the sequential loop stops retrying here as well
+                        }
+                        __syncthreads();   // every thread has read s_sum / s_T before thread 0 moves the poses
+                        if (last_ok >= 0) {
+                            err_at_trial = true;   // the active edges' errors were last computed at this trial's pose
+                            if (tid == 0) {
+                                s_Tn = s_Tq[last_ok];
+                                if (accepted) s_T = s_Tn;
+                            }
+                        }
+                        have_lin = false;
+                        __syncthreads();
+                        break;
+                    }
                     // thread 0: solve, trial pose
                     double dx[6] = {0, 0, 0, 0, 0, 0};
                     if (tid == 0) {
@@ -559,6 +662,16 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
 
 using namespace ovs;
 
+// OVS_POSE_BATCH_RETRIES: the retries 1 .. 9 of an iteration in one pass -- 1 always, 0 never, unset (-1): by work per thread (see
+// pose_optimize_host). Read once per process, like the switches of ovs::tuning().
+static int pose_batch_retries_env() {
+    static const int v = [] {
+        const char* e = std::getenv("OVS_POSE_BATCH_RETRIES");
+        return e && e[0] ? (std::atoi(e) != 0 ? 1 : 0) : -1;
+    }();
+    return v;
+}
+
 // ovs_pose_set_variant(OVS_POSE_VARIANT_RESET_EACH_ROUND, 0 | 1): process-wide, read at every launch
 static std::atomic<int> g_pose_reset_each_round{0};
 
@@ -567,7 +680,7 @@ extern "C" {
 static ovs_status pose_optimize_batch_dev(int model, const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
                                           const ovs_ba_cam& cam, double focal_x_baseline, int32_t setup_type, double* d_poses_out,
                                           uint8_t* d_outlier, int32_t* d_num_valid, void* stream, int threads_default = 256, int groups = 1,
-                                          double* d_gpart = nullptr, unsigned int* d_gsync = nullptr) {
+                                          double* d_gpart = nullptr, unsigned int* d_gsync = nullptr, int batch_retries_auto = 0) {
     if (!d_poses_in || !d_obs || !d_obs_offsets || !d_poses_out || !d_outlier || !d_num_valid || batch < 1) return OVS_ERR_INVALID;
     // workgroup size: the kernel is one latency-bound workgroup per frame; more waves hide the f64 latency of the per-observation work
     // but pay in barriers (measured per 2000-observation frame in DESIGN.md section 3.6)
@@ -580,7 +693,7 @@ static ovs_status pose_optimize_batch_dev(int model, const double* d_poses_in, c
         OVS_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(k_pose_optimize<MODEL, TT>), sizeof(double) * 28 * (TT + 8), configured)); \
         hipLaunchKernelGGL((k_pose_optimize<MODEL, TT>), dim3(batch, groups > 1 ? 8 * groups : 1), dim3(TT), lds, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, \
                            cam, BF, ST, d_poses_out, d_outlier, d_num_valid, g_pose_reset_each_round.load(std::memory_order_relaxed), groups, d_gpart, \
-                           d_gsync);                                                                                                  \
+                           d_gsync, pose_batch_retries_env() < 0 ? batch_retries_auto : pose_batch_retries_env());                  \
     } while (0)
     if (model == 1) {
         if (T == 512) OVS_POSE_LAUNCH(1, 512, 0.0, 0);
@@ -679,12 +792,17 @@ static ovs_status pose_optimize_host(int model, int32_t device, const double* po
     const int groups_env = tuning().pose_groups;
     int groups = groups_env > 0 ? std::min(groups_env, kMaxGroups) : (n_obs >= 1200 ? 4 : 1);
     for (;;) {
+        // retries 1 .. 9 of an iteration in ONE pass (k_pose_optimize): nine trial poses per observation pay where a thread holds few
+        // observations -- means over 8 frames, one pass / one by one (profiles/r04aj_pose_batched_retries.txt): four workgroups 1300
+        // observations 0.322 / 0.347 ms, 2000: 0.337 / 0.370, 300: 0.271 / 0.322; one workgroup 300: 0.245 / 0.256 but 1300: 0.408 / 0.394,
+        // 2000: 0.478 / 0.439 (a sequence that accepts its second or third trial has then evaluated seven poses for nothing). Same bits.
+        const int batch_retries = (groups > 1 || n_obs <= 512) ? 1 : 0;
         const int threads = groups > 1 ? 256 : ((model == 1 ? n_obs >= 1500 : n_obs >= 768) ? 512 : 256);
         const ovs_status st = pose_optimize_batch_dev(model, reinterpret_cast<double*>(d), reinterpret_cast<ovs_pose_obs*>(d + off_obs),
                                                       reinterpret_cast<int32_t*>(d + off_off), 1, *cam, focal_x_baseline, setup_type,
                                                       reinterpret_cast<double*>(d + off_out), d + off_fl, reinterpret_cast<int32_t*>(d + off_nv),
                                                       scratch.stream, threads, groups, reinterpret_cast<double*>(d + off_part),
-                                                      reinterpret_cast<unsigned int*>(d + off_sync));
+                                                      reinterpret_cast<unsigned int*>(d + off_sync), batch_retries);
         if (st != OVS_OK) return st;
         OVS_HIP_TRY(hipMemcpyAsync(h + off_out, d + off_out, out_bytes, hipMemcpyDeviceToHost, scratch.stream));
         OVS_HIP_TRY(hipStreamSynchronize(scratch.stream));

@@ -5,6 +5,8 @@ Equirectangular frames: 2e-8. The LM loop ends a round on the sign of a gain rat
 converged, so which trial is the last depends on the summation order; the CPU oracle itself moves by up to 5.2e-9 on these very
 frames when its observations are permuted (tests/test_ba.py::test_pose_oracle_order_sensitivity), and so does the device result
 between its 256- and 512-thread workgroups."""
+import os
+
 import numpy as np
 import pytest
 
@@ -157,3 +159,39 @@ def test_grouped_pose_optimiser_beside_a_saturated_device():
     finally:
         stop.set()
         th.join()
+
+
+def test_batched_retries_give_the_sequential_results(tmp_path):
+    """Round 4: after an iteration's first trial is rejected the nine retries g2o would make one by one are solved on nine lanes and
+    evaluated in one pass over the observations. Same arithmetic per trial, same decisions in the same order: the results must be the bits
+    of the sequential form (OVS_POSE_BATCH_RETRIES=0, read once per process: a child process computes them), for one and for four
+    workgroups per frame, perspective and equirectangular."""
+    import subprocess
+    import sys
+    from openvslam_amd import ba
+    from openvslam_amd.synth import synth_pose_frame_equirect
+    from oracle import binding as ob
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from openvslam_amd import ba\n"
+        "from openvslam_amd.synth import synth_pose_frame, synth_pose_frame_equirect\n"
+        "from oracle import binding as ob\n"
+        "out = {}\n"
+        "for n, seed in ((300, 1), (1000, 2), (1300, 3), (2500, 4), (60, 5)):\n"
+        "    T0, obs, cam, bf, _ = synth_pose_frame(ob.POSE_OBS_DTYPE, n, seed)\n"
+        "    T, fl, nv = ba.pose_optimize(T0, obs, cam, bf)\n"
+        "    out['p%%d' %% n] = np.concatenate([T.ravel(), fl.astype(float), [nv]])\n"
+        "for n, seed in ((400, 6), (2000, 7)):\n"
+        "    T0, obs, cols, rows, _ = synth_pose_frame_equirect(ob.POSE_OBS_DTYPE, n, seed, seam_frac=0.1, pole_frac=0.05)\n"
+        "    T, fl, nv = ba.pose_optimize_equirect(T0, obs, cols, rows)\n"
+        "    out['e%%d' %% n] = np.concatenate([T.ravel(), fl.astype(float), [nv]])\n"
+        "np.savez(sys.argv[1], **out)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = {}
+    for tag, env in (("batched", {}), ("sequential", {"OVS_POSE_BATCH_RETRIES": "0"})):
+        f = str(tmp_path / (tag + ".npz"))
+        subprocess.check_call([sys.executable, "-c", code, f], env=dict(os.environ, **env), timeout=300)
+        res[tag] = np.load(f)
+    assert sorted(res["batched"].files) == sorted(res["sequential"].files) and len(res["batched"].files) == 7
+    for k in res["batched"].files:
+        assert np.array_equal(res["batched"][k], res["sequential"][k]), k
