@@ -179,3 +179,50 @@ def orb_descriptors(blurred, xs, ys, angles_deg, pattern):
 
     bits = sample(pat[:, 0], pat[:, 1]) < sample(pat[:, 2], pat[:, 3])
     return np.packbits(bits, axis=1, bitorder="little")
+
+
+# ---- rule 14: the brute-force Hamming matcher (match::robust) -----------------------------------------------------------------------------
+def hamming_matrix(a, b):
+    """All-pairs Hamming distances of two sets of 256-bit descriptors, (len(a), len(b)): |x ^ y| = |x| + |y| - 2 x.y over the bit vectors
+    (an integer matrix product -- no popcount, no xor)."""
+    A = np.unpackbits(np.asarray(a, np.uint8).reshape(-1, 32), axis=1).astype(np.int32)
+    B = np.unpackbits(np.asarray(b, np.uint8).reshape(-1, 32), axis=1).astype(np.int32)
+    return A.sum(1)[:, None] + B.sum(1)[None, :] - 2 * (A @ B.T)
+
+
+def robust_brute_force_match(desc_frm, desc_kf, kf_valid=None, lowe_ratio=0.8, frm_valid=None):
+    """Rule 14 from its text: keyframe keypoints in index order (those with a live landmark), each against all frame keypoints nobody has
+    claimed yet; the nearest (lowest index on ties) is accepted iff its distance is at most 50 and not `ratio * second < best` in float;
+    an accepted frame keypoint is claimed. Distances of claimed / masked frame keypoints count as the 256 both minima start from.
+    Returns (frame index, keyframe index) pairs in keyframe order."""
+    D = hamming_matrix(desc_kf, desc_frm)
+    free = np.ones(len(desc_frm), bool) if frm_valid is None else np.asarray(frm_valid).astype(bool).copy()
+    pairs = []
+    for j in range(len(desc_kf)):
+        if kf_valid is not None and not kf_valid[j]:
+            continue
+        d = np.where(free, D[j], 256)
+        if len(d) == 0:
+            continue
+        i = int(np.argmin(d))
+        best = int(d[i])
+        second = int(np.partition(d, 1)[1]) if len(d) > 1 else 256
+        if best > 50 or np.float32(lowe_ratio) * np.float32(second) < np.float32(best):
+            continue
+        pairs.append((i, j))
+        free[i] = False
+    return np.asarray(pairs, np.int32).reshape(-1, 2)
+
+
+def hamming_best2(q, t, t_valid=None):
+    """Nearest and second-nearest target of every query (lowest index on ties; masked targets do not take part; 256 where there is none)."""
+    D = hamming_matrix(q, t)
+    if t_valid is not None:
+        D = np.where(np.asarray(t_valid).astype(bool)[None, :], D, 256)
+    if D.shape[1] == 0:
+        return np.full(len(D), -1, np.int32), np.full(len(D), 256, np.uint16), np.full(len(D), 256, np.uint16)
+    bi = np.argmin(D, 1).astype(np.int32)
+    b = D[np.arange(len(D)), bi]
+    s = np.partition(D, 1, axis=1)[:, 1] if D.shape[1] > 1 else np.full(len(D), 256)
+    bi = np.where(b < 256, bi, -1).astype(np.int32)
+    return bi, b.astype(np.uint16), np.asarray(s).astype(np.uint16)

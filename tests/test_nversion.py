@@ -166,3 +166,30 @@ def test_golden_angles_and_descriptors_follow_from_the_numpy_chain(oracle):
         assert np.array_equal(d, desc[sel]), level
         n += len(sel)
     assert n == len(kps) == 1008
+
+
+def test_matcher_second_restatement(oracle):
+    """Rule 14 (match::robust's brute-force matcher) and the best / second-best kernel contract restated over an integer matrix product:
+    the golden pairs of the two golden frames come out of the numpy form alone, and on random descriptor sets with clusters of
+    near-duplicates, landmark masks and frame-side masks it equals the C oracle pair for pair."""
+    g = np.load(os.path.join(GOLDEN, "orb_752x480_seed0.npz"))
+    got = nv.robust_brute_force_match(g["desc_a"], g["desc_b"], None, 0.9)
+    assert np.array_equal(got, g["pairs_ab_ratio09"]) and len(got) > 300
+    rng = np.random.default_rng(3)
+    for n1, n2, ratio in ((300, 280, 0.8), (64, 500, 0.9), (1, 40, 0.75), (200, 1, 1.01), (150, 150, 0.6)):
+        base = rng.integers(0, 256, (max(n1, n2), 32), dtype=np.uint8)
+        d1 = base[:n1].copy()
+        d2 = base[rng.permutation(max(n1, n2))[:n2]].copy()
+        for d in (d1, d2):   # a few flipped bits: most keypoints have a near neighbour on the other side, some have several
+            flips = rng.integers(0, 256, (len(d), 6))
+            for k in range(6):
+                d[np.arange(len(d)), flips[:, k] >> 3] ^= (1 << (flips[:, k] & 7)).astype(np.uint8)
+        d2[: n2 // 5] = d2[rng.integers(0, n2, n2 // 5)]   # exact duplicates on the keyframe side: claim conflicts
+        kf_valid = (rng.random(n2) < 0.8).astype(np.uint8)
+        frm_valid = (rng.random(n1) < 0.9).astype(np.uint8)
+        for kv, fv in ((None, None), (kf_valid, None), (kf_valid, frm_valid)):
+            want = oracle.robust_brute_force_match(d1, d2, kv, ratio, frm_valid=fv)
+            assert np.array_equal(nv.robust_brute_force_match(d1, d2, kv, ratio, fv), want), (n1, n2, ratio)
+        wi, wb, ws = oracle.hamming_best2(d2, d1, frm_valid)
+        gi, gb, gs = nv.hamming_best2(d2, d1, frm_valid)
+        assert np.array_equal(gb, wb) and np.array_equal(gs, ws) and np.array_equal(gi, wi)
