@@ -1,0 +1,132 @@
+"""A SECOND, independent restatement of optimize::pose_optimizer::optimize (perspective mono / stereo edges) in plain numpy, written from
+oracle/ORACLE_SPEC.md rules 15 and 25 and the published g2o algorithm (OptimizationAlgorithmLevenberg, RobustKernelHuber, SE3Quat::exp) --
+not from oracle/ovo_pose.cc: whole-array edge arithmetic, numpy's LAPACK solve instead of a hand-written Cholesky. tests/test_nversion.py
+compares it with the C oracle. The normal equations are summed in another order (pairwise numpy sums), so agreement is to the stated
+tolerance of the optimiser (2e-8; rule 25, "How far the result is defined"), with identical inlier flags away from the chi2 gates.
+Test infrastructure only."""
+import numpy as np
+
+CHI2_2D = float(np.float32(5.99146))
+CHI2_3D = float(np.float32(7.81473))
+SQRT_CHI2_2D = float(np.sqrt(np.float32(5.99146)))
+SQRT_CHI2_3D = float(np.sqrt(np.float32(7.81473)))
+
+
+def _se3_exp(u):
+    w, v = u[:3], u[3:]
+    th = np.sqrt(w @ w)
+    O = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    O2 = O @ O
+    if th < 0.00001:
+        R = np.eye(3) + O + O2
+        V = R
+    else:
+        R = np.eye(3) + np.sin(th) / th * O + (1 - np.cos(th)) / (th * th) * O2
+        V = np.eye(3) + (1 - np.cos(th)) / (th * th) * O + (th - np.sin(th)) / (th ** 3) * O2
+    return R, V @ v
+
+
+def _edges(R, t, obs, cam, bf):
+    """Residuals (n, 3), Jacobians (n, 3, 6) w.r.t. (omega, upsilon), stereo mask; the third row is zero for monocular observations."""
+    fx, fy, cx, cy = cam
+    p = obs["pos_w"] @ R.T + t
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    iz = 1.0 / z
+    iz2 = iz * iz
+    st = obs["is_stereo"] != 0
+    u = fx * x * iz + cx
+    e = np.stack([obs["obs_x"] - u, obs["obs_y"] - (fy * y * iz + cy), np.where(st, obs["obs_x_right"] - (u - bf * iz), 0.0)], 1)
+    J = np.zeros((len(obs), 3, 6))
+    J[:, 0] = np.stack([x * y * iz2 * fx, -(1 + x * x * iz2) * fx, y * iz * fx, -iz * fx, np.zeros_like(x), x * iz2 * fx], 1)
+    J[:, 1] = np.stack([(1 + y * y * iz2) * fy, -x * y * iz2 * fy, -x * iz * fy, np.zeros_like(x), -iz * fy, y * iz2 * fy], 1)
+    J2 = J[:, 0].copy()
+    J2[:, 0] -= bf * y * iz2
+    J2[:, 1] += bf * x * iz2
+    J2[:, 5] -= bf * iz2
+    J[:, 2] = np.where(st[:, None], J2, 0.0)
+    return e, J, st
+
+
+def _chi2(R, t, obs, cam, bf):
+    e, _, st = _edges(R, t, obs, cam, bf)
+    return obs["inv_sigma_sq"] * (e * e).sum(1), st
+
+
+def _robust_sum(c2, delta):
+    if delta <= 0:
+        return c2.sum()
+    return np.where(c2 > delta * delta, 2 * np.sqrt(c2) * delta - delta * delta, c2).sum()
+
+
+def pose_optimize(T0, obs, cam, bf=0.0, setup_type=None):
+    """Returns (pose 3x4, outlier flags, num_valid) as the C oracle's ovo_pose_optimize."""
+    if setup_type is None:
+        setup_type = 1 if bf != 0.0 else 0
+    huber = SQRT_CHI2_2D if setup_type == 0 else SQRT_CHI2_3D
+    R, t = np.array(T0[:, :3], float), np.array(T0[:, 3], float)
+    n = len(obs)
+    out = np.zeros(n, bool)
+    if n < 5:
+        return np.concatenate([R, t[:, None]], 1), out, 0
+    active = np.ones(n, bool)
+    num_bad = 0
+    for rnd in range(4):
+        delta = huber if rnd < 3 else 0.0   # Huber in rounds 0 .. 2
+        o = obs[active]
+        lam, ni = 0.0, 2.0
+        Rn, tn = R, t
+        err_at_trial = False
+        for it in range(10):
+            err_at_trial = False
+            e, J, _ = _edges(R, t, o, cam, bf)
+            c2 = o["inv_sigma_sq"] * (e * e).sum(1)
+            rho1 = np.ones(len(o))
+            if delta > 0:
+                big = c2 > delta * delta
+                rho1 = np.where(big, delta / np.sqrt(np.where(big, c2, 1.0)), 1.0)
+            W = rho1 * o["inv_sigma_sq"]
+            H = np.einsum("n,nra,nrb->ab", W, J, J)
+            b = -np.einsum("n,nra,nr->a", W, J, e)
+            chi = _robust_sum(c2, delta)
+            if it == 0:
+                lam, ni = 1e-5 * np.abs(np.diag(H)).max(), 2.0
+            rho, qmax = 0.0, 0
+            while True:
+                A = H + lam * np.eye(6)
+                ok = True
+                try:
+                    np.linalg.cholesky(A)   # g2o: the step exists iff the damped system is positive definite
+                    dx = np.linalg.solve(A, b)
+                except np.linalg.LinAlgError:
+                    ok = False
+                temp, scale = np.finfo(float).max, 1e-3
+                if ok:
+                    E, et = _se3_exp(dx)
+                    Rn, tn = E @ R, E @ t + et
+                    temp = _robust_sum(_chi2(Rn, tn, o, cam, bf)[0], delta)
+                    scale = dx @ (lam * dx + b) + 1e-3
+                    err_at_trial = True
+                rho = (chi - temp) / scale
+                if rho > 0 and np.isfinite(temp):
+                    lam *= max(1.0 / 3.0, min(1.0 - (2 * rho - 1) ** 3, 2.0 / 3.0))
+                    ni = 2.0
+                    chi = temp
+                    R, t = Rn, tn
+                else:
+                    lam *= ni
+                    ni *= 2
+                qmax += 1
+                if not (rho < 0 and qmax < 10):
+                    break
+            if qmax == 10 or rho == 0:
+                break
+        # re-classification: previous outliers at the estimate, inliers where their errors were last computed (the last trial state)
+        c_est, st = _chi2(R, t, obs, cam, bf)
+        c_err = _chi2(Rn, tn, obs, cam, bf)[0] if err_at_trial else c_est
+        c2 = np.where(active, c_err, c_est)
+        out = np.where(st, CHI2_3D, CHI2_2D) < c2
+        active = ~out
+        num_bad = int(out.sum())
+        if n - num_bad < 5:
+            break
+    return np.concatenate([R, t[:, None]], 1), out, n - num_bad

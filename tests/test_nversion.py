@@ -193,3 +193,18 @@ def test_matcher_second_restatement(oracle):
         wi, wb, ws = oracle.hamming_best2(d2, d1, frm_valid)
         gi, gb, gs = nv.hamming_best2(d2, d1, frm_valid)
         assert np.array_equal(gb, wb) and np.array_equal(gs, ws) and np.array_equal(gi, wi)
+
+
+@pytest.mark.parametrize("n,stereo_frac,outlier_frac,pose_err,seed", [(1500, 0.4, 0.1, 1.0, 1), (2000, 0.0, 0.2, 2.0, 2), (300, 1.0, 0.05, 0.5, 3),
+                                                                      (60, 0.5, 0.0, 1.0, 4), (7, 0.5, 0.0, 1.0, 5), (3, 0.0, 0.0, 1.0, 6)])
+def test_pose_optimizer_second_restatement(oracle, n, stereo_frac, outlier_frac, pose_err, seed):
+    """optimize::pose_optimizer::optimize a second time (tests/nversion_pose.py: numpy edges and LAPACK solve, written from rules 15 / 25)
+    against the C oracle: the same inlier flags and number of valid observations, the pose to 2e-8 (the normal equations are summed in a
+    different order: rule 25's stated spread)."""
+    import nversion_pose as nvp
+    from openvslam_amd.synth import synth_pose_frame
+    T0, obs, cam, bf, _ = synth_pose_frame(oracle.POSE_OBS_DTYPE, n, seed, stereo_frac, outlier_frac, pose_err)
+    wT, wout, wnv = oracle.pose_optimize(T0, obs, cam, bf)
+    T, out, nv = nvp.pose_optimize(T0, obs, cam, bf)
+    assert nv == wnv and np.array_equal(out, wout.astype(bool))
+    assert np.allclose(T, wT, rtol=0, atol=2e-8), np.abs(T - wT).max()
