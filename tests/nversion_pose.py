@@ -47,8 +47,31 @@ def _edges(R, t, obs, cam, bf):
     return e, J, st
 
 
-def _chi2(R, t, obs, cam, bf):
-    e, _, st = _edges(R, t, obs, cam, bf)
+def _edges_equirect(R, t, obs, cam, bf):
+    """Rule 26: u = cols (1/2 + atan2(x, z) / 2 pi), v = rows (1/2 + asin(y / |p|) / pi), e = z - (u, v), no wrap-around at the seam;
+    J = -d(u, v) / d(omega, upsilon) with dp = (-[p]x | I). cam = (cols, rows, -, -)."""
+    cols, rows = cam[0], cam[1]
+    p = obs["pos_w"] @ R.T + t
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    L = np.sqrt((p * p).sum(1))
+    rxz2 = x * x + z * z
+    e = np.stack([obs["obs_x"] - cols * (0.5 + np.arctan2(x, z) / (2 * np.pi)), obs["obs_y"] - rows * (0.5 + np.arcsin(y / L) / np.pi),
+                  np.zeros_like(x)], 1)
+    dp = np.zeros((len(obs), 3, 6))   # d p / d (omega, upsilon): columns 0..2 = -[p]x, 3..5 = I
+    dp[:, 0, 1], dp[:, 0, 2] = z, -y
+    dp[:, 1, 0], dp[:, 1, 2] = -z, x
+    dp[:, 2, 0], dp[:, 2, 1] = y, -x
+    dp[:, 0, 3] = dp[:, 1, 4] = dp[:, 2, 5] = 1.0
+    dL = (p[:, :, None] * dp).sum(1) / L[:, None]
+    du = (cols / (2 * np.pi)) * (z[:, None] * dp[:, 0] - x[:, None] * dp[:, 2]) / rxz2[:, None]
+    dv = (rows / np.pi) * (L[:, None] * dp[:, 1] - y[:, None] * dL) / (L * np.sqrt(rxz2))[:, None]
+    J = np.zeros((len(obs), 3, 6))
+    J[:, 0], J[:, 1] = -du, -dv
+    return e, J, np.zeros(len(obs), bool)
+
+
+def _chi2(R, t, obs, cam, bf, edges=None):
+    e, _, st = (edges or _edges)(R, t, obs, cam, bf)
     return obs["inv_sigma_sq"] * (e * e).sum(1), st
 
 
@@ -58,8 +81,14 @@ def _robust_sum(c2, delta):
     return np.where(c2 > delta * delta, 2 * np.sqrt(c2) * delta - delta * delta, c2).sum()
 
 
-def pose_optimize(T0, obs, cam, bf=0.0, setup_type=None):
+def pose_optimize_equirect(T0, obs, cols, rows):
+    """Equirectangular frames (monocular rig: Huber sqrtf(5.99146f), gate 5.99146f)."""
+    return pose_optimize(T0, obs, (float(cols), float(rows), 0.0, 0.0), 0.0, 0, _edges_equirect)
+
+
+def pose_optimize(T0, obs, cam, bf=0.0, setup_type=None, edges=None):
     """Returns (pose 3x4, outlier flags, num_valid) as the C oracle's ovo_pose_optimize."""
+    edges = edges or _edges
     if setup_type is None:
         setup_type = 1 if bf != 0.0 else 0
     huber = SQRT_CHI2_2D if setup_type == 0 else SQRT_CHI2_3D
@@ -78,7 +107,7 @@ def pose_optimize(T0, obs, cam, bf=0.0, setup_type=None):
         err_at_trial = False
         for it in range(10):
             err_at_trial = False
-            e, J, _ = _edges(R, t, o, cam, bf)
+            e, J, _ = edges(R, t, o, cam, bf)
             c2 = o["inv_sigma_sq"] * (e * e).sum(1)
             rho1 = np.ones(len(o))
             if delta > 0:
@@ -103,7 +132,7 @@ def pose_optimize(T0, obs, cam, bf=0.0, setup_type=None):
                 if ok:
                     E, et = _se3_exp(dx)
                     Rn, tn = E @ R, E @ t + et
-                    temp = _robust_sum(_chi2(Rn, tn, o, cam, bf)[0], delta)
+                    temp = _robust_sum(_chi2(Rn, tn, o, cam, bf, edges)[0], delta)
                     scale = dx @ (lam * dx + b) + 1e-3
                     err_at_trial = True
                 rho = (chi - temp) / scale
@@ -121,8 +150,8 @@ def pose_optimize(T0, obs, cam, bf=0.0, setup_type=None):
             if qmax == 10 or rho == 0:
                 break
         # re-classification: previous outliers at the estimate, inliers where their errors were last computed (the last trial state)
-        c_est, st = _chi2(R, t, obs, cam, bf)
-        c_err = _chi2(Rn, tn, obs, cam, bf)[0] if err_at_trial else c_est
+        c_est, st = _chi2(R, t, obs, cam, bf, edges)
+        c_err = _chi2(Rn, tn, obs, cam, bf, edges)[0] if err_at_trial else c_est
         c2 = np.where(active, c_err, c_est)
         out = np.where(st, CHI2_3D, CHI2_2D) < c2
         active = ~out

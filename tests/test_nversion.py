@@ -208,3 +208,19 @@ def test_pose_optimizer_second_restatement(oracle, n, stereo_frac, outlier_frac,
     T, out, nv = nvp.pose_optimize(T0, obs, cam, bf)
     assert nv == wnv and np.array_equal(out, wout.astype(bool))
     assert np.allclose(T, wT, rtol=0, atol=2e-8), np.abs(T - wT).max()
+
+
+@pytest.mark.parametrize("n,outlier_frac,pose_err,seam,pole,seed", [(1500, 0.1, 1.0, 0.0, 0.0, 1), (2000, 0.2, 2.0, 0.1, 0.05, 2), (300, 0.05, 0.5, 0.3, 0.3, 3),
+                                                                     (7, 0.0, 1.0, 0.0, 0.0, 4)])
+def test_equirect_pose_optimizer_second_restatement(oracle, n, outlier_frac, pose_err, seam, pole, seed):
+    """The equirectangular pose-only edge (rule 26: atan2 / asin projection, no wrap-around at the seam) through the same numpy optimiser,
+    with bearings on the +-180 degree seam and near the poles, against the C oracle."""
+    import nversion_pose as nvp
+    from openvslam_amd.synth import synth_pose_frame_equirect
+    T0, obs, cols, rows, _ = synth_pose_frame_equirect(oracle.POSE_OBS_DTYPE, n, seed, outlier_frac=outlier_frac, pose_err=pose_err,
+                                                       seam_frac=seam, pole_frac=pole)
+    wT, wout, wnv = oracle.pose_optimize_equirect(T0, obs, cols, rows)
+    T, out, nv = nvp.pose_optimize_equirect(T0, obs, cols, rows)
+    flips = int((out != wout.astype(bool)).sum())
+    assert flips <= max(1, n // 500) and abs(nv - wnv) <= flips     # (the tolerance of tests/test_gpu_pose.py for these frames)
+    assert np.allclose(T, wT, rtol=0, atol=1e-7), np.abs(T - wT).max()
