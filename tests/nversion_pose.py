@@ -159,3 +159,74 @@ def pose_optimize(T0, obs, cam, bf=0.0, setup_type=None, edges=None):
         if n - num_bad < 5:
             break
     return np.concatenate([R, t[:, None]], 1), out, n - num_bad
+
+
+# ---- rule 15: one Levenberg-Marquardt linearisation of local BA (the blocks ovo_ba_linearize* return) --------------------------------------
+def _quat_rot(q):
+    x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    return np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], 1),
+                     np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], 1),
+                     np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)], 1)
+
+
+def ba_linearize(poses, pose_fixed, points, edges, cam, huber_delta, bf=None, equirect=False):
+    """Hpp (n_pose, 6, 6), bp, Hll (n_pt, 3, 3), bl, Hpl (n_edge, 6, 3), chi2 (plain, robust) of one set of edges: e = z - pi(R X + t),
+    J_point = -(d pi / d p) R, J_pose = -(d pi / d p) (-[p]x | I), Huber on chi2 = w e.e with the second-derivative term dropped,
+    b = -J^T W e; fixed keyframes get no pose blocks (their edges still feed the landmark blocks). bf: stereo edges (third residual
+    u_right = u - bf / z); equirect: cam = (cols, rows, -, -), the projection of rule 26."""
+    poses = np.asarray(poses, float).reshape(-1, 7)
+    points = np.asarray(points, float).reshape(-1, 3)
+    R_all = _quat_rot(poses[:, 3:])
+    k, j = edges["pose_idx"], edges["point_idx"]
+    R = R_all[k]
+    p = np.einsum("nab,nb->na", R, points[j]) + poses[k, :3]
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    n = len(edges)
+    rows_e = 3 if bf is not None else 2
+    dpi = np.zeros((n, rows_e, 3))   # d pi / d p
+    if equirect:
+        cols, rws = cam[0], cam[1]
+        L = np.sqrt((p * p).sum(1))
+        rxz2 = x * x + z * z
+        e = np.stack([edges["obs_x"] - cols * (0.5 + np.arctan2(x, z) / (2 * np.pi)), edges["obs_y"] - rws * (0.5 + np.arcsin(y / L) / np.pi)], 1)
+        dpi[:, 0, 0], dpi[:, 0, 2] = (cols / (2 * np.pi)) * z / rxz2, -(cols / (2 * np.pi)) * x / rxz2
+        s = (rws / np.pi) / (L * np.sqrt(rxz2))
+        # d asin(y / L) = (L dy - y dL) / (L sqrt(x^2 + z^2)), dL = p.dp / L
+        dpi[:, 1] = s[:, None] * (np.stack([np.zeros(n), L, np.zeros(n)], 1) - y[:, None] * p / L[:, None])
+    else:
+        fx, fy, cx, cy = cam
+        iz = 1.0 / z
+        u = fx * x * iz + cx
+        cols_e = [edges["obs_x"] - u, edges["obs_y"] - (fy * y * iz + cy)]
+        dpi[:, 0, 0], dpi[:, 0, 2] = fx * iz, -fx * x * iz * iz
+        dpi[:, 1, 1], dpi[:, 1, 2] = fy * iz, -fy * y * iz * iz
+        if bf is not None:
+            cols_e.append(edges["obs_x_right"] - (u - bf * iz))
+            dpi[:, 2, 0], dpi[:, 2, 2] = fx * iz, -fx * x * iz * iz + bf * iz * iz
+        e = np.stack(cols_e, 1)
+    dp = np.zeros((n, 3, 6))
+    dp[:, 0, 1], dp[:, 0, 2] = z, -y
+    dp[:, 1, 0], dp[:, 1, 2] = -z, x
+    dp[:, 2, 0], dp[:, 2, 1] = y, -x
+    dp[:, 0, 3] = dp[:, 1, 4] = dp[:, 2, 5] = 1.0
+    Jl = -np.einsum("nrc,ncd->nrd", dpi, R)
+    Jp = -np.einsum("nrc,ncd->nrd", dpi, dp)
+    w = edges["inv_sigma_sq"]
+    c2 = w * (e * e).sum(1)
+    rho0, rho1 = c2.copy(), np.ones(n)
+    if huber_delta > 0:
+        big = c2 > huber_delta * huber_delta
+        sq = np.sqrt(np.where(big, c2, 1.0))
+        rho0 = np.where(big, 2 * sq * huber_delta - huber_delta * huber_delta, c2)
+        rho1 = np.where(big, huber_delta / sq, 1.0)
+    W = rho1 * w
+    free = np.ones(len(poses), bool) if pose_fixed is None else ~np.asarray(pose_fixed).astype(bool)
+    fe = free[k]
+    out = dict(Hpp=np.zeros((len(poses), 6, 6)), bp=np.zeros((len(poses), 6)), Hll=np.zeros((len(points), 3, 3)), bl=np.zeros((len(points), 3)))
+    np.add.at(out["Hll"], j, W[:, None, None] * np.einsum("nra,nrb->nab", Jl, Jl))
+    np.add.at(out["bl"], j, -W[:, None] * np.einsum("nra,nr->na", Jl, e))
+    np.add.at(out["Hpp"], k[fe], (W[:, None, None] * np.einsum("nra,nrb->nab", Jp, Jp))[fe])
+    np.add.at(out["bp"], k[fe], (-W[:, None] * np.einsum("nra,nr->na", Jp, e))[fe])
+    out["Hpl"] = np.where(fe[:, None, None], W[:, None, None] * np.einsum("nra,nrb->nab", Jp, Jl), 0.0)
+    out["chi2"] = np.array([c2.sum(), rho0.sum()])
+    return out

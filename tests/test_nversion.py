@@ -224,3 +224,39 @@ def test_equirect_pose_optimizer_second_restatement(oracle, n, outlier_frac, pos
     flips = int((out != wout.astype(bool)).sum())
     assert flips <= max(1, n // 500) and abs(nv - wnv) <= flips     # (the tolerance of tests/test_gpu_pose.py for these frames)
     assert np.allclose(T, wT, rtol=0, atol=1e-7), np.abs(T - wT).max()
+
+
+def _blocks_close(got, want, rtol=1e-11):
+    for k in ("Hpp", "bp", "Hll", "bl", "Hpl", "chi2"):
+        scale = max(float(np.abs(want[k]).max()), 1e-300)
+        assert np.allclose(got[k], want[k], rtol=rtol, atol=rtol * scale), (k, float(np.abs(got[k] - want[k]).max() / scale))
+
+
+def test_ba_linearisation_second_restatement(oracle):
+    """The blocks of one local-BA linearisation (rule 15: residuals, 2x3 / 3x3 point and 2x6 / 3x6 pose Jacobians, Huber weights, Hpp, bp,
+    Hll, bl, the per-edge Hpl, both chi2 sums) from whole-array numpy (tests/nversion_pose.py: chain rule through d pi / d p) against the C
+    oracle's edge loops: monocular, stereo and equirectangular edges, with fixed keyframes and with / without the robust kernel."""
+    import nversion_pose as nvp
+    from openvslam_amd.synth import synth_local_ba
+    from test_ba import _lba_scene
+    d = synth_local_ba(n_pose=8, n_pt=900, obs_per_pose=300, seed=2, pose_noise=0.03, point_noise=0.03, n_fixed=2)
+    for delta in (0.0, float(np.sqrt(np.float32(5.99146)))):
+        want = oracle.ba_linearize(d["poses"], d["pose_fixed"], d["points"], d["edges"], d["cam"], delta)
+        _blocks_close(nvp.ba_linearize(d["poses"], d["pose_fixed"], d["points"], d["edges"], d["cam"], delta), want)
+    s, mono, st, bf, _, _ = _lba_scene(4, n_pose=7, n_pt=700, obs_per_pose=250, stereo_frac=1.0)
+    want = oracle.ba_linearize_stereo(s["poses"], s["pose_fixed"], s["points"], st, s["cam"], bf, 2.7955)
+    _blocks_close(nvp.ba_linearize(s["poses"], s["pose_fixed"], s["points"], st, s["cam"], 2.7955, bf=bf), want)
+    # equirectangular: landmarks all around the keyframes (the seam and the poles included)
+    rng = np.random.default_rng(8)
+    pts = rng.normal(size=(600, 3)) * 6.0
+    poses = np.zeros((5, 7))
+    poses[:, :3] = rng.normal(size=(5, 3)) * 0.3
+    q = rng.normal(size=(5, 4)) * 0.05 + np.array([0, 0, 0, 1.0])
+    poses[:, 3:] = q / np.linalg.norm(q, axis=1)[:, None]
+    e = np.zeros(1500, oracle.BA_EDGE_DTYPE)
+    e["pose_idx"], e["point_idx"] = rng.integers(0, 5, 1500), rng.integers(0, 600, 1500)
+    e["obs_x"], e["obs_y"] = rng.uniform(0, 3840, 1500), rng.uniform(0, 1920, 1500)
+    e["inv_sigma_sq"] = rng.choice([1.0, 0.69, 0.48], 1500)
+    fixed = np.array([1, 0, 0, 1, 0], np.uint8)
+    want = oracle.ba_linearize_equirect(poses, fixed, pts, e, 3840, 1920, 2.4477)
+    _blocks_close(nvp.ba_linearize(poses, fixed, pts, e, (3840.0, 1920.0, 0.0, 0.0), 2.4477, equirect=True), want, rtol=1e-10)
