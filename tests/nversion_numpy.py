@@ -226,3 +226,40 @@ def hamming_best2(q, t, t_valid=None):
     s = np.partition(D, 1, axis=1)[:, 1] if D.shape[1] > 1 else np.full(len(D), 256)
     bi = np.where(b < 256, bi, -1).astype(np.int32)
     return bi, b.astype(np.uint16), np.asarray(s).astype(np.uint16)
+
+
+# ---- rule 16: the keypoint grid (data::assign_keypoints_to_grid / get_keypoints_in_cell) -----------------------------------------------------
+def _grid_inv(min_v, max_v, n_cells):
+    return np.float32(np.float64(n_cells) / np.float64(np.float32(max_v) - np.float32(min_v)))
+
+
+def grid_cells(xs, ys, min_x, min_y, max_x, max_y, n_cols, n_rows):
+    """Cell of every keypoint, (cx, cy, inside): cvRound((pt - min) * inv) in float, half to even; outside the grid = in no cell."""
+    F = np.float32
+    cx = np.rint((np.asarray(xs, F) - F(min_x)) * _grid_inv(min_x, max_x, n_cols)).astype(np.int64)
+    cy = np.rint((np.asarray(ys, F) - F(min_y)) * _grid_inv(min_y, max_y, n_rows)).astype(np.int64)
+    return cx, cy, (cx >= 0) & (cx < n_cols) & (cy >= 0) & (cy < n_rows)
+
+
+def keypoints_in_cell(xs, ys, octaves, ref_x, ref_y, margin, min_x, min_y, max_x, max_y, n_cols, n_rows, min_level=-1, max_level=-1):
+    """Indices of the keypoints in the cells the square (ref +- margin) touches, cell columns first, then cell rows, ascending keypoint index
+    inside a cell; level filter only when (0 < min_level) or (0 <= max_level); strictly inside the square."""
+    F = np.float32
+    xs, ys = np.asarray(xs, F), np.asarray(ys, F)
+    cx, cy, inside = grid_cells(xs, ys, min_x, min_y, max_x, max_y, n_cols, n_rows)
+    iw, ih = _grid_inv(min_x, max_x, n_cols), _grid_inv(min_y, max_y, n_rows)
+    rx, ry, m = F(ref_x), F(ref_y), F(margin)
+    x_lo = max(0, int(np.floor((rx - F(min_x) - m) * iw)))
+    x_hi = min(n_cols - 1, int(np.ceil((rx - F(min_x) + m) * iw)))
+    y_lo = max(0, int(np.floor((ry - F(min_y) - m) * ih)))
+    y_hi = min(n_rows - 1, int(np.ceil((ry - F(min_y) + m) * ih)))
+    if x_lo >= n_cols or x_hi < 0 or y_lo >= n_rows or y_hi < 0:
+        return np.zeros(0, np.int32)
+    sel = inside & (cx >= x_lo) & (cx <= x_hi) & (cy >= y_lo) & (cy <= y_hi)
+    if (0 < min_level) or (0 <= max_level):
+        oc = np.asarray(octaves)
+        sel &= ~((oc < min_level) | ((0 <= max_level) & (oc > max_level)))
+    sel &= (np.abs(xs - rx) < m) & (np.abs(ys - ry) < m)
+    idx = np.nonzero(sel)[0]
+    order = np.lexsort((idx, cy[idx], cx[idx]))   # primary: cell column, then cell row, then keypoint index
+    return idx[order].astype(np.int32)

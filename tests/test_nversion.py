@@ -260,3 +260,33 @@ def test_ba_linearisation_second_restatement(oracle):
     fixed = np.array([1, 0, 0, 1, 0], np.uint8)
     want = oracle.ba_linearize_equirect(poses, fixed, pts, e, 3840, 1920, 2.4477)
     _blocks_close(nvp.ba_linearize(poses, fixed, pts, e, (3840.0, 1920.0, 0.0, 0.0), 2.4477, equirect=True), want, rtol=1e-10)
+
+
+def test_grid_second_restatement(oracle):
+    """Rule 16 (the 64 x 48 keypoint grid behind every windowed matcher): cell assignment by cvRound in float and the area query's cell range,
+    order, level filter and strict distance test, whole-array, against the C oracle -- keypoints on cell borders and outside the image, queries
+    at the borders, every level-filter combination."""
+    rng = np.random.default_rng(12)
+    cols, rows = 752, 480
+    gp = oracle.grid_params(cols, rows)
+    n = 3000
+    kps = np.zeros(n, oracle.KP_DTYPE)
+    kps["x"] = rng.uniform(-8, cols + 8, n).astype(np.float32)
+    kps["y"] = rng.uniform(-8, rows + 8, n).astype(np.float32)
+    kps["x"][:400] = (np.round(kps["x"][:400] / 11.75) * 11.75).astype(np.float32)    # on cell borders (752 / 64 = 11.75)
+    kps["y"][:400] = (np.round(kps["y"][:400] / 10.0) * 10.0 + rng.choice([0.0, 5.0], 400)).astype(np.float32)
+    kps["octave"] = rng.integers(0, 8, n)
+    start, items = oracle.assign_keypoints_to_grid(gp, kps)
+    cx, cy, inside = nv.grid_cells(kps["x"], kps["y"], 0.0, 0.0, cols, rows, 64, 48)
+    cell = cx * 48 + cy   # (the oracle's CSR is x-major)
+    counts = np.bincount(cell[inside], minlength=64 * 48)
+    assert np.array_equal(np.diff(start), counts) and len(items) == int(inside.sum())
+    for c in rng.integers(0, 64 * 48, 200):
+        assert np.array_equal(items[start[c]:start[c + 1]], np.nonzero(inside & (cell == c))[0])
+    for _ in range(300):
+        rx, ry = float(rng.uniform(-20, cols + 20)), float(rng.uniform(-20, rows + 20))
+        m = float(rng.choice([3.0, 7.5, 15.0, 40.0, 120.0]))
+        lo, hi = [(-1, -1), (0, -1), (2, -1), (-1, 3), (1, 4), (3, 3), (0, 0)][int(rng.integers(0, 7))]
+        want = oracle.get_keypoints_in_cell(gp, kps, rx, ry, m, lo, hi)
+        got = nv.keypoints_in_cell(kps["x"], kps["y"], kps["octave"], rx, ry, m, 0.0, 0.0, cols, rows, 64, 48, lo, hi)
+        assert np.array_equal(got, want), (rx, ry, m, lo, hi)
