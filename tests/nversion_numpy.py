@@ -263,3 +263,54 @@ def keypoints_in_cell(xs, ys, octaves, ref_x, ref_y, margin, min_x, min_y, max_x
     idx = np.nonzero(sel)[0]
     order = np.lexsort((idx, cy[idx], cx[idx]))   # primary: cell column, then cell row, then keypoint index
     return idx[order].astype(np.int32)
+
+
+# ---- rule 17: match::angle_checker ------------------------------------------------------------------------------------------------------------
+def angle_checker_invalid(delta_angles):
+    """True for the entries outside the three fullest 30-degree bins: delta wrapped once into [0, 360), bin = cvRound(delta * (1 / 30)) in
+    float (half to even), equal counts -> the lower bin first."""
+    F = np.float32
+    d = np.asarray(delta_angles, F).copy()
+    d = np.where(d < 0, d + F(360.0), d).astype(F)
+    d = np.where(d >= F(360.0), d - F(360.0), d).astype(F)
+    b = np.rint(d * F(1.0 / 30.0)).astype(np.int64)
+    counts = np.bincount(b, minlength=30)[:30]
+    keep = np.argsort(-counts, kind="stable")[:3]
+    return ~np.isin(b, keep)
+
+
+# ---- rule 18: projection::match_frame_and_landmarks -------------------------------------------------------------------------------------------
+def projection_match_frame_and_landmarks(xs, ys, octaves, desc, scale_factors, lm_xy, lm_level, lm_desc, cols, rows, margin=5.0, lowe_ratio=0.6,
+                                         x_right=None, occupied=None, lm_x_right=None, lm_valid=None):
+    """assigned[l] = the frame keypoint given to local landmark l (or -1): landmarks in order; candidates = the grid's answer around the
+    reprojection with radius margin * scale_factors[pred] on levels [pred - 1, pred], in the grid's order; keypoints that hold a landmark (also
+    one given earlier in this call) are skipped; a stereo keypoint must agree on x_right within the radius; best / second with strict < and
+    their levels; accepted iff best <= 100 and not (both on one level and best > ratio * second)."""
+    F = np.float32
+    occ = np.zeros(len(xs), bool) if occupied is None else np.asarray(occupied).astype(bool).copy()
+    D = hamming_matrix(lm_desc, desc)
+    assigned = np.full(len(lm_xy), -1, np.int32)
+    for l in range(len(lm_xy)):
+        if lm_valid is not None and not lm_valid[l]:
+            continue
+        pred = int(lm_level[l])
+        r = F(margin) * F(scale_factors[pred])
+        cand = keypoints_in_cell(xs, ys, octaves, lm_xy[l][0], lm_xy[l][1], r, 0.0, 0.0, cols, rows, 64, 48, pred - 1, pred)
+        best = second = 256
+        best_level = second_level = best_idx = -1
+        for i in cand:
+            if occ[i]:
+                continue
+            if x_right is not None and 0 < x_right[i] and r < abs(F(lm_x_right[l]) - F(x_right[i])):
+                continue
+            d = int(D[l, i])
+            if d < best:
+                second, second_level = best, best_level
+                best, best_level, best_idx = d, int(octaves[i]), int(i)
+            elif d < second:
+                second, second_level = d, int(octaves[i])
+        if best > 100 or (best_level == second_level and F(best) > F(lowe_ratio) * F(second)):
+            continue
+        assigned[l] = best_idx
+        occ[best_idx] = True
+    return assigned

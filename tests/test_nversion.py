@@ -290,3 +290,45 @@ def test_grid_second_restatement(oracle):
         want = oracle.get_keypoints_in_cell(gp, kps, rx, ry, m, lo, hi)
         got = nv.keypoints_in_cell(kps["x"], kps["y"], kps["octave"], rx, ry, m, 0.0, 0.0, cols, rows, 64, 48, lo, hi)
         assert np.array_equal(got, want), (rx, ry, m, lo, hi)
+
+
+def test_angle_checker_second_restatement(oracle):
+    rng = np.random.default_rng(2)
+    for n in (0, 1, 5, 400, 3000):
+        d = np.concatenate([rng.normal(12.0, 4.0, n // 2), rng.uniform(-359.9, 719.0, n - n // 2)]).astype(np.float32)
+        d[: n // 10] = (np.round(d[: n // 10] / 15.0) * 15.0).astype(np.float32)   # on bin borders (half-to-even decides)
+        assert np.array_equal(nv.angle_checker_invalid(d), oracle.angle_checker_invalid(d)), n
+    ties = np.array([10.0] * 4 + [40.0] * 4 + [70.0] * 4 + [100.0] * 4 + [130.0] * 2, np.float32)   # four bins of equal size: the lower three stay
+    assert np.array_equal(nv.angle_checker_invalid(ties), oracle.angle_checker_invalid(ties))
+
+
+def test_projection_matcher_second_restatement(oracle):
+    """Rule 18 (projection::match_frame_and_landmarks, the local-map matcher of every tracked frame) from its text over the numpy grid
+    and distance matrix: sequential claims, the level window, the stereo gate, the level-aware ratio test -- equal to the C oracle landmark
+    for landmark on a frame with clustered descriptors, occupied keypoints, stereo keypoints and invalid landmarks."""
+    rng = np.random.default_rng(21)
+    cols, rows, n, m = 752, 480, 1500, 900
+    kps = np.zeros(n, oracle.KP_DTYPE)
+    kps["x"] = rng.uniform(0, cols, n).astype(np.float32)
+    kps["y"] = rng.uniform(0, rows, n).astype(np.float32)
+    kps["octave"] = rng.integers(0, 8, n)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    src = rng.integers(0, n, m)                      # every landmark was seen near some keypoint, with a few flipped bits
+    lm_desc = desc[src].copy()
+    flips = rng.integers(0, 256, (m, 10))
+    for k in range(10):
+        lm_desc[np.arange(m), flips[:, k] >> 3] ^= (1 << (flips[:, k] & 7)).astype(np.uint8)
+    lm_xy = np.stack([kps["x"][src] + rng.normal(0, 2.0, m), kps["y"][src] + rng.normal(0, 2.0, m)], 1).astype(np.float32)
+    lm_level = np.clip(kps["octave"][src] + rng.integers(-1, 2, m), 0, 7).astype(np.int32)
+    x_right = np.where(rng.random(n) < 0.4, kps["x"] - rng.uniform(1, 30, n), -1.0).astype(np.float32)
+    lm_x_right = (lm_xy[:, 0] - rng.uniform(1, 30, m)).astype(np.float32)
+    occupied = (rng.random(n) < 0.1).astype(np.uint8)
+    lm_valid = (rng.random(m) < 0.9).astype(np.uint8)
+    gp = oracle.grid_params(cols, rows)
+    for margin, ratio, xr in ((5.0, 0.6, None), (15.0, 0.9, x_right), (5.0, 0.75, x_right)):
+        want, nm = oracle.projection_match_frame_and_landmarks(gp, kps, desc, sf, lm_xy, lm_level, lm_desc, margin, ratio, xr, occupied,
+                                                               lm_x_right if xr is not None else None, lm_valid)
+        got = nv.projection_match_frame_and_landmarks(kps["x"], kps["y"], kps["octave"], desc, sf, lm_xy, lm_level, lm_desc, cols, rows, margin, ratio,
+                                                      xr, occupied, lm_x_right if xr is not None else None, lm_valid)
+        assert nm > 200 and np.array_equal(got, want), (margin, ratio, int((got != want).sum()))
