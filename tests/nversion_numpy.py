@@ -314,3 +314,78 @@ def projection_match_frame_and_landmarks(xs, ys, octaves, desc, scale_factors, l
         assigned[l] = best_idx
         occ[best_idx] = True
     return assigned
+
+
+# ---- rule 21: camera::reproject_to_image and projection::match_current_and_last_frames ---------------------------------------------------------
+def reproject_to_image(model, cam, pose_cw, pos_w, min_x, min_y, max_x, max_y):
+    """(in image, u, v, x_right) of world points (n, 3) under pose_cw (3 x 4): perspective (cam = fx, fy, cx, cy, focal_x_baseline): z <= 0
+    is rejected, x_right = u - fx_b / z as float; equirectangular (cam = cols, rows): bearing -> (longitude, latitude); bounds inclusive."""
+    T = np.asarray(pose_cw, float)
+    p = np.asarray(pos_w, float) @ T[:, :3].T + T[:, 3]
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    if model == 0:
+        fx, fy, cx, cy, fxb = cam
+        with np.errstate(divide="ignore", invalid="ignore"):
+            iz = 1.0 / z
+            u, v = fx * x * iz + cx, fy * y * iz + cy
+            xr = (u - fxb * iz).astype(np.float32)
+        ok = z > 0
+    else:
+        cols, rows = cam[0], cam[1]
+        L = np.sqrt((p * p).sum(1))
+        b = p / L[:, None]
+        lat, lon = -np.arcsin(b[:, 1]), np.arctan2(b[:, 0], b[:, 2])
+        u, v = cols * (0.5 + lon / (2 * np.pi)), rows * (0.5 - lat / np.pi)
+        xr = np.full(len(p), -1.0, np.float32)
+        ok = np.ones(len(p), bool)
+    ok = ok & (u >= min_x) & (u <= max_x) & (v >= min_y) & (v <= max_y)
+    return ok, u, v, xr
+
+
+def projection_match_current_and_last_frames(model, setup, cam, true_baseline, cols, rows, xs, ys, octaves, angles, desc, pose_cw_curr,
+                                             last_octaves, last_angles, last_pos_w, last_lm_desc, pose_cw_last, scale_factors, margin,
+                                             check_orientation=True, x_right=None, occupied=None, last_valid=None):
+    """assigned[i] = the current keypoint that takes over last frame's landmark i (or -1). The last frame's landmarks in order, reprojected with
+    the current pose; radius margin * scale_factors[level in the last frame]; level window [l - 1, l + 1], or [l, top] / [0, l] when a
+    non-monocular rig moved forward / backward by more than the baseline (z of the current camera centre in the last camera's frame); occupied
+    keypoints (also those taken earlier in this call) skipped; stereo keypoints must agree on x_right within the radius; the nearest
+    descriptor wins if its distance is <= 100; with the orientation check, the matches outside the three fullest bins of
+    (last angle - current angle) are undone."""
+    F = np.float32
+    Tc, Tl = np.asarray(pose_cw_curr, float), np.asarray(pose_cw_last, float)
+    centre_curr = -Tc[:, :3].T @ Tc[:, 3]
+    z_lc = (Tl[:, :3] @ centre_curr + Tl[:, 3])[2]
+    forward = setup != 0 and z_lc > true_baseline
+    backward = setup != 0 and z_lc < -true_baseline
+    ok, u, v, xr_lm = reproject_to_image(model, cam, Tc, last_pos_w, 0.0, 0.0, float(cols), float(rows))
+    occ = np.zeros(len(xs), bool) if occupied is None else np.asarray(occupied).astype(bool).copy()
+    D = hamming_matrix(last_lm_desc, desc)
+    n_levels = len(scale_factors)
+    assigned = np.full(len(last_pos_w), -1, np.int32)
+    deltas, owners = [], []
+    for i in range(len(last_pos_w)):
+        if (last_valid is not None and not last_valid[i]) or not ok[i]:
+            continue
+        lvl = int(last_octaves[i])
+        r = F(margin) * F(scale_factors[lvl])
+        lo, hi = (lvl, n_levels - 1) if forward else ((0, lvl) if backward else (lvl - 1, lvl + 1))
+        cand = keypoints_in_cell(xs, ys, octaves, F(u[i]), F(v[i]), r, 0.0, 0.0, cols, rows, 64, 48, lo, hi)
+        best, best_idx = 256, -1
+        for k in cand:
+            if occ[k]:
+                continue
+            if x_right is not None and 0 < x_right[k] and r < abs(F(xr_lm[i]) - F(x_right[k])):
+                continue
+            d = int(D[i, k])
+            if d < best:
+                best, best_idx = d, int(k)
+        if best > 100:
+            continue
+        assigned[i] = best_idx
+        occ[best_idx] = True
+        deltas.append(F(last_angles[i]) - F(angles[best_idx]))
+        owners.append(i)
+    if check_orientation and deltas:
+        bad = angle_checker_invalid(np.asarray(deltas, F))
+        assigned[np.asarray(owners)[bad]] = -1
+    return assigned

@@ -332,3 +332,53 @@ def test_projection_matcher_second_restatement(oracle):
         got = nv.projection_match_frame_and_landmarks(kps["x"], kps["y"], kps["octave"], desc, sf, lm_xy, lm_level, lm_desc, cols, rows, margin, ratio,
                                                       xr, occupied, lm_x_right if xr is not None else None, lm_valid)
         assert nm > 200 and np.array_equal(got, want), (margin, ratio, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("setup,dz", [(0, 0.0), (1, 0.0), (1, 0.4), (1, -0.4)])
+def test_current_and_last_frames_matcher_second_restatement(oracle, setup, dz):
+    """Rule 21's matcher of every tracked frame (projection::match_current_and_last_frames) from its text: reprojection with the current pose,
+    the motion-dependent level window (monocular; stereo rig standing, moving forward, moving backward by more than the baseline), claims,
+    the stereo gate, best <= 100, the orientation histogram -- equal to the C oracle landmark for landmark."""
+    rng = np.random.default_rng(31 + setup)
+    cols, rows, n = 752, 480, 1200
+    fx = fy = 420.0
+    cx, cy, fxb, base = cols / 2.0, rows / 2.0, 42.0, 0.1
+    cam = oracle.Camera(0, setup, fx, fy, cx, cy, fxb, base, cols, rows)
+    gp = oracle.grid_params(cols, rows)
+    pts = np.stack([rng.uniform(-4, 4, n), rng.uniform(-2.5, 2.5, n), rng.uniform(3, 12, n)], 1)
+    T_last = np.concatenate([np.eye(3), np.zeros((3, 1))], 1)
+    a = 0.01
+    Rc = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    T_curr = np.concatenate([Rc, np.array([[0.02], [-0.01], [-dz]])], 1)   # the current camera centre sits at about z = dz in the last frame
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+
+    def observe(T, noise):
+        p = pts @ T[:, :3].T + T[:, 3]
+        k = np.zeros(n, oracle.KP_DTYPE)
+        k["x"] = (fx * p[:, 0] / p[:, 2] + cx + rng.normal(0, noise, n)).astype(np.float32)
+        k["y"] = (fy * p[:, 1] / p[:, 2] + cy + rng.normal(0, noise, n)).astype(np.float32)
+        return k, p[:, 2]
+
+    last, _ = observe(T_last, 0.0)
+    curr, zc = observe(T_curr, 0.8)
+    last["octave"] = rng.integers(0, 8, n)
+    curr["octave"] = np.clip(last["octave"] + rng.integers(-2, 3, n), 0, 7)
+    last["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    curr["angle"] = np.mod(last["angle"] + rng.normal(8, 3, n) + np.where(rng.random(n) < 0.15, 90, 0), 360).astype(np.float32)
+    desc_l = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    desc_c = desc_l.copy()
+    flips = rng.integers(0, 256, (n, 12))
+    for k in range(12):
+        desc_c[np.arange(n), flips[:, k] >> 3] ^= (1 << (flips[:, k] & 7)).astype(np.uint8)
+    perm = rng.permutation(n)                      # the current frame lists its keypoints in another order
+    curr, desc_c, zc = curr[perm], desc_c[perm], zc[perm]
+    x_right = np.where(rng.random(n) < 0.5, curr["x"] - fxb / zc + rng.normal(0, 0.5, n), -1.0).astype(np.float32) if setup else None
+    occupied = (rng.random(n) < 0.08).astype(np.uint8)
+    last_valid = (rng.random(n) < 0.9).astype(np.uint8)
+    for margin, orient in ((7.0, True), (15.0, False)):
+        want, nm = oracle.projection_match_current_and_last_frames(cam, gp, curr, desc_c, T_curr, last, pts, desc_l, T_last, sf, margin, orient, x_right,
+                                                                   occupied, last_valid)
+        got = nv.projection_match_current_and_last_frames(0, setup, (fx, fy, cx, cy, fxb), base, cols, rows, curr["x"], curr["y"], curr["octave"],
+                                                          curr["angle"], desc_c, T_curr, last["octave"], last["angle"], pts, desc_l, T_last, sf, margin,
+                                                          orient, x_right, occupied, last_valid)
+        assert nm > 150 and np.array_equal(got, want), (setup, dz, margin, int((got != want).sum()), nm)
