@@ -389,3 +389,101 @@ def projection_match_current_and_last_frames(model, setup, cam, true_baseline, c
         bad = angle_checker_invalid(np.asarray(deltas, F))
         assigned[np.asarray(owners)[bad]] = -1
     return assigned
+
+
+# ---- rule 19: match::area::match_in_consistent_area (the initialiser's matcher) ----------------------------------------------------------------
+def area_match_in_consistent_area(oct_1, ang_1, desc_1, xs_2, ys_2, oct_2, ang_2, desc_2, prev_matched_pts, cols, rows, margin=10, lowe_ratio=0.9,
+                                  check_orientation=True):
+    """(number of matches, matched[i1] = keypoint of frame 2 or -1, updated prev_matched_pts): level-0 keypoints of frame 1 in order, each
+    against the level-0 keypoints of frame 2 inside the window around its previously matched point; a target currently matched at a
+    distance <= d does not take part; accepted iff best <= 50 and not (ratio * second < best); an accepted target is taken from its earlier
+    owner; every acceptance enters the orientation histogram (also those stolen later); matches outside the three fullest bins are undone;
+    the surviving matches move prev_matched_pts to their target."""
+    F = np.float32
+    n1, n2 = len(oct_1), len(xs_2)
+    D = hamming_matrix(desc_1, desc_2)
+    m12 = np.full(n1, -1, np.int32)
+    m21 = np.full(n2, -1, np.int32)
+    mdist = np.full(n2, 256, np.int64)
+    hist_delta, hist_owner = [], []
+    for i1 in range(n1):
+        if oct_1[i1] > 0:
+            continue
+        cand = keypoints_in_cell(xs_2, ys_2, oct_2, prev_matched_pts[i1][0], prev_matched_pts[i1][1], F(margin), 0.0, 0.0, cols, rows, 64, 48, 0, 0)
+        best = second = 256
+        best_idx = -1
+        for i2 in cand:
+            d = int(D[i1, i2])
+            if mdist[i2] <= d:
+                continue
+            if d < best:
+                second, best, best_idx = best, d, int(i2)
+            elif d < second:
+                second = d
+        if best > 50 or F(second) * F(lowe_ratio) < F(best):
+            continue
+        if m21[best_idx] >= 0:
+            m12[m21[best_idx]] = -1
+        m12[i1], m21[best_idx], mdist[best_idx] = best_idx, i1, best
+        hist_delta.append(F(ang_1[i1]) - F(ang_2[best_idx]))
+        hist_owner.append(i1)
+    if check_orientation and hist_delta:
+        bad = angle_checker_invalid(np.asarray(hist_delta, F))
+        m12[np.asarray(hist_owner)[bad]] = -1
+    prev = np.array(prev_matched_pts, F, copy=True)
+    ok = m12 >= 0
+    prev[ok, 0], prev[ok, 1] = np.asarray(xs_2, F)[m12[ok]], np.asarray(ys_2, F)[m12[ok]]
+    return int(ok.sum()), m12, prev
+
+
+# ---- rule 19: match::bow_tree -----------------------------------------------------------------------------------------------------------
+def _bow_pairs(ang_a, desc_a, fv_a, live_a, ang_b, desc_b, fv_b, usable_b, lowe_ratio, check_orientation):
+    """The walk both bow_tree matchers share: vocabulary nodes present on both sides in ascending id; side a's keypoints of the node in
+    their stored order (those with a live landmark), each against side b's keypoints of the same node that are still free; strict-less
+    best / second; accept iff best <= 50 and not (ratio * second < best). Returns match_of_b[idx_b] = idx_a (or -1) after the orientation
+    filter (delta = angle_a - angle_b)."""
+    F = np.float32
+    D = hamming_matrix(desc_a, desc_b)
+    match_of_b = np.full(len(ang_b), -1, np.int32)
+    free_b = np.array(usable_b, bool, copy=True)
+    deltas, keys = [], []
+    for node in sorted(set(fv_a) & set(fv_b)):
+        members_b = np.asarray(fv_b[node], np.int64)
+        for ia in fv_a[node]:
+            if not live_a[ia]:
+                continue
+            cand = members_b[free_b[members_b]]
+            if len(cand) == 0:
+                continue
+            d = D[ia, cand]
+            first = int(np.argmin(d))                       # np.argmin: the first of equals, as the strict '<' scan
+            best = int(d[first])
+            second = int(np.delete(d, first).min()) if len(d) > 1 else 256
+            if best > 50 or F(lowe_ratio) * F(second) < F(best):
+                continue
+            ib = int(cand[first])
+            match_of_b[ib], free_b[ib] = ia, False
+            deltas.append(F(ang_a[ia]) - F(ang_b[ib]))
+            keys.append(ib)
+    if check_orientation and deltas:
+        match_of_b[np.asarray(keys)[angle_checker_invalid(np.asarray(deltas, F))]] = -1
+    return match_of_b
+
+
+def bow_match_frame_and_keyframe(kf_angles, kf_desc, kf_fv, kf_has_landmark, frm_angles, frm_desc, frm_fv, lowe_ratio=0.6, check_orientation=True):
+    """(number of matches, landmark_source[frame keypoint] = keyframe keypoint whose landmark it receives, or -1)."""
+    live = np.ones(len(kf_angles), bool) if kf_has_landmark is None else np.asarray(kf_has_landmark, bool)
+    m = _bow_pairs(kf_angles, kf_desc, kf_fv, live, frm_angles, frm_desc, frm_fv, np.ones(len(frm_angles), bool), lowe_ratio, check_orientation)
+    return int((m >= 0).sum()), m
+
+
+def bow_match_keyframes(ang_1, desc_1, fv_1, has_lm_1, ang_2, desc_2, fv_2, has_lm_2, lowe_ratio=0.6, check_orientation=True):
+    """(number of matches, matched_2_in_1[keyframe-1 keypoint] = keyframe-2 keypoint or -1): as above with keyframe 1 as the walking side,
+    keyframe 2's keypoints usable when they carry a live landmark and are not matched yet."""
+    live_1 = np.ones(len(ang_1), bool) if has_lm_1 is None else np.asarray(has_lm_1, bool)
+    live_2 = np.ones(len(ang_2), bool) if has_lm_2 is None else np.asarray(has_lm_2, bool)
+    m21 = _bow_pairs(ang_1, desc_1, fv_1, live_1, ang_2, desc_2, fv_2, live_2, lowe_ratio, check_orientation)
+    m12 = np.full(len(ang_1), -1, np.int32)
+    hit = np.nonzero(m21 >= 0)[0]
+    m12[m21[hit]] = hit
+    return len(hit), m12

@@ -382,3 +382,60 @@ def test_current_and_last_frames_matcher_second_restatement(oracle, setup, dz):
                                                           curr["angle"], desc_c, T_curr, last["octave"], last["angle"], pts, desc_l, T_last, sf, margin,
                                                           orient, x_right, occupied, last_valid)
         assert nm > 150 and np.array_equal(got, want), (setup, dz, margin, int((got != want).sum()), nm)
+
+
+def test_area_matcher_second_restatement(oracle):
+    """Rule 19's match::area (the monocular initialiser's matcher): windows around the previously matched points, targets changing owner,
+    the histogram that keeps stolen entries, the update of prev_matched_pts -- equal to the C oracle match for match, twice in a row (the second
+    call starts from the first call's prev_matched_pts, as the initialiser does frame after frame)."""
+    rng = np.random.default_rng(41)
+    cols, rows, n = 752, 480, 1400
+    gp = oracle.grid_params(cols, rows)
+    k1 = np.zeros(n, oracle.KP_DTYPE)
+    k1["x"], k1["y"] = rng.uniform(0, cols, n).astype(np.float32), rng.uniform(0, rows, n).astype(np.float32)
+    k1["octave"] = np.where(rng.random(n) < 0.7, 0, rng.integers(1, 8, n))
+    k1["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    perm = rng.permutation(n)
+    k2 = k1[perm].copy()
+    k2["x"] = (k2["x"] + rng.normal(3, 2.5, n)).astype(np.float32)
+    k2["y"] = (k2["y"] + rng.normal(-2, 2.5, n)).astype(np.float32)
+    k2["angle"] = np.mod(k2["angle"] + rng.normal(5, 3, n) + np.where(rng.random(n) < 0.1, 120, 0), 360).astype(np.float32)
+    d1 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    d1[: n // 6] = d1[rng.integers(0, n, n // 6)]          # look-alikes: several frame-1 keypoints compete for one target
+    d2 = d1[perm].copy()
+    flips = rng.integers(0, 256, (n, 8))
+    for k in range(8):
+        d2[np.arange(n), flips[:, k] >> 3] ^= (1 << (flips[:, k] & 7)).astype(np.uint8)
+    prev_o = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], 1), np.float32)
+    prev_n = prev_o.copy()
+    for margin, ratio, orient in ((20, 0.9, True), (12, 0.8, True), (30, 0.95, False)):
+        nm, want = oracle.area_match_in_consistent_area(gp, k1, d1, k2, d2, prev_o, margin, ratio, orient)   # (updates prev_o in place)
+        gn, got, prev_n = nv.area_match_in_consistent_area(k1["octave"], k1["angle"], d1, k2["x"], k2["y"], k2["octave"], k2["angle"], d2, prev_n, cols,
+                                                           rows, margin, ratio, orient)
+        assert nm > 100 and gn == nm and np.array_equal(got, want), (margin, ratio, int((got != want).sum()))
+        assert np.array_equal(prev_n, prev_o)
+
+
+def _two_extracted_frames(oracle, shift):
+    ox = oracle.OrbExtractor(oracle.make_params(1000))
+    ka, da = ox.extract(synth.synth_frame(480, 752, seed=21))
+    kb, db = ox.extract(synth.synth_frame(480, 752, seed=21, shift=shift, noise_seed=77))
+    return ka, da, kb, db
+
+
+@pytest.mark.parametrize("ratio,orient", [(0.75, True), (0.6, True), (0.9, False)])
+def test_bow_tree_matchers_second_restatement(oracle, ratio, orient):
+    """Rule 19's bow_tree walk (common nodes in ascending id, first-come claims inside a node, the ratio test, the orientation histogram) for
+    both of its users, on two extracted frames with a synthetic vocabulary assignment and a node missing on one side."""
+    ka, da, kb, db = _two_extracted_frames(oracle, (3, 2))
+    for n_nodes in (120, 25):      # 25 nodes: long lists, many candidates per keypoint, more contested targets
+        fa, fb = synth.synth_bow(da, seed=1, n_nodes=n_nodes), synth.synth_bow(db, seed=1, n_nodes=n_nodes)
+        fb.pop(sorted(fb)[3])
+        rng = np.random.default_rng(2)
+        live_a, live_b = rng.random(len(ka)) < 0.85, rng.random(len(kb)) < 0.8
+        wn, want = oracle.bow_match_frame_and_keyframe(ka, da, fa, kb, db, fb, ratio, orient, live_a.astype(np.uint8))
+        gn, got = nv.bow_match_frame_and_keyframe(ka["angle"], da, fa, live_a, kb["angle"], db, fb, ratio, orient)
+        assert wn > 30 and gn == wn and np.array_equal(got, want)
+        wn, want = oracle.bow_match_keyframes(ka, da, fa, kb, db, fb, ratio, orient, live_a.astype(np.uint8), live_b.astype(np.uint8))
+        gn, got = nv.bow_match_keyframes(ka["angle"], da, fa, live_a, kb["angle"], db, fb, live_b, ratio, orient)
+        assert wn > 20 and gn == wn and np.array_equal(got, want)
