@@ -487,3 +487,150 @@ def bow_match_keyframes(ang_1, desc_1, fv_1, has_lm_1, ang_2, desc_2, fv_2, has_
     hit = np.nonzero(m21 >= 0)[0]
     m12[m21[hit]] = hit
     return len(hit), m12
+
+
+# ---- rule 23: match::robust::match_for_triangulation ----------------------------------------------------------------------------------------
+def robust_match_for_triangulation(ang_1, oct_1, desc_1, fv_1, bearings_1, has_lm_1, x_right_1, ang_2, desc_2, fv_2, bearings_2, has_lm_2, x_right_2,
+                                   E_12, epipole_in_2, scale_factors, check_orientation=True):
+    """(number of matches, matched_2_in_1): the bow_tree walk over keypoints WITHOUT a landmark on either side. A keyframe-2 keypoint is
+    eligible for keyframe-1 keypoint i iff it is free, its distance is <= 50, it is not within 3 degrees of the epipole (unless one of
+    the two is a stereo keypoint) and the pair passes check_epipolar_constraint; the scan keeps 'd <= best', so among the eligible ones
+    the smallest distance wins and the LAST of equals."""
+    F = np.float32
+    n1, n2 = len(ang_1), len(ang_2)
+    D = hamming_matrix(desc_1, desc_2)
+    b1, b2 = np.asarray(bearings_1, np.float64), np.asarray(bearings_2, np.float64)
+    E, ep = np.asarray(E_12, np.float64).reshape(3, 3), np.asarray(epipole_in_2, np.float64)
+    stereo_1 = np.zeros(n1, bool) if x_right_1 is None else np.asarray(x_right_1, F) >= 0
+    stereo_2 = np.zeros(n2, bool) if x_right_2 is None else np.asarray(x_right_2, F) >= 0
+    lm_1 = np.zeros(n1, bool) if has_lm_1 is None else np.asarray(has_lm_1, bool)
+    lm_2 = np.zeros(n2, bool) if has_lm_2 is None else np.asarray(has_lm_2, bool)
+    near_epipole = 0.99862953475 < (ep[0] * b2[:, 0] + ep[1] * b2[:, 1]) + ep[2] * b2[:, 2]
+    # epipolar planes of all keyframe-2 bearings, seen from keyframe 1: e = E_12 b_2 (rows left to right)
+    e = np.stack([(E[r, 0] * b2[:, 0] + E[r, 1] * b2[:, 1]) + E[r, 2] * b2[:, 2] for r in range(3)], 1)
+    e_norm = np.sqrt((e[:, 0] * e[:, 0] + e[:, 1] * e[:, 1]) + e[:, 2] * e[:, 2])
+    thr = 0.2 * np.pi / 180.0
+    free_2 = ~lm_2
+    m12 = np.full(n1, -1, np.int32)
+    deltas, owners = [], []
+    for node in sorted(set(fv_1) & set(fv_2)):
+        members_2 = np.asarray(fv_2[node], np.int64)
+        for i1 in fv_1[node]:
+            if lm_1[i1]:
+                continue
+            cand = members_2[free_2[members_2]]
+            cand = cand[D[i1, cand] <= 50]
+            if not stereo_1[i1]:
+                cand = cand[stereo_2[cand] | ~near_epipole[cand]]
+            if len(cand) == 0:
+                continue
+            with np.errstate(invalid="ignore"):
+                cos_res = ((e[cand, 0] * b1[i1, 0] + e[cand, 1] * b1[i1, 1]) + e[cand, 2] * b1[i1, 2]) / e_norm[cand]
+                residual = np.pi / 2.0 - np.abs(np.arccos(cos_res))        # (the sign is upstream's: a negative cosine always passes)
+            cand = cand[residual < thr * float(scale_factors[oct_1[i1]])]
+            if len(cand) == 0:
+                continue
+            d = D[i1, cand]
+            i2 = int(cand[np.nonzero(d == d.min())[0][-1]])
+            m12[i1], free_2[i2] = i2, False
+            deltas.append(F(ang_1[i1]) - F(ang_2[i2]))
+            owners.append(i1)
+    if check_orientation and deltas:
+        m12[np.asarray(owners)[angle_checker_invalid(np.asarray(deltas, F))]] = -1
+    return int((m12 >= 0).sum()), m12
+
+
+# ---- rules 21 (match_frame_and_keyframe) and 22 (fuse::replace_duplication): landmarks with a valid distance range ----------------------------
+def predict_scale_level(max_valid_dist, cam_to_lm_dist, log_scale_factor, n_levels):
+    """landmark::predict_scale_level: ceil(logf(max_valid_dist_ / dist) / log_scale_factor) in float, clamped to [0, n_levels - 1]."""
+    F = np.float32
+    with np.errstate(divide="ignore", invalid="ignore"):
+        lvl = np.ceil(np.log(F(max_valid_dist) / F(cam_to_lm_dist), dtype=F) / F(log_scale_factor))
+    return int(min(max(int(lvl), 0), n_levels - 1))
+
+
+def _in_valid_range(dist_min_max, dist):
+    """The getters' gate: (float)(0.7 * min_valid_dist_) <= dist <= (float)(1.3 * max_valid_dist_)."""
+    F = np.float32
+    return not (dist < float(F(0.7 * float(dist_min_max[0]))) or float(F(1.3 * float(dist_min_max[1]))) < dist)
+
+
+def projection_match_frame_and_keyframe(model, cam, cols, rows, xs, ys, octaves, angles, desc, pose_cw_curr, kf_angles, kf_pos_w, kf_dist_min_max,
+                                        kf_lm_desc, scale_factors, log_scale_factor, margin, hamm_dist_thr, check_orientation=True, occupied=None,
+                                        kf_valid=None):
+    """assigned[i] = current keypoint that receives the keyframe's landmark i (or -1): reprojection with the current pose, the landmark's
+    valid distance range, the predicted level's radius and the level window [pred - 1, pred + 1], free keypoints only (claims are
+    sequential), nearest descriptor if <= hamm_dist_thr, orientation histogram of (keyframe angle - current angle)."""
+    F = np.float32
+    T = np.asarray(pose_cw_curr, float)
+    centre = -T[:, :3].T @ T[:, 3]
+    ok, u, v, _ = reproject_to_image(model, cam, T, kf_pos_w, 0.0, 0.0, float(cols), float(rows))
+    occ = np.zeros(len(xs), bool) if occupied is None else np.asarray(occupied).astype(bool).copy()
+    D = hamming_matrix(kf_lm_desc, desc)
+    assigned = np.full(len(kf_pos_w), -1, np.int32)
+    deltas, owners = [], []
+    for i in range(len(kf_pos_w)):
+        if (kf_valid is not None and not kf_valid[i]) or not ok[i]:
+            continue
+        dist = float(np.linalg.norm(np.asarray(kf_pos_w[i], float) - centre))
+        if not _in_valid_range(kf_dist_min_max[i], dist):
+            continue
+        pred = predict_scale_level(kf_dist_min_max[i][1], dist, log_scale_factor, len(scale_factors))
+        cand = keypoints_in_cell(xs, ys, octaves, F(u[i]), F(v[i]), F(margin) * F(scale_factors[pred]), 0.0, 0.0, cols, rows, 64, 48, pred - 1, pred + 1)
+        cand = [k for k in cand if not occ[k]]
+        if not cand:
+            continue
+        d = D[i, cand]
+        best = int(np.argmin(d))
+        if d[best] > hamm_dist_thr:
+            continue
+        assigned[i] = cand[best]
+        occ[cand[best]] = True
+        deltas.append(F(kf_angles[i]) - F(angles[cand[best]]))
+        owners.append(i)
+    if check_orientation and deltas:
+        assigned[np.asarray(owners)[angle_checker_invalid(np.asarray(deltas, F))]] = -1
+    return assigned
+
+
+def fuse_replace_duplication(model, cam, cols, rows, xs, ys, octaves, desc, pose_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc, scale_factors,
+                             inv_level_sigma_sq, log_scale_factor, margin=3.0, x_right=None, lm_valid=None):
+    """best_idx[l] = the keyframe keypoint landmark l would be fused with (or -1). No claims: every landmark sees all keypoints."""
+    F = np.float32
+    T = np.asarray(pose_cw, float)
+    centre = -T[:, :3].T @ T[:, 3]
+    ok, u, v, xr_lm = reproject_to_image(model, cam, T, lm_pos_w, 0.0, 0.0, float(cols), float(rows))
+    D = hamming_matrix(lm_desc, desc)
+    xs64, ys64 = np.asarray(xs, F).astype(float), np.asarray(ys, F).astype(float)
+    best_idx = np.full(len(lm_pos_w), -1, np.int32)
+    for l in range(len(lm_pos_w)):
+        if (lm_valid is not None and not lm_valid[l]) or not ok[l]:
+            continue
+        ray = np.asarray(lm_pos_w[l], float) - centre
+        dist = float(np.linalg.norm(ray))
+        if not _in_valid_range(lm_dist_min_max[l], dist):
+            continue
+        if float(ray @ np.asarray(lm_normal[l], float)) < 0.5 * dist:
+            continue
+        pred = predict_scale_level(lm_dist_min_max[l][1], dist, log_scale_factor, len(scale_factors))
+        cand = np.asarray(keypoints_in_cell(xs, ys, octaves, F(u[l]), F(v[l]), F(margin) * F(scale_factors[pred]), 0.0, 0.0, cols, rows, 64, 48), np.int64)
+        if len(cand) == 0:
+            continue
+        lv = np.asarray(octaves)[cand]
+        cand = cand[(lv >= pred - 1) & (lv <= pred)]
+        ex, ey = u[l] - xs64[cand], v[l] - ys64[cand]
+        e2 = ex * ex + ey * ey
+        gate = np.full(len(cand), float(F(5.99146)))
+        if x_right is not None:
+            st = np.asarray(x_right, F)[cand] >= 0
+            er = (F(xr_lm[l]) - np.asarray(x_right, F)[cand]).astype(float)        # float - float, widened for the sum
+            e2 = np.where(st, e2 + er * er, e2)
+            gate = np.where(st, float(F(7.81473)), gate)
+        cand = cand[~(gate < e2 * np.asarray(inv_level_sigma_sq, F)[np.asarray(octaves)[cand]].astype(float))]
+        if len(cand) == 0:
+            continue
+        d = D[l, cand]
+        k = int(np.argmin(d))
+        if d[k] <= 50:
+            best_idx[l] = cand[k]
+    return best_idx

@@ -439,3 +439,139 @@ def test_bow_tree_matchers_second_restatement(oracle, ratio, orient):
         wn, want = oracle.bow_match_keyframes(ka, da, fa, kb, db, fb, ratio, orient, live_a.astype(np.uint8), live_b.astype(np.uint8))
         gn, got = nv.bow_match_keyframes(ka["angle"], da, fa, live_a, kb["angle"], db, fb, live_b, ratio, orient)
         assert wn > 20 and gn == wn and np.array_equal(got, want)
+
+
+def _rot(axis, deg):
+    a = np.asarray(axis, float) / np.linalg.norm(axis)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    t = np.deg2rad(deg)
+    return np.eye(3) + np.sin(t) * K + (1 - np.cos(t)) * (K @ K)
+
+
+@pytest.mark.parametrize("orient,stereo,forward", [(True, False, False), (False, True, False), (True, True, True), (True, False, True)])
+def test_triangulation_matcher_second_restatement(oracle, orient, stereo, forward):
+    """Rule 23: two keyframes seeing the same 1500 points (15 % moved off their epipolar line, a fifth with look-alike descriptors), keypoints
+    with landmarks excluded on both sides, the 3-degree epipole gate (forward motion puts the epipole inside the image) and its stereo
+    exemption, the one-sided epipolar residual, 'last of equal distances wins', the orientation histogram."""
+    rows, cols, n = 720, 1280, 1500
+    rng = np.random.default_rng(10 + forward)
+    fx = fy = 0.7 * cols
+    cx, cy = cols / 2.0, rows / 2.0
+    R2 = _rot((0, 1, 0), 0.5 if forward else 4.0) @ _rot((1, 0, 0), 1.5)
+    t2 = np.array([0.02, 0.01, 0.7]) if forward else np.array([-0.6, 0.05, 0.1])
+    X = np.stack([rng.uniform(-4, 4, n), rng.uniform(-2.5, 2.5, n), rng.uniform(4, 15, n)], 1)
+    P2 = X @ R2.T + t2
+    u1 = np.stack([fx * X[:, 0] / X[:, 2] + cx, fy * X[:, 1] / X[:, 2] + cy], 1)
+    u2 = np.stack([fx * P2[:, 0] / P2[:, 2] + cx, fy * P2[:, 1] / P2[:, 2] + cy], 1)
+    k1, d1 = synth.synth_keypoints(n, rows, cols, seed=31)
+    k2 = k1.copy()
+    k1["x"], k1["y"] = u1[:, 0], u1[:, 1]
+    k2["x"], k2["y"] = u2[:, 0] + rng.normal(0, 0.4, n), u2[:, 1] + rng.normal(0, 0.4, n)
+    off = rng.random(n) < 0.15
+    k2["y"][off] += rng.uniform(8, 40, int(off.sum()))
+    k2["angle"] = (k1["angle"] + np.where(rng.random(n) < 0.8, rng.normal(0, 4, n), rng.uniform(0, 360, n))) % 360
+    d2 = np.stack([synth.flip_bits(rng, d1[i], 45) for i in range(n)])
+    dup = rng.integers(0, n, n // 5)
+    d2[dup] = np.stack([synth.flip_bits(rng, d1[(i + 1) % n], 20) for i in dup])
+    perm = rng.permutation(n)
+    k2, d2 = k2[perm], d2[perm]
+
+    def bearings(k):
+        b = np.stack([(k["x"].astype(np.float64) - cx) / fx, (k["y"].astype(np.float64) - cy) / fy, np.ones(len(k))], 1)
+        return b / np.linalg.norm(b, axis=1)[:, None]
+
+    b1, b2 = bearings(k1), bearings(k2)
+    R12, t12 = R2.T, -R2.T @ t2                      # x1 = R12 x2 + t12
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    E12 = tx @ R12
+    epipole = t2 / np.linalg.norm(t2)                # keyframe 1's centre seen from keyframe 2
+    fv1, fv2 = synth.synth_bow(d1, seed=2, n_nodes=60), synth.synth_bow(d2, seed=2, n_nodes=60)
+    h1, h2 = (rng.random(n) < 0.3).astype(np.uint8), (rng.random(n) < 0.3).astype(np.uint8)
+    x1 = x2 = None
+    if stereo:
+        x1 = np.where(rng.random(n) < 0.4, k1["x"] - 10, -1.0).astype(np.float32)
+        x2 = np.where(rng.random(n) < 0.4, k2["x"] - 10, -1.0).astype(np.float32)
+    sf = np.cumprod(np.concatenate([[1.0], np.full(7, 1.2)]).astype(np.float32)).astype(np.float32)
+    wn, want = oracle.robust_match_for_triangulation(k1, d1, fv1, b1, k2, d2, fv2, b2, E12, epipole, sf, orient, h1, h2, x1, x2)
+    gn, got = nv.robust_match_for_triangulation(k1["angle"], k1["octave"], d1, fv1, b1, h1, x1, k2["angle"], d2, fv2, b2, h2, x2, E12, epipole, sf, orient)
+    assert wn > 100 and gn == wn and np.array_equal(got, want), (wn, gn, int((got != want).sum()))
+    if forward and not stereo:       # the epipole gate did remove candidates in this scene
+        near = (b2 @ epipole) > 0.99862953475
+        assert near.sum() > 5 and not near[want[want >= 0]].any()
+
+
+def _keyframe_and_landmarks(model, rows, cols, n, seed):
+    """A keyframe of n keypoints; landmarks = its keypoints back-projected at random depths (reprojecting onto them up to noise), a tenth
+    replaced by points anywhere; per landmark a valid distance range consistent with some level near the keypoint's, and a mean normal."""
+    rng = np.random.default_rng(seed)
+    ck, cd = synth.synth_keypoints(n, rows, cols, seed=seed)
+    R = _rot((0, 1, 0), 2.0) @ _rot((1, 0, 0), -1.0)
+    t = np.array([0.05, -0.02, 0.3])
+    T = np.concatenate([R, t[:, None]], 1)
+    fx = fy = 0.6 * cols
+    cx, cy = cols / 2.0, rows / 2.0
+    depth = rng.uniform(2.0, 20.0, n)
+    u, v = ck["x"].astype(float) + rng.normal(0, 1.5, n), ck["y"].astype(float) + rng.normal(0, 1.5, n)
+    if model == 0:
+        pc = np.stack([(u - cx) / fx * depth, (v - cy) / fy * depth, depth], 1)
+    else:
+        lon, lat = (u / cols - 0.5) * 2 * np.pi, -(v / rows - 0.5) * np.pi
+        pc = np.stack([np.cos(lat) * np.sin(lon), -np.sin(lat), np.cos(lat) * np.cos(lon)], 1) * depth[:, None]
+    pw = (pc - t) @ R
+    m = int(1.2 * n)
+    src = np.concatenate([rng.permutation(n), rng.integers(0, n, m - n)])
+    lk = ck[src].copy()
+    lk["angle"] = (lk["angle"] + np.where(rng.random(m) < 0.8, rng.normal(0, 5, m), rng.uniform(0, 360, m))) % 360
+    lpw = pw[src] + rng.normal(0, 0.002, (m, 3))
+    ld = np.stack([synth.flip_bits(rng, cd[i], 60) for i in src])
+    far = rng.random(m) < 0.1
+    lpw[far] = rng.uniform(-30, 30, (int(far.sum()), 3))
+    valid = (rng.random(m) < 0.9).astype(np.uint8)
+    ray = lpw - (-R.T @ t)
+    dist = np.linalg.norm(ray, axis=1)
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    lvl = np.clip(lk["octave"] + rng.integers(-1, 2, m), 0, 7)
+    dmax = (dist * sf[lvl] * rng.uniform(0.85, 1.0, m)).astype(np.float32)
+    dmin = (dmax / sf[7] * rng.uniform(0.5, 1.3, m)).astype(np.float32)
+    nrm = ray / dist[:, None]
+    flip = rng.random(m) < 0.15
+    nrm[flip] = rng.normal(0, 1, (int(flip.sum()), 3))
+    return ck, cd, T, lk, lpw, ld, valid, np.ascontiguousarray(np.stack([dmin, dmax], 1)), nrm, sf, (fx, fy, cx, cy)
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_frame_and_keyframe_projection_matcher_second_restatement(oracle, model):
+    """Rule 21's relocalisation matcher: the landmark's distance range through the float getters, predict_scale_level in float, the level window
+    around the prediction, sequential claims, the caller's Hamming threshold."""
+    rows, cols, n = (480, 960, 1500) if model == 1 else (480, 752, 1200)
+    ck, cd, T, lk, lpw, ld, valid, dmm, _, sf, (fx, fy, cx, cy) = _keyframe_and_landmarks(model, rows, cols, n, 60 + model)
+    occ = (np.random.default_rng(17).random(n) < 0.1).astype(np.uint8)
+    cam = oracle.Camera(model, 0, fx, fy, cx, cy, 0.0, 0.0, cols, rows)
+    gp = oracle.grid_params(cols, rows)
+    lsf = float(np.log(np.float32(1.2)))
+    camt = (fx, fy, cx, cy, 0.0) if model == 0 else (cols, rows)
+    for margin, thr, orient in ((10.0, 100, True), (20.0, 50, False)):
+        want, wn = oracle.projection_match_frame_and_keyframe(cam, gp, ck, cd, T, lk, lpw, dmm, ld, sf, lsf, margin, thr, orient, curr_occupied=occ,
+                                                              kf_valid=valid)
+        got = nv.projection_match_frame_and_keyframe(model, camt, cols, rows, ck["x"], ck["y"], ck["octave"], ck["angle"], cd, T, lk["angle"], lpw, dmm, ld,
+                                                     sf, lsf, margin, thr, orient, occ, valid)
+        assert wn > n // 20 and np.array_equal(got, want), (model, margin, int((got != want).sum()), wn)
+
+
+@pytest.mark.parametrize("model,setup", [(0, 0), (0, 1), (1, 0)])
+def test_fuse_candidate_search_second_restatement(oracle, model, setup):
+    """Rule 22: viewing-angle gate, every grid candidate of the predicted radius, levels [pred - 1, pred], the chi-square gate on the
+    reprojection error (three components for a stereo keypoint), best Hamming <= 50, no claims."""
+    rows, cols, n = (480, 960, 1500) if model == 1 else (480, 752, 1200)
+    ck, cd, T, lk, lpw, ld, valid, dmm, nrm, sf, (fx, fy, cx, cy) = _keyframe_and_landmarks(model, rows, cols, n, 40 + model + setup)
+    rng = np.random.default_rng(7)
+    ils = (1.0 / (sf * sf)).astype(np.float32)
+    cam = oracle.Camera(model, setup, fx, fy, cx, cy, 0.12 * fx, 0.12, cols, rows)
+    gp = oracle.grid_params(cols, rows)
+    lsf = float(np.log(np.float32(1.2)))
+    xr = np.where(rng.random(n) < 0.6, ck["x"] - 0.12 * fx / rng.uniform(2, 20, n), -1.0).astype(np.float32) if setup else None
+    camt = (fx, fy, cx, cy, 0.12 * fx) if model == 0 else (cols, rows)
+    for margin in (3.0, 8.0):
+        want, wn = oracle.fuse_replace_duplication(cam, gp, ck, cd, T, lpw, dmm, nrm, ld, sf, ils, lsf, margin, kf_stereo_x_right=xr, lm_valid=valid)
+        got = nv.fuse_replace_duplication(model, camt, cols, rows, ck["x"], ck["y"], ck["octave"], cd, T, lpw, dmm, nrm, ld, sf, ils, lsf, margin, xr, valid)
+        assert wn > n // 40 and np.array_equal(got, want), (model, setup, margin, int((got != want).sum()), wn, int((got >= 0).sum()))
