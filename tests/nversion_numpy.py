@@ -634,3 +634,72 @@ def fuse_replace_duplication(model, cam, cols, rows, xs, ys, octaves, desc, pose
         if d[k] <= 50:
             best_idx[l] = cand[k]
     return best_idx
+
+
+# ---- rule 20: match::stereo::compute ----------------------------------------------------------------------------------------------------------
+def stereo_compute(pyr_left, pyr_right, kps_left, desc_left, kps_right, desc_right, scale_factors, inv_scale_factors, focal_x_baseline,
+                   true_baseline, outlier_factor=2.0):
+    """(stereo_x_right, depths) per left keypoint (-1 where there is none). pyr_* = the extractors' level images (lists of uint8 arrays);
+    keypoints as structured arrays with x, y, octave."""
+    F = np.float32
+    nl = len(kps_left)
+    rows0 = pyr_left[0].shape[0]
+    xr_out, depth_out = np.full(nl, -1.0, F), np.full(nl, -1.0, F)
+    if nl == 0 or len(kps_right) == 0:
+        return xr_out, depth_out
+    D = hamming_matrix(desc_left, desc_right)
+    sf, isf = np.asarray(scale_factors, F), np.asarray(inv_scale_factors, F)
+    xr_all, yr, oct_r = np.asarray(kps_right["x"], F), np.asarray(kps_right["y"], F), np.asarray(kps_right["octave"])
+    # the right keypoints of every image row: those whose band y +- 2 * scale covers it, in keypoint order
+    band = F(2.0) * sf[oct_r]
+    row_lo = np.maximum(np.floor(yr - band).astype(np.int64), 0)
+    row_hi = np.minimum(np.ceil(yr + band).astype(np.int64), rows0 - 1)
+    max_disp = F(focal_x_baseline) / F(true_baseline)
+    accepted = []                                             # (L1 distance, left keypoint)
+    for i in range(nl):
+        x_l, y_l, lvl = F(kps_left["x"][i]), F(kps_left["y"][i]), int(kps_left["octave"][i])
+        row = int(y_l)
+        cand = np.nonzero((row_lo <= row) & (row <= row_hi))[0]
+        cand = cand[np.abs(oct_r[cand] - lvl) <= 1]
+        cand = cand[(xr_all[cand] >= x_l - max_disp) & (xr_all[cand] <= x_l)]
+        if len(cand) == 0 or x_l < 0:
+            continue
+        d = D[i, cand]
+        b = int(np.argmin(d))
+        if d[b] >= 75:
+            continue
+        # sub-pixel: slide an 11 x 11 window (centre value removed) over the right level image, shifts -5 .. +5
+        s = isf[lvl]
+        cx_l, cy_l, cx_r = int(np.rint(x_l * s)), int(np.rint(y_l * s)), int(np.rint(xr_all[cand[b]] * s))
+        img_l, img_r = pyr_left[lvl], pyr_right[lvl]
+        if not (0 <= cx_r - 10 and cx_r + 11 < img_r.shape[1]):
+            continue
+        win_l = img_l[cy_l - 5:cy_l + 6, cx_l - 5:cx_l + 6].astype(F)
+        win_l = win_l - win_l[5, 5]
+        cost = np.empty(11, F)
+        for k, shift in enumerate(range(-5, 6)):
+            win_r = img_r[cy_l - 5:cy_l + 6, cx_r + shift - 5:cx_r + shift + 6].astype(F)
+            cost[k] = np.abs(win_l - (win_r - win_r[5, 5])).sum(dtype=np.float64)      # integers < 2^24: exact in any order
+        k = int(np.argmin(cost))
+        if k == 0 or k == 10:
+            continue
+        c1, c2, c3 = cost[k - 1], cost[k], cost[k + 1]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            delta = (c1 - c3) / (F(2.0) * (c1 + c3 - F(2.0) * c2))
+        if delta < -1 or 1 < delta:
+            continue
+        x_r = sf[lvl] * (F(cx_r) + F(k - 5) + delta)
+        disp = x_l - x_r
+        if not (0 <= disp < max_disp):
+            continue
+        if disp <= 0:
+            disp, x_r = F(0.01), x_l - F(0.01)
+        xr_out[i], depth_out[i] = x_r, F(focal_x_baseline) / disp
+        accepted.append((float(c2), i))
+    if accepted:
+        dists = sorted(a[0] for a in accepted)
+        median = dists[len(dists) // 2]
+        for c, i in accepted:
+            if F(outlier_factor) * F(median) < F(c):
+                xr_out[i] = depth_out[i] = -1.0
+    return xr_out, depth_out

@@ -575,3 +575,22 @@ def test_fuse_candidate_search_second_restatement(oracle, model, setup):
         want, wn = oracle.fuse_replace_duplication(cam, gp, ck, cd, T, lpw, dmm, nrm, ld, sf, ils, lsf, margin, kf_stereo_x_right=xr, lm_valid=valid)
         got = nv.fuse_replace_duplication(model, camt, cols, rows, ck["x"], ck["y"], ck["octave"], cd, T, lpw, dmm, nrm, ld, sf, ils, lsf, margin, xr, valid)
         assert wn > n // 40 and np.array_equal(got, want), (model, setup, margin, int((got != want).sum()), wn, int((got >= 0).sum()))
+
+
+@pytest.mark.parametrize("rows,cols,nfeat,seed", [(240, 400, 500, 3), (376, 620, 1000, 1)])
+def test_stereo_matcher_second_restatement(oracle, rows, cols, nfeat, seed):
+    """Rule 20: row bands, the octave and disparity gates, Hamming < 75, the 11 x 11 centred-window L1 search on the keypoint's pyramid level, the float
+    parabola, the disparity range and the median outlier rule -- stereo_x_right and depth equal to the C oracle bit for bit, for the default
+    factor 2.0 and the 2.1 variant."""
+    left, right, _ = synth.synth_stereo_pair(rows, cols, seed=seed)
+    oxl, oxr = oracle.OrbExtractor(oracle.make_params(nfeat)), oracle.OrbExtractor(oracle.make_params(nfeat))
+    kl, dl = oxl.extract(left)
+    kr, dr = oxr.extract(right)
+    tabs = oracle.orb_tables(oxl.params)
+    n_levels = oxl.params.num_levels
+    pyr_l, pyr_r = [oxl.level_image(l) for l in range(n_levels)], [oxr.level_image(l) for l in range(n_levels)]
+    for f21 in (False, True):
+        wx, wd, wn = oracle.stereo_compute(oxl, oxr, kl, dl, kr, dr, 386.1448, 0.5372, outlier_factor_21=f21)
+        gx, gd = nv.stereo_compute(pyr_l, pyr_r, kl, dl, kr, dr, tabs["scale_factors"], tabs["inv_scale_factors"], 386.1448, 0.5372, 2.1 if f21 else 2.0)
+        assert wn > nfeat // 10 and np.array_equal(gx >= 0, wx >= 0), (int(((gx >= 0) != (wx >= 0)).sum()), wn)
+        assert np.array_equal(gx.view(np.uint32), wx.view(np.uint32)) and np.array_equal(gd.view(np.uint32), wd.view(np.uint32))
