@@ -703,3 +703,107 @@ def stereo_compute(pyr_left, pyr_right, kps_left, desc_left, kps_right, desc_rig
             if F(outlier_factor) * F(median) < F(c):
                 xr_out[i] = depth_out[i] = -1.0
     return xr_out, depth_out
+
+
+# ---- rule 27: the loop closer's matchers -------------------------------------------------------------------------------------------------------
+def _sim3_to_pose(sim3_cw):
+    """[sR | t'] -> (R | t'/s) with s = the length of sR's first row."""
+    S = np.asarray(sim3_cw, float)
+    s = np.sqrt(S[0, :3] @ S[0, :3])
+    return np.concatenate([S[:, :3] / s, (S[:, 3] / s)[:, None]], 1)
+
+
+def _sim3_candidates(model, cam, cols, rows, xs, ys, octaves, T, pos_w, dist_min_max, normal, scale_factors, log_scale_factor, margin, valid):
+    """Per landmark that passes rule 22's gates under pose T: (landmark, candidate keypoints of levels [pred - 1, pred] inside the radius)."""
+    F = np.float32
+    centre = -T[:, :3].T @ T[:, 3]
+    ok, u, v, _ = reproject_to_image(model, cam, T, pos_w, 0.0, 0.0, float(cols), float(rows))
+    for l in range(len(pos_w)):
+        if (valid is not None and not valid[l]) or not ok[l]:
+            continue
+        ray = np.asarray(pos_w[l], float) - centre
+        dist = float(np.linalg.norm(ray))
+        if not _in_valid_range(dist_min_max[l], dist) or float(ray @ np.asarray(normal[l], float)) < 0.5 * dist:
+            continue
+        pred = predict_scale_level(dist_min_max[l][1], dist, log_scale_factor, len(scale_factors))
+        cand = np.asarray(keypoints_in_cell(xs, ys, octaves, F(u[l]), F(v[l]), F(margin) * F(scale_factors[pred]), 0.0, 0.0, cols, rows, 64, 48), np.int64)
+        if len(cand):
+            lv = np.asarray(octaves)[cand]
+            cand = cand[(lv >= pred - 1) & (lv <= pred)]
+        yield l, cand
+
+
+def fuse_detect_duplication(model, cam, cols, rows, xs, ys, octaves, desc, sim3_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc, scale_factors,
+                            log_scale_factor, margin, lm_valid=None):
+    """best_idx[l]: rule 22 without the chi-square gate, under the pose recovered from the Sim3; no claims."""
+    D = hamming_matrix(lm_desc, desc)
+    best_idx = np.full(len(lm_pos_w), -1, np.int32)
+    for l, cand in _sim3_candidates(model, cam, cols, rows, xs, ys, octaves, _sim3_to_pose(sim3_cw), lm_pos_w, lm_dist_min_max, lm_normal, scale_factors,
+                                    log_scale_factor, margin, lm_valid):
+        if len(cand):
+            k = int(np.argmin(D[l, cand]))
+            if D[l, cand[k]] <= 50:
+                best_idx[l] = cand[k]
+    return best_idx
+
+
+def projection_match_by_sim3_transform(model, cam, cols, rows, xs, ys, octaves, desc, sim3_cw, lm_pos_w, lm_dist_min_max, lm_normal, lm_desc,
+                                       scale_factors, log_scale_factor, margin, occupied=None, lm_valid=None):
+    """assigned[l]: the same gates; a keypoint holding a match (given, or made earlier in this call) is not a candidate; best <= 50."""
+    D = hamming_matrix(lm_desc, desc)
+    occ = np.zeros(len(xs), bool) if occupied is None else np.asarray(occupied).astype(bool).copy()
+    assigned = np.full(len(lm_pos_w), -1, np.int32)
+    for l, cand in _sim3_candidates(model, cam, cols, rows, xs, ys, octaves, _sim3_to_pose(sim3_cw), lm_pos_w, lm_dist_min_max, lm_normal, scale_factors,
+                                    log_scale_factor, margin, lm_valid):
+        cand = cand[~occ[cand]] if len(cand) else cand
+        if len(cand):
+            k = int(np.argmin(D[l, cand]))
+            if D[l, cand[k]] <= 50:
+                assigned[l] = cand[k]
+                occ[cand[k]] = True
+    return assigned
+
+
+def projection_match_keyframes_mutually(cam, cols, rows, kps_1, desc_1, pose_cw_1, lm_pos_w_1, lm_dist_1, lm_desc_1, lm_valid_1, kps_2, desc_2, pose_cw_2,
+                                        lm_pos_w_2, lm_dist_2, lm_desc_2, lm_valid_2, s_12, rot_12, trans_12, scale_factors, log_scale_factor, margin):
+    """(number of pairs, matched_2_in_1): each keyframe's landmarks moved into the other keyframe's camera by Sim3_12 resp. its inverse
+    (perspective cameras), nearest descriptor (<= 100) among the keypoints of levels [pred - 1, pred] within the radius, no claims; a pair
+    stays iff both directions choose each other."""
+    F = np.float32
+    fx, fy, cx, cy = cam
+    R12, t12 = np.asarray(rot_12, float).reshape(3, 3), np.asarray(trans_12, float)
+
+    def one_way(T_from, pos_w, dist_mm, lm_desc, valid, A, b, kps_to, desc_to):
+        D = hamming_matrix(lm_desc, desc_to)
+        p = (np.asarray(pos_w, float) @ T_from[:, :3].T + T_from[:, 3]) @ A.T + b
+        pick = np.full(len(pos_w), -1, np.int64)
+        for l in range(len(pos_w)):
+            x, y, z = p[l]
+            if (valid is not None and not valid[l]) or z <= 0:
+                continue
+            u, v = fx * x / z + cx, fy * y / z + cy
+            if not (0.0 <= u <= cols and 0.0 <= v <= rows):
+                continue
+            dist = float(np.sqrt(x * x + y * y + z * z))
+            if not _in_valid_range(dist_mm[l], dist):
+                continue
+            pred = predict_scale_level(dist_mm[l][1], dist, log_scale_factor, len(scale_factors))
+            cand = np.asarray(keypoints_in_cell(kps_to["x"], kps_to["y"], kps_to["octave"], F(u), F(v), F(margin) * F(scale_factors[pred]), 0.0, 0.0, cols,
+                                                rows, 64, 48), np.int64)
+            if len(cand):
+                lv = kps_to["octave"][cand]
+                cand = cand[(lv >= pred - 1) & (lv <= pred)]
+            if len(cand):
+                k = int(np.argmin(D[l, cand]))
+                if D[l, cand[k]] <= 100:
+                    pick[l] = cand[k]
+        return pick
+
+    A21 = R12.T / s_12
+    in_2 = one_way(np.asarray(pose_cw_1, float), lm_pos_w_1, lm_dist_1, lm_desc_1, lm_valid_1, A21, -A21 @ t12, kps_2, desc_2)
+    in_1 = one_way(np.asarray(pose_cw_2, float), lm_pos_w_2, lm_dist_2, lm_desc_2, lm_valid_2, s_12 * R12, t12, kps_1, desc_1)
+    out = np.full(len(kps_1), -1, np.int32)
+    for i1, i2 in enumerate(in_2):
+        if i2 >= 0 and in_1[i2] == i1:
+            out[i1] = i2
+    return int((out >= 0).sum()), out

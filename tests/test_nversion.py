@@ -594,3 +594,78 @@ def test_stereo_matcher_second_restatement(oracle, rows, cols, nfeat, seed):
         gx, gd = nv.stereo_compute(pyr_l, pyr_r, kl, dl, kr, dr, tabs["scale_factors"], tabs["inv_scale_factors"], 386.1448, 0.5372, 2.1 if f21 else 2.0)
         assert wn > nfeat // 10 and np.array_equal(gx >= 0, wx >= 0), (int(((gx >= 0) != (wx >= 0)).sum()), wn)
         assert np.array_equal(gx.view(np.uint32), wx.view(np.uint32)) and np.array_equal(gd.view(np.uint32), wd.view(np.uint32))
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_sim3_matchers_second_restatement(oracle, model):
+    """Rule 27: the pose recovered from [sR | st], then fuse::detect_duplication (no chi-square gate, no claims) and
+    projection::match_by_Sim3_transform (claims in landmark order, pre-occupied keypoints; a third of the landmarks duplicated so that claims decide)."""
+    rows, cols, n = (480, 960, 1500) if model == 1 else (480, 752, 1200)
+    ck, cd, T, lk, lpw, ld, valid, dmm, nrm, sf, (fx, fy, cx, cy) = _keyframe_and_landmarks(model, rows, cols, n, 80 + model)
+    cam = oracle.Camera(model, 0, fx, fy, cx, cy, 0.0, 0.0, cols, rows)
+    gp = oracle.grid_params(cols, rows)
+    lsf = float(np.log(np.float32(1.2)))
+    camt = (fx, fy, cx, cy, 0.0) if model == 0 else (cols, rows)
+    rng = np.random.default_rng(5)
+    extra = rng.integers(0, len(lpw), len(lpw) // 3)
+    lpw2 = np.concatenate([lpw, lpw[extra] + rng.normal(0, 0.002, (len(extra), 3))])
+    dmm2, nrm2, valid2 = np.concatenate([dmm, dmm[extra]]), np.concatenate([nrm, nrm[extra]]), np.concatenate([valid, valid[extra]])
+    ld2 = np.concatenate([ld, np.stack([synth.flip_bits(rng, ld[i], 6) for i in extra])])
+    occ = (rng.random(n) < 0.1).astype(np.uint8)
+    for scale, margin in ((1.7, 4.0), (0.6, 10.0)):
+        S = np.concatenate([scale * T[:, :3], scale * T[:, 3:]], 1)
+        want, wn = oracle.fuse_detect_duplication(cam, gp, ck, cd, S, lpw, dmm, nrm, ld, sf, lsf, margin, lm_valid=valid)
+        got = nv.fuse_detect_duplication(model, camt, cols, rows, ck["x"], ck["y"], ck["octave"], cd, S, lpw, dmm, nrm, ld, sf, lsf, margin, valid)
+        assert wn > n // 20 and np.array_equal(got, want), ("detect", model, scale, int((got != want).sum()))
+        want, wn = oracle.projection_match_by_sim3_transform(cam, gp, ck, cd, S, lpw2, dmm2, nrm2, ld2, sf, lsf, margin, kf_occupied=occ, lm_valid=valid2)
+        got = nv.projection_match_by_sim3_transform(model, camt, cols, rows, ck["x"], ck["y"], ck["octave"], cd, S, lpw2, dmm2, nrm2, ld2, sf, lsf, margin, occ,
+                                                    valid2)
+        assert wn > n // 20 and np.array_equal(got, want), ("by_sim3", model, scale, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("s_12", [1.0, 1.35])
+def test_mutual_sim3_matcher_second_restatement(oracle, s_12):
+    """Rule 27's projection::match_keyframes_mutually: two keyframes of the same 1500 points, keyframe 2's map s_12 times smaller; both directions
+    through Sim3_12 and its inverse, agreement of the two picks."""
+    rows, cols, n = 720, 1280, 1500
+    rng = np.random.default_rng(22)
+    fx = fy = 0.7 * cols
+    cx, cy = cols / 2.0, rows / 2.0
+    R1, t1 = np.eye(3), np.zeros(3)
+    R2, t2 = _rot((0, 1, 0), 4.0) @ _rot((1, 0, 0), 1.5), np.array([-0.6, 0.05, 0.1])
+    X = np.stack([rng.uniform(-4, 4, n), rng.uniform(-2.5, 2.5, n), rng.uniform(4, 15, n)], 1)
+    p1, p2 = X @ R1.T + t1, X @ R2.T + t2
+    k1, d1 = synth.synth_keypoints(n, rows, cols, seed=33)
+    k2 = k1.copy()
+    k1["x"], k1["y"] = fx * p1[:, 0] / p1[:, 2] + cx + rng.normal(0, 0.5, n), fy * p1[:, 1] / p1[:, 2] + cy + rng.normal(0, 0.5, n)
+    k2["x"], k2["y"] = fx * p2[:, 0] / p2[:, 2] + cx + rng.normal(0, 0.5, n), fy * p2[:, 1] / p2[:, 2] + cy + rng.normal(0, 0.5, n)
+    k2["octave"] = np.clip(k1["octave"] + rng.integers(-1, 2, n), 0, 7)
+    d2 = np.stack([synth.flip_bits(rng, d1[i], 40) for i in range(n)])
+    dup = rng.integers(0, n, n // 6)
+    d2[dup] = np.stack([synth.flip_bits(rng, d1[(i + 7) % n], 25) for i in dup])
+    perm = rng.permutation(n)
+    k2, d2, X2, p2 = k2[perm], d2[perm], X[perm] / s_12, p2[perm]
+    T1 = np.concatenate([R1, t1[:, None]], 1)
+    T2 = np.concatenate([R2, (t2 / s_12)[:, None]], 1)
+    R12, t12 = R1 @ R2.T, t1 - R1 @ R2.T @ t2
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    inv = np.argsort(perm)
+
+    def ranges(dist, octave):
+        lvl = np.clip(octave + rng.integers(0, 2, n), 0, 7)
+        dmax = (dist * sf[lvl] * rng.uniform(0.85, 1.0, n)).astype(np.float32)
+        return np.ascontiguousarray(np.stack([(dmax / sf[7] * rng.uniform(0.5, 1.3, n)).astype(np.float32), dmax], 1))
+
+    dm1 = ranges(np.linalg.norm(p2[inv], axis=1) / s_12, k2["octave"][inv])
+    dm2 = ranges(np.linalg.norm(p1[perm], axis=1), k1["octave"][perm])
+    l1 = np.stack([synth.flip_bits(rng, d1[i], 10) for i in range(n)])
+    l2 = np.stack([synth.flip_bits(rng, d2[i], 10) for i in range(n)])
+    v1, v2 = (rng.random(n) < 0.85).astype(np.uint8), (rng.random(n) < 0.85).astype(np.uint8)
+    cam = oracle.Camera(0, 0, fx, fy, cx, cy, 0.0, 0.0, cols, rows)
+    gp = oracle.grid_params(cols, rows)
+    lsf = float(np.log(np.float32(1.2)))
+    for margin in (7.5, 15.0):
+        wn, want = oracle.projection_match_keyframes_mutually(cam, gp, k1, d1, T1, X, dm1, l1, v1, k2, d2, T2, X2, dm2, l2, v2, s_12, R12, t12, sf, lsf, margin)
+        gn, got = nv.projection_match_keyframes_mutually((fx, fy, cx, cy), cols, rows, k1, d1, T1, X, dm1, l1, v1, k2, d2, T2, X2, dm2, l2, v2, s_12, R12, t12,
+                                                         sf, lsf, margin)
+        assert wn > n // 5 and gn == wn and np.array_equal(got, want), (s_12, margin, wn, gn, int((got != want).sum()))
