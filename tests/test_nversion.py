@@ -669,3 +669,38 @@ def test_mutual_sim3_matcher_second_restatement(oracle, s_12):
         gn, got = nv.projection_match_keyframes_mutually((fx, fy, cx, cy), cols, rows, k1, d1, T1, X, dm1, l1, v1, k2, d2, T2, X2, dm2, l2, v2, s_12, R12, t12,
                                                          sf, lsf, margin)
         assert wn > n // 5 and gn == wn and np.array_equal(got, want), (s_12, margin, wn, gn, int((got != want).sum()))
+
+
+def test_whole_extractor_in_numpy_reproduces_the_golden_vectors(oracle):
+    """orb_extractor::extract as one numpy pipeline (tests/nversion_extract.py: tables, pyramid, cell loop + FAST, closed-form quad-tree,
+    orientation, blur, rBRIEF, scaling) with no oracle C code in it: the committed golden files come out of it byte for byte -- all seven
+    keypoint fields and the descriptors of 1008 + 1002 + the small frame's keypoints, and the per-level candidate counts."""
+    import nversion_extract as nx
+    pat = oracle.orb_pattern()          # (the 256 x 4 table is data, shared with the product through orb_pattern.inc)
+    g = np.load(os.path.join(GOLDEN, "orb_752x480_seed0.npz"))
+    for key, img in (("a", synth.synth_frame(480, 752, seed=0)), ("b", synth.synth_frame(480, 752, seed=0, shift=(5, 0), noise_seed=4242))):
+        k, d, n_cand = nx.extract(img, pat, 1000)
+        want = g["kps_" + key]
+        assert len(k) == len(want) and k.tobytes() == np.ascontiguousarray(want).tobytes() and np.array_equal(d, g["desc_" + key]), key
+        if key == "a":
+            assert np.array_equal(n_cand, g["n_cand"])
+    g2 = np.load(os.path.join(GOLDEN, "orb_331x203_seed5.npz"))
+    k, d, _ = nx.extract(synth.synth_frame(203, 331, seed=5), pat, 300)
+    assert k.tobytes() == np.ascontiguousarray(g2["kps"]).tobytes() and np.array_equal(d, g2["desc"])
+
+
+@pytest.mark.parametrize("rows,cols,nfeat,scale,levels,seed", [(480, 640, 2000, 1.2, 8, 2), (500, 300, 700, 1.2, 8, 4), (97, 131, 200, 1.2, 8, 3),
+                                                              (360, 480, 1500, 1.1, 12, 6), (240, 320, 400, 1.5, 4, 7), (45, 60, 50, 1.2, 8, 8)])
+def test_whole_extractor_in_numpy_equals_the_oracle(oracle, rows, cols, nfeat, scale, levels, seed):
+    """The same pipeline against the C oracle beyond the golden inputs: portrait and tiny frames (levels that end up without a cell), other scale
+    factors / level counts / budgets (over- and under-subscribed levels), also with a low-contrast frame that makes cells fall back to min_fast_thr."""
+    import nversion_extract as nx
+    pat = oracle.orb_pattern()
+    img = synth.synth_frame(rows, cols, seed=seed)
+    flat = (100 + (img.astype(np.int32) - 128) // 6).astype(np.uint8)         # contrast / 6: most cells need the low threshold
+    for im in (img, flat):
+        p = oracle.make_params(nfeat)
+        p.scale_factor, p.num_levels = scale, levels
+        wk, wd = oracle.OrbExtractor(p).extract(im)
+        k, d, _ = nx.extract(im, pat, nfeat, scale, levels)
+        assert len(k) == len(wk) and k.tobytes() == np.ascontiguousarray(wk).tobytes() and np.array_equal(d, wd), (len(k), len(wk))
