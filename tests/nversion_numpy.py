@@ -807,3 +807,34 @@ def projection_match_keyframes_mutually(cam, cols, rows, kps_1, desc_1, pose_cw_
         if i2 >= 0 and in_1[i2] == i1:
             out[i1] = i2
     return int((out >= 0).sum()), out
+
+
+# ---- rule 29: DBoW2 TemplatedVocabulary::transform ---------------------------------------------------------------------------------------------
+def bow_transform(vocab, desc, levelsup=4):
+    """(word id, weight, node id at `levelsup` levels above the words) of every descriptor: all features descend together, level by level, each
+    to its nearest child (first of equals in child order); a feature stops at a leaf. vocab = dict(child_start, children, desc, weight,
+    word_id, depth)."""
+    cs, ch = np.asarray(vocab["child_start"], np.int64), np.asarray(vocab["children"], np.int64)
+    bits_nodes = np.unpackbits(np.asarray(vocab["desc"], np.uint8), axis=1).astype(np.int32)
+    bits = np.unpackbits(np.asarray(desc, np.uint8).reshape(-1, 32), axis=1).astype(np.int32)
+    n, depth = len(bits), int(vocab["depth"])
+    cur = np.zeros(n, np.int64)
+    node_at = np.zeros(n, np.int64)                     # the root, unless the descent passes level depth - levelsup
+    level = 0
+    while True:
+        if level == depth - levelsup:
+            node_at = cur.copy()
+        n_kids = cs[cur + 1] - cs[cur]
+        moving = np.nonzero(n_kids > 0)[0]
+        if len(moving) == 0:
+            break
+        width = int(n_kids[moving].max())
+        slot = np.arange(width)[None, :]
+        kid = ch[np.minimum(cs[cur[moving]][:, None] + slot, len(ch) - 1)]                                   # (m, width), ragged tails masked below
+        dist = (bits[moving][:, None, :] != bits_nodes[kid]).sum(2)
+        dist = np.where(slot < n_kids[moving][:, None], dist, 1 << 20)
+        cur[moving] = kid[np.arange(len(moving)), np.argmin(dist, axis=1)]
+        level += 1
+    if levelsup <= 0:
+        node_at = cur.copy()
+    return np.asarray(vocab["word_id"])[cur].astype(np.int32), np.asarray(vocab["weight"], np.float64)[cur], node_at.astype(np.int32)

@@ -704,3 +704,19 @@ def test_whole_extractor_in_numpy_equals_the_oracle(oracle, rows, cols, nfeat, s
         wk, wd = oracle.OrbExtractor(p).extract(im)
         k, d, _ = nx.extract(im, pat, nfeat, scale, levels)
         assert len(k) == len(wk) and k.tobytes() == np.ascontiguousarray(wk).tobytes() and np.array_equal(d, wd), (len(k), len(wk))
+
+
+@pytest.mark.parametrize("k,depth", [(10, 4), (6, 3), (3, 6)])
+def test_bow_transform_second_restatement(oracle, k, depth):
+    """Rule 29 (DBoW2 transform): the level-synchronous numpy descent (bit-vector distances, first minimum in child order, ragged last level,
+    zero-weight words) equals the oracle's per-feature loop for every levelsup, on descriptors near the words and on random ones."""
+    vocab = synth.synth_vocabulary(k, depth, seed=k + depth)
+    rng = np.random.default_rng(9)
+    leaves = np.nonzero(vocab["word_id"] >= 0)[0]
+    near = np.stack([synth.flip_bits(rng, vocab["desc"][i], 30) for i in rng.choice(leaves, 600)])
+    desc = np.concatenate([near, rng.integers(0, 256, (200, 32), dtype=np.uint8), vocab["desc"][leaves[:50]]])
+    for levelsup in range(0, depth + 2):
+        w, wt, nd = oracle.bow_transform(vocab, desc, levelsup)
+        gw, gwt, gnd = nv.bow_transform(vocab, desc, levelsup)
+        assert np.array_equal(gw, w) and np.array_equal(gwt, wt) and np.array_equal(gnd, nd), (k, depth, levelsup)
+    assert (w >= 0).all() and len(np.unique(w)) > 100 or k == 3
