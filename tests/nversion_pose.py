@@ -169,14 +169,14 @@ def _quat_rot(q):
                      np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)], 1)
 
 
-def ba_linearize(poses, pose_fixed, points, edges, cam, huber_delta, bf=None, equirect=False):
+def ba_linearize(poses, pose_fixed, points, edges, cam, huber_delta, bf=None, equirect=False, rot=None):
     """Hpp (n_pose, 6, 6), bp, Hll (n_pt, 3, 3), bl, Hpl (n_edge, 6, 3), chi2 (plain, robust) of one set of edges: e = z - pi(R X + t),
     J_point = -(d pi / d p) R, J_pose = -(d pi / d p) (-[p]x | I), Huber on chi2 = w e.e with the second-derivative term dropped,
     b = -J^T W e; fixed keyframes get no pose blocks (their edges still feed the landmark blocks). bf: stereo edges (third residual
     u_right = u - bf / z); equirect: cam = (cols, rows, -, -), the projection of rule 26."""
     poses = np.asarray(poses, float).reshape(-1, 7)
     points = np.asarray(points, float).reshape(-1, 3)
-    R_all = _quat_rot(poses[:, 3:])
+    R_all = _quat_rot(poses[:, 3:]) if rot is None else np.asarray(rot, float)      # rot: rotation matrices given directly (local BA's state)
     k, j = edges["pose_idx"], edges["point_idx"]
     R = R_all[k]
     p = np.einsum("nab,nb->na", R, points[j]) + poses[k, :3]
@@ -230,3 +230,150 @@ def ba_linearize(poses, pose_fixed, points, edges, cam, huber_delta, bf=None, eq
     out["Hpl"] = np.where(fe[:, None, None], W[:, None, None] * np.einsum("nra,nrb->nab", Jp, Jl), 0.0)
     out["chi2"] = np.array([c2.sum(), rho0.sum()])
     return out
+
+
+# ---- rule 28: optimize::local_bundle_adjuster::optimize behind the graph build ---------------------------------------------------------------
+def _edge_chi2_depth(R, t, X, edges, cam, bf=None, equirect=False):
+    """(chi2, depth_is_positive) of every edge at one state."""
+    p = np.einsum("nab,nb->na", R[edges["pose_idx"]], X[edges["point_idx"]]) + t[edges["pose_idx"]]
+    if equirect:
+        cols, rows = cam[0], cam[1]
+        L = np.sqrt((p * p).sum(1))
+        ss = (edges["obs_x"] - cols * (0.5 + np.arctan2(p[:, 0], p[:, 2]) / (2 * np.pi))) ** 2 + \
+             (edges["obs_y"] - rows * (0.5 + np.arcsin(p[:, 1] / L) / np.pi)) ** 2
+        return edges["inv_sigma_sq"] * ss, np.ones(len(p), bool)
+    fx, fy, cx, cy = cam
+    u = fx * p[:, 0] / p[:, 2] + cx
+    ss = (edges["obs_x"] - u) ** 2 + (edges["obs_y"] - (fy * p[:, 1] / p[:, 2] + cy)) ** 2
+    if bf is not None:
+        ss = ss + (edges["obs_x_right"] - (u - bf / p[:, 2])) ** 2
+    return edges["inv_sigma_sq"] * ss, p[:, 2] > 0
+
+
+def local_ba_optimize(poses, pose_fixed, points, mono, cam, stereo=None, bf=0.0, num_first_iter=5, num_second_iter=10, setup_type=None, equirect=False):
+    """The two rounds of rule 28 WITHOUT the elimination of the landmarks: every trial solves the whole damped system over (free keyframes,
+    landmarks with an active edge) with LAPACK -- mathematically the same step as the Schur form the oracle and the library take.
+    Returns dict(R, t, points, mono_outlier, stereo_outlier, info = (chi2 at the start / end of round 1, of round 2, iterations of each))."""
+    poses = np.asarray(poses, float).reshape(-1, 7)
+    R, t, X = _quat_rot(poses[:, 3:]), poses[:, :3].copy(), np.array(points, float).reshape(-1, 3)
+    n_pose, n_pt = len(poses), len(X)
+    free = np.ones(n_pose, bool) if pose_fixed is None else ~np.asarray(pose_fixed).astype(bool)
+    slot = np.cumsum(free) - 1
+    nf = int(free.sum())
+    if setup_type is None:
+        setup_type = 1 if bf != 0.0 else 0
+    huber = SQRT_CHI2_2D if setup_type == 0 else SQRT_CHI2_3D
+    stereo = np.zeros(0, mono.dtype) if stereo is None else stereo
+    sets = [(mono, None)] + ([(stereo, bf)] if len(stereo) else [])
+
+    def linearize(R, t, X, active, delta):
+        B = None
+        for (edges, b), act in zip(sets, active):
+            o = ba_linearize(np.concatenate([t, np.zeros((n_pose, 4))], 1), ~free, X, edges[act], cam, delta, bf=b, equirect=equirect, rot=R)
+            o["edges"] = [edges[act]]
+            o["Hpl"] = [o["Hpl"]]
+            if B is None:
+                B = o
+            else:
+                for key in ("Hpp", "bp", "Hll", "bl", "chi2"):
+                    B[key] = B[key] + o[key]
+                B["Hpl"] += o["Hpl"]
+                B["edges"] += o["edges"]
+        return B
+
+    def solve(B, lam):
+        k = np.concatenate([e["pose_idx"] for e in B["edges"]])
+        j = np.concatenate([e["point_idx"] for e in B["edges"]])
+        W = np.concatenate(B["Hpl"])
+        used = np.zeros(n_pt, bool)
+        used[j] = True
+        col = np.cumsum(used) - 1
+        na = int(used.sum())
+        n = 6 * nf + 3 * na
+        A, g = np.zeros((n, n)), np.zeros(n)
+        for q in np.nonzero(free)[0]:
+            s = 6 * slot[q]
+            A[s:s + 6, s:s + 6] = B["Hpp"][q]
+            g[s:s + 6] = B["bp"][q]
+        for a in np.nonzero(used)[0]:
+            s = 6 * nf + 3 * col[a]
+            A[s:s + 3, s:s + 3] = B["Hll"][a]
+            g[s:s + 3] = B["bl"][a]
+        for e in np.nonzero(free[k])[0]:
+            r, c = 6 * slot[k[e]], 6 * nf + 3 * col[j[e]]
+            A[r:r + 6, c:c + 3] += W[e]
+            A[c:c + 3, r:r + 6] += W[e].T
+        A[np.arange(n), np.arange(n)] += lam
+        try:
+            np.linalg.cholesky(A)
+        except np.linalg.LinAlgError:
+            return None
+        dx = np.linalg.solve(A, g)
+        dxp, dxl = np.zeros((n_pose, 6)), np.zeros((n_pt, 3))
+        dxp[free] = dx[:6 * nf].reshape(-1, 6)
+        dxl[used] = dx[6 * nf:].reshape(-1, 3)
+        return dxp, dxl, float(dx @ (lam * dx + g))
+
+    def run_round(R, t, X, active, iters, delta):
+        cur = linearize(R, t, X, active, delta)
+        chi = chi_start = cur["chi2"][1]
+        err_state = (R, t, X)
+        n_edges = sum(int(a.sum()) for a in active)
+        if iters <= 0 or n_edges == 0:
+            return R, t, X, chi_start, chi, 0, err_state
+        seen = np.zeros(n_pt, bool)
+        for (edges, _), act in zip(sets, active):
+            seen[edges["point_idx"][act]] = True
+        diag = [np.abs(np.einsum("kii->ki", cur["Hpp"][free])).max()] if nf else []
+        if seen.any():
+            diag.append(np.abs(np.einsum("kii->ki", cur["Hll"][seen])).max())
+        lam, ni, n_iter = 1e-5 * max(diag), 2.0, 0
+        for _ in range(iters):
+            n_iter += 1
+            rho, qmax = 0.0, 0
+            err_state = (R, t, X)
+            while True:
+                sol = solve(cur, lam)
+                temp, scale = np.finfo(float).max, 1e-3
+                if sol is not None:
+                    dxp, dxl, gain = sol
+                    Rn, tn = R.copy(), t.copy()
+                    for q in np.nonzero(free)[0]:
+                        E, et = _se3_exp(dxp[q])
+                        Rn[q], tn[q] = E @ R[q], E @ t[q] + et
+                    Xn = X + dxl
+                    trial = linearize(Rn, tn, Xn, active, delta)
+                    err_state = (Rn, tn, Xn)
+                    temp, scale = trial["chi2"][1], gain + 1e-3
+                rho = (chi - temp) / scale
+                if sol is not None and rho > 0 and np.isfinite(temp):
+                    lam *= max(1.0 / 3.0, min(1.0 - (2 * rho - 1) ** 3, 2.0 / 3.0))
+                    ni, chi = 2.0, temp
+                    R, t, X, cur = Rn, tn, Xn, trial
+                else:
+                    lam *= ni
+                    ni *= 2
+                    if not np.isfinite(lam):
+                        break
+                qmax += 1
+                if not (rho < 0 and qmax < 10):
+                    break
+            if qmax == 10 or rho == 0 or not np.isfinite(lam):
+                break
+        return R, t, X, chi_start, chi, n_iter, err_state
+
+    def judge(err_state, R, t, X):
+        chi = [_edge_chi2_depth(*err_state, edges, cam, b, equirect)[0] for edges, b in sets]
+        depth = [_edge_chi2_depth(R, t, X, edges, cam, b, equirect)[1] for edges, b in sets]
+        return chi, depth
+
+    gates = [CHI2_2D, CHI2_3D]
+    info = np.zeros(6)
+    everything = [np.ones(len(edges), bool) for edges, _ in sets]
+    R, t, X, info[0], info[1], info[4], err = run_round(R, t, X, everything, num_first_iter, huber)
+    chi_r1, depth = judge(err, R, t, X)
+    out_r1 = [(gates[i] < chi_r1[i]) | ~depth[i] for i in range(len(sets))]
+    R, t, X, info[2], info[3], info[5], err = run_round(R, t, X, [~o for o in out_r1], num_second_iter, 0.0)
+    chi_r2, depth = judge(err, R, t, X)
+    flags = [(gates[i] < np.where(out_r1[i], chi_r1[i], chi_r2[i])) | ~depth[i] for i in range(len(sets))]
+    return dict(R=R, t=t, points=X, mono_outlier=flags[0], stereo_outlier=flags[1] if len(sets) > 1 else np.zeros(0, bool), info=info)

@@ -720,3 +720,84 @@ def test_bow_transform_second_restatement(oracle, k, depth):
         gw, gwt, gnd = nv.bow_transform(vocab, desc, levelsup)
         assert np.array_equal(gw, w) and np.array_equal(gwt, wt) and np.array_equal(gnd, nd), (k, depth, levelsup)
     assert (w >= 0).all() and len(np.unique(w)) > 100 or k == 3
+
+
+def _small_lba_scene(seed, stereo_frac, outlier_frac=0.04):
+    from openvslam_amd.ba import EDGE_STEREO_DTYPE, quat_to_rot
+    d = synth.synth_local_ba(n_pose=7, n_pt=260, obs_per_pose=150, seed=seed, pose_noise=0.03, point_noise=0.03, n_fixed=2)
+    rng = np.random.default_rng(seed + 100)
+    e = d["edges"].copy()
+    bad = rng.random(len(e)) < outlier_frac
+    e["obs_x"][bad] += rng.choice([-1, 1], int(bad.sum())) * rng.uniform(15, 60, int(bad.sum()))
+    bf = 0.12 * d["cam"][0]
+    is_st = rng.random(len(e)) < stereo_frac
+    st = np.zeros(int(is_st.sum()), EDGE_STEREO_DTYPE)
+    if len(st):
+        es = e[is_st]
+        for k in ("pose_idx", "point_idx", "obs_x", "obs_y", "inv_sigma_sq"):
+            st[k] = es[k]
+        z = np.empty(len(es))
+        for p in np.unique(es["pose_idx"]):
+            sel = es["pose_idx"] == p
+            z[sel] = (d["points_true"][es["point_idx"][sel]] @ quat_to_rot(d["poses_true"][p, 3:]).T + d["poses_true"][p, :3])[:, 2]
+        st["obs_x_right"] = es["obs_x"] - bf / z + rng.normal(0, 1, len(es))
+    return d, np.ascontiguousarray(e[~is_st]), st, bf
+
+
+@pytest.mark.parametrize("seed,stereo_frac", [(1, 0.0), (2, 0.35), (3, 1.0)])
+def test_local_ba_second_restatement(oracle, seed, stereo_frac):
+    """Rule 28 (local_bundle_adjuster::optimize behind the graph build) a second time, in another FORM: tests/nversion_pose.py keeps the landmarks
+    in the system -- every Levenberg-Marquardt trial is one LAPACK solve over (free keyframes, landmarks) -- where the oracle and the library
+    eliminate them; blocks from the numpy linearisation. Same iteration counts, same outlier flags, chi2 to 1e-9, states to 1e-7 (the bound the
+    library's own solver is held to)."""
+    import nversion_pose as npz
+    from oracle import lba
+    d, mono, st, bf = _small_lba_scene(seed, stereo_frac)
+    if stereo_frac == 1.0:
+        mono = mono[:0]
+    want = lba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], mono, d["cam"], st if len(st) else None, bf if len(st) else 0.0)
+    got = npz.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], mono, d["cam"], st if len(st) else None, bf if len(st) else 0.0)
+    assert np.array_equal(got["info"][4:], want["info"][4:]) and want["info"][4] >= 3, (got["info"], want["info"])
+    assert np.allclose(got["info"][:4], want["info"][:4], rtol=1e-9)
+    assert np.array_equal(got["mono_outlier"], want["mono_outlier"]) and np.array_equal(got["stereo_outlier"], want["stereo_outlier"])
+    assert want["mono_outlier"].sum() + want["stereo_outlier"].sum() > 10
+    Rw = npz._quat_rot(want["poses"][:, 3:])
+    seen = np.zeros(len(d["points"]), bool)
+    seen[mono["point_idx"]] = True
+    seen[st["point_idx"]] = True
+    assert np.abs(got["R"] - Rw).max() < 1e-7 and np.abs(got["t"] - want["poses"][:, :3]).max() < 1e-7
+    assert np.abs(got["points"][seen] - want["points"][seen]).max() < 1e-7 and np.array_equal(got["points"][~seen], want["points"][~seen])
+    print("local BA, two forms: pose", np.abs(got["t"] - want["poses"][:, :3]).max(), "points", np.abs(got["points"][seen] - want["points"][seen]).max())
+
+
+def test_local_ba_equirect_second_restatement(oracle):
+    """The same two forms over the equirectangular edge (rule 26): six keyframes inside a shell of 300 landmarks, exact observations plus noise,
+    3 % displaced by 60 px."""
+    import nversion_pose as npz
+    from oracle import lba
+    rng = np.random.default_rng(2)
+    n_pose, n_pt, per, cols, rows = 6, 300, 160, 3840, 1920
+    pts = rng.normal(size=(n_pt, 3))
+    pts *= (rng.uniform(3.0, 9.0, n_pt) / np.linalg.norm(pts, axis=1))[:, None]
+    poses = np.zeros((n_pose, 7))
+    poses[:, 6] = 1.0
+    poses[:, :3] = rng.normal(0, 0.5, (n_pose, 3))
+    edges = np.zeros(n_pose * per, oracle.BA_EDGE_DTYPE)
+    for i in range(n_pose):
+        sel = rng.choice(n_pt, per, replace=False)
+        u, v = synth.equirect_project(pts[sel] + poses[i, :3], cols, rows)
+        e = edges[i * per:(i + 1) * per]
+        e["pose_idx"], e["point_idx"], e["obs_x"], e["obs_y"], e["inv_sigma_sq"] = i, sel, u + rng.normal(0, 0.7, per), v + rng.normal(0, 0.7, per), 1.0
+    edges["obs_y"][rng.random(len(edges)) < 0.03] += 60.0
+    fixed = np.zeros(n_pose, np.uint8)
+    fixed[:2] = 1
+    p0, x0 = poses.copy(), pts + rng.normal(0, 0.01, pts.shape)
+    p0[2:, :3] += rng.normal(0, 0.01, (n_pose - 2, 3))
+    want = lba.local_ba_optimize_equirect(p0, fixed, x0, edges, cols, rows)
+    got = npz.local_ba_optimize(p0, fixed, x0, edges, (float(cols), float(rows), 0.0, 0.0), None, 0.0, setup_type=0, equirect=True)
+    assert np.array_equal(got["info"][4:], want["info"][4:]) and np.allclose(got["info"][:4], want["info"][:4], rtol=1e-9)
+    assert np.array_equal(got["mono_outlier"], want["mono_outlier"]) and want["mono_outlier"].sum() > 10
+    seen = np.zeros(n_pt, bool)
+    seen[edges["point_idx"]] = True
+    assert np.abs(got["R"] - npz._quat_rot(want["poses"][:, 3:])).max() < 1e-7 and np.abs(got["t"] - want["poses"][:, :3]).max() < 1e-7
+    assert np.abs(got["points"][seen] - want["points"][seen]).max() < 1e-7
