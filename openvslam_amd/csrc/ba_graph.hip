@@ -884,8 +884,21 @@ namespace ovs {
 
 // The reduced camera system is stored the way the device solver wants it (ba_solve.hip): pitch n_pad = 6 n_free rounded up to 16, an identity
 // block on the padding, the right-hand side as row n_pad, zero rows behind it. The padding survives a solve, so it is written once here.
+static ovs_status solver_workspace_create(ovs_ba_graph* g, hipStream_t s);
+
 ovs_status ba_graph_ensure_solver(ovs_ba_graph* g, hipStream_t s) {
     if (g->d_Hinv) return OVS_OK;
+    const ovs_status st = solver_workspace_create(g, s);
+    if (st != OVS_OK) {   // d_Hinv doubles as the "work space is ready" mark: a half-built one must not pass for ready on the next call
+        (void)hipStreamSynchronize(s);
+        if (g->d_solver_arena) (void)hipFree(g->d_solver_arena);
+        g->d_solver_arena = nullptr;
+        g->d_Hinv = nullptr;
+    }
+    return st;
+}
+
+static ovs_status solver_workspace_create(ovs_ba_graph* g, hipStream_t s) {
     const size_t ne = std::max<size_t>((size_t)g->n_edge(), 1);
     const int n = 6 * std::max(g->n_free, 1), n_pad = dense_solve_pad(n);
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };

@@ -803,7 +803,10 @@ static ovs_status pose_optimize_host(int model, int32_t device, const double* po
                                                       reinterpret_cast<double*>(d + off_out), d + off_fl, reinterpret_cast<int32_t*>(d + off_nv),
                                                       scratch.stream, threads, groups, reinterpret_cast<double*>(d + off_part),
                                                       reinterpret_cast<unsigned int*>(d + off_sync), batch_retries);
-        if (st != OVS_OK) return st;
+        if (st != OVS_OK) {
+            (void)hipStreamSynchronize(scratch.stream);   // the upload may still be reading the pinned block the next call overwrites
+            return st;
+        }
         OVS_HIP_TRY(hipMemcpyAsync(h + off_out, d + off_out, out_bytes, hipMemcpyDeviceToHost, scratch.stream));
         OVS_HIP_TRY(hipStreamSynchronize(scratch.stream));
         int32_t nv = 0;
