@@ -361,13 +361,15 @@ __global__ __launch_bounds__(256) void k_fuse_best(FuseArgs a, int32_t* __restri
     do {
         if (a.lm_valid && !a.lm_valid[l]) break;
         const double* Xw = a.lm_pos_w + 3 * (size_t)l;
-        double X1[3];
-        const double* X = Xw;
+        // (held by value: a pointer that is either the global position or a local array put that array, 32 bytes, in scratch memory)
+        double X[3] = {Xw[0], Xw[1], Xw[2]};
         if (a.variant == kFuseMutual) {
-            X1[0] = (a.P1[0] * Xw[0] + a.P1[1] * Xw[1]) + a.P1[2] * Xw[2] + a.P1[9];
-            X1[1] = (a.P1[3] * Xw[0] + a.P1[4] * Xw[1]) + a.P1[5] * Xw[2] + a.P1[10];
-            X1[2] = (a.P1[6] * Xw[0] + a.P1[7] * Xw[1]) + a.P1[8] * Xw[2] + a.P1[11];
-            X = X1;
+            const double x0 = (a.P1[0] * X[0] + a.P1[1] * X[1]) + a.P1[2] * X[2] + a.P1[9];
+            const double x1 = (a.P1[3] * X[0] + a.P1[4] * X[1]) + a.P1[5] * X[2] + a.P1[10];
+            const double x2 = (a.P1[6] * X[0] + a.P1[7] * X[1]) + a.P1[8] * X[2] + a.P1[11];
+            X[0] = x0;
+            X[1] = x1;
+            X[2] = x2;
         }
         double u, v;
         float x_right;

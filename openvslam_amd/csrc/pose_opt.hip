@@ -429,7 +429,9 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                 double rho = 0;
                 int qmax = 0;
                 do {
-                    if (qmax == 1 && batch_retries) {
+                    // (the 512-thread build never batches: the host picks 512 threads only for one-workgroup frames of 768 or more
+                    // observations, where the one-by-one form measured faster, and without this block the build needs no scratch memory)
+                    if (kPoseThreads == 256 && qmax == 1 && batch_retries) {
                         // ---- The first trial was rejected. g2o would now retry up to nine times with lambda * nu, nu doubling -- a sequence
                         // that does not depend on the outcomes, and (in a converged round, where the gain ratio is rounding noise) usually runs
                         // to the end: nine times [one lane's solve, a pass over the observations, a reduction, four barriers]. Round 4: the nine
