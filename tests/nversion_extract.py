@@ -74,8 +74,9 @@ def fast_candidates(level_img, ini_thr, min_thr):
     return np.concatenate(xs).astype(F), np.concatenate(ys).astype(F), np.concatenate(sc).astype(F)
 
 
-def extract(img, pattern, max_num_keypts=1000, scale_factor=1.2, num_levels=8, ini_fast_thr=20, min_fast_thr=7):
-    """(keypoints, descriptors, candidates per level) of one grey image."""
+def extract(img, pattern, max_num_keypts=1000, scale_factor=1.2, num_levels=8, ini_fast_thr=20, min_fast_thr=7, tree_switch_factor=3, tree_tie_order=0,
+            blur_taps=0):
+    """(keypoints, descriptors, candidates per level) of one grey image; the last three arguments are ORACLE_SPEC's run-time variants."""
     sf, budget = tables(max_num_keypts, scale_factor, num_levels)
     kps, descs, n_cand = [], [], []
     for l, lvl_img in enumerate(pyramid(np.asarray(img, np.uint8), sf)):
@@ -84,7 +85,7 @@ def extract(img, pattern, max_num_keypts=1000, scale_factor=1.2, num_levels=8, i
         if len(cx) == 0:
             continue
         rows, cols = lvl_img.shape
-        keep = np.asarray(tree_model(cx, cy, cs, BORDER, cols - BORDER, BORDER, rows - BORDER, budget[l]), np.int64)
+        keep = np.asarray(tree_model(cx, cy, cs, BORDER, cols - BORDER, BORDER, rows - BORDER, budget[l], tree_switch_factor, tree_tie_order), np.int64)
         px, py = cx[keep].astype(np.int64) + BORDER, cy[keep].astype(np.int64) + BORDER
         ang = nv.ic_angle(lvl_img, px, py)
         k = np.zeros(len(keep), KP)
@@ -92,7 +93,7 @@ def extract(img, pattern, max_num_keypts=1000, scale_factor=1.2, num_levels=8, i
         k["size"] = F(np.uint32(F(PATCH) * sf[l]))
         k["angle"], k["response"], k["octave"], k["class_id"] = ang, cs[keep], l, -1
         kps.append(k)
-        descs.append(nv.orb_descriptors(nv.gaussian_blur_7x7(lvl_img), px, py, ang, pattern))
+        descs.append(nv.orb_descriptors(nv.gaussian_blur_7x7(lvl_img, blur_taps), px, py, ang, pattern))
     if not kps:
         return np.zeros(0, KP), np.zeros((0, 32), np.uint8), n_cand
     return np.concatenate(kps), np.concatenate(descs), n_cand

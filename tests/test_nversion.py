@@ -801,3 +801,21 @@ def test_local_ba_equirect_second_restatement(oracle):
     seen[edges["point_idx"]] = True
     assert np.abs(got["R"] - npz._quat_rot(want["poses"][:, 3:])).max() < 1e-7 and np.abs(got["t"] - want["poses"][:, :3]).max() < 1e-7
     assert np.abs(got["points"][seen] - want["points"][seen]).max() < 1e-7
+
+
+@pytest.mark.parametrize("factor,tie,taps", [(1, 0, 0), (3, 1, 0), (3, 0, 1), (1, 1, 1)])
+def test_whole_extractor_in_numpy_follows_the_variant_switches(oracle, factor, tie, taps):
+    """The run-time variants of rules 6, 7 and 10 (quad-tree switch factor 3 | 1, order of equal counts, blur taps) have a second form too: the
+    numpy pipeline with the same three switches equals the oracle under ovo_orb_set_variant, and each switch does change the output."""
+    import nversion_extract as nx
+    pat = oracle.orb_pattern()
+    img = synth.synth_frame(480, 752, seed=12)
+    ox = oracle.OrbExtractor(oracle.make_params(1000))
+    k0, d0 = ox.extract(img)
+    ox.set_variant("tree_switch_factor", factor)
+    ox.set_variant("tree_tie_order", tie)
+    ox.set_variant("blur_taps", taps)
+    wk, wd = ox.extract(img)
+    k, d, _ = nx.extract(img, pat, 1000, tree_switch_factor=factor, tree_tie_order=tie, blur_taps=taps)
+    assert len(k) == len(wk) and k.tobytes() == np.ascontiguousarray(wk).tobytes() and np.array_equal(d, wd)
+    assert len(wk) != len(k0) or wk.tobytes() != np.ascontiguousarray(k0).tobytes() or not np.array_equal(wd, d0)

@@ -13,7 +13,8 @@ import math
 import numpy as np
 
 
-def tree_model(xs, ys, scores, min_x, max_x, min_y, max_y, N):
+def tree_model(xs, ys, scores, min_x, max_x, min_y, max_y, N, switch_factor=3, tie_order=0):
+    # switch_factor / tie_order: ORACLE_SPEC's run-time variants of rules 6 and 7 (3 | 1; equal counts: later-created node first | earlier first)
     n = len(xs)
     if n == 0:
         return []
@@ -65,7 +66,7 @@ def tree_model(xs, ys, scores, min_x, max_x, min_y, max_y, N):
             proc = [i for i in range(L) if nonleaf[i]]
         else:
             pool = [i for i in range(L) if nonleaf[i]]
-            pool.sort(key=lambda i: (-cnt[i], i))
+            pool.sort(key=lambda i: (-cnt[i], i if tie_order == 0 else -i))
             size = L
             proc = []
             for i in pool:
@@ -102,7 +103,7 @@ def tree_model(xs, ys, scores, min_x, max_x, min_y, max_y, N):
         if phase == 1:
             if N <= size or size == prev:
                 break
-            if N < size + 3 * npool:
+            if N < size + switch_factor * npool:
                 phase = 2
         else:
             if N <= size or size == prev:
