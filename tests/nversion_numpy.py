@@ -266,9 +266,10 @@ def keypoints_in_cell(xs, ys, octaves, ref_x, ref_y, margin, min_x, min_y, max_x
 
 
 # ---- rule 17: match::angle_checker ------------------------------------------------------------------------------------------------------------
-def angle_checker_invalid(delta_angles):
+def angle_checker_invalid(delta_angles, keep_rule=0):
     """True for the entries outside the three fullest 30-degree bins: delta wrapped once into [0, 360), bin = cvRound(delta * (1 / 30)) in
-    float (half to even), equal counts -> the lower bin first."""
+    float (half to even), equal counts -> the lower bin first. keep_rule = 1 (the variant of rule 17, ORB-SLAM2's ComputeThreeMaxima): a second
+    bin holding less than 0.1 x the fullest is dropped together with the third, a third bin below that alone."""
     F = np.float32
     d = np.asarray(delta_angles, F).copy()
     d = np.where(d < 0, d + F(360.0), d).astype(F)
@@ -276,6 +277,12 @@ def angle_checker_invalid(delta_angles):
     b = np.rint(d * F(1.0 / 30.0)).astype(np.int64)
     counts = np.bincount(b, minlength=30)[:30]
     keep = np.argsort(-counts, kind="stable")[:3]
+    if keep_rule == 1:
+        floor = F(0.1) * F(counts[keep[0]])
+        if F(counts[keep[1]]) < floor:
+            keep = keep[:1]
+        elif F(counts[keep[2]]) < floor:
+            keep = keep[:2]
     return ~np.isin(b, keep)
 
 
@@ -638,7 +645,7 @@ def fuse_replace_duplication(model, cam, cols, rows, xs, ys, octaves, desc, pose
 
 # ---- rule 20: match::stereo::compute ----------------------------------------------------------------------------------------------------------
 def stereo_compute(pyr_left, pyr_right, kps_left, desc_left, kps_right, desc_right, scale_factors, inv_scale_factors, focal_x_baseline,
-                   true_baseline, outlier_factor=2.0):
+                   true_baseline, outlier_factor=2.0, parabola_double=False):
     """(stereo_x_right, depths) per left keypoint (-1 where there is none). pyr_* = the extractors' level images (lists of uint8 arrays);
     keypoints as structured arrays with x, y, octave."""
     F = np.float32
@@ -685,7 +692,10 @@ def stereo_compute(pyr_left, pyr_right, kps_left, desc_left, kps_right, desc_rig
             continue
         c1, c2, c3 = cost[k - 1], cost[k], cost[k + 1]
         with np.errstate(divide="ignore", invalid="ignore"):
-            delta = (c1 - c3) / (F(2.0) * (c1 + c3 - F(2.0) * c2))
+            if parabola_double:      # rule 20's variant: the quotient in double, rounded to float once
+                delta = F((float(c1) - float(c3)) / (2.0 * (float(c1) + float(c3) - 2.0 * float(c2))))
+            else:
+                delta = (c1 - c3) / (F(2.0) * (c1 + c3 - F(2.0) * c2))
         if delta < -1 or 1 < delta:
             continue
         x_r = sf[lvl] * (F(cx_r) + F(k - 5) + delta)

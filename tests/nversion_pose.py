@@ -86,7 +86,7 @@ def pose_optimize_equirect(T0, obs, cols, rows):
     return pose_optimize(T0, obs, (float(cols), float(rows), 0.0, 0.0), 0.0, 0, _edges_equirect)
 
 
-def pose_optimize(T0, obs, cam, bf=0.0, setup_type=None, edges=None):
+def pose_optimize(T0, obs, cam, bf=0.0, setup_type=None, edges=None, reset_each_round=False):
     """Returns (pose 3x4, outlier flags, num_valid) as the C oracle's ovo_pose_optimize."""
     edges = edges or _edges
     if setup_type is None:
@@ -101,6 +101,8 @@ def pose_optimize(T0, obs, cam, bf=0.0, setup_type=None, edges=None):
     num_bad = 0
     for rnd in range(4):
         delta = huber if rnd < 3 else 0.0   # Huber in rounds 0 .. 2
+        if reset_each_round:                # rule 25 (iv)'s variant: every round starts from the input pose again
+            R, t = np.array(T0[:, :3], float), np.array(T0[:, 3], float)
         o = obs[active]
         lam, ni = 0.0, 2.0
         Rn, tn = R, t

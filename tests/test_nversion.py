@@ -819,3 +819,46 @@ def test_whole_extractor_in_numpy_follows_the_variant_switches(oracle, factor, t
     k, d, _ = nx.extract(img, pat, 1000, tree_switch_factor=factor, tree_tie_order=tie, blur_taps=taps)
     assert len(k) == len(wk) and k.tobytes() == np.ascontiguousarray(wk).tobytes() and np.array_equal(d, wd)
     assert len(wk) != len(k0) or wk.tobytes() != np.ascontiguousarray(k0).tobytes() or not np.array_equal(wd, d0)
+
+
+def test_remaining_variants_second_restatement(oracle):
+    """The round-4 switches in their second form: rule 20's double parabola (stereo_x_right and depth bit for bit), rule 25 (iv)'s per-round
+    vertex re-set (flags identical, pose to 2e-8), rule 17's ORB-SLAM2 keep rule (bin by bin on histograms with a dominant mode)."""
+    import nversion_pose as nvp
+    from openvslam_amd.synth import synth_pose_frame
+    # stereo: parabola in double, with both outlier factors
+    left, right, _ = synth.synth_stereo_pair(240, 400, seed=3)
+    oxl, oxr = oracle.OrbExtractor(oracle.make_params(500)), oracle.OrbExtractor(oracle.make_params(500))
+    kl, dl = oxl.extract(left)
+    kr, dr = oxr.extract(right)
+    tabs = oracle.orb_tables(oxl.params)
+    pyr_l, pyr_r = [oxl.level_image(l) for l in range(8)], [oxr.level_image(l) for l in range(8)]
+    for f21 in (False, True):
+        wx, wd, wn = oracle.stereo_compute(oxl, oxr, kl, dl, kr, dr, 386.1448, 0.5372, outlier_factor_21=f21, parabola_double=True)
+        gx, gd = nv.stereo_compute(pyr_l, pyr_r, kl, dl, kr, dr, tabs["scale_factors"], tabs["inv_scale_factors"], 386.1448, 0.5372, 2.1 if f21 else 2.0, True)
+        assert wn > 50 and np.array_equal(gx.view(np.uint32), wx.view(np.uint32)) and np.array_equal(gd.view(np.uint32), wd.view(np.uint32))
+    # (on these frames the double quotient rounds to the float one everywhere or moves it by an ulp: equality with the oracle is the point)
+    # pose optimiser: the frame vertex re-set every round
+    oracle.pose_set_variant("reset_each_round", 1)
+    try:
+        for n, sf, of, pe, seed in ((1500, 0.4, 0.1, 1.0, 1), (300, 0.0, 0.2, 2.0, 2)):
+            T0, obs, cam, bf, _ = synth_pose_frame(oracle.POSE_OBS_DTYPE, n, seed, sf, of, pe)
+            wT, wout, wnv = oracle.pose_optimize(T0, obs, cam, bf)
+            T, out, nval = nvp.pose_optimize(T0, obs, cam, bf, reset_each_round=True)
+            assert nval == wnv and np.array_equal(out, wout.astype(bool)) and np.allclose(T, wT, rtol=0, atol=2e-8)
+    finally:
+        oracle.pose_set_variant("reset_each_round", 0)
+    # angle checker: ORB-SLAM2's keep rule
+    rng = np.random.default_rng(4)
+    oracle.match_set_variant("angle_keep_rule", 1)
+    try:
+        changed = 0
+        for trial in range(40):
+            n = int(rng.integers(20, 400))
+            d = np.where(rng.random(n) < rng.uniform(0.6, 0.98), rng.normal(rng.uniform(0, 360), 6, n), rng.uniform(-360, 720, n)).astype(np.float32)
+            want = oracle.angle_checker_invalid(d)
+            assert np.array_equal(nv.angle_checker_invalid(d, 1), want)
+            changed += int(not np.array_equal(nv.angle_checker_invalid(d, 0), want))
+        assert changed > 5
+    finally:
+        oracle.match_set_variant("angle_keep_rule", 0)
