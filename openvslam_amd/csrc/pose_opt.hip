@@ -359,16 +359,19 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
         __syncthreads();
     };
 
-    PoseD T0;
-    for (int i = 0; i < 9; ++i) T0.R[i] = poses_in[12 * (size_t)p + i];
-    for (int i = 0; i < 3; ++i) T0.t[i] = poses_in[12 * (size_t)p + 9 + i];
+    // the input pose is read where it is needed (here and, under reset_each_round, at the start of a round): held in registers across the
+    // kernel it cost 24 of them for nothing -- the 512-thread build kept it in scratch memory
+    auto load_input_pose = [&]() {
+        for (int i = 0; i < 9; ++i) s_T.R[i] = poses_in[12 * (size_t)p + i];
+        for (int i = 0; i < 3; ++i) s_T.t[i] = poses_in[12 * (size_t)p + 9 + i];
+    };
     uint32_t active = 0xFFFFFFFFu;   // bit k <-> observation gtid + gstride * k
     int st_any = 0;
     for (int i = gtid; i < n; i += gstride) outlier[i] = 0;
     if (MODEL == 0)
         for (int i = tid; i < n; i += kPoseThreads) st_any |= obs[i].is_stereo;   // (every workgroup scans the whole frame: the flag must be the same in all)
     const bool has_stereo = MODEL == 0 && __builtin_amdgcn_readfirstlane(__syncthreads_or(st_any)) != 0;
-    if (tid == 0) s_T = T0;
+    if (tid == 0) load_input_pose();
     __syncthreads();
     int num_bad = 0;
     if (n >= 5) {
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
             // estimate carries over from round to round (the frame vertex is initialised once, before the loop)
             const bool robust = trial < 3;
             if (reset_each_round) {   // rule 25 (iv)'s alternative (ORB-SLAM2): every round starts from the input pose again (kernel argument: uniform)
-                if (tid == 0) s_T = T0;
+                if (tid == 0) load_input_pose();
                 __syncthreads();
             }
             double lambda = 0, ni = 2;   // held identically by every thread (all control flow below is workgroup-uniform)
