@@ -862,3 +862,66 @@ def test_remaining_variants_second_restatement(oracle):
         assert changed > 5
     finally:
         oracle.match_set_variant("angle_keep_rule", 0)
+
+
+def test_small_tie_heavy_cases_of_every_list_matcher(oracle):
+    """600 small random cases (0 .. 40 keypoints, descriptors drawn from THREE base patterns with a few flipped bits, positions on a coarse lattice,
+    angles from a handful of values): equal Hamming distances, equal histogram counts, candidates exactly on window edges and empty inputs
+    everywhere -- the places where only the tie rules decide. Second restatements against the oracle: brute force (rule 14), area (19),
+    both bow_tree matchers (19), frame-and-landmarks (18)."""
+    rng = np.random.default_rng(2024)
+    cols, rows = 200, 120
+    gp = oracle.grid_params(cols, rows)
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    base = rng.integers(0, 256, (3, 32), dtype=np.uint8)
+
+    def frame(n):
+        k = np.zeros(n, oracle.KP_DTYPE)
+        k["x"] = (rng.integers(0, 41, n) * 5).astype(np.float32)          # lattice of 5 px: |dx| == margin happens
+        k["y"] = (rng.integers(0, 25, n) * 5).astype(np.float32)
+        k["octave"] = rng.integers(0, 3, n)
+        k["angle"] = rng.choice(np.array([0, 15, 45, 100, 200, 355], np.float32), n)
+        d = base[rng.integers(0, 3, n)].copy()
+        for j in range(n):
+            for b in rng.integers(0, 256, rng.integers(0, 4)):
+                d[j, b >> 3] ^= np.uint8(1 << (b & 7))
+        return k, d
+
+    def bow(n):
+        fv = {}
+        for i, node in enumerate(rng.integers(0, 4, n)):
+            fv.setdefault(int(node), []).append(i)
+        return fv
+
+    for case in range(600):
+        n1, n2 = int(rng.integers(0, 41)), int(rng.integers(0, 41))
+        k1, d1 = frame(n1)
+        k2, d2 = frame(n2)
+        ratio = float(rng.choice([0.6, 0.9, 1.0]))
+        orient = bool(rng.integers(0, 2))
+        if n1 and n2:
+            v = (rng.random(n2) < 0.8).astype(np.uint8)
+            assert np.array_equal(nv.robust_brute_force_match(d1, d2, v, ratio), oracle.robust_brute_force_match(d1, d2, v, ratio)), ("bf", case)
+        margin = int(rng.choice([5, 10, 20]))
+        prev_o = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], 1), np.float32).reshape(-1, 2)
+        prev_n = prev_o.copy()
+        wn, want = oracle.area_match_in_consistent_area(gp, k1, d1, k2, d2, prev_o, margin, ratio, orient)
+        gn, got, prev_n = nv.area_match_in_consistent_area(k1["octave"], k1["angle"], d1, k2["x"], k2["y"], k2["octave"], k2["angle"], d2, prev_n, cols, rows,
+                                                           margin, ratio, orient)
+        assert gn == wn and np.array_equal(got, want) and np.array_equal(prev_n, prev_o), ("area", case)
+        f1, f2 = bow(n1), bow(n2)
+        l1, l2 = rng.random(n1) < 0.8, rng.random(n2) < 0.8
+        wn, want = oracle.bow_match_frame_and_keyframe(k1, d1, f1, k2, d2, f2, ratio, orient, l1.astype(np.uint8))
+        gn, got = nv.bow_match_frame_and_keyframe(k1["angle"], d1, f1, l1, k2["angle"], d2, f2, ratio, orient)
+        assert gn == wn and np.array_equal(got, want), ("bow frame", case)
+        wn, want = oracle.bow_match_keyframes(k1, d1, f1, k2, d2, f2, ratio, orient, l1.astype(np.uint8), l2.astype(np.uint8))
+        gn, got = nv.bow_match_keyframes(k1["angle"], d1, f1, l1, k2["angle"], d2, f2, l2, ratio, orient)
+        assert gn == wn and np.array_equal(got, want), ("bow keyframes", case)
+        m = int(rng.integers(0, 30))
+        lk, ld = frame(m)
+        lm_xy = np.ascontiguousarray(np.stack([lk["x"], lk["y"]], 1), np.float32).reshape(-1, 2)
+        lvl = lk["octave"].astype(np.int32)
+        occ = (rng.random(n1) < 0.1).astype(np.uint8)
+        want, nm = oracle.projection_match_frame_and_landmarks(gp, k1, d1, sf, lm_xy, lvl, ld, float(margin), ratio, None, occ, None, None)
+        got = nv.projection_match_frame_and_landmarks(k1["x"], k1["y"], k1["octave"], d1, sf, lm_xy, lvl, ld, cols, rows, float(margin), ratio, None, occ, None, None)
+        assert np.array_equal(got, want), ("frame and landmarks", case)
