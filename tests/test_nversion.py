@@ -925,3 +925,55 @@ def test_small_tie_heavy_cases_of_every_list_matcher(oracle):
         want, nm = oracle.projection_match_frame_and_landmarks(gp, k1, d1, sf, lm_xy, lvl, ld, float(margin), ratio, None, occ, None, None)
         got = nv.projection_match_frame_and_landmarks(k1["x"], k1["y"], k1["octave"], d1, sf, lm_xy, lvl, ld, cols, rows, float(margin), ratio, None, occ, None, None)
         assert np.array_equal(got, want), ("frame and landmarks", case)
+
+
+def test_triangulation_matcher_ties(oracle):
+    """Rule 23 where only its tie rule decides: every point lies in ONE epipolar plane (y = 0 with a baseline along x), so every pairing passes
+    check_epipolar_constraint, and the descriptors come from three base patterns -- many candidates at EQUAL distance, of which the LAST in
+    node order must win ('d <= best'), and a target taken earlier is gone for later keypoints."""
+    rng = np.random.default_rng(77)
+    fx = fy = 400.0
+    cx, cy = 320.0, 240.0
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    base = rng.integers(0, 256, (3, 32), dtype=np.uint8)
+    R2, t2 = np.eye(3), np.array([-0.5, 0.0, 0.0])
+    E12 = np.array([[0, 0, 0], [0, 0, -0.5], [0, 0.5, 0]]) * -1.0          # [t12]x R12 with t12 = (0.5, 0, 0), R12 = I
+    ep = t2 / np.linalg.norm(t2)
+    n_ties = 0
+    for case in range(200):
+        n = int(rng.integers(1, 30))
+        X = np.stack([rng.uniform(-3, 3, n), np.zeros(n), rng.uniform(3, 9, n)], 1)
+        P2 = X + t2
+        k1, k2 = np.zeros(n, oracle.KP_DTYPE), np.zeros(n, oracle.KP_DTYPE)
+        k1["x"], k1["y"] = fx * X[:, 0] / X[:, 2] + cx, cy
+        k2["x"], k2["y"] = fx * P2[:, 0] / P2[:, 2] + cx, cy
+        k1["octave"], k2["octave"] = rng.integers(0, 4, n), rng.integers(0, 4, n)
+        k1["angle"] = rng.choice(np.array([0, 20, 100, 250], np.float32), n)
+        k2["angle"] = rng.choice(np.array([0, 20, 100, 250], np.float32), n)
+        d1, d2 = base[rng.integers(0, 3, n)].copy(), base[rng.integers(0, 3, n)].copy()
+        for d in (d1, d2):
+            for j in range(n):
+                for b in rng.integers(0, 256, rng.integers(0, 3)):
+                    d[j, b >> 3] ^= np.uint8(1 << (b & 7))
+        perm = rng.permutation(n)
+        k2, d2 = k2[perm], d2[perm]
+
+        def bearings(k):
+            b = np.stack([(k["x"].astype(np.float64) - cx) / fx, (k["y"].astype(np.float64) - cy) / fy, np.ones(len(k))], 1)
+            return b / np.linalg.norm(b, axis=1)[:, None]
+
+        b1, b2 = bearings(k1), bearings(k2)
+        fv1, fv2 = {}, {}
+        for i, node in enumerate(rng.integers(0, 2, n)):
+            fv1.setdefault(int(node), []).append(i)
+        for i, node in enumerate(rng.integers(0, 2, n)):
+            fv2.setdefault(int(node), []).append(i)
+        h1, h2 = (rng.random(n) < 0.2).astype(np.uint8), (rng.random(n) < 0.2).astype(np.uint8)
+        orient = bool(rng.integers(0, 2))
+        wn, want = oracle.robust_match_for_triangulation(k1, d1, fv1, b1, k2, d2, fv2, b2, E12, ep, sf, orient, h1, h2, None, None)
+        gn, got = nv.robust_match_for_triangulation(k1["angle"], k1["octave"], d1, fv1, b1, h1, None, k2["angle"], d2, fv2, b2, h2, None, E12, ep, sf, orient)
+        assert gn == wn and np.array_equal(got, want), (case, n, got, want)
+        D = nv.hamming_matrix(d1, d2)
+        for i1 in np.nonzero(want >= 0)[0]:
+            n_ties += int((D[i1] == D[i1, want[i1]]).sum() > 1)
+    assert n_ties > 200      # the accepted distance was shared by another keypoint of keyframe 2 in many of the matches
