@@ -34,3 +34,6 @@ for f in glob.glob('gpurun_out/r05a_trace/**/*kernel_stats.csv', recursive=True)
             print(line); out.write(line + "\n")
 PY
 find gpurun_out/r05a_trace -name '*.csv' -size +4M -delete
+
+# the tie rules on the device (written without one at the end of round 4)
+timeout 600 python tools/tie_fuzz_gpu.py 300 > gpurun_out/r05a_tie_fuzz.txt 2>&1; echo "tie fuzz rc=$?"; tail -6 gpurun_out/r05a_tie_fuzz.txt
