@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU (a multiple of 8: frames come in 8-frame scenes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="wall-time budget of the CPU-oracle sample (cpu_baseline + parity); at least 8 frames run")
     ap.add_argument("--no-ba", action="store_true", help="skip the local-BA side section (profiling runs)")
     ap.add_argument("--pipeline", type=int, default=1, help="sub-batches of the extract issued on overlapping internal streams (1 = off)")
     ap.add_argument("--chains", type=int, default=1, help="independent extract->match pipelines the batch is split over (own handles and "
@@ -176,7 +177,8 @@ def main():
     # of the timed region come from HBM (bench hygiene)
     frames = synth_video(ROWS, COLS, B, seed=100 + rank)
     d_frames = torch.from_numpy(frames).cuda()
-    d_frames_alt = torch.from_numpy(synth_video(ROWS, COLS, B, seed=900 + rank)).cuda()
+    frames_alt = synth_video(ROWS, COLS, B, seed=900 + rank)
+    d_frames_alt = torch.from_numpy(frames_alt).cuda()
     n_chain = max(1, args.chains)
     if B % (8 * n_chain):
         raise SystemExit("--batch must be a multiple of 8 * --chains")
@@ -221,6 +223,7 @@ def main():
             k = self.k % self.n_buf
             self.k += 1
             b = self.bufs[k]
+            self.last = (k, self.k & 1)                      # (output buffer set, input batch) of the most recent step: the parity check reads it
             if args.overlap:
                 self.s_ext.wait_event(self.ev_match[k])      # the matcher of two steps ago has released this buffer set
             self.ex.extract_batch_dev(self.frames[self.k & 1], b["kps"], b["desc"], b["cnt"], stream=self.s_ext.cuda_stream)
@@ -261,6 +264,17 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    # ---- the LAST timed step's outputs, copied to the host before anything else touches the buffers: what the parity check below compares
+    # with the CPU oracle (so the checked bytes are the ones the timed schedule itself produced: level-0 split, overlap, second stream)
+    last_out = None
+    if rank == 0:
+        last_out = []
+        for ch in chains:
+            k, which = ch.last
+            b = ch.bufs[k]
+            last_out.append(dict(which=which, cap=ch.ex.max_keypoints,
+                                 kps=b["kps"].cpu().numpy().view(np.uint8).reshape(Bc, -1, 28), desc=b["desc"].cpu().numpy(),
+                                 cnt=b["cnt"].cpu().numpy(), pairs=b["pairs"].cpu().numpy(), mcnt=b["mcnt"].cpu().numpy()))
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -337,6 +351,38 @@ def main():
         for i in range(min(4, Bc)):
             k = int(ref_cnt[i])
             popc_same = popc_same and bool(torch.equal(ref_pairs[i, :k], b["pairs"][i, :k]))
+        ch.mt.set_near_path("matrix")
+
+    # ---- north_star's own form of the all-pairs stage (popcount on the vector ALU, "no MFMA") under the SAME schedule and the same clock as
+    # `value`: K steps bracketed by barriers, max over ranks. The last step runs on the same input batch as the last step of the main region,
+    # so its outputs must equal the snapshot taken there (counts, keypoint records, descriptors, match pairs).
+    for ch in chains:
+        ch.mt.set_near_path("popcount")
+        ch.ex.set_fast_split(bool(args.fast_split))
+    for _ in range(2 + (args.steps & 1)):
+        step()
+    barrier()
+    tp0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed_popc = time.perf_counter() - tp0
+    if world > 1:
+        tt = torch.tensor([elapsed_popc], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed_popc = float(tt.item())
+    popc_sched_same = None
+    if rank == 0:
+        popc_sched_same = True
+        for ch, lo_ in zip(chains, last_out):
+            k, which = ch.last
+            b = ch.bufs[k]
+            popc_sched_same = popc_sched_same and which == lo_["which"] and np.array_equal(b["cnt"].cpu().numpy(), lo_["cnt"]) \
+                and np.array_equal(b["mcnt"].cpu().numpy(), lo_["mcnt"]) and np.array_equal(b["desc"].cpu().numpy(), lo_["desc"])
+            pr = b["pairs"].cpu().numpy()
+            for i in range(Bc):
+                popc_sched_same = popc_sched_same and np.array_equal(pr[i, :lo_["mcnt"][i]], lo_["pairs"][i, :lo_["mcnt"][i]])
+    for ch in chains:
         ch.mt.set_near_path("matrix")
 
     kp_step = matches_step = pairs_step = 0
@@ -488,9 +534,14 @@ def main():
             except Exception as ex_:   # a side section must never cost the headline line
                 class_lat = {"error": repr(ex_)}
 
+        # ---- CPU oracle on a bounded sample of the frames of the LAST timed step: its wall time is cpu_baseline (rank 0, N = 1 only), its
+        # outputs are the parity check of that step's keypoint records, descriptors and match pairs (N > 1: eight frames, check only)
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:   # the CPU baseline is a rank-0, N = 1 section (the scaling runs skip it)
-            cpu = cpu_baseline(frames)
+        parity = {"checked_frames": 0, "bit_exact": None, "note": "--no-cpu-baseline: the oracle did not run"}
+        if not args.no_cpu_baseline:
+            cpu, parity = cpu_baseline((frames, frames_alt), last_out, Bc, budget_s=args.cpu_budget_s if world == 1 else 0.0)
+            if world > 1:
+                cpu = None
 
         out = {
             "metric": "ORB kpts+descriptors/sec and Hamming matches/sec @1920x1080, 8-level pyramid",
@@ -529,7 +580,10 @@ def main():
             "local_ba": ba_res,
             "local_ba_large": ba_large,
             "other_configs": side,
-            "parity": "bit-exact vs in-repo CPU oracle (from-spec restatement; upstream source unavailable: parity unpinned)",
+            "parity": parity,
+            "value_popcount_near_path": round(kp_all * args.steps / elapsed_popc, 1),
+            "ms_per_step_popcount_near_path": round(elapsed_popc / args.steps * 1e3, 4),
+            "popcount_near_path_same_outputs_as_value_run": popc_sched_same,
             **({"test_hook": "OVS_BENCH_ONE_DEVICE=1: all ranks on ONE device over gloo -- a code-path test, not a measurement"} if one_device else {}),
         }
         if cpu:
@@ -552,6 +606,9 @@ def main():
         if native_multi is not None:
             out["local_ba_native_multi"] = native_multi
         print(json.dumps(out))
+        if out["parity"]["bit_exact"] is False or popc_sched_same is False:
+            sys.stdout.flush()
+            raise SystemExit("bench.py: PARITY FAILURE (%s; popcount-form outputs equal: %s)" % (json.dumps(out["parity"]), popc_sched_same))
 
 
 def bench_local_ba(world, rank, dist, torch, iters=20, n_pose=50, n_pt=20000, obs_per_pose=2000):
@@ -698,35 +755,63 @@ def bench_other_configs(iters=10):
     return out
 
 
-def cpu_baseline(frames, budget_s=12.0):
-    """The CPU oracle ("port": from-spec restatement, there is no reference source to build) timed on this box's host cores on a
-    bounded sample of the same workload: extract + brute_force_match of consecutive frames of the bench's own video."""
+def cpu_baseline(frame_sets, last_out, Bc, budget_s=12.0):
+    """The CPU oracle ("port": from-spec restatement, there is no reference source to build) on a bounded sample of the frames the LAST timed
+    step processed: extract + brute_force_match in the bench's own pairing (frame b against b-1 inside its 8-frame scene, the scene's first
+    frame against its last). Two results: the wall time of the oracle work (cpu_baseline) and, computed afterwards outside that clock, the
+    comparison of the oracle's outputs with the bytes the timed GPU schedule left in its output buffers (parity)."""
     from oracle import binding as ob
     ob.build()
     threads = min(8, os.cpu_count() or 1)   # upstream's optional OpenMP shape: parallel over the 8 pyramid levels
     ox = ob.OrbExtractor(ob.make_params(NFEAT), threads=threads)
-    n_kp = 0
-    n_match = 0
-    n_frames = 0
-    prev_desc = None
+    n_total = Bc * len(last_out)
+    res = {}       # global frame index -> (keypoint records, descriptors)
+    pairs = {}     # global frame index (keyframe side) -> oracle match pairs against its `prev` frame
+    n_kp = n_match = 0
     t0 = time.perf_counter()
-    i = 0
-    while True:
-        k, d = ox.extract(frames[i % len(frames)])
-        if prev_desc is not None:
-            n_match += len(ob.robust_brute_force_match(prev_desc, d, None, LOWE_RATIO))
-        prev_desc = d
+    g = 0
+    while g < n_total:
+        c, b = divmod(g, Bc)
+        k, d = ox.extract(frame_sets[last_out[c]["which"]][g])
+        res[g] = (k, d)
         n_kp += len(k)
-        n_frames += 1
-        i += 1
-        if time.perf_counter() - t0 > budget_s and n_frames >= 8:
+        if b % 8:
+            pairs[g] = ob.robust_brute_force_match(res[g - 1][1], d, None, LOWE_RATIO)
+            n_match += len(pairs[g])
+        first = c * Bc + (b // 8) * 8
+        if b == min((b // 8) * 8 + 7, Bc - 1) and first != g:      # the scene is complete: its first frame is matched against its last
+            pairs[first] = ob.robust_brute_force_match(d, res[first][1], None, LOWE_RATIO)
+            n_match += len(pairs[first])
+        g += 1
+        if g % 8 == 0 and time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": round(n_kp / dt, 1), "unit": "keypoints+descriptors/s", "cores": threads, "kind": "port",
-            "kind_note": "scalar from-spec restatement (oracle/): no SIMD resize / FAST / GaussianBlur as upstream gets from OpenCV, so the ratio to it "
-                         "overstates what the GPU path gains over a real OpenVSLAM build",
-            "sample": "%d frames 1920x1080 (extract, OpenMP over levels) + %d brute_force_match calls, %.1f s wall" % (n_frames, n_frames - 1, dt),
-            "frames_per_sec": round(n_frames / dt, 3), "matches_per_sec": round(n_match / dt, 1)}
+    n_frames = g
+    # ---- parity of the timed step (outside the clock above)
+    bad = []
+    for g in range(n_frames):
+        c, b = divmod(g, Bc)
+        lo = last_out[c]
+        k, d = res[g]
+        n = int(lo["cnt"][b])
+        if n != len(k) or not np.array_equal(lo["kps"][b, :n].reshape(-1), k.view(np.uint8).reshape(-1)):
+            bad.append("frame %d: keypoint records (gpu %d, oracle %d)" % (g, n, len(k)))
+        elif not np.array_equal(lo["desc"][b, :n], d):
+            bad.append("frame %d: descriptors" % g)
+        if g in pairs:
+            m = int(lo["mcnt"][b])
+            if m != len(pairs[g]) or not np.array_equal(lo["pairs"][b, :m], pairs[g]):
+                bad.append("frame %d: match pairs (gpu %d, oracle %d)" % (g, m, len(pairs[g])))
+    parity = {"checked_frames": n_frames, "checked_match_problems": len(pairs), "bit_exact": not bad,
+              "what": "the LAST timed step's output buffers (28-byte keypoint records, 32-byte descriptors, brute_force_match index pairs) against the "
+                      "in-repo CPU oracle run on the same frames; the oracle is a from-spec restatement (upstream source unavailable: parity unpinned)",
+              **({"mismatches": bad[:8]} if bad else {})}
+    cpu = {"value": round(n_kp / dt, 1), "unit": "keypoints+descriptors/s", "cores": threads, "kind": "port",
+           "kind_note": "scalar from-spec restatement (oracle/): no SIMD resize / FAST / GaussianBlur as upstream gets from OpenCV, so the ratio to it "
+                        "overstates what the GPU path gains over a real OpenVSLAM build",
+           "sample": "%d frames 1920x1080 (extract, OpenMP over levels) + %d brute_force_match calls, %.1f s wall" % (n_frames, len(pairs), dt),
+           "frames_per_sec": round(n_frames / dt, 3), "matches_per_sec": round(n_match / dt, 1)}
+    return cpu, parity
 
 
 if __name__ == "__main__":

@@ -18,7 +18,7 @@ unsigned int area::match_in_consistent_area(data::frame& frm_1, data::frame& frm
     // both frames resident: module::initializer matches its init frame against every incoming frame until the map is created
     const int device = detail::device_of(frm_2);
     if (!detail::guarded("ovs_area_match_in_consistent_area_f", [&] {
-            const auto h1 = detail::device_handle_of(frm_1), h2 = detail::device_handle_of(frm_2);
+            const auto h1 = detail::device_handle_on(frm_1, device), h2 = detail::device_handle_of(frm_2);
             return ovs_area_match_in_consistent_area_f(detail::window_ctx(device).get(n2, n1), detail::dev(h1), detail::dev(h2),
                                                       reinterpret_cast<float*>(prev_matched_pts.data()), matched_indices_2_in_frm_1.data(), margin,
                                                       lowe_ratio_, check_orientation_ ? 1 : 0, &num_matches);

@@ -24,7 +24,7 @@ unsigned int bow_tree::match_frame_and_keyframe(data::keyframe* keyfrm, data::fr
     // keyframe's landmark flags and the two BoW feature vectors travel
     const int device = detail::device_of(frm);
     if (!detail::guarded("ovs_bow_match_frame_and_keyframe_f", [&] {
-            const auto hk = detail::device_handle_of(*keyfrm), hf = detail::device_handle_of(frm);
+            const auto hk = detail::device_handle_on(*keyfrm, device), hf = detail::device_handle_of(frm);
             return ovs_bow_match_frame_and_keyframe_f(detail::window_ctx(device).get(n_frm, n_kf), detail::dev(hk), valid.data(), kid.data(), kst.data(),
                                                      kit.data(), (int)kid.size(), detail::dev(hf), fid.data(), fst.data(), fit.data(), (int)fid.size(),
                                                      lowe_ratio_, check_orientation_ ? 1 : 0, matched.data(), &num_matches);
@@ -51,7 +51,7 @@ unsigned int bow_tree::match_keyframes(data::keyframe* keyfrm_1, data::keyframe*
     int32_t num_matches = 0;
     const int device = detail::device_of(*keyfrm_1);
     if (!detail::guarded("ovs_bow_match_keyframes_f", [&] {
-            const auto h1 = detail::device_handle_of(*keyfrm_1), h2 = detail::device_handle_of(*keyfrm_2);
+            const auto h1 = detail::device_handle_of(*keyfrm_1), h2 = detail::device_handle_on(*keyfrm_2, device);
             return ovs_bow_match_keyframes_f(detail::window_ctx(device).get(n2, n1), detail::dev(h1), v1.data(), id1.data(), st1.data(), it1.data(),
                                             (int)id1.size(), detail::dev(h2), v2.data(), id2.data(), st2.data(), it2.data(), (int)id2.size(), lowe_ratio_,
                                             check_orientation_ ? 1 : 0, matched.data(), &num_matches);

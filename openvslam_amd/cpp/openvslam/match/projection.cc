@@ -199,7 +199,7 @@ unsigned int projection::match_keyframes_mutually(data::keyframe* keyfrm_1, data
     const int nmax = n1 > n2 ? n1 : n2;
     const int device = detail::device_of(*keyfrm_1);
     if (!detail::guarded("ovs_projection_match_keyframes_mutually_f", [&] {
-            const auto h1 = detail::device_handle_of(*keyfrm_1), h2 = detail::device_handle_of(*keyfrm_2);
+            const auto h1 = detail::device_handle_of(*keyfrm_1), h2 = detail::device_handle_on(*keyfrm_2, device);
             return ovs_projection_match_keyframes_mutually_f(
                       detail::window_ctx(device).get(nmax, nmax), &cam_1, detail::dev(h1), pose_1, f1.pos.data(), f1.dist.data(), f1.desc.data(),
                       f1.valid.data(), &cam_2, detail::dev(h2), pose_2, f2.pos.data(), f2.dist.data(), f2.desc.data(), f2.valid.data(), (double)s_12, R, t,

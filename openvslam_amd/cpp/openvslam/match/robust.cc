@@ -163,7 +163,7 @@ unsigned int robust::match_for_triangulation(data::keyframe* keyfrm_1, data::key
     // create_new_landmarks calls this for ~10-20 covisible keyframes per new keyframe
     const int device = detail::device_of(*keyfrm_1);
     if (!detail::guarded("ovs_robust_match_for_triangulation_f", [&] {
-            const auto h1 = detail::device_handle_of(*keyfrm_1, true), h2 = detail::device_handle_of(*keyfrm_2, true);
+            const auto h1 = detail::device_handle_of(*keyfrm_1, true), h2 = detail::device_handle_on(*keyfrm_2, device, true);
             return ovs_robust_match_for_triangulation_f(detail::window_ctx(device).get(n2, n1), detail::dev(h1), has_1.data(), id1.data(), st1.data(),
                                                        it1.data(), (int)id1.size(), detail::dev(h2), has_2.data(), id2.data(), st2.data(), it2.data(),
                                                        (int)id2.size(), E, epipole, keyfrm_1->scale_factors_.data(),

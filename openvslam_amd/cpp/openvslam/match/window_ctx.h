@@ -3,6 +3,7 @@
 #pragma once
 #include <ovslam_hip.h>
 
+#include <atomic>
 #include <initializer_list>
 #include <memory>
 #include <mutex>
@@ -116,6 +117,38 @@ inline std::shared_ptr<void> device_handle_of(const F& frm, bool want_bearings =
             const int st = ovs_frame_dev_attach_bearings(static_cast<ovs_frame_dev*>(h), b.data());
             if (st != OVS_OK) throw util::device_error(st, std::string("ovs_frame_dev_attach_bearings: ") + ovs_last_error());
         });
+}
+// The handle of `frm` for a call that runs on `device`. Two-object matchers (bow_tree, area, match_for_triangulation,
+// match_keyframes_mutually) run on the first object's device; with frames spread over several GPUs (frame i -> GPU i mod G) the second
+// object may be resident elsewhere, and the ABI refuses a handle of another device (OVS_ERR_INVALID). Then a temporary handle is built on
+// the call's device from the host members (one upload, freed when the call returns); the object's own cache stays where it is.
+inline std::atomic<int>& foreign_handles_built() {   // counts the temporary handles; force_foreign_handles() makes EVERY call build one (test hook:
+    static std::atomic<int> n{0};                     // the foreign-device path on a one-GPU box)
+    return n;
+}
+inline std::atomic<bool>& force_foreign_handles() {
+    static std::atomic<bool> on{false};
+    return on;
+}
+template <class F>
+inline std::shared_ptr<void> device_handle_on(const F& frm, int device, bool want_bearings = false) {
+    if (frm.device_cache_->device == device && !force_foreign_handles().load()) return device_handle_of(frm, want_bearings);
+    ++foreign_handles_built();
+    const ovs_grid_params gp = grid_of(frm.camera_);
+    ovs_frame_dev* f = nullptr;
+    const bool stereo = !frm.stereo_x_right_.empty();
+    int st = ovs_frame_dev_create(device, &gp, reinterpret_cast<const ovs_keypoint*>(frm.undist_keypts_.data()), frm.descriptors_.data,
+                                  stereo ? frm.stereo_x_right_.data() : nullptr, (int32_t)frm.undist_keypts_.size(), &f);
+    if (st != OVS_OK) throw util::device_error(st, std::string("ovs_frame_dev_create (foreign device): ") + ovs_last_error());
+    std::shared_ptr<void> h(f, [](void* p) { ovs_frame_dev_destroy(static_cast<ovs_frame_dev*>(p)); });
+    if (want_bearings) {
+        std::vector<double> b(3 * frm.bearings_.size());
+        for (size_t i = 0; i < frm.bearings_.size(); ++i)
+            for (int a = 0; a < 3; ++a) b[3 * i + (size_t)a] = frm.bearings_[i](a);
+        st = ovs_frame_dev_attach_bearings(f, b.data());
+        if (st != OVS_OK) throw util::device_error(st, std::string("ovs_frame_dev_attach_bearings (foreign device): ") + ovs_last_error());
+    }
+    return h;
 }
 inline const ovs_frame_dev* dev(const std::shared_ptr<void>& h) { return static_cast<const ovs_frame_dev*>(h.get()); }
 template <class F>

@@ -21,6 +21,7 @@
 #include "openvslam/match/fuse.h"
 #include "openvslam/match/projection.h"
 #include "openvslam/match/robust.h"
+#include "openvslam/match/window_ctx.h"
 #include "openvslam/util/device_policy.h"
 
 #include <ovslam_hip.h>
@@ -213,6 +214,30 @@ int main(int argc, char** argv) {
         expect(c == ref, model == camera::model_type_t::Fisheye ? "a fisheye camera gives the perspective results (no refusal)" : "a radial-division camera gives the perspective results");
     }
     s.cam.model_type_ = camera::model_type_t::Perspective;
+    // ---- two-object matchers whose second object is resident on ANOTHER device (frame i -> GPU i mod G): the shim builds a temporary handle on
+    // the call's device instead of handing the ABI a foreign one (which it refuses with OVS_ERR_INVALID). On a one-GPU box the hook forces that
+    // path for every two-object call; with two devices the frames really live on different ones.
+    {
+        Objects o(s, 0);
+        Counts c;
+        match::detail::force_foreign_handles() = true;
+        const int before = match::detail::foreign_handles_built().load();
+        tracking_calls(s, o.fa, *o.kf, c);
+        mapping_calls(s, *o.kf, *o.kt1, *o.kt2, c);
+        match::detail::force_foreign_handles() = false;
+        expect(c == ref && match::detail::foreign_handles_built().load() >= before + 2, "temporary handles for the second object (forced): same results");
+    }
+    if (ovs_device_count() >= 2) {
+        Objects o(s, 0);
+        o.fb.device_cache_->device = 1;   // frame b, and the keyframes made from it (shared cache), live on device 1; frame a on device 0
+        Counts c;
+        const int before = match::detail::foreign_handles_built().load();
+        tracking_calls(s, o.fa, *o.kf, c);
+        mapping_calls(s, *o.kf, *o.kt1, *o.kt2, c);
+        expect(c == ref && match::detail::foreign_handles_built().load() > before, "frame on device 0, keyframe on device 1: same results, no exception");
+    } else {
+        std::printf("skip mixed devices: ovs_device_count() = %d\n", ovs_device_count());
+    }
     // ---- device 1
     if (ovs_device_count() >= 2) {
         Objects o(s, 1);

@@ -53,6 +53,20 @@ def test_single_gpu_line_has_the_contract_fields():
 
 
 @pytest.mark.gpu
+def test_parity_field_is_a_measurement_of_the_timed_step():
+    """`parity` in the bench line is computed, not printed: the last timed step's keypoint records, descriptors and match pairs (64-frame 1080p
+    batch, level-0 split, matcher overlapped on the second stream) against the CPU oracle on >= 8 of those frames; the popcount-form run of the
+    same schedule must leave the same outputs. A mismatch makes bench.py exit non-zero."""
+    r = _run("--steps", "3", "--warmup", "1", "--no-ba", "--batch", "64", "--live-pmc", "0", "--cpu-budget-s", "1", timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    par = d["parity"]
+    assert par["bit_exact"] is True and par["checked_frames"] >= 8 and par["checked_match_problems"] >= 8
+    assert d["popcount_near_path_same_outputs_as_value_run"] is True and d["value_popcount_near_path"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.gpu
 def test_two_ranks_code_path_on_one_device():
     """`bench.py --gpus 2` end to end on a one-GPU box: the script starts its two ranks itself (torch.distributed.run on 127.0.0.1); the
     OVS_BENCH_ONE_DEVICE test hook puts both on device 0 over gloo. Checks what the driver's scaling run relies on: ONE JSON line, from rank 0,

@@ -25,3 +25,13 @@ def test_fuzz_slice(oracle, seed):
     assert fz.fuzz_reprojection(rng, 3, lines.append), lines[-4:]
     assert fz.fuzz_sim3(rng, 2, lines.append), lines[-4:]
     assert len(lines) > 50
+
+
+@pytest.mark.parametrize("seed", [2024, 7])
+def test_tie_heavy_small_cases(oracle, seed):
+    """tools/tie_fuzz_gpu.py inside the suite: 150 small cases per seed whose outcome only the tie rules decide (three base descriptors, a 5-px
+    lattice, six angles) through brute_force_match, area, both bow_tree matchers and projection::match_frame_and_landmarks, against the oracle:
+    where a parallel resolver and a sequential loop would diverge if the replay order were wrong."""
+    import tie_fuzz_gpu
+    bad = tie_fuzz_gpu.run(150, seed)
+    assert not any(bad.values()), bad

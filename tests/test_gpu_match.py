@@ -183,3 +183,32 @@ def test_near_paths_agree_on_large_batch(match):
     for b in range(B):
         k = out["matrix"][1][b]
         assert np.array_equal(out["matrix"][0][b, :k], out["popcount"][0][b, :k])
+
+
+def test_full_size_batch_against_the_oracle(match, oracle, near_path):
+    """The regime bench.py times: one launch over 64 problems of ~2000 x 2000 (cap 2048). 16 of the 64 problems (every fourth) are compared
+    with the CPU oracle pair by pair; duplicates clusters and heavy-noise rows keep the claim resolver and the ratio test busy."""
+    import torch
+    rng = np.random.default_rng(19)
+    B, cap = 64, 2048
+    n1 = rng.integers(1900, 2049, B).astype(np.int32)
+    n2 = rng.integers(1900, 2049, B).astype(np.int32)
+    n1[0] = n2[0] = cap
+    d2 = rng.integers(0, 256, size=(B, cap, 32), dtype=np.uint8)
+    d1 = d2[:, rng.permutation(cap)].copy()
+    d1 ^= (rng.random((B, cap, 32)) < 0.03).astype(np.uint8) * rng.integers(1, 256, size=(B, cap, 32), dtype=np.uint8)
+    d1[:, 100:140] = d1[:, 100:101]                                 # duplicates: several frame descriptors claim one keyframe descriptor
+    d2[:, 500:520] = d2[:, 500:501]                                 # and the other way round: best == second best, the ratio test rejects
+    d1[:, 900:1000] ^= (rng.random((B, 100, 32)) < 0.25).astype(np.uint8) * rng.integers(1, 256, size=(B, 100, 32), dtype=np.uint8)  # around THR_LOW
+    td1, td2 = torch.from_numpy(d1).cuda(), torch.from_numpy(d2).cuda()
+    tn1, tn2 = torch.from_numpy(n1).cuda(), torch.from_numpy(n2).cuda()
+    m = match.robust(0.9, False, max_n1=cap, max_n2=cap, max_batch=B, near_path=near_path)
+    pairs = torch.zeros((B, cap, 2), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    m.brute_force_match_batch_dev(td1, tn1, td2, tn2, pairs, cnt, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    pairs, cnt = pairs.cpu().numpy(), cnt.cpu().numpy()
+    for b in range(0, B, 4):
+        want = oracle.robust_brute_force_match(d1[b, :n1[b]], d2[b, :n2[b]], None, 0.9)
+        assert len(want) > 1000
+        assert cnt[b] == len(want) and np.array_equal(pairs[b, :cnt[b]], want), b

@@ -1,5 +1,7 @@
 """GPU parity: HIP orb_extractor (through the C ABI) == CPU oracle, bit for bit, stage by stage and end to end.
 Oracle = from-spec restatement (PARITY UNPINNED vs upstream, see oracle/ovo_oracle.h)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -234,6 +236,37 @@ def test_large_batch_takes_the_many_problem_tree_kernel(hip, oracle):
             assert cnt[b] == len(wk)
             assert np.array_equal(kps[b, :cnt[b]].reshape(-1), wk.view(np.uint8).reshape(-1))
             assert np.array_equal(desc[b, :cnt[b]], wd)
+
+
+@pytest.mark.parametrize("split", [True, False])
+def test_timed_regime_1080p_batch_of_64_against_the_oracle(hip, oracle, split):
+    """The regime bench.py times (SURVEY 8(d), configs[1]): a device-resident 1920x1080 batch of 64 frames, 2000 features -- six-cell FAST
+    workgroups, XCD-sliced launches, k_tree<512> with ~10 k candidates per level-0 problem, level-0 split on and off. 16 of the 64 frames
+    (every fourth; both 8-frame scene positions) are compared with the CPU oracle: 28-byte keypoint records and descriptors, byte for byte."""
+    import torch
+    from openvslam_amd.synth import synth_video
+    rows, cols, B = 1080, 1920, 64
+    imgs = synth_video(rows, cols, B, seed=321)
+    ex = hip.orb_extractor(hip.orb_params(2000, 1.2, 8, 20, 7), max_rows=rows, max_cols=cols, max_batch=B)
+    ex.set_fast_split(split)
+    cap = ex.max_keypoints
+    d_img = torch.from_numpy(imgs).cuda()
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    for _ in range(2):   # twice: the second call runs on warm pools and recycled scratch, as every timed step does
+        ex.extract_batch_dev(d_img, d_kps, d_desc, d_cnt, stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    cnt = d_cnt.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+    desc = d_desc.cpu().numpy()
+    ox = oracle.OrbExtractor(oracle.make_params(2000), threads=min(8, os.cpu_count() or 1))
+    for b in list(range(0, B, 4)) + [B - 1]:
+        wk, wd = ox.extract(imgs[b])
+        assert cnt[b] == len(wk) and len(wk) > 1500, b
+        assert np.array_equal(kps[b, :cnt[b]].reshape(-1), wk.view(np.uint8).reshape(-1)), b
+        assert np.array_equal(desc[b, :cnt[b]], wd), b
 
 
 def test_two_extractors_run_concurrently_from_two_threads(hip, oracle):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""GPU side of tests/test_nversion.py::test_small_tie_heavy_cases_of_every_list_matcher (written without a device at the end of round 4: run it
-first thing in round 5, tools/gpu_r05_a.sh): small random cases whose outcome only the tie rules decide -- descriptors from three base patterns,
+"""GPU side of tests/test_nversion.py::test_small_tie_heavy_cases_of_every_list_matcher (also a -m gpu test since round 5:
+tests/test_gpu_fuzz.py::test_tie_heavy_small_cases): small random cases whose outcome only the tie rules decide -- descriptors from three base patterns,
 positions on a 5-px lattice (window edges), a handful of angles -- through the HIP matchers and the CPU oracle. Prints one line per matcher,
 exits 1 on any difference. Usage: python tools/tie_fuzz_gpu.py [cases]"""
 import os
@@ -14,10 +14,10 @@ from oracle import binding as oracle   # noqa: E402  (the checker)
 from openvslam_amd import match       # noqa: E402
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+def run(cases=300, seed=2024):
+    """-> {matcher: number of cases whose result differs from the oracle's}"""
     oracle.build()
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(seed)
     cols, rows = 200, 120
     gp, ogp = match.grid_params(cols, rows), oracle.grid_params(cols, rows)
     sf = (1.2 ** np.arange(8)).astype(np.float32)
@@ -78,6 +78,12 @@ def main():
         got, gn = m_proj.match_frame_and_landmarks(gp, k1, d1, sf, lm_xy, lvl, ld, float(margin), frm_occupied=occ)
         want, wn = oracle.projection_match_frame_and_landmarks(ogp, k1, d1, sf, lm_xy, lvl, ld, float(margin), ratio, frm_occupied=occ)
         bad["frame_and_landmarks"] += int(not (gn == wn and np.array_equal(got, want)))
+    return bad
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    bad = run(cases)
     for name, n in bad.items():
         print("%-22s %4d cases, %d differ from the oracle" % (name, cases, n))
     sys.exit(1 if any(bad.values()) else 0)
