@@ -377,20 +377,26 @@ def main():
         for ch, lo_ in zip(chains, last_out):
             k, which = ch.last
             b = ch.bufs[k]
-            popc_sched_same = popc_sched_same and which == lo_["which"] and np.array_equal(b["cnt"].cpu().numpy(), lo_["cnt"]) \
-                and np.array_equal(b["mcnt"].cpu().numpy(), lo_["mcnt"]) and np.array_equal(b["desc"].cpu().numpy(), lo_["desc"])
-            pr = b["pairs"].cpu().numpy()
-            for i in range(Bc):
-                popc_sched_same = popc_sched_same and np.array_equal(pr[i, :lo_["mcnt"][i]], lo_["pairs"][i, :lo_["mcnt"][i]])
+            cnt_, mcnt_ = b["cnt"].cpu().numpy(), b["mcnt"].cpu().numpy()
+            popc_sched_same = popc_sched_same and which == lo_["which"] and np.array_equal(cnt_, lo_["cnt"]) and np.array_equal(mcnt_, lo_["mcnt"])
+            if popc_sched_same:   # rows behind a frame's count are stale bytes of earlier steps: compare the valid prefixes only
+                ds, pr = b["desc"].cpu().numpy(), b["pairs"].cpu().numpy()
+                kp_ = b["kps"].cpu().numpy().view(np.uint8).reshape(Bc, -1, 28)
+                for i in range(Bc):
+                    popc_sched_same = popc_sched_same and np.array_equal(ds[i, :cnt_[i]], lo_["desc"][i, :cnt_[i]]) \
+                        and np.array_equal(kp_[i, :cnt_[i]], lo_["kps"][i, :cnt_[i]]) and np.array_equal(pr[i, :mcnt_[i]], lo_["pairs"][i, :mcnt_[i]])
     for ch in chains:
         ch.mt.set_near_path("matrix")
 
+    # units per step: with two output buffer sets each one is permanently paired with one of the two alternating input batches (step parity
+    # picks both), so the mean over the buffer sets is the exact per-step average of the timed region (K even; +-1 step's difference else)
     kp_step = matches_step = pairs_step = 0
     for ch in chains:
-        cnt = ch.bufs[0]["cnt"].cpu().numpy().astype(np.int64)
-        kp_step += int(cnt.sum())
-        matches_step += int(ch.bufs[0]["mcnt"].cpu().numpy().astype(np.int64).sum())
-        pairs_step += int((cnt * cnt[ch.prev.cpu().numpy()]).sum())
+        for b in ch.bufs:
+            cnt = b["cnt"].cpu().numpy().astype(np.int64)
+            kp_step += cnt.sum() / float(ch.n_buf)
+            matches_step += b["mcnt"].cpu().numpy().astype(np.int64).sum() / float(ch.n_buf)
+            pairs_step += (cnt * cnt[ch.prev.cpu().numpy()]).sum() / float(ch.n_buf)
     totals = torch.tensor([kp_step, matches_step, pairs_step], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <stdint.h>
 
@@ -129,18 +130,18 @@ const Tuning& tuning();
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: remember the largest size set for one kernel on every device
 struct LdsAttrCache {
     std::atomic<size_t> set[kMaxTuningDevices] = {};
+    std::mutex mu;   // hipFuncSetAttribute is last-writer-wins: two threads' first launches with different sizes must not leave the smaller one set
 };
 inline hipError_t ensure_dynamic_lds(const void* fn, size_t bytes, LdsAttrCache& c) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const bool cached = dev >= 0 && dev < kMaxTuningDevices;
-    if (cached && bytes <= c.set[dev].load(std::memory_order_acquire)) return hipSuccess;
+    if (cached && bytes <= c.set[dev].load(std::memory_order_acquire)) return hipSuccess;   // fast path: no lock once the size is covered
+    std::lock_guard<std::mutex> lock(c.mu);
+    if (cached && bytes <= c.set[dev].load(std::memory_order_acquire)) return hipSuccess;   // another thread set at least this much meanwhile
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess && cached) {
-        size_t cur = c.set[dev].load(std::memory_order_relaxed);
-        while (cur < bytes && !c.set[dev].compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
-    }
+    if (e == hipSuccess && cached) c.set[dev].store(bytes, std::memory_order_release);       // under the lock the attribute only ever grows
     return e;
 }
 
