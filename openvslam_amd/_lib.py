@@ -51,6 +51,7 @@ SYMBOLS = {
     "ovs_orb_extract_batch_dev": (_i32, [_vp, _vp, _i32, _i32, _i32, _sz, _sz, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ovs_orb_set_pipeline": (_i32, [_vp, _i32]),
     "ovs_orb_set_fast_split": (_i32, [_vp, _i32]),
+    "ovs_orb_set_pyramid_chain": (_i32, [_vp, _i32]),
     "ovs_orb_set_variant": (_i32, [_vp, _i32, _i32]),
     "ovs_orb_profile_read_aux": (_i32, [_vp, C.POINTER(_f), C.POINTER(_i32)]),
     "ovs_orb_pyramid_level": (_i32, [_vp, _i32, _i32, _vp, C.POINTER(_i32), C.POINTER(_i32)]),

@@ -36,6 +36,7 @@ const Tuning& tuning() {
         v.pose_threads = num("OVS_POSE_THREADS", 0);
         v.pose_groups = std::max(0, num("OVS_POSE_GROUPS", 0));
         v.ba_trace = std::getenv("OVS_BA_TRACE") != nullptr;
+        v.pyr_chain = std::max(0, num("OVS_PYR_CHAIN", 2));
         return v;
     }();
     return t;
@@ -88,6 +89,90 @@ static bool resize_windows_ok(const ResizeTap* xt, int dcols, const ResizeTap* y
     return true;
 }
 
+
+// The tile grid and the per-level regions of k_pyramid_chain (orb_pyramid.hip) for one geometry. Both axes separately: tile t of T owns
+// [t size_l / T, (t + 1) size_l / T) of level l (a partition of every level); it computes, bottom-up, R_{L-1} = owned and
+// R_{l-1} = hull(owned_{l-1}, tap footprint of R_l); R_0 is the footprint alone (level 0 is only read). ok = false when a region exceeds what
+// the kernel stages (unusual scale factors or level counts): the per-level launches run then.
+struct ChainPlanHost {
+    bool ok = false;
+    int TX = 0, TY = 0, bufA = 0, bufB = 0, tap_cap = 0;
+    std::vector<ChainSpan> spans;   // [level][TX x-spans, TY y-spans]
+};
+static void build_chain_plan(const FrameGeo& geo, const std::vector<ResizeTap>& taps, ChainPlanHost& out) {
+    out = ChainPlanHost();
+    const int L = geo.num_levels;
+    if (L < 2) return;
+    const int TX = std::max(1, (geo.lv[0].cols + 127) / 128), TY = std::max(1, (geo.lv[0].rows + 95) / 96);
+    out.TX = TX;
+    out.TY = TY;
+    out.spans.assign((size_t)L * (TX + TY), ChainSpan{0, 0, 0, 0});
+    bool ok = true;
+    for (int axis = 0; axis < 2; ++axis) {
+        const int T = axis ? TY : TX;
+        for (int t = 0; t < T; ++t) {
+            int c0[OVS_MAX_LEVELS], c1[OVS_MAX_LEVELS], o0[OVS_MAX_LEVELS], o1[OVS_MAX_LEVELS];
+            for (int l = 0; l < L; ++l) {
+                const int64_t size = axis ? geo.lv[l].rows : geo.lv[l].cols;
+                o0[l] = (int)(t * size / T);
+                o1[l] = (int)((t + 1) * size / T);
+            }
+            c0[L - 1] = o0[L - 1];
+            c1[L - 1] = o1[L - 1];
+            for (int l = L - 1; l >= 1; --l) {
+                const ResizeTap* tab = taps.data() + (axis ? geo.lv[l].ytab_off : geo.lv[l].xtab_off);
+                int f0 = 0, f1 = 0;
+                if (c1[l] > c0[l]) {
+                    f0 = tab[c0[l]].o0;
+                    f1 = tab[c1[l] - 1].o1 + 1;
+                    for (int i = c0[l]; i < c1[l]; ++i) {   // (the tables are monotone; this does not rely on it)
+                        f0 = std::min(f0, (int)tab[i].o0);
+                        f1 = std::max(f1, (int)tab[i].o1 + 1);
+                    }
+                }
+                if (l - 1 == 0) {
+                    o0[0] = o1[0] = 0;
+                    c0[0] = axis ? f0 : (f0 & ~3);
+                    c1[0] = f1;
+                } else if (o1[l - 1] > o0[l - 1] && f1 > f0) {
+                    c0[l - 1] = std::min(o0[l - 1], f0);
+                    c1[l - 1] = std::max(o1[l - 1], f1);
+                } else if (f1 > f0) {
+                    c0[l - 1] = f0;
+                    c1[l - 1] = f1;
+                } else {
+                    c0[l - 1] = o0[l - 1];
+                    c1[l - 1] = o1[l - 1];
+                }
+            }
+            for (int l = 0; l < L; ++l) {
+                if (c1[l] > 32767) ok = false;
+                out.spans[(size_t)l * (TX + TY) + (axis ? TX + t : t)] = ChainSpan{(int16_t)c0[l], (int16_t)c1[l], (int16_t)o0[l], (int16_t)o1[l]};
+                const int ext = c1[l] - c0[l];
+                if (l == 0 ? (axis ? ext > kChainMaxH0 : ext > kChainMaxW0) : (!axis && ext > kChainMaxW)) ok = false;
+            }
+        }
+    }
+    // LDS: level 0, 2, 4, .. regions in buffer A, the odd levels in buffer B; the taps of the tile with the most of them
+    int bufA = 16, bufB = 16, tap_cap = 0;
+    for (int tj = 0; tj < TY; ++tj)
+        for (int ti = 0; ti < TX; ++ti) {
+            int ntap = 0;
+            for (int l = 0; l < L; ++l) {
+                const ChainSpan X = out.spans[(size_t)l * (TX + TY) + ti], Y = out.spans[(size_t)l * (TX + TY) + TX + tj];
+                const int W = X.c1 - X.c0, H = Y.c1 - Y.c0, bytes = (((W + 3) & ~3) * H + 15) & ~15;
+                (l & 1 ? bufB : bufA) = std::max(l & 1 ? bufB : bufA, bytes);
+                if (l >= 1) ntap += W + H;
+            }
+            tap_cap = std::max(tap_cap, ntap);
+        }
+    out.bufA = bufA;
+    out.bufB = bufB;
+    out.tap_cap = tap_cap;
+    if (chain_lds_bytes(bufA, bufB, tap_cap) > (size_t)kChainMaxLds) ok = false;
+    out.ok = ok;
+}
+
 }   // namespace ovs
 
 using namespace ovs;
@@ -110,6 +195,9 @@ struct ovs_orb {
     size_t taps_cap = 0;
     CellDesc* d_cells = nullptr;
     size_t cells_cap = 0;
+    ChainPlanHost chain;             // k_pyramid_chain's tile grid and regions for the current geometry (chain.ok: usable)
+    ChainSpan* d_chain = nullptr;    // its spans on the device
+    size_t chain_cap = 0;
     int32_t variant = 0;   // FrameGeo::variant
     DevBuffers d{};
     size_t pyr_cap = 0, cand_cap = 0, node_cap = 0, kps_cap = 0;
@@ -173,6 +261,7 @@ struct ovs_orb {
     // FAST on level 0 needs no pyramid: it runs on aux_stream BESIDE the seven resize launches (VALU-bound next to latency / bandwidth-bound),
     // the remaining levels follow the pyramid on the main stream (ovs_orb_set_fast_split; default on)
     bool fast_split = true;
+    bool pyr_chain_enabled = true;   // ovs_orb_set_variant-independent A/B switch of the one-launch pyramid (ovs_orb_set_pyramid_chain)
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_aux_fork = nullptr, ev_aux_join = nullptr;
     StageProfiler<1> prof_aux;
@@ -336,6 +425,13 @@ ovs_status ensure_geometry(ovs_orb* h, int rows, int cols) {
     OVS_HIP_TRY(hipMemcpy(h->d_geo, &geo, sizeof(FrameGeo), hipMemcpyHostToDevice));
     if (!taps.empty()) OVS_HIP_TRY(hipMemcpy(h->d_taps, taps.data(), taps.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
     if (!cells.empty()) OVS_HIP_TRY(hipMemcpy(h->d_cells, cells.data(), cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
+    ChainPlanHost chain;
+    build_chain_plan(geo, taps, chain);
+    if (chain.ok && chain.spans.size() <= h->chain_cap)
+        OVS_HIP_TRY(hipMemcpy(h->d_chain, chain.spans.data(), chain.spans.size() * sizeof(ChainSpan), hipMemcpyHostToDevice));
+    else
+        chain.ok = false;
+    h->chain = std::move(chain);
     h->geo = geo;
     h->taps.swap(taps);
     h->cur_rows = rows;
@@ -371,8 +467,13 @@ ovs_status run_chain(ovs_orb* h, StageProfiler<4>& prof, const uint8_t* d_images
         OVS_HIP_TRY(launch_tree(geo, d, nb, h->aux_stream, 0, 1));
         OVS_HIP_TRY(hipEventRecord(h->ev_aux_join, h->aux_stream));
     }
-    // A1: each level from the previous one
-    for (int l = 1; l < L; ++l) {
+    // A1: each level from the previous one -- for a tracker's single frame (or a stereo pair) all levels in ONE launch (k_pyramid_chain: the
+    // seven dependent launches cost 40 us of a 0.24 ms extract), for batches level by level (the throughput form)
+    const bool chained = h->chain.ok && L > 1 && nb <= tuning().pyr_chain && h->pyr_chain_enabled && !((uintptr_t)img & 3) && !(frame_stride & 3) && !(stride & 3);
+    if (chained)
+        OVS_HIP_TRY(launch_pyramid_chain(img, frame_stride, (int)stride, d.pyr, d.pyr_frame_bytes, d.geo, h->d_taps, h->d_chain, h->chain.TX, h->chain.TY,
+                                         h->chain.bufA, h->chain.bufB, h->chain.tap_cap, nb, s));
+    for (int l = 1; l < L && !chained; ++l) {
         const LevelGeo& g = geo.lv[l];
         const LevelGeo& gp = geo.lv[l - 1];
         const uint8_t* src = (l == 1) ? img : d.pyr + gp.plane_off;
@@ -552,6 +653,8 @@ ovs_status ovs_orb_create(const ovs_orb_params* params, int32_t max_rows, int32_
     CREATE_TRY(hipMalloc(&h->d_taps, h->taps_cap * sizeof(ResizeTap)));
     h->cells_cap = cells_max.size() + 64;   // (the cell count is monotone in rows and cols: the largest image has the most cells)
     CREATE_TRY(hipMalloc(&h->d_cells, h->cells_cap * sizeof(CellDesc)));
+    h->chain_cap = (size_t)L * ((size_t)(max_cols + 127) / 128 + (size_t)(max_rows + 95) / 96 + 2);   // (the tile grid is monotone in rows and cols)
+    CREATE_TRY(hipMalloc(&h->d_chain, h->chain_cap * sizeof(ChainSpan)));
     CREATE_TRY(hipMalloc(&h->d.pyr, std::max<size_t>(h->d.pyr_frame_bytes * B, 256)));
     CREATE_TRY(hipMalloc(&h->d.cand, std::max<size_t>(cand_entries * B * sizeof(uint64_t), 256)));
     CREATE_TRY(hipMalloc(&h->d.cand_count, sizeof(uint32_t) * B * L));
@@ -598,6 +701,7 @@ ovs_status ovs_orb_destroy(ovs_orb* h) {
     hipFree(h->d_geo);
     hipFree(h->d_taps);
     hipFree(h->d_cells);
+    hipFree(h->d_chain);
     hipFree(h->d.pyr);
     hipFree(h->d.cand);
     hipFree(h->d.cand_count);
@@ -718,6 +822,12 @@ ovs_status ovs_debug_inject_hip_failures(int32_t skip_calls, int32_t n_calls) {
 ovs_status ovs_orb_set_fast_split(ovs_orb* h, int32_t enable) {
     if (!h) return OVS_ERR_INVALID;
     h->fast_split = enable != 0;
+    return OVS_OK;
+}
+
+ovs_status ovs_orb_set_pyramid_chain(ovs_orb* h, int32_t enable) {
+    if (!h) return OVS_ERR_INVALID;
+    h->pyr_chain_enabled = enable != 0;
     return OVS_OK;
 }
 

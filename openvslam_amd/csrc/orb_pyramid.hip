@@ -358,4 +358,145 @@ hipError_t launch_resize(const uint8_t* src, size_t src_frame_stride, int src_pi
     return hipGetLastError();
 }
 
+// ================================================================================================================================
+// k_pyramid_chain (round 5): ALL levels of ONE frame (or a few) in a single launch -- the tracker's per-frame extract spent 7 x 5.7 us in
+// seven DEPENDENT resize launches (plus the gaps between them) for ~1 us of arithmetic each (profiles/r04g_tracked_frame_trace.txt).
+// A workgroup owns one tile of every level (the levels are partitioned by the same TX x TY grid, proportionally) and computes the chain
+// level 0 -> 1 -> ... -> L-1 for its tile entirely in LDS: the region R_l it computes at level l is its owned tile plus whatever the next
+// level's region needs of level l (the tap footprint: a halo of 1-2 pixels per level and side, recomputed redundantly by the neighbours --
+// identical integers, and only the OWNED pixels are stored to the level's plane). No workgroup waits for another one, so there are no
+// flags, no grid barrier and no ordering between launches: one launch, L - 1 workgroup barriers. The regions (ChainSpan, per level and tile
+// column / row) are computed on the host with the tap tables (orb_api.hip build_chain_plan); the arithmetic is the generic kernel's
+// (the same integers as v4): h = (S[o0] a0 + S[o1] a1) >> 4 per source row, out = (((b0 h0) >> 16) + ((b1 h1) >> 16) + 2) >> 2.
+// Throughput is NOT the point (about 1.2x the pixels, byte-wise LDS reads): the batch path keeps the per-level kernels above.
+constexpr int kChainThreads = 1024;
+constexpr int kChainRowsPerThread = 8;   // level-0 staging: 16 waves x 8 rows = at most 128 source rows, one row of <= 64 words per wave step
+
+__global__ __launch_bounds__(kChainThreads) void k_pyramid_chain(const uint8_t* __restrict__ img0, size_t frame_stride0, int pitch0,
+                                                                uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
+                                                                const FrameGeo* __restrict__ geo, const ResizeTap* __restrict__ taps,
+                                                                const ChainSpan* __restrict__ plan, int TX, int TY, int bufA_bytes,
+                                                                int bufB_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t chain_smem[];
+    uint8_t* const bufA = chain_smem;
+    uint8_t* const bufB = chain_smem + bufA_bytes;
+    ChainSpan* const s_span = reinterpret_cast<ChainSpan*>(chain_smem + bufA_bytes + bufB_bytes);   // [2 * OVS_MAX_LEVELS]: x spans, then y spans
+    int4* const s_lv = reinterpret_cast<int4*>(s_span + 2 * OVS_MAX_LEVELS);                          // [OVS_MAX_LEVELS]: xtab_off, ytab_off, plane_off, pitch
+    ResizeTap* const s_tap = reinterpret_cast<ResizeTap*>(s_lv + OVS_MAX_LEVELS);                     // per level l >= 1: W_l x-taps, then H_l y-taps
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = TX * TY;
+    const int frame = (int)blockIdx.x / tiles, tile = (int)blockIdx.x - frame * tiles;
+    const int tj = tile / TX, ti = tile - tj * TX;
+    const int L = geo->num_levels;
+    // ---- this tile's spans -> LDS (one global round trip)
+    if (tid < 2 * L) {
+        const int l = tid < L ? tid : tid - L;
+        s_span[tid < L ? l : OVS_MAX_LEVELS + l] = plan[l * (TX + TY) + (tid < L ? ti : TX + tj)];
+        if (tid < L) s_lv[l] = int4{(int)geo->lv[l].xtab_off, (int)geo->lv[l].ytab_off, (int)geo->lv[l].plane_off, geo->lv[l].pitch};
+    }
+    __syncthreads();
+    // ---- every tap this tile needs (one per thread and round) and the level-0 source rectangle: all requests first, then the LDS writes
+    int n_taps = 0;
+    for (int l = 1; l < L; ++l) n_taps += (s_span[l].c1 - s_span[l].c0) + (s_span[OVS_MAX_LEVELS + l].c1 - s_span[OVS_MAX_LEVELS + l].c0);
+    const ChainSpan X0 = s_span[0], Y0 = s_span[OVS_MAX_LEVELS];
+    const int sp0 = ((X0.c1 - X0.c0) + 3) & ~3, nw0 = sp0 >> 2, H0 = Y0.c1 - Y0.c0;
+    const uint8_t* const s0 = img0 + (size_t)frame * frame_stride0;
+    uint32_t v0[kChainRowsPerThread];
+#pragma unroll
+    for (int k = 0; k < kChainRowsPerThread; ++k) {
+        const int r = wave + 16 * k;
+        v0[k] = 0;
+        if (r < H0 && lane < nw0) {
+            const int gx = X0.c0 + 4 * lane;
+            const uint8_t* p = s0 + (size_t)(Y0.c0 + r) * pitch0 + gx;
+            if (gx + 4 <= pitch0) {   // (base, pitch and frame stride are multiples of 4: the launcher's condition)
+                v0[k] = *reinterpret_cast<const uint32_t*>(p);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (gx + b < pitch0) v0[k] |= (uint32_t)p[b] << (8 * b);
+            }
+        }
+    }
+    for (int base = 0; base < n_taps; base += kChainThreads) {
+        const int t = base + tid;
+        int src = -1, cum = 0;
+        for (int l = 1; l < L; ++l) {
+            const ChainSpan X = s_span[l], Y = s_span[OVS_MAX_LEVELS + l];
+            const int W = X.c1 - X.c0, H = Y.c1 - Y.c0;
+            if (t >= cum && t < cum + W + H) {
+                const int u = t - cum;
+                src = u < W ? s_lv[l].x + X.c0 + u : s_lv[l].y + Y.c0 + (u - W);
+            }
+            cum += W + H;
+        }
+        if (src >= 0) s_tap[t] = taps[src];
+    }
+#pragma unroll
+    for (int k = 0; k < kChainRowsPerThread; ++k) {
+        const int r = wave + 16 * k;
+        if (r < H0 && lane < nw0) reinterpret_cast<uint32_t*>(bufA)[r * nw0 + lane] = v0[k];
+    }
+    __syncthreads();
+    // ---- the chain
+    const uint8_t* S = bufA;
+    uint8_t* D = bufB;
+    int sx0 = X0.c0, sy0 = Y0.c0, sp = sp0, tap_off = 0;
+    uint8_t* const pf = pyr + (size_t)frame * pyr_frame_bytes;
+    for (int l = 1; l < L; ++l) {
+        const ChainSpan X = s_span[l], Y = s_span[OVS_MAX_LEVELS + l];
+        const int W = X.c1 - X.c0, H = Y.c1 - Y.c0, dp = (W + 3) & ~3;
+        const ResizeTap* const xt = s_tap + tap_off;
+        const ResizeTap* const yt = xt + W;
+        if (W > 0 && H > 0) {
+            const int nchunk = (W + 63) >> 6, nrg = 16 / nchunk;
+            const int chunk = wave % nchunk, rg = wave / nchunk;
+            const int x = chunk * 64 + lane;
+            if (rg < nrg && x < W) {
+                const ResizeTap tx = xt[x];
+                const int xo0 = (int)tx.o0 - sx0, xo1 = (int)tx.o1 - sx0, a0 = tx.a0, a1 = tx.a1;
+                const bool own_x = X.c0 + x >= X.o0 && X.c0 + x < X.o1;
+                const int gpitch = s_lv[l].w;
+                uint8_t* const g = pf + (size_t)s_lv[l].z + (size_t)Y.c0 * gpitch + X.c0 + x;
+#pragma unroll 4
+                for (int y = rg; y < H; y += nrg) {
+                    const ResizeTap ty = yt[y];
+                    const int r0 = ((int)ty.o0 - sy0) * sp, r1 = ((int)ty.o1 - sy0) * sp;
+                    const int s00 = S[r0 + xo0], s01 = S[r0 + xo1], s10 = S[r1 + xo0], s11 = S[r1 + xo1];
+                    const int h0 = (s00 * a0 + s01 * a1) >> 4, h1 = (s10 * a0 + s11 * a1) >> 4;
+                    int v = ((((int)ty.a0 * h0) >> 16) + (((int)ty.a1 * h1) >> 16) + 2) >> 2;
+                    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                    D[y * dp + x] = (uint8_t)v;
+                    if (own_x && Y.c0 + y >= Y.o0 && Y.c0 + y < Y.o1) g[(size_t)y * gpitch] = (uint8_t)v;
+                }
+            }
+        }
+        __syncthreads();
+        tap_off += W + H;
+        sx0 = X.c0;
+        sy0 = Y.c0;
+        sp = dp;
+        const uint8_t* const t = S;
+        S = D;
+        D = const_cast<uint8_t*>(t);
+    }
+}
+
+size_t chain_lds_bytes(int bufA_bytes, int bufB_bytes, int tap_cap) {
+    return (size_t)bufA_bytes + bufB_bytes + sizeof(ChainSpan) * 2 * OVS_MAX_LEVELS + sizeof(int4) * OVS_MAX_LEVELS + sizeof(ResizeTap) * (size_t)tap_cap;
+}
+
+// plan: L x (TX + TY) spans in device memory (orb_api.hip build_chain_plan, uploaded by ensure_geometry); lds = bufA + bufB + spans + taps
+hipError_t launch_pyramid_chain(const uint8_t* img0, size_t frame_stride0, int pitch0, uint8_t* pyr, size_t pyr_frame_bytes, const FrameGeo* d_geo,
+                                const ResizeTap* d_taps, const ChainSpan* d_plan, int TX, int TY, int bufA_bytes, int bufB_bytes, int tap_cap,
+                                int batch, hipStream_t s) {
+    const size_t lds = chain_lds_bytes(bufA_bytes, bufB_bytes, tap_cap);
+    if ((reinterpret_cast<uintptr_t>(img0) & 3) || (frame_stride0 & 3) || (pitch0 & 3)) return hipErrorInvalidValue;   // chain_usable() says so first
+    dim3 grid((unsigned)(TX * TY * batch));
+    hipLaunchKernelGGL(k_pyramid_chain, grid, dim3(kChainThreads), lds, s, img0, frame_stride0, pitch0, pyr, pyr_frame_bytes, d_geo, d_taps, d_plan, TX,
+                       TY, bufA_bytes, bufB_bytes);
+    return hipGetLastError();
+}
+
 }   // namespace ovs

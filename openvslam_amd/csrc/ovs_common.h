@@ -100,7 +100,22 @@ struct DevBuffers {
     uint32_t* lvl_count;          // max_batch * num_levels
 };
 
+// k_pyramid_chain (orb_pyramid.hip): what one tile column (or row) of the TX x TY tile grid covers of one level: the pixels it COMPUTES
+// [c0, c1) and, inside them, the pixels it OWNS, i.e. stores to the level's plane, [o0, o1). Level 0: the source rectangle to stage (c0 of
+// a column span is a multiple of 4), nothing owned.
+struct ChainSpan {
+    int16_t c0, c1, o0, o1;
+};
+constexpr int kChainMaxW = 192;        // widest computed region of a level >= 1 (three 64-lane column chunks)
+constexpr int kChainMaxW0 = 256;       // widest staged level-0 rectangle (64 words)
+constexpr int kChainMaxH0 = 128;       // its height (16 waves x 8 rows)
+constexpr int kChainMaxLds = 64 * 1024;
+size_t chain_lds_bytes(int bufA_bytes, int bufB_bytes, int tap_cap);   // dynamic LDS of one k_pyramid_chain workgroup (bufA, bufB multiples of 16)
+
 // ---- kernel launchers (each defined next to its kernel) ----
+hipError_t launch_pyramid_chain(const uint8_t* img0, size_t frame_stride0, int pitch0, uint8_t* pyr, size_t pyr_frame_bytes, const FrameGeo* d_geo,
+                                const ResizeTap* d_taps, const ChainSpan* d_plan, int TX, int TY, int bufA_bytes, int bufB_bytes, int tap_cap,
+                                int batch, hipStream_t s);
 hipError_t launch_resize(const uint8_t* src, size_t src_frame_stride, int src_pitch, int srows, int scols, uint8_t* dst,
                          size_t dst_frame_stride, int dst_pitch, int drows, int dcols, const ResizeTap* xt, const ResizeTap* yt,
                          int batch, hipStream_t s, int hwin_ok);
@@ -124,6 +139,7 @@ struct Tuning {
     int pose_threads;      // OVS_POSE_THREADS: 256 / 512 (0 = by problem size)
     int pose_groups;       // OVS_POSE_GROUPS: workgroups a single frame's pose optimisation is spread over (0 = by observation count, 1 = one)
     bool ba_trace;         // OVS_BA_TRACE: per-iteration trace of the LM loops on stderr
+    int pyr_chain;         // OVS_PYR_CHAIN: frames per launch up to which the pyramid is ONE k_pyramid_chain launch (default 2; 0 = never)
 };
 const Tuning& tuning();
 

@@ -32,6 +32,19 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// a workgroup-uniform double (read from LDS by every lane) moved to scalar registers: the pose of a sweep costs 24 vector registers otherwise,
+// which the 512-thread build (256 registers per lane) did not have -- it kept part of the linearisation's state in scratch memory
+__device__ __forceinline__ double uniform_d(double v) {
+    union {
+        double d;
+        int i[2];
+    } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+    u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+    return u.d;
+}
+
 __device__ void se3_exp_d(const double* u, PoseD& out) {
     const double wx = u[0], wy = u[1], wz = u[2];
     const double theta = sqrt((wx * wx + wy * wy) + wz * wz);
@@ -394,8 +407,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
 #pragma unroll
                 for (int i = 0; i < 28; ++i) acc[i] = 0;
                 double R[9], t[3];
-                for (int i = 0; i < 9; ++i) R[i] = at_trial ? s_Tn.R[i] : s_T.R[i];
-                for (int i = 0; i < 3; ++i) t[i] = at_trial ? s_Tn.t[i] : s_T.t[i];
+                for (int i = 0; i < 9; ++i) R[i] = uniform_d(at_trial ? s_Tn.R[i] : s_T.R[i]);
+                for (int i = 0; i < 3; ++i) t[i] = uniform_d(at_trial ? s_Tn.t[i] : s_T.t[i]);
                 auto sweep = [&](auto stereo_tag) __attribute__((always_inline)) {
                     for (int k = 0, i = gtid; i < n; i += gstride, ++k)
                         if ((active >> k) & 1u) {
@@ -509,7 +522,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                             rho = (current_chi - temp_chi) / s_scq[q];
                             ++qmax;
                             if (rho > 0 && isfinite(temp_chi)) {
-                                double alpha = 1. - pow(2 * rho - 1, 3.0);
+                                const double tr = 2 * rho - 1;
+                                double alpha = 1. - tr * tr * tr;   // (g2o: pow(2 rho - 1, 3); the library pow was ~150 instructions per lane for a cube)
                                 alpha = fmin(alpha, 2.0 / 3.0);
                                 lambda = lam * fmax(1.0 / 3.0, alpha);
                                 ni = 2;
@@ -599,7 +613,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                     __syncthreads();
                     rho = (current_chi - temp_chi) / scale;
                     if (rho > 0 && isfinite(temp_chi)) {
-                        double alpha = 1. - pow(2 * rho - 1, 3.0);
+                        const double tr = 2 * rho - 1;
+                                double alpha = 1. - tr * tr * tr;   // (g2o: pow(2 rho - 1, 3); the library pow was ~150 instructions per lane for a cube)
                         alpha = fmin(alpha, 2.0 / 3.0);
                         lambda *= fmax(1.0 / 3.0, alpha);
                         ni = 2;

@@ -66,6 +66,8 @@ class orb_extractor:
             _lib.check(self._L.ovs_orb_set_fast_split(self._h, self._fast_split), "ovs_orb_set_fast_split")
         if self._pipeline is not None:
             _lib.check(self._L.ovs_orb_set_pipeline(self._h, self._pipeline), "ovs_orb_set_pipeline")
+        if getattr(self, "_pyramid_chain", None) is not None:
+            _lib.check(self._L.ovs_orb_set_pyramid_chain(self._h, self._pyramid_chain), "ovs_orb_set_pyramid_chain")
         self.max_keypoints = self._L.ovs_orb_max_keypoints(self._h)
         n = self.orb_params_.num_levels
         self.scale_factors_ = np.zeros(n, np.float32)
@@ -184,6 +186,11 @@ class orb_extractor:
         """Level-0 FAST beside the pyramid on an internal stream (default on); off = one FAST launch after the pyramid."""
         _lib.check(self._L.ovs_orb_set_fast_split(self._h, 1 if enable else 0), "ovs_orb_set_fast_split")
         self._fast_split = 1 if enable else 0
+
+    def set_pyramid_chain(self, enable):
+        """All pyramid levels of a single frame / stereo pair in ONE launch (default on); off = level-by-level launches always."""
+        _lib.check(self._L.ovs_orb_set_pyramid_chain(self._h, 1 if enable else 0), "ovs_orb_set_pyramid_chain")
+        self._pyramid_chain = 1 if enable else 0
 
     def set_variant(self, which, value):
         """ovs_orb_set_variant: "tree_switch_factor" (3 | 1), "tree_tie_order" (0 later-created first | 1 earlier first), "blur_taps" (0 | 1) --

@@ -269,6 +269,53 @@ def test_timed_regime_1080p_batch_of_64_against_the_oracle(hip, oracle, split):
         assert np.array_equal(desc[b, :cnt[b]], wd), b
 
 
+@pytest.mark.parametrize("rows,cols,nfeat,levels,scale", [(1080, 1920, 2000, 8, 1.2), (480, 752, 1000, 8, 1.2), (376, 1241, 2000, 8, 1.2), (500, 643, 700, 5, 1.5),
+                                                          (1920, 3840, 4000, 8, 1.2), (301, 403, 300, 12, 1.1), (480, 640, 500, 4, 2.0)])
+def test_one_launch_pyramid_equals_the_level_by_level_one(hip, oracle, rows, cols, nfeat, levels, scale):
+    """k_pyramid_chain (all levels of a single frame in one launch: every workgroup chains its tile through the levels in LDS) against the
+    level-by-level kernels and the oracle: every plane byte-equal, and the keypoints / descriptors that follow from them. Sizes: the four
+    BASELINE geometries, odd widths, other scale factors / level counts (halo growth, tiny last levels), through the host entry and the
+    device-batch entry with two frames in the launch (a stereo pair's shape) at a row pitch that is not the width."""
+    import torch
+    img = synth_frame(rows, cols, seed=77)
+    gp = hip.orb_params(nfeat, scale, levels, 20, 7)
+    ex = hip.orb_extractor(gp, max_rows=rows, max_cols=cols, max_batch=2)
+    ox = oracle.OrbExtractor(oracle.make_params(nfeat, scale, levels, 20, 7))
+    planes = {}
+    for chain in (True, False):
+        ex.set_pyramid_chain(chain)
+        k, d = ex.extract(img)
+        planes[chain] = ([ex.image_pyramid(l) for l in range(levels)], k, d)
+    wk, wd = ox.extract(img)
+    for l in range(levels):
+        want = ox.level_image(l)
+        assert np.array_equal(planes[True][0][l], want), ("chain", l)
+        assert np.array_equal(planes[False][0][l], want), ("levels", l)
+    for chain in (True, False):
+        assert np.array_equal(planes[chain][1].view(np.uint8), wk.view(np.uint8)) and np.array_equal(planes[chain][2], wd)
+    # device-batch entry, two frames, rows at the tensor's own (possibly unaligned) stride
+    ex.set_pyramid_chain(True)
+    img2 = synth_frame(rows, cols, seed=78)
+    pitch = (cols + 3) // 4 * 4 + 4            # rows at a 4-byte aligned pitch that is not the width (the ABI's alignment rule)
+    d_full = torch.zeros((2, rows, pitch), dtype=torch.uint8, device="cuda")
+    d_full[:, :, :cols] = torch.from_numpy(np.stack([img, img2])).cuda()
+    d_img = d_full[:, :, :cols]
+    cap = ex.max_keypoints
+    d_kps = torch.zeros((2, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros((2,), dtype=torch.int32, device="cuda")
+    ex.extract_batch_dev(d_img, d_kps, d_desc, d_cnt, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    wk2, wd2 = ox.extract(img2)
+    for l in range(levels):
+        assert np.array_equal(ex.image_pyramid(l, frame=1), ox.level_image(l)), ("batch frame 1", l)
+    cnt = d_cnt.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(np.uint8).reshape(2, cap, 28)
+    for b, (k_, d_) in enumerate(((wk, wd), (wk2, wd2))):
+        assert cnt[b] == len(k_) and np.array_equal(kps[b, :cnt[b]].reshape(-1), k_.view(np.uint8).reshape(-1))
+        assert np.array_equal(d_desc[b, :cnt[b]].cpu().numpy(), d_)
+
+
 def test_two_extractors_run_concurrently_from_two_threads(hip, oracle):
     """Upstream extracts the left and right image of a stereo frame on two std::threads with two extractor instances: handles are
     independent (own stream, own buffers), so two host threads may call extract() on two handles at the same time."""

@@ -48,11 +48,10 @@ def test_optimiser_kernels_keep_their_register_budgets(ba_kernels):
     assert pose["ovs::k_pose_optimize<0, 256>"]["scratch"] == 0 and pose["ovs::k_pose_optimize<1, 256>"]["scratch"] == 0
 
 
-def test_only_the_512_thread_pose_optimiser_touches_scratch_memory():
-    """Every kernel of the library, read from the code objects: none uses scratch (private memory spilled to HBM) except the 512-thread build of the
-    pose optimiser, which sits at the 256-register ceiling two waves per SIMD leave (120 / 208 bytes per thread; it runs for one-workgroup
-    frames of 768 .. 1199 observations only, where it measured faster than the 256-thread build all the same)."""
+def test_no_kernel_touches_scratch_memory():
+    """Every kernel of the library, read from the code objects: none uses scratch (private memory spilled to HBM). Until round 5 the 512-thread
+    builds of the pose optimiser did (120 / 208 bytes: literal constants of sincos / the Newton steps hoisted out of the iteration loops by
+    machine LICM and reloaded one by one on the lane every trial waits for); pose_opt.o is built with -mllvm -disable-machine-licm since."""
     import kernel_resources as kr
     spilled = {name: scratch for (_, name, _v, _a, _s, scratch, _l, _w) in kr.collect() if scratch}
-    assert set(spilled) <= {"ovs::k_pose_optimize<0, 512>", "ovs::k_pose_optimize<1, 512>"}, spilled
-    assert spilled.get("ovs::k_pose_optimize<0, 512>", 0) <= 128 and spilled.get("ovs::k_pose_optimize<1, 512>", 0) <= 224, spilled
+    assert not spilled, spilled

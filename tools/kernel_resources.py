@@ -26,7 +26,8 @@ def collect(files=None):
             if files is not None and os.path.basename(src) not in files:
                 continue
             base = os.path.splitext(os.path.basename(src))[0]
-            subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-c", src, "-o", os.path.join(td, base + ".o"), "-save-temps=obj"], cwd=CSRC, check=True,
+            extra = {"pose_opt": ["-mllvm", "-disable-machine-licm"], "match_hamming": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}.get(base, [])   # the Makefile's per-file flags
+            subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *extra, "-c", src, "-o", os.path.join(td, base + ".o"), "-save-temps=obj"], cwd=CSRC, check=True,
                            stderr=subprocess.DEVNULL)
             asm = os.path.join(td, base + "-hip-amdgcn-amd-amdhsa-gfx950.s")
             if not os.path.exists(asm):
