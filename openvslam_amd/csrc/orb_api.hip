@@ -36,7 +36,7 @@ const Tuning& tuning() {
         v.pose_threads = num("OVS_POSE_THREADS", 0);
         v.pose_groups = std::max(0, num("OVS_POSE_GROUPS", 0));
         v.ba_trace = std::getenv("OVS_BA_TRACE") != nullptr;
-        v.pyr_chain = std::max(0, num("OVS_PYR_CHAIN", 2));
+        v.pyr_chain = std::max(0, num("OVS_PYR_CHAIN", 1));
         return v;
     }();
     return t;
@@ -261,7 +261,7 @@ struct ovs_orb {
     // FAST on level 0 needs no pyramid: it runs on aux_stream BESIDE the seven resize launches (VALU-bound next to latency / bandwidth-bound),
     // the remaining levels follow the pyramid on the main stream (ovs_orb_set_fast_split; default on)
     bool fast_split = true;
-    bool pyr_chain_enabled = true;   // ovs_orb_set_variant-independent A/B switch of the one-launch pyramid (ovs_orb_set_pyramid_chain)
+    int pyr_chain_max = tuning().pyr_chain;   // frames per launch up to which the pyramid is one k_pyramid_chain launch (ovs_orb_set_pyramid_chain; 0 = never)
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_aux_fork = nullptr, ev_aux_join = nullptr;
     StageProfiler<1> prof_aux;
@@ -469,7 +469,7 @@ ovs_status run_chain(ovs_orb* h, StageProfiler<4>& prof, const uint8_t* d_images
     }
     // A1: each level from the previous one -- for a tracker's single frame (or a stereo pair) all levels in ONE launch (k_pyramid_chain: the
     // seven dependent launches cost 40 us of a 0.24 ms extract), for batches level by level (the throughput form)
-    const bool chained = h->chain.ok && L > 1 && nb <= tuning().pyr_chain && h->pyr_chain_enabled && !((uintptr_t)img & 3) && !(frame_stride & 3) && !(stride & 3);
+    const bool chained = h->chain.ok && L > 1 && nb <= h->pyr_chain_max && !((uintptr_t)img & 3) && !(frame_stride & 3) && !(stride & 3);
     if (chained)
         OVS_HIP_TRY(launch_pyramid_chain(img, frame_stride, (int)stride, d.pyr, d.pyr_frame_bytes, d.geo, h->d_taps, h->d_chain, h->chain.TX, h->chain.TY,
                                          h->chain.bufA, h->chain.bufB, h->chain.tap_cap, nb, s));
@@ -825,9 +825,9 @@ ovs_status ovs_orb_set_fast_split(ovs_orb* h, int32_t enable) {
     return OVS_OK;
 }
 
-ovs_status ovs_orb_set_pyramid_chain(ovs_orb* h, int32_t enable) {
-    if (!h) return OVS_ERR_INVALID;
-    h->pyr_chain_enabled = enable != 0;
+ovs_status ovs_orb_set_pyramid_chain(ovs_orb* h, int32_t max_frames) {
+    if (!h || max_frames < 0) return OVS_ERR_INVALID;
+    h->pyr_chain_max = max_frames;
     return OVS_OK;
 }
 

@@ -419,19 +419,32 @@ __global__ __launch_bounds__(kChainThreads) void k_pyramid_chain(const uint8_t* 
             }
         }
     }
+    // taps travel as LDS-relative records: an x-tap's o0 / o1 become byte offsets inside the source region's row, a y-tap's become the byte offsets of
+    // its two source rows inside the region (both fit 16 bits: regions are < 64 KB) -- the level loop below then has no address multiplications
     for (int base = 0; base < n_taps; base += kChainThreads) {
         const int t = base + tid;
-        int src = -1, cum = 0;
+        int src = -1, cum = 0, sub = 0, mul = 1;
+        int px0 = X0.c0, py0 = Y0.c0, ppitch = sp0;   // the source region of level l: origin and row pitch
         for (int l = 1; l < L; ++l) {
             const ChainSpan X = s_span[l], Y = s_span[OVS_MAX_LEVELS + l];
             const int W = X.c1 - X.c0, H = Y.c1 - Y.c0;
             if (t >= cum && t < cum + W + H) {
                 const int u = t - cum;
                 src = u < W ? s_lv[l].x + X.c0 + u : s_lv[l].y + Y.c0 + (u - W);
+                sub = u < W ? px0 : py0;
+                mul = u < W ? 1 : ppitch;
             }
             cum += W + H;
+            px0 = X.c0;
+            py0 = Y.c0;
+            ppitch = (W + 3) & ~3;
         }
-        if (src >= 0) s_tap[t] = taps[src];
+        if (src >= 0) {
+            ResizeTap tp = taps[src];
+            tp.o0 = (uint16_t)(((int)tp.o0 - sub) * mul);
+            tp.o1 = (uint16_t)(((int)tp.o1 - sub) * mul);
+            s_tap[t] = tp;
+        }
     }
 #pragma unroll
     for (int k = 0; k < kChainRowsPerThread; ++k) {
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(kChainThreads) void k_pyramid_chain(const uint8_t* 
     // ---- the chain
     const uint8_t* S = bufA;
     uint8_t* D = bufB;
-    int sx0 = X0.c0, sy0 = Y0.c0, sp = sp0, tap_off = 0;
+    int tap_off = 0;
     uint8_t* const pf = pyr + (size_t)frame * pyr_frame_bytes;
     for (int l = 1; l < L; ++l) {
         const ChainSpan X = s_span[l], Y = s_span[OVS_MAX_LEVELS + l];
@@ -450,33 +463,36 @@ __global__ __launch_bounds__(kChainThreads) void k_pyramid_chain(const uint8_t* 
         const ResizeTap* const xt = s_tap + tap_off;
         const ResizeTap* const yt = xt + W;
         if (W > 0 && H > 0) {
-            const int nchunk = (W + 63) >> 6, nrg = 16 / nchunk;
-            const int chunk = wave % nchunk, rg = wave / nchunk;
+            const int nchunk = W <= 64 ? 1 : (W <= 128 ? 2 : 3), nrg = W <= 64 ? 16 : (W <= 128 ? 8 : 5);
+            const int chunk = W <= 64 ? 0 : (W <= 128 ? (wave & 1) : wave % 3), rg = W <= 64 ? wave : (W <= 128 ? (wave >> 1) : wave / 3);
             const int x = chunk * 64 + lane;
+            (void)nchunk;
             if (rg < nrg && x < W) {
                 const ResizeTap tx = xt[x];
-                const int xo0 = (int)tx.o0 - sx0, xo1 = (int)tx.o1 - sx0, a0 = tx.a0, a1 = tx.a1;
-                const bool own_x = X.c0 + x >= X.o0 && X.c0 + x < X.o1;
+                const uint8_t* const S0 = S + tx.o0;
+                const uint8_t* const S1 = S + tx.o1;
+                const uint32_t a0 = (uint32_t)(uint16_t)tx.a0, a1 = (uint32_t)(uint16_t)tx.a1;
                 const int gpitch = s_lv[l].w;
-                uint8_t* const g = pf + (size_t)s_lv[l].z + (size_t)Y.c0 * gpitch + X.c0 + x;
+                // rows the tile owns, as a range of the thread's own row sequence rg, rg + nrg, ...: no per-pixel ownership test
+                const bool own_x = X.c0 + x >= X.o0 && X.c0 + x < X.o1;
+                const int oy0 = own_x ? Y.o0 - Y.c0 : H, oy1 = Y.o1 - Y.c0;
+                uint8_t* g = pf + (size_t)s_lv[l].z + (size_t)(Y.c0 + rg) * gpitch + X.c0 + x;
+                uint8_t* dd = D + rg * dp + x;
+                const int dstep = nrg * dp, gstep = nrg * gpitch;
 #pragma unroll 4
-                for (int y = rg; y < H; y += nrg) {
+                for (int y = rg; y < H; y += nrg, dd += dstep, g += gstep) {
                     const ResizeTap ty = yt[y];
-                    const int r0 = ((int)ty.o0 - sy0) * sp, r1 = ((int)ty.o1 - sy0) * sp;
-                    const int s00 = S[r0 + xo0], s01 = S[r0 + xo1], s10 = S[r1 + xo0], s11 = S[r1 + xo1];
-                    const int h0 = (s00 * a0 + s01 * a1) >> 4, h1 = (s10 * a0 + s11 * a1) >> 4;
-                    int v = ((((int)ty.a0 * h0) >> 16) + (((int)ty.a1 * h1) >> 16) + 2) >> 2;
-                    v = v < 0 ? 0 : (v > 255 ? 255 : v);
-                    D[y * dp + x] = (uint8_t)v;
-                    if (own_x && Y.c0 + y >= Y.o0 && Y.c0 + y < Y.o1) g[(size_t)y * gpitch] = (uint8_t)v;
+                    const uint32_t s00 = S0[ty.o0], s01 = S1[ty.o0], s10 = S0[ty.o1], s11 = S1[ty.o1];
+                    const uint32_t h0 = (s00 * a0 + s01 * a1) >> 4, h1 = (s10 * a0 + s11 * a1) >> 4;
+                    // a0 + a1 = b0 + b1 = 2048 and h <= 32640: the sum is <= 1020, (sum + 2) >> 2 <= 255 -- OpenCV's saturate_cast never clamps here
+                    const uint32_t v = ((((uint32_t)(uint16_t)ty.a0 * h0) >> 16) + (((uint32_t)(uint16_t)ty.a1 * h1) >> 16) + 2u) >> 2;
+                    *dd = (uint8_t)v;
+                    if (y >= oy0 && y < oy1) *g = (uint8_t)v;
                 }
             }
         }
         __syncthreads();
         tap_off += W + H;
-        sx0 = X.c0;
-        sy0 = Y.c0;
-        sp = dp;
         const uint8_t* const t = S;
         S = D;
         D = const_cast<uint8_t*>(t);

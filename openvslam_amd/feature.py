@@ -187,10 +187,11 @@ class orb_extractor:
         _lib.check(self._L.ovs_orb_set_fast_split(self._h, 1 if enable else 0), "ovs_orb_set_fast_split")
         self._fast_split = 1 if enable else 0
 
-    def set_pyramid_chain(self, enable):
-        """All pyramid levels of a single frame / stereo pair in ONE launch (default on); off = level-by-level launches always."""
-        _lib.check(self._L.ovs_orb_set_pyramid_chain(self._h, 1 if enable else 0), "ovs_orb_set_pyramid_chain")
-        self._pyramid_chain = 1 if enable else 0
+    def set_pyramid_chain(self, max_frames):
+        """All pyramid levels in ONE launch for calls of at most max_frames frames (default 1: the tracker's single frame); 0 / False = level-by-level
+        launches always."""
+        _lib.check(self._L.ovs_orb_set_pyramid_chain(self._h, int(max_frames)), "ovs_orb_set_pyramid_chain")
+        self._pyramid_chain = int(max_frames)
 
     def set_variant(self, which, value):
         """ovs_orb_set_variant: "tree_switch_factor" (3 | 1), "tree_tie_order" (0 later-created first | 1 earlier first), "blur_taps" (0 | 1) --

@@ -18,15 +18,21 @@ class OrbParams(C.Structure):
                 ("ini_fast_thr", C.c_int32), ("min_fast_thr", C.c_int32)]
 
 
+def _lib_name():
+    # OVS_ORACLE_LIB=liboracle_asan.so: the sanitised build (make -C oracle asan), loaded by tests/test_sanitizers.py in a subprocess that
+    # preloads the sanitizer runtime
+    return os.environ.get("OVS_ORACLE_LIB", "liboracle.so")
+
+
 def build():
-    subprocess.check_call(["make", "-s", "-C", _HERE])
+    subprocess.check_call(["make", "-s", "-C", _HERE] + (["asan"] if _lib_name() == "liboracle_asan.so" else []))
 
 
 def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.path.join(_HERE, "liboracle.so")
+    path = os.path.join(_HERE, _lib_name())
     if not os.path.exists(path):
         build()
     L = C.CDLL(path)

@@ -9,17 +9,21 @@ import pytest
 from openvslam_amd.synth import synth_frame
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHIM = os.path.join(ROOT, "openvslam_amd", "cpp", "test_shim")
+# OVS_SHIM_SUFFIX=_asan (tools/run_asan.sh): every shim program of this file in its AddressSanitizer + UndefinedBehaviorSanitizer build (class shims and
+# the host side of libovslam_hip_asan.so instrumented) -- the same inputs, the same comparisons with the oracle; a sanitizer report aborts the program
+SUFFIX = os.environ.get("OVS_SHIM_SUFFIX", "")
+MAKE_SHIMS = ["make", "-s", "-C", os.path.join(ROOT, "openvslam_amd", "cpp")] + (["asan"] if SUFFIX else [])
+SHIM = os.path.join(ROOT, "openvslam_amd", "cpp", "test_shim" + SUFFIX)
 
 
 def test_shim_builds():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "openvslam_amd", "cpp")])
+    subprocess.check_call(MAKE_SHIMS)
     assert os.path.exists(SHIM)
 
 
 @pytest.mark.gpu
 def test_shim_matches_oracle(oracle, tmp_path):
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "openvslam_amd", "cpp")])
+    subprocess.check_call(MAKE_SHIMS)
     rows, cols, nfeat = 480, 752, 1000
     a = synth_frame(rows, cols, seed=21)
     b = synth_frame(rows, cols, seed=21, shift=(4, 3), noise_seed=5)
@@ -237,7 +241,7 @@ def test_shim_matches_oracle(oracle, tmp_path):
     assert n_bk == wn and np.array_equal(bk_m, want) and wn > 20
 
 
-LBA_SHIM = os.path.join(ROOT, "openvslam_amd", "cpp", "test_lba_shim")
+LBA_SHIM = os.path.join(ROOT, "openvslam_amd", "cpp", "test_lba_shim" + SUFFIX)
 
 
 def _pose7_to_44(p):
@@ -258,7 +262,7 @@ def test_local_bundle_adjuster_class_matches_oracle(oracle, tmp_path, stereo_fra
     import struct
     from oracle import lba
     from test_ba import _lba_scene
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "openvslam_amd", "cpp")])
+    subprocess.check_call(MAKE_SHIMS)
     d, mono, st, bf, _, _ = _lba_scene(11, n_pose=9, n_pt=1200, obs_per_pose=400, stereo_frac=stereo_frac)
     n_kf = len(d["poses"])
     # keyframe 0 has id 0 and is covisible (local but constant, as upstream's `id_ == 0` rule); keyframe 1 is NOT covisible -> a fixed
@@ -352,7 +356,7 @@ def test_robust_match_frame_and_keyframe_class(oracle, tmp_path, check_orientati
     import struct
     from test_gpu_window import _rot
     from openvslam_amd import synth
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "openvslam_amd", "cpp")])
+    subprocess.check_call(MAKE_SHIMS)
     rng = np.random.default_rng(8)
     n_true, n_wrong, n_extra = 500, 60, 300
     n = n_true + n_wrong
@@ -406,7 +410,7 @@ def test_class_boundary_latency_and_two_threads():
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import class_latency
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "openvslam_amd", "cpp")])
+    subprocess.check_call(MAKE_SHIMS)
     r = class_latency.measure(1080, 1920, 2000, 60)
     best = min(r["pageable_no_pyramid"]["median_ms"], r["staged_no_pyramid"]["median_ms"])
     assert best < 0.8, r                      # measured 0.27 ms; generous bound against noisy neighbours
@@ -423,7 +427,7 @@ def test_local_bundle_adjuster_class_equirectangular(oracle, tmp_path):
     import struct
     from oracle import lba
     from test_gpu_ba import _equirect_scene
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "openvslam_amd", "cpp")])
+    subprocess.check_call(MAKE_SHIMS)
     cols, rows = 3840, 1920
     poses, _, pts_all, mono = _equirect_scene(21, n_pose=8, n_pt=1000, obs_per_pose=350, cols=cols, rows=rows)
     lat_ok = np.abs(pts_all[:, 1]) / np.linalg.norm(pts_all, axis=1) < 0.95
@@ -482,7 +486,7 @@ def test_pose_optimizer_class_per_camera_model(oracle, tmp_path, model):
     gets the same float-rounded observations."""
     import struct
     from openvslam_amd.synth import synth_pose_frame, synth_pose_frame_equirect
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "openvslam_amd", "cpp")])
+    subprocess.check_call(MAKE_SHIMS)
     n = 900
     if model == 2:
         T0, obs, cols, rows, _ = synth_pose_frame_equirect(oracle.POSE_OBS_DTYPE, n, 31, outlier_frac=0.1, seam_frac=0.05, pole_frac=0.05)
@@ -527,11 +531,11 @@ def test_shims_never_throw_on_device_failures(tmp_path):
     HIP failures injected below the ABI (ovs_debug_inject_hip_failures): a single failed call anywhere in a tracked frame is retried on
     rebuilt contexts and changes nothing; a device that keeps failing makes extract() return no keypoints and every matcher / the pose
     optimiser return 0 with their outputs untouched -- no exception reaches the caller --, and the classes work again once the device does."""
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "openvslam_amd", "cpp")])
+    subprocess.check_call(MAKE_SHIMS)
     rows, cols, nfeat = 480, 752, 1000
     synth_frame(rows, cols, seed=21).tofile(tmp_path / "a.raw")
     synth_frame(rows, cols, seed=21, shift=(4, 3), noise_seed=5).tofile(tmp_path / "b.raw")
-    r = subprocess.run([os.path.join(ROOT, "openvslam_amd", "cpp", "test_fault_shim"), str(rows), str(cols), str(nfeat), str(tmp_path / "a.raw"),
+    r = subprocess.run([os.path.join(ROOT, "openvslam_amd", "cpp", "test_fault_shim" + SUFFIX), str(rows), str(cols), str(nfeat), str(tmp_path / "a.raw"),
                         str(tmp_path / "b.raw")], capture_output=True, text=True)
     assert r.returncode == 0 and "FAIL" not in r.stdout, r.stdout + r.stderr
     assert "returning the empty result" in r.stderr and "the retry succeeded" in r.stderr   # the failures were logged, not swallowed
@@ -548,14 +552,16 @@ def test_keyframe_residency_shared_cache_and_two_threads(tmp_path):
     race reported in the shim layer fails the test; if the sanitizer cannot run beside the HIP runtime on this box the fact is reported,
     not hidden."""
     cpp = os.path.join(ROOT, "openvslam_amd", "cpp")
-    subprocess.check_call(["make", "-s", "-C", cpp])
+    subprocess.check_call(MAKE_SHIMS)
     rows, cols, nfeat = 480, 752, 1000
     synth_frame(rows, cols, seed=21).tofile(tmp_path / "a.raw")
     synth_frame(rows, cols, seed=21, shift=(4, 3), noise_seed=5).tofile(tmp_path / "b.raw")
     args = [str(rows), str(cols), str(nfeat), str(tmp_path / "a.raw"), str(tmp_path / "b.raw")]
-    r = subprocess.run([os.path.join(cpp, "test_threads_shim")] + args + ["40"], capture_output=True, text=True)
+    r = subprocess.run([os.path.join(cpp, "test_threads_shim" + SUFFIX)] + args + ["40" if not SUFFIX else "6"], capture_output=True, text=True)
     print(r.stdout)
     assert r.returncode == 0 and "ALL OK" in r.stdout and "FAIL" not in r.stdout, r.stdout + r.stderr
+    if SUFFIX:
+        return   # (one sanitizer at a time)
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=0")
     tsan = [os.path.join(cpp, "test_threads_shim_tsan")] + args + ["6"]
     t = subprocess.run(tsan, capture_output=True, text=True, env=env)

@@ -294,7 +294,7 @@ def test_one_launch_pyramid_equals_the_level_by_level_one(hip, oracle, rows, col
     for chain in (True, False):
         assert np.array_equal(planes[chain][1].view(np.uint8), wk.view(np.uint8)) and np.array_equal(planes[chain][2], wd)
     # device-batch entry, two frames, rows at the tensor's own (possibly unaligned) stride
-    ex.set_pyramid_chain(True)
+    ex.set_pyramid_chain(2)
     img2 = synth_frame(rows, cols, seed=78)
     pitch = (cols + 3) // 4 * 4 + 4            # rows at a 4-byte aligned pitch that is not the width (the ABI's alignment rule)
     d_full = torch.zeros((2, rows, pitch), dtype=torch.uint8, device="cuda")

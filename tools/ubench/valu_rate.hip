@@ -169,6 +169,90 @@ __global__ void k_f16_denorm_check(uint32_t* bad) {
     if (n) atomicAdd(bad, n);
 }
 
+// ---- round 5: MIXED streams. The tables above time one opcode back to back; k_fast_cells' pre-test issues a mix of fast-class
+// VOP2 ops (v_sub_u32 / v_add_u32 / v_or_b32: 2.3-2.5 cycles alone) and VOP3 ops (v_alignbyte_b32, v_bitop3_b32: 4.2-4.4 alone) with real
+// dependences. Does a mixed stream issue at the weighted mean of the single-opcode rates (~3.0), or at 4 cycles per instruction whatever the opcode
+// (what SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU on the kernel suggested)? One body = swar_diameter_test's 32 instructions for one 4-pixel group:
+// 5 v_alignbyte, 2 + 16 v_sub / v_add, 2 v_or, 6 v_bitop3, 1 v_and. Run at 4, 7 and 8 waves per SIMD (the kernel runs at 7).
+#define MIX_PRETEST_BODY                                                                                   \
+    asm volatile(                                                                                          \
+        "v_alignbyte_b32 %8, %1, %0, 2\n v_alignbyte_b32 %9, %2, %1, 2\n v_alignbyte_b32 %10, %3, %2, 2\n" \
+        "v_alignbyte_b32 %11, %4, %3, 1\n v_alignbyte_b32 %12, %5, %4, 3\n"                                \
+        "v_sub_u32 %13, %8, %6\n v_add_u32 %14, %8, %6\n"                                                  \
+        "v_sub_u32 %0, %9, %13\n v_sub_u32 %1, %10, %13\n v_sub_u32 %2, %11, %13\n v_sub_u32 %3, %12, %13\n" \
+        "v_sub_u32 %4, %5, %13\n v_sub_u32 %5, %7, %13\n v_sub_u32 %9, %6, %13\n v_sub_u32 %10, %7, %13\n"   \
+        "v_or_b32 %0, %0, %1\n"                                                                            \
+        "v_bitop3_b32 %0, %0, %2, %3 bitop3:0xe0\n v_bitop3_b32 %0, %0, %4, %5 bitop3:0xe0\n v_bitop3_b32 %0, %0, %9, %10 bitop3:0xe0\n" \
+        "v_sub_u32 %1, %14, %11\n v_sub_u32 %2, %14, %12\n v_sub_u32 %3, %14, %8\n v_sub_u32 %4, %14, %7\n"  \
+        "v_sub_u32 %5, %14, %6\n v_sub_u32 %9, %14, %0\n v_sub_u32 %10, %14, %13\n v_sub_u32 %11, %14, %12\n" \
+        "v_or_b32 %1, %1, %2\n"                                                                            \
+        "v_bitop3_b32 %1, %1, %3, %4 bitop3:0xe0\n v_bitop3_b32 %1, %1, %5, %9 bitop3:0xe0\n v_bitop3_b32 %1, %1, %10, %11 bitop3:0xe0\n" \
+        "v_and_b32 %2, %0, %1\n"                                                                           \
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]),     \
+          "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]));
+// the exact scorer's mix: 16-bit VOP2 min / max (2.3 alone) with a v_perm_b32 / v_bfe_u32 (4.2 alone) every fourth instruction
+#define MIX_SCORE_BODY                                                                                     \
+    asm volatile(                                                                                          \
+        "v_min_u16 %8, %0, %1\n v_min_u16 %9, %2, %3\n v_min_u16 %10, %4, %5\n v_bfe_u32 %11, %6, 8, 8\n"   \
+        "v_max_u16 %0, %8, %9\n v_min_u16 %1, %9, %10\n v_max_u16 %2, %10, %11\n v_perm_b32 %3, %7, %6, %5\n" \
+        "v_min_u16 %4, %0, %1\n v_max_u16 %5, %1, %2\n v_min_u16 %6, %2, %3\n v_bfe_u32 %7, %3, 16, 8\n"    \
+        "v_max_u16 %8, %4, %5\n v_min_u16 %9, %5, %6\n v_max_u16 %10, %6, %7\n v_perm_b32 %11, %4, %7, %0\n" \
+        "v_min_u16 %0, %8, %9\n v_min_u16 %1, %9, %10\n v_min_u16 %2, %10, %11\n v_bfe_u32 %3, %11, 8, 8\n"  \
+        "v_max_u16 %4, %0, %1\n v_min_u16 %5, %1, %2\n v_max_u16 %6, %2, %3\n v_perm_b32 %7, %3, %2, %1\n"   \
+        "v_min_u16 %8, %4, %5\n v_max_u16 %9, %5, %6\n v_min_u16 %10, %6, %7\n v_bfe_u32 %11, %7, 16, 8\n"  \
+        "v_max_u16 %0, %8, %9\n v_min_u16 %1, %9, %10\n v_max_u16 %2, %10, %11\n v_perm_b32 %3, %8, %11, %4\n" \
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]),     \
+          "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]));
+// pure fast-class stream with the same dependence shape (reference for the two above)
+#define MIX_VOP2_BODY                                                                                      \
+    asm volatile(                                                                                          \
+        "v_sub_u32 %8, %0, %1\n v_add_u32 %9, %2, %3\n v_or_b32 %10, %4, %5\n v_and_b32 %11, %6, %7\n"     \
+        "v_sub_u32 %0, %8, %9\n v_add_u32 %1, %9, %10\n v_or_b32 %2, %10, %11\n v_and_b32 %3, %7, %6\n"     \
+        "v_sub_u32 %4, %0, %1\n v_add_u32 %5, %1, %2\n v_or_b32 %6, %2, %3\n v_xor_b32 %7, %3, %4\n"        \
+        "v_sub_u32 %8, %4, %5\n v_add_u32 %9, %5, %6\n v_or_b32 %10, %6, %7\n v_and_b32 %11, %4, %7\n"      \
+        "v_sub_u32 %0, %8, %9\n v_add_u32 %1, %9, %10\n v_or_b32 %2, %10, %11\n v_xor_b32 %3, %11, %8\n"    \
+        "v_sub_u32 %4, %0, %1\n v_add_u32 %5, %1, %2\n v_or_b32 %6, %2, %3\n v_and_b32 %7, %3, %2\n"        \
+        "v_sub_u32 %8, %4, %5\n v_add_u32 %9, %5, %6\n v_or_b32 %10, %6, %7\n v_xor_b32 %11, %7, %4\n"      \
+        "v_sub_u32 %0, %8, %9\n v_add_u32 %1, %9, %10\n v_or_b32 %2, %10, %11\n v_and_b32 %3, %8, %11\n"    \
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]),     \
+          "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]));
+#define KERNELMIX(NAME, BODY)                                                          \
+    __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed) {        \
+        uint32_t a[8], t[7];                                                           \
+        for (int i = 0; i < 8; ++i) a[i] = (seed * (threadIdx.x + 1) + i) | 0x80808080u; \
+        for (int i = 0; i < 7; ++i) t[i] = seed + i;                                   \
+        for (int it = 0; it < kIters / 2; ++it) { BODY }                               \
+        uint32_t r = 0;                                                                \
+        for (int i = 0; i < 8; ++i) r ^= a[i];                                         \
+        for (int i = 0; i < 7; ++i) r ^= t[i];                                         \
+        if (r == 0x12345678u) out[threadIdx.x] = r;                                    \
+    }
+KERNELMIX(mix_pretest, MIX_PRETEST_BODY)
+KERNELMIX(mix_score, MIX_SCORE_BODY)
+KERNELMIX(mix_vop2, MIX_VOP2_BODY)
+
+template <typename K>
+int run_mix(const char* name, K kern, uint32_t* d_out, int cus, double clock_ghz, int wg_per_cu) {
+    dim3 grid(cus * wg_per_cu), block(256);   // wg_per_cu workgroups of 4 waves per CU = wg_per_cu waves per SIMD
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, grid, block, 0, 0, d_out, 12345u);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0, 0));
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, block, 0, 0, d_out, 12345u + i);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double instr = (double)cus * wg_per_cu * 4 * (kIters / 2) * 32.0 * reps;   // 32 instructions per body
+    const double per_simd_cycle = instr / (ms * 1e-3) / (cus * 4.0) / (clock_ghz * 1e9);
+    printf("%-12s %d waves/SIMD  %8.3f ms  %.3f wave-instr/cycle/SIMD (@%.2f GHz) => %.2f cycles/instr\n", name, wg_per_cu, ms / reps, per_simd_cycle,
+           clock_ghz, 1.0 / per_simd_cycle);
+    return 0;
+}
+
 template <typename K>
 int run(const char* name, K kern, uint32_t* d_out, int cus, double clock_ghz) {
     const int wg_per_cu = 8;   // 8 x 4 waves = 32 waves / CU = 8 waves / SIMD
@@ -194,7 +278,7 @@ int run(const char* name, K kern, uint32_t* d_out, int cus, double clock_ghz) {
     return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -202,6 +286,14 @@ int main() {
     printf("device %s, %d CUs, clockRate %.3f GHz\n", prop.gcnArchName, cus, ghz);
     uint32_t* d_out;
     CHECK(hipMalloc(&d_out, 4096));
+    if (argc > 1 && argv[1][0] == 'm') {   // `valu_rate mix`: the mixed streams only
+        for (int w : {1, 2, 4, 7, 8}) {
+            if (run_mix("mix_vop2", mix_vop2, d_out, cus, ghz, w)) return 1;
+            if (run_mix("mix_pretest", mix_pretest, d_out, cus, ghz, w)) return 1;
+            if (run_mix("mix_score", mix_score, d_out, cus, ghz, w)) return 1;
+        }
+        return 0;
+    }
     {
         uint32_t* d_bad;
         CHECK(hipMalloc(&d_bad, 4));
