@@ -151,10 +151,10 @@ ovs_status ovs_orb_set_pipeline(ovs_orb* h, int32_t n_sub);
  * launch's own duration. OFF = one FAST launch over all levels after the pyramid (what per-kernel rooflines are quoted on). */
 ovs_status ovs_orb_set_fast_split(ovs_orb* h, int32_t enable);
 
-/* One-launch pyramid for single frames (no upstream counterpart; default max_frames = 1): when a call extracts at most max_frames frames (the
+/* One-launch pyramid for single frames (no upstream counterpart; default max_frames = 2): when a call extracts at most max_frames frames (the
  * tracker's orb_extractor::extract, expected src/openvslam/feature/orb_extractor.cc compute_image_pyramid), all levels are computed by ONE kernel
  * launch (each workgroup chains its tile through every level in LDS) instead of num_levels - 1 dependent launches: lower latency, lower throughput
- * (measured: one frame 28 vs 34 us, two frames 40 vs 38, eight 95 vs 46). Identical bytes in every plane. 0 = level-by-level launches always. */
+ * (measured: one frame 24 vs 37 us, two frames 33.5 vs 35.7, eight 73 vs 46). Identical bytes in every plane. 0 = level-by-level launches always. */
 ovs_status ovs_orb_set_pyramid_chain(ovs_orb* h, int32_t max_frames);
 /* Variants of the three rules of the extraction that upstream's (absent) sources and OpenCV version decide and that cannot be pinned in this
  * repository (oracle/ORACLE_SPEC.md rules 6, 7, 10): if a checkout or an OpenCV build shows the other choice, matching it

@@ -885,6 +885,7 @@ namespace ovs {
 // The reduced camera system is stored the way the device solver wants it (ba_solve.hip): pitch n_pad = 6 n_free rounded up to 16, an identity
 // block on the padding, the right-hand side as row n_pad, zero rows behind it. The padding survives a solve, so it is written once here.
 static ovs_status solver_workspace_create(ovs_ba_graph* g, hipStream_t s);
+ovs_status ba_graph_reset_system(ovs_ba_graph* g, hipStream_t s);
 
 ovs_status ba_graph_ensure_solver(ovs_ba_graph* g, hipStream_t s) {
     if (g->d_Hinv) return OVS_OK;
@@ -922,7 +923,17 @@ static ovs_status solver_workspace_create(ovs_ba_graph* g, hipStream_t s) {
     }
     g->s_pitch = n_pad;
     g->d_rhs = g->d_S + (size_t)n_pad * n_pad;
-    OVS_HIP_TRY(hipMemsetAsync(g->d_S, 0, sizeof(double) * sys, s));
+    return ba_graph_reset_system(g, s);
+}
+
+// The padded system's constant part: everything zero, an identity block on rows / columns n .. n_pad - 1 (ba_solve.hip: "the padding reproduces
+// itself"). Written when the workspace is created -- and again after a FAILED solve: a non-finite entry of S reaches the padding through the
+// trailing update (0 * NaN) before any pivot is tested, and the schur kernels rewrite the n x n part and the right-hand side only, so without the
+// repair every later trial on this graph would fail as well, whatever lambda grows to.
+ovs_status ba_graph_reset_system(ovs_ba_graph* g, hipStream_t s) {
+    if (!g->d_S) return OVS_OK;
+    const int n = 6 * std::max(g->n_free, 1), n_pad = g->s_pitch;
+    OVS_HIP_TRY(hipMemsetAsync(g->d_S, 0, sizeof(double) * dense_solve_doubles(n), s));
     const std::vector<double> ones((size_t)std::max(n_pad - n, 1), 1.0);
     if (n_pad > n)
         OVS_HIP_TRY(hipMemcpy2DAsync(g->d_S + (size_t)n * n_pad + n, sizeof(double) * ((size_t)n_pad + 1), ones.data(), sizeof(double), sizeof(double),

@@ -47,6 +47,7 @@ int dense_solve_max_n();
 int dense_solve_pad(int n);
 size_t dense_solve_doubles(int n);
 ovs_status launch_dense_solve(double* d_S, int n, int32_t* d_fail, hipStream_t s, unsigned long long* d_tstats = nullptr);
+ovs_status ba_graph_reset_system(ovs_ba_graph* g, hipStream_t s);
 ovs_status launch_pose_update(const double* d_T, const int32_t* d_slot_of_pose, int n_pose, const double* d_x, const double* d_bp, double lambda,
                               double* d_Tn, double* d_p7n, double* d_dxp, double* d_scal_pose, hipStream_t s);
 // where the reduced camera system is solved: 0 = on the device (k_chol_solve), 1 = on the host (ba_host_math.h cholesky_solve)
@@ -259,6 +260,10 @@ struct Lm {
                     OVS_HIP_TRY(hipStreamSynchronize(stream));
                     const bool ok = *h_fail == 0;
                     double temp_chi = 1.7976931348623157e308, scale = 1e-3;
+                    if (!ok) {   // a failed factorisation may have left non-finite values in the padding, which no later trial rewrites
+                        st = ovs::ba_graph_reset_system(g, stream);
+                        if (st != OVS_OK) return st;
+                    }
                     if (ok) {
                         temp_chi = h_chi[1];
                         scale = (h_chi[5] + h_chi[4]) + 1e-3;   // keyframes' part, then the landmarks' (g2o's computeScale order)

@@ -121,7 +121,7 @@ __device__ __forceinline__ void factor_diagonal_block(double* __restrict__ P, do
 #pragma unroll
     for (int k = 0; k < kNb; ++k) {
         const double piv = lane_bcast(a[k], k);
-        bad |= !(piv > 0.0);
+        bad |= !(piv > 0.0 && piv < __builtin_inf());   // (+Inf would pass `> 0` and turn into NaN in the Newton steps)
         const double y = rsqrt_newton(piv);
         a[k] = (r == k) ? piv * y : a[k] * y;
         if (lane == k) invd[j0 + k] = y;
@@ -365,6 +365,278 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_solve(double* __restrict
     SOLVE_MARK(6)   // backward substitution
 #undef SOLVE_MARK
 }
+// ================================================================================================================================
+// k_chol_resident (round 5): the same factorisation for systems up to 288 unknowns (BASELINE config 5: 48 free keyframes) with the TRAILING
+// MATRIX RESIDENT IN REGISTERS. k_chol_solve above moves every trailing tile through one compute unit's memory path once per panel (8 MB read +
+// written at n = 288: half of its 250 us, see the header); here a wave keeps its share of the 16 x 16 tiles as matrix-core accumulators for the
+// whole kernel: tile (ti, tc), 1 <= tc <= ti, number t in column-major order, lives in wave t % 8, accumulator slot t / 8 (153 tiles at 18 tile
+// rows: 20 slots = 160 registers). A tile leaves the registers once: after the update by panel tc - 1 it is written into the LDS panel buffer
+// of panel tc, where it is factored / solved and from where the trailing updates of panel tc read their operands. Per panel: wave 0 factors
+// the diagonal block (broadcasts by DPP row_newbcast inside the 16-lane row instead of v_readlane pairs through scalar registers: ~190
+// instead of ~420 cycles per pivot) and forward-substitutes the right-hand side's block, one thread per row solves the rows below it (and
+// takes the block out of its right-hand side entry: the rhs is a vector in LDS here, not a tile row), the finished panel goes to memory for
+// the backward substitution, then every wave runs four v_mfma_f64_16x16x4_f64 per resident tile with A / B from the LDS panel.
+// Same arithmetic per entry as k_chol_solve (fused multiply-adds, the matrix cores' order inside a 16 x 16 x 16 product), same storage, same
+// result to rounding; identical bits from run to run.
+constexpr int kResSlots = 18;      // accumulator slots per wave (144 registers: 19 already spill); tiles beyond 8 x kResSlots live in LDS (lane-major, 2 KB each)
+constexpr int kResMaxPad = 288;
+constexpr int kResMaxTiles = (kResMaxPad / 16) * (kResMaxPad / 16 - 1) / 2;   // 153
+
+template <int N>
+__device__ __forceinline__ double row_bcast_c(double v) {   // lane N of every 16-lane row -> all lanes of that row
+    union {
+        double d;
+        int i[2];
+    } u, w;
+    u.d = v;
+    w.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x150 + N, 0xf, 0xf, false);   // row_newbcast:N
+    w.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x150 + N, 0xf, 0xf, false);
+    return w.d;
+}
+__device__ __forceinline__ double row_bcast(double v, int n) {   // n is a constant after unrolling: the switch folds away
+    switch (n) {
+        case 0: return row_bcast_c<0>(v);
+        case 1: return row_bcast_c<1>(v);
+        case 2: return row_bcast_c<2>(v);
+        case 3: return row_bcast_c<3>(v);
+        case 4: return row_bcast_c<4>(v);
+        case 5: return row_bcast_c<5>(v);
+        case 6: return row_bcast_c<6>(v);
+        case 7: return row_bcast_c<7>(v);
+        case 8: return row_bcast_c<8>(v);
+        case 9: return row_bcast_c<9>(v);
+        case 10: return row_bcast_c<10>(v);
+        case 11: return row_bcast_c<11>(v);
+        case 12: return row_bcast_c<12>(v);
+        case 13: return row_bcast_c<13>(v);
+        case 14: return row_bcast_c<14>(v);
+        default: return row_bcast_c<15>(v);
+    }
+}
+
+// wave 0: the diagonal block (P rows 0..15; lane r of every 16-lane row holds row r) and y = L_dd^-1 rhs_block (vec[j0 ..]); leaves L_dd in P,
+// 1 / L[c][c] in invd
+__device__ __forceinline__ void factor_block_dpp(double* __restrict__ P, double* __restrict__ invd, double* __restrict__ vec, int j0, int lane,
+                                                 int* s_bad) {
+    const int r = lane & 15;
+    double a[kNb];
+#pragma unroll
+    for (int c = 0; c < kNb; ++c) a[c] = P[r * kPitch + c];
+    double s = vec[j0 + r], my_inv = 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < kNb; ++k) {
+        const double piv = row_bcast(a[k], k);
+        bad |= !(piv > 0.0 && piv < __builtin_inf());
+        const double y = rsqrt_newton(piv);
+        a[k] = (r == k) ? piv * y : a[k] * y;
+        my_inv = (r == k) ? y : my_inv;
+#pragma unroll
+        for (int c = k + 1; c < kNb; ++c) a[c] = __builtin_fma(-a[k], row_bcast(a[k], c), a[c]);   // L[c][k] sits in lane c
+    }
+    // forward substitution of the block's right-hand side: lane r carries rhs_r - sum_{c < r} L[r][c] y_c
+#pragma unroll
+    for (int k = 0; k < kNb; ++k) {
+        const double yk = row_bcast(s * my_inv, k);
+        s = (r == k) ? yk : (r > k ? __builtin_fma(-a[k], yk, s) : s);
+    }
+    if (lane < kNb) {
+#pragma unroll
+        for (int c = 0; c < kNb; ++c)
+            if (c <= r) P[r * kPitch + c] = a[c];
+        invd[j0 + r] = my_inv;
+        vec[j0 + r] = s;   // y
+        if (bad) *s_bad = 1;   // (lanes of one wave: the same value, any order)
+    }
+}
+
+// rows below the block, one thread per row: x L_dd^T = p, then the row's right-hand side entry loses x . y_block
+__device__ __forceinline__ void solve_rows_res(double* __restrict__ P, const double* __restrict__ invd, double* __restrict__ vec, int j0, int m,
+                                               int tid, int lane) {
+    double lreg[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int t = lane + 64 * u;   // -> (c, k), k <= c: c = the largest integer with c (c + 1) / 2 <= t
+        int c = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        c += ((c + 1) * (c + 2) / 2 <= t) ? 1 : 0;
+        c -= (c * (c + 1) / 2 > t) ? 1 : 0;
+        const int k = t - c * (c + 1) / 2;
+        lreg[u] = t < kNb * (kNb + 1) / 2 ? P[c * kPitch + k] : 0.0;
+    }
+    double ivreg = invd[j0 + (lane & 15)], yreg = vec[j0 + (lane & 15)];
+    for (int r = kNb + tid; r < m; r += kSolveThreads) {
+        asm volatile("" : "+v"(lreg[0]), "+v"(lreg[1]), "+v"(lreg[2]), "+v"(ivreg), "+v"(yreg));   // broadcasts stay inside the row loop (scalar registers)
+        double x[kNb];
+#pragma unroll
+        for (int c = 0; c < kNb; ++c) x[c] = P[r * kPitch + c];
+        double dot = 0.0;
+#pragma unroll
+        for (int c = 0; c < kNb; ++c) {
+            double v = x[c];
+#pragma unroll
+            for (int k = 0; k < c; ++k) {
+                const int t = c * (c + 1) / 2 + k;
+                v = __builtin_fma(-x[k], lane_bcast(lreg[t >> 6], t & 63), v);
+            }
+            x[c] = v * lane_bcast(ivreg, c);
+            dot = __builtin_fma(x[c], lane_bcast(yreg, c), dot);
+        }
+#pragma unroll
+        for (int c = 0; c < kNb; ++c) P[r * kPitch + c] = x[c];
+        vec[j0 + r] -= dot;
+    }
+}
+
+// Tiles are numbered from the BOTTOM-RIGHT corner: u = NT - 1 - ti, v = NT - 1 - tc (0 <= u <= v <= NT - 2), t = v (v + 1) / 2 + u. Then the
+// tiles panel j still updates (tc > j) are the first jj (jj + 1) / 2 numbers, jj = NT - 1 - j, and the tiles beyond the register slots (kept
+// in LDS) are those of the FIRST tile columns, which leave after one or two updates.
+//
+// One tile's update C -= A B^T as inline assembly with the accumulator TIED ("+v"): through the builtin, a matrix instruction under the
+// (wave-uniform) "is this slot's tile still active" branch made hipcc keep the old and the new accumulator apart -- the untied three-address form,
+// 8 more registers per slot, or whole second copies of the accumulator file across a switch -- and spill a third of the tiles. Wait states
+// inside the string (nothing in it is padded by the compiler): the A operands were just written by the negating v_xor (s_nop before the first
+// matrix instruction); the chain of four accumulates needs none; the result is read by compiler code afterwards (ds_write of a finished
+// tile): a 16-pass f64 matrix instruction needs 18 states before a memory / LDS / VALU reader -- 24 are spent (s_nop 15 + s_nop 7 = 10 ns per tile).
+__device__ __forceinline__ int res_active_tiles(int jj) { return jj * (jj + 1) / 2; }
+__device__ __forceinline__ void tile_update_tied(v4d& c, double a0, double a1, double a2, double a3, double b0, double b1, double b2, double b3) {
+    asm volatile(
+        "s_nop 3\n"
+        "v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n"
+        "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n"
+        "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n"
+        "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n"
+        "s_nop 15\n"
+        "s_nop 7\n"
+        : "+v"(c)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+
+// kTimed: the OVS_BA_TRACE build with phase marks (thread 0 adds its wall_clock64 intervals to tstats[0 .. 7]); the product instantiation carries
+// none -- the marks' branches and 64-bit atomics inside the panel loop cost the register allocator 100 registers' worth of spills.
+// A failed pivot does NOT leave the kernel early (a second exit from the panel loop had the same effect): the factorisation runs on with
+// NaNs and the flag is raised at the end.
+template <bool kTimed>
+__global__ __launch_bounds__(kSolveThreads) void k_chol_resident(double* __restrict__ S, int n_pad, int32_t* __restrict__ fail,
+                                                                unsigned long long* __restrict__ tstats) {
+    extern __shared__ double lds[];
+    const int panel_doubles = n_pad * kPitch;
+    double* P = lds;                      // the panel: row r <-> logical row j0 + r
+    double* Pn = lds + panel_doubles;     // the next panel's columns
+    double* const vec = lds + 2 * (size_t)panel_doubles;   // n_pad: rhs, then y, then x
+    double* const invd = vec + n_pad;                      // n_pad: 1 / L[c][c]
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int kWaves = kSolveThreads / 64;
+    const int rl = lane & 15, kq = lane >> 4;
+    const int NT = n_pad / kNb;
+    const int n_tiles = NT * (NT - 1) / 2;
+    if (tid == 0) s_bad = 0;
+    unsigned long long t_prev = kTimed ? wall_clock64() : 0;
+#define SOLVE_MARK(i)                                        \
+    if (kTimed && tid == 0) {                                \
+        const unsigned long long t_now = wall_clock64();     \
+        atomicAdd(&tstats[i], t_now - t_prev);               \
+        t_prev = t_now;                                      \
+    }
+    // ---- tile t <-> (ti, tc): a table in LDS (ti | tc << 8), built once
+    __shared__ int s_td[kResMaxTiles];
+    for (int t = tid; t < n_tiles; t += kSolveThreads) {
+        int v = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        v += ((v + 1) * (v + 2) / 2 <= t) ? 1 : 0;
+        v -= (v * (v + 1) / 2 > t) ? 1 : 0;
+        const int u = t - v * (v + 1) / 2;
+        s_td[t] = (NT - 1 - u) | ((NT - 1 - v) << 8);
+    }
+    __syncthreads();
+    // ---- this wave's tiles: slots 0 .. kResSlots - 1 in registers, the rest (tiles 8 kResSlots + u, u = wave, wave + 8, ...: the first tile
+    //      columns, which leave after one or two updates) in LDS behind the panels, lane-major: value e of lane l of tile u at T[(u * 4 + e) * 64 + l]
+    double* const T = invd + n_pad;
+    const int n_lds = n_tiles > kWaves * kResSlots ? n_tiles - kWaves * kResSlots : 0;
+    int sd[kResSlots];
+    v4d acc[kResSlots];
+    const int lane_off = kq * n_pad + rl;
+#pragma unroll
+    for (int s = 0; s < kResSlots; ++s) {
+        const int t = kWaves * s + wave;
+        // (a slot without a tile -- small systems -- loads tile 0's values, which nothing reads: its number is never below the active count)
+        sd[s] = __builtin_amdgcn_readfirstlane(s_td[t < n_tiles ? t : 0]);
+        // uniform tile origin + the lane's own 32-bit offset (the same four offsets for every tile): scalar-base loads
+        const double* base = S + (size_t)(kNb * (sd[s] & 0xff)) * n_pad + kNb * (sd[s] >> 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[s][e] = base[lane_off + e * 4 * n_pad];
+    }
+    for (int u = wave; u < n_lds; u += kWaves) {
+        const int d = __builtin_amdgcn_readfirstlane(s_td[kWaves * kResSlots + u]);
+        const double* src = S + (size_t)(kNb * (d & 0xff) + kq) * n_pad + kNb * (d >> 8) + rl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T[(u * 4 + e) * 64 + lane] = src[(size_t)(4 * e) * n_pad];
+    }
+    for (int i = tid; i < n_pad; i += kSolveThreads) vec[i] = S[(size_t)n_pad * n_pad + i];
+    for (int idx = tid; idx < n_pad * kNb; idx += kSolveThreads) {
+        const int r = idx >> 4, c = idx & 15;
+        P[r * kPitch + c] = S[(size_t)r * n_pad + c];
+    }
+    __syncthreads();
+    SOLVE_MARK(0)   // loads
+    for (int j = 0; j < NT; ++j) {
+        const int j0 = j * kNb, m = n_pad - j0;
+        if (wave == 0) factor_block_dpp(P, invd, vec, j0, lane, &s_bad);
+        lds_barrier();
+        SOLVE_MARK(1)   // diagonal block + forward substitution of its rhs + barrier
+        solve_rows_res(P, invd, vec, j0, m, tid, lane);
+        lds_barrier();
+        SOLVE_MARK(2)   // row solves + barrier
+        write_back_panel(S, P, j0, m, n_pad, tid);
+        SOLVE_MARK(3)   // write-back (thread 0's share)
+        // ---- trailing update C -= P_ti P_tc^T of the resident tiles; the tiles of the next panel's column move to its LDS buffer
+        const int jj = NT - 1 - j;
+#pragma unroll
+        for (int s = 0; s < kResSlots; ++s) {
+            if (kWaves * s + wave < res_active_tiles(jj)) {   // (wave-uniform)
+                const int ti = sd[s] & 0xff, tc = sd[s] >> 8;
+                const double* pa = P + (kNb * (ti - j) + rl) * kPitch + kq;
+                const double* pb = P + (kNb * (tc - j) + rl) * kPitch + kq;
+                tile_update_tied(acc[s], -pa[0], -pa[4], -pa[8], -pa[12], pb[0], pb[4], pb[8], pb[12]);
+                if (tc == j + 1) {   // the next panel's column: the tile is final, it moves to that panel's buffer
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Pn[(kNb * (ti - j - 1) + kq + 4 * e) * kPitch + rl] = acc[s][e];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one tile's operands at a time: the scheduler otherwise hoists the LDS reads of all slots (16 registers each)
+        }
+        const int n_act = res_active_tiles(jj);
+        for (int u = wave; u < n_lds; u += kWaves) {   // the tiles that live in LDS
+            if (kWaves * kResSlots + u >= n_act) break;
+            const int d = __builtin_amdgcn_readfirstlane(s_td[kWaves * kResSlots + u]);
+            const int ti = d & 0xff, tc = d >> 8;
+            v4d c4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c4[e] = T[(u * 4 + e) * 64 + lane];
+            const double* pa = P + (kNb * (ti - j) + rl) * kPitch + kq;
+            const double* pb = P + (kNb * (tc - j) + rl) * kPitch + kq;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * s4], pb[4 * s4], c4, 0, 0, 0);
+            if (tc == j + 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Pn[(kNb * (ti - j - 1) + kq + 4 * e) * kPitch + rl] = c4[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[(u * 4 + e) * 64 + lane] = c4[e];
+            }
+        }
+        SOLVE_MARK(4)   // trailing update, wave 0's tiles
+        lds_barrier();
+        SOLVE_MARK(5)   // ... waiting for the other waves
+        double* const t = P;
+        P = Pn;
+        Pn = t;
+    }
+    __syncthreads();   // the panels written back above are read by other threads below
+    backward_substitution(S, vec, invd, n_pad, tid, lane, wave);
+    SOLVE_MARK(6)   // backward substitution
+#undef SOLVE_MARK
+}
 static_assert(kMaxN % kSolveThreads == 0, "columns per thread in the backward substitution");
 
 // ---- LM trial state of the keyframes ------------------------------------------------------------------------------------------------
@@ -483,6 +755,24 @@ size_t dense_solve_doubles(int n) { return (size_t)(dense_solve_pad(n) + kNb) * 
 ovs_status launch_dense_solve(double* d_S, int n, int32_t* d_fail, hipStream_t s, unsigned long long* d_tstats) {
     if (n < 1 || n > dense_solve_max_n()) return OVS_ERR_INVALID;
     const int n_pad = dense_solve_pad(n);
+    if (n_pad <= kResMaxPad && tuning().chol_resident) {   // the trailing matrix fits the register file: k_chol_resident
+        const int nt = n_pad / kNb, n_tiles = nt * (nt - 1) / 2, n_lds = std::max(0, n_tiles - (kSolveThreads / 64) * kResSlots);
+        const size_t lds = sizeof(double) * (2 * (size_t)n_pad * kPitch + 2 * (size_t)n_pad + (size_t)n_lds * 256);
+        static LdsAttrCache cache_r;
+        static LdsAttrCache cache_t;
+        const void* fn = d_tstats ? reinterpret_cast<const void*>(k_chol_resident<true>) : reinterpret_cast<const void*>(k_chol_resident<false>);
+        hipError_t e = ensure_dynamic_lds(fn, lds, d_tstats ? cache_t : cache_r);
+        if (e != hipSuccess) {
+            set_last_error("hipFuncSetAttribute(k_chol_resident)", e);
+            return OVS_ERR_HIP;
+        }
+        if (d_tstats)
+            hipLaunchKernelGGL(k_chol_resident<true>, dim3(1), dim3(kSolveThreads), lds, s, d_S, n_pad, d_fail, d_tstats);
+        else
+            hipLaunchKernelGGL(k_chol_resident<false>, dim3(1), dim3(kSolveThreads), lds, s, d_S, n_pad, d_fail, d_tstats);
+        OVS_LAUNCH_TRY("k_chol_resident");
+        return OVS_OK;
+    }
     const size_t panel = sizeof(double) * (size_t)(n_pad + kNb) * kPitch, rest = sizeof(double) * 2 * (size_t)n_pad;
     const int dbuf = 2 * panel + rest <= (size_t)150 * 1024 ? 1 : 0;   // two panels in LDS up to 528 unknowns
     const size_t lds = (dbuf ? 2 : 1) * panel + rest;
@@ -535,7 +825,7 @@ ovs_status ovs_ba_dense_solve(int32_t device, const double* S, const double* rhs
         unsigned long long h_t[8] = {};
         (void)hipMemcpy(h_t, d_t, sizeof(h_t), hipMemcpyDeviceToHost);
         static const char* nm[7] = {"requests+panel load", "diagonal block", "row solves", "write-back", "trailing (wave 0)", "trailing (others)", "backward"};
-        std::fprintf(stderr, "[k_chol_solve n=%d]", n);
+        std::fprintf(stderr, "[dense solve n=%d]", n);
         for (int i = 0; i < 7; ++i) std::fprintf(stderr, " %s %.1f us,", nm[i], h_t[i] * 0.01);
         std::fprintf(stderr, "\n");
     }

@@ -36,7 +36,8 @@ const Tuning& tuning() {
         v.pose_threads = num("OVS_POSE_THREADS", 0);
         v.pose_groups = std::max(0, num("OVS_POSE_GROUPS", 0));
         v.ba_trace = std::getenv("OVS_BA_TRACE") != nullptr;
-        v.pyr_chain = std::max(0, num("OVS_PYR_CHAIN", 1));
+        v.pyr_chain = std::max(0, num("OVS_PYR_CHAIN", 2));
+        v.chol_resident = num("OVS_CHOL_RESIDENT", 1) != 0;
         return v;
     }();
     return t;

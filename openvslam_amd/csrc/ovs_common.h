@@ -139,7 +139,8 @@ struct Tuning {
     int pose_threads;      // OVS_POSE_THREADS: 256 / 512 (0 = by problem size)
     int pose_groups;       // OVS_POSE_GROUPS: workgroups a single frame's pose optimisation is spread over (0 = by observation count, 1 = one)
     bool ba_trace;         // OVS_BA_TRACE: per-iteration trace of the LM loops on stderr
-    int pyr_chain;         // OVS_PYR_CHAIN: frames per launch up to which the pyramid is ONE k_pyramid_chain launch (default 1: measured 28 vs 34 us for one frame, 40 vs 38 for two; 0 = never)
+    bool chol_resident;    // OVS_CHOL_RESIDENT=0: systems up to 288 unknowns take k_chol_solve (tiles through memory) instead of k_chol_resident
+    int pyr_chain;         // OVS_PYR_CHAIN: frames per launch up to which the pyramid is ONE k_pyramid_chain launch (default 2: measured 24 vs 37 us for one frame, 33.5 vs 35.7 for two, 73 vs 46 for eight; 0 = never)
 };
 const Tuning& tuning();
 

@@ -188,7 +188,7 @@ class orb_extractor:
         self._fast_split = 1 if enable else 0
 
     def set_pyramid_chain(self, max_frames):
-        """All pyramid levels in ONE launch for calls of at most max_frames frames (default 1: the tracker's single frame); 0 / False = level-by-level
+        """All pyramid levels in ONE launch for calls of at most max_frames frames (default 2: the tracker's single frame or stereo pair); 0 / False = level-by-level
         launches always."""
         _lib.check(self._L.ovs_orb_set_pyramid_chain(self._h, int(max_frames)), "ovs_orb_set_pyramid_chain")
         self._pyramid_chain = int(max_frames)

@@ -1,6 +1,8 @@
 """GPU parity of the local-BA linearisation (config 5: 50 keyframes x 2000 observations, 20 000 landmarks, fp64).
 Stated tolerances (BASELINE north_star asks for them): per-edge Hpl blocks bit-exact; sums (Hpp, bp, Hll, bl, chi2) within
 1e-12 relative on one GPU (atomic summation order), the multi-rank path is covered on CPU with 1e-10."""
+import os
+
 import numpy as np
 import pytest
 
@@ -387,9 +389,10 @@ def _spd(rng, n, cond):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1, 6, 15, 16, 17, 30, 96, 282, 288, 600, 1024])
+@pytest.mark.parametrize("n", [1, 6, 15, 16, 17, 30, 33, 48, 96, 144, 150, 208, 256, 272, 282, 287, 288, 289, 304, 600, 1024])
 def test_dense_solve_matches_numpy(n):
-    """k_chol_solve alone (ovs_ba_dense_solve): blocked Cholesky on the f64 matrix cores + both substitutions against numpy's LAPACK solve,
+    """The dense solver alone (ovs_ba_dense_solve: k_chol_resident up to 288 unknowns -- trailing tiles in registers / LDS, every tile-row count from 1
+    to 18 --, k_chol_solve beyond): blocked Cholesky on the f64 matrix cores + both substitutions against numpy's LAPACK solve,
     at sizes that are / are not multiples of the 16-column panel, up to the largest system the one-workgroup solver stages. The error of a
     backward-stable solve is ~cond * eps relative; twice the same call gives the same bits."""
     from openvslam_amd import ba
@@ -410,10 +413,42 @@ def test_dense_solve_matches_numpy(n):
 
 
 @pytest.mark.gpu
+def test_resident_and_through_memory_solvers_agree(tmp_path):
+    """k_chol_resident (default up to 288 unknowns) against k_chol_solve (OVS_CHOL_RESIDENT=0, a process-wide switch: run in a child process) on the
+    same systems: the two differ in the order of the fused multiply-adds only (~cond x 1e-16 relative); the phase-timed instantiation
+    (OVS_BA_TRACE) returns the product instantiation's bits."""
+    import subprocess
+    import sys
+    from openvslam_amd import ba
+    rng = np.random.default_rng(77)
+    cases = {}
+    for n in (40, 96, 200, 288):
+        S = _spd(rng, n, 1e4)
+        rhs = rng.standard_normal(n)
+        cases["S%d" % n], cases["r%d" % n] = S, rhs
+    np.savez(tmp_path / "in.npz", **cases)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from openvslam_amd import ba; d = np.load(%r); "
+            "np.savez(%r, **{'x%%s' %% k[1:]: ba.dense_solve(d[k], d['r' + k[1:]]) for k in d.files if k[0] == 'S'})")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tag, env in (("mem", {"OVS_CHOL_RESIDENT": "0"}), ("timed", {"OVS_BA_TRACE": "1"})):
+        out = tmp_path / ("out_%s.npz" % tag)
+        r = subprocess.run([sys.executable, "-c", code % (root, str(tmp_path / "in.npz"), str(out))], env=dict(os.environ, **env), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = np.load(out)
+        for n in (40, 96, 200, 288):
+            x = ba.dense_solve(cases["S%d" % n], cases["r%d" % n])
+            if tag == "timed":
+                assert np.array_equal(got["x%d" % n], x), n
+                assert "dense solve n=%d" % n in r.stderr
+            else:
+                assert np.abs(got["x%d" % n] - x).max() <= 1e-10 * np.abs(x).max(), n
+
+
+@pytest.mark.gpu
 def test_dense_solve_reports_a_matrix_that_is_not_positive_definite():
     from openvslam_amd import ba
     rng = np.random.default_rng(7)
-    for n, bad_at in ((48, 5), (48, 40), (50, 49)):
+    for n, bad_at in ((48, 5), (48, 40), (50, 49), (288, 3), (288, 280), (400, 17)):
         S = _spd(rng, n, 10.0)
         S[bad_at, bad_at] = -1.0   # an indefinite matrix: some pivot at or before `bad_at` is not positive
         with pytest.raises(RuntimeError, match="positive definite"):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 GPU calls, one parameterised script (replaces the one-off tools/gpu_r04_*.sh). Usage: tools/gpu_r05.sh <tag> <step> [<step> ...]
-# steps: pytest | bench | trace | pmc | tie | fuzz | latency | lba | custom:<cmd>
+# steps: pytest | bench | trace | pmc | tie | fuzz | lba | asan | custom:<cmd>
 cd /root/repo
 tag=$1; shift
 mkdir -p gpurun_out
@@ -22,6 +22,21 @@ tie)
   timeout 600 python tools/tie_fuzz_gpu.py 300 > gpurun_out/${tag}_tie_fuzz.txt 2>&1; echo "tie fuzz rc=$?"; tail -8 gpurun_out/${tag}_tie_fuzz.txt ;;
 fuzz)
   timeout 900 python tools/fuzz_parity.py --seeds 3 > gpurun_out/${tag}_fuzz.txt 2>&1; echo "fuzz rc=$?"; tail -8 gpurun_out/${tag}_fuzz.txt ;;
+lba)
+  timeout 300 python tools/time_lba.py device 6 2>&1 | tail -3
+  OVS_BA_TRACE=1 timeout 120 python tools/chol_trace.py 2>&1 | grep "dense solve" | tee gpurun_out/${tag}_chol_phases.txt
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/${tag}_lba_prof -o lba -- python /root/repo/tools/time_lba.py device 3 > /dev/null 2>&1 )
+  f=$(find gpurun_out/${tag}_lba_prof -name '*kernel_stats.csv' | head -1)
+  python - "$f" <<'PY' > gpurun_out/${tag}_lba_kernel_stats.txt
+import csv, sys
+print("# rocprofv3 --kernel-trace --stats -- python tools/time_lba.py device 3   (3 calls of ovs_local_ba_optimize at BASELINE config 5: 15 LM trials each)")
+for r in csv.DictReader(open(sys.argv[1])):
+    print("%-30s calls %4s avg %9.1f us  %7s %%" % (r["Name"].split("(")[0][:30], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+PY
+  head -14 gpurun_out/${tag}_lba_kernel_stats.txt
+  find gpurun_out/${tag}_lba_prof -name '*.csv' -size +1M -delete; find gpurun_out/${tag}_lba_prof -name '*.db' -delete ;;
+asan)
+  bash tools/run_asan.sh ${tag} ;;
 custom:*)
   cmd="${step#custom:}"; echo "+ $cmd"; timeout 1200 bash -c "$cmd" ;;
 *) echo "unknown step $step" ;;
