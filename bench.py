@@ -518,17 +518,25 @@ def main():
             valu_counts["fast"] = live_valu
         if valu_counts.get("fast"):
             fast_s = iso_ms["fast"] / n_chain * 1e-3
-            # one VALU wave-instruction occupies a SIMD's issue slot for 4 cycles: on this kernel SQ_ACTIVE_INST_VALU (busy quad-cycles) equals
-            # SQ_INSTS_VALU to four digits (profiles/r04b_pmc_sq_summary.txt), i.e. the 2.3-cycle back-to-back rate tools/ubench/valu_rate.hip measures
-            # for 16-bit VOP2 ops is not what a mixed instruction stream gets. (Rounds 2-3 priced every instruction at 4.2 cycles: overstated.)
+            # What one VALU wave-instruction of THIS kernel costs a SIMD: measured with mixed instruction streams at the kernel's 7 waves per SIMD
+            # (tools/ubench/valu_rate mix, profiles/r05d_valu_mix.txt): the pre-test's opcode mix (5 v_alignbyte + 18 v_sub/v_add + 2 v_or + 6 v_bitop3 + 1 v_and
+            # per 4-pixel group, with its real dependences) issues at 3.71 cycles per instruction, the exact scorer's mix (16-bit min / max with a
+            # v_perm / v_bfe every fourth) at 2.69, a pure fast-class VOP2 stream of the same shape at 2.77 -- neither the 2.3-cycle back-to-back rate of
+            # a single opcode nor the 4 cycles per instruction rounds 3-4 priced everything at (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU on this kernel is
+            # the counter's quad-cycle quantisation, not a busy measure). Weighted by the kernel's own mix per wave and cell (~160
+            # pre-test, ~250 scoring, ~136 prologue / compaction / NMS instructions, the last group priced at 4.0): 3.32 cycles.
+            cyc = (160 * 3.71 + 250 * 2.69 + 136 * 4.0) / 546.0
             roofline_valu["k_fast_cells"] = {"unit": "VALU wave-instructions/s", "achieved": round(valu_counts["fast"] / fast_s, 1),
-                                             "peak": round(simd_hz / 4.0, 1), "frac": round(valu_counts["fast"] / fast_s / (simd_hz / 4.0), 4),
+                                             "peak": round(simd_hz / cyc, 1), "frac": round(valu_counts["fast"] / fast_s / (simd_hz / cyc), 4),
+                                             "cycles_per_instruction_model": round(cyc, 3),
+                                             "frac_if_every_instruction_cost_4_cycles": round(valu_counts["fast"] / fast_s / (simd_hz / 4.0), 4),
                                              "launch_ms_alone": round(fast_s * 1e3, 5), "insts_valu_per_launch": valu_counts["fast"],
                                              "insts_source": "rocprofv3 --pmc SQ_INSTS_VALU child pass of this run" if live_valu is not None
                                              else "profiles/pmc_traffic.json (SQ_INSTS_VALU pass)",
-                                             "floor_model": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per VALU wave-instruction (the counter's own "
-                                                            "busy measure: SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU on this kernel); LDS pipe busy 47 % "
-                                                            "beside it (SQ_LDS_IDX_ACTIVE, a third of it bank conflicts)"}
+                                             "floor_model": "256 CUs x 4 SIMDs x 2.4 GHz / 3.32 cycles per VALU wave-instruction (mixed-stream microbenchmark "
+                                                            "at 7 waves per SIMD, weighted by the kernel's instruction mix); about 0.37 of the issue slots "
+                                                            "are free: the kernel is bound by a cell's latency chain (LDS gathers with bank conflicts, "
+                                                            "six barriers) together with the vector ALU, not by the ALU alone"}
         # ---- per-call latency of orb_extractor::extract through the C++ class boundary at THIS config's size, H2D / D2H
         # included (openvslam_amd/cpp/bench_shim; one call = one upload, one kernel chain, one D2H, one wait)
         class_lat = None

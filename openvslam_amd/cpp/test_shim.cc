@@ -348,6 +348,7 @@ int main(int argc, char** argv) {
     std::fwrite(mut_2_in_1.data(), sizeof(int32_t), mut_2_in_1.size(), f);
     std::fwrite(bk_2_in_1.data(), sizeof(int32_t), bk_2_in_1.size(), f);
     std::fclose(f);
-    std::printf("shim ok: %u + %u keypoints, %u matches, scale[7]=%f\n", frm.num_keypts_, keyfrm.num_keypts_, n, extractor.get_scale_factors().at(7));
+    std::printf("shim ok: %u + %u keypoints, %u matches, scale[7]=%f (area %u, frame_and_landmarks %u, bow %u, current_and_last %u, triangulation %u)\n",
+                frm.num_keypts_, keyfrm.num_keypts_, n, extractor.get_scale_factors().at(7), n_area, n_proj, n_bow, n_cl, n_tri);
     return 0;
 }

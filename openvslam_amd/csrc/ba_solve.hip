@@ -548,6 +548,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_resident(double* __restr
         const int u = t - v * (v + 1) / 2;
         s_td[t] = (NT - 1 - u) | ((NT - 1 - v) << 8);
     }
+    if (tid == 0 && n_tiles == 0) s_td[0] = 0;   // (one tile row: the slots' stand-in loads below read tile (0, 0), i.e. valid memory)
     __syncthreads();
     // ---- this wave's tiles: slots 0 .. kResSlots - 1 in registers, the rest (tiles 8 kResSlots + u, u = wave, wave + 8, ...: the first tile
     //      columns, which leave after one or two updates) in LDS behind the panels, lane-major: value e of lane l of tile u at T[(u * 4 + e) * 64 + l]

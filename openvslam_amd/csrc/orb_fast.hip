@@ -72,9 +72,13 @@ constexpr int kMaxSurvivors = 1024;   // NMS survivors are pairwise non-adjacent
 //     only (no vmcnt drain), a cell's geometry is ONE 8-byte record (CellDesc) instead of a chain of dependent scalar loads, and the
 //     NMS survivors of the group's cells are buffered in LDS and appended with ONE global reservation per group instead of one atomic
 //     round trip per cell (that round trip alone was a fifth of a cell's latency).
-// What the measurements say: the kernel is bound by neither the vector ALU (~55 % busy) nor LDS (~60 %) nor HBM
-// (1.2 TB/s) alone but by the latency chain of a cell -- six LDS-only barriers, dependent LDS gathers of the exact scoring / NMS with 3-4x
-// bank conflicts -- at the 24 waves per CU that 26 KB of LDS leave. Halving the pre-test's cycles, an eight-diameter pre-test (-22 %
+// What the measurements say (settled in round 5 by a mixed-stream microbenchmark, tools/ubench/valu_rate mix,
+// profiles/r05d_valu_mix.txt): at this kernel's 7 waves per SIMD the pre-test's real opcode mix issues at 3.71 cycles per wave-instruction, the
+// scorer's 16-bit min / max mix at 2.69 -- weighted by the kernel's mix 3.3, so its 8.76e8 VALU wave-instructions per 256 frames keep the vector
+// ALU ~63 % busy (the "4 cycles per instruction, 0.76-0.78 of the issue slots" of rounds 3-4 read the SQ counters' quad-cycle quantisation as a
+// busy measure). The kernel is bound by neither the vector ALU nor LDS (~47 % busy, a third of it bank conflicts) nor HBM (0.9-1.2 TB/s) alone but
+// by the latency chain of a cell -- six LDS-only barriers, dependent LDS gathers of the exact scoring / NMS with 3-4x bank conflicts -- at the 28
+// waves per CU that 21 KB of LDS leave. Halving the pre-test's cycles, an eight-diameter pre-test (-22 %
 // candidates), 8 workgroups per CU (aliased LDS, 64 VGPRs) each moved the launch by < 3 %; the grouping + prefetch + single reservation
 // are worth ~6 % together (0.50 -> 0.47 ms per 64 frames).
 // LDS: raw tile 5.6 KB + R tile 5.6 KB + score map 4.75 KB + pooled list 4 KB + group buffer 1 KB = 21.1 KB -> 7 workgroups per CU (until late in
