@@ -637,6 +637,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_resident(double* __restr
     backward_substitution(S, vec, invd, n_pad, tid, lane, wave);
     SOLVE_MARK(6)   // backward substitution
 #undef SOLVE_MARK
+    if (tid == 0 && s_bad) atomicOr(fail, 2);   // (s_bad was last written before the panel loop's barriers)
 }
 static_assert(kMaxN % kSolveThreads == 0, "columns per thread in the backward substitution");
 
