@@ -266,6 +266,14 @@ ovs_status ovs_wmatcher_destroy(ovs_wmatcher* w);
  * alone). Applies to every matcher with check_orientation (the device resolvers and, through ovs_match_get_variant, the host-side
  * match::angle_checker of the class shims). */
 #define OVS_MATCH_VARIANT_ANGLE_KEEP_RULE 0
+/* rule 17's tie order: ANGLE_TIE_ORDER 0 (default: of two equally full bins the LOWER one ranks first) | 1 (the higher one). Upstream ranks the
+ * bins with std::sort on their sizes (expected src/openvslam/match/angle_checker.h), which leaves equal sizes to the library. Same scope as above. */
+#define OVS_MATCH_VARIANT_ANGLE_TIE_ORDER 1
+/* rule 14's frame-side test in robust::brute_force_match (expected src/openvslam/match/robust.cc): BF_FRAME_MASK 0 (default: a frame keypoint is
+ * skipped only when this call has already matched it) | 1 (also when it already owns a landmark: `if (frm.landmarks_.at(idx_1)) continue;`, as one
+ * recollection of upstream has it). The ABI takes the mask either way (valid_1 of ovs_robust_brute_force_match); this switch is what the class shim
+ * robust::brute_force_match passes. */
+#define OVS_MATCH_VARIANT_BF_FRAME_MASK 2
 ovs_status ovs_match_set_variant(int32_t which, int32_t value);
 int32_t ovs_match_get_variant(int32_t which);   /* -1 for an unknown variant */
 

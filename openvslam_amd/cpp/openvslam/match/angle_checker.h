@@ -36,8 +36,13 @@ private:
     std::vector<T> collect(const bool kept) const {
         std::vector<unsigned int> order(histogram_length_);
         std::iota(order.begin(), order.end(), 0u);
-        std::stable_sort(order.begin(), order.end(),
-                         [&](unsigned int a, unsigned int b) { return angle_histogram_[a].size() > angle_histogram_[b].size(); });
+        // equal sizes: the lower bin first, or (ovs_match_set_variant(OVS_MATCH_VARIANT_ANGLE_TIE_ORDER, 1)) the higher one -- upstream's std::sort
+        // on the sizes leaves this to the library; the device resolvers read the same switch
+        const bool higher_first = ovs_match_get_variant(OVS_MATCH_VARIANT_ANGLE_TIE_ORDER) == 1;
+        std::stable_sort(order.begin(), order.end(), [&](unsigned int a, unsigned int b) {
+            const size_t sa = angle_histogram_[a].size(), sb = angle_histogram_[b].size();
+            return sa > sb || (higher_first && sa == sb && a > b);
+        });
         // rule 17's alternative, the same process-wide switch the device resolvers read (ovs_match_set_variant): ORB-SLAM2's 0.1 x max rule
         unsigned int n_keep = num_bins_thr_ < histogram_length_ ? num_bins_thr_ : histogram_length_;
         if (ovs_match_get_variant(OVS_MATCH_VARIANT_ANGLE_KEEP_RULE) == 1 && n_keep == 3) {

@@ -68,6 +68,14 @@ unsigned int robust::brute_force_match(data::frame& frm, data::keyframe* keyfrm,
         const auto lm_2 = idx_2 < lms_2.size() ? lms_2[idx_2] : nullptr;
         valid[idx_2] = lm_2 && !lm_2->will_be_erased();
     }
+    // rule 14's frame-side test (ovs_match_set_variant(OVS_MATCH_VARIANT_BF_FRAME_MASK, 1)): frame keypoints that already own a landmark are
+    // skipped like already matched ones; default: no such test (upstream as recalled overwrites curr_frm.landmarks_ wholesale afterwards)
+    std::vector<uint8_t> valid_1;
+    if (ovs_match_get_variant(OVS_MATCH_VARIANT_BF_FRAME_MASK) == 1) {
+        valid_1.assign(num_keypts_1, 1);
+        for (unsigned int idx_1 = 0; idx_1 < num_keypts_1 && idx_1 < frm.landmarks_.size(); ++idx_1)
+            if (frm.landmarks_[idx_1]) valid_1[idx_1] = 0;
+    }
     std::vector<int32_t> pairs((size_t)2 * num_keypts_2);
     int n = 0;
     matches.clear();
@@ -77,7 +85,7 @@ unsigned int robust::brute_force_match(data::frame& frm, data::keyframe* keyfrm,
             "ovs_robust_brute_force_match",
             [&] {
                 return ovs_robust_brute_force_match(matcher_ctx(device).get(num_keypts_1, num_keypts_2), frm.descriptors_.data, (int)num_keypts_1,
-                                                    /*valid_1: upstream's inner loop skips only already matched idx_1*/ nullptr,
+                                                    /*valid_1: by default upstream's inner loop skips only already matched idx_1*/ valid_1.empty() ? nullptr : valid_1.data(),
                                                     keyfrm->descriptors_.data, (int)num_keypts_2, valid.data(), lowe_ratio_, pairs.data(),
                                                     (int)num_keypts_2, &n);
             },

@@ -606,6 +606,7 @@ struct ResolveArgs {
     float lowe_ratio;
     int check_orientation;
     int angle_keep_rule;   // ovs_match_set_variant(OVS_MATCH_VARIANT_ANGLE_KEEP_RULE): filled in by launch_resolve
+    int angle_tie_order;   // ovs_match_set_variant(OVS_MATCH_VARIANT_ANGLE_TIE_ORDER): 0 equal sizes -> lower bin first, 1 higher bin first
     const ovs_keypoint* q_kps;    // area: frame-1 keypoints (angle); bow: keyframe keypoints (angle), indexed through q_items
     const int32_t* q_items;       // bow: query -> keyframe keypoint index (NULL: identity)
     const ovs_keypoint* t_kps;    // area / bow: target keypoints (angle, pt)
@@ -822,7 +823,10 @@ __global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
         // the three fullest bins, equal sizes -> lower bin first (ORACLE_SPEC rule 17); wave 0 picks them
         if (wv == 0) {
             const uint32_t h = lane < 30 ? (uint32_t)hist[lane] : 0u;
-            uint32_t key = lane < 30 ? ((h << 8) | (uint32_t)(31 - lane)) : 0u;   // larger count first, then lower bin
+            // larger count first; equal counts: the lower bin (rule 17 as fixed) or, in the variant, the higher bin -- upstream std::sort's on the
+            // sizes, which leaves the order of equal bins to the library
+            const uint32_t tie_key = a.angle_tie_order ? (uint32_t)(lane + 1) : (uint32_t)(31 - lane);
+            uint32_t key = lane < 30 ? ((h << 8) | tie_key) : 0u;
             for (int k = 0; k < 3; ++k) {
                 uint32_t m = key;
 #pragma unroll
@@ -831,7 +835,7 @@ __global__ __launch_bounds__(64 * NW) void k_list_resolve(ResolveArgs a) {
                     m = o > m ? o : m;
                 }
                 if (lane == 0) {
-                    s_keep[k] = (uint32_t)(31 - (int)(m & 0xFFu));
+                    s_keep[k] = a.angle_tie_order ? (m & 0xFFu) - 1u : (uint32_t)(31 - (int)(m & 0xFFu));
                     s_keep_cnt[k] = m >> 8;
                 }
                 if (key == m) key = 0u;
@@ -903,6 +907,8 @@ using namespace ovs;
 
 // ovs_match_set_variant(OVS_MATCH_VARIANT_ANGLE_KEEP_RULE, 0 | 1): process-wide, read at every resolver launch
 static std::atomic<int> g_angle_keep_rule{0};
+static std::atomic<int> g_angle_tie_order{0};   // OVS_MATCH_VARIANT_ANGLE_TIE_ORDER
+static std::atomic<int> g_bf_frame_mask{0};     // OVS_MATCH_VARIANT_BF_FRAME_MASK (read by the class shim of robust::brute_force_match)
 
 struct ovs_wmatcher {
     int device = 0;
@@ -990,6 +996,7 @@ template <int RULE>
 ovs_status launch_resolve(const ResolveArgs& ra_in, hipStream_t s) {
     ResolveArgs ra = ra_in;
     ra.angle_keep_rule = g_angle_keep_rule.load(std::memory_order_relaxed);
+    ra.angle_tie_order = g_angle_tie_order.load(std::memory_order_relaxed);
     size_t fixed = resolve_lds_bytes(ra.n_q, ra.n_t);
     if (fixed > 150 * 1024) return OVS_ERR_CAPACITY;
     // the queries' list bounds are staged in LDS too unless the problem is so large that they would take the room of everything else
@@ -2652,10 +2659,21 @@ ovs_status ovs_frame_dev_attach_bearings(ovs_frame_dev* f, const double* bearing
 int32_t ovs_frame_dev_device(const ovs_frame_dev* f) { return f ? f->device : -1; }
 
 ovs_status ovs_match_set_variant(int32_t which, int32_t value) {
-    if (which != OVS_MATCH_VARIANT_ANGLE_KEEP_RULE || (value != 0 && value != 1)) return OVS_ERR_INVALID;
-    g_angle_keep_rule.store(value, std::memory_order_relaxed);
-    return OVS_OK;
+    if (value != 0 && value != 1) return OVS_ERR_INVALID;
+    switch (which) {
+        case OVS_MATCH_VARIANT_ANGLE_KEEP_RULE: g_angle_keep_rule.store(value, std::memory_order_relaxed); return OVS_OK;
+        case OVS_MATCH_VARIANT_ANGLE_TIE_ORDER: g_angle_tie_order.store(value, std::memory_order_relaxed); return OVS_OK;
+        case OVS_MATCH_VARIANT_BF_FRAME_MASK: g_bf_frame_mask.store(value, std::memory_order_relaxed); return OVS_OK;
+        default: return OVS_ERR_INVALID;
+    }
 }
-int32_t ovs_match_get_variant(int32_t which) { return which == OVS_MATCH_VARIANT_ANGLE_KEEP_RULE ? g_angle_keep_rule.load(std::memory_order_relaxed) : -1; }
+int32_t ovs_match_get_variant(int32_t which) {
+    switch (which) {
+        case OVS_MATCH_VARIANT_ANGLE_KEEP_RULE: return g_angle_keep_rule.load(std::memory_order_relaxed);
+        case OVS_MATCH_VARIANT_ANGLE_TIE_ORDER: return g_angle_tie_order.load(std::memory_order_relaxed);
+        case OVS_MATCH_VARIANT_BF_FRAME_MASK: return g_bf_frame_mask.load(std::memory_order_relaxed);
+        default: return -1;
+    }
+}
 
 }   // extern "C"

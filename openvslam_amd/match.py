@@ -96,8 +96,10 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 
 
 def set_variant(which, value):
-    """ovs_match_set_variant: "angle_keep_rule" (0 top-3 | 1 top-3 with the 0.1 x max rule), process-wide (oracle/ORACLE_SPEC.md rule 17)."""
-    _lib.check(_lib.lib().ovs_match_set_variant({"angle_keep_rule": 0}[which], int(value)), "ovs_match_set_variant")
+    """ovs_match_set_variant, process-wide: "angle_keep_rule" (0 top-3 | 1 top-3 with the 0.1 x max rule), "angle_tie_order" (0 lower of two equally
+    full bins first | 1 higher first) -- oracle/ORACLE_SPEC.md rule 17 --, "bf_frame_mask" (0 | 1: robust::brute_force_match's class shim also skips
+    frame keypoints that own a landmark, rule 14)."""
+    _lib.check(_lib.lib().ovs_match_set_variant({"angle_keep_rule": 0, "angle_tie_order": 1, "bf_frame_mask": 2}[which], int(value)), "ovs_match_set_variant")
 
 
 def grid_params(cols, rows, num_grid_cols=64, num_grid_rows=48, min_x=0.0, min_y=0.0):

@@ -320,8 +320,9 @@ def get_keypoints_in_cell(gp, kps, ref_x, ref_y, margin, min_level=-1, max_level
 
 
 def match_set_variant(which, value):
-    """ovo_match_set_variant: "angle_keep_rule" (0 top-3 | 1 top-3 with ORB-SLAM2's 0.1 x max rule), process-wide (ORACLE_SPEC rule 17)."""
-    assert lib().ovo_match_set_variant({"angle_keep_rule": 0}[which], int(value)) == 0
+    """ovo_match_set_variant, process-wide (ORACLE_SPEC rule 17): "angle_keep_rule" (0 top-3 | 1 top-3 with ORB-SLAM2's 0.1 x max rule),
+    "angle_tie_order" (0 lower of two equally full bins first | 1 higher first)."""
+    assert lib().ovo_match_set_variant({"angle_keep_rule": 0, "angle_tie_order": 1}[which], int(value)) == 0
 
 
 def angle_checker_invalid(delta_angles):

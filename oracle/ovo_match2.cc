@@ -105,6 +105,9 @@ void for_keypoints_in_cell(const Grid& g, const float* xs, const float* ys, cons
 // sizes; 1 ORB-SLAM2's ComputeThreeMaxima: the second (and with it the third) is dropped when it holds fewer than 0.1 x the fullest bin's
 // entries, the third alone when only it does
 int g_angle_keep_rule = 0;
+// rule 17's tie order as a variant: 0 (default) of two equally full bins the lower one ranks first, 1 the higher one (upstream: std::sort on the
+// sizes, implementation-defined for equal sizes)
+int g_angle_tie_order = 0;
 struct AngleChecker {
     static constexpr int kLen = 30, kKeep = 3;
     std::vector<int> bins[kLen];
@@ -118,7 +121,9 @@ struct AngleChecker {
     std::vector<int> invalid() const {
         int order[kLen];
         std::iota(order, order + kLen, 0);
-        std::stable_sort(order, order + kLen, [&](int a, int b) { return bins[a].size() > bins[b].size(); });
+        std::stable_sort(order, order + kLen, [&](int a, int b) {
+            return bins[a].size() > bins[b].size() || (g_angle_tie_order && bins[a].size() == bins[b].size() && a > b);
+        });
         int n_keep = kKeep;
         if (g_angle_keep_rule) {
             const float max1 = (float)bins[order[0]].size();
@@ -161,8 +166,8 @@ int ovo_get_keypoints_in_cell(const ovo_grid_params* p, const float* xs, const f
 }
 
 int ovo_match_set_variant(int which, int value) {
-    if (which != 0 || (value != 0 && value != 1)) return -1;
-    g_angle_keep_rule = value;
+    if ((which != 0 && which != 1) || (value != 0 && value != 1)) return -1;
+    (which == 0 ? g_angle_keep_rule : g_angle_tie_order) = value;
     return 0;
 }
 

@@ -534,6 +534,45 @@ def test_resolver_under_heavy_contention(match, synth, oracle, n_nodes, ratio, c
     assert gn == wn and np.array_equal(got, want) and np.array_equal(pg.view(np.uint32), po.view(np.uint32))
 
 
+def test_angle_tie_order_variant_on_both_sides(match, oracle):
+    """ORACLE_SPEC rule 17's tie order (equally full bins: lower first | higher first) as a run-time variant of both sides, on a case built so
+    that ONLY the tie decides: area matching with orientation check, four groups of exact-copy matches whose rotation differences fall into
+    bins 1 (12 matches) and 3, 6, 8 (5 matches each). Default keeps bins 1, 3, 6; the variant keeps 1, 6, 8; device == oracle in both."""
+    rng = np.random.default_rng(5)
+    groups = [(1, 12), (3, 5), (6, 5), (8, 5)]
+    n = sum(c for _, c in groups)
+    ka = np.zeros(n, oracle.KP_DTYPE)
+    kb = np.zeros(n, oracle.KP_DTYPE)
+    ka["x"] = kb["x"] = 40.0 + 25.0 * (np.arange(n) % 9)
+    ka["y"] = kb["y"] = 40.0 + 25.0 * (np.arange(n) // 9)
+    ka["size"] = kb["size"] = 31.0
+    da = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    db = da.copy()
+    i = 0
+    for b, c in groups:
+        ka["angle"][i:i + c] = 30.0 * b + 5.0      # delta = angle_a - angle_b = 30 b degrees exactly -> bin b
+        kb["angle"][i:i + c] = 5.0
+        i += c
+    gp, ogp = match.grid_params(320, 240), oracle.grid_params(320, 240)
+    res = {}
+    try:
+        for order in (0, 1):
+            match.set_variant("angle_tie_order", order)
+            oracle.match_set_variant("angle_tie_order", order)
+            w = match.area(0.9, True, max_targets=256, max_queries=256)
+            pg = np.ascontiguousarray(np.stack([ka["x"], ka["y"]], 1), np.float32)
+            po = pg.copy()
+            gn, got = w.match_in_consistent_area(gp, ka, da, kb, db, pg, 10)
+            wn, want = oracle.area_match_in_consistent_area(ogp, ka, da, kb, db, po, 10, 0.9, True)
+            assert gn == wn == 22 and np.array_equal(got, want)
+            res[order] = got.copy()
+    finally:
+        match.set_variant("angle_tie_order", 0)
+        oracle.match_set_variant("angle_tie_order", 0)
+    assert (res[0][12:22] >= 0).all() and (res[0][22:] < 0).all()                                  # bins 1, 3, 6 kept
+    assert (res[1][12:17] < 0).all() and (res[1][17:] >= 0).all() and (res[1][:12] >= 0).all()     # bins 1, 6, 8 kept
+
+
 def test_angle_keep_rule_variant_on_both_sides(match, synth, oracle):
     """ORACLE_SPEC rule 17's alternative (ORB-SLAM2's 0.1 x max rule in angle_checker) as a process-wide run-time variant of BOTH sides
     (ovs_match_set_variant / ovo_match_set_variant): the device resolver and the oracle agree in either setting, and on a frame pair with one

@@ -163,3 +163,23 @@ def test_angle_keep_rule_variant_by_hand(oracle):
     finally:
         oracle.match_set_variant("angle_keep_rule", 0)
     assert inv(d1).sum() == 1
+
+
+def test_angle_tie_order_variant_by_hand(oracle):
+    """rule 17's tie order: bins 2 / 5 / 9 / 11 hold 40 / 7 / 7 / 7 entries -- three candidates for the two places behind the fullest bin. Default:
+    the LOWER bins win (5 and 9 stay, 11 goes); variant: the higher ones (9 and 11 stay, 5 goes). No tie -> no difference. Restorable."""
+    def deltas(counts):   # bin b <-> delta = 30 b degrees
+        return np.concatenate([np.full(c, 30.0 * b, np.float32) for b, c in counts.items()])
+    d = deltas({2: 40, 5: 7, 9: 7, 11: 7})
+    inv = oracle.angle_checker_invalid
+    assert inv(d)[:54].sum() == 0 and inv(d)[54:].sum() == 7              # bins 2, 5, 9 kept
+    no_tie = deltas({2: 40, 5: 9, 9: 8, 11: 7})
+    base = inv(no_tie).copy()
+    try:
+        oracle.match_set_variant("angle_tie_order", 1)
+        got = inv(d)
+        assert got[:40].sum() == 0 and got[40:47].sum() == 7 and got[47:].sum() == 0   # bin 5 dropped, 9 and 11 kept
+        assert np.array_equal(inv(no_tie), base)
+    finally:
+        oracle.match_set_variant("angle_tie_order", 0)
+    assert inv(d)[54:].sum() == 7
