@@ -378,6 +378,12 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_solve(double* __restrict
 // the backward substitution, then every wave runs four v_mfma_f64_16x16x4_f64 per resident tile with A / B from the LDS panel.
 // Same arithmetic per entry as k_chol_solve (fused multiply-adds, the matrix cores' order inside a 16 x 16 x 16 product), same storage, same
 // result to rounding; identical bits from run to run.
+// Measured at 288 unknowns (profiles/r05e_chol_phases.txt, r05e_lba_kernel_stats.txt): 168 us per solve against k_chol_solve's 252 -- loads 13,
+// diagonal blocks 52, row solves 23, write-back 11, trailing update 47 (the f64 matrix pipe's own time is 29: 4400 instructions x 64 cycles over
+// four SIMDs), backward substitution 33. Tried and dropped (profiles/r05k_chol_phases_lookahead_variant.txt): wave 0 factoring the NEXT diagonal
+// block beside the other seven waves' trailing update, with 1 / d instead of 1 / sqrt(d) on the pivot chain -- 174 us: the pivot chain's f64
+// operations slow down by half next to the matrix instructions of the wave that shares its SIMD (72 instead of 52 us), seven owners stretch the
+// trailing update by 8 / 7, and the next panel's column as a phase of its own costs 1.7 us per panel.
 constexpr int kResSlots = 18;      // accumulator slots per wave (144 registers: 19 already spill); tiles beyond 8 x kResSlots live in LDS (lane-major, 2 KB each)
 constexpr int kResMaxPad = 288;
 constexpr int kResMaxTiles = (kResMaxPad / 16) * (kResMaxPad / 16 - 1) / 2;   // 153
@@ -428,18 +434,11 @@ __device__ __forceinline__ void factor_block_dpp(double* __restrict__ P, double*
     for (int k = 0; k < kNb; ++k) {
         const double piv = row_bcast(a[k], k);
         bad |= !(piv > 0.0 && piv < __builtin_inf());
-        // The chain from one pivot to the next runs through the rank-1 update a[r][c] -= u_r u_c / d (u = the unscaled column, d = the pivot):
-        // it needs 1 / d (v_rcp_f64 + two Newton steps: 5 dependent operations), not 1 / sqrt(d) (v_rsq_f64 + three: 10) -- the column's scaling
-        // L[r][k] = u_r / sqrt(d) is computed beside it, off the chain.
-        double rinv = __builtin_amdgcn_rcp(piv);
-        rinv = __builtin_fma(__builtin_fma(-piv, rinv, 1.0), rinv, rinv);
-        rinv = __builtin_fma(__builtin_fma(-piv, rinv, 1.0), rinv, rinv);
-        const double w = a[k] * rinv;   // lane c: u_c / d
-#pragma unroll
-        for (int c = k + 1; c < kNb; ++c) a[c] = __builtin_fma(-a[k], row_bcast(w, c), a[c]);
         const double y = rsqrt_newton(piv);
         a[k] = (r == k) ? piv * y : a[k] * y;
         my_inv = (r == k) ? y : my_inv;
+#pragma unroll
+        for (int c = k + 1; c < kNb; ++c) a[c] = __builtin_fma(-a[k], row_bcast(a[k], c), a[c]);   // L[c][k] sits in lane c
     }
     // forward substitution of the block's right-hand side: lane r carries rhs_r - sum_{c < r} L[r][c] y_c
 #pragma unroll
@@ -557,28 +556,25 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_resident(double* __restr
     }
     if (tid == 0 && n_tiles == 0) s_td[0] = 0;   // (one tile row: the slots' stand-in loads below read tile (0, 0), i.e. valid memory)
     __syncthreads();
-    // ---- the tiles' owners are waves 1 .. 7; wave 0 factors the diagonal blocks one panel AHEAD (below). Owner o = wave - 1 holds tiles
-    //      o, o + 7, ...: slots 0 .. kResSlots - 1 in registers, the rest (the first tile columns, which leave after one or two updates) in LDS
-    //      behind the panels, lane-major: value e of lane l of the u-th LDS tile at T[(u * 4 + e) * 64 + l]
-    constexpr int kOwners = kWaves - 1;
+    // ---- this wave's tiles: slots 0 .. kResSlots - 1 in registers, the rest (tiles 8 kResSlots + u, u = wave, wave + 8, ...: the first tile
+    //      columns, which leave after one or two updates) in LDS behind the panels, lane-major: value e of lane l of tile u at T[(u * 4 + e) * 64 + l]
     double* const T = invd + n_pad;
-    const int n_lds = n_tiles > kOwners * kResSlots ? n_tiles - kOwners * kResSlots : 0;
-    const int owner = wave - 1;   // (-1: wave 0 owns nothing; its slots hold stand-ins nobody reads)
+    const int n_lds = n_tiles > kWaves * kResSlots ? n_tiles - kWaves * kResSlots : 0;
     int sd[kResSlots];
     v4d acc[kResSlots];
     const int lane_off = kq * n_pad + rl;
 #pragma unroll
     for (int s = 0; s < kResSlots; ++s) {
-        const int t = kOwners * s + owner;
-        // (a slot without a tile loads tile 0's values, which nothing reads: its number is never below an active count)
-        sd[s] = __builtin_amdgcn_readfirstlane(s_td[(owner >= 0 && t < n_tiles) ? t : 0]);
+        const int t = kWaves * s + wave;
+        // (a slot without a tile -- small systems -- loads tile 0's values, which nothing reads: its number is never below the active count)
+        sd[s] = __builtin_amdgcn_readfirstlane(s_td[t < n_tiles ? t : 0]);
         // uniform tile origin + the lane's own 32-bit offset (the same four offsets for every tile): scalar-base loads
         const double* base = S + (size_t)(kNb * (sd[s] & 0xff)) * n_pad + kNb * (sd[s] >> 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[s][e] = base[lane_off + e * 4 * n_pad];
     }
-    for (int u = owner; u >= 0 && u < n_lds; u += kOwners) {
-        const int d = __builtin_amdgcn_readfirstlane(s_td[kOwners * kResSlots + u]);
+    for (int u = wave; u < n_lds; u += kWaves) {
+        const int d = __builtin_amdgcn_readfirstlane(s_td[kWaves * kResSlots + u]);
         const double* src = S + (size_t)(kNb * (d & 0xff) + kq) * n_pad + kNb * (d >> 8) + rl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) T[(u * 4 + e) * 64 + lane] = src[(size_t)(4 * e) * n_pad];
@@ -590,87 +586,55 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_resident(double* __restr
     }
     __syncthreads();
     SOLVE_MARK(0)   // loads
-    if (wave == 0) factor_block_dpp(P, invd, vec, 0, lane, &s_bad);
-    lds_barrier();
-    SOLVE_MARK(1)   // diagonal block 0
-    // One panel j: (1) every thread solves rows of panel j (its diagonal block is already factored); (2) the owners update the tiles of the NEXT
-    // panel's column and move them to its buffer Pn, everybody writes panel j back to memory; (3) wave 0 factors the next diagonal block in Pn
-    // WHILE the owners update the rest of their tiles from panel j -- the pivot chain (~3 us per block, nothing can be added to it) used to be
-    // a third of the kernel with seven waves waiting.
     for (int j = 0; j < NT; ++j) {
         const int j0 = j * kNb, m = n_pad - j0;
-        const int jj = NT - 1 - j;
-        const int a_next = res_active_tiles(jj - 1), a_all = res_active_tiles(jj);   // tiles t < a_next: tc > j + 1; a_next <= t < a_all: tc == j + 1
+        if (wave == 0) factor_block_dpp(P, invd, vec, j0, lane, &s_bad);
+        lds_barrier();
+        SOLVE_MARK(1)   // diagonal block + forward substitution of its rhs + barrier
         solve_rows_res(P, invd, vec, j0, m, tid, lane);
         lds_barrier();
         SOLVE_MARK(2)   // row solves + barrier
-        // ---- (2) the next panel's column
-        {
+        write_back_panel(S, P, j0, m, n_pad, tid);
+        SOLVE_MARK(3)   // write-back (thread 0's share)
+        // ---- trailing update C -= P_ti P_tc^T of the resident tiles; the tiles of the next panel's column move to its LDS buffer
+        const int jj = NT - 1 - j;
 #pragma unroll
-            for (int s = 0; s < kResSlots; ++s) {
-                const int t = kOwners * s + owner;
-                if (owner >= 0 && t >= a_next && t < a_all) {   // (wave-uniform)
-                    const int ti = sd[s] & 0xff;
-                    const double* pa = P + (kNb * (ti - j) + rl) * kPitch + kq;
-                    const double* pb = P + (kNb + rl) * kPitch + kq;   // tc - j == 1
-                    tile_update_tied(acc[s], -pa[0], -pa[4], -pa[8], -pa[12], pb[0], pb[4], pb[8], pb[12]);
+        for (int s = 0; s < kResSlots; ++s) {
+            if (kWaves * s + wave < res_active_tiles(jj)) {   // (wave-uniform)
+                const int ti = sd[s] & 0xff, tc = sd[s] >> 8;
+                const double* pa = P + (kNb * (ti - j) + rl) * kPitch + kq;
+                const double* pb = P + (kNb * (tc - j) + rl) * kPitch + kq;
+                tile_update_tied(acc[s], -pa[0], -pa[4], -pa[8], -pa[12], pb[0], pb[4], pb[8], pb[12]);
+                if (tc == j + 1) {   // the next panel's column: the tile is final, it moves to that panel's buffer
 #pragma unroll
                     for (int e = 0; e < 4; ++e) Pn[(kNb * (ti - j - 1) + kq + 4 * e) * kPitch + rl] = acc[s][e];
                 }
-                __builtin_amdgcn_sched_barrier(0);   // one tile's operands at a time: the scheduler otherwise hoists the LDS reads of all slots (16 registers each)
             }
-            for (int u = owner; u >= 0 && u < n_lds; u += kOwners) {
-                const int t = kOwners * kResSlots + u;
-                if (t < a_next) continue;
-                if (t >= a_all) break;
-                const int d = __builtin_amdgcn_readfirstlane(s_td[t]);
-                const int ti = d & 0xff;
-                v4d c4;
+            __builtin_amdgcn_sched_barrier(0);   // one tile's operands at a time: the scheduler otherwise hoists the LDS reads of all slots (16 registers each)
+        }
+        const int n_act = res_active_tiles(jj);
+        for (int u = wave; u < n_lds; u += kWaves) {   // the tiles that live in LDS
+            if (kWaves * kResSlots + u >= n_act) break;
+            const int d = __builtin_amdgcn_readfirstlane(s_td[kWaves * kResSlots + u]);
+            const int ti = d & 0xff, tc = d >> 8;
+            v4d c4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) c4[e] = T[(u * 4 + e) * 64 + lane];
-                const double* pa = P + (kNb * (ti - j) + rl) * kPitch + kq;
-                const double* pb = P + (kNb + rl) * kPitch + kq;
+            for (int e = 0; e < 4; ++e) c4[e] = T[(u * 4 + e) * 64 + lane];
+            const double* pa = P + (kNb * (ti - j) + rl) * kPitch + kq;
+            const double* pb = P + (kNb * (tc - j) + rl) * kPitch + kq;
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * s4], pb[4 * s4], c4, 0, 0, 0);
+            for (int s4 = 0; s4 < 4; ++s4) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * s4], pb[4 * s4], c4, 0, 0, 0);
+            if (tc == j + 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) Pn[(kNb * (ti - j - 1) + kq + 4 * e) * kPitch + rl] = c4[e];
-            }
-        }
-        write_back_panel(S, P, j0, m, n_pad, tid);
-        lds_barrier();
-        SOLVE_MARK(3)   // next column + write-back + barrier
-        // ---- (3) the next diagonal block (wave 0) beside the rest of the trailing update (owners)
-        if (wave == 0 && j + 1 < NT) factor_block_dpp(Pn, invd, vec, j0 + kNb, lane, &s_bad);
-        {
-#pragma unroll
-            for (int s = 0; s < kResSlots; ++s) {
-                if (owner >= 0 && kOwners * s + owner < a_next) {   // (wave-uniform)
-                    const int ti = sd[s] & 0xff, tc = sd[s] >> 8;
-                    const double* pa = P + (kNb * (ti - j) + rl) * kPitch + kq;
-                    const double* pb = P + (kNb * (tc - j) + rl) * kPitch + kq;
-                    tile_update_tied(acc[s], -pa[0], -pa[4], -pa[8], -pa[12], pb[0], pb[4], pb[8], pb[12]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            for (int u = owner; u >= 0 && u < n_lds; u += kOwners) {
-                const int t = kOwners * kResSlots + u;
-                if (t >= a_next) break;
-                const int d = __builtin_amdgcn_readfirstlane(s_td[t]);
-                const int ti = d & 0xff, tc = d >> 8;
-                v4d c4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) c4[e] = T[(u * 4 + e) * 64 + lane];
-                const double* pa = P + (kNb * (ti - j) + rl) * kPitch + kq;
-                const double* pb = P + (kNb * (tc - j) + rl) * kPitch + kq;
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * s4], pb[4 * s4], c4, 0, 0, 0);
+            } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) T[(u * 4 + e) * 64 + lane] = c4[e];
             }
         }
-        SOLVE_MARK(4)   // next diagonal block (thread 0's wave)
+        SOLVE_MARK(4)   // trailing update, wave 0's tiles
         lds_barrier();
-        SOLVE_MARK(5)   // ... waiting for the owners' trailing update
+        SOLVE_MARK(5)   // ... waiting for the other waves
         double* const t = P;
         P = Pn;
         Pn = t;
@@ -800,7 +764,7 @@ ovs_status launch_dense_solve(double* d_S, int n, int32_t* d_fail, hipStream_t s
     if (n < 1 || n > dense_solve_max_n()) return OVS_ERR_INVALID;
     const int n_pad = dense_solve_pad(n);
     if (n_pad <= kResMaxPad && tuning().chol_resident) {   // the trailing matrix fits the register file: k_chol_resident
-        const int nt = n_pad / kNb, n_tiles = nt * (nt - 1) / 2, n_lds = std::max(0, n_tiles - (kSolveThreads / 64 - 1) * kResSlots);
+        const int nt = n_pad / kNb, n_tiles = nt * (nt - 1) / 2, n_lds = std::max(0, n_tiles - (kSolveThreads / 64) * kResSlots);
         const size_t lds = sizeof(double) * (2 * (size_t)n_pad * kPitch + 2 * (size_t)n_pad + (size_t)n_lds * 256);
         static LdsAttrCache cache_r;
         static LdsAttrCache cache_t;
@@ -868,7 +832,7 @@ ovs_status ovs_ba_dense_solve(int32_t device, const double* S, const double* rhs
     if (d_t && e == hipSuccess && st == OVS_OK) {
         unsigned long long h_t[8] = {};
         (void)hipMemcpy(h_t, d_t, sizeof(h_t), hipMemcpyDeviceToHost);
-        static const char* nm[7] = {"requests+panel load", "diagonal block (k_chol_resident: block 0 only)", "row solves", "write-back (resident: + next column)", "trailing (wave 0; resident: the next diagonal block)", "trailing (others)", "backward"};
+        static const char* nm[7] = {"requests+panel load", "diagonal block", "row solves", "write-back", "trailing (wave 0)", "trailing (others)", "backward"};
         std::fprintf(stderr, "[dense solve n=%d]", n);
         for (int i = 0; i < 7; ++i) std::fprintf(stderr, " %s %.1f us,", nm[i], h_t[i] * 0.01);
         std::fprintf(stderr, "\n");
