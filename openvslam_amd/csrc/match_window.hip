@@ -144,6 +144,12 @@ struct WinArgs {
     float margin;
     float sf[OVS_MAX_LEVELS];
     int mode;
+    // Candidates whose Hamming distance can neither win (d > the rule's acceptance threshold) nor make a ratio test fail (fl(d * ratio) >= that
+    // threshold) are left out of the lists altogether: every candidate with d >= dead_from (0: no filter; set per rule by dead_from_*() below).
+    // The sequential rule decides the same with or without them (a dropped best is a reject either way, a dropped second accepts either way, and
+    // so does every later second), but the resolver's rounds are bounded by the chains of queries sharing LIVE candidates and its lists only fit
+    // LDS when they are short: with a 100-px margin (BASELINE config 0) a query has ~110 candidates of which ~1 is alive.
+    uint32_t dead_from;
 };
 
 // One WAVE per query: the lanes take the cells of the query's window (a 100-px margin covers ~340 of the 64 x 48 cells -- a single
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256) void k_window_lists(WinArgs a, uint32_t* __res
         const float ref_x = a.q_xy[2 * q], ref_y = a.q_xy[2 * q + 1];
         const float q_xr = (a.mode != kModeArea && a.t_x_right) ? a.q_x_right[q] : 0.0f;
         uint32_t qd[8];
-        if (FILL) {
+        if (FILL || a.dead_from) {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(a.q_desc + (size_t)q * 32);
 #pragma unroll
             for (int i = 0; i < 8; ++i) qd[i] = src[i];
@@ -217,7 +223,9 @@ __global__ __launch_bounds__(256) void k_window_lists(WinArgs a, uint32_t* __res
                 uint32_t n_pass = 0;
                 for (int k = b; k < e; ++k) {
                     const int idx = a.items[k];
-                    n_pass += passes(idx, a.t_kps[idx]) ? 1u : 0u;
+                    bool ok = passes(idx, a.t_kps[idx]);
+                    if (ok && a.dead_from) ok = hamming256_g(qd, reinterpret_cast<const uint32_t*>(a.t_desc + (size_t)idx * 32)) < a.dead_from;
+                    n_pass += ok ? 1u : 0u;
                 }
                 uint32_t incl = n_pass;
 #pragma unroll
@@ -232,6 +240,7 @@ __global__ __launch_bounds__(256) void k_window_lists(WinArgs a, uint32_t* __res
                         const ovs_keypoint kp = a.t_kps[idx];
                         if (!passes(idx, kp)) continue;
                         const uint32_t d = hamming256_g(qd, reinterpret_cast<const uint32_t*>(a.t_desc + (size_t)idx * 32));
+                        if (a.dead_from && !(d < a.dead_from)) continue;
                         if (pos < key_cap) keys[pos] = (d << 20) | ((uint32_t)(kp.octave & 15) << 16) | (uint32_t)idx;
                         else *overflow = 1u;
                         ++pos;
@@ -473,6 +482,7 @@ struct BowArgs {
     // robust::match_for_triangulation (tri != 0): pair filters d <= THR_LOW, epipole proximity, epipolar constraint; candidates are
     // listed in REVERSE bucket order because upstream lets a later equal distance replace an earlier one
     int tri;
+    uint32_t dead_from;   // as WinArgs::dead_from (bow rule; the triangulation filter d <= THR_LOW is part of its pair test)
     const ovs_keypoint* kf_kps;  // octave of keypoint 1 (threshold scale)
     const float* kf_x_right;
     const float* frm_x_right;
@@ -543,19 +553,27 @@ __global__ __launch_bounds__(256) void k_bow_lists(BowArgs a, uint32_t* __restri
                     ++n;
                 }
             } else {
-            if (!a.frm_valid) n = (uint32_t)(e - b);
-            else
-                for (int k = b; k < e; ++k) n += a.frm_valid[a.frm_items[k]] ? 1u : 0u;
-            if (FILL) {
-                uint32_t qd[8];
+            uint32_t qd[8];
+            if (FILL || a.dead_from) {
                 const uint32_t* src = reinterpret_cast<const uint32_t*>(a.kf_desc + (size_t)kf_idx * 32);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) qd[i] = src[i];
+            }
+            if (!a.frm_valid && !a.dead_from) n = (uint32_t)(e - b);
+            else
+                for (int k = b; k < e; ++k) {
+                    const int idx = a.frm_items[k];
+                    bool ok = !a.frm_valid || a.frm_valid[idx];
+                    if (ok && a.dead_from) ok = hamming256_g(qd, reinterpret_cast<const uint32_t*>(a.frm_desc + (size_t)idx * 32)) < a.dead_from;
+                    n += ok ? 1u : 0u;
+                }
+            if (FILL) {
                 uint32_t pos = offsets[q];
                 for (int k = b; k < e; ++k) {
                     const int idx = a.frm_items[k];
                     if (a.frm_valid && !a.frm_valid[idx]) continue;
                     const uint32_t d = hamming256_g(qd, reinterpret_cast<const uint32_t*>(a.frm_desc + (size_t)idx * 32));
+                    if (a.dead_from && !(d < a.dead_from)) continue;
                     if (pos < key_cap) keys[pos] = (d << 20) | (uint32_t)idx;
                     else *overflow = 1u;
                     ++pos;
@@ -1069,6 +1087,17 @@ ovs_status stage_target(ovs_wmatcher* w, const ovs_frame_dev* res, const ovs_gri
     return OVS_OK;
 }
 
+// WinArgs::dead_from for a rule that accepts iff best <= thr and (ratio rules) !(fl(second * ratio) < best): the smallest distance d > thr with
+// fl(d * ratio) >= thr -- from there on a candidate can neither be an accepted best nor make the ratio test fail (the float product is monotone
+// in d, and "no second at all" counts as distance 256, which then accepts too). 257: nothing is dead; 0 would switch the filter off.
+static uint32_t dead_from_ratio(uint32_t thr, float ratio) {
+    if (!(ratio > 0.0f)) return 257u;
+    for (uint32_t d = thr + 1u; d <= 256u; ++d)
+        if ((float)d * ratio >= (float)thr) return d;
+    return 257u;
+}
+static uint32_t dead_from_thr(uint32_t thr) { return thr + 1u; }   // rules without a ratio test: best <= thr or nothing
+
 template <typename ARGS, typename KCOUNT, typename KFILL>
 ovs_status build_lists(ovs_wmatcher* w, const ARGS& args, int n_q, KCOUNT kcount, KFILL kfill, hipStream_t s, int q_per_block = 4) {
     if (n_q > w->max_q) return OVS_ERR_CAPACITY;
@@ -1279,6 +1308,7 @@ ovs_status ovs_projection_match_frame_and_landmarks_dev(ovs_wmatcher* w, const o
     a.margin = margin;
     for (int l = 0; l < OVS_MAX_LEVELS; ++l) a.sf[l] = l < num_levels ? scale_factors[l] : 1.0f;
     a.mode = kModeProjection;
+    a.dead_from = dead_from_ratio(OVS_HAMMING_DIST_THR_HIGH, lowe_ratio);
     st = build_lists(w, a, m, k_window_lists<false>, k_window_lists<true>, s);
     if (st != OVS_OK) return st;
     ResolveArgs ra{};
@@ -1360,6 +1390,7 @@ ovs_status ovs_area_match_in_consistent_area_dev(ovs_wmatcher* w, const ovs_grid
     a.q_desc = d_desc_1;
     a.margin = (float)margin;
     a.mode = kModeArea;
+    a.dead_from = dead_from_ratio(OVS_HAMMING_DIST_THR_LOW, lowe_ratio);
     st = build_lists(w, a, n1, k_window_lists<false>, k_window_lists<true>, s);
     if (st != OVS_OK) return st;
     ResolveArgs ra{};
@@ -1530,6 +1561,7 @@ static ovs_status bow_match_impl(ovs_wmatcher* w, const ovs_frame_dev* res_kf, c
     a.frm_node_start = d_f_start;
     a.frm_items = d_f_items;
     a.frm_nodes = frm_nodes;
+    a.dead_from = tri ? 0u : dead_from_ratio(OVS_HAMMING_DIST_THR_LOW, lowe_ratio);
     ovs_status st = build_lists(w, a, nq, k_bow_lists<false>, k_bow_lists<true>, s, 256);
     if (st != OVS_OK) return st;
     ResolveArgs ra{};
@@ -1683,6 +1715,7 @@ ovs_status ovs_projection_match_current_and_last_frames(ovs_wmatcher* w, const o
     a.q_desc = w->d_q_desc;
     a.margin = margin;
     a.mode = kModeGeneric;
+    a.dead_from = dead_from_thr(OVS_HAMMING_DIST_THR_HIGH);
     st = build_lists(w, a, n_last, k_window_lists<false>, k_window_lists<true>, s);
     if (st != OVS_OK) return st;
     ResolveArgs ra{};
@@ -1856,6 +1889,7 @@ static ovs_status projection_match_frame_and_keyframe_impl(ovs_wmatcher* w, cons
     a.q_desc = w->d_q_desc;
     a.margin = margin;
     a.mode = kModeGeneric;
+    a.dead_from = dead_from_thr((uint32_t)hamm_dist_thr);
     st = build_lists(w, a, n_kf, k_window_lists<false>, k_window_lists<true>, s);
     if (st != OVS_OK) return st;
     ResolveArgs ra{};
@@ -2025,6 +2059,7 @@ static ovs_status projection_match_by_sim3_transform_impl(ovs_wmatcher* w, const
     a.q_desc = w->d_q_desc;
     a.margin = margin;
     a.mode = kModeGeneric;
+    a.dead_from = dead_from_thr(OVS_HAMMING_DIST_THR_LOW);
     st = build_lists(w, a, m, k_window_lists<false>, k_window_lists<true>, s);
     if (st != OVS_OK) return st;
     ResolveArgs ra{};
@@ -2331,6 +2366,7 @@ ovs_status ovs_projection_match_frame_and_landmarks_f(ovs_wmatcher* w, const ovs
     a.margin = margin;
     for (int l = 0; l < OVS_MAX_LEVELS; ++l) a.sf[l] = l < num_levels ? scale_factors[l] : 1.0f;
     a.mode = kModeProjection;
+    a.dead_from = dead_from_ratio(OVS_HAMMING_DIST_THR_HIGH, lowe_ratio);
     if (stg.overflow) return OVS_ERR_CAPACITY;
     OVS_HIP_TRY(stg.flush(s));
     ovs_status st = build_lists(w, a, m, k_window_lists<false>, k_window_lists<true>, s);
@@ -2382,6 +2418,7 @@ ovs_status ovs_area_match_in_consistent_area_f(ovs_wmatcher* w, const ovs_frame_
     a.q_desc = frm_1->d_desc;
     a.margin = (float)margin;
     a.mode = kModeArea;
+    a.dead_from = dead_from_ratio(OVS_HAMMING_DIST_THR_LOW, lowe_ratio);
     ovs_status st = build_lists(w, a, n1, k_window_lists<false>, k_window_lists<true>, s);
     if (st != OVS_OK) return st;
     ResolveArgs ra{};
@@ -2487,6 +2524,7 @@ ovs_status ovs_projection_match_current_and_last_frames_f(ovs_wmatcher* w, const
     a.q_desc = d_q_desc;
     a.margin = margin;
     a.mode = kModeGeneric;
+    a.dead_from = dead_from_thr(OVS_HAMMING_DIST_THR_HIGH);
     ovs_status st = build_lists(w, a, n_last, k_window_lists<false>, k_window_lists<true>, s);
     if (st != OVS_OK) return st;
     ResolveArgs ra{};

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 GPU calls, one parameterised script (replaces the one-off tools/gpu_r04_*.sh). Usage: tools/gpu_r05.sh <tag> <step> [<step> ...]
-# steps: pytest | bench | trace | pmc | tie | fuzz | lba | asan | custom:<cmd>
+# steps: pytest | bench | trace | pmc | tie | fuzz | lba | asan | area | custom:<cmd>
 cd /root/repo
 tag=$1; shift
 mkdir -p gpurun_out
@@ -37,6 +37,11 @@ PY
   find gpurun_out/${tag}_lba_prof -name '*.csv' -size +1M -delete; find gpurun_out/${tag}_lba_prof -name '*.db' -delete ;;
 asan)
   bash tools/run_asan.sh ${tag} ;;
+area)
+  timeout 120 python tools/area_probe.py 2>&1 | tail -1
+  ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/${tag}_area_prof -o a -- python /root/repo/tools/area_probe.py > /dev/null 2>&1 )
+  python tools/trace_digest.py gpurun_out/${tag}_area_prof gpurun_out/${tag}_area_kernel_stats.txt | head -12
+  find gpurun_out/${tag}_area_prof -name '*.csv' -size +1M -delete; find gpurun_out/${tag}_area_prof -name '*.db' -delete ;;
 custom:*)
   cmd="${step#custom:}"; echo "+ $cmd"; timeout 1200 bash -c "$cmd" ;;
 *) echo "unknown step $step" ;;
