@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_lin_pose(GraphDev g, const double* __re
 // chi2[0..1] = sum of the per-landmark partials; chi2[2] = max |diagonal| over free pose blocks and landmarks with edges (g2o's
 // computeLambdaInit); one workgroup, fixed order
 __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const double* __restrict__ lm_chi, const double* __restrict__ Hpp,
-                                                        const double* __restrict__ Hll, double* __restrict__ chi2) {
+                                                        const double* __restrict__ Hll, double* __restrict__ chi2, double* __restrict__ mirror) {
     __shared__ double s0[1024], s1[1024], s2[1024];
     double a = 0, b = 0, m = 0;
     // four landmarks of a thread in flight (all loads first, then the additions in the order of the plain loop: the same bits)
@@ -366,6 +366,11 @@ __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const doubl
         chi2[0] = s0[0];
         chi2[1] = s1[0];
         chi2[2] = s2[0];
+        if (mirror) {   // a second copy next to the solver's scalars: ONE download brings a Levenberg-Marquardt trial's outcome back
+            mirror[0] = s0[0];
+            mirror[1] = s1[0];
+            mirror[2] = s2[0];
+        }
     }
 }
 
@@ -684,14 +689,14 @@ struct Blob {
 };
 
 ovs_status graph_linearize(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo, double* d_Hpp,
-                           double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s) {
+                           double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror = nullptr) {
     const GraphDev v = g->view();
     hipLaunchKernelGGL(k_lin_landmark, dim3((g->n_pt + 127) / 128), dim3(128), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hll, d_bl,
                        d_Hpl, g->d_lm_tmp);
     OVS_LAUNCH_TRY("k_lin_landmark");
     hipLaunchKernelGGL(k_lin_pose, dim3(g->n_pose), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp);
     OVS_LAUNCH_TRY("k_lin_pose");
-    hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(1024), 0, s, v, g->d_lm_tmp, d_Hpp, d_Hll, d_chi3);
+    hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(1024), 0, s, v, g->d_lm_tmp, d_Hpp, d_Hll, d_chi3, d_chi_mirror);
     OVS_LAUNCH_TRY("k_reduce_scalars");
     return OVS_OK;
 }
@@ -985,8 +990,8 @@ ovs_status ba_graph_edge_chi2(ovs_ba_graph* g, const double* d_poses, const doub
 }
 
 ovs_status ba_graph_linearize(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo, double* d_Hpp,
-                              double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s) {
-    return graph_linearize(g, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi3, s);
+                              double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror) {
+    return graph_linearize(g, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi3, s, d_chi_mirror);
 }
 
 }   // namespace ovs

@@ -31,7 +31,7 @@ ovs_status ba_graph_backsub(ovs_ba_graph* g, const double* d_Hpl, const double* 
 ovs_status ba_graph_set_active(ovs_ba_graph* g, const uint8_t* host_mask, hipStream_t s);
 ovs_status ba_graph_edge_chi2(ovs_ba_graph* g, const double* d_poses, const double* d_points, double* d_chi, uint8_t* d_depth, hipStream_t s);
 ovs_status ba_graph_linearize(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo, double* d_Hpp,
-                              double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s);
+                              double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror = nullptr);
 struct BaGraphInfo {
     int n_free;
     const int32_t* slot;        // pose -> reduced block or -1
@@ -152,7 +152,7 @@ struct Lm {
         A += 3 * b_t;
         d_echi = reinterpret_cast<double*>(A);
         d_edepth = A + b_e;
-        pin_doubles = ovs::dense_solve_doubles(6 * np) + 6 * (size_t)np + 16;   // padded system | bp | chi3, scal, fail
+        pin_doubles = ovs::dense_solve_doubles(6 * np) + 6 * (size_t)np + 16 + 40;   // padded system | bp | chi3, scal, fail | a trial's result block (264 bytes)
         if (sc.pin_cap < pin_doubles) {
             if (sc.h_pin) (void)hipHostFree(sc.h_pin);
             sc.h_pin = nullptr;
@@ -212,7 +212,8 @@ struct Lm {
         st = ovs::ba_graph_linearize(g, d_poses, d_X, huber_mono(robust), huber_stereo(robust), cur.Hpp, cur.bp, cur.Hll, cur.bl, cur.Hpl, cur.chi,
                                      stream);
         if (st != OVS_OK) return st;
-        double* h_chi = h_pin + pin_doubles - 16;
+        double* h_chi = h_pin + pin_doubles - 16 - 40;
+        double* h_blk = h_pin + pin_doubles - 40;   // one download per trial: [0] landmarks' / [1] keyframes' gain-ratio parts, [2..4] chi2 triple, byte 256: fail flag
         OVS_HIP_TRY(hipMemcpyAsync(h_chi, cur.chi, sizeof(double) * 3, hipMemcpyDeviceToHost, stream));
         OVS_HIP_TRY(hipStreamSynchronize(stream));
         double current_chi = h_chi[1];
@@ -249,15 +250,21 @@ struct Lm {
                     if (st != OVS_OK) return st;
                     st = ovs::ba_graph_backsub(g, cur.Hpl, cur.bl, lambda, d_X, d_Xw, stream);
                     if (st != OVS_OK) return st;
+                    // the trial state's chi2 triple is mirrored next to the solver's scalars (gi.d_scal[2..4]; gi.d_fail sits 256 bytes behind
+                    // gi.d_scal in the same arena): ONE 260-byte download per trial instead of three copies (round 5: two copy launches and their
+                    // gaps less per trial). (One kernel writing the values straight into the page-locked block was measured in round 4 -- the
+                    // system-scope flush at its end costs ~50 us per trial.)
                     st = ovs::ba_graph_linearize(g, d_poses_w, d_Xw, huber_mono(robust), huber_stereo(robust), work.Hpp, work.bp, work.Hll, work.bl,
-                                                 work.Hpl, work.chi, stream);
+                                                 work.Hpl, work.chi, stream, gi.d_scal + 2);
                     if (st != OVS_OK) return st;
-                    // (three small copies: one kernel writing the six values straight into the page-locked block was measured -- the
-                    // system-scope flush at its end costs ~50 us per trial, 9.7 instead of 8.9 ms per call)
-                    OVS_HIP_TRY(hipMemcpyAsync(h_chi, work.chi, sizeof(double) * 3, hipMemcpyDeviceToHost, stream));
-                    OVS_HIP_TRY(hipMemcpyAsync(h_chi + 4, gi.d_scal, sizeof(double) * 2, hipMemcpyDeviceToHost, stream));
-                    OVS_HIP_TRY(hipMemcpyAsync(h_fail, gi.d_fail, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                    OVS_HIP_TRY(hipMemcpyAsync(h_blk, gi.d_scal, 256 + sizeof(int32_t), hipMemcpyDeviceToHost, stream));
                     OVS_HIP_TRY(hipStreamSynchronize(stream));
+                    h_chi[0] = h_blk[2];
+                    h_chi[1] = h_blk[3];
+                    h_chi[2] = h_blk[4];
+                    h_chi[4] = h_blk[0];
+                    h_chi[5] = h_blk[1];
+                    *h_fail = *reinterpret_cast<const int32_t*>(reinterpret_cast<const unsigned char*>(h_blk) + 256);
                     const bool ok = *h_fail == 0;
                     double temp_chi = 1.7976931348623157e308, scale = 1e-3;
                     if (!ok) {   // a failed factorisation may have left non-finite values in the padding, which no later trial rewrites

@@ -154,14 +154,23 @@ __device__ __forceinline__ double pose_edge_equirect(const double* R, const doub
     col(0.0, 1.0, 0.0, J[0][4], J[1][4]);
     col(0.0, 0.0, 1.0, J[0][5], J[1][5]);
     const double W = rho1 * o.inv_sigma_sq;
+    // H += J^T (W J), b -= (W J)^T e: the weighted rows A = W J once (12 products), then fused multiply-adds straight into the accumulators --
+    // 54 operations per observation instead of 105 (round 5; separate products and sums until then). The sums associate differently from the
+    // oracle's (its per-entry order is W * (J0a J0b + J1a J1b)): differences of an ulp per term, inside the optimiser's 1e-9 tolerance.
+    double A0[6], A1[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        A0[a] = W * J[0][a];
+        A1[a] = W * J[1][a];
+    }
     int k = 0;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
 #pragma unroll
-        for (int b = a; b < 6; ++b) acc[k++] += W * (J[0][a] * J[0][b] + J[1][a] * J[1][b]);
+        for (int b = a; b < 6; ++b, ++k) acc[k] = __builtin_fma(A0[a], J[0][b], __builtin_fma(A1[a], J[1][b], acc[k]));
     }
 #pragma unroll
-    for (int a = 0; a < 6; ++a) acc[21 + a] += -(W * (J[0][a] * e0 + J[1][a] * e1));
+    for (int a = 0; a < 6; ++a) acc[21 + a] = __builtin_fma(-A0[a], e0, __builtin_fma(-A1[a], e1, acc[21 + a]));
     acc[27] += rho0;
     return c2;
 }
@@ -212,9 +221,17 @@ __device__ __forceinline__ double pose_edge_impl(const double* R, const double* 
     J[2][4] = 0;
     J[2][5] = J[0][5] - bf * invz2;
     const double W = rho1 * o.inv_sigma_sq;
-    // J[0][4], J[1][3] and J[2][4] are exact zeros: their products are +-0 and adding them changes no bit of a sum (x + (+-0) = x; a sum that
-    // is itself a zero then enters acc += W * s, where its sign is lost as well), so those multiply-adds are simply not issued -- 14 of the 54
-    // products of a monocular observation. The compiler may not do this itself (0 * x is not 0 for x = inf / NaN, which the edges never hold).
+    // J[0][4], J[1][3] and J[2][4] are exact zeros: their terms are simply not issued (0 * x is not 0 for x = inf / NaN, which the edges never
+    // hold, so the compiler may not drop them itself). H += J^T (W J), b -= (W J)^T e with the weighted rows A = W J formed once and fused
+    // multiply-adds straight into the accumulators: 52 operations per monocular observation instead of 105 (round 5; DESIGN 7.3 of round 4).
+    // The sums associate differently from the oracle's W * (J0a J0b + J1a J1b): an ulp per term, inside the optimiser's 1e-9 tolerance.
+    double A0[6], A1[6], A2[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        A0[a] = W * J[0][a];
+        A1[a] = W * J[1][a];
+        A2[a] = st ? W * J[2][a] : 0.0;
+    }
     int k = 0;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
@@ -222,16 +239,20 @@ __device__ __forceinline__ double pose_edge_impl(const double* R, const double* 
         for (int b = a; b < 6; ++b, ++k) {
             const bool z0 = a == 4 || b == 4, z1 = a == 3 || b == 3;   // row 0 (and row 2 like it) / row 1 contribute nothing
             if (z0 && z1) continue;                                     // (3, 4): every product is a zero, the sum stays +0
-            double s = z0 ? J[1][a] * J[1][b] : (z1 ? J[0][a] * J[0][b] : J[0][a] * J[0][b] + J[1][a] * J[1][b]);
-            if (st && !z0) s = s + J[2][a] * J[2][b];
-            acc[k] += W * s;
+            double v = acc[k];
+            if (!z1) v = __builtin_fma(A1[a], J[1][b], v);
+            if (!z0) v = __builtin_fma(A0[a], J[0][b], v);
+            if (st && !z0) v = __builtin_fma(A2[a], J[2][b], v);
+            acc[k] = v;
         }
     }
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-        double g = a == 4 ? J[1][a] * e1 : (a == 3 ? J[0][a] * e0 : J[0][a] * e0 + J[1][a] * e1);
-        if (st && a != 4) g = g + J[2][a] * e2;
-        acc[21 + a] += -(W * g);
+        double v = acc[21 + a];
+        if (a != 3) v = __builtin_fma(-A1[a], e1, v);
+        if (a != 4) v = __builtin_fma(-A0[a], e0, v);
+        if (st && a != 4) v = __builtin_fma(-A2[a], e2, v);
+        acc[21 + a] = v;
     }
     acc[27] += rho0;
     return c2;
