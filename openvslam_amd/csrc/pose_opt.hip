@@ -831,7 +831,10 @@ static ovs_status pose_optimize_host(int model, int32_t device, const double* po
     // one size), hence means, and hence a threshold a little above the crossover (tracked 1080p frames carry ~1300 matches: mean of four frame pairs 0.400 -> 0.376 ms). OVS_POSE_GROUPS=g forces g; the one-workgroup form is also the
     // fallback if a barrier is ever abandoned (num_valid == -2).
     const int groups_env = tuning().pose_groups;
-    int groups = groups_env > 0 ? std::min(groups_env, kMaxGroups) : (n_obs >= 1200 ? 4 : 1);
+    // round 5 (after the fused multiply-add accumulation made the per-observation work a third lighter; profiles/r05s_pose_groups.txt, means over 8
+    // frames, 1 / 2 / 4 / 8 workgroups): 300 observations 0.235 / 0.259 / 0.267 / 0.285 ms, 700: 0.275 / 0.283 / 0.285 / 0.302, 1000: 0.320 / 0.322 /
+    // 0.277 / 0.297, 1300: 0.335 / 0.323 / 0.298 / 0.288, 2000: 0.373 / 0.382 / 0.324 / 0.301, 4000: 0.541 / 0.466 / 0.378 / 0.325
+    int groups = groups_env > 0 ? std::min(groups_env, kMaxGroups) : (n_obs >= 1600 ? 8 : (n_obs >= 850 ? 4 : 1));
     for (;;) {
         // retries 1 .. 9 of an iteration in ONE pass (k_pose_optimize): nine trial poses per observation pay where a thread holds few
         // observations -- means over 8 frames, one pass / one by one (profiles/r04aj_pose_batched_retries.txt): four workgroups 1300
