@@ -84,10 +84,15 @@ struct LmScratch {
     size_t d_cap = 0;
     double* h_pin = nullptr;
     size_t pin_cap = 0;
+    unsigned char* h_edge = nullptr;   // pinned: two slots of [chi2 per edge (f64) | depth flag per edge (u8)], the results of edge_chi2 (round 1, final)
+    size_t edge_cap = 0;               // edges per slot
     ~LmScratch() { release(); }
     void release() {
         if (d) (void)hipFree(d);
         if (h_pin) (void)hipHostFree(h_pin);
+        if (h_edge) (void)hipHostFree(h_edge);
+        h_edge = nullptr;
+        edge_cap = 0;
         if (stream) (void)hipStreamDestroy(stream);
         d = nullptr;
         h_pin = nullptr;
@@ -110,6 +115,8 @@ struct Lm {
     uint8_t* d_edepth = nullptr;
     double* h_pin = nullptr;   // pinned: S | rhs | bp | chi3 | scal | fail
     size_t pin_doubles = 0;
+    unsigned char* h_edge = nullptr;   // LmScratch::h_edge
+    size_t edge_cap = 0;
 
     ovs_status init(int device, int np, int npt, size_t ne_max, const double* points) {
         static thread_local LmScratch sc;
@@ -161,6 +168,17 @@ struct Lm {
             sc.pin_cap = pin_doubles;
         }
         h_pin = sc.h_pin;
+        const size_t ne = std::max<size_t>(ne_max, 1);
+        if (sc.edge_cap < ne) {   // (pageable std::vectors here cost a staged 0.9 MB copy and fresh pages twice per call: ~0.3 ms of a 7.7 ms call)
+            if (sc.h_edge) (void)hipHostFree(sc.h_edge);
+            sc.h_edge = nullptr;
+            sc.edge_cap = 0;
+            const size_t cap = (ne + 1023) & ~(size_t)1023;
+            OVS_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sc.h_edge), 2 * cap * 9, hipHostMallocDefault));
+            sc.edge_cap = cap;
+        }
+        h_edge = sc.h_edge;
+        edge_cap = sc.edge_cap;
         OVS_HIP_TRY(hipMemcpyAsync(d_X, points, sizeof(double) * 3 * npt, hipMemcpyHostToDevice, stream));
         OVS_HIP_TRY(hipStreamSynchronize(stream));
         return OVS_OK;
@@ -389,21 +407,23 @@ struct Lm {
     // What upstream reads after optimizer.optimize(): edge->chi2() -- the error STORED by the last computeActiveErrors(), i.e. at the last
     // LM trial state when the round ended on a rejected step (g2o pops the estimate back but leaves the errors) -- and
     // edge->depth_is_positive(), which is evaluated from the vertices' current, accepted estimates (T, d_X).
-    ovs_status edge_chi2(ovs_ba_graph* g, const std::vector<Pose>& T, size_t ne, std::vector<double>& chi, std::vector<uint8_t>& depth) {
+    ovs_status edge_chi2(ovs_ba_graph* g, const std::vector<Pose>& T, size_t ne, int slot, const double*& chi, const uint8_t*& depth) {
         ovs_status st = upload_poses(T, d_poses);
         if (st != OVS_OK) return st;
-        chi.resize(ne);
-        depth.resize(ne);
+        double* const h_chi = reinterpret_cast<double*>(h_edge + (size_t)slot * edge_cap * 9);
+        uint8_t* const h_depth = h_edge + (size_t)slot * edge_cap * 9 + edge_cap * 8;
+        chi = h_chi;
+        depth = h_depth;
         if (err_at_trial) {
             st = ovs::ba_graph_edge_chi2(g, d_poses_n, d_Xn, d_echi, d_edepth, stream);
             if (st != OVS_OK) return st;
-            if (ne) OVS_HIP_TRY(hipMemcpyAsync(chi.data(), d_echi, sizeof(double) * ne, hipMemcpyDeviceToHost, stream));
+            if (ne) OVS_HIP_TRY(hipMemcpyAsync(h_chi, d_echi, sizeof(double) * ne, hipMemcpyDeviceToHost, stream));
         }
         st = ovs::ba_graph_edge_chi2(g, d_poses, d_X, d_echi, d_edepth, stream);
         if (st != OVS_OK) return st;
         if (ne) {
-            if (!err_at_trial) OVS_HIP_TRY(hipMemcpyAsync(chi.data(), d_echi, sizeof(double) * ne, hipMemcpyDeviceToHost, stream));
-            OVS_HIP_TRY(hipMemcpyAsync(depth.data(), d_edepth, ne, hipMemcpyDeviceToHost, stream));
+            if (!err_at_trial) OVS_HIP_TRY(hipMemcpyAsync(h_chi, d_echi, sizeof(double) * ne, hipMemcpyDeviceToHost, stream));
+            OVS_HIP_TRY(hipMemcpyAsync(h_depth, d_edepth, ne, hipMemcpyDeviceToHost, stream));
         }
         OVS_HIP_TRY(hipStreamSynchronize(stream));
         return OVS_OK;
@@ -453,11 +473,11 @@ static ovs_status local_ba_optimize_impl(int model, int32_t device, double* pose
     if (ne == 0) num_first_iter = num_second_iter = 0;
     st = L.run_round(g1.g, T, num_first_iter, true, force_stop_flag, &info_l[0], &info_l[1], &it1);
     if (st != OVS_OK) return st;
-    std::vector<double> chi;
-    std::vector<uint8_t> depth;
-    st = L.edge_chi2(g1.g, T, ne, chi, depth);
+    const double *chi_r1 = nullptr, *chi = nullptr;   // (page-locked slots of the scratch: round 1's stays valid beside the final one)
+    const uint8_t* depth = nullptr;
+    st = L.edge_chi2(g1.g, T, ne, 0, chi_r1, depth);
     if (st != OVS_OK) return st;
-    std::vector<double> chi_r1 = chi;
+    chi = chi_r1;
     std::vector<uint8_t> out_r1(ne);
     for (int i = 0; i < n_mono; ++i) out_r1[i] = (kChi2D < chi[i]) || !depth[i];
     for (int i = 0; i < n_stereo; ++i) out_r1[(size_t)n_mono + i] = (kChi3D < chi[(size_t)n_mono + i]) || !depth[(size_t)n_mono + i];
@@ -476,7 +496,7 @@ static ovs_status local_ba_optimize_impl(int model, int32_t device, double* pose
     }
     // ---- final outlier flags: an edge optimised in round 2 is judged at the final state; a level-1 edge keeps its round-1 chi2
     //      (g2o does not recompute the error of inactive edges) but its depth test sees the final state
-    st = L.edge_chi2(g1.g, T, ne, chi, depth);
+    st = L.edge_chi2(g1.g, T, ne, 1, chi, depth);
     if (st != OVS_OK) return st;
     for (int i = 0; i < n_mono; ++i) {
         const double c = (!stopped && !out_r1[i]) ? chi[i] : chi_r1[i];
