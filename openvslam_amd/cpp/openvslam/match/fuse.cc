@@ -11,12 +11,22 @@ namespace openvslam {
 namespace match {
 
 namespace {
+// the landmarks to check as five flat arrays. Per THREAD and reused from call to call (mapping_module calls this ~40 times per new keyframe with
+// ~2000 landmarks each: five fresh 2 - 64 KB vectors per call were a tenth of a resident call's 0.11 ms in allocation, zero-fill and page faults);
+// entries of landmarks that are not usable keep whatever an earlier call left there -- the kernel reads nothing of an entry whose `valid` is 0
 struct flat_landmarks {
     std::vector<double> pos, normal;
     std::vector<float> dist;
     std::vector<uint8_t> desc, valid;
+    std::vector<int32_t> best;
     template <typename IT, typename PRED>
-    flat_landmarks(IT begin, IT end, size_t m, PRED is_valid) : pos(3 * m), normal(3 * m), dist(2 * m), desc(32 * m), valid(m) {
+    void fill(IT begin, IT end, size_t m, PRED is_valid) {
+        pos.resize(3 * m);
+        normal.resize(3 * m);
+        dist.resize(2 * m);
+        desc.resize(32 * m);
+        valid.resize(m);
+        best.assign(m, -1);
         size_t l = 0;
         for (IT it = begin; it != end; ++it, ++l) {
             data::landmark* lm = *it;
@@ -34,6 +44,10 @@ struct flat_landmarks {
         }
     }
 };
+flat_landmarks& flat_scratch() {
+    thread_local flat_landmarks f;
+    return f;
+}
 }   // namespace
 
 template <typename T>
@@ -41,11 +55,12 @@ unsigned int fuse::replace_duplication(data::keyframe* keyfrm, const T& landmark
     const int n = (int)keyfrm->num_keypts_, m = (int)landmarks_to_check.size();
     if (n == 0 || m == 0) return 0;
     auto usable = [&](data::landmark* lm) { return lm && !lm->will_be_erased() && !lm->is_observed_in_keyframe(keyfrm); };
-    const flat_landmarks f(landmarks_to_check.begin(), landmarks_to_check.end(), (size_t)m, usable);
+    flat_landmarks& f = flat_scratch();
+    f.fill(landmarks_to_check.begin(), landmarks_to_check.end(), (size_t)m, usable);
+    std::vector<int32_t>& best = f.best;
     const ovs_camera cam = detail::camera_of(keyfrm->camera_);
     double pose[12];
     detail::pose12(keyfrm->get_cam_pose(), pose);
-    std::vector<int32_t> best((size_t)m, -1);
     int32_t num = 0;
     const int device = detail::device_of(*keyfrm);
     // the keyframe is resident: mapping_module::fuse_landmark_duplication calls this on ~20 covisible keyframes per new keyframe, and again with
@@ -93,11 +108,12 @@ unsigned int fuse::detect_duplication(data::keyframe* keyfrm, const Mat44_t& Sim
     const auto valid_lms = keyfrm->get_landmarks();
     const std::set<data::landmark*> already_matched(valid_lms.begin(), valid_lms.end());
     auto usable = [&](data::landmark* lm) { return lm && !lm->will_be_erased() && !already_matched.count(lm); };
-    const flat_landmarks f(landmarks_to_check.begin(), landmarks_to_check.end(), (size_t)m, usable);
+    flat_landmarks& f = flat_scratch();
+    f.fill(landmarks_to_check.begin(), landmarks_to_check.end(), (size_t)m, usable);
+    std::vector<int32_t>& best = f.best;
     const ovs_camera cam = detail::camera_of(keyfrm->camera_);
     double sim3[12];
     detail::pose12(Sim3_cw, sim3);
-    std::vector<int32_t> best((size_t)m, -1);
     int32_t num = 0;
     const int device = detail::device_of(*keyfrm);
     if (!detail::guarded("ovs_fuse_detect_duplication_f", [&] {
