@@ -2,6 +2,7 @@
 // the object graph is flattened in the order of local_landmarks, the device returns per landmark the keypoint it is written to.
 #include "projection.h"
 
+#include <algorithm>
 #include <cstring>
 
 #include "window_ctx.h"
@@ -12,9 +13,10 @@ namespace match {
 unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::vector<data::landmark*>& local_landmarks, const float margin) const {
     const int n = (int)frm.num_keypts_, m = (int)local_landmarks.size();
     if (n == 0 || m == 0) return 0;
-    std::vector<float> lm_xy((size_t)2 * m), lm_x_right((size_t)m);
-    std::vector<int32_t> lm_level((size_t)m);
-    std::vector<uint8_t> lm_valid((size_t)m), lm_desc((size_t)32 * m), occupied((size_t)n);
+    std::vector<float>&lm_xy = detail::scratch_vec<float>(0, (size_t)2 * m), &lm_x_right = detail::scratch_vec<float>(1, (size_t)m);
+    std::vector<int32_t>& lm_level = detail::scratch_vec<int32_t>(0, (size_t)m);
+    std::vector<uint8_t>&lm_valid = detail::scratch_vec<uint8_t>(0, (size_t)m), &lm_desc = detail::scratch_vec<uint8_t>(1, (size_t)32 * m),
+                         &occupied = detail::scratch_vec<uint8_t>(2, (size_t)n);
     for (int l = 0; l < m; ++l) {
         const auto* lm = local_landmarks[l];
         lm_valid[l] = lm && lm->is_observable_in_tracking_ && !lm->will_be_erased();
@@ -28,7 +30,8 @@ unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::
     }
     for (int i = 0; i < n; ++i) occupied[i] = frm.landmarks_[i] && frm.landmarks_[i]->has_observation();
     const bool stereo = !frm.stereo_x_right_.empty();
-    std::vector<int32_t> assigned((size_t)m, -1);
+    std::vector<int32_t>& assigned = detail::scratch_vec<int32_t>(1, (size_t)m);
+    std::fill(assigned.begin(), assigned.end(), -1);
     int32_t num_matches = 0;
     // the frame's keypoints, descriptors and grid are resident (uploaded by the first matcher call on this frame)
     const int device = detail::device_of(frm);
@@ -49,8 +52,9 @@ unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::
 unsigned int projection::match_current_and_last_frames(data::frame& curr_frm, const data::frame& last_frm, const float margin) const {
     const int n_curr = (int)curr_frm.num_keypts_, n_last = (int)last_frm.num_keypts_;
     if (n_curr == 0 || n_last == 0) return 0;
-    std::vector<double> last_pos((size_t)3 * n_last);
-    std::vector<uint8_t> last_valid((size_t)n_last), last_desc((size_t)32 * n_last), occupied((size_t)n_curr);
+    std::vector<double>& last_pos = detail::scratch_vec<double>(0, (size_t)3 * n_last);
+    std::vector<uint8_t>&last_valid = detail::scratch_vec<uint8_t>(0, (size_t)n_last), &last_desc = detail::scratch_vec<uint8_t>(1, (size_t)32 * n_last),
+                         &occupied = detail::scratch_vec<uint8_t>(2, (size_t)n_curr);
     for (int i = 0; i < n_last; ++i) {
         const auto* lm = last_frm.landmarks_[i];
         last_valid[i] = lm && !(i < (int)last_frm.outlier_flags_.size() && last_frm.outlier_flags_[i]);
@@ -65,7 +69,8 @@ unsigned int projection::match_current_and_last_frames(data::frame& curr_frm, co
     double pose_curr[12], pose_last[12];
     detail::pose12(curr_frm.cam_pose_cw_, pose_curr);
     detail::pose12(last_frm.cam_pose_cw_, pose_last);
-    std::vector<int32_t> assigned((size_t)n_last, -1);
+    std::vector<int32_t>& assigned = detail::scratch_vec<int32_t>(1, (size_t)n_last);
+    std::fill(assigned.begin(), assigned.end(), -1);
     int32_t num_matches = 0;
     const int device = detail::device_of(curr_frm);
     if (!detail::guarded("ovs_projection_match_current_and_last_frames_f", [&] {
