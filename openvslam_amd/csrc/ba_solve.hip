@@ -1,7 +1,9 @@
 // ba_solve.hip -- the reduced camera system of local BA on the device (round 4):
 //   k_chol_solve    dense Cholesky + both substitutions of  S x = rhs  (S = 6 n_free square, symmetric positive definite after the
 //                   landmarks were eliminated: ba_graph.hip k_schur_pairs / k_schur_rhs) in ONE workgroup, the trailing updates on the
-//                   f64 matrix cores;
+//                   f64 matrix cores; the trailing tiles travel through memory: systems of 289 .. 1024 unknowns;
+//   k_chol_resident (round 5) the same factorisation with the trailing tiles resident in registers / LDS: systems up to 288 unknowns
+//                   (BASELINE config 5), 168 instead of 252 us per solve; described where it is defined, below;
 //   k_pose_update   the Levenberg-Marquardt trial state of the keyframes: T <- exp(dx) T per free keyframe (g2o SE3Quat::exp as in
 //                   ba_host_math.h se3_oplus), the 7-double record the linearisation kernels read, and the keyframes' part of the gain
 //                   ratio's denominator.
