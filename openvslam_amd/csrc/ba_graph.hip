@@ -5,17 +5,26 @@
 // Why: k_ba_linearize issued 1.2 M scattered fp64 atomics per linearisation (0.022 of HBM, sums that change from
 // run to run), and ovs_local_ba_optimize downloaded 16 MB of blocks per Levenberg-Marquardt trial to eliminate the landmarks on the host.
 // Here every sum has a fixed order:
-//   k_lin_landmark   one lane per landmark walks ITS edges in ascending index (mono first, then stereo -- the oracle's association):
+//   k_linearize      (round 5: ONE launch for the two independent halves below, which ran one after the other until then)
+//     lin_landmark   one lane per landmark walks ITS edges in ascending index (mono first, then stereo -- the oracle's association):
 //                    Hll | bl exactly as a sequential loop would add them, Hpl per edge, per-landmark chi2 partials;
-//   k_lin_pose       one workgroup per keyframe over ITS edges: 21 + 6 pose-block terms per lane, fixed-shape tree reduction;
-//   k_reduce_scalars chi2 (and the Levenberg-Marquardt start damping: max |H_jj|) by one workgroup, fixed tree;
+//     lin_pose       one workgroup per keyframe over ITS edges: 21 + 6 pose-block terms per lane, fixed-shape tree reduction;
+//   k_reduce_scalars chi2 (and the Levenberg-Marquardt start damping: max |H_jj|) by one workgroup, fixed tree; at the end of an LM trial
+//                    also the sum of the landmarks' gain-ratio terms (the former k_sum_1024);
 //   k_lm_prepare     (Hll + lambda I)^-1 per landmark and Y_e = W_e Hll^-1 per edge;
-//   k_schur_pairs    one workgroup per pair of free keyframes (a, b >= a): S_ab = [a == b](Hpp_a + lambda I) - sum over the landmarks both
+//   k_schur          (round 5: one launch)
+//     schur_pair     one workgroup per pair of free keyframes (a, b >= a): S_ab = [a == b](Hpp_a + lambda I) - sum over the landmarks both
 //                    observe of Y_ea W_eb^T; the common landmarks are found on the device (k_edge_table: keyframe x landmark -> edge);
-//   k_schur_rhs      g_a = bp_a - sum over a's edges of Y_e bl_j;
-//   ba_solve.hip     Cholesky of the reduced camera system and the keyframes' trial state (round 4; ovs_local_ba_set_solver(1): on the
-//                    host as in rounds 1-3 and in BASELINE's north star -- then 0.7 MB come down and 5 KB go up per trial);
-//   k_backsub        dxl_j = Hll^-1 (bl_j - sum W_e^T dxp), the trial points X + dxl and the landmark part of g2o's gain-ratio scale.
+//     schur_rhs      g_a = bp_a - sum over a's edges of Y_e bl_j, one workgroup per free keyframe;
+//   ba_solve.hip     Cholesky of the reduced camera system (round 4; ovs_local_ba_set_solver(1): on the host as in rounds 1-3 and in
+//                    BASELINE's north star -- then 0.7 MB come down and 5 KB go up per trial);
+//   k_trial_update   (round 5: one launch)
+//     pose_update    T <- exp(dx) T per free keyframe (g2o SE3Quat::exp as in ba_host_math.h se3_oplus), the 7-double records the
+//                    linearisation reads, the keyframes' part of the gain ratio's denominator -- one workgroup;
+//     backsub_landmark  dxl_j = Hll^-1 (bl_j - sum W_e^T dxp), the trial points X + dxl and the landmark's term of g2o's gain-ratio scale
+//                    (k_backsub: the same on increments uploaded by the host solver).
+// Round 5's three mergers are side-by-side only (a workgroup runs one of the two bodies, chosen by its index): the arithmetic of every block,
+// landmark and keyframe is what it was, the results are the same bits, and a trial is 332 instead of 386 us of kernels (profiles/r05ai_*).
 // Per-edge arithmetic is the expression sequence of k_ba_linearize / the oracle (every product individually rounded), so Hpl, Hll and bl
 // are bit-identical to the CPU oracle; Hpp, bp and chi2 are tree sums (1e-15 relative), identical from run to run.
 #include <algorithm>
@@ -199,11 +208,10 @@ struct GraphDev {   // device views shared by the kernels
 };
 
 // ---- linearisation ----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_lin_landmark(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points,
-                                                     double huber_mono, double huber_stereo, double* __restrict__ Hll, double* __restrict__ bl,
-                                                     double* __restrict__ Hpl, double* __restrict__ lm_chi) {
-    const int j = blockIdx.x * 128 + threadIdx.x;
-    if (j >= g.n_pt) return;
+// landmark j by one lane
+__device__ __forceinline__ void lin_landmark(const GraphDev& g, const int j, const double* __restrict__ poses, const double* __restrict__ points,
+                                             double huber_mono, double huber_stereo, double* __restrict__ Hll, double* __restrict__ bl,
+                                             double* __restrict__ Hpl, double* __restrict__ lm_chi) {
     const double* X = points + 3 * (size_t)j;
     double hm[9], gm[3], hs[9], gs[3];   // mono and stereo partial sums kept apart: the oracle adds (mono total) + (stereo total)
 #pragma unroll
@@ -273,10 +281,10 @@ __device__ __forceinline__ void block_sum_256(double (&v)[NV], double (*s_part)[
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_lin_pose(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points,
-                                                 double huber_mono, double huber_stereo, double* __restrict__ Hpp, double* __restrict__ bp) {
-    __shared__ double s_part[4][27];
-    const int k = blockIdx.x;
+// keyframe k by one 256-thread workgroup
+__device__ __forceinline__ void lin_pose(const GraphDev& g, const int k, const double* __restrict__ poses, const double* __restrict__ points,
+                                         double huber_mono, double huber_stereo, double* __restrict__ Hpp, double* __restrict__ bp,
+                                         double (*s_part)[27]) {
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) acc[i] = 0.0;
@@ -320,11 +328,47 @@ __global__ __launch_bounds__(256) void k_lin_pose(GraphDev g, const double* __re
     }
 }
 
+// ONE launch for both halves of a linearisation (round 5: they are independent -- different outputs, the same inputs -- and each is a small
+// latency-bound grid, 50 and 79 workgroups at config 5, that ran one after the other: 28 + 24 us; side by side ~29): workgroups [0, n_pose)
+// take a keyframe each, the rest 256 landmarks each. The arithmetic of a keyframe / a landmark is what it was: the same bits.
+__global__ __launch_bounds__(256) void k_linearize(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points, double huber_mono,
+                                                  double huber_stereo, double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ Hll,
+                                                  double* __restrict__ bl, double* __restrict__ Hpl, double* __restrict__ lm_chi) {
+    __shared__ double s_part[4][27];
+    if ((int)blockIdx.x < g.n_pose) {   // (workgroup-uniform)
+        lin_pose(g, (int)blockIdx.x, poses, points, huber_mono, huber_stereo, Hpp, bp, s_part);
+    } else {
+        const int j = ((int)blockIdx.x - g.n_pose) * 256 + (int)threadIdx.x;
+        if (j < g.n_pt) lin_landmark(g, j, poses, points, huber_mono, huber_stereo, Hll, bl, Hpl, lm_chi);
+    }
+}
+
 // chi2[0..1] = sum of the per-landmark partials; chi2[2] = max |diagonal| over free pose blocks and landmarks with edges (g2o's
-// computeLambdaInit); one workgroup, fixed order
+// computeLambdaInit); one workgroup, fixed order. With `lm_scale` (a Levenberg-Marquardt trial: the landmarks' terms of the gain ratio's
+// denominator, written by the back-substitution) their sum goes to scale_sum[0] -- the additions of the former k_sum_1024, in its order.
 __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const double* __restrict__ lm_chi, const double* __restrict__ Hpp,
-                                                        const double* __restrict__ Hll, double* __restrict__ chi2, double* __restrict__ mirror) {
+                                                        const double* __restrict__ Hll, double* __restrict__ chi2, double* __restrict__ mirror,
+                                                        const double* __restrict__ lm_scale, double* __restrict__ scale_sum) {
     __shared__ double s0[1024], s1[1024], s2[1024];
+    if (lm_scale) {   // (uniform) before the chi2 sums: s0 is reused
+        double a = 0;
+        for (int j0 = threadIdx.x; j0 < g.n_pt; j0 += 4 * 1024) {   // four loads in flight, added in the plain loop's order
+            double c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = j0 + 1024 * u < g.n_pt ? lm_scale[j0 + 1024 * u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + 1024 * u < g.n_pt) a += c[u];
+        }
+        s0[threadIdx.x] = a;
+        __syncthreads();
+        for (int w = 512; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) s0[threadIdx.x] += s0[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) scale_sum[0] = s0[0];
+        __syncthreads();
+    }
     double a = 0, b = 0, m = 0;
     // four landmarks of a thread in flight (all loads first, then the additions in the order of the plain loop: the same bits)
     for (int j0 = threadIdx.x; j0 < g.n_pt; j0 += 4 * 1024) {
@@ -440,15 +484,12 @@ __global__ __launch_bounds__(256) void k_edge_table(const GEdge* __restrict__ ed
 // multiply-adds on two 18-double records), so the arithmetic runs with all lanes busy whatever the overlap of the two keyframes. Lane l
 // accumulates queue entries l, l + 64, ...; the 64 partial blocks of a wave are folded by a fixed xor tree, the four waves' blocks in wave
 // order: the same bits from run to run. (One wave per pair walked the whole list in 32 dependent steps: 107 us per launch at config 5.)
-__global__ __launch_bounds__(256) void k_schur_pairs(const int32_t* __restrict__ pose_start, const int32_t* __restrict__ pose_edges,
-                                                    const int32_t* __restrict__ pose_pt, const int32_t* __restrict__ pair_ab,
-                                                    const int32_t* __restrict__ slot_pose, const int32_t* __restrict__ edge_of, int n_pt,
-                                                    const double* __restrict__ Hpp, const double* __restrict__ Hpl, const double* __restrict__ Y,
-                                                    double lambda, int pitch, double* __restrict__ S) {
-    __shared__ int2 s_queue[4][128];
-    __shared__ double s_part[4][36];
+__device__ __forceinline__ void schur_pair(const int pr, const int32_t* __restrict__ pose_start, const int32_t* __restrict__ pose_edges,
+                                           const int32_t* __restrict__ pose_pt, const int32_t* __restrict__ pair_ab,
+                                           const int32_t* __restrict__ slot_pose, const int32_t* __restrict__ edge_of, int n_pt,
+                                           const double* __restrict__ Hpp, const double* __restrict__ Hpl, const double* __restrict__ Y,
+                                           double lambda, int pitch, double* __restrict__ S, int2 (*s_queue)[128], double (*s_part)[36]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int pr = blockIdx.x;
     const int sa = pair_ab[2 * pr], sb = pair_ab[2 * pr + 1];
     const int ka = slot_pose[sa];
     const int32_t* const tb = edge_of + (size_t)sb * n_pt;
@@ -511,10 +552,10 @@ __global__ __launch_bounds__(256) void k_schur_pairs(const int32_t* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void k_schur_rhs(GraphDev g, const int32_t* __restrict__ slot_pose, const double* __restrict__ bp,
-                                                  const double* __restrict__ bl, const double* __restrict__ Y, double* __restrict__ rhs) {
-    __shared__ double s_part[4][6];
-    const int s = blockIdx.x, k = slot_pose[s];
+// g_s = bp_k - sum over keyframe k's edges of Y_e bl_j (k = the keyframe of block s), one workgroup
+__device__ __forceinline__ void schur_rhs(const GraphDev& g, const int s, const int32_t* __restrict__ slot_pose, const double* __restrict__ bp,
+                                          const double* __restrict__ bl, const double* __restrict__ Y, double* __restrict__ rhs, double (*s_part)[6]) {
+    const int k = slot_pose[s];
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int i = g.pose_start[k] + (int)threadIdx.x; i < g.pose_start[k + 1]; i += 256) {
         const int e = g.pose_edges[i];
@@ -530,19 +571,36 @@ __global__ __launch_bounds__(256) void k_schur_rhs(GraphDev g, const int32_t* __
     }
 }
 
+// The reduced camera system in ONE launch (round 5): workgroups [0, n_free) form the right-hand side rows, the others one block (a, b) of S each.
+// Both read Y and write disjoint parts of the system; as two launches the 48 workgroups of the right-hand side had the chip to themselves for 15 us.
+__global__ __launch_bounds__(256) void k_schur(GraphDev g, int n_free, const int32_t* __restrict__ pose_pt, const int32_t* __restrict__ pair_ab,
+                                              const int32_t* __restrict__ slot_pose, const int32_t* __restrict__ edge_of, const double* __restrict__ Hpp,
+                                              const double* __restrict__ bp, const double* __restrict__ bl, const double* __restrict__ Hpl,
+                                              const double* __restrict__ Y, double lambda, int pitch, double* __restrict__ S, double* __restrict__ rhs) {
+    __shared__ int2 s_queue[4][128];
+    __shared__ double s_part[4][36];
+    __shared__ double s_part6[4][6];
+    if ((int)blockIdx.x < n_free)   // (workgroup-uniform)
+        schur_rhs(g, (int)blockIdx.x, slot_pose, bp, bl, Y, rhs, s_part6);
+    else
+        schur_pair((int)blockIdx.x - n_free, g.pose_start, g.pose_edges, pose_pt, pair_ab, slot_pose, edge_of, g.n_pt, Hpp, Hpl, Y, lambda, pitch, S,
+                   s_queue, s_part);
+}
+
 // dxl_j = Hll^-1 (bl_j - sum_e W_e^T dxp[pose(e)]); X_trial = X + dxl; lm_scale[j] = dxl . (lambda dxl + bl_j)
-__global__ __launch_bounds__(128) void k_backsub(GraphDev g, const double* __restrict__ Hinv, const double* __restrict__ Hpl,
-                                                const double* __restrict__ bl, const double* __restrict__ dxp, double lambda,
-                                                const double* __restrict__ X, double* __restrict__ Xn, double* __restrict__ lm_scale) {
-    const int j = blockIdx.x * 128 + threadIdx.x;
-    if (j >= g.n_pt) return;
+// `dx`: the keyframes' increments, six per reduced block when `slot_of_pose` is given (the device solver's solution vector, read in place),
+// else six per keyframe (the host solver's upload)
+__device__ __forceinline__ void backsub_landmark(const GraphDev& g, const int j, const double* __restrict__ Hinv, const double* __restrict__ Hpl,
+                                                 const double* __restrict__ bl, const double* __restrict__ dx,
+                                                 const int32_t* __restrict__ slot_of_pose, double lambda, const double* __restrict__ X,
+                                                 double* __restrict__ Xn, double* __restrict__ lm_scale) {
     double r[3] = {bl[3 * (size_t)j], bl[3 * (size_t)j + 1], bl[3 * (size_t)j + 2]};
     for (int i = g.lm_start[j]; i < g.lm_start[j + 1]; ++i) {
         const int e = g.lm_edges[i];
         const int k = g.edges[e].pose;
         if (g.fixed[k]) continue;
         const double* W = Hpl + 18 * (size_t)e;
-        const double* d = dxp + 6 * (size_t)k;
+        const double* d = dx + 6 * (size_t)(slot_of_pose ? slot_of_pose[k] : k);   // (k is free here: its slot is >= 0)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             r[c] -= ((W[c] * d[0] + W[3 + c] * d[1]) + (W[6 + c] * d[2] + W[9 + c] * d[3])) + (W[12 + c] * d[4] + W[15 + c] * d[5]);
@@ -558,24 +616,135 @@ __global__ __launch_bounds__(128) void k_backsub(GraphDev g, const double* __res
     lm_scale[j] = sc;
 }
 
-__global__ __launch_bounds__(1024) void k_sum_1024(const double* __restrict__ v, int n, double* __restrict__ out) {
-    __shared__ double s0[1024];
-    double a = 0;
-    for (int j0 = threadIdx.x; j0 < n; j0 += 4 * 1024) {   // four loads in flight, added in the plain loop's order
-        double c[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) c[u] = j0 + 1024 * u < n ? v[j0 + 1024 * u] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (j0 + 1024 * u < n) a += c[u];
+__global__ __launch_bounds__(256) void k_backsub(GraphDev g, const double* __restrict__ Hinv, const double* __restrict__ Hpl,
+                                                const double* __restrict__ bl, const double* __restrict__ dxp, double lambda,
+                                                const double* __restrict__ X, double* __restrict__ Xn, double* __restrict__ lm_scale) {
+    const int j = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (j < g.n_pt) backsub_landmark(g, j, Hinv, Hpl, bl, dxp, nullptr, lambda, X, Xn, lm_scale);
+}
+
+// ---- LM trial state of the keyframes ------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ void dev_rot_to_quat(const double* R, double* q) {   // ba_host_math.h rot_to_quat
+    const double tr = R[0] + R[4] + R[8];
+    if (tr > 0) {
+        double s = sqrt(tr + 1.0);
+        q[3] = 0.5 * s;
+        s = 0.5 / s;
+        q[0] = (R[7] - R[5]) * s;
+        q[1] = (R[2] - R[6]) * s;
+        q[2] = (R[3] - R[1]) * s;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double s = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+        double qq[4];
+        qq[i] = 0.5 * s;
+        s = 0.5 / s;
+        qq[3] = (R[3 * k + j] - R[3 * j + k]) * s;
+        qq[j] = (R[3 * j + i] + R[3 * i + j]) * s;
+        qq[k] = (R[3 * k + i] + R[3 * i + k]) * s;
+        for (int a = 0; a < 4; ++a) q[a] = qq[a];
     }
-    s0[threadIdx.x] = a;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) s0[threadIdx.x] += s0[threadIdx.x + w];
+    if (q[3] < 0)
+        for (int a = 0; a < 4; ++a) q[a] = -q[a];
+    const double nn = sqrt((q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]));
+    for (int a = 0; a < 4; ++a) q[a] /= nn;
+}
+
+__device__ void dev_se3_oplus(const double* TR, const double* Tt, const double* u, double* nR, double* nt) {   // ba_host_math.h se3_oplus
+    const double wx = u[0], wy = u[1], wz = u[2];
+    const double theta = sqrt((wx * wx + wy * wy) + wz * wz);
+    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double O2[9], E[9], V[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) O2[3 * i + j] = (O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j]) + O[3 * i + 2] * O[6 + j];
+    const bool small = theta < 0.00001;
+    const double s = small ? 0.0 : sin(theta), c = small ? 1.0 : cos(theta);
+    for (int i = 0; i < 9; ++i) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        if (small) {
+            E[i] = (I + O[i]) + O2[i];
+            V[i] = E[i];
+        } else {
+            E[i] = (I + s / theta * O[i]) + (1 - c) / (theta * theta) * O2[i];
+            V[i] = (I + (1 - c) / (theta * theta) * O[i]) + (theta - s) / (theta * theta * theta) * O2[i];
+        }
+    }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) nR[3 * i + j] = (E[3 * i] * TR[j] + E[3 * i + 1] * TR[3 + j]) + E[3 * i + 2] * TR[6 + j];
+        const double te = (V[3 * i] * u[3] + V[3 * i + 1] * u[4]) + V[3 * i + 2] * u[5];
+        nt[i] = ((E[3 * i] * Tt[0] + E[3 * i + 1] * Tt[1]) + E[3 * i + 2] * Tt[2]) + te;
+    }
+}
+
+}   // namespace
+
+// T (12 doubles per keyframe: R row-major | t) -> Tn, the 7-double records p7n (t | quaternion x y z w), dxp (6 per keyframe, zeros for
+// fixed ones) and scal_pose = sum over free keyframes, in keyframe order, of dx . (lambda dx + bp)  (the keyframes' part of g2o's
+// computeScale; the landmarks' part comes from k_backsub)
+__device__ __forceinline__ void pose_update(const double* __restrict__ T, const int32_t* __restrict__ slot_of_pose, int n_pose,
+                                            const double* __restrict__ x, const double* __restrict__ bp, double lambda, double* __restrict__ Tn,
+                                            double* __restrict__ p7n, double* __restrict__ dxp, double* __restrict__ scal_pose,
+                                            double (*s_term)[7]) {
+    double sc = 0;
+    for (int base = 0; base < n_pose; base += 256) {
+        const int k = base + (int)threadIdx.x;
+        if (k < n_pose) {
+            const int sl = slot_of_pose[k];
+            double u[6] = {0, 0, 0, 0, 0, 0};
+            double nR[9], nt[3];
+            if (sl >= 0) {
+                for (int a = 0; a < 6; ++a) u[a] = x[6 * (size_t)sl + a];
+                dev_se3_oplus(T + 12 * (size_t)k, T + 12 * (size_t)k + 9, u, nR, nt);
+            } else {
+                for (int a = 0; a < 9; ++a) nR[a] = T[12 * (size_t)k + a];
+                for (int a = 0; a < 3; ++a) nt[a] = T[12 * (size_t)k + 9 + a];
+            }
+            for (int a = 0; a < 9; ++a) Tn[12 * (size_t)k + a] = nR[a];
+            for (int a = 0; a < 3; ++a) {
+                Tn[12 * (size_t)k + 9 + a] = nt[a];
+                p7n[7 * (size_t)k + a] = nt[a];
+            }
+            dev_rot_to_quat(nR, p7n + 7 * (size_t)k + 3);
+            for (int a = 0; a < 6; ++a) {
+                dxp[6 * (size_t)k + a] = u[a];
+                s_term[threadIdx.x][a] = u[a] * (lambda * u[a] + bp[6 * (size_t)k + a]);
+            }
+            s_term[threadIdx.x][6] = sl >= 0 ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int cnt = min(256, n_pose - base);
+            for (int i = 0; i < cnt; ++i)
+                if (s_term[i][6] != 0.0)
+                    for (int a = 0; a < 6; ++a) sc += s_term[i][a];
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = s0[0];
+    if (threadIdx.x == 0) *scal_pose = sc;
+}
+
+
+// The trial state of a Levenberg-Marquardt step in ONE launch (round 5): workgroup 0 advances the keyframes, the others back-substitute 256
+// landmarks each. The landmarks read the keyframes' increments from the solver's solution vector (slot order) instead of the dxp array the
+// keyframe workgroup writes, so the two halves are independent; as two launches the single keyframe workgroup held the queue for 9.5 us.
+__global__ __launch_bounds__(256) void k_trial_update(GraphDev g, const double* __restrict__ T, const int32_t* __restrict__ slot_of_pose,
+                                                     const double* __restrict__ x, const double* __restrict__ bp, double lambda,
+                                                     double* __restrict__ Tn, double* __restrict__ p7n, double* __restrict__ dxp,
+                                                     double* __restrict__ scal_pose, const double* __restrict__ Hinv, const double* __restrict__ Hpl,
+                                                     const double* __restrict__ bl, const double* __restrict__ X, double* __restrict__ Xn,
+                                                     double* __restrict__ lm_scale) {
+    __shared__ double s_term[256][7];   // a keyframe's six products (and whether it is free): thread 0 adds them in keyframe order
+    if (blockIdx.x == 0) {   // (workgroup-uniform)
+        pose_update(T, slot_of_pose, g.n_pose, x, bp, lambda, Tn, p7n, dxp, scal_pose, s_term);
+    } else {
+        const int j = ((int)blockIdx.x - 1) * 256 + (int)threadIdx.x;
+        if (j < g.n_pt) backsub_landmark(g, j, Hinv, Hpl, bl, x, slot_of_pose, lambda, X, Xn, lm_scale);
+    }
 }
 
 // per-edge chi2 = e^T Omega e (no kernel) and the sign of the depth (reproj_edge_wrapper::depth_is_positive)
@@ -645,7 +814,7 @@ struct ovs_ba_graph {
     int32_t *d_pose_pt = nullptr, *d_pair_ab = nullptr, *d_slot_pose = nullptr, *d_slot_of_pose = nullptr, *d_fail = nullptr;
     int32_t* d_edge_of = nullptr;   // [n_free x n_pt], solver arena
     int n_pairs = 0;
-    double* d_lm_tmp = nullptr;   // [3 n_pt] per-landmark partials (chi2 pair, max |diagonal|; or the gain ratio's scale terms)
+    double* d_lm_tmp = nullptr;   // [4 n_pt] per-landmark partials: chi2 pair, max |diagonal|, the gain ratio's scale term
     // solver work space (allocated on first use: ovs_ba_graph_linearize_dev alone does not need it)
     double *d_Hinv = nullptr, *d_Y = nullptr, *d_S = nullptr, *d_rhs = nullptr, *d_dxp = nullptr, *d_scal = nullptr;
     int s_pitch = 0;   // doubles per row of d_S
@@ -690,15 +859,17 @@ struct Blob {
     }
 };
 
+// `trial_scale`: the linearisation closes a Levenberg-Marquardt trial -- the landmarks' gain-ratio terms the back-substitution left in
+// d_lm_tmp[3 n_pt ..) are summed into d_scal[0] by the same launch that sums chi2
 ovs_status graph_linearize(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo, double* d_Hpp,
-                           double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror = nullptr) {
+                           double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror = nullptr,
+                           bool trial_scale = false) {
     const GraphDev v = g->view();
-    hipLaunchKernelGGL(k_lin_landmark, dim3((g->n_pt + 127) / 128), dim3(128), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hll, d_bl,
-                       d_Hpl, g->d_lm_tmp);
-    OVS_LAUNCH_TRY("k_lin_landmark");
-    hipLaunchKernelGGL(k_lin_pose, dim3(g->n_pose), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp);
-    OVS_LAUNCH_TRY("k_lin_pose");
-    hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(1024), 0, s, v, g->d_lm_tmp, d_Hpp, d_Hll, d_chi3, d_chi_mirror);
+    hipLaunchKernelGGL(k_linearize, dim3(g->n_pose + (g->n_pt + 255) / 256), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpp,
+                       d_bp, d_Hll, d_bl, d_Hpl, g->d_lm_tmp);
+    OVS_LAUNCH_TRY("k_linearize");
+    hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(1024), 0, s, v, g->d_lm_tmp, d_Hpp, d_Hll, d_chi3, d_chi_mirror,
+                       trial_scale ? g->d_lm_tmp + 3 * (size_t)g->n_pt : (const double*)nullptr, trial_scale ? g->d_scal : (double*)nullptr);
     OVS_LAUNCH_TRY("k_reduce_scalars");
     return OVS_OK;
 }
@@ -857,7 +1028,7 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     const size_t o_edges = blob.add(edges), o_lm_start = blob.add(lm_start), o_lm_edges = blob.add(lm_edges), o_lm_nmono = blob.add(lm_nmono),
                  o_pose_start = blob.add(pose_start), o_pose_edges = blob.add(pose_edges), o_fixed = blob.add(g->fixed);
     const size_t o_active = blob.add(std::vector<uint8_t>((size_t)std::max(ne, 1), (uint8_t)1));
-    const size_t o_lm_tmp = blob.reserve_bytes(sizeof(double) * 3 * (size_t)n_pt);
+    const size_t o_lm_tmp = blob.reserve_bytes(sizeof(double) * 4 * (size_t)n_pt);
     size_t o_pair_ab = 0, o_slot_pose = 0;
     const size_t o_slot_of_pose = blob.add(g->slot);   // keyframe -> block of the reduced system or -1 (k_pose_update, k_edge_table)
     // the landmark of every entry of pose_edges: k_schur_pairs walks a keyframe's observations without touching the 48-byte edge records
@@ -1005,21 +1176,31 @@ ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_
                        g->d_fail);
     OVS_LAUNCH_TRY("k_lm_prepare");
     if (g->n_free > 0) {
-        hipLaunchKernelGGL(k_schur_pairs, dim3(g->n_pairs), dim3(256), 0, s, g->d_pose_start, g->d_pose_edges, g->d_pose_pt, g->d_pair_ab,
-                           g->d_slot_pose, g->d_edge_of, g->n_pt, d_Hpp, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S);
-        OVS_LAUNCH_TRY("k_schur_pairs");
-        hipLaunchKernelGGL(k_schur_rhs, dim3(g->n_free), dim3(256), 0, s, v, g->d_slot_pose, d_bp, d_bl, g->d_Y, g->d_rhs);
-        OVS_LAUNCH_TRY("k_schur_rhs");
+        hipLaunchKernelGGL(k_schur, dim3(g->n_free + g->n_pairs), dim3(256), 0, s, v, g->n_free, g->d_pose_pt, g->d_pair_ab, g->d_slot_pose,
+                           g->d_edge_of, d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs);
+        OVS_LAUNCH_TRY("k_schur");
     }
     return OVS_OK;
 }
 
+// host-solver path: the keyframes' increments were uploaded to d_dxp (six per keyframe). The landmarks' gain-ratio terms stay in d_lm_tmp[3 n_pt ..):
+// the linearisation of the trial state (ba_graph_linearize with trial_scale) sums them into d_scal[0].
 ovs_status ba_graph_backsub(ovs_ba_graph* g, const double* d_Hpl, const double* d_bl, double lambda, const double* d_X, double* d_Xn, hipStream_t s) {
     const GraphDev v = g->view();
-    hipLaunchKernelGGL(k_backsub, dim3((g->n_pt + 127) / 128), dim3(128), 0, s, v, g->d_Hinv, d_Hpl, d_bl, g->d_dxp, lambda, d_X, d_Xn, g->d_lm_tmp);
+    hipLaunchKernelGGL(k_backsub, dim3((g->n_pt + 255) / 256), dim3(256), 0, s, v, g->d_Hinv, d_Hpl, d_bl, g->d_dxp, lambda, d_X, d_Xn,
+                       g->d_lm_tmp + 3 * (size_t)g->n_pt);
     OVS_LAUNCH_TRY("k_backsub");
-    hipLaunchKernelGGL(k_sum_1024, dim3(1), dim3(1024), 0, s, g->d_lm_tmp, g->n_pt, g->d_scal);
-    OVS_LAUNCH_TRY("k_sum_1024");
+    return OVS_OK;
+}
+
+// device-solver path: keyframes (T -> Tn, the 7-double records, dxp, the keyframes' gain-ratio terms in d_scal[1]) and landmarks (X -> Xn, their
+// terms in d_lm_tmp[3 n_pt ..)) of the trial state from the solution the dense solver left in d_rhs
+ovs_status ba_graph_trial_update(ovs_ba_graph* g, const double* d_T, const double* d_bp, const double* d_Hpl, const double* d_bl, double lambda,
+                                 double* d_Tn, double* d_p7n, const double* d_X, double* d_Xn, hipStream_t s) {
+    const GraphDev v = g->view();
+    hipLaunchKernelGGL(k_trial_update, dim3(1 + (g->n_pt + 255) / 256), dim3(256), 0, s, v, d_T, g->d_slot_of_pose, g->d_rhs, d_bp, lambda, d_Tn, d_p7n,
+                       g->d_dxp, g->d_scal + 1, g->d_Hinv, d_Hpl, d_bl, d_X, d_Xn, g->d_lm_tmp + 3 * (size_t)g->n_pt);
+    OVS_LAUNCH_TRY("k_trial_update");
     return OVS_OK;
 }
 
@@ -1039,8 +1220,9 @@ ovs_status ba_graph_edge_chi2(ovs_ba_graph* g, const double* d_poses, const doub
 }
 
 ovs_status ba_graph_linearize(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo, double* d_Hpp,
-                              double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror) {
-    return graph_linearize(g, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi3, s, d_chi_mirror);
+                              double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror,
+                              bool trial_scale) {
+    return graph_linearize(g, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi3, s, d_chi_mirror, trial_scale);
 }
 
 }   // namespace ovs

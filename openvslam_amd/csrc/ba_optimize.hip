@@ -4,9 +4,10 @@
 // The caller (the class shim) flattens the local map into poses / landmarks / observation edges; this file runs what
 // optimizer.optimize(num_first_iter) -> outlier levels -> optimizer.optimize(num_second_iter) does, on top of ba_graph.hip:
 //   * the state (poses as SE3Quat records, points) and both block sets (current system / trial system) live in HBM for the whole call;
-//   * one Levenberg-Marquardt trial = k_lm_prepare + k_schur_pairs + k_schur_rhs on the device, ONE 0.7 MB download (S | rhs | bp), the
-//     Cholesky of the reduced camera system on the HOST (BASELINE's north star keeps it there; at most 6 n_pose square), 2.4 KB of pose
-//     increments up, k_backsub, the SE3 update of <= 50 poses on the host, and the linearisation of the trial state (3 launches);
+//   * one Levenberg-Marquardt trial = five launches on the device (round 5: k_lm_prepare, k_schur, the dense solver of ba_solve.hip,
+//     k_trial_update, k_linearize + k_reduce_scalars) and ONE 260-byte download; with ovs_local_ba_set_solver(1) (BASELINE's north star keeps the
+//     Cholesky of the reduced camera system on the HOST; at most 6 n_pose square) a 0.7 MB download (S | rhs | bp), 2.4 KB of pose increments
+//     up, k_backsub, the SE3 update of <= 50 poses on the host, and the linearisation of the trial state;
 //   * g2o's damping schedule (ORACLE_SPEC rule 25), the chi-square outlier gates between the two rounds and the final outlier flags.
 // Round 1: 16 MB per trial crossed PCIe and the landmark elimination ran on 8 host threads (117 ms at config 5).
 #include <algorithm>
@@ -31,7 +32,10 @@ ovs_status ba_graph_backsub(ovs_ba_graph* g, const double* d_Hpl, const double* 
 ovs_status ba_graph_set_active(ovs_ba_graph* g, const uint8_t* host_mask, hipStream_t s);
 ovs_status ba_graph_edge_chi2(ovs_ba_graph* g, const double* d_poses, const double* d_points, double* d_chi, uint8_t* d_depth, hipStream_t s);
 ovs_status ba_graph_linearize(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo, double* d_Hpp,
-                              double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror = nullptr);
+                              double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror = nullptr,
+                              bool trial_scale = false);
+ovs_status ba_graph_trial_update(ovs_ba_graph* g, const double* d_T, const double* d_bp, const double* d_Hpl, const double* d_bl, double lambda,
+                                 double* d_Tn, double* d_p7n, const double* d_X, double* d_Xn, hipStream_t s);
 struct BaGraphInfo {
     int n_free;
     const int32_t* slot;        // pose -> reduced block or -1
@@ -48,8 +52,6 @@ int dense_solve_pad(int n);
 size_t dense_solve_doubles(int n);
 ovs_status launch_dense_solve(double* d_S, int n, int32_t* d_fail, hipStream_t s, unsigned long long* d_tstats = nullptr);
 ovs_status ba_graph_reset_system(ovs_ba_graph* g, hipStream_t s);
-ovs_status launch_pose_update(const double* d_T, const int32_t* d_slot_of_pose, int n_pose, const double* d_x, const double* d_bp, double lambda,
-                              double* d_Tn, double* d_p7n, double* d_dxp, double* d_scal_pose, hipStream_t s);
 // where the reduced camera system is solved: 0 = on the device (k_chol_solve), 1 = on the host (ba_host_math.h cholesky_solve)
 std::atomic<int> g_lba_solver{0};
 }   // namespace ovs
@@ -263,20 +265,17 @@ struct Lm {
                         st = ovs::launch_dense_solve(gi.d_S, n, gi.d_fail, stream);
                         if (st != OVS_OK) return st;
                     }
-                    st = ovs::launch_pose_update(d_T, gi.d_slot_of_pose, n_pose, gi.d_rhs, cur.bp, lambda, d_Tw, d_poses_w, gi.d_dxp,
-                                                 gi.d_scal + 1, stream);
-                    if (st != OVS_OK) return st;
-                    st = ovs::ba_graph_backsub(g, cur.Hpl, cur.bl, lambda, d_X, d_Xw, stream);
+                    st = ovs::ba_graph_trial_update(g, d_T, cur.bp, cur.Hpl, cur.bl, lambda, d_Tw, d_poses_w, d_X, d_Xw, stream);
                     if (st != OVS_OK) return st;
                     // the trial state's chi2 triple is mirrored next to the solver's scalars (gi.d_scal[2..4]; gi.d_fail sits 256 bytes behind
                     // gi.d_scal in the same arena): ONE 260-byte download per trial instead of three copies (round 5: two copy launches and their
                     // gaps less per trial). (One kernel writing the values straight into the page-locked block was measured in round 4 -- the
                     // system-scope flush at its end costs ~50 us per trial.)
                     st = ovs::ba_graph_linearize(g, d_poses_w, d_Xw, huber_mono(robust), huber_stereo(robust), work.Hpp, work.bp, work.Hll, work.bl,
-                                                 work.Hpl, work.chi, stream, gi.d_scal + 2);
+                                                 work.Hpl, work.chi, stream, gi.d_scal + 2, true);
                     if (st != OVS_OK) return st;
                     OVS_HIP_TRY(hipMemcpyAsync(h_blk, gi.d_scal, 256 + sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-                    OVS_HIP_TRY(hipStreamSynchronize(stream));
+                    OVS_HIP_TRY(hipStreamSynchronize(stream));   // (polling hipStreamQuery instead: the same 6.5-6.6 ms per call, round 5)
                     h_chi[0] = h_blk[2];
                     h_chi[1] = h_blk[3];
                     h_chi[2] = h_blk[4];
@@ -356,7 +355,7 @@ struct Lm {
                     st = ovs::ba_graph_backsub(g, cur.Hpl, cur.bl, lambda, d_X, d_Xn, stream);
                     if (st != OVS_OK) return st;
                     st = ovs::ba_graph_linearize(g, d_poses_n, d_Xn, huber_mono(robust), huber_stereo(robust), trial.Hpp, trial.bp, trial.Hll,
-                                                 trial.bl, trial.Hpl, trial.chi, stream);
+                                                 trial.bl, trial.Hpl, trial.chi, stream, nullptr, true);
                     if (st != OVS_OK) return st;
                     OVS_HIP_TRY(hipMemcpyAsync(h_chi, trial.chi, sizeof(double) * 3, hipMemcpyDeviceToHost, stream));
                     OVS_HIP_TRY(hipMemcpyAsync(h_chi + 4, gi.d_scal, sizeof(double), hipMemcpyDeviceToHost, stream));

@@ -1,12 +1,10 @@
 // ba_solve.hip -- the reduced camera system of local BA on the device (round 4):
 //   k_chol_solve    dense Cholesky + both substitutions of  S x = rhs  (S = 6 n_free square, symmetric positive definite after the
-//                   landmarks were eliminated: ba_graph.hip k_schur_pairs / k_schur_rhs) in ONE workgroup, the trailing updates on the
+//                   landmarks were eliminated: ba_graph.hip k_schur) in ONE workgroup, the trailing updates on the
 //                   f64 matrix cores; the trailing tiles travel through memory: systems of 289 .. 1024 unknowns;
 //   k_chol_resident (round 5) the same factorisation with the trailing tiles resident in registers / LDS: systems up to 288 unknowns
 //                   (BASELINE config 5), 168 instead of 252 us per solve; described where it is defined, below;
-//   k_pose_update   the Levenberg-Marquardt trial state of the keyframes: T <- exp(dx) T per free keyframe (g2o SE3Quat::exp as in
-//                   ba_host_math.h se3_oplus), the 7-double record the linearisation kernels read, and the keyframes' part of the gain
-//                   ratio's denominator.
+// (The keyframes' trial state -- T <- exp(dx) T -- moved to ba_graph.hip in round 5, where it shares a launch with the back-substitution.)
 // Upstream solves this system on the host (g2o BlockSolver + a dense / CSparse Cholesky inside optimizer.optimize(), expected
 // src/openvslam/optimize/local_bundle_adjuster.cc); until round 4 so did this library (ba_host_math.h cholesky_solve, still selectable:
 // ovs_local_ba_set_solver(1)). One LM trial then cost a 0.66 MB download, 0.47 ms of host arithmetic and two uploads, 15 times per call
@@ -649,112 +647,6 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_resident(double* __restr
 }
 static_assert(kMaxN % kSolveThreads == 0, "columns per thread in the backward substitution");
 
-// ---- LM trial state of the keyframes ------------------------------------------------------------------------------------------------
-namespace {
-
-__device__ void dev_rot_to_quat(const double* R, double* q) {   // ba_host_math.h rot_to_quat
-    const double tr = R[0] + R[4] + R[8];
-    if (tr > 0) {
-        double s = sqrt(tr + 1.0);
-        q[3] = 0.5 * s;
-        s = 0.5 / s;
-        q[0] = (R[7] - R[5]) * s;
-        q[1] = (R[2] - R[6]) * s;
-        q[2] = (R[3] - R[1]) * s;
-    } else {
-        int i = 0;
-        if (R[4] > R[0]) i = 1;
-        if (R[8] > R[4 * i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        double s = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
-        double qq[4];
-        qq[i] = 0.5 * s;
-        s = 0.5 / s;
-        qq[3] = (R[3 * k + j] - R[3 * j + k]) * s;
-        qq[j] = (R[3 * j + i] + R[3 * i + j]) * s;
-        qq[k] = (R[3 * k + i] + R[3 * i + k]) * s;
-        for (int a = 0; a < 4; ++a) q[a] = qq[a];
-    }
-    if (q[3] < 0)
-        for (int a = 0; a < 4; ++a) q[a] = -q[a];
-    const double nn = sqrt((q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]));
-    for (int a = 0; a < 4; ++a) q[a] /= nn;
-}
-
-__device__ void dev_se3_oplus(const double* TR, const double* Tt, const double* u, double* nR, double* nt) {   // ba_host_math.h se3_oplus
-    const double wx = u[0], wy = u[1], wz = u[2];
-    const double theta = sqrt((wx * wx + wy * wy) + wz * wz);
-    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
-    double O2[9], E[9], V[9];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) O2[3 * i + j] = (O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j]) + O[3 * i + 2] * O[6 + j];
-    const bool small = theta < 0.00001;
-    const double s = small ? 0.0 : sin(theta), c = small ? 1.0 : cos(theta);
-    for (int i = 0; i < 9; ++i) {
-        const double I = (i % 4 == 0) ? 1.0 : 0.0;
-        if (small) {
-            E[i] = (I + O[i]) + O2[i];
-            V[i] = E[i];
-        } else {
-            E[i] = (I + s / theta * O[i]) + (1 - c) / (theta * theta) * O2[i];
-            V[i] = (I + (1 - c) / (theta * theta) * O[i]) + (theta - s) / (theta * theta * theta) * O2[i];
-        }
-    }
-    for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) nR[3 * i + j] = (E[3 * i] * TR[j] + E[3 * i + 1] * TR[3 + j]) + E[3 * i + 2] * TR[6 + j];
-        const double te = (V[3 * i] * u[3] + V[3 * i + 1] * u[4]) + V[3 * i + 2] * u[5];
-        nt[i] = ((E[3 * i] * Tt[0] + E[3 * i + 1] * Tt[1]) + E[3 * i + 2] * Tt[2]) + te;
-    }
-}
-
-}   // namespace
-
-// T (12 doubles per keyframe: R row-major | t) -> Tn, the 7-double records p7n (t | quaternion x y z w), dxp (6 per keyframe, zeros for
-// fixed ones) and scal_pose = sum over free keyframes, in keyframe order, of dx . (lambda dx + bp)  (the keyframes' part of g2o's
-// computeScale; the landmarks' part comes from k_backsub)
-__global__ __launch_bounds__(256) void k_pose_update(const double* __restrict__ T, const int32_t* __restrict__ slot_of_pose, int n_pose,
-                                                    const double* __restrict__ x, const double* __restrict__ bp, double lambda,
-                                                    double* __restrict__ Tn, double* __restrict__ p7n, double* __restrict__ dxp,
-                                                    double* __restrict__ scal_pose) {
-    __shared__ double s_term[256][7];   // a keyframe's six products (and whether it is free): thread 0 adds them in keyframe order
-    double sc = 0;
-    for (int base = 0; base < n_pose; base += 256) {
-        const int k = base + (int)threadIdx.x;
-        if (k < n_pose) {
-            const int sl = slot_of_pose[k];
-            double u[6] = {0, 0, 0, 0, 0, 0};
-            double nR[9], nt[3];
-            if (sl >= 0) {
-                for (int a = 0; a < 6; ++a) u[a] = x[6 * (size_t)sl + a];
-                dev_se3_oplus(T + 12 * (size_t)k, T + 12 * (size_t)k + 9, u, nR, nt);
-            } else {
-                for (int a = 0; a < 9; ++a) nR[a] = T[12 * (size_t)k + a];
-                for (int a = 0; a < 3; ++a) nt[a] = T[12 * (size_t)k + 9 + a];
-            }
-            for (int a = 0; a < 9; ++a) Tn[12 * (size_t)k + a] = nR[a];
-            for (int a = 0; a < 3; ++a) {
-                Tn[12 * (size_t)k + 9 + a] = nt[a];
-                p7n[7 * (size_t)k + a] = nt[a];
-            }
-            dev_rot_to_quat(nR, p7n + 7 * (size_t)k + 3);
-            for (int a = 0; a < 6; ++a) {
-                dxp[6 * (size_t)k + a] = u[a];
-                s_term[threadIdx.x][a] = u[a] * (lambda * u[a] + bp[6 * (size_t)k + a]);
-            }
-            s_term[threadIdx.x][6] = sl >= 0 ? 1.0 : 0.0;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int cnt = min(256, n_pose - base);
-            for (int i = 0; i < cnt; ++i)
-                if (s_term[i][6] != 0.0)
-                    for (int a = 0; a < 6; ++a) sc += s_term[i][a];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *scal_pose = sc;
-}
-
 // largest system the one-workgroup solver stages: (n_pad + 16) x 17 + 2 n_pad doubles of LDS (and one thread per unknown)
 int dense_solve_max_n() { return kMaxN; }
 
@@ -794,13 +686,6 @@ ovs_status launch_dense_solve(double* d_S, int n, int32_t* d_fail, hipStream_t s
     }
     hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(kSolveThreads), lds, s, d_S, n_pad, dbuf, d_fail, d_tstats);
     OVS_LAUNCH_TRY("k_chol_solve");
-    return OVS_OK;
-}
-
-ovs_status launch_pose_update(const double* d_T, const int32_t* d_slot_of_pose, int n_pose, const double* d_x, const double* d_bp, double lambda,
-                              double* d_Tn, double* d_p7n, double* d_dxp, double* d_scal_pose, hipStream_t s) {
-    hipLaunchKernelGGL(k_pose_update, dim3(1), dim3(256), 0, s, d_T, d_slot_of_pose, n_pose, d_x, d_bp, lambda, d_Tn, d_p7n, d_dxp, d_scal_pose);
-    OVS_LAUNCH_TRY("k_pose_update");
     return OVS_OK;
 }
 
