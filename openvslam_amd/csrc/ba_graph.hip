@@ -802,7 +802,6 @@ struct ovs_ba_graph {
     int model = 0;
     std::vector<uint8_t> fixed;
     std::vector<int32_t> slot, slot_pose;   // pose -> reduced-system block (-1 fixed); block -> pose
-    std::vector<int32_t> edge_pose, edge_pt;
     // device: ONE allocation + ONE upload per graph (a dozen hipMalloc / hipMemcpy pairs cost more than the kernels of a whole LM trial)
     unsigned char* d_arena = nullptr;
     unsigned char* d_solver_arena = nullptr;
@@ -842,22 +841,6 @@ struct ovs_ba_graph {
 };
 
 namespace {
-
-// host image of the device arena: arrays appended at 256-byte aligned offsets, uploaded with one hipMemcpy
-struct Blob {
-    std::vector<unsigned char> bytes;
-    size_t reserve_bytes(size_t n) {
-        const size_t off = (bytes.size() + 255) & ~(size_t)255;
-        bytes.resize(off + n, 0);
-        return off;
-    }
-    template <typename T>
-    size_t add(const std::vector<T>& v) {
-        const size_t off = reserve_bytes(sizeof(T) * std::max<size_t>(v.size(), 1));
-        if (!v.empty()) std::memcpy(&bytes[off], v.data(), sizeof(T) * v.size());
-        return off;
-    }
-};
 
 // `trial_scale`: the linearisation closes a Levenberg-Marquardt trial -- the landmarks' gain-ratio terms the back-substitution left in
 // d_lm_tmp[3 n_pt ..) are summed into d_scal[0] by the same launch that sums chi2
@@ -966,53 +949,87 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
             g->slot_pose.push_back(k);
         }
     const int ne = n_mono + n_stereo;
-    std::vector<GEdge> edges((size_t)ne);
-    g->edge_pose.resize((size_t)ne);
-    g->edge_pt.resize((size_t)ne);
+    // The build's temporaries and the host image of the arena belong to the calling thread and keep their pages between calls (mapping_module
+    // builds a graph per keyframe: 13 MB of fresh vectors per call were ~3000 page faults, most of the build's 0.6 ms on the host -- round 5).
+    // The image is laid out first and filled in place: no per-array vector, no second copy.
+    struct Scratch {
+        std::vector<int32_t> edge_pose, edge_pt, fl, fp, seen;
+        std::vector<unsigned char> image;
+    };
+    static thread_local Scratch sc;
+    size_t top = 0;
+    auto place = [&top](size_t bytes) {   // 256-byte aligned offsets
+        const size_t off = (top + 255) & ~(size_t)255;
+        top = off + std::max<size_t>(bytes, 1);
+        return off;
+    };
+    const int nf = g->n_free, n_pairs = nf * (nf + 1) / 2;
+    const size_t o_edges = place(sizeof(GEdge) * (size_t)ne), o_lm_start = place(sizeof(int32_t) * ((size_t)n_pt + 1)),
+                 o_lm_edges = place(sizeof(int32_t) * (size_t)ne), o_lm_nmono = place(sizeof(int32_t) * (size_t)n_pt),
+                 o_pose_start = place(sizeof(int32_t) * ((size_t)n_pose + 1)), o_pose_edges = place(sizeof(int32_t) * (size_t)ne),
+                 o_fixed = place((size_t)n_pose), o_active = place((size_t)ne), o_slot_of_pose = place(sizeof(int32_t) * (size_t)n_pose),
+                 o_pose_pt = place(sizeof(int32_t) * (size_t)ne), o_pair_ab = place(sizeof(int32_t) * 2 * (size_t)n_pairs),
+                 o_slot_pose = place(sizeof(int32_t) * (size_t)nf);
+    const size_t upload_bytes = (top + 255) & ~(size_t)255;   // what the device reads before writing it ends here; scratch follows
+    const size_t o_lm_tmp = place(sizeof(double) * 4 * (size_t)n_pt);
+    const size_t arena_bytes = top;
+    if (sc.image.size() < upload_bytes) sc.image.resize(upload_bytes);
+    unsigned char* const img = sc.image.data();
+    GEdge* const edges = reinterpret_cast<GEdge*>(img + o_edges);
+    int32_t* const lm_start = reinterpret_cast<int32_t*>(img + o_lm_start);
+    int32_t* const lm_edges = reinterpret_cast<int32_t*>(img + o_lm_edges);
+    int32_t* const lm_nmono = reinterpret_cast<int32_t*>(img + o_lm_nmono);
+    int32_t* const pose_start = reinterpret_cast<int32_t*>(img + o_pose_start);
+    int32_t* const pose_edges = reinterpret_cast<int32_t*>(img + o_pose_edges);
+    int32_t* const pose_pt = reinterpret_cast<int32_t*>(img + o_pose_pt);
+    if (sc.edge_pose.size() < (size_t)ne) {
+        sc.edge_pose.resize((size_t)ne);
+        sc.edge_pt.resize((size_t)ne);
+    }
+    int32_t* const edge_pose = sc.edge_pose.data();
+    int32_t* const edge_pt = sc.edge_pt.data();
     for (int i = 0; i < n_mono; ++i) {
         edges[i] = GEdge{mono[i].pose_idx, mono[i].point_idx, mono[i].obs_x, mono[i].obs_y, 0.0, mono[i].inv_sigma_sq};
-        g->edge_pose[i] = mono[i].pose_idx;
-        g->edge_pt[i] = mono[i].point_idx;
+        edge_pose[i] = mono[i].pose_idx;
+        edge_pt[i] = mono[i].point_idx;
     }
     for (int i = 0; i < n_stereo; ++i) {
         edges[(size_t)n_mono + i] = GEdge{stereo[i].pose_idx, stereo[i].point_idx, stereo[i].obs_x, stereo[i].obs_y, stereo[i].obs_x_right,
                                           stereo[i].inv_sigma_sq};
-        g->edge_pose[(size_t)n_mono + i] = stereo[i].pose_idx;
-        g->edge_pt[(size_t)n_mono + i] = stereo[i].point_idx;
+        edge_pose[(size_t)n_mono + i] = stereo[i].pose_idx;
+        edge_pt[(size_t)n_mono + i] = stereo[i].point_idx;
     }
     // counting sorts: ascending edge index inside every landmark / keyframe (mono edges have the lower indices, so "mono first" is free)
-    std::vector<int32_t> lm_start((size_t)n_pt + 1, 0), lm_edges((size_t)ne), lm_nmono((size_t)n_pt, 0), pose_start((size_t)n_pose + 1, 0),
-        pose_edges((size_t)ne);
+    std::memset(lm_start, 0, sizeof(int32_t) * ((size_t)n_pt + 1));
+    std::memset(lm_nmono, 0, sizeof(int32_t) * (size_t)n_pt);
+    std::memset(pose_start, 0, sizeof(int32_t) * ((size_t)n_pose + 1));
     for (int e = 0; e < ne; ++e) {
-        ++lm_start[(size_t)g->edge_pt[e] + 1];
-        ++pose_start[(size_t)g->edge_pose[e] + 1];
-        if (e < n_mono) ++lm_nmono[g->edge_pt[e]];
+        ++lm_start[(size_t)edge_pt[e] + 1];
+        ++pose_start[(size_t)edge_pose[e] + 1];
+        if (e < n_mono) ++lm_nmono[edge_pt[e]];
     }
     for (int j = 0; j < n_pt; ++j) lm_start[(size_t)j + 1] += lm_start[j];
     for (int k = 0; k < n_pose; ++k) pose_start[(size_t)k + 1] += pose_start[k];
-    {
-        std::vector<int32_t> fl(lm_start.begin(), lm_start.end() - 1), fp(pose_start.begin(), pose_start.end() - 1);
-        for (int e = 0; e < ne; ++e) {
-            lm_edges[(size_t)fl[g->edge_pt[e]]++] = e;
-            pose_edges[(size_t)fp[g->edge_pose[e]]++] = e;
-        }
+    sc.fl.assign(lm_start, lm_start + n_pt);
+    sc.fp.assign(pose_start, pose_start + n_pose);
+    for (int e = 0; e < ne; ++e) {
+        lm_edges[(size_t)sc.fl[edge_pt[e]]++] = e;
+        pose_edges[(size_t)sc.fp[edge_pose[e]]++] = e;
     }
     // A keyframe observes a landmark at most once (upstream: landmark::add_observation ignores a second observation by the same keyframe).
     // The reduced system relies on that -- k_edge_table keeps ONE edge per (keyframe, landmark), and two edges of one free keyframe to one
     // landmark would need cross terms, while Hpp / Hll / rhs would still count both edges --, so a caller-built edge list that breaks it is refused.
-    {
-        std::vector<int32_t> seen((size_t)n_pose, -1);
-        for (int j = 0; j < n_pt; ++j)
-            for (int i = lm_start[j]; i < lm_start[(size_t)j + 1]; ++i) {
-                const int32_t k = g->edge_pose[lm_edges[i]];
-                if (seen[k] == j) {
-                    ovs::set_last_error_text("ovs_ba_graph_create: keyframe " + std::to_string(k) + " has two edges to landmark " + std::to_string(j));
-                    ovs_ba_graph_destroy(g);
-                    return OVS_ERR_INVALID;
-                }
-                seen[k] = j;
+    sc.seen.assign((size_t)n_pose, -1);
+    for (int j = 0; j < n_pt; ++j)
+        for (int i = lm_start[j]; i < lm_start[(size_t)j + 1]; ++i) {
+            const int32_t k = edge_pose[lm_edges[i]];
+            if (sc.seen[k] == j) {
+                ovs::set_last_error_text("ovs_ba_graph_create: keyframe " + std::to_string(k) + " has two edges to landmark " + std::to_string(j));
+                ovs_ba_graph_destroy(g);
+                return OVS_ERR_INVALID;
             }
-    }
+            sc.seen[k] = j;
+        }
 #define G_TRY(expr)                            \
     do {                                       \
         hipError_t _e = (expr);                \
@@ -1023,23 +1040,14 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
         }                                      \
     } while (0)
     const double t1 = now();
-    Blob blob;
-    blob.bytes.reserve((size_t)ne * 96 + (size_t)n_pt * 32 + ((size_t)1 << 16));
-    const size_t o_edges = blob.add(edges), o_lm_start = blob.add(lm_start), o_lm_edges = blob.add(lm_edges), o_lm_nmono = blob.add(lm_nmono),
-                 o_pose_start = blob.add(pose_start), o_pose_edges = blob.add(pose_edges), o_fixed = blob.add(g->fixed);
-    const size_t o_active = blob.add(std::vector<uint8_t>((size_t)std::max(ne, 1), (uint8_t)1));
-    const size_t o_lm_tmp = blob.reserve_bytes(sizeof(double) * 4 * (size_t)n_pt);
-    size_t o_pair_ab = 0, o_slot_pose = 0;
-    const size_t o_slot_of_pose = blob.add(g->slot);   // keyframe -> block of the reduced system or -1 (k_pose_update, k_edge_table)
-    // the landmark of every entry of pose_edges: k_schur_pairs walks a keyframe's observations without touching the 48-byte edge records
-    std::vector<int32_t> pose_pt((size_t)ne);
-    for (int i = 0; i < ne; ++i) pose_pt[i] = g->edge_pt[pose_edges[i]];
-    const size_t o_pose_pt = blob.add(pose_pt);
-    // reduced system: the blocks (a, b), a <= b in slot order, one wave each (which landmarks two keyframes share is found on the device)
-    if (g->n_free > 0) {
-        const int nf = g->n_free;
-        const int n_pairs = nf * (nf + 1) / 2;
-        std::vector<int32_t> pab((size_t)2 * n_pairs);
+    std::memcpy(img + o_fixed, g->fixed.data(), (size_t)n_pose);
+    std::memset(img + o_active, 1, (size_t)std::max(ne, 1));
+    std::memcpy(img + o_slot_of_pose, g->slot.data(), sizeof(int32_t) * (size_t)n_pose);   // keyframe -> block of the reduced system or -1
+    // the landmark of every entry of pose_edges: the pair blocks of k_schur walk a keyframe's observations without touching the 48-byte edge records
+    for (int i = 0; i < ne; ++i) pose_pt[i] = edge_pt[pose_edges[i]];
+    // reduced system: the blocks (a, b), a <= b in slot order, one workgroup each (which landmarks two keyframes share is found on the device)
+    if (nf > 0) {
+        int32_t* const pab = reinterpret_cast<int32_t*>(img + o_pair_ab);
         int p = 0;
         for (int a = 0; a < nf; ++a)
             for (int b = a; b < nf; ++b) {
@@ -1048,13 +1056,12 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
                 ++p;
             }
         g->n_pairs = n_pairs;
-        o_pair_ab = blob.add(pab);
-        o_slot_pose = blob.add(g->slot_pose);
+        std::memcpy(img + o_slot_pose, g->slot_pose.data(), sizeof(int32_t) * (size_t)nf);
     }
     const double t2 = now();
-    g->d_arena = g_ba_pool.take(device, blob.bytes.size(), &g->arena_cap);
+    g->d_arena = g_ba_pool.take(device, arena_bytes, &g->arena_cap);
     G_TRY(g->d_arena ? hipSuccess : hipErrorOutOfMemory);
-    G_TRY(hipMemcpy(g->d_arena, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
+    G_TRY(hipMemcpy(g->d_arena, img, upload_bytes, hipMemcpyHostToDevice));
     unsigned char* A = g->d_arena;
     g->d_edges = reinterpret_cast<GEdge*>(A + o_edges);
     g->d_lm_start = reinterpret_cast<int32_t*>(A + o_lm_start);
@@ -1073,8 +1080,8 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     }
 #undef G_TRY
     if (trace)
-        std::fprintf(stderr, "[ovs_ba_graph_create] %.2f ms: edge records + counting sorts %.2f, blob %.2f, malloc + upload of %.1f MB %.2f\n",
-                     now() - t0, t1 - t0, t2 - t1, blob.bytes.size() / 1e6, now() - t2);
+        std::fprintf(stderr, "[ovs_ba_graph_create] %.2f ms: edge records + counting sorts %.2f, other arrays %.2f, arena + upload of %.1f MB %.2f\n",
+                     now() - t0, t1 - t0, t2 - t1, upload_bytes / 1e6, now() - t2);
     *out = g;
     return OVS_OK;
 }
@@ -1159,11 +1166,10 @@ ovs_status ba_graph_reset_system(ovs_ba_graph* g, hipStream_t s) {
     if (!g->d_S) return OVS_OK;
     const int n = 6 * std::max(g->n_free, 1), n_pad = g->s_pitch;
     OVS_HIP_TRY(hipMemsetAsync(g->d_S, 0, sizeof(double) * dense_solve_doubles(n), s));
-    const std::vector<double> ones((size_t)std::max(n_pad - n, 1), 1.0);
+    static const double ones[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};   // (n_pad - n < 16; static: the copy needs no wait here)
     if (n_pad > n)
-        OVS_HIP_TRY(hipMemcpy2DAsync(g->d_S + (size_t)n * n_pad + n, sizeof(double) * ((size_t)n_pad + 1), ones.data(), sizeof(double), sizeof(double),
+        OVS_HIP_TRY(hipMemcpy2DAsync(g->d_S + (size_t)n * n_pad + n, sizeof(double) * ((size_t)n_pad + 1), ones, sizeof(double), sizeof(double),
                                      (size_t)(n_pad - n), hipMemcpyHostToDevice, s));
-    OVS_HIP_TRY(hipStreamSynchronize(s));   // `ones` is a local
     return OVS_OK;
 }
 

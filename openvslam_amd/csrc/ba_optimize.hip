@@ -115,8 +115,8 @@ struct Lm {
     double *d_poses = nullptr, *d_poses_n = nullptr, *d_poses_w = nullptr, *d_X = nullptr, *d_Xn = nullptr, *d_Xw = nullptr, *d_echi = nullptr;
     double *d_T = nullptr, *d_Tn = nullptr, *d_Tw = nullptr;   // R | t per keyframe (12 doubles), the state k_pose_update advances
     uint8_t* d_edepth = nullptr;
-    double* h_pin = nullptr;   // pinned: S | rhs | bp | chi3 | scal | fail
-    size_t pin_doubles = 0;
+    double* h_pin = nullptr;   // pinned: S | rhs | bp | staging | chi3 | scal | fail
+    size_t pin_doubles = 0, stage_off = 0;
     unsigned char* h_edge = nullptr;   // LmScratch::h_edge
     size_t edge_cap = 0;
 
@@ -161,7 +161,9 @@ struct Lm {
         A += 3 * b_t;
         d_echi = reinterpret_cast<double*>(A);
         d_edepth = A + b_e;
-        pin_doubles = ovs::dense_solve_doubles(6 * np) + 6 * (size_t)np + 16 + 40;   // padded system | bp | chi3, scal, fail | a trial's result block (264 bytes)
+        // padded system | bp | staging of the keyframes' records (7 + 12 per keyframe) | chi3, scal, fail | a trial's result block (264 bytes)
+        stage_off = ovs::dense_solve_doubles(6 * np) + 6 * (size_t)np;
+        pin_doubles = stage_off + 19 * (size_t)np + 16 + 40;
         if (sc.pin_cap < pin_doubles) {
             if (sc.h_pin) (void)hipHostFree(sc.h_pin);
             sc.h_pin = nullptr;
@@ -196,13 +198,22 @@ struct Lm {
         }
     }
 
-    ovs_status upload_poses(const std::vector<Pose>& T, double* dst) {
+    // the 7-double records (and, for the device solver, R | t) of all keyframes through the page-locked staging area: no wait here -- the area is
+    // written again only at the start of the next round, long after the round's first stream synchronisation
+    ovs_status upload_poses(const std::vector<Pose>& T, double* dst, double* dst_rt) {
         std::vector<double> p7;
         pack_poses(T, p7);
-        double* stage = h_pin + pin_doubles - 0;   // (unused tail guard)
-        (void)stage;
-        OVS_HIP_TRY(hipMemcpyAsync(dst, p7.data(), sizeof(double) * p7.size(), hipMemcpyHostToDevice, stream));
-        OVS_HIP_TRY(hipStreamSynchronize(stream));   // p7 is a local
+        double* const st7 = h_pin + stage_off;
+        std::memcpy(st7, p7.data(), sizeof(double) * p7.size());
+        OVS_HIP_TRY(hipMemcpyAsync(dst, st7, sizeof(double) * p7.size(), hipMemcpyHostToDevice, stream));
+        if (dst_rt) {
+            double* const rt = st7 + 7 * (size_t)n_pose;
+            for (int k = 0; k < n_pose; ++k) {
+                std::memcpy(rt + (size_t)12 * k, T[k].R, sizeof(double) * 9);
+                std::memcpy(rt + (size_t)12 * k + 9, T[k].t, sizeof(double) * 3);
+            }
+            OVS_HIP_TRY(hipMemcpyAsync(dst_rt, rt, sizeof(double) * 12 * (size_t)n_pose, hipMemcpyHostToDevice, stream));
+        }
         return OVS_OK;
     }
 
@@ -216,19 +227,10 @@ struct Lm {
         if (st != OVS_OK) return st;
         const ovs::BaGraphInfo gi = ovs::ba_graph_info(g);
         const int nf = gi.n_free, n = 6 * nf;
-        st = upload_poses(T, d_poses);
-        if (st != OVS_OK) return st;
         // the reduced camera system is solved where ovs_local_ba_set_solver says; systems beyond the one-workgroup solver's LDS go to the host
         const bool dev_solve = ovs::g_lba_solver.load(std::memory_order_relaxed) == 0 && n <= ovs::dense_solve_max_n();
-        if (dev_solve) {
-            std::vector<double> rt((size_t)12 * n_pose);
-            for (int k = 0; k < n_pose; ++k) {
-                std::memcpy(&rt[(size_t)12 * k], T[k].R, sizeof(double) * 9);
-                std::memcpy(&rt[(size_t)12 * k + 9], T[k].t, sizeof(double) * 3);
-            }
-            OVS_HIP_TRY(hipMemcpyAsync(d_T, rt.data(), sizeof(double) * rt.size(), hipMemcpyHostToDevice, stream));
-            OVS_HIP_TRY(hipStreamSynchronize(stream));   // rt is a local
-        }
+        st = upload_poses(T, d_poses, dev_solve ? d_T : nullptr);
+        if (st != OVS_OK) return st;
         st = ovs::ba_graph_linearize(g, d_poses, d_X, huber_mono(robust), huber_stereo(robust), cur.Hpp, cur.bp, cur.Hll, cur.bl, cur.Hpl, cur.chi,
                                      stream);
         if (st != OVS_OK) return st;
@@ -407,7 +409,7 @@ struct Lm {
     // LM trial state when the round ended on a rejected step (g2o pops the estimate back but leaves the errors) -- and
     // edge->depth_is_positive(), which is evaluated from the vertices' current, accepted estimates (T, d_X).
     ovs_status edge_chi2(ovs_ba_graph* g, const std::vector<Pose>& T, size_t ne, int slot, const double*& chi, const uint8_t*& depth) {
-        ovs_status st = upload_poses(T, d_poses);
+        ovs_status st = upload_poses(T, d_poses, nullptr);
         if (st != OVS_OK) return st;
         double* const h_chi = reinterpret_cast<double*>(h_edge + (size_t)slot * edge_cap * 9);
         uint8_t* const h_depth = h_edge + (size_t)slot * edge_cap * 9 + edge_cap * 8;
