@@ -682,7 +682,7 @@ def bench_local_ba(world, rank, dist, torch, iters=20, n_pose=50, n_pt=20000, ob
                         % ("BASELINE configs[4]: " if (n_pose, n_pt, obs_per_pose) == (50, 20000, 2000) else "", n_pose, obs_per_pose, n_pt),
             "ms_per_linearisation": round(dt / iters * 1e3, 4), "edges_per_sec": round(n_edges * iters / dt, 1),
             "algorithmic_GBps": round(alg_bytes * iters / dt / 1e9, 2), "allreduce_bytes": (n_pt * 12 + 2) * 8 if world > 1 else 0,
-            "chi2": float(out["chi2"][0].item()), "kernels": "ovs_ba_graph: k_lin_landmark + k_lin_pose + k_reduce_scalars (no atomics, bit-reproducible)",
+            "chi2": float(out["chi2"][0].item()), "kernels": "ovs_ba_graph: k_linearize (landmark and keyframe workgroups in one launch) + k_reduce_scalars (no atomics, bit-reproducible)",
             "exchange": "ONE packed all-reduce of Hll|bl|chi2 per linearisation" if world > 1 else "none (1 rank)",
             # DESIGN.md section 5, written down before any multi-GPU node ran this: what ms_per_linearisation is expected to be at this N
             "expected_ms_per_linearisation": _expected_lba_ms(world, n_pt, dt / iters * 1e3 if world == 1 else None),
@@ -690,12 +690,12 @@ def bench_local_ba(world, rank, dist, torch, iters=20, n_pose=50, n_pt=20000, ob
 
 
 def _expected_lba_ms(world, n_pt, one_device_ms):
-    """DESIGN.md section 5's model of the sharded linearisation: compute = the one-device time / N (0.071 ms at config 5, 0.271 ms at
+    """DESIGN.md section 5's model of the sharded linearisation: compute = the one-device time / N (0.041 ms at config 5, 0.221 ms at
     local_ba_large when not measured in this run), exchange = a ring all-reduce of the packed (12 n_pt + 2) f64 buffer over xGMI: 2 (N - 1) hops
     of 5-10 us plus 2 (N - 1) / N x bytes at <= 153 GB/s per link. Returned as [low, high]; at N = 1 the measured time itself."""
     if world == 1:
         return [round(one_device_ms, 4), round(one_device_ms, 4)]
-    base = 0.071 if n_pt <= 20000 else 0.271
+    base = 0.041 if n_pt <= 20000 else 0.221
     nbytes = (n_pt * 12 + 2) * 8
     wire = 2.0 * (world - 1) / world * nbytes / 153e9 * 1e3
     return [round(base / world + 2 * (world - 1) * 0.005 + wire, 4), round(base / world + 2 * (world - 1) * 0.010 + 2.0 * wire, 4)]

@@ -329,17 +329,17 @@ __device__ __forceinline__ void lin_pose(const GraphDev& g, const int k, const d
 }
 
 // ONE launch for both halves of a linearisation (round 5: they are independent -- different outputs, the same inputs -- and each is a small
-// latency-bound grid, 50 and 79 workgroups at config 5, that ran one after the other: 28 + 24 us; side by side ~29): workgroups [0, n_pose)
-// take a keyframe each, the rest 256 landmarks each. The arithmetic of a keyframe / a landmark is what it was: the same bits.
+// latency-bound grid, 50 and 157 workgroups at config 5, that ran one after the other: 28 + 24 us; side by side ~29): workgroups [0, n_pose)
+// take a keyframe each, the rest 128 or 256 landmarks each (landmarks_per_workgroup). The arithmetic of a keyframe / a landmark is what it was: the same bits.
 __global__ __launch_bounds__(256) void k_linearize(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points, double huber_mono,
                                                   double huber_stereo, double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ Hll,
-                                                  double* __restrict__ bl, double* __restrict__ Hpl, double* __restrict__ lm_chi) {
+                                                  double* __restrict__ bl, double* __restrict__ Hpl, double* __restrict__ lm_chi, int lm_per_wg) {
     __shared__ double s_part[4][27];
     if ((int)blockIdx.x < g.n_pose) {   // (workgroup-uniform)
         lin_pose(g, (int)blockIdx.x, poses, points, huber_mono, huber_stereo, Hpp, bp, s_part);
     } else {
-        const int j = ((int)blockIdx.x - g.n_pose) * 256 + (int)threadIdx.x;
-        if (j < g.n_pt) lin_landmark(g, j, poses, points, huber_mono, huber_stereo, Hll, bl, Hpl, lm_chi);
+        const int j = ((int)blockIdx.x - g.n_pose) * lm_per_wg + (int)threadIdx.x;
+        if ((int)threadIdx.x < lm_per_wg && j < g.n_pt) lin_landmark(g, j, poses, points, huber_mono, huber_stereo, Hll, bl, Hpl, lm_chi);
     }
 }
 
@@ -616,10 +616,10 @@ __device__ __forceinline__ void backsub_landmark(const GraphDev& g, const int j,
     lm_scale[j] = sc;
 }
 
-__global__ __launch_bounds__(256) void k_backsub(GraphDev g, const double* __restrict__ Hinv, const double* __restrict__ Hpl,
+__global__ __launch_bounds__(128) void k_backsub(GraphDev g, const double* __restrict__ Hinv, const double* __restrict__ Hpl,
                                                 const double* __restrict__ bl, const double* __restrict__ dxp, double lambda,
                                                 const double* __restrict__ X, double* __restrict__ Xn, double* __restrict__ lm_scale) {
-    const int j = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int j = (int)blockIdx.x * 128 + (int)threadIdx.x;
     if (j < g.n_pt) backsub_landmark(g, j, Hinv, Hpl, bl, dxp, nullptr, lambda, X, Xn, lm_scale);
 }
 
@@ -729,21 +729,23 @@ __device__ __forceinline__ void pose_update(const double* __restrict__ T, const 
 }
 
 
-// The trial state of a Levenberg-Marquardt step in ONE launch (round 5): workgroup 0 advances the keyframes, the others back-substitute 256
-// landmarks each. The landmarks read the keyframes' increments from the solver's solution vector (slot order) instead of the dxp array the
+// The trial state of a Levenberg-Marquardt step in ONE launch (round 5): workgroup 0 advances the keyframes, the others back-substitute 128
+// or 256 landmarks each. The landmarks read the keyframes' increments from the solver's solution vector (slot order) instead of the dxp array the
 // keyframe workgroup writes, so the two halves are independent; as two launches the single keyframe workgroup held the queue for 9.5 us.
 __global__ __launch_bounds__(256) void k_trial_update(GraphDev g, const double* __restrict__ T, const int32_t* __restrict__ slot_of_pose,
                                                      const double* __restrict__ x, const double* __restrict__ bp, double lambda,
                                                      double* __restrict__ Tn, double* __restrict__ p7n, double* __restrict__ dxp,
                                                      double* __restrict__ scal_pose, const double* __restrict__ Hinv, const double* __restrict__ Hpl,
                                                      const double* __restrict__ bl, const double* __restrict__ X, double* __restrict__ Xn,
-                                                     double* __restrict__ lm_scale) {
+                                                     double* __restrict__ lm_scale, int32_t* __restrict__ next_fail, int lm_per_wg) {
     __shared__ double s_term[256][7];   // a keyframe's six products (and whether it is free): thread 0 adds them in keyframe order
     if (blockIdx.x == 0) {   // (workgroup-uniform)
+        // the NEXT trial's failure word (the two words alternate): its last reader, the host, consumed it a trial ago -- a memset launch less per trial
+        if (threadIdx.x == 0) *next_fail = 0;
         pose_update(T, slot_of_pose, g.n_pose, x, bp, lambda, Tn, p7n, dxp, scal_pose, s_term);
     } else {
-        const int j = ((int)blockIdx.x - 1) * 256 + (int)threadIdx.x;
-        if (j < g.n_pt) backsub_landmark(g, j, Hinv, Hpl, bl, x, slot_of_pose, lambda, X, Xn, lm_scale);
+        const int j = ((int)blockIdx.x - 1) * lm_per_wg + (int)threadIdx.x;   // (landmarks_per_workgroup, as in k_linearize)
+        if ((int)threadIdx.x < lm_per_wg && j < g.n_pt) backsub_landmark(g, j, Hinv, Hpl, bl, x, slot_of_pose, lambda, X, Xn, lm_scale);
     }
 }
 
@@ -842,14 +844,26 @@ struct ovs_ba_graph {
 
 namespace {
 
+// landmarks per 256-thread workgroup of k_linearize / k_trial_update: 128 (the upper two waves leave at once) while the launch then still fits the
+// chip in one go -- a landmark is a chain of dependent loads, so twice the workgroups on twice the compute units finish sooner --, 256 for larger maps
+static int landmarks_per_workgroup(int n_pose, int n_pt) {
+    static const int forced = [] {
+        const char* e = std::getenv("OVS_BA_LM_PER_WG");   // A/B switch: 128 | 256
+        return e ? std::atoi(e) : 0;
+    }();
+    if (forced == 128 || forced == 256) return forced;
+    return n_pose + (n_pt + 127) / 128 <= 512 ? 128 : 256;
+}
+
 // `trial_scale`: the linearisation closes a Levenberg-Marquardt trial -- the landmarks' gain-ratio terms the back-substitution left in
 // d_lm_tmp[3 n_pt ..) are summed into d_scal[0] by the same launch that sums chi2
 ovs_status graph_linearize(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo, double* d_Hpp,
                            double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror = nullptr,
                            bool trial_scale = false) {
     const GraphDev v = g->view();
-    hipLaunchKernelGGL(k_linearize, dim3(g->n_pose + (g->n_pt + 255) / 256), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpp,
-                       d_bp, d_Hll, d_bl, d_Hpl, g->d_lm_tmp);
+    const int lm_per_wg = landmarks_per_workgroup(g->n_pose, g->n_pt);
+    hipLaunchKernelGGL(k_linearize, dim3(g->n_pose + (g->n_pt + lm_per_wg - 1) / lm_per_wg), dim3(256), 0, s, v, d_poses, d_points, huber_mono,
+                       huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, g->d_lm_tmp, lm_per_wg);
     OVS_LAUNCH_TRY("k_linearize");
     hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(1024), 0, s, v, g->d_lm_tmp, d_Hpp, d_Hll, d_chi3, d_chi_mirror,
                        trial_scale ? g->d_lm_tmp + 3 * (size_t)g->n_pt : (const double*)nullptr, trial_scale ? g->d_scal : (double*)nullptr);
@@ -1148,6 +1162,7 @@ static ovs_status solver_workspace_create(ovs_ba_graph* g, hipStream_t s) {
     g->d_scal = reinterpret_cast<double*>(A + b_hinv + b_y + b_s + b_dxp);
     g->d_fail = reinterpret_cast<int32_t*>(A + b_hinv + b_y + b_s + b_dxp + 256);
     g->d_edge_of = reinterpret_cast<int32_t*>(A + b_hinv + b_y + b_s + b_dxp + 512);
+    OVS_HIP_TRY(hipMemsetAsync(g->d_fail, 0, 2 * sizeof(int32_t), s));   // both failure words (ba_graph_schur)
     OVS_HIP_TRY(hipMemsetAsync(g->d_edge_of, 0xff, b_tab, s));   // -1
     if (g->n_edge() > 0 && g->n_free > 0) {
         hipLaunchKernelGGL(k_edge_table, dim3((g->n_edge() + 255) / 256), dim3(256), 0, s, g->d_edges, g->n_edge(), g->d_slot_of_pose, g->n_pt, g->d_edge_of);
@@ -1174,12 +1189,14 @@ ovs_status ba_graph_reset_system(ovs_ba_graph* g, hipStream_t s) {
 }
 
 // (H + lambda I) dx = b, landmarks eliminated on the device: S (pitch g->s_pitch) and rhs at g->d_S.
+// `fail_word`: 0 / 1 -- which of the two failure words (d_fail[0..1]) this trial reports in; `clear_first`: zero it by a memset here (the host-solver
+// path; the device-solver path has k_trial_update clear the other word for the next trial, and both words at the start of a round)
 ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_bp, const double* d_Hll, const double* d_bl, const double* d_Hpl,
-                          double lambda, hipStream_t s) {
+                          double lambda, hipStream_t s, int fail_word, bool clear_first) {
     const GraphDev v = g->view();
-    OVS_HIP_TRY(hipMemsetAsync(g->d_fail, 0, sizeof(int32_t), s));
+    if (clear_first) OVS_HIP_TRY(hipMemsetAsync(g->d_fail + fail_word, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k_lm_prepare, dim3((std::max(g->n_pt, g->n_edge()) + 255) / 256), dim3(256), 0, s, v, d_Hll, d_Hpl, lambda, g->d_Hinv, g->d_Y,
-                       g->d_fail);
+                       g->d_fail + fail_word);
     OVS_LAUNCH_TRY("k_lm_prepare");
     if (g->n_free > 0) {
         hipLaunchKernelGGL(k_schur, dim3(g->n_free + g->n_pairs), dim3(256), 0, s, v, g->n_free, g->d_pose_pt, g->d_pair_ab, g->d_slot_pose,
@@ -1193,7 +1210,7 @@ ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_
 // the linearisation of the trial state (ba_graph_linearize with trial_scale) sums them into d_scal[0].
 ovs_status ba_graph_backsub(ovs_ba_graph* g, const double* d_Hpl, const double* d_bl, double lambda, const double* d_X, double* d_Xn, hipStream_t s) {
     const GraphDev v = g->view();
-    hipLaunchKernelGGL(k_backsub, dim3((g->n_pt + 255) / 256), dim3(256), 0, s, v, g->d_Hinv, d_Hpl, d_bl, g->d_dxp, lambda, d_X, d_Xn,
+    hipLaunchKernelGGL(k_backsub, dim3((g->n_pt + 127) / 128), dim3(128), 0, s, v, g->d_Hinv, d_Hpl, d_bl, g->d_dxp, lambda, d_X, d_Xn,
                        g->d_lm_tmp + 3 * (size_t)g->n_pt);
     OVS_LAUNCH_TRY("k_backsub");
     return OVS_OK;
@@ -1202,10 +1219,11 @@ ovs_status ba_graph_backsub(ovs_ba_graph* g, const double* d_Hpl, const double* 
 // device-solver path: keyframes (T -> Tn, the 7-double records, dxp, the keyframes' gain-ratio terms in d_scal[1]) and landmarks (X -> Xn, their
 // terms in d_lm_tmp[3 n_pt ..)) of the trial state from the solution the dense solver left in d_rhs
 ovs_status ba_graph_trial_update(ovs_ba_graph* g, const double* d_T, const double* d_bp, const double* d_Hpl, const double* d_bl, double lambda,
-                                 double* d_Tn, double* d_p7n, const double* d_X, double* d_Xn, hipStream_t s) {
+                                 double* d_Tn, double* d_p7n, const double* d_X, double* d_Xn, hipStream_t s, int next_fail_word) {
     const GraphDev v = g->view();
-    hipLaunchKernelGGL(k_trial_update, dim3(1 + (g->n_pt + 255) / 256), dim3(256), 0, s, v, d_T, g->d_slot_of_pose, g->d_rhs, d_bp, lambda, d_Tn, d_p7n,
-                       g->d_dxp, g->d_scal + 1, g->d_Hinv, d_Hpl, d_bl, d_X, d_Xn, g->d_lm_tmp + 3 * (size_t)g->n_pt);
+    const int lm_per_wg = landmarks_per_workgroup(g->n_pose, g->n_pt);
+    hipLaunchKernelGGL(k_trial_update, dim3(1 + (g->n_pt + lm_per_wg - 1) / lm_per_wg), dim3(256), 0, s, v, d_T, g->d_slot_of_pose, g->d_rhs, d_bp, lambda, d_Tn, d_p7n,
+                       g->d_dxp, g->d_scal + 1, g->d_Hinv, d_Hpl, d_bl, d_X, d_Xn, g->d_lm_tmp + 3 * (size_t)g->n_pt, g->d_fail + next_fail_word, lm_per_wg);
     OVS_LAUNCH_TRY("k_trial_update");
     return OVS_OK;
 }

@@ -27,7 +27,7 @@ namespace ovs {
 // ba_graph.hip
 ovs_status ba_graph_ensure_solver(ovs_ba_graph* g, hipStream_t s);
 ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_bp, const double* d_Hll, const double* d_bl, const double* d_Hpl,
-                          double lambda, hipStream_t s);
+                          double lambda, hipStream_t s, int fail_word, bool clear_first);
 ovs_status ba_graph_backsub(ovs_ba_graph* g, const double* d_Hpl, const double* d_bl, double lambda, const double* d_X, double* d_Xn, hipStream_t s);
 ovs_status ba_graph_set_active(ovs_ba_graph* g, const uint8_t* host_mask, hipStream_t s);
 ovs_status ba_graph_edge_chi2(ovs_ba_graph* g, const double* d_poses, const double* d_points, double* d_chi, uint8_t* d_depth, hipStream_t s);
@@ -35,7 +35,7 @@ ovs_status ba_graph_linearize(ovs_ba_graph* g, const double* d_poses, const doub
                               double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror = nullptr,
                               bool trial_scale = false);
 ovs_status ba_graph_trial_update(ovs_ba_graph* g, const double* d_T, const double* d_bp, const double* d_Hpl, const double* d_bl, double lambda,
-                                 double* d_Tn, double* d_p7n, const double* d_X, double* d_Xn, hipStream_t s);
+                                 double* d_Tn, double* d_p7n, const double* d_X, double* d_Xn, hipStream_t s, int next_fail_word);
 struct BaGraphInfo {
     int n_free;
     const int32_t* slot;        // pose -> reduced block or -1
@@ -257,17 +257,18 @@ struct Lm {
             do {
                 const double t0 = now();
                 ++n_trials;
-                st = ovs::ba_graph_schur(g, cur.Hpp, cur.bp, cur.Hll, cur.bl, cur.Hpl, lambda, stream);
+                const int fw = dev_solve ? (n_trials & 1) : 0;   // the device solver's trials alternate between two failure words
+                st = ovs::ba_graph_schur(g, cur.Hpp, cur.bp, cur.Hll, cur.bl, cur.Hpl, lambda, stream, fw, !dev_solve);
                 if (st != OVS_OK) return st;
                 int32_t* h_fail = reinterpret_cast<int32_t*>(h_chi + 8);
                 if (dev_solve) {
                     // ---- the whole trial on the device: solve, keyframe / landmark updates, linearisation at the trial state (into the
                     //      `work` set: a failed solve must leave the last evaluated trial state, which edge_chi2 may still need, untouched)
                     if (n > 0) {
-                        st = ovs::launch_dense_solve(gi.d_S, n, gi.d_fail, stream);
+                        st = ovs::launch_dense_solve(gi.d_S, n, gi.d_fail + fw, stream);
                         if (st != OVS_OK) return st;
                     }
-                    st = ovs::ba_graph_trial_update(g, d_T, cur.bp, cur.Hpl, cur.bl, lambda, d_Tw, d_poses_w, d_X, d_Xw, stream);
+                    st = ovs::ba_graph_trial_update(g, d_T, cur.bp, cur.Hpl, cur.bl, lambda, d_Tw, d_poses_w, d_X, d_Xw, stream, fw ^ 1);
                     if (st != OVS_OK) return st;
                     // the trial state's chi2 triple is mirrored next to the solver's scalars (gi.d_scal[2..4]; gi.d_fail sits 256 bytes behind
                     // gi.d_scal in the same arena): ONE 260-byte download per trial instead of three copies (round 5: two copy launches and their
@@ -276,14 +277,14 @@ struct Lm {
                     st = ovs::ba_graph_linearize(g, d_poses_w, d_Xw, huber_mono(robust), huber_stereo(robust), work.Hpp, work.bp, work.Hll, work.bl,
                                                  work.Hpl, work.chi, stream, gi.d_scal + 2, true);
                     if (st != OVS_OK) return st;
-                    OVS_HIP_TRY(hipMemcpyAsync(h_blk, gi.d_scal, 256 + sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                    OVS_HIP_TRY(hipMemcpyAsync(h_blk, gi.d_scal, 256 + 2 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
                     OVS_HIP_TRY(hipStreamSynchronize(stream));   // (polling hipStreamQuery instead: the same 6.5-6.6 ms per call, round 5)
                     h_chi[0] = h_blk[2];
                     h_chi[1] = h_blk[3];
                     h_chi[2] = h_blk[4];
                     h_chi[4] = h_blk[0];
                     h_chi[5] = h_blk[1];
-                    *h_fail = *reinterpret_cast<const int32_t*>(reinterpret_cast<const unsigned char*>(h_blk) + 256);
+                    *h_fail = reinterpret_cast<const int32_t*>(reinterpret_cast<const unsigned char*>(h_blk) + 256)[fw];
                     const bool ok = *h_fail == 0;
                     double temp_chi = 1.7976931348623157e308, scale = 1e-3;
                     if (!ok) {   // a failed factorisation may have left non-finite values in the padding, which no later trial rewrites
