@@ -428,6 +428,43 @@ def test_dense_solve_matches_numpy(n):
 
 
 @pytest.mark.gpu
+def test_landmark_workgroup_shapes_give_the_same_bits(tmp_path):
+    """k_linearize / k_trial_update give a workgroup 128 landmarks while the launch fits the chip in one go and 256 beyond (maps of more than ~59 k
+    landmarks: no other test is that large). The shape must not change a bit: a child process with OVS_BA_LM_PER_WG=256 (read once per process)
+    against this process (128 at these sizes) on one linearisation and on a whole ovs_local_ba_optimize, stereo edges included."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+from oracle import lba
+from openvslam_amd import ba
+from test_ba import _lba_scene
+d, mono, st, bf, _, _ = _lba_scene(21, n_pose=12, n_pt=3000, obs_per_pose=700, stereo_frac=0.35)
+g = ba.graph(len(d["poses"]), d["pose_fixed"], len(d["points"]), mono, d["cam"], st, bf)
+out = g.linearize_dev(torch.from_numpy(d["poses"]).cuda(), torch.from_numpy(d["points"]).cuda(), lba.SQRT_CHI2_MONO, lba.SQRT_CHI2_STEREO)
+torch.cuda.synchronize()
+res = {"lin_" + k: t.cpu().numpy() for k, t in ba.graph.views(out, g.n_pose, g.n_pt, g.n_edge).items()}
+r = ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], mono, d["cam"], st, bf)
+res.update({"opt_" + k: np.asarray(v) for k, v in r.items()})
+np.savez(sys.argv[1], **res)
+"""
+    outs = {}
+    for tag, env in (("auto", {}), ("w256", {"OVS_BA_LM_PER_WG": "256"}), ("w128", {"OVS_BA_LM_PER_WG": "128"})):
+        out = tmp_path / ("%s.npz" % tag)
+        r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests")), str(out)], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = dict(np.load(out))
+    assert len(outs["auto"]) >= 10 and outs["auto"]["opt_info"][4] >= 3
+    for tag in ("w256", "w128"):
+        for k, v in outs["auto"].items():
+            assert np.array_equal(v, outs[tag][k]), (tag, k)
+
+
+@pytest.mark.gpu
 def test_resident_and_through_memory_solvers_agree(tmp_path):
     """k_chol_resident (default up to 288 unknowns) against k_chol_solve (OVS_CHOL_RESIDENT=0, a process-wide switch: run in a child process) on the
     same systems: the two differ in the order of the fused multiply-adds only (~cond x 1e-16 relative); the phase-timed instantiation
