@@ -21,7 +21,9 @@ pmc)
 tie)
   timeout 600 python tools/tie_fuzz_gpu.py 300 > gpurun_out/${tag}_tie_fuzz.txt 2>&1; echo "tie fuzz rc=$?"; tail -8 gpurun_out/${tag}_tie_fuzz.txt ;;
 fuzz)
-  timeout 900 python tools/fuzz_parity.py --seeds 3 > gpurun_out/${tag}_fuzz.txt 2>&1; echo "fuzz rc=$?"; tail -8 gpurun_out/${tag}_fuzz.txt ;;
+  for seed in 5201 5202; do
+    timeout 600 python tools/fuzz_parity.py --cases 120 --seed $seed > gpurun_out/${tag}_fuzz_${seed}.txt 2>&1; echo "fuzz seed $seed rc=$? $(tail -1 gpurun_out/${tag}_fuzz_${seed}.txt | cut -c1-200)"
+  done ;;
 lba)
   timeout 300 python tools/time_lba.py device 6 2>&1 | tail -3
   OVS_BA_TRACE=1 timeout 120 python tools/chol_trace.py 2>&1 | grep "dense solve" | tee gpurun_out/${tag}_chol_phases.txt
