@@ -3,8 +3,8 @@
 cd /root/repo
 mkdir -p gpurun_out
 : > gpurun_out/schedule_sweep.txt
-for args in "" "--match-first 1" "--chains 2" "--pipeline 2" "--fast-split 0" "--batch 512" "--overlap 0"; do
-  python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-ba $args 2>/dev/null | python -c "
+for args in "" "--chains 2" "--pipeline 2" "--pipeline 4" "--chains 2 --batch 512" ""; do
+  python bench.py --steps 24 --warmup 3 --no-cpu-baseline --no-ba --live-pmc 0 $args 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('%-28s value %.1f M/s  ms_per_step %.3f  frames/step %d  match stages in schedule %.2f + %.2f ms' % ('$args', d['value']/1e6, d['ms_per_step'], d['config']['frames_per_step_per_gpu'], d['stage_ms_per_step']['match_near'], d['stage_ms_per_step']['match_resolve']))" >> gpurun_out/schedule_sweep.txt 2>&1
