@@ -610,6 +610,418 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 #undef FAST_MARK
 }
 
+// ================================================================================================================================
+// v5 (round 6): the WAVE-AUTONOMOUS form. One wavefront owns one cell from its tile to its survivors: no s_barrier anywhere, no other wave
+// to wait for, and the "cell empty -> again with min_fast_thr" decision is a wave-uniform branch. What changed against v4 and why
+// (DESIGN.md section 3.1): v4's cell was a latency chain of six workgroup barriers, four partially filled scoring / suppression passes (one
+// per wave, whatever the candidate count) and an 8 x 5-word window re-read from LDS by every thread (2.5 words per pixel).
+//   * pre-test: lane (band, g) = (lane >> 4, lane & 15) walks DOWN the 16 rows of its band of the cell for the 4-pixel column group g with
+//     a rolling register window: every tile row is read ONCE per band (0.69 words per pixel), converted to the 6-bit form R in registers (no R
+//     tile, no conversion pass), and its centre-aligned word serves three pixel rows (as ring point 8, centre, ring point 0). The loop is
+//     fully unrolled: the window rotates by register renaming.
+//   * the pre-test bits of 16 rows x 4 pixels are collected in two registers per polarity (bit 7 of a byte shifted in per row) and compacted
+//     ONCE per cell into one list (wave prefix sum by DPP, no atomics);
+//   * exact scoring and the 8-neighbour suppression run in passes of 64 candidates, all lanes busy whatever the cell's candidate count;
+//     survivors are compacted by ballot / mbcnt in place over the list;
+//   * the wave requests its next tile by LDS-DMA when its last tile read is behind it, buffers the survivors of its cells and reserves
+//     list space once per group, as v4 did per workgroup.
+// LDS per wave: tile 5.6 KB + score map 4.75 KB + list 2 KB + group buffer 0.5 KB = 12.9 KB.
+constexpr int kWListCap = 1024;      // candidates of a cell in the list; a denser cell (noise at a low threshold) is scored exhaustively instead
+constexpr int kWBufCap = 128;        // survivors of the wave's cells waiting for their list reservation
+constexpr int kWMaxCells = 64;       // the cell index inside the group is a 6-bit field of a buffered survivor
+
+template <bool kTiming>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fast_wave(
+    const FrameGeo* __restrict__ geo, const CellDesc* __restrict__ cell_tab, const uint8_t* __restrict__ img0, size_t stride0, size_t frame_stride0,
+    const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes, uint64_t* __restrict__ cand, size_t cand_frame_entries, uint32_t* __restrict__ cand_count,
+    const uint8_t* __restrict__ mask, int batch, uint32_t batch_magic, int cell_lo, int n_cells, int cells_per_wave, unsigned long long* __restrict__ tstats) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[kTileRowsMax][kTileWords];
+    __shared__ __attribute__((aligned(16))) uint32_t smap[kSmapRows][kSmapWords];
+    __shared__ __attribute__((aligned(16))) uint16_t clist[kWListCap];   // (flags << 12) | (y << 6) | x; the suppression's survivors in place (y << 6 | x)
+    __shared__ uint32_t wbuf[kWBufCap];                                 // (slot << 26) | (score << 12) | (y << 6) | x
+
+    const int lane = threadIdx.x;
+    const int L = geo->num_levels;
+    unsigned long long t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+#define WMARK(i)                                       \
+    if (kTiming) {                                     \
+        const unsigned long long t_now = clock64();    \
+        t_acc[i] += t_now - t_prev;                    \
+        t_prev = t_now;                                \
+    }
+    if (kTiming) t_prev = clock64();
+    // work order as in v4: a wave takes `cells_per_wave` consecutive cells of one frame; XCD k takes the k-th contiguous eighth of the groups,
+    // the frame index runs fastest inside an XCD's share
+    const int n_groups = (n_cells + cells_per_wave - 1) / cells_per_wave;
+    const int per_xcd = (n_groups + 7) >> 3;
+    const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+    const int slot = batch == 1 ? idx : (int)__umulhi((uint32_t)idx, batch_magic), frame = idx - slot * batch;
+    const int group = xcd * per_xcd + slot;
+    if (slot >= per_xcd || group >= n_groups) return;
+    const int cell_first = cell_lo + group * cells_per_wave;
+    const int n_here = min(cells_per_wave, cell_lo + n_cells - cell_first);
+
+    auto level_ref = [&](int level) -> LevelRef {
+        const LevelGeo& g = geo->lv[level];
+        LevelRef r;
+        r.level = level;
+        if (level == 0) {
+            r.img = img0 + (size_t)frame * frame_stride0;
+            r.pitch = (int)stride0;
+        } else {
+            r.img = pyr + (size_t)frame * pyr_frame_bytes + g.plane_off;
+            r.pitch = g.pitch;
+        }
+        r.vec16 = ((r.pitch & 15) == 0) && ((reinterpret_cast<uintptr_t>(r.img) & 15) == 0);
+        r.cand_off = g.cand_off;
+        r.cand_cap = g.cand_cap;
+        r.scale = g.scale;
+        return r;
+    };
+    // the wave's chunks of a tile: chunk 64 * j + lane = (row, column chunk), j < 6 (350 chunks of 16 bytes); byte offsets from the tile's
+    // origin in the current level's plane, recomputed at a level boundary only
+    uint32_t voff[6];
+    auto chunk_offsets = [&](const LevelRef& lv) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int i = 64 * j + lane, r = (i * 0x3334) >> 16, q = i - 5 * r;
+            voff[j] = (uint32_t)(r * lv.pitch + 16 * q);
+        }
+    };
+    const uint32_t lds_tile0 = lds_addr(&tile[0][0]);
+    // tile byte u of row r <-> image (min_x - 3 + u, min_y + r). Rows >= ch and chunks at or beyond the plane's pitch are NOT copied: those
+    // bytes keep what an earlier cell left and only feed pixels outside the testable area, which the `valid` masks remove.
+    auto issue_tile = [&](const LevelRef& lv, uint32_t rec_x, uint32_t rec_y) {
+        const int min_x = (int)(rec_x & 0xffffu), min_y = (int)(rec_x >> 16), cw = (int)(rec_y & 255u), ch = (int)((rec_y >> 8) & 255u);
+        const int gx = min_x - 3;
+        const uint8_t* const base = lv.img + (size_t)min_y * (size_t)lv.pitch + (size_t)gx;
+        if (lv.vec16) {
+            if (cw == kTileRowsMax && ch == kTileRowsMax) {   // a whole cell: every chunk lies inside the plane (gx + 73 <= cols <= pitch)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) glds16(base, voff[j], lds_tile0 + 1024u * (uint32_t)j);
+                if (lane < kChunks - 320) glds16(base, voff[5], lds_tile0 + 5120u);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int i = 64 * j + lane, r = (i * 0x3334) >> 16, q = i - 5 * r;
+                    if (i < kChunks && r < ch && gx + 16 * q < lv.pitch) glds16(base, voff[j], lds_tile0 + 1024u * (uint32_t)j);
+                }
+            }
+        } else {   // 4-byte aligned base / pitch (enforced by the ABI): 1400 words, 64 per wave-instruction
+            for (int j = 0; j < 22; ++j) {
+                const int i = 64 * j + lane;
+                const int r = (i * 0x0ccd) >> 16, c4 = i - 20 * r;   // i / 20 for i < 1536
+                if (i < kTileRowsMax * kTileWords && r < ch && gx + 4 * c4 + 4 <= lv.pitch)
+                    glds4(base, (uint32_t)(r * lv.pitch + 4 * c4), lds_tile0 + 256u * (uint32_t)j);
+            }
+        }
+    };
+
+    const int band = lane >> 4, g = lane & 15;
+    const uint8_t* const tbytes = reinterpret_cast<const uint8_t*>(&tile[0][0]);
+    uint8_t* const sbytes = reinterpret_cast<uint8_t*>(&smap[0][0]);
+    const uint32_t* const trow = &tile[16 * band][g];   // the lane's words g .. g + 3 of its band's 22 tile rows
+    const uint8_t* const fmask = mask ? mask + (size_t)frame * frame_stride0 : nullptr;
+    const int ini_thr = geo->ini_thr, min_thr = geo->min_thr;
+    constexpr int kP = kTileWords * 4, kS = kSmapWords * 4;
+
+    const uint2 d0 = reinterpret_cast<const uint2*>(cell_tab)[cell_first];
+    uint32_t dn_x = d0.x, dn_y = d0.y;
+    LevelRef lr_next = level_ref((int)((dn_y >> 16) & 255u));
+    chunk_offsets(lr_next);
+    issue_tile(lr_next, dn_x, dn_y);
+    LevelRef lr_buf = lr_next;   // level of the survivors waiting in wbuf
+    uint32_t n_buf = 0;          // wave-uniform
+
+    auto flush = [&](const LevelRef& lv) {
+        const uint32_t nb = n_buf;
+        if (nb != 0) {
+            uint32_t b0 = 0;
+            if (lane == 0) b0 = atomicAdd(&cand_count[frame * L + lv.level], nb);
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+            uint64_t* const list = cand + (size_t)frame * cand_frame_entries + lv.cand_off;
+            const uint32_t cap = (uint32_t)lv.cand_cap;
+            for (uint32_t i = lane; i < nb; i += 64) {
+                const uint32_t e = wbuf[i];
+                const uint2 dsc = reinterpret_cast<const uint2*>(cell_tab)[cell_first + (int)(e >> 26)];
+                const uint32_t x = (dsc.x & 0xffffu) + 3u + (e & 63u), y = (dsc.x >> 16) + 3u + ((e >> 6) & 63u), sc = (e >> 12) & 255u;
+                if (base + i < cap) list[base + i] = cand_pack(x, y, sc - 1u, 0);
+            }
+            n_buf = 0;
+        }
+    };
+
+    for (int k = 0; k < n_here; ++k) {
+        WMARK(0)   // previous cell's tail
+        const uint32_t dc_x = dn_x, dc_y = dn_y;
+        const LevelRef lr = lr_next;
+        const int min_x = (int)(dc_x & 0xffffu), min_y = (int)(dc_x >> 16);
+        const int cw = (int)(dc_y & 255u), ch = (int)((dc_y >> 8) & 255u);
+        const int iw = cw - 6, ih = ch - 6;   // testable area (> 0 for every valid cell)
+        const float scale = lr.scale;
+        // score map: zero everywhere a candidate is not scored (such pixels have S <= thr)
+        for (int i = lane; i < kSmapRows * kSmapWords / 4; i += 64) reinterpret_cast<uint4*>(&smap[0][0])[i] = uint4{0u, 0u, 0u, 0u};
+        bool skip = false;
+        if (fmask) {   // upstream: skip the cell if one of its corners is masked (level-0 coordinates, float scale, trunc)
+            auto in_mask = [&](unsigned y, unsigned x) {
+                return fmask[(size_t)(unsigned)(y * scale) * stride0 + (unsigned)(x * scale)] == 0;
+            };
+            skip = in_mask(min_y, min_x) || in_mask(min_y + ch, min_x) || in_mask(min_y, min_x + cw) || in_mask(min_y + ch, min_x + cw);
+        }
+        // valid-pixel masks of the lane's two 8-row blocks: bit t of byte b <-> pixel (4 g + b, 16 band + 8 blk + t)
+        uint32_t valid0 = 0xffffffffu, valid1 = 0xffffffffu;
+        if (iw < kCellSize || ih < kCellSize) {
+            asm volatile("" ::: "memory");
+            uint32_t colm = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) colm |= (4 * g + b < iw) ? (0xffu << (8 * b)) : 0u;
+            const int n0 = min(8, max(0, ih - 16 * band)), n1 = min(8, max(0, ih - 16 * band - 8));
+            valid0 = colm & (((1u << n0) - 1u) * 0x01010101u);
+            valid1 = colm & (((1u << n1) - 1u) * 0x01010101u);
+        }
+        wait_tile();   // this wave's own copies: nobody else reads or writes this tile
+        WMARK(1)   // clear + tile wait
+
+        uint32_t n_out = 0;   // wave-uniform: suppression survivors of this cell (olist = clist in place)
+        if (!skip) {
+            int thr = ini_thr;
+            for (;;) {
+                // ---- 1. four-diameter test on R = (p >> 2) | 0x80, four pixels per register, rolling down the band's rows
+                uint32_t ab0 = 0, ab1 = 0, ad0 = 0, ad1 = 0;   // bright / dark pre-test bits of the two 8-row blocks
+                {
+                    const uint32_t kk = 0x80808080u - (uint32_t)((thr + 1) >> 2) * 0x01010101u;
+                    constexpr uint32_t kM = 0x80808080u;
+                    uint32_t cen[22], l2[22], r2[22], l3[22], r3[22];
+                    // the rows' words are requested kAhead steps before they are used (a step is ~45 vector instructions: the LDS latency is
+                    // covered twice); the scheduling barriers keep hipcc from hoisting all 76 reads (and their 100 registers) to the top
+                    constexpr int kAhead = 2;
+                    uint32_t raw[22][4];
+                    auto request = [&](int rr) {
+                        const uint2 m = *reinterpret_cast<const uint2*>(trow + rr * kTileWords + 1);   // ds_read2_b32: any 4-byte alignment
+                        raw[rr][1] = m.x;
+                        raw[rr][2] = m.y;
+                        if (rr >= 3 && rr < 19) {   // rows that are a pixel row's centre row
+                            raw[rr][0] = trow[rr * kTileWords];
+                            raw[rr][3] = trow[rr * kTileWords + 3];
+                        }
+                    };
+#pragma unroll
+                    for (int rr = 0; rr < kAhead; ++rr) request(rr);
+#pragma unroll
+                    for (int rr = 0; rr < 22; ++rr) {
+                        if (rr + kAhead < 22) request(rr + kAhead);
+                        // pixel group at tile bytes 4 g + 6 .. 4 g + 9: words g + 1 (bytes 2, 3) and g + 2 (bytes 0, 1)
+                        const uint32_t w1 = to_r6(raw[rr][1]), w2 = to_r6(raw[rr][2]);
+                        l2[rr] = w1;                                      // x - 2 .. x + 1
+                        r2[rr] = w2;                                      // x + 2 .. x + 5
+                        cen[rr] = __builtin_amdgcn_alignbyte(w2, w1, 2);   // x .. x + 3
+                        if (rr >= 3 && rr < 19) {
+                            const uint32_t w0 = to_r6(raw[rr][0]), w3 = to_r6(raw[rr][3]);
+                            l3[rr] = __builtin_amdgcn_alignbyte(w1, w0, 3);   // x - 3
+                            r3[rr] = __builtin_amdgcn_alignbyte(w3, w2, 1);   // x + 3
+                        }
+                        if (rr >= 6) {
+                            const int j = rr - 6;   // pixel row of the band: centre = tile row j + 3
+                            const uint32_t c = cen[j + 3];
+                            const uint32_t cb = c - kk, cd = c + kk;
+                            const uint32_t p0 = cen[j + 6], p8 = cen[j], p4 = r3[j + 3], p12 = l3[j + 3];
+                            const uint32_t p2 = r2[j + 5], p14 = l2[j + 5], p6 = r2[j + 1], p10 = l2[j + 1];
+                            const uint32_t bright = and_or3(and_or3(and_or3((p0 - cb) | (p8 - cb), p2 - cb, p10 - cb), p4 - cb, p12 - cb), p6 - cb, p14 - cb);
+                            const uint32_t dark = and_or3(and_or3(and_or3((cd - p0) | (cd - p8), cd - p2, cd - p10), cd - p4, cd - p12), cd - p6, cd - p14);
+                            if (j < 8) {
+                                ab0 = (ab0 >> 1) | (bright & kM);
+                                ad0 = (ad0 >> 1) | (dark & kM);
+                            } else {
+                                ab1 = (ab1 >> 1) | (bright & kM);
+                                ad1 = (ad1 >> 1) | (dark & kM);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                WMARK(2)   // diameter test
+                // ---- 2. one list per cell: exclusive prefix of the lanes' counts, entries (flags << 12) | (y << 6) | x
+                //      flags: 1 = evaluate the dark polarity (the bright test failed), 2 = both tests passed (evaluate both)
+                uint32_t cm0 = (ab0 | ad0) & valid0, cm1 = (ab1 | ad1) & valid1;
+                const uint32_t n_mine = (uint32_t)(__popc(cm0) + __popc(cm1));
+                const uint32_t incl = wave_prefix_incl(n_mine);
+                const int n_cand = __builtin_amdgcn_readlane((int)incl, 63);
+                if (n_cand <= kWListCap) {
+                    uint32_t pos = incl - n_mine;
+                    const uint32_t ebase = ((uint32_t)(16 * band) << 6) | (uint32_t)(4 * g);
+                    while (cm0) {
+                        const int b = __ffs(cm0) - 1;
+                        cm0 &= cm0 - 1;
+                        const uint32_t dk = (ad0 >> b) & 1u, br = (ab0 >> b) & 1u;
+                        clist[pos++] = (uint16_t)((ebase + (((uint32_t)b & 7u) << 6) + ((uint32_t)b >> 3)) | ((dk & ~br) << 12) | ((dk & br) << 13));
+                    }
+                    while (cm1) {
+                        const int b = __ffs(cm1) - 1;
+                        cm1 &= cm1 - 1;
+                        const uint32_t dk = (ad1 >> b) & 1u, br = (ab1 >> b) & 1u;
+                        clist[pos++] = (uint16_t)((ebase + (8u << 6) + (((uint32_t)b & 7u) << 6) + ((uint32_t)b >> 3)) | ((dk & ~br) << 12) | ((dk & br) << 13));
+                    }
+                }
+                WMARK(3)   // prefix + list writes
+                if (n_cand > kWListCap) {
+                    // Dense cell (white noise at a low threshold): more candidates than the list holds. Every lane scores ITS 64 pixels
+                    // exhaustively, both polarities, and suppresses them itself. A pixel the pre-test rejected has S <= thr, so the complete
+                    // score map gives the same survivors as the sparse one (whose unscored pixels read 0).
+                    for (int blk = 0; blk < 2; ++blk)
+                        for (uint32_t m = blk ? valid1 : valid0; m;) {
+                            const int b = __ffs(m) - 1;
+                            m &= m - 1;
+                            const int x = 4 * g + (b >> 3), y = 16 * band + 8 * blk + (b & 7);
+                            uint32_t r[16], c;
+                            load_ring(tbytes + y * kP + x + 3, r, c);
+                            uint32_t sc = fast_strength_bright(r, c);
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) r[q] ^= 0xffu;
+                            sc = mx16(sc, fast_strength_bright(r, c ^ 0xffu));
+                            sbytes[(y + 1) * kS + 4 + x] = (uint8_t)sc;
+                        }
+                    for (int blk = 0; blk < 2; ++blk)
+                        for (uint32_t m = blk ? valid1 : valid0; __builtin_amdgcn_ballot_w64(m != 0) != 0;) {   // wave-uniform trip count: ballots inside
+                            const bool on = m != 0;
+                            const int b = on ? __ffs(m) - 1 : 0;
+                            m &= m - 1;
+                            const int x = 4 * g + (b >> 3), y = 16 * band + 8 * blk + (b & 7);
+                            const uint8_t* q = sbytes + (y + 1) * kS + 4 + x;
+                            const uint32_t sc = q[0];
+                            const uint32_t nb = mx16(mx16(mx16((uint32_t)q[-kS - 1], (uint32_t)q[-kS]), mx16((uint32_t)q[-kS + 1], (uint32_t)q[-1])),
+                                                     mx16(mx16((uint32_t)q[1], (uint32_t)q[kS - 1]), mx16((uint32_t)q[kS], (uint32_t)q[kS + 1])));
+                            const bool keep = on && (int)sc > thr && sc > nb;
+                            const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+                            const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                            if (keep) clist[n_out + off] = (uint16_t)((y << 6) | x);   // survivors are pairwise non-adjacent: at most 1024
+                            n_out += (uint32_t)__popcll(bal);
+                        }
+                } else {
+                    // ---- 3. exact S for the candidates, 64 per pass, into the score map: one polarity per candidate (both where both tests passed)
+                    for (int i0 = 0; i0 < n_cand; i0 += 64) {
+                        const int i = i0 + lane;
+                        if (i < n_cand) {
+                            const uint32_t e = clist[i];
+                            const int x = e & 63, y = (e >> 6) & 63;
+                            uint32_t r[16], c;
+                            load_ring(tbytes + y * kP + x + 3, r, c);
+                            const uint32_t flip = (e & 0x1000u) ? 0xffu : 0u;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) r[q] ^= flip;
+                            c ^= flip;
+                            uint32_t sc = fast_strength_bright(r, c);
+                            if (__builtin_amdgcn_ballot_w64((e & 0x2000u) != 0) != 0) {   // rare: some lane's pixel passed both tests
+                                if (e & 0x2000u) {
+#pragma unroll
+                                    for (int q = 0; q < 16; ++q) r[q] ^= 0xffu;
+                                    sc = mx16(sc, fast_strength_bright(r, c ^ 0xffu));
+                                }
+                            }
+                            sbytes[(y + 1) * kS + 4 + x] = (uint8_t)sc;
+                        }
+                    }
+                    WMARK(4)   // exact scoring
+                    // ---- 4. strict suppression over the 8 neighbours (unevaluated neighbours have S <= thr < S(p): 0 in the map); survivors are
+                    //      compacted in place over the list (a pass writes at most as many entries as it has read)
+                    for (int i0 = 0; i0 < n_cand; i0 += 64) {
+                        const int i = i0 + lane;
+                        bool keep = false;
+                        uint32_t e = 0;
+                        if (i < n_cand) {
+                            e = clist[i] & 0x0fffu;
+                            const int x = e & 63, y = e >> 6;
+                            const uint8_t* q = sbytes + (y + 1) * kS + 4 + x;
+                            const uint32_t sc = q[0];
+                            if ((int)sc > thr) {
+                                const uint32_t nb = mx16(mx16(mx16((uint32_t)q[-kS - 1], (uint32_t)q[-kS]), mx16((uint32_t)q[-kS + 1], (uint32_t)q[-1])),
+                                                         mx16(mx16((uint32_t)q[1], (uint32_t)q[kS - 1]), mx16((uint32_t)q[kS], (uint32_t)q[kS + 1])));
+                                keep = sc > nb;
+                            }
+                        }
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+                        const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                        if (keep) clist[n_out + off] = (uint16_t)e;
+                        n_out += (uint32_t)__popcll(bal);
+                    }
+                }
+                WMARK(5)   // suppression
+                if (n_out != 0 || thr <= min_thr) break;
+                // "if keypts_in_cell.empty()": again with min_fast_thr (rare: flat cells); the tile is intact
+                thr = min_thr;
+                for (int i = lane; i < kSmapRows * kSmapWords / 4; i += 64) reinterpret_cast<uint4*>(&smap[0][0])[i] = uint4{0u, 0u, 0u, 0u};
+            }
+        }
+        // the tile's last readers (the exact scoring) are behind this wave: request the next cell's tile; it lands under the tail below and
+        // the other waves of the CU
+        if (k + 1 < n_here) {
+            const uint2 dsc = reinterpret_cast<const uint2*>(cell_tab)[cell_first + k + 1];
+            dn_x = dsc.x;
+            dn_y = dsc.y;
+            const int nl = (int)((dn_y >> 16) & 255u);
+            if (nl != lr_next.level) {
+                lr_next = level_ref(nl);
+                chunk_offsets(lr_next);
+            }
+            issue_tile(lr_next, dn_x, dn_y);
+        }
+        WMARK(6)   // next tile's request
+        // ---- 5. the cell's survivors join the wave's buffer; the (frame, level) list is reserved once per group (or when the buffer is full /
+        //      the level changes). n_out counts "keypts_in_cell" before upstream's mask filter; masked ones are dropped here. FAST response = S - 1.
+        uint32_t total = n_out;
+        if (total != 0 && fmask) {
+            uint32_t kept = 0;
+            for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                uint32_t o = 0;
+                bool keep = false;
+                if (i < total) {
+                    o = clist[i];
+                    const uint32_t gx = min_x + 3 + (o & 63u), gy = min_y + 3 + ((o >> 6) & 63u);
+                    keep = fmask[(size_t)(unsigned)(gy * scale) * stride0 + (unsigned)(gx * scale)] != 0;
+                }
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+                const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if (keep) clist[kept + off] = (uint16_t)o;   // kept + off <= i
+                kept += (uint32_t)__popcll(bal);
+            }
+            total = kept;
+        }
+        if (total != 0) {
+            if (lr.level != lr_buf.level || n_buf + total > (uint32_t)kWBufCap) flush(lr_buf);
+            lr_buf = lr;
+            if (total <= (uint32_t)kWBufCap) {
+                for (uint32_t i = lane; i < total; i += 64) {
+                    const uint32_t o = clist[i];
+                    const uint32_t sc = sbytes[((o >> 6) + 1u) * kS + 4u + (o & 63u)];
+                    wbuf[n_buf + i] = o | (sc << 12) | ((uint32_t)k << 26);
+                }
+                n_buf += total;
+            } else {
+                // more survivors than the buffer holds (a cell can have 1024): written straight from the list with their own reservation
+                uint32_t b0 = 0;
+                if (lane == 0) b0 = atomicAdd(&cand_count[frame * L + lr.level], total);
+                const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+                uint64_t* const list = cand + (size_t)frame * cand_frame_entries + lr.cand_off;
+                const uint32_t cap = (uint32_t)lr.cand_cap;
+                for (uint32_t i = lane; i < total; i += 64) {
+                    const uint32_t o = clist[i];
+                    const uint32_t sc = sbytes[((o >> 6) + 1u) * kS + 4u + (o & 63u)];
+                    if (base + i < cap) list[base + i] = cand_pack((uint32_t)(min_x + 3) + (o & 63u), (uint32_t)(min_y + 3) + (o >> 6), sc - 1u, 0);
+                }
+            }
+        }
+        WMARK(7)   // buffer / flush
+    }
+    flush(lr_buf);
+    if (kTiming && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) atomicAdd(&tstats[i], t_acc[i]);
+        atomicAdd(&tstats[12], 1ull);
+    }
+#undef WMARK
+}
+
+
 hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
                        const uint8_t* mask, int mask_rows, int batch, hipStream_t s, int cell_lo, int n_cells) {
     (void)mask_rows;
@@ -620,16 +1032,19 @@ hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t*
     // slot = idx / batch as a multiply-high: exact while idx * batch < 2^32 (idx < per_xcd * batch)
     if ((uint64_t)per_xcd * (uint64_t)batch * (uint64_t)batch >= (1ull << 32)) return hipErrorInvalidValue;
     const uint32_t batch_magic = batch > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)batch - 1) / (uint64_t)batch) : 0u;
-    // Six cells per workgroup amortise a group's set-up when the launch holds many times more cells than the chip has workgroup slots
-    // (256 CUs x 7); a tracker's single frame (~1000 cells in this launch) would leave most CUs with one workgroup walking six cells in
-    // turn -- there two per workgroup are best (measured: 1 frame 41.6 -> 22.0 us, 4 frames 59 -> 45 us, 16 frames 144 -> 132 us with three)
     const long long launch_cells = (long long)n_cells * batch;
-    const int cells_auto = (int)std::min<long long>(6, std::max<long long>(2, (launch_cells + 2800) / 5600));
-    const int cells_per_wg = tn.fast_cells > 0 ? std::min(tn.fast_cells, kMaxCellsPerWg) : cells_auto;
+    const bool wave_form = tn.fast_impl != 1;
+    // Cells per group. v4 (workgroup per cell): six consecutive cells amortise a group's set-up when the launch holds many times more cells
+    // than the chip has workgroup slots (256 CUs x 7); a tracker's single frame (~1000 cells in this launch) would leave most CUs with one
+    // workgroup walking six cells in turn -- there two per workgroup are best (measured: 1 frame 41.6 -> 22.0 us, 4 frames 59 -> 45 us,
+    // 16 frames 144 -> 132 us with three). v5 (wave per cell): 256 CUs x 12 waves are resident; a single frame's ~1700 cells are one cell each.
+    const int cells_auto = wave_form ? (int)std::min<long long>(8, std::max<long long>(1, (launch_cells + 6144) / 12288))
+                                     : (int)std::min<long long>(6, std::max<long long>(2, (launch_cells + 2800) / 5600));
+    const int cells_per_wg = tn.fast_cells > 0 ? std::min(tn.fast_cells, wave_form ? kWMaxCells : kMaxCellsPerWg) : cells_auto;
     const unsigned n_groups = ((unsigned)n_cells + (unsigned)cells_per_wg - 1) / (unsigned)cells_per_wg, gper = (n_groups + 7) / 8u;
-    const dim3 grid(8u * gper * (unsigned)batch), block(256);
+    const dim3 grid(8u * gper * (unsigned)batch), block(wave_form ? 64 : 256);
     const size_t pad_lds = (size_t)tn.fast_pad_lds;   // occupancy probe: extra dynamic LDS per workgroup (0 in production)
-    if (tn.fast_timing) {   // tuning aid: per-phase shader cycles of wave 0 of every workgroup, printed per launch
+    if (tn.fast_timing) {   // tuning aid: per-phase shader cycles (v4: of wave 0 of every workgroup; v5: of every wave), printed per launch
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxTuningDevices) return hipErrorInvalidDevice;
         static unsigned long long* d_t[kMaxTuningDevices] = {};
@@ -637,21 +1052,31 @@ hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t*
         std::lock_guard<std::mutex> lock(mu);
         if (!d_t[dev] && hipMalloc(&d_t[dev], 16 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_t[dev], 0, 16 * sizeof(unsigned long long), s);
-        hipLaunchKernelGGL((k_fast_cells<true>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
-                           d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, d_t[dev]);
+        if (wave_form)
+            hipLaunchKernelGGL((k_fast_wave<true>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
+                               d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, d_t[dev]);
+        else
+            hipLaunchKernelGGL((k_fast_cells<true>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
+                               d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, d_t[dev]);
         unsigned long long h_t[16];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h_t, d_t[dev], sizeof(h_t), hipMemcpyDeviceToHost);
-        static const char* nm[12] = {"loop", "tile-wait", "rpass+bar1", "next-issue", "pretest", "pool", "bar2", "score", "bar3", "nms", "bar4", "append+bar5"};
+        static const char* nm4[12] = {"loop", "tile-wait", "rpass+bar1", "next-issue", "pretest", "pool", "bar2", "score", "bar3", "nms", "bar4", "append+bar5"};
+        static const char* nm5[12] = {"tail", "clear+tile-wait", "pretest", "compact", "score", "suppress", "next-issue", "append", "-", "-", "-", "-"};
+        const char* const* nm = wave_form ? nm5 : nm4;
         unsigned long long tot = 0;
         for (int i = 0; i < 12; ++i) tot += h_t[i];
-        fprintf(stderr, "[k_fast_cells timing] %llu workgroups x %d cells, %.0f cycles per cell:", h_t[12], cells_per_wg,
-                (double)tot / ((double)h_t[12] * cells_per_wg + 1e-9));
-        for (int i = 0; i < 12; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)h_t[i] / (double)(tot + 1));
+        fprintf(stderr, "[%s timing] %llu %s x %d cells, %.0f cycles per cell:", wave_form ? "k_fast_wave" : "k_fast_cells", h_t[12],
+                wave_form ? "waves" : "workgroups", cells_per_wg, (double)tot / ((double)h_t[12] * cells_per_wg + 1e-9));
+        for (int i = 0; i < (wave_form ? 8 : 12); ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)h_t[i] / (double)(tot + 1));
         fprintf(stderr, "\n");
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((k_fast_cells<false>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
+    if (wave_form)
+        hipLaunchKernelGGL((k_fast_wave<false>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
+                           d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, (unsigned long long*)nullptr);
+    else
+        hipLaunchKernelGGL((k_fast_cells<false>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
                            d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, (unsigned long long*)nullptr);
     return hipGetLastError();
 }

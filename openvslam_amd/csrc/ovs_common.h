@@ -131,7 +131,8 @@ hipError_t launch_describe(const FrameGeo& hgeo, const DevBuffers& d, const uint
 // launch paths never call getenv, which is not safe against a host application's concurrent setenv. All default to the production setting.
 constexpr int kMaxTuningDevices = 16;
 struct Tuning {
-    int fast_cells;        // OVS_FAST_CELLS: consecutive cells per k_fast_cells workgroup (0 = by launch size)
+    int fast_impl;         // OVS_FAST_IMPL: 0 / unset = k_fast_wave (round 6: one wavefront per cell, no barriers), 1 = k_fast_cells (round 3-5: one workgroup per cell)
+    int fast_cells;        // OVS_FAST_CELLS: consecutive cells per FAST workgroup (0 = by launch size)
     int fast_pad_lds;      // OVS_FAST_PAD_LDS: extra dynamic LDS per k_fast_cells workgroup (occupancy probe)
     bool fast_timing;      // OVS_FAST_TIMING: per-phase cycle counts of k_fast_cells, printed per launch
     bool describe_xcd;     // OVS_DESCRIBE_XCD=0: plain frame-major order in k_describe

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 GPU calls, one parameterised script (replaces the one-off tools/gpu_r04_*.sh). Usage: tools/gpu_r05.sh <tag> <step> [<step> ...]
+# Round-6 GPU calls (same steps as round 5). Usage: tools/gpu_r06.sh <tag> <step> [<step> ...]
 # steps: pytest | bench | trace | pmc | tie | fuzz | lba | asan | area | custom:<cmd>
 cd /root/repo
 tag=$1; shift
