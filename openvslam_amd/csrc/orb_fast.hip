@@ -213,7 +213,7 @@ template <bool kTiming>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_fast_cells(
     const FrameGeo* __restrict__ geo, const CellDesc* __restrict__ cell_tab, const uint8_t* __restrict__ img0, size_t stride0, size_t frame_stride0,
     const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes, uint64_t* __restrict__ cand, size_t cand_frame_entries, uint32_t* __restrict__ cand_count,
-    const uint8_t* __restrict__ mask, int batch, uint32_t batch_magic, int cell_lo, int n_cells, int cells_per_wg, unsigned long long* __restrict__ tstats) {
+    const uint8_t* __restrict__ mask, int batch, uint32_t batch_magic, int cell_lo, int n_cells, int cells_per_wg, int group_major, unsigned long long* __restrict__ tstats) {
     __shared__ __attribute__((aligned(16))) uint32_t tiles[1][kTileRowsMax][kTileWords];
     __shared__ __attribute__((aligned(16))) uint32_t smap[kSmapRows][kSmapWords];
     __shared__ __attribute__((aligned(16))) uint32_t rtile[kTileRowsMax][kTileWords];
@@ -239,11 +239,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     // first tile's load latency are paid once per group, not once per cell). XCD-aware: XCD k takes the k-th contiguous eighth of the
     // groups, the frame index runs fastest inside an XCD's share.
     const int n_groups = (n_cells + cells_per_wg - 1) / cells_per_wg;
-    const int per_xcd = (n_groups + 7) >> 3;
     const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-    const int slot = batch == 1 ? idx : (int)__umulhi((uint32_t)idx, batch_magic), frame = idx - slot * batch;
-    const int group = xcd * per_xcd + slot;
-    if (slot >= per_xcd || group >= n_groups) return;
+    int frame, group;
+    if (group_major) {   // see k_fast_wave
+        const int share = (n_groups * batch + 7) >> 3;
+        const int gid = xcd * share + idx;
+        if (idx >= share || gid >= n_groups * batch) return;
+        frame = gid / n_groups;
+        group = gid - frame * n_groups;
+    } else {
+        const int per_xcd = (n_groups + 7) >> 3;
+        const int slot = batch == 1 ? idx : (int)__umulhi((uint32_t)idx, batch_magic);
+        frame = idx - slot * batch;
+        group = xcd * per_xcd + slot;
+        if (slot >= per_xcd || group >= n_groups) return;
+    }
     const int cell_first = cell_lo + group * cells_per_wg;
     const int n_here = min(cells_per_wg, cell_lo + n_cells - cell_first);
 
@@ -634,11 +644,11 @@ template <bool kTiming>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fast_wave(
     const FrameGeo* __restrict__ geo, const CellDesc* __restrict__ cell_tab, const uint8_t* __restrict__ img0, size_t stride0, size_t frame_stride0,
     const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes, uint64_t* __restrict__ cand, size_t cand_frame_entries, uint32_t* __restrict__ cand_count,
-    const uint8_t* __restrict__ mask, int batch, uint32_t batch_magic, int cell_lo, int n_cells, int cells_per_wave, unsigned long long* __restrict__ tstats) {
+    const uint8_t* __restrict__ mask, int batch, uint32_t batch_magic, int cell_lo, int n_cells, int cells_per_wave, int group_major, unsigned long long* __restrict__ tstats) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[kTileRowsMax][kTileWords];
     __shared__ __attribute__((aligned(16))) uint32_t smap[kSmapRows][kSmapWords];
     __shared__ __attribute__((aligned(16))) uint16_t clist[kWListCap];   // (flags << 12) | (y << 6) | x; the suppression's survivors in place (y << 6 | x)
-    __shared__ uint32_t wbuf[kWBufCap];                                 // (slot << 26) | (score << 12) | (y << 6) | x
+    __shared__ uint64_t wbuf[kWBufCap];                                 // finished candidate entries (cand_pack) waiting for their list reservation
 
     const int lane = threadIdx.x;
     const int L = geo->num_levels;
@@ -653,11 +663,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
     // work order as in v4: a wave takes `cells_per_wave` consecutive cells of one frame; XCD k takes the k-th contiguous eighth of the groups,
     // the frame index runs fastest inside an XCD's share
     const int n_groups = (n_cells + cells_per_wave - 1) / cells_per_wave;
-    const int per_xcd = (n_groups + 7) >> 3;
     const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-    const int slot = batch == 1 ? idx : (int)__umulhi((uint32_t)idx, batch_magic), frame = idx - slot * batch;
-    const int group = xcd * per_xcd + slot;
-    if (slot >= per_xcd || group >= n_groups) return;
+    int frame, group;
+    if (group_major) {
+        // XCD k takes the k-th contiguous eighth of the (frame, group) sequence, groups fastest: waves launched together read neighbouring
+        // pieces of the SAME image rows
+        const int share = (n_groups * batch + 7) >> 3;
+        const int gid = xcd * share + idx;
+        if (idx >= share || gid >= n_groups * batch) return;
+        frame = gid / n_groups;
+        group = gid - frame * n_groups;
+    } else {
+        const int per_xcd = (n_groups + 7) >> 3;
+        const int slot = batch == 1 ? idx : (int)__umulhi((uint32_t)idx, batch_magic);
+        frame = idx - slot * batch;
+        group = xcd * per_xcd + slot;
+        if (slot >= per_xcd || group >= n_groups) return;
+    }
     const int cell_first = cell_lo + group * cells_per_wave;
     const int n_here = min(cells_per_wave, cell_lo + n_cells - cell_first);
 
@@ -733,21 +755,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
     LevelRef lr_buf = lr_next;   // level of the survivors waiting in wbuf
     uint32_t n_buf = 0;          // wave-uniform
 
-    auto flush = [&](const LevelRef& lv) {
-        const uint32_t nb = n_buf;
-        if (nb != 0) {
+    // The group's buffered survivors go to their (frame, level) list with ONE reservation -- whose atomic round trip (microseconds under load) the
+    // wave does not wait for: reserve() only issues it; the entries are written by commit() behind the next cell's tile wait, whose
+    // s_waitcnt vmcnt(0) has retired the atomic by then. The buffer is not appended to in between.
+    uint32_t pend_n = 0, pend_v = 0;   // entries wbuf[0, pend_n) wait for the base lane 0 of pend_v will hold
+    LevelRef pend_lr = lr_buf;
+    auto reserve = [&]() {
+        if (n_buf != 0) {
             uint32_t b0 = 0;
-            if (lane == 0) b0 = atomicAdd(&cand_count[frame * L + lv.level], nb);
-            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
-            uint64_t* const list = cand + (size_t)frame * cand_frame_entries + lv.cand_off;
-            const uint32_t cap = (uint32_t)lv.cand_cap;
-            for (uint32_t i = lane; i < nb; i += 64) {
-                const uint32_t e = wbuf[i];
-                const uint2 dsc = reinterpret_cast<const uint2*>(cell_tab)[cell_first + (int)(e >> 26)];
-                const uint32_t x = (dsc.x & 0xffffu) + 3u + (e & 63u), y = (dsc.x >> 16) + 3u + ((e >> 6) & 63u), sc = (e >> 12) & 255u;
-                if (base + i < cap) list[base + i] = cand_pack(x, y, sc - 1u, 0);
-            }
+            if (lane == 0) b0 = atomicAdd(&cand_count[frame * L + lr_buf.level], n_buf);
+            pend_v = b0;
+            pend_n = n_buf;
+            pend_lr = lr_buf;
             n_buf = 0;
+        }
+    };
+    auto commit = [&]() {
+        const uint32_t nb = pend_n;
+        if (nb != 0) {
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend_v);
+            uint64_t* const list = cand + (size_t)frame * cand_frame_entries + pend_lr.cand_off;
+            const uint32_t cap = (uint32_t)pend_lr.cand_cap;
+            for (uint32_t i = lane; i < nb; i += 64)
+                if (base + i < cap) list[base + i] = wbuf[i];
+            pend_n = 0;
         }
     };
 
@@ -755,6 +786,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
         WMARK(0)   // previous cell's tail
         const uint32_t dc_x = dn_x, dc_y = dn_y;
         const LevelRef lr = lr_next;
+        // the next cell's record: a scalar load issued a whole cell before its use
+        const uint2 dsc_next = reinterpret_cast<const uint2*>(cell_tab)[cell_first + min(k + 1, n_here - 1)];
         const int min_x = (int)(dc_x & 0xffffu), min_y = (int)(dc_x >> 16);
         const int cw = (int)(dc_y & 255u), ch = (int)((dc_y >> 8) & 255u);
         const int iw = cw - 6, ih = ch - 6;   // testable area (> 0 for every valid cell)
@@ -781,6 +814,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
         }
         wait_tile();   // this wave's own copies: nobody else reads or writes this tile
         WMARK(1)   // clear + tile wait
+        commit();   // the previous cells' survivors: their reservation has returned
 
         uint32_t n_out = 0;   // wave-uniform: suppression survivors of this cell (olist = clist in place)
         if (!skip) {
@@ -954,9 +988,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
         // the tile's last readers (the exact scoring) are behind this wave: request the next cell's tile; it lands under the tail below and
         // the other waves of the CU
         if (k + 1 < n_here) {
-            const uint2 dsc = reinterpret_cast<const uint2*>(cell_tab)[cell_first + k + 1];
-            dn_x = dsc.x;
-            dn_y = dsc.y;
+            dn_x = dsc_next.x;
+            dn_y = dsc_next.y;
             const int nl = (int)((dn_y >> 16) & 255u);
             if (nl != lr_next.level) {
                 lr_next = level_ref(nl);
@@ -987,13 +1020,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
             total = kept;
         }
         if (total != 0) {
-            if (lr.level != lr_buf.level || n_buf + total > (uint32_t)kWBufCap) flush(lr_buf);
+            if (n_buf != 0 && (lr.level != lr_buf.level || n_buf + total > (uint32_t)kWBufCap)) {   // rare: a level boundary inside the group, a dense cell
+                reserve();
+                commit();
+            }
             lr_buf = lr;
             if (total <= (uint32_t)kWBufCap) {
                 for (uint32_t i = lane; i < total; i += 64) {
                     const uint32_t o = clist[i];
                     const uint32_t sc = sbytes[((o >> 6) + 1u) * kS + 4u + (o & 63u)];
-                    wbuf[n_buf + i] = o | (sc << 12) | ((uint32_t)k << 26);
+                    wbuf[n_buf + i] = cand_pack((uint32_t)(min_x + 3) + (o & 63u), (uint32_t)(min_y + 3) + (o >> 6), sc - 1u, 0);
                 }
                 n_buf += total;
             } else {
@@ -1010,9 +1046,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
                 }
             }
         }
+        // reserve now what the next cell's survivors might not fit beside (or what nobody will come back for); written out behind the next tile wait
+        if (n_buf > (uint32_t)(kWBufCap / 2) || k + 1 == n_here) reserve();
         WMARK(7)   // buffer / flush
     }
-    flush(lr_buf);
+    commit();
     if (kTiming && lane == 0) {
 #pragma unroll
         for (int i = 0; i < 10; ++i) atomicAdd(&tstats[i], t_acc[i]);
@@ -1054,10 +1092,10 @@ hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t*
         (void)hipMemsetAsync(d_t[dev], 0, 16 * sizeof(unsigned long long), s);
         if (wave_form)
             hipLaunchKernelGGL((k_fast_wave<true>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
-                               d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, d_t[dev]);
+                               d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, tn.fast_map, d_t[dev]);
         else
             hipLaunchKernelGGL((k_fast_cells<true>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
-                               d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, d_t[dev]);
+                               d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, tn.fast_map, d_t[dev]);
         unsigned long long h_t[16];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h_t, d_t[dev], sizeof(h_t), hipMemcpyDeviceToHost);
@@ -1074,10 +1112,10 @@ hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t*
     }
     if (wave_form)
         hipLaunchKernelGGL((k_fast_wave<false>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
-                           d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, (unsigned long long*)nullptr);
+                           d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, tn.fast_map, (unsigned long long*)nullptr);
     else
         hipLaunchKernelGGL((k_fast_cells<false>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
-                           d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, (unsigned long long*)nullptr);
+                           d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, tn.fast_map, (unsigned long long*)nullptr);
     return hipGetLastError();
 }
 

@@ -132,6 +132,7 @@ hipError_t launch_describe(const FrameGeo& hgeo, const DevBuffers& d, const uint
 constexpr int kMaxTuningDevices = 16;
 struct Tuning {
     int fast_impl;         // OVS_FAST_IMPL: 0 / unset = k_fast_wave (round 6: one wavefront per cell, no barriers), 1 = k_fast_cells (round 3-5: one workgroup per cell)
+    int fast_map;          // OVS_FAST_MAP: 1 = k_fast_wave's groups fastest inside an XCD's share (0 = frames fastest)
     int fast_cells;        // OVS_FAST_CELLS: consecutive cells per FAST workgroup (0 = by launch size)
     int fast_pad_lds;      // OVS_FAST_PAD_LDS: extra dynamic LDS per k_fast_cells workgroup (occupancy probe)
     bool fast_timing;      // OVS_FAST_TIMING: per-phase cycle counts of k_fast_cells, printed per launch
