@@ -633,22 +633,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 //     ONCE per cell into one list (wave prefix sum by DPP, no atomics);
 //   * exact scoring and the 8-neighbour suppression run in passes of 64 candidates, all lanes busy whatever the cell's candidate count;
 //     survivors are compacted by ballot / mbcnt in place over the list;
-//   * the wave requests its next tile by LDS-DMA when its last tile read is behind it, buffers the survivors of its cells and reserves
-//     list space once per group, as v4 did per workgroup.
-// LDS per wave: tile 5.6 KB + score map 4.75 KB + list 2 KB + group buffer 0.5 KB = 12.9 KB.
+//   * the kernel is bound by latency (a cell's tile comes from HBM; measured: time ~ waves per CU ^ -0.65), so a wave's LDS is kept small:
+//     the scores of the passes stay in registers until the last ring has been read, THEN the score map is built over the dead tile
+//     (8.2 KB per wave, 19 waves per CU; with a score map of its own 12.9 KB, 12 waves);
+//   * the cell's survivors get their list space by an atomic whose return the wave does not wait for (reserve / commit below).
+// Work order (both kernels, round 6): consecutive waves of an XCD take consecutive cells of the SAME frame, so the waves launched together
+// read neighbouring 64-byte pieces of the same image rows (DRAM pages, L2 lines): 13 % (v4) / 40 % (v5) faster than frames-fastest.
 constexpr int kWListCap = 1024;      // candidates of a cell in the list; a denser cell (noise at a low threshold) is scored exhaustively instead
-constexpr int kWBufCap = 128;        // survivors of the wave's cells waiting for their list reservation
-constexpr int kWMaxCells = 64;       // the cell index inside the group is a 6-bit field of a buffered survivor
+constexpr int kWBufCap = 64;         // survivors of a cell waiting for their list reservation (a cell with more reserves synchronously)
+constexpr int kWMaxCells = 64;
+
+// ring of the pixel whose 7x7 neighbourhood's top-left byte is p, rows `pitch` bytes apart (the staged tile, or the level's plane itself)
+__device__ __forceinline__ void load_ring_pitch(const uint8_t* p, int pitch, uint32_t (&r)[16], uint32_t& c) {
+    c = p[3 * pitch + 3];
+    r[0] = p[6 * pitch + 3];
+    r[1] = p[6 * pitch + 4];
+    r[2] = p[5 * pitch + 5];
+    r[3] = p[4 * pitch + 6];
+    r[4] = p[3 * pitch + 6];
+    r[5] = p[2 * pitch + 6];
+    r[6] = p[1 * pitch + 5];
+    r[7] = p[4];
+    r[8] = p[3];
+    r[9] = p[2];
+    r[10] = p[1 * pitch + 1];
+    r[11] = p[2 * pitch];
+    r[12] = p[3 * pitch];
+    r[13] = p[4 * pitch];
+    r[14] = p[5 * pitch + 1];
+    r[15] = p[6 * pitch + 2];
+}
 
 template <bool kTiming>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fast_wave(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_fast_wave(
     const FrameGeo* __restrict__ geo, const CellDesc* __restrict__ cell_tab, const uint8_t* __restrict__ img0, size_t stride0, size_t frame_stride0,
     const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes, uint64_t* __restrict__ cand, size_t cand_frame_entries, uint32_t* __restrict__ cand_count,
     const uint8_t* __restrict__ mask, int batch, uint32_t batch_magic, int cell_lo, int n_cells, int cells_per_wave, int group_major, unsigned long long* __restrict__ tstats) {
+    // the staged tile; from the moment the exact scoring has read its last ring, its first 4752 bytes are the cell's score map (66 rows x 72 bytes)
     __shared__ __attribute__((aligned(16))) uint32_t tile[kTileRowsMax][kTileWords];
-    __shared__ __attribute__((aligned(16))) uint32_t smap[kSmapRows][kSmapWords];
     __shared__ __attribute__((aligned(16))) uint16_t clist[kWListCap];   // (flags << 12) | (y << 6) | x; the suppression's survivors in place (y << 6 | x)
-    __shared__ uint64_t wbuf[kWBufCap];                                 // finished candidate entries (cand_pack) waiting for their list reservation
+    __shared__ uint8_t cscore[kWListCap];                                // S of the list's candidates until the score map exists
+    __shared__ uint64_t wbuf[kWBufCap];                                  // finished candidate entries (cand_pack) waiting for their list reservation
+    static_assert(sizeof(tile) >= kSmapRows * kSmapWords * 4, "the score map lives in the tile");
 
     const int lane = threadIdx.x;
     const int L = geo->num_levels;
@@ -660,20 +686,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
         t_prev = t_now;                                \
     }
     if (kTiming) t_prev = clock64();
-    // work order as in v4: a wave takes `cells_per_wave` consecutive cells of one frame; XCD k takes the k-th contiguous eighth of the groups,
-    // the frame index runs fastest inside an XCD's share
     const int n_groups = (n_cells + cells_per_wave - 1) / cells_per_wave;
     const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
     int frame, group;
     if (group_major) {
-        // XCD k takes the k-th contiguous eighth of the (frame, group) sequence, groups fastest: waves launched together read neighbouring
-        // pieces of the SAME image rows
+        // XCD k takes the k-th contiguous eighth of the (frame, group) sequence, groups fastest
         const int share = (n_groups * batch + 7) >> 3;
         const int gid = xcd * share + idx;
         if (idx >= share || gid >= n_groups * batch) return;
         frame = gid / n_groups;
         group = gid - frame * n_groups;
-    } else {
+    } else {   // round 3-5: XCD k takes the k-th contiguous eighth of the groups, the frame index runs fastest inside an XCD's share
         const int per_xcd = (n_groups + 7) >> 3;
         const int slot = batch == 1 ? idx : (int)__umulhi((uint32_t)idx, batch_magic);
         frame = idx - slot * batch;
@@ -712,7 +735,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
     };
     const uint32_t lds_tile0 = lds_addr(&tile[0][0]);
     // tile byte u of row r <-> image (min_x - 3 + u, min_y + r). Rows >= ch and chunks at or beyond the plane's pitch are NOT copied: those
-    // bytes keep what an earlier cell left and only feed pixels outside the testable area, which the `valid` masks remove.
+    // bytes keep what was there (an earlier cell's score map) and only feed pixels outside the testable area, which the `valid` masks remove.
     auto issue_tile = [&](const LevelRef& lv, uint32_t rec_x, uint32_t rec_y) {
         const int min_x = (int)(rec_x & 0xffffu), min_y = (int)(rec_x >> 16), cw = (int)(rec_y & 255u), ch = (int)((rec_y >> 8) & 255u);
         const int gx = min_x - 3;
@@ -741,43 +764,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
 
     const int band = lane >> 4, g = lane & 15;
     const uint8_t* const tbytes = reinterpret_cast<const uint8_t*>(&tile[0][0]);
-    uint8_t* const sbytes = reinterpret_cast<uint8_t*>(&smap[0][0]);
+    uint8_t* const sbytes = reinterpret_cast<uint8_t*>(&tile[0][0]);   // the score map: same bytes, later
     const uint32_t* const trow = &tile[16 * band][g];   // the lane's words g .. g + 3 of its band's 22 tile rows
     const uint8_t* const fmask = mask ? mask + (size_t)frame * frame_stride0 : nullptr;
     const int ini_thr = geo->ini_thr, min_thr = geo->min_thr;
     constexpr int kP = kTileWords * 4, kS = kSmapWords * 4;
+    auto clear_smap = [&]() {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int i = lane + 64 * j;
+            if (i < kSmapRows * kSmapWords / 4) reinterpret_cast<uint4*>(&tile[0][0])[i] = uint4{0u, 0u, 0u, 0u};
+        }
+    };
+    static_assert((kSmapRows * kSmapWords) % 4 == 0 && kSmapRows * kSmapWords / 4 <= 5 * 64, "score map is cleared with five 16-byte stores per lane");
 
     const uint2 d0 = reinterpret_cast<const uint2*>(cell_tab)[cell_first];
     uint32_t dn_x = d0.x, dn_y = d0.y;
     LevelRef lr_next = level_ref((int)((dn_y >> 16) & 255u));
     chunk_offsets(lr_next);
     issue_tile(lr_next, dn_x, dn_y);
-    LevelRef lr_buf = lr_next;   // level of the survivors waiting in wbuf
-    uint32_t n_buf = 0;          // wave-uniform
 
-    // The group's buffered survivors go to their (frame, level) list with ONE reservation -- whose atomic round trip (microseconds under load) the
-    // wave does not wait for: reserve() only issues it; the entries are written by commit() behind the next cell's tile wait, whose
-    // s_waitcnt vmcnt(0) has retired the atomic by then. The buffer is not appended to in between.
-    uint32_t pend_n = 0, pend_v = 0;   // entries wbuf[0, pend_n) wait for the base lane 0 of pend_v will hold
-    LevelRef pend_lr = lr_buf;
-    auto reserve = [&]() {
-        if (n_buf != 0) {
-            uint32_t b0 = 0;
-            if (lane == 0) b0 = atomicAdd(&cand_count[frame * L + lr_buf.level], n_buf);
-            pend_v = b0;
-            pend_n = n_buf;
-            pend_lr = lr_buf;
-            n_buf = 0;
-        }
+    // A cell's survivors go to their (frame, level) list with ONE reservation -- whose atomic round trip (microseconds under load) the wave does
+    // not wait for: reserve() only issues it; the entries are written by commit() behind the next cell's tile wait, whose s_waitcnt vmcnt(0)
+    // has retired the atomic by then (or at the end of the wave). The buffer is not written in between.
+    uint32_t pend_n = 0, pend_v = 0;   // entries wbuf[0, pend_n) wait for the base that lane 0 of pend_v will hold
+    int64_t pend_off = 0;
+    uint32_t pend_cap = 0;
+    auto reserve = [&](const LevelRef& lv, uint32_t n) {
+        uint32_t b0 = 0;
+        if (lane == 0) b0 = atomicAdd(&cand_count[frame * L + lv.level], n);
+        pend_v = b0;
+        pend_n = n;
+        pend_off = lv.cand_off;
+        pend_cap = (uint32_t)lv.cand_cap;
     };
     auto commit = [&]() {
         const uint32_t nb = pend_n;
         if (nb != 0) {
             const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend_v);
-            uint64_t* const list = cand + (size_t)frame * cand_frame_entries + pend_lr.cand_off;
-            const uint32_t cap = (uint32_t)pend_lr.cand_cap;
-            for (uint32_t i = lane; i < nb; i += 64)
-                if (base + i < cap) list[base + i] = wbuf[i];
+            uint64_t* const list = cand + (size_t)frame * cand_frame_entries + pend_off;
+            if ((uint32_t)lane < nb && base + (uint32_t)lane < pend_cap) list[base + (uint32_t)lane] = wbuf[lane];
             pend_n = 0;
         }
     };
@@ -792,8 +818,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
         const int cw = (int)(dc_y & 255u), ch = (int)((dc_y >> 8) & 255u);
         const int iw = cw - 6, ih = ch - 6;   // testable area (> 0 for every valid cell)
         const float scale = lr.scale;
-        // score map: zero everywhere a candidate is not scored (such pixels have S <= thr)
-        for (int i = lane; i < kSmapRows * kSmapWords / 4; i += 64) reinterpret_cast<uint4*>(&smap[0][0])[i] = uint4{0u, 0u, 0u, 0u};
         bool skip = false;
         if (fmask) {   // upstream: skip the cell if one of its corners is masked (level-0 coordinates, float scale, trunc)
             auto in_mask = [&](unsigned y, unsigned x) {
@@ -813,10 +837,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
             valid1 = colm & (((1u << n1) - 1u) * 0x01010101u);
         }
         wait_tile();   // this wave's own copies: nobody else reads or writes this tile
-        WMARK(1)   // clear + tile wait
-        commit();   // the previous cells' survivors: their reservation has returned
+        WMARK(1)   // tile wait
+        commit();   // the previous cell's survivors: their reservation has returned
 
-        uint32_t n_out = 0;   // wave-uniform: suppression survivors of this cell (olist = clist in place)
+        uint32_t n_out = 0;   // wave-uniform: suppression survivors of this cell (in place over the list)
         if (!skip) {
             int thr = ini_thr;
             for (;;) {
@@ -900,14 +924,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
                 if (n_cand > kWListCap) {
                     // Dense cell (white noise at a low threshold): more candidates than the list holds. Every lane scores ITS 64 pixels
                     // exhaustively, both polarities, and suppresses them itself. A pixel the pre-test rejected has S <= thr, so the complete
-                    // score map gives the same survivors as the sparse one (whose unscored pixels read 0).
+                    // score map gives the same survivors as the sparse one (whose unscored pixels read 0). The score map takes the tile's
+                    // place, so the rings come from the level's plane itself (slow and rare).
+                    clear_smap();
+                    const uint8_t* const org = lr.img + (size_t)min_y * (size_t)lr.pitch + (size_t)min_x;   // image byte of tile (row 0, byte 3)
                     for (int blk = 0; blk < 2; ++blk)
                         for (uint32_t m = blk ? valid1 : valid0; m;) {
                             const int b = __ffs(m) - 1;
                             m &= m - 1;
                             const int x = 4 * g + (b >> 3), y = 16 * band + 8 * blk + (b & 7);
                             uint32_t r[16], c;
-                            load_ring(tbytes + y * kP + x + 3, r, c);
+                            load_ring_pitch(org + (size_t)y * (size_t)lr.pitch + x, lr.pitch, r, c);
                             uint32_t sc = fast_strength_bright(r, c);
 #pragma unroll
                             for (int q = 0; q < 16; ++q) r[q] ^= 0xffu;
@@ -931,14 +958,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
                             n_out += (uint32_t)__popcll(bal);
                         }
                 } else {
-                    // ---- 3. exact S for the candidates, 64 per pass, into the score map: one polarity per candidate (both where both tests passed)
+                    // ---- 3. exact S for the candidates, 64 per pass: one polarity per candidate (both where both tests passed). The scores
+                    //      wait beside the list until the last ring has been read ...
                     for (int i0 = 0; i0 < n_cand; i0 += 64) {
                         const int i = i0 + lane;
                         if (i < n_cand) {
                             const uint32_t e = clist[i];
                             const int x = e & 63, y = (e >> 6) & 63;
                             uint32_t r[16], c;
-                            load_ring(tbytes + y * kP + x + 3, r, c);
+                            load_ring_pitch(tbytes + y * kP + x + 3, kP, r, c);
                             const uint32_t flip = (e & 0x1000u) ? 0xffu : 0u;
 #pragma unroll
                             for (int q = 0; q < 16; ++q) r[q] ^= flip;
@@ -951,10 +979,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
                                     sc = mx16(sc, fast_strength_bright(r, c ^ 0xffu));
                                 }
                             }
-                            sbytes[(y + 1) * kS + 4 + x] = (uint8_t)sc;
+                            cscore[i] = (uint8_t)sc;
                         }
                     }
                     WMARK(4)   // exact scoring
+                    // ... then the score map takes the tile's place: zero wherever no candidate was scored (such pixels have S <= thr)
+                    clear_smap();
+                    for (int i0 = 0; i0 < n_cand; i0 += 64) {
+                        const int i = i0 + lane;
+                        if (i < n_cand) {
+                            const uint32_t e = clist[i];
+                            sbytes[(((e >> 6) & 63u) + 1u) * kS + 4u + (e & 63u)] = cscore[i];
+                        }
+                    }
                     // ---- 4. strict suppression over the 8 neighbours (unevaluated neighbours have S <= thr < S(p): 0 in the map); survivors are
                     //      compacted in place over the list (a pass writes at most as many entries as it has read)
                     for (int i0 = 0; i0 < n_cand; i0 += 64) {
@@ -978,28 +1015,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
                         n_out += (uint32_t)__popcll(bal);
                     }
                 }
-                WMARK(5)   // suppression
+                WMARK(5)   // score map + suppression
                 if (n_out != 0 || thr <= min_thr) break;
-                // "if keypts_in_cell.empty()": again with min_fast_thr (rare: flat cells); the tile is intact
+                // "if keypts_in_cell.empty()": again with min_fast_thr (rare: flat cells). The score map has taken the tile's place: copy it again.
                 thr = min_thr;
-                for (int i = lane; i < kSmapRows * kSmapWords / 4; i += 64) reinterpret_cast<uint4*>(&smap[0][0])[i] = uint4{0u, 0u, 0u, 0u};
+                issue_tile(lr, dc_x, dc_y);
+                wait_tile();
             }
         }
-        // the tile's last readers (the exact scoring) are behind this wave: request the next cell's tile; it lands under the tail below and
-        // the other waves of the CU
-        if (k + 1 < n_here) {
-            dn_x = dsc_next.x;
-            dn_y = dsc_next.y;
-            const int nl = (int)((dn_y >> 16) & 255u);
-            if (nl != lr_next.level) {
-                lr_next = level_ref(nl);
-                chunk_offsets(lr_next);
-            }
-            issue_tile(lr_next, dn_x, dn_y);
-        }
-        WMARK(6)   // next tile's request
-        // ---- 5. the cell's survivors join the wave's buffer; the (frame, level) list is reserved once per group (or when the buffer is full /
-        //      the level changes). n_out counts "keypts_in_cell" before upstream's mask filter; masked ones are dropped here. FAST response = S - 1.
+        // ---- 5. the cell's survivors: n_out counts "keypts_in_cell" before upstream's mask filter; masked ones are dropped here. FAST response = S - 1.
         uint32_t total = n_out;
         if (total != 0 && fmask) {
             uint32_t kept = 0;
@@ -1020,20 +1044,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
             total = kept;
         }
         if (total != 0) {
-            if (n_buf != 0 && (lr.level != lr_buf.level || n_buf + total > (uint32_t)kWBufCap)) {   // rare: a level boundary inside the group, a dense cell
-                reserve();
-                commit();
-            }
-            lr_buf = lr;
             if (total <= (uint32_t)kWBufCap) {
-                for (uint32_t i = lane; i < total; i += 64) {
-                    const uint32_t o = clist[i];
+                if ((uint32_t)lane < total) {
+                    const uint32_t o = clist[lane];
                     const uint32_t sc = sbytes[((o >> 6) + 1u) * kS + 4u + (o & 63u)];
-                    wbuf[n_buf + i] = cand_pack((uint32_t)(min_x + 3) + (o & 63u), (uint32_t)(min_y + 3) + (o >> 6), sc - 1u, 0);
+                    wbuf[lane] = cand_pack((uint32_t)(min_x + 3) + (o & 63u), (uint32_t)(min_y + 3) + (o >> 6), sc - 1u, 0);
                 }
-                n_buf += total;
+                reserve(lr, total);
             } else {
-                // more survivors than the buffer holds (a cell can have 1024): written straight from the list with their own reservation
+                // more survivors than the buffer holds (a cell can have 1024): written straight from the list, waiting for their reservation
                 uint32_t b0 = 0;
                 if (lane == 0) b0 = atomicAdd(&cand_count[frame * L + lr.level], total);
                 const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
@@ -1046,9 +1065,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
                 }
             }
         }
-        // reserve now what the next cell's survivors might not fit beside (or what nobody will come back for); written out behind the next tile wait
-        if (n_buf > (uint32_t)(kWBufCap / 2) || k + 1 == n_here) reserve();
-        WMARK(7)   // buffer / flush
+        WMARK(6)   // survivors
+        // the score map's last readers are behind this wave: request the next cell's tile
+        if (k + 1 < n_here) {
+            dn_x = dsc_next.x;
+            dn_y = dsc_next.y;
+            const int nl = (int)((dn_y >> 16) & 255u);
+            if (nl != lr_next.level) {
+                lr_next = level_ref(nl);
+                chunk_offsets(lr_next);
+            }
+            issue_tile(lr_next, dn_x, dn_y);
+        }
+        WMARK(7)   // next tile's request
     }
     commit();
     if (kTiming && lane == 0) {
@@ -1058,7 +1087,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_fa
     }
 #undef WMARK
 }
-
 
 hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
                        const uint8_t* mask, int mask_rows, int batch, hipStream_t s, int cell_lo, int n_cells) {
@@ -1075,8 +1103,9 @@ hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t*
     // Cells per group. v4 (workgroup per cell): six consecutive cells amortise a group's set-up when the launch holds many times more cells
     // than the chip has workgroup slots (256 CUs x 7); a tracker's single frame (~1000 cells in this launch) would leave most CUs with one
     // workgroup walking six cells in turn -- there two per workgroup are best (measured: 1 frame 41.6 -> 22.0 us, 4 frames 59 -> 45 us,
-    // 16 frames 144 -> 132 us with three). v5 (wave per cell): 256 CUs x 12 waves are resident; a single frame's ~1700 cells are one cell each.
-    const int cells_auto = wave_form ? (int)std::min<long long>(8, std::max<long long>(1, (launch_cells + 6144) / 12288))
+    // 16 frames 144 -> 132 us with three). v5 (wave per cell): 256 CUs x 12 waves are resident; a single frame's ~1700 cells are one cell each;
+    // in a batch two cells per wave (measured 1 / 2 / 3 / 8: 0.468 / 0.467 / 0.498 / 0.598 ms per 64 frames).
+    const int cells_auto = wave_form ? (launch_cells >= 16384 ? 2 : 1)
                                      : (int)std::min<long long>(6, std::max<long long>(2, (launch_cells + 2800) / 5600));
     const int cells_per_wg = tn.fast_cells > 0 ? std::min(tn.fast_cells, wave_form ? kWMaxCells : kMaxCellsPerWg) : cells_auto;
     const unsigned n_groups = ((unsigned)n_cells + (unsigned)cells_per_wg - 1) / (unsigned)cells_per_wg, gper = (n_groups + 7) / 8u;
@@ -1100,7 +1129,7 @@ hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t*
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h_t, d_t[dev], sizeof(h_t), hipMemcpyDeviceToHost);
         static const char* nm4[12] = {"loop", "tile-wait", "rpass+bar1", "next-issue", "pretest", "pool", "bar2", "score", "bar3", "nms", "bar4", "append+bar5"};
-        static const char* nm5[12] = {"tail", "clear+tile-wait", "pretest", "compact", "score", "suppress", "next-issue", "append", "-", "-", "-", "-"};
+        static const char* nm5[12] = {"tail", "tile-wait", "pretest", "compact", "score", "map+suppress", "survivors", "next-issue", "-", "-", "-", "-"};
         const char* const* nm = wave_form ? nm5 : nm4;
         unsigned long long tot = 0;
         for (int i = 0; i < 12; ++i) tot += h_t[i];
