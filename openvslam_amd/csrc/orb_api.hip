@@ -28,8 +28,9 @@ const Tuning& tuning() {
             return e && e[0] ? std::atoi(e) : dflt;
         };
         Tuning v;
-        v.fast_impl = num("OVS_FAST_IMPL", 0);
-        v.fast_map = num("OVS_FAST_MAP", 0);
+        v.fast_impl = num("OVS_FAST_IMPL", 1);
+        v.fast_map = num("OVS_FAST_MAP", 1);
+        v.fast_pf = std::max(0, num("OVS_FAST_PF", 0));
         v.fast_cells = std::max(0, num("OVS_FAST_CELLS", 0));
         v.fast_pad_lds = std::max(0, num("OVS_FAST_PAD_LDS", 0));
         v.fast_timing = std::getenv("OVS_FAST_TIMING") != nullptr;

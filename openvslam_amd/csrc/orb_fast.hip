@@ -668,7 +668,7 @@ template <bool kTiming>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_fast_wave(
     const FrameGeo* __restrict__ geo, const CellDesc* __restrict__ cell_tab, const uint8_t* __restrict__ img0, size_t stride0, size_t frame_stride0,
     const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes, uint64_t* __restrict__ cand, size_t cand_frame_entries, uint32_t* __restrict__ cand_count,
-    const uint8_t* __restrict__ mask, int batch, uint32_t batch_magic, int cell_lo, int n_cells, int cells_per_wave, int group_major, unsigned long long* __restrict__ tstats) {
+    const uint8_t* __restrict__ mask, int batch, uint32_t batch_magic, int cell_lo, int n_cells, int cells_per_wave, int group_major, int pf_dist, unsigned long long* __restrict__ tstats) {
     // the staged tile; from the moment the exact scoring has read its last ring, its first 4752 bytes are the cell's score map (66 rows x 72 bytes)
     __shared__ __attribute__((aligned(16))) uint32_t tile[kTileRowsMax][kTileWords];
     __shared__ __attribute__((aligned(16))) uint16_t clist[kWListCap];   // (flags << 12) | (y << 6) | x; the suppression's survivors in place (y << 6 | x)
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     if (kTiming) t_prev = clock64();
     const int n_groups = (n_cells + cells_per_wave - 1) / cells_per_wave;
     const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-    int frame, group;
+    int frame, group, gid_pf = -1;
     if (group_major) {
         // XCD k takes the k-th contiguous eighth of the (frame, group) sequence, groups fastest
         const int share = (n_groups * batch + 7) >> 3;
@@ -696,6 +696,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         if (idx >= share || gid >= n_groups * batch) return;
         frame = gid / n_groups;
         group = gid - frame * n_groups;
+        const int g2 = gid + pf_dist;
+        gid_pf = (g2 < (xcd + 1) * share && g2 < n_groups * batch) ? g2 : -1;
     } else {   // round 3-5: XCD k takes the k-th contiguous eighth of the groups, the frame index runs fastest inside an XCD's share
         const int per_xcd = (n_groups + 7) >> 3;
         const int slot = batch == 1 ? idx : (int)__umulhi((uint32_t)idx, batch_magic);
@@ -706,15 +708,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const int cell_first = cell_lo + group * cells_per_wave;
     const int n_here = min(cells_per_wave, cell_lo + n_cells - cell_first);
 
-    auto level_ref = [&](int level) -> LevelRef {
+    auto level_ref_of = [&](int fr, int level) -> LevelRef {
         const LevelGeo& g = geo->lv[level];
         LevelRef r;
         r.level = level;
         if (level == 0) {
-            r.img = img0 + (size_t)frame * frame_stride0;
+            r.img = img0 + (size_t)fr * frame_stride0;
             r.pitch = (int)stride0;
         } else {
-            r.img = pyr + (size_t)frame * pyr_frame_bytes + g.plane_off;
+            r.img = pyr + (size_t)fr * pyr_frame_bytes + g.plane_off;
             r.pitch = g.pitch;
         }
         r.vec16 = ((r.pitch & 15) == 0) && ((reinterpret_cast<uintptr_t>(r.img) & 15) == 0);
@@ -723,6 +725,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         r.scale = g.scale;
         return r;
     };
+    auto level_ref = [&](int level) -> LevelRef { return level_ref_of(frame, level); };
     // the wave's chunks of a tile: chunk 64 * j + lane = (row, column chunk), j < 6 (350 chunks of 16 bytes); byte offsets from the tile's
     // origin in the current level's plane, recomputed at a level boundary only
     uint32_t voff[6];
@@ -762,6 +765,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         }
     };
 
+    // L2 prefetch for a LATER wave of this XCD: three plain loads per lane whose values nobody reads (rows 0 .. 69 x the tile's first and last
+    // word: both 128-byte lines a tile row can touch), issued BEHIND this wave's first copy so that the copy's wait can leave them in flight
+    // (loads retire in issue order: s_waitcnt vmcnt(3)). The later wave's copy then hits the XCD's L2 instead of waiting for HBM. The three
+    // registers stay allocated until the values are "used" by an empty statement at the end of the wave's first cell.
+    uint32_t pf0 = 0, pf1 = 0, pf2 = 0;
+    bool pf_behind_copy = false;
+    auto prefetch_l2 = [&](const LevelRef& lv, uint32_t rec_x, uint32_t rec_y) {
+        const int min_x = (int)(rec_x & 0xffffu), min_y = (int)(rec_x >> 16), ch = (int)((rec_y >> 8) & 255u);
+        const uint8_t* const base = lv.img + (size_t)min_y * (size_t)lv.pitch + (size_t)(min_x - 3);
+        const int ra = min(lane, ch - 1), rb = min(64 + (lane & 7), ch - 1), wb = (lane & 8) ? 76 : 0;
+        pf0 = *reinterpret_cast<const volatile uint32_t*>(base + (size_t)ra * (size_t)lv.pitch);
+        pf1 = *reinterpret_cast<const volatile uint32_t*>(base + (size_t)ra * (size_t)lv.pitch + 76);
+        pf2 = *reinterpret_cast<const volatile uint32_t*>(base + (size_t)rb * (size_t)lv.pitch + wb);
+        pf_behind_copy = true;
+    };
+
     const int band = lane >> 4, g = lane & 15;
     const uint8_t* const tbytes = reinterpret_cast<const uint8_t*>(&tile[0][0]);
     uint8_t* const sbytes = reinterpret_cast<uint8_t*>(&tile[0][0]);   // the score map: same bytes, later
@@ -783,6 +802,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     LevelRef lr_next = level_ref((int)((dn_y >> 16) & 255u));
     chunk_offsets(lr_next);
     issue_tile(lr_next, dn_x, dn_y);
+    if (pf_dist > 0 && gid_pf >= 0) {
+        // the first cell of the group `pf_dist` groups ahead in this XCD's sequence: some wave of this XCD will copy it a few microseconds from now
+        const int f2 = gid_pf / n_groups, g2 = gid_pf - f2 * n_groups;
+        const uint2 d1 = reinterpret_cast<const uint2*>(cell_tab)[cell_lo + g2 * cells_per_wave];
+        LevelRef l1 = level_ref_of(f2, (int)((d1.y >> 16) & 255u));
+        prefetch_l2(l1, d1.x, d1.y);
+    }
 
     // A cell's survivors go to their (frame, level) list with ONE reservation -- whose atomic round trip (microseconds under load) the wave does
     // not wait for: reserve() only issues it; the entries are written by commit() behind the next cell's tile wait, whose s_waitcnt vmcnt(0)
@@ -836,7 +862,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             valid0 = colm & (((1u << n0) - 1u) * 0x01010101u);
             valid1 = colm & (((1u << n1) - 1u) * 0x01010101u);
         }
-        wait_tile();   // this wave's own copies: nobody else reads or writes this tile
+        // this wave's own copies: nobody else reads or writes this tile
+        if (pf_behind_copy) {
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            pf_behind_copy = false;
+        } else {
+            wait_tile();
+        }
         WMARK(1)   // tile wait
         commit();   // the previous cell's survivors: their reservation has returned
 
@@ -1066,6 +1098,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             }
         }
         WMARK(6)   // survivors
+        asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2));   // the prefetch's registers were reserved up to here (its loads landed long ago)
         // the score map's last readers are behind this wave: request the next cell's tile
         if (k + 1 < n_here) {
             dn_x = dsc_next.x;
@@ -1099,14 +1132,12 @@ hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t*
     if ((uint64_t)per_xcd * (uint64_t)batch * (uint64_t)batch >= (1ull << 32)) return hipErrorInvalidValue;
     const uint32_t batch_magic = batch > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)batch - 1) / (uint64_t)batch) : 0u;
     const long long launch_cells = (long long)n_cells * batch;
-    const bool wave_form = tn.fast_impl != 1;
-    // Cells per group. v4 (workgroup per cell): six consecutive cells amortise a group's set-up when the launch holds many times more cells
-    // than the chip has workgroup slots (256 CUs x 7); a tracker's single frame (~1000 cells in this launch) would leave most CUs with one
-    // workgroup walking six cells in turn -- there two per workgroup are best (measured: 1 frame 41.6 -> 22.0 us, 4 frames 59 -> 45 us,
-    // 16 frames 144 -> 132 us with three). v5 (wave per cell): 256 CUs x 12 waves are resident; a single frame's ~1700 cells are one cell each;
-    // in a batch two cells per wave (measured 1 / 2 / 3 / 8: 0.468 / 0.467 / 0.498 / 0.598 ms per 64 frames).
-    const int cells_auto = wave_form ? (launch_cells >= 16384 ? 2 : 1)
-                                     : (int)std::min<long long>(6, std::max<long long>(2, (launch_cells + 2800) / 5600));
+    const bool wave_form = tn.fast_impl == 2;
+    // Cells per group. v4 (workgroup per cell): consecutive cells amortise a group's set-up and let the next tile's copy overlap the current
+    // cell's tail; with the group-major work order (round 6) short groups are best, because the waves in flight then cover a compact run of
+    // cell rows whose image lines are fetched once (measured at 256 frames, 2 / 3 / 4 / 6 cells: 1.603 / 1.600 / 1.626 / 1.66 ms; one frame:
+    // 22.1 us with two, 26.4 with one). v5 (wave per cell): one cell per wave (1 / 2 / 3 / 8: 0.452 / 0.482 / 0.526 / 0.671 ms per 64 frames).
+    const int cells_auto = wave_form ? 1 : (launch_cells >= 65536 ? 3 : 2);
     const int cells_per_wg = tn.fast_cells > 0 ? std::min(tn.fast_cells, wave_form ? kWMaxCells : kMaxCellsPerWg) : cells_auto;
     const unsigned n_groups = ((unsigned)n_cells + (unsigned)cells_per_wg - 1) / (unsigned)cells_per_wg, gper = (n_groups + 7) / 8u;
     const dim3 grid(8u * gper * (unsigned)batch), block(wave_form ? 64 : 256);
@@ -1121,7 +1152,7 @@ hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t*
         (void)hipMemsetAsync(d_t[dev], 0, 16 * sizeof(unsigned long long), s);
         if (wave_form)
             hipLaunchKernelGGL((k_fast_wave<true>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
-                               d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, tn.fast_map, d_t[dev]);
+                               d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, tn.fast_map, tn.fast_pf, d_t[dev]);
         else
             hipLaunchKernelGGL((k_fast_cells<true>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
                                d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, tn.fast_map, d_t[dev]);
@@ -1141,7 +1172,7 @@ hipError_t launch_fast(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t*
     }
     if (wave_form)
         hipLaunchKernelGGL((k_fast_wave<false>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
-                           d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, tn.fast_map, (unsigned long long*)nullptr);
+                           d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, tn.fast_map, tn.fast_pf, (unsigned long long*)nullptr);
     else
         hipLaunchKernelGGL((k_fast_cells<false>), grid, block, pad_lds, s, d.geo, d.cells, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.cand,
                            d.cand_frame_entries, d.cand_count, mask, batch, batch_magic, cell_lo, n_cells, cells_per_wg, tn.fast_map, (unsigned long long*)nullptr);

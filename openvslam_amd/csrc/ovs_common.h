@@ -131,8 +131,9 @@ hipError_t launch_describe(const FrameGeo& hgeo, const DevBuffers& d, const uint
 // launch paths never call getenv, which is not safe against a host application's concurrent setenv. All default to the production setting.
 constexpr int kMaxTuningDevices = 16;
 struct Tuning {
-    int fast_impl;         // OVS_FAST_IMPL: 0 / unset = k_fast_wave (round 6: one wavefront per cell, no barriers), 1 = k_fast_cells (round 3-5: one workgroup per cell)
-    int fast_map;          // OVS_FAST_MAP: 1 = k_fast_wave's groups fastest inside an XCD's share (0 = frames fastest)
+    int fast_impl;         // OVS_FAST_IMPL: 1 / unset = k_fast_cells (one workgroup per cell), 2 = k_fast_wave (round 6 experiment: one wavefront per cell, no barriers; same outputs, same batch time, 3x the single-frame time)
+    int fast_map;          // OVS_FAST_MAP: 1 / unset = groups fastest inside an XCD's share (round 6), 0 = frames fastest (rounds 3-5)
+    int fast_pf;           // OVS_FAST_PF: k_fast_wave's L2 prefetch distance in groups (0 = none)
     int fast_cells;        // OVS_FAST_CELLS: consecutive cells per FAST workgroup (0 = by launch size)
     int fast_pad_lds;      // OVS_FAST_PAD_LDS: extra dynamic LDS per k_fast_cells workgroup (occupancy probe)
     bool fast_timing;      // OVS_FAST_TIMING: per-phase cycle counts of k_fast_cells, printed per launch
