@@ -202,67 +202,29 @@ struct GraphDev {   // device views shared by the kernels
     const int32_t* pose_edges;
     const uint8_t* fixed;        // [n_pose]
     const uint8_t* active;       // [n_edge] 0 = the edge is at g2o level 1 (an outlier of round 1): it contributes nothing
+    // work partition of k_linearize (round 6): one lane per EDGE on both sides
+    const GEdge* ledges;         // [n_edge] the edge records in lm_edges' order (built on the device when the graph is created): a landmark
+                                 // workgroup streams its records instead of gathering 48 of every 128 bytes it fetches
+    const int32_t* lm_of_slot;   // [n_edge] landmark of every entry of lm_edges
+    const int32_t* lm_wg_first;  // [n_lm_wg + 1] first landmark of every landmark workgroup: whole landmarks, at most 256 edges and 256 landmarks
+                                 // (a landmark with more than 256 edges is a workgroup of its own)
+    const int32_t* chunk_kf;     // [n_chunks] keyframe of every chunk of kPoseChunk entries of pose_edges
+    const int32_t* chunk_start;  // [n_pose + 1] first chunk of every keyframe
+    double* pose_part;           // [n_chunks x 27] the chunks' sums of the 21 + 6 pose-block terms
+    int n_lm_wg, n_chunks;
     ovs_ba_cam cam;        // model 1: {cols, rows, -, -}
     double bf;
     int model;             // 0 perspective (mono / stereo edges), 1 equirectangular (mono edges)
 };
 
 // ---- linearisation ----------------------------------------------------------------------------------------------------------
-// landmark j by one lane
-__device__ __forceinline__ void lin_landmark(const GraphDev& g, const int j, const double* __restrict__ poses, const double* __restrict__ points,
-                                             double huber_mono, double huber_stereo, double* __restrict__ Hll, double* __restrict__ bl,
-                                             double* __restrict__ Hpl, double* __restrict__ lm_chi) {
-    const double* X = points + 3 * (size_t)j;
-    double hm[9], gm[3], hs[9], gs[3];   // mono and stereo partial sums kept apart: the oracle adds (mono total) + (stereo total)
-#pragma unroll
-    for (int i = 0; i < 9; ++i) hm[i] = hs[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) gm[i] = gs[i] = 0.0;
-    double c2m = 0, r0m = 0, c2s = 0, r0s = 0;
-    const int e0 = g.lm_start[j], e1 = g.lm_start[j + 1], nm = g.lm_nmono[j];
-    auto body = [&](const bool stereo, double (&h)[9], double (&gg)[3], double& c2a, double& r0a, int i) __attribute__((always_inline)) {
-        const int e = g.lm_edges[i];
-        if (!g.active[e]) {   // exact zeros: the sums of the remaining edges keep their order and value
-            double* hz = Hpl + 18 * (size_t)e;
-#pragma unroll
-            for (int a = 0; a < 18; ++a) hz[a] = 0.0;
-            return;
-        }
-        const GEdge ed = g.edges[e];
-        double Jl[3][6], Jp[3][6], r[3], W, c2, rho0;
-        if (g.model == 1) edge_lin_equirect(poses + 7 * (size_t)ed.pose, X, ed, g.cam, huber_mono, Jl, Jp, r, W, c2, rho0);
-        else edge_lin(poses + 7 * (size_t)ed.pose, X, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-#pragma unroll
-            for (int b = 0; b < 3; ++b) h[3 * a + b] += W * dot3(Jl, a, Jl, b, stereo);
-            double t = Jl[0][a] * r[0];
-            t = t + Jl[1][a] * r[1];
-            if (stereo) t = t + Jl[2][a] * r[2];
-            gg[a] += t;
-        }
-        const bool free_pose = !g.fixed[ed.pose];
-        double* hpl = Hpl + 18 * (size_t)e;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) hpl[3 * a + b] = free_pose ? W * dot3(Jp, a, Jl, b, stereo) : 0.0;
-        c2a += c2;
-        r0a += rho0;
-    };
-    for (int i = e0; i < e0 + nm; ++i) body(false, hm, gm, c2m, r0m, i);
-    for (int i = e0 + nm; i < e1; ++i) body(true, hs, gs, c2s, r0s, i);
-    double* H = Hll + 9 * (size_t)j;
-    double* B = bl + 3 * (size_t)j;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) H[i] = hm[i] + hs[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) B[i] = gm[i] + gs[i];
-    lm_chi[2 * (size_t)j] = c2m + c2s;
-    lm_chi[2 * (size_t)j + 1] = r0m + r0s;
-    // largest |diagonal entry| of this landmark's block (0 without edges): what k_reduce_scalars needs of Hll, 8 bytes instead of a 72-byte row
-    lm_chi[2 * (size_t)g.n_pt + j] = e1 > e0 ? fmax(fmax(fabs(hm[0] + hs[0]), fabs(hm[4] + hs[4])), fabs(hm[8] + hs[8])) : 0.0;
-}
+// Round 6: one lane per EDGE on both sides (rounds 2-5: one lane per landmark walking its edges, one workgroup per keyframe walking 256 of
+// its edges at a time -- chains of dependent gathers, 1.6 k waves for a million edges, 73 % of the wave cycles waiting). The SUMS keep their
+// order: a landmark's contributions are added in ascending edge index, mono before stereo, exactly as the sequential loop did (Hll, bl, chi2
+// partials: the same bits as rounds 2-5 and as the oracle); a keyframe's 27 terms are a fixed-shape tree per chunk of 512 edges, the chunks
+// added in ascending order by k_reduce_scalars (deterministic; not the tree of rounds 2-5: last-bit differences in Hpp / bp).
+constexpr int kPoseChunk = 512;     // entries of pose_edges per keyframe workgroup (two per thread)
+constexpr int kLmSlots = 256;       // edges per landmark workgroup
 
 // fixed-shape reduction of NV per-thread values over a 256-thread workgroup: lanes by xor-shuffle, then the four waves in order
 template <int NV>
@@ -281,25 +243,56 @@ __device__ __forceinline__ void block_sum_256(double (&v)[NV], double (*s_part)[
     __syncthreads();
 }
 
-// keyframe k by one 256-thread workgroup
-__device__ __forceinline__ void lin_pose(const GraphDev& g, const int k, const double* __restrict__ poses, const double* __restrict__ points,
-                                         double huber_mono, double huber_stereo, double* __restrict__ Hpp, double* __restrict__ bp,
-                                         double (*s_part)[27]) {
+// chunk c of keyframe k by one 256-thread workgroup: thread t takes entries t and t + 256 of the chunk, one after the other
+template <int kModel>
+__device__ __forceinline__ void lin_pose_chunk(const GraphDev& g, const int chunk, const double* __restrict__ poses, const double* __restrict__ points,
+                                               double huber_mono, double huber_stereo, double* __restrict__ Hpl, double (*s_part)[27]) {
+    const int k = g.chunk_kf[chunk];
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) acc[i] = 0.0;
-    const bool free_pose = !g.fixed[k];
-    if (free_pose) {
+    const int e1 = g.pose_start[k + 1];
+    const int i0 = g.pose_start[k] + (chunk - g.chunk_start[k]) * kPoseChunk + (int)threadIdx.x;
+    auto zero_hpl = [&](int e) {
+        double2* const h = reinterpret_cast<double2*>(Hpl + 18 * (size_t)e);
+#pragma unroll
+        for (int a = 0; a < 9; ++a) h[a] = double2{0.0, 0.0};
+    };
+    if (g.fixed[k]) {   // (workgroup-uniform) a fixed keyframe's block and its edges' Hpl are zero
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (i0 + 256 * u < e1) zero_hpl(g.pose_edges[i0 + 256 * u]);
+    } else {
         const double* P = poses + 7 * (size_t)k;
-        const int e0 = g.pose_start[k], e1 = g.pose_start[k + 1];
-        for (int i = e0 + (int)threadIdx.x; i < e1; i += 256) {
-            const int e = g.pose_edges[i];
-            if (!g.active[e]) continue;
+        // both entries' gathers (index -> record -> landmark) are issued before either edge is worked on, one after the other
+        int ee[2];
+        GEdge edd[2];
+        double XX[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) ee[u] = i0 + 256 * u < e1 ? g.pose_edges[i0 + 256 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) edd[u] = g.edges[max(ee[u], 0)];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const double* x = points + 3 * (size_t)edd[u].pt;
+            XX[u][0] = x[0];
+            XX[u][1] = x[1];
+            XX[u][2] = x[2];
+        }
+#pragma unroll 1
+        for (int u = 0; u < 2; ++u) {
+            const int e = u ? ee[1] : ee[0];
+            if (e < 0) break;
+            if (!g.active[e]) {   // exact zeros for an edge at g2o level 1
+                zero_hpl(e);
+                continue;
+            }
+            const GEdge ed = u ? edd[1] : edd[0];
+            const double X[3] = {u ? XX[1][0] : XX[0][0], u ? XX[1][1] : XX[0][1], u ? XX[1][2] : XX[0][2]};
             const bool stereo = e >= g.n_mono;
-            const GEdge ed = g.edges[e];
             double Jl[3][6], Jp[3][6], r[3], W, c2, rho0;
-            if (g.model == 1) edge_lin_equirect(P, points + 3 * (size_t)ed.pt, ed, g.cam, huber_mono, Jl, Jp, r, W, c2, rho0);
-            else edge_lin(P, points + 3 * (size_t)ed.pt, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
+            if (kModel == 1) edge_lin_equirect(P, X, ed, g.cam, huber_mono, Jl, Jp, r, W, c2, rho0);
+            else edge_lin(P, X, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
             int t = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
@@ -310,37 +303,177 @@ __device__ __forceinline__ void lin_pose(const GraphDev& g, const int k, const d
                 if (stereo) gq = gq + Jp[2][a] * r[2];
                 acc[t++] += gq;
             }
+            // W_e = W Jp^T Jl: this side walks the edges in ascending index, so a wave's 64 records are 9 KB of consecutive bytes
+            double2* const h = reinterpret_cast<double2*>(Hpl + 18 * (size_t)e);
+#pragma unroll
+            for (int a = 0; a < 6; a += 2) {   // rows a, a + 1: entries 3 a .. 3 a + 5
+                const double h0 = W * dot3(Jp, a, Jl, 0, stereo), h1 = W * dot3(Jp, a, Jl, 1, stereo), h2 = W * dot3(Jp, a, Jl, 2, stereo);
+                const double h3 = W * dot3(Jp, a + 1, Jl, 0, stereo), h4 = W * dot3(Jp, a + 1, Jl, 1, stereo), h5 = W * dot3(Jp, a + 1, Jl, 2, stereo);
+                h[3 * (a >> 1)] = double2{h0, h1};
+                h[3 * (a >> 1) + 1] = double2{h2, h3};
+                h[3 * (a >> 1) + 2] = double2{h4, h5};
+            }
         }
     }
     block_sum_256<27>(acc, s_part);
-    if (threadIdx.x == 0) {
-        double* hp = Hpp + 36 * (size_t)k;
-        double* gp = bp + 6 * (size_t)k;
-        int t = 0;
-        for (int a = 0; a < 6; ++a) {
-            for (int b = a; b < 6; ++b) {
-                hp[6 * a + b] = acc[t];
-                hp[6 * b + a] = acc[t];
-                ++t;
-            }
-            gp[a] = acc[t++];
-        }
+    if (threadIdx.x < 27) {
+        double v = acc[0];
+#pragma unroll
+        for (int i = 1; i < 27; ++i) v = (int)threadIdx.x == i ? acc[i] : v;
+        g.pose_part[27 * (size_t)chunk + threadIdx.x] = v;
     }
 }
 
-// ONE launch for both halves of a linearisation (round 5: they are independent -- different outputs, the same inputs -- and each is a small
-// latency-bound grid, 50 and 157 workgroups at config 5, that ran one after the other: 28 + 24 us; side by side ~29): workgroups [0, n_pose)
-// take a keyframe each, the rest 128 or 256 landmarks each (landmarks_per_workgroup). The arithmetic of a keyframe / a landmark is what it was: the same bits.
-__global__ __launch_bounds__(256) void k_linearize(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points, double huber_mono,
-                                                  double huber_stereo, double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ Hll,
-                                                  double* __restrict__ bl, double* __restrict__ Hpl, double* __restrict__ lm_chi, int lm_per_wg) {
-    __shared__ double s_part[4][27];
-    if ((int)blockIdx.x < g.n_pose) {   // (workgroup-uniform)
-        lin_pose(g, (int)blockIdx.x, poses, points, huber_mono, huber_stereo, Hpp, bp, s_part);
-    } else {
-        const int j = ((int)blockIdx.x - g.n_pose) * lm_per_wg + (int)threadIdx.x;
-        if ((int)threadIdx.x < lm_per_wg && j < g.n_pt) lin_landmark(g, j, poses, points, huber_mono, huber_stereo, Hll, bl, Hpl, lm_chi);
+// landmarks [j0, j1) by one 256-thread workgroup: one lane per edge computes the edge's terms, then one lane per (landmark, term) adds a
+// landmark's terms in its edges' order. s_c: [14][kLmSlots] terms of the slots (9 Hll, 3 bl, chi2, rho), s_d: [5][256] the sums' diagonal, chi2 and robustified chi2 per landmark.
+template <int kModel>
+__device__ __forceinline__ void lin_landmark_wg(const GraphDev& g, const int wg, const double* __restrict__ poses, const double* __restrict__ points,
+                                                double huber_mono, double huber_stereo, double* __restrict__ Hll, double* __restrict__ bl,
+                                                double* __restrict__ lm_chi, double (*s_c)[kLmSlots], double (*s_d)[256]) {   // s_d: [5][256]
+    const int tid = (int)threadIdx.x;
+    const int j0 = g.lm_wg_first[wg], j1 = g.lm_wg_first[wg + 1], n_lm = j1 - j0;
+    const int s0 = g.lm_start[j0], s1 = g.lm_start[j1];
+    const bool big = s1 - s0 > kLmSlots;   // (workgroup-uniform) then n_lm == 1: the landmark's edges pass in pieces, threads 0 .. 13 carry its sums
+    double run_m = 0.0, run_s = 0.0;
+    for (int base = s0; base == s0 || base < s1; base += kLmSlots) {
+        const int s = base + tid;
+        if (s < s1) {
+            const int e = g.lm_edges[s], j = g.lm_of_slot[s];
+            if (!g.active[e]) {   // exact zeros: the sums of the remaining edges keep their order and value
+#pragma unroll
+                for (int q = 0; q < 14; ++q) s_c[q][tid] = 0.0;
+            } else {
+                const bool stereo = e >= g.n_mono;
+                const GEdge ed = g.ledges[s];
+                double Jl[3][6], Jp[3][6], r[3], W, c2, rho0;
+                const double* X = points + 3 * (size_t)j;
+                if (kModel == 1) edge_lin_equirect(poses + 7 * (size_t)ed.pose, X, ed, g.cam, huber_mono, Jl, Jp, r, W, c2, rho0);
+                else edge_lin(poses + 7 * (size_t)ed.pose, X, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) s_c[3 * a + b][tid] = W * dot3(Jl, a, Jl, b, stereo);
+                    double t = Jl[0][a] * r[0];
+                    t = t + Jl[1][a] * r[1];
+                    if (stereo) t = t + Jl[2][a] * r[2];
+                    s_c[9 + a][tid] = t;
+                }
+                s_c[12][tid] = c2;
+                s_c[13][tid] = rho0;
+            }
+        }
+        __syncthreads();
+        if (!big) {
+            for (int u = tid; u < 14 * n_lm; u += 256) {
+                const int l = (int)(((unsigned)u * 0x4925u) >> 18), q = u - 14 * l;   // u / 14 for u < 14 * 256 (0x4925 = ceil(2^18 / 14))
+                const int j = j0 + l;
+                const int a = g.lm_start[j] - base, nm = g.lm_nmono[j], b = g.lm_start[j + 1] - base;
+                double hm = 0.0, hs = 0.0;   // mono and stereo sums kept apart: the oracle adds (mono total) + (stereo total)
+                for (int i = a; i < a + nm; ++i) hm += s_c[q][i];
+                for (int i = a + nm; i < b; ++i) hs += s_c[q][i];
+                const double v = hm + hs;
+                if (q < 9) {
+                    Hll[9 * (size_t)j + q] = v;
+                    if (q == 0 || q == 4 || q == 8) s_d[q >> 2][l] = v;
+                } else if (q < 12) {
+                    bl[3 * (size_t)j + (q - 9)] = v;
+                } else {
+                    s_d[q - 9][l] = v;   // rows 3, 4: the landmark's chi2 and robustified chi2
+                }
+            }
+        } else if (tid < 14) {
+            const int a = g.lm_start[j0], nm = g.lm_nmono[j0];
+            const int m_end = min(a + nm, base + kLmSlots), s_end = min(s1, base + kLmSlots);
+            for (int i = max(a, base); i < m_end; ++i) run_m += s_c[tid][i - base];
+            for (int i = max(a + nm, base); i < s_end; ++i) run_s += s_c[tid][i - base];
+        }
+        __syncthreads();
     }
+    if (big && tid < 14) {
+        const double v = run_m + run_s;
+        if (tid < 9) {
+            Hll[9 * (size_t)j0 + tid] = v;
+            if (tid == 0 || tid == 4 || tid == 8) s_d[tid >> 2][0] = v;
+        } else if (tid < 12) {
+            bl[3 * (size_t)j0 + (tid - 9)] = v;
+        } else {
+            s_d[tid - 9][0] = v;
+        }
+    }
+    __syncthreads();
+    // the workgroup's share of the scalars k_reduce_scalars finishes: chi2, robustified chi2 (sums over its landmarks, fixed shape) and the
+    // largest |diagonal entry| of its landmarks' blocks (0 for a landmark without edges) -- three numbers per workgroup instead of three per landmark
+    double a = 0.0, b = 0.0, m = 0.0;
+    if (tid < n_lm) {
+        const int j = j0 + tid;
+        a = s_d[3][tid];
+        b = s_d[4][tid];
+        m = g.lm_start[j + 1] > g.lm_start[j] ? fmax(fmax(fabs(s_d[0][tid]), fabs(s_d[1][tid])), fabs(s_d[2][tid])) : 0.0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off);
+        b += __shfl_xor(b, off);
+        m = fmax(m, __shfl_xor(m, off));
+    }
+    __syncthreads();   // s_d's readers are done
+    if ((tid & 63) == 0) {
+        s_d[0][tid >> 6] = a;
+        s_d[1][tid >> 6] = b;
+        s_d[2][tid >> 6] = m;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        lm_chi[3 * (size_t)wg] = ((s_d[0][0] + s_d[0][1]) + s_d[0][2]) + s_d[0][3];
+        lm_chi[3 * (size_t)wg + 1] = ((s_d[1][0] + s_d[1][1]) + s_d[1][2]) + s_d[1][3];
+        lm_chi[3 * (size_t)wg + 2] = fmax(fmax(s_d[2][0], s_d[2][1]), fmax(s_d[2][2], s_d[2][3]));
+    }
+}
+
+// the edge records in lm_edges' order, once per graph
+__global__ __launch_bounds__(256) void k_edges_by_slot(const GEdge* __restrict__ edges, const int32_t* __restrict__ lm_edges, int n_edge,
+                                                      GEdge* __restrict__ ledges) {
+    const int s = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (s < n_edge) ledges[s] = edges[lm_edges[s]];
+}
+
+// The two halves of a linearisation are independent (different outputs, the same inputs). Round 5 ran them side by side in ONE launch; as
+// two launches each gets its own register budget: the keyframe side needs ~200 VGPRs (27 running sums beside both Jacobians: two waves per
+// SIMD), the landmark side fewer than 128 (four waves per SIMD) -- merged, every workgroup paid the larger figure.
+template <int kModel>
+__global__ __launch_bounds__(256) void k_lin_pose(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points, double huber_mono,
+                                                 double huber_stereo, double* __restrict__ Hpl) {
+    __shared__ double s_part[4][27];
+    lin_pose_chunk<kModel>(g, (int)blockIdx.x, poses, points, huber_mono, huber_stereo, Hpl, s_part);
+}
+template <int kModel>
+__global__ __launch_bounds__(256) void k_lin_landmark(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points, double huber_mono,
+                                                     double huber_stereo, double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ Hll,
+                                                     double* __restrict__ bl, double* __restrict__ lm_chi) {
+    __shared__ double s_c[14][kLmSlots];
+    __shared__ double s_d[5][256];
+    // first, the keyframes' blocks (k_lin_pose, the launch before this one, has left a keyframe's 27 terms as one sum per chunk of its edges):
+    // the chunks are added in ascending order; Hpp symmetric, bp
+    for (int k = (int)blockIdx.x; k < g.n_pose; k += (int)gridDim.x)
+        if (threadIdx.x < 27) {
+            const int t = (int)threadIdx.x;
+            double v = 0.0;
+            for (int c = g.chunk_start[k]; c < g.chunk_start[k + 1]; ++c) v += g.pose_part[27 * (size_t)c + t];
+            // term t of the upper triangle's rows (a, a .. 5), each followed by the row's right-hand side entry
+            int a = 0, rem = t;
+            while (rem >= 7 - a) {
+                rem -= 7 - a;
+                ++a;
+            }
+            if (rem == 6 - a) {
+                bp[6 * (size_t)k + a] = v;
+            } else {
+                const int b = a + rem;
+                Hpp[36 * (size_t)k + 6 * a + b] = v;
+                Hpp[36 * (size_t)k + 6 * b + a] = v;
+            }
+        }
+    lin_landmark_wg<kModel>(g, (int)blockIdx.x, poses, points, huber_mono, huber_stereo, Hll, bl, lm_chi, s_c, s_d);
 }
 
 // chi2[0..1] = sum of the per-landmark partials; chi2[2] = max |diagonal| over free pose blocks and landmarks with edges (g2o's
@@ -370,27 +503,11 @@ __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const doubl
         __syncthreads();
     }
     double a = 0, b = 0, m = 0;
-    // four landmarks of a thread in flight (all loads first, then the additions in the order of the plain loop: the same bits)
-    for (int j0 = threadIdx.x; j0 < g.n_pt; j0 += 4 * 1024) {
-        double ca[4], cb[4], dm[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + 1024 * u;
-            const bool in = j < g.n_pt;
-            const size_t jj = in ? (size_t)j : 0;
-            const double2 c = reinterpret_cast<const double2*>(lm_chi)[jj];
-            const double d = lm_chi[2 * (size_t)g.n_pt + jj];   // written by k_lin_landmark
-            ca[u] = in ? c.x : 0.0;
-            cb[u] = in ? c.y : 0.0;
-            dm[u] = in ? d : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (j0 + 1024 * u < g.n_pt) {
-                a += ca[u];
-                b += cb[u];
-                m = fmax(m, dm[u]);
-            }
+    // the landmark workgroups' shares (k_lin_landmark), a thread's in ascending order
+    for (int w = threadIdx.x; w < g.n_lm_wg; w += 1024) {
+        a += lm_chi[3 * (size_t)w];
+        b += lm_chi[3 * (size_t)w + 1];
+        m = fmax(m, lm_chi[3 * (size_t)w + 2]);
     }
     for (int k = threadIdx.x; k < g.n_pose; k += 1024)
         if (!g.fixed[k])
@@ -813,6 +930,10 @@ struct ovs_ba_graph {
     int32_t *d_lm_start = nullptr, *d_lm_edges = nullptr, *d_lm_nmono = nullptr, *d_pose_start = nullptr, *d_pose_edges = nullptr;
     uint8_t* d_fixed = nullptr;
     int32_t *d_pose_pt = nullptr, *d_pair_ab = nullptr, *d_slot_pose = nullptr, *d_slot_of_pose = nullptr, *d_fail = nullptr;
+    int32_t *d_lm_of_slot = nullptr, *d_lm_wg_first = nullptr, *d_chunk_kf = nullptr, *d_chunk_start = nullptr;   // k_linearize's work partition
+    double* d_pose_part = nullptr;
+    GEdge* d_ledges = nullptr;
+    int n_lm_wg = 0, n_chunks = 0;
     int32_t* d_edge_of = nullptr;   // [n_free x n_pt], solver arena
     int n_pairs = 0;
     double* d_lm_tmp = nullptr;   // [4 n_pt] per-landmark partials: chi2 pair, max |diagonal|, the gain ratio's scale term
@@ -834,6 +955,14 @@ struct ovs_ba_graph {
         g.pose_edges = d_pose_edges;
         g.fixed = d_fixed;
         g.active = d_active;
+        g.ledges = d_ledges;
+        g.lm_of_slot = d_lm_of_slot;
+        g.lm_wg_first = d_lm_wg_first;
+        g.chunk_kf = d_chunk_kf;
+        g.chunk_start = d_chunk_start;
+        g.pose_part = d_pose_part;
+        g.n_lm_wg = n_lm_wg;
+        g.n_chunks = n_chunks;
         g.cam = cam;
         g.bf = bf;
         g.model = model;
@@ -861,10 +990,16 @@ ovs_status graph_linearize(ovs_ba_graph* g, const double* d_poses, const double*
                            double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror = nullptr,
                            bool trial_scale = false) {
     const GraphDev v = g->view();
-    const int lm_per_wg = landmarks_per_workgroup(g->n_pose, g->n_pt);
-    hipLaunchKernelGGL(k_linearize, dim3(g->n_pose + (g->n_pt + lm_per_wg - 1) / lm_per_wg), dim3(256), 0, s, v, d_poses, d_points, huber_mono,
-                       huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, g->d_lm_tmp, lm_per_wg);
-    OVS_LAUNCH_TRY("k_linearize");
+    if (g->n_chunks > 0) {
+        if (g->model == 1) hipLaunchKernelGGL(k_lin_pose<1>, dim3(g->n_chunks), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl);
+        else hipLaunchKernelGGL(k_lin_pose<0>, dim3(g->n_chunks), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl);
+        OVS_LAUNCH_TRY("k_lin_pose");
+    }
+    if (g->model == 1)
+        hipLaunchKernelGGL(k_lin_landmark<1>, dim3(g->n_lm_wg), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, g->d_lm_tmp);
+    else
+        hipLaunchKernelGGL(k_lin_landmark<0>, dim3(g->n_lm_wg), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, g->d_lm_tmp);
+    OVS_LAUNCH_TRY("k_lin_landmark");
     hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(1024), 0, s, v, g->d_lm_tmp, d_Hpp, d_Hll, d_chi3, d_chi_mirror,
                        trial_scale ? g->d_lm_tmp + 3 * (size_t)g->n_pt : (const double*)nullptr, trial_scale ? g->d_scal : (double*)nullptr);
     OVS_LAUNCH_TRY("k_reduce_scalars");
@@ -984,8 +1119,14 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
                  o_fixed = place((size_t)n_pose), o_active = place((size_t)ne), o_slot_of_pose = place(sizeof(int32_t) * (size_t)n_pose),
                  o_pose_pt = place(sizeof(int32_t) * (size_t)ne), o_pair_ab = place(sizeof(int32_t) * 2 * (size_t)n_pairs),
                  o_slot_pose = place(sizeof(int32_t) * (size_t)nf);
+    // k_linearize's work partition (sizes are upper bounds: the tables are built below, from the counting sorts)
+    const size_t max_chunks = (size_t)ne / kPoseChunk + (size_t)n_pose;
+    const size_t o_lm_of_slot = place(sizeof(int32_t) * (size_t)ne), o_lm_wg_first = place(sizeof(int32_t) * ((size_t)n_pt + 1)),
+                 o_chunk_kf = place(sizeof(int32_t) * max_chunks), o_chunk_start = place(sizeof(int32_t) * ((size_t)n_pose + 1));
     const size_t upload_bytes = (top + 255) & ~(size_t)255;   // what the device reads before writing it ends here; scratch follows
     const size_t o_lm_tmp = place(sizeof(double) * 4 * (size_t)n_pt);
+    const size_t o_pose_part = place(sizeof(double) * 27 * max_chunks);
+    const size_t o_ledges = place(sizeof(GEdge) * (size_t)ne);
     const size_t arena_bytes = top;
     if (sc.image.size() < upload_bytes) sc.image.resize(upload_bytes);
     unsigned char* const img = sc.image.data();
@@ -1029,6 +1170,30 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     for (int e = 0; e < ne; ++e) {
         lm_edges[(size_t)sc.fl[edge_pt[e]]++] = e;
         pose_edges[(size_t)sc.fp[edge_pose[e]]++] = e;
+    }
+    {   // k_linearize: landmark of every slot; runs of whole landmarks with at most kLmSlots edges (and landmarks); chunks of a keyframe's edges
+        int32_t* const lm_of_slot = reinterpret_cast<int32_t*>(img + o_lm_of_slot);
+        int32_t* const wg_first = reinterpret_cast<int32_t*>(img + o_lm_wg_first);
+        int n_wg = 0, first = 0;
+        for (int j = 0; j < n_pt; ++j) {
+            for (int i = lm_start[j]; i < lm_start[(size_t)j + 1]; ++i) lm_of_slot[i] = j;
+            if (j > first && (lm_start[(size_t)j + 1] - lm_start[first] > kLmSlots || j - first >= 256)) {   // j does not fit: it opens the next run
+                wg_first[n_wg++] = first;
+                first = j;
+            }
+        }
+        wg_first[n_wg++] = first;
+        wg_first[n_wg] = n_pt;
+        g->n_lm_wg = n_wg;
+        int32_t* const chunk_kf = reinterpret_cast<int32_t*>(img + o_chunk_kf);
+        int32_t* const chunk_start = reinterpret_cast<int32_t*>(img + o_chunk_start);
+        int n_ch = 0;
+        for (int k = 0; k < n_pose; ++k) {
+            chunk_start[k] = n_ch;
+            for (int i = pose_start[k]; i < pose_start[(size_t)k + 1]; i += kPoseChunk) chunk_kf[n_ch++] = k;
+        }
+        chunk_start[n_pose] = n_ch;
+        g->n_chunks = n_ch;
     }
     // A keyframe observes a landmark at most once (upstream: landmark::add_observation ignores a second observation by the same keyframe).
     // The reduced system relies on that -- k_edge_table keeps ONE edge per (keyframe, landmark), and two edges of one free keyframe to one
@@ -1086,6 +1251,17 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     g->d_fixed = A + o_fixed;
     g->d_active = A + o_active;
     g->d_lm_tmp = reinterpret_cast<double*>(A + o_lm_tmp);
+    g->d_lm_of_slot = reinterpret_cast<int32_t*>(A + o_lm_of_slot);
+    g->d_lm_wg_first = reinterpret_cast<int32_t*>(A + o_lm_wg_first);
+    g->d_chunk_kf = reinterpret_cast<int32_t*>(A + o_chunk_kf);
+    g->d_chunk_start = reinterpret_cast<int32_t*>(A + o_chunk_start);
+    g->d_pose_part = reinterpret_cast<double*>(A + o_pose_part);
+    g->d_ledges = reinterpret_cast<GEdge*>(A + o_ledges);
+    if (ne > 0) {   // null stream: ordered behind the upload above and before whatever stream the caller linearises on (the wait costs ~10 us)
+        hipLaunchKernelGGL(k_edges_by_slot, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, nullptr, g->d_edges, g->d_lm_edges, ne, g->d_ledges);
+        G_TRY(hipGetLastError());
+        G_TRY(hipStreamSynchronize(nullptr));
+    }
     g->d_slot_of_pose = reinterpret_cast<int32_t*>(A + o_slot_of_pose);
     g->d_pose_pt = reinterpret_cast<int32_t*>(A + o_pose_pt);
     if (g->n_free > 0) {
