@@ -678,11 +678,27 @@ def bench_local_ba(world, rank, dist, torch, iters=20, n_pose=50, n_pt=20000, ob
         dt = float(tt.item())
     n_edges = len(d["edges"])
     alg_bytes = n_edges * 32 + n_pose * 56 + n_pt * 24 + n_edges * 144 + n_pt * 96 + n_pose * 336   # ~20.0 MB / iteration at config 5
+    # HBM-side traffic of one linearisation from the committed rocprofv3 --pmc passes (tools/gpu_lba_pmc.sh: FETCH_SIZE and WRITE_SIZE in their own
+    # passes, (2 * FETCH + WRITE) KiB summed over k_lin_pose, k_lin_landmark, k_reduce_scalars); null when the file is missing
+    size_key = "config5" if (n_pose, n_pt, obs_per_pose) == (50, 20000, 2000) else ("large" if (n_pose, n_pt, obs_per_pose) == (200, 100000, 5000) else None)
+    traffic = None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_lba.json")) as fh:
+            traffic = json.load(fh)[size_key]["traffic_bytes_per_linearisation"] if size_key and world == 1 else None
+    except (OSError, KeyError, ValueError):
+        traffic = None
+    gbps = alg_bytes * iters / dt / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_lin_pose + k_lin_landmark + k_reduce_scalars (one linearisation)", "achieved": round(gbps, 2), "peak": 8000.0,
+                "unit": "GB/s", "frac": round(gbps / 8000.0, 4), "algorithmic_bytes_per_linearisation": alg_bytes, "traffic": traffic,
+                "traffic_source": "profiles/pmc_lba.json (tools/gpu_lba_pmc.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH + WRITE)" if traffic else None,
+                "what_bounds_it": "neither bandwidth nor fp64 issue: k_lin_pose keeps 27 running sums beside both Jacobians (218 VGPRs, two waves per SIMD) "
+                                  "and waits on its gathers 54 % of its wave cycles (profiles/r06_lba_pmc_summary.txt)"}
     return {"workload": "%s%d keyframes x %d observations, %d landmarks, fp64, Huber sqrt(5.991)"
                         % ("BASELINE configs[4]: " if (n_pose, n_pt, obs_per_pose) == (50, 20000, 2000) else "", n_pose, obs_per_pose, n_pt),
             "ms_per_linearisation": round(dt / iters * 1e3, 4), "edges_per_sec": round(n_edges * iters / dt, 1),
             "algorithmic_GBps": round(alg_bytes * iters / dt / 1e9, 2), "allreduce_bytes": (n_pt * 12 + 2) * 8 if world > 1 else 0,
-            "chi2": float(out["chi2"][0].item()), "kernels": "ovs_ba_graph: k_linearize (landmark and keyframe workgroups in one launch) + k_reduce_scalars (no atomics, bit-reproducible)",
+            "roofline": roofline,
+            "chi2": float(out["chi2"][0].item()), "kernels": "ovs_ba_graph: k_lin_pose (one lane per edge in keyframe order: the 27 pose-block terms as a fixed-shape sum per 512 edges, Hpl written in edge order) + k_lin_landmark (one lane per edge in landmark order, a landmark's terms added in its edges' order; finishes the keyframes' blocks) + k_reduce_scalars (no atomics, bit-reproducible)",
             "exchange": "ONE packed all-reduce of Hll|bl|chi2 per linearisation" if world > 1 else "none (1 rank)",
             # DESIGN.md section 5, written down before any multi-GPU node ran this: what ms_per_linearisation is expected to be at this N
             "expected_ms_per_linearisation": _expected_lba_ms(world, n_pt, dt / iters * 1e3 if world == 1 else None),
@@ -690,12 +706,12 @@ def bench_local_ba(world, rank, dist, torch, iters=20, n_pose=50, n_pt=20000, ob
 
 
 def _expected_lba_ms(world, n_pt, one_device_ms):
-    """DESIGN.md section 5's model of the sharded linearisation: compute = the one-device time / N (0.041 ms at config 5, 0.221 ms at
+    """DESIGN.md section 5's model of the sharded linearisation: compute = the one-device time / N (0.032 ms at config 5, 0.122 ms at
     local_ba_large when not measured in this run), exchange = a ring all-reduce of the packed (12 n_pt + 2) f64 buffer over xGMI: 2 (N - 1) hops
     of 5-10 us plus 2 (N - 1) / N x bytes at <= 153 GB/s per link. Returned as [low, high]; at N = 1 the measured time itself."""
     if world == 1:
         return [round(one_device_ms, 4), round(one_device_ms, 4)]
-    base = 0.041 if n_pt <= 20000 else 0.221
+    base = 0.032 if n_pt <= 20000 else 0.122
     nbytes = (n_pt * 12 + 2) * 8
     wire = 2.0 * (world - 1) / world * nbytes / 153e9 * 1e3
     return [round(base / world + 2 * (world - 1) * 0.005 + wire, 4), round(base / world + 2 * (world - 1) * 0.010 + 2.0 * wire, 4)]

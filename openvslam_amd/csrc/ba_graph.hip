@@ -200,6 +200,7 @@ struct GraphDev {   // device views shared by the kernels
     const int32_t* lm_nmono;     // [n_pt] how many of the landmark's edges are mono
     const int32_t* pose_start;   // [n_pose + 1] into pose_edges
     const int32_t* pose_edges;
+    const int32_t* pose_pt;      // [n_edge] landmark of every entry of pose_edges
     const uint8_t* fixed;        // [n_pose]
     const uint8_t* active;       // [n_edge] 0 = the edge is at g2o level 1 (an outlier of round 1): it contributes nothing
     // work partition of k_linearize (round 6): one lane per EDGE on both sides
@@ -226,16 +227,34 @@ struct GraphDev {   // device views shared by the kernels
 constexpr int kPoseChunk = 512;     // entries of pose_edges per keyframe workgroup (two per thread)
 constexpr int kLmSlots = 256;       // edges per landmark workgroup
 
-// fixed-shape reduction of NV per-thread values over a 256-thread workgroup: lanes by xor-shuffle, then the four waves in order
+// sum of x over the wave in lane 63: row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, then row_bcast 15 / 31 -- data-parallel moves in the
+// vector ALU (two per double and step) instead of ds_bpermute round trips through the LDS crossbar (round 2-5's xor-shuffle tree: 324 of
+// them per wave for the keyframe side's 27 sums). A fixed shape: the same bits from run to run.
+__device__ __forceinline__ double wave_sum_lane63(double x) {
+#define OVS_DPP_STEP(ctrl, row_mask, bound)                                                                                  \
+    {                                                                                                                        \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, row_mask, 0xf, bound);                        \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, row_mask, 0xf, bound);                        \
+        x = x + __hiloint2double(hi, lo);                                                                                    \
+    }
+    OVS_DPP_STEP(0x111, 0xf, true)    // row_shr:1
+    OVS_DPP_STEP(0x112, 0xf, true)    // row_shr:2
+    OVS_DPP_STEP(0x114, 0xf, true)    // row_shr:4
+    OVS_DPP_STEP(0x118, 0xf, true)    // row_shr:8
+    OVS_DPP_STEP(0x142, 0xa, false)   // row_bcast:15 into rows 1, 3
+    OVS_DPP_STEP(0x143, 0xc, false)   // row_bcast:31 into rows 2, 3
+#undef OVS_DPP_STEP
+    return x;
+}
+
+// fixed-shape reduction of NV per-thread values over a 256-thread workgroup: the lanes of a wave (above), then the four waves in order
 template <int NV>
 __device__ __forceinline__ void block_sum_256(double (&v)[NV], double (*s_part)[NV]) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        double x = v[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-        if (lane == 0) s_part[wv][i] = x;
+        const double x = wave_sum_lane63(v[i]);
+        if (lane == 63) s_part[wv][i] = x;
     }
     __syncthreads();
 #pragma unroll
@@ -268,13 +287,18 @@ __device__ __forceinline__ void lin_pose_chunk(const GraphDev& g, const int chun
         int ee[2];
         GEdge edd[2];
         double XX[2][3];
+        int pt[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) ee[u] = i0 + 256 * u < e1 ? g.pose_edges[i0 + 256 * u] : -1;
+        for (int u = 0; u < 2; ++u) {
+            const bool in = i0 + 256 * u < e1;
+            ee[u] = in ? g.pose_edges[i0 + 256 * u] : -1;
+            pt[u] = in ? g.pose_pt[i0 + 256 * u] : 0;   // the landmark without going through the edge record: one dependent load less
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) edd[u] = g.edges[max(ee[u], 0)];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const double* x = points + 3 * (size_t)edd[u].pt;
+            const double* x = points + 3 * (size_t)pt[u];
             XX[u][0] = x[0];
             XX[u][1] = x[1];
             XX[u][2] = x[2];
@@ -329,12 +353,13 @@ __device__ __forceinline__ void lin_pose_chunk(const GraphDev& g, const int chun
 template <int kModel>
 __device__ __forceinline__ void lin_landmark_wg(const GraphDev& g, const int wg, const double* __restrict__ poses, const double* __restrict__ points,
                                                 double huber_mono, double huber_stereo, double* __restrict__ Hll, double* __restrict__ bl,
-                                                double* __restrict__ lm_chi, double (*s_c)[kLmSlots], double (*s_d)[256]) {   // s_d: [5][256]
+                                                double* __restrict__ lm_chi, double (*s_c)[kLmSlots + 1], double (*s_d)[256]) {   // s_d: [5][256]
     const int tid = (int)threadIdx.x;
     const int j0 = g.lm_wg_first[wg], j1 = g.lm_wg_first[wg + 1], n_lm = j1 - j0;
     const int s0 = g.lm_start[j0], s1 = g.lm_start[j1];
     const bool big = s1 - s0 > kLmSlots;   // (workgroup-uniform) then n_lm == 1: the landmark's edges pass in pieces, threads 0 .. 13 carry its sums
     double run_m = 0.0, run_s = 0.0;
+
     for (int base = s0; base == s0 || base < s1; base += kLmSlots) {
         const int s = base + tid;
         if (s < s1) {
@@ -450,7 +475,7 @@ template <int kModel>
 __global__ __launch_bounds__(256) void k_lin_landmark(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points, double huber_mono,
                                                      double huber_stereo, double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ Hll,
                                                      double* __restrict__ bl, double* __restrict__ lm_chi) {
-    __shared__ double s_c[14][kLmSlots];
+    __shared__ double s_c[14][kLmSlots + 1];   // + 1: the fourteen terms of a slot in fourteen different banks
     __shared__ double s_d[5][256];
     // first, the keyframes' blocks (k_lin_pose, the launch before this one, has left a keyframe's 27 terms as one sum per chunk of its edges):
     // the chunks are added in ascending order; Hpp symmetric, bp
@@ -953,6 +978,7 @@ struct ovs_ba_graph {
         g.lm_nmono = d_lm_nmono;
         g.pose_start = d_pose_start;
         g.pose_edges = d_pose_edges;
+        g.pose_pt = d_pose_pt;
         g.fixed = d_fixed;
         g.active = d_active;
         g.ledges = d_ledges;

@@ -41,7 +41,7 @@ for w in ("lin", "opt"):
             continue
         d = sorted(dur[k])
         print("%-28s calls %5d  avg %8.1f us  median %8.1f  max %8.1f" % (k[:28], len(d), sum(d) / len(d), d[len(d) // 2], d[-1]))
-        if w == "lin" and k.startswith("k_linearize"):
+        if w == "lin" and k.startswith("k_lin_"):
             # the two problem sizes separately: the large problem's launches are the slow ones
             big = [x for x in d if x > 3 * d[0]]
             small = [x for x in d if x <= 3 * d[0]]
@@ -50,5 +50,27 @@ for w in ("lin", "opt"):
         for c in sorted(acc.get(k, {})):
             v = acc[k][c]
             print("      %-24s n=%-4d mean=%.5g  max=%.5g" % (c, len(v), sum(v) / len(v), max(v)))
+    if w == "lin":
+        # traffic of ONE linearisation per problem size: the launches of the large map are the upper half of each kernel's sorted counter values.
+        # FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled (MI355X_MICROARCH.md: it reports half the bytes of a coalesced read stream;
+        # for the gathers of these kernels the factor is an upper bound).
+        import json
+        out = {}
+        for size, pick in (("config5", lambda v: v[: len(v) // 2]), ("large", lambda v: v[-(len(v) // 3):])):
+            tot = 0.0
+            det = {}
+            for k in acc:
+                if not k.startswith(("k_lin_", "k_reduce_scalars")):
+                    continue
+                f = sorted(acc[k].get("FETCH_SIZE", [0.0]))
+                wv = sorted(acc[k].get("WRITE_SIZE", [0.0]))
+                fb = pick(f) or f
+                wb = pick(wv) or wv
+                b = 2 * 1024 * sum(fb) / len(fb) + 1024 * sum(wb) / len(wb)
+                det[k] = round(b)
+                tot += b
+            out[size] = {"traffic_bytes_per_linearisation": round(tot), "per_kernel": det}
+        json.dump(out, open(os.path.join(root, "pmc_lba.json"), "w"), indent=1)
+        print(json.dumps(out))
 PY
 find $out -name '*.csv' -size +2M -delete; find $out -name '*.db' -delete
