@@ -592,6 +592,10 @@ ovs_status ovs_ba_graph_create(int32_t device, int32_t n_pose, const uint8_t* po
 ovs_status ovs_ba_graph_create_equirect(int32_t device, int32_t n_pose, const uint8_t* pose_fixed, int32_t n_pt, const ovs_ba_edge* mono,
                                         int32_t n_mono, int32_t cols, int32_t rows, ovs_ba_graph** out);
 ovs_status ovs_ba_graph_destroy(ovs_ba_graph* g);
+/* The graphs' device arenas are recycled through a small per-device pool (mapping_module builds a graph per keyframe; upstream's
+ * local_bundle_adjuster::optimize builds and drops a g2o::SparseOptimizer per call). A long-lived process that is done with local BA
+ * returns the kept blocks (at most four per device) with this call; graphs that still exist are not touched. */
+ovs_status ovs_ba_pool_trim(void);
 ovs_status ovs_ba_graph_linearize_dev(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo,
                                       double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi2, void* stream);
 

@@ -73,6 +73,7 @@ SYMBOLS = {
     "ovs_ba_graph_create": (_i32, [_i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, C.c_double, C.POINTER(_vp)]),
     "ovs_ba_graph_create_equirect": (_i32, [_i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, C.POINTER(_vp)]),
     "ovs_ba_graph_destroy": (_i32, [_vp]),
+    "ovs_ba_pool_trim": (_i32, []),
     "ovs_ba_graph_linearize_dev": (_i32, [_vp, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ovs_frame_dev_create": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, C.POINTER(_vp)]),
     "ovs_frame_dev_destroy": (_i32, [_vp]),

@@ -13,7 +13,7 @@ namespace match {
 namespace {
 // the landmarks to check as five flat arrays. Per THREAD and reused from call to call (mapping_module calls this ~40 times per new keyframe with
 // ~2000 landmarks each: five fresh 2 - 64 KB vectors per call were a tenth of a resident call's 0.11 ms in allocation, zero-fill and page faults);
-// entries of landmarks that are not usable keep whatever an earlier call left there -- the kernel reads nothing of an entry whose `valid` is 0
+// entries of landmarks that are not usable get zeros in their numeric fields (their descriptor bytes keep what an earlier call left); the kernel reads nothing of an entry whose `valid` is 0
 struct flat_landmarks {
     std::vector<double> pos, normal;
     std::vector<float> dist;
@@ -31,7 +31,11 @@ struct flat_landmarks {
         for (IT it = begin; it != end; ++it, ++l) {
             data::landmark* lm = *it;
             valid[l] = is_valid(lm) ? 1 : 0;
-            if (!valid[l]) continue;
+            if (!valid[l]) {   // defined values for an entry the kernel masks out
+                for (int a = 0; a < 3; ++a) pos[3 * l + a] = normal[3 * l + a] = 0.0;
+                dist[2 * l] = dist[2 * l + 1] = 0.0f;
+                continue;
+            }
             const Vec3_t p = lm->get_pos_in_world(), n = lm->get_obs_mean_normal();
             for (int a = 0; a < 3; ++a) {
                 pos[3 * l + a] = p(a);

@@ -20,7 +20,11 @@ unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::
     for (int l = 0; l < m; ++l) {
         const auto* lm = local_landmarks[l];
         lm_valid[l] = lm && lm->is_observable_in_tracking_ && !lm->will_be_erased();
-        if (!lm_valid[l]) continue;
+        if (!lm_valid[l]) {   // defined values for an entry the kernels mask out (the staging vectors keep earlier calls' contents)
+            lm_xy[2 * l] = lm_xy[2 * l + 1] = lm_x_right[l] = 0.0f;
+            lm_level[l] = 0;
+            continue;
+        }
         lm_xy[2 * l] = (float)lm->reproj_in_tracking_(0);
         lm_xy[2 * l + 1] = (float)lm->reproj_in_tracking_(1);
         lm_x_right[l] = lm->x_right_in_tracking_;
@@ -58,7 +62,10 @@ unsigned int projection::match_current_and_last_frames(data::frame& curr_frm, co
     for (int i = 0; i < n_last; ++i) {
         const auto* lm = last_frm.landmarks_[i];
         last_valid[i] = lm && !(i < (int)last_frm.outlier_flags_.size() && last_frm.outlier_flags_[i]);
-        if (!last_valid[i]) continue;
+        if (!last_valid[i]) {   // defined values for an entry the kernels mask out
+            for (int a = 0; a < 3; ++a) last_pos[(size_t)3 * i + a] = 0.0;
+            continue;
+        }
         const Vec3_t pos_w = lm->get_pos_in_world();
         for (int a = 0; a < 3; ++a) last_pos[(size_t)3 * i + a] = pos_w(a);
         const cv::Mat d = lm->get_descriptor();

@@ -67,7 +67,7 @@ inline window_holder& window_ctx(int device = 0) {
 // Per-thread staging vectors of the shims, reused from call to call: a tracked frame flattens ~2000 landmarks into half a dozen arrays twice
 // (match_current_and_last_frames, match_frame_and_landmarks); fresh std::vectors cost allocation, zero-fill and first-touch page faults of
 // ~110 KB per call (~10 us of a 0.08 - 0.14 ms call). resize() keeps the old contents: entries a call does not write are masked by its `valid`
-// array, which every call writes completely.
+// array, which every call writes completely; the fill loops also give masked entries defined values (zeros) for the numeric fields.
 template <class T>
 inline std::vector<T>& scratch_vec(int slot, size_t n) {
     thread_local std::vector<T> v[8];

@@ -1043,6 +1043,7 @@ struct BaArenaPool {
         size_t cap;
         unsigned char* p;
     };
+    static constexpr size_t kKeepPerDevice = 4;
     std::mutex mu;
     std::vector<Block> free_;
     unsigned char* take(int device, size_t bytes, size_t* cap) {
@@ -1062,23 +1063,51 @@ struct BaArenaPool {
         *cap = want;
         return p;
     }
+    // hipFree of a block under ITS device (the caller's current device is restored)
+    static void release(const Block& b) {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != b.device) (void)hipSetDevice(b.device);
+        (void)hipFree(b.p);
+        if (cur >= 0 && cur != b.device) (void)hipSetDevice(cur);
+    }
     void give(int device, unsigned char* p, size_t cap) {   // the caller guarantees that no work on the block is in flight
         if (!p) return;
-        unsigned char* drop = nullptr;
+        Block drop{-1, 0, nullptr};
         {
             std::lock_guard<std::mutex> lock(mu);
-            if (free_.size() >= 4) {
-                drop = free_.front().p;
-                free_.erase(free_.begin());
+            // the cap is per device: one device's blocks never evict another's
+            size_t mine = 0, oldest = free_.size();
+            for (size_t i = 0; i < free_.size(); ++i)
+                if (free_[i].device == device) {
+                    if (oldest == free_.size()) oldest = i;
+                    ++mine;
+                }
+            if (mine >= kKeepPerDevice) {
+                drop = free_[oldest];
+                free_.erase(free_.begin() + (long)oldest);
             }
             free_.push_back(Block{device, cap, p});
         }
-        if (drop) (void)hipFree(drop);
+        if (drop.p) release(drop);
+    }
+    void trim() {   // ovs_ba_pool_trim: a long-lived process gives the kept blocks back
+        std::vector<Block> all;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            all.swap(free_);
+        }
+        for (const Block& b : all) release(b);
     }
 };
 static BaArenaPool g_ba_pool;
 
 extern "C" {
+
+ovs_status ovs_ba_pool_trim(void) {
+    g_ba_pool.trim();
+    return OVS_OK;
+}
 
 ovs_status ovs_ba_graph_destroy(ovs_ba_graph* g) {
     if (!g) return OVS_OK;

@@ -231,6 +231,9 @@ struct Lm {
         const bool dev_solve = ovs::g_lba_solver.load(std::memory_order_relaxed) == 0 && n <= ovs::dense_solve_max_n();
         st = upload_poses(T, d_poses, dev_solve ? d_T : nullptr);
         if (st != OVS_OK) return st;
+        // both failure words start a round clear: the device solver's trials rely on the PREVIOUS trial's k_trial_update to clear the word they
+        // are about to use, which a round that ran on the host solver (ovs_local_ba_set_solver between rounds) has not done
+        if (dev_solve) OVS_HIP_TRY(hipMemsetAsync(gi.d_fail, 0, 2 * sizeof(int32_t), stream));
         st = ovs::ba_graph_linearize(g, d_poses, d_X, huber_mono(robust), huber_stereo(robust), cur.Hpp, cur.bp, cur.Hll, cur.bl, cur.Hpl, cur.chi,
                                      stream);
         if (st != OVS_OK) return st;

@@ -653,7 +653,12 @@ int dense_solve_max_n() { return kMaxN; }
 int dense_solve_pad(int n) { return (n + kNb - 1) / kNb * kNb; }
 size_t dense_solve_doubles(int n) { return (size_t)(dense_solve_pad(n) + kNb) * dense_solve_pad(n); }   // the padded system's storage
 
-// d_S: the padded system of n unknowns (see above); the solution replaces the right-hand side at d_S + n_pad * n_pad
+// d_S: the padded system of n unknowns (see above); the solution replaces the right-hand side at d_S + n_pad * n_pad.
+// CONTRACT on failure: when the factorisation meets a pivot that is not positive (or not finite) the kernel ORs 2 into *d_fail and -- k_chol_resident
+// does not leave early: its waves run on in lock step -- the matrix, its padding and the solution are then GARBAGE (NaNs). A caller that reuses d_S
+// must rebuild the whole padded system (ba_graph_reset_system does, for ovs_local_ba_optimize) and must not consume the solution; kernels queued
+// behind the solve in the same trial (k_trial_update, the linearisation at the trial state) run on NaN states whose outputs the caller discards
+// when it reads the failure word. tests/test_gpu_ba.py::test_dense_solve_failure_then_success covers both solver kernels.
 ovs_status launch_dense_solve(double* d_S, int n, int32_t* d_fail, hipStream_t s, unsigned long long* d_tstats) {
     if (n < 1 || n > dense_solve_max_n()) return OVS_ERR_INVALID;
     const int n_pad = dense_solve_pad(n);

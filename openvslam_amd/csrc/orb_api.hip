@@ -367,7 +367,7 @@ bool build_geometry(const ovs_orb* h, int rows, int cols, FrameGeo& geo, std::ve
                 g.dx = W;
                 g.dy = (double)H / g.gy;
             }
-            if (g.gx * g.gy > 64) return false;
+            if (g.gx * g.gy > 4096) return false;   // (16-bit node ids: max_nodes below is the binding limit)
         }
         const int nc = std::max(g.n_keypts, g.gx * g.gy) + 16;
         g.max_nodes = 4 * nc;
@@ -411,8 +411,8 @@ bool build_geometry(const ovs_orb* h, int rows, int cols, FrameGeo& geo, std::ve
 ovs_status ensure_geometry(ovs_orb* h, int rows, int cols) {
     if (rows == h->cur_rows && cols == h->cur_cols) return OVS_OK;
     if (rows > h->max_rows || cols > h->max_cols) return OVS_ERR_CAPACITY;
-    // Build into temporaries and commit only after every check and both uploads succeeded: a refused size (e.g. 60 x 1920: more than
-    // 64 root patches) must leave the handle exactly as it was, so that the next call with the previous, valid size still finds host
+    // Build into temporaries and commit only after every check and both uploads succeeded: a refused size (e.g. 60 x 1920 on a handle created for 480 x 1920:
+    // its 85 root patches need more node / keypoint capacity than the handle has) must leave the handle exactly as it was, so that the next call with the previous, valid size still finds host
     // geometry, device geometry and cur_rows / cur_cols in agreement.
     size_t pyr_bytes, cand_entries, node_entries;
     FrameGeo geo;
@@ -640,11 +640,14 @@ ovs_status ovs_orb_create(const ovs_orb_params* params, int32_t max_rows, int32_
     // RATIO of the image, not on its size: a small elongated image can need more of both than the largest image the handle was created
     // for (found by tools/fuzz_parity.py: 1664 x 257 on a 2000 x 1300 handle). Size them for the worst grid.
     {
+        // (round 6: more than 64 root patches run when the handle was CREATED for such a shape -- the largest image's own root grids count
+        // here; a 64:1 strip on a handle created for 4:3 images is refused with OVS_ERR_CAPACITY, not OVS_ERR_INVALID)
         size_t node_worst = 0, kp_worst[2] = {0, 0};
         for (int l = 0; l < L; ++l) {
-            node_worst += (size_t)2 * 4 * (std::max(geo.lv[l].n_keypts, 64) + 16);
-            kp_worst[0] += (size_t)std::max(geo.lv[l].n_keypts + 3, 4 * 64);
-            kp_worst[1] += (size_t)std::max(2 * geo.lv[l].n_keypts + 3, 4 * 64);   // ovs_orb_set_variant(TREE_SWITCH_FACTOR, 1)
+            const int roots = std::max(64, geo.lv[l].gx * geo.lv[l].gy);
+            node_worst += (size_t)2 * 4 * (std::max(geo.lv[l].n_keypts, roots) + 16);
+            kp_worst[0] += (size_t)std::max(geo.lv[l].n_keypts + 3, 4 * roots);
+            kp_worst[1] += (size_t)std::max(2 * geo.lv[l].n_keypts + 3, 4 * roots);   // ovs_orb_set_variant(TREE_SWITCH_FACTOR, 1)
         }
         node_entries = std::max(node_entries, node_worst);
         h->out_cap_variant[0] = (int)kp_worst[0];

@@ -402,6 +402,7 @@ __global__ __launch_bounds__(kChainThreads) void k_pyramid_chain(const uint8_t* 
     const ChainSpan X0 = s_span[0], Y0 = s_span[OVS_MAX_LEVELS];
     const int sp0 = ((X0.c1 - X0.c0) + 3) & ~3, nw0 = sp0 >> 2, H0 = Y0.c1 - Y0.c0;
     const uint8_t* const s0 = img0 + (size_t)frame * frame_stride0;
+    const int cols0 = geo->lv[0].cols;   // a row is read up to its last PIXEL, not up to the pitch: a caller's buffer may end at (rows - 1) * stride + cols
     uint32_t v0[kChainRowsPerThread];
 #pragma unroll
     for (int k = 0; k < kChainRowsPerThread; ++k) {
@@ -410,12 +411,12 @@ __global__ __launch_bounds__(kChainThreads) void k_pyramid_chain(const uint8_t* 
         if (r < H0 && lane < nw0) {
             const int gx = X0.c0 + 4 * lane;
             const uint8_t* p = s0 + (size_t)(Y0.c0 + r) * pitch0 + gx;
-            if (gx + 4 <= pitch0) {   // (base, pitch and frame stride are multiples of 4: the launcher's condition)
+            if (gx + 4 <= cols0) {   // (base, pitch and frame stride are multiples of 4: the launcher's condition)
                 v0[k] = *reinterpret_cast<const uint32_t*>(p);
             } else {
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    if (gx + b < pitch0) v0[k] |= (uint32_t)p[b] << (8 * b);
+                    if (gx + b < cols0) v0[k] |= (uint32_t)p[b] << (8 * b);
             }
         }
     }

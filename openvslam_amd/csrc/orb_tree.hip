@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
                                                       size_t cand_frame_entries, const uint32_t* __restrict__ cand_count,
                                                       NodeRec* __restrict__ nodes, size_t node_frame_entries,
                                                       uint64_t* __restrict__ lvl_kps, uint32_t* __restrict__ lvl_count, int NCmax,
-                                                      int P2max, int level_lo) {
+                                                      int P2max, int Rmax, int level_lo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // ---- LDS carve (all offsets multiples of 16)
     const int NN = 4 * NCmax;
@@ -122,7 +122,9 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
     uint32_t* nxb = sidx + P2max;                                         // [NCmax] bx | ex << 16 of the current nodes
     uint32_t* nyb = nxb + NCmax;                                          // [NCmax] by | ey << 16
     uint32_t* s_wave = nyb + NCmax;                                       // [16]
-    uint32_t* s_misc = s_wave + 16;                                       // [80 + 256]: [0..63] root counts / root pos, [64..] scalars, [80..] root-child counts
+    uint32_t* s_misc = s_wave + 16;                                       // [16] scalars: [0] list size, [1] split count of the sorted phase
+    uint32_t* s_root = s_misc + 16;                                       // [Rmax] list position of a root patch (0xFFFF: empty)
+    uint32_t* s_rcc = s_root + Rmax;                                      // [4 Rmax] the root patches' child counts
 
     OVS_TT_DECL
     OVS_TT_MARK();
@@ -148,8 +150,8 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
     //      counts every candidate into its root AND into the root's child it falls in (the first pass's child counts).
     const int gx = g.gx, gy = g.gy, nroot = gx * gy;
     const double dx = g.dx, dy = g.dy;
-    if (tid < 64) s_misc[tid] = 0;
-    for (int i = tid; i < 256; i += kTreeThreads) s_misc[80 + i] = 0;
+    if (tid < 16) s_misc[tid] = 0;
+    for (int i = tid; i < 5 * Rmax; i += kTreeThreads) s_root[i] = 0;   // (s_rcc follows s_root)
     for (int i = tid; i < NN; i += kTreeThreads) child_cnt[i] = 0;
     __syncthreads();
     // Every candidate sweep works on kSweepLoads candidates per thread at a time, in three separate steps -- all loads, then all LDS
@@ -176,8 +178,8 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
         for (int u = 0; u < kSweepLoads; ++u) {
             const uint32_t i = i0 + u * kTreeThreads;
             if (i < n) {
-                atomicAdd(&s_misc[80 + key[u]], 1u);   // the root's own count is the sum of its four child counts
-                list[i] = (cc[u] & ~0xFFFFull) | (key[u] >> 2);   // the root's raw index; the first pass maps it to the list position through s_misc
+                atomicAdd(&s_rcc[key[u]], 1u);   // the root's own count is the sum of its four child counts
+                list[i] = (cc[u] & ~0xFFFFull) | (key[u] >> 2);   // the root's raw index; the first pass maps it to the list position through s_root
             }
         }
     }
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
     if (tid == 0) {
         uint32_t pos = 0;
         for (int r = 0; r < nroot; ++r) {
-            const uint32_t cnt = s_misc[80 + 4 * r] + s_misc[80 + 4 * r + 1] + s_misc[80 + 4 * r + 2] + s_misc[80 + 4 * r + 3];
+            const uint32_t cnt = s_rcc[4 * r] + s_rcc[4 * r + 1] + s_rcc[4 * r + 2] + s_rcc[4 * r + 3];
             if (cnt) {
                 const int ix = r % gx, iy = r / gx;
                 NodeRec rec;
@@ -195,15 +197,15 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
                 rec.pad = 0;
                 cur[pos] = rec;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) child_cnt[4 * pos + k] = cnt > 1 ? s_misc[80 + 4 * r + k] : 0u;   // leaves carry no child counts
-                s_misc[r] = pos++;
+                for (int k = 0; k < 4; ++k) child_cnt[4 * pos + k] = cnt > 1 ? s_rcc[4 * r + k] : 0u;   // leaves carry no child counts
+                s_root[r] = pos++;
             } else
-                s_misc[r] = 0xFFFFu;
+                s_root[r] = 0xFFFFu;
         }
-        s_misc[64] = pos;   // list size
+        s_misc[0] = pos;   // list size
     }
     __syncthreads();
-    uint32_t size = s_misc[64];
+    uint32_t size = s_misc[0];
     bool first_pass = true, done_final = false;
     unsigned long long* best = nullptr;
 
@@ -305,15 +307,15 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
                 }
             }
             // first rank at which #nodes reaches N
-            if (tid == 0) s_misc[65] = npool_cur;   // M candidate (atomicMin below)
+            if (tid == 0) s_misc[1] = npool_cur;   // M candidate (atomicMin below)
             __syncthreads();
             array_excl_scan<kTreeThreads>(base, base, (int)npool_cur, s_wave);   // base[r] = gain of ranks < r
             for (uint32_t r = tid; r < npool_cur; r += kTreeThreads) {
                 const uint32_t after = size + base[r] + (nch[sidx[r]] - 1u);
-                if (after >= N) atomicMin(&s_misc[65], r + 1u);
+                if (after >= N) atomicMin(&s_misc[1], r + 1u);
             }
             __syncthreads();
-            M = s_misc[65];
+            M = s_misc[1];
             for (uint32_t j = tid; j < size; j += kTreeThreads) rank[j] = kNotInS;
             __syncthreads();
             for (uint32_t r = tid; r < M; r += kTreeThreads) rank[sidx[r]] = r;
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
 #pragma unroll
             for (int u = 0; u < kSweepLoads; ++u) {
                 const uint32_t raw = (uint32_t)cc[u] & 0xFFFFu;
-                nd[u] = first_pass ? s_misc[raw & 63u] : raw;
+                nd[u] = first_pass ? s_root[min(raw, (uint32_t)Rmax - 1u)] : raw;
                 if (!(i0 + u * kTreeThreads < n)) nd[u] = 0;
             }
 #pragma unroll
@@ -496,8 +498,14 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
     if (tid == 0) lvl_count[frame * L + level] = size < kp_cap ? size : kp_cap;
 }
 
-static size_t tree_lds_bytes(int NCmax, int P2max) {
-    return (size_t)(12 * NCmax) * 4 + (size_t)NCmax * 5 * 4 + (size_t)P2max * 4 + (size_t)NCmax * 2 * 4 + 16 * 4 + (80 + 256) * 4;
+static size_t tree_lds_bytes(int NCmax, int P2max, int Rmax) {
+    return (size_t)(12 * NCmax) * 4 + (size_t)NCmax * 5 * 4 + (size_t)P2max * 4 + (size_t)NCmax * 2 * 4 + 16 * 4 + (16 + 5 * (size_t)Rmax) * 4;
+}
+// root patches of the widest root grid, at least 64 (a multiple of 4)
+static int tree_root_cap(const FrameGeo& hgeo) {
+    int r = 64;
+    for (int l = 0; l < hgeo.num_levels; ++l) r = std::max(r, hgeo.lv[l].gx * hgeo.lv[l].gy);
+    return (r + 3) & ~3;
 }
 
 // LDS the quad-tree kernel needs for this geometry (its per-node arrays are sized by the largest level); build_geometry refuses
@@ -508,7 +516,7 @@ size_t tree_lds_bytes_for(const FrameGeo& hgeo) {
     NCmax = (NCmax + 3) & ~3;
     int P2max = 1;
     while (P2max < NCmax) P2max <<= 1;
-    return tree_lds_bytes(NCmax, P2max);
+    return tree_lds_bytes(NCmax, P2max, tree_root_cap(hgeo));
 }
 
 hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hipStream_t s, int level_lo, int n_levels) {
@@ -519,7 +527,8 @@ hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hip
     NCmax = (NCmax + 3) & ~3;
     int P2max = 1;
     while (P2max < NCmax) P2max <<= 1;
-    const size_t lds = tree_lds_bytes(NCmax, P2max);
+    const int Rmax = tree_root_cap(hgeo);
+    const size_t lds = tree_lds_bytes(NCmax, P2max, Rmax);
     // A sweep over a level's candidates is bound by one workgroup's instruction latency (two waves per SIMD at 512 threads), not by
     // memory: with few problems in the launch (a tracker's single frame) 1024 threads halve it; with many, 512 threads let more
     // problems share a CU and win (0.247 vs 0.278 ms per 128 frames).
@@ -533,10 +542,10 @@ hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hip
     dim3 grid(n_levels, batch);
     if (few)
         hipLaunchKernelGGL(k_tree<kTreeThreadsFew>, grid, dim3(kTreeThreadsFew), lds, s, d.geo, d.cand, d.cand_frame_entries, d.cand_count,
-                           reinterpret_cast<NodeRec*>(d.nodes), d.node_frame_entries, d.lvl_kps, d.lvl_count, NCmax, P2max, level_lo);
+                           reinterpret_cast<NodeRec*>(d.nodes), d.node_frame_entries, d.lvl_kps, d.lvl_count, NCmax, P2max, Rmax, level_lo);
     else
         hipLaunchKernelGGL(k_tree<kTreeThreadsBatch>, grid, dim3(kTreeThreadsBatch), lds, s, d.geo, d.cand, d.cand_frame_entries, d.cand_count,
-                           reinterpret_cast<NodeRec*>(d.nodes), d.node_frame_entries, d.lvl_kps, d.lvl_count, NCmax, P2max, level_lo);
+                           reinterpret_cast<NodeRec*>(d.nodes), d.node_frame_entries, d.lvl_kps, d.lvl_count, NCmax, P2max, Rmax, level_lo);
     return hipGetLastError();
 }
 

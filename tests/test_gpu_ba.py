@@ -428,8 +428,30 @@ def test_dense_solve_matches_numpy(n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [48, 288, 304])
+def test_dense_solve_failure_then_success(n):
+    """launch_dense_solve's contract (ba_solve.hip): a system that is not positive definite is REPORTED (OVS_ERR_INVALID, never a silent NaN solution),
+    for the register-resident kernel (n <= 288) and the through-memory one alike, and the next solve of a positive definite system is unaffected."""
+    from openvslam_amd import ba
+    rng = np.random.default_rng(7 + n)
+    S = _spd(rng, n, 1e3)
+    rhs = rng.standard_normal(n)
+    bad = S.copy()
+    bad[n // 2, n // 2] = -abs(bad[n // 2, n // 2])   # a negative pivot in the middle of the factorisation
+    with pytest.raises(Exception):
+        ba.dense_solve(bad, rhs)
+    nan = S.copy()
+    nan[0, 0] = np.nan
+    with pytest.raises(Exception):
+        ba.dense_solve(nan, rhs)
+    x = ba.dense_solve(S, rhs)
+    want = np.linalg.solve(S, rhs)
+    assert np.all(np.isfinite(x)) and np.abs(x - want).max() / np.abs(want).max() < 1e-10
+
+
+@pytest.mark.gpu
 def test_landmark_workgroup_shapes_give_the_same_bits(tmp_path):
-    """k_linearize / k_trial_update give a workgroup 128 landmarks while the launch fits the chip in one go and 256 beyond (maps of more than ~59 k
+    """k_trial_update gives a workgroup 128 landmarks while the launch fits the chip in one go and 256 beyond (maps of more than ~59 k
     landmarks: no other test is that large). The shape must not change a bit: a child process with OVS_BA_LM_PER_WG=256 (read once per process)
     against this process (128 at these sizes) on one linearisation and on a whole ovs_local_ba_optimize, stereo edges included."""
     import subprocess
