@@ -139,9 +139,18 @@ def test_refused_geometry_leaves_the_handle_usable(oracle):
     img = synth_frame(480, 752, seed=3)
     ex = feature.orb_extractor(feature.orb_params(max_num_keypts=1000), max_rows=480, max_cols=1920)
     k0, d0 = ex.extract(img)
-    with pytest.raises(_lib.OvsError) as e:
-        ex.extract(synth_frame(60, 1920, seed=4))
-    assert e.value.status in (-1, -4)
+    refused = 0
+    for rows, cols in ((60, 1920), (46, 1920), (40, 1920)):   # 85, 235 and 941 root patches on level 0
+        strip = synth_frame(rows, cols, seed=4)
+        try:
+            ks, ds = ex.extract(strip)
+        except _lib.OvsError as e:
+            assert e.status in (-1, -4)
+            refused += 1
+            continue
+        ws, wds = oracle.OrbExtractor(oracle.make_params(1000)).extract(strip)   # a strip the handle's capacities cover runs, and runs right
+        assert np.array_equal(ks.view(np.uint8), ws.view(np.uint8)) and np.array_equal(ds, wds), (rows, cols)
+    assert refused >= 1
     k1, d1 = ex.extract(img)
     wk, wd = oracle.OrbExtractor(oracle.make_params(1000)).extract(img)
     assert np.array_equal(k1.view(np.uint8), wk.view(np.uint8)) and np.array_equal(d1, wd)
