@@ -19,11 +19,19 @@
 // "max response per node" directly. One sweep over the candidates per pass plus one at the start (root and root-child counts), instead
 // of two per pass plus four: 1 + P against 2 P + 4 for P passes (P ~ 6-8).
 //
+// Grid form (round 6, batches): the candidates are counted ONCE into a separable grid of the finest depth, every count a pass needs is a
+// look-up in the pyramid of sums above it, and one last pass finds each candidate's final node through the nodes' cell marks: two passes over
+// the candidates instead of 1 + P. Same node machinery, same results; the sweep form stays as the path for single frames and for problems
+// the grid cannot finish (see tree_problem).
+//
 // One 512-thread workgroup per (level, frame) problem (1024 threads finish one problem sooner, 0.076 vs 0.087 ms per 32 frames, but only two
 // such workgroups fit a CU; at 128 frames per launch 512 threads win, 0.247 vs 0.278 ms); node lists (< 4N+64 records) ping-pong in an L2-resident global
 // scratch, everything else lives in LDS. The kernel is latency-bound by design (a handful of passes over ~10^4
 // candidates); throughput comes from running levels x frames problems concurrently.
 #include "ovs_common.h"
+
+#include <algorithm>
+#include <cstdlib>
 
 namespace ovs {
 
@@ -100,13 +108,36 @@ __device__ __forceinline__ uint32_t array_excl_scan(const uint32_t* in, uint32_t
     return total;
 }
 
-template <int kTreeThreads>
-__global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restrict__ geo, uint64_t* __restrict__ cand,
-                                                      size_t cand_frame_entries, const uint32_t* __restrict__ cand_count,
-                                                      NodeRec* __restrict__ nodes, size_t node_frame_entries,
-                                                      uint64_t* __restrict__ lvl_kps, uint32_t* __restrict__ lvl_count, int NCmax,
-                                                      int P2max, int Rmax, int level_lo) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// ---- the count pyramid of the grid form (round 6) ------------------------------------------------------------------------------------
+// A node's split point is a function of its bounds alone and the bounds are the root patch's, halved (ceil) once per depth and axis: the nodes of
+// depth d are the cells of a SEPARABLE grid of (gx << d) x (gy << d) intervals. So the candidates are counted ONCE into the grid of depth D
+// (one LDS atomic each), the coarser grids are sums of four, and every count the passes need -- a node's, its children's -- is a look-up:
+// the passes touch nodes only (rounds 1-5 swept all candidates once per pass: 39 of a single 1080p frame's 56 us). At the end the final nodes
+// mark their cells and one more pass over the candidates feeds "max response per node". Entries are 16-bit (two per LDS word).
+// depth of the finest grid for a level that wants N keypoints from `roots` root patches: one more than the depth at which a UNIFORM tree would
+// reach N nodes (clustered corners go deeper; a level whose tree would go deeper still takes the sweep form), between 4 and 7. Measured at
+// 1080p / N = 434 per 256 frames: depth 4 / 5 / 6 / 7 = 0.212 / 0.216 / 0.270 / 0.489 ms (sweep form 0.307), depth 3 falls back (0.429).
+__host__ __device__ inline int tree_grid_depth(int N, int roots) {
+    int k = 0;
+    while (k < 7 && ((long long)roots << (2 * k)) < (long long)N) ++k;
+    return k + 1 < 4 ? 4 : (k + 1 > 7 ? 7 : k + 1);
+}
+struct GridDims {
+    int D;                 // depth of the finest grid
+    int r0, nroot;         // root patches (r0: rounded up to an even number)
+    int gx, gy;
+    // first entry of depth d's grid: the depths' blocks follow each other, each an even number of entries (depth 0: r0, depth t >= 1: nroot * 4^t)
+    __device__ __forceinline__ int off(int d) const { return d == 0 ? 0 : r0 + nroot * ((((1 << (2 * d)) - 4)) / 3); }
+};
+__device__ __forceinline__ uint32_t grid_get(const uint32_t* w, int idx) { return (w[idx >> 1] >> (16 * (idx & 1))) & 0xFFFFu; }
+// One (level, frame) problem by one workgroup. kGrid: the grid form; returns false (workgroup-uniform) when it cannot finish -- the grid does
+// not fit, or a node of the finest depth would have to be split -- and has then written nothing but LDS: the caller runs the sweep form.
+template <int kTreeThreads, bool kGrid>
+__device__ __forceinline__ bool tree_problem(unsigned char* smem, const FrameGeo* __restrict__ geo, uint64_t* __restrict__ cand,
+                                             size_t cand_frame_entries, const uint32_t* __restrict__ cand_count,
+                                             NodeRec* __restrict__ nodes, size_t node_frame_entries,
+                                             uint64_t* __restrict__ lvl_kps, uint32_t* __restrict__ lvl_count, int NCmax,
+                                             int P2max, int Rmax, int grid_words, int grid_depth, int level, int frame, int level_lo) {
     // ---- LDS carve (all offsets multiples of 16)
     const int NN = 4 * NCmax;
     uint32_t* child_cnt = reinterpret_cast<uint32_t*>(smem);             // [NN] count of child k of current node j at 4j+k
@@ -125,11 +156,11 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
     uint32_t* s_misc = s_wave + 16;                                       // [16] scalars: [0] list size, [1] split count of the sorted phase
     uint32_t* s_root = s_misc + 16;                                       // [Rmax] list position of a root patch (0xFFFF: empty)
     uint32_t* s_rcc = s_root + Rmax;                                      // [4 Rmax] the root patches' child counts
+    uint32_t* gridw = s_rcc + 4 * Rmax;                                   // [grid_words] the count pyramid (grid form), two entries per word
 
     OVS_TT_DECL
     OVS_TT_MARK();
     const int tid = threadIdx.x;
-    const int level = level_lo + (int)blockIdx.x, frame = blockIdx.y;   // the launch covers levels [level_lo, level_lo + gridDim.x)
     const int L = geo->num_levels;
     const LevelGeo& g = geo->lv[level];
     const uint32_t switch_factor = (geo->variant & 1) ? 1u : 3u;   // ORACLE_SPEC rule 6
@@ -143,21 +174,182 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
     uint64_t* out = lvl_kps + (size_t)frame * geo->total_kp_cap + g.kp_base;
     if (n == 0) {
         if (tid == 0) lvl_count[frame * L + level] = 0;
-        return;
+        return true;
     }
 
     // ---- initialize_nodes: root patches, candidates to roots (double division, as upstream's keypt.pt.x / delta_x). The same sweep
     //      counts every candidate into its root AND into the root's child it falls in (the first pass's child counts).
     const int gx = g.gx, gy = g.gy, nroot = gx * gy;
     const double dx = g.dx, dy = g.dy;
-    if (tid < 16) s_misc[tid] = 0;
+    GridDims gd;
+    gd.D = 0;
+    gd.gx = gx;
+    gd.gy = gy;
+    gd.nroot = nroot;
+    gd.r0 = (nroot + 1) & ~1;
+    uint32_t* rc = gridw;    // [4 (gx + gy)] per root column / row: first pixel b, length, ceil(2^32 / length), first pixel of the patch index
+    uint32_t* tabw = gridw;  // [(gx + gy) (2^D + 1)] 16-bit: the cells' first pixels relative to b (entry 2^D: the length), per root column / row
+    bool cache_cells = false;
+    if (kGrid) {
+        // the deepest grid that fits: entries of depths 0 .. D (each depth's block padded to an even count), 12-bit cell indices; the
+        // root patches' tables behind it. Root grids of more than 8 patches along an axis (strips) take the sweep form.
+        if (n > 65535u || gx > 8 || gy > 8) return false;
+        int D = -1;
+        const int Dwant = grid_depth > 0 ? grid_depth : tree_grid_depth((int)N, nroot);
+        for (int t = 1; t <= Dwant; ++t) {
+            int tot = 0;
+            for (int d = 0; d <= t; ++d) tot += ((nroot << (2 * d)) + 1) & ~1;
+            if (tot / 2 + 4 * (gx + gy) + ((gx + gy) * ((1 << t) + 1) + 1) / 2 <= grid_words && (gx << t) <= 4096 && (gy << t) <= 4096) D = t;
+        }
+        if (D < 2) return false;
+        if (tid < 16) s_misc[tid] = tid == 3 ? 0xFFFFFFFFu : 0u;
+        for (int i = tid; i < grid_words / 4; i += kTreeThreads) reinterpret_cast<uint4*>(gridw)[i] = uint4{0u, 0u, 0u, 0u};   // (grid_words is a multiple of 4)
+        __syncthreads();
+        // per root column / row (thread i): its pixel interval as initialize_nodes computes it, the reciprocal of its length, and the first
+        // pixel upstream's (int)(x / delta) sends to patch i -- found with that very expression, so the patch of a pixel is a comparison
+        uint32_t* rc0 = gridw + grid_words - 4 * (gx + gy);   // (the end of the region: its place does not depend on D)
+        if (tid < gx + gy) {
+            const bool ax = tid < gx;
+            const int r = ax ? tid : tid - gx;
+            const double dd = ax ? dx : dy;
+            const uint32_t b = (uint32_t)(int)(dd * r), e = (uint32_t)(int)(dd * (r + 1));
+            const uint32_t len = e > b ? e - b : 0u;
+            uint32_t thr = 0;
+            if (r > 0) {
+                int v = max(0, (int)(dd * r) - 3);
+                for (int guard = 0; guard < 16 && (uint32_t)((double)(float)v / dd) < (uint32_t)r; ++guard) ++v;
+                thr = (uint32_t)v;
+            }
+            rc0[4 * tid] = b;
+            rc0[4 * tid + 1] = len;
+            rc0[4 * tid + 2] = len ? (uint32_t)(((1ull << 32) + len - 1) / len) : 0u;
+            rc0[4 * tid + 3] = thr;
+            atomicMin(&s_misc[3], len);
+            atomicMax(&s_misc[4], len);
+        }
+        __syncthreads();
+        // cells of at least a pixel (the estimate below is then off by at most two) and an exact reciprocal division
+        const uint32_t lmin = s_misc[3], lmax = s_misc[4];
+        while (D >= 2 && ((1u << D) > lmin || ((unsigned long long)lmax * lmax << D) >= (1ull << 32))) --D;
+        if (D < 2) return false;
+        gd.D = D;
+        rc = rc0;
+        tabw = gridw + (gd.off(D + 1) + 1) / 2;
+        cache_cells = (gx << D) <= 256 && (gy << D) <= 256;
+        // the cells' first pixels: entry k of a root column / row by following k's bits down the D halvings (two entries per thread and word)
+        const int n1 = (1 << D) + 1, NT = (gx + gy) * n1;
+        for (int p2 = tid; 2 * p2 < NT; p2 += kTreeThreads) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = 2 * p2 + h;
+                if (e < NT) {
+                    const int i = e / n1, k = e - i * n1;
+                    uint32_t b = 0, en = rc[4 * i + 1];
+                    if (k == n1 - 1) b = en;
+                    else
+                        for (int d = 0; d < D; ++d) {
+                            const uint32_t c = b + ((en - b + 1u) >> 1);
+                            if ((k >> (D - 1 - d)) & 1) b = c;
+                            else en = c;
+                        }
+                    word |= (b & 0xFFFFu) << (16 * h);
+                }
+            }
+            tabw[p2] = word;
+        }
+    }
+    // a candidate's cell of the finest grid: root patch as upstream's double division decides it (through the first-pixel thresholds), then
+    // the D halvings per axis -- the cell is the estimate floor(u 2^D / length) or one of the two cells before it, settled by their first pixels
+    auto axis_cell = [&](uint32_t v, int i) -> uint32_t {
+        const int D = gd.D, n1 = (1 << D) + 1;
+        const uint32_t b = rc[4 * i], len = rc[4 * i + 1], mg = rc[4 * i + 2];
+        const uint32_t u = v > b ? min(v - b, len - 1u) : 0u;
+        const uint32_t est = min((uint32_t)(1 << D) - 1u, __umulhi(u << D, mg));
+        const uint32_t e1 = est > 0u ? est - 1u : 0u;
+        const uint32_t B0 = grid_get(tabw, i * n1 + (int)est), B1 = grid_get(tabw, i * n1 + (int)e1);
+        return est - (u < B0 ? 1u : 0u) - ((est > 0u && u < B1) ? 1u : 0u);
+    };
+    auto finest_cell = [&](uint64_t c, uint32_t& cx_, uint32_t& cy_) {
+        const uint32_t x = cand_x(c) - kOrbPatchRadius, y = cand_y(c) - kOrbPatchRadius;
+        int ix = 0, iy = 0;
+        for (int r = 1; r < gx; ++r) ix += x >= rc[4 * r + 3] ? 1 : 0;
+        for (int r = 1; r < gy; ++r) iy += y >= rc[4 * (gx + r) + 3] ? 1 : 0;
+        cx_ = ((uint32_t)ix << gd.D) + axis_cell(x, ix);
+        cy_ = ((uint32_t)iy << gd.D) + axis_cell(y, gx + iy);
+    };
+    if (!kGrid && tid < 16) s_misc[tid] = 0;   // (the grid form has initialised the scalars above)
     for (int i = tid; i < 5 * Rmax; i += kTreeThreads) s_root[i] = 0;   // (s_rcc follows s_root)
     for (int i = tid; i < NN; i += kTreeThreads) child_cnt[i] = 0;
-    __syncthreads();
+    __syncthreads();   // (grid form: the pyramid was cleared above, the tables are complete)
+    if (kGrid) {
+        OVS_TT_MARK();   // tables, cleared pyramid
+        // ---- the ONE counting pass: every candidate into its cell of the finest grid, then the coarser grids as sums of four
+        const int D = gd.D, WD = gx << D;
+        for (uint32_t i0 = tid; i0 < n; i0 += kTreeThreads * 8) {
+            uint64_t cc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cc[u] = i0 + u * kTreeThreads < n ? list[i0 + u * kTreeThreads] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u * kTreeThreads < n) {
+                    uint32_t cx_, cy_;
+                    finest_cell(cc[u], cx_, cy_);
+                    const int idx = gd.off(D) + (int)cy_ * WD + (int)cx_;
+                    atomicAdd(&gridw[idx >> 1], 1u << (16 * (idx & 1)));
+                    // the cell travels with the candidate (the node field of its list entry is free in this form) to the last pass
+                    if (cache_cells) list[i0 + u * kTreeThreads] = (cc[u] & ~0xFFFFull) | (cy_ << 8) | cx_;
+                }
+        }
+        __syncthreads();
+        OVS_TT_MARK();   // counting pass
+        // two depths per step (a thread adds a 4 x 2 block of depth d + 2 into two entries of depth d + 1 and one of depth d ... per pair of
+        // depth-d entries): half the barriers of one depth per step
+        for (int d = D - 1; d >= 0; d -= 2) {
+            const bool two = d >= 1;               // this step also produces depth d - 1
+            const int Wc = gx << (d + 1), Wd = gx << d, cnt_d = nroot << (2 * d);
+            // unit of work: a 2 x 2 block of depth-d entries (= one entry of depth d - 1): rows 2 y, 2 y + 1, columns 2 x, 2 x + 1
+            const int Wp = two ? (gx << (d - 1)) : 0, cnt_p = two ? (nroot << (2 * (d - 1))) : 0;
+            if (two) {
+                for (int e = tid; e < cnt_p; e += kTreeThreads) {
+                    const int y = e / Wp, x = e - y * Wp;
+                    uint32_t tot = 0;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        // depth-d entries (2 x, 2 y + r) and (2 x + 1, 2 y + r): each the sum of a 2 x 2 block of depth d + 1
+                        const int c0 = gd.off(d + 1) + (2 * (2 * y + r)) * Wc + 4 * x;
+                        const uint32_t t0 = gridw[c0 >> 1], t1 = gridw[(c0 >> 1) + 1], b0 = gridw[(c0 + Wc) >> 1], b1 = gridw[((c0 + Wc) >> 1) + 1];
+                        const uint32_t lo = (t0 & 0xFFFFu) + (t0 >> 16) + (b0 & 0xFFFFu) + (b0 >> 16), hi = (t1 & 0xFFFFu) + (t1 >> 16) + (b1 & 0xFFFFu) + (b1 >> 16);
+                        gridw[(gd.off(d) + (2 * y + r) * Wd + 2 * x) >> 1] = lo | (hi << 16);   // (2 x even, off even, Wd even for d >= 1)
+                        tot += lo + hi;
+                    }
+                    // depth d - 1: 16-bit halves of shared words are written by different threads -> an atomic OR into the cleared word
+                    const int ip = gd.off(d - 1) + e;
+                    atomicOr(&gridw[ip >> 1], tot << (16 * (ip & 1)));
+                }
+            } else {
+                for (int p2 = tid; 2 * p2 < cnt_d; p2 += kTreeThreads) {   // entries 2 p2 and 2 p2 + 1 of depth 0: one word
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int e = 2 * p2 + h;
+                        if (e < cnt_d) {
+                            const int y = e / Wd, x = e - y * Wd;
+                            const int c0 = gd.off(d + 1) + (2 * y) * Wc + 2 * x;
+                            const uint32_t top = gridw[c0 >> 1], bot = gridw[(c0 + Wc) >> 1];
+                            word |= ((top & 0xFFFFu) + (top >> 16) + (bot & 0xFFFFu) + (bot >> 16)) << (16 * h);
+                        }
+                    }
+                    gridw[(gd.off(d) >> 1) + p2] = word;
+                }
+            }
+            __syncthreads();
+        }
+    }
     // Every candidate sweep works on kSweepLoads candidates per thread at a time, in three separate steps -- all loads, then all LDS
     // look-ups, then all counter updates and stores -- so that the look-ups of different candidates overlap: written as one loop
     // they form a chain of dependent LDS round trips per candidate, because no LDS read may move across an LDS atomic.
-    for (uint32_t i0 = tid; i0 < n; i0 += kTreeThreads * kSweepLoads) {
+    for (uint32_t i0 = tid; !kGrid && i0 < n; i0 += kTreeThreads * kSweepLoads) {
         uint64_t cc[kSweepLoads];
         uint32_t key[kSweepLoads];
 #pragma unroll
@@ -187,14 +379,18 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
     if (tid == 0) {
         uint32_t pos = 0;
         for (int r = 0; r < nroot; ++r) {
+            const int ix = r % gx, iy = r / gx;
+            if (kGrid) {   // the root's children are the depth-1 cells (2 ix + (k & 1), 2 iy + (k >> 1))
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s_rcc[4 * r + k] = grid_get(gridw, gd.off(1) + (2 * iy + (k >> 1)) * (2 * gx) + 2 * ix + (k & 1));
+            }
             const uint32_t cnt = s_rcc[4 * r] + s_rcc[4 * r + 1] + s_rcc[4 * r + 2] + s_rcc[4 * r + 3];
             if (cnt) {
-                const int ix = r % gx, iy = r / gx;
                 NodeRec rec;
                 rec.xb = (uint32_t)(int)(dx * ix) | ((uint32_t)(int)(dx * (ix + 1)) << 16);
                 rec.yb = (uint32_t)(int)(dy * iy) | ((uint32_t)(int)(dy * (iy + 1)) << 16);
                 rec.count = cnt;
-                rec.pad = 0;
+                rec.pad = ((uint32_t)iy << 12) | (uint32_t)ix;   // depth << 24 | cell row << 12 | cell column (grid form)
                 cur[pos] = rec;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) child_cnt[4 * pos + k] = cnt > 1 ? s_rcc[4 * r + k] : 0u;   // leaves carry no child counts
@@ -355,6 +551,7 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
                 // divide_node: half = ceil((end - begin) / 2.0)
                 const uint32_t cx = bx + ((ex - bx + 1u) >> 1), cy = by + ((ey - by + 1u) >> 1);
                 uint32_t c = base[j];
+                const uint32_t dep = r.pad >> 24, gix = r.pad & 0xFFFu, giy = (r.pad >> 12) & 0xFFFu;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t cnt = child_cnt[4 * j + k];
@@ -365,16 +562,28 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
                         ch.xb = (k & 1) ? (cx | (ex << 16)) : (bx | (cx << 16));
                         ch.yb = (k & 2) ? (cy | (ey << 16)) : (by | (cy << 16));
                         ch.count = cnt;
-                        ch.pad = 0;
+                        const uint32_t cgx = 2u * gix + (uint32_t)(k & 1), cgy = 2u * giy + (uint32_t)(k >> 1);
+                        ch.pad = ((dep + 1u) << 24) | (cgy << 12) | cgx;
                         nxt[p] = ch;
                         cmap[4 * j + k] = p;
                         my_pool += cnt > 1 ? 1u : 0u;
+                        if (kGrid && !final_pass && cnt > 1u) {   // the child's own child counts: cells of depth dep + 2
+                            if ((int)dep + 2 > gd.D) {
+                                s_misc[2] = 1u;   // a node of the finest depth that may have to be split: the sweep form takes over
+                            } else {
+                                const int Wq = gx << (dep + 2);
+#pragma unroll
+                                for (int kk = 0; kk < 4; ++kk)
+                                    child_nxt[4 * p + kk] = grid_get(gridw, gd.off(dep + 2) + (int)(2u * cgy + (uint32_t)(kk >> 1)) * Wq + (int)(2u * cgx + (uint32_t)(kk & 1)));
+                            }
+                        }
                     }
                 }
             }
         }
         uint32_t npool_new;
         block_excl_scan<kTreeThreads>(my_pool, s_wave, npool_new);   // barriers inside: nxt / cmap / keep_pos / copied child counts now visible
+        if (kGrid && s_misc[2] != 0u) return false;                  // (workgroup-uniform: written before the scan's barriers)
 
         OVS_TT_MARK();   // step 5
         // ---- 6. one sweep over the candidates: move each to its new node and count it into that node's own children (the next pass's
@@ -388,7 +597,53 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
             __syncthreads();
         }
         const uint32_t ncx_cells = (uint32_t)g.ncx;
-        for (uint32_t i0 = tid; i0 < n; i0 += kTreeThreads * kSweepLoads) {
+        if (kGrid && final_pass) {
+            // the final nodes mark their cells (node + 1 at the node's own depth; the leaves partition the plane, so every candidate has exactly
+            // one marked ancestor cell), then ONE pass over the candidates: all D + 1 ancestor cells are read, the marked one names the node
+            {
+                const int words = gd.off(gd.D + 1) / 2;   // the pyramid only: the tables behind it may still be read (finest_cell)
+                for (int i = tid; i < words / 4; i += kTreeThreads) reinterpret_cast<uint4*>(gridw)[i] = uint4{0u, 0u, 0u, 0u};
+                if (tid < (words & 3)) gridw[(words & ~3) + tid] = 0u;
+            }
+            __syncthreads();
+            for (uint32_t j = tid; j < new_size; j += kTreeThreads) {
+                const uint32_t pad = nxt[j].pad, dep = pad >> 24;
+                const int idx = gd.off(dep) + (int)((pad >> 12) & 0xFFFu) * (gx << dep) + (int)(pad & 0xFFFu);
+                atomicOr(&gridw[idx >> 1], (j + 1u) << (16 * (idx & 1)));
+            }
+            __syncthreads();
+            OVS_TT_MARK();   // final nodes' marks
+            const int D = gd.D;
+            for (uint32_t i0 = tid; i0 < n; i0 += kTreeThreads * 4) {
+                uint64_t cc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cc[u] = i0 + u * kTreeThreads < n ? list[i0 + u * kTreeThreads] : 0ull;
+                uint32_t node[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    uint32_t cx_, cy_;
+                    if (cache_cells) {
+                        cx_ = (uint32_t)cc[u] & 0xFFu;
+                        cy_ = ((uint32_t)cc[u] >> 8) & 0xFFu;
+                    } else {
+                        finest_cell(cc[u], cx_, cy_);
+                    }
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int d = 0; d <= 7; ++d)   // all ancestor cells are read at once (independent look-ups); depths beyond D do not exist
+                        if (d <= D) m |= grid_get(gridw, gd.off(d) + (int)(cy_ >> (D - d)) * (gx << d) + (int)(cx_ >> (D - d)));
+                    node[u] = m - 1u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u * kTreeThreads < n && node[u] < new_size) {
+                        const uint64_t c = cc[u];
+                        const unsigned long long key = ((unsigned long long)(cand_score(c) + 1u) << 32) | (0xFFFFFFFFu - cand_order(cand_x(c), cand_y(c), ncx_cells));
+                        __hip_atomic_fetch_max(&best[node[u]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+            }
+        }
+        for (uint32_t i0 = tid; !kGrid && i0 < n; i0 += kTreeThreads * kSweepLoads) {
             uint64_t cc[kSweepLoads];
             uint32_t pp[kSweepLoads], gc[kSweepLoads];   // new node; counter of the new node's child the candidate falls in (or ~0)
 #pragma unroll
@@ -472,6 +727,7 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
 
     // ---- find_keypoints_with_max_response; output in list order
     const uint32_t ncx = (uint32_t)g.ncx;
+    if (kGrid && !done_final) return false;   // (the grid form keeps no node ids in the candidate list)
     if (!done_final) {   // not reachable (the loop ends through its last pass); kept so that an exhausted guard still yields keypoints
         best = reinterpret_cast<unsigned long long*>(smem);   // both child-count arrays: max_nodes entries
         for (uint32_t j = tid; j < size; j += kTreeThreads) best[j] = 0ull;
@@ -496,6 +752,24 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restric
     OVS_TT_MARK();
     OVS_TT_PRINT(n);
     if (tid == 0) lvl_count[frame * L + level] = size < kp_cap ? size : kp_cap;
+    return true;
+}
+
+template <int kTreeThreads>
+__global__ __launch_bounds__(kTreeThreads) void k_tree(const FrameGeo* __restrict__ geo, uint64_t* __restrict__ cand,
+                                                      size_t cand_frame_entries, const uint32_t* __restrict__ cand_count,
+                                                      NodeRec* __restrict__ nodes, size_t node_frame_entries,
+                                                      uint64_t* __restrict__ lvl_kps, uint32_t* __restrict__ lvl_count, int NCmax,
+                                                      int P2max, int Rmax, int grid_words, int grid_depth, int level_lo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int level = level_lo + (int)blockIdx.x, frame = blockIdx.y;   // the launch covers levels [level_lo, level_lo + gridDim.x)
+    // the grid form first (round 6); the sweep form of rounds 1-5 when the grid cannot finish the problem (rare: see tree_problem)
+    if (grid_words > 0 && tree_problem<kTreeThreads, true>(smem, geo, cand, cand_frame_entries, cand_count, nodes, node_frame_entries, lvl_kps, lvl_count,
+                                                           NCmax, P2max, Rmax, grid_words, grid_depth, level, frame, level_lo))
+        return;
+    __syncthreads();
+    tree_problem<kTreeThreads, false>(smem, geo, cand, cand_frame_entries, cand_count, nodes, node_frame_entries, lvl_kps, lvl_count, NCmax, P2max, Rmax,
+                                      grid_words, grid_depth, level, frame, level_lo);
 }
 
 static size_t tree_lds_bytes(int NCmax, int P2max, int Rmax) {
@@ -528,11 +802,32 @@ hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hip
     int P2max = 1;
     while (P2max < NCmax) P2max <<= 1;
     const int Rmax = tree_root_cap(hgeo);
-    const size_t lds = tree_lds_bytes(NCmax, P2max, Rmax);
-    // A sweep over a level's candidates is bound by one workgroup's instruction latency (two waves per SIMD at 512 threads), not by
-    // memory: with few problems in the launch (a tracker's single frame) 1024 threads halve it; with many, 512 threads let more
-    // problems share a CU and win (0.247 vs 0.278 ms per 128 frames).
+    const size_t lds_base = tree_lds_bytes(NCmax, P2max, Rmax);
+    // The kernel is bound by one workgroup's instruction latency, not by memory: with few problems in the launch (a tracker's single frame)
+    // 1024 threads halve it; with many, 512 threads let more problems share a CU and win (0.247 vs 0.278 ms per 128 frames).
     const bool few = (long long)n_levels * batch <= 64;
+    // the count pyramid of the grid form (tree_grid_depth per level): whatever the launch's levels need, and what the 160 KB leave
+    size_t grid_words = 0;
+    static const int forced = [] {
+        const char* e = std::getenv("OVS_TREE_GRID");   // A/B switch: 0 = the sweep form of rounds 1-5 only, d = the finest grid's depth
+        return e ? std::atoi(e) : -1;
+    }();
+    const int grid_depth = forced > 0 ? std::min(forced, 7) : 0;
+    // A tracker's single frame keeps the sweep form: one workgroup has a CU to itself there and both forms take the same ~56 us (measured
+    // 56.9 against 55.5: its passes over the candidates are replaced by tables, a cleared pyramid and a second pass of the same latency), while
+    // in a batch, where the problems share the CUs' vector ALUs, the grid form's fewer instructions count (0.307 -> 0.218 ms per 256 frames).
+    if (forced != 0 && (!few || forced > 0)) {
+        for (int l = level_lo; l < level_lo + n_levels; ++l) {
+            const size_t roots = (size_t)hgeo.lv[l].gx * hgeo.lv[l].gy, axes = (size_t)hgeo.lv[l].gx + hgeo.lv[l].gy;
+            const int D = grid_depth > 0 ? grid_depth : tree_grid_depth(hgeo.lv[l].n_keypts, (int)roots);
+            size_t entries = 0;
+            for (int d = 0; d <= D; ++d) entries += ((roots << (2 * d)) + 1) & ~(size_t)1;
+            grid_words = std::max(grid_words, entries / 2 + 4 * axes + (axes * ((1u << D) + 1) + 1) / 2 + 4);   // + the root columns' / rows' tables
+        }
+        const size_t room = lds_base + 1024 < kMaxLdsPerWorkgroup ? (kMaxLdsPerWorkgroup - lds_base - 1024) / 4 : 0;
+        grid_words = std::min(std::min(grid_words, room), (size_t)(24 * 1024 / 4)) & ~(size_t)3;   // (at most 24 KB: three problems still share a CU in a batch)
+    }
+    const size_t lds = lds_base + 4 * grid_words;
     static LdsAttrCache configured[2];   // per device
     const void* fn = few ? reinterpret_cast<const void*>(k_tree<kTreeThreadsFew>) : reinterpret_cast<const void*>(k_tree<kTreeThreadsBatch>);
     {
@@ -542,10 +837,10 @@ hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hip
     dim3 grid(n_levels, batch);
     if (few)
         hipLaunchKernelGGL(k_tree<kTreeThreadsFew>, grid, dim3(kTreeThreadsFew), lds, s, d.geo, d.cand, d.cand_frame_entries, d.cand_count,
-                           reinterpret_cast<NodeRec*>(d.nodes), d.node_frame_entries, d.lvl_kps, d.lvl_count, NCmax, P2max, Rmax, level_lo);
+                           reinterpret_cast<NodeRec*>(d.nodes), d.node_frame_entries, d.lvl_kps, d.lvl_count, NCmax, P2max, Rmax, (int)grid_words, grid_depth, level_lo);
     else
         hipLaunchKernelGGL(k_tree<kTreeThreadsBatch>, grid, dim3(kTreeThreadsBatch), lds, s, d.geo, d.cand, d.cand_frame_entries, d.cand_count,
-                           reinterpret_cast<NodeRec*>(d.nodes), d.node_frame_entries, d.lvl_kps, d.lvl_count, NCmax, P2max, Rmax, level_lo);
+                           reinterpret_cast<NodeRec*>(d.nodes), d.node_frame_entries, d.lvl_kps, d.lvl_count, NCmax, P2max, Rmax, (int)grid_words, grid_depth, level_lo);
     return hipGetLastError();
 }
 
