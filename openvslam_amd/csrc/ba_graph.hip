@@ -679,10 +679,8 @@ __device__ __forceinline__ void schur_pair(const int pr, const int32_t* __restri
     take(qn);
 #pragma unroll
     for (int i = 0; i < 36; ++i) {
-        double x = acc[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-        if (lane == 0) s_part[wave][i] = x;
+        const double x = wave_sum_lane63(acc[i]);   // (round 6: data-parallel moves instead of 12 ds_bpermute per value -- 432 of a wave's 461 LDS instructions)
+        if (lane == 63) s_part[wave][i] = x;
     }
     __syncthreads();
     if (threadIdx.x < 36) {
