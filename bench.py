@@ -558,9 +558,11 @@ def main():
                                              "insts_source": "rocprofv3 --pmc SQ_INSTS_VALU child pass of this run" if live_valu is not None
                                              else "profiles/pmc_traffic.json (SQ_INSTS_VALU pass)",
                                              "floor_model": "256 CUs x 4 SIMDs x 2.4 GHz / 3.32 cycles per VALU wave-instruction (mixed-stream microbenchmark "
-                                                            "at 7 waves per SIMD, weighted by the kernel's instruction mix); about 0.37 of the issue slots "
-                                                            "are free: the kernel is bound by a cell's latency chain (LDS gathers with bank conflicts, "
-                                                            "six barriers) together with the vector ALU, not by the ALU alone"}
+                                                            "at 7 waves per SIMD, weighted by the kernel's instruction mix). Rounds 3-5 ran at 0.61-0.63 of it: "
+                                                            "what kept the slots free was the wait for a cell's tile, and round 6's group-major work order "
+                                                            "(neighbouring workgroups read neighbouring pieces of the same image rows: HBM-side traffic 1.28x -> "
+                                                            "1.0x the algorithmic bytes) brought it to ~0.8; what is left is the instruction count itself "
+                                                            "(~2100 wave-instructions per 64x64 cell, the same in the barrier-free one-wave-per-cell form)"}
         # ---- per-call latency of orb_extractor::extract through the C++ class boundary at THIS config's size, H2D / D2H
         # included (openvslam_amd/cpp/bench_shim; one call = one upload, one kernel chain, one D2H, one wait)
         class_lat = None

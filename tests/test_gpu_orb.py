@@ -238,6 +238,55 @@ def test_large_batch_takes_the_many_problem_tree_kernel(hip, oracle):
             assert np.array_equal(desc[b, :cnt[b]], wd)
 
 
+def test_alternative_kernel_forms_give_the_same_bytes(tmp_path):
+    """Round 6 left four process-wide switches between kernel forms (read once per process, so each runs in a child): the one-wavefront-per-cell
+    FAST (OVS_FAST_IMPL=2), the frames-fastest work order of rounds 3-5 (OVS_FAST_MAP=0), the quad-tree's sweep form only (OVS_TREE_GRID=0) and
+    its grid form at a forced depth (OVS_TREE_GRID=3: most levels overflow and fall back inside the launch; 7: the deepest grid). Every one must
+    reproduce the default's counts, keypoint records and descriptors byte for byte on a 70-frame batch (which the test above checks against
+    the oracle)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, hashlib, numpy as np
+sys.path.insert(0, %r)
+import torch
+from openvslam_amd import feature
+from openvslam_amd.synth import synth_frame
+rows, cols, B = 240, 320, 70
+imgs = np.stack([synth_frame(rows, cols, seed=200 + b) for b in range(B)])
+ex = feature.orb_extractor(feature.orb_params(max_num_keypts=400), max_rows=rows, max_cols=cols, max_batch=B)
+cap = ex.max_keypoints
+d_img = torch.from_numpy(imgs).cuda()
+d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+d_cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
+h = hashlib.sha256()
+for split in (True, False):
+    ex.set_fast_split(split)
+    ex.extract_batch_dev(d_img, d_kps, d_desc, d_cnt, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    cnt = d_cnt.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+    desc = d_desc.cpu().numpy()
+    h.update(cnt.tobytes())
+    for b in range(B):
+        h.update(kps[b, :cnt[b]].tobytes())
+        h.update(desc[b, :cnt[b]].tobytes())
+print("SHA", h.hexdigest(), int(cnt.sum()))
+"""
+    out = {}
+    for tag, env in (("default", {}), ("wave", {"OVS_FAST_IMPL": "2"}), ("frames_fastest", {"OVS_FAST_MAP": "0"}), ("sweeps", {"OVS_TREE_GRID": "0"}),
+                     ("grid3", {"OVS_TREE_GRID": "3"}), ("grid7", {"OVS_TREE_GRID": "7"})):
+        r = subprocess.run([sys.executable, "-c", code % root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        line = [l for l in r.stdout.splitlines() if l.startswith("SHA")][-1].split()
+        out[tag] = line[1]
+        assert int(line[2]) > 1000
+    for tag, sha in out.items():
+        assert sha == out["default"], tag
+
+
 @pytest.mark.parametrize("split", [True, False])
 def test_timed_regime_1080p_batch_of_64_against_the_oracle(hip, oracle, split):
     """The regime bench.py times (SURVEY 8(d), configs[1]): a device-resident 1920x1080 batch of 64 frames, 2000 features -- six-cell FAST
