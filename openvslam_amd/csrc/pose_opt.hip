@@ -261,16 +261,20 @@ __device__ __forceinline__ double pose_edge_impl(const double* R, const double* 
 constexpr int kPoseMaxObs = 8192;   // <= 32 observations per thread: the inlier flags of a thread fit one register
 // one workgroup per frame, kPoseThreads threads (template parameter: 256 / 512 / 1024, chosen per launch)
 
-template <int MODEL, int kPoseThreads>   // MODEL 0 perspective (mono / stereo edges), 1 equirectangular (mono edges)
+// KREG (round 6): 2 = the launcher knows that no thread owns more than two observations (n <= 2 G kPoseThreads: every tracked frame on the
+// G > 1 path): a thread then loads ITS two 64-byte records once, before the first round, and every one of the ~50 passes of a call reads
+// them from registers -- a pass started with a dependent trip to L2 (~1 us of a ~6 us iteration). 0 = records re-read from memory per pass.
+template <int MODEL, int kPoseThreads, int KREG>   // MODEL 0 perspective (mono / stereo edges), 1 equirectangular (mono edges)
 __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __restrict__ poses_in, const ovs_pose_obs* __restrict__ obs_all,
                                                       const int32_t* __restrict__ obs_offsets, ovs_ba_cam cam, double bf, int setup_type,
                                                       double* __restrict__ poses_out, uint8_t* __restrict__ outlier_all,
-                                                      int32_t* __restrict__ num_valid, int reset_each_round, int G, double* __restrict__ gpart,
-                                                      unsigned int* __restrict__ gsync, int batch_retries) {
+                                                      int32_t* __restrict__ num_valid, int reset_each_round, int G,
+                                                      unsigned long long* __restrict__ gpart, unsigned int epoch0, int batch_retries,
+                                                      int stereo_hint) {
     // G > 1 (round 4, single-frame latency path): the frame's observations are spread over G workgroups (blockIdx.y). Every sum over the
     // observations is then a sum of G workgroup partials exchanged through memory behind a grid-wide barrier; each workgroup adds them in
     // the same order, solves the same 6 x 6 system and takes the same branches, so there is no second barrier and no broadcast.
-    // gpart: [frame][2][G][28] doubles (two epochs), gsync: [frame][2] = arrival counter, abort flag.
+    // gpart: [frame][2][G][56] 64-bit words (two epochs; see exchange()).
     constexpr int kPoseWaves = kPoseThreads / 64;
     constexpr int kRedPitch = kPoseThreads + 8;   // doubles per row of the reduction scratch
     __shared__ double s_part[kPoseWaves][28];
@@ -288,9 +292,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
     if (G > 1 && (blockIdx.y & 7u) != 0u) return;
     const int p = blockIdx.x, grp = G > 1 ? (int)(blockIdx.y >> 3) : 0;
     const int gtid = grp * kPoseThreads + tid, gstride = G * kPoseThreads;   // this thread's observations: gtid, gtid + gstride, ...
-    double* const my_part = gpart ? gpart + (size_t)p * 2 * G * 28 : nullptr;
-    unsigned int* const my_sync = gsync ? gsync + 2 * (size_t)p : nullptr;
-    unsigned int epoch = 0;   // grid barriers passed (workgroup-uniform, the same in every workgroup of the frame)
+    unsigned long long* const my_part = gpart ? gpart + (size_t)p * 2 * G * 56 : nullptr;
+    unsigned int epoch = epoch0;   // epoch0 + exchanges passed (workgroup-uniform, the same in every workgroup of the frame)
     __shared__ int s_abort;
     if (tid == 0) s_abort = 0;
     // exchange nv <= 28 workgroup sums (in s_sum) between the frame's workgroups: afterwards s_sum holds the sums over all of them, added in
@@ -298,32 +301,40 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
     // reported as failed and the caller falls back to one workgroup per frame).
     auto exchange = [&](int nv) -> bool {
         if (G == 1) return true;
+        // Round 6: no arrival counter. Every partial travels as two 64-bit words {flag = epoch : 32 | half of the double : 32} (a 64-bit store is
+        // single-copy atomic, so a word whose flag is this epoch carries this epoch's data: no release fence, no second trip to fetch the data
+        // after the barrier). Round 4-5: [28 stores, barrier, fetch_add with release, spin on the counter, barrier, load the partials, barrier]
+        // = three dependent trips to L2 per exchange, ~2 us of a ~5.5 us iteration. Now: stores, then every thread polls ITS word of the
+        // G x 2 nv -- one trip after the last workgroup's store lands. Two buffers by epoch parity: a workgroup writes epoch e + 2 into the
+        // buffer of epoch e only after it has read every workgroup's e + 1 words, which those wrote after reading epoch e. Epochs start at the
+        // call's epoch0 (host: + 4096 per call), so words left by an earlier call never match.
         ++epoch;
-        double* const mine = my_part + ((size_t)(epoch & 1u) * G + grp) * 28;
-        if (tid < nv) __hip_atomic_store(&mine[tid], s_sum[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_fetch_add(&my_sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned int target = epoch * (unsigned int)G;
-            const unsigned long long t0 = wall_clock64();
-            while (__hip_atomic_load(&my_sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                if (__hip_atomic_load(&my_sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > 5000000ull) {
-                    __hip_atomic_store(&my_sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long* const buf = my_part + (size_t)(epoch & 1u) * G * 56;
+        if (tid < 2 * nv) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(s_sum[tid >> 1]);
+            const unsigned long long half = (tid & 1) ? (bits >> 32) : (bits & 0xffffffffull);
+            __hip_atomic_store(&buf[grp * 56 + tid], ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        uint32_t* const s_w = reinterpret_cast<uint32_t*>(s_red);   // [G][56] halves (s_red is free here: the linearisation's reduction is over)
+        const unsigned long long t0 = wall_clock64();
+        for (int w = tid; w < 2 * nv * G; w += kPoseThreads) {
+            const int g = w / (2 * nv), j = w - g * (2 * nv);
+            unsigned long long v;
+            unsigned int spins = 0;
+            while ((uint32_t)((v = __hip_atomic_load(&buf[g * 56 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) {
+                if ((++spins & 63u) == 0u && wall_clock64() - t0 > 5000000ull) {   // a workgroup of the frame never arrived within 50 ms
                     s_abort = 1;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
             }
+            s_w[g * 56 + j] = (uint32_t)v;
         }
         __syncthreads();
         if (s_abort) return false;
-        // one load per thread, all of them in flight together (G dependent loads per thread cost G round trips to L2), then the sums in
-        // workgroup order from LDS (s_red is free here: the linearisation's reduction is over)
-        if (tid < 28 * G) s_red[tid] = __hip_atomic_load(&my_part[(size_t)(epoch & 1u) * G * 28 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (tid < nv) {
-            double v = s_red[tid];
-            for (int g = 1; g < G; ++g) v += s_red[g * 28 + tid];
+        if (tid < nv) {   // the sums in workgroup order, the same in every workgroup
+            const double* const s_d = reinterpret_cast<const double*>(s_w);
+            double v = s_d[tid];
+            for (int g = 1; g < G; ++g) v += s_d[g * 28 + tid];
             s_sum[tid] = v;
         }
         __syncthreads();
@@ -337,6 +348,20 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
     const int o0 = obs_offsets[p], n = obs_offsets[p + 1] - o0;
     const ovs_pose_obs* obs = obs_all + o0;
     uint8_t* outlier = outlier_all + o0;
+    // this thread's observations gtid, gtid + gstride, ...: body(k, i, record). KREG: the first two from registers (and there are no others)
+    ovs_pose_obs o_r0 = {}, o_r1 = {};
+    if (KREG) {
+        if (gtid < n) o_r0 = obs[gtid];
+        if (gtid + gstride < n) o_r1 = obs[gtid + gstride];
+    }
+    auto for_each_obs = [&](auto&& body) __attribute__((always_inline)) {
+        if (KREG) {
+            if (gtid < n) body(0, gtid, o_r0);
+            if (gtid + gstride < n) body(1, gtid + gstride, o_r1);
+        } else {
+            for (int k = 0, i = gtid; i < n; i += gstride, ++k) body(k, i, obs[i]);
+        }
+    };
     // upstream: ONE Huber delta per frame, chosen by the rig (Monocular -> sqrt_chi_sq_2D, otherwise sqrt_chi_sq_3D); the chi-square
     // outlier gates stay per edge
     // upstream: constexpr float chi_sq_2D = 5.99146; const float sqrt_chi_sq_2D = std::sqrt(chi_sq_2D); (3D: 7.81473) -- FLOAT constants widened
@@ -402,9 +427,11 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
     uint32_t active = 0xFFFFFFFFu;   // bit k <-> observation gtid + gstride * k
     int st_any = 0;
     for (int i = gtid; i < n; i += gstride) outlier[i] = 0;
-    if (MODEL == 0)
-        for (int i = tid; i < n; i += kPoseThreads) st_any |= obs[i].is_stereo;   // (every workgroup scans the whole frame: the flag must be the same in all)
-    const bool has_stereo = MODEL == 0 && __builtin_amdgcn_readfirstlane(__syncthreads_or(st_any)) != 0;
+    // stereo_hint: -1 = find out (every workgroup scans the whole frame: the flag must be the same in all); 0 / 1 = the host has looked (one-frame
+    // calls: with the records in host memory G scans of them would cross PCIe)
+    if (MODEL == 0 && stereo_hint < 0)
+        for (int i = tid; i < n; i += kPoseThreads) st_any |= obs[i].is_stereo;
+    const bool has_stereo = MODEL == 0 && (stereo_hint >= 0 ? stereo_hint != 0 : __builtin_amdgcn_readfirstlane(__syncthreads_or(st_any)) != 0);
     if (tid == 0) load_input_pose();
     __syncthreads();
     int num_bad = 0;
@@ -431,11 +458,9 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                 for (int i = 0; i < 9; ++i) R[i] = uniform_d(at_trial ? s_Tn.R[i] : s_T.R[i]);
                 for (int i = 0; i < 3; ++i) t[i] = uniform_d(at_trial ? s_Tn.t[i] : s_T.t[i]);
                 auto sweep = [&](auto stereo_tag) __attribute__((always_inline)) {
-                    for (int k = 0, i = gtid; i < n; i += gstride, ++k)
-                        if ((active >> k) & 1u) {
-                            const ovs_pose_obs o = obs[i];
-                            pose_edge_impl<MODEL, decltype(stereo_tag)::value>(R, t, o, cam, bf, robust ? huber : 0.0, acc);
-                        }
+                    for_each_obs([&](int k, int, const ovs_pose_obs& o) __attribute__((always_inline)) {
+                        if ((active >> k) & 1u) pose_edge_impl<MODEL, decltype(stereo_tag)::value>(R, t, o, cam, bf, robust ? huber : 0.0, acc);
+                    });
                 };
                 if (has_stereo) sweep(std::true_type{});   // (workgroup-uniform)
                 else sweep(std::false_type{});
@@ -516,15 +541,15 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                             for (int i = 0; i < 3; ++i) t[i] = s_Tq[q].t[i];
                             double pq = 0;
                             auto sweep = [&](auto stereo_tag) __attribute__((always_inline)) {
-                                for (int k = 0, i = gtid; i < n; i += gstride, ++k)
+                                for_each_obs([&](int k, int, const ovs_pose_obs& o) __attribute__((always_inline)) {
                                     if ((active >> k) & 1u) {
-                                        const ovs_pose_obs o = obs[i];
                                         const double c2 = pose_edge_impl<MODEL, decltype(stereo_tag)::value>(R, t, o, cam, bf, 0.0, nullptr);
                                         const double delta = robust ? huber : 0.0;
                                         double r = c2;
                                         if (delta > 0 && c2 > delta * delta) r = 2 * sqrt(c2) * delta - delta * delta;
                                         pq += r;
                                     }
+                                });
                             };
                             if (has_stereo) sweep(std::true_type{});
                             else sweep(std::false_type{});
@@ -614,15 +639,15 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                         for (int i = 0; i < 3; ++i) t[i] = s_Tn.t[i];
                         double part = 0;
                         auto sweep = [&](auto stereo_tag) __attribute__((always_inline)) {
-                            for (int k = 0, i = gtid; i < n; i += gstride, ++k)
+                            for_each_obs([&](int k, int, const ovs_pose_obs& o) __attribute__((always_inline)) {
                                 if ((active >> k) & 1u) {
-                                    const ovs_pose_obs o = obs[i];
                                     const double c2 = pose_edge_impl<MODEL, decltype(stereo_tag)::value>(R, t, o, cam, bf, 0.0, nullptr);
                                     const double delta = robust ? huber : 0.0;
                                     double r = c2;
                                     if (delta > 0 && c2 > delta * delta) r = 2 * sqrt(c2) * delta - delta * delta;
                                     part += r;
                                 }
+                            });
                         };
                         if (has_stereo) sweep(std::true_type{});
                         else sweep(std::false_type{});
@@ -663,15 +688,14 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(const double* __
                 int bad = 0;
                 const uint32_t was_active = active;
                 active = 0;
-                for (int k = 0, i = gtid; i < n; i += gstride, ++k) {
-                    const ovs_pose_obs o = obs[i];
+                for_each_obs([&](int k, int i, const ovs_pose_obs& o) __attribute__((always_inline)) {
                     const bool wa = (was_active >> k) & 1u;
                     const double c2 = pose_edge_impl<MODEL, true>(wa ? Re : R, wa ? te : t, o, cam, bf, 0.0, nullptr);
                     const bool out = ((MODEL == 0 && o.is_stereo) ? kChi3D : kChi2D) < c2;
                     outlier[i] = out ? 1 : 0;
                     if (out) ++bad;
                     else active |= 1u << k;
-                }
+                });
                 // block sum of bad (integers: exact)
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
@@ -713,6 +737,16 @@ static int pose_batch_retries_env() {
     return v;
 }
 
+// OVS_POSE_OBS_REGS=0: observations re-read from memory in every pass (the form of rounds 3-5; same bits, for A/B timing and the test that
+// compares the two forms)
+static bool tuning_pose_obs_regs() {
+    static const bool v = [] {
+        const char* e = std::getenv("OVS_POSE_OBS_REGS");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
 // ovs_pose_set_variant(OVS_POSE_VARIANT_RESET_EACH_ROUND, 0 | 1): process-wide, read at every launch
 static std::atomic<int> g_pose_reset_each_round{0};
 
@@ -721,27 +755,31 @@ extern "C" {
 static ovs_status pose_optimize_batch_dev(int model, const double* d_poses_in, const ovs_pose_obs* d_obs, const int32_t* d_obs_offsets, int32_t batch,
                                           const ovs_ba_cam& cam, double focal_x_baseline, int32_t setup_type, double* d_poses_out,
                                           uint8_t* d_outlier, int32_t* d_num_valid, void* stream, int threads_default = 256, int groups = 1,
-                                          double* d_gpart = nullptr, unsigned int* d_gsync = nullptr, int batch_retries_auto = 0) {
+                                          unsigned long long* d_gpart = nullptr, unsigned int epoch0 = 0, int batch_retries_auto = 0, bool obs_in_regs = false, int stereo_hint = -1) {
     if (!d_poses_in || !d_obs || !d_obs_offsets || !d_poses_out || !d_outlier || !d_num_valid || batch < 1) return OVS_ERR_INVALID;
     // workgroup size: the kernel is one latency-bound workgroup per frame; more waves hide the f64 latency of the per-observation work
     // but pay in barriers (measured per 2000-observation frame in DESIGN.md section 3.6)
     const int threads_env = tuning().pose_threads;
     const int T = threads_env == 256 || threads_env == 512 ? threads_env : threads_default;
     const size_t lds = sizeof(double) * 28 * (size_t)(T + 8);
-#define OVS_POSE_LAUNCH(MODEL, TT, BF, ST)                                                                                              \
+#define OVS_POSE_LAUNCH(MODEL, TT, KR, BF, ST)                                                                                              \
     do {                                                                                                                              \
         static LdsAttrCache configured; /* per device: a second device needs the attribute too (116 KB of dynamic LDS at 512 threads) */  \
-        OVS_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(k_pose_optimize<MODEL, TT>), sizeof(double) * 28 * (TT + 8), configured)); \
-        hipLaunchKernelGGL((k_pose_optimize<MODEL, TT>), dim3(batch, groups > 1 ? 8 * groups : 1), dim3(TT), lds, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, \
+        OVS_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(k_pose_optimize<MODEL, TT, KR>), sizeof(double) * 28 * (TT + 8), configured)); \
+        hipLaunchKernelGGL((k_pose_optimize<MODEL, TT, KR>), dim3(batch, groups > 1 ? 8 * groups : 1), dim3(TT), lds, (hipStream_t)stream, d_poses_in, d_obs, d_obs_offsets, \
                            cam, BF, ST, d_poses_out, d_outlier, d_num_valid, g_pose_reset_each_round.load(std::memory_order_relaxed), groups, d_gpart, \
-                           d_gsync, pose_batch_retries_env() < 0 ? batch_retries_auto : pose_batch_retries_env());                  \
+                           epoch0, pose_batch_retries_env() < 0 ? batch_retries_auto : pose_batch_retries_env(), stereo_hint);      \
     } while (0)
+    // obs_in_regs: the caller knows every frame of the launch has at most 2 * groups * 256 observations (KREG = 2, 256-thread workgroups only)
+    const bool kreg = obs_in_regs && T == 256 && tuning_pose_obs_regs();
     if (model == 1) {
-        if (T == 512) OVS_POSE_LAUNCH(1, 512, 0.0, 0);
-        else OVS_POSE_LAUNCH(1, 256, 0.0, 0);
+        if (T == 512) OVS_POSE_LAUNCH(1, 512, 0, 0.0, 0);
+        else if (kreg) OVS_POSE_LAUNCH(1, 256, 2, 0.0, 0);
+        else OVS_POSE_LAUNCH(1, 256, 0, 0.0, 0);
     } else {
-        if (T == 512) OVS_POSE_LAUNCH(0, 512, focal_x_baseline, (int)setup_type);
-        else OVS_POSE_LAUNCH(0, 256, focal_x_baseline, (int)setup_type);
+        if (T == 512) OVS_POSE_LAUNCH(0, 512, 0, focal_x_baseline, (int)setup_type);
+        else if (kreg) OVS_POSE_LAUNCH(0, 256, 2, focal_x_baseline, (int)setup_type);
+        else OVS_POSE_LAUNCH(0, 256, 0, focal_x_baseline, (int)setup_type);
     }
 #undef OVS_POSE_LAUNCH
     OVS_HIP_TRY(hipGetLastError());
@@ -784,7 +822,7 @@ static ovs_status pose_optimize_host(int model, int32_t device, const double* po
     const size_t off_off = 96, off_sync = 112, off_obs = 128, in_bytes = off_obs + sizeof(ovs_pose_obs) * no;
     const size_t off_out = (in_bytes + 255) & ~(size_t)255, off_nv = off_out + 96, off_fl = off_out + 128, out_bytes = 128 + no;
     constexpr int kMaxGroups = 8;
-    const size_t off_part = (off_out + out_bytes + 255) & ~(size_t)255, total = off_part + sizeof(double) * 2 * kMaxGroups * 28;
+    const size_t off_part = (off_out + out_bytes + 255) & ~(size_t)255, total = off_part + sizeof(unsigned long long) * 2 * kMaxGroups * 56;
     // per-thread, per-device staging that only grows: this runs once per tracked frame, an allocation per call would cost more than
     // the optimisation itself
     struct Scratch {
@@ -792,6 +830,7 @@ static ovs_status pose_optimize_host(int model, int32_t device, const double* po
         hipStream_t stream = nullptr;
         size_t cap = 0;
         int device = -1;
+        unsigned int epoch0 = 0;   // the exchange words' flags of call c are epoch0 + 1 ..: + 4096 per call, so an earlier call's words never match
         void release() {
             if (p) (void)hipFree(p);
             if (h) (void)hipHostFree(h);
@@ -808,6 +847,7 @@ static ovs_status pose_optimize_host(int model, int32_t device, const double* po
         scratch.release();
         const size_t want = std::max<size_t>(total, (size_t)1 << 20);
         OVS_HIP_TRY(hipMalloc(&scratch.p, want));
+        OVS_HIP_TRY(hipMemset(scratch.p, 0, want));   // (exchange flags of a fresh block: zero, which no epoch equals)
         OVS_HIP_TRY(hipHostMalloc(&scratch.h, want, hipHostMallocDefault));
         OVS_HIP_TRY(hipStreamCreateWithFlags(&scratch.stream, hipStreamNonBlocking));
         scratch.cap = want;
@@ -817,9 +857,8 @@ static ovs_status pose_optimize_host(int model, int32_t device, const double* po
     const int32_t offs[2] = {0, n_obs};
     std::memcpy(h, pose_cw_in, sizeof(double) * 12);
     std::memcpy(h + off_off, offs, sizeof(offs));
-    std::memset(h + off_sync, 0, 16);   // the grid barrier's arrival counter and abort flag
+    std::memset(h + off_sync, 0, 16);   // (unused since round 6: the exchange has no arrival counter)
     if (n_obs) std::memcpy(h + off_obs, obs, sizeof(ovs_pose_obs) * (size_t)n_obs);
-    OVS_HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, scratch.stream));
     // one latency-bound workgroup: 512 threads hide the f64 latency of the per-observation work when there is enough of it; measured,
     // 256 / 512 threads: perspective 2000 observations 0.509 / 0.512 ms, 1000: 0.438 / 0.422, 500: 0.286 / 0.293; equirectangular
     // 2000: 1.39 / 1.15, 1000: 0.759 / 0.786, 500: 0.427 / 0.588
@@ -834,7 +873,21 @@ static ovs_status pose_optimize_host(int model, int32_t device, const double* po
     // round 5 (after the fused multiply-add accumulation made the per-observation work a third lighter; profiles/r05s_pose_groups.txt, means over 8
     // frames, 1 / 2 / 4 / 8 workgroups): 300 observations 0.235 / 0.259 / 0.267 / 0.285 ms, 700: 0.275 / 0.283 / 0.285 / 0.302, 1000: 0.320 / 0.322 /
     // 0.277 / 0.297, 1300: 0.335 / 0.323 / 0.298 / 0.288, 2000: 0.373 / 0.382 / 0.324 / 0.301, 4000: 0.541 / 0.466 / 0.378 / 0.325
-    int groups = groups_env > 0 ? std::min(groups_env, kMaxGroups) : (n_obs >= 1600 ? 8 : (n_obs >= 850 ? 4 : 1));
+    // round 6 (observations in registers, exchange without an arrival counter; profiles/r06w_pose_groups.txt, 1 / 2 / 4 / 8 workgroups): 300 observations
+    // 0.222 / 0.234 / 0.238 / 0.251 ms, 700: 0.284 / 0.251 / 0.257 / 0.264, 1000: 0.332 / 0.284 / 0.249 / 0.258, 1300: 0.345 / 0.312 / 0.255 / 0.251,
+    // 2000: 0.383 / 0.370 / 0.280 / 0.262, 4000: 0.553 / 0.461 / 0.363 / 0.277
+    int groups = groups_env > 0 ? std::min(groups_env, kMaxGroups) : (n_obs >= 1600 ? 8 : (n_obs >= 850 ? 4 : (n_obs >= 500 ? 2 : 1)));
+    int stereo_hint = 0;
+    if (model == 0)
+        for (int32_t i = 0; i < n_obs; ++i) stereo_hint |= obs[i].is_stereo != 0;
+    // Round 6, zero copy: when the kernel reads every record exactly once (KREG form), it reads them -- and the pose -- straight from the pinned block
+    // and writes pose, count and flags straight into it: no H2D copy before the launch, no D2H copy after it (two runtime copy commands and their
+    // dependencies, ~20 us of a ~0.25 ms call). The exchange words stay in device memory. OVS_POSE_ZERO_COPY=0: the copies of rounds 3-5.
+    static const bool zero_copy_env = [] {
+        const char* e = std::getenv("OVS_POSE_ZERO_COPY");
+        return !(e && e[0] == '0');
+    }();
+    bool first = true;
     for (;;) {
         // retries 1 .. 9 of an iteration in ONE pass (k_pose_optimize): nine trial poses per observation pay where a thread holds few
         // observations -- means over 8 frames, one pass / one by one (profiles/r04aj_pose_batched_retries.txt): four workgroups 1300
@@ -842,22 +895,26 @@ static ovs_status pose_optimize_host(int model, int32_t device, const double* po
         // 2000: 0.478 / 0.439 (a sequence that accepts its second or third trial has then evaluated seven poses for nothing). Same bits.
         const int batch_retries = (groups > 1 || n_obs <= 512) ? 1 : 0;
         const int threads = groups > 1 ? 256 : ((model == 1 ? n_obs >= 1500 : n_obs >= 768) ? 512 : 256);
-        const ovs_status st = pose_optimize_batch_dev(model, reinterpret_cast<double*>(d), reinterpret_cast<ovs_pose_obs*>(d + off_obs),
-                                                      reinterpret_cast<int32_t*>(d + off_off), 1, *cam, focal_x_baseline, setup_type,
-                                                      reinterpret_cast<double*>(d + off_out), d + off_fl, reinterpret_cast<int32_t*>(d + off_nv),
-                                                      scratch.stream, threads, groups, reinterpret_cast<double*>(d + off_part),
-                                                      reinterpret_cast<unsigned int*>(d + off_sync), batch_retries);
+        const bool in_regs = n_obs <= 2 * groups * 256 && threads == 256 && tuning_pose_obs_regs() && tuning().pose_threads != 512;
+        const bool zero_copy = in_regs && zero_copy_env && first;
+        unsigned char* const io = zero_copy ? h : d;   // where the kernel finds its inputs and leaves its outputs
+        if (!zero_copy) OVS_HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, scratch.stream));
+        const ovs_status st = pose_optimize_batch_dev(model, reinterpret_cast<double*>(io), reinterpret_cast<ovs_pose_obs*>(io + off_obs),
+                                                      reinterpret_cast<int32_t*>(io + off_off), 1, *cam, focal_x_baseline, setup_type,
+                                                      reinterpret_cast<double*>(io + off_out), io + off_fl, reinterpret_cast<int32_t*>(io + off_nv),
+                                                      scratch.stream, threads, groups, reinterpret_cast<unsigned long long*>(d + off_part),
+                                                      (scratch.epoch0 += 4096u), batch_retries, in_regs, stereo_hint);
         if (st != OVS_OK) {
             (void)hipStreamSynchronize(scratch.stream);   // the upload may still be reading the pinned block the next call overwrites
             return st;
         }
-        OVS_HIP_TRY(hipMemcpyAsync(h + off_out, d + off_out, out_bytes, hipMemcpyDeviceToHost, scratch.stream));
+        if (!zero_copy) OVS_HIP_TRY(hipMemcpyAsync(h + off_out, d + off_out, out_bytes, hipMemcpyDeviceToHost, scratch.stream));
         OVS_HIP_TRY(hipStreamSynchronize(scratch.stream));
         int32_t nv = 0;
         std::memcpy(&nv, h + off_nv, sizeof(nv));
         if (nv != -2 || groups == 1) break;
-        groups = 1;   // a workgroup of the frame was not scheduled within 50 ms: run the frame in one workgroup
-        OVS_HIP_TRY(hipMemcpyAsync(d, h, off_obs, hipMemcpyHostToDevice, scratch.stream));   // (re-arms the barrier words)
+        groups = 1;   // a workgroup of the frame was not scheduled within 50 ms: run the frame in one workgroup (inputs through device memory)
+        first = false;
     }
     std::memcpy(pose_cw_out, h + off_out, sizeof(double) * 12);
     std::memcpy(num_valid, h + off_nv, sizeof(int32_t));

@@ -188,10 +188,15 @@ def test_batched_retries_give_the_sequential_results(tmp_path):
         "    out['e%%d' %% n] = np.concatenate([T.ravel(), fl.astype(float), [nv]])\n"
         "np.savez(sys.argv[1], **out)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     res = {}
-    for tag, env in (("batched", {}), ("sequential", {"OVS_POSE_BATCH_RETRIES": "0"})):
+    # round 6: the same for the forms of the data path -- observations held in registers and read straight from the pinned host block
+    # (default), re-read from device memory per pass (OVS_POSE_OBS_REGS=0), registers but through the H2D / D2H copies (OVS_POSE_ZERO_COPY=0)
+    variants = (("batched", {}), ("sequential", {"OVS_POSE_BATCH_RETRIES": "0"}), ("from_memory", {"OVS_POSE_OBS_REGS": "0"}),
+                ("copies", {"OVS_POSE_ZERO_COPY": "0"}))
+    for tag, env in variants:
         f = str(tmp_path / (tag + ".npz"))
         subprocess.check_call([sys.executable, "-c", code, f], env=dict(os.environ, **env), timeout=300)
         res[tag] = np.load(f)
-    assert sorted(res["batched"].files) == sorted(res["sequential"].files) and len(res["batched"].files) == 7
-    for k in res["batched"].files:
-        assert np.array_equal(res["batched"][k], res["sequential"][k]), k
+    for tag, _ in variants[1:]:
+        assert sorted(res["batched"].files) == sorted(res[tag].files) and len(res["batched"].files) == 7
+        for k in res["batched"].files:
+            assert np.array_equal(res["batched"][k], res[tag][k]), (tag, k)
