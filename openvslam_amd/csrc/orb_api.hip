@@ -233,6 +233,7 @@ struct ovs_orb {
     unsigned n_submitted = 0, n_collected = 0;
     int last_slot = -1;              // slot of the last COLLECTED frame (host pyramid getter)
     bool host_pyr = false;
+    bool cand_count_cleared = false;   // ovs_orb_extract_submit has already enqueued the clearing of the candidate counters for the next run_extract
     int host_mode = 0;               // 0: hipMemcpy2DAsync straight from the caller's (pageable) rows (measured 0.054 ms per 1080p frame);
                                      // 1: banded copy through pinned staging (0.12 ms: the CPU memcpy costs more than the runtime's own staging)
     float host_ms[3] = {0, 0, 0};    // h2d | kernels | d2h of the last collected frame (profiling enabled)
@@ -510,7 +511,8 @@ ovs_status run_extract(ovs_orb* h, const uint8_t* d_images, int batch, int rows,
     ovs_status st = ensure_geometry(h, rows, cols);
     if (st != OVS_OK) return st;
     const int L = h->geo.num_levels;
-    OVS_HIP_TRY(hipMemsetAsync(h->d.cand_count, 0, sizeof(uint32_t) * (size_t)batch * L, s));
+    if (!h->cand_count_cleared) OVS_HIP_TRY(hipMemsetAsync(h->d.cand_count, 0, sizeof(uint32_t) * (size_t)batch * L, s));
+    h->cand_count_cleared = false;
     const int nsub = std::min(h->pipeline, batch);
     if (nsub <= 1) {
         st = run_chain(h, h->prof, d_images, 0, batch, stride, frame_stride, d_masks, d_kps, d_desc, d_counts, cap, rows, s);
@@ -919,6 +921,13 @@ ovs_status ovs_orb_extract_submit(ovs_orb* h, const uint8_t* image, int32_t rows
     if (timed)
         for (auto& e : sl.t)
             if (!e) OVS_HIP_TRY(hipEventCreate(&e));
+    // the candidate counters are cleared while the image is still on its way (a 4 us fill kernel that used to run between the upload and the pyramid)
+    OVS_HIP_TRY(hipMemsetAsync(h->d.cand_count, 0, sizeof(uint32_t) * (size_t)h->geo.num_levels, s));
+    h->cand_count_cleared = true;
+    struct ClearedGuard {   // the flag lives inside this call: whatever path leaves it, the next run_extract clears its own counters
+        ovs_orb* h;
+        ~ClearedGuard() { h->cand_count_cleared = false; }
+    } cleared_guard{h};
     if (timed) OVS_HIP_TRY(hipEventRecord(sl.t[0], cs));
     st = upload_plane(h, image, stride, rows, cols, sl.h_in, sl.d_img);
     if (st != OVS_OK) return st;
