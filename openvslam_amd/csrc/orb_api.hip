@@ -40,6 +40,7 @@ const Tuning& tuning() {
         v.pose_groups = std::max(0, num("OVS_POSE_GROUPS", 0));
         v.ba_trace = std::getenv("OVS_BA_TRACE") != nullptr;
         v.pyr_chain = std::max(0, num("OVS_PYR_CHAIN", 2));
+        v.pyr_pair = num("OVS_PYR_PAIR", 1) != 0;
         v.chol_resident = num("OVS_CHOL_RESIDENT", 1) != 0;
         return v;
     }();
@@ -177,6 +178,83 @@ static void build_chain_plan(const FrameGeo& geo, const std::vector<ResizeTap>& 
     out.ok = ok;
 }
 
+// HTapRec of every column pair of a level (ovs_common.h): make_htaps of orb_pyramid.hip with absolute offsets -- the selectors do not depend on the
+// tile origin (a multiple of 4), the first source word becomes relative by one subtraction in the kernel.
+static void build_htaps(const ResizeTap* xt, int cols, std::vector<HTapRec>& out) {
+    for (int x = 0; x < cols; x += 2) {
+        const ResizeTap ta = xt[x], tb = xt[std::min(x + 1, cols - 1)];
+        HTapRec r = {};
+        r.wa = (uint32_t)(ta.o0 >> 2);
+        const int base = 4 * (int)r.wa;
+        const uint32_t sa0 = (uint32_t)(ta.o0 - base) & 7u, sa1 = (uint32_t)(ta.o1 - base) & 7u;
+        const uint32_t sb0 = (uint32_t)(tb.o0 - base) & 7u, sb1 = (uint32_t)(tb.o1 - base) & 7u;
+        r.sel_a = sa0 | 0x0c00u | (sa1 << 16) | 0x0c000000u;
+        r.sel_b = sb0 | 0x0c00u | (sb1 << 16) | 0x0c000000u;
+        r.ca = ((uint32_t)(uint16_t)ta.a0 << 4) | ((uint32_t)(uint16_t)ta.a1 << 20);
+        r.cb = ((uint32_t)(uint16_t)tb.a0 << 4) | ((uint32_t)(uint16_t)tb.a1 << 20);
+        out.push_back(r);
+    }
+}
+
+// The regions of k_resize_pair_u8 (orb_pyramid.hip) for the level pair (l2 - 1, l2) computed from level l2 - 2: one PairSpan per tile column and
+// per tile row of level l2's 128 x 32 grid, x spans first. Returns false -- the pair then runs as two per-level launches -- unless both levels
+// pass v4's window checks, every region fits the kernel's LDS buffers, and the owned ranges partition the middle level.
+static bool build_pair_plan(const FrameGeo& geo, const std::vector<ResizeTap>& taps, int l2, std::vector<PairSpan>& out) {
+    constexpr int kTw = 128, kTh = 32, kTileWords = 48, kTileRows = 44, kGroups = 40, kSrcWords = 56, kSrcRows = 52;   // orb_pyramid.hip's constants
+    out.clear();
+    if (l2 < 2 || l2 >= geo.num_levels) return false;
+    const LevelGeo &g1 = geo.lv[l2 - 1], &g2 = geo.lv[l2];
+    if (!g1.resize_hwin_ok || !g2.resize_hwin_ok) return false;
+    for (int axis = 0; axis < 2; ++axis) {
+        const ResizeTap* t1 = taps.data() + (axis ? g1.ytab_off : g1.xtab_off);
+        const ResizeTap* t2 = taps.data() + (axis ? g2.ytab_off : g2.xtab_off);
+        const int size1 = axis ? g1.rows : g1.cols, size2 = axis ? g2.rows : g2.cols, step = axis ? kTh : kTw;
+        int expect_b0 = 0;   // the owned ranges must follow each other from 0
+        for (int p0 = 0; p0 < size2; p0 += step) {
+            const int p1 = std::min(p0 + step, size2) - 1;
+            const bool last = p0 + step >= size2;
+            PairSpan sp = {};
+            const int first = t2[p0].o0;
+            const int b0 = axis ? first : (first & ~3), b1 = last ? size1 - 1 : t2[p1].o1;
+            if (b1 < t2[p1].o1 || b0 != expect_b0) return false;
+            sp.s_lo = (int16_t)(axis ? first : (first & ~15));
+            sp.b0 = (int16_t)b0;
+            int n, own, hi;   // computed extent (groups / rows), owned extent, last middle index that exists
+            if (!axis) {
+                n = (b1 - b0) / 4 + 1;
+                hi = std::min(b0 + 4 * n - 1, size1 - 1);
+                const int next_b0 = last ? b0 + 4 * n : (t2[p0 + step].o0 & ~3);
+                own = (next_b0 - b0) / 4;
+                if (n > kGroups || (b0 - sp.s_lo) / 4 + n > kTileWords) return false;
+                expect_b0 = next_b0;
+            } else {
+                n = b1 - b0 + 1;
+                hi = b1;
+                const int next_b0 = last ? b0 + n : t2[p0 + step].o0;
+                own = next_b0 - b0;
+                if (n > kTileRows) return false;
+                expect_b0 = next_b0;
+            }
+            if (own < 1 || own > n) return false;
+            int a_lo = t1[b0].o0, a_hi = t1[hi].o1;
+            for (int i = b0; i <= hi; ++i) {   // (the tables are monotone; this does not rely on it)
+                a_lo = std::min(a_lo, (int)t1[i].o0);
+                a_hi = std::max(a_hi, (int)t1[i].o1);
+            }
+            if (!axis) a_lo &= ~15;
+            const int an = axis ? a_hi - a_lo + 1 : (a_hi - a_lo) / 4 + 1;
+            if (an > (axis ? kSrcRows : kSrcWords)) return false;
+            sp.n = (int16_t)n;
+            sp.own = (int16_t)own;
+            sp.a0 = (int16_t)a_lo;
+            sp.an = (int16_t)an;
+            out.push_back(sp);
+        }
+        if (expect_b0 < size1) return false;   // the last tile's region ends where the middle level ends
+    }
+    return true;
+}
+
 }   // namespace ovs
 
 using namespace ovs;
@@ -202,6 +280,13 @@ struct ovs_orb {
     ChainPlanHost chain;             // k_pyramid_chain's tile grid and regions for the current geometry (chain.ok: usable)
     ChainSpan* d_chain = nullptr;    // its spans on the device
     size_t chain_cap = 0;
+    // k_resize_pair_u8's regions for the current geometry: pair_off[l2] = offset of the spans of the level pair (l2 - 1, l2) in d_pair, -1 = no plan
+    int pair_off[OVS_MAX_LEVELS];
+    PairSpan* d_pair = nullptr;
+    size_t pair_cap = 0;
+    int htab_off[OVS_MAX_LEVELS];    // offset of level l's column-pair records in d_htaps (levels with a pair plan only)
+    HTapRec* d_htaps = nullptr;
+    size_t htaps_cap = 0;
     int32_t variant = 0;   // FrameGeo::variant
     DevBuffers d{};
     size_t pyr_cap = 0, cand_cap = 0, node_cap = 0, kps_cap = 0;
@@ -437,6 +522,27 @@ ovs_status ensure_geometry(ovs_orb* h, int rows, int cols) {
     else
         chain.ok = false;
     h->chain = std::move(chain);
+    {
+        std::vector<PairSpan> all, one;
+            for (int l = 0; l < OVS_MAX_LEVELS; ++l) h->pair_off[l] = -1;
+        for (int l2 = 2; l2 < geo.num_levels; ++l2)
+            if (build_pair_plan(geo, taps, l2, one) && all.size() + one.size() <= h->pair_cap) {
+                h->pair_off[l2] = (int)all.size();
+                all.insert(all.end(), one.begin(), one.end());
+            }
+        if (!all.empty()) OVS_HIP_TRY(hipMemcpy(h->d_pair, all.data(), all.size() * sizeof(PairSpan), hipMemcpyHostToDevice));
+        std::vector<HTapRec> recs;
+        for (int l = 0; l < OVS_MAX_LEVELS; ++l) h->htab_off[l] = -1;
+        for (int l = 1; l < geo.num_levels; ++l)
+            if ((l + 1 < geo.num_levels && h->pair_off[l + 1] >= 0) || h->pair_off[l] >= 0) {
+                h->htab_off[l] = (int)recs.size();
+                build_htaps(taps.data() + geo.lv[l].xtab_off, geo.lv[l].cols, recs);
+            }
+        if (recs.size() > h->htaps_cap)
+            for (int l = 0; l < OVS_MAX_LEVELS; ++l) h->pair_off[l] = -1;   // (cannot happen: the capacity covers every level of the largest image)
+        else if (!recs.empty())
+            OVS_HIP_TRY(hipMemcpy(h->d_htaps, recs.data(), recs.size() * sizeof(HTapRec), hipMemcpyHostToDevice));
+    }
     h->geo = geo;
     h->taps.swap(taps);
     h->cur_rows = rows;
@@ -484,6 +590,15 @@ ovs_status run_chain(ovs_orb* h, StageProfiler<4>& prof, const uint8_t* d_images
         const uint8_t* src = (l == 1) ? img : d.pyr + gp.plane_off;
         const size_t src_fs = (l == 1) ? frame_stride : d.pyr_frame_bytes;
         const int src_pitch = (l == 1) ? (int)stride : gp.pitch;
+        // batches: levels l and l + 1 in one launch where the geometry has a plan for the pair (the middle level is written once, never re-read)
+        if (tuning().pyr_pair && l + 1 < L && h->pair_off[l + 1] >= 0 && resize_pair_launchable(src, src_fs, src_pitch, geo.lv[l + 1].rows, geo.lv[l + 1].cols, nb)) {
+            const LevelGeo& g2 = geo.lv[l + 1];
+            OVS_HIP_TRY(launch_resize_pair(src, src_fs, src_pitch, d.pyr + g.plane_off, g.pitch, g.rows, g.cols, d.pyr + g2.plane_off, g2.pitch, g2.rows, g2.cols,
+                                           d.pyr_frame_bytes, h->d_taps + g.ytab_off, h->d_taps + g2.ytab_off, h->d_htaps + h->htab_off[l], h->d_htaps + h->htab_off[l + 1],
+                                           h->d_pair + h->pair_off[l + 1], nb, s));
+            ++l;
+            continue;
+        }
         OVS_HIP_TRY(launch_resize(src, src_fs, src_pitch, gp.rows, gp.cols, d.pyr + g.plane_off, d.pyr_frame_bytes, g.pitch, g.rows, g.cols,
                                   h->d_taps + g.xtab_off, h->d_taps + g.ytab_off, nb, s, g.resize_hwin_ok));
     }
@@ -664,6 +779,11 @@ ovs_status ovs_orb_create(const ovs_orb_params* params, int32_t max_rows, int32_
     CREATE_TRY(hipMalloc(&h->d_cells, h->cells_cap * sizeof(CellDesc)));
     h->chain_cap = (size_t)L * ((size_t)(max_cols + 127) / 128 + (size_t)(max_rows + 95) / 96 + 2);   // (the tile grid is monotone in rows and cols)
     CREATE_TRY(hipMalloc(&h->d_chain, h->chain_cap * sizeof(ChainSpan)));
+    h->pair_cap = (size_t)L * ((size_t)(max_cols + 127) / 128 + (size_t)(max_rows + 31) / 32 + 2);
+    CREATE_TRY(hipMalloc(&h->d_pair, h->pair_cap * sizeof(PairSpan)));
+    for (int l = 0; l < OVS_MAX_LEVELS; ++l) h->pair_off[l] = h->htab_off[l] = -1;
+    h->htaps_cap = h->taps_cap;   // one record per column pair of every level: fewer than there are taps
+    CREATE_TRY(hipMalloc(&h->d_htaps, h->htaps_cap * sizeof(HTapRec)));
     CREATE_TRY(hipMalloc(&h->d.pyr, std::max<size_t>(h->d.pyr_frame_bytes * B, 256)));
     CREATE_TRY(hipMalloc(&h->d.cand, std::max<size_t>(cand_entries * B * sizeof(uint64_t), 256)));
     CREATE_TRY(hipMalloc(&h->d.cand_count, sizeof(uint32_t) * B * L));
@@ -711,6 +831,8 @@ ovs_status ovs_orb_destroy(ovs_orb* h) {
     hipFree(h->d_taps);
     hipFree(h->d_cells);
     hipFree(h->d_chain);
+    hipFree(h->d_pair);
+    hipFree(h->d_htaps);
     hipFree(h->d.pyr);
     hipFree(h->d.cand);
     hipFree(h->d.cand_count);

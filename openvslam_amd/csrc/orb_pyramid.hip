@@ -359,6 +359,306 @@ hipError_t launch_resize(const uint8_t* src, size_t src_frame_stride, int src_pi
 }
 
 // ================================================================================================================================
+// k_resize_pair_u8 (round 6): TWO levels per launch -- level l + 1 AND level l + 2 from a staged rectangle of level l, so the middle level is
+// written once and never read back by the pyramid (the seven per-level launches write every level and read it again:
+// 2.72 GB of traffic per 256 1080p frames against 2.08 GB for three pairs + one single level). A workgroup owns one 128 x 32 tile of the UPPER
+// level (the v4 tile). Stage A computes the region of the MIDDLE level that tile's taps touch (<= 160 x 44, starting on a 4-pixel boundary) from
+// the lower level's rectangle in LDS (<= 224 x 52 bytes) with v4's two passes; the region lands in LDS exactly where v4 would have staged it
+// (same pitch, same 16-byte origin), and the part of it this tile OWNS -- from its own first column / row up to the next tile's -- goes to the
+// middle level's plane: ownership boundaries are multiples of four pixels in x, so every stored word is whole, the regions of neighbouring
+// tiles overlap by a halo of 1-6 columns / 1-2 rows that both compute (identical integers) and only one stores. Stage B is v4's code on that
+// LDS tile. Same integers as two v4 launches (tests: planes byte-equal; the oracle's resize is the reference for both).
+// LDS: bufA = lower rectangle, later the middle region; bufH = stage A's horizontal pass, later stage B's: 28.3 KB, five workgroups per CU.
+// The regions (PairSpan per tile column / tile row) are computed on the host from the tap tables (orb_api.hip build_pair_plan), which also checks
+// that everything fits (pair_ok); a level pair that does not fit runs as two v4 / generic launches.
+constexpr int kPairSrcWords = 56;     // 224-byte pitch of the lower rectangle: 160 middle columns x 1.25 + 2 + 15 <= 217
+constexpr int kPairSrcRows = 52;      // 44 middle rows x 1.2 + 2 (host-checked)
+constexpr int kPairRowChunks = kPairSrcWords / 4;   // 52 rows x 14 sixteen-byte chunks
+constexpr int kPairGroups = 40;       // 4-pixel groups per row of the middle region (160 columns)
+
+struct HTaps {
+    uint32_t sel_a, sel_b, ca, cb;
+    int wa;
+};
+// selectors and coefficients of v4's horizontal pass for the column pair (ta, tb), source offsets relative to `lo` (a multiple of 4)
+__device__ __forceinline__ HTaps make_htaps(const ResizeTap ta, const ResizeTap tb, int lo) {
+    HTaps t;
+    const int a_o0 = ta.o0 - lo;
+    t.wa = a_o0 >> 2;
+    const int base = 4 * t.wa;
+    const uint32_t sa0 = (uint32_t)(a_o0 - base) & 7u, sa1 = (uint32_t)(ta.o1 - lo - base) & 7u;
+    const uint32_t sb0 = (uint32_t)(tb.o0 - lo - base) & 7u, sb1 = (uint32_t)(tb.o1 - lo - base) & 7u;
+    t.sel_a = sa0 | 0x0c00u | (sa1 << 16) | 0x0c000000u;
+    t.sel_b = sb0 | 0x0c00u | (sb1 << 16) | 0x0c000000u;
+    t.ca = ((uint32_t)(uint16_t)ta.a0 << 4) | ((uint32_t)(uint16_t)ta.a1 << 20);
+    t.cb = ((uint32_t)(uint16_t)tb.a0 << 4) | ((uint32_t)(uint16_t)tb.a1 << 20);
+    return t;
+}
+__device__ __forceinline__ uint32_t hpair(uint32_t lo, uint32_t hi, const HTaps& t) {
+    const uint32_t ha = dot2_u16(__builtin_amdgcn_perm(hi, lo, t.sel_a), t.ca);   // 16 * (S[o0] * a0 + S[o1] * a1) < 2^23
+    const uint32_t hb = dot2_u16(__builtin_amdgcn_perm(hi, lo, t.sel_b), t.cb);
+    return __builtin_amdgcn_perm(hb, ha, 0x06050201u);                            // (ha >> 8) | ((hb >> 8) << 16)
+}
+// four output pixels from the horizontal-pass words of their two source rows
+__device__ __forceinline__ uint32_t vgroup(const uint2 h0, const uint2 h1, const ResizeTap ty) {
+    const uint32_t b0 = (uint32_t)(uint16_t)ty.a0, b1 = (uint32_t)(uint16_t)ty.a1;
+    const uint32_t t0 = add_hi16(mul_lo16(b0, h0.x), mul_lo16(b1, h1.x)) + 2u;
+    const uint32_t t1 = add_hi16(mul_hi16(b0, h0.x), mul_hi16(b1, h1.x)) + 2u;
+    const uint32_t t2 = add_hi16(mul_lo16(b0, h0.y), mul_lo16(b1, h1.y)) + 2u;
+    const uint32_t t3 = add_hi16(mul_hi16(b0, h0.y), mul_hi16(b1, h1.y)) + 2u;
+    return pack_shr2(t0, t1, t2, t3, 2u);
+}
+
+// coef = b0 | b1 << 16, w = two 16-bit horizontal-pass values: products of the selected halves (SDWA picks both operands' halves: no extraction)
+#define OVS_MUL_SEL(name, s0, s1)                                                                                                                   \
+    __device__ __forceinline__ uint32_t name(uint32_t coef, uint32_t w) {                                                                           \
+        uint32_t d;                                                                                                                                  \
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" s0 " src1_sel:" s1 : "=v"(d) : "v"(coef), "v"(w));        \
+        return d;                                                                                                                                    \
+    }
+OVS_MUL_SEL(mul_c0_w0, "WORD_0", "WORD_0")
+OVS_MUL_SEL(mul_c0_w1, "WORD_0", "WORD_1")
+OVS_MUL_SEL(mul_c1_w0, "WORD_1", "WORD_0")
+OVS_MUL_SEL(mul_c1_w1, "WORD_1", "WORD_1")
+#undef OVS_MUL_SEL
+// four output pixels: rows h0 (coefficient b0 = low half of coef) and h1 (b1 = high half); the bytes are gathered by shifts and one v_perm_b32
+// instead of four partial-register writes (each of which costs a wait state): t <= 1022, so (t0 | t1 << 16) >> 2 has t0 >> 2 in byte 0 and
+// t1 >> 2 in byte 2
+__device__ __forceinline__ uint32_t vgroup_packed(const uint2 h0, const uint2 h1, const uint32_t coef) {
+    const uint32_t u0 = add_hi16(mul_c0_w0(coef, h0.x), mul_c1_w0(coef, h1.x));
+    const uint32_t u1 = add_hi16(mul_c0_w1(coef, h0.x), mul_c1_w1(coef, h1.x));
+    const uint32_t u2 = add_hi16(mul_c0_w0(coef, h0.y), mul_c1_w0(coef, h1.y));
+    const uint32_t u3 = add_hi16(mul_c0_w1(coef, h0.y), mul_c1_w1(coef, h1.y));
+    const uint32_t p01 = (((u1 << 16) | u0) + 0x00020002u) >> 2, p23 = (((u3 << 16) | u2) + 0x00020002u) >> 2;
+    return __builtin_amdgcn_perm(p23, p01, 0x06040200u);
+}
+
+// One tile's scalars (workgroup-uniform) ...
+struct PairTile {
+    int x0, y0, sx_lo, sy_lo, bx0, nG, nrB, own_g, own_r, ax_lo, nwordsA, ay_lo, nrA, cx_hi;
+    const uint8_t* s;
+    uint8_t *d1, *d2;
+};
+// ... and what a thread fetches for it ahead of time: its three staging chunks, its three column-pair records, its y-tap record
+struct PairFetch {
+    uint4 v[3];
+    uint4 r1, r2, r3;
+    uint32_t w1, w2, w3;
+    ResizeTap ty;
+};
+
+__global__ __launch_bounds__(256) void k_resize_pair_u8(const uint8_t* __restrict__ src, size_t src_frame_stride, int src_pitch,
+                                                       uint8_t* __restrict__ dst1, int pitch1, int rows1, int cols1, uint8_t* __restrict__ dst2,
+                                                       int pitch2, int rows2, int cols2, size_t dst_frame_stride,
+                                                       const ResizeTap* __restrict__ yt1, const ResizeTap* __restrict__ yt2,
+                                                       const HTapRec* __restrict__ ht1, const HTapRec* __restrict__ ht2,
+                                                       const PairSpan* __restrict__ plan, int tiles_x, int tiles_frame, int batch,
+                                                       uint32_t tiles_x_magic, uint32_t tiles_frame_magic) {
+    __shared__ __attribute__((aligned(16))) uint32_t bufA[kPairSrcRows * kPairSrcWords + 4];
+    __shared__ __attribute__((aligned(8))) uint32_t bufH[kPairSrcRows * 2 * kPairGroups];
+    // y taps as LDS records {byte offset of source row o0 in bufH | that of o1 << 16, a0 | a1 << 16}: the vertical passes read them with immediate offsets
+    __shared__ __attribute__((aligned(8))) uint2 s_tyA[48], s_tyB[kTileH];
+    static_assert(kPairSrcRows * kPairSrcWords >= kSrcRows * kSrcWords && kPairSrcRows * 2 * kPairGroups >= kSrcRows * (kTileW / 2), "stage B reuses both buffers");
+    const int tid = threadIdx.x;
+    const int xp = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware order: XCD k owns the k-th contiguous eighth of the tile sequence. (A form in which a workgroup took 2 - 8 consecutive tiles and fetched
+    // tile i + 1 into registers under tile i's arithmetic was measured: 121 VGPRs, 0.70 / 0.75 / 0.78 ms at 2 / 4 / 8 tiles against 0.705 for one tile
+    // per workgroup -- the kernel waits for its vector ALU, not for memory: profiles/r06z_pyr_pair.txt.)
+    const int per_xcd = gridDim.x >> 3;
+    const int first = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (first >= tiles_frame * batch) return;
+    // staging split: thread = (16-byte chunk column c, row phase sph), rows sph, sph + 18, sph + 36
+    const int sph = (tid * 4682) >> 16, sc = tid - sph * kPairRowChunks;   // tid / 14, tid % 14
+    static_assert(kPairRowChunks == 14 && 18 * kPairRowChunks <= 256 && 3 * 18 >= kPairSrcRows, "staging split");
+    const int p2 = 64 + (tid & 15);
+
+    auto decode = [&](int tile_id) -> PairTile {
+        PairTile t;
+        const int frame = (int)udiv_magic((uint32_t)tile_id, (uint32_t)tiles_frame, tiles_frame_magic);
+        const int trem = tile_id - frame * tiles_frame;
+        const int tyi = (int)udiv_magic((uint32_t)trem, (uint32_t)tiles_x, tiles_x_magic), txi = trem - tyi * tiles_x;
+        const PairSpan PX = plan[txi], PY = plan[tiles_x + tyi];
+        t.x0 = txi * kTileW;
+        t.y0 = tyi * kTileH;
+        t.s = src + (size_t)frame * src_frame_stride;
+        t.d1 = dst1 + (size_t)frame * dst_frame_stride;
+        t.d2 = dst2 + (size_t)frame * dst_frame_stride;
+        // stage B's tile origin (v4's sx_lo, sy_lo), the middle region [bx0, bx0 + 4 nG) x [sy_lo, sy_lo + nrB), the lower rectangle
+        t.sx_lo = PX.s_lo; t.sy_lo = PY.s_lo; t.bx0 = PX.b0; t.nG = PX.n; t.nrB = PY.n; t.own_g = PX.own; t.own_r = PY.own;
+        t.ax_lo = PX.a0; t.nwordsA = PX.an; t.ay_lo = PY.a0; t.nrA = PY.an;
+        t.cx_hi = min(t.bx0 + 4 * t.nG - 1, cols1 - 1);   // last middle column that exists
+        return t;
+    };
+    auto fetch = [&](const PairTile& t) -> PairFetch {
+        PairFetch f;
+        // the x taps of this thread's column pairs (host-built records: selectors, coefficients, first source word). stage A: phase 1 = column pairs
+        // 0 .. 63 of the region (lane = pair, wave q takes rows q, q + 4, ..), phase 2 = pairs 64 .. 79 (16 lanes per row group, 16 row groups);
+        // stage B: pair xp of the tile. Pairs outside the region take the last pair's record: values nobody reads.
+        const int jmax1 = t.cx_hi >> 1;
+        const HTapRec* const r1 = ht1 + min((t.bx0 >> 1) + xp, jmax1);
+        const HTapRec* const r2 = ht1 + min((t.bx0 >> 1) + p2, jmax1);
+        const HTapRec* const r3 = ht2 + min((t.x0 >> 1) + xp, (cols2 - 1) >> 1);
+        f.r1 = *reinterpret_cast<const uint4*>(r1);
+        f.r2 = *reinterpret_cast<const uint4*>(r2);
+        f.r3 = *reinterpret_cast<const uint4*>(r3);
+        f.w1 = r1->wa;
+        f.w2 = r2->wa;
+        f.w3 = r3->wa;
+        // the y tap of one row of the middle region (threads 0 .. 47) or of the tile (64 .. 95)
+        f.ty = ResizeTap{0, 0, 0, 0};
+        if (tid < 48) f.ty = yt1[min(t.sy_lo + tid, rows1 - 1)];
+        else if (tid >= 64 && tid < 64 + kTileH) f.ty = yt2[min(t.y0 + tid - 64, rows2 - 1)];
+        // the lower rectangle: one address, two strides
+        const int gx = t.ax_lo + 16 * sc;
+        const bool col_in = sph < 18 && 4 * sc < t.nwordsA, whole = gx + 16 <= src_pitch;
+        const uint8_t* p = t.s + (size_t)(t.ay_lo + sph) * src_pitch + gx;
+#pragma unroll
+        for (int k = 0; k < 3; ++k, p += (size_t)18 * src_pitch) {
+            f.v[k] = uint4{0u, 0u, 0u, 0u};
+            if (col_in && sph + 18 * k < t.nrA) {
+                if (whole) {
+                    f.v[k] = *reinterpret_cast<const uint4*>(p);
+                } else {   // row tail
+                    const uint32_t* p4 = reinterpret_cast<const uint32_t*>(p);
+                    if (gx + 4 <= src_pitch) f.v[k].x = p4[0];
+                    if (gx + 8 <= src_pitch) f.v[k].y = p4[1];
+                    if (gx + 12 <= src_pitch) f.v[k].z = p4[2];
+                }
+            }
+        }
+        return f;
+    };
+
+    const PairTile T = decode(first);
+    const PairFetch F = fetch(T);
+    {
+        // ---- this tile's fetched data -> LDS
+        {
+            const bool col_in = sph < 18 && 4 * sc < T.nwordsA;
+            uint4* const w = reinterpret_cast<uint4*>(&bufA[0]) + sph * kPairRowChunks + sc;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (col_in && sph + 18 * k < T.nrA) w[k * 18 * kPairRowChunks] = F.v[k];
+            if (tid < 48)
+                s_tyA[tid] = uint2{(uint32_t)((F.ty.o0 - T.ay_lo) * (8 * kPairGroups)) | ((uint32_t)((F.ty.o1 - T.ay_lo) * (8 * kPairGroups)) << 16),
+                                   (uint32_t)(uint16_t)F.ty.a0 | ((uint32_t)(uint16_t)F.ty.a1 << 16)};
+            else if (tid >= 64 && tid < 64 + kTileH)
+                s_tyB[tid - 64] = uint2{(uint32_t)((F.ty.o0 - T.sy_lo) * (2 * kTileW)) | ((uint32_t)((F.ty.o1 - T.sy_lo) * (2 * kTileW)) << 16),
+                                        (uint32_t)(uint16_t)F.ty.a0 | ((uint32_t)(uint16_t)F.ty.a1 << 16)};
+        }
+        const HTaps t1 = HTaps{F.r1.x, F.r1.y, F.r1.z, F.r1.w, (int)F.w1 - (T.ax_lo >> 2)};
+        const HTaps t2 = HTaps{F.r2.x, F.r2.y, F.r2.z, F.r2.w, (int)F.w2 - (T.ax_lo >> 2)};
+        const HTaps t3 = HTaps{F.r3.x, F.r3.y, F.r3.z, F.r3.w, (int)F.w3 - (T.sx_lo >> 2)};
+        const PairTile& C = T;
+        __syncthreads();
+        // ---- stage A, horizontal pass: bufH[r][pair] for the 52 rows of the rectangle (rows >= nrA hold stale bytes nobody reads)
+        {
+            const uint32_t* Ts = &bufA[q * kPairSrcWords + t1.wa];
+            uint32_t* H = &bufH[q * (2 * kPairGroups) + xp];
+            static_assert(kPairSrcRows == 52, "thirteen steps of four rows, four steps of sixteen");
+            uint32_t lo[13], hi[13];
+#pragma unroll
+            for (int k = 0; k < 13; ++k) {
+                lo[k] = Ts[4 * k * kPairSrcWords];
+                hi[k] = Ts[4 * k * kPairSrcWords + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 13; ++k) H[4 * k * (2 * kPairGroups)] = hpair(lo[k], hi[k], t1);
+            const int r0 = tid >> 4;
+            const uint32_t* T2 = &bufA[r0 * kPairSrcWords + t2.wa];
+            uint32_t* H2 = &bufH[r0 * (2 * kPairGroups) + p2];
+            uint32_t lo2[4], hi2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in = r0 + 16 * k < kPairSrcRows;
+                lo2[k] = in ? T2[16 * k * kPairSrcWords] : 0u;
+                hi2[k] = in ? T2[16 * k * kPairSrcWords + 1] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (r0 + 16 * k < kPairSrcRows) H2[16 * k * (2 * kPairGroups)] = hpair(lo2[k], hi2[k], t2);
+        }
+        __syncthreads();
+        // ---- stage A, vertical pass: the middle region into bufA (laid out as v4's staged tile: pitch kSrcWords, origin (sx_lo, sy_lo)) and, where
+        // this tile owns it, into the middle level's plane. Thread = (4-pixel group grp, row phase ph), rows ph, ph + 6, ..: constant strides.
+        {
+            const int ph = (tid * 1639) >> 16, grp = tid - ph * kPairGroups;   // tid / 40, tid % 40
+            static_assert(kPairGroups == 40 && 6 * kPairGroups <= 256 && 6 * 8 >= kSrcRows, "vertical split of stage A");
+            const bool gvalid = ph < 6 && grp < C.nG;
+            const int x4 = C.bx0 + 4 * grp;
+            const bool own_ok = grp < C.own_g && x4 < cols1;
+            uint8_t* gp = C.d1 + (size_t)(C.sy_lo + ph) * pitch1 + x4;
+            uint32_t* const tb = &bufA[ph * kSrcWords + ((C.bx0 - C.sx_lo) >> 2) + grp];
+            const uint8_t* const hb = reinterpret_cast<const uint8_t*>(&bufH[0]) + 8 * grp;
+            const uint2* const ty = &s_tyA[ph];
+#pragma unroll
+            for (int k = 0; k < 8; ++k, gp += (size_t)6 * pitch1) {
+                const int row = ph + 6 * k;
+                if (gvalid && row < C.nrB) {
+                    const uint2 t = ty[6 * k];
+                    const uint2 h0 = *reinterpret_cast<const uint2*>(hb + (t.x & 0xffffu));
+                    const uint2 h1 = *reinterpret_cast<const uint2*>(hb + (t.x >> 16));
+                    const uint32_t out = vgroup_packed(h0, h1, t.y);
+                    tb[6 * k * kSrcWords] = out;
+                    if (own_ok && row < C.own_r) *reinterpret_cast<uint32_t*>(gp) = out;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- stage B = v4 on the LDS tile: horizontal pass
+        {
+            const uint32_t* Ts = &bufA[q * kSrcWords + t3.wa];
+            uint32_t* H = &bufH[q * (kTileW / 2) + xp];
+            uint32_t lo[11], hi[11];
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                lo[k] = Ts[4 * k * kSrcWords];
+                hi[k] = Ts[4 * k * kSrcWords + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 11; ++k) H[4 * k * (kTileW / 2)] = hpair(lo[k], hi[k], t3);
+        }
+        __syncthreads();
+        // ---- stage B: vertical pass + store (thread = (group, row phase), rows ph, ph + 8, ..)
+        {
+            const int xg = tid & 31, ph = tid >> 5, x4 = C.x0 + 4 * xg;
+            const bool xok = x4 < cols2;
+            uint8_t* gp = C.d2 + (size_t)(C.y0 + ph) * pitch2 + x4;
+            const uint8_t* const hb = reinterpret_cast<const uint8_t*>(&bufH[0]) + 8 * xg;
+            const uint2* const ty = &s_tyB[ph];
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g, gp += (size_t)8 * pitch2) {
+                if (xok && C.y0 + ph + 8 * g < rows2) {
+                    const uint2 t = ty[8 * g];
+                    const uint2 h0 = *reinterpret_cast<const uint2*>(hb + (t.x & 0xffffu));
+                    const uint2 h1 = *reinterpret_cast<const uint2*>(hb + (t.x >> 16));
+                    *reinterpret_cast<uint32_t*>(gp) = vgroup_packed(h0, h1, t.y);
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_resize_pair(const uint8_t* src, size_t src_frame_stride, int src_pitch, uint8_t* dst1, int pitch1, int rows1, int cols1,
+                              uint8_t* dst2, int pitch2, int rows2, int cols2, size_t dst_frame_stride, const ResizeTap* yt1, const ResizeTap* yt2,
+                              const HTapRec* ht1, const HTapRec* ht2, const PairSpan* plan, int batch, hipStream_t s) {
+    const int tiles_x = (cols2 + kTileW - 1) / kTileW, tiles_y = (rows2 + kTileH - 1) / kTileH;
+    const int tiles_frame = tiles_x * tiles_y;
+    dim3 grid(((tiles_frame * batch + 7) / 8) * 8);
+    auto magic = [](int d) { return d > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d) : 0u; };
+    hipLaunchKernelGGL(k_resize_pair_u8, grid, dim3(256), 0, s, src, src_frame_stride, src_pitch, dst1, pitch1, rows1, cols1, dst2, pitch2, rows2, cols2,
+                       dst_frame_stride, yt1, yt2, ht1, ht2, plan, tiles_x, tiles_frame, batch, magic(tiles_x), magic(tiles_frame));
+    return hipGetLastError();
+}
+// the conditions launch_resize_pair adds to those of the plan (pair_ok): what v4 asks of its source and of the tile count
+bool resize_pair_launchable(const uint8_t* src, size_t src_frame_stride, int src_pitch, int rows2, int cols2, int batch) {
+    const int tiles_x = (cols2 + kTileW - 1) / kTileW, tiles_y = (rows2 + kTileH - 1) / kTileH;
+    const uint64_t tiles_frame = (uint64_t)tiles_x * tiles_y;
+    return ((src_pitch & 15) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && ((src_frame_stride & 15) == 0) &&
+           tiles_frame * tiles_frame * (uint64_t)batch < (1ull << 32);
+}
+
+// ================================================================================================================================
 // k_pyramid_chain (round 5): ALL levels of ONE frame (or a few) in a single launch -- the tracker's per-frame extract spent 7 x 5.7 us in
 // seven DEPENDENT resize launches (plus the gaps between them) for ~1 us of arithmetic each (profiles/r04g_tracked_frame_trace.txt).
 // A workgroup owns one tile of every level (the levels are partitioned by the same TX x TY grid, proportionally) and computes the chain

@@ -106,6 +106,24 @@ struct DevBuffers {
 struct ChainSpan {
     int16_t c0, c1, o0, o1;
 };
+// k_resize_pair_u8 (orb_pyramid.hip): what one tile column (or tile row) of the UPPER level's 128 x 32 tile grid needs of the two levels below it.
+// Column spans: s_lo = origin of stage B's LDS tile (first tap & ~15), b0 = first middle column the tile computes (first tap & ~3), n = 4-pixel
+// groups of the middle region, own = groups it stores (up to the next tile's b0; all of them for the last tile), a0 = first lower column staged
+// (& ~15), an = 32-bit words per staged row. Row spans: s_lo = b0 = first middle row, n = rows of the region, own = rows stored, a0 / an = first
+// lower row / rows staged.
+struct PairSpan {
+    int16_t s_lo, b0, n, own, a0, an, pad0, pad1;
+};
+static_assert(sizeof(PairSpan) == 16, "PairSpan is read as one 128-bit word");
+// k_resize_pair_u8's horizontal pass for the column pair (2 j, min(2 j + 1, cols - 1)) of a level, built on the host from the level's x taps
+// (orb_api.hip build_htaps; the kernel used to derive it per thread and tile: ~25 vector instructions three times over): the two v_perm_b32
+// selectors that pair (S[o0], S[o1]) out of the two aligned source words starting at word wa, and the two coefficient words (16 a0 | 16 a1 << 16).
+struct HTapRec {
+    uint32_t sel_a, sel_b, ca, cb;
+    uint32_t wa;   // o0(2 j) >> 2, in words from the start of the source row
+    uint32_t pad0, pad1, pad2;
+};
+static_assert(sizeof(HTapRec) == 32, "HTapRec: one 128-bit load + one word");
 constexpr int kChainMaxW = 192;        // widest computed region of a level >= 1 (three 64-lane column chunks)
 constexpr int kChainMaxW0 = 256;       // widest staged level-0 rectangle (64 words)
 constexpr int kChainMaxH0 = 128;       // its height (16 waves x 8 rows)
@@ -116,6 +134,10 @@ size_t chain_lds_bytes(int bufA_bytes, int bufB_bytes, int tap_cap);   // dynami
 hipError_t launch_pyramid_chain(const uint8_t* img0, size_t frame_stride0, int pitch0, uint8_t* pyr, size_t pyr_frame_bytes, const FrameGeo* d_geo,
                                 const ResizeTap* d_taps, const ChainSpan* d_plan, int TX, int TY, int bufA_bytes, int bufB_bytes, int tap_cap,
                                 int batch, hipStream_t s);
+hipError_t launch_resize_pair(const uint8_t* src, size_t src_frame_stride, int src_pitch, uint8_t* dst1, int pitch1, int rows1, int cols1,
+                              uint8_t* dst2, int pitch2, int rows2, int cols2, size_t dst_frame_stride, const ResizeTap* yt1, const ResizeTap* yt2,
+                              const HTapRec* ht1, const HTapRec* ht2, const PairSpan* plan, int batch, hipStream_t s);
+bool resize_pair_launchable(const uint8_t* src, size_t src_frame_stride, int src_pitch, int rows2, int cols2, int batch);
 hipError_t launch_resize(const uint8_t* src, size_t src_frame_stride, int src_pitch, int srows, int scols, uint8_t* dst,
                          size_t dst_frame_stride, int dst_pitch, int drows, int dcols, const ResizeTap* xt, const ResizeTap* yt,
                          int batch, hipStream_t s, int hwin_ok);
@@ -143,6 +165,7 @@ struct Tuning {
     int pose_groups;       // OVS_POSE_GROUPS: workgroups a single frame's pose optimisation is spread over (0 = by observation count, 1 = one)
     bool ba_trace;         // OVS_BA_TRACE: per-iteration trace of the LM loops on stderr
     bool chol_resident;    // OVS_CHOL_RESIDENT=0: systems up to 288 unknowns take k_chol_solve (tiles through memory) instead of k_chol_resident
+    bool pyr_pair;         // OVS_PYR_PAIR=0: batches build the pyramid level by level (k_resize_linear_u8 x7) instead of two levels per launch (k_resize_pair_u8, round 6)
     int pyr_chain;         // OVS_PYR_CHAIN: frames per launch up to which the pyramid is ONE k_pyramid_chain launch (default 2: measured 24 vs 37 us for one frame, 33.5 vs 35.7 for two, 73 vs 46 for eight; 0 = never)
 };
 const Tuning& tuning();

@@ -239,7 +239,8 @@ def test_large_batch_takes_the_many_problem_tree_kernel(hip, oracle):
 
 
 def test_alternative_kernel_forms_give_the_same_bytes(tmp_path):
-    """Round 6 left four process-wide switches between kernel forms (read once per process, so each runs in a child): the one-wavefront-per-cell
+    """Round 6 left five process-wide switches between kernel forms (the fifth: OVS_PYR_PAIR=0, the pyramid level by level instead of two levels per launch;
+    the other four: (read once per process, so each runs in a child): the one-wavefront-per-cell
     FAST (OVS_FAST_IMPL=2), the frames-fastest work order of rounds 3-5 (OVS_FAST_MAP=0), the quad-tree's sweep form only (OVS_TREE_GRID=0) and
     its grid form at a forced depth (OVS_TREE_GRID=3: most levels overflow and fall back inside the launch; 7: the deepest grid). Every one must
     reproduce the default's counts, keypoint records and descriptors byte for byte on a 70-frame batch (which the test above checks against
@@ -277,7 +278,7 @@ print("SHA", h.hexdigest(), int(cnt.sum()))
 """
     out = {}
     for tag, env in (("default", {}), ("wave", {"OVS_FAST_IMPL": "2"}), ("frames_fastest", {"OVS_FAST_MAP": "0"}), ("sweeps", {"OVS_TREE_GRID": "0"}),
-                     ("grid3", {"OVS_TREE_GRID": "3"}), ("grid7", {"OVS_TREE_GRID": "7"})):
+                     ("grid3", {"OVS_TREE_GRID": "3"}), ("grid7", {"OVS_TREE_GRID": "7"}), ("pyramid_per_level", {"OVS_PYR_PAIR": "0"})):
         r = subprocess.run([sys.executable, "-c", code % root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (tag, r.stderr[-2000:])
         line = [l for l in r.stdout.splitlines() if l.startswith("SHA")][-1].split()
@@ -455,3 +456,34 @@ def test_extract_pair_equals_two_extracts():
         one.extract_pair(a, b)
     with pytest.raises(ValueError):
         two.extract_pair(a, b, m, None)
+
+
+@pytest.mark.parametrize("rows,cols,levels,scale", [(1080, 1920, 8, 1.2), (480, 752, 8, 1.2), (376, 1241, 8, 1.2), (500, 643, 7, 1.2), (1920, 3840, 8, 1.2),
+                                                    (301, 403, 12, 1.1), (333, 1027, 6, 1.25), (480, 640, 4, 2.0), (97, 4000, 5, 1.2), (2000, 131, 8, 1.2)])
+def test_two_levels_per_launch_pyramid_planes(hip, oracle, rows, cols, levels, scale):
+    """k_resize_pair_u8 (round 6: batches compute levels l + 1 and l + 2 from a staged rectangle of level l; the middle level is stored by the tile
+    that owns each 4-pixel group, the halos are recomputed) against the oracle's cv::resize restatement: every plane of every frame of a
+    three-frame batch byte-equal. Geometries: the four BASELINE sizes, odd widths and heights (ragged last tiles in both levels), very wide and very
+    tall strips (one tile row / one tile column), 7 levels (three pairs, no single level left) and 8 (one left), scale factors whose pairs have no
+    plan (2.0: the launcher falls back to one level per launch) and others that do (1.1, 1.25)."""
+    import torch
+    B = 3
+    imgs = np.stack([synth_frame(rows, cols, seed=900 + b) for b in range(B)])
+    ex = hip.orb_extractor(hip.orb_params(300, scale, levels, 20, 7), max_rows=rows, max_cols=cols, max_batch=B)
+    ex.set_pyramid_chain(0)   # never the one-launch chain: this test is about the batch form
+    ox = oracle.OrbExtractor(oracle.make_params(300, scale, levels, 20, 7))
+    cap = ex.max_keypoints
+    pitch = (cols + 3) // 4 * 4   # (the ABI's alignment rule; 16-byte aligned rows take the two-level kernel from level 0, others from level 1)
+    d_full = torch.zeros((B, rows, pitch), dtype=torch.uint8, device="cuda")
+    d_full[:, :, :cols] = torch.from_numpy(imgs).cuda()
+    d_img = d_full[:, :, :cols]
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    ex.extract_batch_dev(d_img, d_kps, d_desc, d_cnt, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for b in range(B):
+        ox.extract(imgs[b])
+        for l in range(levels):
+            got, want = ex.image_pyramid(l, frame=b), ox.level_image(l)
+            assert got.shape == want.shape and np.array_equal(got, want), (b, l, np.argwhere(got != want)[:5].tolist() if got.shape == want.shape else got.shape)
