@@ -318,6 +318,7 @@ struct ovs_orb {
     unsigned n_submitted = 0, n_collected = 0;
     int last_slot = -1;              // slot of the last COLLECTED frame (host pyramid getter)
     bool host_pyr = false;
+    uint8_t* mirror_out = nullptr;     // set by ovs_orb_extract_submit around its run_extract: the pinned block k_describe also writes the results into
     bool cand_count_cleared = false;   // ovs_orb_extract_submit has already enqueued the clearing of the candidate counters for the next run_extract
     int host_mode = 0;               // 0: hipMemcpy2DAsync straight from the caller's (pageable) rows (measured 0.054 ms per 1080p frame);
                                      // 1: banded copy through pinned staging (0.12 ms: the CPU memcpy costs more than the runtime's own staging)
@@ -616,7 +617,11 @@ ovs_status run_chain(ovs_orb* h, StageProfiler<4>& prof, const uint8_t* d_images
         OVS_HIP_TRY(launch_tree(geo, d, nb, s));
     }
     OVS_HIP_TRY(prof.mark(3, s));
-    OVS_HIP_TRY(launch_describe(geo, d, img, stride, frame_stride, d_kps + (size_t)f0 * cap, d_desc + (size_t)f0 * cap * 32, d_counts + f0, cap, nb, s));
+    // a one-frame host call: the results also go straight into its pinned block (h->mirror_out: [counts 16 B | keypoints | descriptors])
+    uint8_t* const mo = (h->mirror_out && nb == 1 && f0 == 0 && d_kps == h->d_out_kps && cap == h->out_cap) ? h->mirror_out : nullptr;
+    OVS_HIP_TRY(launch_describe(geo, d, img, stride, frame_stride, d_kps + (size_t)f0 * cap, d_desc + (size_t)f0 * cap * 32, d_counts + f0, cap, nb, s,
+                                mo ? reinterpret_cast<ovs_keypoint*>(mo + 16) : nullptr, mo ? mo + h->out_off_desc : nullptr,
+                                mo ? reinterpret_cast<int32_t*>(mo) : nullptr));
     OVS_HIP_TRY(prof.mark(4, s));
     return OVS_OK;
 }
@@ -1048,8 +1053,17 @@ ovs_status ovs_orb_extract_submit(ovs_orb* h, const uint8_t* image, int32_t rows
     h->cand_count_cleared = true;
     struct ClearedGuard {   // the flag lives inside this call: whatever path leaves it, the next run_extract clears its own counters
         ovs_orb* h;
-        ~ClearedGuard() { h->cand_count_cleared = false; }
+        ~ClearedGuard() {
+            h->cand_count_cleared = false;
+            h->mirror_out = nullptr;
+        }
     } cleared_guard{h};
+    // OVS_ORB_ZERO_COPY_OUT=0: results through a D2H copy command after the kernels (rounds 1-5)
+    static const bool zero_copy_out = [] {
+        const char* e = std::getenv("OVS_ORB_ZERO_COPY_OUT");
+        return !(e && e[0] == '0');
+    }();
+    h->mirror_out = zero_copy_out ? sl.h_out : nullptr;
     if (timed) OVS_HIP_TRY(hipEventRecord(sl.t[0], cs));
     st = upload_plane(h, image, stride, rows, cols, sl.h_in, sl.d_img);
     if (st != OVS_OK) return st;
@@ -1067,7 +1081,7 @@ ovs_status ovs_orb_extract_submit(ovs_orb* h, const uint8_t* image, int32_t rows
     if (st != OVS_OK) return st;
     if (timed) OVS_HIP_TRY(hipEventRecord(sl.t[2], s));
     // ONE D2H for counts + keypoints + descriptors (120 KB at 2000 features: cheaper than a count round trip followed by two copies)
-    OVS_HIP_TRY(hipMemcpyAsync(sl.h_out, h->d_out_counts, h->out_block_bytes, hipMemcpyDeviceToHost, s));
+    if (!h->mirror_out) OVS_HIP_TRY(hipMemcpyAsync(sl.h_out, h->d_out_counts, h->out_block_bytes, hipMemcpyDeviceToHost, s));
     sl.has_pyr = false;
     if (h->host_pyr && h->p.num_levels > 1) {
         if (!sl.h_pyr) OVS_HIP_TRY(hipHostMalloc(&sl.h_pyr, h->d.pyr_frame_bytes, hipHostMallocDefault));

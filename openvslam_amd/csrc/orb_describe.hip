@@ -138,7 +138,10 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
                                                 size_t frame_stride0, const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                                 const uint64_t* __restrict__ lvl_kps, const uint32_t* __restrict__ lvl_count,
                                                 ovs_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                int32_t* __restrict__ counts, int cap, int batch, int xcd_map) {
+                                                int32_t* __restrict__ counts, int cap, int batch, int xcd_map, ovs_keypoint* __restrict__ kps_m,
+                                                uint8_t* __restrict__ desc_m, int32_t* __restrict__ counts_m) {
+    // kps_m / desc_m / counts_m (round 6, one-frame host calls): a second copy of every output, written straight into the caller-side pinned
+    // block -- the frame's results then need no D2H copy command after the kernel (nullptr: batches, device-resident callers)
     __shared__ __attribute__((aligned(16))) uint8_t patch[kPatch * kPatchPitch];
     __shared__ __attribute__((aligned(16))) uint16_t hblur[kPatch * kHbPitch];
 
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
         int total = 0;
         for (int l = 0; l < L; ++l) total += cnt[l];
         counts[frame] = total < cap ? total : cap;
+        if (counts_m) counts_m[frame] = total < cap ? total : cap;
     }
     if (slot >= (int)cnt[level]) return;
     int out_idx = slot;
@@ -317,6 +321,7 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
     if (lane < 4) {
         const unsigned long long b = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
         reinterpret_cast<unsigned long long*>(desc + ((size_t)frame * cap + out_idx) * 32)[lane] = b;
+        if (desc_m) reinterpret_cast<unsigned long long*>(desc_m + ((size_t)frame * cap + out_idx) * 32)[lane] = b;
     }
     if (lane == 0) {
         ovs_keypoint k;
@@ -328,16 +333,18 @@ __global__ __launch_bounds__(64) void k_describe(const FrameGeo* __restrict__ ge
         k.octave = level;
         k.class_id = -1;
         kps[(size_t)frame * cap + out_idx] = k;
+        if (kps_m) kps_m[(size_t)frame * cap + out_idx] = k;
     }
 }
 
 hipError_t launch_describe(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
-                           ovs_keypoint* kps, uint8_t* desc, int32_t* counts, int cap, int batch, hipStream_t s) {
+                           ovs_keypoint* kps, uint8_t* desc, int32_t* counts, int cap, int batch, hipStream_t s, ovs_keypoint* kps_m, uint8_t* desc_m,
+                           int32_t* counts_m) {
     const int xcd_map = tuning().describe_xcd ? 1 : 0;   // 0: plain frame-major order (A/B of the XCD mapping)
     const int frames = xcd_map ? ((batch + 7) & ~7) : batch;   // frame 8 g + x on XCD x: pad the last group
     dim3 grid((unsigned)hgeo.total_kp_cap * (unsigned)frames);
     hipLaunchKernelGGL(k_describe, grid, dim3(64), 0, s, d.geo, img0, stride0, frame_stride0, d.pyr, d.pyr_frame_bytes, d.lvl_kps,
-                       d.lvl_count, kps, desc, counts, cap, batch, xcd_map);
+                       d.lvl_count, kps, desc, counts, cap, batch, xcd_map, kps_m, desc_m, counts_m);
     return hipGetLastError();
 }
 

@@ -147,7 +147,8 @@ hipError_t launch_tree(const FrameGeo& hgeo, const DevBuffers& d, int batch, hip
 size_t tree_lds_bytes_for(const FrameGeo& hgeo);
 constexpr size_t kMaxLdsPerWorkgroup = 160 * 1024;
 hipError_t launch_describe(const FrameGeo& hgeo, const DevBuffers& d, const uint8_t* img0, size_t stride0, size_t frame_stride0,
-                           ovs_keypoint* kps, uint8_t* desc, int32_t* counts, int cap, int batch, hipStream_t s);
+                           ovs_keypoint* kps, uint8_t* desc, int32_t* counts, int cap, int batch, hipStream_t s, ovs_keypoint* kps_m = nullptr, uint8_t* desc_m = nullptr,
+                           int32_t* counts_m = nullptr);
 
 // Tuning / A-B switches of the launchers. Read from the environment ONCE per process (first use; thread-safe static initialisation) -- the
 // launch paths never call getenv, which is not safe against a host application's concurrent setenv. All default to the production setting.
