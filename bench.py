@@ -487,7 +487,7 @@ def main():
                 live_valu = int(live["insts_valu"] * (Bc / float(live["batch"])))
             else:
                 traffic_live_note = "live PMC passes unavailable (%s)" % note
-        roof = {"bound": "hbm", "kernel": {"pyramid": "k_resize_linear_u8 (x7)", "fast": "k_fast_cells", "tree": "k_tree",
+        roof = {"bound": "hbm", "kernel": {"pyramid": "k_resize_pair_u8 (x3) + k_resize_linear_u8", "fast": "k_fast_cells", "tree": "k_tree",
                                            "describe": "k_describe", "match_near": "k_hamming_near",
                                            "match_resolve": "k_bf_resolve"}[dom],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),

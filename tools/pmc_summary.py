@@ -48,28 +48,34 @@ for k in sorted(acc, key=lambda k: -sum(acc[k].get("SQ_WAVE_CYCLES", [0]))):
 # re-fetched by another XCD's L2 and Infinity-Cache hits are included.
 if "--json" in sys.argv:
     import json
-    stage_of = {"ovs::k_fast_cells": "fast", "ovs::k_resize_linear_u8": "pyramid", "ovs::k_tree": "tree", "ovs::k_describe": "describe",
-                "ovs::k_hamming_near": "match_near", "ovs::k_bf_resolve": "match_resolve"}
-    launches_per_call = {"pyramid": 7}
+    # a stage's kernels (the pyramid of a batch is three k_resize_pair_u8 launches + one k_resize_linear_u8 since round 6: the stage's figure is the
+    # SUM over its launches divided by the number of stage calls = launches of k_describe, one per extract call)
+    stage_of = {"ovs::k_fast_cells": "fast", "ovs::k_resize_linear_u8": "pyramid", "ovs::k_resize_pair_u8": "pyramid", "ovs::k_tree": "tree",
+                "ovs::k_describe": "describe", "ovs::k_hamming_near": "match_near", "ovs::k_bf_resolve": "match_resolve"}
+    call_marker = {"pyramid": "ovs::k_describe"}   # stages whose calls are not one launch each: counted by this kernel's launches
+    stages = sorted(set(stage_of.values()))
+    def kernels_of(st):
+        return [n for n in acc if stage_of.get(n.replace("void ", "").split("<")[0].strip().split("(")[0].strip()) == st]   # exact kernel (k_hamming_near, not k_hamming_near_popc)
+    def calls_of(st, counter):
+        if st in call_marker:
+            mk = [n for n in acc if n.replace("void ", "").split("<")[0].strip().split("(")[0].strip() == call_marker[st]]
+            return sum(len(acc[n].get(counter, [])) for n in mk) or 1
+        return sum(len(acc[n].get(counter, [])) for n in kernels_of(st)) or 1
     out = {}
-    for k, st in stage_of.items():
-        kk = [n for n in acc if n.replace("void ", "").split("<")[0].strip() == k]   # exact kernel (k_hamming_near, not k_hamming_near_popc)
+    for st in stages:
+        kk = kernels_of(st)
         if not kk:
             continue
         f = sum(sum(acc[n].get("FETCH_SIZE", [])) for n in kk)
         w = sum(sum(acc[n].get("WRITE_SIZE", [])) for n in kk)
-        nf = sum(len(acc[n].get("FETCH_SIZE", [])) for n in kk) or 1
-        nw = sum(len(acc[n].get("WRITE_SIZE", [])) for n in kk) or 1
-        per_launch = (2.0 * f / nf + w / nw) * 1024.0
-        out[st] = int(per_launch * launches_per_call.get(st, 1))
+        out[st] = int((2.0 * f / calls_of(st, "FETCH_SIZE") + w / calls_of(st, "WRITE_SIZE")) * 1024.0)
     # VALU / SALU wave-instructions per stage call (SQ pass) for bench.py's roofline_valu
     for cname, key in (("SQ_INSTS_VALU", "insts_valu"), ("SQ_INSTS_SALU", "insts_salu")):
         d = {}
-        for k, st in stage_of.items():
-            kk = [n for n in acc if n.replace("void ", "").split("<")[0].strip() == k]
-            vals = [v for n in kk for v in acc[n].get(cname, [])]
+        for st in stages:
+            vals = [v for n in kernels_of(st) for v in acc[n].get(cname, [])]
             if vals:
-                d[st] = int(sum(vals) / len(vals) * launches_per_call.get(st, 1))
+                d[st] = int(sum(vals) / calls_of(st, cname))
         if d:
             out[key] = d
     # fingerprints of the kernel sources the counters were collected from, per stage: bench.py refuses a stage's figure when that stage's
