@@ -45,7 +45,9 @@ def test_optimiser_kernels_keep_their_register_budgets(ba_kernels):
     pairs = [v for k, v in ba_kernels.items() if k == "ovs::k_schur"]   # pair blocks + right-hand side rows in one launch (round 5)
     assert len(pairs) == 1 and pairs[0]["scratch"] == 0 and pairs[0]["vgpr"] + pairs[0]["agpr"] <= 168     # 512 / 3 waves per SIMD
     pose = {k: v for k, v in ba_kernels.items() if k.startswith("ovs::k_pose_optimize<")}
-    assert pose["ovs::k_pose_optimize<0, 256>"]["scratch"] == 0 and pose["ovs::k_pose_optimize<1, 256>"]["scratch"] == 0
+    # (third template argument, round 6: 2 = a thread's at most two observations held in registers, 0 = re-read from memory per pass)
+    for name in ("ovs::k_pose_optimize<0, 256, 0>", "ovs::k_pose_optimize<1, 256, 0>", "ovs::k_pose_optimize<0, 256, 2>", "ovs::k_pose_optimize<1, 256, 2>"):
+        assert pose[name]["scratch"] == 0 and pose[name]["vgpr"] + pose[name]["agpr"] <= 256, name   # two waves per SIMD or more
 
 
 def test_no_kernel_touches_scratch_memory():
