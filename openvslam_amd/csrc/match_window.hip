@@ -945,6 +945,7 @@ struct ovs_wmatcher {
     uint32_t* d_offsets = nullptr;
     uint32_t* d_keys = nullptr;
     uint32_t* d_overflow = nullptr;
+    bool overflow_dirty = true;        // the overflow word may be non-zero (build_lists clears it then)
     int32_t* d_assigned = nullptr;      // max(max_q, max_t)
     int32_t* d_num = nullptr;
     // host-API staging
@@ -1101,7 +1102,12 @@ static uint32_t dead_from_thr(uint32_t thr) { return thr + 1u; }   // rules with
 template <typename ARGS, typename KCOUNT, typename KFILL>
 ovs_status build_lists(ovs_wmatcher* w, const ARGS& args, int n_q, KCOUNT kcount, KFILL kfill, hipStream_t s, int q_per_block = 4) {
     if (n_q > w->max_q) return OVS_ERR_CAPACITY;
-    OVS_HIP_TRY(hipMemsetAsync(w->d_overflow, 0, sizeof(uint32_t), s));
+    // the overflow word is zero between calls unless a call ended without having read it as zero (a failed call, an overflow): only then is it cleared
+    // here (round 6: the clearing was a fill kernel and a launch gap in front of every list build).
+    // (Also tried: the counting launch's last workgroup scanning the counts instead of the one-workgroup k_scan_counts launch -- the device-scope
+    // release every workgroup needs before it takes its ticket is an L2 write-back on this multi-XCD part: +20 us per call, dropped.)
+    if (w->overflow_dirty) OVS_HIP_TRY(hipMemsetAsync(w->d_overflow, 0, sizeof(uint32_t), s));
+    w->overflow_dirty = true;
     const dim3 grid((n_q + q_per_block - 1) / q_per_block);
     hipLaunchKernelGGL(kcount, grid, dim3(256), 0, s, args, w->d_counts, (const uint32_t*)w->d_offsets, w->d_keys, w->max_entries, w->d_overflow);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, (const uint32_t*)w->d_counts, n_q, w->d_offsets);
@@ -1162,6 +1168,7 @@ ovs_status fetch_results(ovs_wmatcher* w, int n_out, int32_t* assigned, int32_t*
     OVS_HIP_TRY(hipStreamSynchronize(s));
     std::memcpy(assigned, w->h_res + 8, sizeof(int32_t) * (size_t)n_out);
     *num_matches = w->h_res[1];
+    if (check_overflow && w->h_res[0] == 0) w->overflow_dirty = false;   // read as zero behind every kernel of the call: still zero for the next one
     return (check_overflow && w->h_res[0]) ? OVS_ERR_CAPACITY : OVS_OK;   // (k_fuse_best writes no overflow flag: the word may be stale)
 }
 
@@ -1204,6 +1211,7 @@ ovs_status ovs_wmatcher_create(int32_t max_targets, int32_t max_queries, int32_t
     w->d_overflow = w->d_res_block;
     w->d_num = reinterpret_cast<int32_t*>(w->d_res_block) + 1;
     w->d_assigned = reinterpret_cast<int32_t*>(w->d_res_block) + 8;
+    CREATE_TRY(hipMemset(w->d_res_block, 0, sizeof(int32_t) * 8));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&w->h_res), sizeof(int32_t) * (8 + M), hipHostMallocDefault));
     // per-call query-side staging: keypoints 28 + descriptors 32 + positions 24 + xy 8 + four 4-byte arrays + flags, per query, and the
     // target-side flags; 256-byte alignment slack per array
@@ -1359,6 +1367,7 @@ ovs_status ovs_projection_match_frame_and_landmarks(ovs_wmatcher* w, const ovs_g
     OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipStreamSynchronize(s));
+    if (!overflow) w->overflow_dirty = false;
     return overflow ? OVS_ERR_CAPACITY : OVS_OK;
 }
 
@@ -1438,6 +1447,7 @@ ovs_status ovs_area_match_in_consistent_area(ovs_wmatcher* w, const ovs_grid_par
     OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipStreamSynchronize(s));
+    if (!overflow) w->overflow_dirty = false;
     return overflow ? OVS_ERR_CAPACITY : OVS_OK;
 }
 
@@ -1586,6 +1596,7 @@ static ovs_status bow_match_impl(ovs_wmatcher* w, const ovs_frame_dev* res_kf, c
     OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipStreamSynchronize(s));
+    if (!overflow) w->overflow_dirty = false;
     return overflow ? OVS_ERR_CAPACITY : OVS_OK;
 }
 
@@ -1736,6 +1747,7 @@ ovs_status ovs_projection_match_current_and_last_frames(ovs_wmatcher* w, const o
     OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipStreamSynchronize(s));
+    if (!overflow) w->overflow_dirty = false;
     return overflow ? OVS_ERR_CAPACITY : OVS_OK;
 }
 
@@ -1910,6 +1922,7 @@ static ovs_status projection_match_frame_and_keyframe_impl(ovs_wmatcher* w, cons
     OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipStreamSynchronize(s));
+    if (!overflow) w->overflow_dirty = false;
     return overflow ? OVS_ERR_CAPACITY : OVS_OK;
 }
 
@@ -2080,6 +2093,7 @@ static ovs_status projection_match_by_sim3_transform_impl(ovs_wmatcher* w, const
     OVS_HIP_TRY(hipMemcpyAsync(num_matches, w->d_num, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipMemcpyAsync(&overflow, w->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     OVS_HIP_TRY(hipStreamSynchronize(s));
+    if (!overflow) w->overflow_dirty = false;
     return overflow ? OVS_ERR_CAPACITY : OVS_OK;
 }
 
