@@ -46,14 +46,19 @@ __device__ __forceinline__ uint32_t hamming256_g(const uint32_t (&a)[8], const u
 }
 
 // ---- 1. D1 assign_keypoints_to_grid ---------------------------------------------------------------------------------
+// Round 6: the scan of the cell histogram by wave shuffles (two barriers; the 1024-wide Hillis-Steele loop had twenty) and, when the keypoints fit
+// (items_in_lds: n <= kGridItemsLds), the member lists built and sorted in LDS and written once, coalesced -- the per-cell insertion sort used to walk
+// `items` in global memory, a chain of dependent round trips per cell: 17 -> ~8 us per 2000-keypoint frame, once per tracked frame.
+constexpr int kGridItemsLds = 8192;
 __global__ __launch_bounds__(1024) void k_grid_assign(const ovs_keypoint* __restrict__ kps, int n, GridP gp, int32_t* __restrict__ cell_of,
-                                                     int32_t* __restrict__ cell_start, int32_t* __restrict__ items) {
+                                                     int32_t* __restrict__ cell_start, int32_t* __restrict__ items, int items_in_lds) {
     extern __shared__ int32_t s_grid[];
     const int nc = gp.cols * gp.rows;
     int32_t* cnt = s_grid;            // [nc] histogram, then fill cursor
     int32_t* start = s_grid + nc;     // [nc + 1]
-    __shared__ int32_t s_part[1024];
-    const int tid = threadIdx.x;
+    int32_t* const lit = items_in_lds ? s_grid + 2 * nc + 1 : items;   // [n] the member lists while they are built and sorted
+    __shared__ int32_t s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int c = tid; c < nc; c += 1024) cnt[c] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
@@ -75,15 +80,21 @@ __global__ __launch_bounds__(1024) void k_grid_assign(const ovs_keypoint* __rest
         const int c = tid * per + k;
         if (c < nc) local += cnt[c];
     }
-    s_part[tid] = local;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = tid >= off ? s_part[tid - off] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    int incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
     }
-    int run = s_part[tid] - local;
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    int run = incl - local, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int t = s_w[w];
+        run += w < wv ? t : 0;
+        total += t;
+    }
     for (int k = 0; k < per; ++k) {
         const int c = tid * per + k;
         if (c < nc) {
@@ -91,7 +102,7 @@ __global__ __launch_bounds__(1024) void k_grid_assign(const ovs_keypoint* __rest
             run += cnt[c];
         }
     }
-    if (tid == 1023) start[nc] = s_part[1023];
+    if (tid == 0) start[nc] = total;
     __syncthreads();
     for (int c = tid; c <= nc; c += 1024) {
         cell_start[c] = start[c];
@@ -99,22 +110,26 @@ __global__ __launch_bounds__(1024) void k_grid_assign(const ovs_keypoint* __rest
     }
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
-        const int c = cell_of[i];
-        if (c >= 0) items[atomicAdd(&cnt[c], 1)] = i;
+        const int c = cell_of[i];   // (this thread's own store above)
+        if (c >= 0) lit[atomicAdd(&cnt[c], 1)] = i;
     }
     __syncthreads();   // also makes this workgroup's global writes visible to itself
     // members in ascending keypoint index (upstream pushes them in keypoint order)
     for (int c = tid; c < nc; c += 1024) {
         const int b = start[c], e = start[c + 1];
         for (int i = b + 1; i < e; ++i) {
-            const int v = items[i];
+            const int v = lit[i];
             int j = i - 1;
-            while (j >= b && items[j] > v) {
-                items[j + 1] = items[j];
+            while (j >= b && lit[j] > v) {
+                lit[j + 1] = lit[j];
                 --j;
             }
-            items[j + 1] = v;
+            lit[j + 1] = v;
         }
+    }
+    if (items_in_lds) {
+        __syncthreads();
+        for (int i = tid; i < total; i += 1024) items[i] = lit[i];
     }
 }
 
@@ -1052,10 +1067,11 @@ ovs_status grid_assign(ovs_wmatcher* w, const ovs_grid_params* gp, const ovs_key
     w->gp = make_gridp(*gp);
     w->grid_n = n;
     const int nc = gp->cols * gp->rows;
-    const size_t lds = (size_t)(2 * nc + 1) * sizeof(int32_t);
+    const int in_lds = (n <= kGridItemsLds && (size_t)(2 * nc + 1 + n) * sizeof(int32_t) <= 144 * 1024) ? 1 : 0;
+    const size_t lds = (size_t)(2 * nc + 1 + (in_lds ? n : 0)) * sizeof(int32_t);
     if (lds > 64 * 1024)
         OVS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_assign), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_grid_assign, dim3(1), dim3(1024), lds, s, d_kps, n, w->gp, w->d_cell_of, w->d_cell_start, w->d_items);
+    hipLaunchKernelGGL(k_grid_assign, dim3(1), dim3(1024), lds, s, d_kps, n, w->gp, w->d_cell_of, w->d_cell_start, w->d_items, in_lds);
     OVS_HIP_TRY(hipGetLastError());
     return OVS_OK;
 }
@@ -2324,11 +2340,12 @@ ovs_status ovs_frame_dev_create(int32_t device, const ovs_grid_params* gp, const
             if (stereo_x_right) std::memcpy(st.h + o_xr, stereo_x_right, 4 * (size_t)n);
             F_TRY(hipMemcpyAsync(f->arena, st.h, up_bytes, hipMemcpyHostToDevice, st.stream));
         }
-        const size_t lds = (size_t)(2 * f->n_cells + 1) * sizeof(int32_t);
+        const int in_lds = (n <= kGridItemsLds && (size_t)(2 * f->n_cells + 1 + n) * sizeof(int32_t) <= 144 * 1024) ? 1 : 0;
+        const size_t lds = (size_t)(2 * f->n_cells + 1 + (in_lds ? n : 0)) * sizeof(int32_t);
         if (lds > 64 * 1024)
             F_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_assign), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_grid_assign, dim3(1), dim3(1024), lds, st.stream, (const ovs_keypoint*)f->d_kps, n, f->gp, f->d_cell_of, f->d_cell_start,
-                           f->d_items);
+                           f->d_items, in_lds);
         F_TRY(hipGetLastError());
         F_TRY(hipStreamSynchronize(st.stream));   // the handle is used from other streams afterwards
         rc = OVS_OK;
