@@ -38,6 +38,7 @@
 // result is stated to (ORACLE_SPEC rule 28); identical bits from run to run (no atomics, fixed tile order).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -420,6 +421,123 @@ __device__ __forceinline__ double row_bcast(double v, int n) {   // n is a const
     }
 }
 
+// ---- round 6: the diagonal block's pivot chain, scheduled by hand ---------------------------------------------------------------------
+// factor_block_dpp below compiles to a strictly serial stream: per pivot, ten dependent operations of the reciprocal square root (nothing
+// between them), THEN the 15 - k column updates at five instructions per broadcast (two v_mov 0 for update_dpp's `old`, s_nop, two 32-bit DPP
+// moves) -- ~430 cycles per pivot, 52 us of a 169 us solve. Here every instruction of the block is its own `asm volatile` (the compiler keeps
+// their order, allocates the registers and sees none of the hazards, which are therefore padded inside the strings): a broadcast is ONE
+// v_mov_b64_dpp row_newbcast (the only DPP control 64-bit operations have), column k + 1 is updated first so that the NEXT pivot's chain starts
+// at once, and the remaining column updates and the right-hand side's forward-substitution step are issued BETWEEN the chain's dependent
+// operations. Same operations on the same values as factor_block_dpp (the same bits); lanes r < k carry junk in a[k] and s, as there, and
+// nothing reads it. 1 / L[k][k] and y_k are uniform after their broadcasts: every lane stores them (same address, same value).
+#define OVS_BC64(N, NOP)                                                                                                                    \
+    asm volatile(NOP "v_mov_b64_dpp %0, %1 row_newbcast:" #N " row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));                              \
+    break;
+template <bool kWait>   // kWait: the source was written by one of the two preceding vector instructions (DPP reads need two wait states)
+__device__ __forceinline__ double bc64(double v, int n) {   // n is a constant after unrolling: the switch folds away
+    double o;
+    if (kWait) {
+        switch (n) {
+            case 0: OVS_BC64(0, "s_nop 1\n\t") case 1: OVS_BC64(1, "s_nop 1\n\t") case 2: OVS_BC64(2, "s_nop 1\n\t") case 3: OVS_BC64(3, "s_nop 1\n\t")
+            case 4: OVS_BC64(4, "s_nop 1\n\t") case 5: OVS_BC64(5, "s_nop 1\n\t") case 6: OVS_BC64(6, "s_nop 1\n\t") case 7: OVS_BC64(7, "s_nop 1\n\t")
+            case 8: OVS_BC64(8, "s_nop 1\n\t") case 9: OVS_BC64(9, "s_nop 1\n\t") case 10: OVS_BC64(10, "s_nop 1\n\t") case 11: OVS_BC64(11, "s_nop 1\n\t")
+            case 12: OVS_BC64(12, "s_nop 1\n\t") case 13: OVS_BC64(13, "s_nop 1\n\t") case 14: OVS_BC64(14, "s_nop 1\n\t") default: OVS_BC64(15, "s_nop 1\n\t")
+        }
+    } else {
+        switch (n) {
+            case 0: OVS_BC64(0, "") case 1: OVS_BC64(1, "") case 2: OVS_BC64(2, "") case 3: OVS_BC64(3, "")
+            case 4: OVS_BC64(4, "") case 5: OVS_BC64(5, "") case 6: OVS_BC64(6, "") case 7: OVS_BC64(7, "")
+            case 8: OVS_BC64(8, "") case 9: OVS_BC64(9, "") case 10: OVS_BC64(10, "") case 11: OVS_BC64(11, "")
+            case 12: OVS_BC64(12, "") case 13: OVS_BC64(13, "") case 14: OVS_BC64(14, "") default: OVS_BC64(15, "")
+        }
+    }
+    return o;
+}
+#undef OVS_BC64
+__device__ __forceinline__ double vmul64(double a, double b) {
+    double d;
+    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ double vfma64(double a, double b, double c) {
+    double d;
+    asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ double vfnma64(double a, double b, double c) {   // c - a b, one rounding
+    double d;
+    asm volatile("v_fma_f64 %0, -%1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ double vrsq64(double p) {   // (a transcendental result needs a wait state before a vector instruction reads it)
+    double d;
+    asm volatile("v_rsq_f64 %0, %1\n\ts_nop 0" : "=v"(d) : "v"(p));
+    return d;
+}
+// one pivot step, K a template argument (a `#pragma unroll` over sixteen of these bodies exceeds the unroller's budget: it peeled five steps and
+// left a loop with switch trees over the broadcast lane)
+template <int K>
+__device__ __forceinline__ void factor_steps(double (&a)[kNb], double& s, double y, bool& bad, double* __restrict__ invd_j, double* __restrict__ vec_j) {
+    const double c15 = 1.5, cmh = -0.5;
+    a[K] = vmul64(a[K], y);          // column K of L (lane K: piv * y = L[K][K])
+    const double sy = vmul64(s, y);  // lane K: y_K
+    invd_j[K] = y;
+    double yn = y, h = 0.0;
+    if constexpr (K + 1 < kNb) {   // column K + 1 first: the next pivot is final, its chain starts
+        a[K + 1] = vfnma64(a[K], bc64<true>(a[K], K + 1), a[K + 1]);
+        const double piv = bc64<true>(a[K + 1], K + 1);
+        bad |= !(piv > 0.0 && piv < __builtin_inf());
+        yn = vrsq64(piv);
+        h = vmul64(piv, cmh);
+    }
+    const double yk = bc64<false>(sy, K);
+    vec_j[K] = yk;
+    s = vfnma64(a[K], yk, s);
+    // the three Newton steps of the next pivot, a column update behind each of their dependent operations
+#define OVS_COL(C)                                                                              \
+    if constexpr ((C) < kNb) a[(C) < kNb ? (C) : 0] = vfnma64(a[K], bc64<false>(a[K], (C)), a[(C) < kNb ? (C) : 0]);
+#define OVS_NEWTON(I)                                         \
+    {                                                         \
+        double t = 0.0, e = 0.0;                              \
+        if constexpr (K + 1 < kNb) t = vmul64(h, yn);         \
+        OVS_COL(K + 2 + 3 * (I))                              \
+        if constexpr (K + 1 < kNb) e = vfma64(t, yn, c15);    \
+        OVS_COL(K + 3 + 3 * (I))                              \
+        if constexpr (K + 1 < kNb) yn = vmul64(yn, e);        \
+        OVS_COL(K + 4 + 3 * (I))                              \
+    }
+    OVS_NEWTON(0)
+    OVS_NEWTON(1)
+    OVS_NEWTON(2)
+    OVS_COL(K + 11) OVS_COL(K + 12) OVS_COL(K + 13) OVS_COL(K + 14) OVS_COL(K + 15)   // (the columns the nine slots did not take)
+#undef OVS_NEWTON
+#undef OVS_COL
+    if constexpr (K + 1 < kNb) factor_steps<K + 1>(a, s, yn, bad, invd_j, vec_j);
+}
+__device__ __forceinline__ void factor_block_sched(double* __restrict__ P, double* __restrict__ invd, double* __restrict__ vec, int j0, int lane,
+                                                   int* s_bad) {
+    const int r = lane & 15;
+    double a[kNb];
+#pragma unroll
+    for (int c = 0; c < kNb; ++c) a[c] = P[r * kPitch + c];
+    double s = vec[j0 + r];
+    const double piv = bc64<true>(a[0], 0);
+    bool bad = !(piv > 0.0 && piv < __builtin_inf());
+    double y = vrsq64(piv);
+    {
+        const double h = vmul64(piv, -0.5);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) y = vmul64(y, vfma64(vmul64(h, y), y, 1.5));
+    }
+    factor_steps<0>(a, s, y, bad, invd + j0, vec + j0);
+    if (lane < kNb) {
+#pragma unroll
+        for (int cc = 0; cc < kNb; ++cc)
+            if (cc <= r) P[r * kPitch + cc] = a[cc];
+        if (bad) *s_bad = 1;   // (lanes of one wave: the same value, any order)
+    }
+}
+
 // wave 0: the diagonal block (P rows 0..15; lane r of every 16-lane row holds row r) and y = L_dd^-1 rhs_block (vec[j0 ..]); leaves L_dd in P,
 // 1 / L[c][c] in invd
 __device__ __forceinline__ void factor_block_dpp(double* __restrict__ P, double* __restrict__ invd, double* __restrict__ vec, int j0, int lane,
@@ -521,7 +639,8 @@ __device__ __forceinline__ void tile_update_tied(v4d& c, double a0, double a1, d
 // none -- the marks' branches and 64-bit atomics inside the panel loop cost the register allocator 100 registers' worth of spills.
 // A failed pivot does NOT leave the kernel early (a second exit from the panel loop had the same effect): the factorisation runs on with
 // NaNs and the flag is raised at the end.
-template <bool kTimed>
+// kSched: the diagonal block by factor_block_sched (round 6, default) or by factor_block_dpp (OVS_CHOL_SCHED=0; same bits).
+template <bool kTimed, bool kSched>
 __global__ __launch_bounds__(kSolveThreads) void k_chol_resident(double* __restrict__ S, int n_pad, int32_t* __restrict__ fail,
                                                                 unsigned long long* __restrict__ tstats) {
     extern __shared__ double lds[];
@@ -588,7 +707,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_resident(double* __restr
     SOLVE_MARK(0)   // loads
     for (int j = 0; j < NT; ++j) {
         const int j0 = j * kNb, m = n_pad - j0;
-        if (wave == 0) factor_block_dpp(P, invd, vec, j0, lane, &s_bad);
+        if (wave == 0) {
+            if (kSched) factor_block_sched(P, invd, vec, j0, lane, &s_bad);
+            else factor_block_dpp(P, invd, vec, j0, lane, &s_bad);
+        }
         lds_barrier();
         SOLVE_MARK(1)   // diagonal block + forward substitution of its rhs + barrier
         solve_rows_res(P, invd, vec, j0, m, tid, lane);
@@ -665,18 +787,25 @@ ovs_status launch_dense_solve(double* d_S, int n, int32_t* d_fail, hipStream_t s
     if (n_pad <= kResMaxPad && tuning().chol_resident) {   // the trailing matrix fits the register file: k_chol_resident
         const int nt = n_pad / kNb, n_tiles = nt * (nt - 1) / 2, n_lds = std::max(0, n_tiles - (kSolveThreads / 64) * kResSlots);
         const size_t lds = sizeof(double) * (2 * (size_t)n_pad * kPitch + 2 * (size_t)n_pad + (size_t)n_lds * 256);
-        static LdsAttrCache cache_r;
-        static LdsAttrCache cache_t;
-        const void* fn = d_tstats ? reinterpret_cast<const void*>(k_chol_resident<true>) : reinterpret_cast<const void*>(k_chol_resident<false>);
-        hipError_t e = ensure_dynamic_lds(fn, lds, d_tstats ? cache_t : cache_r);
+        static LdsAttrCache cache[4];
+        static const bool sched = [] {
+            const char* e = std::getenv("OVS_CHOL_SCHED");
+            return !(e && e[0] == '0');
+        }();
+        const int which = (d_tstats ? 2 : 0) + (sched ? 1 : 0);
+        const void* const fns[4] = {reinterpret_cast<const void*>(k_chol_resident<false, false>), reinterpret_cast<const void*>(k_chol_resident<false, true>),
+                                    reinterpret_cast<const void*>(k_chol_resident<true, false>), reinterpret_cast<const void*>(k_chol_resident<true, true>)};
+        hipError_t e = ensure_dynamic_lds(fns[which], lds, cache[which]);
         if (e != hipSuccess) {
             set_last_error("hipFuncSetAttribute(k_chol_resident)", e);
             return OVS_ERR_HIP;
         }
-        if (d_tstats)
-            hipLaunchKernelGGL(k_chol_resident<true>, dim3(1), dim3(kSolveThreads), lds, s, d_S, n_pad, d_fail, d_tstats);
-        else
-            hipLaunchKernelGGL(k_chol_resident<false>, dim3(1), dim3(kSolveThreads), lds, s, d_S, n_pad, d_fail, d_tstats);
+        switch (which) {
+            case 0: hipLaunchKernelGGL((k_chol_resident<false, false>), dim3(1), dim3(kSolveThreads), lds, s, d_S, n_pad, d_fail, d_tstats); break;
+            case 1: hipLaunchKernelGGL((k_chol_resident<false, true>), dim3(1), dim3(kSolveThreads), lds, s, d_S, n_pad, d_fail, d_tstats); break;
+            case 2: hipLaunchKernelGGL((k_chol_resident<true, false>), dim3(1), dim3(kSolveThreads), lds, s, d_S, n_pad, d_fail, d_tstats); break;
+            default: hipLaunchKernelGGL((k_chol_resident<true, true>), dim3(1), dim3(kSolveThreads), lds, s, d_S, n_pad, d_fail, d_tstats); break;
+        }
         OVS_LAUNCH_TRY("k_chol_resident");
         return OVS_OK;
     }
