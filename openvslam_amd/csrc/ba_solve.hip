@@ -515,7 +515,7 @@ __device__ __forceinline__ void factor_steps(double (&a)[kNb], double& s, double
     if constexpr (K + 1 < kNb) factor_steps<K + 1>(a, s, yn, bad, invd_j, vec_j);
 }
 __device__ __forceinline__ void factor_block_sched(double* __restrict__ P, double* __restrict__ invd, double* __restrict__ vec, int j0, int lane,
-                                                   int* s_bad) {
+                                                   int* s_bad, double* __restrict__ dd) {   // dd: this block's copy for the backward substitution
     const int r = lane & 15;
     double a[kNb];
 #pragma unroll
@@ -534,6 +534,8 @@ __device__ __forceinline__ void factor_block_sched(double* __restrict__ P, doubl
 #pragma unroll
         for (int cc = 0; cc < kNb; ++cc)
             if (cc <= r) P[r * kPitch + cc] = a[cc];
+#pragma unroll
+        for (int cc = 0; cc < kNb; ++cc) dd[r * kPitch + cc] = cc < r ? a[cc] : 0.0;   // strictly lower triangle, zeros elsewhere
         if (bad) *s_bad = 1;   // (lanes of one wave: the same value, any order)
     }
 }
@@ -635,6 +637,70 @@ __device__ __forceinline__ void tile_update_tied(v4d& c, double a0, double a1, d
         : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
 }
 
+// Backward substitution of k_chol_resident (round 6). backward_substitution above asks for the L rows of block j - 1 while it works on block j:
+// one step of ~0.3 us of arithmetic then waits out what is left of a ~1.8 us round trip (16 rows x n_pad columns through one CU) -- 18 steps,
+// 33 us of a 169 us solve. Here the rows of TWO blocks ahead are in flight (three register buffers of 16 doubles, rotated; every load is
+// unconditional -- clamped addresses -- so that the compiler can count them and wait for exactly the oldest buffer), and wave 0 takes the
+// diagonal blocks' L from LDS, where factor_block_sched left a copy (DD: strictly lower triangle, zeros elsewhere), instead of their transposes
+// from memory. The block solve keeps residuals in the lanes (lane k's residual is final at step k; zeros above the diagonal make the update a
+// no-op for the finished lanes: no selects): multiply, one v_mov_b64_dpp, one fused multiply-add per step. Same operations on the same values
+// as backward_substitution (the same bits).
+__device__ __forceinline__ void backward_substitution_res(double* __restrict__ S, double* __restrict__ vec, const double* __restrict__ invd,
+                                                          const double* __restrict__ DD, int n_pad, int tid, int lane, int wave) {
+    const int rl = lane & 15;
+    if (wave * 64 >= n_pad) {   // (wave-uniform) waves without a column keep the other waves' barriers company and load nothing
+        for (int jb = n_pad - kNb; jb >= 0; jb -= kNb) {
+            lds_barrier();
+            lds_barrier();
+        }
+        return;
+    }
+    const int col = min(tid, n_pad - 1);
+    auto request = [&](int jb, double (&X)[kNb]) {
+        const double* base = S + (size_t)max(jb, 0) * n_pad + col;
+#pragma unroll
+        for (int k = 0; k < kNb; ++k) X[k] = base[(size_t)k * n_pad];
+    };
+    auto step = [&](int jb, const double (&X)[kNb]) {
+        if (jb < 0) return;   // (uniform)
+        if (wave == 0) {
+            const double* dd = DD + (size_t)(jb >> 4) * (kNb * kPitch);
+            double tt[kNb];
+#pragma unroll
+            for (int k = 0; k < kNb; ++k) tt[k] = dd[k * kPitch + rl];   // L[k][rl]: column rl of L = row rl of L^T (zero for k <= rl)
+            double res = vec[jb + rl];
+            const double iv = invd[jb + rl];
+#pragma unroll
+            for (int k = kNb - 1; k >= 0; --k) {
+                const double xk = bc64<true>(vmul64(res, iv), k);
+                res = vfnma64(tt[k], xk, res);
+            }
+            if (lane < kNb) vec[jb + rl] = vmul64(res, iv);
+        }
+        lds_barrier();
+        if (tid < jb) {
+            double v = vec[tid];
+#pragma unroll
+            for (int k = 0; k < kNb; ++k) v = __builtin_fma(-X[k], vec[jb + k], v);
+            vec[tid] = v;
+        }
+        lds_barrier();
+    };
+    double A[kNb], B[kNb], C[kNb];
+    int jb = n_pad - kNb;
+    request(jb, A);
+    request(jb - kNb, B);
+    for (; jb >= 0; jb -= 3 * kNb) {
+        request(jb - 2 * kNb, C);
+        step(jb, A);
+        request(jb - 3 * kNb, A);
+        step(jb - kNb, B);
+        request(jb - 4 * kNb, B);
+        step(jb - 2 * kNb, C);
+    }
+    if (tid < n_pad) S[(size_t)n_pad * n_pad + tid] = vec[tid];   // (n_pad <= 288 < kSolveThreads)
+}
+
 // kTimed: the OVS_BA_TRACE build with phase marks (thread 0 adds its wall_clock64 intervals to tstats[0 .. 7]); the product instantiation carries
 // none -- the marks' branches and 64-bit atomics inside the panel loop cost the register allocator 100 registers' worth of spills.
 // A failed pivot does NOT leave the kernel early (a second exit from the panel loop had the same effect): the factorisation runs on with
@@ -679,6 +745,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_resident(double* __restr
     //      columns, which leave after one or two updates) in LDS behind the panels, lane-major: value e of lane l of tile u at T[(u * 4 + e) * 64 + l]
     double* const T = invd + n_pad;
     const int n_lds = n_tiles > kWaves * kResSlots ? n_tiles - kWaves * kResSlots : 0;
+    double* const DD = T + (size_t)n_lds * 256;   // kSched: the diagonal blocks' L (NT x 16 x kPitch doubles) for the backward substitution
     int sd[kResSlots];
     v4d acc[kResSlots];
     const int lane_off = kq * n_pad + rl;
@@ -708,7 +775,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_resident(double* __restr
     for (int j = 0; j < NT; ++j) {
         const int j0 = j * kNb, m = n_pad - j0;
         if (wave == 0) {
-            if (kSched) factor_block_sched(P, invd, vec, j0, lane, &s_bad);
+            if (kSched) factor_block_sched(P, invd, vec, j0, lane, &s_bad, DD + (size_t)j * (kNb * kPitch));
             else factor_block_dpp(P, invd, vec, j0, lane, &s_bad);
         }
         lds_barrier();
@@ -762,7 +829,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_resident(double* __restr
         Pn = t;
     }
     __syncthreads();   // the panels written back above are read by other threads below
-    backward_substitution(S, vec, invd, n_pad, tid, lane, wave);
+    if (kSched) backward_substitution_res(S, vec, invd, DD, n_pad, tid, lane, wave);
+    else backward_substitution(S, vec, invd, n_pad, tid, lane, wave);
     SOLVE_MARK(6)   // backward substitution
 #undef SOLVE_MARK
     if (tid == 0 && s_bad) atomicOr(fail, 2);   // (s_bad was last written before the panel loop's barriers)
@@ -786,7 +854,7 @@ ovs_status launch_dense_solve(double* d_S, int n, int32_t* d_fail, hipStream_t s
     const int n_pad = dense_solve_pad(n);
     if (n_pad <= kResMaxPad && tuning().chol_resident) {   // the trailing matrix fits the register file: k_chol_resident
         const int nt = n_pad / kNb, n_tiles = nt * (nt - 1) / 2, n_lds = std::max(0, n_tiles - (kSolveThreads / 64) * kResSlots);
-        const size_t lds = sizeof(double) * (2 * (size_t)n_pad * kPitch + 2 * (size_t)n_pad + (size_t)n_lds * 256);
+        const size_t lds = sizeof(double) * (2 * (size_t)n_pad * kPitch + 2 * (size_t)n_pad + (size_t)n_lds * 256 + (size_t)nt * kNb * kPitch);
         static LdsAttrCache cache[4];
         static const bool sched = [] {
             const char* e = std::getenv("OVS_CHOL_SCHED");
