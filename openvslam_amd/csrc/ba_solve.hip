@@ -515,7 +515,7 @@ __device__ __forceinline__ void factor_steps(double (&a)[kNb], double& s, double
     if constexpr (K + 1 < kNb) factor_steps<K + 1>(a, s, yn, bad, invd_j, vec_j);
 }
 __device__ __forceinline__ void factor_block_sched(double* __restrict__ P, double* __restrict__ invd, double* __restrict__ vec, int j0, int lane,
-                                                   int* s_bad, double* __restrict__ dd) {   // dd: this block's copy for the backward substitution
+                                                   int* s_bad) {
     const int r = lane & 15;
     double a[kNb];
 #pragma unroll
@@ -534,8 +534,6 @@ __device__ __forceinline__ void factor_block_sched(double* __restrict__ P, doubl
 #pragma unroll
         for (int cc = 0; cc < kNb; ++cc)
             if (cc <= r) P[r * kPitch + cc] = a[cc];
-#pragma unroll
-        for (int cc = 0; cc < kNb; ++cc) dd[r * kPitch + cc] = cc < r ? a[cc] : 0.0;   // strictly lower triangle, zeros elsewhere
         if (bad) *s_bad = 1;   // (lanes of one wave: the same value, any order)
     }
 }
@@ -641,7 +639,7 @@ __device__ __forceinline__ void tile_update_tied(v4d& c, double a0, double a1, d
 // one step of ~0.3 us of arithmetic then waits out what is left of a ~1.8 us round trip (16 rows x n_pad columns through one CU) -- 18 steps,
 // 33 us of a 169 us solve. Here the rows of TWO blocks ahead are in flight (three register buffers of 16 doubles, rotated; every load is
 // unconditional -- clamped addresses -- so that the compiler can count them and wait for exactly the oldest buffer), and wave 0 takes the
-// diagonal blocks' L from LDS, where factor_block_sched left a copy (DD: strictly lower triangle, zeros elsewhere), instead of their transposes
+// diagonal blocks' L from LDS, where the panel loop left a copy (DD: strictly lower triangle, zeros elsewhere), instead of their transposes
 // from memory. The block solve keeps residuals in the lanes (lane k's residual is final at step k; zeros above the diagonal make the update a
 // no-op for the finished lanes: no selects): multiply, one v_mov_b64_dpp, one fused multiply-add per step. Same operations on the same values
 // as backward_substitution (the same bits).
@@ -775,11 +773,17 @@ __global__ __launch_bounds__(kSolveThreads) void k_chol_resident(double* __restr
     for (int j = 0; j < NT; ++j) {
         const int j0 = j * kNb, m = n_pad - j0;
         if (wave == 0) {
-            if (kSched) factor_block_sched(P, invd, vec, j0, lane, &s_bad, DD + (size_t)j * (kNb * kPitch));
+            if (kSched) factor_block_sched(P, invd, vec, j0, lane, &s_bad);
             else factor_block_dpp(P, invd, vec, j0, lane, &s_bad);
         }
         lds_barrier();
         SOLVE_MARK(1)   // diagonal block + forward substitution of its rhs + barrier
+        if (kSched && tid >= kSolveThreads - kNb * kNb) {
+            // the block's copy for the backward substitution (strictly lower triangle, zeros elsewhere), made by the upper half of the workgroup, which
+            // owns few or no rows below a block (n_pad <= 288: rows 16 .. 287 go to threads 0 .. 271) -- off wave 0's critical path
+            const int e = tid - (kSolveThreads - kNb * kNb), r = e >> 4, c = e & 15;
+            DD[(size_t)j * (kNb * kPitch) + r * kPitch + c] = c < r ? P[r * kPitch + c] : 0.0;
+        }
         solve_rows_res(P, invd, vec, j0, m, tid, lane);
         lds_barrier();
         SOLVE_MARK(2)   // row solves + barrier
