@@ -506,7 +506,13 @@ __global__ __launch_bounds__(256) void k_lin_landmark(GraphDev g, const double* 
 // denominator, written by the back-substitution) their sum goes to scale_sum[0] -- the additions of the former k_sum_1024, in its order.
 __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const double* __restrict__ lm_chi, const double* __restrict__ Hpp,
                                                         const double* __restrict__ Hll, double* __restrict__ chi2, double* __restrict__ mirror,
-                                                        const double* __restrict__ lm_scale, double* __restrict__ scale_sum) {
+                                                        const double* __restrict__ lm_scale, double* __restrict__ scale_sum,
+                                                        unsigned long long* __restrict__ host_ll, unsigned int seq, const int32_t* __restrict__ fail2) {
+    // host_ll (round 6, the device solver's LM trials): the trial's outcome -- the gain ratio's two parts, the chi2 triple, the two failure words --
+    // also goes straight into a page-locked block as twelve 64-bit words {seq : 32 | half of a double : 32}; the host polls them instead of
+    // enqueuing a 264-byte D2H copy and waiting for the stream (a copy kernel, its launch gap and the wait's wake-up per trial). A word whose
+    // upper half is this trial's sequence number carries this trial's data: no fence (a system-scope release here would write back every dirty
+    // line of the L2 -- the ~50 us per trial that sank "one kernel writes the values into the page-locked block" in round 4).
     __shared__ double s0[1024], s1[1024], s2[1024];
     if (lm_scale) {   // (uniform) before the chi2 sums: s0 is reused
         double a = 0;
@@ -558,6 +564,20 @@ __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const doubl
             mirror[1] = s1[0];
             mirror[2] = s2[0];
         }
+    }
+    if (host_ll && threadIdx.x < 12) {
+        // values: [0] landmarks' / [1] keyframes' gain-ratio parts (scale_sum[0] was written by thread 0 above: same workgroup, behind barriers;
+        // scale_sum[1] by k_trial_update), [2..4] chi2 triple, [5] the two failure words
+        const int i = threadIdx.x >> 1;
+        unsigned long long bits;
+        if (i == 0) bits = (unsigned long long)__double_as_longlong(scale_sum ? scale_sum[0] : 0.0);
+        else if (i == 1) bits = (unsigned long long)__double_as_longlong(scale_sum ? scale_sum[1] : 0.0);
+        else if (i == 2) bits = (unsigned long long)__double_as_longlong(s0[0]);
+        else if (i == 3) bits = (unsigned long long)__double_as_longlong(s1[0]);
+        else if (i == 4) bits = (unsigned long long)__double_as_longlong(s2[0]);
+        else bits = (unsigned long long)(uint32_t)fail2[0] | ((unsigned long long)(uint32_t)fail2[1] << 32);
+        const unsigned long long half = (threadIdx.x & 1) ? (bits >> 32) : (bits & 0xffffffffull);
+        __hip_atomic_store(&host_ll[threadIdx.x], ((unsigned long long)seq << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1012,7 +1032,7 @@ static int landmarks_per_workgroup(int n_pose, int n_pt) {
 // d_lm_tmp[3 n_pt ..) are summed into d_scal[0] by the same launch that sums chi2
 ovs_status graph_linearize(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo, double* d_Hpp,
                            double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror = nullptr,
-                           bool trial_scale = false) {
+                           bool trial_scale = false, unsigned long long* host_ll = nullptr, unsigned int seq = 0) {
     const GraphDev v = g->view();
     if (g->n_chunks > 0) {
         if (g->model == 1) hipLaunchKernelGGL(k_lin_pose<1>, dim3(g->n_chunks), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl);
@@ -1025,7 +1045,8 @@ ovs_status graph_linearize(ovs_ba_graph* g, const double* d_poses, const double*
         hipLaunchKernelGGL(k_lin_landmark<0>, dim3(g->n_lm_wg), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, g->d_lm_tmp);
     OVS_LAUNCH_TRY("k_lin_landmark");
     hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(1024), 0, s, v, g->d_lm_tmp, d_Hpp, d_Hll, d_chi3, d_chi_mirror,
-                       trial_scale ? g->d_lm_tmp + 3 * (size_t)g->n_pt : (const double*)nullptr, trial_scale ? g->d_scal : (double*)nullptr);
+                       trial_scale ? g->d_lm_tmp + 3 * (size_t)g->n_pt : (const double*)nullptr, trial_scale ? g->d_scal : (double*)nullptr,
+                       trial_scale ? host_ll : (unsigned long long*)nullptr, seq, (const int32_t*)g->d_fail);
     OVS_LAUNCH_TRY("k_reduce_scalars");
     return OVS_OK;
 }
@@ -1480,8 +1501,9 @@ ovs_status ba_graph_edge_chi2(ovs_ba_graph* g, const double* d_poses, const doub
 
 ovs_status ba_graph_linearize(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo, double* d_Hpp,
                               double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror,
-                              bool trial_scale) {
-    return graph_linearize(g, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi3, s, d_chi_mirror, trial_scale);
+                              bool trial_scale, unsigned long long* host_ll, unsigned int seq) {
+    return graph_linearize(g, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl, d_chi3, s, d_chi_mirror, trial_scale, host_ll,
+                           seq);
 }
 
 }   // namespace ovs

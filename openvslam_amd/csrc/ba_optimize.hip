@@ -33,7 +33,7 @@ ovs_status ba_graph_set_active(ovs_ba_graph* g, const uint8_t* host_mask, hipStr
 ovs_status ba_graph_edge_chi2(ovs_ba_graph* g, const double* d_poses, const double* d_points, double* d_chi, uint8_t* d_depth, hipStream_t s);
 ovs_status ba_graph_linearize(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo, double* d_Hpp,
                               double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror = nullptr,
-                              bool trial_scale = false);
+                              bool trial_scale = false, unsigned long long* host_ll = nullptr, unsigned int seq = 0);
 ovs_status ba_graph_trial_update(ovs_ba_graph* g, const double* d_T, const double* d_bp, const double* d_Hpl, const double* d_bl, double lambda,
                                  double* d_Tn, double* d_p7n, const double* d_X, double* d_Xn, hipStream_t s, int next_fail_word);
 struct BaGraphInfo {
@@ -163,7 +163,7 @@ struct Lm {
         d_edepth = A + b_e;
         // padded system | bp | staging of the keyframes' records (7 + 12 per keyframe) | chi3, scal, fail | a trial's result block (264 bytes)
         stage_off = ovs::dense_solve_doubles(6 * np) + 6 * (size_t)np;
-        pin_doubles = stage_off + 19 * (size_t)np + 16 + 40;
+        pin_doubles = stage_off + 19 * (size_t)np + 16 + 40 + 16;   // (+ 16: the trial's outcome as flag-carrying words, see run_round)
         if (sc.pin_cap < pin_doubles) {
             if (sc.h_pin) (void)hipHostFree(sc.h_pin);
             sc.h_pin = nullptr;
@@ -237,8 +237,15 @@ struct Lm {
         st = ovs::ba_graph_linearize(g, d_poses, d_X, huber_mono(robust), huber_stereo(robust), cur.Hpp, cur.bp, cur.Hll, cur.bl, cur.Hpl, cur.chi,
                                      stream);
         if (st != OVS_OK) return st;
-        double* h_chi = h_pin + pin_doubles - 16 - 40;
-        double* h_blk = h_pin + pin_doubles - 40;   // one download per trial: [0] landmarks' / [1] keyframes' gain-ratio parts, [2..4] chi2 triple, byte 256: fail flag
+        double* h_chi = h_pin + pin_doubles - 16 - 40 - 16;
+        double* h_blk = h_pin + pin_doubles - 40 - 16;
+        volatile unsigned long long* const h_ll = reinterpret_cast<volatile unsigned long long*>(h_pin + pin_doubles - 16);
+        static thread_local unsigned int ll_seq = 0;   // sequence number of a trial's words: per thread, like the page-locked block they land in
+        for (int i = 0; i < 16; ++i) h_ll[i] = 0ull;    // (the stream is idle here; whatever the block's last user left cannot pass for a word)
+        static const bool ll_notify = [] {   // OVS_BA_LL_NOTIFY=0: a trial's outcome through a D2H copy and a stream synchronisation (rounds 4-5)
+            const char* e = std::getenv("OVS_BA_LL_NOTIFY");
+            return !(e && e[0] == '0');
+        }();   // one download per trial: [0] landmarks' / [1] keyframes' gain-ratio parts, [2..4] chi2 triple, byte 256: fail flag
         OVS_HIP_TRY(hipMemcpyAsync(h_chi, cur.chi, sizeof(double) * 3, hipMemcpyDeviceToHost, stream));
         OVS_HIP_TRY(hipStreamSynchronize(stream));
         double current_chi = h_chi[1];
@@ -277,17 +284,61 @@ struct Lm {
                     // gi.d_scal in the same arena): ONE 260-byte download per trial instead of three copies (round 5: two copy launches and their
                     // gaps less per trial). (One kernel writing the values straight into the page-locked block was measured in round 4 -- the
                     // system-scope flush at its end costs ~50 us per trial.)
+                    const unsigned int seq = ++ll_seq == 0u ? ++ll_seq : ll_seq;   // (never 0: the block starts zeroed)
                     st = ovs::ba_graph_linearize(g, d_poses_w, d_Xw, huber_mono(robust), huber_stereo(robust), work.Hpp, work.bp, work.Hll, work.bl,
-                                                 work.Hpl, work.chi, stream, gi.d_scal + 2, true);
+                                                 work.Hpl, work.chi, stream, gi.d_scal + 2, true,
+                                                 ll_notify ? const_cast<unsigned long long*>(h_ll) : nullptr, seq);
                     if (st != OVS_OK) return st;
-                    OVS_HIP_TRY(hipMemcpyAsync(h_blk, gi.d_scal, 256 + 2 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-                    OVS_HIP_TRY(hipStreamSynchronize(stream));   // (polling hipStreamQuery instead: the same 6.5-6.6 ms per call, round 5)
-                    h_chi[0] = h_blk[2];
-                    h_chi[1] = h_blk[3];
-                    h_chi[2] = h_blk[4];
-                    h_chi[4] = h_blk[0];
-                    h_chi[5] = h_blk[1];
-                    *h_fail = reinterpret_cast<const int32_t*>(reinterpret_cast<const unsigned char*>(h_blk) + 256)[fw];
+                    bool polled = false;
+                    if (ll_notify) {
+                        // Round 6: the trial's last kernel wrote the outcome into the page-locked block as twelve words {seq | half a double};
+                        // poll them (no copy command, no stream wait). Every 4096 polls the stream is asked whether it still runs: a launch
+                        // that died would otherwise never write the words.
+                        unsigned long long w[12];
+                        unsigned int spins = 0;
+                        bool dead = false;
+                        for (int i = 0; i < 12 && !dead;) {
+                            w[i] = h_ll[i];
+                            if ((unsigned int)(w[i] >> 32) == seq) {
+                                ++i;
+                                continue;
+                            }
+                            if ((++spins & 4095u) == 0u) {
+                                const hipError_t q = hipStreamQuery(stream);
+                                if (q != hipErrorNotReady) {   // idle (or failed): one last look, then the copy path decides
+                                    w[i] = h_ll[i];
+                                    if ((unsigned int)(w[i] >> 32) == seq) continue;
+                                    dead = true;
+                                }
+                            }
+                        }
+                        if (!dead) {
+                            auto val = [&](int i) {
+                                const unsigned long long bits = (w[2 * i] & 0xffffffffull) | (w[2 * i + 1] << 32);
+                                double d;
+                                std::memcpy(&d, &bits, sizeof(d));
+                                return d;
+                            };
+                            h_chi[4] = val(0);
+                            h_chi[5] = val(1);
+                            h_chi[0] = val(2);
+                            h_chi[1] = val(3);
+                            h_chi[2] = val(4);
+                            const uint32_t f2[2] = {(uint32_t)(w[10] & 0xffffffffull), (uint32_t)(w[11] & 0xffffffffull)};
+                            *h_fail = (int32_t)f2[fw];
+                            polled = true;
+                        }
+                    }
+                    if (!polled) {
+                        OVS_HIP_TRY(hipMemcpyAsync(h_blk, gi.d_scal, 256 + 2 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                        OVS_HIP_TRY(hipStreamSynchronize(stream));   // (polling hipStreamQuery instead: the same 6.5-6.6 ms per call, round 5)
+                        h_chi[0] = h_blk[2];
+                        h_chi[1] = h_blk[3];
+                        h_chi[2] = h_blk[4];
+                        h_chi[4] = h_blk[0];
+                        h_chi[5] = h_blk[1];
+                        *h_fail = reinterpret_cast<const int32_t*>(reinterpret_cast<const unsigned char*>(h_blk) + 256)[fw];
+                    }
                     const bool ok = *h_fail == 0;
                     double temp_chi = 1.7976931348623157e308, scale = 1e-3;
                     if (!ok) {   // a failed factorisation may have left non-finite values in the padding, which no later trial rewrites

@@ -474,14 +474,18 @@ res.update({"opt_" + k: np.asarray(v) for k, v in r.items()})
 np.savez(sys.argv[1], **res)
 """
     outs = {}
-    for tag, env in (("auto", {}), ("w256", {"OVS_BA_LM_PER_WG": "256"}), ("w128", {"OVS_BA_LM_PER_WG": "128"})):
+    # round 6, the same for: a trial's outcome through a D2H copy + stream wait instead of the flag-carrying words the host polls
+    # (OVS_BA_LL_NOTIFY=0), and the compiler-scheduled diagonal blocks / round-5 backward substitution of the dense solver (OVS_CHOL_SCHED=0)
+    variants = (("auto", {}), ("w256", {"OVS_BA_LM_PER_WG": "256"}), ("w128", {"OVS_BA_LM_PER_WG": "128"}), ("copies", {"OVS_BA_LL_NOTIFY": "0"}),
+                ("chol_r5", {"OVS_CHOL_SCHED": "0"}))
+    for tag, env in variants:
         out = tmp_path / ("%s.npz" % tag)
         r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests")), str(out)], env=dict(os.environ, **env),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[tag] = dict(np.load(out))
     assert len(outs["auto"]) >= 10 and outs["auto"]["opt_info"][4] >= 3
-    for tag in ("w256", "w128"):
+    for tag, _ in variants[1:]:
         for k, v in outs["auto"].items():
             assert np.array_equal(v, outs[tag][k]), (tag, k)
 
