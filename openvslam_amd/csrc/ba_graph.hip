@@ -889,9 +889,79 @@ __device__ __forceinline__ void pose_update(const double* __restrict__ T, const 
 }
 
 
-// The trial state of a Levenberg-Marquardt step in ONE launch (round 5): workgroup 0 advances the keyframes, the others back-substitute 128
-// or 256 landmarks each. The landmarks read the keyframes' increments from the solver's solution vector (slot order) instead of the dxp array the
+// Back-substitution, one lane per EDGE (round 6): the landmarks of workgroup `wg` of k_lin_landmark's partition (whole landmarks, at most kLmSlots
+// edges). A lane per landmark walking its edges (backsub_landmark) is a chain of four dependent loads per edge and 313 waves at config 5: 23 us
+// of latency per Levenberg-Marquardt trial. Here every lane computes ITS slot's W_e^T dx (two dependent loads), and the landmark's lane then
+// subtracts its slots' terms from bl_j in list order -- backsub_landmark's subtractions, in its order: the same bits (an edge of a fixed
+// keyframe, which that loop skips, subtracts +0.0 here, which changes no value).
+__device__ __forceinline__ void backsub_finish(const int j, const double (&r)[3], const double* __restrict__ Hinv, const double* __restrict__ bl,
+                                               double lambda, const double* __restrict__ X, double* __restrict__ Xn, double* __restrict__ lm_scale) {
+    const double* Hi = Hinv + 9 * (size_t)j;
+    double sc = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double dl = (Hi[3 * c] * r[0] + Hi[3 * c + 1] * r[1]) + Hi[3 * c + 2] * r[2];
+        Xn[3 * (size_t)j + c] = X[3 * (size_t)j + c] + dl;
+        sc += dl * (lambda * dl + bl[3 * (size_t)j + c]);
+    }
+    lm_scale[j] = sc;
+}
+__device__ __forceinline__ void backsub_wg(const GraphDev& g, const int wg, const double* __restrict__ Hinv, const double* __restrict__ Hpl,
+                                           const double* __restrict__ bl, const double* __restrict__ dx, const int32_t* __restrict__ slot_of_pose,
+                                           double lambda, const double* __restrict__ X, double* __restrict__ Xn, double* __restrict__ lm_scale,
+                                           double (*s_t)[kLmSlots + 1]) {
+    const int tid = (int)threadIdx.x;
+    const int j0 = g.lm_wg_first[wg], j1 = g.lm_wg_first[wg + 1], n_lm = j1 - j0;
+    const int s0 = g.lm_start[j0], s1 = g.lm_start[j1];
+    const bool big = s1 - s0 > kLmSlots;   // (workgroup-uniform) then n_lm == 1: the landmark's edges pass in pieces, thread 0 carries its residual
+    double run[3] = {0.0, 0.0, 0.0};
+    if (big && tid == 0)
+        for (int c = 0; c < 3; ++c) run[c] = bl[3 * (size_t)j0 + c];
+    for (int base = s0; base == s0 || base < s1; base += kLmSlots) {
+        const int s = base + tid;
+        if (s < s1) {
+            const int sl = slot_of_pose[g.ledges[s].pose];
+            double t[3] = {0.0, 0.0, 0.0};
+            if (sl >= 0) {
+                const double* W = Hpl + 18 * (size_t)g.lm_edges[s];
+                const double* d = dx + 6 * (size_t)sl;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) t[c] = ((W[c] * d[0] + W[3 + c] * d[1]) + (W[6 + c] * d[2] + W[9 + c] * d[3])) + (W[12 + c] * d[4] + W[15 + c] * d[5]);
+            }
+            s_t[0][tid] = t[0];
+            s_t[1][tid] = t[1];
+            s_t[2][tid] = t[2];
+        }
+        __syncthreads();
+        if (!big) {
+            if (tid < n_lm) {
+                const int j = j0 + tid;
+                double r[3] = {bl[3 * (size_t)j], bl[3 * (size_t)j + 1], bl[3 * (size_t)j + 2]};
+                for (int i = g.lm_start[j] - base; i < g.lm_start[j + 1] - base; ++i) {
+                    r[0] -= s_t[0][i];
+                    r[1] -= s_t[1][i];
+                    r[2] -= s_t[2][i];
+                }
+                backsub_finish(j, r, Hinv, bl, lambda, X, Xn, lm_scale);
+            }
+        } else if (tid == 0) {
+            const int n = min(kLmSlots, s1 - base);
+            for (int i = 0; i < n; ++i) {
+                run[0] -= s_t[0][i];
+                run[1] -= s_t[1][i];
+                run[2] -= s_t[2][i];
+            }
+        }
+        __syncthreads();
+    }
+    if (big && tid == 0) backsub_finish(j0, run, Hinv, bl, lambda, X, Xn, lm_scale);
+}
+
+// The trial state of a Levenberg-Marquardt step in ONE launch (round 5): workgroup 0 advances the keyframes, the others back-substitute the
+// landmarks (kByEdge: one workgroup of k_lin_landmark's partition each, one lane per edge -- round 6; else 128 or 256 landmarks each, one lane per
+// landmark). The landmarks read the keyframes' increments from the solver's solution vector (slot order) instead of the dxp array the
 // keyframe workgroup writes, so the two halves are independent; as two launches the single keyframe workgroup held the queue for 9.5 us.
+template <bool kByEdge>
 __global__ __launch_bounds__(256) void k_trial_update(GraphDev g, const double* __restrict__ T, const int32_t* __restrict__ slot_of_pose,
                                                      const double* __restrict__ x, const double* __restrict__ bp, double lambda,
                                                      double* __restrict__ Tn, double* __restrict__ p7n, double* __restrict__ dxp,
@@ -903,6 +973,9 @@ __global__ __launch_bounds__(256) void k_trial_update(GraphDev g, const double* 
         // the NEXT trial's failure word (the two words alternate): its last reader, the host, consumed it a trial ago -- a memset launch less per trial
         if (threadIdx.x == 0) *next_fail = 0;
         pose_update(T, slot_of_pose, g.n_pose, x, bp, lambda, Tn, p7n, dxp, scal_pose, s_term);
+    } else if (kByEdge) {
+        backsub_wg(g, (int)blockIdx.x - 1, Hinv, Hpl, bl, x, slot_of_pose, lambda, X, Xn, lm_scale,
+                   reinterpret_cast<double (*)[kLmSlots + 1]>(&s_term[0][0]));   // (3 x 257 of the 1792 doubles)
     } else {
         const int j = ((int)blockIdx.x - 1) * lm_per_wg + (int)threadIdx.x;   // (landmarks_per_workgroup, as in k_linearize)
         if ((int)threadIdx.x < lm_per_wg && j < g.n_pt) backsub_landmark(g, j, Hinv, Hpl, bl, x, slot_of_pose, lambda, X, Xn, lm_scale);
@@ -947,6 +1020,33 @@ __global__ __launch_bounds__(256) void k_edge_chi2(GraphDev g, const double* __r
     }
     chi2[e] = ed.w * ss;
     depth_pos[e] = z > 0.0 ? 1 : 0;
+}
+
+// local_bundle_adjuster's chi-square gates on the device (round 6; until then both per-edge arrays came down -- 0.9 MB twice per call --, the host
+// judged 100 k edges in two loops and sent the active mask back up). An edge is an outlier when thr < chi2 or its depth is not positive
+// (upstream: `chi_sq_2D < edge->chi2() || !edge->depth_is_positive()`), thr by edge kind; the same double comparisons, so the same flags.
+//   after round 1 (chi_r1 == nullptr):  out[e] from chi[e] / depth[e]; active[e] = !out[e] (level-1 edges are masked, ba_graph_set_active);
+//                                        *n_active += the inliers (integer atomics: any order gives the same count);
+//   final (chi_r1 != nullptr):           an edge optimised in round 2 (`use_final` and not a round-1 outlier) is judged by chi[e], any other by its
+//                                        round-1 value chi_r1[e] (g2o does not recompute the error of an inactive edge); depth[e] is the final state's.
+__global__ __launch_bounds__(256) void k_edge_gate(int n_edge, int n_mono, double thr_mono, double thr_stereo, const double* __restrict__ chi,
+                                                  const uint8_t* __restrict__ depth, const double* __restrict__ chi_r1,
+                                                  const uint8_t* __restrict__ out1, int use_final, uint8_t* __restrict__ out,
+                                                  uint8_t* __restrict__ active, int32_t* __restrict__ n_active) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    bool inlier = false;
+    if (e < n_edge) {
+        const double thr = e < n_mono ? thr_mono : thr_stereo;
+        const double c = chi_r1 ? ((use_final && !out1[e]) ? chi[e] : chi_r1[e]) : chi[e];
+        const bool o = (thr < c) || !depth[e];
+        out[e] = o ? 1 : 0;
+        if (active) active[e] = o ? 0 : 1;
+        inlier = !o;
+    }
+    if (n_active) {
+        const unsigned long long b = __ballot(inlier);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_active, (int32_t)__popcll(b));
+    }
 }
 
 }   // namespace ovs
@@ -1175,9 +1275,14 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     // The build's temporaries and the host image of the arena belong to the calling thread and keep their pages between calls (mapping_module
     // builds a graph per keyframe: 13 MB of fresh vectors per call were ~3000 page faults, most of the build's 0.6 ms on the host -- round 5).
     // The image is laid out first and filled in place: no per-array vector, no second copy.
+    // Round 6: the image is page-locked, so the edge records (4.8 of the 6.0 MB at config 5) go up while the host is still sorting.
     struct Scratch {
         std::vector<int32_t> edge_pose, edge_pt, fl, fp, seen;
-        std::vector<unsigned char> image;
+        unsigned char* image = nullptr;   // page-locked
+        size_t image_cap = 0;
+        ~Scratch() {
+            if (image) (void)hipHostFree(image);
+        }
     };
     static thread_local Scratch sc;
     size_t top = 0;
@@ -1202,8 +1307,26 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     const size_t o_pose_part = place(sizeof(double) * 27 * max_chunks);
     const size_t o_ledges = place(sizeof(GEdge) * (size_t)ne);
     const size_t arena_bytes = top;
-    if (sc.image.size() < upload_bytes) sc.image.resize(upload_bytes);
-    unsigned char* const img = sc.image.data();
+#define G_TRY(expr)                            \
+    do {                                       \
+        hipError_t _e = (expr);                \
+        if (_e != hipSuccess) {                \
+            ovs::set_last_error(#expr, _e);    \
+            ovs_ba_graph_destroy(g);           \
+            return OVS_ERR_HIP;                \
+        }                                      \
+    } while (0)
+    if (sc.image_cap < upload_bytes) {
+        if (sc.image) (void)hipHostFree(sc.image);
+        sc.image = nullptr;
+        sc.image_cap = 0;
+        const size_t cap = upload_bytes + upload_bytes / 4;   // (head room: the next local map is a little larger more often than not)
+        G_TRY(hipHostMalloc(reinterpret_cast<void**>(&sc.image), cap, hipHostMallocDefault));
+        sc.image_cap = cap;
+    }
+    unsigned char* const img = sc.image;
+    g->d_arena = g_ba_pool.take(device, arena_bytes, &g->arena_cap);
+    G_TRY(g->d_arena ? hipSuccess : hipErrorOutOfMemory);
     GEdge* const edges = reinterpret_cast<GEdge*>(img + o_edges);
     int32_t* const lm_start = reinterpret_cast<int32_t*>(img + o_lm_start);
     int32_t* const lm_edges = reinterpret_cast<int32_t*>(img + o_lm_edges);
@@ -1240,6 +1363,9 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
         ++lm_start[(size_t)pt + 1];
         ++pose_start[(size_t)kp + 1];
     }
+    // the records are final: they travel (null stream, page-locked source: the call returns at once) under the remaining passes
+    const size_t early_bytes = std::min(upload_bytes, (o_edges + sizeof(GEdge) * (size_t)ne + 255) & ~(size_t)255);
+    if (ne > 0) G_TRY(hipMemcpyAsync(g->d_arena, img, early_bytes, hipMemcpyHostToDevice, nullptr));
     for (int j = 0; j < n_pt; ++j) lm_start[(size_t)j + 1] += lm_start[j];
     for (int k = 0; k < n_pose; ++k) pose_start[(size_t)k + 1] += pose_start[k];
     sc.fl.assign(lm_start, lm_start + n_pt);
@@ -1291,15 +1417,6 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
         chunk_start[n_pose] = n_ch;
         g->n_chunks = n_ch;
     }
-#define G_TRY(expr)                            \
-    do {                                       \
-        hipError_t _e = (expr);                \
-        if (_e != hipSuccess) {                \
-            ovs::set_last_error(#expr, _e);    \
-            ovs_ba_graph_destroy(g);           \
-            return OVS_ERR_HIP;                \
-        }                                      \
-    } while (0)
     const double t1 = now();
     std::memcpy(img + o_fixed, g->fixed.data(), (size_t)n_pose);
     std::memset(img + o_active, 1, (size_t)std::max(ne, 1));
@@ -1318,9 +1435,10 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
         std::memcpy(img + o_slot_pose, g->slot_pose.data(), sizeof(int32_t) * (size_t)nf);
     }
     const double t2 = now();
-    g->d_arena = g_ba_pool.take(device, arena_bytes, &g->arena_cap);
-    G_TRY(g->d_arena ? hipSuccess : hipErrorOutOfMemory);
-    G_TRY(hipMemcpy(g->d_arena, img, upload_bytes, hipMemcpyHostToDevice));
+    {
+        const size_t from = ne > 0 ? early_bytes : 0;
+        if (upload_bytes > from) G_TRY(hipMemcpyAsync(g->d_arena + from, img + from, upload_bytes - from, hipMemcpyHostToDevice, nullptr));
+    }
     unsigned char* A = g->d_arena;
     g->d_edges = reinterpret_cast<GEdge*>(A + o_edges);
     g->d_lm_start = reinterpret_cast<int32_t*>(A + o_lm_start);
@@ -1340,8 +1458,8 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     if (ne > 0) {   // null stream: ordered behind the upload above and before whatever stream the caller linearises on (the wait costs ~10 us)
         hipLaunchKernelGGL(k_edges_by_slot, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, nullptr, g->d_edges, g->d_lm_edges, ne, g->d_ledges);
         G_TRY(hipGetLastError());
-        G_TRY(hipStreamSynchronize(nullptr));
     }
+    G_TRY(hipStreamSynchronize(nullptr));   // the image is this thread's next graph's as well: nothing of it may still be on its way
     g->d_slot_of_pose = reinterpret_cast<int32_t*>(A + o_slot_of_pose);
     g->d_pose_pt = reinterpret_cast<int32_t*>(A + o_pose_pt);
     if (g->n_free > 0) {
@@ -1478,8 +1596,13 @@ ovs_status ba_graph_trial_update(ovs_ba_graph* g, const double* d_T, const doubl
                                  double* d_Tn, double* d_p7n, const double* d_X, double* d_Xn, hipStream_t s, int next_fail_word) {
     const GraphDev v = g->view();
     const int lm_per_wg = landmarks_per_workgroup(g->n_pose, g->n_pt);
-    hipLaunchKernelGGL(k_trial_update, dim3(1 + (g->n_pt + lm_per_wg - 1) / lm_per_wg), dim3(256), 0, s, v, d_T, g->d_slot_of_pose, g->d_rhs, d_bp, lambda, d_Tn, d_p7n,
-                       g->d_dxp, g->d_scal + 1, g->d_Hinv, d_Hpl, d_bl, d_X, d_Xn, g->d_lm_tmp + 3 * (size_t)g->n_pt, g->d_fail + next_fail_word, lm_per_wg);
+    if (tuning().ba_backsub_edges)
+        hipLaunchKernelGGL(k_trial_update<true>, dim3(1 + g->n_lm_wg), dim3(256), 0, s, v, d_T, g->d_slot_of_pose, g->d_rhs, d_bp, lambda, d_Tn, d_p7n, g->d_dxp,
+                           g->d_scal + 1, g->d_Hinv, d_Hpl, d_bl, d_X, d_Xn, g->d_lm_tmp + 3 * (size_t)g->n_pt, g->d_fail + next_fail_word, lm_per_wg);
+    else
+        hipLaunchKernelGGL(k_trial_update<false>, dim3(1 + (g->n_pt + lm_per_wg - 1) / lm_per_wg), dim3(256), 0, s, v, d_T, g->d_slot_of_pose, g->d_rhs, d_bp, lambda, d_Tn,
+                           d_p7n, g->d_dxp, g->d_scal + 1, g->d_Hinv, d_Hpl, d_bl, d_X, d_Xn, g->d_lm_tmp + 3 * (size_t)g->n_pt, g->d_fail + next_fail_word,
+                           lm_per_wg);
     OVS_LAUNCH_TRY("k_trial_update");
     return OVS_OK;
 }
@@ -1496,6 +1619,16 @@ ovs_status ba_graph_edge_chi2(ovs_ba_graph* g, const double* d_poses, const doub
     if (g->n_edge() == 0) return OVS_OK;
     hipLaunchKernelGGL(k_edge_chi2, dim3((g->n_edge() + 255) / 256), dim3(256), 0, s, g->view(), d_poses, d_points, d_chi, d_depth);
     OVS_LAUNCH_TRY("k_edge_chi2");
+    return OVS_OK;
+}
+
+// k_edge_gate; `write_active`: the verdicts also become the graph's active mask (what ba_graph_set_active uploads on the host-gate path)
+ovs_status ba_graph_edge_gate(ovs_ba_graph* g, double thr_mono, double thr_stereo, const double* d_chi, const uint8_t* d_depth, const double* d_chi_r1,
+                              const uint8_t* d_out1, bool use_final, uint8_t* d_out, bool write_active, int32_t* d_n_active, hipStream_t s) {
+    if (g->n_edge() == 0) return OVS_OK;
+    hipLaunchKernelGGL(k_edge_gate, dim3((g->n_edge() + 255) / 256), dim3(256), 0, s, g->n_edge(), g->n_mono, thr_mono, thr_stereo, d_chi, d_depth, d_chi_r1,
+                       d_out1, use_final ? 1 : 0, d_out, write_active ? g->d_active : nullptr, d_n_active);
+    OVS_LAUNCH_TRY("k_edge_gate");
     return OVS_OK;
 }
 

@@ -31,6 +31,8 @@ ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_
 ovs_status ba_graph_backsub(ovs_ba_graph* g, const double* d_Hpl, const double* d_bl, double lambda, const double* d_X, double* d_Xn, hipStream_t s);
 ovs_status ba_graph_set_active(ovs_ba_graph* g, const uint8_t* host_mask, hipStream_t s);
 ovs_status ba_graph_edge_chi2(ovs_ba_graph* g, const double* d_poses, const double* d_points, double* d_chi, uint8_t* d_depth, hipStream_t s);
+ovs_status ba_graph_edge_gate(ovs_ba_graph* g, double thr_mono, double thr_stereo, const double* d_chi, const uint8_t* d_depth, const double* d_chi_r1,
+                              const uint8_t* d_out1, bool use_final, uint8_t* d_out, bool write_active, int32_t* d_n_active, hipStream_t s);
 ovs_status ba_graph_linearize(ovs_ba_graph* g, const double* d_poses, const double* d_points, double huber_mono, double huber_stereo, double* d_Hpp,
                               double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror = nullptr,
                               bool trial_scale = false, unsigned long long* host_ll = nullptr, unsigned int seq = 0);
@@ -88,11 +90,16 @@ struct LmScratch {
     size_t pin_cap = 0;
     unsigned char* h_edge = nullptr;   // pinned: two slots of [chi2 per edge (f64) | depth flag per edge (u8)], the results of edge_chi2 (round 1, final)
     size_t edge_cap = 0;               // edges per slot
+    double* h_pts = nullptr;           // pinned: the landmarks on their way up (start of the call) and down (its end)
+    size_t pts_cap = 0;                // doubles
     ~LmScratch() { release(); }
     void release() {
         if (d) (void)hipFree(d);
         if (h_pin) (void)hipHostFree(h_pin);
         if (h_edge) (void)hipHostFree(h_edge);
+        if (h_pts) (void)hipHostFree(h_pts);
+        h_pts = nullptr;
+        pts_cap = 0;
         h_edge = nullptr;
         edge_cap = 0;
         if (stream) (void)hipStreamDestroy(stream);
@@ -115,6 +122,12 @@ struct Lm {
     double *d_poses = nullptr, *d_poses_n = nullptr, *d_poses_w = nullptr, *d_X = nullptr, *d_Xn = nullptr, *d_Xw = nullptr, *d_echi = nullptr;
     double *d_T = nullptr, *d_Tn = nullptr, *d_Tw = nullptr;   // R | t per keyframe (12 doubles), the state k_pose_update advances
     uint8_t* d_edepth = nullptr;
+    // the outlier gates on the device (round 6): round 1's chi2 per edge (kept for the final verdict of level-1 edges), a second chi2 array for the
+    // launch whose chi2 nobody reads, round 1's and the final flags, the inlier count
+    double *d_echi_r1 = nullptr, *d_echi_s = nullptr;
+    uint8_t *d_out1 = nullptr, *d_outf = nullptr;
+    int32_t* d_nact = nullptr;
+    double* h_pts = nullptr;   // LmScratch::h_pts
     double* h_pin = nullptr;   // pinned: S | rhs | bp | staging | chi3 | scal | fail
     size_t pin_doubles = 0, stage_off = 0;
     unsigned char* h_edge = nullptr;   // LmScratch::h_edge
@@ -134,7 +147,7 @@ struct Lm {
         const size_t nb = al(sizeof(double) * DevBlocks::doubles(np, npt, ne_max)), b_p = al(sizeof(double) * 7 * np), b_x = al(sizeof(double) * 3 * npt),
                      b_e = al(sizeof(double) * std::max<size_t>(ne_max, 1)), b_d = al(std::max<size_t>(ne_max, 1));
         const size_t b_t = al(sizeof(double) * 12 * np);
-        const size_t need = 3 * nb + 3 * b_p + 3 * b_x + 3 * b_t + b_e + b_d;
+        const size_t need = 3 * nb + 3 * b_p + 3 * b_x + 3 * b_t + 3 * b_e + 3 * b_d + 256;
         if (sc.d_cap < need) {
             if (sc.d) (void)hipFree(sc.d);
             sc.d = nullptr;
@@ -161,6 +174,13 @@ struct Lm {
         A += 3 * b_t;
         d_echi = reinterpret_cast<double*>(A);
         d_edepth = A + b_e;
+        A += b_e + b_d;
+        d_echi_r1 = reinterpret_cast<double*>(A);
+        d_echi_s = reinterpret_cast<double*>(A + b_e);
+        A += 2 * b_e;
+        d_out1 = A;
+        d_outf = A + b_d;
+        d_nact = reinterpret_cast<int32_t*>(A + 2 * b_d);
         // padded system | bp | staging of the keyframes' records (7 + 12 per keyframe) | chi3, scal, fail | a trial's result block (264 bytes)
         stage_off = ovs::dense_solve_doubles(6 * np) + 6 * (size_t)np;
         pin_doubles = stage_off + 19 * (size_t)np + 16 + 40 + 16;   // (+ 16: the trial's outcome as flag-carrying words, see run_round)
@@ -183,8 +203,19 @@ struct Lm {
         }
         h_edge = sc.h_edge;
         edge_cap = sc.edge_cap;
-        OVS_HIP_TRY(hipMemcpyAsync(d_X, points, sizeof(double) * 3 * npt, hipMemcpyHostToDevice, stream));
-        OVS_HIP_TRY(hipStreamSynchronize(stream));
+        if (sc.pts_cap < (size_t)3 * npt) {
+            if (sc.h_pts) (void)hipHostFree(sc.h_pts);
+            sc.h_pts = nullptr;
+            sc.pts_cap = 0;
+            const size_t cap = ((size_t)3 * npt + (size_t)3 * npt / 4 + 511) & ~(size_t)511;
+            OVS_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sc.h_pts), sizeof(double) * cap, hipHostMallocDefault));
+            sc.pts_cap = cap;
+        }
+        h_pts = sc.h_pts;
+        // through the page-locked block, no wait: the landmarks travel while the caller (ovs_local_ba_optimize) indexes the edges; the block is
+        // written next at the end of the call, behind a dozen stream synchronisations
+        std::memcpy(h_pts, points, sizeof(double) * 3 * (size_t)npt);
+        OVS_HIP_TRY(hipMemcpyAsync(d_X, h_pts, sizeof(double) * 3 * (size_t)npt, hipMemcpyHostToDevice, stream));
         return OVS_OK;
     }
 
@@ -484,6 +515,47 @@ struct Lm {
         OVS_HIP_TRY(hipStreamSynchronize(stream));
         return OVS_OK;
     }
+
+    // edge_chi2's two evaluations without the downloads (round 6): the chi2 upstream would read goes to `d_chi_judged`, the depth flags of the
+    // accepted state to d_edepth. Nothing is waited for.
+    ovs_status edge_chi2_dev(ovs_ba_graph* g, const std::vector<Pose>& T, double* d_chi_judged) {
+        ovs_status st = upload_poses(T, d_poses, nullptr);
+        if (st != OVS_OK) return st;
+        if (err_at_trial) {
+            st = ovs::ba_graph_edge_chi2(g, d_poses_n, d_Xn, d_chi_judged, d_edepth, stream);
+            if (st != OVS_OK) return st;
+        }
+        return ovs::ba_graph_edge_chi2(g, d_poses, d_X, err_at_trial ? d_echi_s : d_chi_judged, d_edepth, stream);
+    }
+    // after round 1: flags into d_out1, the graph's active mask, the number of inliers (one 4-byte download and the wait for it)
+    ovs_status gate_round1(ovs_ba_graph* g, const std::vector<Pose>& T, size_t ne, size_t* n_act) {
+        *n_act = 0;
+        if (ne == 0) return OVS_OK;
+        OVS_HIP_TRY(hipMemsetAsync(d_nact, 0, sizeof(int32_t), stream));
+        ovs_status st = edge_chi2_dev(g, T, d_echi_r1);
+        if (st != OVS_OK) return st;
+        st = ovs::ba_graph_edge_gate(g, kChi2D, kChi3D, d_echi_r1, d_edepth, nullptr, nullptr, false, d_out1, true, d_nact, stream);
+        if (st != OVS_OK) return st;
+        int32_t* const h_n = reinterpret_cast<int32_t*>(h_edge);
+        OVS_HIP_TRY(hipMemcpyAsync(h_n, d_nact, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        OVS_HIP_TRY(hipStreamSynchronize(stream));
+        *n_act = (size_t)*h_n;
+        return OVS_OK;
+    }
+    // the final flags (ne bytes, into the page-locked block) and the landmarks (into h_pts) in one wait
+    ovs_status gate_final(ovs_ba_graph* g, const std::vector<Pose>& T, size_t ne, bool round2_ran, const uint8_t*& flags) {
+        flags = h_edge;
+        if (ne) {
+            ovs_status st = edge_chi2_dev(g, T, d_echi);
+            if (st != OVS_OK) return st;
+            st = ovs::ba_graph_edge_gate(g, kChi2D, kChi3D, d_echi, d_edepth, d_echi_r1, d_out1, round2_ran, d_outf, false, nullptr, stream);
+            if (st != OVS_OK) return st;
+            OVS_HIP_TRY(hipMemcpyAsync(h_edge, d_outf, ne, hipMemcpyDeviceToHost, stream));
+        }
+        OVS_HIP_TRY(hipMemcpyAsync(h_pts, d_X, sizeof(double) * 3 * (size_t)n_pt, hipMemcpyDeviceToHost, stream));
+        OVS_HIP_TRY(hipStreamSynchronize(stream));
+        return OVS_OK;
+    }
 };
 
 struct GraphGuard {
@@ -506,19 +578,24 @@ static ovs_status local_ba_optimize_impl(int model, int32_t device, double* pose
         return OVS_ERR_INVALID;
     if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
     OVS_HIP_TRY(hipSetDevice(device));
-    // ---- round 1 graph: all edges (validates the indices)
-    GraphGuard g1;
+    // ---- the work space first (round 6): the landmarks' upload is on its way while the host indexes the edges
     const bool trace = ovs::tuning().ba_trace;
+    const bool dev_gate = ovs::tuning().ba_dev_outliers;
     const double t_begin = Lm::now();
-    ovs_status st = model == 1 ? ovs_ba_graph_create_equirect(device, n_pose, pose_fixed, n_pt, mono, n_mono, (int32_t)cam->fx, (int32_t)cam->fy, &g1.g)
-                               : ovs_ba_graph_create(device, n_pose, pose_fixed, n_pt, mono, n_mono, stereo, n_stereo, cam, focal_x_baseline, &g1.g);
-    if (st != OVS_OK) return st;
-    const double t_g1 = Lm::now();
     const size_t ne = (size_t)n_mono + n_stereo;
     Lm L;
     L.setup_type = setup_type;
-    st = L.init(device, n_pose, n_pt, ne, points);
+    ovs_status st = L.init(device, n_pose, n_pt, ne, points);
     if (st != OVS_OK) return st;
+    // ---- round 1 graph: all edges (validates the indices)
+    GraphGuard g1;
+    st = model == 1 ? ovs_ba_graph_create_equirect(device, n_pose, pose_fixed, n_pt, mono, n_mono, (int32_t)cam->fx, (int32_t)cam->fy, &g1.g)
+                    : ovs_ba_graph_create(device, n_pose, pose_fixed, n_pt, mono, n_mono, stereo, n_stereo, cam, focal_x_baseline, &g1.g);
+    if (st != OVS_OK) {
+        (void)hipStreamSynchronize(L.stream);   // (the landmarks' upload reads the thread's page-locked block)
+        return st;
+    }
+    const double t_g1 = Lm::now();
     std::vector<Pose> T((size_t)n_pose);
     for (int k = 0; k < n_pose; ++k) {
         quat_to_rot(poses + 7 * (size_t)k + 3, T[k].R);
@@ -529,49 +606,76 @@ static ovs_status local_ba_optimize_impl(int model, int32_t device, double* pose
     if (ne == 0) num_first_iter = num_second_iter = 0;
     st = L.run_round(g1.g, T, num_first_iter, true, force_stop_flag, &info_l[0], &info_l[1], &it1);
     if (st != OVS_OK) return st;
-    const double *chi_r1 = nullptr, *chi = nullptr;   // (page-locked slots of the scratch: round 1's stays valid beside the final one)
-    const uint8_t* depth = nullptr;
-    st = L.edge_chi2(g1.g, T, ne, 0, chi_r1, depth);
-    if (st != OVS_OK) return st;
-    chi = chi_r1;
-    std::vector<uint8_t> out_r1(ne);
-    for (int i = 0; i < n_mono; ++i) out_r1[i] = (kChi2D < chi[i]) || !depth[i];
-    for (int i = 0; i < n_stereo; ++i) out_r1[(size_t)n_mono + i] = (kChi3D < chi[(size_t)n_mono + i]) || !depth[(size_t)n_mono + i];
-    const bool stopped = force_stop_flag && *force_stop_flag;
-    if (!stopped) {
-        // ---- round 2: inliers only (outliers go to level 1), no robust kernel. The graph is kept: level-1 edges are masked, they then
-        // contribute exact zeros and the sums over the remaining edges keep their order -- the result a rebuilt graph would give, without
-        // indexing 100 k edges a second time
-        std::vector<uint8_t> act(ne);
+    const double t_r1 = Lm::now();
+    double t_gate1 = t_r1, t_r2 = t_r1;
+    if (dev_gate) {
+        // ---- round 6: the chi-square gates on the device (k_edge_gate): the per-edge arrays stay in HBM, the active mask is written where
+        //      round 2 reads it, 4 bytes come down after round 1 and the flags (one byte per edge) at the end
         size_t n_act = 0;
-        for (size_t e = 0; e < ne; ++e) n_act += (act[e] = out_r1[e] ? 0 : 1);
-        st = ovs::ba_graph_set_active(g1.g, act.data(), L.stream);
+        st = L.gate_round1(g1.g, T, ne, &n_act);
         if (st != OVS_OK) return st;
-        st = L.run_round(g1.g, T, n_act ? num_second_iter : 0, false, force_stop_flag, &info_l[2], &info_l[3], &it2);
+        t_gate1 = Lm::now();
+        const bool stopped = force_stop_flag && *force_stop_flag;
+        if (!stopped) {
+            st = L.run_round(g1.g, T, n_act ? num_second_iter : 0, false, force_stop_flag, &info_l[2], &info_l[3], &it2);
+            if (st != OVS_OK) return st;
+        }
+        t_r2 = Lm::now();
+        const uint8_t* flags = nullptr;
+        st = L.gate_final(g1.g, T, ne, !stopped, flags);
         if (st != OVS_OK) return st;
-    }
-    // ---- final outlier flags: an edge optimised in round 2 is judged at the final state; a level-1 edge keeps its round-1 chi2
-    //      (g2o does not recompute the error of inactive edges) but its depth test sees the final state
-    st = L.edge_chi2(g1.g, T, ne, 1, chi, depth);
-    if (st != OVS_OK) return st;
-    for (int i = 0; i < n_mono; ++i) {
-        const double c = (!stopped && !out_r1[i]) ? chi[i] : chi_r1[i];
-        mono_outlier[i] = (kChi2D < c) || !depth[i];
-    }
-    for (int i = 0; i < n_stereo; ++i) {
-        const size_t e = (size_t)n_mono + i;
-        const double c = (!stopped && !out_r1[e]) ? chi[e] : chi_r1[e];
-        stereo_outlier[i] = (kChi3D < c) || !depth[e];
+        if (n_mono > 0) std::memcpy(mono_outlier, flags, (size_t)n_mono);
+        if (n_stereo > 0) std::memcpy(stereo_outlier, flags + n_mono, (size_t)n_stereo);
+    } else {
+        const double *chi_r1 = nullptr, *chi = nullptr;   // (page-locked slots of the scratch: round 1's stays valid beside the final one)
+        const uint8_t* depth = nullptr;
+        st = L.edge_chi2(g1.g, T, ne, 0, chi_r1, depth);
+        if (st != OVS_OK) return st;
+        chi = chi_r1;
+        std::vector<uint8_t> out_r1(ne);
+        for (int i = 0; i < n_mono; ++i) out_r1[i] = (kChi2D < chi[i]) || !depth[i];
+        for (int i = 0; i < n_stereo; ++i) out_r1[(size_t)n_mono + i] = (kChi3D < chi[(size_t)n_mono + i]) || !depth[(size_t)n_mono + i];
+        t_gate1 = Lm::now();
+        const bool stopped = force_stop_flag && *force_stop_flag;
+        if (!stopped) {
+            // ---- round 2: inliers only (outliers go to level 1), no robust kernel. The graph is kept: level-1 edges are masked, they then
+            // contribute exact zeros and the sums over the remaining edges keep their order -- the result a rebuilt graph would give, without
+            // indexing 100 k edges a second time
+            std::vector<uint8_t> act(ne);
+            size_t n_act = 0;
+            for (size_t e = 0; e < ne; ++e) n_act += (act[e] = out_r1[e] ? 0 : 1);
+            st = ovs::ba_graph_set_active(g1.g, act.data(), L.stream);
+            if (st != OVS_OK) return st;
+            st = L.run_round(g1.g, T, n_act ? num_second_iter : 0, false, force_stop_flag, &info_l[2], &info_l[3], &it2);
+            if (st != OVS_OK) return st;
+        }
+        t_r2 = Lm::now();
+        // ---- final outlier flags: an edge optimised in round 2 is judged at the final state; a level-1 edge keeps its round-1 chi2
+        //      (g2o does not recompute the error of inactive edges) but its depth test sees the final state
+        st = L.edge_chi2(g1.g, T, ne, 1, chi, depth);
+        if (st != OVS_OK) return st;
+        for (int i = 0; i < n_mono; ++i) {
+            const double c = (!stopped && !out_r1[i]) ? chi[i] : chi_r1[i];
+            mono_outlier[i] = (kChi2D < c) || !depth[i];
+        }
+        for (int i = 0; i < n_stereo; ++i) {
+            const size_t e = (size_t)n_mono + i;
+            const double c = (!stopped && !out_r1[e]) ? chi[e] : chi_r1[e];
+            stereo_outlier[i] = (kChi3D < c) || !depth[e];
+        }
+        OVS_HIP_TRY(hipMemcpyAsync(L.h_pts, L.d_X, sizeof(double) * 3 * (size_t)n_pt, hipMemcpyDeviceToHost, L.stream));
+        OVS_HIP_TRY(hipStreamSynchronize(L.stream));
     }
     std::vector<double> p7;
     Lm::pack_poses(T, p7);
     for (int k = 0; k < n_pose; ++k)
         if (!(pose_fixed && pose_fixed[k])) std::memcpy(poses + 7 * (size_t)k, &p7[(size_t)7 * k], sizeof(double) * 7);
-    OVS_HIP_TRY(hipMemcpy(points, L.d_X, sizeof(double) * 3 * (size_t)n_pt, hipMemcpyDeviceToHost));
+    std::memcpy(points, L.h_pts, sizeof(double) * 3 * (size_t)n_pt);
     if (trace)
-        std::fprintf(stderr, "[ovs_local_ba_optimize] total %.2f ms: graph build (round 1) %.2f, %d trials: schur+download %.2f, host cholesky %.2f, "
-                             "update+linearise (device solver: the whole trial) %.2f ms\n",
-                     Lm::now() - t_begin, t_g1 - t_begin, L.n_trials, L.t_schur, L.t_chol, L.t_trial);
+        std::fprintf(stderr, "[ovs_local_ba_optimize] total %.2f ms: work space + graph build %.2f, round 1 %.2f, gates %.2f, round 2 %.2f, final gates + "
+                             "download %.2f; %d trials: schur+download %.2f, host cholesky %.2f, update+linearise (device solver: the whole trial) %.2f ms\n",
+                     Lm::now() - t_begin, t_g1 - t_begin, t_r1 - t_g1, t_gate1 - t_r1, t_r2 - t_gate1, Lm::now() - t_r2, L.n_trials, L.t_schur, L.t_chol,
+                     L.t_trial);
     if (info) {
         info_l[4] = it1;
         info_l[5] = it2;

@@ -42,6 +42,8 @@ const Tuning& tuning() {
         v.pyr_chain = std::max(0, num("OVS_PYR_CHAIN", 2));
         v.pyr_pair = num("OVS_PYR_PAIR", 1) != 0;
         v.chol_resident = num("OVS_CHOL_RESIDENT", 1) != 0;
+        v.ba_backsub_edges = num("OVS_BA_BACKSUB_EDGES", 1) != 0;
+        v.ba_dev_outliers = num("OVS_BA_DEV_OUTLIERS", 1) != 0;
         return v;
     }();
     return t;

@@ -165,6 +165,8 @@ struct Tuning {
     int pose_threads;      // OVS_POSE_THREADS: 256 / 512 (0 = by problem size)
     int pose_groups;       // OVS_POSE_GROUPS: workgroups a single frame's pose optimisation is spread over (0 = by observation count, 1 = one)
     bool ba_trace;         // OVS_BA_TRACE: per-iteration trace of the LM loops on stderr
+    bool ba_backsub_edges; // OVS_BA_BACKSUB_EDGES=0: k_trial_update back-substitutes one lane per LANDMARK walking its edges (rounds 4-5) instead of one lane per edge (round 6; same bits)
+    bool ba_dev_outliers;  // OVS_BA_DEV_OUTLIERS=0: ovs_local_ba_optimize downloads the per-edge chi2 / depth arrays and judges the edges on the host (rounds 1-5) instead of on the device (round 6; same flags)
     bool chol_resident;    // OVS_CHOL_RESIDENT=0: systems up to 288 unknowns take k_chol_solve (tiles through memory) instead of k_chol_resident
     bool pyr_pair;         // OVS_PYR_PAIR=0: batches build the pyramid level by level (k_resize_linear_u8 x7) instead of two levels per launch (k_resize_pair_u8, round 6)
     int pyr_chain;         // OVS_PYR_CHAIN: frames per launch up to which the pyramid is ONE k_pyramid_chain launch (default 2: measured 24 vs 37 us for one frame, 33.5 vs 35.7 for two, 73 vs 46 for eight; 0 = never)

@@ -477,7 +477,10 @@ np.savez(sys.argv[1], **res)
     # round 6, the same for: a trial's outcome through a D2H copy + stream wait instead of the flag-carrying words the host polls
     # (OVS_BA_LL_NOTIFY=0), and the compiler-scheduled diagonal blocks / round-5 backward substitution of the dense solver (OVS_CHOL_SCHED=0)
     variants = (("auto", {}), ("w256", {"OVS_BA_LM_PER_WG": "256"}), ("w128", {"OVS_BA_LM_PER_WG": "128"}), ("copies", {"OVS_BA_LL_NOTIFY": "0"}),
-                ("chol_r5", {"OVS_CHOL_SCHED": "0"}))
+                ("chol_r5", {"OVS_CHOL_SCHED": "0"}),
+                # round 6: back-substitution by one lane per landmark (rounds 4-5) instead of one per edge; the chi-square gates on the host
+                # (both per-edge arrays downloaded, the active mask uploaded) instead of k_edge_gate
+                ("backsub_lm", {"OVS_BA_BACKSUB_EDGES": "0"}), ("host_gates", {"OVS_BA_DEV_OUTLIERS": "0"}))
     for tag, env in variants:
         out = tmp_path / ("%s.npz" % tag)
         r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests")), str(out)], env=dict(os.environ, **env),
@@ -488,6 +491,64 @@ np.savez(sys.argv[1], **res)
     for tag, _ in variants[1:]:
         for k, v in outs["auto"].items():
             assert np.array_equal(v, outs[tag][k]), (tag, k)
+
+
+@pytest.mark.gpu
+def test_a_landmark_with_more_edges_than_a_workgroup_has_lanes(tmp_path, oracle):
+    """A landmark seen by 270 keyframes (168 free: the device solver's size) is a workgroup of its own in k_lin_landmark and in k_trial_update's
+    one-lane-per-edge back-substitution, its edges passing in pieces of 256. The linearisation against the oracle, and the whole optimisation
+    bit-equal to the one-lane-per-landmark back-substitution (OVS_BA_BACKSUB_EDGES=0, child processes) and to the host-side gates."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from openvslam_amd import ba
+from openvslam_amd.synth import synth_local_ba
+from openvslam_amd.ba import EDGE_DTYPE, quat_to_rot
+d = synth_local_ba(n_pose=270, n_pt=400, obs_per_pose=60, seed=5, pose_noise=0.01, point_noise=0.01, n_fixed=102)
+e = d["edges"]
+rng = np.random.default_rng(9)
+extra = []
+for j in (0, 7):   # two landmarks observed by EVERY keyframe
+    have = set(e["pose_idx"][e["point_idx"] == j].tolist())
+    for k in range(270):
+        if k in have: continue
+        pc = quat_to_rot(d["poses_true"][k, 3:]) @ d["points_true"][j] + d["poses_true"][k, :3]
+        r = np.zeros(1, EDGE_DTYPE)
+        r["pose_idx"], r["point_idx"] = k, j
+        r["obs_x"] = d["cam"][0] * pc[0] / pc[2] + d["cam"][2] + rng.normal()
+        r["obs_y"] = d["cam"][1] * pc[1] / pc[2] + d["cam"][3] + rng.normal()
+        r["inv_sigma_sq"] = 1.0
+        extra.append(r)
+edges = np.concatenate([e] + extra)
+edges = edges[rng.permutation(len(edges))]
+assert (edges["point_idx"] == 0).sum() == 270
+r = ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], edges, d["cam"])
+np.savez(sys.argv[1], edges=edges, **{"opt_" + k: np.asarray(v) for k, v in r.items()})
+"""
+    outs = {}
+    variants = (("auto", {}), ("backsub_lm", {"OVS_BA_BACKSUB_EDGES": "0"}), ("host_gates", {"OVS_BA_DEV_OUTLIERS": "0"}))
+    for tag, env in variants:
+        out = tmp_path / ("%s.npz" % tag)
+        r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests")), str(out)], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = dict(np.load(out))
+    info = outs["auto"]["opt_info"]
+    assert info[4] >= 3 and info[3] < info[0]
+    for tag, _ in variants[1:]:
+        for k, v in outs["auto"].items():
+            assert np.array_equal(v, outs[tag][k]), (tag, k)
+    # and the device against the oracle (the test_local_ba_optimize tolerance)
+    from oracle import lba
+    d = synth_local_ba(n_pose=270, n_pt=400, obs_per_pose=60, seed=5, pose_noise=0.01, point_noise=0.01, n_fixed=102)
+    want = lba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], outs["auto"]["edges"], d["cam"])
+    assert np.array_equal(info[4:], want["info"][4:])
+    assert np.allclose(outs["auto"]["opt_poses"], want["poses"], rtol=1e-7, atol=1e-8)
+    assert np.allclose(outs["auto"]["opt_points"], want["points"], rtol=1e-7, atol=1e-8)
+    assert (outs["auto"]["opt_mono_outlier"] != want["mono_outlier"]).sum() <= 1
 
 
 @pytest.mark.gpu
