@@ -348,6 +348,80 @@ __device__ __forceinline__ void lin_pose_chunk(const GraphDev& g, const int chun
     }
 }
 
+// Round 6, late: HALF a chunk (256 entries of a keyframe's edge list) by a 256-thread workgroup, ONE entry per thread -- the keyframe side of
+// k_linearize2. Two entries per thread (lin_pose_chunk) keep 27 running sums alive across both edges' Jacobians: 218 VGPRs, a budget the landmark
+// side would have to share in a merged launch (round 5's merged k_linearize paid exactly that). With one entry a term goes from the Jacobians
+// straight into its wave sum: 78 VGPRs. By itself that bought nothing (1 M edges: 0.119 against 0.122 ms with six instead of two waves per SIMD --
+// the kernel is bound by its 144 bytes of Hpl per edge, not by latency); what it allows is the merged launch. A half chunk's sum is its four
+// waves' sums in wave order; k_reduce_scalars adds the halves in ascending order (a fixed shape; it differs from the two-entry form's in the
+// last bits of Hpp / bp, like every change of the tree so far; Hpl is per edge and keeps its bits).
+template <int kModel>
+__device__ __forceinline__ void lin_pose_half(const GraphDev& g, const int half_chunk, const double* __restrict__ poses, const double* __restrict__ points,
+                                              double huber_mono, double huber_stereo, double* __restrict__ Hpl, double (*s_part)[27]) {   // [4][27]
+    const int chunk = half_chunk >> 1;
+    const int k = g.chunk_kf[chunk];
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
+    const int e1 = g.pose_start[k + 1];
+    const int i = g.pose_start[k] + (chunk - g.chunk_start[k]) * kPoseChunk + (half_chunk & 1) * 256 + (int)threadIdx.x;
+    double Jl[3][6], Jp[3][6], r[3] = {0.0, 0.0, 0.0}, W = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Jl[a][c] = Jp[a][c] = 0.0;
+    bool stereo = false;
+    if (i < e1) {
+        const int e = g.pose_edges[i];
+        double2* const h = reinterpret_cast<double2*>(Hpl + 18 * (size_t)e);
+        bool live = false;
+        if (!g.fixed[k]) {   // (workgroup-uniform) a fixed keyframe's block and its edges' Hpl are zero
+            const int pt = g.pose_pt[i];
+            const GEdge ed = g.edges[e];
+            const double* x = points + 3 * (size_t)pt;
+            const double X[3] = {x[0], x[1], x[2]};
+            if (g.active[e]) {   // (else: exact zeros for an edge at g2o level 1)
+                live = true;
+                stereo = e >= g.n_mono;
+                double c2, rho0;
+                if (kModel == 1) edge_lin_equirect(poses + 7 * (size_t)k, X, ed, g.cam, huber_mono, Jl, Jp, r, W, c2, rho0);
+                else edge_lin(poses + 7 * (size_t)k, X, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
+#pragma unroll
+                for (int a = 0; a < 6; a += 2) {   // rows a, a + 1: entries 3 a .. 3 a + 5
+                    const double h0 = W * dot3(Jp, a, Jl, 0, stereo), h1 = W * dot3(Jp, a, Jl, 1, stereo), h2 = W * dot3(Jp, a, Jl, 2, stereo);
+                    const double h3 = W * dot3(Jp, a + 1, Jl, 0, stereo), h4 = W * dot3(Jp, a + 1, Jl, 1, stereo), h5 = W * dot3(Jp, a + 1, Jl, 2, stereo);
+                    h[3 * (a >> 1)] = double2{h0, h1};
+                    h[3 * (a >> 1) + 1] = double2{h2, h3};
+                    h[3 * (a >> 1) + 2] = double2{h4, h5};
+                }
+            }
+        }
+        if (!live) {
+#pragma unroll
+            for (int a = 0; a < 9; ++a) h[a] = double2{0.0, 0.0};
+        }
+    }
+    int t = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int b = a; b < 6; ++b) {
+            const double x = wave_sum_lane63(W * dot3(Jp, a, Jp, b, stereo));   // (a lane without a live edge: W = 0 and Jp = 0)
+            if (lane == 63) s_part[wv][t] = x;
+            ++t;
+        }
+        double gq = Jp[0][a] * r[0];
+        gq = gq + Jp[1][a] * r[1];
+        if (stereo) gq = gq + Jp[2][a] * r[2];
+        const double x = wave_sum_lane63(gq);
+        if (lane == 63) s_part[wv][t] = x;
+        ++t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        const int q = (int)threadIdx.x;
+        g.pose_part[27 * (size_t)half_chunk + q] = ((s_part[0][q] + s_part[1][q]) + s_part[2][q]) + s_part[3][q];
+    }
+}
+
 // landmarks [j0, j1) by one 256-thread workgroup: one lane per edge computes the edge's terms, then one lane per (landmark, term) adds a
 // landmark's terms in its edges' order. s_c: [14][kLmSlots] terms of the slots (9 Hll, 3 bl, chi2, rho), s_d: [5][256] the sums' diagonal, chi2 and robustified chi2 per landmark.
 template <int kModel>
@@ -455,11 +529,29 @@ __device__ __forceinline__ void lin_landmark_wg(const GraphDev& g, const int wg,
     }
 }
 
-// the edge records in lm_edges' order, once per graph
+// the edge records in lm_edges' order and the landmark of every slot, once per graph (round 6: the slots' landmarks were written by the host's
+// landmark-order pass; together with the duplicate check below that pass was 0.17 of the graph build's 0.47 ms at config 5)
 __global__ __launch_bounds__(256) void k_edges_by_slot(const GEdge* __restrict__ edges, const int32_t* __restrict__ lm_edges, int n_edge,
-                                                      GEdge* __restrict__ ledges) {
+                                                      GEdge* __restrict__ ledges, int32_t* __restrict__ lm_of_slot,
+                                                      unsigned long long* __restrict__ dup_word) {
     const int s = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (s < n_edge) ledges[s] = edges[lm_edges[s]];
+    if (s == 0) *dup_word = ~0ull;   // (k_dup_check is the next launch on the stream)
+    if (s < n_edge) {
+        const GEdge e = edges[lm_edges[s]];
+        ledges[s] = e;
+        lm_of_slot[s] = e.pt;
+    }
+}
+// A keyframe observes a landmark at most once: slot s reports {landmark : 32 | keyframe : 32} when an earlier slot of its landmark has the same
+// keyframe; the smallest report wins, i.e. the first such landmark and its lowest such keyframe, whatever the order the lanes run in.
+__global__ __launch_bounds__(256) void k_dup_check(const GEdge* __restrict__ ledges, const int32_t* __restrict__ lm_start, int n_edge,
+                                                  unsigned long long* __restrict__ dup_word) {
+    const int s = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (s >= n_edge) return;
+    const int j = ledges[s].pt, k = ledges[s].pose;
+    bool dup = false;
+    for (int i = lm_start[j]; i < s; ++i) dup |= ledges[i].pose == k;
+    if (dup) atomicMin(dup_word, ((unsigned long long)(uint32_t)j << 32) | (uint32_t)k);
 }
 
 // The two halves of a linearisation are independent (different outputs, the same inputs). Round 5 ran them side by side in ONE launch; as
@@ -501,19 +593,76 @@ __global__ __launch_bounds__(256) void k_lin_landmark(GraphDev g, const double* 
     lin_landmark_wg<kModel>(g, (int)blockIdx.x, poses, points, huber_mono, huber_stereo, Hll, bl, lm_chi, s_c, s_d);
 }
 
+// Both halves in ONE launch again (round 6, late; round 5's merged k_linearize was split because the keyframe side's 218 VGPRs set the budget of
+// every workgroup -- lin_pose_half needs 78, the landmark side 70): 2 n_chunks keyframe workgroups (half a chunk each) and n_lm_wg landmark
+// workgroups, interleaved one by one while both kinds last so that the keyframe side's stream of Hpl stores (144 bytes per edge: it is bound by
+// them) and the landmark side's LDS reductions share the chip instead of taking turns. The keyframes' blocks are finished (halves added in
+// ascending order) by k_reduce_scalars, the launch behind this one.
+template <int kModel>
+__global__ __launch_bounds__(256) void k_linearize2(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points, double huber_mono,
+                                                   double huber_stereo, double* __restrict__ Hpl, double* __restrict__ Hll, double* __restrict__ bl,
+                                                   double* __restrict__ lm_chi) {
+    __shared__ double s_c[14][kLmSlots + 1];
+    __shared__ double s_d[5][256];
+    const int A = 2 * g.n_chunks, B = g.n_lm_wg, lo = min(A, B), b = (int)blockIdx.x;
+    const bool paired = b < 2 * lo;
+    const bool pose_side = paired ? (b & 1) == 0 : A > B;   // (workgroup-uniform)
+    const int idx = paired ? b >> 1 : b - lo;
+    if (pose_side) lin_pose_half<kModel>(g, idx, poses, points, huber_mono, huber_stereo, Hpl, reinterpret_cast<double (*)[27]>(&s_d[0][0]));
+    else lin_landmark_wg<kModel>(g, idx, poses, points, huber_mono, huber_stereo, Hll, bl, lm_chi, s_c, s_d);
+}
+
+// term t of keyframe k: its half chunks' sums (k_linearize2) added in ascending order, eight loads in flight
+__device__ __forceinline__ double pose_term_sum(const GraphDev& g, const int k, const int t) {
+    double v = 0.0;
+    const int c1 = 2 * g.chunk_start[k + 1];
+    for (int c = 2 * g.chunk_start[k]; c < c1; c += 8) {
+        double p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = c + u < c1 ? g.pose_part[27 * (size_t)(c + u) + t] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c + u < c1) v += p[u];
+    }
+    return v;
+}
+
 // chi2[0..1] = sum of the per-landmark partials; chi2[2] = max |diagonal| over free pose blocks and landmarks with edges (g2o's
 // computeLambdaInit); one workgroup, fixed order. With `lm_scale` (a Levenberg-Marquardt trial: the landmarks' terms of the gain ratio's
 // denominator, written by the back-substitution) their sum goes to scale_sum[0] -- the additions of the former k_sum_1024, in its order.
-__global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const double* __restrict__ lm_chi, const double* __restrict__ Hpp,
+__global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const double* __restrict__ lm_chi, const double* Hpp,   // (Hpp may be Hpp_out: no restrict)
                                                         const double* __restrict__ Hll, double* __restrict__ chi2, double* __restrict__ mirror,
                                                         const double* __restrict__ lm_scale, double* __restrict__ scale_sum,
-                                                        unsigned long long* __restrict__ host_ll, unsigned int seq, const int32_t* __restrict__ fail2) {
+                                                        unsigned long long* __restrict__ host_ll, unsigned int seq, const int32_t* __restrict__ fail2,
+                                                        double* Hpp_out = nullptr, double* __restrict__ bp_out = nullptr) {
     // host_ll (round 6, the device solver's LM trials): the trial's outcome -- the gain ratio's two parts, the chi2 triple, the two failure words --
     // also goes straight into a page-locked block as twelve 64-bit words {seq : 32 | half of a double : 32}; the host polls them instead of
     // enqueuing a 264-byte D2H copy and waiting for the stream (a copy kernel, its launch gap and the wait's wake-up per trial). A word whose
     // upper half is this trial's sequence number carries this trial's data: no fence (a system-scope release here would write back every dirty
     // line of the L2 -- the ~50 us per trial that sank "one kernel writes the values into the page-locked block" in round 4).
     __shared__ double s0[1024], s1[1024], s2[1024];
+    if (Hpp_out && blockIdx.x > 0) {
+        // behind k_linearize2, workgroups 1 ..: the keyframes' blocks from the half chunks' sums (halves in ascending order); Hpp symmetric, bp.
+        // (One workgroup doing this as well was a serial tail of 27 n_pose sums of up to 40 dependent loads: 1 M edges 0.162 against 0.124 ms.)
+        for (int item = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x; item < 27 * g.n_pose; item += ((int)gridDim.x - 1) * 1024) {
+            const int k = item / 27, t = item - 27 * k;
+            const double v = pose_term_sum(g, k, t);
+            // term t of the upper triangle's rows (a, a .. 5), each followed by the row's right-hand side entry
+            int a = 0, rem = t;
+            while (rem >= 7 - a) {
+                rem -= 7 - a;
+                ++a;
+            }
+            if (rem == 6 - a) {
+                bp_out[6 * (size_t)k + a] = v;
+            } else {
+                const int b = a + rem;
+                Hpp_out[36 * (size_t)k + 6 * a + b] = v;
+                Hpp_out[36 * (size_t)k + 6 * b + a] = v;
+            }
+        }
+        return;
+    }
     if (lm_scale) {   // (uniform) before the chi2 sums: s0 is reused
         double a = 0;
         for (int j0 = threadIdx.x; j0 < g.n_pt; j0 += 4 * 1024) {   // four loads in flight, added in the plain loop's order
@@ -540,9 +689,16 @@ __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const doubl
         b += lm_chi[3 * (size_t)w + 1];
         m = fmax(m, lm_chi[3 * (size_t)w + 2]);
     }
-    for (int k = threadIdx.x; k < g.n_pose; k += 1024)
-        if (!g.fixed[k])
-            for (int d = 0; d < 6; ++d) m = fmax(m, fabs(Hpp[36 * (size_t)k + 7 * d]));
+    if (Hpp_out) {   // (uniform) the diagonal entries are other workgroups' to write: this one adds up the same sums (the same bits) for itself
+        for (int item = (int)threadIdx.x; item < 6 * g.n_pose; item += 1024) {
+            const int k = item / 6, d = item - 6 * k;
+            if (!g.fixed[k]) m = fmax(m, fabs(pose_term_sum(g, k, 7 * d - d * (d - 1) / 2)));   // (row d of the 27 terms starts with its diagonal entry)
+        }
+    } else {
+        for (int k = threadIdx.x; k < g.n_pose; k += 1024)
+            if (!g.fixed[k])
+                for (int d = 0; d < 6; ++d) m = fmax(m, fabs(Hpp[36 * (size_t)k + 7 * d]));
+    }
     s0[threadIdx.x] = a;
     s1[threadIdx.x] = b;
     s2[threadIdx.x] = m;
@@ -1134,19 +1290,38 @@ ovs_status graph_linearize(ovs_ba_graph* g, const double* d_poses, const double*
                            double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror = nullptr,
                            bool trial_scale = false, unsigned long long* host_ll = nullptr, unsigned int seq = 0) {
     const GraphDev v = g->view();
-    if (g->n_chunks > 0) {
-        if (g->model == 1) hipLaunchKernelGGL(k_lin_pose<1>, dim3(g->n_chunks), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl);
-        else hipLaunchKernelGGL(k_lin_pose<0>, dim3(g->n_chunks), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl);
-        OVS_LAUNCH_TRY("k_lin_pose");
+    // One launch for both halves (k_linearize2) while the whole grid is resident at once -- there a launch and its gap are a tenth of the work
+    // (config 5: 0.0296 against 0.0325 ms) --, two launches beyond: a million edges are bound by their 285 MB of traffic, and side by side the two
+    // halves get in each other's way (0.131 against 0.125 ms; the landmark side's 39 KB of LDS also caps the keyframe side's waves per CU).
+    // OVS_BA_LIN_MERGED=0 / 1 forces the two launches / the one. The two forms differ in the last bits of Hpp / bp (another summation tree).
+    static const int forced = [] {
+        const char* e = std::getenv("OVS_BA_LIN_MERGED");
+        return e && e[0] ? std::atoi(e) : -1;
+    }();
+    const bool merged = forced >= 0 ? forced != 0 : 2 * g->n_chunks + g->n_lm_wg <= 2048;
+    if (merged) {
+        const unsigned n_wg = (unsigned)(2 * g->n_chunks + g->n_lm_wg);
+        if (g->model == 1)
+            hipLaunchKernelGGL(k_linearize2<1>, dim3(n_wg), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl, d_Hll, d_bl, g->d_lm_tmp);
+        else
+            hipLaunchKernelGGL(k_linearize2<0>, dim3(n_wg), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl, d_Hll, d_bl, g->d_lm_tmp);
+        OVS_LAUNCH_TRY("k_linearize2");
+    } else {
+        if (g->n_chunks > 0) {
+            if (g->model == 1) hipLaunchKernelGGL(k_lin_pose<1>, dim3(g->n_chunks), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl);
+            else hipLaunchKernelGGL(k_lin_pose<0>, dim3(g->n_chunks), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl);
+            OVS_LAUNCH_TRY("k_lin_pose");
+        }
+        if (g->model == 1)
+            hipLaunchKernelGGL(k_lin_landmark<1>, dim3(g->n_lm_wg), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, g->d_lm_tmp);
+        else
+            hipLaunchKernelGGL(k_lin_landmark<0>, dim3(g->n_lm_wg), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, g->d_lm_tmp);
+        OVS_LAUNCH_TRY("k_lin_landmark");
     }
-    if (g->model == 1)
-        hipLaunchKernelGGL(k_lin_landmark<1>, dim3(g->n_lm_wg), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, g->d_lm_tmp);
-    else
-        hipLaunchKernelGGL(k_lin_landmark<0>, dim3(g->n_lm_wg), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpp, d_bp, d_Hll, d_bl, g->d_lm_tmp);
-    OVS_LAUNCH_TRY("k_lin_landmark");
-    hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(1024), 0, s, v, g->d_lm_tmp, d_Hpp, d_Hll, d_chi3, d_chi_mirror,
+    hipLaunchKernelGGL(k_reduce_scalars, dim3(1 + (merged ? (27 * g->n_pose + 1023) / 1024 : 0)), dim3(1024), 0, s, v, g->d_lm_tmp, d_Hpp, d_Hll, d_chi3, d_chi_mirror,
                        trial_scale ? g->d_lm_tmp + 3 * (size_t)g->n_pt : (const double*)nullptr, trial_scale ? g->d_scal : (double*)nullptr,
-                       trial_scale ? host_ll : (unsigned long long*)nullptr, seq, (const int32_t*)g->d_fail);
+                       trial_scale ? host_ll : (unsigned long long*)nullptr, seq, (const int32_t*)g->d_fail, merged ? d_Hpp : (double*)nullptr,
+                       merged ? d_bp : (double*)nullptr);
     OVS_LAUNCH_TRY("k_reduce_scalars");
     return OVS_OK;
 }
@@ -1244,10 +1419,6 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     if (!out || !cam || n_pose < 1 || n_pt < 1 || n_mono < 0 || n_stereo < 0 || (n_mono > 0 && !mono) || (n_stereo > 0 && !stereo))
         return OVS_ERR_INVALID;
     *out = nullptr;
-    for (int i = 0; i < n_mono; ++i)
-        if (mono[i].pose_idx < 0 || mono[i].pose_idx >= n_pose || mono[i].point_idx < 0 || mono[i].point_idx >= n_pt) return OVS_ERR_INVALID;
-    for (int i = 0; i < n_stereo; ++i)
-        if (stereo[i].pose_idx < 0 || stereo[i].pose_idx >= n_pose || stereo[i].point_idx < 0 || stereo[i].point_idx >= n_pt) return OVS_ERR_INVALID;
     if (ovs_device_count() <= device || device < 0) return OVS_ERR_NO_DEVICE;
     OVS_HIP_TRY(hipSetDevice(device));
     const bool trace = ovs::tuning().ba_trace;
@@ -1300,11 +1471,15 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
                  o_slot_pose = place(sizeof(int32_t) * (size_t)nf);
     // k_linearize's work partition (sizes are upper bounds: the tables are built below, from the counting sorts)
     const size_t max_chunks = (size_t)ne / kPoseChunk + (size_t)n_pose;
-    const size_t o_lm_of_slot = place(sizeof(int32_t) * (size_t)ne), o_lm_wg_first = place(sizeof(int32_t) * ((size_t)n_pt + 1)),
+    const size_t o_lm_wg_first = place(sizeof(int32_t) * ((size_t)n_pt + 1)),
                  o_chunk_kf = place(sizeof(int32_t) * max_chunks), o_chunk_start = place(sizeof(int32_t) * ((size_t)n_pose + 1));
     const size_t upload_bytes = (top + 255) & ~(size_t)255;   // what the device reads before writing it ends here; scratch follows
+    const size_t o_dup_host = place(sizeof(unsigned long long));   // (host image only: where the duplicate check's word comes down to)
+    const size_t image_bytes = top;
+    top = upload_bytes;
+    const size_t o_lm_of_slot = place(sizeof(int32_t) * (size_t)ne), o_dup = place(sizeof(unsigned long long));
     const size_t o_lm_tmp = place(sizeof(double) * 4 * (size_t)n_pt);
-    const size_t o_pose_part = place(sizeof(double) * 27 * max_chunks);
+    const size_t o_pose_part = place(sizeof(double) * 27 * 2 * max_chunks);   // (k_linearize2: one sum per HALF chunk)
     const size_t o_ledges = place(sizeof(GEdge) * (size_t)ne);
     const size_t arena_bytes = top;
 #define G_TRY(expr)                            \
@@ -1316,11 +1491,11 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
             return OVS_ERR_HIP;                \
         }                                      \
     } while (0)
-    if (sc.image_cap < upload_bytes) {
+    if (sc.image_cap < image_bytes) {
         if (sc.image) (void)hipHostFree(sc.image);
         sc.image = nullptr;
         sc.image_cap = 0;
-        const size_t cap = upload_bytes + upload_bytes / 4;   // (head room: the next local map is a little larger more often than not)
+        const size_t cap = image_bytes + image_bytes / 4;   // (head room: the next local map is a little larger more often than not)
         G_TRY(hipHostMalloc(reinterpret_cast<void**>(&sc.image), cap, hipHostMallocDefault));
         sc.image_cap = cap;
     }
@@ -1346,8 +1521,13 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     std::memset(lm_start, 0, sizeof(int32_t) * ((size_t)n_pt + 1));
     std::memset(lm_nmono, 0, sizeof(int32_t) * (size_t)n_pt);
     std::memset(pose_start, 0, sizeof(int32_t) * ((size_t)n_pose + 1));
+    bool bad_index = false;   // (round 6: the range check rides on the first pass instead of being a pass of its own)
     for (int i = 0; i < n_mono; ++i) {
         const int32_t kp = mono[i].pose_idx, pt = mono[i].point_idx;
+        if ((uint32_t)kp >= (uint32_t)n_pose || (uint32_t)pt >= (uint32_t)n_pt) {
+            bad_index = true;
+            break;
+        }
         edges[i] = GEdge{kp, pt, mono[i].obs_x, mono[i].obs_y, 0.0, mono[i].inv_sigma_sq};
         edge_pose[i] = kp;
         edge_pt[i] = pt;
@@ -1355,14 +1535,24 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
         ++lm_nmono[pt];
         ++pose_start[(size_t)kp + 1];
     }
-    for (int i = 0; i < n_stereo; ++i) {
+    for (int i = 0; i < n_stereo && !bad_index; ++i) {
         const int32_t kp = stereo[i].pose_idx, pt = stereo[i].point_idx;
+        if ((uint32_t)kp >= (uint32_t)n_pose || (uint32_t)pt >= (uint32_t)n_pt) {
+            bad_index = true;
+            break;
+        }
         edges[(size_t)n_mono + i] = GEdge{kp, pt, stereo[i].obs_x, stereo[i].obs_y, stereo[i].obs_x_right, stereo[i].inv_sigma_sq};
         edge_pose[(size_t)n_mono + i] = kp;
         edge_pt[(size_t)n_mono + i] = pt;
         ++lm_start[(size_t)pt + 1];
         ++pose_start[(size_t)kp + 1];
     }
+    if (bad_index) {
+        ovs::set_last_error_text("ovs_ba_graph_create: an edge's keyframe or landmark index is out of range");
+        ovs_ba_graph_destroy(g);
+        return OVS_ERR_INVALID;
+    }
+    const double t_p1 = now();
     // the records are final: they travel (null stream, page-locked source: the call returns at once) under the remaining passes
     const size_t early_bytes = std::min(upload_bytes, (o_edges + sizeof(GEdge) * (size_t)ne + 255) & ~(size_t)255);
     if (ne > 0) G_TRY(hipMemcpyAsync(g->d_arena, img, early_bytes, hipMemcpyHostToDevice, nullptr));
@@ -1377,27 +1567,16 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
         pose_edges[(size_t)at] = e;
         pose_pt[(size_t)at] = pt;   // the landmark of every entry of pose_edges: k_schur's pair blocks and k_lin_pose walk a keyframe's observations without the 48-byte records
     }
-    // One pass in landmark order:
-    //  * a keyframe observes a landmark at most once (upstream: landmark::add_observation ignores a second observation by the same keyframe).
-    //    The reduced system relies on that -- k_edge_table keeps ONE edge per (keyframe, landmark), and two edges of one free keyframe to one
-    //    landmark would need cross terms, while Hpp / Hll / rhs would still count both edges --, so a caller-built edge list that breaks it is refused;
-    //  * k_lin_landmark's work partition: the landmark of every slot, runs of whole landmarks with at most kLmSlots edges (and 256 landmarks).
+    const double t_p2 = now();
+    // k_lin_landmark's work partition: runs of whole landmarks with at most kLmSlots edges (and 256 landmarks). (The landmark of every slot and
+    // the check that a keyframe observes a landmark at most once -- upstream: landmark::add_observation ignores a second observation by the same
+    // keyframe; the reduced system relies on it: k_edge_table keeps ONE edge per (keyframe, landmark), two edges of one free keyframe to one
+    // landmark would need cross terms while Hpp / Hll / rhs would still count both, so such an edge list is refused -- moved to the device in
+    // round 6: k_edges_by_slot, k_dup_check below.)
     {
-        int32_t* const lm_of_slot = reinterpret_cast<int32_t*>(img + o_lm_of_slot);
         int32_t* const wg_first = reinterpret_cast<int32_t*>(img + o_lm_wg_first);
-        sc.seen.assign((size_t)n_pose, -1);
         int n_wg = 0, first = 0;
         for (int j = 0; j < n_pt; ++j) {
-            for (int i = lm_start[j]; i < lm_start[(size_t)j + 1]; ++i) {
-                lm_of_slot[i] = j;
-                const int32_t k = edge_pose[lm_edges[i]];
-                if (sc.seen[k] == j) {
-                    ovs::set_last_error_text("ovs_ba_graph_create: keyframe " + std::to_string(k) + " has two edges to landmark " + std::to_string(j));
-                    ovs_ba_graph_destroy(g);
-                    return OVS_ERR_INVALID;
-                }
-                sc.seen[k] = j;
-            }
             if (j > first && (lm_start[(size_t)j + 1] - lm_start[first] > kLmSlots || j - first >= 256)) {   // j does not fit: it opens the next run
                 wg_first[n_wg++] = first;
                 first = j;
@@ -1456,10 +1635,25 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     g->d_pose_part = reinterpret_cast<double*>(A + o_pose_part);
     g->d_ledges = reinterpret_cast<GEdge*>(A + o_ledges);
     if (ne > 0) {   // null stream: ordered behind the upload above and before whatever stream the caller linearises on (the wait costs ~10 us)
-        hipLaunchKernelGGL(k_edges_by_slot, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, nullptr, g->d_edges, g->d_lm_edges, ne, g->d_ledges);
+        unsigned long long* const d_dup = reinterpret_cast<unsigned long long*>(A + o_dup);
+        hipLaunchKernelGGL(k_edges_by_slot, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, nullptr, g->d_edges, g->d_lm_edges, ne, g->d_ledges,
+                           g->d_lm_of_slot, d_dup);
         G_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_dup_check, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, nullptr, g->d_ledges, g->d_lm_start, ne, d_dup);
+        G_TRY(hipGetLastError());
+        G_TRY(hipMemcpyAsync(img + o_dup_host, d_dup, sizeof(unsigned long long), hipMemcpyDeviceToHost, nullptr));
     }
     G_TRY(hipStreamSynchronize(nullptr));   // the image is this thread's next graph's as well: nothing of it may still be on its way
+    if (ne > 0) {
+        unsigned long long dup;
+        std::memcpy(&dup, img + o_dup_host, sizeof(dup));
+        if (dup != ~0ull) {
+            ovs::set_last_error_text("ovs_ba_graph_create: keyframe " + std::to_string((uint32_t)dup) + " has two edges to landmark " +
+                                     std::to_string((uint32_t)(dup >> 32)));
+            ovs_ba_graph_destroy(g);
+            return OVS_ERR_INVALID;
+        }
+    }
     g->d_slot_of_pose = reinterpret_cast<int32_t*>(A + o_slot_of_pose);
     g->d_pose_pt = reinterpret_cast<int32_t*>(A + o_pose_pt);
     if (g->n_free > 0) {
@@ -1468,8 +1662,9 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     }
 #undef G_TRY
     if (trace)
-        std::fprintf(stderr, "[ovs_ba_graph_create] %.2f ms: edge records + counting sorts %.2f, other arrays %.2f, arena + upload of %.1f MB %.2f\n",
-                     now() - t0, t1 - t0, t2 - t1, upload_bytes / 1e6, now() - t2);
+        std::fprintf(stderr, "[ovs_ba_graph_create] %.2f ms: edge records + histograms %.2f, scatter %.2f, landmark-order pass %.2f, other arrays %.2f, rest of "
+                             "the %.1f MB upload + k_edges_by_slot %.2f\n",
+                     now() - t0, t_p1 - t0, t_p2 - t_p1, t1 - t_p2, t2 - t1, upload_bytes / 1e6, now() - t2);
     *out = g;
     return OVS_OK;
 }

@@ -378,11 +378,19 @@ struct FuseArgs {
 // kFuseMutual: one direction of projection::match_keyframes_mutually (no viewing-angle gate, distance = |pos in the other keyframe|)
 enum { kFuseReplace = 0, kFuseDetect = 1, kFuseMutual = 2 };
 
+// Round 6: kFuseLanes lanes per landmark. One lane per landmark walked its (up to nine) grid cells one after the other -- cell bounds, item,
+// keypoint record, descriptor: four dependent loads per candidate, 2000 landmarks on eight workgroups, 35 us of latency. Now lane `sub` of a
+// landmark takes the cells whose ordinal in upstream's enumeration (cx outer, cy inner) is sub, sub + 16, ...; the winner is the minimum of
+// {distance : 16 | cell ordinal : 24 | position in the cell : 24} over the sixteen lanes, i.e. the smallest distance and among equal distances
+// the first candidate upstream's loop meets (its `d < best` is strict): the same index. The per-landmark prelude is computed by all sixteen.
+constexpr int kFuseLanes = 16;
 __global__ __launch_bounds__(256) void k_fuse_best(FuseArgs a, int32_t* __restrict__ best_out, int32_t* __restrict__ num_fused) {
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    if (l >= a.m) return;
-    int32_t result = -1;
+    const int gl = blockIdx.x * 256 + threadIdx.x;
+    const int l = gl / kFuseLanes, sub = gl % kFuseLanes;
+    unsigned long long key = ~0ull;
+    int best_idx = -1;
     do {
+        if (l >= a.m) break;
         if (a.lm_valid && !a.lm_valid[l]) break;
         const double* Xw = a.lm_pos_w + 3 * (size_t)l;
         // (held by value: a pointer that is either the global position or a local array put that array, 32 bytes, in scratch memory)
@@ -431,13 +439,14 @@ __global__ __launch_bounds__(256) void k_fuse_best(FuseArgs a, int32_t* __restri
         const uint32_t* src = reinterpret_cast<const uint32_t*>(a.lm_desc + (size_t)l * 32);
 #pragma unroll
         for (int i = 0; i < 8; ++i) qd[i] = src[i];
-        uint32_t best = OVS_MAX_HAMMING_DIST;
-        int best_idx = -1;
-        for (int cx = min_cx; cx <= max_cx; ++cx) {
-            for (int cy = min_cy; cy <= max_cy; ++cy) {
+        const int ny = max_cy - min_cy + 1, n_cells = (max_cx - min_cx + 1) * ny;
+        for (int ord = sub; ord < n_cells; ord += kFuseLanes) {
+            {
+                const int ox = ord / ny;
+                const int cx = min_cx + ox, cy = min_cy + (ord - ox * ny);
                 const int c = cx * g.rows + cy;
-                const int e = a.cell_start[c + 1];
-                for (int k = a.cell_start[c]; k < e; ++k) {
+                const int k0 = a.cell_start[c], e = a.cell_start[c + 1];
+                for (int k = k0; k < e; ++k) {
                     const int idx = a.items[k];
                     const ovs_keypoint kp = a.t_kps[idx];
                     if (!(fabsf(__fsub_rn(kp.x, ref_x)) < r && fabsf(__fsub_rn(kp.y, ref_y)) < r)) continue;
@@ -456,17 +465,27 @@ __global__ __launch_bounds__(256) void k_fuse_best(FuseArgs a, int32_t* __restri
                         }
                     }
                     const uint32_t d = hamming256_g(qd, reinterpret_cast<const uint32_t*>(a.t_desc + (size_t)idx * 32));
-                    if (d < best) {
-                        best = d;
+                    const unsigned long long cand = ((unsigned long long)d << 48) | ((unsigned long long)(ord & 0xffffff) << 24) | (unsigned long long)((uint32_t)(k - k0) & 0xffffffu);
+                    if (cand < key) {   // (within a lane the keys grow with the enumeration: this is upstream's strict `d < best`)
+                        key = cand;
                         best_idx = idx;
                     }
                 }
             }
         }
-        if (best <= a.max_dist) result = best_idx;
     } while (false);
-    best_out[l] = result;
-    const unsigned long long any = __ballot(result >= 0);
+#pragma unroll
+    for (int off = kFuseLanes / 2; off > 0; off >>= 1) {   // (xor partners stay inside the landmark's aligned group of sixteen lanes)
+        const unsigned long long ok = __shfl_xor(key, off);
+        const int oi = __shfl_xor(best_idx, off);
+        if (ok < key) {
+            key = ok;
+            best_idx = oi;
+        }
+    }
+    const int32_t result = (key != ~0ull && (uint32_t)(key >> 48) <= a.max_dist) ? best_idx : -1;
+    if (sub == 0 && l < a.m) best_out[l] = result;
+    const unsigned long long any = __ballot(sub == 0 && l < a.m && result >= 0);
     if ((threadIdx.x & 63) == 0 && any) atomicAdd(num_fused, (int32_t)__popcll(any));
 }
 
@@ -1834,7 +1853,7 @@ static ovs_status fuse_replace_duplication_impl(ovs_wmatcher* w, const ovs_frame
     a.variant = kFuseReplace;
     a.max_dist = OVS_HAMMING_DIST_THR_LOW;
     OVS_HIP_TRY(hipMemsetAsync(w->d_num, 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_fuse_best, dim3((m + 255) / 256), dim3(256), 0, s, a, w->d_assigned, w->d_num);
+    hipLaunchKernelGGL(k_fuse_best, dim3((unsigned)(((size_t)m * kFuseLanes + 255) / 256)), dim3(256), 0, s, a, w->d_assigned, w->d_num);
     OVS_HIP_TRY(hipGetLastError());
     return fetch_results(w, m, best_idx, num_fused, s, false);   // one copy down through the pinned mirror
 }
@@ -2019,7 +2038,7 @@ static ovs_status fuse_detect_duplication_impl(ovs_wmatcher* w, const ovs_frame_
     a.items = tg.items;
     a.gp = tg.gp;
     OVS_HIP_TRY(hipMemsetAsync(w->d_num, 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_fuse_best, dim3((m + 255) / 256), dim3(256), 0, s, a, w->d_assigned, w->d_num);
+    hipLaunchKernelGGL(k_fuse_best, dim3((unsigned)(((size_t)m * kFuseLanes + 255) / 256)), dim3(256), 0, s, a, w->d_assigned, w->d_num);
     OVS_HIP_TRY(hipGetLastError());
     return fetch_results(w, m, best_idx, num_found, s, false);
 }
@@ -2147,7 +2166,7 @@ static ovs_status mutual_pass(ovs_wmatcher* w, const ovs_frame_dev* res_b, const
     a.lm_dist = w->d_q_xy;
     a.lm_desc = w->d_q_desc;
     a.lm_valid = lm_valid_a ? w->d_q_flag : nullptr;
-    hipLaunchKernelGGL(k_fuse_best, dim3((n_a + 255) / 256), dim3(256), 0, s, a, d_out, w->d_num + 1);   // per-direction count: scratch
+    hipLaunchKernelGGL(k_fuse_best, dim3((unsigned)(((size_t)n_a * kFuseLanes + 255) / 256)), dim3(256), 0, s, a, d_out, w->d_num + 1);   // per-direction count: scratch
     OVS_HIP_TRY(hipGetLastError());
     return OVS_OK;
 }

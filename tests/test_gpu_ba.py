@@ -480,7 +480,10 @@ np.savez(sys.argv[1], **res)
                 ("chol_r5", {"OVS_CHOL_SCHED": "0"}),
                 # round 6: back-substitution by one lane per landmark (rounds 4-5) instead of one per edge; the chi-square gates on the host
                 # (both per-edge arrays downloaded, the active mask uploaded) instead of k_edge_gate
-                ("backsub_lm", {"OVS_BA_BACKSUB_EDGES": "0"}), ("host_gates", {"OVS_BA_DEV_OUTLIERS": "0"}))
+                ("backsub_lm", {"OVS_BA_BACKSUB_EDGES": "0"}), ("host_gates", {"OVS_BA_DEV_OUTLIERS": "0"}),
+                # the linearisation as two launches (k_lin_pose with two entries per thread, k_lin_landmark) instead of k_linearize2: another
+                # summation tree for Hpp / bp (last bits), the same bits for everything per edge and per landmark
+                ("lin_two_launches", {"OVS_BA_LIN_MERGED": "0"}))
     for tag, env in variants:
         out = tmp_path / ("%s.npz" % tag)
         r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests")), str(out)], env=dict(os.environ, **env),
@@ -490,6 +493,12 @@ np.savez(sys.argv[1], **res)
     assert len(outs["auto"]) >= 10 and outs["auto"]["opt_info"][4] >= 3
     for tag, _ in variants[1:]:
         for k, v in outs["auto"].items():
+            if tag == "lin_two_launches" and k not in ("lin_Hll", "lin_bl", "lin_Hpl"):
+                if k.startswith("lin_"):
+                    assert np.allclose(v, outs[tag][k], rtol=1e-11, atol=1e-11 * np.abs(v).max()), (tag, k)
+                elif k in ("opt_poses", "opt_points"):
+                    assert np.allclose(v, outs[tag][k], rtol=1e-8, atol=1e-9), (tag, k)
+                continue
             assert np.array_equal(v, outs[tag][k]), (tag, k)
 
 
