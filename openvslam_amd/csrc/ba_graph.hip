@@ -263,9 +263,10 @@ __device__ __forceinline__ void block_sum_256(double (&v)[NV], double (*s_part)[
 }
 
 // chunk c of keyframe k by one 256-thread workgroup: thread t takes entries t and t + 256 of the chunk, one after the other
-template <int kModel>
+template <int kModel, bool kStage>
 __device__ __forceinline__ void lin_pose_chunk(const GraphDev& g, const int chunk, const double* __restrict__ poses, const double* __restrict__ points,
-                                               double huber_mono, double huber_stereo, double* __restrict__ Hpl, double (*s_part)[27]) {
+                                               double huber_mono, double huber_stereo, double* __restrict__ Hpl, double (*s_part)[27],
+                                               double2* __restrict__ s_h) {
     const int k = g.chunk_kf[chunk];
     double acc[27];
 #pragma unroll
@@ -294,6 +295,8 @@ __device__ __forceinline__ void lin_pose_chunk(const GraphDev& g, const int chun
             ee[u] = in ? g.pose_edges[i0 + 256 * u] : -1;
             pt[u] = in ? g.pose_pt[i0 + 256 * u] : 0;   // the landmark without going through the edge record: one dependent load less
         }
+        // (the records' 40-byte gathers were staged through LDS the same way as the stores below -- five coalesced loads per 64 consecutive
+        // records -- and that changed nothing: 0.110 against 0.108 ms at a million edges; the loads are not what the kernel waits for)
 #pragma unroll
         for (int u = 0; u < 2; ++u) edd[u] = g.edges[max(ee[u], 0)];
 #pragma unroll
@@ -306,36 +309,76 @@ __device__ __forceinline__ void lin_pose_chunk(const GraphDev& g, const int chun
 #pragma unroll 1
         for (int u = 0; u < 2; ++u) {
             const int e = u ? ee[1] : ee[0];
-            if (e < 0) break;
-            if (!g.active[e]) {   // exact zeros for an edge at g2o level 1
-                zero_hpl(e);
-                continue;
+            if (!kStage) {
+                if (e < 0) break;
+                if (!g.active[e]) {   // exact zeros for an edge at g2o level 1
+                    zero_hpl(e);
+                    continue;
+                }
             }
-            const GEdge ed = u ? edd[1] : edd[0];
-            const double X[3] = {u ? XX[1][0] : XX[0][0], u ? XX[1][1] : XX[0][1], u ? XX[1][2] : XX[0][2]};
-            const bool stereo = e >= g.n_mono;
-            double Jl[3][6], Jp[3][6], r[3], W, c2, rho0;
-            if (kModel == 1) edge_lin_equirect(P, X, ed, g.cam, huber_mono, Jl, Jp, r, W, c2, rho0);
-            else edge_lin(P, X, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
-            int t = 0;
+            const bool live = kStage ? (e >= 0 && g.active[e]) : true;
+            double2 hv[9];
+            if (kStage) {
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                for (int b = a; b < 6; ++b) acc[t++] += W * dot3(Jp, a, Jp, b, stereo);
-                double gq = Jp[0][a] * r[0];
-                gq = gq + Jp[1][a] * r[1];
-                if (stereo) gq = gq + Jp[2][a] * r[2];
-                acc[t++] += gq;
+                for (int a = 0; a < 9; ++a) hv[a] = double2{0.0, 0.0};
             }
-            // W_e = W Jp^T Jl: this side walks the edges in ascending index, so a wave's 64 records are 9 KB of consecutive bytes
-            double2* const h = reinterpret_cast<double2*>(Hpl + 18 * (size_t)e);
+            if (live) {
+                const GEdge ed = u ? edd[1] : edd[0];
+                const double X[3] = {u ? XX[1][0] : XX[0][0], u ? XX[1][1] : XX[0][1], u ? XX[1][2] : XX[0][2]};
+                const bool stereo = e >= g.n_mono;
+                double Jl[3][6], Jp[3][6], r[3], W, c2, rho0;
+                if (kModel == 1) edge_lin_equirect(P, X, ed, g.cam, huber_mono, Jl, Jp, r, W, c2, rho0);
+                else edge_lin(P, X, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
+                int t = 0;
 #pragma unroll
-            for (int a = 0; a < 6; a += 2) {   // rows a, a + 1: entries 3 a .. 3 a + 5
-                const double h0 = W * dot3(Jp, a, Jl, 0, stereo), h1 = W * dot3(Jp, a, Jl, 1, stereo), h2 = W * dot3(Jp, a, Jl, 2, stereo);
-                const double h3 = W * dot3(Jp, a + 1, Jl, 0, stereo), h4 = W * dot3(Jp, a + 1, Jl, 1, stereo), h5 = W * dot3(Jp, a + 1, Jl, 2, stereo);
-                h[3 * (a >> 1)] = double2{h0, h1};
-                h[3 * (a >> 1) + 1] = double2{h2, h3};
-                h[3 * (a >> 1) + 2] = double2{h4, h5};
+                for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                    for (int b = a; b < 6; ++b) acc[t++] += W * dot3(Jp, a, Jp, b, stereo);
+                    double gq = Jp[0][a] * r[0];
+                    gq = gq + Jp[1][a] * r[1];
+                    if (stereo) gq = gq + Jp[2][a] * r[2];
+                    acc[t++] += gq;
+                }
+                // W_e = W Jp^T Jl: this side walks the edges in ascending index, so a wave's 64 records are 9 KB of consecutive bytes
+                double2* const h = reinterpret_cast<double2*>(Hpl + 18 * (size_t)e);
+#pragma unroll
+                for (int a = 0; a < 6; a += 2) {   // rows a, a + 1: entries 3 a .. 3 a + 5
+                    const double h0 = W * dot3(Jp, a, Jl, 0, stereo), h1 = W * dot3(Jp, a, Jl, 1, stereo), h2 = W * dot3(Jp, a, Jl, 2, stereo);
+                    const double h3 = W * dot3(Jp, a + 1, Jl, 0, stereo), h4 = W * dot3(Jp, a + 1, Jl, 1, stereo), h5 = W * dot3(Jp, a + 1, Jl, 2, stereo);
+                    if (kStage) {
+                        hv[3 * (a >> 1)] = double2{h0, h1};
+                        hv[3 * (a >> 1) + 1] = double2{h2, h3};
+                        hv[3 * (a >> 1) + 2] = double2{h4, h5};
+                    } else {
+                        h[3 * (a >> 1)] = double2{h0, h1};
+                        h[3 * (a >> 1) + 1] = double2{h2, h3};
+                        h[3 * (a >> 1) + 2] = double2{h4, h5};
+                    }
+                }
+            }
+            if (kStage) {
+                // Round 6, late: a lane storing its own 144-byte record writes nine 16-byte pieces, each store instruction touching 64 different
+                // 128-byte lines (9 M partial-line write requests per million edges). When the wave's 64 edges are consecutive (the usual case:
+                // edge lists arrive keyframe by keyframe) the records pass through LDS and every store instruction writes 1 KB of consecutive bytes.
+                const int lane = (int)threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+                const int e_first = __shfl(e, 0);
+                const bool contig = __ballot(e >= 0 && e == e_first + lane) == ~0ull;   // (wave-uniform)
+                if (contig) {
+                    double2* const sh = s_h + (size_t)wv * (64 * 9);
+#pragma unroll
+                    for (int a = 0; a < 9; ++a) sh[lane * 9 + a] = hv[a];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    double2* const h = reinterpret_cast<double2*>(Hpl + 18 * (size_t)e_first);
+#pragma unroll
+                    for (int a = 0; a < 9; ++a) h[a * 64 + lane] = sh[a * 64 + lane];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();   // (the next entry's records overwrite the buffer)
+                } else if (e >= 0) {
+                    double2* const h = reinterpret_cast<double2*>(Hpl + 18 * (size_t)e);
+#pragma unroll
+                    for (int a = 0; a < 9; ++a) h[a] = hv[a];
+                }
             }
         }
     }
@@ -357,7 +400,8 @@ __device__ __forceinline__ void lin_pose_chunk(const GraphDev& g, const int chun
 // last bits of Hpp / bp, like every change of the tree so far; Hpl is per edge and keeps its bits).
 template <int kModel>
 __device__ __forceinline__ void lin_pose_half(const GraphDev& g, const int half_chunk, const double* __restrict__ poses, const double* __restrict__ points,
-                                              double huber_mono, double huber_stereo, double* __restrict__ Hpl, double (*s_part)[27]) {   // [4][27]
+                                              double huber_mono, double huber_stereo, double* __restrict__ Hpl, double (*s_part)[27],   // [4][27]
+                                              double2* __restrict__ s_h) {   // [4 waves][64 x 9]: the records on their way to coalesced stores (lin_pose_chunk)
     const int chunk = half_chunk >> 1;
     const int k = g.chunk_kf[chunk];
     const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
@@ -369,34 +413,46 @@ __device__ __forceinline__ void lin_pose_half(const GraphDev& g, const int half_
 #pragma unroll
         for (int c = 0; c < 6; ++c) Jl[a][c] = Jp[a][c] = 0.0;
     bool stereo = false;
-    if (i < e1) {
-        const int e = g.pose_edges[i];
-        double2* const h = reinterpret_cast<double2*>(Hpl + 18 * (size_t)e);
-        bool live = false;
-        if (!g.fixed[k]) {   // (workgroup-uniform) a fixed keyframe's block and its edges' Hpl are zero
-            const int pt = g.pose_pt[i];
-            const GEdge ed = g.edges[e];
-            const double* x = points + 3 * (size_t)pt;
-            const double X[3] = {x[0], x[1], x[2]};
-            if (g.active[e]) {   // (else: exact zeros for an edge at g2o level 1)
-                live = true;
-                stereo = e >= g.n_mono;
-                double c2, rho0;
-                if (kModel == 1) edge_lin_equirect(poses + 7 * (size_t)k, X, ed, g.cam, huber_mono, Jl, Jp, r, W, c2, rho0);
-                else edge_lin(poses + 7 * (size_t)k, X, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
+    const int e = i < e1 ? g.pose_edges[i] : -1;
+    double2 hv[9];
 #pragma unroll
-                for (int a = 0; a < 6; a += 2) {   // rows a, a + 1: entries 3 a .. 3 a + 5
-                    const double h0 = W * dot3(Jp, a, Jl, 0, stereo), h1 = W * dot3(Jp, a, Jl, 1, stereo), h2 = W * dot3(Jp, a, Jl, 2, stereo);
-                    const double h3 = W * dot3(Jp, a + 1, Jl, 0, stereo), h4 = W * dot3(Jp, a + 1, Jl, 1, stereo), h5 = W * dot3(Jp, a + 1, Jl, 2, stereo);
-                    h[3 * (a >> 1)] = double2{h0, h1};
-                    h[3 * (a >> 1) + 1] = double2{h2, h3};
-                    h[3 * (a >> 1) + 2] = double2{h4, h5};
-                }
+    for (int a = 0; a < 9; ++a) hv[a] = double2{0.0, 0.0};   // (a fixed keyframe's edges and the edges at g2o level 1: exact zeros)
+    if (e >= 0 && !g.fixed[k]) {   // (fixed: workgroup-uniform)
+        const int pt = g.pose_pt[i];
+        const GEdge ed = g.edges[e];
+        const double* x = points + 3 * (size_t)pt;
+        const double X[3] = {x[0], x[1], x[2]};
+        if (g.active[e]) {
+            stereo = e >= g.n_mono;
+            double c2, rho0;
+            if (kModel == 1) edge_lin_equirect(poses + 7 * (size_t)k, X, ed, g.cam, huber_mono, Jl, Jp, r, W, c2, rho0);
+            else edge_lin(poses + 7 * (size_t)k, X, ed, stereo, g.cam, g.bf, stereo ? huber_stereo : huber_mono, Jl, Jp, r, W, c2, rho0);
+#pragma unroll
+            for (int a = 0; a < 6; a += 2) {   // rows a, a + 1: entries 3 a .. 3 a + 5
+                const double h0 = W * dot3(Jp, a, Jl, 0, stereo), h1 = W * dot3(Jp, a, Jl, 1, stereo), h2 = W * dot3(Jp, a, Jl, 2, stereo);
+                const double h3 = W * dot3(Jp, a + 1, Jl, 0, stereo), h4 = W * dot3(Jp, a + 1, Jl, 1, stereo), h5 = W * dot3(Jp, a + 1, Jl, 2, stereo);
+                hv[3 * (a >> 1)] = double2{h0, h1};
+                hv[3 * (a >> 1) + 1] = double2{h2, h3};
+                hv[3 * (a >> 1) + 2] = double2{h4, h5};
             }
         }
-        if (!live) {
+    }
+    {   // the records leave through LDS when the wave's 64 edges are consecutive (see lin_pose_chunk)
+        const int e_first = __shfl(e, 0);
+        const bool contig = __ballot(e >= 0 && e == e_first + lane) == ~0ull;   // (wave-uniform)
+        if (contig) {
+            double2* const sh = s_h + (size_t)__builtin_amdgcn_readfirstlane(wv) * (64 * 9);
 #pragma unroll
-            for (int a = 0; a < 9; ++a) h[a] = double2{0.0, 0.0};
+            for (int a = 0; a < 9; ++a) sh[lane * 9 + a] = hv[a];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            double2* const h = reinterpret_cast<double2*>(Hpl + 18 * (size_t)e_first);
+#pragma unroll
+            for (int a = 0; a < 9; ++a) h[a * 64 + lane] = sh[a * 64 + lane];
+        } else if (e >= 0) {
+            double2* const h = reinterpret_cast<double2*>(Hpl + 18 * (size_t)e);
+#pragma unroll
+            for (int a = 0; a < 9; ++a) h[a] = hv[a];
         }
     }
     int t = 0;
@@ -557,11 +613,12 @@ __global__ __launch_bounds__(256) void k_dup_check(const GEdge* __restrict__ led
 // The two halves of a linearisation are independent (different outputs, the same inputs). Round 5 ran them side by side in ONE launch; as
 // two launches each gets its own register budget: the keyframe side needs ~200 VGPRs (27 running sums beside both Jacobians: two waves per
 // SIMD), the landmark side fewer than 128 (four waves per SIMD) -- merged, every workgroup paid the larger figure.
-template <int kModel>
+template <int kModel, bool kStage>
 __global__ __launch_bounds__(256) void k_lin_pose(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points, double huber_mono,
                                                  double huber_stereo, double* __restrict__ Hpl) {
     __shared__ double s_part[4][27];
-    lin_pose_chunk<kModel>(g, (int)blockIdx.x, poses, points, huber_mono, huber_stereo, Hpl, s_part);
+    __shared__ double2 s_h[kStage ? 4 * 64 * 9 : 1];   // the four waves' 64 records of 144 bytes on their way to coalesced stores
+    lin_pose_chunk<kModel, kStage>(g, (int)blockIdx.x, poses, points, huber_mono, huber_stereo, Hpl, s_part, s_h);
 }
 template <int kModel>
 __global__ __launch_bounds__(256) void k_lin_landmark(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points, double huber_mono,
@@ -602,14 +659,20 @@ template <int kModel>
 __global__ __launch_bounds__(256) void k_linearize2(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points, double huber_mono,
                                                    double huber_stereo, double* __restrict__ Hpl, double* __restrict__ Hll, double* __restrict__ bl,
                                                    double* __restrict__ lm_chi) {
-    __shared__ double s_c[14][kLmSlots + 1];
-    __shared__ double s_d[5][256];
+    // one buffer, two views: the landmark side's s_c[14][kLmSlots + 1] | s_d[5][256]; the keyframe side's s_h[4][64 x 9] (double2) | s_part[4][27]
+    constexpr int kRaw = 14 * (kLmSlots + 1) + 5 * 256;
+    static_assert(kRaw >= 2 * 4 * 64 * 9 + 4 * 27, "the keyframe side's view fits the landmark side's");
+    __shared__ __attribute__((aligned(16))) double s_raw[kRaw];
     const int A = 2 * g.n_chunks, B = g.n_lm_wg, lo = min(A, B), b = (int)blockIdx.x;
     const bool paired = b < 2 * lo;
     const bool pose_side = paired ? (b & 1) == 0 : A > B;   // (workgroup-uniform)
     const int idx = paired ? b >> 1 : b - lo;
-    if (pose_side) lin_pose_half<kModel>(g, idx, poses, points, huber_mono, huber_stereo, Hpl, reinterpret_cast<double (*)[27]>(&s_d[0][0]));
-    else lin_landmark_wg<kModel>(g, idx, poses, points, huber_mono, huber_stereo, Hll, bl, lm_chi, s_c, s_d);
+    if (pose_side)
+        lin_pose_half<kModel>(g, idx, poses, points, huber_mono, huber_stereo, Hpl, reinterpret_cast<double (*)[27]>(s_raw + 2 * 4 * 64 * 9),
+                              reinterpret_cast<double2*>(s_raw));
+    else
+        lin_landmark_wg<kModel>(g, idx, poses, points, huber_mono, huber_stereo, Hll, bl, lm_chi, reinterpret_cast<double (*)[kLmSlots + 1]>(s_raw),
+                                reinterpret_cast<double (*)[256]>(s_raw + 14 * (kLmSlots + 1)));
 }
 
 // term t of keyframe k: its half chunks' sums (k_linearize2) added in ascending order, eight loads in flight
@@ -1290,15 +1353,16 @@ ovs_status graph_linearize(ovs_ba_graph* g, const double* d_poses, const double*
                            double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi3, hipStream_t s, double* d_chi_mirror = nullptr,
                            bool trial_scale = false, unsigned long long* host_ll = nullptr, unsigned int seq = 0) {
     const GraphDev v = g->view();
-    // One launch for both halves (k_linearize2) while the whole grid is resident at once -- there a launch and its gap are a tenth of the work
-    // (config 5: 0.0296 against 0.0325 ms) --, two launches beyond: a million edges are bound by their 285 MB of traffic, and side by side the two
-    // halves get in each other's way (0.131 against 0.125 ms; the landmark side's 39 KB of LDS also caps the keyframe side's waves per CU).
-    // OVS_BA_LIN_MERGED=0 / 1 forces the two launches / the one. The two forms differ in the last bits of Hpp / bp (another summation tree).
-    static const int forced = [] {
+    // One launch for both halves (k_linearize2): config 5 0.0325 -> 0.0249 ms, a million edges 0.124 -> 0.1005 ms per linearisation (a launch and
+    // its gap less; the Hpl records leave through LDS as whole lines; the keyframe side's stores and the landmark side's LDS reductions overlap).
+    // Before the stores were coalesced the merged launch LOST at a million edges (0.131 against 0.125 ms): the partial-line write requests of
+    // the keyframe side were what both halves queued behind. OVS_BA_LIN_MERGED=0: k_lin_pose (two entries per thread) and k_lin_landmark as two
+    // launches (0.110 ms at a million edges with the staged stores, 0.124 without: OVS_BA_HPL_STAGE=0). The two forms differ in the last bits
+    // of Hpp / bp (another summation tree), not in anything per edge or per landmark.
+    static const bool merged = [] {
         const char* e = std::getenv("OVS_BA_LIN_MERGED");
-        return e && e[0] ? std::atoi(e) : -1;
+        return !(e && e[0] == '0');
     }();
-    const bool merged = forced >= 0 ? forced != 0 : 2 * g->n_chunks + g->n_lm_wg <= 2048;
     if (merged) {
         const unsigned n_wg = (unsigned)(2 * g->n_chunks + g->n_lm_wg);
         if (g->model == 1)
@@ -1308,8 +1372,15 @@ ovs_status graph_linearize(ovs_ba_graph* g, const double* d_poses, const double*
         OVS_LAUNCH_TRY("k_linearize2");
     } else {
         if (g->n_chunks > 0) {
-            if (g->model == 1) hipLaunchKernelGGL(k_lin_pose<1>, dim3(g->n_chunks), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl);
-            else hipLaunchKernelGGL(k_lin_pose<0>, dim3(g->n_chunks), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl);
+            static const bool stage = [] {   // OVS_BA_HPL_STAGE=0: every lane stores its own record (round 6's first form)
+                const char* e = std::getenv("OVS_BA_HPL_STAGE");
+                return !(e && e[0] == '0');
+            }();
+            if (stage) {
+                if (g->model == 1) hipLaunchKernelGGL((k_lin_pose<1, true>), dim3(g->n_chunks), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl);
+                else hipLaunchKernelGGL((k_lin_pose<0, true>), dim3(g->n_chunks), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl);
+            } else if (g->model == 1) hipLaunchKernelGGL((k_lin_pose<1, false>), dim3(g->n_chunks), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl);
+            else hipLaunchKernelGGL((k_lin_pose<0, false>), dim3(g->n_chunks), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl);
             OVS_LAUNCH_TRY("k_lin_pose");
         }
         if (g->model == 1)
