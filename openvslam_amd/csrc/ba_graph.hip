@@ -829,23 +829,50 @@ __global__ __launch_bounds__(256) void k_lm_prepare(GraphDev g, const double* __
 #pragma unroll
             for (int i = 0; i < 9; ++i) Hinv[9 * (size_t)t + i] = Hi[i];
     }
-    if (t >= g.n_edge) return;
-    const int e = t, j = g.edges[e].pt;
-    double Hi[9];
-    if (!inv3_sym_d(Hll + 9 * (size_t)j, lambda, Hi)) {
-        *fail = 1;
-        return;
+    // Round 6, late: Y leaves through LDS -- a lane storing its own 144-byte record writes nine 16-byte pieces, each store instruction touching 64
+    // different lines (0.9 M partial-line write requests per launch at config 5); a wave's 64 records are 9216 consecutive bytes: 14.0 -> 10.4 us.
+    __shared__ double2 s_y[4 * 64 * 9];
+    const int lane = (int)threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int e = t;
+    bool ok = e < g.n_edge;
+    double2 yv[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) yv[i] = double2{0.0, 0.0};
+    if (ok) {
+        const int j = g.edges[e].pt;
+        double Hi[9];
+        if (!inv3_sym_d(Hll + 9 * (size_t)j, lambda, Hi)) {
+            *fail = 1;
+            ok = false;
+        } else {
+            if (g.lm_edges[g.lm_start[j]] == e) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Hinv[9 * (size_t)j + i] = Hi[i];
+            }
+            const double* W = Hpl + 18 * (size_t)e;
+            double y[18];
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) y[3 * a + c] = (W[3 * a] * Hi[c] + W[3 * a + 1] * Hi[3 + c]) + W[3 * a + 2] * Hi[6 + c];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) yv[i] = double2{y[2 * i], y[2 * i + 1]};
+        }
     }
-    if (g.lm_edges[g.lm_start[j]] == e) {
+    if (__ballot(ok) == ~0ull) {   // (wave-uniform) the usual case: 64 records, all computed
+        double2* const sh = s_y + (size_t)wv * (64 * 9);
 #pragma unroll
-        for (int i = 0; i < 9; ++i) Hinv[9 * (size_t)j + i] = Hi[i];
+        for (int i = 0; i < 9; ++i) sh[lane * 9 + i] = yv[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double2* const out = reinterpret_cast<double2*>(Y + 18 * (size_t)(e - lane));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) out[i * 64 + lane] = sh[i * 64 + lane];
+    } else if (ok) {   // (a record whose landmark block could not be inverted stays unwritten, as before: the trial is reported failed)
+        double2* const out = reinterpret_cast<double2*>(Y + 18 * (size_t)e);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) out[i] = yv[i];
     }
-    const double* W = Hpl + 18 * (size_t)e;
-    double* y = Y + 18 * (size_t)e;
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) y[3 * a + c] = (W[3 * a] * Hi[c] + W[3 * a + 1] * Hi[3 + c]) + W[3 * a + 2] * Hi[6 + c];
 }
 
 // edge_of[s * n_pt + j] = the edge of free keyframe s (slot order) to landmark j, or -1: what k_schur_pairs intersects two keyframes'
@@ -1262,9 +1289,15 @@ __global__ __launch_bounds__(256) void k_edge_gate(int n_edge, int n_mono, doubl
         if (active) active[e] = o ? 0 : 1;
         inlier = !o;
     }
-    if (n_active) {
+    if (n_active) {   // one atomic per workgroup (one per wave -- 1563 on one address at config 5 -- made this launch 20 us)
+        __shared__ int32_t s_cnt[4];
         const unsigned long long b = __ballot(inlier);
-        if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_active, (int32_t)__popcll(b));
+        if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (int32_t)__popcll(b);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int32_t c = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+            if (c) atomicAdd(n_active, c);
+        }
     }
 }
 
