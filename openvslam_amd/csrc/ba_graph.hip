@@ -993,6 +993,170 @@ __global__ __launch_bounds__(256) void k_schur(GraphDev g, int n_free, const int
                    s_queue, s_part);
 }
 
+// ---- round 6, late: the pairs' common landmarks found ONCE per graph ----------------------------------------------------------------
+// schur_pair's scan (every wave walks a quarter of keyframe a's observations and looks each landmark up in keyframe b's row of edge_of) does
+// not depend on the trial: 23 of k_schur's 61 us at config 5 went into repeating it fifteen times per call. k_pair_lists runs it twice when the
+// solver work space is created -- counting, then (behind an exclusive scan of the 4 n_pairs counts) writing the (edge of a, edge of b) entries of
+// every (pair, wave) in the order the queue would have met them --, and k_schur_l's lane l of wave w takes entries l, l + 64, ... of ITS list:
+// the entries the queue handed that lane, in that order, so S keeps its bits.
+template <bool kFill>
+__global__ __launch_bounds__(256) void k_pair_lists(const int32_t* __restrict__ pose_start, const int32_t* __restrict__ pose_edges,
+                                                   const int32_t* __restrict__ pose_pt, const int32_t* __restrict__ pair_ab,
+                                                   const int32_t* __restrict__ slot_pose, const int32_t* __restrict__ edge_of, int n_pt,
+                                                   int32_t* __restrict__ cnt, const int32_t* __restrict__ off, int2* __restrict__ ent) {
+    const int pr = (int)blockIdx.x, lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int sa = pair_ab[2 * pr], sb = pair_ab[2 * pr + 1];
+    const int ka = slot_pose[sa];
+    const int32_t* const tb = edge_of + (size_t)sb * n_pt;
+    const int i_lo = pose_start[ka], i_hi = pose_start[ka + 1];
+    const int quarter = ((i_hi - i_lo + 255) >> 8) << 6;   // (schur_pair's split)
+    const int i0 = i_lo + wave * quarter, i1 = min(i0 + quarter, i_hi);
+    int qn = 0;
+    const int at = kFill ? off[4 * pr + wave] : 0;
+    for (int base = i0; base < i1; base += 64) {
+        const int i = base + lane;
+        int ea = 0, eb = -1;
+        if (i < i1) {
+            ea = pose_edges[i];
+            eb = tb[pose_pt[i]];
+        }
+        const unsigned long long bal = __ballot(eb >= 0);
+        if (kFill && eb >= 0)
+            ent[at + qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = int2{ea, eb};
+        qn += __popcll(bal);
+    }
+    if (!kFill && lane == 0) cnt[4 * pr + wave] = qn;
+}
+
+// off[i] = cnt[0] + ... + cnt[i - 1], i = 0 .. n (one workgroup; n = 4 n_pairs is a few thousand)
+__global__ __launch_bounds__(1024) void k_scan_i32(const int32_t* __restrict__ cnt, int n, int32_t* __restrict__ off) {
+    __shared__ int32_t s_sum[1024];
+    const int tid = (int)threadIdx.x, per = (n + 1023) / 1024, lo = min(tid * per, n), hi = min(lo + per, n);
+    int32_t t = 0;
+    for (int i = lo; i < hi; ++i) t += cnt[i];
+    s_sum[tid] = t;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int32_t v = tid >= d ? s_sum[tid - d] : 0;
+        __syncthreads();
+        s_sum[tid] += v;
+        __syncthreads();
+    }
+    int32_t run = s_sum[tid] - t;
+    for (int i = lo; i < hi; ++i) {
+        off[i] = run;
+        run += cnt[i];
+    }
+    if (tid == 1023) off[n] = s_sum[1023];
+}
+
+// schur_pair on the lists
+template <bool kCoop>
+__device__ __forceinline__ void schur_pair_l(const int pr, const int32_t* __restrict__ pair_ab, const int32_t* __restrict__ slot_pose,
+                                             const int32_t* __restrict__ off, const int2* __restrict__ ent, const double* __restrict__ Hpp,
+                                             const double* __restrict__ Hpl, const double* __restrict__ Y, double lambda, int pitch,
+                                             double* __restrict__ S, double (*s_part)[36], double2* __restrict__ s_rec) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int sa = pair_ab[2 * pr], sb = pair_ab[2 * pr + 1];
+    const int ka = slot_pose[sa];
+    double acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+    const int s1 = off[4 * pr + wave + 1];
+    if (!kCoop) {
+        for (int idx = off[4 * pr + wave] + lane; idx < s1; idx += 64) {
+            const int2 en = ent[idx];
+            const double* y = Y + 18 * (size_t)en.x;
+            const double* W2 = Hpl + 18 * (size_t)en.y;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) acc[6 * a + b] += (y[3 * a] * W2[3 * b] + y[3 * a + 1] * W2[3 * b + 1]) + y[3 * a + 2] * W2[3 * b + 2];
+        }
+    } else {
+        // A lane reading its own two 144-byte records issues 18 loads that each touch 64 different lines: the address unit of the CU takes a line
+        // per clock, 2300 clocks per batch of 64 entries -- and a diagonal pair (a, a) has all of a's ~2000 edges, eight batches per wave on ONE
+        // CU: the launch waited for those 48 workgroups. Here the wave fetches the batch's 2 x 64 records as 2 x 576 16-byte pieces, consecutive
+        // lanes taking consecutive pieces of a record (seven records per instruction, ~14 lines), through LDS; every lane then reads its own
+        // records from there (stride 144 bytes: conflict-free for 16-byte reads). The products and their order are those of the loop above.
+        double2* const buf = s_rec + (size_t)wave * (64 * 9);
+        const double2* const Y2 = reinterpret_cast<const double2*>(Y);
+        const double2* const H2 = reinterpret_cast<const double2*>(Hpl);
+        for (int base = off[4 * pr + wave]; base < s1; base += 64) {
+            const int cnt = min(64, s1 - base);
+            int2 en = int2{0, 0};
+            if (lane < cnt) en = ent[base + lane];
+            double2 ly[9], lw[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int p = 64 * r + lane, rec = (p * 7282) >> 16, part = p - 9 * rec;   // rec = p / 9 for p < 576
+                const int ea = __shfl(en.x, rec), eb = __shfl(en.y, rec);
+                ly[r] = double2{0.0, 0.0};
+                lw[r] = double2{0.0, 0.0};
+                if (rec < cnt) {
+                    ly[r] = Y2[(size_t)ea * 9 + part];
+                    lw[r] = H2[(size_t)eb * 9 + part];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 9; ++r) buf[64 * r + lane] = ly[r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            double2 y2[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) y2[i] = buf[9 * lane + i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 9; ++r) buf[64 * r + lane] = lw[r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < cnt) {
+                const double y[18] = {y2[0].x, y2[0].y, y2[1].x, y2[1].y, y2[2].x, y2[2].y, y2[3].x, y2[3].y, y2[4].x, y2[4].y,
+                                      y2[5].x, y2[5].y, y2[6].x, y2[6].y, y2[7].x, y2[7].y, y2[8].x, y2[8].y};
+#pragma unroll
+                for (int bp = 0; bp < 3; ++bp) {   // rows 2 bp, 2 bp + 1 of W: doubles 6 bp .. 6 bp + 5
+                    const double2 w0 = buf[9 * lane + 3 * bp], w1 = buf[9 * lane + 3 * bp + 1], w2 = buf[9 * lane + 3 * bp + 2];
+                    const double w[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        acc[6 * a + 2 * bp] += (y[3 * a] * w[0] + y[3 * a + 1] * w[1]) + y[3 * a + 2] * w[2];
+                        acc[6 * a + 2 * bp + 1] += (y[3 * a] * w[3] + y[3 * a + 1] * w[4]) + y[3 * a + 2] * w[5];
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // (the next batch overwrites the buffer)
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+        const double x = wave_sum_lane63(acc[i]);
+        if (lane == 63) s_part[wave][i] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        const int t = threadIdx.x, a = t / 6, b = t - 6 * a;
+        double v = -(((s_part[0][t] + s_part[1][t]) + s_part[2][t]) + s_part[3][t]);
+        if (sa == sb) v = (Hpp[36 * (size_t)ka + 6 * a + b] + (a == b ? lambda : 0.0)) + v;
+        S[(size_t)(6 * sa + a) * pitch + 6 * sb + b] = v;
+        if (sa != sb) S[(size_t)(6 * sb + b) * pitch + 6 * sa + a] = v;
+    }
+}
+
+template <bool kCoop>
+__global__ __launch_bounds__(256) void k_schur_l(GraphDev g, int n_free, const int32_t* __restrict__ pair_ab, const int32_t* __restrict__ slot_pose,
+                                                const int32_t* __restrict__ off, const int2* __restrict__ ent, const double* __restrict__ Hpp,
+                                                const double* __restrict__ bp, const double* __restrict__ bl, const double* __restrict__ Hpl,
+                                                const double* __restrict__ Y, double lambda, int pitch, double* __restrict__ S,
+                                                double* __restrict__ rhs) {
+    __shared__ double s_part[4][36];
+    __shared__ double s_part6[4][6];
+    __shared__ double2 s_rec[kCoop ? 4 * 64 * 9 : 1];   // a batch's 64 records per wave
+    if ((int)blockIdx.x < n_free) schur_rhs(g, (int)blockIdx.x, slot_pose, bp, bl, Y, rhs, s_part6);   // (workgroup-uniform)
+    else schur_pair_l<kCoop>((int)blockIdx.x - n_free, pair_ab, slot_pose, off, ent, Hpp, Hpl, Y, lambda, pitch, S, s_part, s_rec);
+}
+
 // dxl_j = Hll^-1 (bl_j - sum_e W_e^T dxp[pose(e)]); X_trial = X + dxl; lm_scale[j] = dxl . (lambda dxl + bl_j)
 // `dx`: the keyframes' increments, six per reduced block when `slot_of_pose` is given (the device solver's solution vector, read in place),
 // else six per keyframe (the host solver's upload)
@@ -1330,6 +1494,11 @@ struct ovs_ba_graph {
     GEdge* d_ledges = nullptr;
     int n_lm_wg = 0, n_chunks = 0;
     int32_t* d_edge_of = nullptr;   // [n_free x n_pt], solver arena
+    // the pairs' common landmarks (k_pair_lists): [4 n_pairs + 1] offsets, one (edge of a, edge of b) per entry; pl_bound = sum over the landmarks of
+    // n (n + 1) / 2, n = the landmark's edges (graph_create): no list can be longer
+    int32_t *d_pl_cnt = nullptr, *d_pl_off = nullptr;
+    int2* d_pl_ent = nullptr;
+    size_t pl_bound = 0;
     int n_pairs = 0;
     double* d_lm_tmp = nullptr;   // [4 n_pt] per-landmark partials: chi2 pair, max |diagonal|, the gain ratio's scale term
     // solver work space (allocated on first use: ovs_ba_graph_linearize_dev alone does not need it)
@@ -1680,7 +1849,10 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     {
         int32_t* const wg_first = reinterpret_cast<int32_t*>(img + o_lm_wg_first);
         int n_wg = 0, first = 0;
+        size_t pl_bound = 0;
         for (int j = 0; j < n_pt; ++j) {
+            const size_t nj = (size_t)(lm_start[(size_t)j + 1] - lm_start[j]);
+            pl_bound += nj * (nj + 1) / 2;
             if (j > first && (lm_start[(size_t)j + 1] - lm_start[first] > kLmSlots || j - first >= 256)) {   // j does not fit: it opens the next run
                 wg_first[n_wg++] = first;
                 first = j;
@@ -1689,6 +1861,7 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
         wg_first[n_wg++] = first;
         wg_first[n_wg] = n_pt;
         g->n_lm_wg = n_wg;
+        g->pl_bound = pl_bound;
         // k_lin_pose: chunks of kPoseChunk entries of a keyframe's edge list
         int32_t* const chunk_kf = reinterpret_cast<int32_t*>(img + o_chunk_kf);
         int32_t* const chunk_start = reinterpret_cast<int32_t*>(img + o_chunk_start);
@@ -1825,7 +1998,9 @@ static ovs_status solver_workspace_create(ovs_ba_graph* g, hipStream_t s) {
     const size_t b_hinv = al(sizeof(double) * 9 * (size_t)g->n_pt), b_y = al(sizeof(double) * 18 * ne),
                  b_s = al(sizeof(double) * (sys + 6 * (size_t)g->n_pose)), b_dxp = al(sizeof(double) * 6 * (size_t)g->n_pose),
                  b_tab = al(sizeof(int32_t) * (size_t)std::max(g->n_free, 1) * (size_t)g->n_pt);
-    g->d_solver_arena = g_ba_pool.take(g->device, b_hinv + b_y + b_s + b_dxp + 512 + b_tab, &g->solver_cap);
+    const size_t n_lists = (size_t)4 * (size_t)std::max(g->n_pairs, 0);
+    const size_t b_plc = al(sizeof(int32_t) * (n_lists + 1)), b_ple = al(sizeof(int2) * std::max<size_t>(g->pl_bound, 1));
+    g->d_solver_arena = g_ba_pool.take(g->device, b_hinv + b_y + b_s + b_dxp + 512 + b_tab + 2 * b_plc + b_ple, &g->solver_cap);
     OVS_HIP_TRY(g->d_solver_arena ? hipSuccess : hipErrorOutOfMemory);
     unsigned char* A = g->d_solver_arena;
     g->d_Hinv = reinterpret_cast<double*>(A);
@@ -1840,6 +2015,19 @@ static ovs_status solver_workspace_create(ovs_ba_graph* g, hipStream_t s) {
     if (g->n_edge() > 0 && g->n_free > 0) {
         hipLaunchKernelGGL(k_edge_table, dim3((g->n_edge() + 255) / 256), dim3(256), 0, s, g->d_edges, g->n_edge(), g->d_slot_of_pose, g->n_pt, g->d_edge_of);
         OVS_LAUNCH_TRY("k_edge_table");
+    }
+    g->d_pl_cnt = reinterpret_cast<int32_t*>(A + b_hinv + b_y + b_s + b_dxp + 512 + b_tab);
+    g->d_pl_off = reinterpret_cast<int32_t*>(A + b_hinv + b_y + b_s + b_dxp + 512 + b_tab + b_plc);
+    g->d_pl_ent = reinterpret_cast<int2*>(A + b_hinv + b_y + b_s + b_dxp + 512 + b_tab + 2 * b_plc);
+    if (g->n_edge() > 0 && g->n_free > 0 && g->n_pairs > 0) {   // behind k_edge_table on the same stream
+        hipLaunchKernelGGL(k_pair_lists<false>, dim3(g->n_pairs), dim3(256), 0, s, g->d_pose_start, g->d_pose_edges, g->d_pose_pt, g->d_pair_ab, g->d_slot_pose,
+                           g->d_edge_of, g->n_pt, g->d_pl_cnt, (const int32_t*)nullptr, (int2*)nullptr);
+        OVS_LAUNCH_TRY("k_pair_lists<count>");
+        hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, s, g->d_pl_cnt, (int)n_lists, g->d_pl_off);
+        OVS_LAUNCH_TRY("k_scan_i32");
+        hipLaunchKernelGGL(k_pair_lists<true>, dim3(g->n_pairs), dim3(256), 0, s, g->d_pose_start, g->d_pose_edges, g->d_pose_pt, g->d_pair_ab, g->d_slot_pose,
+                           g->d_edge_of, g->n_pt, (int32_t*)nullptr, g->d_pl_off, g->d_pl_ent);
+        OVS_LAUNCH_TRY("k_pair_lists<fill>");
     }
     g->s_pitch = n_pad;
     g->d_rhs = g->d_S + (size_t)n_pad * n_pad;
@@ -1872,8 +2060,23 @@ ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_
                        g->d_fail + fail_word);
     OVS_LAUNCH_TRY("k_lm_prepare");
     if (g->n_free > 0) {
-        hipLaunchKernelGGL(k_schur, dim3(g->n_free + g->n_pairs), dim3(256), 0, s, v, g->n_free, g->d_pose_pt, g->d_pair_ab, g->d_slot_pose,
-                           g->d_edge_of, d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs);
+        static const bool lists = [] {   // OVS_BA_SCHUR_LISTS=0: every trial's launch scans for the pairs' common landmarks itself (rounds 4-6)
+            const char* e = std::getenv("OVS_BA_SCHUR_LISTS");
+            return !(e && e[0] == '0');
+        }();
+        static const bool coop = [] {   // OVS_BA_SCHUR_COOP=0: every lane gathers its own two records
+            const char* e = std::getenv("OVS_BA_SCHUR_COOP");
+            return !(e && e[0] == '0');
+        }();
+        if (lists && g->n_edge() > 0 && coop)
+            hipLaunchKernelGGL(k_schur_l<true>, dim3(g->n_free + g->n_pairs), dim3(256), 0, s, v, g->n_free, g->d_pair_ab, g->d_slot_pose, g->d_pl_off, g->d_pl_ent,
+                               d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs);
+        else if (lists && g->n_edge() > 0)
+            hipLaunchKernelGGL(k_schur_l<false>, dim3(g->n_free + g->n_pairs), dim3(256), 0, s, v, g->n_free, g->d_pair_ab, g->d_slot_pose, g->d_pl_off, g->d_pl_ent,
+                               d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs);
+        else
+            hipLaunchKernelGGL(k_schur, dim3(g->n_free + g->n_pairs), dim3(256), 0, s, v, g->n_free, g->d_pose_pt, g->d_pair_ab, g->d_slot_pose,
+                               g->d_edge_of, d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs);
         OVS_LAUNCH_TRY("k_schur");
     }
     return OVS_OK;

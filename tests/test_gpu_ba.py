@@ -483,7 +483,9 @@ np.savez(sys.argv[1], **res)
                 ("backsub_lm", {"OVS_BA_BACKSUB_EDGES": "0"}), ("host_gates", {"OVS_BA_DEV_OUTLIERS": "0"}),
                 # the linearisation as two launches (k_lin_pose with two entries per thread, k_lin_landmark) instead of k_linearize2: another
                 # summation tree for Hpp / bp (last bits), the same bits for everything per edge and per landmark
-                ("lin_two_launches", {"OVS_BA_LIN_MERGED": "0"}))
+                ("lin_two_launches", {"OVS_BA_LIN_MERGED": "0"}),
+                # the pairs' common landmarks found by every trial's k_schur itself (rounds 4-6) instead of once per graph (k_pair_lists)
+                ("schur_scan", {"OVS_BA_SCHUR_LISTS": "0"}))
     for tag, env in variants:
         out = tmp_path / ("%s.npz" % tag)
         r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests")), str(out)], env=dict(os.environ, **env),
@@ -538,7 +540,8 @@ r = ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], edges, d["cam
 np.savez(sys.argv[1], edges=edges, **{"opt_" + k: np.asarray(v) for k, v in r.items()})
 """
     outs = {}
-    variants = (("auto", {}), ("backsub_lm", {"OVS_BA_BACKSUB_EDGES": "0"}), ("host_gates", {"OVS_BA_DEV_OUTLIERS": "0"}))
+    variants = (("auto", {}), ("backsub_lm", {"OVS_BA_BACKSUB_EDGES": "0"}), ("host_gates", {"OVS_BA_DEV_OUTLIERS": "0"}),
+                ("schur_scan", {"OVS_BA_SCHUR_LISTS": "0"}))
     for tag, env in variants:
         out = tmp_path / ("%s.npz" % tag)
         r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests")), str(out)], env=dict(os.environ, **env),
