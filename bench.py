@@ -684,7 +684,7 @@ def bench_local_ba(world, rank, dist, torch, iters=20, n_pose=50, n_pt=20000, ob
     n_edges = len(d["edges"])
     alg_bytes = n_edges * 32 + n_pose * 56 + n_pt * 24 + n_edges * 144 + n_pt * 96 + n_pose * 336   # ~20.0 MB / iteration at config 5
     # HBM-side traffic of one linearisation from the committed rocprofv3 --pmc passes (tools/gpu_lba_pmc.sh: FETCH_SIZE and WRITE_SIZE in their own
-    # passes, (2 * FETCH + WRITE) KiB summed over k_lin_pose, k_lin_landmark, k_reduce_scalars); null when the file is missing
+    # passes, (2 * FETCH + WRITE) KiB summed over k_linearize2 and k_reduce_scalars); null when the file is missing
     size_key = "config5" if (n_pose, n_pt, obs_per_pose) == (50, 20000, 2000) else ("large" if (n_pose, n_pt, obs_per_pose) == (200, 100000, 5000) else None)
     traffic = None
     try:
@@ -693,17 +693,19 @@ def bench_local_ba(world, rank, dist, torch, iters=20, n_pose=50, n_pt=20000, ob
     except (OSError, KeyError, ValueError):
         traffic = None
     gbps = alg_bytes * iters / dt / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_lin_pose + k_lin_landmark + k_reduce_scalars (one linearisation)", "achieved": round(gbps, 2), "peak": 8000.0,
+    roofline = {"bound": "hbm", "kernel": "k_linearize2 + k_reduce_scalars (one linearisation)", "achieved": round(gbps, 2), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(gbps / 8000.0, 4), "algorithmic_bytes_per_linearisation": alg_bytes, "traffic": traffic,
                 "traffic_source": "profiles/pmc_lba.json (tools/gpu_lba_pmc.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH + WRITE)" if traffic else None,
-                "what_bounds_it": "neither bandwidth nor fp64 issue: k_lin_pose keeps 27 running sums beside both Jacobians (218 VGPRs, two waves per SIMD) "
-                                  "and waits on its gathers 54 % of its wave cycles (profiles/r06_lba_pmc_summary.txt)"}
+                "what_bounds_it": "its traffic at the rate partial-line requests allow: 1.5x the algorithmic bytes (the edge records are read by both "
+                                  "halves), gathered 24-byte landmarks and 40-byte records; the 144-byte Hpl records leave as whole lines since round 6 "
+                                  "(through LDS: 0.124 -> 0.100 ms per million edges); six waves per SIMD instead of two changed nothing "
+                                  "(profiles/r06an_lba_pmc_summary.txt, DESIGN.md 3.6)"}
     return {"workload": "%s%d keyframes x %d observations, %d landmarks, fp64, Huber sqrt(5.991)"
                         % ("BASELINE configs[4]: " if (n_pose, n_pt, obs_per_pose) == (50, 20000, 2000) else "", n_pose, obs_per_pose, n_pt),
             "ms_per_linearisation": round(dt / iters * 1e3, 4), "edges_per_sec": round(n_edges * iters / dt, 1),
             "algorithmic_GBps": round(alg_bytes * iters / dt / 1e9, 2), "allreduce_bytes": (n_pt * 12 + 2) * 8 if world > 1 else 0,
             "roofline": roofline,
-            "chi2": float(out["chi2"][0].item()), "kernels": "ovs_ba_graph: k_lin_pose (one lane per edge in keyframe order: the 27 pose-block terms as a fixed-shape sum per 512 edges, Hpl written in edge order) + k_lin_landmark (one lane per edge in landmark order, a landmark's terms added in its edges' order; finishes the keyframes' blocks) + k_reduce_scalars (no atomics, bit-reproducible)",
+            "chi2": float(out["chi2"][0].item()), "kernels": "ovs_ba_graph: k_linearize2 (ONE launch: keyframe-side workgroups -- one lane per edge in keyframe order, the 27 pose-block terms as a fixed-shape sum per 256 edges, the 144-byte Hpl records written as whole lines through LDS -- interleaved with landmark-side workgroups -- one lane per edge in landmark order, a landmark's terms added in its edges' order) + k_reduce_scalars (finishes the keyframes' blocks and the scalars; no atomics, bit-reproducible)",
             "exchange": "ONE packed all-reduce of Hll|bl|chi2 per linearisation" if world > 1 else "none (1 rank)",
             # DESIGN.md section 5, written down before any multi-GPU node ran this: what ms_per_linearisation is expected to be at this N
             "expected_ms_per_linearisation": _expected_lba_ms(world, n_pt, dt / iters * 1e3 if world == 1 else None),

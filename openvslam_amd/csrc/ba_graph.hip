@@ -675,16 +675,17 @@ __global__ __launch_bounds__(256) void k_linearize2(GraphDev g, const double* __
                                 reinterpret_cast<double (*)[256]>(s_raw + 14 * (kLmSlots + 1)));
 }
 
-// term t of keyframe k: its half chunks' sums (k_linearize2) added in ascending order, eight loads in flight
+// term t of keyframe k: its half chunks' sums (k_linearize2) added in ascending order, up to 24 loads in flight (a keyframe of 5000 observations
+// has 20 half chunks: with eight in flight the launch took 15.7 us at 200 keyframes x 5000 observations, three dependent round trips per sum)
 __device__ __forceinline__ double pose_term_sum(const GraphDev& g, const int k, const int t) {
     double v = 0.0;
     const int c1 = 2 * g.chunk_start[k + 1];
-    for (int c = 2 * g.chunk_start[k]; c < c1; c += 8) {
-        double p[8];
+    for (int c = 2 * g.chunk_start[k]; c < c1; c += 24) {
+        double p[24];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = c + u < c1 ? g.pose_part[27 * (size_t)(c + u) + t] : 0.0;
+        for (int u = 0; u < 24; ++u) p[u] = c + u < c1 ? g.pose_part[27 * (size_t)(c + u) + t] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 24; ++u)
             if (c + u < c1) v += p[u];
     }
     return v;
@@ -1082,10 +1083,13 @@ __device__ __forceinline__ void schur_pair_l(const int pr, const int32_t* __rest
         double2* const buf = s_rec + (size_t)wave * (64 * 9);
         const double2* const Y2 = reinterpret_cast<const double2*>(Y);
         const double2* const H2 = reinterpret_cast<const double2*>(Hpl);
-        for (int base = off[4 * pr + wave]; base < s1; base += 64) {
+        const int s0 = off[4 * pr + wave];
+        int2 en_next = int2{0, 0};
+        if (s0 + lane < s1) en_next = ent[s0 + lane];
+        for (int base = s0; base < s1; base += 64) {
             const int cnt = min(64, s1 - base);
-            int2 en = int2{0, 0};
-            if (lane < cnt) en = ent[base + lane];
+            const int2 en = en_next;
+            if (base + 64 + lane < s1) en_next = ent[base + 64 + lane];   // (the next batch's entries travel under this batch's records: a round trip less per batch)
             double2 ly[9], lw[9];
 #pragma unroll
             for (int r = 0; r < 9; ++r) {
@@ -1149,12 +1153,20 @@ __global__ __launch_bounds__(256) void k_schur_l(GraphDev g, int n_free, const i
                                                 const int32_t* __restrict__ off, const int2* __restrict__ ent, const double* __restrict__ Hpp,
                                                 const double* __restrict__ bp, const double* __restrict__ bl, const double* __restrict__ Hpl,
                                                 const double* __restrict__ Y, double lambda, int pitch, double* __restrict__ S,
-                                                double* __restrict__ rhs) {
+                                                double* __restrict__ rhs, int xcd_order, int n_pairs) {
     __shared__ double s_part[4][36];
     __shared__ double s_part6[4][6];
     __shared__ double2 s_rec[kCoop ? 4 * 64 * 9 : 1];   // a batch's 64 records per wave
-    if ((int)blockIdx.x < n_free) schur_rhs(g, (int)blockIdx.x, slot_pose, bp, bl, Y, rhs, s_part6);   // (workgroup-uniform)
-    else schur_pair_l<kCoop>((int)blockIdx.x - n_free, pair_ab, slot_pose, off, ent, Hpp, Hpl, Y, lambda, pitch, S, s_part, s_rec);
+    // grid: 8 ceil(n_pairs / 8) pair workgroups, then n_free right-hand-side workgroups. xcd_order (an experiment, off): consecutive workgroups go
+    // to different XCDs (eight L2 caches); XCD x then takes the x-th contiguous eighth of the pairs, i.e. (almost) whole rows a of the pair
+    // table, so that a's Y records are fetched into ONE L2 instead of eight -- slower (see the launch), the work per row is too unequal.
+    const int per = (n_pairs + 7) >> 3, q = (int)blockIdx.x;
+    if (q >= 8 * per) {   // (workgroup-uniform)
+        schur_rhs(g, q - 8 * per, slot_pose, bp, bl, Y, rhs, s_part6);
+    } else {
+        const int pr = xcd_order ? (q & 7) * per + (q >> 3) : q;
+        if (pr < n_pairs) schur_pair_l<kCoop>(pr, pair_ab, slot_pose, off, ent, Hpp, Hpl, Y, lambda, pitch, S, s_part, s_rec);
+    }
 }
 
 // dxl_j = Hll^-1 (bl_j - sum_e W_e^T dxp[pose(e)]); X_trial = X + dxl; lm_scale[j] = dxl . (lambda dxl + bl_j)
@@ -1880,6 +1892,8 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     // reduced system: the blocks (a, b), a <= b in slot order, one workgroup each (which landmarks two keyframes share is found on the device)
     if (nf > 0) {
         int32_t* const pab = reinterpret_cast<int32_t*>(img + o_pair_ab);
+        // a-major: a row (a, a .. nf - 1) stays together (k_schur_l hands contiguous runs of pairs to one XCD) and starts with its longest list,
+        // the diagonal pair's (all of a's landmarks). "All diagonal pairs first" was measured: no change.
         int p = 0;
         for (int a = 0; a < nf; ++a)
             for (int b = a; b < nf; ++b) {
@@ -2068,12 +2082,16 @@ ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_
             const char* e = std::getenv("OVS_BA_SCHUR_COOP");
             return !(e && e[0] == '0');
         }();
+        static const int xcd = [] {   // OVS_BA_SCHUR_XCD=1: contiguous runs of pairs per XCD (measured: 47.6 against 40.5 us -- the rows of the pair table are unequal work, and one XCD gets the longest)
+            const char* e = std::getenv("OVS_BA_SCHUR_XCD");
+            return e && e[0] == '1' ? 1 : 0;
+        }();
         if (lists && g->n_edge() > 0 && coop)
-            hipLaunchKernelGGL(k_schur_l<true>, dim3(g->n_free + g->n_pairs), dim3(256), 0, s, v, g->n_free, g->d_pair_ab, g->d_slot_pose, g->d_pl_off, g->d_pl_ent,
-                               d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs);
+            hipLaunchKernelGGL(k_schur_l<true>, dim3(g->n_free + 8 * ((g->n_pairs + 7) / 8)), dim3(256), 0, s, v, g->n_free, g->d_pair_ab, g->d_slot_pose, g->d_pl_off, g->d_pl_ent,
+                               d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs, xcd, g->n_pairs);
         else if (lists && g->n_edge() > 0)
-            hipLaunchKernelGGL(k_schur_l<false>, dim3(g->n_free + g->n_pairs), dim3(256), 0, s, v, g->n_free, g->d_pair_ab, g->d_slot_pose, g->d_pl_off, g->d_pl_ent,
-                               d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs);
+            hipLaunchKernelGGL(k_schur_l<false>, dim3(g->n_free + 8 * ((g->n_pairs + 7) / 8)), dim3(256), 0, s, v, g->n_free, g->d_pair_ab, g->d_slot_pose, g->d_pl_off, g->d_pl_ent,
+                               d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs, xcd, g->n_pairs);
         else
             hipLaunchKernelGGL(k_schur, dim3(g->n_free + g->n_pairs), dim3(256), 0, s, v, g->n_free, g->d_pose_pt, g->d_pair_ab, g->d_slot_pose,
                                g->d_edge_of, d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs);

@@ -41,7 +41,7 @@ for w in ("lin", "opt"):
             continue
         d = sorted(dur[k])
         print("%-28s calls %5d  avg %8.1f us  median %8.1f  max %8.1f" % (k[:28], len(d), sum(d) / len(d), d[len(d) // 2], d[-1]))
-        if w == "lin" and k.startswith("k_lin_"):
+        if w == "lin" and k.startswith("k_lin"):
             # the two problem sizes separately: the large problem's launches are the slow ones
             big = [x for x in d if x > 3 * d[0]]
             small = [x for x in d if x <= 3 * d[0]]
@@ -60,7 +60,7 @@ for w in ("lin", "opt"):
             tot = 0.0
             det = {}
             for k in acc:
-                if not k.startswith(("k_lin_", "k_reduce_scalars")):
+                if not k.startswith(("k_lin", "k_reduce_scalars")):
                     continue
                 f = sorted(acc[k].get("FETCH_SIZE", [0.0]))
                 wv = sorted(acc[k].get("WRITE_SIZE", [0.0]))
