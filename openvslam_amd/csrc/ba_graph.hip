@@ -1149,23 +1149,24 @@ __device__ __forceinline__ void schur_pair_l(const int pr, const int32_t* __rest
 }
 
 template <bool kCoop>
-__global__ __launch_bounds__(256) void k_schur_l(GraphDev g, int n_free, const int32_t* __restrict__ pair_ab, const int32_t* __restrict__ slot_pose,
+__global__ __launch_bounds__(256) void k_schur_l(GraphDev g, int n_free,   // (three waves per SIMD forced: 172 bytes of scratch) const int32_t* __restrict__ pair_ab, const int32_t* __restrict__ slot_pose,
                                                 const int32_t* __restrict__ off, const int2* __restrict__ ent, const double* __restrict__ Hpp,
                                                 const double* __restrict__ bp, const double* __restrict__ bl, const double* __restrict__ Hpl,
                                                 const double* __restrict__ Y, double lambda, int pitch, double* __restrict__ S,
-                                                double* __restrict__ rhs, int xcd_order, int n_pairs) {
+                                                double* __restrict__ rhs, const int32_t* __restrict__ wg_pair, int n_pair_wg) {
     __shared__ double s_part[4][36];
     __shared__ double s_part6[4][6];
     __shared__ double2 s_rec[kCoop ? 4 * 64 * 9 : 1];   // a batch's 64 records per wave
-    // grid: 8 ceil(n_pairs / 8) pair workgroups, then n_free right-hand-side workgroups. xcd_order (an experiment, off): consecutive workgroups go
-    // to different XCDs (eight L2 caches); XCD x then takes the x-th contiguous eighth of the pairs, i.e. (almost) whole rows a of the pair
-    // table, so that a's Y records are fetched into ONE L2 instead of eight -- slower (see the launch), the work per row is too unequal.
-    const int per = (n_pairs + 7) >> 3, q = (int)blockIdx.x;
-    if (q >= 8 * per) {   // (workgroup-uniform)
-        schur_rhs(g, q - 8 * per, slot_pose, bp, bl, Y, rhs, s_part6);
+    // grid: n_pair_wg pair workgroups, then n_free right-hand-side workgroups. wg_pair (graph_create) names the pair of every workgroup, -1 = none:
+    // consecutive workgroups go to different XCDs (eight L2 caches), and the table gives every XCD whole ROWS a of the pair table, dealt so that
+    // the eight get equal work -- the workgroups running side by side on an XCD then gather the same keyframe's Y records (and W records that
+    // recur row after row) from ITS L2: in launch order k_schur_l fetched 94-190 MB per launch for 29 MB of distinct records.
+    const int q = (int)blockIdx.x;
+    if (q >= n_pair_wg) {   // (workgroup-uniform)
+        schur_rhs(g, q - n_pair_wg, slot_pose, bp, bl, Y, rhs, s_part6);
     } else {
-        const int pr = xcd_order ? (q & 7) * per + (q >> 3) : q;
-        if (pr < n_pairs) schur_pair_l<kCoop>(pr, pair_ab, slot_pose, off, ent, Hpp, Hpl, Y, lambda, pitch, S, s_part, s_rec);
+        const int pr = wg_pair ? wg_pair[q] : q;
+        if (pr >= 0) schur_pair_l<kCoop>(pr, pair_ab, slot_pose, off, ent, Hpp, Hpl, Y, lambda, pitch, S, s_part, s_rec);
     }
 }
 
@@ -1512,6 +1513,8 @@ struct ovs_ba_graph {
     int2* d_pl_ent = nullptr;
     size_t pl_bound = 0;
     int n_pairs = 0;
+    int32_t* d_wg_pair = nullptr;   // [n_pair_wg] k_schur_l's work order: whole rows of the pair table per XCD, -1 = no pair
+    int n_pair_wg = 0;
     double* d_lm_tmp = nullptr;   // [4 n_pt] per-landmark partials: chi2 pair, max |diagonal|, the gain ratio's scale term
     // solver work space (allocated on first use: ovs_ba_graph_linearize_dev alone does not need it)
     double *d_Hinv = nullptr, *d_Y = nullptr, *d_S = nullptr, *d_rhs = nullptr, *d_dxp = nullptr, *d_scal = nullptr;
@@ -1753,7 +1756,7 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
                  o_pose_start = place(sizeof(int32_t) * ((size_t)n_pose + 1)), o_pose_edges = place(sizeof(int32_t) * (size_t)ne),
                  o_fixed = place((size_t)n_pose), o_active = place((size_t)ne), o_slot_of_pose = place(sizeof(int32_t) * (size_t)n_pose),
                  o_pose_pt = place(sizeof(int32_t) * (size_t)ne), o_pair_ab = place(sizeof(int32_t) * 2 * (size_t)n_pairs),
-                 o_slot_pose = place(sizeof(int32_t) * (size_t)nf);
+                 o_slot_pose = place(sizeof(int32_t) * (size_t)nf), o_wg_pair = place(sizeof(int32_t) * 8 * ((size_t)n_pairs / 8 + (size_t)nf + 1));
     // k_linearize's work partition (sizes are upper bounds: the tables are built below, from the counting sorts)
     const size_t max_chunks = (size_t)ne / kPoseChunk + (size_t)n_pose;
     const size_t o_lm_wg_first = place(sizeof(int32_t) * ((size_t)n_pt + 1)),
@@ -1902,6 +1905,21 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
                 ++p;
             }
         g->n_pairs = n_pairs;
+        // k_schur_l's work order. Rows are dealt to the eight XCDs in serpentine order (rows 0 .. 7 to XCDs 0 .. 7, rows 8 .. 15 to XCDs 7 .. 0,
+        // ...: row a has nf - a pairs, so the eight sums come out within a row's length of each other); XCD x's i-th pair is workgroup 8 i + x.
+        {
+            int32_t* const wp = reinterpret_cast<int32_t*>(img + o_wg_pair);
+            int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int cap = n_pairs / 8 + nf + 1;
+            for (int i = 0; i < 8 * cap; ++i) wp[i] = -1;
+            int first = 0;   // index of pair (a, a)
+            for (int a = 0; a < nf; ++a) {
+                const int x = ((a >> 3) & 1) ? 7 - (a & 7) : (a & 7);
+                for (int b = a; b < nf; ++b) wp[(size_t)8 * fill[x]++ + x] = first + (b - a);
+                first += nf - a;
+            }
+            g->n_pair_wg = 8 * *std::max_element(fill, fill + 8);
+        }
         std::memcpy(img + o_slot_pose, g->slot_pose.data(), sizeof(int32_t) * (size_t)nf);
     }
     const double t2 = now();
@@ -1949,6 +1967,7 @@ static ovs_status graph_create(int model, int32_t device, int32_t n_pose, const 
     g->d_pose_pt = reinterpret_cast<int32_t*>(A + o_pose_pt);
     if (g->n_free > 0) {
         g->d_pair_ab = reinterpret_cast<int32_t*>(A + o_pair_ab);
+        g->d_wg_pair = reinterpret_cast<int32_t*>(A + o_wg_pair);
         g->d_slot_pose = reinterpret_cast<int32_t*>(A + o_slot_pose);
     }
 #undef G_TRY
@@ -2082,16 +2101,18 @@ ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_
             const char* e = std::getenv("OVS_BA_SCHUR_COOP");
             return !(e && e[0] == '0');
         }();
-        static const int xcd = [] {   // OVS_BA_SCHUR_XCD=1: contiguous runs of pairs per XCD (measured: 47.6 against 40.5 us -- the rows of the pair table are unequal work, and one XCD gets the longest)
+        static const bool xcd = [] {   // OVS_BA_SCHUR_XCD=0: pairs in launch order (a-major), whatever XCD a workgroup lands on
             const char* e = std::getenv("OVS_BA_SCHUR_XCD");
-            return e && e[0] == '1' ? 1 : 0;
+            return !(e && e[0] == '0');
         }();
+        const int32_t* const wgp = xcd ? g->d_wg_pair : nullptr;
+        const int n_pwg = xcd ? g->n_pair_wg : g->n_pairs;
         if (lists && g->n_edge() > 0 && coop)
-            hipLaunchKernelGGL(k_schur_l<true>, dim3(g->n_free + 8 * ((g->n_pairs + 7) / 8)), dim3(256), 0, s, v, g->n_free, g->d_pair_ab, g->d_slot_pose, g->d_pl_off, g->d_pl_ent,
-                               d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs, xcd, g->n_pairs);
+            hipLaunchKernelGGL(k_schur_l<true>, dim3(g->n_free + n_pwg), dim3(256), 0, s, v, g->n_free, g->d_pair_ab, g->d_slot_pose, g->d_pl_off, g->d_pl_ent,
+                               d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs, wgp, n_pwg);
         else if (lists && g->n_edge() > 0)
-            hipLaunchKernelGGL(k_schur_l<false>, dim3(g->n_free + 8 * ((g->n_pairs + 7) / 8)), dim3(256), 0, s, v, g->n_free, g->d_pair_ab, g->d_slot_pose, g->d_pl_off, g->d_pl_ent,
-                               d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs, xcd, g->n_pairs);
+            hipLaunchKernelGGL(k_schur_l<false>, dim3(g->n_free + n_pwg), dim3(256), 0, s, v, g->n_free, g->d_pair_ab, g->d_slot_pose, g->d_pl_off, g->d_pl_ent,
+                               d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs, wgp, n_pwg);
         else
             hipLaunchKernelGGL(k_schur, dim3(g->n_free + g->n_pairs), dim3(256), 0, s, v, g->n_free, g->d_pose_pt, g->d_pair_ab, g->d_slot_pose,
                                g->d_edge_of, d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs);
