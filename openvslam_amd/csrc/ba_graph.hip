@@ -1148,8 +1148,9 @@ __device__ __forceinline__ void schur_pair_l(const int pr, const int32_t* __rest
     }
 }
 
+// (212 VGPRs, two waves per SIMD; three forced by amdgpu_waves_per_eu: 172 bytes of scratch)
 template <bool kCoop>
-__global__ __launch_bounds__(256) void k_schur_l(GraphDev g, int n_free,   // (three waves per SIMD forced: 172 bytes of scratch) const int32_t* __restrict__ pair_ab, const int32_t* __restrict__ slot_pose,
+__global__ __launch_bounds__(256) void k_schur_l(GraphDev g, int n_free, const int32_t* __restrict__ pair_ab, const int32_t* __restrict__ slot_pose,
                                                 const int32_t* __restrict__ off, const int2* __restrict__ ent, const double* __restrict__ Hpp,
                                                 const double* __restrict__ bp, const double* __restrict__ bl, const double* __restrict__ Hpl,
                                                 const double* __restrict__ Y, double lambda, int pitch, double* __restrict__ S,
