@@ -691,6 +691,29 @@ __device__ __forceinline__ double pose_term_sum(const GraphDev& g, const int k, 
     return v;
 }
 
+// What the ten-level LDS tree (s[t] += s[t + w], w = 512 .. 1, a barrier per level) leaves in s[0], with ONE barrier: lane t of wave 0 folds
+// s[t + 64 j], j = 0 .. 15, in the tree's own pairing (levels 512 .. 64 pair j with j + 8, 4, 2, 1), the last six levels are lane shifts
+// (lane t < w adds lane t + w): the same additions on the same operands, the same bits; twenty barriers of sixteen waves less per launch.
+// All 1024 threads call it; the result is thread 0's. The caller puts a barrier before it reuses s.
+__device__ __forceinline__ double tree_sum_1024(double* __restrict__ s, const double v) {
+    s[threadIdx.x] = v;
+    __syncthreads();
+    double x = 0.0;
+    if (threadIdx.x < 64) {
+        double u[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) u[j] = s[threadIdx.x + 64 * j];
+#pragma unroll
+        for (int h = 8; h >= 1; h >>= 1)
+#pragma unroll
+            for (int j = 0; j < h; ++j) u[j] = u[j] + u[j + h];
+        x = u[0];
+#pragma unroll
+        for (int w = 32; w >= 1; w >>= 1) x = x + __shfl_down(x, w);
+    }
+    return x;
+}
+
 // chi2[0..1] = sum of the per-landmark partials; chi2[2] = max |diagonal| over free pose blocks and landmarks with edges (g2o's
 // computeLambdaInit); one workgroup, fixed order. With `lm_scale` (a Levenberg-Marquardt trial: the landmarks' terms of the gain ratio's
 // denominator, written by the back-substitution) their sum goes to scale_sum[0] -- the additions of the former k_sum_1024, in its order.
@@ -737,14 +760,9 @@ __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const doubl
             for (int u = 0; u < 4; ++u)
                 if (j0 + 1024 * u < g.n_pt) a += c[u];
         }
-        s0[threadIdx.x] = a;
-        __syncthreads();
-        for (int w = 512; w > 0; w >>= 1) {
-            if ((int)threadIdx.x < w) s0[threadIdx.x] += s0[threadIdx.x + w];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) scale_sum[0] = s0[0];
-        __syncthreads();
+        const double tot = tree_sum_1024(s0, a);
+        if (threadIdx.x == 0) scale_sum[0] = tot;
+        __syncthreads();   // (s0 is reused below)
     }
     double a = 0, b = 0, m = 0;
     // the landmark workgroups' shares (k_lin_landmark), a thread's in ascending order
@@ -763,28 +781,46 @@ __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const doubl
             if (!g.fixed[k])
                 for (int d = 0; d < 6; ++d) m = fmax(m, fabs(Hpp[36 * (size_t)k + 7 * d]));
     }
-    s0[threadIdx.x] = a;
     s1[threadIdx.x] = b;
     s2[threadIdx.x] = m;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) {
-            s0[threadIdx.x] += s0[threadIdx.x + w];
-            s1[threadIdx.x] += s1[threadIdx.x + w];
-            s2[threadIdx.x] = fmax(s2[threadIdx.x], s2[threadIdx.x + w]);
+    const double ta = tree_sum_1024(s0, a);   // (its barrier also covers s1 and s2)
+    double tb = 0.0, tm = 0.0;
+    if (threadIdx.x < 64) {
+        double u[16], x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            u[j] = s1[threadIdx.x + 64 * j];
+            x[j] = s2[threadIdx.x + 64 * j];
         }
-        __syncthreads();
+#pragma unroll
+        for (int h = 8; h >= 1; h >>= 1)
+#pragma unroll
+            for (int j = 0; j < h; ++j) {
+                u[j] = u[j] + u[j + h];
+                x[j] = fmax(x[j], x[j + h]);
+            }
+        tb = u[0];
+        tm = x[0];
+#pragma unroll
+        for (int w = 32; w >= 1; w >>= 1) {
+            tb = tb + __shfl_down(tb, w);
+            tm = fmax(tm, __shfl_down(tm, w));
+        }
     }
     if (threadIdx.x == 0) {
-        chi2[0] = s0[0];
-        chi2[1] = s1[0];
-        chi2[2] = s2[0];
+        s0[0] = ta;   // (read by the result words below)
+        s1[0] = tb;
+        s2[0] = tm;
+        chi2[0] = ta;
+        chi2[1] = tb;
+        chi2[2] = tm;
         if (mirror) {   // a second copy next to the solver's scalars: ONE download brings a Levenberg-Marquardt trial's outcome back
-            mirror[0] = s0[0];
-            mirror[1] = s1[0];
-            mirror[2] = s2[0];
+            mirror[0] = ta;
+            mirror[1] = tb;
+            mirror[2] = tm;
         }
     }
+    __syncthreads();
     if (host_ll && threadIdx.x < 12) {
         // values: [0] landmarks' / [1] keyframes' gain-ratio parts (scale_sum[0] was written by thread 0 above: same workgroup, behind barriers;
         // scale_sum[1] by k_trial_update), [2..4] chi2 triple, [5] the two failure words

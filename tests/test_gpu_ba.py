@@ -671,3 +671,32 @@ def test_local_ba_beyond_the_device_solvers_size_takes_the_host_solve():
         ba.local_ba_set_solver("device")
     assert np.array_equal(a["poses"], b["poses"]) and np.array_equal(a["points"], b["points"])
     assert a["info"][3] < 0.5 * a["info"][0] and a["info"][4] >= 3
+
+
+@pytest.mark.gpu
+def test_local_ba_edge_counts_order_and_threads():
+    """The late-round-6 data paths at their corners: no edge at all, one edge, 63 / 65 edges (a wave's staged records and their fall-back), an edge
+    list that is NOT keyframe-major (every lane stores its own Hpl record), and two threads calling at once (page-locked images and blocks are per
+    thread): finite states, the same flags, and the same bits from both threads as from a single-threaded call."""
+    import threading
+    from openvslam_amd import ba
+    d = synth_local_ba(n_pose=6, n_pt=300, obs_per_pose=100, seed=1, pose_noise=0.01, point_noise=0.01, n_fixed=2)
+    e = d["edges"]
+    for n in (0, 1, 63, 65):
+        r = ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], e[:n], d["cam"])
+        assert np.isfinite(r["poses"]).all() and np.isfinite(r["points"]).all() and len(r["mono_outlier"]) == n
+        assert (r["info"][4] == 0) == (n == 0) and r["info"][3] <= r["info"][0]
+    r1 = ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], e, d["cam"])
+    r2 = ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], e[::-1].copy(), d["cam"])
+    assert np.abs(r1["poses"] - r2["poses"]).max() < 1e-11 and np.abs(r1["points"] - r2["points"]).max() < 1e-11
+    assert np.array_equal(r1["mono_outlier"], r2["mono_outlier"][::-1])
+    outs = [None, None]
+
+    def work(i):
+        for _ in range(10):
+            outs[i] = ba.local_ba_optimize(d["poses"], d["pose_fixed"], d["points"], e, d["cam"])
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for o in outs:
+        assert np.array_equal(o["poses"], r1["poses"]) and np.array_equal(o["points"], r1["points"]) and np.array_equal(o["mono_outlier"], r1["mono_outlier"])
