@@ -766,10 +766,23 @@ __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const doubl
     }
     double a = 0, b = 0, m = 0;
     // the landmark workgroups' shares (k_lin_landmark), a thread's in ascending order
-    for (int w = threadIdx.x; w < g.n_lm_wg; w += 1024) {
-        a += lm_chi[3 * (size_t)w];
-        b += lm_chi[3 * (size_t)w + 1];
-        m = fmax(m, lm_chi[3 * (size_t)w + 2]);
+    for (int w0 = threadIdx.x; w0 < g.n_lm_wg; w0 += 8 * 1024) {   // eight triples in flight (a million edges: 4000 workgroups' shares, four
+        double ca[8], cb[8], cm[8];                                 // dependent round trips with one at a time), added in the plain loop's order
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool in = w0 + 1024 * u < g.n_lm_wg;
+            const size_t w = in ? (size_t)(w0 + 1024 * u) : 0;
+            ca[u] = in ? lm_chi[3 * w] : 0.0;
+            cb[u] = in ? lm_chi[3 * w + 1] : 0.0;
+            cm[u] = in ? lm_chi[3 * w + 2] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (w0 + 1024 * u < g.n_lm_wg) {
+                a += ca[u];
+                b += cb[u];
+                m = fmax(m, cm[u]);
+            }
     }
     if (Hpp_out) {   // (uniform) the diagonal entries are other workgroups' to write: this one adds up the same sums (the same bits) for itself
         for (int item = (int)threadIdx.x; item < 6 * g.n_pose; item += 1024) {
