@@ -1562,6 +1562,7 @@ struct ovs_ba_graph {
     int32_t *d_pl_cnt = nullptr, *d_pl_off = nullptr;
     int2* d_pl_ent = nullptr;
     size_t pl_bound = 0;
+    bool pl_ready = false;   // the lists exist (solver work space created, bound within the cap)
     int n_pairs = 0;
     int32_t* d_wg_pair = nullptr;   // [n_pair_wg] k_schur_l's work order: whole rows of the pair table per XCD, -1 = no pair
     int n_pair_wg = 0;
@@ -2082,7 +2083,10 @@ static ovs_status solver_workspace_create(ovs_ba_graph* g, hipStream_t s) {
                  b_s = al(sizeof(double) * (sys + 6 * (size_t)g->n_pose)), b_dxp = al(sizeof(double) * 6 * (size_t)g->n_pose),
                  b_tab = al(sizeof(int32_t) * (size_t)std::max(g->n_free, 1) * (size_t)g->n_pt);
     const size_t n_lists = (size_t)4 * (size_t)std::max(g->n_pairs, 0);
-    const size_t b_plc = al(sizeof(int32_t) * (n_lists + 1)), b_ple = al(sizeof(int2) * std::max<size_t>(g->pl_bound, 1));
+    // the lists' offsets are 32-bit and their storage is sized by the bound: a map whose bound is beyond 2^28 entries (2 GB; e.g. hundreds of
+    // keyframes that all observe the same landmarks) keeps the per-trial scan (k_schur) instead
+    const bool pl_ok = g->pl_bound <= ((size_t)1 << 28);
+    const size_t b_plc = al(sizeof(int32_t) * (n_lists + 1)), b_ple = al(sizeof(int2) * (pl_ok ? std::max<size_t>(g->pl_bound, 1) : 1));
     g->d_solver_arena = g_ba_pool.take(g->device, b_hinv + b_y + b_s + b_dxp + 512 + b_tab + 2 * b_plc + b_ple, &g->solver_cap);
     OVS_HIP_TRY(g->d_solver_arena ? hipSuccess : hipErrorOutOfMemory);
     unsigned char* A = g->d_solver_arena;
@@ -2102,7 +2106,9 @@ static ovs_status solver_workspace_create(ovs_ba_graph* g, hipStream_t s) {
     g->d_pl_cnt = reinterpret_cast<int32_t*>(A + b_hinv + b_y + b_s + b_dxp + 512 + b_tab);
     g->d_pl_off = reinterpret_cast<int32_t*>(A + b_hinv + b_y + b_s + b_dxp + 512 + b_tab + b_plc);
     g->d_pl_ent = reinterpret_cast<int2*>(A + b_hinv + b_y + b_s + b_dxp + 512 + b_tab + 2 * b_plc);
-    if (g->n_edge() > 0 && g->n_free > 0 && g->n_pairs > 0) {   // behind k_edge_table on the same stream
+    g->pl_ready = false;
+    if (pl_ok && g->n_edge() > 0 && g->n_free > 0 && g->n_pairs > 0) {   // behind k_edge_table on the same stream
+        g->pl_ready = true;
         hipLaunchKernelGGL(k_pair_lists<false>, dim3(g->n_pairs), dim3(256), 0, s, g->d_pose_start, g->d_pose_edges, g->d_pose_pt, g->d_pair_ab, g->d_slot_pose,
                            g->d_edge_of, g->n_pt, g->d_pl_cnt, (const int32_t*)nullptr, (int2*)nullptr);
         OVS_LAUNCH_TRY("k_pair_lists<count>");
@@ -2157,10 +2163,10 @@ ovs_status ba_graph_schur(ovs_ba_graph* g, const double* d_Hpp, const double* d_
         }();
         const int32_t* const wgp = xcd ? g->d_wg_pair : nullptr;
         const int n_pwg = xcd ? g->n_pair_wg : g->n_pairs;
-        if (lists && g->n_edge() > 0 && coop)
+        if (lists && g->pl_ready && coop)
             hipLaunchKernelGGL(k_schur_l<true>, dim3(g->n_free + n_pwg), dim3(256), 0, s, v, g->n_free, g->d_pair_ab, g->d_slot_pose, g->d_pl_off, g->d_pl_ent,
                                d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs, wgp, n_pwg);
-        else if (lists && g->n_edge() > 0)
+        else if (lists && g->pl_ready)
             hipLaunchKernelGGL(k_schur_l<false>, dim3(g->n_free + n_pwg), dim3(256), 0, s, v, g->n_free, g->d_pair_ab, g->d_slot_pose, g->d_pl_off, g->d_pl_ent,
                                d_Hpp, d_bp, d_bl, d_Hpl, g->d_Y, lambda, g->s_pitch, g->d_S, g->d_rhs, wgp, n_pwg);
         else
