@@ -23,6 +23,12 @@
 //                    linearisation reads, the keyframes' part of the gain ratio's denominator -- one workgroup;
 //     backsub_landmark  dxl_j = Hll^-1 (bl_j - sum W_e^T dxp), the trial points X + dxl and the landmark's term of g2o's gain-ratio scale
 //                    (k_backsub: the same on increments uploaded by the host solver).
+// Round 6 (DESIGN.md section 3.6 has the measurements): one lane per EDGE on both sides of the linearisation and in the back-substitution; both
+// halves of a linearisation in ONE launch again (k_linearize2: the keyframe side fell from 218 to 78 VGPRs with one entry per thread), the
+// keyframes' blocks finished by extra workgroups of k_reduce_scalars; every 144-byte record (Hpl, Y) leaves through LDS as whole lines -- a lane
+// storing its own record issued nine partial-line requests, and those, not bytes, were what the kernels queued behind; the pairs' common
+// landmarks listed once per graph (k_pair_lists) and k_schur_l gathering its records cooperatively, whole rows of the pair table per XCD; the
+// chi-square gates (k_edge_gate) and the graph build's landmark-order pass (k_edges_by_slot, k_dup_check) on the device.
 // Round 5's three mergers are side-by-side only (a workgroup runs one of the two bodies, chosen by its index): the arithmetic of every block,
 // landmark and keyframe is what it was, the results are the same bits, and a trial is 332 instead of 386 us of kernels (profiles/r05ai_*).
 // Per-edge arithmetic is the expression sequence of k_ba_linearize / the oracle (every product individually rounded), so Hpl, Hll and bl

@@ -4,8 +4,9 @@
 // The caller (the class shim) flattens the local map into poses / landmarks / observation edges; this file runs what
 // optimizer.optimize(num_first_iter) -> outlier levels -> optimizer.optimize(num_second_iter) does, on top of ba_graph.hip:
 //   * the state (poses as SE3Quat records, points) and both block sets (current system / trial system) live in HBM for the whole call;
-//   * one Levenberg-Marquardt trial = five launches on the device (round 5: k_lm_prepare, k_schur, the dense solver of ba_solve.hip,
-//     k_trial_update, k_linearize + k_reduce_scalars) and ONE 260-byte download; with ovs_local_ba_set_solver(1) (BASELINE's north star keeps the
+//   * one Levenberg-Marquardt trial = six launches on the device (round 6: k_lm_prepare, k_schur_l, the dense solver of ba_solve.hip,
+//     k_trial_update, k_linearize2, k_reduce_scalars: ~230 us at config 5) whose outcome the host polls from twelve flag-carrying words in
+//     page-locked memory (OVS_BA_LL_NOTIFY=0: ONE 260-byte download); with ovs_local_ba_set_solver(1) (BASELINE's north star keeps the
 //     Cholesky of the reduced camera system on the HOST; at most 6 n_pose square) a 0.7 MB download (S | rhs | bp), 2.4 KB of pose increments
 //     up, k_backsub, the SE3 update of <= 50 poses on the host, and the linearisation of the trial state;
 //   * g2o's damping schedule (ORACLE_SPEC rule 25), the chi-square outlier gates between the two rounds and the final outlier flags.
