@@ -664,7 +664,9 @@ __global__ __launch_bounds__(256) void k_lin_landmark(GraphDev g, const double* 
 template <int kModel>
 __global__ __launch_bounds__(256) void k_linearize2(GraphDev g, const double* __restrict__ poses, const double* __restrict__ points, double huber_mono,
                                                    double huber_stereo, double* __restrict__ Hpl, double* __restrict__ Hll, double* __restrict__ bl,
-                                                   double* __restrict__ lm_chi) {
+                                                   double* __restrict__ lm_chi, double* __restrict__ chi2) {
+    // chi2[2], the largest |diagonal entry|, is a maximum the workgroups of k_reduce_scalars (the next launch) put together with atomics: cleared here
+    if (blockIdx.x == 0 && threadIdx.x == 0) chi2[2] = 0.0;
     // one buffer, two views: the landmark side's s_c[14][kLmSlots + 1] | s_d[5][256]; the keyframe side's s_h[4][64 x 9] (double2) | s_part[4][27]
     constexpr int kRaw = 14 * (kLmSlots + 1) + 5 * 256;
     static_assert(kRaw >= 2 * 4 * 64 * 9 + 4 * 27, "the keyframe side's view fits the landmark side's");
@@ -737,6 +739,10 @@ __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const doubl
     if (Hpp_out && blockIdx.x > 0) {
         // behind k_linearize2, workgroups 1 ..: the keyframes' blocks from the half chunks' sums (halves in ascending order); Hpp symmetric, bp.
         // (One workgroup doing this as well was a serial tail of 27 n_pose sums of up to 40 dependent loads: 1 M edges 0.162 against 0.124 ms.)
+        // The free keyframes' diagonal entries also go into chi2[2] = the largest |diagonal entry| (g2o's computeLambdaInit), as an atomic maximum
+        // on the bit pattern (non-negative doubles order like integers; a maximum does not depend on the order of its operands): workgroup 0 used
+        // to add up those 6 n_pose sums a second time for itself -- a third of this launch's 13.6 us at 200 keyframes x 5000 observations.
+        double dmax = 0.0;
         for (int item = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x; item < 27 * g.n_pose; item += ((int)gridDim.x - 1) * 1024) {
             const int k = item / 27, t = item - 27 * k;
             const double v = pose_term_sum(g, k, t);
@@ -752,8 +758,12 @@ __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const doubl
                 const int b = a + rem;
                 Hpp_out[36 * (size_t)k + 6 * a + b] = v;
                 Hpp_out[36 * (size_t)k + 6 * b + a] = v;
+                if (rem == 0 && !g.fixed[k]) dmax = fmax(dmax, fabs(v));
             }
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off));
+        if ((threadIdx.x & 63) == 0 && dmax > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(chi2 + 2), (unsigned long long)__double_as_longlong(dmax));
         return;
     }
     if (lm_scale) {   // (uniform) before the chi2 sums: s0 is reused
@@ -790,11 +800,7 @@ __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const doubl
                 m = fmax(m, cm[u]);
             }
     }
-    if (Hpp_out) {   // (uniform) the diagonal entries are other workgroups' to write: this one adds up the same sums (the same bits) for itself
-        for (int item = (int)threadIdx.x; item < 6 * g.n_pose; item += 1024) {
-            const int k = item / 6, d = item - 6 * k;
-            if (!g.fixed[k]) m = fmax(m, fabs(pose_term_sum(g, k, 7 * d - d * (d - 1) / 2)));   // (row d of the 27 terms starts with its diagonal entry)
-        }
+    if (Hpp_out) {   // (uniform) the keyframes' diagonal entries reach chi2[2] from the workgroups that add them up (above): the landmarks' part here
     } else {
         for (int k = threadIdx.x; k < g.n_pose; k += 1024)
             if (!g.fixed[k])
@@ -832,11 +838,15 @@ __global__ __launch_bounds__(1024) void k_reduce_scalars(GraphDev g, const doubl
         s2[0] = tm;
         chi2[0] = ta;
         chi2[1] = tb;
-        chi2[2] = tm;
+        if (Hpp_out) {
+            if (tm > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(chi2 + 2), (unsigned long long)__double_as_longlong(tm));
+        } else {
+            chi2[2] = tm;
+        }
         if (mirror) {   // a second copy next to the solver's scalars: ONE download brings a Levenberg-Marquardt trial's outcome back
             mirror[0] = ta;
             mirror[1] = tb;
-            mirror[2] = tm;
+            mirror[2] = tm;   // (behind k_linearize2: the landmarks' part only -- no reader: an LM trial consumes [0], [1] and the gain ratio's parts)
         }
     }
     __syncthreads();
@@ -1640,9 +1650,9 @@ ovs_status graph_linearize(ovs_ba_graph* g, const double* d_poses, const double*
     if (merged) {
         const unsigned n_wg = (unsigned)(2 * g->n_chunks + g->n_lm_wg);
         if (g->model == 1)
-            hipLaunchKernelGGL(k_linearize2<1>, dim3(n_wg), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl, d_Hll, d_bl, g->d_lm_tmp);
+            hipLaunchKernelGGL(k_linearize2<1>, dim3(n_wg), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl, d_Hll, d_bl, g->d_lm_tmp, d_chi3);
         else
-            hipLaunchKernelGGL(k_linearize2<0>, dim3(n_wg), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl, d_Hll, d_bl, g->d_lm_tmp);
+            hipLaunchKernelGGL(k_linearize2<0>, dim3(n_wg), dim3(256), 0, s, v, d_poses, d_points, huber_mono, huber_stereo, d_Hpl, d_Hll, d_bl, g->d_lm_tmp, d_chi3);
         OVS_LAUNCH_TRY("k_linearize2");
     } else {
         if (g->n_chunks > 0) {
