@@ -699,7 +699,7 @@ def bench_local_ba(world, rank, dist, torch, iters=20, n_pose=50, n_pt=20000, ob
                 "what_bounds_it": "its traffic at the rate partial-line requests allow: 1.5x the algorithmic bytes (the edge records are read by both "
                                   "halves), gathered 24-byte landmarks and 40-byte records; the 144-byte Hpl records leave as whole lines since round 6 "
                                   "(through LDS: 0.124 -> 0.100 ms per million edges); six waves per SIMD instead of two changed nothing "
-                                  "(profiles/r06an_lba_pmc_summary.txt, DESIGN.md 3.6)"}
+                                  "(profiles/r06ay_lba_pmc_summary.txt, DESIGN.md 3.6)"}
     return {"workload": "%s%d keyframes x %d observations, %d landmarks, fp64, Huber sqrt(5.991)"
                         % ("BASELINE configs[4]: " if (n_pose, n_pt, obs_per_pose) == (50, 20000, 2000) else "", n_pose, obs_per_pose, n_pt),
             "ms_per_linearisation": round(dt / iters * 1e3, 4), "edges_per_sec": round(n_edges * iters / dt, 1),
